@@ -1,0 +1,94 @@
+"""Synthetic benchmark inputs -- own code, no reference
+counterpart (the reference ships no benchmark).
+
+``CenteredBandedNLP(n, m)`` is the seeded sparse banded NLP used for BASELINE
+configs 3-5 and for the projected-CG microbench:
+
+* ``A0``: m x n CSR, ``bw`` contiguous nonzeros per row starting at
+  ``clip(i*stride + stride//2 - 7, 0, n-bw)``, ``stride = n // m``.
+* ``Q = tridiag(-e, 2+d, -e)`` (SPD), objective
+  ``f = 1/2 dl'Q dl - eps q'dl + rho/4 sum(dl^4)``, ``dl = x - x_feas``.
+* constraint ``c(x) = A0 x + kappa/2 W (x*x) - b`` with ``W = A0*A0`` and ``b``
+  chosen so that ``c(x_feas) = 0``; Jacobian has A0's pattern (value refresh
+  only); constraint Hessian ``diag(kappa W'v)``.
+
+Everything here is host-side numpy/scipy; ``device_callbacks`` re-expresses the
+callbacks on device buffers for the GPU configs (user-land code: it may use
+torch freely, the library's own arithmetic never does).
+"""
+import numpy as np
+import scipy.sparse as sps
+
+
+class CenteredBandedNLP:
+    def __init__(self, n, m, bw=15, seed=0, kappa=0.1, rho=0.1, eps=1e-3):
+        rng = np.random.default_rng(seed)
+        a = rng.standard_normal(m * bw)
+        d = rng.uniform(0, 1, n)
+        e = rng.uniform(0, 1, n - 1)
+        q = rng.standard_normal(n)
+        x_feas = rng.uniform(-1, 1, n)
+        self.x0 = x_feas + 0.1 * np.random.default_rng(seed + 12345) \
+            .standard_normal(n)
+
+        stride = n // m
+        start = np.clip(np.arange(m) * stride + stride // 2 - 7, 0, n - bw)
+        indptr = (np.arange(m + 1) * bw).astype(np.int32)
+        indices = (start[:, None] + np.arange(bw)[None, :]) \
+            .astype(np.int32).ravel()
+        self.A0 = sps.csr_matrix((a, indices, indptr), shape=(m, n))
+        self.W = sps.csr_matrix((a * a, indices, indptr), shape=(m, n))
+        self.Wt = sps.csr_matrix(self.W.T)
+        self.Q = sps.diags([-e, 2 + d, -e], [-1, 0, 1], format='csr')
+        self.Q.indices = self.Q.indices.astype(np.int32)
+        self.Q.indptr = self.Q.indptr.astype(np.int32)
+        self.q, self.x_feas = q, x_feas
+        self.n, self.m, self.bw = n, m, bw
+        self.kappa, self.rho, self.eps = kappa, rho, eps
+        self.b = self.A0.dot(x_feas) + 0.5 * kappa * self.W.dot(x_feas ** 2)
+        # position of the diagonal entry inside each CSR row of Q
+        self._qdiag = np.flatnonzero(
+            self.Q.indices == np.repeat(np.arange(n), np.diff(self.Q.indptr)))
+
+    # ---- objective ------------------------------------------------------
+    def fun(self, x):
+        dl = x - self.x_feas
+        return (0.5 * dl.dot(self.Q.dot(dl)) - self.eps * self.q.dot(dl)
+                + 0.25 * self.rho * np.sum(dl ** 4))
+
+    def grad(self, x):
+        dl = x - self.x_feas
+        return self.Q.dot(dl) - self.eps * self.q + self.rho * dl ** 3
+
+    def hess(self, x):
+        dl = x - self.x_feas
+        H = self.Q.copy()
+        H.data[self._qdiag] += 3 * self.rho * dl ** 2
+        return H
+
+    # ---- constraint -----------------------------------------------------
+    def constr_fun(self, x):
+        return self.A0.dot(x) + 0.5 * self.kappa * self.W.dot(x * x) - self.b
+
+    def constr_jac(self, x):
+        data = self.A0.data + self.kappa * self.W.data * x[self.A0.indices]
+        return sps.csr_matrix((data, self.A0.indices, self.A0.indptr),
+                              shape=self.A0.shape)
+
+    def constr_hess(self, x, v):
+        return sps.diags(self.kappa * self.Wt.dot(v), format='csr')
+
+    # ---- assembled pieces used by the microbench ------------------------
+    def lagrangian_hessian_matrix(self, x, v):
+        """hess(x) + constr_hess(x, v) as one CSR matrix (nnz = 3n-2)."""
+        dl = x - self.x_feas
+        H = self.Q.copy()
+        H.data[self._qdiag] += 3 * self.rho * dl ** 2 \
+            + self.kappa * self.Wt.dot(v)
+        return H
+
+    def constraints(self, ns, kind=('equals', 0)):
+        """Constraint objects built from namespace ``ns`` (this package, or
+        the reference when generating golden vectors)."""
+        return ns.NonlinearConstraint(self.constr_fun, kind, self.constr_jac,
+                                      self.constr_hess)

@@ -1,0 +1,288 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory by RUNNING THE REFERENCE.
+
+Run in the build container only (it needs /root/reference):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+The reference is imported unmodified from /root/reference; two harness shims
+live here: scipy >= 1.12 probes a dtype-less
+LinearOperator with an int8 vector, which breaks the reference's
+``np.zeros_like(p); result += ...`` accumulation, so ``dtype=float`` is
+defaulted for operators built from a bare matvec.  Numerics are untouched.
+
+Outputs (numbers only -- no reference source travels):
+  qp_small.json     reference outputs for every case in tests/cases_small.py
+  banded_*.npz      projected_cg / modified_dogleg / Z,LS,Y traces on the
+                    seeded banded problem
+  e2e.json          end-to-end minimize_constrained traces (tests/problems.py,
+                    README example, banded NLPs)
+"""
+import json
+import os
+import sys
+import warnings
+
+import numpy as np
+import scipy.sparse as sps
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.dont_write_bytecode = True
+sys.path.insert(0, "/root/reference")
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import scipy.sparse.linalg._interface as _iface  # noqa: E402
+
+_orig_init = _iface._CustomLinearOperator.__init__
+
+
+def _init(self, shape, matvec, rmatvec=None, matmat=None, dtype=None,
+          rmatmat=None):
+    _orig_init(self, shape, matvec, rmatvec=rmatvec, matmat=matmat,
+               dtype=float if dtype is None else dtype, rmatmat=rmatmat)
+
+
+_iface._CustomLinearOperator.__init__ = _init
+
+import ipsolver as ref  # noqa: E402  (the REFERENCE package)
+from ipsolver._large_scale_constrained import qp_subproblem as rqp  # noqa: E402
+from ipsolver._large_scale_constrained import projections as rproj  # noqa: E402
+assert ref.__file__.startswith("/root/reference"), ref.__file__
+
+import cases_small as cs  # noqa: E402
+import problems  # noqa: E402
+import banded_setup  # noqa: E402
+
+synthetic = banded_setup.load_synthetic()
+
+
+def jf(v):
+    """JSON-safe float / list."""
+    if isinstance(v, (bool, np.bool_)):
+        return bool(v)
+    if isinstance(v, (int, np.integer)):
+        return int(v)
+    if isinstance(v, (float, np.floating)):
+        v = float(v)
+        if np.isinf(v):
+            return "inf" if v > 0 else "-inf"
+        if np.isnan(v):
+            return "nan"
+        return v
+    if isinstance(v, np.ndarray):
+        return [jf(t) for t in v.tolist()]
+    if isinstance(v, (list, tuple)):
+        return [jf(t) for t in v]
+    raise TypeError(type(v))
+
+
+def small_cases():
+    out = {"sphere": [], "box": [], "box_sphere": [], "dogleg": [], "pcg": []}
+    for z, d, r in cs.SPHERE:
+        for line in (False, True):
+            out["sphere"].append(jf(rqp.sphere_intersections(z, d, r, line)))
+    for z, d, lb, ub in cs.BOX:
+        for line in (False, True):
+            out["box"].append(jf(rqp.box_intersections(z, d, lb, ub, line)))
+    for z, d, lb, ub, r in cs.BOX_SPHERE:
+        for line in (False, True):
+            out["box_sphere"].append(
+                jf(rqp.box_sphere_intersections(z, d, lb, ub, r, line)))
+    for A, b, r, lb, ub in cs.DOGLEG:
+        A = np.array(A, dtype=float)
+        _, _, Y = rproj.projections(A)
+        out["dogleg"].append(jf(rqp.modified_dogleg(A, Y, np.array(b, float),
+                                                    r, lb, ub)))
+    for case in cs.PCG:
+        H = sps.csc_matrix(np.array(case["H"], dtype=float))
+        A = sps.csc_matrix(np.array(case["A"], dtype=float))
+        c = np.array(case["c"], dtype=float)
+        b = np.array(case["b"], dtype=float)
+        Z, _, Y = rproj.projections(A)
+        try:
+            x, info = rqp.projected_cg(H, c, Z, Y, b, return_all=True,
+                                       **case["kw"])
+            rec = {"x": jf(x), "niter": info["niter"],
+                   "stop_cond": info["stop_cond"],
+                   "hits_boundary": bool(info["hits_boundary"]),
+                   "allvecs": [jf(v) for v in info["allvecs"]]}
+        except ValueError as e:
+            rec = {"raises": str(e)}
+        out["pcg"].append(rec)
+
+    # projections on the 3x8 matrix, every method available here
+    A38 = np.array(cs.A38, dtype=float)
+    proj = {}
+    for method, A in (("AugmentedSystem", sps.csc_matrix(A38)),
+                      ("QRFactorization", A38), ("SVDFactorization", A38)):
+        Z, LS, Y = rproj.projections(A, method)
+        proj[method] = {
+            "Z": [jf(Z.dot(np.array(p, float))) for p in cs.A38_POINTS_N],
+            "LS": [jf(LS.dot(np.array(p, float))) for p in cs.A38_POINTS_N],
+            "Y": [jf(Y.dot(np.array(p, float))) for p in cs.A38_POINTS_M]}
+    out["proj38"] = proj
+    out["orth"] = [jf(rproj.orthogonality(A38, np.array(v)))
+                   for v in cs.ORTH_VECTORS]
+
+    # dense-vs-sparse comparison matrices, seeded vectors
+    for key, A in (("diag4", cs.diag4_matrix()), ("diag3", cs.diag3_matrix())):
+        rng = np.random.RandomState(0)
+        m, n = A.shape
+        Zs, LSs, Ys = rproj.projections(sps.csc_matrix(A))
+        Zd, LSd, Yd = rproj.projections(A)
+        rec = {"Z_sparse": [], "LS_sparse": [], "Y_sparse": [],
+               "Z_dense": [], "LS_dense": [], "Y_dense": []}
+        for _ in range(3):
+            z = rng.normal(size=n)
+            x = rng.normal(size=m)
+            rec["Z_sparse"].append(jf(Zs.dot(z)))
+            rec["LS_sparse"].append(jf(LSs.dot(z)))
+            rec["Y_sparse"].append(jf(Ys.dot(x)))
+            rec["Z_dense"].append(jf(Zd.dot(z)))
+            rec["LS_dense"].append(jf(LSd.dot(z)))
+            rec["Y_dense"].append(jf(Yd.dot(x)))
+        out[key] = rec
+    return out
+
+
+def banded_traces(n, m, full_vectors):
+    """projected_cg / dogleg / projection traces on the Appendix C matrices."""
+    inst = banded_setup.BandedInstance(n, m)
+    A, H, c, bvec = inst.A, inst.H, inst.c, inst.b
+    Z, LS, Y = rproj.projections(A)
+    out = {}
+    stride = inst.stride
+
+    def keep(vec):
+        vec = np.asarray(vec)
+        return vec if full_vectors else vec[::stride]
+
+    out["Z"] = np.array([keep(Z.dot(p)) for p in inst.probes_n])
+    out["LS"] = np.array([keep(LS.dot(p)) for p in inst.probes_n])
+    out["Y"] = np.array([keep(Y.dot(p)) for p in inst.probes_m])
+
+    zero_b = np.zeros(m)
+    gnorm = np.linalg.norm(Z.dot(c))
+    out["gnorm"] = np.array([gnorm])
+    for name, kw in inst.pcg_variants(gnorm).items():
+        xs, info = rqp.projected_cg(H, c, Z, Y, zero_b, return_all=True, **kw)
+        out["pcg_%s_x" % name] = keep(xs)
+        out["pcg_%s_info" % name] = np.array(
+            [info["niter"], info["stop_cond"], int(info["hits_boundary"])])
+        out["pcg_%s_allvecs" % name] = np.array(
+            [keep(t) for t in info["allvecs"]])
+    # non-zero b (row-space start) with a ball
+    y_b = Y.dot(bvec)
+    xs, info = rqp.projected_cg(H, c, Z, Y, bvec, tol=0, max_iter=10,
+                                trust_radius=10 * np.linalg.norm(y_b),
+                                return_all=True)
+    out["pcg_rowstart_x"] = keep(xs)
+    out["pcg_rowstart_info"] = np.array(
+        [info["niter"], info["stop_cond"], int(info["hits_boundary"])])
+    out["y_b"] = keep(y_b)
+    out["y_b_norm_max"] = np.array([np.linalg.norm(y_b), np.abs(y_b).max()])
+
+    dl = []
+    for radius, lo, hi in inst.dogleg_cfg(y_b):
+        dl.append(keep(rqp.modified_dogleg(A, Y, bvec, radius,
+                                           np.full(n, lo), np.full(n, hi))))
+    out["dogleg"] = np.array(dl)
+    out["stride"] = np.array([1 if full_vectors else stride])
+    return out
+
+
+def run_e2e(name, fun, x0, grad, hess, constraints, **kw):
+    rows = []
+
+    def cb(state):
+        rows.append([int(state.niter), int(state.cg_niter),
+                     float(state.trust_radius), float(state.penalty),
+                     float(getattr(state, "barrier_parameter", np.nan)),
+                     float(state.optimality),
+                     float(state.constr_violation), int(state.nfev)])
+        return False
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res = ref.minimize_constrained(fun, x0, grad, hess, constraints,
+                                       callback=cb, **kw)
+    rec = {"x": jf(np.asarray(res.x)) if np.size(res.x) <= 64
+           else jf(np.asarray(res.x)[::max(1, np.size(res.x) // 50)]),
+           "status": int(res.status), "niter": int(res.niter),
+           "cg_niter": int(res.cg_niter), "nfev": int(res.nfev),
+           "ngev": int(res.ngev), "nhev": int(res.nhev),
+           "ncev": int(res.ncev), "njev": int(res.njev),
+           "method": res.method, "optimality": jf(res.optimality),
+           "constr_violation": jf(res.constr_violation),
+           "trust_radius": jf(res.trust_radius), "penalty": jf(res.penalty),
+           "fun": jf(float(res.fun)),
+           "v": jf(np.asarray(res.v)) if np.size(res.v) <= 64 else None,
+           "keys": sorted(res.keys()),
+           "trace": jf(rows)}
+    if "s" in res:
+        rec["s"] = jf(np.asarray(res.s)) if np.size(res.s) <= 64 else None
+        rec["barrier_parameter"] = jf(res.barrier_parameter)
+    print("  %-28s status %d niter %d cg %d" % (name, rec["status"],
+                                                 rec["niter"],
+                                                 rec["cg_niter"]))
+    return rec
+
+
+def e2e():
+    out = {}
+    for p in problems.exact_hessian_problems() + problems.fd_hessian_problems():
+        out[p.name] = run_e2e(p.name, p.fun, p.x0, p.grad, p.hess_arg(),
+                              p.constraints(ref))
+    # Maratos via the SQP method explicitly; README example = hyperbolic_ineq
+    p = problems.Maratos()
+    out["maratos_sqp"] = run_e2e("maratos_sqp", p.fun, p.x0, p.grad, p.hess,
+                                 p.constraints(ref),
+                                 method="equality_constrained_sqp")
+    # banded NLPs (Appendix C) at small n: equality (both methods) and
+    # box + inequality (barrier)
+    for n, m in ((2000, 200),):
+        prob = synthetic.CenteredBandedNLP(n, m, eps=1e-3)
+        for method in ("tr_interior_point", "equality_constrained_sqp"):
+            key = "banded_eq_n%d_%s" % (n, method)
+            out[key] = run_e2e(key, prob.fun, prob.x0, prob.grad, prob.hess,
+                               prob.constraints(ref), method=method)
+    prob = synthetic.CenteredBandedNLP(400, 40, eps=1.0)
+    cons = (prob.constraints(ref, ("less", 0.0)),
+            ref.BoxConstraint(("interval", -0.8, 0.8)))
+    out["banded_ineq_n400"] = run_e2e("banded_ineq_n400", prob.fun, prob.x0,
+                                      prob.grad, prob.hess, cons)
+    # dense equality QP (config-2 style, small)
+    rng = np.random.default_rng(0)
+    n, m = 60, 12
+    A = rng.standard_normal((m, n))
+    G = rng.standard_normal((n, n)) / np.sqrt(n)
+    Hd = G.dot(G.T) + np.eye(n)
+    c = rng.standard_normal(n)
+    xf = rng.standard_normal(n)
+    bq = A.dot(xf)
+    out["dense_eq_qp_n60"] = run_e2e(
+        "dense_eq_qp_n60", lambda x: 0.5 * x.dot(Hd.dot(x)) + c.dot(x),
+        np.zeros(n), lambda x: Hd.dot(x) + c, lambda x: Hd,
+        ref.LinearConstraint(A, ("equals", bq)),
+        method="equality_constrained_sqp")
+    return out
+
+
+def main():
+    print("small cases ...")
+    with open(os.path.join(HERE, "qp_small.json"), "w") as f:
+        json.dump(small_cases(), f)
+    print("banded traces ...")
+    np.savez_compressed(os.path.join(HERE, "banded_n2000.npz"),
+                        **banded_traces(2000, 200, True))
+    np.savez_compressed(os.path.join(HERE, "banded_n20000.npz"),
+                        **banded_traces(20000, 2000, False))
+    print("end-to-end ...")
+    with open(os.path.join(HERE, "e2e.json"), "w") as f:
+        json.dump(e2e(), f)
+    print("done")
+
+
+if __name__ == "__main__":
+    main()
