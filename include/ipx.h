@@ -1,0 +1,103 @@
+/*
+ * ipx.h -- C ABI of the MI355X-native trust-region subproblem kernels.
+ *
+ * Drop-in boundary for the hot path of antonior92/ip-nonlinear-solver
+ * (SURVEY.md section 8(b)).  The reference is pure Python: its "FFI" for this
+ * path is the duck-typed operator seam
+ *
+ *     H.dot(v), A.dot(v), A.T.dot(v)        qp_subproblem.py:376,379,410,503,634
+ *     Z.dot(v), LS.dot(v), Y.dot(v)         projections.py:402-404
+ *     np.dot / norm / elementwise algebra   qp_subproblem.py:99-232,502-634
+ *
+ * so the entry points below are what a ctypes binding of that seam binds
+ * (INTEGRATION.md shows the stub).  Conventions:
+ *   - every pointer is a DEVICE pointer owned by the caller (the Python host
+ *     keeps them alive as torch tensors); the library allocates nothing the
+ *     caller can see except opaque handles with an explicit *_destroy;
+ *   - every call takes the hipStream_t to enqueue on (as void*), never
+ *     synchronises the device, and returns 0 or a negative IPX_E* code;
+ *   - fp64 values, int32 indices (scipy's defaults);
+ *   - reductions are two-stage and fixed-order: stage 1 writes one partial
+ *     per workgroup into a caller workspace, stage 2 sums them in index
+ *     order, so results do not depend on scheduling.
+ */
+#ifndef IPX_H
+#define IPX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IPX_OK 0
+#define IPX_EINVAL (-1)    /* bad argument */
+#define IPX_ELAUNCH (-2)   /* HIP launch / runtime error */
+#define IPX_ENOTSPD (-3)   /* factorization met a non-positive pivot */
+#define IPX_ENOMEM (-4)
+
+/* Number of doubles of reduction workspace any entry point may need. */
+#define IPX_WS_DOUBLES 65536
+/* Max partials a fused kernel writes per reduced quantity. */
+#define IPX_MAX_PARTIALS 2048
+
+const char *ipx_version(void);
+/* Text of the last HIP error seen by this thread ("" if none). */
+const char *ipx_last_error(void);
+int ipx_device_info(int *cu_count, int *lds_bytes, char *arch, int arch_len);
+
+/* ---- vectors (np elementwise algebra; qp_subproblem.py:212-216,312,580,622,628)
+ * out = a*x + b*y (y may be NULL when b == 0); in-place allowed. */
+int ipx_axpby(int64_t n, double a, const double *x, double b, const double *y,
+              double *out, void *stream);
+/* out = x * y elementwise (diagonal scaling S.dot(d), tr_interior_point.py:111) */
+int ipx_mul(int64_t n, const double *x, const double *y, double *out, void *stream);
+int ipx_fill(int64_t n, double value, double *out, void *stream);
+/* out = min(max(x, lb), ub): reinforce_box_boundaries, qp_subproblem.py:310-317 */
+int ipx_clip(int64_t n, const double *x, const double *lb, const double *ub,
+             double *out, void *stream);
+/* out[i] = a*x[i] + b (scalar shift) */
+int ipx_affine(int64_t n, double a, const double *x, double b, double *out, void *stream);
+
+/* ---- reductions.  `out` is a device array; `ws` >= IPX_WS_DOUBLES doubles.
+ * ipx_dot:      out[0] = sum x*y                      (np.dot)
+ * ipx_norms:    out[0] = sum x^2, out[1] = max |x|    (norm(.), norm(., inf))
+ * ipx_box_inside: out[0] = #{i: x<lb or x>ub}         (inside_box_boundaries :306-308)
+ * ipx_box_sphere_reduce (box_intersections :198-216 + sphere_intersections :112-114):
+ *   out[0]=d.d out[1]=z.d out[2]=z.z
+ *   out[3]=max_i min(t_lb,t_ub) out[4]=min_i max(t_lb,t_ub) over d_i != 0
+ *   out[5]=#{i: d_i==0 and (z_i<lb_i or z_i>ub_i)}   out[6]=#{i: d_i != 0}
+ *   with z' = z0 + zs*z? no: z is used as given; d is scaled by `dscale`
+ *   (the reference passes alpha*p, :585). lb/ub may be NULL (= -inf/+inf). */
+int ipx_dot(int64_t n, const double *x, const double *y, double *out,
+            double *ws, void *stream);
+int ipx_norms(int64_t n, const double *x, double *out, double *ws, void *stream);
+int ipx_box_inside(int64_t n, const double *x, const double *lb, const double *ub,
+                   double *out, double *ws, void *stream);
+int ipx_box_sphere_reduce(int64_t n, const double *z, const double *d, double dscale,
+                          const double *lb, const double *ub, double *out,
+                          double *ws, void *stream);
+
+/* ---- CSR SpMV (scipy _sparsetools csr_matvec; every A.dot / A.T.dot / H.dot).
+ * Row tiles: `tiles` holds ntiles+1 row indices (tile t = rows
+ * [tiles[t], tiles[t+1])) with at most IPX_SPMV_TILE_NNZ nonzeros each unless
+ * a single row is longer; build them with ipx_csr_tiles_host.
+ *
+ * y_out = alpha * (A x)_i  [+ diag_i * x_i]  [+ beta * yin_i]
+ * and, when red != NULL, red[0] = sum_i y_out_i^2, red[1] = sum_i xrow_i * y_out_i
+ * (xrow = x when the matrix is square, used for p'Hp; pass square=0 otherwise).
+ */
+#define IPX_SPMV_TILE_NNZ 2048
+int ipx_csr_tiles_host(int64_t nrows, const int32_t *rowptr_host, int32_t tile_nnz,
+                       int32_t max_rows, int32_t *tiles_out, int64_t cap);
+int ipx_csr_spmv(int64_t nrows, int64_t ncols, const int32_t *rowptr,
+                 const int32_t *colidx, const double *val,
+                 const int32_t *tiles, int32_t ntiles,
+                 const double *x, double alpha,
+                 const double *diag, double beta, const double *yin,
+                 double *yout, int square, double *red, double *ws, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IPX_H */

@@ -1,0 +1,157 @@
+// fp64 CSR SpMV for gfx950 with LDS-staged row tiles ("CSR-stream").
+//
+// A workgroup owns a tile of consecutive rows whose nonzeros form ONE
+// contiguous range of val/colidx.  Phase 1 streams that range from HBM with
+// fully coalesced loads (lane i -> element i), multiplies by the gathered
+// x[col] (served by L2 / Infinity Cache: the x vector of a banded Jacobian is
+// reused by neighbouring rows) and parks the products in LDS.  Phase 2 gives
+// each row to one lane, which adds its products left to right -- the same
+// order as scipy's csr_matvec, so row sums are bit-identical to the
+// reference's `A.dot(x)` (compiled with -ffp-contract=off).
+//
+// Fused epilogue (what the projected-CG loop needs, qp_subproblem.py:556,624;
+// projections.py:52,67): y = alpha*Ax [+ diag*x] [+ beta*yin], and per-tile
+// partials of sum(y^2) and sum(x_row*y) written in tile order.
+//
+// Algorithmic HBM bytes per launch: 12*nnz + 4*(rows+1) + 8*rows + 8*cols
+// (+8*rows for each of diag / yin).
+#include "ipx_common.h"
+
+namespace {
+
+constexpr int TILE_NNZ = IPX_SPMV_TILE_NNZ;
+
+template <bool HAS_DIAG, bool HAS_YIN, bool REDUCE>
+__global__ void __launch_bounds__(IPX_BLOCK)
+k_csr_spmv(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
+           const double *__restrict__ val, const int32_t *__restrict__ tiles,
+           const double *__restrict__ x, double alpha, const double *__restrict__ diag,
+           double beta, const double *yin, double *yout, int square,
+           double *__restrict__ partial, int ntiles) {
+  __shared__ double prod[TILE_NNZ];
+  __shared__ double red_lds[IPX_BLOCK / IPX_WAVE];
+  const int tile = blockIdx.x;
+  const int r0 = tiles[tile], r1 = tiles[tile + 1];
+  const int s = rowptr[r0], e = rowptr[r1];
+  double acc_yy = 0.0, acc_xy = 0.0;
+
+  if (e - s <= TILE_NNZ) {
+    // Phase 1: coalesced stream of the tile's nonzeros.
+    for (int j = s + (int)threadIdx.x; j < e; j += IPX_BLOCK)
+      prod[j - s] = val[j] * x[colidx[j]];
+    __syncthreads();
+    // Phase 2: one lane per row, left-to-right row sums out of LDS.
+    for (int r = r0 + (int)threadIdx.x; r < r1; r += IPX_BLOCK) {
+      const int a = rowptr[r] - s, b = rowptr[r + 1] - s;
+      double sum = 0.0;
+      for (int k = a; k < b; ++k) sum += prod[k];
+      double y = alpha * sum;
+      if (HAS_DIAG) y += diag[r] * x[r];
+      if (HAS_YIN) y += beta * yin[r];
+      yout[r] = y;
+      if (REDUCE) {
+        acc_yy += y * y;
+        if (square) acc_xy += x[r] * y;
+      }
+    }
+  } else {
+    // A tile is over-long only when it is a single very long row: the whole
+    // workgroup strides it and the lane sums are folded in a fixed order.
+    for (int r = r0; r < r1; ++r) {
+      const int a = rowptr[r], b = rowptr[r + 1];
+      double part = 0.0;
+      for (int j = a + (int)threadIdx.x; j < b; j += IPX_BLOCK) part += val[j] * x[colidx[j]];
+      double sum = ipx_block_reduce<IPX_SUM>(part, red_lds);
+      if (threadIdx.x == 0) {
+        double y = alpha * sum;
+        if (HAS_DIAG) y += diag[r] * x[r];
+        if (HAS_YIN) y += beta * yin[r];
+        yout[r] = y;
+        if (REDUCE) {
+          acc_yy += y * y;
+          if (square) acc_xy += x[r] * y;
+        }
+      }
+    }
+  }
+  if (REDUCE) {
+    double a = ipx_block_reduce<IPX_SUM>(acc_yy, red_lds);
+    double b = ipx_block_reduce<IPX_SUM>(acc_xy, red_lds);
+    if (threadIdx.x == 0) { partial[tile] = a; partial[ntiles + tile] = b; }
+  }
+}
+
+// Fold per-tile partials (any count) into red[0..1] in tile order.
+__global__ void __launch_bounds__(IPX_BLOCK)
+k_spmv_fold(const double *partial, int ntiles, double *red) {
+  __shared__ double lds[IPX_BLOCK / IPX_WAVE];
+  double a = ipx_sum_partials<IPX_SUM>(partial, ntiles, lds);
+  double b = ipx_sum_partials<IPX_SUM>(partial + ntiles, ntiles, lds);
+  if (threadIdx.x == 0) { red[0] = a; red[1] = b; }
+}
+
+template <bool D, bool Y, bool R>
+void launch(int ntiles, hipStream_t st, const int32_t *rowptr, const int32_t *colidx,
+            const double *val, const int32_t *tiles, const double *x, double alpha,
+            const double *diag, double beta, const double *yin, double *yout, int square,
+            double *partial) {
+  hipLaunchKernelGGL((k_csr_spmv<D, Y, R>), dim3(ntiles), dim3(IPX_BLOCK), 0, st, rowptr, colidx,
+                     val, tiles, x, alpha, diag, beta, yin, yout, square, partial, ntiles);
+}
+
+}  // namespace
+
+extern "C" {
+
+// Host-side symbolic step: cut rows into tiles of <= tile_nnz nonzeros and
+// <= max_rows rows (a longer single row gets a tile of its own).
+int ipx_csr_tiles_host(int64_t nrows, const int32_t *rowptr, int32_t tile_nnz,
+                       int32_t max_rows, int32_t *tiles_out, int64_t cap) {
+  if (nrows < 0 || !rowptr || !tiles_out || tile_nnz < 1 || max_rows < 1) return IPX_EINVAL;
+  int64_t nt = 0;
+  int64_t r = 0;
+  if (cap < 1) return IPX_EINVAL;
+  tiles_out[0] = 0;
+  while (r < nrows) {
+    int64_t r_end = r + 1;   // always take at least one row
+    while (r_end < nrows && r_end - r < max_rows &&
+           rowptr[r_end + 1] - rowptr[r] <= tile_nnz)
+      ++r_end;
+    ++nt;
+    if (nt >= cap) return IPX_EINVAL;
+    tiles_out[nt] = (int32_t)r_end;
+    r = r_end;
+  }
+  return (int)nt;
+}
+
+int ipx_csr_spmv(int64_t nrows, int64_t ncols, const int32_t *rowptr, const int32_t *colidx,
+                 const double *val, const int32_t *tiles, int32_t ntiles, const double *x,
+                 double alpha, const double *diag, double beta, const double *yin, double *yout,
+                 int square, double *red, double *ws, void *stream) {
+  if (nrows < 0 || ncols < 0 || !rowptr || !tiles || !x || !yout || ntiles < 0) return IPX_EINVAL;
+  if (nrows == 0 || ntiles == 0) {
+    if (red) hipMemsetAsync(red, 0, 2 * sizeof(double), (hipStream_t)stream);
+    return IPX_OK;
+  }
+  if (red && (!ws || 2 * (int64_t)ntiles > IPX_WS_DOUBLES)) return IPX_EINVAL;
+  if (beta == 0.0) yin = nullptr;
+  hipStream_t st = (hipStream_t)stream;
+  const bool D = diag != nullptr, Y = yin != nullptr, R = red != nullptr;
+#define GO(d, y, r)                                                                          \
+  launch<d, y, r>(ntiles, st, rowptr, colidx, val, tiles, x, alpha, diag, beta, yin, yout, \
+                  square, ws)
+  if (D) { if (Y) { if (R) GO(true, true, true); else GO(true, true, false); }
+           else   { if (R) GO(true, false, true); else GO(true, false, false); } }
+  else   { if (Y) { if (R) GO(false, true, true); else GO(false, true, false); }
+           else   { if (R) GO(false, false, true); else GO(false, false, false); } }
+#undef GO
+  IPX_CHECK_LAUNCH();
+  if (R) {
+    hipLaunchKernelGGL(k_spmv_fold, dim3(1), dim3(IPX_BLOCK), 0, st, ws, ntiles, red);
+    IPX_CHECK_LAUNCH();
+  }
+  return IPX_OK;
+}
+
+}  // extern "C"

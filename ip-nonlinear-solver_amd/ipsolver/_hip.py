@@ -1,0 +1,86 @@
+"""ctypes binding of ``libipx.so`` (include/ipx.h) -- the only way this package
+reaches the GPU.  There is no CPU fallback: if the library is missing, or no
+HIP device is visible when a kernel is needed, the import / call fails loudly.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libipx.so")
+
+WS_DOUBLES = 65536          # IPX_WS_DOUBLES
+SPMV_TILE_NNZ = 2048        # IPX_SPMV_TILE_NNZ
+
+_c = ctypes
+_P, _I64, _I32, _F64 = _c.c_void_p, _c.c_int64, _c.c_int32, _c.c_double
+
+# name -> argtypes; every function returns int unless listed in _RESTYPES.
+_SIGNATURES = {
+    "ipx_device_info": [_c.POINTER(_c.c_int), _c.POINTER(_c.c_int), _c.c_char_p, _c.c_int],
+    "ipx_axpby": [_I64, _F64, _P, _F64, _P, _P, _P],
+    "ipx_mul": [_I64, _P, _P, _P, _P],
+    "ipx_fill": [_I64, _F64, _P, _P],
+    "ipx_clip": [_I64, _P, _P, _P, _P, _P],
+    "ipx_affine": [_I64, _F64, _P, _F64, _P, _P],
+    "ipx_dot": [_I64, _P, _P, _P, _P, _P],
+    "ipx_norms": [_I64, _P, _P, _P, _P],
+    "ipx_box_inside": [_I64, _P, _P, _P, _P, _P, _P],
+    "ipx_box_sphere_reduce": [_I64, _P, _P, _F64, _P, _P, _P, _P, _P],
+    "ipx_csr_tiles_host": [_I64, _P, _I32, _I32, _P, _I64],
+    "ipx_csr_spmv": [_I64, _I64, _P, _P, _P, _P, _I32, _P, _F64, _P, _F64, _P, _P,
+                     _c.c_int, _P, _P, _P],
+}
+_RESTYPES = {"ipx_version": _c.c_char_p, "ipx_last_error": _c.c_char_p}
+
+_lib = None
+
+
+class IpxError(RuntimeError):
+    pass
+
+
+_ERRORS = {-1: "invalid argument", -2: "HIP launch/runtime error",
+           -3: "matrix is not positive definite", -4: "out of memory"}
+
+
+def load():
+    """Load libipx.so (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise IpxError(
+            "libipx.so not found at %s: build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` or "
+            "`make -C ip-nonlinear-solver_amd/csrc`. This package has no CPU "
+            "fallback." % LIB_PATH)
+    # torch bundles its own HIP runtime under the same SONAME as /opt/rocm's;
+    # import it first so libipx.so binds to the runtime torch's allocator and
+    # streams live in (two runtimes in one process see no device).
+    import torch  # noqa: F401
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, args in _SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is absent
+        fn.argtypes = args
+        fn.restype = _c.c_int
+    for name, res in _RESTYPES.items():
+        getattr(lib, name).restype = res
+    _lib = lib
+    return lib
+
+
+def exported_symbols():
+    return sorted(list(_SIGNATURES) + list(_RESTYPES))
+
+
+def check(code, what=""):
+    if code < 0:
+        detail = load().ipx_last_error().decode() if code == -2 else ""
+        raise IpxError("%s failed: %s (code %d) %s" % (what or "ipx call",
+                                                       _ERRORS.get(code, "?"), code, detail))
+    return code
+
+
+def call(name, *args):
+    """Call an int-returning entry point and raise on a negative status."""
+    return check(getattr(load(), name)(*args), name)

@@ -1,0 +1,307 @@
+"""Device-resident vectors and matrices: the operand types of the operator seam.
+
+``DVec`` / ``DeviceCSR`` / ``DeviceDense`` own HBM through torch tensors
+(plumbing only: allocation, streams, host<->device copies) and do ALL
+arithmetic through the hand-written kernels in ``libipx.so``.  They expose the
+duck-typed surface the reference's hot path uses (``.dot``, ``.T.dot``,
+``+ - *`` on vectors; qp_subproblem.py:376-410,502-634), so the host control
+flow reads like the reference's.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _hip
+
+_F64 = torch.float64
+_I32 = torch.int32
+
+
+def _require_gpu():
+    if not torch.cuda.is_available():
+        raise _hip.IpxError("no HIP device visible: the ipsolver product path "
+                            "is GPU-only (there is no CPU fallback)")
+
+
+class _Context:
+    """Per-process scratch: reduction workspace and scalar read-back slots."""
+    _inst = None
+
+    def __init__(self):
+        _require_gpu()
+        _hip.load()
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        self.ws = torch.empty(_hip.WS_DOUBLES, dtype=_F64, device=self.device)
+        self.out = torch.zeros(16, dtype=_F64, device=self.device)
+
+    @classmethod
+    def get(cls):
+        if cls._inst is None:
+            cls._inst = cls()
+        return cls._inst
+
+
+def ctx():
+    return _Context.get()
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _empty(n):
+    return torch.empty(int(n), dtype=_F64, device=ctx().device)
+
+
+def _read(k):
+    """Read back the first k reduction outputs (one blocking D2H copy)."""
+    return ctx().out[:k].tolist()
+
+
+# ---------------------------------------------------------------------------
+class DVec:
+    """fp64 device vector with numpy-like arithmetic routed to ipx kernels."""
+    __slots__ = ("t",)
+    __array_priority__ = 1000
+
+    def __init__(self, t):
+        assert t.dtype == _F64 and t.dim() == 1 and t.is_cuda
+        self.t = t if t.is_contiguous() else t.contiguous()
+
+    # -- construction / conversion
+    @staticmethod
+    def from_host(a):
+        _require_gpu()
+        a = np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(-1))
+        return DVec(torch.from_numpy(a).to(ctx().device))
+
+    @staticmethod
+    def zeros(n):
+        return DVec.full(n, 0.0)
+
+    @staticmethod
+    def full(n, value):
+        out = _empty(n)
+        _hip.call("ipx_fill", int(n), float(value), _p(out), stream_ptr())
+        return DVec(out)
+
+    def to_host(self):
+        return self.t.cpu().numpy()
+
+    def copy(self):
+        return DVec(self.t.clone())
+
+    def __len__(self):
+        return self.t.numel()
+
+    @property
+    def shape(self):
+        return (self.t.numel(),)
+
+    @property
+    def size(self):
+        return self.t.numel()
+
+    def __getitem__(self, key):
+        if isinstance(key, slice):
+            return DVec(self.t[key])
+        raise TypeError("DVec supports slice views only")
+
+    # -- arithmetic (each one kernel launch)
+    def _axpby(self, a, other, b):
+        out = _empty(len(self))
+        _hip.call("ipx_axpby", len(self), float(a), _p(self.t), float(b),
+                  _p(other.t) if other is not None else None, _p(out), stream_ptr())
+        return DVec(out)
+
+    def __add__(self, o):
+        if isinstance(o, DVec):
+            return self._axpby(1.0, o, 1.0)
+        out = _empty(len(self))
+        _hip.call("ipx_affine", len(self), 1.0, _p(self.t), float(o), _p(out), stream_ptr())
+        return DVec(out)
+
+    __radd__ = __add__
+
+    def __sub__(self, o):
+        if isinstance(o, DVec):
+            return self._axpby(1.0, o, -1.0)
+        return self.__add__(-float(o))
+
+    def __rsub__(self, o):          # scalar - vec
+        out = _empty(len(self))
+        _hip.call("ipx_affine", len(self), -1.0, _p(self.t), float(o), _p(out), stream_ptr())
+        return DVec(out)
+
+    def __neg__(self):
+        return self._axpby(-1.0, None, 0.0)
+
+    def __mul__(self, o):
+        if isinstance(o, DVec):
+            out = _empty(len(self))
+            _hip.call("ipx_mul", len(self), _p(self.t), _p(o.t), _p(out), stream_ptr())
+            return DVec(out)
+        return self._axpby(float(o), None, 0.0)
+
+    __rmul__ = __mul__
+
+    def dot(self, o):
+        c = ctx()
+        _hip.call("ipx_dot", len(self), _p(self.t), _p(o.t), _p(c.out), _p(c.ws), stream_ptr())
+        return _read(1)[0]
+
+    def sumsq_amax(self):
+        c = ctx()
+        _hip.call("ipx_norms", len(self), _p(self.t), _p(c.out), _p(c.ws), stream_ptr())
+        return _read(2)
+
+
+def norm(v):
+    if len(v) == 0:
+        return 0.0
+    return float(np.sqrt(v.sumsq_amax()[0]))
+
+
+def norm_inf(v):
+    if len(v) == 0:
+        return 0.0
+    return v.sumsq_amax()[1]
+
+
+def clip(x, lb, ub):
+    out = _empty(len(x))
+    _hip.call("ipx_clip", len(x), _p(x.t), _p(lb.t), _p(ub.t), _p(out), stream_ptr())
+    return DVec(out)
+
+
+def count_outside_box(x, lb, ub):
+    c = ctx()
+    _hip.call("ipx_box_inside", len(x), _p(x.t), _p(lb.t), _p(ub.t), _p(c.out), _p(c.ws),
+              stream_ptr())
+    return _read(1)[0]
+
+
+def box_sphere_reduce(z, d, dscale, lb, ub):
+    c = ctx()
+    _hip.call("ipx_box_sphere_reduce", len(z), _p(z.t), _p(d.t), float(dscale),
+              _p(lb.t) if lb is not None else None, _p(ub.t) if ub is not None else None,
+              _p(c.out), _p(c.ws), stream_ptr())
+    return _read(7)
+
+
+def hstack(parts):
+    return DVec(torch.cat([p.t for p in parts]))
+
+
+# ---------------------------------------------------------------------------
+def _tiles_for(rowptr_host, tile_nnz=_hip.SPMV_TILE_NNZ, max_rows=1024):
+    nrows = len(rowptr_host) - 1
+    cap = nrows + 2
+    tiles = np.empty(cap, dtype=np.int32)
+    rp = np.ascontiguousarray(rowptr_host, dtype=np.int32)
+    nt = _hip.call("ipx_csr_tiles_host", nrows, rp.ctypes.data_as(ctypes.c_void_p),
+                   int(tile_nnz), int(max_rows), tiles.ctypes.data_as(ctypes.c_void_p), cap)
+    return tiles[:nt + 1].copy()
+
+
+class CSRPattern:
+    """Sparsity pattern (device + host copies) with its SpMV row tiles and a
+    lazily built transpose.  Patterns are immutable and shared by every value
+    refresh of a Jacobian/Hessian (hard part 7)."""
+
+    def __init__(self, indptr, indices, shape):
+        _require_gpu()
+        self.shape = (int(shape[0]), int(shape[1]))
+        self.indptr_h = np.ascontiguousarray(indptr, dtype=np.int32)
+        self.indices_h = np.ascontiguousarray(indices, dtype=np.int32)
+        dev = ctx().device
+        self.indptr = torch.from_numpy(self.indptr_h).to(dev)
+        self.indices = torch.from_numpy(self.indices_h).to(dev)
+        tiles = _tiles_for(self.indptr_h)
+        self.ntiles = len(tiles) - 1
+        self.tiles = torch.from_numpy(tiles).to(dev)
+        self.nnz = int(self.indptr_h[-1])
+        self._transpose = None
+
+    def same_as(self, indptr, indices):
+        return (len(indptr) == len(self.indptr_h) and len(indices) == len(self.indices_h)
+                and np.array_equal(indptr, self.indptr_h)
+                and np.array_equal(indices, self.indices_h))
+
+    def transpose(self):
+        """(pattern of A', permutation with valT = val[perm]) -- symbolic, once."""
+        if self._transpose is None:
+            import scipy.sparse as sps
+            m, n = self.shape
+            tag = sps.csr_matrix((np.arange(1, self.nnz + 1, dtype=np.float64),
+                                  self.indices_h, self.indptr_h), shape=(m, n))
+            t = sps.csr_matrix(tag.T)
+            t.sort_indices()
+            perm = (t.data - 1).astype(np.int64)
+            pat = CSRPattern(t.indptr, t.indices, (n, m))
+            self._transpose = (pat, torch.from_numpy(perm).to(ctx().device))
+        return self._transpose
+
+
+class DeviceCSR:
+    """CSR matrix in HBM: ``dot`` and ``T.dot`` are owner-computes SpMVs (the
+    transpose is stored as a second CSR, so there are no atomics)."""
+
+    def __init__(self, pattern, val):
+        self.pattern = pattern
+        self.val = val
+        self.shape = pattern.shape
+        self._T = None
+
+    @staticmethod
+    def from_scipy(M, pattern=None):
+        import scipy.sparse as sps
+        M = sps.csr_matrix(M)
+        if not M.has_sorted_indices:
+            M = M.sorted_indices()
+        if pattern is None or not pattern.same_as(M.indptr, M.indices):
+            pattern = CSRPattern(M.indptr, M.indices, M.shape)
+        val = torch.from_numpy(np.ascontiguousarray(M.data, dtype=np.float64)).to(ctx().device)
+        return DeviceCSR(pattern, val)
+
+    def to_scipy(self):
+        import scipy.sparse as sps
+        p = self.pattern
+        return sps.csr_matrix((self.val.cpu().numpy(), p.indices_h, p.indptr_h), shape=p.shape)
+
+    @property
+    def T(self):
+        if self._T is None:
+            pat, perm = self.pattern.transpose()
+            self._T = DeviceCSR(pat, self.val[perm])
+            self._T._T = self
+        return self._T
+
+    def spmv(self, x, alpha=1.0, diag=None, beta=0.0, yin=None, out=None, reduce=False):
+        """out = alpha*A x [+ diag*x] [+ beta*yin]; optionally leaves
+        (sum out^2, sum x*out) in the context's scalar slots."""
+        p = self.pattern
+        m, n = p.shape
+        assert len(x) == n, (len(x), n)
+        if out is None:
+            out = DVec(_empty(m))
+        c = ctx()
+        _hip.call("ipx_csr_spmv", m, n, _p(p.indptr), _p(p.indices), _p(self.val),
+                  _p(p.tiles), p.ntiles, _p(x.t), float(alpha),
+                  _p(diag.t) if diag is not None else None, float(beta),
+                  _p(yin.t) if yin is not None else None, _p(out.t),
+                  1 if m == n else 0, _p(c.out) if reduce else None, _p(c.ws), stream_ptr())
+        return out
+
+    def dot(self, x):
+        return self.spmv(x)
+
+    matvec = dot
+
+    def frobenius_norm(self):
+        return norm(DVec(self.val))

@@ -1,0 +1,133 @@
+"""GPU parity of the primitive kernels (through the C ABI) against numpy/scipy
+on the same seeded inputs.  Elementwise results and CSR row sums must be
+bit-identical (the kernels are built with -ffp-contract=off and sum rows left
+to right like scipy's csr_matvec); reductions agree to rounding."""
+import numpy as np
+import pytest
+import scipy.sparse as sps
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dv():
+    from ipsolver import device
+    return device
+
+
+@pytest.mark.parametrize("n", [1, 7, 64, 1000, 65537, 1 << 20])
+def test_elementwise_bitexact(dv, n):
+    rng = np.random.default_rng(n)
+    x, y = rng.standard_normal(n), rng.standard_normal(n)
+    X, Y = dv.DVec.from_host(x), dv.DVec.from_host(y)
+    assert np.array_equal((X + Y).to_host(), x + y)
+    assert np.array_equal((X - Y).to_host(), x - y)
+    assert np.array_equal((X * Y).to_host(), x * y)
+    assert np.array_equal((-X).to_host(), -x)
+    assert np.array_equal((2.5 * X).to_host(), 2.5 * x)
+    assert np.array_equal((X + 0.3 * Y).to_host(), x + 0.3 * y)
+    assert np.array_equal((X + 1.25).to_host(), x + 1.25)
+    assert np.array_equal((1.0 - X).to_host(), 1.0 - x)
+    lb, ub = np.full(n, -0.5), np.full(n, 0.25)
+    assert np.array_equal(dv.clip(X, dv.DVec.from_host(lb), dv.DVec.from_host(ub)).to_host(),
+                          np.minimum(np.maximum(x, lb), ub))
+    # odd-offset views take the 8-byte path
+    if n > 3:
+        assert np.array_equal((X[1:] + Y[1:]).to_host(), x[1:] + y[1:])
+        assert np.array_equal((X[1:n - 1] - Y[2:]).to_host(), x[1:n - 1] - y[2:])
+
+
+@pytest.mark.parametrize("n", [1, 63, 4097, 1 << 20])
+def test_reductions(dv, n):
+    rng = np.random.default_rng(n + 1)
+    x, y = rng.standard_normal(n), rng.standard_normal(n)
+    X, Y = dv.DVec.from_host(x), dv.DVec.from_host(y)
+    assert abs(X.dot(Y) - x.dot(y)) <= 1e-13 * np.sqrt(n) * max(1, abs(x.dot(y)))
+    assert abs(dv.norm(X) - np.linalg.norm(x)) <= 1e-14 * np.linalg.norm(x)
+    assert dv.norm_inf(X) == np.abs(x).max()
+    # determinism: same bits on every call
+    assert X.dot(Y) == X.dot(Y)
+    lb, ub = -np.abs(rng.standard_normal(n)), np.abs(rng.standard_normal(n))
+    cnt = dv.count_outside_box(X, dv.DVec.from_host(lb), dv.DVec.from_host(ub))
+    assert cnt == np.count_nonzero((x < lb) | (x > ub))
+
+
+def test_box_sphere_reduce(dv):
+    rng = np.random.default_rng(3)
+    n = 50001
+    z, d = rng.standard_normal(n), rng.standard_normal(n)
+    d[::7] = 0.0
+    lb, ub = z - np.abs(rng.standard_normal(n)), z + np.abs(rng.standard_normal(n))
+    lb[::5], ub[::3] = -np.inf, np.inf
+    z[14] = ub[14] + 1.0            # a d==0 coordinate outside the box
+    alpha = 0.37
+    out = dv.box_sphere_reduce(dv.DVec.from_host(z), dv.DVec.from_host(d), alpha,
+                               dv.DVec.from_host(lb), dv.DVec.from_host(ub))
+    dd = alpha * d
+    nz = dd != 0
+    t1, t2 = (lb[nz] - z[nz]) / dd[nz], (ub[nz] - z[nz]) / dd[nz]
+    assert abs(out[0] - dd.dot(dd)) < 1e-10 and abs(out[1] - z.dot(dd)) < 1e-10
+    assert abs(out[2] - z.dot(z)) < 1e-9
+    assert out[3] == np.max(np.minimum(t1, t2))
+    assert out[4] == np.min(np.maximum(t1, t2))
+    assert out[5] == np.count_nonzero(~nz & ((z < lb) | (z > ub)))
+    assert out[6] == np.count_nonzero(nz)
+
+
+def _random_csr(m, n, density, rng, empty_rows=True):
+    M = sps.random(m, n, density=density, format="csr", random_state=np.random.RandomState(5),
+                   data_rvs=rng.standard_normal)
+    if empty_rows and m > 4:
+        M = sps.csr_matrix(M.toarray() * (np.arange(m)[:, None] % 4 != 1))
+    M.sort_indices()
+    return M
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (5, 9), (300, 200), (2000, 2000), (40, 5000)])
+def test_csr_spmv_bitexact(dv, shape):
+    rng = np.random.default_rng(11)
+    m, n = shape
+    M = _random_csr(m, n, min(1.0, 20.0 / n), rng)
+    x = rng.standard_normal(n)
+    A = dv.DeviceCSR.from_scipy(M)
+    X = dv.DVec.from_host(x)
+    assert np.array_equal(A.dot(X).to_host(), M.dot(x))
+    y = rng.standard_normal(m)
+    assert np.array_equal(A.T.dot(dv.DVec.from_host(y)).to_host(), sps.csr_matrix(M.T).dot(y))
+    # fused epilogue: r - A x with sum of squares
+    r = rng.standard_normal(m)
+    out = A.spmv(X, alpha=-1.0, beta=1.0, yin=dv.DVec.from_host(r), reduce=True)
+    want = r - M.dot(x)
+    assert np.array_equal(out.to_host(), want)
+    red = dv.ctx().out[:2].tolist()
+    assert abs(red[0] - want.dot(want)) <= 1e-12 * max(1.0, want.dot(want))
+
+
+def test_csr_spmv_long_rows_and_banded(dv):
+    rng = np.random.default_rng(12)
+    # one dense row far beyond the LDS tile, among short ones
+    dense = np.zeros((6, 9000))
+    dense[2, :] = rng.standard_normal(9000)
+    dense[0, :3] = 1.0
+    dense[5, 17] = -2.0
+    M = sps.csr_matrix(dense)
+    x = rng.standard_normal(9000)
+    got = dv.DeviceCSR.from_scipy(M).dot(dv.DVec.from_host(x)).to_host()
+    want = M.dot(x)
+    assert np.array_equal(got[[0, 1, 3, 4, 5]], want[[0, 1, 3, 4, 5]])
+    assert abs(got[2] - want[2]) <= 1e-12 * np.abs(dense[2]).dot(np.abs(x))
+    # Appendix C banded Jacobian and tridiagonal Hessian with the p'Hp epilogue
+    from banded_setup import BandedInstance
+    inst = BandedInstance(20000, 2000)
+    A = dv.DeviceCSR.from_scipy(inst.A)
+    H = dv.DeviceCSR.from_scipy(inst.H)
+    p = rng.standard_normal(20000)
+    P = dv.DVec.from_host(p)
+    assert np.array_equal(A.dot(P).to_host(), inst.A.dot(p))
+    hp = H.spmv(P, reduce=True)
+    red = dv.ctx().out[:2].tolist()
+    assert np.array_equal(hp.to_host(), inst.H.dot(p))
+    assert abs(red[1] - p.dot(inst.H.dot(p))) <= 1e-12 * abs(p.dot(inst.H.dot(p)))
+    d = rng.standard_normal(20000)
+    hp2 = H.spmv(P, diag=dv.DVec.from_host(d))
+    assert np.array_equal(hp2.to_host(), inst.H.dot(p) + d * p)
