@@ -59,6 +59,12 @@ int ipx_clip(int64_t n, const double *x, const double *lb, const double *ub,
 /* out[i] = a*x[i] + b (scalar shift) */
 int ipx_affine(int64_t n, double a, const double *x, double b, double *out, void *stream);
 
+/* out[i] = sign[i] * (x[idx[i]] - shift[i]); sign / shift may be NULL.  Row
+ * selection + sign flip of the canonical constraint form
+ * (_canonical_constraint.py:240-248) and permutation of constraint-space vectors. */
+int ipx_gather(int64_t n, const double *x, const int32_t *idx, const double *sign,
+               const double *shift, double *out, void *stream);
+
 /* ---- reductions.  `out` is a device array; `ws` >= IPX_WS_DOUBLES doubles.
  * ipx_dot:      out[0] = sum x*y                      (np.dot)
  * ipx_norms:    out[0] = sum x^2, out[1] = max |x|    (norm(.), norm(., inf))
@@ -96,6 +102,22 @@ int ipx_csr_spmv(int64_t nrows, int64_t ncols, const int32_t *rowptr,
                  const double *x, double alpha,
                  const double *diag, double beta, const double *yin,
                  double *yout, int square, double *red, double *ws, void *stream);
+
+/* ---- banded SPD solve with S = A A' (normal equations, projections.py:58-90;
+ * replaces SuperLU solve :102,120 / CHOLMOD :62).  Partitioned (SPIKE-style)
+ * LDL': see csrc/banded.hip.  Half bandwidth <= ipx_banded_kmax(). */
+int ipx_banded_kmax(void);
+void *ipx_banded_create(int64_t m, int32_t k, int32_t chunk);
+void ipx_banded_destroy(void *handle);
+int ipx_banded_levels(void *handle);
+/* band[d*m+i] = S[i][i-d], d = 0..k; must outlive the solves. */
+int ipx_banded_factor(void *handle, const double *band, void *stream);
+/* Blocking: IPX_OK, or IPX_ENOTSPD when a pivot was <= 0 (rank-deficient A). */
+int ipx_banded_status(void *handle, void *stream);
+int ipx_banded_solve(void *handle, const double *w, double *x, void *stream);
+/* band of (P A)(P A)' for CSR A with row order perm (NULL = identity). */
+int ipx_aat_band(int64_t m, int32_t k, const int32_t *rowptr, const int32_t *colidx,
+                 const double *val, const int32_t *perm, double *band, void *stream);
 
 #ifdef __cplusplus
 }

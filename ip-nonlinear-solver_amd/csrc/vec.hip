@@ -35,6 +35,15 @@ struct OpAffine {
   __device__ double operator()(int64_t i) const { return a * x[i] + b; }
 };
 
+struct OpGather {   // out[i] = sign[i] * (x[idx[i]] - shift[i])
+  const double *x; const int32_t *idx; const double *sign, *shift;
+  __device__ double operator()(int64_t i) const {
+    double v = x[idx[i]];
+    if (shift) v -= shift[i];
+    return sign ? sign[i] * v : v;
+  }
+};
+
 template <typename F>
 __global__ void __launch_bounds__(IPX_BLOCK) k_map(int64_t n, F f, double *out) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -216,6 +225,12 @@ int ipx_clip(int64_t n, const double *x, const double *lb, const double *ub, dou
 int ipx_affine(int64_t n, double a, const double *x, double b, double *out, void *stream) {
   if (n < 0 || !x || !out) return IPX_EINVAL;
   return launch_map(n, OpAffine{a, b, x}, out, stream);
+}
+
+int ipx_gather(int64_t n, const double *x, const int32_t *idx, const double *sign,
+               const double *shift, double *out, void *stream) {
+  if (n < 0 || !x || !idx || !out) return IPX_EINVAL;
+  return launch_map(n, OpGather{x, idx, sign, shift}, out, stream);
 }
 
 int ipx_dot(int64_t n, const double *x, const double *y, double *out, double *ws, void *stream) {

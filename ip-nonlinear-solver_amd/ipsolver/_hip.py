@@ -22,6 +22,7 @@ _SIGNATURES = {
     "ipx_fill": [_I64, _F64, _P, _P],
     "ipx_clip": [_I64, _P, _P, _P, _P, _P],
     "ipx_affine": [_I64, _F64, _P, _F64, _P, _P],
+    "ipx_gather": [_I64, _P, _P, _P, _P, _P, _P],
     "ipx_dot": [_I64, _P, _P, _P, _P, _P],
     "ipx_norms": [_I64, _P, _P, _P, _P],
     "ipx_box_inside": [_I64, _P, _P, _P, _P, _P, _P],
@@ -29,8 +30,16 @@ _SIGNATURES = {
     "ipx_csr_tiles_host": [_I64, _P, _I32, _I32, _P, _I64],
     "ipx_csr_spmv": [_I64, _I64, _P, _P, _P, _P, _I32, _P, _F64, _P, _F64, _P, _P,
                      _c.c_int, _P, _P, _P],
+    "ipx_banded_kmax": [],
+    "ipx_banded_levels": [_P],
+    "ipx_banded_factor": [_P, _P, _P],
+    "ipx_banded_status": [_P, _P],
+    "ipx_banded_solve": [_P, _P, _P, _P],
+    "ipx_aat_band": [_I64, _I32, _P, _P, _P, _P, _P, _P],
 }
-_RESTYPES = {"ipx_version": _c.c_char_p, "ipx_last_error": _c.c_char_p}
+_RESTYPES = {"ipx_version": _c.c_char_p, "ipx_last_error": _c.c_char_p,
+             "ipx_banded_create": _P, "ipx_banded_destroy": None}
+_EXTRA_ARGTYPES = {"ipx_banded_create": [_I64, _I32, _I32], "ipx_banded_destroy": [_P]}
 
 _lib = None
 
@@ -65,6 +74,8 @@ def load():
         fn.restype = _c.c_int
     for name, res in _RESTYPES.items():
         getattr(lib, name).restype = res
+    for name, args in _EXTRA_ARGTYPES.items():
+        getattr(lib, name).argtypes = args
     _lib = lib
     return lib
 

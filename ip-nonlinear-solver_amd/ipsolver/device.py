@@ -63,6 +63,9 @@ def _read(k):
     return ctx().out[:k].tolist()
 
 
+read_slots = _read
+
+
 # ---------------------------------------------------------------------------
 class DVec:
     """fp64 device vector with numpy-like arithmetic routed to ipx kernels."""
@@ -118,6 +121,14 @@ class DVec:
         _hip.call("ipx_axpby", len(self), float(a), _p(self.t), float(b),
                   _p(other.t) if other is not None else None, _p(out), stream_ptr())
         return DVec(out)
+
+    def add_scaled(self, o, a):
+        """self + a*o in one pass (1.0*x is exact, so this equals x + a*o)."""
+        return self._axpby(1.0, o, a)
+
+    def scaled_sub(self, a, o):
+        """a*self - o in one pass."""
+        return self._axpby(a, o, -1.0)
 
     def __add__(self, o):
         if isinstance(o, DVec):
@@ -282,9 +293,11 @@ class DeviceCSR:
             self._T._T = self
         return self._T
 
-    def spmv(self, x, alpha=1.0, diag=None, beta=0.0, yin=None, out=None, reduce=False):
-        """out = alpha*A x [+ diag*x] [+ beta*yin]; optionally leaves
-        (sum out^2, sum x*out) in the context's scalar slots."""
+    def spmv(self, x, alpha=1.0, diag=None, beta=0.0, yin=None, out=None, reduce=False,
+             slot=0):
+        """out = alpha*A x [+ diag*x] [+ beta*yin]; with ``reduce`` leaves
+        (sum out^2, sum x*out) in scalar slots [2*slot, 2*slot+1] of the context
+        (read them back with ``read_slots``)."""
         p = self.pattern
         m, n = p.shape
         assert len(x) == n, (len(x), n)
@@ -295,8 +308,19 @@ class DeviceCSR:
                   _p(p.tiles), p.ntiles, _p(x.t), float(alpha),
                   _p(diag.t) if diag is not None else None, float(beta),
                   _p(yin.t) if yin is not None else None, _p(out.t),
-                  1 if m == n else 0, _p(c.out) if reduce else None, _p(c.ws), stream_ptr())
+                  1 if m == n else 0,
+                  ctypes.c_void_p(c.out.data_ptr() + 16 * slot) if reduce else None,
+                  _p(c.ws), stream_ptr())
         return out
+
+    def matvec_sumsq(self, x, slot=0):
+        """(A x, ||A x||^2) -- one blocking read."""
+        out = self.spmv(x, reduce=True, slot=slot)
+        return out, read_slots(2 * slot + 1)[2 * slot]
+
+    def rmatvec_sub(self, v, x, reduce=False, slot=0):
+        """x - A'v (optionally leaving ||.||^2 in the slot)."""
+        return self.T.spmv(v, alpha=-1.0, beta=1.0, yin=x, reduce=reduce, slot=slot)
 
     def dot(self, x):
         return self.spmv(x)

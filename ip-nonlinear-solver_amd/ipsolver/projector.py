@@ -1,0 +1,239 @@
+"""Projection operators Z, LS, Y on the device (reference projections.py).
+
+Formulation: normal equations, the reference's ``NormalEquation`` method
+(projections.py:58-90) -- ``v = (AA')^-1 A x``; ``z = x - A'v`` with the same
+orthogonality-driven refinement loop (:69-78) and the same measure
+``||A z|| / (||A||_F ||z||)`` (:23-55).  The reference's default sparse method
+(AugmentedSystem, SuperLU) and dense method (pivoted QR) compute the same
+three operators; SURVEY.md section 7 records agreement to <= 4e-16 on the
+benchmark problems.
+
+``(AA')^-1`` on MI355X:
+  * sparse A whose ``AA'`` is banded (after a bandwidth-reducing row order found
+    once per sparsity pattern on the host -- symbolic work only): partitioned
+    banded LDL' kernels (csrc/banded.hip);
+  * dense A: Gram matrix + dense Cholesky kernels (csrc/dense.hip).
+All numeric work runs on the GPU; there is no host factorization fallback.
+"""
+import ctypes
+import warnings
+
+import numpy as np
+import torch
+
+from . import _hip
+from . import device as dv
+from .device import DVec, DeviceCSR, CSRPattern, _p, stream_ptr, ctx
+
+_F64 = torch.float64
+
+
+class _Symbolic:
+    """Pattern-level analysis of S = A A' (host, once per pattern)."""
+
+    def __init__(self, pattern):
+        import scipy.sparse as sps
+        from scipy.sparse.csgraph import reverse_cuthill_mckee
+        m, n = pattern.shape
+        ones = np.ones(pattern.nnz, dtype=np.float32)
+        B = sps.csr_matrix((ones, pattern.indices_h, pattern.indptr_h), shape=(m, n))
+        S = sps.csr_matrix(B.dot(B.T))
+        S.sort_indices()
+
+        def half_bw(M):
+            coo = M.tocoo()
+            return int(np.max(np.abs(coo.row - coo.col))) if coo.nnz else 0
+
+        self.k = half_bw(S)
+        self.perm = None
+        if self.k > 1 and m > 2:
+            perm = np.ascontiguousarray(reverse_cuthill_mckee(S, symmetric_mode=True),
+                                        dtype=np.int32)
+            k2 = half_bw(S[perm][:, perm])
+            if k2 < self.k:
+                self.k, self.perm = k2, perm
+        self.m = m
+
+
+_SYMBOLIC_ATTR = "_ipx_aat_symbolic"
+
+
+def _symbolic_for(pattern):
+    sym = getattr(pattern, _SYMBOLIC_ATTR, None)
+    if sym is None:
+        sym = _Symbolic(pattern)
+        setattr(pattern, _SYMBOLIC_ATTR, sym)
+    return sym
+
+
+class BandedNormalSolver:
+    """(A A')^-1 for sparse A with banded A A' (half bandwidth <= kmax)."""
+
+    def __init__(self, A, chunk=64):
+        sym = _symbolic_for(A.pattern)
+        kmax = _hip.load().ipx_banded_kmax()
+        if sym.k > kmax:
+            raise NotImplementedError(
+                "A A' has half bandwidth %d after reordering; the device banded "
+                "solver handles <= %d (no host fallback)" % (sym.k, kmax))
+        self.m = sym.m
+        self.k = max(sym.k, 1)
+        dev = ctx().device
+        self.perm = None
+        if sym.perm is not None:
+            self.perm = torch.from_numpy(sym.perm).to(dev)          # new row i = old row perm[i]
+            inv = np.empty_like(sym.perm)
+            inv[sym.perm] = np.arange(self.m, dtype=np.int32)
+            self.iperm = torch.from_numpy(inv).to(dev)
+        self.band = torch.empty((self.k + 1) * self.m, dtype=_F64, device=dev)
+        lib = _hip.load()
+        self.handle = lib.ipx_banded_create(self.m, self.k, int(chunk))
+        if not self.handle:
+            raise _hip.IpxError("ipx_banded_create failed (m=%d, k=%d)" % (self.m, self.k))
+        p = A.pattern
+        _hip.call("ipx_aat_band", self.m, self.k, _p(p.indptr), _p(p.indices), _p(A.val),
+                  _p(self.perm), _p(self.band), stream_ptr())
+        _hip.call("ipx_banded_factor", ctypes.c_void_p(self.handle), _p(self.band), stream_ptr())
+        rc = lib.ipx_banded_status(ctypes.c_void_p(self.handle), stream_ptr())
+        if rc == -3:
+            raise np.linalg.LinAlgError("Singular Jacobian matrix: A A' is not positive definite")
+        _hip.check(rc, "ipx_banded_status")
+
+    def __del__(self):
+        h, self.handle = getattr(self, "handle", None), None
+        if h:
+            try:
+                _hip.load().ipx_banded_destroy(ctypes.c_void_p(h))
+            except Exception:
+                pass
+
+    def _gather(self, x, idx):
+        out = dv._empty(len(x))
+        _hip.call("ipx_gather", len(x), _p(x.t), _p(idx), None, None, _p(out), stream_ptr())
+        return DVec(out)
+
+    def solve(self, w):
+        """v = (A A')^-1 w, in the caller's (unpermuted) row order."""
+        if self.perm is not None:
+            w = self._gather(w, self.perm)
+        out = dv._empty(self.m)
+        _hip.call("ipx_banded_solve", ctypes.c_void_p(self.handle), _p(w.t), _p(out), stream_ptr())
+        v = DVec(out)
+        if self.perm is not None:
+            v = self._gather(v, self.iperm)
+        return v
+
+
+class _Op:
+    """Operator object returned by ``projections`` (duck type of scipy's
+    LinearOperator as used by the reference: shape / dot / matvec)."""
+
+    def __init__(self, shape, fn):
+        self.shape = shape
+        self._fn = fn
+
+    def dot(self, x):
+        return self._fn(x if isinstance(x, DVec) else DVec.from_host(x))
+
+    matvec = dot
+
+
+class NormalEquationProjector:
+    """Z, LS, Y for a device matrix ``A`` with an ``(AA')^-1`` solver object.
+
+    ``stats`` counts solves / refinement steps (SURVEY.md 3.3 measured 0
+    refinements on the benchmark; the counters let tests assert the same).
+    """
+
+    def __init__(self, A, solver, orth_tol=1e-12, max_refin=3):
+        self.A, self.solver = A, solver
+        self.orth_tol, self.max_refin = orth_tol, max_refin
+        self.m, self.n = A.shape
+        self.norm_A = A.frobenius_norm() if self.m > 0 else 0.0
+        self.stats = {"solves": 0, "refinements": 0}
+
+    # -- reference projections.py:23-55, with ||A z|| from the fused SpMV epilogue
+    def _orthogonality(self, z):
+        """z's ||z||^2 was left in slot 0 by the SpMV that produced it; A z
+        goes to slot 1 so one read-back serves both norms."""
+        Az = self.A.spmv(z, reduce=True, slot=1)
+        red = dv.read_slots(3)
+        norm_z, norm_Az = float(np.sqrt(red[0])), float(np.sqrt(red[2]))
+        if norm_z == 0 or self.norm_A == 0:
+            return 0.0, Az
+        return norm_Az / (self.norm_A * norm_z), Az
+
+    def _apply_inv(self, w):
+        self.stats["solves"] += 1
+        return self.solver.solve(w)
+
+    def null_space(self, x):
+        if self.m == 0:
+            return x.copy()
+        v = self._apply_inv(self.A.dot(x))
+        z = self.A.rmatvec_sub(v, x, reduce=True)    # x - A'v, ||z||^2 -> slot 0
+        k = 0
+        while True:                                  # projections.py:72-78
+            orth, Az = self._orthogonality(z)
+            if not orth > self.orth_tol or k >= self.max_refin:
+                break
+            v = self._apply_inv(Az)
+            z = self.A.rmatvec_sub(v, z, reduce=True)
+            k += 1
+            self.stats["refinements"] += 1
+        return z
+
+    def least_squares(self, x):
+        if self.m == 0:
+            return DVec.zeros(0)
+        return self._apply_inv(self.A.dot(x))
+
+    def row_space(self, x):
+        if self.m == 0:
+            return DVec.zeros(self.n)
+        return self.A.T.dot(self._apply_inv(x))
+
+    def operators(self):
+        return (_Op((self.n, self.n), self.null_space),
+                _Op((self.m, self.n), self.least_squares),
+                _Op((self.n, self.m), self.row_space))
+
+
+def as_device_matrix(A):
+    """Upload a scipy sparse matrix / ndarray (device matrices pass through).
+    An empty matrix is forced to the sparse representation like the
+    reference does (projections.py:368-369)."""
+    import scipy.sparse as sps
+    from .dense import DeviceDense
+    if isinstance(A, (DeviceCSR, DeviceDense)):
+        return A
+    m, n = np.shape(A)
+    if sps.issparse(A) or m * n == 0:
+        return DeviceCSR.from_scipy(sps.csr_matrix(A))
+    return DeviceDense.from_host(np.asarray(A, dtype=float))
+
+
+def projections(A, method=None, orth_tol=1e-12, max_refin=3, tol=1e-15):
+    """Device counterpart of ``projections`` (projections.py:290-406).
+
+    ``A`` is a DeviceCSR / DeviceDense (or a scipy / numpy matrix, uploaded).
+    ``method`` accepts the reference's names; every one maps to the device
+    normal-equation solve (the operators are the same; see module docstring).
+    """
+    from .dense import DenseNormalSolver
+    A = as_device_matrix(A)
+    sparse = isinstance(A, DeviceCSR)
+    if sparse:
+        if method not in (None, "NormalEquation", "AugmentedSystem"):
+            raise ValueError("Method not allowed for sparse matrix.")
+    else:
+        if method not in (None, "QRFactorization", "SVDFactorization"):
+            raise ValueError("Method not allowed for dense array.")
+    m, n = A.shape
+    if m == 0:
+        solver = None
+    elif sparse:
+        solver = BandedNormalSolver(A)
+    else:
+        solver = DenseNormalSolver(A)
+    return NormalEquationProjector(A, solver, orth_tol, max_refin).operators()

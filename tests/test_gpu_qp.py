@@ -1,0 +1,245 @@
+"""GPU parity of the hot path (projections, modified_dogleg, projected_cg and
+the intersection helpers) through the C ABI, against
+
+  * the golden fixtures produced by the reference itself, and
+  * the CPU oracle on the same seeded inputs,
+
+tolerance 1e-10 relative (BASELINE.json north_star), integer outputs
+(niter / stop_cond / hits_boundary) exact.
+"""
+import numpy as np
+import pytest
+import scipy.sparse as sps
+
+import cases_small as cs
+from banded_setup import BandedInstance
+from conftest import unjson
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+@pytest.fixture(scope="module")
+def ips():
+    import ipsolver.qp as qp
+    import ipsolver.projector as proj
+    import ipsolver.device as dv
+
+    class NS:
+        pass
+    ns = NS()
+    ns.qp, ns.proj, ns.dv = qp, proj, dv
+    return ns
+
+
+def host(v):
+    return v.to_host() if hasattr(v, "to_host") else np.asarray(v, dtype=float)
+
+
+def close(a, b, tol=TOL):
+    a, b = host(a), np.asarray(b, dtype=float)
+    assert a.shape == b.shape
+    fin = np.isfinite(b)
+    assert np.array_equal(np.isfinite(a), fin)
+    assert np.array_equal(a[~fin], b[~fin])
+    scale = max(1.0, np.max(np.abs(b[fin]))) if fin.any() else 1.0
+    assert np.max(np.abs(a[fin] - b[fin]), initial=0.0) <= tol * scale
+
+
+def check_interval(got, want):
+    want = unjson(want)
+    assert bool(got[2]) == bool(want[2])
+    close(np.array(got[:2], dtype=float), want[:2])
+
+
+def test_intersections_small(ips, qp_small):
+    it = iter(qp_small["sphere"])
+    for z, d, r in cs.SPHERE:
+        for line in (False, True):
+            check_interval(ips.qp.sphere_intersections(z, d, r, line), next(it))
+    it = iter(qp_small["box"])
+    for z, d, lb, ub in cs.BOX:
+        for line in (False, True):
+            check_interval(ips.qp.box_intersections(z, d, lb, ub, line), next(it))
+    it = iter(qp_small["box_sphere"])
+    for z, d, lb, ub, r in cs.BOX_SPHERE:
+        for line in (False, True):
+            check_interval(ips.qp.box_sphere_intersections(z, d, lb, ub, r, line), next(it))
+
+
+@pytest.mark.parametrize("idx", range(len(cs.PCG)))
+def test_projected_cg_small(ips, qp_small, idx):
+    case, want = cs.PCG[idx], qp_small["pcg"][idx]
+    H = ips.dv.DeviceCSR.from_scipy(sps.csr_matrix(np.array(case["H"], dtype=float)))
+    A = sps.csc_matrix(np.array(case["A"], dtype=float))
+    c = np.array(case["c"], dtype=float)
+    b = np.array(case["b"], dtype=float)
+    Z, _, Y = ips.proj.projections(A)
+    if case.get("raises"):
+        with pytest.raises(ValueError) as err:
+            ips.qp.projected_cg(H, c, Z, Y, b, **case["kw"])
+        assert str(err.value)[:20] == want["raises"][:20]
+        return
+    for return_all in (True, False):
+        x, info = ips.qp.projected_cg(H, c, Z, Y, b, return_all=return_all, **case["kw"])
+        assert info["stop_cond"] == want["stop_cond"]
+        assert info["hits_boundary"] == want["hits_boundary"]
+        close(x, unjson(want["x"]), 1e-6 if case.get("knife_edge") else 1e-9)
+        if case.get("knife_edge"):
+            continue
+        assert info["niter"] == want["niter"]
+        if return_all:
+            assert len(info["allvecs"]) == len(want["allvecs"])
+            for a, w in zip(info["allvecs"], want["allvecs"]):
+                close(a, unjson(w), 1e-9)
+
+
+def test_modified_dogleg_small(ips, qp_small):
+    for (A, b, r, lb, ub), want in zip(cs.DOGLEG, qp_small["dogleg"]):
+        A = np.array(A, dtype=float)
+        Ad = ips.proj.as_device_matrix(A)
+        _, _, Y = ips.proj.projections(Ad)
+        close(ips.qp.modified_dogleg(Ad, Y, np.array(b, float), r, lb, ub), unjson(want))
+
+
+@pytest.mark.parametrize("kind", ["sparse", "dense"])
+def test_projections_3x8(ips, qp_small, kind):
+    A38 = np.array(cs.A38, dtype=float)
+    A = sps.csc_matrix(A38) if kind == "sparse" else A38
+    Z, LS, Y = ips.proj.projections(A)
+    want = qp_small["proj38"]["AugmentedSystem" if kind == "sparse" else "QRFactorization"]
+    for p, wz, wl in zip(cs.A38_POINTS_N, want["Z"], want["LS"]):
+        p = np.array(p, float)
+        close(Z.dot(p), unjson(wz), 1e-9)
+        close(LS.matvec(p), unjson(wl), 1e-9)
+        assert np.max(np.abs(A38.dot(host(Z.dot(p))))) < 1e-8
+    for p, wy in zip(cs.A38_POINTS_M, want["Y"]):
+        close(Y.dot(np.array(p, float)), unjson(wy), 1e-10)
+
+
+@pytest.mark.parametrize("key", ["diag4", "diag3"])
+def test_dense_vs_sparse(ips, qp_small, key):
+    A = cs.diag4_matrix() if key == "diag4" else cs.diag3_matrix()
+    m, n = A.shape
+    rng = np.random.RandomState(0)
+    Zs, LSs, Ys = ips.proj.projections(sps.csc_matrix(A))
+    Zd, LSd, Yd = ips.proj.projections(A)
+    want = qp_small[key]
+    for k in range(3):
+        z, x = rng.normal(size=n), rng.normal(size=m)
+        close(Zs.dot(z), want["Z_sparse"][k], 1e-10)
+        close(Zd.dot(z), want["Z_dense"][k], 1e-10)
+        close(LSs.dot(z), want["LS_sparse"][k], 1e-10)
+        close(LSd.dot(z), want["LS_dense"][k], 1e-10)
+        close(Ys.dot(x), want["Y_sparse"][k], 1e-10)
+        close(Yd.dot(x), want["Y_dense"][k], 1e-10)
+
+
+def test_projection_errors(ips):
+    A38 = np.array(cs.A38, dtype=float)
+    with pytest.raises(ValueError):
+        ips.proj.projections(A38, "AugmentedSystem")
+    with pytest.raises(ValueError):
+        ips.proj.projections(sps.csc_matrix(A38), "QRFactorization")
+    Z, LS, Y = ips.proj.projections(np.empty((0, 5)))
+    np.testing.assert_array_equal(host(Z.dot(np.arange(5.0))), np.arange(5.0))
+    # rank-deficient Jacobian: the device factorization reports it
+    with pytest.raises(np.linalg.LinAlgError):
+        ips.proj.projections(sps.csr_matrix(np.array([[1., 2, 0], [2., 4, 0]])))
+
+
+@pytest.mark.parametrize("m,k,chunk", [(1, 1, 64), (5, 1, 64), (70, 1, 8), (1000, 1, 16),
+                                       (1000, 2, 16), (777, 3, 12), (4000, 4, 32),
+                                       (100000, 1, 64), (30000, 2, 64)])
+def test_banded_solver(ips, m, k, chunk):
+    """(A A')^-1 against scipy's sparse LU on random SPD band matrices built
+    as A A' from a random banded A."""
+    import ctypes
+    import torch
+    from ipsolver import _hip
+    rng = np.random.default_rng(m + k)
+    n = 3 * m + 3 * k + 1
+    # row i touches columns [3i, 3i + 3k] -> rows i, i+k share a column: half bandwidth k
+    rows, cols, vals = [], [], []
+    for d in range(3 * k + 1):
+        rows.append(np.arange(m))
+        cols.append(3 * np.arange(m) + d)
+        vals.append(rng.standard_normal(m))
+    A = sps.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))),
+                       shape=(m, n))
+    A.sort_indices()
+    S = sps.csc_matrix(A.dot(A.T))
+    Ad = ips.dv.DeviceCSR.from_scipy(A)
+    solver = ips.proj.BandedNormalSolver(Ad, chunk=chunk)
+    assert solver.k == k
+    w = rng.standard_normal(m)
+    got = solver.solve(ips.dv.DVec.from_host(w)).to_host()
+    want = sps.linalg.splu(S).solve(w) if m > 1 else w / S[0, 0]
+    err = np.max(np.abs(got - want)) / np.max(np.abs(want))
+    assert err < 1e-11, err
+    # bitwise reproducible
+    again = solver.solve(ips.dv.DVec.from_host(w)).to_host()
+    assert np.array_equal(got, again)
+
+
+def test_banded_solver_with_reordering(ips):
+    """Rows given in an order that makes A A' wide; RCM (symbolic, host) brings
+    it back to a band and the permutation is folded into the solve."""
+    rng = np.random.default_rng(5)
+    m = 3000
+    inst = BandedInstance(30000, m)
+    shuffle = rng.permutation(m)
+    A = sps.csr_matrix(inst.A[shuffle])
+    A.sort_indices()
+    Ad = ips.dv.DeviceCSR.from_scipy(A)
+    solver = ips.proj.BandedNormalSolver(Ad)
+    assert solver.perm is not None and solver.k <= 3
+    w = rng.standard_normal(m)
+    got = solver.solve(ips.dv.DVec.from_host(w)).to_host()
+    want = sps.linalg.splu(sps.csc_matrix(A.dot(A.T))).solve(w)
+    assert np.max(np.abs(got - want)) / np.max(np.abs(want)) < 1e-11
+
+
+@pytest.mark.parametrize("size", ["n2000", "n20000"])
+def test_banded_traces(ips, size, banded2000, banded20000):
+    import oracle
+    gold = banded2000 if size == "n2000" else banded20000
+    n, m = (2000, 200) if size == "n2000" else (20000, 2000)
+    inst = BandedInstance(n, m)
+    s = int(gold["stride"][0])
+    A = ips.dv.DeviceCSR.from_scipy(inst.A)
+    H = ips.dv.DeviceCSR.from_scipy(inst.H)
+    Z, LS, Y = ips.proj.projections(A)
+    for p, w in zip(inst.probes_n, gold["Z"]):
+        close(host(Z.dot(p))[::s], w)
+    for p, w in zip(inst.probes_n, gold["LS"]):
+        close(host(LS.dot(p))[::s], w)
+    for p, w in zip(inst.probes_m, gold["Y"]):
+        close(host(Y.dot(p))[::s], w)
+
+    gnorm = float(gold["gnorm"][0])
+    Zo, _, Yo = oracle.projections(inst.A)
+    for name, kw in inst.pcg_variants(gnorm).items():
+        want = gold["pcg_%s_info" % name]
+        for return_all in (True, False):
+            x, info = ips.qp.projected_cg(H, inst.c, Z, Y, np.zeros(m),
+                                          return_all=return_all, **kw)
+            assert [info["niter"], info["stop_cond"], int(info["hits_boundary"])] == list(want), name
+            close(host(x)[::s], gold["pcg_%s_x" % name])
+            if return_all:
+                for a, w in zip(info["allvecs"], gold["pcg_%s_allvecs" % name]):
+                    close(host(a)[::s], w)
+        # full-vector check against the oracle on the same inputs
+        xo, _ = oracle.projected_cg(inst.H, inst.c, Zo, Yo, np.zeros(m), **kw)
+        close(x, xo)
+
+    y_b = host(Y.dot(inst.b))
+    x, info = ips.qp.projected_cg(H, inst.c, Z, Y, inst.b, tol=0, max_iter=10,
+                                  trust_radius=10 * np.linalg.norm(y_b))
+    assert [info["niter"], info["stop_cond"],
+            int(info["hits_boundary"])] == list(gold["pcg_rowstart_info"])
+    close(host(x)[::s], gold["pcg_rowstart_x"])
+
+    for (radius, lo, hi), w in zip(inst.dogleg_cfg(y_b), gold["dogleg"]):
+        got = ips.qp.modified_dogleg(A, Y, inst.b, radius, np.full(n, lo), np.full(n, hi))
+        close(host(got)[::s], w)
