@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""Headline benchmark: projected-CG iterations/s (fp64) at n=1e6, m=1e5.
+
+A "step" is ONE projected-CG iteration (reference qp_subproblem.py:549-634) on
+the synthetic sparse banded problem of BASELINE.json config 3 (SURVEY.md
+Appendix C: CSR Jacobian 1e5 x 1e6 with 15 nnz/row, tridiagonal-plus-diagonal
+Lagrangian Hessian), run with tol=0 and an infinite trust radius so exactly K
+iterations execute.  All inputs are resident in HBM when the timed region
+starts.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--n 1000000] [--m 100000]
+
+N > 1 is launched by torch.distributed.run (one rank per GPU).  The
+subproblem state is replicated and the batch of independent trust-region
+subproblems is sharded over ranks (multi-GPU): rank r solves
+its own seeded instance; there is no data-path collective, value = total
+iterations of all ranks / max time over ranks.
+
+Prints ONE JSON line (see the driver contract in the task statement) with
+`roofline` for the dominant kernel (the H.p CSR SpMV) and `cpu_baseline`
+(the oracle = numpy/scipy restatement of the reference path, 1 host thread).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "ip-nonlinear-solver_amd"))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def spmv_bytes(nnz, rows, cols, extra_row_vectors=0):
+    """Algorithmic HBM bytes of one CSR SpMV launch."""
+    return 12 * nnz + 4 * (rows + 1) + 8 * rows + 8 * cols + 8 * rows * extra_row_vectors
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--n", type=int, default=1000000)
+    ap.add_argument("--m", type=int, default=100000)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--cpu-iters", type=int, default=30)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks (WORLD_SIZE=%d)"
+                         % (args.gpus, args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from ipsolver import _hip, cg_fused, projector
+    from ipsolver import device as dv
+    from ipsolver.operators import DeviceHessian
+    from ipsolver.synthetic import CenteredBandedNLP
+
+    n, m = args.n, args.m
+    K, W = args.steps, args.warmup
+    lib = _hip.load()
+
+    # ---- synthetic instance (seed differs per rank: independent subproblems)
+    t0 = time.time()
+    prob = CenteredBandedNLP(n, m, seed=rank)
+    x = prob.x0
+    v = 0.1 * np.random.default_rng(7 + rank).standard_normal(m)
+    A_h = prob.constr_jac(x)
+    H_h = prob.hess(x)
+    hdiag_h = prob.kappa * prob.Wt.dot(v)
+    c_h = prob.grad(x)
+    t_gen = time.time() - t0
+
+    A = dv.DeviceCSR.from_scipy(A_h)
+    H = DeviceHessian(n, csr=dv.DeviceCSR.from_scipy(H_h), diag=dv.DVec.from_host(hdiag_h))
+    c = dv.DVec.from_host(c_h)
+    b = dv.DVec.zeros(m)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    Z, LS, Y = projector.projections(A)
+    torch.cuda.synchronize()
+    t_factor = time.time() - t0
+    P = Z.projector
+
+    # ---- prime the loop exactly like projected_cg does (untimed)
+    x0 = Y.dot(-b)
+    r0 = Z.dot(H.dot(x0) + c)
+    g0 = Z.dot(r0)
+    rt_g = g0.sumsq_amax()[0]
+    L = cg_fused._Loop(H, P, None, None)
+    st = dv.stream_ptr()
+    L.x.copy_(x0.t)
+    L.r.copy_(r0.t)
+    _hip.call("ipx_axpby", n, -1.0, dv._p(g0.t), 0.0, None, dv._p(L.p), st)
+    init = np.zeros(L.state.numel())
+    init[cg_fused.ST_RTG0] = rt_g
+    init[cg_fused.ST_TOL] = 0.0
+    init[cg_fused.ST_RADIUS] = np.inf
+    init[cg_fused.ST_ORTH_RHS] = P.orth_tol * P.norm_A
+    L.state.copy_(torch.from_numpy(init))
+    _hip.check(lib.ipx_cg_hp(L.ref(), st), "ipx_cg_hp")
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- warmup, then EXACTLY K timed iterations
+    _hip.check(lib.ipx_cg_iterate(L.ref(), 0, W, st), "warmup")
+    barrier()
+    t0 = time.perf_counter()
+    _hip.check(lib.ipx_cg_iterate(L.ref(), W, W + K, st), "timed")
+    barrier()
+    elapsed = time.perf_counter() - t0
+    s = L.state.tolist()
+    if int(s[cg_fused.ST_STOP]) != 0 or int(s[cg_fused.ST_IT_DONE]) != W + K:
+        raise SystemExit("timed region did not run %d iterations: stop=%s done=%s"
+                         % (K, s[cg_fused.ST_STOP], s[cg_fused.ST_IT_DONE]))
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # ---- per-kernel attribution with HIP events on the launch stream
+    ms = (ctypes.c_float * 7)()
+    kt = min(K, 100)
+    _hip.check(lib.ipx_cg_iterate_timed(L.ref(), W + K, W + K + kt, ms, st), "timed-events")
+    names = ["step1", "spmv_A_r", "banded_solve", "spmv_r_minus_Atv", "spmv_A_g", "step2",
+             "spmv_H_p"]
+    per_kernel_us = {k: 1e3 * ms[i] / kt for i, k in enumerate(names)}
+
+    nnzA, nnzH = A.pattern.nnz, H.csr.pattern.nnz
+    bytes_hp = spmv_bytes(nnzH, n, n, extra_row_vectors=1)           # + diag vector
+    algo = {
+        "spmv_H_p": bytes_hp,
+        "spmv_A_r": spmv_bytes(nnzA, m, n),
+        "spmv_A_g": spmv_bytes(nnzA, m, n),
+        "spmv_r_minus_Atv": spmv_bytes(nnzA, n, m, extra_row_vectors=1),
+        "step1": 5 * 8 * n,     # read x,p,r,Hp; write r
+        "step2": 5 * 8 * n,     # read x,p,g;   write x,p
+    }
+    dom = "spmv_H_p"
+    achieved = algo[dom] / (per_kernel_us[dom] * 1e-6) / 1e9
+    iter_bytes = sum(algo.values()) + 4 * 8 * m
+    result = {
+        "metric": "projected-CG iters/sec (fp64) at n=1e6,m=1e5",
+        "value": world * K / elapsed,
+        "unit": "iterations/s",
+        "n_gpus": world,
+        "steps": K,
+        "warmup": W,
+        "ms_per_step": 1e3 * elapsed / K,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": "config3: sparse banded NLP subproblem, CSR Jacobian "
+                               "bandwidth 15, tol=0, trust_radius=inf",
+                   "n": n, "m": m, "nnz_A": nnzA, "nnz_H": nnzH,
+                   "parallelism": "1 subproblem per GPU" if world > 1 else "single GPU"},
+        "roofline": {"bound": "hbm", "kernel": "k_csr_spmv (H.p with p'Hp epilogue)",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_launch": algo[dom],
+                     "avg_launch_us": per_kernel_us[dom]},
+        "per_kernel_us": per_kernel_us,
+        "whole_iteration": {"algorithmic_bytes": iter_bytes,
+                            "achieved_GBs": iter_bytes / (elapsed / K) / 1e9,
+                            "frac_of_hbm_peak": iter_bytes / (elapsed / K) / 1e9 / HBM_PEAK_GBS},
+        "setup_s": {"generate_host": t_gen, "factor_device": t_factor},
+    }
+
+    # ---- CPU baseline: the oracle (numpy/scipy restatement), rank 0, N=1 only
+    if rank == 0 and world == 1 and not args.no_cpu:
+        import oracle
+        os.environ.setdefault("OMP_NUM_THREADS", "1")
+        t0 = time.time()
+        Zo, _, Yo = oracle.projections(A_h)            # AugmentedSystem (SuperLU), as the reference
+        t_fac = time.time() - t0
+        H_full = H_h + __import__("scipy.sparse", fromlist=["diags"]).diags(hdiag_h)
+        kc = args.cpu_iters
+        t0 = time.time()
+        xo, info = oracle.projected_cg(H_full, c_h, Zo, Yo, np.zeros(m), tol=0, max_iter=kc)
+        t_cg = time.time() - t0
+        result["cpu_baseline"] = {
+            "value": info["niter"] / t_cg, "unit": "iterations/s", "cores": 1, "kind": "port",
+            "sample": "%d projected-CG iterations of the same n=%d, m=%d instance through "
+                      "oracle/ (scipy SuperLU augmented-system projections, numpy vectors); "
+                      "factorization %.1f s not included" % (info["niter"], n, m, t_fac)}
+        # parity of the GPU iterates with the CPU oracle after the same number of iterations
+        xg, ginfo = cg_fused.projected_cg(H, c, Z, Y, b, tol=0, max_iter=kc)
+        err = np.max(np.abs(xg.to_host() - xo)) / np.max(np.abs(xo))
+        result["parity_vs_oracle"] = {"iterations": kc, "max_rel_err": float(err)}
+
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -119,6 +119,36 @@ int ipx_banded_solve(void *handle, const double *w, double *x, void *stream);
 int ipx_aat_band(int64_t m, int32_t k, const int32_t *rowptr, const int32_t *colidx,
                  const double *val, const int32_t *perm, double *band, void *stream);
 
+/* ---- device-resident projected CG (qp_subproblem.py:549-634): see csrc/cg.hip.
+ * The argument block holds device pointers only; every member is 8 bytes. */
+typedef struct ipx_cg_args {
+  int64_t n, m;
+  const int32_t *A_rowptr, *A_colidx; const double *A_val; const int32_t *A_tiles; int64_t A_ntiles;
+  const int32_t *At_rowptr, *At_colidx; const double *At_val; const int32_t *At_tiles; int64_t At_ntiles;
+  const int32_t *H_rowptr, *H_colidx; const double *H_val; const int32_t *H_tiles; int64_t H_ntiles;
+  const double *H_diag;
+  void *banded;
+  double *x, *p, *r, *Hp;
+  double *w, *v, *t;
+  const double *lb, *ub;
+  double *state;
+  double *part1, *part2, *part3, *part4;
+  int64_t vec_grid;
+} ipx_cg_args;
+int ipx_cg_state_size(void);
+int ipx_cg_vec_grid(int64_t n);
+/* Hp = H p (+ diag*p) with p'Hp partials: primes the loop. */
+int ipx_cg_hp(const ipx_cg_args *a, void *stream);
+/* Enqueue iterations [it_begin, it_end); never synchronises. */
+int ipx_cg_iterate(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, void *stream);
+/* Same launches with HIP events around each kernel class; synchronises once at
+ * the end and returns per-class totals in ms_out[0..6] = {step1, A r, banded,
+ * r-A'v, A g, step2, H p}.  For per-kernel attribution in bench.py. */
+int ipx_cg_iterate_timed(const ipx_cg_args *a, int32_t it_begin, int32_t it_end,
+                         float *ms_out, void *stream);
+/* Finish iteration `it` after the host handled a stop-5/6 event. */
+int ipx_cg_resume(const ipx_cg_args *a, int32_t it, int32_t mode, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -214,7 +214,8 @@ k_reduced_matrix(int m, int c, int P, const double *__restrict__ band,
 template <int K>
 __global__ void __launch_bounds__(IPX_WAVE)
 k_solve_chunks(int m, int c, int P, const double *__restrict__ Dinv, const double *__restrict__ L,
-               const double *__restrict__ w, double *__restrict__ y) {
+               const double *w, double *y, const double *__restrict__ guard) {
+  if (guard && *guard != 0.0) return;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= P) return;
   const int q = c + K, base = t * q;
@@ -251,7 +252,9 @@ k_solve_chunks(int m, int c, int P, const double *__restrict__ Dinv, const doubl
 template <int K>
 __global__ void __launch_bounds__(IPX_BLOCK)
 k_reduced_rhs(int m, int c, int P, const double *__restrict__ band, const double *__restrict__ w,
-              const double *__restrict__ y, double *__restrict__ g) {
+              const double *__restrict__ y, double *__restrict__ g,
+              const double *__restrict__ guard) {
+  if (guard && *guard != 0.0) return;
   const int mR = (P - 1) * K;
   const int qrow = blockIdx.x * blockDim.x + threadIdx.x;
   if (qrow >= mR) return;
@@ -270,7 +273,9 @@ k_reduced_rhs(int m, int c, int P, const double *__restrict__ band, const double
 template <int K>
 __global__ void __launch_bounds__(IPX_BLOCK)
 k_correct(int m, int c, int P, const double *__restrict__ V, const double *__restrict__ W,
-          const double *__restrict__ xs, double *__restrict__ x) {
+          const double *__restrict__ xs, double *__restrict__ x,
+          const double *__restrict__ guard) {
+  if (guard && *guard != 0.0) return;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m) return;
   const int q = c + K;
@@ -335,25 +340,26 @@ struct Launch {
     }
     return IPX_OK;
   }
-  static int down(Banded *h, int li, const double *w, double *y, hipStream_t st) {
+  static int down(Banded *h, int li, const double *w, double *y, const double *guard,
+                  hipStream_t st) {
     Level &lv = h->lev[li];
     int grid = (lv.P + IPX_WAVE - 1) / IPX_WAVE;
     hipLaunchKernelGGL(k_solve_chunks<K>, dim3(grid), dim3(IPX_WAVE), 0, st, lv.m, lv.c, lv.P,
-                       lv.Dinv, lv.L, w, y);
+                       lv.Dinv, lv.L, w, y, guard);
     IPX_CHECK_LAUNCH();
     if (lv.mR > 0) {
       Level &nx = h->lev[li + 1];
       hipLaunchKernelGGL(k_reduced_rhs<K>, dim3((lv.mR + IPX_BLOCK - 1) / IPX_BLOCK),
-                         dim3(IPX_BLOCK), 0, st, lv.m, lv.c, lv.P, lv.band, w, y, nx.rhs);
+                         dim3(IPX_BLOCK), 0, st, lv.m, lv.c, lv.P, lv.band, w, y, nx.rhs, guard);
       IPX_CHECK_LAUNCH();
     }
     return IPX_OK;
   }
-  static int up(Banded *h, int li, double *x, hipStream_t st) {
+  static int up(Banded *h, int li, double *x, const double *guard, hipStream_t st) {
     Level &lv = h->lev[li];
     Level &nx = h->lev[li + 1];
     hipLaunchKernelGGL(k_correct<K>, dim3((lv.m + IPX_BLOCK - 1) / IPX_BLOCK), dim3(IPX_BLOCK), 0,
-                       st, lv.m, lv.c, lv.P, lv.V, lv.W, nx.sol, x);
+                       st, lv.m, lv.c, lv.P, lv.V, lv.W, nx.sol, x, guard);
     IPX_CHECK_LAUNCH();
     return IPX_OK;
   }
@@ -373,10 +379,12 @@ struct Launch {
   }
 
 int level_factor(Banded *h, int li, hipStream_t st) { DISPATCH_K(h->lev[li].k, factor(h, li, st)) }
-int level_down(Banded *h, int li, const double *w, double *y, hipStream_t st) {
-  DISPATCH_K(h->lev[li].k, down(h, li, w, y, st))
+int level_down(Banded *h, int li, const double *w, double *y, const double *guard, hipStream_t st) {
+  DISPATCH_K(h->lev[li].k, down(h, li, w, y, guard, st))
 }
-int level_up(Banded *h, int li, double *x, hipStream_t st) { DISPATCH_K(h->lev[li].k, up(h, li, x, st)) }
+int level_up(Banded *h, int li, double *x, const double *guard, hipStream_t st) {
+  DISPATCH_K(h->lev[li].k, up(h, li, x, guard, st))
+}
 
 template <typename T>
 T *dalloc(Banded *h, size_t n) {
@@ -482,21 +490,7 @@ int ipx_banded_status(void *handle, void *stream) {
 
 // x = S^-1 w.  w and x are length m; x may alias w.
 int ipx_banded_solve(void *handle, const double *w, double *x, void *stream) {
-  if (!handle || !w || !x) return IPX_EINVAL;
-  Banded *h = (Banded *)handle;
-  hipStream_t st = (hipStream_t)stream;
-  for (int li = 0; li < h->nlev; ++li) {
-    const double *in = li == 0 ? w : h->lev[li].rhs;
-    double *out = li == 0 ? x : h->lev[li].sol;
-    int rc = level_down(h, li, in, out, st);
-    if (rc != IPX_OK) return rc;
-  }
-  for (int li = h->nlev - 2; li >= 0; --li) {
-    double *out = li == 0 ? x : h->lev[li].sol;
-    int rc = level_up(h, li, out, st);
-    if (rc != IPX_OK) return rc;
-  }
-  return IPX_OK;
+  return ipx_banded_solve_guarded(handle, w, x, nullptr, (hipStream_t)stream);
 }
 
 // band[d*m+i] = (A A')[pi, p(i-d)] with rows taken in the order perm (NULL =
@@ -514,3 +508,21 @@ int ipx_aat_band(int64_t m, int32_t k, const int32_t *rowptr, const int32_t *col
 }
 
 }  // extern "C"
+
+int ipx_banded_solve_guarded(void *handle, const double *w, double *x, const double *guard,
+                             hipStream_t st) {
+  if (!handle || !w || !x) return IPX_EINVAL;
+  Banded *h = (Banded *)handle;
+  for (int li = 0; li < h->nlev; ++li) {
+    const double *in = li == 0 ? w : h->lev[li].rhs;
+    double *out = li == 0 ? x : h->lev[li].sol;
+    int rc = level_down(h, li, in, out, guard, st);
+    if (rc != IPX_OK) return rc;
+  }
+  for (int li = h->nlev - 2; li >= 0; --li) {
+    double *out = li == 0 ? x : h->lev[li].sol;
+    int rc = level_up(h, li, out, guard, st);
+    if (rc != IPX_OK) return rc;
+  }
+  return IPX_OK;
+}

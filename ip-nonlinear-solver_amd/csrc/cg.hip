@@ -1,0 +1,249 @@
+// Device-resident projected CG iteration (Steihaug-Toint; reference
+// qp_subproblem.py:549-634) for gfx950.
+//
+// The reference loop has three scalar-gated branches per iteration
+// (rt_g < tol :551, p'Hp <= 0 :558, ||x_next|| >= radius :583).  Reading those
+// scalars on the host costs more than the HBM time of the whole iteration, so
+// here they never leave the device: every kernel's prologue folds the
+// per-workgroup partial sums left by its predecessor in a FIXED order (so all
+// workgroups derive bit-identical scalars), takes the branch, and workgroup 0
+// records it in a small state block.  A non-zero `stop` field turns every
+// later kernel of the stream into a no-op; the host reads the state block
+// only once per batch of iterations.
+//
+// One iteration = 2 streaming vector kernels + 4 SpMVs + the banded solve:
+//
+//   step1  alpha = rt_g / p'Hp;  r += alpha*Hp;  partials of ||x+alpha p||^2,
+//          # of box violations of x + alpha p            (x itself untouched)
+//   spmv   w = A r
+//   banded v = (AA')^-1 w
+//   spmv   r = r - A'v  (= g_next; the reference sets r = g, :632), ||g||^2 partials
+//   spmv   t = A g, ||t||^2 partials                     (orthogonality, projections.py:52)
+//   step2  checks: ||x_next|| >= radius -> stop 2; box violated -> stop 5 (host
+//          finishes the iteration); orthogonality > tol -> stop 6 (host refines);
+//          else beta = ||g||^2/rt_g;  x += alpha p;  p = beta p - g
+//   spmv   Hp = H p (+ diag*p), p'Hp partials
+//
+// Because x is only advanced in step2, every early exit leaves (x, p, alpha)
+// exactly as the reference's exit paths (:565-576, :585-596) need them.
+#include "ipx_common.h"
+#include <vector>
+
+// state block layout (doubles)
+enum {
+  ST_RTG0 = 0, ST_RTG1 = 1,   // rt_g, double buffered by iteration parity
+  ST_TOL = 2, ST_RADIUS = 3, ST_ALPHA = 4, ST_STOP = 5, ST_NITER = 6, ST_BETA = 7,
+  ST_PTHP = 8, ST_ORTH_RHS = 9,   // orth_tol * ||A||_F  (0 disables the check)
+  ST_XNORM2 = 10, ST_VIOL = 11, ST_ORTH = 12, ST_IT_DONE = 13,
+  ST_SIZE = 16
+};
+
+namespace {
+
+constexpr int VB = IPX_BLOCK;
+
+__global__ void __launch_bounds__(VB)
+k_cg_step1(int64_t n, double *st, int parity, const double *__restrict__ p1, int np1,
+           const double *__restrict__ x, const double *__restrict__ p, double *r,
+           const double *__restrict__ Hp, const double *__restrict__ lb,
+           const double *__restrict__ ub, double *__restrict__ p2) {
+  __shared__ double lds[VB / IPX_WAVE];
+  if (st[ST_STOP] != 0.0) return;
+  // p'Hp from the partials of the SpMV that produced Hp (second half: x.y sums)
+  const double ptHp = ipx_sum_partials<IPX_SUM>(p1 + np1, np1, lds);
+  const double rtg = st[parity ? ST_RTG1 : ST_RTG0];
+  const double tol = st[ST_TOL];
+  if (rtg < tol) {                                   // qp_subproblem.py:551
+    if (blockIdx.x == 0 && threadIdx.x == 0) st[ST_STOP] = 4.0;
+    return;
+  }
+  if (ptHp <= 0.0) {                                 // :558
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      st[ST_NITER] += 1.0; st[ST_PTHP] = ptHp; st[ST_STOP] = 3.0;
+    }
+    return;
+  }
+  const double alpha = rtg / ptHp;                   // :579
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    st[ST_NITER] += 1.0; st[ST_PTHP] = ptHp; st[ST_ALPHA] = alpha;
+  }
+  double sx = 0.0, viol = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const double pi = p[i];
+    const double xn = x[i] + alpha * pi;             // :580 (not stored)
+    sx += xn * xn;
+    if (lb) viol += ((lb[i] <= xn) && (xn <= ub[i])) ? 0.0 : 1.0;   // :599
+    r[i] = r[i] + alpha * Hp[i];                     // :622
+  }
+  const double a = ipx_block_reduce<IPX_SUM>(sx, lds);
+  const double b = ipx_block_reduce<IPX_SUM>(viol, lds);
+  if (threadIdx.x == 0) { p2[blockIdx.x] = a; p2[gridDim.x + blockIdx.x] = b; }
+}
+
+// mode bit0: skip the radius / box checks (host already handled them)
+//      bit1: skip the orthogonality check (host already refined)
+__global__ void __launch_bounds__(VB)
+k_cg_step2(int64_t n, double *st, int parity, int mode, const double *__restrict__ p2, int np2,
+           const double *__restrict__ p3, int np3, const double *__restrict__ p4, int np4,
+           double *x, double *p, const double *__restrict__ g) {
+  __shared__ double lds[VB / IPX_WAVE];
+  if (st[ST_STOP] != 0.0) return;
+  const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
+  if (!(mode & 1)) {
+    const double xn2 = ipx_sum_partials<IPX_SUM>(p2, np2, lds);
+    const double viol = ipx_sum_partials<IPX_SUM>(p2 + np2, np2, lds);
+    if (sqrt(xn2) >= st[ST_RADIUS]) {                // :583
+      if (lead) { st[ST_XNORM2] = xn2; st[ST_STOP] = 2.0; }
+      return;
+    }
+    if (viol > 0.0) {                                // :599-616 continues on the host
+      if (lead) { st[ST_VIOL] = viol; st[ST_STOP] = 5.0; }
+      return;
+    }
+  }
+  const double gg = ipx_sum_partials<IPX_SUM>(p3, np3, lds);     // ||g_next||^2
+  if (!(mode & 2)) {
+    const double tt = ipx_sum_partials<IPX_SUM>(p4, np4, lds);   // ||A g_next||^2
+    const double rhs = st[ST_ORTH_RHS];
+    // orthogonality(A, g) > orth_tol  <=>  ||A g|| > orth_tol ||A||_F ||g||
+    if (rhs > 0.0 && gg > 0.0 && sqrt(tt) > rhs * sqrt(gg)) {
+      if (lead) { st[ST_ORTH] = sqrt(tt) / sqrt(gg); st[ST_STOP] = 6.0; }
+      return;
+    }
+  }
+  const double rtg = st[parity ? ST_RTG1 : ST_RTG0];
+  const double beta = gg / rtg;                      // :627
+  const double alpha = st[ST_ALPHA];
+  if (lead) {
+    st[parity ? ST_RTG0 : ST_RTG1] = gg;             // :633
+    st[ST_BETA] = beta;
+    st[ST_IT_DONE] += 1.0;
+  }
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const double pi = p[i];
+    x[i] = x[i] + alpha * pi;                        // :580,630
+    p[i] = beta * pi - g[i];                         // :628
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int ipx_cg_state_size(void) { return ST_SIZE; }
+int ipx_cg_vec_grid(int64_t n) { return ipx_grid_for(n, VB * 2); }
+
+static int launch_hp(const ipx_cg_args *a, const double *guard, hipStream_t st) {
+  ipx_csr_view H{(int)a->n, (int)a->n, a->H_rowptr, a->H_colidx, a->H_val, a->H_tiles, (int)a->H_ntiles};
+  return ipx_spmv_launch(H, a->p, 1.0, a->H_diag, 0.0, nullptr, a->Hp, a->part1, guard, st);
+}
+
+// Hp = H p with p'Hp partials (the tail of an iteration, also used once by
+// the host to prime the loop).
+int ipx_cg_hp(const ipx_cg_args *a, void *stream) {
+  if (!a) return IPX_EINVAL;
+  return launch_hp(a, nullptr, (hipStream_t)stream);
+}
+
+// Tail of an iteration after the host handled a stop-5 / stop-6 event:
+// step2 with the given mode, then Hp = H p.
+int ipx_cg_resume(const ipx_cg_args *a, int32_t it, int32_t mode, void *stream) {
+  if (!a) return IPX_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const double *guard = a->state + ST_STOP;
+  hipLaunchKernelGGL(k_cg_step2, dim3((unsigned)a->vec_grid), dim3(VB), 0, st, a->n, a->state, it & 1, mode,
+                     a->part2, (int)a->vec_grid, a->part3, (int)a->At_ntiles, a->part4, (int)a->A_ntiles,
+                     a->x, a->p, a->r);
+  IPX_CHECK_LAUNCH();
+  return launch_hp(a, guard, st);
+}
+
+// Enqueue iterations it_begin .. it_end-1.  Never synchronises.
+static int cg_iterate(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, hipStream_t st,
+                      hipEvent_t *ev);
+
+int ipx_cg_iterate(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, void *stream) {
+  if (!a || it_end < it_begin) return IPX_EINVAL;
+  return cg_iterate(a, it_begin, it_end, (hipStream_t)stream, nullptr);
+}
+
+// Instrumented variant for bench.py: HIP events are recorded on `stream`
+// around every kernel class of every iteration; after one final stream
+// synchronise the per-class totals (ms) are returned in ms_out[0..6]:
+// step1, spmv A r, banded solve, spmv r-A'v, spmv A g, step2, spmv H p.
+// Slower than ipx_cg_iterate (event records between kernels) -- use it for
+// per-kernel attribution, not for the throughput number.
+#define IPX_CG_NCLASS 7
+int ipx_cg_iterate_timed(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, float *ms_out,
+                         void *stream) {
+  if (!a || it_end < it_begin || !ms_out) return IPX_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int per_it = IPX_CG_NCLASS + 1;
+  const int nit = it_end - it_begin;
+  std::vector<hipEvent_t> ev((size_t)nit * per_it);
+  for (auto &e : ev)
+    if (hipEventCreate(&e) != hipSuccess) return IPX_ELAUNCH;
+  int rc = IPX_OK;
+  for (int i = 0; i < nit && rc == IPX_OK; ++i)
+    rc = cg_iterate(a, it_begin + i, it_begin + i + 1, st, ev.data() + (size_t)i * per_it);
+  if (hipStreamSynchronize(st) != hipSuccess) rc = IPX_ELAUNCH;
+  for (int c = 0; c < IPX_CG_NCLASS; ++c) ms_out[c] = 0.f;
+  if (rc == IPX_OK) {
+    for (int i = 0; i < nit; ++i)
+      for (int c = 0; c < IPX_CG_NCLASS; ++c) {
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, ev[(size_t)i * per_it + c], ev[(size_t)i * per_it + c + 1]);
+        ms_out[c] += ms;
+      }
+  }
+  for (auto &e : ev) (void)hipEventDestroy(e);
+  return rc;
+}
+
+static int cg_iterate(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, hipStream_t st,
+                      hipEvent_t *ev) {
+  const double *guard = a->state + ST_STOP;
+  ipx_csr_view A{(int)a->m, (int)a->n, a->A_rowptr, a->A_colidx, a->A_val, a->A_tiles, (int)a->A_ntiles};
+  ipx_csr_view At{(int)a->n, (int)a->m, a->At_rowptr, a->At_colidx, a->At_val, a->At_tiles, (int)a->At_ntiles};
+#define MARK(i) do { if (ev) (void)hipEventRecord(ev[i], st); } while (0)
+  for (int it = it_begin; it < it_end; ++it) {
+    MARK(0);
+    hipLaunchKernelGGL(k_cg_step1, dim3((unsigned)a->vec_grid), dim3(VB), 0, st, a->n, a->state, it & 1,
+                       a->part1, (int)a->H_ntiles, a->x, a->p, a->r, a->Hp, a->lb, a->ub, a->part2);
+    IPX_CHECK_LAUNCH();
+    MARK(1);
+    int rc;
+    if (a->m > 0) {
+      // w = A r_next
+      rc = ipx_spmv_launch(A, a->r, 1.0, nullptr, 0.0, nullptr, a->w, nullptr, guard, st);
+      if (rc) return rc;
+      MARK(2);
+      // v = (AA')^-1 w
+      rc = ipx_banded_solve_guarded(a->banded, a->w, a->v, guard, st);
+      if (rc) return rc;
+      MARK(3);
+      // r = r - A'v  (g_next), partials of ||g||^2
+      rc = ipx_spmv_launch(At, a->v, -1.0, nullptr, 1.0, a->r, a->r, a->part3, guard, st);
+      if (rc) return rc;
+      MARK(4);
+      // t = A g, partials of ||t||^2
+      rc = ipx_spmv_launch(A, a->r, 1.0, nullptr, 0.0, nullptr, a->t, a->part4, guard, st);
+      if (rc) return rc;
+      MARK(5);
+    }
+    hipLaunchKernelGGL(k_cg_step2, dim3((unsigned)a->vec_grid), dim3(VB), 0, st, a->n, a->state, it & 1,
+                       a->m > 0 ? 0 : 2, a->part2, (int)a->vec_grid, a->part3, (int)a->At_ntiles,
+                       a->part4, (int)a->A_ntiles, a->x, a->p, a->r);
+    IPX_CHECK_LAUNCH();
+    MARK(6);
+    rc = launch_hp(a, guard, st);
+    if (rc) return rc;
+    MARK(7);
+  }
+#undef MARK
+  return IPX_OK;
+}
+
+}  // extern "C"

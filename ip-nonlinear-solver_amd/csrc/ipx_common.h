@@ -92,3 +92,17 @@ __device__ __forceinline__ double ipx_sum_partials(const double *part, int count
     v = ipx_combine<OP>(v, part[i]);
   return ipx_block_reduce<OP>(v, lds);
 }
+
+// ---- internal (non-ABI) launchers shared between translation units --------
+struct ipx_csr_view {
+  int nrows, ncols;
+  const int32_t *rowptr, *colidx;
+  const double *val;
+  const int32_t *tiles;
+  int ntiles;
+};
+int ipx_spmv_launch(const ipx_csr_view &A, const double *x, double alpha, const double *diag,
+                    double beta, const double *yin, double *yout, double *partial,
+                    const double *guard, hipStream_t st);
+int ipx_banded_solve_guarded(void *handle, const double *w, double *x, const double *guard,
+                             hipStream_t st);

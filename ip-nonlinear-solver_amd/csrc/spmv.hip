@@ -27,9 +27,10 @@ k_csr_spmv(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colid
            const double *__restrict__ val, const int32_t *__restrict__ tiles,
            const double *__restrict__ x, double alpha, const double *__restrict__ diag,
            double beta, const double *yin, double *yout, int square,
-           double *__restrict__ partial, int ntiles) {
+           double *__restrict__ partial, int ntiles, const double *__restrict__ guard) {
   __shared__ double prod[TILE_NNZ];
   __shared__ double red_lds[IPX_BLOCK / IPX_WAVE];
+  if (guard && *guard != 0.0) return;   // device-side stop flag of the fused CG loop
   const int tile = blockIdx.x;
   const int r0 = tiles[tile], r1 = tiles[tile + 1];
   const int s = rowptr[r0], e = rowptr[r1];
@@ -94,12 +95,34 @@ template <bool D, bool Y, bool R>
 void launch(int ntiles, hipStream_t st, const int32_t *rowptr, const int32_t *colidx,
             const double *val, const int32_t *tiles, const double *x, double alpha,
             const double *diag, double beta, const double *yin, double *yout, int square,
-            double *partial) {
+            double *partial, const double *guard) {
   hipLaunchKernelGGL((k_csr_spmv<D, Y, R>), dim3(ntiles), dim3(IPX_BLOCK), 0, st, rowptr, colidx,
-                     val, tiles, x, alpha, diag, beta, yin, yout, square, partial, ntiles);
+                     val, tiles, x, alpha, diag, beta, yin, yout, square, partial, ntiles, guard);
 }
 
 }  // namespace
+
+// Internal launcher shared with cg.hip: per-tile partials go to `partial`
+// (2*ntiles doubles: sum y^2 then sum x*y) and are NOT folded; `guard` is an
+// optional device stop flag.
+int ipx_spmv_launch(const ipx_csr_view &A, const double *x, double alpha, const double *diag,
+                    double beta, const double *yin, double *yout, double *partial,
+                    const double *guard, hipStream_t st) {
+  if (A.nrows == 0 || A.ntiles == 0) return IPX_OK;
+  if (beta == 0.0) yin = nullptr;
+  const bool D = diag != nullptr, Y = yin != nullptr, R = partial != nullptr;
+  const int square = A.nrows == A.ncols;
+#define GO(d, y, r)                                                                       \
+  launch<d, y, r>(A.ntiles, st, A.rowptr, A.colidx, A.val, A.tiles, x, alpha, diag, beta, \
+                  yin, yout, square, partial, guard)
+  if (D) { if (Y) { if (R) GO(true, true, true); else GO(true, true, false); }
+           else   { if (R) GO(true, false, true); else GO(true, false, false); } }
+  else   { if (Y) { if (R) GO(false, true, true); else GO(false, true, false); }
+           else   { if (R) GO(false, false, true); else GO(false, false, false); } }
+#undef GO
+  IPX_CHECK_LAUNCH();
+  return IPX_OK;
+}
 
 extern "C" {
 
@@ -131,7 +154,7 @@ int ipx_csr_spmv(int64_t nrows, int64_t ncols, const int32_t *rowptr, const int3
                  int square, double *red, double *ws, void *stream) {
   if (nrows < 0 || ncols < 0 || !rowptr || !tiles || !x || !yout || ntiles < 0) return IPX_EINVAL;
   if (nrows == 0 || ntiles == 0) {
-    if (red) hipMemsetAsync(red, 0, 2 * sizeof(double), (hipStream_t)stream);
+    if (red) (void)hipMemsetAsync(red, 0, 2 * sizeof(double), (hipStream_t)stream);
     return IPX_OK;
   }
   if (red && (!ws || 2 * (int64_t)ntiles > IPX_WS_DOUBLES)) return IPX_EINVAL;
@@ -140,7 +163,7 @@ int ipx_csr_spmv(int64_t nrows, int64_t ncols, const int32_t *rowptr, const int3
   const bool D = diag != nullptr, Y = yin != nullptr, R = red != nullptr;
 #define GO(d, y, r)                                                                          \
   launch<d, y, r>(ntiles, st, rowptr, colidx, val, tiles, x, alpha, diag, beta, yin, yout, \
-                  square, ws)
+                  square, ws, nullptr)
   if (D) { if (Y) { if (R) GO(true, true, true); else GO(true, true, false); }
            else   { if (R) GO(true, false, true); else GO(true, false, false); } }
   else   { if (Y) { if (R) GO(false, true, true); else GO(false, true, false); }

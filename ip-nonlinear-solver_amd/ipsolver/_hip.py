@@ -30,6 +30,12 @@ _SIGNATURES = {
     "ipx_csr_tiles_host": [_I64, _P, _I32, _I32, _P, _I64],
     "ipx_csr_spmv": [_I64, _I64, _P, _P, _P, _P, _I32, _P, _F64, _P, _F64, _P, _P,
                      _c.c_int, _P, _P, _P],
+    "ipx_cg_state_size": [],
+    "ipx_cg_vec_grid": [_I64],
+    "ipx_cg_hp": [_P, _P],
+    "ipx_cg_resume": [_P, _I32, _I32, _P],
+    "ipx_cg_iterate": [_P, _I32, _I32, _P],
+    "ipx_cg_iterate_timed": [_P, _I32, _I32, _P, _P],
     "ipx_banded_kmax": [],
     "ipx_banded_levels": [_P],
     "ipx_banded_factor": [_P, _P, _P],

@@ -1,9 +1,272 @@
-"""Device-resident projected CG (fused kernels, no per-iteration host sync)."""
+"""Device-resident projected CG: host side of csrc/cg.hip.
+
+Same algorithm and results as ``qp.projected_cg`` (reference
+qp_subproblem.py:416-643); the per-iteration scalars stay on the GPU and the
+host reads one 128-byte state block per *batch* of iterations instead of three
+scalars per iteration.  Rare events (box-infeasible iterate, projection
+refinement) hand the iteration back to the host, which finishes it with the
+general kernels and resumes the loop.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _hip
+from . import device as dv
+from .device import DVec, DeviceCSR, _p, stream_ptr, ctx
+
+_TINY = 1e-25
+_P = ctypes.c_void_p
+_I64 = ctypes.c_int64
+
+# state block indices (csrc/cg.hip)
+ST_RTG0, ST_RTG1, ST_TOL, ST_RADIUS, ST_ALPHA, ST_STOP, ST_NITER, ST_BETA = range(8)
+ST_PTHP, ST_ORTH_RHS, ST_XNORM2, ST_VIOL, ST_ORTH, ST_IT_DONE = 8, 9, 10, 11, 12, 13
+
+
+class CgArgs(ctypes.Structure):
+    _fields_ = [(name, typ) for name, typ in (
+        ("n", _I64), ("m", _I64),
+        ("A_rowptr", _P), ("A_colidx", _P), ("A_val", _P), ("A_tiles", _P), ("A_ntiles", _I64),
+        ("At_rowptr", _P), ("At_colidx", _P), ("At_val", _P), ("At_tiles", _P), ("At_ntiles", _I64),
+        ("H_rowptr", _P), ("H_colidx", _P), ("H_val", _P), ("H_tiles", _P), ("H_ntiles", _I64),
+        ("H_diag", _P), ("banded", _P),
+        ("x", _P), ("p", _P), ("r", _P), ("Hp", _P),
+        ("w", _P), ("v", _P), ("t", _P),
+        ("lb", _P), ("ub", _P), ("state", _P),
+        ("part1", _P), ("part2", _P), ("part3", _P), ("part4", _P),
+        ("vec_grid", _I64))]
+
+
+def _hessian_parts(H):
+    """(csr, diag) for the Hessian operator types the fused loop understands."""
+    from .operators import DeviceHessian
+    if isinstance(H, DeviceCSR) and H.shape[0] == H.shape[1]:
+        return H, None
+    if isinstance(H, DeviceHessian) and H.csr is not None:
+        return H.csr, H.diag
+    return None
 
 
 def supports(H, Z, Y):
-    return False
+    from .projector import BandedNormalSolver, NormalEquationProjector
+    P = getattr(Z, "projector", None)
+    if P is None or getattr(Y, "projector", None) is not P:
+        return False
+    if not isinstance(P, NormalEquationProjector) or not isinstance(P.A, DeviceCSR):
+        return False
+    if P.m == 0 or not isinstance(P.solver, BandedNormalSolver) or P.solver.perm is not None:
+        return False
+    return _hessian_parts(H) is not None
 
 
-def projected_cg(*args, **kwargs):
-    raise NotImplementedError
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class _Loop:
+    """Buffers + argument block for one projected_cg call."""
+
+    def __init__(self, H, P, lb, ub):
+        lib = _hip.load()
+        A = P.A
+        At = A.T
+        Hc, Hd = _hessian_parts(H)
+        self.n, self.m = P.n, P.m
+        n, m = self.n, self.m
+        dev = ctx().device
+        f64 = torch.float64
+        self.x = torch.empty(n, dtype=f64, device=dev)
+        self.p = torch.empty(n, dtype=f64, device=dev)
+        self.r = torch.empty(n, dtype=f64, device=dev)
+        self.Hp = torch.empty(n, dtype=f64, device=dev)
+        self.w = torch.empty(m, dtype=f64, device=dev)
+        self.v = torch.empty(m, dtype=f64, device=dev)
+        self.t = torch.empty(m, dtype=f64, device=dev)
+        self.state = torch.zeros(lib.ipx_cg_state_size(), dtype=f64, device=dev)
+        grid = lib.ipx_cg_vec_grid(n)
+        self.part1 = torch.zeros(2 * Hc.pattern.ntiles, dtype=f64, device=dev)
+        self.part2 = torch.zeros(2 * grid, dtype=f64, device=dev)
+        self.part3 = torch.zeros(2 * At.pattern.ntiles, dtype=f64, device=dev)
+        self.part4 = torch.zeros(2 * A.pattern.ntiles, dtype=f64, device=dev)
+        self.keep = (A, At, Hc, Hd, lb, ub, P)
+        a = CgArgs()
+        a.n, a.m = n, m
+        for pre, M in (("A", A), ("At", At), ("H", Hc)):
+            pat = M.pattern
+            setattr(a, pre + "_rowptr", _ptr(pat.indptr))
+            setattr(a, pre + "_colidx", _ptr(pat.indices))
+            setattr(a, pre + "_val", _ptr(M.val))
+            setattr(a, pre + "_tiles", _ptr(pat.tiles))
+            setattr(a, pre + "_ntiles", pat.ntiles)
+        a.H_diag = _ptr(Hd.t) if Hd is not None else None
+        a.banded = ctypes.c_void_p(P.solver.handle)
+        for name in ("x", "p", "r", "Hp", "w", "v", "t", "state",
+                     "part1", "part2", "part3", "part4"):
+            setattr(a, name, _ptr(getattr(self, name)))
+        a.lb = _ptr(lb.t) if lb is not None else None
+        a.ub = _ptr(ub.t) if ub is not None else None
+        a.vec_grid = grid
+        self.args = a
+
+    def ref(self):
+        return ctypes.byref(self.args)
+
+
+def projected_cg(H, c, Z, Y, b, trust_radius=np.inf, lb=None, ub=None, tol=None,
+                 max_iter=None, max_infeasible_iter=None, batch=None, stats=None):
+    from . import qp
+    lib = _hip.load()
+    P = Z.projector
+    n, m = len(c), len(b)
+    has_box = lb is not None or ub is not None
+    if has_box:
+        lb = lb if lb is not None else DVec.full(n, -np.inf)
+        ub = ub if ub is not None else DVec.full(n, np.inf)
+
+    # ---- initial point, residual, direction (qp_subproblem.py:502-512)
+    x0 = Y.dot(-b)
+    r0 = Z.dot(H.dot(x0) + c)
+    g0 = Z.dot(r0)
+    rt_g = g0.sumsq_amax()[0]            # norm(g)**2
+    tr_distance = trust_radius - dv.norm(x0)
+    if tr_distance < 0:
+        raise ValueError("Trust region problem does not have a solution.")
+    if tr_distance < _TINY:
+        return x0, {'niter': 0, 'stop_cond': 2, 'hits_boundary': True}
+
+    if tol is None:                       # :529-542
+        tol = max(min(0.01 * np.sqrt(rt_g), 0.1 * rt_g), _TINY)
+    if max_iter is None:
+        max_iter = n - m
+    max_iter = min(max_iter, n - m)
+    if max_infeasible_iter is None:
+        max_infeasible_iter = n - m
+
+    L = _Loop(H, P, lb if has_box else None, ub if has_box else None)
+    st = stream_ptr()
+    L.x.copy_(x0.t)
+    L.r.copy_(r0.t)
+    _hip.call("ipx_axpby", n, -1.0, _p(g0.t), 0.0, None, _p(L.p), st)      # p = -g
+    init = np.zeros(L.state.numel())
+    init[ST_RTG0] = rt_g
+    init[ST_TOL] = tol
+    init[ST_RADIUS] = trust_radius
+    init[ST_ORTH_RHS] = P.orth_tol * P.norm_A
+    L.state.copy_(torch.from_numpy(init))
+    _hip.check(lib.ipx_cg_hp(L.ref(), st), "ipx_cg_hp")
+
+    X, Pv, R = DVec(L.x), DVec(L.p), DVec(L.r)
+    hits_boundary = False
+    stop_cond = 1
+    counter = 0
+    last_viol_it = -2
+    last_feasible_x = DVec.zeros(n)
+    it = 0
+    nbatch = batch if batch else 2
+    broke = False
+    while it < max_iter:
+        end = min(max_iter, it + nbatch)
+        _hip.check(lib.ipx_cg_iterate(L.ref(), it, end, st), "ipx_cg_iterate")
+        s = L.state.tolist()             # one blocking read per batch
+        if stats is not None:
+            stats["batches"] = stats.get("batches", 0) + 1
+        stop = int(s[ST_STOP])
+        if stop == 0:
+            it = end
+            if not batch:
+                nbatch = min(2 * nbatch, 64)
+            continue
+        it_stop = int(s[ST_IT_DONE])     # index of the iteration that raised the flag
+        alpha = s[ST_ALPHA]
+        if stop == 4:                     # :551
+            stop_cond = 4
+            broke = True
+            break
+        if stop == 3:                     # :558-576
+            if np.isinf(trust_radius):
+                raise ValueError("Negative curvature not allowed "
+                                 "for unrestrited problems.")
+            _, al, hit = qp.box_sphere_intersections(X, Pv, lb, ub, trust_radius,
+                                                     entire_line=True)
+            xf = X.add_scaled(Pv, al) if hit else X
+            xf = qp.reinforce_box_boundaries(xf, lb, ub)
+            L.x = xf.t
+            stop_cond, hits_boundary, broke = 3, True, True
+            break
+        if stop == 2:                     # :583-596
+            _, theta, hit = qp.box_sphere_intersections(X, Pv, lb, ub, trust_radius,
+                                                        dscale=alpha)
+            xf = X.add_scaled(Pv, theta * alpha) if hit else X
+            xf = qp.reinforce_box_boundaries(xf, lb, ub)
+            L.x = xf.t
+            stop_cond, hits_boundary, broke = 2, True, True
+            break
+        mode = 0
+        if stop == 5:                     # :599-616 x_next outside the box
+            if last_viol_it != it_stop - 1:
+                counter = 0
+            counter += 1
+            last_viol_it = it_stop
+            _, theta, hit = qp.box_sphere_intersections(X, Pv, lb, ub, trust_radius,
+                                                        dscale=alpha)
+            if hit:
+                last_feasible_x = qp.reinforce_box_boundaries(
+                    X.add_scaled(Pv, theta * alpha), lb, ub)
+                counter = 0
+                last_viol_it = -2
+            if counter > max_infeasible_iter:
+                broke = True
+                break
+            mode = 1
+            # the orthogonality check has not run yet for this iteration
+            s2 = _resume(lib, L, it_stop, mode, st)
+            if int(s2[ST_STOP]) == 6:
+                stop, mode = 6, 1
+            else:
+                it = it_stop + 1
+                continue
+        if stop == 6:                     # projections.py:72-78 refinement
+            _refine(P, L, R)
+            s2 = _resume(lib, L, it_stop, mode | 2, st)
+            it = it_stop + 1
+            continue
+        raise _hip.IpxError("unexpected CG stop code %d" % stop)
+
+    x = DVec(L.x)
+    if has_box and not qp.inside_box_boundaries(x, lb, ub):     # :636-638
+        x = last_feasible_x
+        hits_boundary = True
+    niter = int(L.state[ST_NITER].item())
+    return x, {'niter': niter, 'stop_cond': stop_cond, 'hits_boundary': hits_boundary}
+
+
+def _resume(lib, L, it_stop, mode, st):
+    """Clear the stop flag, finish iteration ``it_stop`` (step2 + Hp)."""
+    L.state[ST_STOP] = 0.0
+    _hip.check(lib.ipx_cg_resume(L.ref(), it_stop, mode, st), "ipx_cg_resume")
+    return L.state.tolist()
+
+
+def _refine(P, L, R):
+    """Iterative refinement of g = Z r (projections.py:69-78) on the buffers of
+    the fused loop: L.r holds g, L.t holds A g."""
+    Az = DVec(L.t)
+    k = 0
+    while k < P.max_refin:
+        v = P._apply_inv(Az)
+        z = P.A.rmatvec_sub(v, R, reduce=True)       # ||z||^2 -> slot 0
+        L.r.copy_(z.t)
+        k += 1
+        P.stats["refinements"] += 1
+        orth, Az = P._orthogonality(R)
+        L.t.copy_(Az.t)
+        if not orth > P.orth_tol:
+            break
+    if k > 0:
+        # step2 derives beta from the ||g||^2 partials: replace them by the
+        # refined value (one non-zero entry, the rest adds exact zeros)
+        gg = dv.read_slots(1)[0]
+        L.part3.zero_()
+        L.part3[0] = gg

@@ -194,9 +194,12 @@ class NormalEquationProjector:
         return self.A.T.dot(self._apply_inv(x))
 
     def operators(self):
-        return (_Op((self.n, self.n), self.null_space),
-                _Op((self.m, self.n), self.least_squares),
-                _Op((self.n, self.m), self.row_space))
+        ops = (_Op((self.n, self.n), self.null_space),
+               _Op((self.m, self.n), self.least_squares),
+               _Op((self.n, self.m), self.row_space))
+        for op in ops:
+            op.projector = self      # lets the fused CG loop recognise its own operators
+        return ops
 
 
 def as_device_matrix(A):
