@@ -115,6 +115,8 @@ int ipx_banded_factor(void *handle, const double *band, void *stream);
 /* Blocking: IPX_OK, or IPX_ENOTSPD when a pivot was <= 0 (rank-deficient A). */
 int ipx_banded_status(void *handle, void *stream);
 int ipx_banded_solve(void *handle, const double *w, double *x, void *stream);
+/* One-kernel-per-level variant of the same solve (cross-check / LDS fallback). */
+int ipx_banded_solve_multilaunch(void *handle, const double *w, double *x, void *stream);
 /* band of (P A)(P A)' for CSR A with row order perm (NULL = identity). */
 int ipx_aat_band(int64_t m, int32_t k, const int32_t *rowptr, const int32_t *colidx,
                  const double *val, const int32_t *perm, double *band, void *stream);

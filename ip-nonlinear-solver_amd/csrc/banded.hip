@@ -43,6 +43,14 @@ struct Banded {
   int nlev;
   Level lev[MAX_LEVELS];
   int *flag;                  // device: != 0 after a non-positive pivot
+  double *gL, *gR;            // halves of the level-1 right-hand side (fast path)
+  bool fast;                  // three-launch path usable (LDS budget)
+  int down_T;                 // chunks per workgroup in k_down0
+  size_t lds_down;
+  int mid_buf;                // doubles of LDS in k_middle for the level vectors
+  double *slab;               // factor data of levels >= 1, contiguous
+  size_t nslab;               // its length in doubles
+  int nslab_lds;              // = nslab when the slab is staged in LDS, else 0
   std::vector<void *> allocs;
 };
 
@@ -323,6 +331,349 @@ k_aat_band(int m, int k, const int32_t *__restrict__ rowptr, const int32_t *__re
   band[(int64_t)d * m + i] = s;
 }
 
+
+// ===================================================================== fast
+// Three-launch solve.  The multi-launch sweep above pays one dependent global
+// load per recurrence step (tens of microseconds at m = 1e5); here
+//   k_down0   a workgroup stages the rows of its T chunks in LDS with coalesced
+//             loads, each lane runs its chunk's LDL' recurrence out of LDS with
+//             the multipliers prefetched in register blocks, and the two halves
+//             of every reduced right-hand side entry are written out;
+//   k_middle  ONE workgroup holds every remaining level in LDS and walks down
+//             and back up with __syncthreads() instead of kernel boundaries;
+//   k_correct the level-0 up sweep (elementwise, all CUs).
+// Same arithmetic in the same order as the multi-launch path: bitwise equal.
+constexpr int DOWN_T = 256;          // threads per workgroup in k_down0 (T <= 64 of them own a chunk)
+constexpr int MID_T = 512;
+constexpr int JB = 8;                // recurrence steps per register block
+constexpr size_t LDS_LIMIT = 160 * 1024 - 512;
+
+// Cooperative global -> LDS fill with U loads in flight per lane (a plain copy
+// loop exposes one full memory latency per iteration).  `val(i)` produces
+// element i (normally one global load).
+template <int U, typename Val>
+__device__ __forceinline__ void stage(double *dst, int n, Val val) {
+  const int step = blockDim.x;
+  int i = threadIdx.x;
+  for (; i + (U - 1) * step < n; i += U * step) {
+    double v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = val(i + u * step);
+#pragma unroll
+    for (int u = 0; u < U; ++u) dst[i + u * step] = v[u];
+  }
+  for (; i < n; i += step) dst[i] = val(i);
+}
+
+struct LevDev {
+  int m, k, c, P, q, mR;
+  const double *band, *Dinv, *L, *V, *W;
+  int oB, oD, oL, oV, oW;     // offsets of the same tables inside the level slab (levels >= 1)
+};
+struct LevArgs {
+  int nlev;
+  LevDev lev[MAX_LEVELS];
+};
+
+// Dinv / L are indexed [step][column]; the column stride is CS when known at
+// compile time (LDS-staged tables of k_down0) or P otherwise.  The tables have
+// q + K zero-initialised rows and multipliers that would reach outside the
+// chunk are stored as 0, so the recurrences need no bounds tests.  One lane
+// issues every instruction of its chain, so the loops are written for
+// instruction count: blocks of JB steps are loaded into registers (constant
+// address offsets), the chain is one FMA per band entry, then the block is
+// stored.  (FMA contraction is explicit here: the solve has no bitwise
+// counterpart in the reference, unlike the SpMV / vector kernels.)
+template <int K, int CS>
+__device__ __forceinline__ void chunk_solve(double *__restrict__ b, int ct,
+                                            const double *__restrict__ Dinv,
+                                            const double *__restrict__ L, int P, int t) {
+  const int cs = CS ? CS : P;
+  const double *lp = L + t;
+  const double *dp = Dinv + t;
+  double zw[K];
+#pragma unroll
+  for (int r = 0; r < K; ++r) zw[r] = 0.0;
+  // ---- forward: z_j = w_j - sum_d l_{j,j-d} z_{j-d}
+  int j = 0;
+  for (; j + JB <= ct; j += JB) {
+    double wv[JB], lc[JB][K];
+    const double *lj = lp + (int64_t)j * K * cs;
+#pragma unroll
+    for (int jj = 0; jj < JB; ++jj) {
+      wv[jj] = b[j + jj];
+#pragma unroll
+      for (int d = 0; d < K; ++d) lc[jj][d] = lj[(jj * K + d) * cs];
+    }
+#pragma unroll
+    for (int jj = 0; jj < JB; ++jj) {
+      double z = wv[jj];
+#pragma unroll
+      for (int d = 0; d < K; ++d) z = __builtin_fma(-lc[jj][d], zw[d], z);
+#pragma unroll
+      for (int r = K - 1; r > 0; --r) zw[r] = zw[r - 1];
+      zw[0] = z;
+      wv[jj] = z;
+    }
+#pragma unroll
+    for (int jj = 0; jj < JB; ++jj) b[j + jj] = wv[jj];
+  }
+  for (; j < ct; ++j) {
+    double z = b[j];
+#pragma unroll
+    for (int d = 0; d < K; ++d) z = __builtin_fma(-lp[((int64_t)j * K + d) * cs], zw[d], z);
+#pragma unroll
+    for (int r = K - 1; r > 0; --r) zw[r] = zw[r - 1];
+    zw[0] = z;
+    b[j] = z;
+  }
+  // ---- backward: y_j = z_j / d_j - sum_d l_{j+d,j} y_{j+d}
+  double yw[K];
+#pragma unroll
+  for (int r = 0; r < K; ++r) yw[r] = 0.0;
+  j = ct;
+  for (; j - JB >= 0; j -= JB) {          // rows j-1 .. j-JB
+    double wv[JB], lc[JB][K];
+    const int jb = j - JB;
+    const double *lj = lp + (int64_t)jb * K * cs;
+    const double *dj = dp + (int64_t)jb * cs;
+#pragma unroll
+    for (int jj = 0; jj < JB; ++jj) {       // jj-th row of the block is jb + jj
+      wv[jj] = b[jb + jj] * dj[jj * cs];
+#pragma unroll
+      for (int d = 1; d <= K; ++d) lc[jj][d - 1] = lj[((jj + d) * K + (d - 1)) * cs];
+    }
+#pragma unroll
+    for (int jj = JB - 1; jj >= 0; --jj) {
+      double v = wv[jj];
+#pragma unroll
+      for (int d = 0; d < K; ++d) v = __builtin_fma(-lc[jj][d], yw[d], v);
+#pragma unroll
+      for (int r = K - 1; r > 0; --r) yw[r] = yw[r - 1];
+      yw[0] = v;
+      wv[jj] = v;
+    }
+#pragma unroll
+    for (int jj = 0; jj < JB; ++jj) b[jb + jj] = wv[jj];
+  }
+  for (--j; j >= 0; --j) {
+    double v = b[j] * dp[(int64_t)j * cs];
+#pragma unroll
+    for (int d = 1; d <= K; ++d)
+      v = __builtin_fma(-lp[((int64_t)(j + d) * K + (d - 1)) * cs], yw[d - 1], v);
+#pragma unroll
+    for (int r = K - 1; r > 0; --r) yw[r] = yw[r - 1];
+    yw[0] = v;
+    b[j] = v;
+  }
+}
+
+// reduced rhs halves for chunk t held at LDS address b (its separator rows,
+// still holding w, follow the interior rows).  cE / cF are this chunk's K x K
+// coupling blocks: cE[j*K+a] = E[j][a] (first K rows), cF[jj*K+a] = F[ct-K+jj][a].
+template <int K>
+__device__ __forceinline__ void chunk_rhs_halves(const double *b, int P, int t, int ct,
+                                                 const double *cE, const double *cF,
+                                                 double *gL, double *gR) {
+  if (t < P - 1) {
+#pragma unroll
+    for (int a = 0; a < K; ++a) {
+      double r = b[ct + a];
+#pragma unroll
+      for (int jj = 0; jj < K; ++jj)
+        if (ct - K + jj >= 0) r -= cF[jj * K + a] * b[ct - K + jj];
+      gL[t * K + a] = r;
+    }
+  }
+  if (t > 0) {
+#pragma unroll
+    for (int a = 0; a < K; ++a) {
+      double r = 0.0;
+#pragma unroll
+      for (int j = 0; j < K; ++j)
+        if (j < ct) r -= cE[j * K + a] * b[j];
+      gR[(t - 1) * K + a] = r;     // added to gL by the consumer: g = gL + gR
+    }
+  }
+}
+
+template <int K, int T>
+__global__ void __launch_bounds__(DOWN_T)
+k_down0(LevDev lv, const double *w, double *y, double *__restrict__ gL,
+        double *__restrict__ gR, const double *__restrict__ guard) {
+  extern __shared__ double sm[];
+  if (guard && *guard != 0.0) return;
+  const int q = lv.q, P = lv.P, m = lv.m, c = lv.c;
+  const int qk = q + K;                  // table rows (K zero rows of padding)
+  const int t0 = blockIdx.x * T;
+  const int tcount = min(T, P - t0);
+  const int row0 = t0 * q;
+  const int rend = min(m, (t0 + tcount) * q);
+  const int nrows = rend - row0;
+  double *sw = sm;                       // T*q      rows of this workgroup's chunks
+  double *sD = sw + (size_t)T * q;       // qk*T     1/d   [step][lane]
+  double *sL = sD + (size_t)qk * T;      // qk*K*T   l     [step*K+d][lane]
+  double *sE = sL + (size_t)qk * K * T;  // T*K*K    coupling to the left separator
+  double *sF = sE + (size_t)T * K * K;   // T*K*K    coupling to the right separator
+  // One staging phase: every global load of the kernel is issued here.
+  const double *wp = w + row0;
+  stage<16>(sw, nrows, [=](int i) { return wp[i]; });
+  // columns t0 .. t0+tcount-1 of the [step][chunk] tables (lanes past the last
+  // chunk re-read column P-1; never used)
+  const double *Dg = lv.Dinv, *Lg = lv.L, *Bg = lv.band;
+  stage<16>(sD, qk * T, [=](int i) {
+    const int j = i / T, tl = i - j * T;
+    return Dg[(int64_t)j * P + min(t0 + tl, P - 1)];
+  });
+  stage<16>(sL, qk * K * T, [=](int i) {
+    const int j = i / T, tl = i - j * T;
+    return Lg[(int64_t)j * P + min(t0 + tl, P - 1)];
+  });
+  stage<4>(sE, T * K * K, [=](int i) {
+    const int tl = i / (K * K), r = i - tl * K * K, j = r / K, a = r - j * K;
+    const int t = min(t0 + tl, P - 1);
+    return t > 0 ? coupE<K>(Bg, m, t * q, j, a) : 0.0;
+  });
+  stage<4>(sF, T * K * K, [=](int i) {
+    const int tl = i / (K * K), r = i - tl * K * K, jj = r / K, a = r - jj * K;
+    const int t = min(t0 + tl, P - 1);
+    const int ct = chunk_rows(m, q, c, P, t);
+    return (t < P - 1 && ct - K + jj >= 0) ? coupF<K>(Bg, m, t * q, ct, ct - K + jj, a) : 0.0;
+  });
+  __syncthreads();
+  const int tl = threadIdx.x, t = t0 + tl;
+  if (tl < tcount) {
+    const int ct = chunk_rows(m, q, c, P, t);
+    double *b = sw + tl * q;
+    chunk_solve<K, T>(b, ct, sD, sL, T, tl);
+    chunk_rhs_halves<K>(b, P, t, ct, sE + tl * K * K, sF + tl * K * K, gL, gR);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nrows; i += blockDim.x) y[row0 + i] = sw[i];
+}
+
+// Factor data of the levels >= 1 lives in one contiguous slab; k_middle copies
+// the whole slab into LDS with a single coalesced sweep (one memory latency),
+// after which every phase below touches LDS only.  `fb` is the slab base the
+// level tables are addressed from: the LDS copy (STAGED) or global memory.
+template <int K, int DEPTH>
+struct Mid {
+  // buf holds this level's right-hand side; on return it holds the solution.
+  // (DEPTH is the level index: static indexing keeps the descriptors in SGPRs)
+  static __device__ __forceinline__ void run(const LevArgs &a, double *buf, const double *fb) {
+    const LevDev &lv = a.lev[DEPTH];
+    double *nbuf = buf + lv.m;               // next level lives right behind
+    const double *Dp = fb + lv.oD, *Lp = fb + lv.oL, *Vp = fb + lv.oV, *Wp = fb + lv.oW;
+    const double *Bp = fb + lv.oB;
+    for (int t = threadIdx.x; t < lv.P; t += blockDim.x) {
+      const int ct = chunk_rows(lv.m, lv.q, lv.c, lv.P, t);
+      chunk_solve<K, 0>(buf + t * lv.q, ct, Dp, Lp, lv.P, t);
+    }
+    __syncthreads();
+    if (lv.mR > 0) {
+      for (int qrow = threadIdx.x; qrow < lv.mR; qrow += blockDim.x) {
+        const int t = qrow / K, a2 = qrow % K;
+        const int base = t * lv.q, ct = lv.c;
+        double r = buf[base + ct + a2];
+        for (int j = ct - K; j < ct; ++j)
+          if (j >= 0) r -= coupF<K>(Bp, lv.m, base, ct, j, a2) * buf[base + j];
+        const int base2 = (t + 1) * lv.q;
+        const int ct2 = chunk_rows(lv.m, lv.q, lv.c, lv.P, t + 1);
+        for (int j = 0; j < K && j < ct2; ++j)
+          r -= coupE<K>(Bp, lv.m, base2, j, a2) * buf[base2 + j];
+        nbuf[qrow] = r;
+      }
+      __syncthreads();
+      if constexpr (2 * K - 1 <= KMAX && DEPTH + 1 < MAX_LEVELS)
+        Mid<2 * K - 1, DEPTH + 1>::run(a, nbuf, fb);
+      __syncthreads();
+      for (int i = threadIdx.x; i < lv.m; i += blockDim.x) {
+        int t = i / lv.q;
+        if (t > lv.P - 1) t = lv.P - 1;
+        const int j = i - t * lv.q;
+        const int ct = chunk_rows(lv.m, lv.q, lv.c, lv.P, t);
+        if (j >= ct) { buf[i] = nbuf[t * K + (j - ct)]; continue; }
+        double v = buf[i];
+        if (t > 0) {
+#pragma unroll
+          for (int a2 = 0; a2 < K; ++a2) v -= Vp[(int64_t)i * K + a2] * nbuf[(t - 1) * K + a2];
+        }
+        if (t < lv.P - 1) {
+#pragma unroll
+          for (int a2 = 0; a2 < K; ++a2) v -= Wp[(int64_t)i * K + a2] * nbuf[t * K + a2];
+        }
+        buf[i] = v;
+      }
+      __syncthreads();
+    }
+  }
+};
+
+template <int K1, bool STAGED>
+__global__ void __launch_bounds__(MID_T)
+k_middle(LevArgs a, int nbuf_total, const double *__restrict__ slab, int nslab,
+         const double *__restrict__ gL, const double *__restrict__ gR, double *__restrict__ xs,
+         const double *__restrict__ guard) {
+  extern __shared__ double sm[];
+  if (guard && *guard != 0.0) return;
+  const int m1 = a.lev[1].m;
+  stage<8>(sm, m1, [=](int i) { return gL[i] + gR[i]; });
+  if constexpr (STAGED) {
+    double *coef = sm + nbuf_total;
+    stage<16>(coef, nslab, [=](int i) { return slab[i]; });
+    __syncthreads();
+    Mid<K1, 1>::run(a, sm, coef);
+  } else {
+    __syncthreads();
+    Mid<K1, 1>::run(a, sm, slab);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < m1; i += blockDim.x) xs[i] = sm[i];
+}
+
+constexpr int DOWN_CHUNKS = 16;      // chunks (recurrence lanes) per workgroup in k_down0
+
+template <int K>
+int launch_down0(const LevDev &lv, size_t lds, const double *w, double *y, double *gL,
+                 double *gR, const double *guard, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void *)k_down0<K, DOWN_CHUNKS>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);
+    attr_set = true;
+  }
+  const int grid = (lv.P + DOWN_CHUNKS - 1) / DOWN_CHUNKS;
+  hipLaunchKernelGGL((k_down0<K, DOWN_CHUNKS>), dim3(grid), dim3(DOWN_T), lds, st, lv, w, y, gL,
+                     gR, guard);
+  IPX_CHECK_LAUNCH();
+  return IPX_OK;
+}
+
+template <int K1, bool STAGED>
+int launch_middle_impl(const LevArgs &a, int nbuf_total, const double *slab, int nslab,
+                       const double *gL, const double *gR, double *xs, const double *guard,
+                       hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void *)k_middle<K1, STAGED>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);
+    attr_set = true;
+  }
+  const size_t lds = ((size_t)nbuf_total + (STAGED ? nslab : 0)) * sizeof(double);
+  hipLaunchKernelGGL((k_middle<K1, STAGED>), dim3(1), dim3(MID_T), lds, st, a, nbuf_total, slab,
+                     nslab, gL, gR, xs, guard);
+  IPX_CHECK_LAUNCH();
+  return IPX_OK;
+}
+
+template <int K1>
+int launch_middle(const LevArgs &a, int nbuf_total, const double *slab, int nslab, bool staged,
+                  const double *gL, const double *gR, double *xs, const double *guard,
+                  hipStream_t st) {
+  return staged ? launch_middle_impl<K1, true>(a, nbuf_total, slab, nslab, gL, gR, xs, guard, st)
+                : launch_middle_impl<K1, false>(a, nbuf_total, slab, nslab, gL, gR, xs, guard, st);
+}
+
 template <int K>
 struct Launch {
   static int factor(Banded *h, int li, hipStream_t st) {
@@ -407,14 +758,19 @@ void *ipx_banded_create(int64_t m64, int32_t k, int32_t chunk) {
   if (k == 0) k = 1;                 // diagonal matrices ride the k = 1 path
   Banded *h = new Banded();
   h->nlev = 0;
+  h->gL = h->gR = h->slab = nullptr;
+  h->fast = false;
   int m = (int)m64, kk = k;
-  if (chunk <= 0) chunk = 32;
+  if (chunk <= 0) chunk = 64;
   bool ok = true;
+  // ---- geometry of every level
   while (true) {
     if (h->nlev >= MAX_LEVELS || kk > KMAX) { ok = false; break; }
     Level &lv = h->lev[h->nlev++];
     lv.m = m; lv.k = kk;
     lv.c = chunk < kk ? kk : chunk;
+    // odd row pitch q = c + k: lanes of a wave then hit distinct LDS banks
+    if (((lv.c + kk) & 1) == 0) lv.c += 1;
     // The separator system of a level has half bandwidth 2k-1.  When that
     // would exceed the compiled kernels, stop recursing: this level becomes
     // one chunk swept by a single lane (only reached for wide bands, where
@@ -423,27 +779,64 @@ void *ipx_banded_create(int64_t m64, int32_t k, int32_t chunk) {
     lv.q = lv.c + kk;
     // single chunk when everything fits in one (<= q rows)
     lv.P = (m <= lv.q) ? 1 : (m + lv.q - 1) / lv.q;
-    // the last chunk must keep >= 1 interior row: (P-1)*q < m holds by ceil
     lv.mR = (lv.P - 1) * kk;
-    lv.band = nullptr;
-    const int steps = lv.c + kk;
-    lv.Dinv = dalloc<double>(h, (size_t)steps * lv.P);
-    lv.L = dalloc<double>(h, (size_t)steps * kk * lv.P);
-    lv.V = dalloc<double>(h, (size_t)m * kk);
-    lv.W = dalloc<double>(h, (size_t)m * kk);
-    lv.rhs = lv.sol = nullptr;
-    if (h->nlev > 1) {
-      lv.band = dalloc<double>(h, (size_t)(kk + 1) * m);
-      lv.rhs = dalloc<double>(h, m);
-      lv.sol = dalloc<double>(h, m);
-      if (!lv.band || !lv.rhs || !lv.sol) { ok = false; break; }
-    }
-    if (!lv.Dinv || !lv.L || !lv.V || !lv.W) { ok = false; break; }
+    lv.band = lv.Dinv = lv.L = lv.V = lv.W = lv.rhs = lv.sol = nullptr;
     if (lv.P == 1) break;
     m = lv.mR;
     kk = 2 * kk - 1;
   }
+  // ---- storage: level 0 on its own, levels >= 1 carved from one slab
+  auto need = [](const Level &lv, size_t &nD, size_t &nL, size_t &nV, size_t &nB) {
+    nD = (size_t)(lv.q + lv.k) * lv.P;   // k rows of zero padding behind the q steps
+    nL = nD * lv.k; nV = (size_t)lv.m * lv.k; nB = (size_t)(lv.k + 1) * lv.m;
+  };
+  if (ok) {
+    size_t nD, nL, nV, nB;
+    Level &l0 = h->lev[0];
+    need(l0, nD, nL, nV, nB);
+    l0.Dinv = dalloc<double>(h, nD); l0.L = dalloc<double>(h, nL);
+    l0.V = dalloc<double>(h, nV);    l0.W = dalloc<double>(h, nV);
+    ok = l0.Dinv && l0.L && l0.V && l0.W;
+    if (ok) ok = hipMemset(l0.Dinv, 0, nD * sizeof(double)) == hipSuccess &&
+                 hipMemset(l0.L, 0, nL * sizeof(double)) == hipSuccess;
+    size_t tot = 0;
+    for (int li = 1; li < h->nlev; ++li) { need(h->lev[li], nD, nL, nV, nB); tot += nD + nL + 2 * nV + nB; }
+    h->nslab = tot;
+    if (ok && tot > 0) {
+      h->slab = dalloc<double>(h, tot);
+      ok = h->slab != nullptr && hipMemset(h->slab, 0, tot * sizeof(double)) == hipSuccess;
+      double *p = h->slab;
+      for (int li = 1; ok && li < h->nlev; ++li) {
+        Level &lv = h->lev[li];
+        need(lv, nD, nL, nV, nB);
+        lv.Dinv = p; p += nD; lv.L = p; p += nL; lv.V = p; p += nV; lv.W = p; p += nV;
+        lv.band = p; p += nB;
+        lv.rhs = dalloc<double>(h, lv.m);
+        lv.sol = dalloc<double>(h, lv.m);
+        ok = lv.rhs && lv.sol;
+      }
+    }
+  }
   h->flag = dalloc<int>(h, 1);
+  if (ok) {
+    const Level &l0 = h->lev[0];
+    // k_down0 stages (k+2) tables of T*q doubles.  Few chunks per workgroup =
+    // many workgroups, so the staging loads spread over the CUs.
+    h->down_T = DOWN_CHUNKS;
+    h->lds_down = ((size_t)DOWN_CHUNKS * l0.q + (size_t)(l0.k + 1) * DOWN_CHUNKS * (l0.q + l0.k) +
+                   2 * (size_t)DOWN_CHUNKS * l0.k * l0.k) * sizeof(double);
+    size_t vec = 0;
+    for (int li = 1; li < h->nlev; ++li) vec += (size_t)h->lev[li].m;
+    h->mid_buf = (int)vec;
+    h->nslab_lds = ((vec + h->nslab) * sizeof(double) <= LDS_LIMIT) ? (int)h->nslab : 0;
+    h->fast = h->lds_down <= LDS_LIMIT && vec * sizeof(double) <= LDS_LIMIT;
+    if (h->fast && l0.mR > 0) {
+      h->gL = dalloc<double>(h, l0.mR);
+      h->gR = dalloc<double>(h, l0.mR);
+      if (!h->gL || !h->gR) ok = false;
+      else if (hipMemset(h->gR, 0, (size_t)l0.mR * sizeof(double)) != hipSuccess) ok = false;
+    }
+  }
   if (!ok || !h->flag) {
     for (void *p : h->allocs) (void)hipFree(p);
     delete h;
@@ -509,10 +902,56 @@ int ipx_aat_band(int64_t m, int32_t k, const int32_t *rowptr, const int32_t *col
 
 }  // extern "C"
 
+namespace {
+
+LevDev to_dev(const Level &lv, const double *slab) {
+  LevDev d{lv.m, lv.k, lv.c, lv.P, lv.q, lv.mR, lv.band, lv.Dinv, lv.L, lv.V, lv.W, 0, 0, 0, 0, 0};
+  if (slab && lv.Dinv >= slab) {
+    d.oB = (int)(lv.band - slab); d.oD = (int)(lv.Dinv - slab); d.oL = (int)(lv.L - slab);
+    d.oV = (int)(lv.V - slab);    d.oW = (int)(lv.W - slab);
+  }
+  return d;
+}
+
+int fast_down0(Banded *h, const double *w, double *y, const double *guard, hipStream_t st) {
+  const LevDev lv = to_dev(h->lev[0], nullptr);
+  switch (lv.k) {
+#define D0(kk) case kk: return launch_down0<kk>(lv, h->lds_down, w, y, h->gL, h->gR, guard, st)
+    D0(1); D0(2); D0(3); D0(4); D0(5); D0(6); D0(7); D0(8);
+#undef D0
+  }
+  return IPX_EINVAL;
+}
+
+int fast_middle(Banded *h, const double *guard, hipStream_t st) {
+  LevArgs a;
+  a.nlev = h->nlev;
+  for (int li = 0; li < h->nlev; ++li) a.lev[li] = to_dev(h->lev[li], li ? h->slab : nullptr);
+  double *xs = h->lev[1].sol;
+  switch (h->lev[1].k) {
+#define MD(kk) case kk: return launch_middle<kk>(a, h->mid_buf, h->slab, (int)h->nslab, h->nslab_lds > 0, h->gL, h->gR, xs, guard, st)
+    MD(1); MD(3); MD(5); MD(7);
+#undef MD
+  }
+  return IPX_EINVAL;
+}
+
+}  // namespace
+
+extern "C" int ipx_banded_solve_multilaunch(void *handle, const double *w, double *x,
+                                            void *stream);
+
 int ipx_banded_solve_guarded(void *handle, const double *w, double *x, const double *guard,
                              hipStream_t st) {
   if (!handle || !w || !x) return IPX_EINVAL;
   Banded *h = (Banded *)handle;
+  if (h->fast) {
+    int rc = fast_down0(h, w, x, guard, st);
+    if (rc != IPX_OK || h->nlev == 1) return rc;
+    rc = fast_middle(h, guard, st);
+    if (rc != IPX_OK) return rc;
+    return level_up(h, 0, x, guard, st);
+  }
   for (int li = 0; li < h->nlev; ++li) {
     const double *in = li == 0 ? w : h->lev[li].rhs;
     double *out = li == 0 ? x : h->lev[li].sol;
@@ -525,4 +964,17 @@ int ipx_banded_solve_guarded(void *handle, const double *w, double *x, const dou
     if (rc != IPX_OK) return rc;
   }
   return IPX_OK;
+}
+
+// The original one-kernel-per-level sweep (kept for cross-checking the fast
+// path and as the fallback when a level does not fit in LDS).
+extern "C" int ipx_banded_solve_multilaunch(void *handle, const double *w, double *x,
+                                            void *stream) {
+  if (!handle || !w || !x) return IPX_EINVAL;
+  Banded *h = (Banded *)handle;
+  const bool keep = h->fast;
+  h->fast = false;
+  int rc = ipx_banded_solve_guarded(handle, w, x, nullptr, (hipStream_t)stream);
+  h->fast = keep;
+  return rc;
 }

@@ -41,6 +41,7 @@ _SIGNATURES = {
     "ipx_banded_factor": [_P, _P, _P],
     "ipx_banded_status": [_P, _P],
     "ipx_banded_solve": [_P, _P, _P, _P],
+    "ipx_banded_solve_multilaunch": [_P, _P, _P, _P],
     "ipx_aat_band": [_I64, _I32, _P, _P, _P, _P, _P, _P],
 }
 _RESTYPES = {"ipx_version": _c.c_char_p, "ipx_last_error": _c.c_char_p,

@@ -180,6 +180,13 @@ def test_banded_solver(ips, m, k, chunk):
     # bitwise reproducible
     again = solver.solve(ips.dv.DVec.from_host(w)).to_host()
     assert np.array_equal(got, again)
+    # the LDS-resident three-launch path against the one-kernel-per-level sweep
+    W = ips.dv.DVec.from_host(w)
+    out = torch.empty(m, dtype=torch.float64, device="cuda")
+    _hip.call("ipx_banded_solve_multilaunch", ctypes.c_void_p(solver.handle),
+              ips.dv._p(W.t), ips.dv._p(out), ips.dv.stream_ptr())
+    ref = out.cpu().numpy()
+    assert np.max(np.abs(got - ref)) <= 1e-13 * np.max(np.abs(ref))
 
 
 def test_banded_solver_with_reordering(ips):
