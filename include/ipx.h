@@ -65,6 +65,20 @@ int ipx_affine(int64_t n, double a, const double *x, double b, double *out, void
 int ipx_gather(int64_t n, const double *x, const int32_t *idx, const double *sign,
                const double *shift, double *out, void *stream);
 
+/* out[idx[i]] = x[i] (refresh of the slack entries of the augmented Jacobian,
+ * tr_interior_point.py:186-191). */
+int ipx_scatter(int64_t n, const double *x, const int32_t *idx, double *out, void *stream);
+/* Barrier elementwise ops (tr_interior_point.py:92-93,216-220,294):
+ * out = max(x, c);  out = v > 0 ? a : c;  s[mask != 0] = -c[mask != 0]. */
+int ipx_max_scalar(int64_t n, const double *x, double c, double *out, void *stream);
+int ipx_where_positive(int64_t n, const double *v, const double *a, double c, double *out,
+                       void *stream);
+int ipx_assign_negated_where(int64_t n, double *s, const double *mask, const double *c,
+                             void *stream);
+/* out[0] = sum log(s_i) over s_i > 0, out[1] = #{s_i <= 0} (the reference's
+ * log-barrier term is -inf when out[1] > 0). */
+int ipx_sum_log(int64_t n, const double *s, double *out, double *ws, void *stream);
+
 /* ---- reductions.  `out` is a device array; `ws` >= IPX_WS_DOUBLES doubles.
  * ipx_dot:      out[0] = sum x*y                      (np.dot)
  * ipx_norms:    out[0] = sum x^2, out[1] = max |x|    (norm(.), norm(., inf))
@@ -102,6 +116,18 @@ int ipx_csr_spmv(int64_t nrows, int64_t ncols, const int32_t *rowptr,
                  const double *x, double alpha,
                  const double *diag, double beta, const double *yin,
                  double *yout, int square, double *red, double *ws, void *stream);
+
+/* ---- dense Jacobian path (projections.py:175-233 QR; here Gram + Cholesky).
+ * A is row-major with leading dimension lda.  ipx_dense_gemv mirrors
+ * ipx_csr_spmv's fused epilogue.  G / X are M x M, M = ipx_dense_padded(m). */
+int ipx_dense_gemv(int64_t m, int64_t n, const double *A, int64_t lda, const double *x,
+                   double alpha, const double *diag, double beta, const double *yin,
+                   double *yout, double *red, double *ws, void *stream);
+int64_t ipx_dense_padded(int64_t m);
+int ipx_gram_f64_mfma(int64_t m, int64_t n, const double *A, int64_t lda, double *G,
+                      void *stream);
+int ipx_chol_factor(int64_t M, double *G, int *flag, void *stream);
+int ipx_chol_inverse(int64_t M, const double *G, double *X, void *stream);
 
 /* ---- banded SPD solve with S = A A' (normal equations, projections.py:58-90;
  * replaces SuperLU solve :102,120 / CHOLMOD :62).  Partitioned (SPIKE-style)

@@ -1,0 +1,335 @@
+// Dense Jacobian path (BASELINE config 2; reference projections.py:175-233
+// uses LAPACK pivoted QR).  On MI355X:
+//   * y = A x             : one wave per row, coalesced along the row (HBM-bound)
+//   * G = A A'            : fp64 MFMA (v_mfma_f64_16x16x4_f64), the only
+//                           matmul-shaped op of the path
+//   * G = L L', G^-1      : blocked right-looking Cholesky and a blocked
+//                           two-sweep inverse, 32x32 tiles through LDS
+// G^-1 is then applied as one dense matvec per projection, so the per-CG-
+// iteration cost of the (AA')^-1 step is a 8*m^2-byte stream instead of two
+// latency-bound triangular sweeps.
+#include "ipx_common.h"
+
+namespace {
+
+constexpr int NB = 32;   // tile edge of the factorization kernels
+
+// ---------------------------------------------------------------- gemv
+// y_r = alpha * sum_c A[r][c] x[c]  [+ diag_r x_r] [+ beta yin_r]; one wave per row.
+// Partial sums per lane over a strided column set, then a wave butterfly:
+// fixed order, independent of scheduling.
+template <bool REDUCE>
+__global__ void __launch_bounds__(IPX_BLOCK)
+k_dense_gemv(int m, int n, const double *__restrict__ A, int64_t lda,
+             const double *__restrict__ x, double alpha, const double *__restrict__ diag,
+             double beta, const double *yin, double *yout, int square,
+             double *__restrict__ partial, const double *__restrict__ guard) {
+  __shared__ double red_lds[IPX_BLOCK / IPX_WAVE];
+  if (guard && *guard != 0.0) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wpb = IPX_BLOCK / IPX_WAVE;
+  double acc_yy = 0.0, acc_xy = 0.0;
+  for (int r = blockIdx.x * wpb + wave; r < m; r += gridDim.x * wpb) {
+    const double *row = A + (int64_t)r * lda;
+    double s = 0.0;
+    for (int c = lane; c < n; c += IPX_WAVE) s += row[c] * x[c];
+    s = ipx_wave_sum(s);
+    if (lane == 0) {
+      double y = alpha * s;
+      if (diag) y += diag[r] * x[r];
+      if (yin) y += beta * yin[r];
+      yout[r] = y;
+      if (REDUCE) {
+        acc_yy += y * y;
+        if (square) acc_xy += x[r] * y;
+      }
+    }
+  }
+  if (REDUCE) {
+    double a = ipx_block_reduce<IPX_SUM>(acc_yy, red_lds);
+    double b = ipx_block_reduce<IPX_SUM>(acc_xy, red_lds);
+    if (threadIdx.x == 0) { partial[blockIdx.x] = a; partial[gridDim.x + blockIdx.x] = b; }
+  }
+}
+
+__global__ void __launch_bounds__(IPX_BLOCK)
+k_fold2(const double *partial, int count, double *red) {
+  __shared__ double lds[IPX_BLOCK / IPX_WAVE];
+  double a = ipx_sum_partials<IPX_SUM>(partial, count, lds);
+  double b = ipx_sum_partials<IPX_SUM>(partial + count, count, lds);
+  if (threadIdx.x == 0) { red[0] = a; red[1] = b; }
+}
+
+// ---------------------------------------------------------------- Gram
+// G[i][j] = sum_k A[i][k] A[j][k] for j <= i, mirrored; G is M x M (M = m
+// rounded up to 32) with an identity tail so it stays SPD.
+// v_mfma_f64_16x16x4_f64: lane l supplies A-operand element (row l&15, k l>>4)
+// and B-operand element (k l>>4, col l&15); D layout col = l&15,
+// row = (l>>4) + 4*reg  (cdna_hip_programming.md section 3).
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+__global__ void __launch_bounds__(IPX_WAVE)
+k_gram_mfma(int m, int n, const double *__restrict__ A, int64_t lda, double *__restrict__ G,
+            int M) {
+  const int ti = blockIdx.y, tj = blockIdx.x;       // 16x16 tile coordinates
+  if (tj > ti) return;
+  const int lane = threadIdx.x;
+  const int r = lane & 15, kq = lane >> 4;
+  const int ri = ti * 16 + r, rj = tj * 16 + r;
+  const double *pa = A + (int64_t)ri * lda;
+  const double *pb = A + (int64_t)rj * lda;
+  const bool va = ri < m, vb = rj < m;
+  v4d acc = {0.0, 0.0, 0.0, 0.0};
+  int k = 0;
+  for (; k + 4 <= n; k += 4) {
+    const double a = va ? pa[k + kq] : 0.0;
+    const double b = vb ? pb[k + kq] : 0.0;
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+  }
+  if (k < n) {
+    const double a = (va && k + kq < n) ? pa[k + kq] : 0.0;
+    const double b = (vb && k + kq < n) ? pb[k + kq] : 0.0;
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) {
+    const int row = ti * 16 + kq + 4 * reg, col = tj * 16 + r;
+    double v = acc[reg];
+    if (row >= m || col >= m) v = (row == col) ? 1.0 : 0.0;
+    G[(int64_t)row * M + col] = v;
+    G[(int64_t)col * M + row] = v;
+  }
+}
+
+// ------------------------------------------------------- blocked Cholesky
+// Diagonal tile: G_kk = L_kk L_kk'.  One workgroup of NB x NB lanes.
+__global__ void __launch_bounds__(NB *NB)
+k_potrf_tile(double *G, int M, int kb, int *flag) {
+  __shared__ double T[NB][NB + 1];
+  const int r = threadIdx.y, c = threadIdx.x;
+  double *g = G + ((int64_t)kb * NB) * M + (int64_t)kb * NB;
+  T[r][c] = g[(int64_t)r * M + c];
+  __syncthreads();
+  for (int j = 0; j < NB; ++j) {
+    if (r == j && c == j) {
+      const double d = T[j][j];
+      if (!(d > 0.0)) atomicOr(flag, 1);
+      T[j][j] = sqrt(d);
+    }
+    __syncthreads();
+    if (c == j && r > j) T[r][j] /= T[j][j];
+    __syncthreads();
+    if (c > j && r >= c) T[r][c] -= T[r][j] * T[c][j];
+    __syncthreads();
+  }
+  g[(int64_t)r * M + c] = (c <= r) ? T[r][c] : 0.0;
+}
+
+// Panel: G_ik <- G_ik L_kk^-T for every tile row i > k (one workgroup each).
+__global__ void __launch_bounds__(NB *NB)
+k_trsm_panel(double *G, int M, int kb) {
+  __shared__ double Lk[NB][NB + 1];
+  __shared__ double P[NB][NB + 1];
+  const int r = threadIdx.y, c = threadIdx.x;
+  const int ib = kb + 1 + blockIdx.x;
+  const double *lk = G + ((int64_t)kb * NB) * M + (int64_t)kb * NB;
+  double *p = G + ((int64_t)ib * NB) * M + (int64_t)kb * NB;
+  Lk[r][c] = lk[(int64_t)r * M + c];
+  P[r][c] = p[(int64_t)r * M + c];
+  __syncthreads();
+  // row r of the tile: x L' = p  ->  x_j = (p_j - sum_{t<j} x_t L[j][t]) / L[j][j]
+  for (int j = 0; j < NB; ++j) {
+    if (c == j) P[r][j] /= Lk[j][j];
+    __syncthreads();
+    if (c > j) P[r][c] -= P[r][j] * Lk[c][j];
+    __syncthreads();
+  }
+  p[(int64_t)r * M + c] = P[r][c];
+}
+
+// Trailing update: G_ij -= L_ik L_jk' for k < j <= i.
+__global__ void __launch_bounds__(NB *NB)
+k_syrk_update(double *G, int M, int kb) {
+  __shared__ double Li[NB][NB + 1];
+  __shared__ double Lj[NB][NB + 1];
+  const int r = threadIdx.y, c = threadIdx.x;
+  const int ib = kb + 1 + blockIdx.y, jb = kb + 1 + blockIdx.x;
+  if (jb > ib) return;
+  Li[r][c] = G[((int64_t)ib * NB + r) * M + (int64_t)kb * NB + c];
+  Lj[r][c] = G[((int64_t)jb * NB + r) * M + (int64_t)kb * NB + c];
+  __syncthreads();
+  double s = 0.0;
+#pragma unroll 8
+  for (int t = 0; t < NB; ++t) s += Li[r][t] * Lj[c][t];
+  G[((int64_t)ib * NB + r) * M + (int64_t)jb * NB + c] -= s;
+}
+
+// ------------------------------------------------------- blocked inverse
+// X starts as I; forward sweep X <- L^-1 X, backward sweep X <- L^-T X.
+// Tile row kb of X: solve with the diagonal tile (one workgroup per tile column).
+template <bool TRANS>
+__global__ void __launch_bounds__(NB *NB)
+k_inv_diag(const double *__restrict__ G, double *X, int M, int kb) {
+  __shared__ double Lk[NB][NB + 1];
+  __shared__ double B[NB][NB + 1];
+  const int r = threadIdx.y, c = threadIdx.x;
+  const int cb = blockIdx.x;
+  const double *lk = G + ((int64_t)kb * NB) * M + (int64_t)kb * NB;
+  double *x = X + ((int64_t)kb * NB) * M + (int64_t)cb * NB;
+  Lk[r][c] = lk[(int64_t)r * M + c];
+  B[r][c] = x[(int64_t)r * M + c];
+  __syncthreads();
+  if (!TRANS) {     // L y = b, column c of the tile
+    for (int j = 0; j < NB; ++j) {
+      if (r == j) B[j][c] /= Lk[j][j];
+      __syncthreads();
+      if (r > j) B[r][c] -= Lk[r][j] * B[j][c];
+      __syncthreads();
+    }
+  } else {          // L' y = b
+    for (int j = NB - 1; j >= 0; --j) {
+      if (r == j) B[j][c] /= Lk[j][j];
+      __syncthreads();
+      if (r < j) B[r][c] -= Lk[j][r] * B[j][c];
+      __syncthreads();
+    }
+  }
+  x[(int64_t)r * M + c] = B[r][c];
+}
+
+// X_i -= L_ik X_k (forward, i > k)   /   X_i -= L_ki' X_k (backward, i < k)
+template <bool TRANS>
+__global__ void __launch_bounds__(NB *NB)
+k_inv_update(const double *__restrict__ G, double *X, int M, int kb) {
+  __shared__ double Lt[NB][NB + 1];
+  __shared__ double Xk[NB][NB + 1];
+  const int r = threadIdx.y, c = threadIdx.x;
+  const int cb = blockIdx.x;
+  const int ib = TRANS ? (int)blockIdx.y : kb + 1 + (int)blockIdx.y;
+  if (TRANS && ib >= kb) return;
+  if (!TRANS) Lt[r][c] = G[((int64_t)ib * NB + r) * M + (int64_t)kb * NB + c];   // L_ik
+  else Lt[r][c] = G[((int64_t)kb * NB + c) * M + (int64_t)ib * NB + r];          // (L_ki)'
+  Xk[r][c] = X[((int64_t)kb * NB + r) * M + (int64_t)cb * NB + c];
+  __syncthreads();
+  double s = 0.0;
+#pragma unroll 8
+  for (int t = 0; t < NB; ++t) s += Lt[r][t] * Xk[t][c];
+  X[((int64_t)ib * NB + r) * M + (int64_t)cb * NB + c] -= s;
+}
+
+__global__ void __launch_bounds__(IPX_BLOCK) k_set_identity(double *X, int M) {
+  const int64_t tot = (int64_t)M * M;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < tot;
+       i += (int64_t)gridDim.x * blockDim.x)
+    X[i] = (i / M == i % M) ? 1.0 : 0.0;
+}
+
+}  // namespace
+
+int ipx_dense_gemv_launch(int m, int n, const double *A, int64_t lda, const double *x,
+                          double alpha, const double *diag, double beta, const double *yin,
+                          double *yout, double *partial, int *npartial, const double *guard,
+                          hipStream_t st) {
+  if (m == 0) { if (npartial) *npartial = 0; return IPX_OK; }
+  if (beta == 0.0) yin = nullptr;
+  const int wpb = IPX_BLOCK / IPX_WAVE;
+  int grid = (m + wpb - 1) / wpb;
+  if (grid > 2048) grid = 2048;
+  if (npartial) *npartial = grid;
+  const int square = m == n;
+  if (partial)
+    hipLaunchKernelGGL(k_dense_gemv<true>, dim3(grid), dim3(IPX_BLOCK), 0, st, m, n, A, lda, x,
+                       alpha, diag, beta, yin, yout, square, partial, guard);
+  else
+    hipLaunchKernelGGL(k_dense_gemv<false>, dim3(grid), dim3(IPX_BLOCK), 0, st, m, n, A, lda, x,
+                       alpha, diag, beta, yin, yout, square, partial, guard);
+  IPX_CHECK_LAUNCH();
+  return IPX_OK;
+}
+
+extern "C" {
+
+// yout = alpha*A x [+ diag*x] [+ beta*yin]; red (optional) = {sum y^2, sum x*y}.
+int ipx_dense_gemv(int64_t m, int64_t n, const double *A, int64_t lda, const double *x,
+                   double alpha, const double *diag, double beta, const double *yin,
+                   double *yout, double *red, double *ws, void *stream) {
+  if (m < 0 || n < 0 || !A || !x || !yout || lda < n) return IPX_EINVAL;
+  if (m == 0) {
+    if (red) (void)hipMemsetAsync(red, 0, 2 * sizeof(double), (hipStream_t)stream);
+    return IPX_OK;
+  }
+  if (red && !ws) return IPX_EINVAL;
+  int np = 0;
+  int rc = ipx_dense_gemv_launch((int)m, (int)n, A, lda, x, alpha, diag, beta, yin, yout,
+                                 red ? ws : nullptr, &np, nullptr, (hipStream_t)stream);
+  if (rc != IPX_OK) return rc;
+  if (red) {
+    hipLaunchKernelGGL(k_fold2, dim3(1), dim3(IPX_BLOCK), 0, (hipStream_t)stream, ws, np, red);
+    IPX_CHECK_LAUNCH();
+  }
+  return IPX_OK;
+}
+
+int64_t ipx_dense_padded(int64_t m) { return ((m + NB - 1) / NB) * NB; }
+
+// G (M x M, M = ipx_dense_padded(m)) = A A' via fp64 MFMA.
+int ipx_gram_f64_mfma(int64_t m, int64_t n, const double *A, int64_t lda, double *G,
+                      void *stream) {
+  if (m < 1 || n < 0 || !A || !G || lda < n) return IPX_EINVAL;
+  const int M = (int)ipx_dense_padded(m);
+  const int tiles = M / 16;
+  hipLaunchKernelGGL(k_gram_mfma, dim3(tiles, tiles), dim3(IPX_WAVE), 0, (hipStream_t)stream,
+                     (int)m, (int)n, A, lda, G, M);
+  IPX_CHECK_LAUNCH();
+  return IPX_OK;
+}
+
+// In place: lower triangle of G <- L with G = L L'.  flag (device int) != 0
+// afterwards when a pivot was not positive.
+int ipx_chol_factor(int64_t M, double *G, int *flag, void *stream) {
+  if (M < NB || M % NB || !G || !flag) return IPX_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = (int)(M / NB);
+  if (hipMemsetAsync(flag, 0, sizeof(int), st) != hipSuccess) return IPX_ELAUNCH;
+  for (int k = 0; k < nb; ++k) {
+    hipLaunchKernelGGL(k_potrf_tile, dim3(1), dim3(NB, NB), 0, st, G, (int)M, k, flag);
+    IPX_CHECK_LAUNCH();
+    const int rest = nb - k - 1;
+    if (rest > 0) {
+      hipLaunchKernelGGL(k_trsm_panel, dim3(rest), dim3(NB, NB), 0, st, G, (int)M, k);
+      IPX_CHECK_LAUNCH();
+      hipLaunchKernelGGL(k_syrk_update, dim3(rest, rest), dim3(NB, NB), 0, st, G, (int)M, k);
+      IPX_CHECK_LAUNCH();
+    }
+  }
+  return IPX_OK;
+}
+
+// X (M x M) <- (L L')^-1 from the factor in the lower triangle of G.
+int ipx_chol_inverse(int64_t M, const double *G, double *X, void *stream) {
+  if (M < NB || M % NB || !G || !X) return IPX_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = (int)(M / NB);
+  hipLaunchKernelGGL(k_set_identity, dim3(1024), dim3(IPX_BLOCK), 0, st, X, (int)M);
+  IPX_CHECK_LAUNCH();
+  for (int k = 0; k < nb; ++k) {                 // X <- L^-1 X
+    hipLaunchKernelGGL(k_inv_diag<false>, dim3(nb), dim3(NB, NB), 0, st, G, X, (int)M, k);
+    IPX_CHECK_LAUNCH();
+    if (nb - k - 1 > 0) {
+      hipLaunchKernelGGL(k_inv_update<false>, dim3(nb, nb - k - 1), dim3(NB, NB), 0, st, G, X,
+                         (int)M, k);
+      IPX_CHECK_LAUNCH();
+    }
+  }
+  for (int k = nb - 1; k >= 0; --k) {            // X <- L^-T X
+    hipLaunchKernelGGL(k_inv_diag<true>, dim3(nb), dim3(NB, NB), 0, st, G, X, (int)M, k);
+    IPX_CHECK_LAUNCH();
+    if (k > 0) {
+      hipLaunchKernelGGL(k_inv_update<true>, dim3(nb, k), dim3(NB, NB), 0, st, G, X, (int)M, k);
+      IPX_CHECK_LAUNCH();
+    }
+  }
+  return IPX_OK;
+}
+
+}  // extern "C"

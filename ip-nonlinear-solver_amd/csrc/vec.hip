@@ -44,6 +44,26 @@ struct OpGather {   // out[i] = sign[i] * (x[idx[i]] - shift[i])
   }
 };
 
+struct OpMaxScalar {   // np.maximum(x, c)
+  const double *x; double c;
+  __device__ double operator()(int64_t i) const { return fmax(x[i], c); }
+};
+struct OpWherePos {    // np.where(v > 0, a, c)
+  const double *v, *a; double c;
+  __device__ double operator()(int64_t i) const { return v[i] > 0.0 ? a[i] : c; }
+};
+struct OpNegMasked {   // s[mask] = -c[mask], other entries unchanged
+  const double *s, *mask, *c;
+  __device__ double operator()(int64_t i) const { return mask[i] != 0.0 ? -c[i] : s[i]; }
+};
+
+__global__ void __launch_bounds__(IPX_BLOCK)
+k_scatter(int64_t n, const double *__restrict__ x, const int32_t *__restrict__ idx, double *out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    out[idx[i]] = x[i];
+}
+
 template <typename F>
 __global__ void __launch_bounds__(IPX_BLOCK) k_map(int64_t n, F f, double *out) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -128,7 +148,18 @@ struct RedBoxSphere {   // see ipx.h
   }
 };
 
+struct RedSumLog {   // sum(log s) and the number of s <= 0 (tr_interior_point.py:93)
+  static constexpr int NQ = 2;
+  const double *s;
+  __device__ void init(Acc<2> &a) const { a.v[0] = 0.0; a.v[1] = 0.0; }
+  __device__ void step(Acc<2> &a, int64_t i) const {
+    const double t = s[i];
+    if (t > 0.0) a.v[0] += log(t); else a.v[1] += 1.0;
+  }
+};
+
 template <typename R> struct RedOps;
+template <> struct RedOps<RedSumLog> { __device__ static constexpr int op(int) { return IPX_SUM; } };
 template <> struct RedOps<RedDot> { __device__ static constexpr int op(int) { return IPX_SUM; } };
 template <> struct RedOps<RedNorms> { __device__ static constexpr int op(int q) { return q == 1 ? IPX_MAX : IPX_SUM; } };
 template <> struct RedOps<RedBoxInside> { __device__ static constexpr int op(int) { return IPX_SUM; } };
@@ -231,6 +262,37 @@ int ipx_gather(int64_t n, const double *x, const int32_t *idx, const double *sig
                const double *shift, double *out, void *stream) {
   if (n < 0 || !x || !idx || !out) return IPX_EINVAL;
   return launch_map(n, OpGather{x, idx, sign, shift}, out, stream);
+}
+
+int ipx_scatter(int64_t n, const double *x, const int32_t *idx, double *out, void *stream) {
+  if (n < 0 || !x || !idx || !out) return IPX_EINVAL;
+  if (n == 0) return IPX_OK;
+  hipLaunchKernelGGL(k_scatter, dim3(ipx_grid_for(n, IPX_BLOCK * 4)), dim3(IPX_BLOCK), 0,
+                     (hipStream_t)stream, n, x, idx, out);
+  IPX_CHECK_LAUNCH();
+  return IPX_OK;
+}
+
+int ipx_max_scalar(int64_t n, const double *x, double c, double *out, void *stream) {
+  if (n < 0 || !x || !out) return IPX_EINVAL;
+  return launch_map(n, OpMaxScalar{x, c}, out, stream);
+}
+
+int ipx_where_positive(int64_t n, const double *v, const double *a, double c, double *out,
+                       void *stream) {
+  if (n < 0 || !v || !a || !out) return IPX_EINVAL;
+  return launch_map(n, OpWherePos{v, a, c}, out, stream);
+}
+
+int ipx_assign_negated_where(int64_t n, double *s, const double *mask, const double *c,
+                             void *stream) {
+  if (n < 0 || !s || !mask || !c) return IPX_EINVAL;
+  return launch_map(n, OpNegMasked{s, mask, c}, s, stream);
+}
+
+int ipx_sum_log(int64_t n, const double *s, double *out, double *ws, void *stream) {
+  if (n < 0 || !s) return IPX_EINVAL;
+  return launch_reduce(n, RedSumLog{s}, out, ws, stream);
 }
 
 int ipx_dot(int64_t n, const double *x, const double *y, double *out, double *ws, void *stream) {

@@ -23,6 +23,15 @@ _SIGNATURES = {
     "ipx_clip": [_I64, _P, _P, _P, _P, _P],
     "ipx_affine": [_I64, _F64, _P, _F64, _P, _P],
     "ipx_gather": [_I64, _P, _P, _P, _P, _P, _P],
+    "ipx_scatter": [_I64, _P, _P, _P, _P],
+    "ipx_max_scalar": [_I64, _P, _F64, _P, _P],
+    "ipx_where_positive": [_I64, _P, _P, _F64, _P, _P],
+    "ipx_assign_negated_where": [_I64, _P, _P, _P, _P],
+    "ipx_sum_log": [_I64, _P, _P, _P, _P],
+    "ipx_dense_gemv": [_I64, _I64, _P, _I64, _P, _F64, _P, _F64, _P, _P, _P, _P, _P],
+    "ipx_gram_f64_mfma": [_I64, _I64, _P, _I64, _P, _P],
+    "ipx_chol_factor": [_I64, _P, _P, _P],
+    "ipx_chol_inverse": [_I64, _P, _P, _P],
     "ipx_dot": [_I64, _P, _P, _P, _P, _P],
     "ipx_norms": [_I64, _P, _P, _P, _P],
     "ipx_box_inside": [_I64, _P, _P, _P, _P, _P, _P],
@@ -45,8 +54,10 @@ _SIGNATURES = {
     "ipx_aat_band": [_I64, _I32, _P, _P, _P, _P, _P, _P],
 }
 _RESTYPES = {"ipx_version": _c.c_char_p, "ipx_last_error": _c.c_char_p,
-             "ipx_banded_create": _P, "ipx_banded_destroy": None}
-_EXTRA_ARGTYPES = {"ipx_banded_create": [_I64, _I32, _I32], "ipx_banded_destroy": [_P]}
+             "ipx_banded_create": _P, "ipx_banded_destroy": None,
+             "ipx_dense_padded": _I64}
+_EXTRA_ARGTYPES = {"ipx_banded_create": [_I64, _I32, _I32], "ipx_banded_destroy": [_P],
+                   "ipx_dense_padded": [_I64]}
 
 _lib = None
 

@@ -1,0 +1,227 @@
+"""HIP backend of the outer loops: the vector / matrix / operator factory that
+``sqp.py`` and ``barrier.py`` are written against.  Every array lives in HBM
+(``DVec`` / ``DeviceCSR`` / ``DeviceDense``) and every arithmetic operation is
+an ipx kernel.  This is the ONLY backend the package ships; tests may inject
+the CPU oracle's backend to exercise the host logic without a GPU.
+"""
+import numpy as np
+import scipy.sparse as sps
+import torch
+
+from . import _hip
+from . import device as dv
+from . import qp, projector
+from .canonical import HessianSum
+from .dense import DeviceDense
+from .device import DVec, DeviceCSR, CSRPattern, _p, stream_ptr, ctx
+from .operators import DeviceHessian, DiagonalOperator
+
+name = "hip"
+
+
+# ---- vectors ---------------------------------------------------------------
+def asvec(a):
+    return a if isinstance(a, DVec) else DVec.from_host(a)
+
+
+def tohost(v):
+    return v.to_host() if isinstance(v, DVec) else np.asarray(v)
+
+
+zeros = DVec.zeros
+full = DVec.full
+hstack = dv.hstack
+norm = dv.norm
+norm_inf = dv.norm_inf
+
+
+def copy(v):
+    return v.copy()
+
+
+def dot(a, b):
+    return a.dot(b)
+
+
+def maximum(v, c):
+    out = dv._empty(len(v))
+    _hip.call("ipx_max_scalar", len(v), _p(v.t), float(c), _p(out), stream_ptr())
+    return DVec(out)
+
+
+def where_positive(v, a, c):
+    out = dv._empty(len(v))
+    _hip.call("ipx_where_positive", len(v), _p(v.t), _p(a.t), float(c), _p(out), stream_ptr())
+    return DVec(out)
+
+
+def sum_log(s):
+    """sum(log s_i), -inf when any s_i <= 0 (tr_interior_point.py:93-95)."""
+    if len(s) == 0:
+        return 0.0
+    c = ctx()
+    _hip.call("ipx_sum_log", len(s), _p(s.t), _p(c.out), _p(c.ws), stream_ptr())
+    total, bad = dv.read_slots(2)
+    return -np.inf if bad > 0 else total
+
+
+def assign_negated_where(s, mask, c):
+    """s[mask] = -c[mask] in place (s is a view of z)."""
+    m = DVec.from_host(np.asarray(mask, dtype=np.float64))
+    _hip.call("ipx_assign_negated_where", len(s), _p(s.t), _p(m.t), _p(c.t), stream_ptr())
+
+
+# ---- matrices / operators ----------------------------------------------------
+_pattern_cache = {}
+
+
+def _upload_csr(M, key):
+    """scipy sparse -> DeviceCSR, re-using the device pattern (tiles, transpose,
+    symbolic factorization) of the previous matrix uploaded under ``key`` when
+    the sparsity pattern is unchanged -- the usual case for a Jacobian."""
+    M = sps.csr_matrix(M)
+    if not M.has_sorted_indices:
+        M = M.sorted_indices()
+    A = DeviceCSR.from_scipy(M, _pattern_cache.get(key))
+    _pattern_cache[key] = A.pattern
+    return A
+
+
+def matrix(J, key="jac"):
+    if isinstance(J, (DeviceCSR, DeviceDense)):
+        return J
+    if sps.issparse(J) or 0 in np.shape(J):
+        return _upload_csr(J, (key, np.shape(J)))
+    return DeviceDense.from_host(J)
+
+
+def diagonal_operator(d):
+    return DiagonalOperator(d)
+
+
+class HostCallbackOperator:
+    """User operator that only lives on the host (e.g. a finite-difference
+    Hessian): the vector crosses PCIe for the call.  Outside the accelerated
+    path by construction (_numdiff row)."""
+
+    def __init__(self, op):
+        self.op = op
+        self.shape = op.shape
+
+    def dot(self, p):
+        return DVec.from_host(self.op.dot(p.to_host()))
+
+
+class PaddedOperator:
+    """[[H, 0], [0, 0]] acting on z = [x; s] for an x-space operator H."""
+
+    def __init__(self, op, n_vars, n_total):
+        self.op, self.n_vars, self.n_total = op, n_vars, n_total
+
+    def dot(self, p):
+        return dv.hstack((self.op.dot(p[:self.n_vars]),
+                          DVec.zeros(self.n_total - self.n_vars)))
+
+
+def _extend_pattern(pattern, n_total):
+    """CSR pattern of [[H, 0], [0, 0]] (n_total x n_total) sharing H's columns."""
+    cache = getattr(pattern, "_ipx_extended", None)
+    if cache is None:
+        cache = pattern._ipx_extended = {}
+    if n_total not in cache:
+        extra = n_total - pattern.shape[0]
+        indptr = np.concatenate((pattern.indptr_h,
+                                 np.full(extra, pattern.indptr_h[-1], dtype=np.int32)))
+        cache[n_total] = CSRPattern(indptr, pattern.indices_h, (n_total, n_total))
+    return cache[n_total]
+
+
+def hessian_operator(terms, n_vars, slack_block):
+    """Device operator for the Lagrangian Hessian terms (HessianSum from
+    canonical.lagrangian_hessian) and, in barrier problems, the diagonal slack
+    block: ``[Hx p_x ; slack_block * p_s]`` (tr_interior_point.py:222-241)."""
+    flat = terms.flat_terms() if isinstance(terms, HessianSum) else list(terms)
+    n_total = n_vars + (len(slack_block) if slack_block is not None else 0)
+    csr, diag, others = None, None, []
+    host_sparse, host_diag = None, None
+    for h in flat:
+        if sps.issparse(h):
+            h = sps.csr_matrix(h)
+            d = h.diagonal()
+            if h.nnz == np.count_nonzero(d) or (h - sps.diags(d)).count_nonzero() == 0:
+                host_diag = d if host_diag is None else host_diag + d      # purely diagonal term
+            else:
+                # several sparse terms are merged on the host so the product
+                # stays ONE fused SpMV (differs from term-by-term by rounding only)
+                host_sparse = h if host_sparse is None else host_sparse + h
+        elif isinstance(h, DeviceCSR) and csr is None:
+            csr = h
+        elif isinstance(h, DVec):
+            diag = h if diag is None else diag + h
+        elif isinstance(h, (DeviceCSR, DeviceHessian, DeviceDense)):
+            others.append(h)
+        elif isinstance(h, np.ndarray):
+            others.append(DeviceDense.from_host(h))
+        else:
+            others.append(HostCallbackOperator(h))
+    if host_sparse is not None:
+        up = _upload_csr(host_sparse, ("hess", host_sparse.shape))
+        if csr is None:
+            csr = up
+        else:
+            others.append(up)
+    if host_diag is not None:
+        hd = DVec.from_host(host_diag)
+        diag = hd if diag is None else diag + hd
+    if slack_block is None:
+        return DeviceHessian(n_vars, csr, diag, others)
+    # z-space: extend the CSR block with empty slack rows, put the slack block
+    # on the diagonal, pad any other x-space term
+    if csr is not None:
+        csr = DeviceCSR(_extend_pattern(csr.pattern, n_total), csr.val)
+    xdiag = diag if diag is not None else DVec.zeros(n_vars)
+    zdiag = dv.hstack((xdiag, slack_block))
+    return DeviceHessian(n_total, csr, zdiag,
+                         [PaddedOperator(h, n_vars, n_total) for h in others])
+
+
+def augmented_jacobian(J_eq, J_ineq, s, n_vars, n_eq, n_ineq):
+    """[[J_eq, 0], [J_ineq, diag(s)]] (tr_interior_point.py:141-194) with the
+    slack entries written on the device."""
+    if sps.issparse(J_eq) or sps.issparse(J_ineq):
+        J_eq, J_ineq = sps.csr_matrix(J_eq), sps.csr_matrix(J_ineq)
+        J = sps.vstack([J_eq, J_ineq], format="csr")
+        J.sort_indices()
+        # one extra entry at the end of every inequality row (largest column)
+        shift = np.concatenate((np.zeros(n_eq + 1, dtype=np.int64),
+                                np.arange(1, n_ineq + 1, dtype=np.int64)))
+        indptr = J.indptr.astype(np.int64) + shift
+        nnz = int(indptr[-1])
+        slots = (indptr[n_eq + 1:] - 1).astype(np.int64)
+        mask = np.zeros(nnz, dtype=bool)
+        mask[slots] = True
+        indices = np.empty(nnz, dtype=np.int32)
+        data = np.zeros(nnz)
+        indices[mask] = n_vars + np.arange(n_ineq)
+        indices[~mask] = J.indices
+        data[~mask] = J.data
+        A = _upload_csr(sps.csr_matrix((data, indices, indptr.astype(np.int32)),
+                                       shape=(n_eq + n_ineq, n_vars + n_ineq)),
+                        ("augjac", n_vars, n_eq, n_ineq))
+        idx = torch.from_numpy(slots.astype(np.int32)).to(ctx().device)
+        _hip.call("ipx_scatter", n_ineq, _p(s.t), _p(idx), _p(A.val), stream_ptr())
+        return A
+    s_h = s.to_host()
+    top = np.hstack((np.atleast_2d(J_eq).reshape(n_eq, n_vars), np.zeros((n_eq, n_ineq))))
+    bot = np.hstack((np.atleast_2d(J_ineq).reshape(n_ineq, n_vars), np.diag(s_h)))
+    return DeviceDense.from_host(np.vstack((top, bot)))
+
+
+# ---- the trust-region subproblem (HIP kernels) ---------------------------
+def projections(A, method=None):
+    return projector.projections(A, method)
+
+
+modified_dogleg = qp.modified_dogleg
+projected_cg = qp.projected_cg
+box_intersections = qp.box_intersections

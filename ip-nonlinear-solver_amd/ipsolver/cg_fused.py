@@ -44,7 +44,7 @@ def _hessian_parts(H):
     from .operators import DeviceHessian
     if isinstance(H, DeviceCSR) and H.shape[0] == H.shape[1]:
         return H, None
-    if isinstance(H, DeviceHessian) and H.csr is not None:
+    if isinstance(H, DeviceHessian) and H.csr is not None and not H.others:
         return H.csr, H.diag
     return None
 

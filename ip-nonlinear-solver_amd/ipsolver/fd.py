@@ -1,0 +1,47 @@
+"""Finite-difference Hessian-vector products (host side, user callbacks).
+
+The reference vendors scipy's ``approx_derivative`` and adds an
+``as_linear_operator`` mode (ipsolver/_numdiff.py:403-441); only that mode is
+reachable from the solver path (``hess='2-point'|'3-point'|'cs'``), so only it
+is provided.  Each product is one or two evaluations of a *user* callback on
+the host, which is why SURVEY.md section 2 leaves it outside the accelerated
+path: vectors cross to the host for the call and come back.
+"""
+import numpy as np
+
+FD_METHODS = ('2-point', '3-point', 'cs')
+_EPS = np.finfo(np.float64).eps
+_REL_STEP = {'2-point': _EPS ** 0.5, '3-point': _EPS ** (1 / 3), 'cs': _EPS ** 0.5}
+
+
+class FiniteDifferenceOperator:
+    """J(x0).p approximated by differences of ``fun`` (shape (m, n), ``dot``)."""
+
+    def __init__(self, fun, x0, method):
+        if method not in FD_METHODS:
+            raise ValueError("Unknown method '%s'. " % method)
+        self.fun = lambda x: np.atleast_1d(fun(x))
+        self.x0 = np.atleast_1d(np.asarray(x0, dtype=float))
+        self.f0 = self.fun(self.x0)
+        self.h = _REL_STEP[method]
+        self.method = method
+        self.shape = (self.f0.size, self.x0.size)
+        self.host_only = True      # tells the device backend to round-trip vectors
+
+    def dot(self, p):
+        p = np.asarray(p, dtype=float)
+        if not p.any():
+            return np.zeros(self.shape[0])
+        norm_p = np.linalg.norm(p)
+        if self.method == '2-point':          # _numdiff.py:408-415
+            dx = self.h / norm_p
+            return (self.fun(self.x0 + dx * p) - self.f0) / dx
+        if self.method == '3-point':          # :417-427
+            dx = 2 * self.h / norm_p
+            f1 = self.fun(self.x0 - (dx / 2) * p)
+            f2 = self.fun(self.x0 + (dx / 2) * p)
+            return (f2 - f1) / dx
+        dx = self.h / norm_p                  # 'cs' :429-437
+        return self.fun(self.x0 + dx * p * 1.j).imag / dx
+
+    matvec = dot

@@ -1,0 +1,234 @@
+"""``minimize_constrained``: the public driver of the drop-in boundary.
+
+Signature, defaults, method names, result fields, counters, status codes and
+exceptions follow the reference's ``ipsolver/_minimize_constrained.py:96-565``
+(cited below).  The user's callbacks are evaluated on the host with numpy
+arrays, as in the reference; everything between two callback evaluations --
+the trust-region subproblem solves, projections, merit-function algebra --
+runs on the GPU through ``backend_hip``.  Results are returned as numpy
+arrays.
+"""
+import time
+from copy import deepcopy
+from warnings import warn
+
+import numpy as np
+import scipy.sparse as sps
+from scipy.optimize import OptimizeResult
+
+from . import backend as _backend
+from .barrier import tr_interior_point
+from .canonical import lagrangian_hessian, to_canonical, empty_canonical_constraint
+from .constraints import (NonlinearConstraint, LinearConstraint, BoxConstraint, wrap_hessian)
+from .fd import FiniteDifferenceOperator, FD_METHODS
+from .sqp import equality_constrained_sqp
+
+__all__ = ['minimize_constrained']
+
+TERMINATION_MESSAGES = {
+    0: "The maximum number of function evaluations is exceeded.",
+    1: "`gtol` termination condition is satisfied.",
+    2: "`xtol` termination condition is satisfied.",
+    3: "`callback` function requested termination"
+}
+
+_METHODS = {'equality_constrained_sqp': 'equality_constrained_sqp',
+            'equality-constrained-sqp': 'equality_constrained_sqp',   # docstring spelling
+            'tr_interior_point': 'tr_interior_point',
+            'tr-interior-point': 'tr_interior_point'}
+
+_VECTOR_FIELDS = ("x", "v", "s", "grad", "constr")
+
+
+class _Memoize:
+    """Gradient cache used with finite-difference Hessians
+    (_minimize_constrained.py:28-40; keeps a reference to x, not a copy)."""
+
+    def __init__(self, fun, x0, f0):
+        self.fun, self._x, self._f = fun, x0, f0
+
+    def __call__(self, x):
+        if not np.array_equal(x, self._x):
+            self._x = x
+            self._f = self.fun(x)
+        return self._f
+
+
+def _print_header(method):
+    if method == 'equality_constrained_sqp':
+        cols = ("niter", "f evals", "CG iter", "tr radius", "penalty", "opt", "c viol")
+        widths = (7, 7, 7, 10, 10, 10, 10)
+    else:
+        cols = ("niter", "f evals", "CG iter", "barrier param", "tr radius", "penalty", "opt",
+                "c viol")
+        widths = (7, 7, 7, 13, 10, 10, 10, 10)
+    print("|" + "|".join("{0:^{1}}".format(c, w) for c, w in zip(cols, widths)) + "|")
+    print("|" + "|".join("-" * (w - 1) + ":" if w == 7 else ":" + "-" * (w - 2) + ":"
+                         for w in widths) + "|")
+
+
+def _print_iter(method, state):
+    head = "|{0:>7}|{1:>7}|{2:>7}|".format(state.niter, state.nfev, state.cg_niter)
+    vals = [state.trust_radius, state.penalty, state.optimality, state.constr_violation]
+    if method == 'tr_interior_point':
+        head += "   {0:^1.2e}  |".format(state.barrier_parameter)
+    print(head + "".join(" {0:^1.2e} |".format(v) for v in vals))
+
+
+def minimize_constrained(fun, x0, grad, hess='2-point', constraints=(), method=None,
+                         xtol=1e-8, gtol=1e-8, sparse_jacobian=None, options={},
+                         callback=None, max_iter=1000, verbose=0):
+    """Minimize a scalar function subject to constraints (see the reference's
+    docstring, _minimize_constrained.py:101-372, for the full parameter list).
+
+    ``method`` is ``'equality_constrained_sqp'`` or ``'tr_interior_point'``
+    (hyphenated spellings are accepted too); ``None`` picks by constraint type.
+    Returns a ``scipy.optimize.OptimizeResult`` with the reference's fields.
+    """
+    xp = _backend.get()
+    x0 = np.atleast_1d(x0).astype(float)                     # :374-379
+    n_vars = np.size(x0)
+    f0 = fun(x0)
+    g0 = np.atleast_1d(grad(x0))
+
+    def plain_grad(x):
+        return np.atleast_1d(grad(x))
+    grad_wrapped = _Memoize(plain_grad, x0, g0) if hess in FD_METHODS else plain_grad
+
+    if callable(hess):                                       # :395-422
+        hess_wrapped = wrap_hessian(hess, hess(x0), 1)
+    elif hess in FD_METHODS:
+        def hess_wrapped(x):
+            return FiniteDifferenceOperator(grad_wrapped, x, hess)
+    else:
+        hess_wrapped = hess
+
+    if isinstance(constraints, (NonlinearConstraint, LinearConstraint, BoxConstraint)):
+        constraints = [constraints]                          # :425-437
+    copied = [deepcopy(c) for c in constraints]
+    for c in copied:
+        x0 = c.evaluate_and_initialize(x0, sparse_jacobian)
+    constr = (empty_canonical_constraint(x0, n_vars, sparse_jacobian) if len(copied) == 0
+              else to_canonical(copied))
+    host_lagr_hess = lagrangian_hessian(constr, hess_wrapped)
+
+    state = OptimizeResult(niter=0, nfev=1, ngev=1, ncev=1, njev=1, nhev=0,
+                           cg_niter=0, cg_info={})           # :443-450
+    options = dict(options)
+    return_all = options.get("return_all", False)
+    if return_all:
+        state.allvecs, state.allmult = [], []
+
+    if method is None:                                       # :453-457
+        method = 'equality_constrained_sqp' if constr.n_ineq == 0 else 'tr_interior_point'
+    if method not in _METHODS:
+        raise ValueError("Unknown optimization ``method``.")
+    method = _METHODS[method]
+    interior = method == 'tr_interior_point'
+    barrier_tol = options.get("barrier_tol", 1e-8)
+
+    def user_view(state):
+        """State as the user's callback sees it: host arrays."""
+        view = OptimizeResult(state)
+        for k in _VECTOR_FIELDS:
+            if k in view:
+                view[k] = xp.tohost(view[k])
+        return view
+
+    def stop_criteria(state):                                # :460-502
+        if verbose >= 2:
+            _print_iter(method, state)
+        state.status = None
+        if callback is not None and callback(user_view(state)):
+            state.status = 3
+        elif state.optimality < gtol and state.constr_violation < gtol:
+            state.status = 1
+        elif state.trust_radius < xtol and (not interior
+                                            or state.barrier_parameter < barrier_tol):
+            state.status = 2
+        elif state.niter > max_iter:
+            state.status = 0
+        return state.status in (0, 1, 2, 3)
+
+    # ---- host callbacks seen from the device loops --------------------------
+    def fun_dev(x):
+        return fun(xp.tohost(x))
+
+    def grad_dev(x):
+        return xp.asvec(grad_wrapped(xp.tohost(x)))
+
+    def constr_dev(x):
+        c_ineq, c_eq = constr.constr(xp.tohost(x))
+        return xp.asvec(c_ineq), xp.asvec(c_eq)
+
+    def jac_host(x):
+        return constr.jac(xp.tohost(x))
+
+    if verbose >= 2:
+        _print_header(method)
+    start_time = time.time()
+    x0_dev, g0_dev = xp.asvec(x0), xp.asvec(g0)
+    if not interior:                                         # :512-530
+        if constr.n_ineq > 0:
+            raise ValueError("'equality_constrained_sqp' does not support "
+                             "inequality constraints.")
+
+        def fun_and_constr(x):
+            xh = xp.tohost(x)
+            _, c_eq = constr.constr(xh)
+            return fun(xh), xp.asvec(c_eq)
+
+        def grad_and_jac(x):
+            xh = xp.tohost(x)
+            _, J_eq = constr.jac(xh)
+            return xp.asvec(grad_wrapped(xh)), xp.matrix(J_eq)
+
+        def lagr_hess(x, v):
+            terms = host_lagr_hess(xp.tohost(x), xp.tohost(v))
+            return xp.hessian_operator(terms, n_vars, None)
+
+        result = equality_constrained_sqp(
+            fun_and_constr, grad_and_jac, lagr_hess, x0_dev, f0, g0_dev,
+            xp.asvec(constr.c_eq0), xp.matrix(constr.J_eq0), stop_criteria, state, xp,
+            **options)
+    else:                                                    # :532-544
+        if constr.n_ineq == 0:
+            warn("The problem only has equality constraints. The solver "
+                 "'equality_constrained_sqp' is a better choice for those situations.")
+
+        def lagr_hess_terms(x, v_eq, v_ineq):
+            return host_lagr_hess(xp.tohost(x), xp.tohost(v_eq), xp.tohost(v_ineq))
+
+        options.pop("barrier_tol", None)
+        result = tr_interior_point(
+            fun_dev, grad_dev, lagr_hess_terms, n_vars, constr.n_ineq, constr.n_eq,
+            constr_dev, jac_host, x0_dev, f0, g0_dev, xp.asvec(constr.c_ineq0),
+            constr.J_ineq0, xp.asvec(constr.c_eq0), constr.J_eq0, stop_criteria,
+            constr.enforce_feasibility, xtol, state, xp, **options)
+
+    result.execution_time = time.time() - start_time         # :548-564
+    result.method = method
+    result.message = TERMINATION_MESSAGES[result.status]
+    for k in _VECTOR_FIELDS:
+        if k in result:
+            result[k] = xp.tohost(result[k])
+    if "jac" in result and hasattr(result.jac, "to_scipy"):
+        result.jac = result.jac.to_scipy()
+    elif "jac" in result and hasattr(result.jac, "to_host"):
+        result.jac = result.jac.to_host()
+    if return_all:
+        for k in ("allvecs", "allmult", "allslack"):
+            if k in result:
+                result[k] = [xp.tohost(t) for t in result[k]]
+    if verbose >= 2:
+        print("")
+        print((7 * 3 + 10 * 4 + (8 if not interior else 22)) * "-")
+        print("")
+    if verbose >= 1:
+        print(result.message)
+        print("Number of iteractions: {0}, function evaluations: {1}, "
+              "CG iterations: {2}, optimality: {3:.2e}, "
+              "constraint violation: {4:.2e}, execution time: {5:4.2} s."
+              .format(result.niter, result.nfev, result.cg_niter, result.optimality,
+                      result.constr_violation, result.execution_time))
+    return result

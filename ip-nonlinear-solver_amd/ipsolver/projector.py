@@ -202,6 +202,17 @@ class NormalEquationProjector:
         return ops
 
 
+def orthogonality(A, g):
+    """``||A g|| / (||A||_F ||g||)`` (reference projections.py:23-55)."""
+    A = as_device_matrix(A)
+    g = g if isinstance(g, DVec) else DVec.from_host(g)
+    norm_g = dv.norm(g)
+    norm_A = A.frobenius_norm()
+    if norm_g == 0 or norm_A == 0:
+        return 0
+    return dv.norm(A.dot(g)) / (norm_A * norm_g)
+
+
 def as_device_matrix(A):
     """Upload a scipy sparse matrix / ndarray (device matrices pass through).
     An empty matrix is forced to the sparse representation like the

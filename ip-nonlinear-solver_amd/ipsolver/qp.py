@@ -129,7 +129,11 @@ def _full(n, value):
 def modified_dogleg(A, Y, b, trust_radius, lb, ub):
     """Reference: qp_subproblem.py:320-413."""
     b = _vec(b)
-    lb, ub = _vec(lb), _vec(ub)
+    lb, ub = _optvec(lb), _optvec(ub)       # None = no bound on that side
+    if (lb is None) != (ub is None):
+        n = A.shape[1]
+        lb = lb if lb is not None else _full(n, -_INF)
+        ub = ub if ub is not None else _full(n, _INF)
     newton = -Y.dot(b)
     if inside_box_boundaries(newton, lb, ub) and dv.norm(newton) <= trust_radius:
         return newton

@@ -1,0 +1,159 @@
+"""Byrd-Omojokun trust-region SQP outer loop over backend vectors.
+
+Control flow, constants, counters and accept/reject rules follow the
+reference's ``_large_scale_constrained/equality_constrained_sqp.py:18-252``
+line by line (cited below); every vector lives where the backend ``xp`` keeps
+it (HBM for ``backend_hip``) and only scalars come back to the host -- norms
+and dot products, a handful per outer iteration.  The trust-region subproblem
+(normal step, tangential step, projections) is delegated to ``xp``, i.e. to
+the HIP kernels.
+"""
+import numpy as np
+
+__all__ = ['equality_constrained_sqp']
+
+
+def equality_constrained_sqp(fun_and_constr, grad_and_jac, lagr_hess, x0, fun0, grad0,
+                             constr0, jac0, stop_criteria, state, xp,
+                             trust_lb=None, trust_ub=None, initial_penalty=1.0,
+                             initial_trust_radius=1.0, scaling=None, return_all=False,
+                             factorization_method=None):
+    PENALTY_FACTOR = 0.3               # :50-60
+    LARGE_REDUCTION_RATIO = 0.9
+    INTERMEDIARY_REDUCTION_RATIO = 0.3
+    SUFFICIENT_REDUCTION_RATIO = 1e-8
+    TRUST_ENLARGEMENT_FACTOR_L = 7.0
+    TRUST_ENLARGEMENT_FACTOR_S = 2.0
+    MAX_TRUST_REDUCTION = 0.5
+    MIN_TRUST_REDUCTION = 0.1
+    SOC_THRESHOLD = 0.1
+    TR_FACTOR = 0.8
+    BOX_FACTOR = 0.5
+
+    n = len(x0)
+    norm, dot = xp.norm, xp.dot
+    # No box at all (pure equality SQP): keep None so the kernels skip the
+    # bound passes; the reference materialises +-inf vectors (:65-68).
+    boxed = trust_lb is not None or trust_ub is not None
+    if boxed:
+        trust_lb = trust_lb if trust_lb is not None else xp.full(n, -np.inf)
+        trust_ub = trust_ub if trust_ub is not None else xp.full(n, np.inf)
+
+    def inf_norm_or_zero(b):
+        return xp.norm_inf(b) if len(b) > 0 else 0
+
+    x = xp.copy(x0)                                           # :71-83
+    trust_radius = initial_trust_radius
+    penalty = initial_penalty
+    f, c, b, A = fun0, grad0, constr0, jac0
+    S = scaling(x) if scaling is not None else None
+    Z, LS, Y = xp.projections(A, factorization_method)
+    v = -LS.dot(c)
+
+    state.optimality = xp.norm_inf(c + A.T.dot(v))            # :86-99
+    state.constr_violation = inf_norm_or_zero(b)
+    state.niter += 1
+    state.x, state.v, state.fun, state.grad = x, v, f, c
+    state.constr, state.jac = b, A
+    state.trust_radius, state.penalty = trust_radius, penalty
+    if return_all:
+        state.allvecs += [xp.copy(x)]
+        state.allmult += [xp.copy(v)]
+
+    compute_hess = True
+    while not stop_criteria(state):                           # :102
+        if compute_hess:
+            H = lagr_hess(x, v)
+            state.nhev += 1
+
+        # normal step (:113-116)
+        dn = xp.modified_dogleg(A, Y, b, TR_FACTOR * trust_radius,
+                                BOX_FACTOR * trust_lb if boxed else None,
+                                BOX_FACTOR * trust_ub if boxed else None)
+
+        # tangential step (:125-132)
+        c_t = H.dot(dn) + c
+        b_t = xp.zeros(len(b))
+        trust_radius_t = np.sqrt(trust_radius ** 2 - norm(dn) ** 2)
+        lb_t = trust_lb - dn if boxed else None
+        ub_t = trust_ub - dn if boxed else None
+        dt, info_cg = xp.projected_cg(H, c_t, Z, Y, b_t, trust_radius_t, lb_t, ub_t)
+
+        d = dn + dt                                           # :135-153
+        quadratic_model = 1 / 2 * dot(H.dot(d), d) + dot(c, d)
+        linearized_constr = A.dot(d) + b
+        norm_b = norm(b)
+        vpred = max(1e-16, norm_b - norm(linearized_constr))
+        previous_penalty = penalty
+        if quadratic_model > 0:
+            penalty = max(penalty, quadratic_model / ((1 - PENALTY_FACTOR) * vpred))
+        predicted_reduction = -quadratic_model + penalty * vpred
+
+        merit_function = f + penalty * norm_b                 # :156-169
+        x_next = x + (S.dot(d) if S is not None else d)
+        f_next, b_next = fun_and_constr(x_next)
+        state.nfev += 1
+        state.ncev += 1
+        actual_reduction = merit_function - (f_next + penalty * norm(b_next))
+        reduction_ratio = actual_reduction / predicted_reduction
+
+        norm_d = None
+        if reduction_ratio < SUFFICIENT_REDUCTION_RATIO and \
+                norm(dn) <= SOC_THRESHOLD * norm(dt):         # :172-193 second-order correction
+            y = -Y.dot(b_next)
+            if boxed:
+                _, t, intersect = xp.box_intersections(d, y, trust_lb, trust_ub)
+            else:
+                # an unbounded box never clips the segment (ta, tb = 0, 1) unless y == 0
+                intersect = norm(y) != 0
+                t = 1 if intersect else 0
+            step = d + t * y
+            x_soc = x + (S.dot(step) if S is not None else step)
+            f_soc, b_soc = fun_and_constr(x_soc)
+            state.nfev += 1
+            state.ncev += 1
+            ratio_soc = (merit_function - (f_soc + penalty * norm(b_soc))) / predicted_reduction
+            if intersect and ratio_soc >= SUFFICIENT_REDUCTION_RATIO:
+                x_next, f_next, b_next = x_soc, f_soc, b_soc
+                reduction_ratio = ratio_soc
+
+        if reduction_ratio >= LARGE_REDUCTION_RATIO:          # :196-212
+            trust_radius = max(TRUST_ENLARGEMENT_FACTOR_L * norm(d), trust_radius)
+        elif reduction_ratio >= INTERMEDIARY_REDUCTION_RATIO:
+            trust_radius = max(TRUST_ENLARGEMENT_FACTOR_S * norm(d), trust_radius)
+        elif reduction_ratio < SUFFICIENT_REDUCTION_RATIO:
+            trust_reduction = (1 - SUFFICIENT_REDUCTION_RATIO) / (1 - reduction_ratio)
+            new_trust_radius = trust_reduction * norm(d)
+            if new_trust_radius >= MAX_TRUST_REDUCTION * trust_radius:
+                trust_radius *= MAX_TRUST_REDUCTION
+            elif new_trust_radius >= MIN_TRUST_REDUCTION * trust_radius:
+                trust_radius = new_trust_radius
+            else:
+                trust_radius *= MIN_TRUST_REDUCTION
+
+        state.niter += 1                                      # :215-242
+        if reduction_ratio >= SUFFICIENT_REDUCTION_RATIO:
+            x = x_next
+            f, b = f_next, b_next
+            c, A = grad_and_jac(x)
+            S = scaling(x) if scaling is not None else None
+            state.ngev += 1
+            state.njev += 1
+            Z, LS, Y = xp.projections(A, None)                # method only honoured at entry (:225)
+            v = -LS.dot(c)
+            compute_hess = True
+            state.x, state.v, state.fun, state.grad = x, v, f, c
+            state.constr, state.jac = b, A
+            state.optimality = xp.norm_inf(c + A.T.dot(v))
+            state.constr_violation = inf_norm_or_zero(b)
+        else:
+            penalty = previous_penalty
+            compute_hess = False
+        state.trust_radius = trust_radius                     # :244-250
+        state.penalty = penalty
+        state.cg_niter += info_cg["niter"]
+        state.cg_info = info_cg
+        if return_all:
+            state.allvecs.append(xp.copy(x))
+            state.allmult.append(xp.copy(v))
+    return state
