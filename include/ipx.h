@@ -126,6 +126,9 @@ int ipx_dense_gemv(int64_t m, int64_t n, const double *A, int64_t lda, const dou
 int64_t ipx_dense_padded(int64_t m);
 int ipx_gram_f64_mfma(int64_t m, int64_t n, const double *A, int64_t lda, double *G,
                       void *stream);
+/* Same G from a CSR A (sparse Jacobian whose A A' is not narrow-banded). */
+int ipx_aat_dense(int64_t m, const int32_t *rowptr, const int32_t *colidx, const double *val,
+                  double *G, void *stream);
 int ipx_chol_factor(int64_t M, double *G, int *flag, void *stream);
 int ipx_chol_inverse(int64_t M, const double *G, double *X, void *stream);
 

@@ -101,6 +101,32 @@ k_gram_mfma(int m, int n, const double *__restrict__ A, int64_t lda, double *__r
   }
 }
 
+// G = A A' for a CSR A whose A A' is not narrow-banded: one lane per (i, j <= i),
+// merge join of the two sorted rows.  Same padded layout as k_gram_mfma.
+__global__ void __launch_bounds__(IPX_BLOCK)
+k_aat_dense(int m, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
+            const double *__restrict__ val, double *__restrict__ G, int M) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)M * M) return;
+  const int i = (int)(idx / M), j = (int)(idx % M);
+  if (j > i) return;
+  double s = 0.0;
+  if (i < m && j < m) {
+    int p = rowptr[i], pe = rowptr[i + 1];
+    int u = rowptr[j], ue = rowptr[j + 1];
+    while (p < pe && u < ue) {
+      const int cp = colidx[p], cu = colidx[u];
+      if (cp == cu) { s += val[p] * val[u]; ++p; ++u; }
+      else if (cp < cu) ++p;
+      else ++u;
+    }
+  } else {
+    s = (i == j) ? 1.0 : 0.0;
+  }
+  G[(int64_t)i * M + j] = s;
+  G[(int64_t)j * M + i] = s;
+}
+
 // ------------------------------------------------------- blocked Cholesky
 // Diagonal tile: G_kk = L_kk L_kk'.  One workgroup of NB x NB lanes.
 __global__ void __launch_bounds__(NB *NB)
@@ -280,6 +306,18 @@ int ipx_gram_f64_mfma(int64_t m, int64_t n, const double *A, int64_t lda, double
   const int tiles = M / 16;
   hipLaunchKernelGGL(k_gram_mfma, dim3(tiles, tiles), dim3(IPX_WAVE), 0, (hipStream_t)stream,
                      (int)m, (int)n, A, lda, G, M);
+  IPX_CHECK_LAUNCH();
+  return IPX_OK;
+}
+
+// G (M x M padded) = A A' for CSR A (dense fallback of the sparse path).
+int ipx_aat_dense(int64_t m, const int32_t *rowptr, const int32_t *colidx, const double *val,
+                  double *G, void *stream) {
+  if (m < 1 || !rowptr || !G) return IPX_EINVAL;
+  const int M = (int)ipx_dense_padded(m);
+  const int64_t tot = (int64_t)M * M;
+  hipLaunchKernelGGL(k_aat_dense, dim3((unsigned)((tot + IPX_BLOCK - 1) / IPX_BLOCK)),
+                     dim3(IPX_BLOCK), 0, (hipStream_t)stream, (int)m, rowptr, colidx, val, G, M);
   IPX_CHECK_LAUNCH();
   return IPX_OK;
 }

@@ -152,7 +152,8 @@ int ipx_csr_spmv(int64_t nrows, int64_t ncols, const int32_t *rowptr, const int3
                  const double *val, const int32_t *tiles, int32_t ntiles, const double *x,
                  double alpha, const double *diag, double beta, const double *yin, double *yout,
                  int square, double *red, double *ws, void *stream) {
-  if (nrows < 0 || ncols < 0 || !rowptr || !tiles || !x || !yout || ntiles < 0) return IPX_EINVAL;
+  if (nrows < 0 || ncols < 0 || ntiles < 0) return IPX_EINVAL;
+  if (nrows > 0 && (!rowptr || !tiles || !yout || (!x && ncols > 0))) return IPX_EINVAL;
   if (nrows == 0 || ntiles == 0) {
     if (red) (void)hipMemsetAsync(red, 0, 2 * sizeof(double), (hipStream_t)stream);
     return IPX_OK;

@@ -224,8 +224,8 @@ extern "C" {
 
 int ipx_axpby(int64_t n, double a, const double *x, double b, const double *y,
               double *out, void *stream) {
-  if (n < 0 || !x || !out) return IPX_EINVAL;
   if (n == 0) return IPX_OK;
+  if (n < 0 || !x || !out) return IPX_EINVAL;
   if (b == 0.0) y = nullptr;
   if ((n & 1) == 0 && aligned16(x) && aligned16(out) && (!y || aligned16(y))) {
     int grid = ipx_grid_for(n / 2, IPX_BLOCK * 2);
@@ -238,33 +238,39 @@ int ipx_axpby(int64_t n, double a, const double *x, double b, const double *y,
 }
 
 int ipx_mul(int64_t n, const double *x, const double *y, double *out, void *stream) {
+  if (n == 0) return IPX_OK;
   if (n < 0 || !x || !y || !out) return IPX_EINVAL;
   return launch_map(n, OpMul{x, y}, out, stream);
 }
 
 int ipx_fill(int64_t n, double value, double *out, void *stream) {
+  if (n == 0) return IPX_OK;
   if (n < 0 || !out) return IPX_EINVAL;
   return launch_map(n, OpFill{value}, out, stream);
 }
 
 int ipx_clip(int64_t n, const double *x, const double *lb, const double *ub, double *out,
              void *stream) {
+  if (n == 0) return IPX_OK;
   if (n < 0 || !x || !lb || !ub || !out) return IPX_EINVAL;
   return launch_map(n, OpClip{x, lb, ub}, out, stream);
 }
 
 int ipx_affine(int64_t n, double a, const double *x, double b, double *out, void *stream) {
+  if (n == 0) return IPX_OK;
   if (n < 0 || !x || !out) return IPX_EINVAL;
   return launch_map(n, OpAffine{a, b, x}, out, stream);
 }
 
 int ipx_gather(int64_t n, const double *x, const int32_t *idx, const double *sign,
                const double *shift, double *out, void *stream) {
+  if (n == 0) return IPX_OK;
   if (n < 0 || !x || !idx || !out) return IPX_EINVAL;
   return launch_map(n, OpGather{x, idx, sign, shift}, out, stream);
 }
 
 int ipx_scatter(int64_t n, const double *x, const int32_t *idx, double *out, void *stream) {
+  if (n == 0) return IPX_OK;
   if (n < 0 || !x || !idx || !out) return IPX_EINVAL;
   if (n == 0) return IPX_OK;
   hipLaunchKernelGGL(k_scatter, dim3(ipx_grid_for(n, IPX_BLOCK * 4)), dim3(IPX_BLOCK), 0,
@@ -274,47 +280,50 @@ int ipx_scatter(int64_t n, const double *x, const int32_t *idx, double *out, voi
 }
 
 int ipx_max_scalar(int64_t n, const double *x, double c, double *out, void *stream) {
+  if (n == 0) return IPX_OK;
   if (n < 0 || !x || !out) return IPX_EINVAL;
   return launch_map(n, OpMaxScalar{x, c}, out, stream);
 }
 
 int ipx_where_positive(int64_t n, const double *v, const double *a, double c, double *out,
                        void *stream) {
+  if (n == 0) return IPX_OK;
   if (n < 0 || !v || !a || !out) return IPX_EINVAL;
   return launch_map(n, OpWherePos{v, a, c}, out, stream);
 }
 
 int ipx_assign_negated_where(int64_t n, double *s, const double *mask, const double *c,
                              void *stream) {
+  if (n == 0) return IPX_OK;
   if (n < 0 || !s || !mask || !c) return IPX_EINVAL;
   return launch_map(n, OpNegMasked{s, mask, c}, s, stream);
 }
 
 int ipx_sum_log(int64_t n, const double *s, double *out, double *ws, void *stream) {
-  if (n < 0 || !s) return IPX_EINVAL;
+  if (n < 0 || (n > 0 && !s)) return IPX_EINVAL;
   return launch_reduce(n, RedSumLog{s}, out, ws, stream);
 }
 
 int ipx_dot(int64_t n, const double *x, const double *y, double *out, double *ws, void *stream) {
-  if (n < 0 || !x || !y) return IPX_EINVAL;
+  if (n < 0 || (n > 0 && (!x || !y))) return IPX_EINVAL;
   return launch_reduce(n, RedDot{x, y}, out, ws, stream);
 }
 
 int ipx_norms(int64_t n, const double *x, double *out, double *ws, void *stream) {
-  if (n < 0 || !x) return IPX_EINVAL;
+  if (n < 0 || (n > 0 && !x)) return IPX_EINVAL;
   return launch_reduce(n, RedNorms{x}, out, ws, stream);
 }
 
 int ipx_box_inside(int64_t n, const double *x, const double *lb, const double *ub, double *out,
                    double *ws, void *stream) {
-  if (n < 0 || !x || !lb || !ub) return IPX_EINVAL;
+  if (n < 0 || (n > 0 && (!x || !lb || !ub))) return IPX_EINVAL;
   return launch_reduce(n, RedBoxInside{x, lb, ub}, out, ws, stream);
 }
 
 int ipx_box_sphere_reduce(int64_t n, const double *z, const double *d, double dscale,
                           const double *lb, const double *ub, double *out, double *ws,
                           void *stream) {
-  if (n < 0 || !z || !d) return IPX_EINVAL;
+  if (n < 0 || (n > 0 && (!z || !d))) return IPX_EINVAL;
   return launch_reduce(n, RedBoxSphere{z, d, lb, ub, dscale}, out, ws, stream);
 }
 

@@ -78,7 +78,11 @@ class DeviceDense:
 
 
 class DenseNormalSolver:
-    """(A A')^-1 for a DeviceDense A: MFMA Gram, blocked Cholesky, explicit inverse."""
+    """(A A')^-1 through a dense Cholesky: MFMA Gram for a DeviceDense A, sparse
+    row products for a DeviceCSR A whose A A' is too wide for the banded
+    solver; blocked Cholesky; explicit inverse applied as one matvec."""
+
+    MAX_ROWS_FROM_SPARSE = 16384     # 2 GiB of G^-1
 
     def __init__(self, A):
         lib = _hip.load()
@@ -89,7 +93,11 @@ class DenseNormalSolver:
         G = torch.empty((M, M), dtype=_F64, device=dev)
         flag = torch.zeros(1, dtype=torch.int32, device=dev)
         st = stream_ptr()
-        _hip.call("ipx_gram_f64_mfma", m, n, _p(A.t), n, _p(G), st)
+        if isinstance(A, DeviceDense):
+            _hip.call("ipx_gram_f64_mfma", m, n, _p(A.t), n, _p(G), st)
+        else:
+            p = A.pattern
+            _hip.call("ipx_aat_dense", m, _p(p.indptr), _p(p.indices), _p(A.val), _p(G), st)
         _hip.call("ipx_chol_factor", M, _p(G), _p(flag), st)
         if int(flag.item()) != 0:
             raise np.linalg.LinAlgError("Singular Jacobian matrix: A A' is not positive definite")

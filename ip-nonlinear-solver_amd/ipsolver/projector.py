@@ -247,7 +247,17 @@ def projections(A, method=None, orth_tol=1e-12, max_refin=3, tol=1e-15):
     if m == 0:
         solver = None
     elif sparse:
-        solver = BandedNormalSolver(A)
+        if _symbolic_for(A.pattern).k <= _hip.load().ipx_banded_kmax():
+            solver = BandedNormalSolver(A)
+        elif m <= DenseNormalSolver.MAX_ROWS_FROM_SPARSE:
+            solver = DenseNormalSolver(A)       # wide band: dense Cholesky of A A' on the device
+        else:
+            raise NotImplementedError(
+                "A A' has half bandwidth %d after reordering and %d rows: beyond both the "
+                "banded (<= %d) and the dense (<= %d rows) device factorizations; there is "
+                "no host fallback" % (_symbolic_for(A.pattern).k, m,
+                                      _hip.load().ipx_banded_kmax(),
+                                      DenseNormalSolver.MAX_ROWS_FROM_SPARSE))
     else:
         solver = DenseNormalSolver(A)
     return NormalEquationProjector(A, solver, orth_tol, max_refin).operators()

@@ -1,0 +1,57 @@
+"""The C-ABI library loads on a machine without a GPU and exports every
+symbol include/ipx.h declares (no compute calls here)."""
+import ctypes
+import os
+import re
+
+from ipsolver import _hip
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "ipx.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ipx_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = ctypes.CDLL(_hip.LIB_PATH)
+    names = declared_symbols()
+    assert len(names) > 30
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_binding_covers_the_header():
+    bound = set(_hip.exported_symbols()) | set(_hip._EXTRA_ARGTYPES)
+    assert set(declared_symbols()) <= bound, sorted(set(declared_symbols()) - bound)
+
+
+def test_host_only_entry_points():
+    lib = _hip.load()
+    assert lib.ipx_version().decode().startswith("ipx")
+    assert lib.ipx_banded_kmax() >= 1
+    assert lib.ipx_cg_state_size() >= 14
+    assert lib.ipx_dense_padded(33) == 64
+    import numpy as np
+    rowptr = np.array([0, 3, 3, 5000, 5001], dtype=np.int32)
+    tiles = np.zeros(8, dtype=np.int32)
+    nt = lib.ipx_csr_tiles_host(4, rowptr.ctypes.data_as(ctypes.c_void_p), 2048, 1024,
+                                tiles.ctypes.data_as(ctypes.c_void_p), 8)
+    assert nt == 3 and list(tiles[:4]) == [0, 2, 3, 4]      # the long row gets its own tile
+
+
+def test_product_fails_loudly_without_gpu():
+    import pytest
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from ipsolver import device
+    with pytest.raises(_hip.IpxError, match="GPU-only"):
+        device.DVec.from_host([1.0, 2.0])
+    import ipsolver
+    import problems
+    p = problems.Maratos()
+    with pytest.raises(_hip.IpxError):
+        ipsolver.minimize_constrained(p.fun, p.x0, p.grad, p.hess, p.constraints(ipsolver))
