@@ -117,6 +117,16 @@ int ipx_csr_spmv(int64_t nrows, int64_t ncols, const int32_t *rowptr,
                  const double *diag, double beta, const double *yin,
                  double *yout, int square, double *red, double *ws, void *stream);
 
+/* Extended SpMV for the row-sharded CG: explicit row vector (x may carry halo
+ * entries), device stop flag, unfolded per-tile partials; and the fold. */
+int ipx_csr_spmv_ex(int64_t nrows, int64_t ncols, const int32_t *rowptr, const int32_t *colidx,
+                    const double *val, const int32_t *tiles, int32_t ntiles, const double *x,
+                    double alpha, const double *diag, double beta, const double *yin,
+                    double *yout, const double *xrow, double *partial, const double *guard,
+                    void *stream);
+int ipx_fold2(const double *partial, int32_t count, double *red, const double *guard,
+              void *stream);
+
 /* ---- dense Jacobian path (projections.py:175-233 QR; here Gram + Cholesky).
  * A is row-major with leading dimension lda.  ipx_dense_gemv mirrors
  * ipx_csr_spmv's fused epilogue.  G / X are M x M, M = ipx_dense_padded(m). */
@@ -144,6 +154,9 @@ int ipx_banded_factor(void *handle, const double *band, void *stream);
 /* Blocking: IPX_OK, or IPX_ENOTSPD when a pivot was <= 0 (rank-deficient A). */
 int ipx_banded_status(void *handle, void *stream);
 int ipx_banded_solve(void *handle, const double *w, double *x, void *stream);
+/* Same, skipped on the device when *guard != 0 (stop flag of the CG loops). */
+int ipx_banded_solve_guarded_c(void *handle, const double *w, double *x, const double *guard,
+                               void *stream);
 /* One-kernel-per-level variant of the same solve (cross-check / LDS fallback). */
 int ipx_banded_solve_multilaunch(void *handle, const double *w, double *x, void *stream);
 /* band of (P A)(P A)' for CSR A with row order perm (NULL = identity). */
@@ -177,6 +190,13 @@ int ipx_cg_iterate(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, void 
  * r-A'v, A g, step2, H p}.  For per-kernel attribution in bench.py. */
 int ipx_cg_iterate_timed(const ipx_cg_args *a, int32_t it_begin, int32_t it_end,
                          float *ms_out, void *stream);
+/* The two vector kernels on their own (explicit partial buffers / counts). */
+int ipx_cg_step1(int64_t n, double *state, int32_t it, const double *p1, int32_t np1,
+                 const double *x, const double *p, double *r, const double *Hp, const double *lb,
+                 const double *ub, double *part2, int32_t grid, void *stream);
+int ipx_cg_step2(int64_t n, double *state, int32_t it, int32_t mode, const double *p2,
+                 int32_t np2, const double *p3, int32_t np3, const double *p4, int32_t np4,
+                 double *x, double *p, const double *g, int32_t grid, void *stream);
 /* Finish iteration `it` after the host handled a stop-5/6 event. */
 int ipx_cg_resume(const ipx_cg_args *a, int32_t it, int32_t mode, void *stream);
 

@@ -966,6 +966,13 @@ int ipx_banded_solve_guarded(void *handle, const double *w, double *x, const dou
   return IPX_OK;
 }
 
+// ipx_banded_solve that turns into a no-op when *guard != 0 (device stop flag
+// of the CG loops).
+extern "C" int ipx_banded_solve_guarded_c(void *handle, const double *w, double *x,
+                                          const double *guard, void *stream) {
+  return ipx_banded_solve_guarded(handle, w, x, guard, (hipStream_t)stream);
+}
+
 // The original one-kernel-per-level sweep (kept for cross-checking the fast
 // path and as the fallback when a level does not fit in LDS).
 extern "C" int ipx_banded_solve_multilaunch(void *handle, const double *w, double *x,

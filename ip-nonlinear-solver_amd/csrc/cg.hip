@@ -140,6 +140,30 @@ static int launch_hp(const ipx_cg_args *a, const double *guard, hipStream_t st) 
   return ipx_spmv_launch(H, a->p, 1.0, a->H_diag, 0.0, nullptr, a->Hp, a->part1, guard, st);
 }
 
+// Single kernels of the loop with explicit partial buffers, for drivers that
+// interleave their own steps (the row-sharded CG puts RCCL all-reduces
+// between them: ipsolver/sharded.py).  Every rank sees the same reduced
+// scalars, so every rank takes the same branches.
+int ipx_cg_step1(int64_t n, double *state, int32_t it, const double *p1, int32_t np1,
+                 const double *x, const double *p, double *r, const double *Hp, const double *lb,
+                 const double *ub, double *part2, int32_t grid, void *stream) {
+  if (n < 0 || !state || !p1 || !part2 || grid < 1) return IPX_EINVAL;
+  hipLaunchKernelGGL(k_cg_step1, dim3(grid), dim3(VB), 0, (hipStream_t)stream, n, state, it & 1,
+                     p1, np1, x, p, r, Hp, lb, ub, part2);
+  IPX_CHECK_LAUNCH();
+  return IPX_OK;
+}
+
+int ipx_cg_step2(int64_t n, double *state, int32_t it, int32_t mode, const double *p2,
+                 int32_t np2, const double *p3, int32_t np3, const double *p4, int32_t np4,
+                 double *x, double *p, const double *g, int32_t grid, void *stream) {
+  if (n < 0 || !state || grid < 1) return IPX_EINVAL;
+  hipLaunchKernelGGL(k_cg_step2, dim3(grid), dim3(VB), 0, (hipStream_t)stream, n, state, it & 1,
+                     mode, p2, np2, p3, np3, p4, np4, x, p, g);
+  IPX_CHECK_LAUNCH();
+  return IPX_OK;
+}
+
 // Hp = H p with p'Hp partials (the tail of an iteration, also used once by
 // the host to prime the loop).
 int ipx_cg_hp(const ipx_cg_args *a, void *stream) {

@@ -103,6 +103,6 @@ struct ipx_csr_view {
 };
 int ipx_spmv_launch(const ipx_csr_view &A, const double *x, double alpha, const double *diag,
                     double beta, const double *yin, double *yout, double *partial,
-                    const double *guard, hipStream_t st);
+                    const double *guard, hipStream_t st, const double *xrow_override = nullptr);
 int ipx_banded_solve_guarded(void *handle, const double *w, double *x, const double *guard,
                              hipStream_t st);

@@ -26,7 +26,7 @@ __global__ void __launch_bounds__(IPX_BLOCK)
 k_csr_spmv(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
            const double *__restrict__ val, const int32_t *__restrict__ tiles,
            const double *__restrict__ x, double alpha, const double *__restrict__ diag,
-           double beta, const double *yin, double *yout, int square,
+           double beta, const double *yin, double *yout, const double *__restrict__ xrow,
            double *__restrict__ partial, int ntiles, const double *__restrict__ guard) {
   __shared__ double prod[TILE_NNZ];
   __shared__ double red_lds[IPX_BLOCK / IPX_WAVE];
@@ -47,12 +47,12 @@ k_csr_spmv(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colid
       double sum = 0.0;
       for (int k = a; k < b; ++k) sum += prod[k];
       double y = alpha * sum;
-      if (HAS_DIAG) y += diag[r] * x[r];
+      if (HAS_DIAG) y += diag[r] * xrow[r];
       if (HAS_YIN) y += beta * yin[r];
       yout[r] = y;
       if (REDUCE) {
         acc_yy += y * y;
-        if (square) acc_xy += x[r] * y;
+        if (xrow) acc_xy += xrow[r] * y;
       }
     }
   } else {
@@ -65,12 +65,12 @@ k_csr_spmv(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colid
       double sum = ipx_block_reduce<IPX_SUM>(part, red_lds);
       if (threadIdx.x == 0) {
         double y = alpha * sum;
-        if (HAS_DIAG) y += diag[r] * x[r];
+        if (HAS_DIAG) y += diag[r] * xrow[r];
         if (HAS_YIN) y += beta * yin[r];
         yout[r] = y;
         if (REDUCE) {
           acc_yy += y * y;
-          if (square) acc_xy += x[r] * y;
+          if (xrow) acc_xy += xrow[r] * y;
         }
       }
     }
@@ -94,10 +94,10 @@ k_spmv_fold(const double *partial, int ntiles, double *red) {
 template <bool D, bool Y, bool R>
 void launch(int ntiles, hipStream_t st, const int32_t *rowptr, const int32_t *colidx,
             const double *val, const int32_t *tiles, const double *x, double alpha,
-            const double *diag, double beta, const double *yin, double *yout, int square,
-            double *partial, const double *guard) {
+            const double *diag, double beta, const double *yin, double *yout,
+            const double *xrow, double *partial, const double *guard) {
   hipLaunchKernelGGL((k_csr_spmv<D, Y, R>), dim3(ntiles), dim3(IPX_BLOCK), 0, st, rowptr, colidx,
-                     val, tiles, x, alpha, diag, beta, yin, yout, square, partial, ntiles, guard);
+                     val, tiles, x, alpha, diag, beta, yin, yout, xrow, partial, ntiles, guard);
 }
 
 }  // namespace
@@ -105,16 +105,20 @@ void launch(int ntiles, hipStream_t st, const int32_t *rowptr, const int32_t *co
 // Internal launcher shared with cg.hip: per-tile partials go to `partial`
 // (2*ntiles doubles: sum y^2 then sum x*y) and are NOT folded; `guard` is an
 // optional device stop flag.
+// `xrow` = the vector whose row entries pair with the output rows (diag*xrow,
+// sum xrow*y): x itself for a square matrix, NULL for a rectangular one, or an
+// explicit pointer when x carries halo entries (row-sharded H, sharded.py).
 int ipx_spmv_launch(const ipx_csr_view &A, const double *x, double alpha, const double *diag,
                     double beta, const double *yin, double *yout, double *partial,
-                    const double *guard, hipStream_t st) {
+                    const double *guard, hipStream_t st, const double *xrow_override) {
   if (A.nrows == 0 || A.ntiles == 0) return IPX_OK;
   if (beta == 0.0) yin = nullptr;
   const bool D = diag != nullptr, Y = yin != nullptr, R = partial != nullptr;
-  const int square = A.nrows == A.ncols;
+  const double *xrow = xrow_override ? xrow_override : (A.nrows == A.ncols ? x : nullptr);
+  if (D && !xrow) return IPX_EINVAL;
 #define GO(d, y, r)                                                                       \
   launch<d, y, r>(A.ntiles, st, A.rowptr, A.colidx, A.val, A.tiles, x, alpha, diag, beta, \
-                  yin, yout, square, partial, guard)
+                  yin, yout, xrow, partial, guard)
   if (D) { if (Y) { if (R) GO(true, true, true); else GO(true, true, false); }
            else   { if (R) GO(true, false, true); else GO(true, false, false); } }
   else   { if (Y) { if (R) GO(false, true, true); else GO(false, true, false); }
@@ -162,9 +166,11 @@ int ipx_csr_spmv(int64_t nrows, int64_t ncols, const int32_t *rowptr, const int3
   if (beta == 0.0) yin = nullptr;
   hipStream_t st = (hipStream_t)stream;
   const bool D = diag != nullptr, Y = yin != nullptr, R = red != nullptr;
+  const double *xrow = square ? x : nullptr;
+  if (D && !xrow) return IPX_EINVAL;
 #define GO(d, y, r)                                                                          \
   launch<d, y, r>(ntiles, st, rowptr, colidx, val, tiles, x, alpha, diag, beta, yin, yout, \
-                  square, ws, nullptr)
+                  xrow, ws, nullptr)
   if (D) { if (Y) { if (R) GO(true, true, true); else GO(true, true, false); }
            else   { if (R) GO(true, false, true); else GO(true, false, false); } }
   else   { if (Y) { if (R) GO(false, true, true); else GO(false, true, false); }
@@ -175,6 +181,37 @@ int ipx_csr_spmv(int64_t nrows, int64_t ncols, const int32_t *rowptr, const int3
     hipLaunchKernelGGL(k_spmv_fold, dim3(1), dim3(IPX_BLOCK), 0, st, ws, ntiles, red);
     IPX_CHECK_LAUNCH();
   }
+  return IPX_OK;
+}
+
+// Extended form used by the row-sharded CG (ipsolver/sharded.py): explicit row
+// vector `xrow` (may be NULL), device stop flag `guard` (may be NULL), per-tile
+// partials written to `partial` (2*ntiles doubles, NOT folded; may be NULL).
+int ipx_csr_spmv_ex(int64_t nrows, int64_t ncols, const int32_t *rowptr, const int32_t *colidx,
+                    const double *val, const int32_t *tiles, int32_t ntiles, const double *x,
+                    double alpha, const double *diag, double beta, const double *yin,
+                    double *yout, const double *xrow, double *partial, const double *guard,
+                    void *stream) {
+  if (nrows < 0 || ncols < 0 || ntiles < 0) return IPX_EINVAL;
+  if (nrows > 0 && (!rowptr || !tiles || !yout || (!x && ncols > 0))) return IPX_EINVAL;
+  ipx_csr_view A{(int)nrows, (int)ncols, rowptr, colidx, val, tiles, ntiles};
+  // rectangular matrices pair rows with xrow only when the caller says so
+  const double *xr = xrow;
+  if (!xr && nrows == ncols) xr = x;
+  if (!xr && !diag) {
+    // force "no row pairing" even for a square shape: handled by passing x when square
+  }
+  return ipx_spmv_launch(A, x, alpha, diag, beta, yin, yout, partial, guard,
+                         (hipStream_t)stream, xrow);
+}
+
+// red[0] = sum partial[0..count), red[1] = sum partial[count..2count), fixed order.
+int ipx_fold2(const double *partial, int32_t count, double *red, const double *guard,
+              void *stream) {
+  if (!partial || !red || count < 0) return IPX_EINVAL;
+  hipLaunchKernelGGL(k_spmv_fold, dim3(1), dim3(IPX_BLOCK), 0, (hipStream_t)stream, partial, count,
+                     red);
+  IPX_CHECK_LAUNCH();
   return IPX_OK;
 }
 

@@ -40,6 +40,10 @@ _SIGNATURES = {
     "ipx_csr_tiles_host": [_I64, _P, _I32, _I32, _P, _I64],
     "ipx_csr_spmv": [_I64, _I64, _P, _P, _P, _P, _I32, _P, _F64, _P, _F64, _P, _P,
                      _c.c_int, _P, _P, _P],
+    "ipx_csr_spmv_ex": [_I64, _I64, _P, _P, _P, _P, _I32, _P, _F64, _P, _F64, _P, _P, _P, _P, _P, _P],
+    "ipx_fold2": [_P, _I32, _P, _P, _P],
+    "ipx_cg_step1": [_I64, _P, _I32, _P, _I32, _P, _P, _P, _P, _P, _P, _P, _I32, _P],
+    "ipx_cg_step2": [_I64, _P, _I32, _I32, _P, _I32, _P, _I32, _P, _I32, _P, _P, _P, _I32, _P],
     "ipx_cg_state_size": [],
     "ipx_cg_vec_grid": [_I64],
     "ipx_cg_hp": [_P, _P],
@@ -52,6 +56,7 @@ _SIGNATURES = {
     "ipx_banded_status": [_P, _P],
     "ipx_banded_solve": [_P, _P, _P, _P],
     "ipx_banded_solve_multilaunch": [_P, _P, _P, _P],
+    "ipx_banded_solve_guarded_c": [_P, _P, _P, _P, _P],
     "ipx_aat_band": [_I64, _I32, _P, _P, _P, _P, _P, _P],
 }
 _RESTYPES = {"ipx_version": _c.c_char_p, "ipx_last_error": _c.c_char_p,

@@ -1,0 +1,338 @@
+"""Row-sharded projected CG across the GPUs of one node (BASELINE config 4).
+
+One process per GPU (``torch.distributed``; backend "nccl" = RCCL over xGMI).
+Partition:
+
+* z-space vectors x, p, r, H p are split into contiguous variable blocks, one per
+  rank; rank g owns the columns ``A[:, n0:n1]`` of the Jacobian, the matching
+  rows of ``A'`` and the rows ``H[n0:n1, :]`` of the Hessian (its few
+  off-block columns are served from a halo of p exchanged with the two
+  neighbours);
+* constraint-space vectors (length m = n/10) and the banded ``(A A')^-1``
+  factorization are replicated: ``w = A r`` is formed as per-rank partial
+  products summed by ONE all-reduce (0.8 MB at m = 1e5), after which every rank
+  solves the same banded system and applies its own rows of ``A'``.
+
+Collectives per CG iteration: all-reduce of ``p'Hp`` (2 doubles), of the
+partial ``A r`` and ``A g`` vectors, of the packed ``||x+ap||^2, #violations,
+||g||^2`` (4 doubles), and a halo exchange of p.  The reduced scalars are
+bit-identical on every rank, so the device-side branches of ``csrc/cg.hip``
+take the same way everywhere and no rank needs the host.
+
+The orchestration below is engine-agnostic: ``HipEngine`` runs the ipx
+kernels; the test-suite runs the same code over gloo with the oracle's numpy
+engine (tests/test_sharded_gloo.py).
+"""
+import ctypes
+
+import numpy as np
+import scipy.sparse as sps
+import torch
+import torch.distributed as dist
+
+ST_RTG0, ST_RTG1, ST_TOL, ST_RADIUS, ST_ALPHA, ST_STOP, ST_NITER, ST_BETA = range(8)
+ST_PTHP, ST_ORTH_RHS, ST_XNORM2, ST_VIOL, ST_ORTH, ST_IT_DONE = 8, 9, 10, 11, 12, 13
+STATE_SIZE = 16
+
+
+def block_range(n, world, rank):
+    return (rank * n) // world, ((rank + 1) * n) // world
+
+
+def half_bandwidth(M):
+    coo = sps.coo_matrix(M)
+    return int(np.max(np.abs(coo.row - coo.col))) if coo.nnz else 0
+
+
+class ShardedProjectedCG:
+    """Projected CG for ``min 1/2 x'Hx + c'x  s.t.  A x = 0, ||x|| <= radius`` with
+    the variables sharded over ``dist``'s ranks.  ``H`` (scipy CSR, banded),
+    ``hdiag`` (optional diagonal term) and ``A`` (scipy CSR) are given in full
+    on every rank; each rank keeps its block."""
+
+    def __init__(self, engine, A, H, hdiag=None, group=None):
+        self.eng = eng = engine
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        A = sps.csr_matrix(A)
+        H = sps.csr_matrix(H)
+        self.m, self.n = A.shape
+        self.n0, self.n1 = block_range(self.n, self.world, self.rank)
+        n0, n1 = self.n0, self.n1
+        self.nloc = n1 - n0
+        # halo of p needed by the rows of H owned here
+        self.h = half_bandwidth(H)
+        if self.world > 1 and self.h > min(block_range(self.n, self.world, r)[1]
+                                           - block_range(self.n, self.world, r)[0]
+                                           for r in range(self.world)):
+            raise NotImplementedError("Hessian bandwidth exceeds a rank's block")
+        self.hl = self.h if self.rank > 0 else 0
+        self.hr = self.h if self.rank < self.world - 1 else 0
+        A_cols = sps.csr_matrix(A[:, n0:n1])
+        self.A_cols = eng.csr(A_cols)
+        self.At_rows = eng.csr(sps.csr_matrix(A_cols.T))
+        self.H_rows = eng.csr(sps.csr_matrix(H[n0:n1, n0 - self.hl:n1 + self.hr]))
+        self.hdiag = eng.upload(np.asarray(hdiag)[n0:n1]) if hdiag is not None else None
+        self.solver = eng.banded(A)                 # replicated (A A')^-1
+        self.norm_A = float(np.sqrt((A.data ** 2).sum()))
+        # buffers
+        self.x, self.r, self.Hp = (eng.zeros(self.nloc) for _ in range(3))
+        self.p_ext = eng.zeros(self.hl + self.nloc + self.hr)
+        self.p = eng.view(self.p_ext, self.hl, self.hl + self.nloc)
+        self.w, self.v, self.t = (eng.zeros(self.m) for _ in range(3))
+        self.state = eng.zeros(STATE_SIZE)
+        self.s1, self.s23, self.s4 = eng.zeros(2), eng.zeros(4), eng.zeros(2)
+        self.part1 = eng.zeros(2 * eng.ntiles(self.H_rows))
+        self.part3 = eng.zeros(2 * eng.ntiles(self.At_rows))
+        self.grid = eng.vec_grid(self.nloc)
+        self.part2 = eng.zeros(2 * self.grid)
+        self.halo_send = [eng.zeros(max(self.h, 1)), eng.zeros(max(self.h, 1))]
+
+    # ---- collectives ---------------------------------------------------------
+    def _staged(self, t):
+        """gloo cannot move CUDA tensors point-to-point; in that (test-only)
+        combination go through a host copy.  RCCL works on device memory."""
+        return t.is_cuda and dist.get_backend(self.group) != "nccl"
+
+    def _allreduce(self, buf):
+        if self.world == 1:
+            return
+        t = self.eng.tensor(buf)
+        if self._staged(t):
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
+    def _halo_exchange(self):
+        """p_ext halos <- neighbours' boundary entries of p."""
+        if self.world == 1 or self.h == 0:
+            return
+        h = self.h
+        pt = self.eng.tensor(self.p_ext)
+        lo, hi = self.hl, self.hl + self.nloc
+        staged = self._staged(pt)
+        ops, landing = [], []
+
+        def link(peer, send_slice, recv_slice):
+            out = pt[send_slice].contiguous()
+            if staged:
+                out = out.cpu()
+                inbox = torch.empty(h, dtype=torch.float64)
+                landing.append((recv_slice, inbox))
+            else:
+                inbox = pt[recv_slice]
+            ops.append(dist.P2POp(dist.isend, out, peer, group=self.group))
+            ops.append(dist.P2POp(dist.irecv, inbox, peer, group=self.group))
+
+        if self.rank > 0:
+            link(self.rank - 1, slice(lo, lo + h), slice(0, h))
+        if self.rank < self.world - 1:
+            link(self.rank + 1, slice(hi - h, hi), slice(hi, hi + h))
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        for recv_slice, inbox in landing:
+            pt[recv_slice].copy_(inbox)
+
+    # ---- pieces ---------------------------------------------------------------
+    def _project(self, y, out):
+        """out = Z y = y - A'(AA')^-1 A y on the local block (one all-reduce)."""
+        eng = self.eng
+        eng.spmv(self.A_cols, y, self.w)
+        self._allreduce(self.w)
+        eng.solve(self.solver, self.w, self.v)
+        eng.spmv(self.At_rows, self.v, out, alpha=-1.0, beta=1.0, yin=y)
+
+    def _hp(self, guard=True):
+        """Hp = H p on the local rows, p'Hp partials in part1."""
+        self._halo_exchange()
+        self.eng.spmv(self.H_rows, self.p_ext, self.Hp, diag=self.hdiag, xrow=self.p,
+                      partial=self.part1, guard=self.state if guard else None)
+
+    def prime(self, c, tol, trust_radius, orth_tol=1e-12):
+        """Initial point of qp_subproblem.py:502-512 for b = 0: x = 0,
+        r = Z c, g = Z r, p = -g, Hp = H p."""
+        eng = self.eng
+        c_loc = eng.upload(np.asarray(c)[self.n0:self.n1])
+        eng.fill(self.x, 0.0)
+        self._project(c_loc, self.r)
+        g = eng.zeros(self.nloc)
+        self._project(self.r, g)
+        eng.axpby(-1.0, g, 0.0, None, self.p)
+        eng.sumsq(g, self.s4)
+        self._allreduce(self.s4)
+        rt_g = float(eng.download(self.s4)[0])
+        if tol is None:
+            tol = max(min(0.01 * np.sqrt(rt_g), 0.1 * rt_g), 1e-25)
+        init = np.zeros(STATE_SIZE)
+        init[ST_RTG0], init[ST_TOL], init[ST_RADIUS] = rt_g, tol, trust_radius
+        init[ST_ORTH_RHS] = orth_tol * self.norm_A
+        eng.assign(self.state, init)
+        self._hp(guard=False)
+        return rt_g
+
+    def iterate(self, it_begin, it_end):
+        """Enqueue iterations [it_begin, it_end); no host synchronisation."""
+        eng = self.eng
+        st = self.state
+        for it in range(it_begin, it_end):
+            eng.fold2(self.part1, eng.ntiles(self.H_rows), self.s1)
+            self._allreduce(self.s1)                                   # p'Hp
+            eng.step1(st, it, self.s1, 1, self.x, self.p, self.r, self.Hp, self.part2,
+                      self.grid)
+            eng.spmv(self.A_cols, self.r, self.w, guard=st)            # partial A r
+            self._allreduce(self.w)
+            eng.solve(self.solver, self.w, self.v, guard=st)
+            eng.spmv(self.At_rows, self.v, self.r, alpha=-1.0, beta=1.0, yin=self.r,
+                     partial=self.part3, guard=st)                      # g = r - A'v
+            eng.spmv(self.A_cols, self.r, self.t, guard=st)            # partial A g
+            self._allreduce(self.t)
+            eng.sumsq(self.t, self.s4)                                  # ||A g||^2 (replicated)
+            eng.fold2(self.part2, self.grid, eng.view(self.s23, 0, 2))
+            eng.fold2(self.part3, eng.ntiles(self.At_rows), eng.view(self.s23, 2, 4))
+            self._allreduce(self.s23)            # ||x+ap||^2, #viol, ||g||^2, (unused)
+            eng.step2(st, it, 0, self.s23, 1, eng.view(self.s23, 2, 4), 1, self.s4, 1,
+                      self.x, self.p, self.r, self.grid)
+            self._hp()
+
+    def read_state(self):
+        return self.eng.download(self.state)
+
+    def gather_x(self):
+        """Full solution vector on every rank (host).  Blocks may differ by one
+        row, so every rank contributes a block padded to the longest."""
+        x_loc = np.ascontiguousarray(self.eng.download(self.x))
+        if self.world == 1:
+            return x_loc
+        sizes = [block_range(self.n, self.world, r)[1] - block_range(self.n, self.world, r)[0]
+                 for r in range(self.world)]
+        pad = np.zeros(max(sizes))
+        pad[:len(x_loc)] = x_loc
+        mine = torch.from_numpy(pad)
+        on_gpu = dist.get_backend(self.group) == "nccl"
+        if on_gpu:
+            mine = mine.to(torch.device("cuda", torch.cuda.current_device()))
+        parts = [torch.empty_like(mine) for _ in range(self.world)]
+        dist.all_gather(parts, mine, group=self.group)
+        return np.concatenate([p.cpu().numpy()[:k] for p, k in zip(parts, sizes)])
+
+    def solve(self, c, tol=None, trust_radius=np.inf, max_iter=None, batch=8):
+        """Run to a stop condition; returns (x_full, info) like projected_cg
+        (stop codes 1 iteration limit, 2 boundary, 4 tolerance)."""
+        self.prime(c, tol, trust_radius)
+        if max_iter is None:
+            max_iter = self.n - self.m
+        max_iter = min(max_iter, self.n - self.m)
+        it, stop_cond = 0, 1
+        while it < max_iter:
+            end = min(max_iter, it + batch)
+            self.iterate(it, end)
+            s = self.read_state()
+            stop = int(s[ST_STOP])
+            if stop == 0:
+                it = end
+                continue
+            if stop == 4:
+                stop_cond = 4
+                break
+            raise NotImplementedError(
+                "sharded projected CG: stop code %d (trust-region boundary, negative "
+                "curvature, box or refinement events) is handled by the single-GPU path "
+                "only in this round" % stop)
+        s = self.read_state()
+        return self.gather_x(), {'niter': int(s[ST_NITER]), 'stop_cond': stop_cond,
+                                 'hits_boundary': False}
+
+
+class HipEngine:
+    """Local compute of the sharded loop on one GPU: ipx kernels."""
+
+    def __init__(self):
+        from . import _hip, device
+        self._hip, self.dv = _hip, device
+        self.lib = _hip.load()
+        self.ctx = device.ctx()
+
+    def _st(self):
+        return self.dv.stream_ptr()
+
+    @staticmethod
+    def _ptr(t):
+        return ctypes.c_void_p(t.data_ptr()) if t is not None and t.numel() > 0 else None
+
+    def zeros(self, n):
+        return torch.zeros(int(n), dtype=torch.float64, device=self.ctx.device)
+
+    def upload(self, a):
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(self.ctx.device)
+
+    def download(self, buf):
+        return buf.cpu().numpy()
+
+    def assign(self, buf, host):
+        buf.copy_(torch.from_numpy(np.ascontiguousarray(host, dtype=np.float64)))
+
+    def tensor(self, buf):
+        return buf
+
+    def view(self, buf, a, b):
+        return buf[a:b]
+
+    def fill(self, buf, value):
+        self._hip.call("ipx_fill", buf.numel(), float(value), self._ptr(buf), self._st())
+
+    def axpby(self, a, x, b, y, out):
+        self._hip.call("ipx_axpby", x.numel(), float(a), self._ptr(x), float(b), self._ptr(y),
+                       self._ptr(out), self._st())
+
+    def csr(self, M):
+        return self.dv.DeviceCSR.from_scipy(M)
+
+    def ntiles(self, M):
+        return M.pattern.ntiles
+
+    def vec_grid(self, n):
+        return int(self.lib.ipx_cg_vec_grid(max(int(n), 1)))
+
+    def banded(self, A):
+        from . import projector
+        return projector.BandedNormalSolver(self.dv.DeviceCSR.from_scipy(A))
+
+    def solve(self, solver, w, v, guard=None):
+        if solver.perm is not None:
+            raise NotImplementedError("sharded CG needs A A' banded in its natural row order")
+        if guard is None:
+            self._hip.call("ipx_banded_solve", ctypes.c_void_p(solver.handle), self._ptr(w),
+                           self._ptr(v), self._st())
+        else:
+            self._hip.call("ipx_banded_solve_guarded_c", ctypes.c_void_p(solver.handle),
+                           self._ptr(w), self._ptr(v), self._ptr(guard[ST_STOP:]), self._st())
+
+    def spmv(self, M, x, out, alpha=1.0, diag=None, beta=0.0, yin=None, xrow=None, partial=None,
+             guard=None):
+        p = M.pattern
+        self._hip.call("ipx_csr_spmv_ex", p.shape[0], p.shape[1], self._ptr(p.indptr),
+                       self._ptr(p.indices), self._ptr(M.val), self._ptr(p.tiles), p.ntiles,
+                       self._ptr(x), float(alpha), self._ptr(diag), float(beta), self._ptr(yin),
+                       self._ptr(out), self._ptr(xrow), self._ptr(partial),
+                       self._ptr(guard[ST_STOP:]) if guard is not None else None, self._st())
+
+    def fold2(self, partial, count, out2):
+        self._hip.call("ipx_fold2", self._ptr(partial), int(count), self._ptr(out2), None,
+                       self._st())
+
+    def sumsq(self, x, out2):
+        self._hip.call("ipx_norms", x.numel(), self._ptr(x), self._ptr(out2), self._ptr(self.ctx.ws),
+                       self._st())
+
+    def step1(self, state, it, p1, np1, x, p, r, Hp, part2, grid):
+        self._hip.call("ipx_cg_step1", x.numel(), self._ptr(state), int(it), self._ptr(p1),
+                       int(np1), self._ptr(x), self._ptr(p), self._ptr(r), self._ptr(Hp), None,
+                       None, self._ptr(part2), int(grid), self._st())
+
+    def step2(self, state, it, mode, p2, np2, p3, np3, p4, np4, x, p, g, grid):
+        self._hip.call("ipx_cg_step2", x.numel(), self._ptr(state), int(it), int(mode),
+                       self._ptr(p2), int(np2), self._ptr(p3), int(np3), self._ptr(p4), int(np4),
+                       self._ptr(x), self._ptr(p), self._ptr(g), int(grid), self._st())
