@@ -108,6 +108,7 @@ int ipx_box_sphere_reduce(int64_t n, const double *z, const double *d, double ds
  * (xrow = x when the matrix is square, used for p'Hp; pass square=0 otherwise).
  */
 #define IPX_SPMV_TILE_NNZ 2048
+#define IPX_SPMV_TILE_ROWS 1024   /* max rows per tile the fast path takes */
 int ipx_csr_tiles_host(int64_t nrows, const int32_t *rowptr_host, int32_t tile_nnz,
                        int32_t max_rows, int32_t *tiles_out, int64_t cap);
 int ipx_csr_spmv(int64_t nrows, int64_t ncols, const int32_t *rowptr,
@@ -185,6 +186,10 @@ int ipx_cg_vec_grid(int64_t n);
 int ipx_cg_hp(const ipx_cg_args *a, void *stream);
 /* Enqueue iterations [it_begin, it_end); never synchronises. */
 int ipx_cg_iterate(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, void *stream);
+/* hipGraph replay: capture two iterations once, replay them npairs times. */
+void *ipx_cg_graph_create(const ipx_cg_args *a, void *stream);
+int ipx_cg_graph_launch(void *graph, int32_t npairs, void *stream);
+void ipx_cg_graph_destroy(void *graph);
 /* Same launches with HIP events around each kernel class; synchronises once at
  * the end and returns per-class totals in ms_out[0..6] = {step1, A r, banded,
  * r-A'v, A g, step2, H p}.  For per-kernel attribution in bench.py. */

@@ -18,7 +18,7 @@
 //   spmv   w = A r
 //   banded v = (AA')^-1 w
 //   spmv   r = r - A'v  (= g_next; the reference sets r = g, :632), ||g||^2 partials
-//   spmv   t = A g, ||t||^2 partials                     (orthogonality, projections.py:52)
+//   resid  ||A g||^2 = ||w - (AA')v||^2 partials          (orthogonality, projections.py:52)
 //   step2  checks: ||x_next|| >= radius -> stop 2; box violated -> stop 5 (host
 //          finishes the iteration); orthogonality > tol -> stop 6 (host refines);
 //          else beta = ||g||^2/rt_g;  x += alpha p;  p = beta p - g
@@ -42,43 +42,69 @@ namespace {
 
 constexpr int VB = IPX_BLOCK;
 
+constexpr int VU = 4;        // elements per lane per trip, loads issued together
+
 __global__ void __launch_bounds__(VB)
 k_cg_step1(int64_t n, double *st, int parity, const double *__restrict__ p1, int np1,
            const double *__restrict__ x, const double *__restrict__ p, double *r,
            const double *__restrict__ Hp, const double *__restrict__ lb,
-           const double *__restrict__ ub, double *__restrict__ p2) {
+           const double *__restrict__ ub, double *__restrict__ p2, int nchunks) {
   __shared__ double lds[VB / IPX_WAVE];
+  // chunk c of nchunks: a contiguous run of elements, owned by a fixed XCD
+  const int c = ipx_xcd_item(blockIdx.x, nchunks);
+  if (c < 0) return;
+  const int64_t len = (n + nchunks - 1) / nchunks;
+  const int64_t lo_i = (int64_t)c * len, hi_i = min(n, lo_i + len);
+  int64_t i0 = lo_i + threadIdx.x;
+  // First trip's operands are requested before the prologue: the streaming
+  // loads overlap the scalar fold instead of queueing behind it.
+  double xv[VU], pv[VU], rv[VU], hv[VU], lo[VU], hi[VU];
+#pragma unroll
+  for (int u = 0; u < VU; ++u) {
+    const int64_t i = min(i0 + u * VB, n - 1);
+    xv[u] = x[i]; pv[u] = p[i]; rv[u] = r[i]; hv[u] = Hp[i];
+    if (lb) { lo[u] = lb[i]; hi[u] = ub[i]; }
+  }
   if (st[ST_STOP] != 0.0) return;
+  const bool lead = c == 0 && threadIdx.x == 0;
   // p'Hp from the partials of the SpMV that produced Hp (second half: x.y sums)
   const double ptHp = ipx_sum_partials<IPX_SUM>(p1 + np1, np1, lds);
   const double rtg = st[parity ? ST_RTG1 : ST_RTG0];
   const double tol = st[ST_TOL];
   if (rtg < tol) {                                   // qp_subproblem.py:551
-    if (blockIdx.x == 0 && threadIdx.x == 0) st[ST_STOP] = 4.0;
+    if (lead) st[ST_STOP] = 4.0;
     return;
   }
   if (ptHp <= 0.0) {                                 // :558
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-      st[ST_NITER] += 1.0; st[ST_PTHP] = ptHp; st[ST_STOP] = 3.0;
-    }
+    if (lead) { st[ST_NITER] += 1.0; st[ST_PTHP] = ptHp; st[ST_STOP] = 3.0; }
     return;
   }
   const double alpha = rtg / ptHp;                   // :579
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    st[ST_NITER] += 1.0; st[ST_PTHP] = ptHp; st[ST_ALPHA] = alpha;
-  }
+  if (lead) { st[ST_NITER] += 1.0; st[ST_PTHP] = ptHp; st[ST_ALPHA] = alpha; }
   double sx = 0.0, viol = 0.0;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const double pi = p[i];
-    const double xn = x[i] + alpha * pi;             // :580 (not stored)
-    sx += xn * xn;
-    if (lb) viol += ((lb[i] <= xn) && (xn <= ub[i])) ? 0.0 : 1.0;   // :599
-    r[i] = r[i] + alpha * Hp[i];                     // :622
+  while (true) {
+#pragma unroll
+    for (int u = 0; u < VU; ++u) {
+      const int64_t i = i0 + u * VB;
+      if (i < hi_i) {
+        const double xn = xv[u] + alpha * pv[u];     // :580 (not stored)
+        sx += xn * xn;
+        if (lb) viol += ((lo[u] <= xn) && (xn <= hi[u])) ? 0.0 : 1.0;   // :599
+        r[i] = rv[u] + alpha * hv[u];                // :622
+      }
+    }
+    i0 += VU * VB;
+    if (i0 >= hi_i) break;
+#pragma unroll
+    for (int u = 0; u < VU; ++u) {
+      const int64_t i = min(i0 + u * VB, n - 1);
+      xv[u] = x[i]; pv[u] = p[i]; rv[u] = r[i]; hv[u] = Hp[i];
+      if (lb) { lo[u] = lb[i]; hi[u] = ub[i]; }
+    }
   }
   const double a = ipx_block_reduce<IPX_SUM>(sx, lds);
   const double b = ipx_block_reduce<IPX_SUM>(viol, lds);
-  if (threadIdx.x == 0) { p2[blockIdx.x] = a; p2[gridDim.x + blockIdx.x] = b; }
+  if (threadIdx.x == 0) { p2[c] = a; p2[nchunks + c] = b; }
 }
 
 // mode bit0: skip the radius / box checks (host already handled them)
@@ -86,13 +112,28 @@ k_cg_step1(int64_t n, double *st, int parity, const double *__restrict__ p1, int
 __global__ void __launch_bounds__(VB)
 k_cg_step2(int64_t n, double *st, int parity, int mode, const double *__restrict__ p2, int np2,
            const double *__restrict__ p3, int np3, const double *__restrict__ p4, int np4,
-           double *x, double *p, const double *__restrict__ g) {
-  __shared__ double lds[VB / IPX_WAVE];
+           double *x, double *p, const double *__restrict__ g, int nchunks) {
+  __shared__ double lds[4 * (VB / IPX_WAVE)];
+  const int c = ipx_xcd_item(blockIdx.x, nchunks);   // same element -> XCD map as step1
+  if (c < 0) return;
+  const int64_t len = (n + nchunks - 1) / nchunks;
+  const int64_t lo_i = (int64_t)c * len, hi_i = min(n, lo_i + len);
+  int64_t i0 = lo_i + threadIdx.x;
+  double xv[VU], pv[VU], gv[VU];
+#pragma unroll
+  for (int u = 0; u < VU; ++u) {
+    const int64_t i = min(i0 + u * VB, n - 1);
+    xv[u] = x[i]; pv[u] = p[i]; gv[u] = g[i];
+  }
   if (st[ST_STOP] != 0.0) return;
-  const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
+  const bool lead = c == 0 && threadIdx.x == 0;
+  // ||x+ap||^2, #violations, ||g||^2, ||A g||^2 folded together (one latency)
+  const double *const parts[4] = {p2, p2 + np2, p3, p4};
+  const int counts[4] = {(mode & 1) ? 0 : np2, (mode & 1) ? 0 : np2, np3, (mode & 2) ? 0 : np4};
+  double red[4];
+  ipx_sum_partials_multi<4>(parts, counts, lds, red);
   if (!(mode & 1)) {
-    const double xn2 = ipx_sum_partials<IPX_SUM>(p2, np2, lds);
-    const double viol = ipx_sum_partials<IPX_SUM>(p2 + np2, np2, lds);
+    const double xn2 = red[0], viol = red[1];
     if (sqrt(xn2) >= st[ST_RADIUS]) {                // :583
       if (lead) { st[ST_XNORM2] = xn2; st[ST_STOP] = 2.0; }
       return;
@@ -102,9 +143,9 @@ k_cg_step2(int64_t n, double *st, int parity, int mode, const double *__restrict
       return;
     }
   }
-  const double gg = ipx_sum_partials<IPX_SUM>(p3, np3, lds);     // ||g_next||^2
+  const double gg = red[2];                          // ||g_next||^2
   if (!(mode & 2)) {
-    const double tt = ipx_sum_partials<IPX_SUM>(p4, np4, lds);   // ||A g_next||^2
+    const double tt = red[3];                        // ||A g_next||^2
     const double rhs = st[ST_ORTH_RHS];
     // orthogonality(A, g) > orth_tol  <=>  ||A g|| > orth_tol ||A||_F ||g||
     if (rhs > 0.0 && gg > 0.0 && sqrt(tt) > rhs * sqrt(gg)) {
@@ -120,11 +161,22 @@ k_cg_step2(int64_t n, double *st, int parity, int mode, const double *__restrict
     st[ST_BETA] = beta;
     st[ST_IT_DONE] += 1.0;
   }
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const double pi = p[i];
-    x[i] = x[i] + alpha * pi;                        // :580,630
-    p[i] = beta * pi - g[i];                         // :628
+  while (true) {
+#pragma unroll
+    for (int u = 0; u < VU; ++u) {
+      const int64_t i = i0 + u * VB;
+      if (i < hi_i) {
+        x[i] = xv[u] + alpha * pv[u];                // :580,630
+        p[i] = beta * pv[u] - gv[u];                 // :628
+      }
+    }
+    i0 += VU * VB;
+    if (i0 >= hi_i) break;
+#pragma unroll
+    for (int u = 0; u < VU; ++u) {
+      const int64_t i = min(i0 + u * VB, n - 1);
+      xv[u] = x[i]; pv[u] = p[i]; gv[u] = g[i];
+    }
   }
 }
 
@@ -148,8 +200,8 @@ int ipx_cg_step1(int64_t n, double *state, int32_t it, const double *p1, int32_t
                  const double *x, const double *p, double *r, const double *Hp, const double *lb,
                  const double *ub, double *part2, int32_t grid, void *stream) {
   if (n < 0 || !state || !p1 || !part2 || grid < 1) return IPX_EINVAL;
-  hipLaunchKernelGGL(k_cg_step1, dim3(grid), dim3(VB), 0, (hipStream_t)stream, n, state, it & 1,
-                     p1, np1, x, p, r, Hp, lb, ub, part2);
+  hipLaunchKernelGGL(k_cg_step1, dim3(ipx_xcd_grid(grid)), dim3(VB), 0, (hipStream_t)stream, n,
+                     state, it & 1, p1, np1, x, p, r, Hp, lb, ub, part2, grid);
   IPX_CHECK_LAUNCH();
   return IPX_OK;
 }
@@ -158,8 +210,8 @@ int ipx_cg_step2(int64_t n, double *state, int32_t it, int32_t mode, const doubl
                  int32_t np2, const double *p3, int32_t np3, const double *p4, int32_t np4,
                  double *x, double *p, const double *g, int32_t grid, void *stream) {
   if (n < 0 || !state || grid < 1) return IPX_EINVAL;
-  hipLaunchKernelGGL(k_cg_step2, dim3(grid), dim3(VB), 0, (hipStream_t)stream, n, state, it & 1,
-                     mode, p2, np2, p3, np3, p4, np4, x, p, g);
+  hipLaunchKernelGGL(k_cg_step2, dim3(ipx_xcd_grid(grid)), dim3(VB), 0, (hipStream_t)stream, n,
+                     state, it & 1, mode, p2, np2, p3, np3, p4, np4, x, p, g, grid);
   IPX_CHECK_LAUNCH();
   return IPX_OK;
 }
@@ -177,9 +229,9 @@ int ipx_cg_resume(const ipx_cg_args *a, int32_t it, int32_t mode, void *stream) 
   if (!a) return IPX_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const double *guard = a->state + ST_STOP;
-  hipLaunchKernelGGL(k_cg_step2, dim3((unsigned)a->vec_grid), dim3(VB), 0, st, a->n, a->state, it & 1, mode,
-                     a->part2, (int)a->vec_grid, a->part3, (int)a->At_ntiles, a->part4, (int)a->A_ntiles,
-                     a->x, a->p, a->r);
+  hipLaunchKernelGGL(k_cg_step2, dim3(ipx_xcd_grid((int)a->vec_grid)), dim3(VB), 0, st, a->n,
+                     a->state, it & 1, mode, a->part2, (int)a->vec_grid, a->part3,
+                     (int)a->At_ntiles, a->part4, 256, a->x, a->p, a->r, (int)a->vec_grid);
   IPX_CHECK_LAUNCH();
   return launch_hp(a, guard, st);
 }
@@ -191,6 +243,47 @@ static int cg_iterate(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, hi
 int ipx_cg_iterate(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, void *stream) {
   if (!a || it_end < it_begin) return IPX_EINVAL;
   return cg_iterate(a, it_begin, it_end, (hipStream_t)stream, nullptr);
+}
+
+// hipGraph replay of the loop: two consecutive iterations (even + odd parity
+// of the double-buffered rt_g) are captured once; every replay runs two more
+// iterations without per-kernel host launch work.
+struct ipx_cg_graph {
+  hipGraph_t graph;
+  hipGraphExec_t exec;
+};
+
+void *ipx_cg_graph_create(const ipx_cg_args *a, void *stream) {
+  if (!a) return nullptr;
+  hipStream_t st = (hipStream_t)stream;
+  ipx_cg_graph *g = new ipx_cg_graph();
+  if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) { delete g; return nullptr; }
+  int rc = cg_iterate(a, 0, 2, st, nullptr);
+  hipError_t e = hipStreamEndCapture(st, &g->graph);
+  if (rc != IPX_OK || e != hipSuccess) { delete g; return nullptr; }
+  if (hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0) != hipSuccess) {
+    (void)hipGraphDestroy(g->graph);
+    delete g;
+    return nullptr;
+  }
+  return g;
+}
+
+// Run 2*npairs iterations (the iteration index must be even when this starts).
+int ipx_cg_graph_launch(void *graph, int32_t npairs, void *stream) {
+  if (!graph || npairs < 0) return IPX_EINVAL;
+  ipx_cg_graph *g = (ipx_cg_graph *)graph;
+  for (int i = 0; i < npairs; ++i)
+    if (hipGraphLaunch(g->exec, (hipStream_t)stream) != hipSuccess) return IPX_ELAUNCH;
+  return IPX_OK;
+}
+
+void ipx_cg_graph_destroy(void *graph) {
+  if (!graph) return;
+  ipx_cg_graph *g = (ipx_cg_graph *)graph;
+  (void)hipGraphExecDestroy(g->exec);
+  (void)hipGraphDestroy(g->graph);
+  delete g;
 }
 
 // Instrumented variant for bench.py: HIP events are recorded on `stream`
@@ -232,10 +325,12 @@ static int cg_iterate(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, hi
   ipx_csr_view A{(int)a->m, (int)a->n, a->A_rowptr, a->A_colidx, a->A_val, a->A_tiles, (int)a->A_ntiles};
   ipx_csr_view At{(int)a->n, (int)a->m, a->At_rowptr, a->At_colidx, a->At_val, a->At_tiles, (int)a->At_ntiles};
 #define MARK(i) do { if (ev) (void)hipEventRecord(ev[i], st); } while (0)
+  int np4 = 1;
   for (int it = it_begin; it < it_end; ++it) {
     MARK(0);
-    hipLaunchKernelGGL(k_cg_step1, dim3((unsigned)a->vec_grid), dim3(VB), 0, st, a->n, a->state, it & 1,
-                       a->part1, (int)a->H_ntiles, a->x, a->p, a->r, a->Hp, a->lb, a->ub, a->part2);
+    hipLaunchKernelGGL(k_cg_step1, dim3(ipx_xcd_grid((int)a->vec_grid)), dim3(VB), 0, st, a->n,
+                       a->state, it & 1, a->part1, (int)a->H_ntiles, a->x, a->p, a->r,
+                       a->Hp, a->lb, a->ub, a->part2, (int)a->vec_grid);
     IPX_CHECK_LAUNCH();
     MARK(1);
     int rc;
@@ -252,14 +347,15 @@ static int cg_iterate(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, hi
       rc = ipx_spmv_launch(At, a->v, -1.0, nullptr, 1.0, a->r, a->r, a->part3, guard, st);
       if (rc) return rc;
       MARK(4);
-      // t = A g, partials of ||t||^2
-      rc = ipx_spmv_launch(A, a->r, 1.0, nullptr, 0.0, nullptr, a->t, a->part4, guard, st);
+      // ||A g||^2 for the orthogonality test, as the constraint-space residual
+      // ||w - (A A') v||^2 (see k_band_residual); part4 must hold >= 256 doubles
+      rc = ipx_banded_residual_launch(a->banded, a->w, a->v, a->part4, &np4, guard, st);
       if (rc) return rc;
       MARK(5);
     }
-    hipLaunchKernelGGL(k_cg_step2, dim3((unsigned)a->vec_grid), dim3(VB), 0, st, a->n, a->state, it & 1,
-                       a->m > 0 ? 0 : 2, a->part2, (int)a->vec_grid, a->part3, (int)a->At_ntiles,
-                       a->part4, (int)a->A_ntiles, a->x, a->p, a->r);
+    hipLaunchKernelGGL(k_cg_step2, dim3(ipx_xcd_grid((int)a->vec_grid)), dim3(VB), 0, st, a->n,
+                       a->state, it & 1, a->m > 0 ? 0 : 2, a->part2, (int)a->vec_grid, a->part3,
+                       (int)a->At_ntiles, a->part4, np4, a->x, a->p, a->r, (int)a->vec_grid);
     IPX_CHECK_LAUNCH();
     MARK(6);
     rc = launch_hp(a, guard, st);

@@ -27,6 +27,21 @@ static inline int ipx_grid_for(int64_t n, int per_block, int cap = IPX_VEC_GRID_
   return (int)g;
 }
 
+// ---- XCD-aware work mapping ---------------------------------------------
+// Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one), and
+// each XCD has its own 4 MiB L2.  Every kernel of the CG loop therefore maps
+// work item t (row tile, or chunk of vector elements) so that XCD k always
+// owns the k-th eighth of the index space: the slices of x, p, r, Hp an XCD
+// read or wrote in one kernel are the slices it needs in the next, and can be
+// served from its own L2 instead of the fabric.  Launch ipx_xcd_grid(n) work-
+// groups; ipx_xcd_item returns the item or -1 for the few padding groups.
+static inline int ipx_xcd_grid(int nitems) { return 8 * ((nitems + 7) / 8); }
+__device__ __forceinline__ int ipx_xcd_item(int block, int nitems) {
+  const int per = (nitems + 7) >> 3;
+  const int t = (block & 7) * per + (block >> 3);
+  return ((block >> 3) < per && t < nitems) ? t : -1;
+}
+
 // ---- fixed-order reductions -------------------------------------------
 // Wave: butterfly over 64 lanes (xor 32,16,...,1); every lane ends with the
 // same bits.  Block: wave results through LDS, summed in wave order.
@@ -93,6 +108,38 @@ __device__ __forceinline__ double ipx_sum_partials(const double *part, int count
   return ipx_block_reduce<OP>(v, lds);
 }
 
+// Fold NQ partial arrays at once: all loads are issued together and the block
+// reduction uses ONE barrier pair for all quantities (a prologue that folds
+// them one after the other pays the memory latency and two barriers per
+// quantity).  Same fixed summation order as ipx_sum_partials.  `lds` needs
+// NQ * blockDim/64 doubles.
+template <int NQ>
+__device__ __forceinline__ void ipx_sum_partials_multi(const double *const (&part)[NQ],
+                                                       const int (&count)[NQ], double *lds,
+                                                       double (&out)[NQ]) {
+  double v[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    v[q] = 0.0;
+    for (int i = threadIdx.x; i < count[q]; i += blockDim.x) v[q] += part[q][i];
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    v[q] = ipx_wave_sum(v[q]);
+    if (lane == 0) lds[q * nw + wave] = v[q];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    double r = lds[q * nw];
+    for (int w = 1; w < nw; ++w) r += lds[q * nw + w];
+    out[q] = r;
+  }
+  __syncthreads();
+}
+
 // ---- internal (non-ABI) launchers shared between translation units --------
 struct ipx_csr_view {
   int nrows, ncols;
@@ -106,3 +153,6 @@ int ipx_spmv_launch(const ipx_csr_view &A, const double *x, double alpha, const 
                     const double *guard, hipStream_t st, const double *xrow_override = nullptr);
 int ipx_banded_solve_guarded(void *handle, const double *w, double *x, const double *guard,
                              hipStream_t st);
+// partial[0..*npartial) <- per-workgroup sums of ||w - (A A') v||^2 (<= 256 of them)
+int ipx_banded_residual_launch(void *handle, const double *w, const double *v, double *partial,
+                               int *npartial, const double *guard, hipStream_t st);

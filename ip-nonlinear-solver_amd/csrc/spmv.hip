@@ -20,6 +20,7 @@
 namespace {
 
 constexpr int TILE_NNZ = IPX_SPMV_TILE_NNZ;
+constexpr int TILE_ROWS = IPX_SPMV_TILE_ROWS;   // max rows per tile (ipx_csr_tiles_host max_rows)
 
 template <bool HAS_DIAG, bool HAS_YIN, bool REDUCE>
 __global__ void __launch_bounds__(IPX_BLOCK)
@@ -29,19 +30,86 @@ k_csr_spmv(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colid
            double beta, const double *yin, double *yout, const double *__restrict__ xrow,
            double *__restrict__ partial, int ntiles, const double *__restrict__ guard) {
   __shared__ double prod[TILE_NNZ];
+  __shared__ int rp[TILE_ROWS + 1];
   __shared__ double red_lds[IPX_BLOCK / IPX_WAVE];
   if (guard && *guard != 0.0) return;   // device-side stop flag of the fused CG loop
-  const int tile = blockIdx.x;
+  const int tile = ipx_xcd_item(blockIdx.x, ntiles);
+  if (tile < 0) return;
   const int r0 = tiles[tile], r1 = tiles[tile + 1];
   const int s = rowptr[r0], e = rowptr[r1];
   double acc_yy = 0.0, acc_xy = 0.0;
 
-  if (e - s <= TILE_NNZ) {
-    // Phase 1: coalesced stream of the tile's nonzeros.
+  const int nrows = r1 - r0;
+  if (e - s <= TILE_NNZ && nrows <= TILE_ROWS) {
+    // Phase 1: coalesced stream of the tile's nonzeros.  All loads of a lane
+    // are issued before the first use (a rolled loop would pay one full
+    // memory latency per trip: the kernel is latency-, not bandwidth-limited
+    // otherwise), then the gathers, then the LDS stores.
+    constexpr int U = TILE_NNZ / IPX_BLOCK;
+    constexpr int Q = TILE_ROWS / IPX_BLOCK;
+    const int tid = threadIdx.x;
+    int rpv[Q + 1];
+#pragma unroll
+    for (int q = 0; q <= Q; ++q) {
+      const int i = tid + q * IPX_BLOCK;
+      rpv[q] = (i <= nrows) ? rowptr[r0 + i] - s : 0;
+    }
+    if (e > s) {
+      int c[U];
+      double v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int jj = min(s + tid + u * IPX_BLOCK, e - 1);
+        c[u] = colidx[jj];
+        v[u] = val[jj];
+      }
+      double xg[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) xg[u] = x[c[u]];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int jj = s + tid + u * IPX_BLOCK;
+        if (jj < e) prod[jj - s] = v[u] * xg[u];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q <= Q; ++q) {
+      const int i = tid + q * IPX_BLOCK;
+      if (i <= nrows) rp[i] = rpv[q];
+    }
+    // epilogue operands of this lane's rows: issued now, consumed after the barrier
+    double dg[Q], xr[Q], yi[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const int r = r0 + min(tid + q * IPX_BLOCK, nrows - 1);
+      dg[q] = HAS_DIAG ? diag[r] : 0.0;
+      xr[q] = xrow ? xrow[r] : 0.0;
+      yi[q] = HAS_YIN ? yin[r] : 0.0;
+    }
+    __syncthreads();
+    // Phase 2: one lane per row, left-to-right row sums out of LDS.
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const int i = tid + q * IPX_BLOCK;
+      if (i < nrows) {
+        const int a = rp[i], b = rp[i + 1];
+        double sum = 0.0;
+        for (int k = a; k < b; ++k) sum += prod[k];
+        double y = alpha * sum;
+        if (HAS_DIAG) y += dg[q] * xr[q];
+        if (HAS_YIN) y += beta * yi[q];
+        yout[r0 + i] = y;
+        if (REDUCE) {
+          acc_yy += y * y;
+          if (xrow) acc_xy += xr[q] * y;
+        }
+      }
+    }
+  } else if (e - s <= TILE_NNZ) {
+    // (tiles with more rows than TILE_ROWS: generic loops)
     for (int j = s + (int)threadIdx.x; j < e; j += IPX_BLOCK)
       prod[j - s] = val[j] * x[colidx[j]];
     __syncthreads();
-    // Phase 2: one lane per row, left-to-right row sums out of LDS.
     for (int r = r0 + (int)threadIdx.x; r < r1; r += IPX_BLOCK) {
       const int a = rowptr[r] - s, b = rowptr[r + 1] - s;
       double sum = 0.0;
@@ -96,7 +164,7 @@ void launch(int ntiles, hipStream_t st, const int32_t *rowptr, const int32_t *co
             const double *val, const int32_t *tiles, const double *x, double alpha,
             const double *diag, double beta, const double *yin, double *yout,
             const double *xrow, double *partial, const double *guard) {
-  hipLaunchKernelGGL((k_csr_spmv<D, Y, R>), dim3(ntiles), dim3(IPX_BLOCK), 0, st, rowptr, colidx,
+  hipLaunchKernelGGL((k_csr_spmv<D, Y, R>), dim3(ipx_xcd_grid(ntiles)), dim3(IPX_BLOCK), 0, st, rowptr, colidx,
                      val, tiles, x, alpha, diag, beta, yin, yout, xrow, partial, ntiles, guard);
 }
 

@@ -50,6 +50,7 @@ _SIGNATURES = {
     "ipx_cg_resume": [_P, _I32, _I32, _P],
     "ipx_cg_iterate": [_P, _I32, _I32, _P],
     "ipx_cg_iterate_timed": [_P, _I32, _I32, _P, _P],
+    "ipx_cg_graph_launch": [_P, _I32, _P],
     "ipx_banded_kmax": [],
     "ipx_banded_levels": [_P],
     "ipx_banded_factor": [_P, _P, _P],
@@ -61,9 +62,10 @@ _SIGNATURES = {
 }
 _RESTYPES = {"ipx_version": _c.c_char_p, "ipx_last_error": _c.c_char_p,
              "ipx_banded_create": _P, "ipx_banded_destroy": None,
-             "ipx_dense_padded": _I64}
+             "ipx_dense_padded": _I64, "ipx_cg_graph_create": _P, "ipx_cg_graph_destroy": None}
 _EXTRA_ARGTYPES = {"ipx_banded_create": [_I64, _I32, _I32], "ipx_banded_destroy": [_P],
-                   "ipx_dense_padded": [_I64]}
+                   "ipx_dense_padded": [_I64], "ipx_cg_graph_create": [_P, _P],
+                   "ipx_cg_graph_destroy": [_P]}
 
 _lib = None
 

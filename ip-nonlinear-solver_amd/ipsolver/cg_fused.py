@@ -89,7 +89,7 @@ class _Loop:
         self.part1 = torch.zeros(2 * Hc.pattern.ntiles, dtype=f64, device=dev)
         self.part2 = torch.zeros(2 * grid, dtype=f64, device=dev)
         self.part3 = torch.zeros(2 * At.pattern.ntiles, dtype=f64, device=dev)
-        self.part4 = torch.zeros(2 * A.pattern.ntiles, dtype=f64, device=dev)
+        self.part4 = torch.zeros(256, dtype=f64, device=dev)     # ||w - (AA')v||^2 partials
         self.keep = (A, At, Hc, Hd, lb, ub, P)
         a = CgArgs()
         a.n, a.m = n, m
@@ -157,7 +157,7 @@ def projected_cg(H, c, Z, Y, b, trust_radius=np.inf, lb=None, ub=None, tol=None,
     L.state.copy_(torch.from_numpy(init))
     _hip.check(lib.ipx_cg_hp(L.ref(), st), "ipx_cg_hp")
 
-    X, Pv, R = DVec(L.x), DVec(L.p), DVec(L.r)
+    X, R = DVec(L.x), DVec(L.r)
     hits_boundary = False
     stop_cond = 1
     counter = 0
@@ -180,6 +180,7 @@ def projected_cg(H, c, Z, Y, b, trust_radius=np.inf, lb=None, ub=None, tol=None,
             continue
         it_stop = int(s[ST_IT_DONE])     # index of the iteration that raised the flag
         alpha = s[ST_ALPHA]
+        Pv = DVec(L.p)
         if stop == 4:                     # :551
             stop_cond = 4
             broke = True
@@ -251,8 +252,8 @@ def _resume(lib, L, it_stop, mode, st):
 
 def _refine(P, L, R):
     """Iterative refinement of g = Z r (projections.py:69-78) on the buffers of
-    the fused loop: L.r holds g, L.t holds A g."""
-    Az = DVec(L.t)
+    the fused loop: L.r holds g."""
+    Az = P.A.dot(R)          # the loop only formed ||A g||^2 (as a constraint-space residual)
     k = 0
     while k < P.max_refin:
         v = P._apply_inv(Az)
