@@ -154,6 +154,11 @@ int ipx_banded_levels(void *handle);
 int ipx_banded_factor(void *handle, const double *band, void *stream);
 /* Blocking: IPX_OK, or IPX_ENOTSPD when a pivot was <= 0 (rank-deficient A). */
 int ipx_banded_status(void *handle, void *stream);
+/* After ipx_banded_status: 1 when the separator system was found diagonal to
+ * working precision (|off-diagonal| <= 2^-56 |diagonal|) so solves skip the
+ * middle kernel; ipx_banded_set_decoupling(h, 0) forces the full path. */
+int ipx_banded_decoupled(void *handle);
+int ipx_banded_set_decoupling(void *handle, int allow);
 int ipx_banded_solve(void *handle, const double *w, double *x, void *stream);
 /* Same, skipped on the device when *guard != 0 (stop flag of the CG loops). */
 int ipx_banded_solve_guarded_c(void *handle, const double *w, double *x, const double *guard,

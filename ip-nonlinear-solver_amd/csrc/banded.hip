@@ -44,6 +44,9 @@ struct Banded {
   Level lev[MAX_LEVELS];
   int *flag;                  // device: != 0 after a non-positive pivot
   double *gL, *gR;            // halves of the level-1 right-hand side (fast path)
+  double *ybuf;               // level-0 down-sweep result (fast path is out of place)
+  double *rinv;               // 1 / diag of the level-1 matrix (decoupled path)
+  bool decoupled;             // level-1 system numerically diagonal: skip the middle kernel
   bool fast;                  // three-launch path usable (LDS budget)
   int down_T;                 // chunks per workgroup in k_down0
   size_t lds_down;
@@ -305,6 +308,91 @@ k_correct(int m, int c, int P, const double *__restrict__ V, const double *__res
     for (int a = 0; a < K; ++a) v -= W[(int64_t)i * K + a] * xs[t * K + a];
   }
   x[i] = v;
+}
+
+// Level-0 up sweep of the three-launch path, out of place (y -> x), optionally
+// fused with the normal-equation residual ||w - S x||^2 (k_band_residual): the
+// corrected values of the 2K neighbours a row needs are recomputed from y, so
+// no second pass over x (and no extra kernel boundary) is needed.
+// Separator solution.  Normally the middle kernel's output `xs`.  When the
+// separator (Schur complement) system is diagonal to working precision --
+// S^-1 of a well-conditioned band matrix decays geometrically, so with chunks
+// of 64 rows the coupling between neighbouring separators is often below
+// 2^-56 of the diagonal -- it is evaluated in place as (gL + gR) / R_tt and the
+// middle kernel is skipped (checked numerically at every factorization,
+// k = 1 only; see k_decoupling_check).
+struct SepValues {
+  const double *xs, *gL, *gR, *rinv;
+  __device__ __forceinline__ double operator()(int q) const {
+    return xs ? xs[q] : (gL[q] + gR[q]) * rinv[q];
+  }
+};
+
+__global__ void __launch_bounds__(IPX_BLOCK)
+k_decoupling_check(int mR, const double *__restrict__ Rband, double *__restrict__ rinv,
+                   int *flag) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= mR) return;
+  const double d = Rband[t];
+  const double lo = Rband[(int64_t)mR + t];                       // R[t][t-1]
+  const double up = (t + 1 < mR) ? Rband[(int64_t)mR + t + 1] : 0.0;   // R[t+1][t]
+  rinv[t] = 1.0 / d;
+  const double tiny = 1.3877787807814457e-17;                     // 2^-56
+  if (!(fmax(fabs(lo), fabs(up)) <= tiny * fabs(d))) atomicOr(flag, 2);
+}
+
+template <int K>
+__device__ __forceinline__ double corrected_at(int i, int m, int c, int P, const double *V,
+                                               const double *W, const SepValues &xs,
+                                               const double *y) {
+  const int q = c + K;
+  int t = i / q;
+  if (t > P - 1) t = P - 1;
+  const int j = i - t * q;
+  const int ct = chunk_rows(m, q, c, P, t);
+  if (j >= ct) return xs(t * K + (j - ct));
+  double v = y[i];
+  if (t > 0) {
+#pragma unroll
+    for (int a = 0; a < K; ++a) v -= V[(int64_t)i * K + a] * xs((t - 1) * K + a);
+  }
+  if (t < P - 1) {
+#pragma unroll
+    for (int a = 0; a < K; ++a) v -= W[(int64_t)i * K + a] * xs(t * K + a);
+  }
+  return v;
+}
+
+template <int K, bool RESID>
+__global__ void __launch_bounds__(IPX_BLOCK)
+k_correct_oop(int m, int c, int P, const double *__restrict__ V, const double *__restrict__ W,
+              SepValues xs, const double *__restrict__ y, double *__restrict__ x,
+              const double *__restrict__ band, const double *__restrict__ w,
+              double *__restrict__ partial, const double *__restrict__ guard) {
+  __shared__ double lds[IPX_BLOCK / IPX_WAVE];
+  if (guard && *guard != 0.0) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  double acc = 0.0;
+  if (i < m) {
+    const double vi = corrected_at<K>(i, m, c, P, V, W, xs, y);
+    x[i] = vi;
+    if (RESID) {
+      double s = band[i] * vi;
+#pragma unroll
+      for (int d = 1; d <= K; ++d) {
+        if (i - d >= 0)
+          s += band[(int64_t)d * m + i] * corrected_at<K>(i - d, m, c, P, V, W, xs, y);
+        if (i + d < m)
+          s += band[(int64_t)d * m + i + d] * corrected_at<K>(i + d, m, c, P, V, W, xs, y);
+      }
+      const double res = w[i] - s;
+      acc = res * res;
+    }
+  }
+  if (RESID) {
+    const double a = ipx_block_reduce<IPX_SUM>(acc, lds);
+    if (threadIdx.x == 0) partial[blockIdx.x] = a;
+  }
 }
 
 // ---- S = A A' in band storage: one lane per (row i, offset d), merge join
@@ -758,7 +846,8 @@ void *ipx_banded_create(int64_t m64, int32_t k, int32_t chunk) {
   if (k == 0) k = 1;                 // diagonal matrices ride the k = 1 path
   Banded *h = new Banded();
   h->nlev = 0;
-  h->gL = h->gR = h->slab = nullptr;
+  h->gL = h->gR = h->slab = h->ybuf = h->rinv = nullptr;
+  h->decoupled = false;
   h->fast = false;
   int m = (int)m64, kk = k;
   if (chunk <= 0) chunk = 64;
@@ -833,7 +922,9 @@ void *ipx_banded_create(int64_t m64, int32_t k, int32_t chunk) {
     if (h->fast && l0.mR > 0) {
       h->gL = dalloc<double>(h, l0.mR);
       h->gR = dalloc<double>(h, l0.mR);
-      if (!h->gL || !h->gR) ok = false;
+      h->ybuf = dalloc<double>(h, l0.m);
+      h->rinv = dalloc<double>(h, l0.mR);
+      if (!h->gL || !h->gR || !h->ybuf || !h->rinv) ok = false;
       else if (hipMemset(h->gR, 0, (size_t)l0.mR * sizeof(double)) != hipSuccess) ok = false;
     }
   }
@@ -862,9 +953,16 @@ int ipx_banded_factor(void *handle, const double *band, void *stream) {
   hipStream_t st = (hipStream_t)stream;
   if (hipMemsetAsync(h->flag, 0, sizeof(int), st) != hipSuccess) return IPX_ELAUNCH;
   h->lev[0].band = const_cast<double *>(band);
+  h->decoupled = false;
   for (int li = 0; li < h->nlev; ++li) {
     int rc = level_factor(h, li, st);
     if (rc != IPX_OK) return rc;
+  }
+  if (h->fast && h->nlev >= 2 && h->lev[0].k == 1 && h->rinv) {
+    const int mR = h->lev[0].mR;
+    hipLaunchKernelGGL(k_decoupling_check, dim3((mR + IPX_BLOCK - 1) / IPX_BLOCK), dim3(IPX_BLOCK),
+                       0, st, mR, h->lev[1].band, h->rinv, h->flag);
+    IPX_CHECK_LAUNCH();
   }
   return IPX_OK;
 }
@@ -878,7 +976,18 @@ int ipx_banded_status(void *handle, void *stream) {
       hipSuccess)
     return IPX_ELAUNCH;
   if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return IPX_ELAUNCH;
-  return f ? IPX_ENOTSPD : IPX_OK;
+  h->decoupled = h->fast && h->nlev >= 2 && h->lev[0].k == 1 && h->rinv && !(f & 2);
+  return (f & 1) ? IPX_ENOTSPD : IPX_OK;
+}
+
+// 1 when solves skip the middle kernel (separator system diagonal to working
+// precision); valid after ipx_banded_status.
+int ipx_banded_decoupled(void *handle) { return handle && ((Banded *)handle)->decoupled; }
+
+int ipx_banded_set_decoupling(void *handle, int allow) {
+  if (!handle) return IPX_EINVAL;
+  if (!allow) ((Banded *)handle)->decoupled = false;
+  return IPX_OK;
 }
 
 // x = S^-1 w.  w and x are length m; x may alias w.
@@ -941,17 +1050,65 @@ int fast_middle(Banded *h, const double *guard, hipStream_t st) {
 extern "C" int ipx_banded_solve_multilaunch(void *handle, const double *w, double *x,
                                             void *stream);
 
+namespace {
+template <int K>
+int launch_correct_oop(Banded *h, double *x, const double *w, double *partial, int *npartial,
+                       const double *guard, hipStream_t st) {
+  const Level &lv = h->lev[0];
+  const int grid = (lv.m + IPX_BLOCK - 1) / IPX_BLOCK;
+  if (npartial) *npartial = grid;
+  const SepValues xs = h->decoupled ? SepValues{nullptr, h->gL, h->gR, h->rinv}
+                                    : SepValues{h->lev[1].sol, nullptr, nullptr, nullptr};
+  if (partial)
+    hipLaunchKernelGGL((k_correct_oop<K, true>), dim3(grid), dim3(IPX_BLOCK), 0, st, lv.m, lv.c,
+                       lv.P, lv.V, lv.W, xs, h->ybuf, x, lv.band, w, partial, guard);
+  else
+    hipLaunchKernelGGL((k_correct_oop<K, false>), dim3(grid), dim3(IPX_BLOCK), 0, st, lv.m, lv.c,
+                       lv.P, lv.V, lv.W, xs, h->ybuf, x, lv.band, w, partial, guard);
+  IPX_CHECK_LAUNCH();
+  return IPX_OK;
+}
+
+// Fast path.  `partial` != NULL additionally yields per-workgroup sums of
+// ||w - S x||^2 (needs x != w).
+int fast_solve(Banded *h, const double *w, double *x, double *partial, int *npartial,
+               const double *guard, hipStream_t st) {
+  if (h->nlev == 1) {              // one chunk holds everything: no separators
+    int rc = fast_down0(h, w, x, guard, st);
+    if (rc != IPX_OK || !partial) return rc;
+    return ipx_banded_residual_launch(h, w, x, partial, npartial, guard, st);
+  }
+  int rc = fast_down0(h, w, h->ybuf, guard, st);
+  if (rc != IPX_OK) return rc;
+  if (!h->decoupled) {
+    rc = fast_middle(h, guard, st);
+    if (rc != IPX_OK) return rc;
+  }
+  switch (h->lev[0].k) {
+#define CO(kk) case kk: return launch_correct_oop<kk>(h, x, w, partial, npartial, guard, st)
+    CO(1); CO(2); CO(3); CO(4); CO(5); CO(6); CO(7); CO(8);
+#undef CO
+  }
+  return IPX_EINVAL;
+}
+}  // namespace
+
+// Solve + residual partials in one go (the CG loop's projection step).
+int ipx_banded_solve_resid_launch(void *handle, const double *w, double *x, double *partial,
+                                  int *npartial, const double *guard, hipStream_t st) {
+  if (!handle || !w || !x || !partial || w == x) return IPX_EINVAL;
+  Banded *h = (Banded *)handle;
+  if (h->fast) return fast_solve(h, w, x, partial, npartial, guard, st);
+  int rc = ipx_banded_solve_guarded(handle, w, x, guard, st);
+  if (rc != IPX_OK) return rc;
+  return ipx_banded_residual_launch(handle, w, x, partial, npartial, guard, st);
+}
+
 int ipx_banded_solve_guarded(void *handle, const double *w, double *x, const double *guard,
                              hipStream_t st) {
   if (!handle || !w || !x) return IPX_EINVAL;
   Banded *h = (Banded *)handle;
-  if (h->fast) {
-    int rc = fast_down0(h, w, x, guard, st);
-    if (rc != IPX_OK || h->nlev == 1) return rc;
-    rc = fast_middle(h, guard, st);
-    if (rc != IPX_OK) return rc;
-    return level_up(h, 0, x, guard, st);
-  }
+  if (h->fast) return fast_solve(h, w, x, nullptr, nullptr, guard, st);
   for (int li = 0; li < h->nlev; ++li) {
     const double *in = li == 0 ? w : h->lev[li].rhs;
     double *out = li == 0 ? x : h->lev[li].sol;

@@ -231,7 +231,8 @@ int ipx_cg_resume(const ipx_cg_args *a, int32_t it, int32_t mode, void *stream) 
   const double *guard = a->state + ST_STOP;
   hipLaunchKernelGGL(k_cg_step2, dim3(ipx_xcd_grid((int)a->vec_grid)), dim3(VB), 0, st, a->n,
                      a->state, it & 1, mode, a->part2, (int)a->vec_grid, a->part3,
-                     (int)a->At_ntiles, a->part4, 256, a->x, a->p, a->r, (int)a->vec_grid);
+                     (int)a->At_ntiles, a->part4, (int)((a->m + 255) / 256), a->x, a->p, a->r,
+                     (int)a->vec_grid);
   IPX_CHECK_LAUNCH();
   return launch_hp(a, guard, st);
 }
@@ -339,18 +340,16 @@ static int cg_iterate(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, hi
       rc = ipx_spmv_launch(A, a->r, 1.0, nullptr, 0.0, nullptr, a->w, nullptr, guard, st);
       if (rc) return rc;
       MARK(2);
-      // v = (AA')^-1 w
-      rc = ipx_banded_solve_guarded(a->banded, a->w, a->v, guard, st);
+      // v = (AA')^-1 w, and ||A g||^2 for the orthogonality test as the
+      // constraint-space residual ||w - (A A') v||^2 from the same launch
+      // (see k_correct_oop / k_band_residual); part4 holds ceil(m/256) doubles
+      rc = ipx_banded_solve_resid_launch(a->banded, a->w, a->v, a->part4, &np4, guard, st);
       if (rc) return rc;
       MARK(3);
       // r = r - A'v  (g_next), partials of ||g||^2
       rc = ipx_spmv_launch(At, a->v, -1.0, nullptr, 1.0, a->r, a->r, a->part3, guard, st);
       if (rc) return rc;
       MARK(4);
-      // ||A g||^2 for the orthogonality test, as the constraint-space residual
-      // ||w - (A A') v||^2 (see k_band_residual); part4 must hold >= 256 doubles
-      rc = ipx_banded_residual_launch(a->banded, a->w, a->v, a->part4, &np4, guard, st);
-      if (rc) return rc;
       MARK(5);
     }
     hipLaunchKernelGGL(k_cg_step2, dim3(ipx_xcd_grid((int)a->vec_grid)), dim3(VB), 0, st, a->n,

@@ -153,6 +153,10 @@ int ipx_spmv_launch(const ipx_csr_view &A, const double *x, double alpha, const 
                     const double *guard, hipStream_t st, const double *xrow_override = nullptr);
 int ipx_banded_solve_guarded(void *handle, const double *w, double *x, const double *guard,
                              hipStream_t st);
+// x = (A A')^-1 w and partial[0..*npartial) <- per-workgroup sums of ||w - (A A') x||^2
+// in one go; the partial buffer needs ceil(m / 256) doubles.
+int ipx_banded_solve_resid_launch(void *handle, const double *w, double *x, double *partial,
+                                  int *npartial, const double *guard, hipStream_t st);
 // partial[0..*npartial) <- per-workgroup sums of ||w - (A A') v||^2 (<= 256 of them)
 int ipx_banded_residual_launch(void *handle, const double *w, const double *v, double *partial,
                                int *npartial, const double *guard, hipStream_t st);

@@ -53,6 +53,8 @@ _SIGNATURES = {
     "ipx_cg_graph_launch": [_P, _I32, _P],
     "ipx_banded_kmax": [],
     "ipx_banded_levels": [_P],
+    "ipx_banded_decoupled": [_P],
+    "ipx_banded_set_decoupling": [_P, _c.c_int],
     "ipx_banded_factor": [_P, _P, _P],
     "ipx_banded_status": [_P, _P],
     "ipx_banded_solve": [_P, _P, _P, _P],

@@ -89,7 +89,7 @@ class _Loop:
         self.part1 = torch.zeros(2 * Hc.pattern.ntiles, dtype=f64, device=dev)
         self.part2 = torch.zeros(2 * grid, dtype=f64, device=dev)
         self.part3 = torch.zeros(2 * At.pattern.ntiles, dtype=f64, device=dev)
-        self.part4 = torch.zeros(256, dtype=f64, device=dev)     # ||w - (AA')v||^2 partials
+        self.part4 = torch.zeros((m + 255) // 256 + 1, dtype=f64, device=dev)   # ||w-(AA')v||^2 partials
         self.keep = (A, At, Hc, Hd, lb, ub, P)
         a = CgArgs()
         a.n, a.m = n, m

@@ -25,5 +25,5 @@ for name in ("ipx_banded_solve", "ipx_banded_solve_multilaunch"):
     for _ in range(N):
         fn(ctypes.c_void_p(solver.handle), dv._p(w.t), dv._p(out), st)
     torch.cuda.synchronize()
-    print(name, "chunk", chunk, "levels", lib.ipx_banded_levels(ctypes.c_void_p(solver.handle)),
+    print(name, "decoupled", lib.ipx_banded_decoupled(ctypes.c_void_p(solver.handle)), "chunk", chunk, "levels", lib.ipx_banded_levels(ctypes.c_void_p(solver.handle)),
           "us/solve %.2f" % ((time.perf_counter() - t0) / N * 1e6))
