@@ -188,6 +188,9 @@ def hessian_operator(terms, n_vars, slack_block):
 def augmented_jacobian(J_eq, J_ineq, s, n_vars, n_eq, n_ineq):
     """[[J_eq, 0], [J_ineq, diag(s)]] (tr_interior_point.py:141-194) with the
     slack entries written on the device."""
+    if isinstance(J_eq, DeviceCSR) and isinstance(J_ineq, DeviceCSR):
+        from . import device_mode
+        return device_mode.augmented_jacobian(J_eq, J_ineq, s, n_vars, n_eq, n_ineq)
     if sps.issparse(J_eq) or sps.issparse(J_ineq):
         J_eq, J_ineq = sps.csr_matrix(J_eq), sps.csr_matrix(J_ineq)
         J = sps.vstack([J_eq, J_ineq], format="csr")

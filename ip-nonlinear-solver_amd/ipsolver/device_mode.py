@@ -1,0 +1,342 @@
+"""Device-callback mode of ``minimize_constrained``.
+
+When ``x0`` is a CUDA tensor the user's callbacks are called with CUDA
+tensors and return device objects, so nothing crosses PCIe between two
+iterations:
+
+    fun(x) -> float | 0-d tensor          grad(x) -> 1-D tensor
+    hess(x) -> DeviceCSR | 1-D tensor (diagonal) | DeviceHessian | None
+    NonlinearConstraint.fun(x) -> 1-D tensor
+    NonlinearConstraint.jac(x) -> DeviceCSR (a fixed CSRPattern, values refreshed)
+    NonlinearConstraint.hess(x, v) -> DeviceCSR | 1-D tensor (diagonal) | None
+    LinearConstraint(A)  with A a scipy sparse matrix or a DeviceCSR
+    BoxConstraint(kind)  unchanged
+
+The canonical form (row selection, sign flips, stacking of several
+constraints, multiplier re-signing; reference _canonical_constraint.py:
+169-480) and the barrier's augmented Jacobian (tr_interior_point.py:165-194)
+are value refreshes on patterns built once: gather / scatter kernels over
+index maps computed on the host at initialisation (symbolic work only).
+Finite-difference Hessians are not available in this mode (they evaluate host
+callbacks by construction).
+"""
+import numpy as np
+import scipy.sparse as sps
+import torch
+
+from . import _hip
+from . import device as dv
+from .canonical import parse_constraint, HessianSum
+from .constraints import (NonlinearConstraint, LinearConstraint, BoxConstraint, check_kind,
+                          check_enforce_feasibility, is_feasible, reinforce_box, _INFEASIBLE)
+from .device import DVec, DeviceCSR, CSRPattern, _p, stream_ptr, ctx
+
+_F64 = torch.float64
+
+
+def is_device_vector(x):
+    return torch.is_tensor(x) and x.is_cuda
+
+
+def as_dvec(t):
+    if isinstance(t, DVec):
+        return t
+    if not torch.is_tensor(t):
+        raise TypeError("device-callback mode: expected a CUDA tensor, got %r" % type(t))
+    return DVec(t.to(_F64).reshape(-1).contiguous())
+
+
+def _idx(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(ctx().device)
+
+
+def _vec(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(ctx().device)
+
+
+def gather(x, idx, sign=None, shift=None, out=None):
+    n = idx.numel()
+    out = dv._empty(n) if out is None else out
+    _hip.call("ipx_gather", n, _p(x), _p(idx), _p(sign), _p(shift), _p(out), stream_ptr())
+    return out
+
+
+def scatter(x, idx, out):
+    _hip.call("ipx_scatter", idx.numel(), _p(x), _p(idx), _p(out), stream_ptr())
+
+
+class RowSelection:
+    """J[rows, :] scaled by ``sign`` per row, as a value refresh on a pattern
+    derived once from J's pattern (_canonical_constraint.py:251-265)."""
+
+    def __init__(self, pattern, rows, sign):
+        indptr, indices = pattern.indptr_h.astype(np.int64), pattern.indices_h
+        counts = indptr[rows + 1] - indptr[rows]
+        new_indptr = np.concatenate(([0], np.cumsum(counts))).astype(np.int32)
+        src = (np.concatenate([np.arange(indptr[r], indptr[r + 1]) for r in rows])
+               if len(rows) else np.empty(0, dtype=np.int64))
+        self.identity = (len(rows) == pattern.shape[0]
+                         and np.array_equal(rows, np.arange(pattern.shape[0]))
+                         and (sign is None or np.all(sign == 1)))
+        self.pattern = pattern if self.identity else CSRPattern(
+            new_indptr, indices[src] if len(src) else np.empty(0, np.int32),
+            (len(rows), pattern.shape[1]))
+        self.src = _idx(src)
+        self.sign = None if sign is None or np.all(sign == 1) else _vec(np.repeat(sign, counts))
+
+    def apply(self, J):
+        if self.identity:
+            return J
+        if self.src.numel() == 0:
+            return DeviceCSR(self.pattern, dv._empty(0))
+        return DeviceCSR(self.pattern, gather(J.val, self.src, self.sign))
+
+
+class DeviceRowMap:
+    """Device twin of canonical._RowMap."""
+
+    def __init__(self, kind, n_vars):
+        (self.eq, self.ineq, val_eq, val_ineq, self.sign_h,
+         self.fun_len) = parse_constraint(kind)
+        self.n_eq, self.n_ineq, self.n_vars = len(self.eq), len(self.ineq), n_vars
+        self.eq_idx, self.ineq_idx = _idx(self.eq), _idx(self.ineq)
+        self.val_eq, self.val_ineq = _vec(val_eq), _vec(val_ineq)
+        self.sign = _vec(self.sign_h)
+        self._sel = {}
+        # multipliers back in the user's row order (reference :210-218), as
+        # three gathers from [v; 0]
+        def inverse(index_sets, total):
+            out = np.full(self.fun_len, total, dtype=np.int64)      # -> the appended zero
+            for pos, rows in index_sets:
+                out[rows] = pos
+            return _idx(out)
+        up = np.flatnonzero(self.sign_h == 1)
+        lo = np.flatnonzero(self.sign_h == -1)
+        self.m_eq = inverse([(np.arange(self.n_eq), self.eq)], self.n_eq)
+        self.m_up = inverse([(up, self.ineq[up])], self.n_ineq)
+        self.m_lo = inverse([(lo, self.ineq[lo])], self.n_ineq)
+
+    def values(self, c):
+        c_eq = DVec(gather(c.t, self.eq_idx, None, self.val_eq)) if self.n_eq else DVec.zeros(0)
+        c_ineq = DVec(gather(c.t, self.ineq_idx, self.sign, self.val_ineq)) if self.n_ineq \
+            else DVec.zeros(0)
+        return c_ineq, c_eq
+
+    def jac(self, J):
+        key = id(J.pattern)
+        if key not in self._sel:
+            self._sel[key] = (RowSelection(J.pattern, self.ineq, self.sign_h),
+                              RowSelection(J.pattern, self.eq, None), J.pattern)
+        sel_ineq, sel_eq, _ = self._sel[key]
+        return sel_ineq.apply(J), sel_eq.apply(J)
+
+    def multipliers(self, v_eq, v_ineq):
+        zero = torch.zeros(1, dtype=_F64, device=ctx().device)
+        ve = torch.cat((v_eq.t, zero))
+        vi = torch.cat((v_ineq.t, zero))
+        v = DVec(gather(ve, self.m_eq))
+        return v + DVec(gather(vi, self.m_up)) - DVec(gather(vi, self.m_lo))
+
+
+def _identity_csr(n):
+    pat = CSRPattern(np.arange(n + 1, dtype=np.int32), np.arange(n, dtype=np.int32), (n, n))
+    return DeviceCSR(pat, torch.ones(n, dtype=_F64, device=ctx().device))
+
+
+class _DeviceConstraint:
+    """One user constraint evaluated on the device + its canonical row map."""
+
+    def __init__(self, user, x0):
+        n = len(x0)
+        if isinstance(user, BoxConstraint):
+            J = _identity_csr(n)
+            self.fun = lambda x: x
+            self.jac = lambda x: J
+            self.hess = None
+            f0 = x0
+        elif isinstance(user, LinearConstraint):
+            A = user.A if isinstance(user.A, DeviceCSR) else DeviceCSR.from_scipy(
+                sps.csr_matrix(user.A))
+            self.fun = lambda x: A.dot(x)
+            self.jac = lambda x: A
+            self.hess = None
+            f0 = A.dot(x0)
+        elif isinstance(user, NonlinearConstraint):
+            if user._hess in ('2-point', '3-point', 'cs'):
+                raise NotImplementedError("finite-difference Hessians need host callbacks; "
+                                          "pass numpy x0 or give `hess` explicitly")
+            ufun, ujac, uhess = user._fun, user._jac, user._hess
+            self.fun = lambda x: as_dvec(ufun(x.t))
+            self.jac = lambda x: _check_jac(ujac(x.t))
+            self.hess = None if uhess is None else (lambda x, v: uhess(x.t, v.t))
+            f0 = self.fun(x0)
+        else:
+            raise ValueError("Unknown Constraint type.")
+        m = len(f0)
+        self.kind = check_kind(user.kind, m)
+        self.enforce = check_enforce_feasibility(user.enforce_feasibility, m)
+        self.x0 = x0
+        if self.enforce.any():
+            f0_h = f0.to_host()
+            if not is_feasible(self.kind, self.enforce, f0_h):
+                if isinstance(user, BoxConstraint):     # reference _constraints.py:332-340
+                    from warnings import warn
+                    warn("The initial point was changed in order to stay inside box "
+                         "constraints.")
+                    self.x0 = DVec.from_host(reinforce_box(self.kind, self.enforce, f0_h))
+                    f0 = self.x0
+                else:
+                    raise ValueError(_INFEASIBLE)
+        self.rows = DeviceRowMap(self.kind, n)
+        self.f0 = f0
+        self.J0 = self.jac(self.x0)
+
+    @property
+    def n_eq(self):
+        return self.rows.n_eq
+
+    @property
+    def n_ineq(self):
+        return self.rows.n_ineq
+
+
+def _check_jac(J):
+    if not isinstance(J, DeviceCSR):
+        raise TypeError("device-callback mode: `jac` must return an ipsolver.device.DeviceCSR "
+                        "(dense Jacobians: use host callbacks)")
+    return J
+
+
+_vstack_cache = {}
+
+
+def vstack_csr(parts, n_cols):
+    """Stack DeviceCSR blocks vertically; the stacked pattern is built once per
+    combination of part patterns, values are concatenated."""
+    parts = [p for p in parts]
+    if len(parts) == 1:
+        return parts[0]
+    key = tuple(id(p.pattern) for p in parts)
+    hit = _vstack_cache.get(key)
+    if hit is None:
+        indptr = [np.zeros(1, dtype=np.int64)]
+        off = 0
+        for p in parts:
+            indptr.append(p.pattern.indptr_h[1:].astype(np.int64) + off)
+            off += p.pattern.nnz
+        pat = CSRPattern(np.concatenate(indptr).astype(np.int32),
+                         np.concatenate([p.pattern.indices_h for p in parts]),
+                         (sum(p.shape[0] for p in parts), n_cols))
+        hit = _vstack_cache[key] = (pat, [p.pattern for p in parts])   # keep parts alive
+    return DeviceCSR(hit[0], torch.cat([p.val for p in parts]))
+
+
+class DeviceCanonical:
+    """Device twin of canonical.CanonicalConstraint for a list of constraints."""
+
+    def __init__(self, constraints, x0):
+        self.parts = []
+        for c in constraints:
+            part = _DeviceConstraint(c, x0)
+            x0 = part.x0
+            self.parts.append(part)
+        for part in self.parts:       # reference _canonical_constraint.py:382-383
+            if part.x0 is not x0 and not torch.equal(part.x0.t, x0.t):
+                raise RuntimeError("Unmatching initial point.")
+        self.x0 = x0
+        self.n_vars = len(x0)
+        self.n_eq = sum(p.n_eq for p in self.parts)
+        self.n_ineq = sum(p.n_ineq for p in self.parts)
+        self.enforce_feasibility = np.hstack(
+            [p.enforce[p.rows.ineq] if p.n_ineq else np.empty(0, dtype=bool)
+             for p in self.parts]) if self.parts else np.empty(0, dtype=bool)
+        self._empty = DeviceCSR(CSRPattern(np.zeros(1, np.int32), np.empty(0, np.int32),
+                                           (0, self.n_vars)), dv._empty(0))
+        vals = [p.rows.values(p.f0) for p in self.parts]
+        self.c_ineq0, self.c_eq0 = self._stack_values(vals)
+        self.J_ineq0, self.J_eq0 = self._stack_jacs([p.rows.jac(p.J0) for p in self.parts])
+        self.hess = self._hess if any(p.hess is not None for p in self.parts) else None
+
+    def _stack_values(self, pairs):
+        ineq = [a for a, _ in pairs if len(a)]
+        eq = [b for _, b in pairs if len(b)]
+        return (dv.hstack(ineq) if ineq else DVec.zeros(0),
+                dv.hstack(eq) if eq else DVec.zeros(0))
+
+    def _stack_jacs(self, pairs):
+        ineq = [a for a, _ in pairs if a.shape[0]]
+        eq = [b for _, b in pairs if b.shape[0]]
+        return (vstack_csr(ineq, self.n_vars) if ineq else self._empty,
+                vstack_csr(eq, self.n_vars) if eq else self._empty)
+
+    def constr(self, x):
+        return self._stack_values([p.rows.values(p.fun(x)) for p in self.parts])
+
+    def jac(self, x):
+        return self._stack_jacs([p.rows.jac(p.jac(x)) for p in self.parts])
+
+    def _hess(self, x, v_eq, v_ineq):
+        terms, i_eq, i_ineq = [], 0, 0
+        for p in self.parts:
+            if p.hess is not None:
+                v = p.rows.multipliers(v_eq[i_eq:i_eq + p.n_eq], v_ineq[i_ineq:i_ineq + p.n_ineq])
+                terms.append(_as_term(p.hess(x, v)))
+            i_eq += p.n_eq
+            i_ineq += p.n_ineq
+        return terms
+
+
+def _as_term(h):
+    """Normalise a Hessian callback's return value to a device term."""
+    from .operators import DeviceHessian
+    if h is None or isinstance(h, (DeviceCSR, DVec, DeviceHessian)):
+        return h
+    if torch.is_tensor(h) and h.dim() == 1:
+        return as_dvec(h)                      # diagonal
+    raise TypeError("device-callback mode: a Hessian callback must return a DeviceCSR, a 1-D "
+                    "CUDA tensor (diagonal) or a DeviceHessian, got %r" % type(h))
+
+
+def lagrangian_hessian(canonical, hess):
+    """Device twin of canonical.lagrangian_hessian (terms in hess_list order)."""
+    def lagr_hess(x, v_eq=None, v_ineq=None):
+        terms = []
+        if hess is not None:
+            terms.append(_as_term(hess(x.t)))
+        if canonical.hess is not None:
+            terms.extend(canonical.hess(x, v_eq if v_eq is not None else DVec.zeros(0),
+                                        v_ineq if v_ineq is not None else DVec.zeros(0)))
+        return HessianSum(len(x), [t for t in terms if t is not None])
+    return lagr_hess
+
+
+_aug_cache = {}
+
+
+def augmented_jacobian(J_eq, J_ineq, s, n_vars, n_eq, n_ineq):
+    """[[J_eq, 0], [J_ineq, diag(s)]] for DeviceCSR blocks: the pattern and the
+    destination index of every value are built once; a refresh is three scatters."""
+    key = (id(J_eq.pattern), id(J_ineq.pattern))
+    hit = _aug_cache.get(key)
+    if hit is None:
+        pe, pi = J_eq.pattern, J_ineq.pattern
+        ip_e, ip_i = pe.indptr_h.astype(np.int64), pi.indptr_h.astype(np.int64)
+        indptr = np.concatenate((ip_e, ip_e[-1] + ip_i[1:] + np.arange(1, n_ineq + 1)))
+        nnz = int(indptr[-1])
+        slots = indptr[n_eq + 1:] - 1
+        dst_i = (np.arange(pi.nnz) + ip_e[-1]
+                 + np.repeat(np.arange(n_ineq), np.diff(ip_i)))
+        indices = np.empty(nnz, dtype=np.int32)
+        indices[:pe.nnz] = pe.indices_h
+        indices[dst_i] = pi.indices_h
+        indices[slots] = n_vars + np.arange(n_ineq)
+        pat = CSRPattern(indptr.astype(np.int32), indices, (n_eq + n_ineq, n_vars + n_ineq))
+        hit = _aug_cache[key] = (pat, _idx(np.arange(pe.nnz)), _idx(dst_i), _idx(slots), pe, pi)
+    pat, dst_e, dst_i, slots = hit[:4]
+    val = dv._empty(pat.nnz)
+    if dst_e.numel():
+        scatter(J_eq.val, dst_e, val)
+    if dst_i.numel():
+        scatter(J_ineq.val, dst_i, val)
+    scatter(s.t, slots, val)
+    return DeviceCSR(pat, val)

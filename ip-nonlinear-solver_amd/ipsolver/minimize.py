@@ -75,6 +75,112 @@ def _print_iter(method, state):
     print(head + "".join(" {0:^1.2e} |".format(v) for v in vals))
 
 
+def _is_cuda_tensor(x):
+    try:
+        import torch
+    except ImportError:
+        return False
+    return torch.is_tensor(x) and x.is_cuda
+
+
+def _make_stop_criteria(method, gtol, xtol, max_iter, barrier_tol, callback, verbose, view):
+    """The two closures of _minimize_constrained.py:460-502 (status codes 0-3)."""
+    interior = method == 'tr_interior_point'
+
+    def stop_criteria(state):
+        if verbose >= 2:
+            _print_iter(method, state)
+        state.status = None
+        if callback is not None and callback(view(state)):
+            state.status = 3
+        elif state.optimality < gtol and state.constr_violation < gtol:
+            state.status = 1
+        elif state.trust_radius < xtol and (not interior
+                                            or state.barrier_parameter < barrier_tol):
+            state.status = 2
+        elif state.niter > max_iter:
+            state.status = 0
+        return state.status in (0, 1, 2, 3)
+    return stop_criteria
+
+
+def _minimize_device(fun, x0, grad, hess, constraints, method, xtol, gtol, options, callback,
+                     max_iter, verbose, xp):
+    """Device-callback mode: ``x0`` is a CUDA tensor, callbacks take and return
+    device objects (see device_mode.py); results carry CUDA tensors."""
+    from . import device_mode as dm
+    if xp.name != "hip":
+        raise RuntimeError("device-callback mode needs the HIP backend")
+    if hess in FD_METHODS:
+        raise NotImplementedError("finite-difference Hessians evaluate host callbacks; pass a "
+                                  "numpy x0, or give `hess` explicitly (a DeviceCSR / diagonal)")
+    x0_dev = dm.as_dvec(x0.detach().clone())
+    n_vars = len(x0_dev)
+    f0 = float(fun(x0_dev.t))
+    g0 = dm.as_dvec(grad(x0_dev.t))
+    if isinstance(constraints, (NonlinearConstraint, LinearConstraint, BoxConstraint)):
+        constraints = [constraints]
+    canon = dm.DeviceCanonical(list(constraints), x0_dev)
+    x0_dev = canon.x0
+    lagr = dm.lagrangian_hessian(canon, hess if callable(hess) else None)
+
+    state = OptimizeResult(niter=0, nfev=1, ngev=1, ncev=1, njev=1, nhev=0, cg_niter=0,
+                           cg_info={})
+    options = dict(options)
+    return_all = options.get("return_all", False)
+    if return_all:
+        state.allvecs, state.allmult = [], []
+    if method is None:
+        method = 'equality_constrained_sqp' if canon.n_ineq == 0 else 'tr_interior_point'
+    if method not in _METHODS:
+        raise ValueError("Unknown optimization ``method``.")
+    method = _METHODS[method]
+    barrier_tol = options.pop("barrier_tol", 1e-8)
+
+    def tensors(state):
+        view = OptimizeResult(state)
+        for k in _VECTOR_FIELDS:
+            if k in view and hasattr(view[k], "t"):
+                view[k] = view[k].t
+        return view
+    stop_criteria = _make_stop_criteria(method, gtol, xtol, max_iter, barrier_tol, callback,
+                                        verbose, tensors)
+    if verbose >= 2:
+        _print_header(method)
+    start_time = time.time()
+    if method == 'equality_constrained_sqp':
+        if canon.n_ineq > 0:
+            raise ValueError("'equality_constrained_sqp' does not support "
+                             "inequality constraints.")
+        result = equality_constrained_sqp(
+            lambda x: (float(fun(x.t)), canon.constr(x)[1]),
+            lambda x: (dm.as_dvec(grad(x.t)), canon.jac(x)[1]),
+            lambda x, v: xp.hessian_operator(lagr(x, v), n_vars, None),
+            x0_dev, f0, g0, canon.c_eq0, canon.J_eq0, stop_criteria, state, xp, **options)
+    else:
+        if canon.n_ineq == 0:
+            warn("The problem only has equality constraints. The solver "
+                 "'equality_constrained_sqp' is a better choice for those situations.")
+        result = tr_interior_point(
+            lambda x: float(fun(x.t)), lambda x: dm.as_dvec(grad(x.t)), lagr, n_vars,
+            canon.n_ineq, canon.n_eq, canon.constr, canon.jac, x0_dev, f0, g0, canon.c_ineq0,
+            canon.J_ineq0, canon.c_eq0, canon.J_eq0, stop_criteria, canon.enforce_feasibility,
+            xtol, state, xp, **options)
+    result.execution_time = time.time() - start_time
+    result.method = method
+    result.message = TERMINATION_MESSAGES[result.status]
+    for k in _VECTOR_FIELDS:
+        if k in result and hasattr(result[k], "t"):
+            result[k] = result[k].t
+    if return_all:
+        for k in ("allvecs", "allmult", "allslack"):
+            if k in result:
+                result[k] = [t.t for t in result[k]]
+    if verbose >= 1:
+        print(result.message)
+    return result
+
+
 def minimize_constrained(fun, x0, grad, hess='2-point', constraints=(), method=None,
                          xtol=1e-8, gtol=1e-8, sparse_jacobian=None, options={},
                          callback=None, max_iter=1000, verbose=0):
@@ -86,6 +192,9 @@ def minimize_constrained(fun, x0, grad, hess='2-point', constraints=(), method=N
     Returns a ``scipy.optimize.OptimizeResult`` with the reference's fields.
     """
     xp = _backend.get()
+    if _is_cuda_tensor(x0):
+        return _minimize_device(fun, x0, grad, hess, constraints, method, xtol, gtol, options,
+                                callback, max_iter, verbose, xp)
     x0 = np.atleast_1d(x0).astype(float)                     # :374-379
     n_vars = np.size(x0)
     f0 = fun(x0)

@@ -92,3 +92,55 @@ class CenteredBandedNLP:
         the reference when generating golden vectors)."""
         return ns.NonlinearConstraint(self.constr_fun, kind, self.constr_jac,
                                       self.constr_hess)
+
+
+class DeviceCallbacks:
+    """The same NLP with every callback on the GPU (device-callback mode of
+    ``minimize_constrained``): user-land code, so it uses torch elementwise ops
+    freely; matrix-vector products go through the library's DeviceCSR."""
+
+    def __init__(self, prob):
+        import torch
+        from .device import DeviceCSR, DVec
+        self.torch, self.DVec, self.DeviceCSR = torch, DVec, DeviceCSR
+        dev = torch.device("cuda", torch.cuda.current_device())
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
+        self.p = prob
+        self.Q = DeviceCSR.from_scipy(prob.Q)
+        self.A0 = DeviceCSR.from_scipy(prob.A0)
+        self.W = DeviceCSR(self.A0.pattern, t(prob.W.data))
+        self.Wt = self.W.T
+        self.col = self.A0.pattern.indices.long()
+        self.qdiag = torch.from_numpy(prob._qdiag).to(dev)
+        self.q, self.x_feas, self.b = t(prob.q), t(prob.x_feas), t(prob.b)
+        self.x0 = t(prob.x0)
+
+    def fun(self, x):
+        dl = x - self.x_feas
+        qd = self.Q.dot(self.DVec(dl)).t
+        return float(0.5 * dl.dot(qd) - self.p.eps * self.q.dot(dl)
+                     + 0.25 * self.p.rho * (dl ** 4).sum())
+
+    def grad(self, x):
+        dl = x - self.x_feas
+        return self.Q.dot(self.DVec(dl)).t - self.p.eps * self.q + self.p.rho * dl ** 3
+
+    def hess(self, x):
+        dl = x - self.x_feas
+        val = self.Q.val.clone()
+        val[self.qdiag] += 3 * self.p.rho * dl ** 2
+        return self.DeviceCSR(self.Q.pattern, val)
+
+    def constr_fun(self, x):
+        return (self.A0.dot(self.DVec(x)).t
+                + 0.5 * self.p.kappa * self.W.dot(self.DVec(x * x)).t - self.b)
+
+    def constr_jac(self, x):
+        return self.DeviceCSR(self.A0.pattern,
+                              self.A0.val + self.p.kappa * self.W.val * x[self.col])
+
+    def constr_hess(self, x, v):
+        return self.p.kappa * self.Wt.dot(self.DVec(v)).t        # diagonal
+
+    def constraints(self, ns, kind=('equals', 0)):
+        return ns.NonlinearConstraint(self.constr_fun, kind, self.constr_jac, self.constr_hess)

@@ -27,13 +27,25 @@ def cb(st):
 
 
 if cfg == "config3":
-    n = int(sys.argv[2]) if len(sys.argv) > 2 else 1000000
-    m = int(sys.argv[3]) if len(sys.argv) > 3 else 100000
+    nums = [a for a in sys.argv[2:] if not a.startswith("--")]
+    n = int(nums[0]) if len(nums) > 0 else 1000000
+    m = int(nums[1]) if len(nums) > 1 else 100000
     prob = CenteredBandedNLP(n, m, eps=1e-3)
-    t0 = time.time()
-    res = ipsolver.minimize_constrained(prob.fun, prob.x0, prob.grad, prob.hess,
-                                        prob.constraints(ipsolver), method="tr_interior_point",
-                                        callback=cb)
+    if "--device" in sys.argv:          # device-callback mode: x0 and callbacks on the GPU
+        import torch
+        from ipsolver.synthetic import DeviceCallbacks
+        dc = DeviceCallbacks(prob)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        res = ipsolver.minimize_constrained(dc.fun, dc.x0, dc.grad, dc.hess,
+                                            dc.constraints(ipsolver), method="tr_interior_point",
+                                            callback=cb)
+        cfg = "config3-device-callbacks"
+    else:
+        t0 = time.time()
+        res = ipsolver.minimize_constrained(prob.fun, prob.x0, prob.grad, prob.hess,
+                                            prob.constraints(ipsolver),
+                                            method="tr_interior_point", callback=cb)
 else:
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
     m = int(sys.argv[3]) if len(sys.argv) > 3 else 2000

@@ -104,3 +104,35 @@ def test_product_never_imports_the_oracle():
     out = subprocess.run([sys.executable, "-W", "ignore", "-c", code], capture_output=True,
                          text=True)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+
+
+# ---- device-callback mode (x0 is a CUDA tensor; nothing crosses PCIe) -------
+@pytest.mark.parametrize("method", ["tr_interior_point", "equality_constrained_sqp"])
+def test_device_callbacks_banded_equality(method, e2e_golden):
+    import torch
+    syn = load_synthetic()
+    prob = syn.CenteredBandedNLP(2000, 200, eps=1e-3)
+    from ipsolver.synthetic import DeviceCallbacks
+    dc = DeviceCallbacks(prob)
+    res, rows = run(dc.fun, dc.x0, dc.grad, dc.hess, dc.constraints(ipsolver), method=method)
+    assert torch.is_tensor(res.x) and res.x.is_cuda
+    gold = e2e_golden["banded_eq_n2000_%s" % method]
+    res.x = res.x.cpu().numpy()
+    compare(res, rows, gold, rtol=1e-6)
+
+
+def test_device_callbacks_box_inequality(e2e_golden):
+    import torch
+    syn = load_synthetic()
+    prob = syn.CenteredBandedNLP(400, 40, eps=1.0)
+    from ipsolver.synthetic import DeviceCallbacks
+    dc = DeviceCallbacks(prob)
+    cons = (dc.constraints(ipsolver, ("less", 0.0)),
+            ipsolver.BoxConstraint(("interval", -0.8, 0.8)))
+    res, rows = run(dc.fun, dc.x0, dc.grad, dc.hess, cons)
+    gold = e2e_golden["banded_ineq_n400"]
+    assert res.status == gold["status"]
+    compare(res, rows, gold, rtol=1e-6, prefix=12)
+    gx = np.asarray(unjson(gold["x"]))
+    assert np.allclose(res.x.cpu().numpy()[::max(1, 400 // 50)], gx, atol=1e-5)
+    assert res.s.shape[0] == 840 and res.s.is_cuda
