@@ -210,6 +210,26 @@ int ipx_cg_step2(int64_t n, double *state, int32_t it, int32_t mode, const doubl
 /* Finish iteration `it` after the host handled a stop-5/6 event. */
 int ipx_cg_resume(const ipx_cg_args *a, int32_t it, int32_t mode, void *stream);
 
+/* band of (P A) diag(wcol) (P A)' (column weights; wcol NULL = ones). */
+int ipx_aat_band_w(int64_t m, int32_t k, const int32_t *rowptr, const int32_t *colidx,
+                   const double *val, const int32_t *perm, const double *wcol, double *band,
+                   void *stream);
+
+/* ---- analytic elimination of box-like rows of A A' (csrc/boxschur.hip): groups
+ * of one or two rows that touch the same shared column (plus a private entry
+ * each).  factor: 1x1 / 2x2 inverses, the rows' shared-column entries (alpha)
+ * and the Schur column weights 1 - alpha'B^-1 alpha; tsolve: t = B^-1 w on those
+ * rows and u[col] = alpha't; vsolve: v = t - B^-1 (alpha * y[col]). */
+int ipx_pairs_factor(int32_t ng, const int32_t *rowp, const int32_t *rowq, const int32_t *pos_a,
+                     const int32_t *pos_s, const double *val, const int32_t *col, double *alpha,
+                     double *inv, double *weight_col, int *flag, void *stream);
+int ipx_pairs_tsolve(int32_t ng, const int32_t *rowp, const int32_t *rowq, const double *inv,
+                     const double *alpha, const double *w, double *t, const int32_t *col,
+                     double *u, void *stream);
+int ipx_pairs_vsolve(int32_t ng, const int32_t *rowp, const int32_t *rowq, const double *inv,
+                     const double *alpha, const double *t, const double *y, const int32_t *col,
+                     double *v, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

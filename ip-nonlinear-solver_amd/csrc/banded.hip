@@ -400,7 +400,7 @@ k_correct_oop(int m, int c, int P, const double *__restrict__ V, const double *_
 __global__ void __launch_bounds__(IPX_BLOCK)
 k_aat_band(int m, int k, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
            const double *__restrict__ val, const int32_t *__restrict__ perm,
-           double *__restrict__ band) {
+           const double *__restrict__ wcol, double *__restrict__ band) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (int64_t)m * (k + 1)) return;
   const int d = (int)(idx / m), i = (int)(idx % m);
@@ -411,7 +411,7 @@ k_aat_band(int m, int k, const int32_t *__restrict__ rowptr, const int32_t *__re
     int u = rowptr[r2], ue = rowptr[r2 + 1];
     while (p < pe && u < ue) {
       const int cp = colidx[p], cu = colidx[u];
-      if (cp == cu) { s += val[p] * val[u]; ++p; ++u; }
+      if (cp == cu) { s += wcol ? val[p] * val[u] * wcol[cp] : val[p] * val[u]; ++p; ++u; }
       else if (cp < cu) ++p;
       else ++u;
     }
@@ -997,16 +997,22 @@ int ipx_banded_solve(void *handle, const double *w, double *x, void *stream) {
 
 // band[d*m+i] = (A A')[pi, p(i-d)] with rows taken in the order perm (NULL =
 // identity); reference: the matrix CHOLMOD factors in projections.py:62.
-int ipx_aat_band(int64_t m, int32_t k, const int32_t *rowptr, const int32_t *colidx,
-                 const double *val, const int32_t *perm, double *band, void *stream) {
+int ipx_aat_band_w(int64_t m, int32_t k, const int32_t *rowptr, const int32_t *colidx,
+                   const double *val, const int32_t *perm, const double *wcol, double *band,
+                   void *stream) {
   if (m < 0 || k < 0 || !rowptr || !band) return IPX_EINVAL;
   if (m == 0) return IPX_OK;
   int64_t tot = m * (k + 1);
   hipLaunchKernelGGL(k_aat_band, dim3((unsigned)((tot + IPX_BLOCK - 1) / IPX_BLOCK)),
                      dim3(IPX_BLOCK), 0, (hipStream_t)stream, (int)m, k, rowptr, colidx, val, perm,
-                     band);
+                     wcol, band);
   IPX_CHECK_LAUNCH();
   return IPX_OK;
+}
+
+int ipx_aat_band(int64_t m, int32_t k, const int32_t *rowptr, const int32_t *colidx,
+                 const double *val, const int32_t *perm, double *band, void *stream) {
+  return ipx_aat_band_w(m, k, rowptr, colidx, val, perm, nullptr, band, stream);
 }
 
 }  // extern "C"

@@ -1,0 +1,140 @@
+"""``(A A')^-1`` with the box-like rows of ``A`` eliminated analytically
+(kernels in csrc/boxschur.hip).
+
+Barrier problems with bounds on the variables (BASELINE config 5) put two rows
+``-e_j' + s_lb``, ``+e_j' + s_ub`` per bounded variable into the augmented
+Jacobian.  They make ``A A'`` wide (half bandwidth ~40 for the banded
+benchmark, 1e6 rows) although they only couple pairwise and through one
+column.  Here such *simple* rows -- exactly one entry in a column shared with
+other rows plus at most one entry in a private column -- are grouped per
+shared column (one or two rows per group) and eliminated in closed form; what
+remains is ``Sigma = A_R diag(w) A_R'`` over the general rows, which keeps the
+band of ``A_R A_R'`` and goes to the partitioned banded solver.
+
+The classification is symbolic (sparsity pattern only, once per pattern on the
+host); all arithmetic is on the device.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _hip
+from . import device as dv
+from .device import DVec, DeviceCSR, _p, stream_ptr, ctx
+
+_F64 = torch.float64
+
+
+def _i32(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(ctx().device)
+
+
+class BoxRowAnalysis:
+    """Pattern-level split of the rows of A into simple (grouped) and general."""
+
+    def __init__(self, pattern):
+        m, n = pattern.shape
+        indptr, indices = pattern.indptr_h.astype(np.int64), pattern.indices_h
+        nnz_row = np.diff(indptr)
+        col_count = np.bincount(indices, minlength=n)
+        private = col_count[indices] == 1                     # per nonzero
+        csum = np.concatenate(([0], np.cumsum(~private)))
+        shared_in_row = csum[indptr[1:]] - csum[indptr[:-1]]
+        simple = (nnz_row >= 1) & (nnz_row <= 2) & (shared_in_row == 1)
+        # position of the shared / private entry of every simple row
+        pos_a = np.full(m, -1, dtype=np.int64)
+        pos_s = np.full(m, -1, dtype=np.int64)
+        rows_of_nz = np.repeat(np.arange(m), nnz_row)
+        nz = np.arange(len(indices))
+        sel = simple[rows_of_nz]
+        pos_a[rows_of_nz[sel & ~private]] = nz[sel & ~private]
+        pos_s[rows_of_nz[sel & private]] = nz[sel & private]
+        shared_col = np.where(simple, indices[np.maximum(pos_a, 0)], -1)
+        # groups: shared columns with one or two simple rows; more -> general rows
+        srows = np.flatnonzero(simple)
+        order = np.argsort(shared_col[srows], kind="stable")
+        srows = srows[order]
+        cols, start, count = np.unique(shared_col[srows], return_index=True, return_counts=True)
+        ok = count <= 2
+        demoted = np.concatenate([srows[s:s + c] for s, c in zip(start[~ok], count[~ok])]) \
+            if (~ok).any() else np.empty(0, dtype=np.int64)
+        simple[demoted] = False
+        self.col = cols[ok].astype(np.int32)
+        self.rowp = srows[start[ok]].astype(np.int32)
+        self.rowq = np.where(count[ok] == 2, srows[np.minimum(start[ok] + 1, len(srows) - 1)],
+                             -1).astype(np.int32)
+        self.pos_a, self.pos_s = pos_a.astype(np.int32), pos_s.astype(np.int32)
+        self.general = np.flatnonzero(~simple).astype(np.int64)
+        self.n_simple = int(simple.sum())
+        self.m, self.n = m, n
+
+    @property
+    def worthwhile(self):
+        return self.n_simple >= max(8, self.m // 4) and len(self.general) > 0
+
+
+_ANALYSIS_ATTR = "_ipx_box_analysis"
+
+
+def analysis_for(pattern):
+    a = getattr(pattern, _ANALYSIS_ATTR, None)
+    if a is None:
+        a = BoxRowAnalysis(pattern)
+        setattr(pattern, _ANALYSIS_ATTR, a)
+    return a
+
+
+class BoxSchurNormalSolver:
+    """(A A')^-1 through per-variable elimination of the simple rows and a
+    banded solve on the Schur complement of the general rows."""
+
+    def __init__(self, A):
+        from .device_mode import RowSelection
+        from .projector import BandedNormalSolver
+        an = analysis_for(A.pattern)
+        self.an, self.m, self.n = an, an.m, an.n
+        pat = A.pattern
+        cache = getattr(pat, "_ipx_box_device", None)
+        if cache is None:
+            sel = getattr(pat, "_ipx_box_general_pattern", None) or RowSelection(pat, an.general,
+                                                                                None)
+            pat._ipx_box_general_pattern = sel
+            cache = pat._ipx_box_device = {
+                "rowp": _i32(an.rowp), "rowq": _i32(an.rowq), "col": _i32(an.col),
+                "pos_a": _i32(an.pos_a), "pos_s": _i32(an.pos_s),
+                "general": _i32(an.general),
+                "sel": sel}
+        self.c = cache
+        self.ng = len(an.col)
+        dev = ctx().device
+        self.alpha = torch.zeros(self.m, dtype=_F64, device=dev)
+        self.inv = torch.empty(3 * max(self.ng, 1), dtype=_F64, device=dev)
+        self.wcol = torch.ones(self.n, dtype=_F64, device=dev)
+        flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        st = stream_ptr()
+        _hip.call("ipx_pairs_factor", self.ng, _p(cache["rowp"]), _p(cache["rowq"]),
+                  _p(cache["pos_a"]), _p(cache["pos_s"]), _p(A.val), _p(cache["col"]),
+                  _p(self.alpha), _p(self.inv), _p(self.wcol), _p(flag), st)
+        self.A_R = cache["sel"].apply(A)                 # general rows (value gather)
+        self.inner = BandedNormalSolver(self.A_R, col_weights=self.wcol)   # Sigma = A_R W A_R'
+        if int(flag.item()) != 0:
+            raise np.linalg.LinAlgError("Singular Jacobian matrix: A A' is not positive definite")
+        self.u = torch.zeros(self.n, dtype=_F64, device=dev)      # only grouped columns are written
+        self.t = torch.zeros(self.m, dtype=_F64, device=dev)
+
+    def solve(self, w):
+        c, st = self.c, stream_ptr()
+        _hip.call("ipx_pairs_tsolve", self.ng, _p(c["rowp"]), _p(c["rowq"]), _p(self.inv),
+                  _p(self.alpha), _p(w.t), _p(self.t), _p(c["col"]), _p(self.u), st)
+        mR = len(self.an.general)
+        w_R = dv._empty(mR)
+        _hip.call("ipx_gather", mR, _p(w.t), _p(c["general"]), None, None, _p(w_R), st)
+        rhs = self.A_R.spmv(DVec(self.u), alpha=-1.0, beta=1.0, yin=DVec(w_R))
+        v_R = self.inner.solve(rhs)
+        y = self.A_R.T.dot(v_R)
+        v = dv._empty(self.m)
+        _hip.call("ipx_pairs_vsolve", self.ng, _p(c["rowp"]), _p(c["rowq"]), _p(self.inv),
+                  _p(self.alpha), _p(self.t), _p(y.t), _p(c["col"]), _p(v), st)
+        _hip.call("ipx_scatter", mR, _p(v_R.t), _p(c["general"]), _p(v), st)
+        return DVec(v)

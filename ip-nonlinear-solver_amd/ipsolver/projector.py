@@ -69,7 +69,9 @@ def _symbolic_for(pattern):
 class BandedNormalSolver:
     """(A A')^-1 for sparse A with banded A A' (half bandwidth <= kmax)."""
 
-    def __init__(self, A, chunk=64):
+    def __init__(self, A, chunk=64, col_weights=None):
+        """``col_weights`` (device tensor, one per column of A) factors
+        ``A diag(w) A'`` instead (Schur complements, boxschur.py)."""
         sym = _symbolic_for(A.pattern)
         kmax = _hip.load().ipx_banded_kmax()
         if sym.k > kmax:
@@ -91,8 +93,8 @@ class BandedNormalSolver:
         if not self.handle:
             raise _hip.IpxError("ipx_banded_create failed (m=%d, k=%d)" % (self.m, self.k))
         p = A.pattern
-        _hip.call("ipx_aat_band", self.m, self.k, _p(p.indptr), _p(p.indices), _p(A.val),
-                  _p(self.perm), _p(self.band), stream_ptr())
+        _hip.call("ipx_aat_band_w", self.m, self.k, _p(p.indptr), _p(p.indices), _p(A.val),
+                  _p(self.perm), _p(col_weights), _p(self.band), stream_ptr())
         _hip.call("ipx_banded_factor", ctypes.c_void_p(self.handle), _p(self.band), stream_ptr())
         rc = lib.ipx_banded_status(ctypes.c_void_p(self.handle), stream_ptr())
         if rc == -3:
@@ -213,6 +215,19 @@ def orthogonality(A, g):
     return dv.norm(A.dot(g)) / (norm_A * norm_g)
 
 
+def _box_schur_applies(A, kmax):
+    """Pattern test: enough box-like rows, and the general rows alone are banded."""
+    from .boxschur import analysis_for
+    from .device_mode import RowSelection
+    an = analysis_for(A.pattern)
+    if not an.worthwhile:
+        return False
+    cache = getattr(A.pattern, "_ipx_box_general_pattern", None)
+    if cache is None:
+        cache = A.pattern._ipx_box_general_pattern = RowSelection(A.pattern, an.general, None)
+    return _symbolic_for(cache.pattern).k <= kmax
+
+
 def as_device_matrix(A):
     """Upload a scipy sparse matrix / ndarray (device matrices pass through).
     An empty matrix is forced to the sparse representation like the
@@ -247,8 +262,12 @@ def projections(A, method=None, orth_tol=1e-12, max_refin=3, tol=1e-15):
     if m == 0:
         solver = None
     elif sparse:
-        if _symbolic_for(A.pattern).k <= _hip.load().ipx_banded_kmax():
+        kmax = _hip.load().ipx_banded_kmax()
+        if _symbolic_for(A.pattern).k <= kmax:
             solver = BandedNormalSolver(A)
+        elif _box_schur_applies(A, kmax):
+            from .boxschur import BoxSchurNormalSolver
+            solver = BoxSchurNormalSolver(A)    # bound rows eliminated analytically, banded rest
         elif m <= DenseNormalSolver.MAX_ROWS_FROM_SPARSE:
             solver = DenseNormalSolver(A)       # wide band: dense Cholesky of A A' on the device
         else:
