@@ -184,6 +184,7 @@ typedef struct ipx_cg_args {
   double *state;
   double *part1, *part2, *part3, *part4;
   int64_t vec_grid;
+  int64_t solver_kind;   /* 0: `banded` is an ipx_banded handle; 1: an ipx_boxschur_args* */
 } ipx_cg_args;
 int ipx_cg_state_size(void);
 int ipx_cg_vec_grid(int64_t n);
@@ -229,6 +230,20 @@ int ipx_pairs_tsolve(int32_t ng, const int32_t *rowp, const int32_t *rowq, const
 int ipx_pairs_vsolve(int32_t ng, const int32_t *rowp, const int32_t *rowq, const double *inv,
                      const double *alpha, const double *t, const double *y, const int32_t *col,
                      double *v, void *stream);
+
+/* Prepared argument block of one box-Schur (A A')^-1 (all members 8 bytes). */
+typedef struct ipx_boxschur_args {
+  int64_t m, n, ng, mR;
+  const int32_t *rowp, *rowq, *col, *general;
+  const double *inv, *alpha;
+  const int32_t *AR_rowptr, *AR_colidx; const double *AR_val; const int32_t *AR_tiles; int64_t AR_ntiles;
+  const int32_t *ARt_rowptr, *ARt_colidx; const double *ARt_val; const int32_t *ARt_tiles; int64_t ARt_ntiles;
+  void *inner;                       /* ipx_banded handle of the Schur complement */
+  double *t, *u, *wR, *rhs, *vR, *y; /* scratch: m, n, mR, mR, mR, n doubles */
+} ipx_boxschur_args;
+/* v = (A A')^-1 w; partial (optional, ceil(mR/256) doubles) receives the residual partials. */
+int ipx_boxschur_solve(const ipx_boxschur_args *a, const double *w, double *v, double *partial,
+                       int32_t *npartial, const double *guard, void *stream);
 
 #ifdef __cplusplus
 }

@@ -144,4 +144,39 @@ int ipx_pairs_vsolve(int32_t ng, const int32_t *rowp, const int32_t *rowq, const
   return IPX_OK;
 }
 
+// One (A A')^-1 application from a prepared argument block (every pointer is a
+// device pointer; see ipsolver/boxschur.py which owns the buffers), plus the
+// per-workgroup partials of the normal-equation residual.  The eliminated
+// rows satisfy their equations exactly by construction, so the residual of
+// the whole system is the residual of the Schur system on the general rows.
+int ipx_boxschur_solve(const ipx_boxschur_args *a, const double *w, double *v, double *partial,
+                       int32_t *npartial, const double *guard, void *stream) {
+  if (!a || !w || !v) return IPX_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  int rc = ipx_pairs_tsolve((int)a->ng, a->rowp, a->rowq, a->inv, a->alpha, w, a->t, a->col, a->u, st);
+  if (rc) return rc;
+  rc = ipx_gather(a->mR, w, a->general, nullptr, nullptr, a->wR, st);
+  if (rc) return rc;
+  ipx_csr_view AR{(int)a->mR, (int)a->n, a->AR_rowptr, a->AR_colidx, a->AR_val, a->AR_tiles,
+                  (int)a->AR_ntiles};
+  ipx_csr_view ARt{(int)a->n, (int)a->mR, a->ARt_rowptr, a->ARt_colidx, a->ARt_val, a->ARt_tiles,
+                   (int)a->ARt_ntiles};
+  // rhs = w_R - A_R u
+  rc = ipx_spmv_launch(AR, a->u, -1.0, nullptr, 1.0, a->wR, a->rhs, nullptr, guard, st);
+  if (rc) return rc;
+  int np = 0;
+  if (partial)
+    rc = ipx_banded_solve_resid_launch(a->inner, a->rhs, a->vR, partial, &np, guard, st);
+  else
+    rc = ipx_banded_solve_guarded(a->inner, a->rhs, a->vR, guard, st);
+  if (rc) return rc;
+  if (npartial) *npartial = np;
+  // y = A_R' v_R
+  rc = ipx_spmv_launch(ARt, a->vR, 1.0, nullptr, 0.0, nullptr, a->y, nullptr, guard, st);
+  if (rc) return rc;
+  rc = ipx_pairs_vsolve((int)a->ng, a->rowp, a->rowq, a->inv, a->alpha, a->t, a->y, a->col, v, st);
+  if (rc) return rc;
+  return ipx_scatter(a->mR, a->vR, a->general, v, st);
+}
+
 }  // extern "C"

@@ -343,7 +343,11 @@ static int cg_iterate(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, hi
       // v = (AA')^-1 w, and ||A g||^2 for the orthogonality test as the
       // constraint-space residual ||w - (A A') v||^2 from the same launch
       // (see k_correct_oop / k_band_residual); part4 holds ceil(m/256) doubles
-      rc = ipx_banded_solve_resid_launch(a->banded, a->w, a->v, a->part4, &np4, guard, st);
+      if (a->solver_kind == 1)
+        rc = ipx_boxschur_solve((const ipx_boxschur_args *)a->banded, a->w, a->v, a->part4, &np4,
+                                guard, st);
+      else
+        rc = ipx_banded_solve_resid_launch(a->banded, a->w, a->v, a->part4, &np4, guard, st);
       if (rc) return rc;
       MARK(3);
       // r = r - A'v  (g_next), partials of ||g||^2

@@ -85,6 +85,20 @@ def analysis_for(pattern):
     return a
 
 
+_P, _I64 = ctypes.c_void_p, ctypes.c_int64
+
+
+class BoxSchurArgs(ctypes.Structure):
+    """Mirror of ipx_boxschur_args (include/ipx.h)."""
+    _fields_ = [(k, _I64) for k in ("m", "n", "ng", "mR")] + \
+               [(k, _P) for k in ("rowp", "rowq", "col", "general", "inv", "alpha")] + \
+               [("AR_rowptr", _P), ("AR_colidx", _P), ("AR_val", _P), ("AR_tiles", _P),
+                ("AR_ntiles", _I64),
+                ("ARt_rowptr", _P), ("ARt_colidx", _P), ("ARt_val", _P), ("ARt_tiles", _P),
+                ("ARt_ntiles", _I64), ("inner", _P)] + \
+               [(k, _P) for k in ("t", "u", "wR", "rhs", "vR", "y")]
+
+
 class BoxSchurNormalSolver:
     """(A A')^-1 through per-variable elimination of the simple rows and a
     banded solve on the Schur complement of the general rows."""
@@ -122,6 +136,38 @@ class BoxSchurNormalSolver:
             raise np.linalg.LinAlgError("Singular Jacobian matrix: A A' is not positive definite")
         self.u = torch.zeros(self.n, dtype=_F64, device=dev)      # only grouped columns are written
         self.t = torch.zeros(self.m, dtype=_F64, device=dev)
+        self._args = None
+
+    perm = None        # rows are taken in the caller's order (cg_fused.supports)
+
+    def c_args(self):
+        """Argument block for ipx_boxschur_solve (the device-resident CG loop);
+        None when the Schur system needs a row permutation."""
+        if self.inner.perm is not None:
+            return None
+        if self._args is None:
+            mR, dev = len(self.an.general), ctx().device
+            self._scratch = [torch.zeros(k, dtype=_F64, device=dev) for k in (mR, mR, mR, self.n)]
+            a = BoxSchurArgs()
+            a.m, a.n, a.ng, a.mR = self.m, self.n, self.ng, mR
+            c = self.c
+            a.rowp, a.rowq, a.col = (c[k].data_ptr() for k in ("rowp", "rowq", "col"))
+            a.general = c["general"].data_ptr()
+            a.inv, a.alpha = self.inv.data_ptr(), self.alpha.data_ptr()
+            ARt = self.A_R.T
+            self._keep = ARt
+            for pre, M in (("AR", self.A_R), ("ARt", ARt)):
+                pat = M.pattern
+                setattr(a, pre + "_rowptr", pat.indptr.data_ptr())
+                setattr(a, pre + "_colidx", pat.indices.data_ptr())
+                setattr(a, pre + "_val", M.val.data_ptr() if M.val.numel() else None)
+                setattr(a, pre + "_tiles", pat.tiles.data_ptr())
+                setattr(a, pre + "_ntiles", pat.ntiles)
+            a.inner = self.inner.handle
+            a.t, a.u = self.t.data_ptr(), self.u.data_ptr()
+            a.wR, a.rhs, a.vR, a.y = (t.data_ptr() for t in self._scratch)
+            self._args = a
+        return self._args
 
     def solve(self, w):
         c, st = self.c, stream_ptr()

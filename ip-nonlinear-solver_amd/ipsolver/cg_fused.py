@@ -36,7 +36,12 @@ class CgArgs(ctypes.Structure):
         ("w", _P), ("v", _P), ("t", _P),
         ("lb", _P), ("ub", _P), ("state", _P),
         ("part1", _P), ("part2", _P), ("part3", _P), ("part4", _P),
-        ("vec_grid", _I64))]
+        ("vec_grid", _I64), ("solver_kind", _I64))]
+
+
+# Counters over the life of the process (diagnostics: how often the device loop
+# had to hand an iteration back to the host).
+STATS = {"calls": 0, "iterations": 0, "batches": 0, "box_events": 0, "refine_events": 0}
 
 
 def _hessian_parts(H):
@@ -49,14 +54,25 @@ def _hessian_parts(H):
     return None
 
 
+def _solver_kind(solver):
+    """0: banded handle, 1: box-Schur argument block, None: not usable here."""
+    from .projector import BandedNormalSolver
+    from .boxschur import BoxSchurNormalSolver
+    if isinstance(solver, BandedNormalSolver):
+        return 0 if solver.perm is None else None
+    if isinstance(solver, BoxSchurNormalSolver):
+        return 1 if solver.c_args() is not None else None
+    return None
+
+
 def supports(H, Z, Y):
-    from .projector import BandedNormalSolver, NormalEquationProjector
+    from .projector import NormalEquationProjector
     P = getattr(Z, "projector", None)
     if P is None or getattr(Y, "projector", None) is not P:
         return False
     if not isinstance(P, NormalEquationProjector) or not isinstance(P.A, DeviceCSR):
         return False
-    if P.m == 0 or not isinstance(P.solver, BandedNormalSolver) or P.solver.perm is not None:
+    if P.m == 0 or _solver_kind(P.solver) is None:
         return False
     return _hessian_parts(H) is not None
 
@@ -101,7 +117,11 @@ class _Loop:
             setattr(a, pre + "_tiles", _ptr(pat.tiles))
             setattr(a, pre + "_ntiles", pat.ntiles)
         a.H_diag = _ptr(Hd.t) if Hd is not None else None
-        a.banded = ctypes.c_void_p(P.solver.handle)
+        a.solver_kind = _solver_kind(P.solver)
+        if a.solver_kind == 1:
+            a.banded = ctypes.cast(ctypes.pointer(P.solver.c_args()), ctypes.c_void_p)
+        else:
+            a.banded = ctypes.c_void_p(P.solver.handle)
         for name in ("x", "p", "r", "Hp", "w", "v", "t", "state",
                      "part1", "part2", "part3", "part4"):
             setattr(a, name, _ptr(getattr(self, name)))
@@ -170,6 +190,7 @@ def projected_cg(H, c, Z, Y, b, trust_radius=np.inf, lb=None, ub=None, tol=None,
         end = min(max_iter, it + nbatch)
         _hip.check(lib.ipx_cg_iterate(L.ref(), it, end, st), "ipx_cg_iterate")
         s = L.state.tolist()             # one blocking read per batch
+        STATS["batches"] += 1
         if stats is not None:
             stats["batches"] = stats.get("batches", 0) + 1
         stop = int(s[ST_STOP])
@@ -206,6 +227,7 @@ def projected_cg(H, c, Z, Y, b, trust_radius=np.inf, lb=None, ub=None, tol=None,
             break
         mode = 0
         if stop == 5:                     # :599-616 x_next outside the box
+            STATS["box_events"] += 1
             if last_viol_it != it_stop - 1:
                 counter = 0
             counter += 1
@@ -229,6 +251,7 @@ def projected_cg(H, c, Z, Y, b, trust_radius=np.inf, lb=None, ub=None, tol=None,
                 it = it_stop + 1
                 continue
         if stop == 6:                     # projections.py:72-78 refinement
+            STATS["refine_events"] += 1
             _refine(P, L, R)
             s2 = _resume(lib, L, it_stop, mode | 2, st)
             it = it_stop + 1
@@ -240,6 +263,8 @@ def projected_cg(H, c, Z, Y, b, trust_radius=np.inf, lb=None, ub=None, tol=None,
         x = last_feasible_x
         hits_boundary = True
     niter = int(L.state[ST_NITER].item())
+    STATS["calls"] += 1
+    STATS["iterations"] += niter
     return x, {'niter': niter, 'stop_cond': stop_cond, 'hits_boundary': hits_boundary}
 
 

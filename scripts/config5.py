@@ -26,4 +26,5 @@ print(json.dumps({"n": n, "m": m, "status": int(res.status), "niter": int(res.ni
                   "barrier_parameter": float(res.barrier_parameter), "wall_s": wall,
                   "cg_it_per_s": res.cg_niter / wall,
                   "active_bounds": int(np.sum(np.abs(np.abs(x) - 0.8) < 1e-6)),
-                  "fun": float(res.fun)}))
+                  "fun": float(res.fun),
+                  "fused_cg_stats": __import__("ipsolver.cg_fused", fromlist=["STATS"]).STATS}))
