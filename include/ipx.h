@@ -164,6 +164,9 @@ int ipx_banded_solve(void *handle, const double *w, double *x, void *stream);
 int ipx_banded_solve_guarded_c(void *handle, const double *w, double *x, const double *guard,
                                void *stream);
 /* One-kernel-per-level variant of the same solve (cross-check / LDS fallback). */
+/* solve + per-workgroup partials of ||w - (A A') x||^2 (ceil(m/256) doubles). */
+int ipx_banded_solve_resid(void *handle, const double *w, double *x, double *partial,
+                           int32_t *npartial, const double *guard, void *stream);
 int ipx_banded_solve_multilaunch(void *handle, const double *w, double *x, void *stream);
 /* band of (P A)(P A)' for CSR A with row order perm (NULL = identity). */
 int ipx_aat_band(int64_t m, int32_t k, const int32_t *rowptr, const int32_t *colidx,
@@ -208,6 +211,21 @@ int ipx_cg_step1(int64_t n, double *state, int32_t it, const double *p1, int32_t
 int ipx_cg_step2(int64_t n, double *state, int32_t it, int32_t mode, const double *p2,
                  int32_t np2, const double *p3, int32_t np3, const double *p4, int32_t np4,
                  double *x, double *p, const double *g, int32_t grid, void *stream);
+/* Row-sharded loop: halo_pack writes the first/last h entries of the local g
+ * into slot `rank` of out[world][2h] and zeroes the other slots (an all-reduce
+ * of `out` then gathers every rank's boundary values); halo_apply performs
+ * p = beta p - g on the hl / hr halo copies next to the owned block, a no-op
+ * unless step2 completed (state stop code 0). */
+int ipx_cg_halo_pack(int64_t n, int32_t h, int32_t rank, int32_t world, const double *g,
+                     double *out, void *stream);
+/* One launch for a rank's whole contribution to the packed all-reduce:
+ * out[0..4) = sums of part2[0..np2), part2[np2..2np2), part3[0..np3),
+ * part3[np3..2np3); out[4..4+2h*world) = halo_pack(g). */
+int ipx_cg_shard_pack(const double *part2, int32_t np2, const double *part3, int32_t np3,
+                      int64_t n, int32_t h, int32_t rank, int32_t world, const double *g,
+                      double *out, void *stream);
+int ipx_cg_halo_apply(const double *state, int32_t hl, int32_t hr, const double *g_left,
+                      const double *g_right, double *p_left, double *p_right, void *stream);
 /* Finish iteration `it` after the host handled a stop-5/6 event. */
 int ipx_cg_resume(const ipx_cg_args *a, int32_t it, int32_t mode, void *stream);
 

@@ -1176,6 +1176,18 @@ extern "C" int ipx_banded_solve_guarded_c(void *handle, const double *w, double 
   return ipx_banded_solve_guarded(handle, w, x, guard, (hipStream_t)stream);
 }
 
+// Solve plus the per-workgroup partial sums of ||w - (A A') x||^2 (the
+// constraint-space form of the orthogonality test);
+// partial needs ceil(m / 256) doubles, *npartial receives how many were written.
+extern "C" int ipx_banded_solve_resid(void *handle, const double *w, double *x, double *partial,
+                                      int32_t *npartial, const double *guard, void *stream) {
+  if (!partial || !npartial) return IPX_EINVAL;
+  int np = 0;
+  int rc = ipx_banded_solve_resid_launch(handle, w, x, partial, &np, guard, (hipStream_t)stream);
+  *npartial = np;
+  return rc;
+}
+
 // The original one-kernel-per-level sweep (kept for cross-checking the fast
 // path and as the fallback when a level does not fit in LDS).
 extern "C" int ipx_banded_solve_multilaunch(void *handle, const double *w, double *x,

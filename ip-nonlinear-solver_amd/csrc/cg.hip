@@ -180,6 +180,56 @@ k_cg_step2(int64_t n, double *st, int parity, int mode, const double *__restrict
   }
 }
 
+// Row-sharded loop (ipsolver/sharded.py): the first and last h entries of the
+// local g go into this rank's slot of a [world][2h] buffer whose other slots
+// are zeroed, so that the sum over ranks (all-reduce) is a gather of every
+// rank's boundary values -- they travel with the packed scalars instead of a
+// separate neighbour exchange.
+__global__ void __launch_bounds__(256)
+k_cg_halo_pack(int64_t n, int h, int rank, int world, const double *__restrict__ g,
+               double *__restrict__ out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= 2 * h * world) return;
+  const int q = idx / (2 * h), j = idx % (2 * h);
+  double v = 0.0;
+  if (q == rank) v = j < h ? g[j] : g[n - 2 * h + j];
+  out[idx] = v;
+}
+
+// The whole per-rank contribution to the second all-reduce of an iteration in
+// one launch: out[0..4) = folded partials (||x+ap||^2, #violations, ||g||^2,
+// g'r), out[4..) = boundary slots as in k_cg_halo_pack.
+__global__ void __launch_bounds__(256)
+k_cg_shard_pack(const double *__restrict__ p2, int np2, const double *__restrict__ p3, int np3,
+                int64_t n, int h, int rank, int world, const double *__restrict__ g,
+                double *__restrict__ out) {
+  __shared__ double lds[4 * 4];
+  const double *const parts[4] = {p2, p2 + np2, p3, p3 + np3};
+  const int counts[4] = {np2, np2, np3, np3};
+  double red[4];
+  ipx_sum_partials_multi<4>(parts, counts, lds, red);
+  if (threadIdx.x < 4) out[threadIdx.x] = red[threadIdx.x];
+  for (int idx = threadIdx.x; idx < 2 * h * world; idx += blockDim.x) {
+    const int q = idx / (2 * h), j = idx % (2 * h);
+    double v = 0.0;
+    if (q == rank) v = j < h ? g[j] : g[n - 2 * h + j];
+    out[4 + idx] = v;
+  }
+}
+
+// p = beta p - g on the halo copies of the neighbours' boundary entries: the
+// same expression k_cg_step2 applies to the owned entries, so owner and copy
+// stay bit-identical.  No-op unless step2 completed its update.
+__global__ void __launch_bounds__(256)
+k_cg_halo_apply(const double *__restrict__ st, int hl, int hr, const double *__restrict__ gl,
+                const double *__restrict__ gr, double *pl, double *pr) {
+  if (st[ST_STOP] != 0.0) return;
+  const double beta = st[ST_BETA];
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < hl) pl[t] = beta * pl[t] - gl[t];
+  if (t < hr) pr[t] = beta * pr[t] - gr[t];
+}
+
 }  // namespace
 
 extern "C" {
@@ -212,6 +262,42 @@ int ipx_cg_step2(int64_t n, double *state, int32_t it, int32_t mode, const doubl
   if (n < 0 || !state || grid < 1) return IPX_EINVAL;
   hipLaunchKernelGGL(k_cg_step2, dim3(ipx_xcd_grid(grid)), dim3(VB), 0, (hipStream_t)stream, n,
                      state, it & 1, mode, p2, np2, p3, np3, p4, np4, x, p, g, grid);
+  IPX_CHECK_LAUNCH();
+  return IPX_OK;
+}
+
+int ipx_cg_halo_pack(int64_t n, int32_t h, int32_t rank, int32_t world, const double *g,
+                     double *out, void *stream) {
+  if (h < 0 || world < 1 || rank < 0 || rank >= world || n < h) return IPX_EINVAL;
+  if (h == 0) return IPX_OK;
+  if (!g || !out) return IPX_EINVAL;
+  const int total = 2 * h * world;
+  hipLaunchKernelGGL(k_cg_halo_pack, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     n, h, rank, world, g, out);
+  IPX_CHECK_LAUNCH();
+  return IPX_OK;
+}
+
+int ipx_cg_shard_pack(const double *part2, int32_t np2, const double *part3, int32_t np3,
+                      int64_t n, int32_t h, int32_t rank, int32_t world, const double *g,
+                      double *out, void *stream) {
+  if (!part2 || !part3 || !out || np2 < 0 || np3 < 0 || h < 0 || world < 1 || rank < 0 ||
+      rank >= world || n < h || (h > 0 && !g))
+    return IPX_EINVAL;
+  hipLaunchKernelGGL(k_cg_shard_pack, dim3(1), dim3(256), 0, (hipStream_t)stream, part2, np2,
+                     part3, np3, n, h, rank, world, g, out);
+  IPX_CHECK_LAUNCH();
+  return IPX_OK;
+}
+
+int ipx_cg_halo_apply(const double *state, int32_t hl, int32_t hr, const double *g_left,
+                      const double *g_right, double *p_left, double *p_right, void *stream) {
+  if (!state || hl < 0 || hr < 0) return IPX_EINVAL;
+  const int hm = hl > hr ? hl : hr;
+  if (hm == 0) return IPX_OK;
+  if ((hl && (!g_left || !p_left)) || (hr && (!g_right || !p_right))) return IPX_EINVAL;
+  hipLaunchKernelGGL(k_cg_halo_apply, dim3((hm + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     state, hl, hr, g_left, g_right, p_left, p_right);
   IPX_CHECK_LAUNCH();
   return IPX_OK;
 }

@@ -263,12 +263,7 @@ int ipx_csr_spmv_ex(int64_t nrows, int64_t ncols, const int32_t *rowptr, const i
   if (nrows < 0 || ncols < 0 || ntiles < 0) return IPX_EINVAL;
   if (nrows > 0 && (!rowptr || !tiles || !yout || (!x && ncols > 0))) return IPX_EINVAL;
   ipx_csr_view A{(int)nrows, (int)ncols, rowptr, colidx, val, tiles, ntiles};
-  // rectangular matrices pair rows with xrow only when the caller says so
-  const double *xr = xrow;
-  if (!xr && nrows == ncols) xr = x;
-  if (!xr && !diag) {
-    // force "no row pairing" even for a square shape: handled by passing x when square
-  }
+  // rows pair with `xrow`; a square matrix without one pairs them with x itself
   return ipx_spmv_launch(A, x, alpha, diag, beta, yin, yout, partial, guard,
                          (hipStream_t)stream, xrow);
 }

@@ -60,11 +60,16 @@ _SIGNATURES = {
     "ipx_banded_solve": [_P, _P, _P, _P],
     "ipx_banded_solve_multilaunch": [_P, _P, _P, _P],
     "ipx_banded_solve_guarded_c": [_P, _P, _P, _P, _P],
+    "ipx_banded_solve_resid": [_P, _P, _P, _P, _P, _P, _P],
+    "ipx_cg_halo_pack": [_I64, _I32, _I32, _I32, _P, _P, _P],
+    "ipx_cg_shard_pack": [_P, _I32, _P, _I32, _I64, _I32, _I32, _I32, _P, _P, _P],
+    "ipx_cg_halo_apply": [_P, _I32, _I32, _P, _P, _P, _P, _P],
     "ipx_aat_band": [_I64, _I32, _P, _P, _P, _P, _P, _P],
     "ipx_aat_band_w": [_I64, _I32, _P, _P, _P, _P, _P, _P, _P],
     "ipx_pairs_factor": [_I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "ipx_pairs_tsolve": [_I32, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "ipx_pairs_vsolve": [_I32, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "ipx_boxschur_solve": [_P, _P, _P, _P, _P, _P, _P],
 }
 _RESTYPES = {"ipx_version": _c.c_char_p, "ipx_last_error": _c.c_char_p,
              "ipx_banded_create": _P, "ipx_banded_destroy": None,

@@ -171,6 +171,12 @@ class BoxSchurNormalSolver:
 
     def solve(self, w):
         c, st = self.c, stream_ptr()
+        args = self.c_args()
+        if args is not None:                 # whole application behind one ABI call
+            v = dv._empty(self.m)
+            _hip.call("ipx_boxschur_solve", ctypes.byref(args), _p(w.t), _p(v), None, None, None,
+                      st)
+            return DVec(v)
         _hip.call("ipx_pairs_tsolve", self.ng, _p(c["rowp"]), _p(c["rowq"]), _p(self.inv),
                   _p(self.alpha), _p(w.t), _p(self.t), _p(c["col"]), _p(self.u), st)
         mR = len(self.an.general)

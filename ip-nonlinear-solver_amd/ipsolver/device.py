@@ -46,7 +46,13 @@ def ctx():
     return _Context.get()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_ptr():
+    """Raw hipStream_t of torch's current stream on the context's device."""
+    if _raw_stream is not None:            # ~0.3 us; the Stream object below costs ~8 us
+        return ctypes.c_void_p(_raw_stream(ctx().device.index))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

@@ -73,11 +73,13 @@ class RowSelection:
         indptr, indices = pattern.indptr_h.astype(np.int64), pattern.indices_h
         counts = indptr[rows + 1] - indptr[rows]
         new_indptr = np.concatenate(([0], np.cumsum(counts))).astype(np.int32)
-        src = (np.concatenate([np.arange(indptr[r], indptr[r + 1]) for r in rows])
-               if len(rows) else np.empty(0, dtype=np.int64))
         self.identity = (len(rows) == pattern.shape[0]
                          and np.array_equal(rows, np.arange(pattern.shape[0]))
                          and (sign is None or np.all(sign == 1)))
+        # source position of every selected nonzero: start of its row + offset inside the row
+        total = int(new_indptr[-1])
+        src = (np.repeat(indptr[rows] - new_indptr[:-1], counts) + np.arange(total)
+               if total and not self.identity else np.empty(0, dtype=np.int64))
         self.pattern = pattern if self.identity else CSRPattern(
             new_indptr, indices[src] if len(src) else np.empty(0, np.int32),
             (len(rows), pattern.shape[1]))

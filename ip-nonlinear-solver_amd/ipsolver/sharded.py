@@ -6,18 +6,22 @@ Partition:
 * z-space vectors x, p, r, H p are split into contiguous variable blocks, one per
   rank; rank g owns the columns ``A[:, n0:n1]`` of the Jacobian, the matching
   rows of ``A'`` and the rows ``H[n0:n1, :]`` of the Hessian (its few
-  off-block columns are served from a halo of p exchanged with the two
-  neighbours);
+  off-block columns are served from halo copies of the neighbours' boundary
+  entries of p);
 * constraint-space vectors (length m = n/10) and the banded ``(A A')^-1``
   factorization are replicated: ``w = A r`` is formed as per-rank partial
   products summed by ONE all-reduce (0.8 MB at m = 1e5), after which every rank
-  solves the same banded system and applies its own rows of ``A'``.
+  solves the same banded system and applies its own rows of ``A'``.  The
+  orthogonality test uses the constraint-space residual ``||w - (AA')v||``
+  (DESIGN.md section 4), which is replicated as well and needs no collective.
 
-Collectives per CG iteration: all-reduce of ``p'Hp`` (2 doubles), of the
-partial ``A r`` and ``A g`` vectors, of the packed ``||x+ap||^2, #violations,
-||g||^2`` (4 doubles), and a halo exchange of p.  The reduced scalars are
-bit-identical on every rank, so the device-side branches of ``csrc/cg.hip``
-take the same way everywhere and no rank needs the host.
+Collectives per CG iteration: THREE all-reduces and nothing else --
+``p'Hp`` (2 doubles); the partial ``A r`` vector; one packed buffer with
+``||x+ap||^2, #violations, ||g||^2`` and every rank's boundary entries of g.
+The halo copies of p are then advanced locally with the same ``beta p - g``
+the owner applies (bit-identical), so there is no neighbour exchange.  The
+reduced scalars are bit-identical on every rank, so the device-side branches of
+``csrc/cg.hip`` take the same way everywhere and no rank needs the host.
 
 The orchestration below is engine-agnostic: ``HipEngine`` runs the ipx
 kernels; the test-suite runs the same code over gloo with the oracle's numpy
@@ -82,59 +86,47 @@ class ShardedProjectedCG:
         self.p = eng.view(self.p_ext, self.hl, self.hl + self.nloc)
         self.w, self.v, self.t = (eng.zeros(self.m) for _ in range(3))
         self.state = eng.zeros(STATE_SIZE)
-        self.s1, self.s23, self.s4 = eng.zeros(2), eng.zeros(4), eng.zeros(2)
+        self.s1, self.s4 = eng.zeros(2), eng.zeros(2)
         self.part1 = eng.zeros(2 * eng.ntiles(self.H_rows))
         self.part3 = eng.zeros(2 * eng.ntiles(self.At_rows))
+        self.part4 = eng.zeros((self.m + 255) // 256 + 1)
         self.grid = eng.vec_grid(self.nloc)
         self.part2 = eng.zeros(2 * self.grid)
-        self.halo_send = [eng.zeros(max(self.h, 1)), eng.zeros(max(self.h, 1))]
+        # packed all-reduce buffer: 4 scalars + [world][2h] boundary entries
+        self.pack = eng.zeros(4 + 2 * self.h * self.world)
+        h, r = self.h, self.rank
+        self.g_left = eng.view(self.pack, 4 + (2 * (r - 1) + 1) * h, 4 + 2 * r * h) \
+            if self.hl else None                       # right boundary of rank-1
+        self.g_right = eng.view(self.pack, 4 + 2 * (r + 1) * h, 4 + (2 * (r + 1) + 1) * h) \
+            if self.hr else None                       # left boundary of rank+1
+        self.p_left = eng.view(self.p_ext, 0, self.hl) if self.hl else None
+        self.p_right = eng.view(self.p_ext, self.hl + self.nloc,
+                                self.hl + self.nloc + self.hr) if self.hr else None
 
     # ---- collectives ---------------------------------------------------------
-    def _staged(self, t):
-        """gloo cannot move CUDA tensors point-to-point; in that (test-only)
-        combination go through a host copy.  RCCL works on device memory."""
-        return t.is_cuda and dist.get_backend(self.group) != "nccl"
-
     def _allreduce(self, buf):
         if self.world == 1:
             return
         t = self.eng.tensor(buf)
-        if self._staged(t):
-            h = t.cpu()
+        if t.is_cuda and dist.get_backend(self.group) != "nccl":
+            h = t.cpu()          # gloo (test-only combination): stage through the host
             dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
             t.copy_(h)
         else:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
-    def _halo_exchange(self):
-        """p_ext halos <- neighbours' boundary entries of p."""
+    def _seed_p_halo(self):
+        """p halos <- neighbours' boundary entries of p (priming only; inside
+        the loop the halos are advanced locally)."""
         if self.world == 1 or self.h == 0:
             return
-        h = self.h
-        pt = self.eng.tensor(self.p_ext)
-        lo, hi = self.hl, self.hl + self.nloc
-        staged = self._staged(pt)
-        ops, landing = [], []
-
-        def link(peer, send_slice, recv_slice):
-            out = pt[send_slice].contiguous()
-            if staged:
-                out = out.cpu()
-                inbox = torch.empty(h, dtype=torch.float64)
-                landing.append((recv_slice, inbox))
-            else:
-                inbox = pt[recv_slice]
-            ops.append(dist.P2POp(dist.isend, out, peer, group=self.group))
-            ops.append(dist.P2POp(dist.irecv, inbox, peer, group=self.group))
-
-        if self.rank > 0:
-            link(self.rank - 1, slice(lo, lo + h), slice(0, h))
-        if self.rank < self.world - 1:
-            link(self.rank + 1, slice(hi - h, hi), slice(hi, hi + h))
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
-        for recv_slice, inbox in landing:
-            pt[recv_slice].copy_(inbox)
+        eng = self.eng
+        eng.halo_pack(self.p, self.h, self.rank, self.world, eng.view(self.pack, 4, None))
+        self._allreduce(self.pack)
+        if self.hl:
+            eng.axpby(1.0, self.g_left, 0.0, None, self.p_left)
+        if self.hr:
+            eng.axpby(1.0, self.g_right, 0.0, None, self.p_right)
 
     # ---- pieces ---------------------------------------------------------------
     def _project(self, y, out):
@@ -147,7 +139,6 @@ class ShardedProjectedCG:
 
     def _hp(self, guard=True):
         """Hp = H p on the local rows, p'Hp partials in part1."""
-        self._halo_exchange()
         self.eng.spmv(self.H_rows, self.p_ext, self.Hp, diag=self.hdiag, xrow=self.p,
                       partial=self.part1, guard=self.state if guard else None)
 
@@ -170,6 +161,7 @@ class ShardedProjectedCG:
         init[ST_RTG0], init[ST_TOL], init[ST_RADIUS] = rt_g, tol, trust_radius
         init[ST_ORTH_RHS] = orth_tol * self.norm_A
         eng.assign(self.state, init)
+        self._seed_p_halo()
         self._hp(guard=False)
         return rt_g
 
@@ -177,24 +169,24 @@ class ShardedProjectedCG:
         """Enqueue iterations [it_begin, it_end); no host synchronisation."""
         eng = self.eng
         st = self.state
+        nH, nAt = eng.ntiles(self.H_rows), eng.ntiles(self.At_rows)
+        scal2, scal3 = eng.view(self.pack, 0, 2), eng.view(self.pack, 2, 4)
         for it in range(it_begin, it_end):
-            eng.fold2(self.part1, eng.ntiles(self.H_rows), self.s1)
+            eng.fold2(self.part1, nH, self.s1)
             self._allreduce(self.s1)                                   # p'Hp
             eng.step1(st, it, self.s1, 1, self.x, self.p, self.r, self.Hp, self.part2,
                       self.grid)
             eng.spmv(self.A_cols, self.r, self.w, guard=st)            # partial A r
             self._allreduce(self.w)
-            eng.solve(self.solver, self.w, self.v, guard=st)
+            np4 = eng.solve_resid(self.solver, self.w, self.v, self.part4, guard=st)
             eng.spmv(self.At_rows, self.v, self.r, alpha=-1.0, beta=1.0, yin=self.r,
                      partial=self.part3, guard=st)                      # g = r - A'v
-            eng.spmv(self.A_cols, self.r, self.t, guard=st)            # partial A g
-            self._allreduce(self.t)
-            eng.sumsq(self.t, self.s4)                                  # ||A g||^2 (replicated)
-            eng.fold2(self.part2, self.grid, eng.view(self.s23, 0, 2))
-            eng.fold2(self.part3, eng.ntiles(self.At_rows), eng.view(self.s23, 2, 4))
-            self._allreduce(self.s23)            # ||x+ap||^2, #viol, ||g||^2, (unused)
-            eng.step2(st, it, 0, self.s23, 1, eng.view(self.s23, 2, 4), 1, self.s4, 1,
+            eng.shard_pack(self.part2, self.grid, self.part3, nAt, self.r, self.h, self.rank,
+                           self.world, self.pack)
+            self._allreduce(self.pack)     # ||x+ap||^2, #viol, ||g||^2 + boundary g of all ranks
+            eng.step2(st, it, 0, scal2, 1, scal3, 1, self.part4, np4,
                       self.x, self.p, self.r, self.grid)
+            eng.halo_apply(st, self.g_left, self.g_right, self.p_left, self.p_right)
             self._hp()
 
     def read_state(self):
@@ -309,6 +301,32 @@ class HipEngine:
         else:
             self._hip.call("ipx_banded_solve_guarded_c", ctypes.c_void_p(solver.handle),
                            self._ptr(w), self._ptr(v), self._ptr(guard[ST_STOP:]), self._st())
+
+    def solve_resid(self, solver, w, v, partial, guard=None):
+        """v = (A A')^-1 w plus partial sums of ||w - (A A')v||^2; returns their count."""
+        if solver.perm is not None:
+            raise NotImplementedError("sharded CG needs A A' banded in its natural row order")
+        npart = ctypes.c_int32(0)
+        self._hip.call("ipx_banded_solve_resid", ctypes.c_void_p(solver.handle), self._ptr(w),
+                       self._ptr(v), self._ptr(partial), ctypes.byref(npart),
+                       self._ptr(guard[ST_STOP:]) if guard is not None else None, self._st())
+        return int(npart.value)
+
+    def halo_pack(self, g, h, rank, world, out):
+        self._hip.call("ipx_cg_halo_pack", g.numel(), int(h), int(rank), int(world), self._ptr(g),
+                       self._ptr(out), self._st())
+
+    def shard_pack(self, part2, np2, part3, np3, g, h, rank, world, out):
+        self._hip.call("ipx_cg_shard_pack", self._ptr(part2), int(np2), self._ptr(part3), int(np3),
+                       g.numel(), int(h), int(rank), int(world), self._ptr(g), self._ptr(out),
+                       self._st())
+
+    def halo_apply(self, state, g_left, g_right, p_left, p_right):
+        hl = p_left.numel() if p_left is not None else 0
+        hr = p_right.numel() if p_right is not None else 0
+        if hl or hr:
+            self._hip.call("ipx_cg_halo_apply", self._ptr(state), hl, hr, self._ptr(g_left),
+                           self._ptr(g_right), self._ptr(p_left), self._ptr(p_right), self._st())
 
     def spmv(self, M, x, out, alpha=1.0, diag=None, beta=0.0, yin=None, xrow=None, partial=None,
              guard=None):

@@ -50,7 +50,11 @@ class NumpyEngine:
 
     def banded(self, A):
         A = sps.csr_matrix(A)
-        return spla.splu(sps.csc_matrix(A.dot(A.T)))
+        S = sps.csc_matrix(A.dot(A.T))
+        lu = spla.splu(S)
+        lu_S = type("Factor", (), {})()
+        lu_S.solve, lu_S.S = lu.solve, sps.csr_matrix(S)
+        return lu_S
 
     @staticmethod
     def _stopped(guard):
@@ -59,6 +63,31 @@ class NumpyEngine:
     def solve(self, solver, w, v, guard=None):
         if not self._stopped(guard):
             v[:] = solver.solve(w)
+
+    def solve_resid(self, solver, w, v, partial, guard=None):      # k_correct_oop<RESID>
+        if not self._stopped(guard):
+            v[:] = solver.solve(w)
+            res = w - solver.S.dot(v)
+            partial[0] = res.dot(res)
+        return 1
+
+    def halo_pack(self, g, h, rank, world, out):                    # k_cg_halo_pack
+        out[:2 * h * world] = 0.0
+        out[2 * h * rank:2 * h * rank + h] = g[:h]
+        out[2 * h * rank + h:2 * h * (rank + 1)] = g[len(g) - h:]
+
+    def shard_pack(self, part2, np2, part3, np3, g, h, rank, world, out):   # k_cg_shard_pack
+        out[0], out[1] = part2[:np2].sum(), part2[np2:2 * np2].sum()
+        out[2], out[3] = part3[:np3].sum(), part3[np3:2 * np3].sum()
+        self.halo_pack(g, h, rank, world, out[4:])
+
+    def halo_apply(self, st, g_left, g_right, p_left, p_right):     # k_cg_halo_apply
+        if st[ST_STOP] != 0:
+            return
+        if p_left is not None:
+            p_left[:] = st[ST_BETA] * p_left - g_left
+        if p_right is not None:
+            p_right[:] = st[ST_BETA] * p_right - g_right
 
     def spmv(self, M, x, out, alpha=1.0, diag=None, beta=0.0, yin=None, xrow=None, partial=None,
              guard=None):

@@ -1,7 +1,7 @@
 """Row-sharded projected CG (ipsolver/sharded.py) over gloo on CPUs, world size
 1 and 2 (and 3: uneven blocks, interior rank with two neighbours), with the
 oracle's numpy engine in place of the HIP kernels.  Checks the partitioning,
-the halo exchange, the all-reduces and the device-style state machine against
+the locally advanced halos, the three all-reduces and the device-style state machine against
 the single-process oracle."""
 import os
 import socket
@@ -22,7 +22,15 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, n, m, iters, tol, out_dir):
+def _wide_hessian(H):
+    """SPD Hessian of half bandwidth 3 (halo of three entries per side)."""
+    import scipy.sparse as sps
+    n = H.shape[0]
+    return sps.csr_matrix(H + sps.diags([0.1 * np.ones(n - 3), 0.5 * np.ones(n),
+                                         0.1 * np.ones(n - 3)], [-3, 0, 3]))
+
+
+def _worker(rank, world, port, n, m, iters, tol, out_dir, wide=False):
     for p in (ROOT, os.path.join(ROOT, "ip-nonlinear-solver_amd"), os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -34,7 +42,7 @@ def _worker(rank, world, port, n, m, iters, tol, out_dir):
         from ipsolver.sharded import ShardedProjectedCG
         from oracle.numpy_engine import NumpyEngine
         inst = BandedInstance(n, m)
-        cg = ShardedProjectedCG(NumpyEngine(), inst.A, inst.H)
+        cg = ShardedProjectedCG(NumpyEngine(), inst.A, _wide_hessian(inst.H) if wide else inst.H)
         x, info = cg.solve(inst.c, tol=tol, max_iter=iters)
         if rank == 0:
             np.savez(os.path.join(out_dir, "w%d.npz" % world), x=x,
@@ -70,4 +78,21 @@ def test_sharded_cg_default_tolerance(tmp_path):
     Z, _, Y = oracle.projections(inst.A)
     xo, info = oracle.projected_cg(inst.H, inst.c, Z, Y, np.zeros(m))
     assert list(got["info"]) == [info["niter"], info["stop_cond"]] and info["stop_cond"] == 4
+    assert np.max(np.abs(got["x"] - xo)) <= 1e-11 * np.max(np.abs(xo))
+
+
+def test_sharded_cg_wide_halo(tmp_path):
+    """Half bandwidth 3: three boundary entries per side travel in the packed
+    all-reduce and the halo copies of p are advanced locally."""
+    import oracle
+    from banded_setup import BandedInstance
+    n, m, iters = 1500, 150, 20
+    port = _free_port()
+    mp.spawn(_worker, args=(3, port, n, m, iters, 0.0, str(tmp_path), True), nprocs=3, join=True)
+    got = np.load(os.path.join(str(tmp_path), "w3.npz"))
+    inst = BandedInstance(n, m)
+    Z, _, Y = oracle.projections(inst.A)
+    xo, info = oracle.projected_cg(_wide_hessian(inst.H), inst.c, Z, Y, np.zeros(m), tol=0,
+                                   max_iter=iters)
+    assert list(got["info"]) == [info["niter"], info["stop_cond"]]
     assert np.max(np.abs(got["x"] - xo)) <= 1e-11 * np.max(np.abs(xo))
