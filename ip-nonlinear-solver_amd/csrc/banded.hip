@@ -47,6 +47,7 @@ struct Banded {
   double *ybuf;               // level-0 down-sweep result (fast path is out of place)
   double *rinv;               // 1 / diag of the level-1 matrix (decoupled path)
   bool decoupled;             // level-1 system numerically diagonal: skip the middle kernel
+  bool upper_done;            // levels >= 1 factored (deferred while a decoupled solve may do)
   bool fast;                  // three-launch path usable (LDS budget)
   int down_T;                 // chunks per workgroup in k_down0
   size_t lds_down;
@@ -640,6 +641,133 @@ k_down0(LevDev lv, const double *w, double *y, double *__restrict__ gL,
   for (int i = threadIdx.x; i < nrows; i += blockDim.x) y[row0 + i] = sw[i];
 }
 
+// LDS-staged factorization of T chunks per workgroup (the one-lane-per-chunk
+// kernel k_factor_chunks pays a global-memory round trip per recurrence step:
+// ~120 us at m = 1e5).  Band rows are staged with coalesced loads; one lane per
+// chunk runs the LDL' recurrence out of LDS into [step][chunk] tables kept in
+// LDS; then 2K lanes per chunk compute the spike columns B^-1 E / B^-1 F with
+// the same chunk_solve the solve path uses; a cooperative sweep writes the
+// tables and the spikes out.
+template <int K>
+constexpr int factor_chunks_per_wg() { return K <= 2 ? 16 : (K <= 4 ? 8 : 4); }
+
+template <int K>
+size_t factor_lds_doubles(int q) {
+  constexpr int T = factor_chunks_per_wg<K>();
+  const size_t qk = q + K;
+  return (size_t)(K + 1) * T * q + qk * T + qk * K * T + (size_t)2 * K * T * q;
+}
+
+template <int K, int T>
+__global__ void __launch_bounds__(DOWN_T)
+k_factor_lds(int m, int c, int P, const double *__restrict__ band, double *__restrict__ Dinv,
+             double *__restrict__ L, double *__restrict__ V, double *__restrict__ W, int *flag) {
+  static_assert(2 * K * T <= DOWN_T, "one lane per spike column");
+  extern __shared__ double sm[];
+  const int q = c + K, qk = q + K, TQ = T * q;
+  const int t0 = blockIdx.x * T;
+  const int tcount = min(T, P - t0);
+  const int row0 = t0 * q;
+  const int nrows = min(m, (t0 + tcount) * q) - row0;
+  double *sB = sm;                             // (K+1) x TQ   band rows  [d][local row]
+  double *sD = sB + (size_t)(K + 1) * TQ;      // qk*T         1/d        [step][lane]
+  double *sL = sD + (size_t)qk * T;            // qk*K*T       l          [step*K+d][lane]
+  double *sX = sL + (size_t)qk * K * T;        // 2K*T x q     spike columns [task][row]
+  stage<16>(sB, (K + 1) * TQ, [=](int i) {
+    const int d = i / TQ, r = i - d * TQ;
+    return r < nrows ? band[(int64_t)d * m + row0 + r] : 0.0;
+  });
+  for (int i = threadIdx.x; i < qk * T * (K + 1) + 2 * K * TQ; i += blockDim.x) sD[i] = 0.0;
+  __syncthreads();
+
+  // ---- LDL' of the interior blocks, one lane per chunk (k_factor_chunks' recurrence)
+  if ((int)threadIdx.x < tcount) {
+    const int tl = threadIdx.x, t = t0 + tl;
+    const int ct = chunk_rows(m, q, c, P, t);
+    const double *bp = sB + tl * q;
+    double lw[K][K], dw[K];
+#pragma unroll
+    for (int r = 0; r < K; ++r) {
+      dw[r] = 1.0;
+#pragma unroll
+      for (int d = 0; d < K; ++d) lw[r][d] = 0.0;
+    }
+    bool bad = false;
+    for (int j = 0; j < ct; ++j) {
+      double lrow[K];
+#pragma unroll
+      for (int d = K; d >= 1; --d) {
+        double sv = 0.0;
+        if (d <= j) {
+          sv = bp[d * TQ + j];
+#pragma unroll
+          for (int e = K; e > d; --e)
+            if (e <= j) sv -= lrow[e - 1] * dw[e - 1] * lw[d - 1][e - d - 1];
+          sv = sv / dw[d - 1];
+        }
+        lrow[d - 1] = sv;
+      }
+      double dj = bp[j];
+#pragma unroll
+      for (int e = K; e >= 1; --e)
+        if (e <= j) dj -= lrow[e - 1] * lrow[e - 1] * dw[e - 1];
+      bad |= !(dj > 0.0);
+      sD[j * T + tl] = 1.0 / dj;
+#pragma unroll
+      for (int d = 1; d <= K; ++d) sL[(j * K + (d - 1)) * T + tl] = lrow[d - 1];
+#pragma unroll
+      for (int r = K - 1; r > 0; --r) {
+        dw[r] = dw[r - 1];
+#pragma unroll
+        for (int d = 0; d < K; ++d) lw[r][d] = lw[r - 1][d];
+      }
+      dw[0] = dj;
+#pragma unroll
+      for (int d = 0; d < K; ++d) lw[0][d] = lrow[d];
+    }
+    if (bad) atomicOr(flag, 1);
+  }
+  __syncthreads();
+
+  // ---- spikes: lane (chunk, side, a) solves B x = E[:, a] (side 0) or F[:, a] (side 1)
+  if ((int)threadIdx.x < 2 * K * tcount) {
+    const int id = threadIdx.x;
+    const int tl = id / (2 * K), rem = id - tl * 2 * K, side = rem / K, a = rem - side * K;
+    const int t = t0 + tl;
+    if (!(side == 0 && t == 0) && !(side == 1 && t == P - 1)) {
+      const int ct = chunk_rows(m, q, c, P, t);
+      const double *bp = sB + tl * q;
+      double *x = sX + (size_t)id * q;
+      if (side == 0) {           // E[j][a] = T[base+j][base-K+a], d = j+K-a, rows j <= a
+        for (int j = 0; j <= a && j < ct; ++j) x[j] = bp[(j + K - a) * TQ + j];
+      } else {                   // F[j][a] = T[base+ct+a][base+j], d = ct+a-j <= K
+        for (int j = max(0, ct + a - K); j < ct; ++j) x[j] = bp[(ct + a - j) * TQ + ct + a];
+      }
+      chunk_solve<K, T>(x, ct, sD, sL, T, tl);
+    }
+  }
+  __syncthreads();
+
+  // ---- write-out (tables are [step][chunk] with q+K rows; rows past the chunk stay 0)
+  for (int i = threadIdx.x; i < qk * T; i += blockDim.x) {
+    const int j = i / T, tl = i - j * T;
+    if (tl < tcount) Dinv[(int64_t)j * P + t0 + tl] = sD[i];
+  }
+  for (int i = threadIdx.x; i < qk * K * T; i += blockDim.x) {
+    const int j = i / T, tl = i - j * T;
+    if (tl < tcount) L[(int64_t)j * P + t0 + tl] = sL[i];
+  }
+  for (int i = threadIdx.x; i < nrows * K; i += blockDim.x) {
+    const int r = i / K, a = i - r * K;
+    const int tl = r / q, j = r - tl * q, t = t0 + tl;
+    if (j < chunk_rows(m, q, c, P, t)) {
+      const double *xv = sX + (size_t)(tl * 2 * K + a) * q + j;
+      if (t > 0) V[(int64_t)(row0 + r) * K + a] = xv[0];
+      if (t < P - 1) W[(int64_t)(row0 + r) * K + a] = xv[(size_t)K * q];
+    }
+  }
+}
+
 // Factor data of the levels >= 1 lives in one contiguous slab; k_middle copies
 // the whole slab into LDS with a single coalesced sweep (one memory latency),
 // after which every phase below touches LDS only.  `fb` is the slab base the
@@ -766,9 +894,22 @@ template <int K>
 struct Launch {
   static int factor(Banded *h, int li, hipStream_t st) {
     Level &lv = h->lev[li];
-    int grid = (lv.P + IPX_WAVE - 1) / IPX_WAVE;
-    hipLaunchKernelGGL(k_factor_chunks<K>, dim3(grid), dim3(IPX_WAVE), 0, st, lv.m, lv.c, lv.P,
-                       lv.band, lv.Dinv, lv.L, lv.V, lv.W, h->flag);
+    constexpr int T = factor_chunks_per_wg<K>();
+    const size_t lds = factor_lds_doubles<K>(lv.q) * sizeof(double);
+    if (lds <= LDS_LIMIT) {
+      static bool attr_set = false;
+      if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)k_factor_lds<K, T>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);
+        attr_set = true;
+      }
+      hipLaunchKernelGGL((k_factor_lds<K, T>), dim3((lv.P + T - 1) / T), dim3(DOWN_T), lds, st,
+                         lv.m, lv.c, lv.P, lv.band, lv.Dinv, lv.L, lv.V, lv.W, h->flag);
+    } else {
+      int grid = (lv.P + IPX_WAVE - 1) / IPX_WAVE;
+      hipLaunchKernelGGL(k_factor_chunks<K>, dim3(grid), dim3(IPX_WAVE), 0, st, lv.m, lv.c, lv.P,
+                         lv.band, lv.Dinv, lv.L, lv.V, lv.W, h->flag);
+    }
     IPX_CHECK_LAUNCH();
     if (lv.mR > 0) {
       Level &nx = h->lev[li + 1];
@@ -823,6 +964,25 @@ int level_down(Banded *h, int li, const double *w, double *y, const double *guar
 }
 int level_up(Banded *h, int li, double *x, const double *guard, hipStream_t st) {
   DISPATCH_K(h->lev[li].k, up(h, li, x, guard, st))
+}
+
+bool decoupling_candidate(const Banded *h) {
+  return h->fast && h->nlev >= 2 && h->lev[0].k == 1 && h->rinv;
+}
+
+int factor_upper(Banded *h, hipStream_t st) {
+  for (int li = 1; li < h->nlev; ++li) {
+    int rc = level_factor(h, li, st);
+    if (rc != IPX_OK) return rc;
+  }
+  h->upper_done = true;
+  return IPX_OK;
+}
+
+int read_flag(Banded *h, int *f, hipStream_t st) {
+  if (hipMemcpyAsync(f, h->flag, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess)
+    return IPX_ELAUNCH;
+  return hipStreamSynchronize(st) == hipSuccess ? IPX_OK : IPX_ELAUNCH;
 }
 
 template <typename T>
@@ -954,29 +1114,35 @@ int ipx_banded_factor(void *handle, const double *band, void *stream) {
   if (hipMemsetAsync(h->flag, 0, sizeof(int), st) != hipSuccess) return IPX_ELAUNCH;
   h->lev[0].band = const_cast<double *>(band);
   h->decoupled = false;
-  for (int li = 0; li < h->nlev; ++li) {
-    int rc = level_factor(h, li, st);
-    if (rc != IPX_OK) return rc;
-  }
-  if (h->fast && h->nlev >= 2 && h->lev[0].k == 1 && h->rinv) {
+  // Level 0 and the separator (Schur complement) matrix first.  When the
+  // decoupled path is a candidate the upper levels wait for its verdict
+  // (ipx_banded_status): a decoupled solve never touches them.
+  int rc = level_factor(h, 0, st);
+  if (rc != IPX_OK) return rc;
+  h->upper_done = false;
+  if (decoupling_candidate(h)) {
     const int mR = h->lev[0].mR;
     hipLaunchKernelGGL(k_decoupling_check, dim3((mR + IPX_BLOCK - 1) / IPX_BLOCK), dim3(IPX_BLOCK),
                        0, st, mR, h->lev[1].band, h->rinv, h->flag);
     IPX_CHECK_LAUNCH();
+    return IPX_OK;
   }
-  return IPX_OK;
+  return factor_upper(h, st);
 }
 
 // Blocking read of the pivot flag: IPX_OK or IPX_ENOTSPD.
 int ipx_banded_status(void *handle, void *stream) {
   if (!handle) return IPX_EINVAL;
   Banded *h = (Banded *)handle;
+  hipStream_t st = (hipStream_t)stream;
   int f = 0;
-  if (hipMemcpyAsync(&f, h->flag, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream) !=
-      hipSuccess)
-    return IPX_ELAUNCH;
-  if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return IPX_ELAUNCH;
-  h->decoupled = h->fast && h->nlev >= 2 && h->lev[0].k == 1 && h->rinv && !(f & 2);
+  if (read_flag(h, &f, st) != IPX_OK) return IPX_ELAUNCH;
+  h->decoupled = decoupling_candidate(h) && !(f & 2);
+  if (!h->decoupled && !h->upper_done && !(f & 1)) {
+    int rc = factor_upper(h, st);
+    if (rc != IPX_OK) return rc;
+    if (read_flag(h, &f, st) != IPX_OK) return IPX_ELAUNCH;
+  }
   return (f & 1) ? IPX_ENOTSPD : IPX_OK;
 }
 
@@ -1087,6 +1253,10 @@ int fast_solve(Banded *h, const double *w, double *x, double *partial, int *npar
   int rc = fast_down0(h, w, h->ybuf, guard, st);
   if (rc != IPX_OK) return rc;
   if (!h->decoupled) {
+    if (!h->upper_done) {           // deferred by ipx_banded_factor (decoupled candidate)
+      rc = factor_upper(h, st);
+      if (rc != IPX_OK) return rc;
+    }
     rc = fast_middle(h, guard, st);
     if (rc != IPX_OK) return rc;
   }
@@ -1115,6 +1285,10 @@ int ipx_banded_solve_guarded(void *handle, const double *w, double *x, const dou
   if (!handle || !w || !x) return IPX_EINVAL;
   Banded *h = (Banded *)handle;
   if (h->fast) return fast_solve(h, w, x, nullptr, nullptr, guard, st);
+  if (!h->upper_done) {             // deferred by ipx_banded_factor (decoupled candidate)
+    int rc = factor_upper(h, st);
+    if (rc != IPX_OK) return rc;
+  }
   for (int li = 0; li < h->nlev; ++li) {
     const double *in = li == 0 ? w : h->lev[li].rhs;
     double *out = li == 0 ? x : h->lev[li].sol;

@@ -95,6 +95,13 @@ def matrix(J, key="jac"):
     return DeviceDense.from_host(J)
 
 
+def mark_constant(A):
+    """Declare that A's values never change: ``projections(A)`` is then computed
+    once and re-used."""
+    A.constant = True
+    return A
+
+
 def diagonal_operator(d):
     return DiagonalOperator(d)
 

@@ -23,7 +23,7 @@ class CanonicalConstraint:
     """Record of _canonical_constraint.py:14-46."""
 
     def __init__(self, n_vars, n_ineq, n_eq, constr, jac, hess, sparse_jacobian,
-                 enforce_feasibility, x0, c_ineq0, c_eq0, J_ineq0, J_eq0):
+                 enforce_feasibility, x0, c_ineq0, c_eq0, J_ineq0, J_eq0, constant_jac=False):
         self.n_vars, self.n_ineq, self.n_eq = n_vars, n_ineq, n_eq
         self.constr, self.jac, self.hess = constr, jac, hess
         self.sparse_jacobian = sparse_jacobian
@@ -31,6 +31,10 @@ class CanonicalConstraint:
         self.x0 = x0
         self.c_ineq0, self.c_eq0 = c_ineq0, c_eq0
         self.J_ineq0, self.J_eq0 = J_ineq0, J_eq0
+        # True when jac(x) is the same pair of matrices for every x (linear and
+        # box constraints): the solver then uploads / factors it once
+        # (the reference recomputes, :81,225)
+        self.constant_jac = constant_jac
 
 
 class HessianSum:
@@ -152,11 +156,12 @@ def _nonlinear_to_canonical(nl):
         def hess(x, v_eq=_EMPTY, v_ineq=_EMPTY):
             return nl.hess(x, rows.multipliers(v_eq, v_ineq))
     enforce = nl.enforce_feasibility[rows.ineq] if rows.n_ineq else np.empty(0, dtype=bool)
+    constant = bool(getattr(nl, "constant_jac", False))
+    jac = (lambda x: (J_ineq0, J_eq0)) if constant else (lambda x: convert_jac(nl.jac(x)))
     return CanonicalConstraint(nl.n, rows.n_ineq, rows.n_eq,
-                               lambda x: rows.values(nl.fun(x)),
-                               lambda x: convert_jac(nl.jac(x)),
+                               lambda x: rows.values(nl.fun(x)), jac,
                                hess, nl.sparse_jacobian, enforce, nl.x0,
-                               c_ineq0, c_eq0, J_ineq0, J_eq0)
+                               c_ineq0, c_eq0, J_ineq0, J_eq0, constant)
 
 
 def _stack_values(pairs):
@@ -199,12 +204,14 @@ def _concatenate(parts):
 
     c_ineq0, c_eq0 = _stack_values([(c.c_ineq0, c.c_eq0) for c in parts])
     J_ineq0, J_eq0 = stack_jac([(c.J_ineq0, c.J_eq0) for c in parts])
+    constant = all(c.constant_jac for c in parts)
+    jac = (lambda x: (J_ineq0, J_eq0)) if constant \
+        else (lambda x: stack_jac([c.jac(x) for c in parts]))
     return CanonicalConstraint(
         n_vars, n_ineq, n_eq,
-        lambda x: _stack_values([c.constr(x) for c in parts]),
-        lambda x: stack_jac([c.jac(x) for c in parts]),
+        lambda x: _stack_values([c.constr(x) for c in parts]), jac,
         hess, use_sparse, np.hstack([c.enforce_feasibility for c in parts]),
-        x0, c_ineq0, c_eq0, J_ineq0, J_eq0)
+        x0, c_ineq0, c_eq0, J_ineq0, J_eq0, constant)
 
 
 def to_canonical(constraints):

@@ -200,6 +200,7 @@ class LinearConstraint(_Initialised):
                                  self.enforce_feasibility)
         nl.fun, nl.jac, nl.hess = nl._fun, nl._jac, None
         nl.isinitialized = True
+        nl.constant_jac = True          # lets the solver keep one upload / factorization (N1)
         for name in ("m", "n", "sparse_jacobian", "x0", "f0", "J0"):
             setattr(nl, name, getattr(self, name))
         return nl

@@ -287,8 +287,14 @@ def minimize_constrained(fun, x0, grad, hess='2-point', constraints=(), method=N
             _, c_eq = constr.constr(xh)
             return fun(xh), xp.asvec(c_eq)
 
+        A0 = xp.matrix(constr.J_eq0)
+        if constr.constant_jac:
+            xp.mark_constant(A0)       # one upload, one factorization for the whole run (N1)
+
         def grad_and_jac(x):
             xh = xp.tohost(x)
+            if constr.constant_jac:
+                return xp.asvec(grad_wrapped(xh)), A0
             _, J_eq = constr.jac(xh)
             return xp.asvec(grad_wrapped(xh)), xp.matrix(J_eq)
 
@@ -298,7 +304,7 @@ def minimize_constrained(fun, x0, grad, hess='2-point', constraints=(), method=N
 
         result = equality_constrained_sqp(
             fun_and_constr, grad_and_jac, lagr_hess, x0_dev, f0, g0_dev,
-            xp.asvec(constr.c_eq0), xp.matrix(constr.J_eq0), stop_criteria, state, xp,
+            xp.asvec(constr.c_eq0), A0, stop_criteria, state, xp,
             **options)
     else:                                                    # :532-544
         if constr.n_ineq == 0:

@@ -251,6 +251,17 @@ def projections(A, method=None, orth_tol=1e-12, max_refin=3, tol=1e-15):
     """
     from .dense import DenseNormalSolver
     A = as_device_matrix(A)
+    if getattr(A, "constant", False):          # values declared immutable: factor once (N1)
+        key = (method, orth_tol, max_refin, tol)
+        cached = getattr(A, "_ipx_projections", None)
+        if cached is None or cached[0] != key:
+            A.constant = False
+            try:
+                cached = A._ipx_projections = (key, projections(A, method, orth_tol, max_refin,
+                                                                tol))
+            finally:
+                A.constant = True
+        return cached[1]
     sparse = isinstance(A, DeviceCSR)
     if sparse:
         if method not in (None, "NormalEquation", "AugmentedSystem"):

@@ -65,6 +65,10 @@ def assign_negated_where(s, mask, c):
     s[mask] = -c[mask]
 
 
+def mark_constant(A):
+    return A          # the host backend refactors every time, like the reference
+
+
 def matrix(J, key=None):
     return J
 

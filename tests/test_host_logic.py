@@ -158,3 +158,27 @@ def test_return_all_and_callback_stop():
                                              p.constraints(ipsolver),
                                              callback=lambda st: st.niter >= 3)
     assert stop.status == 3 and stop.message.startswith("`callback`")
+
+
+def test_constant_jacobian_is_flagged():
+    """Linear and box constraints canonicalise to a Jacobian that is the same
+    pair of matrices for every x (the solver then factors it once: SURVEY.md
+    section 8(f) N1); a nonlinear constraint in the mix clears the flag."""
+    from ipsolver.canonical import to_canonical
+    x0 = np.array([0.5, 0.5, 0.5])
+    lin = ipsolver.LinearConstraint(np.array([[1.0, 1.0, 1.0], [1.0, -1.0, 0.0]]),
+                                    ("interval", [0, -1], [2, np.inf]))
+    box = ipsolver.BoxConstraint(("greater", 0.0))
+    nl = ipsolver.NonlinearConstraint(lambda x: np.array([x.dot(x)]), ("less", 4.0),
+                                      lambda x: 2 * x[None, :], lambda x, v: 2 * v[0] * np.eye(3))
+    for c in (lin, box, nl):
+        c.evaluate_and_initialize(x0)
+    both = to_canonical([lin, box])
+    assert both.constant_jac
+    J1, J2 = both.jac(x0), both.jac(x0 + 1.0)
+    assert J1[0] is J2[0] and J1[1] is J2[1]
+    dense = lambda M: M.toarray() if sps.issparse(M) else np.asarray(M)
+    assert np.array_equal(dense(J1[0]), dense(both.J_ineq0))
+    mixed = to_canonical([lin, nl])
+    assert not mixed.constant_jac
+    assert not to_canonical(nl).constant_jac
