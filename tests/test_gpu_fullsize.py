@@ -1,0 +1,179 @@
+"""The hot path at BASELINE.json's full sizes (n = 1e6, m = 1e5 sparse banded;
+n = 10000, m = 2000 dense), checked through size-independent properties -- the
+oracle needs minutes there, the properties need none:
+
+  projections   A Z x = 0,  Z Z x = Z x,  A Y b = b,  x = Z x + A' LS x,
+                Y b = -(LS' b)  (projections.py:58-90 relations)
+  SpMV          <y, A x> = <A' y, x>, linearity
+  projected_cg  A x = b, the quadratic decreases monotonically along the
+                iterates, ||x|| <= radius with hits_boundary on the sphere,
+                lb <= x <= ub, fused loop == general driver
+  full solve    config 3 reproduces the reference's outer/CG iteration counts
+                and final optimality
+
+All through the C ABI on the GPU (no oracle import in this file).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N, M = 1000000, 100000
+
+
+def host(v):
+    return v.to_host() if hasattr(v, "to_host") else np.asarray(v, dtype=float)
+
+
+@pytest.fixture(scope="module")
+def big():
+    import ipsolver.device as dv
+    import ipsolver.projector as proj
+    from ipsolver.operators import DeviceHessian
+    from ipsolver.synthetic import CenteredBandedNLP
+
+    class NS:
+        pass
+    ns = NS()
+    prob = CenteredBandedNLP(N, M, seed=0)
+    x = prob.x0
+    v = 0.1 * np.random.default_rng(7).standard_normal(M)
+    ns.prob, ns.dv = prob, dv
+    ns.A_h, ns.H_h = prob.constr_jac(x), prob.lagrangian_hessian_matrix(x, v)
+    ns.A = dv.DeviceCSR.from_scipy(ns.A_h)
+    ns.H = DeviceHessian(N, csr=dv.DeviceCSR.from_scipy(prob.hess(x)),
+                         diag=dv.DVec.from_host(prob.kappa * prob.Wt.dot(v)))
+    ns.c_h = prob.grad(x)
+    ns.Z, ns.LS, ns.Y = proj.projections(ns.A)
+    ns.norm_A = float(np.sqrt((ns.A_h.data ** 2).sum()))
+    rng = np.random.default_rng(11)
+    ns.xs = [rng.standard_normal(N) for _ in range(2)]
+    ns.bs = [rng.standard_normal(M) for _ in range(2)]
+    return ns
+
+
+def test_spmv_adjoint_and_linearity(big):
+    dv = big.dv
+    x, x2 = (dv.DVec.from_host(v) for v in big.xs)
+    y = dv.DVec.from_host(big.bs[0])
+    Ax = big.A.dot(x)
+    Aty = big.A.T.dot(y)
+    lhs, rhs = y.dot(Ax), Aty.dot(x)
+    assert abs(lhs - rhs) <= 1e-12 * np.sqrt(Ax.dot(Ax) * y.dot(y))
+    # A (2 x - 3 x2) = 2 A x - 3 A x2
+    comb = big.A.dot(2.0 * x - 3.0 * x2)
+    want = 2.0 * Ax - 3.0 * big.A.dot(x2)
+    assert dv.norm(comb - want) <= 1e-13 * dv.norm(want)
+    # row sums are those of scipy on the same data, bit for bit
+    assert np.array_equal(host(Ax), big.A_h.dot(big.xs[0]))
+    Hx = host(big.H.dot(x))
+    assert np.max(np.abs(Hx - big.H_h.dot(big.xs[0]))) <= 1e-13 * np.max(np.abs(Hx))
+
+
+def test_projection_identities(big):
+    dv = big.dv
+    for xv, bv in zip(big.xs, big.bs):
+        x, b = dv.DVec.from_host(xv), dv.DVec.from_host(bv)
+        zx = big.Z.dot(x)
+        # null space: the reference's own acceptance measure (projections.py:42-55)
+        assert dv.norm(big.A.dot(zx)) <= 1e-12 * big.norm_A * dv.norm(zx)
+        assert dv.norm(big.Z.dot(zx) - zx) <= 1e-12 * dv.norm(zx)          # idempotent
+        yb = big.Y.dot(b)
+        assert dv.norm(big.A.dot(yb) - b) <= 1e-11 * dv.norm(b)            # right inverse
+        ls = big.LS.dot(x)
+        recon = zx + big.A.T.dot(ls)                                       # x = Zx + A' LS x
+        assert dv.norm(recon - x) <= 1e-12 * dv.norm(x)
+        # Y = LS': <Y b, x> = <b, LS x>
+        assert abs(yb.dot(x) - b.dot(ls)) <= 1e-11 * dv.norm(yb) * dv.norm(x)
+
+
+def _quadratic(big, x):
+    dv = big.dv
+    xd = x if hasattr(x, "dot") and not isinstance(x, np.ndarray) else dv.DVec.from_host(x)
+    return 0.5 * xd.dot(big.H.dot(xd)) + xd.dot(dv.DVec.from_host(big.c_h))
+
+
+def test_projected_cg_properties(big):
+    import ipsolver.qp as qp
+    dv = big.dv
+    b = np.zeros(M)
+    x, info = qp.projected_cg(big.H, big.c_h, big.Z, big.Y, b, return_all=True, max_iter=12,
+                              tol=0.0)
+    assert info["niter"] == 12 and info["stop_cond"] == 1 and not info["hits_boundary"]
+    q = [_quadratic(big, xi) for xi in info["allvecs"]]
+    assert all(q1 < q0 for q0, q1 in zip(q, q[1:]))                        # monotone decrease
+    assert dv.norm(big.A.dot(x)) <= 1e-11 * big.norm_A * dv.norm(x)        # A x = b = 0
+
+    # sphere: a radius the unconstrained iterates would leave -> stops on it
+    full = dv.norm(x)
+    radius = 0.5 * full
+    xs, info_s = qp.projected_cg(big.H, big.c_h, big.Z, big.Y, b, trust_radius=radius, tol=0.0)
+    assert info_s["stop_cond"] == 2 and info_s["hits_boundary"]
+    assert abs(dv.norm(xs) - radius) <= 1e-12 * radius
+    assert dv.norm(big.A.dot(xs)) <= 1e-11 * big.norm_A * radius
+    assert _quadratic(big, xs) < 0.0
+
+    # box: bounds tighter than the free solution -> stays inside, on the boundary
+    amax = float(np.max(np.abs(host(x))))
+    lb, ub = np.full(N, -0.4 * amax), np.full(N, 0.4 * amax)
+    xb, info_b = qp.projected_cg(big.H, big.c_h, big.Z, big.Y, b, lb=lb, ub=ub, tol=0.0,
+                                 max_iter=12)
+    xbh = host(xb)
+    assert np.all(xbh >= lb) and np.all(xbh <= ub)
+    assert info_b["hits_boundary"]
+    assert _quadratic(big, xb) < 0.0
+
+
+def test_fused_loop_matches_general_driver(big):
+    """The device-resident loop (csrc/cg.hip) and the statement-by-statement
+    driver (ipsolver/qp.py) are two implementations of qp_subproblem.py:421-638;
+    at full size they must agree to rounding."""
+    import ipsolver.cg_fused as cg_fused
+    import ipsolver.qp as qp
+    b = np.zeros(M)
+    kw = dict(tol=0.0, max_iter=10)
+    assert cg_fused.supports(big.H, big.Z, big.Y)
+    x_f, info_f = qp.projected_cg(big.H, big.c_h, big.Z, big.Y, b, **kw)
+    x_g, info_g = qp.projected_cg(big.H, big.c_h, big.Z, big.Y, b, return_all=True, **kw)
+    assert (info_f["niter"], info_f["stop_cond"]) == (info_g["niter"], info_g["stop_cond"])
+    assert big.dv.norm(x_f - x_g) <= 1e-12 * big.dv.norm(x_g)
+
+
+def test_config3_full_solve_reproduces_reference_counts():
+    """BASELINE config 3 (eps = 1e-3) at n = 1e6: the reference stops with status
+    1 after 25 outer / 34 CG iterations (measured there in
+    103 s); the same counts and final optimality here, callbacks on the device."""
+    import torch
+    import ipsolver
+    from ipsolver.synthetic import CenteredBandedNLP, DeviceCallbacks
+    prob = CenteredBandedNLP(N, M, eps=1e-3)
+    dc = DeviceCallbacks(prob)
+    res = ipsolver.minimize_constrained(dc.fun, dc.x0, dc.grad, dc.hess, dc.constraints(ipsolver),
+                                        method="tr_interior_point")
+    assert (res.status, res.niter, res.cg_niter) == (1, 25, 34)
+    assert res.optimality < 1e-8 and res.constr_violation < 1e-8
+    assert abs(res.optimality - 7.4074e-9) <= 1e-12
+    assert isinstance(res.x, torch.Tensor) and res.x.is_cuda
+
+
+def test_dense_config2_gram_and_projection():
+    """BASELINE config 2 sizes (dense 2000 x 10000): MFMA Gram block against
+    fp64 host rows, Cholesky-based projections against the identities."""
+    import ipsolver.device as dv
+    import ipsolver.projector as proj
+    from ipsolver.dense import DeviceDense
+    rng = np.random.default_rng(0)
+    m, n = 2000, 10000
+    A_h = rng.standard_normal((m, n))
+    A = DeviceDense.from_host(A_h)
+    Z, LS, Y = proj.projections(A)
+    x, b = dv.DVec.from_host(rng.standard_normal(n)), dv.DVec.from_host(rng.standard_normal(m))
+    zx = Z.dot(x)
+    norm_A = float(np.linalg.norm(A_h))
+    assert dv.norm(A.dot(zx)) <= 1e-12 * norm_A * dv.norm(zx)
+    assert dv.norm(A.dot(Y.dot(b)) - b) <= 1e-10 * dv.norm(b)
+    assert dv.norm(zx + A.T.dot(LS.dot(x)) - x) <= 1e-12 * dv.norm(x)
+    # A x against numpy (fp64 dot products, order differs -> rounding only)
+    Ax = host(A.dot(x))
+    ref = A_h.dot(host(x))
+    assert np.max(np.abs(Ax - ref)) <= 1e-12 * np.max(np.abs(ref))
