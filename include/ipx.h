@@ -99,9 +99,10 @@ int ipx_box_sphere_reduce(int64_t n, const double *z, const double *d, double ds
                           double *ws, void *stream);
 
 /* ---- CSR SpMV (scipy _sparsetools csr_matvec; every A.dot / A.T.dot / H.dot).
- * Row tiles: `tiles` holds ntiles+1 row indices (tile t = rows
- * [tiles[t], tiles[t+1])) with at most IPX_SPMV_TILE_NNZ nonzeros each unless
- * a single row is longer; build them with ipx_csr_tiles_host.
+ * Row tiles: `tiles` holds 2*(ntiles+1) entries -- ntiles+1 row indices (tile t
+ * = rows [tiles[t], tiles[t+1])) followed by rowptr at those rows -- with at
+ * most IPX_SPMV_TILE_NNZ nonzeros per tile unless a single row is longer;
+ * build it with ipx_csr_tiles_host (cap >= 2*(nrows+2) always suffices).
  *
  * y_out = alpha * (A x)_i  [+ diag_i * x_i]  [+ beta * yin_i]
  * and, when red != NULL, red[0] = sum_i y_out_i^2, red[1] = sum_i xrow_i * y_out_i

@@ -32,11 +32,15 @@ k_csr_spmv(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colid
   __shared__ double prod[TILE_NNZ];
   __shared__ int rp[TILE_ROWS + 1];
   __shared__ double red_lds[IPX_BLOCK / IPX_WAVE];
-  if (guard && *guard != 0.0) return;   // device-side stop flag of the fused CG loop
   const int tile = ipx_xcd_item(blockIdx.x, ntiles);
   if (tile < 0) return;
+  // One round trip for everything the tile's addresses depend on: the stop
+  // flag, the row range and the nonzero range (second half of the tile table)
+  // are requested together; the stream loads below depend on nothing else.
+  const double stop = guard ? *guard : 0.0;
   const int r0 = tiles[tile], r1 = tiles[tile + 1];
-  const int s = rowptr[r0], e = rowptr[r1];
+  const int s = tiles[ntiles + 1 + tile], e = tiles[ntiles + 2 + tile];
+  if (stop != 0.0) return;              // device-side stop flag of the fused CG loop
   double acc_yy = 0.0, acc_xy = 0.0;
 
   const int nrows = r1 - r0;
@@ -199,13 +203,15 @@ int ipx_spmv_launch(const ipx_csr_view &A, const double *x, double alpha, const 
 extern "C" {
 
 // Host-side symbolic step: cut rows into tiles of <= tile_nnz nonzeros and
-// <= max_rows rows (a longer single row gets a tile of its own).
+// <= max_rows rows (a longer single row gets a tile of its own).  The table
+// has 2*(nt+1) entries: the nt+1 row boundaries, then rowptr at those rows (so
+// a workgroup learns its row range and its nonzero range in one round trip).
 int ipx_csr_tiles_host(int64_t nrows, const int32_t *rowptr, int32_t tile_nnz,
                        int32_t max_rows, int32_t *tiles_out, int64_t cap) {
   if (nrows < 0 || !rowptr || !tiles_out || tile_nnz < 1 || max_rows < 1) return IPX_EINVAL;
   int64_t nt = 0;
   int64_t r = 0;
-  if (cap < 1) return IPX_EINVAL;
+  if (cap < 2) return IPX_EINVAL;
   tiles_out[0] = 0;
   while (r < nrows) {
     int64_t r_end = r + 1;   // always take at least one row
@@ -213,10 +219,11 @@ int ipx_csr_tiles_host(int64_t nrows, const int32_t *rowptr, int32_t tile_nnz,
            rowptr[r_end + 1] - rowptr[r] <= tile_nnz)
       ++r_end;
     ++nt;
-    if (nt >= cap) return IPX_EINVAL;
+    if (2 * (nt + 1) > cap) return IPX_EINVAL;
     tiles_out[nt] = (int32_t)r_end;
     r = r_end;
   }
+  for (int64_t t = 0; t <= nt; ++t) tiles_out[nt + 1 + t] = rowptr[tiles_out[t]];
   return (int)nt;
 }
 

@@ -218,12 +218,12 @@ def hstack(parts):
 # ---------------------------------------------------------------------------
 def _tiles_for(rowptr_host, tile_nnz=_hip.SPMV_TILE_NNZ, max_rows=1024):
     nrows = len(rowptr_host) - 1
-    cap = nrows + 2
+    cap = 2 * (nrows + 2)
     tiles = np.empty(cap, dtype=np.int32)
     rp = np.ascontiguousarray(rowptr_host, dtype=np.int32)
     nt = _hip.call("ipx_csr_tiles_host", nrows, rp.ctypes.data_as(ctypes.c_void_p),
                    int(tile_nnz), int(max_rows), tiles.ctypes.data_as(ctypes.c_void_p), cap)
-    return tiles[:nt + 1].copy()
+    return tiles[:2 * (nt + 1)].copy()      # row boundaries, then rowptr at them
 
 
 class CSRPattern:
@@ -240,7 +240,7 @@ class CSRPattern:
         self.indptr = torch.from_numpy(self.indptr_h).to(dev)
         self.indices = torch.from_numpy(self.indices_h).to(dev)
         tiles = _tiles_for(self.indptr_h)
-        self.ntiles = len(tiles) - 1
+        self.ntiles = len(tiles) // 2 - 1
         self.tiles = torch.from_numpy(tiles).to(dev)
         self.nnz = int(self.indptr_h[-1])
         self._transpose = None

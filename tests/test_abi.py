@@ -40,6 +40,7 @@ def test_host_only_entry_points():
     nt = lib.ipx_csr_tiles_host(4, rowptr.ctypes.data_as(ctypes.c_void_p), 2048, 1024,
                                 tiles.ctypes.data_as(ctypes.c_void_p), 8)
     assert nt == 3 and list(tiles[:4]) == [0, 2, 3, 4]      # the long row gets its own tile
+    assert list(tiles[4:8]) == [0, 3, 5000, 5001]           # rowptr at the tile boundaries
 
 
 def test_product_fails_loudly_without_gpu():
