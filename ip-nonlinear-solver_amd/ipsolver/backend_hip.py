@@ -165,7 +165,8 @@ def hessian_operator(terms, n_vars, slack_block):
             csr = h
         elif isinstance(h, DVec):
             diag = h if diag is None else diag + h
-        elif isinstance(h, (DeviceCSR, DeviceHessian, DeviceDense)):
+        elif isinstance(h, (DeviceCSR, DeviceHessian, DeviceDense)) \
+                or getattr(h, "device_operator", False):
             others.append(h)
         elif isinstance(h, np.ndarray):
             others.append(DeviceDense.from_host(h))

@@ -164,13 +164,16 @@ class _DeviceConstraint:
             self.hess = None
             f0 = A.dot(x0)
         elif isinstance(user, NonlinearConstraint):
-            if user._hess in ('2-point', '3-point', 'cs'):
-                raise NotImplementedError("finite-difference Hessians need host callbacks; "
-                                          "pass numpy x0 or give `hess` explicitly")
             ufun, ujac, uhess = user._fun, user._jac, user._hess
             self.fun = lambda x: as_dvec(ufun(x.t))
             self.jac = lambda x: _check_jac(ujac(x.t))
-            self.hess = None if uhess is None else (lambda x, v: uhess(x.t, v.t))
+            if uhess in ('2-point', '3-point', 'cs'):
+                # d/dx [J(x)' v] by differences (reference _constraints.py:136-146), on the device
+                from .fd import DeviceFiniteDifferenceOperator
+                self.hess = lambda x, v: DeviceFiniteDifferenceOperator(
+                    lambda xt: _check_jac(ujac(xt)).T.dot(v), x, uhess)
+            else:
+                self.hess = None if uhess is None else (lambda x, v: uhess(x.t, v.t))
             f0 = self.fun(x0)
         else:
             raise ValueError("Unknown Constraint type.")
@@ -291,7 +294,8 @@ class DeviceCanonical:
 def _as_term(h):
     """Normalise a Hessian callback's return value to a device term."""
     from .operators import DeviceHessian
-    if h is None or isinstance(h, (DeviceCSR, DVec, DeviceHessian)):
+    if h is None or isinstance(h, (DeviceCSR, DVec, DeviceHessian)) \
+            or getattr(h, "device_operator", False):
         return h
     if torch.is_tensor(h) and h.dim() == 1:
         return as_dvec(h)                      # diagonal

@@ -6,6 +6,11 @@ reachable from the solver path (``hess='2-point'|'3-point'|'cs'``), so only it
 is provided.  Each product is one or two evaluations of a *user* callback on
 the host, which is why SURVEY.md section 2 leaves it outside the accelerated
 path: vectors cross to the host for the call and come back.
+
+``DeviceFiniteDifferenceOperator`` is the same rule for device-callback mode
+(SURVEY.md section 8(f) N4): the callback takes and returns CUDA tensors, the
+perturbed point and the difference quotient are ipx kernels, nothing crosses
+PCIe.
 """
 import numpy as np
 
@@ -43,5 +48,45 @@ class FiniteDifferenceOperator:
             return (f2 - f1) / dx
         dx = self.h / norm_p                  # 'cs' :429-437
         return self.fun(self.x0 + dx * p * 1.j).imag / dx
+
+    matvec = dot
+
+
+class DeviceFiniteDifferenceOperator:
+    """The rule above with ``fun``: CUDA tensor -> CUDA tensor (or DVec) and
+    device vectors throughout.  'cs' needs complex arithmetic the ipx kernels do
+    not have and is refused."""
+    device_operator = True       # backend_hip.hessian_operator keeps it on the device
+
+    def __init__(self, fun, x0, method, f0=None):
+        from .device import DVec
+        if method not in FD_METHODS:
+            raise ValueError("Unknown method '%s'. " % method)
+        if method == 'cs':
+            raise NotImplementedError("complex-step differences are not available in "
+                                      "device-callback mode; use '2-point' or '3-point'")
+        self._DVec = DVec
+        self.fun = lambda x: self._vec(fun(x.t))
+        self.x0 = x0
+        self.f0 = self._vec(f0) if f0 is not None else self.fun(x0)
+        self.h = _REL_STEP[method]
+        self.method = method
+        self.shape = (len(self.f0), len(x0))
+
+    def _vec(self, v):
+        return v if isinstance(v, self._DVec) else self._DVec(v)
+
+    def dot(self, p):
+        from . import device as dv
+        norm_p = dv.norm(p)
+        if norm_p == 0:
+            return self._DVec.zeros(self.shape[0])
+        if self.method == '2-point':          # _numdiff.py:408-415
+            dx = self.h / norm_p
+            return (self.fun(self.x0.add_scaled(p, dx)) - self.f0) * (1.0 / dx)
+        dx = 2 * self.h / norm_p              # '3-point' :417-427
+        f1 = self.fun(self.x0.add_scaled(p, -(dx / 2)))
+        f2 = self.fun(self.x0.add_scaled(p, dx / 2))
+        return (f2 - f1) * (1.0 / dx)
 
     matvec = dot

@@ -111,9 +111,10 @@ def _minimize_device(fun, x0, grad, hess, constraints, method, xtol, gtol, optio
     from . import device_mode as dm
     if xp.name != "hip":
         raise RuntimeError("device-callback mode needs the HIP backend")
-    if hess in FD_METHODS:
-        raise NotImplementedError("finite-difference Hessians evaluate host callbacks; pass a "
-                                  "numpy x0, or give `hess` explicitly (a DeviceCSR / diagonal)")
+    if hess in FD_METHODS:           # N4: differences of the device gradient callback
+        from .fd import DeviceFiniteDifferenceOperator
+        fd_method = hess
+        hess = lambda xt: DeviceFiniteDifferenceOperator(grad, dm.as_dvec(xt), fd_method)
     x0_dev = dm.as_dvec(x0.detach().clone())
     n_vars = len(x0_dev)
     f0 = float(fun(x0_dev.t))

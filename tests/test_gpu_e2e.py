@@ -1,5 +1,7 @@
 """End-to-end parity of minimize_constrained on the HIP backend (the product
 path: no backend injection) against the reference's golden traces."""
+import warnings
+
 import numpy as np
 import pytest
 
@@ -119,6 +121,37 @@ def test_device_callbacks_banded_equality(method, e2e_golden):
     gold = e2e_golden["banded_eq_n2000_%s" % method]
     res.x = res.x.cpu().numpy()
     compare(res, rows, gold, rtol=1e-6)
+
+
+@pytest.mark.parametrize("fd", ["2-point", "3-point"])
+def test_device_callbacks_finite_difference_hessians(fd):
+    """hess='2-point'/'3-point' for the objective and for the constraint in
+    device-callback mode: same rule as the host
+    finite-difference operator (_numdiff.py:403-441), evaluated with device
+    callbacks.  Host mode with the same settings is the comparison."""
+    import torch
+    syn = load_synthetic()
+    prob = syn.CenteredBandedNLP(600, 60, eps=1e-3)
+    from ipsolver.synthetic import DeviceCallbacks
+    dc = DeviceCallbacks(prob)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        dev = ipsolver.minimize_constrained(
+            dc.fun, dc.x0, dc.grad, fd,
+            ipsolver.NonlinearConstraint(dc.constr_fun, ("equals", 0), dc.constr_jac, fd),
+            method="tr_interior_point")
+        hst = ipsolver.minimize_constrained(
+            prob.fun, prob.x0, prob.grad, fd,
+            ipsolver.NonlinearConstraint(prob.constr_fun, ("equals", 0), prob.constr_jac, fd),
+            method="tr_interior_point")
+    assert torch.is_tensor(dev.x) and dev.x.is_cuda
+    assert dev.status == hst.status == 1
+    assert dev.optimality < 1e-8 and dev.constr_violation < 1e-8
+    assert abs(dev.niter - hst.niter) <= 2
+    assert np.max(np.abs(dev.x.cpu().numpy() - hst.x)) <= 1e-6 * np.max(np.abs(hst.x))
+    with pytest.raises(NotImplementedError, match="complex-step"):
+        ipsolver.minimize_constrained(dc.fun, dc.x0, dc.grad, "cs",
+                                      dc.constraints(ipsolver), method="tr_interior_point")
 
 
 def test_device_callbacks_box_inequality(e2e_golden):
