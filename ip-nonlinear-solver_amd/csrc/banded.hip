@@ -439,20 +439,50 @@ constexpr size_t LDS_LIMIT = 160 * 1024 - 512;
 
 // Cooperative global -> LDS fill with U loads in flight per lane (a plain copy
 // loop exposes one full memory latency per iteration).  `val(i)` produces
-// element i (normally one global load).
+// element i (normally one global load).  Rounds of U predicated loads: an
+// array of up to U * blockDim elements costs ONE memory latency.
 template <int U, typename Val>
 __device__ __forceinline__ void stage(double *dst, int n, Val val) {
   const int step = blockDim.x;
-  int i = threadIdx.x;
-  for (; i + (U - 1) * step < n; i += U * step) {
+  for (int base = threadIdx.x; base < n; base += U * step) {
     double v[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) v[u] = val(i + u * step);
+    for (int u = 0; u < U; ++u) {
+      const int i = base + u * step;
+      v[u] = i < n ? val(i) : 0.0;
+    }
 #pragma unroll
-    for (int u = 0; u < U; ++u) dst[i + u * step] = v[u];
+    for (int u = 0; u < U; ++u) {
+      const int i = base + u * step;
+      if (i < n) dst[i] = v[u];
+    }
   }
-  for (; i < n; i += step) dst[i] = val(i);
 }
+
+// The same in two halves, so that several arrays can be in flight together:
+// load() all of them, then store() all of them (one latency for the lot).
+template <int U>
+struct StageRegs {
+  double v[U];
+  template <typename Val>
+  __device__ __forceinline__ void load(int n, Val val) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = threadIdx.x + u * blockDim.x;
+      v[u] = i < n ? val(i) : 0.0;
+    }
+  }
+  // elements past U * blockDim (unusual chunk sizes) take the slow road
+  template <typename Val>
+  __device__ __forceinline__ void store(double *dst, int n, Val val) const {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = threadIdx.x + u * blockDim.x;
+      if (i < n) dst[i] = v[u];
+    }
+    for (int i = threadIdx.x + U * blockDim.x; i < n; i += blockDim.x) dst[i] = val(i);
+  }
+};
 
 struct LevDev {
   int m, k, c, P, q, mR;
@@ -604,31 +634,41 @@ k_down0(LevDev lv, const double *w, double *y, double *__restrict__ gL,
   double *sL = sD + (size_t)qk * T;      // qk*K*T   l     [step*K+d][lane]
   double *sE = sL + (size_t)qk * K * T;  // T*K*K    coupling to the left separator
   double *sF = sE + (size_t)T * K * K;   // T*K*K    coupling to the right separator
-  // One staging phase: every global load of the kernel is issued here.
+  // One staging phase: every global load of the kernel is issued before the
+  // first LDS store (one memory latency for the lot).
   const double *wp = w + row0;
-  stage<16>(sw, nrows, [=](int i) { return wp[i]; });
   // columns t0 .. t0+tcount-1 of the [step][chunk] tables (lanes past the last
   // chunk re-read column P-1; never used)
   const double *Dg = lv.Dinv, *Lg = lv.L, *Bg = lv.band;
-  stage<16>(sD, qk * T, [=](int i) {
+  auto f_w = [=](int i) { return wp[i]; };
+  auto f_D = [=](int i) {
     const int j = i / T, tl = i - j * T;
     return Dg[(int64_t)j * P + min(t0 + tl, P - 1)];
-  });
-  stage<16>(sL, qk * K * T, [=](int i) {
+  };
+  auto f_L = [=](int i) {
     const int j = i / T, tl = i - j * T;
     return Lg[(int64_t)j * P + min(t0 + tl, P - 1)];
-  });
-  stage<4>(sE, T * K * K, [=](int i) {
+  };
+  auto f_E = [=](int i) {
     const int tl = i / (K * K), r = i - tl * K * K, j = r / K, a = r - j * K;
     const int t = min(t0 + tl, P - 1);
     return t > 0 ? coupE<K>(Bg, m, t * q, j, a) : 0.0;
-  });
-  stage<4>(sF, T * K * K, [=](int i) {
+  };
+  auto f_F = [=](int i) {
     const int tl = i / (K * K), r = i - tl * K * K, jj = r / K, a = r - jj * K;
     const int t = min(t0 + tl, P - 1);
     const int ct = chunk_rows(m, q, c, P, t);
     return (t < P - 1 && ct - K + jj >= 0) ? coupF<K>(Bg, m, t * q, ct, ct - K + jj, a) : 0.0;
-  });
+  };
+  // register budgets sized for 64-row chunks with T = 16; anything larger
+  // takes StageRegs::store's slow loop
+  StageRegs<5> g_w, g_D;
+  StageRegs<5 * K> g_L;
+  StageRegs<(T * K * K + DOWN_T - 1) / DOWN_T> g_E, g_F;
+  g_w.load(nrows, f_w);          g_D.load(qk * T, f_D);      g_L.load(qk * K * T, f_L);
+  g_E.load(T * K * K, f_E);      g_F.load(T * K * K, f_F);
+  g_w.store(sw, nrows, f_w);     g_D.store(sD, qk * T, f_D); g_L.store(sL, qk * K * T, f_L);
+  g_E.store(sE, T * K * K, f_E); g_F.store(sF, T * K * K, f_F);
   __syncthreads();
   const int tl = threadIdx.x, t = t0 + tl;
   if (tl < tcount) {
@@ -848,6 +888,198 @@ k_middle(LevArgs a, int nbuf_total, const double *__restrict__ slab, int nslab,
 }
 
 constexpr int DOWN_CHUNKS = 16;      // chunks (recurrence lanes) per workgroup in k_down0
+
+// Decoupled path in ONE launch.  When the separator system is diagonal
+// (SepValues above) a separator value needs only the two chunks next to it, so
+// a workgroup that also solves one chunk to the left and two to the right of
+// its T own chunks (the recurrence lanes are otherwise idle) has everything
+// for the corrected solution of its rows AND their normal-equation residual:
+// no y / gL / gR round trip through memory and no second kernel.
+//   local chunk l = 0 .. T+2  <->  global chunk t = t0 - 1 + l;  own: l = 1 .. T
+template <int K, int T>
+__global__ void __launch_bounds__(DOWN_T)
+k_solve_decoupled(LevDev lv, const double *__restrict__ w, double *__restrict__ x,
+                  const double *__restrict__ rinv, double *__restrict__ partial,
+                  const double *__restrict__ guard) {
+  constexpr int NCH = T + 3;
+  extern __shared__ double sm[];
+  __shared__ double red_lds[DOWN_T / IPX_WAVE];
+  if (guard && *guard != 0.0) return;
+  const int q = lv.q, P = lv.P, m = lv.m, c = lv.c;
+  const int qk = q + K;
+  const int t0 = blockIdx.x * T, tfirst = t0 - 1;
+  const int64_t rfirst = (int64_t)tfirst * q;          // global row of local row 0 (may be < 0)
+  const int NB = T * q + K;                            // band rows kept for the residual
+  double *sw = sm;                          // NCH*q     rows: w, then y
+  double *sx = sw + (size_t)NCH * q;        // NCH*q     corrected solution
+  double *sD = sx + (size_t)NCH * q;        // qk*NCH    1/d   [step][l]
+  double *sL = sD + (size_t)qk * NCH;       // qk*K*NCH  l     [step*K+d][l]
+  double *sE = sL + (size_t)qk * K * NCH;   // NCH*K*K
+  double *sF = sE + (size_t)NCH * K * K;    // NCH*K*K
+  double *sB = sF + (size_t)NCH * K * K;    // (K+1)*NB  band rows of the own rows (+K)
+  double *sgL = sB + (size_t)(K + 1) * NB;  // NCH*K
+  double *sgR = sgL + (size_t)NCH * K + K;  // NCH*K, K entries of slack in front
+  double *sxs = sgR + (size_t)NCH * K;      // NCH*K     separator values
+  double *srinv = sxs + (size_t)NCH * K;    // NCH*K     1 / R_tt
+  double *sw0 = srinv + (size_t)NCH * K;    // T*q       w of the own rows (sw turns into y)
+  const int NV = (T + 2) * q - (q - K);     // rows whose corrected value is needed
+  double *sV = sw0 + (size_t)T * q;         // NV*K      spikes of those rows
+  double *sW = sV + (size_t)NV * K;         // NV*K
+  const double *Dg = lv.Dinv, *Lg = lv.L, *Bg = lv.band, *Vg = lv.V, *Wg = lv.W;
+  // every global load of the kernel is issued in this one staging phase
+  auto f_w = [=](int i) {
+    const int64_t g = rfirst + i;
+    return (g >= 0 && g < m) ? w[g] : 0.0;
+  };
+  auto f_D = [=](int i) {
+    const int j = i / NCH, l = i - j * NCH;
+    return Dg[(int64_t)j * P + min(max(tfirst + l, 0), P - 1)];
+  };
+  auto f_L = [=](int i) {
+    const int j = i / NCH, l = i - j * NCH;
+    return Lg[(int64_t)j * P + min(max(tfirst + l, 0), P - 1)];
+  };
+  auto f_E = [=](int i) {
+    const int l = i / (K * K), r = i - l * K * K, j = r / K, a = r - j * K;
+    const int t = tfirst + l;
+    return (t > 0 && t < P) ? coupE<K>(Bg, m, t * q, j, a) : 0.0;
+  };
+  auto f_F = [=](int i) {
+    const int l = i / (K * K), r = i - l * K * K, jj = r / K, a = r - jj * K;
+    const int t = tfirst + l;
+    if (t < 0 || t >= P - 1) return 0.0;
+    const int ct = chunk_rows(m, q, c, P, t);
+    return ct - K + jj >= 0 ? coupF<K>(Bg, m, t * q, ct, ct - K + jj, a) : 0.0;
+  };
+  auto f_B = [=](int i) {
+    const int d = i / NB, r = i - d * NB;
+    const int64_t g = (int64_t)t0 * q + r;
+    return g < m ? Bg[(int64_t)d * m + g] : 0.0;
+  };
+  auto f_w0 = [=](int i) {
+    const int64_t g = (int64_t)t0 * q + i;
+    return g < m ? w[g] : 0.0;
+  };
+  auto f_V = [=](int i) {
+    const int64_t gi = (rfirst + q - K) * K + i;         // element index in the m x K spikes
+    return (gi >= 0 && gi < (int64_t)m * K) ? Vg[gi] : 0.0;
+  };
+  auto f_W = [=](int i) {
+    const int64_t gi = (rfirst + q - K) * K + i;
+    return (gi >= 0 && gi < (int64_t)m * K) ? Wg[gi] : 0.0;
+  };
+  auto f_r = [=](int i) {
+    const int l = i / K, t = tfirst + l;
+    return (t >= 0 && t < P - 1) ? rinv[(int64_t)t * K + (i - l * K)] : 0.0;
+  };
+  // register budgets sized for the default 64-row chunks (q = 65); larger
+  // arrays spill into StageRegs::store's slow loop
+  StageRegs<5> g_w, g_D, g_w0;
+  StageRegs<5 * K> g_L, g_V, g_W;
+  StageRegs<5 * (K + 1)> g_B;
+  StageRegs<K * K> g_E, g_F;
+  StageRegs<K> g_r;
+  g_w.load(NCH * q, f_w);       g_D.load(qk * NCH, f_D);     g_L.load(qk * K * NCH, f_L);
+  g_E.load(NCH * K * K, f_E);   g_F.load(NCH * K * K, f_F);  g_B.load((K + 1) * NB, f_B);
+  g_w0.load(T * q, f_w0);       g_V.load(NV * K, f_V);       g_W.load(NV * K, f_W);
+  g_r.load((NCH - 1) * K, f_r);
+  g_w.store(sw, NCH * q, f_w);       g_D.store(sD, qk * NCH, f_D);
+  g_L.store(sL, qk * K * NCH, f_L);  g_E.store(sE, NCH * K * K, f_E);
+  g_F.store(sF, NCH * K * K, f_F);   g_B.store(sB, (K + 1) * NB, f_B);
+  g_w0.store(sw0, T * q, f_w0);      g_V.store(sV, NV * K, f_V);
+  g_W.store(sW, NV * K, f_W);        g_r.store(srinv, (NCH - 1) * K, f_r);
+  __syncthreads();
+
+  // ---- chunk recurrences + the two halves of every separator's reduced rhs
+  if ((int)threadIdx.x < NCH) {
+    const int l = threadIdx.x, t = tfirst + l;
+    if (t >= 0 && t < P) {
+      const int ct = chunk_rows(m, q, c, P, t);
+      double *b = sw + l * q;
+      chunk_solve<K, NCH>(b, ct, sD, sL, NCH, l);
+      chunk_rhs_halves<K>(b, P, t, ct, sE + l * K * K, sF + l * K * K, sgL - (int64_t)tfirst * K,
+                          sgR - (int64_t)tfirst * K);
+    }
+  }
+  __syncthreads();
+  // ---- separator values  xs_t = (gL_t + gR_t) / R_tt   for t = t0-1 .. t0+T
+  for (int i = threadIdx.x; i < (NCH - 1) * K; i += blockDim.x) {
+    const int l = i / K, t = tfirst + l;
+    sxs[i] = (t >= 0 && t < P - 1) ? (sgL[i] + sgR[i]) * srinv[i] : 0.0;
+  }
+  __syncthreads();
+  // ---- corrected solution on the own rows and the K rows either side of them
+  for (int li = q - K + (int)threadIdx.x; li < (T + 2) * q; li += blockDim.x) {
+    const int l = li / q, j = li - l * q, t = tfirst + l;
+    const int64_t g = rfirst + li;
+    double v = 0.0;
+    if (t >= 0 && t < P && g < m) {
+      const int ct = chunk_rows(m, q, c, P, t);
+      if (j >= ct) {
+        v = sxs[l * K + (j - ct)];
+      } else {
+        v = sw[li];
+        if (t > 0) {
+#pragma unroll
+          for (int a = 0; a < K; ++a) v -= sV[(li - (q - K)) * K + a] * sxs[(l - 1) * K + a];
+        }
+        if (t < P - 1) {
+#pragma unroll
+          for (int a = 0; a < K; ++a) v -= sW[(li - (q - K)) * K + a] * sxs[l * K + a];
+        }
+      }
+      if (l >= 1 && l <= T) x[g] = v;
+    }
+    sx[li] = v;
+  }
+  if (!partial) return;
+  __syncthreads();
+  // ---- residual of the own rows out of LDS:  w_i - sum_d S[i][i+-d] x[i+-d]
+  double acc = 0.0;
+  for (int r = threadIdx.x; r < T * q; r += blockDim.x) {
+    const int64_t g = (int64_t)t0 * q + r;
+    if (g < m) {
+      const int li = q + r;
+      double sum = sB[r] * sx[li];
+#pragma unroll
+      for (int d = 1; d <= K; ++d) {
+        if (g - d >= 0) sum += sB[d * NB + r] * sx[li - d];
+        if (g + d < m) sum += sB[d * NB + r + d] * sx[li + d];
+      }
+      const double res = sw0[r] - sum;
+      acc += res * res;
+    }
+  }
+  const double tot = ipx_block_reduce<IPX_SUM>(acc, red_lds);
+  if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+template <int K>
+size_t decoupled_lds_doubles(int q) {
+  constexpr int T = DOWN_CHUNKS, NCH = T + 3;
+  const size_t qk = q + K;
+  return (size_t)2 * NCH * q + qk * NCH * (K + 1) + (size_t)2 * NCH * K * K +
+         (size_t)(K + 1) * (T * q + K) + (size_t)4 * NCH * K + K + (size_t)T * q +
+         (size_t)2 * K * ((T + 2) * q - (q - K));
+}
+
+template <int K>
+int launch_solve_decoupled(const LevDev &lv, const double *w, double *x, const double *rinv,
+                           double *partial, int *npartial, const double *guard, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void *)k_solve_decoupled<K, DOWN_CHUNKS>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);
+    attr_set = true;
+  }
+  const int grid = (lv.P + DOWN_CHUNKS - 1) / DOWN_CHUNKS;
+  if (npartial) *npartial = grid;
+  hipLaunchKernelGGL((k_solve_decoupled<K, DOWN_CHUNKS>), dim3(grid), dim3(DOWN_T),
+                     decoupled_lds_doubles<K>(lv.q) * sizeof(double), st, lv, w, x, rinv, partial,
+                     guard);
+  IPX_CHECK_LAUNCH();
+  return IPX_OK;
+}
 
 template <int K>
 int launch_down0(const LevDev &lv, size_t lds, const double *w, double *y, double *gL,
@@ -1250,6 +1482,10 @@ int fast_solve(Banded *h, const double *w, double *x, double *partial, int *npar
     if (rc != IPX_OK || !partial) return rc;
     return ipx_banded_residual_launch(h, w, x, partial, npartial, guard, st);
   }
+  if (h->decoupled && w != x && h->lev[0].k == 1 &&
+      decoupled_lds_doubles<1>(h->lev[0].q) * sizeof(double) <= LDS_LIMIT)
+    return launch_solve_decoupled<1>(to_dev(h->lev[0], nullptr), w, x, h->rinv, partial, npartial,
+                                     guard, st);
   int rc = fast_down0(h, w, h->ybuf, guard, st);
   if (rc != IPX_OK) return rc;
   if (!h->decoupled) {
