@@ -621,7 +621,7 @@ __global__ void __launch_bounds__(DOWN_T)
 k_down0(LevDev lv, const double *w, double *y, double *__restrict__ gL,
         double *__restrict__ gR, const double *__restrict__ guard) {
   extern __shared__ double sm[];
-  if (guard && *guard != 0.0) return;
+  const double stop = guard ? *guard : 0.0;   // requested with the staging loads, tested after
   const int q = lv.q, P = lv.P, m = lv.m, c = lv.c;
   const int qk = q + K;                  // table rows (K zero rows of padding)
   const int t0 = blockIdx.x * T;
@@ -667,6 +667,7 @@ k_down0(LevDev lv, const double *w, double *y, double *__restrict__ gL,
   StageRegs<(T * K * K + DOWN_T - 1) / DOWN_T> g_E, g_F;
   g_w.load(nrows, f_w);          g_D.load(qk * T, f_D);      g_L.load(qk * K * T, f_L);
   g_E.load(T * K * K, f_E);      g_F.load(T * K * K, f_F);
+  if (stop != 0.0) return;
   g_w.store(sw, nrows, f_w);     g_D.store(sD, qk * T, f_D); g_L.store(sL, qk * K * T, f_L);
   g_E.store(sE, T * K * K, f_E); g_F.store(sF, T * K * K, f_F);
   __syncthreads();
@@ -904,7 +905,7 @@ k_solve_decoupled(LevDev lv, const double *__restrict__ w, double *__restrict__ 
   constexpr int NCH = T + 3;
   extern __shared__ double sm[];
   __shared__ double red_lds[DOWN_T / IPX_WAVE];
-  if (guard && *guard != 0.0) return;
+  const double stop = guard ? *guard : 0.0;   // requested with the staging loads, tested after
   const int q = lv.q, P = lv.P, m = lv.m, c = lv.c;
   const int qk = q + K;
   const int t0 = blockIdx.x * T, tfirst = t0 - 1;
@@ -983,6 +984,7 @@ k_solve_decoupled(LevDev lv, const double *__restrict__ w, double *__restrict__ 
   g_E.load(NCH * K * K, f_E);   g_F.load(NCH * K * K, f_F);  g_B.load((K + 1) * NB, f_B);
   g_w0.load(T * q, f_w0);       g_V.load(NV * K, f_V);       g_W.load(NV * K, f_W);
   g_r.load((NCH - 1) * K, f_r);
+  if (stop != 0.0) return;
   g_w.store(sw, NCH * q, f_w);       g_D.store(sD, qk * NCH, f_D);
   g_L.store(sL, qk * K * NCH, f_L);  g_E.store(sE, NCH * K * K, f_E);
   g_F.store(sF, NCH * K * K, f_F);   g_B.store(sB, (K + 1) * NB, f_B);

@@ -62,6 +62,7 @@ __device__ __forceinline__ double ipx_wave_min(double v) {
 }
 
 enum { IPX_SUM = 0, IPX_MAX = 1, IPX_MIN = 2 };
+#define IPX_FOLD_U 4             // partial-fold loads in flight per lane and quantity
 
 template <int OP>
 __device__ __forceinline__ double ipx_combine(double a, double b) {
@@ -102,9 +103,19 @@ __device__ __forceinline__ double ipx_block_reduce(double v, double *lds) {
 template <int OP>
 __device__ __forceinline__ double ipx_sum_partials(const double *part, int count,
                                                    double *lds) {
+  // rounds of IPX_FOLD_U predicated loads issued together (a load-add loop
+  // would pay one memory latency per trip); same accumulation order
   double v = ipx_identity<OP>();
-  for (int i = threadIdx.x; i < count; i += blockDim.x)
-    v = ipx_combine<OP>(v, part[i]);
+  for (int base = threadIdx.x; base < count; base += IPX_FOLD_U * blockDim.x) {
+    double t[IPX_FOLD_U];
+#pragma unroll
+    for (int u = 0; u < IPX_FOLD_U; ++u) {
+      const int i = base + u * blockDim.x;
+      t[u] = i < count ? part[i] : ipx_identity<OP>();
+    }
+#pragma unroll
+    for (int u = 0; u < IPX_FOLD_U; ++u) v = ipx_combine<OP>(v, t[u]);
+  }
   return ipx_block_reduce<OP>(v, lds);
 }
 
@@ -118,10 +129,27 @@ __device__ __forceinline__ void ipx_sum_partials_multi(const double *const (&par
                                                        const int (&count)[NQ], double *lds,
                                                        double (&out)[NQ]) {
   double v[NQ];
+  int longest = 0;
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
     v[q] = 0.0;
-    for (int i = threadIdx.x; i < count[q]; i += blockDim.x) v[q] += part[q][i];
+    longest = max(longest, count[q]);
+  }
+  for (int base = threadIdx.x; base < longest; base += IPX_FOLD_U * blockDim.x) {
+    double t[NQ][IPX_FOLD_U];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+      for (int u = 0; u < IPX_FOLD_U; ++u) {
+        const int i = base + u * blockDim.x;
+        t[q][u] = i < count[q] ? part[q][i] : 0.0;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+      for (int u = 0; u < IPX_FOLD_U; ++u) v[q] += t[q][u];
+    }
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nw = (blockDim.x + 63) >> 6;

@@ -58,6 +58,16 @@ k_csr_spmv(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colid
       const int i = tid + q * IPX_BLOCK;
       rpv[q] = (i <= nrows) ? rowptr[r0 + i] - s : 0;
     }
+    // epilogue operands of this lane's rows: requested with the first batch
+    // (before the dependent gathers), consumed after the barrier
+    double dg[Q], xr[Q], yi[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const int r = r0 + min(tid + q * IPX_BLOCK, nrows - 1);
+      dg[q] = HAS_DIAG ? diag[r] : 0.0;
+      xr[q] = xrow ? xrow[r] : 0.0;
+      yi[q] = HAS_YIN ? yin[r] : 0.0;
+    }
     if (e > s) {
       int c[U];
       double v[U];
@@ -80,15 +90,6 @@ k_csr_spmv(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colid
     for (int q = 0; q <= Q; ++q) {
       const int i = tid + q * IPX_BLOCK;
       if (i <= nrows) rp[i] = rpv[q];
-    }
-    // epilogue operands of this lane's rows: issued now, consumed after the barrier
-    double dg[Q], xr[Q], yi[Q];
-#pragma unroll
-    for (int q = 0; q < Q; ++q) {
-      const int r = r0 + min(tid + q * IPX_BLOCK, nrows - 1);
-      dg[q] = HAS_DIAG ? diag[r] : 0.0;
-      xr[q] = xrow ? xrow[r] : 0.0;
-      yi[q] = HAS_YIN ? yin[r] : 0.0;
     }
     __syncthreads();
     // Phase 2: one lane per row, left-to-right row sums out of LDS.
