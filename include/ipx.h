@@ -227,6 +227,24 @@ int ipx_cg_shard_pack(const double *part2, int32_t np2, const double *part3, int
                       double *out, void *stream);
 int ipx_cg_halo_apply(const double *state, int32_t hl, int32_t hr, const double *g_left,
                       const double *g_right, double *p_left, double *p_right, void *stream);
+/* One segment of a row-sharded iteration (the kernels between two all-reduces)
+ * in a single call.  `a` describes the rank's block: n = local variables,
+ * A_* = A[:, block] (m x n), At_* = its transpose, H_* = H[block, block+halo]
+ * (n x (hl+n+hr)), p = the owned part of e->p_ext.  Phases:
+ *   0 (after the all-reduce of e->s1):   step1;  w = A_cols r
+ *   1 (after the all-reduce of a->w):    v = (AA')^-1 w + residual partials;
+ *                                        r <- r - A_rows' v;  shard_pack -> e->pack
+ *   2 (after the all-reduce of e->pack): step2;  halo_apply;  Hp = H_rows p_ext;
+ *                                        e->s1 <- folded p'Hp partials        */
+typedef struct ipx_shard_ext {
+  double *p_ext;
+  int64_t hl, hr, h, rank, world;
+  double *s1;         /* 2 doubles */
+  double *pack;       /* 4 + 2*h*world doubles */
+  int64_t np4;        /* residual partial count of the last phase 1 (set by the library) */
+} ipx_shard_ext;
+int ipx_cg_shard_segment(const ipx_cg_args *a, ipx_shard_ext *e, int32_t phase, int32_t it,
+                         void *stream);
 /* Finish iteration `it` after the host handled a stop-5/6 event. */
 int ipx_cg_resume(const ipx_cg_args *a, int32_t it, int32_t mode, void *stream);
 

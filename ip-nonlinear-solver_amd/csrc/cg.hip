@@ -303,6 +303,50 @@ int ipx_cg_halo_apply(const double *state, int32_t hl, int32_t hr, const double 
   return IPX_OK;
 }
 
+int ipx_cg_shard_segment(const ipx_cg_args *a, ipx_shard_ext *e, int32_t phase, int32_t it,
+                         void *stream) {
+  if (!a || !e || phase < 0 || phase > 2) return IPX_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const double *guard = a->state + ST_STOP;
+  const int grid = (int)a->vec_grid;
+  int rc = IPX_OK;
+  if (phase == 0) {
+    rc = ipx_cg_step1(a->n, a->state, it, e->s1, 1, a->x, a->p, a->r, a->Hp, nullptr, nullptr,
+                      a->part2, grid, stream);
+    if (rc) return rc;
+    ipx_csr_view A{(int)a->m, (int)a->n, a->A_rowptr, a->A_colidx, a->A_val, a->A_tiles,
+                   (int)a->A_ntiles};
+    return ipx_spmv_launch(A, a->r, 1.0, nullptr, 0.0, nullptr, a->w, nullptr, guard, st);
+  }
+  if (phase == 1) {
+    int np4 = 0;
+    rc = ipx_banded_solve_resid_launch(a->banded, a->w, a->v, a->part4, &np4, guard, st);
+    if (rc) return rc;
+    e->np4 = np4;
+    ipx_csr_view At{(int)a->n, (int)a->m, a->At_rowptr, a->At_colidx, a->At_val, a->At_tiles,
+                    (int)a->At_ntiles};
+    rc = ipx_spmv_launch(At, a->v, -1.0, nullptr, 1.0, a->r, a->r, a->part3, guard, st);
+    if (rc) return rc;
+    return ipx_cg_shard_pack(a->part2, grid, a->part3, (int)a->At_ntiles, a->n, (int)e->h,
+                             (int)e->rank, (int)e->world, a->r, e->pack, stream);
+  }
+  const int h = (int)e->h, rank = (int)e->rank;
+  rc = ipx_cg_step2(a->n, a->state, it, 0, e->pack, 1, e->pack + 2, 1, a->part4, (int)e->np4,
+                    a->x, a->p, a->r, grid, stream);
+  if (rc) return rc;
+  rc = ipx_cg_halo_apply(a->state, (int)e->hl, (int)e->hr,
+                         e->hl ? e->pack + 4 + (2 * (rank - 1) + 1) * h : nullptr,
+                         e->hr ? e->pack + 4 + 2 * (rank + 1) * h : nullptr,
+                         e->p_ext, e->p_ext + e->hl + a->n, stream);
+  if (rc) return rc;
+  ipx_csr_view H{(int)a->n, (int)(e->hl + a->n + e->hr), a->H_rowptr, a->H_colidx, a->H_val,
+                 a->H_tiles, (int)a->H_ntiles};
+  rc = ipx_spmv_launch(H, e->p_ext, 1.0, a->H_diag, 0.0, nullptr, a->Hp, a->part1, guard, st,
+                       a->p);
+  if (rc) return rc;
+  return ipx_fold2(a->part1, (int)a->H_ntiles, e->s1, nullptr, stream);
+}
+
 // Hp = H p with p'Hp partials (the tail of an iteration, also used once by
 // the host to prime the loop).
 int ipx_cg_hp(const ipx_cg_args *a, void *stream) {

@@ -39,6 +39,13 @@ ST_PTHP, ST_ORTH_RHS, ST_XNORM2, ST_VIOL, ST_ORTH, ST_IT_DONE = 8, 9, 10, 11, 12
 STATE_SIZE = 16
 
 
+class ShardExt(ctypes.Structure):
+    """Mirror of ipx_shard_ext (include/ipx.h)."""
+    _fields_ = [("p_ext", ctypes.c_void_p)] + \
+               [(k, ctypes.c_int64) for k in ("hl", "hr", "h", "rank", "world")] + \
+               [("s1", ctypes.c_void_p), ("pack", ctypes.c_void_p), ("np4", ctypes.c_int64)]
+
+
 def block_range(n, world, rank):
     return (rank * n) // world, ((rank + 1) * n) // world
 
@@ -102,6 +109,7 @@ class ShardedProjectedCG:
         self.p_left = eng.view(self.p_ext, 0, self.hl) if self.hl else None
         self.p_right = eng.view(self.p_ext, self.hl + self.nloc,
                                 self.hl + self.nloc + self.hr) if self.hr else None
+        self.np4 = 1
 
     # ---- collectives ---------------------------------------------------------
     def _allreduce(self, buf):
@@ -163,31 +171,21 @@ class ShardedProjectedCG:
         eng.assign(self.state, init)
         self._seed_p_halo()
         self._hp(guard=False)
+        eng.fold2(self.part1, eng.ntiles(self.H_rows), self.s1)
         return rt_g
 
     def iterate(self, it_begin, it_end):
-        """Enqueue iterations [it_begin, it_end); no host synchronisation."""
+        """Enqueue iterations [it_begin, it_end); no host synchronisation.  Each
+        iteration is three local segments separated by the three all-reduces
+        (s1 holds this rank's folded p'Hp partials on entry)."""
         eng = self.eng
-        st = self.state
-        nH, nAt = eng.ntiles(self.H_rows), eng.ntiles(self.At_rows)
-        scal2, scal3 = eng.view(self.pack, 0, 2), eng.view(self.pack, 2, 4)
         for it in range(it_begin, it_end):
-            eng.fold2(self.part1, nH, self.s1)
             self._allreduce(self.s1)                                   # p'Hp
-            eng.step1(st, it, self.s1, 1, self.x, self.p, self.r, self.Hp, self.part2,
-                      self.grid)
-            eng.spmv(self.A_cols, self.r, self.w, guard=st)            # partial A r
-            self._allreduce(self.w)
-            np4 = eng.solve_resid(self.solver, self.w, self.v, self.part4, guard=st)
-            eng.spmv(self.At_rows, self.v, self.r, alpha=-1.0, beta=1.0, yin=self.r,
-                     partial=self.part3, guard=st)                      # g = r - A'v
-            eng.shard_pack(self.part2, self.grid, self.part3, nAt, self.r, self.h, self.rank,
-                           self.world, self.pack)
+            eng.segment(self, 0, it)
+            self._allreduce(self.w)                                    # partial A r
+            eng.segment(self, 1, it)
             self._allreduce(self.pack)     # ||x+ap||^2, #viol, ||g||^2 + boundary g of all ranks
-            eng.step2(st, it, 0, scal2, 1, scal3, 1, self.part4, np4,
-                      self.x, self.p, self.r, self.grid)
-            eng.halo_apply(st, self.g_left, self.g_right, self.p_left, self.p_right)
-            self._hp()
+            eng.segment(self, 2, it)
 
     def read_state(self):
         return self.eng.download(self.state)
@@ -238,8 +236,66 @@ class ShardedProjectedCG:
                                  'hits_boundary': False}
 
 
-class HipEngine:
+class SegmentsByKernel:
+    """The three local segments of an iteration, kernel by kernel (what
+    ipx_cg_shard_segment does in one call).  The numpy engine of the test-suite
+    inherits this; HipEngine overrides it with the single C call."""
+
+    def segment(self, cg, phase, it):
+        st = cg.state
+        if phase == 0:
+            self.step1(st, it, cg.s1, 1, cg.x, cg.p, cg.r, cg.Hp, cg.part2, cg.grid)
+            self.spmv(cg.A_cols, cg.r, cg.w, guard=st)                 # partial A r
+        elif phase == 1:
+            cg.np4 = self.solve_resid(cg.solver, cg.w, cg.v, cg.part4, guard=st)
+            self.spmv(cg.At_rows, cg.v, cg.r, alpha=-1.0, beta=1.0, yin=cg.r,
+                      partial=cg.part3, guard=st)                       # g = r - A'v
+            self.shard_pack(cg.part2, cg.grid, cg.part3, self.ntiles(cg.At_rows), cg.r, cg.h,
+                            cg.rank, cg.world, cg.pack)
+        else:
+            self.step2(st, it, 0, self.view(cg.pack, 0, 2), 1, self.view(cg.pack, 2, 4), 1,
+                       cg.part4, cg.np4, cg.x, cg.p, cg.r, cg.grid)
+            self.halo_apply(st, cg.g_left, cg.g_right, cg.p_left, cg.p_right)
+            cg._hp()
+            self.fold2(cg.part1, self.ntiles(cg.H_rows), cg.s1)
+
+
+class HipEngine(SegmentsByKernel):
     """Local compute of the sharded loop on one GPU: ipx kernels."""
+
+    def segment(self, cg, phase, it):
+        args = getattr(cg, "_c_args", None)
+        if args is None:
+            args = cg._c_args = self._build_args(cg)
+        self._hip.call("ipx_cg_shard_segment", ctypes.byref(args[0]), ctypes.byref(args[1]),
+                       int(phase), int(it), self._st())
+
+    def _build_args(self, cg):
+        from .cg_fused import CgArgs
+        if cg.solver.perm is not None:
+            raise NotImplementedError("sharded CG needs A A' banded in its natural row order")
+        a = CgArgs()
+        a.n, a.m = cg.nloc, cg.m
+        for pre, M in (("A", cg.A_cols), ("At", cg.At_rows), ("H", cg.H_rows)):
+            pat = M.pattern
+            setattr(a, pre + "_rowptr", pat.indptr.data_ptr())
+            setattr(a, pre + "_colidx", pat.indices.data_ptr())
+            setattr(a, pre + "_val", M.val.data_ptr() if M.val.numel() else None)
+            setattr(a, pre + "_tiles", pat.tiles.data_ptr())
+            setattr(a, pre + "_ntiles", pat.ntiles)
+        a.H_diag = cg.hdiag.data_ptr() if cg.hdiag is not None else None
+        a.banded = cg.solver.handle
+        a.x, a.p, a.r, a.Hp = (t.data_ptr() for t in (cg.x, cg.p, cg.r, cg.Hp))
+        a.w, a.v, a.t = cg.w.data_ptr(), cg.v.data_ptr(), cg.t.data_ptr()
+        a.state = cg.state.data_ptr()
+        a.part1, a.part2, a.part3, a.part4 = (t.data_ptr() for t in (cg.part1, cg.part2,
+                                                                       cg.part3, cg.part4))
+        a.vec_grid, a.solver_kind = cg.grid, 0
+        e = ShardExt()
+        e.p_ext = cg.p_ext.data_ptr()
+        e.hl, e.hr, e.h, e.rank, e.world = cg.hl, cg.hr, cg.h, cg.rank, cg.world
+        e.s1, e.pack, e.np4 = cg.s1.data_ptr(), cg.pack.data_ptr(), 1
+        return a, e
 
     def __init__(self):
         from . import _hip, device

@@ -14,7 +14,12 @@ ST_RTG0, ST_RTG1, ST_TOL, ST_RADIUS, ST_ALPHA, ST_STOP, ST_NITER, ST_BETA = rang
 ST_PTHP, ST_ORTH_RHS, ST_XNORM2, ST_VIOL, ST_ORTH, ST_IT_DONE = 8, 9, 10, 11, 12, 13
 
 
-class NumpyEngine:
+def _segments_base():
+    from ipsolver.sharded import SegmentsByKernel
+    return SegmentsByKernel
+
+
+class NumpyEngine(_segments_base()):
     def zeros(self, n):
         return np.zeros(int(n))
 
