@@ -889,6 +889,17 @@ k_middle(LevArgs a, int nbuf_total, const double *__restrict__ slab, int nslab,
 }
 
 constexpr int DOWN_CHUNKS = 16;      // chunks (recurrence lanes) per workgroup in k_down0
+#ifndef IPX_DEC_CHUNKS
+#define IPX_DEC_CHUNKS 4
+#endif
+constexpr int DEC_CHUNKS = IPX_DEC_CHUNKS;   // own chunks per workgroup in k_solve_decoupled
+
+#ifdef IPX_PHASE_TIMING              // diagnostic build only (scripts/phase_timing.sh)
+__device__ unsigned long long ipx_dbg_stamps[16];
+#define IPX_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) ipx_dbg_stamps[k] = wall_clock64(); } while (0)
+#else
+#define IPX_STAMP(k) do { } while (0)
+#endif
 
 // Decoupled path in ONE launch.  When the separator system is diagonal
 // (SepValues above) a separator value needs only the two chunks next to it, so
@@ -905,6 +916,7 @@ k_solve_decoupled(LevDev lv, const double *__restrict__ w, double *__restrict__ 
   constexpr int NCH = T + 3;
   extern __shared__ double sm[];
   __shared__ double red_lds[DOWN_T / IPX_WAVE];
+  IPX_STAMP(0);
   const double stop = guard ? *guard : 0.0;   // requested with the staging loads, tested after
   const int q = lv.q, P = lv.P, m = lv.m, c = lv.c;
   const int qk = q + K;
@@ -973,24 +985,33 @@ k_solve_decoupled(LevDev lv, const double *__restrict__ w, double *__restrict__ 
     const int l = i / K, t = tfirst + l;
     return (t >= 0 && t < P - 1) ? rinv[(int64_t)t * K + (i - l * K)] : 0.0;
   };
-  // register budgets sized for the default 64-row chunks (q = 65); larger
+  // register budgets sized for the default 64-row chunks (q <= QD); larger
   // arrays spill into StageRegs::store's slow loop
-  StageRegs<5> g_w, g_D, g_w0;
-  StageRegs<5 * K> g_L, g_V, g_W;
-  StageRegs<5 * (K + 1)> g_B;
-  StageRegs<K * K> g_E, g_F;
-  StageRegs<K> g_r;
+  constexpr int QD = 66 + K;
+  constexpr int UW = (NCH * QD + DOWN_T - 1) / DOWN_T;              // rows incl. halo chunks
+  constexpr int UT = (NCH * (QD + K) + DOWN_T - 1) / DOWN_T;        // one table column set
+  constexpr int UO = (T * QD + K + DOWN_T - 1) / DOWN_T;            // own rows
+  constexpr int US = (NCH * K * K + DOWN_T - 1) / DOWN_T;
+  StageRegs<UW> g_w;
+  StageRegs<UT> g_D;
+  StageRegs<UO> g_w0;
+  StageRegs<UT * K> g_L;
+  StageRegs<UW * K> g_V, g_W;
+  StageRegs<UO *(K + 1)> g_B;
+  StageRegs<US> g_E, g_F, g_r;
   g_w.load(NCH * q, f_w);       g_D.load(qk * NCH, f_D);     g_L.load(qk * K * NCH, f_L);
   g_E.load(NCH * K * K, f_E);   g_F.load(NCH * K * K, f_F);  g_B.load((K + 1) * NB, f_B);
   g_w0.load(T * q, f_w0);       g_V.load(NV * K, f_V);       g_W.load(NV * K, f_W);
   g_r.load((NCH - 1) * K, f_r);
   if (stop != 0.0) return;
+  IPX_STAMP(1);
   g_w.store(sw, NCH * q, f_w);       g_D.store(sD, qk * NCH, f_D);
   g_L.store(sL, qk * K * NCH, f_L);  g_E.store(sE, NCH * K * K, f_E);
   g_F.store(sF, NCH * K * K, f_F);   g_B.store(sB, (K + 1) * NB, f_B);
   g_w0.store(sw0, T * q, f_w0);      g_V.store(sV, NV * K, f_V);
   g_W.store(sW, NV * K, f_W);        g_r.store(srinv, (NCH - 1) * K, f_r);
   __syncthreads();
+  IPX_STAMP(2);
 
   // ---- chunk recurrences + the two halves of every separator's reduced rhs
   if ((int)threadIdx.x < NCH) {
@@ -1003,13 +1024,16 @@ k_solve_decoupled(LevDev lv, const double *__restrict__ w, double *__restrict__ 
                           sgR - (int64_t)tfirst * K);
     }
   }
+  IPX_STAMP(3);
   __syncthreads();
+  IPX_STAMP(4);
   // ---- separator values  xs_t = (gL_t + gR_t) / R_tt   for t = t0-1 .. t0+T
   for (int i = threadIdx.x; i < (NCH - 1) * K; i += blockDim.x) {
     const int l = i / K, t = tfirst + l;
     sxs[i] = (t >= 0 && t < P - 1) ? (sgL[i] + sgR[i]) * srinv[i] : 0.0;
   }
   __syncthreads();
+  IPX_STAMP(5);
   // ---- corrected solution on the own rows and the K rows either side of them
   for (int li = q - K + (int)threadIdx.x; li < (T + 2) * q; li += blockDim.x) {
     const int l = li / q, j = li - l * q, t = tfirst + l;
@@ -1036,6 +1060,7 @@ k_solve_decoupled(LevDev lv, const double *__restrict__ w, double *__restrict__ 
   }
   if (!partial) return;
   __syncthreads();
+  IPX_STAMP(6);
   // ---- residual of the own rows out of LDS:  w_i - sum_d S[i][i+-d] x[i+-d]
   double acc = 0.0;
   for (int r = threadIdx.x; r < T * q; r += blockDim.x) {
@@ -1054,11 +1079,12 @@ k_solve_decoupled(LevDev lv, const double *__restrict__ w, double *__restrict__ 
   }
   const double tot = ipx_block_reduce<IPX_SUM>(acc, red_lds);
   if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+  IPX_STAMP(7);
 }
 
 template <int K>
 size_t decoupled_lds_doubles(int q) {
-  constexpr int T = DOWN_CHUNKS, NCH = T + 3;
+  constexpr int T = DEC_CHUNKS, NCH = T + 3;
   const size_t qk = q + K;
   return (size_t)2 * NCH * q + qk * NCH * (K + 1) + (size_t)2 * NCH * K * K +
          (size_t)(K + 1) * (T * q + K) + (size_t)4 * NCH * K + K + (size_t)T * q +
@@ -1070,13 +1096,13 @@ int launch_solve_decoupled(const LevDev &lv, const double *w, double *x, const d
                            double *partial, int *npartial, const double *guard, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void *)k_solve_decoupled<K, DOWN_CHUNKS>,
+    (void)hipFuncSetAttribute((const void *)k_solve_decoupled<K, DEC_CHUNKS>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);
     attr_set = true;
   }
-  const int grid = (lv.P + DOWN_CHUNKS - 1) / DOWN_CHUNKS;
+  const int grid = (lv.P + DEC_CHUNKS - 1) / DEC_CHUNKS;
   if (npartial) *npartial = grid;
-  hipLaunchKernelGGL((k_solve_decoupled<K, DOWN_CHUNKS>), dim3(grid), dim3(DOWN_T),
+  hipLaunchKernelGGL((k_solve_decoupled<K, DEC_CHUNKS>), dim3(grid), dim3(DOWN_T),
                      decoupled_lds_doubles<K>(lv.q) * sizeof(double), st, lv, w, x, rinv, partial,
                      guard);
   IPX_CHECK_LAUNCH();
@@ -1232,6 +1258,13 @@ T *dalloc(Banded *h, size_t n) {
 extern "C" {
 
 int ipx_banded_kmax(void) { return KMAX; }
+
+#ifdef IPX_PHASE_TIMING
+int ipx_debug_stamps(unsigned long long *out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(ipx_dbg_stamps), 16 * sizeof(unsigned long long)) ==
+                 hipSuccess ? 0 : -1;
+}
+#endif
 
 // Plan the level hierarchy for an m x m SPD matrix of half bandwidth k.
 // `chunk` = interior rows per chunk (0 = default).  Returns a handle or NULL.

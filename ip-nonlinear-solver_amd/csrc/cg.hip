@@ -65,12 +65,20 @@ k_cg_step1(int64_t n, double *st, int parity, const double *__restrict__ p1, int
     xv[u] = x[i]; pv[u] = p[i]; rv[u] = r[i]; hv[u] = Hp[i];
     if (lb) { lo[u] = lb[i]; hi[u] = ub[i]; }
   }
-  if (st[ST_STOP] != 0.0) return;
-  const bool lead = c == 0 && threadIdx.x == 0;
-  // p'Hp from the partials of the SpMV that produced Hp (second half: x.y sums)
-  const double ptHp = ipx_sum_partials<IPX_SUM>(p1 + np1, np1, lds);
+  // p'Hp from the partials of the SpMV that produced Hp (second half: x.y sums);
+  // its loads and the state words travel with the operand loads above
+  const double *const fparts[1] = {p1 + np1};
+  const int fcounts[1] = {np1};
+  ipx_fold_regs<1> fold;
+  fold.load(fparts, fcounts);
+  const double stop = st[ST_STOP];
   const double rtg = st[parity ? ST_RTG1 : ST_RTG0];
   const double tol = st[ST_TOL];
+  if (stop != 0.0) return;
+  const bool lead = c == 0 && threadIdx.x == 0;
+  double fout[1];
+  fold.finish(fparts, fcounts, lds, fout);
+  const double ptHp = fout[0];
   if (rtg < tol) {                                   // qp_subproblem.py:551
     if (lead) st[ST_STOP] = 4.0;
     return;
@@ -125,16 +133,23 @@ k_cg_step2(int64_t n, double *st, int parity, int mode, const double *__restrict
     const int64_t i = min(i0 + u * VB, n - 1);
     xv[u] = x[i]; pv[u] = p[i]; gv[u] = g[i];
   }
-  if (st[ST_STOP] != 0.0) return;
-  const bool lead = c == 0 && threadIdx.x == 0;
-  // ||x+ap||^2, #violations, ||g||^2, ||A g||^2 folded together (one latency)
+  // ||x+ap||^2, #violations, ||g||^2, ||A g||^2 folded together; their loads and
+  // the state words travel with the operand loads above (one latency in all)
   const double *const parts[4] = {p2, p2 + np2, p3, p4};
   const int counts[4] = {(mode & 1) ? 0 : np2, (mode & 1) ? 0 : np2, np3, (mode & 2) ? 0 : np4};
+  ipx_fold_regs<4> fold;
+  fold.load(parts, counts);
+  const double stop = st[ST_STOP];
+  const double radius = st[ST_RADIUS], orth_rhs = st[ST_ORTH_RHS];
+  const double rtg = st[parity ? ST_RTG1 : ST_RTG0];
+  const double alpha = st[ST_ALPHA];
+  if (stop != 0.0) return;
+  const bool lead = c == 0 && threadIdx.x == 0;
   double red[4];
-  ipx_sum_partials_multi<4>(parts, counts, lds, red);
+  fold.finish(parts, counts, lds, red);
   if (!(mode & 1)) {
     const double xn2 = red[0], viol = red[1];
-    if (sqrt(xn2) >= st[ST_RADIUS]) {                // :583
+    if (sqrt(xn2) >= radius) {                       // :583
       if (lead) { st[ST_XNORM2] = xn2; st[ST_STOP] = 2.0; }
       return;
     }
@@ -146,16 +161,14 @@ k_cg_step2(int64_t n, double *st, int parity, int mode, const double *__restrict
   const double gg = red[2];                          // ||g_next||^2
   if (!(mode & 2)) {
     const double tt = red[3];                        // ||A g_next||^2
-    const double rhs = st[ST_ORTH_RHS];
+    const double rhs = orth_rhs;
     // orthogonality(A, g) > orth_tol  <=>  ||A g|| > orth_tol ||A||_F ||g||
     if (rhs > 0.0 && gg > 0.0 && sqrt(tt) > rhs * sqrt(gg)) {
       if (lead) { st[ST_ORTH] = sqrt(tt) / sqrt(gg); st[ST_STOP] = 6.0; }
       return;
     }
   }
-  const double rtg = st[parity ? ST_RTG1 : ST_RTG0];
   const double beta = gg / rtg;                      // :627
-  const double alpha = st[ST_ALPHA];
   if (lead) {
     st[parity ? ST_RTG0 : ST_RTG1] = gg;             // :633
     st[ST_BETA] = beta;

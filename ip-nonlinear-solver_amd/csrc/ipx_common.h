@@ -168,6 +168,52 @@ __device__ __forceinline__ void ipx_sum_partials_multi(const double *const (&par
   __syncthreads();
 }
 
+// The same fold in two halves: load() requests the first IPX_FOLD_U * blockDim
+// entries of every array (no use yet), finish() adds them -- plus any entries
+// beyond, the slow way -- and reduces.  Lets a kernel put the fold's loads in
+// flight together with its first operand loads (one memory latency for both).
+template <int NQ>
+struct ipx_fold_regs {
+  double t[NQ][IPX_FOLD_U];
+  __device__ __forceinline__ void load(const double *const (&part)[NQ], const int (&count)[NQ]) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+      for (int u = 0; u < IPX_FOLD_U; ++u) {
+        const int i = threadIdx.x + u * blockDim.x;
+        t[q][u] = i < count[q] ? part[q][i] : 0.0;
+      }
+    }
+  }
+  __device__ __forceinline__ void finish(const double *const (&part)[NQ], const int (&count)[NQ],
+                                         double *lds, double (&out)[NQ]) const {
+    double v[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      v[q] = 0.0;
+#pragma unroll
+      for (int u = 0; u < IPX_FOLD_U; ++u) v[q] += t[q][u];
+      for (int i = threadIdx.x + IPX_FOLD_U * blockDim.x; i < count[q]; i += blockDim.x)
+        v[q] += part[q][i];
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      v[q] = ipx_wave_sum(v[q]);
+      if (lane == 0) lds[q * nw + wave] = v[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      double r = lds[q * nw];
+      for (int w = 1; w < nw; ++w) r += lds[q * nw + w];
+      out[q] = r;
+    }
+    __syncthreads();
+  }
+};
+
 // ---- internal (non-ABI) launchers shared between translation units --------
 struct ipx_csr_view {
   int nrows, ncols;

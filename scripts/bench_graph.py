@@ -6,7 +6,8 @@ import numpy as np, torch
 from ipsolver import _hip, cg_fused, projector, device as dv
 from ipsolver.operators import DeviceHessian
 from ipsolver.synthetic import CenteredBandedNLP
-n, m = 1000000, 100000
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
+m = n // 10
 prob = CenteredBandedNLP(n, m)
 x = prob.x0
 v = 0.1 * np.random.default_rng(7).standard_normal(m)
@@ -28,8 +29,8 @@ lib.ipx_cg_hp(L.ref(), st)
 lib.ipx_cg_iterate(L.ref(), 0, 20, st)
 torch.cuda.synchronize()
 K = 200
-t0 = time.perf_counter(); lib.ipx_cg_iterate(L.ref(), 20, 20 + K, st); torch.cuda.synchronize()
-print("eager  us/iter %.2f" % ((time.perf_counter() - t0) / K * 1e6))
+t0 = time.perf_counter(); lib.ipx_cg_iterate(L.ref(), 20, 20 + K, st); th = time.perf_counter() - t0; torch.cuda.synchronize()
+print("n=%d eager  us/iter %.2f  (host enqueue %.2f)" % (n, (time.perf_counter() - t0) / K * 1e6, th / K * 1e6))
 g = lib.ipx_cg_graph_create(L.ref(), st)
 torch.cuda.synchronize()
 assert g, "graph capture failed"
