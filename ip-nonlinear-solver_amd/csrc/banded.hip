@@ -894,12 +894,8 @@ constexpr int DOWN_CHUNKS = 16;      // chunks (recurrence lanes) per workgroup 
 #endif
 constexpr int DEC_CHUNKS = IPX_DEC_CHUNKS;   // own chunks per workgroup in k_solve_decoupled
 
-#ifdef IPX_PHASE_TIMING              // diagnostic build only (scripts/phase_timing.sh)
-__device__ unsigned long long ipx_dbg_stamps[16];
-#define IPX_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) ipx_dbg_stamps[k] = wall_clock64(); } while (0)
-#else
-#define IPX_STAMP(k) do { } while (0)
-#endif
+IPX_STAMP_DECL(ipx_dbg_stamps);
+#define IPX_STAMP(k) IPX_STAMP_TO(ipx_dbg_stamps, k)
 
 // Decoupled path in ONE launch.  When the separator system is diagonal
 // (SepValues above) a separator value needs only the two chunks next to it, so
@@ -1259,12 +1255,7 @@ extern "C" {
 
 int ipx_banded_kmax(void) { return KMAX; }
 
-#ifdef IPX_PHASE_TIMING
-int ipx_debug_stamps(unsigned long long *out) {
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(ipx_dbg_stamps), 16 * sizeof(unsigned long long)) ==
-                 hipSuccess ? 0 : -1;
-}
-#endif
+IPX_STAMP_EXPORT(ipx_debug_stamps, ipx_dbg_stamps)
 
 // Plan the level hierarchy for an m x m SPD matrix of half bandwidth k.
 // `chunk` = interior rows per chunk (0 = default).  Returns a handle or NULL.

@@ -40,6 +40,9 @@ enum {
 
 namespace {
 
+IPX_STAMP_DECL(ipx_dbg_cg);
+#define CG_STAMP(k) IPX_STAMP_TO(ipx_dbg_cg, k)
+
 constexpr int VB = IPX_BLOCK;
 
 constexpr int VU = 8;        // elements per lane per trip, loads issued together (one trip at n = 1e6)
@@ -56,8 +59,17 @@ k_cg_step1(int64_t n, double *st, int parity, const double *__restrict__ p1, int
   const int64_t len = (n + nchunks - 1) / nchunks;
   const int64_t lo_i = (int64_t)c * len, hi_i = min(n, lo_i + len);
   int64_t i0 = lo_i + threadIdx.x;
-  // First trip's operands are requested before the prologue: the streaming
-  // loads overlap the scalar fold instead of queueing behind it.
+  // Request order = arrival order (vmcnt counts in order): first the state
+  // words and the partials of p'Hp (second half of the SpMV's partials: x.y
+  // sums), then the first trip's operands.  The scalar fold below then runs
+  // while the operand loads are still streaming in.
+  const double *const fparts[1] = {p1 + np1};
+  const int fcounts[1] = {np1};
+  const double stop = st[ST_STOP];
+  const double rtg = st[parity ? ST_RTG1 : ST_RTG0];
+  const double tol = st[ST_TOL];
+  ipx_fold_regs<1> fold;
+  fold.load(fparts, fcounts);
   double xv[VU], pv[VU], rv[VU], hv[VU], lo[VU], hi[VU];
 #pragma unroll
   for (int u = 0; u < VU; ++u) {
@@ -65,15 +77,6 @@ k_cg_step1(int64_t n, double *st, int parity, const double *__restrict__ p1, int
     xv[u] = x[i]; pv[u] = p[i]; rv[u] = r[i]; hv[u] = Hp[i];
     if (lb) { lo[u] = lb[i]; hi[u] = ub[i]; }
   }
-  // p'Hp from the partials of the SpMV that produced Hp (second half: x.y sums);
-  // its loads and the state words travel with the operand loads above
-  const double *const fparts[1] = {p1 + np1};
-  const int fcounts[1] = {np1};
-  ipx_fold_regs<1> fold;
-  fold.load(fparts, fcounts);
-  const double stop = st[ST_STOP];
-  const double rtg = st[parity ? ST_RTG1 : ST_RTG0];
-  const double tol = st[ST_TOL];
   if (stop != 0.0) return;
   const bool lead = c == 0 && threadIdx.x == 0;
   double fout[1];
@@ -122,31 +125,35 @@ k_cg_step2(int64_t n, double *st, int parity, int mode, const double *__restrict
            const double *__restrict__ p3, int np3, const double *__restrict__ p4, int np4,
            double *x, double *p, const double *__restrict__ g, int nchunks) {
   __shared__ double lds[4 * (VB / IPX_WAVE)];
+  CG_STAMP(0);
   const int c = ipx_xcd_item(blockIdx.x, nchunks);   // same element -> XCD map as step1
   if (c < 0) return;
   const int64_t len = (n + nchunks - 1) / nchunks;
   const int64_t lo_i = (int64_t)c * len, hi_i = min(n, lo_i + len);
   int64_t i0 = lo_i + threadIdx.x;
+  // Request order = arrival order: state words and the four partial arrays
+  // (||x+ap||^2, #violations, ||g||^2, ||A g||^2) first, operands after, so the
+  // fold runs while the operands stream in.
+  const double *const parts[4] = {p2, p2 + np2, p3, p4};
+  const int counts[4] = {(mode & 1) ? 0 : np2, (mode & 1) ? 0 : np2, np3, (mode & 2) ? 0 : np4};
+  const double stop = st[ST_STOP];
+  const double radius = st[ST_RADIUS], orth_rhs = st[ST_ORTH_RHS];
+  const double rtg = st[parity ? ST_RTG1 : ST_RTG0];
+  const double alpha = st[ST_ALPHA];
+  ipx_fold_regs<4> fold;
+  fold.load(parts, counts);
   double xv[VU], pv[VU], gv[VU];
 #pragma unroll
   for (int u = 0; u < VU; ++u) {
     const int64_t i = min(i0 + u * VB, n - 1);
     xv[u] = x[i]; pv[u] = p[i]; gv[u] = g[i];
   }
-  // ||x+ap||^2, #violations, ||g||^2, ||A g||^2 folded together; their loads and
-  // the state words travel with the operand loads above (one latency in all)
-  const double *const parts[4] = {p2, p2 + np2, p3, p4};
-  const int counts[4] = {(mode & 1) ? 0 : np2, (mode & 1) ? 0 : np2, np3, (mode & 2) ? 0 : np4};
-  ipx_fold_regs<4> fold;
-  fold.load(parts, counts);
-  const double stop = st[ST_STOP];
-  const double radius = st[ST_RADIUS], orth_rhs = st[ST_ORTH_RHS];
-  const double rtg = st[parity ? ST_RTG1 : ST_RTG0];
-  const double alpha = st[ST_ALPHA];
   if (stop != 0.0) return;
+  CG_STAMP(1);
   const bool lead = c == 0 && threadIdx.x == 0;
   double red[4];
   fold.finish(parts, counts, lds, red);
+  CG_STAMP(2);
   if (!(mode & 1)) {
     const double xn2 = red[0], viol = red[1];
     if (sqrt(xn2) >= radius) {                       // :583
@@ -191,6 +198,7 @@ k_cg_step2(int64_t n, double *st, int parity, int mode, const double *__restrict
       xv[u] = x[i]; pv[u] = p[i]; gv[u] = g[i];
     }
   }
+  CG_STAMP(3);
 }
 
 // Row-sharded loop (ipsolver/sharded.py): the first and last h entries of the
@@ -244,6 +252,8 @@ k_cg_halo_apply(const double *__restrict__ st, int hl, int hr, const double *__r
 }
 
 }  // namespace
+
+IPX_STAMP_EXPORT(ipx_debug_stamps_cg, ipx_dbg_cg)
 
 extern "C" {
 

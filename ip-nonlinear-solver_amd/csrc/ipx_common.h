@@ -43,22 +43,52 @@ __device__ __forceinline__ int ipx_xcd_item(int block, int nitems) {
 }
 
 // ---- fixed-order reductions -------------------------------------------
-// Wave: butterfly over 64 lanes (xor 32,16,...,1); every lane ends with the
-// same bits.  Block: wave results through LDS, summed in wave order.
+// Wave: DPP butterfly inside each row of 16 lanes (xor 1, xor 2, half-row
+// mirror, row mirror: four v_mov_dpp pairs, no LDS crossbar), then the four
+// row totals are read as scalars and combined in row order; every lane ends
+// with the same bits.  (__shfl_xor compiles to ds_bpermute: ~6x the latency.)
+// All 64 lanes must be active.  Block: wave results through LDS, in wave order.
+template <int CTRL>
+__device__ __forceinline__ double ipx_dpp(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double ipx_readlane(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+#define IPX_WAVE_REDUCE(v, COMB)                                                  \
+  do {                                                                            \
+    v = COMB(v, ipx_dpp<0xB1>(v));  /* quad_perm [1,0,3,2] */                     \
+    v = COMB(v, ipx_dpp<0x4E>(v));  /* quad_perm [2,3,0,1] */                     \
+    v = COMB(v, ipx_dpp<0x141>(v)); /* row_half_mirror     */                     \
+    v = COMB(v, ipx_dpp<0x140>(v)); /* row_mirror          */                     \
+    const double r0 = ipx_readlane(v, 0), r1 = ipx_readlane(v, 16);               \
+    const double r2 = ipx_readlane(v, 32), r3 = ipx_readlane(v, 48);              \
+    v = COMB(COMB(r0, r1), COMB(r2, r3));                                         \
+  } while (0)
+#define IPX_ADD(a, b) ((a) + (b))
 __device__ __forceinline__ double ipx_wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, IPX_WAVE);
+  IPX_WAVE_REDUCE(v, IPX_ADD);
   return v;
 }
 __device__ __forceinline__ double ipx_wave_max(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, IPX_WAVE));
+  IPX_WAVE_REDUCE(v, fmax);
   return v;
 }
 __device__ __forceinline__ double ipx_wave_min(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off, IPX_WAVE));
+  IPX_WAVE_REDUCE(v, fmin);
   return v;
+}
+
+// Workgroup barrier for exchanges that go through LDS only: waits for this
+// wave's LDS traffic, NOT for its outstanding global loads/stores
+// (__syncthreads() also drains vmcnt -- ~2 us when stores are in flight).
+__device__ __forceinline__ void ipx_lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 enum { IPX_SUM = 0, IPX_MAX = 1, IPX_MIN = 2 };
@@ -91,10 +121,10 @@ __device__ __forceinline__ double ipx_block_reduce(double v, double *lds) {
   const int nw = (blockDim.x + 63) >> 6;
   v = ipx_wave_reduce<OP>(v);
   if (lane == 0) lds[wave] = v;
-  __syncthreads();
+  ipx_lds_barrier();
   double r = lds[0];
   for (int w = 1; w < nw; ++w) r = ipx_combine<OP>(r, lds[w]);
-  __syncthreads();
+  ipx_lds_barrier();
   return r;
 }
 
@@ -158,14 +188,14 @@ __device__ __forceinline__ void ipx_sum_partials_multi(const double *const (&par
     v[q] = ipx_wave_sum(v[q]);
     if (lane == 0) lds[q * nw + wave] = v[q];
   }
-  __syncthreads();
+  ipx_lds_barrier();
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
     double r = lds[q * nw];
     for (int w = 1; w < nw; ++w) r += lds[q * nw + w];
     out[q] = r;
   }
-  __syncthreads();
+  ipx_lds_barrier();
 }
 
 // The same fold in two halves: load() requests the first IPX_FOLD_U * blockDim
@@ -203,16 +233,33 @@ struct ipx_fold_regs {
       v[q] = ipx_wave_sum(v[q]);
       if (lane == 0) lds[q * nw + wave] = v[q];
     }
-    __syncthreads();
+    ipx_lds_barrier();
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       double r = lds[q * nw];
       for (int w = 1; w < nw; ++w) r += lds[q * nw + w];
       out[q] = r;
     }
-    __syncthreads();
+    ipx_lds_barrier();
   }
 };
+
+// ---- diagnostic build only (-DIPX_PHASE_TIMING, scripts/phase_timing.py): in-kernel
+// wall-clock stamps of workgroup 0, one array per translation unit.
+#ifdef IPX_PHASE_TIMING
+#define IPX_STAMP_DECL(name) __device__ unsigned long long name[16]
+#define IPX_STAMP_TO(name, k) \
+  do { if (blockIdx.x == 0 && threadIdx.x == 0) name[k] = wall_clock64(); } while (0)
+#define IPX_STAMP_EXPORT(fn, name)                                                         \
+  extern "C" int fn(unsigned long long *out) {                                             \
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(name), 16 * sizeof(unsigned long long)) ==  \
+                   hipSuccess ? 0 : -1;                                                    \
+  }
+#else
+#define IPX_STAMP_DECL(name)
+#define IPX_STAMP_TO(name, k) do { } while (0)
+#define IPX_STAMP_EXPORT(fn, name)
+#endif
 
 // ---- internal (non-ABI) launchers shared between translation units --------
 struct ipx_csr_view {

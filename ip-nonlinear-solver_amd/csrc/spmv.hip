@@ -19,6 +19,9 @@
 
 namespace {
 
+IPX_STAMP_DECL(ipx_dbg_spmv);
+#define SPMV_STAMP(k) IPX_STAMP_TO(ipx_dbg_spmv, k)
+
 constexpr int TILE_NNZ = IPX_SPMV_TILE_NNZ;
 constexpr int TILE_ROWS = IPX_SPMV_TILE_ROWS;   // max rows per tile (ipx_csr_tiles_host max_rows)
 
@@ -32,6 +35,7 @@ k_csr_spmv(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colid
   __shared__ double prod[TILE_NNZ];
   __shared__ int rp[TILE_ROWS + 1];
   __shared__ double red_lds[IPX_BLOCK / IPX_WAVE];
+  SPMV_STAMP(0);
   const int tile = ipx_xcd_item(blockIdx.x, ntiles);
   if (tile < 0) return;
   // One round trip for everything the tile's addresses depend on: the stop
@@ -41,6 +45,7 @@ k_csr_spmv(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colid
   const int r0 = tiles[tile], r1 = tiles[tile + 1];
   const int s = tiles[ntiles + 1 + tile], e = tiles[ntiles + 2 + tile];
   if (stop != 0.0) return;              // device-side stop flag of the fused CG loop
+  SPMV_STAMP(1);
   double acc_yy = 0.0, acc_xy = 0.0;
 
   const int nrows = r1 - r0;
@@ -56,7 +61,7 @@ k_csr_spmv(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colid
 #pragma unroll
     for (int q = 0; q <= Q; ++q) {
       const int i = tid + q * IPX_BLOCK;
-      rpv[q] = (i <= nrows) ? rowptr[r0 + i] - s : 0;
+      rpv[q] = rowptr[r0 + min(i, nrows)] - s;     // unconditional: no branch, no wait per load
     }
     // epilogue operands of this lane's rows: requested with the first batch
     // (before the dependent gathers), consumed after the barrier
@@ -77,9 +82,15 @@ k_csr_spmv(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colid
         c[u] = colidx[jj];
         v[u] = val[jj];
       }
+      SPMV_STAMP(2);
       double xg[U];
 #pragma unroll
+#ifdef IPX_EXP_NOGATHER              // experiment: what do the gathers cost?
+      for (int u = 0; u < U; ++u) xg[u] = (double)c[u];
+#else
       for (int u = 0; u < U; ++u) xg[u] = x[c[u]];
+#endif
+      SPMV_STAMP(3);
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int jj = s + tid + u * IPX_BLOCK;
@@ -91,25 +102,47 @@ k_csr_spmv(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colid
       const int i = tid + q * IPX_BLOCK;
       if (i <= nrows) rp[i] = rpv[q];
     }
+    SPMV_STAMP(4);
     __syncthreads();
-    // Phase 2: one lane per row, left-to-right row sums out of LDS.
+    SPMV_STAMP(5);
+    // Phase 2: one lane per row, left-to-right row sums out of LDS.  The y
+    // values stay in registers until the block reduction is done: the stores
+    // are the last thing the workgroup issues (nothing waits on them).
+    double yq[Q];
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
       const int i = tid + q * IPX_BLOCK;
+      yq[q] = 0.0;
       if (i < nrows) {
         const int a = rp[i], b = rp[i + 1];
         double sum = 0.0;
+#ifdef IPX_EXP_NOROWS                // experiment: what does the LDS row-sum phase cost?
+        sum = prod[a] + (double)b;
+#else
         for (int k = a; k < b; ++k) sum += prod[k];
+#endif
         double y = alpha * sum;
         if (HAS_DIAG) y += dg[q] * xr[q];
         if (HAS_YIN) y += beta * yi[q];
-        yout[r0 + i] = y;
+        yq[q] = y;
         if (REDUCE) {
           acc_yy += y * y;
           if (xrow) acc_xy += xr[q] * y;
         }
       }
     }
+    if (REDUCE) {
+      const double a = ipx_block_reduce<IPX_SUM>(acc_yy, red_lds);
+      const double b = ipx_block_reduce<IPX_SUM>(acc_xy, red_lds);
+      if (threadIdx.x == 0) { partial[tile] = a; partial[ntiles + tile] = b; }
+    }
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const int i = tid + q * IPX_BLOCK;
+      if (i < nrows) yout[r0 + i] = yq[q];
+    }
+    SPMV_STAMP(7);
+    return;
   } else if (e - s <= TILE_NNZ) {
     // (tiles with more rows than TILE_ROWS: generic loops)
     for (int j = s + (int)threadIdx.x; j < e; j += IPX_BLOCK)
@@ -148,11 +181,13 @@ k_csr_spmv(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colid
       }
     }
   }
+  SPMV_STAMP(6);
   if (REDUCE) {
     double a = ipx_block_reduce<IPX_SUM>(acc_yy, red_lds);
     double b = ipx_block_reduce<IPX_SUM>(acc_xy, red_lds);
     if (threadIdx.x == 0) { partial[tile] = a; partial[ntiles + tile] = b; }
   }
+  SPMV_STAMP(7);
 }
 
 // Fold per-tile partials (any count) into red[0..1] in tile order.
@@ -200,6 +235,8 @@ int ipx_spmv_launch(const ipx_csr_view &A, const double *x, double alpha, const 
   IPX_CHECK_LAUNCH();
   return IPX_OK;
 }
+
+IPX_STAMP_EXPORT(ipx_debug_stamps_spmv, ipx_dbg_spmv)
 
 extern "C" {
 

@@ -33,3 +33,36 @@ print("n=%d m=%d decoupled=%d  (wall_clock64 ticks of 10 ns)" % (n, m, lib.ipx_b
 for k in range(7):
     print("  %-22s %6.2f us" % (names[k + 1], acc[k] / R * 0.01))
 print("  total in-kernel        %6.2f us" % (acc.sum() / R * 0.01))
+
+# ---- the loop's last H.p SpMV and last step2 (workgroup 0) -------------------
+from ipsolver import cg_fused
+from ipsolver.operators import DeviceHessian
+x = prob.x0
+vv = 0.1 * np.random.default_rng(7).standard_normal(m)
+H = DeviceHessian(n, dv.DeviceCSR.from_scipy(prob.hess(x)), dv.DVec.from_host(prob.kappa * prob.Wt.dot(vv)))
+c = dv.DVec.from_host(prob.grad(x)); b = dv.DVec.zeros(m)
+P = Z.projector
+st = dv.stream_ptr()
+x0 = Y.dot(-b); r0 = Z.dot(H.dot(x0) + c); g0 = Z.dot(r0); rt_g = g0.sumsq_amax()[0]
+L = cg_fused._Loop(H, P, None, None)
+L.x.copy_(x0.t); L.r.copy_(r0.t)
+_hip.call("ipx_axpby", n, -1.0, dv._p(g0.t), 0.0, None, dv._p(L.p), st)
+init = np.zeros(L.state.numel()); init[0] = rt_g; init[3] = np.inf; init[9] = P.orth_tol * P.norm_A
+L.state.copy_(torch.from_numpy(init))
+lib.ipx_cg_hp(L.ref(), st)
+acc_s, acc_c = np.zeros(7), np.zeros(3)
+for rep in range(40):
+    lib.ipx_cg_iterate(L.ref(), 2 * rep, 2 * rep + 2, st)
+    torch.cuda.synchronize()
+    out = (ctypes.c_ulonglong * 16)(); lib.ipx_debug_stamps_spmv(out)
+    acc_s += np.diff(np.array(list(out)[:8], dtype=np.float64))
+    out = (ctypes.c_ulonglong * 16)(); lib.ipx_debug_stamps_cg(out)
+    acc_c += np.diff(np.array(list(out)[:4], dtype=np.float64))
+print("H.p SpMV, workgroup 0:")
+for k, nm in enumerate(["tile info + guard", "batch-1 loads landed (colidx,val,...)", "gathers issued", "gathers landed + LDS stores", "barrier", "row sums + y stores", "reduce + partial"]):
+    print("  %-40s %6.2f us" % (nm, acc_s[k] / 40 * 0.01))
+print("  total %.2f us" % (acc_s.sum() / 40 * 0.01))
+print("step2, workgroup 0:")
+for k, nm in enumerate(["operand + partial + state loads", "fold", "update + stores"]):
+    print("  %-40s %6.2f us" % (nm, acc_c[k] / 40 * 0.01))
+print("  total %.2f us" % (acc_c.sum() / 40 * 0.01))
