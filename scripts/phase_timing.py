@@ -1,5 +1,5 @@
-"""In-kernel phase timing of k_solve_decoupled (diagnostic build: compile csrc with
--DIPX_PHASE_TIMING into ip-nonlinear-solver_amd/lib_dbg/libipx.so; dev tool)."""
+"""In-kernel phase timing (workgroup 0) of the banded solve, the H.p SpMV and step2.
+Needs the diagnostic build:  make -C ip-nonlinear-solver_amd/csrc phase-timing   (dev tool)."""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "ip-nonlinear-solver_amd"))
