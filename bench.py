@@ -64,9 +64,25 @@ def sharded_leg(args, world, rank, A_h, H_h, hdiag_h, c_h, n, m, K, W):
     if int(s[ST_STOP]) != 0 or int(s[ST_IT_DONE]) != W + K:
         raise SystemExit("timed region did not run %d iterations: stop=%s done=%s"
                          % (K, s[ST_STOP], s[ST_IT_DONE]))
-    tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    tt = torch.tensor([elapsed], dtype=torch.float64,
+                      device="cuda" if dist.get_backend() == "nccl" else "cpu")
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     elapsed = float(tt.item())
+    # ---- untimed: the sharded iterate against the single-GPU fused loop (rank 0)
+    x_sharded = cg.gather_x()                      # collective
+    parity = None
+    if rank == 0:
+        try:
+            from ipsolver import device as dv, projector, qp
+            from ipsolver.operators import DeviceHessian
+            H1 = DeviceHessian(n, csr=dv.DeviceCSR.from_scipy(H_h), diag=dv.DVec.from_host(hdiag_h))
+            Z1, _, Y1 = projector.projections(dv.DeviceCSR.from_scipy(A_h))
+            x1, info1 = qp.projected_cg(H1, c_h, Z1, Y1, np.zeros(m), tol=0.0, max_iter=W + K)
+            x1 = x1.to_host()
+            parity = {"iterations": int(info1["niter"]),
+                      "max_rel_diff": float(np.max(np.abs(x_sharded - x1)) / np.max(np.abs(x1)))}
+        except Exception as exc:                   # never lose the measurement over the check
+            parity = {"error": repr(exc)}
     nnzA, nnzH = A_h.nnz, H_h.nnz
     iter_bytes = (spmv_bytes(nnzH, n, n, 1) + spmv_bytes(nnzA, m, n)
                   + spmv_bytes(nnzA, n, m, 1) + 2 * 5 * 8 * n + 4 * 8 * m)
@@ -86,6 +102,7 @@ def sharded_leg(args, world, rank, A_h, H_h, hdiag_h, c_h, n, m, K, W):
                      "unit": "GB/s",
                      "frac": iter_bytes / (elapsed / K) / 1e9 / (HBM_PEAK_GBS * world),
                      "traffic": None},
+        "parity_vs_single_gpu": parity,
         "collectives_per_iteration": {"all_reduce": 3, "halo_exchange": 0,
                                       "bytes_all_reduce": 8 * m + 8 * (6 + 2 * cg.h * world)},
     }
@@ -115,9 +132,16 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks (WORLD_SIZE=%d)"
                          % (args.gpus, args.gpus, world))
-    torch.cuda.set_device(local_rank)
+    # IPX_BENCH_BACKEND=gloo lets the N > 1 leg be exercised on a one-GPU box (all ranks share
+    # cuda:0, collectives staged through the host); the measured configuration is nccl = RCCL.
+    backend = os.environ.get("IPX_BENCH_BACKEND", "nccl")
+    device_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend)
 
     from ipsolver import _hip, cg_fused, projector
     from ipsolver import device as dv
