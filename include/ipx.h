@@ -68,6 +68,8 @@ int ipx_gather(int64_t n, const double *x, const int32_t *idx, const double *sig
 /* out[idx[i]] = x[i] (refresh of the slack entries of the augmented Jacobian,
  * tr_interior_point.py:186-191). */
 int ipx_scatter(int64_t n, const double *x, const int32_t *idx, double *out, void *stream);
+/* out[idx[i]] += x[i], idx without repeats (no atomics). */
+int ipx_scatter_add(int64_t n, const double *x, const int32_t *idx, double *out, void *stream);
 /* Barrier elementwise ops (tr_interior_point.py:92-93,216-220,294):
  * out = max(x, c);  out = v > 0 ? a : c;  s[mask != 0] = -c[mask != 0]. */
 int ipx_max_scalar(int64_t n, const double *x, double c, double *out, void *stream);

@@ -58,6 +58,14 @@ struct OpNegMasked {   // s[mask] = -c[mask], other entries unchanged
 };
 
 __global__ void __launch_bounds__(IPX_BLOCK)
+k_scatter_add(int64_t n, const double *__restrict__ x, const int32_t *__restrict__ idx,
+              double *out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    out[idx[i]] += x[i];
+}
+
+__global__ void __launch_bounds__(IPX_BLOCK)
 k_scatter(int64_t n, const double *__restrict__ x, const int32_t *__restrict__ idx, double *out) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
@@ -274,6 +282,17 @@ int ipx_scatter(int64_t n, const double *x, const int32_t *idx, double *out, voi
   if (n < 0 || !x || !idx || !out) return IPX_EINVAL;
   if (n == 0) return IPX_OK;
   hipLaunchKernelGGL(k_scatter, dim3(ipx_grid_for(n, IPX_BLOCK * 4)), dim3(IPX_BLOCK), 0,
+                     (hipStream_t)stream, n, x, idx, out);
+  IPX_CHECK_LAUNCH();
+  return IPX_OK;
+}
+
+// out[idx[i]] += x[i]; idx must not repeat (no atomics).  Merges the values of
+// several sparse terms into their union pattern (backend_hip.hessian_operator).
+int ipx_scatter_add(int64_t n, const double *x, const int32_t *idx, double *out, void *stream) {
+  if (n == 0) return IPX_OK;
+  if (n < 0 || !x || !idx || !out) return IPX_EINVAL;
+  hipLaunchKernelGGL(k_scatter_add, dim3(ipx_grid_for(n, IPX_BLOCK * 4)), dim3(IPX_BLOCK), 0,
                      (hipStream_t)stream, n, x, idx, out);
   IPX_CHECK_LAUNCH();
   return IPX_OK;

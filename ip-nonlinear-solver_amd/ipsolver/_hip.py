@@ -24,6 +24,7 @@ _SIGNATURES = {
     "ipx_affine": [_I64, _F64, _P, _F64, _P, _P],
     "ipx_gather": [_I64, _P, _P, _P, _P, _P, _P],
     "ipx_scatter": [_I64, _P, _P, _P, _P],
+    "ipx_scatter_add": [_I64, _P, _P, _P, _P],
     "ipx_max_scalar": [_I64, _P, _F64, _P, _P],
     "ipx_where_positive": [_I64, _P, _P, _F64, _P, _P],
     "ipx_assign_negated_where": [_I64, _P, _P, _P, _P],

@@ -143,6 +143,41 @@ def _extend_pattern(pattern, n_total):
     return cache[n_total]
 
 
+_merge_cache = {}
+
+
+def _merge_sparse_terms(terms):
+    """Sum of scipy CSR matrices as a DeviceCSR on the union of their patterns.
+    The union pattern and the position of every term's nonzeros in it are
+    symbolic work (host, cached per combination of patterns); the values are
+    uploaded and added by ipx_scatter_add."""
+    shape = terms[0].shape
+    key = tuple((t.shape, t.nnz, hash(t.indptr.tobytes()), hash(t.indices.tobytes()))
+                for t in terms)
+    hit = _merge_cache.get(key)
+    if hit is None:
+        ncols = shape[1]
+        keys = []
+        for t in terms:
+            rows = np.repeat(np.arange(shape[0], dtype=np.int64), np.diff(t.indptr))
+            keys.append(rows * ncols + t.indices.astype(np.int64))
+        union = np.unique(np.concatenate(keys))                      # sorted (row, col) pairs
+        urows = (union // ncols).astype(np.int64)
+        indptr = np.concatenate(([0], np.cumsum(np.bincount(urows, minlength=shape[0]))))
+        pattern = CSRPattern(indptr.astype(np.int32), (union % ncols).astype(np.int32), shape)
+        maps = [torch.from_numpy(np.searchsorted(union, k).astype(np.int32)).to(ctx().device)
+                for k in keys]
+        hit = _merge_cache[key] = (pattern, maps)
+        if len(_merge_cache) > 16:
+            _merge_cache.pop(next(iter(_merge_cache)))
+    pattern, maps = hit
+    val = torch.zeros(pattern.nnz, dtype=torch.float64, device=ctx().device)
+    for t, idx in zip(terms, maps):
+        data = torch.from_numpy(np.ascontiguousarray(t.data, dtype=np.float64)).to(ctx().device)
+        _hip.call("ipx_scatter_add", t.nnz, _p(data), _p(idx), _p(val), stream_ptr())
+    return DeviceCSR(pattern, val)
+
+
 def hessian_operator(terms, n_vars, slack_block):
     """Device operator for the Lagrangian Hessian terms (HessianSum from
     canonical.lagrangian_hessian) and, in barrier problems, the diagonal slack
@@ -150,17 +185,19 @@ def hessian_operator(terms, n_vars, slack_block):
     flat = terms.flat_terms() if isinstance(terms, HessianSum) else list(terms)
     n_total = n_vars + (len(slack_block) if slack_block is not None else 0)
     csr, diag, others = None, None, []
-    host_sparse, host_diag = None, None
+    sparse_terms = []
     for h in flat:
         if sps.issparse(h):
             h = sps.csr_matrix(h)
-            d = h.diagonal()
-            if h.nnz == np.count_nonzero(d) or (h - sps.diags(d)).count_nonzero() == 0:
-                host_diag = d if host_diag is None else host_diag + d      # purely diagonal term
+            if not h.has_canonical_format:
+                h = h.copy()
+                h.sum_duplicates()
+            rows = np.repeat(np.arange(h.shape[0], dtype=np.int32), np.diff(h.indptr))
+            if np.array_equal(rows, h.indices):          # purely diagonal pattern
+                d = DVec.from_host(h.diagonal() if h.nnz < h.shape[0] else h.data)
+                diag = d if diag is None else diag + d
             else:
-                # several sparse terms are merged on the host so the product
-                # stays ONE fused SpMV (differs from term-by-term by rounding only)
-                host_sparse = h if host_sparse is None else host_sparse + h
+                sparse_terms.append(h)
         elif isinstance(h, DeviceCSR) and csr is None:
             csr = h
         elif isinstance(h, DVec):
@@ -172,15 +209,16 @@ def hessian_operator(terms, n_vars, slack_block):
             others.append(DeviceDense.from_host(h))
         else:
             others.append(HostCallbackOperator(h))
-    if host_sparse is not None:
-        up = _upload_csr(host_sparse, ("hess", host_sparse.shape))
+    if sparse_terms:
+        # several sparse terms become ONE matrix on their union pattern (symbolic
+        # on the host, values summed on the device), so the product stays one
+        # fused SpMV; differs from term-by-term products by rounding only
+        up = (_upload_csr(sparse_terms[0], ("hess", sparse_terms[0].shape))
+              if len(sparse_terms) == 1 else _merge_sparse_terms(sparse_terms))
         if csr is None:
             csr = up
         else:
             others.append(up)
-    if host_diag is not None:
-        hd = DVec.from_host(host_diag)
-        diag = hd if diag is None else diag + hd
     if slack_block is None:
         return DeviceHessian(n_vars, csr, diag, others)
     # z-space: extend the CSR block with empty slack rows, put the slack block

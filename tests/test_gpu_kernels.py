@@ -131,3 +131,41 @@ def test_csr_spmv_long_rows_and_banded(dv):
     d = rng.standard_normal(20000)
     hp2 = H.spmv(P, diag=dv.DVec.from_host(d))
     assert np.array_equal(hp2.to_host(), inst.H.dot(p) + d * p)
+
+
+def test_hessian_terms_merge_on_device():
+    """Several sparse Lagrangian-Hessian terms (objective + constraints) become one
+    CSR matrix on the union of their patterns, values summed on the device
+    (backend_hip._merge_sparse_terms); diagonal terms add up as vectors.  The
+    operator must act like the sum of the terms (tr_interior_point.py:222-241)."""
+    import scipy.sparse as sps
+    from ipsolver import backend_hip as bh
+    from ipsolver.device import DVec
+    rng = np.random.default_rng(5)
+    n = 3000
+
+    def sym(density, seed):
+        M = sps.random(n, n, density=density, random_state=seed, format="csr")
+        return sps.csr_matrix(M + M.T)
+    terms = [sym(0.002, 1), sps.diags(rng.standard_normal(n), format="csr"), sym(0.001, 2),
+             sps.diags([rng.standard_normal(n - 1), rng.standard_normal(n), rng.standard_normal(n - 1)],
+                       [-1, 0, 1], format="csr")]
+    total = sum(terms[1:], terms[0])
+    p = rng.standard_normal(n)
+    for slack in (None, DVec.from_host(rng.uniform(1, 2, 40))):
+        H = bh.hessian_operator(list(terms), n, slack)
+        assert H.csr is not None and not H.others          # one fused SpMV, usable by the CG loop
+        if slack is None:
+            got = H.dot(DVec.from_host(p)).to_host()
+            want = total.dot(p)
+        else:
+            ps = rng.standard_normal(40)
+            got = H.dot(DVec.from_host(np.concatenate((p, ps)))).to_host()
+            want = np.concatenate((total.dot(p), slack.to_host() * ps))
+        assert np.max(np.abs(got - want)) <= 1e-13 * np.max(np.abs(want))
+    # same patterns, new values: the cached union pattern is reused
+    terms2 = [t * 2.0 for t in terms]
+    H2 = bh.hessian_operator(list(terms2), n, None)
+    assert H2.csr.pattern is bh.hessian_operator(list(terms), n, None).csr.pattern
+    assert np.max(np.abs(H2.dot(DVec.from_host(p)).to_host() - 2 * total.dot(p))) \
+        <= 1e-13 * np.max(np.abs(total.dot(p)))
