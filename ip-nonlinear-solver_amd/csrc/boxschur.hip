@@ -101,6 +101,65 @@ k_pairs_vsolve(int ng, const int32_t *__restrict__ rowp, const int32_t *__restri
   }
 }
 
+// tsolve for the groups and, in the same launch, the gather of the general
+// rows' right-hand side:  threads [0, ng) -> groups, [ng, ng + mR) -> wR[i] = w[general[i]].
+__global__ void __launch_bounds__(IPX_BLOCK)
+k_pairs_tsolve_gather(int ng, int mR, const int32_t *__restrict__ rowp,
+                      const int32_t *__restrict__ rowq, const double *__restrict__ inv,
+                      const double *__restrict__ alpha, const double *__restrict__ w,
+                      double *__restrict__ t, const int32_t *__restrict__ col,
+                      double *__restrict__ u, const int32_t *__restrict__ general,
+                      double *__restrict__ wR, const double *__restrict__ guard) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (guard && *guard != 0.0) return;
+  if (g >= ng) {
+    const int i = g - ng;
+    if (i < mR) wR[i] = w[general[i]];
+    return;
+  }
+  const int p = rowp[g], q = rowq[g];
+  const double wp = w[p];
+  if (q < 0) {
+    const double tp = inv[3 * g] * wp;
+    t[p] = tp;
+    u[col[g]] = alpha[p] * tp;
+  } else {
+    const double wq = w[q];
+    const double tp = inv[3 * g] * wp + inv[3 * g + 1] * wq;
+    const double tq = inv[3 * g + 1] * wp + inv[3 * g + 2] * wq;
+    t[p] = tp; t[q] = tq;
+    u[col[g]] = alpha[p] * tp + alpha[q] * tq;
+  }
+}
+
+// vsolve for the groups and the scatter of the general rows' solution:
+// threads [0, ng) -> groups, [ng, ng + mR) -> v[general[i]] = vR[i].
+__global__ void __launch_bounds__(IPX_BLOCK)
+k_pairs_vsolve_scatter(int ng, int mR, const int32_t *__restrict__ rowp,
+                       const int32_t *__restrict__ rowq, const double *__restrict__ inv,
+                       const double *__restrict__ alpha, const double *__restrict__ t,
+                       const double *__restrict__ y, const int32_t *__restrict__ col,
+                       double *__restrict__ v, const int32_t *__restrict__ general,
+                       const double *__restrict__ vR, const double *__restrict__ guard) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (guard && *guard != 0.0) return;
+  if (g >= ng) {
+    const int i = g - ng;
+    if (i < mR) v[general[i]] = vR[i];
+    return;
+  }
+  const int p = rowp[g], q = rowq[g];
+  const double yj = y[col[g]];
+  const double rp = alpha[p] * yj;
+  if (q < 0) {
+    v[p] = t[p] - inv[3 * g] * rp;
+  } else {
+    const double rq = alpha[q] * yj;
+    v[p] = t[p] - (inv[3 * g] * rp + inv[3 * g + 1] * rq);
+    v[q] = t[q] - (inv[3 * g + 1] * rp + inv[3 * g + 2] * rq);
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -153,10 +212,14 @@ int ipx_boxschur_solve(const ipx_boxschur_args *a, const double *w, double *v, d
                        int32_t *npartial, const double *guard, void *stream) {
   if (!a || !w || !v) return IPX_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  int rc = ipx_pairs_tsolve((int)a->ng, a->rowp, a->rowq, a->inv, a->alpha, w, a->t, a->col, a->u, st);
-  if (rc) return rc;
-  rc = ipx_gather(a->mR, w, a->general, nullptr, nullptr, a->wR, st);
-  if (rc) return rc;
+  int rc = IPX_OK;
+  const int tot = (int)(a->ng + a->mR);
+  if (tot > 0) {
+    hipLaunchKernelGGL(k_pairs_tsolve_gather, dim3((tot + IPX_BLOCK - 1) / IPX_BLOCK),
+                       dim3(IPX_BLOCK), 0, st, (int)a->ng, (int)a->mR, a->rowp, a->rowq, a->inv,
+                       a->alpha, w, a->t, a->col, a->u, a->general, a->wR, guard);
+    IPX_CHECK_LAUNCH();
+  }
   ipx_csr_view AR{(int)a->mR, (int)a->n, a->AR_rowptr, a->AR_colidx, a->AR_val, a->AR_tiles,
                   (int)a->AR_ntiles};
   ipx_csr_view ARt{(int)a->n, (int)a->mR, a->ARt_rowptr, a->ARt_colidx, a->ARt_val, a->ARt_tiles,
@@ -174,9 +237,13 @@ int ipx_boxschur_solve(const ipx_boxschur_args *a, const double *w, double *v, d
   // y = A_R' v_R
   rc = ipx_spmv_launch(ARt, a->vR, 1.0, nullptr, 0.0, nullptr, a->y, nullptr, guard, st);
   if (rc) return rc;
-  rc = ipx_pairs_vsolve((int)a->ng, a->rowp, a->rowq, a->inv, a->alpha, a->t, a->y, a->col, v, st);
-  if (rc) return rc;
-  return ipx_scatter(a->mR, a->vR, a->general, v, st);
+  if (tot > 0) {
+    hipLaunchKernelGGL(k_pairs_vsolve_scatter, dim3((tot + IPX_BLOCK - 1) / IPX_BLOCK),
+                       dim3(IPX_BLOCK), 0, st, (int)a->ng, (int)a->mR, a->rowp, a->rowq, a->inv,
+                       a->alpha, a->t, a->y, a->col, v, a->general, a->vR, guard);
+    IPX_CHECK_LAUNCH();
+  }
+  return IPX_OK;
 }
 
 }  // extern "C"
