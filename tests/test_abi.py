@@ -56,3 +56,28 @@ def test_product_fails_loudly_without_gpu():
     p = problems.Maratos()
     with pytest.raises(_hip.IpxError):
         ipsolver.minimize_constrained(p.fun, p.x0, p.grad, p.hess, p.constraints(ipsolver))
+
+
+def test_header_is_plain_c_and_structs_match_the_bindings(tmp_path):
+    """include/ipx.h is the C ABI: it must compile as C99 on its own, and the argument blocks
+    mirrored with ctypes must have the layout the compiler gives them."""
+    import shutil
+    import subprocess
+    import pytest
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    from ipsolver.boxschur import BoxSchurArgs
+    from ipsolver.cg_fused import CgArgs
+    from ipsolver.sharded import ShardExt
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "ipx.h"\n'
+                   'int main(void) { printf("%zu %zu %zu %zu %zu\\n", sizeof(ipx_cg_args), '
+                   'sizeof(ipx_boxschur_args), sizeof(ipx_shard_ext), '
+                   'offsetof(ipx_cg_args, state), offsetof(ipx_shard_ext, np4)); return 0; }\n')
+    exe = tmp_path / "sizes"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    str(src), "-o", str(exe)], check=True)
+    got = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True,
+                                          text=True).stdout.split()]
+    assert got == [ctypes.sizeof(CgArgs), ctypes.sizeof(BoxSchurArgs), ctypes.sizeof(ShardExt),
+                   CgArgs.state.offset, ShardExt.np4.offset]
