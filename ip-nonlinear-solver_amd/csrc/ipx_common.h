@@ -140,8 +140,11 @@ __device__ __forceinline__ double ipx_sum_partials(const double *part, int count
     double t[IPX_FOLD_U];
 #pragma unroll
     for (int u = 0; u < IPX_FOLD_U; ++u) {
+      // unconditional clamped load + select: a predicated load compiles to a
+      // branch with a full s_waitcnt per load
       const int i = base + u * blockDim.x;
-      t[u] = i < count ? part[i] : ipx_identity<OP>();
+      const double ld = part[min(i, count - 1)];
+      t[u] = i < count ? ld : ipx_identity<OP>();
     }
 #pragma unroll
     for (int u = 0; u < IPX_FOLD_U; ++u) v = ipx_combine<OP>(v, t[u]);
@@ -172,7 +175,8 @@ __device__ __forceinline__ void ipx_sum_partials_multi(const double *const (&par
 #pragma unroll
       for (int u = 0; u < IPX_FOLD_U; ++u) {
         const int i = base + u * blockDim.x;
-        t[q][u] = i < count[q] ? part[q][i] : 0.0;
+        const double ld = part[q][max(min(i, count[q] - 1), 0)];   // part[q] readable even if count 0
+        t[q][u] = i < count[q] ? ld : 0.0;
       }
     }
 #pragma unroll
@@ -210,8 +214,11 @@ struct ipx_fold_regs {
     for (int q = 0; q < NQ; ++q) {
 #pragma unroll
       for (int u = 0; u < IPX_FOLD_U; ++u) {
+        // unconditional clamped load + select (see ipx_sum_partials); part[q]
+        // must be a readable address even when count[q] is 0
         const int i = threadIdx.x + u * blockDim.x;
-        t[q][u] = i < count[q] ? part[q][i] : 0.0;
+        const double ld = part[q][max(min(i, count[q] - 1), 0)];
+        t[q][u] = i < count[q] ? ld : 0.0;
       }
     }
   }
