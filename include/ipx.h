@@ -191,6 +191,13 @@ typedef struct ipx_cg_args {
   double *part1, *part2, *part3, *part4;
   int64_t vec_grid;
   int64_t solver_kind;   /* 0: `banded` is an ipx_banded handle; 1: an ipx_boxschur_args* */
+  /* step2 fused into the H.p SpMV (banded H): H_hmax > 0 = widest distance of a row tile's
+   * columns from its own row range (<= 64, <= rows of every tile), pb = 2 x H_ntiles x
+   * 2*H_hmax doubles of scratch (tile-boundary copies of p, by iteration parity).
+   * pb == NULL or H_hmax == 0: separate step2 and H.p launches. */
+  double *pb;
+  int64_t H_hmax;
+  int64_t H_tile_rows;   /* rows of H's longest row tile (0 = unknown) */
 } ipx_cg_args;
 int ipx_cg_state_size(void);
 int ipx_cg_vec_grid(int64_t n);

@@ -1531,6 +1531,20 @@ int fast_solve(Banded *h, const double *w, double *x, double *partial, int *npar
 }
 }  // namespace
 
+// How many residual partials ipx_banded_solve_resid_launch writes for this
+// factorization (depends on the path the solve takes).
+int ipx_banded_resid_count(void *handle) {
+  if (!handle) return 0;
+  Banded *h = (Banded *)handle;
+  const Level &l0 = h->lev[0];
+  if (h->fast && h->nlev > 1 && h->decoupled && l0.k == 1 &&
+      decoupled_lds_doubles<1>(l0.q) * sizeof(double) <= LDS_LIMIT)
+    return (l0.P + DEC_CHUNKS - 1) / DEC_CHUNKS;
+  if (h->fast && h->nlev > 1) return (l0.m + IPX_BLOCK - 1) / IPX_BLOCK;
+  const int grid = (l0.m + IPX_BLOCK - 1) / IPX_BLOCK;           // k_band_residual
+  return grid > 256 ? 256 : grid;
+}
+
 // Solve + residual partials in one go (the CG loop's projection step).
 int ipx_banded_solve_resid_launch(void *handle, const double *w, double *x, double *partial,
                                   int *npartial, const double *guard, hipStream_t st) {

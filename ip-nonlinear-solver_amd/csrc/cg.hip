@@ -217,6 +217,207 @@ k_cg_halo_pack(int64_t n, int h, int rank, int world, const double *__restrict__
   out[idx] = v;
 }
 
+// ---- step2 fused into the H.p SpMV (banded Hessians) ------------------------
+// step2 rewrites p (and x) element by element and the SpMV right behind it reads
+// p back; for a Hessian whose row tiles touch only a few columns outside
+// their own row range (halo <= hmax on either side: every banded H) the two
+// are one kernel: a workgroup forms p_next = beta p - g on its row range plus
+// halo in LDS, stores its own part of p_next and x_next, and takes the SpMV's
+// gathers out of LDS.  The halo entries of p are owned (and overwritten in
+// place) by the neighbouring workgroups, so their OLD values come from `pb`:
+// every tile's first/last hmax entries of p, saved by the kernel that produced
+// p (double buffered by iteration parity).  Same expressions in the same
+// order as k_cg_step2 + k_csr_spmv: bit-identical results.
+constexpr int FUSE_HMAX = 64;                       // widest halo taken on this path
+constexpr int FT_NNZ = IPX_SPMV_TILE_NNZ;
+
+template <bool HAS_DIAG, int Q, int QS>
+__global__ void __launch_bounds__(IPX_BLOCK)
+k_cg_step2_hp(int n, double *st, int parity, int mode, const double *__restrict__ p2, int np2,
+              const double *__restrict__ p3, int np3, const double *__restrict__ p4, int np4,
+              double *x, double *p, const double *__restrict__ g,
+              const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
+              const double *__restrict__ val, const int32_t *__restrict__ tiles, int ntiles,
+              const double *__restrict__ diag, double *__restrict__ Hp,
+              double *__restrict__ partial, int hmax, const double *__restrict__ pb_in,
+              double *__restrict__ pb_out) {
+  __shared__ double prod[FT_NNZ];
+  __shared__ double span[QS * IPX_BLOCK];
+  __shared__ int rp[Q * IPX_BLOCK + 1];
+  __shared__ double lds[4 * (IPX_BLOCK / IPX_WAVE)];
+  const int tile = ipx_xcd_item(blockIdx.x, ntiles);
+  if (tile < 0) return;
+  const int tid = threadIdx.x;
+  // request order = arrival order: state words and partials first (the fold
+  // runs while the operands stream in), then the tile's data
+  // (register budget: the partial arrays get as many in-flight loads as their usual
+  // lengths need -- step1's <= 512, the SpMV's ~n/1024, the solve's ~m/260 -- not 4 each)
+  const double *const partsA[3] = {p2, p2 + np2, p4};
+  const int countsA[3] = {(mode & 1) ? 0 : np2, (mode & 1) ? 0 : np2, (mode & 2) ? 0 : np4};
+  const double *const partsB[1] = {p3};
+  const int countsB[1] = {np3};
+  const double stop = st[ST_STOP];
+  const double radius = st[ST_RADIUS], orth_rhs = st[ST_ORTH_RHS];
+  const double rtg = st[parity ? ST_RTG1 : ST_RTG0];
+  const double alpha = st[ST_ALPHA];
+  ipx_fold_regs<3, 2> foldA;
+  ipx_fold_regs<1, 4> foldB;
+  foldA.load(partsA, countsA);
+  foldB.load(partsB, countsB);
+  const int r0 = tiles[tile], r1 = tiles[tile + 1];
+  const int s = tiles[ntiles + 1 + tile], e = tiles[ntiles + 2 + tile];
+  const int nrows = r1 - r0;
+  const int c_lo = max(r0 - hmax, 0), c_hi = min(r1 + hmax, n);
+  const int nspan = c_hi - c_lo;
+  // Q / QS: row / span elements per lane, sized by the launcher from the longest tile
+  constexpr int U = FT_NNZ / IPX_BLOCK;
+  int c[U];
+  double v[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int jj = min(s + tid + u * IPX_BLOCK, max(e - 1, s));
+    c[u] = colidx[jj];
+    v[u] = val[jj];
+  }
+  // span operands: element j of the span is column c_lo + j
+  double sp[QS], sg[QS];
+  const double *pbl = pb_in + (int64_t)(tile - 1) * 2 * hmax + hmax;   // right part of tile-1
+  const double *pbr = pb_in + (int64_t)(tile + 1) * 2 * hmax;          // left part of tile+1
+#pragma unroll
+  for (int k = 0; k < QS; ++k) {
+    const int j = min(tid + k * IPX_BLOCK, nspan - 1);
+    const int col = c_lo + j;
+    sg[k] = g[col];
+    // one unconditional load through a selected address (a predicated load would
+    // cost a branch and a full wait): left halo = last hmax entries of the previous
+    // tile, right halo = first hmax entries of the next one, else p itself
+    const double *src = col < r0 ? pbl + (col - (r0 - hmax)) : (col >= r1 ? pbr + (col - r1) : p + col);
+    sp[k] = *src;
+  }
+  if (stop != 0.0) return;
+  const bool lead = tile == 0 && tid == 0;
+  double red[4], loc[4];
+  foldA.local(partsA, countsA, loc);               // loc = {xn2, viol, tt}
+  foldB.local(partsB, countsB, loc + 3);           // loc[3] = gg
+  {
+    const double tt_local = loc[2];
+    loc[2] = loc[3];                               // -> {xn2, viol, gg, tt}, k_cg_step2's order
+    loc[3] = tt_local;
+  }
+  ipx_block_sum_multi<4>(loc, lds, red);
+  if (!(mode & 1)) {
+    const double xn2 = red[0], viol = red[1];
+    if (sqrt(xn2) >= radius) {                       // :583
+      if (lead) { st[ST_XNORM2] = xn2; st[ST_STOP] = 2.0; }
+      return;
+    }
+    if (viol > 0.0) {                                // :599-616 continues on the host
+      if (lead) { st[ST_VIOL] = viol; st[ST_STOP] = 5.0; }
+      return;
+    }
+  }
+  const double gg = red[2];                          // ||g_next||^2
+  if (!(mode & 2)) {
+    const double tt = red[3];                        // ||A g_next||^2
+    if (orth_rhs > 0.0 && gg > 0.0 && sqrt(tt) > orth_rhs * sqrt(gg)) {
+      if (lead) { st[ST_ORTH] = sqrt(tt) / sqrt(gg); st[ST_STOP] = 6.0; }
+      return;
+    }
+  }
+  const double beta = gg / rtg;                      // :627
+  if (lead) {
+    st[parity ? ST_RTG0 : ST_RTG1] = gg;             // :633
+    st[ST_BETA] = beta;
+    st[ST_IT_DONE] += 1.0;
+  }
+  // p_next on the span (LDS), x_next / p_next / boundary copies on the own rows
+  double *pbo = pb_out + (int64_t)tile * 2 * hmax;
+#pragma unroll
+  for (int k = 0; k < QS; ++k) {
+    const int j = tid + k * IPX_BLOCK;
+    if (j < nspan) {
+      const int col = c_lo + j;
+      const double pn = beta * sp[k] - sg[k];        // :628
+      span[j] = pn;
+      if (col >= r0 && col < r1) {
+        p[col] = pn;
+        if (col - r0 < hmax) pbo[col - r0] = pn;
+        if (r1 - col <= hmax) pbo[hmax + (col - (r1 - hmax))] = pn;
+      }
+    }
+  }
+  // row pointers, x and the diagonal entries of this lane's rows: requested only now (their registers
+  // are not held while the bulk loads are in flight), landed by the time they are needed
+  double sx[QS];
+#pragma unroll
+  for (int k = 0; k < QS; ++k) sx[k] = x[min(max(c_lo + tid + k * IPX_BLOCK, r0), r1 - 1)];
+  double dg[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q)
+    dg[q] = HAS_DIAG ? diag[r0 + min(tid + q * IPX_BLOCK, nrows - 1)] : 0.0;
+  int rpv[Q + 1];
+#pragma unroll
+  for (int q = 0; q <= Q; ++q) rpv[q] = rowptr[r0 + min(tid + q * IPX_BLOCK, nrows)] - s;
+  ipx_lds_barrier();
+  // SpMV phase 1: products with the gathers served from the span
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int jj = s + tid + u * IPX_BLOCK;
+    if (jj < e) prod[jj - s] = v[u] * span[c[u] - c_lo];
+  }
+#pragma unroll
+  for (int q = 0; q <= Q; ++q) {
+    const int i = tid + q * IPX_BLOCK;
+    if (i <= nrows) rp[i] = rpv[q];
+  }
+  ipx_lds_barrier();
+  // phase 2: row sums, diagonal term, partials of y'y and p'y
+  double acc_yy = 0.0, acc_xy = 0.0, yq[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const int i = tid + q * IPX_BLOCK;
+    yq[q] = 0.0;
+    if (i < nrows) {
+      const int a = rp[i], b = rp[i + 1];
+      double sum = 0.0;
+      for (int k = a; k < b; ++k) sum += prod[k];
+      const double xr = span[r0 - c_lo + i];
+      double y = 1.0 * sum;
+      if (HAS_DIAG) y += dg[q] * xr;
+      yq[q] = y;
+      acc_yy += y * y;
+      acc_xy += xr * y;
+    }
+  }
+  const double a2 = ipx_block_reduce<IPX_SUM>(acc_yy, lds);
+  const double b2 = ipx_block_reduce<IPX_SUM>(acc_xy, lds);
+  if (tid == 0) { partial[tile] = a2; partial[ntiles + tile] = b2; }
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const int i = tid + q * IPX_BLOCK;
+    if (i < nrows) Hp[r0 + i] = yq[q];
+  }
+#pragma unroll
+  for (int k = 0; k < QS; ++k) {
+    const int col = c_lo + tid + k * IPX_BLOCK;
+    if (col >= r0 && col < r1) x[col] = sx[k] + alpha * sp[k];   // :580,630
+  }
+}
+
+// First / last hmax entries of p for every row tile of H (both parities): what
+// k_cg_step2_hp reads as its halo.  Launched by the unfused producers of p.
+__global__ void __launch_bounds__(IPX_BLOCK)
+k_cg_save_pb(const double *__restrict__ p, const int32_t *__restrict__ tiles, int ntiles,
+             int hmax, double *__restrict__ pb) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= ntiles * 2 * hmax) return;
+  const int t = idx / (2 * hmax), j = idx - t * 2 * hmax;
+  const int r0 = tiles[t], r1 = tiles[t + 1];
+  const double v = j < hmax ? p[r0 + j] : p[r1 - hmax + (j - hmax)];
+  pb[idx] = v;
+  pb[(int64_t)ntiles * 2 * hmax + idx] = v;
+}
+
 // The whole per-rank contribution to the second all-reduce of an iteration in
 // one launch: out[0..4) = folded partials (||x+ap||^2, #violations, ||g||^2,
 // g'r), out[4..) = boundary slots as in k_cg_halo_pack.
@@ -261,9 +462,46 @@ int ipx_cg_state_size(void) { return ST_SIZE; }
 // 2 workgroups per CU: measured best for step2 at n = 1e6 (9.3 us vs 10.8 us with 1024)
 int ipx_cg_vec_grid(int64_t n) { return ipx_grid_for(n, VB * 2, 512); }
 
+static bool fused_hp(const ipx_cg_args *a) { return a->pb != nullptr && a->H_hmax > 0; }
+
+// Unfused H.p; when the fused step2+H.p kernel is in use it also saves the tile
+// boundaries of the p it was given (that kernel's halo source).
 static int launch_hp(const ipx_cg_args *a, const double *guard, hipStream_t st) {
   ipx_csr_view H{(int)a->n, (int)a->n, a->H_rowptr, a->H_colidx, a->H_val, a->H_tiles, (int)a->H_ntiles};
-  return ipx_spmv_launch(H, a->p, 1.0, a->H_diag, 0.0, nullptr, a->Hp, a->part1, guard, st);
+  int rc = ipx_spmv_launch(H, a->p, 1.0, a->H_diag, 0.0, nullptr, a->Hp, a->part1, guard, st);
+  if (rc || !fused_hp(a)) return rc;
+  const int tot = (int)(a->H_ntiles * 2 * a->H_hmax);
+  hipLaunchKernelGGL(k_cg_save_pb, dim3((tot + IPX_BLOCK - 1) / IPX_BLOCK), dim3(IPX_BLOCK), 0, st,
+                     a->p, a->H_tiles, (int)a->H_ntiles, (int)a->H_hmax, a->pb);
+  IPX_CHECK_LAUNCH();
+  return IPX_OK;
+}
+
+// step2 + H.p in one launch (see k_cg_step2_hp); iteration `it` reads the halo
+// copies of parity it & 1 and leaves those of p_next in the other one.
+static int launch_step2_hp(const ipx_cg_args *a, int it, int mode, int np4, hipStream_t st) {
+  const int64_t half = a->H_ntiles * 2 * a->H_hmax;
+  const double *pb_in = a->pb + (it & 1) * half;
+  double *pb_out = a->pb + ((it + 1) & 1) * half;
+  const dim3 grid(ipx_xcd_grid((int)a->H_ntiles)), block(IPX_BLOCK);
+#define FUSED_ARGS                                                                            \
+  (int)a->n, a->state, it & 1, mode, a->part2, (int)a->vec_grid, a->part3, (int)a->At_ntiles, \
+      a->part4, np4, a->x, a->p, a->r, a->H_rowptr, a->H_colidx, a->H_val, a->H_tiles,        \
+      (int)a->H_ntiles, a->H_diag, a->Hp, a->part1, (int)a->H_hmax, pb_in, pb_out
+  // H_hmax carries the longest tile's row count in its upper half (set by the host
+  // binding): short tiles (3 nonzeros per row -> 683 rows) take the 3-elements-per-lane
+  // instantiation, which needs fewer registers
+  const bool small = a->H_tile_rows > 0 && a->H_tile_rows + 2 * a->H_hmax <= 3 * IPX_BLOCK;
+  if (a->H_diag) {
+    if (small) hipLaunchKernelGGL((k_cg_step2_hp<true, 3, 3>), grid, block, 0, st, FUSED_ARGS);
+    else hipLaunchKernelGGL((k_cg_step2_hp<true, 4, 5>), grid, block, 0, st, FUSED_ARGS);
+  } else {
+    if (small) hipLaunchKernelGGL((k_cg_step2_hp<false, 3, 3>), grid, block, 0, st, FUSED_ARGS);
+    else hipLaunchKernelGGL((k_cg_step2_hp<false, 4, 5>), grid, block, 0, st, FUSED_ARGS);
+  }
+#undef FUSED_ARGS
+  IPX_CHECK_LAUNCH();
+  return IPX_OK;
 }
 
 // Single kernels of the loop with explicit partial buffers, for drivers that
@@ -383,9 +621,11 @@ int ipx_cg_resume(const ipx_cg_args *a, int32_t it, int32_t mode, void *stream) 
   if (!a) return IPX_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const double *guard = a->state + ST_STOP;
+  const int np4 = a->m > 0 ? ipx_banded_resid_count(a->solver_kind == 1
+                                 ? ((const ipx_boxschur_args *)a->banded)->inner : a->banded) : 1;
   hipLaunchKernelGGL(k_cg_step2, dim3(ipx_xcd_grid((int)a->vec_grid)), dim3(VB), 0, st, a->n,
                      a->state, it & 1, mode, a->part2, (int)a->vec_grid, a->part3,
-                     (int)a->At_ntiles, a->part4, (int)((a->m + 255) / 256), a->x, a->p, a->r,
+                     (int)a->At_ntiles, a->part4, np4, a->x, a->p, a->r,
                      (int)a->vec_grid);
   IPX_CHECK_LAUNCH();
   return launch_hp(a, guard, st);
@@ -510,12 +750,17 @@ static int cg_iterate(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, hi
       MARK(4);
       MARK(5);
     }
-    hipLaunchKernelGGL(k_cg_step2, dim3(ipx_xcd_grid((int)a->vec_grid)), dim3(VB), 0, st, a->n,
-                       a->state, it & 1, a->m > 0 ? 0 : 2, a->part2, (int)a->vec_grid, a->part3,
-                       (int)a->At_ntiles, a->part4, np4, a->x, a->p, a->r, (int)a->vec_grid);
-    IPX_CHECK_LAUNCH();
-    MARK(6);
-    rc = launch_hp(a, guard, st);
+    if (fused_hp(a)) {
+      MARK(6);
+      rc = launch_step2_hp(a, it, a->m > 0 ? 0 : 2, np4, st);
+    } else {
+      hipLaunchKernelGGL(k_cg_step2, dim3(ipx_xcd_grid((int)a->vec_grid)), dim3(VB), 0, st, a->n,
+                         a->state, it & 1, a->m > 0 ? 0 : 2, a->part2, (int)a->vec_grid, a->part3,
+                         (int)a->At_ntiles, a->part4, np4, a->x, a->p, a->r, (int)a->vec_grid);
+      IPX_CHECK_LAUNCH();
+      MARK(6);
+      rc = launch_hp(a, guard, st);
+    }
     if (rc) return rc;
     MARK(7);
   }

@@ -206,14 +206,36 @@ __device__ __forceinline__ void ipx_sum_partials_multi(const double *const (&par
 // entries of every array (no use yet), finish() adds them -- plus any entries
 // beyond, the slow way -- and reduces.  Lets a kernel put the fold's loads in
 // flight together with its first operand loads (one memory latency for both).
+// Block-wide sums of NQ per-thread values in one barrier pair, every thread gets
+// all results (fixed order: lanes by DPP butterfly, waves in wave order).
 template <int NQ>
+__device__ __forceinline__ void ipx_block_sum_multi(double (&v)[NQ], double *lds,
+                                                    double (&out)[NQ]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    v[q] = ipx_wave_sum(v[q]);
+    if (lane == 0) lds[q * nw + wave] = v[q];
+  }
+  ipx_lds_barrier();
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    double r = lds[q * nw];
+    for (int w = 1; w < nw; ++w) r += lds[q * nw + w];
+    out[q] = r;
+  }
+  ipx_lds_barrier();
+}
+
+template <int NQ, int FU = IPX_FOLD_U>
 struct ipx_fold_regs {
-  double t[NQ][IPX_FOLD_U];
+  double t[NQ][FU];
   __device__ __forceinline__ void load(const double *const (&part)[NQ], const int (&count)[NQ]) {
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
 #pragma unroll
-      for (int u = 0; u < IPX_FOLD_U; ++u) {
+      for (int u = 0; u < FU; ++u) {
         // unconditional clamped load + select (see ipx_sum_partials); part[q]
         // must be a readable address even when count[q] is 0
         const int i = threadIdx.x + u * blockDim.x;
@@ -222,32 +244,23 @@ struct ipx_fold_regs {
       }
     }
   }
-  __device__ __forceinline__ void finish(const double *const (&part)[NQ], const int (&count)[NQ],
-                                         double *lds, double (&out)[NQ]) const {
-    double v[NQ];
+  // this thread's share of every sum (entries beyond FU * blockDim the slow way)
+  __device__ __forceinline__ void local(const double *const (&part)[NQ], const int (&count)[NQ],
+                                        double *v) const {
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       v[q] = 0.0;
 #pragma unroll
-      for (int u = 0; u < IPX_FOLD_U; ++u) v[q] += t[q][u];
-      for (int i = threadIdx.x + IPX_FOLD_U * blockDim.x; i < count[q]; i += blockDim.x)
+      for (int u = 0; u < FU; ++u) v[q] += t[q][u];
+      for (int i = threadIdx.x + FU * blockDim.x; i < count[q]; i += blockDim.x)
         v[q] += part[q][i];
     }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nw = (blockDim.x + 63) >> 6;
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      v[q] = ipx_wave_sum(v[q]);
-      if (lane == 0) lds[q * nw + wave] = v[q];
-    }
-    ipx_lds_barrier();
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      double r = lds[q * nw];
-      for (int w = 1; w < nw; ++w) r += lds[q * nw + w];
-      out[q] = r;
-    }
-    ipx_lds_barrier();
+  }
+  __device__ __forceinline__ void finish(const double *const (&part)[NQ], const int (&count)[NQ],
+                                         double *lds, double (&out)[NQ]) const {
+    double v[NQ];
+    local(part, count, v);
+    ipx_block_sum_multi<NQ>(v, lds, out);
   }
 };
 
@@ -283,6 +296,7 @@ int ipx_banded_solve_guarded(void *handle, const double *w, double *x, const dou
                              hipStream_t st);
 // x = (A A')^-1 w and partial[0..*npartial) <- per-workgroup sums of ||w - (A A') x||^2
 // in one go; the partial buffer needs ceil(m / 256) doubles.
+int ipx_banded_resid_count(void *handle);
 int ipx_banded_solve_resid_launch(void *handle, const double *w, double *x, double *partial,
                                   int *npartial, const double *guard, hipStream_t st);
 // partial[0..*npartial) <- per-workgroup sums of ||w - (A A') v||^2 (<= 256 of them)

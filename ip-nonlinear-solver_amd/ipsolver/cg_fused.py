@@ -8,6 +8,7 @@ refinement) hand the iteration back to the host, which finishes it with the
 general kernels and resumes the loop.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -36,7 +37,7 @@ class CgArgs(ctypes.Structure):
         ("w", _P), ("v", _P), ("t", _P),
         ("lb", _P), ("ub", _P), ("state", _P),
         ("part1", _P), ("part2", _P), ("part3", _P), ("part4", _P),
-        ("vec_grid", _I64), ("solver_kind", _I64))]
+        ("vec_grid", _I64), ("solver_kind", _I64), ("pb", _P), ("H_hmax", _I64), ("H_tile_rows", _I64))]
 
 
 # Counters over the life of the process (diagnostics: how often the device loop
@@ -52,6 +53,36 @@ def _hessian_parts(H):
     if isinstance(H, DeviceHessian) and H.csr is not None and not H.others:
         return H.csr, H.diag
     return None
+
+
+FUSE_HMAX = 64          # csrc/cg.hip FUSE_HMAX
+
+
+def fuse_halo(pattern):
+    """Halo width for the fused step2 + H.p kernel (csrc/cg.hip k_cg_step2_hp), or 0
+    when the pattern does not qualify: square, every row tile on the SpMV's fast
+    path and non-empty, columns of a tile within ``hmax <= 64`` of its row range,
+    every tile at least ``hmax`` rows long.  Symbolic; cached on the pattern."""
+    cached = getattr(pattern, "_ipx_fuse_halo", None)
+    if cached is not None:
+        return cached
+    hmax = 0
+    n = pattern.shape[0]
+    nt = pattern.ntiles
+    if pattern.shape[0] == pattern.shape[1] and nt > 0 and pattern.nnz > 0:
+        t = pattern.tiles_h
+        r0, r1 = t[:nt].astype(np.int64), t[1:nt + 1].astype(np.int64)
+        s, e = t[nt + 1:2 * nt + 1].astype(np.int64), t[nt + 2:2 * nt + 2].astype(np.int64)
+        ok = np.all(e > s) and np.all(e - s <= _hip.SPMV_TILE_NNZ) and np.all(r1 - r0 <= 1024)
+        if ok:
+            idx = pattern.indices_h
+            cmin = np.minimum.reduceat(idx, s)
+            cmax = np.maximum.reduceat(idx, s)
+            h = int(max(np.max(r0 - cmin), np.max(cmax + 1 - r1), 1))
+            if h <= FUSE_HMAX and h <= int(np.min(r1 - r0)):
+                hmax = h
+    pattern._ipx_fuse_halo = hmax
+    return hmax
 
 
 def _solver_kind(solver):
@@ -128,6 +159,13 @@ class _Loop:
         a.lb = _ptr(lb.t) if lb is not None else None
         a.ub = _ptr(ub.t) if ub is not None else None
         a.vec_grid = grid
+        # banded Hessian: step2 rides inside the H.p SpMV (one launch less per iteration)
+        hmax = 0 if os.environ.get("IPX_NO_FUSE") else fuse_halo(Hc.pattern)
+        if hmax > 0:
+            self.pb = torch.zeros(2 * Hc.pattern.ntiles * 2 * hmax, dtype=f64, device=dev)
+            a.pb, a.H_hmax = _ptr(self.pb), hmax
+            th = Hc.pattern.tiles_h
+            a.H_tile_rows = int(np.max(np.diff(th[:Hc.pattern.ntiles + 1])))
         self.args = a
 
     def ref(self):

@@ -241,6 +241,7 @@ class CSRPattern:
         self.indices = torch.from_numpy(self.indices_h).to(dev)
         tiles = _tiles_for(self.indptr_h)
         self.ntiles = len(tiles) // 2 - 1
+        self.tiles_h = tiles
         self.tiles = torch.from_numpy(tiles).to(dev)
         self.nnz = int(self.indptr_h[-1])
         self._transpose = None

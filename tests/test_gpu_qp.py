@@ -354,3 +354,35 @@ def test_box_schur_solver(ips, n, m):
     x = rng.standard_normal(A.shape[1])
     z = host(Z.dot(x))
     assert np.max(np.abs(A.dot(z))) <= 1e-9 * np.max(np.abs(x))
+
+
+@pytest.mark.parametrize("variant", ["plain", "sphere", "box"])
+def test_step2_fused_into_hp_is_bit_identical(ips, variant, monkeypatch):
+    """For banded Hessians step2 runs inside the H.p SpMV (k_cg_step2_hp); it uses the
+    same expressions in the same order as the two separate kernels, so whole CG
+    runs must agree bit for bit, through every kind of exit."""
+    import ipsolver.cg_fused as cg_fused
+    n, m = 20000, 2000
+    inst = BandedInstance(n, m)
+    A = ips.dv.DeviceCSR.from_scipy(inst.A)
+    H = ips.dv.DeviceCSR.from_scipy(inst.H)
+    assert cg_fused.fuse_halo(H.pattern) == 1            # tridiagonal
+    Z, LS, Y = ips.proj.projections(A)
+    b = np.zeros(m)
+    x_free, _ = ips.qp.projected_cg(H, inst.c, Z, Y, b, tol=1e-12)
+    kw = {"plain": dict(tol=1e-12),
+          "sphere": dict(trust_radius=0.5 * ips.dv.norm(x_free)),
+          "box": dict(lb=np.full(n, -0.3 * np.max(np.abs(host(x_free)))),
+                      ub=np.full(n, 0.3 * np.max(np.abs(host(x_free)))))}[variant]
+    runs = []
+    for no_fuse in ("", "1"):
+        if no_fuse:
+            monkeypatch.setenv("IPX_NO_FUSE", "1")
+        else:
+            monkeypatch.delenv("IPX_NO_FUSE", raising=False)
+        x, info = ips.qp.projected_cg(H, inst.c, Z, Y, b, **kw)
+        runs.append((host(x), info))
+    (x1, i1), (x2, i2) = runs
+    assert (i1["niter"], i1["stop_cond"], i1["hits_boundary"]) == \
+        (i2["niter"], i2["stop_cond"], i2["hits_boundary"])
+    assert np.array_equal(x1, x2)
