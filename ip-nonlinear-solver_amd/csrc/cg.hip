@@ -228,7 +228,7 @@ k_cg_halo_pack(int64_t n, int h, int rank, int world, const double *__restrict__
 // every tile's first/last hmax entries of p, saved by the kernel that produced
 // p (double buffered by iteration parity).  Same expressions in the same
 // order as k_cg_step2 + k_csr_spmv: bit-identical results.
-constexpr int FUSE_HMAX = 64;                       // widest halo taken on this path
+// (halo <= 64 and <= the shortest tile: checked by the host binding, cg_fused.fuse_halo)
 constexpr int FT_NNZ = IPX_SPMV_TILE_NNZ;
 
 template <bool HAS_DIAG, int Q, int QS>
