@@ -221,8 +221,10 @@ def main():
     ms = (ctypes.c_float * 7)()
     kt = min(K, 100)
     _hip.check(lib.ipx_cg_iterate_timed(L.ref(), W + K, W + K + kt, ms, st), "timed-events")
-    names = ["step1", "spmv_A_r", "banded_solve_with_residual", "spmv_r_minus_Atv", None, "step2",
-             "spmv_H_p"]
+    fused1, fused2 = bool(L.args.A_span), bool(L.args.H_hmax)
+    names = [None if fused1 else "step1", "step1_spmv_A_r" if fused1 else "spmv_A_r",
+             "banded_solve_with_residual", "spmv_r_minus_Atv", None,
+             None if fused2 else "step2", "step2_spmv_H_p" if fused2 else "spmv_H_p"]
     per_kernel_us = {k: 1e3 * ms[i] / kt for i, k in enumerate(names) if k}
 
     # ---- the dominant kernel on its own: K back-to-back launches of the H.p SpMV
@@ -230,12 +232,18 @@ def main():
     # stream.  This is the kernel's own duration, the quantity rocprofv3
     # --kernel-trace reports; the per_kernel_us figures above additionally
     # contain the dependency gap in front of each kernel.
+    # With a banded Hessian step2 rides inside that SpMV (k_cg_step2_hp): the fused
+    # kernel is then the dominant one and is what gets timed (mode 3 = no stop tests).
+    def dominant():
+        if fused2:
+            return lib.ipx_cg_step2_hp(L.ref(), 0, 3, st)
+        return lib.ipx_cg_hp(L.ref(), st)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for _ in range(20):
-        lib.ipx_cg_hp(L.ref(), st)
+        dominant()
     ev0.record()
     for _ in range(K):
-        lib.ipx_cg_hp(L.ref(), st)
+        dominant()
     ev1.record()
     torch.cuda.synchronize()
     hp_us = 1e3 * ev0.elapsed_time(ev1) / K
@@ -249,10 +257,16 @@ def main():
         "step1": 5 * 8 * n,     # read x,p,r,Hp; write r
         "step2": 5 * 8 * n,     # read x,p,g;   write x,p
     }
-    dom = "spmv_H_p"
+    if fused2:      # p is read once instead of twice
+        algo["step2_spmv_H_p"] = algo.pop("spmv_H_p") + algo.pop("step2") - 8 * n
+    if fused1:      # r_next is not read back by the SpMV
+        algo["step1_spmv_A_r"] = algo.pop("spmv_A_r") + algo.pop("step1") - 8 * n
+    dom = "step2_spmv_H_p" if fused2 else "spmv_H_p"
+    dom_label = ("k_cg_step2_hp (step2 fused into the H.p SpMV, p'Hp epilogue)" if fused2
+                 else "k_csr_spmv (H.p with p'Hp epilogue)")
     achieved = algo[dom] / (hp_us * 1e-6) / 1e9
     traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "r01e_pmc_traffic.json")
+    pmc_path = os.path.join(ROOT, "profiles", "r01f_pmc_traffic.json")
     if os.path.exists(pmc_path) and (n, m) == (1000000, 100000):
         with open(pmc_path) as f:
             traffic = json.load(f)["kernels"].get(dom, {}).get("hbm_bytes_per_launch")
@@ -274,12 +288,12 @@ def main():
                                "bandwidth 15, tol=0, trust_radius=inf",
                    "n": n, "m": m, "nnz_A": nnzA, "nnz_H": nnzH,
                    "parallelism": "1 subproblem per GPU" if world > 1 else "single GPU"},
-        "roofline": {"bound": "hbm", "kernel": "k_csr_spmv (H.p with p'Hp epilogue)",
+        "roofline": {"bound": "hbm", "kernel": dom_label,
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, "
                                        "FETCH x2 gfx950 correction calibrated in-run), "
-                                       "profiles/r01e_pmc_traffic.json",
+                                       "profiles/r01f_pmc_traffic.json",
                      "algorithmic_bytes_per_launch": algo[dom],
                      "avg_launch_us": hp_us,
                      "avg_launch_us_in_loop_with_gap": per_kernel_us[dom],

@@ -198,6 +198,14 @@ typedef struct ipx_cg_args {
   double *pb;
   int64_t H_hmax;
   int64_t H_tile_rows;   /* rows of H's longest row tile (0 = unknown) */
+  /* step1 fused into the A.r SpMV (banded A, no box): A_own = 2*(A_ntiles+1) ints -- the
+   * first column each row tile owns (A_ntiles+1 entries, a partition of [0, n)), then one
+   * past the last column it touches; A_span = longest own-start-to-last-touched distance
+   * (<= 2048); r_next = n doubles of scratch.  Any of them 0 / NULL, or lb given: separate
+   * launches. */
+  double *r_next;
+  const int32_t *A_own;
+  int64_t A_span;
 } ipx_cg_args;
 int ipx_cg_state_size(void);
 int ipx_cg_vec_grid(int64_t n);
@@ -254,6 +262,8 @@ typedef struct ipx_shard_ext {
 } ipx_shard_ext;
 int ipx_cg_shard_segment(const ipx_cg_args *a, ipx_shard_ext *e, int32_t phase, int32_t it,
                          void *stream);
+/* The fused step2 + H.p launch alone (needs pb / H_hmax in the argument block). */
+int ipx_cg_step2_hp(const ipx_cg_args *a, int32_t it, int32_t mode, void *stream);
 /* Finish iteration `it` after the host handled a stop-5/6 event. */
 int ipx_cg_resume(const ipx_cg_args *a, int32_t it, int32_t mode, void *stream);
 

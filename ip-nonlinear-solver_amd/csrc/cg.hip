@@ -404,6 +404,131 @@ k_cg_step2_hp(int n, double *st, int parity, int mode, const double *__restrict_
   }
 }
 
+// ---- step1 fused into the A.r SpMV (banded Jacobians, no box) ----------------
+// step1 rewrites r element by element and the SpMV right behind it reads r
+// back.  When the row tiles of A sweep the columns monotonically (every banded
+// A) the columns are dealt to the tiles -- tile t owns [own[t], own[t+1]) -- and
+// a workgroup forms r_next = r + alpha Hp on its own columns plus the few
+// columns beyond them that its rows still touch, in LDS, stores its own part
+// and takes the SpMV's gathers out of LDS.  r_next goes to a second buffer
+// (the columns beyond the own range belong to the next tile, which must still
+// see the old r); the r - A'v SpMV that follows reads it and writes g back into
+// r, so outside the iteration nothing changes.  Same expressions in the same
+// order as k_cg_step1 + k_csr_spmv; the ||x + alpha p||^2 partials are per tile
+// instead of per vector chunk (same values up to the order of summation).
+template <int QS>
+__global__ void __launch_bounds__(IPX_BLOCK)
+k_cg_step1_ar(int n, double *st, int parity, const double *__restrict__ p1, int np1,
+              const double *__restrict__ x, const double *__restrict__ p,
+              const double *__restrict__ r, double *__restrict__ r_next,
+              const double *__restrict__ Hp, const int32_t *__restrict__ rowptr,
+              const int32_t *__restrict__ colidx, const double *__restrict__ val,
+              const int32_t *__restrict__ tiles, int ntiles, const int32_t *__restrict__ own,
+              double *__restrict__ w, double *__restrict__ part2) {
+  __shared__ double prod[FT_NNZ];
+  __shared__ double span[QS * IPX_BLOCK];
+  __shared__ int rp[IPX_SPMV_TILE_ROWS + 1];
+  __shared__ double lds[IPX_BLOCK / IPX_WAVE];
+  const int tile = ipx_xcd_item(blockIdx.x, ntiles);
+  if (tile < 0) return;
+  const int tid = threadIdx.x;
+  const double *const fparts[1] = {p1 + np1};
+  const int fcounts[1] = {np1};
+  const double stop = st[ST_STOP];
+  const double rtg = st[parity ? ST_RTG1 : ST_RTG0];
+  const double tol = st[ST_TOL];
+  ipx_fold_regs<1, 6> fold;                      // p'Hp partials: one per row tile of H
+  fold.load(fparts, fcounts);
+  const int r0 = tiles[tile], r1 = tiles[tile + 1];
+  const int s = tiles[ntiles + 1 + tile], e = tiles[ntiles + 2 + tile];
+  const int nrows = r1 - r0;
+  const int o0 = own[tile], o1 = own[tile + 1];          // own columns
+  const int c_hi = own[ntiles + 1 + tile];               // one past the last column touched (>= o1)
+  const int nspan = c_hi - o0;
+  constexpr int U = FT_NNZ / IPX_BLOCK;
+  int c[U];
+  double v[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int jj = min(s + tid + u * IPX_BLOCK, max(e - 1, s));
+    c[u] = colidx[jj];
+    v[u] = val[jj];
+  }
+  double sr[QS], sh[QS], sxv[QS], spv[QS];
+#pragma unroll
+  for (int k = 0; k < QS; ++k) {
+    const int col = o0 + min(tid + k * IPX_BLOCK, nspan - 1);
+    sr[k] = r[col];
+    sh[k] = Hp[col];
+    sxv[k] = x[col];
+    spv[k] = p[col];
+  }
+  if (stop != 0.0) return;
+  const bool lead = tile == 0 && tid == 0;
+  double fout[1];
+  fold.finish(fparts, fcounts, lds, fout);
+  const double ptHp = fout[0];
+  if (rtg < tol) {                                   // qp_subproblem.py:551
+    if (lead) st[ST_STOP] = 4.0;
+    return;
+  }
+  if (ptHp <= 0.0) {                                 // :558
+    if (lead) { st[ST_NITER] += 1.0; st[ST_PTHP] = ptHp; st[ST_STOP] = 3.0; }
+    return;
+  }
+  const double alpha = rtg / ptHp;                   // :579
+  if (lead) { st[ST_NITER] += 1.0; st[ST_PTHP] = ptHp; st[ST_ALPHA] = alpha; }
+  double sx = 0.0;
+#pragma unroll
+  for (int k = 0; k < QS; ++k) {
+    const int j = tid + k * IPX_BLOCK;
+    if (j < nspan) {
+      const double rn = sr[k] + alpha * sh[k];       // :622
+      span[j] = rn;
+      if (o0 + j < o1) {                             // own column
+        const double xn = sxv[k] + alpha * spv[k];   // :580 (not stored)
+        sx += xn * xn;
+        r_next[o0 + j] = rn;
+      }
+    }
+  }
+  int rpv[(IPX_SPMV_TILE_ROWS / IPX_BLOCK) + 1];
+#pragma unroll
+  for (int q = 0; q <= IPX_SPMV_TILE_ROWS / IPX_BLOCK; ++q)
+    rpv[q] = rowptr[r0 + min(tid + q * IPX_BLOCK, nrows)] - s;
+  ipx_lds_barrier();
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int jj = s + tid + u * IPX_BLOCK;
+    if (jj < e) prod[jj - s] = v[u] * span[c[u] - o0];
+  }
+#pragma unroll
+  for (int q = 0; q <= IPX_SPMV_TILE_ROWS / IPX_BLOCK; ++q) {
+    const int i = tid + q * IPX_BLOCK;
+    if (i <= nrows) rp[i] = rpv[q];
+  }
+  ipx_lds_barrier();
+  double yq[IPX_SPMV_TILE_ROWS / IPX_BLOCK];
+#pragma unroll
+  for (int q = 0; q < IPX_SPMV_TILE_ROWS / IPX_BLOCK; ++q) {
+    const int i = tid + q * IPX_BLOCK;
+    yq[q] = 0.0;
+    if (i < nrows) {
+      const int a = rp[i], b = rp[i + 1];
+      double sum = 0.0;
+      for (int k = a; k < b; ++k) sum += prod[k];
+      yq[q] = 1.0 * sum;
+    }
+  }
+  const double tot = ipx_block_reduce<IPX_SUM>(sx, lds);
+  if (tid == 0) { part2[tile] = tot; part2[ntiles + tile] = 0.0; }
+#pragma unroll
+  for (int q = 0; q < IPX_SPMV_TILE_ROWS / IPX_BLOCK; ++q) {
+    const int i = tid + q * IPX_BLOCK;
+    if (i < nrows) w[r0 + i] = yq[q];
+  }
+}
+
 // First / last hmax entries of p for every row tile of H (both parities): what
 // k_cg_step2_hp reads as its halo.  Launched by the unfused producers of p.
 __global__ void __launch_bounds__(IPX_BLOCK)
@@ -477,6 +602,34 @@ static int launch_hp(const ipx_cg_args *a, const double *guard, hipStream_t st) 
   return IPX_OK;
 }
 
+static bool fused_ar(const ipx_cg_args *a) {
+  return a->r_next != nullptr && a->A_own != nullptr && a->A_span > 0 && !a->lb && a->m > 0;
+}
+// entries per half of part2: one per row tile of A (fused step1) or per vector chunk
+static int part2_count(const ipx_cg_args *a) {
+  return fused_ar(a) ? (int)a->A_ntiles : (int)a->vec_grid;
+}
+
+// step1 + A.r in one launch (see k_cg_step1_ar): r_next <- r + alpha Hp, w <- A r_next
+static int launch_step1_ar(const ipx_cg_args *a, int it, hipStream_t st) {
+  const dim3 grid(ipx_xcd_grid((int)a->A_ntiles)), block(IPX_BLOCK);
+#define FUSED_ARGS                                                                         \
+  (int)a->n, a->state, it & 1, a->part1, (int)a->H_ntiles, a->x, a->p, a->r, a->r_next,   \
+      a->Hp, a->A_rowptr, a->A_colidx, a->A_val, a->A_tiles, (int)a->A_ntiles, a->A_own,   \
+      a->w, a->part2
+  const int qs = (int)((a->A_span + IPX_BLOCK - 1) / IPX_BLOCK);
+  switch (qs) {
+    case 1: case 2: hipLaunchKernelGGL(k_cg_step1_ar<2>, grid, block, 0, st, FUSED_ARGS); break;
+    case 3: case 4: hipLaunchKernelGGL(k_cg_step1_ar<4>, grid, block, 0, st, FUSED_ARGS); break;
+    case 5: case 6: hipLaunchKernelGGL(k_cg_step1_ar<6>, grid, block, 0, st, FUSED_ARGS); break;
+    case 7: case 8: hipLaunchKernelGGL(k_cg_step1_ar<8>, grid, block, 0, st, FUSED_ARGS); break;
+    default: return IPX_EINVAL;
+  }
+#undef FUSED_ARGS
+  IPX_CHECK_LAUNCH();
+  return IPX_OK;
+}
+
 // step2 + H.p in one launch (see k_cg_step2_hp); iteration `it` reads the halo
 // copies of parity it & 1 and leaves those of p_next in the other one.
 static int launch_step2_hp(const ipx_cg_args *a, int it, int mode, int np4, hipStream_t st) {
@@ -485,7 +638,7 @@ static int launch_step2_hp(const ipx_cg_args *a, int it, int mode, int np4, hipS
   double *pb_out = a->pb + ((it + 1) & 1) * half;
   const dim3 grid(ipx_xcd_grid((int)a->H_ntiles)), block(IPX_BLOCK);
 #define FUSED_ARGS                                                                            \
-  (int)a->n, a->state, it & 1, mode, a->part2, (int)a->vec_grid, a->part3, (int)a->At_ntiles, \
+  (int)a->n, a->state, it & 1, mode, a->part2, part2_count(a), a->part3, (int)a->At_ntiles,   \
       a->part4, np4, a->x, a->p, a->r, a->H_rowptr, a->H_colidx, a->H_val, a->H_tiles,        \
       (int)a->H_ntiles, a->H_diag, a->Hp, a->part1, (int)a->H_hmax, pb_in, pb_out
   // H_hmax carries the longest tile's row count in its upper half (set by the host
@@ -615,6 +768,15 @@ int ipx_cg_hp(const ipx_cg_args *a, void *stream) {
   return launch_hp(a, nullptr, (hipStream_t)stream);
 }
 
+// The fused step2 + H.p kernel on its own (iteration `it`, step2 mode bits as
+// in ipx_cg_resume); IPX_EINVAL when the argument block does not enable it.
+int ipx_cg_step2_hp(const ipx_cg_args *a, int32_t it, int32_t mode, void *stream) {
+  if (!a || !fused_hp(a)) return IPX_EINVAL;
+  const int np4 = a->m > 0 ? ipx_banded_resid_count(a->solver_kind == 1
+                                 ? ((const ipx_boxschur_args *)a->banded)->inner : a->banded) : 1;
+  return launch_step2_hp(a, it, mode, np4, (hipStream_t)stream);
+}
+
 // Tail of an iteration after the host handled a stop-5 / stop-6 event:
 // step2 with the given mode, then Hp = H p.
 int ipx_cg_resume(const ipx_cg_args *a, int32_t it, int32_t mode, void *stream) {
@@ -624,7 +786,7 @@ int ipx_cg_resume(const ipx_cg_args *a, int32_t it, int32_t mode, void *stream) 
   const int np4 = a->m > 0 ? ipx_banded_resid_count(a->solver_kind == 1
                                  ? ((const ipx_boxschur_args *)a->banded)->inner : a->banded) : 1;
   hipLaunchKernelGGL(k_cg_step2, dim3(ipx_xcd_grid((int)a->vec_grid)), dim3(VB), 0, st, a->n,
-                     a->state, it & 1, mode, a->part2, (int)a->vec_grid, a->part3,
+                     a->state, it & 1, mode, a->part2, part2_count(a), a->part3,
                      (int)a->At_ntiles, a->part4, np4, a->x, a->p, a->r,
                      (int)a->vec_grid);
   IPX_CHECK_LAUNCH();
@@ -723,17 +885,28 @@ static int cg_iterate(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, hi
   int np4 = 1;
   for (int it = it_begin; it < it_end; ++it) {
     MARK(0);
-    hipLaunchKernelGGL(k_cg_step1, dim3(ipx_xcd_grid((int)a->vec_grid)), dim3(VB), 0, st, a->n,
-                       a->state, it & 1, a->part1, (int)a->H_ntiles, a->x, a->p, a->r,
-                       a->Hp, a->lb, a->ub, a->part2, (int)a->vec_grid);
-    IPX_CHECK_LAUNCH();
-    MARK(1);
     int rc;
-    if (a->m > 0) {
-      // w = A r_next
-      rc = ipx_spmv_launch(A, a->r, 1.0, nullptr, 0.0, nullptr, a->w, nullptr, guard, st);
+    const bool fuse1 = fused_ar(a);
+    const double *r_in = fuse1 ? a->r_next : a->r;      // what the r - A'v SpMV reads
+    if (fuse1) {
+      MARK(1);
+      rc = launch_step1_ar(a, it, st);                // r_next = r + alpha Hp;  w = A r_next
       if (rc) return rc;
       MARK(2);
+    } else {
+      hipLaunchKernelGGL(k_cg_step1, dim3(ipx_xcd_grid((int)a->vec_grid)), dim3(VB), 0, st, a->n,
+                         a->state, it & 1, a->part1, (int)a->H_ntiles, a->x, a->p, a->r,
+                         a->Hp, a->lb, a->ub, a->part2, (int)a->vec_grid);
+      IPX_CHECK_LAUNCH();
+      MARK(1);
+    }
+    if (a->m > 0) {
+      if (!fuse1) {
+        // w = A r_next
+        rc = ipx_spmv_launch(A, a->r, 1.0, nullptr, 0.0, nullptr, a->w, nullptr, guard, st);
+        if (rc) return rc;
+        MARK(2);
+      }
       // v = (AA')^-1 w, and ||A g||^2 for the orthogonality test as the
       // constraint-space residual ||w - (A A') v||^2 from the same launch
       // (see k_correct_oop / k_band_residual); part4 holds ceil(m/256) doubles
@@ -745,7 +918,7 @@ static int cg_iterate(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, hi
       if (rc) return rc;
       MARK(3);
       // r = r - A'v  (g_next), partials of ||g||^2
-      rc = ipx_spmv_launch(At, a->v, -1.0, nullptr, 1.0, a->r, a->r, a->part3, guard, st);
+      rc = ipx_spmv_launch(At, a->v, -1.0, nullptr, 1.0, r_in, a->r, a->part3, guard, st);
       if (rc) return rc;
       MARK(4);
       MARK(5);
@@ -755,7 +928,7 @@ static int cg_iterate(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, hi
       rc = launch_step2_hp(a, it, a->m > 0 ? 0 : 2, np4, st);
     } else {
       hipLaunchKernelGGL(k_cg_step2, dim3(ipx_xcd_grid((int)a->vec_grid)), dim3(VB), 0, st, a->n,
-                         a->state, it & 1, a->m > 0 ? 0 : 2, a->part2, (int)a->vec_grid, a->part3,
+                         a->state, it & 1, a->m > 0 ? 0 : 2, a->part2, part2_count(a), a->part3,
                          (int)a->At_ntiles, a->part4, np4, a->x, a->p, a->r, (int)a->vec_grid);
       IPX_CHECK_LAUNCH();
       MARK(6);

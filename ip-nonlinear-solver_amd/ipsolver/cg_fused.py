@@ -37,7 +37,8 @@ class CgArgs(ctypes.Structure):
         ("w", _P), ("v", _P), ("t", _P),
         ("lb", _P), ("ub", _P), ("state", _P),
         ("part1", _P), ("part2", _P), ("part3", _P), ("part4", _P),
-        ("vec_grid", _I64), ("solver_kind", _I64), ("pb", _P), ("H_hmax", _I64), ("H_tile_rows", _I64))]
+        ("vec_grid", _I64), ("solver_kind", _I64), ("pb", _P), ("H_hmax", _I64), ("H_tile_rows", _I64),
+        ("r_next", _P), ("A_own", _P), ("A_span", _I64))]
 
 
 # Counters over the life of the process (diagnostics: how often the device loop
@@ -83,6 +84,36 @@ def fuse_halo(pattern):
                 hmax = h
     pattern._ipx_fuse_halo = hmax
     return hmax
+
+
+def fuse_own(pattern):
+    """Column ownership for the fused step1 + A.r kernel (csrc/cg.hip k_cg_step1_ar):
+    ``(own, span)`` or None.  Qualifies when every row tile is on the SpMV's fast path
+    and non-empty and the tiles sweep the columns monotonically (first column touched
+    non-decreasing from tile to tile: every banded Jacobian); tile t then owns the
+    columns from its first touched column up to the next tile's.  Symbolic; cached."""
+    cached = getattr(pattern, "_ipx_fuse_own", False)
+    if cached is not False:
+        return cached
+    out = None
+    nt, n = pattern.ntiles, pattern.shape[1]
+    if nt > 0 and pattern.nnz > 0:
+        t = pattern.tiles_h
+        r0, r1 = t[:nt].astype(np.int64), t[1:nt + 1].astype(np.int64)
+        s, e = t[nt + 1:2 * nt + 1].astype(np.int64), t[nt + 2:2 * nt + 2].astype(np.int64)
+        if np.all(e > s) and np.all(e - s <= _hip.SPMV_TILE_NNZ) and np.all(r1 - r0 <= 1024):
+            idx = pattern.indices_h
+            cmin = np.minimum.reduceat(idx, s).astype(np.int64)
+            cmax = np.maximum.reduceat(idx, s).astype(np.int64)
+            if np.all(np.diff(cmin) >= 0):
+                own = np.concatenate(([0], cmin[1:], [n]))
+                c_hi = np.maximum(cmax + 1, own[1:])
+                span = int(np.max(c_hi - own[:-1]))
+                if span <= 2048:
+                    table = np.concatenate((own, c_hi, [n])).astype(np.int32)
+                    out = (torch.from_numpy(table).to(ctx().device), span)
+    pattern._ipx_fuse_own = out
+    return out
 
 
 def _solver_kind(solver):
@@ -134,7 +165,7 @@ class _Loop:
         self.state = torch.zeros(lib.ipx_cg_state_size(), dtype=f64, device=dev)
         grid = lib.ipx_cg_vec_grid(n)
         self.part1 = torch.zeros(2 * Hc.pattern.ntiles, dtype=f64, device=dev)
-        self.part2 = torch.zeros(2 * grid, dtype=f64, device=dev)
+        self.part2 = torch.zeros(2 * max(grid, A.pattern.ntiles), dtype=f64, device=dev)
         self.part3 = torch.zeros(2 * At.pattern.ntiles, dtype=f64, device=dev)
         self.part4 = torch.zeros((m + 255) // 256 + 1, dtype=f64, device=dev)   # ||w-(AA')v||^2 partials
         self.keep = (A, At, Hc, Hd, lb, ub, P)
@@ -166,6 +197,13 @@ class _Loop:
             a.pb, a.H_hmax = _ptr(self.pb), hmax
             th = Hc.pattern.tiles_h
             a.H_tile_rows = int(np.max(np.diff(th[:Hc.pattern.ntiles + 1])))
+        # banded Jacobian, no box: step1 rides inside the A.r SpMV
+        own = None if (os.environ.get("IPX_NO_FUSE") or lb is not None or m == 0) \
+            else fuse_own(A.pattern)
+        if own is not None:
+            self.r_next = torch.empty(n, dtype=f64, device=dev)
+            self.own = own[0]
+            a.r_next, a.A_own, a.A_span = _ptr(self.r_next), _ptr(self.own), own[1]
         self.args = a
 
     def ref(self):

@@ -45,9 +45,12 @@ kernels = {}
 names = {"spmv_A_r": ("k_csr_spmv<false, false, false>",),
          "spmv_r_minus_Atv": ("k_csr_spmv<false, true, true>",),
          "spmv_H_p": ("k_csr_spmv<true, false, true>",),
-         "step1": ("k_cg_step1",), "step2": ("k_cg_step2",),
+         "step1": ("k_cg_step1(",), "step2": ("k_cg_step2(",),
+         "step1_spmv_A_r": ("k_cg_step1_ar",), "step2_spmv_H_p": ("k_cg_step2_hp",),
          "banded_solve_with_residual": ("k_solve_decoupled",)}
 for label, keys in names.items():
+    if not any(all(s_ in k for s_ in keys) for k in fetch):
+        continue                      # kernel not in this build's loop (fused / unfused)
     fv, wv = find(fetch, *keys), find(write, *keys)
     # launches of the loop only: the modal size class (priming launches differ)
     f_kb = sorted(fv)[len(fv) // 2]
