@@ -275,7 +275,7 @@ k_cg_step2_hp(int n, double *st, int parity, int mode, const double *__restrict_
   double v[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
-    const int jj = min(s + tid + u * IPX_BLOCK, max(e - 1, s));
+    const int jj = min(s + tid + u * IPX_BLOCK, max(e - 1, 0));   // empty tile: any valid entry
     c[u] = colidx[jj];
     v[u] = val[jj];
   }

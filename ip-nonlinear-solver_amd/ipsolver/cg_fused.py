@@ -62,7 +62,7 @@ FUSE_HMAX = 64          # csrc/cg.hip FUSE_HMAX
 def fuse_halo(pattern):
     """Halo width for the fused step2 + H.p kernel (csrc/cg.hip k_cg_step2_hp), or 0
     when the pattern does not qualify: square, every row tile on the SpMV's fast
-    path and non-empty, columns of a tile within ``hmax <= 64`` of its row range,
+    path, columns of a tile within ``hmax <= 64`` of its row range,
     every tile at least ``hmax`` rows long.  Symbolic; cached on the pattern."""
     cached = getattr(pattern, "_ipx_fuse_halo", None)
     if cached is not None:
@@ -74,12 +74,15 @@ def fuse_halo(pattern):
         t = pattern.tiles_h
         r0, r1 = t[:nt].astype(np.int64), t[1:nt + 1].astype(np.int64)
         s, e = t[nt + 1:2 * nt + 1].astype(np.int64), t[nt + 2:2 * nt + 2].astype(np.int64)
-        ok = np.all(e > s) and np.all(e - s <= _hip.SPMV_TILE_NNZ) and np.all(r1 - r0 <= 1024)
+        ok = np.all(e - s <= _hip.SPMV_TILE_NNZ) and np.all(r1 - r0 <= 1024)
         if ok:
+            # tiles without nonzeros (the empty slack rows of a z-space Hessian) only
+            # update p and x; the halo is set by the others
+            full = np.flatnonzero(e > s)
             idx = pattern.indices_h
-            cmin = np.minimum.reduceat(idx, s)
-            cmax = np.maximum.reduceat(idx, s)
-            h = int(max(np.max(r0 - cmin), np.max(cmax + 1 - r1), 1))
+            cmin = np.minimum.reduceat(idx, s[full])
+            cmax = np.maximum.reduceat(idx, s[full])
+            h = int(max(np.max(r0[full] - cmin), np.max(cmax + 1 - r1[full]), 1))
             if h <= FUSE_HMAX and h <= int(np.min(r1 - r0)):
                 hmax = h
     pattern._ipx_fuse_halo = hmax
