@@ -392,3 +392,50 @@ def test_step2_fused_into_hp_is_bit_identical(ips, variant, monkeypatch):
         # the fused step1 sums ||x + alpha p||^2 per row tile of A instead of per vector
         # chunk: the iterates themselves are computed by identical expressions
         assert np.max(np.abs(x1 - x2)) <= 1e-13 * np.max(np.abs(x2))
+
+
+@pytest.mark.parametrize("n,m,hbw,abw,seed", [(5000, 400, 2, 9, 0), (12345, 1500, 3, 6, 1),
+                                               (3001, 299, 1, 21, 2), (40000, 2500, 5, 30, 3)])
+def test_fused_kernels_on_other_band_shapes(ips, n, m, hbw, abw, seed, monkeypatch):
+    """The two fused kernels (step1 in A.r, step2 in H.p) against the separate launches on
+    banded problems of other shapes: Hessian half bandwidth 1..5, Jacobian rows of ragged
+    length with irregular starts, sizes that are no multiple of anything."""
+    import scipy.sparse as sps
+    import ipsolver.cg_fused as cg_fused
+    rng = np.random.default_rng(seed)
+    # SPD banded Hessian: diagonally dominant
+    offs = list(range(-hbw, hbw + 1))
+    bands = [rng.uniform(-1, 1, n - abs(o)) for o in offs]
+    Hm = sps.diags(bands, offs, format="csr")
+    Hm = sps.csr_matrix(0.5 * (Hm + Hm.T) + sps.diags(np.full(n, 2.0 * hbw + 1.0)))
+    # Jacobian: row i has 3..abw contiguous entries starting near i*n/m (monotone starts)
+    starts = np.minimum((np.arange(m) * (n // m) + rng.integers(0, 3, m)), n - abw)
+    starts = np.maximum.accumulate(starts)
+    lens = rng.integers(3, abw + 1, m)
+    rows = np.repeat(np.arange(m), lens)
+    cols = np.concatenate([s + np.arange(k) for s, k in zip(starts, lens)])
+    Am = sps.csr_matrix((rng.standard_normal(len(cols)), (rows, cols)), shape=(m, n))
+    A = ips.dv.DeviceCSR.from_scipy(Am)
+    H = ips.dv.DeviceCSR.from_scipy(Hm)
+    Z, LS, Y = ips.proj.projections(A)
+    c = rng.standard_normal(n)
+    assert cg_fused.supports(H, Z, Y)
+    assert cg_fused.fuse_halo(H.pattern) == hbw
+    # (whether step1 also fuses depends on how many columns a row tile of A spans: <= 2048)
+    runs = []
+    for no_fuse in ("", "1"):
+        if no_fuse:
+            monkeypatch.setenv("IPX_NO_FUSE", "1")
+        else:
+            monkeypatch.delenv("IPX_NO_FUSE", raising=False)
+        x, info = ips.qp.projected_cg(H, c, Z, Y, np.zeros(m), tol=1e-14, max_iter=60)
+        runs.append((host(x), info))
+    (x1, i1), (x2, i2) = runs
+    assert (i1["niter"], i1["stop_cond"]) == (i2["niter"], i2["stop_cond"])
+    assert np.max(np.abs(x1 - x2)) <= 1e-12 * np.max(np.abs(x2))
+    # and against the CPU oracle
+    import oracle
+    Zo, _, Yo = oracle.projections(Am)
+    xo, io = oracle.projected_cg(Hm, c, Zo, Yo, np.zeros(m), tol=1e-14, max_iter=60)
+    assert io["niter"] == i1["niter"]
+    assert np.max(np.abs(x1 - xo)) <= 1e-9 * np.max(np.abs(xo))
