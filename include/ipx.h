@@ -110,6 +110,7 @@ int ipx_box_sphere_reduce(int64_t n, const double *z, const double *d, double ds
  * and, when red != NULL, red[0] = sum_i y_out_i^2, red[1] = sum_i xrow_i * y_out_i
  * (xrow = x when the matrix is square, used for p'Hp; pass square=0 otherwise).
  */
+#define IPX_FOLD_WS_DOUBLES 16384
 #define IPX_SPMV_TILE_NNZ 2048
 #define IPX_SPMV_TILE_ROWS 1024   /* max rows per tile the fast path takes */
 int ipx_csr_tiles_host(int64_t nrows, const int32_t *rowptr_host, int32_t tile_nnz,
@@ -206,6 +207,9 @@ typedef struct ipx_cg_args {
   double *r_next;
   const int32_t *A_own;
   int64_t A_span;
+  /* IPX_FOLD_WS_DOUBLES doubles of scratch: partial-sum arrays longer than ~1000 entries
+   * (n beyond ~1e6) are compacted into it before the consumers fold them; NULL = never. */
+  double *fold_ws;
 } ipx_cg_args;
 int ipx_cg_state_size(void);
 int ipx_cg_vec_grid(int64_t n);

@@ -529,6 +529,29 @@ k_cg_step1_ar(int n, double *st, int parity, const double *__restrict__ p1, int 
   }
 }
 
+// Large problems: the per-tile partial arrays grow with n while every consumer
+// workgroup folds all of them, so beyond ~1000 entries they are first compacted
+// to one entry per 1024 (fixed order: deterministic).  Up to three arrays per
+// launch; array k takes blocks [first[k], first[k+1]): its half h, chunk c is
+// block first[k] + h*G[k] + c.
+struct CompactJob {
+  const double *in[3];
+  double *out[3];
+  int count[3], halves[3], G[3], first[4];
+};
+__global__ void __launch_bounds__(IPX_BLOCK)
+k_compact_partials(CompactJob job, const double *__restrict__ guard) {
+  __shared__ double lds[IPX_BLOCK / IPX_WAVE];
+  if (guard && *guard != 0.0) return;
+  int k = 0;
+  while (k < 2 && (int)blockIdx.x >= job.first[k + 1]) ++k;
+  const int b = blockIdx.x - job.first[k];
+  const int half = b / job.G[k], chunk = b - half * job.G[k];
+  const int lo = chunk * 1024, len = min(1024, job.count[k] - lo);
+  const double v = ipx_sum_partials<IPX_SUM>(job.in[k] + (int64_t)half * job.count[k] + lo, len, lds);
+  if (threadIdx.x == 0) job.out[k][half * job.G[k] + chunk] = v;
+}
+
 // First / last hmax entries of p for every row tile of H (both parities): what
 // k_cg_step2_hp reads as its halo.  Launched by the unfused producers of p.
 __global__ void __launch_bounds__(IPX_BLOCK)
@@ -602,6 +625,38 @@ static int launch_hp(const ipx_cg_args *a, const double *guard, hipStream_t st) 
   return IPX_OK;
 }
 
+// Host side of k_compact_partials: queue arrays, launch once, hand back the
+// (pointer, entries per half) the consumer should fold.
+struct Compactor {
+  const ipx_cg_args *a;
+  CompactJob job;
+  int n = 0, used = 0;
+  explicit Compactor(const ipx_cg_args *args) : a(args) { job.first[0] = 0; }
+  // returns true (and rewrites ptr / count) when the array will be compacted
+  bool add(const double *&ptr, int &count, int halves, int limit) {
+    if (!a->fold_ws || count <= limit || n >= 3) return false;
+    const int G = (count + 1023) / 1024;
+    if (used + halves * G > IPX_FOLD_WS_DOUBLES) return false;
+    job.in[n] = ptr; job.count[n] = count; job.halves[n] = halves; job.G[n] = G;
+    job.out[n] = a->fold_ws + used;
+    job.first[n + 1] = job.first[n] + halves * G;
+    ptr = a->fold_ws + used;
+    count = G;
+    used += halves * G;
+    ++n;
+    return true;
+  }
+  int launch(const double *guard, hipStream_t st) {
+    if (n == 0) return IPX_OK;
+    for (int k = n; k < 3; ++k) job.first[k + 1] = job.first[n];
+    hipLaunchKernelGGL(k_compact_partials, dim3(job.first[n]), dim3(IPX_BLOCK), 0, st, job, guard);
+    IPX_CHECK_LAUNCH();
+    n = 0;                       // `used` keeps growing: later arrays get fresh scratch
+    job.first[0] = 0;
+    return IPX_OK;
+  }
+};
+
 static bool fused_ar(const ipx_cg_args *a) {
   return a->r_next != nullptr && a->A_own != nullptr && a->A_span > 0 && !a->lb && a->m > 0;
 }
@@ -611,10 +666,11 @@ static int part2_count(const ipx_cg_args *a) {
 }
 
 // step1 + A.r in one launch (see k_cg_step1_ar): r_next <- r + alpha Hp, w <- A r_next
-static int launch_step1_ar(const ipx_cg_args *a, int it, hipStream_t st) {
+static int launch_step1_ar(const ipx_cg_args *a, int it, const double *p1, int np1,
+                           hipStream_t st) {
   const dim3 grid(ipx_xcd_grid((int)a->A_ntiles)), block(IPX_BLOCK);
 #define FUSED_ARGS                                                                         \
-  (int)a->n, a->state, it & 1, a->part1, (int)a->H_ntiles, a->x, a->p, a->r, a->r_next,   \
+  (int)a->n, a->state, it & 1, p1, np1, a->x, a->p, a->r, a->r_next,                       \
       a->Hp, a->A_rowptr, a->A_colidx, a->A_val, a->A_tiles, (int)a->A_ntiles, a->A_own,   \
       a->w, a->part2
   const int qs = (int)((a->A_span + IPX_BLOCK - 1) / IPX_BLOCK);
@@ -632,14 +688,16 @@ static int launch_step1_ar(const ipx_cg_args *a, int it, hipStream_t st) {
 
 // step2 + H.p in one launch (see k_cg_step2_hp); iteration `it` reads the halo
 // copies of parity it & 1 and leaves those of p_next in the other one.
-static int launch_step2_hp(const ipx_cg_args *a, int it, int mode, int np4, hipStream_t st) {
+static int launch_step2_hp(const ipx_cg_args *a, int it, int mode, const double *p2, int np2,
+                           const double *p3, int np3, const double *p4, int np4,
+                           hipStream_t st) {
   const int64_t half = a->H_ntiles * 2 * a->H_hmax;
   const double *pb_in = a->pb + (it & 1) * half;
   double *pb_out = a->pb + ((it + 1) & 1) * half;
   const dim3 grid(ipx_xcd_grid((int)a->H_ntiles)), block(IPX_BLOCK);
 #define FUSED_ARGS                                                                            \
-  (int)a->n, a->state, it & 1, mode, a->part2, part2_count(a), a->part3, (int)a->At_ntiles,   \
-      a->part4, np4, a->x, a->p, a->r, a->H_rowptr, a->H_colidx, a->H_val, a->H_tiles,        \
+  (int)a->n, a->state, it & 1, mode, p2, np2, p3, np3, p4, np4, a->x, a->p, a->r,             \
+      a->H_rowptr, a->H_colidx, a->H_val, a->H_tiles,                                         \
       (int)a->H_ntiles, a->H_diag, a->Hp, a->part1, (int)a->H_hmax, pb_in, pb_out
   // H_hmax carries the longest tile's row count in its upper half (set by the host
   // binding): short tiles (3 nonzeros per row -> 683 rows) take the 3-elements-per-lane
@@ -774,7 +832,8 @@ int ipx_cg_step2_hp(const ipx_cg_args *a, int32_t it, int32_t mode, void *stream
   if (!a || !fused_hp(a)) return IPX_EINVAL;
   const int np4 = a->m > 0 ? ipx_banded_resid_count(a->solver_kind == 1
                                  ? ((const ipx_boxschur_args *)a->banded)->inner : a->banded) : 1;
-  return launch_step2_hp(a, it, mode, np4, (hipStream_t)stream);
+  return launch_step2_hp(a, it, mode, a->part2, part2_count(a), a->part3, (int)a->At_ntiles,
+                         a->part4, np4, (hipStream_t)stream);
 }
 
 // Tail of an iteration after the host handled a stop-5 / stop-6 event:
@@ -888,14 +947,20 @@ static int cg_iterate(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, hi
     int rc;
     const bool fuse1 = fused_ar(a);
     const double *r_in = fuse1 ? a->r_next : a->r;      // what the r - A'v SpMV reads
+    Compactor cmp(a);
+    const double *p1 = a->part1;
+    int np1 = (int)a->H_ntiles;
+    cmp.add(p1, np1, 2, 1024);
+    rc = cmp.launch(guard, st);
+    if (rc) return rc;
     if (fuse1) {
       MARK(1);
-      rc = launch_step1_ar(a, it, st);                // r_next = r + alpha Hp;  w = A r_next
+      rc = launch_step1_ar(a, it, p1, np1, st);       // r_next = r + alpha Hp;  w = A r_next
       if (rc) return rc;
       MARK(2);
     } else {
       hipLaunchKernelGGL(k_cg_step1, dim3(ipx_xcd_grid((int)a->vec_grid)), dim3(VB), 0, st, a->n,
-                         a->state, it & 1, a->part1, (int)a->H_ntiles, a->x, a->p, a->r,
+                         a->state, it & 1, p1, np1, a->x, a->p, a->r,
                          a->Hp, a->lb, a->ub, a->part2, (int)a->vec_grid);
       IPX_CHECK_LAUNCH();
       MARK(1);
@@ -923,13 +988,22 @@ static int cg_iterate(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, hi
       MARK(4);
       MARK(5);
     }
+    const double *p2 = a->part2, *p3 = a->part3, *p4 = a->part4;
+    int np2 = part2_count(a), np3 = (int)a->At_ntiles, n4 = np4;
+    cmp.add(p2, np2, 2, 512);
+    if (a->m > 0) {
+      cmp.add(p3, np3, 2, 1024);
+      cmp.add(p4, n4, 1, 512);
+    }
+    rc = cmp.launch(guard, st);
+    if (rc) return rc;
     if (fused_hp(a)) {
       MARK(6);
-      rc = launch_step2_hp(a, it, a->m > 0 ? 0 : 2, np4, st);
+      rc = launch_step2_hp(a, it, a->m > 0 ? 0 : 2, p2, np2, p3, np3, p4, n4, st);
     } else {
       hipLaunchKernelGGL(k_cg_step2, dim3(ipx_xcd_grid((int)a->vec_grid)), dim3(VB), 0, st, a->n,
-                         a->state, it & 1, a->m > 0 ? 0 : 2, a->part2, part2_count(a), a->part3,
-                         (int)a->At_ntiles, a->part4, np4, a->x, a->p, a->r, (int)a->vec_grid);
+                         a->state, it & 1, a->m > 0 ? 0 : 2, p2, np2, p3, np3, p4, n4, a->x, a->p,
+                         a->r, (int)a->vec_grid);
       IPX_CHECK_LAUNCH();
       MARK(6);
       rc = launch_hp(a, guard, st);

@@ -38,7 +38,7 @@ class CgArgs(ctypes.Structure):
         ("lb", _P), ("ub", _P), ("state", _P),
         ("part1", _P), ("part2", _P), ("part3", _P), ("part4", _P),
         ("vec_grid", _I64), ("solver_kind", _I64), ("pb", _P), ("H_hmax", _I64), ("H_tile_rows", _I64),
-        ("r_next", _P), ("A_own", _P), ("A_span", _I64))]
+        ("r_next", _P), ("A_own", _P), ("A_span", _I64), ("fold_ws", _P))]
 
 
 # Counters over the life of the process (diagnostics: how often the device loop
@@ -193,6 +193,8 @@ class _Loop:
         a.lb = _ptr(lb.t) if lb is not None else None
         a.ub = _ptr(ub.t) if ub is not None else None
         a.vec_grid = grid
+        self.fold_ws = torch.zeros(16384, dtype=f64, device=dev)      # IPX_FOLD_WS_DOUBLES
+        a.fold_ws = _ptr(self.fold_ws)
         # banded Hessian: step2 rides inside the H.p SpMV (one launch less per iteration)
         hmax = 0 if os.environ.get("IPX_NO_FUSE") else fuse_halo(Hc.pattern)
         if hmax > 0:

@@ -177,3 +177,31 @@ def test_dense_config2_gram_and_projection():
     Ax = host(A.dot(x))
     ref = A_h.dot(host(x))
     assert np.max(np.abs(Ax - ref)) <= 1e-12 * np.max(np.abs(ref))
+
+
+def test_partial_compaction_beyond_1e6():
+    """Past n ~ 1e6 the per-tile partial arrays exceed what a consumer workgroup folds in one
+    round; the loop then compacts them first (k_compact_partials).  The device-resident
+    loop must still agree with the statement-by-statement driver."""
+    import ipsolver.cg_fused as cg_fused
+    import ipsolver.device as dv
+    import ipsolver.projector as proj
+    import ipsolver.qp as qp
+    from ipsolver.operators import DeviceHessian
+    from ipsolver.synthetic import CenteredBandedNLP
+    n, m = 3000000, 300000
+    prob = CenteredBandedNLP(n, m, seed=0)
+    x = prob.x0
+    v = 0.1 * np.random.default_rng(7).standard_normal(m)
+    A = dv.DeviceCSR.from_scipy(prob.constr_jac(x))
+    H = DeviceHessian(n, csr=dv.DeviceCSR.from_scipy(prob.hess(x)),
+                      diag=dv.DVec.from_host(prob.kappa * prob.Wt.dot(v)))
+    assert H.csr.pattern.ntiles > 1024 and A.T.pattern.ntiles > 1024
+    Z, LS, Y = proj.projections(A)
+    assert cg_fused.supports(H, Z, Y)
+    c, b = prob.grad(x), np.zeros(m)
+    x_f, info_f = qp.projected_cg(H, c, Z, Y, b, tol=0.0, max_iter=8)
+    x_g, info_g = qp.projected_cg(H, c, Z, Y, b, tol=0.0, max_iter=8, return_all=True)
+    assert (info_f["niter"], info_f["stop_cond"]) == (info_g["niter"], info_g["stop_cond"])
+    assert dv.norm(x_f - x_g) <= 1e-12 * dv.norm(x_g)
+    assert dv.norm(A.dot(x_f)) <= 1e-11 * float(np.sqrt((A.val ** 2).sum().item())) * dv.norm(x_f)
