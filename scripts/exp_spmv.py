@@ -1,5 +1,11 @@
 """Experiment: H.p SpMV time with the gathers / the row-sum phase removed (results are wrong on
-purpose; dev tool).  IPX_LIB_DIR selects the library build."""
+purpose; dev tool).  IPX_LIB_DIR selects the library build, e.g.
+
+    cd ip-nonlinear-solver_amd/csrc && mkdir -p ../lib_exp_NOGATHER && \
+      hipcc -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -DIPX_EXP_NOGATHER \
+            -I../../include -shared -o ../lib_exp_NOGATHER/libipx.so *.hip
+    IPX_LIB_DIR=lib_exp_NOGATHER python scripts/exp_spmv.py
+"""
 import ctypes, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "ip-nonlinear-solver_amd"))
