@@ -215,7 +215,7 @@ class ShardedProjectedCG:
         if max_iter is None:
             max_iter = self.n - self.m
         max_iter = min(max_iter, self.n - self.m)
-        it, stop_cond = 0, 1
+        it, stop_cond, hits_boundary = 0, 1, False
         while it < max_iter:
             end = min(max_iter, it + batch)
             self.iterate(it, end)
@@ -227,13 +227,39 @@ class ShardedProjectedCG:
             if stop == 4:
                 stop_cond = 4
                 break
+            if stop in (2, 3):
+                # trust-region boundary (qp_subproblem.py:583-596) or negative curvature
+                # (:558-576): move to the sphere along p.  The three inner products are
+                # summed over the ranks; every rank then takes the same step on its block.
+                if stop == 3 and np.isinf(trust_radius):
+                    raise ValueError("Negative curvature not allowed for unrestricted "
+                                     "problems.")
+                self._to_boundary(float(s[ST_ALPHA]), trust_radius, entire_line=(stop == 3))
+                stop_cond, hits_boundary = stop, True
+                break
             raise NotImplementedError(
-                "sharded projected CG: stop code %d (trust-region boundary, negative "
-                "curvature, box or refinement events) is handled by the single-GPU path "
-                "only in this round" % stop)
+                "sharded projected CG: stop code %d (box or refinement events) is handled by "
+                "the single-GPU path only" % stop)
         s = self.read_state()
         return self.gather_x(), {'niter': int(s[ST_NITER]), 'stop_cond': stop_cond,
-                                 'hits_boundary': False}
+                                 'hits_boundary': hits_boundary}
+
+    def _to_boundary(self, alpha, trust_radius, entire_line):
+        """x <- x + theta d with d = p (negative curvature: the whole line, the positive
+        root) or d = alpha p (step leaving the region: the segment), theta from
+        sphere_intersections on the all-reduced d.d, x.d, x.x."""
+        from .qp import _sphere_from_scalars
+        eng = self.eng
+        scale = 1.0 if entire_line else alpha
+        dots = eng.zeros(4)
+        eng.dots3(self.x, self.p, dots)               # x.x, x.p, p.p on this block
+        self._allreduce(dots)
+        xx, xp, pp = (float(v) for v in eng.download(dots)[:3])
+        ta, tb, intersect = _sphere_from_scalars(scale * scale * pp, scale * xp, xx, trust_radius,
+                                                 entire_line)
+        if intersect:
+            eng.axpby(1.0, self.x, tb * scale, self.p, self.x)
+
 
 
 class SegmentsByKernel:
@@ -383,6 +409,14 @@ class HipEngine(SegmentsByKernel):
         if hl or hr:
             self._hip.call("ipx_cg_halo_apply", self._ptr(state), hl, hr, self._ptr(g_left),
                            self._ptr(g_right), self._ptr(p_left), self._ptr(p_right), self._st())
+
+    def dots3(self, x, p, out):
+        """out[0..3) = x.x, x.p, p.p"""
+        c = self.ctx
+        for k, (a, b) in enumerate(((x, x), (x, p), (p, p))):
+            self._hip.call("ipx_dot", a.numel(), self._ptr(a), self._ptr(b), self._ptr(c.out),
+                           self._ptr(c.ws), self._st())
+            out[k:k + 1].copy_(c.out[:1])
 
     def spmv(self, M, x, out, alpha=1.0, diag=None, beta=0.0, yin=None, xrow=None, partial=None,
              guard=None):

@@ -94,6 +94,9 @@ class NumpyEngine(_segments_base()):
         if p_right is not None:
             p_right[:] = st[ST_BETA] * p_right - g_right
 
+    def dots3(self, x, p, out):
+        out[0], out[1], out[2] = x.dot(x), x.dot(p), p.dot(p)
+
     def spmv(self, M, x, out, alpha=1.0, diag=None, beta=0.0, yin=None, xrow=None, partial=None,
              guard=None):
         if self._stopped(guard):

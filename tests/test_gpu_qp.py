@@ -268,6 +268,15 @@ def test_sharded_engine_single_rank(ips):
     xf, inf2 = ips.qp.projected_cg(H, inst.c, Z, Y, np.zeros(2000), tol=0, max_iter=40)
     assert info["niter"] == inf2["niter"] == 40 and info["stop_cond"] == inf2["stop_cond"]
     assert np.max(np.abs(x - xf.to_host())) <= 1e-12 * np.max(np.abs(x))
+    # trust-region exit: both drivers end on the sphere at the same point
+    radius = 0.4 * float(np.linalg.norm(x))
+    cg2 = ShardedProjectedCG(HipEngine(), inst.A, inst.H, hdiag)
+    xs, info_s = cg2.solve(inst.c, trust_radius=radius)
+    xq, info_q = ips.qp.projected_cg(H, inst.c, Z, Y, np.zeros(2000), trust_radius=radius)
+    assert (info_s["niter"], info_s["stop_cond"], info_s["hits_boundary"]) == \
+        (info_q["niter"], 2, True) and info_q["stop_cond"] == 2
+    assert abs(np.linalg.norm(xs) - radius) <= 1e-12 * radius
+    assert np.max(np.abs(xs - xq.to_host())) <= 1e-11 * np.max(np.abs(xs))
 
 
 def _two_rank_worker(rank, world, port, out_path):

@@ -30,7 +30,16 @@ def _wide_hessian(H):
                                          0.1 * np.ones(n - 3)], [-3, 0, 3]))
 
 
-def _worker(rank, world, port, n, m, iters, tol, out_dir, wide=False):
+def _variant_hessian(H, variant):
+    import scipy.sparse as sps
+    if variant == "wide":
+        return _wide_hessian(H)
+    if variant == "indefinite":          # negative curvature along the way
+        return sps.csr_matrix(H - 3.0 * sps.identity(H.shape[0]))
+    return H
+
+
+def _worker(rank, world, port, n, m, iters, tol, out_dir, wide=False, radius=np.inf):
     for p in (ROOT, os.path.join(ROOT, "ip-nonlinear-solver_amd"), os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -42,11 +51,13 @@ def _worker(rank, world, port, n, m, iters, tol, out_dir, wide=False):
         from ipsolver.sharded import ShardedProjectedCG
         from oracle.numpy_engine import NumpyEngine
         inst = BandedInstance(n, m)
-        cg = ShardedProjectedCG(NumpyEngine(), inst.A, _wide_hessian(inst.H) if wide else inst.H)
-        x, info = cg.solve(inst.c, tol=tol, max_iter=iters)
+        variant = wide if isinstance(wide, str) else ("wide" if wide else "plain")
+        cg = ShardedProjectedCG(NumpyEngine(), inst.A, _variant_hessian(inst.H, variant))
+        x, info = cg.solve(inst.c, tol=tol, max_iter=iters, trust_radius=radius)
         if rank == 0:
             np.savez(os.path.join(out_dir, "w%d.npz" % world), x=x,
-                     info=np.array([info["niter"], info["stop_cond"]]))
+                     info=np.array([info["niter"], info["stop_cond"],
+                                    int(info["hits_boundary"])]))
     finally:
         dist.destroy_process_group()
 
@@ -63,8 +74,33 @@ def test_sharded_cg_matches_oracle(world, tmp_path):
     inst = BandedInstance(n, m)
     Z, _, Y = oracle.projections(inst.A)
     xo, info = oracle.projected_cg(inst.H, inst.c, Z, Y, np.zeros(m), tol=0, max_iter=iters)
-    assert list(got["info"]) == [info["niter"], info["stop_cond"]]
+    assert list(got["info"][:2]) == [info["niter"], info["stop_cond"]]
     assert np.max(np.abs(got["x"] - xo)) <= 1e-11 * np.max(np.abs(xo))
+
+
+@pytest.mark.parametrize("variant,radius", [("plain", 0.5), ("indefinite", 2.0)])
+def test_sharded_cg_trust_region_exits(variant, radius, tmp_path):
+    """Leaving the trust region (stop_cond 2) and negative curvature (stop_cond 3) end on
+    the sphere: the step length comes from all-reduced inner products
+    (qp_subproblem.py:558-596)."""
+    import oracle
+    from banded_setup import BandedInstance
+    n, m = 2000, 200
+    inst = BandedInstance(n, m)
+    Z, _, Y = oracle.projections(inst.A)
+    H = _variant_hessian(inst.H, variant)
+    if variant == "plain":
+        x_free, _ = oracle.projected_cg(H, inst.c, Z, Y, np.zeros(m))
+        radius = radius * np.linalg.norm(x_free)
+    xo, info = oracle.projected_cg(H, inst.c, Z, Y, np.zeros(m), trust_radius=radius)
+    assert info["stop_cond"] == (2 if variant == "plain" else 3) and info["hits_boundary"]
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, n, m, None, None, str(tmp_path), variant, radius), nprocs=2,
+             join=True)
+    got = np.load(os.path.join(str(tmp_path), "w2.npz"))
+    assert list(got["info"]) == [info["niter"], info["stop_cond"], 1]
+    assert abs(np.linalg.norm(got["x"]) - radius) <= 1e-12 * radius
+    assert np.max(np.abs(got["x"] - xo)) <= 1e-10 * np.max(np.abs(xo))
 
 
 def test_sharded_cg_default_tolerance(tmp_path):
@@ -77,7 +113,7 @@ def test_sharded_cg_default_tolerance(tmp_path):
     inst = BandedInstance(n, m)
     Z, _, Y = oracle.projections(inst.A)
     xo, info = oracle.projected_cg(inst.H, inst.c, Z, Y, np.zeros(m))
-    assert list(got["info"]) == [info["niter"], info["stop_cond"]] and info["stop_cond"] == 4
+    assert list(got["info"][:2]) == [info["niter"], info["stop_cond"]] and info["stop_cond"] == 4
     assert np.max(np.abs(got["x"] - xo)) <= 1e-11 * np.max(np.abs(xo))
 
 
@@ -94,5 +130,5 @@ def test_sharded_cg_wide_halo(tmp_path):
     Z, _, Y = oracle.projections(inst.A)
     xo, info = oracle.projected_cg(_wide_hessian(inst.H), inst.c, Z, Y, np.zeros(m), tol=0,
                                    max_iter=iters)
-    assert list(got["info"]) == [info["niter"], info["stop_cond"]]
+    assert list(got["info"][:2]) == [info["niter"], info["stop_cond"]]
     assert np.max(np.abs(got["x"] - xo)) <= 1e-11 * np.max(np.abs(xo))
