@@ -168,6 +168,9 @@ int ipx_banded_solve(void *handle, const double *w, double *x, void *stream);
 int ipx_banded_solve_guarded_c(void *handle, const double *w, double *x, const double *guard,
                                void *stream);
 /* One-kernel-per-level variant of the same solve (cross-check / LDS fallback). */
+/* After ipx_banded_status: 1 when solves take the single-launch decoupled path; then
+ * out[0] = constraint rows per workgroup of that kernel, out[1] = its workgroups. */
+int ipx_banded_decoupled_geometry(void *handle, int32_t *out);
 /* solve + per-workgroup partials of ||w - (A A') x||^2 (ceil(m/256) doubles). */
 int ipx_banded_solve_resid(void *handle, const double *w, double *x, double *partial,
                            int32_t *npartial, const double *guard, void *stream);
@@ -210,6 +213,12 @@ typedef struct ipx_cg_args {
   /* IPX_FOLD_WS_DOUBLES doubles of scratch: partial-sum arrays longer than ~1000 entries
    * (n beyond ~1e6) are compacted into it before the consumers fold them; NULL = never. */
   double *fold_ws;
+  /* g = r - A'v as the tail of the single-launch decoupled banded solve (tridiagonal A A'):
+   * At_vown = workgroups+1 ints, the variables each workgroup of that kernel owns (those
+   * whose first constraint lies in its rows; see ipx_banded_decoupled_geometry); At_qv =
+   * ceil(most variables of one workgroup / 256) <= 16.  NULL / 0: separate SpMV. */
+  const int32_t *At_vown;
+  int64_t At_qv;
 } ipx_cg_args;
 int ipx_cg_state_size(void);
 int ipx_cg_vec_grid(int64_t n);

@@ -904,12 +904,27 @@ IPX_STAMP_DECL(ipx_dbg_stamps);
 // for the corrected solution of its rows AND their normal-equation residual:
 // no y / gL / gR round trip through memory and no second kernel.
 //   local chunk l = 0 .. T+2  <->  global chunk t = t0 - 1 + l;  own: l = 1 .. T
-template <int K, int T>
+// Optional tail of k_solve_decoupled: g = r - A'v on the variables this workgroup's
+// constraint rows are the first to touch (tridiagonal A A' <=> a variable sees at most
+// two constraints, and they are adjacent, so every v it needs is in this workgroup's
+// LDS).  A' in CSR; vown[b] .. vown[b+1] = variables of workgroup b; part3 = per-
+// workgroup partials of ||g||^2 (second half zero, like a rectangular SpMV's).
+struct AtvJob {
+  const int32_t *rowptr, *colidx;
+  const double *val;
+  const double *r_in;
+  double *g_out;
+  const int32_t *vown;
+  double *part3;
+};
+
+template <int K, int T, int QV>
 __global__ void __launch_bounds__(DOWN_T)
 k_solve_decoupled(LevDev lv, const double *__restrict__ w, double *__restrict__ x,
                   const double *__restrict__ rinv, double *__restrict__ partial,
-                  const double *__restrict__ guard) {
+                  const double *__restrict__ guard, AtvJob atv) {
   constexpr int NCH = T + 3;
+  constexpr int QA = QV > 0 ? QV : 1;
   extern __shared__ double sm[];
   __shared__ double red_lds[DOWN_T / IPX_WAVE];
   IPX_STAMP(0);
@@ -999,6 +1014,18 @@ k_solve_decoupled(LevDev lv, const double *__restrict__ w, double *__restrict__ 
   g_E.load(NCH * K * K, f_E);   g_F.load(NCH * K * K, f_F);  g_B.load((K + 1) * NB, f_B);
   g_w0.load(T * q, f_w0);       g_V.load(NV * K, f_V);       g_W.load(NV * K, f_W);
   g_r.load((NCH - 1) * K, f_r);
+  // A'v tail: row pointers of this workgroup's variables travel with the staging loads
+  int av0 = 0, avn = 0, ra[QA], rb[QA];
+  if (QV > 0) {
+    av0 = atv.vown[blockIdx.x];
+    avn = atv.vown[blockIdx.x + 1] - av0;
+#pragma unroll
+    for (int k = 0; k < QA; ++k) {
+      const int j = av0 + min((int)threadIdx.x + k * DOWN_T, max(avn - 1, 0));
+      ra[k] = atv.rowptr[j];
+      rb[k] = atv.rowptr[j + 1];
+    }
+  }
   if (stop != 0.0) return;
   IPX_STAMP(1);
   g_w.store(sw, NCH * q, f_w);       g_D.store(sD, qk * NCH, f_D);
@@ -1008,6 +1035,23 @@ k_solve_decoupled(LevDev lv, const double *__restrict__ w, double *__restrict__ 
   g_W.store(sW, NV * K, f_W);        g_r.store(srinv, (NCH - 1) * K, f_r);
   __syncthreads();
   IPX_STAMP(2);
+  // A'v tail: the (at most two) entries of every row and r, requested now so that they
+  // arrive while the chunk recurrences run
+  int ac0[QA], ac1[QA];
+  double aw0[QA], aw1[QA], ar[QA];
+  if (QV > 0) {
+#pragma unroll
+    for (int k = 0; k < QA; ++k) {
+      const int j = av0 + min((int)threadIdx.x + k * DOWN_T, max(avn - 1, 0));
+      // (clamped: an empty row re-reads a neighbouring entry, never out of bounds)
+      const int e0 = max(min(ra[k], rb[k] - 1), 0), e1 = max(rb[k] - 1, e0);
+      ac0[k] = atv.colidx[e0];
+      ac1[k] = atv.colidx[e1];
+      aw0[k] = atv.val[e0];
+      aw1[k] = atv.val[e1];
+      ar[k] = atv.r_in[j];
+    }
+  }
 
   // ---- chunk recurrences + the two halves of every separator's reduced rhs
   if ((int)threadIdx.x < NCH) {
@@ -1054,9 +1098,33 @@ k_solve_decoupled(LevDev lv, const double *__restrict__ w, double *__restrict__ 
     }
     sx[li] = v;
   }
-  if (!partial) return;
+  if (!partial && QV == 0) return;
   __syncthreads();
   IPX_STAMP(6);
+  if (QV > 0) {
+    // ---- g = r - A'v on this workgroup's variables, v out of LDS (sx)
+    double gacc = 0.0;
+#pragma unroll
+    for (int k = 0; k < QA; ++k) {
+      const int jl = (int)threadIdx.x + k * DOWN_T;
+      if (jl < avn) {
+        const int len = rb[k] - ra[k];
+        double sum = 0.0;
+        if (len > 0) sum += aw0[k] * sx[ac0[k] - rfirst];
+        if (len > 1) sum += aw1[k] * sx[ac1[k] - rfirst];
+        double y = -1.0 * sum;
+        y += 1.0 * ar[k];
+        atv.g_out[av0 + jl] = y;
+        gacc += y * y;
+      }
+    }
+    const double gtot = ipx_block_reduce<IPX_SUM>(gacc, red_lds);
+    if (threadIdx.x == 0) {
+      atv.part3[blockIdx.x] = gtot;
+      atv.part3[gridDim.x + blockIdx.x] = 0.0;
+    }
+    if (!partial) return;
+  }
   // ---- residual of the own rows out of LDS:  w_i - sum_d S[i][i+-d] x[i+-d]
   double acc = 0.0;
   for (int r = threadIdx.x; r < T * q; r += blockDim.x) {
@@ -1087,22 +1155,38 @@ size_t decoupled_lds_doubles(int q) {
          (size_t)2 * K * ((T + 2) * q - (q - K));
 }
 
-template <int K>
-int launch_solve_decoupled(const LevDev &lv, const double *w, double *x, const double *rinv,
-                           double *partial, int *npartial, const double *guard, hipStream_t st) {
+template <int K, int QV>
+int launch_solve_decoupled_q(const LevDev &lv, const double *w, double *x, const double *rinv,
+                             double *partial, int *npartial, const double *guard,
+                             const AtvJob &atv, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void *)k_solve_decoupled<K, DEC_CHUNKS>,
+    (void)hipFuncSetAttribute((const void *)k_solve_decoupled<K, DEC_CHUNKS, QV>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);
     attr_set = true;
   }
   const int grid = (lv.P + DEC_CHUNKS - 1) / DEC_CHUNKS;
   if (npartial) *npartial = grid;
-  hipLaunchKernelGGL((k_solve_decoupled<K, DEC_CHUNKS>), dim3(grid), dim3(DOWN_T),
+  hipLaunchKernelGGL((k_solve_decoupled<K, DEC_CHUNKS, QV>), dim3(grid), dim3(DOWN_T),
                      decoupled_lds_doubles<K>(lv.q) * sizeof(double), st, lv, w, x, rinv, partial,
-                     guard);
+                     guard, atv);
   IPX_CHECK_LAUNCH();
   return IPX_OK;
+}
+
+// qv = variables per lane of the A'v tail (0: plain solve)
+template <int K>
+int launch_solve_decoupled(const LevDev &lv, const double *w, double *x, const double *rinv,
+                           double *partial, int *npartial, const double *guard, hipStream_t st,
+                           const AtvJob *atv = nullptr, int qv = 0) {
+  const AtvJob none{};
+  if (!atv || qv <= 0)
+    return launch_solve_decoupled_q<K, 0>(lv, w, x, rinv, partial, npartial, guard, none, st);
+  if (qv <= 4) return launch_solve_decoupled_q<K, 4>(lv, w, x, rinv, partial, npartial, guard, *atv, st);
+  if (qv <= 8) return launch_solve_decoupled_q<K, 8>(lv, w, x, rinv, partial, npartial, guard, *atv, st);
+  if (qv <= 12) return launch_solve_decoupled_q<K, 12>(lv, w, x, rinv, partial, npartial, guard, *atv, st);
+  if (qv <= 16) return launch_solve_decoupled_q<K, 16>(lv, w, x, rinv, partial, npartial, guard, *atv, st);
+  return IPX_EINVAL;
 }
 
 template <int K>
@@ -1543,6 +1627,37 @@ int ipx_banded_resid_count(void *handle) {
   if (h->fast && h->nlev > 1) return (l0.m + IPX_BLOCK - 1) / IPX_BLOCK;
   const int grid = (l0.m + IPX_BLOCK - 1) / IPX_BLOCK;           // k_band_residual
   return grid > 256 ? 256 : grid;
+}
+
+// Geometry of the single-launch decoupled solve: out[0] = constraint rows per workgroup,
+// out[1] = workgroups; returns 1 when that path is the one solves take, else 0.
+extern "C" int ipx_banded_decoupled_geometry(void *handle, int32_t *out) {
+  if (!handle || !out) return 0;
+  Banded *h = (Banded *)handle;
+  const Level &l0 = h->lev[0];
+  if (!(h->fast && h->nlev > 1 && h->decoupled && l0.k == 1 &&
+        decoupled_lds_doubles<1>(l0.q) * sizeof(double) <= LDS_LIMIT))
+    return 0;
+  out[0] = DEC_CHUNKS * l0.q;
+  out[1] = (l0.P + DEC_CHUNKS - 1) / DEC_CHUNKS;
+  return 1;
+}
+
+// Decoupled solve + residual partials + g = r_in - A'v (see AtvJob) in one launch.
+// IPX_EINVAL when the factorization is not on the decoupled path.
+int ipx_banded_solve_resid_atv_launch(void *handle, const double *w, double *x, double *partial,
+                                      int *npartial, const int32_t *At_rowptr,
+                                      const int32_t *At_colidx, const double *At_val,
+                                      const double *r_in, double *g_out, const int32_t *vown,
+                                      int qv, double *part3, const double *guard,
+                                      hipStream_t st) {
+  if (!handle || !w || !x || !partial || w == x) return IPX_EINVAL;
+  int32_t geo[2];
+  if (!ipx_banded_decoupled_geometry(handle, geo)) return IPX_EINVAL;
+  Banded *h = (Banded *)handle;
+  const AtvJob job{At_rowptr, At_colidx, At_val, r_in, g_out, vown, part3};
+  return launch_solve_decoupled<1>(to_dev(h->lev[0], nullptr), w, x, h->rinv, partial, npartial,
+                                   guard, st, &job, qv);
 }
 
 // Solve + residual partials in one go (the CG loop's projection step).

@@ -664,6 +664,15 @@ static bool fused_ar(const ipx_cg_args *a) {
 static int part2_count(const ipx_cg_args *a) {
   return fused_ar(a) ? (int)a->A_ntiles : (int)a->vec_grid;
 }
+static int part4_count(const ipx_cg_args *a) {
+  return a->m > 0 ? ipx_banded_resid_count(a->solver_kind == 1
+                        ? ((const ipx_boxschur_args *)a->banded)->inner : a->banded) : 1;
+}
+// entries per half of part3: one per row tile of A', or per workgroup of the solve when
+// g = r - A'v is its tail
+static int part3_count(const ipx_cg_args *a) {
+  return (a->solver_kind == 0 && a->At_vown && a->At_qv > 0) ? part4_count(a) : (int)a->At_ntiles;
+}
 
 // step1 + A.r in one launch (see k_cg_step1_ar): r_next <- r + alpha Hp, w <- A r_next
 static int launch_step1_ar(const ipx_cg_args *a, int it, const double *p1, int np1,
@@ -830,10 +839,8 @@ int ipx_cg_hp(const ipx_cg_args *a, void *stream) {
 // in ipx_cg_resume); IPX_EINVAL when the argument block does not enable it.
 int ipx_cg_step2_hp(const ipx_cg_args *a, int32_t it, int32_t mode, void *stream) {
   if (!a || !fused_hp(a)) return IPX_EINVAL;
-  const int np4 = a->m > 0 ? ipx_banded_resid_count(a->solver_kind == 1
-                                 ? ((const ipx_boxschur_args *)a->banded)->inner : a->banded) : 1;
-  return launch_step2_hp(a, it, mode, a->part2, part2_count(a), a->part3, (int)a->At_ntiles,
-                         a->part4, np4, (hipStream_t)stream);
+  return launch_step2_hp(a, it, mode, a->part2, part2_count(a), a->part3, part3_count(a),
+                         a->part4, part4_count(a), (hipStream_t)stream);
 }
 
 // Tail of an iteration after the host handled a stop-5 / stop-6 event:
@@ -842,11 +849,9 @@ int ipx_cg_resume(const ipx_cg_args *a, int32_t it, int32_t mode, void *stream) 
   if (!a) return IPX_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const double *guard = a->state + ST_STOP;
-  const int np4 = a->m > 0 ? ipx_banded_resid_count(a->solver_kind == 1
-                                 ? ((const ipx_boxschur_args *)a->banded)->inner : a->banded) : 1;
   hipLaunchKernelGGL(k_cg_step2, dim3(ipx_xcd_grid((int)a->vec_grid)), dim3(VB), 0, st, a->n,
                      a->state, it & 1, mode, a->part2, part2_count(a), a->part3,
-                     (int)a->At_ntiles, a->part4, np4, a->x, a->p, a->r,
+                     part3_count(a), a->part4, part4_count(a), a->x, a->p, a->r,
                      (int)a->vec_grid);
   IPX_CHECK_LAUNCH();
   return launch_hp(a, guard, st);
@@ -944,13 +949,13 @@ static int cg_iterate(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, hi
   int np4 = 1;
   for (int it = it_begin; it < it_end; ++it) {
     MARK(0);
-    int rc;
+    int rc, np3 = (int)a->At_ntiles;
     const bool fuse1 = fused_ar(a);
     const double *r_in = fuse1 ? a->r_next : a->r;      // what the r - A'v SpMV reads
     Compactor cmp(a);
     const double *p1 = a->part1;
     int np1 = (int)a->H_ntiles;
-    cmp.add(p1, np1, 2, 1024);
+    cmp.add(p1, np1, 2, 2048);      // beyond what a consumer folds in one or two rounds
     rc = cmp.launch(guard, st);
     if (rc) return rc;
     if (fuse1) {
@@ -975,25 +980,38 @@ static int cg_iterate(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, hi
       // v = (AA')^-1 w, and ||A g||^2 for the orthogonality test as the
       // constraint-space residual ||w - (A A') v||^2 from the same launch
       // (see k_correct_oop / k_band_residual); part4 holds ceil(m/256) doubles
-      if (a->solver_kind == 1)
-        rc = ipx_boxschur_solve((const ipx_boxschur_args *)a->banded, a->w, a->v, a->part4, &np4,
-                                guard, st);
-      else
-        rc = ipx_banded_solve_resid_launch(a->banded, a->w, a->v, a->part4, &np4, guard, st);
-      if (rc) return rc;
-      MARK(3);
-      // r = r - A'v  (g_next), partials of ||g||^2
-      rc = ipx_spmv_launch(At, a->v, -1.0, nullptr, 1.0, r_in, a->r, a->part3, guard, st);
-      if (rc) return rc;
-      MARK(4);
+      np3 = (int)a->At_ntiles;
+      if (a->solver_kind == 0 && a->At_vown && a->At_qv > 0) {
+        // decoupled banded solve with g = r - A'v as its tail (one launch for both);
+        // ||g||^2 partials are then per workgroup of that kernel
+        rc = ipx_banded_solve_resid_atv_launch(a->banded, a->w, a->v, a->part4, &np4,
+                                               a->At_rowptr, a->At_colidx, a->At_val, r_in, a->r,
+                                               a->At_vown, (int)a->At_qv, a->part3, guard, st);
+        if (rc) return rc;
+        np3 = np4;
+        MARK(3);
+        MARK(4);
+      } else {
+        if (a->solver_kind == 1)
+          rc = ipx_boxschur_solve((const ipx_boxschur_args *)a->banded, a->w, a->v, a->part4,
+                                  &np4, guard, st);
+        else
+          rc = ipx_banded_solve_resid_launch(a->banded, a->w, a->v, a->part4, &np4, guard, st);
+        if (rc) return rc;
+        MARK(3);
+        // r = r - A'v  (g_next), partials of ||g||^2
+        rc = ipx_spmv_launch(At, a->v, -1.0, nullptr, 1.0, r_in, a->r, a->part3, guard, st);
+        if (rc) return rc;
+        MARK(4);
+      }
       MARK(5);
     }
     const double *p2 = a->part2, *p3 = a->part3, *p4 = a->part4;
-    int np2 = part2_count(a), np3 = (int)a->At_ntiles, n4 = np4;
-    cmp.add(p2, np2, 2, 512);
+    int np2 = part2_count(a), n4 = np4;
+    cmp.add(p2, np2, 2, 1024);
     if (a->m > 0) {
-      cmp.add(p3, np3, 2, 1024);
-      cmp.add(p4, n4, 1, 512);
+      cmp.add(p3, np3, 2, 2048);
+      cmp.add(p4, n4, 1, 1024);
     }
     rc = cmp.launch(guard, st);
     if (rc) return rc;

@@ -297,6 +297,12 @@ int ipx_banded_solve_guarded(void *handle, const double *w, double *x, const dou
 // x = (A A')^-1 w and partial[0..*npartial) <- per-workgroup sums of ||w - (A A') x||^2
 // in one go; the partial buffer needs ceil(m / 256) doubles.
 int ipx_banded_resid_count(void *handle);
+int ipx_banded_solve_resid_atv_launch(void *handle, const double *w, double *x, double *partial,
+                                      int *npartial, const int32_t *At_rowptr,
+                                      const int32_t *At_colidx, const double *At_val,
+                                      const double *r_in, double *g_out, const int32_t *vown,
+                                      int qv, double *part3, const double *guard,
+                                      hipStream_t st);
 int ipx_banded_solve_resid_launch(void *handle, const double *w, double *x, double *partial,
                                   int *npartial, const double *guard, hipStream_t st);
 // partial[0..*npartial) <- per-workgroup sums of ||w - (A A') v||^2 (<= 256 of them)

@@ -38,7 +38,8 @@ class CgArgs(ctypes.Structure):
         ("lb", _P), ("ub", _P), ("state", _P),
         ("part1", _P), ("part2", _P), ("part3", _P), ("part4", _P),
         ("vec_grid", _I64), ("solver_kind", _I64), ("pb", _P), ("H_hmax", _I64), ("H_tile_rows", _I64),
-        ("r_next", _P), ("A_own", _P), ("A_span", _I64), ("fold_ws", _P))]
+        ("r_next", _P), ("A_own", _P), ("A_span", _I64), ("fold_ws", _P),
+        ("At_vown", _P), ("At_qv", _I64))]
 
 
 # Counters over the life of the process (diagnostics: how often the device loop
@@ -119,6 +120,45 @@ def fuse_own(pattern):
     return out
 
 
+def fuse_vown(At_pattern, rows_per_wg, nwg):
+    """Variables owned by each workgroup of the single-launch decoupled solve, for the
+    fused g = r - A'v tail (csrc/banded.hip AtvJob): ``(table, qv)`` or None.  A variable
+    belongs to the workgroup whose constraint rows contain the first constraint that
+    touches it.  Qualifies when every variable sees at most two constraints and they are
+    adjacent (tridiagonal A A'), the owners are non-decreasing along the variables, and no
+    workgroup gets more than 4096 of them.  Symbolic; cached per geometry."""
+    key = ("_ipx_fuse_vown", int(rows_per_wg), int(nwg))
+    cache = getattr(At_pattern, "_ipx_fuse_vown", None)
+    if cache is not None and cache[0] == key:
+        return cache[1]
+    out = None
+    n = At_pattern.shape[0]
+    ip, idx = At_pattern.indptr_h.astype(np.int64), At_pattern.indices_h.astype(np.int64)
+    lens = np.diff(ip)
+    if At_pattern.nnz > 0 and lens.max() <= 2:
+        nonempty = lens > 0
+        first = np.full(n, -1, dtype=np.int64)
+        first[nonempty] = idx[ip[:-1][nonempty]]
+        last = first.copy()
+        last[nonempty] = idx[ip[1:][nonempty] - 1]
+        if np.all(last - first <= 1):
+            # rows without entries go with the next variable that has some
+            filled = first.copy()
+            nxt = n
+            pos = np.where(nonempty, np.arange(n), n)
+            nxt_idx = np.minimum.accumulate(pos[::-1])[::-1]
+            filled = np.where(nxt_idx < n, first[np.minimum(nxt_idx, n - 1)], idx.max())
+            owner = filled // rows_per_wg
+            if np.all(np.diff(owner) >= 0) and owner.max() < nwg:
+                vown = np.searchsorted(owner, np.arange(nwg + 1), side="left")
+                vmax = int(np.max(np.diff(vown)))
+                qv = (vmax + 255) // 256
+                if 0 < qv <= 16:
+                    out = (torch.from_numpy(vown.astype(np.int32)).to(ctx().device), qv)
+    At_pattern._ipx_fuse_vown = (key, out)
+    return out
+
+
 def _solver_kind(solver):
     """0: banded handle, 1: box-Schur argument block, None: not usable here."""
     from .projector import BandedNormalSolver
@@ -169,7 +209,8 @@ class _Loop:
         grid = lib.ipx_cg_vec_grid(n)
         self.part1 = torch.zeros(2 * Hc.pattern.ntiles, dtype=f64, device=dev)
         self.part2 = torch.zeros(2 * max(grid, A.pattern.ntiles), dtype=f64, device=dev)
-        self.part3 = torch.zeros(2 * At.pattern.ntiles, dtype=f64, device=dev)
+        self.part3 = torch.zeros(2 * max(At.pattern.ntiles, (m + 255) // 256 + 1), dtype=f64,
+                                 device=dev)
         self.part4 = torch.zeros((m + 255) // 256 + 1, dtype=f64, device=dev)   # ||w-(AA')v||^2 partials
         self.keep = (A, At, Hc, Hd, lb, ub, P)
         a = CgArgs()
@@ -209,6 +250,18 @@ class _Loop:
             self.r_next = torch.empty(n, dtype=f64, device=dev)
             self.own = own[0]
             a.r_next, a.A_own, a.A_span = _ptr(self.r_next), _ptr(self.own), own[1]
+        # tridiagonal A A' on the single-launch solve: g = r - A'v rides in that launch
+        if a.solver_kind == 0 and not os.environ.get("IPX_NO_FUSE"):
+            geo = (ctypes.c_int32 * 2)()
+            # (the tail holds ~185 registers: two workgroups per CU.  It pays while the
+            # whole grid is resident at once -- up to 512 workgroups, m ~ 1.3e5; beyond
+            # that the separate SpMV streams better: measured 161 vs 170 us at n = 4e6)
+            if lib.ipx_banded_decoupled_geometry(ctypes.c_void_p(P.solver.handle), geo) \
+                    and geo[1] <= 512:
+                vown = fuse_vown(At.pattern, geo[0], geo[1])
+                if vown is not None:
+                    self.vown = vown[0]
+                    a.At_vown, a.At_qv = _ptr(self.vown), vown[1]
         self.args = a
 
     def ref(self):
