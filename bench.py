@@ -221,9 +221,10 @@ def main():
     ms = (ctypes.c_float * 7)()
     kt = min(K, 100)
     _hip.check(lib.ipx_cg_iterate_timed(L.ref(), W + K, W + K + kt, ms, st), "timed-events")
-    fused1, fused2 = bool(L.args.A_span), bool(L.args.H_hmax)
+    fused1, fused2, fused3 = bool(L.args.A_span), bool(L.args.H_hmax), bool(L.args.At_qv)
     names = [None if fused1 else "step1", "step1_spmv_A_r" if fused1 else "spmv_A_r",
-             "banded_solve_with_residual", "spmv_r_minus_Atv", None,
+             "banded_solve_residual_r_minus_Atv" if fused3 else "banded_solve_with_residual",
+             None if fused3 else "spmv_r_minus_Atv", None,
              None if fused2 else "step2", "step2_spmv_H_p" if fused2 else "spmv_H_p"]
     per_kernel_us = {k: 1e3 * ms[i] / kt for i, k in enumerate(names) if k}
 
@@ -261,12 +262,14 @@ def main():
         algo["step2_spmv_H_p"] = algo.pop("spmv_H_p") + algo.pop("step2") - 8 * n
     if fused1:      # r_next is not read back by the SpMV
         algo["step1_spmv_A_r"] = algo.pop("spmv_A_r") + algo.pop("step1") - 8 * n
+    if fused3:      # v is not read back by the SpMV
+        algo["banded_solve_residual_r_minus_Atv"] = algo.pop("spmv_r_minus_Atv") - 8 * m
     dom = "step2_spmv_H_p" if fused2 else "spmv_H_p"
     dom_label = ("k_cg_step2_hp (step2 fused into the H.p SpMV, p'Hp epilogue)" if fused2
                  else "k_csr_spmv (H.p with p'Hp epilogue)")
     achieved = algo[dom] / (hp_us * 1e-6) / 1e9
     traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "r01f_pmc_traffic.json")
+    pmc_path = os.path.join(ROOT, "profiles", "r01g_pmc_traffic.json")
     if os.path.exists(pmc_path) and (n, m) == (1000000, 100000):
         with open(pmc_path) as f:
             traffic = json.load(f)["kernels"].get(dom, {}).get("hbm_bytes_per_launch")
@@ -293,7 +296,7 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, "
                                        "FETCH x2 gfx950 correction calibrated in-run), "
-                                       "profiles/r01f_pmc_traffic.json",
+                                       "profiles/r01g_pmc_traffic.json",
                      "algorithmic_bytes_per_launch": algo[dom],
                      "avg_launch_us": hp_us,
                      "avg_launch_us_in_loop_with_gap": per_kernel_us[dom],

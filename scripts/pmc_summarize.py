@@ -14,7 +14,8 @@ fetch_dir, write_dir, out = sys.argv[1:4]
 
 
 def per_kernel(d, counter):
-    f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
+    f = max(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True),
+            key=os.path.getmtime)                      # newest pass in that directory
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == counter:
@@ -27,8 +28,8 @@ fetch, write = per_kernel(fetch_dir, "FETCH_SIZE"), per_kernel(write_dir, "WRITE
 
 def find(acc, *keys):
     hits = [k for k in acc if all(s in k for s in keys)]
-    assert len(hits) == 1, (keys, hits)
-    return acc[hits[0]]
+    assert hits, keys
+    return acc[max(hits, key=lambda k: len(acc[k]))]   # several instantiations: the loop's
 
 
 nc = 8000000
