@@ -219,6 +219,8 @@ typedef struct ipx_cg_args {
    * ceil(most variables of one workgroup / 256) <= 16.  NULL / 0: separate SpMV. */
   const int32_t *At_vown;
   int64_t At_qv;
+  int64_t A_tile_nnz;    /* nonzeros per row tile of the table in A_tiles when step1 is fused
+                          * (1024 or 0 = IPX_SPMV_TILE_NNZ) */
 } ipx_cg_args;
 int ipx_cg_state_size(void);
 int ipx_cg_vec_grid(int64_t n);

@@ -416,7 +416,7 @@ k_cg_step2_hp(int n, double *st, int parity, int mode, const double *__restrict_
 // r, so outside the iteration nothing changes.  Same expressions in the same
 // order as k_cg_step1 + k_csr_spmv; the ||x + alpha p||^2 partials are per tile
 // instead of per vector chunk (same values up to the order of summation).
-template <int QS>
+template <int QS, int TN>
 __global__ void __launch_bounds__(IPX_BLOCK)
 k_cg_step1_ar(int n, double *st, int parity, const double *__restrict__ p1, int np1,
               const double *__restrict__ x, const double *__restrict__ p,
@@ -425,7 +425,7 @@ k_cg_step1_ar(int n, double *st, int parity, const double *__restrict__ p1, int 
               const int32_t *__restrict__ colidx, const double *__restrict__ val,
               const int32_t *__restrict__ tiles, int ntiles, const int32_t *__restrict__ own,
               double *__restrict__ w, double *__restrict__ part2) {
-  __shared__ double prod[FT_NNZ];
+  __shared__ double prod[TN];
   __shared__ double span[QS * IPX_BLOCK];
   __shared__ int rp[IPX_SPMV_TILE_ROWS + 1];
   __shared__ double lds[IPX_BLOCK / IPX_WAVE];
@@ -445,7 +445,7 @@ k_cg_step1_ar(int n, double *st, int parity, const double *__restrict__ p1, int 
   const int o0 = own[tile], o1 = own[tile + 1];          // own columns
   const int c_hi = own[ntiles + 1 + tile];               // one past the last column touched (>= o1)
   const int nspan = c_hi - o0;
-  constexpr int U = FT_NNZ / IPX_BLOCK;
+  constexpr int U = TN / IPX_BLOCK;
   int c[U];
   double v[U];
 #pragma unroll
@@ -683,13 +683,20 @@ static int launch_step1_ar(const ipx_cg_args *a, int it, const double *p1, int n
       a->Hp, a->A_rowptr, a->A_colidx, a->A_val, a->A_tiles, (int)a->A_ntiles, a->A_own,   \
       a->w, a->part2
   const int qs = (int)((a->A_span + IPX_BLOCK - 1) / IPX_BLOCK);
+  const bool half = a->A_tile_nnz == 1024;      // tiles of 1024 nonzeros (own table)
+#define GO(Q)                                                                              \
+  do {                                                                                     \
+    if (half) hipLaunchKernelGGL((k_cg_step1_ar<Q, 1024>), grid, block, 0, st, FUSED_ARGS); \
+    else hipLaunchKernelGGL((k_cg_step1_ar<Q, FT_NNZ>), grid, block, 0, st, FUSED_ARGS);    \
+  } while (0)
   switch (qs) {
-    case 1: case 2: hipLaunchKernelGGL(k_cg_step1_ar<2>, grid, block, 0, st, FUSED_ARGS); break;
-    case 3: case 4: hipLaunchKernelGGL(k_cg_step1_ar<4>, grid, block, 0, st, FUSED_ARGS); break;
-    case 5: case 6: hipLaunchKernelGGL(k_cg_step1_ar<6>, grid, block, 0, st, FUSED_ARGS); break;
-    case 7: case 8: hipLaunchKernelGGL(k_cg_step1_ar<8>, grid, block, 0, st, FUSED_ARGS); break;
+    case 1: case 2: GO(2); break;
+    case 3: case 4: GO(4); break;
+    case 5: case 6: GO(6); break;
+    case 7: case 8: GO(8); break;
     default: return IPX_EINVAL;
   }
+#undef GO
 #undef FUSED_ARGS
   IPX_CHECK_LAUNCH();
   return IPX_OK;

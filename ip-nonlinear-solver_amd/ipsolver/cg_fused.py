@@ -39,7 +39,7 @@ class CgArgs(ctypes.Structure):
         ("part1", _P), ("part2", _P), ("part3", _P), ("part4", _P),
         ("vec_grid", _I64), ("solver_kind", _I64), ("pb", _P), ("H_hmax", _I64), ("H_tile_rows", _I64),
         ("r_next", _P), ("A_own", _P), ("A_span", _I64), ("fold_ws", _P),
-        ("At_vown", _P), ("At_qv", _I64))]
+        ("At_vown", _P), ("At_qv", _I64), ("A_tile_nnz", _I64))]
 
 
 # Counters over the life of the process (diagnostics: how often the device loop
@@ -90,22 +90,30 @@ def fuse_halo(pattern):
     return hmax
 
 
-def fuse_own(pattern):
+def fuse_own(pattern, tile_nnz=None):
     """Column ownership for the fused step1 + A.r kernel (csrc/cg.hip k_cg_step1_ar):
-    ``(own, span)`` or None.  Qualifies when every row tile is on the SpMV's fast path
-    and non-empty and the tiles sweep the columns monotonically (first column touched
-    non-decreasing from tile to tile: every banded Jacobian); tile t then owns the
-    columns from its first touched column up to the next tile's.  Symbolic; cached."""
-    cached = getattr(pattern, "_ipx_fuse_own", False)
+    ``(own, span, tiles, ntiles)`` or None.  Qualifies when every row tile is on the
+    SpMV's fast path and non-empty and the tiles sweep the columns monotonically (first
+    column touched non-decreasing from tile to tile: every banded Jacobian); tile t then
+    owns the columns from its first touched column up to the next tile's.  ``tile_nnz``
+    = 1024 cuts its own, finer row tiles for this kernel (twice the workgroups, half the
+    registers); None uses the pattern's SpMV tiles.  Symbolic; cached."""
+    attr = "_ipx_fuse_own_%s" % (tile_nnz or "std")
+    cached = getattr(pattern, attr, False)
     if cached is not False:
         return cached
     out = None
-    nt, n = pattern.ntiles, pattern.shape[1]
+    n = pattern.shape[1]
+    if tile_nnz:
+        t = dv._tiles_for(pattern.indptr_h, tile_nnz, 1024)
+        nt = len(t) // 2 - 1
+    else:
+        t, nt = pattern.tiles_h, pattern.ntiles
     if nt > 0 and pattern.nnz > 0:
-        t = pattern.tiles_h
         r0, r1 = t[:nt].astype(np.int64), t[1:nt + 1].astype(np.int64)
         s, e = t[nt + 1:2 * nt + 1].astype(np.int64), t[nt + 2:2 * nt + 2].astype(np.int64)
-        if np.all(e > s) and np.all(e - s <= _hip.SPMV_TILE_NNZ) and np.all(r1 - r0 <= 1024):
+        if np.all(e > s) and np.all(e - s <= (tile_nnz or _hip.SPMV_TILE_NNZ)) \
+                and np.all(r1 - r0 <= 1024):
             idx = pattern.indices_h
             cmin = np.minimum.reduceat(idx, s).astype(np.int64)
             cmax = np.maximum.reduceat(idx, s).astype(np.int64)
@@ -115,8 +123,11 @@ def fuse_own(pattern):
                 span = int(np.max(c_hi - own[:-1]))
                 if span <= 2048:
                     table = np.concatenate((own, c_hi, [n])).astype(np.int32)
-                    out = (torch.from_numpy(table).to(ctx().device), span)
-    pattern._ipx_fuse_own = out
+                    dev = ctx().device
+                    tiles = torch.from_numpy(np.ascontiguousarray(t)).to(dev) if tile_nnz \
+                        else pattern.tiles
+                    out = (torch.from_numpy(table).to(dev), span, tiles, nt)
+    setattr(pattern, attr, out)
     return out
 
 
@@ -244,12 +255,17 @@ class _Loop:
             th = Hc.pattern.tiles_h
             a.H_tile_rows = int(np.max(np.diff(th[:Hc.pattern.ntiles + 1])))
         # banded Jacobian, no box: step1 rides inside the A.r SpMV
+        tn = int(os.environ.get("IPX_FUSE_TN", "0")) or None
         own = None if (os.environ.get("IPX_NO_FUSE") or lb is not None or m == 0) \
-            else fuse_own(A.pattern)
+            else fuse_own(A.pattern, tn)
         if own is not None:
             self.r_next = torch.empty(n, dtype=f64, device=dev)
-            self.own = own[0]
+            self.own, self.own_tiles = own[0], own[2]
             a.r_next, a.A_own, a.A_span = _ptr(self.r_next), _ptr(self.own), own[1]
+            a.A_tiles, a.A_ntiles, a.A_tile_nnz = _ptr(self.own_tiles), own[3], tn or 0
+            if self.part2.numel() < 2 * own[3]:
+                self.part2 = torch.zeros(2 * own[3], dtype=f64, device=dev)
+                a.part2 = _ptr(self.part2)
         # tridiagonal A A' on the single-launch solve: g = r - A'v rides in that launch
         if a.solver_kind == 0 and not os.environ.get("IPX_NO_FUSE"):
             geo = (ctypes.c_int32 * 2)()
