@@ -150,6 +150,7 @@ class _DeviceConstraint:
 
     def __init__(self, user, x0):
         n = len(x0)
+        self.constant_jac = isinstance(user, (BoxConstraint, LinearConstraint))
         if isinstance(user, BoxConstraint):
             J = _identity_csr(n)
             self.fun = lambda x: x
@@ -261,6 +262,9 @@ class DeviceCanonical:
         self.c_ineq0, self.c_eq0 = self._stack_values(vals)
         self.J_ineq0, self.J_eq0 = self._stack_jacs([p.rows.jac(p.J0) for p in self.parts])
         self.hess = self._hess if any(p.hess is not None for p in self.parts) else None
+        # linear / box constraints only: jac(x) is the same pair of matrices for every x
+        # (canonical.CanonicalConstraint.constant_jac)
+        self.constant_jac = all(p.constant_jac for p in self.parts)
 
     def _stack_values(self, pairs):
         ineq = [a for a, _ in pairs if len(a)]
@@ -278,6 +282,8 @@ class DeviceCanonical:
         return self._stack_values([p.rows.values(p.fun(x)) for p in self.parts])
 
     def jac(self, x):
+        if self.constant_jac:
+            return self.J_ineq0, self.J_eq0
         return self._stack_jacs([p.rows.jac(p.jac(x)) for p in self.parts])
 
     def _hess(self, x, v_eq, v_ineq):

@@ -153,6 +153,8 @@ def _minimize_device(fun, x0, grad, hess, constraints, method, xtol, gtol, optio
         if canon.n_ineq > 0:
             raise ValueError("'equality_constrained_sqp' does not support "
                              "inequality constraints.")
+        if canon.constant_jac:
+            xp.mark_constant(canon.J_eq0)      # one factorization for the whole run (N1)
         result = equality_constrained_sqp(
             lambda x: (float(fun(x.t)), canon.constr(x)[1]),
             lambda x: (dm.as_dvec(grad(x.t)), canon.jac(x)[1]),

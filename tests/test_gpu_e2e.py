@@ -169,3 +169,42 @@ def test_device_callbacks_box_inequality(e2e_golden):
     gx = np.asarray(unjson(gold["x"]))
     assert np.allclose(res.x.cpu().numpy()[::max(1, 400 // 50)], gx, atol=1e-5)
     assert res.s.shape[0] == 840 and res.s.is_cuda
+
+
+def test_device_callbacks_linear_constraint_factors_once(monkeypatch):
+    """Equality-constrained QP with a LinearConstraint in device-callback mode: the
+    Jacobian is constant, so the projections are built once for the whole run
+     and the result matches host-callback mode."""
+    import torch
+    from banded_setup import BandedInstance
+    import ipsolver.projector as projector
+    from ipsolver.device import DeviceCSR, DVec
+    n, m = 4000, 400
+    inst = BandedInstance(n, m)
+    b = inst.A.dot(np.random.default_rng(1).standard_normal(n))
+    Hd = DeviceCSR.from_scipy(inst.H)
+    cd = torch.from_numpy(inst.c).cuda()
+    calls = {"n": 0}
+    real = projector.BandedNormalSolver.__init__
+
+    def counting(self, *a, **k):
+        calls["n"] += 1
+        return real(self, *a, **k)
+    monkeypatch.setattr(projector.BandedNormalSolver, "__init__", counting)
+    lin = ipsolver.LinearConstraint(inst.A, ("equals", b))
+    dev = ipsolver.minimize_constrained(
+        lambda x: float(0.5 * x.dot(Hd.dot(DVec(x)).t) + cd.dot(x)), torch.zeros(n, dtype=torch.float64, device="cuda"),
+        lambda x: Hd.dot(DVec(x)).t + cd, lambda x: Hd, lin, method="equality_constrained_sqp")
+    dev_factorizations = calls["n"]
+    hst = ipsolver.minimize_constrained(
+        lambda x: 0.5 * x.dot(inst.H.dot(x)) + inst.c.dot(x), np.zeros(n),
+        lambda x: inst.H.dot(x) + inst.c, lambda x: inst.H,
+        ipsolver.LinearConstraint(inst.A, ("equals", b)), method="equality_constrained_sqp")
+    # (a convex QP: both runs reach the same point; which of gtol / xtol fires first at the
+    # merit function's rounding floor depends on the last bits of the callbacks' sums)
+    assert hst.status == 1 and dev.status in (1, 2)
+    assert dev.optimality < 1e-6 and dev.constr_violation < 1e-8
+    assert abs(dev.fun - hst.fun) <= 1e-10 * abs(hst.fun)
+    assert dev_factorizations == 1 and calls["n"] == 2          # one per run
+    assert np.max(np.abs(dev.x.cpu().numpy() - hst.x)) <= 1e-6 * np.max(np.abs(hst.x))
+    assert np.max(np.abs(inst.A.dot(hst.x) - b)) <= 1e-8 * np.max(np.abs(b))
