@@ -1015,13 +1015,17 @@ k_solve_decoupled(LevDev lv, const double *__restrict__ w, double *__restrict__ 
   g_w0.load(T * q, f_w0);       g_V.load(NV * K, f_V);       g_W.load(NV * K, f_W);
   g_r.load((NCH - 1) * K, f_r);
   // A'v tail: row pointers of this workgroup's variables travel with the staging loads
+  // (waves 1..3 only: wave 0 owns the chunk recurrences and must not queue behind
+  // the tail's load issue; ATV_T lanes share the workgroup's variables)
+  constexpr int ATV_T = DOWN_T - IPX_WAVE;
+  const int ta = (int)threadIdx.x - IPX_WAVE;
   int av0 = 0, avn = 0, ra[QA], rb[QA];
-  if (QV > 0) {
+  if (QV > 0 && ta >= 0) {
     av0 = atv.vown[blockIdx.x];
     avn = atv.vown[blockIdx.x + 1] - av0;
 #pragma unroll
     for (int k = 0; k < QA; ++k) {
-      const int j = av0 + min((int)threadIdx.x + k * DOWN_T, max(avn - 1, 0));
+      const int j = av0 + min(ta + k * ATV_T, max(avn - 1, 0));
       ra[k] = atv.rowptr[j];
       rb[k] = atv.rowptr[j + 1];
     }
@@ -1039,10 +1043,10 @@ k_solve_decoupled(LevDev lv, const double *__restrict__ w, double *__restrict__ 
   // arrive while the chunk recurrences run
   int ac0[QA], ac1[QA];
   double aw0[QA], aw1[QA], ar[QA];
-  if (QV > 0) {
+  if (QV > 0 && ta >= 0) {
 #pragma unroll
     for (int k = 0; k < QA; ++k) {
-      const int j = av0 + min((int)threadIdx.x + k * DOWN_T, max(avn - 1, 0));
+      const int j = av0 + min(ta + k * ATV_T, max(avn - 1, 0));
       // (clamped: an empty row re-reads a neighbouring entry, never out of bounds)
       const int e0 = max(min(ra[k], rb[k] - 1), 0), e1 = max(rb[k] - 1, e0);
       ac0[k] = atv.colidx[e0];
@@ -1106,8 +1110,8 @@ k_solve_decoupled(LevDev lv, const double *__restrict__ w, double *__restrict__ 
     double gacc = 0.0;
 #pragma unroll
     for (int k = 0; k < QA; ++k) {
-      const int jl = (int)threadIdx.x + k * DOWN_T;
-      if (jl < avn) {
+      const int jl = ta + k * ATV_T;
+      if (ta >= 0 && jl < avn) {
         const int len = rb[k] - ra[k];
         double sum = 0.0;
         if (len > 0) sum += aw0[k] * sx[ac0[k] - rfirst];

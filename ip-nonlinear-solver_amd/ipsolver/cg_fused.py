@@ -163,7 +163,7 @@ def fuse_vown(At_pattern, rows_per_wg, nwg):
             if np.all(np.diff(owner) >= 0) and owner.max() < nwg:
                 vown = np.searchsorted(owner, np.arange(nwg + 1), side="left")
                 vmax = int(np.max(np.diff(vown)))
-                qv = (vmax + 255) // 256
+                qv = (vmax + 191) // 192          # 192 lanes per workgroup work on the tail
                 if 0 < qv <= 16:
                     out = (torch.from_numpy(vown.astype(np.int32)).to(ctx().device), qv)
     At_pattern._ipx_fuse_vown = (key, out)

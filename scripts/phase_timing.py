@@ -50,10 +50,12 @@ _hip.call("ipx_axpby", n, -1.0, dv._p(g0.t), 0.0, None, dv._p(L.p), st)
 init = np.zeros(L.state.numel()); init[0] = rt_g; init[3] = np.inf; init[9] = P.orth_tol * P.norm_A
 L.state.copy_(torch.from_numpy(init))
 lib.ipx_cg_hp(L.ref(), st)
-acc_s, acc_c = np.zeros(7), np.zeros(3)
+acc_s, acc_c, acc_b = np.zeros(7), np.zeros(3), np.zeros(7)
 for rep in range(40):
     lib.ipx_cg_iterate(L.ref(), 2 * rep, 2 * rep + 2, st)
     torch.cuda.synchronize()
+    out = (ctypes.c_ulonglong * 16)(); lib.ipx_debug_stamps(out)
+    acc_b += np.diff(np.array(list(out)[:8], dtype=np.float64))
     out = (ctypes.c_ulonglong * 16)(); lib.ipx_debug_stamps_spmv(out)
     acc_s += np.diff(np.array(list(out)[:8], dtype=np.float64))
     out = (ctypes.c_ulonglong * 16)(); lib.ipx_debug_stamps_cg(out)
@@ -66,3 +68,7 @@ print("step2, workgroup 0:")
 for k, nm in enumerate(["operand + partial + state loads", "fold", "update + stores"]):
     print("  %-40s %6.2f us" % (nm, acc_c[k] / 40 * 0.01))
 print("  total %.2f us" % (acc_c.sum() / 40 * 0.01))
+print("banded solve in the loop (with the g = r - A'v tail when fused), workgroup 0:")
+for k in range(7):
+    print("  %-22s %6.2f us" % (names[k + 1], acc_b[k] / 40 * 0.01))
+print("  total %.2f us" % (acc_b.sum() / 40 * 0.01))
