@@ -245,6 +245,7 @@ k_cg_step2_hp(int n, double *st, int parity, int mode, const double *__restrict_
   __shared__ double span[QS * IPX_BLOCK];
   __shared__ int rp[Q * IPX_BLOCK + 1];
   __shared__ double lds[4 * (IPX_BLOCK / IPX_WAVE)];
+  CG_STAMP(0);
   const int tile = ipx_xcd_item(blockIdx.x, ntiles);
   if (tile < 0) return;
   const int tid = threadIdx.x;
@@ -295,6 +296,7 @@ k_cg_step2_hp(int n, double *st, int parity, int mode, const double *__restrict_
     sp[k] = *src;
   }
   if (stop != 0.0) return;
+  CG_STAMP(1);
   const bool lead = tile == 0 && tid == 0;
   double red[4], loc[4];
   foldA.local(partsA, countsA, loc);               // loc = {xn2, viol, tt}
@@ -324,6 +326,7 @@ k_cg_step2_hp(int n, double *st, int parity, int mode, const double *__restrict_
       return;
     }
   }
+  CG_STAMP(2);
   const double beta = gg / rtg;                      // :627
   if (lead) {
     st[parity ? ST_RTG0 : ST_RTG1] = gg;             // :633
@@ -358,7 +361,9 @@ k_cg_step2_hp(int n, double *st, int parity, int mode, const double *__restrict_
   int rpv[Q + 1];
 #pragma unroll
   for (int q = 0; q <= Q; ++q) rpv[q] = rowptr[r0 + min(tid + q * IPX_BLOCK, nrows)] - s;
+  CG_STAMP(3);
   ipx_lds_barrier();
+  CG_STAMP(4);
   // SpMV phase 1: products with the gathers served from the span
 #pragma unroll
   for (int u = 0; u < U; ++u) {
@@ -371,6 +376,7 @@ k_cg_step2_hp(int n, double *st, int parity, int mode, const double *__restrict_
     if (i <= nrows) rp[i] = rpv[q];
   }
   ipx_lds_barrier();
+  CG_STAMP(5);
   // phase 2: row sums, diagonal term, partials of y'y and p'y
   double acc_yy = 0.0, acc_xy = 0.0, yq[Q];
 #pragma unroll
@@ -389,6 +395,7 @@ k_cg_step2_hp(int n, double *st, int parity, int mode, const double *__restrict_
       acc_xy += xr * y;
     }
   }
+  CG_STAMP(6);
   const double a2 = ipx_block_reduce<IPX_SUM>(acc_yy, lds);
   const double b2 = ipx_block_reduce<IPX_SUM>(acc_xy, lds);
   if (tid == 0) { partial[tile] = a2; partial[ntiles + tile] = b2; }
@@ -402,6 +409,7 @@ k_cg_step2_hp(int n, double *st, int parity, int mode, const double *__restrict_
     const int col = c_lo + tid + k * IPX_BLOCK;
     if (col >= r0 && col < r1) x[col] = sx[k] + alpha * sp[k];   // :580,630
   }
+  CG_STAMP(7);
 }
 
 // ---- step1 fused into the A.r SpMV (banded Jacobians, no box) ----------------
@@ -429,6 +437,7 @@ k_cg_step1_ar(int n, double *st, int parity, const double *__restrict__ p1, int 
   __shared__ double span[QS * IPX_BLOCK];
   __shared__ int rp[IPX_SPMV_TILE_ROWS + 1];
   __shared__ double lds[IPX_BLOCK / IPX_WAVE];
+  CG_STAMP(8);
   const int tile = ipx_xcd_item(blockIdx.x, ntiles);
   if (tile < 0) return;
   const int tid = threadIdx.x;
@@ -464,6 +473,7 @@ k_cg_step1_ar(int n, double *st, int parity, const double *__restrict__ p1, int 
     spv[k] = p[col];
   }
   if (stop != 0.0) return;
+  CG_STAMP(9);
   const bool lead = tile == 0 && tid == 0;
   double fout[1];
   fold.finish(fparts, fcounts, lds, fout);
@@ -476,6 +486,7 @@ k_cg_step1_ar(int n, double *st, int parity, const double *__restrict__ p1, int 
     if (lead) { st[ST_NITER] += 1.0; st[ST_PTHP] = ptHp; st[ST_STOP] = 3.0; }
     return;
   }
+  CG_STAMP(10);
   const double alpha = rtg / ptHp;                   // :579
   if (lead) { st[ST_NITER] += 1.0; st[ST_PTHP] = ptHp; st[ST_ALPHA] = alpha; }
   double sx = 0.0;
@@ -496,7 +507,9 @@ k_cg_step1_ar(int n, double *st, int parity, const double *__restrict__ p1, int 
 #pragma unroll
   for (int q = 0; q <= IPX_SPMV_TILE_ROWS / IPX_BLOCK; ++q)
     rpv[q] = rowptr[r0 + min(tid + q * IPX_BLOCK, nrows)] - s;
+  CG_STAMP(11);
   ipx_lds_barrier();
+  CG_STAMP(12);
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int jj = s + tid + u * IPX_BLOCK;
@@ -520,6 +533,7 @@ k_cg_step1_ar(int n, double *st, int parity, const double *__restrict__ p1, int 
       yq[q] = 1.0 * sum;
     }
   }
+  CG_STAMP(13);
   const double tot = ipx_block_reduce<IPX_SUM>(sx, lds);
   if (tid == 0) { part2[tile] = tot; part2[ntiles + tile] = 0.0; }
 #pragma unroll
@@ -527,6 +541,7 @@ k_cg_step1_ar(int n, double *st, int parity, const double *__restrict__ p1, int 
     const int i = tid + q * IPX_BLOCK;
     if (i < nrows) w[r0 + i] = yq[q];
   }
+  CG_STAMP(14);
 }
 
 // Large problems: the per-tile partial arrays grow with n while every consumer

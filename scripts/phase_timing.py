@@ -59,7 +59,9 @@ for rep in range(40):
     out = (ctypes.c_ulonglong * 16)(); lib.ipx_debug_stamps_spmv(out)
     acc_s += np.diff(np.array(list(out)[:8], dtype=np.float64))
     out = (ctypes.c_ulonglong * 16)(); lib.ipx_debug_stamps_cg(out)
-    acc_c += np.diff(np.array(list(out)[:4], dtype=np.float64))
+    tt = np.array(list(out), dtype=np.float64)
+    acc_c2 = globals().setdefault("acc_c2", np.zeros(7)); acc_c2 += np.diff(tt[:8])
+    acc_c1 = globals().setdefault("acc_c1", np.zeros(6)); acc_c1 += np.diff(tt[8:15])
 print("H.p SpMV, workgroup 0:")
 for k, nm in enumerate(["tile info + guard", "batch-1 loads landed (colidx,val,...)", "gathers issued", "gathers landed + LDS stores", "barrier", "row sums + y stores", "reduce + partial"]):
     print("  %-40s %6.2f us" % (nm, acc_s[k] / 40 * 0.01))
@@ -72,3 +74,11 @@ print("banded solve in the loop (with the g = r - A'v tail when fused), workgrou
 for k in range(7):
     print("  %-22s %6.2f us" % (names[k + 1], acc_b[k] / 40 * 0.01))
 print("  total %.2f us" % (acc_b.sum() / 40 * 0.01))
+print("fused step2 + H.p (k_cg_step2_hp), workgroup 0:")
+for k, nm in enumerate(["loads issued, state landed", "fold", "p_next span + x/p stores issued", "barrier", "products", "rows", "reduce + stores"]):
+    print("  %-40s %6.2f us" % (nm, acc_c2[k] / 40 * 0.01))
+print("  total %.2f us" % (acc_c2.sum() / 40 * 0.01))
+print("fused step1 + A.r (k_cg_step1_ar), workgroup 0:")
+for k, nm in enumerate(["loads issued, state landed", "fold", "r_next span + stores issued", "barrier", "products + rows", "reduce + stores"]):
+    print("  %-40s %6.2f us" % (nm, acc_c1[k] / 40 * 0.01))
+print("  total %.2f us" % (acc_c1.sum() / 40 * 0.01))
