@@ -231,7 +231,7 @@ k_cg_halo_pack(int64_t n, int h, int rank, int world, const double *__restrict__
 // (halo <= 64 and <= the shortest tile: checked by the host binding, cg_fused.fuse_halo)
 constexpr int FT_NNZ = IPX_SPMV_TILE_NNZ;
 
-template <bool HAS_DIAG, int Q, int QS>
+template <bool HAS_DIAG, int Q, int QS, bool BOX>
 __global__ void __launch_bounds__(IPX_BLOCK)
 k_cg_step2_hp(int n, double *st, int parity, int mode, const double *__restrict__ p2, int np2,
               const double *__restrict__ p3, int np3, const double *__restrict__ p4, int np4,
@@ -253,18 +253,25 @@ k_cg_step2_hp(int n, double *st, int parity, int mode, const double *__restrict_
   // runs while the operands stream in), then the tile's data
   // (register budget: the partial arrays get as many in-flight loads as their usual
   // lengths need -- step1's <= 512, the SpMV's ~n/1024, the solve's ~m/260 -- not 4 each)
-  const double *const partsA[3] = {p2, p2 + np2, p4};
-  const int countsA[3] = {(mode & 1) ? 0 : np2, (mode & 1) ? 0 : np2, (mode & 2) ? 0 : np4};
+  // BOX = false (no bounds): the violation counts are all zero and are not read; the
+  // ||x + alpha p||^2 partials -- one per row tile of A when step1 is fused -- get the
+  // freed register instead
+  const double *const partsA[2] = {BOX ? p2 + np2 : p2, p4};
+  const int countsA[2] = {(mode & 1) ? 0 : np2, (mode & 2) ? 0 : np4};
   const double *const partsB[1] = {p3};
   const int countsB[1] = {np3};
+  const double *const partsC[1] = {BOX ? p2 : p2 + np2};     // BOX: xn2;  else unused (count 0)
+  const int countsC[1] = {(BOX && !(mode & 1)) ? np2 : 0};
   const double stop = st[ST_STOP];
   const double radius = st[ST_RADIUS], orth_rhs = st[ST_ORTH_RHS];
   const double rtg = st[parity ? ST_RTG1 : ST_RTG0];
   const double alpha = st[ST_ALPHA];
-  ipx_fold_regs<3, 2> foldA;
-  ipx_fold_regs<1, 4> foldB;
+  ipx_fold_regs<2, BOX ? 2 : 3> foldA;         // BOX: {viol, tt}      else {xn2, tt}
+  ipx_fold_regs<1, 4> foldB;                   // gg
+  ipx_fold_regs<1, BOX ? 2 : 1> foldC;         // BOX: xn2
   foldA.load(partsA, countsA);
   foldB.load(partsB, countsB);
+  if (BOX) foldC.load(partsC, countsC);
   const int r0 = tiles[tile], r1 = tiles[tile + 1];
   const int s = tiles[ntiles + 1 + tile], e = tiles[ntiles + 2 + tile];
   const int nrows = r1 - r0;
@@ -299,12 +306,15 @@ k_cg_step2_hp(int n, double *st, int parity, int mode, const double *__restrict_
   CG_STAMP(1);
   const bool lead = tile == 0 && tid == 0;
   double red[4], loc[4];
-  foldA.local(partsA, countsA, loc);               // loc = {xn2, viol, tt}
-  foldB.local(partsB, countsB, loc + 3);           // loc[3] = gg
   {
-    const double tt_local = loc[2];
-    loc[2] = loc[3];                               // -> {xn2, viol, gg, tt}, k_cg_step2's order
-    loc[3] = tt_local;
+    double la[2], lb1[1], lc[1] = {0.0};
+    foldA.local(partsA, countsA, la);
+    foldB.local(partsB, countsB, lb1);
+    if (BOX) foldC.local(partsC, countsC, lc);
+    loc[0] = BOX ? lc[0] : la[0];                  // xn2      (k_cg_step2's order:
+    loc[1] = BOX ? la[0] : 0.0;                    // viol      xn2, viol, gg, tt)
+    loc[2] = lb1[0];                               // gg
+    loc[3] = la[1];                                // tt
   }
   ipx_block_sum_multi<4>(loc, lds, red);
   if (!(mode & 1)) {
@@ -734,13 +744,18 @@ static int launch_step2_hp(const ipx_cg_args *a, int it, int mode, const double 
   // binding): short tiles (3 nonzeros per row -> 683 rows) take the 3-elements-per-lane
   // instantiation, which needs fewer registers
   const bool small = a->H_tile_rows > 0 && a->H_tile_rows + 2 * a->H_hmax <= 3 * IPX_BLOCK;
+  const bool box = a->lb != nullptr;
+#define GO(D, QQ, QSS)                                                                       \
+  do {                                                                                       \
+    if (box) hipLaunchKernelGGL((k_cg_step2_hp<D, QQ, QSS, true>), grid, block, 0, st, FUSED_ARGS); \
+    else hipLaunchKernelGGL((k_cg_step2_hp<D, QQ, QSS, false>), grid, block, 0, st, FUSED_ARGS);    \
+  } while (0)
   if (a->H_diag) {
-    if (small) hipLaunchKernelGGL((k_cg_step2_hp<true, 3, 3>), grid, block, 0, st, FUSED_ARGS);
-    else hipLaunchKernelGGL((k_cg_step2_hp<true, 4, 5>), grid, block, 0, st, FUSED_ARGS);
+    if (small) GO(true, 3, 3); else GO(true, 4, 5);
   } else {
-    if (small) hipLaunchKernelGGL((k_cg_step2_hp<false, 3, 3>), grid, block, 0, st, FUSED_ARGS);
-    else hipLaunchKernelGGL((k_cg_step2_hp<false, 4, 5>), grid, block, 0, st, FUSED_ARGS);
+    if (small) GO(false, 3, 3); else GO(false, 4, 5);
   }
+#undef GO
 #undef FUSED_ARGS
   IPX_CHECK_LAUNCH();
   return IPX_OK;
