@@ -149,9 +149,9 @@ def fuse_vown(At_pattern, rows_per_wg, nwg):
     if At_pattern.nnz > 0 and lens.max() <= 2:
         nonempty = lens > 0
         first = np.full(n, -1, dtype=np.int64)
-        first[nonempty] = idx[ip[:-1][nonempty]]
         last = first.copy()
-        last[nonempty] = idx[ip[1:][nonempty] - 1]
+        e0, e1 = idx[ip[:-1][nonempty]], idx[ip[1:][nonempty] - 1]     # rows of 1 or 2 entries,
+        first[nonempty], last[nonempty] = np.minimum(e0, e1), np.maximum(e0, e1)   # any order
         if np.all(last - first <= 1):
             # rows without entries go with the next variable that has some
             filled = first.copy()
