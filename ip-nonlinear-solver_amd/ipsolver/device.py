@@ -292,6 +292,27 @@ class DeviceCSR:
         p = self.pattern
         return sps.csr_matrix((self.val.cpu().numpy(), p.indices_h, p.indptr_h), shape=p.shape)
 
+    def with_sorted_indices(self):
+        """This matrix with the column indices of every row in increasing order (the
+        normal-equation assembly merges sorted rows).  Matrices built by ``from_scipy`` are
+        sorted already; a hand-made pattern is checked once and, if need be, re-ordered
+        through a cached permutation of the values."""
+        pat = self.pattern
+        info = getattr(pat, "_ipx_sorted", None)
+        if info is None:
+            rows = np.repeat(np.arange(pat.shape[0], dtype=np.int64), np.diff(pat.indptr_h))
+            key = rows * max(pat.shape[1], 1) + pat.indices_h.astype(np.int64)
+            if np.all(np.diff(key) >= 0):
+                info = (None, None)
+            else:
+                order = np.argsort(key, kind="stable")
+                spat = CSRPattern(pat.indptr_h, pat.indices_h[order], pat.shape)
+                info = (spat, torch.from_numpy(order).to(ctx().device))
+            pat._ipx_sorted = info
+        if info[0] is None:
+            return self
+        return DeviceCSR(info[0], self.val[info[1]])
+
     @property
     def T(self):
         if self._T is None:

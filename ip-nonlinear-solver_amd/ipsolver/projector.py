@@ -234,7 +234,9 @@ def as_device_matrix(A):
     reference does (projections.py:368-369)."""
     import scipy.sparse as sps
     from .dense import DeviceDense
-    if isinstance(A, (DeviceCSR, DeviceDense)):
+    if isinstance(A, DeviceCSR):
+        return A.with_sorted_indices()
+    if isinstance(A, DeviceDense):
         return A
     m, n = np.shape(A)
     if sps.issparse(A) or m * n == 0:

@@ -448,3 +448,25 @@ def test_fused_kernels_on_other_band_shapes(ips, n, m, hbw, abw, seed, monkeypat
     xo, io = oracle.projected_cg(Hm, c, Zo, Yo, np.zeros(m), tol=1e-14, max_iter=60)
     assert io["niter"] == i1["niter"]
     assert np.max(np.abs(x1 - xo)) <= 1e-9 * np.max(np.abs(xo))
+
+
+def test_projections_accept_unsorted_device_csr(ips):
+    """A DeviceCSR assembled by hand (device-callback mode) may list a row's columns in any
+    order; the projections must not depend on it."""
+    import torch
+    from ipsolver.device import CSRPattern, DeviceCSR
+    inst = BandedInstance(2000, 200)
+    A = inst.A.tocsr()
+    rng = np.random.default_rng(0)
+    indices, data = A.indices.copy(), A.data.copy()
+    for i in range(A.shape[0]):                      # shuffle every row
+        a, b = A.indptr[i], A.indptr[i + 1]
+        perm = rng.permutation(b - a)
+        indices[a:b], data[a:b] = indices[a:b][perm], data[a:b][perm]
+    Au = DeviceCSR(CSRPattern(A.indptr, indices, A.shape), torch.from_numpy(data).cuda())
+    Zs, LSs, Ys = ips.proj.projections(ips.dv.DeviceCSR.from_scipy(A))
+    Zu, LSu, Yu = ips.proj.projections(Au)
+    x, b = rng.standard_normal(2000), rng.standard_normal(200)
+    close(Zu.dot(x), host(Zs.dot(x)), 1e-12)
+    close(LSu.dot(x), host(LSs.dot(x)), 1e-12)
+    close(Yu.dot(b), host(Ys.dot(b)), 1e-12)
