@@ -469,14 +469,15 @@ k_cg_step1_ar(int n, double *st, int parity, const double *__restrict__ p1, int 
   double v[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
-    const int jj = min(s + tid + u * IPX_BLOCK, max(e - 1, s));
+    const int jj = min(s + tid + u * IPX_BLOCK, max(e - 1, 0));   // empty tile: any valid entry
     c[u] = colidx[jj];
     v[u] = val[jj];
   }
   double sr[QS], sh[QS], sxv[QS], spv[QS];
 #pragma unroll
   for (int k = 0; k < QS; ++k) {
-    const int col = o0 + min(tid + k * IPX_BLOCK, nspan - 1);
+    // (a tile without nonzeros owns nothing: nspan = 0, the clamps keep its loads in range)
+    const int col = min(o0 + max(min(tid + k * IPX_BLOCK, nspan - 1), 0), n - 1);
     sr[k] = r[col];
     sh[k] = Hp[col];
     sxv[k] = x[col];
@@ -829,6 +830,8 @@ int ipx_cg_shard_segment(const ipx_cg_args *a, ipx_shard_ext *e, int32_t phase, 
   const int grid = (int)a->vec_grid;
   int rc = IPX_OK;
   if (phase == 0) {
+    if (fused_ar(a))                               // step1 inside the partial A.r SpMV
+      return launch_step1_ar(a, it, e->s1, 1, st);
     rc = ipx_cg_step1(a->n, a->state, it, e->s1, 1, a->x, a->p, a->r, a->Hp, nullptr, nullptr,
                       a->part2, grid, stream);
     if (rc) return rc;
@@ -837,15 +840,24 @@ int ipx_cg_shard_segment(const ipx_cg_args *a, ipx_shard_ext *e, int32_t phase, 
     return ipx_spmv_launch(A, a->r, 1.0, nullptr, 0.0, nullptr, a->w, nullptr, guard, st);
   }
   if (phase == 1) {
-    int np4 = 0;
-    rc = ipx_banded_solve_resid_launch(a->banded, a->w, a->v, a->part4, &np4, guard, st);
-    if (rc) return rc;
+    int np4 = 0, np3 = (int)a->At_ntiles;
+    const double *r_in = fused_ar(a) ? a->r_next : a->r;
+    if (a->At_vown && a->At_qv > 0) {              // g = r - A'v as the tail of the solve
+      rc = ipx_banded_solve_resid_atv_launch(a->banded, a->w, a->v, a->part4, &np4, a->At_rowptr,
+                                             a->At_colidx, a->At_val, r_in, a->r, a->At_vown,
+                                             (int)a->At_qv, a->part3, guard, st);
+      if (rc) return rc;
+      np3 = np4;
+    } else {
+      rc = ipx_banded_solve_resid_launch(a->banded, a->w, a->v, a->part4, &np4, guard, st);
+      if (rc) return rc;
+      ipx_csr_view At{(int)a->n, (int)a->m, a->At_rowptr, a->At_colidx, a->At_val, a->At_tiles,
+                      (int)a->At_ntiles};
+      rc = ipx_spmv_launch(At, a->v, -1.0, nullptr, 1.0, r_in, a->r, a->part3, guard, st);
+      if (rc) return rc;
+    }
     e->np4 = np4;
-    ipx_csr_view At{(int)a->n, (int)a->m, a->At_rowptr, a->At_colidx, a->At_val, a->At_tiles,
-                    (int)a->At_ntiles};
-    rc = ipx_spmv_launch(At, a->v, -1.0, nullptr, 1.0, a->r, a->r, a->part3, guard, st);
-    if (rc) return rc;
-    return ipx_cg_shard_pack(a->part2, grid, a->part3, (int)a->At_ntiles, a->n, (int)e->h,
+    return ipx_cg_shard_pack(a->part2, part2_count(a), a->part3, np3, a->n, (int)e->h,
                              (int)e->rank, (int)e->world, a->r, e->pack, stream);
   }
   const int h = (int)e->h, rank = (int)e->rank;

@@ -112,14 +112,22 @@ def fuse_own(pattern, tile_nnz=None):
     if nt > 0 and pattern.nnz > 0:
         r0, r1 = t[:nt].astype(np.int64), t[1:nt + 1].astype(np.int64)
         s, e = t[nt + 1:2 * nt + 1].astype(np.int64), t[nt + 2:2 * nt + 2].astype(np.int64)
-        if np.all(e > s) and np.all(e - s <= (tile_nnz or _hip.SPMV_TILE_NNZ)) \
-                and np.all(r1 - r0 <= 1024):
+        if np.all(e - s <= (tile_nnz or _hip.SPMV_TILE_NNZ)) and np.all(r1 - r0 <= 1024):
+            # tiles without nonzeros (rows of a column block that belong to other ranks'
+            # constraints) own no columns
+            full = np.flatnonzero(e > s)
             idx = pattern.indices_h
-            cmin = np.minimum.reduceat(idx, s).astype(np.int64)
-            cmax = np.maximum.reduceat(idx, s).astype(np.int64)
-            if np.all(np.diff(cmin) >= 0):
-                own = np.concatenate(([0], cmin[1:], [n]))
-                c_hi = np.maximum(cmax + 1, own[1:])
+            cmin_f = np.minimum.reduceat(idx, s[full]).astype(np.int64)
+            cmax_f = np.maximum.reduceat(idx, s[full]).astype(np.int64)
+            if np.all(np.diff(cmin_f) >= 0):
+                # first own column per tile: a full tile starts at its first touched column
+                # (the first full tile at 0), an empty tile where the next full one does
+                start = np.full(nt + 1, n, dtype=np.int64)
+                start[full] = cmin_f
+                start[full[0]] = 0
+                own = np.minimum.accumulate(start[::-1])[::-1]
+                c_hi = own[1:].copy()
+                c_hi[full] = np.maximum(cmax_f + 1, own[1:][full])
                 span = int(np.max(c_hi - own[:-1]))
                 if span <= 2048:
                     table = np.concatenate((own, c_hi, [n])).astype(np.int32)

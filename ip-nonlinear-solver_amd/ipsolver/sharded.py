@@ -95,10 +95,10 @@ class ShardedProjectedCG:
         self.state = eng.zeros(STATE_SIZE)
         self.s1, self.s4 = eng.zeros(2), eng.zeros(2)
         self.part1 = eng.zeros(2 * eng.ntiles(self.H_rows))
-        self.part3 = eng.zeros(2 * eng.ntiles(self.At_rows))
+        self.part3 = eng.zeros(2 * max(eng.ntiles(self.At_rows), (self.m + 255) // 256 + 1))
         self.part4 = eng.zeros((self.m + 255) // 256 + 1)
         self.grid = eng.vec_grid(self.nloc)
-        self.part2 = eng.zeros(2 * self.grid)
+        self.part2 = eng.zeros(2 * max(self.grid, eng.ntiles(self.A_cols)))
         # packed all-reduce buffer: 4 scalars + [world][2h] boundary entries
         self.pack = eng.zeros(4 + 2 * self.h * self.world)
         h, r = self.h, self.rank
@@ -317,6 +317,23 @@ class HipEngine(SegmentsByKernel):
         a.part1, a.part2, a.part3, a.part4 = (t.data_ptr() for t in (cg.part1, cg.part2,
                                                                        cg.part3, cg.part4))
         a.vec_grid, a.solver_kind = cg.grid, 0
+        # the single-GPU loop's fusions, rank-local (csrc/cg.hip): step1 inside the partial
+        # A.r SpMV, g = r - A'v as the tail of the replicated banded solve
+        import os
+        from . import cg_fused
+        if not os.environ.get("IPX_NO_FUSE"):
+            own = cg_fused.fuse_own(cg.A_cols.pattern)
+            if own is not None and own[3] <= cg.part2.numel() // 2:
+                cg.r_next = self.zeros(cg.nloc)
+                cg.own = own[0]
+                a.r_next, a.A_own, a.A_span = cg.r_next.data_ptr(), cg.own.data_ptr(), own[1]
+            geo = (ctypes.c_int32 * 2)()
+            if self.lib.ipx_banded_decoupled_geometry(ctypes.c_void_p(cg.solver.handle), geo) \
+                    and geo[1] <= 512 and geo[1] <= cg.part3.numel() // 2:
+                vown = cg_fused.fuse_vown(cg.At_rows.pattern, geo[0], geo[1])
+                if vown is not None:
+                    cg.vown = vown[0]
+                    a.At_vown, a.At_qv = cg.vown.data_ptr(), vown[1]
         e = ShardExt()
         e.p_ext = cg.p_ext.data_ptr()
         e.hl, e.hr, e.h, e.rank, e.world = cg.hl, cg.hr, cg.h, cg.rank, cg.world

@@ -298,8 +298,12 @@ def _two_rank_worker(rank, world, port, out_path):
         hdiag = np.abs(np.random.default_rng(3).standard_normal(20000))
         cg = ShardedProjectedCG(HipEngine(), inst.A, inst.H, hdiag)
         x, info = cg.solve(inst.c, tol=0.0, max_iter=30)
+        args = cg._c_args[0]
+        fused = torch.tensor([float(args.A_span > 0), float(args.At_qv > 0)])
+        dist.all_reduce(fused, op=dist.ReduceOp.MIN)          # engaged on every rank?
         if rank == 0:
-            np.savez(out_path, x=x, info=np.array([info["niter"], info["stop_cond"]]))
+            np.savez(out_path, x=x, info=np.array([info["niter"], info["stop_cond"]]),
+                     fused=fused.numpy())
     finally:
         dist.destroy_process_group()
 
@@ -328,6 +332,9 @@ def test_sharded_hip_engine_multi_rank(world, tmp_path):
                                    tol=0, max_iter=30)
     assert list(got["info"]) == [info["niter"], info["stop_cond"]]
     assert np.max(np.abs(got["x"] - xo)) <= 1e-10 * np.max(np.abs(xo))
+    # the rank-local fusions (step1 in the partial A.r SpMV over a column block with empty
+    # row tiles; g = r - A'v in the replicated solve) were the path taken on every rank
+    assert list(got["fused"]) == [1.0, 1.0]
 
 
 @pytest.mark.parametrize("n,m", [(400, 40), (6000, 600)])
