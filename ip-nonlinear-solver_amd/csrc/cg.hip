@@ -120,10 +120,18 @@ k_cg_step1(int64_t n, double *st, int parity, const double *__restrict__ p1, int
 
 // mode bit0: skip the radius / box checks (host already handled them)
 //      bit1: skip the orthogonality check (host already refined)
+// Halo copies of the neighbouring ranks' boundary entries of p (row-sharded loop): advanced
+// by the same launch with the same expression (see k_cg_halo_apply).
+struct HaloJob {
+  int hl, hr;
+  const double *gl, *gr;
+  double *pl, *pr;
+};
+
 __global__ void __launch_bounds__(VB)
 k_cg_step2(int64_t n, double *st, int parity, int mode, const double *__restrict__ p2, int np2,
            const double *__restrict__ p3, int np3, const double *__restrict__ p4, int np4,
-           double *x, double *p, const double *__restrict__ g, int nchunks) {
+           double *x, double *p, const double *__restrict__ g, int nchunks, HaloJob halo) {
   __shared__ double lds[4 * (VB / IPX_WAVE)];
   CG_STAMP(0);
   const int c = ipx_xcd_item(blockIdx.x, nchunks);   // same element -> XCD map as step1
@@ -180,6 +188,10 @@ k_cg_step2(int64_t n, double *st, int parity, int mode, const double *__restrict
     st[parity ? ST_RTG0 : ST_RTG1] = gg;             // :633
     st[ST_BETA] = beta;
     st[ST_IT_DONE] += 1.0;
+  }
+  if (c == 0) {                                      // halo copies: p = beta p - g as below
+    for (int t = threadIdx.x; t < halo.hl; t += VB) halo.pl[t] = beta * halo.pl[t] - halo.gl[t];
+    for (int t = threadIdx.x; t < halo.hr; t += VB) halo.pr[t] = beta * halo.pr[t] - halo.gr[t];
   }
   while (true) {
 #pragma unroll
@@ -781,7 +793,7 @@ int ipx_cg_step2(int64_t n, double *state, int32_t it, int32_t mode, const doubl
                  double *x, double *p, const double *g, int32_t grid, void *stream) {
   if (n < 0 || !state || grid < 1) return IPX_EINVAL;
   hipLaunchKernelGGL(k_cg_step2, dim3(ipx_xcd_grid(grid)), dim3(VB), 0, (hipStream_t)stream, n,
-                     state, it & 1, mode, p2, np2, p3, np3, p4, np4, x, p, g, grid);
+                     state, it & 1, mode, p2, np2, p3, np3, p4, np4, x, p, g, grid, HaloJob{});
   IPX_CHECK_LAUNCH();
   return IPX_OK;
 }
@@ -861,14 +873,14 @@ int ipx_cg_shard_segment(const ipx_cg_args *a, ipx_shard_ext *e, int32_t phase, 
                              (int)e->rank, (int)e->world, a->r, e->pack, stream);
   }
   const int h = (int)e->h, rank = (int)e->rank;
-  rc = ipx_cg_step2(a->n, a->state, it, 0, e->pack, 1, e->pack + 2, 1, a->part4, (int)e->np4,
-                    a->x, a->p, a->r, grid, stream);
-  if (rc) return rc;
-  rc = ipx_cg_halo_apply(a->state, (int)e->hl, (int)e->hr,
-                         e->hl ? e->pack + 4 + (2 * (rank - 1) + 1) * h : nullptr,
-                         e->hr ? e->pack + 4 + 2 * (rank + 1) * h : nullptr,
-                         e->p_ext, e->p_ext + e->hl + a->n, stream);
-  if (rc) return rc;
+  const HaloJob halo{(int)e->hl, (int)e->hr,
+                     e->hl ? e->pack + 4 + (2 * (rank - 1) + 1) * h : nullptr,
+                     e->hr ? e->pack + 4 + 2 * (rank + 1) * h : nullptr,
+                     e->p_ext, e->p_ext + e->hl + a->n};
+  hipLaunchKernelGGL(k_cg_step2, dim3(ipx_xcd_grid(grid)), dim3(VB), 0, st, a->n, a->state,
+                     it & 1, 0, e->pack, 1, e->pack + 2, 1, a->part4, (int)e->np4, a->x, a->p,
+                     a->r, grid, halo);
+  IPX_CHECK_LAUNCH();
   ipx_csr_view H{(int)a->n, (int)(e->hl + a->n + e->hr), a->H_rowptr, a->H_colidx, a->H_val,
                  a->H_tiles, (int)a->H_ntiles};
   rc = ipx_spmv_launch(H, e->p_ext, 1.0, a->H_diag, 0.0, nullptr, a->Hp, a->part1, guard, st,
@@ -901,7 +913,7 @@ int ipx_cg_resume(const ipx_cg_args *a, int32_t it, int32_t mode, void *stream) 
   hipLaunchKernelGGL(k_cg_step2, dim3(ipx_xcd_grid((int)a->vec_grid)), dim3(VB), 0, st, a->n,
                      a->state, it & 1, mode, a->part2, part2_count(a), a->part3,
                      part3_count(a), a->part4, part4_count(a), a->x, a->p, a->r,
-                     (int)a->vec_grid);
+                     (int)a->vec_grid, HaloJob{});
   IPX_CHECK_LAUNCH();
   return launch_hp(a, guard, st);
 }
@@ -1070,7 +1082,7 @@ static int cg_iterate(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, hi
     } else {
       hipLaunchKernelGGL(k_cg_step2, dim3(ipx_xcd_grid((int)a->vec_grid)), dim3(VB), 0, st, a->n,
                          a->state, it & 1, a->m > 0 ? 0 : 2, p2, np2, p3, np3, p4, n4, a->x, a->p,
-                         a->r, (int)a->vec_grid);
+                         a->r, (int)a->vec_grid, HaloJob{});
       IPX_CHECK_LAUNCH();
       MARK(6);
       rc = launch_hp(a, guard, st);
