@@ -119,7 +119,7 @@ def main():
     ap.add_argument("--n", type=int, default=1000000)
     ap.add_argument("--m", type=int, default=100000)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--cpu-iters", type=int, default=30)
+    ap.add_argument("--cpu-iters", type=int, default=400)
     args = ap.parse_args()
 
     import numpy as np
@@ -339,15 +339,17 @@ def main():
     # ---- CPU baseline: the oracle (numpy/scipy restatement), rank 0, N=1 only
     if rank == 0 and world == 1 and not args.no_cpu:
         import oracle
-        os.environ.setdefault("OMP_NUM_THREADS", "1")
-        t0 = time.time()
-        Zo, _, Yo = oracle.projections(A_h)            # AugmentedSystem (SuperLU), as the reference
-        t_fac = time.time() - t0
-        H_full = H_h + __import__("scipy.sparse", fromlist=["diags"]).diags(hdiag_h)
-        kc = args.cpu_iters
-        t0 = time.time()
-        xo, info = oracle.projected_cg(H_full, c_h, Zo, Yo, np.zeros(m), tol=0, max_iter=kc)
-        t_cg = time.time() - t0
+        from threadpoolctl import threadpool_limits
+        torch.set_num_threads(1)
+        with threadpool_limits(limits=1):               # "cores": 1 below is what actually ran
+            t0 = time.time()
+            Zo, _, Yo = oracle.projections(A_h)        # AugmentedSystem (SuperLU), as the reference
+            t_fac = time.time() - t0
+            H_full = H_h + __import__("scipy.sparse", fromlist=["diags"]).diags(hdiag_h)
+            kc = args.cpu_iters
+            t0 = time.time()
+            xo, info = oracle.projected_cg(H_full, c_h, Zo, Yo, np.zeros(m), tol=0, max_iter=kc)
+            t_cg = time.time() - t0
         result["cpu_baseline"] = {
             "value": info["niter"] / t_cg, "unit": "iterations/s", "cores": 1, "kind": "port",
             "sample": "%d projected-CG iterations of the same n=%d, m=%d instance through "
