@@ -11,18 +11,26 @@
 // later kernel of the stream into a no-op; the host reads the state block
 // only once per batch of iterations.
 //
-// One iteration = 2 streaming vector kernels + 4 SpMVs + the banded solve:
+// One iteration, step by step (general sparsity: one launch each):
 //
 //   step1  alpha = rt_g / p'Hp;  r += alpha*Hp;  partials of ||x+alpha p||^2,
 //          # of box violations of x + alpha p            (x itself untouched)
 //   spmv   w = A r
-//   banded v = (AA')^-1 w
+//   banded v = (AA')^-1 w, with ||A g||^2 = ||w - (AA')v||^2 partials from the same
+//          launch(es)                                    (orthogonality, projections.py:52)
 //   spmv   r = r - A'v  (= g_next; the reference sets r = g, :632), ||g||^2 partials
-//   resid  ||A g||^2 = ||w - (AA')v||^2 partials          (orthogonality, projections.py:52)
 //   step2  checks: ||x_next|| >= radius -> stop 2; box violated -> stop 5 (host
 //          finishes the iteration); orthogonality > tol -> stop 6 (host refines);
 //          else beta = ||g||^2/rt_g;  x += alpha p;  p = beta p - g
 //   spmv   Hp = H p (+ diag*p), p'Hp partials
+//
+// For banded problems the steps pair up into THREE launches (same arithmetic):
+//   k_cg_step1_ar      step1 inside the A.r SpMV        (banded A, no box)
+//   k_solve_decoupled  the banded solve with g = r - A'v as its tail (banded.hip;
+//                      tridiagonal A A', separator system numerically diagonal)
+//   k_cg_step2_hp      step2 inside the H.p SpMV        (banded H)
+// each falling back to the separate launches when its structural condition fails
+// (checked symbolically by ipsolver/cg_fused.py).
 //
 // Because x is only advanced in step2, every early exit leaves (x, p, alpha)
 // exactly as the reference's exit paths (:565-576, :585-596) need them.
