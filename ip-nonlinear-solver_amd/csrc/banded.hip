@@ -431,7 +431,11 @@ k_aat_band(int m, int k, const int32_t *__restrict__ rowptr, const int32_t *__re
 //   k_middle  ONE workgroup holds every remaining level in LDS and walks down
 //             and back up with __syncthreads() instead of kernel boundaries;
 //   k_correct the level-0 up sweep (elementwise, all CUs).
-// Same arithmetic in the same order as the multi-launch path: bitwise equal.
+// Same arithmetic as the multi-launch path (explicit FMA in the recurrences: equal
+// to ~1e-16).  When the separator system is numerically diagonal (k = 1, checked at
+// every factorization) the whole solve is ONE launch, k_solve_decoupled, further
+// down: no middle kernel, correction and residual out of LDS, optionally g = r - A'v
+// as its tail.
 constexpr int DOWN_T = 256;          // threads per workgroup in k_down0 (T <= 64 of them own a chunk)
 constexpr int MID_T = 512;
 constexpr int JB = 8;                // recurrence steps per register block
