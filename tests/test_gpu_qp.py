@@ -477,3 +477,31 @@ def test_projections_accept_unsorted_device_csr(ips):
     close(Zu.dot(x), host(Zs.dot(x)), 1e-12)
     close(LSu.dot(x), host(LSs.dot(x)), 1e-12)
     close(Yu.dot(b), host(Ys.dot(b)), 1e-12)
+
+
+@pytest.mark.parametrize("n,m", [(2, 1), (3, 1), (5, 2), (9, 3), (17, 4), (64, 8), (257, 30)])
+def test_device_loop_at_tiny_sizes(ips, n, m):
+    """The device-resident loop and its fused kernels at sizes of a few rows (one tile,
+    halo clipped at both ends, fewer chunks than a workgroup solves) against the oracle:
+    same iteration count, same exit, same point."""
+    import scipy.sparse as sps
+    import ipsolver.cg_fused as cg_fused
+    import oracle
+    rng = np.random.default_rng(n)
+    H = sps.diags([rng.uniform(-1, 1, n - 1), np.full(n, 3.0), rng.uniform(-1, 1, n - 1)],
+                  [-1, 0, 1], format="csr")
+    H = sps.csr_matrix(0.5 * (H + H.T))
+    stride = max(n // m, 1)
+    rows = np.repeat(np.arange(m), 2)
+    cols = np.minimum(np.concatenate([[i * stride, i * stride + 1] for i in range(m)]), n - 1)
+    A = sps.csr_matrix((rng.standard_normal(2 * m), (rows, cols)), shape=(m, n))
+    A.sum_duplicates()
+    c = rng.standard_normal(n)
+    Ad, Hd = ips.dv.DeviceCSR.from_scipy(A), ips.dv.DeviceCSR.from_scipy(H)
+    Z, LS, Y = ips.proj.projections(Ad)
+    assert cg_fused.supports(Hd, Z, Y)
+    x, info = ips.qp.projected_cg(Hd, c, Z, Y, np.zeros(m), tol=1e-14)
+    Zo, _, Yo = oracle.projections(A)
+    xo, io = oracle.projected_cg(H, c, Zo, Yo, np.zeros(m), tol=1e-14)
+    assert (info["niter"], info["stop_cond"]) == (io["niter"], io["stop_cond"])
+    close(x, xo, 1e-12)
