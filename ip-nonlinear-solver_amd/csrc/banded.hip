@@ -342,6 +342,67 @@ k_decoupling_check(int mR, const double *__restrict__ Rband, double *__restrict_
   if (!(fmax(fabs(lo), fabs(up)) <= tiny * fabs(d))) atomicOr(flag, 2);
 }
 
+// Block form for half bandwidth K > 1: the separator system is block tridiagonal with
+// K x K blocks.  One lane per separator t: inverse of its diagonal block (Gauss-Jordan on
+// the SPD block, K <= 8) into rinv[t][K][K], and the coupling block to separator t-1
+// tested entry by entry against 2^-56 sqrt(d_a d_b).  The diagonal blocks of a Schur
+// complement of an SPD matrix are SPD; a non-positive pivot raises the factor flag.
+template <int K>
+__global__ void __launch_bounds__(IPX_BLOCK)
+k_decoupling_check_block(int nsep, const double *__restrict__ Rband, double *__restrict__ rinv,
+                         int *flag) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nsep) return;
+  const int mR = nsep * K;
+  // R[(t,a)][(t,b)], a >= b: offset a - b, row t*K + a
+  double D[K][K], Inv[K][K];
+#pragma unroll
+  for (int a = 0; a < K; ++a) {
+#pragma unroll
+    for (int b = 0; b < K; ++b) {
+      const int hi = a > b ? a : b, lo = a > b ? b : a;
+      D[a][b] = Rband[(int64_t)(hi - lo) * mR + (int64_t)t * K + hi];
+      Inv[a][b] = a == b ? 1.0 : 0.0;
+    }
+  }
+  const double tiny = 1.3877787807814457e-17;                     // 2^-56
+  bool coupled = false, bad = false;
+  if (t > 0) {
+    // R[(t,a)][(t-1,b)]: offset K + a - b (1 .. 2K-1), row t*K + a
+#pragma unroll
+    for (int a = 0; a < K; ++a) {
+#pragma unroll
+      for (int b = 0; b < K; ++b) {
+        const double v = Rband[(int64_t)(K + a - b) * mR + (int64_t)t * K + a];
+        const double db = Rband[(int64_t)(t - 1) * K + b];
+        if (!(fabs(v) <= tiny * sqrt(fabs(D[a][a] * db)))) coupled = true;
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < K; ++c) {
+    const double piv = D[c][c];
+    if (!(piv > 0.0)) bad = true;
+    const double ip = 1.0 / piv;
+#pragma unroll
+    for (int b = 0; b < K; ++b) { D[c][b] *= ip; Inv[c][b] *= ip; }
+#pragma unroll
+    for (int a = 0; a < K; ++a) {
+      if (a != c) {
+        const double f = D[a][c];
+#pragma unroll
+        for (int b = 0; b < K; ++b) { D[a][b] -= f * D[c][b]; Inv[a][b] -= f * Inv[c][b]; }
+      }
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < K; ++a)
+#pragma unroll
+    for (int b = 0; b < K; ++b) rinv[((int64_t)t * K + a) * K + b] = Inv[a][b];
+  if (coupled) atomicOr(flag, 2);
+  if (bad) atomicOr(flag, 1);
+}
+
 template <int K>
 __device__ __forceinline__ double corrected_at(int i, int m, int c, int P, const double *V,
                                                const double *W, const SepValues &xs,
@@ -948,8 +1009,8 @@ k_solve_decoupled(LevDev lv, const double *__restrict__ w, double *__restrict__ 
   double *sgL = sB + (size_t)(K + 1) * NB;  // NCH*K
   double *sgR = sgL + (size_t)NCH * K + K;  // NCH*K, K entries of slack in front
   double *sxs = sgR + (size_t)NCH * K;      // NCH*K     separator values
-  double *srinv = sxs + (size_t)NCH * K;    // NCH*K     1 / R_tt
-  double *sw0 = srinv + (size_t)NCH * K;    // T*q       w of the own rows (sw turns into y)
+  double *srinv = sxs + (size_t)NCH * K;    // NCH*K*K   inverse of the separators' diagonal blocks
+  double *sw0 = srinv + (size_t)NCH * K * K;   // T*q    w of the own rows (sw turns into y)
   const int NV = (T + 2) * q - (q - K);     // rows whose corrected value is needed
   double *sV = sw0 + (size_t)T * q;         // NV*K      spikes of those rows
   double *sW = sV + (size_t)NV * K;         // NV*K
@@ -997,8 +1058,8 @@ k_solve_decoupled(LevDev lv, const double *__restrict__ w, double *__restrict__ 
     return (gi >= 0 && gi < (int64_t)m * K) ? Wg[gi] : 0.0;
   };
   auto f_r = [=](int i) {
-    const int l = i / K, t = tfirst + l;
-    return (t >= 0 && t < P - 1) ? rinv[(int64_t)t * K + (i - l * K)] : 0.0;
+    const int l = i / (K * K), t = tfirst + l;
+    return (t >= 0 && t < P - 1) ? rinv[(int64_t)t * K * K + (i - l * K * K)] : 0.0;
   };
   // register budgets sized for the default 64-row chunks (q <= QD); larger
   // arrays spill into StageRegs::store's slow loop
@@ -1013,11 +1074,11 @@ k_solve_decoupled(LevDev lv, const double *__restrict__ w, double *__restrict__ 
   StageRegs<UT * K> g_L;
   StageRegs<UW * K> g_V, g_W;
   StageRegs<UO *(K + 1)> g_B;
-  StageRegs<US> g_E, g_F, g_r;
+  StageRegs<US> g_E, g_F, g_r;                 // K*K entries per chunk / separator each
   g_w.load(NCH * q, f_w);       g_D.load(qk * NCH, f_D);     g_L.load(qk * K * NCH, f_L);
   g_E.load(NCH * K * K, f_E);   g_F.load(NCH * K * K, f_F);  g_B.load((K + 1) * NB, f_B);
   g_w0.load(T * q, f_w0);       g_V.load(NV * K, f_V);       g_W.load(NV * K, f_W);
-  g_r.load((NCH - 1) * K, f_r);
+  g_r.load((NCH - 1) * K * K, f_r);
   // A'v tail: row pointers of this workgroup's variables travel with the staging loads
   // (waves 1..3 only: wave 0 owns the chunk recurrences and must not queue behind
   // the tail's load issue; ATV_T lanes share the workgroup's variables)
@@ -1040,7 +1101,7 @@ k_solve_decoupled(LevDev lv, const double *__restrict__ w, double *__restrict__ 
   g_L.store(sL, qk * K * NCH, f_L);  g_E.store(sE, NCH * K * K, f_E);
   g_F.store(sF, NCH * K * K, f_F);   g_B.store(sB, (K + 1) * NB, f_B);
   g_w0.store(sw0, T * q, f_w0);      g_V.store(sV, NV * K, f_V);
-  g_W.store(sW, NV * K, f_W);        g_r.store(srinv, (NCH - 1) * K, f_r);
+  g_W.store(sW, NV * K, f_W);        g_r.store(srinv, (NCH - 1) * K * K, f_r);
   __syncthreads();
   IPX_STAMP(2);
   // A'v tail: the (at most two) entries of every row and r, requested now so that they
@@ -1078,7 +1139,14 @@ k_solve_decoupled(LevDev lv, const double *__restrict__ w, double *__restrict__ 
   // ---- separator values  xs_t = (gL_t + gR_t) / R_tt   for t = t0-1 .. t0+T
   for (int i = threadIdx.x; i < (NCH - 1) * K; i += blockDim.x) {
     const int l = i / K, t = tfirst + l;
-    sxs[i] = (t >= 0 && t < P - 1) ? (sgL[i] + sgR[i]) * srinv[i] : 0.0;
+    double v = 0.0;
+    if (t >= 0 && t < P - 1) {
+      const int a = i - l * K;
+#pragma unroll
+      for (int b = 0; b < K; ++b)
+        v += srinv[(l * K + a) * K + b] * (sgL[l * K + b] + sgR[l * K + b]);
+    }
+    sxs[i] = v;
   }
   __syncthreads();
   IPX_STAMP(5);
@@ -1159,7 +1227,8 @@ size_t decoupled_lds_doubles(int q) {
   constexpr int T = DEC_CHUNKS, NCH = T + 3;
   const size_t qk = q + K;
   return (size_t)2 * NCH * q + qk * NCH * (K + 1) + (size_t)2 * NCH * K * K +
-         (size_t)(K + 1) * (T * q + K) + (size_t)4 * NCH * K + K + (size_t)T * q +
+         (size_t)(K + 1) * (T * q + K) + (size_t)3 * NCH * K + (size_t)NCH * K * K + K +
+         (size_t)T * q +
          (size_t)2 * K * ((T + 2) * q - (q - K));
 }
 
@@ -1190,11 +1259,14 @@ int launch_solve_decoupled(const LevDev &lv, const double *w, double *x, const d
   const AtvJob none{};
   if (!atv || qv <= 0)
     return launch_solve_decoupled_q<K, 0>(lv, w, x, rinv, partial, npartial, guard, none, st);
+  if constexpr (K != 1) return IPX_EINVAL;      // the A'v tail needs a tridiagonal A A'
+  else {
   if (qv <= 4) return launch_solve_decoupled_q<K, 4>(lv, w, x, rinv, partial, npartial, guard, *atv, st);
   if (qv <= 8) return launch_solve_decoupled_q<K, 8>(lv, w, x, rinv, partial, npartial, guard, *atv, st);
   if (qv <= 12) return launch_solve_decoupled_q<K, 12>(lv, w, x, rinv, partial, npartial, guard, *atv, st);
   if (qv <= 16) return launch_solve_decoupled_q<K, 16>(lv, w, x, rinv, partial, npartial, guard, *atv, st);
   return IPX_EINVAL;
+  }
 }
 
 template <int K>
@@ -1314,9 +1386,23 @@ int level_up(Banded *h, int li, double *x, const double *guard, hipStream_t st) 
   DISPATCH_K(h->lev[li].k, up(h, li, x, guard, st))
 }
 
-bool decoupling_candidate(const Banded *h) {
-  return h->fast && h->nlev >= 2 && h->lev[0].k == 1 && h->rinv;
+// LDS need of the single-launch decoupled solve for this handle's level 0
+size_t decoupled_lds_bytes(const Banded *h) {
+  const Level &l0 = h->lev[0];
+  switch (l0.k) {
+#define DL(kk) case kk: return decoupled_lds_doubles<kk>(l0.q) * sizeof(double)
+    DL(1); DL(2); DL(3); DL(4); DL(5); DL(6); DL(7); DL(8);
+#undef DL
+  }
+  return (size_t)-1;
 }
+
+bool decoupling_candidate(const Banded *h) {
+  return h->fast && h->nlev >= 2 && h->rinv && decoupled_lds_bytes(h) <= LDS_LIMIT;
+}
+
+// the separator values as (gL + gR) / R_tt inside the three-launch path: scalar blocks only
+bool decoupled_scalar(const Banded *h) { return h->decoupled && h->lev[0].k == 1; }
 
 int factor_upper(Banded *h, hipStream_t st) {
   for (int li = 1; li < h->nlev; ++li) {
@@ -1433,7 +1519,7 @@ void *ipx_banded_create(int64_t m64, int32_t k, int32_t chunk) {
       h->gL = dalloc<double>(h, l0.mR);
       h->gR = dalloc<double>(h, l0.mR);
       h->ybuf = dalloc<double>(h, l0.m);
-      h->rinv = dalloc<double>(h, l0.mR);
+      h->rinv = dalloc<double>(h, (size_t)l0.mR * l0.k);       // K x K per separator
       if (!h->gL || !h->gR || !h->ybuf || !h->rinv) ok = false;
       else if (hipMemset(h->gR, 0, (size_t)l0.mR * sizeof(double)) != hipSuccess) ok = false;
     }
@@ -1471,9 +1557,22 @@ int ipx_banded_factor(void *handle, const double *band, void *stream) {
   if (rc != IPX_OK) return rc;
   h->upper_done = false;
   if (decoupling_candidate(h)) {
-    const int mR = h->lev[0].mR;
-    hipLaunchKernelGGL(k_decoupling_check, dim3((mR + IPX_BLOCK - 1) / IPX_BLOCK), dim3(IPX_BLOCK),
-                       0, st, mR, h->lev[1].band, h->rinv, h->flag);
+    const int mR = h->lev[0].mR, K0 = h->lev[0].k, nsep = mR / K0;
+    const dim3 grid((nsep + IPX_BLOCK - 1) / IPX_BLOCK), block(IPX_BLOCK);
+    switch (K0) {
+      case 1:
+        hipLaunchKernelGGL(k_decoupling_check, grid, block, 0, st, mR, h->lev[1].band, h->rinv,
+                           h->flag);
+        break;
+#define DC(kk)                                                                              \
+  case kk:                                                                                  \
+    hipLaunchKernelGGL(k_decoupling_check_block<kk>, grid, block, 0, st, nsep, h->lev[1].band, \
+                       h->rinv, h->flag);                                                   \
+    break
+      DC(2); DC(3); DC(4); DC(5); DC(6); DC(7); DC(8);
+#undef DC
+      default: return IPX_EINVAL;
+    }
     IPX_CHECK_LAUNCH();
     return IPX_OK;
   }
@@ -1579,7 +1678,7 @@ int launch_correct_oop(Banded *h, double *x, const double *w, double *partial, i
   const Level &lv = h->lev[0];
   const int grid = (lv.m + IPX_BLOCK - 1) / IPX_BLOCK;
   if (npartial) *npartial = grid;
-  const SepValues xs = h->decoupled ? SepValues{nullptr, h->gL, h->gR, h->rinv}
+  const SepValues xs = decoupled_scalar(h) ? SepValues{nullptr, h->gL, h->gR, h->rinv}
                                     : SepValues{h->lev[1].sol, nullptr, nullptr, nullptr};
   if (partial)
     hipLaunchKernelGGL((k_correct_oop<K, true>), dim3(grid), dim3(IPX_BLOCK), 0, st, lv.m, lv.c,
@@ -1600,13 +1699,18 @@ int fast_solve(Banded *h, const double *w, double *x, double *partial, int *npar
     if (rc != IPX_OK || !partial) return rc;
     return ipx_banded_residual_launch(h, w, x, partial, npartial, guard, st);
   }
-  if (h->decoupled && w != x && h->lev[0].k == 1 &&
-      decoupled_lds_doubles<1>(h->lev[0].q) * sizeof(double) <= LDS_LIMIT)
-    return launch_solve_decoupled<1>(to_dev(h->lev[0], nullptr), w, x, h->rinv, partial, npartial,
-                                     guard, st);
+  if (h->decoupled && w != x) {
+    const LevDev lv = to_dev(h->lev[0], nullptr);
+    switch (lv.k) {
+#define SD(kk) case kk: return launch_solve_decoupled<kk>(lv, w, x, h->rinv, partial, npartial, guard, st)
+      SD(1); SD(2); SD(3); SD(4); SD(5); SD(6); SD(7); SD(8);
+#undef SD
+    }
+    return IPX_EINVAL;
+  }
   int rc = fast_down0(h, w, h->ybuf, guard, st);
   if (rc != IPX_OK) return rc;
-  if (!h->decoupled) {
+  if (!decoupled_scalar(h)) {
     if (!h->upper_done) {           // deferred by ipx_banded_factor (decoupled candidate)
       rc = factor_upper(h, st);
       if (rc != IPX_OK) return rc;
@@ -1629,8 +1733,7 @@ int ipx_banded_resid_count(void *handle) {
   if (!handle) return 0;
   Banded *h = (Banded *)handle;
   const Level &l0 = h->lev[0];
-  if (h->fast && h->nlev > 1 && h->decoupled && l0.k == 1 &&
-      decoupled_lds_doubles<1>(l0.q) * sizeof(double) <= LDS_LIMIT)
+  if (h->fast && h->nlev > 1 && h->decoupled)
     return (l0.P + DEC_CHUNKS - 1) / DEC_CHUNKS;
   if (h->fast && h->nlev > 1) return (l0.m + IPX_BLOCK - 1) / IPX_BLOCK;
   const int grid = (l0.m + IPX_BLOCK - 1) / IPX_BLOCK;           // k_band_residual
@@ -1643,8 +1746,7 @@ extern "C" int ipx_banded_decoupled_geometry(void *handle, int32_t *out) {
   if (!handle || !out) return 0;
   Banded *h = (Banded *)handle;
   const Level &l0 = h->lev[0];
-  if (!(h->fast && h->nlev > 1 && h->decoupled && l0.k == 1 &&
-        decoupled_lds_doubles<1>(l0.q) * sizeof(double) <= LDS_LIMIT))
+  if (!(h->fast && h->nlev > 1 && h->decoupled && l0.k == 1))
     return 0;
   out[0] = DEC_CHUNKS * l0.q;
   out[1] = (l0.P + DEC_CHUNKS - 1) / DEC_CHUNKS;

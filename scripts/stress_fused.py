@@ -47,5 +47,18 @@ for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 24):
             print("MISMATCH seed %d %s n=%d m=%d hbw=%d: %s vs %s, dx=%.2e" % (seed, name, n, m, hbw, i1, i2, np.max(np.abs(x1 - x2))))
     os.environ.pop("IPX_NO_FUSE", None)
     L = cf._Loop(H, Z.projector, None, None)
-    print(seed, "n=%d m=%d hbw=%d k=%d  fused: H %d A %d Atv %d" % (n, m, hbw, Z.projector.solver.k if hasattr(Z.projector.solver, "k") else -1, L.args.H_hmax, L.args.A_span, L.args.At_qv))
+    from ipsolver import _hip
+    import ctypes
+    dec = _hip.load().ipx_banded_decoupled(ctypes.c_void_p(Z.projector.solver.handle))
+    # the solver against a direct sparse solve of (A A') v = w
+    w = rng.standard_normal(m)
+    v = Z.projector.solver.solve(dv.DVec.from_host(w)).to_host()
+    S = (Am @ Am.T).tocsc()
+    import scipy.sparse.linalg as spla
+    vref = spla.spsolve(S, w)
+    serr = np.max(np.abs(v - vref)) / np.max(np.abs(vref))
+    if serr > 1e-9:
+        bad += 1
+        print("SOLVE MISMATCH seed %d: %.2e" % (seed, serr))
+    print(seed, "n=%d m=%d hbw=%d k=%d decoupled=%d solve_err=%.1e  fused: H %d A %d Atv %d" % (n, m, hbw, Z.projector.solver.k if hasattr(Z.projector.solver, "k") else -1, dec, serr, L.args.H_hmax, L.args.A_span, L.args.At_qv))
 print("mismatches:", bad)
