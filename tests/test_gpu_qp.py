@@ -334,7 +334,9 @@ def test_sharded_hip_engine_multi_rank(world, tmp_path):
     assert np.max(np.abs(got["x"] - xo)) <= 1e-10 * np.max(np.abs(xo))
     # the rank-local fusions (step1 in the partial A.r SpMV over a column block with empty
     # row tiles; g = r - A'v in the replicated solve) were the path taken on every rank
-    assert list(got["fused"]) == [1.0, 1.0]
+    import os
+    if not os.environ.get("IPX_NO_FUSE"):
+        assert list(got["fused"]) == [1.0, 1.0]
 
 
 @pytest.mark.parametrize("n,m", [(400, 40), (6000, 600)])
