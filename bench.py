@@ -311,7 +311,7 @@ def main():
                  else "k_csr_spmv (H.p with p'Hp epilogue)")
     achieved = algo[dom] / (hp_us * 1e-6) / 1e9
     traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "r01g_pmc_traffic.json")
+    pmc_path = os.path.join(ROOT, "profiles", "r01i_pmc_traffic.json")
     if os.path.exists(pmc_path) and (n, m) == (1000000, 100000):
         with open(pmc_path) as f:
             traffic = json.load(f)["kernels"].get(dom, {}).get("hbm_bytes_per_launch")
@@ -338,7 +338,7 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, "
                                        "FETCH x2 gfx950 correction calibrated in-run), "
-                                       "profiles/r01g_pmc_traffic.json",
+                                       "profiles/r01i_pmc_traffic.json",
                      "algorithmic_bytes_per_launch": algo[dom],
                      "avg_launch_us": hp_us,
                      "avg_launch_us_in_loop_with_gap": per_kernel_us[dom],
