@@ -208,3 +208,27 @@ def test_device_callbacks_linear_constraint_factors_once(monkeypatch):
     assert dev_factorizations == 1 and calls["n"] == 2          # one per run
     assert np.max(np.abs(dev.x.cpu().numpy() - hst.x)) <= 1e-6 * np.max(np.abs(hst.x))
     assert np.max(np.abs(inst.A.dot(hst.x) - b)) <= 1e-8 * np.max(np.abs(b))
+
+
+def test_config5_style_moderate_size():
+    """BASELINE config 5 at n = 2e4 (N = 62000 variables with slacks, M = 42000 rows): box on
+    every variable + nonlinear inequalities, tr_interior_point, callbacks on the device.  The
+    reference run of this instance (327 s on the survey host) ends with status 1 after 62
+    outer iterations with 5611 bounds active; its CG count (34885) is in the chaotic regime
+    and is only bracketed here."""
+    import torch
+    syn = load_synthetic()
+    from ipsolver.synthetic import DeviceCallbacks
+    prob = syn.CenteredBandedNLP(20000, 2000, eps=1.0)
+    dc = DeviceCallbacks(prob)
+    cons = (dc.constraints(ipsolver, ("less", 0.0)), ipsolver.BoxConstraint(("interval", -0.8, 0.8)))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res = ipsolver.minimize_constrained(dc.fun, dc.x0, dc.grad, dc.hess, cons)
+    x = res.x.cpu().numpy()
+    assert res.status == 1 and res.optimality < 1e-8 and res.constr_violation < 1e-8
+    assert abs(res.niter - 62) <= 3
+    assert 25000 < res.cg_niter < 45000
+    assert int(np.sum(np.abs(np.abs(x) - 0.8) < 1e-6)) == 5611
+    assert np.all(np.abs(x) <= 0.8 + 1e-12)
+    assert abs(res.fun - (-3036.756804356163)) <= 1e-6 * 3036.76
