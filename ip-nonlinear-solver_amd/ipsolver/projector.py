@@ -228,6 +228,63 @@ def _box_schur_applies(A, kmax):
     return _symbolic_for(cache.pattern).k <= kmax
 
 
+class IterativeNormalSolver:
+    """``(A A')^-1`` without a factorization, for sparse Jacobians whose ``A A'`` is neither
+    banded (after reordering) nor small enough for the dense device Cholesky: Jacobi-
+    preconditioned conjugate gradients on ``A (A' v) = w`` -- two SpMVs and a few vector
+    kernels per inner iteration, everything on the device.  The reference factors any
+    sparse A with SuperLU (projections.py:93-172); this keeps such problems solvable here
+    (at the speed of an iterative solve) instead of refusing them.  The inner solve runs to
+    the floor of fp64; the projector's orthogonality-driven refinement
+    (projections.py:72-78) sits on top of it as usual."""
+
+    perm = None
+    RTOL, MAXIT = 1e-15, 2000
+
+    def __init__(self, A):
+        self.A, self.At = A, A.T
+        self.m = A.shape[0]
+        sq = DVec(A.val) * DVec(A.val)
+        rowsq = DeviceCSR(A.pattern, sq.t).dot(DVec.full(A.shape[1], 1.0))
+        d = rowsq.to_host()
+        if not np.all(d > 0):
+            raise np.linalg.LinAlgError("Singular Jacobian matrix: a row of A is zero")
+        self.dinv = DVec.from_host(1.0 / d)
+
+    def solve(self, w):
+        v = DVec.zeros(self.m)
+        r = w.copy()
+        norm_w = dv.norm(w)
+        if norm_w == 0:
+            return v
+        z = self.dinv * r
+        p = z.copy()
+        rz = r.dot(z)
+        best = np.inf
+        stalled = 0
+        for _ in range(self.MAXIT):
+            Sp = self.A.dot(self.At.dot(p))
+            pSp = p.dot(Sp)
+            if not pSp > 0:
+                raise np.linalg.LinAlgError("Singular Jacobian matrix: A A' is not positive "
+                                            "definite")
+            alpha = rz / pSp
+            v = v.add_scaled(p, alpha)
+            r = r.add_scaled(Sp, -alpha)
+            nr = dv.norm(r)
+            if nr <= self.RTOL * norm_w:
+                break
+            stalled = stalled + 1 if nr >= best else 0      # fp64 floor reached
+            best = min(best, nr)
+            if stalled >= 5:
+                break
+            z = self.dinv * r
+            rz_next = r.dot(z)
+            p = z.add_scaled(p, rz_next / rz)
+            rz = rz_next
+        return v
+
+
 def as_device_matrix(A):
     """Upload a scipy sparse matrix / ndarray (device matrices pass through).
     An empty matrix is forced to the sparse representation like the
@@ -284,12 +341,8 @@ def projections(A, method=None, orth_tol=1e-12, max_refin=3, tol=1e-15):
         elif m <= DenseNormalSolver.MAX_ROWS_FROM_SPARSE:
             solver = DenseNormalSolver(A)       # wide band: dense Cholesky of A A' on the device
         else:
-            raise NotImplementedError(
-                "A A' has half bandwidth %d after reordering and %d rows: beyond both the "
-                "banded (<= %d) and the dense (<= %d rows) device factorizations; there is "
-                "no host fallback" % (_symbolic_for(A.pattern).k, m,
-                                      _hip.load().ipx_banded_kmax(),
-                                      DenseNormalSolver.MAX_ROWS_FROM_SPARSE))
+            # general sparsity beyond both device factorizations: matrix-free solve
+            solver = IterativeNormalSolver(A)
     else:
         solver = DenseNormalSolver(A)
     return NormalEquationProjector(A, solver, orth_tol, max_refin).operators()

@@ -545,3 +545,39 @@ def test_single_launch_banded_solve_with_block_separators(ips, k):
     _hip.call("ipx_banded_solve_multilaunch", ctypes.c_void_p(solver.handle), ips.dv._p(wd.t),
               ips.dv._p(v2.t), ips.dv.stream_ptr())
     assert np.max(np.abs(v - host(v2))) <= 1e-12 * np.max(np.abs(v))
+
+
+def test_general_sparse_jacobian_beyond_the_factorizations(ips, monkeypatch):
+    """A sparse Jacobian with scattered columns and more rows than the dense device Cholesky
+    takes: neither banded nor small.  The projections then run on the matrix-free solver
+    (Jacobi-preconditioned CG on A A', projector.IterativeNormalSolver) and must still be
+    the reference's operators (projections.py:290-406), here against the CPU oracle."""
+    import oracle
+    from ipsolver.dense import DenseNormalSolver
+    from ipsolver.projector import IterativeNormalSolver
+    # (the dense limit is lowered so that a size the CPU oracle factors in a second takes
+    # the same route as a 20000-row Jacobian would)
+    monkeypatch.setattr(DenseNormalSolver, "MAX_ROWS_FROM_SPARSE", 100)
+    rng = np.random.default_rng(0)
+    m, n = 3000, 9000
+    rows = np.repeat(np.arange(m), 4)
+    cols = rng.integers(0, n, 4 * m)
+    A = sps.csr_matrix((rng.standard_normal(4 * m), (rows, cols)), shape=(m, n))
+    A.sum_duplicates()
+    Z, LS, Y = ips.proj.projections(ips.dv.DeviceCSR.from_scipy(A))
+    assert isinstance(Z.projector.solver, IterativeNormalSolver)
+    Zo, LSo, Yo = oracle.projections(A)
+    x, b = rng.standard_normal(n), rng.standard_normal(m)
+    close(Z.dot(x), Zo.dot(x), 1e-9)
+    close(LS.dot(x), LSo.dot(x), 1e-9)
+    close(Y.dot(b), Yo.dot(b), 1e-9)
+    zx = Z.dot(x)
+    norm_A = float(np.sqrt((A.data ** 2).sum()))
+    assert ips.dv.norm(ips.dv.DeviceCSR.from_scipy(A).dot(zx)) <= 1e-12 * norm_A * ips.dv.norm(zx)
+    # and a projected-CG solve on top of it (general driver)
+    H = sps.diags(rng.uniform(1, 2, n), format="csr")
+    c = rng.standard_normal(n)
+    xg, info = ips.qp.projected_cg(ips.dv.DeviceCSR.from_scipy(H), c, Z, Y, np.zeros(m), max_iter=30)
+    xo, io = oracle.projected_cg(H, c, Zo, Yo, np.zeros(m), max_iter=30)
+    assert info["niter"] == io["niter"] and info["stop_cond"] == io["stop_cond"]
+    close(xg, xo, 1e-8)
