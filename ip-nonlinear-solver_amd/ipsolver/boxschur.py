@@ -21,7 +21,7 @@ import torch
 
 from . import _hip
 from . import device as dv
-from .device import DVec, DeviceCSR, _p, stream_ptr, ctx
+from .device import DVec, _p, stream_ptr, ctx
 
 _F64 = torch.float64
 

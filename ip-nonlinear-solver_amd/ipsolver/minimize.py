@@ -13,7 +13,6 @@ from copy import deepcopy
 from warnings import warn
 
 import numpy as np
-import scipy.sparse as sps
 from scipy.optimize import OptimizeResult
 
 from . import backend as _backend

@@ -1,8 +1,6 @@
 """Device operator types of the seam besides plain matrices."""
-import numpy as np
 
-from . import device as dv
-from .device import DVec, DeviceCSR
+from .device import DVec
 
 
 class DiagonalOperator:

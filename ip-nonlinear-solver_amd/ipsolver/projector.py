@@ -16,14 +16,13 @@ benchmark problems.
 All numeric work runs on the GPU; there is no host factorization fallback.
 """
 import ctypes
-import warnings
 
 import numpy as np
 import torch
 
 from . import _hip
 from . import device as dv
-from .device import DVec, DeviceCSR, CSRPattern, _p, stream_ptr, ctx
+from .device import DVec, DeviceCSR, _p, stream_ptr, ctx
 
 _F64 = torch.float64
 
