@@ -86,7 +86,7 @@ class ShardedProjectedCG:
         self.H_rows = eng.csr(sps.csr_matrix(H[n0:n1, n0 - self.hl:n1 + self.hr]))
         self.hdiag = eng.upload(np.asarray(hdiag)[n0:n1]) if hdiag is not None else None
         self.solver = eng.banded(A)                 # replicated (A A')^-1
-        self.norm_A = float(np.sqrt((A.data ** 2).sum()))
+        self.norm_A = eng.frobenius(A)
         # buffers
         self.x, self.r, self.Hp = (eng.zeros(self.nloc) for _ in range(3))
         self.p_ext = eng.zeros(self.hl + self.nloc + self.hr)
@@ -389,7 +389,12 @@ class HipEngine(SegmentsByKernel):
 
     def banded(self, A):
         from . import projector
-        return projector.BandedNormalSolver(self.dv.DeviceCSR.from_scipy(A))
+        self._A_full = self.dv.DeviceCSR.from_scipy(A)
+        return projector.BandedNormalSolver(self._A_full)
+
+    def frobenius(self, A):
+        """||A||_F on the device (of the matrix just handed to banded())."""
+        return self._A_full.frobenius_norm()
 
     def solve(self, solver, w, v, guard=None):
         if solver.perm is not None:

@@ -53,6 +53,9 @@ class NumpyEngine(_segments_base()):
     def vec_grid(self, n):
         return 1
 
+    def frobenius(self, A):
+        return float(np.sqrt((sps.csr_matrix(A).data ** 2).sum()))
+
     def banded(self, A):
         A = sps.csr_matrix(A)
         S = sps.csc_matrix(A.dot(A.T))
