@@ -108,7 +108,7 @@ k_factor_chunks(int m, int c, int P, const double *__restrict__ band, double *__
 #pragma unroll
     for (int e = K; e >= 1; --e)
       if (e <= j) dj -= lrow[e - 1] * lrow[e - 1] * dw[e - 1];
-    if (!(dj > 0.0)) atomicOr(flag, 1);
+    if (!(dj > IPX_PIVOT_RTOL * band[i])) atomicOr(flag, 1);
     Dinv[(int64_t)j * P + t] = 1.0 / dj;
 #pragma unroll
     for (int d = 1; d <= K; ++d) L[((int64_t)j * K + (d - 1)) * P + t] = lrow[d - 1];
@@ -382,7 +382,7 @@ k_decoupling_check_block(int nsep, const double *__restrict__ Rband, double *__r
 #pragma unroll
   for (int c = 0; c < K; ++c) {
     const double piv = D[c][c];
-    if (!(piv > 0.0)) bad = true;
+    if (!(piv > IPX_PIVOT_RTOL * Rband[(int64_t)t * K + c])) bad = true;
     const double ip = 1.0 / piv;
 #pragma unroll
     for (int b = 0; b < K; ++b) { D[c][b] *= ip; Inv[c][b] *= ip; }
@@ -817,7 +817,7 @@ k_factor_lds(int m, int c, int P, const double *__restrict__ band, double *__res
 #pragma unroll
       for (int e = K; e >= 1; --e)
         if (e <= j) dj -= lrow[e - 1] * lrow[e - 1] * dw[e - 1];
-      bad |= !(dj > 0.0);
+      bad |= !(dj > IPX_PIVOT_RTOL * bp[j]);
       sD[j * T + tl] = 1.0 / dj;
 #pragma unroll
       for (int d = 1; d <= K; ++d) sL[(j * K + (d - 1)) * T + tl] = lrow[d - 1];

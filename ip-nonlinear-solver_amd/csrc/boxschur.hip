@@ -39,23 +39,25 @@ k_pairs_factor(int ng, const int32_t *__restrict__ rowp, const int32_t *__restri
   const double sp = pos_s[p] >= 0 ? val[pos_s[p]] : 0.0;
   alpha[p] = ap;
   const double b11 = ap * ap + sp * sp;
-  double D;
+  double wgt;      // 1 - alpha' B^-1 alpha, in its cancellation-free form
   if (q < 0) {
     if (!(b11 > 0.0)) atomicOr(flag, 1);
     inv[3 * g] = 1.0 / b11; inv[3 * g + 1] = 0.0; inv[3 * g + 2] = 0.0;
-    D = ap * ap / b11;
+    wgt = sp * sp / b11;
   } else {
     const double aq = val[pos_a[q]];
     const double sq = pos_s[q] >= 0 ? val[pos_s[q]] : 0.0;
     alpha[q] = aq;
     const double b22 = aq * aq + sq * sq, b12 = ap * aq;
-    const double det = b11 * b22 - b12 * b12;
+    // (ap^2+sp^2)(aq^2+sq^2) - (ap aq)^2 without the cancellation (slacks of active bounds
+    // are ~1e-8 next to ap = aq = 1)
+    const double det = ap * ap * (sq * sq) + sp * sp * (aq * aq) + sp * sp * (sq * sq);
     if (!(det > 0.0) || !(b11 > 0.0)) atomicOr(flag, 1);
     const double i11 = b22 / det, i12 = -b12 / det, i22 = b11 / det;
     inv[3 * g] = i11; inv[3 * g + 1] = i12; inv[3 * g + 2] = i22;
-    D = ap * (i11 * ap + i12 * aq) + aq * (i12 * ap + i22 * aq);
+    wgt = (sp * sp) * (sq * sq) / det;
   }
-  weight_col[col[g]] = 1.0 - D;
+  weight_col[col[g]] = wgt;
 }
 
 // t_S = B^-1 w_S (written at the simple rows of t) and u[col_g] = alpha' t.

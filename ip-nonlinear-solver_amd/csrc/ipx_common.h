@@ -6,6 +6,10 @@
 
 #define IPX_BLOCK 256            // 4 waves: one per SIMD of a CU
 #define IPX_WAVE 64
+// A pivot of an LDL' / Cholesky factorization of S = A A' that has lost this many digits
+// against its diagonal entry marks A as numerically rank deficient (IPX_ENOTSPD): the
+// callers then fall back to the reference's SVD projections (projections.py:101-108).
+#define IPX_PIVOT_RTOL 1.1368683772161603e-13   // 2^-43
 #define IPX_VEC_GRID_CAP 1024    // grid-stride cap for streaming kernels (4 WG/CU)
 
 // Records the HIP error text for ipx_last_error() (defined in misc.hip).

@@ -13,8 +13,15 @@ benchmark problems.
     once per sparsity pattern on the host -- symbolic work only): partitioned
     banded LDL' kernels (csrc/banded.hip);
   * dense A: Gram matrix + dense Cholesky kernels (csrc/dense.hip).
-All numeric work runs on the GPU; there is no host factorization fallback.
+All numeric work of the full-rank path runs on the GPU.  A numerically rank-deficient
+Jacobian (a pivot of the device factorization lost against its diagonal) takes the
+reference's own exit: a warning and the SVD projections (projections.py:101-108,
+181-187,236-287) -- the thin SVD of the (small, dense) matrix is LAPACK on the host as in
+the reference, its factors are uploaded once and every operator application is device
+matvecs (``SVDProjector``).
 """
+from warnings import warn
+
 import ctypes
 
 import numpy as np
@@ -203,6 +210,75 @@ class NormalEquationProjector:
         return ops
 
 
+class SVDProjector:
+    """Z, LS, Y from a thin SVD ``A = U diag(s) Vt`` with the singular values ``<= tol``
+    dropped -- the reference's ``svd_factorization_projections`` (projections.py:236-287)
+    statement by statement, on device vectors.  Reached for rank-deficient Jacobians (with
+    the reference's warning) and for ``method='SVDFactorization'``."""
+
+    MAX_ELEMENTS = 1 << 25      # dense copy of A on the host: 256 MiB
+
+    def __init__(self, A, orth_tol, max_refin, tol):
+        import scipy.linalg
+        from .dense import DeviceDense
+        self.A = A
+        self.m, self.n = A.shape
+        if self.m * self.n > self.MAX_ELEMENTS:
+            raise np.linalg.LinAlgError(
+                "Singular Jacobian matrix (%d x %d): too large for the dense SVD fallback"
+                % (self.m, self.n))
+        Ah = A.to_scipy().toarray() if isinstance(A, DeviceCSR) else A.to_host()
+        U, sv, Vt = scipy.linalg.svd(Ah, full_matrices=False)       # :240
+        keep = sv > tol                                             # :243-245
+        self.rank = int(np.count_nonzero(keep))
+        self.U = DeviceDense.from_host(U[:, keep])
+        self.Vt = DeviceDense.from_host(Vt[keep, :])
+        self.inv_s = DVec.from_host(1.0 / sv[keep])
+        self.orth_tol, self.max_refin = orth_tol, max_refin
+        self.norm_A = A.frobenius_norm() if self.m > 0 else 0.0
+        self.stats = {"solves": 0, "refinements": 0}
+
+    def _apply_inv(self, x):
+        """v = U 1/s V' x = pinv(A') x  (:250-253)"""
+        self.stats["solves"] += 1
+        if self.rank == 0:
+            return DVec.zeros(self.m)
+        return self.U.dot(self.inv_s * self.Vt.dot(x))
+
+    def _orth(self, z):
+        norm_z = dv.norm(z)
+        if norm_z == 0 or self.norm_A == 0:
+            return 0.0
+        return dv.norm(self.A.dot(z)) / (self.norm_A * norm_z)
+
+    def null_space(self, x):                                        # :248-270
+        z = self.A.rmatvec_sub(self._apply_inv(x), x)
+        k = 0
+        while self._orth(z) > self.orth_tol:
+            if k >= self.max_refin:
+                break
+            z = self.A.rmatvec_sub(self._apply_inv(z), z)
+            k += 1
+            self.stats["refinements"] += 1
+        return z
+
+    def least_squares(self, x):                                     # :273-278
+        return self._apply_inv(x)
+
+    def row_space(self, x):                                         # :281-286
+        if self.rank == 0:
+            return DVec.zeros(self.n)
+        return self.Vt.T.dot(self.inv_s * self.U.T.dot(x))
+
+    def operators(self):
+        ops = (_Op((self.n, self.n), self.null_space),
+               _Op((self.m, self.n), self.least_squares),
+               _Op((self.n, self.m), self.row_space))
+        for op in ops:
+            op.projector = self
+        return ops
+
+
 def orthogonality(A, g):
     """``||A g|| / (||A||_F ||g||)`` (reference projections.py:23-55)."""
     A = as_device_matrix(A)
@@ -328,20 +404,30 @@ def projections(A, method=None, orth_tol=1e-12, max_refin=3, tol=1e-15):
         if method not in (None, "QRFactorization", "SVDFactorization"):
             raise ValueError("Method not allowed for dense array.")
     m, n = A.shape
-    if m == 0:
-        solver = None
-    elif sparse:
-        kmax = _hip.load().ipx_banded_kmax()
-        if _symbolic_for(A.pattern).k <= kmax:
-            solver = BandedNormalSolver(A)
-        elif _box_schur_applies(A, kmax):
-            from .boxschur import BoxSchurNormalSolver
-            solver = BoxSchurNormalSolver(A)    # bound rows eliminated analytically, banded rest
-        elif m <= DenseNormalSolver.MAX_ROWS_FROM_SPARSE:
-            solver = DenseNormalSolver(A)       # wide band: dense Cholesky of A A' on the device
+    if method == "SVDFactorization":
+        return SVDProjector(A, orth_tol, max_refin, tol).operators()
+    try:
+        if m == 0:
+            solver = None
+        elif sparse:
+            kmax = _hip.load().ipx_banded_kmax()
+            if _symbolic_for(A.pattern).k <= kmax:
+                solver = BandedNormalSolver(A)
+            elif _box_schur_applies(A, kmax):
+                from .boxschur import BoxSchurNormalSolver
+                solver = BoxSchurNormalSolver(A)    # bound rows eliminated analytically
+            elif m <= DenseNormalSolver.MAX_ROWS_FROM_SPARSE:
+                solver = DenseNormalSolver(A)       # wide band: dense Cholesky of A A'
+            else:
+                # general sparsity beyond both device factorizations: matrix-free solve
+                solver = IterativeNormalSolver(A)
         else:
-            # general sparsity beyond both device factorizations: matrix-free solve
-            solver = IterativeNormalSolver(A)
-    else:
-        solver = DenseNormalSolver(A)
+            solver = DenseNormalSolver(A)
+    except np.linalg.LinAlgError:
+        # the reference's exits: projections.py:101-108 (sparse), :181-187 (dense)
+        warn("Singular Jacobian matrix. Using dense SVD decomposition to perform the "
+             "factorizations." if sparse else
+             "Singular Jacobian matrix. Using SVD decomposition to perform the "
+             "factorizations.")
+        return SVDProjector(A, orth_tol, max_refin, tol).operators()
     return NormalEquationProjector(A, solver, orth_tol, max_refin).operators()

@@ -121,6 +121,14 @@ ORTH_VECTORS = [
      99434.98929065, -1285.37653682, -4109.21503806, 2935.29289083],
 ]
 
+# rank-deficient Jacobians (reference: SVD fallback with a warning,
+# projections.py:101-108,181-187): a zero row; a row that is the sum of the others
+RANK_DEFICIENT = {
+    "zero_row": [[1, 2, 3, 4, 0, 5, 0, 7], [0, 8, 7, 0, 1, 5, 9, 0], [0] * 8],
+    "sum_row": [[1, 2, 3, 4, 0, 5, 0, 7], [0, 8, 7, 0, 1, 5, 9, 0],
+                [1, 10, 10, 4, 1, 10, 9, 7]],
+}
+
 
 def diag4_matrix():
     """[D D D D] with D = diag(1..100) (test_projections.py:110-111)."""

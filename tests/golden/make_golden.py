@@ -17,6 +17,11 @@ Outputs (numbers only -- no reference source travels):
                     seeded banded problem
   e2e.json          end-to-end minimize_constrained traces (tests/problems.py,
                     README example, banded NLPs)
+  qp_extra.json     projection refinement cases (test_projections.py:48-65,141-156:
+                    orth_tol=1e-18, max_refin 100 / 10) and rank-deficient Jacobians
+                    (SVD fallback, projections.py:101-108,181-187,236-287)
+  config2.json      (``--big`` only: minutes) dense equality QP of BASELINE config 2 at
+                    n=4000/m=800 and n=10000/m=2000: scalar traces + strided x
 """
 import json
 import os
@@ -192,6 +197,75 @@ def banded_traces(n, m, full_vectors):
     return out
 
 
+def extra_cases():
+    """Refinement and rank-deficient projection cases."""
+    out = {}
+    A38 = np.array(cs.A38, dtype=float)
+    ref = {}
+    for method, A, max_refin in (("AugmentedSystem", sps.csc_matrix(A38), 100),
+                                 ("QRFactorization", A38, 10),
+                                 ("SVDFactorization", A38, 10)):
+        Z, LS, Y = rproj.projections(A, method, orth_tol=1e-18, max_refin=max_refin)
+        zs = [Z.dot(np.array(p, float)) for p in cs.A38_POINTS_N]
+        ref[method] = {"max_refin": max_refin, "Z": [jf(z) for z in zs],
+                       "orth": [jf(rproj.orthogonality(A38, z)) for z in zs]}
+    out["proj38_refine"] = ref
+
+    rank = {}
+    for name, rows in cs.RANK_DEFICIENT.items():
+        A = np.array(rows, dtype=float)
+        rec = {}
+        for kind, M in (("sparse", sps.csc_matrix(A)), ("dense", A)):
+            with warnings.catch_warnings(record=True) as w:
+                warnings.simplefilter("always")
+                Z, LS, Y = rproj.projections(M)
+                rec[kind] = {
+                    "warnings": [str(x.message) for x in w],
+                    "Z": [jf(Z.dot(np.array(p, float))) for p in cs.A38_POINTS_N[:3]],
+                    "LS": [jf(LS.dot(np.array(p, float))) for p in cs.A38_POINTS_N[:3]],
+                    "Y": [jf(Y.dot(np.array(p, float))) for p in cs.A38_POINTS_M]}
+        rec["singular_values"] = jf(np.linalg.svd(A, compute_uv=False))
+        rank[name] = rec
+    out["rank_deficient"] = rank
+    return out
+
+
+def banded_refine_traces(n, m):
+    """projected_cg on the Appendix C matrices with projections that refine on
+    every application (orth_tol far below the attainable orthogonality), so the
+    refinement loop projections.py:126-139 runs inside the CG loop."""
+    inst = banded_setup.BandedInstance(n, m)
+    out = {}
+    for max_refin in (1, 3):
+        Z, LS, Y = rproj.projections(inst.A, orth_tol=1e-30, max_refin=max_refin)
+        out["refine%d_Z" % max_refin] = np.array([Z.dot(p) for p in inst.probes_n])
+        gnorm = np.linalg.norm(Z.dot(inst.c))
+        for name, kw in inst.pcg_variants(gnorm).items():
+            if name not in ("free", "box"):
+                continue
+            xs, info = rqp.projected_cg(inst.H, inst.c, Z, Y, np.zeros(m), **kw)
+            out["refine%d_pcg_%s_x" % (max_refin, name)] = xs
+            out["refine%d_pcg_%s_info" % (max_refin, name)] = np.array(
+                [info["niter"], info["stop_cond"], int(info["hits_boundary"])])
+    return out
+
+
+def config2(n, m):
+    """BASELINE config 2: dense random equality-constrained QP."""
+    rng = np.random.default_rng(0)
+    A = rng.standard_normal((m, n))
+    G = rng.standard_normal((n, n)) / np.sqrt(n)
+    Hd = G.dot(G.T) + np.eye(n)
+    c = rng.standard_normal(n)
+    xf = rng.standard_normal(n)
+    bq = A.dot(xf)
+    rec = run_e2e("config2_n%d" % n, lambda x: 0.5 * x.dot(Hd.dot(x)) + c.dot(x),
+                  np.zeros(n), lambda x: Hd.dot(x) + c, lambda x: Hd,
+                  ref.LinearConstraint(A, ("equals", bq)),
+                  method="equality_constrained_sqp")
+    return rec
+
+
 def run_e2e(name, fun, x0, grad, hess, constraints, **kw):
     rows = []
 
@@ -270,12 +344,23 @@ def e2e():
 
 
 def main():
+    if "--big" in sys.argv:
+        out = {}
+        for n, m in ((4000, 800), (10000, 2000)):
+            out["config2_n%d" % n] = config2(n, m)
+        with open(os.path.join(HERE, "config2.json"), "w") as f:
+            json.dump(out, f)
+        return
     print("small cases ...")
     with open(os.path.join(HERE, "qp_small.json"), "w") as f:
         json.dump(small_cases(), f)
     print("banded traces ...")
+    with open(os.path.join(HERE, "qp_extra.json"), "w") as f:
+        json.dump(extra_cases(), f)
     np.savez_compressed(os.path.join(HERE, "banded_n2000.npz"),
                         **banded_traces(2000, 200, True))
+    np.savez_compressed(os.path.join(HERE, "banded_refine_n2000.npz"),
+                        **banded_refine_traces(2000, 200))
     np.savez_compressed(os.path.join(HERE, "banded_n20000.npz"),
                         **banded_traces(20000, 2000, False))
     print("end-to-end ...")

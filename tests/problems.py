@@ -215,3 +215,62 @@ def fd_hessian_problems():
             _with_fd(Rosenbrock, '2-point', "_fd2")(10),
             _with_fd(EqIneqRosenbrock, '2-point', "_fd2")(),
             _with_fd(Elec, '2-point', "_fd2")(10)]
+
+
+# ---- device-callback twins (x is a CUDA tensor; see ipsolver/device_mode.py) ----------
+def _row_csr(values):
+    """1 x n Jacobian as a DeviceCSR on a fixed (cached) pattern."""
+    import torch
+    from ipsolver.device import CSRPattern, DeviceCSR
+    n = len(values)
+    pat = _row_csr.patterns.get(n)
+    if pat is None:
+        pat = _row_csr.patterns[n] = CSRPattern(np.array([0, n], dtype=np.int32),
+                                                np.arange(n, dtype=np.int32), (1, n))
+    return DeviceCSR(pat, torch.stack(list(values)).to(torch.float64))
+
+
+_row_csr.patterns = {}
+
+
+class DeviceMaratos(Maratos):
+    """Maratos with torch callbacks (same expressions as the host problem)."""
+
+    def device_x0(self):
+        import torch
+        return torch.tensor(self.x0, dtype=torch.float64, device="cuda")
+
+    def fun(self, x):
+        return float(2 * (x[0] ** 2 + x[1] ** 2 - 1) - x[0])
+
+    def grad(self, x):
+        import torch
+        return torch.stack([4 * x[0] - 1, 4 * x[1]])
+
+    def constraints(self, ns):
+        import torch
+        return ns.NonlinearConstraint(
+            lambda x: (x[0] ** 2 + x[1] ** 2).reshape(1), ("equals", 1),
+            lambda x: _row_csr([4 * x[0], 4 * x[1]]),
+            lambda x, v: torch.stack([2 * v[0], 2 * v[0]]))
+
+
+class DeviceHyperbolicIneq(HyperbolicIneq):
+    def device_x0(self):
+        import torch
+        return torch.tensor(self.x0, dtype=torch.float64, device="cuda")
+
+    def fun(self, x):
+        return float(0.5 * (x[0] - 2) ** 2 + 0.5 * (x[1] - 0.5) ** 2)
+
+    def grad(self, x):
+        import torch
+        return torch.stack([x[0] - 2, x[1] - 0.5])
+
+    def constraints(self, ns):
+        import torch
+        nl = ns.NonlinearConstraint(
+            lambda x: (1 / (x[0] + 1) - x[1]).reshape(1), ("greater", 0.25),
+            lambda x: _row_csr([-1 / (x[0] + 1) ** 2, -torch.ones_like(x[0])]),
+            lambda x, v: torch.stack([2 * v[0] / (x[0] + 1) ** 3, torch.zeros_like(x[0])]))
+        return (nl, ns.BoxConstraint(("greater",)))

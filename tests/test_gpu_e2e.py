@@ -154,6 +154,29 @@ def test_device_callbacks_finite_difference_hessians(fd):
                                       dc.constraints(ipsolver), method="tr_interior_point")
 
 
+@pytest.mark.parametrize("cls,name", [(problems.DeviceMaratos, "maratos"),
+                                      (problems.DeviceHyperbolicIneq, "hyperbolic_ineq")])
+@pytest.mark.parametrize("fd,tag", [("2-point", "_fd2"), ("3-point", "_fd3")])
+def test_device_finite_difference_hessians_vs_reference(cls, name, fd, tag, e2e_golden):
+    """N4 against the REFERENCE: the finite-difference Hessian operator of device-callback
+    mode (fd.DeviceFiniteDifferenceOperator, the rule of _numdiff.py:403-441 evaluated with
+    device callbacks) on the reference's own finite-difference test problems
+    (test_minimized_constrained.py), against the traces the reference produced with
+    ``hess='2-point'|'3-point'``."""
+    import torch
+    p = cls()
+    res, rows = run(p.fun, p.device_x0(), p.grad, fd, p.constraints(ipsolver))
+    gold = e2e_golden[name + tag]
+    assert torch.is_tensor(res.x) and res.x.is_cuda
+    assert res.status == gold["status"] == 1
+    assert res.optimality < 1e-8 and res.constr_violation < 1e-8
+    # same policy as the host finite-difference runs (trace_policy): a prefix of the trace,
+    # then the solution; differences of gradients amplify last-bit noise by 1/h ~ 1e8
+    compare(res, rows, gold, rtol=1e-4, prefix=8)
+    assert abs(res.niter - gold["niter"]) <= 2 and abs(res.cg_niter - gold["cg_niter"]) <= 2
+    np.testing.assert_allclose(res.x.cpu().numpy(), unjson(gold["x"]), rtol=1e-6, atol=1e-7)
+
+
 def test_device_callbacks_box_inequality(e2e_golden):
     import torch
     syn = load_synthetic()

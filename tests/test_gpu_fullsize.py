@@ -205,3 +205,100 @@ def test_partial_compaction_beyond_1e6():
     assert (info_f["niter"], info_f["stop_cond"]) == (info_g["niter"], info_g["stop_cond"])
     assert dv.norm(x_f - x_g) <= 1e-12 * dv.norm(x_g)
     assert dv.norm(A.dot(x_f)) <= 1e-11 * float(np.sqrt((A.val ** 2).sum().item())) * dv.norm(x_f)
+
+
+def _config2_problem(n, m):
+    """BASELINE config 2: draws in the generator's order."""
+    rng = np.random.default_rng(0)
+    A = rng.standard_normal((m, n))
+    G = rng.standard_normal((n, n)) / np.sqrt(n)
+    Hd = G.dot(G.T) + np.eye(n)
+    c = rng.standard_normal(n)
+    xf = rng.standard_normal(n)
+    return A, Hd, c, A.dot(xf)
+
+
+@pytest.mark.parametrize("n,m", [(4000, 800), (10000, 2000)])
+def test_config2_full_solve_against_reference_trace(n, m, config2_golden):
+    """BASELINE config 2 -- dense random equality-constrained QP, equality_constrained_sqp --
+    at full size (n=10000, m=2000) and at n=4000/m=800, against scalar traces of the
+    REFERENCE run on the same seeded problem (tests/golden/config2.json).
+
+    Integer columns (niter, cg_niter, nfev) exact, trust radius / penalty to 1e-12,
+    optimality to 1e-9 relative + the rounding floor of its terms (1e-14 ||grad||), x to 1e-9.
+    At n=4000 the accept/reject test of the reference's LAST iteration sits on the merit
+    function's rounding floor (actual reduction ~1e-13 |f|): the reference accepts and stops
+    on gtol (status 1); a build whose sums round differently may reject and stop two
+    iterations later on xtol (status 2) at the same point.  That divergence is bounded here:
+    every row before the last must match, the final point must match the reference's."""
+    import warnings
+    import ipsolver
+    from conftest import unjson
+    gold = config2_golden["config2_n%d" % n]
+    A, Hd, c, bq = _config2_problem(n, m)
+    rows = []
+
+    def cb(state):
+        rows.append([int(state.niter), int(state.cg_niter), float(state.trust_radius),
+                     float(state.penalty), float(state.optimality),
+                     float(state.constr_violation), int(state.nfev)])
+        return False
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res = ipsolver.minimize_constrained(
+            lambda x: 0.5 * x.dot(Hd.dot(x)) + c.dot(x), np.zeros(n), lambda x: Hd.dot(x) + c,
+            lambda x: Hd, ipsolver.LinearConstraint(A, ("equals", bq)),
+            method="equality_constrained_sqp", callback=cb)
+    want = np.array([[r[0], r[1], r[2], r[3], r[5], r[6], r[7]] for r in unjson(gold["trace"])],
+                    dtype=float)
+    got = np.array(rows, dtype=float)
+    k = len(want) - 1                      # rows before the reference's last iteration
+    assert len(got) >= len(want)
+    for col in (0, 1, 6):
+        assert np.array_equal(got[:k, col], want[:k, col])
+    assert np.allclose(got[:k, 2:4], want[:k, 2:4], rtol=1e-12, atol=0)
+    floor = 1e-14 * want[0, 4]
+    assert np.all(np.abs(got[:k, 4] - want[:k, 4]) <= 1e-9 * want[:k, 4] + floor)
+    # constraint violation: O(100) for three iterations, then the rounding noise of A x - b
+    assert np.all(np.abs(got[:k, 5] - want[:k, 5]) <= 1e-10 * want[:k, 5] + 1e-13 * want[0, 5])
+    gx = np.asarray(unjson(gold["x"]), dtype=float)
+    x = np.asarray(res.x)[::max(1, n // 50)]
+    assert np.max(np.abs(x - gx)) <= 1e-9 * np.max(np.abs(gx))
+    assert abs(res.fun - gold["fun"]) <= 1e-12 * abs(gold["fun"])
+    assert res.optimality < 2e-8 and res.constr_violation < 1e-10
+    if n == 10000:                         # the configuration BASELINE.json names
+        assert (res.status, res.niter, res.cg_niter) == (gold["status"], gold["niter"],
+                                                         gold["cg_niter"])
+        assert np.array_equal(got[:, 1], want[:, 1]) and len(got) == len(want)
+        assert abs(got[-1, 4] - want[-1, 4]) <= 1e-6 * want[-1, 4]
+    else:
+        assert res.status in (1, 2) and abs(res.niter - gold["niter"]) <= 2
+
+
+def test_config5_full_size_properties():
+    """BASELINE config 5 at its full size on one GPU: n = 5e5 variables, box on every variable
+    + 5e4 nonlinear inequalities (N = 1.55e6 with slacks, M = 1.05e6 rows), the full
+    tr_interior_point loop with device callbacks.  The reference cannot run this size (many
+    hours), so the checks are properties: termination on gtol, bounds and
+    inequalities respected, and the size-independent trends of the reference's own runs of
+    this generator at n = 4e3 and n = 2e4 (27 % / 28 % of the bounds
+    active, f/n = -0.1518 at n = 2e4, 57 / 62 outer iterations)."""
+    import warnings
+    import ipsolver
+    from ipsolver.synthetic import CenteredBandedNLP, DeviceCallbacks
+    n, m = 500000, 50000
+    prob = CenteredBandedNLP(n, m, eps=1.0)
+    dc = DeviceCallbacks(prob)
+    cons = (dc.constraints(ipsolver, ("less", 0.0)), ipsolver.BoxConstraint(("interval", -0.8, 0.8)))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res = ipsolver.minimize_constrained(dc.fun, dc.x0, dc.grad, dc.hess, cons)
+    x = res.x.cpu().numpy()
+    assert res.status == 1 and res.optimality < 1e-8 and res.constr_violation < 1e-8
+    assert np.all(np.abs(x) <= 0.8 + 1e-12)                         # box respected
+    assert np.max(prob.constr_fun(x)) <= 1e-8                       # c(x) <= 0
+    assert res.s.shape[0] == m + 2 * n and float(res.s.min()) > 0   # slacks interior
+    active = int(np.sum(np.abs(np.abs(x) - 0.8) < 1e-6))
+    assert 0.25 * n < active < 0.31 * n
+    assert abs(res.fun / n - (-0.15184)) <= 0.01 * 0.15184
+    assert 55 <= res.niter <= 85 and 10000 < res.cg_niter < 100000

@@ -10,20 +10,15 @@ import scipy.sparse as sps
 
 import cases_small as cs
 from banded_setup import BandedInstance
-from conftest import unjson
+from conftest import unjson, rel_err, close_projection
+from conftest import close as _close
 import oracle
 
 RTOL = 1e-12
 
 
-def close(a, b, tol=RTOL):
-    a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
-    assert a.shape == b.shape
-    fin = np.isfinite(b)
-    assert np.array_equal(np.isfinite(a), fin)
-    assert np.array_equal(a[~fin], b[~fin])
-    scale = max(1.0, np.max(np.abs(b[fin]))) if fin.any() else 1.0
-    assert np.max(np.abs(a[fin] - b[fin]), initial=0.0) <= tol * scale
+def close(a, b, tol=RTOL, zero_scale=None):
+    _close(a, b, tol, zero_scale)
 
 
 def check_interval(got, want):
@@ -117,7 +112,7 @@ def test_projections_3x8(qp_small, method):
                               else "AugmentedSystem"]
     for p, wz, wl in zip(cs.A38_POINTS_N, want["Z"], want["LS"]):
         p = np.array(p, float)
-        close(Z.dot(p), unjson(wz), 1e-9)      # projection of 1e5-sized data
+        close_projection(Z.dot(p), unjson(wz), p, 1e-12)
         close(LS.matvec(p), unjson(wl), 1e-10)
         assert np.max(np.abs(A38.dot(Z.dot(p)))) < 1e-8
     for p, wy in zip(cs.A38_POINTS_M, want["Y"]):
@@ -199,3 +194,66 @@ def test_banded_traces(size, method, banded2000, banded20000):
         got = oracle.modified_dogleg(inst.A, Y, inst.b, radius,
                                      np.full(n, lo), np.full(n, hi))
         close(got[::s], w, 1e-10)
+
+
+# ---- projection refinement (reference test_projections.py:48-65,141-156) -----
+@pytest.mark.parametrize("method", ["AugmentedSystem", "NormalEquation", "QRFactorization",
+                                    "SVDFactorization"])
+def test_projections_refinement(qp_extra, method):
+    A38 = np.array(cs.A38, dtype=float)
+    sparse = method in ("AugmentedSystem", "NormalEquation")
+    gold = qp_extra["proj38_refine"][method if method != "NormalEquation" else "AugmentedSystem"]
+    Z, _, _ = oracle.projections(sps.csc_matrix(A38) if sparse else A38, method,
+                                 orth_tol=1e-18, max_refin=gold["max_refin"])
+    for i, (p, want) in enumerate(zip(cs.A38_POINTS_N, gold["Z"])):
+        p = np.array(p, float)
+        z = Z.dot(p)
+        # the reference's own assertions
+        assert np.max(np.abs(A38.dot(z))) < 1.5e-14 * max(1.0, np.max(np.abs(p)))
+        assert oracle.orthogonality(A38, z) < 1.5e-16
+        if i < 3:
+            close(z, want, 1e-12)
+        else:
+            # p = row 3 of A + 1e-10 e_8: Z p is 1e-10-sized, what is left after cancelling
+            # 16 digits of p; the reference's own three methods differ by 2e-5 on it
+            close(z, want, 1e-4)
+            assert np.max(np.abs(z - np.array(want))) <= 1e-15 * np.max(np.abs(p))
+
+
+@pytest.mark.parametrize("name,kind", [("zero_row", "sparse"), ("zero_row", "dense"),
+                                       ("sum_row", "sparse")])
+def test_rank_deficient_fallback(qp_extra, name, kind):
+    """Rank-deficient Jacobian: SVD fallback with the reference's warning
+    (projections.py:101-108,181-187,236-287).  (sum_row / dense is not compared: there the
+    reference's pivoted-QR rank test does not fire and its operators return 1e13-sized noise.)"""
+    A = np.array(cs.RANK_DEFICIENT[name], dtype=float)
+    gold = qp_extra["rank_deficient"][name][kind]
+    assert len(gold["warnings"]) == 1 and gold["warnings"][0].startswith("Singular Jacobian")
+    if name == "sum_row" and not np.linalg.svd(A, compute_uv=False)[-1] <= 1e-15:
+        pytest.skip("this LAPACK leaves the rounding-level singular value above tol=1e-15")
+    with pytest.warns(UserWarning, match="Singular Jacobian matrix"):
+        Z, LS, Y = oracle.projections(sps.csc_matrix(A) if kind == "sparse" else A)
+    for p, wz, wl in zip(cs.A38_POINTS_N[:3], gold["Z"], gold["LS"]):
+        close(Z.dot(np.array(p, float)), wz, 1e-10)
+        close(LS.dot(np.array(p, float)), wl, 1e-9)
+    for p, wy in zip(cs.A38_POINTS_M, gold["Y"]):
+        close(Y.dot(np.array(p, float)), wy, 1e-10)
+
+
+@pytest.mark.parametrize("method", ["AugmentedSystem", "NormalEquation"])
+@pytest.mark.parametrize("max_refin", [1, 3])
+def test_banded_traces_with_refinement(banded_refine2000, method, max_refin):
+    """projected_cg with projections that refine on every application."""
+    gold = banded_refine2000
+    n, m = 2000, 200
+    inst = BandedInstance(n, m)
+    Z, LS, Y = oracle.projections(inst.A, method, orth_tol=1e-30, max_refin=max_refin)
+    for p, w in zip(inst.probes_n, gold["refine%d_Z" % max_refin]):
+        close(Z.dot(p), w, 1e-12)
+    for name, kw in inst.pcg_variants(1.0).items():
+        if name not in ("free", "box"):
+            continue
+        x, info = oracle.projected_cg(inst.H, inst.c, Z, Y, np.zeros(m), **kw)
+        assert [info["niter"], info["stop_cond"], int(info["hits_boundary"])] == \
+            list(gold["refine%d_pcg_%s_info" % (max_refin, name)])
+        close(x, gold["refine%d_pcg_%s_x" % (max_refin, name)], 1e-10)
