@@ -32,11 +32,182 @@ sys.path.insert(0, os.path.join(ROOT, "ip-nonlinear-solver_amd"))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PMC_PROFILE = "r01i_pmc_traffic.json"      # see roofline.traffic_source
 
 
 def spmv_bytes(nnz, rows, cols, extra_row_vectors=0):
     """Algorithmic HBM bytes of one CSR SpMV launch."""
     return 12 * nnz + 4 * (rows + 1) + 8 * rows + 8 * cols + 8 * rows * extra_row_vectors
+
+
+def single_gpu_measure(A_h, H_h, hdiag_h, c_h, n, m, K, W, repeats=20):
+    """Upload one subproblem, factor, prime the device loop like projected_cg does, then
+    W warm-up + EXACTLY K timed iterations (the contract's region), `repeats` further K-step
+    regions (median / min / max), HIP-event attribution per kernel, and the dominant kernel
+    on its own."""
+    import numpy as np
+    import torch
+    from ipsolver import _hip, cg_fused, projector
+    from ipsolver import device as dv
+    from ipsolver.operators import DeviceHessian
+    lib = _hip.load()
+    A = dv.DeviceCSR.from_scipy(A_h)
+    H = DeviceHessian(n, csr=dv.DeviceCSR.from_scipy(H_h), diag=dv.DVec.from_host(hdiag_h))
+    c = dv.DVec.from_host(c_h)
+    b = dv.DVec.zeros(m)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    Z, LS, Y = projector.projections(A)
+    torch.cuda.synchronize()
+    t_factor = time.time() - t0
+    P = Z.projector
+
+    # ---- prime the loop exactly like projected_cg does (untimed)
+    x0 = Y.dot(-b)
+    r0 = Z.dot(H.dot(x0) + c)
+    g0 = Z.dot(r0)
+    rt_g = g0.sumsq_amax()[0]
+    L = cg_fused._Loop(H, P, None, None)
+    st = dv.stream_ptr()
+    init = np.zeros(L.state.numel())
+    init[cg_fused.ST_RTG0] = rt_g
+    init[cg_fused.ST_TOL] = 0.0
+    init[cg_fused.ST_RADIUS] = np.inf
+    init[cg_fused.ST_ORTH_RHS] = P.orth_tol * P.norm_A
+    init_dev = torch.from_numpy(init).to(L.state.device)
+
+    def prime():
+        """x = x0, r = Z(H x0 + c), p = -g, state reset, Hp = H p: device copies and one
+        SpMV, no host synchronisation."""
+        L.x.copy_(x0.t)
+        L.r.copy_(r0.t)
+        _hip.call("ipx_axpby", n, -1.0, dv._p(g0.t), 0.0, None, dv._p(L.p), st)
+        L.state.copy_(init_dev)
+        _hip.check(lib.ipx_cg_hp(L.ref(), st), "ipx_cg_hp")
+
+    # With tol = 0 the CG would run into an exactly zero residual after ~500 iterations
+    # (p'Hp = 0 ends it).  Whatever K is asked for, the loop is therefore restarted from
+    # the same subproblem every SEG iterations (five device launches, <0.3 % of a segment).
+    SEG = 200
+
+    def run(it0, it1, what):
+        it = it0
+        while it < it1:
+            j = it % SEG
+            if j == 0:
+                prime()
+            end = min(it1, it - j + SEG)
+            _hip.check(lib.ipx_cg_iterate(L.ref(), j, j + (end - it), st), what)
+            it = end
+
+    def check_ran(total):
+        s = L.state.tolist()
+        expected_done = (total - 1) % SEG + 1 if total > 0 else 0
+        if int(s[cg_fused.ST_STOP]) != 0 or int(s[cg_fused.ST_IT_DONE]) != expected_done:
+            raise SystemExit("timed region did not run its iterations: stop=%s done=%s (expected "
+                             "%d in the last segment)" % (s[cg_fused.ST_STOP],
+                                                          s[cg_fused.ST_IT_DONE], expected_done))
+
+    # ---- warmup, then EXACTLY K timed iterations
+    run(0, W, "warmup")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(W, W + K, "timed")
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    check_ran(W + K)
+    # ---- the same K-step region again, `repeats` times (spread of the measurement)
+    rates = []
+    done = W + K
+    for _ in range(repeats):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(done, done + K, "repeat")
+        torch.cuda.synchronize()
+        rates.append(K / (time.perf_counter() - t0))
+        done += K
+    check_ran(done)
+    rates.sort()
+    repeat = {"regions": repeats, "steps_each": K,
+              "iterations_per_s": {"median": rates[len(rates) // 2], "min": rates[0],
+                                   "max": rates[-1]}} if rates else None
+
+    # ---- per-kernel attribution with HIP events on the launch stream
+    ms = (ctypes.c_float * 7)()
+    kt = max(2, min(K, 100))
+    prime()
+    _hip.check(lib.ipx_cg_iterate(L.ref(), 0, 20, st), "pre-events")
+    _hip.check(lib.ipx_cg_iterate_timed(L.ref(), 20, 20 + kt, ms, st), "timed-events")
+    fused1, fused2, fused3 = bool(L.args.A_span), bool(L.args.H_hmax), bool(L.args.At_qv)
+    names = [None if fused1 else "step1", "step1_spmv_A_r" if fused1 else "spmv_A_r",
+             "banded_solve_residual_r_minus_Atv" if fused3 else "banded_solve_with_residual",
+             None if fused3 else "spmv_r_minus_Atv", None,
+             None if fused2 else "step2", "step2_spmv_H_p" if fused2 else "spmv_H_p"]
+    per_kernel_us = {k: 1e3 * ms[i] / kt for i, k in enumerate(names) if k}
+
+    # ---- the dominant kernel on its own: back-to-back launches (same arguments as in the
+    # loop) between two HIP events on the launch stream, in `repeats` groups of K.  This is
+    # the kernel's own duration, the quantity rocprofv3 --kernel-trace reports; the
+    # per_kernel_us figures above additionally contain the dependency gap in front of each
+    # kernel.  With a banded Hessian step2 rides inside the H.p SpMV (k_cg_step2_hp): the
+    # fused kernel is then the dominant one (mode 3 = no stop tests).
+    def dominant():
+        if fused2:
+            return lib.ipx_cg_step2_hp(L.ref(), 0, 3, st)
+        return lib.ipx_cg_hp(L.ref(), st)
+    for _ in range(20):
+        dominant()
+    groups = []
+    for _ in range(max(1, repeats)):
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(K):
+            dominant()
+        ev1.record()
+        torch.cuda.synchronize()
+        groups.append(1e3 * ev0.elapsed_time(ev1) / K)
+    groups.sort()
+    hp_us = groups[len(groups) // 2]
+
+    nnzA, nnzH = A.pattern.nnz, H.csr.pattern.nnz
+    bytes_hp = spmv_bytes(nnzH, n, n, extra_row_vectors=1)           # + diag vector
+    algo = {
+        "spmv_H_p": bytes_hp,
+        "spmv_A_r": spmv_bytes(nnzA, m, n),
+        "spmv_r_minus_Atv": spmv_bytes(nnzA, n, m, extra_row_vectors=1),
+        "step1": 5 * 8 * n,     # read x,p,r,Hp; write r
+        "step2": 5 * 8 * n,     # read x,p,g;   write x,p
+    }
+    if fused2:      # p is read once instead of twice
+        algo["step2_spmv_H_p"] = algo.pop("spmv_H_p") + algo.pop("step2") - 8 * n
+    if fused1:      # r_next is not read back by the SpMV
+        algo["step1_spmv_A_r"] = algo.pop("spmv_A_r") + algo.pop("step1") - 8 * n
+    if fused3:      # v is not read back by the SpMV
+        algo["banded_solve_residual_r_minus_Atv"] = algo.pop("spmv_r_minus_Atv") - 8 * m
+    dom = "step2_spmv_H_p" if fused2 else "spmv_H_p"
+    dom_label = ("k_cg_step2_hp (step2 fused into the H.p SpMV, p'Hp epilogue)" if fused2
+                 else "k_csr_spmv (H.p with p'Hp epilogue)")
+    achieved = algo[dom] / (hp_us * 1e-6) / 1e9
+    iter_bytes = sum(algo.values()) + 4 * 8 * m
+    med_rate = repeat["iterations_per_s"]["median"] if repeat else K / elapsed
+    return {
+        "A": A, "H": H, "c": c, "b": b, "Z": Z, "Y": Y, "elapsed": elapsed, "repeat": repeat,
+        "t_factor": t_factor, "nnzA": nnzA, "nnzH": nnzH, "dom": dom,
+        "per_kernel_us": per_kernel_us,
+        "roofline": {"bound": "hbm", "kernel": dom_label,
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS,
+                     "algorithmic_bytes_per_launch": algo[dom],
+                     "avg_launch_us": hp_us,
+                     "avg_launch_us_min_max": [groups[0], groups[-1]],
+                     "avg_launch_us_in_loop_with_gap": per_kernel_us[dom],
+                     "method": "median of %d groups of %d back-to-back launches, each between "
+                               "two HIP events on the launch stream" % (len(groups), K)},
+        "whole_iteration": {"algorithmic_bytes": iter_bytes,
+                            "achieved_GBs": iter_bytes * med_rate / 1e9,
+                            "frac_of_hbm_peak": iter_bytes * med_rate / 1e9 / HBM_PEAK_GBS,
+                            "at": "median of the repeated regions"},
+    }
 
 
 def sharded_leg(args, world, rank, A_h, H_h, hdiag_h, c_h, n, m, K, W):
@@ -138,6 +309,10 @@ def main():
     ap.add_argument("--m", type=int, default=100000)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-iters", type=int, default=400)
+    ap.add_argument("--repeats", type=int, default=20,
+                    help="further K-step regions after the contract's one (median/min/max)")
+    ap.add_argument("--no-big", action="store_true",
+                    help="skip the out-of-Infinity-Cache measurement (n=4e6, m=4e5)")
     args = ap.parse_args()
 
     import numpy as np
@@ -184,141 +359,22 @@ def main():
     if world > 1:
         return sharded_leg(args, world, rank, A_h, H_h, hdiag_h, c_h, n, m, K, W)
 
-    A = dv.DeviceCSR.from_scipy(A_h)
-    H = DeviceHessian(n, csr=dv.DeviceCSR.from_scipy(H_h), diag=dv.DVec.from_host(hdiag_h))
-    c = dv.DVec.from_host(c_h)
-    b = dv.DVec.zeros(m)
-    torch.cuda.synchronize()
-    t0 = time.time()
-    Z, LS, Y = projector.projections(A)
-    torch.cuda.synchronize()
-    t_factor = time.time() - t0
-    P = Z.projector
-
-    # ---- prime the loop exactly like projected_cg does (untimed)
-    x0 = Y.dot(-b)
-    r0 = Z.dot(H.dot(x0) + c)
-    g0 = Z.dot(r0)
-    rt_g = g0.sumsq_amax()[0]
-    L = cg_fused._Loop(H, P, None, None)
-    st = dv.stream_ptr()
-    init = np.zeros(L.state.numel())
-    init[cg_fused.ST_RTG0] = rt_g
-    init[cg_fused.ST_TOL] = 0.0
-    init[cg_fused.ST_RADIUS] = np.inf
-    init[cg_fused.ST_ORTH_RHS] = P.orth_tol * P.norm_A
-    init_dev = torch.from_numpy(init).to(L.state.device)
-
-    def prime():
-        """x = x0, r = Z(H x0 + c), p = -g, state reset, Hp = H p: device copies and one
-        SpMV, no host synchronisation."""
-        L.x.copy_(x0.t)
-        L.r.copy_(r0.t)
-        _hip.call("ipx_axpby", n, -1.0, dv._p(g0.t), 0.0, None, dv._p(L.p), st)
-        L.state.copy_(init_dev)
-        _hip.check(lib.ipx_cg_hp(L.ref(), st), "ipx_cg_hp")
-
-    # With tol = 0 the CG would run into an exactly zero residual after ~500 iterations
-    # (p'Hp = 0 ends it).  Whatever K is asked for, the loop is therefore restarted from
-    # the same subproblem every SEG iterations (five device launches, <0.3 % of a segment).
-    SEG = 200
-
-    def run(it0, it1, what):
-        it = it0
-        while it < it1:
-            j = it % SEG
-            if j == 0:
-                prime()
-            end = min(it1, it - j + SEG)
-            _hip.check(lib.ipx_cg_iterate(L.ref(), j, j + (end - it), st), what)
-            it = end
-
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # ---- warmup, then EXACTLY K timed iterations
-    run(0, W, "warmup")
-    barrier()
-    t0 = time.perf_counter()
-    run(W, W + K, "timed")
-    barrier()
-    elapsed = time.perf_counter() - t0
-    s = L.state.tolist()
-    expected_done = (W + K - 1) % SEG + 1 if W + K > 0 else 0
-    if int(s[cg_fused.ST_STOP]) != 0 or int(s[cg_fused.ST_IT_DONE]) != expected_done:
-        raise SystemExit("timed region did not run %d iterations: stop=%s done=%s (expected %d "
-                         "in the last segment)" % (K, s[cg_fused.ST_STOP],
-                                                   s[cg_fused.ST_IT_DONE], expected_done))
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-
-    # ---- per-kernel attribution with HIP events on the launch stream
-    ms = (ctypes.c_float * 7)()
-    kt = max(2, min(K, 100))
-    prime()
-    _hip.check(lib.ipx_cg_iterate(L.ref(), 0, 20, st), "pre-events")
-    _hip.check(lib.ipx_cg_iterate_timed(L.ref(), 20, 20 + kt, ms, st), "timed-events")
-    fused1, fused2, fused3 = bool(L.args.A_span), bool(L.args.H_hmax), bool(L.args.At_qv)
-    names = [None if fused1 else "step1", "step1_spmv_A_r" if fused1 else "spmv_A_r",
-             "banded_solve_residual_r_minus_Atv" if fused3 else "banded_solve_with_residual",
-             None if fused3 else "spmv_r_minus_Atv", None,
-             None if fused2 else "step2", "step2_spmv_H_p" if fused2 else "spmv_H_p"]
-    per_kernel_us = {k: 1e3 * ms[i] / kt for i, k in enumerate(names) if k}
-
-    # ---- the dominant kernel on its own: K back-to-back launches of the H.p SpMV
-    # (same arguments as in the loop) between two HIP events on the launch
-    # stream.  This is the kernel's own duration, the quantity rocprofv3
-    # --kernel-trace reports; the per_kernel_us figures above additionally
-    # contain the dependency gap in front of each kernel.
-    # With a banded Hessian step2 rides inside that SpMV (k_cg_step2_hp): the fused
-    # kernel is then the dominant one and is what gets timed (mode 3 = no stop tests).
-    def dominant():
-        if fused2:
-            return lib.ipx_cg_step2_hp(L.ref(), 0, 3, st)
-        return lib.ipx_cg_hp(L.ref(), st)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    for _ in range(20):
-        dominant()
-    ev0.record()
-    for _ in range(K):
-        dominant()
-    ev1.record()
-    torch.cuda.synchronize()
-    hp_us = 1e3 * ev0.elapsed_time(ev1) / K
-
-    nnzA, nnzH = A.pattern.nnz, H.csr.pattern.nnz
-    bytes_hp = spmv_bytes(nnzH, n, n, extra_row_vectors=1)           # + diag vector
-    algo = {
-        "spmv_H_p": bytes_hp,
-        "spmv_A_r": spmv_bytes(nnzA, m, n),
-        "spmv_r_minus_Atv": spmv_bytes(nnzA, n, m, extra_row_vectors=1),
-        "step1": 5 * 8 * n,     # read x,p,r,Hp; write r
-        "step2": 5 * 8 * n,     # read x,p,g;   write x,p
-    }
-    if fused2:      # p is read once instead of twice
-        algo["step2_spmv_H_p"] = algo.pop("spmv_H_p") + algo.pop("step2") - 8 * n
-    if fused1:      # r_next is not read back by the SpMV
-        algo["step1_spmv_A_r"] = algo.pop("spmv_A_r") + algo.pop("step1") - 8 * n
-    if fused3:      # v is not read back by the SpMV
-        algo["banded_solve_residual_r_minus_Atv"] = algo.pop("spmv_r_minus_Atv") - 8 * m
-    dom = "step2_spmv_H_p" if fused2 else "spmv_H_p"
-    dom_label = ("k_cg_step2_hp (step2 fused into the H.p SpMV, p'Hp epilogue)" if fused2
-                 else "k_csr_spmv (H.p with p'Hp epilogue)")
-    achieved = algo[dom] / (hp_us * 1e-6) / 1e9
-    traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "r01i_pmc_traffic.json")
+    r1 = single_gpu_measure(A_h, H_h, hdiag_h, c_h, n, m, K, W, repeats=args.repeats)
+    A, H, c, b, Z, Y = (r1.pop(k) for k in ("A", "H", "c", "b", "Z", "Y"))
+    elapsed = r1["elapsed"]
+    traffic, traffic_src = None, None
+    pmc_path = os.path.join(ROOT, "profiles", PMC_PROFILE)
     if os.path.exists(pmc_path) and (n, m) == (1000000, 100000):
         with open(pmc_path) as f:
-            traffic = json.load(f)["kernels"].get(dom, {}).get("hbm_bytes_per_launch")
-    iter_bytes = sum(algo.values()) + 4 * 8 * m
+            pmc = json.load(f)
+        traffic = pmc["kernels"].get(r1["dom"], {}).get("hbm_bytes_per_launch")
+        traffic_src = ("STORED, not measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                       "(separate passes, FETCH x2 gfx950 correction calibrated in-run on kernels "
+                       "of known byte count) of this same command, profiles/%s, kernels at "
+                       "commit %s" % (PMC_PROFILE, pmc.get("source_commit", "?")))
     result = {
         "metric": "projected-CG iters/sec (fp64) at n=1e6,m=1e5",
-        "value": world * K / elapsed,
+        "value": K / elapsed,
         "unit": "iterations/s",
         "n_gpus": world,
         "steps": K,
@@ -331,25 +387,32 @@ def main():
         "data": "synthetic",
         "config": {"workload": "config3: sparse banded NLP subproblem, CSR Jacobian "
                                "bandwidth 15, tol=0, trust_radius=inf",
-                   "n": n, "m": m, "nnz_A": nnzA, "nnz_H": nnzH,
-                   "parallelism": "1 subproblem per GPU" if world > 1 else "single GPU"},
-        "roofline": {"bound": "hbm", "kernel": dom_label,
-                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, "
-                                       "FETCH x2 gfx950 correction calibrated in-run), "
-                                       "profiles/r01i_pmc_traffic.json",
-                     "algorithmic_bytes_per_launch": algo[dom],
-                     "avg_launch_us": hp_us,
-                     "avg_launch_us_in_loop_with_gap": per_kernel_us[dom],
-                     "method": "%d back-to-back launches between two HIP events on the "
-                               "launch stream" % K},
-        "per_kernel_us": per_kernel_us,
-        "whole_iteration": {"algorithmic_bytes": iter_bytes,
-                            "achieved_GBs": iter_bytes / (elapsed / K) / 1e9,
-                            "frac_of_hbm_peak": iter_bytes / (elapsed / K) / 1e9 / HBM_PEAK_GBS},
-        "setup_s": {"generate_host": t_gen, "factor_device": t_factor},
+                   "n": n, "m": m, "nnz_A": r1["nnzA"], "nnz_H": r1["nnzH"],
+                   "parallelism": "single GPU"},
+        "repeat": r1["repeat"],
+        "roofline": dict(r1["roofline"], traffic=traffic, traffic_source=traffic_src),
+        "per_kernel_us": r1["per_kernel_us"],
+        "whole_iteration": r1["whole_iteration"],
+        "setup_s": {"generate_host": t_gen, "factor_device": r1["t_factor"]},
     }
+
+    # ---- the same measurement past the 256 MiB Infinity Cache (working set ~480 MB): the
+    # n=1e6 working set (~120 MB) is cache resident, so its "HBM" fraction is partly an
+    # Infinity-Cache fraction; this one is not.
+    if (n, m) == (1000000, 100000) and not args.no_big:
+        nb, mb = 4000000, 400000
+        probb = CenteredBandedNLP(nb, mb, seed=0)
+        xb = probb.x0
+        vb = 0.1 * np.random.default_rng(7).standard_normal(mb)
+        rb = single_gpu_measure(probb.constr_jac(xb), probb.hess(xb), probb.kappa * probb.Wt.dot(vb),
+                                probb.grad(xb), nb, mb, K, W, repeats=args.repeats)
+        result["roofline_out_of_cache"] = dict(
+            rb["roofline"], traffic=None, n=nb, m=mb,
+            iterations_per_s=K / rb["elapsed"], ms_per_step=1e3 * rb["elapsed"] / K,
+            repeat=rb["repeat"], per_kernel_us=rb["per_kernel_us"],
+            whole_iteration=rb["whole_iteration"])
+        del rb, probb
+        torch.cuda.empty_cache()
 
     # ---- second half of the metric: wall-clock of the whole config-3 solve to
     # gtol = 1e-8 (minimize_constrained, tr_interior_point, device-callback mode:

@@ -1,0 +1,60 @@
+"""Measured deviation of the end-to-end traces from the reference's goldens (the numbers the
+tolerances in tests/test_gpu_e2e.py are set from).  Run on the GPU box:
+    python scripts/parity_report.py > gpurun_out/parity_report.json"""
+import json, os, sys, warnings
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "ip-nonlinear-solver_amd"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import numpy as np
+import ipsolver, problems
+from conftest import unjson
+from test_host_logic import run
+from banded_setup import load_synthetic
+
+gold = json.load(open(os.path.join(ROOT, "tests", "golden", "e2e.json")))
+syn = load_synthetic()
+out = {}
+
+
+def report(name, res, rows):
+    g = gold[name]
+    want = np.array([[np.nan if isinstance(v, str) and v == "nan" else v for v in r]
+                     for r in unjson(g["trace"])], dtype=float)
+    got = np.array(rows, dtype=float)
+    k = min(len(want), len(got))
+    # first row where an integer column differs
+    ints = np.all(got[:k][:, [0, 1, 7]] == want[:k][:, [0, 1, 7]], axis=1)
+    first_int = int(np.argmin(ints)) if not ints.all() else k
+    rec = {"rows": [len(got), len(want)], "int_cols_equal_rows": first_int,
+           "status": [int(res.status), g["status"]], "niter": [int(res.niter), g["niter"]],
+           "cg_niter": [int(res.cg_niter), g["cg_niter"]]}
+    for col, nm in ((2, "trust_radius"), (3, "penalty"), (4, "barrier"), (5, "optimality"),
+                    (6, "constr_violation")):
+        a, b = got[:first_int, col], want[:first_int, col]
+        ok = np.isfinite(b) & (b != 0)
+        rel = np.abs(a[ok] - b[ok]) / np.abs(b[ok])
+        rec[nm + "_max_rel"] = float(rel.max()) if rel.size else 0.0
+        # rows until the relative deviation first exceeds 1e-9
+        bad = np.flatnonzero(rel > 1e-9)
+        rec[nm + "_rows_within_1e-9"] = int(bad[0]) if bad.size else int(ok.sum())
+    gx = np.asarray(unjson(g["x"]), dtype=float)
+    x = np.asarray(res.x if not hasattr(res.x, "cpu") else res.x.cpu().numpy())
+    if x.size != gx.size:
+        x = x[::max(1, x.size // 50)]
+    rec["x_rel"] = float(np.max(np.abs(x - gx)) / np.max(np.abs(gx)))
+    out[name] = rec
+
+
+warnings.simplefilter("ignore")
+for p in problems.exact_hessian_problems() + problems.fd_hessian_problems():
+    res, rows = run(p.fun, p.x0, p.grad, p.hess_arg(), p.constraints(ipsolver))
+    report(p.name, res, rows)
+prob = syn.CenteredBandedNLP(2000, 200, eps=1e-3)
+for method in ("tr_interior_point", "equality_constrained_sqp"):
+    res, rows = run(prob.fun, prob.x0, prob.grad, prob.hess, prob.constraints(ipsolver), method=method)
+    report("banded_eq_n2000_%s" % method, res, rows)
+prob = syn.CenteredBandedNLP(400, 40, eps=1.0)
+cons = (prob.constraints(ipsolver, ("less", 0.0)), ipsolver.BoxConstraint(("interval", -0.8, 0.8)))
+res, rows = run(prob.fun, prob.x0, prob.grad, prob.hess, cons)
+report("banded_ineq_n400", res, rows)
+print(json.dumps(out, indent=1))
