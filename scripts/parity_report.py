@@ -42,6 +42,7 @@ def report(name, res, rows):
     if x.size != gx.size:
         x = x[::max(1, x.size // 50)]
     rec["x_rel"] = float(np.max(np.abs(x - gx)) / np.max(np.abs(gx)))
+    rec["rows_raw"] = [[float(v) for v in r] for r in rows]
     out[name] = rec
 
 

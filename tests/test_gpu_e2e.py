@@ -9,24 +9,11 @@ import ipsolver
 import problems
 from banded_setup import load_synthetic
 from conftest import unjson
-from test_host_logic import run, compare
+from test_host_logic import run, compare, trace_policy
 
 pytestmark = pytest.mark.gpu
 
 ALL = problems.exact_hessian_problems() + problems.fd_hessian_problems()
-
-
-def trace_policy(name):
-    """(rtol, prefix) of the trace comparison.  Exact-Hessian problems follow
-    the reference's whole trace.  Finite-difference Hessians amplify last-bit
-    differences of p by 1/h ~ 1e8 in every H.p, and elec runs hundreds of CG
-    iterations, so those traces agree on a prefix and then take different
-    (equally valid) paths to the same solution."""
-    if "_fd" in name:
-        return 1e-4, 8
-    if name.startswith("elec"):
-        return 1e-6, 25
-    return 1e-6, None
 
 
 @pytest.mark.parametrize("prob", ALL, ids=[p.name for p in ALL])
@@ -37,8 +24,7 @@ def test_textbook_problems(prob, e2e_golden):
     if prob.x_opt is not None:
         np.testing.assert_array_almost_equal(res.x, prob.x_opt, decimal=5)
     assert res.optimality < 1e-8 and res.constr_violation < 1e-8
-    rtol, prefix = trace_policy(prob.name)
-    compare(res, rows, gold, rtol=rtol, prefix=prefix)
+    compare(res, rows, gold, **trace_policy(prob.name))
 
 
 def test_readme_example():
@@ -54,7 +40,7 @@ def test_banded_equality_nlp(method, e2e_golden):
     prob = syn.CenteredBandedNLP(2000, 200, eps=1e-3)
     res, rows = run(prob.fun, prob.x0, prob.grad, prob.hess, prob.constraints(ipsolver),
                     method=method)
-    compare(res, rows, e2e_golden["banded_eq_n2000_%s" % method], rtol=1e-6)
+    compare(res, rows, e2e_golden["banded_eq_n2000_%s" % method])
 
 
 def test_banded_box_inequality_nlp(e2e_golden):
@@ -65,7 +51,7 @@ def test_banded_box_inequality_nlp(e2e_golden):
     res, rows = run(prob.fun, prob.x0, prob.grad, prob.hess, cons)
     gold = e2e_golden["banded_ineq_n400"]
     assert res.status == gold["status"]
-    compare(res, rows, gold, rtol=1e-6, prefix=16)     # see test_host_logic for the prefix
+    compare(res, rows, gold, prefix=16)     # see test_host_logic for the prefix
     gx = np.asarray(unjson(gold["x"]))
     assert np.allclose(np.asarray(res.x)[::max(1, 400 // 50)], gx, atol=1e-5)
 
@@ -82,7 +68,7 @@ def test_dense_equality_qp(e2e_golden):
                     lambda x: Hd.dot(x) + c, lambda x: Hd,
                     ipsolver.LinearConstraint(A, ("equals", bq)),
                     method="equality_constrained_sqp")
-    compare(res, rows, e2e_golden["dense_eq_qp_n60"], rtol=1e-6, prefix=12)
+    compare(res, rows, e2e_golden["dense_eq_qp_n60"], prefix=12)
 
 
 def test_product_never_imports_the_oracle():
@@ -120,7 +106,7 @@ def test_device_callbacks_banded_equality(method, e2e_golden):
     assert torch.is_tensor(res.x) and res.x.is_cuda
     gold = e2e_golden["banded_eq_n2000_%s" % method]
     res.x = res.x.cpu().numpy()
-    compare(res, rows, gold, rtol=1e-6)
+    compare(res, rows, gold)
 
 
 @pytest.mark.parametrize("fd", ["2-point", "3-point"])
@@ -172,7 +158,7 @@ def test_device_finite_difference_hessians_vs_reference(cls, name, fd, tag, e2e_
     assert res.optimality < 1e-8 and res.constr_violation < 1e-8
     # same policy as the host finite-difference runs (trace_policy): a prefix of the trace,
     # then the solution; differences of gradients amplify last-bit noise by 1/h ~ 1e8
-    compare(res, rows, gold, rtol=1e-4, prefix=8)
+    compare(res, rows, gold, rtol=1e-6, prefix=8)
     assert abs(res.niter - gold["niter"]) <= 2 and abs(res.cg_niter - gold["cg_niter"]) <= 2
     np.testing.assert_allclose(res.x.cpu().numpy(), unjson(gold["x"]), rtol=1e-6, atol=1e-7)
 
@@ -188,7 +174,7 @@ def test_device_callbacks_box_inequality(e2e_golden):
     res, rows = run(dc.fun, dc.x0, dc.grad, dc.hess, cons)
     gold = e2e_golden["banded_ineq_n400"]
     assert res.status == gold["status"]
-    compare(res, rows, gold, rtol=1e-6, prefix=12)
+    compare(res, rows, gold, prefix=12)
     gx = np.asarray(unjson(gold["x"]))
     assert np.allclose(res.x.cpu().numpy()[::max(1, 400 // 50)], gx, atol=1e-5)
     assert res.s.shape[0] == 840 and res.s.is_cuda
