@@ -278,6 +278,23 @@ typedef struct ipx_shard_ext {
 int ipx_cg_shard_segment(const ipx_cg_args *a, ipx_shard_ext *e, int32_t phase, int32_t it,
                          void *stream);
 /* The fused step2 + H.p launch alone (needs pb / H_hmax in the argument block). */
+/* ---- partitioned row-sharded loop (ipsolver/sharded.py FusedShardedCG; replaces the
+ * per-iteration body of qp_subproblem.py:549-634 on one rank of a node).  `a` describes the
+ * rank's extended local problem (own rows / variables + halo copies); the scalars travel
+ * through two all-reduced device buffers.  Ranges are in units of the partial arrays'
+ * entries (row tiles / solve workgroups) and select the rank's OWN part. */
+typedef struct ipx_shard2_ext {
+  double *s1;              /* [2]  s1[1] = p'Hp (own sum, then all-reduced) */
+  double *pack;            /* [4]  ||x+ap||^2, #violations, ||g||^2, ||A g||^2 */
+  int64_t p1_lo, p1_hi;    /* own row tiles of H               (part1) */
+  int64_t p2_lo, p2_hi;    /* own entries of part2 (row tiles of A with the fused step1) */
+  int64_t p3_lo, p3_hi;    /* own entries of part3 (||g||^2 partials) */
+  int64_t p4_lo, p4_hi;    /* own entries of part4 (||w - (AA')v||^2 partials) */
+  int64_t own_lo, own_hi;  /* own variables, local indices (reduction range of step1) */
+} ipx_shard2_ext;
+int ipx_cg_shard2_segment(const ipx_cg_args *a, const ipx_shard2_ext *e, int32_t phase,
+                          int32_t it, int32_t mode, void *stream);
+int ipx_cg_shard2_fold_hp(const ipx_cg_args *a, const ipx_shard2_ext *e, void *stream);
 int ipx_cg_step2_hp(const ipx_cg_args *a, int32_t it, int32_t mode, void *stream);
 /* Finish iteration `it` after the host handled a stop-5/6 event. */
 int ipx_cg_resume(const ipx_cg_args *a, int32_t it, int32_t mode, void *stream);

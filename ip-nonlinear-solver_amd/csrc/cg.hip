@@ -59,7 +59,11 @@ __global__ void __launch_bounds__(VB)
 k_cg_step1(int64_t n, double *st, int parity, const double *__restrict__ p1, int np1,
            const double *__restrict__ x, const double *__restrict__ p, double *r,
            const double *__restrict__ Hp, const double *__restrict__ lb,
-           const double *__restrict__ ub, double *__restrict__ p2, int nchunks) {
+           const double *__restrict__ ub, double *__restrict__ p2, int nchunks,
+           int64_t red_lo, int64_t red_hi) {
+  // [red_lo, red_hi): the elements that count in ||x + alpha p||^2 and the box test (all of
+  // them on one GPU; a rank's own variables in the row-sharded loop, whose halo copies are
+  // updated by the same launch)
   __shared__ double lds[VB / IPX_WAVE];
   // chunk c of nchunks: a contiguous run of elements, owned by a fixed XCD
   const int c = ipx_xcd_item(blockIdx.x, nchunks);
@@ -107,8 +111,10 @@ k_cg_step1(int64_t n, double *st, int parity, const double *__restrict__ p1, int
       const int64_t i = i0 + u * VB;
       if (i < hi_i) {
         const double xn = xv[u] + alpha * pv[u];     // :580 (not stored)
-        sx += xn * xn;
-        if (lb) viol += ((lo[u] <= xn) && (xn <= hi[u])) ? 0.0 : 1.0;   // :599
+        if (i >= red_lo && i < red_hi) {
+          sx += xn * xn;
+          if (lb) viol += ((lo[u] <= xn) && (xn <= hi[u])) ? 0.0 : 1.0;   // :599
+        }
         r[i] = rv[u] + alpha * hv[u];                // :622
       }
     }
@@ -633,6 +639,24 @@ k_cg_shard_pack(const double *__restrict__ p2, int np2, const double *__restrict
   }
 }
 
+// Partitioned row-sharded loop (ipsolver/sharded.py): up to four sub-ranges of partial
+// arrays -- the entries produced by a rank's OWN tiles / workgroups -- summed in a fixed
+// order into out[0..4): the rank's contribution to an all-reduce.
+struct RangeJob {
+  const double *ptr[4];   // readable even where count is 0
+  int count[4];
+  int active;             // bit q: out[q] is written
+};
+
+__global__ void __launch_bounds__(256)
+k_cg_range_pack(RangeJob job, double *__restrict__ out, const double *__restrict__ guard) {
+  __shared__ double lds[4 * 4];
+  if (guard && *guard != 0.0) return;
+  double red[4];
+  ipx_sum_partials_multi<4>(job.ptr, job.count, lds, red);
+  if (threadIdx.x < 4 && ((job.active >> threadIdx.x) & 1)) out[threadIdx.x] = red[threadIdx.x];
+}
+
 // p = beta p - g on the halo copies of the neighbours' boundary entries: the
 // same expression k_cg_step2 applies to the owned entries, so owner and copy
 // stay bit-identical.  No-op unless step2 completed its update.
@@ -791,7 +815,7 @@ int ipx_cg_step1(int64_t n, double *state, int32_t it, const double *p1, int32_t
                  const double *ub, double *part2, int32_t grid, void *stream) {
   if (n < 0 || !state || !p1 || !part2 || grid < 1) return IPX_EINVAL;
   hipLaunchKernelGGL(k_cg_step1, dim3(ipx_xcd_grid(grid)), dim3(VB), 0, (hipStream_t)stream, n,
-                     state, it & 1, p1, np1, x, p, r, Hp, lb, ub, part2, grid);
+                     state, it & 1, p1, np1, x, p, r, Hp, lb, ub, part2, grid, (int64_t)0, n);
   IPX_CHECK_LAUNCH();
   return IPX_OK;
 }
@@ -895,6 +919,101 @@ int ipx_cg_shard_segment(const ipx_cg_args *a, ipx_shard_ext *e, int32_t phase, 
                        a->p);
   if (rc) return rc;
   return ipx_fold2(a->part1, (int)a->H_ntiles, e->s1, nullptr, stream);
+}
+
+// One local segment of an iteration of the PARTITIONED row-sharded loop (ipsolver/sharded.py
+// FusedShardedCG).  The argument block describes the rank's extended local problem (own
+// rows / variables plus halo copies): the kernels are those of the single-GPU loop; what is
+// specific is (a) their reduction inputs are the all-reduced scalars (e->s1, e->pack, one
+// entry each) instead of the predecessor's partial arrays, and (b) the partials they leave
+// are summed over the rank's own tiles only.
+//   phase 0 (after the all-reduce of s1): step1 (+ A.r), solve (+ g = r - A'v), own sums of
+//           ||x+ap||^2, #violations, ||g||^2, ||A g||^2 -> e->pack[0..4)
+//   phase 1 (after the all-reduce of pack and the halo exchange of g): step2 (+ H.p),
+//           own sum of p'Hp -> e->s1[1]
+int ipx_cg_shard2_segment(const ipx_cg_args *a, const ipx_shard2_ext *e, int32_t phase,
+                          int32_t it, int32_t mode, void *stream) {
+  if (!a || !e || phase < 0 || phase > 1 || !e->s1 || !e->pack || a->solver_kind != 0)
+    return IPX_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const double *guard = a->state + ST_STOP;
+  const int grid = (int)a->vec_grid;
+  int rc = IPX_OK;
+  if (phase == 0) {
+    const bool fuse1 = fused_ar(a);
+    if (fuse1) {
+      rc = launch_step1_ar(a, it, e->s1, 1, st);
+      if (rc) return rc;
+    } else {
+      hipLaunchKernelGGL(k_cg_step1, dim3(ipx_xcd_grid(grid)), dim3(VB), 0, st, a->n, a->state,
+                         it & 1, e->s1, 1, a->x, a->p, a->r, a->Hp, a->lb, a->ub, a->part2, grid,
+                         e->own_lo, e->own_hi);
+      IPX_CHECK_LAUNCH();
+      ipx_csr_view A{(int)a->m, (int)a->n, a->A_rowptr, a->A_colidx, a->A_val, a->A_tiles,
+                     (int)a->A_ntiles};
+      rc = ipx_spmv_launch(A, a->r, 1.0, nullptr, 0.0, nullptr, a->w, nullptr, guard, st);
+      if (rc) return rc;
+    }
+    int np4 = 0, np3 = (int)a->At_ntiles;
+    const double *r_in = fuse1 ? a->r_next : a->r;
+    if (a->At_vown && a->At_qv > 0) {
+      rc = ipx_banded_solve_resid_atv_launch(a->banded, a->w, a->v, a->part4, &np4, a->At_rowptr,
+                                             a->At_colidx, a->At_val, r_in, a->r, a->At_vown,
+                                             (int)a->At_qv, a->part3, guard, st);
+      if (rc) return rc;
+      np3 = np4;
+    } else {
+      rc = ipx_banded_solve_resid_launch(a->banded, a->w, a->v, a->part4, &np4, guard, st);
+      if (rc) return rc;
+      ipx_csr_view At{(int)a->n, (int)a->m, a->At_rowptr, a->At_colidx, a->At_val, a->At_tiles,
+                      (int)a->At_ntiles};
+      rc = ipx_spmv_launch(At, a->v, -1.0, nullptr, 1.0, r_in, a->r, a->part3, guard, st);
+      if (rc) return rc;
+    }
+    if (e->p4_hi > np4 || e->p3_hi > np3 || e->p2_hi > part2_count(a)) return IPX_EINVAL;
+    const int np2 = part2_count(a);
+    RangeJob job;
+    job.ptr[0] = a->part2 + e->p2_lo;        job.count[0] = (int)(e->p2_hi - e->p2_lo);
+    job.ptr[1] = a->part2 + np2 + e->p2_lo;  job.count[1] = (int)(e->p2_hi - e->p2_lo);
+    job.ptr[2] = a->part3 + e->p3_lo;        job.count[2] = (int)(e->p3_hi - e->p3_lo);
+    job.ptr[3] = a->part4 + e->p4_lo;        job.count[3] = (int)(e->p4_hi - e->p4_lo);
+    job.active = 15;
+    hipLaunchKernelGGL(k_cg_range_pack, dim3(1), dim3(256), 0, st, job, e->pack, guard);
+    IPX_CHECK_LAUNCH();
+    return IPX_OK;
+  }
+  // phase 1
+  if (fused_hp(a)) {
+    rc = launch_step2_hp(a, it, mode, e->pack, 1, e->pack + 2, 1, e->pack + 3, 1, st);
+  } else {
+    hipLaunchKernelGGL(k_cg_step2, dim3(ipx_xcd_grid(grid)), dim3(VB), 0, st, a->n, a->state,
+                       it & 1, mode, e->pack, 1, e->pack + 2, 1, e->pack + 3, 1, a->x, a->p, a->r,
+                       grid, HaloJob{});
+    IPX_CHECK_LAUNCH();
+    rc = launch_hp(a, guard, st);
+  }
+  if (rc) return rc;
+  if (e->p1_hi > a->H_ntiles) return IPX_EINVAL;
+  RangeJob job;
+  for (int q = 0; q < 4; ++q) { job.ptr[q] = a->part1; job.count[q] = 0; }
+  job.ptr[1] = a->part1 + a->H_ntiles + e->p1_lo;  job.count[1] = (int)(e->p1_hi - e->p1_lo);
+  job.active = 2;
+  hipLaunchKernelGGL(k_cg_range_pack, dim3(1), dim3(256), 0, st, job, e->s1, guard);
+  IPX_CHECK_LAUNCH();
+  return IPX_OK;
+}
+
+// The own-range sum of the p'Hp partials on its own (priming the sharded loop).
+int ipx_cg_shard2_fold_hp(const ipx_cg_args *a, const ipx_shard2_ext *e, void *stream) {
+  if (!a || !e || !e->s1 || e->p1_hi > a->H_ntiles) return IPX_EINVAL;
+  RangeJob job;
+  for (int q = 0; q < 4; ++q) { job.ptr[q] = a->part1; job.count[q] = 0; }
+  job.ptr[1] = a->part1 + a->H_ntiles + e->p1_lo;  job.count[1] = (int)(e->p1_hi - e->p1_lo);
+  job.active = 2;
+  hipLaunchKernelGGL(k_cg_range_pack, dim3(1), dim3(256), 0, (hipStream_t)stream, job, e->s1,
+                     (const double *)nullptr);
+  IPX_CHECK_LAUNCH();
+  return IPX_OK;
 }
 
 // Hp = H p with p'Hp partials (the tail of an iteration, also used once by
@@ -1035,7 +1154,7 @@ static int cg_iterate(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, hi
     } else {
       hipLaunchKernelGGL(k_cg_step1, dim3(ipx_xcd_grid((int)a->vec_grid)), dim3(VB), 0, st, a->n,
                          a->state, it & 1, p1, np1, a->x, a->p, a->r,
-                         a->Hp, a->lb, a->ub, a->part2, (int)a->vec_grid);
+                         a->Hp, a->lb, a->ub, a->part2, (int)a->vec_grid, (int64_t)0, a->n);
       IPX_CHECK_LAUNCH();
       MARK(1);
     }

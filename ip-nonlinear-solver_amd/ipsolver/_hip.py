@@ -68,6 +68,8 @@ _SIGNATURES = {
     "ipx_cg_step2_hp": [_P, _I32, _I32, _P],
     "ipx_cg_shard_segment": [_P, _P, _I32, _I32, _P],
     "ipx_cg_halo_apply": [_P, _I32, _I32, _P, _P, _P, _P, _P],
+    "ipx_cg_shard2_segment": [_P, _P, _I32, _I32, _I32, _P],
+    "ipx_cg_shard2_fold_hp": [_P, _P, _P],
     "ipx_aat_band": [_I64, _I32, _P, _P, _P, _P, _P, _P],
     "ipx_aat_band_w": [_I64, _I32, _P, _P, _P, _P, _P, _P, _P],
     "ipx_pairs_factor": [_I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],

@@ -105,6 +105,12 @@ class DVec:
     def copy(self):
         return DVec(self.t.clone())
 
+    def zeros_like(self):
+        return DVec.zeros(len(self))
+
+    def full_like(self, value):
+        return DVec.full(len(self), value)
+
     def __len__(self):
         return self.t.numel()
 
@@ -191,12 +197,16 @@ def norm_inf(v):
 
 
 def clip(x, lb, ub):
+    if not isinstance(x, DVec):          # distributed vectors (sharded.ShardVec) bring their own
+        return x._clip(lb, ub)
     out = _empty(len(x))
     _hip.call("ipx_clip", len(x), _p(x.t), _p(lb.t), _p(ub.t), _p(out), stream_ptr())
     return DVec(out)
 
 
 def count_outside_box(x, lb, ub):
+    if not isinstance(x, DVec):
+        return x._count_outside_box(lb, ub)
     c = ctx()
     _hip.call("ipx_box_inside", len(x), _p(x.t), _p(lb.t), _p(ub.t), _p(c.out), _p(c.ws),
               stream_ptr())
@@ -204,6 +214,8 @@ def count_outside_box(x, lb, ub):
 
 
 def box_sphere_reduce(z, d, dscale, lb, ub):
+    if not isinstance(z, DVec):
+        return z._box_sphere_reduce(d, dscale, lb, ub)
     c = ctx()
     _hip.call("ipx_box_sphere_reduce", len(z), _p(z.t), _p(d.t), float(dscale),
               _p(lb.t) if lb is not None else None, _p(ub.t) if ub is not None else None,
@@ -216,7 +228,21 @@ def hstack(parts):
 
 
 # ---------------------------------------------------------------------------
-def _tiles_for(rowptr_host, tile_nnz=_hip.SPMV_TILE_NNZ, max_rows=1024):
+def _tiles_for(rowptr_host, tile_nnz=_hip.SPMV_TILE_NNZ, max_rows=1024, row_breaks=None):
+    """SpMV row tiles: row boundaries, then rowptr at them.  ``row_breaks`` forces tile
+    boundaries at the given rows (the sharded loop sums per-tile partials over a rank's own
+    rows only, so own / halo rows must not share a tile)."""
+    if row_breaks is not None and len(row_breaks):
+        rp = np.ascontiguousarray(rowptr_host, dtype=np.int64)
+        cuts = sorted(set([0, len(rp) - 1] + [int(b) for b in row_breaks if 0 < b < len(rp) - 1]))
+        bounds = []
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            t = _tiles_for((rp[a:b + 1] - rp[a]).astype(np.int32), tile_nnz, max_rows)
+            k = len(t) // 2
+            bounds.extend(int(v) + a for v in t[:k - 1])
+        bounds.append(len(rp) - 1)
+        rows = np.array(bounds, dtype=np.int64)
+        return np.concatenate((rows, rp[rows])).astype(np.int32)
     nrows = len(rowptr_host) - 1
     cap = 2 * (nrows + 2)
     tiles = np.empty(cap, dtype=np.int32)
@@ -231,7 +257,7 @@ class CSRPattern:
     lazily built transpose.  Patterns are immutable and shared by every value
     refresh of a Jacobian/Hessian (hard part 7)."""
 
-    def __init__(self, indptr, indices, shape):
+    def __init__(self, indptr, indices, shape, row_breaks=None):
         _require_gpu()
         self.shape = (int(shape[0]), int(shape[1]))
         self.indptr_h = np.ascontiguousarray(indptr, dtype=np.int32)
@@ -239,7 +265,7 @@ class CSRPattern:
         dev = ctx().device
         self.indptr = torch.from_numpy(self.indptr_h).to(dev)
         self.indices = torch.from_numpy(self.indices_h).to(dev)
-        tiles = _tiles_for(self.indptr_h)
+        tiles = _tiles_for(self.indptr_h, row_breaks=row_breaks)
         self.ntiles = len(tiles) // 2 - 1
         self.tiles_h = tiles
         self.tiles = torch.from_numpy(tiles).to(dev)
@@ -251,7 +277,16 @@ class CSRPattern:
                 and np.array_equal(indptr, self.indptr_h)
                 and np.array_equal(indices, self.indices_h))
 
-    def transpose(self):
+    def tile_range(self, row_lo, row_hi):
+        """Tiles covering exactly rows [row_lo, row_hi) (both must be tile boundaries)."""
+        b = self.tiles_h[:self.ntiles + 1]
+        t0, t1 = int(np.searchsorted(b, row_lo)), int(np.searchsorted(b, row_hi))
+        if b[t0] != row_lo or b[t1] != row_hi:
+            raise ValueError("rows [%d, %d) do not start / end on tile boundaries"
+                             % (row_lo, row_hi))
+        return t0, t1
+
+    def transpose(self, row_breaks=None):
         """(pattern of A', permutation with valT = val[perm]) -- symbolic, once."""
         if self._transpose is None:
             import scipy.sparse as sps
@@ -261,7 +296,7 @@ class CSRPattern:
             t = sps.csr_matrix(tag.T)
             t.sort_indices()
             perm = (t.data - 1).astype(np.int64)
-            pat = CSRPattern(t.indptr, t.indices, (n, m))
+            pat = CSRPattern(t.indptr, t.indices, (n, m), row_breaks=row_breaks)
             self._transpose = (pat, torch.from_numpy(perm).to(ctx().device))
         return self._transpose
 
@@ -277,13 +312,13 @@ class DeviceCSR:
         self._T = None
 
     @staticmethod
-    def from_scipy(M, pattern=None):
+    def from_scipy(M, pattern=None, row_breaks=None):
         import scipy.sparse as sps
         M = sps.csr_matrix(M)
         if not M.has_sorted_indices:
             M = M.sorted_indices()
         if pattern is None or not pattern.same_as(M.indptr, M.indices):
-            pattern = CSRPattern(M.indptr, M.indices, M.shape)
+            pattern = CSRPattern(M.indptr, M.indices, M.shape, row_breaks=row_breaks)
         val = torch.from_numpy(np.ascontiguousarray(M.data, dtype=np.float64)).to(ctx().device)
         return DeviceCSR(pattern, val)
 

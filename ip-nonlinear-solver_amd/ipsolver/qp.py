@@ -29,7 +29,8 @@ _INF = float("inf")
 
 
 def _vec(x):
-    return x if isinstance(x, DVec) else DVec.from_host(x)
+    # DVec, or a distributed vector with the same surface (sharded.ShardVec)
+    return x if hasattr(x, "sumsq_amax") else DVec.from_host(x)
 
 
 def _optvec(x):
@@ -130,18 +131,17 @@ def modified_dogleg(A, Y, b, trust_radius, lb, ub):
     """Reference: qp_subproblem.py:320-413."""
     b = _vec(b)
     lb, ub = _optvec(lb), _optvec(ub)       # None = no bound on that side
-    if (lb is None) != (ub is None):
-        n = A.shape[1]
-        lb = lb if lb is not None else _full(n, -_INF)
-        ub = ub if ub is not None else _full(n, _INF)
     newton = -Y.dot(b)
+    if (lb is None) != (ub is None):
+        lb = lb if lb is not None else newton.full_like(-_INF)
+        ub = ub if ub is not None else newton.full_like(_INF)
     if inside_box_boundaries(newton, lb, ub) and dv.norm(newton) <= trust_radius:
         return newton
 
     g = A.T.dot(b)
     Ag = A.dot(g)
     cauchy = (-g.dot(g) / Ag.dot(Ag)) * g
-    origin = DVec.zeros(len(cauchy))
+    origin = cauchy.zeros_like()
 
     step = newton - cauchy
     _, alpha, hit = box_sphere_intersections(cauchy, step, lb, ub, trust_radius)
@@ -168,11 +168,16 @@ def projected_cg(H, c, Z, Y, b, trust_radius=np.inf, lb=None, ub=None, tol=None,
     if not return_all and cg_fused.supports(H, Z, Y):
         return cg_fused.projected_cg(H, c, Z, Y, b, trust_radius, lb, ub, tol,
                                      max_iter, max_infeasible_iter)
+    if not return_all and getattr(getattr(Z, "projector", None), "fused_sharded", False):
+        from . import sharded            # the device-resident loop of the row-sharded solver
+        if sharded.fused_supports(H, Z, Y):
+            return sharded.fused_projected_cg(H, c, Z, Y, b, trust_radius, lb, ub, tol,
+                                              max_iter, max_infeasible_iter)
     n, m = len(c), len(b)
     has_box = lb is not None or ub is not None
     if has_box:
-        lb = lb if lb is not None else _full(n, -_INF)
-        ub = ub if ub is not None else _full(n, _INF)
+        lb = lb if lb is not None else c.full_like(-_INF)
+        ub = ub if ub is not None else c.full_like(_INF)
 
     x = Y.dot(-b)                                        # :502-505
     r = Z.dot(H.dot(x) + c)
@@ -203,7 +208,7 @@ def projected_cg(H, c, Z, Y, b, trust_radius=np.inf, lb=None, ub=None, tol=None,
     hits_boundary = False
     stop_cond = 1
     counter = 0
-    last_feasible_x = DVec.zeros(n)     # reference: np.empty_like (:547)
+    last_feasible_x = c.zeros_like()    # reference: np.empty_like (:547)
     k = 0
     for _ in range(max_iter):
         if rt_g < tol:                                   # :551

@@ -1,31 +1,44 @@
-"""Row-sharded projected CG across the GPUs of one node (BASELINE config 4).
+"""Row-partitioned trust-region subproblem solver across the GPUs of one node
+(BASELINE configs 4 and 5).
 
 One process per GPU (``torch.distributed``; backend "nccl" = RCCL over xGMI).
-Partition:
 
-* z-space vectors x, p, r, H p are split into contiguous variable blocks, one per
-  rank; rank g owns the columns ``A[:, n0:n1]`` of the Jacobian, the matching
-  rows of ``A'`` and the rows ``H[n0:n1, :]`` of the Hessian (its few
-  off-block columns are served from halo copies of the neighbours' boundary
-  entries of p);
-* constraint-space vectors (length m = n/10) and the banded ``(A A')^-1``
-  factorization are replicated: ``w = A r`` is formed as per-rank partial
-  products summed by ONE all-reduce (0.8 MB at m = 1e5), after which every rank
-  solves the same banded system and applies its own rows of ``A'``.  The
-  orthogonality test uses the constraint-space residual ``||w - (AA')v||``
-  (DESIGN.md section 4), which is replicated as well and needs no collective.
+Partition.  The constraint rows are cut into blocks of ``row_block`` rows (the rows one
+workgroup of the single-launch banded solve owns, csrc/banded.hip) and every rank gets a
+contiguous run of blocks together with the variables those rows bring in: rank g owns the
+rows ``[R0, R1)`` and the variables from the first column of row ``R0`` up to the first
+column of the next rank's first row -- BOTH spaces are partitioned, nothing is replicated.
+Next to what it owns a rank keeps HALO copies: one block of rows on either side and the
+variables those rows touch.  Its local problem -- rows ``E = own + halo rows`` of the
+Jacobian (complete rows), the matching rows of ``A'`` and of the Hessian -- is an ordinary
+banded problem, so every local operation is the single-GPU kernel (or, in the tests, its
+numpy restatement) on the extended local arrays:
 
-Collectives per CG iteration: THREE all-reduces and nothing else --
-``p'Hp`` (2 doubles); the partial ``A r`` vector; one packed buffer with
-``||x+ap||^2, #violations, ||g||^2`` and every rank's boundary entries of g.
-The halo copies of p are then advanced locally with the same ``beta p - g``
-the owner applies (bit-identical), so there is no neighbour exchange.  The
-reduced scalars are bit-identical on every rank, so the device-side branches of
-``csrc/cg.hip`` take the same way everywhere and no rank needs the host.
+* elementwise operations act on own + halo entries alike and keep the copies consistent;
+* ``A x`` is exact on every local row (rows are complete);
+* ``A'v``, ``H p`` and ``(A A')^-1 w`` are exact on the own entries and wrong only near the
+  far ends of the halo: ``(A A')^-1`` of the banded benchmark decays geometrically (what the
+  decoupled single-launch solve relies on, checked numerically at every factorization,
+  DESIGN.md section 4), so truncating the system one block (260 rows) away changes an own
+  entry by less than 2^-56 of its size; the wrong halo entries are then overwritten by the
+  owners' values in a neighbour exchange.
 
-The orchestration below is engine-agnostic: ``HipEngine`` runs the ipx
-kernels; the test-suite runs the same code over gloo with the oracle's numpy
-engine (tests/test_sharded_gloo.py).
+Communication per projected-CG iteration of the device-resident loop
+(``FusedShardedCG``): TWO small all-reduces (``p'Hp``; then ``||x+ap||^2``, the box
+violation count, ``||g||^2``, ``||A g||^2`` packed in 4 doubles) and ONE neighbour
+exchange of the halo of ``g`` (point-to-point, at most a block's columns per side,
+overlapping the second all-reduce).  The reduced scalars are bit-identical on every rank,
+so the device-side branches of csrc/cg.hip go the same way everywhere.
+
+``ShardVec`` has the surface of ``device.DVec`` (arithmetic, ``dot``, ``sumsq_amax`` ...),
+with reductions summed over the ranks, so the reference's algorithms in ``qp.py``
+(projected CG with its box / trust-region / negative-curvature logic, modified dogleg,
+intersections: qp_subproblem.py:66-643) and the outer loops ``sqp.py`` / ``barrier.py``
+run on distributed vectors unchanged (``backend_sharded``).
+
+Local arithmetic goes through a small ``ops`` object: ``HipOps`` (ipx kernels; the product)
+or the numpy twin in ``oracle/numpy_local.py`` that lets tests/test_sharded_gloo.py run the
+same orchestration over gloo on CPUs.
 """
 import ctypes
 
@@ -34,435 +47,786 @@ import scipy.sparse as sps
 import torch
 import torch.distributed as dist
 
-ST_RTG0, ST_RTG1, ST_TOL, ST_RADIUS, ST_ALPHA, ST_STOP, ST_NITER, ST_BETA = range(8)
-ST_PTHP, ST_ORTH_RHS, ST_XNORM2, ST_VIOL, ST_ORTH, ST_IT_DONE = 8, 9, 10, 11, 12, 13
-STATE_SIZE = 16
+ROW_BLOCK = 260          # DEC_CHUNKS * (chunk + k) of csrc/banded.hip for k = 1, chunk = 64
 
 
-class ShardExt(ctypes.Structure):
-    """Mirror of ipx_shard_ext (include/ipx.h)."""
-    _fields_ = [("p_ext", ctypes.c_void_p)] + \
-               [(k, ctypes.c_int64) for k in ("hl", "hr", "h", "rank", "world")] + \
-               [("s1", ctypes.c_void_p), ("pack", ctypes.c_void_p), ("np4", ctypes.c_int64)]
+# --------------------------------------------------------------------------- layout
+class ShardLayout:
+    """Symbolic partition of a Jacobian pattern (CSR, sorted, first column of a row
+    non-decreasing: every banded Jacobian) over ``world`` ranks.  Computed identically on
+    every rank from the global pattern."""
+
+    def __init__(self, indptr, indices, shape, world, rank, row_block=ROW_BLOCK, halo_blocks=1):
+        m, n = int(shape[0]), int(shape[1])
+        indptr = np.asarray(indptr, dtype=np.int64)
+        indices = np.asarray(indices, dtype=np.int64)
+        if m == 0 or np.any(np.diff(indptr) == 0):
+            raise NotImplementedError("row sharding needs a Jacobian without empty rows")
+        first = indices[indptr[:-1]]
+        last = np.maximum.reduceat(indices, indptr[:-1])
+        if np.any(np.diff(first) < 0) or np.any(np.diff(last) < 0):
+            raise NotImplementedError("row sharding needs a banded Jacobian (first and last "
+                                      "column non-decreasing from row to row)")
+        nb = (m + row_block - 1) // row_block
+        if nb < world:
+            raise ValueError("%d constraint rows give %d blocks of %d: too few for %d ranks"
+                             % (m, nb, row_block, world))
+        self.m, self.n, self.world, self.rank = m, n, world, rank
+        self.row_block, self.halo_rows = row_block, halo_blocks * row_block
+        R = [min(m, ((r * nb) // world) * row_block) for r in range(world)] + [m]
+        C = [0] + [int(first[R[r]]) for r in range(1, world)] + [n]
+        self.row_cuts, self.col_cuts = R, C
+        self.ranks = []
+        for r in range(world):
+            E0 = max(0, R[r] - self.halo_rows)
+            E1 = min(m, R[r + 1] + self.halo_rows)
+            x0 = 0 if r == 0 else min(C[r], int(first[E0]))
+            x1 = n if r == world - 1 else max(C[r + 1], int(last[E1 - 1]) + 1)
+            self.ranks.append(dict(R0=R[r], R1=R[r + 1], E0=E0, E1=E1, c0=C[r], c1=C[r + 1],
+                                   x0=x0, x1=x1))
+        for r in range(world):
+            me = self.ranks[r]
+            if r > 0:
+                le = self.ranks[r - 1]
+                if me["x0"] < le["c0"] or me["E0"] < le["R0"]:
+                    raise ValueError("halo of rank %d reaches beyond its neighbour: fewer "
+                                     "ranks or a larger problem" % r)
+            if r < world - 1:
+                ri = self.ranks[r + 1]
+                if me["x1"] > ri["c1"] or me["E1"] > ri["R1"]:
+                    raise ValueError("halo of rank %d reaches beyond its neighbour: fewer "
+                                     "ranks or a larger problem" % r)
+        self.me = self.ranks[rank]
+
+    def geom(self, kind, rank=None):
+        """(global start of the local array, local length, own_lo, own_hi) for
+        ``kind`` = "col" (variables) / "row" (constraints)."""
+        d = self.ranks[self.rank if rank is None else rank]
+        if kind == "col":
+            return d["x0"], d["x1"] - d["x0"], d["c0"] - d["x0"], d["c1"] - d["x0"]
+        return d["E0"], d["E1"] - d["E0"], d["R0"] - d["E0"], d["R1"] - d["E0"]
+
+    def sends(self, kind):
+        """How many own entries the left / right neighbour keeps as its halo."""
+        r = self.rank
+        left = right = 0
+        if r > 0:
+            _, ln, _, hi = self.geom(kind, r - 1)
+            left = ln - hi                  # right halo of the left neighbour
+        if r < self.world - 1:
+            _, _, lo, _ = self.geom(kind, r + 1)
+            right = lo                      # left halo of the right neighbour
+        return left, right
+
+    def global_len(self, kind):
+        return self.n if kind == "col" else self.m
 
 
-def block_range(n, world, rank):
-    return (rank * n) // world, ((rank + 1) * n) // world
+# --------------------------------------------------------------------------- communication
+class ShardComm:
+    """The collectives of the sharded solver over ``torch.distributed``."""
 
-
-def half_bandwidth(M):
-    coo = sps.coo_matrix(M)
-    return int(np.max(np.abs(coo.row - coo.col))) if coo.nnz else 0
-
-
-class ShardedProjectedCG:
-    """Projected CG for ``min 1/2 x'Hx + c'x  s.t.  A x = 0, ||x|| <= radius`` with
-    the variables sharded over ``dist``'s ranks.  ``H`` (scipy CSR, banded),
-    ``hdiag`` (optional diagonal term) and ``A`` (scipy CSR) are given in full
-    on every rank; each rank keeps its block."""
-
-    def __init__(self, engine, A, H, hdiag=None, group=None):
-        self.eng = eng = engine
+    def __init__(self, group=None):
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        A = sps.csr_matrix(A)
-        H = sps.csr_matrix(H)
-        self.m, self.n = A.shape
-        self.n0, self.n1 = block_range(self.n, self.world, self.rank)
-        n0, n1 = self.n0, self.n1
-        self.nloc = n1 - n0
-        # halo of p needed by the rows of H owned here
-        self.h = half_bandwidth(H)
-        if self.world > 1 and self.h > min(block_range(self.n, self.world, r)[1]
-                                           - block_range(self.n, self.world, r)[0]
-                                           for r in range(self.world)):
-            raise NotImplementedError("Hessian bandwidth exceeds a rank's block")
-        self.hl = self.h if self.rank > 0 else 0
-        self.hr = self.h if self.rank < self.world - 1 else 0
-        A_cols = sps.csr_matrix(A[:, n0:n1])
-        self.A_cols = eng.csr(A_cols)
-        self.At_rows = eng.csr(sps.csr_matrix(A_cols.T))
-        self.H_rows = eng.csr(sps.csr_matrix(H[n0:n1, n0 - self.hl:n1 + self.hr]))
-        self.hdiag = eng.upload(np.asarray(hdiag)[n0:n1]) if hdiag is not None else None
-        self.solver = eng.banded(A)                 # replicated (A A')^-1
-        self.norm_A = eng.frobenius(A)
-        # buffers
-        self.x, self.r, self.Hp = (eng.zeros(self.nloc) for _ in range(3))
-        self.p_ext = eng.zeros(self.hl + self.nloc + self.hr)
-        self.p = eng.view(self.p_ext, self.hl, self.hl + self.nloc)
-        self.w, self.v, self.t = (eng.zeros(self.m) for _ in range(3))
-        self.state = eng.zeros(STATE_SIZE)
-        self.s1, self.s4 = eng.zeros(2), eng.zeros(2)
-        self.part1 = eng.zeros(2 * eng.ntiles(self.H_rows))
-        self.part3 = eng.zeros(2 * max(eng.ntiles(self.At_rows), (self.m + 255) // 256 + 1))
-        self.part4 = eng.zeros((self.m + 255) // 256 + 1)
-        self.grid = eng.vec_grid(self.nloc)
-        self.part2 = eng.zeros(2 * max(self.grid, eng.ntiles(self.A_cols)))
-        # packed all-reduce buffer: 4 scalars + [world][2h] boundary entries
-        self.pack = eng.zeros(4 + 2 * self.h * self.world)
-        h, r = self.h, self.rank
-        self.g_left = eng.view(self.pack, 4 + (2 * (r - 1) + 1) * h, 4 + 2 * r * h) \
-            if self.hl else None                       # right boundary of rank-1
-        self.g_right = eng.view(self.pack, 4 + 2 * (r + 1) * h, 4 + (2 * (r + 1) + 1) * h) \
-            if self.hr else None                       # left boundary of rank+1
-        self.p_left = eng.view(self.p_ext, 0, self.hl) if self.hl else None
-        self.p_right = eng.view(self.p_ext, self.hl + self.nloc,
-                                self.hl + self.nloc + self.hr) if self.hr else None
-        self.np4 = 1
+        self.on = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if self.on else 1
+        self.rank = dist.get_rank(group) if self.on else 0
+        self.backend = dist.get_backend(group) if self.on else "none"
+        self.stats = {"all_reduce": 0, "all_reduce_bytes": 0, "exchange": 0, "exchange_bytes": 0}
 
-    # ---- collectives ---------------------------------------------------------
-    def _allreduce(self, buf):
+    def all_reduce(self, t, op="sum"):
+        """In place on a torch tensor (CUDA under nccl; CUDA tensors are staged through the
+        host under gloo, a test-only combination)."""
         if self.world == 1:
             return
-        t = self.eng.tensor(buf)
-        if t.is_cuda and dist.get_backend(self.group) != "nccl":
-            h = t.cpu()          # gloo (test-only combination): stage through the host
-            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+        self.stats["all_reduce"] += 1
+        self.stats["all_reduce_bytes"] += t.numel() * t.element_size()
+        rop = {"sum": dist.ReduceOp.SUM, "max": dist.ReduceOp.MAX, "min": dist.ReduceOp.MIN}[op]
+        if t.is_cuda and self.backend != "nccl":
+            h = t.cpu()
+            dist.all_reduce(h, op=rop, group=self.group)
             t.copy_(h)
         else:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_reduce(t, op=rop, group=self.group)
 
-    def _seed_p_halo(self):
-        """p halos <- neighbours' boundary entries of p (priming only; inside
-        the loop the halos are advanced locally)."""
-        if self.world == 1 or self.h == 0:
-            return
-        eng = self.eng
-        eng.halo_pack(self.p, self.h, self.rank, self.world, eng.view(self.pack, 4, None))
-        self._allreduce(self.pack)
-        if self.hl:
-            eng.axpby(1.0, self.g_left, 0.0, None, self.p_left)
-        if self.hr:
-            eng.axpby(1.0, self.g_right, 0.0, None, self.p_right)
-
-    # ---- pieces ---------------------------------------------------------------
-    def _project(self, y, out):
-        """out = Z y = y - A'(AA')^-1 A y on the local block (one all-reduce)."""
-        eng = self.eng
-        eng.spmv(self.A_cols, y, self.w)
-        self._allreduce(self.w)
-        eng.solve(self.solver, self.w, self.v)
-        eng.spmv(self.At_rows, self.v, out, alpha=-1.0, beta=1.0, yin=y)
-
-    def _hp(self, guard=True):
-        """Hp = H p on the local rows, p'Hp partials in part1."""
-        self.eng.spmv(self.H_rows, self.p_ext, self.Hp, diag=self.hdiag, xrow=self.p,
-                      partial=self.part1, guard=self.state if guard else None)
-
-    def prime(self, c, tol, trust_radius, orth_tol=1e-12):
-        """Initial point of qp_subproblem.py:502-512 for b = 0: x = 0,
-        r = Z c, g = Z r, p = -g, Hp = H p."""
-        eng = self.eng
-        c_loc = eng.upload(np.asarray(c)[self.n0:self.n1])
-        eng.fill(self.x, 0.0)
-        self._project(c_loc, self.r)
-        g = eng.zeros(self.nloc)
-        self._project(self.r, g)
-        eng.axpby(-1.0, g, 0.0, None, self.p)
-        eng.sumsq(g, self.s4)
-        self._allreduce(self.s4)
-        rt_g = float(eng.download(self.s4)[0])
-        if tol is None:
-            tol = max(min(0.01 * np.sqrt(rt_g), 0.1 * rt_g), 1e-25)
-        init = np.zeros(STATE_SIZE)
-        init[ST_RTG0], init[ST_TOL], init[ST_RADIUS] = rt_g, tol, trust_radius
-        init[ST_ORTH_RHS] = orth_tol * self.norm_A
-        eng.assign(self.state, init)
-        self._seed_p_halo()
-        self._hp(guard=False)
-        eng.fold2(self.part1, eng.ntiles(self.H_rows), self.s1)
-        return rt_g
-
-    def iterate(self, it_begin, it_end):
-        """Enqueue iterations [it_begin, it_end); no host synchronisation.  Each
-        iteration is three local segments separated by the three all-reduces
-        (s1 holds this rank's folded p'Hp partials on entry)."""
-        eng = self.eng
-        for it in range(it_begin, it_end):
-            self._allreduce(self.s1)                                   # p'Hp
-            eng.segment(self, 0, it)
-            self._allreduce(self.w)                                    # partial A r
-            eng.segment(self, 1, it)
-            self._allreduce(self.pack)     # ||x+ap||^2, #viol, ||g||^2 + boundary g of all ranks
-            eng.segment(self, 2, it)
-
-    def read_state(self):
-        return self.eng.download(self.state)
-
-    def gather_x(self):
-        """Full solution vector on every rank (host).  Blocks may differ by one
-        row, so every rank contributes a block padded to the longest."""
-        x_loc = np.ascontiguousarray(self.eng.download(self.x))
+    def reduce_floats(self, values, op="sum", device=None):
+        """All-reduce of a few host scalars (one blocking round)."""
         if self.world == 1:
-            return x_loc
-        sizes = [block_range(self.n, self.world, r)[1] - block_range(self.n, self.world, r)[0]
-                 for r in range(self.world)]
-        pad = np.zeros(max(sizes))
-        pad[:len(x_loc)] = x_loc
-        mine = torch.from_numpy(pad)
-        on_gpu = dist.get_backend(self.group) == "nccl"
-        if on_gpu:
-            mine = mine.to(torch.device("cuda", torch.cuda.current_device()))
-        parts = [torch.empty_like(mine) for _ in range(self.world)]
-        dist.all_gather(parts, mine, group=self.group)
-        return np.concatenate([p.cpu().numpy()[:k] for p, k in zip(parts, sizes)])
+            return [float(v) for v in values]
+        t = torch.tensor([float(v) for v in values], dtype=torch.float64)
+        if self.backend == "nccl":
+            t = t.to(device if device is not None
+                     else torch.device("cuda", torch.cuda.current_device()))
+        self.all_reduce(t, op)
+        return t.tolist()
 
-    def solve(self, c, tol=None, trust_radius=np.inf, max_iter=None, batch=8):
-        """Run to a stop condition; returns (x_full, info) like projected_cg
-        (stop codes 1 iteration limit, 2 boundary, 4 tolerance)."""
-        self.prime(c, tol, trust_radius)
-        if max_iter is None:
-            max_iter = self.n - self.m
-        max_iter = min(max_iter, self.n - self.m)
-        it, stop_cond, hits_boundary = 0, 1, False
-        while it < max_iter:
-            end = min(max_iter, it + batch)
-            self.iterate(it, end)
-            s = self.read_state()
-            stop = int(s[ST_STOP])
-            if stop == 0:
-                it = end
-                continue
-            if stop == 4:
-                stop_cond = 4
-                break
-            if stop in (2, 3):
-                # trust-region boundary (qp_subproblem.py:583-596) or negative curvature
-                # (:558-576): move to the sphere along p.  The three inner products are
-                # summed over the ranks; every rank then takes the same step on its block.
-                if stop == 3 and np.isinf(trust_radius):
-                    raise ValueError("Negative curvature not allowed for unrestricted "
-                                     "problems.")
-                self._to_boundary(float(s[ST_ALPHA]), trust_radius, entire_line=(stop == 3))
-                stop_cond, hits_boundary = stop, True
-                break
-            raise NotImplementedError(
-                "sharded projected CG: stop code %d (box or refinement events) is handled by "
-                "the single-GPU path only" % stop)
-        s = self.read_state()
-        return self.gather_x(), {'niter': int(s[ST_NITER]), 'stop_cond': stop_cond,
-                                 'hits_boundary': hits_boundary}
-
-    def _to_boundary(self, alpha, trust_radius, entire_line):
-        """x <- x + theta d with d = p (negative curvature: the whole line, the positive
-        root) or d = alpha p (step leaving the region: the segment), theta from
-        sphere_intersections on the all-reduced d.d, x.d, x.x."""
-        from .qp import _sphere_from_scalars
-        eng = self.eng
-        scale = 1.0 if entire_line else alpha
-        dots = eng.zeros(4)
-        eng.dots3(self.x, self.p, dots)               # x.x, x.p, p.p on this block
-        self._allreduce(dots)
-        xx, xp, pp = (float(v) for v in eng.download(dots)[:3])
-        ta, tb, intersect = _sphere_from_scalars(scale * scale * pp, scale * xp, xx, trust_radius,
-                                                 entire_line)
-        if intersect:
-            eng.axpby(1.0, self.x, tb * scale, self.p, self.x)
+    def exchange(self, t, own_lo, own_hi, send_left, send_right):
+        """Halo update of the local extended 1-D tensor ``t``: entries [0, own_lo) come from
+        the left neighbour's last own entries, [own_hi, len) from the right neighbour's
+        first; this rank sends its first ``send_left`` / last ``send_right`` own entries."""
+        if self.world == 1:
+            return
+        n = t.numel()
+        stage = t.is_cuda and self.backend != "nccl"
+        buf = t.cpu() if stage else t
+        ops, r = [], self.rank
+        if r > 0:
+            if send_left:
+                ops.append(dist.P2POp(dist.isend, buf[own_lo:own_lo + send_left].contiguous()
+                                      if stage else buf[own_lo:own_lo + send_left], r - 1,
+                                      self.group))
+            if own_lo:
+                ops.append(dist.P2POp(dist.irecv, buf[0:own_lo], r - 1, self.group))
+        if r < self.world - 1:
+            if send_right:
+                ops.append(dist.P2POp(dist.isend, buf[own_hi - send_right:own_hi], r + 1,
+                                      self.group))
+            if n - own_hi:
+                ops.append(dist.P2POp(dist.irecv, buf[own_hi:n], r + 1, self.group))
+        if ops:
+            self.stats["exchange"] += 1
+            self.stats["exchange_bytes"] += 8 * (send_left * (r > 0)
+                                                 + send_right * (r < self.world - 1))
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        if stage:
+            if own_lo:
+                t[0:own_lo].copy_(buf[0:own_lo])
+            if n - own_hi:
+                t[own_hi:n].copy_(buf[own_hi:n])
 
 
-
-class SegmentsByKernel:
-    """The three local segments of an iteration, kernel by kernel (what
-    ipx_cg_shard_segment does in one call).  The numpy engine of the test-suite
-    inherits this; HipEngine overrides it with the single C call."""
-
-    def segment(self, cg, phase, it):
-        st = cg.state
-        if phase == 0:
-            self.step1(st, it, cg.s1, 1, cg.x, cg.p, cg.r, cg.Hp, cg.part2, cg.grid)
-            self.spmv(cg.A_cols, cg.r, cg.w, guard=st)                 # partial A r
-        elif phase == 1:
-            cg.np4 = self.solve_resid(cg.solver, cg.w, cg.v, cg.part4, guard=st)
-            self.spmv(cg.At_rows, cg.v, cg.r, alpha=-1.0, beta=1.0, yin=cg.r,
-                      partial=cg.part3, guard=st)                       # g = r - A'v
-            self.shard_pack(cg.part2, cg.grid, cg.part3, self.ntiles(cg.At_rows), cg.r, cg.h,
-                            cg.rank, cg.world, cg.pack)
-        else:
-            self.step2(st, it, 0, self.view(cg.pack, 0, 2), 1, self.view(cg.pack, 2, 4), 1,
-                       cg.part4, cg.np4, cg.x, cg.p, cg.r, cg.grid)
-            self.halo_apply(st, cg.g_left, cg.g_right, cg.p_left, cg.p_right)
-            cg._hp()
-            self.fold2(cg.part1, self.ntiles(cg.H_rows), cg.s1)
-
-
-class HipEngine(SegmentsByKernel):
-    """Local compute of the sharded loop on one GPU: ipx kernels."""
-
-    def segment(self, cg, phase, it):
-        args = getattr(cg, "_c_args", None)
-        if args is None:
-            args = cg._c_args = self._build_args(cg)
-        self._hip.call("ipx_cg_shard_segment", ctypes.byref(args[0]), ctypes.byref(args[1]),
-                       int(phase), int(it), self._st())
-
-    def _build_args(self, cg):
-        from .cg_fused import CgArgs
-        if cg.solver.perm is not None:
-            raise NotImplementedError("sharded CG needs A A' banded in its natural row order")
-        a = CgArgs()
-        a.n, a.m = cg.nloc, cg.m
-        for pre, M in (("A", cg.A_cols), ("At", cg.At_rows), ("H", cg.H_rows)):
-            pat = M.pattern
-            setattr(a, pre + "_rowptr", pat.indptr.data_ptr())
-            setattr(a, pre + "_colidx", pat.indices.data_ptr())
-            setattr(a, pre + "_val", M.val.data_ptr() if M.val.numel() else None)
-            setattr(a, pre + "_tiles", pat.tiles.data_ptr())
-            setattr(a, pre + "_ntiles", pat.ntiles)
-        a.H_diag = cg.hdiag.data_ptr() if cg.hdiag is not None else None
-        a.banded = cg.solver.handle
-        a.x, a.p, a.r, a.Hp = (t.data_ptr() for t in (cg.x, cg.p, cg.r, cg.Hp))
-        a.w, a.v, a.t = cg.w.data_ptr(), cg.v.data_ptr(), cg.t.data_ptr()
-        a.state = cg.state.data_ptr()
-        a.part1, a.part2, a.part3, a.part4 = (t.data_ptr() for t in (cg.part1, cg.part2,
-                                                                       cg.part3, cg.part4))
-        a.vec_grid, a.solver_kind = cg.grid, 0
-        # the single-GPU loop's fusions, rank-local (csrc/cg.hip): step1 inside the partial
-        # A.r SpMV, g = r - A'v as the tail of the replicated banded solve
-        import os
-        from . import cg_fused
-        if not os.environ.get("IPX_NO_FUSE"):
-            own = cg_fused.fuse_own(cg.A_cols.pattern)
-            if own is not None and own[3] <= cg.part2.numel() // 2:
-                cg.r_next = self.zeros(cg.nloc)
-                cg.own = own[0]
-                a.r_next, a.A_own, a.A_span = cg.r_next.data_ptr(), cg.own.data_ptr(), own[1]
-            geo = (ctypes.c_int32 * 2)()
-            if self.lib.ipx_banded_decoupled_geometry(ctypes.c_void_p(cg.solver.handle), geo) \
-                    and geo[1] <= 512 and geo[1] <= cg.part3.numel() // 2:
-                vown = cg_fused.fuse_vown(cg.At_rows.pattern, geo[0], geo[1])
-                if vown is not None:
-                    cg.vown = vown[0]
-                    a.At_vown, a.At_qv = cg.vown.data_ptr(), vown[1]
-        e = ShardExt()
-        e.p_ext = cg.p_ext.data_ptr()
-        e.hl, e.hr, e.h, e.rank, e.world = cg.hl, cg.hr, cg.h, cg.rank, cg.world
-        e.s1, e.pack, e.np4 = cg.s1.data_ptr(), cg.pack.data_ptr(), 1
-        return a, e
+# --------------------------------------------------------------------------- local arithmetic
+class HipOps:
+    """Local arithmetic of the sharded solver on one GPU: device.DVec / DeviceCSR and the
+    ipx kernels (the product path; fails loudly without the library or a GPU)."""
+    name = "hip"
+    fused = True
 
     def __init__(self):
-        from . import _hip, device
-        self._hip, self.dv = _hip, device
-        self.lib = _hip.load()
-        self.ctx = device.ctx()
+        from . import device as dv
+        self.dv = dv
+        dv.ctx()
 
-    def _st(self):
-        return self.dv.stream_ptr()
+    def from_host(self, a):
+        return self.dv.DVec.from_host(a)
 
-    @staticmethod
-    def _ptr(t):
-        return ctypes.c_void_p(t.data_ptr()) if t is not None and t.numel() > 0 else None
+    def to_host(self, v):
+        return v.to_host()
+
+    def tensor(self, v):
+        return v.t
 
     def zeros(self, n):
-        return torch.zeros(int(n), dtype=torch.float64, device=self.ctx.device)
+        return self.dv.DVec.zeros(n)
 
-    def upload(self, a):
-        return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(self.ctx.device)
+    def full(self, n, value):
+        return self.dv.DVec.full(n, value)
 
-    def download(self, buf):
-        return buf.cpu().numpy()
+    def copy(self, v):
+        return v.copy()
 
-    def assign(self, buf, host):
-        buf.copy_(torch.from_numpy(np.ascontiguousarray(host, dtype=np.float64)))
+    def add_scaled(self, x, o, a):
+        return x.add_scaled(o, a)
 
-    def tensor(self, buf):
-        return buf
+    def scaled_sub(self, x, a, o):
+        return x.scaled_sub(a, o)
 
-    def view(self, buf, a, b):
-        return buf[a:b]
+    def sumsq_amax(self, v):
+        return v.sumsq_amax() if len(v) else [0.0, 0.0]
 
-    def fill(self, buf, value):
-        self._hip.call("ipx_fill", buf.numel(), float(value), self._ptr(buf), self._st())
+    def dot(self, a, b):
+        return a.dot(b) if len(a) else 0.0
 
-    def axpby(self, a, x, b, y, out):
-        self._hip.call("ipx_axpby", x.numel(), float(a), self._ptr(x), float(b), self._ptr(y),
-                       self._ptr(out), self._st())
+    def clip(self, x, lb, ub):
+        return self.dv.clip(x, lb, ub)
 
-    def csr(self, M):
-        return self.dv.DeviceCSR.from_scipy(M)
+    def count_outside_box(self, x, lb, ub):
+        return self.dv.count_outside_box(x, lb, ub) if len(x) else 0.0
 
-    def ntiles(self, M):
-        return M.pattern.ntiles
+    def box_sphere_reduce(self, z, d, dscale, lb, ub):
+        return self.dv.box_sphere_reduce(z, d, dscale, lb, ub)
 
-    def vec_grid(self, n):
-        return int(self.lib.ipx_cg_vec_grid(max(int(n), 1)))
+    def csr(self, M, row_breaks=None, col_breaks=None):
+        """Local block on the device; row tiles (and those of the stored transpose) are cut
+        at the own / halo boundaries so per-tile partial sums can be taken over own tiles."""
+        A = self.dv.DeviceCSR.from_scipy(sps.csr_matrix(M), row_breaks=row_breaks)
+        if col_breaks is not None:
+            A.pattern.transpose(row_breaks=col_breaks)
+        return A
 
-    def banded(self, A):
-        from . import projector
-        self._A_full = self.dv.DeviceCSR.from_scipy(A)
-        return projector.BandedNormalSolver(self._A_full)
+    def refresh(self, A, data):
+        """Same pattern, new values (host array)."""
+        val = torch.from_numpy(np.ascontiguousarray(data, dtype=np.float64)).to(A.val.device)
+        return self.dv.DeviceCSR(A.pattern, val)
 
-    def frobenius(self, A):
-        """||A||_F on the device (of the matrix just handed to banded())."""
-        return self._A_full.frobenius_norm()
+    def rmatvec(self, A, v):
+        return A.T.dot(v)
 
-    def solve(self, solver, w, v, guard=None):
-        if solver.perm is not None:
-            raise NotImplementedError("sharded CG needs A A' banded in its natural row order")
-        if guard is None:
-            self._hip.call("ipx_banded_solve", ctypes.c_void_p(solver.handle), self._ptr(w),
-                           self._ptr(v), self._st())
+    def hessian(self, n, H_csr, diag):
+        from .operators import DeviceHessian
+        return DeviceHessian(n, csr=H_csr, diag=diag)
+
+    def normal_solver(self, A):
+        from .projector import BandedNormalSolver
+        return BandedNormalSolver(A)
+
+    def frob_sq_rows(self, A, r0, r1):
+        ip = A.pattern.indptr_h
+        v = self.dv.DVec(A.val[int(ip[r0]):int(ip[r1])])
+        return v.sumsq_amax()[0] if len(v) else 0.0
+
+
+# --------------------------------------------------------------------------- context
+class Sharding:
+    """Layout + communicator + local arithmetic of one sharded problem."""
+
+    def __init__(self, layout, comm, ops):
+        self.lay, self.comm, self.ops = layout, comm, ops
+
+    # -- construction of distributed vectors
+    def from_global(self, a, kind):
+        g0, ln, _, _ = self.lay.geom(kind)
+        a = np.asarray(a, dtype=float)
+        assert a.shape == (self.lay.global_len(kind),), (a.shape, kind)
+        return ShardVec(self.ops.from_host(a[g0:g0 + ln]), self, kind)
+
+    def zeros(self, kind):
+        return ShardVec(self.ops.zeros(self.lay.geom(kind)[1]), self, kind)
+
+    def full(self, kind, value):
+        return ShardVec(self.ops.full(self.lay.geom(kind)[1], value), self, kind)
+
+    def kind_of_len(self, k):
+        if k == self.lay.n and k != self.lay.m:
+            return "col"
+        if k == self.lay.m and k != self.lay.n:
+            return "row"
+        raise ValueError("cannot tell variables from constraints by length %d" % k)
+
+    def sync(self, v):
+        """Overwrite the halo entries of ``v`` with their owners' values."""
+        _, _, lo, hi = self.lay.geom(v.kind)
+        sl, sr = self.lay.sends(v.kind)
+        self.comm.exchange(self.ops.tensor(v.loc), lo, hi, sl, sr)
+        return v
+
+
+class ShardVec:
+    """Distributed fp64 vector: the local extended array (own + halo entries) with the
+    arithmetic surface of ``device.DVec``; reductions run over the own entries and are
+    summed over the ranks."""
+    __slots__ = ("loc", "sh", "kind")
+    __array_priority__ = 1000
+
+    def __init__(self, loc, sh, kind):
+        self.loc, self.sh, self.kind = loc, sh, kind
+
+    def _new(self, loc):
+        return ShardVec(loc, self.sh, self.kind)
+
+    def own(self):
+        _, _, lo, hi = self.sh.lay.geom(self.kind)
+        return self.loc[lo:hi]
+
+    def __len__(self):
+        return self.sh.lay.global_len(self.kind)
+
+    @property
+    def shape(self):
+        return (len(self),)
+
+    def copy(self):
+        return self._new(self.sh.ops.copy(self.loc))
+
+    def zeros_like(self):
+        return self.sh.zeros(self.kind)
+
+    def full_like(self, value):
+        return self.sh.full(self.kind, value)
+
+    def to_host(self):
+        """The global vector on every rank (collective)."""
+        sh = self.sh
+        own = np.ascontiguousarray(sh.ops.to_host(self.own()))
+        if sh.comm.world == 1:
+            return own
+        cuts = sh.lay.col_cuts if self.kind == "col" else sh.lay.row_cuts
+        sizes = np.diff(cuts)
+        pad = np.zeros(int(sizes.max()))
+        pad[:len(own)] = own
+        mine = torch.from_numpy(pad)
+        if sh.comm.backend == "nccl":
+            mine = mine.to(torch.device("cuda", torch.cuda.current_device()))
+        parts = [torch.empty_like(mine) for _ in range(sh.comm.world)]
+        dist.all_gather(parts, mine, group=sh.comm.group)
+        return np.concatenate([p.cpu().numpy()[:k] for p, k in zip(parts, sizes)])
+
+    # -- elementwise (own and halo alike: copies stay consistent)
+    def _other(self, o):
+        assert isinstance(o, ShardVec) and o.kind == self.kind, "mismatched distributed vectors"
+        return o.loc
+
+    def add_scaled(self, o, a):
+        return self._new(self.sh.ops.add_scaled(self.loc, self._other(o), a))
+
+    def scaled_sub(self, a, o):
+        return self._new(self.sh.ops.scaled_sub(self.loc, a, self._other(o)))
+
+    def __add__(self, o):
+        return self._new(self.loc + (self._other(o) if isinstance(o, ShardVec) else float(o)))
+
+    __radd__ = __add__
+
+    def __sub__(self, o):
+        return self._new(self.loc - (self._other(o) if isinstance(o, ShardVec) else float(o)))
+
+    def __rsub__(self, o):
+        return self._new(float(o) - self.loc)
+
+    def __neg__(self):
+        return self._new(-self.loc)
+
+    def __mul__(self, o):
+        return self._new(self.loc * (self._other(o) if isinstance(o, ShardVec) else float(o)))
+
+    __rmul__ = __mul__
+
+    # -- reductions
+    def dot(self, o):
+        v = self.sh.ops.dot(self.own(), o.own())
+        return self.sh.comm.reduce_floats([v])[0]
+
+    def sumsq_amax(self):
+        ss, am = self.sh.ops.sumsq_amax(self.own())
+        if self.sh.comm.world == 1:
+            return [ss, am]
+        return [self.sh.comm.reduce_floats([ss])[0], self.sh.comm.reduce_floats([am], "max")[0]]
+
+    def _clip(self, lb, ub):
+        return self._new(self.sh.ops.clip(self.loc, lb.loc, ub.loc))
+
+    def _count_outside_box(self, lb, ub):
+        v = self.sh.ops.count_outside_box(self.own(), lb.own(), ub.own())
+        return self.sh.comm.reduce_floats([v])[0]
+
+    def _box_sphere_reduce(self, d, dscale, lb, ub):
+        """The 7 quantities of device.box_sphere_reduce over the ranks: d.d, z.d, z.z and the
+        count of zero-direction coordinates outside the box are sums, ta = max over ranks,
+        tb = min (qp_subproblem.py:215-216)."""
+        r = self.sh.ops.box_sphere_reduce(self.own(), d.own(), dscale,
+                                          lb.own() if lb is not None else None,
+                                          ub.own() if ub is not None else None)
+        c = self.sh.comm
+        if c.world == 1:
+            return list(r)
+        s = c.reduce_floats([r[0], r[1], r[2], r[5], r[6]])
+        ta = c.reduce_floats([r[3]], "max")[0]
+        tb = c.reduce_floats([r[4]], "min")[0]
+        return [s[0], s[1], s[2], ta, tb, s[3], s[4]]
+
+
+# --------------------------------------------------------------------------- operators
+class ShardCSR:
+    """Row block ``A[E, X]`` of a sparse matrix whose rows follow the constraint partition
+    (the Jacobian): ``dot`` maps variables to constraints (exact on every local row),
+    ``T.dot`` constraints to variables (own entries exact, halo synchronised)."""
+
+    def __init__(self, sh, local, transposed=False, other=None):
+        self.sh, self.local, self.transposed = sh, local, transposed
+        self._T = other
+        m, n = sh.lay.m, sh.lay.n
+        self.shape = (n, m) if transposed else (m, n)
+
+    @staticmethod
+    def from_global(sh, A):
+        d = sh.lay.me
+        A = sps.csr_matrix(A)
+        loc = sps.csr_matrix(A[d["E0"]:d["E1"], d["x0"]:d["x1"]])
+        _, _, lo, hi = sh.lay.geom("row")
+        _, _, clo, chi = sh.lay.geom("col")
+        return ShardCSR(sh, sh.ops.csr(loc, row_breaks=[lo, hi], col_breaks=[clo, chi]))
+
+    @property
+    def T(self):
+        if self._T is None:
+            self._T = ShardCSR(self.sh, self.local, not self.transposed, self)
+        return self._T
+
+    def with_values(self, data):
+        """Same pattern, new local values (value refresh of a Jacobian)."""
+        return ShardCSR(self.sh, self.sh.ops.refresh(self.local, data))
+
+    def dot(self, x):
+        sh = self.sh
+        if not self.transposed:
+            assert x.kind == "col"
+            return ShardVec(self.local.dot(x.loc), sh, "row")
+        assert x.kind == "row"
+        return sh.sync(ShardVec(sh.ops.rmatvec(self.local, x.loc), sh, "col"))
+
+    matvec = dot
+
+    def frobenius_norm(self):
+        _, _, lo, hi = self.sh.lay.geom("row")
+        return float(np.sqrt(self.sh.comm.reduce_floats(
+            [self.sh.ops.frob_sq_rows(self.local, lo, hi)])[0]))
+
+
+class ShardHessian:
+    """Rows ``H[X, X]`` of a banded Hessian (+ optional diagonal term) on a rank's variables:
+    exact on the own entries, halo synchronised."""
+
+    def __init__(self, sh, local):
+        self.sh, self.local = sh, local
+        self.shape = (sh.lay.n, sh.lay.n)
+
+    @staticmethod
+    def from_global(sh, H, hdiag=None):
+        d = sh.lay.me
+        H = sps.csr_matrix(H)
+        loc = sps.csr_matrix(H[d["x0"]:d["x1"], d["x0"]:d["x1"]])
+        _, ln, lo, hi = sh.lay.geom("col")
+        csr = sh.ops.csr(loc, row_breaks=[lo, hi])
+        diag = sh.ops.from_host(np.asarray(hdiag, dtype=float)[d["x0"]:d["x1"]]) \
+            if hdiag is not None else None
+        return ShardHessian(sh, sh.ops.hessian(ln, csr, diag))
+
+    def dot(self, p):
+        assert p.kind == "col"
+        return self.sh.sync(ShardVec(self.local.dot(p.loc), self.sh, "col"))
+
+    matvec = dot
+
+
+class _ShardOp:
+    def __init__(self, shape, fn, projector):
+        self.shape, self._fn, self.projector = shape, fn, projector
+
+    def dot(self, x):
+        return self._fn(x)
+
+    matvec = dot
+
+
+class ShardProjector:
+    """Z, LS, Y of the distributed Jacobian through the normal equations
+    (projections.py:58-90, refinement loop :69-78, orthogonality :23-55): the local banded
+    solve on the extended rows is exact on the own rows (module docstring)."""
+
+    def __init__(self, A, orth_tol=1e-12, max_refin=3):
+        self.A, self.sh = A, A.sh
+        self.orth_tol, self.max_refin = orth_tol, max_refin
+        self.solver = self.sh.ops.normal_solver(A.local)
+        self.norm_A = A.frobenius_norm()
+        self.stats = {"solves": 0, "refinements": 0}
+        self.fused_sharded = bool(getattr(self.sh.ops, "fused", False))
+
+    def _apply_inv(self, w):
+        self.stats["solves"] += 1
+        return self.sh.sync(ShardVec(self.solver.solve(w.loc), self.sh, "row"))
+
+    def orthogonality(self, z):
+        norm_z = np.sqrt(z.sumsq_amax()[0])
+        if norm_z == 0 or self.norm_A == 0:
+            return 0.0, None
+        Az = self.A.dot(z)
+        return float(np.sqrt(Az.sumsq_amax()[0]) / (self.norm_A * norm_z)), Az
+
+    def null_space(self, x):
+        v = self._apply_inv(self.A.dot(x))
+        z = x - self.A.T.dot(v)
+        k = 0
+        while True:
+            orth, Az = self.orthogonality(z)
+            if not orth > self.orth_tol or k >= self.max_refin:
+                break
+            z = z - self.A.T.dot(self._apply_inv(Az))
+            k += 1
+            self.stats["refinements"] += 1
+        return z
+
+    def least_squares(self, x):
+        return self._apply_inv(self.A.dot(x))
+
+    def row_space(self, x):
+        return self.A.T.dot(self._apply_inv(x))
+
+    def operators(self):
+        m, n = self.A.shape
+        return (_ShardOp((n, n), self.null_space, self), _ShardOp((m, n), self.least_squares, self),
+                _ShardOp((n, m), self.row_space, self))
+
+
+def projections(A, method=None, orth_tol=1e-12, max_refin=3, tol=1e-15):
+    """Sharded counterpart of ``projector.projections`` for a ``ShardCSR`` Jacobian."""
+    if method not in (None, "NormalEquation", "AugmentedSystem"):
+        raise ValueError("Method not allowed for sparse matrix.")
+    return ShardProjector(A, orth_tol, max_refin).operators()
+
+
+# --------------------------------------------------------------------------- fused loop
+# counters over the life of the process (tests assert the device-resident path was taken)
+STATS = {"fused_calls": 0, "iterations": 0, "batches": 0, "box_events": 0, "refine_events": 0}
+
+ST_RTG0, ST_RTG1, ST_TOL, ST_RADIUS, ST_ALPHA, ST_STOP, ST_NITER, ST_BETA = range(8)
+ST_PTHP, ST_ORTH_RHS, ST_XNORM2, ST_VIOL, ST_ORTH, ST_IT_DONE = 8, 9, 10, 11, 12, 13
+_TINY = 1e-25
+
+
+class Shard2Ext(ctypes.Structure):
+    """Mirror of ipx_shard2_ext (include/ipx.h)."""
+    _fields_ = [("s1", ctypes.c_void_p), ("pack", ctypes.c_void_p)] + \
+               [(k, ctypes.c_int64) for k in ("p1_lo", "p1_hi", "p2_lo", "p2_hi", "p3_lo", "p3_hi",
+                                              "p4_lo", "p4_hi", "own_lo", "own_hi")]
+
+
+def fused_supports(H, Z, Y):
+    P = getattr(Z, "projector", None)
+    if not isinstance(P, ShardProjector) or getattr(Y, "projector", None) is not P:
+        return False
+    if not isinstance(H, ShardHessian) or not P.fused_sharded:
+        return False
+    from . import cg_fused
+    from .projector import BandedNormalSolver
+    return (isinstance(P.solver, BandedNormalSolver) and P.solver.perm is None
+            and cg_fused._hessian_parts(H.local) is not None)
+
+
+class FusedShardedCG:
+    """Device-resident projected CG on one rank's extended local problem: the kernels and
+    the argument block of the single-GPU loop (``cg_fused._Loop``), driven segment by
+    segment between the two all-reduces and the halo exchange of an iteration."""
+
+    def __init__(self, H, P, lb, ub):
+        from . import _hip, cg_fused
+        from . import device as dv
+        from .projector import NormalEquationProjector
+        self._hip, self.dv = _hip, dv
+        self.lib = _hip.load()
+        sh = self.sh = P.sh
+        A_loc = P.A.local
+        # the local problem as the single-GPU loop sees it
+        local_P = getattr(P, "_local_projector", None)
+        if local_P is None:
+            local_P = P._local_projector = NormalEquationProjector.__new__(NormalEquationProjector)
+            local_P.A, local_P.solver = A_loc, P.solver
+            local_P.orth_tol, local_P.max_refin = P.orth_tol, P.max_refin
+            local_P.m, local_P.n = A_loc.shape
+            local_P.norm_A = P.norm_A
+            local_P.stats = P.stats
+        self.P = P
+        self.L = L = cg_fused._Loop(H.local, local_P, lb.loc if lb is not None else None,
+                                    ub.loc if ub is not None else None)
+        a = L.args
+        dev = dv.ctx().device
+        self.s1 = torch.zeros(2, dtype=torch.float64, device=dev)
+        self.pack = torch.zeros(4, dtype=torch.float64, device=dev)
+        e = self.ext = Shard2Ext()
+        e.s1, e.pack = self.s1.data_ptr(), self.pack.data_ptr()
+        _, _, clo, chi = sh.lay.geom("col")
+        _, _, rlo, rhi = sh.lay.geom("row")
+        e.own_lo, e.own_hi = clo, chi
+        Hc, _ = cg_fused._hessian_parts(H.local)
+        e.p1_lo, e.p1_hi = Hc.pattern.tile_range(clo, chi)
+        if a.A_span:                       # step1 inside A.r: partials per row tile of A
+            if getattr(L, "own_tiles", None) is not A_loc.pattern.tiles:
+                raise _hip.IpxError("sharded loop: the fused step1 must use the pattern's row tiles")
+            e.p2_lo, e.p2_hi = A_loc.pattern.tile_range(rlo, rhi)
+        else:                              # vector kernel, masked to the own variables
+            e.p2_lo, e.p2_hi = 0, int(a.vec_grid)
+        geo = (ctypes.c_int32 * 2)()
+        decoupled = self.lib.ipx_banded_decoupled_geometry(ctypes.c_void_p(P.solver.handle), geo)
+        if not decoupled or geo[0] != sh.lay.row_block or rlo % geo[0] or \
+                (rhi % geo[0] and sh.lay.me["R1"] != sh.lay.m):
+            raise NotImplementedError(
+                "row-sharded projected CG needs the numerically decoupled single-launch banded "
+                "solve with %d rows per workgroup (DESIGN.md section 5); this factorization "
+                "reports decoupled=%d, rows per workgroup %d" % (sh.lay.row_block, decoupled,
+                                                                  geo[0]))
+        w0, w1 = rlo // geo[0], (rhi + geo[0] - 1) // geo[0]
+        e.p4_lo, e.p4_hi = w0, w1
+        if a.At_qv:                        # g = r - A'v rides in the solve: partials per workgroup
+            e.p3_lo, e.p3_hi = w0, w1
         else:
-            self._hip.call("ipx_banded_solve_guarded_c", ctypes.c_void_p(solver.handle),
-                           self._ptr(w), self._ptr(v), self._ptr(guard[ST_STOP:]), self._st())
+            At = A_loc.T
+            e.p3_lo, e.p3_hi = At.pattern.tile_range(clo, chi)
+        self.col_geom = (clo, chi) + sh.lay.sends("col")
 
-    def solve_resid(self, solver, w, v, partial, guard=None):
-        """v = (A A')^-1 w plus partial sums of ||w - (A A')v||^2; returns their count."""
-        if solver.perm is not None:
-            raise NotImplementedError("sharded CG needs A A' banded in its natural row order")
-        npart = ctypes.c_int32(0)
-        self._hip.call("ipx_banded_solve_resid", ctypes.c_void_p(solver.handle), self._ptr(w),
-                       self._ptr(v), self._ptr(partial), ctypes.byref(npart),
-                       self._ptr(guard[ST_STOP:]) if guard is not None else None, self._st())
-        return int(npart.value)
+    def _segment(self, phase, it, mode=0):
+        self._hip.call("ipx_cg_shard2_segment", self.L.ref(), ctypes.byref(self.ext), int(phase),
+                       int(it), int(mode), self.dv.stream_ptr())
 
-    def halo_pack(self, g, h, rank, world, out):
-        self._hip.call("ipx_cg_halo_pack", g.numel(), int(h), int(rank), int(world), self._ptr(g),
-                       self._ptr(out), self._st())
+    def prime(self, x0, r0, g0, rt_g, tol, trust_radius):
+        L, n = self.L, self.L.n
+        st = self.dv.stream_ptr()
+        L.x.copy_(x0.loc.t)
+        L.r.copy_(r0.loc.t)
+        self._hip.call("ipx_axpby", n, -1.0, self.dv._p(g0.loc.t), 0.0, None, self.dv._p(L.p), st)
+        init = np.zeros(L.state.numel())
+        init[ST_RTG0], init[ST_TOL], init[ST_RADIUS] = rt_g, tol, trust_radius
+        init[ST_ORTH_RHS] = self.P.orth_tol * self.P.norm_A
+        L.state.copy_(torch.from_numpy(init))
+        self._hip.check(self.lib.ipx_cg_hp(L.ref(), st), "ipx_cg_hp")
+        self._hip.call("ipx_cg_shard2_fold_hp", L.ref(), ctypes.byref(self.ext), st)
 
-    def shard_pack(self, part2, np2, part3, np3, g, h, rank, world, out):
-        self._hip.call("ipx_cg_shard_pack", self._ptr(part2), int(np2), self._ptr(part3), int(np3),
-                       g.numel(), int(h), int(rank), int(world), self._ptr(g), self._ptr(out),
-                       self._st())
+    def iterate(self, it_begin, it_end):
+        """Enqueue iterations [it_begin, it_end): per iteration two all-reduces and one halo
+        exchange, no host synchronisation."""
+        comm = self.sh.comm
+        clo, chi, sl, sr = self.col_geom
+        for it in range(it_begin, it_end):
+            comm.all_reduce(self.s1)                                   # p'Hp
+            self._segment(0, it)
+            comm.all_reduce(self.pack)          # ||x+ap||^2, #violations, ||g||^2, ||A g||^2
+            comm.exchange(self.L.r, clo, chi, sl, sr)                  # halo of g
+            self._segment(1, it, 0)
 
-    def halo_apply(self, state, g_left, g_right, p_left, p_right):
-        hl = p_left.numel() if p_left is not None else 0
-        hr = p_right.numel() if p_right is not None else 0
-        if hl or hr:
-            self._hip.call("ipx_cg_halo_apply", self._ptr(state), hl, hr, self._ptr(g_left),
-                           self._ptr(g_right), self._ptr(p_left), self._ptr(p_right), self._st())
+    def resume(self, it, mode):
+        """Finish iteration ``it`` after the host handled a box / refinement event."""
+        self.L.state[ST_STOP] = 0.0
+        self._segment(1, it, mode)
+        return self.L.state.tolist()
 
-    def dots3(self, x, p, out):
-        """out[0..3) = x.x, x.p, p.p"""
-        c = self.ctx
-        for k, (a, b) in enumerate(((x, x), (x, p), (p, p))):
-            self._hip.call("ipx_dot", a.numel(), self._ptr(a), self._ptr(b), self._ptr(c.out),
-                           self._ptr(c.ws), self._st())
-            out[k:k + 1].copy_(c.out[:1])
 
-    def spmv(self, M, x, out, alpha=1.0, diag=None, beta=0.0, yin=None, xrow=None, partial=None,
-             guard=None):
-        p = M.pattern
-        self._hip.call("ipx_csr_spmv_ex", p.shape[0], p.shape[1], self._ptr(p.indptr),
-                       self._ptr(p.indices), self._ptr(M.val), self._ptr(p.tiles), p.ntiles,
-                       self._ptr(x), float(alpha), self._ptr(diag), float(beta), self._ptr(yin),
-                       self._ptr(out), self._ptr(xrow), self._ptr(partial),
-                       self._ptr(guard[ST_STOP:]) if guard is not None else None, self._st())
+def fused_projected_cg(H, c, Z, Y, b, trust_radius=np.inf, lb=None, ub=None, tol=None,
+                       max_iter=None, max_infeasible_iter=None, batch=None):
+    """qp_subproblem.py:416-643 on distributed vectors with the device-resident loop; the
+    rare events (trust-region exit, negative curvature, box-infeasible iterate, projection
+    refinement) are finished on the host with the distributed forms of the reference's
+    helper routines, exactly as ``cg_fused.projected_cg`` does on one GPU."""
+    from . import qp
+    from . import device as dv
+    P = Z.projector
+    sh = P.sh
+    n, m = len(c), len(b)
+    has_box = lb is not None or ub is not None
+    if has_box:
+        lb = lb if lb is not None else c.full_like(-np.inf)
+        ub = ub if ub is not None else c.full_like(np.inf)
 
-    def fold2(self, partial, count, out2):
-        self._hip.call("ipx_fold2", self._ptr(partial), int(count), self._ptr(out2), None,
-                       self._st())
+    x0 = Y.dot(-b)                                       # :502-512
+    r0 = Z.dot(H.dot(x0) + c)
+    g0 = Z.dot(r0)
+    rt_g = g0.sumsq_amax()[0]
+    tr_distance = trust_radius - dv.norm(x0)
+    if tr_distance < 0:
+        raise ValueError("Trust region problem does not have a solution.")
+    if tr_distance < _TINY:
+        return x0, {'niter': 0, 'stop_cond': 2, 'hits_boundary': True}
+    if tol is None:
+        tol = max(min(0.01 * np.sqrt(rt_g), 0.1 * rt_g), _TINY)
+    if max_iter is None:
+        max_iter = n - m
+    max_iter = min(max_iter, n - m)
+    if max_infeasible_iter is None:
+        max_infeasible_iter = n - m
 
-    def sumsq(self, x, out2):
-        self._hip.call("ipx_norms", x.numel(), self._ptr(x), self._ptr(out2), self._ptr(self.ctx.ws),
-                       self._st())
+    F = FusedShardedCG(H, P, lb if has_box else None, ub if has_box else None)
+    F.prime(x0, r0, g0, rt_g, tol, trust_radius)
+    L = F.L
+    DV = dv.DVec
 
-    def step1(self, state, it, p1, np1, x, p, r, Hp, part2, grid):
-        self._hip.call("ipx_cg_step1", x.numel(), self._ptr(state), int(it), self._ptr(p1),
-                       int(np1), self._ptr(x), self._ptr(p), self._ptr(r), self._ptr(Hp), None,
-                       None, self._ptr(part2), int(grid), self._st())
+    def X():
+        return ShardVec(DV(L.x), sh, "col")
 
-    def step2(self, state, it, mode, p2, np2, p3, np3, p4, np4, x, p, g, grid):
-        self._hip.call("ipx_cg_step2", x.numel(), self._ptr(state), int(it), int(mode),
-                       self._ptr(p2), int(np2), self._ptr(p3), int(np3), self._ptr(p4), int(np4),
-                       self._ptr(x), self._ptr(p), self._ptr(g), int(grid), self._st())
+    def Pv():
+        return ShardVec(DV(L.p), sh, "col")
+
+    hits_boundary, stop_cond = False, 1
+    counter, last_viol_it = 0, -2
+    last_feasible_x = c.zeros_like()
+    it = 0
+    nbatch = batch if batch else 2
+    while it < max_iter:
+        end = min(max_iter, it + nbatch)
+        F.iterate(it, end)
+        s = L.state.tolist()             # one blocking read per batch
+        STATS["batches"] += 1
+        stop = int(s[ST_STOP])
+        if stop == 0:
+            it = end
+            if not batch:
+                nbatch = min(2 * nbatch, 64)
+            continue
+        it_stop = int(s[ST_IT_DONE])
+        alpha = s[ST_ALPHA]
+        if stop == 4:                     # :551
+            stop_cond = 4
+            break
+        if stop == 3:                     # :558-576
+            if np.isinf(trust_radius):
+                raise ValueError("Negative curvature not allowed "
+                                 "for unrestrited problems.")
+            _, al, hit = qp.box_sphere_intersections(X(), Pv(), lb, ub, trust_radius,
+                                                     entire_line=True)
+            xf = X().add_scaled(Pv(), al) if hit else X()
+            xf = qp.reinforce_box_boundaries(xf, lb, ub)
+            L.x = xf.loc.t
+            stop_cond, hits_boundary = 3, True
+            break
+        if stop == 2:                     # :583-596
+            _, theta, hit = qp.box_sphere_intersections(X(), Pv(), lb, ub, trust_radius,
+                                                        dscale=alpha)
+            xf = X().add_scaled(Pv(), theta * alpha) if hit else X()
+            xf = qp.reinforce_box_boundaries(xf, lb, ub)
+            L.x = xf.loc.t
+            stop_cond, hits_boundary = 2, True
+            break
+        mode = 0
+        if stop == 5:                     # :599-616 x_next outside the box
+            STATS["box_events"] += 1
+            if last_viol_it != it_stop - 1:
+                counter = 0
+            counter += 1
+            last_viol_it = it_stop
+            _, theta, hit = qp.box_sphere_intersections(X(), Pv(), lb, ub, trust_radius,
+                                                        dscale=alpha)
+            if hit:
+                last_feasible_x = qp.reinforce_box_boundaries(
+                    X().add_scaled(Pv(), theta * alpha), lb, ub)
+                counter = 0
+                last_viol_it = -2
+            if counter > max_infeasible_iter:
+                break
+            mode = 1
+            s2 = F.resume(it_stop, mode)
+            if int(s2[ST_STOP]) == 6:
+                stop, mode = 6, 1
+            else:
+                it = it_stop + 1
+                continue
+        if stop == 6:                     # projections.py:72-78 refinement
+            STATS["refine_events"] += 1
+            _refine_sharded(F)
+            F.resume(it_stop, mode | 2)
+            it = it_stop + 1
+            continue
+        raise RuntimeError("unexpected CG stop code %d" % stop)
+
+    x = ShardVec(DV(L.x), sh, "col")
+    if has_box and not qp.inside_box_boundaries(x, lb, ub):     # :636-638
+        x = last_feasible_x
+        hits_boundary = True
+    niter = int(L.state[ST_NITER].item())
+    STATS["fused_calls"] += 1
+    STATS["iterations"] += niter
+    return x, {'niter': niter, 'stop_cond': stop_cond, 'hits_boundary': hits_boundary}
+
+
+def _refine_sharded(F):
+    """Iterative refinement of g = Z r (projections.py:69-78) on the buffers of the fused
+    loop (L.r holds g, own + synchronised halo); the refined ||g||^2 replaces the packed
+    value step2 derives beta from."""
+    P, sh, L = F.P, F.sh, F.L
+    g = ShardVec(F.dv.DVec(L.r), sh, "col")
+    k = 0
+    while k < P.max_refin:
+        orth, Az = P.orthogonality(g)
+        if k > 0 and not orth > P.orth_tol:
+            break
+        g = g - P.A.T.dot(P._apply_inv(Az))
+        k += 1
+        P.stats["refinements"] += 1
+    L.r.copy_(g.loc.t)
+    F.pack[2] = g.sumsq_amax()[0]

@@ -357,34 +357,51 @@ def test_banded_traces(ips, size, banded2000, banded20000):
         close(host(got)[::s], w)
 
 
-def test_sharded_engine_single_rank(ips):
-    """The row-sharded CG driver with the HIP engine (world size 1: same
-    kernels, no neighbours) against the fused single-GPU loop."""
-    from ipsolver.sharded import ShardedProjectedCG, HipEngine
-    inst = BandedInstance(20000, 2000)
-    rng = np.random.default_rng(3)
-    hdiag = np.abs(rng.standard_normal(20000))
-    cg = ShardedProjectedCG(HipEngine(), inst.A, inst.H, hdiag)
-    x, info = cg.solve(inst.c, tol=0.0, max_iter=40)
-    from ipsolver.operators import DeviceHessian
-    A = ips.dv.DeviceCSR.from_scipy(inst.A)
-    H = DeviceHessian(20000, ips.dv.DeviceCSR.from_scipy(inst.H), ips.dv.DVec.from_host(hdiag))
-    Z, _, Y = ips.proj.projections(A)
-    xf, inf2 = ips.qp.projected_cg(H, inst.c, Z, Y, np.zeros(2000), tol=0, max_iter=40)
-    assert info["niter"] == inf2["niter"] == 40 and info["stop_cond"] == inf2["stop_cond"]
-    assert np.max(np.abs(x - xf.to_host())) <= 1e-12 * np.max(np.abs(x))
-    # trust-region exit: both drivers end on the sphere at the same point
-    radius = 0.4 * float(np.linalg.norm(x))
-    cg2 = ShardedProjectedCG(HipEngine(), inst.A, inst.H, hdiag)
-    xs, info_s = cg2.solve(inst.c, trust_radius=radius)
-    xq, info_q = ips.qp.projected_cg(H, inst.c, Z, Y, np.zeros(2000), trust_radius=radius)
-    assert (info_s["niter"], info_s["stop_cond"], info_s["hits_boundary"]) == \
-        (info_q["niter"], 2, True) and info_q["stop_cond"] == 2
-    assert abs(np.linalg.norm(xs) - radius) <= 1e-12 * radius
-    assert np.max(np.abs(xs - xq.to_host())) <= 1e-11 * np.max(np.abs(xs))
+def _sharded_problem(world, rank, n, m):
+    from ipsolver import sharded
+    inst = BandedInstance(n, m)
+    A = inst.A.tocsr()
+    lay = sharded.ShardLayout(A.indptr, A.indices, A.shape, world, rank)
+    sh = sharded.Sharding(lay, sharded.ShardComm(), sharded.HipOps())
+    return inst, sh, sharded.ShardCSR.from_global(sh, inst.A), \
+        sharded.ShardHessian.from_global(sh, inst.H)
 
 
-def _two_rank_worker(rank, world, port, out_path):
+def test_sharded_fused_loop_single_rank(ips):
+    """The partitioned sharded solver with the HIP kernels at world size 1 (same kernels, no
+    neighbours, own-range partial sums = everything) against the single-GPU device loop:
+    every exit of the loop, refinement included."""
+    from ipsolver import sharded
+    n, m = 20000, 2000
+    inst, sh, A, H = _sharded_problem(1, 0, n, m)
+    Z, LS, Y = sharded.projections(A)
+    A1 = ips.dv.DeviceCSR.from_scipy(inst.A)
+    H1 = ips.dv.DeviceCSR.from_scipy(inst.H)
+    Z1, _, Y1 = ips.proj.projections(A1)
+    c = sh.from_global(inst.c, "col")
+    gnorm = ips.dv.norm(Z1.dot(inst.c))
+    for name, kw in inst.pcg_variants(gnorm).items():
+        kws = dict(kw)
+        for key in ("lb", "ub"):
+            if key in kws:
+                kws[key] = sh.from_global(kws[key], "col")
+        calls = sharded.STATS["fused_calls"]
+        x, info = ips.qp.projected_cg(H, c, Z, Y, sh.zeros("row"), **kws)
+        assert sharded.STATS["fused_calls"] == calls + 1, "device-resident sharded loop not taken"
+        x1, info1 = ips.qp.projected_cg(H1, inst.c, Z1, Y1, np.zeros(m), **kw)
+        assert info == info1, (name, info, info1)
+        close(x.to_host(), host(x1), 1e-12)
+    Zr, _, Yr = sharded.projections(A, orth_tol=1e-30, max_refin=2)
+    ev = sharded.STATS["refine_events"]
+    x, info = ips.qp.projected_cg(H, c, Zr, Yr, sh.zeros("row"), tol=0, max_iter=12)
+    assert sharded.STATS["refine_events"] - ev >= 11
+    Z2, _, Y2 = ips.proj.projections(A1, orth_tol=1e-30, max_refin=2)
+    x1, info1 = ips.qp.projected_cg(H1, inst.c, Z2, Y2, np.zeros(m), tol=0, max_iter=12)
+    assert info == info1
+    close(x.to_host(), host(x1), 1e-12)
+
+
+def _multi_rank_worker(rank, world, port, out_path):
     import os
     import sys
     import torch
@@ -397,51 +414,64 @@ def _two_rank_worker(rank, world, port, out_path):
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from banded_setup import BandedInstance
-        from ipsolver.sharded import ShardedProjectedCG, HipEngine
-        inst = BandedInstance(20000, 2000)
-        hdiag = np.abs(np.random.default_rng(3).standard_normal(20000))
-        cg = ShardedProjectedCG(HipEngine(), inst.A, inst.H, hdiag)
-        x, info = cg.solve(inst.c, tol=0.0, max_iter=30)
-        args = cg._c_args[0]
-        fused = torch.tensor([float(args.A_span > 0), float(args.At_qv > 0)])
-        dist.all_reduce(fused, op=dist.ReduceOp.MIN)          # engaged on every rank?
+        from ipsolver import sharded, qp
+        n, m = 20000, 2000
+        inst, sh, A, H = _sharded_problem(world, rank, n, m)
+        Z, LS, Y = sharded.projections(A)
+        c = sh.from_global(inst.c, "col")
+        out = {}
+        gnorm = float(np.sqrt(Z.dot(c).sumsq_amax()[0]))
+        for name, kw in inst.pcg_variants(gnorm).items():
+            kws = dict(kw)
+            for key in ("lb", "ub"):
+                if key in kws:
+                    kws[key] = sh.from_global(kws[key], "col")
+            x, info = qp.projected_cg(H, c, Z, Y, sh.zeros("row"), **kws)
+            out["pcg_%s_x" % name] = x.to_host()
+            out["pcg_%s_info" % name] = np.array([info["niter"], info["stop_cond"],
+                                                  int(info["hits_boundary"])])
+        Zr, _, Yr = sharded.projections(A, orth_tol=1e-30, max_refin=2)
+        x, info = qp.projected_cg(H, c, Zr, Yr, sh.zeros("row"), tol=0, max_iter=15)
+        out["refine_x"] = x.to_host()
+        out["stats"] = np.array([sharded.STATS[k] for k in ("fused_calls", "box_events",
+                                                            "refine_events")]
+                                + [sh.comm.stats["exchange"]])
+        flags = torch.tensor([float(sharded.STATS["fused_calls"])])
+        dist.all_reduce(flags, op=dist.ReduceOp.MIN)          # engaged on every rank?
+        out["fused_min"] = flags.numpy()
         if rank == 0:
-            np.savez(out_path, x=x, info=np.array([info["niter"], info["stop_cond"]]),
-                     fused=fused.numpy())
+            np.savez(out_path, **out)
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("world", [2, 3])
-def test_sharded_hip_engine_multi_rank(world, tmp_path):
-    """The HIP kernels under the row partition: `world` processes share cuda:0
-    and talk over gloo (RCCL refuses two ranks on one device; the collectives
-    are staged through the host in this test only).  Exercises the halo
-    columns of H, the explicit row vector of the fused SpMV epilogue and the
-    replicated banded solve against the oracle."""
+def test_sharded_fused_loop_multi_rank(world, tmp_path, banded20000):
+    """The HIP kernels under the row partition: `world` processes share cuda:0 and talk over
+    gloo (RCCL refuses two ranks on one device; the collectives are staged through the host in
+    this test only).  The device-resident loop -- two all-reduces and one halo exchange of g
+    per iteration -- against the REFERENCE's golden traces (every exit of the loop: tolerance,
+    trust region, box events) and, with refining projections, against the oracle."""
     import socket
-    import scipy.sparse as sps
     import torch.multiprocessing as mp
     import oracle
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     out = str(tmp_path / "x.npz")
-    mp.spawn(_two_rank_worker, args=(world, port, out), nprocs=world, join=True)
-    got = np.load(out)
+    mp.spawn(_multi_rank_worker, args=(world, port, out), nprocs=world, join=True)
+    got, gold = np.load(out), banded20000
+    st = int(gold["stride"][0])
     inst = BandedInstance(20000, 2000)
-    hdiag = np.abs(np.random.default_rng(3).standard_normal(20000))
-    Z, _, Y = oracle.projections(inst.A)
-    xo, info = oracle.projected_cg(inst.H + sps.diags(hdiag), inst.c, Z, Y, np.zeros(2000),
-                                   tol=0, max_iter=30)
-    assert list(got["info"]) == [info["niter"], info["stop_cond"]]
-    assert np.max(np.abs(got["x"] - xo)) <= 1e-10 * np.max(np.abs(xo))
-    # the rank-local fusions (step1 in the partial A.r SpMV over a column block with empty
-    # row tiles; g = r - A'v in the replicated solve) were the path taken on every rank
-    import os
-    if not os.environ.get("IPX_NO_FUSE"):
-        assert list(got["fused"]) == [1.0, 1.0]
+    for name in inst.pcg_variants(1.0):
+        assert list(got["pcg_%s_info" % name]) == list(gold["pcg_%s_info" % name]), name
+        close(got["pcg_%s_x" % name][::st], gold["pcg_%s_x" % name])
+    Zo, _, Yo = oracle.projections(inst.A, "NormalEquation", orth_tol=1e-30, max_refin=2)
+    xo, _ = oracle.projected_cg(inst.H, inst.c, Zo, Yo, np.zeros(2000), tol=0, max_iter=15)
+    close(got["refine_x"], xo)
+    fused_calls, box_events, refine_events, exchanges = got["stats"]
+    assert got["fused_min"][0] >= 6 and box_events > 0 and refine_events >= 14
+    assert exchanges > 100
 
 
 @pytest.mark.parametrize("n,m", [(400, 40), (6000, 600)])
