@@ -978,7 +978,11 @@ int ipx_cg_shard2_segment(const ipx_cg_args *a, const ipx_shard2_ext *e, int32_t
     job.ptr[2] = a->part3 + e->p3_lo;        job.count[2] = (int)(e->p3_hi - e->p3_lo);
     job.ptr[3] = a->part4 + e->p4_lo;        job.count[3] = (int)(e->p4_hi - e->p4_lo);
     job.active = 15;
-    hipLaunchKernelGGL(k_cg_range_pack, dim3(1), dim3(256), 0, st, job, e->pack, guard);
+    // NOT guarded by the stop flag: once an iteration has raised it, the remaining iterations
+    // of the batch are no-ops but their all-reduces still run; re-packing the (unchanged)
+    // own sums keeps the reduced values those of the iteration that stopped
+    hipLaunchKernelGGL(k_cg_range_pack, dim3(1), dim3(256), 0, st, job, e->pack,
+                       (const double *)nullptr);
     IPX_CHECK_LAUNCH();
     return IPX_OK;
   }
@@ -998,7 +1002,8 @@ int ipx_cg_shard2_segment(const ipx_cg_args *a, const ipx_shard2_ext *e, int32_t
   for (int q = 0; q < 4; ++q) { job.ptr[q] = a->part1; job.count[q] = 0; }
   job.ptr[1] = a->part1 + a->H_ntiles + e->p1_lo;  job.count[1] = (int)(e->p1_hi - e->p1_lo);
   job.active = 2;
-  hipLaunchKernelGGL(k_cg_range_pack, dim3(1), dim3(256), 0, st, job, e->s1, guard);
+  hipLaunchKernelGGL(k_cg_range_pack, dim3(1), dim3(256), 0, st, job, e->s1,
+                     (const double *)nullptr);      // see phase 0
   IPX_CHECK_LAUNCH();
   return IPX_OK;
 }
