@@ -210,36 +210,48 @@ def single_gpu_measure(A_h, H_h, hdiag_h, c_h, n, m, K, W, repeats=20):
     }
 
 
-def sharded_leg(args, world, rank, A_h, H_h, hdiag_h, c_h, n, m, K, W):
-    """N > 1: row-sharded projected CG with RCCL collectives (strong scaling)."""
+def _sharded_setup(A_h, H_h, hdiag_h, c_h):
+    """Partition one subproblem over the ranks and prime the device-resident sharded loop
+    (tol = 0, infinite radius) exactly like projected_cg does."""
     import numpy as np
-    import torch
-    import torch.distributed as dist
-    from ipsolver.sharded import ShardedProjectedCG, HipEngine, ST_STOP, ST_IT_DONE
+    from ipsolver import sharded
+    world, rank = sharded.ShardComm().world, sharded.ShardComm().rank
+    A_h = A_h.tocsr()
+    lay = sharded.ShardLayout(A_h.indptr, A_h.indices, A_h.shape, world, rank)
+    sh = sharded.Sharding(lay, sharded.ShardComm(), sharded.HipOps())
+    A = sharded.ShardCSR.from_global(sh, A_h)
+    H = sharded.ShardHessian.from_global(sh, H_h, hdiag_h)
+    Z, LS, Y = sharded.projections(A)
+    c = sh.from_global(c_h, "col")
+    b = sh.zeros("row")
+    x0 = Y.dot(-b)
+    r0 = Z.dot(H.dot(x0) + c)
+    g0 = Z.dot(r0)
+    rt_g = g0.sumsq_amax()[0]
+    F = sharded.FusedShardedCG(H, Z.projector, None, None)
+    return sh, F, (x0, r0, g0, rt_g, 0.0, np.inf)
 
-    cg = ShardedProjectedCG(HipEngine(), A_h, H_h, hdiag_h)
-    cg.prime(c_h, 0.0, np.inf)
 
-    def barrier():
-        torch.cuda.synchronize()
-        dist.barrier()
-        torch.cuda.synchronize()
-
-    # tol = 0: the CG reaches an exactly zero residual after ~500 iterations, so the loop is
-    # restarted from the primed state every SEG iterations (device copies, no collective)
+def _sharded_run(F, primed, K, W, dist, torch):
+    """W warm-up + K timed iterations (restart from the primed state every SEG iterations:
+    device copies and one SpMV, no collective); max over ranks of the elapsed time."""
+    from ipsolver.sharded import ST_STOP, ST_IT_DONE
     SEG = 200
-    primed = {k: getattr(cg, k).clone() for k in ("x", "r", "p_ext", "Hp", "state", "s1")}
 
     def run(it0, it1):
         it = it0
         while it < it1:
             j = it % SEG
-            if j == 0 and it > 0:
-                for k, t in primed.items():
-                    getattr(cg, k).copy_(t)
+            if j == 0:
+                F.prime(*primed)
             end = min(it1, it - j + SEG)
-            cg.iterate(j, j + (end - it))
+            F.iterate(j, j + (end - it))
             it = end
+
+    def barrier():
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
 
     run(0, W)
     barrier()
@@ -247,7 +259,7 @@ def sharded_leg(args, world, rank, A_h, H_h, hdiag_h, c_h, n, m, K, W):
     run(W, W + K)
     barrier()
     elapsed = time.perf_counter() - t0
-    s = cg.read_state()
+    s = F.L.state.tolist()
     last_segment = (W + K - 1) % SEG + 1
     if int(s[ST_STOP]) != 0 or int(s[ST_IT_DONE]) != last_segment:
         raise SystemExit("timed region did not run %d iterations: stop=%s done=%s (expected %d in "
@@ -255,9 +267,25 @@ def sharded_leg(args, world, rank, A_h, H_h, hdiag_h, c_h, n, m, K, W):
     tt = torch.tensor([elapsed], dtype=torch.float64,
                       device="cuda" if dist.get_backend() == "nccl" else "cpu")
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    elapsed = float(tt.item())
+    return float(tt.item()), last_segment
+
+
+def sharded_leg(args, world, rank, A_h, H_h, hdiag_h, c_h, n, m, K, W):
+    """N > 1: the SAME n=1e6 / m=1e5 subproblem row-partitioned over the ranks (BASELINE
+    config 4, strong scaling; ipsolver/sharded.py): both spaces partitioned, per iteration
+    two RCCL all-reduces (2 + 4 doubles) and one neighbour exchange of the halo of g."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from ipsolver import sharded
+    from ipsolver.synthetic import CenteredBandedNLP
+
+    sh, F, primed = _sharded_setup(A_h, H_h, hdiag_h, c_h)
+    elapsed, last_segment = _sharded_run(F, primed, K, W, dist, torch)
+    calls = dict(sh.comm.stats)
+
     # ---- untimed: the sharded iterate against the single-GPU fused loop (rank 0)
-    x_sharded = cg.gather_x()                      # collective
+    x_sharded = sharded.ShardVec(sharded.HipOps().dv.DVec(F.L.x), sh, "col").to_host()
     parity = None
     if rank == 0:
         try:
@@ -270,21 +298,63 @@ def sharded_leg(args, world, rank, A_h, H_h, hdiag_h, c_h, n, m, K, W):
             x1 = x1.to_host()
             parity = {"iterations": int(info1["niter"]),
                       "max_rel_diff": float(np.max(np.abs(x_sharded - x1)) / np.max(np.abs(x1)))}
+            del H1, Z1, Y1
         except Exception as exc:                   # never lose the measurement over the check
             parity = {"error": repr(exc)}
+
+    # ---- latency floor of the two collectives the loop uses, measured here: back-to-back
+    # all-reduces of the 4-double pack / exchanges of the halo of g, stream-synchronised once
+    def floor(fn, reps=200):
+        for _ in range(20):
+            fn()
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return 1e6 * (time.perf_counter() - t0) / reps
+    clo, chi, sl, sr = F.col_geom
+    scratch = torch.zeros(4, dtype=torch.float64, device="cuda")
+    lat_allreduce = floor(lambda: sh.comm.all_reduce(scratch))
+    halo_buf = F.L.r.clone()
+    lat_exchange = floor(lambda: sh.comm.exchange(halo_buf, clo, chi, sl, sr))
+
+    # ---- a weak-scaling point in the same run: n = world * 1e6 (per-GPU work fixed)
+    weak = None
+    if not args.no_weak:
+        try:
+            nw, mw = n * world, m * world
+            probw = CenteredBandedNLP(nw, mw, seed=0)
+            xw = probw.x0
+            vw = 0.1 * np.random.default_rng(7).standard_normal(mw)
+            shw, Fw, primedw = _sharded_setup(probw.constr_jac(xw), probw.hess(xw),
+                                              probw.kappa * probw.Wt.dot(vw), probw.grad(xw))
+            ew, _ = _sharded_run(Fw, primedw, K, W, dist, torch)
+            weak = {"n": nw, "m": mw, "iterations_per_s": K / ew, "ms_per_step": 1e3 * ew / K,
+                    "note": "per-GPU work = the 1-GPU benchmark's (n=1e6 per rank); compare "
+                            "with the n_gpus=1 value for weak-scaling efficiency"}
+            del shw, Fw, primedw, probw
+        except Exception as exc:
+            weak = {"error": repr(exc)}
+
     nnzA, nnzH = A_h.nnz, H_h.nnz
     iter_bytes = (spmv_bytes(nnzH, n, n, 1) + spmv_bytes(nnzA, m, n)
                   + spmv_bytes(nnzA, n, m, 1) + 2 * 5 * 8 * n + 4 * 8 * m)
+    per_it = {k: v / max(1, (W + K)) for k, v in calls.items()}
+    lo, hi = sh.lay.geom("col")[2:]
     result = {
         "metric": "projected-CG iters/sec (fp64) at n=1e6,m=1e5",
         "value": K / elapsed, "unit": "iterations/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "config4: the config-3 subproblem row-partitioned over %d GPUs, "
-                               "three RCCL all-reduces per iteration (p'Hp; partial A.r; packed "
-                               "norms + boundary entries of g), halos advanced locally" % world,
+        "config": {"workload": "config4: the config-3 subproblem row-partitioned over %d GPUs: "
+                               "constraint rows AND variables partitioned (nothing replicated), "
+                               "per iteration 2 RCCL all-reduces (2 and 4 doubles) + 1 "
+                               "neighbour exchange of the halo of g" % world,
                    "n": n, "m": m, "nnz_A": int(nnzA), "nnz_H": int(nnzH),
-                   "parallelism": "rows sharded x%d, constraint space replicated" % world},
+                   "parallelism": "rows and variables sharded x%d, halo = 1 block of %d rows"
+                                  % (world, sh.lay.row_block)},
         "roofline": {"bound": "hbm", "kernel": "whole iteration (collective-latency bound at "
                                                "this size, see DESIGN.md section 5)",
                      "achieved": iter_bytes / (elapsed / K) / 1e9, "peak": HBM_PEAK_GBS * world,
@@ -292,8 +362,17 @@ def sharded_leg(args, world, rank, A_h, H_h, hdiag_h, c_h, n, m, K, W):
                      "frac": iter_bytes / (elapsed / K) / 1e9 / (HBM_PEAK_GBS * world),
                      "traffic": None},
         "parity_vs_single_gpu": parity,
-        "collectives_per_iteration": {"all_reduce": 3, "halo_exchange": 0,
-                                      "bytes_all_reduce": 8 * m + 8 * (6 + 2 * cg.h * world)},
+        "collectives_per_iteration": {
+            "all_reduce": per_it["all_reduce"], "all_reduce_bytes": per_it["all_reduce_bytes"],
+            "neighbour_exchange": per_it["exchange"],
+            "exchange_bytes_sent_by_rank0": per_it["exchange_bytes"],
+            "halo_columns_rank0": [int(lo), int(sh.lay.geom("col")[1] - hi)]},
+        "collective_latency_floor_us": {"all_reduce_4_doubles": lat_allreduce,
+                                        "halo_exchange": lat_exchange,
+                                        "method": "200 back-to-back calls through "
+                                                  "torch.distributed (%s), one stream "
+                                                  "synchronise" % dist.get_backend()},
+        "weak_scaling_point": weak,
     }
     if rank == 0:
         print(json.dumps(result))
@@ -311,6 +390,8 @@ def main():
     ap.add_argument("--cpu-iters", type=int, default=400)
     ap.add_argument("--repeats", type=int, default=20,
                     help="further K-step regions after the contract's one (median/min/max)")
+    ap.add_argument("--no-weak", action="store_true",
+                    help="N > 1: skip the weak-scaling point (n = N * 1e6)")
     ap.add_argument("--no-big", action="store_true",
                     help="skip the out-of-Infinity-Cache measurement (n=4e6, m=4e5)")
     args = ap.parse_args()

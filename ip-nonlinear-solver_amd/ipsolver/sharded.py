@@ -663,10 +663,14 @@ class FusedShardedCG:
         L.x.copy_(x0.loc.t)
         L.r.copy_(r0.loc.t)
         self._hip.call("ipx_axpby", n, -1.0, self.dv._p(g0.loc.t), 0.0, None, self.dv._p(L.p), st)
-        init = np.zeros(L.state.numel())
-        init[ST_RTG0], init[ST_TOL], init[ST_RADIUS] = rt_g, tol, trust_radius
-        init[ST_ORTH_RHS] = self.P.orth_tol * self.P.norm_A
-        L.state.copy_(torch.from_numpy(init))
+        key = (rt_g, tol, trust_radius)
+        if getattr(self, "_init_key", None) != key:      # (a restart re-uses the device copy)
+            init = np.zeros(L.state.numel())
+            init[ST_RTG0], init[ST_TOL], init[ST_RADIUS] = rt_g, tol, trust_radius
+            init[ST_ORTH_RHS] = self.P.orth_tol * self.P.norm_A
+            self._init_dev = torch.from_numpy(init).to(L.state.device)
+            self._init_key = key
+        L.state.copy_(self._init_dev)
         self._hip.check(self.lib.ipx_cg_hp(L.ref(), st), "ipx_cg_hp")
         self._hip.call("ipx_cg_shard2_fold_hp", L.ref(), ctypes.byref(self.ext), st)
 
@@ -830,3 +834,147 @@ def _refine_sharded(F):
         P.stats["refinements"] += 1
     L.r.copy_(g.loc.t)
     F.pack[2] = g.sumsq_amax()[0]
+
+
+# --------------------------------------------------------------------------- outer loops
+class _Empty:
+    """A distributed vector of global length 0 (the slack / inequality-multiplier slices of a
+    problem without inequalities)."""
+    kind = None
+
+    def __len__(self):
+        return 0
+
+
+def _slice(self, key):
+    """``z[:n]`` / ``z[n:n]``: the whole vector or nothing -- what barrier.py asks of z = [x; s]
+    when there are no slacks."""
+    if not isinstance(key, slice) or key.step not in (None, 1):
+        raise TypeError("ShardVec supports whole / empty slices only")
+    n = len(self)
+    start, stop, _ = key.indices(n)
+    if start == 0 and stop == n:
+        return self
+    if stop <= start:
+        return _Empty()
+    raise NotImplementedError("partial slices of a distributed vector")
+
+
+ShardVec.__getitem__ = _slice
+
+
+class ShardedBackend:
+    """The vector / matrix / operator factory ``sqp.py`` and ``barrier.py`` are written
+    against (cf. backend_hip), for one sharded problem: every vector is a ``ShardVec``, the
+    Jacobian a ``ShardCSR``, the Hessian a ``ShardHessian``; scalars (norms, dot products)
+    are all-reduced.  Equality-constrained problems (BASELINE configs 3 / 4: both outer
+    methods); inequality constraints need the slack rows sharded too and are refused."""
+    name = "sharded"
+
+    def __init__(self, sh):
+        self.sh = sh
+
+    def asvec(self, a):
+        if isinstance(a, (ShardVec, _Empty)):
+            return a
+        a = np.asarray(a, dtype=float)
+        return self.sh.from_global(a, self.sh.kind_of_len(len(a)))
+
+    def tohost(self, v):
+        return v.to_host() if isinstance(v, ShardVec) else np.asarray(v)
+
+    def zeros(self, n):
+        return _Empty() if n == 0 else self.sh.zeros(self.sh.kind_of_len(n))
+
+    def full(self, n, value):
+        return self.sh.full(self.sh.kind_of_len(n), value)
+
+    def copy(self, v):
+        return v.copy()
+
+    def hstack(self, parts):
+        parts = [p for p in parts if len(p)]
+        if len(parts) != 1:
+            raise NotImplementedError("sharded backend: stacked vectors (inequality constraints)")
+        return parts[0]
+
+    def norm(self, v):
+        return float(np.sqrt(v.sumsq_amax()[0])) if len(v) else 0.0
+
+    def norm_inf(self, v):
+        return v.sumsq_amax()[1] if len(v) else 0.0
+
+    def dot(self, a, b):
+        return a.dot(b)
+
+    def sum_log(self, s):
+        if len(s):
+            raise NotImplementedError("sharded backend: slack variables")
+        return 0.0
+
+    def matrix(self, J, key=None):
+        return J
+
+    def mark_constant(self, A):
+        return A
+
+    def hessian_operator(self, terms, n_vars, slack_block):
+        if slack_block is not None or not isinstance(terms, ShardHessian):
+            raise NotImplementedError("sharded backend: the Lagrangian Hessian callback must "
+                                      "return a ShardHessian")
+        return terms
+
+    def projections(self, A, method=None):
+        return projections(A, method)
+
+    def modified_dogleg(self, A, Y, b, trust_radius, lb, ub):
+        from . import qp
+        return qp.modified_dogleg(A, Y, b, trust_radius, lb, ub)
+
+    def projected_cg(self, H, c, Z, Y, b, trust_radius, lb, ub):
+        from . import qp
+        return qp.projected_cg(H, c, Z, Y, b, trust_radius, lb, ub)
+
+    def box_intersections(self, z, d, lb, ub, entire_line=False):
+        from . import qp
+        return qp.box_intersections(z, d, lb, ub, entire_line)
+
+
+def minimize_equality_constrained(sh, fun, grad, lagr_hess, constr, jac, x0, method=None,
+                                  xtol=1e-8, gtol=1e-8, max_iter=1000, callback=None, **options):
+    """``minimize_constrained`` for an equality-constrained NLP on distributed data (the full
+    solve of BASELINE config 4): the same outer loops (``sqp.equality_constrained_sqp`` /
+    ``barrier.tr_interior_point``, reference _minimize_constrained.py:441-565) over the
+    sharded backend.  Callbacks take and return distributed objects:
+
+        fun(x) -> float (already summed over the ranks)      grad(x) -> ShardVec
+        constr(x) -> ShardVec (rows)                          jac(x) -> ShardCSR
+        lagr_hess(x, v) -> ShardHessian
+    """
+    import time
+    from scipy.optimize import OptimizeResult
+    from .barrier import tr_interior_point
+    from .minimize import TERMINATION_MESSAGES, _METHODS, _make_stop_criteria
+    from .sqp import equality_constrained_sqp
+    xp = ShardedBackend(sh)
+    method = _METHODS[method or 'equality_constrained_sqp']
+    state = OptimizeResult(niter=0, nfev=1, ngev=1, ncev=1, njev=1, nhev=0, cg_niter=0,
+                           cg_info={})
+    stop_criteria = _make_stop_criteria(method, gtol, xtol, max_iter, 1e-8, callback, 0,
+                                        lambda s: s)
+    n, m = sh.lay.n, sh.lay.m
+    f0, g0, c0, J0 = fun(x0), grad(x0), constr(x0), jac(x0)
+    start = time.time()
+    if method == 'equality_constrained_sqp':
+        result = equality_constrained_sqp(
+            lambda x: (fun(x), constr(x)), lambda x: (grad(x), jac(x)), lagr_hess,
+            x0, f0, g0, c0, J0, stop_criteria, state, xp, **options)
+    else:
+        result = tr_interior_point(
+            fun, grad, lambda x, v_eq, v_ineq: lagr_hess(x, v_eq), n, 0, m,
+            lambda x: (_Empty(), constr(x)), lambda x: (None, jac(x)), x0, f0, g0,
+            _Empty(), None, c0, J0, stop_criteria, None, xtol, state, xp, **options)
+    result.execution_time = time.time() - start
+    result.method = method
+    result.message = TERMINATION_MESSAGES[result.status]
+    return result

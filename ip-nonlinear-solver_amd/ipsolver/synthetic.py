@@ -144,3 +144,68 @@ class DeviceCallbacks:
 
     def constraints(self, ns, kind=('equals', 0)):
         return ns.NonlinearConstraint(self.constr_fun, kind, self.constr_jac, self.constr_hess)
+
+
+class ShardedCallbacks:
+    """The same NLP on row-sharded data (``ipsolver.sharded``): every callback works on the
+    rank's own + halo entries and returns distributed objects.  User-land code written with
+    the distributed vectors' own arithmetic, so it runs on whatever local backend the
+    ``Sharding`` context carries (HIP kernels; the numpy twin in the CPU tests)."""
+
+    def __init__(self, prob, sh):
+        from . import sharded
+        self.p, self.sh, self.S = prob, sh, sharded
+        self.Q = sharded.ShardHessian.from_global(sh, prob.Q)
+        self.A0 = sharded.ShardCSR.from_global(sh, prob.A0)
+        self.W = self.A0.with_values(self._local_data(prob.W))
+        self.q = sh.from_global(prob.q, "col")
+        self.x_feas = sh.from_global(prob.x_feas, "col")
+        self.b = sh.from_global(prob.b, "row")
+        self.x0 = sh.from_global(prob.x0, "col")
+        d = sh.lay.me
+        loc = sps.csr_matrix(prob.A0[d["E0"]:d["E1"], d["x0"]:d["x1"]])
+        self._a0 = loc.data.copy()
+        self._w = self._local_data(prob.W)
+        self._cols = loc.indices.astype(np.int64)
+        Ql = sps.csr_matrix(prob.Q[d["x0"]:d["x1"], d["x0"]:d["x1"]])
+        _, _, lo, hi = sh.lay.geom("col")
+        self._Q_local = sh.ops.csr(Ql, row_breaks=[lo, hi])
+        self._nloc = Ql.shape[0]
+        self._torch = None
+        if hasattr(self.x0.loc, "t"):             # device arrays: gather with torch (user-land)
+            import torch
+            self._torch = torch
+            dev = self.x0.loc.t.device
+            self._a0_d = torch.from_numpy(self._a0).to(dev)
+            self._w_d = torch.from_numpy(self._w).to(dev)
+            self._cols_d = torch.from_numpy(self._cols).to(dev)
+
+    def _local_data(self, M):
+        d = self.sh.lay.me
+        return sps.csr_matrix(M[d["E0"]:d["E1"], d["x0"]:d["x1"]]).data.copy()
+
+    def fun(self, x):
+        dl = x - self.x_feas
+        d2 = dl * dl
+        return (0.5 * dl.dot(self.Q.dot(dl)) - self.p.eps * self.q.dot(dl)
+                + 0.25 * self.p.rho * d2.dot(d2))
+
+    def grad(self, x):
+        dl = x - self.x_feas
+        return self.Q.dot(dl) - self.p.eps * self.q + self.p.rho * (dl * dl * dl)
+
+    def constr_fun(self, x):
+        return self.A0.dot(x) + 0.5 * self.p.kappa * self.W.dot(x * x) - self.b
+
+    def constr_jac(self, x):
+        if self._torch is not None:
+            val = self._a0_d + self.p.kappa * self._w_d * x.loc.t[self._cols_d]
+            from .device import DeviceCSR
+            return self.S.ShardCSR(self.sh, DeviceCSR(self.A0.local.pattern, val))
+        return self.A0.with_values(self._a0 + self.p.kappa * self._w * x.loc[self._cols])
+
+    def lagr_hess(self, x, v):
+        dl = x - self.x_feas
+        diag = 3 * self.p.rho * (dl * dl) + self.p.kappa * self.W.T.dot(v)
+        return self.S.ShardHessian(self.sh, self.sh.ops.hessian(self._nloc, self._Q_local,
+                                                                diag.loc))

@@ -20,6 +20,7 @@ Outputs (numbers only -- no reference source travels):
   qp_extra.json     projection refinement cases (test_projections.py:48-65,141-156:
                     orth_tol=1e-18, max_refin 100 / 10) and rank-deficient Jacobians
                     (SVD fallback, projections.py:101-108,181-187,236-287)
+  e2e_n20000.json   (``--n20000``) banded equality NLP at n=20000 / m=2000, both methods
   config2.json      (``--big`` only: minutes) dense equality QP of BASELINE config 2 at
                     n=4000/m=800 and n=10000/m=2000: scalar traces + strided x
 """
@@ -344,6 +345,17 @@ def e2e():
 
 
 def main():
+    if "--n20000" in sys.argv:
+        # banded equality NLP at a size the row-sharded solver can split (8 blocks of 260 rows)
+        out = {}
+        prob = synthetic.CenteredBandedNLP(20000, 2000, eps=1e-3)
+        for method in ("tr_interior_point", "equality_constrained_sqp"):
+            key = "banded_eq_n20000_%s" % method
+            out[key] = run_e2e(key, prob.fun, prob.x0, prob.grad, prob.hess,
+                               prob.constraints(ref), method=method)
+        with open(os.path.join(HERE, "e2e_n20000.json"), "w") as f:
+            json.dump(out, f)
+        return
     if "--big" in sys.argv:
         out = {}
         for n, m in ((4000, 800), (10000, 2000)):

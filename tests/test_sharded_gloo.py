@@ -95,6 +95,70 @@ def _worker(rank, world, port, out_path):
         dist.destroy_process_group()
 
 
+def _solve_worker(rank, world, port, method, out_path):
+    _setup(rank, world, port)
+    try:
+        from banded_setup import load_synthetic
+        from ipsolver import sharded
+        from ipsolver.synthetic import ShardedCallbacks
+        from oracle.numpy_local import NumpyOps
+        prob = load_synthetic().CenteredBandedNLP(N, M, eps=1e-3)
+        A = prob.A0.tocsr()
+        lay = sharded.ShardLayout(A.indptr, A.indices, A.shape, world, rank)
+        sh = sharded.Sharding(lay, sharded.ShardComm(), NumpyOps())
+        cb = ShardedCallbacks(prob, sh)
+        rows = []
+
+        def record(state):
+            rows.append([int(state.niter), int(state.cg_niter), float(state.trust_radius),
+                         float(state.penalty), float(getattr(state, "barrier_parameter", np.nan)),
+                         float(state.optimality), float(state.constr_violation),
+                         int(state.nfev)])
+            return False
+        res = sharded.minimize_equality_constrained(
+            sh, cb.fun, cb.grad, cb.lagr_hess, cb.constr_fun, cb.constr_jac, cb.x0,
+            method=method, callback=record)
+        x = res.x.to_host()
+        if rank == 0:
+            np.savez(out_path, x=x, rows=np.array(rows),
+                     counts=np.array([res.status, res.niter, res.cg_niter, res.nfev, res.ngev,
+                                      res.nhev, res.ncev, res.njev]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("method", ["equality_constrained_sqp", "tr_interior_point"])
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_full_solve_matches_reference(world, method, tmp_path):
+    """BASELINE config 4 end to end at n = 20000: the whole equality-constrained solve (outer
+    loops sqp.py / barrier.py over the sharded backend, sharded callbacks) against the trace
+    of the REFERENCE on the same seeded problem (tests/golden/e2e_n20000.json)."""
+    import json
+    from conftest import unjson
+    from test_host_logic import EPS
+    path = str(tmp_path / "solve.npz")
+    mp.spawn(_solve_worker, args=(world, _free_port(), method, path), nprocs=world, join=True)
+    got = np.load(path)
+    with open(os.path.join(ROOT, "tests", "golden", "e2e_n20000.json")) as f:
+        gold = json.load(f)["banded_eq_n20000_%s" % method]
+    assert list(got["counts"]) == [gold[k] for k in ("status", "niter", "cg_niter", "nfev", "ngev",
+                                                     "nhev", "ncev", "njev")]
+    want = np.array([[np.nan if isinstance(v, str) else v for v in r]
+                     for r in unjson(gold["trace"])], dtype=float)
+    rows = got["rows"]
+    assert rows.shape == want.shape
+    for col in (0, 1, 7):
+        assert np.array_equal(rows[:, col], want[:, col])
+    for col in (2, 3, 4, 5, 6):
+        ok = np.isfinite(want[:, col])
+        if not ok.any():
+            continue
+        floor = 256 * EPS * np.max(np.abs(want[ok, col]))
+        assert np.all(np.abs(rows[ok, col] - want[ok, col]) <= 1e-9 * np.abs(want[ok, col]) + floor)
+    gx = np.asarray(unjson(gold["x"]))
+    close(got["x"][::max(1, N // 50)], gx, 1e-9)
+
+
 @pytest.fixture(scope="module")
 def runs(tmp_path_factory):
     """One spawn per world size; every test below reads its outputs."""
