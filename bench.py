@@ -338,6 +338,31 @@ def sharded_leg(args, world, rank, A_h, H_h, hdiag_h, c_h, n, m, K, W):
         except Exception as exc:
             weak = {"error": repr(exc)}
 
+    # ---- the whole config-4 solve to gtol on the sharded backend (second half of the metric)
+    full_solve = None
+    try:
+        import warnings
+        from ipsolver.synthetic import ShardedCallbacks
+        cb = ShardedCallbacks(CenteredBandedNLP(n, m, eps=1e-3), sh)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for attempt in range(2):              # first call pays one-off symbolic set-up
+                torch.cuda.synchronize()
+                dist.barrier()
+                t0 = time.time()
+                res = sharded.minimize_equality_constrained(
+                    sh, cb.fun, cb.grad, cb.lagr_hess, cb.constr_fun, cb.constr_jac, cb.x0,
+                    method="tr_interior_point")
+                torch.cuda.synchronize()
+                wall = time.time() - t0
+        full_solve = {"seconds": wall, "status": int(res.status), "niter": int(res.niter),
+                      "cg_niter": int(res.cg_niter), "optimality": float(res.optimality),
+                      "constr_violation": float(res.constr_violation),
+                      "note": "config 4 = config 3 (eps=1e-3) sharded; the reference reaches "
+                              "status 1 in 25 outer / 34 CG iterations"}
+    except Exception as exc:
+        full_solve = {"error": repr(exc)}
+
     nnzA, nnzH = A_h.nnz, H_h.nnz
     iter_bytes = (spmv_bytes(nnzH, n, n, 1) + spmv_bytes(nnzA, m, n)
                   + spmv_bytes(nnzA, n, m, 1) + 2 * 5 * 8 * n + 4 * 8 * m)
@@ -373,6 +398,7 @@ def sharded_leg(args, world, rank, A_h, H_h, hdiag_h, c_h, n, m, K, W):
                                                   "torch.distributed (%s), one stream "
                                                   "synchronise" % dist.get_backend()},
         "weak_scaling_point": weak,
+        "wall_clock_to_gtol": full_solve,
     }
     if rank == 0:
         print(json.dumps(result))
