@@ -244,40 +244,6 @@ int ipx_cg_step1(int64_t n, double *state, int32_t it, const double *p1, int32_t
 int ipx_cg_step2(int64_t n, double *state, int32_t it, int32_t mode, const double *p2,
                  int32_t np2, const double *p3, int32_t np3, const double *p4, int32_t np4,
                  double *x, double *p, const double *g, int32_t grid, void *stream);
-/* Row-sharded loop: halo_pack writes the first/last h entries of the local g
- * into slot `rank` of out[world][2h] and zeroes the other slots (an all-reduce
- * of `out` then gathers every rank's boundary values); halo_apply performs
- * p = beta p - g on the hl / hr halo copies next to the owned block, a no-op
- * unless step2 completed (state stop code 0). */
-int ipx_cg_halo_pack(int64_t n, int32_t h, int32_t rank, int32_t world, const double *g,
-                     double *out, void *stream);
-/* One launch for a rank's whole contribution to the packed all-reduce:
- * out[0..4) = sums of part2[0..np2), part2[np2..2np2), part3[0..np3),
- * part3[np3..2np3); out[4..4+2h*world) = halo_pack(g). */
-int ipx_cg_shard_pack(const double *part2, int32_t np2, const double *part3, int32_t np3,
-                      int64_t n, int32_t h, int32_t rank, int32_t world, const double *g,
-                      double *out, void *stream);
-int ipx_cg_halo_apply(const double *state, int32_t hl, int32_t hr, const double *g_left,
-                      const double *g_right, double *p_left, double *p_right, void *stream);
-/* One segment of a row-sharded iteration (the kernels between two all-reduces)
- * in a single call.  `a` describes the rank's block: n = local variables,
- * A_* = A[:, block] (m x n), At_* = its transpose, H_* = H[block, block+halo]
- * (n x (hl+n+hr)), p = the owned part of e->p_ext.  Phases:
- *   0 (after the all-reduce of e->s1):   step1;  w = A_cols r
- *   1 (after the all-reduce of a->w):    v = (AA')^-1 w + residual partials;
- *                                        r <- r - A_rows' v;  shard_pack -> e->pack
- *   2 (after the all-reduce of e->pack): step2;  halo_apply;  Hp = H_rows p_ext;
- *                                        e->s1 <- folded p'Hp partials        */
-typedef struct ipx_shard_ext {
-  double *p_ext;
-  int64_t hl, hr, h, rank, world;
-  double *s1;         /* 2 doubles */
-  double *pack;       /* 4 + 2*h*world doubles */
-  int64_t np4;        /* residual partial count of the last phase 1 (set by the library) */
-} ipx_shard_ext;
-int ipx_cg_shard_segment(const ipx_cg_args *a, ipx_shard_ext *e, int32_t phase, int32_t it,
-                         void *stream);
-/* The fused step2 + H.p launch alone (needs pb / H_hmax in the argument block). */
 /* ---- partitioned row-sharded loop (ipsolver/sharded.py FusedShardedCG; replaces the
  * per-iteration body of qp_subproblem.py:549-634 on one rank of a node).  `a` describes the
  * rank's extended local problem (own rows / variables + halo copies); the scalars travel
@@ -295,6 +261,7 @@ typedef struct ipx_shard2_ext {
 int ipx_cg_shard2_segment(const ipx_cg_args *a, const ipx_shard2_ext *e, int32_t phase,
                           int32_t it, int32_t mode, void *stream);
 int ipx_cg_shard2_fold_hp(const ipx_cg_args *a, const ipx_shard2_ext *e, void *stream);
+/* The fused step2 + H.p launch alone (needs pb / H_hmax in the argument block). */
 int ipx_cg_step2_hp(const ipx_cg_args *a, int32_t it, int32_t mode, void *stream);
 /* Finish iteration `it` after the host handled a stop-5/6 event. */
 int ipx_cg_resume(const ipx_cg_args *a, int32_t it, int32_t mode, void *stream);

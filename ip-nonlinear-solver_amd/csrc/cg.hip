@@ -134,18 +134,10 @@ k_cg_step1(int64_t n, double *st, int parity, const double *__restrict__ p1, int
 
 // mode bit0: skip the radius / box checks (host already handled them)
 //      bit1: skip the orthogonality check (host already refined)
-// Halo copies of the neighbouring ranks' boundary entries of p (row-sharded loop): advanced
-// by the same launch with the same expression (see k_cg_halo_apply).
-struct HaloJob {
-  int hl, hr;
-  const double *gl, *gr;
-  double *pl, *pr;
-};
-
 __global__ void __launch_bounds__(VB)
 k_cg_step2(int64_t n, double *st, int parity, int mode, const double *__restrict__ p2, int np2,
            const double *__restrict__ p3, int np3, const double *__restrict__ p4, int np4,
-           double *x, double *p, const double *__restrict__ g, int nchunks, HaloJob halo) {
+           double *x, double *p, const double *__restrict__ g, int nchunks) {
   __shared__ double lds[4 * (VB / IPX_WAVE)];
   CG_STAMP(0);
   const int c = ipx_xcd_item(blockIdx.x, nchunks);   // same element -> XCD map as step1
@@ -203,10 +195,6 @@ k_cg_step2(int64_t n, double *st, int parity, int mode, const double *__restrict
     st[ST_BETA] = beta;
     st[ST_IT_DONE] += 1.0;
   }
-  if (c == 0) {                                      // halo copies: p = beta p - g as below
-    for (int t = threadIdx.x; t < halo.hl; t += VB) halo.pl[t] = beta * halo.pl[t] - halo.gl[t];
-    for (int t = threadIdx.x; t < halo.hr; t += VB) halo.pr[t] = beta * halo.pr[t] - halo.gr[t];
-  }
   while (true) {
 #pragma unroll
     for (int u = 0; u < VU; ++u) {
@@ -225,22 +213,6 @@ k_cg_step2(int64_t n, double *st, int parity, int mode, const double *__restrict
     }
   }
   CG_STAMP(3);
-}
-
-// Row-sharded loop (ipsolver/sharded.py): the first and last h entries of the
-// local g go into this rank's slot of a [world][2h] buffer whose other slots
-// are zeroed, so that the sum over ranks (all-reduce) is a gather of every
-// rank's boundary values -- they travel with the packed scalars instead of a
-// separate neighbour exchange.
-__global__ void __launch_bounds__(256)
-k_cg_halo_pack(int64_t n, int h, int rank, int world, const double *__restrict__ g,
-               double *__restrict__ out) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= 2 * h * world) return;
-  const int q = idx / (2 * h), j = idx % (2 * h);
-  double v = 0.0;
-  if (q == rank) v = j < h ? g[j] : g[n - 2 * h + j];
-  out[idx] = v;
 }
 
 // ---- step2 fused into the H.p SpMV (banded Hessians) ------------------------
@@ -618,27 +590,6 @@ k_cg_save_pb(const double *__restrict__ p, const int32_t *__restrict__ tiles, in
   pb[(int64_t)ntiles * 2 * hmax + idx] = v;
 }
 
-// The whole per-rank contribution to the second all-reduce of an iteration in
-// one launch: out[0..4) = folded partials (||x+ap||^2, #violations, ||g||^2,
-// g'r), out[4..) = boundary slots as in k_cg_halo_pack.
-__global__ void __launch_bounds__(256)
-k_cg_shard_pack(const double *__restrict__ p2, int np2, const double *__restrict__ p3, int np3,
-                int64_t n, int h, int rank, int world, const double *__restrict__ g,
-                double *__restrict__ out) {
-  __shared__ double lds[4 * 4];
-  const double *const parts[4] = {p2, p2 + np2, p3, p3 + np3};
-  const int counts[4] = {np2, np2, np3, np3};
-  double red[4];
-  ipx_sum_partials_multi<4>(parts, counts, lds, red);
-  if (threadIdx.x < 4) out[threadIdx.x] = red[threadIdx.x];
-  for (int idx = threadIdx.x; idx < 2 * h * world; idx += blockDim.x) {
-    const int q = idx / (2 * h), j = idx % (2 * h);
-    double v = 0.0;
-    if (q == rank) v = j < h ? g[j] : g[n - 2 * h + j];
-    out[4 + idx] = v;
-  }
-}
-
 // Partitioned row-sharded loop (ipsolver/sharded.py): up to four sub-ranges of partial
 // arrays -- the entries produced by a rank's OWN tiles / workgroups -- summed in a fixed
 // order into out[0..4): the rank's contribution to an all-reduce.
@@ -655,19 +606,6 @@ k_cg_range_pack(RangeJob job, double *__restrict__ out, const double *__restrict
   double red[4];
   ipx_sum_partials_multi<4>(job.ptr, job.count, lds, red);
   if (threadIdx.x < 4 && ((job.active >> threadIdx.x) & 1)) out[threadIdx.x] = red[threadIdx.x];
-}
-
-// p = beta p - g on the halo copies of the neighbours' boundary entries: the
-// same expression k_cg_step2 applies to the owned entries, so owner and copy
-// stay bit-identical.  No-op unless step2 completed its update.
-__global__ void __launch_bounds__(256)
-k_cg_halo_apply(const double *__restrict__ st, int hl, int hr, const double *__restrict__ gl,
-                const double *__restrict__ gr, double *pl, double *pr) {
-  if (st[ST_STOP] != 0.0) return;
-  const double beta = st[ST_BETA];
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < hl) pl[t] = beta * pl[t] - gl[t];
-  if (t < hr) pr[t] = beta * pr[t] - gr[t];
 }
 
 }  // namespace
@@ -807,9 +745,7 @@ static int launch_step2_hp(const ipx_cg_args *a, int it, int mode, const double 
 }
 
 // Single kernels of the loop with explicit partial buffers, for drivers that
-// interleave their own steps (the row-sharded CG puts RCCL all-reduces
-// between them: ipsolver/sharded.py).  Every rank sees the same reduced
-// scalars, so every rank takes the same branches.
+// interleave their own steps.
 int ipx_cg_step1(int64_t n, double *state, int32_t it, const double *p1, int32_t np1,
                  const double *x, const double *p, double *r, const double *Hp, const double *lb,
                  const double *ub, double *part2, int32_t grid, void *stream) {
@@ -825,100 +761,9 @@ int ipx_cg_step2(int64_t n, double *state, int32_t it, int32_t mode, const doubl
                  double *x, double *p, const double *g, int32_t grid, void *stream) {
   if (n < 0 || !state || grid < 1) return IPX_EINVAL;
   hipLaunchKernelGGL(k_cg_step2, dim3(ipx_xcd_grid(grid)), dim3(VB), 0, (hipStream_t)stream, n,
-                     state, it & 1, mode, p2, np2, p3, np3, p4, np4, x, p, g, grid, HaloJob{});
+                     state, it & 1, mode, p2, np2, p3, np3, p4, np4, x, p, g, grid);
   IPX_CHECK_LAUNCH();
   return IPX_OK;
-}
-
-int ipx_cg_halo_pack(int64_t n, int32_t h, int32_t rank, int32_t world, const double *g,
-                     double *out, void *stream) {
-  if (h < 0 || world < 1 || rank < 0 || rank >= world || n < h) return IPX_EINVAL;
-  if (h == 0) return IPX_OK;
-  if (!g || !out) return IPX_EINVAL;
-  const int total = 2 * h * world;
-  hipLaunchKernelGGL(k_cg_halo_pack, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream,
-                     n, h, rank, world, g, out);
-  IPX_CHECK_LAUNCH();
-  return IPX_OK;
-}
-
-int ipx_cg_shard_pack(const double *part2, int32_t np2, const double *part3, int32_t np3,
-                      int64_t n, int32_t h, int32_t rank, int32_t world, const double *g,
-                      double *out, void *stream) {
-  if (!part2 || !part3 || !out || np2 < 0 || np3 < 0 || h < 0 || world < 1 || rank < 0 ||
-      rank >= world || n < h || (h > 0 && !g))
-    return IPX_EINVAL;
-  hipLaunchKernelGGL(k_cg_shard_pack, dim3(1), dim3(256), 0, (hipStream_t)stream, part2, np2,
-                     part3, np3, n, h, rank, world, g, out);
-  IPX_CHECK_LAUNCH();
-  return IPX_OK;
-}
-
-int ipx_cg_halo_apply(const double *state, int32_t hl, int32_t hr, const double *g_left,
-                      const double *g_right, double *p_left, double *p_right, void *stream) {
-  if (!state || hl < 0 || hr < 0) return IPX_EINVAL;
-  const int hm = hl > hr ? hl : hr;
-  if (hm == 0) return IPX_OK;
-  if ((hl && (!g_left || !p_left)) || (hr && (!g_right || !p_right))) return IPX_EINVAL;
-  hipLaunchKernelGGL(k_cg_halo_apply, dim3((hm + 255) / 256), dim3(256), 0, (hipStream_t)stream,
-                     state, hl, hr, g_left, g_right, p_left, p_right);
-  IPX_CHECK_LAUNCH();
-  return IPX_OK;
-}
-
-int ipx_cg_shard_segment(const ipx_cg_args *a, ipx_shard_ext *e, int32_t phase, int32_t it,
-                         void *stream) {
-  if (!a || !e || phase < 0 || phase > 2) return IPX_EINVAL;
-  hipStream_t st = (hipStream_t)stream;
-  const double *guard = a->state + ST_STOP;
-  const int grid = (int)a->vec_grid;
-  int rc = IPX_OK;
-  if (phase == 0) {
-    if (fused_ar(a))                               // step1 inside the partial A.r SpMV
-      return launch_step1_ar(a, it, e->s1, 1, st);
-    rc = ipx_cg_step1(a->n, a->state, it, e->s1, 1, a->x, a->p, a->r, a->Hp, nullptr, nullptr,
-                      a->part2, grid, stream);
-    if (rc) return rc;
-    ipx_csr_view A{(int)a->m, (int)a->n, a->A_rowptr, a->A_colidx, a->A_val, a->A_tiles,
-                   (int)a->A_ntiles};
-    return ipx_spmv_launch(A, a->r, 1.0, nullptr, 0.0, nullptr, a->w, nullptr, guard, st);
-  }
-  if (phase == 1) {
-    int np4 = 0, np3 = (int)a->At_ntiles;
-    const double *r_in = fused_ar(a) ? a->r_next : a->r;
-    if (a->At_vown && a->At_qv > 0) {              // g = r - A'v as the tail of the solve
-      rc = ipx_banded_solve_resid_atv_launch(a->banded, a->w, a->v, a->part4, &np4, a->At_rowptr,
-                                             a->At_colidx, a->At_val, r_in, a->r, a->At_vown,
-                                             (int)a->At_qv, a->part3, guard, st);
-      if (rc) return rc;
-      np3 = np4;
-    } else {
-      rc = ipx_banded_solve_resid_launch(a->banded, a->w, a->v, a->part4, &np4, guard, st);
-      if (rc) return rc;
-      ipx_csr_view At{(int)a->n, (int)a->m, a->At_rowptr, a->At_colidx, a->At_val, a->At_tiles,
-                      (int)a->At_ntiles};
-      rc = ipx_spmv_launch(At, a->v, -1.0, nullptr, 1.0, r_in, a->r, a->part3, guard, st);
-      if (rc) return rc;
-    }
-    e->np4 = np4;
-    return ipx_cg_shard_pack(a->part2, part2_count(a), a->part3, np3, a->n, (int)e->h,
-                             (int)e->rank, (int)e->world, a->r, e->pack, stream);
-  }
-  const int h = (int)e->h, rank = (int)e->rank;
-  const HaloJob halo{(int)e->hl, (int)e->hr,
-                     e->hl ? e->pack + 4 + (2 * (rank - 1) + 1) * h : nullptr,
-                     e->hr ? e->pack + 4 + 2 * (rank + 1) * h : nullptr,
-                     e->p_ext, e->p_ext + e->hl + a->n};
-  hipLaunchKernelGGL(k_cg_step2, dim3(ipx_xcd_grid(grid)), dim3(VB), 0, st, a->n, a->state,
-                     it & 1, 0, e->pack, 1, e->pack + 2, 1, a->part4, (int)e->np4, a->x, a->p,
-                     a->r, grid, halo);
-  IPX_CHECK_LAUNCH();
-  ipx_csr_view H{(int)a->n, (int)(e->hl + a->n + e->hr), a->H_rowptr, a->H_colidx, a->H_val,
-                 a->H_tiles, (int)a->H_ntiles};
-  rc = ipx_spmv_launch(H, e->p_ext, 1.0, a->H_diag, 0.0, nullptr, a->Hp, a->part1, guard, st,
-                       a->p);
-  if (rc) return rc;
-  return ipx_fold2(a->part1, (int)a->H_ntiles, e->s1, nullptr, stream);
 }
 
 // One local segment of an iteration of the PARTITIONED row-sharded loop (ipsolver/sharded.py
@@ -992,7 +837,7 @@ int ipx_cg_shard2_segment(const ipx_cg_args *a, const ipx_shard2_ext *e, int32_t
   } else {
     hipLaunchKernelGGL(k_cg_step2, dim3(ipx_xcd_grid(grid)), dim3(VB), 0, st, a->n, a->state,
                        it & 1, mode, e->pack, 1, e->pack + 2, 1, e->pack + 3, 1, a->x, a->p, a->r,
-                       grid, HaloJob{});
+                       grid);
     IPX_CHECK_LAUNCH();
     rc = launch_hp(a, guard, st);
   }
@@ -1045,7 +890,7 @@ int ipx_cg_resume(const ipx_cg_args *a, int32_t it, int32_t mode, void *stream) 
   hipLaunchKernelGGL(k_cg_step2, dim3(ipx_xcd_grid((int)a->vec_grid)), dim3(VB), 0, st, a->n,
                      a->state, it & 1, mode, a->part2, part2_count(a), a->part3,
                      part3_count(a), a->part4, part4_count(a), a->x, a->p, a->r,
-                     (int)a->vec_grid, HaloJob{});
+                     (int)a->vec_grid);
   IPX_CHECK_LAUNCH();
   return launch_hp(a, guard, st);
 }
@@ -1214,7 +1059,7 @@ static int cg_iterate(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, hi
     } else {
       hipLaunchKernelGGL(k_cg_step2, dim3(ipx_xcd_grid((int)a->vec_grid)), dim3(VB), 0, st, a->n,
                          a->state, it & 1, a->m > 0 ? 0 : 2, p2, np2, p3, np3, p4, n4, a->x, a->p,
-                         a->r, (int)a->vec_grid, HaloJob{});
+                         a->r, (int)a->vec_grid);
       IPX_CHECK_LAUNCH();
       MARK(6);
       rc = launch_hp(a, guard, st);

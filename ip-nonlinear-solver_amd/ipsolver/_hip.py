@@ -63,11 +63,7 @@ _SIGNATURES = {
     "ipx_banded_solve_guarded_c": [_P, _P, _P, _P, _P],
     "ipx_banded_solve_resid": [_P, _P, _P, _P, _P, _P, _P],
     "ipx_banded_decoupled_geometry": [_P, _P],
-    "ipx_cg_halo_pack": [_I64, _I32, _I32, _I32, _P, _P, _P],
-    "ipx_cg_shard_pack": [_P, _I32, _P, _I32, _I64, _I32, _I32, _I32, _P, _P, _P],
     "ipx_cg_step2_hp": [_P, _I32, _I32, _P],
-    "ipx_cg_shard_segment": [_P, _P, _I32, _I32, _P],
-    "ipx_cg_halo_apply": [_P, _I32, _I32, _P, _P, _P, _P, _P],
     "ipx_cg_shard2_segment": [_P, _P, _I32, _I32, _I32, _P],
     "ipx_cg_shard2_fold_hp": [_P, _P, _P],
     "ipx_aat_band": [_I64, _I32, _P, _P, _P, _P, _P, _P],
