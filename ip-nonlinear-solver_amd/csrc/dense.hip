@@ -61,43 +61,118 @@ k_fold2(const double *partial, int count, double *red) {
 }
 
 // ---------------------------------------------------------------- Gram
-// G[i][j] = sum_k A[i][k] A[j][k] for j <= i, mirrored; G is M x M (M = m
-// rounded up to 32) with an identity tail so it stays SPD.
-// v_mfma_f64_16x16x4_f64: lane l supplies A-operand element (row l&15, k l>>4)
-// and B-operand element (k l>>4, col l&15); D layout col = l&15,
-// row = (l>>4) + 4*reg  (cdna_hip_programming.md section 3).
+// G[i][j] = sum_k A[i][k] A[j][k] for j <= i, mirrored; G is M x M (M = m rounded up to 32)
+// with an identity tail so it stays SPD.  The one matmul-shaped operation of the path, on
+// the fp64 matrix cores (v_mfma_f64_16x16x4_f64: lane l supplies A-operand element
+// (row l&15, k l>>4) and B-operand element (k l>>4, col l&15); D layout col = l&15,
+// row = (l>>4) + 4*reg; cdna_hip_programming.md section 3).
+//
+// A workgroup (4 waves) owns a 64 x 64 tile of the lower triangle of G; wave w the 32 x 32
+// quadrant (w>>1, w&1) = 2 x 2 MFMA tiles, 4 accumulators.  K is walked in chunks of 32
+// columns: the two 64-row panels of A (one when the tile sits on the diagonal) are staged
+// in LDS by 16-byte loads -- 16 lanes cover the 256 contiguous bytes of a row's chunk -- and
+// the loads of chunk c+1 are issued into registers before the MFMAs of chunk c, so global
+// latency hides behind 32 MFMAs per wave.  LDS rows are pitched 34 doubles: the 16 rows x 2
+// k-values a half-wave reads per ds_read_b64 then fall into 32 distinct bank pairs.
 typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
 
-__global__ void __launch_bounds__(IPX_WAVE)
-k_gram_mfma(int m, int n, const double *__restrict__ A, int64_t lda, double *__restrict__ G,
-            int M) {
-  const int ti = blockIdx.y, tj = blockIdx.x;       // 16x16 tile coordinates
-  if (tj > ti) return;
-  const int lane = threadIdx.x;
-  const int r = lane & 15, kq = lane >> 4;
-  const int ri = ti * 16 + r, rj = tj * 16 + r;
-  const double *pa = A + (int64_t)ri * lda;
-  const double *pb = A + (int64_t)rj * lda;
-  const bool va = ri < m, vb = rj < m;
-  v4d acc = {0.0, 0.0, 0.0, 0.0};
-  int k = 0;
-  for (; k + 4 <= n; k += 4) {
-    const double a = va ? pa[k + kq] : 0.0;
-    const double b = vb ? pb[k + kq] : 0.0;
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+constexpr int GT = 64;          // tile edge of G per workgroup
+constexpr int GK = 32;          // K chunk
+constexpr int GP = GK + 2;      // LDS row pitch (doubles)
+
+template <bool VEC>
+__device__ __forceinline__ void gram_fetch(const double *__restrict__ A, int64_t lda, int m,
+                                           int n, int row0, int k0, int tid, v2d (&reg)[4]) {
+  // panel of 64 rows x 32 columns = 1024 double2; thread t takes double2 number t + 256*u
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int idx = tid + u * IPX_BLOCK;
+    const int r = idx >> 4, c = (idx & 15) * 2;
+    const int row = row0 + r, k = k0 + c;
+    v2d v = {0.0, 0.0};
+    if (row < m) {
+      const double *src = A + (int64_t)row * lda + k;
+      if (VEC && k + 1 < n) v = *reinterpret_cast<const v2d *>(src);
+      else {
+        if (k < n) v.x = src[0];
+        if (k + 1 < n) v.y = src[1];
+      }
+    }
+    reg[u] = v;
   }
-  if (k < n) {
-    const double a = (va && k + kq < n) ? pa[k + kq] : 0.0;
-    const double b = (vb && k + kq < n) ? pb[k + kq] : 0.0;
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+}
+
+__device__ __forceinline__ void gram_stash(double *panel, int tid, const v2d (&reg)[4]) {
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int idx = tid + u * IPX_BLOCK;
+    const int r = idx >> 4, c = (idx & 15) * 2;
+    *reinterpret_cast<v2d *>(panel + r * GP + c) = reg[u];
+  }
+}
+
+template <bool VEC>
+__global__ void __launch_bounds__(IPX_BLOCK)
+k_gram_mfma(int m, int n, const double *__restrict__ A, int64_t lda, double *__restrict__ G,
+            int M, int ntile) {
+  __shared__ __attribute__((aligned(16))) double sA[GT * GP];
+  __shared__ __attribute__((aligned(16))) double sB[GT * GP];
+  // linear block index -> (ti, tj) with tj <= ti
+  int ti = (int)((sqrt(8.0 * blockIdx.x + 1.0) - 1.0) * 0.5);
+  while ((ti + 1) * (ti + 2) / 2 <= (int)blockIdx.x) ++ti;
+  while (ti * (ti + 1) / 2 > (int)blockIdx.x) --ti;
+  const int tj = (int)blockIdx.x - ti * (ti + 1) / 2;
+  if (ti >= ntile) return;
+  const bool diag = ti == tj;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
+  const int lr = lane & 15, lk = lane >> 4;
+  v4d acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+  v2d ra[4], rb[4];
+  gram_fetch<VEC>(A, lda, m, n, ti * GT, 0, tid, ra);
+  if (!diag) gram_fetch<VEC>(A, lda, m, n, tj * GT, 0, tid, rb);
+  const double *pB = diag ? sA : sB;
+  for (int k0 = 0; k0 < n; k0 += GK) {
+    gram_stash(sA, tid, ra);
+    if (!diag) gram_stash(sB, tid, rb);
+    __syncthreads();
+    if (k0 + GK < n) {                       // next chunk's loads fly during the MFMAs
+      gram_fetch<VEC>(A, lda, m, n, ti * GT, k0 + GK, tid, ra);
+      if (!diag) gram_fetch<VEC>(A, lda, m, n, tj * GT, k0 + GK, tid, rb);
+    }
+#pragma unroll
+    for (int kk = 0; kk < GK; kk += 4) {
+      const double a0 = sA[(wr + lr) * GP + kk + lk];
+      const double a1 = sA[(wr + 16 + lr) * GP + kk + lk];
+      const double b0 = pB[(wc + lr) * GP + kk + lk];
+      const double b1 = pB[(wc + 16 + lr) * GP + kk + lk];
+      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    __syncthreads();
   }
 #pragma unroll
-  for (int reg = 0; reg < 4; ++reg) {
-    const int row = ti * 16 + kq + 4 * reg, col = tj * 16 + r;
-    double v = acc[reg];
-    if (row >= m || col >= m) v = (row == col) ? 1.0 : 0.0;
-    G[(int64_t)row * M + col] = v;
-    G[(int64_t)col * M + row] = v;
+  for (int a = 0; a < 2; ++a) {
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int row = ti * GT + wr + 16 * a + lk + 4 * reg;
+        const int col = tj * GT + wc + 16 * b + lr;
+        if (row >= M || col >= M || col > row) continue;      // lower triangle (+ mirror)
+        double v = acc[a][b][reg];
+        if (row >= m || col >= m) v = (row == col) ? 1.0 : 0.0;
+        G[(int64_t)row * M + col] = v;
+        G[(int64_t)col * M + row] = v;
+      }
+    }
   }
 }
 
@@ -303,9 +378,16 @@ int ipx_gram_f64_mfma(int64_t m, int64_t n, const double *A, int64_t lda, double
                       void *stream) {
   if (m < 1 || n < 0 || !A || !G || lda < n) return IPX_EINVAL;
   const int M = (int)ipx_dense_padded(m);
-  const int tiles = M / 16;
-  hipLaunchKernelGGL(k_gram_mfma, dim3(tiles, tiles), dim3(IPX_WAVE), 0, (hipStream_t)stream,
-                     (int)m, (int)n, A, lda, G, M);
+  const int nt = (M + GT - 1) / GT;
+  const dim3 grid(nt * (nt + 1) / 2), block(IPX_BLOCK);
+  // 16-byte loads need every row start 16-byte aligned
+  const bool vec = (lda % 2 == 0) && (((uintptr_t)A) % 16 == 0);
+  if (vec)
+    hipLaunchKernelGGL(k_gram_mfma<true>, grid, block, 0, (hipStream_t)stream, (int)m, (int)n, A,
+                       lda, G, M, nt);
+  else
+    hipLaunchKernelGGL(k_gram_mfma<false>, grid, block, 0, (hipStream_t)stream, (int)m, (int)n, A,
+                       lda, G, M, nt);
   IPX_CHECK_LAUNCH();
   return IPX_OK;
 }

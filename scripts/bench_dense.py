@@ -1,0 +1,58 @@
+"""Dense-Jacobian factorization kernels at BASELINE config 2's size (A: 2000 x 10000):
+Gram (fp64 MFMA), Cholesky, inverse, gemv -- HIP-event times and rates.
+    python scripts/bench_dense.py [m] [n]"""
+import ctypes, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "ip-nonlinear-solver_amd"))
+import numpy as np, torch
+from ipsolver import _hip, device as dv
+from ipsolver.dense import DeviceDense
+m = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
+lib = _hip.load()
+rng = np.random.default_rng(0)
+A_h = rng.standard_normal((m, n))
+A = DeviceDense.from_host(A_h)
+M = int(lib.ipx_dense_padded(m))
+G = torch.empty((M, M), dtype=torch.float64, device="cuda")
+X = torch.empty((M, M), dtype=torch.float64, device="cuda")
+flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+st = dv.stream_ptr()
+
+
+def timed(fn, reps=5):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+out = {"m": m, "n": n, "M": M}
+t = timed(lambda: _hip.call("ipx_gram_f64_mfma", m, n, dv._p(A.t), n, dv._p(G), st))
+out["gram_ms"] = t
+out["gram_TFs_full"] = 2.0 * m * m * n / (t * 1e-3) / 1e12          # counting the full product
+out["gram_TFs_computed"] = out["gram_TFs_full"] * (M // 16 + 1) / (2 * (M // 16))   # lower triangle of tiles
+Gh = G.cpu().numpy()[:m, :m]
+ref = A_h @ A_h.T
+out["gram_rel_err"] = float(np.max(np.abs(Gh - ref)) / np.max(np.abs(ref)))
+G0 = G.clone()
+
+
+def chol():
+    G.copy_(G0)
+    _hip.call("ipx_chol_factor", M, dv._p(G), dv._p(flag), st)
+
+
+t_copy = timed(lambda: G.copy_(G0))
+out["chol_ms"] = timed(chol) - t_copy
+out["inverse_ms"] = timed(lambda: _hip.call("ipx_chol_inverse", M, dv._p(G), dv._p(X), st), reps=3)
+Xh = X.cpu().numpy()[:m, :m]
+out["inverse_resid"] = float(np.max(np.abs(Xh @ ref - np.eye(m))))
+x = dv.DVec.from_host(rng.standard_normal(n))
+t = timed(lambda: A.gemv(x), reps=50)
+out["gemv_A_us"] = 1e3 * t
+out["gemv_A_GBs"] = 8.0 * m * n / (t * 1e-3) / 1e9
+print(json.dumps(out, indent=1))

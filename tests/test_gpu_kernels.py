@@ -169,3 +169,27 @@ def test_hessian_terms_merge_on_device():
     assert H2.csr.pattern is bh.hessian_operator(list(terms), n, None).csr.pattern
     assert np.max(np.abs(H2.dot(DVec.from_host(p)).to_host() - 2 * total.dot(p))) \
         <= 1e-13 * np.max(np.abs(total.dot(p)))
+
+
+@pytest.mark.parametrize("m,n", [(3, 8), (16, 4), (77, 1001), (130, 64), (64, 33), (200, 1000),
+                                 (513, 2050)])
+def test_gram_mfma_tiled(m, n):
+    """G = A A' on the fp64 matrix cores (csrc/dense.hip k_gram_mfma: 64 x 64 tiles through
+    LDS) against numpy, at sizes that are no multiple of the tile, of the K chunk, or of the
+    16-byte load (odd row length -> scalar loads); padded tail = identity."""
+    import torch
+    from ipsolver import _hip, device as dv
+    lib = _hip.load()
+    rng = np.random.default_rng(m * 1000 + n)
+    A_h = rng.standard_normal((m, n))
+    A = torch.from_numpy(A_h).cuda()
+    M = int(lib.ipx_dense_padded(m))
+    G = torch.full((M, M), np.nan, dtype=torch.float64, device="cuda")
+    _hip.call("ipx_gram_f64_mfma", m, n, dv._p(A), n, dv._p(G), dv.stream_ptr())
+    Gh = G.cpu().numpy()
+    ref = A_h @ A_h.T
+    assert np.max(np.abs(Gh[:m, :m] - ref)) <= 1e-13 * np.max(np.abs(ref))
+    assert np.array_equal(Gh, Gh.T)                       # mirrored exactly
+    tail = np.eye(M)
+    tail[:m, :m] = Gh[:m, :m]
+    assert np.array_equal(Gh, tail)                       # identity in the padding
