@@ -144,7 +144,8 @@ int ipx_gram_f64_mfma(int64_t m, int64_t n, const double *A, int64_t lda, double
 /* Same G from a CSR A (sparse Jacobian whose A A' is not narrow-banded). */
 int ipx_aat_dense(int64_t m, const int32_t *rowptr, const int32_t *colidx, const double *val,
                   double *G, void *stream);
-int ipx_chol_factor(int64_t M, double *G, int *flag, void *stream);
+/* work: M + 1 doubles; work[M] <- min pivot / original diagonal (~1/cond(G)). */
+int ipx_chol_factor(int64_t M, double *G, int *flag, double *work, void *stream);
 int ipx_chol_inverse(int64_t M, const double *G, double *X, void *stream);
 
 /* ---- banded SPD solve with S = A A' (normal equations, projections.py:58-90;

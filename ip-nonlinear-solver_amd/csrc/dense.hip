@@ -204,8 +204,16 @@ k_aat_dense(int m, const int32_t *__restrict__ rowptr, const int32_t *__restrict
 
 // ------------------------------------------------------- blocked Cholesky
 // Diagonal tile: G_kk = L_kk L_kk'.  One workgroup of NB x NB lanes.
+// work[0..M) = the diagonal of G before the factorization; work[M] = running minimum of
+// pivot / original diagonal entry (how many digits the factorization lost: ~1/cond(G)).
+__global__ void __launch_bounds__(IPX_BLOCK) k_save_diag(const double *G, int M, double *work) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < M) work[i] = G[(int64_t)i * M + i];
+  if (i == 0) work[M] = 1.0;
+}
+
 __global__ void __launch_bounds__(NB *NB)
-k_potrf_tile(double *G, int M, int kb, int *flag) {
+k_potrf_tile(double *G, int M, int kb, int *flag, double *work) {
   __shared__ double T[NB][NB + 1];
   const int r = threadIdx.y, c = threadIdx.x;
   double *g = G + ((int64_t)kb * NB) * M + (int64_t)kb * NB;
@@ -214,7 +222,10 @@ k_potrf_tile(double *G, int M, int kb, int *flag) {
   for (int j = 0; j < NB; ++j) {
     if (r == j && c == j) {
       const double d = T[j][j];
-      if (!(d > 0.0)) atomicOr(flag, 1);
+      const double d0 = work[kb * NB + j];
+      // numerically rank deficient: the pivot lost 43 bits against its diagonal entry
+      if (!(d > IPX_PIVOT_RTOL * d0)) atomicOr(flag, 1);
+      else work[M] = fmin(work[M], d / d0);       // (one workgroup at a time: no race)
       T[j][j] = sqrt(d);
     }
     __syncthreads();
@@ -404,15 +415,19 @@ int ipx_aat_dense(int64_t m, const int32_t *rowptr, const int32_t *colidx, const
   return IPX_OK;
 }
 
-// In place: lower triangle of G <- L with G = L L'.  flag (device int) != 0
-// afterwards when a pivot was not positive.
-int ipx_chol_factor(int64_t M, double *G, int *flag, void *stream) {
-  if (M < NB || M % NB || !G || !flag) return IPX_EINVAL;
+// In place: lower triangle of G <- L with G = L L'.  flag (device int) != 0 afterwards when a
+// pivot fell below IPX_PIVOT_RTOL x its original diagonal entry (numerically rank deficient
+// Jacobian); work (M + 1 doubles): work[M] = min pivot / diagonal, an estimate of 1/cond(G).
+int ipx_chol_factor(int64_t M, double *G, int *flag, double *work, void *stream) {
+  if (M < NB || M % NB || !G || !flag || !work) return IPX_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int nb = (int)(M / NB);
   if (hipMemsetAsync(flag, 0, sizeof(int), st) != hipSuccess) return IPX_ELAUNCH;
+  hipLaunchKernelGGL(k_save_diag, dim3(((int)M + IPX_BLOCK - 1) / IPX_BLOCK), dim3(IPX_BLOCK), 0,
+                     st, G, (int)M, work);
+  IPX_CHECK_LAUNCH();
   for (int k = 0; k < nb; ++k) {
-    hipLaunchKernelGGL(k_potrf_tile, dim3(1), dim3(NB, NB), 0, st, G, (int)M, k, flag);
+    hipLaunchKernelGGL(k_potrf_tile, dim3(1), dim3(NB, NB), 0, st, G, (int)M, k, flag, work);
     IPX_CHECK_LAUNCH();
     const int rest = nb - k - 1;
     if (rest > 0) {

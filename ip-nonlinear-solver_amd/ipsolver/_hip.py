@@ -32,7 +32,7 @@ _SIGNATURES = {
     "ipx_dense_gemv": [_I64, _I64, _P, _I64, _P, _F64, _P, _F64, _P, _P, _P, _P, _P],
     "ipx_gram_f64_mfma": [_I64, _I64, _P, _I64, _P, _P],
     "ipx_aat_dense": [_I64, _P, _P, _P, _P, _P],
-    "ipx_chol_factor": [_I64, _P, _P, _P],
+    "ipx_chol_factor": [_I64, _P, _P, _P, _P],
     "ipx_chol_inverse": [_I64, _P, _P, _P],
     "ipx_dot": [_I64, _P, _P, _P, _P, _P],
     "ipx_norms": [_I64, _P, _P, _P, _P],

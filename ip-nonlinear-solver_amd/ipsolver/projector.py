@@ -194,12 +194,18 @@ class NormalEquationProjector:
     def least_squares(self, x):
         if self.m == 0:
             return DVec.zeros(0)
-        return self._apply_inv(self.A.dot(x))
+        v = self._apply_inv(self.A.dot(x))
+        for _ in range(getattr(self.solver, "refine_steps", 0)):     # ill-conditioned dense A
+            v = v + self._apply_inv(self.A.dot(self.A.rmatvec_sub(v, x)))
+        return v
 
     def row_space(self, x):
         if self.m == 0:
             return DVec.zeros(self.n)
-        return self.A.T.dot(self._apply_inv(x))
+        y = self.A.T.dot(self._apply_inv(x))
+        for _ in range(getattr(self.solver, "refine_steps", 0)):
+            y = y + self.A.T.dot(self._apply_inv(x - self.A.dot(y)))
+        return y
 
     def operators(self):
         ops = (_Op((self.n, self.n), self.null_space),

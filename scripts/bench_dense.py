@@ -17,6 +17,7 @@ M = int(lib.ipx_dense_padded(m))
 G = torch.empty((M, M), dtype=torch.float64, device="cuda")
 X = torch.empty((M, M), dtype=torch.float64, device="cuda")
 flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+work = torch.zeros(M + 1, dtype=torch.float64, device="cuda")
 st = dv.stream_ptr()
 
 
@@ -43,7 +44,7 @@ G0 = G.clone()
 
 def chol():
     G.copy_(G0)
-    _hip.call("ipx_chol_factor", M, dv._p(G), dv._p(flag), st)
+    _hip.call("ipx_chol_factor", M, dv._p(G), dv._p(flag), dv._p(work), st)
 
 
 t_copy = timed(lambda: G.copy_(G0))

@@ -751,3 +751,42 @@ def test_banded_traces_with_refinement(ips, banded_refine2000, max_refin):
             assert P.stats["refinements"] - rf0 >= max_refin * info["niter"]
             if not return_all:          # the device-resident loop: one hand-back per iteration
                 assert cg_fused.STATS["refine_events"] - ev0 >= info["niter"] - 1
+
+
+@pytest.mark.parametrize("cond", [1e3, 1e5, 1e6])
+def test_dense_ill_conditioned(ips, cond):
+    """Dense Jacobians far from the benchmark's conditioning (cond(A) = 2.6 there).
+
+    (1) Applying the explicit inverse of G = A A' loses what two triangular solves with its
+    Cholesky factor lose: both are limited by the normal equations (cond(A)^2 eps), so the
+    one-matvec form is no liability.  (2) What the normal equations lose against the
+    reference's pivoted QR (projections.py:175-233, error ~cond(A) eps) is recovered by the
+    refinement steps the solver enables from its measured pivot loss: Z, LS and Y agree with
+    the QR operators to 1e-10 or QR's own accuracy."""
+    import scipy.linalg
+    import oracle
+    rng = np.random.default_rng(int(np.log10(cond)))
+    m, n = 200, 1000
+    U, _ = np.linalg.qr(rng.standard_normal((m, m)))
+    V, _ = np.linalg.qr(rng.standard_normal((n, m)))
+    A = (U * np.logspace(0, -np.log10(cond), m)) @ V.T
+    x, b = rng.standard_normal(n), rng.standard_normal(m)
+    Zo, LSo, Yo = oracle.projections(A)              # pivoted QR, as the reference
+    Z, LS, Y = ips.proj.projections(A)
+    solver = Z.projector.solver
+    assert solver.pivot_ratio < 1e-3 and solver.refine_steps >= 1
+
+    def rel(a, b):
+        return np.max(np.abs(host(a) - b)) / np.max(np.abs(b))
+    # (1) one application of (A A')^-1: explicit inverse vs two triangular solves
+    w = A @ x
+    v_true = LSo.dot(x)
+    v_inv = solver.solve(ips.dv.DVec.from_host(w))
+    v_trsv = scipy.linalg.cho_solve(scipy.linalg.cho_factor(A @ A.T), w)
+    assert rel(v_inv, v_true) <= 5 * rel(v_trsv, v_true)
+    # (2) the operators, refined
+    tol = max(1e-10, 50 * cond * np.finfo(float).eps)
+    assert rel(LS.dot(x), v_true) <= tol
+    assert rel(Y.dot(b), Yo.dot(b)) <= tol
+    assert rel(Z.dot(x), Zo.dot(x)) <= tol
+    assert ips.proj.orthogonality(A, Z.dot(x)) <= 1e-12
