@@ -164,6 +164,11 @@ int ipx_banded_status(void *handle, void *stream);
  * middle kernel; ipx_banded_set_decoupling(h, 0) forces the full path. */
 int ipx_banded_decoupled(void *handle);
 int ipx_banded_set_decoupling(void *handle, int allow);
+/* k = 1: level (1..7) at which the cyclic reduction of A A' has decoupled -- the single-launch
+ * solve is then a parallel cyclic reduction over windows of rows; 0 = chunk recurrences.
+ * ipx_banded_set_decoupling(h, 2) switches back to the chunk form (cross-checks);
+ * (h, 16 + L) forces the reduction to stop at level L (tests: an inexact solve). */
+int ipx_banded_pcr_level(void *handle);
 int ipx_banded_solve(void *handle, const double *w, double *x, void *stream);
 /* Same, skipped on the device when *guard != 0 (stop flag of the CG loops). */
 int ipx_banded_solve_guarded_c(void *handle, const double *w, double *x, const double *guard,
@@ -222,6 +227,11 @@ typedef struct ipx_cg_args {
   int64_t At_qv;
   int64_t A_tile_nnz;    /* nonzeros per row tile of the table in A_tiles when step1 is fused
                           * (1024 or 0 = IPX_SPMV_TILE_NNZ) */
+  /* the rows of A' once more in ELL(2) form for that tail (2n ints, 2n doubles: entry t of
+   * variable j at [t*n + j]; an absent entry repeats a valid column with value 0): indexed by
+   * the variable alone, so the tail's loads need no row-pointer round trip.  NULL: CSR. */
+  const int32_t *At_ell_col;
+  const double *At_ell_val;
 } ipx_cg_args;
 int ipx_cg_state_size(void);
 int ipx_cg_vec_grid(int64_t n);

@@ -55,8 +55,15 @@ struct Banded {
   double *slab;               // factor data of levels >= 1, contiguous
   size_t nslab;               // its length in doubles
   int nslab_lds;              // = nslab when the slab is staged in LDS, else 0
+  // parallel cyclic reduction (k = 1): scratch for the factor-time level check, per-level
+  // flags (device), and the level at which the reduced system is numerically diagonal
+  double *pcr_buf;            // 2 x 3m doubles (a, b, c ping-pong)
+  int *pcr_flags;             // PCR_LMAX + 1 ints: bit 0 of [s] = level s still coupled
+  int pcr_L;                  // 0: PCR solve not usable
   std::vector<void *> allocs;
 };
+
+constexpr int PCR_LMAX = 7;     // reduction distance up to 2^7 = 128 rows
 
 __device__ __forceinline__ int chunk_rows(int m, int q, int c, int P, int t) {
   // interior rows of chunk t: all chunks have c rows except the last, which
@@ -981,6 +988,12 @@ struct AtvJob {
   double *g_out;
   const int32_t *vown;
   double *part3;
+  // the same rows of A' in ELL(2) form (every variable sees at most two constraints):
+  // ell_col[t * n + j] / ell_val[t * n + j], t = 0, 1; an absent entry repeats a valid
+  // column with value 0.  Indexed by the variable alone: no row-pointer round trip.
+  const int32_t *ell_col;
+  const double *ell_val;
+  int64_t ell_n;
 };
 
 template <int K, int T, int QV>
@@ -1222,6 +1235,249 @@ k_solve_decoupled(LevDev lv, const double *__restrict__ w, double *__restrict__ 
   IPX_STAMP(7);
 }
 
+
+// ---------------------------------------------------------------- PCR (k = 1)
+// Tridiagonal S = A A' of the banded benchmark: instead of one lane sweeping a 64-row chunk
+// forwards and backwards (130 dependent steps), the whole workgroup reduces its window of
+// rows by PARALLEL CYCLIC REDUCTION: at level s every row eliminates its neighbours at
+// distance 2^s,
+//     alpha = -a_i / b_{i-h},  gamma = -c_i / b_{i+h}
+//     a_i <- alpha a_{i-h},  c_i <- gamma c_{i+h},
+//     b_i <- b_i + alpha c_{i-h} + gamma a_{i+h},  d_i <- d_i + alpha d_{i-h} + gamma d_{i+h},
+// all rows at once out of LDS (ping-pong buffers, one LDS barrier per level).  Because the
+// inverse of S decays geometrically, after L levels (L <= 7, found at every factorization by
+// running the reduction on the matrix alone, k_pcr_check_level) the remaining couplings are
+// below 2^-56 of the diagonal: x_i = d_i / b_i, and a window of the own rows plus 2^L rows on
+// either side gives the own rows exactly -- the same decay the chunk decoupling relies on.
+// No factor tables are read at all (the band is 2 doubles per row); same rows per workgroup
+// as k_solve_decoupled (DEC_CHUNKS * q), so the residual / A'v tail bookkeeping is unchanged.
+__global__ void __launch_bounds__(IPX_BLOCK)
+k_pcr_check_level(int m, int h, const double *__restrict__ in, double *__restrict__ out,
+                  int *flags, int level) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const double *ia = in, *ib = in + m, *ic = in + 2 * (int64_t)m;
+  const double a = ia[i], b = ib[i], c = ic[i];
+  double al = 0.0, ga = 0.0, an = 0.0, cn = 0.0, bn = b;
+  if (i - h >= 0) {
+    al = -a / ib[i - h];
+    an = al * ia[i - h];
+    bn = __builtin_fma(al, ic[i - h], bn);
+  }
+  if (i + h < m) {
+    ga = -c / ib[i + h];
+    cn = ga * ic[i + h];
+    bn = __builtin_fma(ga, ia[i + h], bn);
+  }
+  out[i] = an; out[m + i] = bn; out[2 * (int64_t)m + i] = cn;
+  const double tiny = 1.3877787807814457e-17;                     // 2^-56
+  if (!(fmax(fabs(an), fabs(cn)) <= tiny * bn)) atomicOr(flags + level, 1);
+  if (!(bn > 0.0)) atomicOr(flags + level, 2);
+}
+
+__global__ void __launch_bounds__(IPX_BLOCK)
+k_pcr_init(int m, const double *__restrict__ band, double *__restrict__ out, int *flags) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < PCR_LMAX + 1) flags[i] = 0;
+  if (i >= m) return;
+  out[i] = i >= 1 ? band[(int64_t)m + i] : 0.0;                   // a_i = S[i][i-1]
+  out[m + i] = band[i];
+  out[2 * (int64_t)m + i] = i + 1 < m ? band[(int64_t)m + i + 1] : 0.0;
+}
+
+constexpr int PCR_RMAX = 4 * 66 + 2 * (1 << PCR_LMAX) + 8;        // window rows (q <= 66)
+constexpr int PCR_NR = (PCR_RMAX + IPX_BLOCK - 1) / IPX_BLOCK;    // rows per lane
+
+// The matrix is symmetric: only the sub-diagonal a_i = S[i][i-h] is carried (c_i = a_{i+h}
+// is read from the neighbour), with the reciprocal of the diagonal next to it so that a level
+// costs one v_rcp_f64 + one Newton step per row instead of two IEEE divisions:
+//     al = -a_i r_{i-h},  ga = -a_{i+h} r_{i+h}           (r = 1/b)
+//     a_i <- al a_{i-h},  b_i <- b_i + al a_i + ga a_{i+h},  d_i <- d_i + al d_{i-h} + ga d_{i+h}
+// Rows outside the window (or the matrix) are identity rows with a = 0: no bounds branches.
+__device__ __forceinline__ double pcr_rcp(double b) {
+  double r = __builtin_amdgcn_rcp(b);
+  return __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);      // one Newton step: full precision
+}
+
+template <int QV>
+__global__ void __launch_bounds__(IPX_BLOCK)
+k_solve_pcr(int m, int rows_wg, int L, const double *__restrict__ band,
+            const double *__restrict__ w, double *__restrict__ x, double *__restrict__ partial,
+            const double *__restrict__ guard, AtvJob atv) {
+  constexpr int QA = QV > 0 ? QV : 1;
+  constexpr int PAD = 1 << PCR_LMAX;                 // identity rows either side of the window
+  constexpr int RS = PCR_RMAX + 2 * PAD;
+  __shared__ double pa[2][RS], pr[2][RS], pd[2][RS];
+  __shared__ double sx[PCR_RMAX];
+  __shared__ double red_lds[IPX_BLOCK / IPX_WAVE];
+  IPX_STAMP(0);
+  const double stop = guard ? *guard : 0.0;
+  const int H = 1 << L;
+  const int R = rows_wg + 2 * H;
+  const int64_t own0 = (int64_t)blockIdx.x * rows_wg;
+  const int64_t g0 = own0 - H;                      // global row of window row 0
+  const int tid = threadIdx.x;
+  // the matrix rows (static data: requested first), then w (the predecessor's output)
+  double a[PCR_NR], b[PCR_NR], d[PCR_NR];
+#pragma unroll
+  for (int k = 0; k < PCR_NR; ++k) {
+    const int64_t g = g0 + tid + k * IPX_BLOCK;
+    const bool in = tid + k * IPX_BLOCK < R && g >= 0 && g < m;
+    const int64_t gc = min(max(g, (int64_t)0), (int64_t)m - 1);
+    const double bv = band[gc], av = band[(int64_t)m + gc];
+    a[k] = (in && g >= 1 && tid + k * IPX_BLOCK >= 1) ? av : 0.0;     // (row 0 of the window: cut)
+    b[k] = in ? bv : 1.0;
+    const double wv = w[gc];
+    d[k] = in ? wv : 0.0;
+  }
+  // A'v tail: this workgroup's variables (requested with the staging loads)
+  int av0 = 0, avn = 0;
+  if (QV > 0) {
+    av0 = atv.vown[blockIdx.x];
+    avn = atv.vown[blockIdx.x + 1] - av0;
+  }
+  if (stop != 0.0) return;
+  IPX_STAMP(1);
+  // level-0 rows kept for the residual
+  double a0[PCR_NR], b0[PCR_NR], w0[PCR_NR];
+#pragma unroll
+  for (int k = 0; k < PCR_NR; ++k) { a0[k] = a[k]; b0[k] = b[k]; w0[k] = d[k]; }
+  // A'v tail: the two ELL entries of every variable and r, requested now so that they arrive
+  // while the reduction runs
+  int ac0[QA], ac1[QA];
+  double aw0[QA], aw1[QA], ar[QA];
+  if (QV > 0) {
+#pragma unroll
+    for (int k = 0; k < QA; ++k) {
+      const int64_t j = av0 + min(tid + k * IPX_BLOCK, max(avn - 1, 0));
+      ac0[k] = atv.ell_col[j];
+      ac1[k] = atv.ell_col[atv.ell_n + j];
+      aw0[k] = atv.ell_val[j];
+      aw1[k] = atv.ell_val[atv.ell_n + j];
+      ar[k] = atv.r_in[j];
+    }
+  }
+  IPX_STAMP(2);
+  // identity padding: rows [-PAD, 0) and [R, R + PAD) of both buffers (a = 0, r = 1, d = 0)
+  for (int i = tid; i < 2 * PAD; i += IPX_BLOCK) {
+    const int r = i < PAD ? i : R + i;              // storage index = window row + PAD
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { pa[u][r] = 0.0; pr[u][r] = 1.0; pd[u][r] = 0.0; }
+  }
+  // (a of the row just past the window's end is its coupling into the window: cut too)
+  for (int s = 0; s < L; ++s) {
+    const int h = 1 << s, cur = s & 1;
+    double rc[PCR_NR];
+#pragma unroll
+    for (int k = 0; k < PCR_NR; ++k) {
+      const int r = tid + k * IPX_BLOCK;
+      rc[k] = pcr_rcp(b[k]);
+      if (r < R) { pa[cur][PAD + r] = a[k]; pr[cur][PAD + r] = rc[k]; pd[cur][PAD + r] = d[k]; }
+    }
+    ipx_lds_barrier();
+#pragma unroll
+    for (int k = 0; k < PCR_NR; ++k) {
+      const int r = PAD + min(tid + k * IPX_BLOCK, R - 1);
+      const double alo = pa[cur][r - h], rlo = pr[cur][r - h], dlo = pd[cur][r - h];
+      const double ahi = pa[cur][r + h], rhi = pr[cur][r + h], dhi = pd[cur][r + h];
+      const double al = -a[k] * rlo, ga = -ahi * rhi;
+      double bn = __builtin_fma(al, a[k], b[k]);
+      bn = __builtin_fma(ga, ahi, bn);
+      double dn = __builtin_fma(al, dlo, d[k]);
+      dn = __builtin_fma(ga, dhi, dn);
+      a[k] = al * alo; b[k] = bn; d[k] = dn;
+    }
+  }
+  IPX_STAMP(3);
+  // ---- x = d / b; own rows to memory, the window to LDS for the tail / residual
+#pragma unroll
+  for (int k = 0; k < PCR_NR; ++k) {
+    const int r = tid + k * IPX_BLOCK;
+    if (r < R) {
+      const double xv = d[k] / b[k];
+      sx[r] = xv;
+      const int64_t g = g0 + r;
+      if (r >= H && r < H + rows_wg && g < m) x[g] = xv;
+    }
+  }
+  if (!partial && QV == 0) return;
+  ipx_lds_barrier();
+  IPX_STAMP(6);
+  if (QV > 0) {
+    // ---- g = r - A'v on this workgroup's variables, v out of LDS (sx)
+    double gacc = 0.0;
+#pragma unroll
+    for (int k = 0; k < QA; ++k) {
+      const int jl = tid + k * IPX_BLOCK;
+      if (jl < avn) {
+        // (an absent entry carries value 0 and a valid column: same sum as the CSR row)
+        double sum = aw0[k] * sx[ac0[k] - g0];
+        sum += aw1[k] * sx[ac1[k] - g0];
+        double y = -1.0 * sum;
+        y += 1.0 * ar[k];
+        atv.g_out[av0 + jl] = y;
+        gacc += y * y;
+      }
+    }
+    const double gtot = ipx_block_reduce<IPX_SUM>(gacc, red_lds);
+    if (tid == 0) {
+      atv.part3[blockIdx.x] = gtot;
+      atv.part3[gridDim.x + blockIdx.x] = 0.0;
+    }
+    if (!partial) return;
+  }
+  // ---- residual of the own rows:  w_i - (a_i x_{i-1} + b_i x_i + a_{i+1} x_{i+1})
+  // (a_{i+1} of the row below: the level-0 sub-diagonal of the neighbouring lane, via LDS)
+#pragma unroll
+  for (int k = 0; k < PCR_NR; ++k) {
+    const int r = tid + k * IPX_BLOCK;
+    if (r < R) pa[0][PAD + r] = a0[k];
+  }
+  ipx_lds_barrier();
+  double acc = 0.0;
+#pragma unroll
+  for (int k = 0; k < PCR_NR; ++k) {
+    const int r = tid + k * IPX_BLOCK;
+    const int64_t g = g0 + r;
+    if (r >= H && r < H + rows_wg && g < m) {
+      double sum = b0[k] * sx[r];
+      sum += a0[k] * sx[r - 1];
+      sum += pa[0][PAD + r + 1] * sx[r + 1];
+      const double res = w0[k] - sum;
+      acc += res * res;
+    }
+  }
+  const double tot = ipx_block_reduce<IPX_SUM>(acc, red_lds);
+  if (tid == 0) partial[blockIdx.x] = tot;
+  IPX_STAMP(7);
+}
+
+template <int QV>
+int launch_solve_pcr_q(const LevDev &lv, int L, const double *w, double *x, double *partial,
+                       int *npartial, const double *guard, const AtvJob &atv, hipStream_t st) {
+  const int rows_wg = DEC_CHUNKS * lv.q;
+  const int grid = (lv.P + DEC_CHUNKS - 1) / DEC_CHUNKS;
+  if (npartial) *npartial = grid;
+  hipLaunchKernelGGL((k_solve_pcr<QV>), dim3(grid), dim3(IPX_BLOCK), 0, st, lv.m, rows_wg, L,
+                     lv.band, w, x, partial, guard, atv);
+  IPX_CHECK_LAUNCH();
+  return IPX_OK;
+}
+
+int launch_solve_pcr(const LevDev &lv, int L, const double *w, double *x, double *partial,
+                     int *npartial, const double *guard, hipStream_t st,
+                     const AtvJob *atv = nullptr, int qv = 0) {
+  const AtvJob none{};
+  if (!atv || qv <= 0)
+    return launch_solve_pcr_q<0>(lv, L, w, x, partial, npartial, guard, none, st);
+  // the tail's lanes are the whole workgroup here (256 instead of 192): fewer variables each
+  const int per = (qv * (DOWN_T - IPX_WAVE) + IPX_BLOCK - 1) / IPX_BLOCK;
+  if (per <= 4) return launch_solve_pcr_q<4>(lv, L, w, x, partial, npartial, guard, *atv, st);
+  if (per <= 8) return launch_solve_pcr_q<8>(lv, L, w, x, partial, npartial, guard, *atv, st);
+  if (per <= 12) return launch_solve_pcr_q<12>(lv, L, w, x, partial, npartial, guard, *atv, st);
+  return IPX_EINVAL;
+}
+
 template <int K>
 size_t decoupled_lds_doubles(int q) {
   constexpr int T = DEC_CHUNKS, NCH = T + 3;
@@ -1413,8 +1669,9 @@ int factor_upper(Banded *h, hipStream_t st) {
   return IPX_OK;
 }
 
-int read_flag(Banded *h, int *f, hipStream_t st) {
-  if (hipMemcpyAsync(f, h->flag, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess)
+// flag[0] = pivot / coupling bits; flag[1 ..] = the PCR level flags: ONE blocking read
+int read_flag(Banded *h, int *f, hipStream_t st, int count = 1) {
+  if (hipMemcpyAsync(f, h->flag, count * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess)
     return IPX_ELAUNCH;
   return hipStreamSynchronize(st) == hipSuccess ? IPX_OK : IPX_ELAUNCH;
 }
@@ -1445,6 +1702,9 @@ void *ipx_banded_create(int64_t m64, int32_t k, int32_t chunk) {
   h->gL = h->gR = h->slab = h->ybuf = h->rinv = nullptr;
   h->decoupled = false;
   h->fast = false;
+  h->pcr_buf = nullptr;
+  h->pcr_flags = nullptr;
+  h->pcr_L = 0;
   int m = (int)m64, kk = k;
   if (chunk <= 0) chunk = 64;
   bool ok = true;
@@ -1502,7 +1762,13 @@ void *ipx_banded_create(int64_t m64, int32_t k, int32_t chunk) {
       }
     }
   }
-  h->flag = dalloc<int>(h, 1);
+  h->flag = dalloc<int>(h, 2 + PCR_LMAX);
+  if (ok && h->flag && h->lev[0].k == 1 && h->nlev >= 2 &&
+      DEC_CHUNKS * h->lev[0].q + 2 * (1 << PCR_LMAX) <= PCR_RMAX) {
+    h->pcr_buf = dalloc<double>(h, (size_t)6 * h->lev[0].m);
+    h->pcr_flags = h->flag + 1;
+    if (!h->pcr_buf) ok = false;
+  }
   if (ok) {
     const Level &l0 = h->lev[0];
     // k_down0 stages (k+2) tables of T*q doubles.  Few chunks per workgroup =
@@ -1556,6 +1822,19 @@ int ipx_banded_factor(void *handle, const double *band, void *stream) {
   int rc = level_factor(h, 0, st);
   if (rc != IPX_OK) return rc;
   h->upper_done = false;
+  h->pcr_L = 0;
+  if (decoupling_candidate(h) && h->pcr_buf) {
+    // the cyclic reduction of the matrix alone: at which level has it decoupled?
+    const int m0 = h->lev[0].m;
+    const dim3 grid((max(m0, PCR_LMAX + 1) + IPX_BLOCK - 1) / IPX_BLOCK), block(IPX_BLOCK);
+    double *b0 = h->pcr_buf, *b1 = h->pcr_buf + (size_t)3 * m0;
+    hipLaunchKernelGGL(k_pcr_init, grid, block, 0, st, m0, band, b0, h->pcr_flags);
+    for (int s = 0; s < PCR_LMAX; ++s) {
+      hipLaunchKernelGGL(k_pcr_check_level, grid, block, 0, st, m0, 1 << s, (s & 1) ? b1 : b0,
+                         (s & 1) ? b0 : b1, h->pcr_flags, s + 1);
+    }
+    IPX_CHECK_LAUNCH();
+  }
   if (decoupling_candidate(h)) {
     const int mR = h->lev[0].mR, K0 = h->lev[0].k, nsep = mR / K0;
     const dim3 grid((nsep + IPX_BLOCK - 1) / IPX_BLOCK), block(IPX_BLOCK);
@@ -1584,9 +1863,18 @@ int ipx_banded_status(void *handle, void *stream) {
   if (!handle) return IPX_EINVAL;
   Banded *h = (Banded *)handle;
   hipStream_t st = (hipStream_t)stream;
-  int f = 0;
-  if (read_flag(h, &f, st) != IPX_OK) return IPX_ELAUNCH;
+  int fl[2 + PCR_LMAX] = {0};
+  if (read_flag(h, fl, st, h->pcr_flags ? 2 + PCR_LMAX : 1) != IPX_OK) return IPX_ELAUNCH;
+  int f = fl[0];
   h->decoupled = decoupling_candidate(h) && !(f & 2);
+  h->pcr_L = 0;
+  if (h->decoupled && h->pcr_flags && !(f & 1)) {
+    const int *pf = fl + 1;
+    for (int s = 1; s <= PCR_LMAX; ++s) {
+      if (pf[s] & 2) break;                 // a non-positive reduced diagonal: not this path
+      if (!(pf[s] & 1)) { h->pcr_L = s; break; }
+    }
+  }
   if (!h->decoupled && !h->upper_done && !(f & 1)) {
     int rc = factor_upper(h, st);
     if (rc != IPX_OK) return rc;
@@ -1602,8 +1890,17 @@ int ipx_banded_decoupled(void *handle) { return handle && ((Banded *)handle)->de
 int ipx_banded_set_decoupling(void *handle, int allow) {
   if (!handle) return IPX_EINVAL;
   if (!allow) ((Banded *)handle)->decoupled = false;
+  if (allow == 2) ((Banded *)handle)->pcr_L = 0;     // keep the chunk form of the decoupled solve
+  // test hook: force the reduction to stop at level allow - 16 (an INEXACT solve when that is
+  // below the measured level: gives the fused residual something real to measure)
+  if (allow > 16 && allow <= 16 + PCR_LMAX && ((Banded *)handle)->pcr_L > 0)
+    ((Banded *)handle)->pcr_L = allow - 16;
   return IPX_OK;
 }
+
+// Level at which the cyclic reduction of this factorization's matrix has decoupled (the
+// single-launch solve then runs as parallel cyclic reduction); 0 when that path is off.
+int ipx_banded_pcr_level(void *handle) { return handle ? ((Banded *)handle)->pcr_L : 0; }
 
 // x = S^-1 w.  w and x are length m; x may alias w.
 int ipx_banded_solve(void *handle, const double *w, double *x, void *stream) {
@@ -1701,6 +1998,8 @@ int fast_solve(Banded *h, const double *w, double *x, double *partial, int *npar
   }
   if (h->decoupled && w != x) {
     const LevDev lv = to_dev(h->lev[0], nullptr);
+    if (h->pcr_L > 0 && lv.k == 1)          // tridiagonal: parallel cyclic reduction
+      return launch_solve_pcr(lv, h->pcr_L, w, x, partial, npartial, guard, st);
     switch (lv.k) {
 #define SD(kk) case kk: return launch_solve_decoupled<kk>(lv, w, x, h->rinv, partial, npartial, guard, st)
       SD(1); SD(2); SD(3); SD(4); SD(5); SD(6); SD(7); SD(8);
@@ -1760,12 +2059,16 @@ int ipx_banded_solve_resid_atv_launch(void *handle, const double *w, double *x, 
                                       const int32_t *At_colidx, const double *At_val,
                                       const double *r_in, double *g_out, const int32_t *vown,
                                       int qv, double *part3, const double *guard,
-                                      hipStream_t st) {
+                                      hipStream_t st, const int32_t *ell_col,
+                                      const double *ell_val, int64_t ell_n) {
   if (!handle || !w || !x || !partial || w == x) return IPX_EINVAL;
   int32_t geo[2];
   if (!ipx_banded_decoupled_geometry(handle, geo)) return IPX_EINVAL;
   Banded *h = (Banded *)handle;
-  const AtvJob job{At_rowptr, At_colidx, At_val, r_in, g_out, vown, part3};
+  const AtvJob job{At_rowptr, At_colidx, At_val, r_in, g_out, vown, part3, ell_col, ell_val, ell_n};
+  if (h->pcr_L > 0 && ell_col && ell_val)
+    return launch_solve_pcr(to_dev(h->lev[0], nullptr), h->pcr_L, w, x, partial, npartial, guard,
+                            st, &job, qv);
   return launch_solve_decoupled<1>(to_dev(h->lev[0], nullptr), w, x, h->rinv, partial, npartial,
                                    guard, st, &job, qv);
 }

@@ -804,7 +804,8 @@ int ipx_cg_shard2_segment(const ipx_cg_args *a, const ipx_shard2_ext *e, int32_t
     if (a->At_vown && a->At_qv > 0) {
       rc = ipx_banded_solve_resid_atv_launch(a->banded, a->w, a->v, a->part4, &np4, a->At_rowptr,
                                              a->At_colidx, a->At_val, r_in, a->r, a->At_vown,
-                                             (int)a->At_qv, a->part3, guard, st);
+                                             (int)a->At_qv, a->part3, guard, st, a->At_ell_col,
+                                             a->At_ell_val, a->n);
       if (rc) return rc;
       np3 = np4;
     } else {
@@ -1024,7 +1025,8 @@ static int cg_iterate(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, hi
         // ||g||^2 partials are then per workgroup of that kernel
         rc = ipx_banded_solve_resid_atv_launch(a->banded, a->w, a->v, a->part4, &np4,
                                                a->At_rowptr, a->At_colidx, a->At_val, r_in, a->r,
-                                               a->At_vown, (int)a->At_qv, a->part3, guard, st);
+                                               a->At_vown, (int)a->At_qv, a->part3, guard, st,
+                                               a->At_ell_col, a->At_ell_val, a->n);
         if (rc) return rc;
         np3 = np4;
         MARK(3);

@@ -55,6 +55,7 @@ _SIGNATURES = {
     "ipx_banded_kmax": [],
     "ipx_banded_levels": [_P],
     "ipx_banded_decoupled": [_P],
+    "ipx_banded_pcr_level": [_P],
     "ipx_banded_set_decoupling": [_P, _c.c_int],
     "ipx_banded_factor": [_P, _P, _P],
     "ipx_banded_status": [_P, _P],

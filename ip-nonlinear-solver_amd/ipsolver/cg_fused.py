@@ -39,7 +39,8 @@ class CgArgs(ctypes.Structure):
         ("part1", _P), ("part2", _P), ("part3", _P), ("part4", _P),
         ("vec_grid", _I64), ("solver_kind", _I64), ("pb", _P), ("H_hmax", _I64), ("H_tile_rows", _I64),
         ("r_next", _P), ("A_own", _P), ("A_span", _I64), ("fold_ws", _P),
-        ("At_vown", _P), ("At_qv", _I64), ("A_tile_nnz", _I64))]
+        ("At_vown", _P), ("At_qv", _I64), ("A_tile_nnz", _I64),
+        ("At_ell_col", _P), ("At_ell_val", _P))]
 
 
 # Counters over the life of the process (diagnostics: how often the device loop
@@ -178,6 +179,33 @@ def fuse_vown(At_pattern, rows_per_wg, nwg):
     return out
 
 
+def ell_rows(At):
+    """The rows of ``At`` (every one with at most two entries: checked by ``fuse_vown``) in
+    ELL(2) form for the tail of the banded solve: ``(col, val)`` with entry t of row j at
+    ``[t * n + j]``.  The column table and the gather map are symbolic (cached on the
+    pattern); the values are one gather per call."""
+    pat = At.pattern
+    cache = getattr(pat, "_ipx_ell2", None)
+    if cache is None:
+        n = pat.shape[0]
+        ip = pat.indptr_h.astype(np.int64)
+        lens = np.diff(ip)
+        last = max(pat.nnz - 1, 0)
+        e0 = np.minimum(ip[:-1], last)                       # rows without entries: any valid one
+        e1 = np.where(lens > 1, ip[:-1] + 1, e0)
+        src = np.concatenate((e0, e1))
+        mask = np.concatenate((lens > 0, lens > 1)).astype(np.float64)
+        col = pat.indices_h[src] if pat.nnz else np.zeros(2 * n, dtype=np.int32)
+        dev = ctx().device
+        cache = pat._ipx_ell2 = (torch.from_numpy(np.ascontiguousarray(col, dtype=np.int32)).to(dev),
+                                 torch.from_numpy(src.astype(np.int32)).to(dev),
+                                 torch.from_numpy(mask).to(dev))
+    col, src, mask = cache
+    val = torch.empty(src.numel(), dtype=torch.float64, device=col.device)
+    _hip.call("ipx_gather", src.numel(), _p(At.val), _p(src), _p(mask), None, _p(val), stream_ptr())
+    return col, val
+
+
 def _solver_kind(solver):
     """0: banded handle, 1: box-Schur argument block, None: not usable here."""
     from .projector import BandedNormalSolver
@@ -286,6 +314,8 @@ class _Loop:
                 if vown is not None:
                     self.vown = vown[0]
                     a.At_vown, a.At_qv = _ptr(self.vown), vown[1]
+                    self.ell_col, self.ell_val = ell_rows(At)
+                    a.At_ell_col, a.At_ell_val = _ptr(self.ell_col), _ptr(self.ell_val)
         self.args = a
 
     def ref(self):

@@ -60,6 +60,14 @@ class _Symbolic:
                 self.k, self.perm = k2, perm
         self.m = m
 
+    def __del__(self):
+        # handles parked by BandedNormalSolver for the next factorization on this pattern
+        for _, handle, _ in self.__dict__.get("_handle_pool", []):
+            try:
+                _hip.load().ipx_banded_destroy(ctypes.c_void_p(handle))
+            except Exception:
+                pass
+
 
 _SYMBOLIC_ATTR = "_ipx_aat_symbolic"
 
@@ -93,11 +101,22 @@ class BandedNormalSolver:
             inv = np.empty_like(sym.perm)
             inv[sym.perm] = np.arange(self.m, dtype=np.int32)
             self.iperm = torch.from_numpy(inv).to(dev)
-        self.band = torch.empty((self.k + 1) * self.m, dtype=_F64, device=dev)
+        # handle + band storage are recycled per pattern: creating / destroying a handle is a
+        # dozen hipMalloc / hipFree calls (~0.5 ms), more than the numeric refresh itself
         lib = _hip.load()
-        self.handle = lib.ipx_banded_create(self.m, self.k, int(chunk))
-        if not self.handle:
-            raise _hip.IpxError("ipx_banded_create failed (m=%d, k=%d)" % (self.m, self.k))
+        self._pool = sym.__dict__.setdefault("_handle_pool", [])
+        self._key = (self.m, self.k, int(chunk))
+        self.handle, self.band = None, None
+        for i, (key, handle, band) in enumerate(self._pool):
+            if key == self._key:
+                self.handle, self.band = handle, band
+                del self._pool[i]
+                break
+        if self.handle is None:
+            self.band = torch.empty((self.k + 1) * self.m, dtype=_F64, device=dev)
+            self.handle = lib.ipx_banded_create(self.m, self.k, int(chunk))
+            if not self.handle:
+                raise _hip.IpxError("ipx_banded_create failed (m=%d, k=%d)" % (self.m, self.k))
         p = A.pattern
         _hip.call("ipx_aat_band_w", self.m, self.k, _p(p.indptr), _p(p.indices), _p(A.val),
                   _p(self.perm), _p(col_weights), _p(self.band), stream_ptr())
@@ -107,13 +126,20 @@ class BandedNormalSolver:
             raise np.linalg.LinAlgError("Singular Jacobian matrix: A A' is not positive definite")
         _hip.check(rc, "ipx_banded_status")
 
+    POOL_MAX = 4
+
     def __del__(self):
         h, self.handle = getattr(self, "handle", None), None
-        if h:
-            try:
+        if not h:
+            return
+        pool = getattr(self, "_pool", None)
+        try:
+            if pool is not None and len(pool) < self.POOL_MAX:
+                pool.append((self._key, h, self.band))       # next factorization on this pattern
+            else:
                 _hip.load().ipx_banded_destroy(ctypes.c_void_p(h))
-            except Exception:
-                pass
+        except Exception:
+            pass
 
     def _gather(self, x, idx):
         out = dv._empty(len(x))

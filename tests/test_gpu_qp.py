@@ -237,6 +237,9 @@ def test_orthogonality_from_the_normal_equation_residual(ips, n, m):
     _hip.call("ipx_aat_band_w", m, solver.k, ips.dv._p(pat.indptr), ips.dv._p(pat.indices),
               ips.dv._p(A2d.val), None, None, ips.dv._p(band2), ips.dv.stream_ptr())
     solver.band.copy_(band2)                      # residual against S2 = A2 A2'
+    # (the chunk-recurrence form of the solve: the cyclic-reduction form has no factorization
+    # to go stale -- its residual is checked in test_banded_solve_by_parallel_cyclic_reduction)
+    _hip.load().ipx_banded_set_decoupling(ctypes.c_void_p(solver.handle), 2)
     r = rng.standard_normal(n)
     w = A2.dot(r)
     wd = ips.dv.DVec.from_host(w)
@@ -790,3 +793,58 @@ def test_dense_ill_conditioned(ips, cond):
     assert rel(Y.dot(b), Yo.dot(b)) <= tol
     assert rel(Z.dot(x), Zo.dot(x)) <= tol
     assert ips.proj.orthogonality(A, Z.dot(x)) <= 1e-12
+
+
+@pytest.mark.parametrize("n,m", [(2000, 200), (3000, 300), (20000, 2000), (1000000, 100000)])
+def test_banded_solve_by_parallel_cyclic_reduction(ips, n, m):
+    """Tridiagonal A A' (the banded benchmark): the single-launch solve runs as parallel
+    cyclic reduction over windows of rows (csrc/banded.hip k_solve_pcr), the level at which
+    the reduction has decoupled being measured at every factorization.  Against a direct
+    sparse solve, against the chunk-recurrence form of the same launch, and the fused
+    residual ||w - S v||^2 against numpy."""
+    import ctypes
+    import torch
+    from ipsolver import _hip
+    lib = _hip.load()
+    inst = BandedInstance(n, m)
+    A = inst.A.tocsr()
+    solver = ips.proj.BandedNormalSolver(ips.dv.DeviceCSR.from_scipy(A))
+    h = ctypes.c_void_p(solver.handle)
+    if m <= 260:
+        return        # one chunk-workgroup at most: nothing to decouple from
+    L = lib.ipx_banded_pcr_level(h)
+    assert lib.ipx_banded_decoupled(h) == 1 and 1 <= L <= 7
+    rng = np.random.default_rng(m)
+    w = rng.standard_normal(m)
+    wd = ips.dv.DVec.from_host(w)
+    S = sps.csc_matrix(A @ A.T)
+    want = sps.linalg.splu(S).solve(w)
+    v = torch.empty(m, dtype=torch.float64, device="cuda")
+    part = torch.zeros((m + 255) // 256 + 1, dtype=torch.float64, device="cuda")
+    npart = ctypes.c_int32(0)
+    _hip.call("ipx_banded_solve_resid", h, ips.dv._p(wd.t), ips.dv._p(v), ips.dv._p(part),
+              ctypes.byref(npart), None, ips.dv.stream_ptr())
+    got = v.cpu().numpy()
+    assert np.max(np.abs(got - want)) <= 1e-12 * np.max(np.abs(want))
+    res = float(np.sum(part.cpu().numpy()[:npart.value]))
+    res_np = float(np.sum((w - S @ got) ** 2))
+    assert 0.25 * res_np <= res <= 4 * res_np + 1e-300       # both are rounding noise
+    assert res <= 1e-28 * np.sum(w ** 2)
+    again = torch.empty_like(v)
+    _hip.call("ipx_banded_solve", h, ips.dv._p(wd.t), ips.dv._p(again), ips.dv.stream_ptr())
+    assert torch.equal(again, v)                            # bitwise reproducible
+    # a reduction stopped two levels early is an inexact solve: the fused residual must be
+    # the residual of what the kernel returned (the orthogonality measure, projections.py:52)
+    if L > 2:
+        lib.ipx_banded_set_decoupling(h, 16 + L - 2)
+        _hip.call("ipx_banded_solve_resid", h, ips.dv._p(wd.t), ips.dv._p(again), ips.dv._p(part),
+                  ctypes.byref(npart), None, ips.dv.stream_ptr())
+        rough = again.cpu().numpy()
+        res = float(np.sum(part.cpu().numpy()[:npart.value]))
+        res_np = float(np.sum((w - S @ rough) ** 2))
+        assert res_np > 1e-20 * np.sum(w ** 2) and abs(res - res_np) <= 1e-10 * res_np
+    lib.ipx_banded_set_decoupling(h, 2)                     # the chunk-recurrence form
+    assert lib.ipx_banded_pcr_level(h) == 0
+    v2 = torch.empty_like(v)
+    _hip.call("ipx_banded_solve", h, ips.dv._p(wd.t), ips.dv._p(v2), ips.dv.stream_ptr())
+    assert np.max(np.abs(v2.cpu().numpy() - got)) <= 1e-13 * np.max(np.abs(got))
