@@ -1285,6 +1285,7 @@ k_pcr_init(int m, const double *__restrict__ band, double *__restrict__ out, int
   out[2 * (int64_t)m + i] = i + 1 < m ? band[(int64_t)m + i + 1] : 0.0;
 }
 
+typedef double v2d __attribute__((ext_vector_type(2)));
 constexpr int PCR_RMAX = 4 * 66 + 2 * (1 << PCR_LMAX) + 8;        // window rows (q <= 66)
 constexpr int PCR_NR = (PCR_RMAX + IPX_BLOCK - 1) / IPX_BLOCK;    // rows per lane
 
@@ -1299,7 +1300,7 @@ __device__ __forceinline__ double pcr_rcp(double b) {
   return __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);      // one Newton step: full precision
 }
 
-template <int QV>
+template <int QV, int NR>
 __global__ void __launch_bounds__(IPX_BLOCK)
 k_solve_pcr(int m, int rows_wg, int L, const double *__restrict__ band,
             const double *__restrict__ w, double *__restrict__ x, double *__restrict__ partial,
@@ -1311,6 +1312,13 @@ k_solve_pcr(int m, int rows_wg, int L, const double *__restrict__ band,
   __shared__ double sx[PCR_RMAX];
   __shared__ double red_lds[IPX_BLOCK / IPX_WAVE];
   IPX_STAMP(0);
+  // A'v tail: this workgroup's variables -- the FIRST loads of the kernel, so that the tail's
+  // own loads (which need them) can be issued while the solve's inputs are still in flight
+  int av0 = 0, avn = 0;
+  if (QV > 0) {
+    av0 = atv.vown[blockIdx.x];
+    avn = atv.vown[blockIdx.x + 1] - av0;
+  }
   const double stop = guard ? *guard : 0.0;
   const int H = 1 << L;
   const int R = rows_wg + 2 * H;
@@ -1318,9 +1326,9 @@ k_solve_pcr(int m, int rows_wg, int L, const double *__restrict__ band,
   const int64_t g0 = own0 - H;                      // global row of window row 0
   const int tid = threadIdx.x;
   // the matrix rows (static data: requested first), then w (the predecessor's output)
-  double a[PCR_NR], b[PCR_NR], d[PCR_NR];
+  double a[NR], b[NR], d[NR];
 #pragma unroll
-  for (int k = 0; k < PCR_NR; ++k) {
+  for (int k = 0; k < NR; ++k) {
     const int64_t g = g0 + tid + k * IPX_BLOCK;
     const bool in = tid + k * IPX_BLOCK < R && g >= 0 && g < m;
     const int64_t gc = min(max(g, (int64_t)0), (int64_t)m - 1);
@@ -1330,33 +1338,34 @@ k_solve_pcr(int m, int rows_wg, int L, const double *__restrict__ band,
     const double wv = w[gc];
     d[k] = in ? wv : 0.0;
   }
-  // A'v tail: this workgroup's variables (requested with the staging loads)
-  int av0 = 0, avn = 0;
+  // A'v tail: the two ELL entries of every variable and r, requested now so that they arrive
+  // while the reduction runs.  A lane takes PAIRS of consecutive variables (16-byte loads of
+  // the values and of r, 8-byte loads of the columns: half the load instructions -- the tail
+  // is bound by the CU's load issue, 2600 variables x 5 arrays per workgroup); pairs start at
+  // an even variable so every load is naturally aligned (the planes are padded to even length)
+  constexpr int QP = (QA + 1) / 2;
+  typedef int v2i __attribute__((ext_vector_type(2)));
+  const int64_t vb = av0 & ~1;                       // first pair (may start one before av0)
+  v2i ac0[QP], ac1[QP];
+  v2d aw0[QP], aw1[QP], ar[QP];
   if (QV > 0) {
-    av0 = atv.vown[blockIdx.x];
-    avn = atv.vown[blockIdx.x + 1] - av0;
+    const int64_t last = max((int64_t)av0 + avn - 1, vb) & ~(int64_t)1;
+#pragma unroll
+    for (int k = 0; k < QP; ++k) {
+      const int64_t j = min(vb + 2 * (int64_t)(tid + k * IPX_BLOCK), last);
+      ac0[k] = *reinterpret_cast<const v2i *>(atv.ell_col + j);
+      ac1[k] = *reinterpret_cast<const v2i *>(atv.ell_col + atv.ell_n + j);
+      aw0[k] = *reinterpret_cast<const v2d *>(atv.ell_val + j);
+      aw1[k] = *reinterpret_cast<const v2d *>(atv.ell_val + atv.ell_n + j);
+      ar[k] = *reinterpret_cast<const v2d *>(atv.r_in + j);
+    }
   }
   if (stop != 0.0) return;
   IPX_STAMP(1);
   // level-0 rows kept for the residual
-  double a0[PCR_NR], b0[PCR_NR], w0[PCR_NR];
+  double a0[NR], b0[NR], w0[NR];
 #pragma unroll
-  for (int k = 0; k < PCR_NR; ++k) { a0[k] = a[k]; b0[k] = b[k]; w0[k] = d[k]; }
-  // A'v tail: the two ELL entries of every variable and r, requested now so that they arrive
-  // while the reduction runs
-  int ac0[QA], ac1[QA];
-  double aw0[QA], aw1[QA], ar[QA];
-  if (QV > 0) {
-#pragma unroll
-    for (int k = 0; k < QA; ++k) {
-      const int64_t j = av0 + min(tid + k * IPX_BLOCK, max(avn - 1, 0));
-      ac0[k] = atv.ell_col[j];
-      ac1[k] = atv.ell_col[atv.ell_n + j];
-      aw0[k] = atv.ell_val[j];
-      aw1[k] = atv.ell_val[atv.ell_n + j];
-      ar[k] = atv.r_in[j];
-    }
-  }
+  for (int k = 0; k < NR; ++k) { a0[k] = a[k]; b0[k] = b[k]; w0[k] = d[k]; }
   IPX_STAMP(2);
   // identity padding: rows [-PAD, 0) and [R, R + PAD) of both buffers (a = 0, r = 1, d = 0)
   for (int i = tid; i < 2 * PAD; i += IPX_BLOCK) {
@@ -1367,16 +1376,16 @@ k_solve_pcr(int m, int rows_wg, int L, const double *__restrict__ band,
   // (a of the row just past the window's end is its coupling into the window: cut too)
   for (int s = 0; s < L; ++s) {
     const int h = 1 << s, cur = s & 1;
-    double rc[PCR_NR];
+    double rc[NR];
 #pragma unroll
-    for (int k = 0; k < PCR_NR; ++k) {
+    for (int k = 0; k < NR; ++k) {
       const int r = tid + k * IPX_BLOCK;
       rc[k] = pcr_rcp(b[k]);
       if (r < R) { pa[cur][PAD + r] = a[k]; pr[cur][PAD + r] = rc[k]; pd[cur][PAD + r] = d[k]; }
     }
     ipx_lds_barrier();
 #pragma unroll
-    for (int k = 0; k < PCR_NR; ++k) {
+    for (int k = 0; k < NR; ++k) {
       const int r = PAD + min(tid + k * IPX_BLOCK, R - 1);
       const double alo = pa[cur][r - h], rlo = pr[cur][r - h], dlo = pd[cur][r - h];
       const double ahi = pa[cur][r + h], rhi = pr[cur][r + h], dhi = pd[cur][r + h];
@@ -1391,7 +1400,7 @@ k_solve_pcr(int m, int rows_wg, int L, const double *__restrict__ band,
   IPX_STAMP(3);
   // ---- x = d / b; own rows to memory, the window to LDS for the tail / residual
 #pragma unroll
-  for (int k = 0; k < PCR_NR; ++k) {
+  for (int k = 0; k < NR; ++k) {
     const int r = tid + k * IPX_BLOCK;
     if (r < R) {
       const double xv = d[k] / b[k];
@@ -1407,16 +1416,25 @@ k_solve_pcr(int m, int rows_wg, int L, const double *__restrict__ band,
     // ---- g = r - A'v on this workgroup's variables, v out of LDS (sx)
     double gacc = 0.0;
 #pragma unroll
-    for (int k = 0; k < QA; ++k) {
-      const int jl = tid + k * IPX_BLOCK;
-      if (jl < avn) {
-        // (an absent entry carries value 0 and a valid column: same sum as the CSR row)
-        double sum = aw0[k] * sx[ac0[k] - g0];
-        sum += aw1[k] * sx[ac1[k] - g0];
-        double y = -1.0 * sum;
-        y += 1.0 * ar[k];
-        atv.g_out[av0 + jl] = y;
-        gacc += y * y;
+    for (int k = 0; k < QP; ++k) {
+      const int64_t j = vb + 2 * (int64_t)(tid + k * IPX_BLOCK);
+      // (an absent entry carries value 0 and a valid column: same sum as the CSR row)
+      double y0 = -1.0 * (aw0[k].x * sx[ac0[k].x - g0] + aw1[k].x * sx[ac1[k].x - g0]);
+      y0 += 1.0 * ar[k].x;
+      double y1 = -1.0 * (aw0[k].y * sx[ac0[k].y - g0] + aw1[k].y * sx[ac1[k].y - g0]);
+      y1 += 1.0 * ar[k].y;
+      const bool in0 = j >= av0 && j < (int64_t)av0 + avn;
+      const bool in1 = j + 1 >= av0 && j + 1 < (int64_t)av0 + avn;
+      if (in0 && in1) {
+        *reinterpret_cast<v2d *>(atv.g_out + j) = (v2d){y0, y1};
+        gacc += y0 * y0;
+        gacc += y1 * y1;
+      } else if (in0) {
+        atv.g_out[j] = y0;
+        gacc += y0 * y0;
+      } else if (in1) {
+        atv.g_out[j + 1] = y1;
+        gacc += y1 * y1;
       }
     }
     const double gtot = ipx_block_reduce<IPX_SUM>(gacc, red_lds);
@@ -1429,14 +1447,14 @@ k_solve_pcr(int m, int rows_wg, int L, const double *__restrict__ band,
   // ---- residual of the own rows:  w_i - (a_i x_{i-1} + b_i x_i + a_{i+1} x_{i+1})
   // (a_{i+1} of the row below: the level-0 sub-diagonal of the neighbouring lane, via LDS)
 #pragma unroll
-  for (int k = 0; k < PCR_NR; ++k) {
+  for (int k = 0; k < NR; ++k) {
     const int r = tid + k * IPX_BLOCK;
     if (r < R) pa[0][PAD + r] = a0[k];
   }
   ipx_lds_barrier();
   double acc = 0.0;
 #pragma unroll
-  for (int k = 0; k < PCR_NR; ++k) {
+  for (int k = 0; k < NR; ++k) {
     const int r = tid + k * IPX_BLOCK;
     const int64_t g = g0 + r;
     if (r >= H && r < H + rows_wg && g < m) {
@@ -1458,8 +1476,13 @@ int launch_solve_pcr_q(const LevDev &lv, int L, const double *w, double *x, doub
   const int rows_wg = DEC_CHUNKS * lv.q;
   const int grid = (lv.P + DEC_CHUNKS - 1) / DEC_CHUNKS;
   if (npartial) *npartial = grid;
-  hipLaunchKernelGGL((k_solve_pcr<QV>), dim3(grid), dim3(IPX_BLOCK), 0, st, lv.m, rows_wg, L,
-                     lv.band, w, x, partial, guard, atv);
+  // rows per lane: the window is rows_wg + 2^(L+1) rows
+  if (rows_wg + 2 * (1 << L) <= 2 * IPX_BLOCK)
+    hipLaunchKernelGGL((k_solve_pcr<QV, 2>), dim3(grid), dim3(IPX_BLOCK), 0, st, lv.m, rows_wg, L,
+                       lv.band, w, x, partial, guard, atv);
+  else
+    hipLaunchKernelGGL((k_solve_pcr<QV, PCR_NR>), dim3(grid), dim3(IPX_BLOCK), 0, st, lv.m,
+                       rows_wg, L, lv.band, w, x, partial, guard, atv);
   IPX_CHECK_LAUNCH();
   return IPX_OK;
 }
@@ -1471,7 +1494,8 @@ int launch_solve_pcr(const LevDev &lv, int L, const double *w, double *x, double
   if (!atv || qv <= 0)
     return launch_solve_pcr_q<0>(lv, L, w, x, partial, npartial, guard, none, st);
   // the tail's lanes are the whole workgroup here (256 instead of 192): fewer variables each
-  const int per = (qv * (DOWN_T - IPX_WAVE) + IPX_BLOCK - 1) / IPX_BLOCK;
+  // (+1: pairs start at an even variable, possibly one before the workgroup's first)
+  const int per = (qv * (DOWN_T - IPX_WAVE) + 1 + IPX_BLOCK - 1) / IPX_BLOCK;
   if (per <= 4) return launch_solve_pcr_q<4>(lv, L, w, x, partial, npartial, guard, *atv, st);
   if (per <= 8) return launch_solve_pcr_q<8>(lv, L, w, x, partial, npartial, guard, *atv, st);
   if (per <= 12) return launch_solve_pcr_q<12>(lv, L, w, x, partial, npartial, guard, *atv, st);

@@ -182,7 +182,8 @@ def fuse_vown(At_pattern, rows_per_wg, nwg):
 def ell_rows(At):
     """The rows of ``At`` (every one with at most two entries: checked by ``fuse_vown``) in
     ELL(2) form for the tail of the banded solve: ``(col, val)`` with entry t of row j at
-    ``[t * n + j]``.  The column table and the gather map are symbolic (cached on the
+    ``[t * n + j]`` (csrc/banded.hip reads pairs of rows with 16-byte loads: n must be even
+    -- asserted by the caller -- and the buffers 16-byte aligned, which torch's are).  The column table and the gather map are symbolic (cached on the
     pattern); the values are one gather per call."""
     pat = At.pattern
     cache = getattr(pat, "_ipx_ell2", None)
@@ -314,8 +315,9 @@ class _Loop:
                 if vown is not None:
                     self.vown = vown[0]
                     a.At_vown, a.At_qv = _ptr(self.vown), vown[1]
-                    self.ell_col, self.ell_val = ell_rows(At)
-                    a.At_ell_col, a.At_ell_val = _ptr(self.ell_col), _ptr(self.ell_val)
+                    if n % 2 == 0:      # pairs of variables per 16-byte load (csrc/banded.hip)
+                        self.ell_col, self.ell_val = ell_rows(At)
+                        a.At_ell_col, a.At_ell_val = _ptr(self.ell_col), _ptr(self.ell_val)
         self.args = a
 
     def ref(self):
