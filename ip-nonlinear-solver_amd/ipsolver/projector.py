@@ -408,6 +408,23 @@ def as_device_matrix(A):
     return DeviceDense.from_host(np.asarray(A, dtype=float))
 
 
+def normal_solver_for(A):
+    """The ``(A A')^-1`` solver ``projections`` picks for a full-row-rank device matrix."""
+    from .dense import DenseNormalSolver, DeviceDense
+    if isinstance(A, DeviceDense):
+        return DenseNormalSolver(A)
+    kmax = _hip.load().ipx_banded_kmax()
+    m = A.shape[0]
+    if _symbolic_for(A.pattern).k <= kmax:
+        return BandedNormalSolver(A)
+    if _box_schur_applies(A, kmax):
+        from .boxschur import BoxSchurNormalSolver
+        return BoxSchurNormalSolver(A)          # bound rows eliminated analytically
+    if m <= DenseNormalSolver.MAX_ROWS_FROM_SPARSE:
+        return DenseNormalSolver(A)             # wide band: dense Cholesky of A A'
+    return IterativeNormalSolver(A)             # general sparsity: matrix-free solve
+
+
 def projections(A, method=None, orth_tol=1e-12, max_refin=3, tol=1e-15):
     """Device counterpart of ``projections`` (projections.py:290-406).
 
@@ -439,22 +456,7 @@ def projections(A, method=None, orth_tol=1e-12, max_refin=3, tol=1e-15):
     if method == "SVDFactorization":
         return SVDProjector(A, orth_tol, max_refin, tol).operators()
     try:
-        if m == 0:
-            solver = None
-        elif sparse:
-            kmax = _hip.load().ipx_banded_kmax()
-            if _symbolic_for(A.pattern).k <= kmax:
-                solver = BandedNormalSolver(A)
-            elif _box_schur_applies(A, kmax):
-                from .boxschur import BoxSchurNormalSolver
-                solver = BoxSchurNormalSolver(A)    # bound rows eliminated analytically
-            elif m <= DenseNormalSolver.MAX_ROWS_FROM_SPARSE:
-                solver = DenseNormalSolver(A)       # wide band: dense Cholesky of A A'
-            else:
-                # general sparsity beyond both device factorizations: matrix-free solve
-                solver = IterativeNormalSolver(A)
-        else:
-            solver = DenseNormalSolver(A)
+        solver = None if m == 0 else normal_solver_for(A)
     except np.linalg.LinAlgError:
         # the reference's exits: projections.py:101-108 (sparse), :181-187 (dense)
         warn("Singular Jacobian matrix. Using dense SVD decomposition to perform the "

@@ -276,61 +276,204 @@ class HipOps:
         v = self.dv.DVec(A.val[int(ip[r0]):int(ip[r1])])
         return v.sumsq_amax()[0] if len(v) else 0.0
 
+    # -- barrier problems (z = [x; s])
+    def concat(self, parts):
+        return self.dv.hstack(parts)
+
+    def maximum(self, v, c):
+        from . import backend_hip
+        return backend_hip.maximum(v, c)
+
+    def where_positive(self, v, a, c):
+        from . import backend_hip
+        return backend_hip.where_positive(v, a, c)
+
+    def sum_log(self, s):
+        """(sum of log s_i over s_i > 0, number of s_i <= 0)"""
+        from . import _hip
+        if len(s) == 0:
+            return 0.0, 0.0
+        c = self.dv.ctx()
+        _hip.call("ipx_sum_log", len(s), self.dv._p(s.t), self.dv._p(c.out), self.dv._p(c.ws),
+                  self.dv.stream_ptr())
+        total, bad = self.dv.read_slots(2)
+        return total, bad
+
+    def augmented_box(self, J, s_nl, s_lb, s_ub):
+        """Local block of the barrier problem's augmented Jacobian for nonlinear inequality
+        rows + a box on every variable (tr_interior_point.py:141-194 on the canonical rows of
+        _canonical_constraint.py:350-355: nonlinear rows, all lower bounds, all upper bounds):
+
+            [ J   diag(s_nl)      0           0      ]
+            [ -I      0       diag(s_lb)      0      ]
+            [ +I      0           0       diag(s_ub) ]
+
+        on a pattern built once per Jacobian pattern; a refresh is four scatters."""
+        from . import _hip
+        dvm = self.dv
+        pat = J.pattern
+        cache = getattr(pat, "_ipx_aug_box", None)
+        mE, nX = pat.shape
+        if cache is None:
+            ip = pat.indptr_h.astype(np.int64)
+            cnt = np.diff(ip)
+            rows_nl = ip + np.arange(mE + 1)                       # one slack entry per row
+            nnz_nl = int(rows_nl[-1])
+            indptr = np.concatenate((rows_nl, nnz_nl + 2 * np.arange(1, 2 * nX + 1)))
+            nnz = int(indptr[-1])
+            indices = np.empty(nnz, dtype=np.int32)
+            template = np.zeros(nnz)
+            pos_J = (np.arange(pat.nnz) + np.repeat(np.arange(mE), cnt)).astype(np.int64)
+            indices[pos_J] = pat.indices_h
+            pos_snl = rows_nl[1:] - 1
+            indices[pos_snl] = nX + np.arange(mE)
+            base = nnz_nl + 2 * np.arange(nX)
+            indices[base], template[base] = np.arange(nX), -1.0            # -I
+            pos_slb = base + 1
+            indices[pos_slb] = nX + mE + np.arange(nX)
+            base2 = nnz_nl + 2 * nX + 2 * np.arange(nX)
+            indices[base2], template[base2] = np.arange(nX), 1.0           # +I
+            pos_sub = base2 + 1
+            indices[pos_sub] = nX + mE + nX + np.arange(nX)
+            apat = dvm.CSRPattern(indptr.astype(np.int32), indices, (mE + 2 * nX, nX + mE + 2 * nX))
+            dev = dvm.ctx().device
+            t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(dev)
+            cache = pat._ipx_aug_box = (apat, torch.from_numpy(template).to(dev), t(pos_J), t(pos_snl),
+                                        t(pos_slb), t(pos_sub))
+        apat, template, pos_J, pos_snl, pos_slb, pos_sub = cache
+        val = template.clone()
+        st = dvm.stream_ptr()
+        for src, idx in ((J.val, pos_J), (s_nl.t, pos_snl), (s_lb.t, pos_slb), (s_ub.t, pos_sub)):
+            if idx.numel():
+                _hip.call("ipx_scatter", idx.numel(), dvm._p(src), dvm._p(idx), dvm._p(val), st)
+        return dvm.DeviceCSR(apat, val)
+
+    def hessian_z(self, Hx, slack_block):
+        """[[Hx, 0], [0, diag(slack_block)]] for the local x-space operator ``Hx``."""
+        from . import backend_hip
+        from .operators import DeviceHessian
+        n_x = Hx.shape[0] if hasattr(Hx, "shape") else Hx.n
+        n_tot = n_x + len(slack_block)
+        csr = self.dv.DeviceCSR(backend_hip._extend_pattern(Hx.csr.pattern, n_tot), Hx.csr.val)
+        xdiag = Hx.diag if Hx.diag is not None else self.dv.DVec.zeros(n_x)
+        return DeviceHessian(n_tot, csr, self.dv.hstack((xdiag, slack_block)))
+
+    def any_normal_solver(self, A):
+        """(A A')^-1 for a local block of any supported structure: the selection of
+        ``projector.projections`` (banded, box rows eliminated analytically, dense)."""
+        from . import projector
+        return projector.normal_solver_for(A)
+
+
+class _Empty:
+    """A distributed vector of global length 0 (the slack / inequality-multiplier slices of a
+    problem without inequalities)."""
+    kind = None
+
+    def __len__(self):
+        return 0
+
 
 # --------------------------------------------------------------------------- context
+def _kinds(kind):
+    return (kind,) if isinstance(kind, str) else tuple(kind)
+
+
 class Sharding:
-    """Layout + communicator + local arithmetic of one sharded problem."""
+    """Layout + communicator + local arithmetic of one sharded problem.
+
+    A distributed vector lives in a SPACE: "col" (one entry per variable), "row" (one per
+    constraint row of the partitioned Jacobian) or a tuple of those -- the segments of a
+    stacked vector such as the barrier problem's z = [x; s_nl; s_lb; s_ub] = ("col", "row",
+    "col", "col").  Locally a vector is the concatenation of its segments' extended arrays
+    (own + halo entries each); globally the concatenation of the segments' global vectors."""
 
     def __init__(self, layout, comm, ops):
         self.lay, self.comm, self.ops = layout, comm, ops
+        self._segs = {}
+        self.spaces = {}                 # global length -> space (what xp.zeros(n) means)
+        if layout.n != layout.m:
+            self.spaces[layout.n], self.spaces[layout.m] = "col", "row"
+
+    def register(self, kind):
+        self.spaces[self.global_len(kind)] = kind if isinstance(kind, str) else tuple(kind)
+
+    def segments(self, kind):
+        """Per segment: (kind, local offset, local length, own_lo, own_hi, send_left,
+        send_right, global offset, global length)."""
+        key = _kinds(kind)
+        t = self._segs.get(key)
+        if t is None:
+            t, off, goff = [], 0, 0
+            for k in key:
+                _, ln, lo, hi = self.lay.geom(k)
+                sl, sr = self.lay.sends(k)
+                t.append((k, off, ln, lo, hi, sl, sr, goff, self.lay.global_len(k)))
+                off += ln
+                goff += self.lay.global_len(k)
+            self._segs[key] = t
+        return t
+
+    def local_len(self, kind):
+        return sum(seg[2] for seg in self.segments(kind))
+
+    def global_len(self, kind):
+        return sum(seg[8] for seg in self.segments(kind))
 
     # -- construction of distributed vectors
     def from_global(self, a, kind):
-        g0, ln, _, _ = self.lay.geom(kind)
         a = np.asarray(a, dtype=float)
-        assert a.shape == (self.lay.global_len(kind),), (a.shape, kind)
-        return ShardVec(self.ops.from_host(a[g0:g0 + ln]), self, kind)
+        assert a.shape == (self.global_len(kind),), (a.shape, kind)
+        parts = []
+        for k, _, ln, _, _, _, _, goff, _ in self.segments(kind):
+            g0 = self.lay.geom(k)[0]
+            parts.append(a[goff + g0:goff + g0 + ln])
+        return ShardVec(self.ops.from_host(np.concatenate(parts)), self, kind)
 
     def zeros(self, kind):
-        return ShardVec(self.ops.zeros(self.lay.geom(kind)[1]), self, kind)
+        return ShardVec(self.ops.zeros(self.local_len(kind)), self, kind)
 
     def full(self, kind, value):
-        return ShardVec(self.ops.full(self.lay.geom(kind)[1], value), self, kind)
+        return ShardVec(self.ops.full(self.local_len(kind), value), self, kind)
 
     def kind_of_len(self, k):
-        if k == self.lay.n and k != self.lay.m:
-            return "col"
-        if k == self.lay.m and k != self.lay.n:
-            return "row"
-        raise ValueError("cannot tell variables from constraints by length %d" % k)
+        if k in self.spaces:
+            return self.spaces[k]
+        raise ValueError("no distributed space of length %d is registered" % k)
 
     def sync(self, v):
         """Overwrite the halo entries of ``v`` with their owners' values."""
-        _, _, lo, hi = self.lay.geom(v.kind)
-        sl, sr = self.lay.sends(v.kind)
-        self.comm.exchange(self.ops.tensor(v.loc), lo, hi, sl, sr)
+        t = self.ops.tensor(v.loc)
+        for _, off, ln, lo, hi, sl, sr, _, _ in self.segments(v.kind):
+            self.comm.exchange(t[off:off + ln], lo, hi, sl, sr)
         return v
 
 
 class ShardVec:
-    """Distributed fp64 vector: the local extended array (own + halo entries) with the
-    arithmetic surface of ``device.DVec``; reductions run over the own entries and are
-    summed over the ranks."""
+    """Distributed fp64 vector: the local extended array (own + halo entries of every
+    segment) with the arithmetic surface of ``device.DVec``; reductions run over the own
+    entries and are summed over the ranks."""
     __slots__ = ("loc", "sh", "kind")
     __array_priority__ = 1000
 
     def __init__(self, loc, sh, kind):
-        self.loc, self.sh, self.kind = loc, sh, kind
+        self.loc, self.sh, self.kind = loc, sh, kind if isinstance(kind, str) else tuple(kind)
 
     def _new(self, loc):
         return ShardVec(loc, self.sh, self.kind)
 
+    def owns(self):
+        """The own part of every segment (views)."""
+        return [self.loc[off + lo:off + hi]
+                for _, off, _, lo, hi, _, _, _, _ in self.sh.segments(self.kind)]
+
     def own(self):
-        _, _, lo, hi = self.sh.lay.geom(self.kind)
-        return self.loc[lo:hi]
+        parts = self.owns()
+        assert len(parts) == 1
+        return parts[0]
 
     def __len__(self):
-        return self.sh.lay.global_len(self.kind)
+        return self.sh.global_len(self.kind)
 
     @property
     def shape(self):
@@ -345,26 +488,52 @@ class ShardVec:
     def full_like(self, value):
         return self.sh.full(self.kind, value)
 
+    def __getitem__(self, key):
+        """Slices along segment boundaries (``z[:n_vars]``, ``z[n_vars:]``): a VIEW on the
+        selected segments -- barrier.py writes the slacks through it
+        (tr_interior_point.py:62-63,92)."""
+        if not isinstance(key, slice) or key.step not in (None, 1):
+            raise TypeError("ShardVec supports slices along segment boundaries only")
+        n = len(self)
+        start, stop, _ = key.indices(n)
+        if stop <= start:
+            return _Empty()
+        segs = self.sh.segments(self.kind)
+        first = [i for i, sg in enumerate(segs) if sg[7] == start]
+        last = [i for i, sg in enumerate(segs) if sg[7] + sg[8] == stop]
+        if not first or not last:
+            raise NotImplementedError("slice [%d:%d] does not follow the segments of %r"
+                                      % (start, stop, self.kind))
+        i0, i1 = first[0], last[0]
+        kinds = tuple(sg[0] for sg in segs[i0:i1 + 1])
+        lo, hi = segs[i0][1], segs[i1][1] + segs[i1][2]
+        return ShardVec(self.loc[lo:hi], self.sh, kinds[0] if len(kinds) == 1 else kinds)
+
     def to_host(self):
         """The global vector on every rank (collective)."""
         sh = self.sh
-        own = np.ascontiguousarray(sh.ops.to_host(self.own()))
-        if sh.comm.world == 1:
-            return own
-        cuts = sh.lay.col_cuts if self.kind == "col" else sh.lay.row_cuts
-        sizes = np.diff(cuts)
-        pad = np.zeros(int(sizes.max()))
-        pad[:len(own)] = own
-        mine = torch.from_numpy(pad)
-        if sh.comm.backend == "nccl":
-            mine = mine.to(torch.device("cuda", torch.cuda.current_device()))
-        parts = [torch.empty_like(mine) for _ in range(sh.comm.world)]
-        dist.all_gather(parts, mine, group=sh.comm.group)
-        return np.concatenate([p.cpu().numpy()[:k] for p, k in zip(parts, sizes)])
+        out = []
+        for (k, off, _, lo, hi, _, _, _, _) in sh.segments(self.kind):
+            own = np.ascontiguousarray(sh.ops.to_host(self.loc[off + lo:off + hi]))
+            if sh.comm.world == 1:
+                out.append(own)
+                continue
+            cuts = sh.lay.col_cuts if k == "col" else sh.lay.row_cuts
+            sizes = np.diff(cuts)
+            pad = np.zeros(int(sizes.max()))
+            pad[:len(own)] = own
+            mine = torch.from_numpy(pad)
+            if sh.comm.backend == "nccl":
+                mine = mine.to(torch.device("cuda", torch.cuda.current_device()))
+            parts = [torch.empty_like(mine) for _ in range(sh.comm.world)]
+            dist.all_gather(parts, mine, group=sh.comm.group)
+            out.append(np.concatenate([p.cpu().numpy()[:kk] for p, kk in zip(parts, sizes)]))
+        return np.concatenate(out)
 
     # -- elementwise (own and halo alike: copies stay consistent)
     def _other(self, o):
-        assert isinstance(o, ShardVec) and o.kind == self.kind, "mismatched distributed vectors"
+        assert isinstance(o, ShardVec) and o.kind == self.kind, \
+            "mismatched distributed vectors: %r vs %r" % (self.kind, getattr(o, "kind", o))
         return o.loc
 
     def add_scaled(self, o, a):
@@ -392,13 +561,17 @@ class ShardVec:
 
     __rmul__ = __mul__
 
-    # -- reductions
+    # -- reductions (own entries of every segment, then over the ranks)
     def dot(self, o):
-        v = self.sh.ops.dot(self.own(), o.own())
+        ops = self.sh.ops
+        v = sum(ops.dot(a, b) for a, b in zip(self.owns(), o.owns()))
         return self.sh.comm.reduce_floats([v])[0]
 
     def sumsq_amax(self):
-        ss, am = self.sh.ops.sumsq_amax(self.own())
+        ss, am = 0.0, 0.0
+        for a in self.owns():
+            s1, a1 = self.sh.ops.sumsq_amax(a)
+            ss, am = ss + s1, max(am, a1)
         if self.sh.comm.world == 1:
             return [ss, am]
         return [self.sh.comm.reduce_floats([ss])[0], self.sh.comm.reduce_floats([am], "max")[0]]
@@ -407,35 +580,46 @@ class ShardVec:
         return self._new(self.sh.ops.clip(self.loc, lb.loc, ub.loc))
 
     def _count_outside_box(self, lb, ub):
-        v = self.sh.ops.count_outside_box(self.own(), lb.own(), ub.own())
+        v = sum(self.sh.ops.count_outside_box(a, l, u)
+                for a, l, u in zip(self.owns(), lb.owns(), ub.owns()))
         return self.sh.comm.reduce_floats([v])[0]
 
     def _box_sphere_reduce(self, d, dscale, lb, ub):
-        """The 7 quantities of device.box_sphere_reduce over the ranks: d.d, z.d, z.z and the
-        count of zero-direction coordinates outside the box are sums, ta = max over ranks,
-        tb = min (qp_subproblem.py:215-216)."""
-        r = self.sh.ops.box_sphere_reduce(self.own(), d.own(), dscale,
-                                          lb.own() if lb is not None else None,
-                                          ub.own() if ub is not None else None)
+        """The 7 quantities of device.box_sphere_reduce over the segments and the ranks: d.d,
+        z.d, z.z and the count of zero-direction coordinates outside the box are sums,
+        ta = max, tb = min (qp_subproblem.py:215-216)."""
+        tot = [0.0, 0.0, 0.0, -np.inf, np.inf, 0.0, 0.0]
+        lbs = lb.owns() if lb is not None else [None] * len(self.owns())
+        ubs = ub.owns() if ub is not None else [None] * len(self.owns())
+        for z, dd, l, u in zip(self.owns(), d.owns(), lbs, ubs):
+            if len(z) == 0:
+                continue
+            r = self.sh.ops.box_sphere_reduce(z, dd, dscale, l, u)
+            for i in (0, 1, 2, 5, 6):
+                tot[i] += r[i]
+            tot[3], tot[4] = max(tot[3], r[3]), min(tot[4], r[4])
         c = self.sh.comm
         if c.world == 1:
-            return list(r)
-        s = c.reduce_floats([r[0], r[1], r[2], r[5], r[6]])
-        ta = c.reduce_floats([r[3]], "max")[0]
-        tb = c.reduce_floats([r[4]], "min")[0]
+            return tot
+        s = c.reduce_floats([tot[0], tot[1], tot[2], tot[5], tot[6]])
+        ta = c.reduce_floats([tot[3]], "max")[0]
+        tb = c.reduce_floats([tot[4]], "min")[0]
         return [s[0], s[1], s[2], ta, tb, s[3], s[4]]
 
 
 # --------------------------------------------------------------------------- operators
 class ShardCSR:
-    """Row block ``A[E, X]`` of a sparse matrix whose rows follow the constraint partition
-    (the Jacobian): ``dot`` maps variables to constraints (exact on every local row),
-    ``T.dot`` constraints to variables (own entries exact, halo synchronised)."""
+    """A sparse matrix whose rows follow a distributed space and whose columns another (the
+    Jacobian: rows = constraints, columns = variables; the barrier problem's augmented
+    Jacobian: rows = inequality rows, columns = z).  The local block holds COMPLETE rows over
+    the rank's extended column range, so ``dot`` is exact on every local row; ``T.dot`` is
+    exact on the own entries, its halo is synchronised."""
 
-    def __init__(self, sh, local, transposed=False, other=None):
+    def __init__(self, sh, local, transposed=False, other=None, row_kind="row", col_kind="col"):
         self.sh, self.local, self.transposed = sh, local, transposed
         self._T = other
-        m, n = sh.lay.m, sh.lay.n
+        self.row_kind, self.col_kind = row_kind, col_kind
+        m, n = sh.global_len(row_kind), sh.global_len(col_kind)
         self.shape = (n, m) if transposed else (m, n)
 
     @staticmethod
@@ -450,36 +634,39 @@ class ShardCSR:
     @property
     def T(self):
         if self._T is None:
-            self._T = ShardCSR(self.sh, self.local, not self.transposed, self)
+            self._T = ShardCSR(self.sh, self.local, not self.transposed, self, self.row_kind,
+                               self.col_kind)
         return self._T
 
     def with_values(self, data):
         """Same pattern, new local values (value refresh of a Jacobian)."""
-        return ShardCSR(self.sh, self.sh.ops.refresh(self.local, data))
+        return ShardCSR(self.sh, self.sh.ops.refresh(self.local, data), row_kind=self.row_kind,
+                        col_kind=self.col_kind)
 
     def dot(self, x):
         sh = self.sh
         if not self.transposed:
-            assert x.kind == "col"
-            return ShardVec(self.local.dot(x.loc), sh, "row")
-        assert x.kind == "row"
-        return sh.sync(ShardVec(sh.ops.rmatvec(self.local, x.loc), sh, "col"))
+            assert x.kind == self.col_kind, (x.kind, self.col_kind)
+            return ShardVec(self.local.dot(x.loc), sh, self.row_kind)
+        assert x.kind == self.row_kind, (x.kind, self.row_kind)
+        return sh.sync(ShardVec(sh.ops.rmatvec(self.local, x.loc), sh, self.col_kind))
 
     matvec = dot
 
     def frobenius_norm(self):
-        _, _, lo, hi = self.sh.lay.geom("row")
-        return float(np.sqrt(self.sh.comm.reduce_floats(
-            [self.sh.ops.frob_sq_rows(self.local, lo, hi)])[0]))
+        ops, tot, r0 = self.sh.ops, 0.0, 0
+        for _, off, ln, lo, hi, _, _, _, _ in self.sh.segments(self.row_kind):
+            tot += ops.frob_sq_rows(self.local, off + lo, off + hi)
+        return float(np.sqrt(self.sh.comm.reduce_floats([tot])[0]))
 
 
 class ShardHessian:
     """Rows ``H[X, X]`` of a banded Hessian (+ optional diagonal term) on a rank's variables:
     exact on the own entries, halo synchronised."""
 
-    def __init__(self, sh, local):
-        self.sh, self.local = sh, local
-        self.shape = (sh.lay.n, sh.lay.n)
+    def __init__(self, sh, local, kind="col"):
+        self.sh, self.local, self.kind = sh, local, kind
+        self.shape = (sh.global_len(kind),) * 2
 
     @staticmethod
     def from_global(sh, H, hdiag=None):
@@ -493,8 +680,8 @@ class ShardHessian:
         return ShardHessian(sh, sh.ops.hessian(ln, csr, diag))
 
     def dot(self, p):
-        assert p.kind == "col"
-        return self.sh.sync(ShardVec(self.local.dot(p.loc), self.sh, "col"))
+        assert p.kind == self.kind, (p.kind, self.kind)
+        return self.sh.sync(ShardVec(self.local.dot(p.loc), self.sh, self.kind))
 
     matvec = dot
 
@@ -517,14 +704,16 @@ class ShardProjector:
     def __init__(self, A, orth_tol=1e-12, max_refin=3):
         self.A, self.sh = A, A.sh
         self.orth_tol, self.max_refin = orth_tol, max_refin
-        self.solver = self.sh.ops.normal_solver(A.local)
+        plain = A.row_kind == "row" and A.col_kind == "col"
+        self.solver = (self.sh.ops.normal_solver(A.local) if plain
+                       else self.sh.ops.any_normal_solver(A.local))
         self.norm_A = A.frobenius_norm()
         self.stats = {"solves": 0, "refinements": 0}
-        self.fused_sharded = bool(getattr(self.sh.ops, "fused", False))
+        self.fused_sharded = bool(getattr(self.sh.ops, "fused", False)) and plain
 
     def _apply_inv(self, w):
         self.stats["solves"] += 1
-        return self.sh.sync(ShardVec(self.solver.solve(w.loc), self.sh, "row"))
+        return self.sh.sync(ShardVec(self.solver.solve(w.loc), self.sh, self.A.row_kind))
 
     def orthogonality(self, z):
         norm_z = np.sqrt(z.sumsq_amax()[0])
@@ -837,30 +1026,21 @@ def _refine_sharded(F):
 
 
 # --------------------------------------------------------------------------- outer loops
-class _Empty:
-    """A distributed vector of global length 0 (the slack / inequality-multiplier slices of a
-    problem without inequalities)."""
-    kind = None
+class _DiagOp:
+    def __init__(self, d):
+        self.d = d
 
-    def __len__(self):
-        return 0
-
-
-def _slice(self, key):
-    """``z[:n]`` / ``z[n:n]``: the whole vector or nothing -- what barrier.py asks of z = [x; s]
-    when there are no slacks."""
-    if not isinstance(key, slice) or key.step not in (None, 1):
-        raise TypeError("ShardVec supports whole / empty slices only")
-    n = len(self)
-    start, stop, _ = key.indices(n)
-    if start == 0 and stop == n:
-        return self
-    if stop <= start:
-        return _Empty()
-    raise NotImplementedError("partial slices of a distributed vector")
+    def dot(self, x):
+        return self.d * x
 
 
-ShardVec.__getitem__ = _slice
+class BoxInequalityJacobian:
+    """Jacobian of the canonical inequality rows ``[c_nl(x); lb - x; x - ub] <= 0``
+    (_canonical_constraint.py:169-360: the nonlinear rows, then all lower bounds, then all
+    upper bounds): the distributed nonlinear block; the box blocks -I / +I stay symbolic."""
+
+    def __init__(self, J_nl):
+        self.J_nl = J_nl
 
 
 class ShardedBackend:
@@ -868,8 +1048,11 @@ class ShardedBackend:
     against (cf. backend_hip), for one sharded problem: every vector is a ``ShardVec``, the
     Jacobian a ``ShardCSR``, the Hessian a ``ShardHessian``; scalars (norms, dot products)
     are all-reduced.  Equality-constrained problems (BASELINE configs 3 / 4: both outer
-    methods); inequality constraints need the slack rows sharded too and are refused."""
+    methods) and nonlinear inequalities + a box on every variable (config 5: barrier method,
+    z = [x; s_nl; s_lb; s_ub] with every segment partitioned like the space it belongs to)."""
     name = "sharded"
+    INEQ = ("row", "col", "col")
+    Z = ("col", "row", "col", "col")
 
     def __init__(self, sh):
         self.sh = sh
@@ -894,9 +1077,10 @@ class ShardedBackend:
 
     def hstack(self, parts):
         parts = [p for p in parts if len(p)]
-        if len(parts) != 1:
-            raise NotImplementedError("sharded backend: stacked vectors (inequality constraints)")
-        return parts[0]
+        if len(parts) == 1:
+            return parts[0]
+        kinds = sum((_kinds(p.kind) for p in parts), ())
+        return ShardVec(self.sh.ops.concat([p.loc for p in parts]), self.sh, kinds)
 
     def norm(self, v):
         return float(np.sqrt(v.sumsq_amax()[0])) if len(v) else 0.0
@@ -907,10 +1091,29 @@ class ShardedBackend:
     def dot(self, a, b):
         return a.dot(b)
 
+    def maximum(self, v, c):
+        return v._new(self.sh.ops.maximum(v.loc, c))
+
+    def where_positive(self, v, a, c):
+        return v._new(self.sh.ops.where_positive(v.loc, a.loc, c))
+
     def sum_log(self, s):
-        if len(s):
-            raise NotImplementedError("sharded backend: slack variables")
-        return 0.0
+        """sum(log s_i), -inf when any s_i <= 0 (tr_interior_point.py:93-95)."""
+        if not len(s):
+            return 0.0
+        tot, bad = 0.0, 0.0
+        for part in s.owns():
+            t, b = self.sh.ops.sum_log(part)
+            tot, bad = tot + t, bad + b
+        tot, bad = self.sh.comm.reduce_floats([tot, bad])
+        return -np.inf if bad > 0 else tot
+
+    def assign_negated_where(self, s, mask, c):
+        if np.asarray(mask).any():
+            raise NotImplementedError("sharded backend: enforce_feasibility")
+
+    def diagonal_operator(self, d):
+        return _DiagOp(d)
 
     def matrix(self, J, key=None):
         return J
@@ -918,11 +1121,25 @@ class ShardedBackend:
     def mark_constant(self, A):
         return A
 
+    def augmented_jacobian(self, J_eq, J_ineq, s, n_vars, n_eq, n_ineq):
+        """[[J_eq, 0], [J_ineq, diag(s)]] (tr_interior_point.py:141-194) as a distributed
+        matrix from the inequality rows' space to z-space."""
+        if n_eq or not isinstance(J_ineq, BoxInequalityJacobian):
+            raise NotImplementedError("sharded backend: inequality rows must come from "
+                                      "BoxInequalityJacobian (no equality rows next to them)")
+        sh = self.sh
+        segs = sh.segments(self.INEQ)
+        parts = [s.loc[off:off + ln] for _, off, ln, *_ in segs]
+        local = sh.ops.augmented_box(J_ineq.J_nl.local, *parts)
+        return ShardCSR(sh, local, row_kind=self.INEQ, col_kind=self.Z)
+
     def hessian_operator(self, terms, n_vars, slack_block):
-        if slack_block is not None or not isinstance(terms, ShardHessian):
+        if not isinstance(terms, ShardHessian):
             raise NotImplementedError("sharded backend: the Lagrangian Hessian callback must "
                                       "return a ShardHessian")
-        return terms
+        if slack_block is None:
+            return terms
+        return ShardHessian(self.sh, self.sh.ops.hessian_z(terms.local, slack_block.loc), self.Z)
 
     def projections(self, A, method=None):
         return projections(A, method)
@@ -976,5 +1193,52 @@ def minimize_equality_constrained(sh, fun, grad, lagr_hess, constr, jac, x0, met
             _Empty(), None, c0, J0, stop_criteria, None, xtol, state, xp, **options)
     result.execution_time = time.time() - start
     result.method = method
+    result.message = TERMINATION_MESSAGES[result.status]
+    return result
+
+
+def minimize_box_inequality(sh, fun, grad, lagr_hess, constr_nl, jac_nl, x0, lb, ub, xtol=1e-8,
+                            gtol=1e-8, max_iter=1000, callback=None, **options):
+    """``minimize_constrained(..., constraints=(NonlinearConstraint(c, ('less', 0)),
+    BoxConstraint(('interval', lb, ub))))`` on distributed data -- BASELINE config 5: the
+    barrier method ``barrier.tr_interior_point`` (reference tr_interior_point.py:254-355) over
+    the sharded backend, with the canonical inequality rows ``[c_nl(x); lb - x; x - ub]`` and
+    their slacks partitioned like the rows / variables they belong to.  Callbacks:
+
+        fun(x) -> float      grad(x) -> ShardVec      constr_nl(x) -> ShardVec (rows)
+        jac_nl(x) -> ShardCSR      lagr_hess(x, v_nl) -> ShardHessian   (v_nl: row multipliers)
+    """
+    import time
+    from scipy.optimize import OptimizeResult
+    from .barrier import tr_interior_point
+    from .minimize import TERMINATION_MESSAGES, _make_stop_criteria
+    xp = ShardedBackend(sh)
+    n, m = sh.lay.n, sh.lay.m
+    n_ineq = m + 2 * n
+    sh.register(xp.INEQ)
+    sh.register(xp.Z)
+    state = OptimizeResult(niter=0, nfev=1, ngev=1, ncev=1, njev=1, nhev=0, cg_niter=0,
+                           cg_info={})
+    stop_criteria = _make_stop_criteria('tr_interior_point', gtol, xtol, max_iter, 1e-8, callback,
+                                        0, lambda s: s)
+
+    def constr(x):
+        return xp.hstack((constr_nl(x), lb - x, x - ub)), _Empty()
+
+    def jac(x):
+        return BoxInequalityJacobian(jac_nl(x)), None
+
+    def hess(x, v_eq, v_ineq):
+        return lagr_hess(x, v_ineq[:m])            # box rows have no curvature
+
+    f0, g0 = fun(x0), grad(x0)
+    c0, _ = constr(x0)
+    J0, _ = jac(x0)
+    start = time.time()
+    result = tr_interior_point(fun, grad, hess, n, n_ineq, 0, constr, jac, x0, f0, g0, c0, J0,
+                               _Empty(), None, stop_criteria, np.zeros(n_ineq, dtype=bool), xtol,
+                               state, xp, **options)
+    result.execution_time = time.time() - start
+    result.method = 'tr_interior_point'
     result.message = TERMINATION_MESSAGES[result.status]
     return result

@@ -116,3 +116,36 @@ class NumpyOps:
         ip = A.M.indptr
         d = A.M.data[ip[r0]:ip[r1]]
         return float(d.dot(d))
+
+    # -- barrier problems (z = [x; s])
+    def concat(self, parts):
+        return np.concatenate(parts)
+
+    def maximum(self, v, c):
+        return np.maximum(v, c)
+
+    def where_positive(self, v, a, c):
+        return np.where(v > 0, a, c)
+
+    def sum_log(self, s):
+        pos = s > 0
+        return float(np.sum(np.log(s[pos]))), float(np.count_nonzero(~pos))
+
+    def augmented_box(self, J, s_nl, s_lb, s_ub):                  # tr_interior_point.py:141-194
+        mE, nX = J.M.shape
+        I = sps.identity(nX, format="csr")
+        return _LocalCSR(sps.bmat([[J.M, sps.diags(s_nl), None, None],
+                                   [-I, None, sps.diags(s_lb), None],
+                                   [I, None, None, sps.diags(s_ub)]], format="csr"))
+
+    def hessian_z(self, Hx, slack_block):
+        class _Z:
+            def __init__(self, Hx, sb):
+                self.Hx, self.sb, self.nx = Hx, sb, Hx.H.shape[0]
+
+            def dot(self, p):
+                return np.concatenate((self.Hx.dot(p[:self.nx]), self.sb * p[self.nx:]))
+        return _Z(Hx, slack_block)
+
+    def any_normal_solver(self, A):
+        return _LocalSolver(A)

@@ -21,6 +21,7 @@ Outputs (numbers only -- no reference source travels):
                     orth_tol=1e-18, max_refin 100 / 10) and rank-deficient Jacobians
                     (SVD fallback, projections.py:101-108,181-187,236-287)
   e2e_n20000.json   (``--n20000``) banded equality NLP at n=20000 / m=2000, both methods
+  e2e_ineq_n12000.json  (``--ineq12000``: 4 minutes) box + inequality NLP at n=12000 / m=1200
   config2.json      (``--big`` only: minutes) dense equality QP of BASELINE config 2 at
                     n=4000/m=800 and n=10000/m=2000: scalar traces + strided x
 """
@@ -355,6 +356,15 @@ def main():
                                prob.constraints(ref), method=method)
         with open(os.path.join(HERE, "e2e_n20000.json"), "w") as f:
             json.dump(out, f)
+        return
+    if "--ineq12000" in sys.argv:
+        # config-5 style (box + nonlinear inequalities) at a size the row-sharded solver can
+        # split; 225 s with the reference
+        prob = synthetic.CenteredBandedNLP(12000, 1200, eps=1.0)
+        cons = (prob.constraints(ref, ("less", 0.0)), ref.BoxConstraint(("interval", -0.8, 0.8)))
+        rec = run_e2e("banded_ineq_n12000", prob.fun, prob.x0, prob.grad, prob.hess, cons)
+        with open(os.path.join(HERE, "e2e_ineq_n12000.json"), "w") as f:
+            json.dump({"banded_ineq_n12000": rec}, f)
         return
     if "--big" in sys.argv:
         out = {}

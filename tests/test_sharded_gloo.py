@@ -159,6 +159,66 @@ def test_sharded_full_solve_matches_reference(world, method, tmp_path):
     close(got["x"][::max(1, N // 50)], gx, 1e-9)
 
 
+def _barrier_worker(rank, world, port, out_path):
+    _setup(rank, world, port)
+    try:
+        from banded_setup import load_synthetic
+        from ipsolver import sharded
+        from ipsolver.synthetic import ShardedCallbacks
+        from oracle.numpy_local import NumpyOps
+        n, m = 12000, 1200
+        prob = load_synthetic().CenteredBandedNLP(n, m, eps=1.0)
+        A = prob.A0.tocsr()
+        lay = sharded.ShardLayout(A.indptr, A.indices, A.shape, world, rank)
+        sh = sharded.Sharding(lay, sharded.ShardComm(), NumpyOps())
+        cb = ShardedCallbacks(prob, sh)
+        rows = []
+
+        def record(state):
+            rows.append([int(state.niter), int(state.cg_niter), float(state.trust_radius),
+                         float(state.penalty), float(state.barrier_parameter),
+                         float(state.optimality), float(state.constr_violation),
+                         int(state.nfev)])
+            return len(rows) >= 24          # the comparable prefix of the trace (see the test)
+        res = sharded.minimize_box_inequality(
+            sh, cb.fun, cb.grad, cb.lagr_hess, cb.constr_fun, cb.constr_jac, cb.x0,
+            sh.full("col", -0.8), sh.full("col", 0.8), callback=record)
+        x, s = res.x.to_host(), res.s.to_host()
+        if rank == 0:
+            np.savez(out_path, x=x, s=s, rows=np.array(rows), status=res.status)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_barrier_box_inequality_matches_reference(tmp_path):
+    """BASELINE config 5 in small (n = 12000 variables with a box on each, 1200 nonlinear
+    inequalities: z-space 37200, 25200 inequality rows): the barrier method over the sharded
+    backend, two ranks, against the trace of the REFERENCE on the same seeded problem
+    (tests/golden/e2e_ineq_n12000.json; the reference needs 225 s for its 64 outer / 26090 CG
+    iterations).  Thousands of CG iterations amplify last-bit differences until an accept /
+    reject branch flips after ~20 outer iterations (every implementation, the single-GPU one
+    too: tests/test_gpu_e2e.py), so the first 16 outer iterations are compared: iteration
+    counters exact, floats to 1e-6."""
+    import json
+    from conftest import unjson
+    path = str(tmp_path / "barrier.npz")
+    mp.spawn(_barrier_worker, args=(2, _free_port(), path), nprocs=2, join=True)
+    got = np.load(path)
+    with open(os.path.join(ROOT, "tests", "golden", "e2e_ineq_n12000.json")) as f:
+        gold = json.load(f)["banded_ineq_n12000"]
+    want = np.array(unjson(gold["trace"]), dtype=float)
+    rows = got["rows"]
+    k = 16
+    assert len(rows) >= k and int(got["status"]) == 3          # stopped by the callback
+    for col in (0, 1, 7):
+        assert np.array_equal(rows[:k, col], want[:k, col]), col
+    for col in (2, 3, 4, 5, 6):
+        assert np.allclose(rows[:k, col], want[:k, col], rtol=1e-6, atol=1e-12), col
+    # slacks interior, box respected along the way
+    assert got["s"].min() > 0 and np.all(np.abs(got["x"]) < 0.8)
+    assert got["s"].shape == (1200 + 2 * 12000,)
+
+
 @pytest.fixture(scope="module")
 def runs(tmp_path_factory):
     """One spawn per world size; every test below reads its outputs."""
