@@ -321,3 +321,72 @@ def test_sharded_full_solve_hip(method, tmp_path):
     gx = np.asarray(unjson(gold["x"]))
     x = got["x"][::max(1, 20000 // 50)]
     assert np.max(np.abs(x - gx)) <= 1e-9 * np.max(np.abs(gx))
+
+
+def _sharded_barrier_worker(rank, world, port, out_path):
+    import os
+    import sys
+    import torch
+    import torch.distributed as dist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "ip-nonlinear-solver_amd"), os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ipsolver import sharded
+        from ipsolver.synthetic import CenteredBandedNLP, ShardedCallbacks
+        n, m = 12000, 1200
+        prob = CenteredBandedNLP(n, m, eps=1.0)
+        A = prob.A0.tocsr()
+        lay = sharded.ShardLayout(A.indptr, A.indices, A.shape, world, rank)
+        sh = sharded.Sharding(lay, sharded.ShardComm(), sharded.HipOps())
+        cb = ShardedCallbacks(prob, sh)
+        rows = []
+
+        def record(state):
+            rows.append([int(state.niter), int(state.cg_niter), float(state.trust_radius),
+                         float(state.penalty), float(state.barrier_parameter),
+                         float(state.optimality), float(state.constr_violation),
+                         int(state.nfev)])
+            return len(rows) >= 18
+        res = sharded.minimize_box_inequality(
+            sh, cb.fun, cb.grad, cb.lagr_hess, cb.constr_fun, cb.constr_jac, cb.x0,
+            sh.full("col", -0.8), sh.full("col", 0.8), callback=record)
+        x, s = res.x.to_host(), res.s.to_host()
+        solver = type(res.jac).__name__
+        if rank == 0:
+            np.savez(out_path, x=x, s=s, rows=np.array(rows), status=res.status)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_barrier_box_inequality_hip(tmp_path):
+    """BASELINE config 5 in small on the sharded backend with the HIP kernels (two ranks share
+    cuda:0 over gloo): distributed z = [x; s_nl; s_lb; s_ub], the local augmented Jacobians
+    factored by the box-Schur solver, against the REFERENCE's trace
+    (tests/golden/e2e_ineq_n12000.json) over the comparable prefix (16 outer iterations)."""
+    import json
+    import os
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    path = str(tmp_path / "barrier.npz")
+    mp.spawn(_sharded_barrier_worker, args=(2, port, path), nprocs=2, join=True)
+    got = np.load(path)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "tests", "golden", "e2e_ineq_n12000.json")) as f:
+        gold = json.load(f)["banded_ineq_n12000"]
+    want = np.array(unjson(gold["trace"]), dtype=float)
+    rows = got["rows"]
+    k = 16
+    assert len(rows) >= k and int(got["status"]) == 3
+    for col in (0, 1, 7):
+        assert np.array_equal(rows[:k, col], want[:k, col]), col
+    for col in (2, 3, 4, 5, 6):
+        assert np.allclose(rows[:k, col], want[:k, col], rtol=1e-6, atol=1e-12), col
+    assert got["s"].min() > 0 and np.all(np.abs(got["x"]) < 0.8)
