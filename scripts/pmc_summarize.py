@@ -11,6 +11,8 @@ and the gfx950 read under-count (MI355X_MICROARCH.md, HBM section) in the same r
 import collections, csv, glob, json, os, sys
 
 fetch_dir, write_dir, out = sys.argv[1:4]
+size_note = sys.argv[4] if len(sys.argv) > 4 else "n=1e6, m=1e5"
+commit = sys.argv[5] if len(sys.argv) > 5 else "?"
 
 
 def per_kernel(d, counter):
@@ -48,7 +50,8 @@ names = {"spmv_A_r": ("k_csr_spmv<false, false, false>",),
          "spmv_H_p": ("k_csr_spmv<true, false, true>",),
          "step1": ("k_cg_step1(",), "step2": ("k_cg_step2(",),
          "step1_spmv_A_r": ("k_cg_step1_ar",), "step2_spmv_H_p": ("k_cg_step2_hp",),
-         "banded_solve_with_residual": ("k_solve_decoupled",)}
+         "banded_solve_with_residual": ("k_solve_decoupled",),
+         "banded_solve_pcr": ("k_solve_pcr",)}
 for label, keys in names.items():
     if not any(all(s_ in k for s_ in keys) for k in fetch):
         continue                      # kernel not in this build's loop (fused / unfused)
@@ -60,8 +63,9 @@ for label, keys in names.items():
                       "hbm_read_bytes": f_kb * 1024 * rf, "hbm_write_bytes": w_kb * 1024,
                       "hbm_bytes_per_launch": f_kb * 1024 * rf + w_kb * 1024}
 json.dump({"source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over "
-                     "scripts/pmc_workload.py (40 CG iterations, n=1e6, m=1e5), MI355X; "
-                     "summarised by scripts/pmc_summarize.py",
+                     "scripts/pmc_workload.py (40 CG iterations, %s), MI355X; "
+                     "summarised by scripts/pmc_summarize.py" % size_note,
+           "source_commit": commit,
            "correction": "FETCH_SIZE under-reports streaming reads 2x on gfx950 "
                          "(MI355X_MICROARCH.md section HBM); calibrated here on kernels with known "
                          "byte counts: read_factor below; WRITE_SIZE is exact",

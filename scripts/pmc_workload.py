@@ -1,6 +1,6 @@
 """Workload for the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE):
 calibration kernels with known byte counts, then 40 iterations of the fused
-CG loop at n=1e6, m=1e5."""
+CG loop at n (default 1e6), m = n/10."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "ip-nonlinear-solver_amd"))
@@ -18,7 +18,8 @@ for _ in range(10):
 for _ in range(10):
     lib.ipx_axpby(nc, 1.5, dv._p(a), 0.5, dv._p(b), dv._p(o), st)
 torch.cuda.synchronize()
-n, m = 1000000, 100000
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
+m = n // 10
 prob = CenteredBandedNLP(n, m)
 x = prob.x0
 v = 0.1 * np.random.default_rng(7).standard_normal(m)
