@@ -32,7 +32,7 @@ sys.path.insert(0, os.path.join(ROOT, "ip-nonlinear-solver_amd"))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PMC_PROFILE = "r01i_pmc_traffic.json"      # see roofline.traffic_source
+PMC_PROFILE = "r02_pmc_traffic_n1e6.json"      # see roofline.traffic_source
 
 
 def spmv_bytes(nnz, rows, cols, extra_row_vectors=0):
@@ -513,8 +513,17 @@ def main():
         vb = 0.1 * np.random.default_rng(7).standard_normal(mb)
         rb = single_gpu_measure(probb.constr_jac(xb), probb.hess(xb), probb.kappa * probb.Wt.dot(vb),
                                 probb.grad(xb), nb, mb, K, W, repeats=args.repeats)
+        traffic_b, src_b = None, None
+        pmc_b = os.path.join(ROOT, "profiles", "r02_pmc_traffic_n4e6.json")
+        if os.path.exists(pmc_b):
+            with open(pmc_b) as f:
+                pj = json.load(f)
+            traffic_b = pj["kernels"].get(rb["dom"], {}).get("hbm_bytes_per_launch")
+            src_b = ("STORED, not measured in this run: profiles/r02_pmc_traffic_n4e6.json "
+                     "(rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes), kernels at "
+                     "commit %s" % pj.get("source_commit", "?"))
         result["roofline_out_of_cache"] = dict(
-            rb["roofline"], traffic=None, n=nb, m=mb,
+            rb["roofline"], traffic=traffic_b, traffic_source=src_b, n=nb, m=mb,
             iterations_per_s=K / rb["elapsed"], ms_per_step=1e3 * rb["elapsed"] / K,
             repeat=rb["repeat"], per_kernel_us=rb["per_kernel_us"],
             whole_iteration=rb["whole_iteration"])
