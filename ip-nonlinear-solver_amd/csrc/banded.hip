@@ -57,7 +57,6 @@ struct Banded {
   int nslab_lds;              // = nslab when the slab is staged in LDS, else 0
   // parallel cyclic reduction (k = 1): scratch for the factor-time level check, per-level
   // flags (device), and the level at which the reduced system is numerically diagonal
-  double *pcr_buf;            // 2 x 3m doubles (a, b, c ping-pong)
   int *pcr_flags;             // PCR_LMAX + 1 ints: bit 0 of [s] = level s still coupled
   int pcr_L;                  // 0: PCR solve not usable
   std::vector<void *> allocs;
@@ -1246,45 +1245,11 @@ k_solve_decoupled(LevDev lv, const double *__restrict__ w, double *__restrict__ 
 //     b_i <- b_i + alpha c_{i-h} + gamma a_{i+h},  d_i <- d_i + alpha d_{i-h} + gamma d_{i+h},
 // all rows at once out of LDS (ping-pong buffers, one LDS barrier per level).  Because the
 // inverse of S decays geometrically, after L levels (L <= 7, found at every factorization by
-// running the reduction on the matrix alone, k_pcr_check_level) the remaining couplings are
+// running the reduction on the matrix alone, k_pcr_check) the remaining couplings are
 // below 2^-56 of the diagonal: x_i = d_i / b_i, and a window of the own rows plus 2^L rows on
 // either side gives the own rows exactly -- the same decay the chunk decoupling relies on.
 // No factor tables are read at all (the band is 2 doubles per row); same rows per workgroup
 // as k_solve_decoupled (DEC_CHUNKS * q), so the residual / A'v tail bookkeeping is unchanged.
-__global__ void __launch_bounds__(IPX_BLOCK)
-k_pcr_check_level(int m, int h, const double *__restrict__ in, double *__restrict__ out,
-                  int *flags, int level) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= m) return;
-  const double *ia = in, *ib = in + m, *ic = in + 2 * (int64_t)m;
-  const double a = ia[i], b = ib[i], c = ic[i];
-  double al = 0.0, ga = 0.0, an = 0.0, cn = 0.0, bn = b;
-  if (i - h >= 0) {
-    al = -a / ib[i - h];
-    an = al * ia[i - h];
-    bn = __builtin_fma(al, ic[i - h], bn);
-  }
-  if (i + h < m) {
-    ga = -c / ib[i + h];
-    cn = ga * ic[i + h];
-    bn = __builtin_fma(ga, ia[i + h], bn);
-  }
-  out[i] = an; out[m + i] = bn; out[2 * (int64_t)m + i] = cn;
-  const double tiny = 1.3877787807814457e-17;                     // 2^-56
-  if (!(fmax(fabs(an), fabs(cn)) <= tiny * bn)) atomicOr(flags + level, 1);
-  if (!(bn > 0.0)) atomicOr(flags + level, 2);
-}
-
-__global__ void __launch_bounds__(IPX_BLOCK)
-k_pcr_init(int m, const double *__restrict__ band, double *__restrict__ out, int *flags) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < PCR_LMAX + 1) flags[i] = 0;
-  if (i >= m) return;
-  out[i] = i >= 1 ? band[(int64_t)m + i] : 0.0;                   // a_i = S[i][i-1]
-  out[m + i] = band[i];
-  out[2 * (int64_t)m + i] = i + 1 < m ? band[(int64_t)m + i + 1] : 0.0;
-}
-
 typedef double v2d __attribute__((ext_vector_type(2)));
 constexpr int PCR_RMAX = 4 * 66 + 2 * (1 << PCR_LMAX) + 8;        // window rows (q <= 66)
 constexpr int PCR_NR = (PCR_RMAX + IPX_BLOCK - 1) / IPX_BLOCK;    // rows per lane
@@ -1298,6 +1263,65 @@ constexpr int PCR_NR = (PCR_RMAX + IPX_BLOCK - 1) / IPX_BLOCK;    // rows per la
 __device__ __forceinline__ double pcr_rcp(double b) {
   double r = __builtin_amdgcn_rcp(b);
   return __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);      // one Newton step: full precision
+}
+
+// Factor-time check in ONE launch: the reduction of the matrix alone (no right-hand side) on
+// the same windows as the solve, all PCR_LMAX levels; a workgroup tests its own rows after
+// every level: flags[s] bit 0 = a coupling at distance 2^s is still above 2^-56 of the
+// diagonal, bit 1 = a reduced diagonal entry is not positive.
+__global__ void __launch_bounds__(IPX_BLOCK)
+k_pcr_check(int m, int rows_wg, const double *__restrict__ band, int *flags) {
+  constexpr int PAD = 1 << PCR_LMAX;
+  constexpr int RS = PCR_RMAX + 2 * PAD;
+  __shared__ double pa[2][RS], pr[2][RS];
+  const int H = 1 << PCR_LMAX;
+  const int R = rows_wg + 2 * H;
+  const int64_t g0 = (int64_t)blockIdx.x * rows_wg - H;
+  const int tid = threadIdx.x;
+  double a[PCR_NR], b[PCR_NR];
+  bool own[PCR_NR];
+#pragma unroll
+  for (int k = 0; k < PCR_NR; ++k) {
+    const int r = tid + k * IPX_BLOCK;
+    const int64_t g = g0 + r;
+    const bool in = r < R && g >= 0 && g < m;
+    const int64_t gc = min(max(g, (int64_t)0), (int64_t)m - 1);
+    const double bv = band[gc], av = band[(int64_t)m + gc];
+    a[k] = (in && g >= 1 && r >= 1) ? av : 0.0;
+    b[k] = in ? bv : 1.0;
+    own[k] = in && r >= H && r < H + rows_wg;
+  }
+  for (int i = tid; i < 2 * PAD; i += IPX_BLOCK) {
+    const int r = i < PAD ? i : R + i;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { pa[u][r] = 0.0; pr[u][r] = 1.0; }
+  }
+  const double tiny = 1.3877787807814457e-17;                     // 2^-56
+  for (int s = 0; s < PCR_LMAX; ++s) {
+    const int h = 1 << s, cur = s & 1;
+#pragma unroll
+    for (int k = 0; k < PCR_NR; ++k) {
+      const int r = tid + k * IPX_BLOCK;
+      if (r < R) { pa[cur][PAD + r] = a[k]; pr[cur][PAD + r] = pcr_rcp(b[k]); }
+    }
+    ipx_lds_barrier();
+    int bits = 0;
+#pragma unroll
+    for (int k = 0; k < PCR_NR; ++k) {
+      const int r = PAD + min(tid + k * IPX_BLOCK, R - 1);
+      const double alo = pa[cur][r - h], rlo = pr[cur][r - h];
+      const double ahi = pa[cur][r + h], rhi = pr[cur][r + h];
+      const double al = -a[k] * rlo, ga = -ahi * rhi;
+      double bn = __builtin_fma(al, a[k], b[k]);
+      bn = __builtin_fma(ga, ahi, bn);
+      a[k] = al * alo; b[k] = bn;
+      if (own[k]) {
+        if (!(fabs(a[k]) <= tiny * bn)) bits |= 1;
+        if (!(bn > 0.0)) bits |= 2;
+      }
+    }
+    if (bits) atomicOr(flags + s + 1, bits);
+  }
 }
 
 template <int QV, int NR>
@@ -1726,7 +1750,6 @@ void *ipx_banded_create(int64_t m64, int32_t k, int32_t chunk) {
   h->gL = h->gR = h->slab = h->ybuf = h->rinv = nullptr;
   h->decoupled = false;
   h->fast = false;
-  h->pcr_buf = nullptr;
   h->pcr_flags = nullptr;
   h->pcr_L = 0;
   int m = (int)m64, kk = k;
@@ -1789,9 +1812,7 @@ void *ipx_banded_create(int64_t m64, int32_t k, int32_t chunk) {
   h->flag = dalloc<int>(h, 2 + PCR_LMAX);
   if (ok && h->flag && h->lev[0].k == 1 && h->nlev >= 2 &&
       DEC_CHUNKS * h->lev[0].q + 2 * (1 << PCR_LMAX) <= PCR_RMAX) {
-    h->pcr_buf = dalloc<double>(h, (size_t)6 * h->lev[0].m);
     h->pcr_flags = h->flag + 1;
-    if (!h->pcr_buf) ok = false;
   }
   if (ok) {
     const Level &l0 = h->lev[0];
@@ -1847,16 +1868,13 @@ int ipx_banded_factor(void *handle, const double *band, void *stream) {
   if (rc != IPX_OK) return rc;
   h->upper_done = false;
   h->pcr_L = 0;
-  if (decoupling_candidate(h) && h->pcr_buf) {
+  if (decoupling_candidate(h) && h->pcr_flags) {
     // the cyclic reduction of the matrix alone: at which level has it decoupled?
-    const int m0 = h->lev[0].m;
-    const dim3 grid((max(m0, PCR_LMAX + 1) + IPX_BLOCK - 1) / IPX_BLOCK), block(IPX_BLOCK);
-    double *b0 = h->pcr_buf, *b1 = h->pcr_buf + (size_t)3 * m0;
-    hipLaunchKernelGGL(k_pcr_init, grid, block, 0, st, m0, band, b0, h->pcr_flags);
-    for (int s = 0; s < PCR_LMAX; ++s) {
-      hipLaunchKernelGGL(k_pcr_check_level, grid, block, 0, st, m0, 1 << s, (s & 1) ? b1 : b0,
-                         (s & 1) ? b0 : b1, h->pcr_flags, s + 1);
-    }
+    const Level &l0 = h->lev[0];
+    if (hipMemsetAsync(h->pcr_flags, 0, (PCR_LMAX + 1) * sizeof(int), st) != hipSuccess)
+      return IPX_ELAUNCH;
+    hipLaunchKernelGGL(k_pcr_check, dim3((l0.P + DEC_CHUNKS - 1) / DEC_CHUNKS), dim3(IPX_BLOCK), 0,
+                       st, l0.m, DEC_CHUNKS * l0.q, band, h->pcr_flags);
     IPX_CHECK_LAUNCH();
   }
   if (decoupling_candidate(h)) {
