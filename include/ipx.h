@@ -255,6 +255,24 @@ int ipx_cg_step1(int64_t n, double *state, int32_t it, const double *p1, int32_t
 int ipx_cg_step2(int64_t n, double *state, int32_t it, int32_t mode, const double *p2,
                  int32_t np2, const double *p3, int32_t np3, const double *p4, int32_t np4,
                  double *x, double *p, const double *g, int32_t grid, void *stream);
+/* ---- matrix-free (A A')^-1 w: Jacobi-preconditioned CG on A (A' v) = w, device resident
+ * (csrc/pcg.hip; replaces the sparse LU of projections.py:93-172 for Jacobians beyond both
+ * device factorizations).  State block (doubles): [0],[1] r'z by iteration parity, [2],[3]
+ * smallest ||r||, [4],[5] stall counter, [6] done (0 running, 1 converged, 2 fp64 floor,
+ * 3 not positive definite), [7] iterations, [8] ||w||, [9] rtol, [10] last ||r||. */
+typedef struct ipx_pcg_args {
+  int64_t m, n;
+  const int32_t *A_rowptr, *A_colidx; const double *A_val; const int32_t *A_tiles; int64_t A_ntiles;
+  const int32_t *At_rowptr, *At_colidx; const double *At_val; const int32_t *At_tiles; int64_t At_ntiles;
+  const double *dinv;       /* 1 / diag(A A') */
+  double *v, *r, *p, *Sp;   /* m-vectors */
+  double *t;                /* n-vector: A' p */
+  double *state;            /* ipx_pcg_state_size() doubles */
+  double *part1, *part2;    /* 2 * A_ntiles and 2 * grid doubles */
+  int64_t grid;             /* ipx_cg_vec_grid(m) */
+} ipx_pcg_args;
+int ipx_pcg_state_size(void);
+int ipx_pcg_iterate(const ipx_pcg_args *a, int32_t it_begin, int32_t it_end, void *stream);
 /* ---- partitioned row-sharded loop (ipsolver/sharded.py FusedShardedCG; replaces the
  * per-iteration body of qp_subproblem.py:549-634 on one rank of a node).  `a` describes the
  * rank's extended local problem (own rows / variables + halo copies); the scalars travel

@@ -1,0 +1,148 @@
+// Matrix-free (A A')^-1 w for sparse Jacobians whose A A' is neither banded nor small enough
+// for the dense Cholesky: Jacobi-preconditioned conjugate gradients on A (A' v) = w, entirely
+// on the device (ipsolver/projector.py IterativeNormalSolver; the reference factors any sparse
+// A with SuperLU, projections.py:93-172).  One call enqueues a batch of iterations:
+//
+//   t  = A' p                                   (CSR SpMV)
+//   Sp = A t, partials of p'Sp                  (CSR SpMV, fused epilogue)
+//   k_pcg_update     alpha = rz / p'Sp;  v += alpha p;  r -= alpha Sp;  partials of ||r||^2, r'z
+//   k_pcg_direction  convergence / stall tests;  beta = rz_next / rz;  p = D^-1 r + beta p
+//
+// The scalars never leave the device: every kernel's prologue folds its predecessor's partial
+// sums in a fixed order (all workgroups derive the same bits), workgroup 0 records the
+// decision in the state block, and a non-zero `done` turns the rest of the batch into no-ops;
+// the host reads the state once per batch.  State words that one kernel both reads and
+// updates are double buffered by iteration parity.
+#include "ipx_common.h"
+
+enum {
+  PS_RZ0 = 0, PS_RZ1 = 1,        // r'z by parity
+  PS_BEST0 = 2, PS_BEST1 = 3,    // smallest ||r|| so far
+  PS_STALL0 = 4, PS_STALL1 = 5,  // consecutive iterations without improvement
+  PS_DONE = 6,                   // 0 running, 1 converged, 2 fp64 floor reached, 3 not positive definite
+  PS_ITERS = 7, PS_NORM_W = 8, PS_RTOL = 9, PS_NORM_R = 10,
+  PS_SIZE = 16
+};
+
+namespace {
+
+constexpr int PB = IPX_BLOCK;
+constexpr int PU = 4;
+
+__global__ void __launch_bounds__(PB)
+k_pcg_update(int64_t m, double *st, int parity, const double *__restrict__ p1, int np1,
+             double *v, double *r, const double *__restrict__ p, const double *__restrict__ Sp,
+             const double *__restrict__ dinv, double *__restrict__ p2, int nchunks) {
+  __shared__ double lds[2 * (PB / IPX_WAVE)];
+  const int c = ipx_xcd_item(blockIdx.x, nchunks);
+  if (c < 0) return;
+  if (st[PS_DONE] != 0.0) return;
+  const double rz = st[parity ? PS_RZ1 : PS_RZ0];
+  const double pSp = ipx_sum_partials<IPX_SUM>(p1 + np1, np1, lds);     // second half: x.y sums
+  const bool lead = c == 0 && threadIdx.x == 0;
+  if (!(pSp > 0.0)) {                       // A A' not positive definite: rank-deficient A
+    if (lead) st[PS_DONE] = 3.0;
+    return;
+  }
+  const double alpha = rz / pSp;
+  const int64_t len = (m + nchunks - 1) / nchunks;
+  const int64_t lo = (int64_t)c * len, hi = min(m, lo + len);
+  double srr = 0.0, srz = 0.0;
+  for (int64_t i0 = lo + threadIdx.x; i0 < hi; i0 += (int64_t)PU * PB) {
+    double vv[PU], rv[PU], pv[PU], sv[PU], dv[PU];
+#pragma unroll
+    for (int u = 0; u < PU; ++u) {
+      const int64_t i = min(i0 + (int64_t)u * PB, m - 1);
+      vv[u] = v[i]; rv[u] = r[i]; pv[u] = p[i]; sv[u] = Sp[i]; dv[u] = dinv[i];
+    }
+#pragma unroll
+    for (int u = 0; u < PU; ++u) {
+      const int64_t i = i0 + (int64_t)u * PB;
+      if (i < hi) {
+        const double rn = rv[u] - alpha * sv[u];
+        v[i] = vv[u] + alpha * pv[u];
+        r[i] = rn;
+        srr += rn * rn;
+        srz += rn * (dv[u] * rn);
+      }
+    }
+  }
+  double red[2] = {srr, srz}, out[2];
+  ipx_block_sum_multi<2>(red, lds, out);
+  if (threadIdx.x == 0) { p2[c] = out[0]; p2[nchunks + c] = out[1]; }
+}
+
+__global__ void __launch_bounds__(PB)
+k_pcg_direction(int64_t m, double *st, int parity, const double *__restrict__ p2, int np2,
+                const double *__restrict__ r, double *p, const double *__restrict__ dinv,
+                int nchunks) {
+  __shared__ double lds[2 * (PB / IPX_WAVE)];
+  const int c = ipx_xcd_item(blockIdx.x, nchunks);
+  if (c < 0) return;
+  if (st[PS_DONE] != 0.0) return;
+  const double rz = st[parity ? PS_RZ1 : PS_RZ0];
+  const double best = st[parity ? PS_BEST1 : PS_BEST0];
+  const double stall = st[parity ? PS_STALL1 : PS_STALL0];
+  const double norm_w = st[PS_NORM_W], rtol = st[PS_RTOL];
+  const double *const parts[2] = {p2, p2 + np2};
+  const int counts[2] = {np2, np2};
+  double red[2];
+  ipx_sum_partials_multi<2>(parts, counts, lds, red);
+  const double nr = sqrt(red[0]), rz_next = red[1];
+  const bool lead = c == 0 && threadIdx.x == 0;
+  const double stall_next = nr >= best ? stall + 1.0 : 0.0;
+  int done = 0;
+  if (nr <= rtol * norm_w) done = 1;
+  else if (stall_next >= 5.0) done = 2;              // the floor of fp64 has been reached
+  if (lead) {
+    st[PS_ITERS] += 1.0;
+    st[PS_NORM_R] = nr;
+    st[parity ? PS_RZ0 : PS_RZ1] = rz_next;
+    st[parity ? PS_BEST0 : PS_BEST1] = fmin(best, nr);
+    st[parity ? PS_STALL0 : PS_STALL1] = stall_next;
+    if (done) st[PS_DONE] = (double)done;
+  }
+  if (done) return;
+  const double beta = rz_next / rz;
+  const int64_t len = (m + nchunks - 1) / nchunks;
+  const int64_t lo = (int64_t)c * len, hi = min(m, lo + len);
+  for (int64_t i = lo + threadIdx.x; i < hi; i += PB) p[i] = dinv[i] * r[i] + beta * p[i];
+}
+
+}  // namespace
+
+extern "C" {
+
+int ipx_pcg_state_size(void) { return PS_SIZE; }
+
+// Enqueue iterations [it_begin, it_end) of the preconditioned CG on A A' v = w.  The caller
+// has set v = 0, r = w, p = D^-1 r and the state block (PS_RZ0 = r'D^-1 r, PS_BEST0 = inf,
+// PS_NORM_W, PS_RTOL).  part1 needs 2 * A_ntiles doubles, part2 2 * grid (grid =
+// ipx_cg_vec_grid(m)).  Never synchronises.
+int ipx_pcg_iterate(const ipx_pcg_args *a, int32_t it_begin, int32_t it_end, void *stream) {
+  if (!a || it_end < it_begin || !a->state || !a->part1 || !a->part2 || a->grid < 1)
+    return IPX_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const double *guard = a->state + PS_DONE;
+  ipx_csr_view A{(int)a->m, (int)a->n, a->A_rowptr, a->A_colidx, a->A_val, a->A_tiles,
+                 (int)a->A_ntiles};
+  ipx_csr_view At{(int)a->n, (int)a->m, a->At_rowptr, a->At_colidx, a->At_val, a->At_tiles,
+                  (int)a->At_ntiles};
+  const int grid = (int)a->grid;
+  for (int it = it_begin; it < it_end; ++it) {
+    int rc = ipx_spmv_launch(At, a->p, 1.0, nullptr, 0.0, nullptr, a->t, nullptr, guard, st);
+    if (rc) return rc;
+    rc = ipx_spmv_launch(A, a->t, 1.0, nullptr, 0.0, nullptr, a->Sp, a->part1, guard, st, a->p);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_pcg_update, dim3(ipx_xcd_grid(grid)), dim3(PB), 0, st, a->m, a->state,
+                       it & 1, a->part1, (int)a->A_ntiles, a->v, a->r, a->p, a->Sp, a->dinv,
+                       a->part2, grid);
+    IPX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_pcg_direction, dim3(ipx_xcd_grid(grid)), dim3(PB), 0, st, a->m, a->state,
+                       it & 1, a->part2, grid, a->r, a->p, a->dinv, grid);
+    IPX_CHECK_LAUNCH();
+  }
+  return IPX_OK;
+}
+
+}  // extern "C"

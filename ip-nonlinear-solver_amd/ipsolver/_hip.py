@@ -65,6 +65,8 @@ _SIGNATURES = {
     "ipx_banded_solve_resid": [_P, _P, _P, _P, _P, _P, _P],
     "ipx_banded_decoupled_geometry": [_P, _P],
     "ipx_cg_step2_hp": [_P, _I32, _I32, _P],
+    "ipx_pcg_state_size": [],
+    "ipx_pcg_iterate": [_P, _I32, _I32, _P],
     "ipx_cg_shard2_segment": [_P, _P, _I32, _I32, _I32, _P],
     "ipx_cg_shard2_fold_hp": [_P, _P, _P],
     "ipx_aat_band": [_I64, _I32, _P, _P, _P, _P, _P, _P],

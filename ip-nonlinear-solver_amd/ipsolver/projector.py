@@ -335,60 +335,92 @@ def _box_schur_applies(A, kmax):
     return _symbolic_for(cache.pattern).k <= kmax
 
 
+class PcgArgs(ctypes.Structure):
+    """Mirror of ipx_pcg_args (include/ipx.h)."""
+    _P, _I = ctypes.c_void_p, ctypes.c_int64
+    _fields_ = [("m", _I), ("n", _I),
+                ("A_rowptr", _P), ("A_colidx", _P), ("A_val", _P), ("A_tiles", _P), ("A_ntiles", _I),
+                ("At_rowptr", _P), ("At_colidx", _P), ("At_val", _P), ("At_tiles", _P),
+                ("At_ntiles", _I), ("dinv", _P), ("v", _P), ("r", _P), ("p", _P), ("Sp", _P),
+                ("t", _P), ("state", _P), ("part1", _P), ("part2", _P), ("grid", _I)]
+
+
 class IterativeNormalSolver:
     """``(A A')^-1`` without a factorization, for sparse Jacobians whose ``A A'`` is neither
     banded (after reordering) nor small enough for the dense device Cholesky: Jacobi-
-    preconditioned conjugate gradients on ``A (A' v) = w`` -- two SpMVs and a few vector
-    kernels per inner iteration, everything on the device.  The reference factors any
-    sparse A with SuperLU (projections.py:93-172); this keeps such problems solvable here
-    (at the speed of an iterative solve) instead of refusing them.  The inner solve runs to
-    the floor of fp64; the projector's orthogonality-driven refinement
-    (projections.py:72-78) sits on top of it as usual."""
+    preconditioned conjugate gradients on ``A (A' v) = w``, device resident (csrc/pcg.hip):
+    one C call enqueues a batch of iterations, convergence and stall tests are taken on the
+    device, the host reads one state block per batch.  The reference factors any sparse A
+    with SuperLU (projections.py:93-172); this keeps such problems solvable here (at the
+    speed of an iterative solve) instead of refusing them.  The inner solve runs to the
+    floor of fp64; the projector's orthogonality-driven refinement (projections.py:72-78)
+    sits on top of it as usual."""
 
     perm = None
     RTOL, MAXIT = 1e-15, 2000
+    PS_RZ0, PS_BEST0, PS_DONE, PS_ITERS, PS_NORM_W, PS_RTOL = 0, 2, 6, 7, 8, 9
 
     def __init__(self, A):
+        lib = _hip.load()
         self.A, self.At = A, A.T
-        self.m = A.shape[0]
+        self.m, n = A.shape
         sq = DVec(A.val) * DVec(A.val)
-        rowsq = DeviceCSR(A.pattern, sq.t).dot(DVec.full(A.shape[1], 1.0))
+        rowsq = DeviceCSR(A.pattern, sq.t).dot(DVec.full(n, 1.0))
         d = rowsq.to_host()
         if not np.all(d > 0):
             raise np.linalg.LinAlgError("Singular Jacobian matrix: a row of A is zero")
         self.dinv = DVec.from_host(1.0 / d)
+        dev, m = ctx().device, self.m
+        z = lambda k: torch.zeros(int(k), dtype=_F64, device=dev)
+        self.r, self.p, self.Sp, self.t = z(m), z(m), z(m), z(n)
+        self.state = z(lib.ipx_pcg_state_size())
+        self.grid = int(lib.ipx_cg_vec_grid(max(m, 1)))
+        self.part1, self.part2 = z(2 * A.pattern.ntiles), z(2 * self.grid)
+        a = self.args = PcgArgs()
+        a.m, a.n = m, n
+        for pre, M in (("A", A), ("At", self.At)):
+            pat = M.pattern
+            setattr(a, pre + "_rowptr", pat.indptr.data_ptr())
+            setattr(a, pre + "_colidx", pat.indices.data_ptr())
+            setattr(a, pre + "_val", M.val.data_ptr())
+            setattr(a, pre + "_tiles", pat.tiles.data_ptr())
+            setattr(a, pre + "_ntiles", pat.ntiles)
+        a.dinv = self.dinv.t.data_ptr()
+        a.r, a.p, a.Sp, a.t = (t.data_ptr() for t in (self.r, self.p, self.Sp, self.t))
+        a.state, a.part1, a.part2 = (t.data_ptr() for t in (self.state, self.part1, self.part2))
+        a.grid = self.grid
+        self.stats = {"solves": 0, "iterations": 0, "batches": 0}
 
     def solve(self, w):
+        lib = _hip.load()
         v = DVec.zeros(self.m)
-        r = w.copy()
         norm_w = dv.norm(w)
         if norm_w == 0:
             return v
-        z = self.dinv * r
-        p = z.copy()
-        rz = r.dot(z)
-        best = np.inf
-        stalled = 0
-        for _ in range(self.MAXIT):
-            Sp = self.A.dot(self.At.dot(p))
-            pSp = p.dot(Sp)
-            if not pSp > 0:
-                raise np.linalg.LinAlgError("Singular Jacobian matrix: A A' is not positive "
-                                            "definite")
-            alpha = rz / pSp
-            v = v.add_scaled(p, alpha)
-            r = r.add_scaled(Sp, -alpha)
-            nr = dv.norm(r)
-            if nr <= self.RTOL * norm_w:
+        self.r.copy_(w.t)
+        z0 = self.dinv * w
+        self.p.copy_(z0.t)
+        init = np.zeros(self.state.numel())
+        init[self.PS_RZ0] = w.dot(z0)
+        init[self.PS_BEST0] = np.inf
+        init[self.PS_NORM_W], init[self.PS_RTOL] = norm_w, self.RTOL
+        self.state.copy_(torch.from_numpy(init))
+        self.args.v = v.t.data_ptr()
+        it, batch = 0, 8
+        while it < self.MAXIT:
+            end = min(self.MAXIT, it + batch)
+            _hip.check(lib.ipx_pcg_iterate(ctypes.byref(self.args), it, end, stream_ptr()),
+                       "ipx_pcg_iterate")
+            s = self.state.tolist()               # one blocking read per batch
+            self.stats["batches"] += 1
+            if s[self.PS_DONE] != 0:
+                if s[self.PS_DONE] == 3:
+                    raise np.linalg.LinAlgError("Singular Jacobian matrix: A A' is not positive "
+                                                "definite")
                 break
-            stalled = stalled + 1 if nr >= best else 0      # fp64 floor reached
-            best = min(best, nr)
-            if stalled >= 5:
-                break
-            z = self.dinv * r
-            rz_next = r.dot(z)
-            p = z.add_scaled(p, rz_next / rz)
-            rz = rz_next
+            it, batch = end, min(2 * batch, 64)
+        self.stats["solves"] += 1
+        self.stats["iterations"] += int(s[self.PS_ITERS])
         return v
 
 

@@ -848,3 +848,37 @@ def test_banded_solve_by_parallel_cyclic_reduction(ips, n, m):
     v2 = torch.empty_like(v)
     _hip.call("ipx_banded_solve", h, ips.dv._p(wd.t), ips.dv._p(v2), ips.dv.stream_ptr())
     assert np.max(np.abs(v2.cpu().numpy() - got)) <= 1e-13 * np.max(np.abs(got))
+
+
+def test_iterative_normal_solver_on_the_device(ips):
+    """m = 20000 rows (more than the dense device Cholesky takes) with A A' of half bandwidth 11
+    (more than the banded solver takes): the projections run on the device-resident
+    preconditioned CG (csrc/pcg.hip) -- one C call per batch of inner iterations, convergence
+    decided on the device -- and must be the reference's operators, here against the oracle."""
+    import oracle
+    from ipsolver.projector import IterativeNormalSolver
+    rng = np.random.default_rng(1)
+    m = 20000
+    n = 2 * m + 24
+    cols = (2 * np.arange(m)[:, None] + np.arange(24)[None, :]).ravel()
+    A = sps.csr_matrix((rng.standard_normal(24 * m), (np.repeat(np.arange(m), 24), cols)),
+                       shape=(m, n))
+    Z, LS, Y = ips.proj.projections(ips.dv.DeviceCSR.from_scipy(A))
+    solver = Z.projector.solver
+    assert isinstance(solver, IterativeNormalSolver)
+    Zo, LSo, Yo = oracle.projections(A)
+    x, b = rng.standard_normal(n), rng.standard_normal(m)
+    close(Z.dot(x), Zo.dot(x), 1e-9)
+    close(LS.dot(x), LSo.dot(x), 1e-9)
+    close(Y.dot(b), Yo.dot(b), 1e-9)
+    # several inner iterations per host read-back: the loop is device resident
+    assert solver.stats["solves"] >= 3
+    assert solver.stats["iterations"] >= 4 * solver.stats["batches"]
+    zx = Z.dot(x)
+    norm_A = float(np.sqrt((A.data ** 2).sum()))
+    assert ips.dv.norm(ips.dv.DeviceCSR.from_scipy(A).dot(zx)) <= 1e-12 * norm_A * ips.dv.norm(zx)
+    # a zero row is a rank-deficient Jacobian: reported, not iterated on
+    A0 = A.tolil()
+    A0[5, :] = 0
+    with pytest.raises(np.linalg.LinAlgError):
+        IterativeNormalSolver(ips.dv.DeviceCSR.from_scipy(sps.csr_matrix(A0)))
