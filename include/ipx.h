@@ -232,6 +232,14 @@ typedef struct ipx_cg_args {
    * the variable alone, so the tail's loads need no row-pointer round trip.  NULL: CSR. */
   const int32_t *At_ell_col;
   const double *At_ell_val;
+  /* 3 x H_ntiles doubles of scratch, or NULL.  With both fused kernels in use the trust-region
+   * test's ||x + alpha p||^2 is then formed as xx + 2 alpha xp + alpha^2 pp from per-tile sums
+   * of x'x, x'p, p'p that the step2 + H.p kernel leaves here (step1 + A.r no longer reads x
+   * and p).  The caller seeds entries [0], [H_ntiles], [2 H_ntiles] with x'x, x'p, p'p of the
+   * primed / resumed state (rest zero).  Measured (bench.py, MI355X): +2.4 % it/s at n=1e6,
+   * +5.4 % at n=4e6, the step2 + H.p kernel itself 7 % slower; the host binding leaves it off
+   * unless IPX_RECUR=1 (the direct sum is what the reference computes). */
+  double *part5;
 } ipx_cg_args;
 int ipx_cg_state_size(void);
 int ipx_cg_vec_grid(int64_t n);

@@ -43,6 +43,7 @@ enum {
   ST_TOL = 2, ST_RADIUS = 3, ST_ALPHA = 4, ST_STOP = 5, ST_NITER = 6, ST_BETA = 7,
   ST_PTHP = 8, ST_ORTH_RHS = 9,   // orth_tol * ||A||_F  (0 disables the check)
   ST_XNORM2 = 10, ST_VIOL = 11, ST_ORTH = 12, ST_IT_DONE = 13,
+  ST_XN2R = 14,                   // ||x + alpha p||^2 by recurrence (see k_cg_step1_ar<.., RECUR>)
   ST_SIZE = 16
 };
 
@@ -238,11 +239,15 @@ k_cg_step2_hp(int n, double *st, int parity, int mode, const double *__restrict_
               const double *__restrict__ val, const int32_t *__restrict__ tiles, int ntiles,
               const double *__restrict__ diag, double *__restrict__ Hp,
               double *__restrict__ partial, int hmax, const double *__restrict__ pb_in,
-              double *__restrict__ pb_out) {
+              double *__restrict__ pb_out, double *__restrict__ part5) {
+  // part5 (optional, 3 x ntiles): per-tile sums of x_next'x_next, x_next'p_next, p_next'p_next,
+  // from which the next iteration gets ||x + alpha p||^2 = xx + 2 alpha xp + alpha^2 pp without
+  // reading x and p again (mode bit 2: this launch takes its own ||x + alpha p||^2 that way,
+  // from the state block, instead of folding p2)
   __shared__ double prod[FT_NNZ];
   __shared__ double span[QS * IPX_BLOCK];
   __shared__ int rp[Q * IPX_BLOCK + 1];
-  __shared__ double lds[4 * (IPX_BLOCK / IPX_WAVE)];
+  __shared__ double lds[5 * (IPX_BLOCK / IPX_WAVE)];
   CG_STAMP(0);
   const int tile = ipx_xcd_item(blockIdx.x, ntiles);
   if (tile < 0) return;
@@ -255,7 +260,8 @@ k_cg_step2_hp(int n, double *st, int parity, int mode, const double *__restrict_
   // ||x + alpha p||^2 partials -- one per row tile of A when step1 is fused -- get the
   // freed register instead
   const double *const partsA[2] = {BOX ? p2 + np2 : p2, p4};
-  const int countsA[2] = {(mode & 1) ? 0 : np2, (mode & 2) ? 0 : np4};
+  const int countsA[2] = {(mode & 5) ? 0 : np2, (mode & 2) ? 0 : np4};
+  const double xn2_rec = st[ST_XN2R];
   const double *const partsB[1] = {p3};
   const int countsB[1] = {np3};
   const double *const partsC[1] = {BOX ? p2 : p2 + np2};     // BOX: xn2;  else unused (count 0)
@@ -316,7 +322,7 @@ k_cg_step2_hp(int n, double *st, int parity, int mode, const double *__restrict_
   }
   ipx_block_sum_multi<4>(loc, lds, red);
   if (!(mode & 1)) {
-    const double xn2 = red[0], viol = red[1];
+    const double xn2 = (mode & 4) ? xn2_rec : red[0], viol = red[1];
     if (sqrt(xn2) >= radius) {                       // :583
       if (lead) { st[ST_XNORM2] = xn2; st[ST_STOP] = 2.0; }
       return;
@@ -404,18 +410,43 @@ k_cg_step2_hp(int n, double *st, int parity, int mode, const double *__restrict_
     }
   }
   CG_STAMP(6);
-  const double a2 = ipx_block_reduce<IPX_SUM>(acc_yy, lds);
-  const double b2 = ipx_block_reduce<IPX_SUM>(acc_xy, lds);
-  if (tid == 0) { partial[tile] = a2; partial[ntiles + tile] = b2; }
+  {
+    double red2[2] = {acc_yy, acc_xy}, out2[2];
+    ipx_block_sum_multi<2>(red2, lds, out2);
+    if (tid == 0) { partial[tile] = out2[0]; partial[ntiles + tile] = out2[1]; }
+  }
 #pragma unroll
   for (int q = 0; q < Q; ++q) {
     const int i = tid + q * IPX_BLOCK;
     if (i < nrows) Hp[r0 + i] = yq[q];
   }
+  // x_next = x + alpha p on the own rows (x was requested before the SpMV phases and has
+  // landed), with the sums the next iteration's trust-region test is formed from (p_next of
+  // the same element is in the span)
+  double axx = 0.0, axp = 0.0, app = 0.0;
 #pragma unroll
   for (int k = 0; k < QS; ++k) {
-    const int col = c_lo + tid + k * IPX_BLOCK;
-    if (col >= r0 && col < r1) x[col] = sx[k] + alpha * sp[k];   // :580,630
+    const int j = tid + k * IPX_BLOCK;
+    const int col = c_lo + j;
+    if (col >= r0 && col < r1) {
+      const double xn = sx[k] + alpha * sp[k];       // :580,630
+      x[col] = xn;
+      if (part5) {
+        const double pn = span[j];
+        axx += xn * xn;
+        axp += xn * pn;
+        app += pn * pn;
+      }
+    }
+  }
+  if (part5) {
+    double red3[3] = {axx, axp, app}, out3[3];
+    ipx_block_sum_multi<3>(red3, lds, out3);
+    if (tid == 0) {
+      part5[tile] = out3[0];
+      part5[ntiles + tile] = out3[1];
+      part5[2 * ntiles + tile] = out3[2];
+    }
   }
   CG_STAMP(7);
 }
@@ -432,7 +463,13 @@ k_cg_step2_hp(int n, double *st, int parity, int mode, const double *__restrict_
 // r, so outside the iteration nothing changes.  Same expressions in the same
 // order as k_cg_step1 + k_csr_spmv; the ||x + alpha p||^2 partials are per tile
 // instead of per vector chunk (same values up to the order of summation).
-template <int QS, int TN>
+// RECUR: ||x + alpha p||^2 is not summed here (x and p are not read at all: 16 of the 67 MB
+// this kernel moves at n = 1e6) but formed as xx + 2 alpha xp + alpha^2 pp from the three sums
+// the previous step2 + H.p launch left in part5 -- by ONE extra workgroup of this grid (item
+// `ntiles`), which leaves it in the state block for the coming step2.  Algebraically the same
+// number; it differs from the direct sum by rounding, and only feeds the comparison with the
+// trust radius (:583) -- on an exit the boundary point is computed from fresh reductions.
+template <int QS, int TN, bool RECUR>
 __global__ void __launch_bounds__(IPX_BLOCK)
 k_cg_step1_ar(int n, double *st, int parity, const double *__restrict__ p1, int np1,
               const double *__restrict__ x, const double *__restrict__ p,
@@ -440,15 +477,30 @@ k_cg_step1_ar(int n, double *st, int parity, const double *__restrict__ p1, int 
               const double *__restrict__ Hp, const int32_t *__restrict__ rowptr,
               const int32_t *__restrict__ colidx, const double *__restrict__ val,
               const int32_t *__restrict__ tiles, int ntiles, const int32_t *__restrict__ own,
-              double *__restrict__ w, double *__restrict__ part2) {
+              double *__restrict__ w, double *__restrict__ part2,
+              const double *__restrict__ p5, int np5) {
   __shared__ double prod[TN];
   __shared__ double span[QS * IPX_BLOCK];
   __shared__ int rp[IPX_SPMV_TILE_ROWS + 1];
-  __shared__ double lds[IPX_BLOCK / IPX_WAVE];
+  __shared__ double lds[3 * (IPX_BLOCK / IPX_WAVE)];
   CG_STAMP(8);
-  const int tile = ipx_xcd_item(blockIdx.x, ntiles);
+  const int tile = ipx_xcd_item(blockIdx.x, RECUR ? ntiles + 1 : ntiles);
   if (tile < 0) return;
   const int tid = threadIdx.x;
+  if (RECUR && tile == ntiles) {
+    // the extra workgroup: alpha like everybody else, then the three sums
+    if (st[ST_STOP] != 0.0) return;
+    const double rtg = st[parity ? ST_RTG1 : ST_RTG0];
+    const double ptHp = ipx_sum_partials<IPX_SUM>(p1 + np1, np1, lds);
+    if (rtg < st[ST_TOL] || ptHp <= 0.0) return;
+    const double alpha = rtg / ptHp;
+    const double *const parts[3] = {p5, p5 + np5, p5 + 2 * np5};
+    const int counts[3] = {np5, np5, np5};
+    double red[3];
+    ipx_sum_partials_multi<3>(parts, counts, lds, red);
+    if (tid == 0) st[ST_XN2R] = red[0] + 2.0 * alpha * red[1] + alpha * alpha * red[2];
+    return;
+  }
   const double *const fparts[1] = {p1 + np1};
   const int fcounts[1] = {np1};
   const double stop = st[ST_STOP];
@@ -478,8 +530,8 @@ k_cg_step1_ar(int n, double *st, int parity, const double *__restrict__ p1, int 
     const int col = min(o0 + max(min(tid + k * IPX_BLOCK, nspan - 1), 0), n - 1);
     sr[k] = r[col];
     sh[k] = Hp[col];
-    sxv[k] = x[col];
-    spv[k] = p[col];
+    sxv[k] = RECUR ? 0.0 : x[col];
+    spv[k] = RECUR ? 0.0 : p[col];
   }
   if (stop != 0.0) return;
   CG_STAMP(9);
@@ -506,8 +558,10 @@ k_cg_step1_ar(int n, double *st, int parity, const double *__restrict__ p1, int 
       const double rn = sr[k] + alpha * sh[k];       // :622
       span[j] = rn;
       if (o0 + j < o1) {                             // own column
-        const double xn = sxv[k] + alpha * spv[k];   // :580 (not stored)
-        sx += xn * xn;
+        if (!RECUR) {
+          const double xn = sxv[k] + alpha * spv[k]; // :580 (not stored)
+          sx += xn * xn;
+        }
         r_next[o0 + j] = rn;
       }
     }
@@ -543,8 +597,10 @@ k_cg_step1_ar(int n, double *st, int parity, const double *__restrict__ p1, int 
     }
   }
   CG_STAMP(13);
-  const double tot = ipx_block_reduce<IPX_SUM>(sx, lds);
-  if (tid == 0) { part2[tile] = tot; part2[ntiles + tile] = 0.0; }
+  if (!RECUR) {
+    const double tot = ipx_block_reduce<IPX_SUM>(sx, lds);
+    if (tid == 0) { part2[tile] = tot; part2[ntiles + tile] = 0.0; }
+  }
 #pragma unroll
   for (int q = 0; q < IPX_SPMV_TILE_ROWS / IPX_BLOCK; ++q) {
     const int i = tid + q * IPX_BLOCK;
@@ -665,6 +721,12 @@ struct Compactor {
   }
 };
 
+static bool fused_ar(const ipx_cg_args *a);
+static bool fused_hp(const ipx_cg_args *a);
+// ||x + alpha p||^2 by recurrence (see k_cg_step1_ar<.., RECUR>): both fused kernels in use and
+// scratch for the three sums given
+static bool xn2_recur(const ipx_cg_args *a) { return a->part5 && fused_ar(a) && fused_hp(a); }
+
 static bool fused_ar(const ipx_cg_args *a) {
   return a->r_next != nullptr && a->A_own != nullptr && a->A_span > 0 && !a->lb && a->m > 0;
 }
@@ -684,18 +746,20 @@ static int part3_count(const ipx_cg_args *a) {
 
 // step1 + A.r in one launch (see k_cg_step1_ar): r_next <- r + alpha Hp, w <- A r_next
 static int launch_step1_ar(const ipx_cg_args *a, int it, const double *p1, int np1,
-                           hipStream_t st) {
-  const dim3 grid(ipx_xcd_grid((int)a->A_ntiles)), block(IPX_BLOCK);
+                           hipStream_t st, const double *p5 = nullptr, int np5 = 0) {
+  const bool recur = p5 != nullptr;             // (+1: the workgroup that forms ||x + alpha p||^2)
+  const dim3 grid(ipx_xcd_grid((int)a->A_ntiles + (recur ? 1 : 0))), block(IPX_BLOCK);
 #define FUSED_ARGS                                                                         \
   (int)a->n, a->state, it & 1, p1, np1, a->x, a->p, a->r, a->r_next,                       \
       a->Hp, a->A_rowptr, a->A_colidx, a->A_val, a->A_tiles, (int)a->A_ntiles, a->A_own,   \
-      a->w, a->part2
+      a->w, a->part2, p5, np5
   const int qs = (int)((a->A_span + IPX_BLOCK - 1) / IPX_BLOCK);
   const bool half = a->A_tile_nnz == 1024;      // tiles of 1024 nonzeros (own table)
 #define GO(Q)                                                                              \
   do {                                                                                     \
-    if (half) hipLaunchKernelGGL((k_cg_step1_ar<Q, 1024>), grid, block, 0, st, FUSED_ARGS); \
-    else hipLaunchKernelGGL((k_cg_step1_ar<Q, FT_NNZ>), grid, block, 0, st, FUSED_ARGS);    \
+    if (half) hipLaunchKernelGGL((k_cg_step1_ar<Q, 1024, false>), grid, block, 0, st, FUSED_ARGS); \
+    else if (recur) hipLaunchKernelGGL((k_cg_step1_ar<Q, FT_NNZ, true>), grid, block, 0, st, FUSED_ARGS); \
+    else hipLaunchKernelGGL((k_cg_step1_ar<Q, FT_NNZ, false>), grid, block, 0, st, FUSED_ARGS);    \
   } while (0)
   switch (qs) {
     case 1: case 2: GO(2); break;
@@ -722,7 +786,8 @@ static int launch_step2_hp(const ipx_cg_args *a, int it, int mode, const double 
 #define FUSED_ARGS                                                                            \
   (int)a->n, a->state, it & 1, mode, p2, np2, p3, np3, p4, np4, a->x, a->p, a->r,             \
       a->H_rowptr, a->H_colidx, a->H_val, a->H_tiles,                                         \
-      (int)a->H_ntiles, a->H_diag, a->Hp, a->part1, (int)a->H_hmax, pb_in, pb_out
+      (int)a->H_ntiles, a->H_diag, a->Hp, a->part1, (int)a->H_hmax, pb_in, pb_out,           \
+      (xn2_recur(a) ? a->part5 : nullptr)
   // H_hmax carries the longest tile's row count in its upper half (set by the host
   // binding): short tiles (3 nonzeros per row -> 683 rows) take the 3-elements-per-lane
   // instantiation, which needs fewer registers
@@ -995,11 +1060,15 @@ static int cg_iterate(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, hi
     const double *p1 = a->part1;
     int np1 = (int)a->H_ntiles;
     cmp.add(p1, np1, 2, 2048);      // beyond what a consumer folds in one or two rounds
+    const bool recur = xn2_recur(a);
+    const double *p5 = recur ? a->part5 : nullptr;
+    int np5 = (int)a->H_ntiles;
+    if (recur) cmp.add(p5, np5, 3, 2048);
     rc = cmp.launch(guard, st);
     if (rc) return rc;
     if (fuse1) {
       MARK(1);
-      rc = launch_step1_ar(a, it, p1, np1, st);       // r_next = r + alpha Hp;  w = A r_next
+      rc = launch_step1_ar(a, it, p1, np1, st, p5, np5);   // r_next = r + alpha Hp;  w = A r_next
       if (rc) return rc;
       MARK(2);
     } else {
@@ -1048,7 +1117,7 @@ static int cg_iterate(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, hi
     }
     const double *p2 = a->part2, *p3 = a->part3, *p4 = a->part4;
     int np2 = part2_count(a), n4 = np4;
-    cmp.add(p2, np2, 2, 1024);
+    if (!recur) cmp.add(p2, np2, 2, 1024);
     if (a->m > 0) {
       cmp.add(p3, np3, 2, 2048);
       cmp.add(p4, n4, 1, 1024);
@@ -1057,7 +1126,8 @@ static int cg_iterate(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, hi
     if (rc) return rc;
     if (fused_hp(a)) {
       MARK(6);
-      rc = launch_step2_hp(a, it, a->m > 0 ? 0 : 2, p2, np2, p3, np3, p4, n4, st);
+      rc = launch_step2_hp(a, it, (a->m > 0 ? 0 : 2) | (recur ? 4 : 0), p2, np2, p3, np3, p4, n4,
+                           st);
     } else {
       hipLaunchKernelGGL(k_cg_step2, dim3(ipx_xcd_grid((int)a->vec_grid)), dim3(VB), 0, st, a->n,
                          a->state, it & 1, a->m > 0 ? 0 : 2, p2, np2, p3, np3, p4, n4, a->x, a->p,

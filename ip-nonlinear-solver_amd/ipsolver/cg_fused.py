@@ -40,7 +40,7 @@ class CgArgs(ctypes.Structure):
         ("vec_grid", _I64), ("solver_kind", _I64), ("pb", _P), ("H_hmax", _I64), ("H_tile_rows", _I64),
         ("r_next", _P), ("A_own", _P), ("A_span", _I64), ("fold_ws", _P),
         ("At_vown", _P), ("At_qv", _I64), ("A_tile_nnz", _I64),
-        ("At_ell_col", _P), ("At_ell_val", _P))]
+        ("At_ell_col", _P), ("At_ell_val", _P), ("part5", _P))]
 
 
 # Counters over the life of the process (diagnostics: how often the device loop
@@ -237,7 +237,7 @@ def _ptr(t):
 class _Loop:
     """Buffers + argument block for one projected_cg call."""
 
-    def __init__(self, H, P, lb, ub):
+    def __init__(self, H, P, lb, ub, recur=True):
         lib = _hip.load()
         A = P.A
         At = A.T
@@ -318,10 +318,31 @@ class _Loop:
                     if n % 2 == 0:      # pairs of variables per 16-byte load (csrc/banded.hip)
                         self.ell_col, self.ell_val = ell_rows(At)
                         a.At_ell_col, a.At_ell_val = _ptr(self.ell_col), _ptr(self.ell_val)
+        # Optional (IPX_RECUR=1), both fused kernels in use: ||x + alpha p||^2 by recurrence from
+        # sums the step2 + H.p kernel accumulates, so step1 + A.r does not read x and p (csrc/cg.hip
+        # RECUR).  Off by default: +2.4 % it/s at n=1e6 (+5.4 % at n=4e6) for a 7 % slower dominant
+        # kernel, and the trust-region test's norm is then rounded differently from the direct
+        # sum the reference computes.
+        self.part5 = None
+        if recur and a.A_span and a.H_hmax and os.environ.get("IPX_RECUR"):
+            self.part5 = torch.zeros(3 * Hc.pattern.ntiles, dtype=f64, device=dev)
+            a.part5 = _ptr(self.part5)
         self.args = a
 
     def ref(self):
         return ctypes.byref(self.args)
+
+    def seed_sums(self):
+        """x'x, x'p, p'p of the current (x, p) into the scratch the recurrence starts from:
+        after priming the loop, and after the host finished an iteration with the separate
+        kernels (which do not leave these sums)."""
+        if self.part5 is None:
+            return
+        r = dv.box_sphere_reduce(DVec(self.x), DVec(self.p), 1.0, None, None)
+        nt = self.part5.numel() // 3
+        self.part5.zero_()
+        seed = torch.tensor([r[2], r[1], r[0]], dtype=torch.float64, device=self.part5.device)
+        self.part5[0::nt][:3].copy_(seed)
 
 
 def projected_cg(H, c, Z, Y, b, trust_radius=np.inf, lb=None, ub=None, tol=None,
@@ -366,6 +387,7 @@ def projected_cg(H, c, Z, Y, b, trust_radius=np.inf, lb=None, ub=None, tol=None,
     init[ST_ORTH_RHS] = P.orth_tol * P.norm_A
     L.state.copy_(torch.from_numpy(init))
     _hip.check(lib.ipx_cg_hp(L.ref(), st), "ipx_cg_hp")
+    L.seed_sums()
 
     X, R = DVec(L.x), DVec(L.r)
     hits_boundary = False
@@ -462,6 +484,7 @@ def _resume(lib, L, it_stop, mode, st):
     """Clear the stop flag, finish iteration ``it_stop`` (step2 + Hp)."""
     L.state[ST_STOP] = 0.0
     _hip.check(lib.ipx_cg_resume(L.ref(), it_stop, mode, st), "ipx_cg_resume")
+    L.seed_sums()
     return L.state.tolist()
 
 

@@ -806,7 +806,7 @@ class FusedShardedCG:
             local_P.stats = P.stats
         self.P = P
         self.L = L = cg_fused._Loop(H.local, local_P, lb.loc if lb is not None else None,
-                                    ub.loc if ub is not None else None)
+                                    ub.loc if ub is not None else None, recur=False)
         a = L.args
         dev = dv.ctx().device
         self.s1 = torch.zeros(2, dtype=torch.float64, device=dev)

@@ -882,3 +882,30 @@ def test_iterative_normal_solver_on_the_device(ips):
     A0[5, :] = 0
     with pytest.raises(np.linalg.LinAlgError):
         IterativeNormalSolver(ips.dv.DeviceCSR.from_scipy(sps.csr_matrix(A0)))
+
+
+def test_trust_region_norm_by_recurrence(ips, monkeypatch):
+    """IPX_RECUR=1: ||x + alpha p||^2 formed from sums the fused step2 + H.p kernel leaves
+    (step1 + A.r then does not read x and p).  Same iterates; exits on the trust region at the
+    same iteration and point as the default path (direct sum)."""
+    inst = BandedInstance(20000, 2000)
+    A = ips.dv.DeviceCSR.from_scipy(inst.A)
+    H = ips.dv.DeviceCSR.from_scipy(inst.H)
+    Z, LS, Y = ips.proj.projections(A)
+    b = np.zeros(2000)
+    x_free, _ = ips.qp.projected_cg(H, inst.c, Z, Y, b, tol=1e-12)
+    runs = {}
+    for flag in ("", "1"):
+        if flag:
+            monkeypatch.setenv("IPX_RECUR", "1")
+        else:
+            monkeypatch.delenv("IPX_RECUR", raising=False)
+        out = []
+        for kw in (dict(tol=0, max_iter=40), dict(trust_radius=0.5 * ips.dv.norm(x_free)),
+                   dict(tol=1e-12)):
+            x, info = ips.qp.projected_cg(H, inst.c, Z, Y, b, **kw)
+            out.append((host(x), info))
+        runs[flag] = out
+    for (x0, i0), (x1, i1) in zip(runs[""], runs["1"]):
+        assert i0 == i1
+        assert np.max(np.abs(x0 - x1)) <= 1e-13 * np.max(np.abs(x0))
