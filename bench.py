@@ -12,13 +12,19 @@ starts.
 
 N > 1 is launched by torch.distributed.run (one rank per GPU): the SAME
 n=1e6 / m=1e5 problem is row-partitioned over the ranks (BASELINE config 4,
-ipsolver/sharded.py) with RCCL all-reduces on the CG inner products and on
-the partial A.r products and a neighbour halo exchange of p; value =
-iterations of the shared problem / max time over ranks ("strong" scaling).
+ipsolver/sharded.py: constraint rows and variables both partitioned) with two
+small RCCL all-reduces per iteration (p'Hp; the packed norms) and a neighbour
+exchange of the halo of g; value = iterations of the shared problem / max
+time over ranks ("strong" scaling).  The JSON also carries the measured
+latency floor of those collectives, a weak-scaling point (n = N * 1e6) and the
+whole config-4 solve on the sharded backend.
 
 Prints ONE JSON line (see the driver contract in the task statement) with
-`roofline` for the dominant kernel (the H.p CSR SpMV) and `cpu_baseline`
-(the oracle = numpy/scipy restatement of the reference path, 1 host thread).
+`roofline` for the dominant kernel (step2 fused into the H.p CSR SpMV),
+`roofline_out_of_cache` (the same measurement at n=4e6, past the Infinity
+Cache), `repeat` (median / min / max over further K-step regions) and
+`cpu_baseline` (the oracle = numpy/scipy restatement of the reference path,
+1 host thread).
 """
 import argparse
 import ctypes
