@@ -32,7 +32,20 @@ k_dense_gemv(int m, int n, const double *__restrict__ A, int64_t lda,
   for (int r = blockIdx.x * wpb + wave; r < m; r += gridDim.x * wpb) {
     const double *row = A + (int64_t)r * lda;
     double s = 0.0;
-    for (int c = lane; c < n; c += IPX_WAVE) s += row[c] * x[c];
+    {
+      // lane l sums elements l, l+64, l+128, ... in that order (what the results of the
+      // dense path are pinned to); eight loads of each operand are issued before the first
+      // product so that a wave keeps 8 KB in flight instead of 1
+      int c = lane;
+      for (; c + 7 * IPX_WAVE < n; c += 8 * IPX_WAVE) {
+        double a[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { a[u] = row[c + u * IPX_WAVE]; b[u] = x[c + u * IPX_WAVE]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += a[u] * b[u];
+      }
+      for (; c < n; c += IPX_WAVE) s += row[c] * x[c];
+    }
     s = ipx_wave_sum(s);
     if (lane == 0) {
       double y = alpha * s;
