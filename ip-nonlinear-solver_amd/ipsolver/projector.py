@@ -440,6 +440,10 @@ def as_device_matrix(A):
     return DeviceDense.from_host(np.asarray(A, dtype=float))
 
 
+BANDED_SINGLE_CHUNK_K = 5          # half bandwidth from which the banded solver is one serial chunk
+BANDED_SINGLE_CHUNK_ROWS = 8192
+
+
 def normal_solver_for(A):
     """The ``(A A')^-1`` solver ``projections`` picks for a full-row-rank device matrix."""
     from .dense import DenseNormalSolver, DeviceDense
@@ -447,8 +451,16 @@ def normal_solver_for(A):
         return DenseNormalSolver(A)
     kmax = _hip.load().ipx_banded_kmax()
     m = A.shape[0]
-    if _symbolic_for(A.pattern).k <= kmax:
+    k = _symbolic_for(A.pattern).k
+    # Half bandwidths 5-8 have no separator level in csrc/banded.hip (its reduced system would
+    # be wider than the compiled kernels): the whole band is one chunk swept by a single lane,
+    # 80-100 ms per solve at m = 1e5.  Beyond a few thousand rows the device-resident
+    # preconditioned CG is 20x faster there (scripts/bench_banded_k.py,
+    # profiles/r02_banded_by_bandwidth.txt) and as accurate after the projector's refinement.
+    if k <= kmax and not (k >= BANDED_SINGLE_CHUNK_K and m > BANDED_SINGLE_CHUNK_ROWS):
         return BandedNormalSolver(A)
+    if k <= kmax and m > DenseNormalSolver.MAX_ROWS_FROM_SPARSE:
+        return IterativeNormalSolver(A)
     if _box_schur_applies(A, kmax):
         from .boxschur import BoxSchurNormalSolver
         return BoxSchurNormalSolver(A)          # bound rows eliminated analytically

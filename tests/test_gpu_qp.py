@@ -909,3 +909,26 @@ def test_trust_region_norm_by_recurrence(ips, monkeypatch):
     for (x0, i0), (x1, i1) in zip(runs[""], runs["1"]):
         assert i0 == i1
         assert np.max(np.abs(x0 - x1)) <= 1e-13 * np.max(np.abs(x0))
+
+
+def test_wide_band_takes_the_iterative_solver(ips):
+    """Half bandwidth 6 at m = 20000: inside what the banded factorization accepts, but there it
+    is a single chunk swept by one lane (80 ms per solve at m = 1e5); ``projections`` routes
+    such Jacobians to the device-resident preconditioned CG (2.5 ms,
+    profiles/r02_banded_by_bandwidth.txt).  Same operators: against the oracle."""
+    import oracle
+    from ipsolver.projector import IterativeNormalSolver, _symbolic_for
+    rng = np.random.default_rng(6)
+    m, k = 20000, 6
+    cols = (4 * np.arange(m)[:, None] + np.arange(4 * k)[None, :]).ravel()
+    A = sps.csr_matrix((rng.standard_normal(len(cols)), (np.repeat(np.arange(m), 4 * k), cols)),
+                       shape=(m, 4 * m + 4 * k))
+    Ad = ips.dv.DeviceCSR.from_scipy(A)
+    assert 5 <= _symbolic_for(Ad.pattern).k <= 8
+    Z, LS, Y = ips.proj.projections(Ad)
+    assert isinstance(Z.projector.solver, IterativeNormalSolver)
+    Zo, LSo, Yo = oracle.projections(A)
+    x, b = rng.standard_normal(A.shape[1]), rng.standard_normal(m)
+    close(Z.dot(x), Zo.dot(x), 1e-9)
+    close(LS.dot(x), LSo.dot(x), 1e-9)
+    close(Y.dot(b), Yo.dot(b), 1e-9)
