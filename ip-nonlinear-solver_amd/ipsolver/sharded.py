@@ -160,6 +160,60 @@ class ShardComm:
         self.all_reduce(t, op)
         return t.tolist()
 
+    def reduce_mixed(self, sums=(), maxs=(), mins=()):
+        """Sums, maxima and minima of host scalars over the ranks in ONE collective (an
+        all-gather of every rank's values, combined locally in rank order: bit-identical on
+        every rank)."""
+        ns, nx, nn = len(sums), len(maxs), len(mins)
+        if self.world == 1:
+            return [float(v) for v in sums], [float(v) for v in maxs], [float(v) for v in mins]
+        t = torch.tensor([float(v) for v in (*sums, *maxs, *mins)], dtype=torch.float64)
+        if self.backend == "nccl":
+            t = t.to(torch.device("cuda", torch.cuda.current_device()))
+        parts = [torch.empty_like(t) for _ in range(self.world)]
+        self.stats["all_reduce"] += 1
+        self.stats["all_reduce_bytes"] += 8 * t.numel() * self.world
+        dist.all_gather(parts, t, group=self.group)
+        g = torch.stack(parts).cpu()
+        return (g[:, :ns].sum(0).tolist(), g[:, ns:ns + nx].max(0).values.tolist() if nx else [],
+                g[:, ns + nx:].min(0).values.tolist() if nn else [])
+
+    def exchange_many(self, jobs):
+        """Several halo updates (tensor, own_lo, own_hi, send_left, send_right) as ONE batch of
+        point-to-point operations (the segments of a stacked vector)."""
+        if self.world == 1:
+            return
+        ops, staged, r = [], [], self.rank
+        for t, own_lo, own_hi, send_left, send_right in jobs:
+            n = t.numel()
+            stage = t.is_cuda and self.backend != "nccl"
+            buf = t.cpu() if stage else t
+            if stage:
+                staged.append((t, buf, own_lo, own_hi))
+            if r > 0:
+                if send_left:
+                    ops.append(dist.P2POp(dist.isend, buf[own_lo:own_lo + send_left], r - 1,
+                                          self.group))
+                if own_lo:
+                    ops.append(dist.P2POp(dist.irecv, buf[0:own_lo], r - 1, self.group))
+            if r < self.world - 1:
+                if send_right:
+                    ops.append(dist.P2POp(dist.isend, buf[own_hi - send_right:own_hi], r + 1,
+                                          self.group))
+                if n - own_hi:
+                    ops.append(dist.P2POp(dist.irecv, buf[own_hi:n], r + 1, self.group))
+            self.stats["exchange_bytes"] += 8 * (send_left * (r > 0)
+                                                 + send_right * (r < self.world - 1))
+        if ops:
+            self.stats["exchange"] += 1
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        for t, buf, own_lo, own_hi in staged:
+            if own_lo:
+                t[0:own_lo].copy_(buf[0:own_lo])
+            if t.numel() - own_hi:
+                t[own_hi:].copy_(buf[own_hi:])
+
     def exchange(self, t, own_lo, own_hi, send_left, send_right):
         """Halo update of the local extended 1-D tensor ``t``: entries [0, own_lo) come from
         the left neighbour's last own entries, [own_hi, len) from the right neighbour's
@@ -444,8 +498,13 @@ class Sharding:
     def sync(self, v):
         """Overwrite the halo entries of ``v`` with their owners' values."""
         t = self.ops.tensor(v.loc)
-        for _, off, ln, lo, hi, sl, sr, _, _ in self.segments(v.kind):
+        segs = self.segments(v.kind)
+        if len(segs) == 1:
+            _, off, ln, lo, hi, sl, sr, _, _ = segs[0]
             self.comm.exchange(t[off:off + ln], lo, hi, sl, sr)
+        else:
+            self.comm.exchange_many([(t[off:off + ln], lo, hi, sl, sr)
+                                     for _, off, ln, lo, hi, sl, sr, _, _ in segs])
         return v
 
 
@@ -574,7 +633,8 @@ class ShardVec:
             ss, am = ss + s1, max(am, a1)
         if self.sh.comm.world == 1:
             return [ss, am]
-        return [self.sh.comm.reduce_floats([ss])[0], self.sh.comm.reduce_floats([am], "max")[0]]
+        sums, maxs, _ = self.sh.comm.reduce_mixed([ss], [am])
+        return [sums[0], maxs[0]]
 
     def _clip(self, lb, ub):
         return self._new(self.sh.ops.clip(self.loc, lb.loc, ub.loc))
@@ -601,10 +661,8 @@ class ShardVec:
         c = self.sh.comm
         if c.world == 1:
             return tot
-        s = c.reduce_floats([tot[0], tot[1], tot[2], tot[5], tot[6]])
-        ta = c.reduce_floats([tot[3]], "max")[0]
-        tb = c.reduce_floats([tot[4]], "min")[0]
-        return [s[0], s[1], s[2], ta, tb, s[3], s[4]]
+        s, ta, tb = c.reduce_mixed([tot[0], tot[1], tot[2], tot[5], tot[6]], [tot[3]], [tot[4]])
+        return [s[0], s[1], s[2], ta[0], tb[0], s[3], s[4]]
 
 
 # --------------------------------------------------------------------------- operators
