@@ -200,7 +200,11 @@ typedef struct ipx_cg_args {
   double *state;
   double *part1, *part2, *part3, *part4;
   int64_t vec_grid;
-  int64_t solver_kind;   /* 0: `banded` is an ipx_banded handle; 1: an ipx_boxschur_args* */
+  int64_t solver_kind;   /* 0: `banded` is an ipx_banded handle; 1: an ipx_boxschur_args*;
+                          * 2: dense Jacobian -- A_val / At_val are row-major m x n / n x m matrices
+                          * (the index arrays NULL), `banded` is G^-1 (M x M doubles, M = m rounded up
+                          * to 32; w and v M long, zero tail), H is CSR or, with H_rowptr NULL, a
+                          * row-major n x n matrix in H_val; part1/3/4 hold 2 x 2048 doubles */
   /* step2 fused into the H.p SpMV (banded H): H_hmax > 0 = widest distance of a row tile's
    * columns from its own row range (<= 64, <= rows of every tile), pb = 2 x H_ntiles x
    * 2*H_hmax doubles of scratch (tile-boundary copies of p, by iteration parity).

@@ -35,6 +35,7 @@
 // Because x is only advanced in step2, every early exit leaves (x, p, alpha)
 // exactly as the reference's exit paths (:565-576, :585-596) need them.
 #include "ipx_common.h"
+#include <algorithm>
 #include <vector>
 
 // state block layout (doubles)
@@ -678,7 +679,22 @@ static bool fused_hp(const ipx_cg_args *a) { return a->pb != nullptr && a->H_hma
 
 // Unfused H.p; when the fused step2+H.p kernel is in use it also saves the tile
 // boundaries of the p it was given (that kernel's halo source).
+static bool dense_loop(const ipx_cg_args *a) { return a->solver_kind == 2; }
+// entries per half of part1: row tiles of a CSR Hessian / workgroups of the dense matvec
+static int part1_count(const ipx_cg_args *a) {
+  if (dense_loop(a) && !a->H_rowptr) {
+    const int g = (int)((a->n + 3) / 4);
+    return g > 2048 ? 2048 : g;
+  }
+  return (int)a->H_ntiles;
+}
+
 static int launch_hp(const ipx_cg_args *a, const double *guard, hipStream_t st) {
+  if (dense_loop(a) && !a->H_rowptr) {           // dense Hessian (row major n x n in H_val)
+    int np = 0;
+    return ipx_dense_gemv_launch((int)a->n, (int)a->n, a->H_val, a->n, a->p, 1.0, a->H_diag, 0.0,
+                                 nullptr, a->Hp, a->part1, &np, guard, st);
+  }
   ipx_csr_view H{(int)a->n, (int)a->n, a->H_rowptr, a->H_colidx, a->H_val, a->H_tiles, (int)a->H_ntiles};
   int rc = ipx_spmv_launch(H, a->p, 1.0, a->H_diag, 0.0, nullptr, a->Hp, a->part1, guard, st);
   if (rc || !fused_hp(a)) return rc;
@@ -953,10 +969,17 @@ int ipx_cg_resume(const ipx_cg_args *a, int32_t it, int32_t mode, void *stream) 
   if (!a) return IPX_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const double *guard = a->state + ST_STOP;
+  int np3, np4;
+  if (dense_loop(a)) {                        // workgroups of the dense matvecs (rows / 4, capped)
+    np3 = (int)std::min<int64_t>((a->n + 3) / 4, 2048);
+    np4 = (int)std::min<int64_t>((a->m + 3) / 4, 2048);
+  } else {
+    np3 = part3_count(a);
+    np4 = part4_count(a);
+  }
   hipLaunchKernelGGL(k_cg_step2, dim3(ipx_xcd_grid((int)a->vec_grid)), dim3(VB), 0, st, a->n,
-                     a->state, it & 1, mode, a->part2, part2_count(a), a->part3,
-                     part3_count(a), a->part4, part4_count(a), a->x, a->p, a->r,
-                     (int)a->vec_grid);
+                     a->state, it & 1, mode, a->part2, part2_count(a), a->part3, np3, a->part4,
+                     np4, a->x, a->p, a->r, (int)a->vec_grid);
   IPX_CHECK_LAUNCH();
   return launch_hp(a, guard, st);
 }
@@ -1044,8 +1067,50 @@ int ipx_cg_iterate_timed(const ipx_cg_args *a, int32_t it_begin, int32_t it_end,
   return rc;
 }
 
+// Dense Jacobian (BASELINE config 2; solver_kind 2): the same state machine over the dense
+// matvecs of csrc/dense.hip, whose epilogues carry the reductions.  A (m x n) and A' (n x m)
+// row major in A_val / At_val, `banded` = G^-1 (M x M, M = m rounded up to 32; w and v are M
+// long with a zero tail), H dense (H_rowptr NULL) or CSR.  Seven launches per iteration:
+// step1, w = A r, v = G^-1 w, g = r - A'v, t = A g (the reference's orthogonality measure,
+// projections.py:52, literally), step2, Hp = H p.
+static int cg_iterate_dense(const ipx_cg_args *a, int32_t it_begin, int32_t it_end,
+                            hipStream_t st) {
+  const double *guard = a->state + ST_STOP;
+  const int n = (int)a->n, m = (int)a->m;
+  const int M = ((m + 31) / 32) * 32;
+  const int grid = (int)a->vec_grid;
+  const double *Ginv = (const double *)a->banded;
+  for (int it = it_begin; it < it_end; ++it) {
+    hipLaunchKernelGGL(k_cg_step1, dim3(ipx_xcd_grid(grid)), dim3(VB), 0, st, a->n, a->state,
+                       it & 1, a->part1, part1_count(a), a->x, a->p, a->r, a->Hp, a->lb, a->ub,
+                       a->part2, grid, (int64_t)0, a->n);
+    IPX_CHECK_LAUNCH();
+    int np = 0, np3 = 0, np4 = 0;
+    int rc = ipx_dense_gemv_launch(m, n, a->A_val, n, a->r, 1.0, nullptr, 0.0, nullptr, a->w,
+                                   nullptr, &np, guard, st);
+    if (rc) return rc;
+    rc = ipx_dense_gemv_launch(M, M, Ginv, M, a->w, 1.0, nullptr, 0.0, nullptr, a->v, nullptr, &np,
+                               guard, st);
+    if (rc) return rc;
+    rc = ipx_dense_gemv_launch(n, m, a->At_val, m, a->v, -1.0, nullptr, 1.0, a->r, a->r, a->part3,
+                               &np3, guard, st);                      // g = r - A'v, ||g||^2
+    if (rc) return rc;
+    rc = ipx_dense_gemv_launch(m, n, a->A_val, n, a->r, 1.0, nullptr, 0.0, nullptr, a->t, a->part4,
+                               &np4, guard, st);                      // ||A g||^2
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_cg_step2, dim3(ipx_xcd_grid(grid)), dim3(VB), 0, st, a->n, a->state,
+                       it & 1, 0, a->part2, grid, a->part3, np3, a->part4, np4, a->x, a->p, a->r,
+                       grid);
+    IPX_CHECK_LAUNCH();
+    rc = launch_hp(a, guard, st);
+    if (rc) return rc;
+  }
+  return IPX_OK;
+}
+
 static int cg_iterate(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, hipStream_t st,
                       hipEvent_t *ev) {
+  if (dense_loop(a)) return ev ? IPX_EINVAL : cg_iterate_dense(a, it_begin, it_end, st);
   const double *guard = a->state + ST_STOP;
   ipx_csr_view A{(int)a->m, (int)a->n, a->A_rowptr, a->A_colidx, a->A_val, a->A_tiles, (int)a->A_ntiles};
   ipx_csr_view At{(int)a->n, (int)a->m, a->At_rowptr, a->At_colidx, a->At_val, a->At_tiles, (int)a->At_ntiles};

@@ -298,6 +298,12 @@ int ipx_spmv_launch(const ipx_csr_view &A, const double *x, double alpha, const 
                     const double *guard, hipStream_t st, const double *xrow_override = nullptr);
 int ipx_banded_solve_guarded(void *handle, const double *w, double *x, const double *guard,
                              hipStream_t st);
+// yout = alpha A x [+ diag x] [+ beta yin] for a row-major dense A; partial (optional) gets
+// per-workgroup sums of y^2 then of x.y (square A), *npartial entries per half
+int ipx_dense_gemv_launch(int m, int n, const double *A, int64_t lda, const double *x,
+                          double alpha, const double *diag, double beta, const double *yin,
+                          double *yout, double *partial, int *npartial, const double *guard,
+                          hipStream_t st);
 // x = (A A')^-1 w and partial[0..*npartial) <- per-workgroup sums of ||w - (A A') x||^2
 // in one go; the partial buffer needs ceil(m / 256) doubles.
 int ipx_banded_resid_count(void *handle);

@@ -58,6 +58,19 @@ def _hessian_parts(H):
     return None
 
 
+def _dense_hessian(H):
+    """The dense matrix behind a Hessian operator that is nothing else (a DeviceDense, or the
+    DeviceHessian backend_hip builds from one ndarray term), or None."""
+    from .dense import DeviceDense
+    from .operators import DeviceHessian
+    if isinstance(H, DeviceDense) and H.shape[0] == H.shape[1]:
+        return H
+    if isinstance(H, DeviceHessian) and H.csr is None and H.diag is None \
+            and len(H.others) == 1 and isinstance(H.others[0], DeviceDense):
+        return H.others[0]
+    return None
+
+
 FUSE_HMAX = 64          # csrc/cg.hip FUSE_HMAX
 
 
@@ -223,7 +236,14 @@ def supports(H, Z, Y):
     P = getattr(Z, "projector", None)
     if P is None or getattr(Y, "projector", None) is not P:
         return False
-    if not isinstance(P, NormalEquationProjector) or not isinstance(P.A, DeviceCSR):
+    if not isinstance(P, NormalEquationProjector):
+        return False
+    from .dense import DeviceDense, DenseNormalSolver
+    if isinstance(P.A, DeviceDense):          # dense Jacobian (config 2): dense or CSR Hessian
+        return (P.m > 0 and isinstance(P.solver, DenseNormalSolver)
+                and not getattr(P.solver, "refine_steps", 0)
+                and (_dense_hessian(H) is not None or _hessian_parts(H) is not None))
+    if not isinstance(P.A, DeviceCSR):
         return False
     if P.m == 0 or _solver_kind(P.solver) is None:
         return False
@@ -238,6 +258,10 @@ class _Loop:
     """Buffers + argument block for one projected_cg call."""
 
     def __init__(self, H, P, lb, ub, recur=True):
+        from .dense import DeviceDense
+        if isinstance(P.A, DeviceDense):
+            self._init_dense(H, P, lb, ub)
+            return
         lib = _hip.load()
         A = P.A
         At = A.T
@@ -327,6 +351,48 @@ class _Loop:
         if recur and a.A_span and a.H_hmax and os.environ.get("IPX_RECUR"):
             self.part5 = torch.zeros(3 * Hc.pattern.ntiles, dtype=f64, device=dev)
             a.part5 = _ptr(self.part5)
+        self.args = a
+
+    def _init_dense(self, H, P, lb, ub):
+        """Argument block for a dense Jacobian (csrc/cg.hip cg_iterate_dense)."""
+        from .dense import DeviceDense
+        lib = _hip.load()
+        A, At = P.A, P.A.T
+        self.n, self.m = n, m = P.n, P.m
+        M = P.solver.M
+        dev, f64 = ctx().device, torch.float64
+        z = lambda k: torch.zeros(int(k), dtype=f64, device=dev)
+        self.x, self.p, self.r, self.Hp = z(n), z(n), z(n), z(n)
+        self.w, self.v, self.t = z(M), z(M), z(m)
+        self.state = z(lib.ipx_cg_state_size())
+        grid = lib.ipx_cg_vec_grid(n)
+        self.part1, self.part3, self.part4 = z(2 * 2048), z(2 * 2048), z(2 * 2048)
+        self.part2 = z(2 * grid)
+        self.part5 = None
+        a = CgArgs()
+        a.n, a.m = n, m
+        a.A_val, a.At_val = _ptr(A.t), _ptr(At.t)
+        Hd_ = _dense_hessian(H)
+        if Hd_ is not None:
+            a.H_val = _ptr(Hd_.t)
+            self.keep = (A, At, Hd_, lb, ub, P)
+        else:
+            Hc, Hd = _hessian_parts(H)
+            pat = Hc.pattern
+            a.H_rowptr, a.H_colidx, a.H_val = _ptr(pat.indptr), _ptr(pat.indices), _ptr(Hc.val)
+            a.H_tiles, a.H_ntiles = _ptr(pat.tiles), pat.ntiles
+            a.H_diag = _ptr(Hd.t) if Hd is not None else None
+            self.part1 = z(2 * max(pat.ntiles, 1))
+            self.keep = (A, At, Hc, Hd, lb, ub, P)
+        a.banded = ctypes.c_void_p(P.solver.Ginv.t.data_ptr())
+        a.solver_kind = 2
+        for name in ("x", "p", "r", "Hp", "w", "v", "t", "state",
+                     "part1", "part2", "part3", "part4"):
+            setattr(a, name, _ptr(getattr(self, name)))
+        a.lb = _ptr(lb.t) if lb is not None else None
+        a.ub = _ptr(ub.t) if ub is not None else None
+        a.vec_grid = grid
+        self.fold_ws = None
         self.args = a
 
     def ref(self):

@@ -932,3 +932,41 @@ def test_wide_band_takes_the_iterative_solver(ips):
     close(Z.dot(x), Zo.dot(x), 1e-9)
     close(LS.dot(x), LSo.dot(x), 1e-9)
     close(Y.dot(b), Yo.dot(b), 1e-9)
+
+
+@pytest.mark.parametrize("hessian", ["dense", "csr"])
+def test_dense_jacobian_device_loop(ips, hessian):
+    """Dense Jacobians (BASELINE config 2) on the device-resident loop (csrc/cg.hip
+    cg_iterate_dense): same iterates, counts and exits as the statement-by-statement driver
+    and as the oracle (pivoted QR projections, like the reference) -- tolerance exit,
+    trust-region exit, and a box."""
+    import oracle
+    import ipsolver.cg_fused as cg_fused
+    from ipsolver.dense import DeviceDense
+    rng = np.random.default_rng(3)
+    m, n = 60, 400
+    A = rng.standard_normal((m, n))
+    G = rng.standard_normal((n, n)) / np.sqrt(n)
+    Hh = G @ G.T + np.eye(n)
+    if hessian == "csr":
+        Hh = np.triu(np.tril(Hh, 2), -2)
+        H = ips.dv.DeviceCSR.from_scipy(sps.csr_matrix(Hh))
+    else:
+        H = DeviceDense.from_host(Hh)
+    c = rng.standard_normal(n)
+    b = A @ rng.standard_normal(n) * 0.01
+    Z, LS, Y = ips.proj.projections(DeviceDense.from_host(A))
+    assert cg_fused.supports(H, Z, Y)
+    Zo, _, Yo = oracle.projections(A)
+    x_free, _ = oracle.projected_cg(sps.csr_matrix(Hh), c, Zo, Yo, b, tol=1e-14)
+    for kw in (dict(tol=1e-14), dict(), dict(trust_radius=0.6 * np.linalg.norm(x_free)),
+               dict(lb=np.full(n, -0.5 * np.abs(x_free).max()),
+                    ub=np.full(n, 0.5 * np.abs(x_free).max()), max_iter=25)):
+        calls = cg_fused.STATS["calls"]
+        x, info = ips.qp.projected_cg(H, c, Z, Y, b, **kw)
+        assert cg_fused.STATS["calls"] == calls + 1          # the device-resident loop ran
+        xg, info_g = ips.qp.projected_cg(H, c, Z, Y, b, return_all=True, **kw)
+        xo, info_o = oracle.projected_cg(sps.csr_matrix(Hh), c, Zo, Yo, b, **kw)
+        assert info == {k: info_g[k] for k in info} == {k: info_o[k] for k in info}, kw
+        close(x, xo, 1e-9)
+        close(x, host(xg), 1e-11)
