@@ -214,6 +214,37 @@ class ShardComm:
             if t.numel() - own_hi:
                 t[own_hi:].copy_(buf[own_hi:])
 
+    def prepare_exchange(self, t, own_lo, own_hi, send_left, send_right):
+        """The halo update of ``exchange`` for a FIXED buffer as a callable: the point-to-point
+        operations are built once (the device-resident loop repeats the same exchange every
+        iteration; building them costs more host time than issuing them).  CUDA buffers under
+        gloo (a test-only combination) fall back to the staged form."""
+        if self.world == 1:
+            return lambda: None
+        if t.is_cuda and self.backend != "nccl":
+            return lambda: self.exchange(t, own_lo, own_hi, send_left, send_right)
+        n, r, ops = t.numel(), self.rank, []
+        if r > 0:
+            if send_left:
+                ops.append(dist.P2POp(dist.isend, t[own_lo:own_lo + send_left], r - 1, self.group))
+            if own_lo:
+                ops.append(dist.P2POp(dist.irecv, t[0:own_lo], r - 1, self.group))
+        if r < self.world - 1:
+            if send_right:
+                ops.append(dist.P2POp(dist.isend, t[own_hi - send_right:own_hi], r + 1, self.group))
+            if n - own_hi:
+                ops.append(dist.P2POp(dist.irecv, t[own_hi:n], r + 1, self.group))
+        nbytes = 8 * (send_left * (r > 0) + send_right * (r < self.world - 1))
+        stats, batch = self.stats, dist.batch_isend_irecv
+
+        def go():
+            if ops:
+                stats["exchange"] += 1
+                stats["exchange_bytes"] += nbytes
+                for w in batch(ops):
+                    w.wait()
+        return go
+
     def exchange(self, t, own_lo, own_hi, send_left, send_right):
         """Halo update of the local extended 1-D tensor ``t``: entries [0, own_lo) come from
         the left neighbour's last own entries, [own_hi, len) from the right neighbour's
@@ -899,6 +930,7 @@ class FusedShardedCG:
             At = A_loc.T
             e.p3_lo, e.p3_hi = At.pattern.tile_range(clo, chi)
         self.col_geom = (clo, chi) + sh.lay.sends("col")
+        self._exchange_g = sh.comm.prepare_exchange(self.L.r, *self.col_geom)
 
     def _segment(self, phase, it, mode=0):
         self._hip.call("ipx_cg_shard2_segment", self.L.ref(), ctypes.byref(self.ext), int(phase),
@@ -924,13 +956,12 @@ class FusedShardedCG:
     def iterate(self, it_begin, it_end):
         """Enqueue iterations [it_begin, it_end): per iteration two all-reduces and one halo
         exchange, no host synchronisation."""
-        comm = self.sh.comm
-        clo, chi, sl, sr = self.col_geom
+        comm, exchange_g = self.sh.comm, self._exchange_g
         for it in range(it_begin, it_end):
             comm.all_reduce(self.s1)                                   # p'Hp
             self._segment(0, it)
             comm.all_reduce(self.pack)          # ||x+ap||^2, #violations, ||g||^2, ||A g||^2
-            comm.exchange(self.L.r, clo, chi, sl, sr)                  # halo of g
+            exchange_g()                                               # halo of g
             self._segment(1, it, 0)
 
     def resume(self, it, mode):

@@ -286,6 +286,41 @@ def test_sharded_refinement_and_collectives(world, runs):
     close(got["refine_x"], runs[1]["refine_x"], 1e-12)
 
 
+def _exchange_worker(rank, world, port, out_path):
+    _setup(rank, world, port)
+    try:
+        import torch
+        from ipsolver.sharded import ShardComm
+        comm = ShardComm()
+        # a local array of 3 halo + 10 own + 2 halo entries; neighbours keep 2 / 3 of ours
+        lo, hi = (3 if rank > 0 else 0), (3 if rank > 0 else 0) + 10
+        n = hi + (2 if rank < world - 1 else 0)
+        t = torch.full((n,), -1.0, dtype=torch.float64)
+        go = comm.prepare_exchange(t, lo, hi, 2, 3)
+        seen = []
+        for rep in range(3):                       # the prepared operations are reusable
+            t[lo:hi] = 100.0 * rank + rep + torch.arange(10, dtype=torch.float64)
+            go()
+            seen.append(t.clone().numpy())
+        np.save(out_path + ".%d.npy" % rank, np.array(seen))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_prepared_halo_exchange(tmp_path):
+    """ShardComm.prepare_exchange (the form the device-resident loop issues every iteration;
+    here on CPU tensors over gloo, the same code that runs on CUDA tensors over RCCL): left
+    halo <- the left neighbour's last own entries, right halo <- the right neighbour's first."""
+    path = str(tmp_path / "ex")
+    mp.spawn(_exchange_worker, args=(3, _free_port(), path), nprocs=3, join=True)
+    got = [np.load(path + ".%d.npy" % r) for r in range(3)]
+    for rep in range(3):
+        own = [100.0 * r + rep + np.arange(10.0) for r in range(3)]
+        assert np.array_equal(got[0][rep], np.concatenate((own[0], own[1][:2])))
+        assert np.array_equal(got[1][rep], np.concatenate((own[0][-3:], own[1], own[2][:2])))
+        assert np.array_equal(got[2][rep], np.concatenate((own[1][-3:], own[2])))
+
+
 def test_layout_partitions_both_spaces():
     from banded_setup import BandedInstance
     from ipsolver.sharded import ShardLayout
