@@ -287,17 +287,23 @@ int ipx_pcg_state_size(void);
 int ipx_pcg_iterate(const ipx_pcg_args *a, int32_t it_begin, int32_t it_end, void *stream);
 /* ---- partitioned row-sharded loop (ipsolver/sharded.py FusedShardedCG; replaces the
  * per-iteration body of qp_subproblem.py:549-634 on one rank of a node).  `a` describes the
- * rank's extended local problem (own rows / variables + halo copies); the scalars travel
- * through two all-reduced device buffers.  Ranges are in units of the partial arrays'
- * entries (row tiles / solve workgroups) and select the rank's OWN part. */
+ * rank's extended local problem (own rows / variables + halo copies; solver_kind 0 or 1); the
+ * scalars travel through two all-reduced device buffers.  Ranges are in units of the partial
+ * arrays' entries (row tiles / solve workgroups) and select the rank's OWN part. */
 typedef struct ipx_shard2_ext {
-  double *s1;              /* [2]  s1[1] = p'Hp (own sum, then all-reduced) */
-  double *pack;            /* [4]  ||x+ap||^2, #violations, ||g||^2, ||A g||^2 */
-  int64_t p1_lo, p1_hi;    /* own row tiles of H               (part1) */
-  int64_t p2_lo, p2_hi;    /* own entries of part2 (row tiles of A with the fused step1) */
-  int64_t p3_lo, p3_hi;    /* own entries of part3 (||g||^2 partials) */
-  int64_t p4_lo, p4_hi;    /* own entries of part4 (||w - (AA')v||^2 partials) */
-  int64_t own_lo, own_hi;  /* own variables, local indices (reduction range of step1) */
+  double *s1;                    /* [2]  s1[1] = p'Hp (own sum, then all-reduced) */
+  double *pack;                  /* [4]  ||x+ap||^2, #violations, ||g||^2, ||A g||^2 */
+  int64_t nseg;                  /* segments of the local vector space: 1 (x-space) .. 4 (the
+                                  * barrier problem's z = [x; s_nl; s_lb; s_ub]), each laid out
+                                  * [left halo | own | right halo] */
+  int64_t own_lo[4], own_hi[4];  /* own elements per segment, local indices (step1's reductions) */
+  int64_t p1_lo[4], p1_hi[4];    /* own row tiles of H per segment                 (part1) */
+  int64_t p3_lo[4], p3_hi[4];    /* own entries of part3 (||g||^2 partials) per segment; with
+                                  * g = r - A'v fused into the banded solve: its own workgroups,
+                                  * segment 0 only */
+  int64_t p2_lo, p2_hi;          /* own entries of part2 (row tiles of A with the fused step1;
+                                  * every vector chunk otherwise: step1 masks by element) */
+  int64_t p4_lo, p4_hi;          /* own workgroups of the (inner) banded solve (part4) */
 } ipx_shard2_ext;
 int ipx_cg_shard2_segment(const ipx_cg_args *a, const ipx_shard2_ext *e, int32_t phase,
                           int32_t it, int32_t mode, void *stream);

@@ -57,15 +57,31 @@ constexpr int VB = IPX_BLOCK;
 
 constexpr int VU = 8;        // elements per lane per trip, loads issued together (one trip at n = 1e6)
 
+// The elements that count in step1's reductions: everything on one GPU; in the row-sharded
+// loop a rank's OWN entries -- one range per segment of the local vector (x-space: one;
+// the barrier problem's z = [x; s_nl; s_lb; s_ub]: four), halo copies in between.
+struct OwnRanges {
+  int64_t lo[4], hi[4];
+  __device__ __forceinline__ bool has(int64_t i) const {
+    return (i >= lo[0] && i < hi[0]) || (i >= lo[1] && i < hi[1]) || (i >= lo[2] && i < hi[2]) ||
+           (i >= lo[3] && i < hi[3]);
+  }
+};
+static OwnRanges own_all(int64_t n) {
+  OwnRanges o;
+  for (int k = 0; k < 4; ++k) { o.lo[k] = 0; o.hi[k] = 0; }
+  o.hi[0] = n;
+  return o;
+}
+
 __global__ void __launch_bounds__(VB)
 k_cg_step1(int64_t n, double *st, int parity, const double *__restrict__ p1, int np1,
            const double *__restrict__ x, const double *__restrict__ p, double *r,
            const double *__restrict__ Hp, const double *__restrict__ lb,
-           const double *__restrict__ ub, double *__restrict__ p2, int nchunks,
-           int64_t red_lo, int64_t red_hi) {
-  // [red_lo, red_hi): the elements that count in ||x + alpha p||^2 and the box test (all of
-  // them on one GPU; a rank's own variables in the row-sharded loop, whose halo copies are
-  // updated by the same launch)
+           const double *__restrict__ ub, double *__restrict__ p2, int nchunks, OwnRanges own) {
+  // own: the elements that count in ||x + alpha p||^2 and the box test (all of them on one
+  // GPU; a rank's own entries in the row-sharded loop, whose halo copies are updated by the
+  // same launch)
   __shared__ double lds[VB / IPX_WAVE];
   // chunk c of nchunks: a contiguous run of elements, owned by a fixed XCD
   const int c = ipx_xcd_item(blockIdx.x, nchunks);
@@ -113,7 +129,7 @@ k_cg_step1(int64_t n, double *st, int parity, const double *__restrict__ p1, int
       const int64_t i = i0 + u * VB;
       if (i < hi_i) {
         const double xn = xv[u] + alpha * pv[u];     // :580 (not stored)
-        if (i >= red_lo && i < red_hi) {
+        if (own.has(i)) {
           sx += xn * xn;
           if (lb) viol += ((lo[u] <= xn) && (xn <= hi[u])) ? 0.0 : 1.0;   // :599
         }
@@ -651,18 +667,24 @@ k_cg_save_pb(const double *__restrict__ p, const int32_t *__restrict__ tiles, in
 // arrays -- the entries produced by a rank's OWN tiles / workgroups -- summed in a fixed
 // order into out[0..4): the rank's contribution to an all-reduce.
 struct RangeJob {
-  const double *ptr[4];   // readable even where count is 0
-  int count[4];
-  int active;             // bit q: out[q] is written
+  const double *ptr[4][4];   // [piece][quantity]; readable even where the count is 0
+  int count[4][4];
+  int npieces;
+  int active;                // bit q: out[q] is written
 };
 
 __global__ void __launch_bounds__(256)
 k_cg_range_pack(RangeJob job, double *__restrict__ out, const double *__restrict__ guard) {
   __shared__ double lds[4 * 4];
   if (guard && *guard != 0.0) return;
-  double red[4];
-  ipx_sum_partials_multi<4>(job.ptr, job.count, lds, red);
-  if (threadIdx.x < 4 && ((job.active >> threadIdx.x) & 1)) out[threadIdx.x] = red[threadIdx.x];
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int pc = 0; pc < job.npieces; ++pc) {          // one piece per segment, in order
+    double red[4];
+    ipx_sum_partials_multi<4>(job.ptr[pc], job.count[pc], lds, red);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] += red[q];
+  }
+  if (threadIdx.x < 4 && ((job.active >> threadIdx.x) & 1)) out[threadIdx.x] = acc[threadIdx.x];
 }
 
 }  // namespace
@@ -832,7 +854,7 @@ int ipx_cg_step1(int64_t n, double *state, int32_t it, const double *p1, int32_t
                  const double *ub, double *part2, int32_t grid, void *stream) {
   if (n < 0 || !state || !p1 || !part2 || grid < 1) return IPX_EINVAL;
   hipLaunchKernelGGL(k_cg_step1, dim3(ipx_xcd_grid(grid)), dim3(VB), 0, (hipStream_t)stream, n,
-                     state, it & 1, p1, np1, x, p, r, Hp, lb, ub, part2, grid, (int64_t)0, n);
+                     state, it & 1, p1, np1, x, p, r, Hp, lb, ub, part2, grid, own_all(n));
   IPX_CHECK_LAUNCH();
   return IPX_OK;
 }
@@ -857,9 +879,41 @@ int ipx_cg_step2(int64_t n, double *state, int32_t it, int32_t mode, const doubl
 //           ||x+ap||^2, #violations, ||g||^2, ||A g||^2 -> e->pack[0..4)
 //   phase 1 (after the all-reduce of pack and the halo exchange of g): step2 (+ H.p),
 //           own sum of p'Hp -> e->s1[1]
+static OwnRanges own_of(const ipx_shard2_ext *e) {
+  OwnRanges o;
+  for (int k = 0; k < 4; ++k) {
+    o.lo[k] = k < e->nseg ? e->own_lo[k] : 0;
+    o.hi[k] = k < e->nseg ? e->own_hi[k] : 0;
+  }
+  return o;
+}
+
+// own sum of the p'Hp partials (second half of part1) over the segments' own row tiles
+static int pack_hp(const ipx_cg_args *a, const ipx_shard2_ext *e, hipStream_t st) {
+  const int np1 = part1_count(a);
+  RangeJob job;
+  job.npieces = (int)e->nseg;
+  job.active = 2;
+  for (int pc = 0; pc < 4; ++pc)
+    for (int q = 0; q < 4; ++q) { job.ptr[pc][q] = a->part1; job.count[pc][q] = 0; }
+  for (int pc = 0; pc < (int)e->nseg; ++pc) {
+    if (e->p1_hi[pc] > np1) return IPX_EINVAL;
+    job.ptr[pc][1] = a->part1 + np1 + e->p1_lo[pc];
+    job.count[pc][1] = (int)(e->p1_hi[pc] - e->p1_lo[pc]);
+  }
+  // NOT guarded by the stop flag: once an iteration has raised it, the remaining iterations
+  // of the batch are no-ops but their all-reduces still run; re-packing the (unchanged)
+  // own sums keeps the reduced values those of the iteration that stopped
+  hipLaunchKernelGGL(k_cg_range_pack, dim3(1), dim3(256), 0, st, job, e->s1,
+                     (const double *)nullptr);
+  IPX_CHECK_LAUNCH();
+  return IPX_OK;
+}
+
 int ipx_cg_shard2_segment(const ipx_cg_args *a, const ipx_shard2_ext *e, int32_t phase,
                           int32_t it, int32_t mode, void *stream) {
-  if (!a || !e || phase < 0 || phase > 1 || !e->s1 || !e->pack || a->solver_kind != 0)
+  if (!a || !e || phase < 0 || phase > 1 || !e->s1 || !e->pack || a->solver_kind > 1 ||
+      e->nseg < 1 || e->nseg > 4)
     return IPX_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const double *guard = a->state + ST_STOP;
@@ -873,7 +927,7 @@ int ipx_cg_shard2_segment(const ipx_cg_args *a, const ipx_shard2_ext *e, int32_t
     } else {
       hipLaunchKernelGGL(k_cg_step1, dim3(ipx_xcd_grid(grid)), dim3(VB), 0, st, a->n, a->state,
                          it & 1, e->s1, 1, a->x, a->p, a->r, a->Hp, a->lb, a->ub, a->part2, grid,
-                         e->own_lo, e->own_hi);
+                         own_of(e));
       IPX_CHECK_LAUNCH();
       ipx_csr_view A{(int)a->m, (int)a->n, a->A_rowptr, a->A_colidx, a->A_val, a->A_tiles,
                      (int)a->A_ntiles};
@@ -882,7 +936,7 @@ int ipx_cg_shard2_segment(const ipx_cg_args *a, const ipx_shard2_ext *e, int32_t
     }
     int np4 = 0, np3 = (int)a->At_ntiles;
     const double *r_in = fuse1 ? a->r_next : a->r;
-    if (a->At_vown && a->At_qv > 0) {
+    if (a->solver_kind == 0 && a->At_vown && a->At_qv > 0) {
       rc = ipx_banded_solve_resid_atv_launch(a->banded, a->w, a->v, a->part4, &np4, a->At_rowptr,
                                              a->At_colidx, a->At_val, r_in, a->r, a->At_vown,
                                              (int)a->At_qv, a->part3, guard, st, a->At_ell_col,
@@ -890,26 +944,35 @@ int ipx_cg_shard2_segment(const ipx_cg_args *a, const ipx_shard2_ext *e, int32_t
       if (rc) return rc;
       np3 = np4;
     } else {
-      rc = ipx_banded_solve_resid_launch(a->banded, a->w, a->v, a->part4, &np4, guard, st);
+      if (a->solver_kind == 1)      // box rows eliminated analytically, banded Schur complement
+        rc = ipx_boxschur_solve((const ipx_boxschur_args *)a->banded, a->w, a->v, a->part4, &np4,
+                                guard, st);
+      else
+        rc = ipx_banded_solve_resid_launch(a->banded, a->w, a->v, a->part4, &np4, guard, st);
       if (rc) return rc;
       ipx_csr_view At{(int)a->n, (int)a->m, a->At_rowptr, a->At_colidx, a->At_val, a->At_tiles,
                       (int)a->At_ntiles};
       rc = ipx_spmv_launch(At, a->v, -1.0, nullptr, 1.0, r_in, a->r, a->part3, guard, st);
       if (rc) return rc;
     }
-    if (e->p4_hi > np4 || e->p3_hi > np3 || e->p2_hi > part2_count(a)) return IPX_EINVAL;
     const int np2 = part2_count(a);
+    if (e->p4_hi > np4 || e->p2_hi > np2) return IPX_EINVAL;
     RangeJob job;
-    job.ptr[0] = a->part2 + e->p2_lo;        job.count[0] = (int)(e->p2_hi - e->p2_lo);
-    job.ptr[1] = a->part2 + np2 + e->p2_lo;  job.count[1] = (int)(e->p2_hi - e->p2_lo);
-    job.ptr[2] = a->part3 + e->p3_lo;        job.count[2] = (int)(e->p3_hi - e->p3_lo);
-    job.ptr[3] = a->part4 + e->p4_lo;        job.count[3] = (int)(e->p4_hi - e->p4_lo);
+    job.npieces = (int)e->nseg;
     job.active = 15;
-    // NOT guarded by the stop flag: once an iteration has raised it, the remaining iterations
-    // of the batch are no-ops but their all-reduces still run; re-packing the (unchanged)
-    // own sums keeps the reduced values those of the iteration that stopped
+    for (int pc = 0; pc < 4; ++pc)
+      for (int q = 0; q < 4; ++q) { job.ptr[pc][q] = a->part2; job.count[pc][q] = 0; }
+    // ||x+ap||^2, #violations and ||A g||^2 are single ranges (piece 0); ||g||^2 one per segment
+    job.ptr[0][0] = a->part2 + e->p2_lo;        job.count[0][0] = (int)(e->p2_hi - e->p2_lo);
+    job.ptr[0][1] = a->part2 + np2 + e->p2_lo;  job.count[0][1] = (int)(e->p2_hi - e->p2_lo);
+    job.ptr[0][3] = a->part4 + e->p4_lo;        job.count[0][3] = (int)(e->p4_hi - e->p4_lo);
+    for (int pc = 0; pc < (int)e->nseg; ++pc) {
+      if (e->p3_hi[pc] > np3) return IPX_EINVAL;
+      job.ptr[pc][2] = a->part3 + e->p3_lo[pc];
+      job.count[pc][2] = (int)(e->p3_hi[pc] - e->p3_lo[pc]);
+    }
     hipLaunchKernelGGL(k_cg_range_pack, dim3(1), dim3(256), 0, st, job, e->pack,
-                       (const double *)nullptr);
+                       (const double *)nullptr);            // unguarded: see pack_hp
     IPX_CHECK_LAUNCH();
     return IPX_OK;
   }
@@ -924,28 +987,13 @@ int ipx_cg_shard2_segment(const ipx_cg_args *a, const ipx_shard2_ext *e, int32_t
     rc = launch_hp(a, guard, st);
   }
   if (rc) return rc;
-  if (e->p1_hi > a->H_ntiles) return IPX_EINVAL;
-  RangeJob job;
-  for (int q = 0; q < 4; ++q) { job.ptr[q] = a->part1; job.count[q] = 0; }
-  job.ptr[1] = a->part1 + a->H_ntiles + e->p1_lo;  job.count[1] = (int)(e->p1_hi - e->p1_lo);
-  job.active = 2;
-  hipLaunchKernelGGL(k_cg_range_pack, dim3(1), dim3(256), 0, st, job, e->s1,
-                     (const double *)nullptr);      // see phase 0
-  IPX_CHECK_LAUNCH();
-  return IPX_OK;
+  return pack_hp(a, e, st);
 }
 
 // The own-range sum of the p'Hp partials on its own (priming the sharded loop).
 int ipx_cg_shard2_fold_hp(const ipx_cg_args *a, const ipx_shard2_ext *e, void *stream) {
-  if (!a || !e || !e->s1 || e->p1_hi > a->H_ntiles) return IPX_EINVAL;
-  RangeJob job;
-  for (int q = 0; q < 4; ++q) { job.ptr[q] = a->part1; job.count[q] = 0; }
-  job.ptr[1] = a->part1 + a->H_ntiles + e->p1_lo;  job.count[1] = (int)(e->p1_hi - e->p1_lo);
-  job.active = 2;
-  hipLaunchKernelGGL(k_cg_range_pack, dim3(1), dim3(256), 0, (hipStream_t)stream, job, e->s1,
-                     (const double *)nullptr);
-  IPX_CHECK_LAUNCH();
-  return IPX_OK;
+  if (!a || !e || !e->s1 || e->nseg < 1 || e->nseg > 4) return IPX_EINVAL;
+  return pack_hp(a, e, (hipStream_t)stream);
 }
 
 // Hp = H p with p'Hp partials (the tail of an iteration, also used once by
@@ -1083,7 +1131,7 @@ static int cg_iterate_dense(const ipx_cg_args *a, int32_t it_begin, int32_t it_e
   for (int it = it_begin; it < it_end; ++it) {
     hipLaunchKernelGGL(k_cg_step1, dim3(ipx_xcd_grid(grid)), dim3(VB), 0, st, a->n, a->state,
                        it & 1, a->part1, part1_count(a), a->x, a->p, a->r, a->Hp, a->lb, a->ub,
-                       a->part2, grid, (int64_t)0, a->n);
+                       a->part2, grid, own_all(a->n));
     IPX_CHECK_LAUNCH();
     int np = 0, np3 = 0, np4 = 0;
     int rc = ipx_dense_gemv_launch(m, n, a->A_val, n, a->r, 1.0, nullptr, 0.0, nullptr, a->w,
@@ -1139,7 +1187,7 @@ static int cg_iterate(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, hi
     } else {
       hipLaunchKernelGGL(k_cg_step1, dim3(ipx_xcd_grid((int)a->vec_grid)), dim3(VB), 0, st, a->n,
                          a->state, it & 1, p1, np1, a->x, a->p, a->r,
-                         a->Hp, a->lb, a->ub, a->part2, (int)a->vec_grid, (int64_t)0, a->n);
+                         a->Hp, a->lb, a->ub, a->part2, (int)a->vec_grid, own_all(a->n));
       IPX_CHECK_LAUNCH();
       MARK(1);
     }

@@ -130,17 +130,20 @@ class PaddedOperator:
                           DVec.zeros(self.n_total - self.n_vars)))
 
 
-def _extend_pattern(pattern, n_total):
-    """CSR pattern of [[H, 0], [0, 0]] (n_total x n_total) sharing H's columns."""
+def _extend_pattern(pattern, n_total, row_breaks=None):
+    """CSR pattern of [[H, 0], [0, 0]] (n_total x n_total) sharing H's columns (row tiles cut
+    at ``row_breaks``: the sharded solver's own / halo boundaries)."""
     cache = getattr(pattern, "_ipx_extended", None)
     if cache is None:
         cache = pattern._ipx_extended = {}
-    if n_total not in cache:
+    key = n_total if row_breaks is None else (n_total, tuple(int(b) for b in row_breaks))
+    if key not in cache:
         extra = n_total - pattern.shape[0]
         indptr = np.concatenate((pattern.indptr_h,
                                  np.full(extra, pattern.indptr_h[-1], dtype=np.int32)))
-        cache[n_total] = CSRPattern(indptr, pattern.indices_h, (n_total, n_total))
-    return cache[n_total]
+        cache[key] = CSRPattern(indptr, pattern.indices_h, (n_total, n_total),
+                                row_breaks=row_breaks)
+    return cache[key]
 
 
 _merge_cache = {}

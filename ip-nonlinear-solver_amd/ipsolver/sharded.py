@@ -215,26 +215,36 @@ class ShardComm:
                 t[own_hi:].copy_(buf[own_hi:])
 
     def prepare_exchange(self, t, own_lo, own_hi, send_left, send_right):
-        """The halo update of ``exchange`` for a FIXED buffer as a callable: the point-to-point
-        operations are built once (the device-resident loop repeats the same exchange every
-        iteration; building them costs more host time than issuing them).  CUDA buffers under
-        gloo (a test-only combination) fall back to the staged form."""
+        """``prepare_exchange_many`` for one buffer."""
+        return self.prepare_exchange_many([(t, own_lo, own_hi, send_left, send_right)])
+
+    def prepare_exchange_many(self, jobs):
+        """The halo updates of ``exchange_many`` for FIXED buffers as a callable: the
+        point-to-point operations are built once (the device-resident loop repeats the same
+        exchange every iteration; building them costs more host time than issuing them) and
+        issued as one batch.  CUDA buffers under gloo (a test-only combination) fall back to
+        the staged form."""
         if self.world == 1:
             return lambda: None
-        if t.is_cuda and self.backend != "nccl":
-            return lambda: self.exchange(t, own_lo, own_hi, send_left, send_right)
-        n, r, ops = t.numel(), self.rank, []
-        if r > 0:
-            if send_left:
-                ops.append(dist.P2POp(dist.isend, t[own_lo:own_lo + send_left], r - 1, self.group))
-            if own_lo:
-                ops.append(dist.P2POp(dist.irecv, t[0:own_lo], r - 1, self.group))
-        if r < self.world - 1:
-            if send_right:
-                ops.append(dist.P2POp(dist.isend, t[own_hi - send_right:own_hi], r + 1, self.group))
-            if n - own_hi:
-                ops.append(dist.P2POp(dist.irecv, t[own_hi:n], r + 1, self.group))
-        nbytes = 8 * (send_left * (r > 0) + send_right * (r < self.world - 1))
+        jobs = list(jobs)
+        if any(j[0].is_cuda for j in jobs) and self.backend != "nccl":
+            return lambda: self.exchange_many(jobs)
+        r, ops, nbytes = self.rank, [], 0
+        for t, own_lo, own_hi, send_left, send_right in jobs:
+            n = t.numel()
+            if r > 0:
+                if send_left:
+                    ops.append(dist.P2POp(dist.isend, t[own_lo:own_lo + send_left], r - 1,
+                                          self.group))
+                if own_lo:
+                    ops.append(dist.P2POp(dist.irecv, t[0:own_lo], r - 1, self.group))
+            if r < self.world - 1:
+                if send_right:
+                    ops.append(dist.P2POp(dist.isend, t[own_hi - send_right:own_hi], r + 1,
+                                          self.group))
+                if n - own_hi:
+                    ops.append(dist.P2POp(dist.irecv, t[own_hi:n], r + 1, self.group))
+            nbytes += 8 * (send_left * (r > 0) + send_right * (r < self.world - 1))
         stats, batch = self.stats, dist.batch_isend_irecv
 
         def go():
@@ -384,7 +394,7 @@ class HipOps:
         total, bad = self.dv.read_slots(2)
         return total, bad
 
-    def augmented_box(self, J, s_nl, s_lb, s_ub):
+    def augmented_box(self, J, s_nl, s_lb, s_ub, col_breaks=None):
         """Local block of the barrier problem's augmented Jacobian for nonlinear inequality
         rows + a box on every variable (tr_interior_point.py:141-194 on the canonical rows of
         _canonical_constraint.py:350-355: nonlinear rows, all lower bounds, all upper bounds):
@@ -393,7 +403,9 @@ class HipOps:
             [ -I      0       diag(s_lb)      0      ]
             [ +I      0           0       diag(s_ub) ]
 
-        on a pattern built once per Jacobian pattern; a refresh is four scatters."""
+        on a pattern built once per Jacobian pattern; a refresh is four scatters.
+        ``col_breaks``: row-tile boundaries of the stored transpose (the own / halo
+        boundaries of the z segments, for per-tile partial sums over own entries)."""
         from . import _hip
         dvm = self.dv
         pat = J.pattern
@@ -421,6 +433,8 @@ class HipOps:
             pos_sub = base2 + 1
             indices[pos_sub] = nX + mE + nX + np.arange(nX)
             apat = dvm.CSRPattern(indptr.astype(np.int32), indices, (mE + 2 * nX, nX + mE + 2 * nX))
+            if col_breaks is not None:
+                apat.transpose(row_breaks=col_breaks)
             dev = dvm.ctx().device
             t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(dev)
             cache = pat._ipx_aug_box = (apat, torch.from_numpy(template).to(dev), t(pos_J), t(pos_snl),
@@ -433,13 +447,14 @@ class HipOps:
                 _hip.call("ipx_scatter", idx.numel(), dvm._p(src), dvm._p(idx), dvm._p(val), st)
         return dvm.DeviceCSR(apat, val)
 
-    def hessian_z(self, Hx, slack_block):
-        """[[Hx, 0], [0, diag(slack_block)]] for the local x-space operator ``Hx``."""
+    def hessian_z(self, Hx, slack_block, breaks=None):
+        """[[Hx, 0], [0, diag(slack_block)]] for the local x-space operator ``Hx`` (row tiles
+        cut at ``breaks``)."""
         from . import backend_hip
         from .operators import DeviceHessian
         n_x = Hx.shape[0] if hasattr(Hx, "shape") else Hx.n
         n_tot = n_x + len(slack_block)
-        csr = self.dv.DeviceCSR(backend_hip._extend_pattern(Hx.csr.pattern, n_tot), Hx.csr.val)
+        csr = self.dv.DeviceCSR(backend_hip._extend_pattern(Hx.csr.pattern, n_tot, breaks), Hx.csr.val)
         xdiag = Hx.diag if Hx.diag is not None else self.dv.DVec.zeros(n_x)
         return DeviceHessian(n_tot, csr, self.dv.hstack((xdiag, slack_block)))
 
@@ -798,7 +813,8 @@ class ShardProjector:
                        else self.sh.ops.any_normal_solver(A.local))
         self.norm_A = A.frobenius_norm()
         self.stats = {"solves": 0, "refinements": 0}
-        self.fused_sharded = bool(getattr(self.sh.ops, "fused", False)) and plain
+        self.fused_sharded = bool(getattr(self.sh.ops, "fused", False))
+        self.plain = plain
 
     def _apply_inv(self, w):
         self.stats["solves"] += 1
@@ -854,21 +870,41 @@ _TINY = 1e-25
 
 class Shard2Ext(ctypes.Structure):
     """Mirror of ipx_shard2_ext (include/ipx.h)."""
-    _fields_ = [("s1", ctypes.c_void_p), ("pack", ctypes.c_void_p)] + \
-               [(k, ctypes.c_int64) for k in ("p1_lo", "p1_hi", "p2_lo", "p2_hi", "p3_lo", "p3_hi",
-                                              "p4_lo", "p4_hi", "own_lo", "own_hi")]
+    _A4 = ctypes.c_int64 * 4
+    _fields_ = [("s1", ctypes.c_void_p), ("pack", ctypes.c_void_p), ("nseg", ctypes.c_int64),
+                ("own_lo", _A4), ("own_hi", _A4), ("p1_lo", _A4), ("p1_hi", _A4),
+                ("p3_lo", _A4), ("p3_hi", _A4), ("p2_lo", ctypes.c_int64),
+                ("p2_hi", ctypes.c_int64), ("p4_lo", ctypes.c_int64), ("p4_hi", ctypes.c_int64)]
+
+
+def _banded_of(P):
+    """The banded factorization whose workgroups follow the partition of the "row" space:
+    the solver itself (x-space problems) or the Schur complement of the nonlinear rows (the
+    barrier problem: box rows eliminated analytically), or None."""
+    from .projector import BandedNormalSolver
+    from .boxschur import BoxSchurNormalSolver
+    sv = P.solver
+    if P.plain:
+        return sv if isinstance(sv, BandedNormalSolver) and sv.perm is None else None
+    if P.A.row_kind != ShardedBackend.INEQ or P.A.col_kind != ShardedBackend.Z:
+        return None
+    if not isinstance(sv, BoxSchurNormalSolver) or sv.c_args() is None:
+        return None
+    # the rows left to the banded solve must be exactly the nonlinear rows, in order
+    mE = P.sh.lay.geom("row")[1]
+    if len(sv.an.general) != mE or not np.array_equal(sv.an.general, np.arange(mE)):
+        return None
+    return sv.inner
 
 
 def fused_supports(H, Z, Y):
     P = getattr(Z, "projector", None)
     if not isinstance(P, ShardProjector) or getattr(Y, "projector", None) is not P:
         return False
-    if not isinstance(H, ShardHessian) or not P.fused_sharded:
+    if not isinstance(H, ShardHessian) or not P.fused_sharded or H.kind != P.A.col_kind:
         return False
     from . import cg_fused
-    from .projector import BandedNormalSolver
-    return (isinstance(P.solver, BandedNormalSolver) and P.solver.perm is None
-            and cg_fused._hessian_parts(H.local) is not None)
+    return _banded_of(P) is not None and cg_fused._hessian_parts(H.local) is not None
 
 
 class FusedShardedCG:
@@ -894,6 +930,7 @@ class FusedShardedCG:
             local_P.norm_A = P.norm_A
             local_P.stats = P.stats
         self.P = P
+        self.kind = H.kind
         self.L = L = cg_fused._Loop(H.local, local_P, lb.loc if lb is not None else None,
                                     ub.loc if ub is not None else None, recur=False)
         a = L.args
@@ -902,19 +939,22 @@ class FusedShardedCG:
         self.pack = torch.zeros(4, dtype=torch.float64, device=dev)
         e = self.ext = Shard2Ext()
         e.s1, e.pack = self.s1.data_ptr(), self.pack.data_ptr()
-        _, _, clo, chi = sh.lay.geom("col")
+        segs = sh.segments(self.kind)
         _, _, rlo, rhi = sh.lay.geom("row")
-        e.own_lo, e.own_hi = clo, chi
+        e.nseg = len(segs)
         Hc, _ = cg_fused._hessian_parts(H.local)
-        e.p1_lo, e.p1_hi = Hc.pattern.tile_range(clo, chi)
+        for k, (_, off, _, lo, hi, *_rest) in enumerate(segs):
+            e.own_lo[k], e.own_hi[k] = off + lo, off + hi
+            e.p1_lo[k], e.p1_hi[k] = Hc.pattern.tile_range(off + lo, off + hi)
         if a.A_span:                       # step1 inside A.r: partials per row tile of A
             if getattr(L, "own_tiles", None) is not A_loc.pattern.tiles:
                 raise _hip.IpxError("sharded loop: the fused step1 must use the pattern's row tiles")
             e.p2_lo, e.p2_hi = A_loc.pattern.tile_range(rlo, rhi)
-        else:                              # vector kernel, masked to the own variables
+        else:                              # vector kernel, masked to the own entries
             e.p2_lo, e.p2_hi = 0, int(a.vec_grid)
         geo = (ctypes.c_int32 * 2)()
-        decoupled = self.lib.ipx_banded_decoupled_geometry(ctypes.c_void_p(P.solver.handle), geo)
+        banded = _banded_of(P)
+        decoupled = self.lib.ipx_banded_decoupled_geometry(ctypes.c_void_p(banded.handle), geo)
         if not decoupled or geo[0] != sh.lay.row_block or rlo % geo[0] or \
                 (rhi % geo[0] and sh.lay.me["R1"] != sh.lay.m):
             raise NotImplementedError(
@@ -925,12 +965,13 @@ class FusedShardedCG:
         w0, w1 = rlo // geo[0], (rhi + geo[0] - 1) // geo[0]
         e.p4_lo, e.p4_hi = w0, w1
         if a.At_qv:                        # g = r - A'v rides in the solve: partials per workgroup
-            e.p3_lo, e.p3_hi = w0, w1
+            e.p3_lo[0], e.p3_hi[0] = w0, w1
         else:
-            At = A_loc.T
-            e.p3_lo, e.p3_hi = At.pattern.tile_range(clo, chi)
-        self.col_geom = (clo, chi) + sh.lay.sends("col")
-        self._exchange_g = sh.comm.prepare_exchange(self.L.r, *self.col_geom)
+            Atp = A_loc.T.pattern
+            for k in range(len(segs)):
+                e.p3_lo[k], e.p3_hi[k] = Atp.tile_range(e.own_lo[k], e.own_hi[k])
+        self._exchange_g = sh.comm.prepare_exchange_many(
+            [(self.L.r[off:off + ln], lo, hi, sl, sr) for _, off, ln, lo, hi, sl, sr, _, _ in segs])
 
     def _segment(self, phase, it, mode=0):
         self._hip.call("ipx_cg_shard2_segment", self.L.ref(), ctypes.byref(self.ext), int(phase),
@@ -1010,10 +1051,10 @@ def fused_projected_cg(H, c, Z, Y, b, trust_radius=np.inf, lb=None, ub=None, tol
     DV = dv.DVec
 
     def X():
-        return ShardVec(DV(L.x), sh, "col")
+        return ShardVec(DV(L.x), sh, F.kind)
 
     def Pv():
-        return ShardVec(DV(L.p), sh, "col")
+        return ShardVec(DV(L.p), sh, F.kind)
 
     hits_boundary, stop_cond = False, 1
     counter, last_viol_it = 0, -2
@@ -1086,7 +1127,7 @@ def fused_projected_cg(H, c, Z, Y, b, trust_radius=np.inf, lb=None, ub=None, tol
             continue
         raise RuntimeError("unexpected CG stop code %d" % stop)
 
-    x = ShardVec(DV(L.x), sh, "col")
+    x = ShardVec(DV(L.x), sh, F.kind)
     if has_box and not qp.inside_box_boundaries(x, lb, ub):     # :636-638
         x = last_feasible_x
         hits_boundary = True
@@ -1101,7 +1142,7 @@ def _refine_sharded(F):
     loop (L.r holds g, own + synchronised halo); the refined ||g||^2 replaces the packed
     value step2 derives beta from."""
     P, sh, L = F.P, F.sh, F.L
-    g = ShardVec(F.dv.DVec(L.r), sh, "col")
+    g = ShardVec(F.dv.DVec(L.r), sh, F.kind)
     k = 0
     while k < P.max_refin:
         orth, Az = P.orthogonality(g)
@@ -1145,6 +1186,10 @@ class ShardedBackend:
 
     def __init__(self, sh):
         self.sh = sh
+
+    def _z_breaks(self):
+        """Own / halo boundaries of the z segments in the local z vector."""
+        return [off + b for _, off, _, lo, hi, *_ in self.sh.segments(self.Z) for b in (lo, hi)]
 
     def asvec(self, a):
         if isinstance(a, (ShardVec, _Empty)):
@@ -1219,7 +1264,7 @@ class ShardedBackend:
         sh = self.sh
         segs = sh.segments(self.INEQ)
         parts = [s.loc[off:off + ln] for _, off, ln, *_ in segs]
-        local = sh.ops.augmented_box(J_ineq.J_nl.local, *parts)
+        local = sh.ops.augmented_box(J_ineq.J_nl.local, *parts, col_breaks=self._z_breaks())
         return ShardCSR(sh, local, row_kind=self.INEQ, col_kind=self.Z)
 
     def hessian_operator(self, terms, n_vars, slack_block):
@@ -1228,7 +1273,8 @@ class ShardedBackend:
                                       "return a ShardHessian")
         if slack_block is None:
             return terms
-        return ShardHessian(self.sh, self.sh.ops.hessian_z(terms.local, slack_block.loc), self.Z)
+        return ShardHessian(self.sh, self.sh.ops.hessian_z(terms.local, slack_block.loc,
+                                                          breaks=self._z_breaks()), self.Z)
 
     def projections(self, A, method=None):
         return projections(A, method)

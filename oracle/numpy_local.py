@@ -131,14 +131,14 @@ class NumpyOps:
         pos = s > 0
         return float(np.sum(np.log(s[pos]))), float(np.count_nonzero(~pos))
 
-    def augmented_box(self, J, s_nl, s_lb, s_ub):                  # tr_interior_point.py:141-194
+    def augmented_box(self, J, s_nl, s_lb, s_ub, col_breaks=None):                  # tr_interior_point.py:141-194
         mE, nX = J.M.shape
         I = sps.identity(nX, format="csr")
         return _LocalCSR(sps.bmat([[J.M, sps.diags(s_nl), None, None],
                                    [-I, None, sps.diags(s_lb), None],
                                    [I, None, None, sps.diags(s_ub)]], format="csr"))
 
-    def hessian_z(self, Hx, slack_block):
+    def hessian_z(self, Hx, slack_block, breaks=None):
         class _Z:
             def __init__(self, Hx, sb):
                 self.Hx, self.sb, self.nx = Hx, sb, Hx.H.shape[0]

@@ -358,7 +358,8 @@ def _sharded_barrier_worker(rank, world, port, out_path):
         x, s = res.x.to_host(), res.s.to_host()
         solver = type(res.jac).__name__
         if rank == 0:
-            np.savez(out_path, x=x, s=s, rows=np.array(rows), status=res.status)
+            np.savez(out_path, x=x, s=s, rows=np.array(rows), status=res.status,
+                     fused=sharded.STATS["fused_calls"], cg=sharded.STATS["iterations"])
     finally:
         dist.destroy_process_group()
 
@@ -390,3 +391,6 @@ def test_sharded_barrier_box_inequality_hip(tmp_path):
     for col in (2, 3, 4, 5, 6):
         assert np.allclose(rows[:k, col], want[:k, col], rtol=1e-6, atol=1e-12), col
     assert got["s"].min() > 0 and np.all(np.abs(got["x"]) < 0.8)
+    # every CG call ran on the device-resident loop (four-segment own ranges, csrc/cg.hip
+    # ipx_cg_shard2_segment with the box-Schur solve)
+    assert int(got["fused"]) >= 10 and int(got["cg"]) == int(rows[-1, 1])
