@@ -35,6 +35,7 @@ extern "C" {
 #define IPX_ELAUNCH (-2)   /* HIP launch / runtime error */
 #define IPX_ENOTSPD (-3)   /* factorization met a non-positive pivot */
 #define IPX_ENOMEM (-4)
+#define IPX_EUNSUPPORTED (-5) /* this solver has no path for the matrix at hand: take another */
 
 /* Number of doubles of reduction workspace any entry point may need. */
 #define IPX_WS_DOUBLES 65536
@@ -169,6 +170,12 @@ int ipx_banded_set_decoupling(void *handle, int allow);
  * ipx_banded_set_decoupling(h, 2) switches back to the chunk form (cross-checks);
  * (h, 16 + L) forces the reduction to stop at level L (tests: an inexact solve). */
 int ipx_banded_pcr_level(void *handle);
+/* After ipx_banded_status: correction steps per solve when the factorization runs defect
+ * correction on the single-launch solve (separator blocks coupled and the separator level
+ * long or -- half bandwidth 5..8 -- not compiled), else 0; *eta (may be NULL) = measured
+ * contraction bound.  ipx_banded_status returns IPX_EUNSUPPORTED for half bandwidth 5..8
+ * when the bound is >= 0.5: the caller takes another solver. */
+int ipx_banded_refine_steps(void *handle, double *eta);
 int ipx_banded_solve(void *handle, const double *w, double *x, void *stream);
 /* Same, skipped on the device when *guard != 0 (stop flag of the CG loops). */
 int ipx_banded_solve_guarded_c(void *handle, const double *w, double *x, const double *guard,

@@ -27,6 +27,9 @@ namespace {
 
 constexpr int KMAX = 8;       // largest half bandwidth with a compiled kernel
 constexpr int MAX_LEVELS = 8;
+constexpr int WIDE_MIN_ROWS = 2048;   // below: one serially swept chunk is fast enough
+constexpr int ITER_TOP_MIN_ROWS = 1024;   // a serial top level longer than this is worth avoiding
+constexpr double ITER_ETA_MAX = 0.5;      // contraction bound up to which defect correction is used
 
 struct Level {
   int m, k, c, P, q;          // size, half bandwidth, interior size, chunks, q = c + k
@@ -49,6 +52,11 @@ struct Banded {
   bool decoupled;             // level-1 system numerically diagonal: skip the middle kernel
   bool upper_done;            // levels >= 1 factored (deferred while a decoupled solve may do)
   bool fast;                  // three-launch path usable (LDS budget)
+  bool fast_plan;             // ... as planned at creation (a factorization may step down)
+  bool wide;                  // half bandwidth 5..8 with chunks: the separator system (half
+                              // bandwidth 2k-1 > KMAX) is only FORMED, to test that its blocks
+                              // decouple; solves run the single-launch decoupled kernel or not
+                              // at all (ipx_banded_status: IPX_EUNSUPPORTED)
   int down_T;                 // chunks per workgroup in k_down0
   size_t lds_down;
   int mid_buf;                // doubles of LDS in k_middle for the level vectors
@@ -59,6 +67,14 @@ struct Banded {
   // flags (device), and the level at which the reduced system is numerically diagonal
   int *pcr_flags;             // PCR_LMAX + 1 ints: bit 0 of [s] = level s still coupled
   int pcr_L;                  // 0: PCR solve not usable
+  // defect correction on the single-launch solve (separator blocks coupled, top level too
+  // long for a serial sweep or not compiled): see iter_solve
+  bool mid_fits;              // k_middle's level vectors fit in LDS
+  bool iter_cand;             // geometry qualifies; iter_buf / eta allocated
+  int iter_N;                 // correction steps per solve (0: mode off), set by ipx_banded_status
+  double *iter_buf;           // 4 m doubles: x (two copies), residual, correction
+  double *eta;                // device: max_t || D_t^-1 [E_t,t-1  E_t,t+1] ||_inf  (block Jacobi)
+  double eta_host;
   std::vector<void *> allocs;
 };
 
@@ -328,6 +344,12 @@ k_correct(int m, int c, int P, const double *__restrict__ V, const double *__res
 // 2^-56 of the diagonal -- it is evaluated in place as (gL + gR) / R_tt and the
 // middle kernel is skipped (checked numerically at every factorization,
 // k = 1 only; see k_decoupling_check).
+// max into a non-negative device double (its bit pattern orders like the value)
+__device__ __forceinline__ void eta_max(double *eta, double v) {
+  if (!(v >= 0.0)) v = 1.0e300;                                   // NaN: no contraction claimed
+  atomicMax((unsigned long long *)eta, (unsigned long long)__double_as_longlong(v));
+}
+
 struct SepValues {
   const double *xs, *gL, *gR, *rinv;
   __device__ __forceinline__ double operator()(int q) const {
@@ -337,7 +359,7 @@ struct SepValues {
 
 __global__ void __launch_bounds__(IPX_BLOCK)
 k_decoupling_check(int mR, const double *__restrict__ Rband, double *__restrict__ rinv,
-                   int *flag) {
+                   int *flag, double *eta) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= mR) return;
   const double d = Rband[t];
@@ -345,7 +367,10 @@ k_decoupling_check(int mR, const double *__restrict__ Rband, double *__restrict_
   const double up = (t + 1 < mR) ? Rband[(int64_t)mR + t + 1] : 0.0;   // R[t+1][t]
   rinv[t] = 1.0 / d;
   const double tiny = 1.3877787807814457e-17;                     // 2^-56
-  if (!(fmax(fabs(lo), fabs(up)) <= tiny * fabs(d))) atomicOr(flag, 2);
+  if (!(fmax(fabs(lo), fabs(up)) <= tiny * fabs(d))) {
+    atomicOr(flag, 2);
+    if (eta) eta_max(eta, (fabs(lo) + fabs(up)) / fabs(d));
+  }
 }
 
 // Block form for half bandwidth K > 1: the separator system is block tridiagonal with
@@ -356,7 +381,7 @@ k_decoupling_check(int mR, const double *__restrict__ Rband, double *__restrict_
 template <int K>
 __global__ void __launch_bounds__(IPX_BLOCK)
 k_decoupling_check_block(int nsep, const double *__restrict__ Rband, double *__restrict__ rinv,
-                         int *flag) {
+                         int *flag, double *eta) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= nsep) return;
   const int mR = nsep * K;
@@ -407,6 +432,42 @@ k_decoupling_check_block(int nsep, const double *__restrict__ Rband, double *__r
     for (int b = 0; b < K; ++b) rinv[((int64_t)t * K + a) * K + b] = Inv[a][b];
   if (coupled) atomicOr(flag, 2);
   if (bad) atomicOr(flag, 1);
+  // contraction bound of block Jacobi on the separator system (what replacing R by its
+  // diagonal blocks costs): max row sum of |D_t^-1 E_t,t-1| + |D_t^-1 E_t,t+1|; only
+  // evaluated by separators with a coupled neighbour
+  bool coupled_up = false;
+  if (eta && t + 1 < nsep) {
+#pragma unroll
+    for (int b = 0; b < K; ++b) {
+      const double db = Rband[(int64_t)(t + 1) * K + b];
+#pragma unroll
+      for (int c = 0; c < K; ++c) {
+        const double v = Rband[(int64_t)(K + b - c) * mR + (int64_t)(t + 1) * K + b];
+        if (!(fabs(v) <= tiny * sqrt(fabs(db * Rband[(int64_t)t * K + c])))) coupled_up = true;
+      }
+    }
+  }
+  if (eta && (coupled || coupled_up)) {
+    double worst = 0.0;
+#pragma unroll
+    for (int a = 0; a < K; ++a) {
+      double rs = 0.0;
+#pragma unroll
+      for (int b = 0; b < K; ++b) {
+        double lo = 0.0, up = 0.0;
+#pragma unroll
+        for (int c = 0; c < K; ++c) {
+          // E_t,t-1[c][b] = R[(t,c)][(t-1,b)];  E_t,t+1[c][b] = R[(t+1,b)][(t,c)]
+          if (t > 0) lo += Inv[a][c] * Rband[(int64_t)(K + c - b) * mR + (int64_t)t * K + c];
+          if (t + 1 < nsep)
+            up += Inv[a][c] * Rband[(int64_t)(K + b - c) * mR + (int64_t)(t + 1) * K + b];
+        }
+        rs += fabs(lo) + fabs(up);
+      }
+      worst = fmax(worst, rs);
+    }
+    if (worst > 0.0) eta_max(eta, worst);
+  }
 }
 
 template <int K>
@@ -1690,16 +1751,16 @@ int level_up(Banded *h, int li, double *x, const double *guard, hipStream_t st) 
   DISPATCH_K(h->lev[li].k, up(h, li, x, guard, st))
 }
 
-// LDS need of the single-launch decoupled solve for this handle's level 0
-size_t decoupled_lds_bytes(const Banded *h) {
-  const Level &l0 = h->lev[0];
-  switch (l0.k) {
-#define DL(kk) case kk: return decoupled_lds_doubles<kk>(l0.q) * sizeof(double)
+// LDS need of the single-launch decoupled solve for half bandwidth k, row pitch q
+size_t decoupled_lds_for(int k, int q) {
+  switch (k) {
+#define DL(kk) case kk: return decoupled_lds_doubles<kk>(q) * sizeof(double)
     DL(1); DL(2); DL(3); DL(4); DL(5); DL(6); DL(7); DL(8);
 #undef DL
   }
   return (size_t)-1;
 }
+size_t decoupled_lds_bytes(const Banded *h) { return decoupled_lds_for(h->lev[0].k, h->lev[0].q); }
 
 bool decoupling_candidate(const Banded *h) {
   return h->fast && h->nlev >= 2 && h->rinv && decoupled_lds_bytes(h) <= LDS_LIMIT;
@@ -1749,7 +1810,13 @@ void *ipx_banded_create(int64_t m64, int32_t k, int32_t chunk) {
   h->nlev = 0;
   h->gL = h->gR = h->slab = h->ybuf = h->rinv = nullptr;
   h->decoupled = false;
-  h->fast = false;
+  h->fast = h->fast_plan = false;
+  h->wide = false;
+  h->mid_fits = false;
+  h->iter_cand = false;
+  h->iter_N = 0;
+  h->iter_buf = h->eta = nullptr;
+  h->eta_host = 0.0;
   h->pcr_flags = nullptr;
   h->pcr_L = 0;
   int m = (int)m64, kk = k;
@@ -1757,17 +1824,28 @@ void *ipx_banded_create(int64_t m64, int32_t k, int32_t chunk) {
   bool ok = true;
   // ---- geometry of every level
   while (true) {
-    if (h->nlev >= MAX_LEVELS || kk > KMAX) { ok = false; break; }
+    if (h->nlev >= MAX_LEVELS || (kk > KMAX && !h->wide)) { ok = false; break; }
     Level &lv = h->lev[h->nlev++];
     lv.m = m; lv.k = kk;
     lv.c = chunk < kk ? kk : chunk;
     // odd row pitch q = c + k: lanes of a wave then hit distinct LDS banks
     if (((lv.c + kk) & 1) == 0) lv.c += 1;
     // The separator system of a level has half bandwidth 2k-1.  When that
-    // would exceed the compiled kernels, stop recursing: this level becomes
-    // one chunk swept by a single lane (only reached for wide bands, where
-    // the level is already small).
-    if (2 * kk - 1 > KMAX && m > lv.c + kk) lv.c = m;
+    // would exceed the compiled kernels there is no recursion below this level:
+    //  * level 0 of a long band (k = 5..8, beyond WIDE_MIN_ROWS rows) is still cut into
+    //    chunks; its separator matrix is formed to test whether its K x K blocks decouple
+    //    numerically (the usual case: the chunk is ~8 bandwidths long), and then the
+    //    single-launch decoupled solve needs nothing above level 0.  If they do not,
+    //    ipx_banded_status says IPX_EUNSUPPORTED and the caller takes another solver;
+    //  * otherwise the level becomes one chunk swept by a single lane (short systems and
+    //    upper levels, where the level is already small).
+    if (h->wide) {                       // the formed-only separator level
+      lv.c = m;
+    } else if (2 * kk - 1 > KMAX && m > lv.c + kk) {
+      if (h->nlev == 1 && m > WIDE_MIN_ROWS && decoupled_lds_for(kk, lv.c + kk) <= LDS_LIMIT)
+        h->wide = true;
+      else lv.c = m;
+    }
     lv.q = lv.c + kk;
     // single chunk when everything fits in one (<= q rows)
     lv.P = (m <= lv.q) ? 1 : (m + lv.q - 1) / lv.q;
@@ -1825,7 +1903,16 @@ void *ipx_banded_create(int64_t m64, int32_t k, int32_t chunk) {
     for (int li = 1; li < h->nlev; ++li) vec += (size_t)h->lev[li].m;
     h->mid_buf = (int)vec;
     h->nslab_lds = ((vec + h->nslab) * sizeof(double) <= LDS_LIMIT) ? (int)h->nslab : 0;
-    h->fast = h->lds_down <= LDS_LIMIT && vec * sizeof(double) <= LDS_LIMIT;
+    h->mid_fits = vec * sizeof(double) <= LDS_LIMIT;
+    const bool long_top = h->wide || (h->nlev >= 2 && h->lev[h->nlev - 1].m > ITER_TOP_MIN_ROWS);
+    h->fast = h->lds_down <= LDS_LIMIT && (long_top || h->mid_fits);
+    h->fast_plan = h->fast;
+    h->iter_cand = h->fast && long_top && decoupled_lds_for(l0.k, l0.q) <= LDS_LIMIT;
+    if (h->iter_cand) {
+      h->iter_buf = dalloc<double>(h, (size_t)4 * l0.m + 1);
+      if (!h->iter_buf) ok = false;
+      else h->eta = h->iter_buf + (size_t)4 * l0.m;
+    }
     if (h->fast && l0.mR > 0) {
       h->gL = dalloc<double>(h, l0.mR);
       h->gR = dalloc<double>(h, l0.mR);
@@ -1861,6 +1948,7 @@ int ipx_banded_factor(void *handle, const double *band, void *stream) {
   if (hipMemsetAsync(h->flag, 0, sizeof(int), st) != hipSuccess) return IPX_ELAUNCH;
   h->lev[0].band = const_cast<double *>(band);
   h->decoupled = false;
+  h->fast = h->fast_plan;
   // Level 0 and the separator (Schur complement) matrix first.  When the
   // decoupled path is a candidate the upper levels wait for its verdict
   // (ipx_banded_status): a decoupled solve never touches them.
@@ -1877,18 +1965,20 @@ int ipx_banded_factor(void *handle, const double *band, void *stream) {
                        st, l0.m, DEC_CHUNKS * l0.q, band, h->pcr_flags);
     IPX_CHECK_LAUNCH();
   }
+  h->iter_N = 0;
   if (decoupling_candidate(h)) {
+    if (h->eta && hipMemsetAsync(h->eta, 0, sizeof(double), st) != hipSuccess) return IPX_ELAUNCH;
     const int mR = h->lev[0].mR, K0 = h->lev[0].k, nsep = mR / K0;
     const dim3 grid((nsep + IPX_BLOCK - 1) / IPX_BLOCK), block(IPX_BLOCK);
     switch (K0) {
       case 1:
         hipLaunchKernelGGL(k_decoupling_check, grid, block, 0, st, mR, h->lev[1].band, h->rinv,
-                           h->flag);
+                           h->flag, h->eta);
         break;
 #define DC(kk)                                                                              \
   case kk:                                                                                  \
     hipLaunchKernelGGL(k_decoupling_check_block<kk>, grid, block, 0, st, nsep, h->lev[1].band, \
-                       h->rinv, h->flag);                                                   \
+                       h->rinv, h->flag, h->eta);                                           \
     break
       DC(2); DC(3); DC(4); DC(5); DC(6); DC(7); DC(8);
 #undef DC
@@ -1917,6 +2007,24 @@ int ipx_banded_status(void *handle, void *stream) {
       if (!(pf[s] & 1)) { h->pcr_L = s; break; }
     }
   }
+  h->iter_N = 0;
+  if (!h->decoupled && h->iter_cand && decoupling_candidate(h) && !(f & 1)) {
+    // coupled separator blocks and a top level that is long (or not compiled): solves become
+    // defect correction on the single-launch solve when block Jacobi contracts fast enough
+    double eta = 0.0;
+    if (hipMemcpyAsync(&eta, h->eta, sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+      return IPX_ELAUNCH;
+    h->eta_host = eta;
+    if (eta > 0.0 && eta < ITER_ETA_MAX) {
+      // x_0 = M^-1 w is off by eta, every step gains another factor: eta^(N+1) <= 2^-54
+      int N = (int)ceil(54.0 * 0.6931471805599453 / -log(eta)) - 1;
+      h->iter_N = N < 1 ? 1 : N;
+    }
+  }
+  if (h->iter_N > 0) return IPX_OK;
+  if (h->wide && !h->decoupled) return (f & 1) ? IPX_ENOTSPD : IPX_EUNSUPPORTED;
+  if (!h->decoupled && !h->mid_fits) h->fast = false;     // level by level (k_middle needs LDS)
   if (!h->decoupled && !h->upper_done && !(f & 1)) {
     int rc = factor_upper(h, st);
     if (rc != IPX_OK) return rc;
@@ -1938,6 +2046,15 @@ int ipx_banded_set_decoupling(void *handle, int allow) {
   if (allow > 16 && allow <= 16 + PCR_LMAX && ((Banded *)handle)->pcr_L > 0)
     ((Banded *)handle)->pcr_L = allow - 16;
   return IPX_OK;
+}
+
+// Correction steps per solve when this factorization runs defect correction on the
+// single-launch solve (coupled separator blocks, no usable separator level), else 0;
+// *eta (optional) receives the measured block-Jacobi contraction bound.
+int ipx_banded_refine_steps(void *handle, double *eta) {
+  if (!handle) return 0;
+  if (eta) *eta = ((Banded *)handle)->eta_host;
+  return ((Banded *)handle)->iter_N;
 }
 
 // Level at which the cyclic reduction of this factorization's matrix has decoupled (the
@@ -2029,6 +2146,80 @@ int launch_correct_oop(Banded *h, double *x, const double *w, double *partial, i
   return IPX_OK;
 }
 
+// r = w - S (xa + d), xb = xa + d   (d == nullptr: r = w - S xa only)
+__global__ void __launch_bounds__(IPX_BLOCK)
+k_band_update_resid(int m, int k, const double *__restrict__ band, const double *__restrict__ w,
+                    const double *__restrict__ xa, const double *__restrict__ d,
+                    double *__restrict__ xb, double *__restrict__ r,
+                    const double *__restrict__ guard) {
+  if (guard && *guard != 0.0) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  auto X = [&](int j) { return d ? xa[j] + d[j] : xa[j]; };
+  const double xi = X(i);
+  double s = band[i] * xi;
+  for (int dd = 1; dd <= k; ++dd) {
+    if (i - dd >= 0) s += band[(int64_t)dd * m + i] * X(i - dd);
+    if (i + dd < m) s += band[(int64_t)dd * m + i + dd] * X(i + dd);
+  }
+  if (xb) xb[i] = xi;
+  r[i] = w[i] - s;
+}
+
+__global__ void __launch_bounds__(IPX_BLOCK)
+k_band_add(int m, const double *__restrict__ xa, const double *__restrict__ d,
+           double *__restrict__ x, const double *__restrict__ guard) {
+  if (guard && *guard != 0.0) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < m) x[i] = xa[i] + d[i];
+}
+
+int solve_decoupled_k(const LevDev &lv, const double *w, double *x, const double *rinv,
+                      const double *guard, hipStream_t st) {
+  switch (lv.k) {
+#define SD(kk) case kk: return launch_solve_decoupled<kk>(lv, w, x, rinv, nullptr, nullptr, guard, st)
+    SD(1); SD(2); SD(3); SD(4); SD(5); SD(6); SD(7); SD(8);
+#undef SD
+  }
+  return IPX_EINVAL;
+}
+
+// Defect correction on the single-launch solve.  With coupled separator blocks that kernel
+// applies M^-1, where M is S with the separator system R replaced by its diagonal blocks
+// (exactly: every workgroup computes its separators from its own halo chunks), and
+// I - M^-1 S contracts like block Jacobi on R: rho <= eta, measured at the factorization
+// (k_decoupling_check_block).  N steps of  x <- x + M^-1 (w - S x)  with N fixed from eta
+// (ipx_banded_status) give S^-1 w to working precision without a separator level, without
+// host synchronisation and bitwise reproducibly -- instead of a serial sweep over the
+// (P-1) k separator rows by one lane (1.7 ms at m = 1e5, k = 3; no compiled kernel at all
+// for k >= 5).
+int iter_solve(Banded *h, const double *w, double *x, double *partial, int *npartial,
+               const double *guard, hipStream_t st) {
+  const LevDev lv = to_dev(h->lev[0], nullptr);
+  const int m = lv.m;
+  double *xa = h->iter_buf, *xb = xa + m, *r = xb + m, *d = r + m;
+  const dim3 grid((m + IPX_BLOCK - 1) / IPX_BLOCK), block(IPX_BLOCK);
+  int rc = solve_decoupled_k(lv, w, xa, h->rinv, guard, st);
+  if (rc != IPX_OK) return rc;
+  hipLaunchKernelGGL(k_band_update_resid, grid, block, 0, st, m, lv.k, lv.band, w, xa,
+                     (const double *)nullptr, (double *)nullptr, r, guard);
+  IPX_CHECK_LAUNCH();
+  for (int it = 1; it <= h->iter_N; ++it) {
+    rc = solve_decoupled_k(lv, r, d, h->rinv, guard, st);
+    if (rc != IPX_OK) return rc;
+    if (it < h->iter_N) {
+      hipLaunchKernelGGL(k_band_update_resid, grid, block, 0, st, m, lv.k, lv.band, w, xa, d, xb, r,
+                         guard);
+      double *t = xa; xa = xb; xb = t;
+    } else {
+      hipLaunchKernelGGL(k_band_add, grid, block, 0, st, m, xa, d, x, guard);
+    }
+    IPX_CHECK_LAUNCH();
+  }
+  if (partial) return ipx_banded_residual_launch(h, w, x, partial, npartial, guard, st);
+  return IPX_OK;
+}
+
 // Fast path.  `partial` != NULL additionally yields per-workgroup sums of
 // ||w - S x||^2 (needs x != w).
 int fast_solve(Banded *h, const double *w, double *x, double *partial, int *npartial,
@@ -2049,6 +2240,11 @@ int fast_solve(Banded *h, const double *w, double *x, double *partial, int *npar
     }
     return IPX_EINVAL;
   }
+  if (h->iter_N > 0 && !h->decoupled) {
+    if (w == x) return IPX_EINVAL;
+    return iter_solve(h, w, x, partial, npartial, guard, st);
+  }
+  if (h->wide) return IPX_EUNSUPPORTED;      // no compiled separator level (see ipx_banded_create)
   int rc = fast_down0(h, w, h->ybuf, guard, st);
   if (rc != IPX_OK) return rc;
   if (!decoupled_scalar(h)) {
@@ -2076,7 +2272,7 @@ int ipx_banded_resid_count(void *handle) {
   const Level &l0 = h->lev[0];
   if (h->fast && h->nlev > 1 && h->decoupled)
     return (l0.P + DEC_CHUNKS - 1) / DEC_CHUNKS;
-  if (h->fast && h->nlev > 1) return (l0.m + IPX_BLOCK - 1) / IPX_BLOCK;
+  if (h->fast && h->nlev > 1 && h->iter_N == 0) return (l0.m + IPX_BLOCK - 1) / IPX_BLOCK;
   const int grid = (l0.m + IPX_BLOCK - 1) / IPX_BLOCK;           // k_band_residual
   return grid > 256 ? 256 : grid;
 }
@@ -2131,6 +2327,7 @@ int ipx_banded_solve_guarded(void *handle, const double *w, double *x, const dou
   if (!handle || !w || !x) return IPX_EINVAL;
   Banded *h = (Banded *)handle;
   if (h->fast) return fast_solve(h, w, x, nullptr, nullptr, guard, st);
+  if (h->wide) return IPX_EUNSUPPORTED;
   if (!h->upper_done) {             // deferred by ipx_banded_factor (decoupled candidate)
     int rc = factor_upper(h, st);
     if (rc != IPX_OK) return rc;

@@ -56,6 +56,7 @@ _SIGNATURES = {
     "ipx_banded_levels": [_P],
     "ipx_banded_decoupled": [_P],
     "ipx_banded_pcr_level": [_P],
+    "ipx_banded_refine_steps": [_P, _P],
     "ipx_banded_set_decoupling": [_P, _c.c_int],
     "ipx_banded_factor": [_P, _P, _P],
     "ipx_banded_status": [_P, _P],
@@ -91,7 +92,8 @@ class IpxError(RuntimeError):
 
 
 _ERRORS = {-1: "invalid argument", -2: "HIP launch/runtime error",
-           -3: "matrix is not positive definite", -4: "out of memory"}
+           -3: "matrix is not positive definite", -4: "out of memory",
+           -5: "no path in this solver for the matrix at hand"}
 
 
 def load():

@@ -80,6 +80,11 @@ def _symbolic_for(pattern):
     return sym
 
 
+class BandedNotDecoupled(NotImplementedError):
+    """Half bandwidth 5..8 on a long band whose separator blocks do not decouple numerically
+    (csrc/banded.hip ipx_banded_create: there is no compiled separator level for them)."""
+
+
 class BandedNormalSolver:
     """(A A')^-1 for sparse A with banded A A' (half bandwidth <= kmax)."""
 
@@ -124,6 +129,9 @@ class BandedNormalSolver:
         rc = lib.ipx_banded_status(ctypes.c_void_p(self.handle), stream_ptr())
         if rc == -3:
             raise np.linalg.LinAlgError("Singular Jacobian matrix: A A' is not positive definite")
+        if rc == -5:
+            raise BandedNotDecoupled("A A' (m=%d, half bandwidth %d): separator blocks of the "
+                                     "partitioned factorization are coupled" % (self.m, self.k))
         _hip.check(rc, "ipx_banded_status")
 
     POOL_MAX = 4
@@ -440,10 +448,6 @@ def as_device_matrix(A):
     return DeviceDense.from_host(np.asarray(A, dtype=float))
 
 
-BANDED_SINGLE_CHUNK_K = 5          # half bandwidth from which the banded solver is one serial chunk
-BANDED_SINGLE_CHUNK_ROWS = 8192
-
-
 def normal_solver_for(A):
     """The ``(A A')^-1`` solver ``projections`` picks for a full-row-rank device matrix."""
     from .dense import DenseNormalSolver, DeviceDense
@@ -452,15 +456,17 @@ def normal_solver_for(A):
     kmax = _hip.load().ipx_banded_kmax()
     m = A.shape[0]
     k = _symbolic_for(A.pattern).k
-    # Half bandwidths 5-8 have no separator level in csrc/banded.hip (its reduced system would
-    # be wider than the compiled kernels): the whole band is one chunk swept by a single lane,
-    # 80-100 ms per solve at m = 1e5.  Beyond a few thousand rows the device-resident
-    # preconditioned CG is 20x faster there (scripts/bench_banded_k.py,
-    # profiles/r02_banded_by_bandwidth.txt) and as accurate after the projector's refinement.
-    if k <= kmax and not (k >= BANDED_SINGLE_CHUNK_K and m > BANDED_SINGLE_CHUNK_ROWS):
-        return BandedNormalSolver(A)
-    if k <= kmax and m > DenseNormalSolver.MAX_ROWS_FROM_SPARSE:
-        return IterativeNormalSolver(A)
+    if k <= kmax:
+        try:
+            return BandedNormalSolver(A)
+        except BandedNotDecoupled:
+            # Half bandwidths 5-8 on a long band run the single-launch decoupled solve (the
+            # separator system, half bandwidth 2k-1, is only formed to test that its blocks
+            # decouple).  When they do not, a serial sweep would take 80-100 ms per solve at
+            # m = 1e5: the device-resident preconditioned CG is 20x faster and as accurate
+            # after the projector's refinement (profiles/r02_banded_by_bandwidth.txt).
+            if m > DenseNormalSolver.MAX_ROWS_FROM_SPARSE:
+                return IterativeNormalSolver(A)
     if _box_schur_applies(A, kmax):
         from .boxschur import BoxSchurNormalSolver
         return BoxSchurNormalSolver(A)          # bound rows eliminated analytically

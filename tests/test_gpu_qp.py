@@ -671,7 +671,8 @@ def test_single_launch_banded_solve_with_block_separators(ips, k):
     lib = _hip.load()
     # whether the separator blocks decouple is a property of the numbers (checked at every
     # factorization); for these matrices they do at k = 2, 3.  Half bandwidths beyond 4 have
-    # no separator level (2k-1 > 8: one chunk).  Either way the result must be right.
+    # no compiled separator level (2k-1 > 8): decoupled, or defect correction on the
+    # single-launch solve (test_banded_defect_correction).  Either way the result must be right.
     if solver.k == 2:
         assert lib.ipx_banded_decoupled(ctypes.c_void_p(solver.handle)) == 1
     w = rng.standard_normal(m)
@@ -679,6 +680,8 @@ def test_single_launch_banded_solve_with_block_separators(ips, k):
     v = host(solver.solve(wd))
     vref = spla.spsolve(S, w)
     assert np.max(np.abs(v - vref)) <= 1e-10 * np.max(np.abs(vref))
+    if solver.k >= 5:
+        return                      # no level-by-level sweep to compare with
     v2 = ips.dv.DVec.zeros(m)
     _hip.call("ipx_banded_solve_multilaunch", ctypes.c_void_p(solver.handle), ips.dv._p(wd.t),
               ips.dv._p(v2.t), ips.dv.stream_ptr())
@@ -911,27 +914,110 @@ def test_trust_region_norm_by_recurrence(ips, monkeypatch):
         assert np.max(np.abs(x0 - x1)) <= 1e-13 * np.max(np.abs(x0))
 
 
-def test_wide_band_takes_the_iterative_solver(ips):
-    """Half bandwidth 6 at m = 20000: inside what the banded factorization accepts, but there it
-    is a single chunk swept by one lane (80 ms per solve at m = 1e5); ``projections`` routes
-    such Jacobians to the device-resident preconditioned CG (2.5 ms,
-    profiles/r02_banded_by_bandwidth.txt).  Same operators: against the oracle."""
-    import oracle
-    from ipsolver.projector import IterativeNormalSolver, _symbolic_for
-    rng = np.random.default_rng(6)
-    m, k = 20000, 6
-    cols = (4 * np.arange(m)[:, None] + np.arange(4 * k)[None, :]).ravel()
-    A = sps.csr_matrix((rng.standard_normal(len(cols)), (np.repeat(np.arange(m), 4 * k), cols)),
-                       shape=(m, 4 * m + 4 * k))
+@pytest.mark.parametrize("kA", [4, 5, 6, 7, 8, 9])
+def test_banded_defect_correction(ips, kA):
+    """Half bandwidths 3..8 at m = 1e5.  The separator system of the
+    partitioned factorization has half bandwidth 2k-1: a serial sweep over 4200..11000 rows
+    for k = 3, 4 (1.7 / 3.0 ms per solve in round 1) and no compiled kernel at all for
+    k >= 5 (the whole band was one serially swept chunk: 80-100 ms).  Now the separator
+    matrix is only formed, the contraction of block Jacobi on it is measured at the
+    factorization (eta), and a solve is N(eta) steps of defect correction on the
+    single-launch solve (csrc/banded.hip iter_solve): 34-180 us.  Against a sparse LU, the
+    fused residual against numpy, bitwise reproducible, through ``projections``."""
+    import ctypes
+    import torch
+    import scipy.sparse.linalg as spla
+    from ipsolver import _hip
+    from ipsolver.projector import BandedNormalSolver
+    rng = np.random.default_rng(kA)
+    m = 100000
+    cols = (4 * np.arange(m)[:, None] + np.arange(4 * kA)[None, :]).ravel()
+    A = sps.csr_matrix((rng.standard_normal(len(cols)), (np.repeat(np.arange(m), 4 * kA), cols)),
+                       shape=(m, 4 * m + 4 * kA))
     Ad = ips.dv.DeviceCSR.from_scipy(A)
-    assert 5 <= _symbolic_for(Ad.pattern).k <= 8
+    Z, LS, Y = ips.proj.projections(Ad)
+    solver = Z.projector.solver
+    assert isinstance(solver, BandedNormalSolver) and solver.k == kA - 1
+    lib = _hip.load()
+    h = ctypes.c_void_p(solver.handle)
+    eta = ctypes.c_double(0.0)
+    steps = lib.ipx_banded_refine_steps(h, ctypes.byref(eta))
+    assert lib.ipx_banded_decoupled(h) == 1 or (1 <= steps <= 8 and 0 < eta.value < 1e-3)
+    S = (A @ A.T).tocsc()
+    w = rng.standard_normal(m)
+    wd = ips.dv.DVec.from_host(w)
+    v = host(solver.solve(wd))
+    vref = spla.splu(S).solve(w)
+    assert np.max(np.abs(v - vref)) <= 1e-12 * np.max(np.abs(vref))
+    assert np.array_equal(v, host(solver.solve(wd)))
+    # the solve + residual form the CG loop uses
+    out = torch.empty(m, dtype=torch.float64, device="cuda")
+    part = torch.zeros((m + 255) // 256 + 1, dtype=torch.float64, device="cuda")
+    npart = ctypes.c_int32(0)
+    _hip.call("ipx_banded_solve_resid", h, ips.dv._p(wd.t), ips.dv._p(out), ips.dv._p(part),
+              ctypes.byref(npart), None, ips.dv.stream_ptr())
+    assert np.array_equal(out.cpu().numpy(), v)
+    res2 = float(part[:npart.value].sum().item())
+    assert res2 <= 1e-24 * float(np.sum(w ** 2)) * S.shape[0]
+    # the operators
+    x = rng.standard_normal(A.shape[1])
+    z = host(Z.dot(x))
+    assert np.max(np.abs(A @ z)) <= 1e-11 * np.max(np.abs(x)) * np.sqrt(4 * kA)
+
+
+def _moving_average_rows(m, k, eps, rng):
+    """Row i = k+1 nearly equal weights on columns i..i+k plus ``eps`` on a private column:
+    S = A A' is the triangle-kernel Toeplitz matrix + eps^2 I, half bandwidth k, whose
+    inverse decays the more slowly the smaller eps is (cond ~ (k+1)^2 / eps^2)."""
+    cols = (np.arange(m)[:, None] + np.arange(k + 1)[None, :]).ravel()
+    rows = np.repeat(np.arange(m), k + 1)
+    vals = (1.0 + 0.01 * rng.standard_normal((m, k + 1))).ravel()
+    return sps.csr_matrix((np.concatenate((vals, np.full(m, eps))),
+                           (np.concatenate((rows, np.arange(m))),
+                            np.concatenate((cols, m + k + np.arange(m))))), shape=(m, 2 * m + k))
+
+
+def test_banded_defect_correction_many_steps(ips):
+    """A slowly decaying inverse (half bandwidth 6, contraction bound 0.26): 27 correction
+    steps still give the direct solve to 1e-13."""
+    import ctypes
+    import scipy.sparse.linalg as spla
+    from ipsolver import _hip
+    from ipsolver.projector import BandedNormalSolver
+    rng = np.random.default_rng(6)
+    m = 20000
+    A = _moving_average_rows(m, 6, 0.3, rng)
+    solver = BandedNormalSolver(ips.dv.DeviceCSR.from_scipy(A))
+    eta = ctypes.c_double(0.0)
+    steps = _hip.load().ipx_banded_refine_steps(ctypes.c_void_p(solver.handle), ctypes.byref(eta))
+    assert solver.k == 6 and 10 <= steps <= 54 and 0.05 < eta.value < 0.5
+    w = rng.standard_normal(m)
+    v = host(solver.solve(ips.dv.DVec.from_host(w)))
+    vref = spla.splu((A @ A.T).tocsc()).solve(w)
+    assert np.max(np.abs(v - vref)) <= 1e-12 * np.max(np.abs(vref))
+
+
+def test_coupled_wide_band_takes_the_iterative_solver(ips):
+    """Half bandwidth 6 with chunks that do NOT decouple (a slowly decaying inverse): block
+    Jacobi on the separators is not known to contract fast enough (bound >= 0.5), the banded
+    solver reports IPX_EUNSUPPORTED and ``projections`` takes the device-resident
+    preconditioned CG.  Same operators: against the oracle."""
+    import oracle
+    from ipsolver.projector import (BandedNormalSolver, BandedNotDecoupled, IterativeNormalSolver,
+                                    _symbolic_for)
+    rng = np.random.default_rng(6)
+    m = 20000
+    A = _moving_average_rows(m, 6, 0.1, rng)
+    Ad = ips.dv.DeviceCSR.from_scipy(A)
+    assert _symbolic_for(Ad.pattern).k == 6
+    with pytest.raises(BandedNotDecoupled):
+        BandedNormalSolver(Ad)
     Z, LS, Y = ips.proj.projections(Ad)
     assert isinstance(Z.projector.solver, IterativeNormalSolver)
     Zo, LSo, Yo = oracle.projections(A)
-    x, b = rng.standard_normal(A.shape[1]), rng.standard_normal(m)
-    close(Z.dot(x), Zo.dot(x), 1e-9)
-    close(LS.dot(x), LSo.dot(x), 1e-9)
-    close(Y.dot(b), Yo.dot(b), 1e-9)
+    x = rng.standard_normal(A.shape[1])
+    close(Z.dot(x), Zo.dot(x), 1e-8)
+    close(Y.dot(A @ x), Yo.dot(A @ x), 1e-8)
 
 
 @pytest.mark.parametrize("hessian", ["dense", "csr"])
