@@ -329,10 +329,11 @@ int ipx_aat_band_w(int64_t m, int32_t k, const int32_t *rowptr, const int32_t *c
  * of one or two rows that touch the same shared column (plus a private entry
  * each).  factor: 1x1 / 2x2 inverses, the rows' shared-column entries (alpha)
  * and the Schur column weights 1 - alpha'B^-1 alpha; tsolve: t = B^-1 w on those
- * rows and u[col] = alpha't; vsolve: v = t - B^-1 (alpha * y[col]). */
+ * rows and u[col] = alpha't; vsolve: v = t - B^-1 (alpha * y[col]).  grp (may be NULL):
+ * 4 doubles per group, the rows' entries (a_p, s_p, a_q, s_q) for ipx_boxschur_project. */
 int ipx_pairs_factor(int32_t ng, const int32_t *rowp, const int32_t *rowq, const int32_t *pos_a,
                      const int32_t *pos_s, const double *val, const int32_t *col, double *alpha,
-                     double *inv, double *weight_col, int *flag, void *stream);
+                     double *inv, double *weight_col, int *flag, double *grp, void *stream);
 int ipx_pairs_tsolve(int32_t ng, const int32_t *rowp, const int32_t *rowq, const double *inv,
                      const double *alpha, const double *w, double *t, const int32_t *col,
                      double *u, void *stream);
@@ -349,10 +350,27 @@ typedef struct ipx_boxschur_args {
   const int32_t *ARt_rowptr, *ARt_colidx; const double *ARt_val; const int32_t *ARt_tiles; int64_t ARt_ntiles;
   void *inner;                       /* ipx_banded handle of the Schur complement */
   double *t, *u, *wR, *rhs, *vR, *y; /* scratch: m, n, mR, mR, mR, n doubles */
+  /* group tables for ipx_boxschur_project (NULL: only ipx_boxschur_solve is available):
+   * gcol = 3 ints per group (shared column, private column of row p, of row q; -1: the row
+   * has none, -2 in the q slot: single-row group),
+   * grp = 4 doubles per group (a_p, s_p, a_q, s_q; written by ipx_pairs_factor),
+   * gen_cols = the ngen columns that belong to no group, ny = 1 + last column A_R touches,
+   * up = n doubles of scratch (zero beyond ny). */
+  const int32_t *gcol; const double *grp; const int32_t *gen_cols; int64_t ngen;
+  int64_t ny;
+  double *up;
 } ipx_boxschur_args;
 /* v = (A A')^-1 w; partial (optional, ceil(mR/256) doubles) receives the residual partials. */
 int ipx_boxschur_solve(const ipx_boxschur_args *a, const double *w, double *v, double *partial,
                        int32_t *npartial, const double *guard, void *stream);
+/* g = r - A'(A A')^-1 A r (the CG loop's projection; g may alias r) with the simple rows
+ * handled per group on r itself instead of as matrix rows: 6 launches and ~1/3 of the traffic
+ * of  A r -> ipx_boxschur_solve -> r - A'v.  part_g: 2 x ipx_boxschur_project_count(a) doubles
+ * (||g||^2 partials; second half zero), part_res / npart_res as ipx_boxschur_solve's. */
+int ipx_boxschur_project_count(const ipx_boxschur_args *a);
+int ipx_boxschur_project(const ipx_boxschur_args *a, const double *r, double *g, double *part_g,
+                         int32_t *npart_g, double *part_res, int32_t *npart_res,
+                         const double *guard, void *stream);
 
 #ifdef __cplusplus
 }

@@ -31,32 +31,25 @@ k_pairs_factor(int ng, const int32_t *__restrict__ rowp, const int32_t *__restri
                const int32_t *__restrict__ pos_a, const int32_t *__restrict__ pos_s,
                const double *__restrict__ val, double *__restrict__ alpha,
                double *__restrict__ inv, double *__restrict__ weight_col,
-               const int32_t *__restrict__ col, int *flag) {
+               const int32_t *__restrict__ col, int *flag, double *__restrict__ grp) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= ng) return;
   const int p = rowp[g], q = rowq[g];
   const double ap = val[pos_a[p]];
   const double sp = pos_s[p] >= 0 ? val[pos_s[p]] : 0.0;
   alpha[p] = ap;
-  const double b11 = ap * ap + sp * sp;
-  double wgt;      // 1 - alpha' B^-1 alpha, in its cancellation-free form
-  if (q < 0) {
-    if (!(b11 > 0.0)) atomicOr(flag, 1);
-    inv[3 * g] = 1.0 / b11; inv[3 * g + 1] = 0.0; inv[3 * g + 2] = 0.0;
-    wgt = sp * sp / b11;
-  } else {
-    const double aq = val[pos_a[q]];
-    const double sq = pos_s[q] >= 0 ? val[pos_s[q]] : 0.0;
+  double aq = 0.0, sq = 0.0;
+  if (q >= 0) {
+    aq = val[pos_a[q]];
+    sq = pos_s[q] >= 0 ? val[pos_s[q]] : 0.0;
     alpha[q] = aq;
-    const double b22 = aq * aq + sq * sq, b12 = ap * aq;
-    // (ap^2+sp^2)(aq^2+sq^2) - (ap aq)^2 without the cancellation (slacks of active bounds
-    // are ~1e-8 next to ap = aq = 1)
-    const double det = ap * ap * (sq * sq) + sp * sp * (aq * aq) + sp * sp * (sq * sq);
-    if (!(det > 0.0) || !(b11 > 0.0)) atomicOr(flag, 1);
-    const double i11 = b22 / det, i12 = -b12 / det, i22 = b11 / det;
-    inv[3 * g] = i11; inv[3 * g + 1] = i12; inv[3 * g + 2] = i22;
-    wgt = (sp * sp) * (sq * sq) / det;
   }
+  if (grp) {                 // (ap, sp, aq, sq) per group: what the fused projection reads
+    grp[4 * g] = ap; grp[4 * g + 1] = sp; grp[4 * g + 2] = aq; grp[4 * g + 3] = sq;
+  }
+  double i11, i12, i22, wgt;
+  if (!ipx_group_inverse(q >= 0, ap, sp, aq, sq, i11, i12, i22, wgt)) atomicOr(flag, 1);
+  inv[3 * g] = i11; inv[3 * g + 1] = i12; inv[3 * g + 2] = i22;
   weight_col[col[g]] = wgt;
 }
 
@@ -162,7 +155,186 @@ k_pairs_vsolve_scatter(int ng, int mR, const int32_t *__restrict__ rowp,
   }
 }
 
+// ---- the whole projection g = r - A'(A A')^-1 A r without the simple rows ever being
+// multiplied as matrix rows (the CG loop's use).  The simple rows' part
+// of w = A r, of the solve and of A'v is per-group arithmetic on r itself:
+//   pre :  w_p, w_q from r (the rows' one or two entries) -> t = B^-1 w_S -> u = r - alpha't
+//   ...    rhs = A_R u (= A_R r - A_R alpha't),  v_R = Sigma^-1 rhs,  y = A_R' v_R   (general rows)
+//   post:  y_c = (A_R' v_R)_c from the column's few entries, w, t recomputed,
+//          v_S = t - B^-1 (alpha y[col]);  g on the group's columns
+//          (shared column: r - (y + a_p v_p + a_q v_q); private columns: r - s v), and
+//          g = r - y on the columns that belong to no group; ||g||^2 partials.
+// The simple rows' values are formed with the operation order of the SpMV-based path (row
+// sums left to right, y = alpha * sum + beta * yin; general rows before the simple ones in
+// a column of A' -- true of the barrier problem's [nonlinear; lower; upper] row order); the
+// Schur right-hand side and the ||g||^2 partial sums are associated differently, so the two
+// paths agree to rounding, not bitwise.
+// u <- r - (alpha't on the shared columns, 0 elsewhere), on the columns A_R touches
+// ([0, ny)): the Schur right-hand side is then ONE product, rhs = A_R u = A_R r - A_R (alpha't).
+__global__ void __launch_bounds__(IPX_BLOCK)
+k_pairs_pre(int ng, int ngen, ipx_group_tab T, const int32_t *__restrict__ gen_cols, int ny,
+            const double *__restrict__ r, double *__restrict__ u,
+            const double *__restrict__ guard) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (guard && *guard != 0.0) return;
+  if (g >= ng) {
+    if (g - ng < ngen) {
+      const int c = gen_cols[g - ng];
+      if (c < ny) u[c] = r[c];
+    }
+    return;
+  }
+  int c, cp, cq;
+  double ap, sp, aq, sq, rc, rp, rq, wp, wq;
+  ipx_group_w(T, g, r, c, cp, cq, ap, sp, aq, sq, rc, rp, rq, wp, wq);
+  double i11, i12, i22, wgt, ut;
+  ipx_group_inverse(cq != -2, ap, sp, aq, sq, i11, i12, i22, wgt);
+  if (cq == -2) {
+    ut = ap * (i11 * wp);
+  } else {
+    const double tp = i11 * wp + i12 * wq;
+    const double tq = i12 * wp + i22 * wq;
+    ut = ap * tp + aq * tq;
+  }
+  if (c < ny) u[c] = rc - ut;
+}
+
+constexpr int POST_ITEMS = 4;      // items per thread: 1024 per workgroup = one partial
+
+__global__ void __launch_bounds__(IPX_BLOCK)
+k_pairs_post(int ng, int ngen, ipx_group_tab T, const int32_t *__restrict__ gen_cols,
+             const double *r, const int32_t *__restrict__ yrp,
+             const int32_t *__restrict__ ycol, const double *__restrict__ yval,
+             const double *__restrict__ vR, int ny, double *gout,
+             double *__restrict__ part, int npart, const double *__restrict__ guard) {
+  __shared__ double lds[IPX_BLOCK / IPX_WAVE];
+  if (guard && *guard != 0.0) return;
+  // y_c = (A_R' v_R)_c: the column's few general-row entries, summed left to right like the
+  // SpMV's row sum (columns beyond ny are touched by no general row)
+  auto ycolumn = [&](int c) {
+    double sum = 0.0;
+    if (c < ny) {
+      const int b = yrp[c + 1];
+      for (int k = yrp[c]; k < b; ++k) sum += yval[k] * vR[ycol[k]];
+    }
+    return 1.0 * sum;
+  };
+  double acc = 0.0;
+  const int nitems = ng + ngen;
+#pragma unroll 2
+  for (int k = 0; k < POST_ITEMS; ++k) {
+    const int i = (blockIdx.x * POST_ITEMS + k) * IPX_BLOCK + threadIdx.x;
+    if (i >= nitems) continue;
+    // all independent loads first: tables, r on the item's columns, the row pointers of y
+    const bool grp = i < ng;
+    int c, cp = -1, cq = -1;
+    double ap = 0.0, sp = 0.0, aq = 0.0, sq = 0.0;
+    if (grp) {
+      c = T.gcol[3 * i]; cp = T.gcol[3 * i + 1]; cq = T.gcol[3 * i + 2];
+      ap = T.grp[4 * i]; sp = T.grp[4 * i + 1]; aq = T.grp[4 * i + 2]; sq = T.grp[4 * i + 3];
+    } else {
+      c = gen_cols[i - ng];
+    }
+    const double rc = r[c];
+    const double rp = cp >= 0 ? r[cp] : 0.0;
+    const double rq = cq >= 0 ? r[cq] : 0.0;
+    const double yj = ycolumn(c);
+    if (grp) {
+      const bool has_q = cq != -2;
+      double i11, i12, i22, wgt;
+      ipx_group_inverse(has_q, ap, sp, aq, sq, i11, i12, i22, wgt);
+      const double wp = cp < 0 ? ap * rc : (cp > c ? ap * rc + sp * rp : sp * rp + ap * rc);
+      const double wq = cq < 0 ? aq * rc : (cq > c ? aq * rc + sq * rq : sq * rq + aq * rc);
+      const double ep = ap * yj;
+      double vp, vq = 0.0;
+      if (!has_q) {
+        const double tp = i11 * wp;
+        vp = tp - i11 * ep;
+      } else {
+        const double tp = i11 * wp + i12 * wq;
+        const double tq = i12 * wp + i22 * wq;
+        const double eq = aq * yj;
+        vp = tp - (i11 * ep + i12 * eq);
+        vq = tq - (i12 * ep + i22 * eq);
+      }
+      // column c of A': general rows (y), then row p, then row q
+      double sum = yj + ap * vp;
+      if (has_q) sum += aq * vq;
+      double gc = -1.0 * sum;
+      gc += 1.0 * rc;
+      gout[c] = gc;
+      acc += gc * gc;
+      if (cp >= 0) {
+        double gp = -1.0 * (sp * vp);
+        gp += 1.0 * rp;
+        gout[cp] = gp;
+        acc += gp * gp;
+      }
+      if (cq >= 0) {
+        double gq = -1.0 * (sq * vq);
+        gq += 1.0 * rq;
+        gout[cq] = gq;
+        acc += gq * gq;
+      }
+    } else {
+      double gc = -1.0 * yj;
+      gc += 1.0 * rc;
+      gout[c] = gc;
+      acc += gc * gc;
+    }
+  }
+  const double tot = ipx_block_reduce<IPX_SUM>(acc, lds);
+  if (threadIdx.x == 0) {
+    part[blockIdx.x] = tot;
+    part[npart + blockIdx.x] = 0.0;
+  }
+}
+
 }  // namespace
+
+extern "C" int ipx_boxschur_project_count(const ipx_boxschur_args *a);
+
+// have_up != 0: a->up already holds r - alpha't (the CG loop's step1 kernel forms it while it
+// updates r: csrc/cg.hip k_cg_step1_box)
+int ipx_boxschur_project_from(const ipx_boxschur_args *a, const double *r, double *g,
+                              double *part_g, int32_t *npart_g, double *part_res,
+                              int32_t *npart_res, const double *guard, int have_up,
+                              hipStream_t stream) {
+  if (!a || !r || !g || !part_g || !a->gcol || !a->grp || !a->up ||
+      (a->ngen > 0 && !a->gen_cols))
+    return IPX_EINVAL;
+  hipStream_t st = stream;
+  const ipx_group_tab T{a->gcol, a->grp};
+  const int ng = (int)a->ng;
+  const int64_t items = a->ng + a->ngen;
+  if (items > 0 && !have_up) {
+    hipLaunchKernelGGL(k_pairs_pre, dim3((unsigned)((items + IPX_BLOCK - 1) / IPX_BLOCK)),
+                       dim3(IPX_BLOCK), 0, st, ng, (int)a->ngen, T, a->gen_cols, (int)a->ny, r,
+                       a->up, guard);
+    IPX_CHECK_LAUNCH();
+  }
+  ipx_csr_view AR{(int)a->mR, (int)a->n, a->AR_rowptr, a->AR_colidx, a->AR_val, a->AR_tiles,
+                  (int)a->AR_ntiles};
+  // rhs = A_R (r - alpha't)   (= w_R - A_R u of ipx_boxschur_solve, one product)
+  int rc = ipx_spmv_launch(AR, a->up, 1.0, nullptr, 0.0, nullptr, a->rhs, nullptr, guard, st);
+  if (rc) return rc;
+  int np = 0;
+  if (part_res)
+    rc = ipx_banded_solve_resid_launch(a->inner, a->rhs, a->vR, part_res, &np, guard, st);
+  else
+    rc = ipx_banded_solve_guarded(a->inner, a->rhs, a->vR, guard, st);
+  if (rc) return rc;
+  if (npart_res) *npart_res = np;
+  const int nblk = ipx_boxschur_project_count(a);
+  if (npart_g) *npart_g = nblk;
+  if (nblk > 0) {
+    hipLaunchKernelGGL(k_pairs_post, dim3(nblk), dim3(IPX_BLOCK), 0, st, ng, (int)a->ngen, T,
+                       a->gen_cols, r, a->ARt_rowptr, a->ARt_colidx, a->ARt_val, a->vR, (int)a->ny,
+                       g, part_g, nblk, guard);
+    IPX_CHECK_LAUNCH();
+  }
+  return IPX_OK;
+}
 
 extern "C" {
 
@@ -171,14 +343,14 @@ extern "C" {
 // (bit 0 set when a block is not positive definite).
 int ipx_pairs_factor(int32_t ng, const int32_t *rowp, const int32_t *rowq, const int32_t *pos_a,
                      const int32_t *pos_s, const double *val, const int32_t *col, double *alpha,
-                     double *inv, double *weight_col, int *flag, void *stream) {
+                     double *inv, double *weight_col, int *flag, double *grp, void *stream) {
   if (ng < 0) return IPX_EINVAL;
   if (ng == 0) return IPX_OK;
   if (!rowp || !rowq || !pos_a || !pos_s || !val || !col || !alpha || !inv || !weight_col || !flag)
     return IPX_EINVAL;
   hipLaunchKernelGGL(k_pairs_factor, dim3((ng + IPX_BLOCK - 1) / IPX_BLOCK), dim3(IPX_BLOCK), 0,
                      (hipStream_t)stream, ng, rowp, rowq, pos_a, pos_s, val, alpha, inv, weight_col,
-                     col, flag);
+                     col, flag, grp);
   IPX_CHECK_LAUNCH();
   return IPX_OK;
 }
@@ -246,6 +418,25 @@ int ipx_boxschur_solve(const ipx_boxschur_args *a, const double *w, double *v, d
     IPX_CHECK_LAUNCH();
   }
   return IPX_OK;
+}
+
+// Number of ||g||^2 partials ipx_boxschur_project writes (per half of its partial array).
+int ipx_boxschur_project_count(const ipx_boxschur_args *a) {
+  if (!a) return 0;
+  const int64_t items = a->ng + a->ngen;
+  return (int)((items + IPX_BLOCK * POST_ITEMS - 1) / (IPX_BLOCK * POST_ITEMS));
+}
+
+// g = r - A'(A A')^-1 A r in one call (g may alias r): the CG loop's projection step.
+// part_g (2 x ipx_boxschur_project_count doubles) receives the ||g||^2 partials (second half
+// zero), part_res / *npart_res the residual partials of the Schur system (= ||A g||^2, see
+// ipx_boxschur_solve).  Needs the group tables of the argument block (gcol, grp, gen_cols);
+// IPX_EINVAL without them.
+int ipx_boxschur_project(const ipx_boxschur_args *a, const double *r, double *g, double *part_g,
+                         int32_t *npart_g, double *part_res, int32_t *npart_res,
+                         const double *guard, void *stream) {
+  return ipx_boxschur_project_from(a, r, g, part_g, npart_g, part_res, npart_res, guard, 0,
+                                   (hipStream_t)stream);
 }
 
 }  // extern "C"

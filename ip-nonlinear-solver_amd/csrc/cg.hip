@@ -105,7 +105,7 @@ k_cg_step1(int64_t n, double *st, int parity, const double *__restrict__ p1, int
   for (int u = 0; u < VU; ++u) {
     const int64_t i = min(i0 + u * VB, n - 1);
     xv[u] = x[i]; pv[u] = p[i]; rv[u] = r[i]; hv[u] = Hp[i];
-    if (lb) { lo[u] = lb[i]; hi[u] = ub[i]; }
+    if (lb) { lo[u] = lb[i]; hi[u] = ub ? ub[i] : HUGE_VAL; }
   }
   if (stop != 0.0) return;
   const bool lead = c == 0 && threadIdx.x == 0;
@@ -142,12 +142,113 @@ k_cg_step1(int64_t n, double *st, int parity, const double *__restrict__ p1, int
     for (int u = 0; u < VU; ++u) {
       const int64_t i = min(i0 + u * VB, n - 1);
       xv[u] = x[i]; pv[u] = p[i]; rv[u] = r[i]; hv[u] = Hp[i];
-      if (lb) { lo[u] = lb[i]; hi[u] = ub[i]; }
+      if (lb) { lo[u] = lb[i]; hi[u] = ub ? ub[i] : HUGE_VAL; }
     }
   }
   const double a = ipx_block_reduce<IPX_SUM>(sx, lds);
   const double b = ipx_block_reduce<IPX_SUM>(viol, lds);
   if (threadIdx.x == 0) { p2[c] = a; p2[nchunks + c] = b; }
+}
+
+// step1 for the barrier problem's box-Schur projection (solver_kind 1 with group tables):
+// the same updates and sums as k_cg_step1, but the elements are visited group by group
+// (shared column + the rows' private columns; then the columns of no group), so that the
+// first stage of the projection -- w_S from r_next, t = B^-1 w_S, up = r_next - alpha't
+// (csrc/boxschur.hip k_pairs_pre) -- happens on the values just formed instead of in a
+// launch of its own that reads r again.  SB_ITEMS items per thread: one partial per 2048.
+constexpr int SB_ITEMS = 8;
+
+__global__ void __launch_bounds__(IPX_BLOCK)
+k_cg_step1_box(double *st, int parity, const double *__restrict__ p1, int np1,
+               const double *__restrict__ x, const double *__restrict__ p, double *__restrict__ r,
+               const double *__restrict__ Hp, const double *__restrict__ lb,
+               const double *__restrict__ ub, double *__restrict__ p2, int nblk, int ng, int ngen,
+               ipx_group_tab T, const int32_t *__restrict__ gen_cols, int ny,
+               double *__restrict__ up) {
+  __shared__ double lds[IPX_BLOCK / IPX_WAVE];
+  const int blk = ipx_xcd_item(blockIdx.x, nblk);
+  if (blk < 0) return;
+  const double *const fparts[1] = {p1 + np1};
+  const int fcounts[1] = {np1};
+  const double stop = st[ST_STOP];
+  const double rtg = st[parity ? ST_RTG1 : ST_RTG0];
+  const double tol = st[ST_TOL];
+  ipx_fold_regs<1> fold;
+  fold.load(fparts, fcounts);
+  if (stop != 0.0) return;
+  const bool lead = blk == 0 && threadIdx.x == 0;
+  double fout[1];
+  fold.finish(fparts, fcounts, lds, fout);
+  const double ptHp = fout[0];
+  if (rtg < tol) {                                   // qp_subproblem.py:551
+    if (lead) st[ST_STOP] = 4.0;
+    return;
+  }
+  if (ptHp <= 0.0) {                                 // :558
+    if (lead) { st[ST_NITER] += 1.0; st[ST_PTHP] = ptHp; st[ST_STOP] = 3.0; }
+    return;
+  }
+  const double alpha = rtg / ptHp;                   // :579
+  if (lead) { st[ST_NITER] += 1.0; st[ST_PTHP] = ptHp; st[ST_ALPHA] = alpha; }
+  double sx = 0.0, viol = 0.0;
+  const int nitems = ng + ngen;
+#pragma unroll 2
+  for (int k = 0; k < SB_ITEMS; ++k) {
+    const int i = (blk * SB_ITEMS + k) * IPX_BLOCK + threadIdx.x;
+    if (i >= nitems) continue;
+    // every load of the item is requested before the first use: the tables, then the (up
+    // to three) elements' x, p, r, Hp and bounds
+    const bool grp = i < ng;
+    int e[3];
+    double ap = 0.0, sp = 0.0, aq = 0.0, sq = 0.0;
+    if (grp) {
+      e[0] = T.gcol[3 * i]; e[1] = T.gcol[3 * i + 1]; e[2] = T.gcol[3 * i + 2];
+      ap = T.grp[4 * i]; sp = T.grp[4 * i + 1]; aq = T.grp[4 * i + 2]; sq = T.grp[4 * i + 3];
+    } else {
+      e[0] = gen_cols[i - ng]; e[1] = -1; e[2] = -1;
+    }
+    double xv[3], pv[3], rv[3], hv[3], lo[3], hi[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const int j = e[t] >= 0 ? e[t] : e[0];
+      xv[t] = x[j]; pv[t] = p[j]; rv[t] = r[j]; hv[t] = Hp[j];
+      lo[t] = lb ? lb[j] : -HUGE_VAL;
+      hi[t] = ub ? ub[j] : HUGE_VAL;
+    }
+    double rn[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const double xn = xv[t] + alpha * pv[t];                 // :580 (not stored)
+      rn[t] = rv[t] + alpha * hv[t];                           // :622
+      if (e[t] >= 0) {
+        sx += xn * xn;
+        if (lb) viol += ((lo[t] <= xn) && (xn <= hi[t])) ? 0.0 : 1.0;   // :599
+        r[e[t]] = rn[t];
+      }
+    }
+    const int c = e[0];
+    if (grp) {
+      const int cp = e[1], cq = e[2];
+      const double rc = rn[0], rp = cp >= 0 ? rn[1] : 0.0, rq = cq >= 0 ? rn[2] : 0.0;
+      const double wp = cp < 0 ? ap * rc : (cp > c ? ap * rc + sp * rp : sp * rp + ap * rc);
+      const double wq = cq < 0 ? aq * rc : (cq > c ? aq * rc + sq * rq : sq * rq + aq * rc);
+      double i11, i12, i22, wgt, ut;
+      ipx_group_inverse(cq != -2, ap, sp, aq, sq, i11, i12, i22, wgt);
+      if (cq == -2) {
+        ut = ap * (i11 * wp);
+      } else {
+        const double tp = i11 * wp + i12 * wq;
+        const double tq = i12 * wp + i22 * wq;
+        ut = ap * tp + aq * tq;
+      }
+      if (c < ny) up[c] = rc - ut;
+    } else if (c < ny) {
+      up[c] = rn[0];
+    }
+  }
+  const double a = ipx_block_reduce<IPX_SUM>(sx, lds);
+  const double b = ipx_block_reduce<IPX_SUM>(viol, lds);
+  if (threadIdx.x == 0) { p2[blk] = a; p2[nblk + blk] = b; }
 }
 
 // mode bit0: skip the radius / box checks (host already handled them)
@@ -765,11 +866,24 @@ static bool fused_hp(const ipx_cg_args *a);
 // scratch for the three sums given
 static bool xn2_recur(const ipx_cg_args *a) { return a->part5 && fused_ar(a) && fused_hp(a); }
 
+// solver_kind 1 with the group tables present: the fused box-Schur projection
+static bool box_project(const ipx_cg_args *a) {
+  if (a->solver_kind != 1 || !a->banded) return false;
+  const ipx_boxschur_args *b = (const ipx_boxschur_args *)a->banded;
+  return b->gcol != nullptr && b->grp != nullptr && b->up != nullptr && !fused_ar(a);
+}
+
 static bool fused_ar(const ipx_cg_args *a) {
   return a->r_next != nullptr && a->A_own != nullptr && a->A_span > 0 && !a->lb && a->m > 0;
 }
 // entries per half of part2: one per row tile of A (fused step1) or per vector chunk
+static int step1_box_blocks(const ipx_cg_args *a) {
+  const ipx_boxschur_args *b = (const ipx_boxschur_args *)a->banded;
+  const int64_t per = (int64_t)IPX_BLOCK * SB_ITEMS;
+  return (int)((b->ng + b->ngen + per - 1) / per);
+}
 static int part2_count(const ipx_cg_args *a) {
+  if (box_project(a)) return step1_box_blocks(a);
   return fused_ar(a) ? (int)a->A_ntiles : (int)a->vec_grid;
 }
 static int part4_count(const ipx_cg_args *a) {
@@ -779,6 +893,7 @@ static int part4_count(const ipx_cg_args *a) {
 // entries per half of part3: one per row tile of A', or per workgroup of the solve when
 // g = r - A'v is its tail
 static int part3_count(const ipx_cg_args *a) {
+  if (box_project(a)) return ipx_boxschur_project_count((const ipx_boxschur_args *)a->banded);
   return (a->solver_kind == 0 && a->At_vown && a->At_qv > 0) ? part4_count(a) : (int)a->At_ntiles;
 }
 
@@ -955,7 +1070,8 @@ int ipx_cg_shard2_segment(const ipx_cg_args *a, const ipx_shard2_ext *e, int32_t
       rc = ipx_spmv_launch(At, a->v, -1.0, nullptr, 1.0, r_in, a->r, a->part3, guard, st);
       if (rc) return rc;
     }
-    const int np2 = part2_count(a);
+    // (this path runs k_cg_step1 / k_cg_step1_ar, never the box-Schur step1)
+    const int np2 = fuse1 ? (int)a->A_ntiles : grid;
     if (e->p4_hi > np4 || e->p2_hi > np2) return IPX_EINVAL;
     RangeJob job;
     job.npieces = (int)e->nseg;
@@ -1184,6 +1300,16 @@ static int cg_iterate(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, hi
       rc = launch_step1_ar(a, it, p1, np1, st, p5, np5);   // r_next = r + alpha Hp;  w = A r_next
       if (rc) return rc;
       MARK(2);
+    } else if (a->m > 0 && box_project(a)) {
+      const ipx_boxschur_args *b = (const ipx_boxschur_args *)a->banded;
+      const int nblk = step1_box_blocks(a);
+      hipLaunchKernelGGL(k_cg_step1_box, dim3(ipx_xcd_grid(nblk)), dim3(IPX_BLOCK), 0, st,
+                         a->state, it & 1, p1, np1, a->x, a->p, a->r, a->Hp, a->lb, a->ub,
+                         a->part2, nblk, (int)b->ng, (int)b->ngen,
+                         ipx_group_tab{b->gcol, b->grp}, b->gen_cols, (int)b->ny,
+                         b->up);
+      IPX_CHECK_LAUNCH();
+      MARK(1);
     } else {
       hipLaunchKernelGGL(k_cg_step1, dim3(ipx_xcd_grid((int)a->vec_grid)), dim3(VB), 0, st, a->n,
                          a->state, it & 1, p1, np1, a->x, a->p, a->r,
@@ -1191,7 +1317,17 @@ static int cg_iterate(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, hi
       IPX_CHECK_LAUNCH();
       MARK(1);
     }
-    if (a->m > 0) {
+    if (a->m > 0 && box_project(a)) {
+      // simple (box) rows eliminated analytically and never multiplied as matrix rows:
+      // g = r - A'(A A')^-1 A r in one call (csrc/boxschur.hip ipx_boxschur_project)
+      int32_t n3 = 0, n4 = 0;
+      rc = ipx_boxschur_project_from((const ipx_boxschur_args *)a->banded, a->r, a->r, a->part3,
+                                     &n3, a->part4, &n4, guard, 1, st);
+      if (rc) return rc;
+      np3 = n3;
+      np4 = n4;
+      MARK(2); MARK(3); MARK(4); MARK(5);
+    } else if (a->m > 0) {
       if (!fuse1) {
         // w = A r_next
         rc = ipx_spmv_launch(A, a->r, 1.0, nullptr, 0.0, nullptr, a->w, nullptr, guard, st);

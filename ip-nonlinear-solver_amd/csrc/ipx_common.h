@@ -268,6 +268,51 @@ struct ipx_fold_regs {
   }
 };
 
+// ---- box-Schur group tables (csrc/boxschur.hip; also read by the CG loop's step1)
+#ifdef __HIPCC__
+struct ipx_group_tab {
+  const int32_t *gcol;      // 3 per group: shared column, private column of p, of q
+                            // (-1: the row has none; q: -2 = single-row group)
+  const double *grp;        // 4 per group: ap, sp, aq, sq
+};
+
+// inverse (i11, i12, i22) of B = [[ap^2 + sp^2, ap aq], [ap aq, aq^2 + sq^2]] (single row: 1/b11)
+// and the Schur column weight 1 - alpha' B^-1 alpha, both in cancellation-free form (slacks of
+// active bounds are ~1e-8 next to ap = aq = 1).  One definition for the factorization and for
+// the kernels that re-derive the inverse from (ap, sp, aq, sq) instead of reading it: same bits.
+__device__ __forceinline__ bool ipx_group_inverse(bool has_q, double ap, double sp, double aq,
+                                                  double sq, double &i11, double &i12,
+                                                  double &i22, double &wgt) {
+  const double b11 = ap * ap + sp * sp;
+  if (!has_q) {
+    i11 = 1.0 / b11; i12 = 0.0; i22 = 0.0;
+    wgt = sp * sp / b11;
+    return b11 > 0.0;
+  }
+  const double b22 = aq * aq + sq * sq, b12 = ap * aq;
+  // (ap^2+sp^2)(aq^2+sq^2) - (ap aq)^2 without the cancellation
+  const double det = ap * ap * (sq * sq) + sp * sp * (aq * aq) + sp * sp * (sq * sq);
+  i11 = b22 / det; i12 = -b12 / det; i22 = b11 / det;
+  wgt = (sp * sp) * (sq * sq) / det;
+  return det > 0.0 && b11 > 0.0;
+}
+
+__device__ __forceinline__ void ipx_group_w(const ipx_group_tab &T, int g, const double *__restrict__ r,
+                                        int &c, int &cp, int &cq, double &ap, double &sp,
+                                        double &aq, double &sq, double &rc, double &rp, double &rq,
+                                        double &wp, double &wq) {
+  c = T.gcol[3 * g]; cp = T.gcol[3 * g + 1]; cq = T.gcol[3 * g + 2];
+  ap = T.grp[4 * g]; sp = T.grp[4 * g + 1]; aq = T.grp[4 * g + 2]; sq = T.grp[4 * g + 3];
+  rc = r[c];
+  rp = cp >= 0 ? r[cp] : 0.0;
+  rq = cq >= 0 ? r[cq] : 0.0;
+  // row sums in column order (0 + first + second)
+  wp = cp < 0 ? ap * rc : (cp > c ? ap * rc + sp * rp : sp * rp + ap * rc);
+  wq = cq < 0 ? aq * rc : (cq > c ? aq * rc + sq * rq : sq * rq + aq * rc);
+}
+
+#endif
+
 // ---- diagnostic build only (-DIPX_PHASE_TIMING, scripts/phase_timing.py): in-kernel
 // wall-clock stamps of workgroup 0, one array per translation unit.
 #ifdef IPX_PHASE_TIMING
@@ -298,6 +343,11 @@ int ipx_spmv_launch(const ipx_csr_view &A, const double *x, double alpha, const 
                     const double *guard, hipStream_t st, const double *xrow_override = nullptr);
 int ipx_banded_solve_guarded(void *handle, const double *w, double *x, const double *guard,
                              hipStream_t st);
+// ipx_boxschur_project with a->up (= r - alpha't) optionally prepared by the caller
+int ipx_boxschur_project_from(const ipx_boxschur_args *a, const double *r, double *g,
+                              double *part_g, int32_t *npart_g, double *part_res,
+                              int32_t *npart_res, const double *guard, int have_up,
+                              hipStream_t stream);
 // yout = alpha A x [+ diag x] [+ beta yin] for a row-major dense A; partial (optional) gets
 // per-workgroup sums of y^2 then of x.y (square A), *npartial entries per half
 int ipx_dense_gemv_launch(int m, int n, const double *A, int64_t lda, const double *x,

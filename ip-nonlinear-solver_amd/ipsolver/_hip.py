@@ -72,10 +72,12 @@ _SIGNATURES = {
     "ipx_cg_shard2_fold_hp": [_P, _P, _P],
     "ipx_aat_band": [_I64, _I32, _P, _P, _P, _P, _P, _P],
     "ipx_aat_band_w": [_I64, _I32, _P, _P, _P, _P, _P, _P, _P],
-    "ipx_pairs_factor": [_I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "ipx_pairs_factor": [_I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "ipx_pairs_tsolve": [_I32, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "ipx_pairs_vsolve": [_I32, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "ipx_boxschur_solve": [_P, _P, _P, _P, _P, _P, _P],
+    "ipx_boxschur_project": [_P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "ipx_boxschur_project_count": [_P],
 }
 _RESTYPES = {"ipx_version": _c.c_char_p, "ipx_last_error": _c.c_char_p,
              "ipx_banded_create": _P, "ipx_banded_destroy": None,

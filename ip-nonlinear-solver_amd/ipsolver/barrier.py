@@ -132,7 +132,7 @@ def tr_interior_point(fun, grad, lagr_hess, n_vars, n_ineq, n_eq, constr, jac, x
     grad0_sub, jac0_sub = subprob.grad0, subprob.jac0
     if n_ineq > 0:                                            # :306-308
         trust_lb = xp.hstack((xp.full(n_vars, -np.inf), xp.full(n_ineq, -BOUNDARY_PARAMETER)))
-        trust_ub = xp.full(n_vars + n_ineq, np.inf)
+        trust_ub = None                    # no upper bounds (sqp keeps that side off the kernels)
     else:
         trust_lb = trust_ub = None         # all-infinite box: skipped by the kernels
 

@@ -96,7 +96,9 @@ class BoxSchurArgs(ctypes.Structure):
                 ("AR_ntiles", _I64),
                 ("ARt_rowptr", _P), ("ARt_colidx", _P), ("ARt_val", _P), ("ARt_tiles", _P),
                 ("ARt_ntiles", _I64), ("inner", _P)] + \
-               [(k, _P) for k in ("t", "u", "wR", "rhs", "vR", "y")]
+               [(k, _P) for k in ("t", "u", "wR", "rhs", "vR", "y")] + \
+               [("gcol", _P), ("grp", _P), ("gen_cols", _P), ("ngen", _I64), ("ny", _I64),
+                ("up", _P)]
 
 
 class BoxSchurNormalSolver:
@@ -114,10 +116,20 @@ class BoxSchurNormalSolver:
             sel = getattr(pat, "_ipx_box_general_pattern", None) or RowSelection(pat, an.general,
                                                                                 None)
             pat._ipx_box_general_pattern = sel
+            # tables of ipx_boxschur_project: per group the shared column and the rows' private
+            # columns; the columns outside every group
+            idx = pat.indices_h
+            priv = lambda rows: np.where((rows >= 0) & (an.pos_s[np.maximum(rows, 0)] >= 0),
+                                         idx[np.maximum(an.pos_s[np.maximum(rows, 0)], 0)], -1)
+            gcol = np.stack((an.col, priv(an.rowp), np.where(an.rowq >= 0, priv(an.rowq), -2)),
+                            axis=1).astype(np.int32)        # (-2: single-row group)
+            in_group = np.zeros(an.n, dtype=bool)
+            in_group[gcol[gcol >= 0]] = True
             cache = pat._ipx_box_device = {
                 "rowp": _i32(an.rowp), "rowq": _i32(an.rowq), "col": _i32(an.col),
                 "pos_a": _i32(an.pos_a), "pos_s": _i32(an.pos_s),
                 "general": _i32(an.general),
+                "gcol": _i32(gcol.ravel()), "gen_cols": _i32(np.flatnonzero(~in_group)),
                 "sel": sel}
         self.c = cache
         self.ng = len(an.col)
@@ -125,11 +137,12 @@ class BoxSchurNormalSolver:
         self.alpha = torch.zeros(self.m, dtype=_F64, device=dev)
         self.inv = torch.empty(3 * max(self.ng, 1), dtype=_F64, device=dev)
         self.wcol = torch.ones(self.n, dtype=_F64, device=dev)
+        self.grp = torch.empty(4 * max(self.ng, 1), dtype=_F64, device=dev)
         flag = torch.zeros(1, dtype=torch.int32, device=dev)
         st = stream_ptr()
         _hip.call("ipx_pairs_factor", self.ng, _p(cache["rowp"]), _p(cache["rowq"]),
                   _p(cache["pos_a"]), _p(cache["pos_s"]), _p(A.val), _p(cache["col"]),
-                  _p(self.alpha), _p(self.inv), _p(self.wcol), _p(flag), st)
+                  _p(self.alpha), _p(self.inv), _p(self.wcol), _p(flag), _p(self.grp), st)
         self.A_R = cache["sel"].apply(A)                 # general rows (value gather)
         self.inner = BandedNormalSolver(self.A_R, col_weights=self.wcol)   # Sigma = A_R W A_R'
         if int(flag.item()) != 0:
@@ -166,6 +179,13 @@ class BoxSchurNormalSolver:
             a.inner = self.inner.handle
             a.t, a.u = self.t.data_ptr(), self.u.data_ptr()
             a.wR, a.rhs, a.vR, a.y = (t.data_ptr() for t in self._scratch)
+            # the fused projection (ipx_boxschur_project): group tables; ny = one past the last
+            # column A_R touches (the slack columns of the box rows lie behind it)
+            a.gcol, a.grp = c["gcol"].data_ptr(), self.grp.data_ptr()
+            a.gen_cols, a.ngen = c["gen_cols"].data_ptr(), c["gen_cols"].numel()
+            a.ny = int(self.A_R.pattern.indices_h.max()) + 1 if self.A_R.pattern.nnz else 0
+            self._up = torch.zeros(self.n, dtype=_F64, device=dev)
+            a.up = self._up.data_ptr()
             self._args = a
         return self._args
 

@@ -280,9 +280,11 @@ class _Loop:
         self.state = torch.zeros(lib.ipx_cg_state_size(), dtype=f64, device=dev)
         grid = lib.ipx_cg_vec_grid(n)
         self.part1 = torch.zeros(2 * Hc.pattern.ntiles, dtype=f64, device=dev)
-        self.part2 = torch.zeros(2 * max(grid, A.pattern.ntiles), dtype=f64, device=dev)
-        self.part3 = torch.zeros(2 * max(At.pattern.ntiles, (m + 255) // 256 + 1), dtype=f64,
+        # (box-Schur projection: step1 writes one partial per 2048 elements, csrc/cg.hip SB_ITEMS)
+        self.part2 = torch.zeros(2 * max(grid, A.pattern.ntiles, n // 2048 + 2), dtype=f64,
                                  device=dev)
+        self.part3 = torch.zeros(2 * max(At.pattern.ntiles, (m + 255) // 256 + 1, n // 1024 + 2),
+                                 dtype=f64, device=dev)
         self.part4 = torch.zeros((m + 255) // 256 + 1, dtype=f64, device=dev)   # ||w-(AA')v||^2 partials
         self.keep = (A, At, Hc, Hd, lb, ub, P)
         a = CgArgs()
@@ -418,6 +420,7 @@ def projected_cg(H, c, Z, Y, b, trust_radius=np.inf, lb=None, ub=None, tol=None,
     P = Z.projector
     n, m = len(c), len(b)
     has_box = lb is not None or ub is not None
+    ub_given = ub is not None
     if has_box:
         lb = lb if lb is not None else DVec.full(n, -np.inf)
         ub = ub if ub is not None else DVec.full(n, np.inf)
@@ -441,7 +444,8 @@ def projected_cg(H, c, Z, Y, b, trust_radius=np.inf, lb=None, ub=None, tol=None,
     if max_infeasible_iter is None:
         max_infeasible_iter = n - m
 
-    L = _Loop(H, P, lb if has_box else None, ub if has_box else None)
+    # (no upper bounds given: the loop's kernels do not read a vector of +inf)
+    L = _Loop(H, P, lb if has_box else None, ub if has_box and ub_given else None)
     st = stream_ptr()
     L.x.copy_(x0.t)
     L.r.copy_(r0.t)

@@ -35,6 +35,9 @@ def equality_constrained_sqp(fun_and_constr, grad_and_jac, lagr_hess, x0, fun0, 
     # No box at all (pure equality SQP): keep None so the kernels skip the
     # bound passes; the reference materialises +-inf vectors (:65-68).
     boxed = trust_lb is not None or trust_ub is not None
+    # one-sided boxes (the barrier problem: only lower bounds, on the slacks) keep the missing
+    # side None towards projected_cg, whose kernels then skip that bound vector
+    lb_free, ub_free = trust_lb is None, trust_ub is None
     if boxed:
         trust_lb = trust_lb if trust_lb is not None else xp.full(n, -np.inf)
         trust_ub = trust_ub if trust_ub is not None else xp.full(n, np.inf)
@@ -77,7 +80,8 @@ def equality_constrained_sqp(fun_and_constr, grad_and_jac, lagr_hess, x0, fun0, 
         trust_radius_t = np.sqrt(trust_radius ** 2 - norm(dn) ** 2)
         lb_t = trust_lb - dn if boxed else None
         ub_t = trust_ub - dn if boxed else None
-        dt, info_cg = xp.projected_cg(H, c_t, Z, Y, b_t, trust_radius_t, lb_t, ub_t)
+        dt, info_cg = xp.projected_cg(H, c_t, Z, Y, b_t, trust_radius_t,
+                                      None if lb_free else lb_t, None if ub_free else ub_t)
 
         d = dn + dt                                           # :135-153
         quadratic_model = 1 / 2 * dot(H.dot(d), d) + dot(c, d)
