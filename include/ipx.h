@@ -251,6 +251,13 @@ typedef struct ipx_cg_args {
    * +5.4 % at n=4e6, the step2 + H.p kernel itself 7 % slower; the host binding leaves it off
    * unless IPX_RECUR=1 (the direct sum is what the reference computes). */
   double *part5;
+  /* Compact index form of H for the fused step2 + H.p kernel (H_hmax > 0), or NULL:
+   * H_col16 = one uint16 per nonzero, its column as an offset into the row tile's span
+   * (col - max(tile's first row - H_hmax, 0)); H_rowlen = one int per row tile, the common
+   * length of its rows or -1 (then H_rowptr is read for that tile).  Same arithmetic; 2 B
+   * instead of 4 per nonzero and no row pointers on uniform tiles. */
+  const void *H_col16;
+  const int32_t *H_rowlen;
 } ipx_cg_args;
 int ipx_cg_state_size(void);
 int ipx_cg_vec_grid(int64_t n);

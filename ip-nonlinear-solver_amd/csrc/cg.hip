@@ -348,7 +348,11 @@ k_cg_step2(int64_t n, double *st, int parity, int mode, const double *__restrict
 // (halo <= 64 and <= the shortest tile: checked by the host binding, cg_fused.fuse_halo)
 constexpr int FT_NNZ = IPX_SPMV_TILE_NNZ;
 
-template <bool HAS_DIAG, int Q, int QS, bool BOX>
+// C16: the column indices come as 16-bit offsets into the tile's span (col - c_lo, built once
+// per pattern by the host binding) and the row pointers of a tile whose rows all have the
+// same length are not read at all (rowlen[tile] >= 0): 2 + 4/rowlen bytes less per nonzero of
+// the 12 a CSR entry costs -- 10 of the 96 MB this kernel moves at n = 1e6.
+template <bool HAS_DIAG, int Q, int QS, bool BOX, bool C16>
 __global__ void __launch_bounds__(IPX_BLOCK)
 k_cg_step2_hp(int n, double *st, int parity, int mode, const double *__restrict__ p2, int np2,
               const double *__restrict__ p3, int np3, const double *__restrict__ p4, int np4,
@@ -357,7 +361,8 @@ k_cg_step2_hp(int n, double *st, int parity, int mode, const double *__restrict_
               const double *__restrict__ val, const int32_t *__restrict__ tiles, int ntiles,
               const double *__restrict__ diag, double *__restrict__ Hp,
               double *__restrict__ partial, int hmax, const double *__restrict__ pb_in,
-              double *__restrict__ pb_out, double *__restrict__ part5) {
+              double *__restrict__ pb_out, double *__restrict__ part5,
+              const uint16_t *__restrict__ col16, const int32_t *__restrict__ rowlen) {
   // part5 (optional, 3 x ntiles): per-tile sums of x_next'x_next, x_next'p_next, p_next'p_next,
   // from which the next iteration gets ||x + alpha p||^2 = xx + 2 alpha xp + alpha^2 pp without
   // reading x and p again (mode bit 2: this launch takes its own ||x + alpha p||^2 that way,
@@ -406,9 +411,10 @@ k_cg_step2_hp(int n, double *st, int parity, int mode, const double *__restrict_
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int jj = min(s + tid + u * IPX_BLOCK, max(e - 1, 0));   // empty tile: any valid entry
-    c[u] = colidx[jj];
+    c[u] = C16 ? (int)col16[jj] : colidx[jj] - c_lo;
     v[u] = val[jj];
   }
+  const int rl = C16 ? rowlen[tile] : -1;       // >= 0: every row of the tile has rl entries
   // span operands: element j of the span is column c_lo + j
   double sp[QS], sg[QS];
   const double *pbl = pb_in + (int64_t)(tile - 1) * 2 * hmax + hmax;   // right part of tile-1
@@ -491,8 +497,13 @@ k_cg_step2_hp(int n, double *st, int parity, int mode, const double *__restrict_
   for (int q = 0; q < Q; ++q)
     dg[q] = HAS_DIAG ? diag[r0 + min(tid + q * IPX_BLOCK, nrows - 1)] : 0.0;
   int rpv[Q + 1];
+  if (C16 && rl >= 0) {
 #pragma unroll
-  for (int q = 0; q <= Q; ++q) rpv[q] = rowptr[r0 + min(tid + q * IPX_BLOCK, nrows)] - s;
+    for (int q = 0; q <= Q; ++q) rpv[q] = min(tid + q * IPX_BLOCK, nrows) * rl;
+  } else {
+#pragma unroll
+    for (int q = 0; q <= Q; ++q) rpv[q] = rowptr[r0 + min(tid + q * IPX_BLOCK, nrows)] - s;
+  }
   CG_STAMP(3);
   ipx_lds_barrier();
   CG_STAMP(4);
@@ -500,7 +511,7 @@ k_cg_step2_hp(int n, double *st, int parity, int mode, const double *__restrict_
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int jj = s + tid + u * IPX_BLOCK;
-    if (jj < e) prod[jj - s] = v[u] * span[c[u] - c_lo];
+    if (jj < e) prod[jj - s] = v[u] * span[c[u]];
   }
 #pragma unroll
   for (int q = 0; q <= Q; ++q) {
@@ -940,16 +951,19 @@ static int launch_step2_hp(const ipx_cg_args *a, int it, int mode, const double 
   (int)a->n, a->state, it & 1, mode, p2, np2, p3, np3, p4, np4, a->x, a->p, a->r,             \
       a->H_rowptr, a->H_colidx, a->H_val, a->H_tiles,                                         \
       (int)a->H_ntiles, a->H_diag, a->Hp, a->part1, (int)a->H_hmax, pb_in, pb_out,           \
-      (xn2_recur(a) ? a->part5 : nullptr)
+      (xn2_recur(a) ? a->part5 : nullptr), (const uint16_t *)a->H_col16, a->H_rowlen
   // H_hmax carries the longest tile's row count in its upper half (set by the host
   // binding): short tiles (3 nonzeros per row -> 683 rows) take the 3-elements-per-lane
   // instantiation, which needs fewer registers
   const bool small = a->H_tile_rows > 0 && a->H_tile_rows + 2 * a->H_hmax <= 3 * IPX_BLOCK;
   const bool box = a->lb != nullptr;
+  const bool c16 = a->H_col16 != nullptr && a->H_rowlen != nullptr;
 #define GO(D, QQ, QSS)                                                                       \
   do {                                                                                       \
-    if (box) hipLaunchKernelGGL((k_cg_step2_hp<D, QQ, QSS, true>), grid, block, 0, st, FUSED_ARGS); \
-    else hipLaunchKernelGGL((k_cg_step2_hp<D, QQ, QSS, false>), grid, block, 0, st, FUSED_ARGS);    \
+    if (box && c16) hipLaunchKernelGGL((k_cg_step2_hp<D, QQ, QSS, true, true>), grid, block, 0, st, FUSED_ARGS); \
+    else if (box) hipLaunchKernelGGL((k_cg_step2_hp<D, QQ, QSS, true, false>), grid, block, 0, st, FUSED_ARGS); \
+    else if (c16) hipLaunchKernelGGL((k_cg_step2_hp<D, QQ, QSS, false, true>), grid, block, 0, st, FUSED_ARGS); \
+    else hipLaunchKernelGGL((k_cg_step2_hp<D, QQ, QSS, false, false>), grid, block, 0, st, FUSED_ARGS);    \
   } while (0)
   if (a->H_diag) {
     if (small) GO(true, 3, 3); else GO(true, 4, 5);

@@ -40,7 +40,8 @@ class CgArgs(ctypes.Structure):
         ("vec_grid", _I64), ("solver_kind", _I64), ("pb", _P), ("H_hmax", _I64), ("H_tile_rows", _I64),
         ("r_next", _P), ("A_own", _P), ("A_span", _I64), ("fold_ws", _P),
         ("At_vown", _P), ("At_qv", _I64), ("A_tile_nnz", _I64),
-        ("At_ell_col", _P), ("At_ell_val", _P), ("part5", _P))]
+        ("At_ell_col", _P), ("At_ell_val", _P), ("part5", _P),
+        ("H_col16", _P), ("H_rowlen", _P))]
 
 
 # Counters over the life of the process (diagnostics: how often the device loop
@@ -102,6 +103,40 @@ def fuse_halo(pattern):
                 hmax = h
     pattern._ipx_fuse_halo = hmax
     return hmax
+
+
+def compact_columns(pattern, hmax):
+    """Compact index form of a banded square pattern for the fused step2 + H.p kernel
+    (csrc/cg.hip C16): ``(col16, rowlen)`` -- per nonzero its column as a 16-bit offset into
+    the row tile's span (``col - max(first row of the tile - hmax, 0)``), per tile the common
+    length of its rows or -1.  Symbolic; cached on the pattern."""
+    key = ("_ipx_col16", int(hmax))
+    cache = getattr(pattern, "_ipx_col16", None)
+    if cache is not None and cache[0] == key:
+        return cache[1]
+    nt = pattern.ntiles
+    t = pattern.tiles_h
+    r0 = t[:nt].astype(np.int64)
+    s, e = t[nt + 1:2 * nt + 1].astype(np.int64), t[nt + 2:2 * nt + 2].astype(np.int64)
+    c_lo = np.maximum(r0 - hmax, 0)
+    off = pattern.indices_h.astype(np.int64) - np.repeat(c_lo, e - s)
+    assert off.size == 0 or (off.min() >= 0 and off.max() < 65536)
+    lens = np.diff(pattern.indptr_h.astype(np.int64))
+    rows = np.diff(t[:nt + 1].astype(np.int64))
+    first = lens[np.minimum(r0, len(lens) - 1)]
+    uniform = (e - s) == rows * first
+    # (equal totals do not make equal rows: check min == max per tile)
+    nonempty = rows > 0
+    lo = np.minimum.reduceat(lens, r0[nonempty]) if nonempty.any() else np.array([])
+    hi = np.maximum.reduceat(lens, r0[nonempty]) if nonempty.any() else np.array([])
+    same = np.zeros(nt, dtype=bool)
+    same[nonempty] = lo == hi
+    rowlen = np.where(uniform & same, first, -1).astype(np.int32)
+    dev = ctx().device
+    out = (torch.from_numpy(off.astype(np.uint16).view(np.int16)).to(dev),
+           torch.from_numpy(rowlen).to(dev))
+    pattern._ipx_col16 = (key, out)
+    return out
 
 
 def fuse_own(pattern, tile_nnz=None):
@@ -317,6 +352,9 @@ class _Loop:
             a.pb, a.H_hmax = _ptr(self.pb), hmax
             th = Hc.pattern.tiles_h
             a.H_tile_rows = int(np.max(np.diff(th[:Hc.pattern.ntiles + 1])))
+            if not os.environ.get("IPX_NO_C16"):
+                self.H_col16, self.H_rowlen = compact_columns(Hc.pattern, hmax)
+                a.H_col16, a.H_rowlen = _ptr(self.H_col16), _ptr(self.H_rowlen)
         # banded Jacobian, no box: step1 rides inside the A.r SpMV
         tn = int(os.environ.get("IPX_FUSE_TN", "0")) or None
         own = None if (os.environ.get("IPX_NO_FUSE") or lb is not None or m == 0) \
