@@ -258,6 +258,9 @@ typedef struct ipx_cg_args {
    * instead of 4 per nonzero and no row pointers on uniform tiles. */
   const void *H_col16;
   const int32_t *H_rowlen;
+  /* The same for the fused step1 + A.r kernel (A_span > 0, standard tiles, no IPX_RECUR):
+   * one uint16 per nonzero of A, col - A_own[its row tile]; NULL: A_colidx is read. */
+  const void *A_col16;
 } ipx_cg_args;
 int ipx_cg_state_size(void);
 int ipx_cg_vec_grid(int64_t n);

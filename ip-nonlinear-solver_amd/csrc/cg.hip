@@ -598,7 +598,9 @@ k_cg_step2_hp(int n, double *st, int parity, int mode, const double *__restrict_
 // `ntiles`), which leaves it in the state block for the coming step2.  Algebraically the same
 // number; it differs from the direct sum by rounding, and only feeds the comparison with the
 // trust radius (:583) -- on an exit the boundary point is computed from fresh reductions.
-template <int QS, int TN, bool RECUR>
+// C16: column indices as 16-bit offsets into the tile's span (col - own[tile]; the host
+// binding builds them once per pattern), 2 bytes instead of 4 per nonzero.
+template <int QS, int TN, bool RECUR, bool C16>
 __global__ void __launch_bounds__(IPX_BLOCK)
 k_cg_step1_ar(int n, double *st, int parity, const double *__restrict__ p1, int np1,
               const double *__restrict__ x, const double *__restrict__ p,
@@ -607,7 +609,7 @@ k_cg_step1_ar(int n, double *st, int parity, const double *__restrict__ p1, int 
               const int32_t *__restrict__ colidx, const double *__restrict__ val,
               const int32_t *__restrict__ tiles, int ntiles, const int32_t *__restrict__ own,
               double *__restrict__ w, double *__restrict__ part2,
-              const double *__restrict__ p5, int np5) {
+              const double *__restrict__ p5, int np5, const uint16_t *__restrict__ col16) {
   __shared__ double prod[TN];
   __shared__ double span[QS * IPX_BLOCK];
   __shared__ int rp[IPX_SPMV_TILE_ROWS + 1];
@@ -649,7 +651,7 @@ k_cg_step1_ar(int n, double *st, int parity, const double *__restrict__ p1, int 
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int jj = min(s + tid + u * IPX_BLOCK, max(e - 1, 0));   // empty tile: any valid entry
-    c[u] = colidx[jj];
+    c[u] = C16 ? (int)col16[jj] : colidx[jj] - o0;
     v[u] = val[jj];
   }
   double sr[QS], sh[QS], sxv[QS], spv[QS];
@@ -705,7 +707,7 @@ k_cg_step1_ar(int n, double *st, int parity, const double *__restrict__ p1, int 
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int jj = s + tid + u * IPX_BLOCK;
-    if (jj < e) prod[jj - s] = v[u] * span[c[u] - o0];
+    if (jj < e) prod[jj - s] = v[u] * span[c[u]];
   }
 #pragma unroll
   for (int q = 0; q <= IPX_SPMV_TILE_ROWS / IPX_BLOCK; ++q) {
@@ -916,14 +918,15 @@ static int launch_step1_ar(const ipx_cg_args *a, int it, const double *p1, int n
 #define FUSED_ARGS                                                                         \
   (int)a->n, a->state, it & 1, p1, np1, a->x, a->p, a->r, a->r_next,                       \
       a->Hp, a->A_rowptr, a->A_colidx, a->A_val, a->A_tiles, (int)a->A_ntiles, a->A_own,   \
-      a->w, a->part2, p5, np5
+      a->w, a->part2, p5, np5, (const uint16_t *)a->A_col16
   const int qs = (int)((a->A_span + IPX_BLOCK - 1) / IPX_BLOCK);
   const bool half = a->A_tile_nnz == 1024;      // tiles of 1024 nonzeros (own table)
 #define GO(Q)                                                                              \
   do {                                                                                     \
-    if (half) hipLaunchKernelGGL((k_cg_step1_ar<Q, 1024, false>), grid, block, 0, st, FUSED_ARGS); \
-    else if (recur) hipLaunchKernelGGL((k_cg_step1_ar<Q, FT_NNZ, true>), grid, block, 0, st, FUSED_ARGS); \
-    else hipLaunchKernelGGL((k_cg_step1_ar<Q, FT_NNZ, false>), grid, block, 0, st, FUSED_ARGS);    \
+    if (half) hipLaunchKernelGGL((k_cg_step1_ar<Q, 1024, false, false>), grid, block, 0, st, FUSED_ARGS); \
+    else if (recur) hipLaunchKernelGGL((k_cg_step1_ar<Q, FT_NNZ, true, false>), grid, block, 0, st, FUSED_ARGS); \
+    else if (a->A_col16) hipLaunchKernelGGL((k_cg_step1_ar<Q, FT_NNZ, false, true>), grid, block, 0, st, FUSED_ARGS); \
+    else hipLaunchKernelGGL((k_cg_step1_ar<Q, FT_NNZ, false, false>), grid, block, 0, st, FUSED_ARGS);    \
   } while (0)
   switch (qs) {
     case 1: case 2: GO(2); break;

@@ -41,7 +41,7 @@ class CgArgs(ctypes.Structure):
         ("r_next", _P), ("A_own", _P), ("A_span", _I64), ("fold_ws", _P),
         ("At_vown", _P), ("At_qv", _I64), ("A_tile_nnz", _I64),
         ("At_ell_col", _P), ("At_ell_val", _P), ("part5", _P),
-        ("H_col16", _P), ("H_rowlen", _P))]
+        ("H_col16", _P), ("H_rowlen", _P), ("A_col16", _P))]
 
 
 # Counters over the life of the process (diagnostics: how often the device loop
@@ -186,6 +186,23 @@ def fuse_own(pattern, tile_nnz=None):
                     out = (torch.from_numpy(table).to(dev), span, tiles, nt)
     setattr(pattern, attr, out)
     return out
+
+
+def own_columns16(pattern):
+    """Column indices of a pattern that qualifies for ``fuse_own`` (standard tiles) as 16-bit
+    offsets from the first column its row tile owns (csrc/cg.hip k_cg_step1_ar C16).
+    Symbolic; cached."""
+    cached = getattr(pattern, "_ipx_own_col16", None)
+    if cached is None:
+        own = fuse_own(pattern)[0].cpu().numpy().astype(np.int64)
+        nt = pattern.ntiles
+        t = pattern.tiles_h
+        s, e = t[nt + 1:2 * nt + 1].astype(np.int64), t[nt + 2:2 * nt + 2].astype(np.int64)
+        off = pattern.indices_h.astype(np.int64) - np.repeat(own[:nt], e - s)
+        assert off.size == 0 or (off.min() >= 0 and off.max() < 65536)
+        cached = pattern._ipx_own_col16 = torch.from_numpy(
+            off.astype(np.uint16).view(np.int16)).to(ctx().device)
+    return cached
 
 
 def fuse_vown(At_pattern, rows_per_wg, nwg):
@@ -367,6 +384,9 @@ class _Loop:
             if self.part2.numel() < 2 * own[3]:
                 self.part2 = torch.zeros(2 * own[3], dtype=f64, device=dev)
                 a.part2 = _ptr(self.part2)
+            if tn is None and not os.environ.get("IPX_NO_C16"):
+                self.A_col16 = own_columns16(A.pattern)
+                a.A_col16 = _ptr(self.A_col16)
         # tridiagonal A A' on the single-launch solve: g = r - A'v rides in that launch
         if a.solver_kind == 0 and not os.environ.get("IPX_NO_FUSE"):
             geo = (ctypes.c_int32 * 2)()
