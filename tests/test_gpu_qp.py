@@ -512,6 +512,92 @@ def test_box_schur_solver(ips, n, m):
     assert np.max(np.abs(A.dot(z))) <= 1e-9 * np.max(np.abs(x))
 
 
+@pytest.mark.parametrize("bounds", ["all", "ragged"])
+def test_box_schur_projection_without_matrix_rows(ips, bounds):
+    """The CG loop's projection for barrier problems (csrc/boxschur.hip ipx_boxschur_project,
+    csrc/cg.hip k_cg_step1_box): g = r - A'(A A')^-1 A r with the box rows handled per group
+    on r itself -- never multiplied as rows of A or A'.  Against the operator built from the
+    SpMVs and ipx_boxschur_solve (same formulas: 1e-13), against a direct sparse solve, with
+    every variable bounded on both sides and with a ragged mix (lower only, upper only, both,
+    none: single-row groups and x-columns outside every group); then a whole projected-CG run
+    with slack bounds through the device loop against the oracle."""
+    import ctypes
+    import torch
+    import oracle
+    import ipsolver.cg_fused as cg_fused
+    from ipsolver import _hip
+    from ipsolver.boxschur import BoxSchurNormalSolver
+    n, m = 6000, 600
+    rng = np.random.default_rng(7)
+    inst = BandedInstance(n, m)
+    J = inst.A
+    if bounds == "all":
+        L = U = np.arange(n)
+    else:
+        kind = rng.integers(0, 4, n)                    # 0 none, 1 lower, 2 upper, 3 both
+        L, U = np.flatnonzero(kind & 1), np.flatnonzero(kind & 2)
+    nl, nu = len(L), len(U)
+    I = sps.eye(n, format="csr")
+    s = rng.uniform(1e-6, 2.0, m + nl + nu)             # some slacks of (nearly) active bounds
+    A = sps.bmat([[J, sps.diags(s[:m]), None, None],
+                  [-I[L], None, sps.diags(s[m:m + nl]), None],
+                  [I[U], None, None, sps.diags(s[m + nl:])]], format="csr")
+    A.sort_indices()
+    N, M = A.shape[1], A.shape[0]
+    Ad = ips.dv.DeviceCSR.from_scipy(A)
+    Z, LS, Y = ips.proj.projections(Ad)
+    solver = Z.projector.solver
+    assert isinstance(solver, BoxSchurNormalSolver)
+    args = solver.c_args()
+    assert args is not None and args.gcol and args.ngen == N - (n if bounds == "all" else
+                                                                 len(np.union1d(L, U))) - nl - nu
+    r = rng.standard_normal(N)
+    rd = ips.dv.DVec.from_host(r)
+    lib = _hip.load()
+    nblk = lib.ipx_boxschur_project_count(ctypes.byref(args))
+    g = torch.empty(N, dtype=torch.float64, device="cuda")
+    pg = torch.zeros(2 * nblk, dtype=torch.float64, device="cuda")
+    pres = torch.zeros(M // 256 + 2, dtype=torch.float64, device="cuda")
+    n3, n4 = ctypes.c_int32(0), ctypes.c_int32(0)
+    _hip.call("ipx_boxschur_project", ctypes.byref(args), ips.dv._p(rd.t), ips.dv._p(g),
+              ips.dv._p(pg), ctypes.byref(n3), ips.dv._p(pres), ctypes.byref(n4), None,
+              ips.dv.stream_ptr())
+    got = g.cpu().numpy()
+    # the SpMV form with the same solver
+    v = solver.solve(Ad.dot(rd))
+    ref_dev = host(Ad.rmatvec_sub(v, rd))
+    assert np.max(np.abs(got - ref_dev)) <= 1e-13 * np.max(np.abs(r))
+    # a direct sparse solve
+    lu = sps.linalg.splu(sps.csc_matrix(A @ A.T))
+    want = r - A.T @ lu.solve(A @ r)
+    assert np.max(np.abs(got - want)) <= 1e-10 * np.max(np.abs(r))
+    assert n3.value == nblk
+    assert abs(float(pg[:nblk].sum()) - float(got @ got)) <= 1e-12 * float(got @ got)
+    # in place
+    g2 = rd.t.clone()
+    _hip.call("ipx_boxschur_project", ctypes.byref(args), ips.dv._p(g2), ips.dv._p(g2),
+              ips.dv._p(pg), ctypes.byref(n3), ips.dv._p(pres), ctypes.byref(n4), None,
+              ips.dv.stream_ptr())
+    assert np.array_equal(g2.cpu().numpy(), got)
+    # the device loop on the barrier-shaped subproblem: bounds on the slacks only
+    Hz = sps.block_diag([inst.H, sps.diags(rng.uniform(0.5, 2.0, N - n))], format="csr")
+    Hd = ips.dv.DeviceCSR.from_scipy(Hz)
+    c = rng.standard_normal(N)
+    b = np.zeros(M)
+    lb = np.concatenate((np.full(n, -np.inf), np.full(N - n, -0.995)))
+    assert cg_fused.supports(Hd, Z, Y)
+    before = dict(cg_fused.STATS)
+    x, info = cg_fused.projected_cg(Hd, ips.dv.DVec.from_host(c), Z, Y, ips.dv.DVec.from_host(b),
+                                    trust_radius=5.0, lb=ips.dv.DVec.from_host(lb), tol=1e-10)
+    assert cg_fused.STATS["calls"] == before["calls"] + 1
+    Zo, _, Yo = oracle.projections(A)
+    xo, io = oracle.projected_cg(Hz, c, Zo, Yo, b, trust_radius=5.0, lb=lb,
+                                 ub=np.full(N, np.inf), tol=1e-10)
+    assert (info["stop_cond"], info["hits_boundary"]) == (io["stop_cond"], io["hits_boundary"])
+    assert abs(info["niter"] - io["niter"]) <= 1
+    close(x, xo, 1e-8)
+
+
 @pytest.mark.parametrize("variant", ["plain", "sphere", "box"])
 def test_step2_fused_into_hp_is_bit_identical(ips, variant, monkeypatch):
     """For banded Hessians step2 runs inside the H.p SpMV (k_cg_step2_hp); it uses the
