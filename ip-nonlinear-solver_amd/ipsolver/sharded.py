@@ -972,6 +972,8 @@ class FusedShardedCG:
                 e.p3_lo[k], e.p3_hi[k] = Atp.tile_range(e.own_lo[k], e.own_hi[k])
         self._exchange_g = sh.comm.prepare_exchange_many(
             [(self.L.r[off:off + ln], lo, hi, sl, sr) for _, off, ln, lo, hi, sl, sr, _, _ in segs])
+        # (own range and send counts of the first segment: bench.py measures the exchange's floor)
+        self.col_geom = (segs[0][3], segs[0][4], segs[0][5], segs[0][6])
 
     def _segment(self, phase, it, mode=0):
         self._hip.call("ipx_cg_shard2_segment", self.L.ref(), ctypes.byref(self.ext), int(phase),

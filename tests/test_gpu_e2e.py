@@ -394,3 +394,36 @@ def test_sharded_barrier_box_inequality_hip(tmp_path):
     # every CG call ran on the device-resident loop (four-segment own ranges, csrc/cg.hip
     # ipx_cg_shard2_segment with the box-Schur solve)
     assert int(got["fused"]) >= 10 and int(got["cg"]) == int(rows[-1, 1])
+
+
+def test_bench_two_rank_rehearsal():
+    """``bench.py --gpus 2`` exactly as the driver launches it (torch.distributed.run, one rank
+    per process), here with both ranks on cuda:0 and the collectives over gloo
+    (IPX_BENCH_BACKEND=gloo: a correctness rehearsal of the N > 1 leg, not a measurement):
+    one JSON line, the sharded iterate equal to the single-GPU loop's, the reference's 25 / 34
+    trace for the full config-4 solve, collective counts per iteration as designed."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, IPX_BENCH_BACKEND="gloo")
+    out = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+         "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+         "--gpus", "2", "--steps", "12", "--warmup", "3", "--no-weak"],
+        cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 12 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["parity_vs_single_gpu"]["max_rel_diff"] < 1e-12
+    fs = d["wall_clock_to_gtol"]
+    assert (fs["status"], fs["niter"], fs["cg_niter"]) == (1, 25, 34)
+    per = d["collectives_per_iteration"]
+    assert per["all_reduce"] <= 2.5 and per["neighbour_exchange"] <= 1.5
