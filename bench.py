@@ -74,6 +74,11 @@ def single_gpu_measure(A_h, H_h, hdiag_h, c_h, n, m, K, W, repeats=20):
     g0 = Z.dot(r0)
     rt_g = g0.sumsq_amax()[0]
     L = cg_fused._Loop(H, P, None, None)
+    # what cg_fused.projected_cg does for trust_radius=inf without a box (the workload of this
+    # bench line): norm(x_next) >= inf cannot be True, the norm is not formed.  The same loop
+    # with a finite (never reached) radius is measured below as `finite_trust_radius`.
+    no_radius = 0 if os.environ.get("IPX_KEEP_XN2") else 1
+    L.args.no_radius = no_radius
     st = dv.stream_ptr()
     init = np.zeros(L.state.numel())
     init[cg_fused.ST_RTG0] = rt_g
@@ -145,6 +150,28 @@ def single_gpu_measure(A_h, H_h, hdiag_h, c_h, n, m, K, W, repeats=20):
     repeat = {"regions": repeats, "steps_each": K,
               "iterations_per_s": {"median": rates[len(rates) // 2], "min": rates[0],
                                    "max": rates[-1]}} if rates else None
+    # ---- the same loop with a finite trust radius that is never reached (1e300): the
+    # ||x + alpha p||^2 sums are formed and tested every iteration (the SQP's usage)
+    finite = None
+    if repeats > 0:
+        L.args.no_radius = 0
+        init_inf = init_dev
+        init[cg_fused.ST_RADIUS] = 1e300
+        init_dev = torch.from_numpy(init).to(L.state.device)
+        fr = []
+        run(0, W, "finite-radius warmup")
+        for _ in range(min(5, repeats)):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run(W, W + K, "finite-radius")
+            torch.cuda.synchronize()
+            fr.append(K / (time.perf_counter() - t0))
+        check_ran(W + K)
+        fr.sort()
+        finite = {"trust_radius": 1e300, "iterations_per_s": fr[len(fr) // 2],
+                  "regions": len(fr), "steps_each": K}
+        L.args.no_radius = no_radius
+        init_dev = init_inf
 
     # ---- per-kernel attribution with HIP events on the launch stream
     ms = (ctypes.c_float * 7)()
@@ -196,7 +223,7 @@ def single_gpu_measure(A_h, H_h, hdiag_h, c_h, n, m, K, W, repeats=20):
         algo["step2_spmv_H_p"] = algo.pop("spmv_H_p") + algo.pop("step2") - 8 * n
     if fused1:      # r_next is not read back by the SpMV
         algo["step1_spmv_A_r"] = algo.pop("spmv_A_r") + algo.pop("step1") - 8 * n
-        if L.part5 is not None:     # ||x + alpha p||^2 by recurrence: x and p are not read
+        if L.part5 is not None or no_radius:     # ||x + alpha p||^2 not summed here: x, p not read
             algo["step1_spmv_A_r"] -= 2 * 8 * n
     if fused3:      # v is not read back by the SpMV
         algo["banded_solve_residual_r_minus_Atv"] = algo.pop("spmv_r_minus_Atv") - 8 * m
@@ -208,6 +235,7 @@ def single_gpu_measure(A_h, H_h, hdiag_h, c_h, n, m, K, W, repeats=20):
     med_rate = repeat["iterations_per_s"]["median"] if repeat else K / elapsed
     return {
         "A": A, "H": H, "c": c, "b": b, "Z": Z, "Y": Y, "elapsed": elapsed, "repeat": repeat,
+        "finite": finite,
         "t_factor": t_factor, "nnzA": nnzA, "nnzH": nnzH, "dom": dom,
         "per_kernel_us": per_kernel_us,
         "roofline": {"bound": "hbm", "kernel": dom_label,
@@ -509,10 +537,12 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": "config3: sparse banded NLP subproblem, CSR Jacobian "
-                               "bandwidth 15, tol=0, trust_radius=inf",
+                               "bandwidth 15, tol=0, trust_radius=inf (the norm test that cannot "
+                               "trigger is skipped; see finite_trust_radius)",
                    "n": n, "m": m, "nnz_A": r1["nnzA"], "nnz_H": r1["nnzH"],
                    "parallelism": "single GPU"},
         "repeat": r1["repeat"],
+        "finite_trust_radius": r1["finite"],
         "roofline": dict(r1["roofline"], traffic=traffic, traffic_source=traffic_src),
         "per_kernel_us": r1["per_kernel_us"],
         "whole_iteration": r1["whole_iteration"],

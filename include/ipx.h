@@ -261,6 +261,10 @@ typedef struct ipx_cg_args {
   /* The same for the fused step1 + A.r kernel (A_span > 0, standard tiles, no IPX_RECUR):
    * one uint16 per nonzero of A, col - A_own[its row tile]; NULL: A_colidx is read. */
   const void *A_col16;
+  /* != 0: the trust radius in the state block is +inf (and, fused step1 implying no box, the
+   * tests of qp_subproblem.py:583,599 can never trigger): ||x + alpha p||^2 is not formed --
+   * the fused step1 + A.r kernel then does not read x and p.  Only read when step1 is fused. */
+  int64_t no_radius;
 } ipx_cg_args;
 int ipx_cg_state_size(void);
 int ipx_cg_vec_grid(int64_t n);

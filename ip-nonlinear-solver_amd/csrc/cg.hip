@@ -615,10 +615,11 @@ k_cg_step1_ar(int n, double *st, int parity, const double *__restrict__ p1, int 
   __shared__ int rp[IPX_SPMV_TILE_ROWS + 1];
   __shared__ double lds[3 * (IPX_BLOCK / IPX_WAVE)];
   CG_STAMP(8);
-  const int tile = ipx_xcd_item(blockIdx.x, RECUR ? ntiles + 1 : ntiles);
+  // (RECUR without p5: the norm is not wanted at all -- trust radius +inf -- no extra workgroup)
+  const int tile = ipx_xcd_item(blockIdx.x, (RECUR && p5) ? ntiles + 1 : ntiles);
   if (tile < 0) return;
   const int tid = threadIdx.x;
-  if (RECUR && tile == ntiles) {
+  if (RECUR && p5 && tile == ntiles) {
     // the extra workgroup: alpha like everybody else, then the three sums
     if (st[ST_STOP] != 0.0) return;
     const double rtg = st[parity ? ST_RTG1 : ST_RTG0];
@@ -911,8 +912,12 @@ static int part3_count(const ipx_cg_args *a) {
 }
 
 // step1 + A.r in one launch (see k_cg_step1_ar): r_next <- r + alpha Hp, w <- A r_next
+// no_xn2: trust radius +inf and no box -- ||x + alpha p||^2 is not formed at all (it can only
+// feed a comparison that is always false): x and p are not read, 16 of the kernel's 56 MB at
+// n = 1e6 (the RECUR instantiation without its summing workgroup)
 static int launch_step1_ar(const ipx_cg_args *a, int it, const double *p1, int np1,
-                           hipStream_t st, const double *p5 = nullptr, int np5 = 0) {
+                           hipStream_t st, const double *p5 = nullptr, int np5 = 0,
+                           bool no_xn2 = false) {
   const bool recur = p5 != nullptr;             // (+1: the workgroup that forms ||x + alpha p||^2)
   const dim3 grid(ipx_xcd_grid((int)a->A_ntiles + (recur ? 1 : 0))), block(IPX_BLOCK);
 #define FUSED_ARGS                                                                         \
@@ -925,6 +930,8 @@ static int launch_step1_ar(const ipx_cg_args *a, int it, const double *p1, int n
   do {                                                                                     \
     if (half) hipLaunchKernelGGL((k_cg_step1_ar<Q, 1024, false, false>), grid, block, 0, st, FUSED_ARGS); \
     else if (recur) hipLaunchKernelGGL((k_cg_step1_ar<Q, FT_NNZ, true, false>), grid, block, 0, st, FUSED_ARGS); \
+    else if (no_xn2 && a->A_col16) hipLaunchKernelGGL((k_cg_step1_ar<Q, FT_NNZ, true, true>), grid, block, 0, st, FUSED_ARGS); \
+    else if (no_xn2) hipLaunchKernelGGL((k_cg_step1_ar<Q, FT_NNZ, true, false>), grid, block, 0, st, FUSED_ARGS); \
     else if (a->A_col16) hipLaunchKernelGGL((k_cg_step1_ar<Q, FT_NNZ, false, true>), grid, block, 0, st, FUSED_ARGS); \
     else hipLaunchKernelGGL((k_cg_step1_ar<Q, FT_NNZ, false, false>), grid, block, 0, st, FUSED_ARGS);    \
   } while (0)
@@ -1307,6 +1314,9 @@ static int cg_iterate(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, hi
     int np1 = (int)a->H_ntiles;
     cmp.add(p1, np1, 2, 2048);      // beyond what a consumer folds in one or two rounds
     const bool recur = xn2_recur(a);
+    // trust radius +inf, no box (fused step1 implies no box): the radius / box tests of
+    // qp_subproblem.py:583,599 cannot trigger; their sums are neither formed nor folded
+    const bool no_xn2 = fuse1 && !recur && a->no_radius != 0;
     const double *p5 = recur ? a->part5 : nullptr;
     int np5 = (int)a->H_ntiles;
     if (recur) cmp.add(p5, np5, 3, 2048);
@@ -1314,7 +1324,7 @@ static int cg_iterate(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, hi
     if (rc) return rc;
     if (fuse1) {
       MARK(1);
-      rc = launch_step1_ar(a, it, p1, np1, st, p5, np5);   // r_next = r + alpha Hp;  w = A r_next
+      rc = launch_step1_ar(a, it, p1, np1, st, p5, np5, no_xn2);   // r_next = r + alpha Hp;  w = A r_next
       if (rc) return rc;
       MARK(2);
     } else if (a->m > 0 && box_project(a)) {
@@ -1383,7 +1393,7 @@ static int cg_iterate(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, hi
     }
     const double *p2 = a->part2, *p3 = a->part3, *p4 = a->part4;
     int np2 = part2_count(a), n4 = np4;
-    if (!recur) cmp.add(p2, np2, 2, 1024);
+    if (!recur && !no_xn2) cmp.add(p2, np2, 2, 1024);
     if (a->m > 0) {
       cmp.add(p3, np3, 2, 2048);
       cmp.add(p4, n4, 1, 1024);
@@ -1392,12 +1402,12 @@ static int cg_iterate(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, hi
     if (rc) return rc;
     if (fused_hp(a)) {
       MARK(6);
-      rc = launch_step2_hp(a, it, (a->m > 0 ? 0 : 2) | (recur ? 4 : 0), p2, np2, p3, np3, p4, n4,
-                           st);
+      rc = launch_step2_hp(a, it, (a->m > 0 ? 0 : 2) | (recur ? 4 : 0) | (no_xn2 ? 1 : 0), p2, np2,
+                           p3, np3, p4, n4, st);
     } else {
       hipLaunchKernelGGL(k_cg_step2, dim3(ipx_xcd_grid((int)a->vec_grid)), dim3(VB), 0, st, a->n,
-                         a->state, it & 1, a->m > 0 ? 0 : 2, p2, np2, p3, np3, p4, n4, a->x, a->p,
-                         a->r, (int)a->vec_grid);
+                         a->state, it & 1, (a->m > 0 ? 0 : 2) | (no_xn2 ? 1 : 0), p2, np2, p3, np3,
+                         p4, n4, a->x, a->p, a->r, (int)a->vec_grid);
       IPX_CHECK_LAUNCH();
       MARK(6);
       rc = launch_hp(a, guard, st);

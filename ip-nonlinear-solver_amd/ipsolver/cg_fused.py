@@ -41,7 +41,7 @@ class CgArgs(ctypes.Structure):
         ("r_next", _P), ("A_own", _P), ("A_span", _I64), ("fold_ws", _P),
         ("At_vown", _P), ("At_qv", _I64), ("A_tile_nnz", _I64),
         ("At_ell_col", _P), ("At_ell_val", _P), ("part5", _P),
-        ("H_col16", _P), ("H_rowlen", _P), ("A_col16", _P))]
+        ("H_col16", _P), ("H_rowlen", _P), ("A_col16", _P), ("no_radius", _I64))]
 
 
 # Counters over the life of the process (diagnostics: how often the device loop
@@ -504,6 +504,12 @@ def projected_cg(H, c, Z, Y, b, trust_radius=np.inf, lb=None, ub=None, tol=None,
 
     # (no upper bounds given: the loop's kernels do not read a vector of +inf)
     L = _Loop(H, P, lb if has_box else None, ub if has_box and ub_given else None)
+    # Unbounded trust region and no box (the reference's default trust_radius=np.inf): the
+    # test norm(x_next) >= trust_radius of qp_subproblem.py:583 is always False, so the norm
+    # is not formed (the fused step1 + A.r kernel then reads neither x nor p)
+    if np.isinf(trust_radius) and trust_radius > 0 and not has_box \
+            and not os.environ.get("IPX_KEEP_XN2"):
+        L.args.no_radius = 1
     st = stream_ptr()
     L.x.copy_(x0.t)
     L.r.copy_(r0.t)
