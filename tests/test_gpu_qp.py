@@ -512,6 +512,32 @@ def test_box_schur_solver(ips, n, m):
     assert np.max(np.abs(A.dot(z))) <= 1e-9 * np.max(np.abs(x))
 
 
+def test_unbounded_trust_region_skips_the_norm(ips, monkeypatch):
+    """trust_radius=inf without a box: ``norm(x_next) >= trust_radius`` (qp_subproblem.py:583)
+    cannot be True, the device loop does not form the norm (csrc/cg.hip no_xn2).  Same
+    iterates, bit for bit, as with the norm formed; and a finite radius still stops."""
+    n, m = 20000, 2000
+    inst = BandedInstance(n, m)
+    A = ips.dv.DeviceCSR.from_scipy(inst.A)
+    H = ips.dv.DeviceCSR.from_scipy(inst.H)
+    Z, LS, Y = ips.proj.projections(A)
+    b = np.zeros(m)
+    runs = []
+    for keep in ("", "1"):
+        if keep:
+            monkeypatch.setenv("IPX_KEEP_XN2", "1")
+        else:
+            monkeypatch.delenv("IPX_KEEP_XN2", raising=False)
+        x, info = ips.qp.projected_cg(H, inst.c, Z, Y, b, tol=1e-12)
+        runs.append((host(x), info))
+    assert runs[0][1] == runs[1][1] and np.array_equal(runs[0][0], runs[1][0])
+    monkeypatch.delenv("IPX_KEEP_XN2", raising=False)
+    radius = 0.5 * float(np.linalg.norm(runs[0][0]))
+    x, info = ips.qp.projected_cg(H, inst.c, Z, Y, b, trust_radius=radius, tol=1e-12)
+    assert info["stop_cond"] == 2 and info["hits_boundary"]
+    assert abs(np.linalg.norm(host(x)) - radius) <= 1e-12 * radius
+
+
 @pytest.mark.parametrize("bounds", ["all", "ragged"])
 def test_box_schur_projection_without_matrix_rows(ips, bounds):
     """The CG loop's projection for barrier problems (csrc/boxschur.hip ipx_boxschur_project,
