@@ -1185,12 +1185,14 @@ k_solve_decoupled(LevDev lv, const double *__restrict__ w, double *__restrict__ 
 #pragma unroll
     for (int k = 0; k < QA; ++k) {
       const int j = av0 + min(ta + k * ATV_T, max(avn - 1, 0));
-      // (clamped: an empty row re-reads a neighbouring entry, never out of bounds)
-      const int e0 = max(min(ra[k], rb[k] - 1), 0), e1 = max(rb[k] - 1, e0);
-      ac0[k] = atv.colidx[e0];
-      ac1[k] = atv.colidx[e1];
-      aw0[k] = atv.val[e0];
-      aw1[k] = atv.val[e1];
+      if (K == 1) {
+        // (clamped: an empty row re-reads a neighbouring entry, never out of bounds)
+        const int e0 = max(min(ra[k], rb[k] - 1), 0), e1 = max(rb[k] - 1, e0);
+        ac0[k] = atv.colidx[e0];
+        ac1[k] = atv.colidx[e1];
+        aw0[k] = atv.val[e0];
+        aw1[k] = atv.val[e1];
+      }
       ar[k] = atv.r_in[j];
     }
   }
@@ -1259,8 +1261,14 @@ k_solve_decoupled(LevDev lv, const double *__restrict__ w, double *__restrict__ 
       if (ta >= 0 && jl < avn) {
         const int len = rb[k] - ra[k];
         double sum = 0.0;
-        if (len > 0) sum += aw0[k] * sx[ac0[k] - rfirst];
-        if (len > 1) sum += aw1[k] * sx[ac1[k] - rfirst];
+        if (K == 1) {
+          if (len > 0) sum += aw0[k] * sx[ac0[k] - rfirst];
+          if (len > 1) sum += aw1[k] * sx[ac1[k] - rfirst];
+        } else {
+          // half bandwidth K: up to K + 1 constraints per variable, all within K rows of the
+          // first (which lies in this workgroup's rows): read here, not held in registers
+          for (int e = ra[k]; e < rb[k]; ++e) sum += atv.val[e] * sx[atv.colidx[e] - rfirst];
+        }
         double y = -1.0 * sum;
         y += 1.0 * ar[k];
         atv.g_out[av0 + jl] = y;
@@ -1624,7 +1632,7 @@ int launch_solve_decoupled(const LevDev &lv, const double *w, double *x, const d
   const AtvJob none{};
   if (!atv || qv <= 0)
     return launch_solve_decoupled_q<K, 0>(lv, w, x, rinv, partial, npartial, guard, none, st);
-  if constexpr (K != 1) return IPX_EINVAL;      // the A'v tail needs a tridiagonal A A'
+  if constexpr (K > 4) return IPX_EINVAL;       // the A'v tail is compiled for half bandwidth <= 4
   else {
   if (qv <= 4) return launch_solve_decoupled_q<K, 4>(lv, w, x, rinv, partial, npartial, guard, *atv, st);
   if (qv <= 8) return launch_solve_decoupled_q<K, 8>(lv, w, x, rinv, partial, npartial, guard, *atv, st);
@@ -2283,7 +2291,7 @@ extern "C" int ipx_banded_decoupled_geometry(void *handle, int32_t *out) {
   if (!handle || !out) return 0;
   Banded *h = (Banded *)handle;
   const Level &l0 = h->lev[0];
-  if (!(h->fast && h->nlev > 1 && h->decoupled && l0.k == 1))
+  if (!(h->fast && h->nlev > 1 && h->decoupled))
     return 0;
   out[0] = DEC_CHUNKS * l0.q;
   out[1] = (l0.P + DEC_CHUNKS - 1) / DEC_CHUNKS;
@@ -2307,8 +2315,14 @@ int ipx_banded_solve_resid_atv_launch(void *handle, const double *w, double *x, 
   if (h->pcr_L > 0 && ell_col && ell_val)
     return launch_solve_pcr(to_dev(h->lev[0], nullptr), h->pcr_L, w, x, partial, npartial, guard,
                             st, &job, qv);
-  return launch_solve_decoupled<1>(to_dev(h->lev[0], nullptr), w, x, h->rinv, partial, npartial,
-                                   guard, st, &job, qv);
+  const LevDev lv = to_dev(h->lev[0], nullptr);
+  switch (lv.k) {
+    case 1: return launch_solve_decoupled<1>(lv, w, x, h->rinv, partial, npartial, guard, st, &job, qv);
+    case 2: return launch_solve_decoupled<2>(lv, w, x, h->rinv, partial, npartial, guard, st, &job, qv);
+    case 3: return launch_solve_decoupled<3>(lv, w, x, h->rinv, partial, npartial, guard, st, &job, qv);
+    case 4: return launch_solve_decoupled<4>(lv, w, x, h->rinv, partial, npartial, guard, st, &job, qv);
+  }
+  return IPX_EINVAL;
 }
 
 // Solve + residual partials in one go (the CG loop's projection step).

@@ -205,14 +205,16 @@ def own_columns16(pattern):
     return cached
 
 
-def fuse_vown(At_pattern, rows_per_wg, nwg):
+def fuse_vown(At_pattern, rows_per_wg, nwg, k=1):
     """Variables owned by each workgroup of the single-launch decoupled solve, for the
     fused g = r - A'v tail (csrc/banded.hip AtvJob): ``(table, qv)`` or None.  A variable
     belongs to the workgroup whose constraint rows contain the first constraint that
-    touches it.  Qualifies when every variable sees at most two constraints and they are
-    adjacent (tridiagonal A A'), the owners are non-decreasing along the variables, and no
-    workgroup gets more than 4096 of them.  Symbolic; cached per geometry."""
-    key = ("_ipx_fuse_vown", int(rows_per_wg), int(nwg))
+    touches it.  Qualifies when every variable sees at most ``k + 1`` constraints, all within
+    ``k`` rows of the first (``k`` = half bandwidth of A A', <= 4: the kernel keeps the
+    solution of its own rows and ``k`` rows either side in LDS), the owners are
+    non-decreasing along the variables, and no workgroup gets more than 4096 of them.
+    Symbolic; cached per geometry."""
+    key = ("_ipx_fuse_vown", int(rows_per_wg), int(nwg), int(k))
     cache = getattr(At_pattern, "_ipx_fuse_vown", None)
     if cache is not None and cache[0] == key:
         return cache[1]
@@ -220,16 +222,15 @@ def fuse_vown(At_pattern, rows_per_wg, nwg):
     n = At_pattern.shape[0]
     ip, idx = At_pattern.indptr_h.astype(np.int64), At_pattern.indices_h.astype(np.int64)
     lens = np.diff(ip)
-    if At_pattern.nnz > 0 and lens.max() <= 2:
+    if At_pattern.nnz > 0 and lens.max() <= k + 1 and 1 <= k <= 4:
         nonempty = lens > 0
         first = np.full(n, -1, dtype=np.int64)
         last = first.copy()
-        e0, e1 = idx[ip[:-1][nonempty]], idx[ip[1:][nonempty] - 1]     # rows of 1 or 2 entries,
-        first[nonempty], last[nonempty] = np.minimum(e0, e1), np.maximum(e0, e1)   # any order
-        if np.all(last - first <= 1):
+        starts = ip[:-1][nonempty]
+        first[nonempty] = np.minimum.reduceat(idx, starts)      # entries in any order
+        last[nonempty] = np.maximum.reduceat(idx, starts)
+        if np.all(last - first <= k):
             # rows without entries go with the next variable that has some
-            filled = first.copy()
-            nxt = n
             pos = np.where(nonempty, np.arange(n), n)
             nxt_idx = np.minimum.accumulate(pos[::-1])[::-1]
             filled = np.where(nxt_idx < n, first[np.minimum(nxt_idx, n - 1)], idx.max())
@@ -395,11 +396,13 @@ class _Loop:
             # that the separate SpMV streams better: measured 161 vs 170 us at n = 4e6)
             if lib.ipx_banded_decoupled_geometry(ctypes.c_void_p(P.solver.handle), geo) \
                     and geo[1] <= 512:
-                vown = fuse_vown(At.pattern, geo[0], geo[1])
+                kS = int(getattr(P.solver, "k", 1))
+                vown = fuse_vown(At.pattern, geo[0], geo[1], kS) if kS <= 4 else None
                 if vown is not None:
                     self.vown = vown[0]
                     a.At_vown, a.At_qv = _ptr(self.vown), vown[1]
-                    if n % 2 == 0:      # pairs of variables per 16-byte load (csrc/banded.hip)
+                    # tridiagonal A A': ELL(2) rows, pairs of variables per 16-byte load
+                    if n % 2 == 0 and kS == 1:
                         self.ell_col, self.ell_val = ell_rows(At)
                         a.At_ell_col, a.At_ell_val = _ptr(self.ell_col), _ptr(self.ell_val)
         # Optional (IPX_RECUR=1), both fused kernels in use: ||x + alpha p||^2 by recurrence from

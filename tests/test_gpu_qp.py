@@ -663,7 +663,9 @@ def test_step2_fused_into_hp_is_bit_identical(ips, variant, monkeypatch):
 
 
 @pytest.mark.parametrize("n,m,hbw,abw,seed", [(5000, 400, 2, 9, 0), (12345, 1500, 3, 6, 1),
-                                               (3001, 299, 1, 21, 2), (40000, 2500, 5, 30, 3)])
+                                               (3001, 299, 1, 21, 2), (40000, 2500, 5, 30, 3),
+                                               (30000, 3000, 2, 30, 4), (30000, 3000, 1, 30, 5),
+                                               (30000, 3000, 1, 22, 5)])
 def test_fused_kernels_on_other_band_shapes(ips, n, m, hbw, abw, seed, monkeypatch):
     """The two fused kernels (step1 in A.r, step2 in H.p) against the separate launches on
     banded problems of other shapes: Hessian half bandwidth 1..5, Jacobian rows of ragged
@@ -690,6 +692,15 @@ def test_fused_kernels_on_other_band_shapes(ips, n, m, hbw, abw, seed, monkeypat
     assert cg_fused.supports(H, Z, Y)
     assert cg_fused.fuse_halo(H.pattern) == hbw
     # (whether step1 also fuses depends on how many columns a row tile of A spans: <= 2048)
+    # half bandwidth 2..4 of A A' with decoupled separators: g = r - A'v rides in the banded
+    # solve's launch (up to k + 1 constraints per variable, read in the kernel's tail)
+    kS = Z.projector.solver.k
+    if seed >= 4:
+        import ctypes
+        from ipsolver import _hip
+        assert 2 <= kS <= 4
+        assert _hip.load().ipx_banded_decoupled(ctypes.c_void_p(Z.projector.solver.handle)) == 1
+        assert cg_fused._Loop(H, Z.projector, None, None).args.At_qv > 0
     runs = []
     for no_fuse in ("", "1"):
         if no_fuse:
