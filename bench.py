@@ -508,7 +508,20 @@ def main():
     t_gen = time.time() - t0
 
     if world > 1:
-        return sharded_leg(args, world, rank, A_h, H_h, hdiag_h, c_h, n, m, K, W)
+        try:
+            return sharded_leg(args, world, rank, A_h, H_h, hdiag_h, c_h, n, m, K, W)
+        except Exception as exc:         # a failure must be readable in the bench line
+            import traceback
+            if rank == 0:
+                print(json.dumps({
+                    "metric": "projected-CG iters/sec (fp64) at n=1e6,m=1e5", "value": 0.0,
+                    "unit": "iterations/s", "n_gpus": world, "steps": K, "warmup": W,
+                    "ms_per_step": None, "higher_is_better": True, "scaling": "strong",
+                    "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                    "config": {"workload": "config4 sharded over %d GPUs: FAILED" % world},
+                    "error": repr(exc), "traceback": traceback.format_exc()[-1500:]}))
+                sys.stdout.flush()
+            raise
 
     r1 = single_gpu_measure(A_h, H_h, hdiag_h, c_h, n, m, K, W, repeats=args.repeats)
     A, H, c, b, Z, Y = (r1.pop(k) for k in ("A", "H", "c", "b", "Z", "Y"))
