@@ -206,7 +206,8 @@ k_pairs_post(int ng, int ngen, ipx_group_tab T, const int32_t *__restrict__ gen_
              const double *r, const int32_t *__restrict__ yrp,
              const int32_t *__restrict__ ycol, const double *__restrict__ yval,
              const double *__restrict__ vR, int ny, double *gout,
-             double *__restrict__ part, int npart, const double *__restrict__ guard) {
+             double *__restrict__ part, int npart, const double *__restrict__ guard,
+             ipx_own_ranges own) {
   __shared__ double lds[IPX_BLOCK / IPX_WAVE];
   if (guard && *guard != 0.0) return;
   // y_c = (A_R' v_R)_c: the column's few general-row entries, summed left to right like the
@@ -263,24 +264,24 @@ k_pairs_post(int ng, int ngen, ipx_group_tab T, const int32_t *__restrict__ gen_
       double gc = -1.0 * sum;
       gc += 1.0 * rc;
       gout[c] = gc;
-      acc += gc * gc;
+      if (own.has(c)) acc += gc * gc;
       if (cp >= 0) {
         double gp = -1.0 * (sp * vp);
         gp += 1.0 * rp;
         gout[cp] = gp;
-        acc += gp * gp;
+        if (own.has(cp)) acc += gp * gp;
       }
       if (cq >= 0) {
         double gq = -1.0 * (sq * vq);
         gq += 1.0 * rq;
         gout[cq] = gq;
-        acc += gq * gq;
+        if (own.has(cq)) acc += gq * gq;
       }
     } else {
       double gc = -1.0 * yj;
       gc += 1.0 * rc;
       gout[c] = gc;
-      acc += gc * gc;
+      if (own.has(c)) acc += gc * gc;
     }
   }
   const double tot = ipx_block_reduce<IPX_SUM>(acc, lds);
@@ -299,7 +300,7 @@ extern "C" int ipx_boxschur_project_count(const ipx_boxschur_args *a);
 int ipx_boxschur_project_from(const ipx_boxschur_args *a, const double *r, double *g,
                               double *part_g, int32_t *npart_g, double *part_res,
                               int32_t *npart_res, const double *guard, int have_up,
-                              hipStream_t stream) {
+                              hipStream_t stream, const ipx_own_ranges *own) {
   if (!a || !r || !g || !part_g || !a->gcol || !a->grp || !a->up ||
       (a->ngen > 0 && !a->gen_cols))
     return IPX_EINVAL;
@@ -327,10 +328,13 @@ int ipx_boxschur_project_from(const ipx_boxschur_args *a, const double *r, doubl
   if (npart_res) *npart_res = np;
   const int nblk = ipx_boxschur_project_count(a);
   if (npart_g) *npart_g = nblk;
+  ipx_own_ranges all;                                    // every column counts
+  for (int k = 0; k < 4; ++k) { all.lo[k] = 0; all.hi[k] = 0; }
+  all.hi[0] = a->n;
   if (nblk > 0) {
     hipLaunchKernelGGL(k_pairs_post, dim3(nblk), dim3(IPX_BLOCK), 0, st, ng, (int)a->ngen, T,
                        a->gen_cols, r, a->ARt_rowptr, a->ARt_colidx, a->ARt_val, a->vR, (int)a->ny,
-                       g, part_g, nblk, guard);
+                       g, part_g, nblk, guard, own ? *own : all);
     IPX_CHECK_LAUNCH();
   }
   return IPX_OK;

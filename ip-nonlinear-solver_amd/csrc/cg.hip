@@ -57,16 +57,7 @@ constexpr int VB = IPX_BLOCK;
 
 constexpr int VU = 8;        // elements per lane per trip, loads issued together (one trip at n = 1e6)
 
-// The elements that count in step1's reductions: everything on one GPU; in the row-sharded
-// loop a rank's OWN entries -- one range per segment of the local vector (x-space: one;
-// the barrier problem's z = [x; s_nl; s_lb; s_ub]: four), halo copies in between.
-struct OwnRanges {
-  int64_t lo[4], hi[4];
-  __device__ __forceinline__ bool has(int64_t i) const {
-    return (i >= lo[0] && i < hi[0]) || (i >= lo[1] && i < hi[1]) || (i >= lo[2] && i < hi[2]) ||
-           (i >= lo[3] && i < hi[3]);
-  }
-};
+typedef ipx_own_ranges OwnRanges;      // (ipx_common.h)
 static OwnRanges own_all(int64_t n) {
   OwnRanges o;
   for (int k = 0; k < 4; ++k) { o.lo[k] = 0; o.hi[k] = 0; }
@@ -164,7 +155,7 @@ k_cg_step1_box(double *st, int parity, const double *__restrict__ p1, int np1,
                const double *__restrict__ Hp, const double *__restrict__ lb,
                const double *__restrict__ ub, double *__restrict__ p2, int nblk, int ng, int ngen,
                ipx_group_tab T, const int32_t *__restrict__ gen_cols, int ny,
-               double *__restrict__ up) {
+               double *__restrict__ up, OwnRanges own) {
   __shared__ double lds[IPX_BLOCK / IPX_WAVE];
   const int blk = ipx_xcd_item(blockIdx.x, nblk);
   if (blk < 0) return;
@@ -221,8 +212,10 @@ k_cg_step1_box(double *st, int parity, const double *__restrict__ p1, int np1,
       const double xn = xv[t] + alpha * pv[t];                 // :580 (not stored)
       rn[t] = rv[t] + alpha * hv[t];                           // :622
       if (e[t] >= 0) {
-        sx += xn * xn;
-        if (lb) viol += ((lo[t] <= xn) && (xn <= hi[t])) ? 0.0 : 1.0;   // :599
+        if (own.has(e[t])) {                                   // (sharded: own entries only)
+          sx += xn * xn;
+          if (lb) viol += ((lo[t] <= xn) && (xn <= hi[t])) ? 0.0 : 1.0;   // :599
+        }
         r[e[t]] = rn[t];
       }
     }
@@ -1060,56 +1053,80 @@ int ipx_cg_shard2_segment(const ipx_cg_args *a, const ipx_shard2_ext *e, int32_t
   int rc = IPX_OK;
   if (phase == 0) {
     const bool fuse1 = fused_ar(a);
-    if (fuse1) {
-      rc = launch_step1_ar(a, it, e->s1, 1, st);
-      if (rc) return rc;
-    } else {
-      hipLaunchKernelGGL(k_cg_step1, dim3(ipx_xcd_grid(grid)), dim3(VB), 0, st, a->n, a->state,
-                         it & 1, e->s1, 1, a->x, a->p, a->r, a->Hp, a->lb, a->ub, a->part2, grid,
-                         own_of(e));
+    const bool boxp = box_project(a);
+    int np4 = 0, np3 = (int)a->At_ntiles, np2 = fuse1 ? (int)a->A_ntiles : grid;
+    if (boxp) {
+      // barrier problem: the projection without the box rows as matrix rows (csrc/boxschur.hip);
+      // the kernels count a rank's own entries only (element mask), so the own sums are the
+      // sums over ALL their partials
+      const ipx_boxschur_args *b = (const ipx_boxschur_args *)a->banded;
+      const OwnRanges own = own_of(e);
+      np2 = step1_box_blocks(a);
+      hipLaunchKernelGGL(k_cg_step1_box, dim3(ipx_xcd_grid(np2)), dim3(IPX_BLOCK), 0, st, a->state,
+                         it & 1, e->s1, 1, a->x, a->p, a->r, a->Hp, a->lb, a->ub, a->part2, np2,
+                         (int)b->ng, (int)b->ngen, ipx_group_tab{b->gcol, b->grp}, b->gen_cols,
+                         (int)b->ny, b->up, own);
       IPX_CHECK_LAUNCH();
-      ipx_csr_view A{(int)a->m, (int)a->n, a->A_rowptr, a->A_colidx, a->A_val, a->A_tiles,
-                     (int)a->A_ntiles};
-      rc = ipx_spmv_launch(A, a->r, 1.0, nullptr, 0.0, nullptr, a->w, nullptr, guard, st);
+      int32_t n3 = 0, n4 = 0;
+      rc = ipx_boxschur_project_from(b, a->r, a->r, a->part3, &n3, a->part4, &n4, guard, 1, st, &own);
       if (rc) return rc;
-    }
-    int np4 = 0, np3 = (int)a->At_ntiles;
-    const double *r_in = fuse1 ? a->r_next : a->r;
-    if (a->solver_kind == 0 && a->At_vown && a->At_qv > 0) {
-      rc = ipx_banded_solve_resid_atv_launch(a->banded, a->w, a->v, a->part4, &np4, a->At_rowptr,
-                                             a->At_colidx, a->At_val, r_in, a->r, a->At_vown,
-                                             (int)a->At_qv, a->part3, guard, st, a->At_ell_col,
-                                             a->At_ell_val, a->n);
-      if (rc) return rc;
-      np3 = np4;
+      np3 = n3;
+      np4 = n4;
     } else {
-      if (a->solver_kind == 1)      // box rows eliminated analytically, banded Schur complement
-        rc = ipx_boxschur_solve((const ipx_boxschur_args *)a->banded, a->w, a->v, a->part4, &np4,
-                                guard, st);
-      else
-        rc = ipx_banded_solve_resid_launch(a->banded, a->w, a->v, a->part4, &np4, guard, st);
-      if (rc) return rc;
-      ipx_csr_view At{(int)a->n, (int)a->m, a->At_rowptr, a->At_colidx, a->At_val, a->At_tiles,
-                      (int)a->At_ntiles};
-      rc = ipx_spmv_launch(At, a->v, -1.0, nullptr, 1.0, r_in, a->r, a->part3, guard, st);
-      if (rc) return rc;
+      if (fuse1) {
+        rc = launch_step1_ar(a, it, e->s1, 1, st);
+        if (rc) return rc;
+      } else {
+        hipLaunchKernelGGL(k_cg_step1, dim3(ipx_xcd_grid(grid)), dim3(VB), 0, st, a->n, a->state,
+                           it & 1, e->s1, 1, a->x, a->p, a->r, a->Hp, a->lb, a->ub, a->part2, grid,
+                           own_of(e));
+        IPX_CHECK_LAUNCH();
+        ipx_csr_view A{(int)a->m, (int)a->n, a->A_rowptr, a->A_colidx, a->A_val, a->A_tiles,
+                       (int)a->A_ntiles};
+        rc = ipx_spmv_launch(A, a->r, 1.0, nullptr, 0.0, nullptr, a->w, nullptr, guard, st);
+        if (rc) return rc;
+      }
+      const double *r_in = fuse1 ? a->r_next : a->r;
+      if (a->solver_kind == 0 && a->At_vown && a->At_qv > 0) {
+        rc = ipx_banded_solve_resid_atv_launch(a->banded, a->w, a->v, a->part4, &np4,
+                                               a->At_rowptr, a->At_colidx, a->At_val, r_in, a->r,
+                                               a->At_vown, (int)a->At_qv, a->part3, guard, st,
+                                               a->At_ell_col, a->At_ell_val, a->n);
+        if (rc) return rc;
+        np3 = np4;
+      } else {
+        if (a->solver_kind == 1)    // box rows eliminated analytically, banded Schur complement
+          rc = ipx_boxschur_solve((const ipx_boxschur_args *)a->banded, a->w, a->v, a->part4,
+                                  &np4, guard, st);
+        else
+          rc = ipx_banded_solve_resid_launch(a->banded, a->w, a->v, a->part4, &np4, guard, st);
+        if (rc) return rc;
+        ipx_csr_view At{(int)a->n, (int)a->m, a->At_rowptr, a->At_colidx, a->At_val, a->At_tiles,
+                        (int)a->At_ntiles};
+        rc = ipx_spmv_launch(At, a->v, -1.0, nullptr, 1.0, r_in, a->r, a->part3, guard, st);
+        if (rc) return rc;
+      }
     }
-    // (this path runs k_cg_step1 / k_cg_step1_ar, never the box-Schur step1)
-    const int np2 = fuse1 ? (int)a->A_ntiles : grid;
-    if (e->p4_hi > np4 || e->p2_hi > np2) return IPX_EINVAL;
+    if (e->p4_hi > np4 || (!boxp && e->p2_hi > np2)) return IPX_EINVAL;
     RangeJob job;
     job.npieces = (int)e->nseg;
     job.active = 15;
     for (int pc = 0; pc < 4; ++pc)
       for (int q = 0; q < 4; ++q) { job.ptr[pc][q] = a->part2; job.count[pc][q] = 0; }
     // ||x+ap||^2, #violations and ||A g||^2 are single ranges (piece 0); ||g||^2 one per segment
-    job.ptr[0][0] = a->part2 + e->p2_lo;        job.count[0][0] = (int)(e->p2_hi - e->p2_lo);
-    job.ptr[0][1] = a->part2 + np2 + e->p2_lo;  job.count[0][1] = (int)(e->p2_hi - e->p2_lo);
-    job.ptr[0][3] = a->part4 + e->p4_lo;        job.count[0][3] = (int)(e->p4_hi - e->p4_lo);
-    for (int pc = 0; pc < (int)e->nseg; ++pc) {
-      if (e->p3_hi[pc] > np3) return IPX_EINVAL;
-      job.ptr[pc][2] = a->part3 + e->p3_lo[pc];
-      job.count[pc][2] = (int)(e->p3_hi[pc] - e->p3_lo[pc]);
+    const int64_t p2lo = boxp ? 0 : e->p2_lo, p2hi = boxp ? np2 : e->p2_hi;
+    job.ptr[0][0] = a->part2 + p2lo;        job.count[0][0] = (int)(p2hi - p2lo);
+    job.ptr[0][1] = a->part2 + np2 + p2lo;  job.count[0][1] = (int)(p2hi - p2lo);
+    job.ptr[0][3] = a->part4 + e->p4_lo;    job.count[0][3] = (int)(e->p4_hi - e->p4_lo);
+    if (boxp) {
+      job.ptr[0][2] = a->part3;
+      job.count[0][2] = np3;
+    } else {
+      for (int pc = 0; pc < (int)e->nseg; ++pc) {
+        if (e->p3_hi[pc] > np3) return IPX_EINVAL;
+        job.ptr[pc][2] = a->part3 + e->p3_lo[pc];
+        job.count[pc][2] = (int)(e->p3_hi[pc] - e->p3_lo[pc]);
+      }
     }
     hipLaunchKernelGGL(k_cg_range_pack, dim3(1), dim3(256), 0, st, job, e->pack,
                        (const double *)nullptr);            // unguarded: see pack_hp
@@ -1334,7 +1351,7 @@ static int cg_iterate(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, hi
                          a->state, it & 1, p1, np1, a->x, a->p, a->r, a->Hp, a->lb, a->ub,
                          a->part2, nblk, (int)b->ng, (int)b->ngen,
                          ipx_group_tab{b->gcol, b->grp}, b->gen_cols, (int)b->ny,
-                         b->up);
+                         b->up, own_all(a->n));
       IPX_CHECK_LAUNCH();
       MARK(1);
     } else {

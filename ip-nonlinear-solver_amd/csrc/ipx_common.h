@@ -268,6 +268,19 @@ struct ipx_fold_regs {
   }
 };
 
+// The elements that count in a reduction: everything on one GPU; in the row-sharded loop a
+// rank's OWN entries -- one range per segment of the local vector (x-space: one; the barrier
+// problem's z = [x; s_nl; s_lb; s_ub]: four), halo copies in between.
+struct ipx_own_ranges {
+  int64_t lo[4], hi[4];
+#ifdef __HIPCC__
+  __device__ __forceinline__ bool has(int64_t i) const {
+    return (i >= lo[0] && i < hi[0]) || (i >= lo[1] && i < hi[1]) || (i >= lo[2] && i < hi[2]) ||
+           (i >= lo[3] && i < hi[3]);
+  }
+#endif
+};
+
 // ---- box-Schur group tables (csrc/boxschur.hip; also read by the CG loop's step1)
 #ifdef __HIPCC__
 struct ipx_group_tab {
@@ -347,7 +360,7 @@ int ipx_banded_solve_guarded(void *handle, const double *w, double *x, const dou
 int ipx_boxschur_project_from(const ipx_boxschur_args *a, const double *r, double *g,
                               double *part_g, int32_t *npart_g, double *part_res,
                               int32_t *npart_res, const double *guard, int have_up,
-                              hipStream_t stream);
+                              hipStream_t stream, const ipx_own_ranges *own = nullptr);
 // yout = alpha A x [+ diag x] [+ beta yin] for a row-major dense A; partial (optional) gets
 // per-workgroup sums of y^2 then of x.y (square A), *npartial entries per half
 int ipx_dense_gemv_launch(int m, int n, const double *A, int64_t lda, const double *x,
