@@ -391,11 +391,11 @@ class _Loop:
         # tridiagonal A A' on the single-launch solve: g = r - A'v rides in that launch
         if a.solver_kind == 0 and not os.environ.get("IPX_NO_FUSE"):
             geo = (ctypes.c_int32 * 2)()
-            # (the tail holds ~185 registers: two workgroups per CU.  It pays while the
-            # whole grid is resident at once -- up to 512 workgroups, m ~ 1.3e5; beyond
-            # that the separate SpMV streams better: measured 161 vs 170 us at n = 4e6)
+            # (round 1's chunk-recurrence solve streamed better with a separate SpMV beyond 512
+            # workgroups; with the cyclic-reduction solve the fused tail wins there too: 7.47 vs
+            # 7.14 k it/s at n = 4e6.  IPX_TAIL_MAXWG restores a limit for A/B runs.)
             if lib.ipx_banded_decoupled_geometry(ctypes.c_void_p(P.solver.handle), geo) \
-                    and geo[1] <= 512:
+                    and geo[1] <= int(os.environ.get("IPX_TAIL_MAXWG", "1000000000")):
                 kS = int(getattr(P.solver, "k", 1))
                 vown = fuse_vown(At.pattern, geo[0], geo[1], kS) if kS <= 4 else None
                 if vown is not None:
