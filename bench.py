@@ -160,13 +160,15 @@ def single_gpu_measure(A_h, H_h, hdiag_h, c_h, n, m, K, W, repeats=20):
         init_dev = torch.from_numpy(init).to(L.state.device)
         fr = []
         run(0, W, "finite-radius warmup")
+        done_f = W
         for _ in range(min(5, repeats)):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            run(W, W + K, "finite-radius")
+            run(done_f, done_f + K, "finite-radius")
             torch.cuda.synchronize()
             fr.append(K / (time.perf_counter() - t0))
-        check_ran(W + K)
+            done_f += K
+        check_ran(done_f)
         fr.sort()
         finite = {"trust_radius": 1e300, "iterations_per_s": fr[len(fr) // 2],
                   "regions": len(fr), "steps_each": K}

@@ -427,3 +427,29 @@ def test_bench_two_rank_rehearsal():
     assert (fs["status"], fs["niter"], fs["cg_niter"]) == (1, 25, 34)
     per = d["collectives_per_iteration"]
     assert per["all_reduce"] <= 2.5 and per["neighbour_exchange"] <= 1.5
+
+
+def test_bench_contract_with_odd_step_counts():
+    """``bench.py --steps K --warmup W`` for a K that is no divisor of anything (the driver
+    chooses K and W): one JSON line with the contract's keys, the roofline and CPU-baseline
+    objects, the finite-radius figure next to the headline."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "7",
+                          "--warmup", "3", "--no-big", "--repeats", "2", "--cpu-iters", "20"],
+                         cwd=root, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["steps"] == 7 and d["warmup"] == 3 and d["n_gpus"] == 1 and d["value"] > 1000
+    assert 0.3 < d["roofline"]["frac"] < 1.0 and d["cpu_baseline"]["value"] > 0
+    assert d["finite_trust_radius"]["iterations_per_s"] > 1000
+    assert d["parity_vs_oracle"]["max_rel_err"] < 1e-10
