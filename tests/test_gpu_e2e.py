@@ -364,9 +364,10 @@ def _sharded_barrier_worker(rank, world, port, out_path):
         dist.destroy_process_group()
 
 
-def test_sharded_barrier_box_inequality_hip(tmp_path):
-    """BASELINE config 5 in small on the sharded backend with the HIP kernels (two ranks share
-    cuda:0 over gloo): distributed z = [x; s_nl; s_lb; s_ub], the local augmented Jacobians
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_barrier_box_inequality_hip(world, tmp_path):
+    """BASELINE config 5 in small on the sharded backend with the HIP kernels (2 and 3 ranks share
+    cuda:0 over gloo; the middle rank has halos on both sides): distributed z = [x; s_nl; s_lb; s_ub], the local augmented Jacobians
     factored by the box-Schur solver, against the REFERENCE's trace
     (tests/golden/e2e_ineq_n12000.json) over the comparable prefix (16 outer iterations)."""
     import json
@@ -377,7 +378,7 @@ def test_sharded_barrier_box_inequality_hip(tmp_path):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     path = str(tmp_path / "barrier.npz")
-    mp.spawn(_sharded_barrier_worker, args=(2, port, path), nprocs=2, join=True)
+    mp.spawn(_sharded_barrier_worker, args=(world, port, path), nprocs=world, join=True)
     got = np.load(path)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     with open(os.path.join(root, "tests", "golden", "e2e_ineq_n12000.json")) as f:

@@ -190,10 +190,11 @@ def _barrier_worker(rank, world, port, out_path):
         dist.destroy_process_group()
 
 
-def test_sharded_barrier_box_inequality_matches_reference(tmp_path):
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_barrier_box_inequality_matches_reference(world, tmp_path):
     """BASELINE config 5 in small (n = 12000 variables with a box on each, 1200 nonlinear
     inequalities: z-space 37200, 25200 inequality rows): the barrier method over the sharded
-    backend, two ranks, against the trace of the REFERENCE on the same seeded problem
+    backend, two and three ranks (a middle rank has halos on both sides), against the trace of the REFERENCE on the same seeded problem
     (tests/golden/e2e_ineq_n12000.json; the reference needs 225 s for its 64 outer / 26090 CG
     iterations).  Thousands of CG iterations amplify last-bit differences until an accept /
     reject branch flips after ~20 outer iterations (every implementation, the single-GPU one
@@ -202,7 +203,7 @@ def test_sharded_barrier_box_inequality_matches_reference(tmp_path):
     import json
     from conftest import unjson
     path = str(tmp_path / "barrier.npz")
-    mp.spawn(_barrier_worker, args=(2, _free_port(), path), nprocs=2, join=True)
+    mp.spawn(_barrier_worker, args=(world, _free_port(), path), nprocs=world, join=True)
     got = np.load(path)
     with open(os.path.join(ROOT, "tests", "golden", "e2e_ineq_n12000.json")) as f:
         gold = json.load(f)["banded_ineq_n12000"]
