@@ -512,6 +512,55 @@ def test_box_schur_solver(ips, n, m):
     assert np.max(np.abs(A.dot(z))) <= 1e-9 * np.max(np.abs(x))
 
 
+def test_hip_graph_replay_of_the_loop(ips):
+    """``ipx_cg_graph_create / _launch`` (two captured iterations replayed) against the same
+    iterations enqueued eagerly: bit-identical iterates and state."""
+    import ctypes
+    import torch
+    import ipsolver.cg_fused as cg_fused
+    from ipsolver import _hip
+    n, m = 20000, 2000
+    inst = BandedInstance(n, m)
+    dv = ips.dv
+    A = dv.DeviceCSR.from_scipy(inst.A)
+    H = dv.DeviceCSR.from_scipy(inst.H)
+    Z, LS, Y = ips.proj.projections(A)
+    P = Z.projector
+    lib = _hip.load()
+    c, b = dv.DVec.from_host(inst.c), dv.DVec.zeros(m)
+    x0 = Y.dot(-b)
+    r0 = Z.dot(H.dot(x0) + c)
+    g0 = Z.dot(r0)
+    rt_g = g0.sumsq_amax()[0]
+    side = torch.cuda.Stream()           # graphs cannot be captured on the legacy default stream
+    outs = []
+    with torch.cuda.stream(side):
+        st = dv.stream_ptr()
+        for use_graph in (False, True):
+            L = cg_fused._Loop(H, P, None, None)
+            L.x.copy_(x0.t)
+            L.r.copy_(r0.t)
+            _hip.call("ipx_axpby", n, -1.0, dv._p(g0.t), 0.0, None, dv._p(L.p), st)
+            init = np.zeros(L.state.numel())
+            init[cg_fused.ST_RTG0], init[cg_fused.ST_RADIUS] = rt_g, np.inf
+            init[cg_fused.ST_ORTH_RHS] = P.orth_tol * P.norm_A
+            L.state.copy_(torch.from_numpy(init))
+            _hip.check(lib.ipx_cg_hp(L.ref(), st), "ipx_cg_hp")
+            if use_graph:
+                g = lib.ipx_cg_graph_create(L.ref(), st)
+                assert g
+                _hip.check(lib.ipx_cg_graph_launch(ctypes.c_void_p(g), 6, st), "graph launch")
+                torch.cuda.synchronize()
+                lib.ipx_cg_graph_destroy(ctypes.c_void_p(g))
+            else:
+                _hip.check(lib.ipx_cg_iterate(L.ref(), 0, 12, st), "ipx_cg_iterate")
+            torch.cuda.synchronize()
+            outs.append((L.x.cpu().numpy().copy(), L.state.tolist()))
+    (xe, se), (xg, sg) = outs
+    assert se[cg_fused.ST_IT_DONE] == 12 and sg[cg_fused.ST_IT_DONE] == 12
+    assert np.array_equal(xe, xg) and se == sg
+
+
 def test_unbounded_trust_region_skips_the_norm(ips, monkeypatch):
     """trust_radius=inf without a box: ``norm(x_next) >= trust_radius`` (qp_subproblem.py:583)
     cannot be True, the device loop does not form the norm (csrc/cg.hip no_xn2).  Same
