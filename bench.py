@@ -86,12 +86,6 @@ def single_gpu_measure(A_h, H_h, hdiag_h, c_h, n, m, K, W, repeats=20):
     init[cg_fused.ST_RADIUS] = np.inf
     init[cg_fused.ST_ORTH_RHS] = P.orth_tol * P.norm_A
     init_dev = torch.from_numpy(init).to(L.state.device)
-    seed5 = None
-    if L.part5 is not None:
-        L.x.copy_(x0.t)
-        _hip.call("ipx_axpby", n, -1.0, dv._p(g0.t), 0.0, None, dv._p(L.p), st)
-        L.seed_sums()
-        seed5 = L.part5.clone()
 
     def prime():
         """x = x0, r = Z(H x0 + c), p = -g, state reset, Hp = H p: device copies and one
@@ -101,8 +95,6 @@ def single_gpu_measure(A_h, H_h, hdiag_h, c_h, n, m, K, W, repeats=20):
         _hip.call("ipx_axpby", n, -1.0, dv._p(g0.t), 0.0, None, dv._p(L.p), st)
         L.state.copy_(init_dev)
         _hip.check(lib.ipx_cg_hp(L.ref(), st), "ipx_cg_hp")
-        if L.part5 is not None:          # x'x, x'p, p'p of the primed state (device copy)
-            L.part5.copy_(seed5)
 
     # With tol = 0 the CG would run into an exactly zero residual after ~500 iterations
     # (p'Hp = 0 ends it).  Whatever K is asked for, the loop is therefore restarted from
@@ -225,7 +217,7 @@ def single_gpu_measure(A_h, H_h, hdiag_h, c_h, n, m, K, W, repeats=20):
         algo["step2_spmv_H_p"] = algo.pop("spmv_H_p") + algo.pop("step2") - 8 * n
     if fused1:      # r_next is not read back by the SpMV
         algo["step1_spmv_A_r"] = algo.pop("spmv_A_r") + algo.pop("step1") - 8 * n
-        if L.part5 is not None or no_radius:     # ||x + alpha p||^2 not summed here: x, p not read
+        if no_radius:     # ||x + alpha p||^2 not formed: x, p not read
             algo["step1_spmv_A_r"] -= 2 * 8 * n
     if fused3:      # v is not read back by the SpMV
         algo["banded_solve_residual_r_minus_Atv"] = algo.pop("spmv_r_minus_Atv") - 8 * m

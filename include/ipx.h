@@ -243,14 +243,6 @@ typedef struct ipx_cg_args {
    * the variable alone, so the tail's loads need no row-pointer round trip.  NULL: CSR. */
   const int32_t *At_ell_col;
   const double *At_ell_val;
-  /* 3 x H_ntiles doubles of scratch, or NULL.  With both fused kernels in use the trust-region
-   * test's ||x + alpha p||^2 is then formed as xx + 2 alpha xp + alpha^2 pp from per-tile sums
-   * of x'x, x'p, p'p that the step2 + H.p kernel leaves here (step1 + A.r no longer reads x
-   * and p).  The caller seeds entries [0], [H_ntiles], [2 H_ntiles] with x'x, x'p, p'p of the
-   * primed / resumed state (rest zero).  Measured (bench.py, MI355X): +2.4 % it/s at n=1e6,
-   * +5.4 % at n=4e6, the step2 + H.p kernel itself 7 % slower; the host binding leaves it off
-   * unless IPX_RECUR=1 (the direct sum is what the reference computes). */
-  double *part5;
   /* Compact index form of H for the fused step2 + H.p kernel (H_hmax > 0), or NULL:
    * H_col16 = one uint16 per nonzero, its column as an offset into the row tile's span
    * (col - max(tile's first row - H_hmax, 0)); H_rowlen = one int per row tile, the common
@@ -258,7 +250,7 @@ typedef struct ipx_cg_args {
    * instead of 4 per nonzero and no row pointers on uniform tiles. */
   const void *H_col16;
   const int32_t *H_rowlen;
-  /* The same for the fused step1 + A.r kernel (A_span > 0, standard tiles, no IPX_RECUR):
+  /* The same for the fused step1 + A.r kernel (A_span > 0, standard tiles):
    * one uint16 per nonzero of A, col - A_own[its row tile]; NULL: A_colidx is read. */
   const void *A_col16;
   /* != 0: the trust radius in the state block is +inf (and, fused step1 implying no box, the
@@ -272,10 +264,6 @@ int ipx_cg_vec_grid(int64_t n);
 int ipx_cg_hp(const ipx_cg_args *a, void *stream);
 /* Enqueue iterations [it_begin, it_end); never synchronises. */
 int ipx_cg_iterate(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, void *stream);
-/* hipGraph replay: capture two iterations once, replay them npairs times. */
-void *ipx_cg_graph_create(const ipx_cg_args *a, void *stream);
-int ipx_cg_graph_launch(void *graph, int32_t npairs, void *stream);
-void ipx_cg_graph_destroy(void *graph);
 /* Same launches with HIP events around each kernel class; synchronises once at
  * the end and returns per-class totals in ms_out[0..6] = {step1, A r, banded,
  * r-A'v, A g, step2, H p}.  For per-kernel attribution in bench.py. */
@@ -325,9 +313,37 @@ typedef struct ipx_shard2_ext {
   int64_t p2_lo, p2_hi;          /* own entries of part2 (row tiles of A with the fused step1;
                                   * every vector chunk otherwise: step1 masks by element) */
   int64_t p4_lo, p4_hi;          /* own workgroups of the (inner) banded solve (part4) */
+  /* Peer mailbox (ipx_peer_create) or NULL.  With it the scalars are all-reduced and the halo
+   * of g exchanged INSIDE the loop's own launches (the kernels write into the peers' HBM over
+   * xGMI); without it the caller all-reduces s1 / pack and exchanges the halo between the
+   * phases itself. */
+  void *peer;
+  int64_t seg_lo[4], seg_hi[4];  /* the segments' local extents [left halo | own | right halo] */
+  int64_t send_left[4], send_right[4];   /* own entries the left / right neighbour keeps as halo */
 } ipx_shard2_ext;
 int ipx_cg_shard2_segment(const ipx_cg_args *a, const ipx_shard2_ext *e, int32_t phase,
                           int32_t it, int32_t mode, void *stream);
+/* Iterations [it_begin, it_end), both phases, communication included (needs e->peer): one
+ * call per batch, nothing between the iterations on the host. */
+int ipx_cg_shard2_iterate(const ipx_cg_args *a, const ipx_shard2_ext *e, int32_t it_begin,
+                          int32_t it_end, void *stream);
+
+/* ---- peer mailboxes (csrc/peer.hip): the transport of the sharded loop's two all-reduces
+ * (torch.distributed all_reduce in round 2; qp_subproblem.py:556,583,626 are the reduction
+ * points) and of its halo exchange, rank to rank through hipIpc-mapped device memory.
+ * create -> export (ipx_peer_handle_bytes() bytes) -> hand the blobs around -> import every
+ * other rank's -> ipx_peer_ready.  halo_cap: doubles per side a rank may receive. */
+int ipx_peer_handle_bytes(void);
+void *ipx_peer_create(int32_t rank, int32_t world, int64_t halo_cap);
+int ipx_peer_export(void *peer, void *handle_out);
+int ipx_peer_import(void *peer, int32_t rank, const void *handle_in);
+int ipx_peer_ready(void *peer);
+int64_t ipx_peer_halo_capacity(void *peer);
+int ipx_peer_sequence(void *peer, int64_t *out2);
+void ipx_peer_destroy(void *peer);
+/* `reps` all-reduces (sum) of nq <= 8 doubles back to back: the mailbox path's latency probe. */
+int ipx_peer_allreduce(void *peer, int32_t nq, const double *in, double *out, int *failed,
+                       int32_t reps, void *stream);
 int ipx_cg_shard2_fold_hp(const ipx_cg_args *a, const ipx_shard2_ext *e, void *stream);
 /* The fused step2 + H.p launch alone (needs pb / H_hmax in the argument block). */
 int ipx_cg_step2_hp(const ipx_cg_args *a, int32_t it, int32_t mode, void *stream);

@@ -44,7 +44,6 @@ enum {
   ST_TOL = 2, ST_RADIUS = 3, ST_ALPHA = 4, ST_STOP = 5, ST_NITER = 6, ST_BETA = 7,
   ST_PTHP = 8, ST_ORTH_RHS = 9,   // orth_tol * ||A||_F  (0 disables the check)
   ST_XNORM2 = 10, ST_VIOL = 11, ST_ORTH = 12, ST_IT_DONE = 13,
-  ST_XN2R = 14,                   // ||x + alpha p||^2 by recurrence (see k_cg_step1_ar<.., RECUR>)
   ST_SIZE = 16
 };
 
@@ -354,16 +353,12 @@ k_cg_step2_hp(int n, double *st, int parity, int mode, const double *__restrict_
               const double *__restrict__ val, const int32_t *__restrict__ tiles, int ntiles,
               const double *__restrict__ diag, double *__restrict__ Hp,
               double *__restrict__ partial, int hmax, const double *__restrict__ pb_in,
-              double *__restrict__ pb_out, double *__restrict__ part5,
+              double *__restrict__ pb_out,
               const uint16_t *__restrict__ col16, const int32_t *__restrict__ rowlen) {
-  // part5 (optional, 3 x ntiles): per-tile sums of x_next'x_next, x_next'p_next, p_next'p_next,
-  // from which the next iteration gets ||x + alpha p||^2 = xx + 2 alpha xp + alpha^2 pp without
-  // reading x and p again (mode bit 2: this launch takes its own ||x + alpha p||^2 that way,
-  // from the state block, instead of folding p2)
   __shared__ double prod[FT_NNZ];
   __shared__ double span[QS * IPX_BLOCK];
   __shared__ int rp[Q * IPX_BLOCK + 1];
-  __shared__ double lds[5 * (IPX_BLOCK / IPX_WAVE)];
+  __shared__ double lds[4 * (IPX_BLOCK / IPX_WAVE)];
   CG_STAMP(0);
   const int tile = ipx_xcd_item(blockIdx.x, ntiles);
   if (tile < 0) return;
@@ -376,8 +371,7 @@ k_cg_step2_hp(int n, double *st, int parity, int mode, const double *__restrict_
   // ||x + alpha p||^2 partials -- one per row tile of A when step1 is fused -- get the
   // freed register instead
   const double *const partsA[2] = {BOX ? p2 + np2 : p2, p4};
-  const int countsA[2] = {(mode & 5) ? 0 : np2, (mode & 2) ? 0 : np4};
-  const double xn2_rec = st[ST_XN2R];
+  const int countsA[2] = {(mode & 1) ? 0 : np2, (mode & 2) ? 0 : np4};
   const double *const partsB[1] = {p3};
   const int countsB[1] = {np3};
   const double *const partsC[1] = {BOX ? p2 : p2 + np2};     // BOX: xn2;  else unused (count 0)
@@ -439,7 +433,7 @@ k_cg_step2_hp(int n, double *st, int parity, int mode, const double *__restrict_
   }
   ipx_block_sum_multi<4>(loc, lds, red);
   if (!(mode & 1)) {
-    const double xn2 = (mode & 4) ? xn2_rec : red[0], viol = red[1];
+    const double xn2 = red[0], viol = red[1];
     if (sqrt(xn2) >= radius) {                       // :583
       if (lead) { st[ST_XNORM2] = xn2; st[ST_STOP] = 2.0; }
       return;
@@ -543,32 +537,11 @@ k_cg_step2_hp(int n, double *st, int parity, int mode, const double *__restrict_
     if (i < nrows) Hp[r0 + i] = yq[q];
   }
   // x_next = x + alpha p on the own rows (x was requested before the SpMV phases and has
-  // landed), with the sums the next iteration's trust-region test is formed from (p_next of
-  // the same element is in the span)
-  double axx = 0.0, axp = 0.0, app = 0.0;
+  // landed)
 #pragma unroll
   for (int k = 0; k < QS; ++k) {
-    const int j = tid + k * IPX_BLOCK;
-    const int col = c_lo + j;
-    if (col >= r0 && col < r1) {
-      const double xn = sx[k] + alpha * sp[k];       // :580,630
-      x[col] = xn;
-      if (part5) {
-        const double pn = span[j];
-        axx += xn * xn;
-        axp += xn * pn;
-        app += pn * pn;
-      }
-    }
-  }
-  if (part5) {
-    double red3[3] = {axx, axp, app}, out3[3];
-    ipx_block_sum_multi<3>(red3, lds, out3);
-    if (tid == 0) {
-      part5[tile] = out3[0];
-      part5[ntiles + tile] = out3[1];
-      part5[2 * ntiles + tile] = out3[2];
-    }
+    const int col = c_lo + tid + k * IPX_BLOCK;
+    if (col >= r0 && col < r1) x[col] = sx[k] + alpha * sp[k];       // :580,630
   }
   CG_STAMP(7);
 }
@@ -585,15 +558,12 @@ k_cg_step2_hp(int n, double *st, int parity, int mode, const double *__restrict_
 // r, so outside the iteration nothing changes.  Same expressions in the same
 // order as k_cg_step1 + k_csr_spmv; the ||x + alpha p||^2 partials are per tile
 // instead of per vector chunk (same values up to the order of summation).
-// RECUR: ||x + alpha p||^2 is not summed here (x and p are not read at all: 16 of the 67 MB
-// this kernel moves at n = 1e6) but formed as xx + 2 alpha xp + alpha^2 pp from the three sums
-// the previous step2 + H.p launch left in part5 -- by ONE extra workgroup of this grid (item
-// `ntiles`), which leaves it in the state block for the coming step2.  Algebraically the same
-// number; it differs from the direct sum by rounding, and only feeds the comparison with the
-// trust radius (:583) -- on an exit the boundary point is computed from fresh reductions.
+// NOXN2: trust radius +inf -- ||x + alpha p||^2 can only feed a comparison that is always false
+// (:583) and is not formed: x and p are not read at all (16 of the 56 MB this kernel moves at
+// n = 1e6).
 // C16: column indices as 16-bit offsets into the tile's span (col - own[tile]; the host
 // binding builds them once per pattern), 2 bytes instead of 4 per nonzero.
-template <int QS, int TN, bool RECUR, bool C16>
+template <int QS, int TN, bool NOXN2, bool C16>
 __global__ void __launch_bounds__(IPX_BLOCK)
 k_cg_step1_ar(int n, double *st, int parity, const double *__restrict__ p1, int np1,
               const double *__restrict__ x, const double *__restrict__ p,
@@ -602,30 +572,15 @@ k_cg_step1_ar(int n, double *st, int parity, const double *__restrict__ p1, int 
               const int32_t *__restrict__ colidx, const double *__restrict__ val,
               const int32_t *__restrict__ tiles, int ntiles, const int32_t *__restrict__ own,
               double *__restrict__ w, double *__restrict__ part2,
-              const double *__restrict__ p5, int np5, const uint16_t *__restrict__ col16) {
+              const uint16_t *__restrict__ col16) {
   __shared__ double prod[TN];
   __shared__ double span[QS * IPX_BLOCK];
   __shared__ int rp[IPX_SPMV_TILE_ROWS + 1];
-  __shared__ double lds[3 * (IPX_BLOCK / IPX_WAVE)];
+  __shared__ double lds[IPX_BLOCK / IPX_WAVE];
   CG_STAMP(8);
-  // (RECUR without p5: the norm is not wanted at all -- trust radius +inf -- no extra workgroup)
-  const int tile = ipx_xcd_item(blockIdx.x, (RECUR && p5) ? ntiles + 1 : ntiles);
+  const int tile = ipx_xcd_item(blockIdx.x, ntiles);
   if (tile < 0) return;
   const int tid = threadIdx.x;
-  if (RECUR && p5 && tile == ntiles) {
-    // the extra workgroup: alpha like everybody else, then the three sums
-    if (st[ST_STOP] != 0.0) return;
-    const double rtg = st[parity ? ST_RTG1 : ST_RTG0];
-    const double ptHp = ipx_sum_partials<IPX_SUM>(p1 + np1, np1, lds);
-    if (rtg < st[ST_TOL] || ptHp <= 0.0) return;
-    const double alpha = rtg / ptHp;
-    const double *const parts[3] = {p5, p5 + np5, p5 + 2 * np5};
-    const int counts[3] = {np5, np5, np5};
-    double red[3];
-    ipx_sum_partials_multi<3>(parts, counts, lds, red);
-    if (tid == 0) st[ST_XN2R] = red[0] + 2.0 * alpha * red[1] + alpha * alpha * red[2];
-    return;
-  }
   const double *const fparts[1] = {p1 + np1};
   const int fcounts[1] = {np1};
   const double stop = st[ST_STOP];
@@ -655,8 +610,8 @@ k_cg_step1_ar(int n, double *st, int parity, const double *__restrict__ p1, int 
     const int col = min(o0 + max(min(tid + k * IPX_BLOCK, nspan - 1), 0), n - 1);
     sr[k] = r[col];
     sh[k] = Hp[col];
-    sxv[k] = RECUR ? 0.0 : x[col];
-    spv[k] = RECUR ? 0.0 : p[col];
+    sxv[k] = NOXN2 ? 0.0 : x[col];
+    spv[k] = NOXN2 ? 0.0 : p[col];
   }
   if (stop != 0.0) return;
   CG_STAMP(9);
@@ -683,7 +638,7 @@ k_cg_step1_ar(int n, double *st, int parity, const double *__restrict__ p1, int 
       const double rn = sr[k] + alpha * sh[k];       // :622
       span[j] = rn;
       if (o0 + j < o1) {                             // own column
-        if (!RECUR) {
+        if (!NOXN2) {
           const double xn = sxv[k] + alpha * spv[k]; // :580 (not stored)
           sx += xn * xn;
         }
@@ -722,7 +677,7 @@ k_cg_step1_ar(int n, double *st, int parity, const double *__restrict__ p1, int 
     }
   }
   CG_STAMP(13);
-  if (!RECUR) {
+  if (!NOXN2) {
     const double tot = ipx_block_reduce<IPX_SUM>(sx, lds);
     if (tid == 0) { part2[tile] = tot; part2[ntiles + tile] = 0.0; }
   }
@@ -793,6 +748,100 @@ k_cg_range_pack(RangeJob job, double *__restrict__ out, const double *__restrict
     for (int q = 0; q < 4; ++q) acc[q] += red[q];
   }
   if (threadIdx.x < 4 && ((job.active >> threadIdx.x) & 1)) out[threadIdx.x] = acc[threadIdx.x];
+}
+
+// The same own-range sums, all-reduced over the ranks INSIDE the kernel (peer mailboxes,
+// csrc/peer.hip): workgroup 0 adds up the rank's partials, stores the sums as LL words into
+// every rank's mailbox (its own included), waits for the W contributions to its own mailbox
+// and adds them in rank order -- every rank derives the same bits -- into out[q].  The other
+// workgroups (when a halo plan is given) move the halo of g the same way: the first / last own
+// entries of every segment go to the neighbours' mailboxes, the neighbours' arrive in this
+// rank's and are copied into the halo entries of g.  Everything a later kernel of this rank
+// reads (out, g) is written by this kernel to local memory: no fences, no flags beyond the
+// sequence numbers inside the LL words.  A wait that times out (a peer died) raises stop code
+// 7 in the state block.
+struct HaloPlan {
+  int nseg;                                   // 0: no halo exchange in this launch
+  int seg_lo[4], own_lo[4], own_hi[4], seg_hi[4], send_left[4], send_right[4];
+};
+
+__global__ void __launch_bounds__(256)
+k_cg_pack_comm(RangeJob job, double *__restrict__ out, ipx_peer_view pv, uint32_t seq,
+               HaloPlan hp, double *__restrict__ g, uint32_t hseq, double *__restrict__ st) {
+  __shared__ double lds[4 * 4];
+  __shared__ double vals[IPX_MAX_PEERS * 4];
+  const int tid = threadIdx.x;
+  const long long deadline = (long long)wall_clock64() + IPX_PEER_TIMEOUT_TICKS;
+  if (blockIdx.x == 0) {
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int pc = 0; pc < job.npieces; ++pc) {          // one piece per segment, in order
+      double red[4];
+      ipx_sum_partials_multi<4>(job.ptr[pc], job.count[pc], lds, red);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q] += red[q];
+    }
+    const int slot = seq & (IPX_PEER_SLOTS - 1);
+    if (tid < 4 * pv.world) {
+      const int r = tid >> 2, q = tid & 3;
+      if ((job.active >> q) & 1) {
+        const double mine = q == 0 ? acc[0] : (q == 1 ? acc[1] : (q == 2 ? acc[2] : acc[3]));
+        ipx_ll_store(pv.mbox[r] + ipx_peer_scal_word(slot, pv.rank, q), mine, seq);
+      }
+    }
+    bool ok = true;
+    if (tid < 4 * pv.world) {
+      const int r = tid >> 2, q = tid & 3;
+      double v = 0.0;
+      if ((job.active >> q) & 1)
+        ok = ipx_ll_load(pv.mbox[pv.rank] + ipx_peer_scal_word(slot, r, q), seq, v, deadline);
+      vals[tid] = v;
+    }
+    if (!ok) st[ST_STOP] = 7.0;
+    __syncthreads();
+    if (tid < 4 && ((job.active >> tid) & 1)) {
+      double s = 0.0;
+      for (int r = 0; r < pv.world; ++r) s += vals[4 * r + tid];        // rank order
+      out[tid] = s;
+    }
+    return;
+  }
+  // ---- halo of g
+  const int par = hseq & 1;
+  const int nth = (gridDim.x - 1) * blockDim.x, me = (blockIdx.x - 1) * blockDim.x + tid;
+  int64_t offL = 0, offR = 0;                   // cumulative counts towards the left / right neighbour
+  for (int k = 0; k < hp.nseg; ++k) {
+    if (pv.rank > 0)
+      for (int j = me; j < hp.send_left[k]; j += nth)       // my first own entries: the left
+        ipx_ll_store(pv.mbox[pv.rank - 1] + ipx_peer_halo_word(pv.cap, 1, par, offL + j),   // neighbour's right halo
+                     g[hp.own_lo[k] + j], hseq);
+    if (pv.rank < pv.world - 1)
+      for (int j = me; j < hp.send_right[k]; j += nth)      // my last own entries: the right
+        ipx_ll_store(pv.mbox[pv.rank + 1] + ipx_peer_halo_word(pv.cap, 0, par, offR + j),   // neighbour's left halo
+                     g[hp.own_hi[k] - hp.send_right[k] + j], hseq);
+    offL += hp.send_left[k];
+    offR += hp.send_right[k];
+  }
+  bool ok = true;
+  offL = offR = 0;
+  const unsigned long long *mine = pv.mbox[pv.rank];
+  for (int k = 0; k < hp.nseg; ++k) {
+    const int nl = hp.own_lo[k] - hp.seg_lo[k], nr = hp.seg_hi[k] - hp.own_hi[k];
+    if (pv.rank > 0)
+      for (int j = me; j < nl; j += nth) {
+        double v = 0.0;
+        ok = ipx_ll_load(mine + ipx_peer_halo_word(pv.cap, 0, par, offL + j), hseq, v, deadline) && ok;
+        g[hp.seg_lo[k] + j] = v;
+      }
+    if (pv.rank < pv.world - 1)
+      for (int j = me; j < nr; j += nth) {
+        double v = 0.0;
+        ok = ipx_ll_load(mine + ipx_peer_halo_word(pv.cap, 1, par, offR + j), hseq, v, deadline) && ok;
+        g[hp.own_hi[k] + j] = v;
+      }
+    offL += nl;
+    offR += nr;
+  }
+  if (!ok) st[ST_STOP] = 7.0;
 }
 
 }  // namespace
@@ -869,9 +918,6 @@ struct Compactor {
 
 static bool fused_ar(const ipx_cg_args *a);
 static bool fused_hp(const ipx_cg_args *a);
-// ||x + alpha p||^2 by recurrence (see k_cg_step1_ar<.., RECUR>): both fused kernels in use and
-// scratch for the three sums given
-static bool xn2_recur(const ipx_cg_args *a) { return a->part5 && fused_ar(a) && fused_hp(a); }
 
 // solver_kind 1 with the group tables present: the fused box-Schur projection
 static bool box_project(const ipx_cg_args *a) {
@@ -907,22 +953,19 @@ static int part3_count(const ipx_cg_args *a) {
 // step1 + A.r in one launch (see k_cg_step1_ar): r_next <- r + alpha Hp, w <- A r_next
 // no_xn2: trust radius +inf and no box -- ||x + alpha p||^2 is not formed at all (it can only
 // feed a comparison that is always false): x and p are not read, 16 of the kernel's 56 MB at
-// n = 1e6 (the RECUR instantiation without its summing workgroup)
+// n = 1e6
 static int launch_step1_ar(const ipx_cg_args *a, int it, const double *p1, int np1,
-                           hipStream_t st, const double *p5 = nullptr, int np5 = 0,
-                           bool no_xn2 = false) {
-  const bool recur = p5 != nullptr;             // (+1: the workgroup that forms ||x + alpha p||^2)
-  const dim3 grid(ipx_xcd_grid((int)a->A_ntiles + (recur ? 1 : 0))), block(IPX_BLOCK);
+                           hipStream_t st, bool no_xn2 = false) {
+  const dim3 grid(ipx_xcd_grid((int)a->A_ntiles)), block(IPX_BLOCK);
 #define FUSED_ARGS                                                                         \
   (int)a->n, a->state, it & 1, p1, np1, a->x, a->p, a->r, a->r_next,                       \
       a->Hp, a->A_rowptr, a->A_colidx, a->A_val, a->A_tiles, (int)a->A_ntiles, a->A_own,   \
-      a->w, a->part2, p5, np5, (const uint16_t *)a->A_col16
+      a->w, a->part2, (const uint16_t *)a->A_col16
   const int qs = (int)((a->A_span + IPX_BLOCK - 1) / IPX_BLOCK);
   const bool half = a->A_tile_nnz == 1024;      // tiles of 1024 nonzeros (own table)
 #define GO(Q)                                                                              \
   do {                                                                                     \
     if (half) hipLaunchKernelGGL((k_cg_step1_ar<Q, 1024, false, false>), grid, block, 0, st, FUSED_ARGS); \
-    else if (recur) hipLaunchKernelGGL((k_cg_step1_ar<Q, FT_NNZ, true, false>), grid, block, 0, st, FUSED_ARGS); \
     else if (no_xn2 && a->A_col16) hipLaunchKernelGGL((k_cg_step1_ar<Q, FT_NNZ, true, true>), grid, block, 0, st, FUSED_ARGS); \
     else if (no_xn2) hipLaunchKernelGGL((k_cg_step1_ar<Q, FT_NNZ, true, false>), grid, block, 0, st, FUSED_ARGS); \
     else if (a->A_col16) hipLaunchKernelGGL((k_cg_step1_ar<Q, FT_NNZ, false, true>), grid, block, 0, st, FUSED_ARGS); \
@@ -954,7 +997,7 @@ static int launch_step2_hp(const ipx_cg_args *a, int it, int mode, const double 
   (int)a->n, a->state, it & 1, mode, p2, np2, p3, np3, p4, np4, a->x, a->p, a->r,             \
       a->H_rowptr, a->H_colidx, a->H_val, a->H_tiles,                                         \
       (int)a->H_ntiles, a->H_diag, a->Hp, a->part1, (int)a->H_hmax, pb_in, pb_out,           \
-      (xn2_recur(a) ? a->part5 : nullptr), (const uint16_t *)a->H_col16, a->H_rowlen
+      (const uint16_t *)a->H_col16, a->H_rowlen
   // H_hmax carries the longest tile's row count in its upper half (set by the host
   // binding): short tiles (3 nonzeros per row -> 683 rows) take the 3-elements-per-lane
   // instantiation, which needs fewer registers
@@ -1020,6 +1063,48 @@ static OwnRanges own_of(const ipx_shard2_ext *e) {
   return o;
 }
 
+// The rank's own sums to `out`; with a peer mailbox (e->peer) all-reduced over the ranks in
+// the same launch, and -- with_halo -- the halo of g (a->r) exchanged with the neighbours.
+static int launch_pack(const ipx_cg_args *a, const ipx_shard2_ext *e, const RangeJob &job,
+                       double *out, bool with_halo, hipStream_t st) {
+  ipx_peer *peer = (ipx_peer *)e->peer;
+  if (!peer) {
+    hipLaunchKernelGGL(k_cg_range_pack, dim3(1), dim3(256), 0, st, job, out,
+                       (const double *)nullptr);
+    IPX_CHECK_LAUNCH();
+    return IPX_OK;
+  }
+  if (peer->view.world > IPX_MAX_PEERS || !ipx_peer_ready(peer)) return IPX_EINVAL;
+  HaloPlan hp;
+  hp.nseg = 0;
+  int64_t moved = 0;
+  if (with_halo && peer->view.world > 1) {
+    hp.nseg = (int)e->nseg;
+    int64_t inl = 0, inr = 0, outl = 0, outr = 0;
+    for (int k = 0; k < hp.nseg; ++k) {
+      hp.seg_lo[k] = (int)e->seg_lo[k]; hp.seg_hi[k] = (int)e->seg_hi[k];
+      hp.own_lo[k] = (int)e->own_lo[k]; hp.own_hi[k] = (int)e->own_hi[k];
+      hp.send_left[k] = (int)e->send_left[k]; hp.send_right[k] = (int)e->send_right[k];
+      if (hp.seg_lo[k] > hp.own_lo[k] || hp.own_hi[k] > hp.seg_hi[k] || hp.send_left[k] < 0 ||
+          hp.send_right[k] < 0 || hp.send_left[k] + hp.send_right[k] > 2 * (hp.own_hi[k] - hp.own_lo[k]))
+        return IPX_EINVAL;
+      inl += hp.own_lo[k] - hp.seg_lo[k]; inr += hp.seg_hi[k] - hp.own_hi[k];
+      outl += hp.send_left[k]; outr += hp.send_right[k];
+    }
+    // (the neighbours' capacities equal this rank's: one group, one ipx_peer_create argument)
+    if (inl > peer->view.cap || inr > peer->view.cap || outl > peer->view.cap || outr > peer->view.cap)
+      return IPX_EINVAL;
+    moved = inl + inr + outl + outr;
+    if (++peer->hseq == 0) ++peer->hseq;
+  }
+  if (++peer->seq == 0) ++peer->seq;
+  const int halo_wg = hp.nseg ? (int)std::min<int64_t>(16, std::max<int64_t>(1, (moved + 511) / 512)) : 0;
+  hipLaunchKernelGGL(k_cg_pack_comm, dim3(1 + halo_wg), dim3(256), 0, st, job, out, peer->view,
+                     peer->seq, hp, a->r, peer->hseq, a->state);
+  IPX_CHECK_LAUNCH();
+  return IPX_OK;
+}
+
 // own sum of the p'Hp partials (second half of part1) over the segments' own row tiles
 static int pack_hp(const ipx_cg_args *a, const ipx_shard2_ext *e, hipStream_t st) {
   const int np1 = part1_count(a);
@@ -1036,10 +1121,7 @@ static int pack_hp(const ipx_cg_args *a, const ipx_shard2_ext *e, hipStream_t st
   // NOT guarded by the stop flag: once an iteration has raised it, the remaining iterations
   // of the batch are no-ops but their all-reduces still run; re-packing the (unchanged)
   // own sums keeps the reduced values those of the iteration that stopped
-  hipLaunchKernelGGL(k_cg_range_pack, dim3(1), dim3(256), 0, st, job, e->s1,
-                     (const double *)nullptr);
-  IPX_CHECK_LAUNCH();
-  return IPX_OK;
+  return launch_pack(a, e, job, e->s1, false, st);
 }
 
 int ipx_cg_shard2_segment(const ipx_cg_args *a, const ipx_shard2_ext *e, int32_t phase,
@@ -1128,10 +1210,7 @@ int ipx_cg_shard2_segment(const ipx_cg_args *a, const ipx_shard2_ext *e, int32_t
         job.count[pc][2] = (int)(e->p3_hi[pc] - e->p3_lo[pc]);
       }
     }
-    hipLaunchKernelGGL(k_cg_range_pack, dim3(1), dim3(256), 0, st, job, e->pack,
-                       (const double *)nullptr);            // unguarded: see pack_hp
-    IPX_CHECK_LAUNCH();
-    return IPX_OK;
+    return launch_pack(a, e, job, e->pack, true, st);       // unguarded: see pack_hp
   }
   // phase 1
   if (fused_hp(a)) {
@@ -1145,6 +1224,21 @@ int ipx_cg_shard2_segment(const ipx_cg_args *a, const ipx_shard2_ext *e, int32_t
   }
   if (rc) return rc;
   return pack_hp(a, e, st);
+}
+
+// Iterations [it_begin, it_end) of the sharded loop in ONE call: needs the peer mailbox
+// (e->peer), through which the pack kernels all-reduce the scalars and exchange the halo of g
+// themselves -- no collective call, no host between the iterations.
+int ipx_cg_shard2_iterate(const ipx_cg_args *a, const ipx_shard2_ext *e, int32_t it_begin,
+                          int32_t it_end, void *stream) {
+  if (!a || !e || !e->peer || it_end < it_begin) return IPX_EINVAL;
+  for (int it = it_begin; it < it_end; ++it) {
+    int rc = ipx_cg_shard2_segment(a, e, 0, it, 0, stream);
+    if (rc) return rc;
+    rc = ipx_cg_shard2_segment(a, e, 1, it, 0, stream);
+    if (rc) return rc;
+  }
+  return IPX_OK;
 }
 
 // The own-range sum of the p'Hp partials on its own (priming the sharded loop).
@@ -1196,47 +1290,6 @@ static int cg_iterate(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, hi
 int ipx_cg_iterate(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, void *stream) {
   if (!a || it_end < it_begin) return IPX_EINVAL;
   return cg_iterate(a, it_begin, it_end, (hipStream_t)stream, nullptr);
-}
-
-// hipGraph replay of the loop: two consecutive iterations (even + odd parity
-// of the double-buffered rt_g) are captured once; every replay runs two more
-// iterations without per-kernel host launch work.
-struct ipx_cg_graph {
-  hipGraph_t graph;
-  hipGraphExec_t exec;
-};
-
-void *ipx_cg_graph_create(const ipx_cg_args *a, void *stream) {
-  if (!a) return nullptr;
-  hipStream_t st = (hipStream_t)stream;
-  ipx_cg_graph *g = new ipx_cg_graph();
-  if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) { delete g; return nullptr; }
-  int rc = cg_iterate(a, 0, 2, st, nullptr);
-  hipError_t e = hipStreamEndCapture(st, &g->graph);
-  if (rc != IPX_OK || e != hipSuccess) { delete g; return nullptr; }
-  if (hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0) != hipSuccess) {
-    (void)hipGraphDestroy(g->graph);
-    delete g;
-    return nullptr;
-  }
-  return g;
-}
-
-// Run 2*npairs iterations (the iteration index must be even when this starts).
-int ipx_cg_graph_launch(void *graph, int32_t npairs, void *stream) {
-  if (!graph || npairs < 0) return IPX_EINVAL;
-  ipx_cg_graph *g = (ipx_cg_graph *)graph;
-  for (int i = 0; i < npairs; ++i)
-    if (hipGraphLaunch(g->exec, (hipStream_t)stream) != hipSuccess) return IPX_ELAUNCH;
-  return IPX_OK;
-}
-
-void ipx_cg_graph_destroy(void *graph) {
-  if (!graph) return;
-  ipx_cg_graph *g = (ipx_cg_graph *)graph;
-  (void)hipGraphExecDestroy(g->exec);
-  (void)hipGraphDestroy(g->graph);
-  delete g;
 }
 
 // Instrumented variant for bench.py: HIP events are recorded on `stream`
@@ -1330,18 +1383,14 @@ static int cg_iterate(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, hi
     const double *p1 = a->part1;
     int np1 = (int)a->H_ntiles;
     cmp.add(p1, np1, 2, 2048);      // beyond what a consumer folds in one or two rounds
-    const bool recur = xn2_recur(a);
     // trust radius +inf, no box (fused step1 implies no box): the radius / box tests of
     // qp_subproblem.py:583,599 cannot trigger; their sums are neither formed nor folded
-    const bool no_xn2 = fuse1 && !recur && a->no_radius != 0;
-    const double *p5 = recur ? a->part5 : nullptr;
-    int np5 = (int)a->H_ntiles;
-    if (recur) cmp.add(p5, np5, 3, 2048);
+    const bool no_xn2 = fuse1 && a->no_radius != 0;
     rc = cmp.launch(guard, st);
     if (rc) return rc;
     if (fuse1) {
       MARK(1);
-      rc = launch_step1_ar(a, it, p1, np1, st, p5, np5, no_xn2);   // r_next = r + alpha Hp;  w = A r_next
+      rc = launch_step1_ar(a, it, p1, np1, st, no_xn2);   // r_next = r + alpha Hp;  w = A r_next
       if (rc) return rc;
       MARK(2);
     } else if (a->m > 0 && box_project(a)) {
@@ -1410,7 +1459,7 @@ static int cg_iterate(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, hi
     }
     const double *p2 = a->part2, *p3 = a->part3, *p4 = a->part4;
     int np2 = part2_count(a), n4 = np4;
-    if (!recur && !no_xn2) cmp.add(p2, np2, 2, 1024);
+    if (!no_xn2) cmp.add(p2, np2, 2, 1024);
     if (a->m > 0) {
       cmp.add(p3, np3, 2, 2048);
       cmp.add(p4, n4, 1, 1024);
@@ -1419,7 +1468,7 @@ static int cg_iterate(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, hi
     if (rc) return rc;
     if (fused_hp(a)) {
       MARK(6);
-      rc = launch_step2_hp(a, it, (a->m > 0 ? 0 : 2) | (recur ? 4 : 0) | (no_xn2 ? 1 : 0), p2, np2,
+      rc = launch_step2_hp(a, it, (a->m > 0 ? 0 : 2) | (no_xn2 ? 1 : 0), p2, np2,
                            p3, np3, p4, n4, st);
     } else {
       hipLaunchKernelGGL(k_cg_step2, dim3(ipx_xcd_grid((int)a->vec_grid)), dim3(VB), 0, st, a->n,

@@ -281,6 +281,60 @@ struct ipx_own_ranges {
 #endif
 };
 
+// ---- peer mailboxes of the row-sharded loop (csrc/peer.hip) ------------------------
+// Every rank owns one mailbox in its own HBM (uncached allocation) that its peers map through
+// hipIpc and write into directly over xGMI.  Values travel as "LL" words: a double is two
+// 64-bit words, each carrying 32 data bits and a 32-bit sequence number; an aligned 8-byte
+// store is indivisible, so a reader that sees the expected sequence number in both words has
+// the value -- no flag, no fence, one store per word on the writer's side.
+//   words [0, IPX_PEER_SCAL_WORDS): scalars  [slot 0..3][rank][8 quantities][2 words]
+//   then the halo regions              [side: from the left / right neighbour][parity][cap][2 words]
+#define IPX_MAX_PEERS 16
+#define IPX_PEER_SLOTS 4
+#define IPX_PEER_NQ 8
+#define IPX_PEER_SCAL_WORDS (IPX_PEER_SLOTS * IPX_MAX_PEERS * IPX_PEER_NQ * 2)
+#define IPX_PEER_TIMEOUT_TICKS 300000000LL     // 3 s of the 100 MHz wall clock
+struct ipx_peer_view {
+  int rank, world;
+  int64_t cap;                                 // halo capacity (doubles) per side and parity
+  unsigned long long *mbox[IPX_MAX_PEERS];     // every rank's mailbox as mapped here (own: local)
+};
+// host-side object behind ipx_shard2_ext.peer
+struct ipx_peer {
+  ipx_peer_view view;
+  uint32_t seq, hseq;                          // scalar / halo sequence numbers (never 0)
+  void *opened[IPX_MAX_PEERS];                 // hipIpcOpenMemHandle results (to close)
+  int64_t bytes;
+};
+#ifdef __HIPCC__
+__device__ __forceinline__ int64_t ipx_peer_scal_word(int slot, int rank, int q) {
+  return (((int64_t)slot * IPX_MAX_PEERS + rank) * IPX_PEER_NQ + q) * 2;
+}
+__device__ __forceinline__ int64_t ipx_peer_halo_word(int64_t cap, int side, int parity, int64_t i) {
+  return IPX_PEER_SCAL_WORDS + (((int64_t)side * 2 + parity) * cap + i) * 2;
+}
+__device__ __forceinline__ void ipx_ll_store(unsigned long long *dst, double v, uint32_t seq) {
+  const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+  const unsigned long long tag = (unsigned long long)seq << 32;
+  __hip_atomic_store(dst, tag | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(dst + 1, tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// spins until both words carry `seq`; false after IPX_PEER_TIMEOUT_TICKS (a peer died)
+__device__ __forceinline__ bool ipx_ll_load(const unsigned long long *src, uint32_t seq, double &v,
+                                            long long deadline) {
+  while (true) {
+    const unsigned long long a = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned long long b = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if ((uint32_t)(a >> 32) == seq && (uint32_t)(b >> 32) == seq) {
+      v = __longlong_as_double((long long)((a & 0xffffffffull) | (b << 32)));
+      return true;
+    }
+    if ((long long)wall_clock64() > deadline) return false;
+    __builtin_amdgcn_s_sleep(2);
+  }
+}
+#endif
+
 // ---- box-Schur group tables (csrc/boxschur.hip; also read by the CG loop's step1)
 #ifdef __HIPCC__
 struct ipx_group_tab {

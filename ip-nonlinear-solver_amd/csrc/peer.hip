@@ -1,0 +1,152 @@
+// Peer mailboxes for the row-sharded projected-CG loop (ipsolver/sharded.py): the ranks of
+// one node exchange their few scalars per iteration (p'Hp; ||x+ap||^2, #violations, ||g||^2,
+// ||A g||^2: the reductions of qp_subproblem.py:556,583,626) and the halo of g by writing
+// straight into each other's HBM over xGMI -- no collective call and no host between the
+// iterations of a batch.
+//
+// Set-up (host, once per group): every rank allocates its mailbox (uncached device memory),
+// exports a hipIpc handle, the handles travel through the launcher's side channel
+// (torch.distributed.all_gather_object in ipsolver/sharded.py), every rank maps the others'.
+// In the loop the mailboxes are touched by kernels only (csrc/cg.hip k_cg_pack_comm, LL
+// words: ipx_common.h).  Works the same between processes that share one device (the
+// rehearsal topology of the tests) and between the GPUs of a node.
+#include "ipx_common.h"
+#include <string.h>
+#include <new>
+
+namespace {
+
+// all-reduce(sum) of nq doubles and nothing else: the latency probe of bench.py
+__global__ void __launch_bounds__(64)
+k_peer_allreduce(ipx_peer_view pv, uint32_t seq, int nq, const double *__restrict__ in,
+                 double *__restrict__ out, int *__restrict__ failed) {
+  __shared__ double vals[IPX_MAX_PEERS * IPX_PEER_NQ];
+  const int tid = threadIdx.x, slot = seq & (IPX_PEER_SLOTS - 1);
+  const long long deadline = (long long)wall_clock64() + IPX_PEER_TIMEOUT_TICKS;
+  for (int i = tid; i < pv.world * nq; i += blockDim.x) {
+    const int r = i / nq, q = i - r * nq;
+    ipx_ll_store(pv.mbox[r] + ipx_peer_scal_word(slot, pv.rank, q), in[q], seq);
+  }
+  bool ok = true;
+  for (int i = tid; i < pv.world * nq; i += blockDim.x) {
+    const int r = i / nq, q = i - r * nq;
+    double v = 0.0;
+    ok = ipx_ll_load(pv.mbox[pv.rank] + ipx_peer_scal_word(slot, r, q), seq, v, deadline) && ok;
+    vals[r * IPX_PEER_NQ + q] = v;
+  }
+  if (!ok) *failed = 1;
+  __syncthreads();
+  if (tid < nq) {
+    double s = 0.0;
+    for (int r = 0; r < pv.world; ++r) s += vals[r * IPX_PEER_NQ + tid];   // rank order: same bits everywhere
+    out[tid] = s;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int ipx_peer_handle_bytes(void) { return (int)sizeof(hipIpcMemHandle_t); }
+
+void *ipx_peer_create(int32_t rank, int32_t world, int64_t halo_cap) {
+  if (world < 1 || world > IPX_MAX_PEERS || rank < 0 || rank >= world || halo_cap < 0) return nullptr;
+  ipx_peer *p = new (std::nothrow) ipx_peer();
+  if (!p) return nullptr;
+  memset(p, 0, sizeof(*p));
+  p->view.rank = rank;
+  p->view.world = world;
+  p->view.cap = halo_cap;
+  p->seq = p->hseq = 0;
+  p->bytes = 8 * ((int64_t)IPX_PEER_SCAL_WORDS + 2 * 2 * halo_cap * 2);
+  void *mem = nullptr;
+  // uncached: remote writes must be seen by the spinning reader, local polls must not be
+  // served from a stale L2 line
+  hipError_t e = hipExtMallocWithFlags(&mem, (size_t)p->bytes, hipDeviceMallocUncached);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    e = hipExtMallocWithFlags(&mem, (size_t)p->bytes, hipDeviceMallocFinegrained);
+  }
+  if (e != hipSuccess) {
+    ipx_note_error(e, __FILE__, __LINE__);
+    delete p;
+    return nullptr;
+  }
+  if (hipMemset(mem, 0, (size_t)p->bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+    (void)hipFree(mem);
+    delete p;
+    return nullptr;
+  }
+  p->view.mbox[rank] = (unsigned long long *)mem;
+  return p;
+}
+
+int ipx_peer_export(void *peer, void *handle_out) {
+  if (!peer || !handle_out) return IPX_EINVAL;
+  ipx_peer *p = (ipx_peer *)peer;
+  hipIpcMemHandle_t h;
+  hipError_t e = hipIpcGetMemHandle(&h, p->view.mbox[p->view.rank]);
+  if (e != hipSuccess) { ipx_note_error(e, __FILE__, __LINE__); return IPX_ELAUNCH; }
+  memcpy(handle_out, &h, sizeof(h));
+  return IPX_OK;
+}
+
+int ipx_peer_import(void *peer, int32_t rank, const void *handle_in) {
+  if (!peer || !handle_in) return IPX_EINVAL;
+  ipx_peer *p = (ipx_peer *)peer;
+  if (rank < 0 || rank >= p->view.world || rank == p->view.rank || p->view.mbox[rank]) return IPX_EINVAL;
+  hipIpcMemHandle_t h;
+  memcpy(&h, handle_in, sizeof(h));
+  void *mem = nullptr;
+  hipError_t e = hipIpcOpenMemHandle(&mem, h, hipIpcMemLazyEnablePeerAccess);
+  if (e != hipSuccess) { ipx_note_error(e, __FILE__, __LINE__); return IPX_ELAUNCH; }
+  p->opened[rank] = mem;
+  p->view.mbox[rank] = (unsigned long long *)mem;
+  return IPX_OK;
+}
+
+// 1 when every rank's mailbox is mapped
+int ipx_peer_ready(void *peer) {
+  if (!peer) return 0;
+  ipx_peer *p = (ipx_peer *)peer;
+  for (int r = 0; r < p->view.world; ++r)
+    if (!p->view.mbox[r]) return 0;
+  return 1;
+}
+
+int64_t ipx_peer_halo_capacity(void *peer) { return peer ? ((ipx_peer *)peer)->view.cap : 0; }
+
+// scalar / halo exchanges issued so far (identical on every rank of a healthy group)
+int ipx_peer_sequence(void *peer, int64_t *out2) {
+  if (!peer || !out2) return IPX_EINVAL;
+  out2[0] = ((ipx_peer *)peer)->seq;
+  out2[1] = ((ipx_peer *)peer)->hseq;
+  return IPX_OK;
+}
+
+void ipx_peer_destroy(void *peer) {
+  if (!peer) return;
+  ipx_peer *p = (ipx_peer *)peer;
+  for (int r = 0; r < p->view.world; ++r)
+    if (p->opened[r]) (void)hipIpcCloseMemHandle(p->opened[r]);
+  if (p->view.mbox[p->view.rank]) (void)hipFree(p->view.mbox[p->view.rank]);
+  delete p;
+}
+
+// `reps` all-reduces of nq <= 8 doubles, back to back on `stream` (in / out: device arrays;
+// failed: device int, set when a wait timed out).  The measured floor of the mailbox path.
+int ipx_peer_allreduce(void *peer, int32_t nq, const double *in, double *out, int *failed,
+                       int32_t reps, void *stream) {
+  if (!peer || nq < 1 || nq > IPX_PEER_NQ || !in || !out || !failed || !ipx_peer_ready(peer))
+    return IPX_EINVAL;
+  ipx_peer *p = (ipx_peer *)peer;
+  for (int i = 0; i < reps; ++i) {
+    if (++p->seq == 0) ++p->seq;
+    hipLaunchKernelGGL(k_peer_allreduce, dim3(1), dim3(64), 0, (hipStream_t)stream, p->view, p->seq,
+                       (int)nq, in, out, failed);
+  }
+  IPX_CHECK_LAUNCH();
+  return IPX_OK;
+}
+
+}  // extern "C"

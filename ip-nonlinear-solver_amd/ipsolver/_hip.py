@@ -51,7 +51,6 @@ _SIGNATURES = {
     "ipx_cg_resume": [_P, _I32, _I32, _P],
     "ipx_cg_iterate": [_P, _I32, _I32, _P],
     "ipx_cg_iterate_timed": [_P, _I32, _I32, _P, _P],
-    "ipx_cg_graph_launch": [_P, _I32, _P],
     "ipx_banded_kmax": [],
     "ipx_banded_levels": [_P],
     "ipx_banded_decoupled": [_P],
@@ -70,6 +69,13 @@ _SIGNATURES = {
     "ipx_pcg_iterate": [_P, _I32, _I32, _P],
     "ipx_cg_shard2_segment": [_P, _P, _I32, _I32, _I32, _P],
     "ipx_cg_shard2_fold_hp": [_P, _P, _P],
+    "ipx_cg_shard2_iterate": [_P, _P, _I32, _I32, _P],
+    "ipx_peer_handle_bytes": [],
+    "ipx_peer_export": [_P, _P],
+    "ipx_peer_import": [_P, _I32, _P],
+    "ipx_peer_ready": [_P],
+    "ipx_peer_sequence": [_P, _P],
+    "ipx_peer_allreduce": [_P, _I32, _P, _P, _P, _I32, _P],
     "ipx_aat_band": [_I64, _I32, _P, _P, _P, _P, _P, _P],
     "ipx_aat_band_w": [_I64, _I32, _P, _P, _P, _P, _P, _P, _P],
     "ipx_pairs_factor": [_I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
@@ -81,10 +87,11 @@ _SIGNATURES = {
 }
 _RESTYPES = {"ipx_version": _c.c_char_p, "ipx_last_error": _c.c_char_p,
              "ipx_banded_create": _P, "ipx_banded_destroy": None,
-             "ipx_dense_padded": _I64, "ipx_cg_graph_create": _P, "ipx_cg_graph_destroy": None}
+             "ipx_dense_padded": _I64, "ipx_peer_create": _P, "ipx_peer_destroy": None,
+             "ipx_peer_halo_capacity": _I64}
 _EXTRA_ARGTYPES = {"ipx_banded_create": [_I64, _I32, _I32], "ipx_banded_destroy": [_P],
-                   "ipx_dense_padded": [_I64], "ipx_cg_graph_create": [_P, _P],
-                   "ipx_cg_graph_destroy": [_P]}
+                   "ipx_dense_padded": [_I64], "ipx_peer_create": [_I32, _I32, _I64],
+                   "ipx_peer_destroy": [_P], "ipx_peer_halo_capacity": [_P]}
 
 _lib = None
 

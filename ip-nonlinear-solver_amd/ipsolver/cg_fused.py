@@ -40,7 +40,7 @@ class CgArgs(ctypes.Structure):
         ("vec_grid", _I64), ("solver_kind", _I64), ("pb", _P), ("H_hmax", _I64), ("H_tile_rows", _I64),
         ("r_next", _P), ("A_own", _P), ("A_span", _I64), ("fold_ws", _P),
         ("At_vown", _P), ("At_qv", _I64), ("A_tile_nnz", _I64),
-        ("At_ell_col", _P), ("At_ell_val", _P), ("part5", _P),
+        ("At_ell_col", _P), ("At_ell_val", _P),
         ("H_col16", _P), ("H_rowlen", _P), ("A_col16", _P), ("no_radius", _I64))]
 
 
@@ -310,7 +310,7 @@ def _ptr(t):
 class _Loop:
     """Buffers + argument block for one projected_cg call."""
 
-    def __init__(self, H, P, lb, ub, recur=True):
+    def __init__(self, H, P, lb, ub):
         from .dense import DeviceDense
         if isinstance(P.A, DeviceDense):
             self._init_dense(H, P, lb, ub)
@@ -405,15 +405,6 @@ class _Loop:
                     if n % 2 == 0 and kS == 1:
                         self.ell_col, self.ell_val = ell_rows(At)
                         a.At_ell_col, a.At_ell_val = _ptr(self.ell_col), _ptr(self.ell_val)
-        # Optional (IPX_RECUR=1), both fused kernels in use: ||x + alpha p||^2 by recurrence from
-        # sums the step2 + H.p kernel accumulates, so step1 + A.r does not read x and p (csrc/cg.hip
-        # RECUR).  Off by default: +2.4 % it/s at n=1e6 (+5.4 % at n=4e6) for a 7 % slower dominant
-        # kernel, and the trust-region test's norm is then rounded differently from the direct
-        # sum the reference computes.
-        self.part5 = None
-        if recur and a.A_span and a.H_hmax and os.environ.get("IPX_RECUR"):
-            self.part5 = torch.zeros(3 * Hc.pattern.ntiles, dtype=f64, device=dev)
-            a.part5 = _ptr(self.part5)
         self.args = a
 
     def _init_dense(self, H, P, lb, ub):
@@ -431,7 +422,6 @@ class _Loop:
         grid = lib.ipx_cg_vec_grid(n)
         self.part1, self.part3, self.part4 = z(2 * 2048), z(2 * 2048), z(2 * 2048)
         self.part2 = z(2 * grid)
-        self.part5 = None
         a = CgArgs()
         a.n, a.m = n, m
         a.A_val, a.At_val = _ptr(A.t), _ptr(At.t)
@@ -460,18 +450,6 @@ class _Loop:
 
     def ref(self):
         return ctypes.byref(self.args)
-
-    def seed_sums(self):
-        """x'x, x'p, p'p of the current (x, p) into the scratch the recurrence starts from:
-        after priming the loop, and after the host finished an iteration with the separate
-        kernels (which do not leave these sums)."""
-        if self.part5 is None:
-            return
-        r = dv.box_sphere_reduce(DVec(self.x), DVec(self.p), 1.0, None, None)
-        nt = self.part5.numel() // 3
-        self.part5.zero_()
-        seed = torch.tensor([r[2], r[1], r[0]], dtype=torch.float64, device=self.part5.device)
-        self.part5[0::nt][:3].copy_(seed)
 
 
 def projected_cg(H, c, Z, Y, b, trust_radius=np.inf, lb=None, ub=None, tol=None,
@@ -524,7 +502,6 @@ def projected_cg(H, c, Z, Y, b, trust_radius=np.inf, lb=None, ub=None, tol=None,
     init[ST_ORTH_RHS] = P.orth_tol * P.norm_A
     L.state.copy_(torch.from_numpy(init))
     _hip.check(lib.ipx_cg_hp(L.ref(), st), "ipx_cg_hp")
-    L.seed_sums()
 
     X, R = DVec(L.x), DVec(L.r)
     hits_boundary = False
@@ -621,7 +598,6 @@ def _resume(lib, L, it_stop, mode, st):
     """Clear the stop flag, finish iteration ``it_stop`` (step2 + Hp)."""
     L.state[ST_STOP] = 0.0
     _hip.check(lib.ipx_cg_resume(L.ref(), it_stop, mode, st), "ipx_cg_resume")
-    L.seed_sums()
     return L.state.tolist()
 
 

@@ -109,6 +109,7 @@ class BandedNormalSolver:
         # handle + band storage are recycled per pattern: creating / destroying a handle is a
         # dozen hipMalloc / hipFree calls (~0.5 ms), more than the numeric refresh itself
         lib = _hip.load()
+        self._sym = sym          # the pool's handles are destroyed with `sym`: keep it alive
         self._pool = sym.__dict__.setdefault("_handle_pool", [])
         self._key = (self.m, self.k, int(chunk))
         self.handle, self.band = None, None
@@ -469,7 +470,12 @@ def normal_solver_for(A):
                 return IterativeNormalSolver(A)
     if _box_schur_applies(A, kmax):
         from .boxschur import BoxSchurNormalSolver
-        return BoxSchurNormalSolver(A)          # bound rows eliminated analytically
+        try:
+            return BoxSchurNormalSolver(A)      # bound rows eliminated analytically
+        except BandedNotDecoupled:
+            # the Schur complement of the general rows is such a coupled wide band: the
+            # elimination buys nothing, solve with A itself by the paths below
+            pass
     if m <= DenseNormalSolver.MAX_ROWS_FROM_SPARSE:
         return DenseNormalSolver(A)             # wide band: dense Cholesky of A A'
     return IterativeNormalSolver(A)             # general sparsity: matrix-free solve

@@ -41,6 +41,7 @@ or the numpy twin in ``oracle/numpy_local.py`` that lets tests/test_sharded_gloo
 same orchestration over gloo on CPUs.
 """
 import ctypes
+import os
 
 import numpy as np
 import scipy.sparse as sps
@@ -132,7 +133,10 @@ class ShardComm:
         self.world = dist.get_world_size(group) if self.on else 1
         self.rank = dist.get_rank(group) if self.on else 0
         self.backend = dist.get_backend(group) if self.on else "none"
-        self.stats = {"all_reduce": 0, "all_reduce_bytes": 0, "exchange": 0, "exchange_bytes": 0}
+        # (ipc_*: batches / iterations of the device loop that ran on the peer mailboxes --
+        # none of the four counters above moves between their boundaries)
+        self.stats = {"all_reduce": 0, "all_reduce_bytes": 0, "exchange": 0, "exchange_bytes": 0,
+                      "ipc_batches": 0, "ipc_iterations": 0}
 
     def all_reduce(self, t, op="sum"):
         """In place on a torch tensor (CUDA under nccl; CUDA tensors are staged through the
@@ -289,6 +293,101 @@ class ShardComm:
                 t[0:own_lo].copy_(buf[0:own_lo])
             if n - own_hi:
                 t[own_hi:n].copy_(buf[own_hi:n])
+
+
+class PeerMailbox:
+    """This rank's mailbox and its peers', mapped through hipIpc (csrc/peer.hip): the transport
+    of the device-resident loop's scalars and halo when every rank of the group runs on this
+    node.  Construction is collective (the handles travel through
+    ``torch.distributed.all_gather_object`` once); afterwards the mailboxes are touched by
+    kernels only.  ``ok`` is False -- on EVERY rank -- when any rank could not map a peer
+    (ranks on different nodes, IPC refused): the loop then stays on ``torch.distributed``."""
+
+    def __init__(self, comm, halo_cap):
+        from . import _hip
+        self._hip, self.comm = _hip, comm
+        lib = self.lib = _hip.load()
+        self.handle, self.ok, self.error = None, False, None
+        world, rank = comm.world, comm.rank
+        blob, cap = None, int(halo_cap)
+        try:
+            caps = [None] * world
+            dist.all_gather_object(caps, cap, group=comm.group)
+            cap = max(caps)
+            self.handle = lib.ipx_peer_create(rank, world, cap)
+            if not self.handle:
+                raise _hip.IpxError("ipx_peer_create failed: " + lib.ipx_last_error().decode())
+            buf = ctypes.create_string_buffer(lib.ipx_peer_handle_bytes())
+            _hip.call("ipx_peer_export", ctypes.c_void_p(self.handle), buf)
+            blob = (_host_id(), buf.raw)
+        except Exception as exc:                 # keep going: the group decides together below
+            self.error = repr(exc)
+        blobs = [None] * world
+        dist.all_gather_object(blobs, blob, group=comm.group)
+        good = all(b is not None and b[0] == blobs[0][0] for b in blobs)
+        if good:
+            try:
+                for r, b in enumerate(blobs):
+                    if r != rank:
+                        _hip.call("ipx_peer_import", ctypes.c_void_p(self.handle), r, b[1])
+            except Exception as exc:
+                self.error, good = repr(exc), False
+        elif self.error is None:
+            self.error = "ranks on different hosts, or a peer could not export its mailbox"
+        flags = [None] * world
+        dist.all_gather_object(flags, bool(good), group=comm.group)
+        self.ok = all(flags)
+        if self.ok:
+            self.check()
+        else:
+            self.close()
+
+    def check(self):
+        """One all-reduce through the mailboxes against the known answer."""
+        out = self.allreduce([float(self.comm.rank + 1), 1.0])
+        w = self.comm.world
+        if out != [w * (w + 1) / 2.0, float(w)]:
+            raise self._hip.IpxError("peer mailbox self-test failed: %r" % (out,))
+
+    def allreduce(self, values, reps=1):
+        """Sum of up to 8 host scalars over the ranks through the mailboxes (set-up checks and
+        bench.py's latency probe; the loop's reductions never pass through the host)."""
+        from . import device as dv
+        dev = dv.ctx().device
+        t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=dev)
+        out = torch.zeros_like(t)
+        failed = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._hip.call("ipx_peer_allreduce", ctypes.c_void_p(self.handle), t.numel(),
+                       ctypes.c_void_p(t.data_ptr()), ctypes.c_void_p(out.data_ptr()),
+                       ctypes.c_void_p(failed.data_ptr()), int(reps), dv.stream_ptr())
+        if int(failed.item()):
+            raise self._hip.IpxError("peer mailbox: a wait for a peer timed out")
+        return out.tolist()
+
+    def sequence(self):
+        out = (ctypes.c_int64 * 2)()
+        self._hip.call("ipx_peer_sequence", ctypes.c_void_p(self.handle), out)
+        return int(out[0]), int(out[1])
+
+    def close(self):
+        h, self.handle = self.handle, None
+        if h:
+            try:
+                torch.cuda.synchronize()
+                self.lib.ipx_peer_destroy(ctypes.c_void_p(h))
+            except Exception:
+                pass
+
+    __del__ = close
+
+
+def _host_id():
+    import socket
+    try:
+        with open("/proc/sys/kernel/random/boot_id") as f:
+            return socket.gethostname() + ":" + f.read().strip()
+    except OSError:
+        return socket.gethostname()
 
 
 # --------------------------------------------------------------------------- local arithmetic
@@ -491,12 +590,34 @@ class Sharding:
     def __init__(self, layout, comm, ops):
         self.lay, self.comm, self.ops = layout, comm, ops
         self._segs = {}
+        self._mailbox = None
         self.spaces = {}                 # global length -> space (what xp.zeros(n) means)
         if layout.n != layout.m:
             self.spaces[layout.n], self.spaces[layout.m] = "col", "row"
 
     def register(self, kind):
         self.spaces[self.global_len(kind)] = kind if isinstance(kind, str) else tuple(kind)
+
+    def mailbox(self):
+        """The peer mailboxes of this group (``PeerMailbox``; created collectively on first use)
+        or None: one rank, the numpy twin, ``IPX_SHARD_TRANSPORT=dist``, or hipIpc not available
+        between the ranks -- the device loop then reduces through ``torch.distributed``."""
+        if self._mailbox is None:
+            self._mailbox = False
+            if self.comm.world > 1 and getattr(self.ops, "fused", False) \
+                    and os.environ.get("IPX_SHARD_TRANSPORT", "ipc") == "ipc":
+                # room for the halo of the largest stacked vector (the barrier problem's z)
+                segs = self.segments(("col", "row", "col", "col"))
+                cap = max(sum(sg[3] for sg in segs), sum(sg[2] - sg[4] for sg in segs)) + 64
+                mb = PeerMailbox(self.comm, cap)
+                self.mailbox_error = mb.error
+                if mb.ok:
+                    self._mailbox = mb
+        return self._mailbox or None
+
+    @property
+    def transport(self):
+        return "ipc" if self.mailbox() is not None else "dist"
 
     def segments(self, kind):
         """Per segment: (kind, local offset, local length, own_lo, own_hi, send_left,
@@ -815,6 +936,38 @@ class ShardProjector:
         self.stats = {"solves": 0, "refinements": 0}
         self.fused_sharded = bool(getattr(self.sh.ops, "fused", False))
         self.plain = plain
+        self._check_truncation()
+
+    def _check_truncation(self):
+        """The local solve on own + halo rows stands for the global one on the own rows only
+        when ``(A A')^-1`` decays across the halo (module docstring).  Every operator of this
+        projector relies on it (Z, LS, Y; the fused loop and the general driver alike), so it is
+        established here, once per factorization: on the device from the decoupling measured by
+        the factorization itself (csrc/banded.hip: separator couplings below 2^-56), with the
+        numpy twin by the residual of one probe solve on the own rows."""
+        sh = self.sh
+        if sh.comm.world == 1:
+            return
+        if self.fused_sharded:
+            from . import _hip
+            banded = _banded_of(self)
+            geo = (ctypes.c_int32 * 2)()
+            if banded is None or not _hip.load().ipx_banded_decoupled_geometry(
+                    ctypes.c_void_p(banded.handle), geo):
+                raise NotImplementedError(
+                    "row-sharded projections need a banded (A A')^-1 whose partitioned "
+                    "factorization decouples numerically (DESIGN.md section 5): the local solve "
+                    "truncated to own + halo rows would not be the global one")
+            return
+        w = sh.full(self.A.row_kind, 1.0)
+        v = sh.sync(ShardVec(self.solver.solve(w.loc), sh, self.A.row_kind))
+        res = self.A.dot(self.A.T.dot(v)) - w
+        err = np.sqrt(res.sumsq_amax()[0] / max(len(w), 1))
+        if not err <= 1e-9:
+            raise NotImplementedError(
+                "row-sharded projections: the local solve truncated to own + halo rows misses "
+                "the global one by %.1e on the own rows (slowly decaying (A A')^-1: fewer "
+                "ranks or a wider halo)" % err)
 
     def _apply_inv(self, w):
         self.stats["solves"] += 1
@@ -874,7 +1027,9 @@ class Shard2Ext(ctypes.Structure):
     _fields_ = [("s1", ctypes.c_void_p), ("pack", ctypes.c_void_p), ("nseg", ctypes.c_int64),
                 ("own_lo", _A4), ("own_hi", _A4), ("p1_lo", _A4), ("p1_hi", _A4),
                 ("p3_lo", _A4), ("p3_hi", _A4), ("p2_lo", ctypes.c_int64),
-                ("p2_hi", ctypes.c_int64), ("p4_lo", ctypes.c_int64), ("p4_hi", ctypes.c_int64)]
+                ("p2_hi", ctypes.c_int64), ("p4_lo", ctypes.c_int64), ("p4_hi", ctypes.c_int64),
+                ("peer", ctypes.c_void_p), ("seg_lo", _A4), ("seg_hi", _A4),
+                ("send_left", _A4), ("send_right", _A4)]
 
 
 def _banded_of(P):
@@ -932,7 +1087,7 @@ class FusedShardedCG:
         self.P = P
         self.kind = H.kind
         self.L = L = cg_fused._Loop(H.local, local_P, lb.loc if lb is not None else None,
-                                    ub.loc if ub is not None else None, recur=False)
+                                    ub.loc if ub is not None else None)
         a = L.args
         dev = dv.ctx().device
         self.s1 = torch.zeros(2, dtype=torch.float64, device=dev)
@@ -970,8 +1125,18 @@ class FusedShardedCG:
             Atp = A_loc.T.pattern
             for k in range(len(segs)):
                 e.p3_lo[k], e.p3_hi[k] = Atp.tile_range(e.own_lo[k], e.own_hi[k])
-        self._exchange_g = sh.comm.prepare_exchange_many(
-            [(self.L.r[off:off + ln], lo, hi, sl, sr) for _, off, ln, lo, hi, sl, sr, _, _ in segs])
+        for k, (_, off, ln, lo, hi, sl, sr, _, _) in enumerate(segs):
+            e.seg_lo[k], e.seg_hi[k] = off, off + ln
+            e.send_left[k], e.send_right[k] = sl, sr
+        self.mailbox = sh.mailbox()
+        if self.mailbox is not None:
+            # the pack kernels all-reduce the scalars and move the halo of g themselves
+            e.peer = self.mailbox.handle
+            self._exchange_g = None
+        else:
+            self._exchange_g = sh.comm.prepare_exchange_many(
+                [(self.L.r[off:off + ln], lo, hi, sl, sr)
+                 for _, off, ln, lo, hi, sl, sr, _, _ in segs])
         # (own range and send counts of the first segment: bench.py measures the exchange's floor)
         self.col_geom = (segs[0][3], segs[0][4], segs[0][5], segs[0][6])
 
@@ -998,8 +1163,16 @@ class FusedShardedCG:
 
     def iterate(self, it_begin, it_end):
         """Enqueue iterations [it_begin, it_end): per iteration two all-reduces and one halo
-        exchange, no host synchronisation."""
+        exchange, no host synchronisation.  On the peer mailboxes this is ONE C call for the
+        whole batch (the reductions and the exchange happen inside the loop's launches);
+        through ``torch.distributed`` the host issues three collectives per iteration."""
         comm, exchange_g = self.sh.comm, self._exchange_g
+        if self.mailbox is not None:
+            self._hip.call("ipx_cg_shard2_iterate", self.L.ref(), ctypes.byref(self.ext),
+                           int(it_begin), int(it_end), self.dv.stream_ptr())
+            comm.stats["ipc_batches"] += 1
+            comm.stats["ipc_iterations"] += it_end - it_begin
+            return
         for it in range(it_begin, it_end):
             comm.all_reduce(self.s1)                                   # p'Hp
             self._segment(0, it)
@@ -1127,6 +1300,9 @@ def fused_projected_cg(H, c, Z, Y, b, trust_radius=np.inf, lb=None, ub=None, tol
             F.resume(it_stop, mode | 2)
             it = it_stop + 1
             continue
+        if stop == 7:
+            raise RuntimeError("sharded projected CG: a wait on the peer mailboxes timed out "
+                               "(a rank of the group died or fell out of step)")
         raise RuntimeError("unexpected CG stop code %d" % stop)
 
     x = ShardVec(DV(L.x), sh, F.kind)

@@ -68,16 +68,20 @@ def test_header_is_plain_c_and_structs_match_the_bindings(tmp_path):
         pytest.skip("no gcc")
     from ipsolver.boxschur import BoxSchurArgs
     from ipsolver.cg_fused import CgArgs
+    from ipsolver.projector import PcgArgs
     from ipsolver.sharded import Shard2Ext
     src = tmp_path / "sizes.c"
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "ipx.h"\n'
-                   'int main(void) { printf("%zu %zu %zu %zu %zu\\n", sizeof(ipx_cg_args), '
-                   'sizeof(ipx_boxschur_args), sizeof(ipx_shard2_ext), '
-                   'offsetof(ipx_cg_args, state), offsetof(ipx_shard2_ext, own_hi)); return 0; }\n')
+                   'int main(void) { printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", '
+                   'sizeof(ipx_cg_args), sizeof(ipx_boxschur_args), sizeof(ipx_shard2_ext), '
+                   'offsetof(ipx_cg_args, state), offsetof(ipx_shard2_ext, own_hi), '
+                   'sizeof(ipx_pcg_args), offsetof(ipx_shard2_ext, peer), '
+                   'offsetof(ipx_cg_args, no_radius)); return 0; }\n')
     exe = tmp_path / "sizes"
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
                     str(src), "-o", str(exe)], check=True)
     got = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True,
                                           text=True).stdout.split()]
     assert got == [ctypes.sizeof(CgArgs), ctypes.sizeof(BoxSchurArgs), ctypes.sizeof(Shard2Ext),
-                   CgArgs.state.offset, Shard2Ext.own_hi.offset]
+                   CgArgs.state.offset, Shard2Ext.own_hi.offset, ctypes.sizeof(PcgArgs),
+                   Shard2Ext.peer.offset, CgArgs.no_radius.offset]

@@ -404,7 +404,7 @@ def test_sharded_fused_loop_single_rank(ips):
     close(x.to_host(), host(x1), 1e-12)
 
 
-def _multi_rank_worker(rank, world, port, out_path):
+def _multi_rank_worker(rank, world, port, out_path, transport="dist"):
     import os
     import sys
     import torch
@@ -414,12 +414,26 @@ def _multi_rank_worker(rank, world, port, out_path):
         if p not in sys.path:
             sys.path.insert(0, p)
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ["IPX_SHARD_TRANSPORT"] = transport
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from ipsolver import sharded, qp
         n, m = 20000, 2000
         inst, sh, A, H = _sharded_problem(world, rank, n, m)
+        # no torch.distributed call may happen between the boundaries of a batch of the
+        # device loop when it runs on the peer mailboxes
+        leaks = []
+        plain_iterate = sharded.FusedShardedCG.iterate
+
+        def watched(self, it_begin, it_end):
+            keys = ("all_reduce", "exchange")
+            before = [self.sh.comm.stats[k] for k in keys]
+            plain_iterate(self, it_begin, it_end)
+            after = [self.sh.comm.stats[k] for k in keys]
+            if self.mailbox is not None and after != before:
+                leaks.append((before, after))
+        sharded.FusedShardedCG.iterate = watched
         Z, LS, Y = sharded.projections(A)
         c = sh.from_global(inst.c, "col")
         out = {}
@@ -439,6 +453,9 @@ def _multi_rank_worker(rank, world, port, out_path):
         out["stats"] = np.array([sharded.STATS[k] for k in ("fused_calls", "box_events",
                                                             "refine_events")]
                                 + [sh.comm.stats["exchange"]])
+        out["ipc"] = np.array([float(sh.transport == "ipc"), sh.comm.stats["ipc_batches"],
+                               sh.comm.stats["ipc_iterations"], len(leaks)]
+                              + list(sh.mailbox().sequence() if sh.mailbox() else (0, 0)))
         flags = torch.tensor([float(sharded.STATS["fused_calls"])])
         dist.all_reduce(flags, op=dist.ReduceOp.MIN)          # engaged on every rank?
         out["fused_min"] = flags.numpy()
@@ -448,13 +465,20 @@ def _multi_rank_worker(rank, world, port, out_path):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("transport", ["ipc", "dist"])
 @pytest.mark.parametrize("world", [2, 3])
-def test_sharded_fused_loop_multi_rank(world, tmp_path, banded20000):
-    """The HIP kernels under the row partition: `world` processes share cuda:0 and talk over
-    gloo (RCCL refuses two ranks on one device; the collectives are staged through the host in
-    this test only).  The device-resident loop -- two all-reduces and one halo exchange of g
-    per iteration -- against the REFERENCE's golden traces (every exit of the loop: tolerance,
-    trust region, box events) and, with refining projections, against the oracle."""
+def test_sharded_fused_loop_multi_rank(world, transport, tmp_path, banded20000, ips):
+    """The HIP kernels under the row partition: `world` processes share cuda:0.  The
+    device-resident loop -- two all-reduces and one halo exchange of g per iteration --
+    against the REFERENCE's golden traces (every exit of the loop: tolerance, trust region,
+    box events), with refining projections against the oracle, and against the single-GPU
+    device loop to 1e-12.
+
+    transport "ipc": the scalars and the halo travel through the peer mailboxes (hipIpc-mapped
+    device memory, csrc/peer.hip) inside the loop's own launches -- a batch of iterations is
+    ONE C call and no torch.distributed call happens between its boundaries (asserted on
+    ``ShardComm.stats``).  transport "dist": three torch.distributed calls per iteration (over
+    gloo here, staged through the host: RCCL refuses two ranks on one device)."""
     import socket
     import torch.multiprocessing as mp
     import oracle
@@ -462,7 +486,7 @@ def test_sharded_fused_loop_multi_rank(world, tmp_path, banded20000):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     out = str(tmp_path / "x.npz")
-    mp.spawn(_multi_rank_worker, args=(world, port, out), nprocs=world, join=True)
+    mp.spawn(_multi_rank_worker, args=(world, port, out, transport), nprocs=world, join=True)
     got, gold = np.load(out), banded20000
     st = int(gold["stride"][0])
     inst = BandedInstance(20000, 2000)
@@ -474,7 +498,22 @@ def test_sharded_fused_loop_multi_rank(world, tmp_path, banded20000):
     close(got["refine_x"], xo)
     fused_calls, box_events, refine_events, exchanges = got["stats"]
     assert got["fused_min"][0] >= 6 and box_events > 0 and refine_events >= 14
-    assert exchanges > 100
+    is_ipc, ipc_batches, ipc_iterations, leaks, seq, hseq = got["ipc"]
+    if transport == "ipc":
+        assert is_ipc == 1 and leaks == 0 and ipc_batches > 10 and ipc_iterations > 100
+        assert seq >= 2 * ipc_iterations and hseq >= ipc_iterations
+    else:
+        assert is_ipc == 0 and ipc_batches == 0 and exchanges > 100
+    # the same subproblems on the single-GPU device loop
+    A1 = ips.dv.DeviceCSR.from_scipy(inst.A)
+    H1 = ips.dv.DeviceCSR.from_scipy(inst.H)
+    Z1, _, Y1 = ips.proj.projections(A1)
+    gnorm = ips.dv.norm(Z1.dot(inst.c))
+    for name, kw in inst.pcg_variants(gnorm).items():
+        x1, info1 = ips.qp.projected_cg(H1, inst.c, Z1, Y1, np.zeros(2000), **kw)
+        assert list(got["pcg_%s_info" % name]) == [info1["niter"], info1["stop_cond"],
+                                                    int(info1["hits_boundary"])]
+        close(got["pcg_%s_x" % name], host(x1), 1e-12)
 
 
 @pytest.mark.parametrize("n,m", [(400, 40), (6000, 600)])
@@ -510,55 +549,6 @@ def test_box_schur_solver(ips, n, m):
     x = rng.standard_normal(A.shape[1])
     z = host(Z.dot(x))
     assert np.max(np.abs(A.dot(z))) <= 1e-9 * np.max(np.abs(x))
-
-
-def test_hip_graph_replay_of_the_loop(ips):
-    """``ipx_cg_graph_create / _launch`` (two captured iterations replayed) against the same
-    iterations enqueued eagerly: bit-identical iterates and state."""
-    import ctypes
-    import torch
-    import ipsolver.cg_fused as cg_fused
-    from ipsolver import _hip
-    n, m = 20000, 2000
-    inst = BandedInstance(n, m)
-    dv = ips.dv
-    A = dv.DeviceCSR.from_scipy(inst.A)
-    H = dv.DeviceCSR.from_scipy(inst.H)
-    Z, LS, Y = ips.proj.projections(A)
-    P = Z.projector
-    lib = _hip.load()
-    c, b = dv.DVec.from_host(inst.c), dv.DVec.zeros(m)
-    x0 = Y.dot(-b)
-    r0 = Z.dot(H.dot(x0) + c)
-    g0 = Z.dot(r0)
-    rt_g = g0.sumsq_amax()[0]
-    side = torch.cuda.Stream()           # graphs cannot be captured on the legacy default stream
-    outs = []
-    with torch.cuda.stream(side):
-        st = dv.stream_ptr()
-        for use_graph in (False, True):
-            L = cg_fused._Loop(H, P, None, None)
-            L.x.copy_(x0.t)
-            L.r.copy_(r0.t)
-            _hip.call("ipx_axpby", n, -1.0, dv._p(g0.t), 0.0, None, dv._p(L.p), st)
-            init = np.zeros(L.state.numel())
-            init[cg_fused.ST_RTG0], init[cg_fused.ST_RADIUS] = rt_g, np.inf
-            init[cg_fused.ST_ORTH_RHS] = P.orth_tol * P.norm_A
-            L.state.copy_(torch.from_numpy(init))
-            _hip.check(lib.ipx_cg_hp(L.ref(), st), "ipx_cg_hp")
-            if use_graph:
-                g = lib.ipx_cg_graph_create(L.ref(), st)
-                assert g
-                _hip.check(lib.ipx_cg_graph_launch(ctypes.c_void_p(g), 6, st), "graph launch")
-                torch.cuda.synchronize()
-                lib.ipx_cg_graph_destroy(ctypes.c_void_p(g))
-            else:
-                _hip.check(lib.ipx_cg_iterate(L.ref(), 0, 12, st), "ipx_cg_iterate")
-            torch.cuda.synchronize()
-            outs.append((L.x.cpu().numpy().copy(), L.state.tolist()))
-    (xe, se), (xg, sg) = outs
-    assert se[cg_fused.ST_IT_DONE] == 12 and sg[cg_fused.ST_IT_DONE] == 12
-    assert np.array_equal(xe, xg) and se == sg
 
 
 def test_unbounded_trust_region_skips_the_norm(ips, monkeypatch):
@@ -1057,33 +1047,6 @@ def test_iterative_normal_solver_on_the_device(ips):
     A0[5, :] = 0
     with pytest.raises(np.linalg.LinAlgError):
         IterativeNormalSolver(ips.dv.DeviceCSR.from_scipy(sps.csr_matrix(A0)))
-
-
-def test_trust_region_norm_by_recurrence(ips, monkeypatch):
-    """IPX_RECUR=1: ||x + alpha p||^2 formed from sums the fused step2 + H.p kernel leaves
-    (step1 + A.r then does not read x and p).  Same iterates; exits on the trust region at the
-    same iteration and point as the default path (direct sum)."""
-    inst = BandedInstance(20000, 2000)
-    A = ips.dv.DeviceCSR.from_scipy(inst.A)
-    H = ips.dv.DeviceCSR.from_scipy(inst.H)
-    Z, LS, Y = ips.proj.projections(A)
-    b = np.zeros(2000)
-    x_free, _ = ips.qp.projected_cg(H, inst.c, Z, Y, b, tol=1e-12)
-    runs = {}
-    for flag in ("", "1"):
-        if flag:
-            monkeypatch.setenv("IPX_RECUR", "1")
-        else:
-            monkeypatch.delenv("IPX_RECUR", raising=False)
-        out = []
-        for kw in (dict(tol=0, max_iter=40), dict(trust_radius=0.5 * ips.dv.norm(x_free)),
-                   dict(tol=1e-12)):
-            x, info = ips.qp.projected_cg(H, inst.c, Z, Y, b, **kw)
-            out.append((host(x), info))
-        runs[flag] = out
-    for (x0, i0), (x1, i1) in zip(runs[""], runs["1"]):
-        assert i0 == i1
-        assert np.max(np.abs(x0 - x1)) <= 1e-13 * np.max(np.abs(x0))
 
 
 @pytest.mark.parametrize("kA", [4, 5, 6, 7, 8, 9])
