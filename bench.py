@@ -248,9 +248,10 @@ def single_gpu_measure(A_h, H_h, hdiag_h, c_h, n, m, K, W, repeats=20):
     }
 
 
-def _sharded_setup(A_h, H_h, hdiag_h, c_h):
+def _sharded_setup(A_h, H_h, hdiag_h, c_h, transports=(None,)):
     """Partition one subproblem over the ranks and prime the device-resident sharded loop
-    (tol = 0, infinite radius) exactly like projected_cg does."""
+    (tol = 0, infinite radius) exactly like projected_cg does; one loop object per requested
+    transport (None = the default: peer mailboxes when available)."""
     import numpy as np
     from ipsolver import sharded
     world, rank = sharded.ShardComm().world, sharded.ShardComm().rank
@@ -266,8 +267,8 @@ def _sharded_setup(A_h, H_h, hdiag_h, c_h):
     r0 = Z.dot(H.dot(x0) + c)
     g0 = Z.dot(r0)
     rt_g = g0.sumsq_amax()[0]
-    F = sharded.FusedShardedCG(H, Z.projector, None, None)
-    return sh, F, (x0, r0, g0, rt_g, 0.0, np.inf)
+    Fs = [sharded.FusedShardedCG(H, Z.projector, None, None, transport=t) for t in transports]
+    return sh, (Fs[0] if len(Fs) == 1 else Fs), (x0, r0, g0, rt_g, 0.0, np.inf)
 
 
 def _sharded_run(F, primed, K, W, dist, torch):
@@ -311,16 +312,28 @@ def _sharded_run(F, primed, K, W, dist, torch):
 def sharded_leg(args, world, rank, A_h, H_h, hdiag_h, c_h, n, m, K, W):
     """N > 1: the SAME n=1e6 / m=1e5 subproblem row-partitioned over the ranks (BASELINE
     config 4, strong scaling; ipsolver/sharded.py): both spaces partitioned, per iteration
-    two RCCL all-reduces (2 + 4 doubles) and one neighbour exchange of the halo of g."""
+    two all-reduces (2 + 4 doubles) and one neighbour exchange of the halo of g -- through the
+    peer mailboxes (hipIpc-mapped HBM written over xGMI inside the loop's own launches; one C
+    call per batch) when the ranks can map each other, through torch.distributed (RCCL)
+    otherwise.  `value` is the default transport's; both are measured and reported."""
     import numpy as np
     import torch
     import torch.distributed as dist
     from ipsolver import sharded
     from ipsolver.synthetic import CenteredBandedNLP
 
-    sh, F, primed = _sharded_setup(A_h, H_h, hdiag_h, c_h)
+    sh, (F, F_dist), primed = _sharded_setup(A_h, H_h, hdiag_h, c_h, transports=(None, "dist"))
+    transport = "ipc" if F.mailbox is not None else "dist"
+    before = dict(sh.comm.stats)
     elapsed, last_segment = _sharded_run(F, primed, K, W, dist, torch)
-    calls = dict(sh.comm.stats)
+    calls = {k: v - before[k] for k, v in sh.comm.stats.items()}
+    ab = {transport: {"iterations_per_s": K / elapsed, "ms_per_step": 1e3 * elapsed / K}}
+    if transport == "ipc":                      # A/B: the same loop through torch.distributed
+        try:
+            e2, _ = _sharded_run(F_dist, primed, K, W, dist, torch)
+            ab["dist"] = {"iterations_per_s": K / e2, "ms_per_step": 1e3 * e2 / K}
+        except Exception as exc:
+            ab["dist"] = {"error": repr(exc)}
 
     # ---- untimed: the sharded iterate against the single-GPU fused loop (rank 0)
     x_sharded = sharded.ShardVec(sharded.HipOps().dv.DVec(F.L.x), sh, "col").to_host()
@@ -357,6 +370,18 @@ def sharded_leg(args, world, rank, A_h, H_h, hdiag_h, c_h, n, m, K, W):
     lat_allreduce = floor(lambda: sh.comm.all_reduce(scratch))
     halo_buf = F.L.r.clone()
     lat_exchange = floor(lambda: sh.comm.exchange(halo_buf, clo, chi, sl, sr))
+    # the mailbox path's floor: 200 one-workgroup kernels back to back, each storing 4 doubles
+    # into every peer's mailbox and spinning until the peers' have arrived (launch + flag wait)
+    lat_mailbox = None
+    if F.mailbox is not None:
+        F.mailbox.allreduce([1.0, 2.0, 3.0, 4.0], reps=20)
+        dist.barrier()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        F.mailbox.allreduce([1.0, 2.0, 3.0, 4.0], reps=200)
+        ev1.record()
+        torch.cuda.synchronize()
+        lat_mailbox = 1e3 * ev0.elapsed_time(ev1) / 200
 
     # ---- a weak-scaling point in the same run: n = world * 1e6 (per-GPU work fixed)
     weak = None
@@ -370,6 +395,7 @@ def sharded_leg(args, world, rank, A_h, H_h, hdiag_h, c_h, n, m, K, W):
                                               probw.kappa * probw.Wt.dot(vw), probw.grad(xw))
             ew, _ = _sharded_run(Fw, primedw, K, W, dist, torch)
             weak = {"n": nw, "m": mw, "iterations_per_s": K / ew, "ms_per_step": 1e3 * ew / K,
+                    "transport": "ipc" if Fw.mailbox is not None else "dist",
                     "note": "per-GPU work = the 1-GPU benchmark's (n=1e6 per rank); compare "
                             "with the n_gpus=1 value for weak-scaling efficiency"}
             del shw, Fw, primedw, probw
@@ -413,8 +439,17 @@ def sharded_leg(args, world, rank, A_h, H_h, hdiag_h, c_h, n, m, K, W):
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "config4: the config-3 subproblem row-partitioned over %d GPUs: "
                                "constraint rows AND variables partitioned (nothing replicated), "
-                               "per iteration 2 RCCL all-reduces (2 and 4 doubles) + 1 "
-                               "neighbour exchange of the halo of g" % world,
+                               "per iteration 2 all-reduces (2 and 4 doubles) + 1 neighbour "
+                               "exchange of the halo of g; transport of the timed region: %s"
+                               % (world, "peer mailboxes (hipIpc-mapped HBM, writes over xGMI "
+                                         "inside the loop's launches, one C call per batch)"
+                                  if transport == "ipc" else
+                                  "torch.distributed (%s), three calls per iteration from the "
+                                  "host%s" % (dist.get_backend(),
+                                              "; mailboxes unavailable: %s"
+                                              % getattr(sh, "mailbox_error", None)
+                                              if os.environ.get("IPX_SHARD_TRANSPORT", "ipc") == "ipc"
+                                              else "")),
                    "n": n, "m": m, "nnz_A": int(nnzA), "nnz_H": int(nnzH),
                    "parallelism": "rows and variables sharded x%d, halo = 1 block of %d rows"
                                   % (world, sh.lay.row_block)},
@@ -425,16 +460,26 @@ def sharded_leg(args, world, rank, A_h, H_h, hdiag_h, c_h, n, m, K, W):
                      "frac": iter_bytes / (elapsed / K) / 1e9 / (HBM_PEAK_GBS * world),
                      "traffic": None},
         "parity_vs_single_gpu": parity,
-        "collectives_per_iteration": {
-            "all_reduce": per_it["all_reduce"], "all_reduce_bytes": per_it["all_reduce_bytes"],
-            "neighbour_exchange": per_it["exchange"],
-            "exchange_bytes_sent_by_rank0": per_it["exchange_bytes"],
+        "transport": transport,
+        "transport_ab": ab,
+        "host_calls_per_iteration_in_the_timed_region": {
+            "torch_distributed_all_reduce": per_it["all_reduce"],
+            "torch_distributed_exchange": per_it["exchange"],
+            "c_calls": (per_it["ipc_batches"] if transport == "ipc" else 2.0),
+            "note": "ipc: one ipx_cg_shard2_iterate per restart segment of <= 200 iterations; "
+                    "the reductions and the halo exchange happen inside its 5 launches per "
+                    "iteration"},
+        "exchanged_per_iteration": {
+            "all_reduce_doubles": [2, 4],
             "halo_columns_rank0": [int(lo), int(sh.lay.geom("col")[1] - hi)]},
-        "collective_latency_floor_us": {"all_reduce_4_doubles": lat_allreduce,
-                                        "halo_exchange": lat_exchange,
-                                        "method": "200 back-to-back calls through "
-                                                  "torch.distributed (%s), one stream "
-                                                  "synchronise" % dist.get_backend()},
+        "collective_latency_floor_us": {"mailbox_all_reduce_4_doubles_launch_plus_flag_wait":
+                                        lat_mailbox,
+                                        "torch_distributed_all_reduce_4_doubles": lat_allreduce,
+                                        "torch_distributed_halo_exchange": lat_exchange,
+                                        "method": "200 back-to-back operations (HIP events for the "
+                                                  "mailbox kernels; host clock + one stream "
+                                                  "synchronise for torch.distributed over %s)"
+                                                  % dist.get_backend()},
         "weak_scaling_point": weak,
         "wall_clock_to_gtol": full_solve,
     }

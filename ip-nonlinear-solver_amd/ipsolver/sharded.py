@@ -1067,7 +1067,9 @@ class FusedShardedCG:
     the argument block of the single-GPU loop (``cg_fused._Loop``), driven segment by
     segment between the two all-reduces and the halo exchange of an iteration."""
 
-    def __init__(self, H, P, lb, ub):
+    def __init__(self, H, P, lb, ub, transport=None):
+        """``transport``: None = the group's peer mailboxes when it has them ("ipc"), else
+        ``torch.distributed``; "dist" forces the latter (A/B measurements)."""
         from . import _hip, cg_fused
         from . import device as dv
         from .projector import NormalEquationProjector
@@ -1128,7 +1130,7 @@ class FusedShardedCG:
         for k, (_, off, ln, lo, hi, sl, sr, _, _) in enumerate(segs):
             e.seg_lo[k], e.seg_hi[k] = off, off + ln
             e.send_left[k], e.send_right[k] = sl, sr
-        self.mailbox = sh.mailbox()
+        self.mailbox = sh.mailbox() if transport != "dist" else None
         if self.mailbox is not None:
             # the pack kernels all-reduce the scalars and move the halo of g themselves
             e.peer = self.mailbox.handle
