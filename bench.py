@@ -4,9 +4,12 @@
 A "step" is ONE projected-CG iteration (reference qp_subproblem.py:549-634) on
 the synthetic sparse banded problem of BASELINE.json config 3 (SURVEY.md
 Appendix C: CSR Jacobian 1e5 x 1e6 with 15 nnz/row, tridiagonal-plus-diagonal
-Lagrangian Hessian), run with tol=0 and an infinite trust radius so exactly K
-iterations execute.  All inputs are resident in HBM when the timed region
-starts.
+Lagrangian Hessian), run with tol=0 and a finite trust radius that is never
+reached (how the SQP calls it: the norm test of qp_subproblem.py:583 is formed
+and taken every iteration), so exactly K iterations execute; the same loop
+with trust_radius=inf (the norm test cannot trigger and is not formed) is
+reported next to it as `unbounded_trust_region`.  All inputs are resident in
+HBM when the timed region starts.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--n 1000000] [--m 100000]
 
@@ -22,9 +25,12 @@ whole config-4 solve on the sharded backend.
 Prints ONE JSON line (see the driver contract in the task statement) with
 `roofline` for the dominant kernel (step2 fused into the H.p CSR SpMV),
 `roofline_out_of_cache` (the same measurement at n=4e6, past the Infinity
-Cache), `repeat` (median / min / max over further K-step regions) and
-`cpu_baseline` (the oracle = numpy/scipy restatement of the reference path,
-1 host thread).
+Cache), `repeat` (median / min / max over further K-step regions),
+`public_api` (the product function ``ipsolver.qp.projected_cg(tol=0,
+max_iter=K)`` timed as a user calls it), `config5` / `config2` (the other
+single-GPU BASELINE configs to gtol) and `cpu_baseline` (the oracle =
+numpy/scipy restatement of the reference path, the better of 1 / all host
+threads).
 """
 import argparse
 import ctypes
@@ -38,7 +44,38 @@ sys.path.insert(0, os.path.join(ROOT, "ip-nonlinear-solver_amd"))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PMC_PROFILE = "r02_pmc_traffic_n1e6.json"      # see roofline.traffic_source
+FP64_MFMA_PEAK_TFLOPS = 78.6   # AMD datasheet, dense fp64 matrix
+PMC_PROFILE = "r03_pmc_traffic_n1e6.json"      # see roofline.traffic_source
+PMC_PROFILE_BIG = "r03_pmc_traffic_n4e6.json"
+
+
+def kernel_source_hash():
+    """Hash of the sources of the loop's kernels: a stored PMC traffic figure is attached to
+    the bench line only when it was measured on kernels built from exactly these files."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("cg.hip", "banded.hip", "spmv.hip", "ipx_common.h"):
+        with open(os.path.join(ROOT, "ip-nonlinear-solver_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def stored_traffic(profile, kernel):
+    """(bytes per launch, provenance) from profiles/<profile>, or (None, reason)."""
+    path = os.path.join(ROOT, "profiles", profile)
+    if not os.path.exists(path):
+        return None, "no PMC profile for this build (profiles/%s missing)" % profile
+    with open(path) as f:
+        pmc = json.load(f)
+    have, want = pmc.get("kernel_source_hash"), kernel_source_hash()
+    if have != want:
+        return None, ("profiles/%s was measured on other kernel sources (hash %s, this build %s): "
+                      "not attached" % (profile, have, want))
+    val = pmc["kernels"].get(kernel, {}).get("hbm_bytes_per_launch")
+    return val, ("STORED, not measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                 "(separate passes, gfx950 FETCH correction calibrated in-run on kernels of known "
+                 "byte count) over scripts/pmc_workload.py, profiles/%s, same kernel sources "
+                 "(hash %s)" % (profile, want))
 
 
 def spmv_bytes(nnz, rows, cols, extra_row_vectors=0):
@@ -50,7 +87,9 @@ def single_gpu_measure(A_h, H_h, hdiag_h, c_h, n, m, K, W, repeats=20):
     """Upload one subproblem, factor, prime the device loop like projected_cg does, then
     W warm-up + EXACTLY K timed iterations (the contract's region), `repeats` further K-step
     regions (median / min / max), HIP-event attribution per kernel, and the dominant kernel
-    on its own."""
+    on its own.  The timed workload has a FINITE trust radius that is never reached (1e300):
+    ||x + alpha p||^2 is formed and tested every iteration, as in every call the SQP makes;
+    the trust_radius=inf variant (test not formed) is measured after it."""
     import numpy as np
     import torch
     from ipsolver import _hip, cg_fused, projector
@@ -74,18 +113,18 @@ def single_gpu_measure(A_h, H_h, hdiag_h, c_h, n, m, K, W, repeats=20):
     g0 = Z.dot(r0)
     rt_g = g0.sumsq_amax()[0]
     L = cg_fused._Loop(H, P, None, None)
-    # what cg_fused.projected_cg does for trust_radius=inf without a box (the workload of this
-    # bench line): norm(x_next) >= inf cannot be True, the norm is not formed.  The same loop
-    # with a finite (never reached) radius is measured below as `finite_trust_radius`.
-    no_radius = 0 if os.environ.get("IPX_KEEP_XN2") else 1
-    L.args.no_radius = no_radius
     st = dv.stream_ptr()
-    init = np.zeros(L.state.numel())
-    init[cg_fused.ST_RTG0] = rt_g
-    init[cg_fused.ST_TOL] = 0.0
-    init[cg_fused.ST_RADIUS] = np.inf
-    init[cg_fused.ST_ORTH_RHS] = P.orth_tol * P.norm_A
-    init_dev = torch.from_numpy(init).to(L.state.device)
+
+    def state_for(radius):
+        init = np.zeros(L.state.numel())
+        init[cg_fused.ST_RTG0] = rt_g
+        init[cg_fused.ST_TOL] = 0.0
+        init[cg_fused.ST_RADIUS] = radius
+        init[cg_fused.ST_ORTH_RHS] = P.orth_tol * P.norm_A
+        return torch.from_numpy(init).to(L.state.device)
+    init_finite, init_inf = state_for(1e300), state_for(np.inf)
+    mode = {"init": init_finite}
+    L.args.no_radius = 0
 
     def prime():
         """x = x0, r = Z(H x0 + c), p = -g, state reset, Hp = H p: device copies and one
@@ -93,7 +132,7 @@ def single_gpu_measure(A_h, H_h, hdiag_h, c_h, n, m, K, W, repeats=20):
         L.x.copy_(x0.t)
         L.r.copy_(r0.t)
         _hip.call("ipx_axpby", n, -1.0, dv._p(g0.t), 0.0, None, dv._p(L.p), st)
-        L.state.copy_(init_dev)
+        L.state.copy_(mode["init"])
         _hip.check(lib.ipx_cg_hp(L.ref(), st), "ipx_cg_hp")
 
     # With tol = 0 the CG would run into an exactly zero residual after ~500 iterations
@@ -142,32 +181,8 @@ def single_gpu_measure(A_h, H_h, hdiag_h, c_h, n, m, K, W, repeats=20):
     repeat = {"regions": repeats, "steps_each": K,
               "iterations_per_s": {"median": rates[len(rates) // 2], "min": rates[0],
                                    "max": rates[-1]}} if rates else None
-    # ---- the same loop with a finite trust radius that is never reached (1e300): the
-    # ||x + alpha p||^2 sums are formed and tested every iteration (the SQP's usage)
-    finite = None
-    if repeats > 0:
-        L.args.no_radius = 0
-        init_inf = init_dev
-        init[cg_fused.ST_RADIUS] = 1e300
-        init_dev = torch.from_numpy(init).to(L.state.device)
-        fr = []
-        run(0, W, "finite-radius warmup")
-        done_f = W
-        for _ in range(min(5, repeats)):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            run(done_f, done_f + K, "finite-radius")
-            torch.cuda.synchronize()
-            fr.append(K / (time.perf_counter() - t0))
-            done_f += K
-        check_ran(done_f)
-        fr.sort()
-        finite = {"trust_radius": 1e300, "iterations_per_s": fr[len(fr) // 2],
-                  "regions": len(fr), "steps_each": K}
-        L.args.no_radius = no_radius
-        init_dev = init_inf
 
-    # ---- per-kernel attribution with HIP events on the launch stream
+    # ---- per-kernel attribution with HIP events on the launch stream (same workload)
     ms = (ctypes.c_float * 7)()
     kt = max(2, min(K, 100))
     prime()
@@ -179,6 +194,31 @@ def single_gpu_measure(A_h, H_h, hdiag_h, c_h, n, m, K, W, repeats=20):
              None if fused3 else "spmv_r_minus_Atv", None,
              None if fused2 else "step2", "step2_spmv_H_p" if fused2 else "spmv_H_p"]
     per_kernel_us = {k: 1e3 * ms[i] / kt for i, k in enumerate(names) if k}
+
+    # ---- the same loop with trust_radius = inf (the reference's default argument): the test
+    # norm(x_next) >= inf of qp_subproblem.py:583 cannot trigger, the norm is not formed and the
+    # fused step1 + A.r kernel reads neither x nor p
+    unbounded = None
+    if repeats > 0 and not os.environ.get("IPX_KEEP_XN2"):
+        L.args.no_radius = 1
+        mode["init"] = init_inf
+        fr = []
+        run(0, W, "unbounded warmup")
+        done_f = W
+        for _ in range(min(5, repeats)):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run(done_f, done_f + K, "unbounded")
+            torch.cuda.synchronize()
+            fr.append(K / (time.perf_counter() - t0))
+            done_f += K
+        check_ran(done_f)
+        fr.sort()
+        unbounded = {"trust_radius": "inf", "iterations_per_s": fr[len(fr) // 2],
+                     "regions": len(fr), "steps_each": K,
+                     "algorithmic_bytes_less_per_iteration": 2 * 8 * n if fused1 else 0}
+        L.args.no_radius = 0
+        mode["init"] = init_finite
 
     # ---- the dominant kernel on its own: back-to-back launches (same arguments as in the
     # loop) between two HIP events on the launch stream, in `repeats` groups of K.  This is
@@ -217,8 +257,6 @@ def single_gpu_measure(A_h, H_h, hdiag_h, c_h, n, m, K, W, repeats=20):
         algo["step2_spmv_H_p"] = algo.pop("spmv_H_p") + algo.pop("step2") - 8 * n
     if fused1:      # r_next is not read back by the SpMV
         algo["step1_spmv_A_r"] = algo.pop("spmv_A_r") + algo.pop("step1") - 8 * n
-        if no_radius:     # ||x + alpha p||^2 not formed: x, p not read
-            algo["step1_spmv_A_r"] -= 2 * 8 * n
     if fused3:      # v is not read back by the SpMV
         algo["banded_solve_residual_r_minus_Atv"] = algo.pop("spmv_r_minus_Atv") - 8 * m
     dom = "step2_spmv_H_p" if fused2 else "spmv_H_p"
@@ -229,7 +267,7 @@ def single_gpu_measure(A_h, H_h, hdiag_h, c_h, n, m, K, W, repeats=20):
     med_rate = repeat["iterations_per_s"]["median"] if repeat else K / elapsed
     return {
         "A": A, "H": H, "c": c, "b": b, "Z": Z, "Y": Y, "elapsed": elapsed, "repeat": repeat,
-        "finite": finite,
+        "unbounded": unbounded,
         "t_factor": t_factor, "nnzA": nnzA, "nnzH": nnzH, "dom": dom,
         "per_kernel_us": per_kernel_us,
         "roofline": {"bound": "hbm", "kernel": dom_label,
@@ -242,10 +280,147 @@ def single_gpu_measure(A_h, H_h, hdiag_h, c_h, n, m, K, W, repeats=20):
                      "method": "median of %d groups of %d back-to-back launches, each between "
                                "two HIP events on the launch stream" % (len(groups), K)},
         "whole_iteration": {"algorithmic_bytes": iter_bytes,
+                            "algorithmic_bytes_per_kernel": algo,
                             "achieved_GBs": iter_bytes * med_rate / 1e9,
                             "frac_of_hbm_peak": iter_bytes * med_rate / 1e9 / HBM_PEAK_GBS,
                             "at": "median of the repeated regions"},
     }
+
+
+def public_api_leg(H, c, Z, Y, b, K, reps=5):
+    """The product function as a user calls it:
+    ``ipsolver.qp.projected_cg(H, c, Z, Y, b, tol=0, max_iter=K)`` -- initial projections,
+    buffer set-up, the batched device loop with its state polls, the result -- wall clock
+    around the call, for trust_radius = inf and for a finite radius that is never reached."""
+    import numpy as np
+    import torch
+    from ipsolver import qp, cg_fused
+    out = {"call": "ipsolver.qp.projected_cg(H, c, Z, Y, b, trust_radius, tol=0, max_iter=%d)" % K}
+    for name, radius in (("trust_radius_finite", 1e300), ("trust_radius_inf", np.inf)):
+        qp.projected_cg(H, c, Z, Y, b, trust_radius=radius, tol=0, max_iter=K)      # warm
+        rates, batches = [], 0
+        for _ in range(reps):
+            b0 = cg_fused.STATS["batches"]
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            x, info = qp.projected_cg(H, c, Z, Y, b, trust_radius=radius, tol=0, max_iter=K)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            if info["niter"] != K:
+                raise SystemExit("public_api leg: %d iterations instead of %d" % (info["niter"], K))
+            rates.append(K / dt)
+            batches = cg_fused.STATS["batches"] - b0
+        rates.sort()
+        out[name] = {"iterations_per_s": rates[len(rates) // 2], "min": rates[0],
+                     "max": rates[-1], "calls": reps, "state_reads_per_call": batches}
+    return out
+
+
+def config5_leg(run_twice=True):
+    """BASELINE config 5 on one GPU: n=5e5 variables, box on every variable + 5e4 nonlinear
+    inequalities (N = 1.55e6 with slacks), tr_interior_point to gtol with device callbacks;
+    wall clock and the in-solve projected-CG rate (cg_niter / time inside projected_cg)."""
+    import warnings
+    import torch
+    import ipsolver
+    from ipsolver import backend_hip
+    from ipsolver.synthetic import CenteredBandedNLP, DeviceCallbacks
+    n, m = 500000, 50000
+    prob = CenteredBandedNLP(n, m, eps=1.0)
+    dc = DeviceCallbacks(prob)
+    cons = (dc.constraints(ipsolver, ("less", 0.0)), ipsolver.BoxConstraint(("interval", -0.8, 0.8)))
+    timer = {"t": 0.0, "calls": 0}
+    plain = backend_hip.projected_cg
+
+    def timed(*a, **k):
+        t0 = time.perf_counter()
+        out = plain(*a, **k)           # returns after a blocking read of the loop's state
+        timer["t"] += time.perf_counter() - t0
+        timer["calls"] += 1
+        return out
+    backend_hip.projected_cg = timed
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for attempt in range(2 if run_twice else 1):     # first call pays symbolic set-up
+                timer["t"], timer["calls"] = 0.0, 0
+                torch.cuda.synchronize()
+                t0 = time.time()
+                res = ipsolver.minimize_constrained(dc.fun, dc.x0, dc.grad, dc.hess, cons)
+                torch.cuda.synchronize()
+                wall = time.time() - t0
+    finally:
+        backend_hip.projected_cg = plain
+    x = res.x
+    return {"workload": "config5: n=5e5, box + 5e4 nonlinear inequalities, tr_interior_point, "
+                        "device callbacks, gtol=xtol=1e-8",
+            "seconds": wall, "status": int(res.status), "niter": int(res.niter),
+            "cg_niter": int(res.cg_niter), "optimality": float(res.optimality),
+            "constr_violation": float(res.constr_violation),
+            "projected_cg_calls": timer["calls"], "seconds_in_projected_cg": timer["t"],
+            "cg_iterations_per_s_in_solve": res.cg_niter / timer["t"] if timer["t"] else None,
+            "launches_per_cg_iteration": 5,
+            "launches_note": "k_cg_step1_box, SpMV A_R u, k_solve_pcr, k_pairs_post, "
+                             "k_cg_step2_hp by construction (csrc/cg.hip cg_iterate, box_project "
+                             "branch); rocprofv3 launch counts: profiles/r03_config5_kernel_stats.csv",
+            "active_bounds": int((x.abs() > 0.8 - 1e-6).sum().item())}
+
+
+def config2_leg():
+    """BASELINE config 2: dense random equality-constrained QP n=10000, m=2000,
+    equality_constrained_sqp, numpy callbacks (the drop-in usage); wall clock to gtol and the
+    fp64 MFMA Gram kernel G = A A' on its own against the matrix-core peak."""
+    import warnings
+    import numpy as np
+    import torch
+    import ipsolver
+    from ipsolver import _hip
+    from ipsolver import device as dv
+    from ipsolver.dense import DeviceDense
+    n, m = 10000, 2000
+    rng = np.random.default_rng(0)                 # the generator's order (SURVEY.md 8(d))
+    A = rng.standard_normal((m, n))
+    G = rng.standard_normal((n, n)) / np.sqrt(n)
+    Hd = G.dot(G.T) + np.eye(n)
+    c = rng.standard_normal(n)
+    bq = A.dot(rng.standard_normal(n))
+    del G
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for attempt in range(2):
+            torch.cuda.synchronize()
+            t0 = time.time()
+            res = ipsolver.minimize_constrained(
+                lambda x: 0.5 * x.dot(Hd.dot(x)) + c.dot(x), np.zeros(n), lambda x: Hd.dot(x) + c,
+                lambda x: Hd, ipsolver.LinearConstraint(A, ("equals", bq)),
+                method="equality_constrained_sqp")
+            torch.cuda.synchronize()
+            wall = time.time() - t0
+    # the Gram kernel alone
+    Ad = DeviceDense.from_host(A)
+    M = _hip.load().ipx_dense_padded(m)
+    Gd = torch.zeros(M * M, dtype=torch.float64, device=Ad.t.device)
+    st = dv.stream_ptr()
+    gram = lambda: _hip.call("ipx_gram_f64_mfma", m, n, dv._p(Ad.t), n, dv._p(Gd), st)
+    for _ in range(3):
+        gram()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(10):
+        gram()
+    ev1.record()
+    torch.cuda.synchronize()
+    ms = ev0.elapsed_time(ev1) / 10
+    tf = 2.0 * m * m * n / (ms * 1e-3) / 1e12
+    return {"workload": "config2: dense equality QP n=10000, m=2000, equality_constrained_sqp, "
+                        "numpy callbacks, gtol=xtol=1e-8",
+            "seconds": wall, "status": int(res.status), "niter": int(res.niter),
+            "cg_niter": int(res.cg_niter), "optimality": float(res.optimality),
+            "constr_violation": float(res.constr_violation),
+            "reference_trace": "status 1, 15 outer / 28 CG (tests/golden/config2.json)",
+            "gram_mfma": {"kernel": "k_gram_mfma (v_mfma_f64_16x16x4_f64)", "ms": ms,
+                          "flop": 2.0 * m * m * n, "achieved": tf, "peak": FP64_MFMA_PEAK_TFLOPS,
+                          "unit": "TFLOP/s", "frac": tf / FP64_MFMA_PEAK_TFLOPS, "bound": "mfma"}}
 
 
 def _sharded_setup(A_h, H_h, hdiag_h, c_h, transports=(None,)):
@@ -496,7 +671,9 @@ def main():
     ap.add_argument("--n", type=int, default=1000000)
     ap.add_argument("--m", type=int, default=100000)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--cpu-iters", type=int, default=400)
+    ap.add_argument("--cpu-iters", type=int, default=250)
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the config-5 and config-2 full solves")
     ap.add_argument("--repeats", type=int, default=20,
                     help="further K-step regions after the contract's one (median/min/max)")
     ap.add_argument("--no-weak", action="store_true",
@@ -566,15 +743,8 @@ def main():
     A, H, c, b, Z, Y = (r1.pop(k) for k in ("A", "H", "c", "b", "Z", "Y"))
     elapsed = r1["elapsed"]
     traffic, traffic_src = None, None
-    pmc_path = os.path.join(ROOT, "profiles", PMC_PROFILE)
-    if os.path.exists(pmc_path) and (n, m) == (1000000, 100000):
-        with open(pmc_path) as f:
-            pmc = json.load(f)
-        traffic = pmc["kernels"].get(r1["dom"], {}).get("hbm_bytes_per_launch")
-        traffic_src = ("STORED, not measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
-                       "(separate passes, FETCH x2 gfx950 correction calibrated in-run on kernels "
-                       "of known byte count) of this same command, profiles/%s, kernels at "
-                       "commit %s" % (PMC_PROFILE, pmc.get("source_commit", "?")))
+    if (n, m) == (1000000, 100000):
+        traffic, traffic_src = stored_traffic(PMC_PROFILE, r1["dom"])
     result = {
         "metric": "projected-CG iters/sec (fp64) at n=1e6,m=1e5",
         "value": K / elapsed,
@@ -589,17 +759,22 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": "config3: sparse banded NLP subproblem, CSR Jacobian "
-                               "bandwidth 15, tol=0, trust_radius=inf (the norm test that cannot "
-                               "trigger is skipped; see finite_trust_radius)",
+                               "bandwidth 15, tol=0, finite trust radius that is never reached "
+                               "(the norm test of qp_subproblem.py:583 formed every iteration, "
+                               "as in the SQP's calls; trust_radius=inf: see "
+                               "unbounded_trust_region)",
                    "n": n, "m": m, "nnz_A": r1["nnzA"], "nnz_H": r1["nnzH"],
                    "parallelism": "single GPU"},
         "repeat": r1["repeat"],
-        "finite_trust_radius": r1["finite"],
+        "unbounded_trust_region": r1["unbounded"],
         "roofline": dict(r1["roofline"], traffic=traffic, traffic_source=traffic_src),
         "per_kernel_us": r1["per_kernel_us"],
         "whole_iteration": r1["whole_iteration"],
+        "kernel_source_hash": kernel_source_hash(),
         "setup_s": {"generate_host": t_gen, "factor_device": r1["t_factor"]},
     }
+    # ---- the product function as a user calls it
+    result["public_api"] = public_api_leg(H, c, Z, Y, b, K)
 
     # ---- the same measurement past the 256 MiB Infinity Cache (working set ~480 MB): the
     # n=1e6 working set (~120 MB) is cache resident, so its "HBM" fraction is partly an
@@ -611,20 +786,12 @@ def main():
         vb = 0.1 * np.random.default_rng(7).standard_normal(mb)
         rb = single_gpu_measure(probb.constr_jac(xb), probb.hess(xb), probb.kappa * probb.Wt.dot(vb),
                                 probb.grad(xb), nb, mb, K, W, repeats=args.repeats)
-        traffic_b, src_b = None, None
-        pmc_b = os.path.join(ROOT, "profiles", "r02_pmc_traffic_n4e6.json")
-        if os.path.exists(pmc_b):
-            with open(pmc_b) as f:
-                pj = json.load(f)
-            traffic_b = pj["kernels"].get(rb["dom"], {}).get("hbm_bytes_per_launch")
-            src_b = ("STORED, not measured in this run: profiles/r02_pmc_traffic_n4e6.json "
-                     "(rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes), kernels at "
-                     "commit %s" % pj.get("source_commit", "?"))
+        traffic_b, src_b = stored_traffic(PMC_PROFILE_BIG, rb["dom"])
         result["roofline_out_of_cache"] = dict(
             rb["roofline"], traffic=traffic_b, traffic_source=src_b, n=nb, m=mb,
             iterations_per_s=K / rb["elapsed"], ms_per_step=1e3 * rb["elapsed"] / K,
-            repeat=rb["repeat"], per_kernel_us=rb["per_kernel_us"],
-            whole_iteration=rb["whole_iteration"])
+            repeat=rb["repeat"], unbounded_trust_region=rb["unbounded"],
+            per_kernel_us=rb["per_kernel_us"], whole_iteration=rb["whole_iteration"])
         del rb, probb
         torch.cuda.empty_cache()
 
@@ -655,25 +822,44 @@ def main():
             "note": "config 3 (eps=1e-3), gtol=xtol=1e-8; the reference reaches status 1 in 25 "
                     "outer / 34 CG iterations (SURVEY.md Appendix B: 103 s on the survey host)"}
 
-    # ---- CPU baseline: the oracle (numpy/scipy restatement), rank 0, N=1 only
+    # ---- the other single-GPU BASELINE configs to gtol (full sizes)
+    if (n, m) == (1000000, 100000) and not args.no_configs:
+        for key, leg in (("config5", config5_leg), ("config2", config2_leg)):
+            try:
+                torch.cuda.empty_cache()
+                result[key] = leg()
+            except Exception as exc:             # never lose the headline over a side leg
+                result[key] = {"error": repr(exc)}
+
+    # ---- CPU baseline: the oracle (numpy/scipy restatement), rank 0, N=1 only: the better of
+    # one thread and all host cores (the path is SuperLU substitutions + short
+    # BLAS-1 calls, effectively single-threaded)
     if rank == 0 and world == 1 and not args.no_cpu:
         import oracle
-        from threadpoolctl import threadpool_limits
-        torch.set_num_threads(1)
-        with threadpool_limits(limits=1):               # "cores": 1 below is what actually ran
-            t0 = time.time()
-            Zo, _, Yo = oracle.projections(A_h)        # AugmentedSystem (SuperLU), as the reference
-            t_fac = time.time() - t0
-            H_full = H_h + __import__("scipy.sparse", fromlist=["diags"]).diags(hdiag_h)
-            kc = args.cpu_iters
-            t0 = time.time()
-            xo, info = oracle.projected_cg(H_full, c_h, Zo, Yo, np.zeros(m), tol=0, max_iter=kc)
-            t_cg = time.time() - t0
+        from threadpoolctl import threadpool_limits, threadpool_info
+        ncores = os.cpu_count() or 1
+        blas = sorted({"%s %s" % (d.get("internal_api"), d.get("version")) for d in threadpool_info()
+                       if d.get("user_api") == "blas"})
+        t0 = time.time()
+        Zo, _, Yo = oracle.projections(A_h)        # AugmentedSystem (SuperLU), as the reference
+        t_fac = time.time() - t0
+        H_full = H_h + __import__("scipy.sparse", fromlist=["diags"]).diags(hdiag_h)
+        kc = args.cpu_iters
+        runs = {}
+        for threads in sorted({1, ncores}):
+            torch.set_num_threads(threads)
+            with threadpool_limits(limits=threads):
+                t0 = time.time()
+                xo, info = oracle.projected_cg(H_full, c_h, Zo, Yo, np.zeros(m), tol=0, max_iter=kc)
+                runs[threads] = info["niter"] / (time.time() - t0)
+        best = max(runs, key=runs.get)
         result["cpu_baseline"] = {
-            "value": info["niter"] / t_cg, "unit": "iterations/s", "cores": 1, "kind": "port",
+            "value": runs[best], "unit": "iterations/s", "cores": best, "kind": "port",
+            "host_cpu_count": ncores, "blas": blas,
+            "iterations_per_s_by_threads": {str(k): v for k, v in runs.items()},
             "sample": "%d projected-CG iterations of the same n=%d, m=%d instance through "
-                      "oracle/ (scipy SuperLU augmented-system projections, numpy vectors); "
-                      "factorization %.1f s not included" % (info["niter"], n, m, t_fac)}
+                      "oracle/ (scipy SuperLU augmented-system projections, numpy vectors) per "
+                      "thread count; factorization %.1f s not included" % (kc, n, m, t_fac)}
         # parity of the GPU iterates with the CPU oracle after the same number of iterations
         xg, ginfo = cg_fused.projected_cg(H, c, Z, Y, b, tol=0, max_iter=kc)
         err = np.max(np.abs(xg.to_host() - xo)) / np.max(np.abs(xo))

@@ -24,6 +24,13 @@ Outputs (numbers only -- no reference source travels):
   e2e_ineq_n12000.json  (``--ineq12000``: 4 minutes) box + inequality NLP at n=12000 / m=1200
   config2.json      (``--big`` only: minutes) dense equality QP of BASELINE config 2 at
                     n=4000/m=800 and n=10000/m=2000: scalar traces + strided x
+  late_barrier_n400.npz, late_barrier_n12000.npz  (``--late-barrier``: 5 minutes) single
+                    ``projected_cg`` calls of the reference's config-5 style runs, spread
+                    over the run up to the last one (barrier parameter <= 1e-6, slacks of
+                    active bounds ~1e-8): the inputs the reference passed (as the data the
+                    subproblem is assembled from: x, s, the multipliers of the nonlinear
+                    rows, the slack block of the Hessian, c_t, lb_t, the radius) and what it
+                    returned (x, niter, stop_cond, hits_boundary, the first 20 iterates)
 """
 import json
 import os
@@ -345,7 +352,85 @@ def e2e():
     return out
 
 
+def late_barrier(n, m, ncalls):
+    """Single projected_cg calls out of the reference's barrier run on the config-5 style
+    problem (tr_interior_point.py:222-241 assembles H, :141-194 the augmented Jacobian;
+    equality_constrained_sqp.py:125-132 the call).  The hooks only record."""
+    # (the package re-exports functions under the modules' names: go through sys.modules)
+    rsqp = sys.modules["ipsolver._large_scale_constrained.equality_constrained_sqp"]
+    rtip = sys.modules["ipsolver._large_scale_constrained.tr_interior_point"]
+    prob = synthetic.CenteredBandedNLP(n, m, eps=1.0)
+    cons = (prob.constraints(ref, ("less", 0.0)), ref.BoxConstraint(("interval", -0.8, 0.8)))
+    N, n_ineq = n + m + 2 * n, m + 2 * n
+    stride = max(1, N // 400)
+    last, calls = {}, []
+    orig_pcg, orig_proj = rsqp.projected_cg, rsqp.projections
+    orig_lh = rtip.BarrierSubproblem.lagrangian_hessian
+
+    def proj(A, *a, **k):
+        last["A"] = A
+        return orig_proj(A, *a, **k)
+
+    def lh(self, z, v):
+        last["z"], last["v"] = np.array(z), np.array(v)
+        last["Hs"] = np.array(self.lagrangian_hessian_s(z, v))
+        last["mu"] = float(self.barrier_parameter)
+        return orig_lh(self, z, v)
+
+    def pcg(H, c, Z, Y, b, trust_radius, lb, ub, **kw):
+        x, info = orig_pcg(H, c, Z, Y, b, trust_radius, lb, ub, return_all=True, **kw)
+        z, v = last["z"], last["v"]
+        xv, s = z[:n], z[n:]
+        v_nl = v[:m]                              # ('less', 0): sign +1, nonlinear rows first
+        # the subproblem re-assembled from the recorded data must BE the reference's
+        J = prob.constr_jac(xv)
+        eye = sps.identity(n, format="csr")
+        A_re = sps.bmat([[sps.vstack([J, -eye, eye]), sps.diags(s)]], format="csr")
+        dA = abs(A_re - sps.csr_matrix(last["A"]))
+        assert dA.nnz == 0 or dA.max() == 0.0, dA.max()
+        Hx, hd = prob.hess(xv), prob.kappa * prob.Wt.dot(v_nl)
+        p = np.random.default_rng(len(calls)).standard_normal(N)
+        mine = np.hstack((Hx.dot(p[:n]) + hd * p[:n], last["Hs"] * p[n:]))
+        assert np.array_equal(mine, H.dot(p)), np.max(np.abs(mine - H.dot(p)))
+        assert np.all(np.isinf(ub)) and np.all(b == 0)
+        allv = info["allvecs"]
+        calls.append(dict(
+            x_vars=xv.copy(), s=s.copy(), v_nl=v_nl.copy(), Hs=last["Hs"].copy(),
+            c=np.array(c), lb=np.array(lb), radius=float(trust_radius), mu=last["mu"],
+            x=np.array(x), info=np.array([info["niter"], info["stop_cond"],
+                                          int(info["hits_boundary"])]),
+            allvecs=np.array([a[::stride] for a in allv[:20]])))
+        return x, info
+
+    rsqp.projected_cg, rsqp.projections = pcg, proj
+    rtip.BarrierSubproblem.lagrangian_hessian = lh
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            res = ref.minimize_constrained(prob.fun, prob.x0, prob.grad, prob.hess, cons)
+    finally:
+        rsqp.projected_cg, rsqp.projections = orig_pcg, orig_proj
+        rtip.BarrierSubproblem.lagrangian_hessian = orig_lh
+    total = len(calls)
+    picks = sorted(set(int(round(t)) for t in np.linspace(0, total - 1, ncalls)))
+    out = {"n": np.array([n, m]), "stride": np.array([stride]), "picks": np.array(picks),
+           "total_calls": np.array([total]), "status": np.array([res.status, res.niter,
+                                                                 res.cg_niter])}
+    for j, k in enumerate(picks):
+        for key, val in calls[k].items():
+            out["c%d_%s" % (j, key)] = np.asarray(val)
+    print("  late_barrier n=%d: %d projected_cg calls, picked %s, niter %s, mu %s"
+          % (n, total, picks, [int(calls[k]["info"][0]) for k in picks],
+             [calls[k]["mu"] for k in picks]))
+    return out
+
+
 def main():
+    if "--late-barrier" in sys.argv:
+        for n, m, k in ((400, 40, 6), (12000, 1200, 4)):
+            np.savez_compressed(os.path.join(HERE, "late_barrier_n%d.npz" % n),
+                                **late_barrier(n, m, k))
+        return
     if "--n20000" in sys.argv:
         # banded equality NLP at a size the row-sharded solver can split (8 blocks of 260 rows)
         out = {}
