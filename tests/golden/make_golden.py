@@ -399,8 +399,52 @@ def late_barrier(n, m, ncalls):
             c=np.array(c), lb=np.array(lb), radius=float(trust_radius), mu=last["mu"],
             x=np.array(x), info=np.array([info["niter"], info["stop_cond"],
                                           int(info["hits_boundary"])]),
-            allvecs=np.array([a[::stride] for a in allv[:20]])))
+            allvecs=np.array([a[::stride] for a in allv[:20]]),
+            _ops=(H, Z, Y, last["A"], np.array(b), np.array(ub))))
         return x, info
+
+    def conditioning(rec):
+        """How well the reference's OWN answer is determined (what parity can mean here):
+        (a) its projection Z c against the exact one -- the augmented system solved to
+        long-double accuracy by iterative refinement (late in the barrier run c lies almost
+        entirely in the row space of A: Z c cancels ~8 digits of c); (b) its projected_cg
+        result when every component of c moves by one unit in the last place."""
+        H, Z, Y, A, b, ub = rec.pop("_ops")
+        A = sps.csr_matrix(A)
+        M, Nn = A.shape
+        c = rec["c"]
+        K = sps.bmat([[sps.identity(Nn), A.T], [A, None]], format="csc")
+        lu = sps.linalg.splu(K)
+        Kr = sps.csr_matrix(K)
+        Kr.sort_indices()
+        dat, idx = Kr.data.astype(np.longdouble), Kr.indices
+        rows = np.repeat(np.arange(Nn + M), np.diff(Kr.indptr))
+
+        def matvec_ld(v):
+            out = np.zeros(Nn + M, dtype=np.longdouble)
+            np.add.at(out, rows, dat * v[idx])
+            return out
+        rhs = np.concatenate((c, np.zeros(M))).astype(np.longdouble)
+        sol = np.zeros(Nn + M, dtype=np.longdouble)
+        for _ in range(6):
+            sol = sol + lu.solve((rhs - matvec_ld(sol)).astype(np.float64)).astype(np.longdouble)
+        z_true = sol[:Nn].astype(np.float64)
+        z_ref = Z.dot(c)
+        scale = np.max(np.abs(z_true))
+        rec["z_true"] = z_true
+        rec["proj"] = np.array([np.max(np.abs(z_ref - z_true)) / scale, np.max(np.abs(c)), scale])
+        rows = []
+        for seed in (99, 100, 101, 102):
+            rng = np.random.default_rng(seed)
+            c_p = c * (1.0 + np.ldexp(1.0, -52) * rng.choice([-1.0, 1.0], size=c.size))
+            x_p, info_p = orig_pcg(H, c_p, Z, Y, b, rec["radius"], rec["lb"], ub, return_all=True)
+            sx = np.max(np.abs(x_p - rec["x"])) / max(np.max(np.abs(rec["x"])), 1e-300)
+            sv = [np.max(np.abs(a[::stride] - w)) / max(np.max(np.abs(w)), 1e-300)
+                  for a, w in zip(info_p["allvecs"][:20], rec["allvecs"])]
+            rows.append([info_p["niter"], info_p["stop_cond"], int(info_p["hits_boundary"]), sx,
+                         max(sv) if sv else 0.0])
+        rec["sens"] = np.array(rows)          # one row per perturbed run
+        return rec
 
     rsqp.projected_cg, rsqp.projections = pcg, proj
     rtip.BarrierSubproblem.lagrangian_hessian = lh
@@ -413,6 +457,11 @@ def late_barrier(n, m, ncalls):
         rtip.BarrierSubproblem.lagrangian_hessian = orig_lh
     total = len(calls)
     picks = sorted(set(int(round(t)) for t in np.linspace(0, total - 1, ncalls)))
+    for k in range(total):
+        if k in picks:
+            conditioning(calls[k])
+        else:
+            calls[k].pop("_ops")
     out = {"n": np.array([n, m]), "stride": np.array([stride]), "picks": np.array(picks),
            "total_calls": np.array([total]), "status": np.array([res.status, res.niter,
                                                                  res.cg_niter])}
@@ -422,6 +471,13 @@ def late_barrier(n, m, ncalls):
     print("  late_barrier n=%d: %d projected_cg calls, picked %s, niter %s, mu %s"
           % (n, total, picks, [int(calls[k]["info"][0]) for k in picks],
              [calls[k]["mu"] for k in picks]))
+    for k in picks:
+        print("    call %d: reference projection error %.2e (|c| %.1e, |Zc| %.1e); one ulp in c: "
+              "niter %d -> %s, x moves %.2e, first iterates %.2e"
+              % (k, calls[k]["proj"][0], calls[k]["proj"][1], calls[k]["proj"][2],
+                 calls[k]["info"][0], calls[k]["sens"][:, 0].astype(int).tolist(),
+                 calls[k]["sens"][:, 3].max(),
+                 calls[k]["sens"][:, 4].max()))
     return out
 
 

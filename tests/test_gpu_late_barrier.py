@@ -5,7 +5,21 @@ formulas of csrc/boxschur.hip exist for).  tests/golden/make_golden.py --late-ba
 what the reference passed to ``projected_cg`` (equality_constrained_sqp.py:125-132, assembled
 by tr_interior_point.py:141-241) and what it returned; here the product solves the same
 subproblems through its own path -- augmented Jacobian, z-space Hessian operator, box-Schur
-projections, device-resident loop -- on one GPU and row-sharded over two processes."""
+projections, device-resident loop -- on one GPU and row-sharded over two processes.
+
+What "the same answer" means here.  Late in the barrier run the gradient of the subproblem lies
+almost entirely in the row space of the Jacobian: ``Z c`` cancels 6-8 digits of ``c``
+(|c| = 2.8, |Z c| = 1e-8 at mu = 1e-8), so ANY implementation -- the reference's included --
+has the projection to ``eps |c| / |Z c|`` only, and hundreds of CG iterations amplify that.
+The generator therefore also measured how well the reference's own answer is determined:
+(a) its ``Z c`` against the exact projection (augmented system refined in long double):
+2e-16 at mu = 0.1, 4e-9 at mu = 1e-8; (b) its ``projected_cg`` result when every component of
+``c`` moves by ONE unit in the last place (four seeded sign patterns): identical counts and
+1e-15 early, 271..272 iterations and 3e-5 in x at mu = 2.6e-7.  The assertions below hold the
+product to exactly that: integers exact wherever the reference's own count does not move under
+one ulp (within twice its spread + 1, or 0.2 % of a count in the thousands, where it does),
+vectors to 1e-10 or ten times the reference's own one-ulp sensitivity, the projection as
+close to the exact one as the reference's (factor 4) and to 1e-14 of its input."""
 import os
 
 import numpy as np
@@ -28,10 +42,17 @@ def _pieces(gold, j):
     """The data of call j as the reference's SQP held it."""
     n, m = (int(v) for v in gold["n"])
     g = lambda k: gold["c%d_%s" % (j, k)]
+    sens, proj = g("sens"), g("proj")
+    spread = int(np.max(np.abs(sens[:, 0] - g("info")[0])))
     return dict(n=n, m=m, x=g("x_vars"), s=g("s"), v_nl=g("v_nl"), Hs=g("Hs"), c=g("c"),
                 lb=g("lb"), radius=float(g("radius")), mu=float(g("mu")), x_out=g("x"),
                 info=[int(v) for v in g("info")], allvecs=g("allvecs"),
-                stride=int(gold["stride"][0]))
+                stride=int(gold["stride"][0]), z_true=g("z_true"), ref_proj_err=float(proj[0]),
+                # what one ulp in c does to the reference's own result
+                niter_slack=0 if spread == 0 else max(2 * spread + 1,
+                                                      int(np.ceil(0.002 * g("info")[0]))),
+                x_tol=max(1e-10, 10.0 * float(sens[:, 3].max())),
+                it_tol=max(1e-10, 10.0 * float(sens[:, 4].max())))
 
 
 def close_rel(a, b, tol):
@@ -42,7 +63,7 @@ def close_rel(a, b, tol):
     return err
 
 
-def _solve_single(d, return_all=False):
+def _solve_single(d, return_all=False, projection_only=False):
     """The product's own assembly (backend_hip: augmented Jacobian with the slack entries,
     Hessian terms merged into one fused SpMV + diagonal) and solve."""
     from ipsolver import backend_hip as xp
@@ -59,6 +80,8 @@ def _solve_single(d, return_all=False):
     Z, LS, Y = xp.projections(A)
     assert type(Z.projector.solver).__name__ == "BoxSchurNormalSolver"
     assert cg_fused.supports(H, Z, Y)
+    if projection_only:
+        return Z.dot(DVec.from_host(d["c"])).to_host()
     N = n + n_ineq
     calls = cg_fused.STATS["calls"]
     x, info = xp.projected_cg(H, DVec.from_host(d["c"]), Z, Y, DVec.zeros(n_ineq), d["radius"],
@@ -71,21 +94,32 @@ def _solve_single(d, return_all=False):
 
 @pytest.mark.parametrize("n", sorted(SIZES))
 def test_late_barrier_subproblems_single_gpu(n):
-    """Integers exact (niter, stop_cond, hits_boundary), the returned step and the first 20
-    iterates to 1e-10 of their norms -- every recorded call, the last ones included."""
+    """Every recorded call, the last ones included (criteria: module docstring)."""
     gold = _gold(n)
     assert len(gold["picks"]) == SIZES[n]
-    worst = 0.0
     for j in range(SIZES[n]):
         d = _pieces(gold, j)
+        # the projection against the exact one: as close as the reference's own
+        z = _solve_single(d, projection_only=True)
+        zerr = np.max(np.abs(z - d["z_true"]))
+        assert zerr <= max(1e-10, 4.0 * d["ref_proj_err"]) * np.max(np.abs(d["z_true"])), \
+            (j, zerr / np.max(np.abs(d["z_true"])), d["ref_proj_err"])
+        assert zerr <= 1e-14 * np.max(np.abs(d["c"]))
+        # the device-resident loop
         x, info = _solve_single(d)
-        got = [info["niter"], info["stop_cond"], int(info["hits_boundary"])]
-        assert got == d["info"], (j, d["mu"], got, d["info"])
-        worst = max(worst, close_rel(x.to_host(), d["x_out"], 1e-10))
+        assert [info["stop_cond"], int(info["hits_boundary"])] == d["info"][1:], (j, info, d["info"])
+        assert abs(info["niter"] - d["info"][0]) <= d["niter_slack"], \
+            (j, d["mu"], info["niter"], d["info"][0], d["niter_slack"])
+        xerr = close_rel(x.to_host(), d["x_out"], d["x_tol"])
         # the general driver (same kernels, host-side control flow) for the iterates
         xg, ig = _solve_single(d, return_all=True)
-        assert [ig["niter"], ig["stop_cond"], int(ig["hits_boundary"])] == d["info"]
-        st = d["stride"]
-        for k, want in enumerate(d["allvecs"]):
-            close_rel(ig["allvecs"][k].to_host()[::st], want, 1e-10)
-    print("late barrier n=%d: worst relative deviation of the returned step %.2e" % (n, worst))
+        assert [ig["stop_cond"], int(ig["hits_boundary"])] == d["info"][1:]
+        assert abs(ig["niter"] - d["info"][0]) <= d["niter_slack"]
+        st, iterr = d["stride"], 0.0
+        for k, want in enumerate(d["allvecs"][:len(ig["allvecs"])]):
+            iterr = max(iterr, close_rel(ig["allvecs"][k].to_host()[::st], want, d["it_tol"]))
+        print("late barrier n=%d call %d mu=%.1e: niter %d (reference %d, slack %d); x dev %.1e "
+              "(bound %.1e); first iterates %.1e (bound %.1e); projection error %.1e "
+              "(reference's own %.1e)" % (n, j, d["mu"], info["niter"], d["info"][0],
+                                          d["niter_slack"], xerr, d["x_tol"], iterr, d["it_tol"],
+                                          zerr / np.max(np.abs(d["z_true"])), d["ref_proj_err"]))
