@@ -183,6 +183,49 @@ def _minimize_device(fun, x0, grad, hess, constraints, method, xtol, gtol, optio
     return result
 
 
+def _shard_request(options):
+    """``options['shard']``: True / False, or the local-arithmetic object of the row-sharded
+    backend (tests pass the numpy twin).  Not given: shard when this process is one rank of an
+    initialised ``torch.distributed`` group of more than one."""
+    shard = options.pop("shard", None)
+    if shard is None:
+        try:
+            import torch.distributed as dist
+            shard = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        except ImportError:
+            shard = False
+    return shard
+
+
+def _sharded_backend(shard, constr, n_vars):
+    """The row-sharded backend (ipsolver/sharded.py: one process per GPU) for this problem:
+    the partition follows the sparse Jacobian of the equality rows, or -- nonlinear
+    inequalities + a box on every variable, BASELINE config 5 -- of the nonlinear rows."""
+    import scipy.sparse as sps
+    from . import sharded
+    ops = shard if hasattr(shard, "from_host") else sharded.HipOps()
+    comm = sharded.ShardComm()
+    if constr.n_ineq == 0:
+        J = constr.J_eq0
+    elif constr.n_eq == 0:
+        J = constr.J_ineq0[:constr.n_ineq - 2 * n_vars] if sps.issparse(constr.J_ineq0) else None
+    else:
+        raise NotImplementedError("row-sharded solve: equality and inequality constraints "
+                                  "together are not distributed")
+    if J is None or not sps.issparse(J) or J.shape[0] == 0:
+        raise NotImplementedError("row-sharded solve needs a sparse constraint Jacobian with "
+                                  "rows to partition (sparse_jacobian=True)")
+    J = sps.csr_matrix(J)
+    J.sort_indices()
+    lay = sharded.ShardLayout(J.indptr, J.indices, J.shape, comm.world, comm.rank)
+    sh = sharded.Sharding(lay, comm, ops)
+    xp = sharded.ShardedBackend(sh)
+    if constr.n_ineq:
+        sh.register(xp.INEQ)
+        sh.register(xp.Z)
+    return xp
+
+
 def minimize_constrained(fun, x0, grad, hess='2-point', constraints=(), method=None,
                          xtol=1e-8, gtol=1e-8, sparse_jacobian=None, options={},
                          callback=None, max_iter=1000, verbose=0):
@@ -192,11 +235,21 @@ def minimize_constrained(fun, x0, grad, hess='2-point', constraints=(), method=N
     ``method`` is ``'equality_constrained_sqp'`` or ``'tr_interior_point'``
     (hyphenated spellings are accepted too); ``None`` picks by constraint type.
     Returns a ``scipy.optimize.OptimizeResult`` with the reference's fields.
+
+    Launched as one process per GPU (``torch.distributed`` initialised, or
+    ``options={'shard': True}``) the same call runs on the row-sharded backend: the user's
+    callbacks are evaluated on the host with global numpy arrays exactly as here (replicated
+    on every rank), every vector, the Jacobian and the Hessian between two evaluations are
+    partitioned over the ranks (ipsolver/sharded.py), the result carries global arrays.
     """
-    xp = _backend.get()
+    options = dict(options)
+    shard = _shard_request(options)
     if _is_cuda_tensor(x0):
+        if shard:
+            raise NotImplementedError("row-sharded solve: host callbacks (numpy x0) only")
         return _minimize_device(fun, x0, grad, hess, constraints, method, xtol, gtol, options,
-                                callback, max_iter, verbose, xp)
+                                callback, max_iter, verbose, _backend.get())
+    xp = None if shard else _backend.get()
     x0 = np.atleast_1d(x0).astype(float)                     # :374-379
     n_vars = np.size(x0)
     f0 = fun(x0)
@@ -222,10 +275,11 @@ def minimize_constrained(fun, x0, grad, hess='2-point', constraints=(), method=N
     constr = (empty_canonical_constraint(x0, n_vars, sparse_jacobian) if len(copied) == 0
               else to_canonical(copied))
     host_lagr_hess = lagrangian_hessian(constr, hess_wrapped)
+    if shard:
+        xp = _sharded_backend(shard, constr, n_vars)
 
     state = OptimizeResult(niter=0, nfev=1, ngev=1, ncev=1, njev=1, nhev=0,
                            cg_niter=0, cg_info={})           # :443-450
-    options = dict(options)
     return_all = options.get("return_all", False)
     if return_all:
         state.allvecs, state.allmult = [], []

@@ -493,6 +493,13 @@ class HipOps:
         total, bad = self.dv.read_slots(2)
         return total, bad
 
+    def assign_negated_where(self, s, mask, c):
+        """s[mask != 0] = -c[mask != 0] in place (tr_interior_point.py:92)."""
+        from . import _hip
+        if len(s):
+            _hip.call("ipx_assign_negated_where", len(s), self.dv._p(s.t), self.dv._p(mask.t),
+                      self.dv._p(c.t), self.dv.stream_ptr())
+
     def augmented_box(self, J, s_nl, s_lb, s_ub, col_breaks=None):
         """Local block of the barrier problem's augmented Jacobian for nonlinear inequality
         rows + a box on every variable (tr_interior_point.py:141-194 on the canonical rows of
@@ -848,13 +855,24 @@ class ShardCSR:
         self.shape = (n, m) if transposed else (m, n)
 
     @staticmethod
-    def from_global(sh, A):
+    def from_global(sh, A, like=None):
+        """The rank's block (complete rows E0..E1 over its extended columns) of a global
+        matrix.  ``like``: a ShardCSR made from a matrix of the same pattern -- its local
+        pattern (tiles, transpose, symbolic factorization) is reused, only values move."""
         d = sh.lay.me
         A = sps.csr_matrix(A)
         loc = sps.csr_matrix(A[d["E0"]:d["E1"], d["x0"]:d["x1"]])
-        _, _, lo, hi = sh.lay.geom("row")
-        _, _, clo, chi = sh.lay.geom("col")
-        return ShardCSR(sh, sh.ops.csr(loc, row_breaks=[lo, hi], col_breaks=[clo, chi]))
+        if not loc.has_sorted_indices:
+            loc.sort_indices()
+        sig = (loc.shape, loc.nnz, hash(loc.indptr.tobytes()), hash(loc.indices.tobytes()))
+        if like is not None and getattr(like, "_sig", None) == sig:
+            out = like.with_values(loc.data)
+        else:
+            _, _, lo, hi = sh.lay.geom("row")
+            _, _, clo, chi = sh.lay.geom("col")
+            out = ShardCSR(sh, sh.ops.csr(loc, row_breaks=[lo, hi], col_breaks=[clo, chi]))
+        out._sig = sig
+        return out
 
     @property
     def T(self):
@@ -894,15 +912,25 @@ class ShardHessian:
         self.shape = (sh.global_len(kind),) * 2
 
     @staticmethod
-    def from_global(sh, H, hdiag=None):
+    def from_global(sh, H, hdiag=None, like=None):
+        """Rows / columns X of a global banded Hessian (+ diagonal term).  ``like``: a
+        ShardHessian made from a matrix of the same pattern (local pattern reused)."""
         d = sh.lay.me
         H = sps.csr_matrix(H)
         loc = sps.csr_matrix(H[d["x0"]:d["x1"], d["x0"]:d["x1"]])
+        if not loc.has_sorted_indices:
+            loc.sort_indices()
         _, ln, lo, hi = sh.lay.geom("col")
-        csr = sh.ops.csr(loc, row_breaks=[lo, hi])
+        sig = (loc.shape, loc.nnz, hash(loc.indptr.tobytes()), hash(loc.indices.tobytes()))
+        if like is not None and getattr(like, "_sig", None) == sig:
+            csr = sh.ops.refresh(like._csr, loc.data)
+        else:
+            csr = sh.ops.csr(loc, row_breaks=[lo, hi])
         diag = sh.ops.from_host(np.asarray(hdiag, dtype=float)[d["x0"]:d["x1"]]) \
             if hdiag is not None else None
-        return ShardHessian(sh, sh.ops.hessian(ln, csr, diag))
+        out = ShardHessian(sh, sh.ops.hessian(ln, csr, diag))
+        out._sig, out._csr = sig, csr
+        return out
 
     def dot(self, p):
         assert p.kind == self.kind, (p.kind, self.kind)
@@ -1366,6 +1394,8 @@ class ShardedBackend:
 
     def __init__(self, sh):
         self.sh = sh
+        self._like = {}              # last distributed matrix per role (pattern reuse)
+        self._masks = {}
 
     def _z_breaks(self):
         """Own / halo boundaries of the z segments in the local z vector."""
@@ -1375,9 +1405,13 @@ class ShardedBackend:
         if isinstance(a, (ShardVec, _Empty)):
             return a
         a = np.asarray(a, dtype=float)
+        if a.size == 0:
+            return _Empty()
         return self.sh.from_global(a, self.sh.kind_of_len(len(a)))
 
     def tohost(self, v):
+        if isinstance(v, _Empty):
+            return np.zeros(0)
         return v.to_host() if isinstance(v, ShardVec) else np.asarray(v)
 
     def zeros(self, n):
@@ -1423,14 +1457,51 @@ class ShardedBackend:
         return -np.inf if bad > 0 else tot
 
     def assign_negated_where(self, s, mask, c):
-        if np.asarray(mask).any():
-            raise NotImplementedError("sharded backend: enforce_feasibility")
+        """s[mask] = -c[mask] in place through the view of z (tr_interior_point.py:92):
+        elementwise on own and halo entries alike."""
+        mask = np.asarray(mask)
+        if not mask.any():
+            return
+        key = (s.kind, mask.tobytes())
+        m = self._masks.get(key)
+        if m is None:
+            m = self._masks[key] = self.sh.from_global(mask.astype(float), s.kind)
+        self.sh.ops.assign_negated_where(s.loc, m.loc, c.loc)
 
     def diagonal_operator(self, d):
         return _DiagOp(d)
 
-    def matrix(self, J, key=None):
-        return J
+    def matrix(self, J, key="jac"):
+        """A global host matrix (scipy sparse: what the reference's constraint classes hand
+        to the solver, replicated on every rank) becomes the rank's block of it."""
+        if J is None or isinstance(J, (ShardCSR, BoxInequalityJacobian)):
+            return J
+        if not sps.issparse(J):
+            raise NotImplementedError("sharded backend: dense Jacobians are not distributed "
+                                      "(sparse_jacobian=True)")
+        A = self._like[key] = ShardCSR.from_global(self.sh, J, like=self._like.get(key))
+        return A
+
+    def _box_inequality(self, J_ineq, n_vars):
+        """The canonical inequality Jacobian of `nonlinear rows + a box on every variable`
+        (_canonical_constraint.py:350-355: all lower bounds, then all upper bounds) as a
+        BoxInequalityJacobian; anything else is refused."""
+        J = sps.csr_matrix(J_ineq)
+        m = J.shape[0] - 2 * n_vars
+        sig = (J.shape, J.nnz, hash(J.indptr.tobytes()), hash(J.indices.tobytes()))
+        if self._like.get("box_sig") != sig:
+            ok = m == self.sh.lay.m and J.shape[1] == n_vars
+            if ok:
+                eye = sps.identity(n_vars, format="csr")
+                ok = (J[m:] != sps.vstack([-eye, eye], format="csr")).nnz == 0
+            if not ok:
+                raise NotImplementedError(
+                    "sharded backend: inequality constraints must be nonlinear rows followed by "
+                    "an interval BoxConstraint on every variable (BASELINE config 5); got a "
+                    "%d x %d inequality Jacobian for %d partitioned rows"
+                    % (J.shape[0], J.shape[1], self.sh.lay.m))
+            self._like["box_sig"] = sig
+        return BoxInequalityJacobian(self.matrix(J[:m], "jac_nl"))
 
     def mark_constant(self, A):
         return A
@@ -1438,19 +1509,51 @@ class ShardedBackend:
     def augmented_jacobian(self, J_eq, J_ineq, s, n_vars, n_eq, n_ineq):
         """[[J_eq, 0], [J_ineq, diag(s)]] (tr_interior_point.py:141-194) as a distributed
         matrix from the inequality rows' space to z-space."""
-        if n_eq or not isinstance(J_ineq, BoxInequalityJacobian):
-            raise NotImplementedError("sharded backend: inequality rows must come from "
-                                      "BoxInequalityJacobian (no equality rows next to them)")
+        if n_eq:
+            raise NotImplementedError("sharded backend: equality rows next to inequality rows")
+        if not isinstance(J_ineq, BoxInequalityJacobian):
+            J_ineq = self._box_inequality(J_ineq, n_vars)
         sh = self.sh
         segs = sh.segments(self.INEQ)
         parts = [s.loc[off:off + ln] for _, off, ln, *_ in segs]
         local = sh.ops.augmented_box(J_ineq.J_nl.local, *parts, col_breaks=self._z_breaks())
         return ShardCSR(sh, local, row_kind=self.INEQ, col_kind=self.Z)
 
+    def _host_hessian(self, terms):
+        """Host Hessian terms (canonical.HessianSum: scipy sparse matrices, replicated on every
+        rank) as a ShardHessian: diagonal-pattern terms form the diagonal part, the others are
+        summed into the CSR part -- the split backend_hip.hessian_operator makes, so the local
+        products round the same way as on one GPU."""
+        from .canonical import HessianSum
+        flat = terms.flat_terms() if isinstance(terms, HessianSum) else list(terms)
+        n = self.sh.lay.n
+        csr, diag = None, None
+        for h in flat:
+            if isinstance(h, np.ndarray) and h.ndim == 2:
+                h = sps.csr_matrix(h)
+            if not sps.issparse(h):
+                raise NotImplementedError(
+                    "sharded backend: Hessian terms must be sparse matrices (operator terms -- "
+                    "LinearOperator, finite differences -- are not distributed)")
+            h = sps.csr_matrix(h)
+            if not h.has_canonical_format:
+                h = h.copy()
+                h.sum_duplicates()
+            rows = np.repeat(np.arange(h.shape[0], dtype=np.int32), np.diff(h.indptr))
+            if np.array_equal(rows, h.indices):          # purely diagonal pattern
+                d = h.diagonal() if h.nnz < h.shape[0] else h.data
+                diag = d if diag is None else diag + d
+            else:
+                csr = h if csr is None else csr + h
+        if csr is None:
+            csr = sps.csr_matrix((n, n))
+        H = self._like["hess"] = ShardHessian.from_global(self.sh, csr, diag,
+                                                          like=self._like.get("hess"))
+        return H
+
     def hessian_operator(self, terms, n_vars, slack_block):
         if not isinstance(terms, ShardHessian):
-            raise NotImplementedError("sharded backend: the Lagrangian Hessian callback must "
-                                      "return a ShardHessian")
+            terms = self._host_hessian(terms)
         if slack_block is None:
             return terms
         return ShardHessian(self.sh, self.sh.ops.hessian_z(terms.local, slack_block.loc,

@@ -131,6 +131,10 @@ class NumpyOps:
         pos = s > 0
         return float(np.sum(np.log(s[pos]))), float(np.count_nonzero(~pos))
 
+    def assign_negated_where(self, s, mask, c):                 # tr_interior_point.py:92
+        sel = mask != 0
+        s[sel] = -c[sel]
+
     def augmented_box(self, J, s_nl, s_lb, s_ub, col_breaks=None):                  # tr_interior_point.py:141-194
         mE, nX = J.M.shape
         I = sps.identity(nX, format="csr")

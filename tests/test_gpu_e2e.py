@@ -462,3 +462,26 @@ def test_bench_contract_with_odd_step_counts():
     assert d["unbounded_trust_region"]["iterations_per_s"] > d["value"] * 0.9
     assert d["public_api"]["trust_radius_finite"]["iterations_per_s"] > 1000
     assert d["parity_vs_oracle"]["max_rel_err"] < 1e-10
+
+
+@pytest.mark.parametrize("what", ["config4:equality_constrained_sqp", "config4:tr_interior_point",
+                                  "config5"])
+def test_minimize_constrained_dispatches_to_the_sharded_backend(what, tmp_path):
+    """``ipsolver.minimize_constrained`` itself -- the reference's constraint classes, numpy
+    callbacks -- as one rank of a two-process group sharing cuda:0: dispatched to the
+    row-sharded HIP backend (device-resident loop on the peer mailboxes), against the
+    REFERENCE's traces of configs 4 and 5 in small (tests/test_sharded_gloo.py has the same
+    calls on the numpy twin)."""
+    import socket
+    import torch.multiprocessing as mp
+    import test_sharded_gloo as tg
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    path = str(tmp_path / "api.npz")
+    mp.spawn(tg._api_worker, args=(2, port, what, path, "hip"), nprocs=2, join=True)
+    got = np.load(path)
+    if what == "config5":
+        tg.check_config5_prefix(got)
+    else:
+        tg.check_config4(got, what.split(":")[1])

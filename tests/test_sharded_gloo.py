@@ -159,6 +159,155 @@ def test_sharded_full_solve_matches_reference(world, method, tmp_path):
     close(got["x"][::max(1, N // 50)], gx, 1e-9)
 
 
+def _api_worker(rank, world, port, what, out_path, ops_name="numpy"):
+    """``ipsolver.minimize_constrained`` with the reference's constraint classes and host
+    callbacks, one rank of a torch.distributed group: dispatched to the row-sharded backend."""
+    _setup(rank, world, port)
+    try:
+        import warnings
+        import ipsolver
+        from banded_setup import load_synthetic
+        if ops_name == "hip":
+            import torch
+            torch.cuda.set_device(0)
+            shard = True
+        else:
+            from oracle.numpy_local import NumpyOps
+            shard = NumpyOps()
+        rows = []
+        limit = {"config5": 24, "enforce": 14}.get(what)
+
+        def record(state):
+            rows.append([int(state.niter), int(state.cg_niter), float(state.trust_radius),
+                         float(state.penalty), float(getattr(state, "barrier_parameter", np.nan)),
+                         float(state.optimality), float(state.constr_violation),
+                         int(state.nfev)])
+            return limit is not None and len(rows) >= limit
+        syn = load_synthetic()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            if what.startswith("config4"):
+                prob = syn.CenteredBandedNLP(N, M, eps=1e-3)
+                res = ipsolver.minimize_constrained(
+                    prob.fun, prob.x0, prob.grad, prob.hess, prob.constraints(ipsolver),
+                    method=what.split(":")[1], callback=record, options={"shard": shard})
+            else:
+                prob = syn.CenteredBandedNLP(12000, 1200, eps=1.0)
+                box = ipsolver.BoxConstraint(("interval", -0.8, 0.8),
+                                             enforce_feasibility=(what == "enforce"))
+                # (enforced bounds need a strictly feasible start: _constraints.py:161-164)
+                x0 = np.clip(prob.x0, -0.7, 0.7) if what == "enforce" else prob.x0
+                res = ipsolver.minimize_constrained(
+                    prob.fun, x0, prob.grad, prob.hess,
+                    (prob.constraints(ipsolver, ("less", 0.0)), box), callback=record,
+                    options={"shard": shard})
+        assert isinstance(res.x, np.ndarray) and res.x.shape == prob.x0.shape
+        if rank == 0:
+            np.savez(out_path, x=res.x, rows=np.array(rows), status=res.status,
+                     s=res.s if "s" in res else np.zeros(0),
+                     counts=np.array([res.status, res.niter, res.cg_niter, res.nfev, res.ngev,
+                                      res.nhev, res.ncev, res.njev]))
+    finally:
+        dist.destroy_process_group()
+
+
+def check_config4(got, method):
+    import json
+    from conftest import unjson
+    from test_host_logic import EPS
+    with open(os.path.join(ROOT, "tests", "golden", "e2e_n20000.json")) as f:
+        gold = json.load(f)["banded_eq_n20000_%s" % method]
+    assert list(got["counts"]) == [gold[k] for k in ("status", "niter", "cg_niter", "nfev", "ngev",
+                                                     "nhev", "ncev", "njev")]
+    want = np.array([[np.nan if isinstance(v, str) else v for v in r]
+                     for r in unjson(gold["trace"])], dtype=float)
+    rows = got["rows"]
+    assert rows.shape == want.shape
+    for col in (0, 1, 7):
+        assert np.array_equal(rows[:, col], want[:, col])
+    for col in (2, 3, 4, 5, 6):
+        ok = np.isfinite(want[:, col])
+        if not ok.any():
+            continue
+        floor = 256 * EPS * np.max(np.abs(want[ok, col]))
+        assert np.all(np.abs(rows[ok, col] - want[ok, col]) <= 1e-9 * np.abs(want[ok, col]) + floor)
+    gx = np.asarray(unjson(gold["x"]))
+    close(got["x"][::max(1, N // 50)], gx, 1e-9)
+
+
+def check_config5_prefix(got, k=16):
+    import json
+    from conftest import unjson
+    with open(os.path.join(ROOT, "tests", "golden", "e2e_ineq_n12000.json")) as f:
+        gold = json.load(f)["banded_ineq_n12000"]
+    want = np.array(unjson(gold["trace"]), dtype=float)
+    rows = got["rows"]
+    assert len(rows) >= k and int(got["status"]) == 3
+    for col in (0, 1, 7):
+        assert np.array_equal(rows[:k, col], want[:k, col]), col
+    for col in (2, 3, 4, 5, 6):
+        assert np.allclose(rows[:k, col], want[:k, col], rtol=1e-6, atol=1e-12), col
+    assert got["s"].min() > 0 and np.all(np.abs(got["x"]) < 0.8)
+
+
+@pytest.mark.parametrize("method", ["equality_constrained_sqp", "tr_interior_point"])
+def test_minimize_constrained_dispatches_config4(method, tmp_path):
+    """The PUBLIC entry point on two ranks: ``ipsolver.minimize_constrained(fun, x0, grad, hess,
+    NonlinearConstraint(...), method=...)`` with plain numpy callbacks (reference
+    _minimize_constrained.py:96-100, _constraints.py:79) is dispatched to the row-sharded
+    backend -- the canonical Jacobian and Hessian terms are partitioned inside minimize.py --
+    and reproduces the REFERENCE's trace of BASELINE config 4 in small (n = 20000)."""
+    path = str(tmp_path / "api.npz")
+    mp.spawn(_api_worker, args=(2, _free_port(), "config4:" + method, path), nprocs=2, join=True)
+    check_config4(np.load(path), method)
+
+
+def test_minimize_constrained_dispatches_config5(tmp_path):
+    """The same for BASELINE config 5 in small: ``NonlinearConstraint(c, ('less', 0))`` +
+    ``BoxConstraint(('interval', -0.8, 0.8))`` (reference _constraints.py:79,310) -- the
+    canonical inequality Jacobian [J; -I; +I] is recognised inside the sharded backend, its
+    box rows stay symbolic -- against the REFERENCE's trace over the comparable prefix."""
+    path = str(tmp_path / "api5.npz")
+    mp.spawn(_api_worker, args=(2, _free_port(), "config5", path), nprocs=2, join=True)
+    check_config5_prefix(np.load(path))
+
+
+def test_minimize_constrained_sharded_enforce_feasibility(tmp_path):
+    """``enforce_feasibility=True`` on the box (the slack reset s[enforce] = -c[enforce] through
+    the view of z, tr_interior_point.py:92) on two ranks against the same call on the
+    single-process CPU backend of the oracle."""
+    import warnings
+    import ipsolver
+    import oracle.numpy_backend as nb
+    from banded_setup import load_synthetic
+    from ipsolver import backend
+    path = str(tmp_path / "api_enf.npz")
+    mp.spawn(_api_worker, args=(2, _free_port(), "enforce", path), nprocs=2, join=True)
+    got = np.load(path)
+    prob = load_synthetic().CenteredBandedNLP(12000, 1200, eps=1.0)
+    rows = []
+
+    def record(state):
+        rows.append([int(state.niter), int(state.cg_niter), float(state.trust_radius),
+                     float(state.penalty), float(state.barrier_parameter),
+                     float(state.optimality), float(state.constr_violation), int(state.nfev)])
+        return len(rows) >= 14
+    with backend.use(nb), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res = ipsolver.minimize_constrained(
+            prob.fun, np.clip(prob.x0, -0.7, 0.7), prob.grad, prob.hess,
+            (prob.constraints(ipsolver, ("less", 0.0)),
+             ipsolver.BoxConstraint(("interval", -0.8, 0.8), enforce_feasibility=True)),
+            callback=record, options={"shard": False})
+    want, have = np.array(rows), got["rows"]
+    k = 12
+    for col in (0, 1, 7):
+        assert np.array_equal(have[:k, col], want[:k, col]), col
+    for col in (2, 3, 4, 5, 6):
+        assert np.allclose(have[:k, col], want[:k, col], rtol=1e-6, atol=1e-12), col
+    assert np.all(np.abs(got["x"]) < 0.8) and got["s"].min() > 0
+
+
 def _barrier_worker(rank, world, port, out_path):
     _setup(rank, world, port)
     try:
