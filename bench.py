@@ -396,6 +396,22 @@ def config2_leg():
                 method="equality_constrained_sqp")
             torch.cuda.synchronize()
             wall = time.time() - t0
+    # the same solve with everything resident in HBM (device-callback mode)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    At, Ht, ct = (torch.from_numpy(a).to(dev) for a in (A, Hd, c))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for attempt in range(2):
+            torch.cuda.synchronize()
+            t0 = time.time()
+            res_d = ipsolver.minimize_constrained(
+                lambda x: 0.5 * torch.dot(x, Ht @ x) + torch.dot(ct, x),
+                torch.zeros(n, dtype=torch.float64, device=dev), lambda x: Ht @ x + ct,
+                lambda x: Ht, ipsolver.LinearConstraint(At, ("equals", bq)),
+                method="equality_constrained_sqp")
+            torch.cuda.synchronize()
+            wall_d = time.time() - t0
+    del At, Ht
     # the Gram kernel alone
     Ad = DeviceDense.from_host(A)
     M = _hip.load().ipx_dense_padded(m)
@@ -423,6 +439,11 @@ def config2_leg():
             "cg_niter": int(res.cg_niter), "optimality": float(res.optimality),
             "constr_violation": float(res.constr_violation),
             "reference_trace": "status 1, 15 outer / 28 CG (tests/golden/config2.json)",
+            "device_callbacks": {"seconds": wall_d, "status": int(res_d.status),
+                                 "niter": int(res_d.niter), "cg_niter": int(res_d.cg_niter),
+                                 "optimality": float(res_d.optimality),
+                                 "note": "A and H resident in HBM (2-D CUDA tensors): nothing "
+                                         "crosses PCIe between two iterations"},
             "gram_mfma": {"kernel": "k_gram_mfma (v_mfma_f64_16x16x4_f64)", "ms": ms,
                           "flop_executed": flop, "tiles": [nt * (nt + 1) // 2, nt * nt],
                           "achieved": tf, "peak": FP64_MFMA_PEAK_TFLOPS,

@@ -5,11 +5,14 @@ tensors and return device objects, so nothing crosses PCIe between two
 iterations:
 
     fun(x) -> float | 0-d tensor          grad(x) -> 1-D tensor
-    hess(x) -> DeviceCSR | 1-D tensor (diagonal) | DeviceHessian | None
+    hess(x) -> DeviceCSR | 1-D tensor (diagonal) | 2-D tensor / DeviceDense (dense) |
+               DeviceHessian | None
     NonlinearConstraint.fun(x) -> 1-D tensor
     NonlinearConstraint.jac(x) -> DeviceCSR (a fixed CSRPattern, values refreshed)
     NonlinearConstraint.hess(x, v) -> DeviceCSR | 1-D tensor (diagonal) | None
-    LinearConstraint(A)  with A a scipy sparse matrix or a DeviceCSR
+    LinearConstraint(A)  with A a scipy sparse matrix, a DeviceCSR, or -- dense Jacobian,
+                         BASELINE config 2: every row an equality -- a 2-D CUDA tensor /
+                         DeviceDense
     BoxConstraint(kind)  unchanged
 
 The canonical form (row selection, sign flips, stacking of several
@@ -125,12 +128,24 @@ class DeviceRowMap:
         return c_ineq, c_eq
 
     def jac(self, J):
+        from .dense import DeviceDense
+        if isinstance(J, DeviceDense):
+            # a dense Jacobian passes through whole: rows all equalities, in order
+            if self.n_ineq or not np.array_equal(self.eq, np.arange(J.shape[0])):
+                raise NotImplementedError("device-callback mode: a dense constraint Jacobian "
+                                          "must consist of equality rows only (kind 'equals')")
+            return self._no_rows(J.shape[1]), J
         key = id(J.pattern)
         if key not in self._sel:
             self._sel[key] = (RowSelection(J.pattern, self.ineq, self.sign_h),
                               RowSelection(J.pattern, self.eq, None), J.pattern)
         sel_ineq, sel_eq, _ = self._sel[key]
         return sel_ineq.apply(J), sel_eq.apply(J)
+
+    @staticmethod
+    def _no_rows(n_vars):
+        return DeviceCSR(CSRPattern(np.zeros(1, np.int32), np.empty(0, np.int32), (0, n_vars)),
+                         dv._empty(0))
 
     def multipliers(self, v_eq, v_ineq):
         zero = torch.zeros(1, dtype=_F64, device=ctx().device)
@@ -158,8 +173,16 @@ class _DeviceConstraint:
             self.hess = None
             f0 = x0
         elif isinstance(user, LinearConstraint):
-            A = user.A if isinstance(user.A, DeviceCSR) else DeviceCSR.from_scipy(
-                sps.csr_matrix(user.A))
+            from .dense import DeviceDense
+            if isinstance(user.A, (DeviceCSR, DeviceDense)):
+                A = user.A
+            elif torch.is_tensor(user.A) and user.A.dim() == 2:
+                if not user.A.is_cuda:
+                    raise TypeError("device-callback mode: a dense LinearConstraint matrix must "
+                                    "be a CUDA tensor")
+                A = DeviceDense(user.A.to(_F64))       # dense Jacobian resident in HBM
+            else:
+                A = DeviceCSR.from_scipy(sps.csr_matrix(user.A))
             self.fun = lambda x: A.dot(x)
             self.jac = lambda x: A
             self.hess = None
@@ -299,14 +322,34 @@ class DeviceCanonical:
 
 def _as_term(h):
     """Normalise a Hessian callback's return value to a device term."""
+    from .dense import DeviceDense
     from .operators import DeviceHessian
-    if h is None or isinstance(h, (DeviceCSR, DVec, DeviceHessian)) \
+    if h is None or isinstance(h, (DeviceCSR, DVec, DeviceHessian, DeviceDense)) \
             or getattr(h, "device_operator", False):
         return h
     if torch.is_tensor(h) and h.dim() == 1:
         return as_dvec(h)                      # diagonal
+    if torch.is_tensor(h) and h.dim() == 2 and h.is_cuda:
+        return _dense_term(h)                  # dense Hessian resident in HBM
     raise TypeError("device-callback mode: a Hessian callback must return a DeviceCSR, a 1-D "
-                    "CUDA tensor (diagonal) or a DeviceHessian, got %r" % type(h))
+                    "CUDA tensor (diagonal), a 2-D CUDA tensor / DeviceDense (dense) or a "
+                    "DeviceHessian, got %r" % type(h))
+
+
+_dense_terms = {}
+
+
+def _dense_term(t):
+    """DeviceDense wrapper of a 2-D CUDA tensor, one per storage (a callback returning the same
+    resident matrix every iteration gets the same wrapper and its cached transpose)."""
+    from .dense import DeviceDense
+    key = (t.data_ptr(), tuple(t.shape), tuple(t.stride()), t._version)
+    hit = _dense_terms.get(key)
+    if hit is None:
+        if len(_dense_terms) > 4:
+            _dense_terms.clear()
+        hit = _dense_terms[key] = DeviceDense(t.to(_F64))
+    return hit
 
 
 def lagrangian_hessian(canonical, hess):

@@ -280,6 +280,63 @@ def test_config2_full_solve_against_reference_trace(n, m, config2_golden):
         assert abs(got[-1, 4] - want[-1, 4]) <= 1e-9 * want[-1, 4] + floor
 
 
+@pytest.mark.parametrize("n,m", [(4000, 800), (10000, 2000)])
+def test_config2_device_callbacks(n, m, config2_golden):
+    """BASELINE config 2 with everything resident in HBM (device-callback mode with a DENSE
+    Jacobian and Hessian: ``LinearConstraint`` over a 2-D CUDA tensor, ``hess`` returning a 2-D
+    CUDA tensor): nothing crosses PCIe between two iterations -- in host mode the 800 MB
+    Hessian of the full-size problem is the solve's largest cost.  Same criteria against the
+    REFERENCE's trace as the host-callback test above (all rows before the knife-edge ones)."""
+    import time
+    import warnings
+    import torch
+    import ipsolver
+    from conftest import unjson
+    gold = config2_golden["config2_n%d" % n]
+    A, Hd, c, bq = _config2_problem(n, m)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    At, Ht, ct = (torch.from_numpy(a).to(dev) for a in (A, Hd, c))
+    rows = []
+
+    def cb(state):
+        rows.append([int(state.niter), int(state.cg_niter), float(state.trust_radius),
+                     float(state.penalty), float(state.optimality),
+                     float(state.constr_violation), int(state.nfev)])
+        return False
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for attempt in range(2):
+            del rows[:]
+            torch.cuda.synchronize()
+            t0 = time.time()
+            res = ipsolver.minimize_constrained(
+                lambda x: 0.5 * torch.dot(x, Ht @ x) + torch.dot(ct, x),
+                torch.zeros(n, dtype=torch.float64, device=dev), lambda x: Ht @ x + ct,
+                lambda x: Ht, ipsolver.LinearConstraint(At, ("equals", bq)),
+                method="equality_constrained_sqp", callback=cb)
+            torch.cuda.synchronize()
+            wall = time.time() - t0
+    print("config 2 (n=%d) in device-callback mode: %.3f s, status %d, %d outer / %d CG"
+          % (n, wall, res.status, res.niter, res.cg_niter))
+    want = np.array([[r[0], r[1], r[2], r[3], r[5], r[6], r[7]] for r in unjson(gold["trace"])],
+                    dtype=float)
+    got = np.array(rows, dtype=float)
+    k = len(want) - 2
+    assert len(got) >= k
+    for col in (0, 1, 6):
+        assert np.array_equal(got[:k, col], want[:k, col])
+    assert np.allclose(got[:k, 2:4], want[:k, 2:4], rtol=1e-12, atol=0)
+    floor = 1e-14 * want[0, 4]
+    assert np.all(np.abs(got[:k, 4] - want[:k, 4]) <= 1e-9 * want[:k, 4] + floor)
+    assert np.all(np.abs(got[:k, 5] - want[:k, 5]) <= 1e-10 * want[:k, 5] + 1e-13 * want[0, 5])
+    gx = np.asarray(unjson(gold["x"]), dtype=float)
+    x = res.x.cpu().numpy()[::max(1, n // 50)]
+    assert np.max(np.abs(x - gx)) / np.max(np.abs(gx)) <= 1e-7
+    assert abs(float(res.fun) - gold["fun"]) <= 1e-12 * abs(gold["fun"])
+    assert res.optimality < 2e-8 and res.constr_violation < 1e-10
+    assert res.status in (1, 2) and gold["niter"] <= res.niter <= gold["niter"] + 15
+
+
 def test_config5_full_size_properties():
     """BASELINE config 5 at its full size on one GPU: n = 5e5 variables, box on every variable
     + 5e4 nonlinear inequalities (N = 1.55e6 with slacks, M = 1.05e6 rows), the full
