@@ -142,6 +142,13 @@ int ipx_dense_gemv(int64_t m, int64_t n, const double *A, int64_t lda, const dou
 int64_t ipx_dense_padded(int64_t m);
 int ipx_gram_f64_mfma(int64_t m, int64_t n, const double *A, int64_t lda, double *G,
                       void *stream);
+/* The same with the sum over the columns cut into `splits` parts (ipx_gram_splits picks the
+ * count that evens the tiles out over the CUs; partial tiles in ws, ipx_gram_ws_doubles(m,
+ * splits) doubles, added in a fixed order: deterministic). */
+int ipx_gram_splits(int64_t m, int64_t n);
+int64_t ipx_gram_ws_doubles(int64_t m, int32_t splits);
+int ipx_gram_f64_mfma_split(int64_t m, int64_t n, const double *A, int64_t lda, double *G,
+                            double *ws, int32_t splits, void *stream);
 /* Same G from a CSR A (sparse Jacobian whose A A' is not narrow-banded). */
 int ipx_aat_dense(int64_t m, const int32_t *rowptr, const int32_t *colidx, const double *val,
                   double *G, void *stream);

@@ -85,23 +85,54 @@ k_fold2(const double *partial, int count, double *red) {
 // columns: the two 64-row panels of A (one when the tile sits on the diagonal) are staged
 // in LDS by 16-byte loads -- 16 lanes cover the 256 contiguous bytes of a row's chunk -- and
 // the loads of chunk c+1 are issued into registers before the MFMAs of chunk c, so global
-// latency hides behind 32 MFMAs per wave.  LDS rows are pitched 34 doubles: the 16 rows x 2
-// k-values a half-wave reads per ds_read_b64 then fall into 32 distinct bank pairs.
+// latency hides behind 32 MFMAs per wave.
+//
+// LDS layout (round 3).  Round 2 kept a panel as [row][k] with a pitch of 34 doubles and read
+// one double per lane and MFMA; the compiler paired the reads of consecutive k-steps into
+// ds_read2_b64, whose banking is per 16 CONTIGUOUS lanes modulo 32 dwords: rows r and r + 8
+// collided, 4 conflict cycles per MFMA (SQ_LDS_BANK_CONFLICT 84.6 M for 21.15 M MFMAs,
+// profiles/r02_dense_gram_pmc.json).  Now a lane fetches the operands of TWO MFMAs with one
+// ds_read_b128: the sum over k may visit k in any order as long as both operands use the same
+// one, so lane group lk (= lane >> 4) is given the k-values 8 j + 2 lk + {0, 1} of step j --
+// adjacent in memory.  The panel is four sub-panels, one per lk, of 64 rows pitched 10
+// doubles: within the lane groups of ds_read_b128 ({0-3,12-15,20-27}, ... :
+// MI355X_MICROARCH.md, LDS) the 16-byte slot of a lane is (5 row + j) mod 16 -- 5 row is a
+// bijection on 16 rows and the sub-panels are a multiple of 16 slots apart -- so every group
+// covers the 16 slots once: conflict-free, half the LDS instructions.
 typedef double v4d __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
 
 constexpr int GT = 64;          // tile edge of G per workgroup
 constexpr int GK = 32;          // K chunk
-constexpr int GP = GK + 2;      // LDS row pitch (doubles)
+constexpr int GSP = 10;         // sub-panel row pitch (doubles): 8 k-values of one lane group + 2
+constexpr int GSUB = GT * GSP;  // sub-panel (one lane group lk): 640 doubles = 320 slots
+constexpr int GPANEL = 4 * GSUB;
+
+// Which double2 of the 64 x 32 panel thread `tid` moves in its u-th load / LDS store: row r,
+// column pair t (columns 2t, 2t+1).  A wave instruction covers four whole rows' 256-byte
+// chunks (coalesced), and every 8 CONTIGUOUS lanes -- the banking group of ds_write_b128,
+// modulo 32 dwords -- write one lane group's (lk) pairs j = 0..3 of rows b and b + 4: dword
+// offsets 20 row + 4 j = const + {0, 4, ..., 28}, every bank once.  (idx -> (idx >> 4,
+// idx & 15) put the four lk of one row and j on the same banks: 4-way conflicts.)
+__device__ __forceinline__ void gram_slot(int tid, int u, int &r, int &t) {
+  const int lane = tid & 63, wave = tid >> 6;
+  const int c = wave * 4 + u;                    // 16 (wave, u) combinations x 4 rows
+  const int b = 8 * (c >> 1) + 2 * (c & 1);      // rows b, b+1, b+4, b+5
+  const int g = lane >> 3, i = lane & 7;
+  const int j = i & 3, rsel = i >> 2, lk = g & 3, rpair = g >> 2;
+  r = b + 4 * rsel + rpair;
+  t = 4 * j + lk;
+}
 
 template <bool VEC>
 __device__ __forceinline__ void gram_fetch(const double *__restrict__ A, int64_t lda, int m,
                                            int n, int row0, int k0, int tid, v2d (&reg)[4]) {
-  // panel of 64 rows x 32 columns = 1024 double2; thread t takes double2 number t + 256*u
+  // panel of 64 rows x 32 columns = 1024 double2, four per thread (gram_slot: which)
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
-    const int idx = tid + u * IPX_BLOCK;
-    const int r = idx >> 4, c = (idx & 15) * 2;
+    int r, t;
+    gram_slot(tid, u, r, t);
+    const int c = 2 * t;
     const int row = row0 + r, k = k0 + c;
     v2d v = {0.0, 0.0};
     if (row < m) {
@@ -119,24 +150,34 @@ __device__ __forceinline__ void gram_fetch(const double *__restrict__ A, int64_t
 __device__ __forceinline__ void gram_stash(double *panel, int tid, const v2d (&reg)[4]) {
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
-    const int idx = tid + u * IPX_BLOCK;
-    const int r = idx >> 4, c = (idx & 15) * 2;
-    *reinterpret_cast<v2d *>(panel + r * GP + c) = reg[u];
+    int r, t;
+    gram_slot(tid, u, r, t);                      // columns 2t, 2t + 1 = 8 j + 2 lk + {0, 1}
+    const int j = t >> 2, lk = t & 3;
+    *reinterpret_cast<v2d *>(panel + lk * GSUB + r * GSP + 2 * j) = reg[u];
   }
 }
 
 template <bool VEC>
 __global__ void __launch_bounds__(IPX_BLOCK)
 k_gram_mfma(int m, int n, const double *__restrict__ A, int64_t lda, double *__restrict__ G,
-            int M, int ntile) {
-  __shared__ __attribute__((aligned(16))) double sA[GT * GP];
-  __shared__ __attribute__((aligned(16))) double sB[GT * GP];
-  // linear block index -> (ti, tj) with tj <= ti
-  int ti = (int)((sqrt(8.0 * blockIdx.x + 1.0) - 1.0) * 0.5);
-  while ((ti + 1) * (ti + 2) / 2 <= (int)blockIdx.x) ++ti;
-  while (ti * (ti + 1) / 2 > (int)blockIdx.x) --ti;
-  const int tj = (int)blockIdx.x - ti * (ti + 1) / 2;
+            int M, int ntile, int splits, double *__restrict__ ws) {
+  __shared__ __attribute__((aligned(16))) double sA[GPANEL];
+  __shared__ __attribute__((aligned(16))) double sB[GPANEL];
+  // splits > 1: this workgroup sums over the K-chunks [kc0, kc1) only and leaves its 64 x 64
+  // partial tile in ws; k_gram_reduce adds the splits in a fixed order.  (528 tiles on 256
+  // CUs leave 16 CUs with one workgroup more than the rest: 1.30 ms against 1.01 ms for
+  // 496 tiles; finer units balance.)
+  const int ntri = ntile * (ntile + 1) / 2;
+  const int tile = (int)blockIdx.x % ntri, split = (int)blockIdx.x / ntri;
+  // linear tile index -> (ti, tj) with tj <= ti
+  int ti = (int)((sqrt(8.0 * tile + 1.0) - 1.0) * 0.5);
+  while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
+  while (ti * (ti + 1) / 2 > tile) --ti;
+  const int tj = tile - ti * (ti + 1) / 2;
   if (ti >= ntile) return;
+  const int nchunk = (n + GK - 1) / GK;
+  const int kbeg = (int)((int64_t)split * nchunk / splits) * GK;
+  const int kend = min(n, (int)((int64_t)(split + 1) * nchunk / splits) * GK);
   const bool diag = ti == tj;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
@@ -147,29 +188,46 @@ k_gram_mfma(int m, int n, const double *__restrict__ A, int64_t lda, double *__r
 #pragma unroll
     for (int b = 0; b < 2; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
   v2d ra[4], rb[4];
-  gram_fetch<VEC>(A, lda, m, n, ti * GT, 0, tid, ra);
-  if (!diag) gram_fetch<VEC>(A, lda, m, n, tj * GT, 0, tid, rb);
+  gram_fetch<VEC>(A, lda, m, n, ti * GT, kbeg, tid, ra);
+  if (!diag) gram_fetch<VEC>(A, lda, m, n, tj * GT, kbeg, tid, rb);
   const double *pB = diag ? sA : sB;
-  for (int k0 = 0; k0 < n; k0 += GK) {
+  for (int k0 = kbeg; k0 < kend; k0 += GK) {
     gram_stash(sA, tid, ra);
     if (!diag) gram_stash(sB, tid, rb);
     __syncthreads();
-    if (k0 + GK < n) {                       // next chunk's loads fly during the MFMAs
+    if (k0 + GK < kend) {                    // next chunk's loads fly during the MFMAs
       gram_fetch<VEC>(A, lda, m, n, ti * GT, k0 + GK, tid, ra);
       if (!diag) gram_fetch<VEC>(A, lda, m, n, tj * GT, k0 + GK, tid, rb);
     }
+    const double *qa = sA + lk * GSUB + (wr + lr) * GSP;
+    const double *qb = pB + lk * GSUB + (wc + lr) * GSP;
 #pragma unroll
-    for (int kk = 0; kk < GK; kk += 4) {
-      const double a0 = sA[(wr + lr) * GP + kk + lk];
-      const double a1 = sA[(wr + 16 + lr) * GP + kk + lk];
-      const double b0 = pB[(wc + lr) * GP + kk + lk];
-      const double b1 = pB[(wc + 16 + lr) * GP + kk + lk];
-      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+    for (int j = 0; j < GK / 8; ++j) {
+      const v2d a0 = *reinterpret_cast<const v2d *>(qa + 2 * j);
+      const v2d a1 = *reinterpret_cast<const v2d *>(qa + 16 * GSP + 2 * j);
+      const v2d b0 = *reinterpret_cast<const v2d *>(qb + 2 * j);
+      const v2d b1 = *reinterpret_cast<const v2d *>(qb + 16 * GSP + 2 * j);
+      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.x, b0.x, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.x, b1.x, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.x, b0.x, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.x, b1.x, acc[1][1], 0, 0, 0);
+      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.y, b0.y, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.y, b1.y, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.y, b0.y, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.y, b1.y, acc[1][1], 0, 0, 0);
     }
     __syncthreads();
+  }
+  if (splits > 1) {
+    double *out = ws + ((int64_t)split * ntri + tile) * (GT * GT);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg)
+          out[(wr + 16 * a + lk + 4 * reg) * GT + wc + 16 * b + lr] = acc[a][b][reg];
+    return;
   }
 #pragma unroll
   for (int a = 0; a < 2; ++a) {
@@ -187,6 +245,27 @@ k_gram_mfma(int m, int n, const double *__restrict__ A, int64_t lda, double *__r
       }
     }
   }
+}
+
+// Sum of the K-splits' partial tiles (split order: deterministic), lower triangle + mirror.
+__global__ void __launch_bounds__(IPX_BLOCK)
+k_gram_reduce(int m, int M, int ntile, int splits, const double *__restrict__ ws,
+              double *__restrict__ G) {
+  const int ntri = ntile * (ntile + 1) / 2;
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (int64_t)ntri * GT * GT) return;
+  const int tile = (int)(e / (GT * GT)), in = (int)(e % (GT * GT));
+  int ti = (int)((sqrt(8.0 * tile + 1.0) - 1.0) * 0.5);
+  while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
+  while (ti * (ti + 1) / 2 > tile) --ti;
+  const int tj = tile - ti * (ti + 1) / 2;
+  const int row = ti * GT + in / GT, col = tj * GT + in % GT;
+  if (row >= M || col >= M || col > row) return;
+  double v = 0.0;
+  for (int s = 0; s < splits; ++s) v += ws[((int64_t)s * ntri + tile) * (GT * GT) + in];
+  if (row >= m || col >= m) v = (row == col) ? 1.0 : 0.0;
+  G[(int64_t)row * M + col] = v;
+  G[(int64_t)col * M + row] = v;
 }
 
 // G = A A' for a CSR A whose A A' is not narrow-banded: one lane per (i, j <= i),
@@ -398,22 +477,69 @@ int ipx_dense_gemv(int64_t m, int64_t n, const double *A, int64_t lda, const dou
 int64_t ipx_dense_padded(int64_t m) { return ((m + NB - 1) / NB) * NB; }
 
 // G (M x M, M = ipx_dense_padded(m)) = A A' via fp64 MFMA.
-int ipx_gram_f64_mfma(int64_t m, int64_t n, const double *A, int64_t lda, double *G,
-                      void *stream) {
-  if (m < 1 || n < 0 || !A || !G || lda < n) return IPX_EINVAL;
+// K-splits that even out the load: with one split the tiles of the lower triangle are dealt
+// to the CUs whole (528 tiles at m = 2000: one CU in sixteen gets a third workgroup and the
+// launch lasts until it is done); S splits make S times as many, shorter units.  The
+// smallest S <= 8 whose busiest CU carries <= 6 % more than the average, 1 if the matrix is
+// too short to split.
+int ipx_gram_splits(int64_t m, int64_t n) {
   const int M = (int)ipx_dense_padded(m);
   const int nt = (M + GT - 1) / GT;
-  const dim3 grid(nt * (nt + 1) / 2), block(IPX_BLOCK);
+  const int64_t ntri = (int64_t)nt * (nt + 1) / 2;
+  int cus = 256;
+  {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess &&
+        p.multiProcessorCount > 0)
+      cus = p.multiProcessorCount;
+  }
+  const int64_t chunks = (n + GK - 1) / GK;
+  for (int s = 1; s <= 8; ++s) {
+    if (chunks / s < 16) break;
+    const int64_t units = ntri * s;
+    const int64_t busiest = (units + cus - 1) / cus;
+    if ((double)busiest * cus <= 1.06 * (double)units) return s;
+  }
+  return 1;
+}
+
+int64_t ipx_gram_ws_doubles(int64_t m, int32_t splits) {
+  if (splits <= 1) return 0;
+  const int M = (int)ipx_dense_padded(m);
+  const int64_t nt = (M + GT - 1) / GT;
+  return (int64_t)splits * (nt * (nt + 1) / 2) * GT * GT;
+}
+
+// ws: ipx_gram_ws_doubles(m, splits) doubles of scratch (NULL with splits <= 1).
+int ipx_gram_f64_mfma_split(int64_t m, int64_t n, const double *A, int64_t lda, double *G,
+                            double *ws, int32_t splits, void *stream) {
+  if (m < 1 || n < 0 || !A || !G || lda < n || splits < 1 || (splits > 1 && !ws)) return IPX_EINVAL;
+  const int M = (int)ipx_dense_padded(m);
+  const int nt = (M + GT - 1) / GT;
+  const int ntri = nt * (nt + 1) / 2;
+  const dim3 grid(ntri * splits), block(IPX_BLOCK);
   // 16-byte loads need every row start 16-byte aligned
   const bool vec = (lda % 2 == 0) && (((uintptr_t)A) % 16 == 0);
   if (vec)
     hipLaunchKernelGGL(k_gram_mfma<true>, grid, block, 0, (hipStream_t)stream, (int)m, (int)n, A,
-                       lda, G, M, nt);
+                       lda, G, M, nt, (int)splits, ws);
   else
     hipLaunchKernelGGL(k_gram_mfma<false>, grid, block, 0, (hipStream_t)stream, (int)m, (int)n, A,
-                       lda, G, M, nt);
+                       lda, G, M, nt, (int)splits, ws);
   IPX_CHECK_LAUNCH();
+  if (splits > 1) {
+    const int64_t tot = (int64_t)ntri * GT * GT;
+    hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)((tot + IPX_BLOCK - 1) / IPX_BLOCK)),
+                       dim3(IPX_BLOCK), 0, (hipStream_t)stream, (int)m, M, nt, (int)splits, ws, G);
+    IPX_CHECK_LAUNCH();
+  }
   return IPX_OK;
+}
+
+int ipx_gram_f64_mfma(int64_t m, int64_t n, const double *A, int64_t lda, double *G,
+                      void *stream) {
+  return ipx_gram_f64_mfma_split(m, n, A, lda, G, nullptr, 1, stream);
 }
 
 // G (M x M padded) = A A' for CSR A (dense fallback of the sparse path).

@@ -31,6 +31,8 @@ _SIGNATURES = {
     "ipx_sum_log": [_I64, _P, _P, _P, _P],
     "ipx_dense_gemv": [_I64, _I64, _P, _I64, _P, _F64, _P, _F64, _P, _P, _P, _P, _P],
     "ipx_gram_f64_mfma": [_I64, _I64, _P, _I64, _P, _P],
+    "ipx_gram_splits": [_I64, _I64],
+    "ipx_gram_f64_mfma_split": [_I64, _I64, _P, _I64, _P, _P, _I32, _P],
     "ipx_aat_dense": [_I64, _P, _P, _P, _P, _P],
     "ipx_chol_factor": [_I64, _P, _P, _P, _P],
     "ipx_chol_inverse": [_I64, _P, _P, _P],
@@ -87,10 +89,11 @@ _SIGNATURES = {
 }
 _RESTYPES = {"ipx_version": _c.c_char_p, "ipx_last_error": _c.c_char_p,
              "ipx_banded_create": _P, "ipx_banded_destroy": None,
-             "ipx_dense_padded": _I64, "ipx_peer_create": _P, "ipx_peer_destroy": None,
+             "ipx_dense_padded": _I64, "ipx_gram_ws_doubles": _I64, "ipx_peer_create": _P, "ipx_peer_destroy": None,
              "ipx_peer_halo_capacity": _I64}
 _EXTRA_ARGTYPES = {"ipx_banded_create": [_I64, _I32, _I32], "ipx_banded_destroy": [_P],
-                   "ipx_dense_padded": [_I64], "ipx_peer_create": [_I32, _I32, _I64],
+                   "ipx_dense_padded": [_I64], "ipx_gram_ws_doubles": [_I64, _I32],
+                   "ipx_peer_create": [_I32, _I32, _I64],
                    "ipx_peer_destroy": [_P], "ipx_peer_halo_capacity": [_P]}
 
 _lib = None

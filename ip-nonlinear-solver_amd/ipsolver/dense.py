@@ -100,7 +100,10 @@ class DenseNormalSolver:
         flag = torch.zeros(1, dtype=torch.int32, device=dev)
         st = stream_ptr()
         if isinstance(A, DeviceDense):
-            _hip.call("ipx_gram_f64_mfma", m, n, _p(A.t), n, _p(G), st)
+            splits = int(lib.ipx_gram_splits(m, n))
+            ws = torch.empty(int(lib.ipx_gram_ws_doubles(m, splits)), dtype=_F64, device=dev) \
+                if splits > 1 else None
+            _hip.call("ipx_gram_f64_mfma_split", m, n, _p(A.t), n, _p(G), _p(ws), splits, st)
         else:
             p = A.pattern
             _hip.call("ipx_aat_dense", m, _p(p.indptr), _p(p.indices), _p(A.val), _p(G), st)

@@ -32,10 +32,22 @@ def timed(fn, reps=5):
 
 
 out = {"m": m, "n": n, "M": M}
-t = timed(lambda: _hip.call("ipx_gram_f64_mfma", m, n, dv._p(A.t), n, dv._p(G), st))
-out["gram_ms"] = t
-out["gram_TFs_full"] = 2.0 * m * m * n / (t * 1e-3) / 1e12          # counting the full product
-out["gram_TFs_computed"] = out["gram_TFs_full"] * (M // 16 + 1) / (2 * (M // 16))   # lower triangle of tiles
+nt = (M + 63) // 64
+flop = nt * (nt + 1) // 2 * 2.0 * 64 * 64 * n          # executed: tiles on / below the diagonal
+auto = int(lib.ipx_gram_splits(m, n))
+out["gram_splits_auto"] = auto
+out["gram_ms_by_splits"] = {}
+for S in sorted({1, 2, 3, 4, 5, 6, 8, auto}):
+    ws = torch.empty(max(int(lib.ipx_gram_ws_doubles(m, S)), 1), dtype=torch.float64, device="cuda")
+    t = timed(lambda: _hip.call("ipx_gram_f64_mfma_split", m, n, dv._p(A.t), n, dv._p(G),
+                                dv._p(ws), S, st))
+    out["gram_ms_by_splits"][S] = t
+    if S == auto:
+        out["gram_ms"] = t
+        out["gram_TFs_executed"] = flop / (t * 1e-3) / 1e12
+        out["gram_frac_of_78.6TF"] = out["gram_TFs_executed"] / 78.6
+ws = torch.empty(max(int(lib.ipx_gram_ws_doubles(m, auto)), 1), dtype=torch.float64, device="cuda")
+_hip.call("ipx_gram_f64_mfma_split", m, n, dv._p(A.t), n, dv._p(G), dv._p(ws), auto, st)
 Gh = G.cpu().numpy()[:m, :m]
 ref = A_h @ A_h.T
 out["gram_rel_err"] = float(np.max(np.abs(Gh - ref)) / np.max(np.abs(ref)))
