@@ -39,6 +39,11 @@ def copy(v):
     return v.copy()
 
 
+def pack():
+    """Scalar pack: enqueue norms / dot products, read them back together."""
+    return dv.ScalarPack()
+
+
 def dot(a, b):
     return a.dot(b)
 

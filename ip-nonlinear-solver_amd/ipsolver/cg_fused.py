@@ -453,7 +453,7 @@ class _Loop:
 
 
 def projected_cg(H, c, Z, Y, b, trust_radius=np.inf, lb=None, ub=None, tol=None,
-                 max_iter=None, max_infeasible_iter=None, batch=None, stats=None):
+                 max_iter=None, max_infeasible_iter=None, batch=None, stats=None, b_zero=False):
     from . import qp
     lib = _hip.load()
     P = Z.projector
@@ -465,11 +465,18 @@ def projected_cg(H, c, Z, Y, b, trust_radius=np.inf, lb=None, ub=None, tol=None,
         ub = ub if ub is not None else DVec.full(n, np.inf)
 
     # ---- initial point, residual, direction (qp_subproblem.py:502-512)
-    x0 = Y.dot(-b)
-    r0 = Z.dot(H.dot(x0) + c)
+    if b_zero:
+        # b = 0 by construction (the SQP's call): x0 = Y.dot(-0) = 0, H.dot(0) + c = c
+        x0 = DVec.zeros(n)
+        r0 = Z.dot(c)
+        norm_x0 = 0.0
+    else:
+        x0 = Y.dot(-b)
+        r0 = Z.dot(H.dot(x0) + c)
+        norm_x0 = None
     g0 = Z.dot(r0)
     rt_g = g0.sumsq_amax()[0]            # norm(g)**2
-    tr_distance = trust_radius - dv.norm(x0)
+    tr_distance = trust_radius - (dv.norm(x0) if norm_x0 is None else norm_x0)
     if tr_distance < 0:
         raise ValueError("Trust region problem does not have a solution.")
     if tr_distance < _TINY:
@@ -570,8 +577,8 @@ def projected_cg(H, c, Z, Y, b, trust_radius=np.inf, lb=None, ub=None, tol=None,
                 break
             mode = 1
             # the orthogonality check has not run yet for this iteration
-            s2 = _resume(lib, L, it_stop, mode, st)
-            if int(s2[ST_STOP]) == 6:
+            s = _resume(lib, L, it_stop, mode, st)
+            if int(s[ST_STOP]) == 6:
                 stop, mode = 6, 1
             else:
                 it = it_stop + 1
@@ -579,7 +586,7 @@ def projected_cg(H, c, Z, Y, b, trust_radius=np.inf, lb=None, ub=None, tol=None,
         if stop == 6:                     # projections.py:72-78 refinement
             STATS["refine_events"] += 1
             _refine(P, L, R)
-            s2 = _resume(lib, L, it_stop, mode | 2, st)
+            s = _resume(lib, L, it_stop, mode | 2, st)
             it = it_stop + 1
             continue
         raise _hip.IpxError("unexpected CG stop code %d" % stop)
@@ -588,7 +595,8 @@ def projected_cg(H, c, Z, Y, b, trust_radius=np.inf, lb=None, ub=None, tol=None,
     if has_box and not qp.inside_box_boundaries(x, lb, ub):     # :636-638
         x = last_feasible_x
         hits_boundary = True
-    niter = int(L.state[ST_NITER].item())
+    # (the state block read last is current: nothing was enqueued after it on every exit)
+    niter = int(s[ST_NITER]) if max_iter > 0 else 0
     STATS["calls"] += 1
     STATS["iterations"] += niter
     return x, {'niter': niter, 'stop_cond': stop_cond, 'hits_boundary': hits_boundary}

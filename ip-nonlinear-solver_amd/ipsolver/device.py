@@ -24,6 +24,9 @@ def _require_gpu():
                             "is GPU-only (there is no CPU fallback)")
 
 
+PACK_SLOTS = 128
+
+
 class _Context:
     """Per-process scratch: reduction workspace and scalar read-back slots."""
     _inst = None
@@ -33,7 +36,7 @@ class _Context:
         _hip.load()
         self.device = torch.device("cuda", torch.cuda.current_device())
         self.ws = torch.empty(_hip.WS_DOUBLES, dtype=_F64, device=self.device)
-        self.out = torch.zeros(16, dtype=_F64, device=self.device)
+        self.out = torch.zeros(PACK_SLOTS, dtype=_F64, device=self.device)
 
     @classmethod
     def get(cls):
@@ -182,6 +185,63 @@ class DVec:
         c = ctx()
         _hip.call("ipx_norms", len(self), _p(self.t), _p(c.out), _p(c.ws), stream_ptr())
         return _read(2)
+
+
+class ScalarPack:
+    """Reductions enqueued into consecutive slots of the context's output block and read back
+    TOGETHER: one blocking D2H copy serves a whole decision point of the outer loops (the
+    reference reads every norm / dot product as it goes: equality_constrained_sqp.py:138-169).
+    ``dot`` / ``norm`` / ``norm_inf`` return a handle; ``read()`` returns the values, each
+    computed exactly as the unpacked ``DVec.dot`` / ``norm`` / ``norm_inf`` would."""
+
+    def __init__(self):
+        self.c = ctx()
+        self.k = 0
+        self.how = []          # per handle: (slot or None, post-processing)
+
+    def _slot(self, n):
+        base = self.k
+        self.k += n
+        if self.k > PACK_SLOTS:
+            raise _hip.IpxError("ScalarPack: more than %d slots" % PACK_SLOTS)
+        return ctypes.c_void_p(self.c.out.data_ptr() + 8 * base), base
+
+    def dot(self, a, b):
+        if len(a) == 0:
+            self.how.append((None, None))
+        else:
+            ptr, base = self._slot(1)
+            _hip.call("ipx_dot", len(a), _p(a.t), _p(b.t), ptr, _p(self.c.ws), stream_ptr())
+            self.how.append((base, None))
+        return len(self.how) - 1
+
+    def _norms(self, v, which):
+        if len(v) == 0:
+            self.how.append((None, None))
+        else:
+            ptr, base = self._slot(2)
+            _hip.call("ipx_norms", len(v), _p(v.t), ptr, _p(self.c.ws), stream_ptr())
+            self.how.append((base + which, "sqrt" if which == 0 else None))
+        return len(self.how) - 1
+
+    def norm(self, v):
+        return self._norms(v, 0)
+
+    def norm_inf(self, v):
+        return self._norms(v, 1)
+
+    def sumsq(self, v):
+        h = self._norms(v, 0)
+        self.how[h] = (self.how[h][0], None)
+        return h
+
+    def read(self):
+        vals = self.c.out[:self.k].tolist() if self.k else []
+        out = []
+        for slot, post in self.how:
+            v = 0.0 if slot is None else vals[slot]
+            out.append(float(np.sqrt(v)) if post == "sqrt" else v)
+        return out
 
 
 def norm(v):

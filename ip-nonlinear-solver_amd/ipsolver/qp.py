@@ -127,16 +127,22 @@ def _full(n, value):
     return DVec.full(n, value)
 
 
-def modified_dogleg(A, Y, b, trust_radius, lb, ub):
-    """Reference: qp_subproblem.py:320-413."""
+def modified_dogleg(A, Y, b, trust_radius, lb, ub, norm_out=None):
+    """Reference: qp_subproblem.py:320-413.  ``norm_out`` (extension: a list) receives the
+    norm of the returned step when the routine has it anyway (the accepted Newton point), so
+    the caller need not read it back a second time."""
     b = _vec(b)
     lb, ub = _optvec(lb), _optvec(ub)       # None = no bound on that side
     newton = -Y.dot(b)
     if (lb is None) != (ub is None):
         lb = lb if lb is not None else newton.full_like(-_INF)
         ub = ub if ub is not None else newton.full_like(_INF)
-    if inside_box_boundaries(newton, lb, ub) and dv.norm(newton) <= trust_radius:
-        return newton
+    if inside_box_boundaries(newton, lb, ub):
+        norm_newton = dv.norm(newton)
+        if norm_newton <= trust_radius:
+            if norm_out is not None:
+                norm_out.append(norm_newton)
+            return newton
 
     g = A.T.dot(b)
     Ag = A.dot(g)
@@ -161,13 +167,21 @@ def modified_dogleg(A, Y, b, trust_radius, lb, ub):
 
 def projected_cg(H, c, Z, Y, b, trust_radius=np.inf, lb=None, ub=None, tol=None,
                  max_iter=None, max_infeasible_iter=None, return_all=False):
-    """Reference: qp_subproblem.py:416-643 (same stop codes and info dict)."""
+    """Reference: qp_subproblem.py:416-643 (same stop codes and info dict).  ``b=None``
+    (extension) stands for b = 0, the SQP's call (equality_constrained_sqp.py:126): the
+    starting point ``Y.dot(-b)`` is then the zero vector by construction and its solve, its
+    Hessian product and its norm are not formed (same values: 0, and 0 + c = c exactly)."""
     from . import cg_fused
-    c, b = _vec(c), _vec(b)
+    b_zero = b is None
+    c = _vec(c)
+    if b_zero:
+        P = getattr(Z, "projector", None)
+        b = P.sh.zeros(P.A.row_kind) if hasattr(P, "sh") else DVec.zeros(Y.shape[1])
+    b = _vec(b)
     lb, ub = _optvec(lb), _optvec(ub)
     if not return_all and cg_fused.supports(H, Z, Y):
         return cg_fused.projected_cg(H, c, Z, Y, b, trust_radius, lb, ub, tol,
-                                     max_iter, max_infeasible_iter)
+                                     max_iter, max_infeasible_iter, b_zero=b_zero)
     if not return_all and getattr(getattr(Z, "projector", None), "fused_sharded", False):
         from . import sharded            # the device-resident loop of the row-sharded solver
         if sharded.fused_supports(H, Z, Y):

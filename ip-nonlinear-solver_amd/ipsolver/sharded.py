@@ -457,6 +457,9 @@ class HipOps:
     def rmatvec(self, A, v):
         return A.T.dot(v)
 
+    def pack(self):
+        return self.dv.ScalarPack()
+
     def hessian(self, n, H_csr, diag):
         from .operators import DeviceHessian
         return DeviceHessian(n, csr=H_csr, diag=diag)
@@ -1381,6 +1384,60 @@ class BoxInequalityJacobian:
         self.J_nl = J_nl
 
 
+class _ShardPack:
+    """Scalar pack over distributed vectors: the local parts of every quantity are enqueued
+    into ONE local pack (one blocking read), then summed / maximised over the ranks in ONE
+    collective -- instead of a read and a collective per norm or dot product."""
+
+    def __init__(self, sh):
+        self.sh, self.loc = sh, sh.ops.pack()
+        self.items = []            # per handle: ("sum" | "max" | "zero", local handles, sqrt?)
+
+    def dot(self, a, b):
+        if not len(a):
+            self.items.append(("zero", [], False))
+        else:
+            self.items.append(("sum", [self.loc.dot(x, y) for x, y in zip(a.owns(), b.owns())
+                                       if len(x)], False))
+        return len(self.items) - 1
+
+    def norm(self, v):
+        if not len(v):
+            self.items.append(("zero", [], False))
+        else:
+            self.items.append(("sum", [self.loc.sumsq(x) for x in v.owns() if len(x)], True))
+        return len(self.items) - 1
+
+    def norm_inf(self, v):
+        if not len(v):
+            self.items.append(("zero", [], False))
+        else:
+            self.items.append(("max", [self.loc.norm_inf(x) for x in v.owns() if len(x)], False))
+        return len(self.items) - 1
+
+    def read(self):
+        vals = self.loc.read()
+        sums, maxs = [], []
+        for kind, hs, _ in self.items:
+            if kind == "sum":
+                sums.append(sum(vals[h] for h in hs))
+            elif kind == "max":
+                maxs.append(max([vals[h] for h in hs] + [0.0]))
+        if self.sh.comm.world > 1 and (sums or maxs):
+            sums, maxs, _ = self.sh.comm.reduce_mixed(sums, maxs)
+        out, si, mi = [], 0, 0
+        for kind, _, root in self.items:
+            if kind == "sum":
+                out.append(float(np.sqrt(sums[si])) if root else sums[si])
+                si += 1
+            elif kind == "max":
+                out.append(maxs[mi])
+                mi += 1
+            else:
+                out.append(0.0)
+        return out
+
+
 class ShardedBackend:
     """The vector / matrix / operator factory ``sqp.py`` and ``barrier.py`` are written
     against (cf. backend_hip), for one sharded problem: every vector is a ``ShardVec``, the
@@ -1422,6 +1479,9 @@ class ShardedBackend:
 
     def copy(self, v):
         return v.copy()
+
+    def pack(self):
+        return _ShardPack(self.sh)
 
     def hstack(self, parts):
         parts = [p for p in parts if len(p)]
@@ -1562,9 +1622,9 @@ class ShardedBackend:
     def projections(self, A, method=None):
         return projections(A, method)
 
-    def modified_dogleg(self, A, Y, b, trust_radius, lb, ub):
+    def modified_dogleg(self, A, Y, b, trust_radius, lb, ub, norm_out=None):
         from . import qp
-        return qp.modified_dogleg(A, Y, b, trust_radius, lb, ub)
+        return qp.modified_dogleg(A, Y, b, trust_radius, lb, ub, norm_out)
 
     def projected_cg(self, H, c, Z, Y, b, trust_radius, lb, ub):
         from . import qp

@@ -45,6 +45,29 @@ dot = np.dot
 norm = np.linalg.norm
 
 
+class pack:
+    """Host twin of ipsolver.device.ScalarPack (values are immediate here)."""
+
+    def __init__(self):
+        self.vals = []
+
+    def _add(self, v):
+        self.vals.append(float(v))
+        return len(self.vals) - 1
+
+    def dot(self, a, b):
+        return self._add(np.dot(a, b) if len(a) else 0.0)
+
+    def norm(self, v):
+        return self._add(np.linalg.norm(v) if len(v) else 0.0)
+
+    def norm_inf(self, v):
+        return self._add(np.linalg.norm(v, np.inf) if len(v) else 0.0)
+
+    def read(self):
+        return list(self.vals)
+
+
 def norm_inf(v):
     return np.linalg.norm(v, np.inf)
 
@@ -120,13 +143,15 @@ def _bounds(n, lb, ub):
             np.full(n, np.inf) if ub is None else ub)
 
 
-def modified_dogleg(A, Y, b, trust_radius, lb, ub):
+def modified_dogleg(A, Y, b, trust_radius, lb, ub, norm_out=None):
     lb, ub = _bounds(np.shape(A)[1], lb, ub)
     return _qp.modified_dogleg(A, Y, b, trust_radius, lb, ub)
 
 
 def projected_cg(H, c, Z, Y, b, trust_radius, lb, ub):
     lb, ub = _bounds(len(c), lb, ub)
+    if b is None:                      # the SQP's b_t = 0 (equality_constrained_sqp.py:126)
+        b = np.zeros(Y.shape[1])
     return _qp.projected_cg(H, c, Z, Y, b, trust_radius, lb, ub)
 
 

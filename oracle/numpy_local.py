@@ -41,9 +41,35 @@ class _LocalSolver:
         return self.lu.solve(w)
 
 
+class _LocalPack:
+    """Twin of ipsolver.device.ScalarPack on numpy arrays (immediate values)."""
+
+    def __init__(self):
+        self.vals = []
+
+    def _add(self, v):
+        self.vals.append(float(v))
+        return len(self.vals) - 1
+
+    def dot(self, a, b):
+        return self._add(a.dot(b))
+
+    def sumsq(self, v):
+        return self._add(v.dot(v))
+
+    def norm_inf(self, v):
+        return self._add(np.abs(v).max() if len(v) else 0.0)
+
+    def read(self):
+        return list(self.vals)
+
+
 class NumpyOps:
     name = "numpy-oracle"
     fused = False
+
+    def pack(self):
+        return _LocalPack()
 
     def from_host(self, a):
         return np.array(a, dtype=np.float64)
