@@ -251,6 +251,9 @@ def ell_rows(At):
     ``[t * n + j]`` (csrc/banded.hip reads pairs of rows with 16-byte loads: n must be even
     -- asserted by the caller -- and the buffers 16-byte aligned, which torch's are).  The column table and the gather map are symbolic (cached on the
     pattern); the values are one gather per call."""
+    done = getattr(At, "_ipx_ell_done", None)        # same matrix object: same values
+    if done is not None:
+        return done
     pat = At.pattern
     cache = getattr(pat, "_ipx_ell2", None)
     if cache is None:
@@ -270,6 +273,7 @@ def ell_rows(At):
     col, src, mask = cache
     val = torch.empty(src.numel(), dtype=torch.float64, device=col.device)
     _hip.call("ipx_gather", src.numel(), _p(At.val), _p(src), _p(mask), None, _p(val), stream_ptr())
+    At._ipx_ell_done = (col, val)
     return col, val
 
 
@@ -307,11 +311,83 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
+_POOL = {}          # signature -> idle _Loop (buffers + argument block), see _loop_for
+POOL_STATS = {"built": 0, "reused": 0}
+
+
+def _signature(H, P, lb, ub):
+    """What a pooled loop object must share with a new call to be reused: the sparsity
+    patterns (tiles, fused-kernel tables and every buffer size follow from them), the kind of
+    solver and which optional operands exist.  None: this call is not pooled."""
+    from .dense import DeviceDense
+    if isinstance(P.A, DeviceDense):
+        return None
+    Hc, Hd = _hessian_parts(H)
+    flags = tuple(bool(os.environ.get(k)) for k in ("IPX_NO_FUSE", "IPX_NO_C16", "IPX_FUSE_TN",
+                                                    "IPX_TAIL_MAXWG"))
+    return (id(Hc.pattern), Hd is None, id(P.A.pattern), lb is None, ub is None,
+            _solver_kind(P.solver), int(getattr(P.solver, "k", 0)), flags)
+
+
+def _loop_for(H, P, lb, ub):
+    """A loop object for this call: an idle one built for the same patterns with its value
+    pointers re-bound (a projected_cg call otherwise allocates ~15 device buffers and rebuilds
+    the argument block: ~0.15 ms, as much as the kernels of a short solve), else a new one."""
+    key = _signature(H, P, lb, ub)
+    L = _POOL.pop(key, None) if key is not None else None
+    if L is not None and L.rebind(H, P, lb, ub):
+        POOL_STATS["reused"] += 1
+        return L, key
+    POOL_STATS["built"] += 1
+    return _Loop(H, P, lb, ub), key
+
+
+def _release(L, key):
+    """Park the loop object for the next call on the same patterns; the iterate it returned
+    stays the caller's (a fresh buffer takes its place)."""
+    if key is None:
+        return
+    if len(_POOL) >= 4:
+        _POOL.pop(next(iter(_POOL)))
+    _POOL[key] = L
+
+
 class _Loop:
     """Buffers + argument block for one projected_cg call."""
 
+    def rebind(self, H, P, lb, ub):
+        """Point the argument block at the values of a new call on the same patterns.  False
+        when the new factorization takes another solve path than the one the block was laid
+        out for (the decoupling is numerical): the caller then builds a new object."""
+        lib = _hip.load()
+        a = self.args
+        A = P.A
+        At = A.T
+        Hc, Hd = _hessian_parts(H)
+        if a.solver_kind == 0:
+            geo = (ctypes.c_int32 * 2)()
+            ok = bool(lib.ipx_banded_decoupled_geometry(ctypes.c_void_p(P.solver.handle), geo))
+            if (ok, geo[0], geo[1]) != self.geometry:
+                return False
+            a.banded = ctypes.c_void_p(P.solver.handle)
+        else:
+            a.banded = ctypes.cast(ctypes.pointer(P.solver.c_args()), ctypes.c_void_p)
+        a.A_val, a.At_val, a.H_val = _ptr(A.val), _ptr(At.val), _ptr(Hc.val)
+        a.H_diag = _ptr(Hd.t) if Hd is not None else None
+        a.lb = _ptr(lb.t) if lb is not None else None
+        a.ub = _ptr(ub.t) if ub is not None else None
+        if a.At_ell_val:
+            self.ell_col, self.ell_val = ell_rows(At)
+            a.At_ell_col, a.At_ell_val = _ptr(self.ell_col), _ptr(self.ell_val)
+        a.no_radius = 0
+        self.x = torch.empty(self.n, dtype=torch.float64, device=self.state.device)
+        a.x = _ptr(self.x)
+        self.keep = (A, At, Hc, Hd, lb, ub, P)
+        return True
+
     def __init__(self, H, P, lb, ub):
         from .dense import DeviceDense
+        self.geometry = None
         if isinstance(P.A, DeviceDense):
             self._init_dense(H, P, lb, ub)
             return
@@ -394,8 +470,9 @@ class _Loop:
             # (round 1's chunk-recurrence solve streamed better with a separate SpMV beyond 512
             # workgroups; with the cyclic-reduction solve the fused tail wins there too: 7.47 vs
             # 7.14 k it/s at n = 4e6.  IPX_TAIL_MAXWG restores a limit for A/B runs.)
-            if lib.ipx_banded_decoupled_geometry(ctypes.c_void_p(P.solver.handle), geo) \
-                    and geo[1] <= int(os.environ.get("IPX_TAIL_MAXWG", "1000000000")):
+            ok = bool(lib.ipx_banded_decoupled_geometry(ctypes.c_void_p(P.solver.handle), geo))
+            self.geometry = (ok, geo[0], geo[1])
+            if ok and geo[1] <= int(os.environ.get("IPX_TAIL_MAXWG", "1000000000")):
                 kS = int(getattr(P.solver, "k", 1))
                 vown = fuse_vown(At.pattern, geo[0], geo[1], kS) if kS <= 4 else None
                 if vown is not None:
@@ -491,7 +568,7 @@ def projected_cg(H, c, Z, Y, b, trust_radius=np.inf, lb=None, ub=None, tol=None,
         max_infeasible_iter = n - m
 
     # (no upper bounds given: the loop's kernels do not read a vector of +inf)
-    L = _Loop(H, P, lb if has_box else None, ub if has_box and ub_given else None)
+    L, pool_key = _loop_for(H, P, lb if has_box else None, ub if has_box and ub_given else None)
     # Unbounded trust region and no box (the reference's default trust_radius=np.inf): the
     # test norm(x_next) >= trust_radius of qp_subproblem.py:583 is always False, so the norm
     # is not formed (the fused step1 + A.r kernel then reads neither x nor p)
@@ -517,7 +594,10 @@ def projected_cg(H, c, Z, Y, b, trust_radius=np.inf, lb=None, ub=None, tol=None,
     last_viol_it = -2
     last_feasible_x = DVec.zeros(n)
     it = 0
-    nbatch = batch if batch else 2
+    # (batches 4, 8, ..., 64: a solve that meets its tolerance after 2-3 iterations -- the
+    # equality-constrained configs -- is read once; the iterations enqueued behind the stop
+    # are no-ops on the device)
+    nbatch = batch if batch else 4
     broke = False
     while it < max_iter:
         end = min(max_iter, it + nbatch)
@@ -599,6 +679,7 @@ def projected_cg(H, c, Z, Y, b, trust_radius=np.inf, lb=None, ub=None, tol=None,
     niter = int(s[ST_NITER]) if max_iter > 0 else 0
     STATS["calls"] += 1
     STATS["iterations"] += niter
+    _release(L, pool_key)
     return x, {'niter': niter, 'stop_cond': stop_cond, 'hits_boundary': hits_boundary}
 
 
