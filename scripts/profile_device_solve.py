@@ -47,3 +47,5 @@ print(s.getvalue()[:12000])
 s = io.StringIO()
 pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(25)
 print(s.getvalue()[:6000])
+from ipsolver import cg_fused
+print("loop pool:", cg_fused.POOL_STATS, "cg stats:", cg_fused.STATS)
