@@ -264,6 +264,18 @@ typedef struct ipx_cg_args {
    * tests of qp_subproblem.py:583,599 can never trigger): ||x + alpha p||^2 is not formed --
    * the fused step1 + A.r kernel then does not read x and p.  Only read when step1 is fused. */
   int64_t no_radius;
+  /* The whole projection step in ONE launch (csrc/banded.hip k_project_fused): step1, w = A r,
+   * the cyclic-reduction solve and g = r - A'v, for a tridiagonal A A' and a Jacobian whose
+   * rows all have A_rl entries, no box.  A_off16 = one uint16 per entry of A (column - first
+   * column of its row), A_rowfirst = one int per row, P_win = 2 ints per workgroup of the solve
+   * (first column / one past the last column of the span it needs: the columns of its window's
+   * rows and its own variables), P_nspan = the longest span (<= 4096); needs At_vown.  Any of
+   * them 0 / NULL: the separate launches. */
+  const void *A_off16;
+  const int32_t *A_rowfirst;
+  int64_t A_rl;
+  const int32_t *P_win;
+  int64_t P_nspan;
 } ipx_cg_args;
 int ipx_cg_state_size(void);
 int ipx_cg_vec_grid(int64_t n);

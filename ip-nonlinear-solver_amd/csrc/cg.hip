@@ -38,14 +38,7 @@
 #include <algorithm>
 #include <vector>
 
-// state block layout (doubles)
-enum {
-  ST_RTG0 = 0, ST_RTG1 = 1,   // rt_g, double buffered by iteration parity
-  ST_TOL = 2, ST_RADIUS = 3, ST_ALPHA = 4, ST_STOP = 5, ST_NITER = 6, ST_BETA = 7,
-  ST_PTHP = 8, ST_ORTH_RHS = 9,   // orth_tol * ||A||_F  (0 disables the check)
-  ST_XNORM2 = 10, ST_VIOL = 11, ST_ORTH = 12, ST_IT_DONE = 13,
-  ST_SIZE = 16
-};
+// (state block layout: ipx_common.h ST_*)
 
 namespace {
 
@@ -929,19 +922,31 @@ static bool box_project(const ipx_cg_args *a) {
 static bool fused_ar(const ipx_cg_args *a) {
   return a->r_next != nullptr && a->A_own != nullptr && a->A_span > 0 && !a->lb && a->m > 0;
 }
+// step1 + A.r + solve + g in one launch (csrc/banded.hip k_project_fused)
+static bool fused_project(const ipx_cg_args *a) {
+  return a->solver_kind == 0 && a->P_win != nullptr && a->A_off16 != nullptr &&
+         a->A_rowfirst != nullptr && a->A_rl > 0 && a->P_nspan > 0 && a->At_vown != nullptr &&
+         a->r_next != nullptr && !a->lb && a->m > 0;
+}
+// The fused projection reads r on spans that reach into other workgroups' variables, so g
+// cannot overwrite r in place: iteration `it` reads r from one of (a->r, a->r_next) and
+// leaves g in the other; the roles swap every iteration (the reference sets r = g, :632).
+static double *proj_r(const ipx_cg_args *a, int it) { return (it & 1) ? a->r_next : a->r; }
+static double *proj_g(const ipx_cg_args *a, int it) { return (it & 1) ? a->r : a->r_next; }
 // entries per half of part2: one per row tile of A (fused step1) or per vector chunk
 static int step1_box_blocks(const ipx_cg_args *a) {
   const ipx_boxschur_args *b = (const ipx_boxschur_args *)a->banded;
   const int64_t per = (int64_t)IPX_BLOCK * SB_ITEMS;
   return (int)((b->ng + b->ngen + per - 1) / per);
 }
-static int part2_count(const ipx_cg_args *a) {
-  if (box_project(a)) return step1_box_blocks(a);
-  return fused_ar(a) ? (int)a->A_ntiles : (int)a->vec_grid;
-}
 static int part4_count(const ipx_cg_args *a) {
   return a->m > 0 ? ipx_banded_resid_count(a->solver_kind == 1
                         ? ((const ipx_boxschur_args *)a->banded)->inner : a->banded) : 1;
+}
+static int part2_count(const ipx_cg_args *a) {
+  if (box_project(a)) return step1_box_blocks(a);
+  if (fused_project(a)) return part4_count(a);       // one per workgroup of the solve
+  return fused_ar(a) ? (int)a->A_ntiles : (int)a->vec_grid;
 }
 // entries per half of part3: one per row tile of A', or per workgroup of the solve when
 // g = r - A'v is its tail
@@ -988,13 +993,14 @@ static int launch_step1_ar(const ipx_cg_args *a, int it, const double *p1, int n
 // copies of parity it & 1 and leaves those of p_next in the other one.
 static int launch_step2_hp(const ipx_cg_args *a, int it, int mode, const double *p2, int np2,
                            const double *p3, int np3, const double *p4, int np4,
-                           hipStream_t st) {
+                           hipStream_t st, const double *g = nullptr) {
+  if (!g) g = a->r;
   const int64_t half = a->H_ntiles * 2 * a->H_hmax;
   const double *pb_in = a->pb + (it & 1) * half;
   double *pb_out = a->pb + ((it + 1) & 1) * half;
   const dim3 grid(ipx_xcd_grid((int)a->H_ntiles)), block(IPX_BLOCK);
 #define FUSED_ARGS                                                                            \
-  (int)a->n, a->state, it & 1, mode, p2, np2, p3, np3, p4, np4, a->x, a->p, a->r,             \
+  (int)a->n, a->state, it & 1, mode, p2, np2, p3, np3, p4, np4, a->x, a->p, g,                \
       a->H_rowptr, a->H_colidx, a->H_val, a->H_tiles,                                         \
       (int)a->H_ntiles, a->H_diag, a->Hp, a->part1, (int)a->H_hmax, pb_in, pb_out,           \
       (const uint16_t *)a->H_col16, a->H_rowlen
@@ -1278,7 +1284,7 @@ int ipx_cg_resume(const ipx_cg_args *a, int32_t it, int32_t mode, void *stream) 
   }
   hipLaunchKernelGGL(k_cg_step2, dim3(ipx_xcd_grid((int)a->vec_grid)), dim3(VB), 0, st, a->n,
                      a->state, it & 1, mode, a->part2, part2_count(a), a->part3, np3, a->part4,
-                     np4, a->x, a->p, a->r, (int)a->vec_grid);
+                     np4, a->x, a->p, fused_project(a) ? proj_g(a, it) : a->r, (int)a->vec_grid);
   IPX_CHECK_LAUNCH();
   return launch_hp(a, guard, st);
 }
@@ -1388,7 +1394,25 @@ static int cg_iterate(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, hi
     const bool no_xn2 = fuse1 && a->no_radius != 0;
     rc = cmp.launch(guard, st);
     if (rc) return rc;
-    if (fuse1) {
+    const bool proj = fused_project(a);
+    if (proj) {
+      // the whole projection step in one launch; a->r is read (r) and rewritten (g) by
+      // disjoint phases of different workgroups' spans: g goes to r_next, then the roles swap
+      MARK(1);
+      ipx_project_job job;
+      job.st = a->state; job.parity = it & 1; job.p1 = p1 + np1; job.np1 = np1; job.n = (int)a->n;
+      job.x = a->x; job.p = a->p; job.r = proj_r(a, it); job.Hp = a->Hp;
+      job.A_val = a->A_val; job.A_off16 = (const uint16_t *)a->A_off16;
+      job.A_rowfirst = a->A_rowfirst; job.rl = (int)a->A_rl; job.win = a->P_win;
+      job.vown = a->At_vown; job.v = a->v; job.g = proj_g(a, it);
+      job.part2 = a->part2; job.part3 = a->part3; job.part4 = a->part4;
+      job.no_xn2 = a->no_radius != 0; job.nspan = (int)a->P_nspan;
+      int nwg = 0;
+      rc = ipx_banded_project_fused_launch(a->banded, job, &nwg, st);
+      if (rc) return rc;
+      np4 = nwg;
+      MARK(2); MARK(3); MARK(4); MARK(5);
+    } else if (fuse1) {
       MARK(1);
       rc = launch_step1_ar(a, it, p1, np1, st, no_xn2);   // r_next = r + alpha Hp;  w = A r_next
       if (rc) return rc;
@@ -1410,7 +1434,9 @@ static int cg_iterate(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, hi
       IPX_CHECK_LAUNCH();
       MARK(1);
     }
-    if (a->m > 0 && box_project(a)) {
+    if (proj) {
+      np3 = np4;
+    } else if (a->m > 0 && box_project(a)) {
       // simple (box) rows eliminated analytically and never multiplied as matrix rows:
       // g = r - A'(A A')^-1 A r in one call (csrc/boxschur.hip ipx_boxschur_project)
       int32_t n3 = 0, n4 = 0;
@@ -1469,11 +1495,11 @@ static int cg_iterate(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, hi
     if (fused_hp(a)) {
       MARK(6);
       rc = launch_step2_hp(a, it, (a->m > 0 ? 0 : 2) | (no_xn2 ? 1 : 0), p2, np2,
-                           p3, np3, p4, n4, st);
+                           p3, np3, p4, n4, st, proj ? proj_g(a, it) : a->r);
     } else {
       hipLaunchKernelGGL(k_cg_step2, dim3(ipx_xcd_grid((int)a->vec_grid)), dim3(VB), 0, st, a->n,
                          a->state, it & 1, (a->m > 0 ? 0 : 2) | (no_xn2 ? 1 : 0), p2, np2, p3, np3,
-                         p4, n4, a->x, a->p, a->r, (int)a->vec_grid);
+                         p4, n4, a->x, a->p, proj ? proj_g(a, it) : a->r, (int)a->vec_grid);
       IPX_CHECK_LAUNCH();
       MARK(6);
       rc = launch_hp(a, guard, st);

@@ -397,6 +397,45 @@ __device__ __forceinline__ void ipx_group_w(const ipx_group_tab &T, int g, const
 #define IPX_STAMP_EXPORT(fn, name)
 #endif
 
+// ---- state block of the device-resident CG loop (doubles; csrc/cg.hip) -------------------
+enum {
+  ST_RTG0 = 0, ST_RTG1 = 1,   // rt_g, double buffered by iteration parity
+  ST_TOL = 2, ST_RADIUS = 3, ST_ALPHA = 4, ST_STOP = 5, ST_NITER = 6, ST_BETA = 7,
+  ST_PTHP = 8, ST_ORTH_RHS = 9,   // orth_tol * ||A||_F  (0 disables the check)
+  ST_XNORM2 = 10, ST_VIOL = 11, ST_ORTH = 12, ST_IT_DONE = 13,
+  ST_SIZE = 16
+};
+
+// ---- the whole projection step of an iteration in ONE launch (csrc/banded.hip
+// k_project_fused): step1 (alpha, r_next = r + alpha Hp, ||x + alpha p||^2), w = A r_next,
+// v = (A A')^-1 w by parallel cyclic reduction, g = r_next - A'v -- for a tridiagonal A A'
+// (cyclic-reduction solve) and a Jacobian whose rows all have `rl` entries.  Every workgroup of
+// the solve recomputes w on its window of rows (own rows + 2^L either side) from A's rows, so
+// w, r_next and A' (ELL) never travel through memory and A is read once for both products.
+struct ipx_project_job {
+  double *st;                 // CG state block
+  int parity;
+  const double *p1;           // p'Hp partials (np1 of them)
+  int np1;
+  int n;
+  const double *x, *p, *r, *Hp;
+  const double *A_val;        // CSR values, rows of rl entries each
+  const uint16_t *A_off16;    // per entry: column - first column of its row
+  const int32_t *A_rowfirst;  // per row: its first column
+  int rl;
+  const int32_t *win;         // per workgroup: first column, one past the last column of its span
+  const int32_t *vown;        // per workgroup (+1): first own variable
+  double *v, *g;              // own rows of the solve / own variables of g
+  double *part2, *part3, *part4;
+  int no_xn2;
+  int nspan;                  // longest span (doubles of LDS)
+};
+int ipx_banded_project_fused_launch(void *handle, const ipx_project_job &job, int *nwg,
+                                    hipStream_t st);
+// 1 when the handle's solve is the cyclic-reduction form the fused projection builds on;
+// geo[0] = rows per workgroup, geo[1] = workgroups, geo[2] = 2^L (halo rows either side)
+int ipx_banded_project_geometry(void *handle, int32_t *geo);
+
 // ---- internal (non-ABI) launchers shared between translation units --------
 struct ipx_csr_view {
   int nrows, ncols;

@@ -41,12 +41,14 @@ class CgArgs(ctypes.Structure):
         ("r_next", _P), ("A_own", _P), ("A_span", _I64), ("fold_ws", _P),
         ("At_vown", _P), ("At_qv", _I64), ("A_tile_nnz", _I64),
         ("At_ell_col", _P), ("At_ell_val", _P),
-        ("H_col16", _P), ("H_rowlen", _P), ("A_col16", _P), ("no_radius", _I64))]
+        ("H_col16", _P), ("H_rowlen", _P), ("A_col16", _P), ("no_radius", _I64),
+        ("A_off16", _P), ("A_rowfirst", _P), ("A_rl", _I64), ("P_win", _P), ("P_nspan", _I64))]
 
 
 # Counters over the life of the process (diagnostics: how often the device loop
 # had to hand an iteration back to the host).
-STATS = {"calls": 0, "iterations": 0, "batches": 0, "box_events": 0, "refine_events": 0}
+STATS = {"calls": 0, "iterations": 0, "batches": 0, "box_events": 0, "refine_events": 0,
+         "project_calls": 0}      # project_calls: solves that ran the one-launch projection
 
 
 def _hessian_parts(H):
@@ -277,6 +279,54 @@ def ell_rows(At):
     return col, val
 
 
+PF_U, PF_QS, PF_QX = 23, 16, 12      # csrc/banded.hip k_project_fused
+
+
+def fuse_project(pattern, vown_h, rows_wg, nwg, H):
+    """Tables of the one-launch projection (csrc/banded.hip k_project_fused) for a Jacobian
+    pattern and the geometry of the cyclic-reduction solve, or None: every row has the same
+    number ``rl`` of entries; per entry its column as a 16-bit offset from the row's first
+    column; per workgroup of the solve the span of columns it needs (its window's rows -- own
+    rows + H either side -- and its own variables, ``vown_h``); all within the kernel's
+    per-lane budgets.  Symbolic; cached per geometry."""
+    key = ("_ipx_project", int(rows_wg), int(nwg), int(H))
+    cache = getattr(pattern, "_ipx_project", None)
+    if cache is not None and cache[0] == key:
+        return cache[1]
+    out = None
+    m, n = pattern.shape
+    ip, idx = pattern.indptr_h.astype(np.int64), pattern.indices_h.astype(np.int64)
+    lens = np.diff(ip)
+    if m > 0 and pattern.nnz > 0 and lens.min() == lens.max() and lens[0] >= 1:
+        rl = int(lens[0])
+        rows = idx.reshape(m, rl)
+        first, last = rows.min(axis=1), rows.max(axis=1)
+        off = rows - first[:, None]
+        R = rows_wg + 2 * H
+        if off.max() < 65536 and R * rl <= PF_U * 256 and R <= 512 and 6 * (R + 2 * H) >= rl:
+            b = np.arange(nwg, dtype=np.int64)
+            rlo = np.maximum(b * rows_wg - H, 0)
+            rhi = np.minimum((b + 1) * rows_wg + H, m)
+            ok = np.all(rhi > rlo)
+            if ok:
+                # (running min / max: rows need not sweep the columns monotonically)
+                cmin = np.minimum.reduceat(first, rlo)
+                cmax = np.maximum.reduceat(np.append(last, 0), np.stack((rlo, rhi), 1).ravel())[::2]
+                c_lo = np.minimum(cmin, vown_h[:-1])
+                c_hi = np.maximum(cmax + 1, vown_h[1:])
+                nspan = int(np.max(c_hi - c_lo))
+                avn = int(np.max(np.diff(vown_h)))
+                # own variables must lie inside what the window's rows cover or be untouched
+                if nspan <= PF_QS * 256 and avn <= PF_QX * 256 and avn <= 6 * (R + 2 * H):
+                    dev = ctx().device
+                    win = np.stack((c_lo, c_hi), 1).ravel().astype(np.int32)
+                    out = (torch.from_numpy(off.ravel().astype(np.uint16).view(np.int16)).to(dev),
+                           torch.from_numpy(first.astype(np.int32)).to(dev), rl,
+                           torch.from_numpy(win).to(dev), nspan)
+    pattern._ipx_project = (key, out)
+    return out
+
+
 def _solver_kind(solver):
     """0: banded handle, 1: box-Schur argument block, None: not usable here."""
     from .projector import BandedNormalSolver
@@ -324,7 +374,7 @@ def _signature(H, P, lb, ub):
         return None
     Hc, Hd = _hessian_parts(H)
     flags = tuple(bool(os.environ.get(k)) for k in ("IPX_NO_FUSE", "IPX_NO_C16", "IPX_FUSE_TN",
-                                                    "IPX_TAIL_MAXWG"))
+                                                    "IPX_TAIL_MAXWG", "IPX_NO_PROJECT"))
     return (id(Hc.pattern), Hd is None, id(P.A.pattern), lb is None, ub is None,
             _solver_kind(P.solver), int(getattr(P.solver, "k", 0)), flags)
 
@@ -369,6 +419,9 @@ class _Loop:
             ok = bool(lib.ipx_banded_decoupled_geometry(ctypes.c_void_p(P.solver.handle), geo))
             if (ok, geo[0], geo[1]) != self.geometry:
                 return False
+            if self.pcr_L is not None and \
+                    int(lib.ipx_banded_pcr_level(ctypes.c_void_p(P.solver.handle))) != self.pcr_L:
+                return False            # the one-launch projection's windows follow 2^L
             a.banded = ctypes.c_void_p(P.solver.handle)
         else:
             a.banded = ctypes.cast(ctypes.pointer(P.solver.c_args()), ctypes.c_void_p)
@@ -387,7 +440,7 @@ class _Loop:
 
     def __init__(self, H, P, lb, ub):
         from .dense import DeviceDense
-        self.geometry = None
+        self.geometry, self.pcr_L = None, None
         if isinstance(P.A, DeviceDense):
             self._init_dense(H, P, lb, ub)
             return
@@ -482,6 +535,21 @@ class _Loop:
                     if n % 2 == 0 and kS == 1:
                         self.ell_col, self.ell_val = ell_rows(At)
                         a.At_ell_col, a.At_ell_val = _ptr(self.ell_col), _ptr(self.ell_val)
+                    # cyclic-reduction solve, uniform rows, no box: the whole projection step
+                    # (step1, A.r, the solve, g = r - A'v) is ONE launch
+                    L_pcr = int(lib.ipx_banded_pcr_level(ctypes.c_void_p(P.solver.handle)))
+                    if kS == 1 and L_pcr > 0 and lb is None and n % 2 == 0 \
+                            and not os.environ.get("IPX_NO_PROJECT"):
+                        pj = fuse_project(A.pattern, self.vown.cpu().numpy().astype(np.int64),
+                                          geo[0], geo[1], 1 << L_pcr)
+                        if pj is not None:
+                            self.proj_tabs = pj
+                            a.A_off16, a.A_rowfirst, a.A_rl = _ptr(pj[0]), _ptr(pj[1]), pj[2]
+                            a.P_win, a.P_nspan = _ptr(pj[3]), pj[4]
+                            self.pcr_L = L_pcr
+                            if own is None:
+                                self.r_next = torch.empty(n, dtype=f64, device=dev)
+                                a.r_next = _ptr(self.r_next)
         self.args = a
 
     def _init_dense(self, H, P, lb, ub):
@@ -527,6 +595,13 @@ class _Loop:
 
     def ref(self):
         return ctypes.byref(self.args)
+
+    def g_tensor(self, it):
+        """The buffer that holds g (= the next r) after iteration ``it``: with the one-launch
+        projection r and g alternate between two buffers (csrc/cg.hip proj_g)."""
+        if self.args.P_win and it % 2 == 0:
+            return self.r_next
+        return self.r
 
 
 def projected_cg(H, c, Z, Y, b, trust_radius=np.inf, lb=None, ub=None, tol=None,
@@ -587,7 +662,7 @@ def projected_cg(H, c, Z, Y, b, trust_radius=np.inf, lb=None, ub=None, tol=None,
     L.state.copy_(torch.from_numpy(init))
     _hip.check(lib.ipx_cg_hp(L.ref(), st), "ipx_cg_hp")
 
-    X, R = DVec(L.x), DVec(L.r)
+    X = DVec(L.x)
     hits_boundary = False
     stop_cond = 1
     counter = 0
@@ -665,7 +740,7 @@ def projected_cg(H, c, Z, Y, b, trust_radius=np.inf, lb=None, ub=None, tol=None,
                 continue
         if stop == 6:                     # projections.py:72-78 refinement
             STATS["refine_events"] += 1
-            _refine(P, L, R)
+            _refine(P, L, DVec(L.g_tensor(it_stop)))
             s = _resume(lib, L, it_stop, mode | 2, st)
             it = it_stop + 1
             continue
@@ -679,6 +754,7 @@ def projected_cg(H, c, Z, Y, b, trust_radius=np.inf, lb=None, ub=None, tol=None,
     niter = int(s[ST_NITER]) if max_iter > 0 else 0
     STATS["calls"] += 1
     STATS["iterations"] += niter
+    STATS["project_calls"] += 1 if L.args.P_win else 0
     _release(L, pool_key)
     return x, {'niter': niter, 'stop_cond': stop_cond, 'hits_boundary': hits_boundary}
 
@@ -692,13 +768,13 @@ def _resume(lib, L, it_stop, mode, st):
 
 def _refine(P, L, R):
     """Iterative refinement of g = Z r (projections.py:69-78) on the buffers of
-    the fused loop: L.r holds g."""
+    the fused loop: R is the view of the buffer that holds g (``_Loop.g_tensor``)."""
     Az = P.A.dot(R)          # the loop only formed ||A g||^2 (as a constraint-space residual)
     k = 0
     while k < P.max_refin:
         v = P._apply_inv(Az)
         z = P.A.rmatvec_sub(v, R, reduce=True)       # ||z||^2 -> slot 0
-        L.r.copy_(z.t)
+        R.t.copy_(z.t)
         k += 1
         P.stats["refinements"] += 1
         orth, Az = P._orthogonality(R)

@@ -701,6 +701,49 @@ def test_step2_fused_into_hp_is_bit_identical(ips, variant, monkeypatch):
         assert np.max(np.abs(x1 - x2)) <= 1e-13 * np.max(np.abs(x2))
 
 
+@pytest.mark.parametrize("n,m", [(20000, 2000), (100000, 10000), (5210, 521)])
+def test_one_launch_projection_matches_the_separate_kernels(ips, n, m, monkeypatch):
+    """The whole projection step of an iteration -- step1, w = A r, the cyclic-reduction solve,
+    g = r - A'v -- in ONE launch (csrc/banded.hip k_project_fused) against the three-kernel
+    form (IPX_NO_PROJECT=1): the same expressions in the same order, so the iterates agree
+    BIT FOR BIT when no trust-region test is in play, the counts and exits always; with a
+    finite radius ||x + alpha p||^2 is summed per workgroup of the solve instead of per row
+    tile of A (last-bit differences in a number that only feeds a comparison).  Refinement
+    events (the host finishes the iteration on the buffer that holds g) included."""
+    import ipsolver.cg_fused as cg_fused
+    inst = BandedInstance(n, m)
+    A = ips.dv.DeviceCSR.from_scipy(inst.A)
+    H = ips.dv.DeviceCSR.from_scipy(inst.H)
+    b = np.zeros(m)
+    runs = {}
+    for flag in ("", "1"):
+        if flag:
+            monkeypatch.setenv("IPX_NO_PROJECT", "1")
+        else:
+            monkeypatch.delenv("IPX_NO_PROJECT", raising=False)
+        Z, LS, Y = ips.proj.projections(A)
+        x_free, _ = ips.qp.projected_cg(H, inst.c, Z, Y, b, tol=1e-12)
+        out = []
+        before = cg_fused.STATS["project_calls"]
+        for kw in (dict(tol=0, max_iter=41), dict(tol=1e-12),
+                   dict(trust_radius=0.5 * ips.dv.norm(x_free)),
+                   dict(tol=0, max_iter=30, trust_radius=1e300)):
+            x, info = ips.qp.projected_cg(H, inst.c, Z, Y, b, **kw)
+            out.append((host(x), info))
+        Zr, _, Yr = ips.proj.projections(A, orth_tol=1e-30, max_refin=2)   # refines every time
+        x, info = ips.qp.projected_cg(H, inst.c, Zr, Yr, b, tol=0, max_iter=9)
+        out.append((host(x), info))
+        engaged = cg_fused.STATS["project_calls"] - before
+        assert engaged == (0 if flag else 5), engaged
+        runs[flag] = out
+    for k, ((x0, i0), (x1, i1)) in enumerate(zip(runs[""], runs["1"])):
+        assert i0 == i1, (k, i0, i1)
+        if k in (0, 1, 4):
+            assert np.array_equal(x0, x1), k
+        else:
+            assert np.max(np.abs(x0 - x1)) <= 1e-13 * np.max(np.abs(x0)), k
+
+
 @pytest.mark.parametrize("n,m,hbw,abw,seed", [(5000, 400, 2, 9, 0), (12345, 1500, 3, 6, 1),
                                                (3001, 299, 1, 21, 2), (40000, 2500, 5, 30, 3),
                                                (30000, 3000, 2, 30, 4), (30000, 3000, 1, 30, 5),
