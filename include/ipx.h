@@ -269,13 +269,14 @@ typedef struct ipx_cg_args {
    * rows all have A_rl entries, no box.  A_off16 = one uint16 per entry of A (column - first
    * column of its row), A_rowfirst = one int per row, P_win = 2 ints per workgroup of the solve
    * (first column / one past the last column of the span it needs: the columns of its window's
-   * rows and its own variables), P_nspan = the longest span (<= 4096); needs At_vown.  Any of
-   * them 0 / NULL: the separate launches. */
+   * rows and its own variables), P_nspan = the longest span (<= 4096), P_navn below; needs
+   * At_vown and r_next.  Any of them 0 / NULL: the separate launches. */
   const void *A_off16;
   const int32_t *A_rowfirst;
   int64_t A_rl;
   const int32_t *P_win;
   int64_t P_nspan;
+  int64_t P_navn;        /* most own variables of one workgroup (At_vown differences) */
 } ipx_cg_args;
 int ipx_cg_state_size(void);
 int ipx_cg_vec_grid(int64_t n);

@@ -1631,9 +1631,10 @@ k_project_fused(ipx_project_job J, int m, int rows_wg, int L, const double *__re
   const int H = 1 << L;
   const int R = rows_wg + 2 * H;
   const int RS = R + 2 * H;                         // PCR rows incl. identity padding
+  const int usize = max(6 * RS, (J.navn + 1) & ~1);
   double *span = pf_lds;                            // [nspan]
   double *U = span + ((J.nspan + 1) & ~1);          // union: products | PCR ping-pong | t
-  double *sx = U + 6 * RS;                          // [R]: w, then v
+  double *sx = U + usize;                           // [R]: w, then v
   double *red = sx + R;                             // [8]
   double *pa0 = U, *pa1 = U + RS, *pr0 = U + 2 * RS, *pr1 = U + 3 * RS, *pd0 = U + 4 * RS,
          *pd1 = U + 5 * RS;
@@ -1725,7 +1726,7 @@ k_project_fused(ipx_project_job J, int m, int rows_wg, int L, const double *__re
   }
   // (ipx_block_reduce ends with a barrier: the span is complete for every lane)
   // ---- 3. w = A r_next on the window rows, in rounds of as many rows as the union holds
-  const int rpr = (6 * RS) / rl;                     // rows per round
+  const int rpr = usize / rl;                        // rows per round
   for (int r0 = 0; r0 < rhi - rlo; r0 += rpr) {
     const int rb = rlo - (int)g0 + r0;               // first window row of the round
 #pragma unroll
@@ -2609,9 +2610,11 @@ int ipx_banded_project_fused_launch(void *handle, const ipx_project_job &job, in
   const int rows_wg = geo[0], nwg = geo[1], L = h->pcr_L, H = geo[2];
   const int R = rows_wg + 2 * H, RS = R + 2 * H;
   if (job.rl < 1 || (int64_t)R * job.rl > (int64_t)PF_U * IPX_BLOCK || job.nspan > PF_QS * IPX_BLOCK ||
-      job.nspan < 1 || 6 * RS < job.rl || R > 2 * IPX_BLOCK)
+      job.nspan < 1 || 6 * RS < job.rl || R > 2 * IPX_BLOCK || job.navn < 1 ||
+      job.navn > PF_QX * IPX_BLOCK)
     return IPX_EINVAL;
-  const size_t lds = sizeof(double) * (size_t)(((job.nspan + 1) & ~1) + 6 * RS + R + 8);
+  const int usize = std::max(6 * RS, (job.navn + 1) & ~1);
+  const size_t lds = sizeof(double) * (size_t)(((job.nspan + 1) & ~1) + usize + R + 8);
   if (nwg_out) *nwg_out = nwg;
   static bool attr_set = false;
   if (!attr_set) {

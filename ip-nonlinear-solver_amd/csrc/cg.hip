@@ -1406,7 +1406,7 @@ static int cg_iterate(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, hi
       job.A_rowfirst = a->A_rowfirst; job.rl = (int)a->A_rl; job.win = a->P_win;
       job.vown = a->At_vown; job.v = a->v; job.g = proj_g(a, it);
       job.part2 = a->part2; job.part3 = a->part3; job.part4 = a->part4;
-      job.no_xn2 = a->no_radius != 0; job.nspan = (int)a->P_nspan;
+      job.no_xn2 = a->no_radius != 0; job.nspan = (int)a->P_nspan; job.navn = (int)a->P_navn;
       int nwg = 0;
       rc = ipx_banded_project_fused_launch(a->banded, job, &nwg, st);
       if (rc) return rc;

@@ -429,6 +429,7 @@ struct ipx_project_job {
   double *part2, *part3, *part4;
   int no_xn2;
   int nspan;                  // longest span (doubles of LDS)
+  int navn;                   // most own variables of one workgroup
 };
 int ipx_banded_project_fused_launch(void *handle, const ipx_project_job &job, int *nwg,
                                     hipStream_t st);

@@ -42,7 +42,8 @@ class CgArgs(ctypes.Structure):
         ("At_vown", _P), ("At_qv", _I64), ("A_tile_nnz", _I64),
         ("At_ell_col", _P), ("At_ell_val", _P),
         ("H_col16", _P), ("H_rowlen", _P), ("A_col16", _P), ("no_radius", _I64),
-        ("A_off16", _P), ("A_rowfirst", _P), ("A_rl", _I64), ("P_win", _P), ("P_nspan", _I64))]
+        ("A_off16", _P), ("A_rowfirst", _P), ("A_rl", _I64), ("P_win", _P), ("P_nspan", _I64),
+        ("P_navn", _I64))]
 
 
 # Counters over the life of the process (diagnostics: how often the device loop
@@ -310,19 +311,21 @@ def fuse_project(pattern, vown_h, rows_wg, nwg, H):
             ok = np.all(rhi > rlo)
             if ok:
                 # (running min / max: rows need not sweep the columns monotonically)
-                cmin = np.minimum.reduceat(first, rlo)
-                cmax = np.maximum.reduceat(np.append(last, 0), np.stack((rlo, rhi), 1).ravel())[::2]
+                pairs = np.stack((rlo, rhi), 1).ravel()
+                cmin = np.minimum.reduceat(np.append(first, n), pairs)[::2]
+                cmax = np.maximum.reduceat(np.append(last, 0), pairs)[::2]
                 c_lo = np.minimum(cmin, vown_h[:-1])
                 c_hi = np.maximum(cmax + 1, vown_h[1:])
                 nspan = int(np.max(c_hi - c_lo))
                 avn = int(np.max(np.diff(vown_h)))
                 # own variables must lie inside what the window's rows cover or be untouched
-                if nspan <= PF_QS * 256 and avn <= PF_QX * 256 and avn <= 6 * (R + 2 * H):
+                lds = 8 * (nspan + max(6 * (R + 2 * H), avn) + R + 16)
+                if nspan <= PF_QS * 256 and 0 < avn <= PF_QX * 256 and lds <= 80 * 1024:
                     dev = ctx().device
                     win = np.stack((c_lo, c_hi), 1).ravel().astype(np.int32)
                     out = (torch.from_numpy(off.ravel().astype(np.uint16).view(np.int16)).to(dev),
                            torch.from_numpy(first.astype(np.int32)).to(dev), rl,
-                           torch.from_numpy(win).to(dev), nspan)
+                           torch.from_numpy(win).to(dev), nspan, avn)
     pattern._ipx_project = (key, out)
     return out
 
@@ -545,7 +548,7 @@ class _Loop:
                         if pj is not None:
                             self.proj_tabs = pj
                             a.A_off16, a.A_rowfirst, a.A_rl = _ptr(pj[0]), _ptr(pj[1]), pj[2]
-                            a.P_win, a.P_nspan = _ptr(pj[3]), pj[4]
+                            a.P_win, a.P_nspan, a.P_navn = _ptr(pj[3]), pj[4], pj[5]
                             self.pcr_L = L_pcr
                             if own is None:
                                 self.r_next = torch.empty(n, dtype=f64, device=dev)
