@@ -377,7 +377,7 @@ def _signature(H, P, lb, ub):
         return None
     Hc, Hd = _hessian_parts(H)
     flags = tuple(bool(os.environ.get(k)) for k in ("IPX_NO_FUSE", "IPX_NO_C16", "IPX_FUSE_TN",
-                                                    "IPX_TAIL_MAXWG", "IPX_NO_PROJECT"))
+                                                    "IPX_TAIL_MAXWG", "IPX_PROJECT"))
     return (id(Hc.pattern), Hd is None, id(P.A.pattern), lb is None, ub is None,
             _solver_kind(P.solver), int(getattr(P.solver, "k", 0)), flags)
 
@@ -539,10 +539,16 @@ class _Loop:
                         self.ell_col, self.ell_val = ell_rows(At)
                         a.At_ell_col, a.At_ell_val = _ptr(self.ell_col), _ptr(self.ell_val)
                     # cyclic-reduction solve, uniform rows, no box: the whole projection step
-                    # (step1, A.r, the solve, g = r - A'v) is ONE launch
+                    # (step1, A.r, the solve, g = r - A'v) as ONE launch -- OPT-IN (IPX_PROJECT=1).
+                    # Measured (round 3, MI355X, n = 1e6): one launch and 31 MB less traffic per
+                    # iteration, but 59 KB of LDS and 256 registers per lane leave 1.5 workgroups
+                    # per CU on one long dependent chain (loads -> alpha -> products -> reduction
+                    # -> scatter -> tail): 23.0 us against 10.3 + 11.5 us for the two separate
+                    # kernels with an infinite trust radius, 45 us against 23.8 us with a finite
+                    # one (register spills); 170 us against 62 us at n = 4e6.  Same bits.
                     L_pcr = int(lib.ipx_banded_pcr_level(ctypes.c_void_p(P.solver.handle)))
                     if kS == 1 and L_pcr > 0 and lb is None and n % 2 == 0 \
-                            and not os.environ.get("IPX_NO_PROJECT"):
+                            and os.environ.get("IPX_PROJECT"):
                         pj = fuse_project(A.pattern, self.vown.cpu().numpy().astype(np.int64),
                                           geo[0], geo[1], 1 << L_pcr)
                         if pj is not None:

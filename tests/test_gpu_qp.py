@@ -704,8 +704,9 @@ def test_step2_fused_into_hp_is_bit_identical(ips, variant, monkeypatch):
 @pytest.mark.parametrize("n,m", [(20000, 2000), (100000, 10000), (5210, 521)])
 def test_one_launch_projection_matches_the_separate_kernels(ips, n, m, monkeypatch):
     """The whole projection step of an iteration -- step1, w = A r, the cyclic-reduction solve,
-    g = r - A'v -- in ONE launch (csrc/banded.hip k_project_fused) against the three-kernel
-    form (IPX_NO_PROJECT=1): the same expressions in the same order, so the iterates agree
+    g = r - A'v -- in ONE launch (csrc/banded.hip k_project_fused; opt-in, IPX_PROJECT=1: it is
+    correct but slower than the separate kernels, cg_fused.py) against the three-kernel
+    form: the same expressions in the same order, so the iterates agree
     BIT FOR BIT when no trust-region test is in play, the counts and exits always; with a
     finite radius ||x + alpha p||^2 is summed per workgroup of the solve instead of per row
     tile of A (last-bit differences in a number that only feeds a comparison).  Refinement
@@ -718,9 +719,9 @@ def test_one_launch_projection_matches_the_separate_kernels(ips, n, m, monkeypat
     runs = {}
     for flag in ("", "1"):
         if flag:
-            monkeypatch.setenv("IPX_NO_PROJECT", "1")
+            monkeypatch.delenv("IPX_PROJECT", raising=False)
         else:
-            monkeypatch.delenv("IPX_NO_PROJECT", raising=False)
+            monkeypatch.setenv("IPX_PROJECT", "1")
         Z, LS, Y = ips.proj.projections(A)
         x_free, _ = ips.qp.projected_cg(H, inst.c, Z, Y, b, tol=1e-12)
         out = []
