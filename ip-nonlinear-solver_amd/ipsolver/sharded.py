@@ -460,6 +460,14 @@ class HipOps:
     def pack(self):
         return self.dv.ScalarPack()
 
+    def from_tensor(self, t):
+        return self.dv.DVec(t.contiguous())
+
+    def row_sumsq(self, A):
+        """sum_j A_ij^2 per local row (diag of A A')."""
+        sq = self.dv.DVec(A.val) * self.dv.DVec(A.val)
+        return self.dv.DeviceCSR(A.pattern, sq.t).dot(self.dv.DVec.full(A.shape[1], 1.0))
+
     def hessian(self, n, H_csr, diag):
         from .operators import DeviceHessian
         return DeviceHessian(n, csr=H_csr, diag=diag)

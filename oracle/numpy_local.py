@@ -71,6 +71,12 @@ class NumpyOps:
     def pack(self):
         return _LocalPack()
 
+    def from_tensor(self, t):
+        return t.numpy().copy()
+
+    def row_sumsq(self, A):
+        return np.asarray(A.M.multiply(A.M).sum(axis=1)).ravel()
+
     def from_host(self, a):
         return np.array(a, dtype=np.float64)
 

@@ -485,3 +485,18 @@ def test_minimize_constrained_dispatches_to_the_sharded_backend(what, tmp_path):
         tg.check_config5_prefix(got)
     else:
         tg.check_config4(got, what.split(":")[1])
+
+
+def test_general_sparsity_sharding_hip(tmp_path):
+    """The all-gather / reduce-scatter partition for Jacobians without a band
+    (ipsolver/sharded_general.py) with the HIP kernels as local arithmetic, two ranks sharing
+    cuda:0: the same checks against the oracle as on the numpy twin."""
+    import socket
+    import torch.multiprocessing as mp
+    import test_sharded_gloo as tg
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    path = str(tmp_path / "general.npz")
+    mp.spawn(tg._general_worker, args=(2, port, path, "hip"), nprocs=2, join=True)
+    tg.check_general(np.load(path))
