@@ -311,9 +311,20 @@ typedef struct ipx_pcg_args {
   double *state;            /* ipx_pcg_state_size() doubles */
   double *part1, *part2;    /* 2 * A_ntiles and 2 * grid doubles */
   int64_t grid;             /* ipx_cg_vec_grid(m) */
+  /* block-Jacobi preconditioner (ipx_blockjacobi_build) or NULL / 0 for the diagonal one:
+   * binv = nblk x 32 x 32 inverse blocks, border = 32 nblk row indices (the rows of block b;
+   * -1 = padding), z = m doubles (M^-1 r), part3 = nblk / 8 + 1 doubles; dinv is then all zero. */
+  const double *binv; const int32_t *border; int64_t nblk;
+  double *z, *part3;
 } ipx_pcg_args;
 int ipx_pcg_state_size(void);
 int ipx_pcg_iterate(const ipx_pcg_args *a, int32_t it_begin, int32_t it_end, void *stream);
+int ipx_blockjacobi_build(int64_t nblk, const int32_t *rowptr, const int32_t *colidx,
+                          const double *val, const int32_t *order, double *binv, int *flag,
+                          void *stream);
+int ipx_blockjacobi_apply(int64_t m, int64_t nblk, const int32_t *order, const double *binv,
+                          const double *r, double *z, double *ws, const double *state,
+                          void *stream);
 /* ---- partitioned row-sharded loop (ipsolver/sharded.py FusedShardedCG; replaces the
  * per-iteration body of qp_subproblem.py:549-634 on one rank of a node).  `a` describes the
  * rank's extended local problem (own rows / variables + halo copies; solver_kind 0 or 1); the

@@ -69,6 +69,8 @@ _SIGNATURES = {
     "ipx_cg_step2_hp": [_P, _I32, _I32, _P],
     "ipx_pcg_state_size": [],
     "ipx_pcg_iterate": [_P, _I32, _I32, _P],
+    "ipx_blockjacobi_build": [_I64, _P, _P, _P, _P, _P, _P, _P],
+    "ipx_blockjacobi_apply": [_I64, _I64, _P, _P, _P, _P, _P, _P, _P],
     "ipx_cg_shard2_segment": [_P, _P, _I32, _I32, _I32, _P],
     "ipx_cg_shard2_fold_hp": [_P, _P, _P],
     "ipx_cg_shard2_iterate": [_P, _P, _I32, _I32, _P],

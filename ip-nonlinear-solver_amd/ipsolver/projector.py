@@ -351,26 +351,34 @@ class PcgArgs(ctypes.Structure):
                 ("A_rowptr", _P), ("A_colidx", _P), ("A_val", _P), ("A_tiles", _P), ("A_ntiles", _I),
                 ("At_rowptr", _P), ("At_colidx", _P), ("At_val", _P), ("At_tiles", _P),
                 ("At_ntiles", _I), ("dinv", _P), ("v", _P), ("r", _P), ("p", _P), ("Sp", _P),
-                ("t", _P), ("state", _P), ("part1", _P), ("part2", _P), ("grid", _I)]
+                ("t", _P), ("state", _P), ("part1", _P), ("part2", _P), ("grid", _I),
+                ("binv", _P), ("border", _P), ("nblk", _I), ("z", _P), ("part3", _P)]
 
 
 class IterativeNormalSolver:
     """``(A A')^-1`` without a factorization, for sparse Jacobians whose ``A A'`` is neither
-    banded (after reordering) nor small enough for the dense device Cholesky: Jacobi-
-    preconditioned conjugate gradients on ``A (A' v) = w``, device resident (csrc/pcg.hip):
+    banded (after reordering) nor small enough for the dense device Cholesky: preconditioned
+    conjugate gradients on ``A (A' v) = w``, device resident (csrc/pcg.hip):
     one C call enqueues a batch of iterations, convergence and stall tests are taken on the
     device, the host reads one state block per batch.  The reference factors any sparse A
     with SuperLU (projections.py:93-172); this keeps such problems solvable here (at the
     speed of an iterative solve) instead of refusing them.  The inner solve runs to the
     floor of fp64; the projector's orthogonality-driven refinement (projections.py:72-78)
-    sits on top of it as usual."""
+    sits on top of it as usual.
+
+    Preconditioner (``precond``): "block" (default) -- block Jacobi: the diagonal 32 x 32 blocks
+    of ``A A'`` with the rows taken in the bandwidth-reducing order of the symbolic analysis
+    (reverse Cuthill-McKee of the pattern of ``A A'``), formed, Cholesky-factored and inverted
+    on the device once per factorization; "jacobi" -- the diagonal (round 2)."""
 
     perm = None
     RTOL, MAXIT = 1e-15, 2000
     PS_RZ0, PS_BEST0, PS_DONE, PS_ITERS, PS_NORM_W, PS_RTOL = 0, 2, 6, 7, 8, 9
+    BLOCK = 32
 
-    def __init__(self, A):
+    def __init__(self, A, precond="block"):
         lib = _hip.load()
+        self.precond = precond
         self.A, self.At = A, A.T
         self.m, n = A.shape
         sq = DVec(A.val) * DVec(A.val)
@@ -398,6 +406,29 @@ class IterativeNormalSolver:
         a.r, a.p, a.Sp, a.t = (t.data_ptr() for t in (self.r, self.p, self.Sp, self.t))
         a.state, a.part1, a.part2 = (t.data_ptr() for t in (self.state, self.part1, self.part2))
         a.grid = self.grid
+        if precond == "block":
+            # rows in the order of the symbolic analysis, padded to whole blocks
+            order = _symbolic_for(A.pattern).perm
+            order = np.arange(m, dtype=np.int32) if order is None else np.asarray(order, np.int32)
+            nblk = (m + self.BLOCK - 1) // self.BLOCK
+            padded = np.full(nblk * self.BLOCK, -1, dtype=np.int32)
+            padded[:m] = order
+            self.border = torch.from_numpy(padded).to(dev)
+            self.binv = torch.empty(nblk * self.BLOCK * self.BLOCK, dtype=_F64, device=dev)
+            flag = torch.zeros(1, dtype=torch.int32, device=dev)
+            pat = A.pattern
+            _hip.call("ipx_blockjacobi_build", nblk, _p(pat.indptr), _p(pat.indices), _p(A.val),
+                      _p(self.border), _p(self.binv), _p(flag), stream_ptr())
+            if int(flag.item()) != 0:
+                raise np.linalg.LinAlgError("Singular Jacobian matrix: a diagonal block of A A' "
+                                            "is not positive definite")
+            self.z, self.part3 = z(m), z(nblk // 8 + 2)
+            self.dinv = DVec.zeros(m)             # (r'z comes from the block kernel)
+            a.dinv = self.dinv.t.data_ptr()
+            a.binv, a.border, a.nblk = self.binv.data_ptr(), self.border.data_ptr(), nblk
+            a.z, a.part3 = self.z.data_ptr(), self.part3.data_ptr()
+        elif precond != "jacobi":
+            raise ValueError("precond must be 'block' or 'jacobi'")
         self.stats = {"solves": 0, "iterations": 0, "batches": 0}
 
     def solve(self, w):
@@ -407,9 +438,16 @@ class IterativeNormalSolver:
         if norm_w == 0:
             return v
         self.r.copy_(w.t)
-        z0 = self.dinv * w
-        self.p.copy_(z0.t)
         init = np.zeros(self.state.numel())
+        if self.precond == "block":
+            self.state.zero_()
+            _hip.call("ipx_blockjacobi_apply", self.m, self.args.nblk, _p(self.border),
+                      _p(self.binv), _p(w.t), _p(self.z), _p(self.part3), _p(self.state),
+                      stream_ptr())
+            z0 = DVec(self.z)
+        else:
+            z0 = self.dinv * w
+        self.p.copy_(z0.t)
         init[self.PS_RZ0] = w.dot(z0)
         init[self.PS_BEST0] = np.inf
         init[self.PS_NORM_W], init[self.PS_RTOL] = norm_w, self.RTOL

@@ -1093,6 +1093,39 @@ def test_iterative_normal_solver_on_the_device(ips):
         IterativeNormalSolver(ips.dv.DeviceCSR.from_scipy(sps.csr_matrix(A0)))
 
 
+@pytest.mark.parametrize("eps", [3.0, 1.0, 0.3])
+def test_block_jacobi_preconditioner_over_condition_numbers(ips, eps):
+    """The inner solve of ``IterativeNormalSolver`` with the block-Jacobi preconditioner
+    (32 x 32 diagonal blocks of A A' in the symbolic analysis' row order, built and inverted on
+    the device: csrc/pcg.hip) against the diagonal one of round 2, on Jacobians whose
+    neighbouring rows are nearly parallel -- moving averages over 12 columns + ``eps`` on a
+    private column, cond(A A') ~ (12 / eps)^2: 16 ... 1600 -- at m = 20000 (beyond the dense
+    Cholesky; half bandwidth 11 is beyond the banded solver).  Same answer as a sparse LU of
+    A A' (1e-9 of it), fewer inner iterations at every conditioning, the more the worse it is."""
+    import scipy.sparse.linalg as spla
+    from ipsolver.projector import IterativeNormalSolver
+    rng = np.random.default_rng(5)
+    m = 20000
+    A = _moving_average_rows(m, 11, eps, rng)
+    Ad = ips.dv.DeviceCSR.from_scipy(A)
+    w = rng.standard_normal(m)
+    want = spla.splu(sps.csc_matrix(A @ A.T)).solve(w)
+    its = {}
+    for precond in ("jacobi", "block"):
+        solver = IterativeNormalSolver(Ad, precond=precond)
+        v = host(solver.solve(ips.dv.DVec.from_host(w)))
+        its[precond] = solver.stats["iterations"]
+        assert np.max(np.abs(v - want)) <= 1e-9 * np.max(np.abs(want)), (precond, eps)
+    print("eps %.1f: inner iterations jacobi %d, block Jacobi %d" % (eps, its["jacobi"], its["block"]))
+    assert its["block"] < its["jacobi"]
+    if eps <= 1.0:
+        assert its["block"] <= 0.6 * its["jacobi"]
+    # through the public seam the block preconditioner is the default
+    Z, LS, Y = ips.proj.projections(Ad)
+    assert isinstance(Z.projector.solver, IterativeNormalSolver) \
+        and Z.projector.solver.precond == "block"
+
+
 @pytest.mark.parametrize("kA", [4, 5, 6, 7, 8, 9])
 def test_banded_defect_correction(ips, kA):
     """Half bandwidths 3..8 at m = 1e5.  The separator system of the
