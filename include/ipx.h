@@ -277,6 +277,12 @@ typedef struct ipx_cg_args {
   const int32_t *P_win;
   int64_t P_nspan;
   int64_t P_navn;        /* most own variables of one workgroup (At_vown differences) */
+  /* != 0: the Hessian is an operator the CALLER applies between two iterations (reference
+   * _canonical_constraint.py:119-139 allows LinearOperator terms: finite differences, user
+   * callbacks): the loop's launches leave out H.p; after every iteration the caller writes
+   * Hp = H p and the scalar p'Hp into part1[1] (H_ntiles = 1, the H_* arrays unused).  The
+   * branches and step lengths stay on the device. */
+  int64_t H_operator;
 } ipx_cg_args;
 int ipx_cg_state_size(void);
 int ipx_cg_vec_grid(int64_t n);

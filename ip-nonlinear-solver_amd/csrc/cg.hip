@@ -847,13 +847,16 @@ int ipx_cg_state_size(void) { return ST_SIZE; }
 // 2 workgroups per CU: measured best for step2 at n = 1e6 (9.3 us vs 10.8 us with 1024)
 int ipx_cg_vec_grid(int64_t n) { return ipx_grid_for(n, VB * 2, 512); }
 
-static bool fused_hp(const ipx_cg_args *a) { return a->pb != nullptr && a->H_hmax > 0; }
+static bool fused_hp(const ipx_cg_args *a) {
+  return a->pb != nullptr && a->H_hmax > 0 && !a->H_operator;
+}
 
 // Unfused H.p; when the fused step2+H.p kernel is in use it also saves the tile
 // boundaries of the p it was given (that kernel's halo source).
 static bool dense_loop(const ipx_cg_args *a) { return a->solver_kind == 2; }
 // entries per half of part1: row tiles of a CSR Hessian / workgroups of the dense matvec
 static int part1_count(const ipx_cg_args *a) {
+  if (a->H_operator) return 1;                   // [unused, p'Hp] written by the caller
   if (dense_loop(a) && !a->H_rowptr) {
     const int g = (int)((a->n + 3) / 4);
     return g > 2048 ? 2048 : g;
@@ -862,6 +865,7 @@ static int part1_count(const ipx_cg_args *a) {
 }
 
 static int launch_hp(const ipx_cg_args *a, const double *guard, hipStream_t st) {
+  if (a->H_operator) return IPX_OK;              // the caller applies H between the iterations
   if (dense_loop(a) && !a->H_rowptr) {           // dense Hessian (row major n x n in H_val)
     int np = 0;
     return ipx_dense_gemv_launch((int)a->n, (int)a->n, a->H_val, a->n, a->p, 1.0, a->H_diag, 0.0,

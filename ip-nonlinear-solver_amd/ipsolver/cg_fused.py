@@ -43,13 +43,14 @@ class CgArgs(ctypes.Structure):
         ("At_ell_col", _P), ("At_ell_val", _P),
         ("H_col16", _P), ("H_rowlen", _P), ("A_col16", _P), ("no_radius", _I64),
         ("A_off16", _P), ("A_rowfirst", _P), ("A_rl", _I64), ("P_win", _P), ("P_nspan", _I64),
-        ("P_navn", _I64))]
+        ("P_navn", _I64), ("H_operator", _I64))]
 
 
 # Counters over the life of the process (diagnostics: how often the device loop
 # had to hand an iteration back to the host).
 STATS = {"calls": 0, "iterations": 0, "batches": 0, "box_events": 0, "refine_events": 0,
-         "project_calls": 0}      # project_calls: solves that ran the one-launch projection
+         "project_calls": 0,      # project_calls: solves that ran the one-launch projection
+         "operator_calls": 0}     # solves whose Hessian was an operator applied by the host
 
 
 def _hessian_parts(H):
@@ -357,7 +358,11 @@ def supports(H, Z, Y):
         return False
     if P.m == 0 or _solver_kind(P.solver) is None:
         return False
-    return _hessian_parts(H) is not None
+    # a CSR (+ diagonal) Hessian rides inside the loop's launches; any other operator with
+    # ``dot`` over device vectors (finite differences, user callbacks, dense or padded terms:
+    # _canonical_constraint.py:119-139) is applied between two iterations, the scalar branches
+    # stay on the device all the same
+    return _hessian_parts(H) is not None or hasattr(H, "dot")
 
 
 def _ptr(t):
@@ -375,6 +380,8 @@ def _signature(H, P, lb, ub):
     from .dense import DeviceDense
     if isinstance(P.A, DeviceDense):
         return None
+    if _hessian_parts(H) is None:
+        return None                      # operator Hessians: not pooled
     Hc, Hd = _hessian_parts(H)
     flags = tuple(bool(os.environ.get(k)) for k in ("IPX_NO_FUSE", "IPX_NO_C16", "IPX_FUSE_TN",
                                                     "IPX_TAIL_MAXWG", "IPX_PROJECT"))
@@ -450,7 +457,9 @@ class _Loop:
         lib = _hip.load()
         A = P.A
         At = A.T
-        Hc, Hd = _hessian_parts(H)
+        parts = _hessian_parts(H)
+        self.operator = None if parts is not None else H
+        Hc, Hd = parts if parts is not None else (None, None)
         self.n, self.m = P.n, P.m
         n, m = self.n, self.m
         dev = ctx().device
@@ -464,7 +473,8 @@ class _Loop:
         self.t = torch.empty(m, dtype=f64, device=dev)
         self.state = torch.zeros(lib.ipx_cg_state_size(), dtype=f64, device=dev)
         grid = lib.ipx_cg_vec_grid(n)
-        self.part1 = torch.zeros(2 * Hc.pattern.ntiles, dtype=f64, device=dev)
+        self.part1 = torch.zeros(2 * (Hc.pattern.ntiles if Hc is not None else 1), dtype=f64,
+                                 device=dev)
         # (box-Schur projection: step1 writes one partial per 2048 elements, csrc/cg.hip SB_ITEMS)
         self.part2 = torch.zeros(2 * max(grid, A.pattern.ntiles, n // 2048 + 2), dtype=f64,
                                  device=dev)
@@ -475,6 +485,9 @@ class _Loop:
         a = CgArgs()
         a.n, a.m = n, m
         for pre, M in (("A", A), ("At", At), ("H", Hc)):
+            if M is None:                 # operator Hessian: applied by the host (H_operator)
+                a.H_ntiles, a.H_operator = 1, 1
+                continue
             pat = M.pattern
             setattr(a, pre + "_rowptr", _ptr(pat.indptr))
             setattr(a, pre + "_colidx", _ptr(pat.indices))
@@ -496,7 +509,7 @@ class _Loop:
         self.fold_ws = torch.zeros(16384, dtype=f64, device=dev)      # IPX_FOLD_WS_DOUBLES
         a.fold_ws = _ptr(self.fold_ws)
         # banded Hessian: step2 rides inside the H.p SpMV (one launch less per iteration)
-        hmax = 0 if os.environ.get("IPX_NO_FUSE") else fuse_halo(Hc.pattern)
+        hmax = 0 if (os.environ.get("IPX_NO_FUSE") or Hc is None) else fuse_halo(Hc.pattern)
         if hmax > 0:
             self.pb = torch.zeros(2 * Hc.pattern.ntiles * 2 * hmax, dtype=f64, device=dev)
             a.pb, a.H_hmax = _ptr(self.pb), hmax
@@ -605,6 +618,14 @@ class _Loop:
     def ref(self):
         return ctypes.byref(self.args)
 
+    def apply_operator(self):
+        """Operator Hessians: Hp = H p by the operator's own ``dot`` and p'Hp into the slot the
+        next step1 folds (part1[1]); enqueued, no host synchronisation of its own."""
+        Hp = self.operator.dot(DVec(self.p))
+        self.Hp.copy_(Hp.t)
+        _hip.call("ipx_dot", self.n, _p(self.p), _p(self.Hp),
+                  ctypes.c_void_p(self.part1.data_ptr() + 8), _p(ctx().ws), stream_ptr())
+
     def g_tensor(self, it):
         """The buffer that holds g (= the next r) after iteration ``it``: with the one-launch
         projection r and g alternate between two buffers (csrc/cg.hip proj_g)."""
@@ -670,6 +691,9 @@ def projected_cg(H, c, Z, Y, b, trust_radius=np.inf, lb=None, ub=None, tol=None,
     init[ST_ORTH_RHS] = P.orth_tol * P.norm_A
     L.state.copy_(torch.from_numpy(init))
     _hip.check(lib.ipx_cg_hp(L.ref(), st), "ipx_cg_hp")
+    if L.operator is not None:
+        L.apply_operator()
+        STATS["operator_calls"] += 1
 
     X = DVec(L.x)
     hits_boundary = False
@@ -681,11 +705,19 @@ def projected_cg(H, c, Z, Y, b, trust_radius=np.inf, lb=None, ub=None, tol=None,
     # (batches 4, 8, ..., 64: a solve that meets its tolerance after 2-3 iterations -- the
     # equality-constrained configs -- is read once; the iterations enqueued behind the stop
     # are no-ops on the device)
-    nbatch = batch if batch else 4
-    broke = False
+    nbatch = batch if batch else (4 if L.operator is None else 2)
+    batch_cap = 64 if L.operator is None else 8       # (an operator is applied once per
+    broke = False                                      #  enqueued iteration, stopped or not)
     while it < max_iter:
         end = min(max_iter, it + nbatch)
-        _hip.check(lib.ipx_cg_iterate(L.ref(), it, end, st), "ipx_cg_iterate")
+        if L.operator is None:
+            _hip.check(lib.ipx_cg_iterate(L.ref(), it, end, st), "ipx_cg_iterate")
+        else:
+            # the operator is applied between the iterations (after a stop: on unchanged p,
+            # harmless); the branches of the iterations were still taken on the device
+            for k in range(it, end):
+                _hip.check(lib.ipx_cg_iterate(L.ref(), k, k + 1, st), "ipx_cg_iterate")
+                L.apply_operator()
         s = L.state.tolist()             # one blocking read per batch
         STATS["batches"] += 1
         if stats is not None:
@@ -694,7 +726,7 @@ def projected_cg(H, c, Z, Y, b, trust_radius=np.inf, lb=None, ub=None, tol=None,
         if stop == 0:
             it = end
             if not batch:
-                nbatch = min(2 * nbatch, 64)
+                nbatch = min(2 * nbatch, batch_cap)
             continue
         it_stop = int(s[ST_IT_DONE])     # index of the iteration that raised the flag
         alpha = s[ST_ALPHA]
@@ -772,6 +804,8 @@ def _resume(lib, L, it_stop, mode, st):
     """Clear the stop flag, finish iteration ``it_stop`` (step2 + Hp)."""
     L.state[ST_STOP] = 0.0
     _hip.check(lib.ipx_cg_resume(L.ref(), it_stop, mode, st), "ipx_cg_resume")
+    if L.operator is not None:
+        L.apply_operator()
     return L.state.tolist()
 
 

@@ -701,6 +701,42 @@ def test_step2_fused_into_hp_is_bit_identical(ips, variant, monkeypatch):
         assert np.max(np.abs(x1 - x2)) <= 1e-13 * np.max(np.abs(x2))
 
 
+def test_device_loop_with_an_operator_hessian(ips):
+    """A Hessian that is only an operator (``dot`` over device vectors -- what the reference's
+    LinearOperator terms are: finite differences, user callbacks, _canonical_constraint.py:
+    119-139) keeps the device-resident loop: the operator is applied between two iterations,
+    the scalar-gated branches (qp_subproblem.py:551,558,583) stay on the device and the host
+    reads the state once per batch instead of ~8 scalars per iteration.  Same exits and
+    iterates as the CSR Hessian inside the loop (p'Hp is summed in another order: 1e-12)."""
+    import ipsolver.cg_fused as cg_fused
+    inst = BandedInstance(20000, 2000)
+    A = ips.dv.DeviceCSR.from_scipy(inst.A)
+    H = ips.dv.DeviceCSR.from_scipy(inst.H)
+
+    class Operator:
+        shape = H.shape
+        calls = 0
+
+        def dot(self, p):
+            Operator.calls += 1
+            return H.dot(p)
+    Z, LS, Y = ips.proj.projections(A)
+    b = np.zeros(2000)
+    gnorm = ips.dv.norm(Z.dot(inst.c))
+    assert cg_fused.supports(Operator(), Z, Y)
+    for name, kw in inst.pcg_variants(gnorm).items():
+        before, batches = cg_fused.STATS["operator_calls"], cg_fused.STATS["batches"]
+        Operator.calls = 0
+        x, info = ips.qp.projected_cg(Operator(), inst.c, Z, Y, b, **kw)
+        assert cg_fused.STATS["operator_calls"] == before + 1, "device loop not taken"
+        x1, info1 = ips.qp.projected_cg(H, inst.c, Z, Y, b, **kw)
+        assert info == info1, (name, info, info1)
+        close(x, host(x1), 1e-12)
+        if info["niter"] >= 20:           # several iterations per state read
+            reads = cg_fused.STATS["batches"] - batches - 0
+            assert reads <= info["niter"] // 2 + 8, (name, reads, info["niter"])
+
+
 @pytest.mark.parametrize("n,m", [(20000, 2000), (100000, 10000), (5210, 521)])
 def test_one_launch_projection_matches_the_separate_kernels(ips, n, m, monkeypatch):
     """The whole projection step of an iteration -- step1, w = A r, the cyclic-reduction solve,
