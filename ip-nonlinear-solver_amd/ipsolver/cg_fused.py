@@ -450,7 +450,7 @@ class _Loop:
 
     def __init__(self, H, P, lb, ub):
         from .dense import DeviceDense
-        self.geometry, self.pcr_L = None, None
+        self.geometry, self.pcr_L, self.operator = None, None, None
         if isinstance(P.A, DeviceDense):
             self._init_dense(H, P, lb, ub)
             return
