@@ -729,12 +729,13 @@ def test_device_loop_with_an_operator_hessian(ips):
         Operator.calls = 0
         x, info = ips.qp.projected_cg(Operator(), inst.c, Z, Y, b, **kw)
         assert cg_fused.STATS["operator_calls"] == before + 1, "device loop not taken"
+        reads = cg_fused.STATS["batches"] - batches
         x1, info1 = ips.qp.projected_cg(H, inst.c, Z, Y, b, **kw)
         assert info == info1, (name, info, info1)
         close(x, host(x1), 1e-12)
-        if info["niter"] >= 20:           # several iterations per state read
-            reads = cg_fused.STATS["batches"] - batches - 0
-            assert reads <= info["niter"] // 2 + 8, (name, reads, info["niter"])
+        if name in ("free", "ball") and info["niter"] >= 20:
+            # several iterations per state read (box events hand every iteration to the host)
+            assert reads <= info["niter"] // 4 + 4, (name, reads, info["niter"])
 
 
 @pytest.mark.parametrize("n,m", [(20000, 2000), (100000, 10000), (5210, 521)])
