@@ -695,72 +695,114 @@ def projected_cg(H, c, Z, Y, b, trust_radius=np.inf, lb=None, ub=None, tol=None,
         L.apply_operator()
         STATS["operator_calls"] += 1
 
-    X = DVec(L.x)
-    hits_boundary = False
-    stop_cond = 1
-    counter = 0
-    last_viol_it = -2
-    last_feasible_x = DVec.zeros(n)
+    class Driver:
+        """The single-GPU loop behind ``run_device_loop``."""
+        first_batch = 4 if L.operator is None else 2
+        batch_cap = 64 if L.operator is None else 8   # (an operator is applied once per
+                                                      #  enqueued iteration, stopped or not)
+        def iterate(self, it, end):
+            if L.operator is None:
+                _hip.check(lib.ipx_cg_iterate(L.ref(), it, end, st), "ipx_cg_iterate")
+            else:
+                # the operator is applied between the iterations (after a stop: on unchanged
+                # p, harmless); the branches of the iterations were still taken on the device
+                for k in range(it, end):
+                    _hip.check(lib.ipx_cg_iterate(L.ref(), k, k + 1, st), "ipx_cg_iterate")
+                    L.apply_operator()
+
+        def read_state(self):
+            return L.state.tolist()
+
+        def X(self):
+            return DVec(L.x)
+
+        def Pv(self):
+            return DVec(L.p)
+
+        def set_x(self, v):
+            L.x = v.t
+
+        def zeros(self):
+            return DVec.zeros(n)
+
+        def resume(self, it_stop, mode):
+            return _resume(lib, L, it_stop, mode, st)
+
+        def refine(self, it_stop):
+            _refine(P, L, DVec(L.g_tensor(it_stop)))
+
+    x, niter, stop_cond, hits_boundary = run_device_loop(
+        Driver(), STATS, lb, ub, trust_radius, max_iter, max_infeasible_iter, batch, stats)
+    STATS["calls"] += 1
+    STATS["iterations"] += niter
+    STATS["project_calls"] += 1 if L.args.P_win else 0
+    _release(L, pool_key)
+    return x, {'niter': niter, 'stop_cond': stop_cond, 'hits_boundary': hits_boundary}
+
+
+def run_device_loop(D, counters, lb, ub, trust_radius, max_iter, max_infeasible_iter,
+                    batch=None, stats=None):
+    """The host side of the device-resident loop, ONE routine for the single-GPU and the
+    row-sharded drivers (``D``: iterate / read_state / X / Pv / set_x / zeros / resume /
+    refine over their own vector types).  Batches of iterations are enqueued, the state block
+    is read once per batch, and the rare events are finished here with the reference's helper
+    routines -- qp_subproblem.py:551 tolerance, :558-576 negative curvature, :583-596
+    trust-region exit, :599-616 box-infeasible iterates with the ``counter`` /
+    ``last_feasible_x`` bookkeeping, projections.py:72-78 refinement (stop codes 4, 3, 2, 5, 6
+    of csrc/cg.hip).  Returns ``(x, niter, stop_cond, hits_boundary)``."""
+    from . import qp
+    has_box = lb is not None or ub is not None
+    hits_boundary, stop_cond = False, 1
+    counter, last_viol_it = 0, -2
+    last_feasible_x = D.zeros()
     it = 0
-    # (batches 4, 8, ..., 64: a solve that meets its tolerance after 2-3 iterations -- the
-    # equality-constrained configs -- is read once; the iterations enqueued behind the stop
-    # are no-ops on the device)
-    nbatch = batch if batch else (4 if L.operator is None else 2)
-    batch_cap = 64 if L.operator is None else 8       # (an operator is applied once per
-    broke = False                                      #  enqueued iteration, stopped or not)
+    nbatch = batch if batch else D.first_batch
+    s = None
     while it < max_iter:
         end = min(max_iter, it + nbatch)
-        if L.operator is None:
-            _hip.check(lib.ipx_cg_iterate(L.ref(), it, end, st), "ipx_cg_iterate")
-        else:
-            # the operator is applied between the iterations (after a stop: on unchanged p,
-            # harmless); the branches of the iterations were still taken on the device
-            for k in range(it, end):
-                _hip.check(lib.ipx_cg_iterate(L.ref(), k, k + 1, st), "ipx_cg_iterate")
-                L.apply_operator()
-        s = L.state.tolist()             # one blocking read per batch
-        STATS["batches"] += 1
+        D.iterate(it, end)
+        s = D.read_state()               # one blocking read per batch
+        counters["batches"] += 1
         if stats is not None:
             stats["batches"] = stats.get("batches", 0) + 1
         stop = int(s[ST_STOP])
         if stop == 0:
             it = end
             if not batch:
-                nbatch = min(2 * nbatch, batch_cap)
+                nbatch = min(2 * nbatch, D.batch_cap)
             continue
         it_stop = int(s[ST_IT_DONE])     # index of the iteration that raised the flag
         alpha = s[ST_ALPHA]
-        Pv = DVec(L.p)
         if stop == 4:                     # :551
             stop_cond = 4
-            broke = True
             break
         if stop == 3:                     # :558-576
             if np.isinf(trust_radius):
                 raise ValueError("Negative curvature not allowed "
                                  "for unrestrited problems.")
+            X, Pv = D.X(), D.Pv()
             _, al, hit = qp.box_sphere_intersections(X, Pv, lb, ub, trust_radius,
                                                      entire_line=True)
             xf = X.add_scaled(Pv, al) if hit else X
-            xf = qp.reinforce_box_boundaries(xf, lb, ub)
-            L.x = xf.t
-            stop_cond, hits_boundary, broke = 3, True, True
+            D.set_x(qp.reinforce_box_boundaries(xf, lb, ub))
+            stop_cond, hits_boundary = 3, True
             break
         if stop == 2:                     # :583-596
+            X, Pv = D.X(), D.Pv()
             _, theta, hit = qp.box_sphere_intersections(X, Pv, lb, ub, trust_radius,
                                                         dscale=alpha)
             xf = X.add_scaled(Pv, theta * alpha) if hit else X
-            xf = qp.reinforce_box_boundaries(xf, lb, ub)
-            L.x = xf.t
-            stop_cond, hits_boundary, broke = 2, True, True
+            D.set_x(qp.reinforce_box_boundaries(xf, lb, ub))
+            stop_cond, hits_boundary = 2, True
             break
         mode = 0
         if stop == 5:                     # :599-616 x_next outside the box
-            STATS["box_events"] += 1
+            counters["box_events"] += 1
             if last_viol_it != it_stop - 1:
                 counter = 0
             counter += 1
             last_viol_it = it_stop
+            X, Pv = D.X(), D.Pv()
             _, theta, hit = qp.box_sphere_intersections(X, Pv, lb, ub, trust_radius,
                                                         dscale=alpha)
             if hit:
@@ -769,35 +811,33 @@ def projected_cg(H, c, Z, Y, b, trust_radius=np.inf, lb=None, ub=None, tol=None,
                 counter = 0
                 last_viol_it = -2
             if counter > max_infeasible_iter:
-                broke = True
                 break
             mode = 1
             # the orthogonality check has not run yet for this iteration
-            s = _resume(lib, L, it_stop, mode, st)
+            s = D.resume(it_stop, mode)
             if int(s[ST_STOP]) == 6:
                 stop, mode = 6, 1
             else:
                 it = it_stop + 1
                 continue
         if stop == 6:                     # projections.py:72-78 refinement
-            STATS["refine_events"] += 1
-            _refine(P, L, DVec(L.g_tensor(it_stop)))
-            s = _resume(lib, L, it_stop, mode | 2, st)
+            counters["refine_events"] += 1
+            D.refine(it_stop)
+            s = D.resume(it_stop, mode | 2)
             it = it_stop + 1
             continue
+        if stop == 7:
+            raise _hip.IpxError("sharded projected CG: a wait on the peer mailboxes timed out "
+                                "(a rank of the group died or fell out of step)")
         raise _hip.IpxError("unexpected CG stop code %d" % stop)
 
-    x = DVec(L.x)
+    x = D.X()
     if has_box and not qp.inside_box_boundaries(x, lb, ub):     # :636-638
         x = last_feasible_x
         hits_boundary = True
     # (the state block read last is current: nothing was enqueued after it on every exit)
-    niter = int(s[ST_NITER]) if max_iter > 0 else 0
-    STATS["calls"] += 1
-    STATS["iterations"] += niter
-    STATS["project_calls"] += 1 if L.args.P_win else 0
-    _release(L, pool_key)
-    return x, {'niter': niter, 'stop_cond': stop_cond, 'hits_boundary': hits_boundary}
+    niter = int(s[ST_NITER]) if s is not None else 0
+    return x, niter, stop_cond, hits_boundary
 
 
 def _resume(lib, L, it_stop, mode, st):

@@ -1269,91 +1269,38 @@ def fused_projected_cg(H, c, Z, Y, b, trust_radius=np.inf, lb=None, ub=None, tol
     L = F.L
     DV = dv.DVec
 
-    def X():
-        return ShardVec(DV(L.x), sh, F.kind)
+    class Driver:
+        """The sharded loop behind ``cg_fused.run_device_loop`` (the same event handling as on
+        one GPU, over distributed vectors)."""
+        first_batch, batch_cap = 2, 64
 
-    def Pv():
-        return ShardVec(DV(L.p), sh, F.kind)
+        def iterate(self, it, end):
+            F.iterate(it, end)
 
-    hits_boundary, stop_cond = False, 1
-    counter, last_viol_it = 0, -2
-    last_feasible_x = c.zeros_like()
-    it = 0
-    nbatch = batch if batch else 2
-    while it < max_iter:
-        end = min(max_iter, it + nbatch)
-        F.iterate(it, end)
-        s = L.state.tolist()             # one blocking read per batch
-        STATS["batches"] += 1
-        stop = int(s[ST_STOP])
-        if stop == 0:
-            it = end
-            if not batch:
-                nbatch = min(2 * nbatch, 64)
-            continue
-        it_stop = int(s[ST_IT_DONE])
-        alpha = s[ST_ALPHA]
-        if stop == 4:                     # :551
-            stop_cond = 4
-            break
-        if stop == 3:                     # :558-576
-            if np.isinf(trust_radius):
-                raise ValueError("Negative curvature not allowed "
-                                 "for unrestrited problems.")
-            _, al, hit = qp.box_sphere_intersections(X(), Pv(), lb, ub, trust_radius,
-                                                     entire_line=True)
-            xf = X().add_scaled(Pv(), al) if hit else X()
-            xf = qp.reinforce_box_boundaries(xf, lb, ub)
-            L.x = xf.loc.t
-            stop_cond, hits_boundary = 3, True
-            break
-        if stop == 2:                     # :583-596
-            _, theta, hit = qp.box_sphere_intersections(X(), Pv(), lb, ub, trust_radius,
-                                                        dscale=alpha)
-            xf = X().add_scaled(Pv(), theta * alpha) if hit else X()
-            xf = qp.reinforce_box_boundaries(xf, lb, ub)
-            L.x = xf.loc.t
-            stop_cond, hits_boundary = 2, True
-            break
-        mode = 0
-        if stop == 5:                     # :599-616 x_next outside the box
-            STATS["box_events"] += 1
-            if last_viol_it != it_stop - 1:
-                counter = 0
-            counter += 1
-            last_viol_it = it_stop
-            _, theta, hit = qp.box_sphere_intersections(X(), Pv(), lb, ub, trust_radius,
-                                                        dscale=alpha)
-            if hit:
-                last_feasible_x = qp.reinforce_box_boundaries(
-                    X().add_scaled(Pv(), theta * alpha), lb, ub)
-                counter = 0
-                last_viol_it = -2
-            if counter > max_infeasible_iter:
-                break
-            mode = 1
-            s2 = F.resume(it_stop, mode)
-            if int(s2[ST_STOP]) == 6:
-                stop, mode = 6, 1
-            else:
-                it = it_stop + 1
-                continue
-        if stop == 6:                     # projections.py:72-78 refinement
-            STATS["refine_events"] += 1
+        def read_state(self):
+            return L.state.tolist()
+
+        def X(self):
+            return ShardVec(DV(L.x), sh, F.kind)
+
+        def Pv(self):
+            return ShardVec(DV(L.p), sh, F.kind)
+
+        def set_x(self, v):
+            L.x = v.loc.t
+
+        def zeros(self):
+            return c.zeros_like()
+
+        def resume(self, it_stop, mode):
+            return F.resume(it_stop, mode)
+
+        def refine(self, it_stop):
             _refine_sharded(F)
-            F.resume(it_stop, mode | 2)
-            it = it_stop + 1
-            continue
-        if stop == 7:
-            raise RuntimeError("sharded projected CG: a wait on the peer mailboxes timed out "
-                               "(a rank of the group died or fell out of step)")
-        raise RuntimeError("unexpected CG stop code %d" % stop)
 
-    x = ShardVec(DV(L.x), sh, F.kind)
-    if has_box and not qp.inside_box_boundaries(x, lb, ub):     # :636-638
-        x = last_feasible_x
-        hits_boundary = True
-    niter = int(L.state[ST_NITER].item())
+    from . import cg_fused
+    x, niter, stop_cond, hits_boundary = cg_fused.run_device_loop(
+        Driver(), STATS, lb, ub, trust_radius, max_iter, max_infeasible_iter, batch)
     STATS["fused_calls"] += 1
     STATS["iterations"] += niter
     return x, {'niter': niter, 'stop_cond': stop_cond, 'hits_boundary': hits_boundary}
