@@ -36,6 +36,8 @@ extern "C" {
 #define IPX_ENOTSPD (-3)   /* factorization met a non-positive pivot */
 #define IPX_ENOMEM (-4)
 #define IPX_EUNSUPPORTED (-5) /* this solver has no path for the matrix at hand: take another */
+#define IPX_EILLCOND (-6)  /* ipx_banded_status: factorization complete, but a pivot lost 43 bits
+                            * against its diagonal entry (numerically rank-deficient Jacobian) */
 
 /* Number of doubles of reduction workspace any entry point may need. */
 #define IPX_WS_DOUBLES 65536
@@ -165,7 +167,9 @@ void ipx_banded_destroy(void *handle);
 int ipx_banded_levels(void *handle);
 /* band[d*m+i] = S[i][i-d], d = 0..k; must outlive the solves. */
 int ipx_banded_factor(void *handle, const double *band, void *stream);
-/* Blocking: IPX_OK, or IPX_ENOTSPD when a pivot was <= 0 (rank-deficient A). */
+/* Blocking: IPX_OK; IPX_ENOTSPD when a pivot was <= 0 (rank-deficient A); IPX_EILLCOND when
+ * every pivot is positive but one lost 43 bits (solves are available; the Python host takes the
+ * reference's SVD exit, projections.py:101-108, when the matrix is small enough for it). */
 int ipx_banded_status(void *handle, void *stream);
 /* After ipx_banded_status: 1 when the separator system was found diagonal to
  * working precision (|off-diagonal| <= 2^-56 |diagonal|) so solves skip the

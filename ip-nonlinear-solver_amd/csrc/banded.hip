@@ -130,7 +130,7 @@ k_factor_chunks(int m, int c, int P, const double *__restrict__ band, double *__
 #pragma unroll
     for (int e = K; e >= 1; --e)
       if (e <= j) dj -= lrow[e - 1] * lrow[e - 1] * dw[e - 1];
-    if (!(dj > IPX_PIVOT_RTOL * band[i])) atomicOr(flag, 1);
+    if (!(dj > IPX_PIVOT_RTOL * band[i])) atomicOr(flag, (dj > 0.0) ? 1 : 5);   // 4: not positive
     Dinv[(int64_t)j * P + t] = 1.0 / dj;
 #pragma unroll
     for (int d = 1; d <= K; ++d) L[((int64_t)j * K + (d - 1)) * P + t] = lrow[d - 1];
@@ -397,7 +397,7 @@ k_decoupling_check_block(int nsep, const double *__restrict__ Rband, double *__r
     }
   }
   const double tiny = 1.3877787807814457e-17;                     // 2^-56
-  bool coupled = false, bad = false;
+  bool coupled = false, bad = false, hard = false;
   if (t > 0) {
     // R[(t,a)][(t-1,b)]: offset K + a - b (1 .. 2K-1), row t*K + a
 #pragma unroll
@@ -413,7 +413,7 @@ k_decoupling_check_block(int nsep, const double *__restrict__ Rband, double *__r
 #pragma unroll
   for (int c = 0; c < K; ++c) {
     const double piv = D[c][c];
-    if (!(piv > IPX_PIVOT_RTOL * Rband[(int64_t)t * K + c])) bad = true;
+    if (!(piv > IPX_PIVOT_RTOL * Rband[(int64_t)t * K + c])) { bad = true; hard |= !(piv > 0.0); }
     const double ip = 1.0 / piv;
 #pragma unroll
     for (int b = 0; b < K; ++b) { D[c][b] *= ip; Inv[c][b] *= ip; }
@@ -431,7 +431,7 @@ k_decoupling_check_block(int nsep, const double *__restrict__ Rband, double *__r
 #pragma unroll
     for (int b = 0; b < K; ++b) rinv[((int64_t)t * K + a) * K + b] = Inv[a][b];
   if (coupled) atomicOr(flag, 2);
-  if (bad) atomicOr(flag, 1);
+  if (bad) atomicOr(flag, hard ? 5 : 1);
   // contraction bound of block Jacobi on the separator system (what replacing R by its
   // diagonal blocks costs): max row sum of |D_t^-1 E_t,t-1| + |D_t^-1 E_t,t+1|; only
   // evaluated by separators with a coupled neighbour
@@ -865,7 +865,7 @@ k_factor_lds(int m, int c, int P, const double *__restrict__ band, double *__res
 #pragma unroll
       for (int d = 0; d < K; ++d) lw[r][d] = 0.0;
     }
-    bool bad = false;
+    bool bad = false, hard = false;
     for (int j = 0; j < ct; ++j) {
       double lrow[K];
 #pragma unroll
@@ -885,6 +885,7 @@ k_factor_lds(int m, int c, int P, const double *__restrict__ band, double *__res
       for (int e = K; e >= 1; --e)
         if (e <= j) dj -= lrow[e - 1] * lrow[e - 1] * dw[e - 1];
       bad |= !(dj > IPX_PIVOT_RTOL * bp[j]);
+      hard |= !(dj > 0.0);
       sD[j * T + tl] = 1.0 / dj;
 #pragma unroll
       for (int d = 1; d <= K; ++d) sL[(j * K + (d - 1)) * T + tl] = lrow[d - 1];
@@ -898,7 +899,7 @@ k_factor_lds(int m, int c, int P, const double *__restrict__ band, double *__res
 #pragma unroll
       for (int d = 0; d < K; ++d) lw[0][d] = lrow[d];
     }
-    if (bad) atomicOr(flag, 1);
+    if (bad) atomicOr(flag, hard ? 5 : 1);
   }
   __syncthreads();
 
@@ -2295,14 +2296,18 @@ int ipx_banded_status(void *handle, void *stream) {
     }
   }
   if (h->iter_N > 0) return IPX_OK;
-  if (h->wide && !h->decoupled) return (f & 1) ? IPX_ENOTSPD : IPX_EUNSUPPORTED;
+  if (h->wide && !h->decoupled)
+    return (f & 4) ? IPX_ENOTSPD : ((f & 1) ? IPX_EILLCOND : IPX_EUNSUPPORTED);
   if (!h->decoupled && !h->mid_fits) h->fast = false;     // level by level (k_middle needs LDS)
   if (!h->decoupled && !h->upper_done && !(f & 1)) {
     int rc = factor_upper(h, st);
     if (rc != IPX_OK) return rc;
     if (read_flag(h, &f, st) != IPX_OK) return IPX_ELAUNCH;
   }
-  return (f & 1) ? IPX_ENOTSPD : IPX_OK;
+  // bit 4: a pivot was not positive (A A' not SPD: rank-deficient A); bit 1 alone: a pivot
+  // lost IPX_PIVOT_RTOL against its diagonal entry -- the factorization is complete and
+  // usable, the caller decides (SVD exit when the matrix is small enough, refinement otherwise)
+  return (f & 4) ? IPX_ENOTSPD : ((f & 1) ? IPX_EILLCOND : IPX_OK);
 }
 
 // 1 when solves skip the middle kernel (separator system diagonal to working

@@ -316,9 +316,11 @@ k_potrf_tile(double *G, int M, int kb, int *flag, double *work) {
       const double d = T[j][j];
       const double d0 = work[kb * NB + j];
       // numerically rank deficient: the pivot lost 43 bits against its diagonal entry
-      if (!(d > IPX_PIVOT_RTOL * d0)) atomicOr(flag, 1);
-      else work[M] = fmin(work[M], d / d0);       // (one workgroup at a time: no race)
-      T[j][j] = sqrt(d);
+      // flag bit 1: the pivot lost 43 bits against its diagonal entry (numerically rank
+      // deficient, the factorization goes on); bit 4: it is not positive (no factorization)
+      if (!(d > IPX_PIVOT_RTOL * d0)) atomicOr(flag, (d > 0.0) ? 1 : 5);
+      if (d > 0.0) work[M] = fmin(work[M], d / d0);     // (one workgroup at a time: no race)
+      T[j][j] = sqrt(d > 0.0 ? d : 1.0);
     }
     __syncthreads();
     if (c == j && r > j) T[r][j] /= T[j][j];

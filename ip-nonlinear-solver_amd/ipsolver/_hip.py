@@ -107,7 +107,8 @@ class IpxError(RuntimeError):
 
 _ERRORS = {-1: "invalid argument", -2: "HIP launch/runtime error",
            -3: "matrix is not positive definite", -4: "out of memory",
-           -5: "no path in this solver for the matrix at hand"}
+           -5: "no path in this solver for the matrix at hand",
+           -6: "factorization complete but numerically rank deficient"}
 
 
 def load():

@@ -109,8 +109,13 @@ class DenseNormalSolver:
             _hip.call("ipx_aat_dense", m, _p(p.indptr), _p(p.indices), _p(A.val), _p(G), st)
         work = torch.empty(M + 1, dtype=_F64, device=dev)
         _hip.call("ipx_chol_factor", M, _p(G), _p(flag), _p(work), st)
-        if int(flag.item()) != 0:
+        fl = int(flag.item())
+        if fl & 4:
             raise np.linalg.LinAlgError("Singular Jacobian matrix: A A' is not positive definite")
+        # bit 1 alone: every pivot positive, one lost 43 bits (numerically rank deficient):
+        # ``projections`` takes the SVD exit when the matrix is small enough, else keeps this
+        # factorization with its refinement steps (pivot_ratio below)
+        self.ill_conditioned = bool(fl & 1)
         # Digits lost by the factorization (~1/cond(A)^2).  The reference's pivoted QR
         # (projections.py:175-233) loses cond(A), not cond(A)^2: for an ill-conditioned
         # Jacobian the least-squares and row-space operators get that back by refinement

@@ -130,6 +130,13 @@ class BandedNormalSolver:
         rc = lib.ipx_banded_status(ctypes.c_void_p(self.handle), stream_ptr())
         if rc == -3:
             raise np.linalg.LinAlgError("Singular Jacobian matrix: A A' is not positive definite")
+        # -6: every pivot positive but one lost 43 bits against its diagonal entry: numerically
+        # rank deficient.  ``projections`` takes the reference's SVD exit when the matrix is
+        # small enough for a dense SVD, and otherwise keeps this factorization (the reference's
+        # sparse LU only bails on exact singularity) under the orthogonality-driven refinement
+        self.ill_conditioned = rc == -6
+        if rc == -6:
+            rc = 0
         if rc == -5:
             raise BandedNotDecoupled("A A' (m=%d, half bandwidth %d): separator blocks of the "
                                      "partitioned factorization are coupled" % (self.m, self.k))
@@ -551,6 +558,12 @@ def projections(A, method=None, orth_tol=1e-12, max_refin=3, tol=1e-15):
         return SVDProjector(A, orth_tol, max_refin, tol).operators()
     try:
         solver = None if m == 0 else normal_solver_for(A)
+        inner = getattr(solver, "inner", solver)           # (box-Schur: its banded Schur solve)
+        if getattr(inner, "ill_conditioned", False):
+            if m * n <= SVDProjector.MAX_ELEMENTS:
+                raise np.linalg.LinAlgError("numerically rank deficient")
+            warn("Ill-conditioned Jacobian matrix (a pivot of A A' lost 43 bits); too large for "
+                 "the dense SVD fallback: keeping the factorization under iterative refinement.")
     except np.linalg.LinAlgError:
         # the reference's exits: projections.py:101-108 (sparse), :181-187 (dense)
         warn("Singular Jacobian matrix. Using dense SVD decomposition to perform the "
