@@ -1130,6 +1130,32 @@ def test_iterative_normal_solver_on_the_device(ips):
         IterativeNormalSolver(ips.dv.DeviceCSR.from_scipy(sps.csr_matrix(A0)))
 
 
+def test_ill_conditioned_full_rank_jacobian_too_large_for_the_svd_exit(ips):
+    """A pivot of the device factorization that has lost 43 bits marks the Jacobian numerically
+    rank deficient.  Small matrices then take the reference's SVD exit (goldens:
+    test_rank_deficient_fallback); a large sparse one (here 40000 x 80001: a dense SVD is out of
+    reach) used to abort -- the reference's sparse LU only bails on EXACT singularity
+    (projections.py:101-108).  Now the pivots being positive, the factorization is kept (a
+    warning says so) and the orthogonality-driven refinement of the null-space operator
+    (projections.py:69-78) recovers what the conditioning loses."""
+    rng = np.random.default_rng(2)
+    m = 40000
+    A = _moving_average_rows(m, 1, 2e-7, rng)           # pivots ~ 1e-14 of the diagonal
+    Ad = ips.dv.DeviceCSR.from_scipy(A)
+    with pytest.warns(UserWarning, match="Ill-conditioned Jacobian"):
+        Z, LS, Y = ips.proj.projections(Ad)
+    assert type(Z.projector.solver).__name__ == "BandedNormalSolver"
+    x = rng.standard_normal(A.shape[1])
+    z = Z.dot(x)
+    assert Z.projector.stats["refinements"] >= 1
+    assert ips.proj.orthogonality(Ad, z) <= 1e-9
+    # an exactly dependent pair of rows is still refused
+    B = A.tolil()
+    B[7, :] = B[6, :]
+    with pytest.raises(np.linalg.LinAlgError):
+        ips.proj.projections(ips.dv.DeviceCSR.from_scipy(sps.csr_matrix(B)))
+
+
 @pytest.mark.parametrize("eps", [3.0, 1.0, 0.3])
 def test_block_jacobi_preconditioner_over_condition_numbers(ips, eps):
     """The inner solve of ``IterativeNormalSolver`` with the block-Jacobi preconditioner
