@@ -1146,8 +1146,7 @@ def test_ill_conditioned_full_rank_jacobian_too_large_for_the_svd_exit(ips):
     j = np.arange(m // 2)
     rows = np.concatenate((2 * j, 2 * j, 2 * j + 1, 2 * j + 1, 2 * j + 1, 2 * j[:-1] + 1))
     cols = np.concatenate((3 * j, 3 * j + 1, 3 * j, 3 * j + 1, 3 * j + 2, 3 * j[:-1] + 3))
-    vals = np.concatenate((np.ones(m), np.ones(m // 2), np.full(m // 2, delta),
-                           np.full(m // 2 - 1, 1e-3)))
+    vals = np.concatenate((np.ones(2 * m), np.full(m // 2, delta), np.full(m // 2 - 1, 1e-3)))
     A = sps.csr_matrix((vals, (rows, cols)), shape=(m, 3 * (m // 2)))
     assert A.shape[0] * A.shape[1] > 2 ** 25
     Ad = ips.dv.DeviceCSR.from_scipy(A)
@@ -1159,7 +1158,8 @@ def test_ill_conditioned_full_rank_jacobian_too_large_for_the_svd_exit(ips):
     assert ips.proj.orthogonality(Ad, z) <= 1e-9
     # an exactly dependent pair of rows is still refused
     vals0 = vals.copy()
-    vals0[m + m // 2 + 3] = 0.0                    # delta of pair 3 -> rows 6 and 7 identical
+    vals0[2 * m + 3] = 0.0                         # delta of pair 3 -> rows 6 and 7 identical
+    vals0[2 * m + m // 2 + 3] = 0.0                # (and no link out of row 7)
     B = sps.csr_matrix((vals0, (rows, cols)), shape=A.shape)
     B.eliminate_zeros()
     with pytest.raises(np.linalg.LinAlgError):
