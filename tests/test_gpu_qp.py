@@ -1141,12 +1141,12 @@ def test_ill_conditioned_full_rank_jacobian_too_large_for_the_svd_exit(ips):
     rng = np.random.default_rng(2)
     m, delta = 40000, 2e-7
     # pairs of nearly parallel rows: (1, 1, 0) and (1, 1, delta) on three private columns,
-    # weakly tied to the next pair: the second pivot of every pair is ~ delta^2 / 2 of its
+    # tied (by delta too) to the next pair: the second pivot of every pair is ~ delta^2 / 2 of its
     # diagonal entry, i.e. 2e-14 < 2^-43
     j = np.arange(m // 2)
     rows = np.concatenate((2 * j, 2 * j, 2 * j + 1, 2 * j + 1, 2 * j + 1, 2 * j[:-1] + 1))
     cols = np.concatenate((3 * j, 3 * j + 1, 3 * j, 3 * j + 1, 3 * j + 2, 3 * j[:-1] + 3))
-    vals = np.concatenate((np.ones(2 * m), np.full(m // 2, delta), np.full(m // 2 - 1, 1e-3)))
+    vals = np.concatenate((np.ones(2 * m), np.full(m // 2, delta), np.full(m // 2 - 1, delta)))
     A = sps.csr_matrix((vals, (rows, cols)), shape=(m, 3 * (m // 2)))
     assert A.shape[0] * A.shape[1] > 2 ** 25
     Ad = ips.dv.DeviceCSR.from_scipy(A)
