@@ -2518,7 +2518,10 @@ int fast_solve(Banded *h, const double *w, double *x, double *partial, int *npar
     return IPX_EINVAL;
   }
   if (h->iter_N > 0 && !h->decoupled) {
-    if (w == x) return IPX_EINVAL;
+    // (x may alias w as the contract of ipx_banded_solve says: the correction steps read w
+    // and write scratch, x is only written by the last launch; the residual partials read w
+    // after that, so they need the two apart)
+    if (w == x && partial) return IPX_EINVAL;
     return iter_solve(h, w, x, partial, npartial, guard, st);
   }
   if (h->wide) return IPX_EUNSUPPORTED;      // no compiled separator level (see ipx_banded_create)

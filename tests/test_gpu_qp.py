@@ -1235,6 +1235,10 @@ def test_banded_defect_correction(ips, kA):
     vref = spla.splu(S).solve(w)
     assert np.max(np.abs(v - vref)) <= 1e-12 * np.max(np.abs(vref))
     assert np.array_equal(v, host(solver.solve(wd)))
+    # in place (x may alias w: the contract of ipx_banded_solve), whichever form the solve takes
+    inplace = wd.t.clone()
+    _hip.call("ipx_banded_solve", h, ips.dv._p(inplace), ips.dv._p(inplace), ips.dv.stream_ptr())
+    assert np.array_equal(inplace.cpu().numpy(), v)
     # the solve + residual form the CG loop uses
     out = torch.empty(m, dtype=torch.float64, device="cuda")
     part = torch.zeros((m + 255) // 256 + 1, dtype=torch.float64, device="cuda")
