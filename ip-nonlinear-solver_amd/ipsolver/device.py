@@ -347,8 +347,17 @@ class CSRPattern:
         return t0, t1
 
     def transpose(self, row_breaks=None):
-        """(pattern of A', permutation with valT = val[perm]) -- symbolic, once."""
+        """(pattern of A', permutation with valT = val[perm]) -- symbolic, once.  ``row_breaks``
+        (tile boundaries of the transpose) must be given by the first caller: a later request
+        for other boundaries is refused instead of silently keeping the cached tiles."""
+        breaks = None if row_breaks is None else tuple(int(b) for b in row_breaks)
+        if self._transpose is not None and breaks is not None \
+                and breaks != getattr(self, "_transpose_breaks", None):
+            raise _hip.IpxError("CSRPattern.transpose: the transpose of this pattern was already "
+                                "built with row breaks %r, now asked for %r"
+                                % (getattr(self, "_transpose_breaks", None), breaks))
         if self._transpose is None:
+            self._transpose_breaks = breaks
             import scipy.sparse as sps
             m, n = self.shape
             tag = sps.csr_matrix((np.arange(1, self.nnz + 1, dtype=np.float64),
