@@ -217,7 +217,15 @@ def _sharded_backend(shard, constr, n_vars):
                                   "rows to partition (sparse_jacobian=True)")
     J = sps.csr_matrix(J)
     J.sort_indices()
-    lay = sharded.ShardLayout(J.indptr, J.indices, J.shape, comm.world, comm.rank)
+    try:
+        lay = sharded.ShardLayout(J.indptr, J.indices, J.shape, comm.world, comm.rank)
+    except (NotImplementedError, ValueError):
+        # no band to follow (or too few row blocks for the ranks): the plain block partition
+        # with all-gather / reduce-scatter products (ipsolver/sharded_general.py)
+        if constr.n_ineq:
+            raise
+        from . import sharded_general
+        return sharded_general.GeneralBackend(sharded_general.general_sharding(J.shape, ops, comm))
     sh = sharded.Sharding(lay, comm, ops)
     xp = sharded.ShardedBackend(sh)
     if constr.n_ineq:

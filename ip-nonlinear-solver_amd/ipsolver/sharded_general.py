@@ -26,9 +26,10 @@ import scipy.sparse as sps
 import torch
 import torch.distributed as dist
 
-from .sharded import ShardVec, Sharding, ShardComm, _ShardOp
+from .sharded import ShardVec, Sharding, ShardComm, ShardedBackend, _ShardOp
 
-__all__ = ["GeneralLayout", "GeneralCSR", "GeneralHessian", "projections", "general_sharding"]
+__all__ = ["GeneralLayout", "GeneralCSR", "GeneralHessian", "GeneralBackend", "projections",
+           "general_sharding"]
 
 
 class GeneralLayout:
@@ -271,3 +272,43 @@ def projections(A, method=None, orth_tol=1e-12, max_refin=3, tol=1e-15):
     if method not in (None, "NormalEquation", "AugmentedSystem"):
         raise ValueError("Method not allowed for sparse matrix.")
     return GeneralProjector(A, orth_tol, max_refin).operators()
+
+
+class GeneralBackend(ShardedBackend):
+    """The backend of the outer loops (``sqp.py`` / ``barrier.py``) on the plain block
+    partition: what ``minimize_constrained`` dispatches to when the Jacobian has no band for
+    ``sharded.ShardLayout`` to follow.  Equality-constrained problems (both outer methods)."""
+    name = "sharded-general"
+
+    def matrix(self, J, key="jac"):
+        if J is None or isinstance(J, GeneralCSR):
+            return J
+        if not sps.issparse(J):
+            raise NotImplementedError("sharded backend: dense Jacobians are not distributed")
+        return GeneralCSR.from_global(self.sh, J)
+
+    def augmented_jacobian(self, J_eq, J_ineq, s, n_vars, n_eq, n_ineq):
+        raise NotImplementedError("row-sharded solve without a banded Jacobian: equality "
+                                  "constraints only")
+
+    def hessian_operator(self, terms, n_vars, slack_block):
+        if slack_block is not None:
+            raise NotImplementedError("row-sharded solve without a banded Jacobian: equality "
+                                      "constraints only")
+        if isinstance(terms, GeneralHessian):
+            return terms
+        from .canonical import HessianSum
+        flat = terms.flat_terms() if isinstance(terms, HessianSum) else list(terms)
+        total = None
+        for h in flat:
+            if isinstance(h, np.ndarray) and h.ndim == 2:
+                h = sps.csr_matrix(h)
+            if not sps.issparse(h):
+                raise NotImplementedError("sharded backend: Hessian terms must be sparse matrices")
+            total = sps.csr_matrix(h) if total is None else total + sps.csr_matrix(h)
+        if total is None:
+            total = sps.csr_matrix((self.sh.lay.n, self.sh.lay.n))
+        return GeneralHessian.from_global(self.sh, total)
+
+    def projections(self, A, method=None):
+        return projections(A, method)

@@ -581,3 +581,70 @@ def test_general_sparsity_sharding_matches_the_oracle(world, tmp_path):
     path = str(tmp_path / "general.npz")
     mp.spawn(_general_worker, args=(world, _free_port(), path), nprocs=world, join=True)
     check_general(np.load(path))
+
+
+def _general_api_worker(rank, world, port, out_path):
+    _setup(rank, world, port)
+    try:
+        import warnings
+        import ipsolver
+        from oracle.numpy_local import NumpyOps
+        A_h, H_h, c_h, b_h = _random_problem(m=120, n=500, seed=11)
+        rows = []
+
+        def record(state):
+            rows.append([int(state.niter), int(state.cg_niter), float(state.trust_radius),
+                         float(state.penalty), float(state.optimality),
+                         float(state.constr_violation), int(state.nfev)])
+            return False
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            res = ipsolver.minimize_constrained(
+                lambda x: 0.5 * x.dot(H_h.dot(x)) + c_h.dot(x), np.zeros(len(c_h)),
+                lambda x: H_h.dot(x) + c_h, lambda x: H_h,
+                ipsolver.LinearConstraint(A_h, ("equals", b_h)), callback=record,
+                options={"shard": NumpyOps()})
+        if rank == 0:
+            np.savez(out_path, x=res.x, rows=np.array(rows), status=res.status)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_minimize_constrained_dispatches_a_jacobian_without_band(tmp_path):
+    """``minimize_constrained`` on two ranks with a LinearConstraint of random sparsity: no band
+    for the halo partition to follow, so the dispatch falls back to the plain block partition
+    (all-gather / reduce-scatter products, distributed inner CG: sharded_general.py).  Against
+    the same call on the single-process CPU backend of the oracle."""
+    import warnings
+    import ipsolver
+    import oracle.numpy_backend as nb
+    from ipsolver import backend
+    path = str(tmp_path / "gen_api.npz")
+    mp.spawn(_general_api_worker, args=(2, _free_port(), path), nprocs=2, join=True)
+    got = np.load(path)
+    A_h, H_h, c_h, b_h = _random_problem(m=120, n=500, seed=11)
+    rows = []
+
+    def record(state):
+        rows.append([int(state.niter), int(state.cg_niter), float(state.trust_radius),
+                     float(state.penalty), float(state.optimality),
+                     float(state.constr_violation), int(state.nfev)])
+        return False
+    with backend.use(nb), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res = ipsolver.minimize_constrained(
+            lambda x: 0.5 * x.dot(H_h.dot(x)) + c_h.dot(x), np.zeros(len(c_h)),
+            lambda x: H_h.dot(x) + c_h, lambda x: H_h,
+            ipsolver.LinearConstraint(A_h, ("equals", b_h)), callback=record,
+            options={"shard": False})
+    want, have = np.array(rows), got["rows"]
+    # (the end game of this un-centred quadratic sits on the merit function's rounding floor --
+    # SURVEY.md section 7, hard part 4: gtol or xtol, a few iterations apart; the trace before it
+    # and the solution must agree)
+    assert int(got["status"]) in (1, 2) and res.status in (1, 2)
+    k = min(len(have), len(want)) - 4
+    assert k >= 8
+    for col in (0, 1, 6):
+        assert np.array_equal(have[:k, col], want[:k, col]), col
+    assert np.allclose(have[:k, 2:6], want[:k, 2:6], rtol=1e-6, atol=1e-10)
+    close(got["x"], res.x, 1e-6)
