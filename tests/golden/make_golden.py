@@ -275,7 +275,7 @@ def config2(n, m):
     return rec
 
 
-def run_e2e(name, fun, x0, grad, hess, constraints, **kw):
+def _trace_of(fun, x0, grad, hess, constraints, kw):
     rows = []
 
     def cb(state):
@@ -290,6 +290,45 @@ def run_e2e(name, fun, x0, grad, hess, constraints, **kw):
         warnings.simplefilter("ignore")
         res = ref.minimize_constrained(fun, x0, grad, hess, constraints,
                                        callback=cb, **kw)
+    return res, rows
+
+
+def one_ulp_sensitivity(rows, x, fun, x0, grad, hess, constraints, kw, seeds=(31, 32, 33)):
+    """How well the reference's OWN trace is determined: the same run with every component of
+    the objective gradient moved by one unit in the last place (seeded sign patterns).
+    Returns ``stable_rows`` -- the leading rows whose integer columns (niter, cg_niter, nfev)
+    are the same in every perturbed run -- and, per row of that prefix and float column, the
+    largest absolute change; plus the largest relative change of the final x (None when a
+    perturbed run ends elsewhere in the trace)."""
+    ref_rows = np.array([[np.nan if v is None else v for v in r] for r in rows], dtype=float)
+    stable = len(ref_rows)
+    sens = np.zeros((len(ref_rows), 8))
+    x_sens, same_end = 0.0, True
+    for seed in seeds:
+        rng = np.random.default_rng(seed)
+        signs = rng.choice([-1.0, 1.0], size=np.size(x0))
+        res_p, rows_p = _trace_of(fun, x0, lambda xx: np.asarray(grad(xx), dtype=float)
+                                  * (1.0 + np.ldexp(1.0, -52) * signs), hess, constraints, kw)
+        pr = np.array(rows_p, dtype=float)
+        k = min(len(pr), len(ref_rows))
+        ints = (0, 1, 7)
+        agree = np.all(pr[:k][:, ints] == ref_rows[:k][:, ints], axis=1)
+        first_bad = int(np.argmin(agree)) if not agree.all() else k
+        stable = min(stable, first_bad)
+        if len(pr) != len(ref_rows) or first_bad < k:
+            same_end = False
+        with np.errstate(invalid="ignore"):
+            d = np.abs(pr[:k] - ref_rows[:k])
+        d[~np.isfinite(d)] = 0.0
+        sens[:k] = np.maximum(sens[:k], d)
+        xp = np.asarray(res_p.x)
+        x_sens = max(x_sens, float(np.max(np.abs(xp - x)) / max(np.max(np.abs(x)), 1e-300)))
+    return {"stable_rows": int(stable), "rows": jf(sens[:stable]),
+            "x": x_sens if same_end else None, "seeds": list(seeds)}
+
+
+def run_e2e(name, fun, x0, grad, hess, constraints, **kw):
+    res, rows = _trace_of(fun, x0, grad, hess, constraints, kw)
     rec = {"x": jf(np.asarray(res.x)) if np.size(res.x) <= 64
            else jf(np.asarray(res.x)[::max(1, np.size(res.x) // 50)]),
            "status": int(res.status), "niter": int(res.niter),
@@ -303,12 +342,16 @@ def run_e2e(name, fun, x0, grad, hess, constraints, **kw):
            "v": jf(np.asarray(res.v)) if np.size(res.v) <= 64 else None,
            "keys": sorted(res.keys()),
            "trace": jf(rows)}
+    if "--no-sens" not in sys.argv:
+        rec["one_ulp"] = one_ulp_sensitivity(rows, np.asarray(res.x), fun, x0, grad, hess,
+                                             constraints, kw)
     if "s" in res:
         rec["s"] = jf(np.asarray(res.s)) if np.size(res.s) <= 64 else None
         rec["barrier_parameter"] = jf(res.barrier_parameter)
-    print("  %-28s status %d niter %d cg %d" % (name, rec["status"],
-                                                 rec["niter"],
-                                                 rec["cg_niter"]))
+    print("  %-28s status %d niter %d cg %d   stable rows under one ulp: %s of %d, x moves %s"
+          % (name, rec["status"], rec["niter"], rec["cg_niter"],
+             rec.get("one_ulp", {}).get("stable_rows"), len(rows),
+             rec.get("one_ulp", {}).get("x")))
     return rec
 
 
@@ -486,6 +529,10 @@ def main():
         for n, m, k in ((400, 40, 6), (12000, 1200, 4)):
             np.savez_compressed(os.path.join(HERE, "late_barrier_n%d.npz" % n),
                                 **late_barrier(n, m, k))
+        return
+    if "--e2e" in sys.argv:
+        with open(os.path.join(HERE, "e2e.json"), "w") as f:
+            json.dump(e2e(), f)
         return
     if "--n20000" in sys.argv:
         # banded equality NLP at a size the row-sharded solver can split (8 blocks of 260 rows)
