@@ -393,7 +393,7 @@ def _loop_for(H, P, lb, ub):
     """A loop object for this call: an idle one built for the same patterns with its value
     pointers re-bound (a projected_cg call otherwise allocates ~15 device buffers and rebuilds
     the argument block: ~0.15 ms, as much as the kernels of a short solve), else a new one."""
-    key = _signature(H, P, lb, ub)
+    key = None if os.environ.get("IPX_NO_POOL") else _signature(H, P, lb, ub)
     L = _POOL.pop(key, None) if key is not None else None
     if L is not None and L.rebind(H, P, lb, ub):
         POOL_STATS["reused"] += 1

@@ -49,9 +49,12 @@ def compare(res, rows, gold, rtol=1e-10, prefix=None, x_rtol=1e-10, amplify=10.0
 
       * integer columns: exact;
       * float columns: ``|got - want| <= rtol |want| + amplify x (the reference's own movement)
-        + 16 eps x (largest value of the column)``, rtol = 1e-10 -- the last term is the
-        rounding floor of quantities formed as differences of O(scale) numbers (optimality,
-        constraint violation);
+        + 256 eps x (largest value of the column)``, rtol = 1e-10 -- the last term is the
+        rounding floor of quantities formed as differences of O(scale) numbers: optimality and
+        constraint violation fall to 1e-9 of their first values while the iterates they are
+        formed from stay O(1), and iterates that agree to 1e-14 (the bar is 1e-10) leave them
+        an absolute difference of ~100 eps (measured: 2.2e-14 on a violation of 4e-6, README
+        example, row 8);
       * when the whole trace is stable: counters, status, result keys exact and the final x to
         ``x_rtol`` + amplify x its own movement.
 
@@ -80,7 +83,7 @@ def compare(res, rows, gold, rtol=1e-10, prefix=None, x_rtol=1e-10, amplify=10.0
         assert np.array_equal(np.isfinite(a), ok)
         if not ok.any():
             continue
-        floor = 16 * EPS * np.max(np.abs(want[:, col][np.isfinite(want[:, col])]))
+        floor = 256 * EPS * np.max(np.abs(want[:, col][np.isfinite(want[:, col])]))
         err = np.abs(a[ok] - b[ok])
         bound = rtol * np.abs(b[ok]) + amplify * sens[:k, col][ok] + floor
         assert np.all(err <= bound), (TRACE_COLS[col], int(np.argmax(err / bound)),
@@ -98,8 +101,14 @@ ALL = problems.exact_hessian_problems() + problems.fd_hessian_problems()
 
 
 def trace_policy(name):
-    """(kept for the callers' signature: the compared rows and tolerances now come from the
-    ``one_ulp`` record of every golden trace, see ``compare``)"""
+    """Keyword arguments of ``compare`` per golden trace.  The compared rows and bounds come
+    from the trace's ``one_ulp`` record; one class needs more: forward-difference Hessians
+    (``hess='2-point'``) divide the rounding of TWO gradient evaluations by h ~ 1.5e-8, so
+    every H.p carries a relative noise of eps / h ~ 1e-8 that depends on the last bits of p --
+    it does not show in the one-ulp record (the probe scales both evaluations alike) and any
+    two implementations see it differently: those traces are held to 1e-6."""
+    if name.endswith("_fd2"):
+        return dict(rtol=1e-6)
     return {}
 
 
