@@ -97,6 +97,40 @@ def compare(res, rows, gold, rtol=1e-10, prefix=None, x_rtol=1e-10, amplify=10.0
         assert np.max(np.abs(x - gx)) <= (x_rtol + amplify * x_move) * np.max(np.abs(gx))
 
 
+def compare_rows(rows, gold, x=None, rtol=1e-10, amplify=10.0, min_rows=8):
+    """``compare`` for runs that only carry their trace rows (and optionally the final x): the
+    multi-process tests.  Compares the rows the reference's own trace is stable on (golden
+    ``one_ulp``; fewer when the run was stopped earlier) and returns how many."""
+    want = np.array([[np.nan if isinstance(v, str) and v == "nan" else v for v in r]
+                     for r in unjson(gold["trace"])], dtype=float)
+    got = np.array(rows, dtype=float)
+    ulp = gold["one_ulp"]
+    stable = int(ulp["stable_rows"])
+    sens = np.array(unjson(ulp["rows"]), dtype=float).reshape(stable, 8)
+    k = min(stable, len(got))
+    assert k >= min(stable, min_rows), (k, stable, len(got))
+    for col in (0, 1, 7):
+        assert np.array_equal(got[:k, col], want[:k, col]), TRACE_COLS[col]
+    for col in (2, 3, 4, 5, 6):
+        a, b = got[:k, col], want[:k, col]
+        ok = np.isfinite(b)
+        assert np.array_equal(np.isfinite(a), ok)
+        if not ok.any():
+            continue
+        floor = 256 * EPS * np.max(np.abs(want[:, col][np.isfinite(want[:, col])]))
+        err = np.abs(a[ok] - b[ok])
+        bound = rtol * np.abs(b[ok]) + amplify * sens[:k, col][ok] + floor
+        assert np.all(err <= bound), (TRACE_COLS[col], int(np.argmax(err / bound)),
+                                      float(np.max(err / bound)))
+    if x is not None and k == len(want) and ulp["x"] is not None:
+        gx = np.asarray(unjson(gold["x"]), dtype=float)
+        xs = np.asarray(x)
+        if xs.size != gx.size:
+            xs = xs[::max(1, xs.size // 50)]
+        assert np.max(np.abs(xs - gx)) <= (rtol + amplify * float(ulp["x"])) * np.max(np.abs(gx))
+    return k
+
+
 ALL = problems.exact_hessian_problems() + problems.fd_hessian_problems()
 
 

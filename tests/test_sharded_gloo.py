@@ -132,31 +132,11 @@ def _solve_worker(rank, world, port, method, out_path):
 def test_sharded_full_solve_matches_reference(world, method, tmp_path):
     """BASELINE config 4 end to end at n = 20000: the whole equality-constrained solve (outer
     loops sqp.py / barrier.py over the sharded backend, sharded callbacks) against the trace
-    of the REFERENCE on the same seeded problem (tests/golden/e2e_n20000.json)."""
-    import json
-    from conftest import unjson
-    from test_host_logic import EPS
+    of the REFERENCE on the same seeded problem (tests/golden/e2e_n20000.json): counters exact,
+    every row and the solution at 1e-10 + 10 x the reference's own one-ulp movement."""
     path = str(tmp_path / "solve.npz")
     mp.spawn(_solve_worker, args=(world, _free_port(), method, path), nprocs=world, join=True)
-    got = np.load(path)
-    with open(os.path.join(ROOT, "tests", "golden", "e2e_n20000.json")) as f:
-        gold = json.load(f)["banded_eq_n20000_%s" % method]
-    assert list(got["counts"]) == [gold[k] for k in ("status", "niter", "cg_niter", "nfev", "ngev",
-                                                     "nhev", "ncev", "njev")]
-    want = np.array([[np.nan if isinstance(v, str) else v for v in r]
-                     for r in unjson(gold["trace"])], dtype=float)
-    rows = got["rows"]
-    assert rows.shape == want.shape
-    for col in (0, 1, 7):
-        assert np.array_equal(rows[:, col], want[:, col])
-    for col in (2, 3, 4, 5, 6):
-        ok = np.isfinite(want[:, col])
-        if not ok.any():
-            continue
-        floor = 256 * EPS * np.max(np.abs(want[ok, col]))
-        assert np.all(np.abs(rows[ok, col] - want[ok, col]) <= 1e-9 * np.abs(want[ok, col]) + floor)
-    gx = np.asarray(unjson(gold["x"]))
-    close(got["x"][::max(1, N // 50)], gx, 1e-9)
+    check_config4(np.load(path), method)
 
 
 def _api_worker(rank, world, port, what, out_path, ops_name="numpy"):
@@ -175,7 +155,7 @@ def _api_worker(rank, world, port, what, out_path, ops_name="numpy"):
             from oracle.numpy_local import NumpyOps
             shard = NumpyOps()
         rows = []
-        limit = {"config5": 24, "enforce": 14}.get(what)
+        limit = {"config5": 34, "enforce": 14}.get(what)
 
         def record(state):
             rows.append([int(state.niter), int(state.cg_niter), float(state.trust_radius),
@@ -213,40 +193,27 @@ def _api_worker(rank, world, port, what, out_path, ops_name="numpy"):
 
 def check_config4(got, method):
     import json
-    from conftest import unjson
-    from test_host_logic import EPS
+    from test_host_logic import compare_rows
     with open(os.path.join(ROOT, "tests", "golden", "e2e_n20000.json")) as f:
         gold = json.load(f)["banded_eq_n20000_%s" % method]
     assert list(got["counts"]) == [gold[k] for k in ("status", "niter", "cg_niter", "nfev", "ngev",
                                                      "nhev", "ncev", "njev")]
-    want = np.array([[np.nan if isinstance(v, str) else v for v in r]
-                     for r in unjson(gold["trace"])], dtype=float)
-    rows = got["rows"]
-    assert rows.shape == want.shape
-    for col in (0, 1, 7):
-        assert np.array_equal(rows[:, col], want[:, col])
-    for col in (2, 3, 4, 5, 6):
-        ok = np.isfinite(want[:, col])
-        if not ok.any():
-            continue
-        floor = 256 * EPS * np.max(np.abs(want[ok, col]))
-        assert np.all(np.abs(rows[ok, col] - want[ok, col]) <= 1e-9 * np.abs(want[ok, col]) + floor)
-    gx = np.asarray(unjson(gold["x"]))
-    close(got["x"][::max(1, N // 50)], gx, 1e-9)
+    # every row (the reference's own trace is stable on all of them under one ulp), floats to
+    # 1e-10 + 10 x the reference's own movement, the final x likewise
+    assert compare_rows(got["rows"], gold, x=got["x"]) == len(gold["trace"])
 
 
-def check_config5_prefix(got, k=16):
+def check_config5_prefix(got, min_rows=16):
+    """Against the reference's barrier run at n = 12000: the rows its own trace is stable on
+    under one ulp in the gradient (32 of 64; fewer when the run was stopped earlier), floats
+    to 1e-10 + 10 x the reference's own movement."""
     import json
-    from conftest import unjson
+    from test_host_logic import compare_rows
     with open(os.path.join(ROOT, "tests", "golden", "e2e_ineq_n12000.json")) as f:
         gold = json.load(f)["banded_ineq_n12000"]
-    want = np.array(unjson(gold["trace"]), dtype=float)
-    rows = got["rows"]
-    assert len(rows) >= k and int(got["status"]) == 3
-    for col in (0, 1, 7):
-        assert np.array_equal(rows[:k, col], want[:k, col]), col
-    for col in (2, 3, 4, 5, 6):
-        assert np.allclose(rows[:k, col], want[:k, col], rtol=1e-6, atol=1e-12), col
+    assert int(got["status"]) == 3
+    # (stopped by the callback: the last recorded row is the hand-over's repeat, not a step)
+    assert compare_rows(got["rows"][:-1], gold, min_rows=min_rows) >= min_rows
     assert got["s"].min() > 0 and np.all(np.abs(got["x"]) < 0.8)
 
 
@@ -303,8 +270,8 @@ def test_minimize_constrained_sharded_enforce_feasibility(tmp_path):
     k = 12
     for col in (0, 1, 7):
         assert np.array_equal(have[:k, col], want[:k, col]), col
-    for col in (2, 3, 4, 5, 6):
-        assert np.allclose(have[:k, col], want[:k, col], rtol=1e-6, atol=1e-12), col
+    for col in (2, 3, 4, 5, 6):            # (two builds of this package: 1e-9)
+        assert np.allclose(have[:k, col], want[:k, col], rtol=1e-9, atol=1e-13), col
     assert np.all(np.abs(got["x"]) < 0.8) and got["s"].min() > 0
 
 
@@ -346,26 +313,13 @@ def test_sharded_barrier_box_inequality_matches_reference(world, tmp_path):
     backend, two and three ranks (a middle rank has halos on both sides), against the trace of the REFERENCE on the same seeded problem
     (tests/golden/e2e_ineq_n12000.json; the reference needs 225 s for its 64 outer / 26090 CG
     iterations).  Thousands of CG iterations amplify last-bit differences until an accept /
-    reject branch flips after ~20 outer iterations (every implementation, the single-GPU one
-    too: tests/test_gpu_e2e.py), so the first 16 outer iterations are compared: iteration
-    counters exact, floats to 1e-6."""
-    import json
-    from conftest import unjson
+    reject branch flips: under one ulp in the gradient the reference's own trace keeps its
+    counters for 32 of 64 rows (golden ``one_ulp``).  The 24 rows this run records are inside
+    that: counters exact, floats to 1e-10 + 10 x the reference's own movement."""
     path = str(tmp_path / "barrier.npz")
     mp.spawn(_barrier_worker, args=(world, _free_port(), path), nprocs=world, join=True)
     got = np.load(path)
-    with open(os.path.join(ROOT, "tests", "golden", "e2e_ineq_n12000.json")) as f:
-        gold = json.load(f)["banded_ineq_n12000"]
-    want = np.array(unjson(gold["trace"]), dtype=float)
-    rows = got["rows"]
-    k = 16
-    assert len(rows) >= k and int(got["status"]) == 3          # stopped by the callback
-    for col in (0, 1, 7):
-        assert np.array_equal(rows[:k, col], want[:k, col]), col
-    for col in (2, 3, 4, 5, 6):
-        assert np.allclose(rows[:k, col], want[:k, col], rtol=1e-6, atol=1e-12), col
-    # slacks interior, box respected along the way
-    assert got["s"].min() > 0 and np.all(np.abs(got["x"]) < 0.8)
+    check_config5_prefix(got, min_rows=24)
     assert got["s"].shape == (1200 + 2 * 12000,)
 
 
