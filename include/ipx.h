@@ -287,11 +287,6 @@ typedef struct ipx_cg_args {
    * Hp = H p and the scalar p'Hp into part1[1] (H_ntiles = 1, the H_* arrays unused).  The
    * branches and step lengths stay on the device. */
   int64_t H_operator;
-  /* Row tiles [t0, t1) of H (H_dia_tiles = t0 | t1 << 32) whose rows all have H_dia_rl entries
-   * at the same offsets from the row index (H_dia_off: up to 8 signed bytes, entry k in byte
-   * k): the fused step2 + H.p kernel computes their columns instead of reading H_col16.  0:
-   * none. */
-  int64_t H_dia_tiles, H_dia_rl, H_dia_off;
 } ipx_cg_args;
 int ipx_cg_state_size(void);
 int ipx_cg_vec_grid(int64_t n);

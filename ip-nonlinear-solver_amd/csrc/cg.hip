@@ -347,13 +347,7 @@ k_cg_step2_hp(int n, double *st, int parity, int mode, const double *__restrict_
               const double *__restrict__ diag, double *__restrict__ Hp,
               double *__restrict__ partial, int hmax, const double *__restrict__ pb_in,
               double *__restrict__ pb_out,
-              const uint16_t *__restrict__ col16, const int32_t *__restrict__ rowlen,
-              int dia_t0, int dia_t1, int dia_rl, long long dia_off) {
-  // Tiles [dia_t0, dia_t1): every row has dia_rl entries at the SAME offsets from its own
-  // index (a matrix stored by diagonals in CSR clothes -- the tridiagonal-plus-diagonal
-  // Lagrangian Hessian of the banded benchmark: offsets -1, 0, +1; packed as signed bytes in
-  // dia_off).  There the columns are arithmetic, no index is read at all: 2 bytes per nonzero
-  // less on top of C16, 6 of the 86 MB this kernel moves at n = 1e6.
+              const uint16_t *__restrict__ col16, const int32_t *__restrict__ rowlen) {
   __shared__ double prod[FT_NNZ];
   __shared__ double span[QS * IPX_BLOCK];
   __shared__ int rp[Q * IPX_BLOCK + 1];
@@ -397,16 +391,10 @@ k_cg_step2_hp(int n, double *st, int parity, int mode, const double *__restrict_
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int jj = min(s + tid + u * IPX_BLOCK, max(e - 1, 0));   // empty tile: any valid entry
-    if (C16 && tile >= dia_t0 && tile < dia_t1) {
-      const int q = jj - s, row = q / dia_rl, kth = q - row * dia_rl;
-      c[u] = (r0 - c_lo) + row + (int)(signed char)((unsigned long long)dia_off >> (8 * kth));
-    } else {
-      c[u] = C16 ? (int)col16[jj] : colidx[jj] - c_lo;
-    }
+    c[u] = C16 ? (int)col16[jj] : colidx[jj] - c_lo;
     v[u] = val[jj];
   }
-  // >= 0: every row of the tile has rl entries (the row pointers are not read)
-  const int rl = !C16 ? -1 : ((tile >= dia_t0 && tile < dia_t1) ? dia_rl : rowlen[tile]);
+  const int rl = C16 ? rowlen[tile] : -1;       // >= 0: every row of the tile has rl entries
   // span operands: element j of the span is column c_lo + j
   double sp[QS], sg[QS];
   const double *pbl = pb_in + (int64_t)(tile - 1) * 2 * hmax + hmax;   // right part of tile-1
@@ -1019,8 +1007,7 @@ static int launch_step2_hp(const ipx_cg_args *a, int it, int mode, const double 
   (int)a->n, a->state, it & 1, mode, p2, np2, p3, np3, p4, np4, a->x, a->p, g,                \
       a->H_rowptr, a->H_colidx, a->H_val, a->H_tiles,                                         \
       (int)a->H_ntiles, a->H_diag, a->Hp, a->part1, (int)a->H_hmax, pb_in, pb_out,           \
-      (const uint16_t *)a->H_col16, a->H_rowlen, (int)(a->H_dia_tiles & 0xffffffff),            \
-      (int)(a->H_dia_tiles >> 32), (int)a->H_dia_rl, (long long)a->H_dia_off
+      (const uint16_t *)a->H_col16, a->H_rowlen
   // H_hmax carries the longest tile's row count in its upper half (set by the host
   // binding): short tiles (3 nonzeros per row -> 683 rows) take the 3-elements-per-lane
   // instantiation, which needs fewer registers

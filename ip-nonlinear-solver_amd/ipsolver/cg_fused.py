@@ -43,8 +43,7 @@ class CgArgs(ctypes.Structure):
         ("At_ell_col", _P), ("At_ell_val", _P),
         ("H_col16", _P), ("H_rowlen", _P), ("A_col16", _P), ("no_radius", _I64),
         ("A_off16", _P), ("A_rowfirst", _P), ("A_rl", _I64), ("P_win", _P), ("P_nspan", _I64),
-        ("P_navn", _I64), ("H_operator", _I64), ("H_dia_tiles", _I64), ("H_dia_rl", _I64),
-        ("H_dia_off", _I64))]
+        ("P_navn", _I64), ("H_operator", _I64))]
 
 
 # Counters over the life of the process (diagnostics: how often the device loop
@@ -141,53 +140,6 @@ def compact_columns(pattern, hmax):
     out = (torch.from_numpy(off.astype(np.uint16).view(np.int16)).to(dev),
            torch.from_numpy(rowlen).to(dev))
     pattern._ipx_col16 = (key, out)
-    return out
-
-
-def diagonal_tiles(pattern):
-    """``(t0, t1, rl, packed offsets)`` -- the longest run of row tiles whose rows all have
-    ``rl`` (<= 8) entries at the same offsets from the row index (within +-127), for the
-    arithmetic columns of csrc/cg.hip k_cg_step2_hp -- or None.  Symbolic; cached."""
-    cached = getattr(pattern, "_ipx_dia", False)
-    if cached is not False:
-        return cached
-    out = None
-    nt = pattern.ntiles
-    t = pattern.tiles_h
-    ip, idx = pattern.indptr_h.astype(np.int64), pattern.indices_h.astype(np.int64)
-    lens = np.diff(ip)
-    if nt > 0 and pattern.nnz > 0:
-        rows = np.repeat(np.arange(pattern.shape[0], dtype=np.int64), lens)
-        off = idx - rows
-        r0, r1 = t[:nt].astype(np.int64), t[1:nt + 1].astype(np.int64)
-        # candidate: the row length / offsets of the middle row
-        mid = pattern.shape[0] // 2
-        rl = int(lens[mid])
-        if 1 <= rl <= 8 and np.abs(off).max() <= 127:
-            ref = off[ip[mid]:ip[mid + 1]]
-            good_row = lens == rl
-            same = np.zeros(pattern.shape[0], dtype=bool)
-            full = np.flatnonzero(good_row)
-            same[full] = np.all(off[ip[full][:, None] + np.arange(rl)[None, :]] == ref[None, :], axis=1)
-            bad_before = np.concatenate(([0], np.cumsum(~same)))
-            tile_ok = (bad_before[r1] - bad_before[r0] == 0) & (r1 > r0)
-            # longest run of consecutive good tiles
-            best, cur0 = (0, 0), None
-            for k in range(nt + 1):
-                if k < nt and tile_ok[k]:
-                    cur0 = k if cur0 is None else cur0
-                else:
-                    if cur0 is not None and k - cur0 > best[1] - best[0]:
-                        best = (cur0, k)
-                    cur0 = None
-            if best[1] > best[0]:
-                packed = 0
-                for k, o in enumerate(ref):
-                    packed |= (int(o) & 0xff) << (8 * k)
-                if packed >= 1 << 63:
-                    packed -= 1 << 64
-                out = (best[0], best[1], rl, packed)
-    pattern._ipx_dia = out
     return out
 
 
@@ -432,7 +384,7 @@ def _signature(H, P, lb, ub):
         return None                      # operator Hessians: not pooled
     Hc, Hd = _hessian_parts(H)
     flags = tuple(bool(os.environ.get(k)) for k in ("IPX_NO_FUSE", "IPX_NO_C16", "IPX_FUSE_TN",
-                                                    "IPX_TAIL_MAXWG", "IPX_PROJECT", "IPX_NO_DIA"))
+                                                    "IPX_TAIL_MAXWG", "IPX_PROJECT"))
     return (id(Hc.pattern), Hd is None, id(P.A.pattern), lb is None, ub is None,
             _solver_kind(P.solver), int(getattr(P.solver, "k", 0)), flags)
 
@@ -566,9 +518,6 @@ class _Loop:
             if not os.environ.get("IPX_NO_C16"):
                 self.H_col16, self.H_rowlen = compact_columns(Hc.pattern, hmax)
                 a.H_col16, a.H_rowlen = _ptr(self.H_col16), _ptr(self.H_rowlen)
-                dia = None if os.environ.get("IPX_NO_DIA") else diagonal_tiles(Hc.pattern)
-                if dia is not None:
-                    a.H_dia_tiles, a.H_dia_rl, a.H_dia_off = dia[0] | (dia[1] << 32), dia[2], dia[3]
         # banded Jacobian, no box: step1 rides inside the A.r SpMV
         tn = int(os.environ.get("IPX_FUSE_TN", "0")) or None
         own = None if (os.environ.get("IPX_NO_FUSE") or lb is not None or m == 0) \
