@@ -414,10 +414,15 @@ def config2_leg():
     del At, Ht
     # the Gram kernel alone
     Ad = DeviceDense.from_host(A)
-    M = _hip.load().ipx_dense_padded(m)
+    lib = _hip.load()
+    M = lib.ipx_dense_padded(m)
     Gd = torch.zeros(M * M, dtype=torch.float64, device=Ad.t.device)
     st = dv.stream_ptr()
-    gram = lambda: _hip.call("ipx_gram_f64_mfma", m, n, dv._p(Ad.t), n, dv._p(Gd), st)
+    splits = int(lib.ipx_gram_splits(m, n))      # K-splits that even the tiles out over the CUs
+    ws = torch.empty(max(int(lib.ipx_gram_ws_doubles(m, splits)), 1), dtype=torch.float64,
+                     device=Ad.t.device)
+    gram = lambda: _hip.call("ipx_gram_f64_mfma_split", m, n, dv._p(Ad.t), n, dv._p(Gd),
+                             dv._p(ws), splits, st)          # what DenseNormalSolver launches
     for _ in range(3):
         gram()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -444,7 +449,8 @@ def config2_leg():
                                  "optimality": float(res_d.optimality),
                                  "note": "A and H resident in HBM (2-D CUDA tensors): nothing "
                                          "crosses PCIe between two iterations"},
-            "gram_mfma": {"kernel": "k_gram_mfma (v_mfma_f64_16x16x4_f64)", "ms": ms,
+            "gram_mfma": {"kernel": "k_gram_mfma (v_mfma_f64_16x16x4_f64) in %d K-splits + "
+                                    "k_gram_reduce" % splits, "ms": ms,
                           "flop_executed": flop, "tiles": [nt * (nt + 1) // 2, nt * nt],
                           "achieved": tf, "peak": FP64_MFMA_PEAK_TFLOPS,
                           "unit": "TFLOP/s", "frac": tf / FP64_MFMA_PEAK_TFLOPS, "bound": "mfma"}}

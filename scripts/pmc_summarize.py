@@ -10,6 +10,9 @@ and the gfx950 read under-count (MI355X_MICROARCH.md, HBM section) in the same r
 """
 import collections, csv, glob, json, os, sys
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import kernel_source_hash          # ties the stored traffic to the kernel sources
+
 fetch_dir, write_dir, out = sys.argv[1:4]
 size_note = sys.argv[4] if len(sys.argv) > 4 else "n=1e6, m=1e5"
 commit = sys.argv[5] if len(sys.argv) > 5 else "?"
@@ -66,6 +69,7 @@ json.dump({"source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separat
                      "scripts/pmc_workload.py (40 CG iterations, %s), MI355X; "
                      "summarised by scripts/pmc_summarize.py" % size_note,
            "source_commit": commit,
+           "kernel_source_hash": kernel_source_hash(),
            "correction": "FETCH_SIZE under-reports streaming reads 2x on gfx950 "
                          "(MI355X_MICROARCH.md section HBM); calibrated here on kernels with known "
                          "byte counts: read_factor below; WRITE_SIZE is exact",

@@ -29,10 +29,10 @@ c = dv.DVec.from_host(prob.grad(x)); bz = dv.DVec.zeros(m)
 Z, LS, Y = projector.projections(A); P = Z.projector
 x0 = Y.dot(-bz); r0 = Z.dot(H.dot(x0) + c); g0 = Z.dot(r0); rt_g = g0.sumsq_amax()[0]
 L = cg_fused._Loop(H, P, None, None)
-L.args.no_radius = 0 if os.environ.get("IPX_KEEP_XN2") else 1     # as bench.py (trust_radius = inf)
+L.args.no_radius = 0          # as bench.py's headline: a finite trust radius that is never reached
 L.x.copy_(x0.t); L.r.copy_(r0.t)
 _hip.call("ipx_axpby", n, -1.0, dv._p(g0.t), 0.0, None, dv._p(L.p), st)
-init = np.zeros(L.state.numel()); init[0] = rt_g; init[3] = np.inf; init[9] = P.orth_tol * P.norm_A
+init = np.zeros(L.state.numel()); init[0] = rt_g; init[3] = 1e300; init[9] = P.orth_tol * P.norm_A
 L.state.copy_(torch.from_numpy(init))
 lib.ipx_cg_hp(L.ref(), st)
 lib.ipx_cg_iterate(L.ref(), 0, 40, st)
