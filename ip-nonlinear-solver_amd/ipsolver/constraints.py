@@ -57,7 +57,8 @@ def check_kind(kind, m):
         if np.size(value) not in (1, m):
             raise ValueError("`%s` has the wrong dimension." % label)
         # (np.resize of a scalar to 1e5 rows is a 5 ms concatenate loop)
-        return np.full(m, float(value)) if np.size(value) == 1 else np.array(value).reshape(m)
+        return np.full(m, float(value.reshape(-1)[0])) if np.size(value) == 1 \
+            else np.array(value).reshape(m)
 
     if one_sided:
         label = {"greater": "lb", "less": "ub", "equals": "c"}[keyword]

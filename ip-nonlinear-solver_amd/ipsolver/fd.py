@@ -22,13 +22,13 @@ _REL_STEP = {'2-point': _EPS ** 0.5, '3-point': _EPS ** (1 / 3), 'cs': _EPS ** 0
 class FiniteDifferenceOperator:
     """J(x0).p approximated by differences of ``fun`` (shape (m, n), ``dot``)."""
 
-    def __init__(self, fun, x0, method):
+    def __init__(self, fun, x0, method, rel_step=None, f0=None):
         if method not in FD_METHODS:
             raise ValueError("Unknown method '%s'. " % method)
         self.fun = lambda x: np.atleast_1d(fun(x))
         self.x0 = np.atleast_1d(np.asarray(x0, dtype=float))
-        self.f0 = self.fun(self.x0)
-        self.h = _REL_STEP[method]
+        self.f0 = self.fun(self.x0) if f0 is None else np.atleast_1d(f0)
+        self.h = _REL_STEP[method] if rel_step is None else rel_step
         self.method = method
         self.shape = (self.f0.size, self.x0.size)
         self.host_only = True      # tells the device backend to round-trip vectors

@@ -24,6 +24,10 @@ Outputs (numbers only -- no reference source travels):
   e2e_ineq_n12000.json  (``--ineq12000``: 4 minutes) box + inequality NLP at n=12000 / m=1200
   config2.json      (``--big`` only: minutes) dense equality QP of BASELINE config 2 at
                     n=4000/m=800 and n=10000/m=2000: scalar traces + strided x
+  api.json          (``--api``) the host-side API either side of the path -- kind grammar,
+                    feasibility enforcement, conversions, canonical form (values, Jacobians,
+                    re-signed Hessians, concatenation), operator-mode finite differences --
+                    on the cases of tests/cases_api.py
   late_barrier_n400.npz, late_barrier_n12000.npz  (``--late-barrier``: 5 minutes) single
                     ``projected_cg`` calls of the reference's config-5 style runs, spread
                     over the run up to the last one (barrier parameter <= 1e-6, slacks of
@@ -525,6 +529,13 @@ def late_barrier(n, m, ncalls):
 
 
 def main():
+    if "--api" in sys.argv:
+        # constraint classes, canonical form, operator-mode finite differences: the cases of
+        # tests/cases_api.py evaluated by the reference's own classes
+        import cases_api
+        with open(os.path.join(HERE, "api.json"), "w") as f:
+            json.dump(cases_api.run(cases_api.reference_api()), f)
+        return
     if "--late-barrier" in sys.argv:
         for n, m, k in ((400, 40, 6), (12000, 1200, 4)):
             np.savez_compressed(os.path.join(HERE, "late_barrier_n%d.npz" % n),
