@@ -516,6 +516,55 @@ def test_sharded_fused_loop_multi_rank(world, transport, tmp_path, banded20000, 
         close(got["pcg_%s_x" % name], host(x1), 1e-12)
 
 
+def _refusal_worker(rank, world, port, out_path):
+    import os
+    import sys
+    import torch
+    import torch.distributed as dist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "ip-nonlinear-solver_amd"), os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ipsolver import sharded
+        from test_sharded_gloo import _slow_decay_jacobian
+        out = {}
+        for name, delta in (("fast", 0.5), ("slow", 0.01)):
+            A = _slow_decay_jacobian(1300, delta)
+            lay = sharded.ShardLayout(A.indptr, A.indices, A.shape, world, rank)
+            sh = sharded.Sharding(lay, sharded.ShardComm(), sharded.HipOps())
+            try:
+                Z, LS, Y = sharded.projections(sharded.ShardCSR.from_global(sh, A))
+                w = sh.from_global(np.ones(1300), "row")
+                out[name] = np.concatenate(([0.0], Y.dot(w).to_host()))
+            except NotImplementedError:
+                out[name] = np.array([1.0])
+        if rank == 0:
+            np.savez(out_path, **out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_projections_refuse_a_slowly_decaying_inverse(tmp_path, ips):
+    """Two processes on the HIP kernels: a Jacobian whose (A A')^-1 decays across the 260-row
+    halo is solved (row-space operator = the global one); one whose inverse does not
+    (0.07 across the halo) is refused by the projector itself -- from the decoupling the
+    device factorization measures -- on every rank, whoever the caller is."""
+    import torch.multiprocessing as mp
+    import scipy.sparse.linalg as spla
+    from test_sharded_gloo import _slow_decay_jacobian, _free_port
+    out = str(tmp_path / "refuse.npz")
+    mp.spawn(_refusal_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = np.load(out)
+    assert got["slow"][0] == 1.0 and got["fast"][0] == 0.0
+    A = _slow_decay_jacobian(1300, 0.5)
+    want = A.T @ spla.splu(sps.csc_matrix(A @ A.T)).solve(np.ones(1300))       # Y = A'(AA')^-1
+    close(got["fast"][1:], want, 1e-12)
+
+
 @pytest.mark.parametrize("n,m", [(400, 40), (6000, 600)])
 def test_box_schur_solver(ips, n, m):
     """(A A')^-1 with the box rows eliminated analytically (csrc/boxschur.hip)

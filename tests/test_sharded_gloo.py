@@ -449,6 +449,102 @@ def test_layout_partitions_both_spaces():
         ShardLayout(A.indptr, A.indices, A.shape, 7, 0)          # a halo wider than a one-block neighbour
 
 
+@pytest.mark.parametrize("n,m", [(N, M), (100000, 10000)])
+def test_halo_truncation_at_the_largest_admitted_rank_count(n, m):
+    """What the partition rests on: a rank's solve with A A' of its own +
+    halo rows stands for the global solve on its OWN rows, and its own entries of A'v / H p
+    need nothing beyond its local arrays -- at the LARGEST rank count the layout admits for
+    the problem (every rank down to two blocks of 260 rows, an interior rank's halos as wide as
+    its neighbours), not only at the 2-3 ranks the end-to-end tests run.  One process, ranks in
+    a loop: the property is about the layout and the matrices, not about the transport."""
+    import scipy.sparse as sps
+    import scipy.sparse.linalg as spla
+    from banded_setup import BandedInstance
+    from ipsolver.sharded import ShardLayout
+    inst = BandedInstance(n, m)
+    A, H = inst.A.tocsr(), sps.csr_matrix(inst.H)
+    world = 1
+    while True:
+        try:
+            ShardLayout(A.indptr, A.indices, A.shape, world + 1, 0)
+            world += 1
+        except ValueError:
+            break
+    assert world == (4 if m == M else 20)
+    rng = np.random.default_rng(1)
+    w, p = rng.standard_normal(m), rng.standard_normal(n)
+    v = spla.splu(sps.csc_matrix(A @ A.T)).solve(w)
+    g, Hp = A.T @ v, H @ p
+    for r in range(world):
+        d = ShardLayout(A.indptr, A.indices, A.shape, world, r).me
+        AE = A[d["E0"]:d["E1"], d["x0"]:d["x1"]]
+        vE = spla.splu(sps.csc_matrix(AE @ AE.T)).solve(w[d["E0"]:d["E1"]])
+        own = slice(d["R0"] - d["E0"], d["R1"] - d["E0"])
+        assert np.max(np.abs(vE[own] - v[d["R0"]:d["R1"]])) <= 1e-13 * np.max(np.abs(v)), r
+        # own variables: A'v from the local rows with the owners' v on them, H p from the local
+        # columns -- exact, the global products' own bits
+        cown = slice(d["c0"] - d["x0"], d["c1"] - d["x0"])
+        assert np.array_equal((AE.T @ v[d["E0"]:d["E1"]])[cown], g[d["c0"]:d["c1"]]), r
+        HE = H[d["x0"]:d["x1"], d["x0"]:d["x1"]]
+        assert np.array_equal((HE @ p[d["x0"]:d["x1"]])[cown], Hp[d["c0"]:d["c1"]]), r
+
+
+def _slow_decay_jacobian(m, delta):
+    """Bidiagonal rows (1, -(1 - delta)): A A' is a shifted discrete Laplacian whose inverse
+    decays like (1 - delta)^|i-j| -- 0.07 across a 260-row halo at delta = 0.01."""
+    import scipy.sparse as sps
+    i = np.arange(m)
+    return sps.csr_matrix((np.tile([1.0, -(1.0 - delta)], m),
+                           (np.repeat(i, 2), np.column_stack((i, i + 1)).ravel())),
+                          shape=(m, m + 1))
+
+
+def _truncation_worker(rank, world, port, out_path):
+    _setup(rank, world, port)
+    try:
+        from ipsolver import sharded
+        from oracle.numpy_local import NumpyOps
+        out = {}
+        for name, delta in (("fast", 0.5), ("slow", 0.01)):
+            A = _slow_decay_jacobian(1300, delta)
+            lay = sharded.ShardLayout(A.indptr, A.indices, A.shape, world, rank)
+            sh = sharded.Sharding(lay, sharded.ShardComm(), NumpyOps())
+            try:
+                sharded.projections(sharded.ShardCSR.from_global(sh, A))
+                out[name] = np.array([0.0])
+            except NotImplementedError as e:
+                out[name] = np.array([1.0])
+                assert "truncated" in str(e)
+        if rank == 0:
+            np.savez(out_path, **out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_slowly_decaying_inverse_is_refused_not_truncated(tmp_path):
+    """The other side of that property: when (A A')^-1 does NOT decay across the halo, the
+    sharded projections refuse the Jacobian (on every rank alike) instead of returning the
+    truncated solve -- for every user of the projector, not only the fused loop."""
+    import scipy.sparse as sps
+    import scipy.sparse.linalg as spla
+    # the premise, measured: own-entry error of the truncated solve on rank 0 of 2
+    from ipsolver.sharded import ShardLayout
+    errs = {}
+    for name, delta in (("fast", 0.5), ("slow", 0.01)):
+        A = _slow_decay_jacobian(1300, delta)
+        w = np.ones(1300)
+        v = spla.splu(sps.csc_matrix(A @ A.T)).solve(w)
+        d = ShardLayout(A.indptr, A.indices, A.shape, 2, 0).me
+        AE = A[d["E0"]:d["E1"], d["x0"]:d["x1"]]
+        vE = spla.splu(sps.csc_matrix(AE @ AE.T)).solve(w[d["E0"]:d["E1"]])
+        errs[name] = np.max(np.abs(vE[:d["R1"]] - v[:d["R1"]])) / np.max(np.abs(v))
+    assert errs["fast"] <= 1e-14 and errs["slow"] >= 1e-4, errs
+    out = str(tmp_path / "trunc.npz")
+    mp.spawn(_truncation_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = np.load(out)
+    assert got["fast"][0] == 0.0 and got["slow"][0] == 1.0
+
+
 # ---------------------------------------------------------------------------------------------
 # Jacobians without a band: all-gather / reduce-scatter partition (ipsolver/sharded_general.py)
 def _random_problem(m=240, n=1100, seed=3):
