@@ -181,8 +181,10 @@ def test_dense_config2_gram_and_projection():
 
 def test_partial_compaction_beyond_1e6():
     """Past n ~ 1e6 the per-tile partial arrays exceed what a consumer workgroup folds in one
-    round; the loop then compacts them first (k_compact_partials).  The device-resident
-    loop must still agree with the statement-by-statement driver."""
+    round; the loop then compacts them first (k_compact_partials).  The device-resident loop
+    must still agree with the statement-by-statement driver: free iterations, a trust radius
+    that is reached, a box that is hit (the host finishes that iteration and the loop is
+    re-primed through the unfused H.p)."""
     import ipsolver.cg_fused as cg_fused
     import ipsolver.device as dv
     import ipsolver.projector as proj
@@ -196,15 +198,25 @@ def test_partial_compaction_beyond_1e6():
     A = dv.DeviceCSR.from_scipy(prob.constr_jac(x))
     H = DeviceHessian(n, csr=dv.DeviceCSR.from_scipy(prob.hess(x)),
                       diag=dv.DVec.from_host(prob.kappa * prob.Wt.dot(v)))
-    assert H.csr.pattern.ntiles > 1024 and A.T.pattern.ntiles > 1024
+    assert H.csr.pattern.ntiles > 2048 and A.pattern.ntiles > 2048
     Z, LS, Y = proj.projections(A)
     assert cg_fused.supports(H, Z, Y)
     c, b = prob.grad(x), np.zeros(m)
-    x_f, info_f = qp.projected_cg(H, c, Z, Y, b, tol=0.0, max_iter=8)
-    x_g, info_g = qp.projected_cg(H, c, Z, Y, b, tol=0.0, max_iter=8, return_all=True)
-    assert (info_f["niter"], info_f["stop_cond"]) == (info_g["niter"], info_g["stop_cond"])
-    assert dv.norm(x_f - x_g) <= 1e-12 * dv.norm(x_g)
-    assert dv.norm(A.dot(x_f)) <= 1e-11 * float(np.sqrt((A.val ** 2).sum().item())) * dv.norm(x_f)
+    gnorm = dv.norm(Z.dot(c))
+    cases = {"free": dict(tol=0.0, max_iter=8),
+             "ball": dict(tol=0.0, max_iter=8, trust_radius=1.2 * gnorm),
+             "box": dict(tol=0.0, max_iter=8, lb=np.full(n, -0.02), ub=np.full(n, 0.03))}
+    for name, kw in cases.items():
+        before = dict(cg_fused.STATS)
+        x_f, info_f = qp.projected_cg(H, c, Z, Y, b, **kw)
+        assert cg_fused.STATS["calls"] == before["calls"] + 1, name
+        x_g, info_g = qp.projected_cg(H, c, Z, Y, b, return_all=True, **kw)
+        assert (info_f["niter"], info_f["stop_cond"], info_f["hits_boundary"]) == \
+            (info_g["niter"], info_g["stop_cond"], info_g["hits_boundary"]), name
+        assert dv.norm(x_f - x_g) <= 1e-12 * dv.norm(x_g), name
+        assert dv.norm(A.dot(x_f)) <= 1e-11 * float(np.sqrt((A.val ** 2).sum().item())) \
+            * dv.norm(x_f), name
+    assert info_f["stop_cond"] in (1, 2, 3, 4)
 
 
 def _config2_problem(n, m):
