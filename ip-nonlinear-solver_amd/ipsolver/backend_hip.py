@@ -189,26 +189,36 @@ def _merge_sparse_terms(terms):
 _dense_cache = {}
 
 
+def _immutable(a):
+    """A numpy array nobody can write through: read-only itself and down its chain of bases."""
+    while isinstance(a, np.ndarray):
+        if a.flags.writeable:
+            return False
+        a = a.base
+    return a is None
+
+
 def _upload_dense_cached(h):
-    """A dense Hessian term returned by a host callback: the reference wraps ``hess(x)`` anew
-    every iteration (_minimize_constrained.py:395-407) -- here that would be an 800 MB upload
-    per outer iteration for BASELINE config 2, although a quadratic objective returns the SAME
-    array every time.  The device copy is therefore kept per (object, buffer, shape) and reused
-    while a strided fingerprint of the contents (4096 entries + the diagonal's ends) is
-    unchanged; any change uploads again."""
+    """A dense Hessian term returned by a host callback.  The reference wraps ``hess(x)`` anew
+    every iteration (_minimize_constrained.py:395-407); here that is an 800 MB upload per outer
+    iteration for BASELINE config 2 (0.9 of its 1.6 s), although a quadratic objective returns
+    the SAME array every time.  Whether an array is unchanged cannot be established for less
+    than the upload costs (a checksum over every entry: 2.8 s instead of 1.6 s, measured) and a
+    sampled fingerprint would silently serve stale values to a callback that refills its
+    buffer in place -- so the device copy is reused only for arrays that CANNOT change: those
+    the caller has marked read-only (``H.setflags(write=False)``, numpy's own immutability
+    contract).  Writable arrays are uploaded every time, like the reference re-wraps them."""
     h = np.asarray(h, dtype=np.float64)
-    flat = h.reshape(-1)
-    step = max(1, flat.size // 4096)
-    finger = (float(flat[::step].sum()), float(flat[0]), float(flat[-1]),
-              float(np.abs(flat[::step]).max()))
-    key = (h.__array_interface__["data"][0], h.shape, h.strides)
+    if h.size == 0 or not _immutable(h) or not h.flags.c_contiguous:
+        return DeviceDense.from_host(h)
+    key = (h.__array_interface__["data"][0], h.shape)
     hit = _dense_cache.get(key)
-    if hit is not None and hit[0] == finger:
+    if hit is not None and hit[0] is h:
         return hit[1]
     if len(_dense_cache) > 2:
         _dense_cache.clear()
     D = DeviceDense.from_host(h)
-    _dense_cache[key] = (finger, D)
+    _dense_cache[key] = (h, D)              # (keeps the array alive: the address stays its own)
     return D
 
 

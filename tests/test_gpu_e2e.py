@@ -71,6 +71,35 @@ def test_dense_equality_qp(e2e_golden):
     compare(res, rows, e2e_golden["dense_eq_qp_n60"])
 
 
+def test_dense_hessian_upload_is_reused_only_for_read_only_arrays():
+    """A dense Hessian returned by a numpy callback is uploaded on every use -- the reference
+    re-wraps it every iteration too (_minimize_constrained.py:395-407) and a callback may refill
+    its buffer in place -- unless the caller marked the array read-only: then the device copy
+    is made once.  An in-place change of a writable array must reach the device."""
+    import ipsolver.backend_hip as bh
+    from ipsolver.canonical import HessianSum
+    rng = np.random.default_rng(0)
+    B = rng.standard_normal((40, 40))
+    Hd = B + B.T
+    p = rng.standard_normal(40)
+    op = bh.hessian_operator(HessianSum(40, [Hd]), 40, None)
+    np.testing.assert_allclose(op.dot(bh.asvec(p)).to_host(), Hd.dot(p), rtol=1e-13)
+    Hd[3, 5] += 2.0                                   # same object, same buffer, new contents
+    Hd[5, 3] += 2.0
+    op2 = bh.hessian_operator(HessianSum(40, [Hd]), 40, None)
+    np.testing.assert_allclose(op2.dot(bh.asvec(p)).to_host(), Hd.dot(p), rtol=1e-13)
+    assert bh._upload_dense_cached(Hd) is not bh._upload_dense_cached(Hd)
+    Hd.setflags(write=False)
+    first = bh._upload_dense_cached(Hd)
+    assert bh._upload_dense_cached(Hd) is first
+    view = Hd[:]                                      # a view of a read-only array: still immutable
+    assert bh._immutable(view)
+    W = rng.standard_normal((8, 8))
+    ro_view = W[:]
+    ro_view.setflags(write=False)                     # read-only view of a WRITABLE base: not immutable
+    assert not bh._immutable(ro_view)
+
+
 def test_product_never_imports_the_oracle():
     """Run a solve in a fresh interpreter: the product must not load oracle.*
     (no CPU fallback), and must have loaded the in-tree libipx.so."""
