@@ -16,6 +16,7 @@ agree to 8e-16 on well-conditioned problems); a rank-deficient Jacobian is
 reported through the pivot flag.
 """
 import ctypes
+import warnings
 
 import numpy as np
 import torch
@@ -41,7 +42,9 @@ class DeviceDense:
     def from_host(a):
         dv._require_gpu()
         a = np.ascontiguousarray(np.atleast_2d(np.asarray(a, dtype=np.float64)))
-        return DeviceDense(torch.from_numpy(a).to(ctx().device))
+        with warnings.catch_warnings():        # (a read-only host array is only read here)
+            warnings.simplefilter("ignore", UserWarning)
+            return DeviceDense(torch.from_numpy(a).to(ctx().device))
 
     def to_host(self):
         return self.t.cpu().numpy()
