@@ -8,6 +8,7 @@ duck-typed surface the reference's hot path uses (``.dot``, ``.T.dot``,
 flow reads like the reference's.
 """
 import ctypes
+import weakref
 
 import numpy as np
 import torch
@@ -25,6 +26,7 @@ def _require_gpu():
 
 
 PACK_SLOTS = 128
+PACK_BASE = 32        # the pack's slots start here: [0, 32) serve the one-off reductions
 
 
 class _Context:
@@ -36,7 +38,8 @@ class _Context:
         _hip.load()
         self.device = torch.device("cuda", torch.cuda.current_device())
         self.ws = torch.empty(_hip.WS_DOUBLES, dtype=_F64, device=self.device)
-        self.out = torch.zeros(PACK_SLOTS, dtype=_F64, device=self.device)
+        self.out = torch.zeros(PACK_BASE + PACK_SLOTS, dtype=_F64, device=self.device)
+        self.open_pack = None          # the ScalarPack with enqueued, unread slots (one at a time)
 
     @classmethod
     def get(cls):
@@ -200,11 +203,18 @@ class ScalarPack:
         self.how = []          # per handle: (slot or None, post-processing)
 
     def _slot(self, n):
+        # the pack's slots are a region of their own ([PACK_BASE, ...)): a one-off reduction
+        # issued between two enqueues (an operator's own norm, say) cannot overwrite them; two
+        # packs with unread slots at the same time would, so that is refused
+        other = self.c.open_pack() if self.c.open_pack is not None else None
+        if other is not None and other is not self:
+            raise _hip.IpxError("ScalarPack: another pack has unread slots")
+        self.c.open_pack = weakref.ref(self)
         base = self.k
         self.k += n
         if self.k > PACK_SLOTS:
             raise _hip.IpxError("ScalarPack: more than %d slots" % PACK_SLOTS)
-        return ctypes.c_void_p(self.c.out.data_ptr() + 8 * base), base
+        return ctypes.c_void_p(self.c.out.data_ptr() + 8 * (PACK_BASE + base)), base
 
     def dot(self, a, b):
         if len(a) == 0:
@@ -236,7 +246,9 @@ class ScalarPack:
         return h
 
     def read(self):
-        vals = self.c.out[:self.k].tolist() if self.k else []
+        vals = self.c.out[PACK_BASE:PACK_BASE + self.k].tolist() if self.k else []
+        if self.c.open_pack is not None and self.c.open_pack() is self:
+            self.c.open_pack = None
         out = []
         for slot, post in self.how:
             v = 0.0 if slot is None else vals[slot]

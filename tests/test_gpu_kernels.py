@@ -52,6 +52,29 @@ def test_reductions(dv, n):
     assert cnt == np.count_nonzero((x < lb) | (x > ub))
 
 
+def test_scalar_pack(dv):
+    """One read for a whole decision point of the SQP loop (ipsolver/sqp.py): every value is
+    the bit the unpacked call returns; a one-off reduction issued between two enqueues (an
+    operator forming its own norm) does not disturb the enqueued slots; two packs with unread
+    slots at once are refused; empty vectors read as 0."""
+    from ipsolver import _hip
+    rng = np.random.default_rng(11)
+    x, y = rng.standard_normal(5000), rng.standard_normal(5000)
+    X, Y = dv.DVec.from_host(x), dv.DVec.from_host(y)
+    E = dv.DVec.from_host(np.empty(0))
+    want = [X.dot(Y), dv.norm(X), dv.norm_inf(Y), 0.0, dv.norm(Y)]
+    pk = dv.ScalarPack()
+    h = [pk.dot(X, Y), pk.norm(X)]
+    assert dv.norm(Y) == want[4] and X.dot(X) > 0          # one-off reductions in between
+    h += [pk.norm_inf(Y), pk.norm(E), pk.norm(Y)]
+    other = dv.ScalarPack()
+    with pytest.raises(_hip.IpxError):
+        other.norm(X)
+    vals = pk.read()
+    assert [vals[k] for k in h] == want
+    assert other.read()[other.norm(X)] == want[1]           # the first pack was read: free again
+
+
 def test_box_sphere_reduce(dv):
     rng = np.random.default_rng(3)
     n = 50001
