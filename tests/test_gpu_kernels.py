@@ -72,7 +72,8 @@ def test_scalar_pack(dv):
         other.norm(X)
     vals = pk.read()
     assert [vals[k] for k in h] == want
-    assert other.read()[other.norm(X)] == want[1]           # the first pack was read: free again
+    h2 = other.norm(X)                                      # the first pack was read: free again
+    assert other.read()[h2] == want[1]
 
 
 def test_box_sphere_reduce(dv):
