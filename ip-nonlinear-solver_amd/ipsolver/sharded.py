@@ -338,8 +338,19 @@ class PeerMailbox:
         dist.all_gather_object(flags, bool(good), group=comm.group)
         self.ok = all(flags)
         if self.ok:
-            self.check()
-        else:
+            # one all-reduce through the mailboxes against the known answer, on every rank; a
+            # group in which it fails anywhere (stores that do not arrive, a wait that times
+            # out) falls back to torch.distributed TOGETHER instead of one rank raising
+            try:
+                self.check()
+                passed = True
+            except Exception as exc:
+                self.error, passed = repr(exc), False
+            dist.all_gather_object(flags, passed, group=comm.group)
+            self.ok = all(flags)
+            if not self.ok and self.error is None:
+                self.error = "the mailbox self-test failed on another rank"
+        if not self.ok:
             self.close()
 
     def check(self):
