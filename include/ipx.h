@@ -361,6 +361,10 @@ typedef struct ipx_shard2_ext {
   void *peer;
   int64_t seg_lo[4], seg_hi[4];  /* the segments' local extents [left halo | own | right halo] */
   int64_t send_left[4], send_right[4];   /* own entries the left / right neighbour keeps as halo */
+  /* != 0 (with peer, one segment, the fused 16-bit-index kernels, no box): ipx_cg_shard2_iterate
+   * does the two all-reduces and the halo exchange in the PROLOGUES of the kernels that consume
+   * them -- 3 launches per iteration instead of 5; the reduced sums are also left in pack. */
+  int64_t fuse_comm;
 } ipx_shard2_ext;
 int ipx_cg_shard2_segment(const ipx_cg_args *a, const ipx_shard2_ext *e, int32_t phase,
                           int32_t it, int32_t mode, void *stream);
@@ -381,6 +385,7 @@ int ipx_peer_import(void *peer, int32_t rank, const void *handle_in);
 int ipx_peer_ready(void *peer);
 int64_t ipx_peer_halo_capacity(void *peer);
 int ipx_peer_sequence(void *peer, int64_t *out2);
+int64_t ipx_peer_fused_launches(void *peer);   /* loop kernels that did a collective in their prologue */
 void ipx_peer_destroy(void *peer);
 /* `reps` all-reduces (sum) of nq <= 8 doubles back to back: the mailbox path's latency probe. */
 int ipx_peer_allreduce(void *peer, int32_t nq, const double *in, double *out, int *failed,

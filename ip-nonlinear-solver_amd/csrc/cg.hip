@@ -337,7 +337,15 @@ constexpr int FT_NNZ = IPX_SPMV_TILE_NNZ;
 // per pattern by the host binding) and the row pointers of a tile whose rows all have the
 // same length are not read at all (rowlen[tile] >= 0): 2 + 4/rowlen bytes less per nonzero of
 // the 12 a CSR entry costs -- 10 of the 96 MB this kernel moves at n = 1e6.
-template <bool HAS_DIAG, int Q, int QS, bool BOX, bool C16>
+// PEER (row-sharded loop on the peer mailboxes, one segment): p2 / p3 / p4 are the rank's OWN
+// ranges of the partial arrays; every workgroup folds them, workgroup 0 sends the four sums to
+// the peers and every workgroup adds up the ranks' contributions in rank order (ipx_peer_sum)
+// -- the all-reduce of qp_subproblem.py:583,599,626 without a launch of its own.  The halo of
+// g travels in the same prologue: the tiles that own the rank's first / last own entries
+// store them into the neighbours' mailboxes, the tiles whose span reaches into the rank's
+// halo take those entries from the mailbox (and write them into g, whose halo the next
+// iteration's step1 reads).
+template <bool HAS_DIAG, int Q, int QS, bool BOX, bool C16, bool PEER>
 __global__ void __launch_bounds__(IPX_BLOCK)
 k_cg_step2_hp(int n, double *st, int parity, int mode, const double *__restrict__ p2, int np2,
               const double *__restrict__ p3, int np3, const double *__restrict__ p4, int np4,
@@ -347,11 +355,13 @@ k_cg_step2_hp(int n, double *st, int parity, int mode, const double *__restrict_
               const double *__restrict__ diag, double *__restrict__ Hp,
               double *__restrict__ partial, int hmax, const double *__restrict__ pb_in,
               double *__restrict__ pb_out,
-              const uint16_t *__restrict__ col16, const int32_t *__restrict__ rowlen) {
+              const uint16_t *__restrict__ col16, const int32_t *__restrict__ rowlen,
+              ipx_peer_job pj, double *g_halo) {
   __shared__ double prod[FT_NNZ];
   __shared__ double span[QS * IPX_BLOCK];
   __shared__ int rp[Q * IPX_BLOCK + 1];
   __shared__ double lds[4 * (IPX_BLOCK / IPX_WAVE)];
+  __shared__ double plds[PEER ? 4 * IPX_MAX_PEERS + 1 : 1];
   CG_STAMP(0);
   const int tile = ipx_xcd_item(blockIdx.x, ntiles);
   if (tile < 0) return;
@@ -410,7 +420,10 @@ k_cg_step2_hp(int n, double *st, int parity, int mode, const double *__restrict_
     const double *src = col < r0 ? pbl + (col - (r0 - hmax)) : (col >= r1 ? pbr + (col - r1) : p + col);
     sp[k] = *src;
   }
-  if (stop != 0.0) return;
+  // (PEER: the collectives below run even when the loop has stopped -- like the pack kernels
+  // they replace -- so that every rank's stores find their readers whatever a workgroup that
+  // starts late reads in the stop word: the lead workgroup of THIS launch may have set it)
+  if (!PEER && stop != 0.0) return;
   CG_STAMP(1);
   const bool lead = tile == 0 && tid == 0;
   double red[4], loc[4];
@@ -425,6 +438,63 @@ k_cg_step2_hp(int n, double *st, int parity, int mode, const double *__restrict_
     loc[3] = la[1];                                // tt
   }
   ipx_block_sum_multi<4>(loc, lds, red);
+  if (PEER) {
+    const ipx_peer_view &pv = pj.pv;
+    const int par = pj.hseq & 1;
+    // push: this tile's own rows that are among the rank's first / last own entries
+#pragma unroll
+    for (int k = 0; k < QS; ++k) {
+      const int col = c_lo + tid + k * IPX_BLOCK;
+      if (tid + k * IPX_BLOCK < nspan && col >= r0 && col < r1) {
+        if (pv.rank > 0 && col >= pj.own_lo && col < pj.own_lo + pj.send_left)
+          ipx_ll_store(pv.mbox[pv.rank - 1] + ipx_peer_halo_word(pv.cap, 1, par, col - pj.own_lo),
+                       sg[k], pj.hseq);
+        if (pv.rank < pv.world - 1 && col >= pj.own_hi - pj.send_right && col < pj.own_hi)
+          ipx_ll_store(pv.mbox[pv.rank + 1]
+                           + ipx_peer_halo_word(pv.cap, 0, par, col - (pj.own_hi - pj.send_right)),
+                       sg[k], pj.hseq);
+      }
+    }
+    double tot[4];
+    bool ok = ipx_peer_sum<4>(pv, pj.seq, 0, red, tile == 0, plds, tot);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) red[q] = tot[q];
+    // (where the launch-per-collective form leaves them: the host's event handlers and the
+    // resumed step2 read the reduced sums there)
+    if (lead && pj.pack_out) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) pj.pack_out[q] = tot[q];
+    }
+    // pull: span entries inside the rank's halo come from the neighbours
+    const long long deadline = (long long)wall_clock64() + IPX_PEER_TIMEOUT_TICKS;
+    const unsigned long long *mine = pv.mbox[pv.rank];
+    bool okh = true;
+#pragma unroll
+    for (int k = 0; k < QS; ++k) {
+      const int col = c_lo + tid + k * IPX_BLOCK;
+      if (tid + k * IPX_BLOCK < nspan) {
+        const bool left = pv.rank > 0 && col >= pj.seg_lo && col < pj.own_lo;
+        const bool right = pv.rank < pv.world - 1 && col >= pj.own_hi && col < pj.seg_hi;
+        if (left || right) {
+          double v = 0.0;
+          okh = ipx_ll_load(mine + ipx_peer_halo_word(pv.cap, left ? 0 : 1, par,
+                                                      left ? col - pj.seg_lo : col - pj.own_hi),
+                            pj.hseq, v, deadline) && okh;
+          sg[k] = v;
+          if (col >= r0 && col < r1) g_halo[col] = v;
+        }
+      }
+    }
+    if (!okh) plds[4 * IPX_MAX_PEERS] = 1.0;         // (reset by ipx_peer_sum, read below)
+    ipx_lds_barrier();
+    const bool okh_all = plds[4 * IPX_MAX_PEERS] == 0.0;
+    if (!ok || !okh_all) {                           // a peer died: stop code 7, every rank alike
+      // (ST_VIOL: which wait -- 1 the sums, 2 the halo -- and on which tile)
+      if (tid == 0) { st[ST_STOP] = 7.0; st[ST_VIOL] = (ok ? 2.0 : 1.0) + 10.0 * tile; }
+      return;
+    }
+    if (stop != 0.0) return;
+  }
   if (!(mode & 1)) {
     const double xn2 = red[0], viol = red[1];
     if (sqrt(xn2) >= radius) {                       // :583
@@ -556,7 +626,9 @@ k_cg_step2_hp(int n, double *st, int parity, int mode, const double *__restrict_
 // n = 1e6).
 // C16: column indices as 16-bit offsets into the tile's span (col - own[tile]; the host
 // binding builds them once per pattern), 2 bytes instead of 4 per nonzero.
-template <int QS, int TN, bool NOXN2, bool C16>
+// PEER: p1 is the rank's own range of the p'Hp partials; summed over the ranks in the prologue
+// (ipx_peer_sum: workgroup 0 sends, every workgroup adds the contributions in rank order).
+template <int QS, int TN, bool NOXN2, bool C16, bool PEER>
 __global__ void __launch_bounds__(IPX_BLOCK)
 k_cg_step1_ar(int n, double *st, int parity, const double *__restrict__ p1, int np1,
               const double *__restrict__ x, const double *__restrict__ p,
@@ -565,11 +637,12 @@ k_cg_step1_ar(int n, double *st, int parity, const double *__restrict__ p1, int 
               const int32_t *__restrict__ colidx, const double *__restrict__ val,
               const int32_t *__restrict__ tiles, int ntiles, const int32_t *__restrict__ own,
               double *__restrict__ w, double *__restrict__ part2,
-              const uint16_t *__restrict__ col16) {
+              const uint16_t *__restrict__ col16, ipx_peer_job pj) {
   __shared__ double prod[TN];
   __shared__ double span[QS * IPX_BLOCK];
   __shared__ int rp[IPX_SPMV_TILE_ROWS + 1];
   __shared__ double lds[IPX_BLOCK / IPX_WAVE];
+  __shared__ double plds[PEER ? IPX_MAX_PEERS + 1 : 1];
   CG_STAMP(8);
   const int tile = ipx_xcd_item(blockIdx.x, ntiles);
   if (tile < 0) return;
@@ -606,11 +679,20 @@ k_cg_step1_ar(int n, double *st, int parity, const double *__restrict__ p1, int 
     sxv[k] = NOXN2 ? 0.0 : x[col];
     spv[k] = NOXN2 ? 0.0 : p[col];
   }
-  if (stop != 0.0) return;
+  if (!PEER && stop != 0.0) return;                  // (PEER: see k_cg_step2_hp)
   CG_STAMP(9);
   const bool lead = tile == 0 && tid == 0;
   double fout[1];
   fold.finish(fparts, fcounts, lds, fout);
+  if (PEER) {
+    double tot[1];
+    if (!ipx_peer_sum<1>(pj.pv, pj.seq, 1, fout, tile == 0, plds, tot)) {
+      if (tid == 0) { st[ST_STOP] = 7.0; st[ST_VIOL] = 3.0 + 10.0 * tile; }
+      return;
+    }
+    fout[0] = tot[0];
+    if (stop != 0.0) return;
+  }
   const double ptHp = fout[0];
   if (rtg < tol) {                                   // qp_subproblem.py:551
     if (lead) st[ST_STOP] = 4.0;
@@ -964,21 +1046,26 @@ static int part3_count(const ipx_cg_args *a) {
 // feed a comparison that is always false): x and p are not read, 16 of the kernel's 56 MB at
 // n = 1e6
 static int launch_step1_ar(const ipx_cg_args *a, int it, const double *p1, int np1,
-                           hipStream_t st, bool no_xn2 = false) {
+                           hipStream_t st, bool no_xn2 = false,
+                           const ipx_peer_job *peer = nullptr) {
   const dim3 grid(ipx_xcd_grid((int)a->A_ntiles)), block(IPX_BLOCK);
+  const ipx_peer_job pj = peer ? *peer : ipx_peer_job{};
 #define FUSED_ARGS                                                                         \
   (int)a->n, a->state, it & 1, p1, np1, a->x, a->p, a->r, a->r_next,                       \
       a->Hp, a->A_rowptr, a->A_colidx, a->A_val, a->A_tiles, (int)a->A_ntiles, a->A_own,   \
-      a->w, a->part2, (const uint16_t *)a->A_col16
+      a->w, a->part2, (const uint16_t *)a->A_col16, pj
   const int qs = (int)((a->A_span + IPX_BLOCK - 1) / IPX_BLOCK);
   const bool half = a->A_tile_nnz == 1024;      // tiles of 1024 nonzeros (own table)
+  if (peer && (half || !a->A_col16)) return IPX_EINVAL;      // (see peer_fusable)
 #define GO(Q)                                                                              \
   do {                                                                                     \
-    if (half) hipLaunchKernelGGL((k_cg_step1_ar<Q, 1024, false, false>), grid, block, 0, st, FUSED_ARGS); \
-    else if (no_xn2 && a->A_col16) hipLaunchKernelGGL((k_cg_step1_ar<Q, FT_NNZ, true, true>), grid, block, 0, st, FUSED_ARGS); \
-    else if (no_xn2) hipLaunchKernelGGL((k_cg_step1_ar<Q, FT_NNZ, true, false>), grid, block, 0, st, FUSED_ARGS); \
-    else if (a->A_col16) hipLaunchKernelGGL((k_cg_step1_ar<Q, FT_NNZ, false, true>), grid, block, 0, st, FUSED_ARGS); \
-    else hipLaunchKernelGGL((k_cg_step1_ar<Q, FT_NNZ, false, false>), grid, block, 0, st, FUSED_ARGS);    \
+    if (peer && no_xn2) hipLaunchKernelGGL((k_cg_step1_ar<Q, FT_NNZ, true, true, true>), grid, block, 0, st, FUSED_ARGS); \
+    else if (peer) hipLaunchKernelGGL((k_cg_step1_ar<Q, FT_NNZ, false, true, true>), grid, block, 0, st, FUSED_ARGS); \
+    else if (half) hipLaunchKernelGGL((k_cg_step1_ar<Q, 1024, false, false, false>), grid, block, 0, st, FUSED_ARGS); \
+    else if (no_xn2 && a->A_col16) hipLaunchKernelGGL((k_cg_step1_ar<Q, FT_NNZ, true, true, false>), grid, block, 0, st, FUSED_ARGS); \
+    else if (no_xn2) hipLaunchKernelGGL((k_cg_step1_ar<Q, FT_NNZ, true, false, false>), grid, block, 0, st, FUSED_ARGS); \
+    else if (a->A_col16) hipLaunchKernelGGL((k_cg_step1_ar<Q, FT_NNZ, false, true, false>), grid, block, 0, st, FUSED_ARGS); \
+    else hipLaunchKernelGGL((k_cg_step1_ar<Q, FT_NNZ, false, false, false>), grid, block, 0, st, FUSED_ARGS);    \
   } while (0)
   switch (qs) {
     case 1: case 2: GO(2); break;
@@ -997,8 +1084,11 @@ static int launch_step1_ar(const ipx_cg_args *a, int it, const double *p1, int n
 // copies of parity it & 1 and leaves those of p_next in the other one.
 static int launch_step2_hp(const ipx_cg_args *a, int it, int mode, const double *p2, int np2,
                            const double *p3, int np3, const double *p4, int np4,
-                           hipStream_t st, const double *g = nullptr) {
+                           hipStream_t st, const double *g = nullptr,
+                           const ipx_peer_job *peer = nullptr) {
   if (!g) g = a->r;
+  const ipx_peer_job pj = peer ? *peer : ipx_peer_job{};
+  double *g_halo = peer ? a->r : nullptr;
   const int64_t half = a->H_ntiles * 2 * a->H_hmax;
   const double *pb_in = a->pb + (it & 1) * half;
   double *pb_out = a->pb + ((it + 1) & 1) * half;
@@ -1007,19 +1097,21 @@ static int launch_step2_hp(const ipx_cg_args *a, int it, int mode, const double 
   (int)a->n, a->state, it & 1, mode, p2, np2, p3, np3, p4, np4, a->x, a->p, g,                \
       a->H_rowptr, a->H_colidx, a->H_val, a->H_tiles,                                         \
       (int)a->H_ntiles, a->H_diag, a->Hp, a->part1, (int)a->H_hmax, pb_in, pb_out,           \
-      (const uint16_t *)a->H_col16, a->H_rowlen
+      (const uint16_t *)a->H_col16, a->H_rowlen, pj, g_halo
   // H_hmax carries the longest tile's row count in its upper half (set by the host
   // binding): short tiles (3 nonzeros per row -> 683 rows) take the 3-elements-per-lane
   // instantiation, which needs fewer registers
   const bool small = a->H_tile_rows > 0 && a->H_tile_rows + 2 * a->H_hmax <= 3 * IPX_BLOCK;
   const bool box = a->lb != nullptr;
   const bool c16 = a->H_col16 != nullptr && a->H_rowlen != nullptr;
+  if (peer && (box || !c16)) return IPX_EINVAL;               // (see peer_fusable)
 #define GO(D, QQ, QSS)                                                                       \
   do {                                                                                       \
-    if (box && c16) hipLaunchKernelGGL((k_cg_step2_hp<D, QQ, QSS, true, true>), grid, block, 0, st, FUSED_ARGS); \
-    else if (box) hipLaunchKernelGGL((k_cg_step2_hp<D, QQ, QSS, true, false>), grid, block, 0, st, FUSED_ARGS); \
-    else if (c16) hipLaunchKernelGGL((k_cg_step2_hp<D, QQ, QSS, false, true>), grid, block, 0, st, FUSED_ARGS); \
-    else hipLaunchKernelGGL((k_cg_step2_hp<D, QQ, QSS, false, false>), grid, block, 0, st, FUSED_ARGS);    \
+    if (peer) hipLaunchKernelGGL((k_cg_step2_hp<D, QQ, QSS, false, true, true>), grid, block, 0, st, FUSED_ARGS); \
+    else if (box && c16) hipLaunchKernelGGL((k_cg_step2_hp<D, QQ, QSS, true, true, false>), grid, block, 0, st, FUSED_ARGS); \
+    else if (box) hipLaunchKernelGGL((k_cg_step2_hp<D, QQ, QSS, true, false, false>), grid, block, 0, st, FUSED_ARGS); \
+    else if (c16) hipLaunchKernelGGL((k_cg_step2_hp<D, QQ, QSS, false, true, false>), grid, block, 0, st, FUSED_ARGS); \
+    else hipLaunchKernelGGL((k_cg_step2_hp<D, QQ, QSS, false, false, false>), grid, block, 0, st, FUSED_ARGS);    \
   } while (0)
   if (a->H_diag) {
     if (small) GO(true, 3, 3); else GO(true, 4, 5);
@@ -1134,12 +1226,75 @@ static int pack_hp(const ipx_cg_args *a, const ipx_shard2_ext *e, hipStream_t st
   return launch_pack(a, e, job, e->s1, false, st);
 }
 
+// The collectives INSIDE the loop's own kernels (k_cg_step1_ar / k_cg_step2_hp, PEER forms): 3
+// launches per iteration instead of 5.  One segment (x-space problems), both fused SpMV
+// kernels in their 16-bit index forms, g = r - A'v as the solve's tail, no box.
+static bool peer_fusable(const ipx_cg_args *a, const ipx_shard2_ext *e) {
+  ipx_peer *peer = (ipx_peer *)e->peer;
+  return peer && e->fuse_comm && e->nseg == 1 && peer->view.world > 1 &&
+         peer->view.world <= IPX_MAX_PEERS && ipx_peer_ready(peer) && fused_ar(a) && fused_hp(a) &&
+         !a->lb && a->A_col16 && a->A_tile_nnz != 1024 && a->H_col16 && a->H_rowlen &&
+         a->solver_kind == 0 && a->At_vown && a->At_qv > 0 && a->m > 0;
+}
+
+static int shard2_segment(const ipx_cg_args *a, const ipx_shard2_ext *e, int32_t phase,
+                          int32_t it, int32_t mode, void *stream, bool fuse_comm);
+
 int ipx_cg_shard2_segment(const ipx_cg_args *a, const ipx_shard2_ext *e, int32_t phase,
                           int32_t it, int32_t mode, void *stream) {
+  return shard2_segment(a, e, phase, it, mode, stream, false);
+}
+
+static int shard2_segment(const ipx_cg_args *a, const ipx_shard2_ext *e, int32_t phase,
+                          int32_t it, int32_t mode, void *stream, bool fuse_comm) {
   if (!a || !e || phase < 0 || phase > 1 || !e->s1 || !e->pack || a->solver_kind > 1 ||
       e->nseg < 1 || e->nseg > 4)
     return IPX_EINVAL;
   hipStream_t st = (hipStream_t)stream;
+  if (fuse_comm) {
+    ipx_peer *peer = (ipx_peer *)e->peer;
+    ipx_peer_job pj{};
+    pj.pv = peer->view;
+    if (phase == 0) {
+      // step1 + A.r with the all-reduce of p'Hp in its prologue (own range of part1's second
+      // half), then the solve with g = r - A'v as its tail; no pack launch
+      const int np1 = part1_count(a);
+      const int cnt = (int)(e->p1_hi[0] - e->p1_lo[0]);
+      if (e->p1_hi[0] > np1 || cnt < 0) return IPX_EINVAL;
+      if (++peer->seq == 0) ++peer->seq;
+      pj.seq = peer->seq;
+      ++peer->fused;
+      // (the kernel folds [p1 + np1, p1 + 2 np1): hand it the own range as that window)
+      const double *p1 = a->part1 + np1 + e->p1_lo[0] - cnt;
+      int rc = launch_step1_ar(a, it, p1, cnt, st, false, &pj);
+      if (rc) return rc;
+      int np4 = 0;
+      return ipx_banded_solve_resid_atv_launch(a->banded, a->w, a->v, a->part4, &np4, a->At_rowptr,
+                                               a->At_colidx, a->At_val, a->r_next, a->r,
+                                               a->At_vown, (int)a->At_qv, a->part3,
+                                               a->state + ST_STOP, st, a->At_ell_col,
+                                               a->At_ell_val, a->n);
+    }
+    // step2 + H.p with the all-reduce of the four sums and the halo exchange of g in its
+    // prologue; the own sums of p'Hp stay in part1 for the next step1
+    const int np2 = (int)a->A_ntiles, np4 = part4_count(a);
+    if (e->p2_hi > np2 || e->p4_hi > np4 || e->p3_hi[0] > np4) return IPX_EINVAL;
+    if (++peer->seq == 0) ++peer->seq;
+    if (++peer->hseq == 0) ++peer->hseq;
+    pj.seq = peer->seq;
+    pj.hseq = peer->hseq;
+    ++peer->fused;
+    pj.seg_lo = (int)e->seg_lo[0]; pj.own_lo = (int)e->own_lo[0];
+    pj.own_hi = (int)e->own_hi[0]; pj.seg_hi = (int)e->seg_hi[0];
+    pj.send_left = (int)e->send_left[0]; pj.send_right = (int)e->send_right[0];
+    pj.pack_out = e->pack;
+    if (pj.own_lo - pj.seg_lo > peer->view.cap || pj.seg_hi - pj.own_hi > peer->view.cap ||
+        pj.send_left > peer->view.cap || pj.send_right > peer->view.cap)
+      return IPX_EINVAL;
+    return launch_step2_hp(a, it, mode, a->part2 + e->p2_lo, (int)(e->p2_hi - e->p2_lo),
+                           a->part3 + e->p3_lo[0], (int)(e->p3_hi[0] - e->p3_lo[0]),
+                           a->part4 + e->p4_lo, (int)(e->p4_hi - e->p4_lo), st, nullptr, &pj);
+  }
   const double *guard = a->state + ST_STOP;
   const int grid = (int)a->vec_grid;
   int rc = IPX_OK;
@@ -1242,10 +1397,11 @@ int ipx_cg_shard2_segment(const ipx_cg_args *a, const ipx_shard2_ext *e, int32_t
 int ipx_cg_shard2_iterate(const ipx_cg_args *a, const ipx_shard2_ext *e, int32_t it_begin,
                           int32_t it_end, void *stream) {
   if (!a || !e || !e->peer || it_end < it_begin) return IPX_EINVAL;
+  const bool fuse = peer_fusable(a, e);
   for (int it = it_begin; it < it_end; ++it) {
-    int rc = ipx_cg_shard2_segment(a, e, 0, it, 0, stream);
+    int rc = shard2_segment(a, e, 0, it, 0, stream, fuse);
     if (rc) return rc;
-    rc = ipx_cg_shard2_segment(a, e, 1, it, 0, stream);
+    rc = shard2_segment(a, e, 1, it, 0, stream, fuse);
     if (rc) return rc;
   }
   return IPX_OK;

@@ -305,6 +305,7 @@ struct ipx_peer {
   uint32_t seq, hseq;                          // scalar / halo sequence numbers (never 0)
   void *opened[IPX_MAX_PEERS];                 // hipIpcOpenMemHandle results (to close)
   int64_t bytes;
+  int64_t fused;                               // launches that did their collective in a prologue
 };
 #ifdef __HIPCC__
 __device__ __forceinline__ int64_t ipx_peer_scal_word(int slot, int rank, int q) {
@@ -332,6 +333,55 @@ __device__ __forceinline__ bool ipx_ll_load(const unsigned long long *src, uint3
     if ((long long)wall_clock64() > deadline) return false;
     __builtin_amdgcn_s_sleep(2);
   }
+}
+#endif
+// What a loop kernel needs to do its rank's part of an all-reduce -- and, for the kernel that
+// consumes g, of the halo exchange -- ITSELF, in its prologue (csrc/cg.hip, PEER variants): the
+// mailboxes, the sequence numbers of this launch, the extents of the (single) segment.
+struct ipx_peer_job {
+  ipx_peer_view pv;
+  uint32_t seq, hseq;
+  int seg_lo, own_lo, own_hi, seg_hi, send_left, send_right;
+  double *pack_out;                              // 4 doubles: the reduced sums, or NULL
+};
+#ifdef __HIPCC__
+// Sum over the ranks of NQ doubles that every workgroup of the launch holds (`mine`: the
+// rank's own sums, the same bits in every workgroup): workgroup `sender` stores them as LL
+// words into every rank's mailbox, every workgroup waits for the W contributions in its own
+// rank's mailbox and adds them in rank order.  lds: NQ * IPX_MAX_PEERS + 1 doubles.  false when
+// a wait timed out (a peer died): the caller raises stop code 7 and returns.
+template <int NQ>
+__device__ __forceinline__ bool ipx_peer_sum(const ipx_peer_view &pv, uint32_t seq, int q0,
+                                             double (&mine)[NQ], bool sender, double *lds,
+                                             double (&out)[NQ]) {
+  const int tid = threadIdx.x, slot = seq & (IPX_PEER_SLOTS - 1);
+  const int r = tid / NQ, q = tid - r * NQ;
+  const bool lane = tid < NQ * pv.world;
+  if (tid == 0) lds[NQ * IPX_MAX_PEERS] = 0.0;
+  if (sender && lane) {
+    double v = mine[0];
+#pragma unroll
+    for (int k = 1; k < NQ; ++k) v = q == k ? mine[k] : v;
+    ipx_ll_store(pv.mbox[r] + ipx_peer_scal_word(slot, pv.rank, q0 + q), v, seq);
+  }
+  ipx_lds_barrier();
+  if (lane) {
+    const long long deadline = (long long)wall_clock64() + IPX_PEER_TIMEOUT_TICKS;
+    double v = 0.0;
+    if (!ipx_ll_load(pv.mbox[pv.rank] + ipx_peer_scal_word(slot, r, q0 + q), seq, v, deadline))
+      lds[NQ * IPX_MAX_PEERS] = 1.0;
+    lds[q * IPX_MAX_PEERS + r] = v;
+  }
+  ipx_lds_barrier();
+  const bool ok = lds[NQ * IPX_MAX_PEERS] == 0.0;
+#pragma unroll
+  for (int k = 0; k < NQ; ++k) {
+    double sum = 0.0;
+    for (int w = 0; w < pv.world; ++w) sum += lds[k * IPX_MAX_PEERS + w];      // rank order
+    out[k] = sum;
+  }
+  ipx_lds_barrier();
+  return ok;
 }
 #endif
 

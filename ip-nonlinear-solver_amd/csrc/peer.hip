@@ -124,6 +124,10 @@ int ipx_peer_sequence(void *peer, int64_t *out2) {
   return IPX_OK;
 }
 
+// loop kernels launched so far that did their part of a collective themselves (the PEER forms
+// of csrc/cg.hip: ipx_shard2_ext.fuse_comm)
+int64_t ipx_peer_fused_launches(void *peer) { return peer ? ((ipx_peer *)peer)->fused : 0; }
+
 void ipx_peer_destroy(void *peer) {
   if (!peer) return;
   ipx_peer *p = (ipx_peer *)peer;

@@ -828,7 +828,8 @@ def run_device_loop(D, counters, lb, ub, trust_radius, max_iter, max_infeasible_
             continue
         if stop == 7:
             raise _hip.IpxError("sharded projected CG: a wait on the peer mailboxes timed out "
-                                "(a rank of the group died or fell out of step)")
+                                "(a rank of the group died or fell out of step; iteration %d, "
+                                "wait code %s)" % (it_stop, s[ST_VIOL]))
         raise _hip.IpxError("unexpected CG stop code %d" % stop)
 
     x = D.X()

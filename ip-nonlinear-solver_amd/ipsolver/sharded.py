@@ -380,6 +380,11 @@ class PeerMailbox:
         self._hip.call("ipx_peer_sequence", ctypes.c_void_p(self.handle), out)
         return int(out[0]), int(out[1])
 
+    def fused_launches(self):
+        """Loop kernels so far that did their part of a collective in their own prologue
+        (``ipx_shard2_ext.fuse_comm``; 2 per iteration: 3 launches instead of 5)."""
+        return int(self.lib.ipx_peer_fused_launches(ctypes.c_void_p(self.handle)))
+
     def close(self):
         h, self.handle = self.handle, None
         if h:
@@ -1079,7 +1084,7 @@ class Shard2Ext(ctypes.Structure):
                 ("p3_lo", _A4), ("p3_hi", _A4), ("p2_lo", ctypes.c_int64),
                 ("p2_hi", ctypes.c_int64), ("p4_lo", ctypes.c_int64), ("p4_hi", ctypes.c_int64),
                 ("peer", ctypes.c_void_p), ("seg_lo", _A4), ("seg_hi", _A4),
-                ("send_left", _A4), ("send_right", _A4)]
+                ("send_left", _A4), ("send_right", _A4), ("fuse_comm", ctypes.c_int64)]
 
 
 def _banded_of(P):
@@ -1185,8 +1190,12 @@ class FusedShardedCG:
             e.send_left[k], e.send_right[k] = sl, sr
         self.mailbox = sh.mailbox() if transport != "dist" else None
         if self.mailbox is not None:
-            # the pack kernels all-reduce the scalars and move the halo of g themselves
+            # the loop's kernels all-reduce the scalars and move the halo of g themselves: in
+            # the prologues of the kernels that consume them (3 launches per iteration; the C
+            # side decides per argument block -- one segment, no box, 16-bit index forms) or
+            # in pack kernels of their own (5 launches; IPX_SHARD_FUSE_COMM=0 forces that)
             e.peer = self.mailbox.handle
+            e.fuse_comm = 0 if os.environ.get("IPX_SHARD_FUSE_COMM", "1") == "0" else 1
             self._exchange_g = None
         else:
             self._exchange_g = sh.comm.prepare_exchange_many(

@@ -414,7 +414,8 @@ def _multi_rank_worker(rank, world, port, out_path, transport="dist"):
         if p not in sys.path:
             sys.path.insert(0, p)
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    os.environ["IPX_SHARD_TRANSPORT"] = transport
+    os.environ["IPX_SHARD_TRANSPORT"] = transport.split("-")[0]
+    os.environ["IPX_SHARD_FUSE_COMM"] = "0" if transport == "ipc-pack" else "1"
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -455,7 +456,8 @@ def _multi_rank_worker(rank, world, port, out_path, transport="dist"):
                                 + [sh.comm.stats["exchange"]])
         out["ipc"] = np.array([float(sh.transport == "ipc"), sh.comm.stats["ipc_batches"],
                                sh.comm.stats["ipc_iterations"], len(leaks)]
-                              + list(sh.mailbox().sequence() if sh.mailbox() else (0, 0)))
+                              + list(sh.mailbox().sequence() if sh.mailbox() else (0, 0))
+                              + [sh.mailbox().fused_launches() if sh.mailbox() else 0])
         flags = torch.tensor([float(sharded.STATS["fused_calls"])])
         dist.all_reduce(flags, op=dist.ReduceOp.MIN)          # engaged on every rank?
         out["fused_min"] = flags.numpy()
@@ -465,7 +467,7 @@ def _multi_rank_worker(rank, world, port, out_path, transport="dist"):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("transport", ["ipc", "dist"])
+@pytest.mark.parametrize("transport", ["ipc", "ipc-pack", "dist"])
 @pytest.mark.parametrize("world", [2, 3])
 def test_sharded_fused_loop_multi_rank(world, transport, tmp_path, banded20000, ips):
     """The HIP kernels under the row partition: `world` processes share cuda:0.  The
@@ -477,7 +479,9 @@ def test_sharded_fused_loop_multi_rank(world, transport, tmp_path, banded20000, 
     transport "ipc": the scalars and the halo travel through the peer mailboxes (hipIpc-mapped
     device memory, csrc/peer.hip) inside the loop's own launches -- a batch of iterations is
     ONE C call and no torch.distributed call happens between its boundaries (asserted on
-    ``ShardComm.stats``).  transport "dist": three torch.distributed calls per iteration (over
+    ``ShardComm.stats``); the collectives are done in the prologues of the kernels that consume
+    them (3 launches per iteration; "ipc-pack": in pack kernels of their own, 5 launches -- the
+    form the problems with a box always take).  transport "dist": three torch.distributed calls per iteration (over
     gloo here, staged through the host: RCCL refuses two ranks on one device)."""
     import socket
     import torch.multiprocessing as mp
@@ -498,10 +502,16 @@ def test_sharded_fused_loop_multi_rank(world, transport, tmp_path, banded20000, 
     close(got["refine_x"], xo)
     fused_calls, box_events, refine_events, exchanges = got["stats"]
     assert got["fused_min"][0] >= 6 and box_events > 0 and refine_events >= 14
-    is_ipc, ipc_batches, ipc_iterations, leaks, seq, hseq = got["ipc"]
-    if transport == "ipc":
+    is_ipc, ipc_batches, ipc_iterations, leaks, seq, hseq, fused = got["ipc"]
+    if transport.startswith("ipc"):
         assert is_ipc == 1 and leaks == 0 and ipc_batches > 10 and ipc_iterations > 100
         assert seq >= 2 * ipc_iterations and hseq >= ipc_iterations
+        # the problems without a box ran with the collectives in the prologues of the loop's
+        # own kernels (3 launches per iteration), the box ones on the pack kernels (5)
+        if transport == "ipc":
+            assert 100 <= fused < 2 * ipc_iterations and fused % 2 == 0
+        else:
+            assert fused == 0
     else:
         assert is_ipc == 0 and ipc_batches == 0 and exchanges > 100
     # the same subproblems on the single-GPU device loop
