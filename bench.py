@@ -585,16 +585,28 @@ def sharded_leg(args, world, rank, A_h, H_h, hdiag_h, c_h, n, m, K, W):
     before = dict(sh.comm.stats)
     elapsed, last_segment = _sharded_run(F, primed, K, W, dist, torch)
     calls = {k: v - before[k] for k, v in sh.comm.stats.items()}
+    x_sharded = sharded.ShardVec(sharded.HipOps().dv.DVec(F.L.x.clone()), sh, "col").to_host()
     ab = {transport: {"iterations_per_s": K / elapsed, "ms_per_step": 1e3 * elapsed / K}}
-    if transport == "ipc":                      # A/B: the same loop through torch.distributed
-        try:
+    launches = 3 if (transport == "ipc" and F.mailbox.fused_launches() > 0) else 5
+    if transport == "ipc":
+        ab["ipc"]["launches_per_iteration"] = launches
+        if launches == 3:                       # A/B: the collectives in pack kernels of their own
+            try:
+                F.ext.fuse_comm = 0
+                e3, _ = _sharded_run(F, primed, K, W, dist, torch)
+                ab["ipc_pack_kernels"] = {"iterations_per_s": K / e3, "ms_per_step": 1e3 * e3 / K,
+                                          "launches_per_iteration": 5}
+            except Exception as exc:
+                ab["ipc_pack_kernels"] = {"error": repr(exc)}
+            finally:
+                F.ext.fuse_comm = 1
+        try:                                    # A/B: the same loop through torch.distributed
             e2, _ = _sharded_run(F_dist, primed, K, W, dist, torch)
             ab["dist"] = {"iterations_per_s": K / e2, "ms_per_step": 1e3 * e2 / K}
         except Exception as exc:
             ab["dist"] = {"error": repr(exc)}
 
     # ---- untimed: the sharded iterate against the single-GPU fused loop (rank 0)
-    x_sharded = sharded.ShardVec(sharded.HipOps().dv.DVec(F.L.x), sh, "col").to_host()
     parity = None
     if rank == 0:
         try:
@@ -700,7 +712,8 @@ def sharded_leg(args, world, rank, A_h, H_h, hdiag_h, c_h, n, m, K, W):
                                "per iteration 2 all-reduces (2 and 4 doubles) + 1 neighbour "
                                "exchange of the halo of g; transport of the timed region: %s"
                                % (world, "peer mailboxes (hipIpc-mapped HBM, writes over xGMI "
-                                         "inside the loop's launches, one C call per batch)"
+                                         "inside the loop's own %d launches per iteration, one "
+                                         "C call per batch)" % launches
                                   if transport == "ipc" else
                                   "torch.distributed (%s), three calls per iteration from the "
                                   "host%s" % (dist.get_backend(),
@@ -725,8 +738,9 @@ def sharded_leg(args, world, rank, A_h, H_h, hdiag_h, c_h, n, m, K, W):
             "torch_distributed_exchange": per_it["exchange"],
             "c_calls": (per_it["ipc_batches"] if transport == "ipc" else 2.0),
             "note": "ipc: one ipx_cg_shard2_iterate per restart segment of <= 200 iterations; "
-                    "the reductions and the halo exchange happen inside its 5 launches per "
-                    "iteration"},
+                    "the reductions and the halo exchange happen inside its %d launches per "
+                    "iteration%s" % (launches, " (in the prologues of the kernels that consume "
+                                               "them)" if launches == 3 else "")},
         "exchanged_per_iteration": {
             "all_reduce_doubles": [2, 4],
             "halo_columns_rank0": [int(lo), int(sh.lay.geom("col")[1] - hi)]},
