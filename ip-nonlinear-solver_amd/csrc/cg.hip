@@ -341,10 +341,10 @@ constexpr int FT_NNZ = IPX_SPMV_TILE_NNZ;
 // ranges of the partial arrays; every workgroup folds them, workgroup 0 sends the four sums to
 // the peers and every workgroup adds up the ranks' contributions in rank order (ipx_peer_sum)
 // -- the all-reduce of qp_subproblem.py:583,599,626 without a launch of its own.  The halo of
-// g travels in the same prologue: the tiles that own the rank's first / last own entries
-// store them into the neighbours' mailboxes, the tiles whose span reaches into the rank's
-// halo take those entries from the mailbox (and write them into g, whose halo the next
-// iteration's step1 reads).
+// g travels in the same prologue: two early workgroups store the rank's first / last own
+// entries into the neighbours' mailboxes, the tiles whose span reaches into the rank's halo
+// take those entries from the mailbox (and write them into g, whose halo the next iteration's
+// step1 reads).
 template <bool HAS_DIAG, int Q, int QS, bool BOX, bool C16, bool PEER>
 __global__ void __launch_bounds__(IPX_BLOCK)
 k_cg_step2_hp(int n, double *st, int parity, int mode, const double *__restrict__ p2, int np2,
@@ -441,20 +441,19 @@ k_cg_step2_hp(int n, double *st, int parity, int mode, const double *__restrict_
   if (PEER) {
     const ipx_peer_view &pv = pj.pv;
     const int par = pj.hseq & 1;
-    // push: this tile's own rows that are among the rank's first / last own entries
-#pragma unroll
-    for (int k = 0; k < QS; ++k) {
-      const int col = c_lo + tid + k * IPX_BLOCK;
-      if (tid + k * IPX_BLOCK < nspan && col >= r0 && col < r1) {
-        if (pv.rank > 0 && col >= pj.own_lo && col < pj.own_lo + pj.send_left)
-          ipx_ll_store(pv.mbox[pv.rank - 1] + ipx_peer_halo_word(pv.cap, 1, par, col - pj.own_lo),
-                       sg[k], pj.hseq);
-        if (pv.rank < pv.world - 1 && col >= pj.own_hi - pj.send_right && col < pj.own_hi)
-          ipx_ll_store(pv.mbox[pv.rank + 1]
-                           + ipx_peer_halo_word(pv.cap, 0, par, col - (pj.own_hi - pj.send_right)),
-                       sg[k], pj.hseq);
-      }
-    }
+    // push: the rank's first / last own entries of g go to the neighbours' halo areas, by
+    // two of the FIRST workgroups dispatched (not by the tiles that own those entries: with
+    // more workgroups than the chip holds at once the last tiles start only after the first
+    // ones have finished, and the first ones wait for the left neighbour's last entries -- a
+    // chain through all the ranks)
+    if (tile == min(1, ntiles - 1) && pv.rank > 0)
+      for (int j = tid; j < pj.send_left; j += IPX_BLOCK)
+        ipx_ll_store(pv.mbox[pv.rank - 1] + ipx_peer_halo_word(pv.cap, 1, par, j),
+                     g[pj.own_lo + j], pj.hseq);
+    if (tile == min(2, ntiles - 1) && pv.rank < pv.world - 1)
+      for (int j = tid; j < pj.send_right; j += IPX_BLOCK)
+        ipx_ll_store(pv.mbox[pv.rank + 1] + ipx_peer_halo_word(pv.cap, 0, par, j),
+                     g[pj.own_hi - pj.send_right + j], pj.hseq);
     double tot[4];
     bool ok = ipx_peer_sum<4>(pv, pj.seq, 0, red, tile == 0, plds, tot);
 #pragma unroll
