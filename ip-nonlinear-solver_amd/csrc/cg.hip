@@ -141,14 +141,19 @@ k_cg_step1(int64_t n, double *st, int parity, const double *__restrict__ p1, int
 // launch of its own that reads r again.  SB_ITEMS items per thread: one partial per 2048.
 constexpr int SB_ITEMS = 8;
 
+// PEER (row-sharded loop on the peer mailboxes): p1 holds zeros for the tiles of halo rows (the
+// PEER form of k_cg_step2_hp and ipx_cg_shard2_fold_hp see to that), so its sum is the rank's
+// own p'Hp; summed over the ranks here (ipx_peer_sum), unguarded like in k_cg_step1_ar.
+template <bool PEER>
 __global__ void __launch_bounds__(IPX_BLOCK)
 k_cg_step1_box(double *st, int parity, const double *__restrict__ p1, int np1,
                const double *__restrict__ x, const double *__restrict__ p, double *__restrict__ r,
                const double *__restrict__ Hp, const double *__restrict__ lb,
                const double *__restrict__ ub, double *__restrict__ p2, int nblk, int ng, int ngen,
                ipx_group_tab T, const int32_t *__restrict__ gen_cols, int ny,
-               double *__restrict__ up, OwnRanges own) {
+               double *__restrict__ up, OwnRanges own, ipx_peer_job pj) {
   __shared__ double lds[IPX_BLOCK / IPX_WAVE];
+  __shared__ double plds[PEER ? IPX_MAX_PEERS + 1 : 1];
   const int blk = ipx_xcd_item(blockIdx.x, nblk);
   if (blk < 0) return;
   const double *const fparts[1] = {p1 + np1};
@@ -158,10 +163,19 @@ k_cg_step1_box(double *st, int parity, const double *__restrict__ p1, int np1,
   const double tol = st[ST_TOL];
   ipx_fold_regs<1> fold;
   fold.load(fparts, fcounts);
-  if (stop != 0.0) return;
+  if (!PEER && stop != 0.0) return;
   const bool lead = blk == 0 && threadIdx.x == 0;
   double fout[1];
   fold.finish(fparts, fcounts, lds, fout);
+  if (PEER) {
+    double tot[1];
+    if (!ipx_peer_sum<1>(pj.pv, pj.seq, 1, fout, blk == 0, plds, tot)) {
+      if (threadIdx.x == 0) { st[ST_STOP] = 7.0; st[ST_VIOL] = 4.0 + 10.0 * blk; }
+      return;
+    }
+    fout[0] = tot[0];
+    if (stop != 0.0) return;
+  }
   const double ptHp = fout[0];
   if (rtg < tol) {                                   // qp_subproblem.py:551
     if (lead) st[ST_STOP] = 4.0;
@@ -447,13 +461,15 @@ k_cg_step2_hp(int n, double *st, int parity, int mode, const double *__restrict_
     // ones have finished, and the first ones wait for the left neighbour's last entries -- a
     // chain through all the ranks)
     if (tile == min(1, ntiles - 1) && pv.rank > 0)
-      for (int j = tid; j < pj.send_left; j += IPX_BLOCK)
-        ipx_ll_store(pv.mbox[pv.rank - 1] + ipx_peer_halo_word(pv.cap, 1, par, j),
-                     g[pj.own_lo + j], pj.hseq);
+      for (int k = 0; k < pj.nseg; ++k)
+        for (int j = tid; j < pj.send_left[k]; j += IPX_BLOCK)
+          ipx_ll_store(pv.mbox[pv.rank - 1] + ipx_peer_halo_word(pv.cap, 1, par, pj.push_l[k] + j),
+                       g[pj.own_lo[k] + j], pj.hseq);
     if (tile == min(2, ntiles - 1) && pv.rank < pv.world - 1)
-      for (int j = tid; j < pj.send_right; j += IPX_BLOCK)
-        ipx_ll_store(pv.mbox[pv.rank + 1] + ipx_peer_halo_word(pv.cap, 0, par, j),
-                     g[pj.own_hi - pj.send_right + j], pj.hseq);
+      for (int k = 0; k < pj.nseg; ++k)
+        for (int j = tid; j < pj.send_right[k]; j += IPX_BLOCK)
+          ipx_ll_store(pv.mbox[pv.rank + 1] + ipx_peer_halo_word(pv.cap, 0, par, pj.push_r[k] + j),
+                       g[pj.own_hi[k] - pj.send_right[k] + j], pj.hseq);
     double tot[4];
     bool ok = ipx_peer_sum<4>(pv, pj.seq, 0, red, tile == 0, plds, tot);
 #pragma unroll
@@ -472,13 +488,10 @@ k_cg_step2_hp(int n, double *st, int parity, int mode, const double *__restrict_
     for (int k = 0; k < QS; ++k) {
       const int col = c_lo + tid + k * IPX_BLOCK;
       if (tid + k * IPX_BLOCK < nspan) {
-        const bool left = pv.rank > 0 && col >= pj.seg_lo && col < pj.own_lo;
-        const bool right = pv.rank < pv.world - 1 && col >= pj.own_hi && col < pj.seg_hi;
-        if (left || right) {
+        const int64_t word = pj.pull_word(col, par);
+        if (word >= 0) {
           double v = 0.0;
-          okh = ipx_ll_load(mine + ipx_peer_halo_word(pv.cap, left ? 0 : 1, par,
-                                                      left ? col - pj.seg_lo : col - pj.own_hi),
-                            pj.hseq, v, deadline) && okh;
+          okh = ipx_ll_load(mine + word, pj.hseq, v, deadline) && okh;
           sg[k] = v;
           if (col >= r0 && col < r1) g_halo[col] = v;
         }
@@ -591,7 +604,13 @@ k_cg_step2_hp(int n, double *st, int parity, int mode, const double *__restrict_
   {
     double red2[2] = {acc_yy, acc_xy}, out2[2];
     ipx_block_sum_multi<2>(red2, lds, out2);
-    if (tid == 0) { partial[tile] = out2[0]; partial[ntiles + tile] = out2[1]; }
+    // (PEER: the tiles of halo rows leave zeros, so that the consumer may fold the whole array
+    // for the rank's own sum -- the barrier problem's own rows are up to four ranges)
+    const bool counts = !PEER || pj.owns_rows(r0, r1);
+    if (tid == 0) {
+      partial[tile] = counts ? out2[0] : 0.0;
+      partial[ntiles + tile] = counts ? out2[1] : 0.0;
+    }
   }
 #pragma unroll
   for (int q = 0; q < Q; ++q) {
@@ -1103,10 +1122,11 @@ static int launch_step2_hp(const ipx_cg_args *a, int it, int mode, const double 
   const bool small = a->H_tile_rows > 0 && a->H_tile_rows + 2 * a->H_hmax <= 3 * IPX_BLOCK;
   const bool box = a->lb != nullptr;
   const bool c16 = a->H_col16 != nullptr && a->H_rowlen != nullptr;
-  if (peer && (box || !c16)) return IPX_EINVAL;               // (see peer_fusable)
+  if (peer && !c16) return IPX_EINVAL;                        // (see peer_fusable)
 #define GO(D, QQ, QSS)                                                                       \
   do {                                                                                       \
-    if (peer) hipLaunchKernelGGL((k_cg_step2_hp<D, QQ, QSS, false, true, true>), grid, block, 0, st, FUSED_ARGS); \
+    if (peer && box) hipLaunchKernelGGL((k_cg_step2_hp<D, QQ, QSS, true, true, true>), grid, block, 0, st, FUSED_ARGS); \
+    else if (peer) hipLaunchKernelGGL((k_cg_step2_hp<D, QQ, QSS, false, true, true>), grid, block, 0, st, FUSED_ARGS); \
     else if (box && c16) hipLaunchKernelGGL((k_cg_step2_hp<D, QQ, QSS, true, true, false>), grid, block, 0, st, FUSED_ARGS); \
     else if (box) hipLaunchKernelGGL((k_cg_step2_hp<D, QQ, QSS, true, false, false>), grid, block, 0, st, FUSED_ARGS); \
     else if (c16) hipLaunchKernelGGL((k_cg_step2_hp<D, QQ, QSS, false, true, false>), grid, block, 0, st, FUSED_ARGS); \
@@ -1206,6 +1226,14 @@ static int launch_pack(const ipx_cg_args *a, const ipx_shard2_ext *e, const Rang
   return IPX_OK;
 }
 
+// zeros over the entries of `part` outside the given ranges (the p'Hp partials of halo tiles
+// after an unfused H.p: the PEER form of k_cg_step1_box folds the whole array)
+__global__ void __launch_bounds__(IPX_BLOCK)
+k_zero_outside(double *__restrict__ part, int n, OwnRanges keep) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && !keep.has(i)) part[i] = 0.0;
+}
+
 // own sum of the p'Hp partials (second half of part1) over the segments' own row tiles
 static int pack_hp(const ipx_cg_args *a, const ipx_shard2_ext *e, hipStream_t st) {
   const int np1 = part1_count(a);
@@ -1222,7 +1250,19 @@ static int pack_hp(const ipx_cg_args *a, const ipx_shard2_ext *e, hipStream_t st
   // NOT guarded by the stop flag: once an iteration has raised it, the remaining iterations
   // of the batch are no-ops but their all-reduces still run; re-packing the (unchanged)
   // own sums keeps the reduced values those of the iteration that stopped
-  return launch_pack(a, e, job, e->s1, false, st);
+  int rc = launch_pack(a, e, job, e->s1, false, st);
+  if (rc || !e->peer || !e->fuse_comm || !box_project(a)) return rc;
+  // the prologue form of k_cg_step1_box folds ALL of part1's second half: zero the entries
+  // an unfused H.p left for the tiles of halo rows
+  OwnRanges keep;
+  for (int k = 0; k < 4; ++k) {
+    keep.lo[k] = k < (int)e->nseg ? e->p1_lo[k] : 0;
+    keep.hi[k] = k < (int)e->nseg ? e->p1_hi[k] : 0;
+  }
+  hipLaunchKernelGGL(k_zero_outside, dim3((np1 + IPX_BLOCK - 1) / IPX_BLOCK), dim3(IPX_BLOCK), 0, st,
+                     a->part1 + np1, np1, keep);
+  IPX_CHECK_LAUNCH();
+  return IPX_OK;
 }
 
 // The collectives INSIDE the loop's own kernels (k_cg_step1_ar / k_cg_step2_hp, PEER forms): 3
@@ -1230,10 +1270,34 @@ static int pack_hp(const ipx_cg_args *a, const ipx_shard2_ext *e, hipStream_t st
 // kernels in their 16-bit index forms, g = r - A'v as the solve's tail, no box.
 static bool peer_fusable(const ipx_cg_args *a, const ipx_shard2_ext *e) {
   ipx_peer *peer = (ipx_peer *)e->peer;
-  return peer && e->fuse_comm && e->nseg == 1 && peer->view.world > 1 &&
-         peer->view.world <= IPX_MAX_PEERS && ipx_peer_ready(peer) && fused_ar(a) && fused_hp(a) &&
-         !a->lb && a->A_col16 && a->A_tile_nnz != 1024 && a->H_col16 && a->H_rowlen &&
-         a->solver_kind == 0 && a->At_vown && a->At_qv > 0 && a->m > 0;
+  if (!(peer && e->fuse_comm && peer->view.world > 1 && peer->view.world <= IPX_MAX_PEERS &&
+        ipx_peer_ready(peer) && fused_hp(a) && a->H_col16 && a->H_rowlen && a->m > 0))
+    return false;
+  // x-space problems: both fused SpMV kernels, g = r - A'v as the solve's tail, no box
+  if (e->nseg == 1 && fused_ar(a) && !a->lb && a->A_col16 && a->A_tile_nnz != 1024 &&
+      a->solver_kind == 0 && a->At_vown && a->At_qv > 0)
+    return true;
+  // the barrier problem's z-space: the projection without the box rows as matrix rows
+  return box_project(a) && a->lb != nullptr;
+}
+
+// the segments' extents and their places in the mailboxes' halo areas
+static int peer_job_geometry(const ipx_shard2_ext *e, const ipx_peer *peer, ipx_peer_job *pj) {
+  pj->nseg = (int)e->nseg;
+  int inl = 0, inr = 0, outl = 0, outr = 0;
+  for (int k = 0; k < pj->nseg; ++k) {
+    pj->seg_lo[k] = (int)e->seg_lo[k]; pj->own_lo[k] = (int)e->own_lo[k];
+    pj->own_hi[k] = (int)e->own_hi[k]; pj->seg_hi[k] = (int)e->seg_hi[k];
+    pj->send_left[k] = (int)e->send_left[k]; pj->send_right[k] = (int)e->send_right[k];
+    if (pj->seg_lo[k] > pj->own_lo[k] || pj->own_hi[k] > pj->seg_hi[k] || pj->send_left[k] < 0 ||
+        pj->send_right[k] < 0)
+      return IPX_EINVAL;
+    pj->off_l[k] = inl; pj->off_r[k] = inr; pj->push_l[k] = outl; pj->push_r[k] = outr;
+    inl += pj->own_lo[k] - pj->seg_lo[k]; inr += pj->seg_hi[k] - pj->own_hi[k];
+    outl += pj->send_left[k]; outr += pj->send_right[k];
+  }
+  const int64_t cap = peer->view.cap;
+  return (inl > cap || inr > cap || outl > cap || outr > cap) ? IPX_EINVAL : IPX_OK;
 }
 
 static int shard2_segment(const ipx_cg_args *a, const ipx_shard2_ext *e, int32_t phase,
@@ -1254,15 +1318,29 @@ static int shard2_segment(const ipx_cg_args *a, const ipx_shard2_ext *e, int32_t
     ipx_peer *peer = (ipx_peer *)e->peer;
     ipx_peer_job pj{};
     pj.pv = peer->view;
+    const bool boxp = box_project(a);
+    const double *stopw = a->state + ST_STOP;
     if (phase == 0) {
-      // step1 + A.r with the all-reduce of p'Hp in its prologue (own range of part1's second
-      // half), then the solve with g = r - A'v as its tail; no pack launch
+      // step1 with the all-reduce of p'Hp in its prologue, then the projection; no pack launch
       const int np1 = part1_count(a);
-      const int cnt = (int)(e->p1_hi[0] - e->p1_lo[0]);
-      if (e->p1_hi[0] > np1 || cnt < 0) return IPX_EINVAL;
       if (++peer->seq == 0) ++peer->seq;
       pj.seq = peer->seq;
       ++peer->fused;
+      if (boxp) {
+        const ipx_boxschur_args *b = (const ipx_boxschur_args *)a->banded;
+        const OwnRanges own = own_of(e);
+        const int nblk = step1_box_blocks(a);
+        hipLaunchKernelGGL(k_cg_step1_box<true>, dim3(ipx_xcd_grid(nblk)), dim3(IPX_BLOCK), 0, st,
+                           a->state, it & 1, a->part1, np1, a->x, a->p, a->r, a->Hp, a->lb, a->ub,
+                           a->part2, nblk, (int)b->ng, (int)b->ngen,
+                           ipx_group_tab{b->gcol, b->grp}, b->gen_cols, (int)b->ny, b->up, own, pj);
+        IPX_CHECK_LAUNCH();
+        int32_t n3 = 0, n4 = 0;
+        return ipx_boxschur_project_from(b, a->r, a->r, a->part3, &n3, a->part4, &n4, stopw, 1, st,
+                                         &own);
+      }
+      const int cnt = (int)(e->p1_hi[0] - e->p1_lo[0]);
+      if (e->p1_hi[0] > np1 || cnt < 0) return IPX_EINVAL;
       // (the kernel folds [p1 + np1, p1 + 2 np1): hand it the own range as that window)
       const double *p1 = a->part1 + np1 + e->p1_lo[0] - cnt;
       int rc = launch_step1_ar(a, it, p1, cnt, st, false, &pj);
@@ -1270,26 +1348,27 @@ static int shard2_segment(const ipx_cg_args *a, const ipx_shard2_ext *e, int32_t
       int np4 = 0;
       return ipx_banded_solve_resid_atv_launch(a->banded, a->w, a->v, a->part4, &np4, a->At_rowptr,
                                                a->At_colidx, a->At_val, a->r_next, a->r,
-                                               a->At_vown, (int)a->At_qv, a->part3,
-                                               a->state + ST_STOP, st, a->At_ell_col,
-                                               a->At_ell_val, a->n);
+                                               a->At_vown, (int)a->At_qv, a->part3, stopw, st,
+                                               a->At_ell_col, a->At_ell_val, a->n);
     }
     // step2 + H.p with the all-reduce of the four sums and the halo exchange of g in its
     // prologue; the own sums of p'Hp stay in part1 for the next step1
-    const int np2 = (int)a->A_ntiles, np4 = part4_count(a);
-    if (e->p2_hi > np2 || e->p4_hi > np4 || e->p3_hi[0] > np4) return IPX_EINVAL;
+    const int np4 = part4_count(a);
+    if (e->p4_hi > np4) return IPX_EINVAL;
+    int rc = peer_job_geometry(e, peer, &pj);
+    if (rc) return rc;
     if (++peer->seq == 0) ++peer->seq;
     if (++peer->hseq == 0) ++peer->hseq;
     pj.seq = peer->seq;
     pj.hseq = peer->hseq;
-    ++peer->fused;
-    pj.seg_lo = (int)e->seg_lo[0]; pj.own_lo = (int)e->own_lo[0];
-    pj.own_hi = (int)e->own_hi[0]; pj.seg_hi = (int)e->seg_hi[0];
-    pj.send_left = (int)e->send_left[0]; pj.send_right = (int)e->send_right[0];
     pj.pack_out = e->pack;
-    if (pj.own_lo - pj.seg_lo > peer->view.cap || pj.seg_hi - pj.own_hi > peer->view.cap ||
-        pj.send_left > peer->view.cap || pj.send_right > peer->view.cap)
-      return IPX_EINVAL;
+    ++peer->fused;
+    if (boxp)       // the kernels counted own entries only: the own sums are the whole arrays
+      return launch_step2_hp(a, it, mode, a->part2, step1_box_blocks(a), a->part3,
+                             ipx_boxschur_project_count((const ipx_boxschur_args *)a->banded),
+                             a->part4 + e->p4_lo, (int)(e->p4_hi - e->p4_lo), st, nullptr, &pj);
+    const int np2 = (int)a->A_ntiles;
+    if (e->p2_hi > np2 || e->p3_hi[0] > np4) return IPX_EINVAL;
     return launch_step2_hp(a, it, mode, a->part2 + e->p2_lo, (int)(e->p2_hi - e->p2_lo),
                            a->part3 + e->p3_lo[0], (int)(e->p3_hi[0] - e->p3_lo[0]),
                            a->part4 + e->p4_lo, (int)(e->p4_hi - e->p4_lo), st, nullptr, &pj);
@@ -1308,10 +1387,10 @@ static int shard2_segment(const ipx_cg_args *a, const ipx_shard2_ext *e, int32_t
       const ipx_boxschur_args *b = (const ipx_boxschur_args *)a->banded;
       const OwnRanges own = own_of(e);
       np2 = step1_box_blocks(a);
-      hipLaunchKernelGGL(k_cg_step1_box, dim3(ipx_xcd_grid(np2)), dim3(IPX_BLOCK), 0, st, a->state,
+      hipLaunchKernelGGL(k_cg_step1_box<false>, dim3(ipx_xcd_grid(np2)), dim3(IPX_BLOCK), 0, st, a->state,
                          it & 1, e->s1, 1, a->x, a->p, a->r, a->Hp, a->lb, a->ub, a->part2, np2,
                          (int)b->ng, (int)b->ngen, ipx_group_tab{b->gcol, b->grp}, b->gen_cols,
-                         (int)b->ny, b->up, own);
+                         (int)b->ny, b->up, own, ipx_peer_job{});
       IPX_CHECK_LAUNCH();
       int32_t n3 = 0, n4 = 0;
       rc = ipx_boxschur_project_from(b, a->r, a->r, a->part3, &n3, a->part4, &n4, guard, 1, st, &own);
@@ -1579,11 +1658,11 @@ static int cg_iterate(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, hi
     } else if (a->m > 0 && box_project(a)) {
       const ipx_boxschur_args *b = (const ipx_boxschur_args *)a->banded;
       const int nblk = step1_box_blocks(a);
-      hipLaunchKernelGGL(k_cg_step1_box, dim3(ipx_xcd_grid(nblk)), dim3(IPX_BLOCK), 0, st,
+      hipLaunchKernelGGL(k_cg_step1_box<false>, dim3(ipx_xcd_grid(nblk)), dim3(IPX_BLOCK), 0, st,
                          a->state, it & 1, p1, np1, a->x, a->p, a->r, a->Hp, a->lb, a->ub,
                          a->part2, nblk, (int)b->ng, (int)b->ngen,
                          ipx_group_tab{b->gcol, b->grp}, b->gen_cols, (int)b->ny,
-                         b->up, own_all(a->n));
+                         b->up, own_all(a->n), ipx_peer_job{});
       IPX_CHECK_LAUNCH();
       MARK(1);
     } else {

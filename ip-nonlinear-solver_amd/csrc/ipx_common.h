@@ -338,11 +338,34 @@ __device__ __forceinline__ bool ipx_ll_load(const unsigned long long *src, uint3
 // What a loop kernel needs to do its rank's part of an all-reduce -- and, for the kernel that
 // consumes g, of the halo exchange -- ITSELF, in its prologue (csrc/cg.hip, PEER variants): the
 // mailboxes, the sequence numbers of this launch, the extents of the (single) segment.
+// Segment k of the local vector is [seg_lo | own_lo .. own_hi | seg_hi) (x-space problems: one
+// segment; the barrier problem's z = [x; s_nl; s_lb; s_ub]: four); in a mailbox's halo areas
+// the segments follow each other: off_l / off_r = entries of the earlier segments' left /
+// right halos (what this rank pulls), push_l / push_r = of their send counts (what it pushes).
 struct ipx_peer_job {
   ipx_peer_view pv;
   uint32_t seq, hseq;
-  int seg_lo, own_lo, own_hi, seg_hi, send_left, send_right;
+  int nseg;
+  int seg_lo[4], own_lo[4], own_hi[4], seg_hi[4], send_left[4], send_right[4];
+  int off_l[4], off_r[4], push_l[4], push_r[4];
   double *pack_out;                              // 4 doubles: the reduced sums, or NULL
+#ifdef __HIPCC__
+  // the halo word of this rank's mailbox that holds local entry `col`, or -1 (own / no peer)
+  __device__ __forceinline__ int64_t pull_word(int col, int par) const {
+    for (int k = 0; k < nseg; ++k) {
+      if (pv.rank > 0 && col >= seg_lo[k] && col < own_lo[k])
+        return ipx_peer_halo_word(pv.cap, 0, par, off_l[k] + (col - seg_lo[k]));
+      if (pv.rank < pv.world - 1 && col >= own_hi[k] && col < seg_hi[k])
+        return ipx_peer_halo_word(pv.cap, 1, par, off_r[k] + (col - own_hi[k]));
+    }
+    return -1;
+  }
+  __device__ __forceinline__ bool owns_rows(int r0, int r1) const {
+    for (int k = 0; k < nseg; ++k)
+      if (r0 >= own_lo[k] && r1 <= own_hi[k]) return true;
+    return false;
+  }
+#endif
 };
 #ifdef __HIPCC__
 // Sum over the ranks of NQ doubles that every workgroup of the launch holds (`mine`: the

@@ -32,5 +32,8 @@ if dist.get_rank() == 0:
                       "cg_it_per_s": res.cg_niter / wall, "optimality": float(res.optimality),
                       "constr_violation": float(res.constr_violation), "fun": float(res.fun),
                       "active_bounds": int(np.sum(np.abs(np.abs(x) - 0.8) < 1e-6)),
-                      "collectives": sh.comm.stats, "fused": sharded.STATS}))
+                      "collectives": sh.comm.stats, "fused": sharded.STATS,
+                      "transport": sh.transport,
+                      "prologue_collective_launches": sh.mailbox().fused_launches() if sh.mailbox()
+                      else 0}))
 dist.destroy_process_group()

@@ -169,7 +169,9 @@ def _sharded_worker(rank, world, port, out_path):
             out["x%d" % j] = x.to_host()
             out["info%d" % j] = np.array([info["niter"], info["stop_cond"],
                                           int(info["hits_boundary"])])
-        out["transport"] = np.array([float(sh.transport == "ipc")])
+        out["transport"] = np.array([float(sh.transport == "ipc"),
+                                     sh.mailbox().fused_launches() if sh.mailbox() else 0,
+                                     sh.comm.stats["ipc_iterations"]])
         if rank == 0:
             np.savez(out_path, **out)
     finally:
@@ -190,6 +192,9 @@ def test_late_barrier_subproblems_two_ranks(tmp_path):
     mp.spawn(_sharded_worker, args=(2, port, path), nprocs=2, join=True)
     got = np.load(path)
     assert got["transport"][0] == 1.0
+    # the four-segment z-space loop did its collectives in the prologues of its own kernels
+    # (k_cg_step1_box / k_cg_step2_hp, PEER forms: 5 launches per iteration, no pack kernels)
+    assert got["transport"][1] == 2 * got["transport"][2] > 0
     gold = _gold(12000)
     for j in range(SIZES[12000]):
         d = _pieces(gold, j)
