@@ -50,6 +50,12 @@ constexpr int VB = IPX_BLOCK;
 constexpr int VU = 8;        // elements per lane per trip, loads issued together (one trip at n = 1e6)
 
 typedef ipx_own_ranges OwnRanges;      // (ipx_common.h)
+// kernel argument of the PEER forms: the peer job; an empty struct for the others (the job is
+// ~350 bytes of kernel arguments the single-GPU launches should not carry: measured +0.2 us on
+// the dominant kernel)
+struct ipx_no_peer {};
+template <bool PEER> struct peer_arg { typedef ipx_no_peer type; };
+template <> struct peer_arg<true> { typedef ipx_peer_job type; };
 static OwnRanges own_all(int64_t n) {
   OwnRanges o;
   for (int k = 0; k < 4; ++k) { o.lo[k] = 0; o.hi[k] = 0; }
@@ -151,7 +157,7 @@ k_cg_step1_box(double *st, int parity, const double *__restrict__ p1, int np1,
                const double *__restrict__ Hp, const double *__restrict__ lb,
                const double *__restrict__ ub, double *__restrict__ p2, int nblk, int ng, int ngen,
                ipx_group_tab T, const int32_t *__restrict__ gen_cols, int ny,
-               double *__restrict__ up, OwnRanges own, ipx_peer_job pj) {
+               double *__restrict__ up, OwnRanges own, typename peer_arg<PEER>::type pj) {
   __shared__ double lds[IPX_BLOCK / IPX_WAVE];
   __shared__ double plds[PEER ? IPX_MAX_PEERS + 1 : 1];
   const int blk = ipx_xcd_item(blockIdx.x, nblk);
@@ -167,7 +173,7 @@ k_cg_step1_box(double *st, int parity, const double *__restrict__ p1, int np1,
   const bool lead = blk == 0 && threadIdx.x == 0;
   double fout[1];
   fold.finish(fparts, fcounts, lds, fout);
-  if (PEER) {
+  if constexpr (PEER) {
     double tot[1];
     if (!ipx_peer_sum<1>(pj.pv, pj.seq, 1, fout, blk == 0, plds, tot)) {
       if (threadIdx.x == 0) { st[ST_STOP] = 7.0; st[ST_VIOL] = 4.0 + 10.0 * blk; }
@@ -370,7 +376,7 @@ k_cg_step2_hp(int n, double *st, int parity, int mode, const double *__restrict_
               double *__restrict__ partial, int hmax, const double *__restrict__ pb_in,
               double *__restrict__ pb_out,
               const uint16_t *__restrict__ col16, const int32_t *__restrict__ rowlen,
-              ipx_peer_job pj, double *g_halo) {
+              typename peer_arg<PEER>::type pj, double *g_halo) {
   __shared__ double prod[FT_NNZ];
   __shared__ double span[QS * IPX_BLOCK];
   __shared__ int rp[Q * IPX_BLOCK + 1];
@@ -452,7 +458,7 @@ k_cg_step2_hp(int n, double *st, int parity, int mode, const double *__restrict_
     loc[3] = la[1];                                // tt
   }
   ipx_block_sum_multi<4>(loc, lds, red);
-  if (PEER) {
+  if constexpr (PEER) {
     const ipx_peer_view &pv = pj.pv;
     const int par = pj.hseq & 1;
     // push: the rank's first / last own entries of g go to the neighbours' halo areas, by
@@ -606,7 +612,8 @@ k_cg_step2_hp(int n, double *st, int parity, int mode, const double *__restrict_
     ipx_block_sum_multi<2>(red2, lds, out2);
     // (PEER: the tiles of halo rows leave zeros, so that the consumer may fold the whole array
     // for the rank's own sum -- the barrier problem's own rows are up to four ranges)
-    const bool counts = !PEER || pj.owns_rows(r0, r1);
+    bool counts = true;
+    if constexpr (PEER) counts = pj.owns_rows(r0, r1);
     if (tid == 0) {
       partial[tile] = counts ? out2[0] : 0.0;
       partial[ntiles + tile] = counts ? out2[1] : 0.0;
@@ -655,7 +662,7 @@ k_cg_step1_ar(int n, double *st, int parity, const double *__restrict__ p1, int 
               const int32_t *__restrict__ colidx, const double *__restrict__ val,
               const int32_t *__restrict__ tiles, int ntiles, const int32_t *__restrict__ own,
               double *__restrict__ w, double *__restrict__ part2,
-              const uint16_t *__restrict__ col16, ipx_peer_job pj) {
+              const uint16_t *__restrict__ col16, typename peer_arg<PEER>::type pj) {
   __shared__ double prod[TN];
   __shared__ double span[QS * IPX_BLOCK];
   __shared__ int rp[IPX_SPMV_TILE_ROWS + 1];
@@ -702,7 +709,7 @@ k_cg_step1_ar(int n, double *st, int parity, const double *__restrict__ p1, int 
   const bool lead = tile == 0 && tid == 0;
   double fout[1];
   fold.finish(fparts, fcounts, lds, fout);
-  if (PEER) {
+  if constexpr (PEER) {
     double tot[1];
     if (!ipx_peer_sum<1>(pj.pv, pj.seq, 1, fout, tile == 0, plds, tot)) {
       if (tid == 0) { st[ST_STOP] = 7.0; st[ST_VIOL] = 3.0 + 10.0 * tile; }
@@ -1068,22 +1075,23 @@ static int launch_step1_ar(const ipx_cg_args *a, int it, const double *p1, int n
                            const ipx_peer_job *peer = nullptr) {
   const dim3 grid(ipx_xcd_grid((int)a->A_ntiles)), block(IPX_BLOCK);
   const ipx_peer_job pj = peer ? *peer : ipx_peer_job{};
+  const ipx_no_peer none{};
 #define FUSED_ARGS                                                                         \
   (int)a->n, a->state, it & 1, p1, np1, a->x, a->p, a->r, a->r_next,                       \
       a->Hp, a->A_rowptr, a->A_colidx, a->A_val, a->A_tiles, (int)a->A_ntiles, a->A_own,   \
-      a->w, a->part2, (const uint16_t *)a->A_col16, pj
+      a->w, a->part2, (const uint16_t *)a->A_col16
   const int qs = (int)((a->A_span + IPX_BLOCK - 1) / IPX_BLOCK);
   const bool half = a->A_tile_nnz == 1024;      // tiles of 1024 nonzeros (own table)
   if (peer && (half || !a->A_col16)) return IPX_EINVAL;      // (see peer_fusable)
 #define GO(Q)                                                                              \
   do {                                                                                     \
-    if (peer && no_xn2) hipLaunchKernelGGL((k_cg_step1_ar<Q, FT_NNZ, true, true, true>), grid, block, 0, st, FUSED_ARGS); \
-    else if (peer) hipLaunchKernelGGL((k_cg_step1_ar<Q, FT_NNZ, false, true, true>), grid, block, 0, st, FUSED_ARGS); \
-    else if (half) hipLaunchKernelGGL((k_cg_step1_ar<Q, 1024, false, false, false>), grid, block, 0, st, FUSED_ARGS); \
-    else if (no_xn2 && a->A_col16) hipLaunchKernelGGL((k_cg_step1_ar<Q, FT_NNZ, true, true, false>), grid, block, 0, st, FUSED_ARGS); \
-    else if (no_xn2) hipLaunchKernelGGL((k_cg_step1_ar<Q, FT_NNZ, true, false, false>), grid, block, 0, st, FUSED_ARGS); \
-    else if (a->A_col16) hipLaunchKernelGGL((k_cg_step1_ar<Q, FT_NNZ, false, true, false>), grid, block, 0, st, FUSED_ARGS); \
-    else hipLaunchKernelGGL((k_cg_step1_ar<Q, FT_NNZ, false, false, false>), grid, block, 0, st, FUSED_ARGS);    \
+    if (peer && no_xn2) hipLaunchKernelGGL((k_cg_step1_ar<Q, FT_NNZ, true, true, true>), grid, block, 0, st, FUSED_ARGS, pj); \
+    else if (peer) hipLaunchKernelGGL((k_cg_step1_ar<Q, FT_NNZ, false, true, true>), grid, block, 0, st, FUSED_ARGS, pj); \
+    else if (half) hipLaunchKernelGGL((k_cg_step1_ar<Q, 1024, false, false, false>), grid, block, 0, st, FUSED_ARGS, none); \
+    else if (no_xn2 && a->A_col16) hipLaunchKernelGGL((k_cg_step1_ar<Q, FT_NNZ, true, true, false>), grid, block, 0, st, FUSED_ARGS, none); \
+    else if (no_xn2) hipLaunchKernelGGL((k_cg_step1_ar<Q, FT_NNZ, true, false, false>), grid, block, 0, st, FUSED_ARGS, none); \
+    else if (a->A_col16) hipLaunchKernelGGL((k_cg_step1_ar<Q, FT_NNZ, false, true, false>), grid, block, 0, st, FUSED_ARGS, none); \
+    else hipLaunchKernelGGL((k_cg_step1_ar<Q, FT_NNZ, false, false, false>), grid, block, 0, st, FUSED_ARGS, none);    \
   } while (0)
   switch (qs) {
     case 1: case 2: GO(2); break;
@@ -1106,6 +1114,7 @@ static int launch_step2_hp(const ipx_cg_args *a, int it, int mode, const double 
                            const ipx_peer_job *peer = nullptr) {
   if (!g) g = a->r;
   const ipx_peer_job pj = peer ? *peer : ipx_peer_job{};
+  const ipx_no_peer none{};
   double *g_halo = peer ? a->r : nullptr;
   const int64_t half = a->H_ntiles * 2 * a->H_hmax;
   const double *pb_in = a->pb + (it & 1) * half;
@@ -1115,7 +1124,7 @@ static int launch_step2_hp(const ipx_cg_args *a, int it, int mode, const double 
   (int)a->n, a->state, it & 1, mode, p2, np2, p3, np3, p4, np4, a->x, a->p, g,                \
       a->H_rowptr, a->H_colidx, a->H_val, a->H_tiles,                                         \
       (int)a->H_ntiles, a->H_diag, a->Hp, a->part1, (int)a->H_hmax, pb_in, pb_out,           \
-      (const uint16_t *)a->H_col16, a->H_rowlen, pj, g_halo
+      (const uint16_t *)a->H_col16, a->H_rowlen
   // H_hmax carries the longest tile's row count in its upper half (set by the host
   // binding): short tiles (3 nonzeros per row -> 683 rows) take the 3-elements-per-lane
   // instantiation, which needs fewer registers
@@ -1125,12 +1134,12 @@ static int launch_step2_hp(const ipx_cg_args *a, int it, int mode, const double 
   if (peer && !c16) return IPX_EINVAL;                        // (see peer_fusable)
 #define GO(D, QQ, QSS)                                                                       \
   do {                                                                                       \
-    if (peer && box) hipLaunchKernelGGL((k_cg_step2_hp<D, QQ, QSS, true, true, true>), grid, block, 0, st, FUSED_ARGS); \
-    else if (peer) hipLaunchKernelGGL((k_cg_step2_hp<D, QQ, QSS, false, true, true>), grid, block, 0, st, FUSED_ARGS); \
-    else if (box && c16) hipLaunchKernelGGL((k_cg_step2_hp<D, QQ, QSS, true, true, false>), grid, block, 0, st, FUSED_ARGS); \
-    else if (box) hipLaunchKernelGGL((k_cg_step2_hp<D, QQ, QSS, true, false, false>), grid, block, 0, st, FUSED_ARGS); \
-    else if (c16) hipLaunchKernelGGL((k_cg_step2_hp<D, QQ, QSS, false, true, false>), grid, block, 0, st, FUSED_ARGS); \
-    else hipLaunchKernelGGL((k_cg_step2_hp<D, QQ, QSS, false, false, false>), grid, block, 0, st, FUSED_ARGS);    \
+    if (peer && box) hipLaunchKernelGGL((k_cg_step2_hp<D, QQ, QSS, true, true, true>), grid, block, 0, st, FUSED_ARGS, pj, g_halo); \
+    else if (peer) hipLaunchKernelGGL((k_cg_step2_hp<D, QQ, QSS, false, true, true>), grid, block, 0, st, FUSED_ARGS, pj, g_halo); \
+    else if (box && c16) hipLaunchKernelGGL((k_cg_step2_hp<D, QQ, QSS, true, true, false>), grid, block, 0, st, FUSED_ARGS, none, g_halo); \
+    else if (box) hipLaunchKernelGGL((k_cg_step2_hp<D, QQ, QSS, true, false, false>), grid, block, 0, st, FUSED_ARGS, none, g_halo); \
+    else if (c16) hipLaunchKernelGGL((k_cg_step2_hp<D, QQ, QSS, false, true, false>), grid, block, 0, st, FUSED_ARGS, none, g_halo); \
+    else hipLaunchKernelGGL((k_cg_step2_hp<D, QQ, QSS, false, false, false>), grid, block, 0, st, FUSED_ARGS, none, g_halo);    \
   } while (0)
   if (a->H_diag) {
     if (small) GO(true, 3, 3); else GO(true, 4, 5);
@@ -1390,7 +1399,7 @@ static int shard2_segment(const ipx_cg_args *a, const ipx_shard2_ext *e, int32_t
       hipLaunchKernelGGL(k_cg_step1_box<false>, dim3(ipx_xcd_grid(np2)), dim3(IPX_BLOCK), 0, st, a->state,
                          it & 1, e->s1, 1, a->x, a->p, a->r, a->Hp, a->lb, a->ub, a->part2, np2,
                          (int)b->ng, (int)b->ngen, ipx_group_tab{b->gcol, b->grp}, b->gen_cols,
-                         (int)b->ny, b->up, own, ipx_peer_job{});
+                         (int)b->ny, b->up, own, ipx_no_peer{});
       IPX_CHECK_LAUNCH();
       int32_t n3 = 0, n4 = 0;
       rc = ipx_boxschur_project_from(b, a->r, a->r, a->part3, &n3, a->part4, &n4, guard, 1, st, &own);
@@ -1662,7 +1671,7 @@ static int cg_iterate(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, hi
                          a->state, it & 1, p1, np1, a->x, a->p, a->r, a->Hp, a->lb, a->ub,
                          a->part2, nblk, (int)b->ng, (int)b->ngen,
                          ipx_group_tab{b->gcol, b->grp}, b->gen_cols, (int)b->ny,
-                         b->up, own_all(a->n), ipx_peer_job{});
+                         b->up, own_all(a->n), ipx_no_peer{});
       IPX_CHECK_LAUNCH();
       MARK(1);
     } else {
