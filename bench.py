@@ -591,10 +591,19 @@ def sharded_leg(args, world, rank, A_h, H_h, hdiag_h, c_h, n, m, K, W):
     if transport == "ipc":
         ab["ipc"]["launches_per_iteration"] = launches
         if launches == 3:                       # A/B: the collectives in pack kernels of their own
+            # (alternating, three regions each: ranks that share one GPU interleave differently
+            # from region to region, a single pair of numbers says little)
             try:
-                F.ext.fuse_comm = 0
-                e3, _ = _sharded_run(F, primed, K, W, dist, torch)
-                ab["ipc_pack_kernels"] = {"iterations_per_s": K / e3, "ms_per_step": 1e3 * e3 / K,
+                t3, t5 = [], []
+                for _ in range(3):
+                    F.ext.fuse_comm = 0
+                    t5.append(_sharded_run(F, primed, K, W, dist, torch)[0])
+                    F.ext.fuse_comm = 1
+                    t3.append(_sharded_run(F, primed, K, W, dist, torch)[0])
+                ab["ipc"]["ms_per_step_regions"] = [1e3 * t / K for t in [elapsed] + t3]
+                ab["ipc_pack_kernels"] = {"iterations_per_s": K / sorted(t5)[1],
+                                          "ms_per_step": 1e3 * sorted(t5)[1] / K,
+                                          "ms_per_step_regions": [1e3 * t / K for t in t5],
                                           "launches_per_iteration": 5}
             except Exception as exc:
                 ab["ipc_pack_kernels"] = {"error": repr(exc)}
