@@ -198,37 +198,52 @@ def _shard_request(options):
 
 
 def _sharded_backend(shard, constr, n_vars):
-    """The row-sharded backend (ipsolver/sharded.py: one process per GPU) for this problem:
-    the partition follows the sparse Jacobian of the equality rows, or -- nonlinear
-    inequalities + a box on every variable, BASELINE config 5 -- of the nonlinear rows."""
+    """The row-sharded backend (one process per GPU) for this problem.  Two shapes run on the
+    banded partition with its device-resident loop (ipsolver/sharded.py): equality rows only,
+    partitioned along their banded Jacobian (BASELINE configs 3 / 4), and nonlinear inequality
+    rows + an interval box on every variable, partitioned along the nonlinear rows (config 5).
+    Everything else the reference accepts with a sparse Jacobian -- no band, equality and
+    inequality rows together, ragged or no boxes -- runs on the plain block partition with
+    all-gather / reduce-scatter products (ipsolver/sharded_general.py)."""
     import scipy.sparse as sps
-    from . import sharded
+    from . import sharded, sharded_general
     ops = shard if hasattr(shard, "from_host") else sharded.HipOps()
     comm = sharded.ShardComm()
-    if constr.n_ineq == 0:
-        J = constr.J_eq0
-    elif constr.n_eq == 0:
-        J = constr.J_ineq0[:constr.n_ineq - 2 * n_vars] if sps.issparse(constr.J_ineq0) else None
-    else:
-        raise NotImplementedError("row-sharded solve: equality and inequality constraints "
-                                  "together are not distributed")
-    if J is None or not sps.issparse(J) or J.shape[0] == 0:
+    n_eq, n_ineq = constr.n_eq, constr.n_ineq
+    if not (sps.issparse(constr.J_eq0) and sps.issparse(constr.J_ineq0)) or n_eq + n_ineq == 0:
         raise NotImplementedError("row-sharded solve needs a sparse constraint Jacobian with "
                                   "rows to partition (sparse_jacobian=True)")
+
+    def general():
+        try:
+            sh = sharded_general.general_sharding((n_eq, n_vars), ops, comm,
+                                                  {"ineq": n_ineq} if n_ineq else None)
+        except ValueError as exc:
+            raise NotImplementedError("row-sharded solve: %s" % exc)
+        return sharded_general.GeneralBackend(sh, n_ineq)
+
+    J, boxed = None, False
+    if n_ineq == 0:
+        J = constr.J_eq0
+    elif n_eq == 0 and n_ineq > 2 * n_vars:
+        # nonlinear rows followed by all lower bounds, then all upper bounds
+        # (_canonical_constraint.py:350-355) of an interval box on every variable?
+        m_nl = n_ineq - 2 * n_vars
+        eye = sps.identity(n_vars, format="csr")
+        tail = sps.csr_matrix(constr.J_ineq0)[m_nl:]
+        if tail.shape[1] == n_vars and (tail != sps.vstack([-eye, eye], format="csr")).nnz == 0:
+            J, boxed = sps.csr_matrix(constr.J_ineq0)[:m_nl], True
+    if J is None:
+        return general()
     J = sps.csr_matrix(J)
     J.sort_indices()
     try:
         lay = sharded.ShardLayout(J.indptr, J.indices, J.shape, comm.world, comm.rank)
     except (NotImplementedError, ValueError):
-        # no band to follow (or too few row blocks for the ranks): the plain block partition
-        # with all-gather / reduce-scatter products (ipsolver/sharded_general.py)
-        if constr.n_ineq:
-            raise
-        from . import sharded_general
-        return sharded_general.GeneralBackend(sharded_general.general_sharding(J.shape, ops, comm))
+        return general()         # no band to follow, or too few row blocks for the ranks
     sh = sharded.Sharding(lay, comm, ops)
     xp = sharded.ShardedBackend(sh)
-    if constr.n_ineq:
+    if boxed:
         sh.register(xp.INEQ)
         sh.register(xp.Z)
     return xp

@@ -778,7 +778,9 @@ class ShardVec:
             if sh.comm.world == 1:
                 out.append(own)
                 continue
-            cuts = sh.lay.col_cuts if k == "col" else sh.lay.row_cuts
+            named = getattr(sh.lay, "cuts", None)       # (the general partition's named spaces)
+            cuts = named[k] if named is not None else \
+                (sh.lay.col_cuts if k == "col" else sh.lay.row_cuts)
             sizes = np.diff(cuts)
             pad = np.zeros(int(sizes.max()))
             pad[:len(own)] = own

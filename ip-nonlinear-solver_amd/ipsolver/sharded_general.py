@@ -17,8 +17,13 @@ the plain one of SURVEY 8(e):
 
 Vectors are ``sharded.ShardVec`` on a layout without halos, so ``qp.projected_cg`` /
 ``modified_dogleg`` / the intersections (the general, host-driven driver) and the outer loops
-run unchanged.  This is the fallback that keeps every sparse problem solvable on N ranks; the
-banded path with its device-resident loop is the fast one.  Local arithmetic: ``HipOps`` or
+run unchanged.  Problems WITH inequality rows -- any mix of equality, inequality and box
+constraints the reference accepts -- run the barrier method on the same partition: the slack
+space is one more block-partitioned space, ``z = [x; s]`` and the rows ``[c_eq; c_ineq + s]`` are
+stacked vectors, the augmented Jacobian ``[[J_eq, 0], [J_ineq, diag(s)]]``
+(tr_interior_point.py:141-194) is assembled from the global host matrices every accepted step
+and cut into the ranks' rows.  This is the fallback that keeps every sparse problem solvable on
+N ranks; the banded path with its device-resident loop is the fast one.  Local arithmetic: ``HipOps`` or
 the numpy twin (tests/test_sharded_gloo.py).
 """
 import numpy as np
@@ -33,16 +38,23 @@ __all__ = ["GeneralLayout", "GeneralCSR", "GeneralHessian", "GeneralBackend", "p
 
 
 class GeneralLayout:
-    """Contiguous equal blocks of rows and of variables, no halos (the surface
-    ``sharded.Sharding`` needs of a layout)."""
+    """Contiguous equal blocks of every space, no halos (the surface ``sharded.Sharding`` needs
+    of a layout).  Spaces: "row" (constraint rows of the partitioned Jacobian), "col"
+    (variables) and any further named ones (``extra``: the barrier problem's inequality rows /
+    slacks)."""
 
-    def __init__(self, shape, world, rank):
+    def __init__(self, shape, world, rank, extra=None):
         m, n = int(shape[0]), int(shape[1])
-        if m < world or n < world:
-            raise ValueError("%d x %d is too small for %d ranks" % (m, n, world))
+        self.sizes = {"row": m, "col": n}
+        self.sizes.update({k: int(v) for k, v in (extra or {}).items()})
+        for k, size in self.sizes.items():
+            if 0 < size < world or (size == 0 and k == "col"):
+                raise ValueError("space %r of %d entries is too small for %d ranks"
+                                 % (k, size, world))
         self.m, self.n, self.world, self.rank = m, n, world, rank
-        self.row_cuts = [(r * m) // world for r in range(world)] + [m]
-        self.col_cuts = [(r * n) // world for r in range(world)] + [n]
+        self.cuts = {k: [(r * size) // world for r in range(world)] + [size]
+                     for k, size in self.sizes.items()}
+        self.row_cuts, self.col_cuts = self.cuts["row"], self.cuts["col"]
         self.row_block, self.halo_rows = 0, 0
         self.ranks = [dict(R0=self.row_cuts[r], R1=self.row_cuts[r + 1], E0=self.row_cuts[r],
                            E1=self.row_cuts[r + 1], c0=self.col_cuts[r], c1=self.col_cuts[r + 1],
@@ -50,36 +62,27 @@ class GeneralLayout:
         self.me = self.ranks[rank]
 
     def geom(self, kind, rank=None):
-        d = self.ranks[self.rank if rank is None else rank]
-        if kind == "col":
-            return d["c0"], d["c1"] - d["c0"], 0, d["c1"] - d["c0"]
-        return d["R0"], d["R1"] - d["R0"], 0, d["R1"] - d["R0"]
+        c = self.cuts[kind]
+        r = self.rank if rank is None else rank
+        return c[r], c[r + 1] - c[r], 0, c[r + 1] - c[r]
 
     def sends(self, kind):
         return 0, 0
 
     def global_len(self, kind):
-        return self.n if kind == "col" else self.m
+        return self.sizes[kind]
 
 
-def general_sharding(shape, ops, comm=None):
+def general_sharding(shape, ops, comm=None, extra=None):
     comm = comm if comm is not None else ShardComm()
-    return Sharding(GeneralLayout(shape, comm.world, comm.rank), comm, ops)
+    return Sharding(GeneralLayout(shape, comm.world, comm.rank, extra), comm, ops)
 
 
-def _cuts(sh, kind):
-    return sh.lay.col_cuts if kind == "col" else sh.lay.row_cuts
-
-
-def _gather_full(sh, v):
-    """The global vector behind a distributed one as a local array of ``ops``: an all-gather
-    of the own blocks (padded to the widest; device to device under RCCL, staged through the
-    host under gloo -- the test-only combination)."""
-    comm, kind = sh.comm, v.kind
-    if comm.world == 1:
-        return v.loc
-    t = sh.ops.tensor(v.loc)
-    cuts = _cuts(sh, kind)
+def _gather_segment(sh, t, kind):
+    """All-gather of one space's own blocks (padded to the widest; device to device under
+    RCCL, staged through the host under gloo -- the test-only combination)."""
+    comm = sh.comm
+    cuts = sh.lay.cuts[kind]
     width = int(max(np.diff(cuts)))
     stage = t.is_cuda and comm.backend != "nccl"
     mine = torch.zeros(width, dtype=t.dtype, device="cpu" if stage else t.device)
@@ -89,64 +92,92 @@ def _gather_full(sh, v):
     comm.stats["all_reduce_bytes"] += 8 * width * comm.world
     dist.all_gather(parts, mine, group=comm.group)
     full = torch.cat([p[:cuts[r + 1] - cuts[r]] for r, p in enumerate(parts)])
-    return sh.ops.from_tensor(full.to(t.device) if stage else full)
+    return full.to(t.device) if stage else full
+
+
+def _gather_full(sh, v):
+    """The global vector behind a distributed one as a local array of ``ops`` (the segments of
+    a stacked vector in their global order)."""
+    if sh.comm.world == 1:
+        return v.loc
+    t = sh.ops.tensor(v.loc)
+    parts = [_gather_segment(sh, t[off:off + ln], k)
+             for k, off, ln, *_ in sh.segments(v.kind) if sh.lay.global_len(k)]
+    return sh.ops.from_tensor(parts[0] if len(parts) == 1 else torch.cat(parts))
 
 
 def _reduce_scatter(sh, partial, kind):
-    """Sum of every rank's full-length partial vector, own block kept (collective).  RCCL has
+    """Sum of every rank's full-length partial vector, own blocks kept (collective).  RCCL has
     the primitive; gloo (the CPU tests) does not: there it is an all-reduce + slice."""
     comm = sh.comm
     if comm.world == 1:
         return ShardVec(partial, sh, kind)
-    g0, ln, _, _ = sh.lay.geom(kind)
     t = sh.ops.tensor(partial)
     comm.stats["all_reduce"] += 1
     comm.stats["all_reduce_bytes"] += t.numel() * 8
+    segs = [sg for sg in sh.segments(kind) if sh.lay.global_len(sg[0])]
+    own = []
     if comm.backend == "nccl":
-        cuts = _cuts(sh, kind)
-        width = int(max(np.diff(cuts)))
-        padded = torch.zeros(comm.world * width, dtype=t.dtype, device=t.device)
-        for r in range(comm.world):
-            padded[r * width:r * width + cuts[r + 1] - cuts[r]] = t[cuts[r]:cuts[r + 1]]
-        out = torch.empty(width, dtype=t.dtype, device=t.device)
-        dist.reduce_scatter_tensor(out, padded, group=comm.group)
-        own = out[:ln].clone()
+        for k, _, ln, _, _, _, _, goff, glen in segs:
+            cuts = sh.lay.cuts[k]
+            width = int(max(np.diff(cuts)))
+            padded = torch.zeros(comm.world * width, dtype=t.dtype, device=t.device)
+            for r in range(comm.world):
+                padded[r * width:r * width + cuts[r + 1] - cuts[r]] = \
+                    t[goff + cuts[r]:goff + cuts[r + 1]]
+            out = torch.empty(width, dtype=t.dtype, device=t.device)
+            dist.reduce_scatter_tensor(out, padded, group=comm.group)
+            own.append(out[:ln].clone())
     else:
         h = t.cpu() if t.is_cuda else t.clone()
         dist.all_reduce(h, group=comm.group)
-        own = h[g0:g0 + ln].clone()
-        own = own.to(t.device) if t.is_cuda else own
-    return ShardVec(sh.ops.from_tensor(own), sh, kind)
+        for k, _, ln, _, _, _, _, goff, _ in segs:
+            g0 = sh.lay.geom(k)[0]
+            piece = h[goff + g0:goff + g0 + ln].clone()
+            own.append(piece.to(t.device) if t.is_cuda else piece)
+    return ShardVec(sh.ops.from_tensor(own[0] if len(own) == 1 else torch.cat(own)), sh, kind)
 
 
 class GeneralCSR:
-    """Rows ``[R0, R1)`` of a sparse matrix, all columns: ``dot`` gathers x, ``T.dot``
-    reduce-scatters the partial products."""
+    """The rank's rows of a sparse matrix, all columns: ``dot`` gathers x, ``T.dot``
+    reduce-scatters the partial products.  Row and column spaces may be stacked (the barrier
+    problem's augmented Jacobian maps z = ("col", "ineq") to the rows ("row", "ineq"))."""
 
-    def __init__(self, sh, local, transposed=False, other=None):
+    def __init__(self, sh, local, transposed=False, other=None, row_kind="row", col_kind="col"):
         self.sh, self.local, self.transposed, self._T = sh, local, transposed, other
-        m, n = sh.lay.m, sh.lay.n
+        self.row_kind, self.col_kind = row_kind, col_kind
+        self.full = None             # the whole matrix (host, replicated) when built from one
+        m, n = sh.global_len(row_kind), sh.global_len(col_kind)
         self.shape = (n, m) if transposed else (m, n)
-        self.row_kind, self.col_kind = "row", "col"
 
     @staticmethod
-    def from_global(sh, A):
-        d = sh.lay.me
-        return GeneralCSR(sh, sh.ops.csr(sps.csr_matrix(sps.csr_matrix(A)[d["R0"]:d["R1"], :])))
+    def from_global(sh, A, row_kind="row", col_kind="col"):
+        A = sps.csr_matrix(A)
+        assert A.shape == (sh.global_len(row_kind), sh.global_len(col_kind)), A.shape
+        blocks = []
+        for k, _, ln, _, _, _, _, goff, _ in sh.segments(row_kind):
+            g0 = sh.lay.geom(k)[0]
+            blocks.append(A[goff + g0:goff + g0 + ln, :])
+        loc = blocks[0] if len(blocks) == 1 else sps.vstack(blocks, format="csr")
+        out = GeneralCSR(sh, sh.ops.csr(sps.csr_matrix(loc)), row_kind=row_kind,
+                         col_kind=col_kind)
+        out.full = A
+        return out
 
     @property
     def T(self):
         if self._T is None:
-            self._T = GeneralCSR(self.sh, self.local, not self.transposed, self)
+            self._T = GeneralCSR(self.sh, self.local, not self.transposed, self, self.row_kind,
+                                 self.col_kind)
         return self._T
 
     def dot(self, x):
         sh = self.sh
         if not self.transposed:
-            assert x.kind == "col"
-            return ShardVec(self.local.dot(_gather_full(sh, x)), sh, "row")
-        assert x.kind == "row"
-        return _reduce_scatter(sh, sh.ops.rmatvec(self.local, x.loc), "col")
+            assert _same_kind(x.kind, self.col_kind), (x.kind, self.col_kind)
+            return ShardVec(self.local.dot(_gather_full(sh, x)), sh, self.row_kind)
+        assert _same_kind(x.kind, self.row_kind), (x.kind, self.row_kind)
+        return _reduce_scatter(sh, sh.ops.rmatvec(self.local, x.loc), self.col_kind)
 
     matvec = dot
 
@@ -157,7 +188,12 @@ class GeneralCSR:
 
     def row_sumsq(self):
         """diag(A A') on the own rows (the Jacobi preconditioner of the inner solve)."""
-        return ShardVec(self.sh.ops.row_sumsq(self.local), self.sh, "row")
+        return ShardVec(self.sh.ops.row_sumsq(self.local), self.sh, self.row_kind)
+
+
+def _same_kind(a, b):
+    from .sharded import _kinds
+    return _kinds(a) == _kinds(b)
 
 
 class GeneralHessian:
@@ -181,29 +217,71 @@ class GeneralHessian:
     matvec = dot
 
 
+class GeneralHessianZ:
+    """``[Hx p_x ; slack_block * p_s]`` on z = [x; s] (tr_interior_point.py:222-241): the rows of
+    the x-space Hessian the rank owns, the slack block elementwise on its own slacks."""
+
+    def __init__(self, Hx, slack_block, n_vars):
+        self.Hx, self.slack, self.n_vars, self.sh = Hx, slack_block, n_vars, Hx.sh
+        n = n_vars + len(slack_block)
+        self.shape = (n, n)
+
+    def dot(self, p):
+        from .sharded import _kinds
+        y_x = self.Hx.dot(p[:self.n_vars])
+        y_s = self.slack * p[self.n_vars:]
+        kinds = _kinds(y_x.kind) + _kinds(y_s.kind)
+        return ShardVec(self.sh.ops.concat([y_x.loc, y_s.loc]), self.sh, kinds)
+
+    matvec = dot
+
+
 class GeneralProjector:
-    """Z, LS, Y through the normal equations (projections.py:58-90) with a matrix-free inner
-    solve: Jacobi-preconditioned CG on ``A (A' v) = w`` over the ranks."""
+    """Z, LS, Y through the normal equations (projections.py:58-90).  ``(A A')^-1``: matrix-free,
+    Jacobi-preconditioned CG on ``A (A' v) = w`` over the ranks -- or, ``replicate``, the
+    option SURVEY.md 8(e) names for the constraint-space solve: all-gather the right-hand side
+    and solve on every rank with a factorization of the WHOLE ``A A'`` (the local arithmetic's
+    own solver: the device factorizations of ``projector.normal_solver_for`` for ``HipOps``).
+    The barrier subproblems take the second form -- their ``A A'`` loses its conditioning with
+    the slacks, which the diagonal preconditioner does not follow -- and need the matrix
+    replicated on the host, which the host-callback route gives."""
 
     RTOL, MAXIT = 1e-15, 2000
 
-    def __init__(self, A, orth_tol=1e-12, max_refin=3):
+    def __init__(self, A, orth_tol=1e-12, max_refin=3, replicate=False):
         self.A, self.sh = A, A.sh
         self.orth_tol, self.max_refin = orth_tol, max_refin
+        self.stats = {"solves": 0, "refinements": 0, "inner_iterations": 0}
+        self.fused_sharded = False
+        self.solver = None
+        if replicate:
+            if A.full is None:
+                raise NotImplementedError("replicated constraint-space solve: the whole matrix "
+                                          "is not at hand")
+            self.solver = self.sh.ops.any_normal_solver(self.sh.ops.csr(sps.csr_matrix(A.full)))
+            self.norm_A = A.frobenius_norm()
+            return
         d = A.row_sumsq()
         d_h = self.sh.ops.to_host(d.loc)
         dmin = self.sh.comm.reduce_mixed(mins=[float(np.min(d_h)) if len(d_h) else np.inf])[2][0]
         if not dmin > 0:
             raise np.linalg.LinAlgError("Singular Jacobian matrix: a row of A is zero")
-        self.dinv = ShardVec(self.sh.ops.from_host(1.0 / d_h), self.sh, "row")
+        self.dinv = ShardVec(self.sh.ops.from_host(1.0 / d_h), self.sh, A.row_kind)
         self.norm_A = A.frobenius_norm()
-        self.stats = {"solves": 0, "refinements": 0, "inner_iterations": 0}
-        self.fused_sharded = False
 
     def _apply_inv(self, w):
-        """v = (A A')^-1 w by preconditioned CG (the recurrences of csrc/pcg.hip)."""
+        """v = (A A')^-1 w: the replicated factorization on the gathered right-hand side, or
+        preconditioned CG over the ranks (the recurrences of csrc/pcg.hip)."""
         self.stats["solves"] += 1
         A = self.A
+        if self.solver is not None:
+            full = self.solver.solve(_gather_full(self.sh, w))
+            parts = []
+            for k, _, ln, _, _, _, _, goff, _ in self.sh.segments(w.kind):
+                g0 = self.sh.lay.geom(k)[0]
+                parts.append(full[goff + g0:goff + g0 + ln])
+            return ShardVec(self.sh.ops.concat(parts) if len(parts) > 1 else
+                            self.sh.ops.copy(parts[0]), self.sh, w.kind)
         v = w.zeros_like()
         norm_w = float(np.sqrt(w.sumsq_amax()[0]))
         if norm_w == 0:
@@ -267,18 +345,44 @@ class GeneralProjector:
                 _ShardOp((n, m), self.row_space, self))
 
 
-def projections(A, method=None, orth_tol=1e-12, max_refin=3, tol=1e-15):
-    """``projections`` (reference projections.py:290-406) for a ``GeneralCSR``."""
+def projections(A, method=None, orth_tol=1e-12, max_refin=3, tol=1e-15, replicate=None):
+    """``projections`` (reference projections.py:290-406) for a ``GeneralCSR``; ``replicate``:
+    see ``GeneralProjector`` (default: for the barrier problem's stacked row space)."""
     if method not in (None, "NormalEquation", "AugmentedSystem"):
         raise ValueError("Method not allowed for sparse matrix.")
-    return GeneralProjector(A, orth_tol, max_refin).operators()
+    if replicate is None:
+        replicate = A.row_kind != "row" and A.full is not None
+    return GeneralProjector(A, orth_tol, max_refin, replicate).operators()
 
 
 class GeneralBackend(ShardedBackend):
     """The backend of the outer loops (``sqp.py`` / ``barrier.py``) on the plain block
-    partition: what ``minimize_constrained`` dispatches to when the Jacobian has no band for
-    ``sharded.ShardLayout`` to follow.  Equality-constrained problems (both outer methods)."""
+    partition: what ``minimize_constrained`` dispatches to when the problem is not one of the
+    two shapes ``sharded.ShardLayout`` follows (a banded equality Jacobian; banded nonlinear
+    inequalities + an interval box on every variable).  Any mix of equality and inequality
+    rows: the spaces "col" (variables), "row" (equality rows) and "ineq" (inequality rows /
+    slacks) are block-partitioned, z = ("col", "ineq") and the rows of the barrier subproblem
+    ("row", "ineq") are stacked vectors."""
     name = "sharded-general"
+
+    def __init__(self, sh, n_ineq=0):
+        super().__init__(sh)
+        self.n_ineq = int(n_ineq)
+        n_eq = sh.lay.sizes["row"]
+        self.INEQ = "ineq"
+        self.Z = ("col", "ineq")
+        self.ROWS = ("row", "ineq") if n_eq else "ineq"
+        if self.n_ineq:
+            lengths = {}
+            for kind in ("col", "ineq", self.Z) + (("row", self.ROWS) if n_eq else ()):
+                ln = sh.global_len(kind)
+                if ln in lengths:
+                    raise NotImplementedError(
+                        "row-sharded solve on the general partition: the spaces %r and %r both "
+                        "have %d entries (vectors are told apart by their length)"
+                        % (lengths[ln], kind, ln))
+                lengths[ln] = kind
+                sh.register(kind)
 
     def matrix(self, J, key="jac"):
         if J is None or isinstance(J, GeneralCSR):
@@ -288,13 +392,18 @@ class GeneralBackend(ShardedBackend):
         return GeneralCSR.from_global(self.sh, J)
 
     def augmented_jacobian(self, J_eq, J_ineq, s, n_vars, n_eq, n_ineq):
-        raise NotImplementedError("row-sharded solve without a banded Jacobian: equality "
-                                  "constraints only")
+        """[[J_eq, 0], [J_ineq, diag(s)]] (tr_interior_point.py:141-194) from the global host
+        matrices and the gathered slacks, cut into the ranks' rows."""
+        if not (sps.issparse(J_ineq) and (n_eq == 0 or sps.issparse(J_eq))):
+            raise NotImplementedError("sharded backend: dense Jacobians are not distributed")
+        s_h = self.tohost(s)
+        blocks = [[sps.csr_matrix(J_ineq), sps.diags(s_h)]]
+        if n_eq:
+            blocks.insert(0, [sps.csr_matrix(J_eq), None])
+        A = sps.bmat(blocks, format="csr")
+        return GeneralCSR.from_global(self.sh, A, row_kind=self.ROWS, col_kind=self.Z)
 
-    def hessian_operator(self, terms, n_vars, slack_block):
-        if slack_block is not None:
-            raise NotImplementedError("row-sharded solve without a banded Jacobian: equality "
-                                      "constraints only")
+    def _x_hessian(self, terms):
         if isinstance(terms, GeneralHessian):
             return terms
         from .canonical import HessianSum
@@ -309,6 +418,12 @@ class GeneralBackend(ShardedBackend):
         if total is None:
             total = sps.csr_matrix((self.sh.lay.n, self.sh.lay.n))
         return GeneralHessian.from_global(self.sh, total)
+
+    def hessian_operator(self, terms, n_vars, slack_block):
+        Hx = self._x_hessian(terms)
+        if slack_block is None:
+            return Hx
+        return GeneralHessianZ(Hx, slack_block, n_vars)
 
     def projections(self, A, method=None):
         return projections(A, method)

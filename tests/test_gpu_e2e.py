@@ -100,6 +100,23 @@ def test_dense_hessian_upload_is_reused_only_for_read_only_arrays():
     assert not bh._immutable(ro_view)
 
 
+def test_sharded_mixed_constraints_hip(tmp_path):
+    """Equality rows, nonlinear inequalities and a ragged box together, random sparsity, on two
+    processes with the HIP kernels (``options={'shard': True}`` -> the plain block partition of
+    ipsolver/sharded_general.py: the barrier method on stacked distributed vectors, the
+    constraint-space solve replicated with the device factorizations): the complete solve
+    against the single-process oracle backend."""
+    import socket
+    import torch.multiprocessing as mp
+    from test_sharded_gloo import _mixed_worker, check_mixed
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    path = str(tmp_path / "mixed_hip.npz")
+    mp.spawn(_mixed_worker, args=(2, port, path, 1000, True), nprocs=2, join=True)
+    check_mixed(np.load(path))
+
+
 def test_product_never_imports_the_oracle():
     """Run a solve in a fresh interpreter: the product must not load oracle.*
     (no CPU fallback), and must have loaded the in-tree libipx.so."""

@@ -698,3 +698,122 @@ def test_minimize_constrained_dispatches_a_jacobian_without_band(tmp_path):
         assert np.array_equal(have[:k, col], want[:k, col]), col
     assert np.allclose(have[:k, 2:6], want[:k, 2:6], rtol=1e-6, atol=1e-10)
     close(got["x"], res.x, 1e-6)
+
+
+# ---------------------------------------------------------------------------------------------
+# equality AND inequality rows, ragged boxes: the barrier method on the plain block partition
+def _mixed_problem():
+    """A small sparse NLP with every kind of row the reference accepts at once: random-sparsity
+    linear equalities, nonlinear inequalities (one-sided and two-sided), a box with missing
+    bounds.  Convex objective, feasible start."""
+    import scipy.sparse as sps
+    rng = np.random.default_rng(5)
+    n, m_eq, m_in = 90, 14, 22
+    A = sps.random(m_eq, n, density=0.08, random_state=np.random.RandomState(1), format="csr")
+    A = sps.csr_matrix(A + sps.csr_matrix((np.ones(m_eq), (np.arange(m_eq), np.arange(m_eq))),
+                                          shape=(m_eq, n)))
+    B = sps.random(m_in, n, density=0.1, random_state=np.random.RandomState(2), format="csr")
+    B = sps.csr_matrix(B + sps.csr_matrix((np.ones(m_in), (np.arange(m_in), 30 + np.arange(m_in))),
+                                          shape=(m_in, n)))
+    x_feas = 0.3 * rng.standard_normal(n)
+    b_eq = A.dot(x_feas)
+    q = rng.uniform(0.5, 2.0, n)
+    c = rng.standard_normal(n)
+    ub_in = B.dot(x_feas) + 0.05 * B.dot(x_feas) ** 2 + rng.uniform(0.2, 1.0, m_in)
+    lb_in = np.where(np.arange(m_in) % 3 == 0, ub_in - 3.0, -np.inf)       # every third: interval
+    lb = np.where(np.arange(n) % 2 == 0, x_feas - 1.0, -np.inf)             # ragged box
+    ub = np.where(np.arange(n) % 5 == 0, np.inf, x_feas + 0.8)
+    return dict(n=n, A=A, b_eq=b_eq, B=B, lb_in=lb_in, ub_in=ub_in, lb=lb, ub=ub, q=q, c=c,
+                x0=x_feas)
+
+
+def _mixed_solve(ipsolver, P, max_iter=1000, **options):
+    import scipy.sparse as sps
+    B = P["B"]
+    cons = [ipsolver.LinearConstraint(P["A"], ("equals", P["b_eq"])),
+            ipsolver.NonlinearConstraint(
+                lambda x: B.dot(x) + 0.05 * B.dot(x) ** 2, ("interval", P["lb_in"], P["ub_in"]),
+                lambda x: sps.csr_matrix(sps.diags(1.0 + 0.1 * B.dot(x)).dot(B)),
+                lambda x, v: sps.csr_matrix(B.T.dot(sps.diags(0.1 * v)).dot(B))),
+            ipsolver.BoxConstraint(("interval", P["lb"], P["ub"]))]
+    rows = []
+
+    def record(state):
+        rows.append([int(state.niter), int(state.cg_niter), float(state.optimality),
+                     float(state.constr_violation), float(state.barrier_parameter)])
+        return False
+    res = ipsolver.minimize_constrained(
+        lambda x: 0.5 * x.dot(P["q"] * x) + P["c"].dot(x), P["x0"],
+        lambda x: P["q"] * x + P["c"], lambda x: sps.diags(P["q"]).tocsr(), cons,
+        sparse_jacobian=True, callback=record, options=options, max_iter=max_iter)
+    return res, np.array(rows)
+
+
+def _mixed_worker(rank, world, port, out_path, max_iter=1000, hip=False):
+    if hip:
+        import torch
+        torch.cuda.set_device(0)
+    _setup(rank, world, port)
+    try:
+        import warnings
+        import ipsolver
+        from oracle.numpy_local import NumpyOps
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            res, rows = _mixed_solve(ipsolver, _mixed_problem(), max_iter,
+                                     shard=True if hip else NumpyOps())
+        if rank == 0:
+            np.savez(out_path, x=res.x, rows=rows, status=res.status, fun=res.fun,
+                     niter=res.niter, v=res.v, s=res.s)
+    finally:
+        dist.destroy_process_group()
+
+
+def check_mixed(got, max_iter=1000):
+    """A sharded run of the mixed problem against the same call on the single-process CPU
+    backend of the oracle.  The two solve their normal equations differently (a factorization
+    of A A' here, the oracle's augmented system there): identical traces while the subproblems
+    are short, then -- hundreds of CG iterations per barrier subproblem -- the usual drift of a
+    barrier trace; complete runs end at the same point to the accuracy the
+    last barrier parameters (1e-8 vs 5e-8) give."""
+    import warnings
+    import ipsolver
+    import oracle.numpy_backend as nb
+    from ipsolver import backend
+    P = _mixed_problem()
+    with backend.use(nb), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res, want = _mixed_solve(ipsolver, P, max_iter, shard=False)
+    have = got["rows"]
+    k = min(12, len(want))
+    assert len(have) >= k and int(got["status"]) == res.status
+    assert np.array_equal(have[:k, :2], want[:k, :2])                    # outer and CG counts
+    assert np.allclose(have[:k, 2:], want[:k, 2:], rtol=1e-6, atol=1e-12)
+    k = min(20, len(have), len(want))
+    assert np.array_equal(have[:k, 0], want[:k, 0]) and np.array_equal(have[:k, 4], want[:k, 4])
+    if res.status != 1:
+        return
+    assert len(have) > 30 and abs(len(have) - len(want)) <= 6
+    assert np.max(np.abs(got["x"] - res.x)) <= 1e-4 * np.max(np.abs(res.x))
+    assert abs(float(got["fun"]) - res.fun) <= 1e-5 * abs(res.fun)
+    # feasibility of what the sharded run returned, by the problem's own functions
+    x = got["x"]
+    assert np.max(np.abs(P["A"].dot(x) - P["b_eq"])) <= 1e-8
+    cin = P["B"].dot(x) + 0.05 * P["B"].dot(x) ** 2
+    assert np.all(cin <= P["ub_in"] + 1e-8) and np.all(cin >= P["lb_in"] - 1e-8)
+    assert np.all(x <= P["ub"] + 1e-8) and np.all(x >= P["lb"] - 1e-8)
+
+
+@pytest.mark.parametrize("world,max_iter", [(2, 20), (3, 9)])
+def test_minimize_constrained_shards_mixed_constraints(world, max_iter, tmp_path):
+    """Equality rows, one- and two-sided nonlinear inequalities and a ragged box in ONE problem,
+    random sparsity: none of the shapes the banded partition follows, so ``minimize_constrained``
+    on `world` ranks runs the barrier method on the plain block partition (z = [x; s] and the
+    rows [c_eq; c_ineq + s] as stacked distributed vectors, the augmented Jacobian cut into the
+    ranks' rows, all-gather / reduce-scatter products, the constraint-space solve replicated
+    after an all-gather of its right-hand side).  The first outer iterations here (over gloo the
+    complete run takes a minute); the complete solve with the HIP kernels:
+    tests/test_gpu_e2e.py::test_sharded_mixed_constraints_hip."""
+    path = str(tmp_path / "mixed.npz")
+    mp.spawn(_mixed_worker, args=(world, _free_port(), path, max_iter), nprocs=world, join=True)
+    check_mixed(np.load(path), max_iter)
