@@ -20,7 +20,9 @@ name = "hip"
 
 
 # ---- vectors ---------------------------------------------------------------
-def asvec(a):
+def asvec(a, space=None):
+    # (space: which vector space the caller means -- "x", "eq", "ineq", "z"; only the
+    # distributed backends, where a length does not always tell, look at it)
     return a if isinstance(a, DVec) else DVec.from_host(a)
 
 
@@ -29,7 +31,11 @@ def tohost(v):
 
 
 zeros = DVec.zeros
-full = DVec.full
+
+
+def full(n, value, space=None):
+    return DVec.full(n, value)
+
 hstack = dv.hstack
 norm = dv.norm
 norm_inf = dv.norm_inf

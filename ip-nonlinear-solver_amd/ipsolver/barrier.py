@@ -65,7 +65,8 @@ class BarrierSubproblem:
         if self.n_ineq == 0:
             return None                    # identity
         xp = self.xp
-        return xp.diagonal_operator(xp.hstack((xp.full(self.n_vars, 1.0), self.get_slack(z))))
+        return xp.diagonal_operator(xp.hstack((xp.full(self.n_vars, 1.0, space="x"),
+                                               self.get_slack(z))))
 
     def gradient_and_jacobian(self, z):                                   # :117-136
         x, s = self.get_variables(z), self.get_slack(z)
@@ -76,7 +77,8 @@ class BarrierSubproblem:
     def _compute_gradient(self, g):                                       # :138-139
         if self.n_ineq == 0:
             return g
-        return self.xp.hstack((g, self.xp.full(self.n_ineq, -self.barrier_parameter)))
+        return self.xp.hstack((g, self.xp.full(self.n_ineq, -self.barrier_parameter,
+                                               space="ineq")))
 
     def _compute_jacobian(self, J_eq, J_ineq, s):                         # :141-194
         if self.n_ineq == 0:
@@ -131,7 +133,8 @@ def tr_interior_point(fun, grad, lagr_hess, n_vars, n_ineq, n_eq, constr, jac, x
     fun0_sub, constr0_sub = subprob.fun0, subprob.constr0
     grad0_sub, jac0_sub = subprob.grad0, subprob.jac0
     if n_ineq > 0:                                            # :306-308
-        trust_lb = xp.hstack((xp.full(n_vars, -np.inf), xp.full(n_ineq, -BOUNDARY_PARAMETER)))
+        trust_lb = xp.hstack((xp.full(n_vars, -np.inf, space="x"),
+                              xp.full(n_ineq, -BOUNDARY_PARAMETER, space="ineq")))
         trust_ub = None                    # no upper bounds (sqp keeps that side off the kernels)
     else:
         trust_lb = trust_ub = None         # all-infinite box: skipped by the kernels

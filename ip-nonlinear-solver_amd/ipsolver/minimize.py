@@ -343,11 +343,11 @@ def minimize_constrained(fun, x0, grad, hess='2-point', constraints=(), method=N
         return fun(xp.tohost(x))
 
     def grad_dev(x):
-        return xp.asvec(grad_wrapped(xp.tohost(x)))
+        return xp.asvec(grad_wrapped(xp.tohost(x)), space="x")
 
     def constr_dev(x):
         c_ineq, c_eq = constr.constr(xp.tohost(x))
-        return xp.asvec(c_ineq), xp.asvec(c_eq)
+        return xp.asvec(c_ineq, space="ineq"), xp.asvec(c_eq, space="eq")
 
     def jac_host(x):
         return constr.jac(xp.tohost(x))
@@ -355,7 +355,7 @@ def minimize_constrained(fun, x0, grad, hess='2-point', constraints=(), method=N
     if verbose >= 2:
         _print_header(method)
     start_time = time.time()
-    x0_dev, g0_dev = xp.asvec(x0), xp.asvec(g0)
+    x0_dev, g0_dev = xp.asvec(x0, space="x"), xp.asvec(g0, space="x")
     if not interior:                                         # :512-530
         if constr.n_ineq > 0:
             raise ValueError("'equality_constrained_sqp' does not support "
@@ -364,7 +364,7 @@ def minimize_constrained(fun, x0, grad, hess='2-point', constraints=(), method=N
         def fun_and_constr(x):
             xh = xp.tohost(x)
             _, c_eq = constr.constr(xh)
-            return fun(xh), xp.asvec(c_eq)
+            return fun(xh), xp.asvec(c_eq, space="eq")
 
         A0 = xp.matrix(constr.J_eq0)
         if constr.constant_jac:
@@ -373,9 +373,9 @@ def minimize_constrained(fun, x0, grad, hess='2-point', constraints=(), method=N
         def grad_and_jac(x):
             xh = xp.tohost(x)
             if constr.constant_jac:
-                return xp.asvec(grad_wrapped(xh)), A0
+                return xp.asvec(grad_wrapped(xh), space="x"), A0
             _, J_eq = constr.jac(xh)
-            return xp.asvec(grad_wrapped(xh)), xp.matrix(J_eq)
+            return xp.asvec(grad_wrapped(xh), space="x"), xp.matrix(J_eq)
 
         def lagr_hess(x, v):
             terms = host_lagr_hess(xp.tohost(x), xp.tohost(v))
@@ -383,7 +383,7 @@ def minimize_constrained(fun, x0, grad, hess='2-point', constraints=(), method=N
 
         result = equality_constrained_sqp(
             fun_and_constr, grad_and_jac, lagr_hess, x0_dev, f0, g0_dev,
-            xp.asvec(constr.c_eq0), A0, stop_criteria, state, xp,
+            xp.asvec(constr.c_eq0, space="eq"), A0, stop_criteria, state, xp,
             **options)
     else:                                                    # :532-544
         if constr.n_ineq == 0:
@@ -396,8 +396,8 @@ def minimize_constrained(fun, x0, grad, hess='2-point', constraints=(), method=N
         options.pop("barrier_tol", None)
         result = tr_interior_point(
             fun_dev, grad_dev, lagr_hess_terms, n_vars, constr.n_ineq, constr.n_eq,
-            constr_dev, jac_host, x0_dev, f0, g0_dev, xp.asvec(constr.c_ineq0),
-            constr.J_ineq0, xp.asvec(constr.c_eq0), constr.J_eq0, stop_criteria,
+            constr_dev, jac_host, x0_dev, f0, g0_dev, xp.asvec(constr.c_ineq0, space="ineq"),
+            constr.J_ineq0, xp.asvec(constr.c_eq0, space="eq"), constr.J_eq0, stop_criteria,
             constr.enforce_feasibility, xtol, state, xp, **options)
 
     result.execution_time = time.time() - start_time         # :548-564

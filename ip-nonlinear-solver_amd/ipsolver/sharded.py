@@ -1438,13 +1438,19 @@ class ShardedBackend:
         """Own / halo boundaries of the z segments in the local z vector."""
         return [off + b for _, off, _, lo, hi, *_ in self.sh.segments(self.Z) for b in (lo, hi)]
 
-    def asvec(self, a):
+    def _kind(self, n, space=None):
+        """The distributed space of a vector of global length n; ``space`` is the caller's name
+        for it ("x", "eq", "ineq", "z") where the backend keeps spaces a length cannot tell
+        apart (the general partition), else the length decides."""
+        return self.sh.kind_of_len(n)
+
+    def asvec(self, a, space=None):
         if isinstance(a, (ShardVec, _Empty)):
             return a
         a = np.asarray(a, dtype=float)
         if a.size == 0:
             return _Empty()
-        return self.sh.from_global(a, self.sh.kind_of_len(len(a)))
+        return self.sh.from_global(a, self._kind(len(a), space))
 
     def tohost(self, v):
         if isinstance(v, _Empty):
@@ -1454,8 +1460,8 @@ class ShardedBackend:
     def zeros(self, n):
         return _Empty() if n == 0 else self.sh.zeros(self.sh.kind_of_len(n))
 
-    def full(self, n, value):
-        return self.sh.full(self.sh.kind_of_len(n), value)
+    def full(self, n, value, space=None):
+        return self.sh.full(self._kind(n, space), value)
 
     def copy(self, v):
         return v.copy()

@@ -372,17 +372,31 @@ class GeneralBackend(ShardedBackend):
         self.INEQ = "ineq"
         self.Z = ("col", "ineq")
         self.ROWS = ("row", "ineq") if n_eq else "ineq"
+        # the callers name the space of every vector they create (asvec / full: "x", "eq",
+        # "ineq", "z"), so spaces of equal size -- a one-sided bound on every variable makes
+        # n_ineq = n_vars -- stay apart; a bare length is looked up only where it is unambiguous
+        self._by_name = {"x": "col", "eq": "row", "ineq": "ineq",
+                         "z": self.Z if self.n_ineq else "col"}
         if self.n_ineq:
-            lengths = {}
+            seen = {}
             for kind in ("col", "ineq", self.Z) + (("row", self.ROWS) if n_eq else ()):
                 ln = sh.global_len(kind)
-                if ln in lengths:
-                    raise NotImplementedError(
-                        "row-sharded solve on the general partition: the spaces %r and %r both "
-                        "have %d entries (vectors are told apart by their length)"
-                        % (lengths[ln], kind, ln))
-                lengths[ln] = kind
-                sh.register(kind)
+                if ln in seen:
+                    sh.spaces.pop(ln, None)
+                    self._ambiguous = getattr(self, "_ambiguous", set()) | {ln}
+                elif ln not in getattr(self, "_ambiguous", ()):
+                    seen[ln] = kind
+                    sh.register(kind)
+
+    def _kind(self, n, space=None):
+        if space is not None:
+            kind = self._by_name[space]
+            assert self.sh.global_len(kind) == n, (space, n, self.sh.global_len(kind))
+            return kind
+        if n in getattr(self, "_ambiguous", ()):
+            raise NotImplementedError("row-sharded solve on the general partition: two spaces "
+                                      "have %d entries and the caller did not name one" % n)
+        return self.sh.kind_of_len(n)
 
     def matrix(self, J, key="jac"):
         if J is None or isinstance(J, GeneralCSR):

@@ -51,8 +51,8 @@ def equality_constrained_sqp(fun_and_constr, grad_and_jac, lagr_hess, x0, fun0, 
     # side None towards projected_cg, whose kernels then skip that bound vector
     lb_free, ub_free = trust_lb is None, trust_ub is None
     if boxed:
-        trust_lb = trust_lb if trust_lb is not None else xp.full(n, -np.inf)
-        trust_ub = trust_ub if trust_ub is not None else xp.full(n, np.inf)
+        trust_lb = trust_lb if trust_lb is not None else xp.full(n, -np.inf, space="z")
+        trust_ub = trust_ub if trust_ub is not None else xp.full(n, np.inf, space="z")
         half_lb, half_ub = BOX_FACTOR * trust_lb, BOX_FACTOR * trust_ub
     else:
         half_lb = half_ub = None

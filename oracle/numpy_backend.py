@@ -17,7 +17,7 @@ from . import qp_subproblem as _qp
 name = "numpy-oracle"
 
 
-def asvec(a):
+def asvec(a, space=None):
     return np.asarray(a, dtype=float)
 
 
@@ -29,7 +29,7 @@ def zeros(n):
     return np.zeros(n)
 
 
-def full(n, value):
+def full(n, value, space=None):
     return np.full(n, float(value))
 
 

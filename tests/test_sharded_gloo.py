@@ -817,3 +817,61 @@ def test_minimize_constrained_shards_mixed_constraints(world, max_iter, tmp_path
     path = str(tmp_path / "mixed.npz")
     mp.spawn(_mixed_worker, args=(world, _free_port(), path, max_iter), nprocs=world, join=True)
     check_mixed(np.load(path), max_iter)
+
+
+def _bounded_solve(ipsolver, max_iter, **options):
+    """Linear equalities + a lower bound on EVERY variable: as many inequality rows as
+    variables -- two distributed spaces of the same size."""
+    import scipy.sparse as sps
+    P = _mixed_problem()
+    cons = [ipsolver.LinearConstraint(P["A"], ("equals", P["b_eq"])),
+            ipsolver.BoxConstraint(("greater", P["x0"] - 0.7))]
+    rows = []
+
+    def record(state):
+        rows.append([int(state.niter), int(state.cg_niter), float(state.optimality),
+                     float(state.constr_violation), float(state.barrier_parameter)])
+        return False
+    res = ipsolver.minimize_constrained(
+        lambda x: 0.5 * x.dot(P["q"] * x) + P["c"].dot(x), P["x0"],
+        lambda x: P["q"] * x + P["c"], lambda x: sps.diags(P["q"]).tocsr(), cons,
+        sparse_jacobian=True, callback=record, options=options, max_iter=max_iter)
+    return res, np.array(rows)
+
+
+def _bounded_worker(rank, world, port, out_path, max_iter):
+    _setup(rank, world, port)
+    try:
+        import warnings
+        import ipsolver
+        from oracle.numpy_local import NumpyOps
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            res, rows = _bounded_solve(ipsolver, max_iter, shard=NumpyOps())
+        if rank == 0:
+            np.savez(out_path, x=res.x, rows=rows, status=res.status, s=res.s)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_minimize_constrained_shards_spaces_of_equal_size(tmp_path):
+    """A bound on every variable gives as many slacks as variables: on the plain block
+    partition the two spaces have the same length, and a vector of that length is told apart by
+    the space its creator names (``xp.asvec(a, space=...)`` / ``xp.full(n, v, space=...)`` in
+    minimize.py / barrier.py / sqp.py), not by its length.  First outer iterations against the
+    single-process oracle backend."""
+    import warnings
+    import ipsolver
+    import oracle.numpy_backend as nb
+    from ipsolver import backend
+    path = str(tmp_path / "bounded.npz")
+    mp.spawn(_bounded_worker, args=(2, _free_port(), path, 14), nprocs=2, join=True)
+    got = np.load(path)
+    with backend.use(nb), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res, want = _bounded_solve(ipsolver, 14, shard=False)
+    have = got["rows"]
+    k = min(10, len(want))
+    assert len(got["s"]) == len(got["x"]) == 90
+    assert np.array_equal(have[:k, :2], want[:k, :2])
+    assert np.allclose(have[:k, 2:], want[:k, 2:], rtol=1e-6, atol=1e-12)
