@@ -968,6 +968,49 @@ class ShardHessian:
     matvec = dot
 
 
+class HostOperatorTerm:
+    """A Hessian term that exists only as a HOST operator -- finite differences of the user's
+    gradient (the reference's default ``hess='2-point'``, _numdiff.py:403-441), BFGS-like
+    updates, any ``LinearOperator`` (_canonical_constraint.py:119-139) -- on a distributed
+    vector: the vector is gathered, the operator applied on every rank (the user's callbacks
+    are replicated host code), the result cut back into the ranks' blocks.  One collective and
+    one host call per product: what a host operator costs on one GPU too (vectors cross to the
+    host for it), times the gather."""
+
+    def __init__(self, sh, op, kind="col"):
+        self.sh, self.op, self.kind = sh, op, kind
+        n = sh.global_len(kind)
+        self.shape = (n, n)
+
+    def dot(self, p):
+        fn = getattr(self.op, "dot", None) or self.op.matvec
+        return self.sh.from_global(np.asarray(fn(p.to_host()), dtype=float).ravel(), self.kind)
+
+    matvec = dot
+
+
+class OperatorSum:
+    """Sum of distributed Hessian terms (a ``ShardHessian`` / ``GeneralHessian`` part and host
+    operators): no matrix to hand to the device-resident loop, so the general driver runs."""
+
+    def __init__(self, sh, parts, kind="col"):
+        self.sh, self.parts, self.kind = sh, list(parts), kind
+        self.shape = self.parts[0].shape
+
+    def dot(self, p):
+        y = self.parts[0].dot(p)
+        for h in self.parts[1:]:
+            y = y + h.dot(p)
+        return y
+
+    matvec = dot
+
+
+def _is_host_operator(h):
+    return (not sps.issparse(h) and not isinstance(h, np.ndarray)
+            and (hasattr(h, "dot") or hasattr(h, "matvec")) and hasattr(h, "shape"))
+
+
 class _ShardOp:
     def __init__(self, shape, fn, projector):
         self.shape, self._fn, self.projector = shape, fn, projector
@@ -1573,14 +1616,16 @@ class ShardedBackend:
         from .canonical import HessianSum
         flat = terms.flat_terms() if isinstance(terms, HessianSum) else list(terms)
         n = self.sh.lay.n
-        csr, diag = None, None
+        csr, diag, host_ops = None, None, []
         for h in flat:
             if isinstance(h, np.ndarray) and h.ndim == 2:
                 h = sps.csr_matrix(h)
+            if _is_host_operator(h):
+                host_ops.append(HostOperatorTerm(self.sh, h))
+                continue
             if not sps.issparse(h):
-                raise NotImplementedError(
-                    "sharded backend: Hessian terms must be sparse matrices (operator terms -- "
-                    "LinearOperator, finite differences -- are not distributed)")
+                raise NotImplementedError("sharded backend: a Hessian term is neither a sparse "
+                                          "matrix nor an operator")
             h = sps.csr_matrix(h)
             if not h.has_canonical_format:
                 h = h.copy()
@@ -1591,17 +1636,22 @@ class ShardedBackend:
                 diag = d if diag is None else diag + d
             else:
                 csr = h if csr is None else csr + h
+        if host_ops and csr is None and diag is None:
+            return host_ops[0] if len(host_ops) == 1 else OperatorSum(self.sh, host_ops)
         if csr is None:
             csr = sps.csr_matrix((n, n))
         H = self._like["hess"] = ShardHessian.from_global(self.sh, csr, diag,
                                                           like=self._like.get("hess"))
-        return H
+        return OperatorSum(self.sh, [H] + host_ops) if host_ops else H
 
     def hessian_operator(self, terms, n_vars, slack_block):
         if not isinstance(terms, ShardHessian):
             terms = self._host_hessian(terms)
         if slack_block is None:
             return terms
+        if not isinstance(terms, ShardHessian):
+            raise NotImplementedError("sharded backend: operator Hessian terms next to the box "
+                                      "form of the barrier problem (BASELINE config 5 shape)")
         return ShardHessian(self.sh, self.sh.ops.hessian_z(terms.local, slack_block.loc,
                                                           breaks=self._z_breaks()), self.Z)
 

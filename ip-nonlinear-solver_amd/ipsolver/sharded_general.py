@@ -418,20 +418,28 @@ class GeneralBackend(ShardedBackend):
         return GeneralCSR.from_global(self.sh, A, row_kind=self.ROWS, col_kind=self.Z)
 
     def _x_hessian(self, terms):
-        if isinstance(terms, GeneralHessian):
+        if isinstance(terms, GeneralHessian) or hasattr(terms, "parts"):
             return terms
         from .canonical import HessianSum
+        from .sharded import HostOperatorTerm, OperatorSum, _is_host_operator
         flat = terms.flat_terms() if isinstance(terms, HessianSum) else list(terms)
-        total = None
+        total, host_ops = None, []
         for h in flat:
             if isinstance(h, np.ndarray) and h.ndim == 2:
                 h = sps.csr_matrix(h)
+            if _is_host_operator(h):              # finite differences, LinearOperator terms
+                host_ops.append(HostOperatorTerm(self.sh, h))
+                continue
             if not sps.issparse(h):
-                raise NotImplementedError("sharded backend: Hessian terms must be sparse matrices")
+                raise NotImplementedError("sharded backend: a Hessian term is neither a sparse "
+                                          "matrix nor an operator")
             total = sps.csr_matrix(h) if total is None else total + sps.csr_matrix(h)
+        if total is None and host_ops:
+            return host_ops[0] if len(host_ops) == 1 else OperatorSum(self.sh, host_ops)
         if total is None:
             total = sps.csr_matrix((self.sh.lay.n, self.sh.lay.n))
-        return GeneralHessian.from_global(self.sh, total)
+        H = GeneralHessian.from_global(self.sh, total)
+        return OperatorSum(self.sh, [H] + host_ops) if host_ops else H
 
     def hessian_operator(self, terms, n_vars, slack_block):
         Hx = self._x_hessian(terms)

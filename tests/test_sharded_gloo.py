@@ -875,3 +875,74 @@ def test_minimize_constrained_shards_spaces_of_equal_size(tmp_path):
     assert len(got["s"]) == len(got["x"]) == 90
     assert np.array_equal(have[:k, :2], want[:k, :2])
     assert np.allclose(have[:k, 2:], want[:k, 2:], rtol=1e-6, atol=1e-12)
+
+
+def _fd_worker(rank, world, port, out_path, which):
+    _setup(rank, world, port)
+    try:
+        import warnings
+        import ipsolver
+        from oracle.numpy_local import NumpyOps
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            res, rows = _fd_solve(ipsolver, which, shard=NumpyOps())
+        if rank == 0:
+            np.savez(out_path, x=res.x, rows=rows, status=res.status)
+    finally:
+        dist.destroy_process_group()
+
+
+def _fd_solve(ipsolver, which, **options):
+    """The reference's DEFAULT Hessian, hess='2-point' (finite differences of the user's
+    gradient: an operator on the host), on (a) the banded equality NLP -- the banded partition
+    -- and (b) the mixed problem -- the plain block partition."""
+    rows = []
+
+    def record(state):
+        rows.append([int(state.niter), int(state.cg_niter), float(state.optimality),
+                     float(state.constr_violation)])
+        return False
+    if which == "banded":
+        from banded_setup import load_synthetic
+        prob = load_synthetic().CenteredBandedNLP(N, M, eps=1e-3)
+        res = ipsolver.minimize_constrained(prob.fun, prob.x0, prob.grad, "2-point",
+                                            prob.constraints(ipsolver), callback=record,
+                                            options=options, max_iter=6)
+    else:
+        P = _mixed_problem()
+        B = P["B"]
+        import scipy.sparse as sps
+        cons = [ipsolver.LinearConstraint(P["A"], ("equals", P["b_eq"])),
+                ipsolver.NonlinearConstraint(
+                    lambda x: B.dot(x) + 0.05 * B.dot(x) ** 2, ("less", P["ub_in"]),
+                    lambda x: sps.csr_matrix(sps.diags(1.0 + 0.1 * B.dot(x)).dot(B)), "2-point")]
+        res = ipsolver.minimize_constrained(
+            lambda x: 0.5 * x.dot(P["q"] * x) + P["c"].dot(x), P["x0"],
+            lambda x: P["q"] * x + P["c"], "2-point", cons, sparse_jacobian=True,
+            callback=record, options=options, max_iter=8)
+    return res, np.array(rows)
+
+
+@pytest.mark.parametrize("which", ["banded", "mixed"])
+def test_minimize_constrained_shards_finite_difference_hessians(which, tmp_path):
+    """``hess='2-point'`` -- the reference's default -- through the sharded dispatch: the
+    Hessian terms are host operators (finite differences of the replicated callbacks), applied
+    to the gathered vector on every rank and cut back into the ranks' blocks
+    (``sharded.HostOperatorTerm``); the general driver runs instead of the device-resident
+    loop.  First outer iterations against the single-process oracle backend."""
+    import warnings
+    import ipsolver
+    import oracle.numpy_backend as nb
+    from ipsolver import backend
+    path = str(tmp_path / "fd.npz")
+    mp.spawn(_fd_worker, args=(2, _free_port(), path, which), nprocs=2, join=True)
+    got = np.load(path)
+    with backend.use(nb), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res, want = _fd_solve(ipsolver, which, shard=False)
+    have = got["rows"]
+    assert len(have) == len(want) >= 5
+    assert np.array_equal(have[:, :2], want[:, :2])
+    # (difference quotients amplify the last bits of the evaluation point by 1/h ~ 1e8)
+    assert np.allclose(have[:, 2:], want[:, 2:], rtol=1e-5, atol=1e-10)
+    assert np.max(np.abs(got["x"] - res.x)) <= 1e-6 * np.max(np.abs(res.x))
