@@ -197,14 +197,16 @@ def _shard_request(options):
     return shard
 
 
-def _sharded_backend(shard, constr, n_vars):
+def _sharded_backend(shard, constr, n_vars, operator_hessian=False):
     """The row-sharded backend (one process per GPU) for this problem.  Two shapes run on the
     banded partition with its device-resident loop (ipsolver/sharded.py): equality rows only,
     partitioned along their banded Jacobian (BASELINE configs 3 / 4), and nonlinear inequality
     rows + an interval box on every variable, partitioned along the nonlinear rows (config 5).
     Everything else the reference accepts with a sparse Jacobian -- no band, equality and
     inequality rows together, ragged or no boxes -- runs on the plain block partition with
-    all-gather / reduce-scatter products (ipsolver/sharded_general.py)."""
+    all-gather / reduce-scatter products (ipsolver/sharded_general.py).  ``operator_hessian``:
+    some Hessian term is a host operator (finite differences, LinearOperator); the box form of
+    the barrier problem has no operator for those, the plain partition has."""
     import scipy.sparse as sps
     from . import sharded, sharded_general
     ops = shard if hasattr(shard, "from_host") else sharded.HipOps()
@@ -231,7 +233,8 @@ def _sharded_backend(shard, constr, n_vars):
         m_nl = n_ineq - 2 * n_vars
         eye = sps.identity(n_vars, format="csr")
         tail = sps.csr_matrix(constr.J_ineq0)[m_nl:]
-        if tail.shape[1] == n_vars and (tail != sps.vstack([-eye, eye], format="csr")).nnz == 0:
+        if tail.shape[1] == n_vars and not operator_hessian \
+                and (tail != sps.vstack([-eye, eye], format="csr")).nnz == 0:
             J, boxed = sps.csr_matrix(constr.J_ineq0)[:m_nl], True
     if J is None:
         return general()
@@ -299,7 +302,11 @@ def minimize_constrained(fun, x0, grad, hess='2-point', constraints=(), method=N
               else to_canonical(copied))
     host_lagr_hess = lagrangian_hessian(constr, hess_wrapped)
     if shard:
-        xp = _sharded_backend(shard, constr, n_vars)
+        from .constraints import _is_operator
+        op_hess = hess in FD_METHODS or (callable(hess) and _is_operator(hess(x0))) \
+            or any(isinstance(c, NonlinearConstraint) and isinstance(c._hess, str)
+                   and c._hess in FD_METHODS for c in copied)
+        xp = _sharded_backend(shard, constr, n_vars, op_hess)
 
     state = OptimizeResult(niter=0, nfev=1, ngev=1, ncev=1, njev=1, nhev=0,
                            cg_niter=0, cg_info={})           # :443-450
