@@ -212,9 +212,9 @@ def _sharded_backend(shard, constr, n_vars, operator_hessian=False):
     ops = shard if hasattr(shard, "from_host") else sharded.HipOps()
     comm = sharded.ShardComm()
     n_eq, n_ineq = constr.n_eq, constr.n_ineq
-    if not (sps.issparse(constr.J_eq0) and sps.issparse(constr.J_ineq0)) or n_eq + n_ineq == 0:
-        raise NotImplementedError("row-sharded solve needs a sparse constraint Jacobian with "
-                                  "rows to partition (sparse_jacobian=True)")
+    if n_eq + n_ineq == 0:
+        raise NotImplementedError("row-sharded solve needs constraint rows to partition")
+    dense = not (sps.issparse(constr.J_eq0) and sps.issparse(constr.J_ineq0))
 
     def general():
         try:
@@ -225,7 +225,9 @@ def _sharded_backend(shard, constr, n_vars, operator_hessian=False):
         return sharded_general.GeneralBackend(sh, n_ineq)
 
     J, boxed = None, False
-    if n_ineq == 0:
+    if dense:
+        pass           # dense Jacobians: rows of a full CSR on the plain partition
+    elif n_ineq == 0:
         J = constr.J_eq0
     elif n_eq == 0 and n_ineq > 2 * n_vars:
         # nonlinear rows followed by all lower bounds, then all upper bounds

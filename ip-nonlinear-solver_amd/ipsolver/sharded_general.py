@@ -401,15 +401,12 @@ class GeneralBackend(ShardedBackend):
     def matrix(self, J, key="jac"):
         if J is None or isinstance(J, GeneralCSR):
             return J
-        if not sps.issparse(J):
-            raise NotImplementedError("sharded backend: dense Jacobians are not distributed")
-        return GeneralCSR.from_global(self.sh, J)
+        # (a dense Jacobian is the rows of a full CSR here)
+        return GeneralCSR.from_global(self.sh, sps.csr_matrix(J))
 
     def augmented_jacobian(self, J_eq, J_ineq, s, n_vars, n_eq, n_ineq):
         """[[J_eq, 0], [J_ineq, diag(s)]] (tr_interior_point.py:141-194) from the global host
         matrices and the gathered slacks, cut into the ranks' rows."""
-        if not (sps.issparse(J_ineq) and (n_eq == 0 or sps.issparse(J_eq))):
-            raise NotImplementedError("sharded backend: dense Jacobians are not distributed")
         s_h = self.tohost(s)
         blocks = [[sps.csr_matrix(J_ineq), sps.diags(s_h)]]
         if n_eq:

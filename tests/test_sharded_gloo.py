@@ -956,3 +956,68 @@ def test_minimize_constrained_shards_finite_difference_hessians(which, tmp_path)
     # (difference quotients amplify the last bits of the evaluation point by 1/h ~ 1e8)
     assert np.allclose(have[:, 2:], want[:, 2:], rtol=1e-5, atol=1e-10)
     assert np.max(np.abs(got["x"] - res.x)) <= 1e-5 * np.max(np.abs(res.x))
+
+
+def _dense_solve(ipsolver, **options):
+    """A small DENSE problem (numpy Jacobians, a dense Hessian): equality rows + inequality
+    rows + bounds."""
+    rng = np.random.default_rng(9)
+    n = 16
+    G = rng.standard_normal((n, n))
+    Hd = G.dot(G.T) / n + np.eye(n)
+    c = rng.standard_normal(n)
+    A = rng.standard_normal((4, n))
+    B = rng.standard_normal((6, n))
+    x0 = 0.1 * rng.standard_normal(n)
+    cons = [ipsolver.LinearConstraint(A, ("equals", A.dot(x0))),
+            ipsolver.LinearConstraint(B, ("less", B.dot(x0) + 0.5)),
+            ipsolver.BoxConstraint(("interval", x0 - 1.0, x0 + np.linspace(0.5, 2.0, n)))]
+    rows = []
+
+    def record(state):
+        rows.append([int(state.niter), int(state.cg_niter), float(state.optimality),
+                     float(state.constr_violation)])
+        return False
+    res = ipsolver.minimize_constrained(lambda x: 0.5 * x.dot(Hd.dot(x)) + c.dot(x), x0,
+                                        lambda x: Hd.dot(x) + c, lambda x: Hd, cons,
+                                        callback=record, options=options)
+    return res, np.array(rows)
+
+
+def _dense_worker(rank, world, port, out_path):
+    _setup(rank, world, port)
+    try:
+        import warnings
+        import ipsolver
+        from oracle.numpy_local import NumpyOps
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            res, rows = _dense_solve(ipsolver, shard=NumpyOps())
+        if rank == 0:
+            np.savez(out_path, x=res.x, rows=rows, status=res.status, fun=res.fun)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_minimize_constrained_shards_dense_problems(tmp_path):
+    """Dense Jacobians and a dense Hessian through the sharded dispatch (rows of full CSR
+    matrices on the plain block partition): the complete solve against the single-process
+    oracle backend."""
+    import warnings
+    import ipsolver
+    import oracle.numpy_backend as nb
+    from ipsolver import backend
+    path = str(tmp_path / "dense.npz")
+    mp.spawn(_dense_worker, args=(2, _free_port(), path), nprocs=2, join=True)
+    got = np.load(path)
+    with backend.use(nb), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res, want = _dense_solve(ipsolver, shard=False)
+    have = got["rows"]
+    assert res.status in (1, 2) and int(got["status"]) == res.status
+    k = min(10, len(want), len(have))
+    assert np.array_equal(have[:k, :2], want[:k, :2])
+    assert np.allclose(have[:k, 2:], want[:k, 2:], rtol=1e-6, atol=1e-12)
+    assert abs(len(have) - len(want)) <= 4
+    assert np.max(np.abs(got["x"] - res.x)) <= 1e-5 * max(1.0, np.max(np.abs(res.x)))
+    assert abs(float(got["fun"]) - res.fun) <= 1e-7 * max(1.0, abs(res.fun))
