@@ -245,7 +245,9 @@ def single_gpu_measure(A_h, H_h, hdiag_h, c_h, n, m, K, W, repeats=20):
     hp_us = groups[len(groups) // 2]
 
     nnzA, nnzH = A.pattern.nnz, H.csr.pattern.nnz
-    bytes_hp = spmv_bytes(nnzH, n, n, extra_row_vectors=1)           # + diag vector
+    # (the diagonal term rides in the CSR values when the pattern has every diagonal entry:
+    # SURVEY.md 8(d)'s "tridiagonal + diagonal Hessian, nnz ~ 3e6" as ONE matrix)
+    bytes_hp = spmv_bytes(nnzH, n, n, extra_row_vectors=0 if H.diag is None else 1)
     algo = {
         "spmv_H_p": bytes_hp,
         "spmv_A_r": spmv_bytes(nnzA, m, n),
@@ -707,7 +709,7 @@ def sharded_leg(args, world, rank, A_h, H_h, hdiag_h, c_h, n, m, K, W):
         full_solve = {"error": repr(exc)}
 
     nnzA, nnzH = A_h.nnz, H_h.nnz
-    iter_bytes = (spmv_bytes(nnzH, n, n, 1) + spmv_bytes(nnzA, m, n)
+    iter_bytes = (spmv_bytes(nnzH, n, n, 0) + spmv_bytes(nnzA, m, n)      # (diagonal term merged)
                   + spmv_bytes(nnzA, n, m, 1) + 2 * 5 * 8 * n + 4 * 8 * m)
     per_it = {k: v / max(1, (W + K)) for k, v in calls.items()}
     lo, hi = sh.lay.geom("col")[2:]

@@ -344,6 +344,21 @@ class CSRPattern:
         self.nnz = int(self.indptr_h[-1])
         self._transpose = None
 
+    def diagonal_positions(self):
+        """Positions (into the value array) of the entries (i, i), one per row, as a device
+        int32 tensor -- or None when the matrix is not square or some row has no diagonal
+        entry.  Symbolic, once per pattern."""
+        if not hasattr(self, "_diag_pos"):
+            pos = None
+            m, n = self.shape
+            if m == n and self.nnz >= m:
+                rows = np.repeat(np.arange(m, dtype=np.int64), np.diff(self.indptr_h))
+                hit = np.flatnonzero(self.indices_h == rows)
+                if len(hit) == m and np.array_equal(rows[hit], np.arange(m)):
+                    pos = torch.from_numpy(hit.astype(np.int32)).to(ctx().device)
+            self._diag_pos = pos
+        return self._diag_pos
+
     def same_as(self, indptr, indices):
         return (len(indptr) == len(self.indptr_h) and len(indices) == len(self.indices_h)
                 and np.array_equal(indptr, self.indptr_h)
