@@ -1329,7 +1329,39 @@ def fused_projected_cg(H, c, Z, Y, b, trust_radius=np.inf, lb=None, ub=None, tol
     if max_infeasible_iter is None:
         max_infeasible_iter = n - m
 
+    return _run_fused(H, P, c, x0, r0, g0, rt_g, tol, trust_radius, lb, ub, has_box, max_iter,
+                      max_infeasible_iter, batch, retry=True)
+
+
+def _run_fused(H, P, c, x0, r0, g0, rt_g, tol, trust_radius, lb, ub, has_box, max_iter,
+               max_infeasible_iter, batch, retry):
+    from . import _hip
+    from . import device as dv
+    sh = P.sh
     F = FusedShardedCG(H, P, lb if has_box else None, ub if has_box else None)
+    try:
+        return _drive_fused(F, c, x0, r0, g0, rt_g, tol, trust_radius, lb, ub, max_iter,
+                            max_infeasible_iter, batch)
+    except _hip.IpxError as exc:
+        # a wait on the peer mailboxes timed out (stop code 7): every rank's waits time out
+        # together, so every rank arrives here.  The mailbox words are in an unknown state:
+        # the group gives the transport up for good and solves this subproblem again through
+        # torch.distributed (nothing of the call's inputs has been overwritten)
+        if not (retry and F.mailbox is not None and "timed out" in str(exc)):
+            raise
+        from warnings import warn
+        warn("row-sharded projected CG: %s -- falling back to the torch.distributed transport "
+             "for the rest of this process" % exc)
+        os.environ["IPX_SHARD_TRANSPORT"] = "dist"
+        sh._mailbox = False
+        return _run_fused(H, P, c, x0, r0, g0, rt_g, tol, trust_radius, lb, ub, has_box, max_iter,
+                          max_infeasible_iter, batch, retry=False)
+
+
+def _drive_fused(F, c, x0, r0, g0, rt_g, tol, trust_radius, lb, ub, max_iter,
+                 max_infeasible_iter, batch):
+    from . import device as dv
+    sh = F.sh
     F.prime(x0, r0, g0, rt_g, tol, trust_radius)
     L = F.L
     DV = dv.DVec
