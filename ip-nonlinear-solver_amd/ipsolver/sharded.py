@@ -1159,7 +1159,28 @@ def fused_supports(H, Z, Y):
     if not isinstance(H, ShardHessian) or not P.fused_sharded or H.kind != P.A.col_kind:
         return False
     from . import cg_fused
-    return _banded_of(P) is not None and cg_fused._hessian_parts(H.local) is not None
+    return _banded_of(P) is not None and cg_fused._hessian_parts(H.local) is not None \
+        and _loop_geometry_ok(P)
+
+
+def _loop_geometry_ok(P):
+    """The device-resident loop sums per-workgroup partials of the banded solve over the rank's
+    OWN rows, so the solve's workgroups must follow the layout's row blocks (260 rows for a
+    tridiagonal A A'; a wider band gives the factorization another chunk size).  Where they do
+    not, the general driver runs on the same distributed vectors instead (``qp.projected_cg``)."""
+    ok = getattr(P, "_loop_geometry", None)
+    if ok is None:
+        from . import _hip
+        sh = P.sh
+        banded = _banded_of(P)
+        geo = (ctypes.c_int32 * 2)()
+        _, _, rlo, rhi = sh.lay.geom("row")
+        dec = _hip.load().ipx_banded_decoupled_geometry(ctypes.c_void_p(banded.handle), geo)
+        ok = bool(dec) and geo[0] == sh.lay.row_block and rlo % geo[0] == 0 and \
+            (rhi % geo[0] == 0 or sh.lay.me["R1"] == sh.lay.m)
+        flags = sh.comm.reduce_floats([0.0 if ok else 1.0])      # the ranks decide together
+        ok = P._loop_geometry = flags[0] == 0.0
+    return ok
 
 
 class FusedShardedCG:
