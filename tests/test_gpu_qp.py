@@ -467,6 +467,80 @@ def _multi_rank_worker(rank, world, port, out_path, transport="dist"):
         dist.destroy_process_group()
 
 
+def _wide_band_worker(rank, world, port, out_path):
+    import os
+    import sys
+    import torch
+    import torch.distributed as dist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "ip-nonlinear-solver_amd"), os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ipsolver import sharded, qp
+        import ipsolver.device as dv
+        import ipsolver.projector as proj
+        from ipsolver.operators import DeviceHessian
+        from ipsolver.synthetic import CenteredBandedNLP
+        n, m = 35184, 4398                       # 8 columns per row step: A A' has half bandwidth 2
+        prob = CenteredBandedNLP(n, m, seed=2)
+        x = prob.x0
+        v = 0.1 * np.random.default_rng(2).standard_normal(m)
+        A_h, H_h = prob.constr_jac(x).tocsr(), prob.hess(x)
+        hd = prob.kappa * prob.Wt.dot(v)
+        c_h = prob.grad(x)
+        lay = sharded.ShardLayout(A_h.indptr, A_h.indices, A_h.shape, world, rank)
+        sh = sharded.Sharding(lay, sharded.ShardComm(), sharded.HipOps())
+        A = sharded.ShardCSR.from_global(sh, A_h)
+        H = sharded.ShardHessian.from_global(sh, H_h, hd)
+        Z, LS, Y = sharded.projections(A)
+        before = sharded.STATS["fused_calls"]
+        c = sh.from_global(c_h, "col")
+        out = {"k": np.array([sharded._banded_of(Z.projector).k]),
+               "loop": np.array([float(sharded.fused_supports(H, Z, Y))])}
+        A1 = dv.DeviceCSR.from_scipy(A_h)
+        H1 = DeviceHessian(n, csr=dv.DeviceCSR.from_scipy(H_h), diag=dv.DVec.from_host(hd))
+        Z1, _, Y1 = proj.projections(A1)
+        cases = {"free": dict(tol=0, max_iter=20),
+                 "box": dict(tol=0, max_iter=20, lb=np.full(n, -0.02), ub=np.full(n, 0.03))}
+        for name, kw in cases.items():
+            ks = {a: (sh.from_global(b, "col") if a in ("lb", "ub") else b) for a, b in kw.items()}
+            xs, info = qp.projected_cg(H, c, Z, Y, sh.zeros("row"), **ks)
+            x1, info1 = qp.projected_cg(H1, c_h, Z1, Y1, np.zeros(m), **kw)
+            out[name] = np.concatenate(([info["niter"], info["stop_cond"], info1["niter"],
+                                         info1["stop_cond"]], xs.to_host() - x1.to_host(),
+                                        [np.max(np.abs(x1.to_host()))]))
+        out["fused_calls"] = np.array([sharded.STATS["fused_calls"] - before])
+        if rank == 0:
+            np.savez(out_path, **out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_wider_band_takes_the_general_driver(tmp_path, ips):
+    """A Jacobian whose A A' has half bandwidth 2: the banded factorization then works in chunks
+    of 67 rows, its workgroups (268 rows) do not follow the layout's 260-row blocks, and the
+    device-resident sharded loop -- which sums per-workgroup partials over a rank's own rows --
+    does not apply.  ``qp.projected_cg`` then runs the general driver on the same distributed
+    vectors (it used to raise NotImplementedError): same iterates as one GPU."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "wide.npz")
+    mp.spawn(_wide_band_worker, args=(2, port, out), nprocs=2, join=True)
+    got = np.load(out)
+    assert int(got["k"][0]) == 2 and got["loop"][0] == 0.0 and int(got["fused_calls"][0]) == 0
+    for name in ("free", "box"):
+        r = got[name]
+        assert list(r[:2]) == list(r[2:4]), name
+        assert np.max(np.abs(r[4:-1])) <= 1e-11 * r[-1], name
+
+
 def _desync_worker(rank, world, port, out_path):
     import os
     import sys
