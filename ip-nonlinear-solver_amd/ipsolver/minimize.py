@@ -251,6 +251,15 @@ def _sharded_backend(shard, constr, n_vars, operator_hessian=False):
     if boxed:
         sh.register(xp.INEQ)
         sh.register(xp.Z)
+    else:
+        # the halo partition rests on (A A')^-1 decaying across one block of rows, which the
+        # projector measures on the numbers (sharded.ShardProjector._check_truncation): ask once
+        # at the initial Jacobian and take the plain partition if it refuses (every rank
+        # arrives at the same answer: the check is collective)
+        try:
+            xp.projections(xp.matrix(J))
+        except NotImplementedError:
+            return general()
     return xp
 
 

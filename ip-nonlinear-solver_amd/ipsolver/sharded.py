@@ -1052,8 +1052,11 @@ class ShardProjector:
             from . import _hip
             banded = _banded_of(self)
             geo = (ctypes.c_int32 * 2)()
-            if banded is None or not _hip.load().ipx_banded_decoupled_geometry(
-                    ctypes.c_void_p(banded.handle), geo):
+            bad = banded is None or not _hip.load().ipx_banded_decoupled_geometry(
+                ctypes.c_void_p(banded.handle), geo)
+            # (the ranks decide together: a refusal on one rank only would leave the others
+            # waiting in the next collective)
+            if sh.comm.reduce_floats([1.0 if bad else 0.0])[0] > 0:
                 raise NotImplementedError(
                     "row-sharded projections need a banded (A A')^-1 whose partitioned "
                     "factorization decouples numerically (DESIGN.md section 5): the local solve "

@@ -445,4 +445,8 @@ class GeneralBackend(ShardedBackend):
         return GeneralHessianZ(Hx, slack_block, n_vars)
 
     def projections(self, A, method=None):
-        return projections(A, method)
+        # through minimize_constrained the matrices come from replicated host callbacks, so the
+        # whole A is at hand on every rank: the constraint-space solve is the replicated
+        # factorization (robust for ill-conditioned A A', one collective per application); the
+        # distributed CG stays for matrices that exist only as their ranks' rows
+        return projections(A, method, replicate=A.full is not None)

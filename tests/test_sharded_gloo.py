@@ -1021,3 +1021,52 @@ def test_minimize_constrained_shards_dense_problems(tmp_path):
     assert abs(len(have) - len(want)) <= 4
     assert np.max(np.abs(got["x"] - res.x)) <= 1e-5 * max(1.0, np.max(np.abs(res.x)))
     assert abs(float(got["fun"]) - res.fun) <= 1e-7 * max(1.0, abs(res.fun))
+
+
+def _slow_solve(ipsolver, **options):
+    import scipy.sparse as sps
+    A = _slow_decay_jacobian(1300, 0.01)
+    n = A.shape[1]
+    rng = np.random.default_rng(4)
+    q = rng.uniform(0.5, 2.0, n)
+    c = rng.standard_normal(n)
+    b = A.dot(0.2 * rng.standard_normal(n))
+    return ipsolver.minimize_constrained(
+        lambda x: 0.5 * x.dot(q * x) + c.dot(x), np.zeros(n), lambda x: q * x + c,
+        lambda x: sps.diags(q).tocsr(), ipsolver.LinearConstraint(A, ("equals", b)),
+        options=options)
+
+
+def _slow_worker(rank, world, port, out_path):
+    _setup(rank, world, port)
+    try:
+        import warnings
+        import ipsolver
+        from oracle.numpy_local import NumpyOps
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            res = _slow_solve(ipsolver, shard=NumpyOps())
+        if rank == 0:
+            np.savez(out_path, x=res.x, status=res.status, niter=res.niter)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_minimize_constrained_takes_the_plain_partition_when_the_halo_one_refuses(tmp_path):
+    """A banded equality Jacobian whose (A A')^-1 does NOT decay across a block of rows: the
+    halo partition refuses it (test_slowly_decaying_inverse_is_refused_not_truncated); the
+    dispatch asks once at the initial Jacobian and runs the solve on the plain block partition
+    instead of failing.  Against the single-process oracle backend."""
+    import warnings
+    import ipsolver
+    import oracle.numpy_backend as nb
+    from ipsolver import backend
+    path = str(tmp_path / "slow.npz")
+    mp.spawn(_slow_worker, args=(2, _free_port(), path), nprocs=2, join=True)
+    got = np.load(path)
+    with backend.use(nb), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res = _slow_solve(ipsolver, shard=False)
+    assert res.status in (1, 2) and int(got["status"]) in (1, 2)
+    assert abs(int(got["niter"]) - res.niter) <= 3
+    assert np.max(np.abs(got["x"] - res.x)) <= 1e-6 * np.max(np.abs(res.x))
