@@ -406,10 +406,14 @@ int ipx_aat_band_w(int64_t m, int32_t k, const int32_t *rowptr, const int32_t *c
  * each).  factor: 1x1 / 2x2 inverses, the rows' shared-column entries (alpha)
  * and the Schur column weights 1 - alpha'B^-1 alpha; tsolve: t = B^-1 w on those
  * rows and u[col] = alpha't; vsolve: v = t - B^-1 (alpha * y[col]).  grp (may be NULL):
- * 4 doubles per group, the rows' entries (a_p, s_p, a_q, s_q) for ipx_boxschur_project. */
+ * 4 doubles per group, the rows' entries (a_p, s_p, a_q, s_q) for ipx_boxschur_project.
+ * grp2 (may be NULL): 2 doubles per group, (s_p, s_q) carrying the signs of (a_p, a_q) -- the
+ * same table in half the bytes when every a is +-1 and no s is negative (box rows); bit 1 of
+ * *flag is set when that does not hold (bit 0: a block is not positive definite). */
 int ipx_pairs_factor(int32_t ng, const int32_t *rowp, const int32_t *rowq, const int32_t *pos_a,
                      const int32_t *pos_s, const double *val, const int32_t *col, double *alpha,
-                     double *inv, double *weight_col, int *flag, double *grp, void *stream);
+                     double *inv, double *weight_col, int *flag, double *grp, double *grp2,
+                     void *stream);
 int ipx_pairs_tsolve(int32_t ng, const int32_t *rowp, const int32_t *rowq, const double *inv,
                      const double *alpha, const double *w, double *t, const int32_t *col,
                      double *u, void *stream);
@@ -435,6 +439,15 @@ typedef struct ipx_boxschur_args {
   const int32_t *gcol; const double *grp; const int32_t *gen_cols; int64_t ngen;
   int64_t ny;
   double *up;
+  /* optional compact tables for the CG loop's two group kernels (NULL: the forms above):
+   * grp2 = ipx_pairs_factor's compact group table (only when its flag bit 1 stayed clear);
+   * yell_col / yell_val = the columns of A_R once more, per ITEM of the projection (the ng
+   * groups by their shared column, then the ngen other columns) in ELL(2) form: entry t of
+   * item i at [t * (ng + ngen) + i], an absent entry = a valid row with value 0.  Indexed by
+   * the item alone, the loads need no column -> row pointer -> entries round trip.  Only when
+   * no such column holds more than two entries. */
+  const double *grp2;
+  const int32_t *yell_col; const double *yell_val;
 } ipx_boxschur_args;
 /* v = (A A')^-1 w; partial (optional, ceil(mR/256) doubles) receives the residual partials. */
 int ipx_boxschur_solve(const ipx_boxschur_args *a, const double *w, double *v, double *partial,

@@ -31,7 +31,8 @@ k_pairs_factor(int ng, const int32_t *__restrict__ rowp, const int32_t *__restri
                const int32_t *__restrict__ pos_a, const int32_t *__restrict__ pos_s,
                const double *__restrict__ val, double *__restrict__ alpha,
                double *__restrict__ inv, double *__restrict__ weight_col,
-               const int32_t *__restrict__ col, int *flag, double *__restrict__ grp) {
+               const int32_t *__restrict__ col, int *flag, double *__restrict__ grp,
+               double *__restrict__ grp2) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= ng) return;
   const int p = rowp[g], q = rowq[g];
@@ -46,6 +47,12 @@ k_pairs_factor(int ng, const int32_t *__restrict__ rowp, const int32_t *__restri
   }
   if (grp) {                 // (ap, sp, aq, sq) per group: what the fused projection reads
     grp[4 * g] = ap; grp[4 * g + 1] = sp; grp[4 * g + 2] = aq; grp[4 * g + 3] = sq;
+  }
+  if (grp2) {                // the compact form (ipx_group_tab::grp2); flag bit 1: not exact
+    grp2[2 * g] = copysign(sp, ap); grp2[2 * g + 1] = copysign(sq, aq);
+    const bool unit = fabs(ap) == 1.0 && !signbit(sp) &&
+                      (q < 0 || (fabs(aq) == 1.0 && !signbit(sq)));
+    if (!unit) atomicOr(flag, 2);
   }
   double i11, i12, i22, wgt;
   if (!ipx_group_inverse(q >= 0, ap, sp, aq, sq, i11, i12, i22, wgt)) atomicOr(flag, 1);
@@ -201,6 +208,10 @@ k_pairs_pre(int ng, int ngen, ipx_group_tab T, const int32_t *__restrict__ gen_c
 
 constexpr int POST_ITEMS = 4;      // items per thread: 1024 per workgroup = one partial
 
+// UNIT: the compact group table (ipx_group_tab::grp2).  YELL: the columns of A_R per item in
+// ELL(2) form (yrp = the column planes, yval = the value planes; ycol unused) -- same sums
+// (0 + first + second; an absent entry adds a signed zero to a sum that is not -0).
+template <bool UNIT, bool YELL>
 __global__ void __launch_bounds__(IPX_BLOCK)
 k_pairs_post(int ng, int ngen, ipx_group_tab T, const int32_t *__restrict__ gen_cols,
              const double *r, const int32_t *__restrict__ yrp,
@@ -210,18 +221,23 @@ k_pairs_post(int ng, int ngen, ipx_group_tab T, const int32_t *__restrict__ gen_
              ipx_own_ranges own) {
   __shared__ double lds[IPX_BLOCK / IPX_WAVE];
   if (guard && *guard != 0.0) return;
+  const int nitems = ng + ngen;
   // y_c = (A_R' v_R)_c: the column's few general-row entries, summed left to right like the
   // SpMV's row sum (columns beyond ny are touched by no general row)
-  auto ycolumn = [&](int c) {
+  auto ycolumn = [&](int c, int i) {
     double sum = 0.0;
-    if (c < ny) {
+    if constexpr (YELL) {
+      const int c0 = yrp[i], c1 = yrp[nitems + i];
+      const double v0 = yval[i], v1 = yval[nitems + i];
+      sum += v0 * vR[c0];
+      sum += v1 * vR[c1];
+    } else if (c < ny) {
       const int b = yrp[c + 1];
       for (int k = yrp[c]; k < b; ++k) sum += yval[k] * vR[ycol[k]];
     }
     return 1.0 * sum;
   };
   double acc = 0.0;
-  const int nitems = ng + ngen;
 #pragma unroll 2
   for (int k = 0; k < POST_ITEMS; ++k) {
     const int i = (blockIdx.x * POST_ITEMS + k) * IPX_BLOCK + threadIdx.x;
@@ -232,14 +248,14 @@ k_pairs_post(int ng, int ngen, ipx_group_tab T, const int32_t *__restrict__ gen_
     double ap = 0.0, sp = 0.0, aq = 0.0, sq = 0.0;
     if (grp) {
       c = T.gcol[3 * i]; cp = T.gcol[3 * i + 1]; cq = T.gcol[3 * i + 2];
-      ap = T.grp[4 * i]; sp = T.grp[4 * i + 1]; aq = T.grp[4 * i + 2]; sq = T.grp[4 * i + 3];
+      ipx_group_coeffs<UNIT>(T, i, ap, sp, aq, sq);
     } else {
       c = gen_cols[i - ng];
     }
     const double rc = r[c];
     const double rp = cp >= 0 ? r[cp] : 0.0;
     const double rq = cq >= 0 ? r[cq] : 0.0;
-    const double yj = ycolumn(c);
+    const double yj = ycolumn(c, i);
     if (grp) {
       const bool has_q = cq != -2;
       double i11, i12, i22, wgt;
@@ -305,7 +321,7 @@ int ipx_boxschur_project_from(const ipx_boxschur_args *a, const double *r, doubl
       (a->ngen > 0 && !a->gen_cols))
     return IPX_EINVAL;
   hipStream_t st = stream;
-  const ipx_group_tab T{a->gcol, a->grp};
+  const ipx_group_tab T{a->gcol, a->grp, a->grp2};
   const int ng = (int)a->ng;
   const int64_t items = a->ng + a->ngen;
   if (items > 0 && !have_up) {
@@ -332,9 +348,18 @@ int ipx_boxschur_project_from(const ipx_boxschur_args *a, const double *r, doubl
   for (int k = 0; k < 4; ++k) { all.lo[k] = 0; all.hi[k] = 0; }
   all.hi[0] = a->n;
   if (nblk > 0) {
-    hipLaunchKernelGGL(k_pairs_post, dim3(nblk), dim3(IPX_BLOCK), 0, st, ng, (int)a->ngen, T,
-                       a->gen_cols, r, a->ARt_rowptr, a->ARt_colidx, a->ARt_val, a->vR, (int)a->ny,
-                       g, part_g, nblk, guard, own ? *own : all);
+    const bool unit = a->grp2 != nullptr, yell = a->yell_col && a->yell_val;
+    const int32_t *yrp = yell ? a->yell_col : a->ARt_rowptr;
+    const double *yval = yell ? a->yell_val : a->ARt_val;
+#define IPX_POST(U, Y)                                                                          \
+    hipLaunchKernelGGL((k_pairs_post<U, Y>), dim3(nblk), dim3(IPX_BLOCK), 0, st, ng,            \
+                       (int)a->ngen, T, a->gen_cols, r, yrp, a->ARt_colidx, yval, a->vR,        \
+                       (int)a->ny, g, part_g, nblk, guard, own ? *own : all)
+    if (unit && yell) IPX_POST(true, true);
+    else if (unit) IPX_POST(true, false);
+    else if (yell) IPX_POST(false, true);
+    else IPX_POST(false, false);
+#undef IPX_POST
     IPX_CHECK_LAUNCH();
   }
   return IPX_OK;
@@ -347,14 +372,15 @@ extern "C" {
 // (bit 0 set when a block is not positive definite).
 int ipx_pairs_factor(int32_t ng, const int32_t *rowp, const int32_t *rowq, const int32_t *pos_a,
                      const int32_t *pos_s, const double *val, const int32_t *col, double *alpha,
-                     double *inv, double *weight_col, int *flag, double *grp, void *stream) {
+                     double *inv, double *weight_col, int *flag, double *grp, double *grp2,
+                     void *stream) {
   if (ng < 0) return IPX_EINVAL;
   if (ng == 0) return IPX_OK;
   if (!rowp || !rowq || !pos_a || !pos_s || !val || !col || !alpha || !inv || !weight_col || !flag)
     return IPX_EINVAL;
   hipLaunchKernelGGL(k_pairs_factor, dim3((ng + IPX_BLOCK - 1) / IPX_BLOCK), dim3(IPX_BLOCK), 0,
                      (hipStream_t)stream, ng, rowp, rowq, pos_a, pos_s, val, alpha, inv, weight_col,
-                     col, flag, grp);
+                     col, flag, grp, grp2);
   IPX_CHECK_LAUNCH();
   return IPX_OK;
 }

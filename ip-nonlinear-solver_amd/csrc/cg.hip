@@ -147,10 +147,11 @@ k_cg_step1(int64_t n, double *st, int parity, const double *__restrict__ p1, int
 // launch of its own that reads r again.  SB_ITEMS items per thread: one partial per 2048.
 constexpr int SB_ITEMS = 8;
 
+// UNIT: the compact group table (ipx_group_tab::grp2, same coefficients bit for bit).
 // PEER (row-sharded loop on the peer mailboxes): p1 holds zeros for the tiles of halo rows (the
 // PEER form of k_cg_step2_hp and ipx_cg_shard2_fold_hp see to that), so its sum is the rank's
 // own p'Hp; summed over the ranks here (ipx_peer_sum), unguarded like in k_cg_step1_ar.
-template <bool PEER>
+template <bool PEER, bool UNIT>
 __global__ void __launch_bounds__(IPX_BLOCK)
 k_cg_step1_box(double *st, int parity, const double *__restrict__ p1, int np1,
                const double *__restrict__ x, const double *__restrict__ p, double *__restrict__ r,
@@ -206,7 +207,7 @@ k_cg_step1_box(double *st, int parity, const double *__restrict__ p1, int np1,
     double ap = 0.0, sp = 0.0, aq = 0.0, sq = 0.0;
     if (grp) {
       e[0] = T.gcol[3 * i]; e[1] = T.gcol[3 * i + 1]; e[2] = T.gcol[3 * i + 2];
-      ap = T.grp[4 * i]; sp = T.grp[4 * i + 1]; aq = T.grp[4 * i + 2]; sq = T.grp[4 * i + 3];
+      ipx_group_coeffs<UNIT>(T, i, ap, sp, aq, sq);
     } else {
       e[0] = gen_cols[i - ng]; e[1] = -1; e[2] = -1;
     }
@@ -944,6 +945,20 @@ k_cg_pack_comm(RangeJob job, double *__restrict__ out, ipx_peer_view pv, uint32_
   if (!ok) st[ST_STOP] = 7.0;
 }
 
+template <bool PEER>
+static void launch_step1_box(const ipx_cg_args *a, const ipx_boxschur_args *b, int it,
+                             const double *p1, int np1, int nblk, const OwnRanges &own,
+                             typename peer_arg<PEER>::type pj, hipStream_t st) {
+  const ipx_group_tab T{b->gcol, b->grp, b->grp2};
+#define IPX_S1BOX(U)                                                                            \
+  hipLaunchKernelGGL((k_cg_step1_box<PEER, U>), dim3(ipx_xcd_grid(nblk)), dim3(IPX_BLOCK), 0,  \
+                     st, a->state, it & 1, p1, np1, a->x, a->p, a->r, a->Hp, a->lb, a->ub,     \
+                     a->part2, nblk, (int)b->ng, (int)b->ngen, T, b->gen_cols, (int)b->ny,     \
+                     b->up, own, pj)
+  if (b->grp2) IPX_S1BOX(true);
+  else IPX_S1BOX(false);
+#undef IPX_S1BOX
+}
 }  // namespace
 
 IPX_STAMP_EXPORT(ipx_debug_stamps_cg, ipx_dbg_cg)
@@ -1339,10 +1354,7 @@ static int shard2_segment(const ipx_cg_args *a, const ipx_shard2_ext *e, int32_t
         const ipx_boxschur_args *b = (const ipx_boxschur_args *)a->banded;
         const OwnRanges own = own_of(e);
         const int nblk = step1_box_blocks(a);
-        hipLaunchKernelGGL(k_cg_step1_box<true>, dim3(ipx_xcd_grid(nblk)), dim3(IPX_BLOCK), 0, st,
-                           a->state, it & 1, a->part1, np1, a->x, a->p, a->r, a->Hp, a->lb, a->ub,
-                           a->part2, nblk, (int)b->ng, (int)b->ngen,
-                           ipx_group_tab{b->gcol, b->grp}, b->gen_cols, (int)b->ny, b->up, own, pj);
+        launch_step1_box<true>(a, b, it, a->part1, np1, nblk, own, pj, st);
         IPX_CHECK_LAUNCH();
         int32_t n3 = 0, n4 = 0;
         return ipx_boxschur_project_from(b, a->r, a->r, a->part3, &n3, a->part4, &n4, stopw, 1, st,
@@ -1396,10 +1408,7 @@ static int shard2_segment(const ipx_cg_args *a, const ipx_shard2_ext *e, int32_t
       const ipx_boxschur_args *b = (const ipx_boxschur_args *)a->banded;
       const OwnRanges own = own_of(e);
       np2 = step1_box_blocks(a);
-      hipLaunchKernelGGL(k_cg_step1_box<false>, dim3(ipx_xcd_grid(np2)), dim3(IPX_BLOCK), 0, st, a->state,
-                         it & 1, e->s1, 1, a->x, a->p, a->r, a->Hp, a->lb, a->ub, a->part2, np2,
-                         (int)b->ng, (int)b->ngen, ipx_group_tab{b->gcol, b->grp}, b->gen_cols,
-                         (int)b->ny, b->up, own, ipx_no_peer{});
+      launch_step1_box<false>(a, b, it, e->s1, 1, np2, own, ipx_no_peer{}, st);
       IPX_CHECK_LAUNCH();
       int32_t n3 = 0, n4 = 0;
       rc = ipx_boxschur_project_from(b, a->r, a->r, a->part3, &n3, a->part4, &n4, guard, 1, st, &own);
@@ -1667,11 +1676,7 @@ static int cg_iterate(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, hi
     } else if (a->m > 0 && box_project(a)) {
       const ipx_boxschur_args *b = (const ipx_boxschur_args *)a->banded;
       const int nblk = step1_box_blocks(a);
-      hipLaunchKernelGGL(k_cg_step1_box<false>, dim3(ipx_xcd_grid(nblk)), dim3(IPX_BLOCK), 0, st,
-                         a->state, it & 1, p1, np1, a->x, a->p, a->r, a->Hp, a->lb, a->ub,
-                         a->part2, nblk, (int)b->ng, (int)b->ngen,
-                         ipx_group_tab{b->gcol, b->grp}, b->gen_cols, (int)b->ny,
-                         b->up, own_all(a->n), ipx_no_peer{});
+      launch_step1_box<false>(a, b, it, p1, np1, nblk, own_all(a->n), ipx_no_peer{}, st);
       IPX_CHECK_LAUNCH();
       MARK(1);
     } else {

@@ -414,7 +414,25 @@ struct ipx_group_tab {
   const int32_t *gcol;      // 3 per group: shared column, private column of p, of q
                             // (-1: the row has none; q: -2 = single-row group)
   const double *grp;        // 4 per group: ap, sp, aq, sq
+  const double *grp2;       // 2 per group, or NULL: (sp, sq) carrying the signs of ap, aq --
+                            // the form of box rows, whose shared-column entries are +-1 and
+                            // whose slack entries are not negative (k_pairs_factor checks
+                            // both): half the table bytes in the CG loop's two group kernels
 };
+
+// (ap, sp, aq, sq) of group g.  UNIT: from the compact table -- the same four doubles, bit
+// for bit (|a| = 1 exactly, s >= 0 with its own sign bit clear)
+template <bool UNIT>
+__device__ __forceinline__ void ipx_group_coeffs(const ipx_group_tab &T, int g, double &ap,
+                                                 double &sp, double &aq, double &sq) {
+  if constexpr (UNIT) {
+    const double ep = T.grp2[2 * g], eq = T.grp2[2 * g + 1];
+    ap = copysign(1.0, ep); sp = fabs(ep);
+    aq = copysign(1.0, eq); sq = fabs(eq);
+  } else {
+    ap = T.grp[4 * g]; sp = T.grp[4 * g + 1]; aq = T.grp[4 * g + 2]; sq = T.grp[4 * g + 3];
+  }
+}
 
 // inverse (i11, i12, i22) of B = [[ap^2 + sp^2, ap aq], [ap aq, aq^2 + sq^2]] (single row: 1/b11)
 // and the Schur column weight 1 - alpha' B^-1 alpha, both in cancellation-free form (slacks of

@@ -82,7 +82,7 @@ _SIGNATURES = {
     "ipx_peer_allreduce": [_P, _I32, _P, _P, _P, _I32, _P],
     "ipx_aat_band": [_I64, _I32, _P, _P, _P, _P, _P, _P],
     "ipx_aat_band_w": [_I64, _I32, _P, _P, _P, _P, _P, _P, _P],
-    "ipx_pairs_factor": [_I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "ipx_pairs_factor": [_I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "ipx_pairs_tsolve": [_I32, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "ipx_pairs_vsolve": [_I32, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "ipx_boxschur_solve": [_P, _P, _P, _P, _P, _P, _P],

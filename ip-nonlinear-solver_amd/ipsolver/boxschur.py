@@ -15,6 +15,7 @@ The classification is symbolic (sparsity pattern only, once per pattern on the
 host); all arithmetic is on the device.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -98,7 +99,7 @@ class BoxSchurArgs(ctypes.Structure):
                 ("ARt_ntiles", _I64), ("inner", _P)] + \
                [(k, _P) for k in ("t", "u", "wR", "rhs", "vR", "y")] + \
                [("gcol", _P), ("grp", _P), ("gen_cols", _P), ("ngen", _I64), ("ny", _I64),
-                ("up", _P)]
+                ("up", _P), ("grp2", _P), ("yell_col", _P), ("yell_val", _P)]
 
 
 class BoxSchurNormalSolver:
@@ -138,15 +139,22 @@ class BoxSchurNormalSolver:
         self.inv = torch.empty(3 * max(self.ng, 1), dtype=_F64, device=dev)
         self.wcol = torch.ones(self.n, dtype=_F64, device=dev)
         self.grp = torch.empty(4 * max(self.ng, 1), dtype=_F64, device=dev)
+        # the same table in half the bytes for rows of the box form (entries +-1, slack >= 0):
+        # what the CG loop's two group kernels read when the factor kernel found it exact
+        self.grp2 = torch.empty(2 * max(self.ng, 1), dtype=_F64, device=dev)
         flag = torch.zeros(1, dtype=torch.int32, device=dev)
         st = stream_ptr()
         _hip.call("ipx_pairs_factor", self.ng, _p(cache["rowp"]), _p(cache["rowq"]),
                   _p(cache["pos_a"]), _p(cache["pos_s"]), _p(A.val), _p(cache["col"]),
-                  _p(self.alpha), _p(self.inv), _p(self.wcol), _p(flag), _p(self.grp), st)
+                  _p(self.alpha), _p(self.inv), _p(self.wcol), _p(flag), _p(self.grp),
+                  _p(self.grp2), st)
         self.A_R = cache["sel"].apply(A)                 # general rows (value gather)
         self.inner = BandedNormalSolver(self.A_R, col_weights=self.wcol)   # Sigma = A_R W A_R'
-        if int(flag.item()) != 0:
+        bits = int(flag.item())
+        if bits & 1:
             raise np.linalg.LinAlgError("Singular Jacobian matrix: A A' is not positive definite")
+        if bits & 2 or os.environ.get("IPX_NO_COMPACT_GROUPS"):
+            self.grp2 = None
         self.u = torch.zeros(self.n, dtype=_F64, device=dev)      # only grouped columns are written
         self.t = torch.zeros(self.m, dtype=_F64, device=dev)
         self._args = None
@@ -186,8 +194,40 @@ class BoxSchurNormalSolver:
             a.ny = int(self.A_R.pattern.indices_h.max()) + 1 if self.A_R.pattern.nnz else 0
             self._up = torch.zeros(self.n, dtype=_F64, device=dev)
             a.up = self._up.data_ptr()
+            a.grp2 = self.grp2.data_ptr() if self.grp2 is not None else None
+            self._yell = self._item_columns(ARt)
+            if self._yell is not None:
+                a.yell_col, a.yell_val = c["yell"][2].data_ptr(), self._yell.data_ptr()
             self._args = a
         return self._args
+
+    def _item_columns(self, ARt):
+        """Values of the columns of A_R per item of the projection, ELL(2) (see
+        ipx_boxschur_args.yell_col in include/ipx.h); the positions are found once per pattern.
+        None when a column holds more than two entries."""
+        c = self.c
+        if "yell" not in c:
+            c["yell"] = None
+            pat = ARt.pattern
+            indptr, indices = pat.indptr_h.astype(np.int64), pat.indices_h
+            cols = np.concatenate((self.an.col.astype(np.int64),
+                                   c["gen_cols"].cpu().numpy().astype(np.int64)))
+            first, cnt = indptr[cols], indptr[cols + 1] - indptr[cols]
+            if len(cols) and len(indices) and cnt.max() <= 2 and \
+                    not os.environ.get("IPX_NO_COMPACT_GROUPS"):
+                have = np.stack((cnt >= 1, cnt >= 2))
+                pos = np.where(have, np.stack((first, first + 1)), 0)
+                col = np.where(have, indices[pos], 0)
+                c["yell"] = (_i32(pos.ravel()),
+                             torch.from_numpy(have.ravel().astype(np.float64)).to(ctx().device),
+                             _i32(col.ravel()))
+        if c["yell"] is None:
+            return None
+        pos, mask, _ = c["yell"]
+        out = dv._empty(pos.numel())
+        _hip.call("ipx_gather", pos.numel(), _p(ARt.val), _p(pos), _p(mask), None, _p(out),
+                  stream_ptr())
+        return out
 
     def solve(self, w):
         c, st = self.c, stream_ptr()

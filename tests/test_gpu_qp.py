@@ -775,15 +775,17 @@ def test_unbounded_trust_region_skips_the_norm(ips, monkeypatch):
     assert abs(np.linalg.norm(host(x)) - radius) <= 1e-12 * radius
 
 
-@pytest.mark.parametrize("bounds", ["all", "ragged"])
-def test_box_schur_projection_without_matrix_rows(ips, bounds):
+@pytest.mark.parametrize("bounds", ["all", "ragged", "scaled"])
+def test_box_schur_projection_without_matrix_rows(ips, bounds, monkeypatch):
     """The CG loop's projection for barrier problems (csrc/boxschur.hip ipx_boxschur_project,
     csrc/cg.hip k_cg_step1_box): g = r - A'(A A')^-1 A r with the box rows handled per group
     on r itself -- never multiplied as rows of A or A'.  Against the operator built from the
     SpMVs and ipx_boxschur_solve (same formulas: 1e-13), against a direct sparse solve, with
     every variable bounded on both sides and with a ragged mix (lower only, upper only, both,
-    none: single-row groups and x-columns outside every group); then a whole projected-CG run
-    with slack bounds through the device loop against the oracle."""
+    none: single-row groups and x-columns outside every group), and with bound rows whose
+    entries are not +-1 ("scaled": the compact group table must be refused); the compact
+    tables (ipx_boxschur_args.grp2, yell_*) against the full ones, bit for bit; then a whole
+    projected-CG run with slack bounds through the device loop against the oracle."""
     import ctypes
     import torch
     import oracle
@@ -794,7 +796,7 @@ def test_box_schur_projection_without_matrix_rows(ips, bounds):
     rng = np.random.default_rng(7)
     inst = BandedInstance(n, m)
     J = inst.A
-    if bounds == "all":
+    if bounds in ("all", "scaled"):
         L = U = np.arange(n)
     else:
         kind = rng.integers(0, 4, n)                    # 0 none, 1 lower, 2 upper, 3 both
@@ -802,9 +804,10 @@ def test_box_schur_projection_without_matrix_rows(ips, bounds):
     nl, nu = len(L), len(U)
     I = sps.eye(n, format="csr")
     s = rng.uniform(1e-6, 2.0, m + nl + nu)             # some slacks of (nearly) active bounds
+    fl, fu = (2.0, 3.0) if bounds == "scaled" else (1.0, 1.0)
     A = sps.bmat([[J, sps.diags(s[:m]), None, None],
-                  [-I[L], None, sps.diags(s[m:m + nl]), None],
-                  [I[U], None, None, sps.diags(s[m + nl:])]], format="csr")
+                  [-fl * I[L], None, sps.diags(s[m:m + nl]), None],
+                  [fu * I[U], None, None, sps.diags(s[m + nl:])]], format="csr")
     A.sort_indices()
     N, M = A.shape[1], A.shape[0]
     Ad = ips.dv.DeviceCSR.from_scipy(A)
@@ -812,8 +815,9 @@ def test_box_schur_projection_without_matrix_rows(ips, bounds):
     solver = Z.projector.solver
     assert isinstance(solver, BoxSchurNormalSolver)
     args = solver.c_args()
-    assert args is not None and args.gcol and args.ngen == N - (n if bounds == "all" else
+    assert args is not None and args.gcol and args.ngen == N - (n if bounds != "ragged" else
                                                                  len(np.union1d(L, U))) - nl - nu
+    assert bool(args.grp2) == (bounds != "scaled") and args.yell_col and args.yell_val
     r = rng.standard_normal(N)
     rd = ips.dv.DVec.from_host(r)
     lib = _hip.load()
@@ -829,8 +833,9 @@ def test_box_schur_projection_without_matrix_rows(ips, bounds):
     # the SpMV form with the same solver
     v = solver.solve(Ad.dot(rd))
     ref_dev = host(Ad.rmatvec_sub(v, rd))
-    assert np.max(np.abs(got - ref_dev)) <= 1e-13 * np.max(np.abs(r))
-    # a direct sparse solve
+    err = np.max(np.abs(got - ref_dev)) / np.max(np.abs(r))
+    assert err <= (1e-12 if bounds == "scaled" else 1e-13), err    # (entries 2, 3: B's inverse
+    # a direct sparse solve                                          is 10x larger)
     lu = sps.linalg.splu(sps.csc_matrix(A @ A.T))
     want = r - A.T @ lu.solve(A @ r)
     assert np.max(np.abs(got - want)) <= 1e-10 * np.max(np.abs(r))
@@ -842,6 +847,17 @@ def test_box_schur_projection_without_matrix_rows(ips, bounds):
               ips.dv._p(pg), ctypes.byref(n3), ips.dv._p(pres), ctypes.byref(n4), None,
               ips.dv.stream_ptr())
     assert np.array_equal(g2.cpu().numpy(), got)
+    # the full tables (4 doubles per group, the columns of A_R through their row pointers)
+    monkeypatch.setenv("IPX_NO_COMPACT_GROUPS", "1")
+    Zf, _, Yf = ips.proj.projections(ips.dv.DeviceCSR.from_scipy(A))
+    fargs = Zf.projector.solver.c_args()
+    assert not fargs.grp2 and not fargs.yell_col and not fargs.yell_val
+    g3, pg3 = torch.empty_like(g), torch.zeros_like(pg)
+    _hip.call("ipx_boxschur_project", ctypes.byref(fargs), ips.dv._p(rd.t), ips.dv._p(g3),
+              ips.dv._p(pg3), ctypes.byref(n3), ips.dv._p(pres), ctypes.byref(n4), None,
+              ips.dv.stream_ptr())
+    assert np.array_equal(g3.cpu().numpy(), got) and torch.equal(pg3, pg)
+    monkeypatch.delenv("IPX_NO_COMPACT_GROUPS")
     # the device loop on the barrier-shaped subproblem: bounds on the slacks only
     Hz = sps.block_diag([inst.H, sps.diags(rng.uniform(0.5, 2.0, N - n))], format="csr")
     Hd = ips.dv.DeviceCSR.from_scipy(Hz)
@@ -859,6 +875,11 @@ def test_box_schur_projection_without_matrix_rows(ips, bounds):
     assert (info["stop_cond"], info["hits_boundary"]) == (io["stop_cond"], io["hits_boundary"])
     assert info["niter"] == io["niter"]
     close(x, xo, 1e-10)
+    # ... and with the full tables: the same iterates bit for bit
+    xf, inf_ = cg_fused.projected_cg(Hd, ips.dv.DVec.from_host(c), Zf, Yf,
+                                     ips.dv.DVec.from_host(b), trust_radius=5.0,
+                                     lb=ips.dv.DVec.from_host(lb), tol=1e-10)
+    assert inf_ == info and np.array_equal(host(xf), host(x))
 
 
 @pytest.mark.parametrize("variant", ["plain", "sphere", "box"])
