@@ -448,6 +448,10 @@ typedef struct ipx_boxschur_args {
    * no such column holds more than two entries. */
   const double *grp2;
   const int32_t *yell_col; const double *yell_val;
+  /* gaffine != 0 (with grp2): group g has the columns (gc0 + g, gc0 + g + gdp, gc0 + g + gdq)
+   * and gen_cols[k] = gen0 + k -- every variable bounded on both sides, the usual
+   * BoxConstraint; the two kernels compute the columns instead of reading gcol / gen_cols. */
+  int64_t gaffine, gc0, gdp, gdq, gen0;
 } ipx_boxschur_args;
 /* v = (A A')^-1 w; partial (optional, ceil(mR/256) doubles) receives the residual partials. */
 int ipx_boxschur_solve(const ipx_boxschur_args *a, const double *w, double *v, double *partial,

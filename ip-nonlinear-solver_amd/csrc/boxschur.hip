@@ -208,10 +208,10 @@ k_pairs_pre(int ng, int ngen, ipx_group_tab T, const int32_t *__restrict__ gen_c
 
 constexpr int POST_ITEMS = 4;      // items per thread: 1024 per workgroup = one partial
 
-// UNIT: the compact group table (ipx_group_tab::grp2).  YELL: the columns of A_R per item in
+// MODE: the form of the group tables (ipx_group_tab).  YELL: the columns of A_R per item in
 // ELL(2) form (yrp = the column planes, yval = the value planes; ycol unused) -- same sums
 // (0 + first + second; an absent entry adds a signed zero to a sum that is not -0).
-template <bool UNIT, bool YELL>
+template <int MODE, bool YELL>
 __global__ void __launch_bounds__(IPX_BLOCK)
 k_pairs_post(int ng, int ngen, ipx_group_tab T, const int32_t *__restrict__ gen_cols,
              const double *r, const int32_t *__restrict__ yrp,
@@ -247,10 +247,10 @@ k_pairs_post(int ng, int ngen, ipx_group_tab T, const int32_t *__restrict__ gen_
     int c, cp = -1, cq = -1;
     double ap = 0.0, sp = 0.0, aq = 0.0, sq = 0.0;
     if (grp) {
-      c = T.gcol[3 * i]; cp = T.gcol[3 * i + 1]; cq = T.gcol[3 * i + 2];
-      ipx_group_coeffs<UNIT>(T, i, ap, sp, aq, sq);
+      ipx_group_cols<MODE>(T, i, c, cp, cq);
+      ipx_group_coeffs<MODE != IPX_GROUPS_FULL>(T, i, ap, sp, aq, sq);
     } else {
-      c = gen_cols[i - ng];
+      c = MODE == IPX_GROUPS_AFFINE ? T.gen0 + (i - ng) : gen_cols[i - ng];
     }
     const double rc = r[c];
     const double rp = cp >= 0 ? r[cp] : 0.0;
@@ -321,7 +321,7 @@ int ipx_boxschur_project_from(const ipx_boxschur_args *a, const double *r, doubl
       (a->ngen > 0 && !a->gen_cols))
     return IPX_EINVAL;
   hipStream_t st = stream;
-  const ipx_group_tab T{a->gcol, a->grp, a->grp2};
+  const ipx_group_tab T = ipx_boxschur_tab(a);
   const int ng = (int)a->ng;
   const int64_t items = a->ng + a->ngen;
   if (items > 0 && !have_up) {
@@ -348,17 +348,21 @@ int ipx_boxschur_project_from(const ipx_boxschur_args *a, const double *r, doubl
   for (int k = 0; k < 4; ++k) { all.lo[k] = 0; all.hi[k] = 0; }
   all.hi[0] = a->n;
   if (nblk > 0) {
-    const bool unit = a->grp2 != nullptr, yell = a->yell_col && a->yell_val;
+    const bool yell = a->yell_col && a->yell_val;
     const int32_t *yrp = yell ? a->yell_col : a->ARt_rowptr;
     const double *yval = yell ? a->yell_val : a->ARt_val;
-#define IPX_POST(U, Y)                                                                          \
-    hipLaunchKernelGGL((k_pairs_post<U, Y>), dim3(nblk), dim3(IPX_BLOCK), 0, st, ng,            \
+#define IPX_POST(M, Y)                                                                          \
+    hipLaunchKernelGGL((k_pairs_post<M, Y>), dim3(nblk), dim3(IPX_BLOCK), 0, st, ng,            \
                        (int)a->ngen, T, a->gen_cols, r, yrp, a->ARt_colidx, yval, a->vR,        \
                        (int)a->ny, g, part_g, nblk, guard, own ? *own : all)
-    if (unit && yell) IPX_POST(true, true);
-    else if (unit) IPX_POST(true, false);
-    else if (yell) IPX_POST(false, true);
-    else IPX_POST(false, false);
+    switch (ipx_group_mode(T) * 2 + (yell ? 1 : 0)) {
+      case 5: IPX_POST(IPX_GROUPS_AFFINE, true); break;
+      case 4: IPX_POST(IPX_GROUPS_AFFINE, false); break;
+      case 3: IPX_POST(IPX_GROUPS_UNIT, true); break;
+      case 2: IPX_POST(IPX_GROUPS_UNIT, false); break;
+      case 1: IPX_POST(IPX_GROUPS_FULL, true); break;
+      default: IPX_POST(IPX_GROUPS_FULL, false);
+    }
 #undef IPX_POST
     IPX_CHECK_LAUNCH();
   }

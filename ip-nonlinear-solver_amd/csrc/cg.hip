@@ -147,11 +147,12 @@ k_cg_step1(int64_t n, double *st, int parity, const double *__restrict__ p1, int
 // launch of its own that reads r again.  SB_ITEMS items per thread: one partial per 2048.
 constexpr int SB_ITEMS = 8;
 
-// UNIT: the compact group table (ipx_group_tab::grp2, same coefficients bit for bit).
+// MODE: the form of the group tables (ipx_group_tab: full, compact coefficients, compact
+// coefficients + computed columns; the same numbers bit for bit).
 // PEER (row-sharded loop on the peer mailboxes): p1 holds zeros for the tiles of halo rows (the
 // PEER form of k_cg_step2_hp and ipx_cg_shard2_fold_hp see to that), so its sum is the rank's
 // own p'Hp; summed over the ranks here (ipx_peer_sum), unguarded like in k_cg_step1_ar.
-template <bool PEER, bool UNIT>
+template <bool PEER, int MODE>
 __global__ void __launch_bounds__(IPX_BLOCK)
 k_cg_step1_box(double *st, int parity, const double *__restrict__ p1, int np1,
                const double *__restrict__ x, const double *__restrict__ p, double *__restrict__ r,
@@ -206,10 +207,11 @@ k_cg_step1_box(double *st, int parity, const double *__restrict__ p1, int np1,
     int e[3];
     double ap = 0.0, sp = 0.0, aq = 0.0, sq = 0.0;
     if (grp) {
-      e[0] = T.gcol[3 * i]; e[1] = T.gcol[3 * i + 1]; e[2] = T.gcol[3 * i + 2];
-      ipx_group_coeffs<UNIT>(T, i, ap, sp, aq, sq);
+      ipx_group_cols<MODE>(T, i, e[0], e[1], e[2]);
+      ipx_group_coeffs<MODE != IPX_GROUPS_FULL>(T, i, ap, sp, aq, sq);
     } else {
-      e[0] = gen_cols[i - ng]; e[1] = -1; e[2] = -1;
+      e[0] = MODE == IPX_GROUPS_AFFINE ? T.gen0 + (i - ng) : gen_cols[i - ng];
+      e[1] = -1; e[2] = -1;
     }
     double xv[3], pv[3], rv[3], hv[3], lo[3], hi[3];
 #pragma unroll
@@ -949,14 +951,17 @@ template <bool PEER>
 static void launch_step1_box(const ipx_cg_args *a, const ipx_boxschur_args *b, int it,
                              const double *p1, int np1, int nblk, const OwnRanges &own,
                              typename peer_arg<PEER>::type pj, hipStream_t st) {
-  const ipx_group_tab T{b->gcol, b->grp, b->grp2};
-#define IPX_S1BOX(U)                                                                            \
-  hipLaunchKernelGGL((k_cg_step1_box<PEER, U>), dim3(ipx_xcd_grid(nblk)), dim3(IPX_BLOCK), 0,  \
+  const ipx_group_tab T = ipx_boxschur_tab(b);
+#define IPX_S1BOX(M)                                                                            \
+  hipLaunchKernelGGL((k_cg_step1_box<PEER, M>), dim3(ipx_xcd_grid(nblk)), dim3(IPX_BLOCK), 0,  \
                      st, a->state, it & 1, p1, np1, a->x, a->p, a->r, a->Hp, a->lb, a->ub,     \
                      a->part2, nblk, (int)b->ng, (int)b->ngen, T, b->gen_cols, (int)b->ny,     \
                      b->up, own, pj)
-  if (b->grp2) IPX_S1BOX(true);
-  else IPX_S1BOX(false);
+  switch (ipx_group_mode(T)) {
+    case IPX_GROUPS_AFFINE: IPX_S1BOX(IPX_GROUPS_AFFINE); break;
+    case IPX_GROUPS_UNIT: IPX_S1BOX(IPX_GROUPS_UNIT); break;
+    default: IPX_S1BOX(IPX_GROUPS_FULL);
+  }
 #undef IPX_S1BOX
 }
 }  // namespace

@@ -99,7 +99,8 @@ class BoxSchurArgs(ctypes.Structure):
                 ("ARt_ntiles", _I64), ("inner", _P)] + \
                [(k, _P) for k in ("t", "u", "wR", "rhs", "vR", "y")] + \
                [("gcol", _P), ("grp", _P), ("gen_cols", _P), ("ngen", _I64), ("ny", _I64),
-                ("up", _P), ("grp2", _P), ("yell_col", _P), ("yell_val", _P)]
+                ("up", _P), ("grp2", _P), ("yell_col", _P), ("yell_val", _P)] + \
+               [(k, _I64) for k in ("gaffine", "gc0", "gdp", "gdq", "gen0")]
 
 
 class BoxSchurNormalSolver:
@@ -126,11 +127,21 @@ class BoxSchurNormalSolver:
                             axis=1).astype(np.int32)        # (-2: single-row group)
             in_group = np.zeros(an.n, dtype=bool)
             in_group[gcol[gcol >= 0]] = True
+            # every variable bounded on both sides: the tables are arithmetic progressions
+            gen = np.flatnonzero(~in_group)
+            affine = None
+            if len(gcol) and (gcol >= 0).all() and \
+                    (gcol[:, 0] == gcol[0, 0] + np.arange(len(gcol))).all() and \
+                    (gcol[:, 1] - gcol[:, 0] == gcol[0, 1] - gcol[0, 0]).all() and \
+                    (gcol[:, 2] - gcol[:, 0] == gcol[0, 2] - gcol[0, 0]).all() and \
+                    (len(gen) == 0 or (gen == gen[0] + np.arange(len(gen))).all()):
+                affine = (int(gcol[0, 0]), int(gcol[0, 1] - gcol[0, 0]),
+                          int(gcol[0, 2] - gcol[0, 0]), int(gen[0]) if len(gen) else 0)
             cache = pat._ipx_box_device = {
                 "rowp": _i32(an.rowp), "rowq": _i32(an.rowq), "col": _i32(an.col),
                 "pos_a": _i32(an.pos_a), "pos_s": _i32(an.pos_s),
                 "general": _i32(an.general),
-                "gcol": _i32(gcol.ravel()), "gen_cols": _i32(np.flatnonzero(~in_group)),
+                "gcol": _i32(gcol.ravel()), "gen_cols": _i32(gen), "affine": affine,
                 "sel": sel}
         self.c = cache
         self.ng = len(an.col)
@@ -195,6 +206,9 @@ class BoxSchurNormalSolver:
             self._up = torch.zeros(self.n, dtype=_F64, device=dev)
             a.up = self._up.data_ptr()
             a.grp2 = self.grp2.data_ptr() if self.grp2 is not None else None
+            if self.grp2 is not None and c["affine"] and not os.environ.get("IPX_NO_AFFINE_GROUPS"):
+                a.gaffine = 1
+                a.gc0, a.gdp, a.gdq, a.gen0 = c["affine"]
             self._yell = self._item_columns(ARt)
             if self._yell is not None:
                 a.yell_col, a.yell_val = c["yell"][2].data_ptr(), self._yell.data_ptr()
