@@ -206,7 +206,15 @@ k_pairs_pre(int ng, int ngen, ipx_group_tab T, const int32_t *__restrict__ gen_c
   if (c < ny) u[c] = rc - ut;
 }
 
-constexpr int POST_ITEMS = 4;      // items per thread: 1024 per workgroup = one partial
+constexpr int POST_ITEMS = 4;      // items per thread, or a few more (ipx_balanced_rounds):
+                                   // 1024+ per workgroup = one partial
+#ifndef IPX_POST_BATCH
+#define IPX_POST_BATCH 1
+#endif
+constexpr int POST_BATCH = IPX_POST_BATCH;   // items in flight together (computed columns)
+static int post_rounds(const ipx_boxschur_args *a) {
+  return POST_ITEMS;
+}
 
 // MODE: the form of the group tables (ipx_group_tab).  YELL: the columns of A_R per item in
 // ELL(2) form (yrp = the column planes, yval = the value planes; ycol unused) -- same sums
@@ -218,7 +226,7 @@ k_pairs_post(int ng, int ngen, ipx_group_tab T, const int32_t *__restrict__ gen_
              const int32_t *__restrict__ ycol, const double *__restrict__ yval,
              const double *__restrict__ vR, int ny, double *gout,
              double *__restrict__ part, int npart, const double *__restrict__ guard,
-             ipx_own_ranges own) {
+             ipx_own_ranges own, int rounds) {
   __shared__ double lds[IPX_BLOCK / IPX_WAVE];
   if (guard && *guard != 0.0) return;
   const int nitems = ng + ngen;
@@ -238,24 +246,9 @@ k_pairs_post(int ng, int ngen, ipx_group_tab T, const int32_t *__restrict__ gen_
     return 1.0 * sum;
   };
   double acc = 0.0;
-#pragma unroll 2
-  for (int k = 0; k < POST_ITEMS; ++k) {
-    const int i = (blockIdx.x * POST_ITEMS + k) * IPX_BLOCK + threadIdx.x;
-    if (i >= nitems) continue;
-    // all independent loads first: tables, r on the item's columns, the row pointers of y
-    const bool grp = i < ng;
-    int c, cp = -1, cq = -1;
-    double ap = 0.0, sp = 0.0, aq = 0.0, sq = 0.0;
-    if (grp) {
-      ipx_group_cols<MODE>(T, i, c, cp, cq);
-      ipx_group_coeffs<MODE != IPX_GROUPS_FULL>(T, i, ap, sp, aq, sq);
-    } else {
-      c = MODE == IPX_GROUPS_AFFINE ? T.gen0 + (i - ng) : gen_cols[i - ng];
-    }
-    const double rc = r[c];
-    const double rp = cp >= 0 ? r[cp] : 0.0;
-    const double rq = cq >= 0 ? r[cq] : 0.0;
-    const double yj = ycolumn(c, i);
+  // one item from its loaded operands (cp / cq < 0: no such column)
+  auto item = [&](bool grp, int c, int cp, int cq, double ap, double sp, double aq, double sq,
+                  double rc, double rp, double rq, double yj) {
     if (grp) {
       const bool has_q = cq != -2;
       double i11, i12, i22, wgt;
@@ -298,6 +291,72 @@ k_pairs_post(int ng, int ngen, ipx_group_tab T, const int32_t *__restrict__ gen_
       gc += 1.0 * rc;
       gout[c] = gc;
       if (own.has(c)) acc += gc * gc;
+    }
+  };
+  if constexpr (MODE == IPX_GROUPS_AFFINE && YELL && POST_BATCH > 0) {
+    // computed columns and item-indexed y: the operands of POST_BATCH items are requested
+    // together (clamped indices, no branches), then their v_R gathers, then the arithmetic --
+    // g may alias r, so the compiler cannot move an item's loads above its predecessor's stores
+    for (int k0 = 0; k0 < rounds; k0 += (POST_BATCH > 0 ? POST_BATCH : 1)) {
+      constexpr int NB = POST_BATCH > 0 ? POST_BATCH : 1;
+      int c[NB], y0[NB], y1[NB];
+      bool grp[NB], valid[NB];
+      double ep[NB], eq[NB], w0[NB], w1[NB];
+      double rc[NB], rp[NB], rq[NB], u0[NB], u1[NB];
+#pragma unroll
+      for (int k = 0; k < NB; ++k) {
+        const int i = (blockIdx.x * rounds + k0 + k) * IPX_BLOCK + threadIdx.x;
+        const bool on = k0 + k < rounds;                      // (uniform)
+        valid[k] = on && i < nitems;
+        const int ic = min(i, nitems - 1);
+        grp[k] = ic < ng;
+        const int gi = min(ic, ng - 1);
+        c[k] = grp[k] ? T.c0 + ic : T.gen0 + (ic - ng);
+        if (on) {
+          y0[k] = yrp[ic]; y1[k] = yrp[nitems + ic];
+          w0[k] = yval[ic]; w1[k] = yval[nitems + ic];
+          ep[k] = T.grp2[2 * gi]; eq[k] = T.grp2[2 * gi + 1];
+          rc[k] = r[c[k]];
+          rp[k] = r[grp[k] ? c[k] + T.dp : c[k]];
+          rq[k] = r[grp[k] ? c[k] + T.dq : c[k]];
+        } else {
+          y0[k] = y1[k] = 0;
+          w0[k] = w1[k] = ep[k] = eq[k] = rc[k] = rp[k] = rq[k] = 0.0;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < NB; ++k) { u0[k] = vR[y0[k]]; u1[k] = vR[y1[k]]; }
+#pragma unroll
+      for (int k = 0; k < NB; ++k) {
+        if (!valid[k]) continue;
+        double sum = 0.0;
+        sum += w0[k] * u0[k];
+        sum += w1[k] * u1[k];
+        item(grp[k], c[k], grp[k] ? c[k] + T.dp : -1, grp[k] ? c[k] + T.dq : -1,
+             copysign(1.0, ep[k]), fabs(ep[k]), copysign(1.0, eq[k]), fabs(eq[k]), rc[k], rp[k],
+             rq[k], 1.0 * sum);
+      }
+    }
+  } else {
+#pragma unroll 2
+    for (int k = 0; k < rounds; ++k) {
+      const int i = (blockIdx.x * rounds + k) * IPX_BLOCK + threadIdx.x;
+      if (i >= nitems) continue;
+      // all independent loads first: tables, r on the item's columns, the row pointers of y
+      const bool grp = i < ng;
+      int c, cp = -1, cq = -1;
+      double ap = 0.0, sp = 0.0, aq = 0.0, sq = 0.0;
+      if (grp) {
+        ipx_group_cols<MODE>(T, i, c, cp, cq);
+        ipx_group_coeffs<MODE != IPX_GROUPS_FULL>(T, i, ap, sp, aq, sq);
+      } else {
+        c = MODE == IPX_GROUPS_AFFINE ? T.gen0 + (i - ng) : gen_cols[i - ng];
+      }
+      const double rc = r[c];
+      const double rp = cp >= 0 ? r[cp] : 0.0;
+      const double rq = cq >= 0 ? r[cq] : 0.0;
+      const double yj = ycolumn(c, i);
+      item(grp, c, cp, cq, ap, sp, aq, sq, rc, rp, rq, yj);
     }
   }
   const double tot = ipx_block_reduce<IPX_SUM>(acc, lds);
@@ -354,7 +413,7 @@ int ipx_boxschur_project_from(const ipx_boxschur_args *a, const double *r, doubl
 #define IPX_POST(M, Y)                                                                          \
     hipLaunchKernelGGL((k_pairs_post<M, Y>), dim3(nblk), dim3(IPX_BLOCK), 0, st, ng,            \
                        (int)a->ngen, T, a->gen_cols, r, yrp, a->ARt_colidx, yval, a->vR,        \
-                       (int)a->ny, g, part_g, nblk, guard, own ? *own : all)
+                       (int)a->ny, g, part_g, nblk, guard, own ? *own : all, post_rounds(a))
     switch (ipx_group_mode(T) * 2 + (yell ? 1 : 0)) {
       case 5: IPX_POST(IPX_GROUPS_AFFINE, true); break;
       case 4: IPX_POST(IPX_GROUPS_AFFINE, false); break;
@@ -457,8 +516,8 @@ int ipx_boxschur_solve(const ipx_boxschur_args *a, const double *w, double *v, d
 // Number of ||g||^2 partials ipx_boxschur_project writes (per half of its partial array).
 int ipx_boxschur_project_count(const ipx_boxschur_args *a) {
   if (!a) return 0;
-  const int64_t items = a->ng + a->ngen;
-  return (int)((items + IPX_BLOCK * POST_ITEMS - 1) / (IPX_BLOCK * POST_ITEMS));
+  const int64_t items = a->ng + a->ngen, per = (int64_t)IPX_BLOCK * post_rounds(a);
+  return (int)((items + per - 1) / per);
 }
 
 // g = r - A'(A A')^-1 A r in one call (g may alias r): the CG loop's projection step.

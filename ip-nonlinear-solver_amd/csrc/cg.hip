@@ -144,8 +144,13 @@ k_cg_step1(int64_t n, double *st, int parity, const double *__restrict__ p1, int
 // (shared column + the rows' private columns; then the columns of no group), so that the
 // first stage of the projection -- w_S from r_next, t = B^-1 w_S, up = r_next - alpha't
 // (csrc/boxschur.hip k_pairs_pre) -- happens on the values just formed instead of in a
-// launch of its own that reads r again.  SB_ITEMS items per thread: one partial per 2048.
+// launch of its own that reads r again.  `rounds` items per thread, SB_ITEMS or a few more
+// (ipx_balanced_rounds: one partial per 2048+ items).
 constexpr int SB_ITEMS = 8;
+#ifndef IPX_SB_BATCH
+#define IPX_SB_BATCH 1
+#endif
+constexpr int SB_BATCH = IPX_SB_BATCH;     // items whose loads are in flight together (computed columns)
 
 // MODE: the form of the group tables (ipx_group_tab: full, compact coefficients, compact
 // coefficients + computed columns; the same numbers bit for bit).
@@ -159,7 +164,8 @@ k_cg_step1_box(double *st, int parity, const double *__restrict__ p1, int np1,
                const double *__restrict__ Hp, const double *__restrict__ lb,
                const double *__restrict__ ub, double *__restrict__ p2, int nblk, int ng, int ngen,
                ipx_group_tab T, const int32_t *__restrict__ gen_cols, int ny,
-               double *__restrict__ up, OwnRanges own, typename peer_arg<PEER>::type pj) {
+               double *__restrict__ up, OwnRanges own, int rounds,
+               typename peer_arg<PEER>::type pj) {
   __shared__ double lds[IPX_BLOCK / IPX_WAVE];
   __shared__ double plds[PEER ? IPX_MAX_PEERS + 1 : 1];
   const int blk = ipx_xcd_item(blockIdx.x, nblk);
@@ -197,30 +203,11 @@ k_cg_step1_box(double *st, int parity, const double *__restrict__ p1, int np1,
   if (lead) { st[ST_NITER] += 1.0; st[ST_PTHP] = ptHp; st[ST_ALPHA] = alpha; }
   double sx = 0.0, viol = 0.0;
   const int nitems = ng + ngen;
-#pragma unroll 2
-  for (int k = 0; k < SB_ITEMS; ++k) {
-    const int i = (blk * SB_ITEMS + k) * IPX_BLOCK + threadIdx.x;
-    if (i >= nitems) continue;
-    // every load of the item is requested before the first use: the tables, then the (up
-    // to three) elements' x, p, r, Hp and bounds
-    const bool grp = i < ng;
-    int e[3];
-    double ap = 0.0, sp = 0.0, aq = 0.0, sq = 0.0;
-    if (grp) {
-      ipx_group_cols<MODE>(T, i, e[0], e[1], e[2]);
-      ipx_group_coeffs<MODE != IPX_GROUPS_FULL>(T, i, ap, sp, aq, sq);
-    } else {
-      e[0] = MODE == IPX_GROUPS_AFFINE ? T.gen0 + (i - ng) : gen_cols[i - ng];
-      e[1] = -1; e[2] = -1;
-    }
-    double xv[3], pv[3], rv[3], hv[3], lo[3], hi[3];
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-      const int j = e[t] >= 0 ? e[t] : e[0];
-      xv[t] = x[j]; pv[t] = p[j]; rv[t] = r[j]; hv[t] = Hp[j];
-      lo[t] = lb ? lb[j] : -HUGE_VAL;
-      hi[t] = ub ? ub[j] : HUGE_VAL;
-    }
+  // one item: the updates of its (up to three) elements and the first stage of the projection
+  // (e[t] < 0: no such element); the same expressions whichever way the operands were loaded
+  auto item = [&](const int (&e)[3], bool grp, double ap, double sp, double aq, double sq,
+                  const double (&xv)[3], const double (&pv)[3], const double (&rv)[3],
+                  const double (&hv)[3], const double (&lo)[3], const double (&hi)[3]) {
     double rn[3];
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
@@ -252,6 +239,97 @@ k_cg_step1_box(double *st, int parity, const double *__restrict__ p1, int np1,
       if (c < ny) up[c] = rc - ut;
     } else if (c < ny) {
       up[c] = rn[0];
+    }
+  };
+  if constexpr (MODE == IPX_GROUPS_AFFINE) {
+    // computed columns: nothing depends on a table, so the loads of SB_BATCH items at a time
+    // are requested before the first use (indices clamped instead of branches; ~200
+    // registers, and one workgroup is resident per CU anyway) -- with the table forms below
+    // the items go one after the other, each a table -> gather round trip
+    for (int k0 = 0; k0 < rounds; k0 += SB_BATCH) {
+      int e[SB_BATCH][3];
+      bool grp[SB_BATCH], valid[SB_BATCH];
+      double ep[SB_BATCH], eq[SB_BATCH];
+      double xv[SB_BATCH][3], pv[SB_BATCH][3], rv[SB_BATCH][3], hv[SB_BATCH][3];
+      double lo[SB_BATCH][3], hi[SB_BATCH][3];
+#pragma unroll
+      for (int k = 0; k < SB_BATCH; ++k) {
+        const int i = (blk * rounds + k0 + k) * IPX_BLOCK + threadIdx.x;
+        const bool on = k0 + k < rounds;                      // (uniform)
+        valid[k] = on && i < nitems;
+        const int ic = min(i, nitems - 1);
+        grp[k] = ic < ng;
+        const int gi = min(ic, ng - 1);
+        const int e0 = grp[k] ? T.c0 + ic : T.gen0 + (ic - ng);
+        e[k][0] = e0; e[k][1] = grp[k] ? e0 + T.dp : e0; e[k][2] = grp[k] ? e0 + T.dq : e0;
+        if (on) {
+          ep[k] = T.grp2[2 * gi]; eq[k] = T.grp2[2 * gi + 1];
+#pragma unroll
+          for (int t = 0; t < 3; ++t) {
+            const int j = e[k][t];
+            xv[k][t] = x[j]; pv[k][t] = p[j]; rv[k][t] = r[j]; hv[k][t] = Hp[j];
+          }
+        } else {
+          ep[k] = eq[k] = 0.0;
+#pragma unroll
+          for (int t = 0; t < 3; ++t) xv[k][t] = pv[k][t] = rv[k][t] = hv[k][t] = 0.0;
+        }
+      }
+      if (lb) {
+#pragma unroll
+        for (int k = 0; k < SB_BATCH; ++k)
+#pragma unroll
+          for (int t = 0; t < 3; ++t) lo[k][t] = k0 + k < rounds ? lb[e[k][t]] : 0.0;
+      } else {
+#pragma unroll
+        for (int k = 0; k < SB_BATCH; ++k)
+#pragma unroll
+          for (int t = 0; t < 3; ++t) lo[k][t] = -HUGE_VAL;
+      }
+      if (ub) {
+#pragma unroll
+        for (int k = 0; k < SB_BATCH; ++k)
+#pragma unroll
+          for (int t = 0; t < 3; ++t) hi[k][t] = k0 + k < rounds ? ub[e[k][t]] : 0.0;
+      } else {
+#pragma unroll
+        for (int k = 0; k < SB_BATCH; ++k)
+#pragma unroll
+          for (int t = 0; t < 3; ++t) hi[k][t] = HUGE_VAL;
+      }
+#pragma unroll
+      for (int k = 0; k < SB_BATCH; ++k) {
+        if (!valid[k]) continue;
+        const int el[3] = {e[k][0], grp[k] ? e[k][1] : -1, grp[k] ? e[k][2] : -1};
+        item(el, grp[k], copysign(1.0, ep[k]), fabs(ep[k]), copysign(1.0, eq[k]), fabs(eq[k]),
+             xv[k], pv[k], rv[k], hv[k], lo[k], hi[k]);
+      }
+    }
+  } else {
+#pragma unroll 2
+    for (int k = 0; k < rounds; ++k) {
+      const int i = (blk * rounds + k) * IPX_BLOCK + threadIdx.x;
+      if (i >= nitems) continue;
+      // every load of the item is requested before the first use: the tables, then the (up
+      // to three) elements' x, p, r, Hp and bounds
+      const bool grp = i < ng;
+      int e[3];
+      double ap = 0.0, sp = 0.0, aq = 0.0, sq = 0.0;
+      if (grp) {
+        ipx_group_cols<MODE>(T, i, e[0], e[1], e[2]);
+        ipx_group_coeffs<MODE != IPX_GROUPS_FULL>(T, i, ap, sp, aq, sq);
+      } else {
+        e[0] = gen_cols[i - ng]; e[1] = -1; e[2] = -1;
+      }
+      double xv[3], pv[3], rv[3], hv[3], lo[3], hi[3];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const int j = e[t] >= 0 ? e[t] : e[0];
+        xv[t] = x[j]; pv[t] = p[j]; rv[t] = r[j]; hv[t] = Hp[j];
+        lo[t] = lb ? lb[j] : -HUGE_VAL;
+        hi[t] = ub ? ub[j] : HUGE_VAL;
+      }
+      item(e, grp, ap, sp, aq, sq, xv, pv, rv, hv, lo, hi);
     }
   }
   const double a = ipx_block_reduce<IPX_SUM>(sx, lds);
@@ -947,6 +1025,9 @@ k_cg_pack_comm(RangeJob job, double *__restrict__ out, ipx_peer_view pv, uint32_
   if (!ok) st[ST_STOP] = 7.0;
 }
 
+static int step1_box_rounds(const ipx_boxschur_args *b) {
+  return ipx_balanced_rounds(b->ng + b->ngen, SB_ITEMS, 2 * SB_ITEMS);
+}
 template <bool PEER>
 static void launch_step1_box(const ipx_cg_args *a, const ipx_boxschur_args *b, int it,
                              const double *p1, int np1, int nblk, const OwnRanges &own,
@@ -956,7 +1037,7 @@ static void launch_step1_box(const ipx_cg_args *a, const ipx_boxschur_args *b, i
   hipLaunchKernelGGL((k_cg_step1_box<PEER, M>), dim3(ipx_xcd_grid(nblk)), dim3(IPX_BLOCK), 0,  \
                      st, a->state, it & 1, p1, np1, a->x, a->p, a->r, a->Hp, a->lb, a->ub,     \
                      a->part2, nblk, (int)b->ng, (int)b->ngen, T, b->gen_cols, (int)b->ny,     \
-                     b->up, own, pj)
+                     b->up, own, step1_box_rounds(b), pj)
   switch (ipx_group_mode(T)) {
     case IPX_GROUPS_AFFINE: IPX_S1BOX(IPX_GROUPS_AFFINE); break;
     case IPX_GROUPS_UNIT: IPX_S1BOX(IPX_GROUPS_UNIT); break;
@@ -1067,7 +1148,7 @@ static double *proj_g(const ipx_cg_args *a, int it) { return (it & 1) ? a->r : a
 // entries per half of part2: one per row tile of A (fused step1) or per vector chunk
 static int step1_box_blocks(const ipx_cg_args *a) {
   const ipx_boxschur_args *b = (const ipx_boxschur_args *)a->banded;
-  const int64_t per = (int64_t)IPX_BLOCK * SB_ITEMS;
+  const int64_t per = (int64_t)IPX_BLOCK * step1_box_rounds(b);
   return (int)((b->ng + b->ngen + per - 1) / per);
 }
 static int part4_count(const ipx_cg_args *a) {

@@ -40,6 +40,21 @@ static inline int ipx_grid_for(int64_t n, int per_block, int cap = IPX_VEC_GRID_
 // served from its own L2 instead of the fabric.  Launch ipx_xcd_grid(n) work-
 // groups; ipx_xcd_item returns the item or -1 for the few padding groups.
 static inline int ipx_xcd_grid(int nitems) { return 8 * ((nitems + 7) / 8); }
+// Rounds of IPX_BLOCK items per workgroup (rmin..rmax) for an item-parallel kernel whose items
+// are heavy on the CU's vector-memory path (the barrier problem's group kernels: ~20 loads per
+// item): with 272 workgroups on 256 CUs the 16 CUs that get two finish twice as late as the
+// others, so the count is chosen to minimise rounds x ceil(workgroups / CUs).
+constexpr int IPX_NUM_CUS = 256;
+static inline int ipx_balanced_rounds(int64_t items, int rmin, int rmax) {
+  int best = rmin;
+  int64_t cost = INT64_MAX;
+  for (int R = rmin; R <= rmax; ++R) {
+    const int64_t nb = (items + (int64_t)IPX_BLOCK * R - 1) / ((int64_t)IPX_BLOCK * R);
+    const int64_t c = R * ((nb + IPX_NUM_CUS - 1) / IPX_NUM_CUS);
+    if (c < cost) { cost = c; best = R; }
+  }
+  return best;
+}
 __device__ __forceinline__ int ipx_xcd_item(int block, int nitems) {
   const int per = (nitems + 7) >> 3;
   const int t = (block & 7) * per + (block >> 3);
