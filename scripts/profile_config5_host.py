@@ -1,4 +1,5 @@
-"""cProfile of a config-5 solve (host side; the device loop shows up as the blocking state reads)."""
+"""cProfile of a config-5 solve, second of two (host side; the device loop shows up as the
+blocking state reads)."""
 import cProfile, io, os, pstats, sys, time, warnings
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "ip-nonlinear-solver_amd"))
@@ -11,6 +12,8 @@ warnings.simplefilter("ignore")
 prob = CenteredBandedNLP(n, m, eps=1.0)
 dc = DeviceCallbacks(prob)
 cons = (dc.constraints(ipsolver, ("less", 0.0)), ipsolver.BoxConstraint(("interval", -0.8, 0.8)))
+ipsolver.minimize_constrained(dc.fun, dc.x0, dc.grad, dc.hess, cons)      # symbolic set-up
+torch.cuda.synchronize()
 pr = cProfile.Profile()
 t0 = time.time()
 pr.enable()
@@ -19,5 +22,5 @@ torch.cuda.synchronize()
 pr.disable()
 print("wall", time.time() - t0, "niter", res.niter, "cg", res.cg_niter)
 s = io.StringIO()
-pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(22)
-print(s.getvalue()[-4200:])
+pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(30)
+print(s.getvalue()[-6000:])
