@@ -213,7 +213,7 @@ constexpr int POST_ITEMS = 4;      // items per thread, or a few more (ipx_balan
 #endif
 constexpr int POST_BATCH = IPX_POST_BATCH;   // items in flight together (computed columns)
 static int post_rounds(const ipx_boxschur_args *a) {
-  return POST_ITEMS;
+  return POST_ITEMS;     // (5 / 6 / 9 rounds measured at config 5: 12.0 / 13.4 / 12.4 against 10.6 us)
 }
 
 // MODE: the form of the group tables (ipx_group_tab).  YELL: the columns of A_R per item in

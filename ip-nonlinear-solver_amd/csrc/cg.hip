@@ -147,6 +147,8 @@ k_cg_step1(int64_t n, double *st, int parity, const double *__restrict__ p1, int
 // launch of its own that reads r again.  `rounds` items per thread, SB_ITEMS or a few more
 // (ipx_balanced_rounds: one partial per 2048+ items).
 constexpr int SB_ITEMS = 8;
+constexpr int SB_RMIN = 5;       // fewest rounds (part2 holds n / 1024 + 2 entries per half:
+                                 // cg_fused.py; 3 rounds are as fast but triple the partials)
 #ifndef IPX_SB_BATCH
 #define IPX_SB_BATCH 1
 #endif
@@ -1026,7 +1028,7 @@ k_cg_pack_comm(RangeJob job, double *__restrict__ out, ipx_peer_view pv, uint32_
 }
 
 static int step1_box_rounds(const ipx_boxschur_args *b) {
-  return ipx_balanced_rounds(b->ng + b->ngen, SB_ITEMS, 2 * SB_ITEMS);
+  return ipx_balanced_rounds(b->ng + b->ngen, SB_RMIN, 2 * SB_ITEMS);
 }
 template <bool PEER>
 static void launch_step1_box(const ipx_cg_args *a, const ipx_boxschur_args *b, int it,

@@ -41,16 +41,20 @@ static inline int ipx_grid_for(int64_t n, int per_block, int cap = IPX_VEC_GRID_
 // groups; ipx_xcd_item returns the item or -1 for the few padding groups.
 static inline int ipx_xcd_grid(int nitems) { return 8 * ((nitems + 7) / 8); }
 // Rounds of IPX_BLOCK items per workgroup (rmin..rmax) for an item-parallel kernel whose items
-// are heavy on the CU's vector-memory path (the barrier problem's group kernels: ~20 loads per
-// item): with 272 workgroups on 256 CUs the 16 CUs that get two finish twice as late as the
-// others, so the count is chosen to minimise rounds x ceil(workgroups / CUs).
+// are heavy on the CU's vector-memory path (k_cg_step1_box: ~20 loads per item).  A CU that gets
+// one workgroup more than the others finishes that much later, and a CU with a single workgroup
+// (one wave per SIMD) cannot overlap its rounds at all -- measured at config 5 (557 k items),
+// rounds -> workgroups -> us: 3 -> 726 -> 17.6, 4 -> 544 -> 19.6, 5 -> 436 -> 18.9,
+// 6 -> 363 -> 20.6, 8 -> 272 -> 22.0, 9 -> 242 -> 21.2.  Cost model: rounds x workgroups per
+// CU (rounded up, at least 2); ties go to the smaller R (more workgroups in flight).
 constexpr int IPX_NUM_CUS = 256;
 static inline int ipx_balanced_rounds(int64_t items, int rmin, int rmax) {
   int best = rmin;
   int64_t cost = INT64_MAX;
   for (int R = rmin; R <= rmax; ++R) {
     const int64_t nb = (items + (int64_t)IPX_BLOCK * R - 1) / ((int64_t)IPX_BLOCK * R);
-    const int64_t c = R * ((nb + IPX_NUM_CUS - 1) / IPX_NUM_CUS);
+    const int64_t per_cu = (nb + IPX_NUM_CUS - 1) / IPX_NUM_CUS;
+    const int64_t c = R * (per_cu < 2 ? 2 : per_cu);
     if (c < cost) { cost = c; best = R; }
   }
   return best;

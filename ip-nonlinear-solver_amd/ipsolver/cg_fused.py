@@ -475,8 +475,8 @@ class _Loop:
         grid = lib.ipx_cg_vec_grid(n)
         self.part1 = torch.zeros(2 * (Hc.pattern.ntiles if Hc is not None else 1), dtype=f64,
                                  device=dev)
-        # (box-Schur projection: step1 writes one partial per 2048 elements, csrc/cg.hip SB_ITEMS)
-        self.part2 = torch.zeros(2 * max(grid, A.pattern.ntiles, n // 2048 + 2), dtype=f64,
+        # (box-Schur projection: step1 writes one partial per >= 1280 elements, csrc/cg.hip SB_RMIN)
+        self.part2 = torch.zeros(2 * max(grid, A.pattern.ntiles, n // 1024 + 2), dtype=f64,
                                  device=dev)
         self.part3 = torch.zeros(2 * max(At.pattern.ntiles, (m + 255) // 256 + 1, n // 1024 + 2),
                                  dtype=f64, device=dev)
