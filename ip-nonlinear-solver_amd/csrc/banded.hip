@@ -1022,10 +1022,10 @@ k_middle(LevArgs a, int nbuf_total, const double *__restrict__ slab, int nslab,
 }
 
 constexpr int DOWN_CHUNKS = 16;      // chunks (recurrence lanes) per workgroup in k_down0
-#ifndef IPX_DEC_CHUNKS
-#define IPX_DEC_CHUNKS 4
-#endif
-constexpr int DEC_CHUNKS = IPX_DEC_CHUNKS;   // own chunks per workgroup in k_solve_decoupled
+// own chunks per workgroup in k_solve_decoupled / k_solve_pcr.  Not a tunable: the fused
+// kernels' window tables and the sharded layout's row blocks (ipsolver/sharded.py ROW_BLOCK)
+// are built for 4 (a build with 2 faults in the headline loop)
+constexpr int DEC_CHUNKS = 4;
 
 IPX_STAMP_DECL(ipx_dbg_stamps);
 #define IPX_STAMP(k) IPX_STAMP_TO(ipx_dbg_stamps, k)
