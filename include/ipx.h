@@ -452,6 +452,10 @@ typedef struct ipx_boxschur_args {
    * and gen_cols[k] = gen0 + k -- every variable bounded on both sides, the usual
    * BoxConstraint; the two kernels compute the columns instead of reading gcol / gen_cols. */
   int64_t gaffine, gc0, gdp, gdq, gen0;
+  /* AR_rowlen = 2, 4, 8 or 16 when EVERY row of A_R has that many entries (entry j of row i at
+   * AR_colidx / AR_val [i * AR_rowlen + j]), else 0: ipx_boxschur_project then forms A_R u
+   * inside the Schur solve's kernel (cyclic-reduction path) instead of by an SpMV launch. */
+  int64_t AR_rowlen;
 } ipx_boxschur_args;
 /* v = (A A')^-1 w; partial (optional, ceil(mR/256) doubles) receives the residual partials. */
 int ipx_boxschur_solve(const ipx_boxschur_args *a, const double *w, double *v, double *partial,

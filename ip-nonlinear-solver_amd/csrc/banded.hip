@@ -1057,6 +1057,20 @@ struct AtvJob {
   int64_t ell_n;
 };
 
+// The right-hand side formed inside k_solve_pcr (barrier problems: w = A_R u, csrc/boxschur.hip)
+// instead of by an SpMV launch of its own.  Needs rows of ONE length 2^logL <= 16 (entry j of
+// row i at [i << logL | j]: no row pointers, so the products' loads depend on nothing); a
+// workgroup forms the rows of its whole window (own rows + 2^L either side: 1.5x the products,
+// which is what one launch, its tile-table round trip and the w round trip through HBM cost
+// less than).  Row sums left to right like every SpMV of the library: same bits as k_csr_spmv.
+struct RowsJob {
+  const int32_t *col;
+  const double *val;
+  const double *x;
+  int logL;
+};
+constexpr int ROWS_U = 32;     // products per lane: window <= 2 * IPX_BLOCK rows of <= 16 entries
+
 template <int K, int T, int QV>
 __global__ void __launch_bounds__(DOWN_T)
 k_solve_decoupled(LevDev lv, const double *__restrict__ w, double *__restrict__ x,
@@ -1394,11 +1408,11 @@ k_pcr_check(int m, int rows_wg, const double *__restrict__ band, int *flags) {
   }
 }
 
-template <int QV, int NR>
+template <int QV, int NR, bool ROWS = false>
 __global__ void __launch_bounds__(IPX_BLOCK)
 k_solve_pcr(int m, int rows_wg, int L, const double *__restrict__ band,
             const double *__restrict__ w, double *__restrict__ x, double *__restrict__ partial,
-            const double *__restrict__ guard, AtvJob atv) {
+            const double *__restrict__ guard, AtvJob atv, RowsJob rows = RowsJob{}) {
   constexpr int QA = QV > 0 ? QV : 1;
   constexpr int PAD = 1 << PCR_LMAX;                 // identity rows either side of the window
   constexpr int RS = PCR_RMAX + 2 * PAD;
@@ -1419,6 +1433,23 @@ k_solve_pcr(int m, int rows_wg, int L, const double *__restrict__ band,
   const int64_t own0 = (int64_t)blockIdx.x * rows_wg;
   const int64_t g0 = own0 - H;                      // global row of window row 0
   const int tid = threadIdx.x;
+  // ROWS: the entries of the window's rows, the head of the kernel's only dependent chain
+  // (entries -> gather of x -> LDS -> row sums), requested before everything else
+  extern __shared__ double rows_prod[];              // R rows of (2^logL + 1) doubles (padded)
+  int rcol[ROWS ? ROWS_U : 1];
+  double rval[ROWS ? ROWS_U : 1];
+  if constexpr (ROWS) {
+    const int64_t nnz = (int64_t)m << rows.logL;
+    const int64_t e0 = g0 * (1 << rows.logL);        // (negative for the first workgroup)
+    const int P = R << rows.logL;
+#pragma unroll
+    for (int u = 0; u < ROWS_U; ++u) {
+      const int e = min(tid + u * IPX_BLOCK, P - 1);
+      const int64_t idx = min(max(e0 + e, (int64_t)0), nnz - 1);
+      rcol[u] = rows.col[idx];
+      rval[u] = rows.val[idx];
+    }
+  }
   // the matrix rows (static data: requested first), then w (the predecessor's output)
   double a[NR], b[NR], d[NR];
 #pragma unroll
@@ -1429,8 +1460,34 @@ k_solve_pcr(int m, int rows_wg, int L, const double *__restrict__ band,
     const double bv = band[gc], av = band[(int64_t)m + gc];
     a[k] = (in && g >= 1 && tid + k * IPX_BLOCK >= 1) ? av : 0.0;     // (row 0 of the window: cut)
     b[k] = in ? bv : 1.0;
-    const double wv = w[gc];
-    d[k] = in ? wv : 0.0;
+    if constexpr (!ROWS) {
+      const double wv = w[gc];
+      d[k] = in ? wv : 0.0;
+    }
+  }
+  if constexpr (ROWS) {
+    const int Lr = 1 << rows.logL, P = R << rows.logL;
+    double xg[ROWS_U];
+#pragma unroll
+    for (int u = 0; u < ROWS_U; ++u) xg[u] = rows.x[rcol[u]];
+#pragma unroll
+    for (int u = 0; u < ROWS_U; ++u) {
+      const int e = tid + u * IPX_BLOCK;
+      if (e < P) rows_prod[(e >> rows.logL) * (Lr + 1) + (e & (Lr - 1))] = rval[u] * xg[u];
+    }
+    ipx_lds_barrier();
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      const int r = tid + k * IPX_BLOCK;
+      const int64_t g = g0 + r;
+      const bool in = r < R && g >= 0 && g < m;
+      double sum = 0.0;
+      if (in) {
+        const double *pr_ = rows_prod + r * (Lr + 1);
+        for (int j = 0; j < Lr; ++j) sum += pr_[j];
+      }
+      d[k] = in ? 1.0 * sum : 0.0;
+    }
   }
   // A'v tail: the two ELL entries of every variable and r, requested now so that they arrive
   // while the reduction runs.  A lane takes PAIRS of consecutive variables (16-byte loads of
@@ -1577,6 +1634,31 @@ int launch_solve_pcr_q(const LevDev &lv, int L, const double *w, double *x, doub
   else
     hipLaunchKernelGGL((k_solve_pcr<QV, PCR_NR>), dim3(grid), dim3(IPX_BLOCK), 0, st, lv.m,
                        rows_wg, L, lv.band, w, x, partial, guard, atv);
+  IPX_CHECK_LAUNCH();
+  return IPX_OK;
+}
+
+// the solve with its right-hand side formed from rows of one length (RowsJob); IPX_EUNSUPPORTED
+// when the window does not fit the kernel's fixed product count
+int launch_solve_pcr_rows(const LevDev &lv, int L, const RowsJob &rows, double *x,
+                          double *partial, int *npartial, const double *guard, hipStream_t st) {
+  const int rows_wg = DEC_CHUNKS * lv.q;
+  const int R = rows_wg + 2 * (1 << L);
+  if (R > 2 * IPX_BLOCK || ((int64_t)R << rows.logL) > (int64_t)ROWS_U * IPX_BLOCK)
+    return IPX_EUNSUPPORTED;
+  const int grid = (lv.P + DEC_CHUNKS - 1) / DEC_CHUNKS;
+  if (npartial) *npartial = grid;
+  const size_t lds = (size_t)R * ((1 << rows.logL) + 1) * sizeof(double);
+  static bool attr_set = false;
+  if (!attr_set) {
+    // (the kernel's static arrays take 41 KB of the CU's 160: the attribute is the dynamic part)
+    (void)hipFuncSetAttribute((const void *)k_solve_pcr<0, 2, true>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(LDS_LIMIT - 44 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((k_solve_pcr<0, 2, true>), dim3(grid), dim3(IPX_BLOCK), lds, st, lv.m, rows_wg,
+                     L, lv.band, nullptr, x, partial, guard, AtvJob{}, rows);
   IPX_CHECK_LAUNCH();
   return IPX_OK;
 }
@@ -2653,6 +2735,21 @@ int ipx_banded_solve_resid_launch(void *handle, const double *w, double *x, doub
   int rc = ipx_banded_solve_guarded(handle, w, x, guard, st);
   if (rc != IPX_OK) return rc;
   return ipx_banded_residual_launch(handle, w, x, partial, npartial, guard, st);
+}
+
+// ipx_banded_solve_resid_launch with w = (rows) x formed inside the solve kernel: only on the
+// cyclic-reduction path (tridiagonal, decoupled); IPX_EUNSUPPORTED otherwise -- the caller then
+// forms w by an SpMV and calls the plain entry.
+int ipx_banded_solve_rows_launch(void *handle, const int32_t *col, const double *val,
+                                 const double *xin, int logL, double *x, double *partial,
+                                 int *npartial, const double *guard, hipStream_t st) {
+  if (!handle || !col || !val || !xin || !x || !partial || logL < 0 || logL > 4) return IPX_EINVAL;
+  Banded *h = (Banded *)handle;
+  if (!(h->fast && h->nlev > 1 && h->decoupled && h->pcr_L > 0)) return IPX_EUNSUPPORTED;
+  const LevDev lv = to_dev(h->lev[0], nullptr);
+  if (lv.k != 1) return IPX_EUNSUPPORTED;
+  return launch_solve_pcr_rows(lv, h->pcr_L, RowsJob{col, val, xin, logL}, x, partial, npartial,
+                               guard, st);
 }
 
 int ipx_banded_solve_guarded(void *handle, const double *w, double *x, const double *guard,

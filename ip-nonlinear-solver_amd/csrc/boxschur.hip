@@ -391,14 +391,25 @@ int ipx_boxschur_project_from(const ipx_boxschur_args *a, const double *r, doubl
   }
   ipx_csr_view AR{(int)a->mR, (int)a->n, a->AR_rowptr, a->AR_colidx, a->AR_val, a->AR_tiles,
                   (int)a->AR_ntiles};
-  // rhs = A_R (r - alpha't)   (= w_R - A_R u of ipx_boxschur_solve, one product)
-  int rc = ipx_spmv_launch(AR, a->up, 1.0, nullptr, 0.0, nullptr, a->rhs, nullptr, guard, st);
-  if (rc) return rc;
+  // rhs = A_R (r - alpha't)   (= w_R - A_R u of ipx_boxschur_solve, one product) and the Schur
+  // solve: ONE launch when A_R's rows have one power-of-two length and the solve is the cyclic
+  // reduction (the product is formed inside it, same bits), else the SpMV and the solve
   int np = 0;
-  if (part_res)
-    rc = ipx_banded_solve_resid_launch(a->inner, a->rhs, a->vR, part_res, &np, guard, st);
-  else
-    rc = ipx_banded_solve_guarded(a->inner, a->rhs, a->vR, guard, st);
+  int rc = IPX_EUNSUPPORTED;
+  if (a->AR_rowlen > 0 && part_res) {
+    int logL = 0;
+    while ((1 << logL) < a->AR_rowlen) ++logL;
+    rc = ipx_banded_solve_rows_launch(a->inner, a->AR_colidx, a->AR_val, a->up, logL, a->vR,
+                                      part_res, &np, guard, st);
+  }
+  if (rc == IPX_EUNSUPPORTED) {
+    rc = ipx_spmv_launch(AR, a->up, 1.0, nullptr, 0.0, nullptr, a->rhs, nullptr, guard, st);
+    if (rc) return rc;
+    if (part_res)
+      rc = ipx_banded_solve_resid_launch(a->inner, a->rhs, a->vR, part_res, &np, guard, st);
+    else
+      rc = ipx_banded_solve_guarded(a->inner, a->rhs, a->vR, guard, st);
+  }
   if (rc) return rc;
   if (npart_res) *npart_res = np;
   const int nblk = ipx_boxschur_project_count(a);

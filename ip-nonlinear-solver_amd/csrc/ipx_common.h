@@ -588,6 +588,9 @@ int ipx_spmv_launch(const ipx_csr_view &A, const double *x, double alpha, const 
                     const double *guard, hipStream_t st, const double *xrow_override = nullptr);
 int ipx_banded_solve_guarded(void *handle, const double *w, double *x, const double *guard,
                              hipStream_t st);
+int ipx_banded_solve_rows_launch(void *handle, const int32_t *col, const double *val,
+                                 const double *xin, int logL, double *x, double *partial,
+                                 int *npartial, const double *guard, hipStream_t st);
 // ipx_boxschur_project with a->up (= r - alpha't) optionally prepared by the caller
 int ipx_boxschur_project_from(const ipx_boxschur_args *a, const double *r, double *g,
                               double *part_g, int32_t *npart_g, double *part_res,

@@ -100,7 +100,7 @@ class BoxSchurArgs(ctypes.Structure):
                [(k, _P) for k in ("t", "u", "wR", "rhs", "vR", "y")] + \
                [("gcol", _P), ("grp", _P), ("gen_cols", _P), ("ngen", _I64), ("ny", _I64),
                 ("up", _P), ("grp2", _P), ("yell_col", _P), ("yell_val", _P)] + \
-               [(k, _I64) for k in ("gaffine", "gc0", "gdp", "gdq", "gen0")]
+               [(k, _I64) for k in ("gaffine", "gc0", "gdp", "gdq", "gen0", "AR_rowlen")]
 
 
 class BoxSchurNormalSolver:
@@ -209,6 +209,10 @@ class BoxSchurNormalSolver:
             if self.grp2 is not None and c["affine"] and not os.environ.get("IPX_NO_AFFINE_GROUPS"):
                 a.gaffine = 1
                 a.gc0, a.gdp, a.gdq, a.gen0 = c["affine"]
+            lens = np.diff(self.A_R.pattern.indptr_h)
+            if len(lens) and lens[0] in (2, 4, 8, 16) and (lens == lens[0]).all() \
+                    and not os.environ.get("IPX_NO_COMPACT_GROUPS"):
+                a.AR_rowlen = int(lens[0])     # A_R u formed inside the Schur solve's kernel
             self._yell = self._item_columns(ARt)
             if self._yell is not None:
                 a.yell_col, a.yell_val = c["yell"][2].data_ptr(), self._yell.data_ptr()

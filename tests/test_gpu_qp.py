@@ -775,7 +775,7 @@ def test_unbounded_trust_region_skips_the_norm(ips, monkeypatch):
     assert abs(np.linalg.norm(host(x)) - radius) <= 1e-12 * radius
 
 
-@pytest.mark.parametrize("bounds", ["all", "ragged", "scaled"])
+@pytest.mark.parametrize("bounds", ["all", "ragged", "scaled", "all-large"])
 def test_box_schur_projection_without_matrix_rows(ips, bounds, monkeypatch):
     """The CG loop's projection for barrier problems (csrc/boxschur.hip ipx_boxschur_project,
     csrc/cg.hip k_cg_step1_box): g = r - A'(A A')^-1 A r with the box rows handled per group
@@ -785,14 +785,17 @@ def test_box_schur_projection_without_matrix_rows(ips, bounds, monkeypatch):
     none: single-row groups and x-columns outside every group), and with bound rows whose
     entries are not +-1 ("scaled": the compact group table must be refused); the compact
     tables (ipx_boxschur_args.grp2, yell_*) against the full ones, bit for bit; then a whole
-    projected-CG run with slack bounds through the device loop against the oracle."""
+    projected-CG run with slack bounds through the device loop against the oracle.
+    "all-large": enough general rows for the cyclic-reduction solve, which then forms the Schur
+    right-hand side A_R u itself (one launch less; the SpMV's scratch stays untouched)."""
     import ctypes
     import torch
     import oracle
     import ipsolver.cg_fused as cg_fused
     from ipsolver import _hip
     from ipsolver.boxschur import BoxSchurNormalSolver
-    n, m = 6000, 600
+    n, m = (30000, 3000) if bounds == "all-large" else (6000, 600)
+    large, bounds = bounds == "all-large", bounds.split("-")[0]
     rng = np.random.default_rng(7)
     inst = BandedInstance(n, m)
     J = inst.A
@@ -827,16 +830,21 @@ def test_box_schur_projection_without_matrix_rows(ips, bounds, monkeypatch):
     pg = torch.zeros(2 * nblk, dtype=torch.float64, device="cuda")
     pres = torch.zeros(M // 256 + 2, dtype=torch.float64, device="cuda")
     n3, n4 = ctypes.c_int32(0), ctypes.c_int32(0)
+    assert args.AR_rowlen == 16                   # 15 entries of the band + the row's slack
+    solver._scratch[1].fill_(float("nan"))        # the scratch an SpMV A_R u would write
     _hip.call("ipx_boxschur_project", ctypes.byref(args), ips.dv._p(rd.t), ips.dv._p(g),
               ips.dv._p(pg), ctypes.byref(n3), ips.dv._p(pres), ctypes.byref(n4), None,
               ips.dv.stream_ptr())
     got = g.cpu().numpy()
+    if large:      # the right-hand side was formed inside the solve kernel
+        assert bool(torch.isnan(solver._scratch[1]).all())
     # the SpMV form with the same solver
     v = solver.solve(Ad.dot(rd))
     ref_dev = host(Ad.rmatvec_sub(v, rd))
     err = np.max(np.abs(got - ref_dev)) / np.max(np.abs(r))
     # (entries 2 and 3 next to slacks of 1e-6: B^-1 is ~10x larger, 3.4e-12 measured)
-    assert err <= (1e-11 if bounds == "scaled" else 1e-13), err
+    # (and 4e-13 at five times the size: slacks of 1e-6 on 30000 variables)
+    assert err <= (1e-11 if bounds == "scaled" else 1e-12 if large else 1e-13), err
     # a direct sparse solve
     lu = sps.linalg.splu(sps.csc_matrix(A @ A.T))
     want = r - A.T @ lu.solve(A @ r)
