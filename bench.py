@@ -406,10 +406,12 @@ def config5_leg(run_twice=True):
             "constr_violation": float(res.constr_violation),
             "projected_cg_calls": timer["calls"], "seconds_in_projected_cg": timer["t"],
             "cg_iterations_per_s_in_solve": res.cg_niter / timer["t"] if timer["t"] else None,
-            "launches_per_cg_iteration": 5,
-            "launches_note": "k_cg_step1_box, SpMV A_R u, k_solve_pcr, k_pairs_post, "
-                             "k_cg_step2_hp by construction (csrc/cg.hip cg_iterate, box_project "
-                             "branch); rocprofv3 launch counts: profiles/r03_config5_kernel_stats.csv",
+            "launches_per_cg_iteration": 4,
+            "launches_note": "k_cg_step1_box, k_solve_pcr (which forms A_R u itself: the rows of "
+                             "A_R have one power-of-two length), k_pairs_post, k_cg_step2_hp by "
+                             "construction (csrc/cg.hip cg_iterate, box_project branch; 5 with a "
+                             "separate SpMV for other row shapes); rocprofv3 launch counts: "
+                             "profiles/r03_config5_kernel_stats.csv",
             "active_bounds": int((x.abs() > 0.8 - 1e-6).sum().item())}
 
 
