@@ -180,6 +180,7 @@ k_cg_step1_box(double *st, int parity, const double *__restrict__ p1, int np1,
   ipx_fold_regs<1> fold;
   fold.load(fparts, fcounts);
   if (!PEER && stop != 0.0) return;
+  if (PEER && stop == 7.0) return;                   // (a mailbox wait timed out: k_cg_step2_hp)
   const bool lead = blk == 0 && threadIdx.x == 0;
   double fout[1];
   fold.finish(fparts, fcounts, lds, fout);
@@ -525,8 +526,12 @@ k_cg_step2_hp(int n, double *st, int parity, int mode, const double *__restrict_
   }
   // (PEER: the collectives below run even when the loop has stopped -- like the pack kernels
   // they replace -- so that every rank's stores find their readers whatever a workgroup that
-  // starts late reads in the stop word: the lead workgroup of THIS launch may have set it)
+  // starts late reads in the stop word: the lead workgroup of THIS launch may have set it).
+  // Except after a mailbox wait has timed out (code 7: a peer is gone or cannot run -- two ranks
+  // sharing one GPU that is full of the other's spinning workgroups): every later launch of
+  // the batch would wait out the 3 s again; the batch is void, the host gives up the transport
   if (!PEER && stop != 0.0) return;
+  if (PEER && stop == 7.0) return;
   CG_STAMP(1);
   const bool lead = tile == 0 && tid == 0;
   double red[4], loc[4];
@@ -788,6 +793,7 @@ k_cg_step1_ar(int n, double *st, int parity, const double *__restrict__ p1, int 
     spv[k] = NOXN2 ? 0.0 : p[col];
   }
   if (!PEER && stop != 0.0) return;                  // (PEER: see k_cg_step2_hp)
+  if (PEER && stop == 7.0) return;
   CG_STAMP(9);
   const bool lead = tile == 0 && tid == 0;
   double fout[1];
@@ -954,6 +960,7 @@ k_cg_pack_comm(RangeJob job, double *__restrict__ out, ipx_peer_view pv, uint32_
   __shared__ double lds[4 * 4];
   __shared__ double vals[IPX_MAX_PEERS * 4];
   const int tid = threadIdx.x;
+  if (st[ST_STOP] == 7.0) return;        // an earlier wait timed out: do not wait it out again
   const long long deadline = (long long)wall_clock64() + IPX_PEER_TIMEOUT_TICKS;
   if (blockIdx.x == 0) {
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
