@@ -263,3 +263,71 @@ def test_constant_jacobian_is_flagged():
     mixed = to_canonical([lin, nl])
     assert not mixed.constant_jac
     assert not to_canonical(nl).constant_jac
+
+
+def _pattern(A):
+    class P:
+        pass
+    p = P()
+    A = sps.csr_matrix(A)
+    A.sort_indices()
+    p.shape, p.indptr_h, p.indices_h, p.nnz = A.shape, A.indptr, A.indices, A.nnz
+    return p
+
+
+def test_half_bandwidth_of_aat_from_the_columns():
+    """projector.half_bandwidth_of_aat reads the half bandwidth of A A' off A's columns (widest
+    last row - first row) instead of forming the product pattern (reference: projections.py
+    factors A A' / the augmented system whatever its band).  Against the product, on random
+    patterns incl. empty rows and columns, and on the barrier problem's augmented Jacobian."""
+    from ipsolver.projector import half_bandwidth_of_aat
+    rng = np.random.default_rng(3)
+    mats = [sps.random(int(rng.integers(1, 50)), int(rng.integers(1, 70)),
+                       density=float(rng.uniform(0.01, 0.3)), format="csr", random_state=k)
+            for k in range(30)]
+    n, m = 300, 30
+    J = sps.csr_matrix((np.ones(15 * m), (np.repeat(np.arange(m), 15),
+                                           np.minimum((9 * np.arange(m))[:, None].repeat(15, 1).ravel()
+                                                      + np.tile(np.arange(15), m), n - 1))),
+                       shape=(m, n))
+    I = sps.eye(n, format="csr")
+    mats.append(sps.bmat([[J, sps.eye(m), None, None], [-I, None, sps.eye(n), None],
+                          [I, None, None, sps.eye(n)]], format="csr"))
+    mats.append(sps.csr_matrix((4, 5)))
+    for A in mats:
+        B = sps.csr_matrix((np.ones(A.nnz), A.indices, A.indptr), shape=A.shape)
+        S = (B @ B.T).tocoo()
+        want = int(np.max(np.abs(S.row - S.col))) if S.nnz else 0
+        assert half_bandwidth_of_aat(_pattern(A)) == want
+
+
+def test_box_row_analysis_groups():
+    """boxschur.BoxRowAnalysis on the barrier problem's augmented Jacobian [J S; -I S_l; I S_u]:
+    every bound row is simple, grouped by its variable (lower row before upper), the general
+    rows are J's; ragged bounds give single-row groups; a column shared by three simple rows is
+    left to the general rows."""
+    from ipsolver.boxschur import BoxRowAnalysis
+    n, m = 40, 4
+    rng = np.random.default_rng(0)
+    J = sps.random(m, n, density=0.4, format="csr", random_state=1)
+    J.data[:] = 1.0
+    I = sps.eye(n, format="csr")
+    L, U = np.arange(n), np.arange(0, n, 2)
+    A = sps.bmat([[J, sps.eye(m), None, None], [-I[L], None, sps.eye(len(L)), None],
+                  [I[U], None, None, sps.eye(len(U))]], format="csr")
+    an = BoxRowAnalysis(_pattern(A))
+    touched = np.unique(J.indices)                    # columns shared with a row of J
+    # a variable with ONE bound row that no row of J touches: its column is private to that
+    # row, which then has no shared entry -- a general row
+    lone = [j for j in range(n) if j % 2 == 1 and j not in touched]
+    assert list(an.general) == list(range(m)) + [m + j for j in lone]
+    assert an.n_simple == len(L) + len(U) - len(lone)
+    cols = {int(c): (int(p), int(q)) for c, p, q in zip(an.col, an.rowp, an.rowq)}
+    assert sorted(cols) == [j for j in range(n) if j not in lone]
+    for j, (p, q) in cols.items():
+        assert p == m + j                             # the lower-bound row comes first
+        assert q == (m + len(L) + j // 2 if j % 2 == 0 else -1)
+    # three simple rows on one column: not a group
+    A3 = sps.vstack([A, sps.csr_matrix(([2.0], ([0], [0])), shape=(1, A.shape[1]))], format="csr")
+    an3 = BoxRowAnalysis(_pattern(A3))
+    assert 0 not in set(an3.col.tolist()) and {m, m + len(L), A3.shape[0] - 1} <= set(an3.general.tolist())
