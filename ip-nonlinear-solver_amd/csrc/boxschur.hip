@@ -208,10 +208,8 @@ k_pairs_pre(int ng, int ngen, ipx_group_tab T, const int32_t *__restrict__ gen_c
 
 constexpr int POST_ITEMS = 4;      // items per thread, or a few more (ipx_balanced_rounds):
                                    // 1024+ per workgroup = one partial
-#ifndef IPX_POST_BATCH
-#define IPX_POST_BATCH 1
-#endif
-constexpr int POST_BATCH = IPX_POST_BATCH;   // items in flight together (computed columns)
+constexpr int POST_BATCH = 1;      // items in flight together, computed columns (2 / 4 measured
+                                   // at config 5: 11.3 / 12.0 against 10.7 us)
 static int post_rounds(const ipx_boxschur_args *a) {
   return POST_ITEMS;     // (5 / 6 / 9 rounds measured at config 5: 12.0 / 13.4 / 12.4 against 10.6 us)
 }
@@ -293,12 +291,12 @@ k_pairs_post(int ng, int ngen, ipx_group_tab T, const int32_t *__restrict__ gen_
       if (own.has(c)) acc += gc * gc;
     }
   };
-  if constexpr (MODE == IPX_GROUPS_AFFINE && YELL && POST_BATCH > 0) {
+  if constexpr (MODE == IPX_GROUPS_AFFINE && YELL) {
     // computed columns and item-indexed y: the operands of POST_BATCH items are requested
     // together (clamped indices, no branches), then their v_R gathers, then the arithmetic --
     // g may alias r, so the compiler cannot move an item's loads above its predecessor's stores
-    for (int k0 = 0; k0 < rounds; k0 += (POST_BATCH > 0 ? POST_BATCH : 1)) {
-      constexpr int NB = POST_BATCH > 0 ? POST_BATCH : 1;
+    for (int k0 = 0; k0 < rounds; k0 += POST_BATCH) {
+      constexpr int NB = POST_BATCH;
       int c[NB], y0[NB], y1[NB];
       bool grp[NB], valid[NB];
       double ep[NB], eq[NB], w0[NB], w1[NB];

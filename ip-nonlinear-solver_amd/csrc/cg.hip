@@ -149,10 +149,10 @@ k_cg_step1(int64_t n, double *st, int parity, const double *__restrict__ p1, int
 constexpr int SB_ITEMS = 8;
 constexpr int SB_RMIN = 5;       // fewest rounds (part2 holds n / 1024 + 2 entries per half:
                                  // cg_fused.py; 3 rounds are as fast but triple the partials)
-#ifndef IPX_SB_BATCH
-#define IPX_SB_BATCH 1
-#endif
-constexpr int SB_BATCH = IPX_SB_BATCH;     // items whose loads are in flight together (computed columns)
+// items whose loads are in flight together in the computed-columns form (measured at config 5
+// with 8 rounds: 1 -> 22.0, 2 -> 22.3, 4 -> 23.9, 8 -> 36 us: the kernel wants workgroups per CU,
+// not loads per lane -- DESIGN.md section 6)
+constexpr int SB_BATCH = 1;
 
 // MODE: the form of the group tables (ipx_group_tab: full, compact coefficients, compact
 // coefficients + computed columns; the same numbers bit for bit).
@@ -245,10 +245,9 @@ k_cg_step1_box(double *st, int parity, const double *__restrict__ p1, int np1,
     }
   };
   if constexpr (MODE == IPX_GROUPS_AFFINE) {
-    // computed columns: nothing depends on a table, so the loads of SB_BATCH items at a time
-    // are requested before the first use (indices clamped instead of branches; ~200
-    // registers, and one workgroup is resident per CU anyway) -- with the table forms below
-    // the items go one after the other, each a table -> gather round trip
+    // computed columns: nothing depends on a table, so all the loads of an item (SB_BATCH items)
+    // are requested at once, indices clamped instead of branches -- with the table forms below
+    // every item is a table -> gather round trip
     for (int k0 = 0; k0 < rounds; k0 += SB_BATCH) {
       int e[SB_BATCH][3];
       bool grp[SB_BATCH], valid[SB_BATCH];
