@@ -13,7 +13,10 @@ HBM when the timed region starts.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--n 1000000] [--m 100000]
 
-N > 1 is launched by torch.distributed.run (one rank per GPU): the SAME
+N > 1 runs one rank per GPU: under torch.distributed.run (RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* from the environment), or -- started directly, the way
+the driver starts N = 1 -- bench.py spawns its N ranks itself as fresh child
+processes from a parent that never touches the GPU (``spawn_ranks``).  The SAME
 n=1e6 / m=1e5 problem is row-partitioned over the ranks (BASELINE config 4,
 ipsolver/sharded.py: constraint rows and variables both partitioned) with two
 small RCCL all-reduces per iteration (p'Hp; the packed norms) and a neighbour
@@ -595,6 +598,8 @@ def sharded_leg(args, world, rank, A_h, H_h, hdiag_h, c_h, n, m, K, W):
     from ipsolver import sharded
     from ipsolver.synthetic import CenteredBandedNLP
 
+    devices = [None] * world
+    dist.all_gather_object(devices, int(torch.cuda.current_device()))
     sh, (F, F_dist), primed = _sharded_setup(A_h, H_h, hdiag_h, c_h, transports=(None, "dist"))
     transport = "ipc" if F.mailbox is not None else "dist"
     before = dict(sh.comm.stats)
@@ -694,7 +699,15 @@ def sharded_leg(args, world, rank, A_h, H_h, hdiag_h, c_h, n, m, K, W):
 
     # ---- a weak-scaling point in the same run: n = world * 1e6 (per-GPU work fixed)
     weak = None
-    if not args.no_weak:
+    shared_gpu = torch.cuda.device_count() < world
+    if shared_gpu and not args.no_weak:
+        # ranks that share one GPU cannot keep n = 1e6 each resident side by side: a rank's
+        # workgroups would fill the chip and spin on words the other rank's kernels, waiting
+        # behind them, can never write (the 3 s deadline, stop code 7).  Not a measurement
+        # the rehearsal can make.
+        weak = {"rehearsal": "skipped", "reason": "%d ranks on %d GPU(s): the weak-scaling point "
+                "needs one GPU per rank" % (world, torch.cuda.device_count())}
+    elif not args.no_weak:
         try:
             nw, mw = n * world, m * world
             probw = CenteredBandedNLP(nw, mw, seed=0)
@@ -770,7 +783,12 @@ def sharded_leg(args, world, rank, A_h, H_h, hdiag_h, c_h, n, m, K, W):
                      "frac": iter_bytes / (elapsed / K) / 1e9 / (HBM_PEAK_GBS * world),
                      "traffic": None},
         "parity_vs_single_gpu": parity,
+        "backend": {"torch_distributed": dist.get_backend(), "world_size_seen": dist.get_world_size(),
+                    "devices_by_rank": devices, "visible_gpus": torch.cuda.device_count()},
         "transport": transport,
+        "transport_fallback_reason": (ipc_error if ipc_error is not None
+                                      else getattr(sh, "mailbox_error", None)
+                                      if transport != "ipc" else None),
         "transport_ab": ab,
         "host_calls_per_iteration_in_the_timed_region": {
             "torch_distributed_all_reduce": per_it["all_reduce"],
@@ -799,6 +817,111 @@ def sharded_leg(args, world, rank, A_h, H_h, hdiag_h, c_h, n, m, K, W):
     dist.destroy_process_group()
 
 
+def failure_line(n_gpus, K, W, error, **more):
+    """The contract's keys with value 0 and a readable ``error``: a failed N > 1 run must still
+    leave one JSON line behind (and a non-zero exit code)."""
+    d = {"metric": "projected-CG iters/sec (fp64) at n=1e6,m=1e5", "value": 0.0,
+         "unit": "iterations/s", "n_gpus": n_gpus, "steps": K, "warmup": W,
+         "ms_per_step": None, "higher_is_better": True, "scaling": "strong",
+         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+         "config": {"workload": "config4 sharded over %d GPUs: FAILED" % n_gpus},
+         "error": error}
+    d.update(more)
+    return d
+
+
+def spawn_ranks(n_gpus, argv, K, W):
+    """``python bench.py --gpus N`` without a launcher: start the N ranks as FRESH child
+    processes of this parent (one per GPU: RANK = LOCAL_RANK = device, WORLD_SIZE, MASTER_ADDR =
+    127.0.0.1 and a free MASTER_PORT in their environment -- what torch.distributed.run would
+    set), which itself never touches the GPU and is not replaced by anything (no exec); relay
+    rank 0's JSON line.  Any rank failing = a non-zero exit code here and one ``error`` line;
+    the other ranks get 60 s to notice (a collective that lost its peer) before they are
+    terminated by PID."""
+    import socket
+    import subprocess
+    import tempfile
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    base = dict(os.environ, IPX_BENCH_SPAWNED="1", WORLD_SIZE=str(n_gpus),
+                LOCAL_WORLD_SIZE=str(n_gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    base.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n_gpus)))
+    cmd = [sys.executable, os.path.abspath(__file__)] + list(argv)
+    procs, errs = [], []
+    for r in range(n_gpus):
+        err = tempfile.TemporaryFile(mode="w+")
+        errs.append(err)
+        procs.append(subprocess.Popen(
+            cmd, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=err, text=True,
+            env=dict(base, RANK=str(r), LOCAL_RANK=str(r)), cwd=ROOT))
+    out = ""
+    first_failure = None
+    while True:
+        codes = [p.poll() for p in procs]
+        if all(c is not None for c in codes):
+            break
+        if first_failure is None and any(c not in (None, 0) for c in codes):
+            first_failure = time.time()
+        if first_failure is not None and time.time() - first_failure > 60:
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            time.sleep(5)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+        if procs[0].poll() is None:
+            try:                                   # (drain rank 0's pipe while waiting)
+                o, _ = procs[0].communicate(timeout=1.0)
+                out += o or ""
+            except subprocess.TimeoutExpired:
+                pass
+        else:
+            time.sleep(0.5)
+    if procs[0].stdout is not None and not procs[0].stdout.closed:
+        out += procs[0].stdout.read() or ""
+    codes = [p.returncode for p in procs]
+    tails = []
+    for r, err in enumerate(errs):
+        err.seek(0)
+        t = err.read()[-1500:]
+        err.close()
+        if codes[r] != 0 and t:
+            tails.append("[rank %d, exit code %s] %s" % (r, codes[r], t))
+    err_tail = "\n".join(tails)[-4000:]
+    rc = next((c for c in codes if c != 0), 0)
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    for ln in out.splitlines():
+        if not ln.startswith("{"):
+            print(ln, file=sys.stderr)
+    if lines:
+        try:
+            d = json.loads(lines[-1])
+        except ValueError:
+            d = None
+        if d is not None:
+            d["launcher"] = ("bench.py spawned %d ranks itself (fresh child processes, RANK / "
+                             "LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment; the parent "
+                             "made no GPU call)" % n_gpus)
+            if rc != 0 and "error" not in d:
+                d["error"] = "rank exit codes %s after the line was printed" % codes
+            if rc != 0:
+                d["stderr_tail"] = err_tail
+            print(json.dumps(d))
+            sys.stdout.flush()
+            if rc != 0 or "error" in d:
+                sys.stderr.write(err_tail)
+                raise SystemExit(rc or 1)
+            return
+    print(json.dumps(failure_line(n_gpus, K, W, "the ranks exited with codes %s without a JSON "
+                                  "line" % codes, stderr_tail=err_tail)))
+    sys.stdout.flush()
+    sys.stderr.write(err_tail)
+    raise SystemExit(rc or 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -818,6 +941,11 @@ def main():
                     help="skip the out-of-Infinity-Cache measurement (n=4e6, m=4e5)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started directly (``python bench.py --gpus N``, the driver's N = 1 form): this process
+        # becomes the launcher.  It has made no GPU call and imports nothing that could.
+        return spawn_ranks(args.gpus, sys.argv[1:], args.steps, args.warmup)
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -826,8 +954,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks (WORLD_SIZE=%d)"
-                         % (args.gpus, args.gpus, world))
+        msg = ("--gpus %d but the launcher started %d ranks (WORLD_SIZE=%d)"
+               % (args.gpus, world, world))
+        if rank == 0:
+            print(json.dumps(failure_line(args.gpus, args.steps, args.warmup, msg)))
+            sys.stdout.flush()
+        raise SystemExit(msg)
     # IPX_BENCH_BACKEND=gloo lets the N > 1 leg be exercised on a one-GPU box (all ranks share
     # cuda:0, collectives staged through the host); the measured configuration is nccl = RCCL.
     backend = os.environ.get("IPX_BENCH_BACKEND", "nccl")
@@ -865,13 +997,8 @@ def main():
         except Exception as exc:         # a failure must be readable in the bench line
             import traceback
             if rank == 0:
-                print(json.dumps({
-                    "metric": "projected-CG iters/sec (fp64) at n=1e6,m=1e5", "value": 0.0,
-                    "unit": "iterations/s", "n_gpus": world, "steps": K, "warmup": W,
-                    "ms_per_step": None, "higher_is_better": True, "scaling": "strong",
-                    "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-                    "config": {"workload": "config4 sharded over %d GPUs: FAILED" % world},
-                    "error": repr(exc), "traceback": traceback.format_exc()[-1500:]}))
+                print(json.dumps(failure_line(world, K, W, repr(exc),
+                                              traceback=traceback.format_exc()[-1500:])))
                 sys.stdout.flush()
             raise
 

@@ -361,11 +361,16 @@ typedef struct ipx_shard2_ext {
   void *peer;
   int64_t seg_lo[4], seg_hi[4];  /* the segments' local extents [left halo | own | right halo] */
   int64_t send_left[4], send_right[4];   /* own entries the left / right neighbour keeps as halo */
-  /* != 0 (with peer, one segment, the fused 16-bit-index kernels, no box): ipx_cg_shard2_iterate
-   * does the two all-reduces and the halo exchange in the PROLOGUES of the kernels that consume
-   * them -- 3 launches per iteration instead of 5; the reduced sums are also left in pack. */
+  /* != 0: ipx_cg_shard2_iterate does the two all-reduces and the halo exchange in the PROLOGUES
+   * of the kernels that consume them -- 3 launches per iteration instead of 5; the reduced
+   * sums are also left in pack.  The GROUP's decision: set it only when ipx_cg_shard2_fusable
+   * returned 1 on EVERY rank (the two forms order an iteration's collectives differently);
+   * a rank whose own argument block does not allow it gets IPX_EINVAL. */
   int64_t fuse_comm;
 } ipx_shard2_ext;
+/* 1 when this rank's argument block allows fuse_comm (peer set, the fused 16-bit-index kernels
+ * and g = r - A'v as the solve's tail for x-space problems, or the box-Schur projection). */
+int ipx_cg_shard2_fusable(const ipx_cg_args *a, const ipx_shard2_ext *e);
 int ipx_cg_shard2_segment(const ipx_cg_args *a, const ipx_shard2_ext *e, int32_t phase,
                           int32_t it, int32_t mode, void *stream);
 /* Iterations [it_begin, it_end), both phases, communication included (needs e->peer): one
@@ -384,6 +389,9 @@ int ipx_peer_export(void *peer, void *handle_out);
 int ipx_peer_import(void *peer, int32_t rank, const void *handle_in);
 int ipx_peer_ready(void *peer);
 int64_t ipx_peer_halo_capacity(void *peer);
+/* Deadline of a kernel's wait for a peer's word (default 10 s); past it the loop records stop
+ * code 7 and returns -- never a hung GPU. */
+int ipx_peer_set_timeout(void *peer, double seconds);
 int ipx_peer_sequence(void *peer, int64_t *out2);
 int64_t ipx_peer_fused_launches(void *peer);   /* loop kernels that did a collective in their prologue */
 void ipx_peer_destroy(void *peer);

@@ -574,7 +574,7 @@ k_cg_step2_hp(int n, double *st, int parity, int mode, const double *__restrict_
       for (int q = 0; q < 4; ++q) pj.pack_out[q] = tot[q];
     }
     // pull: span entries inside the rank's halo come from the neighbours
-    const long long deadline = (long long)wall_clock64() + IPX_PEER_TIMEOUT_TICKS;
+    const long long deadline = (long long)wall_clock64() + pv.timeout_ticks;
     const unsigned long long *mine = pv.mbox[pv.rank];
     bool okh = true;
 #pragma unroll
@@ -960,7 +960,7 @@ k_cg_pack_comm(RangeJob job, double *__restrict__ out, ipx_peer_view pv, uint32_
   __shared__ double vals[IPX_MAX_PEERS * 4];
   const int tid = threadIdx.x;
   if (st[ST_STOP] == 7.0) return;        // an earlier wait timed out: do not wait it out again
-  const long long deadline = (long long)wall_clock64() + IPX_PEER_TIMEOUT_TICKS;
+  const long long deadline = (long long)wall_clock64() + pv.timeout_ticks;
   if (blockIdx.x == 0) {
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
     for (int pc = 0; pc < job.npieces; ++pc) {          // one piece per segment, in order
@@ -1441,6 +1441,9 @@ static int shard2_segment(const ipx_cg_args *a, const ipx_shard2_ext *e, int32_t
     if (phase == 0) {
       // step1 with the all-reduce of p'Hp in its prologue, then the projection; no pack launch
       const int np1 = part1_count(a);
+      // (every argument check comes BEFORE the sequence numbers move: a rank that returns
+      // IPX_EINVAL must not leave its counters out of step with the group's)
+      if (!boxp && (e->p1_hi[0] > np1 || e->p1_hi[0] < e->p1_lo[0])) return IPX_EINVAL;
       if (++peer->seq == 0) ++peer->seq;
       pj.seq = peer->seq;
       ++peer->fused;
@@ -1455,7 +1458,6 @@ static int shard2_segment(const ipx_cg_args *a, const ipx_shard2_ext *e, int32_t
                                          &own);
       }
       const int cnt = (int)(e->p1_hi[0] - e->p1_lo[0]);
-      if (e->p1_hi[0] > np1 || cnt < 0) return IPX_EINVAL;
       // (the kernel folds [p1 + np1, p1 + 2 np1): hand it the own range as that window)
       const double *p1 = a->part1 + np1 + e->p1_lo[0] - cnt;
       int rc = launch_step1_ar(a, it, p1, cnt, st, false, &pj);
@@ -1470,6 +1472,7 @@ static int shard2_segment(const ipx_cg_args *a, const ipx_shard2_ext *e, int32_t
     // prologue; the own sums of p'Hp stay in part1 for the next step1
     const int np4 = part4_count(a);
     if (e->p4_hi > np4) return IPX_EINVAL;
+    if (!boxp && (e->p2_hi > (int)a->A_ntiles || e->p3_hi[0] > np4)) return IPX_EINVAL;
     int rc = peer_job_geometry(e, peer, &pj);
     if (rc) return rc;
     if (++peer->seq == 0) ++peer->seq;
@@ -1482,8 +1485,6 @@ static int shard2_segment(const ipx_cg_args *a, const ipx_shard2_ext *e, int32_t
       return launch_step2_hp(a, it, mode, a->part2, step1_box_blocks(a), a->part3,
                              ipx_boxschur_project_count((const ipx_boxschur_args *)a->banded),
                              a->part4 + e->p4_lo, (int)(e->p4_hi - e->p4_lo), st, nullptr, &pj);
-    const int np2 = (int)a->A_ntiles;
-    if (e->p2_hi > np2 || e->p3_hi[0] > np4) return IPX_EINVAL;
     return launch_step2_hp(a, it, mode, a->part2 + e->p2_lo, (int)(e->p2_hi - e->p2_lo),
                            a->part3 + e->p3_lo[0], (int)(e->p3_hi[0] - e->p3_lo[0]),
                            a->part4 + e->p4_lo, (int)(e->p4_hi - e->p4_lo), st, nullptr, &pj);
@@ -1587,7 +1588,11 @@ static int shard2_segment(const ipx_cg_args *a, const ipx_shard2_ext *e, int32_t
 int ipx_cg_shard2_iterate(const ipx_cg_args *a, const ipx_shard2_ext *e, int32_t it_begin,
                           int32_t it_end, void *stream) {
   if (!a || !e || !e->peer || it_end < it_begin) return IPX_EINVAL;
-  const bool fuse = peer_fusable(a, e);
+  // e->fuse_comm is the GROUP's decision (ipx_cg_shard2_fusable on every rank, the minimum
+  // taken over the ranks by the caller): the two forms order the collectives of an iteration
+  // differently, so a rank may not pick one from its own slice of the matrices
+  const bool fuse = e->fuse_comm != 0;
+  if (fuse && !peer_fusable(a, e)) return IPX_EINVAL;
   for (int it = it_begin; it < it_end; ++it) {
     int rc = shard2_segment(a, e, 0, it, 0, stream, fuse);
     if (rc) return rc;
@@ -1595,6 +1600,17 @@ int ipx_cg_shard2_iterate(const ipx_cg_args *a, const ipx_shard2_ext *e, int32_t
     if (rc) return rc;
   }
   return IPX_OK;
+}
+
+// 1 when THIS rank's argument block allows the collectives in the prologues of the loop's own
+// kernels (3 launches per iteration; peer_fusable: the tables are functions of the rank's
+// slice of A and H).  The ranks must agree before anyone sets e->fuse_comm: the caller
+// reduces this value with MIN over the group (ipsolver/sharded.py FusedShardedCG).
+int ipx_cg_shard2_fusable(const ipx_cg_args *a, const ipx_shard2_ext *e) {
+  if (!a || !e || !e->peer) return 0;
+  ipx_shard2_ext asked = *e;
+  asked.fuse_comm = 1;
+  return peer_fusable(a, &asked) ? 1 : 0;
 }
 
 // The own-range sum of the p'Hp partials on its own (priming the sharded loop).

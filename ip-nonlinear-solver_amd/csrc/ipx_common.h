@@ -312,10 +312,12 @@ struct ipx_own_ranges {
 #define IPX_PEER_SLOTS 4
 #define IPX_PEER_NQ 8
 #define IPX_PEER_SCAL_WORDS (IPX_PEER_SLOTS * IPX_MAX_PEERS * IPX_PEER_NQ * 2)
-#define IPX_PEER_TIMEOUT_TICKS 300000000LL     // 3 s of the 100 MHz wall clock
+#define IPX_PEER_TIMEOUT_TICKS 1000000000LL    // default deadline of a wait: 10 s of the 100 MHz
+                                               // wall clock (ipx_peer_set_timeout changes it)
 struct ipx_peer_view {
   int rank, world;
   int64_t cap;                                 // halo capacity (doubles) per side and parity
+  long long timeout_ticks;                     // a wait longer than this raises stop code 7
   unsigned long long *mbox[IPX_MAX_PEERS];     // every rank's mailbox as mapped here (own: local)
 };
 // host-side object behind ipx_shard2_ext.peer
@@ -339,7 +341,7 @@ __device__ __forceinline__ void ipx_ll_store(unsigned long long *dst, double v, 
   __hip_atomic_store(dst, tag | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   __hip_atomic_store(dst + 1, tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-// spins until both words carry `seq`; false after IPX_PEER_TIMEOUT_TICKS (a peer died)
+// spins until both words carry `seq`; false past the deadline (a peer died or fell out of step)
 __device__ __forceinline__ bool ipx_ll_load(const unsigned long long *src, uint32_t seq, double &v,
                                             long long deadline) {
   while (true) {
@@ -408,7 +410,7 @@ __device__ __forceinline__ bool ipx_peer_sum(const ipx_peer_view &pv, uint32_t s
   }
   ipx_lds_barrier();
   if (lane) {
-    const long long deadline = (long long)wall_clock64() + IPX_PEER_TIMEOUT_TICKS;
+    const long long deadline = (long long)wall_clock64() + pv.timeout_ticks;
     double v = 0.0;
     if (!ipx_ll_load(pv.mbox[pv.rank] + ipx_peer_scal_word(slot, r, q0 + q), seq, v, deadline))
       lds[NQ * IPX_MAX_PEERS] = 1.0;

@@ -22,7 +22,7 @@ k_peer_allreduce(ipx_peer_view pv, uint32_t seq, int nq, const double *__restric
                  double *__restrict__ out, int *__restrict__ failed) {
   __shared__ double vals[IPX_MAX_PEERS * IPX_PEER_NQ];
   const int tid = threadIdx.x, slot = seq & (IPX_PEER_SLOTS - 1);
-  const long long deadline = (long long)wall_clock64() + IPX_PEER_TIMEOUT_TICKS;
+  const long long deadline = (long long)wall_clock64() + pv.timeout_ticks;
   for (int i = tid; i < pv.world * nq; i += blockDim.x) {
     const int r = i / nq, q = i - r * nq;
     ipx_ll_store(pv.mbox[r] + ipx_peer_scal_word(slot, pv.rank, q), in[q], seq);
@@ -57,6 +57,7 @@ void *ipx_peer_create(int32_t rank, int32_t world, int64_t halo_cap) {
   p->view.rank = rank;
   p->view.world = world;
   p->view.cap = halo_cap;
+  p->view.timeout_ticks = IPX_PEER_TIMEOUT_TICKS;
   p->seq = p->hseq = 0;
   p->bytes = 8 * ((int64_t)IPX_PEER_SCAL_WORDS + 2 * 2 * halo_cap * 2);
   void *mem = nullptr;
@@ -112,6 +113,15 @@ int ipx_peer_ready(void *peer) {
   for (int r = 0; r < p->view.world; ++r)
     if (!p->view.mbox[r]) return 0;
   return 1;
+}
+
+// How long a kernel waits for a peer's word before it raises stop code 7 (default 10 s: a peer
+// that is merely slow -- a time-shared GPU, a lazily loaded code object, a profiler -- is not a
+// dead one).
+int ipx_peer_set_timeout(void *peer, double seconds) {
+  if (!peer || !(seconds > 0.0) || seconds > 3600.0) return IPX_EINVAL;
+  ((ipx_peer *)peer)->view.timeout_ticks = (long long)(seconds * 1e8);
+  return IPX_OK;
 }
 
 int64_t ipx_peer_halo_capacity(void *peer) { return peer ? ((ipx_peer *)peer)->view.cap : 0; }

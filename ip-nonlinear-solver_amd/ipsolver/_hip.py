@@ -74,6 +74,8 @@ _SIGNATURES = {
     "ipx_cg_shard2_segment": [_P, _P, _I32, _I32, _I32, _P],
     "ipx_cg_shard2_fold_hp": [_P, _P, _P],
     "ipx_cg_shard2_iterate": [_P, _P, _I32, _I32, _P],
+    "ipx_cg_shard2_fusable": [_P, _P],
+    "ipx_peer_set_timeout": [_P, _F64],
     "ipx_peer_handle_bytes": [],
     "ipx_peer_export": [_P, _P],
     "ipx_peer_import": [_P, _I32, _P],

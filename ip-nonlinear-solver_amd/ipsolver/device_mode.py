@@ -343,13 +343,19 @@ def _dense_term(t):
     """DeviceDense wrapper of a 2-D CUDA tensor, one per storage (a callback returning the same
     resident matrix every iteration gets the same wrapper and its cached transpose)."""
     from .dense import DeviceDense
+    if t.dtype != _F64 or not t.is_contiguous():
+        # the conversion copies: the caller's tensor is not kept alive by the wrapper, and a
+        # callback returning a FRESH tensor per iteration gets the same address and version
+        # back from the caching allocator -- the cache would serve the previous iteration's
+        # matrix (ADVICE r3).  Convert, do not cache.
+        return DeviceDense(t.to(_F64).contiguous())
     key = (t.data_ptr(), tuple(t.shape), tuple(t.stride()), t._version)
     hit = _dense_terms.get(key)
     if hit is None:
         if len(_dense_terms) > 4:
             _dense_terms.clear()
-        hit = _dense_terms[key] = DeviceDense(t.to(_F64))
-    return hit
+        hit = _dense_terms[key] = (t, DeviceDense(t))       # (the entry pins t: aliased, alive)
+    return hit[1]
 
 
 def lagrangian_hessian(canonical, hess):

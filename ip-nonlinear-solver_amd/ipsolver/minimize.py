@@ -8,6 +8,7 @@ the trust-region subproblem solves, projections, merit-function algebra --
 runs on the GPU through ``backend_hip``.  Results are returned as numpy
 arrays.
 """
+import os
 import time
 from copy import deepcopy
 from warnings import warn
@@ -185,15 +186,14 @@ def _minimize_device(fun, x0, grad, hess, constraints, method, xtol, gtol, optio
 
 def _shard_request(options):
     """``options['shard']``: True / False, or the local-arithmetic object of the row-sharded
-    backend (tests pass the numpy twin).  Not given: shard when this process is one rank of an
-    initialised ``torch.distributed`` group of more than one."""
+    backend (tests pass the numpy twin).  Sharding is OPT-IN (the option, or ``IPX_SHARD=1`` in
+    the environment of every rank): a process group that merely exists does not turn a call
+    into a collective one -- a torchrun job running one independent solve per GPU (device
+    callbacks, rank-dependent problems) keeps working.  The sharded call is collective: every
+    rank of the default group must make it with identical arguments."""
     shard = options.pop("shard", None)
     if shard is None:
-        try:
-            import torch.distributed as dist
-            shard = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-        except ImportError:
-            shard = False
+        shard = os.environ.get("IPX_SHARD", "0") not in ("", "0")
     return shard
 
 
@@ -273,8 +273,9 @@ def minimize_constrained(fun, x0, grad, hess='2-point', constraints=(), method=N
     (hyphenated spellings are accepted too); ``None`` picks by constraint type.
     Returns a ``scipy.optimize.OptimizeResult`` with the reference's fields.
 
-    Launched as one process per GPU (``torch.distributed`` initialised, or
-    ``options={'shard': True}``) the same call runs on the row-sharded backend: the user's
+    Launched as one process per GPU with ``options={'shard': True}`` (or ``IPX_SHARD=1``; a
+    collective call: identical arguments on every rank of the initialised ``torch.distributed``
+    group) the same call runs on the row-sharded backend: the user's
     callbacks are evaluated on the host with global numpy arrays exactly as here (replicated
     on every rank), every vector, the Jacobian and the Hessian between two evaluations are
     partitioned over the ranks (ipsolver/sharded.py), the result carries global arrays.

@@ -375,6 +375,11 @@ class PeerMailbox:
             raise self._hip.IpxError("peer mailbox: a wait for a peer timed out")
         return out.tolist()
 
+    def set_timeout(self, seconds):
+        """Deadline of a kernel's wait for a peer's word (default 10 s; past it: stop code 7,
+        the group falls back to torch.distributed together)."""
+        self._hip.call("ipx_peer_set_timeout", ctypes.c_void_p(self.handle), float(seconds))
+
     def sequence(self):
         out = (ctypes.c_int64 * 2)()
         self._hip.call("ipx_peer_sequence", ctypes.c_void_p(self.handle), out)
@@ -1264,7 +1269,7 @@ class FusedShardedCG:
             # side decides per argument block -- one segment, no box, 16-bit index forms) or
             # in pack kernels of their own (5 launches; IPX_SHARD_FUSE_COMM=0 forces that)
             e.peer = self.mailbox.handle
-            e.fuse_comm = 0 if os.environ.get("IPX_SHARD_FUSE_COMM", "1") == "0" else 1
+            e.fuse_comm = self._agree_on_fused_comm(Hc, A_loc, lb is not None)
             self._exchange_g = None
         else:
             self._exchange_g = sh.comm.prepare_exchange_many(
@@ -1272,6 +1277,25 @@ class FusedShardedCG:
                  for _, off, ln, lo, hi, sl, sr, _, _ in segs])
         # (own range and send counts of the first segment: bench.py measures the exchange's floor)
         self.col_geom = (segs[0][3], segs[0][4], segs[0][5], segs[0][6])
+
+    def _agree_on_fused_comm(self, Hc, A_loc, has_box):
+        """1 when EVERY rank's argument block allows the collectives in the prologues of the
+        loop's own kernels (csrc/cg.hip ipx_cg_shard2_fusable: 16-bit index tables, the solve's
+        fused tail -- functions of each rank's own slice of A and H), else 0 on every rank: the
+        two forms order an iteration's collectives differently and share sequence numbers and
+        slots, so a group in which one rank took the pack kernels and another the prologues
+        would read each other's words as the wrong quantity.  One all-reduce (MIN)
+        per pair of patterns, cached on the sharding (the tables are symbolic)."""
+        sh = self.sh
+        asked = 0 if os.environ.get("IPX_SHARD_FUSE_COMM", "1") == "0" else 1
+        key = (id(Hc.pattern), Hc.pattern.nnz, id(A_loc.pattern), A_loc.pattern.nnz, has_box, asked)
+        cache = sh.__dict__.setdefault("_fuse_comm_agreed", {})
+        if key not in cache:
+            mine = asked and int(self.lib.ipx_cg_shard2_fusable(self.L.ref(), ctypes.byref(self.ext)))
+            cache[key] = int(sh.comm.reduce_floats([float(mine)], op="min")[0])
+            # (the patterns are kept alive with the decision: their ids stay theirs)
+            cache[key, "keep"] = (Hc.pattern, A_loc.pattern)
+        return cache[key]
 
     def _segment(self, phase, it, mode=0):
         self._hip.call("ipx_cg_shard2_segment", self.L.ref(), ctypes.byref(self.ext), int(phase),
@@ -1399,7 +1423,7 @@ def _drive_fused(F, c, x0, r0, g0, rt_g, tol, trust_radius, lb, ub, max_iter,
             F.iterate(it, end)
 
         def read_state(self):
-            return L.state.tolist()
+            return agreed(L.state.tolist())
 
         def X(self):
             return ShardVec(DV(L.x), sh, F.kind)
@@ -1414,14 +1438,40 @@ def _drive_fused(F, c, x0, r0, g0, rt_g, tol, trust_radius, lb, ub, max_iter,
             return c.zeros_like()
 
         def resume(self, it_stop, mode):
-            return F.resume(it_stop, mode)
+            return agreed(F.resume(it_stop, mode))
 
         def refine(self, it_stop):
             _refine_sharded(F)
 
+    last = {"stop": 0}
+
+    def agreed(state):
+        """Before the host ACTS on a state block read on the mailbox transport -- an event to
+        handle with torch.distributed collectives, or the end of the subproblem -- the ranks
+        establish together whether any of them saw a wait time out (stop code 7; ADVICE r3:
+        the last communicating launch before a read can time out on one rank and complete on
+        a slower one, which would then pair its next collectives with the other's restarted
+        subproblem).  One all-reduce (MAX) per non-continuing read; a rank that merely
+        continues (stop 0) does not take part: its next batch finds no partner, times out and
+        joins the agreement its peers are waiting in."""
+        last["stop"] = stop = int(state[ST_STOP])
+        if F.mailbox is not None and stop != 0:
+            sh.comm.stats["agreements"] = sh.comm.stats.get("agreements", 0) + 1
+            if sh.comm.reduce_floats([1.0 if stop == 7 else 0.0], op="max")[0] > 0.0:
+                state = list(state)
+                state[ST_STOP] = 7.0
+        return state
+
     from . import cg_fused
     x, niter, stop_cond, hits_boundary = cg_fused.run_device_loop(
         Driver(), STATS, lb, ub, trust_radius, max_iter, max_infeasible_iter, batch)
+    if last["stop"] == 0:
+        # the loop ran out of iterations on a continuing state: this rank has not taken part
+        # in an agreement its peers may be waiting in (they cannot have seen anything but 0 or
+        # 7 in the same read)
+        if int(agreed([0.0] * ST_STOP + [-1.0])[ST_STOP]) == 7:
+            raise F._hip.IpxError("sharded projected CG: a wait on the peer mailboxes timed out "
+                                  "on another rank")
     STATS["fused_calls"] += 1
     STATS["iterations"] += niter
     return x, {'niter': niter, 'stop_cond': stop_cond, 'hits_boundary': hits_boundary}

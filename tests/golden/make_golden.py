@@ -22,6 +22,10 @@ Outputs (numbers only -- no reference source travels):
                     (SVD fallback, projections.py:101-108,181-187,236-287)
   e2e_n20000.json   (``--n20000``) banded equality NLP at n=20000 / m=2000, both methods
   e2e_ineq_n12000.json  (``--ineq12000``: 4 minutes) box + inequality NLP at n=12000 / m=1200
+  config3_n1e6.json (``--config3``: 7 minutes) BASELINE config 3 at its FULL size n=1e6 /
+                    m=1e5 through the reference: all rows of the scalar trace, every 1000th
+                    component of x, the one-ulp record
+  e2e_ineq_n20000.json  (``--c5-n20000``: 25 minutes) box + inequality NLP at n=20000 / m=2000
   config2.json      (``--big`` only: minutes) dense equality QP of BASELINE config 2 at
                     n=4000/m=800 and n=10000/m=2000: scalar traces + strided x
   api.json          (``--api``) the host-side API either side of the path -- kind grammar,
@@ -331,10 +335,10 @@ def one_ulp_sensitivity(rows, x, fun, x0, grad, hess, constraints, kw, seeds=(31
             "x": x_sens if same_end else None, "seeds": list(seeds)}
 
 
-def run_e2e(name, fun, x0, grad, hess, constraints, **kw):
+def run_e2e(name, fun, x0, grad, hess, constraints, x_stride=None, **kw):
     res, rows = _trace_of(fun, x0, grad, hess, constraints, kw)
     rec = {"x": jf(np.asarray(res.x)) if np.size(res.x) <= 64
-           else jf(np.asarray(res.x)[::max(1, np.size(res.x) // 50)]),
+           else jf(np.asarray(res.x)[::x_stride or max(1, np.size(res.x) // 50)]),
            "status": int(res.status), "niter": int(res.niter),
            "cg_niter": int(res.cg_niter), "nfev": int(res.nfev),
            "ngev": int(res.ngev), "nhev": int(res.nhev),
@@ -564,6 +568,27 @@ def main():
         rec = run_e2e("banded_ineq_n12000", prob.fun, prob.x0, prob.grad, prob.hess, cons)
         with open(os.path.join(HERE, "e2e_ineq_n12000.json"), "w") as f:
             json.dump({"banded_ineq_n12000": rec}, f)
+        return
+    if "--config3" in sys.argv:
+        # BASELINE config 3 at FULL size: every row of the scalar trace and
+        # every 1000th component of x; ~100 s per run of the reference (x4 with the one-ulp
+        # re-runs)
+        prob = synthetic.CenteredBandedNLP(1000000, 100000, eps=1e-3)
+        rec = run_e2e("config3_n1e6", prob.fun, prob.x0, prob.grad, prob.hess,
+                      prob.constraints(ref), x_stride=1000, method="tr_interior_point")
+        rec["x_stride"] = 1000
+        with open(os.path.join(HERE, "config3_n1e6.json"), "w") as f:
+            json.dump({"config3_n1e6": rec}, f)
+        return
+    if "--c5-n20000" in sys.argv:
+        # config-5 style at the largest size the survey ran the reference on (327 s per run)
+        prob = synthetic.CenteredBandedNLP(20000, 2000, eps=1.0)
+        cons = (prob.constraints(ref, ("less", 0.0)), ref.BoxConstraint(("interval", -0.8, 0.8)))
+        rec = run_e2e("banded_ineq_n20000", prob.fun, prob.x0, prob.grad, prob.hess, cons,
+                      x_stride=100)
+        rec["x_stride"] = 100
+        with open(os.path.join(HERE, "e2e_ineq_n20000.json"), "w") as f:
+            json.dump({"banded_ineq_n20000": rec}, f)
         return
     if "--big" in sys.argv:
         out = {}

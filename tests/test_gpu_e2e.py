@@ -457,6 +457,108 @@ def test_bench_two_rank_rehearsal():
     assert d["collective_latency_floor_us"]["mailbox_all_reduce_4_doubles_launch_plus_flag_wait"] > 0
 
 
+def _independent_worker(rank, world, port, path):
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    syn = load_synthetic()
+    from ipsolver.synthetic import DeviceCallbacks
+    # rank-dependent problems (sizes differ: a collective solve could not even pair its calls)
+    n = 2000 if rank == 0 else 600
+    prob = syn.CenteredBandedNLP(n, n // 10, eps=1e-3)
+    dc = DeviceCallbacks(prob)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        dev = ipsolver.minimize_constrained(dc.fun, dc.x0, dc.grad, dc.hess,
+                                            dc.constraints(ipsolver), method="tr_interior_point")
+        hst = ipsolver.minimize_constrained(prob.fun, prob.x0, prob.grad, prob.hess,
+                                            prob.constraints(ipsolver), method="tr_interior_point")
+    np.savez(path % rank, x_dev=dev.x.cpu().numpy(), x_host=hst.x,
+             info=[dev.status, dev.niter, dev.cg_niter, hst.status, hst.niter, hst.cg_niter])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_independent_solves_inside_a_process_group(tmp_path, e2e_golden):
+    """a process group that merely EXISTS must not turn ``minimize_constrained``
+    into a collective call.  Two ranks of a gloo group each solve their OWN problem (different
+    sizes), once with device callbacks (which the sharded dispatch used to refuse) and once
+    with numpy callbacks (which it used to pair into one collective solve): both are ordinary
+    single-GPU solves; rank 0's is the reference's trace."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    path = str(tmp_path / "indep%d.npz")
+    mp.spawn(_independent_worker, args=(2, port, path), nprocs=2, join=True)
+    gold = e2e_golden["banded_eq_n2000_tr_interior_point"]
+    for rank in range(2):
+        got = np.load(path % rank)
+        info = got["info"].tolist()
+        assert info[0] == info[3] == 1 and info[1:3] == info[4:6]
+        assert np.max(np.abs(got["x_dev"] - got["x_host"])) <= 1e-9 * np.max(np.abs(got["x_host"]))
+        if rank == 0:
+            assert info[1:3] == [gold["niter"], gold["cg_niter"]]
+
+
+def test_bench_spawns_its_own_ranks():
+    """``python bench.py --gpus 2 --steps 12 --warmup 3`` started DIRECTLY, the way the driver
+    starts the N = 1 run (no torch.distributed.run around it): the parent -- which makes no GPU
+    call -- starts the two ranks as fresh child processes and relays rank 0's line.  Here both
+    ranks share cuda:0 and the rendezvous runs over gloo (IPX_BENCH_BACKEND=gloo); the line says
+    which backend, world size and devices it saw, the transport used and why a fallback was
+    taken if one was; the weak-scaling point, which two ranks cannot hold on one GPU, is
+    reported as skipped instead of timing out."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, IPX_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2",
+                          "--steps", "12", "--warmup", "3"],
+                         cwd=root, env=env, capture_output=True, text=True, timeout=1200)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 12 and d["warmup"] == 3 and d["value"] > 0
+    assert "error" not in d and "spawned 2 ranks" in d["launcher"]
+    assert d["parity_vs_single_gpu"]["max_rel_diff"] < 1e-12
+    assert d["backend"]["world_size_seen"] == 2 and d["backend"]["torch_distributed"] == "gloo"
+    assert d["backend"]["devices_by_rank"] == [0, 0]
+    assert d["transport"] == "ipc" and d["transport_fallback_reason"] is None
+    assert d["weak_scaling_point"]["rehearsal"] == "skipped"
+    fs = d["wall_clock_to_gtol"]
+    assert (fs["status"], fs["niter"], fs["cg_niter"]) == (1, 25, 34)
+
+
+def test_bench_launcher_reports_a_failing_rank():
+    """A rank that dies leaves ONE JSON line with ``error`` and a non-zero exit code behind
+    (here: a backend name torch.distributed does not know)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, IPX_BENCH_BACKEND="no-such-backend")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2",
+                          "--steps", "4", "--warmup", "1", "--n", "20000", "--m", "2000"],
+                         cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] == 0.0 and d["error"]
+
+
 def test_bench_contract_with_odd_step_counts():
     """``bench.py --steps K --warmup W`` for a K that is no divisor of anything (the driver
     chooses K and W): one JSON line with the contract's keys, the roofline and CPU-baseline

@@ -541,7 +541,7 @@ def test_sharded_wider_band_takes_the_general_driver(tmp_path, ips):
         assert np.max(np.abs(r[4:-1])) <= 1e-11 * r[-1], name
 
 
-def _desync_worker(rank, world, port, out_path):
+def _desync_worker(rank, world, port, out_path, mode="lone"):
     import os
     import sys
     import warnings
@@ -562,12 +562,25 @@ def _desync_worker(rank, world, port, out_path):
         c = sh.from_global(inst.c, "col")
         x, info = qp.projected_cg(H, c, Z, Y, sh.zeros("row"), tol=0, max_iter=10)
         ok_before = sh.transport == "ipc"
+        sh.mailbox().set_timeout(2.0)       # (default 10 s: keep the test short)
         lone = 0
-        if rank == 0:                       # one rank falls out of step: an all-reduce alone
+        if mode == "lone" and rank == 0:    # one rank falls out of step: an all-reduce alone
             try:
                 sh.mailbox().allreduce([1.0])
             except _hip.IpxError:
                 lone = 1
+        if mode == "one-sided" and rank == 0:
+            # the LAST communicating launch before a host read times out on rank 0
+            # only -- rank 1 completes it and sees an ordinary end of the subproblem.  Emulated
+            # by writing the stop code into rank 0's state block after the batch.
+            plain = sharded.FusedShardedCG.iterate
+
+            def iterate(self, it_begin, it_end):
+                plain(self, it_begin, it_end)
+                if self.mailbox is not None and it_end == 10:
+                    self.L.state[sharded.ST_STOP] = 7.0
+            sharded.FusedShardedCG.iterate = iterate
+            lone = 1
         with warnings.catch_warnings(record=True) as caught:
             warnings.simplefilter("always")
             x2, info2 = qp.projected_cg(H, c, Z, Y, sh.zeros("row"), tol=0, max_iter=10)
@@ -586,19 +599,22 @@ def _desync_worker(rank, world, port, out_path):
         dist.destroy_process_group()
 
 
-def test_sharded_loop_survives_a_rank_out_of_step(tmp_path, ips):
-    """A peer that falls out of step (here: one rank issues a mailbox all-reduce on its own, so
-    its sequence numbers run one ahead) makes the waits of the device loop time out -- after 3 s,
-    on every rank, with stop code 7 instead of a hung GPU.  The group then gives the mailbox
+@pytest.mark.parametrize("mode", ["lone", "one-sided"])
+def test_sharded_loop_survives_a_rank_out_of_step(mode, tmp_path, ips):
+    """A peer that falls out of step (``lone``: one rank issues a mailbox all-reduce on its own,
+    so its sequence numbers run one ahead) makes the waits of the device loop time out -- after
+    the mailbox's deadline, on every rank, with stop code 7 instead of a hung GPU.  The group then gives the mailbox
     transport up together, warns, and solves the SAME subproblem again through torch.distributed:
-    same iterates as before the incident."""
+    same iterates as before the incident.  ``one-sided``: only ONE rank sees the timeout (in the
+    last launch before a host read, which the other rank completes normally); the ranks agree on
+    it before either acts on its state block, and fall back together all the same."""
     import socket
     import torch.multiprocessing as mp
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     out = str(tmp_path / "desync.npz")
-    mp.spawn(_desync_worker, args=(2, port, out), nprocs=2, join=True)
+    mp.spawn(_desync_worker, args=(2, port, out, mode), nprocs=2, join=True)
     got = np.load(out)
     assert list(got["flags"]) == [1.0, 1.0, 1.0] and int(got["lone"][0]) == 1
     assert list(got["niter"]) == [10, 10, 10]
