@@ -268,13 +268,13 @@ typedef struct ipx_cg_args {
    * tests of qp_subproblem.py:583,599 can never trigger): ||x + alpha p||^2 is not formed --
    * the fused step1 + A.r kernel then does not read x and p.  Only read when step1 is fused. */
   int64_t no_radius;
-  /* The whole projection step in ONE launch (csrc/banded.hip k_project_fused): step1, w = A r,
-   * the cyclic-reduction solve and g = r - A'v, for a tridiagonal A A' and a Jacobian whose
-   * rows all have A_rl entries, no box.  A_off16 = one uint16 per entry of A (column - first
-   * column of its row), A_rowfirst = one int per row, P_win = 2 ints per workgroup of the solve
-   * (first column / one past the last column of the span it needs: the columns of its window's
-   * rows and its own variables), P_nspan = the longest span (<= 4096), P_navn below; needs
-   * At_vown and r_next.  Any of them 0 / NULL: the separate launches. */
+  /* Tables of the RESIDENT form of the loop (csrc/resident.hip: a whole batch of iterations in
+   * one launch, one workgroup per 260 rows of a tridiagonal A A', all of them co-resident; the
+   * per-rank sizes of a multi-GPU run).  For a Jacobian whose rows all have A_rl entries, no
+   * box: A_off16 = one uint16 per entry of A (column - first column of its row), A_rowfirst =
+   * one int per row, P_win = 2 ints per workgroup of the solve (first column / one past the
+   * last column of the span it needs: the columns of its window's rows and its own variables),
+   * P_nspan = the longest span (<= 4096), P_navn below; needs At_vown. */
   const void *A_off16;
   const int32_t *A_rowfirst;
   int64_t A_rl;
@@ -287,7 +287,21 @@ typedef struct ipx_cg_args {
    * Hp = H p and the scalar p'Hp into part1[1] (H_ntiles = 1, the H_* arrays unused).  The
    * branches and step lengths stay on the device. */
   int64_t H_operator;
+  /* != 0 with the tables above: ipx_cg_iterate runs a batch as one resident launch when
+   * ipx_cg_resident_ok says the sizes fit (every row of H at most 4 entries -- the caller's
+   * check --, <= 224 workgroups, spans within the kernel's budgets).  R_ll = the hand-off buffer
+   * (ipx_cg_resident_ll_words(workgroups, R_hw) 8-byte words, zeroed once), R_hw = the longest
+   * halo (columns of a workgroup's span beyond its own variables, either side), R_seq = a HOST
+   * counter owned by the caller (starts at 0; the library advances it by the tags a launch
+   * uses).  A launch in which a hand-off timed out records stop code 8 and leaves x, p, r, Hp
+   * and the state block untouched: clear the code, set resident = 0 and repeat the batch. */
+  int64_t resident;
+  void *R_ll;
+  int64_t R_hw;
+  int64_t *R_seq;
 } ipx_cg_args;
+int ipx_cg_resident_ok(const ipx_cg_args *a);
+int64_t ipx_cg_resident_ll_words(int32_t nwg, int32_t hw);
 int ipx_cg_state_size(void);
 int ipx_cg_vec_grid(int64_t n);
 /* Hp = H p (+ diag*p) with p'Hp partials: primes the loop. */

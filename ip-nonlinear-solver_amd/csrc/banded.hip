@@ -1679,269 +1679,6 @@ int launch_solve_pcr(const LevDev &lv, int L, const double *w, double *x, double
 }
 
 
-// ---------------------------------------------------------------- fused projection (k = 1)
-// One launch for  r_next = r + alpha Hp,  w = A r_next,  v = (A A')^-1 w,  g = r_next - A'v
-// (ipx_project_job, ipx_common.h).  A workgroup owns rows_wg constraint rows and the
-// variables whose first constraint lies in them; it
-//   1. folds the p'Hp partials into alpha (the branches of qp_subproblem.py:551,558 as in
-//      csrc/cg.hip k_cg_step1_ar) while its loads stream in: the entries of A's rows of its
-//      WINDOW (own rows + 2^L rows either side), r and Hp on the columns those rows touch,
-//      x and p on its own variables, the band of A A' on the window;
-//   2. forms r_next on the span in LDS and the partial of ||x + alpha p||^2;
-//   3. w on the window rows: products parked in LDS (in rounds), one lane per row adds them
-//      left to right (scipy's csr_matvec order, as every SpMV of this library);
-//   4. the cyclic reduction of k_solve_pcr on the window (same arithmetic);
-//   5. g on its own variables: t_j = sum_i A_ij v_i scattered from the registers that still
-//      hold A's entries -- first the even rows, then the odd ones: two rows two apart share no
-//      column (A A' is tridiagonal), so every LDS word is written by one lane per pass -- and
-//      g_j = -1 (t_j) + r_next_j, with the ||g||^2 and residual partials of k_solve_pcr.
-// Against the three-kernel form the iteration loses one launch, the round trips of w and
-// r_next and the 24 MB of A' in ELL form; the window's halo rows are the price (A and the
-// span of r, Hp are read (rows_wg + 2^(L+1)) / rows_wg times).  Same bits as the separate
-// kernels except ||x + alpha p||^2, which is summed per workgroup of this kernel.
-constexpr int PF_U = 23;       // entries of A per lane  (window rows * rl <= 23 * 256)
-constexpr int PF_QS = 16;      // span doubles per lane   (<= 4096 columns)
-constexpr int PF_QX = 12;      // own variables per lane  (<= 3072)
-
-template <int NR, bool NOXN2>
-__global__ void __launch_bounds__(IPX_BLOCK, 2)
-k_project_fused(ipx_project_job J, int m, int rows_wg, int L, const double *__restrict__ band,
-                int nwg) {
-  extern __shared__ __attribute__((aligned(16))) double pf_lds[];
-  const int wg = ipx_xcd_item(blockIdx.x, nwg);
-  if (wg < 0) return;
-  const int tid = threadIdx.x;
-  const int H = 1 << L;
-  const int R = rows_wg + 2 * H;
-  const int RS = R + 2 * H;                         // PCR rows incl. identity padding
-  const int usize = max(6 * RS, (J.navn + 1) & ~1);
-  double *span = pf_lds;                            // [nspan]
-  double *U = span + ((J.nspan + 1) & ~1);          // union: products | PCR ping-pong | t
-  double *sx = U + usize;                           // [R]: w, then v
-  double *red = sx + R;                             // [8]
-  double *pa0 = U, *pa1 = U + RS, *pr0 = U + 2 * RS, *pr1 = U + 3 * RS, *pd0 = U + 4 * RS,
-         *pd1 = U + 5 * RS;
-  // ---- 1. requests, in the order they are needed
-  const double *const fparts[1] = {J.p1};
-  const int fcounts[1] = {J.np1};
-  const double stop = J.st[ST_STOP];
-  const double rtg = J.st[J.parity ? ST_RTG1 : ST_RTG0];
-  const double tol = J.st[ST_TOL];
-  ipx_fold_regs<1, 6> fold;
-  fold.load(fparts, fcounts);
-  const int c_lo = J.win[2 * wg], c_hi = J.win[2 * wg + 1];
-  const int nspan = c_hi - c_lo;
-  const int av0 = J.vown[wg], avn = J.vown[wg + 1] - av0;
-  const int64_t own0 = (int64_t)wg * rows_wg;
-  const int64_t g0 = own0 - H;                      // global row of window row 0
-  const int rlo = (int)max(g0, (int64_t)0), rhi = (int)min(g0 + R, (int64_t)m);
-  const int rl = J.rl;
-  const int s = rlo * rl, e = rhi * rl;             // entries of the window's rows
-  double sr[PF_QS], sh[PF_QS];
-#pragma unroll
-  for (int k = 0; k < PF_QS; ++k) {
-    const int col = min(c_lo + min(tid + k * IPX_BLOCK, max(nspan - 1, 0)), J.n - 1);
-    sr[k] = J.r[col];
-    sh[k] = J.Hp[col];
-  }
-  double xv[PF_QX], pv[PF_QX];
-  if (!NOXN2) {
-#pragma unroll
-    for (int k = 0; k < PF_QX; ++k) {
-      const int j = min(av0 + min(tid + k * IPX_BLOCK, max(avn - 1, 0)), J.n - 1);
-      xv[k] = J.x[j];
-      pv[k] = J.p[j];
-    }
-  }
-  double av[PF_U];
-  int acr[PF_U];                 // column in the span (low 16 bits) | window row (high 16 bits)
-#pragma unroll
-  for (int u = 0; u < PF_U; ++u) {
-    const int kk = min(s + tid + u * IPX_BLOCK, max(e - 1, 0));
-    const int row = kk / rl;
-    av[u] = J.A_val[kk];
-    acr[u] = (J.A_rowfirst[row] + (int)J.A_off16[kk] - c_lo) | ((row - (int)g0) << 16);
-  }
-  double a[NR], b[NR];
-#pragma unroll
-  for (int k = 0; k < NR; ++k) {
-    const int64_t g = g0 + tid + k * IPX_BLOCK;
-    const bool in = tid + k * IPX_BLOCK < R && g >= 0 && g < m;
-    const int64_t gc = min(max(g, (int64_t)0), (int64_t)m - 1);
-    const double bv = band[gc], avv = band[(int64_t)m + gc];
-    a[k] = (in && g >= 1 && tid + k * IPX_BLOCK >= 1) ? avv : 0.0;     // (row 0 of the window: cut)
-    b[k] = in ? bv : 1.0;
-  }
-  if (stop != 0.0) return;
-  const bool lead = wg == 0 && tid == 0;
-  double fout[1];
-  fold.finish(fparts, fcounts, red, fout);
-  const double ptHp = fout[0];
-  if (rtg < tol) {                                   // qp_subproblem.py:551
-    if (lead) J.st[ST_STOP] = 4.0;
-    return;
-  }
-  if (ptHp <= 0.0) {                                 // :558
-    if (lead) { J.st[ST_NITER] += 1.0; J.st[ST_PTHP] = ptHp; J.st[ST_STOP] = 3.0; }
-    return;
-  }
-  const double alpha = rtg / ptHp;                   // :579
-  if (lead) { J.st[ST_NITER] += 1.0; J.st[ST_PTHP] = ptHp; J.st[ST_ALPHA] = alpha; }
-  // ---- 2. r_next on the span, ||x + alpha p||^2 on the own variables
-#pragma unroll
-  for (int k = 0; k < PF_QS; ++k) {
-    const int j = tid + k * IPX_BLOCK;
-    if (j < nspan) span[j] = sr[k] + alpha * sh[k];  // :622
-  }
-  if (!NOXN2) {
-    double sxx = 0.0;
-#pragma unroll
-    for (int k = 0; k < PF_QX; ++k) {
-      if (tid + k * IPX_BLOCK < avn) {
-        const double xn = xv[k] + alpha * pv[k];     // :580 (not stored)
-        sxx += xn * xn;
-      }
-    }
-    const double tot = ipx_block_reduce<IPX_SUM>(sxx, red);
-    if (tid == 0) { J.part2[wg] = tot; J.part2[nwg + wg] = 0.0; }
-  } else {
-    ipx_lds_barrier();
-  }
-  // (ipx_block_reduce ends with a barrier: the span is complete for every lane)
-  // ---- 3. w = A r_next on the window rows, in rounds of as many rows as the union holds
-  const int rpr = usize / rl;                        // rows per round
-  for (int r0 = 0; r0 < rhi - rlo; r0 += rpr) {
-    const int rb = rlo - (int)g0 + r0;               // first window row of the round
-#pragma unroll
-    for (int u = 0; u < PF_U; ++u) {
-      const int kk = s + tid + u * IPX_BLOCK;
-      const int lr = (acr[u] >> 16) - rb;
-      if (kk < e && lr >= 0 && lr < rpr) U[kk - s - r0 * rl] = av[u] * span[acr[u] & 0xffff];
-    }
-    ipx_lds_barrier();
-    for (int i = tid; i < min(rpr, rhi - rlo - r0); i += IPX_BLOCK) {
-      const double *pp = U + i * rl;
-      double sum = 0.0;
-      for (int k = 0; k < rl; ++k) sum += pp[k];
-      sx[rb + i] = 1.0 * sum;
-    }
-    ipx_lds_barrier();
-  }
-  // ---- 4. cyclic reduction on the window (k_solve_pcr)
-  double d[NR];
-#pragma unroll
-  for (int k = 0; k < NR; ++k) {
-    const int r = tid + k * IPX_BLOCK;
-    const int64_t g = g0 + r;
-    d[k] = (r < R && g >= 0 && g < m) ? sx[r] : 0.0;
-  }
-  double a0[NR], b0[NR], w0[NR];
-#pragma unroll
-  for (int k = 0; k < NR; ++k) { a0[k] = a[k]; b0[k] = b[k]; w0[k] = d[k]; }
-  ipx_lds_barrier();                                // (everybody has read w before U is reused)
-  for (int i = tid; i < 2 * H; i += IPX_BLOCK) {
-    const int r = i < H ? i : R + i;                // storage index = window row + H
-    pa0[r] = 0.0; pr0[r] = 1.0; pd0[r] = 0.0;
-    pa1[r] = 0.0; pr1[r] = 1.0; pd1[r] = 0.0;
-  }
-  for (int sl = 0; sl < L; ++sl) {
-    const int h = 1 << sl;
-    double *pa = (sl & 1) ? pa1 : pa0, *pr = (sl & 1) ? pr1 : pr0, *pd = (sl & 1) ? pd1 : pd0;
-#pragma unroll
-    for (int k = 0; k < NR; ++k) {
-      const int r = tid + k * IPX_BLOCK;
-      const double rc = pcr_rcp(b[k]);
-      if (r < R) { pa[H + r] = a[k]; pr[H + r] = rc; pd[H + r] = d[k]; }
-    }
-    ipx_lds_barrier();
-#pragma unroll
-    for (int k = 0; k < NR; ++k) {
-      const int r = H + min(tid + k * IPX_BLOCK, R - 1);
-      const double alo = pa[r - h], rlo_ = pr[r - h], dlo = pd[r - h];
-      const double ahi = pa[r + h], rhi_ = pr[r + h], dhi = pd[r + h];
-      const double al = -a[k] * rlo_, ga = -ahi * rhi_;
-      double bn = __builtin_fma(al, a[k], b[k]);
-      bn = __builtin_fma(ga, ahi, bn);
-      double dn = __builtin_fma(al, dlo, d[k]);
-      dn = __builtin_fma(ga, dhi, dn);
-      a[k] = al * alo; b[k] = bn; d[k] = dn;
-    }
-  }
-  ipx_lds_barrier();                                // (last level read before sx / U change)
-#pragma unroll
-  for (int k = 0; k < NR; ++k) {
-    const int r = tid + k * IPX_BLOCK;
-    if (r < R) {
-      const double xvv = d[k] / b[k];
-      sx[r] = xvv;
-      const int64_t g = g0 + r;
-      if (J.v && r >= H && r < H + rows_wg && g < m) J.v[g] = xvv;
-    }
-  }
-  // ---- 5. t = A'v on the own variables: even rows, then odd rows
-  double *t = U;
-  for (int j = tid; j < avn; j += IPX_BLOCK) t[j] = 0.0;
-  ipx_lds_barrier();
-#pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
-#pragma unroll
-    for (int u = 0; u < PF_U; ++u) {
-      const int kk = s + tid + u * IPX_BLOCK;
-      const int j = (acr[u] & 0xffff) + c_lo - av0, wr = acr[u] >> 16;
-      if (kk < e && j >= 0 && j < avn && (((wr + (int)g0) & 1) == pass))
-        t[j] = t[j] + av[u] * sx[wr];
-    }
-    ipx_lds_barrier();
-  }
-  // g = -1 (t) + r_next on the own variables, pairs of consecutive variables per lane in the
-  // order of k_solve_pcr's tail (same partial sums of ||g||^2)
-  {
-    const int64_t vb = av0 & ~1;
-    double gacc = 0.0;
-    for (int64_t j = vb + 2 * (int64_t)tid; j < (int64_t)av0 + avn; j += 2 * IPX_BLOCK) {
-      const bool in0 = j >= av0, in1 = j + 1 < (int64_t)av0 + avn;
-      double y0 = 0.0, y1 = 0.0;
-      if (in0) { y0 = -1.0 * t[j - av0]; y0 += 1.0 * span[j - c_lo]; }
-      if (in1) { y1 = -1.0 * t[j + 1 - av0]; y1 += 1.0 * span[j + 1 - c_lo]; }
-      if (in0 && in1) {
-        *reinterpret_cast<v2d *>(J.g + j) = (v2d){y0, y1};
-        gacc += y0 * y0;
-        gacc += y1 * y1;
-      } else if (in0) {
-        J.g[j] = y0;
-        gacc += y0 * y0;
-      } else if (in1) {
-        J.g[j + 1] = y1;
-        gacc += y1 * y1;
-      }
-    }
-    const double gtot = ipx_block_reduce<IPX_SUM>(gacc, red);
-    if (tid == 0) { J.part3[wg] = gtot; J.part3[nwg + wg] = 0.0; }
-  }
-  // ---- residual of the own rows:  w_i - (a_i v_{i-1} + b_i v_i + a_{i+1} v_{i+1})
-#pragma unroll
-  for (int k = 0; k < NR; ++k) {
-    const int r = tid + k * IPX_BLOCK;
-    if (r < R) pa0[H + r] = a0[k];
-  }
-  ipx_lds_barrier();
-  double acc = 0.0;
-#pragma unroll
-  for (int k = 0; k < NR; ++k) {
-    const int r = tid + k * IPX_BLOCK;
-    const int64_t g = g0 + r;
-    if (r >= H && r < H + rows_wg && g < m) {
-      double sum = b0[k] * sx[r];
-      sum += a0[k] * sx[r - 1];
-      sum += pa0[H + r + 1] * sx[r + 1];
-      const double res = w0[k] - sum;
-      acc += res * res;
-    }
-  }
-  const double tot = ipx_block_reduce<IPX_SUM>(acc, red);
-  if (tid == 0) J.part4[wg] = tot;
-}
-
 template <int K>
 size_t decoupled_lds_doubles(int q) {
   constexpr int T = DEC_CHUNKS, NCH = T + 3;
@@ -2679,51 +2416,21 @@ int ipx_banded_solve_resid_atv_launch(void *handle, const double *w, double *x, 
   return IPX_EINVAL;
 }
 
-int ipx_banded_project_geometry(void *handle, int32_t *geo) {
-  if (!handle || !geo) return 0;
+// The cyclic-reduction form of the single-launch solve as the resident CG kernel
+// (csrc/resident.hip) needs it: rows per workgroup, workgroups, levels, the band.  0 when the
+// factorization's solves take another path.
+int ipx_banded_pcr_view(void *handle, ipx_pcr_view *out) {
+  if (!handle || !out) return 0;
   int32_t g2[2];
   if (!ipx_banded_decoupled_geometry(handle, g2)) return 0;
   Banded *h = (Banded *)handle;
   if (h->pcr_L <= 0) return 0;
-  geo[0] = g2[0];
-  geo[1] = g2[1];
-  geo[2] = 1 << h->pcr_L;
+  out->m = h->lev[0].m;
+  out->rows_wg = g2[0];
+  out->nwg = g2[1];
+  out->L = h->pcr_L;
+  out->band = h->lev[0].band;
   return 1;
-}
-
-int ipx_banded_project_fused_launch(void *handle, const ipx_project_job &job, int *nwg_out,
-                                    hipStream_t st) {
-  int32_t geo[3];
-  if (!ipx_banded_project_geometry(handle, geo)) return IPX_EINVAL;
-  Banded *h = (Banded *)handle;
-  const LevDev lv = to_dev(h->lev[0], nullptr);
-  const int rows_wg = geo[0], nwg = geo[1], L = h->pcr_L, H = geo[2];
-  const int R = rows_wg + 2 * H, RS = R + 2 * H;
-  if (job.rl < 1 || (int64_t)R * job.rl > (int64_t)PF_U * IPX_BLOCK || job.nspan > PF_QS * IPX_BLOCK ||
-      job.nspan < 1 || 6 * RS < job.rl || R > 2 * IPX_BLOCK || job.navn < 1 ||
-      job.navn > PF_QX * IPX_BLOCK)
-    return IPX_EINVAL;
-  const int usize = std::max(6 * RS, (job.navn + 1) & ~1);
-  const size_t lds = sizeof(double) * (size_t)(((job.nspan + 1) & ~1) + usize + R + 8);
-  if (nwg_out) *nwg_out = nwg;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void *)k_project_fused<2, false>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    (void)hipFuncSetAttribute((const void *)k_project_fused<2, true>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    attr_set = true;
-  }
-  if (lds > 96 * 1024) return IPX_EINVAL;
-  const dim3 grid(ipx_xcd_grid(nwg)), block(IPX_BLOCK);
-  if (job.no_xn2)
-    hipLaunchKernelGGL((k_project_fused<2, true>), grid, block, lds, st, job, lv.m, rows_wg, L,
-                       lv.band, nwg);
-  else
-    hipLaunchKernelGGL((k_project_fused<2, false>), grid, block, lds, st, job, lv.m, rows_wg, L,
-                       lv.band, nwg);
-  IPX_CHECK_LAUNCH();
-  return IPX_OK;
 }
 
 // Solve + residual partials in one go (the CG loop's projection step).

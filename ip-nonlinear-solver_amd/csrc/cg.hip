@@ -1142,17 +1142,6 @@ static bool box_project(const ipx_cg_args *a) {
 static bool fused_ar(const ipx_cg_args *a) {
   return a->r_next != nullptr && a->A_own != nullptr && a->A_span > 0 && !a->lb && a->m > 0;
 }
-// step1 + A.r + solve + g in one launch (csrc/banded.hip k_project_fused)
-static bool fused_project(const ipx_cg_args *a) {
-  return a->solver_kind == 0 && a->P_win != nullptr && a->A_off16 != nullptr &&
-         a->A_rowfirst != nullptr && a->A_rl > 0 && a->P_nspan > 0 && a->At_vown != nullptr &&
-         a->r_next != nullptr && !a->lb && a->m > 0;
-}
-// The fused projection reads r on spans that reach into other workgroups' variables, so g
-// cannot overwrite r in place: iteration `it` reads r from one of (a->r, a->r_next) and
-// leaves g in the other; the roles swap every iteration (the reference sets r = g, :632).
-static double *proj_r(const ipx_cg_args *a, int it) { return (it & 1) ? a->r_next : a->r; }
-static double *proj_g(const ipx_cg_args *a, int it) { return (it & 1) ? a->r : a->r_next; }
 // entries per half of part2: one per row tile of A (fused step1) or per vector chunk
 static int step1_box_blocks(const ipx_cg_args *a) {
   const ipx_boxschur_args *b = (const ipx_boxschur_args *)a->banded;
@@ -1165,7 +1154,6 @@ static int part4_count(const ipx_cg_args *a) {
 }
 static int part2_count(const ipx_cg_args *a) {
   if (box_project(a)) return step1_box_blocks(a);
-  if (fused_project(a)) return part4_count(a);       // one per workgroup of the solve
   return fused_ar(a) ? (int)a->A_ntiles : (int)a->vec_grid;
 }
 // entries per half of part3: one per row tile of A', or per workgroup of the solve when
@@ -1650,7 +1638,7 @@ int ipx_cg_resume(const ipx_cg_args *a, int32_t it, int32_t mode, void *stream) 
   }
   hipLaunchKernelGGL(k_cg_step2, dim3(ipx_xcd_grid((int)a->vec_grid)), dim3(VB), 0, st, a->n,
                      a->state, it & 1, mode, a->part2, part2_count(a), a->part3, np3, a->part4,
-                     np4, a->x, a->p, fused_project(a) ? proj_g(a, it) : a->r, (int)a->vec_grid);
+                     np4, a->x, a->p, a->r, (int)a->vec_grid);
   IPX_CHECK_LAUNCH();
   return launch_hp(a, guard, st);
 }
@@ -1741,6 +1729,22 @@ static int cg_iterate_dense(const ipx_cg_args *a, int32_t it_begin, int32_t it_e
 static int cg_iterate(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, hipStream_t st,
                       hipEvent_t *ev) {
   if (dense_loop(a)) return ev ? IPX_EINVAL : cg_iterate_dense(a, it_begin, it_end, st);
+  if (!ev && it_end > it_begin && ipx_cg_resident_ok(a)) {
+    // small banded problems (one CU per workgroup of the solve): the whole batch as ONE
+    // resident launch (csrc/resident.hip), which leaves x, p, r, Hp, the state block and the
+    // partial arrays as these launches would -- the tile boundaries of p for the fused step2 +
+    // H.p kernel (an event handler's resume, a later batch on the separate launches) follow it
+    int rc = ipx_cg_resident_launch(a, it_begin, it_end, part1_count(a), part2_count(a),
+                                    part3_count(a), part4_count(a), st);
+    if (rc) return rc;
+    if (fused_hp(a)) {
+      const int tot = (int)(a->H_ntiles * 2 * a->H_hmax);
+      hipLaunchKernelGGL(k_cg_save_pb, dim3((tot + IPX_BLOCK - 1) / IPX_BLOCK), dim3(IPX_BLOCK), 0,
+                         st, a->p, a->H_tiles, (int)a->H_ntiles, (int)a->H_hmax, a->pb);
+      IPX_CHECK_LAUNCH();
+    }
+    return IPX_OK;
+  }
   const double *guard = a->state + ST_STOP;
   ipx_csr_view A{(int)a->m, (int)a->n, a->A_rowptr, a->A_colidx, a->A_val, a->A_tiles, (int)a->A_ntiles};
   ipx_csr_view At{(int)a->n, (int)a->m, a->At_rowptr, a->At_colidx, a->At_val, a->At_tiles, (int)a->At_ntiles};
@@ -1760,25 +1764,7 @@ static int cg_iterate(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, hi
     const bool no_xn2 = fuse1 && a->no_radius != 0;
     rc = cmp.launch(guard, st);
     if (rc) return rc;
-    const bool proj = fused_project(a);
-    if (proj) {
-      // the whole projection step in one launch; a->r is read (r) and rewritten (g) by
-      // disjoint phases of different workgroups' spans: g goes to r_next, then the roles swap
-      MARK(1);
-      ipx_project_job job;
-      job.st = a->state; job.parity = it & 1; job.p1 = p1 + np1; job.np1 = np1; job.n = (int)a->n;
-      job.x = a->x; job.p = a->p; job.r = proj_r(a, it); job.Hp = a->Hp;
-      job.A_val = a->A_val; job.A_off16 = (const uint16_t *)a->A_off16;
-      job.A_rowfirst = a->A_rowfirst; job.rl = (int)a->A_rl; job.win = a->P_win;
-      job.vown = a->At_vown; job.v = a->v; job.g = proj_g(a, it);
-      job.part2 = a->part2; job.part3 = a->part3; job.part4 = a->part4;
-      job.no_xn2 = a->no_radius != 0; job.nspan = (int)a->P_nspan; job.navn = (int)a->P_navn;
-      int nwg = 0;
-      rc = ipx_banded_project_fused_launch(a->banded, job, &nwg, st);
-      if (rc) return rc;
-      np4 = nwg;
-      MARK(2); MARK(3); MARK(4); MARK(5);
-    } else if (fuse1) {
+    if (fuse1) {
       MARK(1);
       rc = launch_step1_ar(a, it, p1, np1, st, no_xn2);   // r_next = r + alpha Hp;  w = A r_next
       if (rc) return rc;
@@ -1796,9 +1782,7 @@ static int cg_iterate(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, hi
       IPX_CHECK_LAUNCH();
       MARK(1);
     }
-    if (proj) {
-      np3 = np4;
-    } else if (a->m > 0 && box_project(a)) {
+    if (a->m > 0 && box_project(a)) {
       // simple (box) rows eliminated analytically and never multiplied as matrix rows:
       // g = r - A'(A A')^-1 A r in one call (csrc/boxschur.hip ipx_boxschur_project)
       int32_t n3 = 0, n4 = 0;
@@ -1857,11 +1841,11 @@ static int cg_iterate(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, hi
     if (fused_hp(a)) {
       MARK(6);
       rc = launch_step2_hp(a, it, (a->m > 0 ? 0 : 2) | (no_xn2 ? 1 : 0), p2, np2,
-                           p3, np3, p4, n4, st, proj ? proj_g(a, it) : a->r);
+                           p3, np3, p4, n4, st, a->r);
     } else {
       hipLaunchKernelGGL(k_cg_step2, dim3(ipx_xcd_grid((int)a->vec_grid)), dim3(VB), 0, st, a->n,
                          a->state, it & 1, (a->m > 0 ? 0 : 2) | (no_xn2 ? 1 : 0), p2, np2, p3, np3,
-                         p4, n4, a->x, a->p, proj ? proj_g(a, it) : a->r, (int)a->vec_grid);
+                         p4, n4, a->x, a->p, a->r, (int)a->vec_grid);
       IPX_CHECK_LAUNCH();
       MARK(6);
       rc = launch_hp(a, guard, st);

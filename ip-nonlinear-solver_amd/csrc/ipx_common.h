@@ -145,8 +145,16 @@ __device__ __forceinline__ double ipx_block_reduce(double v, double *lds) {
   v = ipx_wave_reduce<OP>(v);
   if (lane == 0) lds[wave] = v;
   ipx_lds_barrier();
-  double r = lds[0];
-  for (int w = 1; w < nw; ++w) r = ipx_combine<OP>(r, lds[w]);
+  double r;
+  if (nw == 4) {
+    // (the usual workgroup: the four partner values requested together -- a loop to a
+    // run-time wave count pays one dependent LDS round trip per wave; same order)
+    const double t0 = lds[0], t1 = lds[1], t2 = lds[2], t3 = lds[3];
+    r = ipx_combine<OP>(ipx_combine<OP>(ipx_combine<OP>(t0, t1), t2), t3);
+  } else {
+    r = lds[0];
+    for (int w = 1; w < nw; ++w) r = ipx_combine<OP>(r, lds[w]);
+  }
   ipx_lds_barrier();
   return r;
 }
@@ -216,11 +224,21 @@ __device__ __forceinline__ void ipx_sum_partials_multi(const double *const (&par
     if (lane == 0) lds[q * nw + wave] = v[q];
   }
   ipx_lds_barrier();
+  if (nw == 4) {                 // (all partner values requested together: ipx_block_reduce)
+    double t[NQ][4];
 #pragma unroll
-  for (int q = 0; q < NQ; ++q) {
-    double r = lds[q * nw];
-    for (int w = 1; w < nw; ++w) r += lds[q * nw + w];
-    out[q] = r;
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+      for (int w = 0; w < 4; ++w) t[q][w] = lds[q * 4 + w];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) out[q] = ((t[q][0] + t[q][1]) + t[q][2]) + t[q][3];
+  } else {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      double r = lds[q * nw];
+      for (int w = 1; w < nw; ++w) r += lds[q * nw + w];
+      out[q] = r;
+    }
   }
   ipx_lds_barrier();
 }
@@ -242,11 +260,21 @@ __device__ __forceinline__ void ipx_block_sum_multi(double (&v)[NQ], double *lds
     if (lane == 0) lds[q * nw + wave] = v[q];
   }
   ipx_lds_barrier();
+  if (nw == 4) {                 // (all partner values requested together: ipx_block_reduce)
+    double t[NQ][4];
 #pragma unroll
-  for (int q = 0; q < NQ; ++q) {
-    double r = lds[q * nw];
-    for (int w = 1; w < nw; ++w) r += lds[q * nw + w];
-    out[q] = r;
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+      for (int w = 0; w < 4; ++w) t[q][w] = lds[q * 4 + w];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) out[q] = ((t[q][0] + t[q][1]) + t[q][2]) + t[q][3];
+  } else {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      double r = lds[q * nw];
+      for (int w = 1; w < nw; ++w) r += lds[q * nw + w];
+      out[q] = r;
+    }
   }
   ipx_lds_barrier();
 }
@@ -546,36 +574,15 @@ enum {
   ST_SIZE = 16
 };
 
-// ---- the whole projection step of an iteration in ONE launch (csrc/banded.hip
-// k_project_fused): step1 (alpha, r_next = r + alpha Hp, ||x + alpha p||^2), w = A r_next,
-// v = (A A')^-1 w by parallel cyclic reduction, g = r_next - A'v -- for a tridiagonal A A'
-// (cyclic-reduction solve) and a Jacobian whose rows all have `rl` entries.  Every workgroup of
-// the solve recomputes w on its window of rows (own rows + 2^L either side) from A's rows, so
-// w, r_next and A' (ELL) never travel through memory and A is read once for both products.
-struct ipx_project_job {
-  double *st;                 // CG state block
-  int parity;
-  const double *p1;           // p'Hp partials (np1 of them)
-  int np1;
-  int n;
-  const double *x, *p, *r, *Hp;
-  const double *A_val;        // CSR values, rows of rl entries each
-  const uint16_t *A_off16;    // per entry: column - first column of its row
-  const int32_t *A_rowfirst;  // per row: its first column
-  int rl;
-  const int32_t *win;         // per workgroup: first column, one past the last column of its span
-  const int32_t *vown;        // per workgroup (+1): first own variable
-  double *v, *g;              // own rows of the solve / own variables of g
-  double *part2, *part3, *part4;
-  int no_xn2;
-  int nspan;                  // longest span (doubles of LDS)
-  int navn;                   // most own variables of one workgroup
+// ---- resident projected-CG kernel (csrc/resident.hip): the cyclic-reduction geometry of a
+// banded handle, and the launcher csrc/cg.hip's loop calls
+struct ipx_pcr_view {
+  int m, rows_wg, nwg, L;
+  const double *band;
 };
-int ipx_banded_project_fused_launch(void *handle, const ipx_project_job &job, int *nwg,
-                                    hipStream_t st);
-// 1 when the handle's solve is the cyclic-reduction form the fused projection builds on;
-// geo[0] = rows per workgroup, geo[1] = workgroups, geo[2] = 2^L (halo rows either side)
-int ipx_banded_project_geometry(void *handle, int32_t *geo);
+int ipx_banded_pcr_view(void *handle, ipx_pcr_view *out);
+int ipx_cg_resident_launch(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, int np1, int np2,
+                           int np3, int np4, hipStream_t st);
 
 // ---- internal (non-ABI) launchers shared between translation units --------
 struct ipx_csr_view {

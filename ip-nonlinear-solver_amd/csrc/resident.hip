@@ -1,0 +1,902 @@
+// The whole projected-CG iteration (reference qp_subproblem.py:549-634) as ONE resident launch
+// per BATCH of iterations, for problems small enough that every workgroup of the banded solve
+// gets a CU of its own (<= 224 workgroups of 260 constraint rows: n <= ~5.8e5 on the
+// benchmark's banded problem -- the per-rank sizes of a multi-GPU run).
+//
+// Why: at n = 1.25e5 the three dependent launches of csrc/cg.hip cost 21.8 us per iteration
+// (profiles/r04_per_rank_sweep.json) for ~3 us of memory traffic: every launch pays its
+// boundary, a state-word round trip, a partial fold before its first store and a block
+// reduction + partial store after its last.  Here a workgroup owns 260 rows of A A' and the
+// variables whose first constraint lies in them (the decomposition of k_solve_pcr's tail) for
+// ALL of the iteration, keeps its matrix entries in registers (row-wise: a lane owns a row of
+// the window of A, a few rows of H, a few columns of A') and its vectors in LDS for the whole
+// batch, and talks to the other workgroups only through 8-byte tagged words ("LL"
+// granules: 32 data bits + a 32-bit sequence number per word, one indivisible store each;
+// ipx_common.h, the form the peer mailboxes use between GPUs) -- no fence, no flag, no grid
+// barrier.  Two hops per iteration, the data dependencies of CG itself:
+//
+//   top      alpha = rt_g / p'Hp                                  (:551,:558,:579 on every WG)
+//   phase P  r_next = r + alpha Hp on the window's columns; w = A r_next on the window's rows
+//            (own rows + 2^L either side: a lane per row, sums left to right out of registers);
+//            cyclic reduction; g = r_next - A'v on the own variables (A' in ELL(2) form, as in
+//            k_solve_pcr's tail); partials of ||x + alpha p||^2, ||g||^2, ||w - (A A')v||^2
+//   hop 2    every WG publishes its three partials and the first / last own entries of g its
+//            neighbours' windows reach; waits for all partials (fixed-order fold: same bits in
+//            every WG) and for its own halo of g
+//   branch   :583 radius, orthogonality (projections.py:72), beta = ||g||^2 / rt_g
+//   phase H  x += alpha p;  p = beta p - g on own + hmax;  Hp = H p on the own rows (row sums
+//            left to right out of registers);  partial of p'Hp
+//   hop 1    partial of p'Hp + the boundary entries of Hp -> everybody / the neighbours
+//
+// The batch's first iteration takes p'Hp from the partial array the previous launch (of any
+// form) left; the last hop doubles as the commit: only a workgroup that has seen every other
+// workgroup's final word writes x, p, r, Hp and the state block back, so a launch in which
+// any wait timed out (stop code 8: a workgroup that never became resident) leaves memory
+// exactly as it found it and the host repeats the batch with the separate launches.
+//
+// Everything a lane does in a phase is written as "all loads, then all arithmetic, then all
+// stores": a workgroup has one or two waves per SIMD and nothing else hides an LDS round trip
+// (the first version, one dependent LDS access after the other, took 27 us per iteration).
+//
+// Arithmetic: element by element the expressions of k_cg_step1_ar / k_solve_pcr /
+// k_cg_step2_hp, row sums left to right, ||g||^2 and the residual summed per workgroup in the
+// order of k_solve_pcr's 256 lanes (lanes 256.. of this kernel's 512 sit those two sums out):
+// bit-identical to the three launches; p'Hp and ||x + alpha p||^2 are summed per
+// workgroup of THIS decomposition instead of per row tile of H / A, so alpha can differ in
+// the last bit (tests: 1e-13 relative over whole solves, identical branch decisions).
+#include "ipx_common.h"
+#include <algorithm>
+
+namespace {
+
+IPX_STAMP_DECL(ipx_dbg_res);
+#ifdef IPX_PHASE_TIMING     // (an interior workgroup: the edge ones have no left / right halo)
+#define RS_STAMP(k) \
+  do { if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) ipx_dbg_res[k] = wall_clock64(); } while (0)
+#define RS_STAMP_SYNC(k) do { ipx_lds_barrier(); RS_STAMP(k); } while (0)
+#else
+#define RS_STAMP(k) do { } while (0)
+#define RS_STAMP_SYNC(k) do { } while (0)
+#endif
+
+typedef unsigned long long ull;
+
+constexpr int RB = 512;       // threads per workgroup: two waves per SIMD, 256 registers per lane
+                              // (256 threads hold twice the static data per lane: the arch VGPRs
+                              // overflow into AGPR copies and 195 scratch words, reloaded in every
+                              // iteration -- 25 us per iteration, measured)
+constexpr int RNR = 1;        // window rows per lane    (<= 512)
+constexpr int RLA = 16;       // entries per row of A held in registers
+constexpr int RQS = 8;        // span doubles per lane   (<= 4096 columns)
+constexpr int RQX = 6;        // own variables per lane  (<= 3072)
+constexpr int RLH = 4;        // entries per row of H held in registers
+constexpr int RHK = 4;        // halo entries per lane and hop (2 * hw <= RHK * RB)
+constexpr int RQP = 3;        // pairs of own variables per lane
+constexpr int R_MAXWG = 256;
+constexpr int R_S2 = 2 * R_MAXWG;                  // word offset of the S2 records (8 words each)
+constexpr int R_HALO = R_S2 + 8 * R_MAXWG;         // word offset of the halo areas
+
+struct ResJob {
+  double *st;
+  int it_begin, it_end, n, m, rows_wg, L, nwg;
+  const double *band;
+  double *x, *p, *r, *Hp;
+  const double *A_val;
+  const uint16_t *A_off16;
+  const int32_t *A_rowfirst;
+  int rl;
+  const int32_t *win, *vown;
+  int nspan, navn;
+  const int32_t *ell_col;       // A' in ELL(2) form: entry t of variable j at [t * n + j]
+  const double *ell_val;
+  const int32_t *H_rowptr, *H_colidx;
+  const double *H_val, *H_diag;
+  int hmax;
+  double *part1, *part2, *part3, *part4;
+  int np1, np2, np3, np4;
+  ull *ll;
+  int hw;
+  uint32_t seq;
+  int no_xn2;
+  long long timeout;
+};
+
+// The packed index registers are unpacked INSIDE the loop: without this the compiler hoists
+// every unpacked LDS address out of it (loop invariant!) and holds ~100 more registers across
+// the whole batch -- which then spill to scratch and are reloaded in every iteration.
+__device__ __forceinline__ int res_opaque(int v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+__device__ __forceinline__ double res_rcp(double b) {        // (csrc/banded.hip pcr_rcp)
+  double r = __builtin_amdgcn_rcp(b);
+  return __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+}
+// One granule = the two tagged words of a double, written by ONE 16-byte write-through store
+// (8-byte sc1 stores are one fabric write each and cost 2.7x per byte: MI355X_MICROARCH.md,
+// stores table; every 8-byte half validates itself, so tearing between the halves is harmless)
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void ll_put(ull *dst, double v, uint32_t tag) {
+  const ull bits = (ull)__double_as_longlong(v);
+  u4 w;
+  w.x = (unsigned)(bits & 0xffffffffull); w.y = tag;
+  w.z = (unsigned)(bits >> 32);           w.w = tag;
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(w) : "memory");
+}
+__device__ __forceinline__ bool ll_hit(const u4 &w, uint32_t tag, double &v) {
+  if (w.y == tag && w.w == tag) {
+    v = __longlong_as_double((long long)((ull)w.x | ((ull)w.z << 32)));
+    return true;
+  }
+  return false;
+}
+__device__ __forceinline__ ull *halo_area(const ResJob &J, int wg, int area) {
+  return J.ll + R_HALO + ((int64_t)(wg * 4 + area) * J.hw) * 2;
+}
+// ipx_block_sum_multi with the wave count a compile-time constant: the partner sums of ALL
+// quantities are requested from LDS together and added in wave order.  (The library routine
+// loops to blockDim / 64 with one dependent LDS round trip per trip: 7 trips x NQ quantities
+// cost 1.1 us for NQ = 2 and 2.4 us for NQ = 4 here -- measured, the largest single item of
+// the first profile.)  Same order of additions: same bits.
+template <int NQ>
+__device__ __forceinline__ void res_block_sum(double (&v)[NQ], double *lds, double (&out)[NQ]) {
+  constexpr int NW = RB / 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    v[q] = ipx_wave_sum(v[q]);
+    if (lane == 0) lds[q * NW + wave] = v[q];
+  }
+  ipx_lds_barrier();
+  double t[NQ][NW];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+#pragma unroll
+    for (int w = 0; w < NW; ++w) t[q][w] = lds[q * NW + w];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    double r = t[q][0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) r += t[q][w];
+    out[q] = r;
+  }
+  ipx_lds_barrier();
+}
+
+// One hop: NS scalars per workgroup (lane t < nwg waits for workgroup t's record) and this
+// workgroup's left / right halo (nl + nr entries, from the neighbours' areas) into LDS at
+// dst_l / dst_r.  Every word of the lane is requested in ONE burst per pass (unconditional
+// loads, no branch between them), then the tags are checked.  false: a wait timed out.
+template <int NS>
+__device__ __forceinline__ bool hop_wait(const ResJob &J, int wg, uint32_t tag, const ull *scal,
+                                         int scal_stride, double (&sv)[NS], int nl, int nr,
+                                         int area_from_left, int area_from_right,
+                                         double *dst_l, double *dst_r, bool want_halo) {
+  const int tid = threadIdx.x;
+  const long long deadline = (long long)wall_clock64() + J.timeout;
+  bool sdone[NS];
+  const bool slane = tid < J.nwg;
+#pragma unroll
+  for (int q = 0; q < NS; ++q) { sdone[q] = !slane; sv[q] = 0.0; }
+  bool hdone[RHK];
+  double hv[RHK];
+  const ull *hsrc[RHK], *ssrc[NS];
+  const int nh = want_halo ? nl + nr : 0;
+  const ull *left = wg > 0 ? halo_area(J, wg - 1, area_from_left) : J.ll;
+  const ull *right = wg < J.nwg - 1 ? halo_area(J, wg + 1, area_from_right) : J.ll;
+#pragma unroll
+  for (int q = 0; q < NS; ++q) ssrc[q] = scal + (int64_t)(slane ? tid : 0) * scal_stride + 2 * q;
+#pragma unroll
+  for (int k = 0; k < RHK; ++k) {
+    const int e = tid + k * RB;
+    hdone[k] = e >= nh;
+    hv[k] = 0.0;
+    hsrc[k] = hdone[k] ? ssrc[0] : (e < nl ? left + 2 * e : right + 2 * (e - nl));
+  }
+  static_assert(RHK == 4, "the load burst below is written for four halo granules per lane");
+  while (true) {
+    // one burst of 16-byte L2 loads (sc1: never served from this CU's L1), one wait
+    // (ONE asm statement: a result must not be touched before the wait at its end)
+    u4 sw[3], hw0, hw1, hw2, hw3;
+    static_assert(NS == 1 || NS == 3, "hop_wait: one or three scalars per workgroup");
+    if constexpr (NS == 3) {
+      asm volatile("global_load_dwordx4 %0, %7, off sc1\n\t"
+                   "global_load_dwordx4 %1, %8, off sc1\n\t"
+                   "global_load_dwordx4 %2, %9, off sc1\n\t"
+                   "global_load_dwordx4 %3, %10, off sc1\n\t"
+                   "global_load_dwordx4 %4, %11, off sc1\n\t"
+                   "global_load_dwordx4 %5, %12, off sc1\n\t"
+                   "global_load_dwordx4 %6, %13, off sc1\n\t"
+                   "s_waitcnt vmcnt(0)"
+                   : "=&v"(sw[0]), "=&v"(sw[1]), "=&v"(sw[2]), "=&v"(hw0), "=&v"(hw1), "=&v"(hw2), "=&v"(hw3)
+                   : "v"(ssrc[0]), "v"(ssrc[1]), "v"(ssrc[2]), "v"(hsrc[0]), "v"(hsrc[1]), "v"(hsrc[2]), "v"(hsrc[3])
+                   : "memory");
+    } else {
+      asm volatile("global_load_dwordx4 %0, %5, off sc1\n\t"
+                   "global_load_dwordx4 %1, %6, off sc1\n\t"
+                   "global_load_dwordx4 %2, %7, off sc1\n\t"
+                   "global_load_dwordx4 %3, %8, off sc1\n\t"
+                   "global_load_dwordx4 %4, %9, off sc1\n\t"
+                   "s_waitcnt vmcnt(0)"
+                   : "=&v"(sw[0]), "=&v"(hw0), "=&v"(hw1), "=&v"(hw2), "=&v"(hw3)
+                   : "v"(ssrc[0]), "v"(hsrc[0]), "v"(hsrc[1]), "v"(hsrc[2]), "v"(hsrc[3])
+                   : "memory");
+    }
+    bool all = true;
+#pragma unroll
+    for (int q = 0; q < NS; ++q) {
+      double v;
+      if (!sdone[q] && ll_hit(sw[q], tag, v)) { sv[q] = v; sdone[q] = true; }
+      all = all && sdone[q];
+    }
+    {
+      const u4 hw[RHK] = {hw0, hw1, hw2, hw3};
+#pragma unroll
+      for (int k = 0; k < RHK; ++k) {
+        double v;
+        if (!hdone[k] && ll_hit(hw[k], tag, v)) { hv[k] = v; hdone[k] = true; }
+        all = all && hdone[k];
+      }
+    }
+    if (all) break;
+    if ((long long)wall_clock64() > deadline) return false;
+    __builtin_amdgcn_s_sleep(1);
+  }
+#pragma unroll
+  for (int k = 0; k < RHK; ++k) {
+    const int e = tid + k * RB;
+    if (e < nh) {
+      if (e < nl) dst_l[e] = hv[k]; else dst_r[e - nl] = hv[k];
+    }
+  }
+  return true;
+}
+
+// publish `cnt` doubles of LDS (src[0..cnt), cnt <= RHK/2 * RB) into one of this workgroup's areas
+__device__ __forceinline__ void halo_put(const ResJob &J, int wg, int area, const double *src,
+                                         int cnt, uint32_t tag) {
+  ull *dst = halo_area(J, wg, area);
+  double v[RHK / 2];
+#pragma unroll
+  for (int k = 0; k < RHK / 2; ++k) v[k] = src[min((int)threadIdx.x + k * RB, max(cnt - 1, 0))];
+#pragma unroll
+  for (int k = 0; k < RHK / 2; ++k) {
+    const int j = threadIdx.x + k * RB;
+    if (j < cnt) ll_put(dst + 2 * j, v[k], tag);
+  }
+}
+
+template <bool NOXN2, bool HAS_DIAG>
+__global__ void __launch_bounds__(RB, 2)
+k_cg_resident(ResJob J) {
+  extern __shared__ __attribute__((aligned(16))) double rs_lds[];
+  const int wg = blockIdx.x, tid = threadIdx.x;
+  const int H = 1 << J.L;
+  const int R = J.rows_wg + 2 * H;
+  const int RS = R + 2 * H;                         // PCR rows incl. identity padding
+  const int nspanP = (J.nspan + 1) & ~1;
+  const int npsp = (J.navn + 2 * J.hmax + 1) & ~1;
+  double *rspan = rs_lds;                           // r / r_next / g on the span
+  double *hspan = rspan + nspanP;                   // Hp on the span
+  double *U = hspan + nspanP;                       // PCR ping-pong (6 RS) | squares of g, of the residual
+  const int usize = max(6 * RS, ((J.navn + 2) & ~1) + RB);
+  double *sx = U + usize;                           // [R]: w, then v
+  double *pspan = sx + ((R + 1) & ~1);              // p on own +- hmax
+  double *aval = pspan + npsp;                      // A's window rows: [R * rl] values
+  const int navnE = (J.navn + 2) & ~1;              // (pairs may start one before av0)
+  double *red = aval + ((R * J.rl + 1) & ~1);       // [32] reductions
+  double *pa0 = U, *pa1 = U + RS, *pr0 = U + 2 * RS, *pr1 = U + 3 * RS, *pd0 = U + 4 * RS,
+         *pd1 = U + 5 * RS;
+
+  // ---- geometry
+  const int c_lo = J.win[2 * wg], c_hi = J.win[2 * wg + 1];
+  const int nspan = c_hi - c_lo;
+  const int av0 = J.vown[wg], av1 = J.vown[wg + 1], avn = av1 - av0;
+  const int nl = av0 - c_lo, nr = c_hi - av1;       // halo columns left / right of the own ones
+  const int pl = wg > 0 ? J.win[2 * (wg - 1) + 1] - av0 : 0;              // own entries the left /
+  const int pr = wg < J.nwg - 1 ? av1 - J.win[2 * (wg + 1)] : 0;          // right neighbour reads
+  const int own_off = av0 - c_lo;                   // span index of the first own variable
+  const int64_t g0 = (int64_t)wg * J.rows_wg - H;   // global row of window row 0
+  const int rl = J.rl;
+  const int p_lo = av0 - J.hmax;                    // column of pspan[0]
+
+  // ---- state words, p'Hp partials (requested first)
+  const double stop0 = J.st[ST_STOP];
+  double rt[2] = {J.st[ST_RTG0], J.st[ST_RTG1]};
+  const double tol = J.st[ST_TOL], radius = J.st[ST_RADIUS], orth_rhs = J.st[ST_ORTH_RHS];
+  const double *const fparts[1] = {J.part1 + J.np1};
+  const int fcounts[1] = {J.np1};
+  ipx_fold_regs<1, 4> fold;
+  fold.load(fparts, fcounts);
+
+  // ---- static data.  Where it lives was decided by measurement: everything in registers
+  // overflows the 256 a lane has at two waves per SIMD (the compiler also hoists every loop
+  // invariant address: res_opaque) and the overflow is reloaded from scratch one dependent
+  // round trip at a time (3.9 us in the H.p phase alone); re-reading A and H row-wise from L2
+  // every iteration is uncoalesced (a wave instruction touches 64 cache lines: +4 us per hop).
+  // So: H's own rows in registers, A's window rows in LDS (filled coalesced, once), A' (ELL,
+  // whose global layout IS lane-major) streamed from L2 under the cyclic reduction.
+  // (i) window row tid of A: values in LDS, span indices packed two per register; the band
+  double a0[RNR], b0[RNR];
+  bool row_in[RNR];
+  int ac2[RLA / 2];
+  {
+    const int r = tid;
+    const int64_t grow = g0 + r;
+    row_in[0] = r < R && grow >= 0 && grow < J.m;
+    const int64_t gc = min(max(grow, (int64_t)0), (int64_t)J.m - 1);
+    const int first = J.A_rowfirst[gc] - c_lo;
+#pragma unroll
+    for (int k = 0; k < RLA / 2; ++k) {
+      const int c0 = row_in[0] ? first + (int)J.A_off16[gc * rl + min(2 * k, rl - 1)] : 0;
+      const int c1 = row_in[0] ? first + (int)J.A_off16[gc * rl + min(2 * k + 1, rl - 1)] : 0;
+      ac2[k] = c0 | (c1 << 16);
+    }
+    const double bv = J.band[gc], avv = J.band[(int64_t)J.m + gc];
+    a0[0] = (row_in[0] && grow >= 1 && r >= 1) ? avv : 0.0;     // (row 0 of the window: cut)
+    b0[0] = row_in[0] ? bv : 1.0;
+  }
+  for (int i = tid; i < R * rl; i += RB) {
+    const int64_t kk = g0 * rl + i;                  // (window row i / rl, its entry i % rl)
+    aval[i] = (kk >= 0 && kk < (int64_t)J.m * rl) ? J.A_val[kk] : 0.0;
+  }
+  // (the sub-diagonal entry of the row below, for the residual of the own rows)
+  double a0n;
+  {
+    const int64_t gn = g0 + tid + 1;
+    const bool in = tid + 1 < R && gn >= 1 && gn < J.m;
+    a0n = in ? J.band[(int64_t)J.m + min(max(gn, (int64_t)0), (int64_t)J.m - 1)] : 0.0;
+  }
+  __builtin_amdgcn_sched_barrier(0);      // (keep the set-up's load groups apart: their
+                                          //  addresses and clamps would all be live at once)
+  // (ii) A' on the own variables, ELL(2): lane t takes the pairs (vb + 2 (t + RB k), +1) -- pairs
+  // start at an even variable like in k_solve_pcr's tail; the window rows of the entries in
+  // registers, the values re-read every iteration (16-byte loads, consecutive lanes consecutive
+  // pairs: the array's own layout)
+  const int64_t vb = av0 & ~1;
+  int ec2[RQP][2];               // window rows of (entry 0 | entry 1 << 16) of variables j, j + 1
+  {
+    const int64_t lastj = max((int64_t)av1 - 1, vb) & ~(int64_t)1;
+#pragma unroll
+    for (int k = 0; k < RQP; ++k) {
+      const int64_t j = min(vb + 2 * (int64_t)(tid + k * RB), lastj);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int64_t jj = min(j + u, (int64_t)J.n - 1);
+        const int c0 = min(max((int)(J.ell_col[jj] - g0), 0), R - 1);
+        const int c1 = min(max((int)(J.ell_col[(int64_t)J.n + jj] - g0), 0), R - 1);
+        ec2[k][u] = c0 | (c1 << 16);
+      }
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);      // (keep the set-up's load groups apart: their
+                                          //  addresses and clamps would all be live at once)
+  // (iii) own rows tid + k RB of H (absent entries: value 0 on a valid column, so the row sums
+  // need no length), x and the diagonal term on them
+  double hv[RQX][RLH], xo[RQX], dg[RQX];
+  int hc2[RQX][RLH / 2];         // pspan indices of the entries, two per register
+#pragma unroll
+  for (int k = 0; k < RQX; ++k) {
+    const int i = min(tid + k * RB, max(avn - 1, 0));
+    const int row = av0 + i;
+    const int a = J.H_rowptr[row], b = J.H_rowptr[row + 1];
+    const bool on = tid + k * RB < avn;
+    int cc[RLH];
+#pragma unroll
+    for (int t = 0; t < RLH; ++t) {
+      const int kk = min(a + t, max(b - 1, a));
+      const bool have = on && a + t < b;
+      const double v = J.H_val[kk];
+      const int c = J.H_colidx[kk];
+      hv[k][t] = have ? v : 0.0;
+      cc[t] = have ? c - p_lo : J.hmax;
+    }
+#pragma unroll
+    for (int t = 0; t < RLH / 2; ++t) hc2[k][t] = cc[2 * t] | (cc[2 * t + 1] << 16);
+    xo[k] = J.x[row];
+    dg[k] = HAS_DIAG ? J.H_diag[row] : 0.0;
+  }
+  __builtin_amdgcn_sched_barrier(0);      // (keep the set-up's load groups apart: their
+                                          //  addresses and clamps would all be live at once)
+  // ---- the vectors into LDS
+#pragma unroll
+  for (int k = 0; k < RQS; ++k) {
+    const int j = tid + k * RB;
+    if (j < nspan) { rspan[j] = J.r[c_lo + j]; hspan[j] = J.Hp[c_lo + j]; }
+  }
+  for (int j = tid; j < avn + 2 * J.hmax; j += RB) {
+    const int col = p_lo + j;
+    pspan[j] = (col >= 0 && col < J.n) ? J.p[col] : 0.0;
+  }
+  __builtin_amdgcn_sched_barrier(0);      // (keep the set-up's load groups apart: their
+                                          //  addresses and clamps would all be live at once)
+  if (stop0 != 0.0) return;                         // (every workgroup alike: nothing was written)
+  const bool lead = wg == 0 && tid == 0;
+  double ptHp;
+  {
+    double fout[1];
+    fold.finish(fparts, fcounts, red, fout);
+    ptHp = fout[0];
+  }
+  // bookkeeping (written back by the lead lane after the commit hop)
+  double st_alpha = J.st[ST_ALPHA], st_beta = J.st[ST_BETA], st_pthp = J.st[ST_PTHP];
+  double st_xn2 = J.st[ST_XNORM2], st_orth = J.st[ST_ORTH];
+  int niter_inc = 0, done_inc = 0, stop = 0;
+  uint32_t hop = 0;                                 // hops so far: tag = J.seq + hop
+  double part_xn2 = 0.0, part_gg = 0.0, part_tt = 0.0;   // totals of the last projection
+  bool have_proj = false;
+  ull *S1 = J.ll, *S2 = J.ll + R_S2;
+
+  const int tid0 = tid;
+  for (int it = J.it_begin; it < J.it_end; ++it) {
+    // (an opaque copy of the lane index per iteration: nothing computed from it -- LDS
+    // addresses, clamps, predicates -- is a loop invariant the compiler could hoist and hold in
+    // registers across the batch; measured: 130 of 262 loop-carried registers were such)
+    const int tid = res_opaque(tid0);
+    const int par = it & 1;
+    const double rtg = rt[par];
+    if (rtg < tol) { stop = 4; break; }                      // qp_subproblem.py:551
+    if (ptHp <= 0.0) { niter_inc += 1; st_pthp = ptHp; stop = 3; break; }   // :558
+    const double alpha = rtg / ptHp;                          // :579
+    niter_inc += 1; st_pthp = ptHp; st_alpha = alpha;
+    RS_STAMP(0);
+    // ================= phase P: r_next, w = A r_next, cyclic reduction, g ====================
+    ipx_lds_barrier();
+#pragma unroll
+    for (int k0 = 0; k0 < RQS; k0 += 4) {
+      double rv[4], hh[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int j = min(tid + (k0 + k) * RB, nspan - 1);
+        rv[k] = rspan[j]; hh[k] = hspan[j];
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int j = tid + (k0 + k) * RB;
+        if (j < nspan) rspan[j] = rv[k] + alpha * hh[k];                 // :622
+      }
+    }
+    double sxx = 0.0;
+    if (!NOXN2) {
+#pragma unroll
+      for (int k0 = 0; k0 < RQX; k0 += 6) {
+        double pv[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) pv[k] = pspan[J.hmax + min(tid + (k0 + k) * RB, avn - 1)];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          if (tid + (k0 + k) * RB < avn) {
+            const double xn = xo[k0 + k] + alpha * pv[k];                // :580 (not stored)
+            sxx += xn * xn;
+          }
+        }
+      }
+    }
+    ipx_lds_barrier();
+    RS_STAMP(1);
+    // w on the window rows: row sums left to right out of registers (scipy's csr_matvec order)
+    double a[RNR], b[RNR], d[RNR], w0[RNR];
+    {
+      const double *arow = aval + min(tid, R - 1) * rl;
+      double sum = 0.0;
+#pragma unroll
+      for (int k0 = 0; k0 < RLA; k0 += 8) {
+        double rr[8], aa[8];
+#pragma unroll
+        for (int k = 0; k < 8; k += 2) {
+          const int pk = res_opaque(ac2[(k0 + k) >> 1]);
+          rr[k] = rspan[pk & 0xffff];
+          rr[k + 1] = rspan[(pk >> 16) & 0xffff];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) aa[k] = arow[min(k0 + k, rl - 1)];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (k0 + k < rl) sum += aa[k] * rr[k];
+      }
+      d[0] = row_in[0] ? 1.0 * sum : 0.0;
+      w0[0] = d[0]; a[0] = a0[0]; b[0] = b0[0];
+    }
+    RS_STAMP(2);
+    // (the values of A' for the tail, requested now, used after the cyclic reduction)
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    v2d e0[RQP], e1[RQP];
+    {
+      const int64_t lastj = max((int64_t)av1 - 1, vb) & ~(int64_t)1;
+#pragma unroll
+      for (int k = 0; k < RQP; ++k) {
+        const int64_t j = min(vb + 2 * (int64_t)(tid + k * RB), lastj);
+        e0[k] = *reinterpret_cast<const v2d *>(J.ell_val + j);
+        e1[k] = *reinterpret_cast<const v2d *>(J.ell_val + (int64_t)J.n + j);
+      }
+    }
+    // cyclic reduction on the window (k_solve_pcr's arithmetic)
+    for (int i = tid; i < 2 * H; i += RB) {
+      const int r = i < H ? i : R + i;                // storage index = window row + H
+      pa0[r] = 0.0; pr0[r] = 1.0; pd0[r] = 0.0;
+      pa1[r] = 0.0; pr1[r] = 1.0; pd1[r] = 0.0;
+    }
+    for (int sl = 0; sl < J.L; ++sl) {
+      const int h = 1 << sl;
+      double *pa = (sl & 1) ? pa1 : pa0, *pr_ = (sl & 1) ? pr1 : pr0, *pd = (sl & 1) ? pd1 : pd0;
+#pragma unroll
+      for (int q = 0; q < RNR; ++q) {
+        const int r = tid + q * RB;
+        const double rc = res_rcp(b[q]);
+        if (r < R) { pa[H + r] = a[q]; pr_[H + r] = rc; pd[H + r] = d[q]; }
+      }
+      ipx_lds_barrier();
+      double alo[RNR], rlo_[RNR], dlo[RNR], ahi[RNR], rhi_[RNR], dhi[RNR];
+#pragma unroll
+      for (int q = 0; q < RNR; ++q) {
+        const int r = H + min(tid + q * RB, R - 1);
+        alo[q] = pa[r - h]; rlo_[q] = pr_[r - h]; dlo[q] = pd[r - h];
+        ahi[q] = pa[r + h]; rhi_[q] = pr_[r + h]; dhi[q] = pd[r + h];
+      }
+#pragma unroll
+      for (int q = 0; q < RNR; ++q) {
+        const double al = -a[q] * rlo_[q], ga = -ahi[q] * rhi_[q];
+        double bn = __builtin_fma(al, a[q], b[q]);
+        bn = __builtin_fma(ga, ahi[q], bn);
+        double dn = __builtin_fma(al, dlo[q], d[q]);
+        dn = __builtin_fma(ga, dhi[q], dn);
+        a[q] = al * alo[q]; b[q] = bn; d[q] = dn;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < RNR; ++q) {
+      const int r = tid + q * RB;
+      if (r < R) sx[r] = d[q] / b[q];
+    }
+    ipx_lds_barrier();
+    RS_STAMP(3);
+    // g = r_next - A'v on the own variables: the expressions of k_solve_pcr's tail; g replaces r
+    // on the span, its squares go to LDS and are added up in THAT kernel's order (its lane t
+    // takes the pairs t, t + 256, ...: same bits of ||g||^2)
+    double *gsq = U;                                  // [2 * pairs] (the PCR buffers are free)
+    {
+      double v4[RQP][4], rn[RQP][2];
+#pragma unroll
+      for (int k = 0; k < RQP; ++k) {
+        const int64_t j = vb + 2 * (int64_t)(tid + k * RB);
+        const int s0 = (int)min(max(j - c_lo, (int64_t)0), (int64_t)nspan - 1);
+        const int s1 = (int)min(max(j + 1 - c_lo, (int64_t)0), (int64_t)nspan - 1);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int pk = res_opaque(ec2[k][u]);
+          v4[k][2 * u] = sx[pk & 0xffff];
+          v4[k][2 * u + 1] = sx[(pk >> 16) & 0xffff];
+        }
+        rn[k][0] = rspan[s0]; rn[k][1] = rspan[s1];
+      }
+#pragma unroll
+      for (int k = 0; k < RQP; ++k) {
+        const int64_t j = vb + 2 * (int64_t)(tid + k * RB);
+        double y0 = -1.0 * (e0[k].x * v4[k][0] + e1[k].x * v4[k][1]);
+        y0 += 1.0 * rn[k][0];
+        double y1 = -1.0 * (e0[k].y * v4[k][2] + e1[k].y * v4[k][3]);
+        y1 += 1.0 * rn[k][1];
+        const bool in0 = j >= av0 && j < (int64_t)av1;
+        const bool in1 = j + 1 >= av0 && j + 1 < (int64_t)av1;
+        if (in0) rspan[j - c_lo] = y0;
+        if (in1) rspan[j + 1 - c_lo] = y1;
+        if (j - vb < navnE) { gsq[j - vb] = in0 ? y0 * y0 : 0.0; gsq[j - vb + 1] = in1 ? y1 * y1 : 0.0; }
+      }
+    }
+    RS_STAMP(4);
+    // the halo of g leaves as soon as g is complete (the scalars follow after the sums below:
+    // the transfer overlaps them); hop 2's tag
+    ipx_lds_barrier();
+    halo_put(J, wg, 2, rspan + own_off, pl, J.seq + hop + 1);                 // to the left neighbour
+    halo_put(J, wg, 3, rspan + own_off + avn - pr, pr, J.seq + hop + 1);      // to the right neighbour
+    // residual of the own rows:  w_i - (a_i v_{i-1} + b_i v_i + a_{i+1} v_{i+1}), squared; summed
+    // like ||g||^2 in the order of k_solve_pcr (its lane t: row t, then row t + 256)
+    double *rsq = U + navnE;                          // (behind gsq: navnE + RB doubles of U)
+    {
+      const int r = min(max(tid, 1), R - 2);
+      const double vm = sx[r - 1], vc = sx[r], vp = sx[r + 1];
+      double res2 = 0.0;
+      if (tid >= H && tid < H + J.rows_wg && g0 + tid < J.m) {
+        double sum = b0[0] * vc;
+        sum += a0[0] * vm;
+        sum += a0n * vp;
+        const double res = w0[0] - sum;
+        res2 = res * res;
+      }
+      rsq[tid] = res2;
+    }
+    ipx_lds_barrier();
+    double gacc = 0.0, acc = 0.0;
+    if (tid < 256) {
+      double q2[2 * ((RQP * RB) / 256)];
+#pragma unroll
+      for (int k = 0; k < (RQP * RB) / 256; ++k) {
+        const int jl = min(2 * (tid + k * 256), navnE - 2);
+        q2[2 * k] = gsq[jl]; q2[2 * k + 1] = gsq[jl + 1];
+      }
+      const double r0_ = rsq[tid], r1_ = rsq[tid + 256];
+#pragma unroll
+      for (int k = 0; k < (RQP * RB) / 256; ++k)
+        if (2 * (tid + k * 256) < navnE) { gacc += q2[2 * k]; gacc += q2[2 * k + 1]; }
+      acc += r0_; acc += r1_;
+    }
+    double mine3[3];
+    {
+      // ||x + alpha p||^2 over all lanes; ||g||^2 and the residual over the first four waves,
+      // waves in order (a 256-thread ipx_block_reduce)
+      const int lane = tid & 63, wave = tid >> 6;
+      const double s0 = ipx_wave_sum(sxx), s1 = ipx_wave_sum(gacc), s2 = ipx_wave_sum(acc);
+      if (lane == 0) { red[wave] = s0; red[8 + wave] = s1; red[16 + wave] = s2; }
+      ipx_lds_barrier();
+      double t0[RB / 64], t1[4], t2[4];
+#pragma unroll
+      for (int w = 0; w < RB / 64; ++w) t0[w] = red[w];
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { t1[w] = red[8 + w]; t2[w] = red[16 + w]; }
+      double r0 = t0[0], r1 = t1[0], r2 = t2[0];
+#pragma unroll
+      for (int w = 1; w < RB / 64; ++w) r0 += t0[w];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) { r1 += t1[w]; r2 += t2[w]; }
+      mine3[0] = r0; mine3[1] = r1; mine3[2] = r2;
+      ipx_lds_barrier();
+    }
+    RS_STAMP(5);
+    // ================= hop 2: partials + halo of g ===========================================
+    ++hop;
+    {
+      const uint32_t tag = J.seq + hop;
+      if (tid < 3) ll_put(S2 + 8 * wg + 2 * tid, tid == 0 ? mine3[0] : (tid == 1 ? mine3[1] : mine3[2]), tag);
+      double sv[4];
+      {
+        double s3[3];
+        const bool ok = hop_wait<3>(J, wg, tag, S2, 8, s3, nl, nr, 3, 2, rspan, rspan + own_off + avn, true);
+        sv[0] = s3[0]; sv[1] = s3[1]; sv[2] = s3[2]; sv[3] = ok ? 0.0 : 1.0;
+      }
+      RS_STAMP(6);
+      RS_STAMP_SYNC(12);
+      double tot[4];
+      res_block_sum<4>(sv, red, tot);                // (barriers inside: the halo is in LDS)
+      if (tot[3] != 0.0) { if (tid == 0) J.st[ST_STOP] = 8.0; return; }
+      part_xn2 = tot[0]; part_gg = tot[1]; part_tt = tot[2];
+      have_proj = true;
+    }
+    if (!NOXN2) {
+      if (sqrt(part_xn2) >= radius) { st_xn2 = part_xn2; stop = 2; break; }      // :583
+    }
+    const double gg = part_gg;
+    if (orth_rhs > 0.0 && gg > 0.0 && sqrt(part_tt) > orth_rhs * sqrt(gg)) {     // projections.py:72
+      st_orth = sqrt(part_tt) / sqrt(gg); stop = 6; break;
+    }
+    const double beta = gg / rtg;                             // :627
+    rt[par ^ 1] = gg;                                         // :633
+    st_beta = beta;
+    done_inc += 1;
+    RS_STAMP(7);
+    // ================= phase H: x, p, Hp = H p ================================================
+    {
+      // x_next on the own variables, then p_next on own +- hmax (lane: entries tid + k RB of
+      // pspan): every old value is read before the barrier, every new one written after it
+      double po[RQX + 1], gv[RQX + 1];
+      const int np_ = avn + 2 * J.hmax;
+#pragma unroll
+      for (int k0 = 0; k0 < RQX; k0 += 6) {
+        double px[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) px[k] = pspan[J.hmax + min(tid + (k0 + k) * RB, avn - 1)];
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+          if (tid + (k0 + k) * RB < avn) xo[k0 + k] = xo[k0 + k] + alpha * px[k];   // :580,630
+      }
+#pragma unroll
+      for (int k = 0; k < RQX + 1; ++k) {
+        const int j = min(tid + k * RB, np_ - 1);
+        const int col = min(max(p_lo + j, 0), J.n - 1);
+        po[k] = pspan[j];
+        gv[k] = rspan[col - c_lo];
+      }
+      ipx_lds_barrier();
+#pragma unroll
+      for (int k = 0; k < RQX + 1; ++k) {
+        const int j = tid + k * RB;
+        const int col = p_lo + j;
+        if (j < np_ && col >= 0 && col < J.n) pspan[j] = beta * po[k] - gv[k];     // :628
+      }
+    }
+    ipx_lds_barrier();
+    RS_STAMP(8);
+    double acc_xy = 0.0;
+#pragma unroll
+    for (int k0 = 0; k0 < RQX; k0 += 3) {
+      double pp[3][RLH], xr[3], y[3];
+#pragma unroll
+      for (int kk = 0; kk < 3; ++kk) {
+        const int k = k0 + kk;
+#pragma unroll
+        for (int t = 0; t < RLH; t += 2) {
+          const int pk = res_opaque(hc2[k][t >> 1]);
+          pp[kk][t] = pspan[pk & 0xffff];
+          pp[kk][t + 1] = pspan[(pk >> 16) & 0xffff];
+        }
+        xr[kk] = pspan[J.hmax + min(tid + k * RB, avn - 1)];
+      }
+#pragma unroll
+      for (int kk = 0; kk < 3; ++kk) {
+        const int k = k0 + kk;
+        double sum = 0.0;
+#pragma unroll
+        for (int t = 0; t < RLH; ++t) sum += hv[k][t] * pp[kk][t];       // (absent entries: + 0.0)
+        y[kk] = 1.0 * sum;
+        if (HAS_DIAG) y[kk] += dg[k] * xr[kk];
+        if (tid + k * RB < avn) acc_xy += xr[kk] * y[kk];
+      }
+      // (hspan is written here and read nowhere in this phase)
+#pragma unroll
+      for (int kk = 0; kk < 3; ++kk)
+        if (tid + (k0 + kk) * RB < avn) hspan[own_off + tid + (k0 + kk) * RB] = y[kk];
+    }
+    if (it + 1 != J.it_end) {                         // (the halo of Hp: hop 1's tag; as above)
+      ipx_lds_barrier();
+      halo_put(J, wg, 0, hspan + own_off, pl, J.seq + hop + 1);
+      halo_put(J, wg, 1, hspan + own_off + avn - pr, pr, J.seq + hop + 1);
+    }
+    double mine1[1], loc1[1] = {acc_xy};
+    res_block_sum<1>(loc1, red, mine1);         // (barriers inside: Hp is complete on the own part)
+    RS_STAMP(9);
+    // ================= hop 1: p'Hp + halo of Hp (the last one of the launch: commit) =========
+    ++hop;
+    {
+      const uint32_t tag = J.seq + hop;
+      const bool last = it + 1 == J.it_end;
+      if (tid == 0) ll_put(S1 + 2 * wg, mine1[0], tag);
+      double sv[2];
+      {
+        double s1[1];
+        const bool ok = hop_wait<1>(J, wg, tag, S1, 2, s1, nl, nr, 1, 0, hspan, hspan + own_off + avn, !last);
+        sv[0] = s1[0]; sv[1] = ok ? 0.0 : 1.0;
+      }
+      RS_STAMP(10);
+      RS_STAMP_SYNC(13);
+      double tot[2];
+      res_block_sum<2>(sv, red, tot);
+      if (tot[1] != 0.0) { if (tid == 0) J.st[ST_STOP] = 8.0; return; }
+      ptHp = tot[0];
+      RS_STAMP(11);
+    }
+  }
+  if (stop != 0) {
+    // commit hop of a stopped launch: every workgroup took the same branch at the same
+    // iteration (the reduced scalars are the same bits everywhere)
+    ++hop;
+    const uint32_t tag = J.seq + hop;
+    if (tid == 0) ll_put(S1 + 2 * wg, 0.0, tag);
+    double sv[2], s1[1];
+    const bool ok = hop_wait<1>(J, wg, tag, S1, 2, s1, 0, 0, 1, 0, hspan, hspan, false);
+    sv[0] = 0.0; sv[1] = ok ? 0.0 : 1.0;
+    double tot[2];
+    res_block_sum<2>(sv, red, tot);
+    if (tot[1] != 0.0) { if (tid == 0) J.st[ST_STOP] = 8.0; return; }
+  }
+  // ================= write-back (every workgroup has passed the launch's last hop) ===========
+  ipx_lds_barrier();
+#pragma unroll
+  for (int k = 0; k < RQX; ++k) {
+    const int i = tid + k * RB;
+    if (i < avn) {
+      J.x[av0 + i] = xo[k];
+      J.p[av0 + i] = pspan[J.hmax + i];
+      J.r[av0 + i] = rspan[own_off + i];
+      J.Hp[av0 + i] = hspan[own_off + i];
+    }
+  }
+  // partial arrays as the separate launches' consumers fold them: the total in entry 0, zeros
+  // behind it (x + 0.0 = x: the next fold returns the same bits)
+  const int gtid = wg * RB + tid, gn = J.nwg * RB;
+  for (int i = gtid + 1; i < J.np1; i += gn) J.part1[J.np1 + i] = 0.0;
+  if (have_proj && (stop == 2 || stop == 6)) {
+    for (int i = gtid + 1; i < 2 * J.np2; i += gn) J.part2[i] = 0.0;
+    for (int i = gtid + 1; i < J.np3; i += gn) J.part3[i] = 0.0;
+    for (int i = gtid + 1; i < J.np4; i += gn) J.part4[i] = 0.0;
+  }
+  if (lead) {
+    J.part1[J.np1] = ptHp;
+    if (have_proj && (stop == 2 || stop == 6)) {
+      J.part2[0] = part_xn2; J.part3[0] = part_gg; J.part4[0] = part_tt;
+    }
+    J.st[ST_RTG0] = rt[0]; J.st[ST_RTG1] = rt[1];
+    J.st[ST_ALPHA] = st_alpha; J.st[ST_BETA] = st_beta; J.st[ST_PTHP] = st_pthp;
+    J.st[ST_XNORM2] = st_xn2; J.st[ST_ORTH] = st_orth;
+    J.st[ST_NITER] += (double)niter_inc;
+    J.st[ST_IT_DONE] += (double)done_inc;
+    if (stop != 0) J.st[ST_STOP] = (double)stop;
+  }
+}
+
+size_t resident_lds_bytes(int nspan, int navn, int hmax, int rows_wg, int L, int rl) {
+  const int H = 1 << L, R = rows_wg + 2 * H, RS = R + 2 * H;
+  const int nspanP = (nspan + 1) & ~1;
+  const int npsp = (navn + 2 * hmax + 1) & ~1;
+  const int navnE = (navn + 2) & ~1;
+  const int usize = std::max(6 * RS, navnE + RB);
+  return sizeof(double) * (size_t)(2 * nspanP + usize + ((R + 1) & ~1) + npsp + ((R * rl + 1) & ~1) + 32);
+}
+
+}  // namespace
+
+IPX_STAMP_EXPORT(ipx_debug_stamps_res, ipx_dbg_res)
+
+// words of the hand-off buffer for `nwg` workgroups with halos of up to `hw` entries
+extern "C" int64_t ipx_cg_resident_ll_words(int32_t nwg, int32_t hw) {
+  return (int64_t)R_HALO + (int64_t)nwg * 4 * hw * 2;
+}
+
+// 1 when the argument block can run the resident form (sizes within the kernel's budgets)
+extern "C" int ipx_cg_resident_ok(const ipx_cg_args *a) {
+  if (!a || !a->resident || !a->R_ll || !a->R_seq || a->solver_kind != 0 || a->lb || a->m <= 0 ||
+      !a->P_win || !a->A_off16 || !a->A_rowfirst || a->A_rl < 1 || a->A_rl > RLA || !a->At_vown ||
+      !a->At_ell_col || !a->At_ell_val || a->H_operator || !a->H_rowptr || a->H_hmax < 1 ||
+      a->H_hmax > 64 || (a->n & 1) || a->n > (1 << 26) || a->m * a->A_rl > (1ll << 30))
+    return 0;
+  ipx_pcr_view pv;
+  if (!ipx_banded_pcr_view(a->banded, &pv)) return 0;
+  const int H = 1 << pv.L, R = pv.rows_wg + 2 * H;
+  const int navnE = ((int)a->P_navn + 2) & ~1;
+  if (pv.nwg > 224 || R > RNR * RB || H < 1 || a->P_nspan > RQS * RB || a->P_nspan < 1 ||
+      a->P_navn < 1 || a->P_navn > RQX * RB || navnE > 2 * RB * RQP || 2 * a->R_hw > RHK * RB ||
+      a->R_hw < 1 || a->P_navn + 2 * a->H_hmax > (RQX + 1) * RB)
+    return 0;
+  if (resident_lds_bytes((int)a->P_nspan, (int)a->P_navn, (int)a->H_hmax, pv.rows_wg, pv.L, (int)a->A_rl) > 158 * 1024)
+    return 0;
+  return 1;
+}
+
+// iterations [it_begin, it_end) in one resident launch (see the top of this file)
+int ipx_cg_resident_launch(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, int np1, int np2,
+                           int np3, int np4, hipStream_t st) {
+  if (!ipx_cg_resident_ok(a) || it_end <= it_begin) return IPX_EINVAL;
+  ipx_pcr_view pv;
+  ipx_banded_pcr_view(a->banded, &pv);
+  ResJob J;
+  J.st = a->state; J.it_begin = it_begin; J.it_end = it_end; J.n = (int)a->n; J.m = pv.m;
+  J.rows_wg = pv.rows_wg; J.L = pv.L; J.nwg = pv.nwg; J.band = pv.band;
+  J.x = a->x; J.p = a->p; J.r = a->r; J.Hp = a->Hp;
+  J.A_val = a->A_val; J.A_off16 = (const uint16_t *)a->A_off16; J.A_rowfirst = a->A_rowfirst;
+  J.rl = (int)a->A_rl; J.win = a->P_win; J.vown = a->At_vown; J.nspan = (int)a->P_nspan;
+  J.navn = (int)a->P_navn;
+  J.ell_col = a->At_ell_col; J.ell_val = a->At_ell_val;
+  J.H_rowptr = a->H_rowptr; J.H_colidx = a->H_colidx; J.H_val = a->H_val; J.H_diag = a->H_diag;
+  J.hmax = (int)a->H_hmax;
+  J.part1 = a->part1; J.part2 = a->part2; J.part3 = a->part3; J.part4 = a->part4;
+  J.np1 = np1; J.np2 = np2; J.np3 = np3; J.np4 = np4;
+  J.ll = (ull *)a->R_ll; J.hw = (int)a->R_hw;
+  J.no_xn2 = a->no_radius != 0;
+  J.timeout = 200000000LL;                           // 2 s of the 100 MHz wall clock
+  // tags: strictly increasing over the life of the buffer (2 per iteration + the commit)
+  const int64_t need = 2 * (int64_t)(it_end - it_begin) + 2;
+  if (*a->R_seq + need >= 0xfffffff0LL) {
+    if (hipMemsetAsync(a->R_ll, 0, (size_t)ipx_cg_resident_ll_words(pv.nwg, J.hw) * 8, st) != hipSuccess)
+      return IPX_ELAUNCH;
+    *a->R_seq = 0;
+  }
+  J.seq = (uint32_t)*a->R_seq;
+  *a->R_seq += need;
+  const size_t lds = resident_lds_bytes(J.nspan, J.navn, J.hmax, J.rows_wg, J.L, J.rl);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void *)k_cg_resident<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_cg_resident<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_cg_resident<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_cg_resident<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
+    attr_set = true;
+  }
+  const dim3 grid(pv.nwg), block(RB);
+  if (J.no_xn2) {
+    if (J.H_diag) hipLaunchKernelGGL((k_cg_resident<true, true>), grid, block, lds, st, J);
+    else hipLaunchKernelGGL((k_cg_resident<true, false>), grid, block, lds, st, J);
+  } else {
+    if (J.H_diag) hipLaunchKernelGGL((k_cg_resident<false, true>), grid, block, lds, st, J);
+    else hipLaunchKernelGGL((k_cg_resident<false, false>), grid, block, lds, st, J);
+  }
+  IPX_CHECK_LAUNCH();
+  return IPX_OK;
+}

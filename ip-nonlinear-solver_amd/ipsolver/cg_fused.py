@@ -43,13 +43,15 @@ class CgArgs(ctypes.Structure):
         ("At_ell_col", _P), ("At_ell_val", _P),
         ("H_col16", _P), ("H_rowlen", _P), ("A_col16", _P), ("no_radius", _I64),
         ("A_off16", _P), ("A_rowfirst", _P), ("A_rl", _I64), ("P_win", _P), ("P_nspan", _I64),
-        ("P_navn", _I64), ("H_operator", _I64))]
+        ("P_navn", _I64), ("H_operator", _I64),
+        ("resident", _I64), ("R_ll", _P), ("R_hw", _I64), ("R_seq", _P))]
 
 
 # Counters over the life of the process (diagnostics: how often the device loop
 # had to hand an iteration back to the host).
 STATS = {"calls": 0, "iterations": 0, "batches": 0, "box_events": 0, "refine_events": 0,
-         "project_calls": 0,      # project_calls: solves that ran the one-launch projection
+         "resident_calls": 0,     # solves whose batches ran as resident launches (csrc/resident.hip)
+         "resident_fallbacks": 0, # batches repeated on the separate launches (stop code 8)
          "operator_calls": 0}     # solves whose Hessian was an operator applied by the host
 
 
@@ -281,11 +283,13 @@ def ell_rows(At):
     return col, val
 
 
-PF_U, PF_QS, PF_QX = 23, 16, 12      # csrc/banded.hip k_project_fused
+PF_U, PF_QS, PF_QX = 23, 16, 12      # csrc/resident.hip RU, RQS, RQX
+RES_MAX_WG, RES_RLH, RES_HK = 224, 4, 8      # csrc/resident.hip: workgroups, entries per row of
+                                             # H in registers, halo entries per lane and hop
 
 
 def fuse_project(pattern, vown_h, rows_wg, nwg, H):
-    """Tables of the one-launch projection (csrc/banded.hip k_project_fused) for a Jacobian
+    """Window tables of the resident loop kernel (csrc/resident.hip) for a Jacobian
     pattern and the geometry of the cyclic-reduction solve, or None: every row has the same
     number ``rl`` of entries; per entry its column as a 16-bit offset from the row's first
     column; per workgroup of the solve the span of columns it needs (its window's rows -- own
@@ -319,14 +323,20 @@ def fuse_project(pattern, vown_h, rows_wg, nwg, H):
                 c_hi = np.maximum(cmax + 1, vown_h[1:])
                 nspan = int(np.max(c_hi - c_lo))
                 avn = int(np.max(np.diff(vown_h)))
-                # own variables must lie inside what the window's rows cover or be untouched
-                lds = 8 * (nspan + max(6 * (R + 2 * H), avn) + R + 16)
-                if nspan <= PF_QS * 256 and 0 < avn <= PF_QX * 256 and lds <= 80 * 1024:
+                # a workgroup's span may reach into its two neighbours' variables only (the
+                # halos travel between neighbours): hw = the longest halo, either side
+                nl, nr = vown_h[:-1] - c_lo, c_hi - vown_h[1:]
+                near = np.all(c_lo[1:] >= vown_h[:-2]) and np.all(c_hi[:-1] <= vown_h[2:])
+                hw = int(max(nl.max(), nr.max(), 1))
+                if nspan <= PF_QS * 256 and 0 < avn <= PF_QX * 256 and near \
+                        and nwg <= RES_MAX_WG and 2 * hw <= RES_HK * 256:
                     dev = ctx().device
                     win = np.stack((c_lo, c_hi), 1).ravel().astype(np.int32)
+                    # (inner boundaries: the smallest halo, which must cover the Hessian's)
+                    inner = int(min(nl[1:].min(), nr[:-1].min())) if nwg > 1 else 1 << 30
                     out = (torch.from_numpy(off.ravel().astype(np.uint16).view(np.int16)).to(dev),
                            torch.from_numpy(first.astype(np.int32)).to(dev), rl,
-                           torch.from_numpy(win).to(dev), nspan, avn)
+                           torch.from_numpy(win).to(dev), nspan, avn, hw, inner)
     pattern._ipx_project = (key, out)
     return out
 
@@ -384,7 +394,7 @@ def _signature(H, P, lb, ub):
         return None                      # operator Hessians: not pooled
     Hc, Hd = _hessian_parts(H)
     flags = tuple(bool(os.environ.get(k)) for k in ("IPX_NO_FUSE", "IPX_NO_C16", "IPX_FUSE_TN",
-                                                    "IPX_TAIL_MAXWG", "IPX_PROJECT"))
+                                                    "IPX_TAIL_MAXWG", "IPX_NO_RESIDENT"))
     return (id(Hc.pattern), Hd is None, id(P.A.pattern), lb is None, ub is None,
             _solver_kind(P.solver), int(getattr(P.solver, "k", 0)), flags)
 
@@ -431,7 +441,7 @@ class _Loop:
                 return False
             if self.pcr_L is not None and \
                     int(lib.ipx_banded_pcr_level(ctypes.c_void_p(P.solver.handle))) != self.pcr_L:
-                return False            # the one-launch projection's windows follow 2^L
+                return False            # the resident kernel's windows follow 2^L
             a.banded = ctypes.c_void_p(P.solver.handle)
         else:
             a.banded = ctypes.cast(ctypes.pointer(P.solver.c_args()), ctypes.c_void_p)
@@ -448,7 +458,7 @@ class _Loop:
         self.keep = (A, At, Hc, Hd, lb, ub, P)
         return True
 
-    def __init__(self, H, P, lb, ub):
+    def __init__(self, H, P, lb, ub, resident=None):
         from .dense import DeviceDense
         self.geometry, self.pcr_L, self.operator = None, None, None
         if isinstance(P.A, DeviceDense):
@@ -551,27 +561,31 @@ class _Loop:
                     if n % 2 == 0 and kS == 1:
                         self.ell_col, self.ell_val = ell_rows(At)
                         a.At_ell_col, a.At_ell_val = _ptr(self.ell_col), _ptr(self.ell_val)
-                    # cyclic-reduction solve, uniform rows, no box: the whole projection step
-                    # (step1, A.r, the solve, g = r - A'v) as ONE launch -- OPT-IN (IPX_PROJECT=1).
-                    # Measured (round 3, MI355X, n = 1e6): one launch and 31 MB less traffic per
-                    # iteration, but 59 KB of LDS and 256 registers per lane leave 1.5 workgroups
-                    # per CU on one long dependent chain (loads -> alpha -> products -> reduction
-                    # -> scatter -> tail): 23.0 us against 10.3 + 11.5 us for the two separate
-                    # kernels with an infinite trust radius, 45 us against 23.8 us with a finite
-                    # one (register spills); 170 us against 62 us at n = 4e6.  Same bits.
+                    # small problems (one CU per workgroup of the cyclic-reduction solve: the
+                    # per-rank sizes of a multi-GPU run), uniform rows, no box, short Hessian
+                    # rows: a whole batch of iterations as ONE resident launch
+                    # (csrc/resident.hip) -- 21.8 -> ~7 us per iteration at n = 1.25e5
+                    # (profiles/r04_per_rank_sweep.json).  resident=False: the separate launches.
                     L_pcr = int(lib.ipx_banded_pcr_level(ctypes.c_void_p(P.solver.handle)))
-                    if kS == 1 and L_pcr > 0 and lb is None and n % 2 == 0 \
-                            and os.environ.get("IPX_PROJECT"):
+                    if resident is None and os.environ.get("IPX_NO_RESIDENT"):
+                        resident = False
+                    if kS == 1 and L_pcr > 0 and lb is None and hmax > 0 and resident is not False \
+                            and int(np.max(np.diff(Hc.pattern.indptr_h))) <= RES_RLH:
                         pj = fuse_project(A.pattern, self.vown.cpu().numpy().astype(np.int64),
                                           geo[0], geo[1], 1 << L_pcr)
-                        if pj is not None:
+                        if pj is not None and hmax <= pj[7]:
                             self.proj_tabs = pj
                             a.A_off16, a.A_rowfirst, a.A_rl = _ptr(pj[0]), _ptr(pj[1]), pj[2]
                             a.P_win, a.P_nspan, a.P_navn = _ptr(pj[3]), pj[4], pj[5]
                             self.pcr_L = L_pcr
-                            if own is None:
-                                self.r_next = torch.empty(n, dtype=f64, device=dev)
-                                a.r_next = _ptr(self.r_next)
+                            words = int(lib.ipx_cg_resident_ll_words(geo[1], pj[6]))
+                            self.ll = torch.zeros(words, dtype=torch.int64, device=dev)
+                            self.ll_seq = ctypes.c_int64(0)
+                            a.R_ll, a.R_hw = _ptr(self.ll), pj[6]
+                            a.R_seq = ctypes.cast(ctypes.pointer(self.ll_seq), ctypes.c_void_p)
+                            a.resident = 1
+                            if not lib.ipx_cg_resident_ok(ctypes.byref(a)):
+                                a.resident = 0
         self.args = a
 
     def _init_dense(self, H, P, lb, ub):
@@ -627,10 +641,7 @@ class _Loop:
                   ctypes.c_void_p(self.part1.data_ptr() + 8), _p(ctx().ws), stream_ptr())
 
     def g_tensor(self, it):
-        """The buffer that holds g (= the next r) after iteration ``it``: with the one-launch
-        projection r and g alternate between two buffers (csrc/cg.hip proj_g)."""
-        if self.args.P_win and it % 2 == 0:
-            return self.r_next
+        """The buffer that holds g (= the next r) after iteration ``it``."""
         return self.r
 
 
@@ -701,6 +712,7 @@ def projected_cg(H, c, Z, Y, b, trust_radius=np.inf, lb=None, ub=None, tol=None,
         batch_cap = 64 if L.operator is None else 8   # (an operator is applied once per
                                                       #  enqueued iteration, stopped or not)
         def iterate(self, it, end):
+            self.last = (it, end)
             if L.operator is None:
                 _hip.check(lib.ipx_cg_iterate(L.ref(), it, end, st), "ipx_cg_iterate")
             else:
@@ -711,7 +723,18 @@ def projected_cg(H, c, Z, Y, b, trust_radius=np.inf, lb=None, ub=None, tol=None,
                     L.apply_operator()
 
         def read_state(self):
-            return L.state.tolist()
+            s = L.state.tolist()
+            if int(s[ST_STOP]) == 8 and L.args.resident:
+                # a hand-off of the resident launch timed out (a workgroup that never became
+                # resident: the GPU shared with another process's kernels).  The launch wrote
+                # nothing back: repeat the batch on the separate launches, for good.
+                L.args.resident = 0
+                STATS["resident_fallbacks"] += 1
+                L.state[ST_STOP] = 0.0
+                _hip.check(lib.ipx_cg_iterate(L.ref(), self.last[0], self.last[1], st),
+                           "ipx_cg_iterate")
+                s = L.state.tolist()
+            return s
 
         def X(self):
             return DVec(L.x)
@@ -735,7 +758,7 @@ def projected_cg(H, c, Z, Y, b, trust_radius=np.inf, lb=None, ub=None, tol=None,
         Driver(), STATS, lb, ub, trust_radius, max_iter, max_infeasible_iter, batch, stats)
     STATS["calls"] += 1
     STATS["iterations"] += niter
-    STATS["project_calls"] += 1 if L.args.P_win else 0
+    STATS["resident_calls"] += 1 if L.args.resident else 0
     _release(L, pool_key)
     return x, {'niter': niter, 'stop_cond': stop_cond, 'hits_boundary': hits_boundary}
 

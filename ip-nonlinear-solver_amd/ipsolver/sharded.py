@@ -1217,12 +1217,11 @@ class FusedShardedCG:
             local_P.stats = P.stats
         self.P = P
         self.kind = H.kind
-        self.L = L = cg_fused._Loop(H.local, local_P, lb.loc if lb is not None else None,
-                                    ub.loc if ub is not None else None)
-        a = L.args
         # (the rank-local loop keeps the separate launches: the own-range partial sums of
         # ipx_cg_shard2_segment follow their workgroups / row tiles)
-        a.P_win, a.P_nspan = None, 0
+        self.L = L = cg_fused._Loop(H.local, local_P, lb.loc if lb is not None else None,
+                                    ub.loc if ub is not None else None, resident=False)
+        a = L.args
         dev = dv.ctx().device
         self.s1 = torch.zeros(2, dtype=torch.float64, device=dev)
         self.pack = torch.zeros(4, dtype=torch.float64, device=dev)
