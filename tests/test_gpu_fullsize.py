@@ -139,21 +139,38 @@ def test_fused_loop_matches_general_driver(big):
     assert big.dv.norm(x_f - x_g) <= 1e-12 * big.dv.norm(x_g)
 
 
-def test_config3_full_solve_reproduces_reference_counts():
-    """BASELINE config 3 (eps = 1e-3) at n = 1e6: the reference stops with status
-    1 after 25 outer / 34 CG iterations (measured there in
-    103 s); the same counts and final optimality here, callbacks on the device."""
+def test_config3_full_solve_reproduces_the_reference_trace():
+    """BASELINE config 3 (eps = 1e-3) at its FULL size n = 1e6 / m = 1e5 against the trace the
+    REFERENCE produced on it (tests/golden/config3_n1e6.json: ``make_golden.py --config3``, 103 s
+    per run of the reference + three one-ulp re-runs): all 25 rows of
+    (niter, cg_niter, trust radius, penalty, barrier parameter, optimality, constraint
+    violation, nfev) through ``compare`` -- integers exact, floats to 1e-10 + 10 x the
+    reference's own one-ulp movement --, every counter of the result, and every 1000th
+    component of x to 1e-10.  Callbacks on the device."""
+    import json
+    import os
     import torch
     import ipsolver
+    from conftest import unjson
+    from test_host_logic import run, compare
     from ipsolver.synthetic import CenteredBandedNLP, DeviceCallbacks
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
+                           "config3_n1e6.json")) as f:
+        gold = json.load(f)["config3_n1e6"]
     prob = CenteredBandedNLP(N, M, eps=1e-3)
     dc = DeviceCallbacks(prob)
-    res = ipsolver.minimize_constrained(dc.fun, dc.x0, dc.grad, dc.hess, dc.constraints(ipsolver),
-                                        method="tr_interior_point")
-    assert (res.status, res.niter, res.cg_niter) == (1, 25, 34)
-    assert res.optimality < 1e-8 and res.constr_violation < 1e-8
-    assert abs(res.optimality - 7.4074e-9) <= 1e-12
+    res, rows = run(dc.fun, dc.x0, dc.grad, dc.hess, dc.constraints(ipsolver),
+                    method="tr_interior_point")
     assert isinstance(res.x, torch.Tensor) and res.x.is_cuda
+    assert (res.status, res.niter, res.cg_niter) == (1, 25, 34) == \
+        (gold["status"], gold["niter"], gold["cg_niter"])
+    assert len(rows) == len(gold["trace"]) == 25 and gold["one_ulp"]["stable_rows"] == 25
+    x = res.x.cpu().numpy()
+    res.x = x[::gold["x_stride"]]                        # (compare checks the golden's sample)
+    compare(res, rows, gold)
+    gx = np.asarray(unjson(gold["x"]), dtype=float)
+    assert gx.size == 1000
+    assert np.max(np.abs(x[::gold["x_stride"]] - gx)) <= 1e-10 * np.max(np.abs(gx))
 
 
 def test_dense_config2_gram_and_projection():
