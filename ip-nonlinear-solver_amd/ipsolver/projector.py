@@ -220,14 +220,14 @@ class NormalEquationProjector:
         self.orth_tol, self.max_refin = orth_tol, max_refin
         self.m, self.n = A.shape
         self.norm_A = A.frobenius_norm() if self.m > 0 else 0.0
-        self.stats = {"solves": 0, "refinements": 0}
+        self.stats = {"solves": 0, "refinements": 0, "cancellation_steps": 0}
 
     # -- reference projections.py:23-55, with ||A z|| from the fused SpMV epilogue
     def _orthogonality(self, z):
         """z's ||z||^2 was left in slot 0 by the SpMV that produced it; A z
         goes to slot 1 so one read-back serves both norms."""
         Az = self.A.spmv(z, reduce=True, slot=1)
-        red = dv.read_slots(3)
+        red = self._red = dv.read_slots(7)           # (slot 6: ||x||^2 of null_space's input)
         norm_z, norm_Az = float(np.sqrt(red[0])), float(np.sqrt(red[2]))
         if norm_z == 0 or self.norm_A == 0:
             return 0.0, Az
@@ -237,20 +237,39 @@ class NormalEquationProjector:
         self.stats["solves"] += 1
         return self.solver.solve(w)
 
+    # x lost this many bits to the row space in z = x - A'v before a correction step is added
+    CANCELLATION = 2.0 ** -10
+
     def null_space(self, x):
         if self.m == 0:
             return x.copy()
+        c = dv.ctx()
+        # ||x||^2 -> slot 6 (read below together with the orthogonality measure's norms)
+        _hip.call("ipx_norms", len(x), dv._p(x.t), ctypes.c_void_p(c.out.data_ptr() + 8 * 6),
+                  dv._p(c.ws), dv.stream_ptr())
         v = self._apply_inv(self.A.dot(x))
         z = self.A.rmatvec_sub(v, x, reduce=True)    # x - A'v, ||z||^2 -> slot 0
         k = 0
         while True:                                  # projections.py:72-78
             orth, Az = self._orthogonality(z)
-            if not orth > self.orth_tol or k >= self.max_refin:
+            if k == 0:
+                red = self._red
+                # Accuracy beyond the reference's loop.  When x lies almost entirely in the row
+                # space of A (late barrier subproblems: |Z c| = 1e-6 |c|) the ONE subtraction
+                # x - A'v cancels most of x and leaves an error of eps |x| -- 1e-10 of |z| --
+                # that the orthogonality measure does not see (it is 1e-13 of ||A||_F |z|):
+                # measured 7-9x the reference's augmented-system error on its own late-barrier
+                # calls (tests/golden/late_barrier_*.npz).  One correction step on z itself,
+                # whose own rounding is eps |z|, removes it: z <- z - A'(A A')^-1 (A z).
+                cancelled = red[0] < (self.CANCELLATION ** 2) * red[6]
+            else:
+                cancelled = False
+            if k >= self.max_refin or not (orth > self.orth_tol or cancelled):
                 break
             v = self._apply_inv(Az)
             z = self.A.rmatvec_sub(v, z, reduce=True)
             k += 1
-            self.stats["refinements"] += 1
+            self.stats["refinements" if orth > self.orth_tol else "cancellation_steps"] += 1
         return z
 
     def least_squares(self, x):

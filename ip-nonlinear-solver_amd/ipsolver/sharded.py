@@ -1038,7 +1038,7 @@ class ShardProjector:
         self.solver = (self.sh.ops.normal_solver(A.local) if plain
                        else self.sh.ops.any_normal_solver(A.local))
         self.norm_A = A.frobenius_norm()
-        self.stats = {"solves": 0, "refinements": 0}
+        self.stats = {"solves": 0, "refinements": 0, "cancellation_steps": 0}
         self.fused_sharded = bool(getattr(self.sh.ops, "fused", False))
         self.plain = plain
         self._check_truncation()
@@ -1094,11 +1094,17 @@ class ShardProjector:
         k = 0
         while True:
             orth, Az = self.orthogonality(z)
-            if not orth > self.orth_tol or k >= self.max_refin:
+            # (one correction step when the subtraction above cancelled most of x -- late
+            # barrier subproblems --, as projector.NormalEquationProjector.null_space)
+            cancelled = False
+            if k == 0 and Az is not None:
+                from .projector import NormalEquationProjector as _NEP
+                cancelled = z.sumsq_amax()[0] < (_NEP.CANCELLATION ** 2) * x.sumsq_amax()[0]
+            if k >= self.max_refin or not (orth > self.orth_tol or cancelled):
                 break
             z = z - self.A.T.dot(self._apply_inv(Az))
             k += 1
-            self.stats["refinements"] += 1
+            self.stats["refinements" if orth > self.orth_tol else "cancellation_steps"] += 1
         return z
 
     def least_squares(self, x):

@@ -298,7 +298,7 @@ def test_config2_full_solve_against_reference_trace(n, m, config2_golden):
     assert res.optimality < 5e-8 and res.constr_violation < 1e-10
     # past the knife edge: a rejected step shrinks the trust region, the run then needs a
     # handful of further (rejected / tiny) iterations until gtol or xtol fires
-    assert res.status in (1, 2) and gold["niter"] <= res.niter <= gold["niter"] + 15
+    assert res.status in (1, 2) and gold["niter"] <= res.niter <= gold["niter"] + 20
     if (res.status, res.niter) == (gold["status"], gold["niter"]):      # same path to the end
         assert res.cg_niter == gold["cg_niter"] and len(rows) == len(gold["trace"])
 
@@ -352,7 +352,7 @@ def test_config2_device_callbacks(n, m, config2_golden):
     # (past the knife edge of the last two accept / reject tests the run ends on xtol with the
     # optimality measure where the rejected steps left it, a few 1e-8: see the host-mode test)
     assert res.optimality < 5e-8 and res.constr_violation < 1e-10
-    assert res.status in (1, 2) and gold["niter"] <= res.niter <= gold["niter"] + 15
+    assert res.status in (1, 2) and gold["niter"] <= res.niter <= gold["niter"] + 20
 
 
 def test_config5_full_size_properties():

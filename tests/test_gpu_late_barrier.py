@@ -17,12 +17,14 @@ The generator therefore also measured how well the reference's own answer is det
 ``c`` moves by ONE unit in the last place (four seeded sign patterns): identical counts and
 1e-15 early, 271..272 iterations and 3e-5 in x at mu = 2.6e-7.  The assertions below hold the
 product to exactly that: integers exact wherever the reference's own count does not move under
-one ulp (within twice its spread + 1, or 0.2 % of a count in the thousands, where it does),
-vectors to 1e-10 or ten times the reference's own one-ulp sensitivity, the projection within
-ten times the reference's own distance from the exact one and within 16 ulp of its INPUT's size
-(measured: 4e-10 of |Z c| against the reference's 6e-11 at mu = 1.3e-6, n = 12000 -- the normal
-equations form ``c - A'v`` by one subtraction that cancels six digits, the reference's
-augmented-system refinement recovers part of them; both are 1e-16-level relative to |c|)."""
+one ulp (within its spread over the four perturbed runs + 0.1 % of the count where it does),
+vectors to 1e-10 or TWICE the reference's own one-ulp sensitivity, the projection NO FURTHER
+from the exact one than the reference's own (or 4 eps) and within 16 ulp of its INPUT's size.
+(Round 3 allowed ten times the reference's figures: the normal equations form ``c - A'v`` by
+one subtraction that cancels six digits and were 7-9x further from the exact projection than
+the reference at mu = 1e-4 ... 1e-6; ``null_space`` now adds one correction step on z itself
+when that subtraction has cancelled more than ten bits -- projector.py -- and is 0.2x the
+reference's distance there: scripts/late_barrier_margins.py prints the table.)"""
 import os
 
 import numpy as np
@@ -51,11 +53,11 @@ def _pieces(gold, j):
                 lb=g("lb"), radius=float(g("radius")), mu=float(g("mu")), x_out=g("x"),
                 info=[int(v) for v in g("info")], allvecs=g("allvecs"),
                 stride=int(gold["stride"][0]), z_true=g("z_true"), ref_proj_err=float(proj[0]),
-                # what one ulp in c does to the reference's own result
-                niter_slack=0 if spread == 0 else max(2 * spread + 1,
-                                                      int(np.ceil(0.002 * g("info")[0]))),
-                x_tol=max(1e-10, 10.0 * float(sens[:, 3].max())),
-                it_tol=max(1e-10, 10.0 * float(sens[:, 4].max())))
+                # what one ulp in c does to the reference's own result: its iteration count's
+                # spread over FOUR perturbed runs (a sample maximum) + 0.1 % of the count
+                niter_slack=0 if spread == 0 else spread + int(np.ceil(0.001 * g("info")[0])),
+                x_tol=max(1e-10, 2.0 * float(sens[:, 3].max())),
+                it_tol=max(1e-10, 2.0 * float(sens[:, 4].max())))
 
 
 def close_rel(a, b, tol):
@@ -105,7 +107,7 @@ def test_late_barrier_subproblems_single_gpu(n):
         # the projection against the exact one: as close as the reference's own
         z = _solve_single(d, projection_only=True)
         zerr = np.max(np.abs(z - d["z_true"]))
-        assert zerr <= max(1e-10, 10.0 * d["ref_proj_err"]) * np.max(np.abs(d["z_true"])), \
+        assert zerr <= max(4 * 2.2204e-16, d["ref_proj_err"]) * np.max(np.abs(d["z_true"])), \
             (j, zerr / np.max(np.abs(d["z_true"])), d["ref_proj_err"])
         assert zerr <= 16 * 2.2204e-16 * np.max(np.abs(d["c"]))
         # the device-resident loop
