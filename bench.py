@@ -4,12 +4,16 @@
 A "step" is ONE projected-CG iteration (reference qp_subproblem.py:549-634) on
 the synthetic sparse banded problem of BASELINE.json config 3 (SURVEY.md
 Appendix C: CSR Jacobian 1e5 x 1e6 with 15 nnz/row, tridiagonal-plus-diagonal
-Lagrangian Hessian), run with tol=0 and a finite trust radius that is never
+Lagrangian Hessian).  `value` times the PRODUCT FUNCTION: one call
+``ipsolver.qp.projected_cg(H, c, Z, Y, b, trust_radius=1e300, tol=0,
+max_iter=K)`` -- its priming (qp_subproblem.py:502-512), the batched device
+loop, its state reads, the result -- with a finite trust radius that is never
 reached (how the SQP calls it: the norm test of qp_subproblem.py:583 is formed
-and taken every iteration), so exactly K iterations execute; the same loop
-with trust_radius=inf (the norm test cannot trigger and is not formed) is
-reported next to it as `unbounded_trust_region`.  All inputs are resident in
-HBM when the timed region starts.
+and taken every iteration), so exactly K iterations execute.  The bare device
+loop (one C call, no priming: the headline of rounds 1-3) is reported as
+`device_loop_only`, the same loop with trust_radius=inf (the norm test cannot
+trigger and is not formed) as `unbounded_trust_region`.  All inputs are
+resident in HBM when the timed region starts.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--n 1000000] [--m 100000]
 
@@ -28,9 +32,9 @@ whole config-4 solve on the sharded backend.
 Prints ONE JSON line (see the driver contract in the task statement) with
 `roofline` for the dominant kernel (step2 fused into the H.p CSR SpMV),
 `roofline_out_of_cache` (the same measurement at n=4e6, past the Infinity
-Cache), `repeat` (median / min / max over further K-step regions),
-`public_api` (the product function ``ipsolver.qp.projected_cg(tol=0,
-max_iter=K)`` timed as a user calls it), `config5` / `config2` (the other
+Cache), `loop_kernels` (per kernel: algorithmic bytes, PMC bytes moved, their
+ratio), `public_api` (the product function over several calls, both radii),
+`config5` / `config2` (the other
 single-GPU BASELINE configs to gtol) and `cpu_baseline` (the oracle =
 numpy/scipy restatement of the reference path, the better of 1 / all host
 threads).
@@ -48,8 +52,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_MFMA_PEAK_TFLOPS = 78.6   # AMD datasheet, dense fp64 matrix
-PMC_PROFILE = "r03_pmc_traffic_n1e6.json"      # see roofline.traffic_source
-PMC_PROFILE_BIG = "r03_pmc_traffic_n4e6.json"
+PMC_PROFILE = "r04_pmc_traffic_n1e6.json"      # see roofline.traffic_source
+PMC_PROFILE_BIG = "r04_pmc_traffic_n4e6.json"
 
 
 def kernel_source_hash():
@@ -79,6 +83,17 @@ def stored_traffic(profile, kernel):
                  "(separate passes, gfx950 FETCH correction calibrated in-run on kernels of known "
                  "byte count) over scripts/pmc_workload.py, profiles/%s, same kernel sources "
                  "(hash %s)" % (profile, want))
+
+
+def traffic_table(profile, algo):
+    """Per loop kernel: algorithmic bytes, the STORED PMC bytes (same-source profile only) and
+    their ratio -- above 1 means bytes moved twice (window halos, a second copy of a matrix)."""
+    out = {}
+    for name, nbytes in algo.items():
+        moved, _ = stored_traffic(profile, name)
+        out[name] = {"algorithmic_bytes": nbytes, "pmc_bytes_moved": moved,
+                     "traffic_over_algorithmic": None if not moved else moved / nbytes}
+    return out
 
 
 def spmv_bytes(nnz, rows, cols, extra_row_vectors=0):
@@ -185,18 +200,7 @@ def single_gpu_measure(A_h, H_h, hdiag_h, c_h, n, m, K, W, repeats=20):
               "iterations_per_s": {"median": rates[len(rates) // 2], "min": rates[0],
                                    "max": rates[-1]}} if rates else None
 
-    # ---- per-kernel attribution with HIP events on the launch stream (same workload)
-    ms = (ctypes.c_float * 7)()
-    kt = max(2, min(K, 100))
-    prime()
-    _hip.check(lib.ipx_cg_iterate(L.ref(), 0, 20, st), "pre-events")
-    _hip.check(lib.ipx_cg_iterate_timed(L.ref(), 20, 20 + kt, ms, st), "timed-events")
     fused1, fused2, fused3 = bool(L.args.A_span), bool(L.args.H_hmax), bool(L.args.At_qv)
-    names = [None if fused1 else "step1", "step1_spmv_A_r" if fused1 else "spmv_A_r",
-             "banded_solve_residual_r_minus_Atv" if fused3 else "banded_solve_with_residual",
-             None if fused3 else "spmv_r_minus_Atv", None,
-             None if fused2 else "step2", "step2_spmv_H_p" if fused2 else "spmv_H_p"]
-    per_kernel_us = {k: 1e3 * ms[i] / kt for i, k in enumerate(names) if k}
 
     # ---- the same loop with trust_radius = inf (the reference's default argument): the test
     # norm(x_next) >= inf of qp_subproblem.py:583 cannot trigger, the norm is not formed and the
@@ -225,9 +229,8 @@ def single_gpu_measure(A_h, H_h, hdiag_h, c_h, n, m, K, W, repeats=20):
 
     # ---- the dominant kernel on its own: back-to-back launches (same arguments as in the
     # loop) between two HIP events on the launch stream, in `repeats` groups of K.  This is
-    # the kernel's own duration, the quantity rocprofv3 --kernel-trace reports; the
-    # per_kernel_us figures above additionally contain the dependency gap in front of each
-    # kernel.  With a banded Hessian step2 rides inside the H.p SpMV (k_cg_step2_hp): the
+    # the kernel's own duration, the quantity rocprofv3 --kernel-trace reports.
+    # With a banded Hessian step2 rides inside the H.p SpMV (k_cg_step2_hp): the
     # fused kernel is then the dominant one (mode 3 = no stop tests).
     def dominant():
         if fused2:
@@ -279,14 +282,12 @@ def single_gpu_measure(A_h, H_h, hdiag_h, c_h, n, m, K, W, repeats=20):
         "A": A, "H": H, "c": c, "b": b, "Z": Z, "Y": Y, "elapsed": elapsed, "repeat": repeat,
         "unbounded": unbounded,
         "t_factor": t_factor, "nnzA": nnzA, "nnzH": nnzH, "dom": dom,
-        "per_kernel_us": per_kernel_us,
         "roofline": {"bound": "hbm", "kernel": dom_label,
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,
                      "algorithmic_bytes_per_launch": algo[dom],
                      "avg_launch_us": hp_us,
                      "avg_launch_us_min_max": [groups[0], groups[-1]],
-                     "avg_launch_us_in_loop_with_gap": per_kernel_us[dom],
                      "method": "median of %d groups of %d back-to-back launches, each between "
                                "two HIP events on the launch stream" % (len(groups), K),
                      "on_the_byte_count_of_rounds_1_2": None if older is None else {
@@ -1004,10 +1005,31 @@ def main():
 
     r1 = single_gpu_measure(A_h, H_h, hdiag_h, c_h, n, m, K, W, repeats=args.repeats)
     A, H, c, b, Z, Y = (r1.pop(k) for k in ("A", "H", "c", "b", "Z", "Y"))
-    elapsed = r1["elapsed"]
     traffic, traffic_src = None, None
     if (n, m) == (1000000, 100000):
         traffic, traffic_src = stored_traffic(PMC_PROFILE, r1["dom"])
+    # ---- the headline: the PRODUCT FUNCTION as a user calls it -- ONE call of
+    # ipsolver.qp.projected_cg(H, c, Z, Y, b, trust_radius, tol=0, max_iter=K), W warm-up
+    # iterations in a call before it, the timed region = the call (synchronised either side):
+    # its priming (x0 = Y(-b), r0 = Z(H x0 + c), g0 = Z r0: qp_subproblem.py:502-512), buffer
+    # set-up, the batched device loop with its state reads, the result.  The bare device loop
+    # (one C call enqueuing K iterations; the former headline) is `device_loop_only`.
+    from ipsolver import qp as _qp
+    if W > 0:
+        _qp.projected_cg(H, c, Z, Y, b, trust_radius=1e300, tol=0, max_iter=W)
+    # (with tol = 0 the CG reaches an exactly zero residual after ~500 iterations: a K beyond
+    # 200 is run as consecutive calls of <= 200 iterations on the same subproblem)
+    chunks = [200] * (K // 200) + ([K % 200] if K % 200 else [])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    done = 0
+    for kc in chunks:
+        _xk, _info = _qp.projected_cg(H, c, Z, Y, b, trust_radius=1e300, tol=0, max_iter=kc)
+        done += _info["niter"]
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if done != K:
+        raise SystemExit("headline call(s) ran %d iterations instead of %d" % (done, K))
     result = {
         "metric": "projected-CG iters/sec (fp64) at n=1e6,m=1e5",
         "value": K / elapsed,
@@ -1022,16 +1044,25 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": "config3: sparse banded NLP subproblem, CSR Jacobian "
-                               "bandwidth 15, tol=0, finite trust radius that is never reached "
-                               "(the norm test of qp_subproblem.py:583 formed every iteration, "
-                               "as in the SQP's calls; trust_radius=inf: see "
-                               "unbounded_trust_region)",
+                               "bandwidth 15: ONE call ipsolver.qp.projected_cg(H, c, Z, Y, b, "
+                               "trust_radius=1e300, tol=0, max_iter=steps) -- priming included; "
+                               "finite trust radius that is never reached (the norm test of "
+                               "qp_subproblem.py:583 formed every iteration, as in the SQP's "
+                               "calls; trust_radius=inf: see unbounded_trust_region)",
                    "n": n, "m": m, "nnz_A": r1["nnzA"], "nnz_H": r1["nnzH"],
                    "parallelism": "single GPU"},
-        "repeat": r1["repeat"],
+        "device_loop_only": {
+            "what": "the bare device loop: ipx_cg_iterate enqueues exactly `steps` iterations of "
+                    "the primed subproblem in one C call (rounds 1-3's headline); no priming, no "
+                    "state reads inside the region",
+            "iterations_per_s": K / r1["elapsed"], "ms_per_step": 1e3 * r1["elapsed"] / K,
+            "repeat": r1["repeat"]},
         "unbounded_trust_region": r1["unbounded"],
-        "roofline": dict(r1["roofline"], traffic=traffic, traffic_source=traffic_src),
-        "per_kernel_us": r1["per_kernel_us"],
+        "roofline": dict(r1["roofline"], traffic=traffic, traffic_source=traffic_src,
+                         frac_on_moved_bytes=None if not traffic else
+                         traffic / (r1["roofline"]["avg_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS),
+        "loop_kernels": traffic_table(PMC_PROFILE, r1["whole_iteration"]["algorithmic_bytes_per_kernel"])
+        if (n, m) == (1000000, 100000) else None,
         "whole_iteration": r1["whole_iteration"],
         "kernel_source_hash": kernel_source_hash(),
         "setup_s": {"generate_host": t_gen, "factor_device": r1["t_factor"]},
@@ -1062,7 +1093,7 @@ def main():
             rb["roofline"], traffic=traffic_b, traffic_source=src_b, n=nb, m=mb,
             iterations_per_s=K / rb["elapsed"], ms_per_step=1e3 * rb["elapsed"] / K,
             repeat=rb["repeat"], unbounded_trust_region=rb["unbounded"],
-            per_kernel_us=rb["per_kernel_us"], whole_iteration=rb["whole_iteration"])
+            whole_iteration=rb["whole_iteration"])
         if isinstance(result.get("measured_stream"), dict) and "axpby_2r1w" in result["measured_stream"]:
             result["roofline_out_of_cache"]["frac_of_measured_stream"] = \
                 result["roofline_out_of_cache"]["achieved"] / result["measured_stream"]["axpby_2r1w"]

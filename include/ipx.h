@@ -308,6 +308,15 @@ int ipx_cg_vec_grid(int64_t n);
 int ipx_cg_hp(const ipx_cg_args *a, void *stream);
 /* Enqueue iterations [it_begin, it_end); never synchronises. */
 int ipx_cg_iterate(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, void *stream);
+/* The state block of a new call from reductions left in device memory (red[idx7[k]], idx < 0:
+ * zero): ||x0||^2; ||t||^2, ||r0||^2, ||A r0||^2; ||r0||^2, ||g0||^2, ||A g0||^2 -- rt_g, the
+ * tolerance (tol_in, or the rule of qp_subproblem.py:529-530 when tol_in is NaN), radius and
+ * orthogonality threshold are written by a one-thread kernel, stop code 9 when a projection
+ * needs the host (refinement, cancellation step) or the start is at the trust-region boundary:
+ * no host read between a call's priming and its first batch. */
+int ipx_cg_prime_state(double *state, const double *red, const int32_t *idx7, double tol_in,
+                       double radius, double orth_tol, double norm_A, double cancellation,
+                       void *stream);
 /* Same launches with HIP events around each kernel class; synchronises once at
  * the end and returns per-class totals in ms_out[0..6] = {step1, A r, banded,
  * r-A'v, A g, step2, H p}.  For per-kernel attribution in bench.py. */

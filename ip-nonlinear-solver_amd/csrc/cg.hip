@@ -1607,6 +1607,54 @@ int ipx_cg_shard2_fold_hp(const ipx_cg_args *a, const ipx_shard2_ext *e, void *s
   return pack_hp(a, e, (hipStream_t)stream);
 }
 
+// The state block of a new call written ON THE DEVICE from reductions its priming left in
+// device memory, so that a projected_cg call needs no host read before its first batch
+// (reference qp_subproblem.py:502-542 evaluates these scalars on the host: five blocking reads
+// here, ~0.3 ms of a call's fixed cost).  red[idx[.]]:
+//   0: ||x0||^2;   1, 2, 3: ||t||^2, ||r0||^2, ||A r0||^2 of r0 = Z t;
+//   4, 5, 6: ||r0||^2, ||g0||^2, ||A g0||^2 of g0 = Z r0   (idx < 0: quantity is 0)
+// Writes rt_g = ||g0||^2, tol (tol_in, or the default rule :529-530 when tol_in is NaN), the
+// radius, the orthogonality threshold -- and stop code 9 when the host must take over: a
+// projection that needs refinement (projections.py:72-78) or the cancellation step
+// (projector.null_space), or no room to the trust-region boundary (:515-526).
+__global__ void k_cg_prime_state(double *st, const double *__restrict__ red, ipx_prime_idx ix,
+                                 double tol_in, double radius, double orth_tol, double norm_A,
+                                 double canc2) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double q[7];
+  for (int k = 0; k < 7; ++k) q[k] = ix.i[k] >= 0 ? red[ix.i[k]] : 0.0;
+  bool bad = false;
+  for (int pj = 0; pj < 2; ++pj) {
+    const double nx2 = q[1 + 3 * pj], nz2 = q[2 + 3 * pj], naz2 = q[3 + 3 * pj];
+    const double nz = sqrt(nz2), naz = sqrt(naz2);
+    const double orth = (nz == 0.0 || norm_A == 0.0) ? 0.0 : naz / (norm_A * nz);
+    if (orth > orth_tol || nz2 < canc2 * nx2) bad = true;
+  }
+  const double rt_g = q[5];
+  const double tr_distance = radius - sqrt(q[0]);
+  if (!(tr_distance >= 1e-25)) bad = true;
+  double tol = tol_in;
+  if (tol_in != tol_in) tol = fmax(fmin(0.01 * sqrt(rt_g), 0.1 * rt_g), 1e-25);
+  for (int k = 0; k < ST_SIZE; ++k) st[k] = 0.0;
+  st[ST_RTG0] = rt_g;
+  st[ST_TOL] = tol;
+  st[ST_RADIUS] = radius;
+  st[ST_ORTH_RHS] = orth_tol * norm_A;
+  st[ST_STOP] = bad ? 9.0 : 0.0;
+}
+
+int ipx_cg_prime_state(double *state, const double *red, const int32_t *idx7, double tol_in,
+                       double radius, double orth_tol, double norm_A, double cancellation,
+                       void *stream) {
+  if (!state || !red || !idx7) return IPX_EINVAL;
+  ipx_prime_idx ix;
+  for (int k = 0; k < 7; ++k) ix.i[k] = idx7[k];
+  hipLaunchKernelGGL(k_cg_prime_state, dim3(1), dim3(64), 0, (hipStream_t)stream, state, red, ix,
+                     tol_in, radius, orth_tol, norm_A, cancellation * cancellation);
+  IPX_CHECK_LAUNCH();
+  return IPX_OK;
+}
+
 // Hp = H p with p'Hp partials (the tail of an iteration, also used once by
 // the host to prime the loop).
 int ipx_cg_hp(const ipx_cg_args *a, void *stream) {

@@ -574,6 +574,8 @@ enum {
   ST_SIZE = 16
 };
 
+struct ipx_prime_idx { int i[7]; };      // (csrc/cg.hip k_cg_prime_state)
+
 // ---- resident projected-CG kernel (csrc/resident.hip): the cyclic-reduction geometry of a
 // banded handle, and the launcher csrc/cg.hip's loop calls
 struct ipx_pcr_view {

@@ -50,6 +50,8 @@ class CgArgs(ctypes.Structure):
 # Counters over the life of the process (diagnostics: how often the device loop
 # had to hand an iteration back to the host).
 STATS = {"calls": 0, "iterations": 0, "batches": 0, "box_events": 0, "refine_events": 0,
+         "primed_on_device": 0,   # calls whose priming read nothing back (ipx_cg_prime_state)
+         "prime_retries": 0,      # ... of which the device sent back to the host-driven priming
          "resident_calls": 0,     # solves whose batches ran as resident launches (csrc/resident.hip)
          "resident_fallbacks": 0, # batches repeated on the separate launches (stop code 8)
          "operator_calls": 0}     # solves whose Hessian was an operator applied by the host
@@ -645,8 +647,61 @@ class _Loop:
         return self.r
 
 
+class _PrimeRetry(Exception):
+    """The device found that the call's priming needs the host (stop code 9)."""
+
+
 def projected_cg(H, c, Z, Y, b, trust_radius=np.inf, lb=None, ub=None, tol=None,
                  max_iter=None, max_infeasible_iter=None, batch=None, stats=None, b_zero=False):
+    """qp_subproblem.py:416-643 on the device-resident loop.  The call first tries a priming
+    that reads nothing back (``_prime_without_reads``): the scalars of :502-542 -- rt_g, the
+    default tolerance, the distance to the trust-region boundary, the orthogonality measures of
+    the two initial projections -- are reduced and tested on the device, which writes the
+    loop's state block itself; the first host read of the call is the state block after the
+    first batch of iterations.  When the device finds that a projection needs a refinement or
+    cancellation step, or that the start sits on the trust-region boundary, it says so in that
+    block (stop code 9) and the call starts over on the host-driven priming below."""
+    P = Z.projector
+    from .projector import NormalEquationProjector
+    if isinstance(P, NormalEquationProjector) and P.m > 0 and len(c) - len(b) >= 1 \
+            and (max_iter is None or max_iter >= 1) and trust_radius >= 0:
+        try:
+            return _projected_cg(H, c, Z, Y, b, trust_radius, lb, ub, tol, max_iter,
+                                 max_infeasible_iter, batch, stats, b_zero, fast=True)
+        except _PrimeRetry:
+            STATS["prime_retries"] += 1
+    return _projected_cg(H, c, Z, Y, b, trust_radius, lb, ub, tol, max_iter,
+                         max_infeasible_iter, batch, stats, b_zero, fast=False)
+
+
+_PRIME_IDX = (ctypes.c_int32 * 7)(12, 4, 0, 2, 10, 6, 8)
+_PRIME_IDX_B0 = (ctypes.c_int32 * 7)(-1, 4, 0, 2, 10, 6, 8)
+
+
+def _prime_without_reads(L, H, c, Z, Y, b, b_zero, P, tol, trust_radius):
+    """x0, r0 = Z(H x0 + c), g0 = Z r0 enqueued with their norms left in the context's reduction
+    block (doubles 0..13), then the state block written by ``ipx_cg_prime_state``."""
+    n = len(c)
+    ctx_ = ctx()
+    if b_zero:
+        x0 = DVec.zeros(n)
+        t = c
+    else:
+        x0 = Y.dot(-b)
+        _hip.call("ipx_norms", n, _p(x0.t), ctypes.c_void_p(ctx_.out.data_ptr() + 8 * 12),
+                  _p(ctx_.ws), stream_ptr())
+        t = H.dot(x0) + c
+    r0 = P.null_space_enqueue(t, 0)          # ||t||^2 -> 4, ||r0||^2 -> 0, ||A r0||^2 -> 2
+    g0 = P.null_space_enqueue(r0, 6)         # ||r0||^2 -> 10, ||g0||^2 -> 6, ||A g0||^2 -> 8
+    _hip.call("ipx_cg_prime_state", _p(L.state), _p(ctx_.out),
+              _PRIME_IDX_B0 if b_zero else _PRIME_IDX,
+              float("nan") if tol is None else float(tol), float(trust_radius),
+              float(P.orth_tol), float(P.norm_A), float(P.CANCELLATION), stream_ptr())
+    return x0, r0, g0
+
+
+def _projected_cg(H, c, Z, Y, b, trust_radius, lb, ub, tol, max_iter, max_infeasible_iter,
+                  batch, stats, b_zero, fast):
     from . import qp
     lib = _hip.load()
     P = Z.projector
@@ -656,6 +711,29 @@ def projected_cg(H, c, Z, Y, b, trust_radius=np.inf, lb=None, ub=None, tol=None,
     if has_box:
         lb = lb if lb is not None else DVec.full(n, -np.inf)
         ub = ub if ub is not None else DVec.full(n, np.inf)
+    if max_iter is None:
+        max_iter = n - m
+    max_iter = min(max_iter, n - m)
+    if max_infeasible_iter is None:
+        max_infeasible_iter = n - m
+    if fast:
+        L, pool_key = _loop_for(H, P, lb if has_box else None,
+                                ub if has_box and ub_given else None)
+        if L.operator is not None:            # (an operator Hessian is applied by the host)
+            _release(L, pool_key)
+            raise _PrimeRetry()
+        if np.isinf(trust_radius) and trust_radius > 0 and not has_box \
+                and not os.environ.get("IPX_KEEP_XN2"):
+            L.args.no_radius = 1
+        st = stream_ptr()
+        x0, r0, g0 = _prime_without_reads(L, H, c, Z, Y, b, b_zero, P, tol, trust_radius)
+        L.x.copy_(x0.t)
+        L.r.copy_(r0.t)
+        _hip.call("ipx_axpby", n, -1.0, _p(g0.t), 0.0, None, _p(L.p), st)      # p = -g
+        _hip.check(lib.ipx_cg_hp(L.ref(), st), "ipx_cg_hp")
+        STATS["primed_on_device"] += 1
+        return _run_loop(L, pool_key, P, lib, st, n, lb, ub, trust_radius, max_iter,
+                         max_infeasible_iter, batch, stats, fast=True)
 
     # ---- initial point, residual, direction (qp_subproblem.py:502-512)
     if b_zero:
@@ -677,11 +755,6 @@ def projected_cg(H, c, Z, Y, b, trust_radius=np.inf, lb=None, ub=None, tol=None,
 
     if tol is None:                       # :529-542
         tol = max(min(0.01 * np.sqrt(rt_g), 0.1 * rt_g), _TINY)
-    if max_iter is None:
-        max_iter = n - m
-    max_iter = min(max_iter, n - m)
-    if max_infeasible_iter is None:
-        max_infeasible_iter = n - m
 
     # (no upper bounds given: the loop's kernels do not read a vector of +inf)
     L, pool_key = _loop_for(H, P, lb if has_box else None, ub if has_box and ub_given else None)
@@ -705,7 +778,12 @@ def projected_cg(H, c, Z, Y, b, trust_radius=np.inf, lb=None, ub=None, tol=None,
     if L.operator is not None:
         L.apply_operator()
         STATS["operator_calls"] += 1
+    return _run_loop(L, pool_key, P, lib, st, n, lb, ub, trust_radius, max_iter,
+                     max_infeasible_iter, batch, stats, fast=False)
 
+
+def _run_loop(L, pool_key, P, lib, st, n, lb, ub, trust_radius, max_iter, max_infeasible_iter,
+              batch, stats, fast):
     class Driver:
         """The single-GPU loop behind ``run_device_loop``."""
         first_batch = 4 if L.operator is None else 2
@@ -724,6 +802,11 @@ def projected_cg(H, c, Z, Y, b, trust_radius=np.inf, lb=None, ub=None, tol=None,
 
         def read_state(self):
             s = L.state.tolist()
+            if fast and int(s[ST_STOP]) == 9:
+                # the device's verdict on the priming: the host must do it (nothing of the
+                # call's inputs was overwritten; the loop's launches were no-ops)
+                _release(L, pool_key)
+                raise _PrimeRetry()
             if int(s[ST_STOP]) == 8 and L.args.resident:
                 # a hand-off of the resident launch timed out (a workgroup that never became
                 # resident: the GPU shared with another process's kernels).  The launch wrote

@@ -272,6 +272,20 @@ class NormalEquationProjector:
             self.stats["refinements" if orth > self.orth_tol else "cancellation_steps"] += 1
         return z
 
+    def null_space_enqueue(self, x, base):
+        """``null_space`` without its read-back: z = x - A'(A A')^-1 A x enqueued, and
+        ||x||^2, ||z||^2, ||A z||^2 left at doubles ``base + 4``, ``base``, ``base + 2`` of the
+        context's reduction block -- the caller (cg_fused.projected_cg's priming) has the
+        DEVICE decide from them whether the refinement / cancellation steps above are needed,
+        and falls back to ``null_space`` when they are.  (slot = base / 2: 16 bytes each.)"""
+        c = dv.ctx()
+        _hip.call("ipx_norms", len(x), dv._p(x.t), ctypes.c_void_p(c.out.data_ptr() + 8 * (base + 4)),
+                  dv._p(c.ws), dv.stream_ptr())
+        v = self._apply_inv(self.A.dot(x))
+        z = self.A.rmatvec_sub(v, x, reduce=True, slot=base // 2)
+        self.A.spmv(z, reduce=True, slot=base // 2 + 1)
+        return z
+
     def least_squares(self, x):
         if self.m == 0:
             return DVec.zeros(0)
