@@ -206,7 +206,7 @@ def single_gpu_measure(A_h, H_h, hdiag_h, c_h, n, m, K, W, repeats=20):
     # norm(x_next) >= inf of qp_subproblem.py:583 cannot trigger, the norm is not formed and the
     # fused step1 + A.r kernel reads neither x nor p
     unbounded = None
-    if repeats > 0 and not os.environ.get("IPX_KEEP_XN2"):
+    if repeats > 0:
         L.args.no_radius = 1
         mode["init"] = init_inf
         fr = []
@@ -449,16 +449,16 @@ def config2_leg():
                 method="equality_constrained_sqp")
             torch.cuda.synchronize()
             wall = time.time() - t0
-        # the same call with the constant Hessian marked read-only (numpy's immutability
-        # contract): its device copy is then uploaded once, not once per outer iteration
-        Hd.setflags(write=False)
+        # the same call with the Hessian declared constant (additive option; or, equivalently,
+        # the array marked H.setflags(write=False)): its device copy is uploaded once, not once
+        # per outer iteration
         for attempt in range(2):
             torch.cuda.synchronize()
             t0 = time.time()
             res_ro = ipsolver.minimize_constrained(
                 lambda x: 0.5 * x.dot(Hd.dot(x)) + c.dot(x), np.zeros(n), lambda x: Hd.dot(x) + c,
                 lambda x: Hd, ipsolver.LinearConstraint(A, ("equals", bq)),
-                method="equality_constrained_sqp")
+                method="equality_constrained_sqp", options={"constant_hessian": True})
             torch.cuda.synchronize()
             wall_ro = time.time() - t0
     # the same solve with everything resident in HBM (device-callback mode)
@@ -509,15 +509,22 @@ def config2_leg():
             "cg_niter": int(res.cg_niter), "optimality": float(res.optimality),
             "constr_violation": float(res.constr_violation),
             "reference_trace": "status 1, 15 outer / 28 CG (tests/golden/config2.json)",
-            "read_only_hessian": {"seconds": wall_ro, "status": int(res_ro.status),
-                                  "niter": int(res_ro.niter), "cg_niter": int(res_ro.cg_niter),
-                                  "note": "same numpy callbacks, hess(x) returns an array "
-                                          "marked H.setflags(write=False): uploaded once"},
+            "constant_hessian": {"seconds": wall_ro, "status": int(res_ro.status),
+                                 "niter": int(res_ro.niter), "cg_niter": int(res_ro.cg_niter),
+                                 "optimality": float(res_ro.optimality),
+                                 "note": "same numpy callbacks, options={'constant_hessian': True} "
+                                         "(or the array marked read-only): the 800 MB Hessian is "
+                                         "uploaded once; the rest is the user's own numpy "
+                                         "callbacks (dense 10000^2 matvecs on the host)"},
             "device_callbacks": {"seconds": wall_d, "status": int(res_d.status),
                                  "niter": int(res_d.niter), "cg_niter": int(res_d.cg_niter),
                                  "optimality": float(res_d.optimality),
                                  "note": "A and H resident in HBM (2-D CUDA tensors): nothing "
-                                         "crosses PCIe between two iterations"},
+                                         "crosses PCIe between two iterations.  NOT a wall clock "
+                                         "to gtol when status is 2: the end game of this QP sits "
+                                         "on the merit function's rounding floor and the run "
+                                         "stops on xtol at an optimality of a few 1e-8 (the "
+                                         "iterate agrees with the reference's)"},
             "gram_mfma": {"kernel": "k_gram_mfma (v_mfma_f64_16x16x4_f64) in %d K-splits + "
                                     "k_gram_reduce" % splits, "ms": ms,
                           "flop_executed": flop, "tiles": [nt * (nt + 1) // 2, nt * nt],

@@ -247,8 +247,8 @@ typedef struct ipx_cg_args {
    * ceil(most variables of one workgroup / 256) <= 16.  NULL / 0: separate SpMV. */
   const int32_t *At_vown;
   int64_t At_qv;
-  int64_t A_tile_nnz;    /* nonzeros per row tile of the table in A_tiles when step1 is fused
-                          * (1024 or 0 = IPX_SPMV_TILE_NNZ) */
+  int64_t A_tile_nnz;    /* must be 0 (a row-tile table of its own for the fused step1 was an
+                          * experiment of round 2; the field keeps the layout) */
   /* the rows of A' once more in ELL(2) form for that tail (2n ints, 2n doubles: entry t of
    * variable j at [t*n + j]; an absent entry repeats a valid column with value 0): indexed by
    * the variable alone, so the tail's loads need no row-pointer round trip.  NULL: CSR. */

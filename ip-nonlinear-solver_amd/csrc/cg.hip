@@ -1178,13 +1178,12 @@ static int launch_step1_ar(const ipx_cg_args *a, int it, const double *p1, int n
       a->Hp, a->A_rowptr, a->A_colidx, a->A_val, a->A_tiles, (int)a->A_ntiles, a->A_own,   \
       a->w, a->part2, (const uint16_t *)a->A_col16
   const int qs = (int)((a->A_span + IPX_BLOCK - 1) / IPX_BLOCK);
-  const bool half = a->A_tile_nnz == 1024;      // tiles of 1024 nonzeros (own table)
-  if (peer && (half || !a->A_col16)) return IPX_EINVAL;      // (see peer_fusable)
+  if (a->A_tile_nnz != 0) return IPX_EINVAL;    // (the 1024-nonzero tile form was removed)
+  if (peer && !a->A_col16) return IPX_EINVAL;   // (see peer_fusable)
 #define GO(Q)                                                                              \
   do {                                                                                     \
     if (peer && no_xn2) hipLaunchKernelGGL((k_cg_step1_ar<Q, FT_NNZ, true, true, true>), grid, block, 0, st, FUSED_ARGS, pj); \
     else if (peer) hipLaunchKernelGGL((k_cg_step1_ar<Q, FT_NNZ, false, true, true>), grid, block, 0, st, FUSED_ARGS, pj); \
-    else if (half) hipLaunchKernelGGL((k_cg_step1_ar<Q, 1024, false, false, false>), grid, block, 0, st, FUSED_ARGS, none); \
     else if (no_xn2 && a->A_col16) hipLaunchKernelGGL((k_cg_step1_ar<Q, FT_NNZ, true, true, false>), grid, block, 0, st, FUSED_ARGS, none); \
     else if (no_xn2) hipLaunchKernelGGL((k_cg_step1_ar<Q, FT_NNZ, true, false, false>), grid, block, 0, st, FUSED_ARGS, none); \
     else if (a->A_col16) hipLaunchKernelGGL((k_cg_step1_ar<Q, FT_NNZ, false, true, false>), grid, block, 0, st, FUSED_ARGS, none); \
@@ -1380,7 +1379,7 @@ static bool peer_fusable(const ipx_cg_args *a, const ipx_shard2_ext *e) {
         ipx_peer_ready(peer) && fused_hp(a) && a->H_col16 && a->H_rowlen && a->m > 0))
     return false;
   // x-space problems: both fused SpMV kernels, g = r - A'v as the solve's tail, no box
-  if (e->nseg == 1 && fused_ar(a) && !a->lb && a->A_col16 && a->A_tile_nnz != 1024 &&
+  if (e->nseg == 1 && fused_ar(a) && !a->lb && a->A_col16 &&
       a->solver_kind == 0 && a->At_vown && a->At_qv > 0)
     return true;
   // the barrier problem's z-space: the projection without the box rows as matrix rows

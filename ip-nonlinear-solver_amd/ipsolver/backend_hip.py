@@ -214,17 +214,20 @@ def _upload_dense_cached(h):
     buffer in place -- so the device copy is reused only for arrays that CANNOT change: those
     the caller has marked read-only (``H.setflags(write=False)``, numpy's own immutability
     contract).  Writable arrays are uploaded every time, like the reference re-wraps them."""
+    # (... or that the caller declared constant: minimize_constrained's ``constant_hessian``)
+    const, orig = getattr(h, "_ipx_constant", False), h
     h = np.asarray(h, dtype=np.float64)
-    if h.size == 0 or not _immutable(h) or not h.flags.c_contiguous:
+    if h.size == 0 or not (const or _immutable(h)) or not h.flags.c_contiguous:
         return DeviceDense.from_host(h)
+    ident = orig if const else h
     key = (h.__array_interface__["data"][0], h.shape)
     hit = _dense_cache.get(key)
-    if hit is not None and hit[0] is h:
+    if hit is not None and hit[0] is ident:
         return hit[1]
     if len(_dense_cache) > 2:
         _dense_cache.clear()
     D = DeviceDense.from_host(h)
-    _dense_cache[key] = (h, D)              # (keeps the array alive: the address stays its own)
+    _dense_cache[key] = (ident, D)          # (keeps the array alive: the address stays its own)
     return D
 
 

@@ -164,7 +164,7 @@ class BoxSchurNormalSolver:
         bits = int(flag.item())
         if bits & 1:
             raise np.linalg.LinAlgError("Singular Jacobian matrix: A A' is not positive definite")
-        if bits & 2 or os.environ.get("IPX_NO_COMPACT_GROUPS"):
+        if bits & 2 or _hip.debug_form("no-compact-groups"):
             self.grp2 = None
         self.u = torch.zeros(self.n, dtype=_F64, device=dev)      # only grouped columns are written
         self.t = torch.zeros(self.m, dtype=_F64, device=dev)
@@ -206,12 +206,12 @@ class BoxSchurNormalSolver:
             self._up = torch.zeros(self.n, dtype=_F64, device=dev)
             a.up = self._up.data_ptr()
             a.grp2 = self.grp2.data_ptr() if self.grp2 is not None else None
-            if self.grp2 is not None and c["affine"] and not os.environ.get("IPX_NO_AFFINE_GROUPS"):
+            if self.grp2 is not None and c["affine"] and not _hip.debug_form("no-affine-groups"):
                 a.gaffine = 1
                 a.gc0, a.gdp, a.gdq, a.gen0 = c["affine"]
             lens = np.diff(self.A_R.pattern.indptr_h)
             if len(lens) and lens[0] in (2, 4, 8, 16) and (lens == lens[0]).all() \
-                    and not os.environ.get("IPX_NO_COMPACT_GROUPS"):
+                    and not _hip.debug_form("no-compact-groups"):
                 a.AR_rowlen = int(lens[0])     # A_R u formed inside the Schur solve's kernel
             self._yell = self._item_columns(ARt)
             if self._yell is not None:
@@ -232,7 +232,7 @@ class BoxSchurNormalSolver:
                                    c["gen_cols"].cpu().numpy().astype(np.int64)))
             first, cnt = indptr[cols], indptr[cols + 1] - indptr[cols]
             if len(cols) and len(indices) and cnt.max() <= 2 and \
-                    not os.environ.get("IPX_NO_COMPACT_GROUPS"):
+                    not _hip.debug_form("no-compact-groups"):
                 have = np.stack((cnt >= 1, cnt >= 2))
                 pos = np.where(have, np.stack((first, first + 1)), 0)
                 col = np.where(have, indices[pos], 0)

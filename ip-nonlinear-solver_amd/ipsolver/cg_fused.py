@@ -395,8 +395,7 @@ def _signature(H, P, lb, ub):
     if _hessian_parts(H) is None:
         return None                      # operator Hessians: not pooled
     Hc, Hd = _hessian_parts(H)
-    flags = tuple(bool(os.environ.get(k)) for k in ("IPX_NO_FUSE", "IPX_NO_C16", "IPX_FUSE_TN",
-                                                    "IPX_TAIL_MAXWG", "IPX_NO_RESIDENT"))
+    flags = os.environ.get("IPX_DEBUG_FORMS", "")
     return (id(Hc.pattern), Hd is None, id(P.A.pattern), lb is None, ub is None,
             _solver_kind(P.solver), int(getattr(P.solver, "k", 0)), flags)
 
@@ -405,7 +404,7 @@ def _loop_for(H, P, lb, ub):
     """A loop object for this call: an idle one built for the same patterns with its value
     pointers re-bound (a projected_cg call otherwise allocates ~15 device buffers and rebuilds
     the argument block: ~0.15 ms, as much as the kernels of a short solve), else a new one."""
-    key = None if os.environ.get("IPX_NO_POOL") else _signature(H, P, lb, ub)
+    key = _signature(H, P, lb, ub)
     L = _POOL.pop(key, None) if key is not None else None
     if L is not None and L.rebind(H, P, lb, ub):
         POOL_STATS["reused"] += 1
@@ -521,39 +520,35 @@ class _Loop:
         self.fold_ws = torch.zeros(16384, dtype=f64, device=dev)      # IPX_FOLD_WS_DOUBLES
         a.fold_ws = _ptr(self.fold_ws)
         # banded Hessian: step2 rides inside the H.p SpMV (one launch less per iteration)
-        hmax = 0 if (os.environ.get("IPX_NO_FUSE") or Hc is None) else fuse_halo(Hc.pattern)
+        no_fuse, no_c16 = _hip.debug_form("no-fuse"), _hip.debug_form("no-c16")
+        hmax = 0 if (no_fuse or Hc is None) else fuse_halo(Hc.pattern)
         if hmax > 0:
             self.pb = torch.zeros(2 * Hc.pattern.ntiles * 2 * hmax, dtype=f64, device=dev)
             a.pb, a.H_hmax = _ptr(self.pb), hmax
             th = Hc.pattern.tiles_h
             a.H_tile_rows = int(np.max(np.diff(th[:Hc.pattern.ntiles + 1])))
-            if not os.environ.get("IPX_NO_C16"):
+            if not no_c16:
                 self.H_col16, self.H_rowlen = compact_columns(Hc.pattern, hmax)
                 a.H_col16, a.H_rowlen = _ptr(self.H_col16), _ptr(self.H_rowlen)
         # banded Jacobian, no box: step1 rides inside the A.r SpMV
-        tn = int(os.environ.get("IPX_FUSE_TN", "0")) or None
-        own = None if (os.environ.get("IPX_NO_FUSE") or lb is not None or m == 0) \
-            else fuse_own(A.pattern, tn)
+        own = None if (no_fuse or lb is not None or m == 0) else fuse_own(A.pattern)
         if own is not None:
             self.r_next = torch.empty(n, dtype=f64, device=dev)
             self.own, self.own_tiles = own[0], own[2]
             a.r_next, a.A_own, a.A_span = _ptr(self.r_next), _ptr(self.own), own[1]
-            a.A_tiles, a.A_ntiles, a.A_tile_nnz = _ptr(self.own_tiles), own[3], tn or 0
+            a.A_tiles, a.A_ntiles, a.A_tile_nnz = _ptr(self.own_tiles), own[3], 0
             if self.part2.numel() < 2 * own[3]:
                 self.part2 = torch.zeros(2 * own[3], dtype=f64, device=dev)
                 a.part2 = _ptr(self.part2)
-            if tn is None and not os.environ.get("IPX_NO_C16"):
+            if not no_c16:
                 self.A_col16 = own_columns16(A.pattern)
                 a.A_col16 = _ptr(self.A_col16)
         # tridiagonal A A' on the single-launch solve: g = r - A'v rides in that launch
-        if a.solver_kind == 0 and not os.environ.get("IPX_NO_FUSE"):
+        if a.solver_kind == 0 and not no_fuse:
             geo = (ctypes.c_int32 * 2)()
-            # (round 1's chunk-recurrence solve streamed better with a separate SpMV beyond 512
-            # workgroups; with the cyclic-reduction solve the fused tail wins there too: 7.47 vs
-            # 7.14 k it/s at n = 4e6.  IPX_TAIL_MAXWG restores a limit for A/B runs.)
             ok = bool(lib.ipx_banded_decoupled_geometry(ctypes.c_void_p(P.solver.handle), geo))
             self.geometry = (ok, geo[0], geo[1])
-            if ok and geo[1] <= int(os.environ.get("IPX_TAIL_MAXWG", "1000000000")):
+            if ok:
                 kS = int(getattr(P.solver, "k", 1))
                 vown = fuse_vown(At.pattern, geo[0], geo[1], kS) if kS <= 4 else None
                 if vown is not None:
@@ -569,7 +564,7 @@ class _Loop:
                     # (csrc/resident.hip) -- 21.8 -> ~7 us per iteration at n = 1.25e5
                     # (profiles/r04_per_rank_sweep.json).  resident=False: the separate launches.
                     L_pcr = int(lib.ipx_banded_pcr_level(ctypes.c_void_p(P.solver.handle)))
-                    if resident is None and os.environ.get("IPX_NO_RESIDENT"):
+                    if resident is None and _hip.debug_form("no-resident"):
                         resident = False
                     if kS == 1 and L_pcr > 0 and lb is None and hmax > 0 and resident is not False \
                             and int(np.max(np.diff(Hc.pattern.indptr_h))) <= RES_RLH:
@@ -723,7 +718,7 @@ def _projected_cg(H, c, Z, Y, b, trust_radius, lb, ub, tol, max_iter, max_infeas
             _release(L, pool_key)
             raise _PrimeRetry()
         if np.isinf(trust_radius) and trust_radius > 0 and not has_box \
-                and not os.environ.get("IPX_KEEP_XN2"):
+                and not _hip.debug_form("keep-xn2"):
             L.args.no_radius = 1
         st = stream_ptr()
         x0, r0, g0 = _prime_without_reads(L, H, c, Z, Y, b, b_zero, P, tol, trust_radius)
@@ -762,7 +757,7 @@ def _projected_cg(H, c, Z, Y, b, trust_radius, lb, ub, tol, max_iter, max_infeas
     # test norm(x_next) >= trust_radius of qp_subproblem.py:583 is always False, so the norm
     # is not formed (the fused step1 + A.r kernel then reads neither x nor p)
     if np.isinf(trust_radius) and trust_radius > 0 and not has_box \
-            and not os.environ.get("IPX_KEEP_XN2"):
+            and not _hip.debug_form("keep-xn2"):
         L.args.no_radius = 1
     st = stream_ptr()
     L.x.copy_(x0.t)

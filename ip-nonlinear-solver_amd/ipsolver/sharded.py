@@ -1272,7 +1272,7 @@ class FusedShardedCG:
             # the loop's kernels all-reduce the scalars and move the halo of g themselves: in
             # the prologues of the kernels that consume them (3 launches per iteration; the C
             # side decides per argument block -- one segment, no box, 16-bit index forms) or
-            # in pack kernels of their own (5 launches; IPX_SHARD_FUSE_COMM=0 forces that)
+            # in pack kernels of their own (5 launches; IPX_DEBUG_FORMS=pack-comm forces that)
             e.peer = self.mailbox.handle
             e.fuse_comm = self._agree_on_fused_comm(Hc, A_loc, lb is not None)
             self._exchange_g = None
@@ -1292,7 +1292,7 @@ class FusedShardedCG:
         would read each other's words as the wrong quantity.  One all-reduce (MIN)
         per pair of patterns, cached on the sharding (the tables are symbolic)."""
         sh = self.sh
-        asked = 0 if os.environ.get("IPX_SHARD_FUSE_COMM", "1") == "0" else 1
+        asked = 0 if self._hip.debug_form("pack-comm") else 1
         key = (id(Hc.pattern), Hc.pattern.nnz, id(A_loc.pattern), A_loc.pattern.nnz, has_box, asked)
         cache = sh.__dict__.setdefault("_fuse_comm_agreed", {})
         if key not in cache:

@@ -1,5 +1,5 @@
 """A/B of the compact tables of the barrier problem's projection (ipx_boxschur_args.grp2,
-yell_*; IPX_NO_COMPACT_GROUPS=1 = the full tables) on BASELINE config 5: bench.config5_leg
+yell_*; IPX_DEBUG_FORMS=no-compact-groups = the full tables) on BASELINE config 5: bench.config5_leg
 in a child process per setting, alternating, [rounds] times.
     python scripts/ab_config5_tables.py [rounds]"""
 import json, os, subprocess, sys
@@ -10,7 +10,7 @@ rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 out = {"compact": [], "full": []}
 for _ in range(rounds):
     for name, flag in (("compact", ""), ("full", "1")):
-        env = dict(os.environ, IPX_NO_COMPACT_GROUPS=flag)
+        env = dict(os.environ, IPX_DEBUG_FORMS="no-compact-groups" if flag else "")
         p = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True,
                            timeout=600)
         legs = [l[4:] for l in p.stdout.splitlines() if l.startswith("LEG ")]

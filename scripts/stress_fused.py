@@ -35,8 +35,8 @@ for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 24):
     for name, kw in variants.items():
         res = []
         for nf in ("", "1"):
-            if nf: os.environ["IPX_NO_FUSE"] = "1"
-            else: os.environ.pop("IPX_NO_FUSE", None)
+            if nf: os.environ["IPX_DEBUG_FORMS"] = "no-fuse"
+            else: os.environ.pop("IPX_DEBUG_FORMS", None)
             x, info = qp.projected_cg(H, c, Z, Y, np.zeros(m), **kw)
             res.append((host(x), info))
         (x1, i1), (x2, i2) = res
@@ -45,7 +45,7 @@ for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 24):
         if not ok:
             bad += 1
             print("MISMATCH seed %d %s n=%d m=%d hbw=%d: %s vs %s, dx=%.2e" % (seed, name, n, m, hbw, i1, i2, np.max(np.abs(x1 - x2))))
-    os.environ.pop("IPX_NO_FUSE", None)
+    os.environ.pop("IPX_DEBUG_FORMS", None)
     L = cf._Loop(H, Z.projector, None, None)
     from ipsolver import _hip
     import ctypes

@@ -100,6 +100,41 @@ def test_dense_hessian_upload_is_reused_only_for_read_only_arrays():
     assert not bh._immutable(ro_view)
 
 
+def test_constant_hessian_option_uploads_once(monkeypatch):
+    """``options={'constant_hessian': True}`` (an ADDITIVE option: the reference's signature is
+    unchanged): ``hess`` is evaluated once and its dense value uploaded once for the whole
+    solve -- BASELINE config 2's fifteen 800 MB uploads -- with the iterates of the plain call
+    (same arithmetic); the caller's array stays writable."""
+    import ipsolver.dense as dense
+    rng = np.random.default_rng(0)
+    n, m = 60, 12
+    A = rng.standard_normal((m, n))
+    G = rng.standard_normal((n, n)) / np.sqrt(n)
+    Hd = G.dot(G.T) + np.eye(n)
+    c = rng.standard_normal(n)
+    bq = A.dot(rng.standard_normal(n))
+    uploads = {"n": 0}
+    real = dense.DeviceDense.from_host
+
+    def counting(a):
+        if np.shape(a) == (n, n):
+            uploads["n"] += 1
+        return real(a)
+    monkeypatch.setattr(dense.DeviceDense, "from_host", staticmethod(counting))
+    out = []
+    for opts in ({}, {"constant_hessian": True}):
+        uploads["n"] = 0
+        res = ipsolver.minimize_constrained(
+            lambda x: 0.5 * x.dot(Hd.dot(x)) + c.dot(x), np.zeros(n), lambda x: Hd.dot(x) + c,
+            lambda x: Hd, ipsolver.LinearConstraint(A, ("equals", bq)),
+            method="equality_constrained_sqp", options=opts)
+        out.append((res, uploads["n"]))
+    (r0, u0), (r1, u1) = out
+    assert u1 == 1 and u0 > 3
+    assert (r0.status, r0.niter, r0.cg_niter) == (r1.status, r1.niter, r1.cg_niter)
+    assert np.array_equal(r0.x, r1.x) and Hd.flags.writeable
+
+
 def test_sharded_mixed_constraints_hip(tmp_path):
     """Equality rows, nonlinear inequalities and a ragged box together, random sparsity, on two
     processes with the HIP kernels (``options={'shard': True}`` -> the plain block partition of

@@ -415,7 +415,10 @@ def _multi_rank_worker(rank, world, port, out_path, transport="dist"):
             sys.path.insert(0, p)
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     os.environ["IPX_SHARD_TRANSPORT"] = transport.split("-")[0]
-    os.environ["IPX_SHARD_FUSE_COMM"] = "0" if transport == "ipc-pack" else "1"
+    if transport == "ipc-pack":
+        os.environ["IPX_DEBUG_FORMS"] = "pack-comm"
+    else:
+        os.environ.pop("IPX_DEBUG_FORMS", None)
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -778,13 +781,13 @@ def test_unbounded_trust_region_skips_the_norm(ips, monkeypatch):
     runs = []
     for keep in ("", "1"):
         if keep:
-            monkeypatch.setenv("IPX_KEEP_XN2", "1")
+            monkeypatch.setenv("IPX_DEBUG_FORMS", "keep-xn2")
         else:
-            monkeypatch.delenv("IPX_KEEP_XN2", raising=False)
+            monkeypatch.delenv("IPX_DEBUG_FORMS", raising=False)
         x, info = ips.qp.projected_cg(H, inst.c, Z, Y, b, tol=1e-12)
         runs.append((host(x), info))
     assert runs[0][1] == runs[1][1] and np.array_equal(runs[0][0], runs[1][0])
-    monkeypatch.delenv("IPX_KEEP_XN2", raising=False)
+    monkeypatch.delenv("IPX_DEBUG_FORMS", raising=False)
     radius = 0.5 * float(np.linalg.norm(runs[0][0]))
     x, info = ips.qp.projected_cg(H, inst.c, Z, Y, b, trust_radius=radius, tol=1e-12)
     assert info["stop_cond"] == 2 and info["hits_boundary"]
@@ -874,7 +877,7 @@ def test_box_schur_projection_without_matrix_rows(ips, bounds, monkeypatch):
               ips.dv.stream_ptr())
     assert np.array_equal(g2.cpu().numpy(), got)
     # the full tables (4 doubles per group, the columns of A_R through their row pointers)
-    monkeypatch.setenv("IPX_NO_COMPACT_GROUPS", "1")
+    monkeypatch.setenv("IPX_DEBUG_FORMS", "no-compact-groups")
     Zf, _, Yf = ips.proj.projections(ips.dv.DeviceCSR.from_scipy(A))
     fargs = Zf.projector.solver.c_args()
     assert not fargs.grp2 and not fargs.yell_col and not fargs.yell_val
@@ -883,7 +886,17 @@ def test_box_schur_projection_without_matrix_rows(ips, bounds, monkeypatch):
               ips.dv._p(pg3), ctypes.byref(n3), ips.dv._p(pres), ctypes.byref(n4), None,
               ips.dv.stream_ptr())
     assert np.array_equal(g3.cpu().numpy(), got) and torch.equal(pg3, pg)
-    monkeypatch.delenv("IPX_NO_COMPACT_GROUPS")
+    # ... and the compact coefficients with the column table READ instead of computed
+    monkeypatch.setenv("IPX_DEBUG_FORMS", "no-affine-groups")
+    Za, _, _ = ips.proj.projections(ips.dv.DeviceCSR.from_scipy(A))
+    aargs = Za.projector.solver.c_args()
+    assert not aargs.gaffine
+    g4, pg4 = torch.empty_like(g), torch.zeros_like(pg)
+    _hip.call("ipx_boxschur_project", ctypes.byref(aargs), ips.dv._p(rd.t), ips.dv._p(g4),
+              ips.dv._p(pg4), ctypes.byref(n3), ips.dv._p(pres), ctypes.byref(n4), None,
+              ips.dv.stream_ptr())
+    assert np.array_equal(g4.cpu().numpy(), got) and torch.equal(pg4, pg)
+    monkeypatch.delenv("IPX_DEBUG_FORMS")
     # the device loop on the barrier-shaped subproblem: bounds on the slacks only
     Hz = sps.block_diag([inst.H, sps.diags(rng.uniform(0.5, 2.0, N - n))], format="csr")
     Hd = ips.dv.DeviceCSR.from_scipy(Hz)
@@ -930,9 +943,9 @@ def test_step2_fused_into_hp_is_bit_identical(ips, variant, monkeypatch):
     runs = []
     for no_fuse in ("", "1"):
         if no_fuse:
-            monkeypatch.setenv("IPX_NO_FUSE", "1")
+            monkeypatch.setenv("IPX_DEBUG_FORMS", "no-fuse")
         else:
-            monkeypatch.delenv("IPX_NO_FUSE", raising=False)
+            monkeypatch.delenv("IPX_DEBUG_FORMS", raising=False)
         x, info = ips.qp.projected_cg(H, inst.c, Z, Y, b, **kw)
         runs.append((host(x), info))
     (x1, i1), (x2, i2) = runs
@@ -944,6 +957,42 @@ def test_step2_fused_into_hp_is_bit_identical(ips, variant, monkeypatch):
         # the fused step1 sums ||x + alpha p||^2 per row tile of A instead of per vector
         # chunk: the iterates themselves are computed by identical expressions
         assert np.max(np.abs(x1 - x2)) <= 1e-13 * np.max(np.abs(x2))
+
+
+@pytest.mark.parametrize("form", ["no-c16", "no-diag-merge", "no-fuse"])
+def test_debug_forms_of_the_three_launch_loop(ips, form, monkeypatch):
+    """Every form the one debug switch (IPX_DEBUG_FORMS, ipsolver/_hip.py) can turn off has a
+    parity test; here the ones of the separate-launch loop at a size that is not resident
+    (n = 1e6 rows are the bench's; 6e5 is the smallest): 32-bit column indices in the fused
+    SpMV kernels (bit-identical), the Hessian's diagonal term as a vector of its own
+    ((h_ii + d_i) p_i against h_ii p_i + d_i p_i: 1e-13), no fused kernels at all (1e-13:
+    ||x + alpha p||^2 per vector chunk instead of per row tile)."""
+    import ipsolver.cg_fused as cg_fused
+    from ipsolver.operators import DeviceHessian
+    n, m = 600000, 60000
+    inst = BandedInstance(n, m)
+    A = ips.dv.DeviceCSR.from_scipy(inst.A)
+    hd = np.random.default_rng(3).uniform(0.0, 0.5, n)
+    b = np.zeros(m)
+    runs = []
+    for flag in ("", form):
+        if flag:
+            monkeypatch.setenv("IPX_DEBUG_FORMS", flag)
+        else:
+            monkeypatch.delenv("IPX_DEBUG_FORMS", raising=False)
+        H = DeviceHessian(n, csr=ips.dv.DeviceCSR.from_scipy(inst.H), diag=ips.dv.DVec.from_host(hd))
+        assert (H.diag is None) == (flag != "no-diag-merge")
+        Z, LS, Y = ips.proj.projections(A)
+        before = cg_fused.STATS["resident_calls"]
+        x, info = ips.qp.projected_cg(H, inst.c, Z, Y, b, tol=0, max_iter=25, trust_radius=1e300)
+        assert cg_fused.STATS["resident_calls"] == before        # the separate launches
+        runs.append((host(x), info))
+    (x1, i1), (x2, i2) = runs
+    assert i1 == i2
+    if form == "no-c16":
+        assert np.array_equal(x1, x2)
+    else:
+        assert np.max(np.abs(x1 - x2)) <= 1e-13 * np.max(np.abs(x1))
 
 
 def test_device_loop_with_an_operator_hessian(ips):
@@ -1003,9 +1052,9 @@ def test_resident_loop_matches_the_separate_launches(ips, n, m, monkeypatch):
     runs = {}
     for flag in ("resident", "separate"):
         if flag == "resident":
-            monkeypatch.delenv("IPX_NO_RESIDENT", raising=False)
+            monkeypatch.delenv("IPX_DEBUG_FORMS", raising=False)
         else:
-            monkeypatch.setenv("IPX_NO_RESIDENT", "1")
+            monkeypatch.setenv("IPX_DEBUG_FORMS", "no-resident")
         Z, LS, Y = ips.proj.projections(A)
         x_free, _ = ips.qp.projected_cg(H, inst.c, Z, Y, b, tol=1e-12)
         out = []
@@ -1069,9 +1118,9 @@ def test_fused_kernels_on_other_band_shapes(ips, n, m, hbw, abw, seed, monkeypat
     runs = []
     for no_fuse in ("", "1"):
         if no_fuse:
-            monkeypatch.setenv("IPX_NO_FUSE", "1")
+            monkeypatch.setenv("IPX_DEBUG_FORMS", "no-fuse")
         else:
-            monkeypatch.delenv("IPX_NO_FUSE", raising=False)
+            monkeypatch.delenv("IPX_DEBUG_FORMS", raising=False)
         x, info = ips.qp.projected_cg(H, c, Z, Y, np.zeros(m), tol=1e-14, max_iter=60)
         runs.append((host(x), info))
     (x1, i1), (x2, i2) = runs
