@@ -314,6 +314,14 @@ int ipx_cg_iterate(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, void 
  * orthogonality threshold are written by a one-thread kernel, stop code 9 when a projection
  * needs the host (refinement, cancellation step) or the start is at the trust-region boundary:
  * no host read between a call's priming and its first batch. */
+/* The whole priming of a call (qp_subproblem.py:502-512: x0 = Y(-b), r0 = Z(H x0 + c), g0 = Z r0,
+ * the state block, p = -g0, Hp = H p) enqueued by ONE call into the loop's own buffers; CSR A
+ * (A_tiles / A_ntiles: its standard SpMV row tiles) and H, solver_kind 0 or 1; b NULL = 0;
+ * red: 14 doubles, ws: IPX_WS_DOUBLES doubles of device memory.  Stop code 9 in the state block
+ * afterwards: the host must prime (ipx_cg_prime_state). */
+int ipx_cg_prime(const ipx_cg_args *a, const int32_t *A_tiles, int32_t A_ntiles, const double *c,
+                 const double *b, double *red, double *ws, double tol_in, double radius,
+                 double orth_tol, double norm_A, double cancellation, void *stream);
 int ipx_cg_prime_state(double *state, const double *red, const int32_t *idx7, double tol_in,
                        double radius, double orth_tol, double norm_A, double cancellation,
                        void *stream);

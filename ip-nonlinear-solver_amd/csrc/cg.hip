@@ -1654,6 +1654,80 @@ int ipx_cg_prime_state(double *state, const double *red, const int32_t *idx7, do
   return IPX_OK;
 }
 
+// The whole priming of a projected_cg call (qp_subproblem.py:502-512) behind ONE entry point:
+//   x0 = Y(-b) = A'(A A')^-1(-b)            (b == NULL: b = 0, x0 = 0)
+//   t  = H x0 + c;   r0 = Z t;   g0 = Z r0  (Z v = v - A'(A A')^-1 A v, each with ||v||^2,
+//                                            ||Z v||^2 and ||A Z v||^2 left in `red`)
+//   the state block (ipx_cg_prime_state);   p = -g0;   Hp = H p
+// into the loop's own buffers (x0 -> a->x, r0 -> a->r, p -> a->p; a->Hp, a->w, a->v, a->t as
+// scratch): the kernels and their order are those the Python host enqueued one ctypes call at
+// a time (ipsolver/projector.py null_space_enqueue), ~25 calls and three copies.  CSR A and H
+// (+ optional diagonal), banded or box-Schur solver; red: >= 14 doubles of device memory, ws:
+// the reduction workspace (IPX_WS_DOUBLES).
+static int prime_solve(const ipx_cg_args *a, const double *w, double *v, void *stream) {
+  if (a->solver_kind == 1)
+    return ipx_boxschur_solve((const ipx_boxschur_args *)a->banded, w, v, nullptr, nullptr, nullptr,
+                              stream);
+  return ipx_banded_solve(a->banded, w, v, stream);
+}
+static int prime_project(const ipx_cg_args *a, const int32_t *A_tiles, int32_t A_ntiles,
+                         const double *x, double *z, double *red, int base, double *ws,
+                         void *stream) {
+  int rc = ipx_norms(a->n, x, red + base + 4, ws, stream);
+  if (rc) return rc;
+  rc = ipx_csr_spmv(a->m, a->n, a->A_rowptr, a->A_colidx, a->A_val, A_tiles, A_ntiles, x, 1.0,
+                    nullptr, 0.0, nullptr, a->w, 0, nullptr, ws, stream);
+  if (rc) return rc;
+  rc = prime_solve(a, a->w, a->v, stream);
+  if (rc) return rc;
+  rc = ipx_csr_spmv(a->n, a->m, a->At_rowptr, a->At_colidx, a->At_val, a->At_tiles,
+                    (int32_t)a->At_ntiles, a->v, -1.0, nullptr, 1.0, x, z, 0, red + base, ws, stream);
+  if (rc) return rc;
+  return ipx_csr_spmv(a->m, a->n, a->A_rowptr, a->A_colidx, a->A_val, A_tiles, A_ntiles, z, 1.0,
+                      nullptr, 0.0, nullptr, a->t, 0, red + base + 2, ws, stream);
+}
+
+int ipx_cg_prime(const ipx_cg_args *a, const int32_t *A_tiles, int32_t A_ntiles, const double *c,
+                 const double *b, double *red, double *ws, double tol_in, double radius,
+                 double orth_tol, double norm_A, double cancellation, void *stream) {
+  if (!a || !c || !red || !ws || !A_tiles || a->solver_kind > 1 || a->m <= 0 || a->H_operator ||
+      !a->H_rowptr || !a->t)
+    return IPX_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  const double *t = c;
+  if (b) {
+    rc = ipx_axpby(a->m, -1.0, b, 0.0, nullptr, a->w, stream);
+    if (rc) return rc;
+    rc = prime_solve(a, a->w, a->v, stream);
+    if (rc) return rc;
+    rc = ipx_csr_spmv(a->n, a->m, a->At_rowptr, a->At_colidx, a->At_val, a->At_tiles,
+                      (int32_t)a->At_ntiles, a->v, 1.0, nullptr, 0.0, nullptr, a->x, 0, nullptr, ws,
+                      stream);
+    if (rc) return rc;
+    rc = ipx_norms(a->n, a->x, red + 12, ws, stream);
+    if (rc) return rc;
+    rc = ipx_csr_spmv(a->n, a->n, a->H_rowptr, a->H_colidx, a->H_val, a->H_tiles,
+                      (int32_t)a->H_ntiles, a->x, 1.0, a->H_diag, 1.0, c, a->Hp, 1, nullptr, ws,
+                      stream);
+    if (rc) return rc;
+    t = a->Hp;
+  } else if (hipMemsetAsync(a->x, 0, (size_t)a->n * sizeof(double), st) != hipSuccess) {
+    return IPX_ELAUNCH;
+  }
+  rc = prime_project(a, A_tiles, A_ntiles, t, a->r, red, 0, ws, stream);
+  if (rc) return rc;
+  rc = prime_project(a, A_tiles, A_ntiles, a->r, a->p, red, 6, ws, stream);
+  if (rc) return rc;
+  const int32_t idx_b[7] = {12, 4, 0, 2, 10, 6, 8}, idx_0[7] = {-1, 4, 0, 2, 10, 6, 8};
+  rc = ipx_cg_prime_state(a->state, red, b ? idx_b : idx_0, tol_in, radius, orth_tol, norm_A,
+                          cancellation, stream);
+  if (rc) return rc;
+  rc = ipx_axpby(a->n, -1.0, a->p, 0.0, nullptr, a->p, stream);      // p = -g0
+  if (rc) return rc;
+  return launch_hp(a, nullptr, st);
+}
+
 // Hp = H p with p'Hp partials (the tail of an iteration, also used once by
 // the host to prime the loop).
 int ipx_cg_hp(const ipx_cg_args *a, void *stream) {

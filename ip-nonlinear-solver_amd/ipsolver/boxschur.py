@@ -107,7 +107,7 @@ class BoxSchurNormalSolver:
     """(A A')^-1 through per-variable elimination of the simple rows and a
     banded solve on the Schur complement of the general rows."""
 
-    def __init__(self, A):
+    def __init__(self, A, any_sparsity=False):
         from .device_mode import RowSelection
         from .projector import BandedNormalSolver
         an = analysis_for(A.pattern)
@@ -160,7 +160,23 @@ class BoxSchurNormalSolver:
                   _p(self.alpha), _p(self.inv), _p(self.wcol), _p(flag), _p(self.grp),
                   _p(self.grp2), st)
         self.A_R = cache["sel"].apply(A)                 # general rows (value gather)
-        self.inner = BandedNormalSolver(self.A_R, col_weights=self.wcol)   # Sigma = A_R W A_R'
+        if any_sparsity:
+            # Sigma = A_R W A_R' = B B' with B = A_R diag(sqrt(w)) (0 < w <= 1): a scaled copy of
+            # the general rows' values goes to the solver of any sparsity -- dense Cholesky up to
+            # 16384 rows, else the device-resident preconditioned CG (projector.py section 4)
+            from .projector import IterativeNormalSolver
+            from .dense import DenseNormalSolver
+            sw = torch.sqrt(self.wcol)
+            idx = getattr(self.A_R.pattern, "_ipx_col_index64", None)
+            if idx is None:
+                idx = self.A_R.pattern._ipx_col_index64 = self.A_R.pattern.indices.to(torch.int64)
+            B = dv.DeviceCSR(self.A_R.pattern, self.A_R.val * sw[idx])
+            self.B = B
+            mR = B.shape[0]
+            self.inner = DenseNormalSolver(B) if mR <= DenseNormalSolver.MAX_ROWS_FROM_SPARSE \
+                else IterativeNormalSolver(B)
+        else:
+            self.inner = BandedNormalSolver(self.A_R, col_weights=self.wcol)   # Sigma = A_R W A_R'
         bits = int(flag.item())
         if bits & 1:
             raise np.linalg.LinAlgError("Singular Jacobian matrix: A A' is not positive definite")
@@ -175,8 +191,8 @@ class BoxSchurNormalSolver:
     def c_args(self):
         """Argument block for ipx_boxschur_solve (the device-resident CG loop);
         None when the Schur system needs a row permutation."""
-        if self.inner.perm is not None:
-            return None
+        if getattr(self.inner, "perm", None) is not None or not hasattr(self.inner, "band"):
+            return None                       # (a dense / iterative Schur solve: host-driven)
         if self._args is None:
             mR, dev = len(self.an.general), ctx().device
             self._scratch = [torch.zeros(k, dtype=_F64, device=dev) for k in (mR, mR, mR, self.n)]

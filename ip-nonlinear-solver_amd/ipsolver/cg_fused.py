@@ -721,11 +721,23 @@ def _projected_cg(H, c, Z, Y, b, trust_radius, lb, ub, tol, max_iter, max_infeas
                 and not _hip.debug_form("keep-xn2"):
             L.args.no_radius = 1
         st = stream_ptr()
-        x0, r0, g0 = _prime_without_reads(L, H, c, Z, Y, b, b_zero, P, tol, trust_radius)
-        L.x.copy_(x0.t)
-        L.r.copy_(r0.t)
-        _hip.call("ipx_axpby", n, -1.0, _p(g0.t), 0.0, None, _p(L.p), st)      # p = -g
-        _hip.check(lib.ipx_cg_hp(L.ref(), st), "ipx_cg_hp")
+        a = L.args
+        if isinstance(P.A, DeviceCSR) and a.solver_kind in (0, 1) and getattr(P.solver, "perm", None) is None \
+                and a.banded and not getattr(P.solver, "refine_steps", 0):
+            # the whole priming behind one C call, into the loop's own buffers
+            ctx_ = ctx()
+            pat = P.A.pattern
+            _hip.call("ipx_cg_prime", L.ref(), _p(pat.tiles), pat.ntiles, _p(c.t),
+                      None if b_zero else _p(b.t), _p(ctx_.out), _p(ctx_.ws),
+                      float("nan") if tol is None else float(tol), float(trust_radius),
+                      float(P.orth_tol), float(P.norm_A), float(P.CANCELLATION), st)
+            P.stats["solves"] += 2 if b_zero else 3
+        else:
+            x0, r0, g0 = _prime_without_reads(L, H, c, Z, Y, b, b_zero, P, tol, trust_radius)
+            L.x.copy_(x0.t)
+            L.r.copy_(r0.t)
+            _hip.call("ipx_axpby", n, -1.0, _p(g0.t), 0.0, None, _p(L.p), st)      # p = -g
+            _hip.check(lib.ipx_cg_hp(L.ref(), st), "ipx_cg_hp")
         STATS["primed_on_device"] += 1
         return _run_loop(L, pool_key, P, lib, st, n, lb, ub, trust_radius, max_iter,
                          max_infeasible_iter, batch, stats, fast=True)

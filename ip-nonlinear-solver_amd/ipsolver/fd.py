@@ -54,18 +54,19 @@ class FiniteDifferenceOperator:
 
 class DeviceFiniteDifferenceOperator:
     """The rule above with ``fun``: CUDA tensor -> CUDA tensor (or DVec) and
-    device vectors throughout.  'cs' needs complex arithmetic the ipx kernels do
-    not have and is refused."""
+    device vectors throughout.  'cs' (_numdiff.py:429-437) hands the user's callback a
+    COMPLEX CUDA tensor ``x0 + i dx p`` -- the callback must be analytic in torch's complex
+    arithmetic, exactly the reference's requirement on numpy callbacks -- and takes the
+    imaginary part of what it returns; the perturbed point and the quotient are two torch
+    elementwise operations on data that never leaves the device (the ipx kernels are real)."""
     device_operator = True       # backend_hip.hessian_operator keeps it on the device
 
     def __init__(self, fun, x0, method, f0=None):
         from .device import DVec
         if method not in FD_METHODS:
             raise ValueError("Unknown method '%s'. " % method)
-        if method == 'cs':
-            raise NotImplementedError("complex-step differences are not available in "
-                                      "device-callback mode; use '2-point' or '3-point'")
         self._DVec = DVec
+        self._raw = fun
         self.fun = lambda x: self._vec(fun(x.t))
         self.x0 = x0
         self.f0 = self._vec(f0) if f0 is not None else self.fun(x0)
@@ -84,6 +85,21 @@ class DeviceFiniteDifferenceOperator:
         if self.method == '2-point':          # _numdiff.py:408-415
             dx = self.h / norm_p
             return (self.fun(self.x0.add_scaled(p, dx)) - self.f0) * (1.0 / dx)
+        if self.method == 'cs':               # :429-437
+            import torch
+            dx = self.h / norm_p
+            try:
+                f1 = self._raw(torch.complex(self.x0.t, p.t * dx))
+            except Exception as exc:          # (a callback built on real-only kernels)
+                raise TypeError("hess='cs': the callback failed on a complex CUDA tensor (%r); "
+                                "complex-step differences need a callback that is analytic in "
+                                "torch's complex arithmetic -- use '2-point' or '3-point'"
+                                % (exc,)) from exc
+            f1 = f1.t if isinstance(f1, self._DVec) else f1
+            if not torch.is_complex(f1):
+                raise TypeError("hess='cs': the callback returned a real tensor for a complex "
+                                "argument (it must be analytic in complex arithmetic)")
+            return self._DVec((f1.imag * (1.0 / dx)).contiguous())
         dx = 2 * self.h / norm_p              # '3-point' :417-427
         f1 = self.fun(self.x0.add_scaled(p, -(dx / 2)))
         f2 = self.fun(self.x0.add_scaled(p, dx / 2))

@@ -391,13 +391,17 @@ def orthogonality(A, g):
     return dv.norm(A.dot(g)) / (norm_A * norm_g)
 
 
-def _box_schur_applies(A, kmax):
-    """Pattern test: enough box-like rows, and the general rows alone are banded."""
+def _box_schur_applies(A, kmax, any_sparsity=False):
+    """Pattern test: enough box-like rows, and the general rows alone are banded -- or, with
+    ``any_sparsity``, of any pattern (the Schur complement then goes to the dense or the
+    iterative solver: boxschur.BoxSchurNormalSolver)."""
     from .boxschur import analysis_for
     from .device_mode import RowSelection
     an = analysis_for(A.pattern)
     if not an.worthwhile:
         return False
+    if any_sparsity:
+        return len(an.general) > 0
     cache = getattr(A.pattern, "_ipx_box_general_pattern", None)
     if cache is None:
         cache = A.pattern._ipx_box_general_pattern = RowSelection(A.pattern, an.general, None)
@@ -584,6 +588,14 @@ def normal_solver_for(A):
             pass
     if m <= DenseNormalSolver.MAX_ROWS_FROM_SPARSE:
         return DenseNormalSolver(A)             # wide band: dense Cholesky of A A'
+    if _box_schur_applies(A, kmax, any_sparsity=True):
+        # barrier problem with a Jacobian of general sparsity (the reference factors any
+        # pattern with SuperLU, projections.py:93-172): the bound rows -- two thirds of the
+        # matrix, and the ones whose slacks ruin the conditioning of A A' late in the barrier
+        # run -- are still eliminated in closed form; what is left to the dense / iterative
+        # solver is the Schur complement of the general rows, J (I - W) J' + S^2
+        from .boxschur import BoxSchurNormalSolver
+        return BoxSchurNormalSolver(A, any_sparsity=True)
     return IterativeNormalSolver(A)             # general sparsity: matrix-free solve
 
 

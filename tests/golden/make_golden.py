@@ -26,6 +26,9 @@ Outputs (numbers only -- no reference source travels):
                     m=1e5 through the reference: all rows of the scalar trace, every 1000th
                     component of x, the one-ulp record
   e2e_ineq_n20000.json  (``--c5-n20000``: 25 minutes) box + inequality NLP at n=20000 / m=2000
+  e2e_cs.json       (``--cs``) the two finite-difference test problems with hess='cs'
+  e2e_sparse_barrier.json  (``--sparse-barrier``: a minute) box + linear inequalities with a
+                    Jacobian of RANDOM sparsity, n=1200 / m=800 (tests/problems.py)
   config2.json      (``--big`` only: minutes) dense equality QP of BASELINE config 2 at
                     n=4000/m=800 and n=10000/m=2000: scalar traces + strided x
   api.json          (``--api``) the host-side API either side of the path -- kind grammar,
@@ -589,6 +592,25 @@ def main():
         rec["x_stride"] = 100
         with open(os.path.join(HERE, "e2e_ineq_n20000.json"), "w") as f:
             json.dump({"banded_ineq_n20000": rec}, f)
+        return
+    if "--cs" in sys.argv:
+        # complex-step Hessian products (hess='cs', _numdiff.py:429-437) on the reference's own
+        # finite-difference test problems
+        out = {}
+        for cls in (problems.Maratos, problems.HyperbolicIneq):
+            p = cls()
+            key = p.name + "_cs"
+            out[key] = run_e2e(key, p.fun, p.x0, p.grad, "cs", p.constraints(ref))
+        with open(os.path.join(HERE, "e2e_cs.json"), "w") as f:
+            json.dump(out, f)
+        return
+    if "--sparse-barrier" in sys.argv:
+        # barrier problem with a Jacobian of random sparsity (tests/problems.py SparseBarrierQP)
+        p = problems.SparseBarrierQP(1200, 800)
+        rec = run_e2e(p.name, p.fun, p.x0, p.grad, p.hess, p.constraints(ref), x_stride=10)
+        rec["x_stride"] = 10
+        with open(os.path.join(HERE, "e2e_sparse_barrier.json"), "w") as f:
+            json.dump({p.name: rec}, f)
         return
     if "--big" in sys.argv:
         out = {}

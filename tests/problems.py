@@ -274,3 +274,38 @@ class DeviceHyperbolicIneq(HyperbolicIneq):
             lambda x: _row_csr([-1 / (x[0] + 1) ** 2, -torch.ones_like(x[0])]),
             lambda x, v: torch.stack([2 * v[0] / (x[0] + 1) ** 3, torch.zeros_like(x[0])]))
         return (nl, ns.BoxConstraint(("greater",)))
+
+
+class SparseBarrierQP(Problem):
+    """Separable convex QP under linear inequalities with a Jacobian of RANDOM sparsity (``per``
+    entries per row at random columns: no band, no reordering makes J J' narrow) and a box on
+    every variable -- the barrier problem shape of BASELINE config 5 without its band.  The
+    reference factors the augmented system of any pattern with SuperLU (projections.py:93-172);
+    here it exercises the box-Schur elimination over a dense / iterative Schur solve."""
+    name = "sparse_barrier_qp"
+
+    def __init__(self, n=1200, m=800, per=4, seed=0):
+        rng = np.random.default_rng(seed)
+        cols = np.concatenate([rng.choice(n, per, replace=False) for _ in range(m)])
+        J = sps.csr_matrix((rng.standard_normal(m * per), cols, np.arange(0, m * per + 1, per)),
+                           shape=(m, n))
+        J.sort_indices()
+        self.n, self.m, self.J = n, m, J
+        self.d = rng.uniform(1.0, 2.0, n)
+        self.q = rng.standard_normal(n)
+        self.x0 = rng.uniform(-0.5, 0.5, n)
+        self.bnd = J.dot(self.x0) + rng.uniform(0.0, 0.5, m)      # strictly feasible at x0
+        self.H = sps.diags(self.d, format="csr")
+
+    def fun(self, x):
+        return 0.5 * x.dot(self.d * x) - self.q.dot(x)
+
+    def grad(self, x):
+        return self.d * x - self.q
+
+    def hess(self, x):
+        return self.H
+
+    def constraints(self, ns):
+        return (ns.LinearConstraint(self.J, ("less", self.bnd)),
+                ns.BoxConstraint(("interval", -0.8, 0.8)))
