@@ -78,7 +78,9 @@ def stored_traffic(profile, kernel):
     if have != want:
         return None, ("profiles/%s was measured on other kernel sources (hash %s, this build %s): "
                       "not attached" % (profile, have, want))
-    val = pmc["kernels"].get(kernel, {}).get("hbm_bytes_per_launch")
+    alias = {"banded_solve_residual_r_minus_Atv": "banded_solve_pcr"}     # (the summary's name)
+    val = (pmc["kernels"].get(kernel) or pmc["kernels"].get(alias.get(kernel, ""), {})) \
+        .get("hbm_bytes_per_launch")
     return val, ("STORED, not measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                  "(separate passes, gfx950 FETCH correction calibrated in-run on kernels of known "
                  "byte count) over scripts/pmc_workload.py, profiles/%s, same kernel sources "
@@ -855,7 +857,10 @@ def spawn_ranks(n_gpus, argv, K, W):
     base = dict(os.environ, IPX_BENCH_SPAWNED="1", WORLD_SIZE=str(n_gpus),
                 LOCAL_WORLD_SIZE=str(n_gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    base.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n_gpus)))
+    # (what torch.distributed.run sets too: with one thread pool of all cores per rank the tiny
+    # host-side tensor ops of the outer loop's collectives take milliseconds each -- measured:
+    # the sharded config-4 solve 3.1 s instead of 0.13 s)
+    base.setdefault("OMP_NUM_THREADS", "1")
     cmd = [sys.executable, os.path.abspath(__file__)] + list(argv)
     procs, errs = [], []
     for r in range(n_gpus):
