@@ -793,7 +793,9 @@ def _run_loop(L, pool_key, P, lib, st, n, lb, ub, trust_radius, max_iter, max_in
               batch, stats, fast):
     class Driver:
         """The single-GPU loop behind ``run_device_loop``."""
-        first_batch = 4 if L.operator is None else 2
+        # (a caller that asks for at most a few dozen iterations gets them in ONE batch: one
+        # state read for the call; the open-ended calls of the SQP start with four)
+        first_batch = (max_iter if 4 < max_iter <= 32 else 4) if L.operator is None else 2
         batch_cap = 64 if L.operator is None else 8   # (an operator is applied once per
                                                       #  enqueued iteration, stopped or not)
         def iterate(self, it, end):
