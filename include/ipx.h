@@ -249,10 +249,13 @@ typedef struct ipx_cg_args {
   int64_t At_qv;
   int64_t A_tile_nnz;    /* must be 0 (a row-tile table of its own for the fused step1 was an
                           * experiment of round 2; the field keeps the layout) */
-  /* the rows of A' once more in ELL(2) form for that tail (2n ints, 2n doubles: entry t of
-   * variable j at [t*n + j]; an absent entry repeats a valid column with value 0): indexed by
-   * the variable alone, so the tail's loads need no row-pointer round trip.  NULL: CSR. */
-  const int32_t *At_ell_col;
+  /* the rows of A' once more in ELL(2) form for that tail, indexed by the variable alone (no
+   * row-pointer round trip): At_ell_val = 2n doubles, entry t of variable j at [t*n + j], t = 0
+   * its FIRST constraint, t = 1 the next row (tridiagonal A A': a variable sees at most two
+   * constraints and they are adjacent), an absent entry 0; At_ell_row = n uint16 (n even), the
+   * first constraint's row as an offset from the first row of the workgroup that owns the
+   * variable (At_vown; < rows per workgroup).  18 bytes per variable.  NULL: CSR. */
+  const uint16_t *At_ell_row;
   const double *At_ell_val;
   /* Compact index form of H for the fused step2 + H.p kernel (H_hmax > 0), or NULL:
    * H_col16 = one uint16 per nonzero, its column as an offset into the row tile's span

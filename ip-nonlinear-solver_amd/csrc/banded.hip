@@ -1049,10 +1049,12 @@ struct AtvJob {
   double *g_out;
   const int32_t *vown;
   double *part3;
-  // the same rows of A' in ELL(2) form (every variable sees at most two constraints):
-  // ell_col[t * n + j] / ell_val[t * n + j], t = 0, 1; an absent entry repeats a valid
-  // column with value 0.  Indexed by the variable alone: no row-pointer round trip.
-  const int32_t *ell_col;
+  // the same rows of A' in ELL(2) form for a tridiagonal A A' (a variable sees at most two
+  // constraints, adjacent rows): ell_val[t * n + j], t = 0 the first constraint of variable j,
+  // t = 1 the row after it (absent: 0); ell_row[j] = the first constraint's row as an offset
+  // from the first row of the workgroup that owns j.  Indexed by the variable alone: no
+  // row-pointer round trip; 18 bytes per variable.
+  const uint16_t *ell_row;
   const double *ell_val;
   int64_t ell_n;
 };
@@ -1495,17 +1497,15 @@ k_solve_pcr(int m, int rows_wg, int L, const double *__restrict__ band,
   // is bound by the CU's load issue, 2600 variables x 5 arrays per workgroup); pairs start at
   // an even variable so every load is naturally aligned (the planes are padded to even length)
   constexpr int QP = (QA + 1) / 2;
-  typedef int v2i __attribute__((ext_vector_type(2)));
   const int64_t vb = av0 & ~1;                       // first pair (may start one before av0)
-  v2i ac0[QP], ac1[QP];
+  unsigned ac[QP];                                   // (two 16-bit row offsets)
   v2d aw0[QP], aw1[QP], ar[QP];
   if (QV > 0) {
     const int64_t last = max((int64_t)av0 + avn - 1, vb) & ~(int64_t)1;
 #pragma unroll
     for (int k = 0; k < QP; ++k) {
       const int64_t j = min(vb + 2 * (int64_t)(tid + k * IPX_BLOCK), last);
-      ac0[k] = *reinterpret_cast<const v2i *>(atv.ell_col + j);
-      ac1[k] = *reinterpret_cast<const v2i *>(atv.ell_col + atv.ell_n + j);
+      ac[k] = *reinterpret_cast<const unsigned *>(atv.ell_row + j);
       aw0[k] = *reinterpret_cast<const v2d *>(atv.ell_val + j);
       aw1[k] = *reinterpret_cast<const v2d *>(atv.ell_val + atv.ell_n + j);
       ar[k] = *reinterpret_cast<const v2d *>(atv.r_in + j);
@@ -1569,10 +1569,12 @@ k_solve_pcr(int m, int rows_wg, int L, const double *__restrict__ band,
 #pragma unroll
     for (int k = 0; k < QP; ++k) {
       const int64_t j = vb + 2 * (int64_t)(tid + k * IPX_BLOCK);
-      // (an absent entry carries value 0 and a valid column: same sum as the CSR row)
-      double y0 = -1.0 * (aw0[k].x * sx[ac0[k].x - g0] + aw1[k].x * sx[ac1[k].x - g0]);
+      // (an absent entry carries value 0: same sum as the CSR row; a pair that reaches into a
+      // neighbour's variables reads that workgroup's offsets -- in range, result unused)
+      const int c0 = H + (int)(ac[k] & 0xffffu), c1 = H + (int)(ac[k] >> 16);
+      double y0 = -1.0 * (aw0[k].x * sx[c0] + aw1[k].x * sx[c0 + 1]);
       y0 += 1.0 * ar[k].x;
-      double y1 = -1.0 * (aw0[k].y * sx[ac0[k].y - g0] + aw1[k].y * sx[ac1[k].y - g0]);
+      double y1 = -1.0 * (aw0[k].y * sx[c1] + aw1[k].y * sx[c1 + 1]);
       y1 += 1.0 * ar[k].y;
       const bool in0 = j >= av0 && j < (int64_t)av0 + avn;
       const bool in1 = j + 1 >= av0 && j + 1 < (int64_t)av0 + avn;
@@ -2396,14 +2398,14 @@ int ipx_banded_solve_resid_atv_launch(void *handle, const double *w, double *x, 
                                       const int32_t *At_colidx, const double *At_val,
                                       const double *r_in, double *g_out, const int32_t *vown,
                                       int qv, double *part3, const double *guard,
-                                      hipStream_t st, const int32_t *ell_col,
+                                      hipStream_t st, const uint16_t *ell_row,
                                       const double *ell_val, int64_t ell_n) {
   if (!handle || !w || !x || !partial || w == x) return IPX_EINVAL;
   int32_t geo[2];
   if (!ipx_banded_decoupled_geometry(handle, geo)) return IPX_EINVAL;
   Banded *h = (Banded *)handle;
-  const AtvJob job{At_rowptr, At_colidx, At_val, r_in, g_out, vown, part3, ell_col, ell_val, ell_n};
-  if (h->pcr_L > 0 && ell_col && ell_val)
+  const AtvJob job{At_rowptr, At_colidx, At_val, r_in, g_out, vown, part3, ell_row, ell_val, ell_n};
+  if (h->pcr_L > 0 && ell_row && ell_val)
     return launch_solve_pcr(to_dev(h->lev[0], nullptr), h->pcr_L, w, x, partial, npartial, guard,
                             st, &job, qv);
   const LevDev lv = to_dev(h->lev[0], nullptr);

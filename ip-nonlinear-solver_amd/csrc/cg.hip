@@ -1453,7 +1453,7 @@ static int shard2_segment(const ipx_cg_args *a, const ipx_shard2_ext *e, int32_t
       return ipx_banded_solve_resid_atv_launch(a->banded, a->w, a->v, a->part4, &np4, a->At_rowptr,
                                                a->At_colidx, a->At_val, a->r_next, a->r,
                                                a->At_vown, (int)a->At_qv, a->part3, stopw, st,
-                                               a->At_ell_col, a->At_ell_val, a->n);
+                                               a->At_ell_row, a->At_ell_val, a->n);
     }
     // step2 + H.p with the all-reduce of the four sums and the halo exchange of g in its
     // prologue; the own sums of p'Hp stay in part1 for the next step1
@@ -1516,7 +1516,7 @@ static int shard2_segment(const ipx_cg_args *a, const ipx_shard2_ext *e, int32_t
         rc = ipx_banded_solve_resid_atv_launch(a->banded, a->w, a->v, a->part4, &np4,
                                                a->At_rowptr, a->At_colidx, a->At_val, r_in, a->r,
                                                a->At_vown, (int)a->At_qv, a->part3, guard, st,
-                                               a->At_ell_col, a->At_ell_val, a->n);
+                                               a->At_ell_row, a->At_ell_val, a->n);
         if (rc) return rc;
         np3 = np4;
       } else {
@@ -1930,7 +1930,7 @@ static int cg_iterate(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, hi
         rc = ipx_banded_solve_resid_atv_launch(a->banded, a->w, a->v, a->part4, &np4,
                                                a->At_rowptr, a->At_colidx, a->At_val, r_in, a->r,
                                                a->At_vown, (int)a->At_qv, a->part3, guard, st,
-                                               a->At_ell_col, a->At_ell_val, a->n);
+                                               a->At_ell_row, a->At_ell_val, a->n);
         if (rc) return rc;
         np3 = np4;
         MARK(3);

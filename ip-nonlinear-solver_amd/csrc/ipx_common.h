@@ -621,7 +621,7 @@ int ipx_banded_solve_resid_atv_launch(void *handle, const double *w, double *x, 
                                       const int32_t *At_colidx, const double *At_val,
                                       const double *r_in, double *g_out, const int32_t *vown,
                                       int qv, double *part3, const double *guard,
-                                      hipStream_t st, const int32_t *ell_col = nullptr,
+                                      hipStream_t st, const uint16_t *ell_row = nullptr,
                                       const double *ell_val = nullptr, int64_t ell_n = 0);
 int ipx_banded_solve_resid_launch(void *handle, const double *w, double *x, double *partial,
                                   int *npartial, const double *guard, hipStream_t st);

@@ -87,7 +87,7 @@ struct ResJob {
   int rl;
   const int32_t *win, *vown;
   int nspan, navn;
-  const int32_t *ell_col;       // A' in ELL(2) form: entry t of variable j at [t * n + j]
+  const uint16_t *ell_row;      // A' in ELL(2) form (ipx_cg_args.At_ell_row / At_ell_val)
   const double *ell_val;
   const int32_t *H_rowptr, *H_colidx;
   const double *H_val, *H_diag;
@@ -363,8 +363,8 @@ k_cg_resident(ResJob J) {
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int64_t jj = min(j + u, (int64_t)J.n - 1);
-        const int c0 = min(max((int)(J.ell_col[jj] - g0), 0), R - 1);
-        const int c1 = min(max((int)(J.ell_col[(int64_t)J.n + jj] - g0), 0), R - 1);
+        const int c0 = min(H + (int)J.ell_row[jj], R - 1);
+        const int c1 = min(c0 + 1, R - 1);
         ec2[k][u] = c0 | (c1 << 16);
       }
     }
@@ -834,7 +834,7 @@ extern "C" int64_t ipx_cg_resident_ll_words(int32_t nwg, int32_t hw) {
 extern "C" int ipx_cg_resident_ok(const ipx_cg_args *a) {
   if (!a || !a->resident || !a->R_ll || !a->R_seq || a->solver_kind != 0 || a->lb || a->m <= 0 ||
       !a->P_win || !a->A_off16 || !a->A_rowfirst || a->A_rl < 1 || a->A_rl > RLA || !a->At_vown ||
-      !a->At_ell_col || !a->At_ell_val || a->H_operator || !a->H_rowptr || a->H_hmax < 1 ||
+      !a->At_ell_row || !a->At_ell_val || a->H_operator || !a->H_rowptr || a->H_hmax < 1 ||
       a->H_hmax > 64 || (a->n & 1) || a->n > (1 << 26) || a->m * a->A_rl > (1ll << 30))
     return 0;
   ipx_pcr_view pv;
@@ -863,7 +863,7 @@ int ipx_cg_resident_launch(const ipx_cg_args *a, int32_t it_begin, int32_t it_en
   J.A_val = a->A_val; J.A_off16 = (const uint16_t *)a->A_off16; J.A_rowfirst = a->A_rowfirst;
   J.rl = (int)a->A_rl; J.win = a->P_win; J.vown = a->At_vown; J.nspan = (int)a->P_nspan;
   J.navn = (int)a->P_navn;
-  J.ell_col = a->At_ell_col; J.ell_val = a->At_ell_val;
+  J.ell_row = a->At_ell_row; J.ell_val = a->At_ell_val;
   J.H_rowptr = a->H_rowptr; J.H_colidx = a->H_colidx; J.H_val = a->H_val; J.H_diag = a->H_diag;
   J.hmax = (int)a->H_hmax;
   J.part1 = a->part1; J.part2 = a->part2; J.part3 = a->part3; J.part4 = a->part4;

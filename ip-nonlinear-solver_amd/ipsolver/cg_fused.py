@@ -40,7 +40,7 @@ class CgArgs(ctypes.Structure):
         ("vec_grid", _I64), ("solver_kind", _I64), ("pb", _P), ("H_hmax", _I64), ("H_tile_rows", _I64),
         ("r_next", _P), ("A_own", _P), ("A_span", _I64), ("fold_ws", _P),
         ("At_vown", _P), ("At_qv", _I64), ("A_tile_nnz", _I64),
-        ("At_ell_col", _P), ("At_ell_val", _P),
+        ("At_ell_row", _P), ("At_ell_val", _P),
         ("H_col16", _P), ("H_rowlen", _P), ("A_col16", _P), ("no_radius", _I64),
         ("A_off16", _P), ("A_rowfirst", _P), ("A_rl", _I64), ("P_win", _P), ("P_nspan", _I64),
         ("P_navn", _I64), ("H_operator", _I64),
@@ -215,7 +215,9 @@ def own_columns16(pattern):
 
 def fuse_vown(At_pattern, rows_per_wg, nwg, k=1):
     """Variables owned by each workgroup of the single-launch decoupled solve, for the
-    fused g = r - A'v tail (csrc/banded.hip AtvJob): ``(table, qv)`` or None.  A variable
+    fused g = r - A'v tail (csrc/banded.hip AtvJob): ``(table, qv, row_rel)`` or None
+    (``row_rel``, host array: every variable's first constraint as an offset from its owner's
+    first row -- the index of the ELL(2) form, ``ell_rows``).  A variable
     belongs to the workgroup whose constraint rows contain the first constraint that
     touches it.  Qualifies when every variable sees at most ``k + 1`` constraints, all within
     ``k`` rows of the first (``k`` = half bandwidth of A A', <= 4: the kernel keeps the
@@ -248,41 +250,49 @@ def fuse_vown(At_pattern, rows_per_wg, nwg, k=1):
                 vmax = int(np.max(np.diff(vown)))
                 qv = (vmax + 191) // 192          # 192 lanes per workgroup work on the tail
                 if 0 < qv <= 16:
-                    out = (torch.from_numpy(vown.astype(np.int32)).to(ctx().device), qv)
+                    out = (torch.from_numpy(vown.astype(np.int32)).to(ctx().device), qv,
+                           filled - owner * rows_per_wg)
     At_pattern._ipx_fuse_vown = (key, out)
     return out
 
 
-def ell_rows(At):
-    """The rows of ``At`` (every one with at most two entries: checked by ``fuse_vown``) in
-    ELL(2) form for the tail of the banded solve: ``(col, val)`` with entry t of row j at
-    ``[t * n + j]`` (csrc/banded.hip reads pairs of rows with 16-byte loads: n must be even
-    -- asserted by the caller -- and the buffers 16-byte aligned, which torch's are).  The column table and the gather map are symbolic (cached on the
-    pattern); the values are one gather per call."""
+def ell_rows(At, row_rel):
+    """The rows of ``At`` (every one with at most two entries, in adjacent columns: checked by
+    ``fuse_vown`` with k = 1, whose ``row_rel`` this takes) in ELL(2) form for the tail of the
+    cyclic-reduction solve: ``(row16, val)`` with ``val[t * n + j]`` = the entry of variable j
+    in its first constraint (t = 0) / in the row after it (t = 1), 0 where absent, and
+    ``row16[j]`` = that first constraint as a 16-bit offset from the first row of the owning
+    workgroup (csrc/banded.hip reads pairs of variables with 16- and 4-byte loads: n must be
+    even -- asserted by the caller -- and the buffers 16-byte aligned, which torch's are).
+    18 bytes per variable instead of the 24 of two full column indices.  The row table and the
+    gather map are symbolic (cached on the pattern); the values are one gather per call."""
     done = getattr(At, "_ipx_ell_done", None)        # same matrix object: same values
-    if done is not None:
-        return done
+    if done is not None and done[0] is row_rel:
+        return done[1], done[2]
     pat = At.pattern
     cache = getattr(pat, "_ipx_ell2", None)
-    if cache is None:
+    if cache is None or cache[0] is not row_rel:
         n = pat.shape[0]
         ip = pat.indptr_h.astype(np.int64)
+        idx = pat.indices_h.astype(np.int64)
         lens = np.diff(ip)
         last = max(pat.nnz - 1, 0)
-        e0 = np.minimum(ip[:-1], last)                       # rows without entries: any valid one
-        e1 = np.where(lens > 1, ip[:-1] + 1, e0)
+        ea = np.minimum(ip[:-1], last)                       # rows without entries: any valid one
+        eb = np.where(lens > 1, ip[:-1] + 1, ea)
+        swap = idx[ea] > idx[eb] if pat.nnz else np.zeros(n, dtype=bool)   # (entries in any order)
+        e0, e1 = np.where(swap, eb, ea), np.where(swap, ea, eb)
         src = np.concatenate((e0, e1))
         mask = np.concatenate((lens > 0, lens > 1)).astype(np.float64)
-        col = pat.indices_h[src] if pat.nnz else np.zeros(2 * n, dtype=np.int32)
         dev = ctx().device
-        cache = pat._ipx_ell2 = (torch.from_numpy(np.ascontiguousarray(col, dtype=np.int32)).to(dev),
+        cache = pat._ipx_ell2 = (row_rel,
+                                 torch.from_numpy(row_rel.astype(np.uint16).view(np.int16)).to(dev),
                                  torch.from_numpy(src.astype(np.int32)).to(dev),
                                  torch.from_numpy(mask).to(dev))
-    col, src, mask = cache
-    val = torch.empty(src.numel(), dtype=torch.float64, device=col.device)
+    _, row16, src, mask = cache
+    val = torch.empty(src.numel(), dtype=torch.float64, device=row16.device)
     _hip.call("ipx_gather", src.numel(), _p(At.val), _p(src), _p(mask), None, _p(val), stream_ptr())
-    At._ipx_ell_done = (col, val)
-    return col, val
+    At._ipx_ell_done = (row_rel, row16, val)
+    return row16, val
 
 
 PF_U, PF_QS, PF_QX = 23, 16, 12      # csrc/resident.hip RU, RQS, RQX
@@ -451,8 +461,8 @@ class _Loop:
         a.lb = _ptr(lb.t) if lb is not None else None
         a.ub = _ptr(ub.t) if ub is not None else None
         if a.At_ell_val:
-            self.ell_col, self.ell_val = ell_rows(At)
-            a.At_ell_col, a.At_ell_val = _ptr(self.ell_col), _ptr(self.ell_val)
+            self.ell_row, self.ell_val = ell_rows(At, self.row_rel)
+            a.At_ell_row, a.At_ell_val = _ptr(self.ell_row), _ptr(self.ell_val)
         a.no_radius = 0
         self.x = torch.empty(self.n, dtype=torch.float64, device=self.state.device)
         a.x = _ptr(self.x)
@@ -554,10 +564,12 @@ class _Loop:
                 if vown is not None:
                     self.vown = vown[0]
                     a.At_vown, a.At_qv = _ptr(self.vown), vown[1]
-                    # tridiagonal A A': ELL(2) rows, pairs of variables per 16-byte load
+                    # tridiagonal A A': ELL(2) rows with one 16-bit row offset per variable, pairs of
+                    # variables per 16-byte load
                     if n % 2 == 0 and kS == 1:
-                        self.ell_col, self.ell_val = ell_rows(At)
-                        a.At_ell_col, a.At_ell_val = _ptr(self.ell_col), _ptr(self.ell_val)
+                        self.row_rel = vown[2]
+                        self.ell_row, self.ell_val = ell_rows(At, self.row_rel)
+                        a.At_ell_row, a.At_ell_val = _ptr(self.ell_row), _ptr(self.ell_val)
                     # small problems (one CU per workgroup of the cyclic-reduction solve: the
                     # per-rank sizes of a multi-GPU run), uniform rows, no box, short Hessian
                     # rows: a whole batch of iterations as ONE resident launch

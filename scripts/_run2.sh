@@ -1,3 +1,2 @@
-mkdir -p gpurun_out/final
-IPX_BENCH_BACKEND=gloo python bench.py --gpus 2 2>/tmp/b2.err | grep '^{' > gpurun_out/final/bench_2rank.json; tail -c 200 gpurun_out/final/bench_2rank.json; echo; tail -3 /tmp/b2.err
-python bench.py 2>/tmp/b.err | grep '^{' > gpurun_out/final/bench_line.json; tail -c 200 gpurun_out/final/bench_line.json; echo
+timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -6
+bash scripts/refresh_profiles.sh wip bench trace pmc config5 2>&1 | tail -30

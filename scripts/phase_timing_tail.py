@@ -29,7 +29,7 @@ L.x.copy_(x0.t); L.r.copy_(r0.t)
 _hip.call("ipx_axpby", n, -1.0, dv._p(g0.t), 0.0, None, dv._p(L.p), st)
 L.state.copy_(torch.from_numpy(init))
 _hip.check(lib.ipx_cg_hp(L.ref(), st), "hp")
-acc = np.zeros(15); R = 40
+acc = np.zeros(16); R = 40
 for it in range(R + 5):
     _hip.check(lib.ipx_cg_iterate(L.ref(), it, it + 1, st), "it")
     torch.cuda.synchronize()
@@ -37,8 +37,12 @@ for it in range(R + 5):
     lib.ipx_debug_stamps(out)
     t = np.array(list(out), dtype=np.float64)
     if it >= 5:
-        acc += np.diff(t)
-names = {0: "0->1 loads issued (+stop test)", 1: "1->2 level-0 copies", 2: "2->3 reduction levels", 5: "3->6 x stored", 6: "6->7 tail + residual"}
+        acc += t - t[0]
+names = {1: "loads issued (+stop test)", 2: "level-0 copies", 3: "reduction levels done",
+         6: "x stored, barrier", 7: "tail + residual done"}
 ts = acc / R * 0.01
-print("stamps (us, workgroup 0):", {k: round(ts[k], 2) for k in range(7)})
+print("stamps (us after kernel start, workgroup 0):")
+for k in (1, 2, 3, 6, 7):
+    if ts[k] > 0:
+        print("  %5.2f  %s" % (ts[k], names[k]))
 print("qv", L.args.At_qv, "fused tail", bool(L.args.At_qv))

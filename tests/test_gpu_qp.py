@@ -995,6 +995,66 @@ def test_debug_forms_of_the_three_launch_loop(ips, form, monkeypatch):
         assert np.max(np.abs(x1 - x2)) <= 1e-13 * np.max(np.abs(x1))
 
 
+@pytest.mark.parametrize("rl,shift,m", [(4, 3, 50001), (9, 5, 40000), (16, 9, 30000),
+                                        (3, 2, 30001)])
+def test_solve_tail_for_rows_of_every_length(ips, rl, shift, m, monkeypatch):
+    """The tail of the cyclic-reduction solve (g = r - A'v from the ELL(2) form of A' with one
+    16-bit row offset per variable, csrc/banded.hip k_solve_pcr / ipsolver/cg_fused.py
+    ell_rows) on Jacobians of other row lengths and overlaps than the benchmark's (3 .. 16
+    entries, every variable-per-lane budget of the kernel), with an odd row count (the last
+    workgroup's partial block) and the entries of A' stored in descending row order: the
+    iterates of the loop without fused kernels to 1e-13, and the projected-CG trace of the
+    host oracle (qp_subproblem.py:332-637) to 1e-10."""
+    import scipy.sparse as sp
+    import ipsolver.cg_fused as cg_fused
+    from ipsolver.operators import DeviceHessian
+    rng = np.random.default_rng(rl * 1000 + shift)
+    n = (m - 1) * shift + rl
+    n += n % 2                               # (the pair loads of the tail want an even n)
+    rows = np.repeat(np.arange(m), rl)
+    cols = (np.arange(m)[:, None] * shift + np.arange(rl)[None, :]).ravel()
+    Ah = sp.csr_matrix((rng.uniform(0.5, 1.5, m * rl) * rng.choice([-1.0, 1.0], m * rl),
+                        (rows, cols)), shape=(m, n))
+    off = rng.uniform(-0.4, 0.4, n - 1)
+    Hh = sp.diags([off, rng.uniform(1.5, 2.5, n), off], [-1, 0, 1], format="csr")
+    c = rng.standard_normal(n)
+    b = np.zeros(m)
+    runs = []
+    for flag in ("", "no-fuse"):
+        if flag:
+            monkeypatch.setenv("IPX_DEBUG_FORMS", flag)
+        else:
+            monkeypatch.delenv("IPX_DEBUG_FORMS", raising=False)
+        A = ips.dv.DeviceCSR.from_scipy(Ah)
+        if rl == 9:
+            # A' with each variable's two entries in descending row order (unsorted CSR rows)
+            At = Ah.T.tocsr()
+            At.sort_indices()
+            ip = At.indptr
+            two = np.flatnonzero(np.diff(ip) == 2)
+            for arr in (At.indices, At.data):
+                lo = arr[ip[two]].copy()
+                arr[ip[two]] = arr[ip[two] + 1]
+                arr[ip[two] + 1] = lo
+            At.has_sorted_indices = False
+            A._T = ips.dv.DeviceCSR.from_scipy(At)
+            A._T._T = A
+        H = DeviceHessian(n, csr=ips.dv.DeviceCSR.from_scipy(Hh))
+        Z, LS, Y = ips.proj.projections(A)
+        L = cg_fused._Loop(H, Z.projector, None, None, resident=False)
+        assert bool(L.args.At_ell_val) == (flag == "") and bool(L.args.At_ell_row) == (flag == "")
+        x, info = ips.qp.projected_cg(H, c, Z, Y, b, tol=0, max_iter=12, trust_radius=1e300)
+        runs.append((host(x), info))
+    (x1, i1), (x2, i2) = runs
+    assert i1 == i2
+    assert np.max(np.abs(x1 - x2)) <= 1e-13 * np.max(np.abs(x1))
+    import oracle
+    Zo, LSo, Yo = oracle.projections(Ah)
+    xo, io = oracle.projected_cg(Hh, c, Zo, Yo, b, tol=0, max_iter=12, trust_radius=1e300)
+    assert io["niter"] == i1["niter"] and io["stop_cond"] == i1["stop_cond"]
+    assert np.max(np.abs(x1 - xo)) <= 1e-10 * np.max(np.abs(xo))
+
+
 def test_device_loop_with_an_operator_hessian(ips):
     """A Hessian that is only an operator (``dot`` over device vectors -- what the reference's
     LinearOperator terms are: finite differences, user callbacks, _canonical_constraint.py:
