@@ -320,11 +320,14 @@ int ipx_cg_iterate(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, void 
 /* The whole priming of a call (qp_subproblem.py:502-512: x0 = Y(-b), r0 = Z(H x0 + c), g0 = Z r0,
  * the state block, p = -g0, Hp = H p) enqueued by ONE call into the loop's own buffers; CSR A
  * (A_tiles / A_ntiles: its standard SpMV row tiles) and H, solver_kind 0 or 1; b NULL = 0;
- * red: 14 doubles, ws: IPX_WS_DOUBLES doubles of device memory.  Stop code 9 in the state block
- * afterwards: the host must prime (ipx_cg_prime_state). */
+ * red: 14 doubles, ws: IPX_WS_DOUBLES doubles of device memory.  first_end > 0: iterations
+ * [0, first_end) are enqueued behind the priming by the same call (as ipx_cg_iterate would).
+ * Stop code 9 in the state block afterwards: the host must prime (ipx_cg_prime_state); the
+ * iterations enqueued with it did nothing. */
 int ipx_cg_prime(const ipx_cg_args *a, const int32_t *A_tiles, int32_t A_ntiles, const double *c,
                  const double *b, double *red, double *ws, double tol_in, double radius,
-                 double orth_tol, double norm_A, double cancellation, void *stream);
+                 double orth_tol, double norm_A, double cancellation, int32_t first_end,
+                 void *stream);
 int ipx_cg_prime_state(double *state, const double *red, const int32_t *idx7, double tol_in,
                        double radius, double orth_tol, double norm_A, double cancellation,
                        void *stream);

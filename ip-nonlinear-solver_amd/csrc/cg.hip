@@ -1616,10 +1616,9 @@ int ipx_cg_shard2_fold_hp(const ipx_cg_args *a, const ipx_shard2_ext *e, void *s
 // radius, the orthogonality threshold -- and stop code 9 when the host must take over: a
 // projection that needs refinement (projections.py:72-78) or the cancellation step
 // (projector.null_space), or no room to the trust-region boundary (:515-526).
-__global__ void k_cg_prime_state(double *st, const double *__restrict__ red, ipx_prime_idx ix,
+__device__ void prime_state_body(double *st, const double *red, const ipx_prime_idx &ix,
                                  double tol_in, double radius, double orth_tol, double norm_A,
                                  double canc2) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
   double q[7];
   for (int k = 0; k < 7; ++k) q[k] = ix.i[k] >= 0 ? red[ix.i[k]] : 0.0;
   bool bad = false;
@@ -1640,6 +1639,33 @@ __global__ void k_cg_prime_state(double *st, const double *__restrict__ red, ipx
   st[ST_RADIUS] = radius;
   st[ST_ORTH_RHS] = orth_tol * norm_A;
   st[ST_STOP] = bad ? 9.0 : 0.0;
+}
+
+__global__ void k_cg_prime_state(double *st, const double *__restrict__ red, ipx_prime_idx ix,
+                                 double tol_in, double radius, double orth_tol, double norm_A,
+                                 double canc2) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  prime_state_body(st, red, ix, tol_in, radius, orth_tol, norm_A, canc2);
+}
+
+// The same behind the folds of the priming's SpMV partials (ipx_cg_prime: up to six products
+// leave per-tile partials in separate regions of the workspace; folded here by the fold
+// kernel's own routine, in its order, instead of by six launches of it)
+struct PrimeFolds {
+  const double *part[6];
+  int count[6], slot[6], n;
+};
+__global__ void __launch_bounds__(IPX_BLOCK)
+k_cg_prime_state_folds(double *st, double *red, PrimeFolds f, ipx_prime_idx ix, double tol_in,
+                       double radius, double orth_tol, double norm_A, double canc2) {
+  __shared__ double lds[IPX_BLOCK / IPX_WAVE];
+  for (int j = 0; j < f.n; ++j) {
+    const double a = ipx_sum_partials<IPX_SUM>(f.part[j], f.count[j], lds);
+    const double b = ipx_sum_partials<IPX_SUM>(f.part[j] + f.count[j], f.count[j], lds);
+    if (threadIdx.x == 0) { red[f.slot[j]] = a; red[f.slot[j] + 1] = b; }
+  }
+  // (thread 0 reads back what it wrote itself)
+  if (threadIdx.x == 0) prime_state_body(st, red, ix, tol_in, radius, orth_tol, norm_A, canc2);
 }
 
 int ipx_cg_prime_state(double *state, const double *red, const int32_t *idx7, double tol_in,
@@ -1664,68 +1690,108 @@ int ipx_cg_prime_state(double *state, const double *red, const int32_t *idx7, do
 // a time (ipsolver/projector.py null_space_enqueue), ~25 calls and three copies.  CSR A and H
 // (+ optional diagonal), banded or box-Schur solver; red: >= 14 doubles of device memory, ws:
 // the reduction workspace (IPX_WS_DOUBLES).
+static int cg_iterate(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, hipStream_t st,
+                      hipEvent_t *ev);
 static int prime_solve(const ipx_cg_args *a, const double *w, double *v, void *stream) {
   if (a->solver_kind == 1)
     return ipx_boxschur_solve((const ipx_boxschur_args *)a->banded, w, v, nullptr, nullptr, nullptr,
                               stream);
   return ipx_banded_solve(a->banded, w, v, stream);
 }
-static int prime_project(const ipx_cg_args *a, const int32_t *A_tiles, int32_t A_ntiles,
-                         const double *x, double *z, double *red, int base, double *ws,
-                         void *stream) {
-  int rc = ipx_norms(a->n, x, red + base + 4, ws, stream);
+// The priming's products with a norm: per-tile partials into the next free region of the
+// workspace, folded later by k_cg_prime_state_folds (deferred) -- or, when the regions of a
+// whole priming do not fit the workspace, folded at once by a launch of the fold kernel.
+struct PrimeRed {
+  double *red, *ws;
+  bool deferred;
+  int64_t off;
+  PrimeFolds f;
+  int spmv(const ipx_csr_view &M, const double *x, double alpha, const double *diag, double beta,
+           const double *yin, double *yout, int slot, hipStream_t st) {
+    if (!deferred)
+      return ipx_csr_spmv(M.nrows, M.ncols, M.rowptr, M.colidx, M.val, M.tiles, M.ntiles, x, alpha,
+                          diag, beta, yin, yout, M.nrows == M.ncols, red + slot, ws, st);
+    double *part = ws + off;
+    off += 2 * (int64_t)M.ntiles;
+    f.part[f.n] = part; f.count[f.n] = M.ntiles; f.slot[f.n] = slot; ++f.n;
+    return ipx_spmv_launch(M, x, alpha, diag, beta, yin, yout, part, nullptr, st);
+  }
+};
+
+// z = sign (x - A'(A A')^-1 A x) with ||z||^2 -> red[base], ||A z||^2 -> red[base + 2] and,
+// unless the caller has it already (have_xnorm), ||x||^2 -> red[base + 4].  sign = -1 writes
+// the negated projection by the same roundings (alpha, beta = 1, -1 instead of -1, 1: a
+// difference and its negation round alike), the norms do not see the sign.
+static int prime_project(const ipx_cg_args *a, const ipx_csr_view &A, const ipx_csr_view &At,
+                         const double *x, double *z, PrimeRed &R, int base, bool have_xnorm,
+                         double sign, hipStream_t st) {
+  int rc = have_xnorm ? IPX_OK : ipx_norms(a->n, x, R.red + base + 4, R.ws + R.off, st);
   if (rc) return rc;
-  rc = ipx_csr_spmv(a->m, a->n, a->A_rowptr, a->A_colidx, a->A_val, A_tiles, A_ntiles, x, 1.0,
-                    nullptr, 0.0, nullptr, a->w, 0, nullptr, ws, stream);
+  rc = ipx_spmv_launch(A, x, 1.0, nullptr, 0.0, nullptr, a->w, nullptr, nullptr, st);
   if (rc) return rc;
-  rc = prime_solve(a, a->w, a->v, stream);
+  rc = prime_solve(a, a->w, a->v, st);
   if (rc) return rc;
-  rc = ipx_csr_spmv(a->n, a->m, a->At_rowptr, a->At_colidx, a->At_val, a->At_tiles,
-                    (int32_t)a->At_ntiles, a->v, -1.0, nullptr, 1.0, x, z, 0, red + base, ws, stream);
+  rc = R.spmv(At, a->v, -sign, nullptr, sign, x, z, base, st);
   if (rc) return rc;
-  return ipx_csr_spmv(a->m, a->n, a->A_rowptr, a->A_colidx, a->A_val, A_tiles, A_ntiles, z, 1.0,
-                      nullptr, 0.0, nullptr, a->t, 0, red + base + 2, ws, stream);
+  return R.spmv(A, z, 1.0, nullptr, 0.0, nullptr, a->t, base + 2, st);
 }
 
 int ipx_cg_prime(const ipx_cg_args *a, const int32_t *A_tiles, int32_t A_ntiles, const double *c,
                  const double *b, double *red, double *ws, double tol_in, double radius,
-                 double orth_tol, double norm_A, double cancellation, void *stream) {
+                 double orth_tol, double norm_A, double cancellation, int32_t first_end,
+                 void *stream) {
   if (!a || !c || !red || !ws || !A_tiles || a->solver_kind > 1 || a->m <= 0 || a->H_operator ||
-      !a->H_rowptr || !a->t)
+      !a->H_rowptr || !a->t || first_end < 0)
     return IPX_EINVAL;
   hipStream_t st = (hipStream_t)stream;
+  const ipx_csr_view A{(int)a->m, (int)a->n, a->A_rowptr, a->A_colidx, a->A_val, A_tiles, A_ntiles};
+  const ipx_csr_view At{(int)a->n, (int)a->m, a->At_rowptr, a->At_colidx, a->At_val, a->At_tiles,
+                        (int)a->At_ntiles};
+  const ipx_csr_view Hm{(int)a->n, (int)a->n, a->H_rowptr, a->H_colidx, a->H_val, a->H_tiles,
+                        (int)a->H_ntiles};
+  // the products' norms come out of their epilogues (no norm kernels); their per-tile partials
+  // wait in the workspace for ONE fold in front of the state kernel when all six regions fit
+  // (n = 1e6: 17 k of the 64 k doubles; a 4096-double tail stays free for ipx_norms)
+  const int64_t need = 2 * (3 * (int64_t)At.ntiles + 2 * (int64_t)A.ntiles + Hm.ntiles) + 4096;
+  const bool single = 2 * std::max<int64_t>(At.ntiles, Hm.ntiles) <= IPX_WS_DOUBLES;
+  if (!single) return IPX_EUNSUPPORTED;
+  PrimeRed R{red, ws, need <= IPX_WS_DOUBLES, 0, PrimeFolds{}};
   int rc;
   const double *t = c;
   if (b) {
-    rc = ipx_axpby(a->m, -1.0, b, 0.0, nullptr, a->w, stream);
+    // x0 = A'(A A')^-1 (-b) = -A' (A A')^-1 b: the solve and the product are odd functions of
+    // their input down to the last bit, so the sign is applied by the product's scalar
+    rc = prime_solve(a, b, a->v, stream);
     if (rc) return rc;
-    rc = prime_solve(a, a->w, a->v, stream);
+    rc = R.spmv(At, a->v, -1.0, nullptr, 0.0, nullptr, a->x, 12, st);
     if (rc) return rc;
-    rc = ipx_csr_spmv(a->n, a->m, a->At_rowptr, a->At_colidx, a->At_val, a->At_tiles,
-                      (int32_t)a->At_ntiles, a->v, 1.0, nullptr, 0.0, nullptr, a->x, 0, nullptr, ws,
-                      stream);
-    if (rc) return rc;
-    rc = ipx_norms(a->n, a->x, red + 12, ws, stream);
-    if (rc) return rc;
-    rc = ipx_csr_spmv(a->n, a->n, a->H_rowptr, a->H_colidx, a->H_val, a->H_tiles,
-                      (int32_t)a->H_ntiles, a->x, 1.0, a->H_diag, 1.0, c, a->Hp, 1, nullptr, ws,
-                      stream);
+    rc = R.spmv(Hm, a->x, 1.0, a->H_diag, 1.0, c, a->Hp, 4, st);
     if (rc) return rc;
     t = a->Hp;
   } else if (hipMemsetAsync(a->x, 0, (size_t)a->n * sizeof(double), st) != hipSuccess) {
     return IPX_ELAUNCH;
   }
-  rc = prime_project(a, A_tiles, A_ntiles, t, a->r, red, 0, ws, stream);
+  rc = prime_project(a, A, At, t, a->r, R, 0, b != nullptr, 1.0, st);
   if (rc) return rc;
-  rc = prime_project(a, A_tiles, A_ntiles, a->r, a->p, red, 6, ws, stream);
+  // g0 = Z r0 lands in p as -g0 (the first direction); its input norm ||r0||^2 is red[0]
+  rc = prime_project(a, A, At, a->r, a->p, R, 6, true, -1.0, st);
   if (rc) return rc;
-  const int32_t idx_b[7] = {12, 4, 0, 2, 10, 6, 8}, idx_0[7] = {-1, 4, 0, 2, 10, 6, 8};
-  rc = ipx_cg_prime_state(a->state, red, b ? idx_b : idx_0, tol_in, radius, orth_tol, norm_A,
-                          cancellation, stream);
-  if (rc) return rc;
-  rc = ipx_axpby(a->n, -1.0, a->p, 0.0, nullptr, a->p, stream);      // p = -g0
-  if (rc) return rc;
-  return launch_hp(a, nullptr, st);
+  const int32_t idx_b[7] = {12, 4, 0, 2, 0, 6, 8}, idx_0[7] = {-1, 4, 0, 2, 0, 6, 8};
+  if (R.deferred) {
+    ipx_prime_idx ix;
+    for (int k = 0; k < 7; ++k) ix.i[k] = (b ? idx_b : idx_0)[k];
+    hipLaunchKernelGGL(k_cg_prime_state_folds, dim3(1), dim3(IPX_BLOCK), 0, st, a->state, red, R.f,
+                       ix, tol_in, radius, orth_tol, norm_A, cancellation * cancellation);
+    IPX_CHECK_LAUNCH();
+  } else {
+    rc = ipx_cg_prime_state(a->state, red, b ? idx_b : idx_0, tol_in, radius, orth_tol, norm_A,
+                            cancellation, stream);
+    if (rc) return rc;
+  }
+  rc = launch_hp(a, nullptr, st);
+  if (rc || first_end == 0) return rc;
+  // the call's first batch behind the same entry (stop code 9: its launches do nothing)
+  return cg_iterate(a, 0, first_end, st, nullptr);
 }
 
 // Hp = H p with p'Hp partials (the tail of an iteration, also used once by

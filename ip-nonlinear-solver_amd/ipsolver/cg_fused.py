@@ -418,9 +418,12 @@ def _loop_for(H, P, lb, ub):
     L = _POOL.pop(key, None) if key is not None else None
     if L is not None and L.rebind(H, P, lb, ub):
         POOL_STATS["reused"] += 1
+        L.enqueued = None
         return L, key
     POOL_STATS["built"] += 1
-    return _Loop(H, P, lb, ub), key
+    L = _Loop(H, P, lb, ub)
+    L.enqueued = None            # (the batch ipx_cg_prime enqueued behind the priming, if any)
+    return L, key
 
 
 def _release(L, key):
@@ -735,14 +738,20 @@ def _projected_cg(H, c, Z, Y, b, trust_radius, lb, ub, tol, max_iter, max_infeas
         st = stream_ptr()
         a = L.args
         if isinstance(P.A, DeviceCSR) and a.solver_kind in (0, 1) and getattr(P.solver, "perm", None) is None \
-                and a.banded and not getattr(P.solver, "refine_steps", 0):
+                and a.banded and not getattr(P.solver, "refine_steps", 0) \
+                and 2 * max(a.At_ntiles, a.H_ntiles) <= 65536:      # (IPX_WS_DOUBLES)
             # the whole priming behind one C call, into the loop's own buffers
             ctx_ = ctx()
             pat = P.A.pattern
+            # ... and the call's first batch behind it (the host's way from here to its own
+            # ipx_cg_iterate call is ~50 us of idle GPU otherwise)
+            first_end = min(max_iter, batch if batch else _first_batch(max_iter, False))
             _hip.call("ipx_cg_prime", L.ref(), _p(pat.tiles), pat.ntiles, _p(c.t),
                       None if b_zero else _p(b.t), _p(ctx_.out), _p(ctx_.ws),
                       float("nan") if tol is None else float(tol), float(trust_radius),
-                      float(P.orth_tol), float(P.norm_A), float(P.CANCELLATION), st)
+                      float(P.orth_tol), float(P.norm_A), float(P.CANCELLATION),
+                      max(first_end, 0), st)
+            L.enqueued = (0, first_end) if first_end > 0 else None
             P.stats["solves"] += 2 if b_zero else 3
         else:
             x0, r0, g0 = _prime_without_reads(L, H, c, Z, Y, b, b_zero, P, tol, trust_radius)
@@ -801,17 +810,30 @@ def _projected_cg(H, c, Z, Y, b, trust_radius, lb, ub, tol, max_iter, max_infeas
                      max_infeasible_iter, batch, stats, fast=False)
 
 
+def _first_batch(max_iter, operator):
+    """Iterations of a call's first batch: a caller that asks for at most a few dozen gets them
+    in ONE batch (one state read for the call); the open-ended calls of the SQP start with
+    four (two with an operator Hessian, which the host applies once per enqueued iteration)."""
+    if operator:
+        return 2
+    return max_iter if 4 < max_iter <= 32 else 4
+
+
 def _run_loop(L, pool_key, P, lib, st, n, lb, ub, trust_radius, max_iter, max_infeasible_iter,
               batch, stats, fast):
     class Driver:
         """The single-GPU loop behind ``run_device_loop``."""
-        # (a caller that asks for at most a few dozen iterations gets them in ONE batch: one
-        # state read for the call; the open-ended calls of the SQP start with four)
-        first_batch = (max_iter if 4 < max_iter <= 32 else 4) if L.operator is None else 2
+        first_batch = _first_batch(max_iter, L.operator is not None)
         batch_cap = 64 if L.operator is None else 8   # (an operator is applied once per
                                                       #  enqueued iteration, stopped or not)
         def iterate(self, it, end):
             self.last = (it, end)
+            if getattr(L, "enqueued", None) is not None:
+                done, L.enqueued = L.enqueued, None
+                if done == (it, end):        # (enqueued with the priming: ipx_cg_prime)
+                    return
+                raise _hip.IpxError("device loop: the batch enqueued with the priming %r is not "
+                                    "the one the driver asks for %r" % (done, (it, end)))
             if L.operator is None:
                 _hip.check(lib.ipx_cg_iterate(L.ref(), it, end, st), "ipx_cg_iterate")
             else:
@@ -881,7 +903,7 @@ def run_device_loop(D, counters, lb, ub, trust_radius, max_iter, max_infeasible_
     has_box = lb is not None or ub is not None
     hits_boundary, stop_cond = False, 1
     counter, last_viol_it = 0, -2
-    last_feasible_x = D.zeros()
+    last_feasible_x = D.zeros() if has_box else None     # (only a box makes iterates infeasible)
     it = 0
     nbatch = batch if batch else D.first_batch
     s = None

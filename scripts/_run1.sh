@@ -1,5 +1,3 @@
-mkdir -p gpurun_out/final
-python bench.py 2>/dev/null | grep '^{' > gpurun_out/final/bench_line.json
-python bench.py --steps 20 --warmup 5 --no-cpu 2>/dev/null | grep '^{' > gpurun_out/final/bench_line_steps20.json
-python scripts/phase_timing_tail.py 2>&1 | tail -7 > gpurun_out/final/pcr_tail_phase_timing.txt
-tail -c 300 gpurun_out/final/bench_line.json
+R=/root/repo; cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/ss; rocprofv3 --kernel-trace --output-format csv -d /tmp/ss -- python3 $R/scripts/_single_shot.py 2>/tmp/ss.err | tail -8
+python3 $R/scripts/_show_shots.py /tmp/ss
