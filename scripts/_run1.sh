@@ -1,3 +1,1 @@
-R=/root/repo; cd /tmp && export TMPDIR=/tmp
-rm -rf /tmp/ss; rocprofv3 --kernel-trace --output-format csv -d /tmp/ss -- python3 $R/scripts/_single_shot.py 2>/tmp/ss.err | tail -8
-python3 $R/scripts/_show_shots.py /tmp/ss
+python scripts/profile_config3.py 2>&1 | cut -c1-160 | head -120
