@@ -324,6 +324,10 @@ int ipx_cg_iterate(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, void 
  * [0, first_end) are enqueued behind the priming by the same call (as ipx_cg_iterate would).
  * Stop code 9 in the state block afterwards: the host must prime (ipx_cg_prime_state); the
  * iterations enqueued with it did nothing. */
+/* doubles of reduction workspace ipx_cg_prime needs for this argument block (the per-tile
+ * partials of its six products wait there for one fold); more than IPX_WS_DOUBLES: the entry
+ * point returns IPX_EUNSUPPORTED and the caller primes launch by launch. */
+int64_t ipx_cg_prime_ws_doubles(const ipx_cg_args *a, int32_t A_ntiles);
 int ipx_cg_prime(const ipx_cg_args *a, const int32_t *A_tiles, int32_t A_ntiles, const double *c,
                  const double *b, double *red, double *ws, double tol_in, double radius,
                  double orth_tol, double norm_A, double cancellation, int32_t first_end,

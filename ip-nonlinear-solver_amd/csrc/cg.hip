@@ -1699,18 +1699,13 @@ static int prime_solve(const ipx_cg_args *a, const double *w, double *v, void *s
   return ipx_banded_solve(a->banded, w, v, stream);
 }
 // The priming's products with a norm: per-tile partials into the next free region of the
-// workspace, folded later by k_cg_prime_state_folds (deferred) -- or, when the regions of a
-// whole priming do not fit the workspace, folded at once by a launch of the fold kernel.
+// workspace, folded later by k_cg_prime_state_folds.
 struct PrimeRed {
   double *red, *ws;
-  bool deferred;
   int64_t off;
   PrimeFolds f;
   int spmv(const ipx_csr_view &M, const double *x, double alpha, const double *diag, double beta,
            const double *yin, double *yout, int slot, hipStream_t st) {
-    if (!deferred)
-      return ipx_csr_spmv(M.nrows, M.ncols, M.rowptr, M.colidx, M.val, M.tiles, M.ntiles, x, alpha,
-                          diag, beta, yin, yout, M.nrows == M.ncols, red + slot, ws, st);
     double *part = ws + off;
     off += 2 * (int64_t)M.ntiles;
     f.part[f.n] = part; f.count[f.n] = M.ntiles; f.slot[f.n] = slot; ++f.n;
@@ -1736,6 +1731,11 @@ static int prime_project(const ipx_cg_args *a, const ipx_csr_view &A, const ipx_
   return R.spmv(A, z, 1.0, nullptr, 0.0, nullptr, a->t, base + 2, st);
 }
 
+int64_t ipx_cg_prime_ws_doubles(const ipx_cg_args *a, int32_t A_ntiles) {
+  if (!a) return -1;
+  return 2 * (3 * a->At_ntiles + 2 * (int64_t)A_ntiles + a->H_ntiles) + 4096;
+}
+
 int ipx_cg_prime(const ipx_cg_args *a, const int32_t *A_tiles, int32_t A_ntiles, const double *c,
                  const double *b, double *red, double *ws, double tol_in, double radius,
                  double orth_tol, double norm_A, double cancellation, int32_t first_end,
@@ -1750,12 +1750,11 @@ int ipx_cg_prime(const ipx_cg_args *a, const int32_t *A_tiles, int32_t A_ntiles,
   const ipx_csr_view Hm{(int)a->n, (int)a->n, a->H_rowptr, a->H_colidx, a->H_val, a->H_tiles,
                         (int)a->H_ntiles};
   // the products' norms come out of their epilogues (no norm kernels); their per-tile partials
-  // wait in the workspace for ONE fold in front of the state kernel when all six regions fit
-  // (n = 1e6: 17 k of the 64 k doubles; a 4096-double tail stays free for ipx_norms)
-  const int64_t need = 2 * (3 * (int64_t)At.ntiles + 2 * (int64_t)A.ntiles + Hm.ntiles) + 4096;
-  const bool single = 2 * std::max<int64_t>(At.ntiles, Hm.ntiles) <= IPX_WS_DOUBLES;
-  if (!single) return IPX_EUNSUPPORTED;
-  PrimeRed R{red, ws, need <= IPX_WS_DOUBLES, 0, PrimeFolds{}};
+  // wait in the workspace for ONE fold in front of the state kernel: six regions (n = 1e6: 17 k
+  // of the 64 k doubles) and a 4096-double tail for ipx_norms.  A problem whose regions do not
+  // fit (n beyond ~5e6 on the benchmark's band) is primed launch by launch by the caller.
+  if (ipx_cg_prime_ws_doubles(a, A_ntiles) > IPX_WS_DOUBLES) return IPX_EUNSUPPORTED;
+  PrimeRed R{red, ws, 0, PrimeFolds{}};
   int rc;
   const double *t = c;
   if (b) {
@@ -1777,17 +1776,11 @@ int ipx_cg_prime(const ipx_cg_args *a, const int32_t *A_tiles, int32_t A_ntiles,
   rc = prime_project(a, A, At, a->r, a->p, R, 6, true, -1.0, st);
   if (rc) return rc;
   const int32_t idx_b[7] = {12, 4, 0, 2, 0, 6, 8}, idx_0[7] = {-1, 4, 0, 2, 0, 6, 8};
-  if (R.deferred) {
-    ipx_prime_idx ix;
-    for (int k = 0; k < 7; ++k) ix.i[k] = (b ? idx_b : idx_0)[k];
-    hipLaunchKernelGGL(k_cg_prime_state_folds, dim3(1), dim3(IPX_BLOCK), 0, st, a->state, red, R.f,
-                       ix, tol_in, radius, orth_tol, norm_A, cancellation * cancellation);
-    IPX_CHECK_LAUNCH();
-  } else {
-    rc = ipx_cg_prime_state(a->state, red, b ? idx_b : idx_0, tol_in, radius, orth_tol, norm_A,
-                            cancellation, stream);
-    if (rc) return rc;
-  }
+  ipx_prime_idx ix;
+  for (int k = 0; k < 7; ++k) ix.i[k] = (b ? idx_b : idx_0)[k];
+  hipLaunchKernelGGL(k_cg_prime_state_folds, dim3(1), dim3(IPX_BLOCK), 0, st, a->state, red, R.f,
+                     ix, tol_in, radius, orth_tol, norm_A, cancellation * cancellation);
+  IPX_CHECK_LAUNCH();
   rc = launch_hp(a, nullptr, st);
   if (rc || first_end == 0) return rc;
   // the call's first batch behind the same entry (stop code 9: its launches do nothing)

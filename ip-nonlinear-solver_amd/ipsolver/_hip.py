@@ -98,12 +98,13 @@ _RESTYPES = {"ipx_version": _c.c_char_p, "ipx_last_error": _c.c_char_p,
              "ipx_banded_create": _P, "ipx_banded_destroy": None,
              "ipx_dense_padded": _I64, "ipx_gram_ws_doubles": _I64, "ipx_peer_create": _P, "ipx_peer_destroy": None,
              "ipx_peer_halo_capacity": _I64, "ipx_peer_fused_launches": _I64,
-             "ipx_cg_resident_ll_words": _I64}
+             "ipx_cg_resident_ll_words": _I64, "ipx_cg_prime_ws_doubles": _I64}
 _EXTRA_ARGTYPES = {"ipx_banded_create": [_I64, _I32, _I32], "ipx_banded_destroy": [_P],
                    "ipx_dense_padded": [_I64], "ipx_gram_ws_doubles": [_I64, _I32],
                    "ipx_peer_create": [_I32, _I32, _I64],
                    "ipx_peer_destroy": [_P], "ipx_peer_halo_capacity": [_P],
-                   "ipx_peer_fused_launches": [_P], "ipx_cg_resident_ll_words": [_I32, _I32]}
+                   "ipx_peer_fused_launches": [_P], "ipx_cg_resident_ll_words": [_I32, _I32],
+                   "ipx_cg_prime_ws_doubles": [_P, _I32]}
 
 _lib = None
 

@@ -739,7 +739,7 @@ def _projected_cg(H, c, Z, Y, b, trust_radius, lb, ub, tol, max_iter, max_infeas
         a = L.args
         if isinstance(P.A, DeviceCSR) and a.solver_kind in (0, 1) and getattr(P.solver, "perm", None) is None \
                 and a.banded and not getattr(P.solver, "refine_steps", 0) \
-                and 2 * max(a.At_ntiles, a.H_ntiles) <= 65536:      # (IPX_WS_DOUBLES)
+                and lib.ipx_cg_prime_ws_doubles(L.ref(), P.A.pattern.ntiles) <= 65536:   # (IPX_WS_DOUBLES)
             # the whole priming behind one C call, into the loop's own buffers
             ctx_ = ctx()
             pat = P.A.pattern

@@ -1,1 +1,1 @@
-python scripts/profile_config3.py 2>&1 | cut -c1-160 | head -120
+timeout 900 python -m pytest tests/test_gpu_qp.py -x -q -k "priming_forms" 2>&1 | tail -5

@@ -1055,6 +1055,49 @@ def test_solve_tail_for_rows_of_every_length(ips, rl, shift, m, monkeypatch):
     assert np.max(np.abs(x1 - xo)) <= 1e-10 * np.max(np.abs(xo))
 
 
+@pytest.mark.parametrize("n,m", [(40000, 4000), (700000, 70000)])
+def test_priming_forms_agree(ips, n, m, monkeypatch):
+    """The three ways a call is primed (qp_subproblem.py:502-530: x0 = Y(-b), r0 = Z(H x0 + c),
+    g0 = Z r0, rt_g, the default tolerance, the distance to the trust-region boundary): ONE C
+    call with the first batch behind it (csrc/cg.hip ipx_cg_prime: norms out of the products'
+    epilogues, one fold, -A'(A A')^-1 b and -g0 by the products' scalars), launch by launch
+    from the host with the state block written on the device (the path of problems whose
+    partials do not fit the reduction workspace), and the reference's order with every scalar
+    read back.  The two device forms give the same iterates bit for bit -- the shortcuts are
+    exact --, the host form to an ulp; for b != 0 and b = 0, at a resident and at a
+    three-launch size."""
+    import ipsolver.cg_fused as cg_fused
+    from ipsolver import _hip
+    inst = BandedInstance(n, m)
+    A = ips.dv.DeviceCSR.from_scipy(inst.A)
+    H = ips.dv.DeviceCSR.from_scipy(inst.H)
+    Z, LS, Y = ips.proj.projections(A)
+    c = ips.dv.DVec.from_host(inst.c)
+    lib = _hip.load()
+    for b_h in (inst.b, None):
+        b = ips.dv.DVec.from_host(b_h) if b_h is not None else ips.dv.DVec.zeros(m)
+        radius = 3.0 * float(np.linalg.norm(inst.b)) + 1.0
+        kw = dict(trust_radius=radius, lb=None, ub=None, tol=None, max_iter=14,
+                  max_infeasible_iter=None, batch=None, stats=None, b_zero=b_h is None)
+        outs = []
+        for form in ("one_call", "by_launch", "host"):
+            before = dict(cg_fused.STATS)
+            with monkeypatch.context() as mp:
+                if form == "by_launch":
+                    mp.setattr(lib, "ipx_cg_prime_ws_doubles", lambda *a: 1 << 40)
+                x, info = cg_fused._projected_cg(H, c, Z, Y, b, fast=form != "host", **kw)
+            primed = cg_fused.STATS["primed_on_device"] - before["primed_on_device"]
+            assert primed == (0 if form == "host" else 1)
+            assert cg_fused.STATS["prime_retries"] == before["prime_retries"]
+            outs.append((host(x), info))
+        assert outs[1][1] == outs[0][1] and outs[2][1] == outs[0][1]
+        assert np.array_equal(outs[1][0], outs[0][0])
+        # (the host sums ||g0||^2 with the norm kernel, the device paths take it from the
+        # product's epilogue: another order, an ulp of rt_g)
+        assert np.max(np.abs(outs[2][0] - outs[0][0])) <= 1e-15 * np.max(np.abs(outs[0][0]))
+        assert outs[0][1]["niter"] >= 3
+
+
 def test_device_loop_with_an_operator_hessian(ips):
     """A Hessian that is only an operator (``dot`` over device vectors -- what the reference's
     LinearOperator terms are: finite differences, user callbacks, _canonical_constraint.py:
