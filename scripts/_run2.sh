@@ -1,9 +1,9 @@
-timeout 1800 python -m pytest tests -m gpu -x -q 2>&1 | tail -4
+bash scripts/refresh_profiles.sh final trace pmc config5 2>&1 | tail -12
 mkdir -p gpurun_out/final
-python bench.py --steps 20 --warmup 5 --no-cpu 2>/dev/null | grep '^{' > gpurun_out/final/bench_line_steps20.json
+cp gpurun_out/final/pmc_traffic_n1e6.json profiles/r04_pmc_traffic_n1e6.json
+cp gpurun_out/final/pmc_traffic_n4e6.json profiles/r04_pmc_traffic_n4e6.json
 python bench.py 2>/dev/null | grep '^{' > gpurun_out/final/bench_line.json
-python - <<'P'
-import json
-for f in ('gpurun_out/final/bench_line_steps20.json','gpurun_out/final/bench_line.json'):
-    d=json.load(open(f)); print(f, d['value'], d['ms_per_step'], d['device_loop_only']['iterations_per_s'], d['wall_clock_to_gtol']['seconds'], d['config5']['seconds'], d['config2']['seconds'], json.dumps(d['public_api']['trust_radius_finite']))
-P
+python bench.py --steps 20 --warmup 5 --no-cpu 2>/dev/null | grep '^{' > gpurun_out/final/bench_line_steps20.json
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/tp; rocprofv3 --kernel-trace --output-format csv -d /tmp/tp -- python3 /root/repo/scripts/trace_public_call.py run 20 > /dev/null 2>/tmp/tp.err
+python3 /root/repo/scripts/trace_public_call.py show /tmp/tp > /root/repo/gpurun_out/final/public_call_timeline.txt 2>&1
