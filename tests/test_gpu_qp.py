@@ -1098,6 +1098,17 @@ def test_priming_forms_agree(ips, n, m, monkeypatch):
         assert outs[0][1]["niter"] >= 3
 
 
+def test_fused_loop_on_random_band_shapes(ips):
+    """tests/fuzz_fused_loop.py: 24 random Jacobians with rows of 2..16 entries, tridiagonal or
+    diagonal A A', row counts around the solve's workgroup size (1, 2, 259..261, 519..521, ...),
+    unconstrained variables, b = 0 and b != 0, three kinds of trust radius -- the loop with its
+    fused kernels (resident where it fits) against the loop without them and against the three
+    launches to 1e-11 (observed: 3e-16), small cases against the host oracle's projected CG
+    (qp_subproblem.py:332-637) to 1e-9."""
+    import fuzz_fused_loop
+    assert fuzz_fused_loop.run(24, 4, verbose=False) <= 1e-11
+
+
 def test_device_loop_with_an_operator_hessian(ips):
     """A Hessian that is only an operator (``dot`` over device vectors -- what the reference's
     LinearOperator terms are: finite differences, user callbacks, _canonical_constraint.py:
