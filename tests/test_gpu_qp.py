@@ -1109,6 +1109,17 @@ def test_fused_loop_on_random_band_shapes(ips):
     assert fuzz_fused_loop.run(24, 4, verbose=False) <= 1e-11
 
 
+def test_box_schur_loop_on_random_shapes(ips):
+    """tests/fuzz_box_schur.py: 16 random barrier-shaped subproblems (rows of J with 3..16
+    entries, bounds on every variable / lower only / a ragged mix, slacks down to 1e-6, three
+    trust radii, a bound on the slacks' step) through the device loop with the box rows
+    eliminated per group (csrc/boxschur.hip): compact against general group tables bit for bit,
+    small cases against the host oracle's projected CG (qp_subproblem.py:332-637) -- same
+    exits, iterates to 1e-9 (observed: 2e-15)."""
+    import fuzz_box_schur
+    assert fuzz_box_schur.run(16, 3, verbose=False) <= 1e-12
+
+
 def test_device_loop_with_an_operator_hessian(ips):
     """A Hessian that is only an operator (``dot`` over device vectors -- what the reference's
     LinearOperator terms are: finite differences, user callbacks, _canonical_constraint.py:
