@@ -1,1 +1,1 @@
-timeout 900 python -m pytest tests/test_gpu_qp.py -x -q -k "random_shapes or random_band" 2>&1 | tail -5
+timeout 900 python -m pytest tests/test_gpu_e2e.py -x -q -k "random_constraint_mixes" --durations=3 2>&1 | tail -8

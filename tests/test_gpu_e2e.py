@@ -220,6 +220,18 @@ def test_sharded_mixed_constraints_hip(tmp_path):
     check_mixed(np.load(path))
 
 
+def test_random_constraint_mixes_against_the_oracle_backend():
+    """tests/fuzz_minimize.py: 10 random small NLPs (convex quartic objective; a random mix of
+    dense / sparse linear equalities, interval and one-sided linear inequalities, a nonlinear
+    ball, ragged boxes -- the reference's three constraint classes in every combination,
+    _constraints.py / _canonical_constraint.py) through ``minimize_constrained`` on the HIP
+    backend against the same calls on the oracle's backend: the first six outer iterations row
+    by row (counts equal, optimality / violation to 1e-6), the end points to 1e-5, both by the
+    barrier method and -- equalities only -- by the SQP."""
+    import fuzz_minimize
+    assert fuzz_minimize.run(10, 5, verbose=False) <= 1e-5
+
+
 def test_product_never_imports_the_oracle():
     """Run a solve in a fresh interpreter: the product must not load oracle.*
     (no CPU fallback), and must have loaded the in-tree libipx.so."""
