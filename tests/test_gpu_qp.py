@@ -1120,6 +1120,17 @@ def test_box_schur_loop_on_random_shapes(ips):
     assert fuzz_box_schur.run(16, 3, verbose=False) <= 1e-12
 
 
+def test_projections_on_random_structures(ips):
+    """tests/fuzz_projections.py: Z, LS, Y (projections.py:14-290) applied to random vectors for
+    20 random Jacobians -- random sparsity of three densities, a band with shuffled rows, block
+    diagonal, a band with two dense rows, dense storage; 1 .. 1500 rows; every third case without
+    the dense Cholesky -- so that the banded solver with and without reordering, the dense
+    Cholesky and the preconditioned CG on A A' each take their turn, against
+    the host oracle's projections: 1e-9 (observed: 2e-13)."""
+    import fuzz_projections
+    assert fuzz_projections.run(20, 2, verbose=False, max_m=1500) <= 1e-9
+
+
 def test_device_loop_with_an_operator_hessian(ips):
     """A Hessian that is only an operator (``dot`` over device vectors -- what the reference's
     LinearOperator terms are: finite differences, user callbacks, _canonical_constraint.py:
