@@ -42,11 +42,15 @@ def _sphere_from_scalars(dd, zd, zz, trust_radius, entire_line):
     """qp_subproblem.py:99-149 given d.d, z.d, z.z."""
     if dd == 0:
         return 0, 0, False
-    if np.isinf(trust_radius):
+    # (a finite radius whose square overflows -- 1e300, "no trust region" in some callers -- is a
+    # sphere no double-precision step reaches: the reference's ``trust_radius**2`` raises
+    # OverflowError there; here it is the infinite sphere)
+    r2 = float(trust_radius) * float(trust_radius)
+    if np.isinf(r2):
         return (-_INF, _INF, True) if entire_line else (0, 1, True)
     a = dd
     b = 2 * zd
-    c = zz - trust_radius ** 2
+    c = zz - r2
     disc = b * b - 4 * a * c
     if disc < 0:
         return 0, 0, False

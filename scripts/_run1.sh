@@ -1,5 +1,1 @@
-timeout 900 python - <<'P' 2>&1 | tail -45 | cut -c1-200
-import sys; sys.path.insert(0,'tests')
-import fuzz_projections
-print(fuzz_projections.run(40, 2, verbose=True, max_m=1500))
-P
+timeout 900 python -m pytest tests/test_gpu_e2e.py -x -q -k "sharded_loop_on_random" --durations=2 2>&1 | tail -6

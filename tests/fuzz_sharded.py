@@ -1,0 +1,98 @@
+"""Randomised cross-check of the row-sharded device loop (ipsolver/sharded.py: halo partition,
+the loop's collectives inside its kernels over the peer mailboxes) on `world` ranks sharing
+cuda:0: random band shapes -- rows of 3..16 entries, tridiagonal A A', row counts that do and do
+not divide into the 260-row blocks, with and without a box, three trust radii -- each solved by
+the sharded loop and, inside every rank, by the single-GPU loop on the whole problem
+(qp_subproblem.py:332-637 both).  A shape the halo partition refuses must be refused by every
+rank alike (NotImplementedError before any collective).
+
+    python tests/fuzz_sharded.py [world] [cases] [seed]    (tests/test_gpu_e2e.py: 2 ranks, 8 cases)"""
+import os, socket, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+import numpy as np
+
+
+def worker(rank, world, port, out_path, cases, seed):
+    import scipy.sparse as sp
+    import torch
+    import torch.distributed as dist
+    for p in (ROOT, os.path.join(ROOT, "ip-nonlinear-solver_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ipsolver import sharded, qp
+        import ipsolver.device as dv
+        import ipsolver.projector as proj
+        from ipsolver.operators import DeviceHessian
+        rng = np.random.default_rng(seed)
+        lines, worst = [], 0.0
+        for case in range(cases):
+            rl = int(rng.integers(3, 17))
+            shift = int(rng.integers((rl + 1) // 2, rl + 1))
+            m = int(rng.choice([1300, 2600, 5000, 5201, 26001]))
+            n = (m - 1) * shift + rl + int(rng.integers(0, 30))
+            n += n % 2
+            rows = np.repeat(np.arange(m), rl)
+            cols = (np.arange(m)[:, None] * shift + np.arange(rl)[None, :]).ravel()
+            A_h = sp.csr_matrix((rng.uniform(0.5, 1.5, m * rl) * rng.choice([-1.0, 1.0], m * rl),
+                                 (rows, cols)), shape=(m, n))
+            off = rng.uniform(-0.4, 0.4, n - 1)
+            H_h = sp.diags([off, rng.uniform(1.5, 2.5, n), off], [-1, 0, 1], format="csr")
+            c_h = rng.standard_normal(n)
+            box = bool(rng.random() < 0.4)
+            kw = dict(tol=0, max_iter=14,
+                      trust_radius=float(rng.choice([1e300, np.inf, 0.02 * np.sqrt(n)])))
+            if box:
+                kw.update(lb=np.full(n, -0.05), ub=np.full(n, 0.08))
+            tag = "case %2d rl=%2d shift=%2d m=%6d n=%7d box=%d radius=%-6g" % (
+                case, rl, shift, m, n, box, kw["trust_radius"])
+            try:
+                lay = sharded.ShardLayout(A_h.indptr, A_h.indices, A_h.shape, world, rank)
+            except NotImplementedError as exc:
+                lines.append(tag + "  refused by the layout: %s" % str(exc)[:60])
+                continue
+            sh = sharded.Sharding(lay, sharded.ShardComm(), sharded.HipOps())
+            A = sharded.ShardCSR.from_global(sh, A_h)
+            H = sharded.ShardHessian.from_global(sh, H_h)
+            Z, LS, Y = sharded.projections(A)
+            c = sh.from_global(c_h, "col")
+            before = sharded.STATS["fused_calls"]
+            ks = {a: (sh.from_global(b, "col") if a in ("lb", "ub") else b) for a, b in kw.items()}
+            xs, info = qp.projected_cg(H, c, Z, Y, sh.zeros("row"), **ks)
+            fused = sharded.STATS["fused_calls"] - before
+            A1 = dv.DeviceCSR.from_scipy(A_h)
+            H1 = DeviceHessian(n, csr=dv.DeviceCSR.from_scipy(H_h))
+            Z1, _, Y1 = proj.projections(A1)
+            x1, info1 = qp.projected_cg(H1, c_h, Z1, Y1, np.zeros(m), **kw)
+            x1 = x1.to_host()
+            d = float(np.max(np.abs(xs.to_host() - x1)) / max(np.max(np.abs(x1)), 1e-300))
+            lines.append(tag + "  loop=%d transport=%s  |dx| %.1e  %s" % (fused, sh.transport, d, info))
+            assert info == info1, (tag, info, info1)
+            assert d <= 1e-10, lines[-1]
+            worst = max(worst, d)
+        if rank == 0:
+            np.savez(out_path, worst=worst, lines=np.array(lines))
+    finally:
+        dist.destroy_process_group()
+
+
+def run(world, cases, seed, out_path, verbose=True):
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(worker, args=(world, port, out_path, cases, seed), nprocs=world, join=True)
+    got = np.load(out_path)
+    if verbose:
+        print("\n".join(got["lines"]))
+    return float(got["worst"]), [str(l) for l in got["lines"]]
+
+
+if __name__ == "__main__":
+    world = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+    w, _ = run(world, int(sys.argv[2]) if len(sys.argv) > 2 else 12,
+               int(sys.argv[3]) if len(sys.argv) > 3 else 0, "/tmp/fuzz_sharded.npz")
+    print("ok, worst deviation of the sharded loop from the single-GPU loop %.1e" % w)

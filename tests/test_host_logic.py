@@ -228,6 +228,19 @@ def test_dense_equality_qp(e2e_golden):
     compare(res, rows, e2e_golden["dense_eq_qp_n60"])
 
 
+def test_sphere_intersection_with_a_radius_whose_square_overflows():
+    """qp_subproblem.py:99-149 squares the radius; for a finite radius beyond 1.3e154 -- 1e300 is
+    a common way to say "no trust region" -- the reference's ``trust_radius**2`` raises
+    OverflowError as soon as a box event calls the routine.  The product treats such a sphere
+    as the infinite one (no double-precision step reaches it)."""
+    from ipsolver import qp
+    assert qp._sphere_from_scalars(2.0, 0.3, 1.0, 1e300, False) == (0, 1, True)
+    assert qp._sphere_from_scalars(2.0, 0.3, 1.0, 1e300, True) == (-np.inf, np.inf, True)
+    assert qp._sphere_from_scalars(2.0, 0.3, 1.0, np.inf, False) == (0, 1, True)
+    ta, tb, hit = qp._sphere_from_scalars(1.0, 0.0, 0.25, 1.0, False)      # z = 0.5, d = 1
+    assert hit and ta == 0 and abs(tb - np.sqrt(0.75)) < 1e-15
+
+
 def test_return_all_and_callback_stop():
     p = problems.HyperbolicIneq()
     with backend.use(npb):
