@@ -1,0 +1,88 @@
+"""Randomised full solves on banded NLPs of other shapes than the benchmark's: the seeded
+``CenteredBandedNLP`` with random row length (3..16), row stride, size and seed -- equality rows
+by both outer methods (BASELINE configs 3/4 style), or inequality rows + a box on every variable
+by the barrier method (config 5 style) -- through ``minimize_constrained`` on the HIP backend
+(device-resident CG loops, resident launch where it fits, box-Schur elimination, pooled loop
+objects re-bound at every outer iteration) against the same calls on the host oracle's backend
+(tr_interior_point.py / equality_constrained_sqp.py over numpy + SuperLU).
+
+    python tests/fuzz_banded_nlp.py [cases] [seed]       (tests/test_gpu_e2e.py runs 8 cases)"""
+import os, sys, warnings
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "ip-nonlinear-solver_amd")); sys.path.insert(0, ROOT)
+import numpy as np
+import ipsolver
+from ipsolver import backend, cg_fused
+from ipsolver.synthetic import CenteredBandedNLP
+import oracle.numpy_backend as nb
+
+
+def solve(prob, cons, method):
+    rows = []
+
+    def record(state):
+        rows.append([int(state.niter), int(state.cg_niter), float(state.optimality),
+                     float(state.constr_violation)])
+        return False
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res = ipsolver.minimize_constrained(prob.fun, prob.x0, prob.grad, prob.hess, cons,
+                                            method=method, callback=record)
+    return res, np.array(rows)
+
+
+def run(cases, seed, verbose=True, max_m=2700):
+    rng = np.random.default_rng(seed)
+    worst = 0.0
+    for case in range(cases):
+        bw = int(rng.integers(3, 17))
+        stride = int(rng.integers((bw + 1) // 2 + 1, bw + 3))
+        m = int(rng.choice([k for k in (40, 261, 700, 1300, 2700) if k <= max_m]))
+        n = m * stride + int(rng.integers(0, stride))
+        kind = str(rng.choice(["eq-barrier", "eq-sqp", "ineq+box"]))
+        if kind == "ineq+box":          # (thousands of CG iterations: minutes on the oracle's side)
+            m = int(rng.choice([40, 120]))
+            n = m * stride + int(rng.integers(0, stride))
+        prob = CenteredBandedNLP(n, m, bw=bw, seed=int(rng.integers(1 << 20)),
+                                 eps=1.0 if kind == "ineq+box" else 1e-3)
+        if kind == "ineq+box":
+            cons = (prob.constraints(ipsolver, ("less", 0.0)),
+                    ipsolver.BoxConstraint(("interval", -0.8, 0.8)))
+            prob.x0 = np.clip(prob.x0, -0.75, 0.75)
+            method = "tr_interior_point"
+        else:
+            cons = prob.constraints(ipsolver)
+            method = "tr_interior_point" if kind == "eq-barrier" else "equality_constrained_sqp"
+        before = dict(cg_fused.STATS)
+        got, rows = solve(prob, cons, method)
+        loops = cg_fused.STATS["calls"] - before["calls"]
+        resident = cg_fused.STATS["resident_calls"] - before["resident_calls"]
+        with backend.use(nb):
+            want, wrows = solve(prob, cons, method)
+        k = min(8, len(rows), len(wrows))
+        dx = float(np.max(np.abs(got.x - want.x)) / max(1.0, np.max(np.abs(want.x))))
+        line = "case %2d %-10s bw=%2d stride=%2d m=%5d n=%6d  status %d/%d  %3d/%3d outer %5d/%5d CG  device loops %d (resident %d)  |dx| %.1e  f %.10g/%.10g" % (
+            case, kind, bw, stride, m, n, got.status, want.status, got.niter, want.niter,
+            got.cg_niter, want.cg_niter, loops, resident, dx, got.fun, want.fun)
+        if verbose:
+            print(line, flush=True)
+        assert got.status in (1, 2) and want.status in (1, 2), line
+        assert loops > 0, line
+        assert np.array_equal(rows[:k, :2], wrows[:k, :2]), line
+        assert np.allclose(rows[:k, 2:], wrows[:k, 2:], rtol=1e-6, atol=1e-10), line
+        # (weakly active constraints leave the end point of a barrier run determined to about
+        # sqrt(mu) = 1e-4 along their direction, the objective to mu times the number of active
+        # constraints -- and the two runs may stop one barrier parameter apart)
+        df = abs(got.fun - want.fun) / max(1.0, abs(want.fun))
+        assert dx <= 1e-4 and got.constr_violation <= 1e-8, line
+        assert df <= 1e-5, (line, got.fun, want.fun, got.barrier_parameter, want.barrier_parameter)
+        if kind != "ineq+box":          # (no barrier end game: the whole trace is comparable)
+            assert (got.niter, got.cg_niter) == (want.niter, want.cg_niter), line
+            assert dx <= 1e-9, line
+        worst = max(worst, dx)
+    return worst
+
+
+if __name__ == "__main__":
+    w = run(int(sys.argv[1]) if len(sys.argv) > 1 else 20, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    print("ok, worst end-point deviation %.1e" % w)

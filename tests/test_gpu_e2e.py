@@ -243,6 +243,18 @@ def test_sharded_loop_on_random_band_shapes(tmp_path):
     assert worst <= 1e-10 and sum("loop=1" in l for l in lines) >= 6, lines
 
 
+def test_full_solves_on_random_band_shapes():
+    """tests/fuzz_banded_nlp.py: 10 seeded banded NLPs of other shapes than the benchmark's (rows
+    of 3..16 entries, other strides, 40..2700 rows) -- equality rows by the barrier method and
+    by the SQP (configs 3/4 style), inequality rows + a box on every variable (config 5 style)
+    -- solved to gtol on the HIP backend (device-resident loops, resident launch where it
+    fits, box-Schur elimination) and on the oracle's backend: equality problems with identical
+    outer / CG counts and end points to 1e-9 (observed: 4e-16), barrier problems on their first
+    eight rows, end point (1e-4: weakly active constraints) and objective (1e-5)."""
+    import fuzz_banded_nlp
+    assert fuzz_banded_nlp.run(10, 1, verbose=False) <= 1e-4
+
+
 def test_product_never_imports_the_oracle():
     """Run a solve in a fresh interpreter: the product must not load oracle.*
     (no CPU fallback), and must have loaded the in-tree libipx.so."""
