@@ -4,7 +4,8 @@ by both outer methods (BASELINE configs 3/4 style), or inequality rows + a box o
 by the barrier method (config 5 style) -- through ``minimize_constrained`` on the HIP backend
 (device-resident CG loops, resident launch where it fits, box-Schur elimination, pooled loop
 objects re-bound at every outer iteration) against the same calls on the host oracle's backend
-(tr_interior_point.py / equality_constrained_sqp.py over numpy + SuperLU).
+(tr_interior_point.py / equality_constrained_sqp.py over numpy + SuperLU), and once more in
+device-callback mode (CUDA-tensor callbacks) against the numpy-callback run.
 
     python tests/fuzz_banded_nlp.py [cases] [seed]       (tests/test_gpu_e2e.py runs 8 cases)"""
 import os, sys, warnings
@@ -59,13 +60,26 @@ def run(cases, seed, verbose=True, max_m=2700):
         resident = cg_fused.STATS["resident_calls"] - before["resident_calls"]
         with backend.use(nb):
             want, wrows = solve(prob, cons, method)
+        # device-callback mode (x0 a CUDA tensor, callbacks on device buffers: nothing crosses
+        # PCIe between two iterations) must walk the same path as the numpy callbacks
+        import torch
+        from ipsolver.synthetic import DeviceCallbacks
+        dc = DeviceCallbacks(prob)
+        if kind == "ineq+box":
+            dcons = (dc.constraints(ipsolver, ("less", 0.0)),
+                     ipsolver.BoxConstraint(("interval", -0.8, 0.8)))
+            dc.x0 = torch.from_numpy(prob.x0).to(dc.x0.device)
+        else:
+            dcons = dc.constraints(ipsolver)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            dres = ipsolver.minimize_constrained(dc.fun, dc.x0, dc.grad, dc.hess, dcons, method=method)
+        ddx = float(np.max(np.abs(dres.x.cpu().numpy() - got.x)) / max(1.0, np.max(np.abs(got.x))))
         k = min(8, len(rows), len(wrows))
         dx = float(np.max(np.abs(got.x - want.x)) / max(1.0, np.max(np.abs(want.x))))
         line = "case %2d %-10s bw=%2d stride=%2d m=%5d n=%6d  status %d/%d  %3d/%3d outer %5d/%5d CG  device loops %d (resident %d)  |dx| %.1e  f %.10g/%.10g" % (
             case, kind, bw, stride, m, n, got.status, want.status, got.niter, want.niter,
             got.cg_niter, want.cg_niter, loops, resident, dx, got.fun, want.fun)
-        if verbose:
-            print(line, flush=True)
         assert got.status in (1, 2) and want.status in (1, 2), line
         assert loops > 0, line
         assert np.array_equal(rows[:k, :2], wrows[:k, :2]), line
@@ -76,9 +90,14 @@ def run(cases, seed, verbose=True, max_m=2700):
         df = abs(got.fun - want.fun) / max(1.0, abs(want.fun))
         assert dx <= 1e-4 and got.constr_violation <= 1e-8, line
         assert df <= 1e-5, (line, got.fun, want.fun, got.barrier_parameter, want.barrier_parameter)
+        line += "  device callbacks %d outer %d CG |dx| %.1e" % (dres.niter, dres.cg_niter, ddx)
+        assert dres.status in (1, 2) and ddx <= (1e-4 if kind == "ineq+box" else 1e-9), line
         if kind != "ineq+box":          # (no barrier end game: the whole trace is comparable)
+            assert (dres.niter, dres.cg_niter) == (got.niter, got.cg_niter), line
             assert (got.niter, got.cg_niter) == (want.niter, want.cg_niter), line
             assert dx <= 1e-9, line
+        if verbose:
+            print(line, flush=True)
         worst = max(worst, dx)
     return worst
 

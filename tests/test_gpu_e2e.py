@@ -250,7 +250,8 @@ def test_full_solves_on_random_band_shapes():
     -- solved to gtol on the HIP backend (device-resident loops, resident launch where it
     fits, box-Schur elimination) and on the oracle's backend: equality problems with identical
     outer / CG counts and end points to 1e-9 (observed: 4e-16), barrier problems on their first
-    eight rows, end point (1e-4: weakly active constraints) and objective (1e-5)."""
+    eight rows, end point (1e-4: weakly active constraints) and objective (1e-5); every problem
+    once more in device-callback mode (same counts, equality end points bit for bit or 1e-16)."""
     import fuzz_banded_nlp
     assert fuzz_banded_nlp.run(10, 1, verbose=False) <= 1e-4
 
