@@ -1,1 +1,1 @@
-timeout 1700 python tests/fuzz_banded_nlp.py 24 1 2>&1 | tail -30 | cut -c1-330
+timeout 900 python -m pytest tests/test_gpu_e2e.py -x -q -k "sharded_solves_on_random" --durations=2 2>&1 | tail -6

@@ -6,7 +6,7 @@ the sharded loop and, inside every rank, by the single-GPU loop on the whole pro
 (qp_subproblem.py:332-637 both).  A shape the halo partition refuses must be refused by every
 rank alike (NotImplementedError before any collective).
 
-    python tests/fuzz_sharded.py [world] [cases] [seed]    (tests/test_gpu_e2e.py: 2 ranks, 8 cases)"""
+    python tests/fuzz_sharded.py [world] [cases] [seed] [solves]    (tests/test_gpu_e2e.py: 2 ranks)"""
 import os, socket, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 import numpy as np
@@ -91,8 +91,99 @@ def run(world, cases, seed, out_path, verbose=True):
     return float(got["worst"]), [str(l) for l in got["lines"]]
 
 
+
+
+# ---- whole solves through the public API ------------------------------------------------------
+def solve_worker(rank, world, port, out_path, cases, seed):
+    """``minimize_constrained(..., options={'shard': True})`` (numpy callbacks, the reference's
+    constraint classes) on random banded NLP shapes -- equality rows by both methods, inequality
+    rows + a box by the barrier method -- against the same call without sharding, inside every
+    rank."""
+    import warnings
+    import torch
+    import torch.distributed as dist
+    for p in (ROOT, os.path.join(ROOT, "ip-nonlinear-solver_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import ipsolver
+        from ipsolver import sharded
+        from ipsolver.synthetic import CenteredBandedNLP
+        rng = np.random.default_rng(seed)
+        lines, worst = [], 0.0
+        for case in range(cases):
+            bw = int(rng.integers(3, 17))
+            stride = int(rng.integers((bw + 1) // 2 + 1, bw + 3))
+            kind = str(rng.choice(["eq-barrier", "eq-sqp", "ineq+box"]))
+            m = int(rng.choice([600, 1300, 2700])) if kind != "ineq+box" else 600
+            n = m * stride + int(rng.integers(0, stride))
+            prob = CenteredBandedNLP(n, m, bw=bw, seed=int(rng.integers(1 << 20)),
+                                     eps=1.0 if kind == "ineq+box" else 1e-3)
+            if kind == "ineq+box":
+                cons = (prob.constraints(ipsolver, ("less", 0.0)),
+                        ipsolver.BoxConstraint(("interval", -0.8, 0.8)))
+                prob.x0 = np.clip(prob.x0, -0.75, 0.75)
+                method, max_iter = "tr_interior_point", 12
+            else:
+                cons = prob.constraints(ipsolver)
+                method = "tr_interior_point" if kind == "eq-barrier" else "equality_constrained_sqp"
+                max_iter = 1000
+            outs = []
+            for shard in (True, False):
+                rows = []
+
+                def record(state):
+                    rows.append([int(state.niter), int(state.cg_niter), float(state.optimality),
+                                 float(state.constr_violation)])
+                    return False
+                before = sharded.STATS["fused_calls"]
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    res = ipsolver.minimize_constrained(
+                        prob.fun, prob.x0, prob.grad, prob.hess, cons, method=method,
+                        callback=record, max_iter=max_iter, options={"shard": True} if shard else {})
+                outs.append((res, np.array(rows), sharded.STATS["fused_calls"] - before))
+            (got, rows, fused), (want, wrows, _) = outs
+            dx = float(np.max(np.abs(got.x - want.x)) / max(1.0, np.max(np.abs(want.x))))
+            lines.append("case %2d %-10s bw=%2d stride=%2d m=%5d n=%6d  %d/%d outer %d/%d CG  sharded loops %d  |dx| %.1e" % (
+                case, kind, bw, stride, m, n, got.niter, want.niter, got.cg_niter, want.cg_niter, fused, dx))
+            k = min(10, len(rows), len(wrows))
+            assert np.array_equal(rows[:k, :2], wrows[:k, :2]), lines[-1]
+            assert np.allclose(rows[:k, 2:], wrows[:k, 2:], rtol=1e-6, atol=1e-10), lines[-1]
+            if kind != "ineq+box":
+                assert (got.status, got.niter, got.cg_niter) == (want.status, want.niter, want.cg_niter), lines[-1]
+                assert dx <= 1e-9, lines[-1]
+            else:
+                assert dx <= 1e-6, lines[-1]
+            worst = max(worst, dx)
+        if rank == 0:
+            np.savez(out_path, worst=worst, lines=np.array(lines))
+    finally:
+        dist.destroy_process_group()
+
+
+def run_solves(world, cases, seed, out_path, verbose=True):
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(solve_worker, args=(world, port, out_path, cases, seed), nprocs=world, join=True)
+    got = np.load(out_path)
+    if verbose:
+        print("\n".join(got["lines"]))
+    return float(got["worst"]), [str(l) for l in got["lines"]]
+
+
 if __name__ == "__main__":
     world = int(sys.argv[1]) if len(sys.argv) > 1 else 2
-    w, _ = run(world, int(sys.argv[2]) if len(sys.argv) > 2 else 12,
-               int(sys.argv[3]) if len(sys.argv) > 3 else 0, "/tmp/fuzz_sharded.npz")
-    print("ok, worst deviation of the sharded loop from the single-GPU loop %.1e" % w)
+    ncase = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+    seed = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+    if len(sys.argv) > 4 and sys.argv[4] == "solves":
+        w, _ = run_solves(world, ncase, seed, "/tmp/fuzz_sharded_solves.npz")
+        print("ok, worst end-point deviation of the sharded solves %.1e" % w)
+    else:
+        w, _ = run(world, ncase, seed, "/tmp/fuzz_sharded.npz")
+        print("ok, worst deviation of the sharded loop from the single-GPU loop %.1e" % w)
