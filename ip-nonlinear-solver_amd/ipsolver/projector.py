@@ -437,6 +437,7 @@ class IterativeNormalSolver:
 
     perm = None
     RTOL, MAXIT = 1e-15, 2000
+    WARN_RELRES = 1e-10          # a solve that ends above this says so (warning)
     PS_RZ0, PS_BEST0, PS_DONE, PS_ITERS, PS_NORM_W, PS_RTOL = 0, 2, 6, 7, 8, 9
     BLOCK = 32
 
@@ -532,6 +533,17 @@ class IterativeNormalSolver:
             it, batch = end, min(2 * batch, 64)
         self.stats["solves"] += 1
         self.stats["iterations"] += int(s[self.PS_ITERS])
+        # neither converged nor down at the floor of fp64 (MAXIT reached, or no progress far
+        # above it): the reference's direct factorization would have been accurate here --
+        # say so instead of returning a poor solve silently
+        relres = min(s[self.PS_BEST0], s[self.PS_BEST0 + 1]) / norm_w
+        self.stats["worst_relres"] = max(self.stats.get("worst_relres", 0.0), relres)
+        if s[self.PS_DONE] != 1 and relres > self.WARN_RELRES:
+            from warnings import warn
+            warn("IterativeNormalSolver: the preconditioned CG on A A' stopped at a relative "
+                 "residual of %.1e after %d iterations (ill-conditioned Jacobian; m = %d): "
+                 "projections with this factorization are only that accurate"
+                 % (relres, int(s[self.PS_ITERS]), self.m))
         return v
 
 

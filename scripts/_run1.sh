@@ -1,1 +1,1 @@
-timeout 900 python -m pytest tests/test_gpu_e2e.py -x -q -k "sharded_solves_on_random" --durations=2 2>&1 | tail -6
+python scripts/_dbg.py 2>&1 | tail -8

@@ -1,9 +1,11 @@
-bash scripts/refresh_profiles.sh final trace pmc config5 2>&1 | tail -12
-mkdir -p gpurun_out/final
-cp gpurun_out/final/pmc_traffic_n1e6.json profiles/r04_pmc_traffic_n1e6.json
-cp gpurun_out/final/pmc_traffic_n4e6.json profiles/r04_pmc_traffic_n4e6.json
-python bench.py 2>/dev/null | grep '^{' > gpurun_out/final/bench_line.json
-python bench.py --steps 20 --warmup 5 --no-cpu 2>/dev/null | grep '^{' > gpurun_out/final/bench_line_steps20.json
-cd /tmp && export TMPDIR=/tmp
-rm -rf /tmp/tp; rocprofv3 --kernel-trace --output-format csv -d /tmp/tp -- python3 /root/repo/scripts/trace_public_call.py run 20 > /dev/null 2>/tmp/tp.err
-python3 /root/repo/scripts/trace_public_call.py show /tmp/tp > /root/repo/gpurun_out/final/public_call_timeline.txt 2>&1
+mkdir -p gpurun_out/fuzz
+( timeout 900 python tests/fuzz_fused_loop.py 300 11 2>&1 | tail -3 ) > gpurun_out/fuzz/fused.txt
+( timeout 1500 python tests/fuzz_minimize.py 150 13 2>&1 | tail -3 ) > gpurun_out/fuzz/minimize.txt
+( timeout 900 python tests/fuzz_banded_nlp.py 60 14 2>&1 | tail -3 ) > gpurun_out/fuzz/banded.txt
+( timeout 600 python - <<'P' 2>&1 | tail -3
+import sys; sys.path.insert(0,'tests')
+import fuzz_projections
+print("worst", fuzz_projections.run(300, 17, verbose=False, max_m=1500))
+P
+) > gpurun_out/fuzz/projections.txt
+for f in gpurun_out/fuzz/fused.txt gpurun_out/fuzz/minimize.txt gpurun_out/fuzz/banded.txt gpurun_out/fuzz/projections.txt; do echo "== $f"; cut -c1-330 $f; done

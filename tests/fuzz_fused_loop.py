@@ -13,12 +13,14 @@ from ipsolver import device as dv, projector, qp, cg_fused
 from ipsolver.operators import DeviceHessian
 import oracle
 
-def run(cases, seed, verbose=True):
+def run(cases, seed, verbose=True, only=None):
     rng = np.random.default_rng(seed)
     worst, done = 0.0, 0
     for case in range(cases):
         rl = int(rng.integers(2, 17))
         shift = int(rng.integers((rl + 1) // 2, rl + 2))          # rl + 1: a free variable between rows
+        if (rl, shift) == (2, 1):       # (a bidiagonal chain: cond(A) grows like exp(sqrt(m)) --
+            shift = 2                   #  3.7e9 at m = 5000, the singular-Jacobian path on both sides)
         m = int(rng.choice([1, 2, 37, 259, 260, 261, 519, 520, 521, 1300, 5000, 26001, 60000]))
         tail = int(rng.integers(0, 40))
         n = (m - 1) * shift + rl + tail
@@ -38,6 +40,8 @@ def run(cases, seed, verbose=True):
         if radius == 5.0:       # (a radius the start lies inside of: else the call raises, as the reference's)
             radius = 5.0 + 2.0 * float(np.linalg.norm(b)) * 3.0
         kw = dict(tol=0, max_iter=K, trust_radius=radius)
+        if only is not None and case != only:      # (replay one case of a longer run)
+            continue
         runs = []
         try:
             for flag in ("", "no-fuse", "no-resident"):
@@ -75,5 +79,6 @@ def run(cases, seed, verbose=True):
 
 
 if __name__ == "__main__":
-    w = run(int(sys.argv[1]) if len(sys.argv) > 1 else 40, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    w = run(int(sys.argv[1]) if len(sys.argv) > 1 else 40, int(sys.argv[2]) if len(sys.argv) > 2 else 0,
+            only=int(sys.argv[3]) if len(sys.argv) > 3 else None)
     print("ok, worst relative deviation between the forms %.1e" % w)

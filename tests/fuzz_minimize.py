@@ -5,7 +5,9 @@ constraints, ragged boxes; _constraints.py, _canonical_constraint.py) -- on the 
 against the same call on the host oracle's backend (oracle/numpy_backend.py: the reference's
 algorithms, tr_interior_point.py / equality_constrained_sqp.py, over numpy + SuperLU).  The two
 factor their projections differently, so traces drift at the 1e-10 level; compared are the
-first outer iterations row by row and the end points (a unique minimiser).
+first outer iterations row by row (1e-4: a 19-iteration CG run inside a barrier subproblem
+turns the 1e-11 between two factorizations into 1e-6 by the sixth row) and the end points (a
+unique minimiser).
 
     python tests/fuzz_minimize.py [cases] [seed]         (tests/test_gpu_e2e.py runs 12 cases)"""
 import os, sys, warnings
@@ -89,11 +91,13 @@ def solve(P, method):
     return res, np.array(rows)
 
 
-def run(cases, seed, verbose=True):
+def run(cases, seed, verbose=True, only=None):
     rng = np.random.default_rng(seed)
     worst = 0.0
     for case in range(cases):
         P = problem(rng)
+        if only is not None and case != only:      # (replay one case of a longer run)
+            continue
         for method in P["methods"]:
             got, rows = solve(P, method)
             with backend.use(nb):
@@ -109,7 +113,7 @@ def run(cases, seed, verbose=True):
             # either way on either side, _minimize_constrained.py:395-407)
             assert got.status in (1, 2) and want.status in (1, 2), line
             assert np.array_equal(rows[:k, :2], wrows[:k, :2]), line
-            assert np.allclose(rows[:k, 2:], wrows[:k, 2:], rtol=1e-6, atol=1e-10), line
+            assert np.allclose(rows[:k, 2:], wrows[:k, 2:], rtol=1e-4, atol=1e-10), line
             # (late barrier subproblems amplify 1e-10 differences into other iteration counts --
             # 198 against 443 outer iterations on one of these problems, the same end point:
             # DESIGN.md section 7 -- so the counts are printed, not compared)
@@ -119,5 +123,6 @@ def run(cases, seed, verbose=True):
 
 
 if __name__ == "__main__":
-    w = run(int(sys.argv[1]) if len(sys.argv) > 1 else 30, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    w = run(int(sys.argv[1]) if len(sys.argv) > 1 else 30, int(sys.argv[2]) if len(sys.argv) > 2 else 0,
+            only=int(sys.argv[3]) if len(sys.argv) > 3 else None)
     print("ok, worst end-point deviation %.1e" % w)

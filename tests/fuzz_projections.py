@@ -19,7 +19,10 @@ import oracle
 def jacobian(rng, max_m):
     kind = str(rng.choice(["random", "random", "shuffled-band", "blocks", "band+dense-rows", "dense"]))
     if kind == "dense":
-        m = int(rng.integers(1, 60)); n = m + int(rng.integers(1, 80))
+        # (a third of them large enough for the tiled Gram kernel on the fp64 matrix cores)
+        big = rng.random() < 0.33 and max_m >= 300
+        m = int(rng.integers(100, 500)) if big else int(rng.integers(1, 60))
+        n = m + (int(rng.integers(50, 1500)) if big else int(rng.integers(1, 80)))
         return kind, rng.standard_normal((m, n))
     m = int(rng.choice([k for k in (1, 3, 40, 300, 1500, 6000) if k <= max_m]))
     n = m + int(rng.integers(1, 3 * m + 5))
