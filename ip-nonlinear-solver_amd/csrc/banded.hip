@@ -1677,6 +1677,9 @@ int launch_solve_pcr(const LevDev &lv, int L, const double *w, double *x, double
   if (per <= 4) return launch_solve_pcr_q<4>(lv, L, w, x, partial, npartial, guard, *atv, st);
   if (per <= 8) return launch_solve_pcr_q<8>(lv, L, w, x, partial, npartial, guard, *atv, st);
   if (per <= 12) return launch_solve_pcr_q<12>(lv, L, w, x, partial, npartial, guard, *atv, st);
+  // (qv = 16, the most the tables allow -- a workgroup that owns ~3000 variables, e.g. a problem
+  // of a single 260-row block with 11 columns per row: found by tests/fuzz_fused_loop.py)
+  if (per <= 16) return launch_solve_pcr_q<16>(lv, L, w, x, partial, npartial, guard, *atv, st);
   return IPX_EINVAL;
 }
 
