@@ -30,6 +30,7 @@ enum {
   PS_DONE = 6,                   // 0 running, 1 converged, 2 no progress any more (the floor of fp64,
                                  // or a stall further up), 3 not positive definite
   PS_ITERS = 7, PS_NORM_W = 8, PS_RTOL = 9, PS_NORM_R = 10,
+  PS_STALL_FAR = 11,             // iterations without progress that end a solve far above the floor
   PS_SIZE = 16
 };
 
@@ -188,8 +189,9 @@ k_pcg_direction(int64_t m, double *st, int parity, const double *__restrict__ p2
   if (nr <= rtol * norm_w) done = 1;
   // no new smallest residual for 5 iterations once the residual is down at 1e-9 ||w||: the floor
   // of fp64.  Further up CG's residuals plateau and oscillate on ill-conditioned systems
-  // (a stop there returned a solve 2e-3 off: tests/fuzz_projections.py): 60 iterations
-  else if (stall_next >= (best <= 1e-9 * norm_w ? 5.0 : 60.0)) done = 2;
+  // (a stop after 5 there returned a solve 2e-3 off: tests/fuzz_projections.py): the caller's
+  // count, PS_STALL_FAR
+  else if (stall_next >= (best <= 1e-9 * norm_w ? 5.0 : fmax(st[PS_STALL_FAR], 5.0))) done = 2;
   if (lead) {
     st[PS_ITERS] += 1.0;
     st[PS_NORM_R] = nr;

@@ -438,7 +438,9 @@ class IterativeNormalSolver:
     perm = None
     RTOL, MAXIT = 1e-15, 2000
     WARN_RELRES = 1e-10          # a solve that ends above this says so (warning)
-    PS_RZ0, PS_BEST0, PS_DONE, PS_ITERS, PS_NORM_W, PS_RTOL = 0, 2, 6, 7, 8, 9
+    PS_RZ0, PS_BEST0, PS_DONE, PS_ITERS, PS_NORM_W, PS_RTOL, PS_STALL_FAR = 0, 2, 6, 7, 8, 9, 11
+    STALL_FAR = 30               # iterations without a new smallest residual that end a solve
+                                 # whose residual is still above 1e-9 ||w|| (5 below that)
     BLOCK = 32
 
     def __init__(self, A, precond="block"):
@@ -516,6 +518,7 @@ class IterativeNormalSolver:
         init[self.PS_RZ0] = w.dot(z0)
         init[self.PS_BEST0] = np.inf
         init[self.PS_NORM_W], init[self.PS_RTOL] = norm_w, self.RTOL
+        init[self.PS_STALL_FAR] = self.STALL_FAR
         self.state.copy_(torch.from_numpy(init))
         self.args.v = v.t.data_ptr()
         it, batch = 0, 8
