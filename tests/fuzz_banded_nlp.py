@@ -80,6 +80,12 @@ def run(cases, seed, verbose=True, max_m=2700):
         line = "case %2d %-10s bw=%2d stride=%2d m=%5d n=%6d  status %d/%d  %3d/%3d outer %5d/%5d CG  device loops %d (resident %d)  |dx| %.1e  f %.10g/%.10g" % (
             case, kind, bw, stride, m, n, got.status, want.status, got.niter, want.niter,
             got.cg_niter, want.cg_niter, loops, resident, dx, got.fun, want.fun)
+        if want.status == 0:
+            # (an instance the REFERENCE's algorithm does not solve within its 1000 iterations --
+            # a box that leaves the inequality rows no interior; nothing to compare)
+            if verbose:
+                print(line + "  -- the oracle's run did not converge: skipped", flush=True)
+            continue
         assert got.status in (1, 2) and want.status in (1, 2), line
         assert loops > 0, line
         assert np.array_equal(rows[:k, :2], wrows[:k, :2]), line
