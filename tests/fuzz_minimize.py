@@ -21,23 +21,31 @@ import oracle.numpy_backend as nb
 
 def problem(rng):
     n = int(rng.integers(4, 41))
+    # one case in seven: a dense equality-constrained problem of a few hundred variables (the
+    # shape of BASELINE config 2: dense Jacobian and Hessian on the device-resident dense loop,
+    # the Gram matrix on the matrix cores)
+    big_dense = bool(rng.random() < 0.15)
+    if big_dense:
+        n = int(rng.integers(120, 500))
     B = rng.standard_normal((n, n)) / np.sqrt(n)
     Q = B @ B.T + np.diag(rng.uniform(0.5, 2.0, n))
     c = rng.standard_normal(n)
     x0 = rng.uniform(-0.3, 0.3, n)
-    sparse = bool(rng.random() < 0.5)
+    sparse = bool(rng.random() < 0.5) and not big_dense
     fun = lambda x: 0.5 * x @ Q @ x + c @ x + 0.05 * np.sum(x ** 4)
     grad = lambda x: Q @ x + c + 0.2 * x ** 3
     hess = (lambda x: sps.csr_matrix(Q + np.diag(0.6 * x ** 2))) if sparse else \
         (lambda x: Q + np.diag(0.6 * x ** 2))
     cons, tags = [], []
     m_eq = int(rng.integers(0, max(1, n // 3) + 1))
+    if big_dense:
+        m_eq = max(m_eq, 8)
     if m_eq:
         A = rng.standard_normal((m_eq, n)) * (rng.random((m_eq, n)) < (0.4 if sparse else 1.0))
         A[np.arange(m_eq), rng.permutation(n)[:m_eq]] += 2.0          # full row rank
         cons.append(ipsolver.LinearConstraint(sps.csr_matrix(A) if sparse else A, ("equals", A @ x0)))
         tags.append("eq%d" % m_eq)
-    if rng.random() < 0.6:
+    if rng.random() < 0.6 and not big_dense:
         k = int(rng.integers(1, max(2, n // 4) + 1))
         C = rng.standard_normal((k, n)) * (rng.random((k, n)) < 0.5)
         C[np.arange(k), rng.permutation(n)[:k]] += 1.0
@@ -48,7 +56,7 @@ def problem(rng):
                 "greater": ("greater", mid - rng.uniform(0.2, 1.0, k))}[kind]
         cons.append(ipsolver.LinearConstraint(sps.csr_matrix(C) if sparse else C, spec))
         tags.append("lin-%s%d" % (kind, k))
-    if rng.random() < 0.5:
+    if rng.random() < 0.5 and not big_dense:
         S = rng.permutation(n)[:max(2, n // 2)]
         r2 = float(np.sum(x0[S] ** 2)) + rng.uniform(0.3, 1.5)
 
@@ -64,7 +72,7 @@ def problem(rng):
             return sps.diags(d).tocsr() if sparse else np.diag(d)
         cons.append(ipsolver.NonlinearConstraint(ball, ("less", r2), ball_jac, ball_hess))
         tags.append("ball")
-    if rng.random() < 0.6:
+    if rng.random() < 0.6 and not big_dense:
         kind = rng.integers(0, 4, n)                       # 0 none, 1 lower, 2 upper, 3 both
         lo = np.where(kind & 1, x0 - rng.uniform(0.1, 1.0, n), -np.inf)
         hi = np.where(kind & 2, x0 + rng.uniform(0.1, 1.0, n), np.inf)
