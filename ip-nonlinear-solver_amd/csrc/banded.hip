@@ -1071,7 +1071,7 @@ struct RowsJob {
   const double *x;
   int logL;
 };
-constexpr int ROWS_U = 32;     // products per lane: window <= 2 * IPX_BLOCK rows of <= 16 entries
+constexpr int ROWS_PRODUCTS = 8192;     // products per workgroup: a window of <= 512 rows of <= 16 entries
 
 template <int K, int T, int QV>
 __global__ void __launch_bounds__(DOWN_T)
@@ -1338,7 +1338,8 @@ k_solve_decoupled(LevDev lv, const double *__restrict__ w, double *__restrict__ 
 // as k_solve_decoupled (DEC_CHUNKS * q), so the residual / A'v tail bookkeeping is unchanged.
 typedef double v2d __attribute__((ext_vector_type(2)));
 constexpr int PCR_RMAX = 4 * 66 + 2 * (1 << PCR_LMAX) + 8;        // window rows (q <= 66)
-constexpr int PCR_NR = (PCR_RMAX + IPX_BLOCK - 1) / IPX_BLOCK;    // rows per lane
+constexpr int PCR_NR = (PCR_RMAX + IPX_BLOCK - 1) / IPX_BLOCK;    // rows per lane (k_pcr_check)
+constexpr int PCR_TB = 512;                                       // lanes per workgroup of k_solve_pcr
 
 // The matrix is symmetric: only the sub-diagonal a_i = S[i][i-h] is carried (c_i = a_{i+h}
 // is read from the neighbour), with the reciprocal of the diagonal next to it so that a level
@@ -1410,8 +1411,12 @@ k_pcr_check(int m, int rows_wg, const double *__restrict__ band, int *flags) {
   }
 }
 
-template <int QV, int NR, bool ROWS = false>
-__global__ void __launch_bounds__(IPX_BLOCK)
+// TB lanes per workgroup: 512 (PCR_TB) -- measured against 256 and 1024 at n = 1e6 / 4e6: the
+// solve with its tail 10.4 / 28.8 us against 10.8 / 29.9 (256) and 12.6 / 38.6 (1024: one
+// workgroup per CU); the form that builds its own right-hand side (config 5) 7.9 us against
+// 9.1 (256) and 8.0 (1024).  One window row per lane, half the tail's loads per lane.
+template <int QV, int NR, bool ROWS, int TB>
+__global__ void __launch_bounds__(TB)
 k_solve_pcr(int m, int rows_wg, int L, const double *__restrict__ band,
             const double *__restrict__ w, double *__restrict__ x, double *__restrict__ partial,
             const double *__restrict__ guard, AtvJob atv, RowsJob rows = RowsJob{}) {
@@ -1420,7 +1425,8 @@ k_solve_pcr(int m, int rows_wg, int L, const double *__restrict__ band,
   constexpr int RS = PCR_RMAX + 2 * PAD;
   __shared__ double pa[2][RS], pr[2][RS], pd[2][RS];
   __shared__ double sx[PCR_RMAX];
-  __shared__ double red_lds[IPX_BLOCK / IPX_WAVE];
+  __shared__ double red_lds[TB / IPX_WAVE];
+  constexpr int RWU = ROWS_PRODUCTS / TB;          // products per lane (ROWS form)
   IPX_STAMP(0);
   // A'v tail: this workgroup's variables -- the FIRST loads of the kernel, so that the tail's
   // own loads (which need them) can be issued while the solve's inputs are still in flight
@@ -1438,15 +1444,15 @@ k_solve_pcr(int m, int rows_wg, int L, const double *__restrict__ band,
   // ROWS: the entries of the window's rows, the head of the kernel's only dependent chain
   // (entries -> gather of x -> LDS -> row sums), requested before everything else
   extern __shared__ double rows_prod[];              // R rows of (2^logL + 1) doubles (padded)
-  int rcol[ROWS ? ROWS_U : 1];
-  double rval[ROWS ? ROWS_U : 1];
+  int rcol[ROWS ? RWU : 1];
+  double rval[ROWS ? RWU : 1];
   if constexpr (ROWS) {
     const int64_t nnz = (int64_t)m << rows.logL;
     const int64_t e0 = g0 * (1 << rows.logL);        // (negative for the first workgroup)
     const int P = R << rows.logL;
 #pragma unroll
-    for (int u = 0; u < ROWS_U; ++u) {
-      const int e = min(tid + u * IPX_BLOCK, P - 1);
+    for (int u = 0; u < RWU; ++u) {
+      const int e = min(tid + u * TB, P - 1);
       const int64_t idx = min(max(e0 + e, (int64_t)0), nnz - 1);
       rcol[u] = rows.col[idx];
       rval[u] = rows.val[idx];
@@ -1456,11 +1462,11 @@ k_solve_pcr(int m, int rows_wg, int L, const double *__restrict__ band,
   double a[NR], b[NR], d[NR];
 #pragma unroll
   for (int k = 0; k < NR; ++k) {
-    const int64_t g = g0 + tid + k * IPX_BLOCK;
-    const bool in = tid + k * IPX_BLOCK < R && g >= 0 && g < m;
+    const int64_t g = g0 + tid + k * TB;
+    const bool in = tid + k * TB < R && g >= 0 && g < m;
     const int64_t gc = min(max(g, (int64_t)0), (int64_t)m - 1);
     const double bv = band[gc], av = band[(int64_t)m + gc];
-    a[k] = (in && g >= 1 && tid + k * IPX_BLOCK >= 1) ? av : 0.0;     // (row 0 of the window: cut)
+    a[k] = (in && g >= 1 && tid + k * TB >= 1) ? av : 0.0;     // (row 0 of the window: cut)
     b[k] = in ? bv : 1.0;
     if constexpr (!ROWS) {
       const double wv = w[gc];
@@ -1469,18 +1475,18 @@ k_solve_pcr(int m, int rows_wg, int L, const double *__restrict__ band,
   }
   if constexpr (ROWS) {
     const int Lr = 1 << rows.logL, P = R << rows.logL;
-    double xg[ROWS_U];
+    double xg[RWU];
 #pragma unroll
-    for (int u = 0; u < ROWS_U; ++u) xg[u] = rows.x[rcol[u]];
+    for (int u = 0; u < RWU; ++u) xg[u] = rows.x[rcol[u]];
 #pragma unroll
-    for (int u = 0; u < ROWS_U; ++u) {
-      const int e = tid + u * IPX_BLOCK;
+    for (int u = 0; u < RWU; ++u) {
+      const int e = tid + u * TB;
       if (e < P) rows_prod[(e >> rows.logL) * (Lr + 1) + (e & (Lr - 1))] = rval[u] * xg[u];
     }
     ipx_lds_barrier();
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
-      const int r = tid + k * IPX_BLOCK;
+      const int r = tid + k * TB;
       const int64_t g = g0 + r;
       const bool in = r < R && g >= 0 && g < m;
       double sum = 0.0;
@@ -1504,7 +1510,7 @@ k_solve_pcr(int m, int rows_wg, int L, const double *__restrict__ band,
     const int64_t last = max((int64_t)av0 + avn - 1, vb) & ~(int64_t)1;
 #pragma unroll
     for (int k = 0; k < QP; ++k) {
-      const int64_t j = min(vb + 2 * (int64_t)(tid + k * IPX_BLOCK), last);
+      const int64_t j = min(vb + 2 * (int64_t)(tid + k * TB), last);
       ac[k] = *reinterpret_cast<const unsigned *>(atv.ell_row + j);
       aw0[k] = *reinterpret_cast<const v2d *>(atv.ell_val + j);
       aw1[k] = *reinterpret_cast<const v2d *>(atv.ell_val + atv.ell_n + j);
@@ -1519,7 +1525,7 @@ k_solve_pcr(int m, int rows_wg, int L, const double *__restrict__ band,
   for (int k = 0; k < NR; ++k) { a0[k] = a[k]; b0[k] = b[k]; w0[k] = d[k]; }
   IPX_STAMP(2);
   // identity padding: rows [-PAD, 0) and [R, R + PAD) of both buffers (a = 0, r = 1, d = 0)
-  for (int i = tid; i < 2 * PAD; i += IPX_BLOCK) {
+  for (int i = tid; i < 2 * PAD; i += TB) {
     const int r = i < PAD ? i : R + i;              // storage index = window row + PAD
 #pragma unroll
     for (int u = 0; u < 2; ++u) { pa[u][r] = 0.0; pr[u][r] = 1.0; pd[u][r] = 0.0; }
@@ -1530,14 +1536,14 @@ k_solve_pcr(int m, int rows_wg, int L, const double *__restrict__ band,
     double rc[NR];
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
-      const int r = tid + k * IPX_BLOCK;
+      const int r = tid + k * TB;
       rc[k] = pcr_rcp(b[k]);
       if (r < R) { pa[cur][PAD + r] = a[k]; pr[cur][PAD + r] = rc[k]; pd[cur][PAD + r] = d[k]; }
     }
     ipx_lds_barrier();
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
-      const int r = PAD + min(tid + k * IPX_BLOCK, R - 1);
+      const int r = PAD + min(tid + k * TB, R - 1);
       const double alo = pa[cur][r - h], rlo = pr[cur][r - h], dlo = pd[cur][r - h];
       const double ahi = pa[cur][r + h], rhi = pr[cur][r + h], dhi = pd[cur][r + h];
       const double al = -a[k] * rlo, ga = -ahi * rhi;
@@ -1552,7 +1558,7 @@ k_solve_pcr(int m, int rows_wg, int L, const double *__restrict__ band,
   // ---- x = d / b; own rows to memory, the window to LDS for the tail / residual
 #pragma unroll
   for (int k = 0; k < NR; ++k) {
-    const int r = tid + k * IPX_BLOCK;
+    const int r = tid + k * TB;
     if (r < R) {
       const double xv = d[k] / b[k];
       sx[r] = xv;
@@ -1568,7 +1574,7 @@ k_solve_pcr(int m, int rows_wg, int L, const double *__restrict__ band,
     double gacc = 0.0;
 #pragma unroll
     for (int k = 0; k < QP; ++k) {
-      const int64_t j = vb + 2 * (int64_t)(tid + k * IPX_BLOCK);
+      const int64_t j = vb + 2 * (int64_t)(tid + k * TB);
       // (an absent entry carries value 0: same sum as the CSR row; a pair that reaches into a
       // neighbour's variables reads that workgroup's offsets -- in range, result unused)
       const int c0 = H + (int)(ac[k] & 0xffffu), c1 = H + (int)(ac[k] >> 16);
@@ -1601,14 +1607,14 @@ k_solve_pcr(int m, int rows_wg, int L, const double *__restrict__ band,
   // (a_{i+1} of the row below: the level-0 sub-diagonal of the neighbouring lane, via LDS)
 #pragma unroll
   for (int k = 0; k < NR; ++k) {
-    const int r = tid + k * IPX_BLOCK;
+    const int r = tid + k * TB;
     if (r < R) pa[0][PAD + r] = a0[k];
   }
   ipx_lds_barrier();
   double acc = 0.0;
 #pragma unroll
   for (int k = 0; k < NR; ++k) {
-    const int r = tid + k * IPX_BLOCK;
+    const int r = tid + k * TB;
     const int64_t g = g0 + r;
     if (r >= H && r < H + rows_wg && g < m) {
       double sum = b0[k] * sx[r];
@@ -1630,12 +1636,13 @@ int launch_solve_pcr_q(const LevDev &lv, int L, const double *w, double *x, doub
   const int grid = (lv.P + DEC_CHUNKS - 1) / DEC_CHUNKS;
   if (npartial) *npartial = grid;
   // rows per lane: the window is rows_wg + 2^(L+1) rows
-  if (rows_wg + 2 * (1 << L) <= 2 * IPX_BLOCK)
-    hipLaunchKernelGGL((k_solve_pcr<QV, 2>), dim3(grid), dim3(IPX_BLOCK), 0, st, lv.m, rows_wg, L,
-                       lv.band, w, x, partial, guard, atv);
+  constexpr int NRL = (PCR_RMAX + PCR_TB - 1) / PCR_TB;
+  if (rows_wg + 2 * (1 << L) <= PCR_TB)
+    hipLaunchKernelGGL((k_solve_pcr<QV, 1, false, PCR_TB>), dim3(grid), dim3(PCR_TB), 0, st, lv.m,
+                       rows_wg, L, lv.band, w, x, partial, guard, atv, RowsJob{});
   else
-    hipLaunchKernelGGL((k_solve_pcr<QV, PCR_NR>), dim3(grid), dim3(IPX_BLOCK), 0, st, lv.m,
-                       rows_wg, L, lv.band, w, x, partial, guard, atv);
+    hipLaunchKernelGGL((k_solve_pcr<QV, NRL, false, PCR_TB>), dim3(grid), dim3(PCR_TB), 0, st,
+                       lv.m, rows_wg, L, lv.band, w, x, partial, guard, atv, RowsJob{});
   IPX_CHECK_LAUNCH();
   return IPX_OK;
 }
@@ -1646,7 +1653,7 @@ int launch_solve_pcr_rows(const LevDev &lv, int L, const RowsJob &rows, double *
                           double *partial, int *npartial, const double *guard, hipStream_t st) {
   const int rows_wg = DEC_CHUNKS * lv.q;
   const int R = rows_wg + 2 * (1 << L);
-  if (R > 2 * IPX_BLOCK || ((int64_t)R << rows.logL) > (int64_t)ROWS_U * IPX_BLOCK)
+  if (R > PCR_TB || ((int64_t)R << rows.logL) > (int64_t)ROWS_PRODUCTS)
     return IPX_EUNSUPPORTED;
   const int grid = (lv.P + DEC_CHUNKS - 1) / DEC_CHUNKS;
   if (npartial) *npartial = grid;
@@ -1654,13 +1661,13 @@ int launch_solve_pcr_rows(const LevDev &lv, int L, const RowsJob &rows, double *
   static bool attr_set = false;
   if (!attr_set) {
     // (the kernel's static arrays take 41 KB of the CU's 160: the attribute is the dynamic part)
-    (void)hipFuncSetAttribute((const void *)k_solve_pcr<0, 2, true>,
+    (void)hipFuncSetAttribute((const void *)k_solve_pcr<0, 1, true, PCR_TB>,
                               hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)(LDS_LIMIT - 44 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_solve_pcr<0, 2, true>), dim3(grid), dim3(IPX_BLOCK), lds, st, lv.m, rows_wg,
-                     L, lv.band, nullptr, x, partial, guard, AtvJob{}, rows);
+  hipLaunchKernelGGL((k_solve_pcr<0, 1, true, PCR_TB>), dim3(grid), dim3(PCR_TB), lds, st, lv.m,
+                     rows_wg, L, lv.band, nullptr, x, partial, guard, AtvJob{}, rows);
   IPX_CHECK_LAUNCH();
   return IPX_OK;
 }
@@ -1671,15 +1678,16 @@ int launch_solve_pcr(const LevDev &lv, int L, const double *w, double *x, double
   const AtvJob none{};
   if (!atv || qv <= 0)
     return launch_solve_pcr_q<0>(lv, L, w, x, partial, npartial, guard, none, st);
-  // the tail's lanes are the whole workgroup here (256 instead of 192): fewer variables each
-  // (+1: pairs start at an even variable, possibly one before the workgroup's first)
-  const int per = (qv * (DOWN_T - IPX_WAVE) + 1 + IPX_BLOCK - 1) / IPX_BLOCK;
+  // the tail's lanes are the whole 512-thread workgroup (not the 192 the tables count with):
+  // fewer variables each (+1: pairs start at an even variable, possibly one before the
+  // workgroup's first).  qv <= 16, the most the tables allow, is a workgroup that owns ~3000
+  // variables -- e.g. a problem of a single 260-row block with 11 columns per row
+  // (tests/fuzz_fused_loop.py): 6 per lane; the benchmark's 2600: 6 as well
+  const int per = (qv * (DOWN_T - IPX_WAVE) + 1 + PCR_TB - 1) / PCR_TB;
+  if (per <= 2) return launch_solve_pcr_q<2>(lv, L, w, x, partial, npartial, guard, *atv, st);
   if (per <= 4) return launch_solve_pcr_q<4>(lv, L, w, x, partial, npartial, guard, *atv, st);
+  if (per <= 6) return launch_solve_pcr_q<6>(lv, L, w, x, partial, npartial, guard, *atv, st);
   if (per <= 8) return launch_solve_pcr_q<8>(lv, L, w, x, partial, npartial, guard, *atv, st);
-  if (per <= 12) return launch_solve_pcr_q<12>(lv, L, w, x, partial, npartial, guard, *atv, st);
-  // (qv = 16, the most the tables allow -- a workgroup that owns ~3000 variables, e.g. a problem
-  // of a single 260-row block with 11 columns per row: found by tests/fuzz_fused_loop.py)
-  if (per <= 16) return launch_solve_pcr_q<16>(lv, L, w, x, partial, npartial, guard, *atv, st);
   return IPX_EINVAL;
 }
 

@@ -39,11 +39,11 @@
 // (the first version, one dependent LDS access after the other, took 27 us per iteration).
 //
 // Arithmetic: element by element the expressions of k_cg_step1_ar / k_solve_pcr /
-// k_cg_step2_hp, row sums left to right, ||g||^2 and the residual summed per workgroup in the
-// order of k_solve_pcr's 256 lanes (lanes 256.. of this kernel's 512 sit those two sums out):
-// bit-identical to the three launches; p'Hp and ||x + alpha p||^2 are summed per
-// workgroup of THIS decomposition instead of per row tile of H / A, so alpha can differ in
-// the last bit (tests: 1e-13 relative over whole solves, identical branch decisions).
+// k_cg_step2_hp, row sums left to right; the sums differ in their order: ||g||^2 and the
+// residual are summed per workgroup by 256 lanes (the order k_solve_pcr had while it ran 256
+// lanes; it runs 512 since), p'Hp and ||x + alpha p||^2 per workgroup of THIS decomposition
+// instead of per row tile of H / A -- so alpha and beta can differ in the last bit (tests:
+// 1e-13 relative over whole solves, identical branch decisions).
 #include "ipx_common.h"
 #include <algorithm>
 
@@ -590,7 +590,7 @@ k_cg_resident(ResJob J) {
     halo_put(J, wg, 2, rspan + own_off, pl, J.seq + hop + 1);                 // to the left neighbour
     halo_put(J, wg, 3, rspan + own_off + avn - pr, pr, J.seq + hop + 1);      // to the right neighbour
     // residual of the own rows:  w_i - (a_i v_{i-1} + b_i v_i + a_{i+1} v_{i+1}), squared; summed
-    // like ||g||^2 in the order of k_solve_pcr (its lane t: row t, then row t + 256)
+    // like ||g||^2 in the order of the 256-lane k_solve_pcr (its lane t: row t, then row t + 256)
     double *rsq = U + navnE;                          // (behind gsq: navnE + RB doubles of U)
     {
       const int r = min(max(tid, 1), R - 2);

@@ -1,13 +1,6 @@
-mkdir -p gpurun_out/fuzz
-( timeout 900 python tests/fuzz_box_schur.py 300 31 2>&1 | tail -2 ) > gpurun_out/fuzz/box.txt
-( timeout 1500 python tests/fuzz_minimize.py 200 33 2>&1 | tail -2 ) > gpurun_out/fuzz/minimize.txt
-( timeout 900 python tests/fuzz_banded_nlp.py 80 34 2>&1 | tail -2 ) > gpurun_out/fuzz/banded.txt
-( timeout 900 python tests/fuzz_sharded.py 2 60 35 2>&1 | grep -v "Gloo\|c10d\|amdgpu" | tail -2 ) > gpurun_out/fuzz/sharded2.txt
-( timeout 900 python tests/fuzz_sharded.py 2 16 36 solves 2>&1 | grep -v "Gloo\|c10d\|amdgpu" | tail -2 ) > gpurun_out/fuzz/sharded2_solves.txt
-( timeout 600 python - <<'P' 2>&1 | tail -3
-import sys; sys.path.insert(0,'tests')
-import fuzz_projections
-print("worst", fuzz_projections.run(400, 37, verbose=False, max_m=1500))
+timeout 1800 python -m pytest tests -m gpu -x -q 2>&1 | tail -4
+python bench.py --no-cpu 2>/dev/null | grep '^{' > gpurun_out/final/bench_tb512.json
+python - <<'P'
+import json
+d=json.load(open('gpurun_out/final/bench_tb512.json')); print(d['value'], d['ms_per_step'], d['device_loop_only']['iterations_per_s'], d['device_loop_only']['repeat']['iterations_per_s'], d['wall_clock_to_gtol']['seconds'], d['config5']['seconds'], d['roofline_out_of_cache']['iterations_per_s'])
 P
-) > gpurun_out/fuzz/projections.txt
-for f in gpurun_out/fuzz/box.txt gpurun_out/fuzz/minimize.txt gpurun_out/fuzz/banded.txt gpurun_out/fuzz/sharded2.txt gpurun_out/fuzz/sharded2_solves.txt gpurun_out/fuzz/projections.txt; do echo "== $f"; cut -c1-330 $f; done
