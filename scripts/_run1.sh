@@ -1,5 +1,6 @@
-R=/root/repo; cd /tmp && export TMPDIR=/tmp
-for t in 512 1024 512 1024; do
-  rm -rf /tmp/p5_$t; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p5_$t -o c5 -- python3 $R/scripts/_dbg5.py $t 500000 50000 > /tmp/c5_$t.out 2>/tmp/c5_$t.err
-  echo "== threads=$t"; grep -E "k_solve_pcr<0, [12], true" $(find /tmp/p5_$t -name '*kernel_stats.csv' | head -1) | sed -e 's/(int,.*)"/"/' | cut -c1-200; grep '^{' /tmp/c5_$t.out | cut -c1-200
-done
+mkdir -p gpurun_out/final
+python bench.py --no-cpu 2>/dev/null | grep '^{' > gpurun_out/final/bench_tb512.json
+python - <<'P'
+import json
+d=json.load(open('gpurun_out/final/bench_tb512.json')); print(d['value'], d['ms_per_step'], d['device_loop_only']['iterations_per_s'], d['device_loop_only']['repeat']['iterations_per_s'], d['wall_clock_to_gtol']['seconds'], d['config5']['seconds'], d['roofline_out_of_cache']['iterations_per_s'])
+P
