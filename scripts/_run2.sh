@@ -1,6 +1,10 @@
-timeout 1800 python -m pytest tests -m gpu -x -q 2>&1 | tail -4
-python bench.py --no-cpu 2>/dev/null | grep '^{' > gpurun_out/final/bench_tb512.json
-python - <<'P'
-import json
-d=json.load(open('gpurun_out/final/bench_tb512.json')); print(d['value'], d['ms_per_step'], d['device_loop_only']['iterations_per_s'], d['device_loop_only']['repeat']['iterations_per_s'], d['wall_clock_to_gtol']['seconds'], d['config5']['seconds'], d['roofline_out_of_cache']['iterations_per_s'])
-P
+bash scripts/refresh_profiles.sh final trace pmc config5 2>&1 | tail -4
+cp gpurun_out/final/pmc_traffic_n1e6.json profiles/r04_pmc_traffic_n1e6.json
+cp gpurun_out/final/pmc_traffic_n4e6.json profiles/r04_pmc_traffic_n4e6.json
+python bench.py 2>/dev/null | grep '^{' > gpurun_out/final/bench_line.json
+python bench.py --steps 20 --warmup 5 --no-cpu 2>/dev/null | grep '^{' > gpurun_out/final/bench_line_steps20.json
+make -C ip-nonlinear-solver_amd/csrc phase-timing > /dev/null 2>&1
+python scripts/phase_timing_tail.py 2>&1 | tail -7 > gpurun_out/final/pcr_tail_phase_timing.txt
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/tp; rocprofv3 --kernel-trace --output-format csv -d /tmp/tp -- python3 /root/repo/scripts/trace_public_call.py run 20 > /dev/null 2>/tmp/tp.err
+python3 /root/repo/scripts/trace_public_call.py show /tmp/tp > /root/repo/gpurun_out/final/public_call_timeline.txt 2>&1
