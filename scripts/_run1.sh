@@ -1,6 +1,7 @@
 mkdir -p gpurun_out/final
-python bench.py --no-cpu 2>/dev/null | grep '^{' > gpurun_out/final/bench_tb512.json
+IPX_BENCH_BACKEND=gloo timeout 900 python bench.py --gpus 2 2>/tmp/b2.err | grep '^{' > gpurun_out/final/bench_2rank.json
+tail -3 /tmp/b2.err | cut -c1-300
 python - <<'P'
 import json
-d=json.load(open('gpurun_out/final/bench_tb512.json')); print(d['value'], d['ms_per_step'], d['device_loop_only']['iterations_per_s'], d['device_loop_only']['repeat']['iterations_per_s'], d['wall_clock_to_gtol']['seconds'], d['config5']['seconds'], d['roofline_out_of_cache']['iterations_per_s'])
+d=json.load(open('gpurun_out/final/bench_2rank.json')); print(d['value'], d['n_gpus'], d['transport'], d.get('parity_vs_single_gpu'), json.dumps(d.get('transport_ab'))[:400], json.dumps(d.get('wall_clock_to_gtol'))[:300])
 P
