@@ -1,7 +1,2 @@
 mkdir -p gpurun_out/final
-IPX_BENCH_BACKEND=gloo timeout 900 python bench.py --gpus 2 2>/tmp/b2.err | grep '^{' > gpurun_out/final/bench_2rank.json
-tail -3 /tmp/b2.err | cut -c1-300
-python - <<'P'
-import json
-d=json.load(open('gpurun_out/final/bench_2rank.json')); print(d['value'], d['n_gpus'], d['transport'], d.get('parity_vs_single_gpu'), json.dumps(d.get('transport_ab'))[:400], json.dumps(d.get('wall_clock_to_gtol'))[:300])
-P
+timeout 900 python scripts/per_rank_sweep.py gpurun_out/final/per_rank_sweep.json 2>&1 | grep -v amdgpu | tail -6 | cut -c1-600
