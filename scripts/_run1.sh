@@ -1,2 +1,6 @@
-mkdir -p gpurun_out/final
-timeout 900 python scripts/per_rank_sweep.py gpurun_out/final/per_rank_sweep.json 2>&1 | grep -v amdgpu | tail -6 | cut -c1-600
+mkdir -p /root/repo/gpurun_out/final
+true
+R=/root/repo; cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/tp; rocprofv3 --kernel-trace --output-format csv -d /tmp/tp -- python3 $R/scripts/trace_public_call.py run 20 > /dev/null 2>/tmp/tp.err
+python3 $R/scripts/trace_public_call.py show /tmp/tp > $R/gpurun_out/final/public_call_timeline.txt 2>&1
+sed -n 10,16p $R/gpurun_out/final/public_call_timeline.txt; tail -1 $R/gpurun_out/final/public_call_timeline.txt
