@@ -3,7 +3,7 @@ Jacobians of many structures -- random sparsity of several densities, a band wit
 shuffled, block diagonal, a band plus a few dense rows, dense storage -- so that every
 ``(A A')^-1`` solver of the product takes its turn (banded with and without reordering, dense
 Cholesky, preconditioned CG, box-Schur), against the host oracle's projections on the same
-seeded inputs.
+seeded inputs; then the modified dogleg step (qp_subproblem.py:320-413) on the same Jacobian.
 
     python tests/fuzz_projections.py [cases] [seed]      (tests/test_gpu_qp.py runs 20 cases of <= 1500 rows;
                                                           the 6000-row cases take minutes of host time)"""
@@ -86,8 +86,23 @@ def run(cases, seed, verbose=True, max_m=6000):
             got = op.dot(dv.DVec.from_host(v)).to_host()
             want = oop.dot(v)
             errs.append(float(np.max(np.abs(got - want)) / max(np.max(np.abs(want)), 1e-300)))
-        line = "case %2d %-16s m=%5d n=%6d nnz=%7d %-22s Z %.1e  LS %.1e  Y %.1e" % (
-            case, kind, m, n, (A != 0).sum(), solver + ("/" + inner if inner != "NoneType" else ""), *errs)
+        # modified_dogleg (qp_subproblem.py:320-413) on the same Jacobian: a radius / box drawn so
+        # that the Newton point is accepted, cut by the sphere, or cut by the box
+        from ipsolver import qp
+        yb = Yo.dot(y)
+        scale = float(np.linalg.norm(yb)) or 1.0
+        mode = int(rng.integers(0, 4))
+        radius = scale * [2.0, 0.5, 2.0, 0.05][mode]
+        if mode == 2:
+            lo_, hi_ = np.full(n, -0.3 * np.max(np.abs(yb))), np.full(n, 0.4 * np.max(np.abs(yb)))
+        else:
+            lo_, hi_ = np.full(n, -np.inf), np.full(n, np.inf)
+        got = qp.modified_dogleg(Ad, Y, y, radius, lo_, hi_).to_host()
+        want = oracle.modified_dogleg(A, Yo, y, radius, lo_, hi_)
+        errs.append(float(np.max(np.abs(got - want)) / max(np.max(np.abs(want)), 1e-300)))
+        line = "case %2d %-16s m=%5d n=%6d nnz=%7d %-22s Z %.1e  LS %.1e  Y %.1e  dogleg(%d) %.1e" % (
+            case, kind, m, n, (A != 0).sum(), solver + ("/" + inner if inner != "NoneType" else ""),
+            errs[0], errs[1], errs[2], mode, errs[3])
         if verbose:
             print(line, flush=True)
         assert max(errs) <= 1e-9, line

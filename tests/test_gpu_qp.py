@@ -1125,7 +1125,9 @@ def test_box_schur_loop_on_random_shapes(ips):
 
 
 def test_projections_on_random_structures(ips):
-    """tests/fuzz_projections.py: Z, LS, Y (projections.py:14-290) applied to random vectors for
+    """tests/fuzz_projections.py: Z, LS, Y (projections.py:14-290) applied to random vectors --
+    and the modified dogleg step (qp_subproblem.py:320-413: Newton point accepted, cut by the
+    sphere, cut by a box) -- for
     20 random Jacobians -- random sparsity of three densities, a band with shuffled rows, block
     diagonal, a band with two dense rows, dense storage; 1 .. 1500 rows; every third case without
     the dense Cholesky -- so that the banded solver with and without reordering, the dense
