@@ -1,5 +1,1 @@
-timeout 900 python - <<'P' 2>&1 | grep -v amdgpu | tail -14 | cut -c1-220
-import sys; sys.path.insert(0,'tests')
-import fuzz_projections
-print("worst", fuzz_projections.run(150, 51, verbose=True, max_m=1500))
-P
+timeout 900 python -m pytest tests/test_gpu_e2e.py -x -q -k "random_constraint_mixes" --durations=2 2>&1 | tail -5

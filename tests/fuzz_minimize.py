@@ -5,8 +5,8 @@ constraints, ragged boxes; _constraints.py, _canonical_constraint.py) -- on the 
 against the same call on the host oracle's backend (oracle/numpy_backend.py: the reference's
 algorithms, tr_interior_point.py / equality_constrained_sqp.py, over numpy + SuperLU).  The two
 factor their projections differently, so traces drift at the 1e-10 level; compared are the
-first outer iterations row by row (1e-4: a 19-iteration CG run inside a barrier subproblem
-turns the 1e-11 between two factorizations into 1e-6 by the sixth row) and the end points (a
+first outer iterations row by row (up to the first long CG call: there the problem itself
+moves by 1e-5 under one ulp) and the end points (a
 unique minimiser).
 
     python tests/fuzz_minimize.py [cases] [seed]         (tests/test_gpu_e2e.py runs 12 cases)"""
@@ -37,6 +37,11 @@ def problem(rng):
     hess = (lambda x: sps.csr_matrix(Q + np.diag(0.6 * x ** 2))) if sparse else \
         (lambda x: Q + np.diag(0.6 * x ** 2))
     cons, tags = [], []
+    # one case in five: the reference's DEFAULT Hessian, finite differences of the gradient (an
+    # operator: applied between the device loop's iterations, _numdiff.py:403-441)
+    if rng.random() < 0.2 and not big_dense:
+        hess = str(rng.choice(["2-point", "3-point"]))
+        tags.append("fd-" + hess)
     m_eq = int(rng.integers(0, max(1, n // 3) + 1))
     if big_dense:
         m_eq = max(m_eq, 8)
@@ -78,8 +83,9 @@ def problem(rng):
         hi = np.where(kind & 2, x0 + rng.uniform(0.1, 1.0, n), np.inf)
         cons.append(ipsolver.BoxConstraint(("interval", lo, hi)))
         tags.append("box")
-    ineq = any(not t.startswith("eq") for t in tags)
-    methods = ["tr_interior_point"] + ([] if ineq or not tags else ["equality_constrained_sqp"])
+    ineq = any(not t.startswith(("eq", "fd-")) for t in tags)
+    has_eq = any(t.startswith("eq") for t in tags)
+    methods = ["tr_interior_point"] + ([] if ineq or not has_eq else ["equality_constrained_sqp"])
     return dict(n=n, fun=fun, grad=grad, hess=hess, x0=x0, cons=cons, tags=tags, sparse=sparse,
                 methods=methods)
 
@@ -110,22 +116,41 @@ def run(cases, seed, verbose=True, only=None):
             got, rows = solve(P, method)
             with backend.use(nb):
                 want, wrows = solve(P, method)
+            # rows compared: the first six, but only up to the first long CG call -- one
+            # box-constrained call of 22 iterations moved 1e-5 between the two sides on
+            # identical inputs, and as far on the oracle alone when its gradient moved by one
+            # ulp (the ``last_feasible_x`` bookkeeping of qp_subproblem.py:599-616 is discrete)
             k = min(6, len(rows), len(wrows))
+            long_cg = np.flatnonzero(np.diff(wrows[:k, 1]) > 12)
+            if len(long_cg):
+                k = int(long_cg[0]) + 1
             dx = float(np.max(np.abs(got.x - want.x)) / max(1.0, np.max(np.abs(want.x))))
             line = "case %2d n=%2d %-5s %-24s %-34s status %d/%d  %3d/%3d outer  |dx| %.1e  opt %.1e/%.1e" % (
                 case, P["n"], "csr" if P["sparse"] else "dense", method, "+".join(P["tags"]) or "-",
                 got.status, want.status, got.niter, want.niter, dx, got.optimality, want.optimality)
             if verbose:
                 print(line, flush=True)
+            if max(got.niter, want.niter) > 300:
+                # a degenerate instance: hundreds of outer iterations at the last barrier
+                # parameters on BOTH sides, the optimality hovering between 2e-8 and 1e-6 (one
+                # case of seed 61: the oracle's run got below gtol after 591, this side had not
+                # after 1000 -- from a trajectory that differs from row 13 on by 1e-11).  Only
+                # the end point says anything there.
+                assert dx <= 1e-4, line
+                continue
             # (1: gtol, 2: xtol -- an end game on the merit function's rounding floor may end
             # either way on either side, _minimize_constrained.py:395-407)
             assert got.status in (1, 2) and want.status in (1, 2), line
             assert np.array_equal(rows[:k, :2], wrows[:k, :2]), line
-            assert np.allclose(rows[:k, 2:], wrows[:k, 2:], rtol=1e-4, atol=1e-10), line
+            # (a finite-difference Hessian product carries ~1e-8 of rounding noise, another draw
+            # of it on each side)
+            rtol = 1e-4 if any(t.startswith("fd-") for t in P["tags"]) else 1e-6
+            assert np.allclose(rows[:k, 2:], wrows[:k, 2:], rtol=rtol, atol=1e-10), line
             # (late barrier subproblems amplify 1e-10 differences into other iteration counts --
             # 198 against 443 outer iterations on one of these problems, the same end point:
             # DESIGN.md section 7 -- so the counts are printed, not compared)
-            assert dx <= 1e-5 and got.constr_violation <= 1e-8, line
+            # (weakly active constraints leave a barrier run's end point determined to ~sqrt(mu))
+            assert dx <= 1e-4 and got.constr_violation <= 1e-8, line
             worst = max(worst, dx)
     return worst
 

@@ -225,11 +225,12 @@ def test_random_constraint_mixes_against_the_oracle_backend():
     dense / sparse linear equalities, interval and one-sided linear inequalities, a nonlinear
     ball, ragged boxes -- the reference's three constraint classes in every combination,
     _constraints.py / _canonical_constraint.py) through ``minimize_constrained`` on the HIP
-    backend against the same calls on the oracle's backend: the first six outer iterations row
-    by row (counts equal, optimality / violation to 1e-6), the end points to 1e-5, both by the
-    barrier method and -- equalities only -- by the SQP."""
+    backend against the same calls on the oracle's backend: the first outer iterations row by
+    row (counts equal, optimality / violation to 1e-6; up to the first long CG call), the end
+    points to 1e-4, both by the barrier method and -- equalities only -- by the SQP; some with
+    the reference's default finite-difference Hessian, some dense with a few hundred variables."""
     import fuzz_minimize
-    assert fuzz_minimize.run(10, 5, verbose=False) <= 1e-5
+    assert fuzz_minimize.run(12, 5, verbose=False) <= 1e-4
 
 
 def test_sharded_loop_on_random_band_shapes(tmp_path):
