@@ -6,7 +6,7 @@ the sharded loop and, inside every rank, by the single-GPU loop on the whole pro
 (qp_subproblem.py:332-637 both).  A shape the halo partition refuses must be refused by every
 rank alike (NotImplementedError before any collective).
 
-    python tests/fuzz_sharded.py [world] [cases] [seed] [solves]    (tests/test_gpu_e2e.py: 2 ranks)"""
+    python tests/fuzz_sharded.py [world] [cases] [seed] [solves|mixes]    (tests/test_gpu_e2e.py: 2 ranks)"""
 import os, socket, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 import numpy as np
@@ -177,11 +177,91 @@ def run_solves(world, cases, seed, out_path, verbose=True):
     return float(got["worst"]), [str(l) for l in got["lines"]]
 
 
+# ---- random mixes of the three constraint classes on the plain block partition ----------------
+def mixes_worker(rank, world, port, out_path, cases, seed):
+    """tests/fuzz_minimize.py's random problems (dense / sparse equalities, linear and nonlinear
+    inequalities, ragged boxes) through ``minimize_constrained(..., options={'shard': True})``:
+    no banded shape, so the plain block partition with its general driver
+    -- against the same call without sharding, inside every rank."""
+    import warnings
+    import torch
+    import torch.distributed as dist
+    for p in (ROOT, os.path.join(ROOT, "ip-nonlinear-solver_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import ipsolver
+        import fuzz_minimize as fm
+        rng = np.random.default_rng(seed)
+        lines, worst = [], 0.0
+        for case in range(cases):
+            P = fm.problem(rng)
+            if any(t.startswith("fd-") for t in P["tags"]):
+                continue
+            method = P["methods"][-1]
+            outs = []
+            for shard in (True, False):
+                rows = []
+
+                def record(state):
+                    rows.append([int(state.niter), int(state.cg_niter), float(state.optimality),
+                                 float(state.constr_violation)])
+                    return False
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    try:
+                        res = ipsolver.minimize_constrained(
+                            P["fun"], P["x0"], P["grad"], P["hess"], P["cons"], method=method,
+                            sparse_jacobian=True, callback=record, max_iter=40,
+                            options={"shard": True} if shard else {})
+                    except NotImplementedError as exc:
+                        res = str(exc)[:70]
+                outs.append((res, np.array(rows)))
+            (got, rows), (want, wrows) = outs
+            tag = "case %2d n=%3d %-24s %-30s" % (case, P["n"], method, "+".join(P["tags"]) or "-")
+            if isinstance(got, str):
+                lines.append(tag + "  refused: " + got)
+                continue
+            k = min(5, len(rows), len(wrows))
+            long_cg = np.flatnonzero(np.diff(wrows[:k, 1]) > 12)
+            if len(long_cg):
+                k = int(long_cg[0]) + 1
+            dx = float(np.max(np.abs(got.x - want.x)) / max(1.0, np.max(np.abs(want.x))))
+            lines.append(tag + "  %d/%d outer  rows compared %d  |dx| %.1e" % (got.niter, want.niter, k, dx))
+            assert np.array_equal(rows[:k, :2], wrows[:k, :2]), lines[-1]
+            assert np.allclose(rows[:k, 2:], wrows[:k, 2:], rtol=1e-6, atol=1e-10), lines[-1]
+            if got.status in (1, 2) and want.status in (1, 2):
+                assert dx <= 1e-4, lines[-1]
+                worst = max(worst, dx)
+        if rank == 0:
+            np.savez(out_path, worst=worst, lines=np.array(lines))
+    finally:
+        dist.destroy_process_group()
+
+
+def run_mixes(world, cases, seed, out_path, verbose=True):
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(mixes_worker, args=(world, port, out_path, cases, seed), nprocs=world, join=True)
+    got = np.load(out_path)
+    if verbose:
+        print("\n".join(got["lines"]))
+    return float(got["worst"]), [str(l) for l in got["lines"]]
+
+
 if __name__ == "__main__":
     world = int(sys.argv[1]) if len(sys.argv) > 1 else 2
     ncase = int(sys.argv[2]) if len(sys.argv) > 2 else 12
     seed = int(sys.argv[3]) if len(sys.argv) > 3 else 0
-    if len(sys.argv) > 4 and sys.argv[4] == "solves":
+    if len(sys.argv) > 4 and sys.argv[4] == "mixes":
+        w, _ = run_mixes(world, ncase, seed, "/tmp/fuzz_sharded_mixes.npz")
+        print("ok, worst end-point deviation of the sharded mixed problems %.1e" % w)
+    elif len(sys.argv) > 4 and sys.argv[4] == "solves":
         w, _ = run_solves(world, ncase, seed, "/tmp/fuzz_sharded_solves.npz")
         print("ok, worst end-point deviation of the sharded solves %.1e" % w)
     else:

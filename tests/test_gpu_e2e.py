@@ -269,6 +269,18 @@ def test_sharded_solves_on_random_band_shapes(tmp_path):
     assert worst <= 1e-6 and sum("sharded loops 0" not in l for l in lines) >= 4, lines
 
 
+def test_sharded_random_constraint_mixes(tmp_path):
+    """tests/fuzz_sharded.py (mixes): the random problems of tests/fuzz_minimize.py -- dense /
+    sparse equalities, linear and nonlinear inequalities, ragged boxes, none of them banded --
+    through ``minimize_constrained(..., options={'shard': True})`` on two ranks sharing cuda:0
+    (the plain block partition with its general driver) against the same call without sharding:
+    first rows of the trace, end points to 1e-4; spaces too small for the ranks are refused
+    with a NotImplementedError on every rank alike."""
+    import fuzz_sharded
+    worst, lines = fuzz_sharded.run_mixes(2, 12, 1, str(tmp_path / "fuzz.npz"), verbose=False)
+    assert worst <= 1e-4 and sum("refused" not in l for l in lines) >= 6, lines
+
+
 def test_product_never_imports_the_oracle():
     """Run a solve in a fresh interpreter: the product must not load oracle.*
     (no CPU fallback), and must have loaded the in-tree libipx.so."""
