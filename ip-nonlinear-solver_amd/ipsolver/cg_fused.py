@@ -52,6 +52,7 @@ class CgArgs(ctypes.Structure):
 STATS = {"calls": 0, "iterations": 0, "batches": 0, "box_events": 0, "refine_events": 0,
          "primed_on_device": 0,   # calls whose priming read nothing back (ipx_cg_prime_state)
          "prime_retries": 0,      # ... of which the device sent back to the host-driven priming
+         "host_primed_directly": 0,   # calls that skipped the device priming after such a retry
          "resident_calls": 0,     # solves whose batches ran as resident launches (csrc/resident.hip)
          "resident_fallbacks": 0, # batches repeated on the separate launches (stop code 8)
          "operator_calls": 0}     # solves whose Hessian was an operator applied by the host
@@ -673,15 +674,35 @@ def projected_cg(H, c, Z, Y, b, trust_radius=np.inf, lb=None, ub=None, tol=None,
     block (stop code 9) and the call starts over on the host-driven priming below."""
     P = Z.projector
     from .projector import NormalEquationProjector
+    # Near convergence Z c is tiny next to c and EVERY call needs the cancellation step: after a
+    # call whose device priming was turned down, calls on the same problem (same patterns: the
+    # loop pool's signature) go to the host priming directly -- until one of them gets by
+    # without refinement or cancellation steps, which the host priming counts anyway.
+    key = _signature(H, P, lb, ub) if isinstance(P, NormalEquationProjector) else None
     if isinstance(P, NormalEquationProjector) and P.m > 0 and len(c) - len(b) >= 1 \
-            and (max_iter is None or max_iter >= 1) and trust_radius >= 0:
+            and (max_iter is None or max_iter >= 1) and trust_radius >= 0 \
+            and not (key is not None and key in _HOST_PRIMED):
         try:
             return _projected_cg(H, c, Z, Y, b, trust_radius, lb, ub, tol, max_iter,
                                  max_infeasible_iter, batch, stats, b_zero, fast=True)
         except _PrimeRetry:
             STATS["prime_retries"] += 1
-    return _projected_cg(H, c, Z, Y, b, trust_radius, lb, ub, tol, max_iter,
-                         max_infeasible_iter, batch, stats, b_zero, fast=False)
+            if key is not None:
+                if len(_HOST_PRIMED) >= 16:
+                    _HOST_PRIMED.clear()
+                _HOST_PRIMED.add(key)
+    steps = None
+    if key is not None and key in _HOST_PRIMED:
+        steps = P.stats["refinements"] + P.stats["cancellation_steps"]
+        STATS["host_primed_directly"] += 1
+    out = _projected_cg(H, c, Z, Y, b, trust_radius, lb, ub, tol, max_iter,
+                        max_infeasible_iter, batch, stats, b_zero, fast=False)
+    if steps is not None and P.stats["refinements"] + P.stats["cancellation_steps"] == steps:
+        _HOST_PRIMED.discard(key)        # (a clean priming: the next call tries the device again)
+    return out
+
+
+_HOST_PRIMED = set()       # pool signatures whose last call needed the host's priming
 
 
 _PRIME_IDX = (ctypes.c_int32 * 7)(12, 4, 0, 2, 10, 6, 8)
