@@ -795,7 +795,11 @@ def _projected_cg(H, c, Z, Y, b, trust_radius, lb, ub, tol, max_iter, max_infeas
         r0 = Z.dot(H.dot(x0) + c)
         norm_x0 = None
     g0 = Z.dot(r0)
-    rt_g = g0.sumsq_amax()[0]            # norm(g)**2
+    # norm(g)**2: the projection's last pass left ||g0||^2 in its reduction block, read with the
+    # orthogonality measure -- the number the device priming starts from (same kernel, same
+    # fold), so the two primings start the loop from the same bits, and one read less
+    red = getattr(P, "_red", None)
+    rt_g = float(red[0]) if red is not None and P.m > 0 else g0.sumsq_amax()[0]
     tr_distance = trust_radius - (dv.norm(x0) if norm_x0 is None else norm_x0)
     if tr_distance < 0:
         raise ValueError("Trust region problem does not have a solution.")
