@@ -767,8 +767,9 @@ def _projected_cg(H, c, Z, Y, b, trust_radius, lb, ub, tol, max_iter, max_infeas
             # ... and the call's first batch behind it (the host's way from here to its own
             # ipx_cg_iterate call is ~50 us of idle GPU otherwise)
             first_end = min(max_iter, batch if batch else _first_batch(max_iter, False))
+            b_rows = None if b_zero else P.rows_in(b)      # (the projector's row order)
             _hip.call("ipx_cg_prime", L.ref(), _p(pat.tiles), pat.ntiles, _p(c.t),
-                      None if b_zero else _p(b.t), _p(ctx_.out), _p(ctx_.ws),
+                      None if b_zero else _p(b_rows.t), _p(ctx_.out), _p(ctx_.ws),
                       float("nan") if tol is None else float(tol), float(trust_radius),
                       float(P.orth_tol), float(P.norm_A), float(P.CANCELLATION),
                       max(first_end, 0), st)

@@ -215,10 +215,22 @@ class NormalEquationProjector:
     refinements on the benchmark; the counters let tests assert the same).
     """
 
-    def __init__(self, A, solver, orth_tol=1e-12, max_refin=3):
+    def __init__(self, A, solver, orth_tol=1e-12, max_refin=3, row_perm=None):
+        """``row_perm`` (host ints, or None): ``A`` is the caller's matrix with its rows taken in
+        this order (``A = A_caller[row_perm]``: the order in which A A' is banded, see
+        ``projections``).  Z does not see the order of the rows; LS returns its multipliers in
+        the caller's order and Y takes its right-hand side in it (``rows_in`` for callers that
+        hand constraint-space vectors to kernels themselves: cg_fused's priming)."""
         self.A, self.solver = A, solver
         self.orth_tol, self.max_refin = orth_tol, max_refin
         self.m, self.n = A.shape
+        self.row_perm = None
+        if row_perm is not None:
+            inv = np.empty(len(row_perm), dtype=np.int32)
+            inv[np.asarray(row_perm)] = np.arange(len(row_perm), dtype=np.int32)
+            dev = ctx().device
+            self.row_perm = torch.from_numpy(np.ascontiguousarray(row_perm, dtype=np.int32)).to(dev)
+            self._row_iperm = torch.from_numpy(inv).to(dev)
         self.norm_A = A.frobenius_norm() if self.m > 0 else 0.0
         self.stats = {"solves": 0, "refinements": 0, "cancellation_steps": 0}
 
@@ -286,17 +298,28 @@ class NormalEquationProjector:
         self.A.spmv(z, reduce=True, slot=base // 2 + 1)
         return z
 
+    def _gather_rows(self, v, idx):
+        out = dv._empty(idx.numel())
+        _hip.call("ipx_gather", idx.numel(), dv._p(v.t), dv._p(idx), None, None, dv._p(out),
+                  dv.stream_ptr())
+        return DVec(out)
+
+    def rows_in(self, b):
+        """A constraint-space vector of the caller in this projector's row order."""
+        return b if self.row_perm is None else self._gather_rows(b, self.row_perm)
+
     def least_squares(self, x):
         if self.m == 0:
             return DVec.zeros(0)
         v = self._apply_inv(self.A.dot(x))
         for _ in range(getattr(self.solver, "refine_steps", 0)):     # ill-conditioned dense A
             v = v + self._apply_inv(self.A.dot(self.A.rmatvec_sub(v, x)))
-        return v
+        return v if self.row_perm is None else self._gather_rows(v, self._row_iperm)
 
     def row_space(self, x):
         if self.m == 0:
             return DVec.zeros(self.n)
+        x = self.rows_in(x)
         y = self.A.T.dot(self._apply_inv(x))
         for _ in range(getattr(self.solver, "refine_steps", 0)):
             y = y + self.A.T.dot(self._apply_inv(x - self.A.dot(y)))
@@ -614,6 +637,28 @@ def normal_solver_for(A):
     return IterativeNormalSolver(A)             # general sparsity: matrix-free solve
 
 
+def _banded_row_order(A):
+    """The row order in which A A' is banded when the natural one is not and the banded solver
+    would be the choice of ``normal_solver_for`` (not the box-Schur elimination, which has its
+    own row bookkeeping); None otherwise."""
+    kmax = _hip.load().ipx_banded_kmax()
+    if half_bandwidth_of_aat(A.pattern) <= kmax:
+        return None
+    if _box_schur_applies(A, kmax):
+        return None
+    sym = _symbolic_for(A.pattern)
+    return sym.perm if (sym.k <= kmax and sym.perm is not None) else None
+
+
+def _rows_in_order(A, perm):
+    """``A[perm]`` as a value refresh on a pattern derived once from A's (cached on it)."""
+    from .device_mode import RowSelection
+    sel = getattr(A.pattern, "_ipx_rows_in_order", None)
+    if sel is None:
+        sel = A.pattern._ipx_rows_in_order = RowSelection(A.pattern, np.asarray(perm, dtype=np.int64), None)
+    return sel.apply(A)
+
+
 def projections(A, method=None, orth_tol=1e-12, max_refin=3, tol=1e-15):
     """Device counterpart of ``projections`` (projections.py:290-406).
 
@@ -644,7 +689,17 @@ def projections(A, method=None, orth_tol=1e-12, max_refin=3, tol=1e-15):
     m, n = A.shape
     if method == "SVDFactorization":
         return SVDProjector(A, orth_tol, max_refin, tol).operators()
+    A_caller, row_perm = A, None
     try:
+        if sparse and m > 0:
+            # A A' banded only after a reordering of the rows (equality rows stacked on
+            # inequality rows: _canonical_constraint.py:169-360): factor the matrix WITH ITS ROWS
+            # IN THAT ORDER instead of permuting inside every solve -- the projections do not see
+            # the order of the rows, and the device-resident CG loop (cg_fused) takes any matrix
+            # whose natural order is banded
+            row_perm = _banded_row_order(A)
+            if row_perm is not None:
+                A = _rows_in_order(A, row_perm)
         solver = None if m == 0 else normal_solver_for(A)
         inner = getattr(solver, "inner", solver)           # (box-Schur: its banded Schur solve)
         if getattr(inner, "ill_conditioned", False):
@@ -658,5 +713,5 @@ def projections(A, method=None, orth_tol=1e-12, max_refin=3, tol=1e-15):
              "factorizations." if sparse else
              "Singular Jacobian matrix. Using SVD decomposition to perform the "
              "factorizations.")
-        return SVDProjector(A, orth_tol, max_refin, tol).operators()
-    return NormalEquationProjector(A, solver, orth_tol, max_refin).operators()
+        return SVDProjector(A_caller, orth_tol, max_refin, tol).operators()
+    return NormalEquationProjector(A, solver, orth_tol, max_refin, row_perm=row_perm).operators()

@@ -1221,6 +1221,7 @@ class FusedShardedCG:
             local_P.m, local_P.n = A_loc.shape
             local_P.norm_A = P.norm_A
             local_P.stats = P.stats
+            local_P.row_perm = None
         self.P = P
         self.kind = H.kind
         # (the rank-local loop keeps the separate launches: the own-range partial sums of

@@ -1,0 +1,53 @@
+"""A banded NLP whose constraint rows alternate between equalities and one-sided inequalities
+(the seeded ``CenteredBandedNLP`` with ``kind = ('interval', lb, ub)``: even rows c_i(x) = 0, odd
+rows c_i(x) <= 0).  The canonical form stacks [equalities; inequalities + slacks]
+(_canonical_constraint.py:169-360), so the augmented Jacobian's natural row order is not banded
+although A A' is after a row permutation."""
+import os, sys, warnings
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "ip-nonlinear-solver_amd")); sys.path.insert(0, ROOT)
+import numpy as np
+
+
+def solve(n, m, bw=15, seed=0, backend_module=None, max_iter=1000):
+    import ipsolver
+    from ipsolver import backend
+    from ipsolver.synthetic import CenteredBandedNLP
+    prob = CenteredBandedNLP(n, m, bw=bw, seed=seed, eps=1.0)
+    lb = np.where(np.arange(m) % 2 == 0, 0.0, -np.inf)
+    cons = prob.constraints(ipsolver, ("interval", lb, np.zeros(m)))
+    rows = []
+
+    def record(state):
+        rows.append([int(state.niter), int(state.cg_niter), float(state.optimality),
+                     float(state.constr_violation), float(state.barrier_parameter)])
+        return False
+
+    def run():
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            return ipsolver.minimize_constrained(prob.fun, prob.x0, prob.grad, prob.hess, cons,
+                                                 callback=record, max_iter=max_iter)
+    if backend_module is not None:
+        with backend.use(backend_module):
+            res = run()
+    else:
+        res = run()
+    return res, np.array(rows)
+
+
+if __name__ == "__main__":
+    import time
+    from ipsolver import cg_fused
+    import oracle.numpy_backend as nb
+    n, m = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (4000, 400)
+    before = dict(cg_fused.STATS)
+    t0 = time.time(); got, rows = solve(n, m); t1 = time.time()
+    loops = cg_fused.STATS["calls"] - before["calls"]
+    want, wrows = solve(n, m, backend_module=nb)
+    k = min(8, len(rows), len(wrows))
+    print("product: status %d, %d outer / %d CG in %.2f s, device loops %d | oracle: status %d, %d / %d"
+          % (got.status, got.niter, got.cg_niter, t1 - t0, loops, want.status, want.niter, want.cg_niter))
+    print("rows equal:", np.array_equal(rows[:k, :2], wrows[:k, :2]),
+          "max rel row diff %.1e" % np.max(np.abs(rows[:k, 2:4] - wrows[:k, 2:4]) / np.maximum(np.abs(wrows[:k, 2:4]), 1e-300)),
+          "|dx| %.1e" % (np.max(np.abs(got.x - want.x)) / max(1.0, np.max(np.abs(want.x)))))

@@ -281,6 +281,31 @@ def test_sharded_random_constraint_mixes(tmp_path):
     assert worst <= 1e-4 and sum("refused" not in l for l in lines) >= 6, lines
 
 
+def test_mixed_equality_inequality_rows_take_the_device_loop():
+    """A banded NLP whose constraint rows ALTERNATE between equalities and inequalities
+    (tests/mixed_banded.py; the canonical form stacks [equalities; inequalities + slacks],
+    _canonical_constraint.py:169-360, so A A' is banded only after a row permutation): the
+    projector factors the Jacobian with its rows in the banded order (ipsolver/projector.py
+    ``projections``: Z does not see the order, LS / Y permute at their boundary) and the
+    subproblems run on the device-resident CG loop instead of the host-driven one -- against
+    the same solve on the oracle's backend (tr_interior_point.py:141-194): first rows of the
+    trace, end point and objective."""
+    import mixed_banded
+    import ipsolver.cg_fused as cg_fused
+    import oracle.numpy_backend as nb
+    before = dict(cg_fused.STATS)
+    got, rows = mixed_banded.solve(4000, 400)
+    assert cg_fused.STATS["calls"] - before["calls"] >= 20          # the device loop, not qp's
+    want, wrows = mixed_banded.solve(4000, 400, backend_module=nb)
+    assert got.status == 1 and want.status == 1
+    k = 8
+    assert np.array_equal(rows[:k, :2], wrows[:k, :2])
+    assert np.allclose(rows[:k, 2:4], wrows[:k, 2:4], rtol=1e-6, atol=1e-12)
+    assert np.max(np.abs(got.x - want.x)) <= 1e-4 * max(1.0, np.max(np.abs(want.x)))
+    assert abs(got.fun - want.fun) <= 1e-6 * max(1.0, abs(want.fun))
+    assert got.constr_violation <= 1e-8
+
+
 def test_product_never_imports_the_oracle():
     """Run a solve in a fresh interpreter: the product must not load oracle.*
     (no CPU fallback), and must have loaded the in-tree libipx.so."""
