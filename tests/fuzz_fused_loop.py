@@ -13,7 +13,7 @@ from ipsolver import device as dv, projector, qp, cg_fused
 from ipsolver.operators import DeviceHessian
 import oracle
 
-def run(cases, seed, verbose=True, only=None):
+def run(cases, seed, verbose=True, only=None, fixed=None):
     rng = np.random.default_rng(seed)
     worst, done = 0.0, 0
     for case in range(cases):
@@ -23,6 +23,8 @@ def run(cases, seed, verbose=True, only=None):
             shift = 2                   #  3.7e9 at m = 5000, the singular-Jacobian path on both sides)
         m = int(rng.choice([1, 2, 37, 259, 260, 261, 519, 520, 521, 1300, 5000, 26001, 60000]))
         tail = int(rng.integers(0, 40))
+        if fixed is not None:           # (a given shape instead of the drawn one: regression cases)
+            rl, shift, m, tail = fixed
         n = (m - 1) * shift + rl + tail
         n += n % 2
         if n - m < 3:
@@ -31,6 +33,13 @@ def run(cases, seed, verbose=True, only=None):
         cols = (np.arange(m)[:, None] * shift + np.arange(rl)[None, :]).ravel()
         Ah = sp.csr_matrix((rng.uniform(0.5, 1.5, m * rl) * rng.choice([-1.0, 1.0], m * rl), (rows, cols)),
                            shape=(m, n))
+        # one case in five: the rows in random order -- A A' is banded only after a row
+        # permutation, which the projector applies once (projector.projections) so that the
+        # loop still sees a banded matrix; b follows the rows
+        shuffled = bool(rng.random() < 0.2) and m > 2
+        if shuffled:
+            Ah = Ah[rng.permutation(m)]
+            Ah.sort_indices()
         off = rng.uniform(-0.4, 0.4, n - 1)
         Hh = sp.diags([off, rng.uniform(1.5, 2.5, n), off], [-1, 0, 1], format="csr")
         c = rng.standard_normal(n)
@@ -61,8 +70,8 @@ def run(cases, seed, verbose=True, only=None):
         (x1, i1, res1), (x2, i2, _), (x3, i3, _) = runs
         scale = max(np.max(np.abs(x2)), 1e-300)
         d12, d13 = np.max(np.abs(x1 - x2)) / scale, np.max(np.abs(x1 - x3)) / scale
-        line = "case %2d rl=%2d shift=%2d m=%6d n=%7d b%d radius=%-6g resident=%d  fused-vs-plain %.1e  vs-three-launch %.1e  %s" % (
-            case, rl, shift, m, n, int(np.any(b)), kw["trust_radius"], res1, d12, d13, i1)
+        line = "case %2d rl=%2d shift=%2d m=%6d n=%7d b%d%s radius=%-6g resident=%d  fused-vs-plain %.1e  vs-three-launch %.1e  %s" % (
+            case, rl, shift, m, n, int(np.any(b)), " shuffled" if shuffled else "", kw["trust_radius"], res1, d12, d13, i1)
         if n <= 30000:
             Zo, LSo, Yo = oracle.projections(Ah)
             xo, io = oracle.projected_cg(Hh, c, Zo, Yo, b, **kw)
