@@ -288,6 +288,11 @@ def minimize_constrained(fun, x0, grad, hess='2-point', constraints=(), method=N
     """
     options = dict(options)
     shard = _shard_request(options)
+    # (an ADDITIVE option, see below; popped before any dispatch so that it never reaches the
+    # outer loops' keyword arguments: device-callback mode keeps its Hessians on the device
+    # anyway, and a non-callable ``hess`` -- finite differences, quasi-Newton -- has no constant
+    # value to keep)
+    constant_hessian = bool(options.pop("constant_hessian", False))
     if _is_cuda_tensor(x0):
         if shard:
             raise NotImplementedError("row-sharded solve: host callbacks (numpy x0) only")
@@ -303,7 +308,7 @@ def minimize_constrained(fun, x0, grad, hess='2-point', constraints=(), method=N
         return np.atleast_1d(grad(x))
     grad_wrapped = _Memoize(plain_grad, x0, g0) if hess in FD_METHODS else plain_grad
 
-    if callable(hess) and options.pop("constant_hessian", False):
+    if callable(hess) and constant_hessian:
         # ADDITIVE option (the reference has none; its signature is unchanged): the objective's
         # Hessian does not depend on x -- a quadratic objective.  ``hess`` is called ONCE (the
         # reference calls it at every accepted step, _minimize_constrained.py:395-407; ``nhev``

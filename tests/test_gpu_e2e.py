@@ -342,6 +342,11 @@ def test_device_callbacks_banded_equality(method, e2e_golden):
     gold = e2e_golden["banded_eq_n2000_%s" % method]
     res.x = res.x.cpu().numpy()
     compare(res, rows, gold)
+    # the additive ``constant_hessian`` option is accepted (and has nothing to do) in
+    # device-callback mode instead of reaching the outer loop's keyword arguments
+    res2, rows2 = run(dc.fun, dc.x0, dc.grad, dc.hess, dc.constraints(ipsolver), method=method,
+                      options={"constant_hessian": True})
+    assert rows2 == rows
 
 
 @pytest.mark.parametrize("fd", ["2-point", "3-point"])

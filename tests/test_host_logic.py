@@ -165,6 +165,19 @@ def test_readme_example(e2e_golden):
     assert set(("s", "barrier_parameter", "tolerance")) <= set(res.keys())
 
 
+def test_constant_hessian_option_with_finite_difference_hessian():
+    """``options={'constant_hessian': True}`` with a ``hess`` that is not callable: the
+    option has nothing to keep and must not travel on into the outer loop's keyword arguments
+    (``TypeError: unexpected keyword 'constant_hessian'``)."""
+    p = problems.HyperbolicIneq()
+    with backend.use(npb):
+        res, _ = run(p.fun, p.x0, p.grad, "2-point", p.constraints(ipsolver),
+                     options={"constant_hessian": True})
+        ref, _ = run(p.fun, p.x0, p.grad, "2-point", p.constraints(ipsolver))
+    assert res.status == ref.status and res.niter == ref.niter
+    np.testing.assert_array_equal(res.x, ref.x)
+
+
 def test_maratos_sqp_method_names(e2e_golden):
     p = problems.Maratos()
     for name in ("equality_constrained_sqp", "equality-constrained-sqp"):
