@@ -6,8 +6,8 @@ One process per GPU (``torch.distributed``; backend "nccl" = RCCL over xGMI).
 Partition.  The constraint rows are cut into blocks of ``row_block`` rows (the rows one
 workgroup of the single-launch banded solve owns, csrc/banded.hip) and every rank gets a
 contiguous run of blocks together with the variables those rows bring in: rank g owns the
-rows ``[R0, R1)`` and the variables from the first column of row ``R0`` up to the first
-column of the next rank's first row -- BOTH spaces are partitioned, nothing is replicated.
+rows ``[R0, R1)`` and the variables whose FIRST constraint is one of them -- BOTH spaces are
+partitioned, nothing is replicated.
 Next to what it owns a rank keeps HALO copies: one block of rows on either side and the
 variables those rows touch.  Its local problem -- rows ``E = own + halo rows`` of the
 Jacobian (complete rows), the matching rows of ``A'`` and of the Hessian -- is an ordinary
@@ -75,7 +75,17 @@ class ShardLayout:
         self.m, self.n, self.world, self.rank = m, n, world, rank
         self.row_block, self.halo_rows = row_block, halo_blocks * row_block
         R = [min(m, ((r * nb) // world) * row_block) for r in range(world)] + [m]
-        C = [0] + [int(first[R[r]]) for r in range(1, world)] + [n]
+        # a variable goes with the FIRST constraint row that touches it (variables no row touches:
+        # with the next one that is touched) -- the ownership of the banded solve's fused tail
+        # and of the resident loop kernel (cg_fused.fuse_vown: a workgroup owns the variables
+        # whose first constraint lies in its rows), so a rank's own variables are exactly its own
+        # workgroups' and both kinds of partial sums cover the same entries.  Rows i and i + 1 of
+        # a banded Jacobian overlap, so this is a few columns to the right of "the first column of
+        # the rank's first row" (rounds 1-4).
+        starts = np.full(n + 1, m, dtype=np.int64)
+        np.minimum.at(starts, indices, np.repeat(np.arange(m, dtype=np.int64), np.diff(indptr)))
+        first_row = np.minimum.accumulate(starts[::-1])[::-1][:n]     # (non-decreasing)
+        C = [0] + [int(np.searchsorted(first_row, R[r], side="left")) for r in range(1, world)] + [n]
         self.row_cuts, self.col_cuts = R, C
         self.ranks = []
         for r in range(world):
