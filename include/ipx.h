@@ -305,6 +305,11 @@ typedef struct ipx_cg_args {
 } ipx_cg_args;
 int ipx_cg_resident_ok(const ipx_cg_args *a);
 int64_t ipx_cg_resident_ll_words(int32_t nwg, int32_t hw);
+/* the kernel's budgets for the host code that builds its tables: workgroups per launch, threads,
+ * span columns / own variables / window rows per workgroup, entries per row of A / of H, halo
+ * entries; and the workgroups of all ranks of a sharded launch together */
+void ipx_cg_resident_limits(int32_t *out8);
+int32_t ipx_cg_resident_max_global(void);
 int ipx_cg_state_size(void);
 int ipx_cg_vec_grid(int64_t n);
 /* Hp = H p (+ diag*p) with p'Hp partials: primes the loop. */
@@ -408,6 +413,12 @@ typedef struct ipx_shard2_ext {
    * returned 1 on EVERY rank (the two forms order an iteration's collectives differently);
    * a rank whose own argument block does not allow it gets IPX_EINVAL. */
   int64_t fuse_comm;
+  /* RESIDENT form of the sharded loop (csrc/resident.hip, PEER; ipx_cg_shard2_resident): this
+   * rank's own blocks [res_wg0, res_wg0 + res_nwg) of its local banded solve are the global
+   * workgroups res_gwg0 .. of res_gnwg (all ranks' own blocks in rank order).  Needs the
+   * resident tables of the argument block and ipx_peer_attach_resident on e->peer; the GROUP's
+   * decision, like fuse_comm. */
+  int64_t res_wg0, res_nwg, res_gwg0, res_gnwg;
 } ipx_shard2_ext;
 /* 1 when this rank's argument block allows fuse_comm (peer set, the fused 16-bit-index kernels
  * and g = r - A'v as the solve's tail for x-space problems, or the box-Schur projection). */
@@ -418,6 +429,17 @@ int ipx_cg_shard2_segment(const ipx_cg_args *a, const ipx_shard2_ext *e, int32_t
  * call per batch, nothing between the iterations on the host. */
 int ipx_cg_shard2_iterate(const ipx_cg_args *a, const ipx_shard2_ext *e, int32_t it_begin,
                           int32_t it_end, void *stream);
+/* The same batch as ONE resident launch per rank (reference loop: qp_subproblem.py:549-634; the
+ * workgroups of all ranks hand their scalars and halos to each other directly, two hops per
+ * iteration).  Writes a rank's OWN entries of x, p, r, Hp only: before the host uses the local
+ * vectors (an event, the end of the loop, a batch on the separate launches) it synchronises
+ * their halos and calls ipx_cg_save_pb.  A wait that times out records stop code 7. */
+int ipx_cg_shard2_resident_ok(const ipx_cg_args *a, const ipx_shard2_ext *e);
+int ipx_cg_shard2_resident(const ipx_cg_args *a, const ipx_shard2_ext *e, int32_t it_begin,
+                           int32_t it_end, void *stream);
+/* p at the row-tile boundaries of H for the fused step2 + H.p kernel, from a->p (after p
+ * changed behind the loop's back: a halo synchronisation). */
+int ipx_cg_save_pb(const ipx_cg_args *a, void *stream);
 
 /* ---- peer mailboxes (csrc/peer.hip): the transport of the sharded loop's two all-reduces
  * (torch.distributed all_reduce in round 2; qp_subproblem.py:556,583,626 are the reduction
@@ -439,6 +461,15 @@ void ipx_peer_destroy(void *peer);
 /* `reps` all-reduces (sum) of nq <= 8 doubles back to back: the mailbox path's latency probe. */
 int ipx_peer_allreduce(void *peer, int32_t nq, const double *in, double *out, int *failed,
                        int32_t reps, void *stream);
+/* Hand-off buffers of the resident loop kernel between the ranks: attach (allocates `words`
+ * 8-byte words -- ipx_cg_resident_ll_words of the largest launch of the group -- uncached,
+ * zeroed) -> export_resident -> hand the blobs around -> import_resident every other rank's
+ * -> resident_ready (builds the device-side pointer table; 1 when complete). */
+int ipx_peer_attach_resident(void *peer, int64_t words);
+int ipx_peer_export_resident(void *peer, void *handle_out);
+int ipx_peer_import_resident(void *peer, int32_t rank, const void *handle_in);
+int ipx_peer_resident_ready(void *peer);
+int64_t ipx_peer_resident_launches(void *peer);
 int ipx_cg_shard2_fold_hp(const ipx_cg_args *a, const ipx_shard2_ext *e, void *stream);
 /* The fused step2 + H.p launch alone (needs pb / H_hmax in the argument block). */
 int ipx_cg_step2_hp(const ipx_cg_args *a, int32_t it, int32_t mode, void *stream);

@@ -1589,6 +1589,25 @@ int ipx_cg_shard2_iterate(const ipx_cg_args *a, const ipx_shard2_ext *e, int32_t
   return IPX_OK;
 }
 
+// The batch as one resident launch per rank (csrc/resident.hip, PEER form).
+int ipx_cg_shard2_resident(const ipx_cg_args *a, const ipx_shard2_ext *e, int32_t it_begin,
+                           int32_t it_end, void *stream) {
+  if (!a || !e) return IPX_EINVAL;
+  return ipx_cg_shard2_resident_launch(a, e, it_begin, it_end, part1_count(a), (hipStream_t)stream);
+}
+
+// p at the row-tile boundaries of H (the fused step2 + H.p kernel reads its neighbours' OLD p
+// there) from the current a->p
+int ipx_cg_save_pb(const ipx_cg_args *a, void *stream) {
+  if (!a) return IPX_EINVAL;
+  if (!fused_hp(a)) return IPX_OK;
+  const int tot = (int)(a->H_ntiles * 2 * a->H_hmax);
+  hipLaunchKernelGGL(k_cg_save_pb, dim3((tot + IPX_BLOCK - 1) / IPX_BLOCK), dim3(IPX_BLOCK), 0,
+                     (hipStream_t)stream, a->p, a->H_tiles, (int)a->H_ntiles, (int)a->H_hmax, a->pb);
+  IPX_CHECK_LAUNCH();
+  return IPX_OK;
+}
+
 // 1 when THIS rank's argument block allows the collectives in the prologues of the loop's own
 // kernels (3 launches per iteration; peer_fusable: the tables are functions of the rank's
 // slice of A and H).  The ranks must agree before anyone sets e->fuse_comm: the caller

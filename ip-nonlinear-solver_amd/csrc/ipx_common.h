@@ -355,6 +355,15 @@ struct ipx_peer {
   void *opened[IPX_MAX_PEERS];                 // hipIpcOpenMemHandle results (to close)
   int64_t bytes;
   int64_t fused;                               // launches that did their collective in a prologue
+  // hand-off buffers of the resident loop kernel's PEER form (csrc/resident.hip;
+  // ipx_peer_attach_resident): every rank's buffer as mapped here, the same table in device
+  // memory, the tag counter (identical on every rank: same launches, same batches)
+  unsigned long long *res[IPX_MAX_PEERS];
+  void *res_opened[IPX_MAX_PEERS];
+  unsigned long long **res_tab;
+  int64_t res_words;
+  uint32_t rseq;
+  int64_t res_launches;
 };
 #ifdef __HIPCC__
 __device__ __forceinline__ int64_t ipx_peer_scal_word(int slot, int rank, int q) {
@@ -585,6 +594,8 @@ struct ipx_pcr_view {
 int ipx_banded_pcr_view(void *handle, ipx_pcr_view *out);
 int ipx_cg_resident_launch(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, int np1, int np2,
                            int np3, int np4, hipStream_t st);
+int ipx_cg_shard2_resident_launch(const ipx_cg_args *a, const ipx_shard2_ext *e, int32_t it_begin,
+                                  int32_t it_end, int np1, hipStream_t st);
 
 // ---- internal (non-ABI) launchers shared between translation units --------
 struct ipx_csr_view {

@@ -138,9 +138,81 @@ int ipx_peer_sequence(void *peer, int64_t *out2) {
 // of csrc/cg.hip: ipx_shard2_ext.fuse_comm)
 int64_t ipx_peer_fused_launches(void *peer) { return peer ? ((ipx_peer *)peer)->fused : 0; }
 
+// ---- hand-off buffers of the resident loop kernel's PEER form (csrc/resident.hip)
+int ipx_peer_attach_resident(void *peer, int64_t words) {
+  if (!peer || words < 1) return IPX_EINVAL;
+  ipx_peer *p = (ipx_peer *)peer;
+  if (p->res[p->view.rank]) return IPX_EINVAL;
+  void *mem = nullptr;
+  hipError_t e = hipExtMallocWithFlags(&mem, (size_t)words * 8, hipDeviceMallocUncached);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    e = hipExtMallocWithFlags(&mem, (size_t)words * 8, hipDeviceMallocFinegrained);
+  }
+  if (e != hipSuccess) { ipx_note_error(e, __FILE__, __LINE__); return IPX_ENOMEM; }
+  if (hipMemset(mem, 0, (size_t)words * 8) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+    (void)hipFree(mem);
+    return IPX_ELAUNCH;
+  }
+  p->res[p->view.rank] = (unsigned long long *)mem;
+  p->res_words = words;
+  p->rseq = 1;
+  return IPX_OK;
+}
+
+int ipx_peer_export_resident(void *peer, void *handle_out) {
+  if (!peer || !handle_out) return IPX_EINVAL;
+  ipx_peer *p = (ipx_peer *)peer;
+  if (!p->res[p->view.rank]) return IPX_EINVAL;
+  hipIpcMemHandle_t h;
+  hipError_t e = hipIpcGetMemHandle(&h, p->res[p->view.rank]);
+  if (e != hipSuccess) { ipx_note_error(e, __FILE__, __LINE__); return IPX_ELAUNCH; }
+  memcpy(handle_out, &h, sizeof(h));
+  return IPX_OK;
+}
+
+int ipx_peer_import_resident(void *peer, int32_t rank, const void *handle_in) {
+  if (!peer || !handle_in) return IPX_EINVAL;
+  ipx_peer *p = (ipx_peer *)peer;
+  if (rank < 0 || rank >= p->view.world || rank == p->view.rank || p->res[rank]) return IPX_EINVAL;
+  hipIpcMemHandle_t h;
+  memcpy(&h, handle_in, sizeof(h));
+  void *mem = nullptr;
+  hipError_t e = hipIpcOpenMemHandle(&mem, h, hipIpcMemLazyEnablePeerAccess);
+  if (e != hipSuccess) { ipx_note_error(e, __FILE__, __LINE__); return IPX_ELAUNCH; }
+  p->res_opened[rank] = mem;
+  p->res[rank] = (unsigned long long *)mem;
+  return IPX_OK;
+}
+
+// builds the device-side table of the buffers; 1 when every rank's is mapped
+int ipx_peer_resident_ready(void *peer) {
+  if (!peer) return 0;
+  ipx_peer *p = (ipx_peer *)peer;
+  for (int r = 0; r < p->view.world; ++r)
+    if (!p->res[r]) return 0;
+  if (!p->res_tab) {
+    void *tab = nullptr;
+    if (hipMalloc(&tab, sizeof(unsigned long long *) * IPX_MAX_PEERS) != hipSuccess) return 0;
+    if (hipMemcpy(tab, p->res, sizeof(unsigned long long *) * IPX_MAX_PEERS, hipMemcpyHostToDevice) !=
+        hipSuccess) {
+      (void)hipFree(tab);
+      return 0;
+    }
+    p->res_tab = (unsigned long long **)tab;
+  }
+  return 1;
+}
+
+int64_t ipx_peer_resident_launches(void *peer) { return peer ? ((ipx_peer *)peer)->res_launches : 0; }
+
 void ipx_peer_destroy(void *peer) {
   if (!peer) return;
   ipx_peer *p = (ipx_peer *)peer;
+  for (int r = 0; r < p->view.world; ++r)
+    if (p->res_opened[r]) (void)hipIpcCloseMemHandle(p->res_opened[r]);
+  if (p->res[p->view.rank]) (void)hipFree(p->res[p->view.rank]);
+  if (p->res_tab) (void)hipFree(p->res_tab);
   for (int r = 0; r < p->view.world; ++r)
     if (p->opened[r]) (void)hipIpcCloseMemHandle(p->opened[r]);
   if (p->view.mbox[p->view.rank]) (void)hipFree(p->view.mbox[p->view.rank]);

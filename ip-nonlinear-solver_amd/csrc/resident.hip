@@ -38,6 +38,27 @@
 // stores": a workgroup has one or two waves per SIMD and nothing else hides an LDS round trip
 // (the first version, one dependent LDS access after the other, took 27 us per iteration).
 //
+// Hand-off buffer.  Scalar records live in TWO arrays used in turn (hop h: array h & 1): a
+// workgroup can only publish hop h + 2 after every workgroup has published hop h + 1, i.e. has
+// passed hop h -- so no word is overwritten while somebody still polls it, whatever the kind of
+// the hops (round 4 alternated by KIND; the commit hop of a launch that stops at the top of an
+// iteration then reused the words of the hop before it: ADVICE r4).  Halos: one slot of six
+// areas per workgroup (Hp / g / p to the left / right neighbour), plus two slots for what the
+// neighbour RANKS write (below).
+//
+// PEER form (the row-sharded loop, ipsolver/sharded.py; one process per GPU): the chain of
+// workgroups simply continues across the ranks.  A rank launches one workgroup per OWN block of
+// its extended local problem (tables indexed by the local block: J.wg0 + blockIdx.x); the scalar
+// records are indexed by the GLOBAL workgroup and every workgroup stores its record into every
+// rank's buffer (hipIpc-mapped, uncached; system-scope stores over xGMI) and polls its own
+// rank's: one flat all-to-all per hop, folded in the same lane order on every rank -- the same
+// bits as one GPU running all the workgroups.  The first / last workgroup of a rank exchange
+// their halos with the neighbour rank's last / first through the two extra slots of the
+// buffers.  A launch starts with a hop 0: the all-reduce of the p'Hp partials the previous
+// launch (of any form) left on each rank, and the edge workgroups' halos of r, Hp and p (the
+// local arrays' halo entries are not maintained by this kernel: the host synchronises them
+// when it leaves the loop).  Budget: all workgroups of all ranks <= 512 (one record per lane).
+//
 // Arithmetic: element by element the expressions of k_cg_step1_ar / k_solve_pcr /
 // k_cg_step2_hp, row sums left to right; the sums differ in their order: ||g||^2 and the
 // residual are summed per workgroup by 256 lanes (the order k_solve_pcr had while it ran 256
@@ -72,9 +93,11 @@ constexpr int RQX = 6;        // own variables per lane  (<= 3072)
 constexpr int RLH = 4;        // entries per row of H held in registers
 constexpr int RHK = 4;        // halo entries per lane and hop (2 * hw <= RHK * RB)
 constexpr int RQP = 3;        // pairs of own variables per lane
-constexpr int R_MAXWG = 256;
-constexpr int R_S2 = 2 * R_MAXWG;                  // word offset of the S2 records (8 words each)
-constexpr int R_HALO = R_S2 + 8 * R_MAXWG;         // word offset of the halo areas
+constexpr int R_MAXG = 512;                        // scalar records per array (one per lane)
+constexpr int R_REC = 8;                           // words per record: 4 granules, 3 used
+constexpr int R_HALO = 2 * R_REC * R_MAXG;         // word offset of the halo slots
+constexpr int R_AREAS = 6;                         // per slot: Hp, g, p to the left (even) / right (odd)
+constexpr int R_MAXLOCAL = 224;                    // workgroups of one launch (all co-resident)
 
 struct ResJob {
   double *st;
@@ -93,13 +116,25 @@ struct ResJob {
   const double *H_val, *H_diag;
   int hmax;
   double *part1, *part2, *part3, *part4;
-  int np1, np2, np3, np4;
+  int p1_off, p1_cnt;           // the p'Hp partials this launch folds / leaves: part1[p1_off ..+p1_cnt)
+  int np2, np3, np4;
   ull *ll;
   int hw;
   uint32_t seq;
   int no_xn2;
   long long timeout;
+  int stop_code;                // what a timed-out wait records: 8 (one GPU), 7 (PEER)
+  // PEER form: nwg workgroups are launched for the local blocks wg0 .. wg0 + nwg - 1; they are
+  // the global workgroups gwg0 .. of gnwg; pll[r] = rank r's buffer as mapped here (own: ll)
+  int wg0, gwg0, gnwg, rank, world;
+  ull *const *pll;
+  double *pack_out;             // 4 doubles: the sums of the last projection for the host's resume
 };
+
+__device__ __forceinline__ ull *res_records(ull *base, uint32_t hop) { return base + (hop & 1) * (R_REC * R_MAXG); }
+__device__ __forceinline__ ull *res_area(ull *base, int slot, int area, int hw) {
+  return base + R_HALO + ((int64_t)(slot * R_AREAS + area) * hw) * 2;
+}
 
 // The packed index registers are unpacked INSIDE the loop: without this the compiler hoists
 // every unpacked LDS address out of it (loop invariant!) and holds ~100 more registers across
@@ -114,14 +149,19 @@ __device__ __forceinline__ double res_rcp(double b) {        // (csrc/banded.hip
 }
 // One granule = the two tagged words of a double, written by ONE 16-byte write-through store
 // (8-byte sc1 stores are one fabric write each and cost 2.7x per byte: MI355X_MICROARCH.md,
-// stores table; every 8-byte half validates itself, so tearing between the halves is harmless)
+// stores table; every 8-byte half validates itself, so tearing between the halves is harmless).
+// SYS: system scope (sc0 sc1) -- the destination may be another GPU's memory.
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+template <bool SYS>
 __device__ __forceinline__ void ll_put(ull *dst, double v, uint32_t tag) {
   const ull bits = (ull)__double_as_longlong(v);
   u4 w;
   w.x = (unsigned)(bits & 0xffffffffull); w.y = tag;
   w.z = (unsigned)(bits >> 32);           w.w = tag;
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(w) : "memory");
+  if constexpr (SYS)
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(w) : "memory");
+  else
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(w) : "memory");
 }
 __device__ __forceinline__ bool ll_hit(const u4 &w, uint32_t tag, double &v) {
   if (w.y == tag && w.w == tag) {
@@ -130,8 +170,23 @@ __device__ __forceinline__ bool ll_hit(const u4 &w, uint32_t tag, double &v) {
   }
   return false;
 }
-__device__ __forceinline__ ull *halo_area(const ResJob &J, int wg, int area) {
-  return J.ll + R_HALO + ((int64_t)(wg * 4 + area) * J.hw) * 2;
+// where workgroup `wg` of this launch publishes area `area` (even: for its left neighbour, odd:
+// for its right one): its own slot -- or, at a rank's edge, the neighbour rank's slot 1 / 0
+template <bool PEER>
+__device__ __forceinline__ ull *halo_dst(const ResJob &J, int wg, int area) {
+  if constexpr (PEER) {
+    if (!(area & 1) && wg == 0 && J.rank > 0) return res_area(J.pll[J.rank - 1], 1, area, J.hw);
+    if ((area & 1) && wg == J.nwg - 1 && J.rank < J.world - 1)
+      return res_area(J.pll[J.rank + 1], 0, area, J.hw);
+  }
+  return res_area(J.ll, wg + 2, area, J.hw);
+}
+// where it finds what its left / right neighbour published for it (area: the neighbour's)
+__device__ __forceinline__ const ull *halo_from_left(const ResJob &J, int wg, int area) {
+  return res_area(J.ll, wg == 0 ? 0 : wg + 1, area, J.hw);
+}
+__device__ __forceinline__ const ull *halo_from_right(const ResJob &J, int wg, int area) {
+  return res_area(J.ll, wg == J.nwg - 1 ? 1 : wg + 3, area, J.hw);
 }
 // ipx_block_sum_multi with the wave count a compile-time constant: the partner sums of ALL
 // quantities are requested from LDS together and added in wave order.  (The library routine
@@ -163,29 +218,51 @@ __device__ __forceinline__ void res_block_sum(double (&v)[NQ], double *lds, doub
   ipx_lds_barrier();
 }
 
-// One hop: NS scalars per workgroup (lane t < nwg waits for workgroup t's record) and this
-// workgroup's left / right halo (nl + nr entries, from the neighbours' areas) into LDS at
+// One hop: NS scalars per workgroup (lane t < nrec waits for record t of `scal`) and this
+// workgroup's left / right halo (nl + nr entries, from the areas `left` / `right`) into LDS at
 // dst_l / dst_r.  Every word of the lane is requested in ONE burst per pass (unconditional
 // loads, no branch between them), then the tags are checked.  false: a wait timed out.
-template <int NS>
-__device__ __forceinline__ bool hop_wait(const ResJob &J, int wg, uint32_t tag, const ull *scal,
-                                         int scal_stride, double (&sv)[NS], int nl, int nr,
-                                         int area_from_left, int area_from_right,
-                                         double *dst_l, double *dst_r, bool want_halo) {
+#define RES_BURST7(SC)                                                                           \
+  asm volatile("global_load_dwordx4 %0, %7, off " SC "\n\t"                                      \
+               "global_load_dwordx4 %1, %8, off " SC "\n\t"                                      \
+               "global_load_dwordx4 %2, %9, off " SC "\n\t"                                      \
+               "global_load_dwordx4 %3, %10, off " SC "\n\t"                                     \
+               "global_load_dwordx4 %4, %11, off " SC "\n\t"                                     \
+               "global_load_dwordx4 %5, %12, off " SC "\n\t"                                     \
+               "global_load_dwordx4 %6, %13, off " SC "\n\t"                                     \
+               "s_waitcnt vmcnt(0)"                                                              \
+               : "=&v"(sw[0]), "=&v"(sw[1]), "=&v"(sw[2]), "=&v"(hw0), "=&v"(hw1), "=&v"(hw2),   \
+                 "=&v"(hw3)                                                                      \
+               : "v"(ssrc[0]), "v"(ssrc[1]), "v"(ssrc[2]), "v"(hsrc[0]), "v"(hsrc[1]),           \
+                 "v"(hsrc[2]), "v"(hsrc[3])                                                      \
+               : "memory")
+#define RES_BURST5(SC)                                                                           \
+  asm volatile("global_load_dwordx4 %0, %5, off " SC "\n\t"                                      \
+               "global_load_dwordx4 %1, %6, off " SC "\n\t"                                      \
+               "global_load_dwordx4 %2, %7, off " SC "\n\t"                                      \
+               "global_load_dwordx4 %3, %8, off " SC "\n\t"                                      \
+               "global_load_dwordx4 %4, %9, off " SC "\n\t"                                      \
+               "s_waitcnt vmcnt(0)"                                                              \
+               : "=&v"(sw[0]), "=&v"(hw0), "=&v"(hw1), "=&v"(hw2), "=&v"(hw3)                    \
+               : "v"(ssrc[0]), "v"(hsrc[0]), "v"(hsrc[1]), "v"(hsrc[2]), "v"(hsrc[3])            \
+               : "memory")
+template <int NS, bool SYS>
+__device__ __forceinline__ bool hop_wait(const ResJob &J, uint32_t tag, const ull *scal, int nrec,
+                                         double (&sv)[NS], const ull *left, const ull *right,
+                                         int nl, int nr, double *dst_l, double *dst_r,
+                                         long long timeout) {
   const int tid = threadIdx.x;
-  const long long deadline = (long long)wall_clock64() + J.timeout;
+  const long long deadline = (long long)wall_clock64() + timeout;
   bool sdone[NS];
-  const bool slane = tid < J.nwg;
+  const bool slane = tid < nrec;
 #pragma unroll
   for (int q = 0; q < NS; ++q) { sdone[q] = !slane; sv[q] = 0.0; }
   bool hdone[RHK];
   double hv[RHK];
   const ull *hsrc[RHK], *ssrc[NS];
-  const int nh = want_halo ? nl + nr : 0;
-  const ull *left = wg > 0 ? halo_area(J, wg - 1, area_from_left) : J.ll;
-  const ull *right = wg < J.nwg - 1 ? halo_area(J, wg + 1, area_from_right) : J.ll;
+  const int nh = nl + nr;
 #pragma unroll
-  for (int q = 0; q < NS; ++q) ssrc[q] = scal + (int64_t)(slane ? tid : 0) * scal_stride + 2 * q;
+  for (int q = 0; q < NS; ++q) ssrc[q] = scal + (int64_t)(slane ? tid : 0) * R_REC + 2 * q;
 #pragma unroll
   for (int k = 0; k < RHK; ++k) {
     const int e = tid + k * RB;
@@ -195,32 +272,15 @@ __device__ __forceinline__ bool hop_wait(const ResJob &J, int wg, uint32_t tag, 
   }
   static_assert(RHK == 4, "the load burst below is written for four halo granules per lane");
   while (true) {
-    // one burst of 16-byte L2 loads (sc1: never served from this CU's L1), one wait
-    // (ONE asm statement: a result must not be touched before the wait at its end)
+    // one burst of 16-byte loads (sc1: never served from this CU's L1; sc0 sc1: nor from an L2
+    // line a peer's store went past), one wait (ONE asm statement: a result must not be touched
+    // before the wait at its end)
     u4 sw[3], hw0, hw1, hw2, hw3;
     static_assert(NS == 1 || NS == 3, "hop_wait: one or three scalars per workgroup");
     if constexpr (NS == 3) {
-      asm volatile("global_load_dwordx4 %0, %7, off sc1\n\t"
-                   "global_load_dwordx4 %1, %8, off sc1\n\t"
-                   "global_load_dwordx4 %2, %9, off sc1\n\t"
-                   "global_load_dwordx4 %3, %10, off sc1\n\t"
-                   "global_load_dwordx4 %4, %11, off sc1\n\t"
-                   "global_load_dwordx4 %5, %12, off sc1\n\t"
-                   "global_load_dwordx4 %6, %13, off sc1\n\t"
-                   "s_waitcnt vmcnt(0)"
-                   : "=&v"(sw[0]), "=&v"(sw[1]), "=&v"(sw[2]), "=&v"(hw0), "=&v"(hw1), "=&v"(hw2), "=&v"(hw3)
-                   : "v"(ssrc[0]), "v"(ssrc[1]), "v"(ssrc[2]), "v"(hsrc[0]), "v"(hsrc[1]), "v"(hsrc[2]), "v"(hsrc[3])
-                   : "memory");
+      if constexpr (SYS) RES_BURST7("sc0 sc1"); else RES_BURST7("sc1");
     } else {
-      asm volatile("global_load_dwordx4 %0, %5, off sc1\n\t"
-                   "global_load_dwordx4 %1, %6, off sc1\n\t"
-                   "global_load_dwordx4 %2, %7, off sc1\n\t"
-                   "global_load_dwordx4 %3, %8, off sc1\n\t"
-                   "global_load_dwordx4 %4, %9, off sc1\n\t"
-                   "s_waitcnt vmcnt(0)"
-                   : "=&v"(sw[0]), "=&v"(hw0), "=&v"(hw1), "=&v"(hw2), "=&v"(hw3)
-                   : "v"(ssrc[0]), "v"(hsrc[0]), "v"(hsrc[1]), "v"(hsrc[2]), "v"(hsrc[3])
-                   : "memory");
+      if constexpr (SYS) RES_BURST5("sc0 sc1"); else RES_BURST5("sc1");
     }
     bool all = true;
 #pragma unroll
@@ -252,25 +312,54 @@ __device__ __forceinline__ bool hop_wait(const ResJob &J, int wg, uint32_t tag, 
   return true;
 }
 
+// this workgroup's record of a hop: NS doubles into the record array of every rank (PEER) /
+// of this GPU
+template <int NS, bool PEER>
+__device__ __forceinline__ void rec_put(const ResJob &J, uint32_t hop, int gw, const double (&v)[NS],
+                                        uint32_t tag) {
+  const int tid = threadIdx.x;
+  if constexpr (PEER) {
+    if (tid < NS * J.world) {
+      const int r = tid / NS, q = tid - r * NS;
+      double val = v[0];
+#pragma unroll
+      for (int k = 1; k < NS; ++k) val = q == k ? v[k] : val;
+      ll_put<true>(res_records(J.pll[r], hop) + (int64_t)R_REC * gw + 2 * q, val, tag);
+    }
+  } else {
+    if (tid < NS) {
+      double val = v[0];
+#pragma unroll
+      for (int k = 1; k < NS; ++k) val = tid == k ? v[k] : val;
+      ll_put<false>(res_records(J.ll, hop) + (int64_t)R_REC * gw + 2 * tid, val, tag);
+    }
+  }
+}
+
 // publish `cnt` doubles of LDS (src[0..cnt), cnt <= RHK/2 * RB) into one of this workgroup's areas
+template <bool PEER>
 __device__ __forceinline__ void halo_put(const ResJob &J, int wg, int area, const double *src,
                                          int cnt, uint32_t tag) {
-  ull *dst = halo_area(J, wg, area);
+  ull *dst = halo_dst<PEER>(J, wg, area);
   double v[RHK / 2];
 #pragma unroll
   for (int k = 0; k < RHK / 2; ++k) v[k] = src[min((int)threadIdx.x + k * RB, max(cnt - 1, 0))];
 #pragma unroll
   for (int k = 0; k < RHK / 2; ++k) {
     const int j = threadIdx.x + k * RB;
-    if (j < cnt) ll_put(dst + 2 * j, v[k], tag);
+    if (j < cnt) ll_put<PEER>(dst + 2 * j, v[k], tag);
   }
 }
 
-template <bool NOXN2, bool HAS_DIAG>
+template <bool NOXN2, bool HAS_DIAG, bool PEER>
 __global__ void __launch_bounds__(RB, 2)
 k_cg_resident(ResJob J) {
   extern __shared__ __attribute__((aligned(16))) double rs_lds[];
   const int wg = blockIdx.x, tid = threadIdx.x;
+  const int wgl = wg + J.wg0;                       // block of the (local) solve: the tables' index
+  const int gw = wg + J.gwg0;                       // global workgroup: the scalar records' index
+  const bool has_left = wg > 0 || (PEER && J.rank > 0);
+  const bool has_right = wg < J.nwg - 1 || (PEER && J.rank < J.world - 1);
   const int H = 1 << J.L;
   const int R = J.rows_wg + 2 * H;
   const int RS = R + 2 * H;                         // PCR rows incl. identity padding
@@ -289,14 +378,14 @@ k_cg_resident(ResJob J) {
          *pd1 = U + 5 * RS;
 
   // ---- geometry
-  const int c_lo = J.win[2 * wg], c_hi = J.win[2 * wg + 1];
+  const int c_lo = J.win[2 * wgl], c_hi = J.win[2 * wgl + 1];
   const int nspan = c_hi - c_lo;
-  const int av0 = J.vown[wg], av1 = J.vown[wg + 1], avn = av1 - av0;
+  const int av0 = J.vown[wgl], av1 = J.vown[wgl + 1], avn = av1 - av0;
   const int nl = av0 - c_lo, nr = c_hi - av1;       // halo columns left / right of the own ones
-  const int pl = wg > 0 ? J.win[2 * (wg - 1) + 1] - av0 : 0;              // own entries the left /
-  const int pr = wg < J.nwg - 1 ? av1 - J.win[2 * (wg + 1)] : 0;          // right neighbour reads
+  const int pl = has_left ? J.win[2 * (wgl - 1) + 1] - av0 : 0;           // own entries the left /
+  const int pr = has_right ? av1 - J.win[2 * (wgl + 1)] : 0;              // right neighbour reads
   const int own_off = av0 - c_lo;                   // span index of the first own variable
-  const int64_t g0 = (int64_t)wg * J.rows_wg - H;   // global row of window row 0
+  const int64_t g0 = (int64_t)wgl * J.rows_wg - H;  // (local) row of window row 0
   const int rl = J.rl;
   const int p_lo = av0 - J.hmax;                    // column of pspan[0]
 
@@ -304,8 +393,8 @@ k_cg_resident(ResJob J) {
   const double stop0 = J.st[ST_STOP];
   double rt[2] = {J.st[ST_RTG0], J.st[ST_RTG1]};
   const double tol = J.st[ST_TOL], radius = J.st[ST_RADIUS], orth_rhs = J.st[ST_ORTH_RHS];
-  const double *const fparts[1] = {J.part1 + J.np1};
-  const int fcounts[1] = {J.np1};
+  const double *const fparts[1] = {J.part1 + J.p1_off};
+  const int fcounts[1] = {J.p1_cnt};
   ipx_fold_regs<1, 4> fold;
   fold.load(fparts, fcounts);
 
@@ -425,7 +514,43 @@ k_cg_resident(ResJob J) {
   uint32_t hop = 0;                                 // hops so far: tag = J.seq + hop
   double part_xn2 = 0.0, part_gg = 0.0, part_tt = 0.0;   // totals of the last projection
   bool have_proj = false;
-  ull *S1 = J.ll, *S2 = J.ll + R_S2;
+  if constexpr (PEER) {
+    // ---- hop 0: p'Hp over the ranks (workgroup 0 of a rank speaks for its partials) and, at a
+    // rank's edges, the neighbour rank's entries of r, Hp and p
+    const uint32_t tag = J.seq;
+    const bool le = wg == 0 && J.rank > 0, re = wg == J.nwg - 1 && J.rank < J.world - 1;
+    ipx_lds_barrier();                              // (the vectors are in LDS)
+    if (le) {
+      halo_put<PEER>(J, wg, 2, rspan + own_off, pl, tag);
+      halo_put<PEER>(J, wg, 0, hspan + own_off, pl, tag);
+      halo_put<PEER>(J, wg, 4, pspan + J.hmax, J.hmax, tag);
+    }
+    if (re) {
+      halo_put<PEER>(J, wg, 3, rspan + own_off + avn - pr, pr, tag);
+      halo_put<PEER>(J, wg, 1, hspan + own_off + avn - pr, pr, tag);
+      halo_put<PEER>(J, wg, 5, pspan + avn, J.hmax, tag);
+    }
+    const double mine0[1] = {wg == 0 ? ptHp : 0.0};
+    rec_put<1, PEER>(J, hop, gw, mine0, tag);
+    double s1[1], dum[1];
+    bool ok = hop_wait<1, PEER>(J, tag, res_records(J.ll, hop), J.gnwg, s1,
+                                halo_from_left(J, wg, 3), halo_from_right(J, wg, 2),
+                                le ? nl : 0, re ? nr : 0, rspan, rspan + own_off + avn, J.timeout);
+    if (le || re) {
+      ok = hop_wait<1, PEER>(J, tag, J.ll, 0, dum, halo_from_left(J, wg, 1), halo_from_right(J, wg, 0),
+                             le ? nl : 0, re ? nr : 0, hspan, hspan + own_off + avn, J.timeout) && ok;
+      ok = hop_wait<1, PEER>(J, tag, J.ll, 0, dum, halo_from_left(J, wg, 5), halo_from_right(J, wg, 4),
+                             le ? J.hmax : 0, re ? J.hmax : 0, pspan, pspan + J.hmax + avn,
+                             J.timeout) && ok;
+    }
+    double sv[2] = {s1[0], ok ? 0.0 : 1.0}, tot[2];
+    res_block_sum<2>(sv, red, tot);                 // (barriers inside: the halos are in LDS)
+    if (tot[1] != 0.0) {
+      if (tid == 0) { J.st[ST_VIOL] = 80.0; J.st[ST_STOP] = (double)J.stop_code; }
+      return;
+    }
+    ptHp = tot[0];
+  }
 
   const int tid0 = tid;
   for (int it = J.it_begin; it < J.it_end; ++it) {
@@ -587,8 +712,8 @@ k_cg_resident(ResJob J) {
     // the halo of g leaves as soon as g is complete (the scalars follow after the sums below:
     // the transfer overlaps them); hop 2's tag
     ipx_lds_barrier();
-    halo_put(J, wg, 2, rspan + own_off, pl, J.seq + hop + 1);                 // to the left neighbour
-    halo_put(J, wg, 3, rspan + own_off + avn - pr, pr, J.seq + hop + 1);      // to the right neighbour
+    halo_put<PEER>(J, wg, 2, rspan + own_off, pl, J.seq + hop + 1);                 // to the left neighbour
+    halo_put<PEER>(J, wg, 3, rspan + own_off + avn - pr, pr, J.seq + hop + 1);      // to the right neighbour
     // residual of the own rows:  w_i - (a_i v_{i-1} + b_i v_i + a_{i+1} v_{i+1}), squared; summed
     // like ||g||^2 in the order of the 256-lane k_solve_pcr (its lane t: row t, then row t + 256)
     double *rsq = U + navnE;                          // (behind gsq: navnE + RB doubles of U)
@@ -646,18 +771,23 @@ k_cg_resident(ResJob J) {
     ++hop;
     {
       const uint32_t tag = J.seq + hop;
-      if (tid < 3) ll_put(S2 + 8 * wg + 2 * tid, tid == 0 ? mine3[0] : (tid == 1 ? mine3[1] : mine3[2]), tag);
+      rec_put<3, PEER>(J, hop, gw, mine3, tag);
       double sv[4];
       {
         double s3[3];
-        const bool ok = hop_wait<3>(J, wg, tag, S2, 8, s3, nl, nr, 3, 2, rspan, rspan + own_off + avn, true);
+        const bool ok = hop_wait<3, PEER>(J, tag, res_records(J.ll, hop), J.gnwg, s3,
+                                          halo_from_left(J, wg, 3), halo_from_right(J, wg, 2), nl, nr,
+                                          rspan, rspan + own_off + avn, J.timeout);
         sv[0] = s3[0]; sv[1] = s3[1]; sv[2] = s3[2]; sv[3] = ok ? 0.0 : 1.0;
       }
       RS_STAMP(6);
       RS_STAMP_SYNC(12);
       double tot[4];
       res_block_sum<4>(sv, red, tot);                // (barriers inside: the halo is in LDS)
-      if (tot[3] != 0.0) { if (tid == 0) J.st[ST_STOP] = 8.0; return; }
+      if (tot[3] != 0.0) {
+        if (tid == 0) { J.st[ST_VIOL] = 82.0; J.st[ST_STOP] = (double)J.stop_code; }
+        return;
+      }
       part_xn2 = tot[0]; part_gg = tot[1]; part_tt = tot[2];
       have_proj = true;
     }
@@ -737,8 +867,8 @@ k_cg_resident(ResJob J) {
     }
     if (it + 1 != J.it_end) {                         // (the halo of Hp: hop 1's tag; as above)
       ipx_lds_barrier();
-      halo_put(J, wg, 0, hspan + own_off, pl, J.seq + hop + 1);
-      halo_put(J, wg, 1, hspan + own_off + avn - pr, pr, J.seq + hop + 1);
+      halo_put<PEER>(J, wg, 0, hspan + own_off, pl, J.seq + hop + 1);
+      halo_put<PEER>(J, wg, 1, hspan + own_off + avn - pr, pr, J.seq + hop + 1);
     }
     double mine1[1], loc1[1] = {acc_xy};
     res_block_sum<1>(loc1, red, mine1);         // (barriers inside: Hp is complete on the own part)
@@ -748,18 +878,27 @@ k_cg_resident(ResJob J) {
     {
       const uint32_t tag = J.seq + hop;
       const bool last = it + 1 == J.it_end;
-      if (tid == 0) ll_put(S1 + 2 * wg, mine1[0], tag);
+      rec_put<1, PEER>(J, hop, gw, mine1, tag);
       double sv[2];
       {
+        // (the launch's last hop is its commit: every workgroup has been seen running by then,
+        // so a word that is late is late, not missing -- eight times the patience, which keeps
+        // "some workgroups commit, one times out" out of reach: ADVICE r4)
         double s1[1];
-        const bool ok = hop_wait<1>(J, wg, tag, S1, 2, s1, nl, nr, 1, 0, hspan, hspan + own_off + avn, !last);
+        const bool ok = hop_wait<1, PEER>(J, tag, res_records(J.ll, hop), J.gnwg, s1,
+                                          halo_from_left(J, wg, 1), halo_from_right(J, wg, 0),
+                                          last ? 0 : nl, last ? 0 : nr, hspan, hspan + own_off + avn,
+                                          last ? 8 * J.timeout : J.timeout);
         sv[0] = s1[0]; sv[1] = ok ? 0.0 : 1.0;
       }
       RS_STAMP(10);
       RS_STAMP_SYNC(13);
       double tot[2];
       res_block_sum<2>(sv, red, tot);
-      if (tot[1] != 0.0) { if (tid == 0) J.st[ST_STOP] = 8.0; return; }
+      if (tot[1] != 0.0) {
+        if (tid == 0) { J.st[ST_VIOL] = 81.0; J.st[ST_STOP] = (double)J.stop_code; }
+        return;
+      }
       ptHp = tot[0];
       RS_STAMP(11);
     }
@@ -769,13 +908,18 @@ k_cg_resident(ResJob J) {
     // iteration (the reduced scalars are the same bits everywhere)
     ++hop;
     const uint32_t tag = J.seq + hop;
-    if (tid == 0) ll_put(S1 + 2 * wg, 0.0, tag);
+    const double zero1[1] = {0.0};
+    rec_put<1, PEER>(J, hop, gw, zero1, tag);
     double sv[2], s1[1];
-    const bool ok = hop_wait<1>(J, wg, tag, S1, 2, s1, 0, 0, 1, 0, hspan, hspan, false);
+    const bool ok = hop_wait<1, PEER>(J, tag, res_records(J.ll, hop), J.gnwg, s1, J.ll, J.ll, 0, 0,
+                                      hspan, hspan, hop > 1 ? 8 * J.timeout : J.timeout);
     sv[0] = 0.0; sv[1] = ok ? 0.0 : 1.0;
     double tot[2];
     res_block_sum<2>(sv, red, tot);
-    if (tot[1] != 0.0) { if (tid == 0) J.st[ST_STOP] = 8.0; return; }
+    if (tot[1] != 0.0) {
+      if (tid == 0) { J.st[ST_VIOL] = 83.0; J.st[ST_STOP] = (double)J.stop_code; }
+      return;
+    }
   }
   // ================= write-back (every workgroup has passed the launch's last hop) ===========
   ipx_lds_barrier();
@@ -791,17 +935,24 @@ k_cg_resident(ResJob J) {
   }
   // partial arrays as the separate launches' consumers fold them: the total in entry 0, zeros
   // behind it (x + 0.0 = x: the next fold returns the same bits)
+  // (PEER: the consumers sum a rank's own range and then over the ranks -- the total sits on
+  // rank 0, zeros elsewhere; the sums of a stopped projection go to the host's pack, which the
+  // resumed step2 reads)
   const int gtid = wg * RB + tid, gn = J.nwg * RB;
-  for (int i = gtid + 1; i < J.np1; i += gn) J.part1[J.np1 + i] = 0.0;
-  if (have_proj && (stop == 2 || stop == 6)) {
+  for (int i = gtid + 1; i < J.p1_cnt; i += gn) J.part1[J.p1_off + i] = 0.0;
+  if (!PEER && have_proj && (stop == 2 || stop == 6)) {
     for (int i = gtid + 1; i < 2 * J.np2; i += gn) J.part2[i] = 0.0;
     for (int i = gtid + 1; i < J.np3; i += gn) J.part3[i] = 0.0;
     for (int i = gtid + 1; i < J.np4; i += gn) J.part4[i] = 0.0;
   }
   if (lead) {
-    J.part1[J.np1] = ptHp;
+    J.part1[J.p1_off] = (!PEER || J.rank == 0) ? ptHp : 0.0;
     if (have_proj && (stop == 2 || stop == 6)) {
-      J.part2[0] = part_xn2; J.part3[0] = part_gg; J.part4[0] = part_tt;
+      if constexpr (PEER) {
+        J.pack_out[0] = part_xn2; J.pack_out[1] = 0.0; J.pack_out[2] = part_gg; J.pack_out[3] = part_tt;
+      } else {
+        J.part2[0] = part_xn2; J.part3[0] = part_gg; J.part4[0] = part_tt;
+      }
     }
     J.st[ST_RTG0] = rt[0]; J.st[ST_RTG1] = rt[1];
     J.st[ST_ALPHA] = st_alpha; J.st[ST_BETA] = st_beta; J.st[ST_PTHP] = st_pthp;
@@ -825,40 +976,75 @@ size_t resident_lds_bytes(int nspan, int navn, int hmax, int rows_wg, int L, int
 
 IPX_STAMP_EXPORT(ipx_debug_stamps_res, ipx_dbg_res)
 
-// words of the hand-off buffer for `nwg` workgroups with halos of up to `hw` entries
+// words of the hand-off buffer for `nwg` launched workgroups with halos of up to `hw` entries
+// (two record arrays, a slot of six areas per workgroup + the two slots the neighbour ranks fill)
 extern "C" int64_t ipx_cg_resident_ll_words(int32_t nwg, int32_t hw) {
-  return (int64_t)R_HALO + (int64_t)nwg * 4 * hw * 2;
+  return (int64_t)R_HALO + ((int64_t)nwg + 2) * R_AREAS * hw * 2;
 }
 
-// 1 when the argument block can run the resident form (sizes within the kernel's budgets)
-extern "C" int ipx_cg_resident_ok(const ipx_cg_args *a) {
-  if (!a || !a->resident || !a->R_ll || !a->R_seq || a->solver_kind != 0 || a->lb || a->m <= 0 ||
-      !a->P_win || !a->A_off16 || !a->A_rowfirst || a->A_rl < 1 || a->A_rl > RLA || !a->At_vown ||
-      !a->At_ell_row || !a->At_ell_val || a->H_operator || !a->H_rowptr || a->H_hmax < 1 ||
-      a->H_hmax > 64 || (a->n & 1) || a->n > (1 << 26) || a->m * a->A_rl > (1ll << 30))
-    return 0;
-  ipx_pcr_view pv;
-  if (!ipx_banded_pcr_view(a->banded, &pv)) return 0;
+// the kernel's budgets, for the host code that builds its tables (ipsolver/cg_fused.py
+// fuse_project): workgroups per launch, threads, span / own variables / window rows per
+// workgroup, entries per row of A and of H, halo entries, workgroups of all ranks together
+extern "C" void ipx_cg_resident_limits(int32_t *out8) {
+  out8[0] = R_MAXLOCAL; out8[1] = RB; out8[2] = RQS * RB; out8[3] = RQX * RB; out8[4] = RNR * RB;
+  out8[5] = RLA; out8[6] = RLH; out8[7] = RHK * RB / 2;
+}
+extern "C" int32_t ipx_cg_resident_max_global(void) { return R_MAXG; }
+
+namespace {
+
+// compute units of the current device (one workgroup per CU: every workgroup of a launch must be
+// resident at once) and the dynamic-LDS attribute, once per device
+int res_device_cus() {
+  static int cus[64];
+  static bool attr[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+  if (cus[dev] == 0) {
+    hipDeviceProp_t p;
+    cus[dev] = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0)
+                   ? p.multiProcessorCount : -1;
+  }
+  if (!attr[dev]) {
+    const int lim = 158 * 1024;
+    hipError_t e = hipSuccess;
+#define RES_ATTR(K) \
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)K, hipFuncAttributeMaxDynamicSharedMemorySize, lim)
+    RES_ATTR((k_cg_resident<false, false, false>)); RES_ATTR((k_cg_resident<false, true, false>));
+    RES_ATTR((k_cg_resident<true, false, false>));  RES_ATTR((k_cg_resident<true, true, false>));
+    RES_ATTR((k_cg_resident<false, false, true>));  RES_ATTR((k_cg_resident<false, true, true>));
+    RES_ATTR((k_cg_resident<true, false, true>));   RES_ATTR((k_cg_resident<true, true, true>));
+#undef RES_ATTR
+    if (e != hipSuccess) { ipx_note_error(e, __FILE__, __LINE__); return 0; }
+    attr[dev] = true;
+  }
+  return cus[dev] > 0 ? cus[dev] : 0;
+}
+
+// the tables of the argument block fit the kernel, for a launch of `nlaunch` of the solve's
+// pv.nwg blocks
+bool res_tables_ok(const ipx_cg_args *a, const ipx_pcr_view &pv, int nlaunch) {
+  if (!a || a->solver_kind != 0 || a->lb || a->m <= 0 || !a->P_win || !a->A_off16 ||
+      !a->A_rowfirst || a->A_rl < 1 || a->A_rl > RLA || !a->At_vown || !a->At_ell_row ||
+      !a->At_ell_val || a->H_operator || !a->H_rowptr || a->H_hmax < 1 || a->H_hmax > 64 ||
+      (a->n & 1) || a->n > (1 << 26) || a->m * a->A_rl > (1ll << 30))
+    return false;
   const int H = 1 << pv.L, R = pv.rows_wg + 2 * H;
   const int navnE = ((int)a->P_navn + 2) & ~1;
-  if (pv.nwg > 224 || R > RNR * RB || H < 1 || a->P_nspan > RQS * RB || a->P_nspan < 1 ||
-      a->P_navn < 1 || a->P_navn > RQX * RB || navnE > 2 * RB * RQP || 2 * a->R_hw > RHK * RB ||
-      a->R_hw < 1 || a->P_navn + 2 * a->H_hmax > (RQX + 1) * RB)
-    return 0;
+  if (nlaunch < 1 || nlaunch > pv.nwg || nlaunch > R_MAXLOCAL || R > RNR * RB || H < 1 ||
+      a->P_nspan > RQS * RB || a->P_nspan < 1 || a->P_navn < 1 || a->P_navn > RQX * RB ||
+      navnE > 2 * RB * RQP || 2 * a->R_hw > RHK * RB || a->R_hw < 1 || a->H_hmax > a->R_hw ||
+      a->P_navn + 2 * a->H_hmax > (RQX + 1) * RB)
+    return false;
   if (resident_lds_bytes((int)a->P_nspan, (int)a->P_navn, (int)a->H_hmax, pv.rows_wg, pv.L, (int)a->A_rl) > 158 * 1024)
-    return 0;
-  return 1;
+    return false;
+  return nlaunch <= res_device_cus();
 }
 
-// iterations [it_begin, it_end) in one resident launch (see the top of this file)
-int ipx_cg_resident_launch(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, int np1, int np2,
-                           int np3, int np4, hipStream_t st) {
-  if (!ipx_cg_resident_ok(a) || it_end <= it_begin) return IPX_EINVAL;
-  ipx_pcr_view pv;
-  ipx_banded_pcr_view(a->banded, &pv);
-  ResJob J;
+void res_job_common(ResJob &J, const ipx_cg_args *a, const ipx_pcr_view &pv, int32_t it_begin,
+                    int32_t it_end) {
   J.st = a->state; J.it_begin = it_begin; J.it_end = it_end; J.n = (int)a->n; J.m = pv.m;
-  J.rows_wg = pv.rows_wg; J.L = pv.L; J.nwg = pv.nwg; J.band = pv.band;
+  J.rows_wg = pv.rows_wg; J.L = pv.L; J.band = pv.band;
   J.x = a->x; J.p = a->p; J.r = a->r; J.Hp = a->Hp;
   J.A_val = a->A_val; J.A_off16 = (const uint16_t *)a->A_off16; J.A_rowfirst = a->A_rowfirst;
   J.rl = (int)a->A_rl; J.win = a->P_win; J.vown = a->At_vown; J.nspan = (int)a->P_nspan;
@@ -867,11 +1053,48 @@ int ipx_cg_resident_launch(const ipx_cg_args *a, int32_t it_begin, int32_t it_en
   J.H_rowptr = a->H_rowptr; J.H_colidx = a->H_colidx; J.H_val = a->H_val; J.H_diag = a->H_diag;
   J.hmax = (int)a->H_hmax;
   J.part1 = a->part1; J.part2 = a->part2; J.part3 = a->part3; J.part4 = a->part4;
-  J.np1 = np1; J.np2 = np2; J.np3 = np3; J.np4 = np4;
-  J.ll = (ull *)a->R_ll; J.hw = (int)a->R_hw;
+  J.hw = (int)a->R_hw;
   J.no_xn2 = a->no_radius != 0;
+}
+
+template <bool PEER>
+void res_launch(const ResJob &J, size_t lds, hipStream_t st) {
+  const dim3 grid(J.nwg), block(RB);
+  if (J.no_xn2) {
+    if (J.H_diag) hipLaunchKernelGGL((k_cg_resident<true, true, PEER>), grid, block, lds, st, J);
+    else hipLaunchKernelGGL((k_cg_resident<true, false, PEER>), grid, block, lds, st, J);
+  } else {
+    if (J.H_diag) hipLaunchKernelGGL((k_cg_resident<false, true, PEER>), grid, block, lds, st, J);
+    else hipLaunchKernelGGL((k_cg_resident<false, false, PEER>), grid, block, lds, st, J);
+  }
+}
+
+}  // namespace
+
+// 1 when the argument block can run the resident form (sizes within the kernel's budgets, one
+// compute unit per workgroup on this device)
+extern "C" int ipx_cg_resident_ok(const ipx_cg_args *a) {
+  if (!a || !a->resident || !a->R_ll || !a->R_seq) return 0;
+  ipx_pcr_view pv;
+  if (!ipx_banded_pcr_view(a->banded, &pv)) return 0;
+  return res_tables_ok(a, pv, pv.nwg) ? 1 : 0;
+}
+
+// iterations [it_begin, it_end) in one resident launch (see the top of this file)
+int ipx_cg_resident_launch(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, int np1, int np2,
+                           int np3, int np4, hipStream_t st) {
+  if (!ipx_cg_resident_ok(a) || it_end <= it_begin) return IPX_EINVAL;
+  ipx_pcr_view pv;
+  ipx_banded_pcr_view(a->banded, &pv);
+  ResJob J{};
+  res_job_common(J, a, pv, it_begin, it_end);
+  J.nwg = pv.nwg;
+  J.p1_off = np1; J.p1_cnt = np1; J.np2 = np2; J.np3 = np3; J.np4 = np4;
+  J.ll = (ull *)a->R_ll;
   J.timeout = 200000000LL;                           // 2 s of the 100 MHz wall clock
-  // tags: strictly increasing over the life of the buffer (2 per iteration + the commit)
+  J.stop_code = 8;
+  J.wg0 = 0; J.gwg0 = 0; J.gnwg = pv.nwg; J.rank = 0; J.world = 1; J.pll = nullptr; J.pack_out = nullptr;
+  // tags: strictly increasing over the life of the buffer (hop 0, 2 per iteration, the commit)
   const int64_t need = 2 * (int64_t)(it_end - it_begin) + 2;
   if (*a->R_seq + need >= 0xfffffff0LL) {
     if (hipMemsetAsync(a->R_ll, 0, (size_t)ipx_cg_resident_ll_words(pv.nwg, J.hw) * 8, st) != hipSuccess)
@@ -880,23 +1103,61 @@ int ipx_cg_resident_launch(const ipx_cg_args *a, int32_t it_begin, int32_t it_en
   }
   J.seq = (uint32_t)*a->R_seq;
   *a->R_seq += need;
-  const size_t lds = resident_lds_bytes(J.nspan, J.navn, J.hmax, J.rows_wg, J.L, J.rl);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void *)k_cg_resident<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
-    (void)hipFuncSetAttribute((const void *)k_cg_resident<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
-    (void)hipFuncSetAttribute((const void *)k_cg_resident<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
-    (void)hipFuncSetAttribute((const void *)k_cg_resident<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
-    attr_set = true;
-  }
-  const dim3 grid(pv.nwg), block(RB);
-  if (J.no_xn2) {
-    if (J.H_diag) hipLaunchKernelGGL((k_cg_resident<true, true>), grid, block, lds, st, J);
-    else hipLaunchKernelGGL((k_cg_resident<true, false>), grid, block, lds, st, J);
-  } else {
-    if (J.H_diag) hipLaunchKernelGGL((k_cg_resident<false, true>), grid, block, lds, st, J);
-    else hipLaunchKernelGGL((k_cg_resident<false, false>), grid, block, lds, st, J);
-  }
+  res_launch<false>(J, resident_lds_bytes(J.nspan, J.navn, J.hmax, J.rows_wg, J.L, J.rl), st);
+  IPX_CHECK_LAUNCH();
+  return IPX_OK;
+}
+
+// ---- PEER form: one rank's part of a batch of the row-sharded loop (ipsolver/sharded.py).
+// e->res_*: this rank's own blocks [res_wg0, res_wg0 + res_nwg) of its local solve are the
+// global workgroups res_gwg0 .. of res_gnwg; e->peer carries the hand-off buffers of all ranks
+// (ipx_peer_attach_resident).  The GROUP decides to take this form (every rank's
+// ipx_cg_shard2_resident_ok, minimum over the ranks): a rank on another form would leave the
+// others waiting for its records.
+extern "C" int ipx_cg_shard2_resident_ok(const ipx_cg_args *a, const ipx_shard2_ext *e) {
+  if (!a || !e || !e->peer || e->nseg != 1 || e->res_nwg < 1) return 0;
+  const ipx_peer *peer = (const ipx_peer *)e->peer;
+  ipx_pcr_view pv;
+  if (!ipx_banded_pcr_view(a->banded, &pv)) return 0;
+  if (e->res_wg0 < 0 || e->res_wg0 + e->res_nwg > pv.nwg) return 0;
+  // (a rank's edge workgroups read the tables of the block beyond: the halo blocks)
+  if ((peer->view.rank > 0 && e->res_wg0 < 1) ||
+      (peer->view.rank < peer->view.world - 1 && e->res_wg0 + e->res_nwg >= pv.nwg))
+    return 0;
+  return res_tables_ok(a, pv, (int)e->res_nwg) ? 1 : 0;
+}
+
+int ipx_cg_shard2_resident_launch(const ipx_cg_args *a, const ipx_shard2_ext *e, int32_t it_begin,
+                                  int32_t it_end, int np1, hipStream_t stream) {
+  if (!ipx_cg_shard2_resident_ok(a, e) || it_end <= it_begin || !e->pack) return IPX_EINVAL;
+  ipx_peer *peer = (ipx_peer *)e->peer;
+  const int world = peer->view.world;
+  if (!peer->res_tab || !ipx_peer_ready(peer) || e->res_gnwg > R_MAXG || e->res_gnwg < e->res_nwg ||
+      e->res_gwg0 < 0 || e->res_gwg0 + e->res_nwg > e->res_gnwg ||
+      ipx_cg_resident_ll_words((int)e->res_nwg, (int)a->R_hw) > peer->res_words ||
+      e->p1_lo[0] < 0 || e->p1_hi[0] > np1 || e->p1_hi[0] <= e->p1_lo[0])
+    return IPX_EINVAL;
+  const int64_t need = 2 * (int64_t)(it_end - it_begin) + 2;
+  if ((int64_t)peer->rseq + need >= 0xfffffff0LL) return IPX_EINVAL;   // (2e9 iterations: the
+                                                    // caller goes back to the separate launches)
+  ipx_pcr_view pv;
+  ipx_banded_pcr_view(a->banded, &pv);
+  ResJob J{};
+  res_job_common(J, a, pv, it_begin, it_end);
+  J.nwg = (int)e->res_nwg;
+  J.p1_off = np1 + (int)e->p1_lo[0]; J.p1_cnt = (int)(e->p1_hi[0] - e->p1_lo[0]);
+  J.np2 = J.np3 = J.np4 = 0;
+  J.ll = peer->res[peer->view.rank];
+  J.timeout = peer->view.timeout_ticks;
+  J.stop_code = 7;
+  J.wg0 = (int)e->res_wg0; J.gwg0 = (int)e->res_gwg0; J.gnwg = (int)e->res_gnwg;
+  J.rank = peer->view.rank; J.world = world;
+  J.pll = peer->res_tab;
+  J.pack_out = e->pack;
+  J.seq = peer->rseq;
+  peer->rseq += (uint32_t)need;
+  ++peer->res_launches;
+  res_launch<true>(J, resident_lds_bytes(J.nspan, J.navn, J.hmax, J.rows_wg, J.L, J.rl), stream);
   IPX_CHECK_LAUNCH();
   return IPX_OK;
 }

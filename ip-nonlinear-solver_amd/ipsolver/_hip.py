@@ -78,6 +78,14 @@ _SIGNATURES = {
     "ipx_cg_shard2_fold_hp": [_P, _P, _P],
     "ipx_cg_shard2_iterate": [_P, _P, _I32, _I32, _P],
     "ipx_cg_shard2_fusable": [_P, _P],
+    "ipx_cg_shard2_resident_ok": [_P, _P],
+    "ipx_cg_shard2_resident": [_P, _P, _I32, _I32, _P],
+    "ipx_cg_save_pb": [_P, _P],
+    "ipx_peer_attach_resident": [_P, _I64],
+    "ipx_peer_export_resident": [_P, _P],
+    "ipx_peer_import_resident": [_P, _I32, _P],
+    "ipx_peer_resident_ready": [_P],
+    "ipx_cg_resident_max_global": [],
     "ipx_peer_set_timeout": [_P, _F64],
     "ipx_peer_handle_bytes": [],
     "ipx_peer_export": [_P, _P],
@@ -98,13 +106,15 @@ _RESTYPES = {"ipx_version": _c.c_char_p, "ipx_last_error": _c.c_char_p,
              "ipx_banded_create": _P, "ipx_banded_destroy": None,
              "ipx_dense_padded": _I64, "ipx_gram_ws_doubles": _I64, "ipx_peer_create": _P, "ipx_peer_destroy": None,
              "ipx_peer_halo_capacity": _I64, "ipx_peer_fused_launches": _I64,
-             "ipx_cg_resident_ll_words": _I64, "ipx_cg_prime_ws_doubles": _I64}
+             "ipx_cg_resident_ll_words": _I64, "ipx_cg_prime_ws_doubles": _I64,
+             "ipx_peer_resident_launches": _I64, "ipx_cg_resident_limits": None}
 _EXTRA_ARGTYPES = {"ipx_banded_create": [_I64, _I32, _I32], "ipx_banded_destroy": [_P],
                    "ipx_dense_padded": [_I64], "ipx_gram_ws_doubles": [_I64, _I32],
                    "ipx_peer_create": [_I32, _I32, _I64],
                    "ipx_peer_destroy": [_P], "ipx_peer_halo_capacity": [_P],
                    "ipx_peer_fused_launches": [_P], "ipx_cg_resident_ll_words": [_I32, _I32],
-                   "ipx_cg_prime_ws_doubles": [_P, _I32]}
+                   "ipx_cg_prime_ws_doubles": [_P, _I32], "ipx_peer_resident_launches": [_P],
+                   "ipx_cg_resident_limits": [_P]}
 
 _lib = None
 

@@ -296,9 +296,20 @@ def ell_rows(At, row_rel):
     return row16, val
 
 
-PF_U, PF_QS, PF_QX = 23, 16, 12      # csrc/resident.hip RU, RQS, RQX
-RES_MAX_WG, RES_RLH, RES_HK = 224, 4, 8      # csrc/resident.hip: workgroups, entries per row of
-                                             # H in registers, halo entries per lane and hop
+_RES_LIMITS = None
+
+
+def resident_limits():
+    """The budgets of csrc/resident.hip, asked of the library (``ipx_cg_resident_limits``): a
+    dict with max_wg (workgroups of one launch), threads, span / own variables / window rows per
+    workgroup, entries per row of A / of H, halo entries either side."""
+    global _RES_LIMITS
+    if _RES_LIMITS is None:
+        out = (ctypes.c_int32 * 8)()
+        _hip.load().ipx_cg_resident_limits(out)
+        _RES_LIMITS = dict(zip(("max_wg", "threads", "span", "own", "rows", "row_A", "row_H", "halo"),
+                               (int(v) for v in out)))
+    return _RES_LIMITS
 
 
 def fuse_project(pattern, vown_h, rows_wg, nwg, H):
@@ -322,7 +333,8 @@ def fuse_project(pattern, vown_h, rows_wg, nwg, H):
         first, last = rows.min(axis=1), rows.max(axis=1)
         off = rows - first[:, None]
         R = rows_wg + 2 * H
-        if off.max() < 65536 and R * rl <= PF_U * 256 and R <= 512 and 6 * (R + 2 * H) >= rl:
+        lim = resident_limits()
+        if off.max() < 65536 and rl <= lim["row_A"] and R <= lim["rows"]:
             b = np.arange(nwg, dtype=np.int64)
             rlo = np.maximum(b * rows_wg - H, 0)
             rhi = np.minimum((b + 1) * rows_wg + H, m)
@@ -341,8 +353,9 @@ def fuse_project(pattern, vown_h, rows_wg, nwg, H):
                 nl, nr = vown_h[:-1] - c_lo, c_hi - vown_h[1:]
                 near = np.all(c_lo[1:] >= vown_h[:-2]) and np.all(c_hi[:-1] <= vown_h[2:])
                 hw = int(max(nl.max(), nr.max(), 1))
-                if nspan <= PF_QS * 256 and 0 < avn <= PF_QX * 256 and near \
-                        and nwg <= RES_MAX_WG and 2 * hw <= RES_HK * 256:
+                # (the launch's workgroup count is the library's check: ipx_cg_resident_ok; a
+                # sharded rank launches its own blocks only)
+                if nspan <= lim["span"] and 0 < avn <= lim["own"] and near and hw <= lim["halo"]:
                     dev = ctx().device
                     win = np.stack((c_lo, c_hi), 1).ravel().astype(np.int32)
                     # (inner boundaries: the smallest halo, which must cover the Hessian's)
@@ -577,13 +590,13 @@ class _Loop:
                     # small problems (one CU per workgroup of the cyclic-reduction solve: the
                     # per-rank sizes of a multi-GPU run), uniform rows, no box, short Hessian
                     # rows: a whole batch of iterations as ONE resident launch
-                    # (csrc/resident.hip) -- 21.8 -> ~7 us per iteration at n = 1.25e5
+                    # (csrc/resident.hip) -- 19.6 -> 16.0 us per iteration at n = 1.25e5
                     # (profiles/r04_per_rank_sweep.json).  resident=False: the separate launches.
                     L_pcr = int(lib.ipx_banded_pcr_level(ctypes.c_void_p(P.solver.handle)))
                     if resident is None and _hip.debug_form("no-resident"):
                         resident = False
                     if kS == 1 and L_pcr > 0 and lb is None and hmax > 0 and resident is not False \
-                            and int(np.max(np.diff(Hc.pattern.indptr_h))) <= RES_RLH:
+                            and int(np.max(np.diff(Hc.pattern.indptr_h))) <= resident_limits()["row_H"]:
                         pj = fuse_project(A.pattern, self.vown.cpu().numpy().astype(np.int64),
                                           geo[0], geo[1], 1 << L_pcr)
                         if pj is not None and hmax <= pj[7]:

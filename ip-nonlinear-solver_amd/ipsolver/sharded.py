@@ -93,6 +93,14 @@ class ShardLayout:
             E1 = min(m, R[r + 1] + self.halo_rows)
             x0 = 0 if r == 0 else min(C[r], int(first[E0]))
             x1 = n if r == world - 1 else max(C[r + 1], int(last[E1 - 1]) + 1)
+            # an even number of local variables (one more halo column where there is room): the
+            # ELL(2) form of A' the solve's tail and the resident loop kernel read takes the
+            # variables in aligned pairs
+            if (x1 - x0) % 2:
+                if x1 < n:
+                    x1 += 1
+                elif x0 > 0:
+                    x0 -= 1
             self.ranks.append(dict(R0=R[r], R1=R[r + 1], E0=E0, E1=E1, c0=C[r], c1=C[r + 1],
                                    x0=x0, x1=x1))
         for r in range(world):
@@ -385,6 +393,42 @@ class PeerMailbox:
             raise self._hip.IpxError("peer mailbox: a wait for a peer timed out")
         return out.tolist()
 
+    def attach_resident(self):
+        """The hand-off buffers of the resident loop kernel's PEER form (csrc/resident.hip), sized
+        for the largest launch the kernel admits; collective, once per mailbox.  True when every
+        rank mapped every other rank's (else the group keeps the separate launches)."""
+        if getattr(self, "_resident", None) is None:
+            from . import cg_fused
+            _hip, lib, comm = self._hip, self.lib, self.comm
+            lim = cg_fused.resident_limits()
+            words = int(lib.ipx_cg_resident_ll_words(lim["max_wg"], lim["halo"]))
+            blob = None
+            try:
+                _hip.call("ipx_peer_attach_resident", ctypes.c_void_p(self.handle), words)
+                buf = ctypes.create_string_buffer(lib.ipx_peer_handle_bytes())
+                _hip.call("ipx_peer_export_resident", ctypes.c_void_p(self.handle), buf)
+                blob = buf.raw
+            except Exception as exc:
+                self.resident_error = repr(exc)
+            blobs = [None] * comm.world
+            dist.all_gather_object(blobs, blob, group=comm.group)
+            good = all(b is not None for b in blobs)
+            if good:
+                try:
+                    for r, b in enumerate(blobs):
+                        if r != comm.rank:
+                            _hip.call("ipx_peer_import_resident", ctypes.c_void_p(self.handle), r, b)
+                    good = bool(lib.ipx_peer_resident_ready(ctypes.c_void_p(self.handle)))
+                except Exception as exc:
+                    self.resident_error, good = repr(exc), False
+            flags = [None] * comm.world
+            dist.all_gather_object(flags, bool(good), group=comm.group)
+            self._resident = all(flags)
+        return self._resident
+
+    def resident_launches(self):
+        return int(self.lib.ipx_peer_resident_launches(ctypes.c_void_p(self.handle)))
+
     def set_timeout(self, seconds):
         """Deadline of a kernel's wait for a peer's word (default 10 s; past it: stop code 7,
         the group falls back to torch.distributed together)."""
@@ -410,6 +454,17 @@ class PeerMailbox:
                 pass
 
     __del__ = close
+
+
+def _device_id():
+    """What tells two ranks that they run on the same GPU: host + the device's UUID (its PCI
+    address where torch does not expose one)."""
+    props = torch.cuda.get_device_properties(torch.cuda.current_device())
+    ident = getattr(props, "uuid", None)
+    if ident is None:
+        ident = (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", -1),
+                 getattr(props, "pci_device_id", torch.cuda.current_device()))
+    return _host_id() + ":" + str(ident)
 
 
 def _host_id():
@@ -1138,7 +1193,9 @@ def projections(A, method=None, orth_tol=1e-12, max_refin=3, tol=1e-15):
 
 # --------------------------------------------------------------------------- fused loop
 # counters over the life of the process (tests assert the device-resident path was taken)
-STATS = {"fused_calls": 0, "iterations": 0, "batches": 0, "box_events": 0, "refine_events": 0}
+STATS = {"fused_calls": 0, "iterations": 0, "batches": 0, "box_events": 0, "refine_events": 0,
+         "resident_batches": 0,       # batches that ran as ONE resident launch per rank
+         "resident_halo_syncs": 0}    # ... and the halo synchronisations the host did after them
 
 ST_RTG0, ST_RTG1, ST_TOL, ST_RADIUS, ST_ALPHA, ST_STOP, ST_NITER, ST_BETA = range(8)
 ST_PTHP, ST_ORTH_RHS, ST_XNORM2, ST_VIOL, ST_ORTH, ST_IT_DONE = 8, 9, 10, 11, 12, 13
@@ -1153,7 +1210,9 @@ class Shard2Ext(ctypes.Structure):
                 ("p3_lo", _A4), ("p3_hi", _A4), ("p2_lo", ctypes.c_int64),
                 ("p2_hi", ctypes.c_int64), ("p4_lo", ctypes.c_int64), ("p4_hi", ctypes.c_int64),
                 ("peer", ctypes.c_void_p), ("seg_lo", _A4), ("seg_hi", _A4),
-                ("send_left", _A4), ("send_right", _A4), ("fuse_comm", ctypes.c_int64)]
+                ("send_left", _A4), ("send_right", _A4), ("fuse_comm", ctypes.c_int64),
+                ("res_wg0", ctypes.c_int64), ("res_nwg", ctypes.c_int64),
+                ("res_gwg0", ctypes.c_int64), ("res_gnwg", ctypes.c_int64)]
 
 
 def _banded_of(P):
@@ -1236,8 +1295,12 @@ class FusedShardedCG:
         self.kind = H.kind
         # (the rank-local loop keeps the separate launches: the own-range partial sums of
         # ipx_cg_shard2_segment follow their workgroups / row tiles)
+        # (resident=None: the tables of the resident kernel are built when the local problem
+        # qualifies; whether the GROUP runs it is decided below)
         self.L = L = cg_fused._Loop(H.local, local_P, lb.loc if lb is not None else None,
-                                    ub.loc if ub is not None else None, resident=False)
+                                    ub.loc if ub is not None else None,
+                                    resident=None if transport != "dist" else False)
+        L.args.resident = 0          # (the single-GPU launch never runs on a rank's local problem)
         a = L.args
         dev = dv.ctx().device
         self.s1 = torch.zeros(2, dtype=torch.float64, device=dev)
@@ -1279,6 +1342,7 @@ class FusedShardedCG:
             e.seg_lo[k], e.seg_hi[k] = off, off + ln
             e.send_left[k], e.send_right[k] = sl, sr
         self.mailbox = sh.mailbox() if transport != "dist" else None
+        self.resident, self.resident_dirty = False, False
         if self.mailbox is not None:
             # the loop's kernels all-reduce the scalars and move the halo of g themselves: in
             # the prologues of the kernels that consume them (3 launches per iteration; the C
@@ -1287,6 +1351,7 @@ class FusedShardedCG:
             e.peer = self.mailbox.handle
             e.fuse_comm = self._agree_on_fused_comm(Hc, A_loc, lb is not None)
             self._exchange_g = None
+            self.resident = self._agree_on_resident(Hc, A_loc, w0, w1)
         else:
             self._exchange_g = sh.comm.prepare_exchange_many(
                 [(self.L.r[off:off + ln], lo, hi, sl, sr)
@@ -1312,6 +1377,80 @@ class FusedShardedCG:
             # (the patterns are kept alive with the decision: their ids stay theirs)
             cache[key, "keep"] = (Hc.pattern, A_loc.pattern)
         return cache[key]
+
+    def _agree_on_resident(self, Hc, A_loc, w0, w1):
+        """True when the GROUP runs a batch as one resident launch per rank (csrc/resident.hip,
+        PEER form): every rank's local problem has the kernel's tables and fits its budgets, all
+        own blocks of all ranks together are within the kernel's record arrays, the hand-off
+        buffers are mapped.  The ranks exchange (tables?, own blocks, longest halo) once per pair
+        of patterns -- the halo capacity and every rank's first global workgroup follow from
+        it -- and take the minimum of their verdicts."""
+        sh, L, e = self.sh, self.L, self.ext
+        self.resident_dirty = False
+        asked = not self._hip.debug_form("no-resident") and e.nseg == 1
+        key = ("res", id(Hc.pattern), Hc.pattern.nnz, id(A_loc.pattern), A_loc.pattern.nnz,
+               getattr(L, "pcr_L", None), asked)
+        cache = sh.__dict__.setdefault("_resident_agreed", {})
+        if key not in cache:
+            have = asked and getattr(L, "proj_tabs", None) is not None
+            if have:
+                # the kernel writes the variables its workgroups own (cg_fused.fuse_vown); they
+                # must be the layout's own range, which the halo synchronisation starts from
+                vown = L.vown.cpu().numpy()
+                have = int(vown[w0]) == int(e.own_lo[0]) and int(vown[w1]) == int(e.own_hi[0])
+            cus = ctypes.c_int(0)
+            self._hip.call("ipx_device_info", ctypes.byref(cus), None, None, 0)
+            mine = (bool(have), int(w1 - w0), int(L.args.R_hw) if have else 0, _device_id(),
+                    int(cus.value))
+            info = [None] * sh.comm.world
+            dist.all_gather_object(info, mine, group=sh.comm.group)
+            ok = all(i[0] for i in info) and \
+                sum(i[1] for i in info) <= int(self.lib.ipx_cg_resident_max_global())
+            # every workgroup of every rank must be running at once, one per compute unit: ranks
+            # that share a device (the one-GPU rehearsal of the tests) share its compute units
+            for dev in {i[3] for i in info}:
+                on = [i for i in info if i[3] == dev]
+                ok = ok and sum(i[1] for i in on) <= min(i[4] for i in on)
+            ok = ok and bool(self.mailbox.attach_resident())      # (collective: every rank or none)
+            verdict = None
+            if ok:
+                verdict = dict(hw=max(i[2] for i in info), gwg0=sum(i[1] for i in info[:sh.comm.rank]),
+                               gnwg=sum(i[1] for i in info))
+            cache[key] = verdict
+            cache[key, "keep"] = (Hc.pattern, A_loc.pattern)
+            if verdict is not None:
+                self._set_resident(verdict, w0, w1)
+                mine_ok = int(self.lib.ipx_cg_shard2_resident_ok(L.ref(), ctypes.byref(e)))
+                if int(sh.comm.reduce_floats([float(mine_ok)], op="min")[0]) == 0:
+                    cache[key] = None
+        verdict = cache[key]
+        if verdict is None:
+            e.res_nwg = 0
+            return False
+        self._set_resident(verdict, w0, w1)
+        return True
+
+    def _set_resident(self, verdict, w0, w1):
+        e = self.ext
+        self.L.args.R_hw = verdict["hw"]
+        e.res_wg0, e.res_nwg = int(w0), int(w1 - w0)
+        e.res_gwg0, e.res_gnwg = verdict["gwg0"], verdict["gnwg"]
+
+    def sync_halos(self):
+        """After resident batches the local x, p, r, Hp hold this rank's OWN entries only:
+        overwrite their halo copies with the owners' values (one batched neighbour exchange) and
+        re-derive what the separate launches keep next to p.  Called before the host touches the
+        vectors: an event, the end of the loop."""
+        if not getattr(self, "resident_dirty", False):
+            return
+        self.resident_dirty = False
+        STATS["resident_halo_syncs"] += 1
+        L = self.L
+        segs = self.sh.segments(self.kind)
+        self.sh.comm.exchange_many([(t[off:off + ln], lo, hi, sl, sr)
+                                    for t in (L.x, L.p, L.r, L.Hp)
+                                    for _, off, ln, lo, hi, sl, sr, _, _ in segs])
+        self._hip.call("ipx_cg_save_pb", L.ref(), self.dv.stream_ptr())
 
     def _segment(self, phase, it, mode=0):
         self._hip.call("ipx_cg_shard2_segment", self.L.ref(), ctypes.byref(self.ext), int(phase),
@@ -1341,8 +1480,16 @@ class FusedShardedCG:
         through ``torch.distributed`` the host issues three collectives per iteration."""
         comm, exchange_g = self.sh.comm, self._exchange_g
         if self.mailbox is not None:
-            self._hip.call("ipx_cg_shard2_iterate", self.L.ref(), ctypes.byref(self.ext),
-                           int(it_begin), int(it_end), self.dv.stream_ptr())
+            if self.resident:
+                # ONE launch per rank for the whole batch; the workgroups of all ranks hand their
+                # scalars and halos to each other (two hops per iteration)
+                self._hip.call("ipx_cg_shard2_resident", self.L.ref(), ctypes.byref(self.ext),
+                               int(it_begin), int(it_end), self.dv.stream_ptr())
+                self.resident_dirty = True
+                STATS["resident_batches"] += 1
+            else:
+                self._hip.call("ipx_cg_shard2_iterate", self.L.ref(), ctypes.byref(self.ext),
+                               int(it_begin), int(it_end), self.dv.stream_ptr())
             comm.stats["ipc_batches"] += 1
             comm.stats["ipc_iterations"] += it_end - it_begin
             return
@@ -1355,6 +1502,7 @@ class FusedShardedCG:
 
     def resume(self, it, mode):
         """Finish iteration ``it`` after the host handled a box / refinement event."""
+        self.sync_halos()
         self.L.state[ST_STOP] = 0.0
         self._segment(1, it, mode)
         return self.L.state.tolist()
@@ -1436,15 +1584,21 @@ def _drive_fused(F, c, x0, r0, g0, rt_g, tol, trust_radius, lb, ub, max_iter,
         first_batch, batch_cap = 2, 64
 
         def iterate(self, it, end):
+            self.end = end
             F.iterate(it, end)
 
         def read_state(self):
-            return agreed(L.state.tolist())
+            # (the read that ends the loop -- out of iterations on a continuing state -- is
+            # agreed on here, before the host's first collective on the result: the halo
+            # synchronisation after resident batches)
+            return agreed(L.state.tolist(), final=self.end >= max_iter)
 
         def X(self):
+            F.sync_halos()
             return ShardVec(DV(L.x), sh, F.kind)
 
         def Pv(self):
+            F.sync_halos()
             return ShardVec(DV(L.p), sh, F.kind)
 
         def set_x(self, v):
@@ -1459,9 +1613,9 @@ def _drive_fused(F, c, x0, r0, g0, rt_g, tol, trust_radius, lb, ub, max_iter,
         def refine(self, it_stop):
             _refine_sharded(F)
 
-    last = {"stop": 0}
+    last = {"stop": 0, "final": False}
 
-    def agreed(state):
+    def agreed(state, final=False):
         """Before the host ACTS on a state block read on the mailbox transport -- an event to
         handle with torch.distributed collectives, or the end of the subproblem -- the ranks
         establish together whether any of them saw a wait time out (stop code 7; ADVICE r3:
@@ -1471,7 +1625,8 @@ def _drive_fused(F, c, x0, r0, g0, rt_g, tol, trust_radius, lb, ub, max_iter,
         continues (stop 0) does not take part: its next batch finds no partner, times out and
         joins the agreement its peers are waiting in."""
         last["stop"] = stop = int(state[ST_STOP])
-        if F.mailbox is not None and stop != 0:
+        if F.mailbox is not None and (stop != 0 or final):
+            last["final"] = last["final"] or stop == 0
             sh.comm.stats["agreements"] = sh.comm.stats.get("agreements", 0) + 1
             if sh.comm.reduce_floats([1.0 if stop == 7 else 0.0], op="max")[0] > 0.0:
                 state = list(state)
@@ -1481,10 +1636,10 @@ def _drive_fused(F, c, x0, r0, g0, rt_g, tol, trust_radius, lb, ub, max_iter,
     from . import cg_fused
     x, niter, stop_cond, hits_boundary = cg_fused.run_device_loop(
         Driver(), STATS, lb, ub, trust_radius, max_iter, max_infeasible_iter, batch)
-    if last["stop"] == 0:
-        # the loop ran out of iterations on a continuing state: this rank has not taken part
-        # in an agreement its peers may be waiting in (they cannot have seen anything but 0 or
-        # 7 in the same read)
+    if last["stop"] == 0 and not last["final"]:
+        # the loop ran out of iterations on a continuing state without a read (max_iter 0):
+        # this rank has not taken part in an agreement its peers may be waiting in (they cannot
+        # have seen anything but 0 or 7 in the same read)
         if int(agreed([0.0] * ST_STOP + [-1.0])[ST_STOP]) == 7:
             raise F._hip.IpxError("sharded projected CG: a wait on the peer mailboxes timed out "
                                   "on another rank")
@@ -1498,6 +1653,7 @@ def _refine_sharded(F):
     loop (L.r holds g, own + synchronised halo); the refined ||g||^2 replaces the packed
     value step2 derives beta from."""
     P, sh, L = F.P, F.sh, F.L
+    F.sync_halos()
     g = ShardVec(F.dv.DVec(L.r), sh, F.kind)
     k = 0
     while k < P.max_refin:

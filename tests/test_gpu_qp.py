@@ -415,8 +415,9 @@ def _multi_rank_worker(rank, world, port, out_path, transport="dist"):
             sys.path.insert(0, p)
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     os.environ["IPX_SHARD_TRANSPORT"] = transport.split("-")[0]
-    if transport == "ipc-pack":
-        os.environ["IPX_DEBUG_FORMS"] = "pack-comm"
+    forms = {"ipc-pack": "pack-comm,no-resident", "ipc": "no-resident"}.get(transport)
+    if forms:
+        os.environ["IPX_DEBUG_FORMS"] = forms
     else:
         os.environ.pop("IPX_DEBUG_FORMS", None)
     torch.cuda.set_device(0)
@@ -461,6 +462,9 @@ def _multi_rank_worker(rank, world, port, out_path, transport="dist"):
                                sh.comm.stats["ipc_iterations"], len(leaks)]
                               + list(sh.mailbox().sequence() if sh.mailbox() else (0, 0))
                               + [sh.mailbox().fused_launches() if sh.mailbox() else 0])
+        out["resident"] = np.array([sharded.STATS["resident_batches"],
+                                    sharded.STATS["resident_halo_syncs"],
+                                    sh.mailbox().resident_launches() if sh.mailbox() else 0])
         flags = torch.tensor([float(sharded.STATS["fused_calls"])])
         dist.all_reduce(flags, op=dist.ReduceOp.MIN)          # engaged on every rank?
         out["fused_min"] = flags.numpy()
@@ -572,6 +576,22 @@ def _desync_worker(rank, world, port, out_path, mode="lone"):
                 sh.mailbox().allreduce([1.0])
             except _hip.IpxError:
                 lone = 1
+        if mode == "resident-lone" and rank == 0:
+            # the resident form: ONE rank enqueues a batch twice.  The first launch pairs with
+            # the peer's; the second finds no partner, its hop 0 times out (stop code 7, nothing
+            # written back), and this rank's tags run ahead of the peer's from then on
+            plain = sharded.FusedShardedCG.iterate
+            fired = []
+
+            def iterate(self, it_begin, it_end):
+                plain(self, it_begin, it_end)
+                if self.resident and not fired:
+                    fired.append(1)
+                    plain(self, it_begin, it_end)
+            sharded.FusedShardedCG.iterate = iterate
+            lone = 1
+        if mode == "resident-lone" and rank != 0:
+            lone = 0
         if mode == "one-sided" and rank == 0:
             # the LAST communicating launch before a host read times out on rank 0
             # only -- rank 1 completes it and sees an ordinary end of the subproblem.  Emulated
@@ -602,7 +622,7 @@ def _desync_worker(rank, world, port, out_path, mode="lone"):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["lone", "one-sided"])
+@pytest.mark.parametrize("mode", ["lone", "one-sided", "resident-lone"])
 def test_sharded_loop_survives_a_rank_out_of_step(mode, tmp_path, ips):
     """A peer that falls out of step (``lone``: one rank issues a mailbox all-reduce on its own,
     so its sequence numbers run one ahead) makes the waits of the device loop time out -- after
@@ -610,7 +630,11 @@ def test_sharded_loop_survives_a_rank_out_of_step(mode, tmp_path, ips):
     transport up together, warns, and solves the SAME subproblem again through torch.distributed:
     same iterates as before the incident.  ``one-sided``: only ONE rank sees the timeout (in the
     last launch before a host read, which the other rank completes normally); the ranks agree on
-    it before either acts on its state block, and fall back together all the same."""
+    it before either acts on its state block, and fall back together all the same.
+    ``resident-lone``: the same for the resident form of the loop (one launch per rank and batch,
+    csrc/resident.hip): one rank's tags run ahead, the workgroups' waits time out on both ranks,
+    nothing is written back, the group falls back to the separate launches over
+    torch.distributed."""
     import socket
     import torch.multiprocessing as mp
     with socket.socket() as s:
@@ -625,7 +649,7 @@ def test_sharded_loop_survives_a_rank_out_of_step(mode, tmp_path, ips):
     close(got["x3"], got["x"], 1e-13)
 
 
-@pytest.mark.parametrize("transport", ["ipc", "ipc-pack", "dist"])
+@pytest.mark.parametrize("transport", ["ipc-resident", "ipc", "ipc-pack", "dist"])
 @pytest.mark.parametrize("world", [2, 3])
 def test_sharded_fused_loop_multi_rank(world, transport, tmp_path, banded20000, ips):
     """The HIP kernels under the row partition: `world` processes share cuda:0.  The
@@ -639,7 +663,11 @@ def test_sharded_fused_loop_multi_rank(world, transport, tmp_path, banded20000, 
     ONE C call and no torch.distributed call happens between its boundaries (asserted on
     ``ShardComm.stats``); the collectives are done in the prologues of the kernels that consume
     them (3 launches per iteration; "ipc-pack": in pack kernels of their own, 5 launches -- the
-    form the problems with a box always take).  transport "dist": three torch.distributed calls per iteration (over
+    form the problems with a box always take).  "ipc-resident" (what a group takes by itself when
+    the problem qualifies: no box, tridiagonal A A'): a batch is ONE resident launch per rank
+    (csrc/resident.hip, PEER form) -- the workgroups of all ranks hand their scalars and halos to
+    each other directly, two hops per iteration; the host synchronises the halos of x, p, r, Hp
+    when it leaves the loop.  transport "dist": three torch.distributed calls per iteration (over
     gloo here, staged through the host: RCCL refuses two ranks on one device)."""
     import socket
     import torch.multiprocessing as mp
@@ -663,13 +691,22 @@ def test_sharded_fused_loop_multi_rank(world, transport, tmp_path, banded20000, 
     is_ipc, ipc_batches, ipc_iterations, leaks, seq, hseq, fused = got["ipc"]
     if transport.startswith("ipc"):
         assert is_ipc == 1 and leaks == 0 and ipc_batches > 10 and ipc_iterations > 100
-        assert seq >= 2 * ipc_iterations and hseq >= ipc_iterations
+        if transport != "ipc-resident":      # (resident launches count their own tags)
+            assert seq >= 2 * ipc_iterations and hseq >= ipc_iterations
         # the problems without a box ran with the collectives in the prologues of the loop's
         # own kernels (3 launches per iteration), the box ones on the pack kernels (5)
+        res_batches, res_syncs, res_launches = got["resident"]
         if transport == "ipc":
             assert 100 <= fused < 2 * ipc_iterations and fused % 2 == 0
+        elif transport == "ipc-resident":
+            # the problems without a box ran as resident launches (one per batch), the box ones
+            # on the pack kernels
+            assert res_batches >= 6 and res_launches == res_batches and 0 < res_syncs <= res_batches
+            assert fused == 0
         else:
             assert fused == 0
+        if transport != "ipc-resident":
+            assert res_batches == 0 and res_launches == 0
     else:
         assert is_ipc == 0 and ipc_batches == 0 and exchanges > 100
     # the same subproblems on the single-GPU device loop
