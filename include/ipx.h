@@ -461,6 +461,11 @@ void ipx_peer_destroy(void *peer);
 /* `reps` all-reduces (sum) of nq <= 8 doubles back to back: the mailbox path's latency probe. */
 int ipx_peer_allreduce(void *peer, int32_t nq, const double *in, double *out, int *failed,
                        int32_t reps, void *stream);
+/* `reps` round trips of one tagged word with `partner` (-1: sit the round out; every rank of
+ * the group calls it once per round, the sequence numbers advance alike): ticks2[0] = 100 MHz
+ * wall-clock ticks of the exchange, ticks2[1] = 1 when a wait timed out (device int64[2]).
+ * The cost of one cross-GPU hand-off, measured before a multi-GPU run (bench.py preflight). */
+int ipx_peer_pingpong(void *peer, int32_t partner, int32_t reps, long long *ticks2, void *stream);
 /* Hand-off buffers of the resident loop kernel between the ranks: attach (allocates `words`
  * 8-byte words -- ipx_cg_resident_ll_words of the largest launch of the group -- uncached,
  * zeroed) -> export_resident -> hand the blobs around -> import_resident every other rank's

@@ -43,9 +43,57 @@ k_peer_allreduce(ipx_peer_view pv, uint32_t seq, int nq, const double *__restric
   }
 }
 
+// `reps` round trips of one tagged word between this rank and `partner` (the lower rank
+// serves): store into the partner's mailbox, spin on the own one.  ticks[0] = wall-clock ticks
+// (100 MHz) of the whole exchange as this rank saw it, ticks[1] = 1 when a wait timed out.
+// What one cross-GPU hand-off of the resident loop kernel costs, measured on the spot.
+__global__ void __launch_bounds__(64)
+k_peer_pingpong(ipx_peer_view pv, int partner, uint32_t seq0, int reps, long long *ticks) {
+  if (threadIdx.x != 0) return;
+  const bool serve = pv.rank < partner;
+  const long long t0 = (long long)wall_clock64();
+  bool ok = true;
+  for (int i = 0; i < reps && ok; ++i) {
+    uint32_t seq = seq0 + (uint32_t)i;
+    if (seq == 0) seq = 1;                          // (never the tag of a zeroed word)
+    const int slot = seq & (IPX_PEER_SLOTS - 1);
+    unsigned long long *out = pv.mbox[partner] + ipx_peer_scal_word(slot, pv.rank, IPX_PEER_NQ - 1);
+    const unsigned long long *in = pv.mbox[pv.rank] + ipx_peer_scal_word(slot, partner, IPX_PEER_NQ - 1);
+    const long long deadline = (long long)wall_clock64() + pv.timeout_ticks;
+    double v = 0.0;
+    if (serve) {
+      ipx_ll_store(out, (double)i, seq);
+      ok = ipx_ll_load(in, seq, v, deadline);
+    } else {
+      ok = ipx_ll_load(in, seq, v, deadline);
+      ipx_ll_store(out, v, seq);
+    }
+  }
+  ticks[0] = (long long)wall_clock64() - t0;
+  ticks[1] = ok ? 0 : 1;
+}
+
 }  // namespace
 
 extern "C" {
+
+// `reps` round trips with `partner` (-1: this rank sits the round out).  COLLECTIVE in its
+// bookkeeping: every rank of the group calls it once per round -- the sequence numbers advance
+// by `reps` on every rank, playing or not.  ticks2: device array of two int64.
+int ipx_peer_pingpong(void *peer, int32_t partner, int32_t reps, long long *ticks2, void *stream) {
+  if (!peer || reps < 1 || reps > (1 << 20)) return IPX_EINVAL;
+  ipx_peer *p = (ipx_peer *)peer;
+  if (partner >= p->view.world || partner == p->view.rank) return IPX_EINVAL;
+  const uint32_t seq0 = p->seq + 1;
+  p->seq += (uint32_t)reps;
+  if (p->seq == 0) p->seq = 1;
+  if (partner < 0) return IPX_OK;
+  if (!ticks2 || !ipx_peer_ready(peer)) return IPX_EINVAL;
+  hipLaunchKernelGGL(k_peer_pingpong, dim3(1), dim3(64), 0, (hipStream_t)stream, p->view,
+                     (int)partner, seq0, (int)reps, ticks2);
+  IPX_CHECK_LAUNCH();
+  return IPX_OK;
+}
 
 int ipx_peer_handle_bytes(void) { return (int)sizeof(hipIpcMemHandle_t); }
 

@@ -81,6 +81,7 @@ _SIGNATURES = {
     "ipx_cg_shard2_resident_ok": [_P, _P],
     "ipx_cg_shard2_resident": [_P, _P, _I32, _I32, _P],
     "ipx_cg_save_pb": [_P, _P],
+    "ipx_peer_pingpong": [_P, _I32, _I32, _P, _P],
     "ipx_peer_attach_resident": [_P, _I64],
     "ipx_peer_export_resident": [_P, _P],
     "ipx_peer_import_resident": [_P, _I32, _P],

@@ -429,6 +429,29 @@ class PeerMailbox:
     def resident_launches(self):
         return int(self.lib.ipx_peer_resident_launches(ctypes.c_void_p(self.handle)))
 
+    def pingpong(self, reps=200):
+        """Round-trip time (us) of one tagged word between this rank and each neighbour, measured
+        inside one kernel per pair (csrc/peer.hip k_peer_pingpong): what a cross-GPU hand-off
+        costs on this node.  Collective (two rounds: pairs (0,1)(2,3).., then (1,2)(3,4)..);
+        returns {neighbour rank: us per round trip} for this rank's neighbours."""
+        from . import device as dv
+        comm, out = self.comm, {}
+        ticks = torch.zeros(2, dtype=torch.int64, device=dv.ctx().device)
+        for parity in (0, 1):
+            r = comm.rank
+            partner = r + 1 if (r - parity) % 2 == 0 else r - 1
+            if r < parity or partner < 0 or partner >= comm.world:
+                partner = -1
+            self._hip.call("ipx_peer_pingpong", ctypes.c_void_p(self.handle), int(partner), int(reps),
+                           ctypes.c_void_p(ticks.data_ptr()), dv.stream_ptr())
+            if partner >= 0:
+                t = ticks.tolist()
+                if t[1]:
+                    raise self._hip.IpxError("peer mailbox: the ping-pong with rank %d timed out"
+                                             % partner)
+                out[partner] = t[0] / 100.0 / reps          # 100 MHz ticks -> us per round trip
+        return out
+
     def set_timeout(self, seconds):
         """Deadline of a kernel's wait for a peer's word (default 10 s; past it: stop code 7,
         the group falls back to torch.distributed together)."""

@@ -687,7 +687,18 @@ def test_bench_two_rank_rehearsal():
     assert (fs["status"], fs["niter"], fs["cg_niter"]) == (1, 25, 34)
     # the timed region ran on the peer mailboxes: no torch.distributed call inside it, one C
     # call per restart segment; the torch.distributed transport was timed next to it
-    assert d["transport"] == "ipc"
+    assert d["transport"] == "ipc" and d["transport_fallback_reason"] is None
+    # the preflight of a multi-GPU run (before any timing): the backend's all-reduce saw every
+    # rank, the peers' buffers are mapped, one tagged-word ping-pong per neighbour pair was timed
+    # ("nccl" is not what this rehearsal runs on: the RCCL count is then null, the key exists)
+    pf = d["preflight"]
+    assert pf["ranks_seen"] == 2 and pf["mailbox_mapped"] and pf["mailbox_error"] is None
+    assert pf["mailbox_pingpong_us"]["0-1"] > 0 and d["mailbox_pingpong_us"] == pf["mailbox_pingpong_us"]
+    assert "rccl_ranks_seen" in d and d["rccl_ranks_seen"] is None
+    assert pf["torch_distributed_backend"] == "gloo" and pf["distinct_devices"] is False
+    # (two ranks of ~190 workgroups each cannot be resident side by side on ONE GPU: the group
+    # refuses the resident form here and runs the three launches)
+    assert pf["resident_form"] is False
     per = d["host_calls_per_iteration_in_the_timed_region"]
     assert per["torch_distributed_all_reduce"] == 0 and per["torch_distributed_exchange"] == 0
     assert 0 < per["c_calls"] <= 0.2
