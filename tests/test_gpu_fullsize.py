@@ -381,4 +381,12 @@ def test_config5_full_size_properties():
     active = int(np.sum(np.abs(np.abs(x) - 0.8) < 1e-6))
     assert 0.25 * n < active < 0.31 * n
     assert abs(res.fun / n - (-0.15184)) <= 0.02 * 0.15184        # measured: -0.15046
-    assert 55 <= res.niter <= 85 and 10000 < res.cg_niter < 100000
+    # ... and the run's OWN record (the brackets above would let a regression that
+    # doubles the CG count pass).  The kernels reduce in fixed orders, so the run is reproducible:
+    # rounds 4 and 5 both took 76 outer / 51 698 CG iterations to 141 840 active bounds
+    # (profiles/r04_bench_line.json, r05_bench_line.json: config5).  A change of a kernel's
+    # summation order moves the chaotic tail a little (the n = 2e4 run: |niter - gold| <= 3 under
+    # such changes), never the active set of a converged run.
+    assert active == 141840
+    assert abs(res.niter - 76) <= 3
+    assert abs(res.cg_niter - 51698) <= 0.10 * 51698
