@@ -199,6 +199,15 @@ def check(code, what=""):
     return code
 
 
+_BOUND = {}
+
+
 def call(name, *args):
-    """Call an int-returning entry point and raise on a negative status."""
-    return check(getattr(load(), name)(*args), name)
+    """Call an int-returning entry point and raise on a negative status.  (The bound function is
+    looked up once per name: ``getattr`` on the CDLL and two Python frames per launch were a
+    third of its host cost.)"""
+    fn = _BOUND.get(name)
+    if fn is None:
+        fn = _BOUND[name] = getattr(load(), name)
+    rc = fn(*args)
+    return rc if rc >= 0 else check(rc, name)

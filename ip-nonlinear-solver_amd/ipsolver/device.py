@@ -56,18 +56,31 @@ _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
 def stream_ptr():
-    """Raw hipStream_t of torch's current stream on the context's device."""
+    """Raw hipStream_t of torch's current stream on the context's device, as the plain integer
+    ctypes converts for a ``void *`` parameter (every entry point declares its argtypes)."""
     if _raw_stream is not None:            # ~0.3 us; the Stream object below costs ~8 us
-        return ctypes.c_void_p(_raw_stream(ctx().device.index))
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        inst = _Context._inst
+        return _raw_stream((inst if inst is not None else ctx()).device.index)
+    return torch.cuda.current_stream().cuda_stream
 
 
 def _p(t):
-    return None if t is None else ctypes.c_void_p(t.data_ptr())
+    """Device address of a tensor for a ``void *`` parameter (an integer: a ctypes.c_void_p
+    object per argument was a fifth of a launch's host cost)."""
+    return None if t is None else t.data_ptr()
 
 
 def _empty(n):
-    return torch.empty(int(n), dtype=_F64, device=ctx().device)
+    inst = _Context._inst
+    return torch.empty(int(n), dtype=_F64, device=(inst if inst is not None else ctx()).device)
+
+
+def _wrap(t):
+    """A DVec around a tensor this module allocated itself (fp64, 1-D, contiguous, on the
+    device: the checks of ``DVec.__init__`` are for tensors that come from outside)."""
+    v = DVec.__new__(DVec)
+    v.t = t
+    return v
 
 
 def _read(k):
@@ -103,7 +116,7 @@ class DVec:
     def full(n, value):
         out = _empty(n)
         _hip.call("ipx_fill", int(n), float(value), _p(out), stream_ptr())
-        return DVec(out)
+        return _wrap(out)
 
     def to_host(self):
         return self.t.cpu().numpy()
@@ -138,7 +151,7 @@ class DVec:
         out = _empty(len(self))
         _hip.call("ipx_axpby", len(self), float(a), _p(self.t), float(b),
                   _p(other.t) if other is not None else None, _p(out), stream_ptr())
-        return DVec(out)
+        return _wrap(out)
 
     def add_scaled(self, o, a):
         """self + a*o in one pass (1.0*x is exact, so this equals x + a*o)."""
@@ -153,7 +166,7 @@ class DVec:
             return self._axpby(1.0, o, 1.0)
         out = _empty(len(self))
         _hip.call("ipx_affine", len(self), 1.0, _p(self.t), float(o), _p(out), stream_ptr())
-        return DVec(out)
+        return _wrap(out)
 
     __radd__ = __add__
 
@@ -165,7 +178,7 @@ class DVec:
     def __rsub__(self, o):          # scalar - vec
         out = _empty(len(self))
         _hip.call("ipx_affine", len(self), -1.0, _p(self.t), float(o), _p(out), stream_ptr())
-        return DVec(out)
+        return _wrap(out)
 
     def __neg__(self):
         return self._axpby(-1.0, None, 0.0)
@@ -174,7 +187,7 @@ class DVec:
         if isinstance(o, DVec):
             out = _empty(len(self))
             _hip.call("ipx_mul", len(self), _p(self.t), _p(o.t), _p(out), stream_ptr())
-            return DVec(out)
+            return _wrap(out)
         return self._axpby(float(o), None, 0.0)
 
     __rmul__ = __mul__
@@ -461,7 +474,7 @@ class DeviceCSR:
         m, n = p.shape
         assert len(x) == n, (len(x), n)
         if out is None:
-            out = DVec(_empty(m))
+            out = _wrap(_empty(m))
         c = ctx()
         _hip.call("ipx_csr_spmv", m, n, _p(p.indptr), _p(p.indices), _p(self.val),
                   _p(p.tiles), p.ntiles, _p(x.t), float(alpha),

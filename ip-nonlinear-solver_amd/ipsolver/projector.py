@@ -668,17 +668,36 @@ def projections(A, method=None, orth_tol=1e-12, max_refin=3, tol=1e-15):
     """
     from .dense import DenseNormalSolver
     A = as_device_matrix(A)
-    if getattr(A, "constant", False):          # values declared immutable: factor once (N1)
-        key = (method, orth_tol, max_refin, tol)
-        cached = getattr(A, "_ipx_projections", None)
-        if cached is None or cached[0] != key:
-            A.constant = False
-            try:
-                cached = A._ipx_projections = (key, projections(A, method, orth_tol, max_refin,
-                                                                tol))
-            finally:
-                A.constant = True
+    # The SAME matrix object with unchanged values: the factorization made for it is returned.
+    # Values declared immutable (``constant``: linear constraints, N1) are factored once per
+    # solve; any other matrix is recognised by its value tensor's version counter -- the
+    # barrier method hands the Jacobian of its last accepted point to the next subproblem
+    # (tr_interior_point.py:338-340: the reference refactors it, 11 of config 3's 25
+    # factorizations).
+    key = (method, orth_tol, max_refin, tol, _values_version(A))
+    cached = getattr(A, "_ipx_projections", None)
+    if cached is not None and cached[0] == key:
         return cached[1]
+    out = _projections(A, method, orth_tol, max_refin, tol)
+    try:
+        A._ipx_projections = (key, out)
+    except AttributeError:
+        pass
+    return out
+
+
+def _values_version(A):
+    """Version counter of the tensor that holds a device matrix's values (None: unknown type,
+    never equal to a cached key's)."""
+    t = getattr(A, "val", None)
+    if t is None:
+        t = getattr(A, "t", None)
+    v = getattr(t, "_version", None)
+    return (id(t), v) if v is not None else object()
+
+
+def _projections(A, method, orth_tol, max_refin, tol):
+    from .dense import DenseNormalSolver
     sparse = isinstance(A, DeviceCSR)
     if sparse:
         if method not in (None, "NormalEquation", "AugmentedSystem"):
