@@ -207,9 +207,11 @@ def _sharded_backend(shard, constr, n_vars, operator_hessian=False):
     """The row-sharded backend (one process per GPU) for this problem.  Two shapes run on the
     banded partition with its device-resident loop (ipsolver/sharded.py): equality rows only,
     partitioned along their banded Jacobian (BASELINE configs 3 / 4), and nonlinear inequality
-    rows + an interval box on every variable, partitioned along the nonlinear rows (config 5).
-    Everything else the reference accepts with a sparse Jacobian -- no band, equality and
-    inequality rows together, ragged or no boxes -- runs on the plain block partition with
+    rows + an interval box on every variable, partitioned along the nonlinear rows (config 5);
+    a third -- equality and inequality rows interleaved along one band -- on the same partition
+    in the merged row order (ipsolver/sharded_mixed.py).
+    Everything else the reference accepts with a sparse Jacobian -- no band, rows whose kinds
+    do not follow the band, ragged or no boxes -- runs on the plain block partition with
     all-gather / reduce-scatter products (ipsolver/sharded_general.py).  ``operator_hessian``:
     some Hessian term is a host operator (finite differences, LinearOperator); the box form of
     the barrier problem has no operator for those, the plain partition has."""
@@ -244,6 +246,14 @@ def _sharded_backend(shard, constr, n_vars, operator_hessian=False):
         if tail.shape[1] == n_vars and not operator_hessian \
                 and (tail != sps.vstack([-eye, eye], format="csr")).nnz == 0:
             J, boxed = sps.csr_matrix(constr.J_ineq0)[:m_nl], True
+    if J is None and not dense and n_eq > 0 and n_ineq > 0 and not operator_hessian:
+        # equality and inequality rows of ONE banded Jacobian (the kinds interleaved along the
+        # band): the banded partition in the merged row order (ipsolver/sharded_mixed.py)
+        from . import sharded_mixed
+        xp = sharded_mixed.try_backend(sps.csr_matrix(constr.J_eq0), sps.csr_matrix(constr.J_ineq0),
+                                       n_vars, ops, comm)
+        if xp is not None:
+            return xp
     if J is None:
         return general()
     J = sps.csr_matrix(J)

@@ -57,7 +57,12 @@ class ShardLayout:
     non-decreasing: every banded Jacobian) over ``world`` ranks.  Computed identically on
     every rank from the global pattern."""
 
-    def __init__(self, indptr, indices, shape, world, rank, row_block=ROW_BLOCK, halo_blocks=1):
+    def __init__(self, indptr, indices, shape, world, rank, row_block=ROW_BLOCK, halo_blocks=1,
+                 subsets=None):
+        """``subsets``: {name: sorted row indices} -- further spaces made of SOME of the rows
+        (the equality / the inequality rows of a Jacobian that is banded with the two kinds
+        interleaved: ipsolver/sharded_mixed.py); a rank owns the members among its own rows
+        and keeps halo copies of those among its halo rows."""
         m, n = int(shape[0]), int(shape[1])
         indptr = np.asarray(indptr, dtype=np.int64)
         indices = np.asarray(indices, dtype=np.int64)
@@ -116,14 +121,23 @@ class ShardLayout:
                     raise ValueError("halo of rank %d reaches beyond its neighbour: fewer "
                                      "ranks or a larger problem" % r)
         self.me = self.ranks[rank]
+        self.subsets = {k: np.asarray(v, dtype=np.int64) for k, v in (subsets or {}).items()}
+        # first global entry of every rank's own part, per space (ShardVec.to_host gathers by it)
+        self.cuts = {"col": C, "row": R}
+        for k, idx in self.subsets.items():
+            self.cuts[k] = [int(np.searchsorted(idx, r, side="left")) for r in R]
 
     def geom(self, kind, rank=None):
         """(global start of the local array, local length, own_lo, own_hi) for
-        ``kind`` = "col" (variables) / "row" (constraints)."""
+        ``kind`` = "col" (variables) / "row" (constraints) / a named subset of the rows."""
         d = self.ranks[self.rank if rank is None else rank]
         if kind == "col":
             return d["x0"], d["x1"] - d["x0"], d["c0"] - d["x0"], d["c1"] - d["x0"]
-        return d["E0"], d["E1"] - d["E0"], d["R0"] - d["E0"], d["R1"] - d["E0"]
+        if kind == "row":
+            return d["E0"], d["E1"] - d["E0"], d["R0"] - d["E0"], d["R1"] - d["E0"]
+        idx = self.subsets[kind]
+        e0, r0, r1, e1 = (int(np.searchsorted(idx, d[k], side="left")) for k in ("E0", "R0", "R1", "E1"))
+        return e0, e1 - e0, r0 - e0, r1 - e0
 
     def sends(self, kind):
         """How many own entries the left / right neighbour keeps as its halo."""
@@ -138,6 +152,8 @@ class ShardLayout:
         return left, right
 
     def global_len(self, kind):
+        if kind in self.subsets:
+            return len(self.subsets[kind])
         return self.n if kind == "col" else self.m
 
 
@@ -549,6 +565,19 @@ class HipOps:
 
     def box_sphere_reduce(self, z, d, dscale, lb, ub):
         return self.dv.box_sphere_reduce(z, d, dscale, lb, ub)
+
+    def index(self, idx):
+        """A host index array as the operand of ``take``."""
+        return torch.from_numpy(np.ascontiguousarray(idx, dtype=np.int32)).to(self.dv.ctx().device)
+
+    def take(self, v, idx):
+        """v[idx] (a gather kernel)."""
+        from . import _hip
+        out = self.dv._empty(idx.numel())
+        if idx.numel():
+            _hip.call("ipx_gather", idx.numel(), self.dv._p(v.t), self.dv._p(idx), None, None,
+                      self.dv._p(out), self.dv.stream_ptr())
+        return self.dv.DVec(out)
 
     def csr(self, M, row_breaks=None, col_breaks=None):
         """Local block on the device; row tiles (and those of the stored transpose) are cut
@@ -1123,7 +1152,10 @@ class ShardProjector:
         self.A, self.sh = A, A.sh
         self.orth_tol, self.max_refin = orth_tol, max_refin
         plain = A.row_kind == "row" and A.col_kind == "col"
-        self.solver = (self.sh.ops.normal_solver(A.local) if plain
+        # (``merged``: the local block is kept in the order in which A A' is banded, another one
+        # than the stacked spaces of its rows -- sharded_mixed.MergedRowsCSR; the solve runs in
+        # that order, ``_apply_inv`` permutes at its boundary)
+        self.solver = (self.sh.ops.normal_solver(A.local) if plain or getattr(A, "merged", False)
                        else self.sh.ops.any_normal_solver(A.local))
         self.norm_A = A.frobenius_norm()
         self.stats = {"solves": 0, "refinements": 0, "cancellation_steps": 0}
@@ -1156,7 +1188,8 @@ class ShardProjector:
                     "truncated to own + halo rows would not be the global one")
             return
         w = sh.full(self.A.row_kind, 1.0)
-        v = sh.sync(ShardVec(self.solver.solve(w.loc), sh, self.A.row_kind))
+        v = self._apply_inv(w)
+        self.stats["solves"] -= 1
         res = self.A.dot(self.A.T.dot(v)) - w
         err = np.sqrt(res.sumsq_amax()[0] / max(len(w), 1))
         if not err <= 1e-9:
@@ -1167,7 +1200,12 @@ class ShardProjector:
 
     def _apply_inv(self, w):
         self.stats["solves"] += 1
-        return self.sh.sync(ShardVec(self.solver.solve(w.loc), self.sh, self.A.row_kind))
+        A = self.A
+        if getattr(A, "merged", False):
+            loc = A.to_stacked(self.solver.solve(A.to_banded(w.loc)))
+        else:
+            loc = self.solver.solve(w.loc)
+        return self.sh.sync(ShardVec(loc, self.sh, A.row_kind))
 
     def orthogonality(self, z):
         norm_z = np.sqrt(z.sumsq_amax()[0])
@@ -1245,7 +1283,7 @@ def _banded_of(P):
     from .projector import BandedNormalSolver
     from .boxschur import BoxSchurNormalSolver
     sv = P.solver
-    if P.plain:
+    if P.plain or getattr(P.A, "merged", False):
         return sv if isinstance(sv, BandedNormalSolver) and sv.perm is None else None
     if P.A.row_kind != ShardedBackend.INEQ or P.A.col_kind != ShardedBackend.Z:
         return None

@@ -127,6 +127,12 @@ class NumpyOps:
         return [float(d.dot(d)), float(z.dot(d)), float(z.dot(z)), ta, tb, zero_out,
                 float(np.count_nonzero(nz))]
 
+    def index(self, idx):
+        return np.asarray(idx, dtype=np.int64)
+
+    def take(self, v, idx):                                      # ipx_gather
+        return np.asarray(v)[idx]
+
     def csr(self, M, row_breaks=None, col_breaks=None):
         return _LocalCSR(M)
 

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Box-side refresh of the evidence under profiles/ (run through gpurun from the repo root):
 # traces go to /tmp, only the summaries to gpurun_out/final/ (copy them into profiles/ by hand).
-#   bash scripts/refresh_profiles.sh <commit> [steps: bench trace pmc config5]
+#   bash scripts/refresh_profiles.sh <commit> [steps: bench trace pmc pmc5 config5]
 COMMIT=${1:-?}; shift
 STEPS=${@:-bench trace pmc config5}
 R=/root/repo; OUT=$R/gpurun_out/final; mkdir -p $OUT
@@ -15,13 +15,18 @@ trace)
   cp $(find /tmp/bp -name '*kernel_stats.csv' | head -1) $OUT/bench_kernel_stats.csv
   (cd $R && python3 scripts/kernel_durations_by_size.py /tmp/bp $OUT/bench_kernel_durations_by_size.json > /dev/null);;
 pmc)
-  for n in 1000000 4000000; do
-    tag=n1e6; note="n=1e6, m=1e5"; [ $n = 4000000 ] && tag=n4e6 && note="n=4e6, m=4e5"
+  for n in 1000000 16000000; do
+    tag=n1e6; note="n=1e6, m=1e5"; [ $n = 16000000 ] && tag=n16e6 && note="n=1.6e7, m=1.6e6"
     for c in FETCH_SIZE WRITE_SIZE; do
-      rm -rf /tmp/pmc_$c; timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -- python3 $R/scripts/pmc_workload.py $n > /dev/null 2>/tmp/pmc_$c.err
+      rm -rf /tmp/pmc_$c; timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -- python3 $R/scripts/pmc_workload.py $n > /dev/null 2>/tmp/pmc_$c.err
     done
     (cd $R && python3 scripts/pmc_summarize.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE $OUT/pmc_traffic_$tag.json "$note" $COMMIT | tail -5)
   done;;
+pmc5)
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rm -rf /tmp/pmc5_$c; timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc5_$c -- python3 $R/scripts/pmc_config5.py > /dev/null 2>/tmp/pmc5_$c.err
+  done
+  (cd $R && python3 scripts/pmc_config5.py --summarize /tmp/pmc5_FETCH_SIZE /tmp/pmc5_WRITE_SIZE $OUT/pmc_traffic_config5.json | tail -8);;
 config5)
   rm -rf /tmp/p5; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p5 -o c5 -- python3 $R/scripts/config5.py 500000 50000 > /tmp/c5.out 2>/tmp/c5.err
   grep '^{' /tmp/c5.out > $OUT/config5_under_trace.json

@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.join(ROOT, "ip-nonlinear-solver_amd")); sys.path.inse
 import numpy as np
 
 
-def solve(n, m, bw=15, seed=0, backend_module=None, max_iter=1000):
+def solve(n, m, bw=15, seed=0, backend_module=None, max_iter=1000, options=None):
     import ipsolver
     from ipsolver import backend
     from ipsolver.synthetic import CenteredBandedNLP
@@ -27,7 +27,8 @@ def solve(n, m, bw=15, seed=0, backend_module=None, max_iter=1000):
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             return ipsolver.minimize_constrained(prob.fun, prob.x0, prob.grad, prob.hess, cons,
-                                                 callback=record, max_iter=max_iter)
+                                                 callback=record, max_iter=max_iter,
+                                                 options=dict(options or {}))
     if backend_module is not None:
         with backend.use(backend_module):
             res = run()

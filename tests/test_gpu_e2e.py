@@ -306,6 +306,30 @@ def test_mixed_equality_inequality_rows_take_the_device_loop():
     assert got.constr_violation <= 1e-8
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_interleaved_rows_hip(world, tmp_path):
+    """The same interleaved problem (tests/mixed_banded.py) through ``minimize_constrained``
+    with ``options={'shard': True}`` on `world` processes sharing cuda:0: the banded (halo)
+    partition in the merged row order (ipsolver/sharded_mixed.py) -- the local augmented
+    Jacobians factored by the plain banded solver, every subproblem on the device-resident
+    sharded loop (z in two segments: the vector kernels with own ranges, the collectives in pack
+    kernels) -- against the single-process oracle backend over the leading outer iterations."""
+    import socket
+    import torch.multiprocessing as mp
+    from test_sharded_gloo import _mixed_banded_worker, check_mixed_banded
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    n, m, max_iter = 12000, 1200, 25
+    path = str(tmp_path / "mixed_banded_hip.npz")
+    mp.spawn(_mixed_banded_worker, args=(world, port, path, n, m, max_iter, True), nprocs=world,
+             join=True)
+    got = np.load(path)
+    backends, fused_calls, cg_niter = (int(v) for v in got["stats"])
+    assert backends == 1 and fused_calls >= 10 and cg_niter > 0      # the fused sharded loop
+    check_mixed_banded(got, n, m, max_iter)
+
+
 def test_product_never_imports_the_oracle():
     """Run a solve in a fresh interpreter: the product must not load oracle.*
     (no CPU fallback), and must have loaded the in-tree libipx.so."""
