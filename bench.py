@@ -586,6 +586,51 @@ def config2_leg():
             torch.cuda.synchronize()
             wall_d = time.time() - t0
     del At, Ht
+    # dense NONLINEAR equality constraints at the same size: the Jacobian changes at every
+    # accepted step, every one of them pays Gram + Cholesky + inverse (the reference: a pivoted
+    # QR per step, 76 % of such a run: projections.py:179)
+    dense_nl = None
+    try:
+        import ipsolver.dense as _dense
+        from ipsolver.synthetic import DenseDeviceCallbacks
+        cbn = DenseDeviceCallbacks.on_device(n, m)
+        built = {"n": 0, "s": 0.0}
+        real_init = _dense.DenseNormalSolver.__init__
+
+        def timed_init(self, Amat):
+            torch.cuda.synchronize()
+            t_ = time.perf_counter()
+            real_init(self, Amat)
+            torch.cuda.synchronize()
+            built["n"] += 1
+            built["s"] += time.perf_counter() - t_
+        _dense.DenseNormalSolver.__init__ = timed_init
+        try:
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                for attempt in range(2):
+                    built["n"], built["s"] = 0, 0.0
+                    torch.cuda.synchronize()
+                    t0 = time.time()
+                    res_n = ipsolver.minimize_constrained(
+                        cbn.fun, cbn.x0, cbn.grad, cbn.hess, cbn.constraints(ipsolver),
+                        method="equality_constrained_sqp")
+                    torch.cuda.synchronize()
+                    wall_n = time.time() - t0
+        finally:
+            _dense.DenseNormalSolver.__init__ = real_init
+        dense_nl = {"workload": "dense nonlinear equality constraints c(x) = A x + kappa/2 W (x*x) "
+                                "- b, n=10000, m=2000 (synthetic.DenseDeviceCallbacks.on_device), "
+                                "equality_constrained_sqp, device callbacks",
+                    "seconds": wall_n, "status": int(res_n.status), "niter": int(res_n.niter),
+                    "cg_niter": int(res_n.cg_niter), "optimality": float(res_n.optimality),
+                    "constr_violation": float(res_n.constr_violation),
+                    "factorizations": built["n"],
+                    "ms_per_factorization_gram_cholesky_inverse": 1e3 * built["s"] / max(built["n"], 1)}
+        del cbn
+        torch.cuda.empty_cache()
+    except Exception as exc:                      # never lose the block over the extra problem
+        dense_nl = {"error": repr(exc)}
     # the Gram kernel alone
     Ad = DeviceDense.from_host(A)
     lib = _hip.load()
@@ -634,6 +679,7 @@ def config2_leg():
                                          "on the merit function's rounding floor and the run "
                                          "stops on xtol at an optimality of a few 1e-8 (the "
                                          "iterate agrees with the reference's)"},
+            "dense_nonlinear": dense_nl,
             "gram_mfma": {"kernel": "k_gram_mfma (v_mfma_f64_16x16x4_f64) in %d K-splits + "
                                     "k_gram_reduce" % splits, "ms": ms,
                           "flop_executed": flop, "tiles": [nt * (nt + 1) // 2, nt * nt],

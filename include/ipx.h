@@ -154,9 +154,14 @@ int ipx_gram_f64_mfma_split(int64_t m, int64_t n, const double *A, int64_t lda, 
 /* Same G from a CSR A (sparse Jacobian whose A A' is not narrow-banded). */
 int ipx_aat_dense(int64_t m, const int32_t *rowptr, const int32_t *colidx, const double *val,
                   double *G, void *stream);
-/* work: M + 1 doubles; work[M] <- min pivot / original diagonal (~1/cond(G)). */
+/* Blocked Cholesky G = L L' in place (64 x 64 tiles, the trailing updates on the fp64 matrix
+ * cores) and X = G^-1 from it (in-place triangular inverse by recursive doubling in G's
+ * storage -- G is consumed --, then X = L^-T L^-1 as MFMA tiles): what a dense NONLINEAR
+ * constraint pays per accepted step (reference: a pivoted QR, projections.py:175-233).
+ * M = ipx_dense_padded(m), a multiple of 64.
+ * work: M + 1 doubles; work[M] <- min pivot / original diagonal (~1/cond(G)). */
 int ipx_chol_factor(int64_t M, double *G, int *flag, double *work, void *stream);
-int ipx_chol_inverse(int64_t M, const double *G, double *X, void *stream);
+int ipx_chol_inverse(int64_t M, double *G, double *X, void *stream);
 
 /* ---- banded SPD solve with S = A A' (normal equations, projections.py:58-90;
  * replaces SuperLU solve :102,120 / CHOLMOD :62).  Partitioned (SPIKE-style)

@@ -12,7 +12,6 @@
 
 namespace {
 
-constexpr int NB = 32;   // tile edge of the factorization kernels
 
 // ---------------------------------------------------------------- gemv
 // y_r = alpha * sum_c A[r][c] x[c]  [+ diag_r x_r] [+ beta yin_r]; one wave per row.
@@ -294,8 +293,98 @@ k_aat_dense(int m, const int32_t *__restrict__ rowptr, const int32_t *__restrict
   G[(int64_t)j * M + i] = s;
 }
 
-// ------------------------------------------------------- blocked Cholesky
-// Diagonal tile: G_kk = L_kk L_kk'.  One workgroup of NB x NB lanes.
+// ------------------------------------------------------- blocked Cholesky + inverse (round 5)
+// G = L L' and G^-1 per accepted step of a dense NONLINEAR constraint (the reference spends
+// 76 % of such a run in its pivoted QR, projections.py:179).  Rounds 1-4: 32 x 32 tiles of scalar
+// FMAs, 441 launches, 2.7 + 3.6 ms at M = 2016.  Now 64 x 64 tiles with every matrix-matrix
+// product on the fp64 matrix cores (the Gram kernel's tile: 4 waves x 2 x 2
+// v_mfma_f64_16x16x4_f64 out of K-permuted LDS panels):
+//   factor   right-looking, per tile column k: the diagonal tile in one workgroup (LDS), the
+//            panel below it by forward substitution (a wave per 64 rows), the trailing
+//            update G_ij -= L_ik L_jk' as MFMA tiles                         (3 launches x M/64)
+//   inverse  X = L^-1 IN PLACE by recursive doubling: all diagonal tiles at once, then per level
+//            s = 64, 128, ...: X21 = -X22 (L21 X11) for every pair of neighbouring s-blocks
+//            -- two batched MFMA launches per level, log2(M/64) levels instead of M/32
+//            dependent sweeps -- with the intermediate L21 X11 parked in the (otherwise unused)
+//            upper triangle; then G^-1 = X'X as MFMA tiles over the rows where X is non-zero.
+constexpr int FB = 64;           // tile edge of the factorization
+
+// element (i, k) of a 64 x K operand panel at p[i * rs + k * ks]
+struct Opnd {
+  const double *p;
+  int64_t rs, ks;
+};
+
+__device__ __forceinline__ void opnd_fetch(const Opnd &O, int k0, int tid, v2d (&reg)[4]) {
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    int r, t;
+    gram_slot(tid, u, r, t);
+    const double *src = O.p + (int64_t)r * O.rs + (int64_t)(k0 + 2 * t) * O.ks;
+    reg[u] = (v2d){src[0], src[O.ks]};
+  }
+}
+
+// acc (the 64 x 64 tile C = P Q', summed over k in [0, K), K a multiple of 32) by the four
+// waves of the workgroup: element (row, col) = (wr + 16 a + lk + 4 reg, wc + 16 b + lr) in
+// acc[a][b][reg] (k_gram_mfma's layout).  sA / sB: GPANEL doubles each.
+__device__ __forceinline__ void tile_pqt(const Opnd &P, const Opnd &Q, int K, v4d (&acc)[2][2],
+                                         double *sA, double *sB) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
+  const int lr = lane & 15, lk = lane >> 4;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+  if (K <= 0) return;
+  v2d ra[4], rb[4];
+  opnd_fetch(P, 0, tid, ra);
+  opnd_fetch(Q, 0, tid, rb);
+  for (int k0 = 0; k0 < K; k0 += GK) {
+    gram_stash(sA, tid, ra);
+    gram_stash(sB, tid, rb);
+    __syncthreads();
+    if (k0 + GK < K) {
+      opnd_fetch(P, k0 + GK, tid, ra);
+      opnd_fetch(Q, k0 + GK, tid, rb);
+    }
+    const double *qa = sA + lk * GSUB + (wr + lr) * GSP;
+    const double *qb = sB + lk * GSUB + (wc + lr) * GSP;
+#pragma unroll
+    for (int j = 0; j < GK / 8; ++j) {
+      const v2d a0 = *reinterpret_cast<const v2d *>(qa + 2 * j);
+      const v2d a1 = *reinterpret_cast<const v2d *>(qa + 16 * GSP + 2 * j);
+      const v2d b0 = *reinterpret_cast<const v2d *>(qb + 2 * j);
+      const v2d b1 = *reinterpret_cast<const v2d *>(qb + 16 * GSP + 2 * j);
+      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.x, b0.x, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.x, b1.x, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.x, b0.x, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.x, b1.x, acc[1][1], 0, 0, 0);
+      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.y, b0.y, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.y, b1.y, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.y, b0.y, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.y, b1.y, acc[1][1], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+}
+
+// for (row, col, value) of the tile held in acc
+#define IPX_TILE_FOREACH(acc, row, col, val, ...)                                    \
+  do {                                                                                \
+    const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;                     \
+    const int wr_ = (wave_ >> 1) * 32, wc_ = (wave_ & 1) * 32;                        \
+    const int lr_ = lane_ & 15, lk_ = lane_ >> 4;                                     \
+    _Pragma("unroll") for (int a_ = 0; a_ < 2; ++a_)                                  \
+    _Pragma("unroll") for (int b_ = 0; b_ < 2; ++b_)                                  \
+    _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                                \
+      const int row = wr_ + 16 * a_ + lk_ + 4 * g_, col = wc_ + 16 * b_ + lr_;        \
+      const double val = acc[a_][b_][g_];                                             \
+      __VA_ARGS__;                                                                    \
+    }                                                                                 \
+  } while (0)
+
 // work[0..M) = the diagonal of G before the factorization; work[M] = running minimum of
 // pivot / original diagonal entry (how many digits the factorization lost: ~1/cond(G)).
 __global__ void __launch_bounds__(IPX_BLOCK) k_save_diag(const double *G, int M, double *work) {
@@ -304,130 +393,253 @@ __global__ void __launch_bounds__(IPX_BLOCK) k_save_diag(const double *G, int M,
   if (i == 0) work[M] = 1.0;
 }
 
-__global__ void __launch_bounds__(NB *NB)
-k_potrf_tile(double *G, int M, int kb, int *flag, double *work) {
-  __shared__ double T[NB][NB + 1];
-  const int r = threadIdx.y, c = threadIdx.x;
-  double *g = G + ((int64_t)kb * NB) * M + (int64_t)kb * NB;
-  T[r][c] = g[(int64_t)r * M + c];
-  __syncthreads();
-  for (int j = 0; j < NB; ++j) {
-    if (r == j && c == j) {
-      const double d = T[j][j];
-      const double d0 = work[kb * NB + j];
-      // numerically rank deficient: the pivot lost 43 bits against its diagonal entry
-      // flag bit 1: the pivot lost 43 bits against its diagonal entry (numerically rank
-      // deficient, the factorization goes on); bit 4: it is not positive (no factorization)
-      if (!(d > IPX_PIVOT_RTOL * d0)) atomicOr(flag, (d > 0.0) ? 1 : 5);
-      if (d > 0.0) work[M] = fmin(work[M], d / d0);     // (one workgroup at a time: no race)
-      T[j][j] = sqrt(d > 0.0 ? d : 1.0);
+// Diagonal tile kb: G_kk = L_kk L_kk' by one workgroup, the tile in REGISTERS: thread (ty, tx)
+// owns the 4 x 4 elements (ty + 16 a, tx + 16 b).  Per column j: its owners publish the column
+// (as updated so far) to LDS, one barrier, every thread forms L[r][j] = col[r] / sqrt(col[j])
+// for its rows and columns itself (same expression everywhere: same bits) and updates its own
+// elements -- one barrier per column and no global access inside the loop (the first version
+// read and wrote the pivot statistics in global memory from the loop's serial section: 60 us
+// per tile).  The strict upper triangle of the tile is zeroed.
+__global__ void __launch_bounds__(IPX_BLOCK)
+k_potrf64(double *G, int M, int kb, int *flag, double *work) {
+  __shared__ double col[2][FB];
+  __shared__ double diag0[FB];
+  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+  double *g = G + ((int64_t)kb * FB) * M + (int64_t)kb * FB;
+  double e[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) e[a][b] = g[(int64_t)(ty + 16 * a) * M + tx + 16 * b];
+  if (tid < FB) diag0[tid] = work[kb * FB + tid];
+  int bits = 0;
+  double ratio = 1.0;
+  // (the columns in four groups of sixteen: the group index is a compile-time constant in each
+  // copy of the inner loop, so every index into e[][] is static -- one 64-trip loop indexed
+  // e[a][j >> 4] dynamically and the tile went to scratch memory: 72 us per tile)
+#pragma unroll
+  for (int b0 = 0; b0 < 4; ++b0) {
+    for (int jx = 0; jx < 16; ++jx) {
+      const int j = 16 * b0 + jx, cur = j & 1;
+      if (tx == jx) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) col[cur][ty + 16 * a] = e[a][b0];
+      }
+      __syncthreads();
+      const double d = col[cur][j];
+      const double dd = d > 0.0 ? d : 1.0;
+      // (1 / sqrt and its product with d instead of sqrt and a division: half the length of
+      // the dependent chain every column waits for; L[j][j] = d / sqrt(d) to an ulp, and every
+      // entry of column j is scaled by the same number)
+      const double rs = rsqrt(dd), sq = dd * rs;
+      if (tid == 0) {
+        // bit 1: the pivot lost 43 bits against its diagonal entry (numerically rank deficient,
+        // the factorization goes on); bit 4: it is not positive (no factorization)
+        if (!(d > IPX_PIVOT_RTOL * diag0[j])) bits |= (d > 0.0) ? 1 : 5;
+        if (d > 0.0) ratio = fmin(ratio, d / diag0[j]);
+      }
+      double lr[4], lc[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) lr[a] = col[cur][ty + 16 * a] * rs;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) lc[b] = b >= b0 ? col[cur][tx + 16 * b] * rs : 0.0;
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const int r = ty + 16 * a;
+        {                                               // the group of column j itself
+          const int c = tx + 16 * b0;
+          if (c == j) e[a][b0] = r == j ? sq : lr[a];                // column j is final
+          else if (c > j && r >= c) e[a][b0] = __builtin_fma(-lr[a], lc[b0], e[a][b0]);
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          if (b > b0 && r >= tx + 16 * b) e[a][b] = __builtin_fma(-lr[a], lc[b], e[a][b]);
+        }
+      }
     }
-    __syncthreads();
-    if (c == j && r > j) T[r][j] /= T[j][j];
-    __syncthreads();
-    if (c > j && r >= c) T[r][c] -= T[r][j] * T[c][j];
-    __syncthreads();
   }
-  g[(int64_t)r * M + c] = (c <= r) ? T[r][c] : 0.0;
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int r = ty + 16 * a, c = tx + 16 * b;
+      g[(int64_t)r * M + c] = (c <= r) ? e[a][b] : 0.0;
+    }
+  if (tid == 0) {
+    if (bits) atomicOr(flag, bits);
+    work[M] = fmin(work[M], ratio);             // (one workgroup at a time: no race)
+  }
 }
 
-// Panel: G_ik <- G_ik L_kk^-T for every tile row i > k (one workgroup each).
-__global__ void __launch_bounds__(NB *NB)
-k_trsm_panel(double *G, int M, int kb) {
-  __shared__ double Lk[NB][NB + 1];
-  __shared__ double P[NB][NB + 1];
-  const int r = threadIdx.y, c = threadIdx.x;
+// v of lane k of the quad, in every lane of the quad (k a constant after unrolling)
+__device__ __forceinline__ double quad_bcast(double v, int k) {
+  switch (k) {
+    case 0: return ipx_dpp<0x00>(v);
+    case 1: return ipx_dpp<0x55>(v);
+    case 2: return ipx_dpp<0xAA>(v);
+    default: return ipx_dpp<0xFF>(v);
+  }
+}
+
+// Panel below the diagonal tile: G_ik <- G_ik L_kk^-T for the tile rows i > kb, 64 rows per
+// workgroup, FOUR lanes per row: x_j = (a_j - sum_{t<j} x_t L[j][t]) / L[j][j] with the sum
+// dealt over the quad (lane q holds x_t for t = q mod 4, in registers: both loops fully
+// unrolled, static indices) and combined by two DPP quad permutes -- the dependent chain per
+// column is j / 4 multiply-adds instead of j (one lane per row: 22 us per tile column; the
+// first version, with the row in LDS, 80).  The reciprocals of the diagonal are formed once.
+__global__ void __launch_bounds__(IPX_BLOCK)
+k_trsm64(double *G, int M, int kb) {
+  __shared__ double Lk[FB][FB + 1];
+  __shared__ double P[FB][FB + 1];
+  __shared__ double rinv[FB];
+  const int tid = threadIdx.x;
   const int ib = kb + 1 + blockIdx.x;
-  const double *lk = G + ((int64_t)kb * NB) * M + (int64_t)kb * NB;
-  double *p = G + ((int64_t)ib * NB) * M + (int64_t)kb * NB;
-  Lk[r][c] = lk[(int64_t)r * M + c];
-  P[r][c] = p[(int64_t)r * M + c];
-  __syncthreads();
-  // row r of the tile: x L' = p  ->  x_j = (p_j - sum_{t<j} x_t L[j][t]) / L[j][j]
-  for (int j = 0; j < NB; ++j) {
-    if (c == j) P[r][j] /= Lk[j][j];
-    __syncthreads();
-    if (c > j) P[r][c] -= P[r][j] * Lk[c][j];
-    __syncthreads();
+  const double *lk = G + ((int64_t)kb * FB) * M + (int64_t)kb * FB;
+  double *p = G + ((int64_t)ib * FB) * M + (int64_t)kb * FB;
+  for (int e = tid; e < FB * FB; e += IPX_BLOCK) {
+    const int r = e >> 6, c = e & 63;
+    Lk[r][c] = lk[(int64_t)r * M + c];
+    P[r][c] = p[(int64_t)r * M + c];
   }
-  p[(int64_t)r * M + c] = P[r][c];
-}
-
-// Trailing update: G_ij -= L_ik L_jk' for k < j <= i.
-__global__ void __launch_bounds__(NB *NB)
-k_syrk_update(double *G, int M, int kb) {
-  __shared__ double Li[NB][NB + 1];
-  __shared__ double Lj[NB][NB + 1];
-  const int r = threadIdx.y, c = threadIdx.x;
-  const int ib = kb + 1 + blockIdx.y, jb = kb + 1 + blockIdx.x;
-  if (jb > ib) return;
-  Li[r][c] = G[((int64_t)ib * NB + r) * M + (int64_t)kb * NB + c];
-  Lj[r][c] = G[((int64_t)jb * NB + r) * M + (int64_t)kb * NB + c];
   __syncthreads();
-  double s = 0.0;
-#pragma unroll 8
-  for (int t = 0; t < NB; ++t) s += Li[r][t] * Lj[c][t];
-  G[((int64_t)ib * NB + r) * M + (int64_t)jb * NB + c] -= s;
-}
-
-// ------------------------------------------------------- blocked inverse
-// X starts as I; forward sweep X <- L^-1 X, backward sweep X <- L^-T X.
-// Tile row kb of X: solve with the diagonal tile (one workgroup per tile column).
-template <bool TRANS>
-__global__ void __launch_bounds__(NB *NB)
-k_inv_diag(const double *__restrict__ G, double *X, int M, int kb) {
-  __shared__ double Lk[NB][NB + 1];
-  __shared__ double B[NB][NB + 1];
-  const int r = threadIdx.y, c = threadIdx.x;
-  const int cb = blockIdx.x;
-  const double *lk = G + ((int64_t)kb * NB) * M + (int64_t)kb * NB;
-  double *x = X + ((int64_t)kb * NB) * M + (int64_t)cb * NB;
-  Lk[r][c] = lk[(int64_t)r * M + c];
-  B[r][c] = x[(int64_t)r * M + c];
+  if (tid < FB) rinv[tid] = 1.0 / Lk[tid][tid];
+  const int row = tid >> 2, q = tid & 3;
+  double x[FB / 4];
+#pragma unroll
+  for (int u = 0; u < FB / 4; ++u) x[u] = P[row][4 * u + q];
   __syncthreads();
-  if (!TRANS) {     // L y = b, column c of the tile
-    for (int j = 0; j < NB; ++j) {
-      if (r == j) B[j][c] /= Lk[j][j];
-      __syncthreads();
-      if (r > j) B[r][c] -= Lk[r][j] * B[j][c];
-      __syncthreads();
-    }
-  } else {          // L' y = b
-    for (int j = NB - 1; j >= 0; --j) {
-      if (r == j) B[j][c] /= Lk[j][j];
-      __syncthreads();
-      if (r < j) B[r][c] -= Lk[j][r] * B[j][c];
-      __syncthreads();
+#pragma unroll
+  for (int uj = 0; uj < FB / 4; ++uj) {
+#pragma unroll
+    for (int qj = 0; qj < 4; ++qj) {
+      const int j = 4 * uj + qj;
+      double s = 0.0;
+#pragma unroll
+      for (int u = 0; u < FB / 4; ++u) {
+        if (u < uj) s = __builtin_fma(x[u], Lk[j][4 * u + q], s);
+      }
+      if (q < qj) s = __builtin_fma(x[uj], Lk[j][4 * uj + q], s);
+      s = s + ipx_dpp<0xB1>(s);                     // quad: lanes 1 0 3 2
+      s = s + ipx_dpp<0x4E>(s);                     //       lanes 2 3 0 1 (same bits in all four)
+      // a_j sits in lane qj of the quad
+      const double aj = quad_bcast(x[uj], qj);
+      const double xj = (aj - s) * rinv[j];
+      if (q == qj) x[uj] = xj;
     }
   }
-  x[(int64_t)r * M + c] = B[r][c];
-}
-
-// X_i -= L_ik X_k (forward, i > k)   /   X_i -= L_ki' X_k (backward, i < k)
-template <bool TRANS>
-__global__ void __launch_bounds__(NB *NB)
-k_inv_update(const double *__restrict__ G, double *X, int M, int kb) {
-  __shared__ double Lt[NB][NB + 1];
-  __shared__ double Xk[NB][NB + 1];
-  const int r = threadIdx.y, c = threadIdx.x;
-  const int cb = blockIdx.x;
-  const int ib = TRANS ? (int)blockIdx.y : kb + 1 + (int)blockIdx.y;
-  if (TRANS && ib >= kb) return;
-  if (!TRANS) Lt[r][c] = G[((int64_t)ib * NB + r) * M + (int64_t)kb * NB + c];   // L_ik
-  else Lt[r][c] = G[((int64_t)kb * NB + c) * M + (int64_t)ib * NB + r];          // (L_ki)'
-  Xk[r][c] = X[((int64_t)kb * NB + r) * M + (int64_t)cb * NB + c];
+#pragma unroll
+  for (int u = 0; u < FB / 4; ++u) P[row][4 * u + q] = x[u];
   __syncthreads();
-  double s = 0.0;
-#pragma unroll 8
-  for (int t = 0; t < NB; ++t) s += Lt[r][t] * Xk[t][c];
-  X[((int64_t)ib * NB + r) * M + (int64_t)cb * NB + c] -= s;
+  for (int e = tid; e < FB * FB; e += IPX_BLOCK) {
+    const int r = e >> 6, c = e & 63;
+    p[(int64_t)r * M + c] = P[r][c];
+  }
 }
 
-__global__ void __launch_bounds__(IPX_BLOCK) k_set_identity(double *X, int M) {
-  const int64_t tot = (int64_t)M * M;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < tot;
-       i += (int64_t)gridDim.x * blockDim.x)
-    X[i] = (i / M == i % M) ? 1.0 : 0.0;
+// Trailing update G_ij -= L_ik L_jk' for kb < j <= i (a workgroup per tile of the lower
+// triangle; a diagonal tile is updated whole).
+__global__ void __launch_bounds__(IPX_BLOCK)
+k_syrk64(double *G, int M, int kb, int rest) {
+  __shared__ __attribute__((aligned(16))) double sA[GPANEL];
+  __shared__ __attribute__((aligned(16))) double sB[GPANEL];
+  const int tile = blockIdx.x;
+  int ti = (int)((sqrt(8.0 * tile + 1.0) - 1.0) * 0.5);
+  while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
+  while (ti * (ti + 1) / 2 > tile) --ti;
+  const int tj = tile - ti * (ti + 1) / 2;
+  if (ti >= rest) return;
+  const int ib = kb + 1 + ti, jb = kb + 1 + tj;
+  const Opnd Pn{G + ((int64_t)ib * FB) * M + (int64_t)kb * FB, M, 1};
+  const Opnd Qn{G + ((int64_t)jb * FB) * M + (int64_t)kb * FB, M, 1};
+  v4d acc[2][2];
+  tile_pqt(Pn, Qn, FB, acc, sA, sB);
+  double *c = G + ((int64_t)ib * FB) * M + (int64_t)jb * FB;
+  IPX_TILE_FOREACH(acc, row, col, val, c[(int64_t)row * M + col] -= val);
+}
+
+// Every diagonal tile of L inverted in place (lower triangular; the strict upper part of the
+// tile zero): column c of the inverse by forward substitution, a lane per column, the column in
+// registers (fully unrolled), L[i][t] an LDS broadcast.
+__global__ void __launch_bounds__(IPX_WAVE)
+k_trtri_diag64(double *G, int M) {
+  __shared__ double Lk[FB][FB + 1];
+  const int lane = threadIdx.x, kb = blockIdx.x;
+  double *g = G + ((int64_t)kb * FB) * M + (int64_t)kb * FB;
+  for (int r = 0; r < FB; ++r) Lk[r][lane] = g[(int64_t)r * M + lane];
+  __syncthreads();
+  // x_i = (e_c[i] - sum_{t<i} L[i][t] x_t) / L[i][i]   (x_t = 0 for t < c: exact zeros)
+  double x[FB];
+#pragma unroll
+  for (int i = 0; i < FB; ++i) {
+    double s = (i == lane) ? 1.0 : 0.0;
+#pragma unroll
+    for (int t = 0; t < i; ++t) s = __builtin_fma(-Lk[i][t], x[t], s);
+    x[i] = (i >= lane) ? s / Lk[i][i] : 0.0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < FB; ++i) Lk[i][lane] = x[i];          // (row i, column lane of the inverse)
+  __syncthreads();
+  for (int r = 0; r < FB; ++r) g[(int64_t)r * M + lane] = Lk[r][lane];
+}
+
+// One level of the in-place triangular inverse: pair p = blockIdx.z of neighbouring blocks of
+// `sb` tiles -- block 1 = tiles [2 p sb, (2 p + 1) sb), block 2 = the tiles after it (up to sb,
+// fewer at the end of the matrix).  STAGE 1: T = L21 X11, stored TRANSPOSED where X12 would be
+// (the upper triangle is free); STAGE 2: X21 = -X22 T into the place of L21.  The K ranges stop
+// where the triangular operands do (tile aligned), so nothing parked in the upper triangle is
+// ever read as data.
+template <int STAGE>
+__global__ void __launch_bounds__(IPX_BLOCK)
+k_trtri_level(double *G, int M, int nb, int sb) {
+  __shared__ __attribute__((aligned(16))) double sA[GPANEL];
+  __shared__ __attribute__((aligned(16))) double sB[GPANEL];
+  const int p = blockIdx.z, tx = blockIdx.x, ty = blockIdx.y;
+  const int b1 = 2 * p * sb, b2 = b1 + sb;              // first tiles of the two blocks
+  const int n2 = min(sb, nb - b2);                      // tiles of block 2
+  if (n2 <= 0 || ty >= n2) return;
+  const int64_t c1 = (int64_t)b1 * FB, r2 = (int64_t)b2 * FB;
+  v4d acc[2][2];
+  if (STAGE == 1) {
+    // T[ty][tx] = sum_k L21[ty][k] X11[k][tx],  k over the tiles tx .. sb-1 of block 1
+    const int k0 = tx * FB, K = sb * FB - k0;
+    const Opnd Pn{G + (r2 + (int64_t)ty * FB) * M + c1 + k0, M, 1};
+    const Opnd Qn{G + (c1 + k0) * M + c1 + (int64_t)tx * FB, 1, M};
+    tile_pqt(Pn, Qn, K, acc, sA, sB);
+    double *t = G + (c1 + (int64_t)tx * FB) * M + r2 + (int64_t)ty * FB;     // (transposed)
+    IPX_TILE_FOREACH(acc, row, col, val, t[(int64_t)col * M + row] = val);
+  } else {
+    // X21[ty][tx] = -sum_k X22[ty][k] T[k][tx],  k over the tiles 0 .. ty of block 2
+    const int K = (ty + 1) * FB;
+    const Opnd Pn{G + (r2 + (int64_t)ty * FB) * M + r2, M, 1};
+    const Opnd Qn{G + (c1 + (int64_t)tx * FB) * M + r2, M, 1};
+    tile_pqt(Pn, Qn, K, acc, sA, sB);
+    double *x = G + (r2 + (int64_t)ty * FB) * M + c1 + (int64_t)tx * FB;
+    IPX_TILE_FOREACH(acc, row, col, val, x[(int64_t)row * M + col] = -val);
+  }
+}
+
+// Y = X'X for the lower triangular X in the lower triangle of G: tile (ti, tj), tj <= ti, sums
+// over the rows from tile ti on (X is zero above); written with its mirror.
+__global__ void __launch_bounds__(IPX_BLOCK)
+k_xtx64(const double *G, int M, int nb, double *Y) {
+  __shared__ __attribute__((aligned(16))) double sA[GPANEL];
+  __shared__ __attribute__((aligned(16))) double sB[GPANEL];
+  const int tile = blockIdx.x;
+  int ti = (int)((sqrt(8.0 * tile + 1.0) - 1.0) * 0.5);
+  while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
+  while (ti * (ti + 1) / 2 > tile) --ti;
+  const int tj = tile - ti * (ti + 1) / 2;
+  if (ti >= nb) return;
+  const int64_t k0 = (int64_t)ti * FB;
+  const Opnd Pn{G + k0 * M + (int64_t)ti * FB, 1, M};
+  const Opnd Qn{G + k0 * M + (int64_t)tj * FB, 1, M};
+  v4d acc[2][2];
+  tile_pqt(Pn, Qn, M - (int)k0, acc, sA, sB);
+  IPX_TILE_FOREACH(acc, row, col, val, {
+    const int64_t gr = (int64_t)ti * FB + row, gc = (int64_t)tj * FB + col;
+    if (gc <= gr) { Y[gr * M + gc] = val; Y[gc * M + gr] = val; }
+  });
 }
 
 }  // namespace
@@ -476,7 +688,7 @@ int ipx_dense_gemv(int64_t m, int64_t n, const double *A, int64_t lda, const dou
   return IPX_OK;
 }
 
-int64_t ipx_dense_padded(int64_t m) { return ((m + NB - 1) / NB) * NB; }
+int64_t ipx_dense_padded(int64_t m) { return ((m + FB - 1) / FB) * FB; }
 
 // G (M x M, M = ipx_dense_padded(m)) = A A' via fp64 MFMA.
 // K-splits that even out the load: with one split the tiles of the lower triangle are dealt
@@ -556,55 +768,52 @@ int ipx_aat_dense(int64_t m, const int32_t *rowptr, const int32_t *colidx, const
   return IPX_OK;
 }
 
-// In place: lower triangle of G <- L with G = L L'.  flag (device int) != 0 afterwards when a
-// pivot fell below IPX_PIVOT_RTOL x its original diagonal entry (numerically rank deficient
-// Jacobian); work (M + 1 doubles): work[M] = min pivot / diagonal, an estimate of 1/cond(G).
+// In place: lower triangle of G <- L with G = L L' (the strict upper triangle of the diagonal
+// tiles is zeroed, the rest of the upper triangle keeps G).  flag (device int) != 0 afterwards
+// when a pivot fell below IPX_PIVOT_RTOL x its original diagonal entry (numerically rank
+// deficient Jacobian); work (M + 1 doubles): work[M] = min pivot / diagonal, an estimate of
+// 1/cond(G).
 int ipx_chol_factor(int64_t M, double *G, int *flag, double *work, void *stream) {
-  if (M < NB || M % NB || !G || !flag || !work) return IPX_EINVAL;
+  if (M < FB || M % FB || !G || !flag || !work) return IPX_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  const int nb = (int)(M / NB);
+  const int nb = (int)(M / FB);
   if (hipMemsetAsync(flag, 0, sizeof(int), st) != hipSuccess) return IPX_ELAUNCH;
   hipLaunchKernelGGL(k_save_diag, dim3(((int)M + IPX_BLOCK - 1) / IPX_BLOCK), dim3(IPX_BLOCK), 0,
                      st, G, (int)M, work);
   IPX_CHECK_LAUNCH();
   for (int k = 0; k < nb; ++k) {
-    hipLaunchKernelGGL(k_potrf_tile, dim3(1), dim3(NB, NB), 0, st, G, (int)M, k, flag, work);
+    hipLaunchKernelGGL(k_potrf64, dim3(1), dim3(IPX_BLOCK), 0, st, G, (int)M, k, flag, work);
     IPX_CHECK_LAUNCH();
     const int rest = nb - k - 1;
     if (rest > 0) {
-      hipLaunchKernelGGL(k_trsm_panel, dim3(rest), dim3(NB, NB), 0, st, G, (int)M, k);
+      hipLaunchKernelGGL(k_trsm64, dim3(rest), dim3(IPX_BLOCK), 0, st, G, (int)M, k);
       IPX_CHECK_LAUNCH();
-      hipLaunchKernelGGL(k_syrk_update, dim3(rest, rest), dim3(NB, NB), 0, st, G, (int)M, k);
+      hipLaunchKernelGGL(k_syrk64, dim3(rest * (rest + 1) / 2), dim3(IPX_BLOCK), 0, st, G, (int)M,
+                         k, rest);
       IPX_CHECK_LAUNCH();
     }
   }
   return IPX_OK;
 }
 
-// X (M x M) <- (L L')^-1 from the factor in the lower triangle of G.
-int ipx_chol_inverse(int64_t M, const double *G, double *X, void *stream) {
-  if (M < NB || M % NB || !G || !X) return IPX_EINVAL;
+// X (M x M) <- (L L')^-1 from the factor in the lower triangle of G.  G is used as the
+// workspace of the triangular inverse: on return its lower triangle holds L^-1.
+int ipx_chol_inverse(int64_t M, double *G, double *X, void *stream) {
+  if (M < FB || M % FB || !G || !X) return IPX_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  const int nb = (int)(M / NB);
-  hipLaunchKernelGGL(k_set_identity, dim3(1024), dim3(IPX_BLOCK), 0, st, X, (int)M);
+  const int nb = (int)(M / FB);
+  hipLaunchKernelGGL(k_trtri_diag64, dim3(nb), dim3(IPX_WAVE), 0, st, G, (int)M);
   IPX_CHECK_LAUNCH();
-  for (int k = 0; k < nb; ++k) {                 // X <- L^-1 X
-    hipLaunchKernelGGL(k_inv_diag<false>, dim3(nb), dim3(NB, NB), 0, st, G, X, (int)M, k);
+  for (int sb = 1; sb < nb; sb *= 2) {
+    const int pairs = (nb + 2 * sb - 1) / (2 * sb);
+    const dim3 grid(sb, sb, pairs), block(IPX_BLOCK);
+    hipLaunchKernelGGL(k_trtri_level<1>, grid, block, 0, st, G, (int)M, nb, sb);
     IPX_CHECK_LAUNCH();
-    if (nb - k - 1 > 0) {
-      hipLaunchKernelGGL(k_inv_update<false>, dim3(nb, nb - k - 1), dim3(NB, NB), 0, st, G, X,
-                         (int)M, k);
-      IPX_CHECK_LAUNCH();
-    }
-  }
-  for (int k = nb - 1; k >= 0; --k) {            // X <- L^-T X
-    hipLaunchKernelGGL(k_inv_diag<true>, dim3(nb), dim3(NB, NB), 0, st, G, X, (int)M, k);
+    hipLaunchKernelGGL(k_trtri_level<2>, grid, block, 0, st, G, (int)M, nb, sb);
     IPX_CHECK_LAUNCH();
-    if (k > 0) {
-      hipLaunchKernelGGL(k_inv_update<true>, dim3(nb, k), dim3(NB, NB), 0, st, G, X, (int)M, k);
-      IPX_CHECK_LAUNCH();
-    }
   }
+  hipLaunchKernelGGL(k_xtx64, dim3(nb * (nb + 1) / 2), dim3(IPX_BLOCK), 0, st, G, (int)M, nb, X);
+  IPX_CHECK_LAUNCH();
   return IPX_OK;
 }
 

@@ -94,6 +94,115 @@ class CenteredBandedNLP:
                                       self.constr_hess)
 
 
+class CenteredDenseNLP:
+    """Dense NONLINEAR equality constraints: the case in which the Jacobian -- and with it the
+    factorization of the projections -- changes at every accepted step (the reference spends
+    76 % of such a run in its pivoted QR, projections.py:179; BASELINE config 2 itself has a
+    constant Jacobian and factors once).  ``A ~ N(0, 1)`` m x n, ``H = G G' / n + I``,
+    objective ``1/2 dl'H dl - eps q'dl`` with ``dl = x - x_feas`` (centred like the banded
+    generator: |f| stays small next to gtol), constraint ``c(x) = A x + kappa/2 W (x*x) - b``
+    with ``W = A*A`` and ``c(x_feas) = 0``: Jacobian ``A + kappa W diag(x)`` (dense, new
+    values every step), constraint Hessian ``diag(kappa W'v)``."""
+
+    def __init__(self, n, m, seed=0, kappa=0.1, eps=1e-3):
+        rng = np.random.default_rng(seed)
+        self.A = rng.standard_normal((m, n))
+        G = rng.standard_normal((n, n)) / np.sqrt(n)
+        self.H = G.dot(G.T) + np.eye(n)
+        self.q = rng.standard_normal(n)
+        self.x_feas = rng.uniform(-1, 1, n)
+        self.x0 = self.x_feas + 0.1 * np.random.default_rng(seed + 12345).standard_normal(n)
+        self.W = self.A * self.A
+        self.n, self.m, self.kappa, self.eps = n, m, kappa, eps
+        self.b = self.A.dot(self.x_feas) + 0.5 * kappa * self.W.dot(self.x_feas ** 2)
+
+    def fun(self, x):
+        dl = x - self.x_feas
+        return 0.5 * dl.dot(self.H.dot(dl)) - self.eps * self.q.dot(dl)
+
+    def grad(self, x):
+        return self.H.dot(x - self.x_feas) - self.eps * self.q
+
+    def hess(self, x):
+        return self.H
+
+    def constr_fun(self, x):
+        return self.A.dot(x) + 0.5 * self.kappa * self.W.dot(x * x) - self.b
+
+    def constr_jac(self, x):
+        return self.A + self.kappa * self.W * x[None, :]
+
+    def constr_hess(self, x, v):
+        return sps.diags(self.kappa * self.W.T.dot(v), format='csr')
+
+    def constraints(self, ns, kind=('equals', 0)):
+        return ns.NonlinearConstraint(self.constr_fun, kind, self.constr_jac, self.constr_hess)
+
+
+class DenseDeviceCallbacks:
+    """``CenteredDenseNLP`` with every callback on the GPU (device-callback mode: 2-D CUDA
+    tensors for the Jacobian and the Hessian; user-land code, torch freely)."""
+
+    def __init__(self, prob):
+        import torch
+        self.torch = torch
+        dev = torch.device("cuda", torch.cuda.current_device())
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
+        self.p = prob
+        self.A, self.W, self.H = t(prob.A), t(prob.W), t(prob.H)
+        self.Wt = self.W.t().contiguous()
+        self.q, self.x_feas, self.b, self.x0 = t(prob.q), t(prob.x_feas), t(prob.b), t(prob.x0)
+
+    @classmethod
+    def on_device(cls, n, m, seed=0, kappa=0.1, eps=1e-3):
+        """The same family at a size whose host generation would take longer than the solve
+        (BASELINE config 2's n = 10000, m = 2000: bench.py): A and the vectors from the numpy
+        generator, ``H = G G' / n + I`` formed on the device from a seeded torch generator."""
+        import torch
+        from types import SimpleNamespace
+        self = cls.__new__(cls)
+        self.torch = torch
+        dev = torch.device("cuda", torch.cuda.current_device())
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
+        rng = np.random.default_rng(seed)
+        self.A = t(rng.standard_normal((m, n)))
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(seed)
+        G = torch.randn((n, n), dtype=torch.float64, device=dev, generator=gen) / np.sqrt(n)
+        self.H = G @ G.t() + torch.eye(n, dtype=torch.float64, device=dev)
+        del G
+        self.q = t(rng.standard_normal(n))
+        self.x_feas = t(rng.uniform(-1, 1, n))
+        self.x0 = self.x_feas + 0.1 * t(np.random.default_rng(seed + 12345).standard_normal(n))
+        self.W = self.A * self.A
+        self.Wt = self.W.t().contiguous()
+        self.b = self.A @ self.x_feas + 0.5 * kappa * (self.W @ (self.x_feas * self.x_feas))
+        self.p = SimpleNamespace(n=n, m=m, kappa=kappa, eps=eps)
+        return self
+
+    def fun(self, x):
+        dl = x - self.x_feas
+        return float(0.5 * dl.dot(self.H @ dl) - self.p.eps * self.q.dot(dl))
+
+    def grad(self, x):
+        return self.H @ (x - self.x_feas) - self.p.eps * self.q
+
+    def hess(self, x):
+        return self.H
+
+    def constr_fun(self, x):
+        return self.A @ x + 0.5 * self.p.kappa * (self.W @ (x * x)) - self.b
+
+    def constr_jac(self, x):
+        return self.A + self.p.kappa * self.W * x[None, :]
+
+    def constr_hess(self, x, v):
+        return self.p.kappa * (self.Wt @ v)                      # diagonal
+
+    def constraints(self, ns, kind=('equals', 0)):
+        return ns.NonlinearConstraint(self.constr_fun, kind, self.constr_jac, self.constr_hess)
+
+
 class DeviceCallbacks:
     """The same NLP with every callback on the GPU (device-callback mode of
     ``minimize_constrained``): user-land code, so it uses torch elementwise ops

@@ -61,7 +61,16 @@ def chol():
 
 t_copy = timed(lambda: G.copy_(G0))
 out["chol_ms"] = timed(chol) - t_copy
-out["inverse_ms"] = timed(lambda: _hip.call("ipx_chol_inverse", M, dv._p(G), dv._p(X), st), reps=3)
+chol()
+L0 = G.clone()
+
+
+def inverse():                  # (the inverse works in G's storage: every repetition from L)
+    G.copy_(L0)
+    _hip.call("ipx_chol_inverse", M, dv._p(G), dv._p(X), st)
+
+
+out["inverse_ms"] = timed(inverse, reps=3) - t_copy
 Xh = X.cpu().numpy()[:m, :m]
 out["inverse_resid"] = float(np.max(np.abs(Xh @ ref - np.eye(m))))
 x = dv.DVec.from_host(rng.standard_normal(n))

@@ -29,6 +29,8 @@ Outputs (numbers only -- no reference source travels):
   e2e_cs.json       (``--cs``) the two finite-difference test problems with hess='cs'
   e2e_sparse_barrier.json  (``--sparse-barrier``: a minute) box + linear inequalities with a
                     Jacobian of RANDOM sparsity, n=1200 / m=800 (tests/problems.py)
+  e2e_dense_nl.json (``--dense-nl``) dense NONLINEAR equality constraints (a factorization per
+                    accepted step): synthetic.CenteredDenseNLP at n = 300, m = 60
   config2.json      (``--big`` only: minutes) dense equality QP of BASELINE config 2 at
                     n=4000/m=800 and n=10000/m=2000: scalar traces + strided x
   api.json          (``--api``) the host-side API either side of the path -- kind grammar,
@@ -611,6 +613,18 @@ def main():
         rec["x_stride"] = 10
         with open(os.path.join(HERE, "e2e_sparse_barrier.json"), "w") as f:
             json.dump({p.name: rec}, f)
+        return
+    if "--dense-nl" in sys.argv:
+        # dense NONLINEAR equality constraints (ipsolver/synthetic.py CenteredDenseNLP): the
+        # Jacobian changes at every accepted step, so every one of them refactors
+        out = {}
+        for n, m in ((300, 60),):
+            prob = synthetic.CenteredDenseNLP(n, m, eps=1e-3)
+            key = "dense_nl_n%d" % n
+            out[key] = run_e2e(key, prob.fun, prob.x0, prob.grad, prob.hess, prob.constraints(ref),
+                               method="equality_constrained_sqp")
+        with open(os.path.join(HERE, "e2e_dense_nl.json"), "w") as f:
+            json.dump(out, f)
         return
     if "--big" in sys.argv:
         out = {}

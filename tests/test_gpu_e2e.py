@@ -168,6 +168,37 @@ def test_general_sparsity_barrier_at_scale():
                                     active[0], active[1]))
 
 
+@pytest.mark.parametrize("mode", ["host", "device"])
+def test_dense_nonlinear_equality_refactors_every_accepted_step(mode, monkeypatch):
+    """Dense NONLINEAR equality constraints (synthetic.CenteredDenseNLP): every accepted step
+    brings a new Jacobian and a new factorization -- MFMA Gram, blocked Cholesky with the
+    trailing updates on the matrix cores, triangular inverse by recursive doubling
+    (csrc/dense.hip; the reference: a pivoted QR per step, projections.py:175-233) -- against
+    the REFERENCE's trace (tests/golden/e2e_dense_nl.json), with numpy callbacks and with the
+    problem resident on the device."""
+    import json
+    import os
+    import ipsolver.dense as dense
+    from ipsolver.synthetic import CenteredDenseNLP, DenseDeviceCallbacks
+    with open(os.path.join(os.path.dirname(__file__), "golden", "e2e_dense_nl.json")) as f:
+        gold = json.load(f)["dense_nl_n300"]
+    built = {"n": 0}
+    real = dense.DenseNormalSolver.__init__
+
+    def counting(self, A):
+        built["n"] += 1
+        real(self, A)
+    monkeypatch.setattr(dense.DenseNormalSolver, "__init__", counting)
+    prob = CenteredDenseNLP(300, 60)
+    cb = prob if mode == "host" else DenseDeviceCallbacks(prob)
+    res, rows = run(cb.fun, cb.x0, cb.grad, cb.hess, cb.constraints(ipsolver),
+                    method="equality_constrained_sqp")
+    if mode == "device":
+        res.x = res.x.cpu().numpy()
+    compare(res, rows, gold)
+    assert built["n"] >= gold["njev"]            # a factorization per Jacobian evaluation
+
+
 def test_constant_hessian_option_uploads_once(monkeypatch):
     """``options={'constant_hessian': True}`` (an ADDITIVE option: the reference's signature is
     unchanged): ``hess`` is evaluated once and its dense value uploaded once for the whole

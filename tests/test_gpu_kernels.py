@@ -217,3 +217,42 @@ def test_gram_mfma_tiled(m, n):
     tail = np.eye(M)
     tail[:m, :m] = Gh[:m, :m]
     assert np.array_equal(Gh, tail)                       # identity in the padding
+
+
+@pytest.mark.parametrize("m", [5, 64, 130, 300, 450, 2000])
+def test_dense_cholesky_and_inverse_on_the_matrix_cores(m):
+    """G = L L' (64 x 64 tiles: diagonal tile in LDS, panel by substitution, trailing update on
+    the fp64 matrix cores) and G^-1 (in-place triangular inverse by recursive doubling, X'X as
+    MFMA tiles: csrc/dense.hip) against numpy, at tile counts that are a power of two, odd (the
+    ragged last pair of every level) and one; padded tail = identity."""
+    import torch
+    from ipsolver import _hip, device as dv
+    lib = _hip.load()
+    rng = np.random.default_rng(m)
+    n = 3 * m + 7
+    A_h = rng.standard_normal((m, n))
+    A = torch.from_numpy(A_h).cuda()
+    M = int(lib.ipx_dense_padded(m))
+    assert M % 64 == 0
+    G = torch.empty((M, M), dtype=torch.float64, device="cuda")
+    st = dv.stream_ptr()
+    _hip.call("ipx_gram_f64_mfma", m, n, dv._p(A), n, dv._p(G), st)
+    G_h = G.cpu().numpy()
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    work = torch.zeros(M + 1, dtype=torch.float64, device="cuda")
+    _hip.call("ipx_chol_factor", M, dv._p(G), dv._p(flag), dv._p(work), st)
+    assert int(flag.item()) == 0
+    L = np.tril(G.cpu().numpy())
+    L_ref = np.linalg.cholesky(G_h)
+    assert np.max(np.abs(L - L_ref)) <= 1e-12 * np.max(np.abs(L_ref))
+    d = np.diag(L_ref) ** 2 / np.diag(G_h)
+    assert abs(float(work[M].item()) - d.min()) <= 1e-10 * d.min()     # min pivot / diagonal
+    X = torch.full((M, M), np.nan, dtype=torch.float64, device="cuda")
+    _hip.call("ipx_chol_inverse", M, dv._p(G), dv._p(X), st)
+    X_h = X.cpu().numpy()
+    assert np.array_equal(X_h, X_h.T)
+    resid = np.max(np.abs(X_h @ G_h - np.eye(M)))
+    assert resid <= 1e-9 * np.linalg.cond(G_h[:m, :m]), resid
+    tail = np.eye(M)
+    tail[:m, :m] = X_h[:m, :m]
+    assert np.allclose(X_h, tail, rtol=0, atol=1e-300)          # identity in the padding

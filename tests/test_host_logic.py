@@ -223,6 +223,22 @@ def test_banded_box_inequality_nlp(e2e_golden):
     assert np.allclose(np.asarray(res.x)[::max(1, 400 // 50)], gx, atol=1e-5)
 
 
+def test_dense_nonlinear_equality_nlp():
+    """Dense NONLINEAR equality constraints (synthetic.CenteredDenseNLP, n = 300, m = 60): the
+    Jacobian changes at every accepted step, so every one of them refactors (the reference: a
+    pivoted QR each, projections.py:179).  Host logic on the oracle's backend against the
+    reference's trace (tests/golden/e2e_dense_nl.json, ``make_golden.py --dense-nl``)."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(__file__), "golden", "e2e_dense_nl.json")) as f:
+        gold = json.load(f)["dense_nl_n300"]
+    prob = load_synthetic().CenteredDenseNLP(300, 60)
+    with backend.use(npb):
+        res, rows = run(prob.fun, prob.x0, prob.grad, prob.hess, prob.constraints(ipsolver),
+                        method="equality_constrained_sqp")
+    compare(res, rows, gold)
+
+
 def test_dense_equality_qp(e2e_golden):
     rng = np.random.default_rng(0)
     n, m = 60, 12
