@@ -936,6 +936,38 @@ def sharded_leg(args, world, rank, A_h, H_h, hdiag_h, c_h, n, m, K, W):
         except Exception as exc:
             weak = {"error": repr(exc)}
 
+    # ---- ranks that share one GPU cannot keep n = 1e6 resident side by side (the group refuses
+    # the resident form, preflight.resident_form false): the SAME code path at a size where every
+    # rank's workgroups fit the chip together, against the three launches on the same size -- the
+    # evidence this build has for the resident PEER kernel on hardware
+    resident_rehearsal = None
+    if shared_gpu and transport == "ipc" and not resident:
+        try:
+            nr, mr = 400000, 40000
+            probr = CenteredBandedNLP(nr, mr, seed=0)
+            xr = probr.x0
+            vr = 0.1 * np.random.default_rng(7).standard_normal(mr)
+            shr, Fr, primedr = _sharded_setup(probr.constr_jac(xr), probr.hess(xr),
+                                              probr.kappa * probr.Wt.dot(vr), probr.grad(xr))
+            resident_rehearsal = {"n": nr, "m": mr, "resident_form": bool(Fr.resident)}
+            if Fr.resident:
+                tr = sorted(_sharded_run(Fr, primedr, K, W, dist, torch)[0] for _ in range(3))[1]
+                xres = Fr.L.x.clone()
+                Fr.resident = False
+                t3 = sorted(_sharded_run(Fr, primedr, K, W, dist, torch)[0] for _ in range(3))[1]
+                Fr.resident = True
+                lo_, hi_ = shr.lay.geom("col")[2:]
+                diff = float((xres[lo_:hi_] - Fr.L.x[lo_:hi_]).abs().max().item())
+                resident_rehearsal.update({
+                    "resident_iterations_per_s": K / tr, "three_launches_iterations_per_s": K / t3,
+                    "own_entries_max_abs_diff_between_the_forms": diff,
+                    "note": "%d ranks on one GPU, every workgroup of both resident at once; the "
+                            "hand-offs between the ranks go through the same hipIpc-mapped "
+                            "buffers as between GPUs" % world})
+            del shr, Fr, primedr, probr
+        except Exception as exc:
+            resident_rehearsal = {"error": repr(exc)}
+
     # ---- the whole config-4 solve to gtol on the sharded backend (second half of the metric)
     full_solve = None
     try:
@@ -1029,6 +1061,7 @@ def sharded_leg(args, world, rank, A_h, H_h, hdiag_h, c_h, n, m, K, W):
                                                   "synchronise for torch.distributed over %s)"
                                                   % dist.get_backend()},
         "weak_scaling_point": weak,
+        "resident_rehearsal": resident_rehearsal,
         "wall_clock_to_gtol": full_solve,
     }
     if rank == 0:

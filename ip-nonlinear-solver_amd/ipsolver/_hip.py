@@ -162,17 +162,17 @@ def load():
 # IPX_DEBUG_FORMS = comma-separated list of kernel forms to turn OFF, for A/B measurements and
 # for the parity tests that compare each form with the plain one (tests/test_gpu_qp.py):
 #   no-fuse            step1 / step2 / g = r - A'v as launches of their own (no fused SpMVs)
-#   no-c16             32-bit column indices in the fused SpMV kernels
 #   no-resident        small problems on the separate launches (no csrc/resident.hip)
 #   no-compact-groups  box-Schur group tables in their general form (44 B per variable)
 #   no-affine-groups   ... with the column table read instead of computed
-#   no-diag-merge      the Hessian's diagonal term as a vector of its own
 #   keep-xn2           ||x + alpha p||^2 formed even for an infinite trust radius
 #   pack-comm          sharded loop: the collectives in pack kernels of their own (5 launches)
 # Anything else that selects behaviour is an argument (``options={'shard': True}``) or a
 # deployment setting (IPX_SHARD, IPX_SHARD_TRANSPORT=dist).
-DEBUG_FORMS = ("no-fuse", "no-c16", "no-resident", "no-compact-groups", "no-affine-groups",
-               "no-diag-merge", "keep-xn2", "pack-comm")
+# (round 5 removed "no-c16" and "no-diag-merge": their A/Bs are settled -- profiles/r03*, r04* --
+# and the 16-bit index tables / the merged diagonal are what every qualifying pattern gets)
+DEBUG_FORMS = ("no-fuse", "no-resident", "no-compact-groups", "no-affine-groups", "keep-xn2",
+               "pack-comm")
 
 
 def debug_form(name):

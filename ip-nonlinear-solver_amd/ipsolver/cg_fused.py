@@ -547,16 +547,15 @@ class _Loop:
         self.fold_ws = torch.zeros(16384, dtype=f64, device=dev)      # IPX_FOLD_WS_DOUBLES
         a.fold_ws = _ptr(self.fold_ws)
         # banded Hessian: step2 rides inside the H.p SpMV (one launch less per iteration)
-        no_fuse, no_c16 = _hip.debug_form("no-fuse"), _hip.debug_form("no-c16")
+        no_fuse = _hip.debug_form("no-fuse")
         hmax = 0 if (no_fuse or Hc is None) else fuse_halo(Hc.pattern)
         if hmax > 0:
             self.pb = torch.zeros(2 * Hc.pattern.ntiles * 2 * hmax, dtype=f64, device=dev)
             a.pb, a.H_hmax = _ptr(self.pb), hmax
             th = Hc.pattern.tiles_h
             a.H_tile_rows = int(np.max(np.diff(th[:Hc.pattern.ntiles + 1])))
-            if not no_c16:
-                self.H_col16, self.H_rowlen = compact_columns(Hc.pattern, hmax)
-                a.H_col16, a.H_rowlen = _ptr(self.H_col16), _ptr(self.H_rowlen)
+            self.H_col16, self.H_rowlen = compact_columns(Hc.pattern, hmax)
+            a.H_col16, a.H_rowlen = _ptr(self.H_col16), _ptr(self.H_rowlen)
         # banded Jacobian, no box: step1 rides inside the A.r SpMV
         own = None if (no_fuse or lb is not None or m == 0) else fuse_own(A.pattern)
         if own is not None:
@@ -567,9 +566,8 @@ class _Loop:
             if self.part2.numel() < 2 * own[3]:
                 self.part2 = torch.zeros(2 * own[3], dtype=f64, device=dev)
                 a.part2 = _ptr(self.part2)
-            if not no_c16:
-                self.A_col16 = own_columns16(A.pattern)
-                a.A_col16 = _ptr(self.A_col16)
+            self.A_col16 = own_columns16(A.pattern)
+            a.A_col16 = _ptr(self.A_col16)
         # tridiagonal A A' on the single-launch solve: g = r - A'v rides in that launch
         if a.solver_kind == 0 and not no_fuse:
             geo = (ctypes.c_int32 * 2)()

@@ -38,7 +38,7 @@ class DeviceHessian:
     def __init__(self, n, csr=None, diag=None, others=()):
         self.n = n
         self.shape = (n, n)
-        if csr is not None and diag is not None and not _hip.debug_form("no-diag-merge"):
+        if csr is not None and diag is not None:
             # a CSR term that has every diagonal entry takes the diagonal terms into its values
             # (one scatter-add per Hessian, on a copy: the caller's matrix is not touched): the
             # product then reads no separate diagonal vector -- 8 n bytes less in every CG

@@ -48,678 +48,12 @@ import scipy.sparse as sps
 import torch
 import torch.distributed as dist
 
-ROW_BLOCK = 260          # DEC_CHUNKS * (chunk + k) of csrc/banded.hip for k = 1, chunk = 64
+from .shard_layout import ROW_BLOCK, ShardLayout                      # noqa: F401  (re-exported)
+from .shard_comm import ShardComm, PeerMailbox, _device_id, _host_id   # noqa: F401
+from .shard_ops import HipOps                                          # noqa: F401
 
 
-# --------------------------------------------------------------------------- layout
-class ShardLayout:
-    """Symbolic partition of a Jacobian pattern (CSR, sorted, first column of a row
-    non-decreasing: every banded Jacobian) over ``world`` ranks.  Computed identically on
-    every rank from the global pattern."""
-
-    def __init__(self, indptr, indices, shape, world, rank, row_block=ROW_BLOCK, halo_blocks=1,
-                 subsets=None):
-        """``subsets``: {name: sorted row indices} -- further spaces made of SOME of the rows
-        (the equality / the inequality rows of a Jacobian that is banded with the two kinds
-        interleaved: ipsolver/sharded_mixed.py); a rank owns the members among its own rows
-        and keeps halo copies of those among its halo rows."""
-        m, n = int(shape[0]), int(shape[1])
-        indptr = np.asarray(indptr, dtype=np.int64)
-        indices = np.asarray(indices, dtype=np.int64)
-        if m == 0 or np.any(np.diff(indptr) == 0):
-            raise NotImplementedError("row sharding needs a Jacobian without empty rows")
-        first = indices[indptr[:-1]]
-        last = np.maximum.reduceat(indices, indptr[:-1])
-        if np.any(np.diff(first) < 0) or np.any(np.diff(last) < 0):
-            raise NotImplementedError("row sharding needs a banded Jacobian (first and last "
-                                      "column non-decreasing from row to row)")
-        nb = (m + row_block - 1) // row_block
-        if nb < world:
-            raise ValueError("%d constraint rows give %d blocks of %d: too few for %d ranks"
-                             % (m, nb, row_block, world))
-        self.m, self.n, self.world, self.rank = m, n, world, rank
-        self.row_block, self.halo_rows = row_block, halo_blocks * row_block
-        R = [min(m, ((r * nb) // world) * row_block) for r in range(world)] + [m]
-        # a variable goes with the FIRST constraint row that touches it (variables no row touches:
-        # with the next one that is touched) -- the ownership of the banded solve's fused tail
-        # and of the resident loop kernel (cg_fused.fuse_vown: a workgroup owns the variables
-        # whose first constraint lies in its rows), so a rank's own variables are exactly its own
-        # workgroups' and both kinds of partial sums cover the same entries.  Rows i and i + 1 of
-        # a banded Jacobian overlap, so this is a few columns to the right of "the first column of
-        # the rank's first row" (rounds 1-4).
-        starts = np.full(n + 1, m, dtype=np.int64)
-        np.minimum.at(starts, indices, np.repeat(np.arange(m, dtype=np.int64), np.diff(indptr)))
-        first_row = np.minimum.accumulate(starts[::-1])[::-1][:n]     # (non-decreasing)
-        C = [0] + [int(np.searchsorted(first_row, R[r], side="left")) for r in range(1, world)] + [n]
-        self.row_cuts, self.col_cuts = R, C
-        self.ranks = []
-        for r in range(world):
-            E0 = max(0, R[r] - self.halo_rows)
-            E1 = min(m, R[r + 1] + self.halo_rows)
-            x0 = 0 if r == 0 else min(C[r], int(first[E0]))
-            x1 = n if r == world - 1 else max(C[r + 1], int(last[E1 - 1]) + 1)
-            # an even number of local variables (one more halo column where there is room): the
-            # ELL(2) form of A' the solve's tail and the resident loop kernel read takes the
-            # variables in aligned pairs
-            if (x1 - x0) % 2:
-                if x1 < n:
-                    x1 += 1
-                elif x0 > 0:
-                    x0 -= 1
-            self.ranks.append(dict(R0=R[r], R1=R[r + 1], E0=E0, E1=E1, c0=C[r], c1=C[r + 1],
-                                   x0=x0, x1=x1))
-        for r in range(world):
-            me = self.ranks[r]
-            if r > 0:
-                le = self.ranks[r - 1]
-                if me["x0"] < le["c0"] or me["E0"] < le["R0"]:
-                    raise ValueError("halo of rank %d reaches beyond its neighbour: fewer "
-                                     "ranks or a larger problem" % r)
-            if r < world - 1:
-                ri = self.ranks[r + 1]
-                if me["x1"] > ri["c1"] or me["E1"] > ri["R1"]:
-                    raise ValueError("halo of rank %d reaches beyond its neighbour: fewer "
-                                     "ranks or a larger problem" % r)
-        self.me = self.ranks[rank]
-        self.subsets = {k: np.asarray(v, dtype=np.int64) for k, v in (subsets or {}).items()}
-        # first global entry of every rank's own part, per space (ShardVec.to_host gathers by it)
-        self.cuts = {"col": C, "row": R}
-        for k, idx in self.subsets.items():
-            self.cuts[k] = [int(np.searchsorted(idx, r, side="left")) for r in R]
-
-    def geom(self, kind, rank=None):
-        """(global start of the local array, local length, own_lo, own_hi) for
-        ``kind`` = "col" (variables) / "row" (constraints) / a named subset of the rows."""
-        d = self.ranks[self.rank if rank is None else rank]
-        if kind == "col":
-            return d["x0"], d["x1"] - d["x0"], d["c0"] - d["x0"], d["c1"] - d["x0"]
-        if kind == "row":
-            return d["E0"], d["E1"] - d["E0"], d["R0"] - d["E0"], d["R1"] - d["E0"]
-        idx = self.subsets[kind]
-        e0, r0, r1, e1 = (int(np.searchsorted(idx, d[k], side="left")) for k in ("E0", "R0", "R1", "E1"))
-        return e0, e1 - e0, r0 - e0, r1 - e0
-
-    def sends(self, kind):
-        """How many own entries the left / right neighbour keeps as its halo."""
-        r = self.rank
-        left = right = 0
-        if r > 0:
-            _, ln, _, hi = self.geom(kind, r - 1)
-            left = ln - hi                  # right halo of the left neighbour
-        if r < self.world - 1:
-            _, _, lo, _ = self.geom(kind, r + 1)
-            right = lo                      # left halo of the right neighbour
-        return left, right
-
-    def global_len(self, kind):
-        if kind in self.subsets:
-            return len(self.subsets[kind])
-        return self.n if kind == "col" else self.m
-
-
-# --------------------------------------------------------------------------- communication
-class ShardComm:
-    """The collectives of the sharded solver over ``torch.distributed``."""
-
-    def __init__(self, group=None):
-        self.group = group
-        self.on = dist.is_available() and dist.is_initialized()
-        self.world = dist.get_world_size(group) if self.on else 1
-        self.rank = dist.get_rank(group) if self.on else 0
-        self.backend = dist.get_backend(group) if self.on else "none"
-        # (ipc_*: batches / iterations of the device loop that ran on the peer mailboxes --
-        # none of the four counters above moves between their boundaries)
-        self.stats = {"all_reduce": 0, "all_reduce_bytes": 0, "exchange": 0, "exchange_bytes": 0,
-                      "ipc_batches": 0, "ipc_iterations": 0}
-
-    def all_reduce(self, t, op="sum"):
-        """In place on a torch tensor (CUDA under nccl; CUDA tensors are staged through the
-        host under gloo, a test-only combination)."""
-        if self.world == 1:
-            return
-        self.stats["all_reduce"] += 1
-        self.stats["all_reduce_bytes"] += t.numel() * t.element_size()
-        rop = {"sum": dist.ReduceOp.SUM, "max": dist.ReduceOp.MAX, "min": dist.ReduceOp.MIN}[op]
-        if t.is_cuda and self.backend != "nccl":
-            h = t.cpu()
-            dist.all_reduce(h, op=rop, group=self.group)
-            t.copy_(h)
-        else:
-            dist.all_reduce(t, op=rop, group=self.group)
-
-    def reduce_floats(self, values, op="sum", device=None):
-        """All-reduce of a few host scalars (one blocking round)."""
-        if self.world == 1:
-            return [float(v) for v in values]
-        t = torch.tensor([float(v) for v in values], dtype=torch.float64)
-        if self.backend == "nccl":
-            t = t.to(device if device is not None
-                     else torch.device("cuda", torch.cuda.current_device()))
-        self.all_reduce(t, op)
-        return t.tolist()
-
-    def reduce_mixed(self, sums=(), maxs=(), mins=()):
-        """Sums, maxima and minima of host scalars over the ranks in ONE collective (an
-        all-gather of every rank's values, combined locally in rank order: bit-identical on
-        every rank)."""
-        ns, nx, nn = len(sums), len(maxs), len(mins)
-        if self.world == 1:
-            return [float(v) for v in sums], [float(v) for v in maxs], [float(v) for v in mins]
-        t = torch.tensor([float(v) for v in (*sums, *maxs, *mins)], dtype=torch.float64)
-        if self.backend == "nccl":
-            t = t.to(torch.device("cuda", torch.cuda.current_device()))
-        parts = [torch.empty_like(t) for _ in range(self.world)]
-        self.stats["all_reduce"] += 1
-        self.stats["all_reduce_bytes"] += 8 * t.numel() * self.world
-        dist.all_gather(parts, t, group=self.group)
-        g = torch.stack(parts).cpu()
-        return (g[:, :ns].sum(0).tolist(), g[:, ns:ns + nx].max(0).values.tolist() if nx else [],
-                g[:, ns + nx:].min(0).values.tolist() if nn else [])
-
-    def exchange_many(self, jobs):
-        """Several halo updates (tensor, own_lo, own_hi, send_left, send_right) as ONE batch of
-        point-to-point operations (the segments of a stacked vector)."""
-        if self.world == 1:
-            return
-        ops, staged, r = [], [], self.rank
-        for t, own_lo, own_hi, send_left, send_right in jobs:
-            n = t.numel()
-            stage = t.is_cuda and self.backend != "nccl"
-            buf = t.cpu() if stage else t
-            if stage:
-                staged.append((t, buf, own_lo, own_hi))
-            if r > 0:
-                if send_left:
-                    ops.append(dist.P2POp(dist.isend, buf[own_lo:own_lo + send_left], r - 1,
-                                          self.group))
-                if own_lo:
-                    ops.append(dist.P2POp(dist.irecv, buf[0:own_lo], r - 1, self.group))
-            if r < self.world - 1:
-                if send_right:
-                    ops.append(dist.P2POp(dist.isend, buf[own_hi - send_right:own_hi], r + 1,
-                                          self.group))
-                if n - own_hi:
-                    ops.append(dist.P2POp(dist.irecv, buf[own_hi:n], r + 1, self.group))
-            self.stats["exchange_bytes"] += 8 * (send_left * (r > 0)
-                                                 + send_right * (r < self.world - 1))
-        if ops:
-            self.stats["exchange"] += 1
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
-        for t, buf, own_lo, own_hi in staged:
-            if own_lo:
-                t[0:own_lo].copy_(buf[0:own_lo])
-            if t.numel() - own_hi:
-                t[own_hi:].copy_(buf[own_hi:])
-
-    def prepare_exchange(self, t, own_lo, own_hi, send_left, send_right):
-        """``prepare_exchange_many`` for one buffer."""
-        return self.prepare_exchange_many([(t, own_lo, own_hi, send_left, send_right)])
-
-    def prepare_exchange_many(self, jobs):
-        """The halo updates of ``exchange_many`` for FIXED buffers as a callable: the
-        point-to-point operations are built once (the device-resident loop repeats the same
-        exchange every iteration; building them costs more host time than issuing them) and
-        issued as one batch.  CUDA buffers under gloo (a test-only combination) fall back to
-        the staged form."""
-        if self.world == 1:
-            return lambda: None
-        jobs = list(jobs)
-        if any(j[0].is_cuda for j in jobs) and self.backend != "nccl":
-            return lambda: self.exchange_many(jobs)
-        r, ops, nbytes = self.rank, [], 0
-        for t, own_lo, own_hi, send_left, send_right in jobs:
-            n = t.numel()
-            if r > 0:
-                if send_left:
-                    ops.append(dist.P2POp(dist.isend, t[own_lo:own_lo + send_left], r - 1,
-                                          self.group))
-                if own_lo:
-                    ops.append(dist.P2POp(dist.irecv, t[0:own_lo], r - 1, self.group))
-            if r < self.world - 1:
-                if send_right:
-                    ops.append(dist.P2POp(dist.isend, t[own_hi - send_right:own_hi], r + 1,
-                                          self.group))
-                if n - own_hi:
-                    ops.append(dist.P2POp(dist.irecv, t[own_hi:n], r + 1, self.group))
-            nbytes += 8 * (send_left * (r > 0) + send_right * (r < self.world - 1))
-        stats, batch = self.stats, dist.batch_isend_irecv
-
-        def go():
-            if ops:
-                stats["exchange"] += 1
-                stats["exchange_bytes"] += nbytes
-                for w in batch(ops):
-                    w.wait()
-        return go
-
-    def exchange(self, t, own_lo, own_hi, send_left, send_right):
-        """Halo update of the local extended 1-D tensor ``t``: entries [0, own_lo) come from
-        the left neighbour's last own entries, [own_hi, len) from the right neighbour's
-        first; this rank sends its first ``send_left`` / last ``send_right`` own entries."""
-        if self.world == 1:
-            return
-        n = t.numel()
-        stage = t.is_cuda and self.backend != "nccl"
-        buf = t.cpu() if stage else t
-        ops, r = [], self.rank
-        if r > 0:
-            if send_left:
-                ops.append(dist.P2POp(dist.isend, buf[own_lo:own_lo + send_left].contiguous()
-                                      if stage else buf[own_lo:own_lo + send_left], r - 1,
-                                      self.group))
-            if own_lo:
-                ops.append(dist.P2POp(dist.irecv, buf[0:own_lo], r - 1, self.group))
-        if r < self.world - 1:
-            if send_right:
-                ops.append(dist.P2POp(dist.isend, buf[own_hi - send_right:own_hi], r + 1,
-                                      self.group))
-            if n - own_hi:
-                ops.append(dist.P2POp(dist.irecv, buf[own_hi:n], r + 1, self.group))
-        if ops:
-            self.stats["exchange"] += 1
-            self.stats["exchange_bytes"] += 8 * (send_left * (r > 0)
-                                                 + send_right * (r < self.world - 1))
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
-        if stage:
-            if own_lo:
-                t[0:own_lo].copy_(buf[0:own_lo])
-            if n - own_hi:
-                t[own_hi:n].copy_(buf[own_hi:n])
-
-
-class PeerMailbox:
-    """This rank's mailbox and its peers', mapped through hipIpc (csrc/peer.hip): the transport
-    of the device-resident loop's scalars and halo when every rank of the group runs on this
-    node.  Construction is collective (the handles travel through
-    ``torch.distributed.all_gather_object`` once); afterwards the mailboxes are touched by
-    kernels only.  ``ok`` is False -- on EVERY rank -- when any rank could not map a peer
-    (ranks on different nodes, IPC refused): the loop then stays on ``torch.distributed``."""
-
-    def __init__(self, comm, halo_cap):
-        from . import _hip
-        self._hip, self.comm = _hip, comm
-        lib = self.lib = _hip.load()
-        self.handle, self.ok, self.error = None, False, None
-        world, rank = comm.world, comm.rank
-        blob, cap = None, int(halo_cap)
-        try:
-            caps = [None] * world
-            dist.all_gather_object(caps, cap, group=comm.group)
-            cap = max(caps)
-            self.handle = lib.ipx_peer_create(rank, world, cap)
-            if not self.handle:
-                raise _hip.IpxError("ipx_peer_create failed: " + lib.ipx_last_error().decode())
-            buf = ctypes.create_string_buffer(lib.ipx_peer_handle_bytes())
-            _hip.call("ipx_peer_export", ctypes.c_void_p(self.handle), buf)
-            blob = (_host_id(), buf.raw)
-        except Exception as exc:                 # keep going: the group decides together below
-            self.error = repr(exc)
-        blobs = [None] * world
-        dist.all_gather_object(blobs, blob, group=comm.group)
-        good = all(b is not None and b[0] == blobs[0][0] for b in blobs)
-        if good:
-            try:
-                for r, b in enumerate(blobs):
-                    if r != rank:
-                        _hip.call("ipx_peer_import", ctypes.c_void_p(self.handle), r, b[1])
-            except Exception as exc:
-                self.error, good = repr(exc), False
-        elif self.error is None:
-            self.error = "ranks on different hosts, or a peer could not export its mailbox"
-        flags = [None] * world
-        dist.all_gather_object(flags, bool(good), group=comm.group)
-        self.ok = all(flags)
-        if self.ok:
-            # one all-reduce through the mailboxes against the known answer, on every rank; a
-            # group in which it fails anywhere (stores that do not arrive, a wait that times
-            # out) falls back to torch.distributed TOGETHER instead of one rank raising
-            try:
-                self.check()
-                passed = True
-            except Exception as exc:
-                self.error, passed = repr(exc), False
-            dist.all_gather_object(flags, passed, group=comm.group)
-            self.ok = all(flags)
-            if not self.ok and self.error is None:
-                self.error = "the mailbox self-test failed on another rank"
-        if not self.ok:
-            self.close()
-
-    def check(self):
-        """One all-reduce through the mailboxes against the known answer."""
-        out = self.allreduce([float(self.comm.rank + 1), 1.0])
-        w = self.comm.world
-        if out != [w * (w + 1) / 2.0, float(w)]:
-            raise self._hip.IpxError("peer mailbox self-test failed: %r" % (out,))
-
-    def allreduce(self, values, reps=1):
-        """Sum of up to 8 host scalars over the ranks through the mailboxes (set-up checks and
-        bench.py's latency probe; the loop's reductions never pass through the host)."""
-        from . import device as dv
-        dev = dv.ctx().device
-        t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=dev)
-        out = torch.zeros_like(t)
-        failed = torch.zeros(1, dtype=torch.int32, device=dev)
-        self._hip.call("ipx_peer_allreduce", ctypes.c_void_p(self.handle), t.numel(),
-                       ctypes.c_void_p(t.data_ptr()), ctypes.c_void_p(out.data_ptr()),
-                       ctypes.c_void_p(failed.data_ptr()), int(reps), dv.stream_ptr())
-        if int(failed.item()):
-            raise self._hip.IpxError("peer mailbox: a wait for a peer timed out")
-        return out.tolist()
-
-    def attach_resident(self):
-        """The hand-off buffers of the resident loop kernel's PEER form (csrc/resident.hip), sized
-        for the largest launch the kernel admits; collective, once per mailbox.  True when every
-        rank mapped every other rank's (else the group keeps the separate launches)."""
-        if getattr(self, "_resident", None) is None:
-            from . import cg_fused
-            _hip, lib, comm = self._hip, self.lib, self.comm
-            lim = cg_fused.resident_limits()
-            words = int(lib.ipx_cg_resident_ll_words(lim["max_wg"], lim["halo"]))
-            blob = None
-            try:
-                _hip.call("ipx_peer_attach_resident", ctypes.c_void_p(self.handle), words)
-                buf = ctypes.create_string_buffer(lib.ipx_peer_handle_bytes())
-                _hip.call("ipx_peer_export_resident", ctypes.c_void_p(self.handle), buf)
-                blob = buf.raw
-            except Exception as exc:
-                self.resident_error = repr(exc)
-            blobs = [None] * comm.world
-            dist.all_gather_object(blobs, blob, group=comm.group)
-            good = all(b is not None for b in blobs)
-            if good:
-                try:
-                    for r, b in enumerate(blobs):
-                        if r != comm.rank:
-                            _hip.call("ipx_peer_import_resident", ctypes.c_void_p(self.handle), r, b)
-                    good = bool(lib.ipx_peer_resident_ready(ctypes.c_void_p(self.handle)))
-                except Exception as exc:
-                    self.resident_error, good = repr(exc), False
-            flags = [None] * comm.world
-            dist.all_gather_object(flags, bool(good), group=comm.group)
-            self._resident = all(flags)
-        return self._resident
-
-    def resident_launches(self):
-        return int(self.lib.ipx_peer_resident_launches(ctypes.c_void_p(self.handle)))
-
-    def pingpong(self, reps=200):
-        """Round-trip time (us) of one tagged word between this rank and each neighbour, measured
-        inside one kernel per pair (csrc/peer.hip k_peer_pingpong): what a cross-GPU hand-off
-        costs on this node.  Collective (two rounds: pairs (0,1)(2,3).., then (1,2)(3,4)..);
-        returns {neighbour rank: us per round trip} for this rank's neighbours."""
-        from . import device as dv
-        comm, out = self.comm, {}
-        ticks = torch.zeros(2, dtype=torch.int64, device=dv.ctx().device)
-        for parity in (0, 1):
-            r = comm.rank
-            partner = r + 1 if (r - parity) % 2 == 0 else r - 1
-            if r < parity or partner < 0 or partner >= comm.world:
-                partner = -1
-            self._hip.call("ipx_peer_pingpong", ctypes.c_void_p(self.handle), int(partner), int(reps),
-                           ctypes.c_void_p(ticks.data_ptr()), dv.stream_ptr())
-            if partner >= 0:
-                t = ticks.tolist()
-                if t[1]:
-                    raise self._hip.IpxError("peer mailbox: the ping-pong with rank %d timed out"
-                                             % partner)
-                out[partner] = t[0] / 100.0 / reps          # 100 MHz ticks -> us per round trip
-        return out
-
-    def set_timeout(self, seconds):
-        """Deadline of a kernel's wait for a peer's word (default 10 s; past it: stop code 7,
-        the group falls back to torch.distributed together)."""
-        self._hip.call("ipx_peer_set_timeout", ctypes.c_void_p(self.handle), float(seconds))
-
-    def sequence(self):
-        out = (ctypes.c_int64 * 2)()
-        self._hip.call("ipx_peer_sequence", ctypes.c_void_p(self.handle), out)
-        return int(out[0]), int(out[1])
-
-    def fused_launches(self):
-        """Loop kernels so far that did their part of a collective in their own prologue
-        (``ipx_shard2_ext.fuse_comm``; 2 per iteration: 3 launches instead of 5)."""
-        return int(self.lib.ipx_peer_fused_launches(ctypes.c_void_p(self.handle)))
-
-    def close(self):
-        h, self.handle = self.handle, None
-        if h:
-            try:
-                torch.cuda.synchronize()
-                self.lib.ipx_peer_destroy(ctypes.c_void_p(h))
-            except Exception:
-                pass
-
-    __del__ = close
-
-
-def _device_id():
-    """What tells two ranks that they run on the same GPU: host + the device's UUID (its PCI
-    address where torch does not expose one)."""
-    props = torch.cuda.get_device_properties(torch.cuda.current_device())
-    ident = getattr(props, "uuid", None)
-    if ident is None:
-        ident = (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", -1),
-                 getattr(props, "pci_device_id", torch.cuda.current_device()))
-    return _host_id() + ":" + str(ident)
-
-
-def _host_id():
-    import socket
-    try:
-        with open("/proc/sys/kernel/random/boot_id") as f:
-            return socket.gethostname() + ":" + f.read().strip()
-    except OSError:
-        return socket.gethostname()
-
-
-# --------------------------------------------------------------------------- local arithmetic
-class HipOps:
-    """Local arithmetic of the sharded solver on one GPU: device.DVec / DeviceCSR and the
-    ipx kernels (the product path; fails loudly without the library or a GPU)."""
-    name = "hip"
-    fused = True
-
-    def __init__(self):
-        from . import device as dv
-        self.dv = dv
-        dv.ctx()
-
-    def from_host(self, a):
-        return self.dv.DVec.from_host(a)
-
-    def to_host(self, v):
-        return v.to_host()
-
-    def tensor(self, v):
-        return v.t
-
-    def zeros(self, n):
-        return self.dv.DVec.zeros(n)
-
-    def full(self, n, value):
-        return self.dv.DVec.full(n, value)
-
-    def copy(self, v):
-        return v.copy()
-
-    def add_scaled(self, x, o, a):
-        return x.add_scaled(o, a)
-
-    def scaled_sub(self, x, a, o):
-        return x.scaled_sub(a, o)
-
-    def sumsq_amax(self, v):
-        return v.sumsq_amax() if len(v) else [0.0, 0.0]
-
-    def dot(self, a, b):
-        return a.dot(b) if len(a) else 0.0
-
-    def clip(self, x, lb, ub):
-        return self.dv.clip(x, lb, ub)
-
-    def count_outside_box(self, x, lb, ub):
-        return self.dv.count_outside_box(x, lb, ub) if len(x) else 0.0
-
-    def box_sphere_reduce(self, z, d, dscale, lb, ub):
-        return self.dv.box_sphere_reduce(z, d, dscale, lb, ub)
-
-    def index(self, idx):
-        """A host index array as the operand of ``take``."""
-        return torch.from_numpy(np.ascontiguousarray(idx, dtype=np.int32)).to(self.dv.ctx().device)
-
-    def take(self, v, idx):
-        """v[idx] (a gather kernel)."""
-        from . import _hip
-        out = self.dv._empty(idx.numel())
-        if idx.numel():
-            _hip.call("ipx_gather", idx.numel(), self.dv._p(v.t), self.dv._p(idx), None, None,
-                      self.dv._p(out), self.dv.stream_ptr())
-        return self.dv.DVec(out)
-
-    def csr(self, M, row_breaks=None, col_breaks=None):
-        """Local block on the device; row tiles (and those of the stored transpose) are cut
-        at the own / halo boundaries so per-tile partial sums can be taken over own tiles."""
-        A = self.dv.DeviceCSR.from_scipy(sps.csr_matrix(M), row_breaks=row_breaks)
-        if col_breaks is not None:
-            A.pattern.transpose(row_breaks=col_breaks)
-        return A
-
-    def refresh(self, A, data):
-        """Same pattern, new values (host array)."""
-        val = torch.from_numpy(np.ascontiguousarray(data, dtype=np.float64)).to(A.val.device)
-        return self.dv.DeviceCSR(A.pattern, val)
-
-    def rmatvec(self, A, v):
-        return A.T.dot(v)
-
-    def pack(self):
-        return self.dv.ScalarPack()
-
-    def from_tensor(self, t):
-        return self.dv.DVec(t.contiguous())
-
-    def row_sumsq(self, A):
-        """sum_j A_ij^2 per local row (diag of A A')."""
-        sq = self.dv.DVec(A.val) * self.dv.DVec(A.val)
-        return self.dv.DeviceCSR(A.pattern, sq.t).dot(self.dv.DVec.full(A.shape[1], 1.0))
-
-    def hessian(self, n, H_csr, diag):
-        from .operators import DeviceHessian
-        return DeviceHessian(n, csr=H_csr, diag=diag)
-
-    def normal_solver(self, A):
-        from .projector import BandedNormalSolver
-        return BandedNormalSolver(A)
-
-    def frob_sq_rows(self, A, r0, r1):
-        ip = A.pattern.indptr_h
-        v = self.dv.DVec(A.val[int(ip[r0]):int(ip[r1])])
-        return v.sumsq_amax()[0] if len(v) else 0.0
-
-    # -- barrier problems (z = [x; s])
-    def concat(self, parts):
-        return self.dv.hstack(parts)
-
-    def maximum(self, v, c):
-        from . import backend_hip
-        return backend_hip.maximum(v, c)
-
-    def where_positive(self, v, a, c):
-        from . import backend_hip
-        return backend_hip.where_positive(v, a, c)
-
-    def sum_log(self, s):
-        """(sum of log s_i over s_i > 0, number of s_i <= 0)"""
-        from . import _hip
-        if len(s) == 0:
-            return 0.0, 0.0
-        c = self.dv.ctx()
-        _hip.call("ipx_sum_log", len(s), self.dv._p(s.t), self.dv._p(c.out), self.dv._p(c.ws),
-                  self.dv.stream_ptr())
-        total, bad = self.dv.read_slots(2)
-        return total, bad
-
-    def assign_negated_where(self, s, mask, c):
-        """s[mask != 0] = -c[mask != 0] in place (tr_interior_point.py:92)."""
-        from . import _hip
-        if len(s):
-            _hip.call("ipx_assign_negated_where", len(s), self.dv._p(s.t), self.dv._p(mask.t),
-                      self.dv._p(c.t), self.dv.stream_ptr())
-
-    def augmented_box(self, J, s_nl, s_lb, s_ub, col_breaks=None):
-        """Local block of the barrier problem's augmented Jacobian for nonlinear inequality
-        rows + a box on every variable (tr_interior_point.py:141-194 on the canonical rows of
-        _canonical_constraint.py:350-355: nonlinear rows, all lower bounds, all upper bounds):
-
-            [ J   diag(s_nl)      0           0      ]
-            [ -I      0       diag(s_lb)      0      ]
-            [ +I      0           0       diag(s_ub) ]
-
-        on a pattern built once per Jacobian pattern; a refresh is four scatters.
-        ``col_breaks``: row-tile boundaries of the stored transpose (the own / halo
-        boundaries of the z segments, for per-tile partial sums over own entries)."""
-        from . import _hip
-        dvm = self.dv
-        pat = J.pattern
-        cache = getattr(pat, "_ipx_aug_box", None)
-        mE, nX = pat.shape
-        if cache is None:
-            ip = pat.indptr_h.astype(np.int64)
-            cnt = np.diff(ip)
-            rows_nl = ip + np.arange(mE + 1)                       # one slack entry per row
-            nnz_nl = int(rows_nl[-1])
-            indptr = np.concatenate((rows_nl, nnz_nl + 2 * np.arange(1, 2 * nX + 1)))
-            nnz = int(indptr[-1])
-            indices = np.empty(nnz, dtype=np.int32)
-            template = np.zeros(nnz)
-            pos_J = (np.arange(pat.nnz) + np.repeat(np.arange(mE), cnt)).astype(np.int64)
-            indices[pos_J] = pat.indices_h
-            pos_snl = rows_nl[1:] - 1
-            indices[pos_snl] = nX + np.arange(mE)
-            base = nnz_nl + 2 * np.arange(nX)
-            indices[base], template[base] = np.arange(nX), -1.0            # -I
-            pos_slb = base + 1
-            indices[pos_slb] = nX + mE + np.arange(nX)
-            base2 = nnz_nl + 2 * nX + 2 * np.arange(nX)
-            indices[base2], template[base2] = np.arange(nX), 1.0           # +I
-            pos_sub = base2 + 1
-            indices[pos_sub] = nX + mE + nX + np.arange(nX)
-            apat = dvm.CSRPattern(indptr.astype(np.int32), indices, (mE + 2 * nX, nX + mE + 2 * nX))
-            if col_breaks is not None:
-                apat.transpose(row_breaks=col_breaks)
-            dev = dvm.ctx().device
-            t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(dev)
-            cache = pat._ipx_aug_box = (apat, torch.from_numpy(template).to(dev), t(pos_J), t(pos_snl),
-                                        t(pos_slb), t(pos_sub))
-        apat, template, pos_J, pos_snl, pos_slb, pos_sub = cache
-        val = template.clone()
-        st = dvm.stream_ptr()
-        for src, idx in ((J.val, pos_J), (s_nl.t, pos_snl), (s_lb.t, pos_slb), (s_ub.t, pos_sub)):
-            if idx.numel():
-                _hip.call("ipx_scatter", idx.numel(), dvm._p(src), dvm._p(idx), dvm._p(val), st)
-        return dvm.DeviceCSR(apat, val)
-
-    def hessian_z(self, Hx, slack_block, breaks=None):
-        """[[Hx, 0], [0, diag(slack_block)]] for the local x-space operator ``Hx`` (row tiles
-        cut at ``breaks``)."""
-        from . import backend_hip
-        from .operators import DeviceHessian
-        n_x = Hx.shape[0] if hasattr(Hx, "shape") else Hx.n
-        n_tot = n_x + len(slack_block)
-        csr = self.dv.DeviceCSR(backend_hip._extend_pattern(Hx.csr.pattern, n_tot, breaks), Hx.csr.val)
-        xdiag = Hx.diag if Hx.diag is not None else self.dv.DVec.zeros(n_x)
-        return DeviceHessian(n_tot, csr, self.dv.hstack((xdiag, slack_block)))
-
-    def any_normal_solver(self, A):
-        """(A A')^-1 for a local block of any supported structure: the selection of
-        ``projector.projections`` (banded, box rows eliminated analytically, dense)."""
-        from . import projector
-        return projector.normal_solver_for(A)
-
-
+# --------------------------------------------------------------------------- vectors
 class _Empty:
     """A distributed vector of global length 0 (the slack / inequality-multiplier slices of a
     problem without inequalities)."""

@@ -8,9 +8,9 @@ R=/root/repo; OUT=$R/gpurun_out/final; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for s in $STEPS; do case $s in
 bench)
-  (cd $R && timeout 600 python3 bench.py 2>/tmp/bench.err | grep '^{' > $OUT/bench_line.json); tail -c 600 $OUT/bench_line.json; echo;;
+  (cd $R && timeout 900 python3 bench.py 2>/tmp/bench.err | grep '^{' > $OUT/bench_line.json); tail -c 600 $OUT/bench_line.json; echo;;
 trace)
-  rm -rf /tmp/bp; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/bp -o b -- python3 $R/bench.py --no-cpu > /tmp/bench_trace.out 2>/tmp/bench_trace.err
+  rm -rf /tmp/bp; timeout 1500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/bp -o b -- python3 $R/bench.py --no-cpu > /tmp/bench_trace.out 2>/tmp/bench_trace.err
   grep '^{' /tmp/bench_trace.out > $OUT/bench_under_trace.json
   cp $(find /tmp/bp -name '*kernel_stats.csv' | head -1) $OUT/bench_kernel_stats.csv
   (cd $R && python3 scripts/kernel_durations_by_size.py /tmp/bp $OUT/bench_kernel_durations_by_size.json > /dev/null);;

@@ -754,6 +754,11 @@ def test_bench_two_rank_rehearsal():
     # (two ranks of ~190 workgroups each cannot be resident side by side on ONE GPU: the group
     # refuses the resident form here and runs the three launches)
     assert pf["resident_form"] is False
+    # ... and the same code path at a size where both ranks' workgroups fit the chip together:
+    # one resident launch per rank and batch, the same iterates as the three launches
+    rr = d["resident_rehearsal"]
+    assert rr["resident_form"] is True and rr["resident_iterations_per_s"] > 0
+    assert rr["own_entries_max_abs_diff_between_the_forms"] < 1e-12
     per = d["host_calls_per_iteration_in_the_timed_region"]
     assert per["torch_distributed_all_reduce"] == 0 and per["torch_distributed_exchange"] == 0
     assert 0 < per["c_calls"] <= 0.2

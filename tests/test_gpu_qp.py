@@ -996,14 +996,13 @@ def test_step2_fused_into_hp_is_bit_identical(ips, variant, monkeypatch):
         assert np.max(np.abs(x1 - x2)) <= 1e-13 * np.max(np.abs(x2))
 
 
-@pytest.mark.parametrize("form", ["no-c16", "no-diag-merge", "no-fuse"])
+@pytest.mark.parametrize("form", ["no-fuse"])
 def test_debug_forms_of_the_three_launch_loop(ips, form, monkeypatch):
     """Every form the one debug switch (IPX_DEBUG_FORMS, ipsolver/_hip.py) can turn off has a
-    parity test; here the ones of the separate-launch loop at a size that is not resident
-    (n = 1e6 rows are the bench's; 6e5 is the smallest): 32-bit column indices in the fused
-    SpMV kernels (bit-identical), the Hessian's diagonal term as a vector of its own
-    ((h_ii + d_i) p_i against h_ii p_i + d_i p_i: 1e-13), no fused kernels at all (1e-13:
-    ||x + alpha p||^2 per vector chunk instead of per row tile)."""
+    parity test; here the one of the separate-launch loop at a size that is not resident
+    (n = 1e6 rows are the bench's; 6e5 is the smallest): no fused kernels at all (1e-13:
+    ||x + alpha p||^2 per vector chunk instead of per row tile).  (The 32-bit column indices
+    and the unmerged diagonal term of rounds 3-4 are gone with their switches.)"""
     import ipsolver.cg_fused as cg_fused
     from ipsolver.operators import DeviceHessian
     n, m = 600000, 60000
@@ -1018,7 +1017,7 @@ def test_debug_forms_of_the_three_launch_loop(ips, form, monkeypatch):
         else:
             monkeypatch.delenv("IPX_DEBUG_FORMS", raising=False)
         H = DeviceHessian(n, csr=ips.dv.DeviceCSR.from_scipy(inst.H), diag=ips.dv.DVec.from_host(hd))
-        assert (H.diag is None) == (flag != "no-diag-merge")
+        assert H.diag is None                                       # merged into the CSR values
         Z, LS, Y = ips.proj.projections(A)
         before = cg_fused.STATS["resident_calls"]
         x, info = ips.qp.projected_cg(H, inst.c, Z, Y, b, tol=0, max_iter=25, trust_radius=1e300)
@@ -1026,10 +1025,7 @@ def test_debug_forms_of_the_three_launch_loop(ips, form, monkeypatch):
         runs.append((host(x), info))
     (x1, i1), (x2, i2) = runs
     assert i1 == i2
-    if form == "no-c16":
-        assert np.array_equal(x1, x2)
-    else:
-        assert np.max(np.abs(x1 - x2)) <= 1e-13 * np.max(np.abs(x1))
+    assert np.max(np.abs(x1 - x2)) <= 1e-13 * np.max(np.abs(x1))
 
 
 @pytest.mark.parametrize("rl,shift,m", [(4, 3, 50001), (9, 5, 40000), (16, 9, 30000),
