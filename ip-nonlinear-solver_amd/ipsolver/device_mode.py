@@ -230,9 +230,14 @@ class _DeviceConstraint:
 
 
 def _check_jac(J):
-    if not isinstance(J, DeviceCSR):
+    """What a device-mode ``jac`` callback may return: a DeviceCSR, or -- dense Jacobians,
+    equality rows only (``DeviceRowMap.jac``) -- a DeviceDense / a 2-D CUDA tensor."""
+    from .dense import DeviceDense
+    if torch.is_tensor(J) and J.dim() == 2 and J.is_cuda:
+        J = DeviceDense(J.to(_F64).contiguous())
+    if not isinstance(J, (DeviceCSR, DeviceDense)):
         raise TypeError("device-callback mode: `jac` must return an ipsolver.device.DeviceCSR "
-                        "(dense Jacobians: use host callbacks)")
+                        "(or, for a dense Jacobian of equality rows, a 2-D CUDA tensor)")
     return J
 
 
