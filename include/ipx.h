@@ -546,6 +546,14 @@ typedef struct ipx_boxschur_args {
    * AR_colidx / AR_val [i * AR_rowlen + j]), else 0: ipx_boxschur_project then forms A_R u
    * inside the Schur solve's kernel (cyclic-reduction path) instead of by an SpMV launch. */
   int64_t AR_rowlen;
+  /* optional (with AR_rowlen, grp2, gaffine, yell_*): ipx_boxschur_project does the per-item
+   * back substitution as the TAIL of the Schur solve's kernel instead of in a launch of its own
+   * (4 -> 3 launches per CG iteration of the barrier problem).  post_own_g / post_own_e =
+   * (workgroups of the solve + 1) ints each: the range of groups / of other columns whose
+   * FIRST general row lies in a workgroup's post_rows_wg rows; post_reach = the largest
+   * distance from an item's first general row to its second.  NULL: the separate launch. */
+  const int32_t *post_own_g, *post_own_e;
+  int64_t post_rows_wg, post_reach;
 } ipx_boxschur_args;
 /* v = (A A')^-1 w; partial (optional, ceil(mR/256) doubles) receives the residual partials. */
 int ipx_boxschur_solve(const ipx_boxschur_args *a, const double *w, double *v, double *partial,

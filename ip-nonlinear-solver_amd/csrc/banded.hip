@@ -1073,6 +1073,29 @@ struct RowsJob {
 };
 constexpr int ROWS_PRODUCTS = 8192;     // products per workgroup: a window of <= 512 rows of <= 16 entries
 
+// Optional tail of the ROWS form (round 5; the barrier problem's projection, csrc/boxschur.hip):
+// the per-item back substitution of k_pairs_post -- y_c = (A_R' v_R)_c from the column's two
+// entries, v_S of the item's group, g on its columns, ||g||^2 partials -- done by the workgroup
+// whose rows are the first to touch the item's column, with v_R out of LDS: one launch and one
+// round trip of v_R through memory less per CG iteration.  Items in the order of
+// ipx_boxschur_args (the ng groups, then the ngen other columns), tables in their compact
+// forms only (grp2 + computed columns + item-indexed ELL(2) columns of A_R): own_g / own_e =
+// per workgroup the range of groups / of other columns it owns (non-decreasing first rows: the
+// host checks).  part: `count` partials per half -- workgroup w writes entry w and zeroes the
+// entries w + k gridDim beyond the grid, so a consumer may fold all `count` of them.
+constexpr int POST_PG = 6;              // group items per lane (<= 6 * 512 per workgroup)
+struct PostJob {
+  const int32_t *own_g, *own_e;
+  int ng, nitems;
+  ipx_group_tab T;
+  const int32_t *yrow;
+  const double *yval;
+  const double *r;
+  double *g;
+  double *part;
+  int count;
+};
+
 template <int K, int T, int QV>
 __global__ void __launch_bounds__(DOWN_T)
 k_solve_decoupled(LevDev lv, const double *__restrict__ w, double *__restrict__ x,
@@ -1415,11 +1438,12 @@ k_pcr_check(int m, int rows_wg, const double *__restrict__ band, int *flags) {
 // solve with its tail 10.4 / 28.8 us against 10.8 / 29.9 (256) and 12.6 / 38.6 (1024: one
 // workgroup per CU); the form that builds its own right-hand side (config 5) 7.9 us against
 // 9.1 (256) and 8.0 (1024).  One window row per lane, half the tail's loads per lane.
-template <int QV, int NR, bool ROWS, int TB>
+template <int QV, int NR, bool ROWS, int TB, bool POST = false>
 __global__ void __launch_bounds__(TB)
 k_solve_pcr(int m, int rows_wg, int L, const double *__restrict__ band,
             const double *__restrict__ w, double *__restrict__ x, double *__restrict__ partial,
-            const double *__restrict__ guard, AtvJob atv, RowsJob rows = RowsJob{}) {
+            const double *__restrict__ guard, AtvJob atv, RowsJob rows = RowsJob{},
+            PostJob post = PostJob{}) {
   constexpr int QA = QV > 0 ? QV : 1;
   constexpr int PAD = 1 << PCR_LMAX;                 // identity rows either side of the window
   constexpr int RS = PCR_RMAX + 2 * PAD;
@@ -1517,6 +1541,37 @@ k_solve_pcr(int m, int rows_wg, int L, const double *__restrict__ band,
       ar[k] = *reinterpret_cast<const v2d *>(atv.r_in + j);
     }
   }
+  // POST tail: the operands of this workgroup's items, requested now (the products of the ROWS
+  // form are in LDS, their registers free) so that they arrive while the reduction runs
+  int pg0 = 0, pgn = 0, pe0 = 0, pen = 0;
+  int py0[POST ? POST_PG + 1 : 1], py1[POST ? POST_PG + 1 : 1];
+  double pw0[POST ? POST_PG + 1 : 1], pw1[POST ? POST_PG + 1 : 1];
+  double pep[POST ? POST_PG : 1], peq[POST ? POST_PG : 1];
+  double prc[POST ? POST_PG + 1 : 1], prp[POST ? POST_PG : 1], prq[POST ? POST_PG : 1];
+  if constexpr (POST) {
+    pg0 = post.own_g[blockIdx.x]; pgn = post.own_g[blockIdx.x + 1] - pg0;
+    pe0 = post.own_e[blockIdx.x]; pen = post.own_e[blockIdx.x + 1] - pe0;
+    const ipx_group_tab &T = post.T;
+#pragma unroll
+    for (int k = 0; k < POST_PG; ++k) {
+      const int i = pg0 + min(tid + k * TB, max(pgn - 1, 0));       // (clamped: no branches)
+      const int gi = min(i, max(post.ng - 1, 0));
+      const int c = T.c0 + gi;
+      py0[k] = post.yrow[gi]; py1[k] = post.yrow[post.nitems + gi];
+      pw0[k] = post.yval[gi]; pw1[k] = post.yval[post.nitems + gi];
+      pep[k] = T.grp2[2 * gi]; peq[k] = T.grp2[2 * gi + 1];
+      prc[k] = post.r[c]; prp[k] = post.r[c + T.dp]; prq[k] = post.r[c + T.dq];
+    }
+    {
+      const int e = min(pe0 + min(tid, max(pen - 1, 0)), max(post.nitems - post.ng - 1, 0));
+      const int i = post.ng + e;
+      py0[POST_PG] = post.yrow[min(i, post.nitems - 1)];
+      py1[POST_PG] = post.yrow[post.nitems + min(i, post.nitems - 1)];
+      pw0[POST_PG] = post.yval[min(i, post.nitems - 1)];
+      pw1[POST_PG] = post.yval[post.nitems + min(i, post.nitems - 1)];
+      prc[POST_PG] = post.r[T.gen0 + e];
+    }
+  }
   if (stop != 0.0) return;
   IPX_STAMP(1);
   // level-0 rows kept for the residual
@@ -1566,7 +1621,7 @@ k_solve_pcr(int m, int rows_wg, int L, const double *__restrict__ band,
       if (r >= H && r < H + rows_wg && g < m) x[g] = xv;
     }
   }
-  if (!partial && QV == 0) return;
+  if (!partial && QV == 0 && !POST) return;
   ipx_lds_barrier();
   IPX_STAMP(6);
   if (QV > 0) {
@@ -1600,6 +1655,73 @@ k_solve_pcr(int m, int rows_wg, int L, const double *__restrict__ band,
     if (tid == 0) {
       atv.part3[blockIdx.x] = gtot;
       atv.part3[gridDim.x + blockIdx.x] = 0.0;
+    }
+    if (!partial) return;
+  }
+  if constexpr (POST) {
+    // ---- k_pairs_post's arithmetic, item by item, v_R out of LDS (sx: the window's solution,
+    // index = row - g0; an item's two rows are its first general row, in this workgroup's own
+    // rows, and at most 2^L rows after it: the host checks)
+    const ipx_group_tab &T = post.T;
+    const int wlim = R - 1;
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < POST_PG; ++k) {
+      if (tid + k * TB < pgn) {
+        const int gi = pg0 + tid + k * TB;
+        const int c = T.c0 + gi, cp = c + T.dp, cq = c + T.dq;
+        const double u0 = sx[min(max((int)(py0[k] - g0), 0), wlim)];
+        const double u1 = sx[min(max((int)(py1[k] - g0), 0), wlim)];
+        double sum = 0.0;
+        sum += pw0[k] * u0;
+        sum += pw1[k] * u1;
+        const double yj = 1.0 * sum;
+        const double ap = copysign(1.0, pep[k]), sp = fabs(pep[k]);
+        const double aq = copysign(1.0, peq[k]), sq = fabs(peq[k]);
+        const double rc = prc[k], rp = prp[k], rq = prq[k];
+        double i11, i12, i22, wgt;
+        ipx_group_inverse(true, ap, sp, aq, sq, i11, i12, i22, wgt);
+        const double wp = cp > c ? ap * rc + sp * rp : sp * rp + ap * rc;
+        const double wq = cq > c ? aq * rc + sq * rq : sq * rq + aq * rc;
+        const double ep = ap * yj, eq = aq * yj;
+        const double tp = i11 * wp + i12 * wq;
+        const double tq = i12 * wp + i22 * wq;
+        const double vp = tp - (i11 * ep + i12 * eq);
+        const double vq = tq - (i12 * ep + i22 * eq);
+        double s3 = yj + ap * vp;
+        s3 += aq * vq;
+        double gc = -1.0 * s3;
+        gc += 1.0 * rc;
+        double gp = -1.0 * (sp * vp);
+        gp += 1.0 * rp;
+        double gq = -1.0 * (sq * vq);
+        gq += 1.0 * rq;
+        post.g[c] = gc; post.g[cp] = gp; post.g[cq] = gq;
+        acc += gc * gc;
+        acc += gp * gp;
+        acc += gq * gq;
+      }
+    }
+    if (tid < pen) {
+      const int e = pe0 + tid;
+      const double u0 = sx[min(max((int)(py0[POST_PG] - g0), 0), wlim)];
+      const double u1 = sx[min(max((int)(py1[POST_PG] - g0), 0), wlim)];
+      double sum = 0.0;
+      sum += pw0[POST_PG] * u0;
+      sum += pw1[POST_PG] * u1;
+      double gc = -1.0 * (1.0 * sum);
+      gc += 1.0 * prc[POST_PG];
+      post.g[T.gen0 + e] = gc;
+      acc += gc * gc;
+    }
+    const double gtot = ipx_block_reduce<IPX_SUM>(acc, red_lds);
+    if (tid == 0) {
+      post.part[blockIdx.x] = gtot;
+      post.part[post.count + blockIdx.x] = 0.0;
+      for (int k = blockIdx.x + gridDim.x; k < post.count; k += gridDim.x) {
+        post.part[k] = 0.0;
+        post.part[post.count + k] = 0.0;
+      }
     }
     if (!partial) return;
   }
@@ -1650,7 +1772,8 @@ int launch_solve_pcr_q(const LevDev &lv, int L, const double *w, double *x, doub
 // the solve with its right-hand side formed from rows of one length (RowsJob); IPX_EUNSUPPORTED
 // when the window does not fit the kernel's fixed product count
 int launch_solve_pcr_rows(const LevDev &lv, int L, const RowsJob &rows, double *x,
-                          double *partial, int *npartial, const double *guard, hipStream_t st) {
+                          double *partial, int *npartial, const double *guard, hipStream_t st,
+                          const PostJob *post = nullptr) {
   const int rows_wg = DEC_CHUNKS * lv.q;
   const int R = rows_wg + 2 * (1 << L);
   if (R > PCR_TB || ((int64_t)R << rows.logL) > (int64_t)ROWS_PRODUCTS)
@@ -1666,8 +1789,20 @@ int launch_solve_pcr_rows(const LevDev &lv, int L, const RowsJob &rows, double *
                               (int)(LDS_LIMIT - 44 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_solve_pcr<0, 1, true, PCR_TB>), dim3(grid), dim3(PCR_TB), lds, st, lv.m,
-                     rows_wg, L, lv.band, nullptr, x, partial, guard, AtvJob{}, rows);
+  if (post) {
+    static bool attr_post = false;
+    if (!attr_post) {
+      (void)hipFuncSetAttribute((const void *)k_solve_pcr<0, 1, true, PCR_TB, true>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(LDS_LIMIT - 44 * 1024));
+      attr_post = true;
+    }
+    hipLaunchKernelGGL((k_solve_pcr<0, 1, true, PCR_TB, true>), dim3(grid), dim3(PCR_TB), lds, st,
+                       lv.m, rows_wg, L, lv.band, nullptr, x, partial, guard, AtvJob{}, rows, *post);
+  } else {
+    hipLaunchKernelGGL((k_solve_pcr<0, 1, true, PCR_TB>), dim3(grid), dim3(PCR_TB), lds, st, lv.m,
+                       rows_wg, L, lv.band, nullptr, x, partial, guard, AtvJob{}, rows);
+  }
   IPX_CHECK_LAUNCH();
   return IPX_OK;
 }
@@ -2462,14 +2597,22 @@ int ipx_banded_solve_resid_launch(void *handle, const double *w, double *x, doub
 // forms w by an SpMV and calls the plain entry.
 int ipx_banded_solve_rows_launch(void *handle, const int32_t *col, const double *val,
                                  const double *xin, int logL, double *x, double *partial,
-                                 int *npartial, const double *guard, hipStream_t st) {
+                                 int *npartial, const double *guard, hipStream_t st,
+                                 const ipx_post_job *pj) {
   if (!handle || !col || !val || !xin || !x || !partial || logL < 0 || logL > 4) return IPX_EINVAL;
   Banded *h = (Banded *)handle;
   if (!(h->fast && h->nlev > 1 && h->decoupled && h->pcr_L > 0)) return IPX_EUNSUPPORTED;
   const LevDev lv = to_dev(h->lev[0], nullptr);
   if (lv.k != 1) return IPX_EUNSUPPORTED;
+  if (!pj)
+    return launch_solve_pcr_rows(lv, h->pcr_L, RowsJob{col, val, xin, logL}, x, partial, npartial,
+                                 guard, st);
+  // the tail's tables were laid out for ONE geometry of the solve (rows per workgroup, level)
+  if (pj->rows_wg != DEC_CHUNKS * lv.q || (1 << h->pcr_L) < pj->reach) return IPX_EUNSUPPORTED;
+  PostJob post{pj->own_g, pj->own_e, pj->ng, pj->nitems, pj->T, pj->yrow, pj->yval, pj->r, pj->g,
+               pj->part, pj->count};
   return launch_solve_pcr_rows(lv, h->pcr_L, RowsJob{col, val, xin, logL}, x, partial, npartial,
-                               guard, st);
+                               guard, st, &post);
 }
 
 int ipx_banded_solve_guarded(void *handle, const double *w, double *x, const double *guard,

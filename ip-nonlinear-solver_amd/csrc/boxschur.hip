@@ -394,11 +394,24 @@ int ipx_boxschur_project_from(const ipx_boxschur_args *a, const double *r, doubl
   // reduction (the product is formed inside it, same bits), else the SpMV and the solve
   int np = 0;
   int rc = IPX_EUNSUPPORTED;
+  const int nblk = ipx_boxschur_project_count(a);
+  bool post_done = false;
   if (a->AR_rowlen > 0 && part_res) {
     int logL = 0;
     while ((1 << logL) < a->AR_rowlen) ++logL;
-    rc = ipx_banded_solve_rows_launch(a->inner, a->AR_colidx, a->AR_val, a->up, logL, a->vR,
-                                      part_res, &np, guard, st);
+    // one GPU, compact tables: the per-item back substitution rides in the solve's kernel
+    // (its partials fill the same `nblk` entries per half: workgroup sums, then zeros)
+    if (!own && a->post_own_g && a->post_own_e && a->grp2 && a->gaffine && a->yell_col &&
+        a->yell_val && nblk > 0) {
+      ipx_post_job pj{a->post_own_g, a->post_own_e, ng, (int)items, T, a->yell_col, a->yell_val,
+                      r, g, part_g, nblk, (int)a->post_rows_wg, (int)a->post_reach};
+      rc = ipx_banded_solve_rows_launch(a->inner, a->AR_colidx, a->AR_val, a->up, logL, a->vR,
+                                        part_res, &np, guard, st, &pj);
+      post_done = rc == IPX_OK;
+    }
+    if (!post_done)
+      rc = ipx_banded_solve_rows_launch(a->inner, a->AR_colidx, a->AR_val, a->up, logL, a->vR,
+                                        part_res, &np, guard, st);
   }
   if (rc == IPX_EUNSUPPORTED) {
     rc = ipx_spmv_launch(AR, a->up, 1.0, nullptr, 0.0, nullptr, a->rhs, nullptr, guard, st);
@@ -410,8 +423,8 @@ int ipx_boxschur_project_from(const ipx_boxschur_args *a, const double *r, doubl
   }
   if (rc) return rc;
   if (npart_res) *npart_res = np;
-  const int nblk = ipx_boxschur_project_count(a);
   if (npart_g) *npart_g = nblk;
+  if (post_done) return IPX_OK;
   ipx_own_ranges all;                                    // every column counts
   for (int k = 0; k < 4; ++k) { all.lo[k] = 0; all.hi[k] = 0; }
   all.hi[0] = a->n;

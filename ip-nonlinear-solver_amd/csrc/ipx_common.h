@@ -610,9 +610,26 @@ int ipx_spmv_launch(const ipx_csr_view &A, const double *x, double alpha, const 
                     const double *guard, hipStream_t st, const double *xrow_override = nullptr);
 int ipx_banded_solve_guarded(void *handle, const double *w, double *x, const double *guard,
                              hipStream_t st);
+#ifdef __HIPCC__
+// the per-item tail of the Schur solve's kernel (csrc/banded.hip PostJob), as csrc/boxschur.hip
+// hands it over: the tables' geometry (rows per workgroup of the solve they were laid out for,
+// how many rows after its first one an item's second row may lie) travels with them
+struct ipx_post_job {
+  const int32_t *own_g, *own_e;
+  int ng, nitems;
+  ipx_group_tab T;
+  const int32_t *yrow;
+  const double *yval;
+  const double *r;
+  double *g;
+  double *part;
+  int count, rows_wg, reach;
+};
 int ipx_banded_solve_rows_launch(void *handle, const int32_t *col, const double *val,
                                  const double *xin, int logL, double *x, double *partial,
-                                 int *npartial, const double *guard, hipStream_t st);
+                                 int *npartial, const double *guard, hipStream_t st,
+                                 const ipx_post_job *post = nullptr);
+#endif
 // ipx_boxschur_project with a->up (= r - alpha't) optionally prepared by the caller
 int ipx_boxschur_project_from(const ipx_boxschur_args *a, const double *r, double *g,
                               double *part_g, int32_t *npart_g, double *part_res,

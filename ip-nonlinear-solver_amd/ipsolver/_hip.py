@@ -167,12 +167,14 @@ def load():
 #   no-affine-groups   ... with the column table read instead of computed
 #   keep-xn2           ||x + alpha p||^2 formed even for an infinite trust radius
 #   pack-comm          sharded loop: the collectives in pack kernels of their own (5 launches)
+#   no-post-tail       barrier problems: the per-item back substitution as a launch of its own
+#                      (k_pairs_post) instead of as the tail of the Schur solve's kernel
 # Anything else that selects behaviour is an argument (``options={'shard': True}``) or a
 # deployment setting (IPX_SHARD, IPX_SHARD_TRANSPORT=dist).
 # (round 5 removed "no-c16" and "no-diag-merge": their A/Bs are settled -- profiles/r03*, r04* --
 # and the 16-bit index tables / the merged diagonal are what every qualifying pattern gets)
 DEBUG_FORMS = ("no-fuse", "no-resident", "no-compact-groups", "no-affine-groups", "keep-xn2",
-               "pack-comm")
+               "pack-comm", "no-post-tail")
 
 
 def debug_form(name):

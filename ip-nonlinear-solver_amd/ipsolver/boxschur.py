@@ -100,7 +100,9 @@ class BoxSchurArgs(ctypes.Structure):
                [(k, _P) for k in ("t", "u", "wR", "rhs", "vR", "y")] + \
                [("gcol", _P), ("grp", _P), ("gen_cols", _P), ("ngen", _I64), ("ny", _I64),
                 ("up", _P), ("grp2", _P), ("yell_col", _P), ("yell_val", _P)] + \
-               [(k, _I64) for k in ("gaffine", "gc0", "gdp", "gdq", "gen0", "AR_rowlen")]
+               [(k, _I64) for k in ("gaffine", "gc0", "gdp", "gdq", "gen0", "AR_rowlen")] + \
+               [("post_own_g", _P), ("post_own_e", _P), ("post_rows_wg", _I64),
+                ("post_reach", _I64)]
 
 
 class BoxSchurNormalSolver:
@@ -232,8 +234,60 @@ class BoxSchurNormalSolver:
             self._yell = self._item_columns(ARt)
             if self._yell is not None:
                 a.yell_col, a.yell_val = c["yell"][2].data_ptr(), self._yell.data_ptr()
+            post = self._post_tables() if (self._yell is not None and a.gaffine and a.AR_rowlen) \
+                else None
+            if post is not None:
+                a.post_own_g, a.post_own_e = post[0].data_ptr(), post[1].data_ptr()
+                a.post_rows_wg, a.post_reach = post[2], post[3]
             self._args = a
         return self._args
+
+    POST_PG, POST_TB = 6, 512            # csrc/banded.hip POST_PG, PCR_TB
+
+    def _post_tables(self):
+        """Item ranges per workgroup of the Schur solve for the fused back substitution
+        (ipx_boxschur_args.post_own_g / post_own_e), or None: an item belongs to the workgroup
+        whose rows contain the FIRST general row of its column; needs every item to have one,
+        first rows non-decreasing along the groups and along the other columns, the second row
+        within reach, and no workgroup with more items than the kernel's lanes take.  Symbolic;
+        cached per geometry of the solve."""
+        if _hip.debug_form("no-post-tail"):
+            return None
+        lib = _hip.load()
+        geo = (ctypes.c_int32 * 2)()
+        if not lib.ipx_banded_decoupled_geometry(ctypes.c_void_p(self.inner.handle), geo):
+            return None
+        rows_wg, nwg = int(geo[0]), int(geo[1])
+        L = int(lib.ipx_banded_pcr_level(ctypes.c_void_p(self.inner.handle)))
+        if L <= 0:
+            return None
+        c = self.c
+        key = ("post", rows_wg, nwg)
+        if key not in c:
+            c[key] = None
+            pat = self._keep.pattern                       # A_R' (rows = columns of A_R)
+            indptr, indices = pat.indptr_h.astype(np.int64), pat.indices_h.astype(np.int64)
+            ng = self.ng
+            cols = np.concatenate((self.an.col.astype(np.int64),
+                                   c["gen_cols"].cpu().numpy().astype(np.int64)))
+            cnt = indptr[cols + 1] - indptr[cols]
+            if len(cols) and cnt.min() >= 1 and cnt.max() <= 2:
+                first = indices[indptr[cols]]
+                second = np.where(cnt > 1, indices[np.minimum(indptr[cols] + 1, len(indices) - 1)],
+                                  first)
+                lo, hi = np.minimum(first, second), np.maximum(first, second)
+                ok = np.all(np.diff(lo[:ng]) >= 0) and np.all(np.diff(lo[ng:]) >= 0)
+                owner = lo // rows_wg
+                if ok and owner.max() < nwg:
+                    own_g = np.searchsorted(owner[:ng], np.arange(nwg + 1), side="left")
+                    own_e = np.searchsorted(owner[ng:], np.arange(nwg + 1), side="left")
+                    if np.diff(own_g).max() <= self.POST_PG * self.POST_TB and \
+                            np.diff(own_e).max() <= self.POST_TB:
+                        c[key] = (_i32(own_g), _i32(own_e), rows_wg, int((hi - lo).max()))
+        post = c[key]
+        if post is None or post[3] > (1 << L):
+            return None
+        return post
 
     def _item_columns(self, ARt):
         """Values of the columns of A_R per item of the projection, ELL(2) (see
