@@ -499,6 +499,7 @@ def config5_leg(run_twice=True):
         timer["calls"] += 1
         return out
     backend_hip.projected_cg = timed
+    other = None
     try:
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
@@ -509,6 +510,25 @@ def config5_leg(run_twice=True):
                 res = ipsolver.minimize_constrained(dc.fun, dc.x0, dc.grad, dc.hess, cons)
                 torch.cuda.synchronize()
                 wall = time.time() - t0
+            main = (timer["t"], timer["calls"])
+            # the same solve with the back substitution as a launch of its own (round 4's four
+            # launches): g is bit-identical, ||g||^2 is summed in another order -- and the run
+            # ends on another barrier level (profiles/r05_config5_levels.json)
+            try:
+                os.environ["IPX_DEBUG_FORMS"] = "no-post-tail"
+                timer["t"], timer["calls"] = 0.0, 0
+                torch.cuda.synchronize()
+                t0 = time.time()
+                res4 = ipsolver.minimize_constrained(dc.fun, dc.x0, dc.grad, dc.hess, cons)
+                torch.cuda.synchronize()
+                other = {"seconds": time.time() - t0, "status": int(res4.status),
+                         "niter": int(res4.niter), "cg_niter": int(res4.cg_niter),
+                         "cg_iterations_per_s_in_solve": res4.cg_niter / timer["t"] if timer["t"] else None,
+                         "launches_per_cg_iteration": 4,
+                         "active_bounds": int((res4.x.abs() > 0.8 - 1e-6).sum().item())}
+            finally:
+                os.environ.pop("IPX_DEBUG_FORMS", None)
+            timer["t"], timer["calls"] = main
     finally:
         backend_hip.projected_cg = plain
     x = res.x
@@ -519,12 +539,17 @@ def config5_leg(run_twice=True):
             "constr_violation": float(res.constr_violation),
             "projected_cg_calls": timer["calls"], "seconds_in_projected_cg": timer["t"],
             "cg_iterations_per_s_in_solve": res.cg_niter / timer["t"] if timer["t"] else None,
-            "launches_per_cg_iteration": 4,
-            "launches_note": "k_cg_step1_box, k_solve_pcr (which forms A_R u itself: the rows of "
-                             "A_R have one power-of-two length), k_pairs_post, k_cg_step2_hp by "
-                             "construction (csrc/cg.hip cg_iterate, box_project branch; 5 with a "
-                             "separate SpMV for other row shapes); rocprofv3 launch counts: "
-                             "profiles/r03_config5_kernel_stats.csv",
+            "launches_per_cg_iteration": 3,
+            "launches_note": "k_cg_step1_box, k_solve_pcr (which forms A_R u itself and, since "
+                             "round 5, does the per-item back substitution as its tail), "
+                             "k_cg_step2_hp by construction (csrc/cg.hip cg_iterate, box_project "
+                             "branch); rocprofv3 launch counts: profiles/r05_config5_kernel_stats.csv",
+            "with_the_back_substitution_as_its_own_launch": other,
+            "trajectory_note": "the two forms compute the same g bit for bit and sum ||g||^2 in "
+                               "different orders (one ulp in beta): level by level their CG counts "
+                               "agree to 2-7 %, but they pass the last level's stopping test on "
+                               "different sides and end one barrier level apart -- compare the "
+                               "per-iteration rates, not the wall clocks",
             "active_bounds": int((x.abs() > 0.8 - 1e-6).sum().item())}
 
 

@@ -8,8 +8,12 @@ import collections, csv, glob, json, os, sys, warnings
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "ip-nonlinear-solver_amd"))
 NC = 8000000
-KERNELS = {"k_cg_step1_box": 86.8e6, "k_pairs_post": 46.0e6, "k_solve_pcr": None,
-           "k_cg_step2_hp": 112.0e6}
+# (round 5: the per-item back substitution -- k_pairs_post, 46.0 MB algorithmic -- is the tail of
+# k_solve_pcr's launch; with IPX_DEBUG_FORMS=no-post-tail it is a launch of its own again)
+KERNELS = {"k_cg_step1_box": 86.8e6, "k_solve_pcr": 19.4e6 + 46.0e6, "k_cg_step2_hp": 112.0e6}
+if os.environ.get("IPX_DEBUG_FORMS", "").find("no-post-tail") >= 0:
+    KERNELS = {"k_cg_step1_box": 86.8e6, "k_pairs_post": 46.0e6, "k_solve_pcr": None,
+               "k_cg_step2_hp": 112.0e6}
 
 
 def summarize(fetch_dir, write_dir, out):
