@@ -52,7 +52,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_MFMA_PEAK_TFLOPS = 78.6   # AMD datasheet, dense fp64 matrix
-PMC_PROFILE = "r04_pmc_traffic_n1e6.json"      # see roofline.traffic_source
+PMC_PROFILE = "r05_pmc_traffic_n1e6.json"      # see roofline.traffic_source
 PMC_PROFILE_BIG = "r05_pmc_traffic_n16e6.json"
 
 

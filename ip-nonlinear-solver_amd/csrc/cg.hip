@@ -1831,8 +1831,20 @@ int ipx_cg_hp(const ipx_cg_args *a, void *stream) {
 // in ipx_cg_resume); IPX_EINVAL when the argument block does not enable it.
 int ipx_cg_step2_hp(const ipx_cg_args *a, int32_t it, int32_t mode, void *stream) {
   if (!a || !fused_hp(a)) return IPX_EINVAL;
-  return launch_step2_hp(a, it, mode, a->part2, part2_count(a), a->part3, part3_count(a),
-                         a->part4, part4_count(a), (hipStream_t)stream);
+  hipStream_t st = (hipStream_t)stream;
+  // long partial arrays are compacted first, as in the loop (cg_iterate): every workgroup folds
+  // all of them, and at n = 1.6e7 the 6000 uncompacted ||g||^2 partials doubled what a
+  // workgroup reads -- bench.py's "dominant kernel on its own" measured 495 us where the same
+  // kernel takes 226 us inside the loop
+  const double *p2 = a->part2, *p3 = a->part3, *p4 = a->part4;
+  int np2 = part2_count(a), np3 = part3_count(a), np4 = part4_count(a);
+  Compactor cmp(a);
+  if (!(mode & 1)) cmp.add(p2, np2, 2, 1024);
+  cmp.add(p3, np3, 2, 2048);
+  if (!(mode & 2)) cmp.add(p4, np4, 1, 1024);
+  int rc = cmp.launch(nullptr, st);
+  if (rc) return rc;
+  return launch_step2_hp(a, it, mode, p2, np2, p3, np3, p4, np4, st);
 }
 
 // Tail of an iteration after the host handled a stop-5 / stop-6 event:
