@@ -2145,7 +2145,12 @@ void *ipx_banded_create(int64_t m64, int32_t k, int32_t chunk) {
     h->nslab_lds = ((vec + h->nslab) * sizeof(double) <= LDS_LIMIT) ? (int)h->nslab : 0;
     h->mid_fits = vec * sizeof(double) <= LDS_LIMIT;
     const bool long_top = h->wide || (h->nlev >= 2 && h->lev[h->nlev - 1].m > ITER_TOP_MIN_ROWS);
-    h->fast = h->lds_down <= LDS_LIMIT && (long_top || h->mid_fits);
+    // (a tridiagonal band is a candidate for the cyclic-reduction solve whatever the size of the
+    // upper levels -- it never touches them: m = 1.6e6 used to fall back to the level-by-level
+    // form because its separator vectors do not fit k_middle's LDS; when the reduction turns
+    // out not to decouple, ipx_banded_status takes `fast` back)
+    const bool pcr_cand = l0.k == 1 && h->nlev >= 2 && h->pcr_flags != nullptr;
+    h->fast = h->lds_down <= LDS_LIMIT && (long_top || h->mid_fits || pcr_cand);
     h->fast_plan = h->fast;
     h->iter_cand = h->fast && long_top && decoupled_lds_for(l0.k, l0.q) <= LDS_LIMIT;
     if (h->iter_cand) {

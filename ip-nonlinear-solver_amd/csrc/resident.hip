@@ -105,6 +105,7 @@ struct ResJob {
   const double *band;
   double *x, *p, *r, *Hp;
   const double *A_val;
+  const double *A_valT;         // STREAM form: the values entry-major, [rl][m] (ipx_cg_resident_prepare)
   const uint16_t *A_off16;
   const int32_t *A_rowfirst;
   int rl;
@@ -351,9 +352,19 @@ __device__ __forceinline__ void halo_put(const ResJob &J, int wg, int area, cons
   }
 }
 
-template <bool NOXN2, bool HAS_DIAG, bool PEER>
-__global__ void __launch_bounds__(RB, 2)
+// STREAM: the form for problems of MORE workgroups than compute units (n = 1e6 on the benchmark's
+// banded problem: 385): two workgroups per CU, so a lane has 128 registers and a workgroup
+// 80 KB of LDS.  The vectors stay on the chip for the whole batch (r / g and p on their spans in
+// LDS, x and Hp on the own variables in registers, Hp's halo in a small LDS area); the MATRIX
+// values are re-read in every iteration, in layouts whose consecutive lanes read consecutive
+// words: A entry-major (A_valT, a copy made per call), H in its CSR order (a lane per row, rows
+// of <= 4 entries: consecutive lanes 24-32 bytes apart), A' in the ELL(2) form as above -- 70 MB
+// per iteration out of L2 / the Infinity Cache instead of the 188 MB the separate launches move
+// through HBM.  Each group of values is requested before the LDS work that precedes its use.
+template <bool NOXN2, bool HAS_DIAG, bool PEER, bool STREAM>
+__global__ void __launch_bounds__(RB, STREAM ? 4 : 2)
 k_cg_resident(ResJob J) {
+  static_assert(!(PEER && STREAM), "the streamed form is a one-GPU form");
   extern __shared__ __attribute__((aligned(16))) double rs_lds[];
   const int wg = blockIdx.x, tid = threadIdx.x;
   const int wgl = wg + J.wg0;                       // block of the (local) solve: the tables' index
@@ -365,15 +376,18 @@ k_cg_resident(ResJob J) {
   const int RS = R + 2 * H;                         // PCR rows incl. identity padding
   const int nspanP = (J.nspan + 1) & ~1;
   const int npsp = (J.navn + 2 * J.hmax + 1) & ~1;
+  const int hwP = (J.hw + 1) & ~1;
   double *rspan = rs_lds;                           // r / r_next / g on the span
-  double *hspan = rspan + nspanP;                   // Hp on the span
-  double *U = hspan + nspanP;                       // PCR ping-pong (6 RS) | squares of g, of the residual
-  const int usize = max(6 * RS, ((J.navn + 2) & ~1) + RB);
+  // Hp: on the span | STREAM: its halo only ([0, nl) left, [hwP, hwP + nr) right) and behind it
+  // the own entries the neighbours read ([2 hwP, +pl) first, [3 hwP, +pr) last ones)
+  double *hspan = rspan + nspanP;
+  double *U = hspan + (STREAM ? 4 * hwP : nspanP);  // PCR ping-pong (6 RS) | squares of g, of the residual
+  const int usize = STREAM ? 6 * RS : max(6 * RS, ((J.navn + 2) & ~1) + RB);
   double *sx = U + usize;                           // [R]: w, then v
   double *pspan = sx + ((R + 1) & ~1);              // p on own +- hmax
-  double *aval = pspan + npsp;                      // A's window rows: [R * rl] values
+  double *aval = pspan + npsp;                      // A's window rows: [R * rl] values (not STREAM)
   const int navnE = (J.navn + 2) & ~1;              // (pairs may start one before av0)
-  double *red = aval + ((R * J.rl + 1) & ~1);       // [32] reductions
+  double *red = aval + (STREAM ? 0 : ((R * J.rl + 1) & ~1));       // [32] reductions
   double *pa0 = U, *pa1 = U + RS, *pr0 = U + 2 * RS, *pr1 = U + 3 * RS, *pd0 = U + 4 * RS,
          *pd1 = U + 5 * RS;
 
@@ -425,10 +439,14 @@ k_cg_resident(ResJob J) {
     a0[0] = (row_in[0] && grow >= 1 && r >= 1) ? avv : 0.0;     // (row 0 of the window: cut)
     b0[0] = row_in[0] ? bv : 1.0;
   }
-  for (int i = tid; i < R * rl; i += RB) {
-    const int64_t kk = g0 * rl + i;                  // (window row i / rl, its entry i % rl)
-    aval[i] = (kk >= 0 && kk < (int64_t)J.m * rl) ? J.A_val[kk] : 0.0;
+  if constexpr (!STREAM) {
+    for (int i = tid; i < R * rl; i += RB) {
+      const int64_t kk = g0 * rl + i;                // (window row i / rl, its entry i % rl)
+      aval[i] = (kk >= 0 && kk < (int64_t)J.m * rl) ? J.A_val[kk] : 0.0;
+    }
   }
+  // (STREAM: this lane's window row in the entry-major copy)
+  const double *const arowT = J.A_valT + min(max(g0 + tid, (int64_t)0), (int64_t)J.m - 1);
   // (the sub-diagonal entry of the row below, for the residual of the own rows)
   double a0n;
   {
@@ -462,8 +480,11 @@ k_cg_resident(ResJob J) {
                                           //  addresses and clamps would all be live at once)
   // (iii) own rows tid + k RB of H (absent entries: value 0 on a valid column, so the row sums
   // need no length), x and the diagonal term on them
-  double hv[RQX][RLH], xo[RQX], dg[RQX];
+  // (STREAM: the values are re-read in every iteration -- hb = the row's first entry, hn = its
+  // length, 0 for a lane without the row; Hp on the own variables lives in ho)
+  double hv[RQX][RLH], xo[RQX], dg[RQX], ho[RQX];
   int hc2[RQX][RLH / 2];         // pspan indices of the entries, two per register
+  int hb[RQX], hn[RQX];
 #pragma unroll
   for (int k = 0; k < RQX; ++k) {
     const int i = min(tid + k * RB, max(avn - 1, 0));
@@ -475,15 +496,19 @@ k_cg_resident(ResJob J) {
     for (int t = 0; t < RLH; ++t) {
       const int kk = min(a + t, max(b - 1, a));
       const bool have = on && a + t < b;
-      const double v = J.H_val[kk];
       const int c = J.H_colidx[kk];
-      hv[k][t] = have ? v : 0.0;
+      if constexpr (!STREAM) {
+        const double v = J.H_val[kk];
+        hv[k][t] = have ? v : 0.0;
+      }
       cc[t] = have ? c - p_lo : J.hmax;
     }
 #pragma unroll
     for (int t = 0; t < RLH / 2; ++t) hc2[k][t] = cc[2 * t] | (cc[2 * t + 1] << 16);
+    hb[k] = a; hn[k] = on ? min(b - a, RLH) : 0;
     xo[k] = J.x[row];
     dg[k] = HAS_DIAG ? J.H_diag[row] : 0.0;
+    if constexpr (STREAM) ho[k] = J.Hp[row];
   }
   __builtin_amdgcn_sched_barrier(0);      // (keep the set-up's load groups apart: their
                                           //  addresses and clamps would all be live at once)
@@ -491,7 +516,14 @@ k_cg_resident(ResJob J) {
 #pragma unroll
   for (int k = 0; k < RQS; ++k) {
     const int j = tid + k * RB;
-    if (j < nspan) { rspan[j] = J.r[c_lo + j]; hspan[j] = J.Hp[c_lo + j]; }
+    if (j < nspan) {
+      rspan[j] = J.r[c_lo + j];
+      if constexpr (!STREAM) hspan[j] = J.Hp[c_lo + j];
+    }
+  }
+  if constexpr (STREAM) {
+    for (int e = tid; e < nl; e += RB) hspan[e] = J.Hp[c_lo + e];
+    for (int e = tid; e < nr; e += RB) hspan[hwP + e] = J.Hp[av1 + e];
   }
   for (int j = tid; j < avn + 2 * J.hmax; j += RB) {
     const int col = p_lo + j;
@@ -566,7 +598,33 @@ k_cg_resident(ResJob J) {
     niter_inc += 1; st_pthp = ptHp; st_alpha = alpha;
     RS_STAMP(0);
     // ================= phase P: r_next, w = A r_next, cyclic reduction, g ====================
+    // (STREAM: this lane's window row of A, entry-major: used after the update of r)
+    double aas[RLA];
+    if constexpr (STREAM) {
+#pragma unroll
+      for (int k = 0; k < RLA; ++k) aas[k] = arowT[(int64_t)min(k, rl - 1) * J.m];
+    }
     ipx_lds_barrier();
+    if constexpr (STREAM) {
+      // own variables: Hp out of registers; the halo columns: Hp as the neighbours sent it
+      double rv[RQX], rh[2], hh[2];
+      int jh[2];
+#pragma unroll
+      for (int k = 0; k < RQX; ++k) rv[k] = rspan[own_off + min(tid + k * RB, avn - 1)];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int e = min(tid + k * RB, max(nl + nr - 1, 0));
+        jh[k] = e < nl ? e : own_off + avn + (e - nl);
+        rh[k] = rspan[min(jh[k], nspan - 1)];
+        hh[k] = hspan[e < nl ? e : hwP + (e - nl)];
+      }
+#pragma unroll
+      for (int k = 0; k < RQX; ++k)
+        if (tid + k * RB < avn) rspan[own_off + tid + k * RB] = rv[k] + alpha * ho[k];   // :622
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+        if (tid + k * RB < nl + nr) rspan[jh[k]] = rh[k] + alpha * hh[k];
+    } else {
 #pragma unroll
     for (int k0 = 0; k0 < RQS; k0 += 4) {
       double rv[4], hh[4];
@@ -580,6 +638,7 @@ k_cg_resident(ResJob J) {
         const int j = tid + (k0 + k) * RB;
         if (j < nspan) rspan[j] = rv[k] + alpha * hh[k];                 // :622
       }
+    }
     }
     double sxx = 0.0;
     if (!NOXN2) {
@@ -614,7 +673,7 @@ k_cg_resident(ResJob J) {
           rr[k + 1] = rspan[(pk >> 16) & 0xffff];
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) aa[k] = arow[min(k0 + k, rl - 1)];
+        for (int k = 0; k < 8; ++k) aa[k] = STREAM ? aas[k0 + k] : arow[min(k0 + k, rl - 1)];
 #pragma unroll
         for (int k = 0; k < 8; ++k)
           if (k0 + k < rl) sum += aa[k] * rr[k];
@@ -678,7 +737,9 @@ k_cg_resident(ResJob J) {
     // g = r_next - A'v on the own variables: the expressions of k_solve_pcr's tail; g replaces r
     // on the span, its squares go to LDS and are added up in THAT kernel's order (its lane t
     // takes the pairs t, t + 256, ...: same bits of ||g||^2)
+    // (STREAM: no room for the squares in LDS -- a lane adds up its own, all eight waves fold)
     double *gsq = U;                                  // [2 * pairs] (the PCR buffers are free)
+    double gdir = 0.0, rdir = 0.0;
     {
       double v4[RQP][4], rn[RQP][2];
 #pragma unroll
@@ -705,7 +766,12 @@ k_cg_resident(ResJob J) {
         const bool in1 = j + 1 >= av0 && j + 1 < (int64_t)av1;
         if (in0) rspan[j - c_lo] = y0;
         if (in1) rspan[j + 1 - c_lo] = y1;
-        if (j - vb < navnE) { gsq[j - vb] = in0 ? y0 * y0 : 0.0; gsq[j - vb + 1] = in1 ? y1 * y1 : 0.0; }
+        if constexpr (STREAM) {
+          gdir += in0 ? y0 * y0 : 0.0;
+          gdir += in1 ? y1 * y1 : 0.0;
+        } else {
+          if (j - vb < navnE) { gsq[j - vb] = in0 ? y0 * y0 : 0.0; gsq[j - vb + 1] = in1 ? y1 * y1 : 0.0; }
+        }
       }
     }
     RS_STAMP(4);
@@ -728,11 +794,11 @@ k_cg_resident(ResJob J) {
         const double res = w0[0] - sum;
         res2 = res * res;
       }
-      rsq[tid] = res2;
+      if constexpr (STREAM) rdir = res2; else rsq[tid] = res2;
     }
     ipx_lds_barrier();
-    double gacc = 0.0, acc = 0.0;
-    if (tid < 256) {
+    double gacc = STREAM ? gdir : 0.0, acc = STREAM ? rdir : 0.0;
+    if (!STREAM && tid < 256) {
       double q2[2 * ((RQP * RB) / 256)];
 #pragma unroll
       for (int k = 0; k < (RQP * RB) / 256; ++k) {
@@ -753,16 +819,17 @@ k_cg_resident(ResJob J) {
       const double s0 = ipx_wave_sum(sxx), s1 = ipx_wave_sum(gacc), s2 = ipx_wave_sum(acc);
       if (lane == 0) { red[wave] = s0; red[8 + wave] = s1; red[16 + wave] = s2; }
       ipx_lds_barrier();
-      double t0[RB / 64], t1[4], t2[4];
+      constexpr int NW12 = STREAM ? RB / 64 : 4;
+      double t0[RB / 64], t1[NW12], t2[NW12];
 #pragma unroll
       for (int w = 0; w < RB / 64; ++w) t0[w] = red[w];
 #pragma unroll
-      for (int w = 0; w < 4; ++w) { t1[w] = red[8 + w]; t2[w] = red[16 + w]; }
+      for (int w = 0; w < NW12; ++w) { t1[w] = red[8 + w]; t2[w] = red[16 + w]; }
       double r0 = t0[0], r1 = t1[0], r2 = t2[0];
 #pragma unroll
       for (int w = 1; w < RB / 64; ++w) r0 += t0[w];
 #pragma unroll
-      for (int w = 1; w < 4; ++w) { r1 += t1[w]; r2 += t2[w]; }
+      for (int w = 1; w < NW12; ++w) { r1 += t1[w]; r2 += t2[w]; }
       mine3[0] = r0; mine3[1] = r1; mine3[2] = r2;
       ipx_lds_barrier();
     }
@@ -809,6 +876,14 @@ k_cg_resident(ResJob J) {
       // pspan): every old value is read before the barrier, every new one written after it
       double po[RQX + 1], gv[RQX + 1];
       const int np_ = avn + 2 * J.hmax;
+      if constexpr (STREAM) {
+        // (the own rows of H, requested ahead of the LDS passes below; absent entries: the
+        // row's last one, multiplied by zero further down)
+#pragma unroll
+        for (int k = 0; k < RQX; ++k)
+#pragma unroll
+          for (int t = 0; t < RLH; ++t) hv[k][t] = J.H_val[hb[k] + min(t, max(hn[k] - 1, 0))];
+      }
 #pragma unroll
       for (int k0 = 0; k0 < RQX; k0 += 6) {
         double px[6];
@@ -855,20 +930,30 @@ k_cg_resident(ResJob J) {
         const int k = k0 + kk;
         double sum = 0.0;
 #pragma unroll
-        for (int t = 0; t < RLH; ++t) sum += hv[k][t] * pp[kk][t];       // (absent entries: + 0.0)
+        for (int t = 0; t < RLH; ++t)                                     // (absent entries: + 0.0)
+          sum += (STREAM ? (t < hn[k] ? hv[k][t] : 0.0) : hv[k][t]) * pp[kk][t];
         y[kk] = 1.0 * sum;
         if (HAS_DIAG) y[kk] += dg[k] * xr[kk];
         if (tid + k * RB < avn) acc_xy += xr[kk] * y[kk];
       }
       // (hspan is written here and read nowhere in this phase)
 #pragma unroll
-      for (int kk = 0; kk < 3; ++kk)
-        if (tid + (k0 + kk) * RB < avn) hspan[own_off + tid + (k0 + kk) * RB] = y[kk];
+      for (int kk = 0; kk < 3; ++kk) {
+        const int i = tid + (k0 + kk) * RB;
+        if constexpr (STREAM) {
+          ho[k0 + kk] = y[kk];
+          if (i < pl) hspan[2 * hwP + i] = y[kk];
+          if (i < avn && i >= avn - pr) hspan[3 * hwP + (i - (avn - pr))] = y[kk];
+        } else {
+          if (i < avn) hspan[own_off + i] = y[kk];
+        }
+      }
     }
     if (it + 1 != J.it_end) {                         // (the halo of Hp: hop 1's tag; as above)
       ipx_lds_barrier();
-      halo_put<PEER>(J, wg, 0, hspan + own_off, pl, J.seq + hop + 1);
-      halo_put<PEER>(J, wg, 1, hspan + own_off + avn - pr, pr, J.seq + hop + 1);
+      halo_put<PEER>(J, wg, 0, STREAM ? hspan + 2 * hwP : hspan + own_off, pl, J.seq + hop + 1);
+      halo_put<PEER>(J, wg, 1, STREAM ? hspan + 3 * hwP : hspan + own_off + avn - pr, pr,
+                     J.seq + hop + 1);
     }
     double mine1[1], loc1[1] = {acc_xy};
     res_block_sum<1>(loc1, red, mine1);         // (barriers inside: Hp is complete on the own part)
@@ -887,7 +972,8 @@ k_cg_resident(ResJob J) {
         double s1[1];
         const bool ok = hop_wait<1, PEER>(J, tag, res_records(J.ll, hop), J.gnwg, s1,
                                           halo_from_left(J, wg, 1), halo_from_right(J, wg, 0),
-                                          last ? 0 : nl, last ? 0 : nr, hspan, hspan + own_off + avn,
+                                          last ? 0 : nl, last ? 0 : nr, hspan,
+                                          STREAM ? hspan + hwP : hspan + own_off + avn,
                                           last ? 8 * J.timeout : J.timeout);
         sv[0] = s1[0]; sv[1] = ok ? 0.0 : 1.0;
       }
@@ -930,7 +1016,7 @@ k_cg_resident(ResJob J) {
       J.x[av0 + i] = xo[k];
       J.p[av0 + i] = pspan[J.hmax + i];
       J.r[av0 + i] = rspan[own_off + i];
-      J.Hp[av0 + i] = hspan[own_off + i];
+      J.Hp[av0 + i] = STREAM ? ho[k] : hspan[own_off + i];
     }
   }
   // partial arrays as the separate launches' consumers fold them: the total in entry 0, zeros

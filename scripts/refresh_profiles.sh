@@ -1,7 +1,7 @@
 #!/bin/bash
 # Box-side refresh of the evidence under profiles/ (run through gpurun from the repo root):
 # traces go to /tmp, only the summaries to gpurun_out/final/ (copy them into profiles/ by hand).
-#   bash scripts/refresh_profiles.sh <commit> [steps: bench trace pmc pmc5 config5]
+#   bash scripts/refresh_profiles.sh <commit> [steps: pmc attach bench bench20 trace pmc5 config5]
 COMMIT=${1:-?}; shift
 STEPS=${@:-bench trace pmc config5}
 R=/root/repo; OUT=$R/gpurun_out/final; mkdir -p $OUT
@@ -22,6 +22,10 @@ pmc)
     done
     (cd $R && python3 scripts/pmc_summarize.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE $OUT/pmc_traffic_$tag.json "$note" $COMMIT | tail -5)
   done;;
+attach)   # (on the box: the bench line's `traffic` reads profiles/, guarded by the source hash)
+  cp $OUT/pmc_traffic_n1e6.json $R/profiles/r05_pmc_traffic_n1e6.json; cp $OUT/pmc_traffic_n16e6.json $R/profiles/r05_pmc_traffic_n16e6.json;;
+bench20)
+  (cd $R && timeout 600 python3 bench.py --steps 20 --warmup 5 2>/dev/null | grep '^{' > $OUT/bench_line_steps20.json);;
 pmc5)
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/pmc5_$c; timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc5_$c -- python3 $R/scripts/pmc_config5.py > /dev/null 2>/tmp/pmc5_$c.err
