@@ -105,7 +105,13 @@ struct ResJob {
   const double *band;
   double *x, *p, *r, *Hp;
   const double *A_val;
-  const double *A_valT;         // STREAM form: the values entry-major, [rl][m] (ipx_cg_resident_prepare)
+  // STREAM form: A's values and 16-bit column offsets entry-major ([rl][m]); H's values
+  // entry-major, rows padded with zeros to RLH ([RLH][n]); per row of H the columns of its RLH
+  // entries as bytes (column - row + hmax; an absent entry: hmax)
+  const double *A_valT;
+  const uint16_t *A_off16T;
+  const double *H_valT;
+  const uint32_t *H_rel;
   const uint16_t *A_off16;
   const int32_t *A_rowfirst;
   int rl;
@@ -251,8 +257,7 @@ template <int NS, bool SYS>
 __device__ __forceinline__ bool hop_wait(const ResJob &J, uint32_t tag, const ull *scal, int nrec,
                                          double (&sv)[NS], const ull *left, const ull *right,
                                          int nl, int nr, double *dst_l, double *dst_r,
-                                         long long timeout) {
-  const int tid = threadIdx.x;
+                                         long long timeout, int tid) {
   const long long deadline = (long long)wall_clock64() + timeout;
   bool sdone[NS];
   const bool slane = tid < nrec;
@@ -317,8 +322,7 @@ __device__ __forceinline__ bool hop_wait(const ResJob &J, uint32_t tag, const ul
 // of this GPU
 template <int NS, bool PEER>
 __device__ __forceinline__ void rec_put(const ResJob &J, uint32_t hop, int gw, const double (&v)[NS],
-                                        uint32_t tag) {
-  const int tid = threadIdx.x;
+                                        uint32_t tag, int tid) {
   if constexpr (PEER) {
     if (tid < NS * J.world) {
       const int r = tid / NS, q = tid - r * NS;
@@ -340,14 +344,14 @@ __device__ __forceinline__ void rec_put(const ResJob &J, uint32_t hop, int gw, c
 // publish `cnt` doubles of LDS (src[0..cnt), cnt <= RHK/2 * RB) into one of this workgroup's areas
 template <bool PEER>
 __device__ __forceinline__ void halo_put(const ResJob &J, int wg, int area, const double *src,
-                                         int cnt, uint32_t tag) {
+                                         int cnt, uint32_t tag, int tid) {
   ull *dst = halo_dst<PEER>(J, wg, area);
   double v[RHK / 2];
 #pragma unroll
-  for (int k = 0; k < RHK / 2; ++k) v[k] = src[min((int)threadIdx.x + k * RB, max(cnt - 1, 0))];
+  for (int k = 0; k < RHK / 2; ++k) v[k] = src[min(tid + k * RB, max(cnt - 1, 0))];
 #pragma unroll
   for (int k = 0; k < RHK / 2; ++k) {
-    const int j = threadIdx.x + k * RB;
+    const int j = tid + k * RB;
     if (j < cnt) ll_put<PEER>(dst + 2 * j, v[k], tag);
   }
 }
@@ -423,17 +427,21 @@ k_cg_resident(ResJob J) {
   double a0[RNR], b0[RNR];
   bool row_in[RNR];
   int ac2[RLA / 2];
+  int afirst;                    // (STREAM) span index of the row's first column, -1: no such row
   {
     const int r = tid;
     const int64_t grow = g0 + r;
     row_in[0] = r < R && grow >= 0 && grow < J.m;
     const int64_t gc = min(max(grow, (int64_t)0), (int64_t)J.m - 1);
     const int first = J.A_rowfirst[gc] - c_lo;
+    afirst = row_in[0] ? first : -1;
+    if constexpr (!STREAM) {
 #pragma unroll
-    for (int k = 0; k < RLA / 2; ++k) {
-      const int c0 = row_in[0] ? first + (int)J.A_off16[gc * rl + min(2 * k, rl - 1)] : 0;
-      const int c1 = row_in[0] ? first + (int)J.A_off16[gc * rl + min(2 * k + 1, rl - 1)] : 0;
-      ac2[k] = c0 | (c1 << 16);
+      for (int k = 0; k < RLA / 2; ++k) {
+        const int c0 = row_in[0] ? first + (int)J.A_off16[gc * rl + min(2 * k, rl - 1)] : 0;
+        const int c1 = row_in[0] ? first + (int)J.A_off16[gc * rl + min(2 * k + 1, rl - 1)] : 0;
+        ac2[k] = c0 | (c1 << 16);
+      }
     }
     const double bv = J.band[gc], avv = J.band[(int64_t)J.m + gc];
     a0[0] = (row_in[0] && grow >= 1 && r >= 1) ? avv : 0.0;     // (row 0 of the window: cut)
@@ -445,8 +453,6 @@ k_cg_resident(ResJob J) {
       aval[i] = (kk >= 0 && kk < (int64_t)J.m * rl) ? J.A_val[kk] : 0.0;
     }
   }
-  // (STREAM: this lane's window row in the entry-major copy)
-  const double *const arowT = J.A_valT + min(max(g0 + tid, (int64_t)0), (int64_t)J.m - 1);
   // (the sub-diagonal entry of the row below, for the residual of the own rows)
   double a0n;
   {
@@ -462,7 +468,7 @@ k_cg_resident(ResJob J) {
   // pairs: the array's own layout)
   const int64_t vb = av0 & ~1;
   int ec2[RQP][2];               // window rows of (entry 0 | entry 1 << 16) of variables j, j + 1
-  {
+  if constexpr (!STREAM) {
     const int64_t lastj = max((int64_t)av1 - 1, vb) & ~(int64_t)1;
 #pragma unroll
     for (int k = 0; k < RQP; ++k) {
@@ -480,32 +486,30 @@ k_cg_resident(ResJob J) {
                                           //  addresses and clamps would all be live at once)
   // (iii) own rows tid + k RB of H (absent entries: value 0 on a valid column, so the row sums
   // need no length), x and the diagonal term on them
-  // (STREAM: the values are re-read in every iteration -- hb = the row's first entry, hn = its
-  // length, 0 for a lane without the row; Hp on the own variables lives in ho)
+  // (STREAM: values and columns are re-read in every iteration, from the entry-major tables; Hp
+  // on the own variables lives in ho)
   double hv[RQX][RLH], xo[RQX], dg[RQX], ho[RQX];
   int hc2[RQX][RLH / 2];         // pspan indices of the entries, two per register
-  int hb[RQX], hn[RQX];
 #pragma unroll
   for (int k = 0; k < RQX; ++k) {
     const int i = min(tid + k * RB, max(avn - 1, 0));
     const int row = av0 + i;
-    const int a = J.H_rowptr[row], b = J.H_rowptr[row + 1];
     const bool on = tid + k * RB < avn;
-    int cc[RLH];
+    if constexpr (!STREAM) {
+      const int a = J.H_rowptr[row], b = J.H_rowptr[row + 1];
+      int cc[RLH];
 #pragma unroll
-    for (int t = 0; t < RLH; ++t) {
-      const int kk = min(a + t, max(b - 1, a));
-      const bool have = on && a + t < b;
-      const int c = J.H_colidx[kk];
-      if constexpr (!STREAM) {
+      for (int t = 0; t < RLH; ++t) {
+        const int kk = min(a + t, max(b - 1, a));
+        const bool have = on && a + t < b;
+        const int c = J.H_colidx[kk];
         const double v = J.H_val[kk];
         hv[k][t] = have ? v : 0.0;
+        cc[t] = have ? c - p_lo : J.hmax;
       }
-      cc[t] = have ? c - p_lo : J.hmax;
-    }
 #pragma unroll
-    for (int t = 0; t < RLH / 2; ++t) hc2[k][t] = cc[2 * t] | (cc[2 * t + 1] << 16);
-    hb[k] = a; hn[k] = on ? min(b - a, RLH) : 0;
+      for (int t = 0; t < RLH / 2; ++t) hc2[k][t] = cc[2 * t] | (cc[2 * t + 1] << 16);
+    }
     xo[k] = J.x[row];
     dg[k] = HAS_DIAG ? J.H_diag[row] : 0.0;
     if constexpr (STREAM) ho[k] = J.Hp[row];
@@ -553,27 +557,27 @@ k_cg_resident(ResJob J) {
     const bool le = wg == 0 && J.rank > 0, re = wg == J.nwg - 1 && J.rank < J.world - 1;
     ipx_lds_barrier();                              // (the vectors are in LDS)
     if (le) {
-      halo_put<PEER>(J, wg, 2, rspan + own_off, pl, tag);
-      halo_put<PEER>(J, wg, 0, hspan + own_off, pl, tag);
-      halo_put<PEER>(J, wg, 4, pspan + J.hmax, J.hmax, tag);
+      halo_put<PEER>(J, wg, 2, rspan + own_off, pl, tag, tid);
+      halo_put<PEER>(J, wg, 0, hspan + own_off, pl, tag, tid);
+      halo_put<PEER>(J, wg, 4, pspan + J.hmax, J.hmax, tag, tid);
     }
     if (re) {
-      halo_put<PEER>(J, wg, 3, rspan + own_off + avn - pr, pr, tag);
-      halo_put<PEER>(J, wg, 1, hspan + own_off + avn - pr, pr, tag);
-      halo_put<PEER>(J, wg, 5, pspan + avn, J.hmax, tag);
+      halo_put<PEER>(J, wg, 3, rspan + own_off + avn - pr, pr, tag, tid);
+      halo_put<PEER>(J, wg, 1, hspan + own_off + avn - pr, pr, tag, tid);
+      halo_put<PEER>(J, wg, 5, pspan + avn, J.hmax, tag, tid);
     }
     const double mine0[1] = {wg == 0 ? ptHp : 0.0};
-    rec_put<1, PEER>(J, hop, gw, mine0, tag);
+    rec_put<1, PEER>(J, hop, gw, mine0, tag, tid);
     double s1[1], dum[1];
     bool ok = hop_wait<1, PEER>(J, tag, res_records(J.ll, hop), J.gnwg, s1,
                                 halo_from_left(J, wg, 3), halo_from_right(J, wg, 2),
-                                le ? nl : 0, re ? nr : 0, rspan, rspan + own_off + avn, J.timeout);
+                                le ? nl : 0, re ? nr : 0, rspan, rspan + own_off + avn, J.timeout, tid);
     if (le || re) {
       ok = hop_wait<1, PEER>(J, tag, J.ll, 0, dum, halo_from_left(J, wg, 1), halo_from_right(J, wg, 0),
-                             le ? nl : 0, re ? nr : 0, hspan, hspan + own_off + avn, J.timeout) && ok;
+                             le ? nl : 0, re ? nr : 0, hspan, hspan + own_off + avn, J.timeout, tid) && ok;
       ok = hop_wait<1, PEER>(J, tag, J.ll, 0, dum, halo_from_left(J, wg, 5), halo_from_right(J, wg, 4),
                              le ? J.hmax : 0, re ? J.hmax : 0, pspan, pspan + J.hmax + avn,
-                             J.timeout) && ok;
+                             J.timeout, tid) && ok;
     }
     double sv[2] = {s1[0], ok ? 0.0 : 1.0}, tot[2];
     res_block_sum<2>(sv, red, tot);                 // (barriers inside: the halos are in LDS)
@@ -600,9 +604,18 @@ k_cg_resident(ResJob J) {
     // ================= phase P: r_next, w = A r_next, cyclic reduction, g ====================
     // (STREAM: this lane's window row of A, entry-major: used after the update of r)
     double aas[RLA];
+    int aof[RLA];
     if constexpr (STREAM) {
+      // (uniform base + the lane's 32-bit row: one address register per lane, not one pair per
+      // load -- and computed from this iteration's opaque lane index, so none is hoisted)
+      const uint32_t growT = (uint32_t)min(max(g0 + tid, (int64_t)0), (int64_t)J.m - 1);
 #pragma unroll
-      for (int k = 0; k < RLA; ++k) aas[k] = arowT[(int64_t)min(k, rl - 1) * J.m];
+      for (int k = 0; k < RLA; ++k) {
+        const double *vb_k = J.A_valT + (int64_t)min(k, rl - 1) * J.m;
+        const uint16_t *ob_k = J.A_off16T + (int64_t)min(k, rl - 1) * J.m;
+        aas[k] = vb_k[growT];
+        aof[k] = (int)ob_k[growT];
+      }
     }
     ipx_lds_barrier();
     if constexpr (STREAM) {
@@ -668,9 +681,14 @@ k_cg_resident(ResJob J) {
         double rr[8], aa[8];
 #pragma unroll
         for (int k = 0; k < 8; k += 2) {
-          const int pk = res_opaque(ac2[(k0 + k) >> 1]);
-          rr[k] = rspan[pk & 0xffff];
-          rr[k + 1] = rspan[(pk >> 16) & 0xffff];
+          if constexpr (STREAM) {
+            rr[k] = rspan[afirst >= 0 ? afirst + aof[k0 + k] : 0];
+            rr[k + 1] = rspan[afirst >= 0 ? afirst + aof[k0 + k + 1] : 0];
+          } else {
+            const int pk = res_opaque(ac2[(k0 + k) >> 1]);
+            rr[k] = rspan[pk & 0xffff];
+            rr[k + 1] = rspan[(pk >> 16) & 0xffff];
+          }
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) aa[k] = STREAM ? aas[k0 + k] : arow[min(k0 + k, rl - 1)];
@@ -685,7 +703,19 @@ k_cg_resident(ResJob J) {
     // (the values of A' for the tail, requested now, used after the cyclic reduction)
     typedef double v2d __attribute__((ext_vector_type(2)));
     v2d e0[RQP], e1[RQP];
-    {
+    int er[RQP][2];                                   // (STREAM) the entries' first window rows
+    if constexpr (STREAM) {
+      const uint32_t lastj = (uint32_t)(max((int64_t)av1 - 1, vb) & ~(int64_t)1);
+      const double *ev1 = J.ell_val + (int64_t)J.n;
+#pragma unroll
+      for (int k = 0; k < RQP; ++k) {
+        const uint32_t j = min((uint32_t)vb + 2u * (uint32_t)(tid + k * RB), lastj);
+        e0[k] = *reinterpret_cast<const v2d *>(J.ell_val + j);
+        e1[k] = *reinterpret_cast<const v2d *>(ev1 + j);
+        er[k][0] = (int)J.ell_row[j];
+        er[k][1] = (int)J.ell_row[min(j + 1u, (uint32_t)J.n - 1u)];
+      }
+    } else {
       const int64_t lastj = max((int64_t)av1 - 1, vb) & ~(int64_t)1;
 #pragma unroll
       for (int k = 0; k < RQP; ++k) {
@@ -749,9 +779,15 @@ k_cg_resident(ResJob J) {
         const int s1 = (int)min(max(j + 1 - c_lo, (int64_t)0), (int64_t)nspan - 1);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-          const int pk = res_opaque(ec2[k][u]);
-          v4[k][2 * u] = sx[pk & 0xffff];
-          v4[k][2 * u + 1] = sx[(pk >> 16) & 0xffff];
+          if constexpr (STREAM) {
+            const int c0 = min(H + er[k][u], R - 1);
+            v4[k][2 * u] = sx[c0];
+            v4[k][2 * u + 1] = sx[min(c0 + 1, R - 1)];
+          } else {
+            const int pk = res_opaque(ec2[k][u]);
+            v4[k][2 * u] = sx[pk & 0xffff];
+            v4[k][2 * u + 1] = sx[(pk >> 16) & 0xffff];
+          }
         }
         rn[k][0] = rspan[s0]; rn[k][1] = rspan[s1];
       }
@@ -778,8 +814,8 @@ k_cg_resident(ResJob J) {
     // the halo of g leaves as soon as g is complete (the scalars follow after the sums below:
     // the transfer overlaps them); hop 2's tag
     ipx_lds_barrier();
-    halo_put<PEER>(J, wg, 2, rspan + own_off, pl, J.seq + hop + 1);                 // to the left neighbour
-    halo_put<PEER>(J, wg, 3, rspan + own_off + avn - pr, pr, J.seq + hop + 1);      // to the right neighbour
+    halo_put<PEER>(J, wg, 2, rspan + own_off, pl, J.seq + hop + 1, tid);                 // to the left neighbour
+    halo_put<PEER>(J, wg, 3, rspan + own_off + avn - pr, pr, J.seq + hop + 1, tid);      // to the right neighbour
     // residual of the own rows:  w_i - (a_i v_{i-1} + b_i v_i + a_{i+1} v_{i+1}), squared; summed
     // like ||g||^2 in the order of the 256-lane k_solve_pcr (its lane t: row t, then row t + 256)
     double *rsq = U + navnE;                          // (behind gsq: navnE + RB doubles of U)
@@ -838,13 +874,13 @@ k_cg_resident(ResJob J) {
     ++hop;
     {
       const uint32_t tag = J.seq + hop;
-      rec_put<3, PEER>(J, hop, gw, mine3, tag);
+      rec_put<3, PEER>(J, hop, gw, mine3, tag, tid);
       double sv[4];
       {
         double s3[3];
         const bool ok = hop_wait<3, PEER>(J, tag, res_records(J.ll, hop), J.gnwg, s3,
                                           halo_from_left(J, wg, 3), halo_from_right(J, wg, 2), nl, nr,
-                                          rspan, rspan + own_off + avn, J.timeout);
+                                          rspan, rspan + own_off + avn, J.timeout, tid);
         sv[0] = s3[0]; sv[1] = s3[1]; sv[2] = s3[2]; sv[3] = ok ? 0.0 : 1.0;
       }
       RS_STAMP(6);
@@ -871,18 +907,25 @@ k_cg_resident(ResJob J) {
     done_inc += 1;
     RS_STAMP(7);
     // ================= phase H: x, p, Hp = H p ================================================
+    uint32_t hrel[RQX];
     {
       // x_next on the own variables, then p_next on own +- hmax (lane: entries tid + k RB of
       // pspan): every old value is read before the barrier, every new one written after it
       double po[RQX + 1], gv[RQX + 1];
       const int np_ = avn + 2 * J.hmax;
       if constexpr (STREAM) {
-        // (the own rows of H, requested ahead of the LDS passes below; absent entries: the
-        // row's last one, multiplied by zero further down)
+        // (the own rows of H, requested ahead of the LDS passes below: absent entries are zeros
+        // of the padded table on the row's own column)
 #pragma unroll
-        for (int k = 0; k < RQX; ++k)
+        for (int k = 0; k < RQX; ++k) {
+          const uint32_t row = (uint32_t)(av0 + min(tid + k * RB, avn - 1));
+          hrel[k] = J.H_rel[row];
 #pragma unroll
-          for (int t = 0; t < RLH; ++t) hv[k][t] = J.H_val[hb[k] + min(t, max(hn[k] - 1, 0))];
+          for (int t = 0; t < RLH; ++t) {
+            const double *hb_t = J.H_valT + (int64_t)t * J.n;
+            hv[k][t] = hb_t[row];
+          }
+        }
       }
 #pragma unroll
       for (int k0 = 0; k0 < RQX; k0 += 6) {
@@ -919,9 +962,15 @@ k_cg_resident(ResJob J) {
         const int k = k0 + kk;
 #pragma unroll
         for (int t = 0; t < RLH; t += 2) {
-          const int pk = res_opaque(hc2[k][t >> 1]);
-          pp[kk][t] = pspan[pk & 0xffff];
-          pp[kk][t + 1] = pspan[(pk >> 16) & 0xffff];
+          if constexpr (STREAM) {
+            const int i = min(tid + k * RB, avn - 1);
+            pp[kk][t] = pspan[i + (int)((hrel[k] >> (8 * t)) & 255u)];
+            pp[kk][t + 1] = pspan[i + (int)((hrel[k] >> (8 * t + 8)) & 255u)];
+          } else {
+            const int pk = res_opaque(hc2[k][t >> 1]);
+            pp[kk][t] = pspan[pk & 0xffff];
+            pp[kk][t + 1] = pspan[(pk >> 16) & 0xffff];
+          }
         }
         xr[kk] = pspan[J.hmax + min(tid + k * RB, avn - 1)];
       }
@@ -931,7 +980,7 @@ k_cg_resident(ResJob J) {
         double sum = 0.0;
 #pragma unroll
         for (int t = 0; t < RLH; ++t)                                     // (absent entries: + 0.0)
-          sum += (STREAM ? (t < hn[k] ? hv[k][t] : 0.0) : hv[k][t]) * pp[kk][t];
+          sum += hv[k][t] * pp[kk][t];
         y[kk] = 1.0 * sum;
         if (HAS_DIAG) y[kk] += dg[k] * xr[kk];
         if (tid + k * RB < avn) acc_xy += xr[kk] * y[kk];
@@ -951,9 +1000,9 @@ k_cg_resident(ResJob J) {
     }
     if (it + 1 != J.it_end) {                         // (the halo of Hp: hop 1's tag; as above)
       ipx_lds_barrier();
-      halo_put<PEER>(J, wg, 0, STREAM ? hspan + 2 * hwP : hspan + own_off, pl, J.seq + hop + 1);
+      halo_put<PEER>(J, wg, 0, STREAM ? hspan + 2 * hwP : hspan + own_off, pl, J.seq + hop + 1, tid);
       halo_put<PEER>(J, wg, 1, STREAM ? hspan + 3 * hwP : hspan + own_off + avn - pr, pr,
-                     J.seq + hop + 1);
+                     J.seq + hop + 1, tid);
     }
     double mine1[1], loc1[1] = {acc_xy};
     res_block_sum<1>(loc1, red, mine1);         // (barriers inside: Hp is complete on the own part)
@@ -963,7 +1012,7 @@ k_cg_resident(ResJob J) {
     {
       const uint32_t tag = J.seq + hop;
       const bool last = it + 1 == J.it_end;
-      rec_put<1, PEER>(J, hop, gw, mine1, tag);
+      rec_put<1, PEER>(J, hop, gw, mine1, tag, tid);
       double sv[2];
       {
         // (the launch's last hop is its commit: every workgroup has been seen running by then,
@@ -974,7 +1023,7 @@ k_cg_resident(ResJob J) {
                                           halo_from_left(J, wg, 1), halo_from_right(J, wg, 0),
                                           last ? 0 : nl, last ? 0 : nr, hspan,
                                           STREAM ? hspan + hwP : hspan + own_off + avn,
-                                          last ? 8 * J.timeout : J.timeout);
+                                          last ? 8 * J.timeout : J.timeout, tid);
         sv[0] = s1[0]; sv[1] = ok ? 0.0 : 1.0;
       }
       RS_STAMP(10);
@@ -995,10 +1044,10 @@ k_cg_resident(ResJob J) {
     ++hop;
     const uint32_t tag = J.seq + hop;
     const double zero1[1] = {0.0};
-    rec_put<1, PEER>(J, hop, gw, zero1, tag);
+    rec_put<1, PEER>(J, hop, gw, zero1, tag, tid);
     double sv[2], s1[1];
     const bool ok = hop_wait<1, PEER>(J, tag, res_records(J.ll, hop), J.gnwg, s1, J.ll, J.ll, 0, 0,
-                                      hspan, hspan, hop > 1 ? 8 * J.timeout : J.timeout);
+                                      hspan, hspan, hop > 1 ? 8 * J.timeout : J.timeout, tid);
     sv[0] = 0.0; sv[1] = ok ? 0.0 : 1.0;
     double tot[2];
     res_block_sum<2>(sv, red, tot);
@@ -1049,13 +1098,43 @@ k_cg_resident(ResJob J) {
   }
 }
 
-size_t resident_lds_bytes(int nspan, int navn, int hmax, int rows_wg, int L, int rl) {
+size_t resident_lds_bytes(int nspan, int navn, int hmax, int rows_wg, int L, int rl, int hw,
+                          bool stream) {
   const int H = 1 << L, R = rows_wg + 2 * H, RS = R + 2 * H;
   const int nspanP = (nspan + 1) & ~1;
   const int npsp = (navn + 2 * hmax + 1) & ~1;
   const int navnE = (navn + 2) & ~1;
+  if (stream)
+    return sizeof(double) * (size_t)(nspanP + 4 * ((hw + 1) & ~1) + 6 * RS + ((R + 1) & ~1) + npsp + 32);
   const int usize = std::max(6 * RS, navnE + RB);
   return sizeof(double) * (size_t)(2 * nspanP + usize + ((R + 1) & ~1) + npsp + ((R * rl + 1) & ~1) + 32);
+}
+
+// H's values entry-major, rows padded with zeros to RLH entries: out[t * n + row]
+__global__ void __launch_bounds__(256)
+k_rows_padded(const int32_t *__restrict__ rowptr, const double *__restrict__ val,
+              double *__restrict__ out, int64_t n) {
+  const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (row >= n) return;
+  const int a = rowptr[row], b = rowptr[row + 1];
+  double v[RLH];
+#pragma unroll
+  for (int t = 0; t < RLH; ++t) v[t] = val[min(a + t, max(b - 1, a))];
+#pragma unroll
+  for (int t = 0; t < RLH; ++t) out[(int64_t)t * n + row] = a + t < b ? v[t] : 0.0;
+}
+
+// A's values entry-major: out[k * m + row] = in[row * rl + k] (a workgroup takes 256 rows
+// through LDS: both sides coalesced)
+__global__ void __launch_bounds__(256)
+k_entry_major(const double *__restrict__ in, double *__restrict__ out, int64_t m, int rl) {
+  extern __shared__ __attribute__((aligned(16))) double em_lds[];
+  const int64_t row0 = (int64_t)blockIdx.x * 256;
+  const int nrows = (int)min((int64_t)256, m - row0);
+  for (int i = threadIdx.x; i < nrows * rl; i += 256) em_lds[i] = in[row0 * rl + i];
+  __syncthreads();
+  if ((int)threadIdx.x < nrows)
+    for (int k = 0; k < rl; ++k) out[(int64_t)k * m + row0 + threadIdx.x] = em_lds[threadIdx.x * rl + k];
 }
 
 }  // namespace
@@ -1096,10 +1175,12 @@ int res_device_cus() {
     hipError_t e = hipSuccess;
 #define RES_ATTR(K) \
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)K, hipFuncAttributeMaxDynamicSharedMemorySize, lim)
-    RES_ATTR((k_cg_resident<false, false, false>)); RES_ATTR((k_cg_resident<false, true, false>));
-    RES_ATTR((k_cg_resident<true, false, false>));  RES_ATTR((k_cg_resident<true, true, false>));
-    RES_ATTR((k_cg_resident<false, false, true>));  RES_ATTR((k_cg_resident<false, true, true>));
-    RES_ATTR((k_cg_resident<true, false, true>));   RES_ATTR((k_cg_resident<true, true, true>));
+    RES_ATTR((k_cg_resident<false, false, false, false>)); RES_ATTR((k_cg_resident<false, true, false, false>));
+    RES_ATTR((k_cg_resident<true, false, false, false>));  RES_ATTR((k_cg_resident<true, true, false, false>));
+    RES_ATTR((k_cg_resident<false, false, true, false>));  RES_ATTR((k_cg_resident<false, true, true, false>));
+    RES_ATTR((k_cg_resident<true, false, true, false>));   RES_ATTR((k_cg_resident<true, true, true, false>));
+    RES_ATTR((k_cg_resident<false, false, false, true>));  RES_ATTR((k_cg_resident<false, true, false, true>));
+    RES_ATTR((k_cg_resident<true, false, false, true>));   RES_ATTR((k_cg_resident<true, true, false, true>));
 #undef RES_ATTR
     if (e != hipSuccess) { ipx_note_error(e, __FILE__, __LINE__); return 0; }
     attr[dev] = true;
@@ -1107,24 +1188,34 @@ int res_device_cus() {
   return cus[dev] > 0 ? cus[dev] : 0;
 }
 
-// the tables of the argument block fit the kernel, for a launch of `nlaunch` of the solve's
-// pv.nwg blocks
-bool res_tables_ok(const ipx_cg_args *a, const ipx_pcr_view &pv, int nlaunch) {
+// the form the tables of the argument block can run as, for a launch of `nlaunch` of the
+// solve's pv.nwg blocks: 0 none, 1 a workgroup per compute unit, 2 (one GPU only) the streamed
+// form, two workgroups per compute unit
+constexpr int RES_STREAM_LDS = 79 * 1024;
+int res_form(const ipx_cg_args *a, const ipx_pcr_view &pv, int nlaunch, bool peer) {
   if (!a || a->solver_kind != 0 || a->lb || a->m <= 0 || !a->P_win || !a->A_off16 ||
       !a->A_rowfirst || a->A_rl < 1 || a->A_rl > RLA || !a->At_vown || !a->At_ell_row ||
       !a->At_ell_val || a->H_operator || !a->H_rowptr || a->H_hmax < 1 || a->H_hmax > 64 ||
       (a->n & 1) || a->n > (1 << 26) || a->m * a->A_rl > (1ll << 30))
-    return false;
+    return 0;
   const int H = 1 << pv.L, R = pv.rows_wg + 2 * H;
   const int navnE = ((int)a->P_navn + 2) & ~1;
-  if (nlaunch < 1 || nlaunch > pv.nwg || nlaunch > R_MAXLOCAL || R > RNR * RB || H < 1 ||
+  if (nlaunch < 1 || nlaunch > pv.nwg || R > RNR * RB || H < 1 ||
       a->P_nspan > RQS * RB || a->P_nspan < 1 || a->P_navn < 1 || a->P_navn > RQX * RB ||
       navnE > 2 * RB * RQP || 2 * a->R_hw > RHK * RB || a->R_hw < 1 || a->H_hmax > a->R_hw ||
       a->P_navn + 2 * a->H_hmax > (RQX + 1) * RB)
-    return false;
-  if (resident_lds_bytes((int)a->P_nspan, (int)a->P_navn, (int)a->H_hmax, pv.rows_wg, pv.L, (int)a->A_rl) > 158 * 1024)
-    return false;
-  return nlaunch <= res_device_cus();
+    return 0;
+  const int cus = res_device_cus();
+  if (nlaunch <= R_MAXLOCAL && nlaunch <= cus &&
+      resident_lds_bytes((int)a->P_nspan, (int)a->P_navn, (int)a->H_hmax, pv.rows_wg, pv.L,
+                         (int)a->A_rl, (int)a->R_hw, false) <= 158 * 1024)
+    return 1;
+  // (the same margin of compute units as R_MAXLOCAL leaves on 256)
+  if (!peer && a->A_valT && a->A_off16T && a->H_valT && a->H_rel && nlaunch <= R_MAXG && nlaunch <= 2 * ((cus * 7) / 8) && a->R_hw <= RB &&
+      resident_lds_bytes((int)a->P_nspan, (int)a->P_navn, (int)a->H_hmax, pv.rows_wg, pv.L,
+                         (int)a->A_rl, (int)a->R_hw, true) <= (size_t)RES_STREAM_LDS)
+    return 2;
+  return 0;
 }
 
 void res_job_common(ResJob &J, const ipx_cg_args *a, const ipx_pcr_view &pv, int32_t it_begin,
@@ -1132,7 +1223,8 @@ void res_job_common(ResJob &J, const ipx_cg_args *a, const ipx_pcr_view &pv, int
   J.st = a->state; J.it_begin = it_begin; J.it_end = it_end; J.n = (int)a->n; J.m = pv.m;
   J.rows_wg = pv.rows_wg; J.L = pv.L; J.band = pv.band;
   J.x = a->x; J.p = a->p; J.r = a->r; J.Hp = a->Hp;
-  J.A_val = a->A_val; J.A_off16 = (const uint16_t *)a->A_off16; J.A_rowfirst = a->A_rowfirst;
+  J.A_val = a->A_val; J.A_valT = a->A_valT; J.A_off16T = (const uint16_t *)a->A_off16T;
+  J.H_valT = a->H_valT; J.H_rel = (const uint32_t *)a->H_rel; J.A_off16 = (const uint16_t *)a->A_off16; J.A_rowfirst = a->A_rowfirst;
   J.rl = (int)a->A_rl; J.win = a->P_win; J.vown = a->At_vown; J.nspan = (int)a->P_nspan;
   J.navn = (int)a->P_navn;
   J.ell_row = a->At_ell_row; J.ell_val = a->At_ell_val;
@@ -1143,15 +1235,16 @@ void res_job_common(ResJob &J, const ipx_cg_args *a, const ipx_pcr_view &pv, int
   J.no_xn2 = a->no_radius != 0;
 }
 
-template <bool PEER>
-void res_launch(const ResJob &J, size_t lds, hipStream_t st) {
+template <bool PEER, bool STREAM>
+void res_launch(const ResJob &J, hipStream_t st) {
   const dim3 grid(J.nwg), block(RB);
+  const size_t lds = resident_lds_bytes(J.nspan, J.navn, J.hmax, J.rows_wg, J.L, J.rl, J.hw, STREAM);
   if (J.no_xn2) {
-    if (J.H_diag) hipLaunchKernelGGL((k_cg_resident<true, true, PEER>), grid, block, lds, st, J);
-    else hipLaunchKernelGGL((k_cg_resident<true, false, PEER>), grid, block, lds, st, J);
+    if (J.H_diag) hipLaunchKernelGGL((k_cg_resident<true, true, PEER, STREAM>), grid, block, lds, st, J);
+    else hipLaunchKernelGGL((k_cg_resident<true, false, PEER, STREAM>), grid, block, lds, st, J);
   } else {
-    if (J.H_diag) hipLaunchKernelGGL((k_cg_resident<false, true, PEER>), grid, block, lds, st, J);
-    else hipLaunchKernelGGL((k_cg_resident<false, false, PEER>), grid, block, lds, st, J);
+    if (J.H_diag) hipLaunchKernelGGL((k_cg_resident<false, true, PEER, STREAM>), grid, block, lds, st, J);
+    else hipLaunchKernelGGL((k_cg_resident<false, false, PEER, STREAM>), grid, block, lds, st, J);
   }
 }
 
@@ -1163,13 +1256,31 @@ extern "C" int ipx_cg_resident_ok(const ipx_cg_args *a) {
   if (!a || !a->resident || !a->R_ll || !a->R_seq) return 0;
   ipx_pcr_view pv;
   if (!ipx_banded_pcr_view(a->banded, &pv)) return 0;
-  return res_tables_ok(a, pv, pv.nwg) ? 1 : 0;
+  return res_form(a, pv, pv.nwg, false);
+}
+
+// Before the first launch after A's values changed: the streamed form (ipx_cg_resident_ok == 2)
+// reads them entry-major from a->A_valT (m * A_rl doubles of the caller's); a no-op otherwise.
+extern "C" int ipx_cg_resident_prepare(const ipx_cg_args *a, void *stream) {
+  if (ipx_cg_resident_ok(a) != 2) return IPX_OK;
+  ipx_pcr_view pv;
+  ipx_banded_pcr_view(a->banded, &pv);
+  const int rl = (int)a->A_rl;
+  hipLaunchKernelGGL(k_entry_major, dim3((unsigned)((pv.m + 255) / 256)), dim3(256),
+                     (size_t)256 * rl * sizeof(double), (hipStream_t)stream, a->A_val,
+                     (double *)a->A_valT, (int64_t)pv.m, rl);
+  IPX_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_rows_padded, dim3((unsigned)((a->n + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, a->H_rowptr, a->H_val, (double *)a->H_valT, (int64_t)a->n);
+  IPX_CHECK_LAUNCH();
+  return IPX_OK;
 }
 
 // iterations [it_begin, it_end) in one resident launch (see the top of this file)
 int ipx_cg_resident_launch(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, int np1, int np2,
                            int np3, int np4, hipStream_t st) {
-  if (!ipx_cg_resident_ok(a) || it_end <= it_begin) return IPX_EINVAL;
+  const int form = ipx_cg_resident_ok(a);
+  if (!form || it_end <= it_begin) return IPX_EINVAL;
   ipx_pcr_view pv;
   ipx_banded_pcr_view(a->banded, &pv);
   ResJob J{};
@@ -1189,7 +1300,7 @@ int ipx_cg_resident_launch(const ipx_cg_args *a, int32_t it_begin, int32_t it_en
   }
   J.seq = (uint32_t)*a->R_seq;
   *a->R_seq += need;
-  res_launch<false>(J, resident_lds_bytes(J.nspan, J.navn, J.hmax, J.rows_wg, J.L, J.rl), st);
+  if (form == 2) res_launch<false, true>(J, st); else res_launch<false, false>(J, st);
   IPX_CHECK_LAUNCH();
   return IPX_OK;
 }
@@ -1210,7 +1321,7 @@ extern "C" int ipx_cg_shard2_resident_ok(const ipx_cg_args *a, const ipx_shard2_
   if ((peer->view.rank > 0 && e->res_wg0 < 1) ||
       (peer->view.rank < peer->view.world - 1 && e->res_wg0 + e->res_nwg >= pv.nwg))
     return 0;
-  return res_tables_ok(a, pv, (int)e->res_nwg) ? 1 : 0;
+  return res_form(a, pv, (int)e->res_nwg, true) == 1 ? 1 : 0;
 }
 
 int ipx_cg_shard2_resident_launch(const ipx_cg_args *a, const ipx_shard2_ext *e, int32_t it_begin,
@@ -1243,7 +1354,7 @@ int ipx_cg_shard2_resident_launch(const ipx_cg_args *a, const ipx_shard2_ext *e,
   J.seq = peer->rseq;
   peer->rseq += (uint32_t)need;
   ++peer->res_launches;
-  res_launch<true>(J, resident_lds_bytes(J.nspan, J.navn, J.hmax, J.rows_wg, J.L, J.rl), stream);
+  res_launch<true, false>(J, stream);
   IPX_CHECK_LAUNCH();
   return IPX_OK;
 }
