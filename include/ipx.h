@@ -307,23 +307,8 @@ typedef struct ipx_cg_args {
   void *R_ll;
   int64_t R_hw;
   int64_t *R_seq;
-  /* Optional, m * A_rl doubles of the caller's: with it problems of MORE workgroups than compute
-   * units (up to two per unit: n = 1e6 on the benchmark's problem) run the resident form too --
-   * vectors on the chip, matrix values re-read per iteration, A's from this entry-major copy,
-   * which ipx_cg_resident_prepare fills (call it after A's or H's values changed, before
-   * ipx_cg_iterate). */
-  double *A_valT;
-  /* with it, all four or none: A_off16T = A_off16 entry-major (A_rl * m uint16, static); H_valT =
-   * 4 * n doubles of the caller's (H's rows padded to 4 entries, entry-major: filled by
-   * ipx_cg_resident_prepare); H_rel = per row of H the columns of its 4 entries as bytes
-   * (column - row + H_hmax, an absent entry: H_hmax), one uint32 per row (static) */
-  const void *A_off16T;
-  double *H_valT;
-  const void *H_rel;
 } ipx_cg_args;
-/* 0: not resident; 1: a workgroup per compute unit; 2: the streamed form (needs A_valT) */
 int ipx_cg_resident_ok(const ipx_cg_args *a);
-int ipx_cg_resident_prepare(const ipx_cg_args *a, void *stream);
 int64_t ipx_cg_resident_ll_words(int32_t nwg, int32_t hw);
 /* the kernel's budgets for the host code that builds its tables: workgroups per launch, threads,
  * span columns / own variables / window rows per workgroup, entries per row of A / of H, halo

@@ -105,13 +105,6 @@ struct ResJob {
   const double *band;
   double *x, *p, *r, *Hp;
   const double *A_val;
-  // STREAM form: A's values and 16-bit column offsets entry-major ([rl][m]); H's values
-  // entry-major, rows padded with zeros to RLH ([RLH][n]); per row of H the columns of its RLH
-  // entries as bytes (column - row + hmax; an absent entry: hmax)
-  const double *A_valT;
-  const uint16_t *A_off16T;
-  const double *H_valT;
-  const uint32_t *H_rel;
   const uint16_t *A_off16;
   const int32_t *A_rowfirst;
   int rl;
@@ -225,6 +218,10 @@ __device__ __forceinline__ void res_block_sum(double (&v)[NQ], double *lds, doub
   ipx_lds_barrier();
 }
 
+// (The hop helpers take the lane index as an argument -- the caller's per-iteration opaque copy:
+// computed from threadIdx.x their 20-odd word addresses are loop invariants the compiler
+// hoists and then spills; passing it in took the kernel from 176 to 32 bytes of scratch per
+// lane and the iteration at n = 5e5 from 18.9 to 15.4 us.)
 // One hop: NS scalars per workgroup (lane t < nrec waits for record t of `scal`) and this
 // workgroup's left / right halo (nl + nr entries, from the areas `left` / `right`) into LDS at
 // dst_l / dst_r.  Every word of the lane is requested in ONE burst per pass (unconditional
@@ -356,19 +353,9 @@ __device__ __forceinline__ void halo_put(const ResJob &J, int wg, int area, cons
   }
 }
 
-// STREAM: the form for problems of MORE workgroups than compute units (n = 1e6 on the benchmark's
-// banded problem: 385): two workgroups per CU, so a lane has 128 registers and a workgroup
-// 80 KB of LDS.  The vectors stay on the chip for the whole batch (r / g and p on their spans in
-// LDS, x and Hp on the own variables in registers, Hp's halo in a small LDS area); the MATRIX
-// values are re-read in every iteration, in layouts whose consecutive lanes read consecutive
-// words: A entry-major (A_valT, a copy made per call), H in its CSR order (a lane per row, rows
-// of <= 4 entries: consecutive lanes 24-32 bytes apart), A' in the ELL(2) form as above -- 70 MB
-// per iteration out of L2 / the Infinity Cache instead of the 188 MB the separate launches move
-// through HBM.  Each group of values is requested before the LDS work that precedes its use.
-template <bool NOXN2, bool HAS_DIAG, bool PEER, bool STREAM>
-__global__ void __launch_bounds__(RB, STREAM ? 4 : 2)
+template <bool NOXN2, bool HAS_DIAG, bool PEER>
+__global__ void __launch_bounds__(RB, 2)
 k_cg_resident(ResJob J) {
-  static_assert(!(PEER && STREAM), "the streamed form is a one-GPU form");
   extern __shared__ __attribute__((aligned(16))) double rs_lds[];
   const int wg = blockIdx.x, tid = threadIdx.x;
   const int wgl = wg + J.wg0;                       // block of the (local) solve: the tables' index
@@ -380,18 +367,15 @@ k_cg_resident(ResJob J) {
   const int RS = R + 2 * H;                         // PCR rows incl. identity padding
   const int nspanP = (J.nspan + 1) & ~1;
   const int npsp = (J.navn + 2 * J.hmax + 1) & ~1;
-  const int hwP = (J.hw + 1) & ~1;
   double *rspan = rs_lds;                           // r / r_next / g on the span
-  // Hp: on the span | STREAM: its halo only ([0, nl) left, [hwP, hwP + nr) right) and behind it
-  // the own entries the neighbours read ([2 hwP, +pl) first, [3 hwP, +pr) last ones)
-  double *hspan = rspan + nspanP;
-  double *U = hspan + (STREAM ? 4 * hwP : nspanP);  // PCR ping-pong (6 RS) | squares of g, of the residual
-  const int usize = STREAM ? 6 * RS : max(6 * RS, ((J.navn + 2) & ~1) + RB);
+  double *hspan = rspan + nspanP;                   // Hp on the span
+  double *U = hspan + nspanP;                       // PCR ping-pong (6 RS) | squares of g, of the residual
+  const int usize = max(6 * RS, ((J.navn + 2) & ~1) + RB);
   double *sx = U + usize;                           // [R]: w, then v
   double *pspan = sx + ((R + 1) & ~1);              // p on own +- hmax
-  double *aval = pspan + npsp;                      // A's window rows: [R * rl] values (not STREAM)
+  double *aval = pspan + npsp;                      // A's window rows: [R * rl] values
   const int navnE = (J.navn + 2) & ~1;              // (pairs may start one before av0)
-  double *red = aval + (STREAM ? 0 : ((R * J.rl + 1) & ~1));       // [32] reductions
+  double *red = aval + ((R * J.rl + 1) & ~1);       // [32] reductions
   double *pa0 = U, *pa1 = U + RS, *pr0 = U + 2 * RS, *pr1 = U + 3 * RS, *pd0 = U + 4 * RS,
          *pd1 = U + 5 * RS;
 
@@ -427,31 +411,25 @@ k_cg_resident(ResJob J) {
   double a0[RNR], b0[RNR];
   bool row_in[RNR];
   int ac2[RLA / 2];
-  int afirst;                    // (STREAM) span index of the row's first column, -1: no such row
   {
     const int r = tid;
     const int64_t grow = g0 + r;
     row_in[0] = r < R && grow >= 0 && grow < J.m;
     const int64_t gc = min(max(grow, (int64_t)0), (int64_t)J.m - 1);
     const int first = J.A_rowfirst[gc] - c_lo;
-    afirst = row_in[0] ? first : -1;
-    if constexpr (!STREAM) {
 #pragma unroll
-      for (int k = 0; k < RLA / 2; ++k) {
-        const int c0 = row_in[0] ? first + (int)J.A_off16[gc * rl + min(2 * k, rl - 1)] : 0;
-        const int c1 = row_in[0] ? first + (int)J.A_off16[gc * rl + min(2 * k + 1, rl - 1)] : 0;
-        ac2[k] = c0 | (c1 << 16);
-      }
+    for (int k = 0; k < RLA / 2; ++k) {
+      const int c0 = row_in[0] ? first + (int)J.A_off16[gc * rl + min(2 * k, rl - 1)] : 0;
+      const int c1 = row_in[0] ? first + (int)J.A_off16[gc * rl + min(2 * k + 1, rl - 1)] : 0;
+      ac2[k] = c0 | (c1 << 16);
     }
     const double bv = J.band[gc], avv = J.band[(int64_t)J.m + gc];
     a0[0] = (row_in[0] && grow >= 1 && r >= 1) ? avv : 0.0;     // (row 0 of the window: cut)
     b0[0] = row_in[0] ? bv : 1.0;
   }
-  if constexpr (!STREAM) {
-    for (int i = tid; i < R * rl; i += RB) {
-      const int64_t kk = g0 * rl + i;                // (window row i / rl, its entry i % rl)
-      aval[i] = (kk >= 0 && kk < (int64_t)J.m * rl) ? J.A_val[kk] : 0.0;
-    }
+  for (int i = tid; i < R * rl; i += RB) {
+    const int64_t kk = g0 * rl + i;                  // (window row i / rl, its entry i % rl)
+    aval[i] = (kk >= 0 && kk < (int64_t)J.m * rl) ? J.A_val[kk] : 0.0;
   }
   // (the sub-diagonal entry of the row below, for the residual of the own rows)
   double a0n;
@@ -468,7 +446,7 @@ k_cg_resident(ResJob J) {
   // pairs: the array's own layout)
   const int64_t vb = av0 & ~1;
   int ec2[RQP][2];               // window rows of (entry 0 | entry 1 << 16) of variables j, j + 1
-  if constexpr (!STREAM) {
+  {
     const int64_t lastj = max((int64_t)av1 - 1, vb) & ~(int64_t)1;
 #pragma unroll
     for (int k = 0; k < RQP; ++k) {
@@ -486,33 +464,28 @@ k_cg_resident(ResJob J) {
                                           //  addresses and clamps would all be live at once)
   // (iii) own rows tid + k RB of H (absent entries: value 0 on a valid column, so the row sums
   // need no length), x and the diagonal term on them
-  // (STREAM: values and columns are re-read in every iteration, from the entry-major tables; Hp
-  // on the own variables lives in ho)
-  double hv[RQX][RLH], xo[RQX], dg[RQX], ho[RQX];
+  double hv[RQX][RLH], xo[RQX], dg[RQX];
   int hc2[RQX][RLH / 2];         // pspan indices of the entries, two per register
 #pragma unroll
   for (int k = 0; k < RQX; ++k) {
     const int i = min(tid + k * RB, max(avn - 1, 0));
     const int row = av0 + i;
+    const int a = J.H_rowptr[row], b = J.H_rowptr[row + 1];
     const bool on = tid + k * RB < avn;
-    if constexpr (!STREAM) {
-      const int a = J.H_rowptr[row], b = J.H_rowptr[row + 1];
-      int cc[RLH];
+    int cc[RLH];
 #pragma unroll
-      for (int t = 0; t < RLH; ++t) {
-        const int kk = min(a + t, max(b - 1, a));
-        const bool have = on && a + t < b;
-        const int c = J.H_colidx[kk];
-        const double v = J.H_val[kk];
-        hv[k][t] = have ? v : 0.0;
-        cc[t] = have ? c - p_lo : J.hmax;
-      }
-#pragma unroll
-      for (int t = 0; t < RLH / 2; ++t) hc2[k][t] = cc[2 * t] | (cc[2 * t + 1] << 16);
+    for (int t = 0; t < RLH; ++t) {
+      const int kk = min(a + t, max(b - 1, a));
+      const bool have = on && a + t < b;
+      const double v = J.H_val[kk];
+      const int c = J.H_colidx[kk];
+      hv[k][t] = have ? v : 0.0;
+      cc[t] = have ? c - p_lo : J.hmax;
     }
+#pragma unroll
+    for (int t = 0; t < RLH / 2; ++t) hc2[k][t] = cc[2 * t] | (cc[2 * t + 1] << 16);
     xo[k] = J.x[row];
     dg[k] = HAS_DIAG ? J.H_diag[row] : 0.0;
-    if constexpr (STREAM) ho[k] = J.Hp[row];
   }
   __builtin_amdgcn_sched_barrier(0);      // (keep the set-up's load groups apart: their
                                           //  addresses and clamps would all be live at once)
@@ -520,14 +493,7 @@ k_cg_resident(ResJob J) {
 #pragma unroll
   for (int k = 0; k < RQS; ++k) {
     const int j = tid + k * RB;
-    if (j < nspan) {
-      rspan[j] = J.r[c_lo + j];
-      if constexpr (!STREAM) hspan[j] = J.Hp[c_lo + j];
-    }
-  }
-  if constexpr (STREAM) {
-    for (int e = tid; e < nl; e += RB) hspan[e] = J.Hp[c_lo + e];
-    for (int e = tid; e < nr; e += RB) hspan[hwP + e] = J.Hp[av1 + e];
+    if (j < nspan) { rspan[j] = J.r[c_lo + j]; hspan[j] = J.Hp[c_lo + j]; }
   }
   for (int j = tid; j < avn + 2 * J.hmax; j += RB) {
     const int col = p_lo + j;
@@ -602,42 +568,7 @@ k_cg_resident(ResJob J) {
     niter_inc += 1; st_pthp = ptHp; st_alpha = alpha;
     RS_STAMP(0);
     // ================= phase P: r_next, w = A r_next, cyclic reduction, g ====================
-    // (STREAM: this lane's window row of A, entry-major: used after the update of r)
-    double aas[RLA];
-    int aof[RLA];
-    if constexpr (STREAM) {
-      // (uniform base + the lane's 32-bit row: one address register per lane, not one pair per
-      // load -- and computed from this iteration's opaque lane index, so none is hoisted)
-      const uint32_t growT = (uint32_t)min(max(g0 + tid, (int64_t)0), (int64_t)J.m - 1);
-#pragma unroll
-      for (int k = 0; k < RLA; ++k) {
-        const double *vb_k = J.A_valT + (int64_t)min(k, rl - 1) * J.m;
-        const uint16_t *ob_k = J.A_off16T + (int64_t)min(k, rl - 1) * J.m;
-        aas[k] = vb_k[growT];
-        aof[k] = (int)ob_k[growT];
-      }
-    }
     ipx_lds_barrier();
-    if constexpr (STREAM) {
-      // own variables: Hp out of registers; the halo columns: Hp as the neighbours sent it
-      double rv[RQX], rh[2], hh[2];
-      int jh[2];
-#pragma unroll
-      for (int k = 0; k < RQX; ++k) rv[k] = rspan[own_off + min(tid + k * RB, avn - 1)];
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const int e = min(tid + k * RB, max(nl + nr - 1, 0));
-        jh[k] = e < nl ? e : own_off + avn + (e - nl);
-        rh[k] = rspan[min(jh[k], nspan - 1)];
-        hh[k] = hspan[e < nl ? e : hwP + (e - nl)];
-      }
-#pragma unroll
-      for (int k = 0; k < RQX; ++k)
-        if (tid + k * RB < avn) rspan[own_off + tid + k * RB] = rv[k] + alpha * ho[k];   // :622
-#pragma unroll
-      for (int k = 0; k < 2; ++k)
-        if (tid + k * RB < nl + nr) rspan[jh[k]] = rh[k] + alpha * hh[k];
-    } else {
 #pragma unroll
     for (int k0 = 0; k0 < RQS; k0 += 4) {
       double rv[4], hh[4];
@@ -651,7 +582,6 @@ k_cg_resident(ResJob J) {
         const int j = tid + (k0 + k) * RB;
         if (j < nspan) rspan[j] = rv[k] + alpha * hh[k];                 // :622
       }
-    }
     }
     double sxx = 0.0;
     if (!NOXN2) {
@@ -681,17 +611,12 @@ k_cg_resident(ResJob J) {
         double rr[8], aa[8];
 #pragma unroll
         for (int k = 0; k < 8; k += 2) {
-          if constexpr (STREAM) {
-            rr[k] = rspan[afirst >= 0 ? afirst + aof[k0 + k] : 0];
-            rr[k + 1] = rspan[afirst >= 0 ? afirst + aof[k0 + k + 1] : 0];
-          } else {
-            const int pk = res_opaque(ac2[(k0 + k) >> 1]);
-            rr[k] = rspan[pk & 0xffff];
-            rr[k + 1] = rspan[(pk >> 16) & 0xffff];
-          }
+          const int pk = res_opaque(ac2[(k0 + k) >> 1]);
+          rr[k] = rspan[pk & 0xffff];
+          rr[k + 1] = rspan[(pk >> 16) & 0xffff];
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) aa[k] = STREAM ? aas[k0 + k] : arow[min(k0 + k, rl - 1)];
+        for (int k = 0; k < 8; ++k) aa[k] = arow[min(k0 + k, rl - 1)];
 #pragma unroll
         for (int k = 0; k < 8; ++k)
           if (k0 + k < rl) sum += aa[k] * rr[k];
@@ -703,19 +628,7 @@ k_cg_resident(ResJob J) {
     // (the values of A' for the tail, requested now, used after the cyclic reduction)
     typedef double v2d __attribute__((ext_vector_type(2)));
     v2d e0[RQP], e1[RQP];
-    int er[RQP][2];                                   // (STREAM) the entries' first window rows
-    if constexpr (STREAM) {
-      const uint32_t lastj = (uint32_t)(max((int64_t)av1 - 1, vb) & ~(int64_t)1);
-      const double *ev1 = J.ell_val + (int64_t)J.n;
-#pragma unroll
-      for (int k = 0; k < RQP; ++k) {
-        const uint32_t j = min((uint32_t)vb + 2u * (uint32_t)(tid + k * RB), lastj);
-        e0[k] = *reinterpret_cast<const v2d *>(J.ell_val + j);
-        e1[k] = *reinterpret_cast<const v2d *>(ev1 + j);
-        er[k][0] = (int)J.ell_row[j];
-        er[k][1] = (int)J.ell_row[min(j + 1u, (uint32_t)J.n - 1u)];
-      }
-    } else {
+    {
       const int64_t lastj = max((int64_t)av1 - 1, vb) & ~(int64_t)1;
 #pragma unroll
       for (int k = 0; k < RQP; ++k) {
@@ -767,9 +680,7 @@ k_cg_resident(ResJob J) {
     // g = r_next - A'v on the own variables: the expressions of k_solve_pcr's tail; g replaces r
     // on the span, its squares go to LDS and are added up in THAT kernel's order (its lane t
     // takes the pairs t, t + 256, ...: same bits of ||g||^2)
-    // (STREAM: no room for the squares in LDS -- a lane adds up its own, all eight waves fold)
     double *gsq = U;                                  // [2 * pairs] (the PCR buffers are free)
-    double gdir = 0.0, rdir = 0.0;
     {
       double v4[RQP][4], rn[RQP][2];
 #pragma unroll
@@ -779,15 +690,9 @@ k_cg_resident(ResJob J) {
         const int s1 = (int)min(max(j + 1 - c_lo, (int64_t)0), (int64_t)nspan - 1);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-          if constexpr (STREAM) {
-            const int c0 = min(H + er[k][u], R - 1);
-            v4[k][2 * u] = sx[c0];
-            v4[k][2 * u + 1] = sx[min(c0 + 1, R - 1)];
-          } else {
-            const int pk = res_opaque(ec2[k][u]);
-            v4[k][2 * u] = sx[pk & 0xffff];
-            v4[k][2 * u + 1] = sx[(pk >> 16) & 0xffff];
-          }
+          const int pk = res_opaque(ec2[k][u]);
+          v4[k][2 * u] = sx[pk & 0xffff];
+          v4[k][2 * u + 1] = sx[(pk >> 16) & 0xffff];
         }
         rn[k][0] = rspan[s0]; rn[k][1] = rspan[s1];
       }
@@ -802,12 +707,7 @@ k_cg_resident(ResJob J) {
         const bool in1 = j + 1 >= av0 && j + 1 < (int64_t)av1;
         if (in0) rspan[j - c_lo] = y0;
         if (in1) rspan[j + 1 - c_lo] = y1;
-        if constexpr (STREAM) {
-          gdir += in0 ? y0 * y0 : 0.0;
-          gdir += in1 ? y1 * y1 : 0.0;
-        } else {
-          if (j - vb < navnE) { gsq[j - vb] = in0 ? y0 * y0 : 0.0; gsq[j - vb + 1] = in1 ? y1 * y1 : 0.0; }
-        }
+        if (j - vb < navnE) { gsq[j - vb] = in0 ? y0 * y0 : 0.0; gsq[j - vb + 1] = in1 ? y1 * y1 : 0.0; }
       }
     }
     RS_STAMP(4);
@@ -830,11 +730,11 @@ k_cg_resident(ResJob J) {
         const double res = w0[0] - sum;
         res2 = res * res;
       }
-      if constexpr (STREAM) rdir = res2; else rsq[tid] = res2;
+      rsq[tid] = res2;
     }
     ipx_lds_barrier();
-    double gacc = STREAM ? gdir : 0.0, acc = STREAM ? rdir : 0.0;
-    if (!STREAM && tid < 256) {
+    double gacc = 0.0, acc = 0.0;
+    if (tid < 256) {
       double q2[2 * ((RQP * RB) / 256)];
 #pragma unroll
       for (int k = 0; k < (RQP * RB) / 256; ++k) {
@@ -855,17 +755,16 @@ k_cg_resident(ResJob J) {
       const double s0 = ipx_wave_sum(sxx), s1 = ipx_wave_sum(gacc), s2 = ipx_wave_sum(acc);
       if (lane == 0) { red[wave] = s0; red[8 + wave] = s1; red[16 + wave] = s2; }
       ipx_lds_barrier();
-      constexpr int NW12 = STREAM ? RB / 64 : 4;
-      double t0[RB / 64], t1[NW12], t2[NW12];
+      double t0[RB / 64], t1[4], t2[4];
 #pragma unroll
       for (int w = 0; w < RB / 64; ++w) t0[w] = red[w];
 #pragma unroll
-      for (int w = 0; w < NW12; ++w) { t1[w] = red[8 + w]; t2[w] = red[16 + w]; }
+      for (int w = 0; w < 4; ++w) { t1[w] = red[8 + w]; t2[w] = red[16 + w]; }
       double r0 = t0[0], r1 = t1[0], r2 = t2[0];
 #pragma unroll
       for (int w = 1; w < RB / 64; ++w) r0 += t0[w];
 #pragma unroll
-      for (int w = 1; w < NW12; ++w) { r1 += t1[w]; r2 += t2[w]; }
+      for (int w = 1; w < 4; ++w) { r1 += t1[w]; r2 += t2[w]; }
       mine3[0] = r0; mine3[1] = r1; mine3[2] = r2;
       ipx_lds_barrier();
     }
@@ -907,26 +806,11 @@ k_cg_resident(ResJob J) {
     done_inc += 1;
     RS_STAMP(7);
     // ================= phase H: x, p, Hp = H p ================================================
-    uint32_t hrel[RQX];
     {
       // x_next on the own variables, then p_next on own +- hmax (lane: entries tid + k RB of
       // pspan): every old value is read before the barrier, every new one written after it
       double po[RQX + 1], gv[RQX + 1];
       const int np_ = avn + 2 * J.hmax;
-      if constexpr (STREAM) {
-        // (the own rows of H, requested ahead of the LDS passes below: absent entries are zeros
-        // of the padded table on the row's own column)
-#pragma unroll
-        for (int k = 0; k < RQX; ++k) {
-          const uint32_t row = (uint32_t)(av0 + min(tid + k * RB, avn - 1));
-          hrel[k] = J.H_rel[row];
-#pragma unroll
-          for (int t = 0; t < RLH; ++t) {
-            const double *hb_t = J.H_valT + (int64_t)t * J.n;
-            hv[k][t] = hb_t[row];
-          }
-        }
-      }
 #pragma unroll
       for (int k0 = 0; k0 < RQX; k0 += 6) {
         double px[6];
@@ -962,15 +846,9 @@ k_cg_resident(ResJob J) {
         const int k = k0 + kk;
 #pragma unroll
         for (int t = 0; t < RLH; t += 2) {
-          if constexpr (STREAM) {
-            const int i = min(tid + k * RB, avn - 1);
-            pp[kk][t] = pspan[i + (int)((hrel[k] >> (8 * t)) & 255u)];
-            pp[kk][t + 1] = pspan[i + (int)((hrel[k] >> (8 * t + 8)) & 255u)];
-          } else {
-            const int pk = res_opaque(hc2[k][t >> 1]);
-            pp[kk][t] = pspan[pk & 0xffff];
-            pp[kk][t + 1] = pspan[(pk >> 16) & 0xffff];
-          }
+          const int pk = res_opaque(hc2[k][t >> 1]);
+          pp[kk][t] = pspan[pk & 0xffff];
+          pp[kk][t + 1] = pspan[(pk >> 16) & 0xffff];
         }
         xr[kk] = pspan[J.hmax + min(tid + k * RB, avn - 1)];
       }
@@ -979,30 +857,20 @@ k_cg_resident(ResJob J) {
         const int k = k0 + kk;
         double sum = 0.0;
 #pragma unroll
-        for (int t = 0; t < RLH; ++t)                                     // (absent entries: + 0.0)
-          sum += hv[k][t] * pp[kk][t];
+        for (int t = 0; t < RLH; ++t) sum += hv[k][t] * pp[kk][t];       // (absent entries: + 0.0)
         y[kk] = 1.0 * sum;
         if (HAS_DIAG) y[kk] += dg[k] * xr[kk];
         if (tid + k * RB < avn) acc_xy += xr[kk] * y[kk];
       }
       // (hspan is written here and read nowhere in this phase)
 #pragma unroll
-      for (int kk = 0; kk < 3; ++kk) {
-        const int i = tid + (k0 + kk) * RB;
-        if constexpr (STREAM) {
-          ho[k0 + kk] = y[kk];
-          if (i < pl) hspan[2 * hwP + i] = y[kk];
-          if (i < avn && i >= avn - pr) hspan[3 * hwP + (i - (avn - pr))] = y[kk];
-        } else {
-          if (i < avn) hspan[own_off + i] = y[kk];
-        }
-      }
+      for (int kk = 0; kk < 3; ++kk)
+        if (tid + (k0 + kk) * RB < avn) hspan[own_off + tid + (k0 + kk) * RB] = y[kk];
     }
     if (it + 1 != J.it_end) {                         // (the halo of Hp: hop 1's tag; as above)
       ipx_lds_barrier();
-      halo_put<PEER>(J, wg, 0, STREAM ? hspan + 2 * hwP : hspan + own_off, pl, J.seq + hop + 1, tid);
-      halo_put<PEER>(J, wg, 1, STREAM ? hspan + 3 * hwP : hspan + own_off + avn - pr, pr,
-                     J.seq + hop + 1, tid);
+      halo_put<PEER>(J, wg, 0, hspan + own_off, pl, J.seq + hop + 1, tid);
+      halo_put<PEER>(J, wg, 1, hspan + own_off + avn - pr, pr, J.seq + hop + 1, tid);
     }
     double mine1[1], loc1[1] = {acc_xy};
     res_block_sum<1>(loc1, red, mine1);         // (barriers inside: Hp is complete on the own part)
@@ -1021,8 +889,7 @@ k_cg_resident(ResJob J) {
         double s1[1];
         const bool ok = hop_wait<1, PEER>(J, tag, res_records(J.ll, hop), J.gnwg, s1,
                                           halo_from_left(J, wg, 1), halo_from_right(J, wg, 0),
-                                          last ? 0 : nl, last ? 0 : nr, hspan,
-                                          STREAM ? hspan + hwP : hspan + own_off + avn,
+                                          last ? 0 : nl, last ? 0 : nr, hspan, hspan + own_off + avn,
                                           last ? 8 * J.timeout : J.timeout, tid);
         sv[0] = s1[0]; sv[1] = ok ? 0.0 : 1.0;
       }
@@ -1065,7 +932,7 @@ k_cg_resident(ResJob J) {
       J.x[av0 + i] = xo[k];
       J.p[av0 + i] = pspan[J.hmax + i];
       J.r[av0 + i] = rspan[own_off + i];
-      J.Hp[av0 + i] = STREAM ? ho[k] : hspan[own_off + i];
+      J.Hp[av0 + i] = hspan[own_off + i];
     }
   }
   // partial arrays as the separate launches' consumers fold them: the total in entry 0, zeros
@@ -1098,43 +965,13 @@ k_cg_resident(ResJob J) {
   }
 }
 
-size_t resident_lds_bytes(int nspan, int navn, int hmax, int rows_wg, int L, int rl, int hw,
-                          bool stream) {
+size_t resident_lds_bytes(int nspan, int navn, int hmax, int rows_wg, int L, int rl) {
   const int H = 1 << L, R = rows_wg + 2 * H, RS = R + 2 * H;
   const int nspanP = (nspan + 1) & ~1;
   const int npsp = (navn + 2 * hmax + 1) & ~1;
   const int navnE = (navn + 2) & ~1;
-  if (stream)
-    return sizeof(double) * (size_t)(nspanP + 4 * ((hw + 1) & ~1) + 6 * RS + ((R + 1) & ~1) + npsp + 32);
   const int usize = std::max(6 * RS, navnE + RB);
   return sizeof(double) * (size_t)(2 * nspanP + usize + ((R + 1) & ~1) + npsp + ((R * rl + 1) & ~1) + 32);
-}
-
-// H's values entry-major, rows padded with zeros to RLH entries: out[t * n + row]
-__global__ void __launch_bounds__(256)
-k_rows_padded(const int32_t *__restrict__ rowptr, const double *__restrict__ val,
-              double *__restrict__ out, int64_t n) {
-  const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (row >= n) return;
-  const int a = rowptr[row], b = rowptr[row + 1];
-  double v[RLH];
-#pragma unroll
-  for (int t = 0; t < RLH; ++t) v[t] = val[min(a + t, max(b - 1, a))];
-#pragma unroll
-  for (int t = 0; t < RLH; ++t) out[(int64_t)t * n + row] = a + t < b ? v[t] : 0.0;
-}
-
-// A's values entry-major: out[k * m + row] = in[row * rl + k] (a workgroup takes 256 rows
-// through LDS: both sides coalesced)
-__global__ void __launch_bounds__(256)
-k_entry_major(const double *__restrict__ in, double *__restrict__ out, int64_t m, int rl) {
-  extern __shared__ __attribute__((aligned(16))) double em_lds[];
-  const int64_t row0 = (int64_t)blockIdx.x * 256;
-  const int nrows = (int)min((int64_t)256, m - row0);
-  for (int i = threadIdx.x; i < nrows * rl; i += 256) em_lds[i] = in[row0 * rl + i];
-  __syncthreads();
-  if ((int)threadIdx.x < nrows)
-    for (int k = 0; k < rl; ++k) out[(int64_t)k * m + row0 + threadIdx.x] = em_lds[threadIdx.x * rl + k];
 }
 
 }  // namespace
@@ -1175,12 +1012,10 @@ int res_device_cus() {
     hipError_t e = hipSuccess;
 #define RES_ATTR(K) \
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)K, hipFuncAttributeMaxDynamicSharedMemorySize, lim)
-    RES_ATTR((k_cg_resident<false, false, false, false>)); RES_ATTR((k_cg_resident<false, true, false, false>));
-    RES_ATTR((k_cg_resident<true, false, false, false>));  RES_ATTR((k_cg_resident<true, true, false, false>));
-    RES_ATTR((k_cg_resident<false, false, true, false>));  RES_ATTR((k_cg_resident<false, true, true, false>));
-    RES_ATTR((k_cg_resident<true, false, true, false>));   RES_ATTR((k_cg_resident<true, true, true, false>));
-    RES_ATTR((k_cg_resident<false, false, false, true>));  RES_ATTR((k_cg_resident<false, true, false, true>));
-    RES_ATTR((k_cg_resident<true, false, false, true>));   RES_ATTR((k_cg_resident<true, true, false, true>));
+    RES_ATTR((k_cg_resident<false, false, false>)); RES_ATTR((k_cg_resident<false, true, false>));
+    RES_ATTR((k_cg_resident<true, false, false>));  RES_ATTR((k_cg_resident<true, true, false>));
+    RES_ATTR((k_cg_resident<false, false, true>));  RES_ATTR((k_cg_resident<false, true, true>));
+    RES_ATTR((k_cg_resident<true, false, true>));   RES_ATTR((k_cg_resident<true, true, true>));
 #undef RES_ATTR
     if (e != hipSuccess) { ipx_note_error(e, __FILE__, __LINE__); return 0; }
     attr[dev] = true;
@@ -1188,34 +1023,24 @@ int res_device_cus() {
   return cus[dev] > 0 ? cus[dev] : 0;
 }
 
-// the form the tables of the argument block can run as, for a launch of `nlaunch` of the
-// solve's pv.nwg blocks: 0 none, 1 a workgroup per compute unit, 2 (one GPU only) the streamed
-// form, two workgroups per compute unit
-constexpr int RES_STREAM_LDS = 79 * 1024;
-int res_form(const ipx_cg_args *a, const ipx_pcr_view &pv, int nlaunch, bool peer) {
+// the tables of the argument block fit the kernel, for a launch of `nlaunch` of the solve's
+// pv.nwg blocks
+bool res_tables_ok(const ipx_cg_args *a, const ipx_pcr_view &pv, int nlaunch) {
   if (!a || a->solver_kind != 0 || a->lb || a->m <= 0 || !a->P_win || !a->A_off16 ||
       !a->A_rowfirst || a->A_rl < 1 || a->A_rl > RLA || !a->At_vown || !a->At_ell_row ||
       !a->At_ell_val || a->H_operator || !a->H_rowptr || a->H_hmax < 1 || a->H_hmax > 64 ||
       (a->n & 1) || a->n > (1 << 26) || a->m * a->A_rl > (1ll << 30))
-    return 0;
+    return false;
   const int H = 1 << pv.L, R = pv.rows_wg + 2 * H;
   const int navnE = ((int)a->P_navn + 2) & ~1;
-  if (nlaunch < 1 || nlaunch > pv.nwg || R > RNR * RB || H < 1 ||
+  if (nlaunch < 1 || nlaunch > pv.nwg || nlaunch > R_MAXLOCAL || R > RNR * RB || H < 1 ||
       a->P_nspan > RQS * RB || a->P_nspan < 1 || a->P_navn < 1 || a->P_navn > RQX * RB ||
       navnE > 2 * RB * RQP || 2 * a->R_hw > RHK * RB || a->R_hw < 1 || a->H_hmax > a->R_hw ||
       a->P_navn + 2 * a->H_hmax > (RQX + 1) * RB)
-    return 0;
-  const int cus = res_device_cus();
-  if (nlaunch <= R_MAXLOCAL && nlaunch <= cus &&
-      resident_lds_bytes((int)a->P_nspan, (int)a->P_navn, (int)a->H_hmax, pv.rows_wg, pv.L,
-                         (int)a->A_rl, (int)a->R_hw, false) <= 158 * 1024)
-    return 1;
-  // (the same margin of compute units as R_MAXLOCAL leaves on 256)
-  if (!peer && a->A_valT && a->A_off16T && a->H_valT && a->H_rel && nlaunch <= R_MAXG && nlaunch <= 2 * ((cus * 7) / 8) && a->R_hw <= RB &&
-      resident_lds_bytes((int)a->P_nspan, (int)a->P_navn, (int)a->H_hmax, pv.rows_wg, pv.L,
-                         (int)a->A_rl, (int)a->R_hw, true) <= (size_t)RES_STREAM_LDS)
-    return 2;
-  return 0;
+    return false;
+  if (resident_lds_bytes((int)a->P_nspan, (int)a->P_navn, (int)a->H_hmax, pv.rows_wg, pv.L, (int)a->A_rl) > 158 * 1024)
+    return false;
+  return nlaunch <= res_device_cus();
 }
 
 void res_job_common(ResJob &J, const ipx_cg_args *a, const ipx_pcr_view &pv, int32_t it_begin,
@@ -1223,8 +1048,7 @@ void res_job_common(ResJob &J, const ipx_cg_args *a, const ipx_pcr_view &pv, int
   J.st = a->state; J.it_begin = it_begin; J.it_end = it_end; J.n = (int)a->n; J.m = pv.m;
   J.rows_wg = pv.rows_wg; J.L = pv.L; J.band = pv.band;
   J.x = a->x; J.p = a->p; J.r = a->r; J.Hp = a->Hp;
-  J.A_val = a->A_val; J.A_valT = a->A_valT; J.A_off16T = (const uint16_t *)a->A_off16T;
-  J.H_valT = a->H_valT; J.H_rel = (const uint32_t *)a->H_rel; J.A_off16 = (const uint16_t *)a->A_off16; J.A_rowfirst = a->A_rowfirst;
+  J.A_val = a->A_val; J.A_off16 = (const uint16_t *)a->A_off16; J.A_rowfirst = a->A_rowfirst;
   J.rl = (int)a->A_rl; J.win = a->P_win; J.vown = a->At_vown; J.nspan = (int)a->P_nspan;
   J.navn = (int)a->P_navn;
   J.ell_row = a->At_ell_row; J.ell_val = a->At_ell_val;
@@ -1235,16 +1059,15 @@ void res_job_common(ResJob &J, const ipx_cg_args *a, const ipx_pcr_view &pv, int
   J.no_xn2 = a->no_radius != 0;
 }
 
-template <bool PEER, bool STREAM>
-void res_launch(const ResJob &J, hipStream_t st) {
+template <bool PEER>
+void res_launch(const ResJob &J, size_t lds, hipStream_t st) {
   const dim3 grid(J.nwg), block(RB);
-  const size_t lds = resident_lds_bytes(J.nspan, J.navn, J.hmax, J.rows_wg, J.L, J.rl, J.hw, STREAM);
   if (J.no_xn2) {
-    if (J.H_diag) hipLaunchKernelGGL((k_cg_resident<true, true, PEER, STREAM>), grid, block, lds, st, J);
-    else hipLaunchKernelGGL((k_cg_resident<true, false, PEER, STREAM>), grid, block, lds, st, J);
+    if (J.H_diag) hipLaunchKernelGGL((k_cg_resident<true, true, PEER>), grid, block, lds, st, J);
+    else hipLaunchKernelGGL((k_cg_resident<true, false, PEER>), grid, block, lds, st, J);
   } else {
-    if (J.H_diag) hipLaunchKernelGGL((k_cg_resident<false, true, PEER, STREAM>), grid, block, lds, st, J);
-    else hipLaunchKernelGGL((k_cg_resident<false, false, PEER, STREAM>), grid, block, lds, st, J);
+    if (J.H_diag) hipLaunchKernelGGL((k_cg_resident<false, true, PEER>), grid, block, lds, st, J);
+    else hipLaunchKernelGGL((k_cg_resident<false, false, PEER>), grid, block, lds, st, J);
   }
 }
 
@@ -1256,31 +1079,13 @@ extern "C" int ipx_cg_resident_ok(const ipx_cg_args *a) {
   if (!a || !a->resident || !a->R_ll || !a->R_seq) return 0;
   ipx_pcr_view pv;
   if (!ipx_banded_pcr_view(a->banded, &pv)) return 0;
-  return res_form(a, pv, pv.nwg, false);
-}
-
-// Before the first launch after A's values changed: the streamed form (ipx_cg_resident_ok == 2)
-// reads them entry-major from a->A_valT (m * A_rl doubles of the caller's); a no-op otherwise.
-extern "C" int ipx_cg_resident_prepare(const ipx_cg_args *a, void *stream) {
-  if (ipx_cg_resident_ok(a) != 2) return IPX_OK;
-  ipx_pcr_view pv;
-  ipx_banded_pcr_view(a->banded, &pv);
-  const int rl = (int)a->A_rl;
-  hipLaunchKernelGGL(k_entry_major, dim3((unsigned)((pv.m + 255) / 256)), dim3(256),
-                     (size_t)256 * rl * sizeof(double), (hipStream_t)stream, a->A_val,
-                     (double *)a->A_valT, (int64_t)pv.m, rl);
-  IPX_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_rows_padded, dim3((unsigned)((a->n + 255) / 256)), dim3(256), 0,
-                     (hipStream_t)stream, a->H_rowptr, a->H_val, (double *)a->H_valT, (int64_t)a->n);
-  IPX_CHECK_LAUNCH();
-  return IPX_OK;
+  return res_tables_ok(a, pv, pv.nwg) ? 1 : 0;
 }
 
 // iterations [it_begin, it_end) in one resident launch (see the top of this file)
 int ipx_cg_resident_launch(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, int np1, int np2,
                            int np3, int np4, hipStream_t st) {
-  const int form = ipx_cg_resident_ok(a);
-  if (!form || it_end <= it_begin) return IPX_EINVAL;
+  if (!ipx_cg_resident_ok(a) || it_end <= it_begin) return IPX_EINVAL;
   ipx_pcr_view pv;
   ipx_banded_pcr_view(a->banded, &pv);
   ResJob J{};
@@ -1300,7 +1105,7 @@ int ipx_cg_resident_launch(const ipx_cg_args *a, int32_t it_begin, int32_t it_en
   }
   J.seq = (uint32_t)*a->R_seq;
   *a->R_seq += need;
-  if (form == 2) res_launch<false, true>(J, st); else res_launch<false, false>(J, st);
+  res_launch<false>(J, resident_lds_bytes(J.nspan, J.navn, J.hmax, J.rows_wg, J.L, J.rl), st);
   IPX_CHECK_LAUNCH();
   return IPX_OK;
 }
@@ -1321,7 +1126,7 @@ extern "C" int ipx_cg_shard2_resident_ok(const ipx_cg_args *a, const ipx_shard2_
   if ((peer->view.rank > 0 && e->res_wg0 < 1) ||
       (peer->view.rank < peer->view.world - 1 && e->res_wg0 + e->res_nwg >= pv.nwg))
     return 0;
-  return res_form(a, pv, (int)e->res_nwg, true) == 1 ? 1 : 0;
+  return res_tables_ok(a, pv, (int)e->res_nwg) ? 1 : 0;
 }
 
 int ipx_cg_shard2_resident_launch(const ipx_cg_args *a, const ipx_shard2_ext *e, int32_t it_begin,
@@ -1354,7 +1159,7 @@ int ipx_cg_shard2_resident_launch(const ipx_cg_args *a, const ipx_shard2_ext *e,
   J.seq = peer->rseq;
   peer->rseq += (uint32_t)need;
   ++peer->res_launches;
-  res_launch<true, false>(J, stream);
+  res_launch<true>(J, resident_lds_bytes(J.nspan, J.navn, J.hmax, J.rows_wg, J.L, J.rl), stream);
   IPX_CHECK_LAUNCH();
   return IPX_OK;
 }

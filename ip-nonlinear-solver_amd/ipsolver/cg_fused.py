@@ -44,8 +44,7 @@ class CgArgs(ctypes.Structure):
         ("H_col16", _P), ("H_rowlen", _P), ("A_col16", _P), ("no_radius", _I64),
         ("A_off16", _P), ("A_rowfirst", _P), ("A_rl", _I64), ("P_win", _P), ("P_nspan", _I64),
         ("P_navn", _I64), ("H_operator", _I64),
-        ("resident", _I64), ("R_ll", _P), ("R_hw", _I64), ("R_seq", _P), ("A_valT", _P),
-        ("A_off16T", _P), ("H_valT", _P), ("H_rel", _P))]
+        ("resident", _I64), ("R_ll", _P), ("R_hw", _I64), ("R_seq", _P))]
 
 
 # Counters over the life of the process (diagnostics: how often the device loop
@@ -313,37 +312,6 @@ def resident_limits():
     return _RES_LIMITS
 
 
-def stream_rows(pattern, hmax):
-    """Per row of a square pattern the columns of its (at most ``row_H``) entries as bytes,
-    ``column - row + hmax`` (an absent entry: ``hmax``, the row's own column), packed into one
-    uint32 -- the table the streamed form of the resident kernel reads instead of the CSR
-    indices; None when a row is longer or an entry further than ``hmax`` from the diagonal.
-    Symbolic; cached on the pattern."""
-    key = ("_ipx_stream_rows", int(hmax))
-    cache = getattr(pattern, "_ipx_stream_rows", None)
-    if cache is not None and cache[0] == key:
-        return cache[1]
-    out = None
-    n = pattern.shape[0]
-    ip, idx = pattern.indptr_h.astype(np.int64), pattern.indices_h.astype(np.int64)
-    lens = np.diff(ip)
-    width = resident_limits()["row_H"]
-    if pattern.shape[0] == pattern.shape[1] and pattern.nnz > 0 and lens.max() <= width \
-            and width == 4 and 0 < hmax <= 127:
-        rows = np.arange(n, dtype=np.int64)
-        packed = np.zeros(n, dtype=np.uint32)
-        ok = True
-        for t in range(width):
-            have = t < lens
-            d = np.where(have, idx[np.minimum(ip[:-1] + t, pattern.nnz - 1)] - rows, 0)
-            ok = ok and bool(np.all(np.abs(d) <= hmax))
-            packed |= ((d + hmax).astype(np.uint32) & np.uint32(255)) << np.uint32(8 * t)
-        if ok:
-            out = torch.from_numpy(packed.view(np.int32)).to(ctx().device)
-    pattern._ipx_stream_rows = (key, out)
-    return out
-
-
 def fuse_project(pattern, vown_h, rows_wg, nwg, H):
     """Window tables of the resident loop kernel (csrc/resident.hip) for a Jacobian
     pattern and the geometry of the cyclic-reduction solve, or None: every row has the same
@@ -485,10 +453,6 @@ def _release(L, key):
 class _Loop:
     """Buffers + argument block for one projected_cg call."""
 
-    def _prepare_resident(self):
-        if self.args.resident and self.args.A_valT:
-            _hip.call("ipx_cg_resident_prepare", ctypes.byref(self.args), stream_ptr())
-
     def rebind(self, H, P, lb, ub):
         """Point the argument block at the values of a new call on the same patterns.  False
         when the new factorization takes another solve path than the one the block was laid
@@ -520,13 +484,11 @@ class _Loop:
         self.x = torch.empty(self.n, dtype=torch.float64, device=self.state.device)
         a.x = _ptr(self.x)
         self.keep = (A, At, Hc, Hd, lb, ub, P)
-        self._prepare_resident()
         return True
 
     def __init__(self, H, P, lb, ub, resident=None):
         from .dense import DeviceDense
         self.geometry, self.pcr_L, self.operator = None, None, None
-        self.stream_tabs = None
         if isinstance(P.A, DeviceDense):
             self._init_dense(H, P, lb, ub)
             return
@@ -646,26 +608,9 @@ class _Loop:
                             a.R_ll, a.R_hw = _ptr(self.ll), pj[6]
                             a.R_seq = ctypes.cast(ctypes.pointer(self.ll_seq), ctypes.c_void_p)
                             a.resident = 1
-                            rel = stream_rows(Hc.pattern, hmax) \
-                                if geo[1] > resident_limits()["max_wg"] else None
-                            if rel is not None:
-                                # more workgroups than compute units: the streamed form (two
-                                # per unit) re-reads the matrices in every iteration, from
-                                # entry-major tables -- the values' refreshed per call
-                                self.stream_tabs = (
-                                    torch.empty(m * pj[2], dtype=f64, device=dev),
-                                    pj[0].view(m, pj[2]).t().contiguous(),
-                                    torch.empty(resident_limits()["row_H"] * n, dtype=f64, device=dev),
-                                    rel)
-                                a.A_valT, a.A_off16T, a.H_valT, a.H_rel = map(_ptr, self.stream_tabs)
-                            form = int(lib.ipx_cg_resident_ok(ctypes.byref(a)))
-                            if form != 2:
-                                self.stream_tabs = None
-                                a.A_valT = a.A_off16T = a.H_valT = a.H_rel = None
-                            if not form:
+                            if not lib.ipx_cg_resident_ok(ctypes.byref(a)):
                                 a.resident = 0
         self.args = a
-        self._prepare_resident()
 
     def _init_dense(self, H, P, lb, ub):
         """Argument block for a dense Jacobian (csrc/cg.hip cg_iterate_dense)."""
