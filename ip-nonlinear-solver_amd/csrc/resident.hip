@@ -188,6 +188,7 @@ __device__ __forceinline__ const ull *halo_from_left(const ResJob &J, int wg, in
 __device__ __forceinline__ const ull *halo_from_right(const ResJob &J, int wg, int area) {
   return res_area(J.ll, wg == J.nwg - 1 ? 1 : wg + 3, area, J.hw);
 }
+#define RED_NEXT (red + 32 * (int)(red_use++ & 1u))
 // ipx_block_sum_multi with the wave count a compile-time constant: the partner sums of ALL
 // quantities are requested from LDS together and added in wave order.  (The library routine
 // loops to blockDim / 64 with one dependent LDS round trip per trip: 7 trips x NQ quantities
@@ -215,7 +216,9 @@ __device__ __forceinline__ void res_block_sum(double (&v)[NQ], double *lds, doub
     for (int w = 1; w < NW; ++w) r += t[q][w];
     out[q] = r;
   }
-  ipx_lds_barrier();
+  // (no barrier behind the reads: consecutive reductions take the two halves of the buffer in
+  // turn -- RED_NEXT --, and between two uses of one half lies the other use's barrier, which
+  // a wave only reaches with its LDS reads complete)
 }
 
 // (The hop helpers take the lane index as an argument -- the caller's per-iteration opaque copy:
@@ -370,12 +373,12 @@ k_cg_resident(ResJob J) {
   double *rspan = rs_lds;                           // r / r_next / g on the span
   double *hspan = rspan + nspanP;                   // Hp on the span
   double *U = hspan + nspanP;                       // PCR ping-pong (6 RS) | squares of g, of the residual
-  const int usize = max(6 * RS, ((J.navn + 2) & ~1) + RB);
+  const int usize = 6 * RS;
   double *sx = U + usize;                           // [R]: w, then v
   double *pspan = sx + ((R + 1) & ~1);              // p on own +- hmax
   double *aval = pspan + npsp;                      // A's window rows: [R * rl] values
-  const int navnE = (J.navn + 2) & ~1;              // (pairs may start one before av0)
-  double *red = aval + ((R * J.rl + 1) & ~1);       // [32] reductions
+  double *red = aval + ((R * J.rl + 1) & ~1);       // [2 x 32] reductions (RED_NEXT)
+  uint32_t red_use = 0;
   double *pa0 = U, *pa1 = U + RS, *pr0 = U + 2 * RS, *pr1 = U + 3 * RS, *pd0 = U + 4 * RS,
          *pd1 = U + 5 * RS;
 
@@ -506,7 +509,7 @@ k_cg_resident(ResJob J) {
   double ptHp;
   {
     double fout[1];
-    fold.finish(fparts, fcounts, red, fout);
+    fold.finish(fparts, fcounts, RED_NEXT, fout);
     ptHp = fout[0];
   }
   // bookkeeping (written back by the lead lane after the commit hop)
@@ -546,7 +549,7 @@ k_cg_resident(ResJob J) {
                              J.timeout, tid) && ok;
     }
     double sv[2] = {s1[0], ok ? 0.0 : 1.0}, tot[2];
-    res_block_sum<2>(sv, red, tot);                 // (barriers inside: the halos are in LDS)
+    res_block_sum<2>(sv, RED_NEXT, tot);                 // (barriers inside: the halos are in LDS)
     if (tot[1] != 0.0) {
       if (tid == 0) { J.st[ST_VIOL] = 80.0; J.st[ST_STOP] = (double)J.stop_code; }
       return;
@@ -678,9 +681,8 @@ k_cg_resident(ResJob J) {
     ipx_lds_barrier();
     RS_STAMP(3);
     // g = r_next - A'v on the own variables: the expressions of k_solve_pcr's tail; g replaces r
-    // on the span, its squares go to LDS and are added up in THAT kernel's order (its lane t
-    // takes the pairs t, t + 256, ...: same bits of ||g||^2)
-    double *gsq = U;                                  // [2 * pairs] (the PCR buffers are free)
+    // on the span; a lane adds up the squares of its own entries (pairs tid, tid + RB, ...)
+    double gacc = 0.0;
     {
       double v4[RQP][4], rn[RQP][2];
 #pragma unroll
@@ -707,7 +709,8 @@ k_cg_resident(ResJob J) {
         const bool in1 = j + 1 >= av0 && j + 1 < (int64_t)av1;
         if (in0) rspan[j - c_lo] = y0;
         if (in1) rspan[j + 1 - c_lo] = y1;
-        if (j - vb < navnE) { gsq[j - vb] = in0 ? y0 * y0 : 0.0; gsq[j - vb + 1] = in1 ? y1 * y1 : 0.0; }
+        gacc += in0 ? y0 * y0 : 0.0;
+        gacc += in1 ? y1 * y1 : 0.0;
       }
     }
     RS_STAMP(4);
@@ -716,9 +719,9 @@ k_cg_resident(ResJob J) {
     ipx_lds_barrier();
     halo_put<PEER>(J, wg, 2, rspan + own_off, pl, J.seq + hop + 1, tid);                 // to the left neighbour
     halo_put<PEER>(J, wg, 3, rspan + own_off + avn - pr, pr, J.seq + hop + 1, tid);      // to the right neighbour
-    // residual of the own rows:  w_i - (a_i v_{i-1} + b_i v_i + a_{i+1} v_{i+1}), squared; summed
-    // like ||g||^2 in the order of the 256-lane k_solve_pcr (its lane t: row t, then row t + 256)
-    double *rsq = U + navnE;                          // (behind gsq: navnE + RB doubles of U)
+    // residual of the own rows:  w_i - (a_i v_{i-1} + b_i v_i + a_{i+1} v_{i+1}), squared (a lane
+    // per window row)
+    double acc = 0.0;
     {
       const int r = min(max(tid, 1), R - 2);
       const double vm = sx[r - 1], vc = sx[r], vp = sx[r + 1];
@@ -730,43 +733,13 @@ k_cg_resident(ResJob J) {
         const double res = w0[0] - sum;
         res2 = res * res;
       }
-      rsq[tid] = res2;
+      acc = res2;
     }
-    ipx_lds_barrier();
-    double gacc = 0.0, acc = 0.0;
-    if (tid < 256) {
-      double q2[2 * ((RQP * RB) / 256)];
-#pragma unroll
-      for (int k = 0; k < (RQP * RB) / 256; ++k) {
-        const int jl = min(2 * (tid + k * 256), navnE - 2);
-        q2[2 * k] = gsq[jl]; q2[2 * k + 1] = gsq[jl + 1];
-      }
-      const double r0_ = rsq[tid], r1_ = rsq[tid + 256];
-#pragma unroll
-      for (int k = 0; k < (RQP * RB) / 256; ++k)
-        if (2 * (tid + k * 256) < navnE) { gacc += q2[2 * k]; gacc += q2[2 * k + 1]; }
-      acc += r0_; acc += r1_;
-    }
+    // ||x + alpha p||^2, ||g||^2 and the residual: wave sums, waves in order
     double mine3[3];
     {
-      // ||x + alpha p||^2 over all lanes; ||g||^2 and the residual over the first four waves,
-      // waves in order (a 256-thread ipx_block_reduce)
-      const int lane = tid & 63, wave = tid >> 6;
-      const double s0 = ipx_wave_sum(sxx), s1 = ipx_wave_sum(gacc), s2 = ipx_wave_sum(acc);
-      if (lane == 0) { red[wave] = s0; red[8 + wave] = s1; red[16 + wave] = s2; }
-      ipx_lds_barrier();
-      double t0[RB / 64], t1[4], t2[4];
-#pragma unroll
-      for (int w = 0; w < RB / 64; ++w) t0[w] = red[w];
-#pragma unroll
-      for (int w = 0; w < 4; ++w) { t1[w] = red[8 + w]; t2[w] = red[16 + w]; }
-      double r0 = t0[0], r1 = t1[0], r2 = t2[0];
-#pragma unroll
-      for (int w = 1; w < RB / 64; ++w) r0 += t0[w];
-#pragma unroll
-      for (int w = 1; w < 4; ++w) { r1 += t1[w]; r2 += t2[w]; }
-      mine3[0] = r0; mine3[1] = r1; mine3[2] = r2;
-      ipx_lds_barrier();
+      double loc3[3] = {sxx, gacc, acc};
+      res_block_sum<3>(loc3, RED_NEXT, mine3);
     }
     RS_STAMP(5);
     // ================= hop 2: partials + halo of g ===========================================
@@ -785,7 +758,7 @@ k_cg_resident(ResJob J) {
       RS_STAMP(6);
       RS_STAMP_SYNC(12);
       double tot[4];
-      res_block_sum<4>(sv, red, tot);                // (barriers inside: the halo is in LDS)
+      res_block_sum<4>(sv, RED_NEXT, tot);                // (barriers inside: the halo is in LDS)
       if (tot[3] != 0.0) {
         if (tid == 0) { J.st[ST_VIOL] = 82.0; J.st[ST_STOP] = (double)J.stop_code; }
         return;
@@ -873,7 +846,7 @@ k_cg_resident(ResJob J) {
       halo_put<PEER>(J, wg, 1, hspan + own_off + avn - pr, pr, J.seq + hop + 1, tid);
     }
     double mine1[1], loc1[1] = {acc_xy};
-    res_block_sum<1>(loc1, red, mine1);         // (barriers inside: Hp is complete on the own part)
+    res_block_sum<1>(loc1, RED_NEXT, mine1);         // (barriers inside: Hp is complete on the own part)
     RS_STAMP(9);
     // ================= hop 1: p'Hp + halo of Hp (the last one of the launch: commit) =========
     ++hop;
@@ -896,7 +869,7 @@ k_cg_resident(ResJob J) {
       RS_STAMP(10);
       RS_STAMP_SYNC(13);
       double tot[2];
-      res_block_sum<2>(sv, red, tot);
+      res_block_sum<2>(sv, RED_NEXT, tot);
       if (tot[1] != 0.0) {
         if (tid == 0) { J.st[ST_VIOL] = 81.0; J.st[ST_STOP] = (double)J.stop_code; }
         return;
@@ -917,7 +890,7 @@ k_cg_resident(ResJob J) {
                                       hspan, hspan, hop > 1 ? 8 * J.timeout : J.timeout, tid);
     sv[0] = 0.0; sv[1] = ok ? 0.0 : 1.0;
     double tot[2];
-    res_block_sum<2>(sv, red, tot);
+    res_block_sum<2>(sv, RED_NEXT, tot);
     if (tot[1] != 0.0) {
       if (tid == 0) { J.st[ST_VIOL] = 83.0; J.st[ST_STOP] = (double)J.stop_code; }
       return;
@@ -969,9 +942,8 @@ size_t resident_lds_bytes(int nspan, int navn, int hmax, int rows_wg, int L, int
   const int H = 1 << L, R = rows_wg + 2 * H, RS = R + 2 * H;
   const int nspanP = (nspan + 1) & ~1;
   const int npsp = (navn + 2 * hmax + 1) & ~1;
-  const int navnE = (navn + 2) & ~1;
-  const int usize = std::max(6 * RS, navnE + RB);
-  return sizeof(double) * (size_t)(2 * nspanP + usize + ((R + 1) & ~1) + npsp + ((R * rl + 1) & ~1) + 32);
+  const int usize = 6 * RS;
+  return sizeof(double) * (size_t)(2 * nspanP + usize + ((R + 1) & ~1) + npsp + ((R * rl + 1) & ~1) + 64);
 }
 
 }  // namespace
