@@ -48,6 +48,9 @@ const char *ipx_version(void);
 /* Text of the last HIP error seen by this thread ("" if none). */
 const char *ipx_last_error(void);
 int ipx_device_info(int *cu_count, int *lds_bytes, char *arch, int arch_len);
+/* Blocking read-back of k <= 512 doubles of device memory behind everything queued on `stream`
+ * (pinned staging buffer inside the library; host_out: k doubles of the caller's). */
+int ipx_read_doubles(const double *dev, int k, double *host_out, void *stream);
 
 /* ---- vectors (np elementwise algebra; qp_subproblem.py:212-216,312,580,622,628)
  * out = a*x + b*y (y may be NULL when b == 0); in-place allowed. */

@@ -17,6 +17,7 @@ _P, _I64, _I32, _F64 = _c.c_void_p, _c.c_int64, _c.c_int32, _c.c_double
 # name -> argtypes; every function returns int unless listed in _RESTYPES.
 _SIGNATURES = {
     "ipx_device_info": [_c.POINTER(_c.c_int), _c.POINTER(_c.c_int), _c.c_char_p, _c.c_int],
+    "ipx_read_doubles": [_P, _c.c_int, _P, _P],
     "ipx_axpby": [_I64, _F64, _P, _F64, _P, _P, _P],
     "ipx_mul": [_I64, _P, _P, _P, _P],
     "ipx_fill": [_I64, _F64, _P, _P],

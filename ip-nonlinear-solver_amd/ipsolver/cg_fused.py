@@ -881,7 +881,7 @@ def _run_loop(L, pool_key, P, lib, st, n, lb, ub, trust_radius, max_iter, max_in
                     L.apply_operator()
 
         def read_state(self):
-            s = L.state.tolist()
+            s = dv.read_doubles(L.state, L.state.numel())
             if fast and int(s[ST_STOP]) == 9:
                 # the device's verdict on the priming: the host must do it (nothing of the
                 # call's inputs was overwritten; the loop's launches were no-ops)
@@ -896,7 +896,7 @@ def _run_loop(L, pool_key, P, lib, st, n, lb, ub, trust_radius, max_iter, max_in
                 L.state[ST_STOP] = 0.0
                 _hip.check(lib.ipx_cg_iterate(L.ref(), self.last[0], self.last[1], st),
                            "ipx_cg_iterate")
-                s = L.state.tolist()
+                s = dv.read_doubles(L.state, L.state.numel())
             return s
 
         def X(self):
@@ -1033,7 +1033,7 @@ def _resume(lib, L, it_stop, mode, st):
     _hip.check(lib.ipx_cg_resume(L.ref(), it_stop, mode, st), "ipx_cg_resume")
     if L.operator is not None:
         L.apply_operator()
-    return L.state.tolist()
+    return dv.read_doubles(L.state, L.state.numel())
 
 
 def _refine(P, L, R):

@@ -900,7 +900,8 @@ class FusedShardedCG:
         self.sync_halos()
         self.L.state[ST_STOP] = 0.0
         self._segment(1, it, mode)
-        return self.L.state.tolist()
+        from . import device as dv
+        return dv.read_doubles(self.L.state, self.L.state.numel())
 
 
 def fused_projected_cg(H, c, Z, Y, b, trust_radius=np.inf, lb=None, ub=None, tol=None,
@@ -986,7 +987,7 @@ def _drive_fused(F, c, x0, r0, g0, rt_g, tol, trust_radius, lb, ub, max_iter,
             # (the read that ends the loop -- out of iterations on a continuing state -- is
             # agreed on here, before the host's first collective on the result: the halo
             # synchronisation after resident batches)
-            return agreed(L.state.tolist(), final=self.end >= max_iter)
+            return agreed(dv.read_doubles(L.state, L.state.numel()), final=self.end >= max_iter)
 
         def X(self):
             F.sync_halos()

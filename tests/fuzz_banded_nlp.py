@@ -93,9 +93,17 @@ def run(cases, seed, verbose=True, max_m=2700):
         # (weakly active constraints leave the end point of a barrier run determined to about
         # sqrt(mu) = 1e-4 along their direction, the objective to mu times the number of active
         # constraints -- and the two runs may stop one barrier parameter apart)
+        # (the point a barrier run ends on solves the subproblem of the PREVIOUS parameter,
+        # 5 x the final one: its objective lies mu_prev x (active constraints) above the
+        # limit -- two runs that end two parameters apart, seed 505 case 48: 1.0e-8 against
+        # 2.6e-7 on a problem with |f| = 19 and 282 constraints, differ by that much)
         df = abs(got.fun - want.fun) / max(1.0, abs(want.fun))
+        n_cons = m + (2 * n if kind == "ineq+box" else 0)
+        gap = 2.0 * 5.0 * max(got.barrier_parameter, want.barrier_parameter) * n_cons \
+            if kind != "eq-sqp" else 0.0
         assert dx <= 1e-4 and got.constr_violation <= 1e-8, line
-        assert df <= 1e-5, (line, got.fun, want.fun, got.barrier_parameter, want.barrier_parameter)
+        assert df <= max(1e-5, gap / max(1.0, abs(want.fun))), \
+            (line, got.fun, want.fun, got.barrier_parameter, want.barrier_parameter)
         line += "  device callbacks %d outer %d CG |dx| %.1e" % (dres.niter, dres.cg_niter, ddx)
         assert dres.status in (1, 2) and ddx <= (1e-4 if kind == "ineq+box" else 1e-9), line
         if kind != "ineq+box":          # (no barrier end game: the whole trace is comparable)

@@ -124,6 +124,12 @@ def run(cases, seed, verbose=True, only=None):
             long_cg = np.flatnonzero(np.diff(wrows[:k, 1]) > 12)
             if len(long_cg):
                 k = int(long_cg[0]) + 1
+            if any(t.startswith("fd-") for t in P["tags"]):
+                # (a finite-difference Hessian product carries ~1e-8 of rounding noise, another
+                # draw of it on each side, and every CG iteration amplifies it: seed 505 case 83
+                # agrees to 1e-16 / 3e-9 / 1e-5 / 2e-4 after 1 / 4 / 13 / 18 CG iterations --
+                # rows are compared while the oracle's count is at most 8)
+                k = max(min(k, int(np.searchsorted(wrows[:k, 1], 8, side="right"))), min(k, 2))
             dx = float(np.max(np.abs(got.x - want.x)) / max(1.0, np.max(np.abs(want.x))))
             line = "case %2d n=%2d %-5s %-24s %-34s status %d/%d  %3d/%3d outer  |dx| %.1e  opt %.1e/%.1e" % (
                 case, P["n"], "csr" if P["sparse"] else "dense", method, "+".join(P["tags"]) or "-",
