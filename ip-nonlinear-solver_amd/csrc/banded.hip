@@ -2019,10 +2019,10 @@ int factor_upper(Banded *h, hipStream_t st) {
 }
 
 // flag[0] = pivot / coupling bits; flag[1 ..] = the PCR level flags: ONE blocking read
+// (through the library's pinned read-back, csrc/misc.hip: a copy into pageable memory costs two
+// runtime synchronisations -- this read ends every factorization)
 int read_flag(Banded *h, int *f, hipStream_t st, int count = 1) {
-  if (hipMemcpyAsync(f, h->flag, count * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess)
-    return IPX_ELAUNCH;
-  return hipStreamSynchronize(st) == hipSuccess ? IPX_OK : IPX_ELAUNCH;
+  return ipx_read_ints(h->flag, count, f, st) == IPX_OK ? IPX_OK : IPX_ELAUNCH;
 }
 
 template <typename T>
@@ -2127,7 +2127,7 @@ void *ipx_banded_create(int64_t m64, int32_t k, int32_t chunk) {
       }
     }
   }
-  h->flag = dalloc<int>(h, 2 + PCR_LMAX);
+  h->flag = dalloc<int>(h, 2 + PCR_LMAX + 1);       // (+1: ipx_read_ints reads whole doubles)
   if (ok && h->flag && h->lev[0].k == 1 && h->nlev >= 2 &&
       DEC_CHUNKS * h->lev[0].q + 2 * (1 << PCR_LMAX) <= PCR_RMAX) {
     h->pcr_flags = h->flag + 1;

@@ -14,6 +14,9 @@
 
 // Records the HIP error text for ipx_last_error() (defined in misc.hip).
 void ipx_note_error(hipError_t e, const char *file, int line);
+// blocking read-back of k ints (csrc/misc.hip: ipx_read_doubles' mechanism); the device array
+// must be readable up to the next multiple of 8 bytes
+int ipx_read_ints(const int *dev, int k, int *host_out, hipStream_t st);
 
 #define IPX_CHECK_LAUNCH()                                   \
   do {                                                       \

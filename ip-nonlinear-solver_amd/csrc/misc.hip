@@ -6,6 +6,7 @@
 #include <chrono>
 
 constexpr int IPX_READ_MAX = 512;
+extern "C" int ipx_read_doubles(const double *dev, int k, double *host_out, void *stream);
 
 // ipx_read_doubles: k doubles into host-coherent memory, the sequence word behind them
 __global__ void __launch_bounds__(IPX_READ_MAX)
@@ -89,3 +90,15 @@ int ipx_read_doubles(const double *dev, int k, double *host_out, void *stream) {
 }
 
 }  // extern "C"
+
+// Inside the library: k ints behind the same mechanism (the pivot flags of a factorization).
+int ipx_read_ints(const int *dev, int k, int *host_out, hipStream_t st) {
+  if (k < 0 || k > 2 * IPX_READ_MAX) return IPX_EINVAL;
+  double tmp[IPX_READ_MAX];
+  // (an odd count reads one int past the end: the callers' buffers are allocations of whole
+  // doubles -- asserted where they are made)
+  int rc = ipx_read_doubles((const double *)dev, (k + 1) / 2, tmp, st);
+  if (rc == IPX_OK) memcpy(host_out, tmp, (size_t)k * sizeof(int));
+  return rc;
+}
+
