@@ -65,7 +65,8 @@ struct Banded {
   int nslab_lds;              // = nslab when the slab is staged in LDS, else 0
   // parallel cyclic reduction (k = 1): scratch for the factor-time level check, per-level
   // flags (device), and the level at which the reduced system is numerically diagonal
-  int *pcr_flags;             // PCR_LMAX + 1 ints: bit 0 of [s] = level s still coupled
+  int *pcr_flags;             // 2 x (PCR_LMAX + 1) ints: [s] != 0 = level s still coupled,
+                              // [PCR_LMAX + 1 + s] != 0 = a reduced diagonal entry not positive
   int pcr_L;                  // 0: PCR solve not usable
   // defect correction on the single-launch solve (separator blocks coupled, top level too
   // long for a serial sweep or not compiled): see iter_solve
@@ -524,8 +525,27 @@ k_correct_oop(int m, int c, int P, const double *__restrict__ V, const double *_
   }
 }
 
-// ---- S = A A' in band storage: one lane per (row i, offset d), merge join
-// of the two sorted CSR rows perm[i] and perm[i-d].
+// ---- S = A A' in band storage: the merge join of the two sorted CSR rows perm[i] and
+// perm[i-d], products added in the order of the columns.
+// k_aat_band: one lane per (row i, offset d) straight out of global memory (any row order).
+// k_aat_band_rows (rows in their own order): a workgroup takes 256 consecutive rows, stages
+// their entries -- one contiguous piece of the CSR arrays -- in LDS with coalesced loads and
+// joins out of LDS, a lane per row, all offsets; a piece that does not fit takes the global
+// path inside the same launch.  (The global join is two dependent loads per step: 32 us at
+// m = 1e5, a third of a refactorization; staged: see DESIGN.md section 3.)
+template <typename Col, typename Val>
+__device__ __forceinline__ double aat_join(int p, int pe, int u, int ue, Col col, Val val,
+                                           const double *__restrict__ wcol) {
+  double s = 0.0;
+  while (p < pe && u < ue) {
+    const int cp = col(p), cu = col(u);
+    if (cp == cu) { s += wcol ? val(p) * val(u) * wcol[cp] : val(p) * val(u); ++p; ++u; }
+    else if (cp < cu) ++p;
+    else ++u;
+  }
+  return s;
+}
+
 __global__ void __launch_bounds__(IPX_BLOCK)
 k_aat_band(int m, int k, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
            const double *__restrict__ val, const int32_t *__restrict__ perm,
@@ -536,16 +556,45 @@ k_aat_band(int m, int k, const int32_t *__restrict__ rowptr, const int32_t *__re
   double s = 0.0;
   if (i - d >= 0) {
     const int r1 = perm ? perm[i] : i, r2 = perm ? perm[i - d] : i - d;
-    int p = rowptr[r1], pe = rowptr[r1 + 1];
-    int u = rowptr[r2], ue = rowptr[r2 + 1];
-    while (p < pe && u < ue) {
-      const int cp = colidx[p], cu = colidx[u];
-      if (cp == cu) { s += wcol ? val[p] * val[u] * wcol[cp] : val[p] * val[u]; ++p; ++u; }
-      else if (cp < cu) ++p;
-      else ++u;
-    }
+    s = aat_join(rowptr[r1], rowptr[r1 + 1], rowptr[r2], rowptr[r2 + 1],
+                 [&](int e) { return colidx[e]; }, [&](int e) { return val[e]; }, wcol);
   }
   band[(int64_t)d * m + i] = s;
+}
+
+constexpr int AAT_CAP = 5120;        // entries a workgroup stages (256 + k rows of <= ~19 entries)
+
+__global__ void __launch_bounds__(IPX_BLOCK)
+k_aat_band_rows(int m, int k, const int32_t *__restrict__ rowptr,
+                const int32_t *__restrict__ colidx, const double *__restrict__ val,
+                const double *__restrict__ wcol, double *__restrict__ band) {
+  __shared__ double sval[AAT_CAP];
+  __shared__ int32_t scol[AAT_CAP];
+  const int i0 = blockIdx.x * IPX_BLOCK, i = i0 + (int)threadIdx.x;
+  const int e0 = rowptr[max(i0 - k, 0)], e1 = rowptr[min(i0 + IPX_BLOCK, m)];
+  const bool staged = e1 - e0 <= AAT_CAP;                  // (uniform over the workgroup)
+  if (staged) {
+    for (int e = e0 + (int)threadIdx.x; e < e1; e += IPX_BLOCK) {
+      scol[e - e0] = colidx[e];
+      sval[e - e0] = val[e];
+    }
+  }
+  __syncthreads();
+  if (i >= m) return;
+  const int p = rowptr[i], pe = rowptr[i + 1];
+  for (int d = 0; d <= k; ++d) {
+    double s = 0.0;
+    if (i - d >= 0) {
+      const int u = rowptr[i - d], ue = rowptr[i - d + 1];
+      if (staged)
+        s = aat_join(p - e0, pe - e0, u - e0, ue - e0, [&](int e) { return scol[e]; },
+                     [&](int e) { return sval[e]; }, wcol);
+      else
+        s = aat_join(p, pe, u, ue, [&](int e) { return colidx[e]; },
+                     [&](int e) { return val[e]; }, wcol);
+    }
+    band[(int64_t)d * m + i] = s;
+  }
 }
 
 
@@ -1377,8 +1426,11 @@ __device__ __forceinline__ double pcr_rcp(double b) {
 
 // Factor-time check in ONE launch: the reduction of the matrix alone (no right-hand side) on
 // the same windows as the solve, all PCR_LMAX levels; a workgroup tests its own rows after
-// every level: flags[s] bit 0 = a coupling at distance 2^s is still above 2^-56 of the
-// diagonal, bit 1 = a reduced diagonal entry is not positive.
+// every level: flags[s + 1] = a coupling at distance 2^s is still above 2^-56 of the diagonal,
+// flags[PCR_LMAX + 1 + s + 1] = a reduced diagonal entry is not positive.  Plain stores of the
+// constant 1, one word per (level, finding): every workgroup raises the first kind below the
+// decoupling level, and atomics on ONE word serialise in L2 at ~45 ns each -- 71 us of this
+// kernel's 78 at m = 1e5 (1540 waves x 7 levels), half of a refactorization.
 __global__ void __launch_bounds__(IPX_BLOCK)
 k_pcr_check(int m, int rows_wg, const double *__restrict__ band, int *flags) {
   constexpr int PAD = 1 << PCR_LMAX;
@@ -1430,7 +1482,11 @@ k_pcr_check(int m, int rows_wg, const double *__restrict__ band, int *flags) {
         if (!(bn > 0.0)) bits |= 2;
       }
     }
-    if (bits) atomicOr(flags + s + 1, bits);
+    const bool any0 = __ballot(bits & 1) != 0, any1 = __ballot(bits & 2) != 0;
+    if ((tid & (IPX_WAVE - 1)) == 0) {
+      if (any0) flags[s + 1] = 1;
+      if (any1) flags[PCR_LMAX + 1 + s + 1] = 1;
+    }
   }
 }
 
@@ -2127,7 +2183,7 @@ void *ipx_banded_create(int64_t m64, int32_t k, int32_t chunk) {
       }
     }
   }
-  h->flag = dalloc<int>(h, 2 + PCR_LMAX + 1);       // (+1: ipx_read_ints reads whole doubles)
+  h->flag = dalloc<int>(h, 1 + 2 * (PCR_LMAX + 1) + 1);   // (+1: ipx_read_ints reads whole doubles)
   if (ok && h->flag && h->lev[0].k == 1 && h->nlev >= 2 &&
       DEC_CHUNKS * h->lev[0].q + 2 * (1 << PCR_LMAX) <= PCR_RMAX) {
     h->pcr_flags = h->flag + 1;
@@ -2204,7 +2260,7 @@ int ipx_banded_factor(void *handle, const double *band, void *stream) {
   if (decoupling_candidate(h) && h->pcr_flags) {
     // the cyclic reduction of the matrix alone: at which level has it decoupled?
     const Level &l0 = h->lev[0];
-    if (hipMemsetAsync(h->pcr_flags, 0, (PCR_LMAX + 1) * sizeof(int), st) != hipSuccess)
+    if (hipMemsetAsync(h->pcr_flags, 0, 2 * (PCR_LMAX + 1) * sizeof(int), st) != hipSuccess)
       return IPX_ELAUNCH;
     hipLaunchKernelGGL(k_pcr_check, dim3((l0.P + DEC_CHUNKS - 1) / DEC_CHUNKS), dim3(IPX_BLOCK), 0,
                        st, l0.m, DEC_CHUNKS * l0.q, band, h->pcr_flags);
@@ -2240,16 +2296,16 @@ int ipx_banded_status(void *handle, void *stream) {
   if (!handle) return IPX_EINVAL;
   Banded *h = (Banded *)handle;
   hipStream_t st = (hipStream_t)stream;
-  int fl[2 + PCR_LMAX] = {0};
-  if (read_flag(h, fl, st, h->pcr_flags ? 2 + PCR_LMAX : 1) != IPX_OK) return IPX_ELAUNCH;
+  int fl[1 + 2 * (PCR_LMAX + 1)] = {0};
+  if (read_flag(h, fl, st, h->pcr_flags ? 1 + 2 * (PCR_LMAX + 1) : 1) != IPX_OK) return IPX_ELAUNCH;
   int f = fl[0];
   h->decoupled = decoupling_candidate(h) && !(f & 2);
   h->pcr_L = 0;
   if (h->decoupled && h->pcr_flags && !(f & 1)) {
-    const int *pf = fl + 1;
+    const int *pf = fl + 1, *pn = fl + 1 + (PCR_LMAX + 1);
     for (int s = 1; s <= PCR_LMAX; ++s) {
-      if (pf[s] & 2) break;                 // a non-positive reduced diagonal: not this path
-      if (!(pf[s] & 1)) { h->pcr_L = s; break; }
+      if (pn[s]) break;                     // a non-positive reduced diagonal: not this path
+      if (!pf[s]) { h->pcr_L = s; break; }
     }
   }
   h->iter_N = 0;
@@ -2323,9 +2379,14 @@ int ipx_aat_band_w(int64_t m, int32_t k, const int32_t *rowptr, const int32_t *c
   if (m < 0 || k < 0 || !rowptr || !band) return IPX_EINVAL;
   if (m == 0) return IPX_OK;
   int64_t tot = m * (k + 1);
-  hipLaunchKernelGGL(k_aat_band, dim3((unsigned)((tot + IPX_BLOCK - 1) / IPX_BLOCK)),
-                     dim3(IPX_BLOCK), 0, (hipStream_t)stream, (int)m, k, rowptr, colidx, val, perm,
-                     wcol, band);
+  if (!perm)
+    hipLaunchKernelGGL(k_aat_band_rows, dim3((unsigned)((m + IPX_BLOCK - 1) / IPX_BLOCK)),
+                       dim3(IPX_BLOCK), 0, (hipStream_t)stream, (int)m, k, rowptr, colidx, val,
+                       wcol, band);
+  else
+    hipLaunchKernelGGL(k_aat_band, dim3((unsigned)((tot + IPX_BLOCK - 1) / IPX_BLOCK)),
+                       dim3(IPX_BLOCK), 0, (hipStream_t)stream, (int)m, k, rowptr, colidx, val, perm,
+                       wcol, band);
   IPX_CHECK_LAUNCH();
   return IPX_OK;
 }
