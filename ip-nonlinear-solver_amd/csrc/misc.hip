@@ -8,16 +8,21 @@
 constexpr int IPX_READ_MAX = 512;
 extern "C" int ipx_read_doubles(const double *dev, int k, double *host_out, void *stream);
 
-// ipx_read_doubles: k doubles into host-coherent memory, the sequence word behind them
+// ipx_read_doubles: k doubles into host-coherent memory as 16-byte granules that validate
+// themselves -- (low word, tag, high word, tag), ONE write-through store each, the tag = the
+// read's sequence number: no fence, no flag behind the data (a system-scope release at this
+// point would first write back every dirty L2 line the loop before it left: +18 us per read
+// behind a batch of CG iterations, measured with a fence + flag version)
+typedef unsigned int ipx_u4 __attribute__((ext_vector_type(4)));
 __global__ void __launch_bounds__(IPX_READ_MAX)
-k_publish(const double *__restrict__ src, int k, double *dst, unsigned long long *word,
-          unsigned long long seq) {
-  if ((int)threadIdx.x < k) dst[threadIdx.x] = src[threadIdx.x];
-  __threadfence_system();
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __hip_atomic_store(word, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
+k_publish(const double *__restrict__ src, int k, ipx_u4 *dst, unsigned int tag) {
+  if ((int)threadIdx.x >= k) return;
+  const unsigned long long bits = (unsigned long long)__double_as_longlong(src[threadIdx.x]);
+  ipx_u4 w;
+  w.x = (unsigned)(bits & 0xffffffffull); w.y = tag;
+  w.z = (unsigned)(bits >> 32);           w.w = tag;
+  ipx_u4 *d = dst + threadIdx.x;
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(d), "v"(w) : "memory");
 }
 
 static thread_local char g_last_error[256] = "";
@@ -47,45 +52,50 @@ int ipx_device_info(int *cu_count, int *lds_bytes, char *arch, int arch_len) {
 }
 
 // Blocking read-back of k <= IPX_READ_MAX doubles of device memory behind everything queued on
-// `stream`: a one-workgroup kernel copies them into a pinned, host-coherent buffer of the
-// library's (one per host thread) and stores a sequence number behind them; the host polls that
-// word.  No runtime synchronisation call on the way (hipMemcpy into pageable memory: 21 us per
+// `stream`: a one-workgroup kernel stores them into a pinned, host-coherent buffer of the
+// library's (one per host thread) as tagged granules (k_publish); the host polls the tags.  No
+// runtime synchronisation call on the way (hipMemcpy into pageable memory: 21 us per
 // read behind a small kernel, hipMemcpyAsync into pinned memory + hipStreamSynchronize: 18 --
 // the outer loops' scalar reads are the host's largest single item of a solve).  A read that
 // has not arrived after 2 s falls back to hipStreamSynchronize (and reports its error).
 int ipx_read_doubles(const double *dev, int k, double *host_out, void *stream) {
-  static thread_local double *pinned = nullptr;      // [IPX_READ_MAX] values, then the sequence word
-  static thread_local unsigned long long seq = 0;
+  static thread_local unsigned int *pinned = nullptr;      // [IPX_READ_MAX] granules of 4 words
+  static thread_local unsigned int seq = 0;
   if (!dev || !host_out || k < 0 || k > IPX_READ_MAX) return IPX_EINVAL;
   if (k == 0) return IPX_OK;
   if (!pinned) {
-    if (hipHostMalloc((void **)&pinned, (IPX_READ_MAX + 1) * sizeof(double),
-                      hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+    if (hipHostMalloc((void **)&pinned, IPX_READ_MAX * 16, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
       pinned = nullptr;
       return IPX_ENOMEM;
     }
-    memset(pinned, 0, (IPX_READ_MAX + 1) * sizeof(double));
+    memset(pinned, 0, IPX_READ_MAX * 16);
   }
   hipStream_t st = (hipStream_t)stream;
-  volatile unsigned long long *word = (volatile unsigned long long *)(pinned + IPX_READ_MAX);
-  ++seq;
-  hipLaunchKernelGGL(k_publish, dim3(1), dim3(IPX_READ_MAX), 0, st, dev, k, pinned,
-                     (unsigned long long *)(pinned + IPX_READ_MAX), seq);
+  if (++seq == 0) ++seq;                                   // (0: the buffer's initial tags)
+  hipLaunchKernelGGL(k_publish, dim3(1), dim3(IPX_READ_MAX), 0, st, dev, k, (ipx_u4 *)pinned, seq);
   if (hipGetLastError() != hipSuccess) return IPX_ELAUNCH;
+  volatile unsigned int *w = pinned;
   const auto t0 = std::chrono::steady_clock::now();
   unsigned spins = 0;
-  while (*word != seq) {
+  int done = 0;                                            // granules [0, done) have arrived
+  while (true) {
+    while (done < k && w[4 * done + 1] == seq && w[4 * done + 3] == seq) ++done;
+    if (done == k) break;
     __builtin_ia32_pause();
     if ((++spins & 0xfffu) == 0 &&
         std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
       hipError_t e = hipStreamSynchronize(st);
       if (e != hipSuccess) { ipx_note_error(e, __FILE__, __LINE__); return IPX_ELAUNCH; }
-      if (*word != seq) return IPX_ELAUNCH;
+      for (done = 0; done < k && w[4 * done + 1] == seq && w[4 * done + 3] == seq; ++done) {}
+      if (done != k) return IPX_ELAUNCH;
       break;
     }
   }
   std::atomic_thread_fence(std::memory_order_acquire);
-  memcpy(host_out, pinned, (size_t)k * sizeof(double));
+  for (int i = 0; i < k; ++i) {
+    const unsigned long long bits = (unsigned long long)w[4 * i] | ((unsigned long long)w[4 * i + 2] << 32);
+    memcpy(host_out + i, &bits, sizeof(double));
+  }
   return IPX_OK;
 }
 
