@@ -393,100 +393,144 @@ __global__ void __launch_bounds__(IPX_BLOCK) k_save_diag(const double *G, int M,
   if (i == 0) work[M] = 1.0;
 }
 
-// Diagonal tile kb: G_kk = L_kk L_kk' by one workgroup, the tile in REGISTERS: thread (ty, tx)
-// owns the 4 x 4 elements (ty + 16 a, tx + 16 b).  Per column j: its owners publish the column
-// (as updated so far) to LDS, one barrier, every thread forms L[r][j] = col[r] / sqrt(col[j])
-// for its rows and columns itself (same expression everywhere: same bits) and updates its own
-// elements -- one barrier per column and no global access inside the loop (the first version
-// read and wrote the pivot statistics in global memory from the loop's serial section: 60 us
-// per tile).  The strict upper triangle of the tile is zeroed.
+// value of lane `lane` (a constant after unrolling) of the wave, in every lane
+__device__ __forceinline__ double lane_bcast(double v, int lane) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, lane);
+  hi = __builtin_amdgcn_readlane(hi, lane);
+  return __hiloint2double(hi, lo);
+}
+
+constexpr int PB = 16;           // column block inside a tile
+
+// 1 / sqrt(d) for a positive, normal d: the hardware estimate (~26 bits) and two Newton steps
+// (the library routine's scaling and special cases are a third of the dependent chain a column
+// of the diagonal block waits for)
+__device__ __forceinline__ double potrf_rsqrt(double d) {
+  double y = __builtin_amdgcn_rsq(d);
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const double e = __builtin_fma(-d * y, y, 1.0);
+    y = __builtin_fma(0.5 * y, e, y);
+  }
+  return y;
+}
+
+// Diagonal tile kb: G_kk = L_kk L_kk' by one workgroup, the tile in LDS, in four column blocks
+// of 16:
+//   (a) the 16 x 16 diagonal block by ONE wave without a barrier: lane r holds row r in
+//       registers, per column the pivot and the column's entries travel by v_readlane
+//       (static lanes: both loops unrolled), L[r][j] = x / sqrt(d) as x * rsqrt(d);
+//   (b) the rows below it: a lane per row, forward substitution out of registers, the block's
+//       entries LDS broadcasts, right-looking (the dependent chain of a step is one multiply
+//       and one multiply-add);
+//   (c) the rank-16 update of what is left, an element per lane and pass.
+// Three barriers per block, twelve per tile (the first version took one per COLUMN and formed
+// every column's entries in all 256 threads: 30 us per tile, the largest item of the
+// Cholesky's 2.0 ms at M = 2048).  The strict upper triangle of the tile is zeroed.
 __global__ void __launch_bounds__(IPX_BLOCK)
 k_potrf64(double *G, int M, int kb, int *flag, double *work) {
-  __shared__ double col[2][FB];
+  __shared__ double T[FB][FB + 1];
+  __shared__ double rinv[FB];
   __shared__ double diag0[FB];
-  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+  const int tid = threadIdx.x;
   double *g = G + ((int64_t)kb * FB) * M + (int64_t)kb * FB;
-  double e[4][4];
+  {
+    double v[FB * FB / IPX_BLOCK];                    // (all sixteen loads in flight)
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+    for (int u = 0; u < FB * FB / IPX_BLOCK; ++u) {
+      const int e = tid + u * IPX_BLOCK;
+      v[u] = g[(int64_t)(e >> 6) * M + (e & 63)];
+    }
 #pragma unroll
-    for (int b = 0; b < 4; ++b) e[a][b] = g[(int64_t)(ty + 16 * a) * M + tx + 16 * b];
-  if (tid < FB) diag0[tid] = work[kb * FB + tid];
-  int bits = 0;
-  double ratio = 1.0;
-  // (the columns in four groups of sixteen: the group index is a compile-time constant in each
-  // copy of the inner loop, so every index into e[][] is static -- one 64-trip loop indexed
-  // e[a][j >> 4] dynamically and the tile went to scratch memory: 72 us per tile)
-#pragma unroll
-  for (int b0 = 0; b0 < 4; ++b0) {
-    for (int jx = 0; jx < 16; ++jx) {
-      const int j = 16 * b0 + jx, cur = j & 1;
-      if (tx == jx) {
-#pragma unroll
-        for (int a = 0; a < 4; ++a) col[cur][ty + 16 * a] = e[a][b0];
-      }
-      __syncthreads();
-      const double d = col[cur][j];
-      const double dd = d > 0.0 ? d : 1.0;
-      // (1 / sqrt and its product with d instead of sqrt and a division: half the length of
-      // the dependent chain every column waits for; L[j][j] = d / sqrt(d) to an ulp, and every
-      // entry of column j is scaled by the same number)
-      const double rs = rsqrt(dd), sq = dd * rs;
-      if (tid == 0) {
-        // bit 1: the pivot lost 43 bits against its diagonal entry (numerically rank deficient,
-        // the factorization goes on); bit 4: it is not positive (no factorization)
-        if (!(d > IPX_PIVOT_RTOL * diag0[j])) bits |= (d > 0.0) ? 1 : 5;
-        if (d > 0.0) ratio = fmin(ratio, d / diag0[j]);
-      }
-      double lr[4], lc[4];
-#pragma unroll
-      for (int a = 0; a < 4; ++a) lr[a] = col[cur][ty + 16 * a] * rs;
-#pragma unroll
-      for (int b = 0; b < 4; ++b) lc[b] = b >= b0 ? col[cur][tx + 16 * b] * rs : 0.0;
-#pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        const int r = ty + 16 * a;
-        {                                               // the group of column j itself
-          const int c = tx + 16 * b0;
-          if (c == j) e[a][b0] = r == j ? sq : lr[a];                // column j is final
-          else if (c > j && r >= c) e[a][b0] = __builtin_fma(-lr[a], lc[b0], e[a][b0]);
-        }
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          if (b > b0 && r >= tx + 16 * b) e[a][b] = __builtin_fma(-lr[a], lc[b], e[a][b]);
-        }
-      }
+    for (int u = 0; u < FB * FB / IPX_BLOCK; ++u) {
+      const int e = tid + u * IPX_BLOCK;
+      T[e >> 6][e & 63] = v[u];
     }
   }
+  if (tid < FB) diag0[tid] = work[kb * FB + tid];
+  __syncthreads();
+  int bits = 0;
+  double ratio = 1.0;
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int b = 0; b < FB / PB; ++b) {
+    const int c0 = PB * b;
+    if (tid < IPX_WAVE) {                             // (a) -- the whole first wave, lanes >= 16 idle along
+      const int r = tid & (PB - 1);
+      double x[PB];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const int r = ty + 16 * a, c = tx + 16 * b;
-      g[(int64_t)r * M + c] = (c <= r) ? e[a][b] : 0.0;
+      for (int c = 0; c < PB; ++c) x[c] = T[c0 + r][c0 + c];
+#pragma unroll
+      for (int j = 0; j < PB; ++j) {
+        const double d = lane_bcast(x[j], j);
+        if (tid == 0) {
+          // bit 1: the pivot lost 43 bits against its diagonal entry (numerically rank deficient,
+          // the factorization goes on); bit 4: it is not positive (no factorization)
+          const double d0 = diag0[c0 + j];
+          if (!(d > IPX_PIVOT_RTOL * d0)) bits |= (d > 0.0) ? 1 : 5;
+          if (d > 0.0) ratio = fmin(ratio, d / d0);
+        }
+        const double dd = d > 0.0 ? d : 1.0;
+        const double rs = potrf_rsqrt(dd);
+        const double l = x[j] * rs;                   // (lane j: d / sqrt(d) = L[j][j] to an ulp)
+        x[j] = l;
+        if (tid == j) rinv[c0 + j] = rs;
+#pragma unroll
+        for (int c = j + 1; c < PB; ++c) x[c] = __builtin_fma(-l, lane_bcast(l, c), x[c]);
+      }
+      if (tid < PB) {
+#pragma unroll
+        for (int c = 0; c < PB; ++c) T[c0 + r][c0 + c] = c <= r ? x[c] : 0.0;
+      }
     }
+    __syncthreads();
+    const int below = FB - c0 - PB;                   // rows under the block
+    if (tid < below) {                                // (b)
+      const int R = c0 + PB + tid;
+      double x[PB];
+#pragma unroll
+      for (int c = 0; c < PB; ++c) x[c] = T[R][c0 + c];
+#pragma unroll
+      for (int j = 0; j < PB; ++j) {
+        const double xj = x[j] * rinv[c0 + j];
+        x[j] = xj;
+#pragma unroll
+        for (int c = j + 1; c < PB; ++c) x[c] = __builtin_fma(-xj, T[c0 + c][c0 + j], x[c]);
+      }
+#pragma unroll
+      for (int c = 0; c < PB; ++c) T[R][c0 + c] = x[c];
+    }
+    __syncthreads();
+    for (int e = tid; e < below * below; e += IPX_BLOCK) {       // (c)
+      const int i = e / below, j = e - i * below;
+      if (j <= i) {
+        const int ri = c0 + PB + i, rj = c0 + PB + j;
+        double sum = 0.0;
+#pragma unroll
+        for (int k = 0; k < PB; ++k) sum = __builtin_fma(T[ri][c0 + k], T[rj][c0 + k], sum);
+        T[ri][rj] -= sum;
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int u = 0; u < FB * FB / IPX_BLOCK; ++u) {
+    const int e = tid + u * IPX_BLOCK, r = e >> 6, c = e & 63;
+    g[(int64_t)r * M + c] = (c <= r) ? T[r][c] : 0.0;
+  }
   if (tid == 0) {
     if (bits) atomicOr(flag, bits);
     work[M] = fmin(work[M], ratio);             // (one workgroup at a time: no race)
   }
 }
 
-// v of lane k of the quad, in every lane of the quad (k a constant after unrolling)
-__device__ __forceinline__ double quad_bcast(double v, int k) {
-  switch (k) {
-    case 0: return ipx_dpp<0x00>(v);
-    case 1: return ipx_dpp<0x55>(v);
-    case 2: return ipx_dpp<0xAA>(v);
-    default: return ipx_dpp<0xFF>(v);
-  }
-}
-
 // Panel below the diagonal tile: G_ik <- G_ik L_kk^-T for the tile rows i > kb, 64 rows per
-// workgroup, FOUR lanes per row: x_j = (a_j - sum_{t<j} x_t L[j][t]) / L[j][j] with the sum
-// dealt over the quad (lane q holds x_t for t = q mod 4, in registers: both loops fully
-// unrolled, static indices) and combined by two DPP quad permutes -- the dependent chain per
-// column is j / 4 multiply-adds instead of j (one lane per row: 22 us per tile column; the
-// first version, with the row in LDS, 80).  The reciprocals of the diagonal are formed once.
+// workgroup, both tiles in LDS, in four column blocks of 16: (1) what the earlier blocks
+// contribute, X[:, :c0] L[c0:c0+16, :c0]', as a small product over all 256 threads (four
+// outputs each); (2) the 16 x 16 triangular solve, a lane per row out of registers,
+// right-looking (one multiply + one multiply-add on the dependent chain per column).  The
+// first version walked all 64 columns with four lanes per row and a DPP combine per column:
+// 22 us per tile column of the panel.
 __global__ void __launch_bounds__(IPX_BLOCK)
 k_trsm64(double *G, int M, int kb) {
   __shared__ double Lk[FB][FB + 1];
@@ -496,40 +540,55 @@ k_trsm64(double *G, int M, int kb) {
   const int ib = kb + 1 + blockIdx.x;
   const double *lk = G + ((int64_t)kb * FB) * M + (int64_t)kb * FB;
   double *p = G + ((int64_t)ib * FB) * M + (int64_t)kb * FB;
-  for (int e = tid; e < FB * FB; e += IPX_BLOCK) {
-    const int r = e >> 6, c = e & 63;
-    Lk[r][c] = lk[(int64_t)r * M + c];
-    P[r][c] = p[(int64_t)r * M + c];
+  {
+    double va[FB * FB / IPX_BLOCK], vb[FB * FB / IPX_BLOCK];
+#pragma unroll
+    for (int u = 0; u < FB * FB / IPX_BLOCK; ++u) {
+      const int e = tid + u * IPX_BLOCK;
+      va[u] = lk[(int64_t)(e >> 6) * M + (e & 63)];
+      vb[u] = p[(int64_t)(e >> 6) * M + (e & 63)];
+    }
+#pragma unroll
+    for (int u = 0; u < FB * FB / IPX_BLOCK; ++u) {
+      const int e = tid + u * IPX_BLOCK;
+      Lk[e >> 6][e & 63] = va[u];
+      P[e >> 6][e & 63] = vb[u];
+    }
   }
   __syncthreads();
   if (tid < FB) rinv[tid] = 1.0 / Lk[tid][tid];
   const int row = tid >> 2, q = tid & 3;
-  double x[FB / 4];
 #pragma unroll
-  for (int u = 0; u < FB / 4; ++u) x[u] = P[row][4 * u + q];
-  __syncthreads();
+  for (int b = 0; b < FB / PB; ++b) {
+    const int c0 = PB * b;
+    if (b > 0) {                                      // (1) columns c0 + 4 q .. + 4 of this row
+      double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 8
+      for (int k = 0; k < c0; ++k) {
+        const double xv = P[row][k];
 #pragma unroll
-  for (int uj = 0; uj < FB / 4; ++uj) {
-#pragma unroll
-    for (int qj = 0; qj < 4; ++qj) {
-      const int j = 4 * uj + qj;
-      double s = 0.0;
-#pragma unroll
-      for (int u = 0; u < FB / 4; ++u) {
-        if (u < uj) s = __builtin_fma(x[u], Lk[j][4 * u + q], s);
+        for (int u = 0; u < 4; ++u) acc[u] = __builtin_fma(xv, Lk[c0 + 4 * q + u][k], acc[u]);
       }
-      if (q < qj) s = __builtin_fma(x[uj], Lk[j][4 * uj + q], s);
-      s = s + ipx_dpp<0xB1>(s);                     // quad: lanes 1 0 3 2
-      s = s + ipx_dpp<0x4E>(s);                     //       lanes 2 3 0 1 (same bits in all four)
-      // a_j sits in lane qj of the quad
-      const double aj = quad_bcast(x[uj], qj);
-      const double xj = (aj - s) * rinv[j];
-      if (q == qj) x[uj] = xj;
-    }
-  }
 #pragma unroll
-  for (int u = 0; u < FB / 4; ++u) P[row][4 * u + q] = x[u];
-  __syncthreads();
+      for (int u = 0; u < 4; ++u) P[row][c0 + 4 * q + u] -= acc[u];
+    }
+    __syncthreads();                                  // (also: rinv, first trip)
+    if (tid < FB) {                                   // (2) row tid
+      double x[PB];
+#pragma unroll
+      for (int c = 0; c < PB; ++c) x[c] = P[tid][c0 + c];
+#pragma unroll
+      for (int j = 0; j < PB; ++j) {
+        const double xj = x[j] * rinv[c0 + j];
+        x[j] = xj;
+#pragma unroll
+        for (int c = j + 1; c < PB; ++c) x[c] = __builtin_fma(-xj, Lk[c0 + c][c0 + j], x[c]);
+      }
+#pragma unroll
+      for (int c = 0; c < PB; ++c) P[tid][c0 + c] = x[c];
+    }
+    __syncthreads();
+  }
   for (int e = tid; e < FB * FB; e += IPX_BLOCK) {
     const int r = e >> 6, c = e & 63;
     p[(int64_t)r * M + c] = P[r][c];
