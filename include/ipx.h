@@ -51,6 +51,14 @@ int ipx_device_info(int *cu_count, int *lds_bytes, char *arch, int arch_len);
 /* Blocking read-back of k <= 512 doubles of device memory behind everything queued on `stream`
  * (pinned staging buffer inside the library; host_out: k doubles of the caller's). */
 int ipx_read_doubles(const double *dev, int k, double *host_out, void *stream);
+/* ... of nd <= IPX_FOLD_MAX scalars, each folded from a partial array (op: 0 sum, 1 max, 2 min) */
+#define IPX_FOLD_MAX 32
+typedef struct {
+  const double *part;
+  int32_t count;
+  int32_t op;
+} ipx_fold_desc;
+int ipx_read_folded(int nd, const ipx_fold_desc *descs, double *host_out, void *stream);
 
 /* ---- vectors (np elementwise algebra; qp_subproblem.py:212-216,312,580,622,628)
  * out = a*x + b*y (y may be NULL when b == 0); in-place allowed. */
@@ -100,6 +108,13 @@ int ipx_sum_log(int64_t n, const double *s, double *out, double *ws, void *strea
 int ipx_dot(int64_t n, const double *x, const double *y, double *out,
             double *ws, void *stream);
 int ipx_norms(int64_t n, const double *x, double *out, double *ws, void *stream);
+/* The first stage of ipx_dot / ipx_norms alone: ipx_reduce_grid(n) partials per quantity at
+ * part[q * grid + workgroup] (norms: q = 0 the sum of squares, q = 1 max |x|), for results only
+ * the host wants -- ipx_read_folded folds them inside the read-back, in the order of the
+ * second launch of ipx_dot / ipx_norms (same bits), so such a reduction is ONE launch. */
+int ipx_reduce_grid(int64_t n);
+int ipx_dot_partials(int64_t n, const double *x, const double *y, double *part, void *stream);
+int ipx_norms_partials(int64_t n, const double *x, double *part, void *stream);
 int ipx_box_inside(int64_t n, const double *x, const double *lb, const double *ub,
                    double *out, double *ws, void *stream);
 int ipx_box_sphere_reduce(int64_t n, const double *z, const double *d, double dscale,

@@ -31,6 +31,75 @@ void ipx_note_error(hipError_t e, const char *file, int line) {
   snprintf(g_last_error, sizeof(g_last_error), "%s (%s:%d)", hipGetErrorString(e), file, line);
 }
 
+// the calling thread's pinned granule buffer and the next tag
+static int read_begin(unsigned int **pinned_out, unsigned int *tag_out) {
+  static thread_local unsigned int *pinned = nullptr;      // [IPX_READ_MAX] granules of 4 words
+  static thread_local unsigned int seq = 0;
+  if (!pinned) {
+    if (hipHostMalloc((void **)&pinned, IPX_READ_MAX * 16, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+      pinned = nullptr;
+      return IPX_ENOMEM;
+    }
+    memset(pinned, 0, IPX_READ_MAX * 16);
+  }
+  if (++seq == 0) ++seq;                                   // (0: the buffer's initial tags)
+  *pinned_out = pinned;
+  *tag_out = seq;
+  return IPX_OK;
+}
+
+// poll the first k granules for `tag`, copy the values out
+static int read_wait(unsigned int *pinned, unsigned int seq, int k, double *host_out, hipStream_t st) {
+  volatile unsigned int *w = pinned;
+  const auto t0 = std::chrono::steady_clock::now();
+  unsigned spins = 0;
+  int done = 0;                                            // granules [0, done) have arrived
+  while (true) {
+    while (done < k && w[4 * done + 1] == seq && w[4 * done + 3] == seq) ++done;
+    if (done == k) break;
+    __builtin_ia32_pause();
+    if ((++spins & 0xfffu) == 0 &&
+        std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+      hipError_t e = hipStreamSynchronize(st);
+      if (e != hipSuccess) { ipx_note_error(e, __FILE__, __LINE__); return IPX_ELAUNCH; }
+      for (done = 0; done < k && w[4 * done + 1] == seq && w[4 * done + 3] == seq; ++done) {}
+      if (done != k) return IPX_ELAUNCH;
+      break;
+    }
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  for (int i = 0; i < k; ++i) {
+    const unsigned long long bits = (unsigned long long)w[4 * i] | ((unsigned long long)w[4 * i + 2] << 32);
+    memcpy(host_out + i, &bits, sizeof(double));
+  }
+  return IPX_OK;
+}
+
+// ipx_read_folded: scalar q = the fold of descs.d[q].count partials (ipx_sum_partials: the
+// order of the reductions' own second stage, same bits), published like k_publish's
+struct FoldDescs { ipx_fold_desc d[IPX_FOLD_MAX]; };
+__global__ void __launch_bounds__(IPX_BLOCK)
+k_publish_folded(FoldDescs descs, int nd, ipx_u4 *dst, unsigned int tag) {
+  __shared__ double lds[IPX_BLOCK / IPX_WAVE];
+  for (int q = 0; q < nd; ++q) {
+    const double *part = descs.d[q].part;
+    const int count = descs.d[q].count, op = descs.d[q].op;
+    double r;
+    if (op == IPX_MAX) r = ipx_sum_partials<IPX_MAX>(part, count, lds);
+    else if (op == IPX_MIN) r = ipx_sum_partials<IPX_MIN>(part, count, lds);
+    else r = ipx_sum_partials<IPX_SUM>(part, count, lds);
+    if (threadIdx.x == 0) {
+      const unsigned long long bits = (unsigned long long)__double_as_longlong(r);
+      ipx_u4 w;
+      w.x = (unsigned)(bits & 0xffffffffull); w.y = tag;
+      w.z = (unsigned)(bits >> 32);           w.w = tag;
+      ipx_u4 *d = dst + q;
+      asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(d), "v"(w) : "memory");
+    }
+    __syncthreads();                                  // (lds is reused by the next fold)
+  }
+}
+
 extern "C" {
 
 const char *ipx_version(void) { return "ipx 0.1 (gfx950)"; }
@@ -59,44 +128,38 @@ int ipx_device_info(int *cu_count, int *lds_bytes, char *arch, int arch_len) {
 // the outer loops' scalar reads are the host's largest single item of a solve).  A read that
 // has not arrived after 2 s falls back to hipStreamSynchronize (and reports its error).
 int ipx_read_doubles(const double *dev, int k, double *host_out, void *stream) {
-  static thread_local unsigned int *pinned = nullptr;      // [IPX_READ_MAX] granules of 4 words
-  static thread_local unsigned int seq = 0;
   if (!dev || !host_out || k < 0 || k > IPX_READ_MAX) return IPX_EINVAL;
   if (k == 0) return IPX_OK;
-  if (!pinned) {
-    if (hipHostMalloc((void **)&pinned, IPX_READ_MAX * 16, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
-      pinned = nullptr;
-      return IPX_ENOMEM;
-    }
-    memset(pinned, 0, IPX_READ_MAX * 16);
-  }
-  hipStream_t st = (hipStream_t)stream;
-  if (++seq == 0) ++seq;                                   // (0: the buffer's initial tags)
-  hipLaunchKernelGGL(k_publish, dim3(1), dim3(IPX_READ_MAX), 0, st, dev, k, (ipx_u4 *)pinned, seq);
+  unsigned int *pinned; unsigned int tag;
+  int rc = read_begin(&pinned, &tag);
+  if (rc != IPX_OK) return rc;
+  hipLaunchKernelGGL(k_publish, dim3(1), dim3(IPX_READ_MAX), 0, (hipStream_t)stream, dev, k,
+                     (ipx_u4 *)pinned, tag);
   if (hipGetLastError() != hipSuccess) return IPX_ELAUNCH;
-  volatile unsigned int *w = pinned;
-  const auto t0 = std::chrono::steady_clock::now();
-  unsigned spins = 0;
-  int done = 0;                                            // granules [0, done) have arrived
-  while (true) {
-    while (done < k && w[4 * done + 1] == seq && w[4 * done + 3] == seq) ++done;
-    if (done == k) break;
-    __builtin_ia32_pause();
-    if ((++spins & 0xfffu) == 0 &&
-        std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
-      hipError_t e = hipStreamSynchronize(st);
-      if (e != hipSuccess) { ipx_note_error(e, __FILE__, __LINE__); return IPX_ELAUNCH; }
-      for (done = 0; done < k && w[4 * done + 1] == seq && w[4 * done + 3] == seq; ++done) {}
-      if (done != k) return IPX_ELAUNCH;
-      break;
-    }
+  return read_wait(pinned, tag, k, host_out, (hipStream_t)stream);
+}
+
+// Blocking read-back of nd <= IPX_FOLD_MAX scalars, each the fold of a partial array a
+// reduction's first stage left (ipx_dot_partials / ipx_norms_partials; op: IPX_SUM 0, IPX_MAX 1,
+// IPX_MIN 2 -- the numbering of csrc/ipx_common.h): the fold runs in the read's own publish
+// kernel, in the order of ipx_dot / ipx_norms' second launch (same bits) -- one launch less per
+// reduction whose result only the host wants.
+int ipx_read_folded(int nd, const ipx_fold_desc *descs, double *host_out, void *stream) {
+  if (!descs || !host_out || nd < 0 || nd > IPX_FOLD_MAX) return IPX_EINVAL;
+  if (nd == 0) return IPX_OK;
+  FoldDescs D;
+  for (int q = 0; q < nd; ++q) {
+    if (!descs[q].part || descs[q].count < 1) return IPX_EINVAL;
+    D.d[q] = descs[q];
   }
-  std::atomic_thread_fence(std::memory_order_acquire);
-  for (int i = 0; i < k; ++i) {
-    const unsigned long long bits = (unsigned long long)w[4 * i] | ((unsigned long long)w[4 * i + 2] << 32);
-    memcpy(host_out + i, &bits, sizeof(double));
-  }
-  return IPX_OK;
+  for (int q = nd; q < IPX_FOLD_MAX; ++q) D.d[q] = descs[0];
+  unsigned int *pinned; unsigned int tag;
+  int rc = read_begin(&pinned, &tag);
+  if (rc != IPX_OK) return rc;
+  hipLaunchKernelGGL(k_publish_folded, dim3(1), dim3(IPX_BLOCK), 0, (hipStream_t)stream, D, nd,
+                     (ipx_u4 *)pinned, tag);
+  if (hipGetLastError() != hipSuccess) return IPX_ELAUNCH;
+  return read_wait(pinned, tag, nd, host_out, (hipStream_t)stream);
 }
 
 }  // extern "C"

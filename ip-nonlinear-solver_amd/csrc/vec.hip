@@ -226,9 +226,33 @@ int launch_reduce(int64_t n, R r, double *out, double *ws, void *stream) {
   return IPX_OK;
 }
 
+// the first stage alone: `grid` partials per quantity at part[q * grid + block] (the fold is
+// left to the read-back: ipx_read_folded)
+template <typename R>
+int launch_reduce_partials(int64_t n, R r, double *part, void *stream) {
+  if (!part) return IPX_EINVAL;
+  const int grid = ipx_grid_for(n, IPX_BLOCK * 4);
+  hipLaunchKernelGGL(k_reduce1<R>, dim3(grid), dim3(IPX_BLOCK), 0, (hipStream_t)stream, n, r, part);
+  IPX_CHECK_LAUNCH();
+  return IPX_OK;
+}
+
 }  // namespace
 
 extern "C" {
+
+// ipx_dot / ipx_norms without their second launch: the partial sums of the first stage, one per
+// workgroup and quantity (ipx_reduce_grid(n) workgroups; norms: sum of squares, then max |x|),
+// for a caller that folds them where it reads them (ipx_read_folded: the same fixed order).
+int ipx_reduce_grid(int64_t n) { return ipx_grid_for(n, IPX_BLOCK * 4); }
+int ipx_dot_partials(int64_t n, const double *x, const double *y, double *part, void *stream) {
+  if (n <= 0 || !x || !y) return IPX_EINVAL;
+  return launch_reduce_partials(n, RedDot{x, y}, part, stream);
+}
+int ipx_norms_partials(int64_t n, const double *x, double *part, void *stream) {
+  if (n <= 0 || !x) return IPX_EINVAL;
+  return launch_reduce_partials(n, RedNorms{x}, part, stream);
+}
 
 int ipx_axpby(int64_t n, double a, const double *x, double b, const double *y,
               double *out, void *stream) {

@@ -9,6 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libipx.so")
 
 WS_DOUBLES = 65536          # IPX_WS_DOUBLES
+VEC_GRID_CAP = 1024         # IPX_VEC_GRID_CAP (tests/test_abi.py checks it against ipx_reduce_grid)
 SPMV_TILE_NNZ = 2048        # IPX_SPMV_TILE_NNZ
 
 _c = ctypes
@@ -18,6 +19,10 @@ _P, _I64, _I32, _F64 = _c.c_void_p, _c.c_int64, _c.c_int32, _c.c_double
 _SIGNATURES = {
     "ipx_device_info": [_c.POINTER(_c.c_int), _c.POINTER(_c.c_int), _c.c_char_p, _c.c_int],
     "ipx_read_doubles": [_P, _c.c_int, _P, _P],
+    "ipx_read_folded": [_c.c_int, _P, _P, _P],
+    "ipx_reduce_grid": [_I64],
+    "ipx_dot_partials": [_I64, _P, _P, _P, _P],
+    "ipx_norms_partials": [_I64, _P, _P, _P],
     "ipx_axpby": [_I64, _F64, _P, _F64, _P, _P, _P],
     "ipx_mul": [_I64, _P, _P, _P, _P],
     "ipx_fill": [_I64, _F64, _P, _P],

@@ -27,6 +27,9 @@ def _require_gpu():
 
 PACK_SLOTS = 128
 PACK_BASE = 32        # the pack's slots start here: [0, 32) serve the one-off reductions
+PARTS_ARENA = 1 << 18   # doubles: 64 pending reductions of two quantities at the largest grid
+FOLD_MAX = 32           # include/ipx.h IPX_FOLD_MAX
+SUM, MAX, MIN = 0, 1, 2
 
 
 class _Context:
@@ -40,6 +43,20 @@ class _Context:
         self.ws = torch.empty(_hip.WS_DOUBLES, dtype=_F64, device=self.device)
         self.out = torch.zeros(PACK_BASE + PACK_SLOTS, dtype=_F64, device=self.device)
         self.open_pack = None          # the ScalarPack with enqueued, unread slots (one at a time)
+        # partial sums of reductions whose results only the host wants (dot / norms): their
+        # second stage runs inside the read-back (``read_folded``); a bump arena, emptied by
+        # the read that ends a decision point
+        self.parts = torch.empty(PARTS_ARENA, dtype=_F64, device=self.device)
+        self.parts_used = 0
+
+    def partials(self, doubles):
+        """Offset of ``doubles`` free entries of the partial arena, or None when it is full
+        (the caller then takes the two-launch reduction)."""
+        off = self.parts_used
+        if off + doubles > PARTS_ARENA:
+            return None
+        self.parts_used = off + doubles
+        return off
 
     @classmethod
     def get(cls):
@@ -98,6 +115,36 @@ def read_doubles(t, k, offset=0):
         return t[offset:offset + k].tolist()
     _hip.call("ipx_read_doubles", t.data_ptr() + 8 * offset, int(k), _READ_PTR, stream_ptr())
     return _READ_BUF[:k]
+
+
+class _FoldDesc(ctypes.Structure):
+    _fields_ = [("part", ctypes.c_void_p), ("count", ctypes.c_int32), ("op", ctypes.c_int32)]
+
+
+_FOLD_BUF = (_FoldDesc * FOLD_MAX)()
+_FOLD_PTR = ctypes.addressof(_FOLD_BUF)
+
+
+def read_folded(descs):
+    """Blocking read of scalars that are still partial sums on the device: ``descs`` = (offset
+    into the context's partial arena, count, SUM / MAX / MIN) per scalar; the fold runs inside
+    the read-back's kernel in the order of the reductions' own second launch (same bits)."""
+    c = ctx()
+    base = c.parts.data_ptr()
+    out = []
+    for i in range(0, len(descs), FOLD_MAX):
+        chunk = descs[i:i + FOLD_MAX]
+        for q, (off, count, op) in enumerate(chunk):
+            d = _FOLD_BUF[q]
+            d.part, d.count, d.op = base + 8 * off, count, op
+        _hip.call("ipx_read_folded", len(chunk), _FOLD_PTR, _READ_PTR, stream_ptr())
+        out.extend(_READ_BUF[:len(chunk)])
+    return out
+
+
+def _reduce_grid(n):
+    g = (n + 1023) // 1024            # csrc/vec.hip launch_reduce: ipx_grid_for(n, 4 * 256)
+    return 1 if g < 1 else (_hip.VEC_GRID_CAP if g > _hip.VEC_GRID_CAP else g)
 
 
 def _read(k):
@@ -211,13 +258,32 @@ class DVec:
 
     def dot(self, o):
         c = ctx()
-        _hip.call("ipx_dot", len(self), _p(self.t), _p(o.t), _p(c.out), _p(c.ws), stream_ptr())
-        return _read(1)[0]
+        n = len(self)
+        g = _reduce_grid(n)
+        off = c.partials(g) if n > 0 else None
+        if off is None:
+            _hip.call("ipx_dot", n, _p(self.t), _p(o.t), _p(c.out), _p(c.ws), stream_ptr())
+            return _read(1)[0]
+        _hip.call("ipx_dot_partials", n, _p(self.t), _p(o.t), c.parts.data_ptr() + 8 * off,
+                  stream_ptr())
+        val = read_folded([(off, g, SUM)])[0]
+        if c.open_pack is None or c.open_pack() is None:
+            c.parts_used = 0
+        return val
 
     def sumsq_amax(self):
         c = ctx()
-        _hip.call("ipx_norms", len(self), _p(self.t), _p(c.out), _p(c.ws), stream_ptr())
-        return _read(2)
+        n = len(self)
+        g = _reduce_grid(n)
+        off = c.partials(2 * g) if n > 0 else None
+        if off is None:
+            _hip.call("ipx_norms", n, _p(self.t), _p(c.out), _p(c.ws), stream_ptr())
+            return _read(2)
+        _hip.call("ipx_norms_partials", n, _p(self.t), c.parts.data_ptr() + 8 * off, stream_ptr())
+        vals = read_folded([(off, g, SUM), (off + g, g, MAX)])
+        if c.open_pack is None or c.open_pack() is None:
+            c.parts_used = 0
+        return vals
 
 
 class ScalarPack:
@@ -230,7 +296,16 @@ class ScalarPack:
     def __init__(self):
         self.c = ctx()
         self.k = 0
-        self.how = []          # per handle: (slot or None, post-processing)
+        self.how = []          # per handle: (slot | ("fold", index into folds) | None, post-processing)
+        self.folds = []        # (offset, count, op) in the context's partial arena
+
+    def _claim(self):
+        # (as for the slots: two packs with unread partials at the same time are refused --
+        # the read that ends one empties the arena)
+        other = self.c.open_pack() if self.c.open_pack is not None else None
+        if other is not None and other is not self:
+            raise _hip.IpxError("ScalarPack: another pack has unread slots")
+        self.c.open_pack = weakref.ref(self)
 
     def _slot(self, n):
         # the pack's slots are a region of their own ([PACK_BASE, ...)): a one-off reduction
@@ -249,6 +324,15 @@ class ScalarPack:
     def dot(self, a, b):
         if len(a) == 0:
             self.how.append((None, None))
+            return len(self.how) - 1
+        g = _reduce_grid(len(a))
+        off = self.c.partials(g)
+        if off is not None:                 # (one launch: the fold rides in the read-back)
+            self._claim()
+            _hip.call("ipx_dot_partials", len(a), _p(a.t), _p(b.t),
+                      self.c.parts.data_ptr() + 8 * off, stream_ptr())
+            self.how.append((("fold", len(self.folds)), None))
+            self.folds.append((off, g, SUM))
         else:
             ptr, base = self._slot(1)
             _hip.call("ipx_dot", len(a), _p(a.t), _p(b.t), ptr, _p(self.c.ws), stream_ptr())
@@ -258,6 +342,15 @@ class ScalarPack:
     def _norms(self, v, which):
         if len(v) == 0:
             self.how.append((None, None))
+            return len(self.how) - 1
+        g = _reduce_grid(len(v))
+        off = self.c.partials(2 * g)
+        if off is not None:
+            self._claim()
+            _hip.call("ipx_norms_partials", len(v), _p(v.t), self.c.parts.data_ptr() + 8 * off,
+                      stream_ptr())
+            self.how.append((("fold", len(self.folds)), "sqrt" if which == 0 else None))
+            self.folds.append((off, g, SUM) if which == 0 else (off + g, g, MAX))
         else:
             ptr, base = self._slot(2)
             _hip.call("ipx_norms", len(v), _p(v.t), ptr, _p(self.c.ws), stream_ptr())
@@ -277,11 +370,18 @@ class ScalarPack:
 
     def read(self):
         vals = read_doubles(self.c.out, self.k, PACK_BASE)
+        folded = read_folded(self.folds) if self.folds else []
         if self.c.open_pack is not None and self.c.open_pack() is self:
             self.c.open_pack = None
+            self.c.parts_used = 0
         out = []
         for slot, post in self.how:
-            v = 0.0 if slot is None else vals[slot]
+            if slot is None:
+                v = 0.0
+            elif isinstance(slot, tuple):
+                v = folded[slot[1]]
+            else:
+                v = vals[slot]
             out.append(float(np.sqrt(v)) if post == "sqrt" else v)
         return out
 

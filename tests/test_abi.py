@@ -85,3 +85,32 @@ def test_header_is_plain_c_and_structs_match_the_bindings(tmp_path):
     assert got == [ctypes.sizeof(CgArgs), ctypes.sizeof(BoxSchurArgs), ctypes.sizeof(Shard2Ext),
                    CgArgs.state.offset, Shard2Ext.own_hi.offset, ctypes.sizeof(PcgArgs),
                    Shard2Ext.peer.offset, CgArgs.no_radius.offset]
+
+
+def test_reduction_grid_and_fold_descriptor_match_the_library():
+    """The host computes the number of partials a one-launch reduction leaves (device.py
+    _reduce_grid) and mirrors ipx_fold_desc: both must agree with the library / the header."""
+    import shutil
+    import subprocess
+    import tempfile
+    from ipsolver import _hip, device
+    lib = _hip.load()
+    for n in (1, 1023, 1024, 1025, 123456, 10 ** 6, 10 ** 6 + 1, 16 * 10 ** 6, 10 ** 9):
+        assert int(lib.ipx_reduce_grid(n)) == device._reduce_grid(n), n
+    assert int(lib.ipx_reduce_grid(10 ** 12)) == _hip.VEC_GRID_CAP
+    if shutil.which("gcc") is None:
+        return
+    with tempfile.TemporaryDirectory() as tmp:
+        src = os.path.join(tmp, "fd.c")
+        with open(src, "w") as f:
+            f.write('#include <stdio.h>\n#include <stddef.h>\n#include "ipx.h"\n'
+                    'int main(void) { printf("%zu %zu %zu %d\\n", sizeof(ipx_fold_desc), '
+                    'offsetof(ipx_fold_desc, count), offsetof(ipx_fold_desc, op), IPX_FOLD_MAX); '
+                    'return 0; }\n')
+        exe = os.path.join(tmp, "fd")
+        subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                        src, "-o", exe], check=True)
+        got = [int(v) for v in subprocess.run([exe], check=True, capture_output=True,
+                                              text=True).stdout.split()]
+    D = device._FoldDesc
+    assert got == [ctypes.sizeof(D), D.count.offset, D.op.offset, device.FOLD_MAX]
