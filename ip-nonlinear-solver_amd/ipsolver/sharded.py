@@ -768,7 +768,25 @@ class FusedShardedCG:
         cache = sh.__dict__.setdefault("_fuse_comm_agreed", {})
         if key not in cache:
             mine = asked and int(self.lib.ipx_cg_shard2_fusable(self.L.ref(), ctypes.byref(self.ext)))
-            cache[key] = int(sh.comm.reduce_floats([float(mine)], op="min")[0])
+            # every workgroup of the prologue kernels spins until its peers' words arrive.  Ranks
+            # on their own GPUs cannot be in each other's way; ranks that SHARE a device (the
+            # one-GPU rehearsals) can: the workgroups of one rank's next kernel take the slots
+            # the other rank's last workgroups are waiting for and never give them back --
+            # measured on config 5 at full size, two ranks on one MI355X: ~890 row tiles of H per
+            # rank deadlock after a few hundred iterations (10 s timeout, fall-back), ~620 run
+            # 50 000 iterations.  So a group that shares a device takes the pack kernels (small
+            # grids) when its row tiles together exceed five per compute unit.
+            cus = ctypes.c_int(0)
+            self._hip.call("ipx_device_info", ctypes.byref(cus), None, None, 0)
+            info = [None] * sh.comm.world
+            dist.all_gather_object(info, (int(mine), _device_id(), int(Hc.pattern.ntiles),
+                                          int(cus.value)), group=sh.comm.group)
+            ok = all(i[0] for i in info)
+            for dev in {i[1] for i in info}:
+                on = [i for i in info if i[1] == dev]
+                if len(on) > 1:
+                    ok = ok and sum(i[2] for i in on) <= 5 * min(i[3] for i in on)
+            cache[key] = int(ok)
             # (the patterns are kept alive with the decision: their ids stay theirs)
             cache[key, "keep"] = (Hc.pattern, A_loc.pattern)
         return cache[key]
