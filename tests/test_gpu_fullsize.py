@@ -417,3 +417,72 @@ def test_config5_full_size_properties():
             assert abs(got - record_levels[mu]) <= 0.10 * max(record_levels[mu], 200), (mu, got)
     assert abs(active - 142928) <= 0.015 * 142928
     assert abs(res.niter - 82) <= 9
+
+
+def _config5_sharded_worker(rank, world, port, out_path):
+    import json
+    import os
+    import sys
+    import time
+    import warnings
+    import torch
+    import torch.distributed as dist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "ip-nonlinear-solver_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ipsolver import sharded
+        from ipsolver.synthetic import CenteredBandedNLP, ShardedCallbacks
+        warnings.simplefilter("ignore")
+        n, m = 500000, 50000
+        prob = CenteredBandedNLP(n, m, eps=1.0)
+        A = prob.A0.tocsr()
+        lay = sharded.ShardLayout(A.indptr, A.indices, A.shape, world, rank)
+        sh = sharded.Sharding(lay, sharded.ShardComm(), sharded.HipOps())
+        cb = ShardedCallbacks(prob, sh)
+        t0 = time.time()
+        res = sharded.minimize_box_inequality(sh, cb.fun, cb.grad, cb.lagr_hess, cb.constr_fun,
+                                              cb.constr_jac, cb.x0, sh.full("col", -0.8),
+                                              sh.full("col", 0.8))
+        torch.cuda.synchronize()
+        x = res.x.to_host()
+        if rank == 0:
+            with open(out_path, "w") as f:
+                json.dump({"status": int(res.status), "niter": int(res.niter),
+                           "cg_niter": int(res.cg_niter), "wall_s": time.time() - t0,
+                           "fun": float(res.fun), "constr_violation": float(res.constr_violation),
+                           "active": int(np.sum(np.abs(np.abs(x) - 0.8) < 1e-6)),
+                           "transport": sh.transport,
+                           "ipc_iterations": int(sh.comm.stats["ipc_iterations"])}, f)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_config5_full_size_two_ranks_sharing_the_gpu(tmp_path):
+    """BASELINE config 5 at full size on the row-sharded backend, two processes on the one GPU:
+    ends like the single-GPU run (objective, active set) and STAYS on the peer-mailbox
+    transport.  (The collectives in the prologues of the loop's own kernels make every
+    workgroup spin for its peer; at this size two ranks sharing a device starved each other of
+    workgroup slots after a few hundred iterations -- a 10 s timeout and 4 minutes over gloo --
+    until the group learned to take the pack kernels when it shares a device:
+    ipsolver/sharded.py _agree_on_fused_comm.)"""
+    import json
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    path = str(tmp_path / "c5s.json")
+    mp.spawn(_config5_sharded_worker, args=(2, port, path), nprocs=2, join=True)
+    got = json.load(open(path))
+    print("config 5 on 2 ranks sharing the GPU:", got)
+    assert got["status"] == 1 and got["constr_violation"] <= 1e-8
+    assert got["transport"] == "ipc" and got["ipc_iterations"] >= 0.9 * got["cg_niter"]
+    assert abs(got["fun"] - (-75229.73145)) <= 1e-3
+    assert abs(got["active"] - 141840) <= 0.015 * 141840
+    assert 60 <= got["niter"] <= 95 and 3.0e4 <= got["cg_niter"] <= 1.2e5
+    assert got["wall_s"] < 60.0
