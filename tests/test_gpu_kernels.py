@@ -256,3 +256,84 @@ def test_dense_cholesky_and_inverse_on_the_matrix_cores(m):
     tail = np.eye(M)
     tail[:m, :m] = X_h[:m, :m]
     assert np.allclose(X_h, tail, rtol=0, atol=1e-300)          # identity in the padding
+
+
+def test_read_back_entries(dv):
+    """ipx_read_doubles / ipx_read_folded (the blocking reads of the outer loops): the values of
+    the device array, bit for bit, for every count the entry accepts; folded reads equal the
+    two-launch reductions bit for bit (same fold order) for sums, maxima and minima."""
+    import ctypes
+    import torch
+    from ipsolver import _hip
+    lib = _hip.load()
+    rng = np.random.default_rng(5)
+    for k in (1, 2, 15, 16, 17, 511, 512):
+        a = rng.standard_normal(600)
+        t = torch.from_numpy(a).cuda()
+        assert dv.read_doubles(t, k) == list(a[:k])
+        assert dv.read_doubles(t, k, 37) == list(a[37:37 + k])
+    assert dv.read_doubles(torch.zeros(4, dtype=torch.float64, device="cuda"), 0) == []
+    buf = (ctypes.c_double * 600)()
+    assert lib.ipx_read_doubles(t.data_ptr(), 513, buf, dv.stream_ptr()) != 0      # over the limit
+    # (many reads in a row: every one sees ITS values -- the tags of the pinned granules)
+    for rep in range(200):
+        t.fill_(float(rep))
+        assert dv.read_doubles(t, 3) == [float(rep)] * 3
+    # folded reads against the two-launch forms
+    for n in (1, 1000, 1023, 1025, 300001, 1 << 20):
+        x, y = rng.standard_normal(n), rng.standard_normal(n)
+        X, Y = dv.DVec.from_host(x), dv.DVec.from_host(y)
+        c = dv.ctx()
+        _hip.call("ipx_dot", n, dv._p(X.t), dv._p(Y.t), dv._p(c.out), dv._p(c.ws), dv.stream_ptr())
+        two = dv.read_doubles(c.out, 1)[0]
+        assert X.dot(Y) == two                                   # (DVec.dot: the folded form)
+        _hip.call("ipx_norms", n, dv._p(X.t), dv._p(c.out), dv._p(c.ws), dv.stream_ptr())
+        two = dv.read_doubles(c.out, 2)
+        assert X.sumsq_amax() == two and two[1] == np.abs(x).max()
+        g = dv._reduce_grid(n)
+        assert g == int(lib.ipx_reduce_grid(n))
+    # minimum / maximum folds of an arbitrary partial array
+    p = rng.standard_normal(777)
+    c = dv.ctx()
+    off = c.partials(777)
+    c.parts[off:off + 777] = torch.from_numpy(p).cuda()
+    got = dv.read_folded([(off, 777, dv.MAX), (off, 777, dv.MIN), (off, 5, dv.SUM)])
+    c.parts_used = 0
+    assert got[0] == p.max() and got[1] == p.min() and abs(got[2] - p[:5].sum()) <= 1e-15 * 5
+
+
+def test_aat_band_staged_and_long_rows(dv):
+    """S = A A' in band storage (ipx_aat_band): the workgroup-staged join of short rows, rows
+    too long for the staging buffer (the same launch joins them out of global memory), a column
+    weighting, rows given in another order -- all against scipy, entry by entry."""
+    import torch
+    from ipsolver import _hip
+    rng = np.random.default_rng(9)
+    for m, width, k in ((1000, 7, 1), (700, 40, 3), (513, 3, 2), (300, 64, 2)):
+        n = m * 3 + width
+        rows = []
+        for i in range(m):
+            cols = np.sort(rng.choice(np.arange(3 * i, 3 * i + width + 3 * k), size=width,
+                                      replace=False))
+            cols = cols[cols < n]
+            rows.append(cols)
+        indptr = np.concatenate(([0], np.cumsum([len(r) for r in rows]))).astype(np.int32)
+        indices = np.concatenate(rows).astype(np.int32)
+        data = rng.standard_normal(len(indices))
+        A = sps.csr_matrix((data, indices, indptr), shape=(m, n))
+        w = rng.uniform(0.5, 2.0, n)
+        for weights, perm in ((None, None), (w, None), (None, rng.permutation(m).astype(np.int32))):
+            B = A if perm is None else A[perm]
+            S = (B.multiply(w) if weights is not None else B).dot(B.T).toarray()
+            kk = min(max(int(np.max(np.abs(np.subtract(*np.nonzero(S))))), 1), 8)
+            band = torch.empty((kk + 1) * m, dtype=torch.float64, device="cuda")
+            T = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).cuda()
+            ip_d, ix_d, v_d = T(indptr, np.int32), T(indices, np.int32), T(data, np.float64)
+            pd = T(perm, np.int32) if perm is not None else None
+            wd = T(w, np.float64) if weights is not None else None
+            _hip.call("ipx_aat_band_w", m, kk, dv._p(ip_d), dv._p(ix_d), dv._p(v_d), dv._p(pd),
+                      dv._p(wd), dv._p(band), dv.stream_ptr())
+            got = band.cpu().numpy().reshape(kk + 1, m)
+            for d in range(kk + 1):
+                want = np.concatenate((np.zeros(d), np.diagonal(S, -d)))
+                assert np.allclose(got[d], want, rtol=1e-13, atol=1e-13), (m, width, d)
