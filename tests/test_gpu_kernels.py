@@ -292,6 +292,17 @@ def test_read_back_entries(dv):
         assert X.sumsq_amax() == two and two[1] == np.abs(x).max()
         g = dv._reduce_grid(n)
         assert g == int(lib.ipx_reduce_grid(n))
+    # a full arena: the reductions take their two-launch forms, same values
+    x, y = rng.standard_normal(4000), rng.standard_normal(4000)
+    X, Y = dv.DVec.from_host(x), dv.DVec.from_host(y)
+    want = (X.dot(Y), X.sumsq_amax())
+    c = dv.ctx()
+    c.parts_used = dv.PARTS_ARENA
+    pk = dv.ScalarPack()
+    h = [pk.dot(X, Y), pk.sumsq(X), pk.norm_inf(X)]
+    assert (X.dot(Y), X.sumsq_amax()) == want
+    vals = pk.read()
+    assert [vals[k] for k in h] == [want[0], want[1][0], want[1][1]] and c.parts_used == 0
     # minimum / maximum folds of an arbitrary partial array
     p = rng.standard_normal(777)
     c = dv.ctx()
