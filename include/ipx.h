@@ -585,6 +585,68 @@ int ipx_boxschur_project(const ipx_boxschur_args *a, const double *r, double *g,
                          int32_t *npart_g, double *part_res, int32_t *npart_res,
                          const double *guard, void *stream);
 
+/* Deferred form of ipx_banded_status (no blocking read): the verdict of the previous, clean
+ * factorization on this handle is ASSUMED for the one just enqueued; a one-thread kernel writes
+ * verdict[0] = 0 when the flags agree, else 1 (then: ipx_banded_status, and repeat the solves).
+ * IPX_EUNSUPPORTED: nothing to assume on this handle. */
+int ipx_banded_status_deferred(void *handle, double *verdict, void *stream);
+
+/* ---- one outer iteration of the trust-region SQP method as three chains of launches whose
+ * decisions are taken on the device (csrc/sqp.hip; reference equality_constrained_sqp.py:102-250,
+ * the Newton point of modified_dogleg qp_subproblem.py:366-373, projected_cg :416-643).
+ * Every chain ends in a one-workgroup kernel that writes the scalar block q (ipx_sqp_block_size()
+ * doubles, layout in csrc/sqp.hip SQ_*, mirrored by ipsolver/sqp_chain.py); the host reads the
+ * block once per chain.  CSR Jacobian and Hessian, banded or box-Schur solver (solver_kind 0 / 1
+ * of the CG loop's argument block), constraint rows in the projector's own order. */
+typedef struct ipx_sqp_args {
+  int64_t n, m;
+  const ipx_cg_args *cg;            /* the CG loop's block: A, A', H, the solver, its buffers;
+                                     * cg->lb / cg->ub must be lbt / ubt below (or NULL) */
+  const int32_t *A_tiles;           /* standard SpMV row tiles of A */
+  int64_t A_ntiles;
+  double *q;                        /* the block */
+  const double *x, *c, *b;          /* iterate (n), gradient (n), constraint value (m) */
+  const double *lb, *ub;            /* trust_lb / trust_ub of the step (n) or NULL */
+  const double *scale;              /* diagonal of S (n) or NULL */
+  double *dn, *ct, *lbt, *ubt, *d, *Hd, *x_next;   /* n each (lbt / ubt NULL with lb / ub) */
+  double *Ad;                       /* m */
+  double *v_out;                    /* m: the multipliers ipx_sqp_refresh writes */
+  double *part;                     /* ipx_sqp_part_doubles() doubles of partial sums */
+  double *red, *ws;                 /* 16 doubles / IPX_WS_DOUBLES of scratch (ipx_cg_prime) */
+  double orth_tol, cancellation;    /* of the projections (ipx_cg_prime) */
+  const double *verdict;            /* device: ipx_banded_status_deferred's word, or NULL */
+  const double *A_norm_part;        /* ipx_norms_partials over A's values (ipx_sqp_refresh folds
+                                     * them into the block's ||A||_F^2), or NULL */
+  int64_t A_norm_grid;
+} ipx_sqp_args;
+int ipx_sqp_block_size(void);
+int64_t ipx_sqp_part_doubles(const ipx_sqp_args *s);
+/* normal step (have_dn == 0: the Newton point, accepted on the device -- block entry
+ * NORMAL_KIND 1 -- or not, 0: the caller computes the dogleg step into s->dn and calls again with
+ * have_dn = 1), c_t = H dn + c, shifted bounds, the projected CG's priming with the tangential
+ * radius of the block and iterations [0, first_end), then ipx_sqp_model. */
+int ipx_sqp_front(const ipx_sqp_args *s, int have_dn, double radius, double penalty, double f,
+                  double norm_b, double tr_factor, double box_factor, double tol_in,
+                  double norm_A, int32_t first_end, void *stream);
+/* the CG loop's trust-region / negative-curvature exits (:565-576, :585-596), d = dn + dt,
+ * x_next = x + S d, the five sums and the model / penalty / predicted reduction (:135-153);
+ * host_cg != 0: the caller finished the CG loop itself (exits included), dt = cg->x as it is */
+int ipx_sqp_model(const ipx_sqp_args *s, double penalty, double f, double norm_b, int host_cg,
+                  void *stream);
+/* ||b_next||, actual / predicted, second-order-correction test, trust-radius ladder, accept
+ * (:156-242); f_next by value or, f_next_dev non-NULL, a device scalar */
+int ipx_sqp_judge(const ipx_sqp_args *s, const double *b_next, double f_next,
+                  const double *f_next_dev, void *stream);
+/* v = -(A A')^-1 A c, ||c + A'v||_inf, ||b||_inf, ||b|| (:83-87, 226-239), ||A||_F^2 */
+int ipx_sqp_refresh(const ipx_sqp_args *s, void *stream);
+/* the decisions' scalar arithmetic on a HOST copy of the block (the same code the kernels run) */
+void ipx_sqp_model_host(double *q);
+void ipx_sqp_ratio_host(double *q);
+void ipx_sqp_radius_host(double *q);
+/* box_sphere_intersections' scalar tail (qp_subproblem.py:99-149,194-234,286-296) from the seven
+ * sums of ipx_box_sphere_reduce: out3 = (ta, tb, intersect) */
+void ipx_sqp_box_sphere_host(const double *sums7, double radius, int entire_line, double *out3);
+
 #ifdef __cplusplus
 }
 #endif

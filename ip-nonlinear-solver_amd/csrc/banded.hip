@@ -76,6 +76,9 @@ struct Banded {
   double *iter_buf;           // 4 m doubles: x (two copies), residual, correction
   double *eta;                // device: max_t || D_t^-1 [E_t,t-1  E_t,t+1] ||_inf  (block Jacobi)
   double eta_host;
+  int last_L;                 // pcr_L of the last factorization that ipx_banded_status found clean
+                              // (no flag bit, decoupled, cyclic reduction usable), else 0: what
+                              // ipx_banded_status_deferred assumes for the next one
   std::vector<void *> allocs;
 };
 
@@ -2081,6 +2084,20 @@ int read_flag(Banded *h, int *f, hipStream_t st, int count = 1) {
   return ipx_read_ints(h->flag, count, f, st) == IPX_OK ? IPX_OK : IPX_ELAUNCH;
 }
 
+// the verdict of ipx_banded_status from the flags, on the device (ipx_banded_status_deferred)
+__global__ void k_status_verdict(const int *__restrict__ flag, const int *__restrict__ pcr_flags,
+                                 int L_assumed, double *__restrict__ verdict) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int f = flag[0];
+  const int *pf = pcr_flags, *pn = pcr_flags + (PCR_LMAX + 1);
+  int L = 0;
+  for (int s = 1; s <= PCR_LMAX; ++s) {
+    if (pn[s]) break;
+    if (!pf[s]) { L = s; break; }
+  }
+  verdict[0] = (f == 0 && L == L_assumed) ? 0.0 : 1.0;
+}
+
 template <typename T>
 T *dalloc(Banded *h, size_t n) {
   void *p = nullptr;
@@ -2115,6 +2132,7 @@ void *ipx_banded_create(int64_t m64, int32_t k, int32_t chunk) {
   h->eta_host = 0.0;
   h->pcr_flags = nullptr;
   h->pcr_L = 0;
+  h->last_L = 0;
   int m = (int)m64, kk = k;
   if (chunk <= 0) chunk = 64;
   bool ok = true;
@@ -2308,6 +2326,7 @@ int ipx_banded_status(void *handle, void *stream) {
       if (!pf[s]) { h->pcr_L = s; break; }
     }
   }
+  h->last_L = (f == 0 && h->decoupled) ? h->pcr_L : 0;
   h->iter_N = 0;
   if (!h->decoupled && h->iter_cand && decoupling_candidate(h) && !(f & 1)) {
     // coupled separator blocks and a top level that is long (or not compiled): solves become
@@ -2336,6 +2355,28 @@ int ipx_banded_status(void *handle, void *stream) {
   // lost IPX_PIVOT_RTOL against its diagonal entry -- the factorization is complete and
   // usable, the caller decides (SVD exit when the matrix is small enough, refinement otherwise)
   return (f & 4) ? IPX_ENOTSPD : ((f & 1) ? IPX_EILLCOND : IPX_OK);
+}
+
+// ipx_banded_status WITHOUT its blocking read, for a handle whose previous factorization was
+// clean and runs the cyclic-reduction solve (tridiagonal A A', decoupled at level L): the host
+// ASSUMES the same verdict for the factorization just enqueued -- the usual case from one
+// accepted step of the outer loop to the next -- and a one-thread kernel derives the real one
+// from the flags on the device: verdict[0] = 0 when it is the assumed one (no pivot finding,
+// separators decoupled, the reduction decoupled at the same level), else 1.  The caller enqueues
+// its solves, reads `verdict` with whatever it reads next anyway (the outer iteration's block,
+// csrc/sqp.hip) and, on a 1, calls ipx_banded_status and repeats them.  IPX_EUNSUPPORTED: no
+// clean previous verdict on this handle -- call ipx_banded_status.
+int ipx_banded_status_deferred(void *handle, double *verdict, void *stream) {
+  if (!handle || !verdict) return IPX_EINVAL;
+  Banded *h = (Banded *)handle;
+  if (h->last_L <= 0 || !h->pcr_flags || !decoupling_candidate(h)) return IPX_EUNSUPPORTED;
+  hipLaunchKernelGGL(k_status_verdict, dim3(1), dim3(IPX_WAVE), 0, (hipStream_t)stream, h->flag,
+                     h->pcr_flags, h->last_L, verdict);
+  IPX_CHECK_LAUNCH();
+  h->decoupled = true;
+  h->pcr_L = h->last_L;
+  h->iter_N = 0;
+  return IPX_OK;
 }
 
 // 1 when solves skip the middle kernel (separator system diagonal to working
@@ -2673,8 +2714,16 @@ int ipx_banded_solve_rows_launch(void *handle, const int32_t *col, const double 
   if (!pj)
     return launch_solve_pcr_rows(lv, h->pcr_L, RowsJob{col, val, xin, logL}, x, partial, npartial,
                                  guard, st);
-  // the tail's tables were laid out for ONE geometry of the solve (rows per workgroup, level)
-  if (pj->rows_wg != DEC_CHUNKS * lv.q || (1 << h->pcr_L) < pj->reach) return IPX_EUNSUPPORTED;
+  // the tail's tables were laid out for ONE geometry of the solve (rows per workgroup, level).
+  // reach: v_R of an item's second general row is read out of the window's LDS copy, of which
+  // only the FIRST halo row past the own rows is exact (the window is cut with identity padding:
+  // halo row j carries an error that grows with j) -- the QV tail's own bound.
+  // count: workgroup b writes part[b] and part[count + b]; with more workgroups than the
+  // consumer folds entries per half those stores would land in the other half / past the end
+  // (boxed problems with few variables per general row): the separate launch then.
+  if (pj->rows_wg != DEC_CHUNKS * lv.q || pj->reach > 1 || (1 << h->pcr_L) < pj->reach)
+    return IPX_EUNSUPPORTED;
+  if ((lv.P + DEC_CHUNKS - 1) / DEC_CHUNKS > pj->count) return IPX_EUNSUPPORTED;
   PostJob post{pj->own_g, pj->own_e, pj->ng, pj->nitems, pj->T, pj->yrow, pj->yval, pj->r, pj->g,
                pj->part, pj->count};
   return launch_solve_pcr_rows(lv, h->pcr_L, RowsJob{col, val, xin, logL}, x, partial, npartial,

@@ -1674,9 +1674,16 @@ struct PrimeFolds {
   const double *part[6];
   int count[6], slot[6], n;
 };
+// radius_dev / norm_A2_dev (optional): the trust radius and ||A||_F^2 as DEVICE scalars that
+// kernels earlier in the stream have written -- the outer iteration's chain (csrc/sqp.hip), whose
+// tangential radius sqrt(Delta^2 - ||dn||^2) never visits the host.
 __global__ void __launch_bounds__(IPX_BLOCK)
 k_cg_prime_state_folds(double *st, double *red, PrimeFolds f, ipx_prime_idx ix, double tol_in,
-                       double radius, double orth_tol, double norm_A, double canc2) {
+                       double radius, double orth_tol, double norm_A, double canc2,
+                       const double *__restrict__ radius_dev,
+                       const double *__restrict__ norm_A2_dev) {
+  if (radius_dev) radius = *radius_dev;
+  if (norm_A2_dev) norm_A = sqrt(*norm_A2_dev);
   // all twelve sums (six jobs x [sum y^2 | sum x y]) in one pass: the loads of every array in
   // flight together, one barrier pair (one after the other: 12 us at n = 1e6; ~3 us this way);
   // the fold kernel's routine and order per array
@@ -1773,6 +1780,17 @@ int ipx_cg_prime(const ipx_cg_args *a, const int32_t *A_tiles, int32_t A_ntiles,
                  const double *b, double *red, double *ws, double tol_in, double radius,
                  double orth_tol, double norm_A, double cancellation, int32_t first_end,
                  void *stream) {
+  return ipx_cg_prime_dev(a, A_tiles, A_ntiles, c, b, red, ws, tol_in, radius, nullptr, orth_tol,
+                          norm_A, nullptr, cancellation, first_end, (hipStream_t)stream);
+}
+
+}  // extern "C"
+
+int ipx_cg_prime_dev(const ipx_cg_args *a, const int32_t *A_tiles, int32_t A_ntiles,
+                     const double *c, const double *b, double *red, double *ws, double tol_in,
+                     double radius, const double *radius_dev, double orth_tol, double norm_A,
+                     const double *norm_A2_dev, double cancellation, int32_t first_end,
+                     hipStream_t stream) {
   if (!a || !c || !red || !ws || !A_tiles || a->solver_kind > 1 || a->m <= 0 || a->H_operator ||
       !a->H_rowptr || !a->t || first_end < 0)
     return IPX_EINVAL;
@@ -1812,13 +1830,16 @@ int ipx_cg_prime(const ipx_cg_args *a, const int32_t *A_tiles, int32_t A_ntiles,
   ipx_prime_idx ix;
   for (int k = 0; k < 7; ++k) ix.i[k] = (b ? idx_b : idx_0)[k];
   hipLaunchKernelGGL(k_cg_prime_state_folds, dim3(1), dim3(IPX_BLOCK), 0, st, a->state, red, R.f,
-                     ix, tol_in, radius, orth_tol, norm_A, cancellation * cancellation);
+                     ix, tol_in, radius, orth_tol, norm_A, cancellation * cancellation, radius_dev,
+                     norm_A2_dev);
   IPX_CHECK_LAUNCH();
   rc = launch_hp(a, nullptr, st);
   if (rc || first_end == 0) return rc;
   // the call's first batch behind the same entry (stop code 9: its launches do nothing)
   return cg_iterate(a, 0, first_end, st, nullptr);
 }
+
+extern "C" {
 
 // Hp = H p with p'Hp partials (the tail of an iteration, also used once by
 // the host to prime the loop).

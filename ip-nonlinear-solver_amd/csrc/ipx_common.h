@@ -600,6 +600,14 @@ int ipx_cg_resident_launch(const ipx_cg_args *a, int32_t it_begin, int32_t it_en
 int ipx_cg_shard2_resident_launch(const ipx_cg_args *a, const ipx_shard2_ext *e, int32_t it_begin,
                                   int32_t it_end, int np1, hipStream_t st);
 
+// ipx_cg_prime with the trust radius and ||A||_F^2 optionally taken from device memory at
+// execution time (radius_dev / norm_A2_dev non-NULL override the by-value arguments)
+int ipx_cg_prime_dev(const ipx_cg_args *a, const int32_t *A_tiles, int32_t A_ntiles,
+                     const double *c, const double *b, double *red, double *ws, double tol_in,
+                     double radius, const double *radius_dev, double orth_tol, double norm_A,
+                     const double *norm_A2_dev, double cancellation, int32_t first_end,
+                     hipStream_t stream);
+
 // ---- internal (non-ABI) launchers shared between translation units --------
 struct ipx_csr_view {
   int nrows, ncols;

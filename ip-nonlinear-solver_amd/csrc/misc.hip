@@ -135,7 +135,10 @@ int ipx_read_doubles(const double *dev, int k, double *host_out, void *stream) {
   if (rc != IPX_OK) return rc;
   hipLaunchKernelGGL(k_publish, dim3(1), dim3(IPX_READ_MAX), 0, (hipStream_t)stream, dev, k,
                      (ipx_u4 *)pinned, tag);
-  if (hipGetLastError() != hipSuccess) return IPX_ELAUNCH;
+  {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { ipx_note_error(e, __FILE__, __LINE__); return IPX_ELAUNCH; }
+  }
   return read_wait(pinned, tag, k, host_out, (hipStream_t)stream);
 }
 
@@ -158,7 +161,10 @@ int ipx_read_folded(int nd, const ipx_fold_desc *descs, double *host_out, void *
   if (rc != IPX_OK) return rc;
   hipLaunchKernelGGL(k_publish_folded, dim3(1), dim3(IPX_BLOCK), 0, (hipStream_t)stream, D, nd,
                      (ipx_u4 *)pinned, tag);
-  if (hipGetLastError() != hipSuccess) return IPX_ELAUNCH;
+  {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { ipx_note_error(e, __FILE__, __LINE__); return IPX_ELAUNCH; }
+  }
   return read_wait(pinned, tag, nd, host_out, (hipStream_t)stream);
 }
 

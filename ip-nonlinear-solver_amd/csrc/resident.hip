@@ -38,7 +38,8 @@
 // stores": a workgroup has one or two waves per SIMD and nothing else hides an LDS round trip
 // (the first version, one dependent LDS access after the other, took 27 us per iteration).
 //
-// Hand-off buffer.  Scalar records live in TWO arrays used in turn (hop h: array h & 1): a
+// Hand-off buffer.  Scalar records live in TWO arrays used in turn (hop h >= 1: array h & 1;
+// hop 0 of a PEER launch has a third, see res_records): a
 // workgroup can only publish hop h + 2 after every workgroup has published hop h + 1, i.e. has
 // passed hop h -- so no word is overwritten while somebody still polls it, whatever the kind of
 // the hops (round 4 alternated by KIND; the commit hop of a launch that stops at the top of an
@@ -95,7 +96,7 @@ constexpr int RHK = 4;        // halo entries per lane and hop (2 * hw <= RHK * 
 constexpr int RQP = 3;        // pairs of own variables per lane
 constexpr int R_MAXG = 512;                        // scalar records per array (one per lane)
 constexpr int R_REC = 8;                           // words per record: 4 granules, 3 used
-constexpr int R_HALO = 2 * R_REC * R_MAXG;         // word offset of the halo slots
+constexpr int R_HALO = 3 * R_REC * R_MAXG;         // word offset of the halo slots (three record arrays)
 constexpr int R_AREAS = 6;                         // per slot: Hp, g, p to the left (even) / right (odd)
 constexpr int R_MAXLOCAL = 224;                    // workgroups of one launch (all co-resident)
 
@@ -131,7 +132,14 @@ struct ResJob {
   double *pack_out;             // 4 doubles: the sums of the last projection for the host's resume
 };
 
-__device__ __forceinline__ ull *res_records(ull *base, uint32_t hop) { return base + (hop & 1) * (R_REC * R_MAXG); }
+// (hop 0 -- the PEER form's opening all-reduce -- has an array of its own: a launch that ran all
+// its iterations ends on an even hop, array 0, and a rank that read stop 0 relaunches without any
+// agreement on the host: its hop-0 records must not land where a slow workgroup of a peer still
+// polls the previous launch's last hop.  Hop 1 of the new launch can only be published after
+// every workgroup of every rank has published ITS hop 0, i.e. has left the previous launch.)
+__device__ __forceinline__ ull *res_records(ull *base, uint32_t hop) {
+  return base + (hop == 0 ? 2 : (int)(hop & 1)) * (R_REC * R_MAXG);
+}
 __device__ __forceinline__ ull *res_area(ull *base, int slot, int area, int hw) {
   return base + R_HALO + ((int64_t)(slot * R_AREAS + area) * hw) * 2;
 }

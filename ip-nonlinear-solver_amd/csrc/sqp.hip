@@ -1,0 +1,608 @@
+// One outer iteration of the trust-region SQP method as a chain of launches with its decisions
+// taken on the device (reference equality_constrained_sqp.py:102-250; the normal step of
+// qp_subproblem.py:320-413, the tangential step of :416-643 through csrc/cg.hip).
+//
+// The reference's outer loop is scalar logic between operator calls: the norm of the normal
+// step sizes the tangential trust region (:125-129), five reductions feed the quadratic model,
+// the penalty update and the predicted reduction (:135-153), one more the accept / reject test
+// and the trust-radius ladder (:156-212).  Read one by one they are ~18 blocking device-to-host
+// copies per iteration; rounds 3-5 packed them into four.  Here an iteration is THREE entry
+// points, each ending in a one-workgroup "decide" kernel that folds the partial sums of the
+// launches before it and writes a block of scalars (SQ_*) -- the host reads that block once per
+// entry and only to learn what it must know to call the user's callbacks:
+//
+//   ipx_sqp_front    normal step (Newton point of the dogleg, accepted on the device when it is
+//                    inside the box and the 0.8-radius ball; otherwise the whole dogleg, on the
+//                    device as well), c_t = H dn + c, the shifted bounds, the priming of the
+//                    projected CG with the tangential radius taken from the block, its first
+//                    batch of iterations, the loop's trust-region / negative-curvature exits
+//                    (:565-576, :585-596: intersections, step, clip), then d = dn + dt,
+//                    x_next = x + S d, (H d).d, c.d, ||A d + b||, ||d||, ||dt|| and the model
+//                    / penalty / predicted reduction
+//   ipx_sqp_judge    ||b_next||, actual / predicted, the second-order-correction test, the
+//                    trust-radius ladder, accept / reject
+//   ipx_sqp_refresh  after an accepted step (and at every entry of the outer loop):
+//                    v = -(A A')^-1 A c, ||c + A'v||_inf, ||b||_inf, ||b||, ||A||_F^2 and the
+//                    verdict on the factorization just made (csrc/banded.hip deferred status)
+//
+// The scalar arithmetic of the decisions is ONE set of functions compiled for the device and
+// for the host (ipx_sqp_*_host: the host-driven outer loop of backends without these chains --
+// dense Jacobians, the row-sharded solver, the CPU tests -- calls the same code, so both forms
+// take the same branches on the same numbers).
+#include "ipx_common.h"
+#include <math.h>
+
+// ---- the block ----------------------------------------------------------------------------
+// (mirrored by ipsolver/sqp.py; doubles)
+enum {
+  SQ_RADIUS = 0,        // trust radius: in; out of `radius` (the ladder's result)
+  SQ_PENALTY = 1,       // penalty: in; raised by `model`, restored by `radius` on a rejection
+  SQ_F = 2,             // f(x)
+  SQ_NORM_B = 3,        // ||b(x)||
+  SQ_NORM_DN = 4,       // ||dn||
+  SQ_RADIUS_T = 5,      // sqrt(radius^2 - ||dn||^2)
+  SQ_NORMAL_KIND = 6,   // 1: the Newton point was accepted; 2: the dogleg ran; 0: the host must
+  SQ_NVIOL = 7,         // box violations of the Newton point
+  SQ_HDD = 8, SQ_CD = 9, SQ_LIN = 10, SQ_NORM_D = 11, SQ_NORM_DT = 12,
+  SQ_QMODEL = 13, SQ_VPRED = 14, SQ_PREV_PENALTY = 15, SQ_PRED = 16, SQ_MERIT = 17,
+  SQ_F_NEXT = 18, SQ_NORM_B_NEXT = 19, SQ_ACTUAL = 20, SQ_RATIO = 21,
+  SQ_SOC = 22,          // 1: the second-order correction is due (the host's: rare)
+  SQ_ACCEPT = 23,
+  SQ_OPT = 24, SQ_VIOL = 25, SQ_NORM_A2 = 26,
+  SQ_FACTOR_BAD = 27,   // != 0: the deferred verdict on the factorization differs from the one
+                        // the solves were enqueued under (the host repeats it, blocking)
+  SQ_EXIT_TAU = 28,     // the step along p taken by the CG loop's boundary exit (diagnostic)
+  SQ_EXIT_DONE = 29,    // 1: the exit of stop code 2 / 3 was finished on the device
+  SQ_X_OUTSIDE = 30,    // box violations of the final CG iterate (:636-638)
+  SQ_CG = 32,           // the CG loop's state block (ST_*, 16 doubles) as of the model kernel
+  SQ_DOGLEG = 48,       // scalars of the device dogleg (diagnostics): coef, alphas, norms
+  SQ_SIZE = 64
+};
+
+// constants of equality_constrained_sqp.py:50-60
+#define SQC_PENALTY_FACTOR 0.3
+#define SQC_LARGE 0.9
+#define SQC_INTERMEDIARY 0.3
+#define SQC_SUFFICIENT 1e-8
+#define SQC_ENLARGE_L 7.0
+#define SQC_ENLARGE_S 2.0
+#define SQC_MAX_REDUCTION 0.5
+#define SQC_MIN_REDUCTION 0.1
+#define SQC_SOC_THRESHOLD 0.1
+
+// ---- the decisions (host + device, -ffp-contract=off on both) --------------------------------
+// :135-153 -- quadratic model, linearised constraint decrease, penalty, predicted reduction, merit
+__host__ __device__ inline void sqp_model(double *q) {
+  const double qm = 1.0 / 2.0 * q[SQ_HDD] + q[SQ_CD];
+  const double vpred = fmax(1e-16, q[SQ_NORM_B] - q[SQ_LIN]);
+  double penalty = q[SQ_PENALTY];
+  q[SQ_PREV_PENALTY] = penalty;
+  if (qm > 0.0) penalty = fmax(penalty, qm / ((1.0 - SQC_PENALTY_FACTOR) * vpred));
+  q[SQ_QMODEL] = qm;
+  q[SQ_VPRED] = vpred;
+  q[SQ_PENALTY] = penalty;
+  q[SQ_PRED] = -qm + penalty * vpred;
+  q[SQ_MERIT] = q[SQ_F] + penalty * q[SQ_NORM_B];
+}
+// :156-173 -- actual against predicted; is the second-order correction due?
+__host__ __device__ inline void sqp_ratio(double *q) {
+  const double actual = q[SQ_MERIT] - (q[SQ_F_NEXT] + q[SQ_PENALTY] * q[SQ_NORM_B_NEXT]);
+  const double ratio = actual / q[SQ_PRED];
+  q[SQ_ACTUAL] = actual;
+  q[SQ_RATIO] = ratio;
+  q[SQ_SOC] = (ratio < SQC_SUFFICIENT && q[SQ_NORM_DN] <= SQC_SOC_THRESHOLD * q[SQ_NORM_DT])
+                  ? 1.0 : 0.0;
+}
+// :196-242 -- the trust-radius ladder, accept / reject (a rejected step takes the penalty back)
+__host__ __device__ inline void sqp_radius(double *q) {
+  const double ratio = q[SQ_RATIO], norm_d = q[SQ_NORM_D];
+  double radius = q[SQ_RADIUS];
+  if (ratio >= SQC_LARGE) {
+    radius = fmax(SQC_ENLARGE_L * norm_d, radius);
+  } else if (ratio >= SQC_INTERMEDIARY) {
+    radius = fmax(SQC_ENLARGE_S * norm_d, radius);
+  } else if (ratio < SQC_SUFFICIENT) {
+    const double reduction = (1.0 - SQC_SUFFICIENT) / (1.0 - ratio);
+    const double shrunk = reduction * norm_d;
+    if (shrunk >= SQC_MAX_REDUCTION * radius) radius *= SQC_MAX_REDUCTION;
+    else if (shrunk >= SQC_MIN_REDUCTION * radius) radius = shrunk;
+    else radius *= SQC_MIN_REDUCTION;
+  }
+  q[SQ_RADIUS] = radius;
+  const bool accept = ratio >= SQC_SUFFICIENT;
+  q[SQ_ACCEPT] = accept ? 1.0 : 0.0;
+  if (!accept) q[SQ_PENALTY] = q[SQ_PREV_PENALTY];
+}
+
+// ---- scalar tails of the intersection routines (qp_subproblem.py:99-149, 194-234, 286-296) ----
+// from the seven sums of RedBoxSphere: d.d, z.d, z.z, max-of-min, min-of-max, #(d == 0 outside)
+struct sq_interval { double ta, tb; bool hit; };
+__host__ __device__ inline sq_interval sq_sphere(double dd, double zd, double zz, double radius,
+                                                 bool entire_line) {
+  if (dd == 0.0) return sq_interval{0.0, 0.0, false};
+  const double r2 = radius * radius;
+  if (isinf(r2)) {
+    if (entire_line) return sq_interval{-HUGE_VAL, HUGE_VAL, true};
+    return sq_interval{0.0, 1.0, true};
+  }
+  const double a = dd, b = 2.0 * zd, c = zz - r2;
+  const double disc = b * b - 4.0 * a * c;
+  if (disc < 0.0) return sq_interval{0.0, 0.0, false};
+  const double aux = b + copysign(sqrt(disc), b);
+  const double t1 = -aux / (2.0 * a), t2 = -2.0 * c / aux;
+  // sorted([t1, t2]) (a NaN -- aux == 0 -- keeps its place like Python's sort does)
+  double ta = t1, tb = t2;
+  if (t2 < t1) { ta = t2; tb = t1; }
+  if (entire_line) return sq_interval{ta, tb, true};
+  if (tb < 0.0 || ta > 1.0) return sq_interval{0.0, 0.0, false};
+  return sq_interval{fmax(0.0, ta), fmin(1.0, tb), true};
+}
+__host__ __device__ inline sq_interval sq_box(double dd, double ta, double tb, double zero_d_outside,
+                                              bool entire_line) {
+  if (dd == 0.0) return sq_interval{0.0, 0.0, false};
+  if (zero_d_outside > 0.0) return sq_interval{0.0, 0.0, false};
+  const bool hit = ta <= tb;
+  if (!entire_line) {
+    if (tb < 0.0 || ta > 1.0) return sq_interval{0.0, 0.0, false};
+    ta = fmax(0.0, ta);
+    tb = fmin(1.0, tb);
+  }
+  return sq_interval{ta, tb, hit};
+}
+// box_sphere_intersections :286-296 from the seven sums r[0..7)
+__host__ __device__ inline sq_interval sq_box_sphere(const double *r, double radius,
+                                                     bool entire_line) {
+  const sq_interval b = sq_box(r[0], r[3], r[4], r[5], entire_line);
+  const sq_interval s = sq_sphere(r[0], r[1], r[2], radius, entire_line);
+  // np.maximum / np.minimum propagate NaN; fmax / fmin do not: keep numpy's semantics
+  double ta = (b.ta != b.ta || s.ta != s.ta) ? NAN : fmax(b.ta, s.ta);
+  double tb = (b.tb != b.tb || s.tb != s.tb) ? NAN : fmin(b.tb, s.tb);
+  return sq_interval{ta, tb, b.hit && s.hit && ta <= tb};
+}
+
+namespace {
+
+constexpr int RB = IPX_BLOCK;
+constexpr int RU = 4;                     // elements per lane and trip of the vector kernels
+
+static int sq_grid(int64_t n) { return ipx_grid_for(n, RB * RU); }
+
+// ---- vector kernels ---------------------------------------------------------------------------
+// violations of v against [f lb, f ub] (either bound may be NULL): partial counts
+__global__ void __launch_bounds__(RB)
+k_sq_boxcount(int64_t n, const double *__restrict__ v, const double *__restrict__ lb,
+              const double *__restrict__ ub, double f, double *__restrict__ part) {
+  __shared__ double lds[RB / IPX_WAVE];
+  double cnt = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * RB;
+  for (int64_t i = (int64_t)blockIdx.x * RB + threadIdx.x; i < n; i += stride) {
+    const double t = v[i];
+    const double lo = lb ? f * lb[i] : -HUGE_VAL, hi = ub ? f * ub[i] : HUGE_VAL;
+    cnt += ((lo <= t) && (t <= hi)) ? 0.0 : 1.0;
+  }
+  const double r = ipx_block_reduce<IPX_SUM>(cnt, lds);
+  if (threadIdx.x == 0) part[blockIdx.x] = r;
+}
+
+// sum of squares + max |.| partials (part[block], part[grid + block])
+__global__ void __launch_bounds__(RB)
+k_sq_norms(int64_t n, const double *__restrict__ v, double *__restrict__ part) {
+  __shared__ double lds[RB / IPX_WAVE];
+  double s = 0.0, mx = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * RB;
+  for (int64_t i = (int64_t)blockIdx.x * RB + threadIdx.x; i < n; i += stride) {
+    const double t = v[i];
+    s += t * t;
+    mx = fmax(mx, fabs(t));
+  }
+  const double a = ipx_block_reduce<IPX_SUM>(s, lds);
+  const double b = ipx_block_reduce<IPX_MAX>(mx, lds);
+  if (threadIdx.x == 0) { part[blockIdx.x] = a; part[gridDim.x + blockIdx.x] = b; }
+}
+
+// lbt = lb - dn, ubt = ub - dn (either side may be absent)
+__global__ void __launch_bounds__(RB)
+k_sq_shift_bounds(int64_t n, const double *__restrict__ lb, const double *__restrict__ ub,
+                  const double *__restrict__ dn, double *__restrict__ lbt,
+                  double *__restrict__ ubt) {
+  const int64_t stride = (int64_t)gridDim.x * RB;
+  for (int64_t i = (int64_t)blockIdx.x * RB + threadIdx.x; i < n; i += stride) {
+    const double t = dn[i];
+    if (lb) lbt[i] = lb[i] - t;
+    if (ub) ubt[i] = ub[i] - t;
+  }
+}
+
+// the seven sums of box_sphere_intersections over (z, dscale * d) -- csrc/vec.hip RedBoxSphere --
+// as partials part[q * grid + block], run only when the CG loop stopped on code 2 or 3 (`st`);
+// dscale = alpha for code 2 (:585), 1 for code 3 (:562, entire line)
+__global__ void __launch_bounds__(RB)
+k_sq_exit_reduce(int64_t n, const double *__restrict__ st, const double *__restrict__ z,
+                 const double *__restrict__ d, const double *__restrict__ lb,
+                 const double *__restrict__ ub, double *__restrict__ part) {
+  __shared__ double lds[RB / IPX_WAVE];
+  const double stop = st[ST_STOP];
+  if (stop != 2.0 && stop != 3.0) return;
+  const double dscale = stop == 2.0 ? st[ST_ALPHA] : 1.0;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = -HUGE_VAL, a4 = HUGE_VAL, a5 = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * RB;
+  for (int64_t i = (int64_t)blockIdx.x * RB + threadIdx.x; i < n; i += stride) {
+    const double zi = z[i], di = dscale * d[i];
+    a0 += di * di; a1 += zi * di; a2 += zi * zi;
+    const double lo = lb ? lb[i] : -HUGE_VAL, hi = ub ? ub[i] : HUGE_VAL;
+    if (di == 0.0) {
+      a5 += (zi < lo || zi > hi) ? 1.0 : 0.0;
+    } else {
+      const double tl = (lo - zi) / di, tu = (hi - zi) / di;
+      a3 = fmax(a3, fmin(tl, tu));
+      a4 = fmin(a4, fmax(tl, tu));
+    }
+  }
+  const int g = gridDim.x, b = blockIdx.x;
+  double r;
+  r = ipx_block_reduce<IPX_SUM>(a0, lds); if (threadIdx.x == 0) part[b] = r;
+  r = ipx_block_reduce<IPX_SUM>(a1, lds); if (threadIdx.x == 0) part[g + b] = r;
+  r = ipx_block_reduce<IPX_SUM>(a2, lds); if (threadIdx.x == 0) part[2 * g + b] = r;
+  r = ipx_block_reduce<IPX_MAX>(a3, lds); if (threadIdx.x == 0) part[3 * g + b] = r;
+  r = ipx_block_reduce<IPX_MIN>(a4, lds); if (threadIdx.x == 0) part[4 * g + b] = r;
+  r = ipx_block_reduce<IPX_SUM>(a5, lds); if (threadIdx.x == 0) part[5 * g + b] = r;
+}
+
+// the scalar tail of that exit: tau = theta * alpha (code 2) / the line's far intersection
+// (code 3), 0 when the segment misses; one workgroup
+__global__ void __launch_bounds__(RB)
+k_sq_exit_decide(const double *__restrict__ st, const double *__restrict__ part, int grid,
+                 double *__restrict__ q) {
+  __shared__ double lds[RB / IPX_WAVE];
+  const double stop = st[ST_STOP];
+  if (stop != 2.0 && stop != 3.0) {
+    if (threadIdx.x == 0) { q[SQ_EXIT_TAU] = 0.0; q[SQ_EXIT_DONE] = 0.0; }
+    return;
+  }
+  double r[7];
+  r[0] = ipx_sum_partials<IPX_SUM>(part, grid, lds);
+  r[1] = ipx_sum_partials<IPX_SUM>(part + grid, grid, lds);
+  r[2] = ipx_sum_partials<IPX_SUM>(part + 2 * grid, grid, lds);
+  r[3] = ipx_sum_partials<IPX_MAX>(part + 3 * grid, grid, lds);
+  r[4] = ipx_sum_partials<IPX_MIN>(part + 4 * grid, grid, lds);
+  r[5] = ipx_sum_partials<IPX_SUM>(part + 5 * grid, grid, lds);
+  r[6] = 0.0;
+  if (threadIdx.x != 0) return;
+  const double radius = st[ST_RADIUS];
+  const sq_interval iv = sq_box_sphere(r, radius, stop == 3.0);
+  // :565-568 x + alpha p with alpha = tb of the entire line; :588-590 x + theta alpha p
+  const double tau = !iv.hit ? 0.0 : (stop == 2.0 ? iv.tb * st[ST_ALPHA] : iv.tb);
+  q[SQ_EXIT_TAU] = tau;
+  q[SQ_EXIT_DONE] = 1.0;
+}
+
+// dt <- clip(dt + tau p) when the exit above ran (tau == 0: dt itself, clipped -- :569,:591 clip
+// in both cases), then the step's vectors and sums:
+//   d = dn + dt,  x_next = x + (scale ? scale * d : d),
+//   partials of ||d||^2, ||dt||^2, c.d and of the box violations of dt (:636)
+__global__ void __launch_bounds__(RB)
+k_sq_step_vectors(int64_t n, int use_exit, const double *__restrict__ q,
+                  const double *__restrict__ dn,
+                  double *__restrict__ dt, const double *__restrict__ p,
+                  const double *__restrict__ lbt, const double *__restrict__ ubt,
+                  const double *__restrict__ x, const double *__restrict__ c,
+                  const double *__restrict__ scale, double *__restrict__ d,
+                  double *__restrict__ x_next, double *__restrict__ part) {
+  __shared__ double lds[RB / IPX_WAVE];
+  // (use_exit == 0: the host finished the CG loop itself, boundary exits included)
+  const bool exit_done = use_exit && q[SQ_EXIT_DONE] != 0.0;
+  const double tau = use_exit ? q[SQ_EXIT_TAU] : 0.0;
+  double s_d = 0.0, s_dt = 0.0, s_cd = 0.0, s_out = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * RB;
+  for (int64_t i = (int64_t)blockIdx.x * RB + threadIdx.x; i < n; i += stride) {
+    double t = dt[i];
+    const double lo = lbt ? lbt[i] : -HUGE_VAL, hi = ubt ? ubt[i] : HUGE_VAL;
+    if (exit_done) {
+      if (tau != 0.0) t = t + tau * p[i];
+      if (lbt || ubt) t = fmin(fmax(t, lo), hi);
+      dt[i] = t;
+    }
+    if (lbt || ubt) s_out += ((lo <= t) && (t <= hi)) ? 0.0 : 1.0;
+    const double di = dn[i] + t;
+    d[i] = di;
+    x_next[i] = x[i] + (scale ? scale[i] * di : di);
+    s_d += di * di;
+    s_dt += t * t;
+    s_cd += c[i] * di;
+  }
+  const int g = gridDim.x, b = blockIdx.x;
+  double r;
+  r = ipx_block_reduce<IPX_SUM>(s_d, lds);   if (threadIdx.x == 0) part[b] = r;
+  r = ipx_block_reduce<IPX_SUM>(s_dt, lds);  if (threadIdx.x == 0) part[g + b] = r;
+  r = ipx_block_reduce<IPX_SUM>(s_cd, lds);  if (threadIdx.x == 0) part[2 * g + b] = r;
+  r = ipx_block_reduce<IPX_SUM>(s_out, lds); if (threadIdx.x == 0) part[3 * g + b] = r;
+}
+
+// ---- decide kernels (one workgroup each) ----------------------------------------------------
+// after the Newton point: ||dn||, inside the box and the ball? the tangential radius
+__global__ void __launch_bounds__(RB)
+k_sq_after_newton(const double *__restrict__ p_nn, int n_nn, const double *__restrict__ p_viol,
+                  int n_viol, double radius, double tr_factor, double *__restrict__ q) {
+  __shared__ double lds[RB / IPX_WAVE];
+  const double nn2 = ipx_sum_partials<IPX_SUM>(p_nn, n_nn, lds);
+  const double nviol = n_viol > 0 ? ipx_sum_partials<IPX_SUM>(p_viol, n_viol, lds) : 0.0;
+  if (threadIdx.x != 0) return;
+  const double norm_dn = sqrt(nn2);
+  const bool ok = nviol == 0.0 && norm_dn <= tr_factor * radius;      // qp_subproblem.py:370-373
+  q[SQ_NVIOL] = nviol;
+  q[SQ_NORM_DN] = norm_dn;
+  q[SQ_NORMAL_KIND] = ok ? 1.0 : 0.0;
+  q[SQ_RADIUS] = radius;
+  q[SQ_RADIUS_T] = sqrt(radius * radius - norm_dn * norm_dn);         // :127
+}
+
+// a normal step the host computed (the dogleg proper): its norm and the tangential radius
+__global__ void __launch_bounds__(RB)
+k_sq_after_given(const double *__restrict__ p_nn, int n_nn, double radius,
+                 double *__restrict__ q) {
+  __shared__ double lds[RB / IPX_WAVE];
+  const double nn2 = ipx_sum_partials<IPX_SUM>(p_nn, n_nn, lds);
+  if (threadIdx.x != 0) return;
+  const double norm_dn = sqrt(nn2);
+  q[SQ_NVIOL] = 0.0;
+  q[SQ_NORM_DN] = norm_dn;
+  q[SQ_NORMAL_KIND] = 2.0;
+  q[SQ_RADIUS] = radius;
+  q[SQ_RADIUS_T] = sqrt(radius * radius - norm_dn * norm_dn);
+}
+
+// the model: folds the step's sums, :135-153, and a copy of the CG loop's state block
+__global__ void __launch_bounds__(RB)
+k_sq_model(const double *__restrict__ p_vec, int g_vec, const double *__restrict__ p_hd, int n_hd,
+           const double *__restrict__ p_ad, int n_ad, const double *__restrict__ cg_state,
+           double penalty, double f, double norm_b, double *__restrict__ q) {
+  __shared__ double lds[5 * (RB / IPX_WAVE)];
+  const double *parts[5] = {p_vec, p_vec + g_vec, p_vec + 2 * g_vec, p_hd + n_hd, p_ad};
+  const int counts[5] = {g_vec, g_vec, g_vec, n_hd, n_ad};
+  double out[5];
+  ipx_sum_partials_multi<5>(parts, counts, lds, out);
+  const double outside = ipx_sum_partials<IPX_SUM>(p_vec + 3 * g_vec, g_vec, lds);
+  if (threadIdx.x < ST_SIZE) q[SQ_CG + threadIdx.x] = cg_state[threadIdx.x];
+  if (threadIdx.x != 0) return;
+  q[SQ_NORM_D] = sqrt(out[0]);
+  q[SQ_NORM_DT] = sqrt(out[1]);
+  q[SQ_CD] = out[2];
+  q[SQ_HDD] = out[3];
+  q[SQ_LIN] = sqrt(out[4]);
+  q[SQ_X_OUTSIDE] = outside;
+  q[SQ_PENALTY] = penalty;
+  q[SQ_F] = f;
+  q[SQ_NORM_B] = norm_b;
+  sqp_model(q);
+}
+
+// the verdict: ||b_next||, :156-173, and -- unless the second-order correction is due, which
+// the host runs -- the ladder and the accept test
+__global__ void __launch_bounds__(RB)
+k_sq_judge(const double *__restrict__ p_bn, int n_bn, double f_next,
+           const double *__restrict__ f_next_dev, double *__restrict__ q) {
+  __shared__ double lds[RB / IPX_WAVE];
+  const double bn2 = n_bn > 0 ? ipx_sum_partials<IPX_SUM>(p_bn, n_bn, lds) : 0.0;
+  if (threadIdx.x != 0) return;
+  q[SQ_F_NEXT] = f_next_dev ? *f_next_dev : f_next;
+  q[SQ_NORM_B_NEXT] = sqrt(bn2);
+  sqp_ratio(q);
+  if (q[SQ_SOC] == 0.0) sqp_radius(q);
+  else q[SQ_ACCEPT] = 0.0;
+}
+
+// the measures of a new iterate (:86-87, 238-239): ||c + A'v||_inf, ||b||_inf, ||b||, and
+// ||A||_F^2 from the partials of ipx_norms_partials over A's values
+__global__ void __launch_bounds__(RB)
+k_sq_measure(const double *__restrict__ p_t, int g_t, const double *__restrict__ p_b, int g_b,
+             const double *__restrict__ p_A, int g_A, const double *__restrict__ verdict,
+             double *__restrict__ q) {
+  __shared__ double lds[RB / IPX_WAVE];
+  const double opt = g_t > 0 ? ipx_sum_partials<IPX_MAX>(p_t + g_t, g_t, lds) : 0.0;
+  const double viol = g_b > 0 ? ipx_sum_partials<IPX_MAX>(p_b + g_b, g_b, lds) : 0.0;
+  const double nb2 = g_b > 0 ? ipx_sum_partials<IPX_SUM>(p_b, g_b, lds) : 0.0;
+  const double na2 = g_A > 0 ? ipx_sum_partials<IPX_SUM>(p_A, g_A, lds) : 0.0;
+  if (threadIdx.x != 0) return;
+  q[SQ_OPT] = opt;
+  q[SQ_VIOL] = viol;
+  q[SQ_NORM_B] = sqrt(nb2);
+  if (g_A > 0) q[SQ_NORM_A2] = na2;
+  q[SQ_FACTOR_BAD] = verdict ? *verdict : 0.0;
+}
+
+}  // namespace
+
+// ---- the argument block (all members 8 bytes; mirrored by ipsolver/sqp_chain.py) ------------
+extern "C" {
+
+
+int ipx_sqp_block_size(void) { return SQ_SIZE; }
+
+// doubles of `part`: the vector kernels' partials (4 quantities, then 6 for the exit's sums), the
+// SpMV partials of H d, A d + b, the Newton point; room for the refresh's three norm pairs
+int64_t ipx_sqp_part_doubles(const ipx_sqp_args *s) {
+  if (!s || !s->cg) return -1;
+  const int64_t g = sq_grid(s->n), gm = sq_grid(s->m);
+  return 4 * g + 6 * g + 2 * s->cg->H_ntiles + 2 * s->A_ntiles + 2 * s->cg->At_ntiles + 2 * g +
+         2 * gm + g + 64;
+}
+
+void ipx_sqp_model_host(double *q) { sqp_model(q); }
+void ipx_sqp_ratio_host(double *q) { sqp_ratio(q); }
+void ipx_sqp_radius_host(double *q) { sqp_radius(q); }
+/* box_sphere_intersections' scalar tail from the seven sums of ipx_box_sphere_reduce:
+ * out3 = (ta, tb, intersect) */
+void ipx_sqp_box_sphere_host(const double *sums7, double radius, int entire_line, double *out3) {
+  const sq_interval iv = sq_box_sphere(sums7, radius, entire_line != 0);
+  out3[0] = iv.ta; out3[1] = iv.tb; out3[2] = iv.hit ? 1.0 : 0.0;
+}
+
+}  // extern "C"
+
+namespace {
+
+struct PartLayout {
+  double *vec, *exit, *hd, *ad, *nn, *viol, *bn, *tn, *tail;
+  int g, gm;
+};
+static PartLayout layout(const ipx_sqp_args *s) {
+  PartLayout L;
+  L.g = sq_grid(s->n); L.gm = sq_grid(s->m);
+  double *p = s->part;
+  L.vec = p;  p += 4 * (int64_t)L.g;
+  L.exit = p; p += 6 * (int64_t)L.g;
+  L.hd = p;   p += 2 * s->cg->H_ntiles;
+  L.ad = p;   p += 2 * s->A_ntiles;
+  L.nn = p;   p += 2 * s->cg->At_ntiles;
+  L.tn = p;   p += 2 * (int64_t)L.g;        // norms of an n-vector (refresh: c + A'v; given dn)
+  L.bn = p;   p += 2 * (int64_t)L.gm;       // norms of an m-vector (b, b_next)
+  L.viol = p; p += L.g;
+  L.tail = p;
+  return L;
+}
+
+static int solve(const ipx_cg_args *a, const double *w, double *v, hipStream_t st) {
+  if (a->solver_kind == 1)
+    return ipx_boxschur_solve((const ipx_boxschur_args *)a->banded, w, v, nullptr, nullptr, nullptr,
+                              st);
+  return ipx_banded_solve(a->banded, w, v, st);
+}
+
+}  // namespace
+
+extern "C" {
+
+// The step's second half on its own: the CG loop's boundary exits, d, x_next, the five sums, the
+// model.  `dt` = cg->x.  (ipx_sqp_front ends with it; the host calls it again after it had to
+// finish the CG itself.)
+int ipx_sqp_model(const ipx_sqp_args *s, double penalty, double f, double norm_b, int host_cg,
+                  void *stream) {
+  if (!s || !s->cg || !s->q || !s->part || !s->x_next) return IPX_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const ipx_cg_args *a = s->cg;
+  const PartLayout L = layout(s);
+  const ipx_csr_view A{(int)s->m, (int)s->n, a->A_rowptr, a->A_colidx, a->A_val, s->A_tiles,
+                       (int)s->A_ntiles};
+  const ipx_csr_view Hm{(int)s->n, (int)s->n, a->H_rowptr, a->H_colidx, a->H_val, a->H_tiles,
+                        (int)a->H_ntiles};
+  if (!host_cg) {
+    hipLaunchKernelGGL(k_sq_exit_reduce, dim3(L.g), dim3(RB), 0, st, s->n, a->state, a->x, a->p,
+                       a->lb, a->ub, L.exit);
+    IPX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_sq_exit_decide, dim3(1), dim3(RB), 0, st, a->state, L.exit, L.g, s->q);
+    IPX_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(k_sq_step_vectors, dim3(L.g), dim3(RB), 0, st, s->n, host_cg ? 0 : 1, s->q,
+                     s->dn, a->x, a->p,
+                     a->lb, a->ub, s->x, s->c, s->scale, s->d, s->x_next, L.vec);
+  IPX_CHECK_LAUNCH();
+  int rc = ipx_spmv_launch(Hm, s->d, 1.0, a->H_diag, 0.0, nullptr, s->Hd, L.hd, nullptr, st);
+  if (rc) return rc;
+  rc = ipx_spmv_launch(A, s->d, 1.0, nullptr, 1.0, s->b, s->Ad, L.ad, nullptr, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_sq_model, dim3(1), dim3(RB), 0, st, L.vec, L.g, L.hd, (int)a->H_ntiles, L.ad,
+                     (int)s->A_ntiles, a->state, penalty, f, norm_b, s->q);
+  IPX_CHECK_LAUNCH();
+  return IPX_OK;
+}
+
+// have_dn == 0: the Newton point of the dogleg into s->dn, its acceptance decided on the
+// device (SQ_NORMAL_KIND 1; 0: the host runs the dogleg and calls again with have_dn = 1).
+// Then c_t, the shifted bounds, the priming of the projected CG with the radius of the block,
+// iterations [0, first_end) and ipx_sqp_model.  box_factor / tr_factor: :43-44 (0.5, 0.8).
+int ipx_sqp_front(const ipx_sqp_args *s, int have_dn, double radius, double penalty, double f,
+                  double norm_b, double tr_factor, double box_factor, double tol_in,
+                  double norm_A, int32_t first_end, void *stream) {
+  if (!s || !s->cg || !s->q || !s->part || !s->dn || !s->ct || s->m <= 0) return IPX_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const ipx_cg_args *a = s->cg;
+  const PartLayout L = layout(s);
+  const ipx_csr_view At{(int)s->n, (int)s->m, a->At_rowptr, a->At_colidx, a->At_val, a->At_tiles,
+                        (int)a->At_ntiles};
+  const ipx_csr_view Hm{(int)s->n, (int)s->n, a->H_rowptr, a->H_colidx, a->H_val, a->H_tiles,
+                        (int)a->H_ntiles};
+  int rc;
+  if (!have_dn) {
+    // newton = -Y b = -A'(A A')^-1 b   (qp_subproblem.py:368)
+    rc = solve(a, s->b, a->v, st);
+    if (rc) return rc;
+    rc = ipx_spmv_launch(At, a->v, -1.0, nullptr, 0.0, nullptr, s->dn, L.nn, nullptr, st);
+    if (rc) return rc;
+    const bool boxed = s->lb || s->ub;
+    if (boxed) {
+      hipLaunchKernelGGL(k_sq_boxcount, dim3(L.g), dim3(RB), 0, st, s->n, s->dn, s->lb, s->ub,
+                         box_factor, L.viol);
+      IPX_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(k_sq_after_newton, dim3(1), dim3(RB), 0, st, L.nn, (int)a->At_ntiles, L.viol,
+                       boxed ? L.g : 0, radius, tr_factor, s->q);
+    IPX_CHECK_LAUNCH();
+  } else {
+    hipLaunchKernelGGL(k_sq_norms, dim3(L.g), dim3(RB), 0, st, s->n, s->dn, L.tn);
+    IPX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_sq_after_given, dim3(1), dim3(RB), 0, st, L.tn, L.g, radius, s->q);
+    IPX_CHECK_LAUNCH();
+  }
+  // c_t = H dn + c   (:125)
+  rc = ipx_spmv_launch(Hm, s->dn, 1.0, a->H_diag, 1.0, s->c, s->ct, nullptr, nullptr, st);
+  if (rc) return rc;
+  if (s->lb || s->ub) {
+    hipLaunchKernelGGL(k_sq_shift_bounds, dim3(L.g), dim3(RB), 0, st, s->n, s->lb, s->ub, s->dn,
+                       s->lbt, s->ubt);
+    IPX_CHECK_LAUNCH();
+  }
+  rc = ipx_cg_prime_dev(a, s->A_tiles, (int32_t)s->A_ntiles, s->ct, nullptr, s->red, s->ws, tol_in,
+                        0.0, s->q + SQ_RADIUS_T, s->orth_tol, norm_A, nullptr, s->cancellation,
+                        first_end, st);
+  if (rc) return rc;
+  return ipx_sqp_model(s, penalty, f, norm_b, 0, stream);
+}
+
+// ||b_next|| and the verdict (f_next by value, or -- f_next_dev non-NULL -- a device scalar the
+// user's objective left)
+int ipx_sqp_judge(const ipx_sqp_args *s, const double *b_next, double f_next,
+                  const double *f_next_dev, void *stream) {
+  if (!s || !s->q || !s->part || (s->m > 0 && !b_next)) return IPX_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const PartLayout L = layout(s);
+  if (s->m > 0) {
+    hipLaunchKernelGGL(k_sq_norms, dim3(L.gm), dim3(RB), 0, st, s->m, b_next, L.bn);
+    IPX_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(k_sq_judge, dim3(1), dim3(RB), 0, st, L.bn, s->m > 0 ? L.gm : 0, f_next,
+                     f_next_dev, s->q);
+  IPX_CHECK_LAUNCH();
+  return IPX_OK;
+}
+
+// v = -LS c (:83,226), optimality, constraint violation, ||b|| (:86-87,238-239)
+int ipx_sqp_refresh(const ipx_sqp_args *s, void *stream) {
+  if (!s || !s->cg || !s->q || !s->part || !s->v_out || s->m <= 0) return IPX_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const ipx_cg_args *a = s->cg;
+  const PartLayout L = layout(s);
+  const ipx_csr_view A{(int)s->m, (int)s->n, a->A_rowptr, a->A_colidx, a->A_val, s->A_tiles,
+                       (int)s->A_ntiles};
+  const ipx_csr_view At{(int)s->n, (int)s->m, a->At_rowptr, a->At_colidx, a->At_val, a->At_tiles,
+                        (int)a->At_ntiles};
+  int rc = ipx_spmv_launch(A, s->c, 1.0, nullptr, 0.0, nullptr, a->w, nullptr, nullptr, st);
+  if (rc) return rc;
+  rc = solve(a, a->w, a->v, st);
+  if (rc) return rc;
+  // c + A'(-v): the products and the row sums of a negated vector are the negated ones, bit for
+  // bit, so the product runs on (A A')^-1 A c itself with alpha = -1
+  rc = ipx_spmv_launch(At, a->v, -1.0, nullptr, 1.0, s->c, s->ct, nullptr, nullptr, st);
+  if (rc) return rc;
+  rc = ipx_axpby(s->m, -1.0, a->v, 0.0, nullptr, s->v_out, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_sq_norms, dim3(L.g), dim3(RB), 0, st, s->n, s->ct, L.tn);
+  IPX_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_sq_norms, dim3(L.gm), dim3(RB), 0, st, s->m, s->b, L.bn);
+  IPX_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_sq_measure, dim3(1), dim3(RB), 0, st, L.tn, L.g, L.bn, L.gm, s->A_norm_part,
+                     s->A_norm_part ? (int)s->A_norm_grid : 0, s->verdict, s->q);
+  IPX_CHECK_LAUNCH();
+  return IPX_OK;
+}
+
+}  // extern "C"

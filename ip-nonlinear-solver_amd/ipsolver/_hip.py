@@ -108,20 +108,30 @@ _SIGNATURES = {
     "ipx_boxschur_solve": [_P, _P, _P, _P, _P, _P, _P],
     "ipx_boxschur_project": [_P, _P, _P, _P, _P, _P, _P, _P, _P],
     "ipx_boxschur_project_count": [_P],
+    "ipx_banded_status_deferred": [_P, _P, _P],
+    "ipx_sqp_block_size": [],
+    "ipx_sqp_front": [_P, _c.c_int, _F64, _F64, _F64, _F64, _F64, _F64, _F64, _F64, _I32, _P],
+    "ipx_sqp_model": [_P, _F64, _F64, _F64, _c.c_int, _P],
+    "ipx_sqp_judge": [_P, _P, _F64, _P, _P],
+    "ipx_sqp_refresh": [_P, _P],
 }
 _RESTYPES = {"ipx_version": _c.c_char_p, "ipx_last_error": _c.c_char_p,
              "ipx_banded_create": _P, "ipx_banded_destroy": None,
              "ipx_dense_padded": _I64, "ipx_gram_ws_doubles": _I64, "ipx_peer_create": _P, "ipx_peer_destroy": None,
              "ipx_peer_halo_capacity": _I64, "ipx_peer_fused_launches": _I64,
              "ipx_cg_resident_ll_words": _I64, "ipx_cg_prime_ws_doubles": _I64,
-             "ipx_peer_resident_launches": _I64, "ipx_cg_resident_limits": None}
+             "ipx_peer_resident_launches": _I64, "ipx_cg_resident_limits": None,
+             "ipx_sqp_part_doubles": _I64, "ipx_sqp_model_host": None, "ipx_sqp_ratio_host": None,
+             "ipx_sqp_radius_host": None, "ipx_sqp_box_sphere_host": None}
 _EXTRA_ARGTYPES = {"ipx_banded_create": [_I64, _I32, _I32], "ipx_banded_destroy": [_P],
                    "ipx_dense_padded": [_I64], "ipx_gram_ws_doubles": [_I64, _I32],
                    "ipx_peer_create": [_I32, _I32, _I64],
                    "ipx_peer_destroy": [_P], "ipx_peer_halo_capacity": [_P],
                    "ipx_peer_fused_launches": [_P], "ipx_cg_resident_ll_words": [_I32, _I32],
                    "ipx_cg_prime_ws_doubles": [_P, _I32], "ipx_peer_resident_launches": [_P],
-                   "ipx_cg_resident_limits": [_P]}
+                   "ipx_cg_resident_limits": [_P], "ipx_sqp_part_doubles": [_P],
+                   "ipx_sqp_model_host": [_P], "ipx_sqp_ratio_host": [_P],
+                   "ipx_sqp_radius_host": [_P], "ipx_sqp_box_sphere_host": [_P, _F64, _c.c_int, _P]}
 
 _lib = None
 

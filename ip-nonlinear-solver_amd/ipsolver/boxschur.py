@@ -243,6 +243,7 @@ class BoxSchurNormalSolver:
         return self._args
 
     POST_PG, POST_TB = 6, 512            # csrc/banded.hip POST_PG, PCR_TB
+    POST_ITEMS_PER_PART = 1024           # csrc/boxschur.hip ipx_boxschur_project_count
 
     def _post_tables(self):
         """Item ranges per workgroup of the Schur solve for the fused back substitution
@@ -285,7 +286,13 @@ class BoxSchurNormalSolver:
                             np.diff(own_e).max() <= self.POST_TB:
                         c[key] = (_i32(own_g), _i32(own_e), rows_wg, int((hi - lo).max()))
         post = c[key]
-        if post is None or post[3] > (1 << L):
+        # (reach <= 1: only the first halo row of the solve's window is exact; nwg <= the count
+        # of ||g||^2 partials per half the consumer folds -- csrc/banded.hip
+        # ipx_banded_solve_rows_launch refuses the same two cases)
+        if post is None or post[3] > 1 or post[3] > (1 << L):
+            return None
+        if nwg > (self.ng + int(c["gen_cols"].numel()) + self.POST_ITEMS_PER_PART - 1) \
+                // self.POST_ITEMS_PER_PART:
             return None
         return post
 

@@ -857,7 +857,13 @@ def _first_batch(max_iter, operator):
 
 
 def _run_loop(L, pool_key, P, lib, st, n, lb, ub, trust_radius, max_iter, max_infeasible_iter,
-              batch, stats, fast):
+              batch, stats, fast, primed_state=None, release=True):
+    """``primed_state``: the state block as somebody already read it behind the batch recorded
+    in ``L.enqueued`` (the outer iteration's chain, sqp_chain.py: its one read carries the
+    loop's block) -- the first ``read_state`` then costs nothing.  ``release=False``: the loop
+    object stays the caller's."""
+    pending = [primed_state]
+
     class Driver:
         """The single-GPU loop behind ``run_device_loop``."""
         first_batch = _first_batch(max_iter, L.operator is not None)
@@ -881,11 +887,15 @@ def _run_loop(L, pool_key, P, lib, st, n, lb, ub, trust_radius, max_iter, max_in
                     L.apply_operator()
 
         def read_state(self):
-            s = dv.read_doubles(L.state, L.state.numel())
+            if pending[0] is not None:
+                s, pending[0] = list(pending[0]), None
+            else:
+                s = dv.read_doubles(L.state, L.state.numel())
             if fast and int(s[ST_STOP]) == 9:
                 # the device's verdict on the priming: the host must do it (nothing of the
                 # call's inputs was overwritten; the loop's launches were no-ops)
-                _release(L, pool_key)
+                if release:
+                    _release(L, pool_key)
                 raise _PrimeRetry()
             if int(s[ST_STOP]) == 8 and L.args.resident:
                 # a hand-off of the resident launch timed out (a workgroup that never became
@@ -922,7 +932,8 @@ def _run_loop(L, pool_key, P, lib, st, n, lb, ub, trust_radius, max_iter, max_in
     STATS["calls"] += 1
     STATS["iterations"] += niter
     STATS["resident_calls"] += 1 if L.args.resident else 0
-    _release(L, pool_key)
+    if release:
+        _release(L, pool_key)
     return x, {'niter': niter, 'stop_cond': stop_cond, 'hits_boundary': hits_boundary}
 
 

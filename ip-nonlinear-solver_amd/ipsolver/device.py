@@ -100,8 +100,22 @@ def _wrap(t):
     return v
 
 
-_READ_BUF = (ctypes.c_double * 512)()
-_READ_PTR = ctypes.addressof(_READ_BUF)
+import threading
+
+
+class _ReadBuffers(threading.local):
+    """Host staging of the blocking reads, one set per Python thread (the C side keeps its
+    pinned buffer and tag per host thread too, and polls with the GIL released: two threads
+    sharing one buffer would overwrite each other's results or descriptors -- ADVICE r5)."""
+
+    def __init__(self):
+        self.buf = (ctypes.c_double * 512)()
+        self.ptr = ctypes.addressof(self.buf)
+        self.fold = None            # (_FoldDesc * FOLD_MAX)(), made on first use
+        self.fold_ptr = None
+
+
+_RB = _ReadBuffers()
 
 
 def read_doubles(t, k, offset=0):
@@ -113,16 +127,15 @@ def read_doubles(t, k, offset=0):
         return []
     if k > 512:
         return t[offset:offset + k].tolist()
-    _hip.call("ipx_read_doubles", t.data_ptr() + 8 * offset, int(k), _READ_PTR, stream_ptr())
-    return _READ_BUF[:k]
+    rb = _RB
+    _hip.call("ipx_read_doubles", t.data_ptr() + 8 * offset, int(k), rb.ptr, stream_ptr())
+    return rb.buf[:k]
 
 
 class _FoldDesc(ctypes.Structure):
     _fields_ = [("part", ctypes.c_void_p), ("count", ctypes.c_int32), ("op", ctypes.c_int32)]
 
 
-_FOLD_BUF = (_FoldDesc * FOLD_MAX)()
-_FOLD_PTR = ctypes.addressof(_FOLD_BUF)
 
 
 def read_folded(descs):
@@ -131,14 +144,18 @@ def read_folded(descs):
     the read-back's kernel in the order of the reductions' own second launch (same bits)."""
     c = ctx()
     base = c.parts.data_ptr()
+    rb = _RB
+    if rb.fold is None:
+        rb.fold = (_FoldDesc * FOLD_MAX)()
+        rb.fold_ptr = ctypes.addressof(rb.fold)
     out = []
     for i in range(0, len(descs), FOLD_MAX):
         chunk = descs[i:i + FOLD_MAX]
         for q, (off, count, op) in enumerate(chunk):
-            d = _FOLD_BUF[q]
+            d = rb.fold[q]
             d.part, d.count, d.op = base + 8 * off, count, op
-        _hip.call("ipx_read_folded", len(chunk), _FOLD_PTR, _READ_PTR, stream_ptr())
-        out.extend(_READ_BUF[:len(chunk)])
+        _hip.call("ipx_read_folded", len(chunk), rb.fold_ptr, rb.ptr, stream_ptr())
+        out.extend(rb.buf[:len(chunk)])
     return out
 
 

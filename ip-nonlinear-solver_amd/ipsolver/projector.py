@@ -674,26 +674,42 @@ def projections(A, method=None, orth_tol=1e-12, max_refin=3, tol=1e-15):
     # barrier method hands the Jacobian of its last accepted point to the next subproblem
     # (tr_interior_point.py:338-340: the reference refactors it, 11 of config 3's 25
     # factorizations).
-    key = (method, orth_tol, max_refin, tol, _values_version(A))
+    #
+    # What the version counter does NOT see: writes through raw pointers (a user kernel, or this
+    # library's own ipx_* entry points called on ``A.val`` directly).  A callback that refills a
+    # preallocated value tensor that way must say so -- ``projector.invalidate(A)`` -- or go
+    # through torch ops (``A.val.copy_(...)``), which bump the counter.  The entry keeps a
+    # reference to the tensor it was made for: a reassigned ``A.val`` can then never collide
+    # with a collected tensor's id.
+    t, version = _values_version(A)
+    key = (method, orth_tol, max_refin, tol, version)
     cached = getattr(A, "_ipx_projections", None)
-    if cached is not None and cached[0] == key:
+    if cached is not None and version is not None and cached[0] == key and cached[2] is t:
         return cached[1]
     out = _projections(A, method, orth_tol, max_refin, tol)
     try:
-        A._ipx_projections = (key, out)
+        A._ipx_projections = (key, out, t)
     except AttributeError:
         pass
     return out
 
 
+def invalidate(A):
+    """Forget the factorization cached on a device matrix (its values were rewritten in place
+    behind torch's back: see ``projections``)."""
+    try:
+        A._ipx_projections = None
+    except AttributeError:
+        pass
+
+
 def _values_version(A):
-    """Version counter of the tensor that holds a device matrix's values (None: unknown type,
-    never equal to a cached key's)."""
+    """(tensor that holds a device matrix's values, its version counter); (None, None) for an
+    unknown type: never cached."""
     t = getattr(A, "val", None)
     if t is None:
         t = getattr(A, "t", None)
-    v = getattr(t, "_version", None)
-    return (id(t), v) if v is not None else object()
+    return t, getattr(t, "_version", None)
 
 
 def _projections(A, method, orth_tol, max_refin, tol):
