@@ -348,8 +348,12 @@ int ipx_cg_iterate(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, void 
 /* The whole priming of a call (qp_subproblem.py:502-512: x0 = Y(-b), r0 = Z(H x0 + c), g0 = Z r0,
  * the state block, p = -g0, Hp = H p) enqueued by ONE call into the loop's own buffers; CSR A
  * (A_tiles / A_ntiles: its standard SpMV row tiles) and H, solver_kind 0 or 1; b NULL = 0;
- * red: 14 doubles, ws: IPX_WS_DOUBLES doubles of device memory.  first_end > 0: iterations
+ * red: 18 doubles, ws: IPX_WS_DOUBLES doubles of device memory.  first_end > 0: iterations
  * [0, first_end) are enqueued behind the priming by the same call (as ipx_cg_iterate would).
+ * With b == NULL each of the two projections may take ONE correction step on the device (the
+ * refinement of projections.py:72-78 / the cancellation step of ipsolver/projector.py, decided
+ * from the same norms by a kernel in between: red[14 + j] = 0 when projection j takes it,
+ * red[16 + j] = 1 once it has).
  * Stop code 9 in the state block afterwards: the host must prime (ipx_cg_prime_state); the
  * iterations enqueued with it did nothing. */
 /* doubles of reduction workspace ipx_cg_prime needs for this argument block (the per-tile
@@ -622,12 +626,15 @@ typedef struct ipx_sqp_args {
 int ipx_sqp_block_size(void);
 int64_t ipx_sqp_part_doubles(const ipx_sqp_args *s);
 /* normal step (have_dn == 0: the Newton point, accepted on the device -- block entry
- * NORMAL_KIND 1 -- or not, 0: the caller computes the dogleg step into s->dn and calls again with
- * have_dn = 1), c_t = H dn + c, shifted bounds, the projected CG's priming with the tangential
- * radius of the block and iterations [0, first_end), then ipx_sqp_model. */
-int ipx_sqp_front(const ipx_sqp_args *s, int have_dn, double radius, double penalty, double f,
-                  double norm_b, double tr_factor, double box_factor, double tol_in,
-                  double norm_A, int32_t first_end, void *stream);
+ * NORMAL_KIND 1 -- or not; then, with_dogleg != 0, the dogleg proper of qp_subproblem.py:375-413
+ * behind it on the device -- NORMAL_KIND 2 --, else 0: the caller computes the dogleg step into
+ * s->dn and calls again with have_dn = 1), c_t = H dn + c, shifted bounds, the projected CG's
+ * priming with the tangential radius of the block and iterations [0, first_end), then
+ * ipx_sqp_model.  (with_dogleg costs nine launches that do nothing when the Newton point stands:
+ * the caller sets it when the last normal step was not the Newton point.) */
+int ipx_sqp_front(const ipx_sqp_args *s, int have_dn, int with_dogleg, double radius,
+                  double penalty, double f, double norm_b, double tr_factor, double box_factor,
+                  double tol_in, double norm_A, int32_t first_end, void *stream);
 /* the CG loop's trust-region / negative-curvature exits (:565-576, :585-596), d = dn + dt,
  * x_next = x + S d, the five sums and the model / penalty / predicted reduction (:135-153);
  * host_cg != 0: the caller finished the CG loop itself (exits included), dt = cg->x as it is */

@@ -1635,9 +1635,12 @@ int ipx_cg_shard2_fold_hp(const ipx_cg_args *a, const ipx_shard2_ext *e, void *s
 // radius, the orthogonality threshold -- and stop code 9 when the host must take over: a
 // projection that needs refinement (projections.py:72-78) or the cancellation step
 // (projector.null_space), or no room to the trust-region boundary (:515-526).
+// taken (may be NULL): taken[pj] != 0 when projection pj already had its one correction step on
+// the device (ipx_cg_prime: k_prime_decide) -- like the host's loop after its first step
+// (projector.null_space, k >= 1) only the orthogonality test then stands.
 __device__ void prime_state_body(double *st, const double *red, const ipx_prime_idx &ix,
                                  double tol_in, double radius, double orth_tol, double norm_A,
-                                 double canc2) {
+                                 double canc2, const double *taken = nullptr) {
   double q[7];
   for (int k = 0; k < 7; ++k) q[k] = ix.i[k] >= 0 ? red[ix.i[k]] : 0.0;
   bool bad = false;
@@ -1645,7 +1648,8 @@ __device__ void prime_state_body(double *st, const double *red, const ipx_prime_
     const double nx2 = q[1 + 3 * pj], nz2 = q[2 + 3 * pj], naz2 = q[3 + 3 * pj];
     const double nz = sqrt(nz2), naz = sqrt(naz2);
     const double orth = (nz == 0.0 || norm_A == 0.0) ? 0.0 : naz / (norm_A * nz);
-    if (orth > orth_tol || nz2 < canc2 * nx2) bad = true;
+    const bool stepped = taken && taken[pj] != 0.0;
+    if (orth > orth_tol || (!stepped && nz2 < canc2 * nx2)) bad = true;
   }
   const double rt_g = q[5];
   const double tr_distance = radius - sqrt(q[0]);
@@ -1677,11 +1681,60 @@ struct PrimeFolds {
 // radius_dev / norm_A2_dev (optional): the trust radius and ||A||_F^2 as DEVICE scalars that
 // kernels earlier in the stream have written -- the outer iteration's chain (csrc/sqp.hip), whose
 // tangential radius sqrt(Delta^2 - ||dn||^2) never visits the host.
+// The correction step of a projection on the device (ipx_cg_prime).  After z = x - A'(A A')^-1 A x
+// and t = A z, k_prime_decide folds their partials into red[base], red[base + 2] and decides
+// what the host's loop decides from the same numbers (projector.null_space: orthogonality above
+// the tolerance, or z cancelled below 2^-10 |x|): red[PR_SKIP + pj] = 0 lets the three guarded
+// launches behind it run -- v = (A A')^-1 t, z <- z - A'v, t = A z -- whose partials (cz, ct) the
+// NEXT decide kernel (or the state kernel) folds over red[base], red[base + 2]; taken:
+// red[PR_TAKEN + pj] = 1.  One step per projection; what it does not settle is the host's (9).
+#define PR_SKIP 14
+#define PR_TAKEN 16
+struct PrimeStep {          // one projection's correction: where its partials wait
+  const double *cz, *ct;    // partials of the corrected z (At_ntiles) / of A z (A_ntiles)
+  int ncz, nct, base, pj;
+};
+__device__ void prime_fold_step(double *red, const PrimeStep &c, double *lds) {
+  // (uniform across the block: red[PR_SKIP + pj] was written by an earlier kernel)
+  if (red[PR_SKIP + c.pj] != 0.0) return;
+  const double *parts[4] = {c.cz, c.cz + c.ncz, c.ct, c.ct + c.nct};
+  const int counts[4] = {c.ncz, c.ncz, c.nct, c.nct};
+  double out[4];
+  ipx_sum_partials_multi<4>(parts, counts, lds, out);
+  if (threadIdx.x == 0) {
+    red[c.base] = out[0]; red[c.base + 1] = out[1];
+    red[c.base + 2] = out[2]; red[c.base + 3] = out[3];
+    red[PR_TAKEN + c.pj] = 1.0;
+  }
+  __syncthreads();
+}
+__global__ void __launch_bounds__(IPX_BLOCK)
+k_prime_decide(double *red, const double *pz, int npz, const double *pt, int npt, int base,
+               int xslot, int pj, double orth_tol, double norm_A, double canc2,
+               const double *__restrict__ norm_A2_dev, PrimeStep prev, int have_prev) {
+  __shared__ double lds[4 * (IPX_BLOCK / IPX_WAVE)];
+  if (have_prev) prime_fold_step(red, prev, lds);       // (||x||^2 of this projection: red[xslot])
+  if (norm_A2_dev) norm_A = sqrt(*norm_A2_dev);
+  const double *parts[4] = {pz, pz + npz, pt, pt + npt};
+  const int counts[4] = {npz, npz, npt, npt};
+  double out[4];
+  ipx_sum_partials_multi<4>(parts, counts, lds, out);
+  if (threadIdx.x != 0) return;
+  red[base] = out[0]; red[base + 1] = out[1];
+  red[base + 2] = out[2]; red[base + 3] = out[3];
+  const double nx2 = red[xslot], nz2 = out[0], naz2 = out[2];
+  const double nz = sqrt(nz2), naz = sqrt(naz2);
+  const double orth = (nz == 0.0 || norm_A == 0.0) ? 0.0 : naz / (norm_A * nz);
+  const bool need = orth > orth_tol || nz2 < canc2 * nx2;
+  red[PR_SKIP + pj] = need ? 0.0 : 1.0;
+  red[PR_TAKEN + pj] = 0.0;
+}
+
 __global__ void __launch_bounds__(IPX_BLOCK)
 k_cg_prime_state_folds(double *st, double *red, PrimeFolds f, ipx_prime_idx ix, double tol_in,
                        double radius, double orth_tol, double norm_A, double canc2,
                        const double *__restrict__ radius_dev,
-                       const double *__restrict__ norm_A2_dev) {
+                       const double *__restrict__ norm_A2_dev, PrimeStep last, int have_last) {
   if (radius_dev) radius = *radius_dev;
   if (norm_A2_dev) norm_A = sqrt(*norm_A2_dev);
   // all twelve sums (six jobs x [sum y^2 | sum x y]) in one pass: the loads of every array in
@@ -1698,14 +1751,20 @@ k_cg_prime_state_folds(double *st, double *red, PrimeFolds f, ipx_prime_idx ix, 
     counts[2 * j] = counts[2 * j + 1] = on ? f.count[j] : 0;
   }
   double out[12];
-  ipx_sum_partials_multi<12>(parts, counts, lds, out);
-  if (threadIdx.x == 0) {
+  if (f.n > 0) {
+    ipx_sum_partials_multi<12>(parts, counts, lds, out);
+    if (threadIdx.x == 0) {
 #pragma unroll
-    for (int j = 0; j < 6; ++j)
-      if (j < f.n) { red[f.slot[j]] = out[2 * j]; red[f.slot[j] + 1] = out[2 * j + 1]; }
+      for (int j = 0; j < 6; ++j)
+        if (j < f.n) { red[f.slot[j]] = out[2 * j]; red[f.slot[j] + 1] = out[2 * j + 1]; }
+    }
+    __syncthreads();
   }
+  if (have_last) prime_fold_step(red, last, lds);
   // (thread 0 reads back what it wrote itself)
-  if (threadIdx.x == 0) prime_state_body(st, red, ix, tol_in, radius, orth_tol, norm_A, canc2);
+  if (threadIdx.x == 0)
+    prime_state_body(st, red, ix, tol_in, radius, orth_tol, norm_A, canc2,
+                     have_last ? red + PR_TAKEN : nullptr);
 }
 
 int ipx_cg_prime_state(double *state, const double *red, const int32_t *idx7, double tol_in,
@@ -1771,9 +1830,52 @@ static int prime_project(const ipx_cg_args *a, const ipx_csr_view &A, const ipx_
   return R.spmv(A, z, 1.0, nullptr, 0.0, nullptr, a->t, base + 2, st);
 }
 
+// ... and with its correction step decided and taken on the device (k_prime_decide): the
+// projection's own partials are folded by the decide kernel (they leave R.f), the step's wait in
+// two more regions for the next decide / the state kernel (`step` out; `prev`: the projection
+// before this one, whose step this decide kernel folds first).  z - A'v' with v' = (A A')^-1 A z
+// is the same expression for z and for -z (every launch an odd function of its input, bit for
+// bit), so the negated second projection needs no sign.
+static int prime_project_stepped(const ipx_cg_args *a, const ipx_csr_view &A,
+                                 const ipx_csr_view &At, const double *x, double *z, PrimeRed &R,
+                                 int base, int xslot, int pj, bool have_xnorm, double sign,
+                                 double orth_tol, double norm_A, const double *norm_A2_dev,
+                                 double canc2, const PrimeStep *prev, PrimeStep *step,
+                                 hipStream_t st) {
+  const int n0 = R.f.n;
+  int rc = prime_project(a, A, At, x, z, R, base, have_xnorm, sign, st);
+  if (rc) return rc;
+  // (the two regions this projection just registered: folded here, not by the state kernel)
+  const double *pz = R.f.part[n0], *pt = R.f.part[n0 + 1];
+  const int npz = R.f.count[n0], npt = R.f.count[n0 + 1];
+  R.f.n = n0;
+  hipLaunchKernelGGL(k_prime_decide, dim3(1), dim3(IPX_BLOCK), 0, st, R.red, pz, npz, pt, npt, base,
+                     xslot, pj, orth_tol, norm_A, canc2, norm_A2_dev, prev ? *prev : PrimeStep{},
+                     prev ? 1 : 0);
+  IPX_CHECK_LAUNCH();
+  const double *skip = R.red + PR_SKIP + pj;
+  if (a->solver_kind == 1)
+    rc = ipx_boxschur_solve((const ipx_boxschur_args *)a->banded, a->t, a->v, nullptr, nullptr, skip,
+                            st);
+  else
+    rc = ipx_banded_solve_guarded(a->banded, a->t, a->v, skip, st);
+  if (rc) return rc;
+  double *cz = R.ws + R.off;
+  R.off += 2 * (int64_t)At.ntiles;
+  double *ct = R.ws + R.off;
+  R.off += 2 * (int64_t)A.ntiles;
+  rc = ipx_spmv_launch(At, a->v, -1.0, nullptr, 1.0, z, z, cz, skip, st);
+  if (rc) return rc;
+  rc = ipx_spmv_launch(A, z, 1.0, nullptr, 0.0, nullptr, a->t, ct, skip, st);
+  if (rc) return rc;
+  *step = PrimeStep{cz, ct, At.ntiles, A.ntiles, base, pj};
+  return IPX_OK;
+}
+
 int64_t ipx_cg_prime_ws_doubles(const ipx_cg_args *a, int32_t A_ntiles) {
   if (!a) return -1;
-  return 2 * (3 * a->At_ntiles + 2 * (int64_t)A_ntiles + a->H_ntiles) + 4096;
+  // (three products by A', two by A, one by H; + the two correction steps' A' and A products)
+  return 2 * (5 * a->At_ntiles + 4 * (int64_t)A_ntiles + a->H_ntiles) + 4096;
 }
 
 int ipx_cg_prime(const ipx_cg_args *a, const int32_t *A_tiles, int32_t A_ntiles, const double *c,
@@ -1821,17 +1923,30 @@ int ipx_cg_prime_dev(const ipx_cg_args *a, const int32_t *A_tiles, int32_t A_nti
   } else if (hipMemsetAsync(a->x, 0, (size_t)a->n * sizeof(double), st) != hipSuccess) {
     return IPX_ELAUNCH;
   }
-  rc = prime_project(a, A, At, t, a->r, R, 0, b != nullptr, 1.0, st);
-  if (rc) return rc;
-  // g0 = Z r0 lands in p as -g0 (the first direction); its input norm ||r0||^2 is red[0]
-  rc = prime_project(a, A, At, a->r, a->p, R, 6, true, -1.0, st);
-  if (rc) return rc;
+  const double canc2 = cancellation * cancellation;
+  PrimeStep s1{}, s2{};
+  if (b) {
+    // (||t||^2 = red[4] comes out of the H x0 + c product's partials, folded by the state
+    // kernel: the first projection's decision would need it earlier -- no step on this path)
+    rc = prime_project(a, A, At, t, a->r, R, 0, true, 1.0, st);
+    if (rc) return rc;
+    rc = prime_project(a, A, At, a->r, a->p, R, 6, true, -1.0, st);
+    if (rc) return rc;
+  } else {
+    rc = prime_project_stepped(a, A, At, t, a->r, R, 0, 4, 0, false, 1.0, orth_tol, norm_A,
+                               norm_A2_dev, canc2, nullptr, &s1, st);
+    if (rc) return rc;
+    // g0 = Z r0 lands in p as -g0 (the first direction); its input norm ||r0||^2 is red[0]
+    rc = prime_project_stepped(a, A, At, a->r, a->p, R, 6, 0, 1, true, -1.0, orth_tol, norm_A,
+                               norm_A2_dev, canc2, &s1, &s2, st);
+    if (rc) return rc;
+  }
   const int32_t idx_b[7] = {12, 4, 0, 2, 0, 6, 8}, idx_0[7] = {-1, 4, 0, 2, 0, 6, 8};
   ipx_prime_idx ix;
   for (int k = 0; k < 7; ++k) ix.i[k] = (b ? idx_b : idx_0)[k];
   hipLaunchKernelGGL(k_cg_prime_state_folds, dim3(1), dim3(IPX_BLOCK), 0, st, a->state, red, R.f,
-                     ix, tol_in, radius, orth_tol, norm_A, cancellation * cancellation, radius_dev,
-                     norm_A2_dev);
+                     ix, tol_in, radius, orth_tol, norm_A, canc2, radius_dev, norm_A2_dev, s2,
+                     b ? 0 : 1);
   IPX_CHECK_LAUNCH();
   rc = launch_hp(a, nullptr, st);
   if (rc || first_end == 0) return rc;

@@ -168,20 +168,53 @@ constexpr int RU = 4;                     // elements per lane and trip of the v
 static int sq_grid(int64_t n) { return ipx_grid_for(n, RB * RU); }
 
 // ---- vector kernels ---------------------------------------------------------------------------
-// violations of v against [f lb, f ub] (either bound may be NULL): partial counts
+// the Newton point's sum of squares (csrc/vec.hip RedNorms' accumulation: the bits of the host
+// form's norm) and its violations of [f lb, f ub] (either bound may be NULL):
+// part[block] / viol[block]
 __global__ void __launch_bounds__(RB)
-k_sq_boxcount(int64_t n, const double *__restrict__ v, const double *__restrict__ lb,
-              const double *__restrict__ ub, double f, double *__restrict__ part) {
+k_sq_newton_check(int64_t n, const double *__restrict__ v, const double *__restrict__ lb,
+                  const double *__restrict__ ub, double f, double *__restrict__ part,
+                  double *__restrict__ viol) {
   __shared__ double lds[RB / IPX_WAVE];
-  double cnt = 0.0;
+  double cnt = 0.0, s = 0.0;
   const int64_t stride = (int64_t)gridDim.x * RB;
   for (int64_t i = (int64_t)blockIdx.x * RB + threadIdx.x; i < n; i += stride) {
     const double t = v[i];
-    const double lo = lb ? f * lb[i] : -HUGE_VAL, hi = ub ? f * ub[i] : HUGE_VAL;
-    cnt += ((lo <= t) && (t <= hi)) ? 0.0 : 1.0;
+    s += t * t;
+    if (lb || ub) {
+      const double lo = lb ? f * lb[i] : -HUGE_VAL, hi = ub ? f * ub[i] : HUGE_VAL;
+      cnt += ((lo <= t) && (t <= hi)) ? 0.0 : 1.0;
+    }
   }
+  const double a = ipx_block_reduce<IPX_SUM>(s, lds);
   const double r = ipx_block_reduce<IPX_SUM>(cnt, lds);
-  if (threadIdx.x == 0) part[blockIdx.x] = r;
+  if (threadIdx.x == 0) { part[blockIdx.x] = a; viol[blockIdx.x] = r; }
+}
+
+// two reductions of different lengths in one launch, each with the grid and the accumulation
+// its stand-alone kernel has (csrc/vec.hip RedDot / RedNorms: same bits): blocks [0, g1) the
+// first, [g1, g1 + g2) the second.  DOTS: sum x y; else sum x^2 (y unused).
+template <bool DOT1, bool DOT2>
+__global__ void __launch_bounds__(RB)
+k_sq_two_sums(int64_t n1, const double *__restrict__ x1, const double *__restrict__ y1, int g1,
+              double *__restrict__ part1, int64_t n2, const double *__restrict__ x2,
+              const double *__restrict__ y2, int g2, double *__restrict__ part2,
+              const double *__restrict__ guard) {
+  __shared__ double lds[RB / IPX_WAVE];
+  if (guard && *guard != 0.0) return;
+  const bool second = (int)blockIdx.x >= g1;
+  const int b = second ? blockIdx.x - g1 : blockIdx.x, G = second ? g2 : g1;
+  const int64_t n = second ? n2 : n1;
+  const double *x = second ? x2 : x1, *y = second ? y2 : y1;
+  const bool dot = second ? DOT2 : DOT1;
+  double s = 0.0;
+  const int64_t stride = (int64_t)G * RB;
+  for (int64_t i = (int64_t)b * RB + threadIdx.x; i < n; i += stride) {
+    const double t = x[i];
+    s += dot ? t * y[i] : t * t;
+  }
+  const double r = ipx_block_reduce<IPX_SUM>(s, lds);
+  if (threadIdx.x == 0) (second ? part2 : part1)[b] = r;
 }
 
 // sum of squares + max |.| partials (part[block], part[grid + block])
@@ -318,6 +351,158 @@ k_sq_step_vectors(int64_t n, int use_exit, const double *__restrict__ q,
   r = ipx_block_reduce<IPX_SUM>(s_out, lds); if (threadIdx.x == 0) part[3 * g + b] = r;
 }
 
+// ---- the dogleg proper on the device (qp_subproblem.py:375-413) -------------------------------
+// Runs behind k_sq_after_newton when the Newton point was turned down (every kernel returns at
+// once when q[SQ_NORMAL_KIND] != 0).  g = A'b and A g come from two guarded SpMVs whose epilogue
+// partials give g.g and (A g).(A g).
+//
+// k_sq_dogleg_reduce: cauchy = coef g with coef = -(g.g) / (Ag.Ag) (:380), and the seven sums of
+// box_sphere_intersections for the three segments the routine may search (:386-407) in ONE pass
+// over g and the Newton point: (cauchy, newton - cauchy), (0, cauchy), (0, newton) -- 18 partial
+// arrays (6 per segment, csrc/vec.hip RedBoxSphere's accumulation and order).
+struct sq_seg { double a0, a1, a2, a3, a4, a5; };
+__device__ __forceinline__ void sq_seg_init(sq_seg &s) {
+  s.a0 = s.a1 = s.a2 = 0.0; s.a3 = -HUGE_VAL; s.a4 = HUGE_VAL; s.a5 = 0.0;
+}
+__device__ __forceinline__ void sq_seg_step(sq_seg &s, double zi, double di, double lo, double hi) {
+  s.a0 += di * di; s.a1 += zi * di; s.a2 += zi * zi;
+  if (di == 0.0) {
+    s.a5 += (zi < lo || zi > hi) ? 1.0 : 0.0;
+  } else {
+    const double tl = (lo - zi) / di, tu = (hi - zi) / di;
+    s.a3 = fmax(s.a3, fmin(tl, tu));
+    s.a4 = fmin(s.a4, fmax(tl, tu));
+  }
+}
+__device__ __forceinline__ void sq_seg_store(const sq_seg &s, double *lds, double *part, int g) {
+  const int b = blockIdx.x;
+  double r;
+  r = ipx_block_reduce<IPX_SUM>(s.a0, lds); if (threadIdx.x == 0) part[b] = r;
+  r = ipx_block_reduce<IPX_SUM>(s.a1, lds); if (threadIdx.x == 0) part[g + b] = r;
+  r = ipx_block_reduce<IPX_SUM>(s.a2, lds); if (threadIdx.x == 0) part[2 * g + b] = r;
+  r = ipx_block_reduce<IPX_MAX>(s.a3, lds); if (threadIdx.x == 0) part[3 * g + b] = r;
+  r = ipx_block_reduce<IPX_MIN>(s.a4, lds); if (threadIdx.x == 0) part[4 * g + b] = r;
+  r = ipx_block_reduce<IPX_SUM>(s.a5, lds); if (threadIdx.x == 0) part[5 * g + b] = r;
+}
+__device__ __forceinline__ void sq_seg_fold(const double *part, int g, double *lds, double *r7) {
+  r7[0] = ipx_sum_partials<IPX_SUM>(part, g, lds);
+  r7[1] = ipx_sum_partials<IPX_SUM>(part + g, g, lds);
+  r7[2] = ipx_sum_partials<IPX_SUM>(part + 2 * g, g, lds);
+  r7[3] = ipx_sum_partials<IPX_MAX>(part + 3 * g, g, lds);
+  r7[4] = ipx_sum_partials<IPX_MIN>(part + 4 * g, g, lds);
+  r7[5] = ipx_sum_partials<IPX_SUM>(part + 5 * g, g, lds);
+  r7[6] = 0.0;
+}
+
+__global__ void __launch_bounds__(RB)
+k_sq_dogleg_reduce(int64_t n, double *__restrict__ q, const double *__restrict__ p_gg, int n_gg,
+                   const double *__restrict__ p_ag, int n_ag, const double *__restrict__ g,
+                   const double *__restrict__ newton, const double *__restrict__ lb,
+                   const double *__restrict__ ub, double bf, double *__restrict__ part) {
+  __shared__ double lds[2 * (RB / IPX_WAVE)];
+  if (q[SQ_NORMAL_KIND] != 0.0) return;
+  const double *parts[2] = {p_gg, p_ag};
+  const int counts[2] = {n_gg, n_ag};
+  double s2[2];
+  ipx_sum_partials_multi<2>(parts, counts, lds, s2);
+  const double coef = -s2[0] / s2[1];                                   // :380
+  if (blockIdx.x == 0 && threadIdx.x == 0) q[SQ_DOGLEG] = coef;
+  sq_seg s1, sb, sc;
+  sq_seg_init(s1); sq_seg_init(sb); sq_seg_init(sc);
+  const int64_t stride = (int64_t)gridDim.x * RB;
+  for (int64_t i = (int64_t)blockIdx.x * RB + threadIdx.x; i < n; i += stride) {
+    const double ni = newton[i], ci = coef * g[i];
+    const double lo = lb ? bf * lb[i] : -HUGE_VAL, hi = ub ? bf * ub[i] : HUGE_VAL;
+    sq_seg_step(s1, ci, ni - ci, lo, hi);
+    sq_seg_step(sb, 0.0, ci, lo, hi);
+    sq_seg_step(sc, 0.0, ni, lo, hi);
+  }
+  const int G = gridDim.x;
+  sq_seg_store(s1, lds, part, G);
+  sq_seg_store(sb, lds, part + 6 * (int64_t)G, G);
+  sq_seg_store(sc, lds, part + 12 * (int64_t)G, G);
+}
+
+// the three intervals and what they make of the two candidate points (:386-407):
+//   x1 = cauchy + alpha (newton - cauchy)   when that segment meets the region, else alpha cauchy
+//   x2 = alpha newton
+// as a mode and two step lengths for k_sq_dogleg_points
+__global__ void __launch_bounds__(RB)
+k_sq_dogleg_decide(double *__restrict__ q, const double *__restrict__ part, int G, double radius) {
+  __shared__ double lds[RB / IPX_WAVE];
+  if (q[SQ_NORMAL_KIND] != 0.0) return;
+  double r1[7], r2[7], r3[7];
+  sq_seg_fold(part, G, lds, r1);
+  sq_seg_fold(part + 6 * (int64_t)G, G, lds, r2);
+  sq_seg_fold(part + 12 * (int64_t)G, G, lds, r3);
+  if (threadIdx.x != 0) return;
+  const sq_interval i1 = sq_box_sphere(r1, radius, false);
+  const sq_interval i2 = sq_box_sphere(r2, radius, false);
+  const sq_interval i3 = sq_box_sphere(r3, radius, false);
+  q[SQ_DOGLEG + 1] = i1.hit ? 1.0 : 0.0;
+  q[SQ_DOGLEG + 2] = i1.hit ? i1.tb : i2.tb;
+  q[SQ_DOGLEG + 3] = i3.tb;
+}
+
+__global__ void __launch_bounds__(RB)
+k_sq_dogleg_points(int64_t n, const double *__restrict__ q, const double *__restrict__ g,
+                   const double *__restrict__ newton, double *__restrict__ x1,
+                   double *__restrict__ x2) {
+  if (q[SQ_NORMAL_KIND] != 0.0) return;
+  const double coef = q[SQ_DOGLEG], a1 = q[SQ_DOGLEG + 2], a3 = q[SQ_DOGLEG + 3];
+  const bool along = q[SQ_DOGLEG + 1] != 0.0;
+  const int64_t stride = (int64_t)gridDim.x * RB;
+  for (int64_t i = (int64_t)blockIdx.x * RB + threadIdx.x; i < n; i += stride) {
+    const double ni = newton[i], ci = coef * g[i];
+    x1[i] = along ? ci + a1 * (ni - ci) : 0.0 + a1 * ci;     // :388 / :393 (origin + alpha cauchy)
+    x2[i] = 0.0 + a3 * ni;                                   // :405
+  }
+}
+
+// the smaller ||A x + b|| wins (strictly; a tie is x2's, :410-413); dn <- the winner, ||dn||^2
+__global__ void __launch_bounds__(RB)
+k_sq_dogleg_take(int64_t n, double *__restrict__ q, const double *__restrict__ p1, int n1,
+                 const double *__restrict__ p2, int n2, const double *__restrict__ x1,
+                 const double *__restrict__ x2, double *__restrict__ dn,
+                 double *__restrict__ part) {
+  __shared__ double lds[2 * (RB / IPX_WAVE)];
+  if (q[SQ_NORMAL_KIND] != 0.0) return;
+  const double *parts[2] = {p1, p2};
+  const int counts[2] = {n1, n2};
+  double s2[2];
+  ipx_sum_partials_multi<2>(parts, counts, lds, s2);
+  const bool first = sqrt(s2[0]) < sqrt(s2[1]);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    q[SQ_DOGLEG + 4] = first ? 1.0 : 2.0;
+    q[SQ_DOGLEG + 5] = sqrt(s2[0]);
+    q[SQ_DOGLEG + 6] = sqrt(s2[1]);
+  }
+  double s = 0.0, mx = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * RB;
+  for (int64_t i = (int64_t)blockIdx.x * RB + threadIdx.x; i < n; i += stride) {
+    const double t = first ? x1[i] : x2[i];
+    dn[i] = t;
+    s += t * t;
+    mx = fmax(mx, fabs(t));
+  }
+  const double a = ipx_block_reduce<IPX_SUM>(s, lds);
+  const double b = ipx_block_reduce<IPX_MAX>(mx, lds);
+  if (threadIdx.x == 0) { part[blockIdx.x] = a; part[gridDim.x + blockIdx.x] = b; }
+}
+
+__global__ void __launch_bounds__(RB)
+k_sq_after_dogleg(const double *__restrict__ p_nn, int n_nn, double radius,
+                  double *__restrict__ q) {
+  __shared__ double lds[RB / IPX_WAVE];
+  if (q[SQ_NORMAL_KIND] != 0.0) return;
+  const double nn2 = ipx_sum_partials<IPX_SUM>(p_nn, n_nn, lds);
+  if (threadIdx.x != 0) return;
+  const double norm_dn = sqrt(nn2);
+  q[SQ_NORM_DN] = norm_dn;
+  q[SQ_NORMAL_KIND] = 2.0;
+  q[SQ_RADIUS_T] = sqrt(radius * radius - norm_dn * norm_dn);
+}
+
 // ---- decide kernels (one workgroup each) ----------------------------------------------------
 // after the Newton point: ||dn||, inside the box and the ball? the tangential radius
 __global__ void __launch_bounds__(RB)
@@ -357,7 +542,7 @@ k_sq_model(const double *__restrict__ p_vec, int g_vec, const double *__restrict
            const double *__restrict__ p_ad, int n_ad, const double *__restrict__ cg_state,
            double penalty, double f, double norm_b, double *__restrict__ q) {
   __shared__ double lds[5 * (RB / IPX_WAVE)];
-  const double *parts[5] = {p_vec, p_vec + g_vec, p_vec + 2 * g_vec, p_hd + n_hd, p_ad};
+  const double *parts[5] = {p_vec, p_vec + g_vec, p_vec + 2 * g_vec, p_hd, p_ad};
   const int counts[5] = {g_vec, g_vec, g_vec, n_hd, n_ad};
   double out[5];
   ipx_sum_partials_multi<5>(parts, counts, lds, out);
@@ -423,8 +608,7 @@ int ipx_sqp_block_size(void) { return SQ_SIZE; }
 int64_t ipx_sqp_part_doubles(const ipx_sqp_args *s) {
   if (!s || !s->cg) return -1;
   const int64_t g = sq_grid(s->n), gm = sq_grid(s->m);
-  return 4 * g + 6 * g + 2 * s->cg->H_ntiles + 2 * s->A_ntiles + 2 * s->cg->At_ntiles + 2 * g +
-         2 * gm + g + 64;
+  return 4 * g + 6 * g + g + gm + 2 * g + 2 * gm + g + 18 * g + 64;
 }
 
 void ipx_sqp_model_host(double *q) { sqp_model(q); }
@@ -442,7 +626,7 @@ void ipx_sqp_box_sphere_host(const double *sums7, double radius, int entire_line
 namespace {
 
 struct PartLayout {
-  double *vec, *exit, *hd, *ad, *nn, *viol, *bn, *tn, *tail;
+  double *vec, *exit, *hd, *ad, *viol, *bn, *tn, *dog, *tail;
   int g, gm;
 };
 static PartLayout layout(const ipx_sqp_args *s) {
@@ -451,12 +635,12 @@ static PartLayout layout(const ipx_sqp_args *s) {
   double *p = s->part;
   L.vec = p;  p += 4 * (int64_t)L.g;
   L.exit = p; p += 6 * (int64_t)L.g;
-  L.hd = p;   p += 2 * s->cg->H_ntiles;
-  L.ad = p;   p += 2 * s->A_ntiles;
-  L.nn = p;   p += 2 * s->cg->At_ntiles;
+  L.hd = p;   p += L.g;
+  L.ad = p;   p += L.gm;
   L.tn = p;   p += 2 * (int64_t)L.g;        // norms of an n-vector (refresh: c + A'v; given dn)
   L.bn = p;   p += 2 * (int64_t)L.gm;       // norms of an m-vector (b, b_next)
   L.viol = p; p += L.g;
+  L.dog = p;  p += 18 * (int64_t)L.g;       // the dogleg's three segments
   L.tail = p;
   return L;
 }
@@ -496,12 +680,17 @@ int ipx_sqp_model(const ipx_sqp_args *s, double penalty, double f, double norm_b
                      s->dn, a->x, a->p,
                      a->lb, a->ub, s->x, s->c, s->scale, s->d, s->x_next, L.vec);
   IPX_CHECK_LAUNCH();
-  int rc = ipx_spmv_launch(Hm, s->d, 1.0, a->H_diag, 0.0, nullptr, s->Hd, L.hd, nullptr, st);
+  int rc = ipx_spmv_launch(Hm, s->d, 1.0, a->H_diag, 0.0, nullptr, s->Hd, nullptr, nullptr, st);
   if (rc) return rc;
-  rc = ipx_spmv_launch(A, s->d, 1.0, nullptr, 1.0, s->b, s->Ad, L.ad, nullptr, st);
+  rc = ipx_spmv_launch(A, s->d, 1.0, nullptr, 1.0, s->b, s->Ad, nullptr, nullptr, st);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_sq_model, dim3(1), dim3(RB), 0, st, L.vec, L.g, L.hd, (int)a->H_ntiles, L.ad,
-                     (int)s->A_ntiles, a->state, penalty, f, norm_b, s->q);
+  // (H d).d and ||A d + b||^2 summed as the host form's dot / norm kernels sum them (the
+  // products' own epilogue sums come in tile order: other bits), one launch for both
+  hipLaunchKernelGGL((k_sq_two_sums<true, false>), dim3(L.g + L.gm), dim3(RB), 0, st, s->n, s->Hd,
+                     s->d, L.g, L.hd, s->m, s->Ad, s->Ad, L.gm, L.ad, nullptr);
+  IPX_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_sq_model, dim3(1), dim3(RB), 0, st, L.vec, L.g, L.hd, L.g, L.ad, L.gm,
+                     a->state, penalty, f, norm_b, s->q);
   IPX_CHECK_LAUNCH();
   return IPX_OK;
 }
@@ -510,10 +699,11 @@ int ipx_sqp_model(const ipx_sqp_args *s, double penalty, double f, double norm_b
 // device (SQ_NORMAL_KIND 1; 0: the host runs the dogleg and calls again with have_dn = 1).
 // Then c_t, the shifted bounds, the priming of the projected CG with the radius of the block,
 // iterations [0, first_end) and ipx_sqp_model.  box_factor / tr_factor: :43-44 (0.5, 0.8).
-int ipx_sqp_front(const ipx_sqp_args *s, int have_dn, double radius, double penalty, double f,
-                  double norm_b, double tr_factor, double box_factor, double tol_in,
-                  double norm_A, int32_t first_end, void *stream) {
+int ipx_sqp_front(const ipx_sqp_args *s, int have_dn, int with_dogleg, double radius,
+                  double penalty, double f, double norm_b, double tr_factor, double box_factor,
+                  double tol_in, double norm_A, int32_t first_end, void *stream) {
   if (!s || !s->cg || !s->q || !s->part || !s->dn || !s->ct || s->m <= 0) return IPX_EINVAL;
+  if (with_dogleg && (!s->d || !s->Hd || !s->Ad)) return IPX_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const ipx_cg_args *a = s->cg;
   const PartLayout L = layout(s);
@@ -526,17 +716,53 @@ int ipx_sqp_front(const ipx_sqp_args *s, int have_dn, double radius, double pena
     // newton = -Y b = -A'(A A')^-1 b   (qp_subproblem.py:368)
     rc = solve(a, s->b, a->v, st);
     if (rc) return rc;
-    rc = ipx_spmv_launch(At, a->v, -1.0, nullptr, 0.0, nullptr, s->dn, L.nn, nullptr, st);
+    rc = ipx_spmv_launch(At, a->v, -1.0, nullptr, 0.0, nullptr, s->dn, nullptr, nullptr, st);
     if (rc) return rc;
     const bool boxed = s->lb || s->ub;
-    if (boxed) {
-      hipLaunchKernelGGL(k_sq_boxcount, dim3(L.g), dim3(RB), 0, st, s->n, s->dn, s->lb, s->ub,
-                         box_factor, L.viol);
-      IPX_CHECK_LAUNCH();
-    }
-    hipLaunchKernelGGL(k_sq_after_newton, dim3(1), dim3(RB), 0, st, L.nn, (int)a->At_ntiles, L.viol,
+    hipLaunchKernelGGL(k_sq_newton_check, dim3(L.g), dim3(RB), 0, st, s->n, s->dn, s->lb, s->ub,
+                       box_factor, L.tn, L.viol);
+    IPX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_sq_after_newton, dim3(1), dim3(RB), 0, st, L.tn, L.g, L.viol,
                        boxed ? L.g : 0, radius, tr_factor, s->q);
     IPX_CHECK_LAUNCH();
+    if (with_dogleg) {
+      // the dogleg proper behind it, every launch a no-op when the Newton point stands (the
+      // SpMVs by their guard: *guard != 0 skips; s->ct, s->d, s->Hd, a->t, a->w, s->Ad are free
+      // at this point of the chain)
+      const ipx_csr_view A{(int)s->m, (int)s->n, a->A_rowptr, a->A_colidx, a->A_val, s->A_tiles,
+                           (int)s->A_ntiles};
+      const double *guard = s->q + SQ_NORMAL_KIND;
+      double *g = s->ct, *x1 = s->d, *x2 = s->Hd;
+      rc = ipx_spmv_launch(At, s->b, 1.0, nullptr, 0.0, nullptr, g, nullptr, guard, st);   // :376
+      if (rc) return rc;
+      rc = ipx_spmv_launch(A, g, 1.0, nullptr, 0.0, nullptr, a->w, nullptr, guard, st);  // :379
+      if (rc) return rc;
+      // g.g and (A g).(A g) as the host form's dot kernel sums them
+      hipLaunchKernelGGL((k_sq_two_sums<true, true>), dim3(L.g + L.gm), dim3(RB), 0, st, s->n, g, g,
+                         L.g, L.tn, s->m, a->w, a->w, L.gm, L.bn, guard);
+      IPX_CHECK_LAUNCH();
+      hipLaunchKernelGGL(k_sq_dogleg_reduce, dim3(L.g), dim3(RB), 0, st, s->n, s->q, L.tn, L.g,
+                         L.bn, L.gm, g, s->dn, s->lb, s->ub, box_factor, L.dog);
+      IPX_CHECK_LAUNCH();
+      hipLaunchKernelGGL(k_sq_dogleg_decide, dim3(1), dim3(RB), 0, st, s->q, L.dog, L.g,
+                         tr_factor * radius);
+      IPX_CHECK_LAUNCH();
+      hipLaunchKernelGGL(k_sq_dogleg_points, dim3(L.g), dim3(RB), 0, st, s->n, s->q, g, s->dn, x1,
+                         x2);
+      IPX_CHECK_LAUNCH();
+      rc = ipx_spmv_launch(A, x1, 1.0, nullptr, 1.0, s->b, s->Ad, nullptr, guard, st);
+      if (rc) return rc;
+      rc = ipx_spmv_launch(A, x2, 1.0, nullptr, 1.0, s->b, a->t, nullptr, guard, st);
+      if (rc) return rc;
+      hipLaunchKernelGGL((k_sq_two_sums<false, false>), dim3(2 * L.gm), dim3(RB), 0, st, s->m,
+                         s->Ad, s->Ad, L.gm, L.bn, s->m, a->t, a->t, L.gm, L.bn + L.gm, guard);
+      IPX_CHECK_LAUNCH();
+      hipLaunchKernelGGL(k_sq_dogleg_take, dim3(L.g), dim3(RB), 0, st, s->n, s->q, L.bn, L.gm,
+                         L.bn + L.gm, L.gm, x1, x2, s->dn, L.tn);
+      IPX_CHECK_LAUNCH();
+      hipLaunchKernelGGL(k_sq_after_dogleg, dim3(1), dim3(RB), 0, st, L.tn, L.g, radius, s->q);
+      IPX_CHECK_LAUNCH();
+    }
   } else {
     hipLaunchKernelGGL(k_sq_norms, dim3(L.g), dim3(RB), 0, st, s->n, s->dn, L.tn);
     IPX_CHECK_LAUNCH();

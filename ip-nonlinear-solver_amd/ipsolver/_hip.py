@@ -110,7 +110,8 @@ _SIGNATURES = {
     "ipx_boxschur_project_count": [_P],
     "ipx_banded_status_deferred": [_P, _P, _P],
     "ipx_sqp_block_size": [],
-    "ipx_sqp_front": [_P, _c.c_int, _F64, _F64, _F64, _F64, _F64, _F64, _F64, _F64, _I32, _P],
+    "ipx_sqp_front": [_P, _c.c_int, _c.c_int, _F64, _F64, _F64, _F64, _F64, _F64, _F64, _F64, _I32,
+                      _P],
     "ipx_sqp_model": [_P, _F64, _F64, _F64, _c.c_int, _P],
     "ipx_sqp_judge": [_P, _P, _F64, _P, _P],
     "ipx_sqp_refresh": [_P, _P],
@@ -189,8 +190,10 @@ def load():
 # deployment setting (IPX_SHARD, IPX_SHARD_TRANSPORT=dist).
 # (round 5 removed "no-c16" and "no-diag-merge": their A/Bs are settled -- profiles/r03*, r04* --
 # and the 16-bit index tables / the merged diagonal are what every qualifying pattern gets)
+#   no-step-chain      the outer iteration's stages host-driven (sqp.HostStages) instead of as
+#                      device chains (csrc/sqp.hip)
 DEBUG_FORMS = ("no-fuse", "no-resident", "no-compact-groups", "no-affine-groups", "keep-xn2",
-               "pack-comm", "no-post-tail")
+               "pack-comm", "no-post-tail", "no-step-chain")
 
 
 def debug_form(name):

@@ -857,16 +857,18 @@ def _first_batch(max_iter, operator):
 
 
 def _run_loop(L, pool_key, P, lib, st, n, lb, ub, trust_radius, max_iter, max_infeasible_iter,
-              batch, stats, fast, primed_state=None, release=True):
+              batch, stats, fast, primed_state=None, release=True, first_batch=None):
     """``primed_state``: the state block as somebody already read it behind the batch recorded
     in ``L.enqueued`` (the outer iteration's chain, sqp_chain.py: its one read carries the
     loop's block) -- the first ``read_state`` then costs nothing.  ``release=False``: the loop
     object stays the caller's."""
     pending = [primed_state]
 
+    _fb = first_batch if first_batch else _first_batch(max_iter, L.operator is not None)
+
     class Driver:
         """The single-GPU loop behind ``run_device_loop``."""
-        first_batch = _first_batch(max_iter, L.operator is not None)
+        first_batch = _fb
         batch_cap = 64 if L.operator is None else 8   # (an operator is applied once per
                                                       #  enqueued iteration, stopped or not)
         def iterate(self, it, end):

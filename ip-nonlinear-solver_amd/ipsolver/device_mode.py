@@ -120,8 +120,17 @@ class DeviceRowMap:
         self.m_eq = inverse([(np.arange(self.n_eq), self.eq)], self.n_eq)
         self.m_up = inverse([(up, self.ineq[up])], self.n_ineq)
         self.m_lo = inverse([(lo, self.ineq[lo])], self.n_ineq)
+        # every row an equality with right-hand side 0, in the caller's order (``('equals', 0)``):
+        # the canonical values ARE the callback's, the multipliers the canonical ones -- no
+        # gather, no copy (c - 0 and 1 * v are the same bits)
+        self.all_eq = (self.n_ineq == 0 and self.n_eq == self.fun_len
+                       and np.array_equal(self.eq, np.arange(self.fun_len))
+                       and not np.any(val_eq))
+        self._none = DVec.zeros(0)
 
     def values(self, c):
+        if self.all_eq:
+            return self._none, c
         c_eq = DVec(gather(c.t, self.eq_idx, None, self.val_eq)) if self.n_eq else DVec.zeros(0)
         c_ineq = DVec(gather(c.t, self.ineq_idx, self.sign, self.val_ineq)) if self.n_ineq \
             else DVec.zeros(0)
@@ -148,6 +157,8 @@ class DeviceRowMap:
                          dv._empty(0))
 
     def multipliers(self, v_eq, v_ineq):
+        if self.all_eq:
+            return v_eq
         zero = torch.zeros(1, dtype=_F64, device=ctx().device)
         ve = torch.cat((v_eq.t, zero))
         vi = torch.cat((v_ineq.t, zero))
@@ -297,8 +308,8 @@ class DeviceCanonical:
     def _stack_values(self, pairs):
         ineq = [a for a, _ in pairs if len(a)]
         eq = [b for _, b in pairs if len(b)]
-        return (dv.hstack(ineq) if ineq else DVec.zeros(0),
-                dv.hstack(eq) if eq else DVec.zeros(0))
+        one = lambda parts: parts[0] if len(parts) == 1 else dv.hstack(parts)   # (no copy of one)
+        return (one(ineq) if ineq else DVec.zeros(0), one(eq) if eq else DVec.zeros(0))
 
     def _stack_jacs(self, pairs):
         ineq = [a for a, _ in pairs if a.shape[0]]

@@ -100,6 +100,9 @@ def _symbolic_for(pattern):
     return sym
 
 
+HANDLE_STATS = {"created": 0, "pooled": 0, "deferred": 0}     # banded handles (diagnostics)
+
+
 class BandedNotDecoupled(NotImplementedError):
     """Half bandwidth 5..8 on a long band whose separator blocks do not decouple numerically
     (csrc/banded.hip ipx_banded_create: there is no compiled separator level for them)."""
@@ -108,9 +111,14 @@ class BandedNotDecoupled(NotImplementedError):
 class BandedNormalSolver:
     """(A A')^-1 for sparse A with banded A A' (half bandwidth <= kmax)."""
 
-    def __init__(self, A, chunk=64, col_weights=None):
+    def __init__(self, A, chunk=64, col_weights=None, deferred=None):
         """``col_weights`` (device tensor, one per column of A) factors
-        ``A diag(w) A'`` instead (Schur complements, boxschur.py)."""
+        ``A diag(w) A'`` instead (Schur complements, boxschur.py).  ``deferred`` (an object with
+        a device tensor ``verdict``: the outer iteration's chain, sqp_chain.py): the blocking
+        read that ends a factorization is left out when the handle's previous factorization was
+        clean -- the same verdict is assumed, a kernel checks it on the device
+        (``ipx_banded_status_deferred``) and the caller reads ``verdict`` with its next block
+        (``self.pending`` until then; ``confirm`` reads it on its own)."""
         sym = _symbolic_for(A.pattern)
         kmax = _hip.load().ipx_banded_kmax()
         if sym.k > kmax:
@@ -138,6 +146,7 @@ class BandedNormalSolver:
                 self.handle, self.band = handle, band
                 del self._pool[i]
                 break
+        HANDLE_STATS["pooled" if self.handle is not None else "created"] += 1
         if self.handle is None:
             self.band = torch.empty((self.k + 1) * self.m, dtype=_F64, device=dev)
             self.handle = lib.ipx_banded_create(self.m, self.k, int(chunk))
@@ -147,6 +156,12 @@ class BandedNormalSolver:
         _hip.call("ipx_aat_band_w", self.m, self.k, _p(p.indptr), _p(p.indices), _p(A.val),
                   _p(self.perm), _p(col_weights), _p(self.band), stream_ptr())
         _hip.call("ipx_banded_factor", ctypes.c_void_p(self.handle), _p(self.band), stream_ptr())
+        self.pending, self.ill_conditioned = False, False
+        if deferred is not None and lib.ipx_banded_status_deferred(
+                ctypes.c_void_p(self.handle), deferred.verdict.data_ptr(), stream_ptr()) == 0:
+            self.pending, self._verdict = True, deferred.verdict
+            HANDLE_STATS["deferred"] += 1
+            return
         rc = lib.ipx_banded_status(ctypes.c_void_p(self.handle), stream_ptr())
         if rc == -3:
             raise np.linalg.LinAlgError("Singular Jacobian matrix: A A' is not positive definite")
@@ -215,7 +230,7 @@ class NormalEquationProjector:
     refinements on the benchmark; the counters let tests assert the same).
     """
 
-    def __init__(self, A, solver, orth_tol=1e-12, max_refin=3, row_perm=None):
+    def __init__(self, A, solver, orth_tol=1e-12, max_refin=3, row_perm=None, lazy_norm=False):
         """``row_perm`` (host ints, or None): ``A`` is the caller's matrix with its rows taken in
         this order (``A = A_caller[row_perm]``: the order in which A A' is banded, see
         ``projections``).  Z does not see the order of the rows; LS returns its multipliers in
@@ -231,8 +246,30 @@ class NormalEquationProjector:
             dev = ctx().device
             self.row_perm = torch.from_numpy(np.ascontiguousarray(row_perm, dtype=np.int32)).to(dev)
             self._row_iperm = torch.from_numpy(inv).to(dev)
-        self.norm_A = A.frobenius_norm() if self.m > 0 else 0.0
+        # ||A||_F: computed on first use (a blocking read) -- or handed over by the outer
+        # iteration's chain, which folds it into the block it reads anyway (norm_partials)
+        self._norm_A = None if (lazy_norm and self.m > 0) else \
+            (A.frobenius_norm() if self.m > 0 else 0.0)
         self.stats = {"solves": 0, "refinements": 0, "cancellation_steps": 0}
+
+    @property
+    def norm_A(self):
+        if self._norm_A is None:
+            self._norm_A = self.A.frobenius_norm()
+        return self._norm_A
+
+    @norm_A.setter
+    def norm_A(self, value):
+        self._norm_A = value
+
+    def norm_partials(self):
+        """First stage of ``A.frobenius_norm()`` enqueued: (partials, count) -- the fold
+        (ipx_sum_partials' order: the bits of the blocking form) is the reader's."""
+        val = self.A.val
+        g = dv._reduce_grid(val.numel())
+        part = dv._empty(2 * g)
+        _hip.call("ipx_norms_partials", val.numel(), _p(val), _p(part), stream_ptr())
+        return part, g
 
     # -- reference projections.py:23-55, with ||A z|| from the fused SpMV epilogue
     def _orthogonality(self, z):
@@ -589,7 +626,7 @@ def as_device_matrix(A):
     return DeviceDense.from_host(np.asarray(A, dtype=float))
 
 
-def normal_solver_for(A):
+def normal_solver_for(A, deferred=None):
     """The ``(A A')^-1`` solver ``projections`` picks for a full-row-rank device matrix."""
     from .dense import DenseNormalSolver, DeviceDense
     if isinstance(A, DeviceDense):
@@ -607,7 +644,7 @@ def normal_solver_for(A):
     k = _symbolic_for(A.pattern).k
     if k <= kmax:
         try:
-            return BandedNormalSolver(A)
+            return BandedNormalSolver(A, deferred=deferred)
         except BandedNotDecoupled:
             # Half bandwidths 5-8 on a long band run the single-launch decoupled solve (the
             # separator system, half bandwidth 2k-1, is only formed to test that its blocks
@@ -659,7 +696,7 @@ def _rows_in_order(A, perm):
     return sel.apply(A)
 
 
-def projections(A, method=None, orth_tol=1e-12, max_refin=3, tol=1e-15):
+def projections(A, method=None, orth_tol=1e-12, max_refin=3, tol=1e-15, deferred=None):
     """Device counterpart of ``projections`` (projections.py:290-406).
 
     ``A`` is a DeviceCSR / DeviceDense (or a scipy / numpy matrix, uploaded).
@@ -685,13 +722,30 @@ def projections(A, method=None, orth_tol=1e-12, max_refin=3, tol=1e-15):
     key = (method, orth_tol, max_refin, tol, version)
     cached = getattr(A, "_ipx_projections", None)
     if cached is not None and version is not None and cached[0] == key and cached[2] is t:
-        return cached[1]
-    out = _projections(A, method, orth_tol, max_refin, tol)
+        # (a caller that cannot take a pending verdict along gets it settled first)
+        if deferred is not None or confirm(A, cached[1]):
+            return cached[1]
+    out = _projections(A, method, orth_tol, max_refin, tol, deferred)
     try:
         A._ipx_projections = (key, out, t)
     except AttributeError:
         pass
     return out
+
+
+def confirm(A, ops):
+    """Settle a factorization whose verdict is still pending (``BandedNormalSolver.pending``)
+    by a blocking read of its own; a verdict that differs from the assumed one forgets the
+    factorization (the next ``projections(A)`` factors again, blocking).  True: ``ops`` stand."""
+    P = getattr(ops[0], "projector", None)
+    solver = getattr(P, "solver", None)
+    if solver is None or not getattr(solver, "pending", False):
+        return True
+    bad = dv.read_doubles(solver._verdict, 1)[0] != 0
+    solver.pending = False
+    if bad:
+        invalidate(A)
+    return not bad
 
 
 def invalidate(A):
@@ -712,7 +766,7 @@ def _values_version(A):
     return t, getattr(t, "_version", None)
 
 
-def _projections(A, method, orth_tol, max_refin, tol):
+def _projections(A, method, orth_tol, max_refin, tol, deferred=None):
     from .dense import DenseNormalSolver
     sparse = isinstance(A, DeviceCSR)
     if sparse:
@@ -735,7 +789,8 @@ def _projections(A, method, orth_tol, max_refin, tol):
             row_perm = _banded_row_order(A)
             if row_perm is not None:
                 A = _rows_in_order(A, row_perm)
-        solver = None if m == 0 else normal_solver_for(A)
+        solver = None if m == 0 else (normal_solver_for(A) if deferred is None
+                                      else normal_solver_for(A, deferred))
         inner = getattr(solver, "inner", solver)           # (box-Schur: its banded Schur solve)
         if getattr(inner, "ill_conditioned", False):
             if m * n <= SVDProjector.MAX_ELEMENTS:
@@ -749,4 +804,5 @@ def _projections(A, method, orth_tol, max_refin, tol):
              "Singular Jacobian matrix. Using SVD decomposition to perform the "
              "factorizations.")
         return SVDProjector(A_caller, orth_tol, max_refin, tol).operators()
-    return NormalEquationProjector(A, solver, orth_tol, max_refin, row_perm=row_perm).operators()
+    return NormalEquationProjector(A, solver, orth_tol, max_refin, row_perm=row_perm,
+                                   lazy_norm=deferred is not None).operators()

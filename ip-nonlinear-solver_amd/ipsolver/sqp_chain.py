@@ -46,7 +46,8 @@ class ChainArgs(ctypes.Structure):
 
 
 STATS = {"fronts": 0, "host_doglegs": 0, "host_cg": 0, "prime_retries": 0, "refreshes": 0,
-         "deferred_factorizations": 0, "verdict_misses": 0, "host_iterations": 0}
+         "deferred_factorizations": 0, "verdict_misses": 0, "host_iterations": 0,
+         "settles_reused": 0}
 
 
 def _block_from(values):
@@ -93,10 +94,13 @@ class StepChain:
         self.ubt = z(n) if has_ub else None
         self.Ad = z(m)
         self.q = z(SIZE)
-        self.red = z(16)
+        self.red = z(24)
         self.verdict = z(2)
         self.part = None
         self.anorm = None
+        self.rargs = None
+        self.last_niter = (3, 3)     # (CG iterations of the last two calls: size the next first batch)
+        self.expect_dogleg = True    # (the last normal step was not the Newton point)
         self.args = ChainArgs()
         a = self.args
         a.n, a.m = n, m
@@ -151,13 +155,51 @@ class StepChain:
         self.keep = (L, P, x, c, b, lb, ub, scale, x_next, v_out)
 
     def read(self):
-        """The block: ONE blocking read."""
-        return dv.read_doubles(self.q, SIZE)
+        """The block: ONE blocking read (a host copy the decision functions can work on)."""
+        return _block_from(dv.read_doubles(self.q, SIZE))
 
-    def front(self, have_dn, radius, penalty, f, norm_b, norm_A, first_end):
+    def bind_refresh(self, P, c, b, v_out):
+        """Operands of ``ipx_sqp_refresh``: the Jacobian, its transpose and the solver of the
+        projector, in a CG argument block of this object's own (no Hessian yet at this point
+        of the outer iteration)."""
+        lib = _hip.load()
+        if self.rargs is None:
+            self.rargs = cg_fused.CgArgs()
+            dev, f64 = ctx().device, torch.float64
+            self.rw = torch.zeros(self.m, dtype=f64, device=dev)
+            self.rv = torch.zeros(self.m, dtype=f64, device=dev)
+        r = self.rargs
+        A, At = P.A, P.A.T
+        r.n, r.m = self.n, self.m
+        for pre, M in (("A", A), ("At", At)):
+            pat = M.pattern
+            setattr(r, pre + "_rowptr", pat.indptr.data_ptr())
+            setattr(r, pre + "_colidx", pat.indices.data_ptr())
+            setattr(r, pre + "_val", M.val.data_ptr())
+            setattr(r, pre + "_tiles", pat.tiles.data_ptr())
+            setattr(r, pre + "_ntiles", pat.ntiles)
+        r.H_ntiles = 0
+        r.solver_kind = cg_fused._solver_kind(P.solver)
+        if r.solver_kind == 1:
+            r.banded = ctypes.cast(ctypes.pointer(P.solver.c_args()), _P)
+        else:
+            r.banded = ctypes.c_void_p(P.solver.handle)
+        r.w, r.v = self.rw.data_ptr(), self.rv.data_ptr()
+        a = self.args
+        a.cg = ctypes.cast(ctypes.pointer(r), _P)
+        a.A_tiles, a.A_ntiles = A.pattern.tiles.data_ptr(), A.pattern.ntiles
+        a.c, a.b, a.v_out = c.t.data_ptr(), b.t.data_ptr(), v_out.data_ptr()
+        need = int(lib.ipx_sqp_part_doubles(ctypes.byref(a)))
+        if self.part is None or self.part.numel() < need:
+            self.part = torch.zeros(need, dtype=torch.float64, device=ctx().device)
+        a.part = self.part.data_ptr()
+        self.keep = (P, A, At, c, b, v_out)
+
+    def front(self, have_dn, with_dogleg, radius, penalty, f, norm_b, norm_A, first_end):
         a = self.args
         # (||A||_F is the host's by now -- the refresh's read brought it: by value)
-        _hip.call("ipx_sqp_front", ctypes.byref(a), int(have_dn), float(radius), float(penalty),
+        _hip.call("ipx_sqp_front", ctypes.byref(a), int(have_dn), int(with_dogleg), float(radius),
+                  float(penalty),
                   float(f), float(norm_b), TR_FACTOR, BOX_FACTOR, float("nan"), float(norm_A),
                   int(first_end), stream_ptr())
         STATS["fronts"] += 1

@@ -30,3 +30,10 @@ torch.cuda.synchronize()
 print("status %d, %d outer / %d CG; %d calls through _hip.call" % (res.status, res.niter, res.cg_niter, sum(counts.values())))
 for name, c in counts.most_common():
     print("  %5d  %s" % (c, name))
+reads = counts["ipx_read_doubles"] + counts["ipx_read_folded"]
+print("blocking reads through the library: %d" % reads)
+from ipsolver import sqp_chain, cg_fused
+print("chain:", dict(sqp_chain.STATS))
+print("cg:", {k: v for k, v in cg_fused.STATS.items() if v})
+from ipsolver import projector
+print("banded handles:", projector.HANDLE_STATS)

@@ -120,8 +120,8 @@ def test_general_sparsity_barrier_vs_reference(monkeypatch):
     seen = []
     real = projector.normal_solver_for
 
-    def spy(A):
-        sv = real(A)
+    def spy(A, *more):
+        sv = real(A, *more)
         seen.append((type(sv).__name__, type(getattr(sv, "inner", None)).__name__))
         return sv
     monkeypatch.setattr(projector, "normal_solver_for", spy)
@@ -931,3 +931,50 @@ def test_general_sparsity_sharding_hip(tmp_path):
     path = str(tmp_path / "general.npz")
     mp.spawn(tg._general_worker, args=(2, port, path, "hip"), nprocs=2, join=True)
     tg.check_general(np.load(path))
+
+
+@pytest.mark.parametrize("case", ["eq_n2000_ip", "eq_n2000_sqp", "ineq_box_n400", "eq_n20000_device"])
+def test_step_chain_and_host_stages_agree_bit_for_bit(case, monkeypatch):
+    """The outer iteration as three device chains per iteration (ipx_sqp_front / _judge /
+    _refresh: decisions on the device, one read of the scalar block per chain) against the same
+    stages driven from the host through the backend's vector operations: the chains sum every
+    scalar in the order of the host form's reduction kernels and run the decision arithmetic
+    the host form calls (ipx_sqp_*_host is the kernels' code), so whole solves agree in every
+    trace row and in every bit of x -- dogleg steps taken on the device, trust-region exits of
+    the CG loop finished on the device, correction steps of the priming's projections included
+    (reference equality_constrained_sqp.py:102-250, qp_subproblem.py:320-413, 565-596)."""
+    syn = load_synthetic()
+    if case.startswith("eq_n2000"):
+        prob = syn.CenteredBandedNLP(2000, 200, eps=1e-3)
+        method = "tr_interior_point" if case.endswith("ip") else "equality_constrained_sqp"
+        make = lambda: ((prob.fun, prob.x0, prob.grad, prob.hess, prob.constraints(ipsolver)))
+        kw = dict(method=method)
+    elif case == "ineq_box_n400":
+        prob = syn.CenteredBandedNLP(400, 40, eps=1.0)
+        make = lambda: (prob.fun, prob.x0, prob.grad, prob.hess,
+                        (prob.constraints(ipsolver, ("less", 0.0)),
+                         ipsolver.BoxConstraint(("interval", -0.8, 0.8))))
+        kw = {}
+    else:
+        prob = syn.CenteredBandedNLP(20000, 2000, eps=1e-3)
+        dc = syn.DeviceCallbacks(prob)
+        make = lambda: (dc.fun, dc.x0, dc.grad, dc.hess, dc.constraints(ipsolver))
+        kw = dict(method="tr_interior_point")
+    from ipsolver import sqp_chain
+    outs = []
+    for form in ("", "no-step-chain"):
+        with monkeypatch.context() as mp:
+            if form:
+                mp.setenv("IPX_DEBUG_FORMS", form)
+            fronts = sqp_chain.STATS["fronts"]
+            outs.append(run(*make(), **kw))
+            assert (sqp_chain.STATS["fronts"] > fronts) == (form == "")
+    (r1, rows1), (r2, rows2) = outs
+    assert r1.status == r2.status and r1.niter == r2.niter and r1.cg_niter == r2.cg_niter
+    assert np.array_equal(np.array(rows1), np.array(rows2), equal_nan=True)
+    x1 = r1.x.cpu().numpy() if hasattr(r1.x, "cpu") else np.asarray(r1.x)
+    x2 = r2.x.cpu().numpy() if hasattr(r2.x, "cpu") else np.asarray(r2.x)
+    assert np.array_equal(x1, x2)
+    v1 = r1.v.cpu().numpy() if hasattr(r1.v, "cpu") else np.asarray(r1.v)
+    v2 = r2.v.cpu().numpy() if hasattr(r2.v, "cpu") else np.asarray(r2.v)
+    assert np.array_equal(v1, v2)
