@@ -350,10 +350,10 @@ int ipx_cg_iterate(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, void 
  * (A_tiles / A_ntiles: its standard SpMV row tiles) and H, solver_kind 0 or 1; b NULL = 0;
  * red: 18 doubles, ws: IPX_WS_DOUBLES doubles of device memory.  first_end > 0: iterations
  * [0, first_end) are enqueued behind the priming by the same call (as ipx_cg_iterate would).
- * With b == NULL each of the two projections may take ONE correction step on the device (the
- * refinement of projections.py:72-78 / the cancellation step of ipsolver/projector.py, decided
- * from the same norms by a kernel in between: red[14 + j] = 0 when projection j takes it,
- * red[16 + j] = 1 once it has).
+ * (Inside ipx_sqp_front the two projections may each take ONE correction step on the device --
+ * the refinement of projections.py:72-78 / the cancellation step of ipsolver/projector.py,
+ * decided from the same norms by a kernel in between: red[14 + j] = 0 when projection j takes
+ * it, red[16 + j] = 1 once it has; this entry point leaves such a priming to the host.)
  * Stop code 9 in the state block afterwards: the host must prime (ipx_cg_prime_state); the
  * iterations enqueued with it did nothing. */
 /* doubles of reduction workspace ipx_cg_prime needs for this argument block (the per-tile
@@ -631,10 +631,13 @@ int64_t ipx_sqp_part_doubles(const ipx_sqp_args *s);
  * s->dn and calls again with have_dn = 1), c_t = H dn + c, shifted bounds, the projected CG's
  * priming with the tangential radius of the block and iterations [0, first_end), then
  * ipx_sqp_model.  (with_dogleg costs nine launches that do nothing when the Newton point stands:
- * the caller sets it when the last normal step was not the Newton point.) */
-int ipx_sqp_front(const ipx_sqp_args *s, int have_dn, int with_dogleg, double radius,
-                  double penalty, double f, double norm_b, double tr_factor, double box_factor,
-                  double tol_in, double norm_A, int32_t first_end, void *stream);
+ * the caller sets it when the last normal step was not the Newton point.)  with_steps != 0: the
+ * priming's two projections may each take one correction step on the device (eight more
+ * launches, no-ops when none is due; without them such a priming ends in stop code 9). */
+int ipx_sqp_front(const ipx_sqp_args *s, int have_dn, int with_dogleg, int with_steps,
+                  double radius, double penalty, double f, double norm_b, double tr_factor,
+                  double box_factor, double tol_in, double norm_A, int32_t first_end,
+                  void *stream);
 /* the CG loop's trust-region / negative-curvature exits (:565-576, :585-596), d = dn + dt,
  * x_next = x + S d, the five sums and the model / penalty / predicted reduction (:135-153);
  * host_cg != 0: the caller finished the CG loop itself (exits included), dt = cg->x as it is */

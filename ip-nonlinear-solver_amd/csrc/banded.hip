@@ -2264,7 +2264,10 @@ int ipx_banded_factor(void *handle, const double *band, void *stream) {
   if (!handle || !band) return IPX_EINVAL;
   Banded *h = (Banded *)handle;
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(h->flag, 0, sizeof(int), st) != hipSuccess) return IPX_ELAUNCH;
+  // (the pivot word and, right behind it, the cyclic reduction's level flags: one memset)
+  if (hipMemsetAsync(h->flag, 0, (h->pcr_flags ? 1 + 2 * (PCR_LMAX + 1) : 1) * sizeof(int), st) !=
+      hipSuccess)
+    return IPX_ELAUNCH;
   h->lev[0].band = const_cast<double *>(band);
   h->decoupled = false;
   h->fast = h->fast_plan;
@@ -2278,8 +2281,6 @@ int ipx_banded_factor(void *handle, const double *band, void *stream) {
   if (decoupling_candidate(h) && h->pcr_flags) {
     // the cyclic reduction of the matrix alone: at which level has it decoupled?
     const Level &l0 = h->lev[0];
-    if (hipMemsetAsync(h->pcr_flags, 0, 2 * (PCR_LMAX + 1) * sizeof(int), st) != hipSuccess)
-      return IPX_ELAUNCH;
     hipLaunchKernelGGL(k_pcr_check, dim3((l0.P + DEC_CHUNKS - 1) / DEC_CHUNKS), dim3(IPX_BLOCK), 0,
                        st, l0.m, DEC_CHUNKS * l0.q, band, h->pcr_flags);
     IPX_CHECK_LAUNCH();

@@ -1644,12 +1644,14 @@ __device__ void prime_state_body(double *st, const double *red, const ipx_prime_
   double q[7];
   for (int k = 0; k < 7; ++k) q[k] = ix.i[k] >= 0 ? red[ix.i[k]] : 0.0;
   bool bad = false;
+  double margin = HUGE_VAL;
   for (int pj = 0; pj < 2; ++pj) {
     const double nx2 = q[1 + 3 * pj], nz2 = q[2 + 3 * pj], naz2 = q[3 + 3 * pj];
     const double nz = sqrt(nz2), naz = sqrt(naz2);
     const double orth = (nz == 0.0 || norm_A == 0.0) ? 0.0 : naz / (norm_A * nz);
     const bool stepped = taken && taken[pj] != 0.0;
     if (orth > orth_tol || (!stepped && nz2 < canc2 * nx2)) bad = true;
+    if (!stepped && nx2 > 0.0) margin = fmin(margin, nz2 / nx2);
   }
   const double rt_g = q[5];
   const double tr_distance = radius - sqrt(q[0]);
@@ -1661,6 +1663,7 @@ __device__ void prime_state_body(double *st, const double *red, const ipx_prime_
   st[ST_TOL] = tol;
   st[ST_RADIUS] = radius;
   st[ST_ORTH_RHS] = orth_tol * norm_A;
+  st[ST_MARGIN] = margin;
   st[ST_STOP] = bad ? 9.0 : 0.0;
 }
 
@@ -1883,7 +1886,7 @@ int ipx_cg_prime(const ipx_cg_args *a, const int32_t *A_tiles, int32_t A_ntiles,
                  double orth_tol, double norm_A, double cancellation, int32_t first_end,
                  void *stream) {
   return ipx_cg_prime_dev(a, A_tiles, A_ntiles, c, b, red, ws, tol_in, radius, nullptr, orth_tol,
-                          norm_A, nullptr, cancellation, first_end, (hipStream_t)stream);
+                          norm_A, nullptr, cancellation, first_end, 0, (hipStream_t)stream);
 }
 
 }  // extern "C"
@@ -1892,7 +1895,7 @@ int ipx_cg_prime_dev(const ipx_cg_args *a, const int32_t *A_tiles, int32_t A_nti
                      const double *c, const double *b, double *red, double *ws, double tol_in,
                      double radius, const double *radius_dev, double orth_tol, double norm_A,
                      const double *norm_A2_dev, double cancellation, int32_t first_end,
-                     hipStream_t stream) {
+                     int steps, hipStream_t stream) {
   if (!a || !c || !red || !ws || !A_tiles || a->solver_kind > 1 || a->m <= 0 || a->H_operator ||
       !a->H_rowptr || !a->t || first_end < 0)
     return IPX_EINVAL;
@@ -1925,10 +1928,10 @@ int ipx_cg_prime_dev(const ipx_cg_args *a, const int32_t *A_tiles, int32_t A_nti
   }
   const double canc2 = cancellation * cancellation;
   PrimeStep s1{}, s2{};
-  if (b) {
-    // (||t||^2 = red[4] comes out of the H x0 + c product's partials, folded by the state
+  if (b || !steps) {
+    // (b: ||t||^2 = red[4] comes out of the H x0 + c product's partials, folded by the state
     // kernel: the first projection's decision would need it earlier -- no step on this path)
-    rc = prime_project(a, A, At, t, a->r, R, 0, true, 1.0, st);
+    rc = prime_project(a, A, At, t, a->r, R, 0, b != nullptr, 1.0, st);
     if (rc) return rc;
     rc = prime_project(a, A, At, a->r, a->p, R, 6, true, -1.0, st);
     if (rc) return rc;
@@ -1946,7 +1949,7 @@ int ipx_cg_prime_dev(const ipx_cg_args *a, const int32_t *A_tiles, int32_t A_nti
   for (int k = 0; k < 7; ++k) ix.i[k] = (b ? idx_b : idx_0)[k];
   hipLaunchKernelGGL(k_cg_prime_state_folds, dim3(1), dim3(IPX_BLOCK), 0, st, a->state, red, R.f,
                      ix, tol_in, radius, orth_tol, norm_A, canc2, radius_dev, norm_A2_dev, s2,
-                     b ? 0 : 1);
+                     (b || !steps) ? 0 : 1);
   IPX_CHECK_LAUNCH();
   rc = launch_hp(a, nullptr, st);
   if (rc || first_end == 0) return rc;

@@ -583,6 +583,8 @@ enum {
   ST_TOL = 2, ST_RADIUS = 3, ST_ALPHA = 4, ST_STOP = 5, ST_NITER = 6, ST_BETA = 7,
   ST_PTHP = 8, ST_ORTH_RHS = 9,   // orth_tol * ||A||_F  (0 disables the check)
   ST_XNORM2 = 10, ST_VIOL = 11, ST_ORTH = 12, ST_IT_DONE = 13,
+  ST_MARGIN = 14,   // written by the priming: min over its two projections of ||Z x||^2 / ||x||^2
+                    // (how far they are from needing the cancellation step: 2^-20)
   ST_SIZE = 16
 };
 
@@ -601,12 +603,15 @@ int ipx_cg_shard2_resident_launch(const ipx_cg_args *a, const ipx_shard2_ext *e,
                                   int32_t it_end, int np1, hipStream_t st);
 
 // ipx_cg_prime with the trust radius and ||A||_F^2 optionally taken from device memory at
-// execution time (radius_dev / norm_A2_dev non-NULL override the by-value arguments)
+// execution time (radius_dev / norm_A2_dev non-NULL override the by-value arguments); steps != 0
+// (b == NULL only): each projection may take one correction step on the device (k_prime_decide)
+// -- eight more launches, no-ops when no step is due; steps == 0: a projection that needs one
+// ends the priming with stop code 9 (the host's)
 int ipx_cg_prime_dev(const ipx_cg_args *a, const int32_t *A_tiles, int32_t A_ntiles,
                      const double *c, const double *b, double *red, double *ws, double tol_in,
                      double radius, const double *radius_dev, double orth_tol, double norm_A,
                      const double *norm_A2_dev, double cancellation, int32_t first_end,
-                     hipStream_t stream);
+                     int steps, hipStream_t stream);
 
 // ---- internal (non-ABI) launchers shared between translation units --------
 struct ipx_csr_view {

@@ -54,6 +54,7 @@ enum {
   SQ_EXIT_TAU = 28,     // the step along p taken by the CG loop's boundary exit (diagnostic)
   SQ_EXIT_DONE = 29,    // 1: the exit of stop code 2 / 3 was finished on the device
   SQ_X_OUTSIDE = 30,    // box violations of the final CG iterate (:636-638)
+  SQ_PRIME_STEPS = 31,  // correction steps the priming's projections took on the device (0..2)
   SQ_CG = 32,           // the CG loop's state block (ST_*, 16 doubles) as of the model kernel
   SQ_DOGLEG = 48,       // scalars of the device dogleg (diagnostics): coef, alphas, norms
   SQ_SIZE = 64
@@ -540,7 +541,8 @@ k_sq_after_given(const double *__restrict__ p_nn, int n_nn, double radius,
 __global__ void __launch_bounds__(RB)
 k_sq_model(const double *__restrict__ p_vec, int g_vec, const double *__restrict__ p_hd, int n_hd,
            const double *__restrict__ p_ad, int n_ad, const double *__restrict__ cg_state,
-           double penalty, double f, double norm_b, double *__restrict__ q) {
+           const double *__restrict__ red, double penalty, double f, double norm_b,
+           double *__restrict__ q) {
   __shared__ double lds[5 * (RB / IPX_WAVE)];
   const double *parts[5] = {p_vec, p_vec + g_vec, p_vec + 2 * g_vec, p_hd, p_ad};
   const int counts[5] = {g_vec, g_vec, g_vec, n_hd, n_ad};
@@ -555,6 +557,7 @@ k_sq_model(const double *__restrict__ p_vec, int g_vec, const double *__restrict
   q[SQ_HDD] = out[3];
   q[SQ_LIN] = sqrt(out[4]);
   q[SQ_X_OUTSIDE] = outside;
+  q[SQ_PRIME_STEPS] = red ? red[16] + red[17] : 0.0;       // (csrc/cg.hip PR_TAKEN)
   q[SQ_PENALTY] = penalty;
   q[SQ_F] = f;
   q[SQ_NORM_B] = norm_b;
@@ -690,7 +693,7 @@ int ipx_sqp_model(const ipx_sqp_args *s, double penalty, double f, double norm_b
                      s->d, L.g, L.hd, s->m, s->Ad, s->Ad, L.gm, L.ad, nullptr);
   IPX_CHECK_LAUNCH();
   hipLaunchKernelGGL(k_sq_model, dim3(1), dim3(RB), 0, st, L.vec, L.g, L.hd, L.g, L.ad, L.gm,
-                     a->state, penalty, f, norm_b, s->q);
+                     a->state, host_cg ? nullptr : s->red, penalty, f, norm_b, s->q);
   IPX_CHECK_LAUNCH();
   return IPX_OK;
 }
@@ -699,9 +702,10 @@ int ipx_sqp_model(const ipx_sqp_args *s, double penalty, double f, double norm_b
 // device (SQ_NORMAL_KIND 1; 0: the host runs the dogleg and calls again with have_dn = 1).
 // Then c_t, the shifted bounds, the priming of the projected CG with the radius of the block,
 // iterations [0, first_end) and ipx_sqp_model.  box_factor / tr_factor: :43-44 (0.5, 0.8).
-int ipx_sqp_front(const ipx_sqp_args *s, int have_dn, int with_dogleg, double radius,
-                  double penalty, double f, double norm_b, double tr_factor, double box_factor,
-                  double tol_in, double norm_A, int32_t first_end, void *stream) {
+int ipx_sqp_front(const ipx_sqp_args *s, int have_dn, int with_dogleg, int with_steps,
+                  double radius, double penalty, double f, double norm_b, double tr_factor,
+                  double box_factor, double tol_in, double norm_A, int32_t first_end,
+                  void *stream) {
   if (!s || !s->cg || !s->q || !s->part || !s->dn || !s->ct || s->m <= 0) return IPX_EINVAL;
   if (with_dogleg && (!s->d || !s->Hd || !s->Ad)) return IPX_EINVAL;
   hipStream_t st = (hipStream_t)stream;
@@ -779,7 +783,7 @@ int ipx_sqp_front(const ipx_sqp_args *s, int have_dn, int with_dogleg, double ra
   }
   rc = ipx_cg_prime_dev(a, s->A_tiles, (int32_t)s->A_ntiles, s->ct, nullptr, s->red, s->ws, tol_in,
                         0.0, s->q + SQ_RADIUS_T, s->orth_tol, norm_A, nullptr, s->cancellation,
-                        first_end, st);
+                        first_end, with_steps, st);
   if (rc) return rc;
   return ipx_sqp_model(s, penalty, f, norm_b, 0, stream);
 }

@@ -110,8 +110,8 @@ _SIGNATURES = {
     "ipx_boxschur_project_count": [_P],
     "ipx_banded_status_deferred": [_P, _P, _P],
     "ipx_sqp_block_size": [],
-    "ipx_sqp_front": [_P, _c.c_int, _c.c_int, _F64, _F64, _F64, _F64, _F64, _F64, _F64, _F64, _I32,
-                      _P],
+    "ipx_sqp_front": [_P, _c.c_int, _c.c_int, _c.c_int, _F64, _F64, _F64, _F64, _F64, _F64, _F64,
+                      _F64, _I32, _P],
     "ipx_sqp_model": [_P, _F64, _F64, _F64, _c.c_int, _P],
     "ipx_sqp_judge": [_P, _P, _F64, _P, _P],
     "ipx_sqp_refresh": [_P, _P],

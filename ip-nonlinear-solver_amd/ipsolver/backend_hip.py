@@ -231,6 +231,18 @@ def _upload_dense_cached(h):
     return D
 
 
+# CG iterations of the last tangential step (the outer loops report them: note_cg_length).  A
+# Hessian assembled between two SHORT solves keeps its diagonal terms as a vector (every
+# product then reads 8 n bytes more); before long ones they are merged into a copy of the CSR
+# values (operators.DeviceHessian).
+_cg_length = {"last": 0}
+MERGE_DIAGONAL_FROM = 12
+
+
+def note_cg_length(niter):
+    _cg_length["last"] = int(niter)
+
+
 def hessian_operator(terms, n_vars, slack_block):
     """Device operator for the Lagrangian Hessian terms (HessianSum from
     canonical.lagrangian_hessian) and, in barrier problems, the diagonal slack
@@ -273,7 +285,8 @@ def hessian_operator(terms, n_vars, slack_block):
         else:
             others.append(up)
     if slack_block is None:
-        return DeviceHessian(n_vars, csr, diag, others)
+        return DeviceHessian(n_vars, csr, diag, others,
+                             merge=_cg_length["last"] >= MERGE_DIAGONAL_FROM)
     # z-space: extend the CSR block with empty slack rows, put the slack block
     # on the diagonal, pad any other x-space term
     if csr is not None:

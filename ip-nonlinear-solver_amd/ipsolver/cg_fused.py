@@ -23,7 +23,7 @@ _I64 = ctypes.c_int64
 
 # state block indices (csrc/cg.hip)
 ST_RTG0, ST_RTG1, ST_TOL, ST_RADIUS, ST_ALPHA, ST_STOP, ST_NITER, ST_BETA = range(8)
-ST_PTHP, ST_ORTH_RHS, ST_XNORM2, ST_VIOL, ST_ORTH, ST_IT_DONE = 8, 9, 10, 11, 12, 13
+ST_PTHP, ST_ORTH_RHS, ST_XNORM2, ST_VIOL, ST_ORTH, ST_IT_DONE, ST_MARGIN = 8, 9, 10, 11, 12, 13, 14
 
 
 class CgArgs(ctypes.Structure):

@@ -6,7 +6,7 @@ iterations:
 
     fun(x) -> float | 0-d tensor          grad(x) -> 1-D tensor
     hess(x) -> DeviceCSR | 1-D tensor (diagonal) | 2-D tensor / DeviceDense (dense) |
-               DeviceHessian | None
+               DeviceHessian | None | a tuple of such terms (their sum)
     NonlinearConstraint.fun(x) -> 1-D tensor
     NonlinearConstraint.jac(x) -> DeviceCSR (a fixed CSRPattern, values refreshed)
     NonlinearConstraint.hess(x, v) -> DeviceCSR | 1-D tensor (diagonal) | None
@@ -330,10 +330,19 @@ class DeviceCanonical:
         for p in self.parts:
             if p.hess is not None:
                 v = p.rows.multipliers(v_eq[i_eq:i_eq + p.n_eq], v_ineq[i_ineq:i_ineq + p.n_ineq])
-                terms.append(_as_term(p.hess(x, v)))
+                terms.extend(_as_terms(p.hess(x, v)))
             i_eq += p.n_eq
             i_ineq += p.n_ineq
         return terms
+
+
+def _as_terms(h):
+    """A Hessian callback's return value as a list of device terms: one term, or a tuple /
+    list of them (a constant matrix and a point-dependent diagonal, say -- summed like the
+    terms of different callbacks are, _canonical_constraint.py:131-137)."""
+    if isinstance(h, (tuple, list)):
+        return [_as_term(t) for t in h]
+    return [_as_term(h)]
 
 
 def _as_term(h):
@@ -379,7 +388,7 @@ def lagrangian_hessian(canonical, hess):
     def lagr_hess(x, v_eq=None, v_ineq=None):
         terms = []
         if hess is not None:
-            terms.append(_as_term(hess(x.t)))
+            terms.extend(_as_terms(hess(x.t)))
         if canonical.hess is not None:
             terms.extend(canonical.hess(x, v_eq if v_eq is not None else DVec.zeros(0),
                                         v_ineq if v_ineq is not None else DVec.zeros(0)))

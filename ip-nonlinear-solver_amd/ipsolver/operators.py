@@ -35,16 +35,19 @@ class DeviceHessian:
     reference does.
     """
 
-    def __init__(self, n, csr=None, diag=None, others=()):
+    def __init__(self, n, csr=None, diag=None, others=(), merge=True):
         self.n = n
         self.shape = (n, n)
-        if csr is not None and diag is not None:
+        if csr is not None and diag is not None and merge:
             # a CSR term that has every diagonal entry takes the diagonal terms into its values
             # (one scatter-add per Hessian, on a copy: the caller's matrix is not touched): the
             # product then reads no separate diagonal vector -- 8 n bytes less in every CG
             # iteration -- and is the ONE matrix SURVEY.md 8(d) counts (nnz ~ 3n for the
             # benchmark's tridiagonal + diagonal Hessian).  Same operator; the diagonal
             # products are rounded with their row's entry instead of after the row sum.
+            # (``merge=False``: the copy + scatter costs two passes over the values, ~20 us at
+            # nnz = 3e6 -- more than the diagonal's 8 n bytes cost a Hessian that is multiplied
+            # a dozen times before the next one replaces it: backend_hip.hessian_operator)
             pos = csr.pattern.diagonal_positions()
             if pos is not None and len(diag) == n:
                 val = csr.val.clone()

@@ -104,6 +104,8 @@ class HostStages:
         lb_t = box.lb - dn if box.lb is not None else None
         ub_t = box.ub - dn if box.ub is not None else None
         dt, info = xp.projected_cg(H, c_t, pt.Z, pt.Y, None, q[RADIUS_T], lb_t, ub_t)
+        if hasattr(xp, "note_cg_length"):
+            xp.note_cg_length(info['niter'])
         d = dn + dt
         pk = xp.pack()
         h_hd, h_cd = pk.dot(H.dot(d), d), pk.dot(pt.c, d)
@@ -232,6 +234,7 @@ class ChainStages:
             chain.front(1, 0, radius, penalty, pt.f, pt.norm_b, P.norm_A, first_end)
             q = chain.read()
         P.stats["solves"] += 3
+        steps_taken = q[sc.PRIME_STEPS]
         L.enqueued = (0, first_end) if first_end > 0 else None
         st = q[sc.CG:sc.CG + 16]
         stop = int(st[cg_fused.ST_STOP])
@@ -259,9 +262,13 @@ class ChainStages:
                 L.enqueued = None
             elif stop == 9:
                 sc.STATS["prime_retries"] += 1
+                chain.expect_steps = True      # (the next primings carry their correction steps)
                 L.enqueued = None
                 cg_fused._release(L, key)
-                dt, info = self.xp.projected_cg(H, c_t, pt.Z, pt.Y, None, radius_t, lb_t, ub_t)
+                # (the host's priming straight away: the device just turned this one down)
+                dt, info = cg_fused._projected_cg(H, c_t, pt.Z, pt.Y, DVec.zeros(m), radius_t,
+                                                  lb_t, ub_t, None, None, None, None, None, True,
+                                                  fast=False)
                 L, key = cg_fused._loop_for(H, P, lb_t, ub_t)
             else:
                 lbf = lb_t if lb_t is not None or not box.any else DVec.full(n, -np.inf)
@@ -276,7 +283,15 @@ class ChainStages:
             q = chain.read()
             chain.keep = chain.keep + (dt,)
         cg_fused._release(L, key)
+        # the next priming carries its correction steps when this one took some, or came within
+        # a factor 64 of needing the cancellation step (the projected gradient shrinks against
+        # the gradient from one outer iteration to the next: the margin announces the first call
+        # that needs one; a call that needs one and has none ends in stop code 9 -- host)
+        if stop != 9:
+            chain.expect_steps = steps_taken > 0 or \
+                st[cg_fused.ST_MARGIN] < 64.0 * P.CANCELLATION ** 2
         chain.last_niter = (chain.last_niter[1], info['niter'])
+        self.xp.note_cg_length(info['niter'])
         t = _Trial()
         t.x_next, t.d, t.cg_info, t.on_chain = DVec(x_next), DVec(chain.d), info, True
         return q, t
@@ -322,8 +337,14 @@ def equality_constrained_sqp(fun_and_constr, grad_and_jac, lagr_hess, x0, fun0, 
     n, m = len(x0), len(constr0)
     box = _Box(xp, n, trust_lb, trust_ub)
     stages = _stages(xp, n, m, x0, box)
-    if state.niter == 0 and hasattr(stages, "chain"):
-        stages.chain.expect_dogleg = True       # (a new solve: its first normal step is long)
+    if state.niter == 0:
+        # a new solve starts from the same launch plan whatever ran before it: its first normal
+        # step is expected long, its first Hessian keeps its diagonal apart (backend_hip
+        # .hessian_operator: that choice rounds differently, so it must not depend on history)
+        if hasattr(stages, "chain"):
+            stages.chain.expect_dogleg = True
+        if hasattr(xp, "note_cg_length"):
+            xp.note_cg_length(0)
 
     def publish(pt):
         state.x, state.v, state.fun, state.grad = pt.x, pt.v, pt.f, pt.c

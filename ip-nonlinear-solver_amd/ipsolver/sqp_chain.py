@@ -26,7 +26,7 @@ _P, _I64, _F64c = ctypes.c_void_p, ctypes.c_int64, ctypes.c_double
 # ---- the block (csrc/sqp.hip SQ_*) -------------------------------------------------------
 (RADIUS, PENALTY, F, NORM_B, NORM_DN, RADIUS_T, NORMAL_KIND, NVIOL, HDD, CD, LIN, NORM_D, NORM_DT,
  QMODEL, VPRED, PREV_PENALTY, PRED, MERIT, F_NEXT, NORM_B_NEXT, ACTUAL, RATIO, SOC, ACCEPT, OPT,
- VIOL, NORM_A2, FACTOR_BAD, EXIT_TAU, EXIT_DONE, X_OUTSIDE) = range(31)
+ VIOL, NORM_A2, FACTOR_BAD, EXIT_TAU, EXIT_DONE, X_OUTSIDE, PRIME_STEPS) = range(32)
 CG = 32
 SIZE = 64
 
@@ -101,6 +101,7 @@ class StepChain:
         self.rargs = None
         self.last_niter = (3, 3)     # (CG iterations of the last two calls: size the next first batch)
         self.expect_dogleg = True    # (the last normal step was not the Newton point)
+        self.expect_steps = False    # (the last priming's projections needed a correction step)
         self.args = ChainArgs()
         a = self.args
         a.n, a.m = n, m
@@ -198,8 +199,8 @@ class StepChain:
     def front(self, have_dn, with_dogleg, radius, penalty, f, norm_b, norm_A, first_end):
         a = self.args
         # (||A||_F is the host's by now -- the refresh's read brought it: by value)
-        _hip.call("ipx_sqp_front", ctypes.byref(a), int(have_dn), int(with_dogleg), float(radius),
-                  float(penalty),
+        _hip.call("ipx_sqp_front", ctypes.byref(a), int(have_dn), int(with_dogleg),
+                  int(self.expect_steps), float(radius), float(penalty),
                   float(f), float(norm_b), TR_FACTOR, BOX_FACTOR, float("nan"), float(norm_A),
                   int(first_end), stream_ptr())
         STATS["fronts"] += 1

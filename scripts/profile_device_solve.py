@@ -15,7 +15,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "ip-nonlinear-solver_amd"))
 import torch
 import ipsolver
-from ipsolver.synthetic import CenteredBandedNLP, DeviceCallbacks
+from ipsolver.synthetic import CenteredBandedNLP, DeviceCallbacks, LeanDeviceCallbacks
+if os.environ.get("LEAN", "1") == "1":        # (LEAN=0: the plain torch callbacks)
+    DeviceCallbacks = LeanDeviceCallbacks
 
 warnings.simplefilter("ignore")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000

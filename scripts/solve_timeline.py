@@ -21,7 +21,9 @@ def run():
     sys.path.insert(0, os.path.join(ROOT, "ip-nonlinear-solver_amd"))
     import torch
     import ipsolver
-    from ipsolver.synthetic import CenteredBandedNLP, DeviceCallbacks
+    from ipsolver.synthetic import CenteredBandedNLP, DeviceCallbacks, LeanDeviceCallbacks
+    if os.environ.get("LEAN", "1") == "1":        # (LEAN=0: the plain torch callbacks)
+        DeviceCallbacks = LeanDeviceCallbacks
     warnings.simplefilter("ignore")
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 1000000
     prob = CenteredBandedNLP(n, n // 10, eps=1e-3)
