@@ -476,6 +476,94 @@ def public_api_leg(H, c, Z, Y, b, K, reps=5):
     return out
 
 
+def config3_leg(n, m, repeats=5):
+    """BASELINE config 3 to gtol on one GPU (minimize_constrained, tr_interior_point,
+    device-callback mode: nothing crosses PCIe): the wall clock (median of ``repeats`` warm
+    solves), how often the host blocked on the device and how many kernels the library
+    launched in one solve, and the projected-CG rate INSIDE the solve (SURVEY.md 8(d)(i):
+    cg_niter / time in projected_cg -- here the GPU time between the first launch of a call's
+    priming and the last launch of its iterations, HIP events inside ipx_sqp_front, plus the
+    host-timed continuations of the calls whose first batch was too short)."""
+    import ctypes
+    import warnings
+    import torch
+    import ipsolver
+    from ipsolver import _hip, sqp, sqp_chain
+    from ipsolver.synthetic import CenteredBandedNLP, DeviceCallbacks, LeanDeviceCallbacks
+    prob = CenteredBandedNLP(n, m, eps=1e-3)
+    lib = _hip.load()
+
+    def solve(dc):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = ipsolver.minimize_constrained(dc.fun, dc.x0, dc.grad, dc.hess,
+                                            dc.constraints(ipsolver), method="tr_interior_point")
+        torch.cuda.synchronize()
+        return res, time.perf_counter() - t0
+
+    out = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for name, cls in (("lean", LeanDeviceCallbacks), ("torch", DeviceCallbacks)):
+            dc = cls(prob)
+            solve(dc)                               # (pays the one-off symbolic set-up)
+            walls = []
+            for _ in range(repeats):
+                res, dt = solve(dc)
+                walls.append(dt)
+            walls.sort()
+            out[name] = (res, walls, dc)
+        res, walls, dc = out["lean"]
+        # one more solve with the calls counted, one with the CG bracketed by events
+        counts = {"reads": 0}
+        plain = _hip.call
+
+        def counting(fname, *a):
+            if fname in ("ipx_read_doubles", "ipx_read_folded"):
+                counts["reads"] += 1
+            return plain(fname, *a)
+        _hip.call = counting
+        launches0 = int(lib.ipx_launch_count())
+        try:
+            solve(dc)
+        finally:
+            _hip.call = plain
+        launches = int(lib.ipx_launch_count()) - launches0
+        before = dict(sqp_chain.STATS)
+        sqp.TIMERS["host_cg_seconds"] = 0.0
+        lib.ipx_sqp_cg_timing(1, None, None)
+        res_t, _ = solve(dc)
+        ms, calls = ctypes.c_double(0.0), ctypes.c_int(0)
+        lib.ipx_sqp_cg_timing(0, ctypes.byref(ms), ctypes.byref(calls))
+        cg_seconds = 1e-3 * ms.value + sqp.TIMERS["host_cg_seconds"]
+        chain = {k: sqp_chain.STATS[k] - before.get(k, 0) for k in sqp_chain.STATS
+                 if sqp_chain.STATS[k] - before.get(k, 0)}
+    res_p, walls_p, _ = out["torch"]
+    return {
+        "seconds": walls[len(walls) // 2], "seconds_min": walls[0], "seconds_max": walls[-1],
+        "repeats": repeats, "status": int(res.status), "niter": int(res.niter),
+        "cg_niter": int(res.cg_niter), "nfev": int(res.nfev),
+        "optimality": float(res.optimality), "constr_violation": float(res.constr_violation),
+        "blocking_reads_per_solve": counts["reads"],
+        "library_launches_per_solve": launches,
+        "cg_iterations_per_s_in_solve": res_t.cg_niter / cg_seconds if cg_seconds else None,
+        "seconds_in_projected_cg": cg_seconds, "projected_cg_calls": int(calls.value),
+        "chain": chain,
+        "callbacks": "synthetic.LeanDeviceCallbacks (user-land: torch elementwise ops + the "
+                     "library's DeviceCSR / ScalarPack; ~20 launches per outer iteration)",
+        "with_plain_torch_callbacks": {
+            "seconds": walls_p[len(walls_p) // 2], "status": int(res_p.status),
+            "niter": int(res_p.niter), "cg_niter": int(res_p.cg_niter),
+            "callbacks": "synthetic.DeviceCallbacks (rounds 1-5: ~60 launches per outer "
+                         "iteration, float(f) by a torch synchronisation)"},
+        "note": "config 3 (eps=1e-3), gtol=xtol=1e-8; the reference reaches status 1 in 25 "
+                "outer / 34 CG iterations (SURVEY.md Appendix B: 103 s on the survey host).  "
+                "blocking reads: ipx_read_doubles / ipx_read_folded calls (the lean callbacks' "
+                "objective reads its three dot products through one of them per evaluation); "
+                "launches: the library's own (ipx_launch_count), the callbacks' torch kernels "
+                "not included"}
+
+
 def config5_leg(run_twice=True):
     """BASELINE config 5 on one GPU: n=5e5 variables, box on every variable + 5e4 nonlinear
     inequalities (N = 1.55e6 with slacks), tr_interior_point to gtol with device callbacks;
@@ -489,6 +577,13 @@ def config5_leg(run_twice=True):
     prob = CenteredBandedNLP(n, m, eps=1.0)
     dc = DeviceCallbacks(prob)
     cons = (dc.constraints(ipsolver, ("less", 0.0)), ipsolver.BoxConstraint(("interval", -0.8, 0.8)))
+    # time inside projected_cg: calls through the backend (host-driven stages) by a host timer
+    # around them (they return after a blocking read of the loop's state); calls that start
+    # inside the outer iteration's front chain by the GPU time of their priming + first batch
+    # (HIP events, ipx_sqp_cg_timing) + the host-timed continuation (sqp.TIMERS)
+    import ctypes
+    from ipsolver import _hip, sqp
+    lib = _hip.load()
     timer = {"t": 0.0, "calls": 0}
     plain = backend_hip.projected_cg
 
@@ -498,30 +593,44 @@ def config5_leg(run_twice=True):
         timer["t"] += time.perf_counter() - t0
         timer["calls"] += 1
         return out
+
+    def clock_start():
+        timer["t"], timer["calls"] = 0.0, 0
+        sqp.TIMERS["host_cg_seconds"] = 0.0
+        lib.ipx_sqp_cg_timing(1, None, None)
+
+    def clock_stop():
+        ms, calls = ctypes.c_double(0.0), ctypes.c_int(0)
+        lib.ipx_sqp_cg_timing(0, ctypes.byref(ms), ctypes.byref(calls))
+        timer["t"] += 1e-3 * ms.value + sqp.TIMERS["host_cg_seconds"]
+        timer["calls"] += int(calls.value)
     backend_hip.projected_cg = timed
     other = None
     try:
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             for attempt in range(2 if run_twice else 1):     # first call pays symbolic set-up
-                timer["t"], timer["calls"] = 0.0, 0
+                clock_start()
                 torch.cuda.synchronize()
                 t0 = time.time()
                 res = ipsolver.minimize_constrained(dc.fun, dc.x0, dc.grad, dc.hess, cons)
                 torch.cuda.synchronize()
                 wall = time.time() - t0
+                clock_stop()
             main = (timer["t"], timer["calls"])
             # the same solve with the back substitution as a launch of its own (round 4's four
             # launches): g is bit-identical, ||g||^2 is summed in another order -- and the run
             # ends on another barrier level (profiles/r05_config5_levels.json)
             try:
                 os.environ["IPX_DEBUG_FORMS"] = "no-post-tail"
-                timer["t"], timer["calls"] = 0.0, 0
+                clock_start()
                 torch.cuda.synchronize()
                 t0 = time.time()
                 res4 = ipsolver.minimize_constrained(dc.fun, dc.x0, dc.grad, dc.hess, cons)
                 torch.cuda.synchronize()
-                other = {"seconds": time.time() - t0, "status": int(res4.status),
+                wall4 = time.time() - t0
+                clock_stop()
+                other = {"seconds": wall4, "status": int(res4.status),
                          "niter": int(res4.niter), "cg_niter": int(res4.cg_niter),
                          "cg_iterations_per_s_in_solve": res4.cg_niter / timer["t"] if timer["t"] else None,
                          "launches_per_cg_iteration": 4,
@@ -1296,6 +1405,7 @@ def main():
     # set-up, the batched device loop with its state reads, the result.  The bare device loop
     # (one C call enqueuing K iterations; the former headline) is `device_loop_only`.
     from ipsolver import qp as _qp
+    b_dev = b
     if W > 0:
         _qp.projected_cg(H, c, Z, Y, b, trust_radius=1e300, tol=0, max_iter=W)
     # (with tol = 0 the CG reaches an exactly zero residual after ~500 iterations: a K beyond
@@ -1334,7 +1444,9 @@ def main():
         "data": "synthetic",
         "config": {"workload": "config3: sparse banded NLP subproblem, CSR Jacobian "
                                "bandwidth 15: ONE call ipsolver.qp.projected_cg(H, c, Z, Y, b, "
-                               "trust_radius=1e300, tol=0, max_iter=steps) -- priming included; "
+                               "trust_radius=1e300, tol=0, max_iter=steps), b a device vector "
+                               "(zeros; x0 = Y(-b) is computed: whether a device vector is zero "
+                               "is not known without reading it) -- priming included; "
                                "finite trust radius that is never reached (the norm test of "
                                "qp_subproblem.py:583 formed every iteration, as in the SQP's "
                                "calls; trust_radius=inf: see unbounded_trust_region)",
@@ -1358,6 +1470,11 @@ def main():
     }
     # ---- the product function as a user calls it
     result["public_api"] = public_api_leg(H, c, Z, Y, b, K)
+    # (b = None -- the extension the SQP's own call uses, equality_constrained_sqp.py:126 passes
+    # zeros -- starts from x0 = 0 without the solve and the two products of Y(-b), H x0 + c)
+    result["public_api"]["with_b_none"] = {
+        k: v["iterations_per_s"] for k, v in public_api_leg(H, c, Z, Y, None, K, reps=3).items()
+        if isinstance(v, dict)}
     # ---- the strong-scaling ceiling at the per-rank sizes, measured in this run
     if (n, m) == (1000000, 100000) and not args.no_sweep:
         try:
@@ -1402,28 +1519,7 @@ def main():
     # gtol = 1e-8 (minimize_constrained, tr_interior_point, device-callback mode:
     # objective / constraint callbacks evaluate on the GPU, nothing crosses PCIe)
     if (n, m) == (1000000, 100000) or os.environ.get("IPX_BENCH_FULL_SOLVE"):
-        import warnings
-        import ipsolver
-        from ipsolver.synthetic import DeviceCallbacks
-        full = CenteredBandedNLP(n, m, eps=1e-3)
-        dc = DeviceCallbacks(full)
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")
-            for attempt in range(2):          # first call pays one-off symbolic set-up
-                torch.cuda.synchronize()
-                t0 = time.time()
-                res = ipsolver.minimize_constrained(dc.fun, dc.x0, dc.grad, dc.hess,
-                                                    dc.constraints(ipsolver),
-                                                    method="tr_interior_point")
-                torch.cuda.synchronize()
-                wall = time.time() - t0
-        result["wall_clock_to_gtol"] = {
-            "seconds": wall, "status": int(res.status), "niter": int(res.niter),
-            "cg_niter": int(res.cg_niter), "nfev": int(res.nfev),
-            "optimality": float(res.optimality),
-            "constr_violation": float(res.constr_violation),
-            "note": "config 3 (eps=1e-3), gtol=xtol=1e-8; the reference reaches status 1 in 25 "
-                    "outer / 34 CG iterations (SURVEY.md Appendix B: 103 s on the survey host)"}
+        result["wall_clock_to_gtol"] = config3_leg(n, m)
 
     # ---- the other single-GPU BASELINE configs to gtol (full sizes)
     if (n, m) == (1000000, 100000) and not args.no_configs:
@@ -1464,7 +1560,7 @@ def main():
                       "oracle/ (scipy SuperLU augmented-system projections, numpy vectors) per "
                       "thread count; factorization %.1f s not included" % (kc, n, m, t_fac)}
         # parity of the GPU iterates with the CPU oracle after the same number of iterations
-        xg, ginfo = cg_fused.projected_cg(H, c, Z, Y, b, tol=0, max_iter=kc)
+        xg, ginfo = cg_fused.projected_cg(H, c, Z, Y, b_dev, tol=0, max_iter=kc)
         err = np.max(np.abs(xg.to_host() - xo)) / np.max(np.abs(xo))
         result["parity_vs_oracle"] = {"iterations": kc, "max_rel_err": float(err)}
 

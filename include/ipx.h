@@ -45,6 +45,8 @@ extern "C" {
 #define IPX_MAX_PARTIALS 2048
 
 const char *ipx_version(void);
+/* Kernel launches of the library since it was loaded (a host counter: diagnostics, bench.py). */
+long long ipx_launch_count(void);
 /* Text of the last HIP error seen by this thread ("" if none). */
 const char *ipx_last_error(void);
 int ipx_device_info(int *cu_count, int *lds_bytes, char *arch, int arch_len);
@@ -649,6 +651,10 @@ int ipx_sqp_judge(const ipx_sqp_args *s, const double *b_next, double f_next,
                   const double *f_next_dev, void *stream);
 /* v = -(A A')^-1 A c, ||c + A'v||_inf, ||b||_inf, ||b|| (:83-87, 226-239), ||A||_F^2 */
 int ipx_sqp_refresh(const ipx_sqp_args *s, void *stream);
+/* measurement aid: on != 0 starts bracketing the projected CG's priming + first batch inside
+ * ipx_sqp_front with HIP events; on == 0 stops, synchronises and returns their GPU time (ms) and
+ * count since the start (the in-solve projected-CG rate of the benchmark) */
+int ipx_sqp_cg_timing(int on, double *ms_total, int *calls);
 /* the decisions' scalar arithmetic on a HOST copy of the block (the same code the kernels run) */
 void ipx_sqp_model_host(double *q);
 void ipx_sqp_ratio_host(double *q);

@@ -18,8 +18,13 @@ void ipx_note_error(hipError_t e, const char *file, int line);
 // must be readable up to the next multiple of 8 bytes
 int ipx_read_ints(const int *dev, int k, int *host_out, hipStream_t st);
 
+// kernel launches of the library since it was loaded (ipx_launch_count; misc.hip): counted where
+// every launch is checked
+extern long long g_ipx_launches;
+
 #define IPX_CHECK_LAUNCH()                                   \
   do {                                                       \
+    ++g_ipx_launches;                                        \
     hipError_t e_ = hipGetLastError();                       \
     if (e_ != hipSuccess) {                                  \
       ipx_note_error(e_, __FILE__, __LINE__);                \

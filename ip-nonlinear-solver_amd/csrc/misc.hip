@@ -100,9 +100,13 @@ k_publish_folded(FoldDescs descs, int nd, ipx_u4 *dst, unsigned int tag) {
   }
 }
 
+long long g_ipx_launches = 0;
+
 extern "C" {
 
 const char *ipx_version(void) { return "ipx 0.1 (gfx950)"; }
+
+long long ipx_launch_count(void) { return g_ipx_launches; }
 
 const char *ipx_last_error(void) { return g_last_error; }
 
@@ -135,6 +139,7 @@ int ipx_read_doubles(const double *dev, int k, double *host_out, void *stream) {
   if (rc != IPX_OK) return rc;
   hipLaunchKernelGGL(k_publish, dim3(1), dim3(IPX_READ_MAX), 0, (hipStream_t)stream, dev, k,
                      (ipx_u4 *)pinned, tag);
+  ++g_ipx_launches;
   {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { ipx_note_error(e, __FILE__, __LINE__); return IPX_ELAUNCH; }
@@ -161,6 +166,7 @@ int ipx_read_folded(int nd, const ipx_fold_desc *descs, double *host_out, void *
   if (rc != IPX_OK) return rc;
   hipLaunchKernelGGL(k_publish_folded, dim3(1), dim3(IPX_BLOCK), 0, (hipStream_t)stream, D, nd,
                      (ipx_u4 *)pinned, tag);
+  ++g_ipx_launches;
   {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { ipx_note_error(e, __FILE__, __LINE__); return IPX_ELAUNCH; }

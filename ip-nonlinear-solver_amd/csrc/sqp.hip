@@ -31,6 +31,8 @@
 // take the same branches on the same numbers).
 #include "ipx_common.h"
 #include <math.h>
+#include <utility>
+#include <vector>
 
 // ---- the block ----------------------------------------------------------------------------
 // (mirrored by ipsolver/sqp.py; doubles)
@@ -601,6 +603,15 @@ k_sq_measure(const double *__restrict__ p_t, int g_t, const double *__restrict__
 }  // namespace
 
 // ---- the argument block (all members 8 bytes; mirrored by ipsolver/sqp_chain.py) ------------
+namespace {
+// Measurement aid (bench.py: the in-solve projected-CG rate of SURVEY.md 8(d)(i)): with timing
+// on, ipx_sqp_front brackets the CG's priming + first batch with HIP events on its stream.
+struct CgTiming {
+  bool on = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+} g_cg_timing;
+}  // namespace
+
 extern "C" {
 
 
@@ -612,6 +623,30 @@ int64_t ipx_sqp_part_doubles(const ipx_sqp_args *s) {
   if (!s || !s->cg) return -1;
   const int64_t g = sq_grid(s->n), gm = sq_grid(s->m);
   return 4 * g + 6 * g + g + gm + 2 * g + 2 * gm + g + 18 * g + 64;
+}
+
+/* on != 0: start collecting; on == 0: stop, synchronise, *ms_total = GPU milliseconds between the
+ * first launch of the projected CG's priming and the last of its first batch, summed over the
+ * ipx_sqp_front calls since timing was switched on, *calls = how many. */
+int ipx_sqp_cg_timing(int on, double *ms_total, int *calls) {
+  if (on) {
+    g_cg_timing.on = true;
+    return IPX_OK;
+  }
+  g_cg_timing.on = false;
+  double tot = 0.0;
+  int n = 0;
+  for (auto &pr : g_cg_timing.ev) {
+    float ms = 0.f;
+    if (hipEventSynchronize(pr.second) == hipSuccess &&
+        hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) { tot += ms; ++n; }
+    (void)hipEventDestroy(pr.first);
+    (void)hipEventDestroy(pr.second);
+  }
+  g_cg_timing.ev.clear();
+  if (ms_total) *ms_total = tot;
+  if (calls) *calls = n;
+  return IPX_OK;
 }
 
 void ipx_sqp_model_host(double *q) { sqp_model(q); }
@@ -781,9 +816,16 @@ int ipx_sqp_front(const ipx_sqp_args *s, int have_dn, int with_dogleg, int with_
                        s->lbt, s->ubt);
     IPX_CHECK_LAUNCH();
   }
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (g_cg_timing.on && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess)
+    (void)hipEventRecord(e0, st);
   rc = ipx_cg_prime_dev(a, s->A_tiles, (int32_t)s->A_ntiles, s->ct, nullptr, s->red, s->ws, tol_in,
                         0.0, s->q + SQ_RADIUS_T, s->orth_tol, norm_A, nullptr, s->cancellation,
                         first_end, with_steps, st);
+  if (e0 && e1) {
+    (void)hipEventRecord(e1, st);
+    g_cg_timing.ev.emplace_back(e0, e1);
+  }
   if (rc) return rc;
   return ipx_sqp_model(s, penalty, f, norm_b, 0, stream);
 }

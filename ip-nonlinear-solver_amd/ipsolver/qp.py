@@ -177,13 +177,27 @@ def projected_cg(H, c, Z, Y, b, trust_radius=np.inf, lb=None, ub=None, tol=None,
     Hessian product and its norm are not formed (same values: 0, and 0 + c = c exactly)."""
     from . import cg_fused
     b_zero = b is None
+    if not b_zero and not hasattr(b, "sumsq_amax"):
+        # a HOST right-hand side (the reference's calling convention: numpy arrays) that is all
+        # zero is the same call: one pass over m doubles on the host instead of a solve, two
+        # products and an upload on the device.  (A device vector is taken as it comes: whether
+        # it is zero is not known without reading it back.)
+        bh = np.asarray(b, dtype=float)
+        if bh.ndim == 1 and not bh.any():
+            b_zero = True
     c = _vec(c)
+    fused = not return_all and cg_fused.supports(H, Z, Y)
     if b_zero:
         P = getattr(Z, "projector", None)
-        b = P.sh.zeros(P.A.row_kind) if hasattr(P, "sh") else DVec.zeros(Y.shape[1])
+        if hasattr(P, "sh"):
+            b = P.sh.zeros(P.A.row_kind)
+        elif fused:
+            b = DVec(dv._empty(Y.shape[1]))      # (its length is all the fused path asks of it)
+        else:
+            b = DVec.zeros(Y.shape[1])
     b = _vec(b)
     lb, ub = _optvec(lb), _optvec(ub)
-    if not return_all and cg_fused.supports(H, Z, Y):
+    if fused:
         return cg_fused.projected_cg(H, c, Z, Y, b, trust_radius, lb, ub, tol,
                                      max_iter, max_infeasible_iter, b_zero=b_zero)
     if not return_all and getattr(getattr(Z, "projector", None), "fused_sharded", False):

@@ -27,6 +27,8 @@ no formula of the method, only the order of the stages and the bookkeeping of th
 
 The second-order correction (:172-193), rare, is host-driven for both.
 """
+import time
+
 import numpy as np
 
 from . import sqp_chain as sc
@@ -37,6 +39,11 @@ from .sqp_chain import (RADIUS, PENALTY, F, NORM_B, NORM_DN, RADIUS_T, HDD, CD, 
 __all__ = ['equality_constrained_sqp']
 
 _SUFFICIENT = 1e-8         # SUFFICIENT_REDUCTION_RATIO (:53): the correction's own acceptance test
+
+# host seconds spent finishing projected-CG calls whose first batch (enqueued by the front chain)
+# did not end them -- with the GPU time of the chains' own CG part (ipx_sqp_cg_timing) the time
+# "inside projected_cg" of a solve (bench.py)
+TIMERS = {"host_cg_seconds": 0.0}
 
 
 class _Point:
@@ -251,6 +258,7 @@ class ChainStages:
             # the loop needs the host: more iterations, a box event, a refinement, a priming the
             # device turned down -- finish it with the general driver, then the model again
             sc.STATS["host_cg"] += 1
+            t_host = time.perf_counter()
             why = "host_cg_stop_%d" % stop if not on_device else "host_cg_outside_box"
             sc.STATS[why] = sc.STATS.get(why, 0) + 1
             c_t, radius_t = DVec(chain.ct), q[RADIUS_T]
@@ -277,6 +285,7 @@ class ChainStages:
                                               max_iter, max_iter, None, None, fast=False,
                                               primed_state=st, release=False,
                                               first_batch=first_end)
+            TIMERS["host_cg_seconds"] += time.perf_counter() - t_host
             L.args.x = dt.t.data_ptr()
             chain.bind(L, P, pt.x, pt.c, pt.b, box.lb, box.ub, scale, x_next)
             chain.model(penalty, pt.f, pt.norm_b, host_cg=True)

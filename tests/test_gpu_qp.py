@@ -1841,3 +1841,89 @@ def test_dense_jacobian_device_loop(ips, hessian):
         assert info == {k: info_g[k] for k in info} == {k: info_o[k] for k in info}, kw
         close(x, xo, 1e-9)
         close(x, host(xg), 1e-11)
+
+
+def test_box_schur_tail_is_refused_when_its_workgroups_outnumber_the_partials(ips):
+    """the per-item back substitution as the tail of the Schur solve's kernel writes
+    one ||g||^2 partial per WORKGROUP OF THE SOLVE into an array the consumer folds
+    ceil(items / 1024) entries of.  General rows of three variables (two variables per row:
+    n = 2 m + 1) give the solve more workgroups (m / 260) than that count (3 m / 1024): the tail
+    must be refused (the separate k_pairs_post launch runs) and the projection, its ||g||^2 and
+    a whole CG run must be right -- before the check they silently were not."""
+    import ctypes
+    import torch
+    import oracle
+    import ipsolver.cg_fused as cg_fused
+    from ipsolver import _hip
+    from ipsolver.boxschur import BoxSchurNormalSolver
+    m = 6000
+    n = 2 * m + 1
+    rng = np.random.default_rng(3)
+    rows = np.repeat(np.arange(m), 3)
+    cols = (2 * np.arange(m)[:, None] + np.arange(3)[None, :]).ravel()
+    J = sps.csr_matrix((rng.standard_normal(3 * m), (rows, cols)), shape=(m, n))
+    I = sps.eye(n, format="csr")
+    s = rng.uniform(1e-4, 2.0, m + 2 * n)
+    A = sps.bmat([[J, sps.diags(s[:m]), None, None],
+                  [-I, None, sps.diags(s[m:m + n]), None],
+                  [I, None, None, sps.diags(s[m + n:])]], format="csr")
+    A.sort_indices()
+    N, M = A.shape[1], A.shape[0]
+    Ad = ips.dv.DeviceCSR.from_scipy(A)
+    Z, LS, Y = ips.proj.projections(Ad)
+    solver = Z.projector.solver
+    assert isinstance(solver, BoxSchurNormalSolver)
+    args = solver.c_args()
+    assert args.AR_rowlen == 4 and args.gaffine and args.grp2       # the tail's other conditions hold
+    lib = _hip.load()
+    nblk = lib.ipx_boxschur_project_count(ctypes.byref(args))
+    geo = (ctypes.c_int32 * 2)()
+    assert lib.ipx_banded_decoupled_geometry(ctypes.c_void_p(solver.inner.handle), geo)
+    assert lib.ipx_banded_pcr_level(ctypes.c_void_p(solver.inner.handle)) > 0
+    assert geo[1] > nblk, (geo[1], nblk)            # more workgroups than partial entries
+    assert not args.post_own_g                      # ... so the tail is not offered
+    r = rng.standard_normal(N)
+    rd = ips.dv.DVec.from_host(r)
+    g = torch.empty(N, dtype=torch.float64, device="cuda")
+    pg = torch.full((2 * nblk + 64,), float("nan"), dtype=torch.float64, device="cuda")
+    pres = torch.zeros(M // 256 + 2, dtype=torch.float64, device="cuda")
+    n3, n4 = ctypes.c_int32(0), ctypes.c_int32(0)
+    _hip.call("ipx_boxschur_project", ctypes.byref(args), ips.dv._p(rd.t), ips.dv._p(g),
+              ips.dv._p(pg), ctypes.byref(n3), ips.dv._p(pres), ctypes.byref(n4), None,
+              ips.dv.stream_ptr())
+    got = g.cpu().numpy()
+    lu = sps.linalg.splu(sps.csc_matrix(A @ A.T))
+    want = r - A.T @ lu.solve(A @ r)
+    assert np.max(np.abs(got - want)) <= 1e-10 * np.max(np.abs(r))
+    assert n3.value == nblk
+    assert bool(torch.isnan(pg[2 * nblk:]).all())   # nothing written past the two halves
+    assert abs(float(pg[:nblk].sum()) - float(got @ got)) <= 1e-12 * float(got @ got)
+    assert float(pg[nblk:2 * nblk].abs().sum()) == 0.0
+    # a C caller that hands the tail's tables over anyway is turned down by the library itself
+    # (the launch falls back to the separate back substitution: same g)
+    from ipsolver.boxschur import _i32
+    own = _i32(np.minimum(np.arange(geo[1] + 1) * 1000, n))
+    forced = type(args).from_buffer_copy(args)
+    forced.post_own_g, forced.post_own_e = own.data_ptr(), own.data_ptr()
+    forced.post_rows_wg, forced.post_reach = geo[0], 1
+    g2 = torch.empty_like(g)
+    pg.fill_(float("nan"))
+    _hip.call("ipx_boxschur_project", ctypes.byref(forced), ips.dv._p(rd.t), ips.dv._p(g2),
+              ips.dv._p(pg), ctypes.byref(n3), ips.dv._p(pres), ctypes.byref(n4), None,
+              ips.dv.stream_ptr())
+    assert np.array_equal(g2.cpu().numpy(), got)
+    assert bool(torch.isnan(pg[2 * nblk:]).all())
+    # the device loop on the barrier-shaped subproblem against the oracle
+    Hz = sps.diags(rng.uniform(0.5, 2.0, N), format="csr")
+    Hd = ips.dv.DeviceCSR.from_scipy(Hz)
+    c = rng.standard_normal(N)
+    b = np.zeros(M)
+    lb = np.concatenate((np.full(n, -np.inf), np.full(N - n, -0.995)))
+    x, info = cg_fused.projected_cg(Hd, ips.dv.DVec.from_host(c), Z, Y, ips.dv.DVec.from_host(b),
+                                    trust_radius=5.0, lb=ips.dv.DVec.from_host(lb), tol=1e-10)
+    Zo, _, Yo = oracle.projections(A)
+    xo, io = oracle.projected_cg(Hz, c, Zo, Yo, b, trust_radius=5.0, lb=lb,
+                                 ub=np.full(N, np.inf), tol=1e-10)
+    assert (info["stop_cond"], info["hits_boundary"], info["niter"]) == \
+        (io["stop_cond"], io["hits_boundary"], io["niter"])
+    close(x, xo, 1e-10)
