@@ -21,6 +21,7 @@ Outputs (numbers only -- no reference source travels):
                     orth_tol=1e-18, max_refin 100 / 10) and rank-deficient Jacobians
                     (SVD fallback, projections.py:101-108,181-187,236-287)
   e2e_n20000.json   (``--n20000``) banded equality NLP at n=20000 / m=2000, both methods
+  e2e_n100000.json  (``--n100000``) the same at n=100000 / m=10000 (world = 8 sharded tests)
   e2e_ineq_n12000.json  (``--ineq12000``: 4 minutes) box + inequality NLP at n=12000 / m=1200
   config3_n1e6.json (``--config3``: 7 minutes) BASELINE config 3 at its FULL size n=1e6 /
                     m=1e5 through the reference: all rows of the scalar trace, every 1000th
@@ -563,6 +564,19 @@ def main():
             out[key] = run_e2e(key, prob.fun, prob.x0, prob.grad, prob.hess,
                                prob.constraints(ref), method=method)
         with open(os.path.join(HERE, "e2e_n20000.json"), "w") as f:
+            json.dump(out, f)
+        return
+    if "--n100000" in sys.argv:
+        # the same at a size that splits over 8 ranks and more (38 blocks of 260 rows): the
+        # world = 8 tests of the row-sharded solver; every 100th component of x
+        out = {}
+        prob = synthetic.CenteredBandedNLP(100000, 10000, eps=1e-3)
+        for method in ("tr_interior_point", "equality_constrained_sqp"):
+            key = "banded_eq_n100000_%s" % method
+            out[key] = run_e2e(key, prob.fun, prob.x0, prob.grad, prob.hess,
+                               prob.constraints(ref), x_stride=100, method=method)
+            out[key]["x_stride"] = 100
+        with open(os.path.join(HERE, "e2e_n100000.json"), "w") as f:
             json.dump(out, f)
         return
     if "--ineq12000" in sys.argv:

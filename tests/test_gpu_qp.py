@@ -404,7 +404,7 @@ def test_sharded_fused_loop_single_rank(ips):
     close(x.to_host(), host(x1), 1e-12)
 
 
-def _multi_rank_worker(rank, world, port, out_path, transport="dist"):
+def _multi_rank_worker(rank, world, port, out_path, transport="dist", n=20000, m=2000):
     import os
     import sys
     import torch
@@ -424,7 +424,7 @@ def _multi_rank_worker(rank, world, port, out_path, transport="dist"):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from ipsolver import sharded, qp
-        n, m = 20000, 2000
+        torch.set_num_threads(1)
         inst, sh, A, H = _sharded_problem(world, rank, n, m)
         # no torch.distributed call may happen between the boundaries of a batch of the
         # device loop when it runs on the peer mailboxes
@@ -548,7 +548,7 @@ def test_sharded_wider_band_takes_the_general_driver(tmp_path, ips):
         assert np.max(np.abs(r[4:-1])) <= 1e-11 * r[-1], name
 
 
-def _desync_worker(rank, world, port, out_path, mode="lone"):
+def _desync_worker(rank, world, port, out_path, mode="lone", n=20000, m=2000):
     import os
     import sys
     import warnings
@@ -564,7 +564,8 @@ def _desync_worker(rank, world, port, out_path, mode="lone"):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from ipsolver import sharded, qp, _hip
-        inst, sh, A, H = _sharded_problem(world, rank, 20000, 2000)
+        torch.set_num_threads(1)
+        inst, sh, A, H = _sharded_problem(world, rank, n, m)
         Z, LS, Y = sharded.projections(A)
         c = sh.from_global(inst.c, "col")
         x, info = qp.projected_cg(H, c, Z, Y, sh.zeros("row"), tol=0, max_iter=10)
@@ -719,6 +720,69 @@ def test_sharded_fused_loop_multi_rank(world, transport, tmp_path, banded20000, 
         assert list(got["pcg_%s_info" % name]) == [info1["niter"], info1["stop_cond"],
                                                     int(info1["hits_boundary"])]
         close(got["pcg_%s_x" % name], host(x1), 1e-12)
+
+
+@pytest.mark.parametrize("transport", ["ipc-resident", "ipc"])
+def test_sharded_fused_loop_eight_ranks(transport, tmp_path, ips):
+    """The rank count of the target node: EIGHT processes share cuda:0 (n = 100000, m = 10000:
+    39 blocks of 260 rows, 4 or 5 per rank, six interior ranks with both neighbours; every
+    workgroup of every rank co-resident for the resident PEER form -- one per compute unit).
+    Every exit of the loop (tolerance, trust region, box events) and the refining projections
+    against the single-GPU device loop to 1e-12 and against the oracle; the mailbox tables for
+    eight peers, the rank-ordered folds over eight contributions, seven neighbour pairs of halo
+    slots."""
+    import socket
+    import torch.multiprocessing as mp
+    import oracle
+    n, m, world = 100000, 10000, 8
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "x8.npz")
+    mp.spawn(_multi_rank_worker, args=(world, port, out, transport, n, m), nprocs=world, join=True)
+    got = np.load(out)
+    inst = BandedInstance(n, m)
+    A1 = ips.dv.DeviceCSR.from_scipy(inst.A)
+    H1 = ips.dv.DeviceCSR.from_scipy(inst.H)
+    Z1, _, Y1 = ips.proj.projections(A1)
+    gnorm = ips.dv.norm(Z1.dot(inst.c))
+    for name, kw in inst.pcg_variants(gnorm).items():
+        x1, info1 = ips.qp.projected_cg(H1, inst.c, Z1, Y1, np.zeros(m), **kw)
+        assert list(got["pcg_%s_info" % name]) == [info1["niter"], info1["stop_cond"],
+                                                    int(info1["hits_boundary"])], name
+        close(got["pcg_%s_x" % name], host(x1), 1e-12)
+    Zo, _, Yo = oracle.projections(inst.A, "NormalEquation", orth_tol=1e-30, max_refin=2)
+    xo, _ = oracle.projected_cg(inst.H, inst.c, Zo, Yo, np.zeros(m), tol=0, max_iter=15)
+    close(got["refine_x"], xo)
+    fused_calls, box_events, refine_events, exchanges = got["stats"]
+    assert got["fused_min"][0] >= 6 and box_events > 0 and refine_events >= 14
+    is_ipc, ipc_batches, ipc_iterations, leaks, seq, hseq, fused = got["ipc"]
+    assert is_ipc == 1 and leaks == 0 and ipc_batches > 10 and ipc_iterations > 100
+    res_batches, res_syncs, res_launches = got["resident"]
+    if transport == "ipc-resident":
+        assert res_batches >= 6 and res_launches == res_batches and fused == 0
+    else:
+        assert res_batches == 0 and 100 <= fused < 2 * ipc_iterations
+
+
+def test_eight_ranks_survive_a_rank_out_of_step(tmp_path, ips):
+    """``resident-lone`` of the test above on EIGHT ranks: one rank enqueues a resident batch
+    twice, its tags run ahead, the waits of all eight ranks' workgroups time out (stop code 7,
+    nothing written back), the group agrees and solves the subproblem again through
+    torch.distributed: the iterates of before the incident."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "desync8.npz")
+    mp.spawn(_desync_worker, args=(8, port, out, "resident-lone", 100000, 10000), nprocs=8,
+             join=True)
+    got = np.load(out)
+    assert list(got["flags"]) == [1.0, 1.0, 1.0] and int(got["lone"][0]) == 1
+    assert list(got["niter"]) == [10, 10, 10]
+    close(got["x2"], got["x"], 1e-13)
+    close(got["x3"], got["x"], 1e-13)
 
 
 def _refusal_worker(rank, world, port, out_path):
