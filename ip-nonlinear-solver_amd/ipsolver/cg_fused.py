@@ -433,9 +433,11 @@ def _loop_for(H, P, lb, ub):
     if L is not None and L.rebind(H, P, lb, ub):
         POOL_STATS["reused"] += 1
         L.enqueued = None
+        if key in _NO_RESIDENT:
+            L.args.resident = 0
         return L, key
     POOL_STATS["built"] += 1
-    L = _Loop(H, P, lb, ub)
+    L = _Loop(H, P, lb, ub, resident=False if key in _NO_RESIDENT else None)
     L.enqueued = None            # (the batch ipx_cg_prime enqueued behind the priming, if any)
     return L, key
 
@@ -673,6 +675,15 @@ class _PrimeRetry(Exception):
     """The device found that the call's priming needs the host (stop code 9)."""
 
 
+class _ResidentGaveUp(Exception):
+    """A resident launch timed out (stop code 8): the call starts over on the separate
+    launches (the loop object has ``resident`` cleared)."""
+
+
+_NO_RESIDENT = set()       # pool signatures whose resident launches timed out once
+_INJECT_RESIDENT_TIMEOUT = []      # tests append one item: the next resident batch "times out"
+
+
 def projected_cg(H, c, Z, Y, b, trust_radius=np.inf, lb=None, ub=None, tol=None,
                  max_iter=None, max_infeasible_iter=None, batch=None, stats=None, b_zero=False):
     """qp_subproblem.py:416-643 on the device-resident loop.  The call first tries a priming
@@ -689,6 +700,19 @@ def projected_cg(H, c, Z, Y, b, trust_radius=np.inf, lb=None, ub=None, tol=None,
     # call whose device priming was turned down, calls on the same problem (same patterns: the
     # loop pool's signature) go to the host priming directly -- until one of them gets by
     # without refinement or cancellation steps, which the host priming counts anyway.
+    try:
+        return _projected_cg_once(H, c, Z, Y, b, trust_radius, lb, ub, tol, max_iter,
+                                  max_infeasible_iter, batch, stats, b_zero)
+    except _ResidentGaveUp:
+        # (once per pattern: the retry and every later call run the separate launches)
+        return _projected_cg_once(H, c, Z, Y, b, trust_radius, lb, ub, tol, max_iter,
+                                  max_infeasible_iter, batch, stats, b_zero)
+
+
+def _projected_cg_once(H, c, Z, Y, b, trust_radius, lb, ub, tol, max_iter, max_infeasible_iter,
+                       batch, stats, b_zero):
+    P = Z.projector
+    from .projector import NormalEquationProjector
     key = _signature(H, P, lb, ub) if isinstance(P, NormalEquationProjector) else None
     if isinstance(P, NormalEquationProjector) and P.m > 0 and len(c) - len(b) >= 1 \
             and (max_iter is None or max_iter >= 1) and trust_radius >= 0 \
@@ -899,16 +923,29 @@ def _run_loop(L, pool_key, P, lib, st, n, lb, ub, trust_radius, max_iter, max_in
                 if release:
                     _release(L, pool_key)
                 raise _PrimeRetry()
+            if _INJECT_RESIDENT_TIMEOUT and L.args.resident and int(s[ST_STOP]) in (0, 4):
+                # (test hook, one shot: what a resident launch leaves when a late workgroup
+                # commits alone -- stop code 8 and HALF of x advanced)
+                _INJECT_RESIDENT_TIMEOUT.pop()
+                L.x[: L.n // 2] += 1.0
+                L.state[ST_STOP] = 8.0
+                s = list(s)
+                s[ST_STOP] = 8.0
             if int(s[ST_STOP]) == 8 and L.args.resident:
                 # a hand-off of the resident launch timed out (a workgroup that never became
-                # resident: the GPU shared with another process's kernels).  The launch wrote
-                # nothing back: repeat the batch on the separate launches, for good.
-                L.args.resident = 0
+                # resident: the GPU shared with another process's kernels).  The workgroups
+                # that saw every record of the commit hop before THEIR deadline have written
+                # their part of x, p, r, Hp back, one that arrived past it has not (or the
+                # other way round: a late one that then finds all records commits alone): the
+                # loop's vectors cannot be trusted.  The CALL's inputs can -- the subproblem is
+                # solved again from its priming, on the separate launches, and this pattern
+                # stays on them (the row-sharded loop does the same on its stop code 7).
                 STATS["resident_fallbacks"] += 1
+                if pool_key is not None:
+                    _NO_RESIDENT.add(pool_key)
+                L.args.resident = 0
                 L.state[ST_STOP] = 0.0
-                _hip.check(lib.ipx_cg_iterate(L.ref(), self.last[0], self.last[1], st),
-                           "ipx_cg_iterate")
-                s = dv.read_doubles(L.state, L.state.numel())
+                raise _ResidentGaveUp()
             return s
 
         def X(self):

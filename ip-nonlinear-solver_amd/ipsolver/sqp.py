@@ -278,6 +278,15 @@ class ChainStages:
                                                   lb_t, ub_t, None, None, None, None, None, True,
                                                   fast=False)
                 L, key = cg_fused._loop_for(H, P, lb_t, ub_t)
+            elif stop == 8:
+                # a resident launch timed out: the loop's vectors are void, the call's inputs
+                # are not -- the tangential step again from its priming, separate launches
+                L.enqueued = None
+                cg_fused.STATS["resident_fallbacks"] += 1
+                if key is not None:
+                    cg_fused._NO_RESIDENT.add(key)
+                dt, info = self.xp.projected_cg(H, c_t, pt.Z, pt.Y, None, radius_t, lb_t, ub_t)
+                L, key = cg_fused._loop_for(H, P, lb_t, ub_t)
             else:
                 lbf = lb_t if lb_t is not None or not box.any else DVec.full(n, -np.inf)
                 ubf = ub_t if ub_t is not None or not box.any else DVec.full(n, np.inf)

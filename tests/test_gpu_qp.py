@@ -1342,6 +1342,40 @@ def test_resident_loop_matches_the_separate_launches(ips, n, m, monkeypatch):
         assert np.max(np.abs(x0 - x1)) <= 1e-13 * np.max(np.abs(x1)), (k, np.max(np.abs(x0 - x1)))
 
 
+def test_resident_timeout_restarts_the_call(ips, monkeypatch):
+    """A resident launch in which a hand-off timed out (stop code 8) may have been committed by
+    some of its workgroups and not by others -- one that arrives past the others' deadline and
+    then finds every record commits alone (the commit hop is not transactional).
+    The loop's vectors are therefore not replayed from: the CALL starts over from its priming on
+    the separate launches, and the pattern stays on them.  Injected: after a resident batch,
+    stop code 8 with half of x advanced.  Same result as an undisturbed call, through the public
+    call and through the outer iteration's chain."""
+    import ipsolver.cg_fused as cg_fused
+    monkeypatch.delenv("IPX_DEBUG_FORMS", raising=False)
+    inst = BandedInstance(20000, 2000)
+    A = ips.dv.DeviceCSR.from_scipy(inst.A)
+    H = ips.dv.DeviceCSR.from_scipy(inst.H)
+    Z, LS, Y = ips.proj.projections(A)
+    b = np.zeros(2000)
+    cg_fused._NO_RESIDENT.clear()
+    x0, i0 = ips.qp.projected_cg(H, inst.c, Z, Y, b, tol=0, max_iter=25)
+    before = dict(cg_fused.STATS)
+    assert before["resident_calls"] > 0
+    cg_fused._INJECT_RESIDENT_TIMEOUT.append(1)
+    x1, i1 = ips.qp.projected_cg(H, inst.c, Z, Y, b, tol=0, max_iter=25)
+    assert not cg_fused._INJECT_RESIDENT_TIMEOUT
+    assert cg_fused.STATS["resident_fallbacks"] == before["resident_fallbacks"] + 1
+    assert i1 == i0
+    assert np.max(np.abs(host(x1) - host(x0))) <= 1e-13 * np.max(np.abs(host(x0)))
+    # the pattern stays on the separate launches
+    calls = cg_fused.STATS["resident_calls"]
+    x2, i2 = ips.qp.projected_cg(H, inst.c, Z, Y, b, tol=0, max_iter=25)
+    assert cg_fused.STATS["resident_calls"] == calls and i2 == i0
+    assert np.array_equal(host(x2), host(x1))
+    cg_fused._NO_RESIDENT.clear()
+    cg_fused._POOL.clear()
+
+
 @pytest.mark.parametrize("n,m,hbw,abw,seed", [(5000, 400, 2, 9, 0), (12345, 1500, 3, 6, 1),
                                                (3001, 299, 1, 21, 2), (40000, 2500, 5, 30, 3),
                                                (30000, 3000, 2, 30, 4), (30000, 3000, 1, 30, 5),
