@@ -490,6 +490,17 @@ void ipx_peer_destroy(void *peer);
 /* `reps` all-reduces (sum) of nq <= 8 doubles back to back: the mailbox path's latency probe. */
 int ipx_peer_allreduce(void *peer, int32_t nq, const double *in, double *out, int *failed,
                        int32_t reps, void *stream);
+/* The outer loops' collectives through the mailboxes (no torch.distributed call, no upload):
+ * all-gather of nq <= 7 scalars per rank, the caller's own in HOST memory (passed to the kernel
+ * by value) -> out (device): world * nq doubles in rank order + 2 (an earlier halo exchange
+ * timed out on some rank / this all-gather did);
+ * halo exchange of nseg <= 4 segments of a local vector (geom: seg_lo, own_lo, own_hi, seg_hi,
+ * send_left, send_right per segment, local indices).  Both collective (every rank, same
+ * arguments' shapes), neither synchronises; failed: device int, set when a wait timed out. */
+int ipx_peer_allgather(void *peer, int32_t nq, const double *vals, double *out, int *failed,
+                       void *stream);
+int ipx_peer_exchange(void *peer, double *v, int32_t nseg, const int64_t *geom, int *failed,
+                      void *stream);
 /* `reps` round trips of one tagged word with `partner` (-1: sit the round out; every rank of
  * the group calls it once per round, the sequence numbers advance alike): ticks2[0] = 100 MHz
  * wall-clock ticks of the exchange, ticks2[1] = 1 when a wait timed out (device int64[2]).

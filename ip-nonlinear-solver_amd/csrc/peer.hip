@@ -16,6 +16,8 @@
 
 namespace {
 
+constexpr long long IPX_PEER_HOST_PATIENCE = 16;
+
 // all-reduce(sum) of nq doubles and nothing else: the latency probe of bench.py
 __global__ void __launch_bounds__(64)
 k_peer_allreduce(ipx_peer_view pv, uint32_t seq, int nq, const double *__restrict__ in,
@@ -41,6 +43,97 @@ k_peer_allreduce(ipx_peer_view pv, uint32_t seq, int nq, const double *__restric
     for (int r = 0; r < pv.world; ++r) s += vals[r * IPX_PEER_NQ + tid];   // rank order: same bits everywhere
     out[tid] = s;
   }
+}
+
+// all-gather of nq <= 7 doubles per rank, the rank's own passed BY VALUE (no upload on the way):
+// out[r * nq + q] = rank r's q-th value, then two failure words.  The
+// outer loops' scalar collectives (a pack of norms and dot products: summed / maximised over
+// the ranks by the host, in rank order -- the same bits on every rank) without a call into
+// torch.distributed.
+struct ipx_vals8 { double v[IPX_PEER_NQ]; };
+__global__ void __launch_bounds__(128)
+k_peer_allgather(ipx_peer_view pv, uint32_t seq, int nq, ipx_vals8 mine, double *__restrict__ out,
+                 int *__restrict__ failed) {
+  // (word nq of every rank: its sticky failure word -- a halo exchange of ITS that timed out
+  // -- so that the whole group learns of it at the same collective)
+  const int tid = threadIdx.x, slot = seq & (IPX_PEER_SLOTS - 1), nw = nq + 1;
+  // Sixteen times the patience of a wait inside the loop's kernels: the host's collectives run
+  // BETWEEN those kernels, and a rank whose kernels are just sitting out their own deadlines
+  // (up to eight times the base one: the resident form's commit hop) is late, not gone.  A wait
+  // that gave up while the late rank then found this rank's words would split the group -- one
+  // rank on the mailboxes, one on the fall-back transport, each waiting for the other.
+  const long long deadline = (long long)wall_clock64() + IPX_PEER_HOST_PATIENCE * pv.timeout_ticks;
+  __shared__ int bad, before;
+  const double failed_mine = (double)*failed;
+  if (tid == 0) { bad = 0; before = 0; }
+  __syncthreads();
+  for (int i = tid; i < pv.world * nw; i += blockDim.x) {
+    const int r = i / nw, q = i - r * nw;
+    double v = mine.v[0];
+#pragma unroll
+    for (int k = 1; k < IPX_PEER_NQ; ++k) v = q == k ? mine.v[k] : v;
+    if (q == nq) v = failed_mine;
+    ipx_ll_store(pv.mbox[r] + ipx_peer_scal_word(slot, pv.rank, q), v, seq);
+  }
+  bool ok = true;
+  for (int i = tid; i < pv.world * nw; i += blockDim.x) {
+    const int r = i / nw, q = i - r * nw;
+    double v = 0.0;
+    ok = ipx_ll_load(pv.mbox[pv.rank] + ipx_peer_scal_word(slot, r, q), seq, v, deadline) && ok;
+    if (q < nq) out[r * nq + q] = v;
+    else if (v != 0.0) before = 1;
+  }
+  if (!ok) bad = 1;
+  __syncthreads();
+  if (tid == 0) {
+    // [world nq]: an EARLIER halo exchange timed out on some rank -- what it left in the halos
+    // cannot be repaired: every rank raises; [world nq + 1]: this collective's own wait did --
+    // the group repeats it on another transport
+    out[pv.world * nq] = (double)before;
+    out[pv.world * nq + 1] = (double)bad;
+  }
+}
+
+// halo exchange of up to four segments of a local vector v (each [seg_lo | own_lo .. own_hi |
+// seg_hi)): this rank's first / last own entries go into the neighbours' halo areas, its own
+// halo entries are taken from what the neighbours stored here -- the conventions of the loop's
+// own kernels (csrc/cg.hip k_cg_step2_hp PEER: areas by parity of the halo sequence number).
+__global__ void __launch_bounds__(IPX_BLOCK)
+k_peer_exchange(ipx_peer_job pj, double *__restrict__ v, int *__restrict__ failed) {
+  const ipx_peer_view &pv = pj.pv;
+  const int tid = threadIdx.x, par = pj.hseq & 1;
+  if (pv.rank > 0)
+    for (int k = 0; k < pj.nseg; ++k)
+      for (int j = tid; j < pj.send_left[k]; j += IPX_BLOCK)
+        ipx_ll_store(pv.mbox[pv.rank - 1] + ipx_peer_halo_word(pv.cap, 1, par, pj.push_l[k] + j),
+                     v[pj.own_lo[k] + j], pj.hseq);
+  if (pv.rank < pv.world - 1)
+    for (int k = 0; k < pj.nseg; ++k)
+      for (int j = tid; j < pj.send_right[k]; j += IPX_BLOCK)
+        ipx_ll_store(pv.mbox[pv.rank + 1] + ipx_peer_halo_word(pv.cap, 0, par, pj.push_r[k] + j),
+                     v[pj.own_hi[k] - pj.send_right[k] + j], pj.hseq);
+  // (the host collectives' patience, see k_peer_allgather: a neighbour that is merely late --
+  // it sat out a wait of its own -- must not cost the halos, which nothing repairs)
+  const long long deadline = (long long)wall_clock64() + IPX_PEER_HOST_PATIENCE * pv.timeout_ticks;
+  const unsigned long long *mine = pv.mbox[pv.rank];
+  bool ok = true;
+  for (int k = 0; k < pj.nseg; ++k) {
+    if (pv.rank > 0)
+      for (int col = pj.seg_lo[k] + tid; col < pj.own_lo[k]; col += IPX_BLOCK) {
+        double t = 0.0;
+        ok = ipx_ll_load(mine + ipx_peer_halo_word(pv.cap, 0, par, pj.off_l[k] + (col - pj.seg_lo[k])),
+                         pj.hseq, t, deadline) && ok;
+        v[col] = t;
+      }
+    if (pv.rank < pv.world - 1)
+      for (int col = pj.own_hi[k] + tid; col < pj.seg_hi[k]; col += IPX_BLOCK) {
+        double t = 0.0;
+        ok = ipx_ll_load(mine + ipx_peer_halo_word(pv.cap, 1, par, pj.off_r[k] + (col - pj.own_hi[k])),
+                         pj.hseq, t, deadline) && ok;
+        v[col] = t;
+      }
+  }
+  if (!ok) *failed = 1;
 }
 
 // `reps` round trips of one tagged word between this rank and `partner` (the lower rank
@@ -265,6 +358,59 @@ void ipx_peer_destroy(void *peer) {
     if (p->opened[r]) (void)hipIpcCloseMemHandle(p->opened[r]);
   if (p->view.mbox[p->view.rank]) (void)hipFree(p->view.mbox[p->view.rank]);
   delete p;
+}
+
+// All-gather of nq <= 7 host scalars per rank (vals: nq doubles of HOST memory, passed to the
+// kernel by value): out (device, world * nq + 1 doubles) receives every rank's values in rank
+// order and, last, two failure words: an earlier halo exchange timed out (failed: device int,
+// sticky, set by ipx_peer_exchange) / this all-gather did.  Collective: every rank calls it with the same nq.
+int ipx_peer_allgather(void *peer, int32_t nq, const double *vals, double *out, int *failed,
+                       void *stream) {
+  if (!peer || nq < 1 || nq > IPX_PEER_NQ - 1 || !vals || !out || !failed || !ipx_peer_ready(peer))
+    return IPX_EINVAL;
+  ipx_peer *p = (ipx_peer *)peer;
+  ipx_vals8 mine{};
+  for (int q = 0; q < nq; ++q) mine.v[q] = vals[q];
+  if (++p->seq == 0) ++p->seq;
+  hipLaunchKernelGGL(k_peer_allgather, dim3(1), dim3(128), 0, (hipStream_t)stream, p->view, p->seq,
+                     (int)nq, mine, out, failed);
+  IPX_CHECK_LAUNCH();
+  return IPX_OK;
+}
+
+// Halo exchange of nseg <= 4 segments of the local vector v.  geom: 6 ints per segment --
+// seg_lo, own_lo, own_hi, seg_hi (local indices), send_left, send_right (own entries the left /
+// right neighbour keeps as halo).  Collective; never synchronises; a wait that times out sets
+// *failed (device int, sticky).
+int ipx_peer_exchange(void *peer, double *v, int32_t nseg, const int64_t *geom, int *failed,
+                      void *stream) {
+  if (!peer || !v || nseg < 1 || nseg > 4 || !geom || !failed || !ipx_peer_ready(peer))
+    return IPX_EINVAL;
+  ipx_peer *p = (ipx_peer *)peer;
+  ipx_peer_job pj;
+  memset(&pj, 0, sizeof(pj));
+  pj.pv = p->view;
+  pj.nseg = nseg;
+  int64_t inl = 0, inr = 0, outl = 0, outr = 0;
+  for (int k = 0; k < nseg; ++k) {
+    const int64_t *g = geom + 6 * k;
+    pj.seg_lo[k] = (int)g[0]; pj.own_lo[k] = (int)g[1]; pj.own_hi[k] = (int)g[2];
+    pj.seg_hi[k] = (int)g[3]; pj.send_left[k] = (int)g[4]; pj.send_right[k] = (int)g[5];
+    if (g[0] > g[1] || g[1] > g[2] || g[2] > g[3] || g[4] < 0 || g[5] < 0 || g[4] > g[2] - g[1] ||
+        g[5] > g[2] - g[1])
+      return IPX_EINVAL;
+    pj.off_l[k] = (int)inl; pj.off_r[k] = (int)inr; pj.push_l[k] = (int)outl; pj.push_r[k] = (int)outr;
+    inl += g[1] - g[0]; inr += g[3] - g[2]; outl += g[4]; outr += g[5];
+  }
+  if (inl > p->view.cap || inr > p->view.cap || outl > p->view.cap || outr > p->view.cap)
+    return IPX_EINVAL;
+  if (++p->hseq == 0) ++p->hseq;
+  pj.hseq = p->hseq;
+  pj.seq = p->seq;
+  hipLaunchKernelGGL(k_peer_exchange, dim3(1), dim3(IPX_BLOCK), 0, (hipStream_t)stream, pj, v,
+                     failed);
+  IPX_CHECK_LAUNCH();
+  return IPX_OK;
 }
 
 // `reps` all-reduces of nq <= 8 doubles, back to back on `stream` (in / out: device arrays;

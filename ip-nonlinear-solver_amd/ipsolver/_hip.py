@@ -100,6 +100,8 @@ _SIGNATURES = {
     "ipx_peer_ready": [_P],
     "ipx_peer_sequence": [_P, _P],
     "ipx_peer_allreduce": [_P, _I32, _P, _P, _P, _I32, _P],
+    "ipx_peer_allgather": [_P, _I32, _P, _P, _P, _P],
+    "ipx_peer_exchange": [_P, _P, _I32, _P, _P, _P],
     "ipx_aat_band": [_I64, _I32, _P, _P, _P, _P, _P, _P],
     "ipx_aat_band_w": [_I64, _I32, _P, _P, _P, _P, _P, _P, _P],
     "ipx_pairs_factor": [_I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],

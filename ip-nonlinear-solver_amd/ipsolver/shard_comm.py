@@ -20,7 +20,14 @@ class ShardComm:
         # (ipc_*: batches / iterations of the device loop that ran on the peer mailboxes --
         # none of the four counters above moves between their boundaries)
         self.stats = {"all_reduce": 0, "all_reduce_bytes": 0, "exchange": 0, "exchange_bytes": 0,
-                      "ipc_batches": 0, "ipc_iterations": 0}
+                      "ipc_batches": 0, "ipc_iterations": 0, "ipc_gathers": 0, "ipc_exchanges": 0}
+        # the group's peer mailboxes once they are mapped (Sharding.mailbox): the few-scalar
+        # collectives and the halo exchanges of the OUTER loops then go through them too --
+        # one kernel each, no call into torch.distributed (over gloo, the tests' and the
+        # one-GPU rehearsal's backend, such a call is 100-250 us of host staging; over RCCL
+        # ~25 us + a synchronisation)
+        self.mbox = None
+        self.on_mailbox_drop = None
 
     def all_reduce(self, t, op="sum"):
         """In place on a torch tensor (CUDA under nccl; CUDA tensors are staged through the
@@ -37,10 +44,35 @@ class ShardComm:
         else:
             dist.all_reduce(t, op=rop, group=self.group)
 
+    def _gather_floats(self, values):
+        """Every rank's values through the mailboxes: a list (by rank) of lists, or None when
+        this collective cannot take that road (no mailbox, too many values)."""
+        mb = self.mbox
+        if mb is None or not 1 <= len(values) <= mb.NQ:
+            return None
+        self.stats["ipc_gathers"] += 1
+        try:
+            return mb.allgather(values)
+        except MailboxOutOfStep as exc:
+            # this collective's own wait timed out -- on every rank (a rank whose sequence
+            # numbers ran ahead waits for tags nobody sends, the others for its): the group
+            # leaves the mailboxes together and repeats the collective on torch.distributed
+            from warnings import warn
+            warn("row-sharded solver: %s -- falling back to the torch.distributed transport for "
+                 "the rest of this process" % exc)
+            self.mbox = None
+            if self.on_mailbox_drop is not None:
+                self.on_mailbox_drop()
+            return None
+
     def reduce_floats(self, values, op="sum", device=None):
         """All-reduce of a few host scalars (one blocking round)."""
         if self.world == 1:
             return [float(v) for v in values]
+        parts = self._gather_floats(values)
+        if parts is not None:                 # (combined in rank order: the same bits everywhere)
+            comb = {"sum": sum, "max": max, "min": min}[op]
+            return [comb(p[q] for p in parts) for q in range(len(values))]
         t = torch.tensor([float(v) for v in values], dtype=torch.float64)
         if self.backend == "nccl":
             t = t.to(device if device is not None
@@ -55,6 +87,11 @@ class ShardComm:
         ns, nx, nn = len(sums), len(maxs), len(mins)
         if self.world == 1:
             return [float(v) for v in sums], [float(v) for v in maxs], [float(v) for v in mins]
+        parts = self._gather_floats([*sums, *maxs, *mins])
+        if parts is not None:
+            return ([sum(p[q] for p in parts) for q in range(ns)],
+                    [max(p[q] for p in parts) for q in range(ns, ns + nx)],
+                    [min(p[q] for p in parts) for q in range(ns + nx, ns + nx + nn)])
         t = torch.tensor([float(v) for v in (*sums, *maxs, *mins)], dtype=torch.float64)
         if self.backend == "nccl":
             t = t.to(torch.device("cuda", torch.cuda.current_device()))
@@ -66,10 +103,24 @@ class ShardComm:
         return (g[:, :ns].sum(0).tolist(), g[:, ns:ns + nx].max(0).values.tolist() if nx else [],
                 g[:, ns + nx:].min(0).values.tolist() if nn else [])
 
-    def exchange_many(self, jobs):
+    def _ipc_exchange(self, whole, jobs):
+        """The halo update of ``jobs`` (segments of the ONE local tensor ``whole``) through the
+        mailboxes; False when it cannot take that road."""
+        mb = self.mbox
+        if mb is None or whole is None or not whole.is_cuda or not 1 <= len(jobs) <= 4:
+            return False
+        if not mb.exchange(whole, jobs):
+            return False
+        self.stats["ipc_exchanges"] += 1
+        return True
+
+    def exchange_many(self, jobs, whole=None):
         """Several halo updates (tensor, own_lo, own_hi, send_left, send_right) as ONE batch of
-        point-to-point operations (the segments of a stacked vector)."""
+        point-to-point operations (the segments of a stacked vector; ``whole``: the local
+        tensor they are slices of, in order)."""
         if self.world == 1:
+            return
+        if self._ipc_exchange(whole, jobs):
             return
         ops, staged, r = [], [], self.rank
         for t, own_lo, own_hi, send_left, send_right in jobs:
@@ -149,6 +200,8 @@ class ShardComm:
         first; this rank sends its first ``send_left`` / last ``send_right`` own entries."""
         if self.world == 1:
             return
+        if self._ipc_exchange(t, [(t, own_lo, own_hi, send_left, send_right)]):
+            return
         n = t.numel()
         stage = t.is_cuda and self.backend != "nccl"
         buf = t.cpu() if stage else t
@@ -177,6 +230,10 @@ class ShardComm:
                 t[0:own_lo].copy_(buf[0:own_lo])
             if n - own_hi:
                 t[own_hi:n].copy_(buf[own_hi:n])
+
+
+class MailboxOutOfStep(RuntimeError):
+    """The wait of a mailbox all-gather timed out (nothing but this collective is lost)."""
 
 
 class PeerMailbox:
@@ -258,6 +315,60 @@ class PeerMailbox:
         if int(failed.item()):
             raise self._hip.IpxError("peer mailbox: a wait for a peer timed out")
         return out.tolist()
+
+    NQ = 7            # IPX_PEER_NQ - 1: scalars per rank of one all-gather (+ the failure word)
+
+    def _buffers(self):
+        if getattr(self, "_gout", None) is None:
+            from . import device as dv
+            dev = dv.ctx().device
+            self._gout = torch.zeros(self.comm.world * self.NQ + 2, dtype=torch.float64, device=dev)
+            self._failed = torch.zeros(2, dtype=torch.int32, device=dev)
+            self._vals = (ctypes.c_double * self.NQ)()
+            self._geom = (ctypes.c_int64 * 24)()
+        return self._gout, self._failed
+
+    def allgather(self, values):
+        """Every rank's ``values`` (<= 8 host scalars) as a list by rank: one kernel that takes
+        them by value, one blocking read (csrc/peer.hip ipx_peer_allgather).  Raises when a
+        wait of this or of an earlier mailbox collective (a halo exchange) timed out."""
+        from . import device as dv
+        out, failed = self._buffers()
+        nq, w = len(values), self.comm.world
+        for q, v in enumerate(values):
+            self._vals[q] = float(v)
+        self._hip.call("ipx_peer_allgather", ctypes.c_void_p(self.handle), nq, self._vals,
+                       ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(failed.data_ptr()),
+                       dv.stream_ptr())
+        got = dv.read_doubles(out, w * nq + 2)
+        if got[w * nq] != 0.0:
+            raise self._hip.IpxError("peer mailbox: a halo exchange timed out on a rank of the "
+                                     "group (a rank died or fell out of step); the halos it "
+                                     "left cannot be trusted")
+        if got[w * nq + 1] != 0.0:
+            raise MailboxOutOfStep("peer mailbox: a wait for a peer timed out (a rank of the "
+                                   "group died or fell out of step)")
+        return [got[r * nq:(r + 1) * nq] for r in range(w)]
+
+    def exchange(self, whole, jobs):
+        """Halo update of the segments ``jobs`` = (slice of ``whole``, own_lo, own_hi, send_left,
+        send_right) of one local CUDA tensor: one kernel, no synchronisation (a wait that times
+        out is reported by the next ``allgather``).  False: not representable (a slice that is
+        not a view into ``whole``)."""
+        from . import device as dv
+        _, failed = self._buffers()
+        base, g = whole.data_ptr(), self._geom
+        for k, (t, own_lo, own_hi, send_left, send_right) in enumerate(jobs):
+            off = (t.data_ptr() - base) // 8
+            if off < 0 or off + t.numel() > whole.numel() or not t.is_contiguous():
+                return False
+            g[6 * k:6 * k + 6] = [off, off + own_lo, off + own_hi, off + t.numel(),
+                                  send_left if self.comm.rank > 0 else 0,
+                                  send_right if self.comm.rank < self.comm.world - 1 else 0]
+        self._hip.call("ipx_peer_exchange", ctypes.c_void_p(self.handle),
+                       ctypes.c_void_p(base), len(jobs), g, ctypes.c_void_p(failed.data_ptr()),
+                       dv.stream_ptr())
+        return True
 
     def attach_resident(self):
         """The hand-off buffers of the resident loop kernel's PEER form (csrc/resident.hip), sized

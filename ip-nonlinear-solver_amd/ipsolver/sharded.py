@@ -103,7 +103,16 @@ class Sharding:
                 self.mailbox_error = mb.error
                 if mb.ok:
                     self._mailbox = mb
+                    # (the outer loops' small collectives take the same road from here on)
+                    if os.environ.get("IPX_SHARD_OUTER", "ipc") == "ipc":
+                        self.comm.mbox = mb
+                        self.comm.on_mailbox_drop = self._drop_mailbox
         return self._mailbox or None
+
+    def _drop_mailbox(self):
+        os.environ["IPX_SHARD_TRANSPORT"] = "dist"
+        self._mailbox = False
+        self.comm.mbox = None
 
     @property
     def transport(self):
@@ -161,7 +170,7 @@ class Sharding:
             self.comm.exchange(t[off:off + ln], lo, hi, sl, sr)
         else:
             self.comm.exchange_many([(t[off:off + ln], lo, hi, sl, sr)
-                                     for _, off, ln, lo, hi, sl, sr, _, _ in segs])
+                                     for _, off, ln, lo, hi, sl, sr, _, _ in segs], whole=t)
         return v
 
 
@@ -980,6 +989,7 @@ def _run_fused(H, P, c, x0, r0, g0, rt_g, tol, trust_radius, lb, ub, has_box, ma
              "for the rest of this process" % exc)
         os.environ["IPX_SHARD_TRANSPORT"] = "dist"
         sh._mailbox = False
+        sh.comm.mbox = None              # (the outer loops' collectives leave it as well)
         return _run_fused(H, P, c, x0, r0, g0, rt_g, tol, trust_radius, lb, ub, has_box, max_iter,
                           max_infeasible_iter, batch, retry=False)
 

@@ -570,7 +570,7 @@ def _desync_worker(rank, world, port, out_path, mode="lone", n=20000, m=2000):
         c = sh.from_global(inst.c, "col")
         x, info = qp.projected_cg(H, c, Z, Y, sh.zeros("row"), tol=0, max_iter=10)
         ok_before = sh.transport == "ipc"
-        sh.mailbox().set_timeout(2.0)       # (default 10 s: keep the test short)
+        sh.mailbox().set_timeout(0.5)       # (default 10 s: keep the test short)
         lone = 0
         if mode == "lone" and rank == 0:    # one rank falls out of step: an all-reduce alone
             try:
