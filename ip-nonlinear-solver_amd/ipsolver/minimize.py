@@ -184,6 +184,79 @@ def _minimize_device(fun, x0, grad, hess, constraints, method, xtol, gtol, optio
     return result
 
 
+def _minimize_distributed(fun, x0, grad, hess, constraints, method, xtol, gtol, options,
+                          callback, max_iter):
+    """``minimize_constrained`` with every callback on DISTRIBUTED data (one process per GPU):
+    ``x0`` is a ``sharded.ShardVec`` -- the rank's variables plus halo copies of a block either
+    side, on its device --, and so is every vector the callbacks see or return:
+
+        fun(x) -> float (the global value: ShardVec.dot reduces over the ranks)
+        grad(x) -> ShardVec
+        hess(x) -> ShardHessian | ShardVec (a diagonal) | a tuple of such terms
+        NonlinearConstraint(fun, kind, jac, hess):  fun(x) -> ShardVec over the constraint rows,
+            jac(x) -> ShardCSR,  hess(x, v) -> as ``hess`` (v: the rows' multipliers)
+        BoxConstraint(('interval', lb, ub)) with scalar bounds
+
+    Two shapes, as on the halo partition of the host-callback route (``_sharded_backend``):
+    one nonlinear constraint of kind ``('equals', 0)`` (BASELINE configs 3 / 4, either method)
+    and one of kind ``('less', 0)`` with an interval box on every variable (config 5).  Nothing
+    is gathered to a host or to one rank (reference _minimize_constrained.py:374-565 evaluates
+    ``fun(x)`` on the whole vector; here x never exists in one place)."""
+    from . import sharded
+    sh = x0.sh
+    if isinstance(constraints, (NonlinearConstraint, LinearConstraint, BoxConstraint)):
+        constraints = [constraints]
+    nl = [c for c in constraints if isinstance(c, NonlinearConstraint)]
+    boxes = [c for c in constraints if isinstance(c, BoxConstraint)]
+    if len(nl) != 1 or len(nl) + len(boxes) != len(list(constraints)) or len(boxes) > 1:
+        raise NotImplementedError("distributed callbacks: one NonlinearConstraint, optionally "
+                                  "with one BoxConstraint")
+    con = nl[0]
+    if not callable(hess) or not callable(con._hess):
+        raise NotImplementedError("distributed callbacks: exact Hessian callbacks (finite "
+                                  "differences evaluate host callbacks)")
+    nloc = sh.local_len("col")
+
+    def terms_of(h):
+        return [t for t in (h if isinstance(h, (tuple, list)) else [h]) if t is not None]
+
+    def lagr_hess(x, v):
+        terms = terms_of(hess(x)) + terms_of(con._hess(x, v))
+        mats = [t for t in terms if isinstance(t, sharded.ShardHessian)]
+        diags = [t for t in terms if isinstance(t, sharded.ShardVec)]
+        if len(mats) == 1 and len(mats) + len(diags) == len(terms) and hasattr(mats[0], "_csr"):
+            # ONE local matrix + diagonal terms: one operator the device-resident loop takes
+            d = None
+            for t in diags:
+                d = t if d is None else d + t
+            return sharded.ShardHessian(sh, sh.ops.hessian(nloc, mats[0]._csr,
+                                                           d.loc if d is not None else None))
+        parts = [t if not isinstance(t, sharded.ShardVec) else sharded._DiagOp(t) for t in terms]
+        return sharded.OperatorSum(sh, parts)
+
+    kind = con.kind
+    options = dict(options)
+    options.pop("barrier_tol", None)
+    if not boxes:
+        if not (isinstance(kind, (tuple, list)) and kind[0] == "equals" and np.all(np.asarray(kind[1]) == 0)):
+            raise NotImplementedError("distributed callbacks: kind ('equals', 0) without a box")
+        return sharded.minimize_equality_constrained(
+            sh, fun, grad, lagr_hess, con._fun, con._jac, x0, method=method, xtol=xtol, gtol=gtol,
+            max_iter=max_iter, callback=callback, **options)
+    bk = boxes[0].kind
+    if not (isinstance(kind, (tuple, list)) and kind[0] == "less" and np.all(np.asarray(kind[1]) == 0)
+            and isinstance(bk, (tuple, list)) and bk[0] == "interval"
+            and np.ndim(bk[1]) == 0 and np.ndim(bk[2]) == 0):
+        raise NotImplementedError("distributed callbacks: kind ('less', 0) with a BoxConstraint("
+                                  "('interval', lb, ub)) of scalar bounds")
+    if _METHODS.get(method or 'tr_interior_point') != 'tr_interior_point':
+        raise ValueError("'equality_constrained_sqp' does not support inequality constraints.")
+    return sharded.minimize_box_inequality(
+        sh, fun, grad, lagr_hess, con._fun, con._jac, x0, sh.full("col", float(bk[1])),
+        sh.full("col", float(bk[2])), xtol=xtol, gtol=gtol, max_iter=max_iter, callback=callback,
+        **options)
+
+
 class _ConstantArray(np.ndarray):
     """The value of a Hessian callback the caller declared constant (``options=
     {'constant_hessian': True}``): backend_hip keeps ONE device copy of it."""
@@ -303,9 +376,18 @@ def minimize_constrained(fun, x0, grad, hess='2-point', constraints=(), method=N
     # anyway, and a non-callable ``hess`` -- finite differences, quasi-Newton -- has no constant
     # value to keep)
     constant_hessian = bool(options.pop("constant_hessian", False))
+    if hasattr(x0, "sh") and hasattr(x0, "owns"):
+        # a DISTRIBUTED start vector (sharded.ShardVec): device-callback mode on the row-sharded
+        # backend -- the callbacks take and return distributed objects, nothing is gathered
+        return _minimize_distributed(fun, x0, grad, hess, constraints, method, xtol, gtol,
+                                     options, callback, max_iter)
     if _is_cuda_tensor(x0):
         if shard:
-            raise NotImplementedError("row-sharded solve: host callbacks (numpy x0) only")
+            raise NotImplementedError(
+                "row-sharded solve with device callbacks: pass the start vector as a distributed "
+                "vector (ipsolver.sharded.ShardVec: its layout tells every callback which rows "
+                "and variables are this rank's) -- see minimize._minimize_distributed; a plain "
+                "CUDA tensor carries no partition")
         return _minimize_device(fun, x0, grad, hess, constraints, method, xtol, gtol, options,
                                 callback, max_iter, verbose, _backend.get())
     xp = None if shard else _backend.get()

@@ -255,6 +255,32 @@ class DeviceCallbacks:
         return ns.NonlinearConstraint(self.constr_fun, kind, self.constr_jac, self.constr_hess)
 
 
+class DistributedCallbacks:
+    """The same NLP for ``minimize_constrained`` on the row-sharded backend with DEVICE
+    callbacks (``minimize._minimize_distributed``): the reference's callback set -- ``fun``,
+    ``grad``, ``hess`` and a ``NonlinearConstraint(fun, kind, jac, hess)`` -- over distributed
+    vectors; every rank holds its own rows and variables (+ halos), nothing is gathered."""
+
+    def __init__(self, prob, sh):
+        self._c = ShardedCallbacks(prob, sh)
+        self.p, self.sh, self.x0 = prob, sh, self._c.x0
+        self.fun, self.grad = self._c.fun, self._c.grad
+        self.constr_fun, self.constr_jac = self._c.constr_fun, self._c.constr_jac
+        from . import sharded
+        self._Q = sharded.ShardHessian(sh, sh.ops.hessian(self._c._nloc, self._c._Q_local, None))
+        self._Q._csr = self._c._Q_local
+
+    def hess(self, x):
+        dl = x - self._c.x_feas
+        return self._Q, 3 * self.p.rho * (dl * dl)        # (matrix term, diagonal term)
+
+    def constr_hess(self, x, v):
+        return self.p.kappa * self._c.W.T.dot(v)          # diagonal
+
+    def constraints(self, ns, kind=('equals', 0)):
+        return ns.NonlinearConstraint(self.constr_fun, kind, self.constr_jac, self.constr_hess)
+
+
 class LeanDeviceCallbacks(DeviceCallbacks):
     """The same callbacks written the way a user who watches the solve's wall clock writes them
     (user-land all the same: torch for the elementwise work, the library's public device types

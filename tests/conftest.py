@@ -18,6 +18,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """A test that hangs (a rank of a multi-process test waiting for a peer that died) must
+    end, not burn the run: 15 minutes per test unless it says otherwise (pytest-timeout, when
+    it is installed)."""
+    if not config.pluginmanager.hasplugin("timeout"):
+        return
+    for item in items:
+        if item.get_closest_marker("timeout") is None:
+            item.add_marker(pytest.mark.timeout(900))
+
+
 def unjson(v):
     """Inverse of make_golden.jf."""
     if isinstance(v, str):

@@ -584,7 +584,7 @@ def test_config5_style_moderate_size():
 
 
 # ---- the row-sharded solver end to end (HIP kernels, ranks share cuda:0 over gloo) ----------
-def _sharded_solve_worker(rank, world, port, method, out_path):
+def _sharded_solve_worker(rank, world, port, method, out_path, public=False):
     import os
     import sys
     import torch
@@ -612,9 +612,19 @@ def _sharded_solve_worker(rank, world, port, method, out_path):
                          float(state.optimality), float(state.constr_violation),
                          int(state.nfev)])
             return False
-        res = sharded.minimize_equality_constrained(
-            sh, cb.fun, cb.grad, cb.lagr_hess, cb.constr_fun, cb.constr_jac, cb.x0,
-            method=method, callback=record)
+        if public:
+            # the PUBLIC entry point: distributed start vector, distributed device callbacks
+            import ipsolver
+            from ipsolver.synthetic import DistributedCallbacks
+            torch.set_num_threads(1)
+            dcb = DistributedCallbacks(prob, sh)
+            res = ipsolver.minimize_constrained(dcb.fun, dcb.x0, dcb.grad, dcb.hess,
+                                                dcb.constraints(ipsolver), method=method,
+                                                callback=record)
+        else:
+            res = sharded.minimize_equality_constrained(
+                sh, cb.fun, cb.grad, cb.lagr_hess, cb.constr_fun, cb.constr_jac, cb.x0,
+                method=method, callback=record)
         x = res.x.to_host()
         if rank == 0:
             np.savez(out_path, x=x, rows=np.array(rows), fused=sharded.STATS["fused_calls"],
@@ -643,6 +653,24 @@ def test_sharded_full_solve_hip(method, tmp_path):
     import test_sharded_gloo as tg
     tg.check_config4(got, method)          # counters exact, every row at 1e-10 + 10 x one ulp
     assert int(got["fused"]) >= 1          # the device-resident sharded loop ran
+
+
+def test_minimize_constrained_with_distributed_device_callbacks(tmp_path):
+    """The public ``minimize_constrained`` with a distributed start vector on two ranks sharing
+    the GPU (HIP kernels, device-resident sharded CG loop, mailbox collectives in the outer
+    loop): the REFERENCE's config-4 trace at n = 20000 (minimize._minimize_distributed)."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    path = str(tmp_path / "pub.npz")
+    mp.spawn(_sharded_solve_worker, args=(2, port, "tr_interior_point", path, True), nprocs=2,
+             join=True)
+    got = np.load(path)
+    import test_sharded_gloo as tg
+    tg.check_config4(got, "tr_interior_point")
+    assert int(got["fused"]) >= 1
 
 
 def _sharded_barrier_worker(rank, world, port, out_path):

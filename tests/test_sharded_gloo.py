@@ -206,6 +206,55 @@ def check_config4(got, method, n=N):
     assert compare_rows(got["rows"], gold, x=x) == len(gold["trace"])
 
 
+def _public_distributed_worker(rank, world, port, method, out_path):
+    _setup(rank, world, port)
+    try:
+        import torch
+        torch.set_num_threads(1)
+        import ipsolver
+        from banded_setup import load_synthetic
+        from ipsolver import sharded
+        from ipsolver.synthetic import DistributedCallbacks
+        from oracle.numpy_local import NumpyOps
+        prob = load_synthetic().CenteredBandedNLP(N, M, eps=1e-3)
+        A = prob.A0.tocsr()
+        lay = sharded.ShardLayout(A.indptr, A.indices, A.shape, world, rank)
+        sh = sharded.Sharding(lay, sharded.ShardComm(), NumpyOps())
+        cb = DistributedCallbacks(prob, sh)
+        rows = []
+
+        def record(state):
+            rows.append([int(state.niter), int(state.cg_niter), float(state.trust_radius),
+                         float(state.penalty), float(getattr(state, "barrier_parameter", np.nan)),
+                         float(state.optimality), float(state.constr_violation),
+                         int(state.nfev)])
+            return False
+        # the PUBLIC entry point with a distributed start vector and distributed callbacks
+        res = ipsolver.minimize_constrained(cb.fun, cb.x0, cb.grad, cb.hess,
+                                            cb.constraints(ipsolver), method=method,
+                                            callback=record)
+        x = res.x.to_host()
+        if rank == 0:
+            np.savez(out_path, x=x, rows=np.array(rows),
+                     counts=np.array([res.status, res.niter, res.cg_niter, res.nfev, res.ngev,
+                                      res.nhev, res.ncev, res.njev]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("method", ["equality_constrained_sqp", "tr_interior_point"])
+def test_minimize_constrained_with_distributed_callbacks(method, tmp_path):
+    """``ipsolver.minimize_constrained(fun, x0, grad, hess, NonlinearConstraint(...))`` with
+    ``x0`` a distributed vector (sharded.ShardVec) and every callback over distributed objects
+    -- the device-callback mode of the row-sharded backend (minimize._minimize_distributed:
+    nothing is gathered; the objective's matrix term, its diagonal term and the constraint's
+    diagonal term are merged into ONE local operator) -- against the REFERENCE's trace of
+    config 4 in small, two ranks."""
+    path = str(tmp_path / "pub.npz")
+    mp.spawn(_public_distributed_worker, args=(2, _free_port(), method, path), nprocs=2, join=True)
+    check_config4(np.load(path), method)
+
+
 @pytest.mark.parametrize("method", ["equality_constrained_sqp", "tr_interior_point"])
 def test_sharded_full_solve_on_eight_ranks(method, tmp_path):
     """The same at the rank count of the target node: EIGHT processes (gloo), n = 100000 /
