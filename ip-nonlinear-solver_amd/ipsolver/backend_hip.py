@@ -204,31 +204,59 @@ def _immutable(a):
     return a is None
 
 
+FINGERPRINT_MIN_BYTES = 1 << 24      # arrays below 16 MB are simply uploaded again
+
+
+def _fingerprint(h):
+    """~1e5 probed entries of a large C-contiguous matrix as bytes: every (size // 65536)-th
+    entry, the diagonal, the first and the last row."""
+    flat = h.reshape(-1)
+    step = max(1, flat.size // 65536)
+    parts = [flat[::step], h[0], h[-1]]
+    if h.ndim == 2:
+        parts.append(np.diagonal(h))
+    return np.concatenate([np.ascontiguousarray(p).ravel() for p in parts]).tobytes()
+
+
 def _upload_dense_cached(h):
     """A dense Hessian term returned by a host callback.  The reference wraps ``hess(x)`` anew
     every iteration (_minimize_constrained.py:395-407); here that is an 800 MB upload per outer
     iteration for BASELINE config 2 (0.9 of its 1.6 s), although a quadratic objective returns
-    the SAME array every time.  Whether an array is unchanged cannot be established for less
-    than the upload costs (a checksum over every entry: 2.8 s instead of 1.6 s, measured) and a
-    sampled fingerprint would silently serve stale values to a callback that refills its
-    buffer in place -- so the device copy is reused only for arrays that CANNOT change: those
-    the caller has marked read-only (``H.setflags(write=False)``, numpy's own immutability
-    contract).  Writable arrays are uploaded every time, like the reference re-wraps them."""
-    # (... or that the caller declared constant: minimize_constrained's ``constant_hessian``)
+    the SAME array every time.  Arrays that CANNOT change -- marked read-only
+    (``H.setflags(write=False)``) or declared constant (``constant_hessian``) -- are uploaded
+    once.  A WRITABLE array at the same address, of the same shape, is recognised by a
+    fingerprint of ~1e5 probed entries (an exact comparison reads as many bytes as the upload
+    moves and is slower than it: 2.8 s instead of 1.6 s, measured): a callback that returns
+    the same matrix gets the device copy, one that computes a new matrix or refills its buffer
+    changes nearly every entry and is uploaded.  What the probe cannot see is an IN-PLACE
+    change of a few off-diagonal entries of a large matrix that touches none of the probed ones
+    -- a callback that does that must return a new array (any new address is uploaded)."""
     const, orig = getattr(h, "_ipx_constant", False), h
     h = np.asarray(h, dtype=np.float64)
-    if h.size == 0 or not (const or _immutable(h)) or not h.flags.c_contiguous:
+    if h.size == 0 or not h.flags.c_contiguous:
+        return DeviceDense.from_host(h)
+    fixed = const or _immutable(h)
+    if not fixed and h.nbytes < FINGERPRINT_MIN_BYTES:
         return DeviceDense.from_host(h)
     ident = orig if const else h
     key = (h.__array_interface__["data"][0], h.shape)
     hit = _dense_cache.get(key)
-    if hit is not None and hit[0] is ident:
-        return hit[1]
+    if hit is not None:
+        if fixed and hit[0] is ident:
+            return hit[1]
+        if not fixed and hit[2] is not None and hit[2] == _fingerprint(h):
+            DENSE_CACHE_STATS["fingerprint_hits"] += 1
+            return hit[1]
     if len(_dense_cache) > 2:
         _dense_cache.clear()
     D = DeviceDense.from_host(h)
-    _dense_cache[key] = (ident, D)          # (keeps the array alive: the address stays its own)
+    DENSE_CACHE_STATS["uploads"] += 1
+    # (the entry keeps the array alive: the address stays its own)
+    _dense_cache[key] = (ident, D, None if fixed else _fingerprint(h))
     return D
+
+
+DENSE_CACHE_STATS = {"uploads": 0, "fingerprint_hits": 0}
 
 
 # CG iterations of the last tangential step (the outer loops report them: note_cg_length).  A

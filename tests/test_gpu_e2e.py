@@ -72,10 +72,10 @@ def test_dense_equality_qp(e2e_golden):
 
 
 def test_dense_hessian_upload_is_reused_only_for_read_only_arrays():
-    """A dense Hessian returned by a numpy callback is uploaded on every use -- the reference
-    re-wraps it every iteration too (_minimize_constrained.py:395-407) and a callback may refill
-    its buffer in place -- unless the caller marked the array read-only: then the device copy
-    is made once.  An in-place change of a writable array must reach the device."""
+    """A SMALL dense Hessian returned by a numpy callback is uploaded on every use -- the
+    reference re-wraps it every iteration too (_minimize_constrained.py:395-407) and a callback
+    may refill its buffer in place -- unless the caller marked the array read-only: then the
+    device copy is made once.  An in-place change of a writable array must reach the device."""
     import ipsolver.backend_hip as bh
     from ipsolver.canonical import HessianSum
     rng = np.random.default_rng(0)
@@ -98,6 +98,24 @@ def test_dense_hessian_upload_is_reused_only_for_read_only_arrays():
     ro_view = W[:]
     ro_view.setflags(write=False)                     # read-only view of a WRITABLE base: not immutable
     assert not bh._immutable(ro_view)
+    # a LARGE writable array (>= 16 MB) at the same address is recognised by a fingerprint of
+    # ~1e5 probed entries: returned again unchanged -> the device copy; refilled in place, or a
+    # new array -> uploaded (BASELINE config 2 through the unchanged API: the 800 MB Hessian of
+    # a quadratic objective goes up once instead of once per outer iteration)
+    big = rng.standard_normal((1500, 1500))
+    big = big + big.T
+    before = dict(bh.DENSE_CACHE_STATS)
+    d1 = bh._upload_dense_cached(big)
+    assert bh._upload_dense_cached(big) is d1
+    assert bh.DENSE_CACHE_STATS["fingerprint_hits"] == before["fingerprint_hits"] + 1
+    big *= 1.0 + 2.0 ** -30                           # refilled in place: every entry moves
+    d2 = bh._upload_dense_cached(big)
+    assert d2 is not d1
+    np.testing.assert_array_equal(d2.to_host(), big)
+    big[7, 7] += 1.0                                  # a diagonal entry alone: probed
+    d3 = bh._upload_dense_cached(big)
+    assert d3 is not d2 and d3.to_host()[7, 7] == big[7, 7]
+    assert bh.DENSE_CACHE_STATS["uploads"] == before["uploads"] + 3
 
 
 def test_general_sparsity_barrier_vs_reference(monkeypatch):
