@@ -319,12 +319,14 @@ def single_gpu_measure(A_h, H_h, hdiag_h, c_h, n, m, K, W, repeats=20):
 
 
 def per_rank_sweep_leg(K=200, W=40, regions=5):
-    """The strong-scaling ceiling measured where one GPU can measure it:
-    the loop at the PER-RANK sizes of an N-GPU run of the n=1e6 / m=1e5 problem (n / N,
-    N = 1, 2, 4, 8; no communication), in its two forms -- the three launches per iteration and
-    the resident kernel (one launch per batch, csrc/resident.hip; the form the sharded loop
-    takes: its cross-rank hand-offs are the same tagged words, sent over xGMI).  Finite trust
-    radius that is never reached.  bound = t(1e6, best form) / t(1e6 / N)."""
+    """The strong-scaling ceiling measured where one GPU can measure it (VERDICT r4 item 1a, r5
+    item 4): the loop at the PER-RANK sizes of an N-GPU run (N = 1, 2, 4, 8; no communication)
+    of the n = 1e6 / m = 1e5 problem AND of problems 4 and 16 times its size, in its two forms
+    -- the three launches per iteration and the resident kernel (one launch per batch,
+    csrc/resident.hip; the form the sharded loop takes where it fits: its cross-rank hand-offs
+    are the same tagged words, sent over xGMI).  Finite trust radius that is never reached.
+    bound(n, N) = t(n, best form) / t(n / N, best form): what N GPUs can gain at most on a
+    problem of n variables before a byte crosses xGMI."""
     import numpy as np
     import torch
     from ipsolver import _hip, cg_fused, projector
@@ -334,9 +336,11 @@ def per_rank_sweep_leg(K=200, W=40, regions=5):
     lib = _hip.load()
     st = dv.stream_ptr()
     SEG = 200
-    rows = []
-    for N in (1, 2, 4, 8):
-        n, m = 1000000 // N, 100000 // N
+    totals = (1000000, 4000000, 16000000)
+    sizes = sorted({t // N for t in totals for N in (1, 2, 4, 8)})
+    by_n = {}
+    for n in sizes:
+        m = n // 10
         prob = CenteredBandedNLP(n, m, seed=0)
         x = prob.x0
         v = 0.1 * np.random.default_rng(7).standard_normal(m)
@@ -344,13 +348,15 @@ def per_rank_sweep_leg(K=200, W=40, regions=5):
         H = DeviceHessian(n, csr=dv.DeviceCSR.from_scipy(prob.hess(x)),
                           diag=dv.DVec.from_host(prob.kappa * prob.Wt.dot(v)))
         c = dv.DVec.from_host(prob.grad(x))
+        del prob
         Z, LS, Y = projector.projections(A)
         P = Z.projector
         x0 = Y.dot(-dv.DVec.zeros(m))
         r0 = Z.dot(H.dot(x0) + c)
         g0 = Z.dot(r0)
         rt_g = g0.sumsq_amax()[0]
-        row = {"N": N, "n": n, "m": m}
+        row = {"n": n, "m": m}
+        reg = regions if n <= 1000000 else 3
         for form, kw in (("three_launches", {"resident": False}), ("resident", {"resident": True})):
             L = cg_fused._Loop(H, P, None, None, **kw)
             if form == "resident" and not L.args.resident:
@@ -375,7 +381,7 @@ def per_rank_sweep_leg(K=200, W=40, regions=5):
                     it = end
             run(W)
             times = []
-            for _ in range(regions):
+            for _ in range(reg):
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 run(K)
@@ -386,18 +392,38 @@ def per_rank_sweep_leg(K=200, W=40, regions=5):
                 raise RuntimeError("per-rank sweep, %s at n=%d: stop=%s done=%s"
                                    % (form, n, sstate[cg_fused.ST_STOP], sstate[cg_fused.ST_IT_DONE]))
             row[form] = {"us_per_iteration": 1e6 * sorted(times)[len(times) // 2]}
-        rows.append(row)
-        del A, H, Z, Y, LS, P
+            del L
+        row["best_us_per_iteration"] = min(r["us_per_iteration"]
+                                           for r in (row["three_launches"], row["resident"]) if r)
+        by_n[n] = row
+        del A, H, Z, Y, LS, P, c, x0, r0, g0
         torch.cuda.empty_cache()
-    best1 = min(r["us_per_iteration"] for r in (rows[0]["three_launches"], rows[0]["resident"]) if r)
-    for row in rows:
+    tables = []
+    for total in totals:
+        t1 = by_n[total]["best_us_per_iteration"]
+        tables.append({"n_total": total, "us_per_iteration_on_one_gpu": t1,
+                       "bound_by_N": {str(N): t1 / by_n[total // N]["best_us_per_iteration"]
+                                      for N in (2, 4, 8)}})
+    # the rows of the n = 1e6 problem in the shape of rounds 4-5 (N, n, the two forms)
+    rows = []
+    t1 = by_n[1000000]["best_us_per_iteration"]
+    for N in (1, 2, 4, 8):
+        r = dict(by_n[1000000 // N], N=N)
         for form in ("three_launches", "resident"):
-            if row[form]:
-                row[form]["speedup_bound"] = best1 / row[form]["us_per_iteration"]
+            if r.get(form):
+                r[form] = dict(r[form], speedup_bound=t1 / r[form]["us_per_iteration"])
+        rows.append(r)
     res8 = rows[-1]["resident"]
-    return {"what": "device loop on ONE GPU at the per-rank sizes of an N-GPU run (n = 1e6 / N), "
-                    "no communication: %d regions of %d iterations each, median" % (regions, K),
+    return {"what": "device loop on ONE GPU at the per-rank sizes of an N-GPU run (n_total / N), "
+                    "no communication: median of %d (3 beyond n = 1e6) regions of %d iterations"
+                    % (regions, K),
             "rows": rows,
+            "per_rank_size": [by_n[n] for n in sizes],
+            "bound_by_problem_size": tables,
+            "reading": "bound_by_N = what N GPUs can gain at most (communication free) on a problem "
+                       "of n_total variables; the >= 6x target at N = 8 needs the per-rank loop to "
+                       "stay on the HBM roofline, i.e. a problem large enough that n_total / 8 still "
+                       "fills a GPU",
             "analytic_floor": {
                 "formula": "t_iteration(N) >= t_resident(1e6 / N) + 2 * (t_hop_xgmi - t_hop_on_chip): "
                            "an iteration has two dependent all-to-all hand-offs (p'Hp; the packed "

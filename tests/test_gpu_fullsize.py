@@ -417,6 +417,16 @@ def test_config5_full_size_properties():
             assert abs(got - record_levels[mu]) <= 0.10 * max(record_levels[mu], 200), (mu, got)
     assert abs(active - 142928) <= 0.015 * 142928
     assert abs(res.niter - 82) <= 9
+    # a run that takes one barrier level more AND about twice the CG iterations of
+    # the other recorded form of the same computation (76 outer / 51 698 CG, the back
+    # substitution as a launch of its own: IPX_DEBUG_FORMS=no-post-tail) must SAY so instead of
+    # passing silently -- the level-by-level record above holds either way
+    if len(levels) > 11 and res.cg_niter > 1.8 * 51698:
+        pytest.xfail("config 5 at full size: %d outer / %d CG iterations -- one barrier level and "
+                     "%.2fx the CG iterations more than the four-launch form of the same "
+                     "arithmetic (76 / 51 698), which passes the level mu = 1.02e-8 by the other "
+                     "side of its stopping test (one ulp in beta; DESIGN.md section 7)"
+                     % (res.niter, res.cg_niter, res.cg_niter / 51698.0))
 
 
 def _config5_sharded_worker(rank, world, port, out_path):
