@@ -52,17 +52,22 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_MFMA_PEAK_TFLOPS = 78.6   # AMD datasheet, dense fp64 matrix
-PMC_PROFILE = "r05_pmc_traffic_n1e6.json"      # see roofline.traffic_source
-PMC_PROFILE_BIG = "r05_pmc_traffic_n16e6.json"
+PMC_PROFILE = "r06_pmc_traffic_n1e6.json"      # see roofline.traffic_source
+PMC_PROFILE_BIG = "r06_pmc_traffic_n16e6.json"
 
 
 def kernel_source_hash():
     """Hash of the sources of the loop's kernels: a stored PMC traffic figure is attached to
     the bench line only when it was measured on kernels built from exactly these files."""
+    import glob
     import hashlib
     h = hashlib.sha256()
-    for name in ("cg.hip", "banded.hip", "spmv.hip", "ipx_common.h"):
-        with open(os.path.join(ROOT, "ip-nonlinear-solver_amd", "csrc", name), "rb") as f:
+    csrc = os.path.join(ROOT, "ip-nonlinear-solver_amd", "csrc")
+    # (every source of the library + the ABI header: VERDICT r5 item 5)
+    for path in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h"))
+                       + [os.path.join(ROOT, "include", "ipx.h")]):
+        with open(path, "rb") as f:
+            h.update(os.path.basename(path).encode())
             h.update(f.read())
     return h.hexdigest()[:16]
 

@@ -352,10 +352,14 @@ int ipx_cg_iterate(const ipx_cg_args *a, int32_t it_begin, int32_t it_end, void 
  * (A_tiles / A_ntiles: its standard SpMV row tiles) and H, solver_kind 0 or 1; b NULL = 0;
  * red: 18 doubles, ws: IPX_WS_DOUBLES doubles of device memory.  first_end > 0: iterations
  * [0, first_end) are enqueued behind the priming by the same call (as ipx_cg_iterate would).
- * (Inside ipx_sqp_front the two projections may each take ONE correction step on the device --
- * the refinement of projections.py:72-78 / the cancellation step of ipsolver/projector.py,
- * decided from the same norms by a kernel in between: red[14 + j] = 0 when projection j takes
- * it, red[16 + j] = 1 once it has; this entry point leaves such a priming to the host.)
+ * steps != 0 (b == NULL only): the two projections may each take ONE correction step on the
+ * device -- the refinement of projections.py:72-78 / the cancellation step of
+ * ipsolver/projector.py, decided from the same norms by a kernel in between (red[14 + j] = 0
+ * when projection j takes it, red[16 + j] = 1 once it has; state block: ST_PRIME_STEPS); six more
+ * launches, no-ops when none is due.  steps == 0: a projection that needs one ends the priming
+ * with stop code 9.  With a tridiagonal A A' on the single-launch solve a projection is the
+ * product A x + that solve with z = x - A'v, ||z||^2 and ||A z||^2 (as the residual
+ * ||A x - (A A') v||^2: the loop's own measure) from its tail -- two launches.
  * Stop code 9 in the state block afterwards: the host must prime (ipx_cg_prime_state); the
  * iterations enqueued with it did nothing. */
 /* doubles of reduction workspace ipx_cg_prime needs for this argument block (the per-tile
@@ -365,7 +369,7 @@ int64_t ipx_cg_prime_ws_doubles(const ipx_cg_args *a, int32_t A_ntiles);
 int ipx_cg_prime(const ipx_cg_args *a, const int32_t *A_tiles, int32_t A_ntiles, const double *c,
                  const double *b, double *red, double *ws, double tol_in, double radius,
                  double orth_tol, double norm_A, double cancellation, int32_t first_end,
-                 void *stream);
+                 int32_t steps, void *stream);
 int ipx_cg_prime_state(double *state, const double *red, const int32_t *idx7, double tol_in,
                        double radius, double orth_tol, double norm_A, double cancellation,
                        void *stream);

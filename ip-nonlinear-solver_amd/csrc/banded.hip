@@ -1109,6 +1109,9 @@ struct AtvJob {
   const uint16_t *ell_row;
   const double *ell_val;
   int64_t ell_n;
+  // +1: g = r_in - A'v;  -1: g = A'v - r_in, the negated projection by the same roundings (the
+  // priming's first direction p = -Z r: csrc/cg.hip prime_project)
+  double sign = 1.0;
 };
 
 // The right-hand side formed inside k_solve_pcr (barrier problems: w = A_R u, csrc/boxschur.hip)
@@ -1361,8 +1364,8 @@ k_solve_decoupled(LevDev lv, const double *__restrict__ w, double *__restrict__ 
           // first (which lies in this workgroup's rows): read here, not held in registers
           for (int e = ra[k]; e < rb[k]; ++e) sum += atv.val[e] * sx[atv.colidx[e] - rfirst];
         }
-        double y = -1.0 * sum;
-        y += 1.0 * ar[k];
+        double y = -atv.sign * sum;
+        y += atv.sign * ar[k];
         atv.g_out[av0 + jl] = y;
         gacc += y * y;
       }
@@ -1692,10 +1695,10 @@ k_solve_pcr(int m, int rows_wg, int L, const double *__restrict__ band,
       // (an absent entry carries value 0: same sum as the CSR row; a pair that reaches into a
       // neighbour's variables reads that workgroup's offsets -- in range, result unused)
       const int c0 = H + (int)(ac[k] & 0xffffu), c1 = H + (int)(ac[k] >> 16);
-      double y0 = -1.0 * (aw0[k].x * sx[c0] + aw1[k].x * sx[c0 + 1]);
-      y0 += 1.0 * ar[k].x;
-      double y1 = -1.0 * (aw0[k].y * sx[c1] + aw1[k].y * sx[c1 + 1]);
-      y1 += 1.0 * ar[k].y;
+      double y0 = -atv.sign * (aw0[k].x * sx[c0] + aw1[k].x * sx[c0 + 1]);
+      y0 += atv.sign * ar[k].x;
+      double y1 = -atv.sign * (aw0[k].y * sx[c1] + aw1[k].y * sx[c1 + 1]);
+      y1 += atv.sign * ar[k].y;
       const bool in0 = j >= av0 && j < (int64_t)av0 + avn;
       const bool in1 = j + 1 >= av0 && j + 1 < (int64_t)av0 + avn;
       if (in0 && in1) {
@@ -2653,12 +2656,13 @@ int ipx_banded_solve_resid_atv_launch(void *handle, const double *w, double *x, 
                                       const double *r_in, double *g_out, const int32_t *vown,
                                       int qv, double *part3, const double *guard,
                                       hipStream_t st, const uint16_t *ell_row,
-                                      const double *ell_val, int64_t ell_n) {
-  if (!handle || !w || !x || !partial || w == x) return IPX_EINVAL;
+                                      const double *ell_val, int64_t ell_n, double sign) {
+  if (!handle || !w || !x || !partial || w == x || (sign != 1.0 && sign != -1.0)) return IPX_EINVAL;
   int32_t geo[2];
   if (!ipx_banded_decoupled_geometry(handle, geo)) return IPX_EINVAL;
   Banded *h = (Banded *)handle;
-  const AtvJob job{At_rowptr, At_colidx, At_val, r_in, g_out, vown, part3, ell_row, ell_val, ell_n};
+  const AtvJob job{At_rowptr, At_colidx, At_val, r_in, g_out, vown, part3, ell_row, ell_val, ell_n,
+                   sign};
   if (h->pcr_L > 0 && ell_row && ell_val)
     return launch_solve_pcr(to_dev(h->lev[0], nullptr), h->pcr_L, w, x, partial, npartial, guard,
                             st, &job, qv);

@@ -1664,6 +1664,7 @@ __device__ void prime_state_body(double *st, const double *red, const ipx_prime_
   st[ST_RADIUS] = radius;
   st[ST_ORTH_RHS] = orth_tol * norm_A;
   st[ST_MARGIN] = margin;
+  st[ST_PRIME_STEPS] = taken ? taken[0] + taken[1] : 0.0;
   st[ST_STOP] = bad ? 9.0 : 0.0;
 }
 
@@ -1680,6 +1681,7 @@ __global__ void k_cg_prime_state(double *st, const double *__restrict__ red, ipx
 struct PrimeFolds {
   const double *part[6];
   int count[6], slot[6], n;
+  int single[6];            // 1: ONE sum per entry (the fused solve's tail), not the SpMV's pair
 };
 // radius_dev / norm_A2_dev (optional): the trust radius and ||A||_F^2 as DEVICE scalars that
 // kernels earlier in the stream have written -- the outer iteration's chain (csrc/sqp.hip), whose
@@ -1694,16 +1696,22 @@ struct PrimeFolds {
 #define PR_SKIP 14
 #define PR_TAKEN 16
 struct PrimeStep {          // one projection's correction: where its partials wait
-  const double *cz, *ct;    // partials of the corrected z (At_ntiles) / of A z (A_ntiles)
+  const double *cz, *ct;    // partials of the corrected ||z||^2 / of ||A z||^2
   int ncz, nct, base, pj;
+  int pairs;                // 1: SpMV epilogue arrays [sum y^2 | sum x y]; 0: one sum each (the
+                            // fused solve's tail: ||z||^2 per workgroup, residual partials)
 };
+__device__ void prime_fold4(const double *pz, int npz, const double *pt, int npt, int pairs,
+                            double *lds, double (&out)[4]) {
+  const double *parts[4] = {pz, pairs ? pz + npz : pz, pt, pairs ? pt + npt : pt};
+  const int counts[4] = {npz, pairs ? npz : 0, npt, pairs ? npt : 0};
+  ipx_sum_partials_multi<4>(parts, counts, lds, out);
+}
 __device__ void prime_fold_step(double *red, const PrimeStep &c, double *lds) {
   // (uniform across the block: red[PR_SKIP + pj] was written by an earlier kernel)
   if (red[PR_SKIP + c.pj] != 0.0) return;
-  const double *parts[4] = {c.cz, c.cz + c.ncz, c.ct, c.ct + c.nct};
-  const int counts[4] = {c.ncz, c.ncz, c.nct, c.nct};
   double out[4];
-  ipx_sum_partials_multi<4>(parts, counts, lds, out);
+  prime_fold4(c.cz, c.ncz, c.ct, c.nct, c.pairs, lds, out);
   if (threadIdx.x == 0) {
     red[c.base] = out[0]; red[c.base + 1] = out[1];
     red[c.base + 2] = out[2]; red[c.base + 3] = out[3];
@@ -1712,16 +1720,14 @@ __device__ void prime_fold_step(double *red, const PrimeStep &c, double *lds) {
   __syncthreads();
 }
 __global__ void __launch_bounds__(IPX_BLOCK)
-k_prime_decide(double *red, const double *pz, int npz, const double *pt, int npt, int base,
-               int xslot, int pj, double orth_tol, double norm_A, double canc2,
+k_prime_decide(double *red, const double *pz, int npz, const double *pt, int npt, int pairs,
+               int base, int xslot, int pj, double orth_tol, double norm_A, double canc2,
                const double *__restrict__ norm_A2_dev, PrimeStep prev, int have_prev) {
   __shared__ double lds[4 * (IPX_BLOCK / IPX_WAVE)];
   if (have_prev) prime_fold_step(red, prev, lds);       // (||x||^2 of this projection: red[xslot])
   if (norm_A2_dev) norm_A = sqrt(*norm_A2_dev);
-  const double *parts[4] = {pz, pz + npz, pt, pt + npt};
-  const int counts[4] = {npz, npz, npt, npt};
   double out[4];
-  ipx_sum_partials_multi<4>(parts, counts, lds, out);
+  prime_fold4(pz, npz, pt, npt, pairs, lds, out);
   if (threadIdx.x != 0) return;
   red[base] = out[0]; red[base + 1] = out[1];
   red[base + 2] = out[2]; red[base + 3] = out[3];
@@ -1748,10 +1754,11 @@ k_cg_prime_state_folds(double *st, double *red, PrimeFolds f, ipx_prime_idx ix, 
   int counts[12];
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
-    const bool on = j < f.n;
+    const bool on = j < f.n, two = on && !f.single[j];
     parts[2 * j] = on ? f.part[j] : f.part[0];
-    parts[2 * j + 1] = on ? f.part[j] + f.count[j] : f.part[0];
-    counts[2 * j] = counts[2 * j + 1] = on ? f.count[j] : 0;
+    parts[2 * j + 1] = two ? f.part[j] + f.count[j] : f.part[0];
+    counts[2 * j] = on ? f.count[j] : 0;
+    counts[2 * j + 1] = two ? f.count[j] : 0;
   }
   double out[12];
   if (f.n > 0) {
@@ -1810,8 +1817,11 @@ struct PrimeRed {
            const double *yin, double *yout, int slot, hipStream_t st) {
     double *part = ws + off;
     off += 2 * (int64_t)M.ntiles;
-    f.part[f.n] = part; f.count[f.n] = M.ntiles; f.slot[f.n] = slot; ++f.n;
+    f.part[f.n] = part; f.count[f.n] = M.ntiles; f.slot[f.n] = slot; f.single[f.n] = 0; ++f.n;
     return ipx_spmv_launch(M, x, alpha, diag, beta, yin, yout, part, nullptr, st);
+  }
+  void single(const double *part, int count, int slot) {
+    f.part[f.n] = part; f.count[f.n] = count; f.slot[f.n] = slot; f.single[f.n] = 1; ++f.n;
   }
 };
 
@@ -1833,6 +1843,44 @@ static int prime_project(const ipx_cg_args *a, const ipx_csr_view &A, const ipx_
   return R.spmv(A, z, 1.0, nullptr, 0.0, nullptr, a->t, base + 2, st);
 }
 
+// The same projection through the loop's own second launch (tridiagonal A A' on the cyclic-
+// reduction / decoupled solve with g = r - A'v as its tail: csrc/banded.hip AtvJob): w = A x by
+// the SpMV, then ONE launch for v = (A A')^-1 w, z = sign (x - A'v), the per-workgroup partials
+// of ||z||^2 (pz) and of ||w - (A A') v||^2 = ||A z||^2 (pt: the orthogonality measure the
+// loop's iterations use, projections.py:52 without a second product by A) -- two launches
+// instead of four.  guard: *guard != 0 skips both (a correction step that is not due).
+static bool prime_has_tail(const ipx_cg_args *a) {
+  return a->solver_kind == 0 && a->At_vown && a->At_qv > 0;
+}
+static int prime_project_tail(const ipx_cg_args *a, const ipx_csr_view &A, const double *x,
+                              double *z, double *pz, double *pt, int *np, double sign,
+                              const double *guard, hipStream_t st) {
+  int rc = ipx_spmv_launch(A, x, 1.0, nullptr, 0.0, nullptr, a->w, nullptr, guard, st);
+  if (rc) return rc;
+  return ipx_banded_solve_resid_atv_launch(a->banded, a->w, a->v, pt, np, a->At_rowptr,
+                                           a->At_colidx, a->At_val, x, z, a->At_vown,
+                                           (int)a->At_qv, pz, guard, st, a->At_ell_row,
+                                           a->At_ell_val, a->n, sign);
+}
+
+// either way, the partials registered for the state kernel's fold
+static int prime_project_any(const ipx_cg_args *a, const ipx_csr_view &A, const ipx_csr_view &At,
+                             const double *x, double *z, PrimeRed &R, int base, bool have_xnorm,
+                             double sign, hipStream_t st) {
+  if (!prime_has_tail(a)) return prime_project(a, A, At, x, z, R, base, have_xnorm, sign, st);
+  int rc = have_xnorm ? IPX_OK : ipx_norms(a->n, x, R.red + base + 4, R.ws + R.off, st);
+  if (rc) return rc;
+  const int cap = (int)((a->m + 255) / 256) + 8;
+  double *pz = R.ws + R.off, *pt = pz + 2 * cap;
+  R.off += 3 * (int64_t)cap;
+  int np = 0;
+  rc = prime_project_tail(a, A, x, z, pz, pt, &np, sign, nullptr, st);
+  if (rc) return rc;
+  R.single(pz, np, base);
+  R.single(pt, np, base + 2);
+  return IPX_OK;
+}
+
 // ... and with its correction step decided and taken on the device (k_prime_decide): the
 // projection's own partials are folded by the decide kernel (they leave R.f), the step's wait in
 // two more regions for the next decide / the state kernel (`step` out; `prev`: the projection
@@ -1846,17 +1894,40 @@ static int prime_project_stepped(const ipx_cg_args *a, const ipx_csr_view &A,
                                  double canc2, const PrimeStep *prev, PrimeStep *step,
                                  hipStream_t st) {
   const int n0 = R.f.n;
-  int rc = prime_project(a, A, At, x, z, R, base, have_xnorm, sign, st);
+  int rc;
+  const double *skip = R.red + PR_SKIP + pj;
+  if (prime_has_tail(a)) {
+    if (!have_xnorm) {
+      rc = ipx_norms(a->n, x, R.red + base + 4, R.ws + R.off, st);
+      if (rc) return rc;
+    }
+    const int cap = (int)((a->m + 255) / 256) + 8;      // (>= workgroups of the solve, twice)
+    double *pz = R.ws + R.off, *pt = pz + 2 * cap, *cz = pt + cap, *ct = cz + 2 * cap;
+    R.off += 6 * (int64_t)cap;
+    int np = 0, npc = 0;
+    rc = prime_project_tail(a, A, x, z, pz, pt, &np, sign, nullptr, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_prime_decide, dim3(1), dim3(IPX_BLOCK), 0, st, R.red, pz, np, pt, np, 0,
+                       base, xslot, pj, orth_tol, norm_A, canc2, norm_A2_dev,
+                       prev ? *prev : PrimeStep{}, prev ? 1 : 0);
+    IPX_CHECK_LAUNCH();
+    // the step: z <- z - A'(A A')^-1 (A z), the same two launches on z itself (in place: the
+    // tail reads and writes one variable per lane), guarded
+    rc = prime_project_tail(a, A, z, z, cz, ct, &npc, 1.0, skip, st);
+    if (rc) return rc;
+    *step = PrimeStep{cz, ct, npc, npc, base, pj, 0};
+    return IPX_OK;
+  }
+  rc = prime_project(a, A, At, x, z, R, base, have_xnorm, sign, st);
   if (rc) return rc;
   // (the two regions this projection just registered: folded here, not by the state kernel)
   const double *pz = R.f.part[n0], *pt = R.f.part[n0 + 1];
   const int npz = R.f.count[n0], npt = R.f.count[n0 + 1];
   R.f.n = n0;
-  hipLaunchKernelGGL(k_prime_decide, dim3(1), dim3(IPX_BLOCK), 0, st, R.red, pz, npz, pt, npt, base,
-                     xslot, pj, orth_tol, norm_A, canc2, norm_A2_dev, prev ? *prev : PrimeStep{},
-                     prev ? 1 : 0);
+  hipLaunchKernelGGL(k_prime_decide, dim3(1), dim3(IPX_BLOCK), 0, st, R.red, pz, npz, pt, npt, 1,
+                     base, xslot, pj, orth_tol, norm_A, canc2, norm_A2_dev,
+                     prev ? *prev : PrimeStep{}, prev ? 1 : 0);
   IPX_CHECK_LAUNCH();
-  const double *skip = R.red + PR_SKIP + pj;
   if (a->solver_kind == 1)
     rc = ipx_boxschur_solve((const ipx_boxschur_args *)a->banded, a->t, a->v, nullptr, nullptr, skip,
                             st);
@@ -1871,7 +1942,7 @@ static int prime_project_stepped(const ipx_cg_args *a, const ipx_csr_view &A,
   if (rc) return rc;
   rc = ipx_spmv_launch(A, z, 1.0, nullptr, 0.0, nullptr, a->t, ct, skip, st);
   if (rc) return rc;
-  *step = PrimeStep{cz, ct, At.ntiles, A.ntiles, base, pj};
+  *step = PrimeStep{cz, ct, At.ntiles, A.ntiles, base, pj, 1};
   return IPX_OK;
 }
 
@@ -1884,9 +1955,9 @@ int64_t ipx_cg_prime_ws_doubles(const ipx_cg_args *a, int32_t A_ntiles) {
 int ipx_cg_prime(const ipx_cg_args *a, const int32_t *A_tiles, int32_t A_ntiles, const double *c,
                  const double *b, double *red, double *ws, double tol_in, double radius,
                  double orth_tol, double norm_A, double cancellation, int32_t first_end,
-                 void *stream) {
+                 int32_t steps, void *stream) {
   return ipx_cg_prime_dev(a, A_tiles, A_ntiles, c, b, red, ws, tol_in, radius, nullptr, orth_tol,
-                          norm_A, nullptr, cancellation, first_end, 0, (hipStream_t)stream);
+                          norm_A, nullptr, cancellation, first_end, steps, (hipStream_t)stream);
 }
 
 }  // extern "C"
@@ -1931,9 +2002,9 @@ int ipx_cg_prime_dev(const ipx_cg_args *a, const int32_t *A_tiles, int32_t A_nti
   if (b || !steps) {
     // (b: ||t||^2 = red[4] comes out of the H x0 + c product's partials, folded by the state
     // kernel: the first projection's decision would need it earlier -- no step on this path)
-    rc = prime_project(a, A, At, t, a->r, R, 0, b != nullptr, 1.0, st);
+    rc = prime_project_any(a, A, At, t, a->r, R, 0, b != nullptr, 1.0, st);
     if (rc) return rc;
-    rc = prime_project(a, A, At, a->r, a->p, R, 6, true, -1.0, st);
+    rc = prime_project_any(a, A, At, a->r, a->p, R, 6, true, -1.0, st);
     if (rc) return rc;
   } else {
     rc = prime_project_stepped(a, A, At, t, a->r, R, 0, 4, 0, false, 1.0, orth_tol, norm_A,

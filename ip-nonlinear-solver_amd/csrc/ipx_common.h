@@ -590,6 +590,7 @@ enum {
   ST_XNORM2 = 10, ST_VIOL = 11, ST_ORTH = 12, ST_IT_DONE = 13,
   ST_MARGIN = 14,   // written by the priming: min over its two projections of ||Z x||^2 / ||x||^2
                     // (how far they are from needing the cancellation step: 2^-20)
+  ST_PRIME_STEPS = 15,   // ... and how many correction steps they took on the device (0..2)
   ST_SIZE = 16
 };
 
@@ -671,7 +672,8 @@ int ipx_banded_solve_resid_atv_launch(void *handle, const double *w, double *x, 
                                       const double *r_in, double *g_out, const int32_t *vown,
                                       int qv, double *part3, const double *guard,
                                       hipStream_t st, const uint16_t *ell_row = nullptr,
-                                      const double *ell_val = nullptr, int64_t ell_n = 0);
+                                      const double *ell_val = nullptr, int64_t ell_n = 0,
+                                      double sign = 1.0);
 int ipx_banded_solve_resid_launch(void *handle, const double *w, double *x, double *partial,
                                   int *npartial, const double *guard, hipStream_t st);
 // partial[0..*npartial) <- per-workgroup sums of ||w - (A A') v||^2 (<= 256 of them)

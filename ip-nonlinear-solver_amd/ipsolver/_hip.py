@@ -60,7 +60,7 @@ _SIGNATURES = {
     "ipx_cg_iterate": [_P, _I32, _I32, _P],
     "ipx_cg_resident_ok": [_P],
     "ipx_cg_prime_state": [_P, _P, _P, _F64, _F64, _F64, _F64, _F64, _P],
-    "ipx_cg_prime": [_P, _P, _I32, _P, _P, _P, _P, _F64, _F64, _F64, _F64, _F64, _I32, _P],
+    "ipx_cg_prime": [_P, _P, _I32, _P, _P, _P, _P, _F64, _F64, _F64, _F64, _F64, _I32, _I32, _P],
     "ipx_cg_iterate_timed": [_P, _I32, _I32, _P, _P],
     "ipx_banded_kmax": [],
     "ipx_banded_levels": [_P],

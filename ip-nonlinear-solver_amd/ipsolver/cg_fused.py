@@ -24,6 +24,7 @@ _I64 = ctypes.c_int64
 # state block indices (csrc/cg.hip)
 ST_RTG0, ST_RTG1, ST_TOL, ST_RADIUS, ST_ALPHA, ST_STOP, ST_NITER, ST_BETA = range(8)
 ST_PTHP, ST_ORTH_RHS, ST_XNORM2, ST_VIOL, ST_ORTH, ST_IT_DONE, ST_MARGIN = 8, 9, 10, 11, 12, 13, 14
+ST_PRIME_STEPS = 15
 
 
 class CgArgs(ctypes.Structure):
@@ -722,6 +723,17 @@ def _projected_cg_once(H, c, Z, Y, b, trust_radius, lb, ub, tol, max_iter, max_i
                                  max_infeasible_iter, batch, stats, b_zero, fast=True)
         except _PrimeRetry:
             STATS["prime_retries"] += 1
+            if b_zero and key is not None and key not in _STEP_PRIMED:
+                # once more on the device, with the projections' correction steps armed (the
+                # same arithmetic as the host's steps; what they do not settle is the host's)
+                if len(_STEP_PRIMED) >= 16:
+                    _STEP_PRIMED.clear()
+                _STEP_PRIMED.add(key)
+                try:
+                    return _projected_cg(H, c, Z, Y, b, trust_radius, lb, ub, tol, max_iter,
+                                         max_infeasible_iter, batch, stats, b_zero, fast=True)
+                except _PrimeRetry:
+                    STATS["prime_retries"] += 1
             if key is not None:
                 if len(_HOST_PRIMED) >= 16:
                     _HOST_PRIMED.clear()
@@ -738,6 +750,7 @@ def _projected_cg_once(H, c, Z, Y, b, trust_radius, lb, ub, tol, max_iter, max_i
 
 
 _HOST_PRIMED = set()       # pool signatures whose last call needed the host's priming
+_STEP_PRIMED = set()       # ... whose primings carry the projections' correction steps (device)
 
 
 _PRIME_IDX = (ctypes.c_int32 * 7)(12, 4, 0, 2, 10, 6, 8)
@@ -803,11 +816,14 @@ def _projected_cg(H, c, Z, Y, b, trust_radius, lb, ub, tol, max_iter, max_infeas
             # ipx_cg_iterate call is ~50 us of idle GPU otherwise)
             first_end = min(max_iter, batch if batch else _first_batch(max_iter, False))
             b_rows = None if b_zero else P.rows_in(b)      # (the projector's row order)
+            # (correction steps of the two projections on the device when the last primings on
+            # these patterns needed them or came close: _STEP_PRIMED)
+            L.stepped = bool(b_zero and pool_key is not None and pool_key in _STEP_PRIMED)
             _hip.call("ipx_cg_prime", L.ref(), _p(pat.tiles), pat.ntiles, _p(c.t),
                       None if b_zero else _p(b_rows.t), _p(ctx_.out), _p(ctx_.ws),
                       float("nan") if tol is None else float(tol), float(trust_radius),
                       float(P.orth_tol), float(P.norm_A), float(P.CANCELLATION),
-                      max(first_end, 0), st)
+                      max(first_end, 0), 1 if L.stepped else 0, st)
             L.enqueued = (0, first_end) if first_end > 0 else None
             P.stats["solves"] += 2 if b_zero else 3
         else:
@@ -923,6 +939,14 @@ def _run_loop(L, pool_key, P, lib, st, n, lb, ub, trust_radius, max_iter, max_in
                 if release:
                     _release(L, pool_key)
                 raise _PrimeRetry()
+            if fast and pool_key is not None and getattr(L, "stepped", None) is not None:
+                # arm / disarm the device's correction steps for the next primings on these
+                # patterns: taken now, or within a factor 64 of the cancellation test
+                if s[ST_PRIME_STEPS] > 0 or s[ST_MARGIN] < 64.0 * P.CANCELLATION ** 2:
+                    _STEP_PRIMED.add(pool_key)
+                else:
+                    _STEP_PRIMED.discard(pool_key)
+                L.stepped = None
             if _INJECT_RESIDENT_TIMEOUT and L.args.resident and int(s[ST_STOP]) in (0, 4):
                 # (test hook, one shot: what a resident launch leaves when a late workgroup
                 # commits alone -- stop code 8 and HALF of x advanced)

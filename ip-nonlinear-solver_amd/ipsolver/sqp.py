@@ -241,10 +241,19 @@ class ChainStages:
             chain.front(1, 0, radius, penalty, pt.f, pt.norm_b, P.norm_A, first_end)
             q = chain.read()
         P.stats["solves"] += 3
-        steps_taken = q[sc.PRIME_STEPS]
-        L.enqueued = (0, first_end) if first_end > 0 else None
         st = q[sc.CG:sc.CG + 16]
         stop = int(st[cg_fused.ST_STOP])
+        if stop == 9 and not chain.expect_steps:
+            # a projection of the priming needs its correction step and none was armed: once
+            # more on the device with the steps (the normal step stands: chain.dn)
+            sc.STATS["prime_rearmed"] = sc.STATS.get("prime_rearmed", 0) + 1
+            chain.expect_steps = True
+            chain.front(1, 0, radius, penalty, pt.f, pt.norm_b, P.norm_A, first_end)
+            q = chain.read()
+            st = q[sc.CG:sc.CG + 16]
+            stop = int(st[cg_fused.ST_STOP])
+        steps_taken = st[cg_fused.ST_PRIME_STEPS]
+        L.enqueued = (0, first_end) if first_end > 0 else None
         on_device = stop == 4 or (stop in (2, 3) and q[sc.EXIT_DONE] != 0) \
             or (stop == 0 and first_end >= max_iter)
         outside = box.any and q[sc.X_OUTSIDE] > 0

@@ -23,7 +23,7 @@ pmc)
     (cd $R && python3 scripts/pmc_summarize.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE $OUT/pmc_traffic_$tag.json "$note" $COMMIT | tail -5)
   done;;
 attach)   # (on the box: the bench line's `traffic` reads profiles/, guarded by the source hash)
-  cp $OUT/pmc_traffic_n1e6.json $R/profiles/r05_pmc_traffic_n1e6.json; cp $OUT/pmc_traffic_n16e6.json $R/profiles/r05_pmc_traffic_n16e6.json;;
+  cp $OUT/pmc_traffic_n1e6.json $R/profiles/r06_pmc_traffic_n1e6.json; cp $OUT/pmc_traffic_n16e6.json $R/profiles/r06_pmc_traffic_n16e6.json;;
 bench20)
   (cd $R && timeout 600 python3 bench.py --steps 20 --warmup 5 2>/dev/null | grep '^{' > $OUT/bench_line_steps20.json);;
 pmc5)

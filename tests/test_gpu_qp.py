@@ -1214,7 +1214,10 @@ def test_priming_forms_agree(ips, n, m, monkeypatch):
             assert cg_fused.STATS["prime_retries"] == before["prime_retries"]
             outs.append((host(x), info))
         assert outs[1][1] == outs[0][1] and outs[2][1] == outs[0][1]
-        assert np.array_equal(outs[1][0], outs[0][0])
+        # (round 6: the one-call form takes its projections through the loop's own solve + tail
+        # launch where the factorization has it -- ||g0||^2 summed per workgroup of the solve
+        # instead of per row tile of the product: an ulp of rt_g against the launch-by-launch form)
+        assert np.max(np.abs(outs[1][0] - outs[0][0])) <= 1e-15 * np.max(np.abs(outs[0][0]))
         # (the host sums ||g0||^2 with the norm kernel, the device paths take it from the
         # product's epilogue: another order, an ulp of rt_g)
         assert np.max(np.abs(outs[2][0] - outs[0][0])) <= 1e-15 * np.max(np.abs(outs[0][0]))
