@@ -61,6 +61,11 @@ typedef struct {
   int32_t op;
 } ipx_fold_desc;
 int ipx_read_folded(int nd, const ipx_fold_desc *descs, double *host_out, void *stream);
+/* ... and their weighted sum left on the device instead (no read): out[0] = ((w[0] r_0 + w[1] r_1)
+ * + w[2] r_2) + ... -- an objective value assembled from dot products that only a later kernel
+ * consumes (ipx_sqp_judge's f_next_dev; ipsolver.device.ScalarPack.combine). */
+int ipx_fold_combine(int nd, const ipx_fold_desc *descs, const double *weights, double *out,
+                     void *stream);
 
 /* ---- vectors (np elementwise algebra; qp_subproblem.py:212-216,312,580,622,628)
  * out = a*x + b*y (y may be NULL when b == 0); in-place allowed. */

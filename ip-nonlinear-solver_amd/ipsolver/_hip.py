@@ -20,6 +20,7 @@ _SIGNATURES = {
     "ipx_device_info": [_c.POINTER(_c.c_int), _c.POINTER(_c.c_int), _c.c_char_p, _c.c_int],
     "ipx_read_doubles": [_P, _c.c_int, _P, _P],
     "ipx_read_folded": [_c.c_int, _P, _P, _P],
+    "ipx_fold_combine": [_c.c_int, _P, _P, _P, _P],
     "ipx_reduce_grid": [_I64],
     "ipx_dot_partials": [_I64, _P, _P, _P, _P],
     "ipx_norms_partials": [_I64, _P, _P, _P],

@@ -86,6 +86,9 @@ class BarrierSubproblem:
         return out
 
     def _compute_function(self, f, c_ineq, s):                            # :88-95
+        if self.n_ineq == 0:
+            return f          # (f - mu * 0.0: the same number; f may still be on the device)
+        f = float(f)
         if self.any_enforced:
             # s[enforce] = -c_ineq[enforce], in place through the view of z
             self.xp.assign_negated_where(s, self.enforce_feasibility, c_ineq)

@@ -224,6 +224,9 @@ class DVec:
 
     def __getitem__(self, key):
         if isinstance(key, slice):
+            if key.indices(len(self)) == (0, len(self), 1):
+                return self       # (the whole vector: a view is the same storage anyway, and the
+                #                    same OBJECT lets callers recognise a point they have seen)
             return DVec(self.t[key])
         raise TypeError("DVec supports slice views only")
 
@@ -301,6 +304,30 @@ class DVec:
         if c.open_pack is None or c.open_pack() is None:
             c.parts_used = 0
         return vals
+
+
+class DeviceScalar:
+    """A double the device holds (``t``: a tensor of one element) and the host may not have read
+    yet: ``float()`` reads it once (a blocking read) and remembers; a kernel that consumes it
+    takes ``t`` and the host learns the value from whatever it reads next anyway
+    (``known``) -- the objective value of a trial point between the user's ``fun`` and the
+    verdict on the step (csrc/sqp.hip ipx_sqp_judge: f_next_dev)."""
+    __slots__ = ("t", "_v")
+
+    def __init__(self, t, value=None):
+        self.t, self._v = t, value
+
+    def __float__(self):
+        if self._v is None:
+            self._v = read_doubles(self.t, 1)[0]
+        return self._v
+
+    def known(self, value):
+        self._v = float(value)
+
+    @property
+    def is_known(self):
+        return self._v is not None
 
 
 class ScalarPack:
@@ -384,6 +411,40 @@ class ScalarPack:
         h = self._norms(v, 0)
         self.how[h] = (self.how[h][0], None)
         return h
+
+    def combine(self, handles, weights):
+        """``((w0 v[h0] + w1 v[h1]) + w2 v[h2]) + ...`` as a ``DeviceScalar`` WITHOUT reading the
+        pack (one launch folds the partial sums and forms the expression on the device, in that
+        order: the bits of the same expression written on the host over ``read()``'s values).
+        Ends the pack like ``read()``.  Reductions that did not leave partial sums (a full
+        arena) are read and the result is a known scalar."""
+        import torch
+        folds = [self.how[h][0] for h in handles]
+        if self.k or not all(isinstance(f, tuple) for f in folds) \
+                or any(self.how[h][1] is not None for h in handles) or len(handles) > FOLD_MAX:
+            v = self.read()
+            acc = None
+            for h, w in zip(handles, weights):
+                term = float(w) * v[h]
+                acc = term if acc is None else acc + term
+            return DeviceScalar(None, acc)
+        rb = _RB
+        if rb.fold is None:
+            rb.fold = (_FoldDesc * FOLD_MAX)()
+            rb.fold_ptr = ctypes.addressof(rb.fold)
+        base = self.c.parts.data_ptr()
+        for q, f in enumerate(folds):
+            off, count, op = self.folds[f[1]]
+            d = rb.fold[q]
+            d.part, d.count, d.op = base + 8 * off, count, op
+        w = (ctypes.c_double * len(handles))(*[float(x) for x in weights])
+        out = torch.empty(1, dtype=torch.float64, device=self.c.device)
+        _hip.call("ipx_fold_combine", len(handles), rb.fold_ptr, ctypes.addressof(w),
+                  out.data_ptr(), stream_ptr())
+        if self.c.open_pack is not None and self.c.open_pack() is self:
+            self.c.open_pack = None
+            self.c.parts_used = 0
+        return DeviceScalar(out)
 
     def read(self):
         vals = read_doubles(self.c.out, self.k, PACK_BASE)

@@ -4,7 +4,8 @@ When ``x0`` is a CUDA tensor the user's callbacks are called with CUDA
 tensors and return device objects, so nothing crosses PCIe between two
 iterations:
 
-    fun(x) -> float | 0-d tensor          grad(x) -> 1-D tensor
+    fun(x) -> float | 0-d tensor | device.DeviceScalar (e.g. ScalarPack.combine: no read)
+    grad(x) -> 1-D tensor
     hess(x) -> DeviceCSR | 1-D tensor (diagonal) | 2-D tensor / DeviceDense (dense) |
                DeviceHessian | None | a tuple of such terms (their sum)
     NonlinearConstraint.fun(x) -> 1-D tensor
@@ -47,6 +48,17 @@ def as_dvec(t):
     if not torch.is_tensor(t):
         raise TypeError("device-callback mode: expected a CUDA tensor, got %r" % type(t))
     return DVec(t.to(_F64).reshape(-1).contiguous())
+
+
+def objective_value(f):
+    """What a device-mode ``fun`` returned, for the outer loops: a float, or -- a value still on
+    the device (``device.DeviceScalar``, a 0-d / one-element CUDA tensor) -- a DeviceScalar that
+    the step's verdict consumes on the device; the host reads it only where it needs it."""
+    if isinstance(f, dv.DeviceScalar):
+        return f
+    if torch.is_tensor(f) and f.is_cuda and f.numel() == 1:
+        return dv.DeviceScalar(f.detach().to(_F64).reshape(1))
+    return float(f)
 
 
 def _idx(a):
@@ -144,17 +156,30 @@ class DeviceRowMap:
                 raise NotImplementedError("device-callback mode: a dense constraint Jacobian "
                                           "must consist of equality rows only (kind 'equals')")
             return self._no_rows(J.shape[1]), J
+        if self.all_eq:
+            return self._no_rows(J.shape[1]), J
         key = id(J.pattern)
         if key not in self._sel:
+            if len(self._sel) >= 4:          # (a row map may outlive a solve: _SPEC_CACHE)
+                self._sel.pop(next(iter(self._sel)))
             self._sel[key] = (RowSelection(J.pattern, self.ineq, self.sign_h),
                               RowSelection(J.pattern, self.eq, None), J.pattern)
         sel_ineq, sel_eq, _ = self._sel[key]
         return sel_ineq.apply(J), sel_eq.apply(J)
 
+    _NO_ROWS = {}
+
     @staticmethod
     def _no_rows(n_vars):
-        return DeviceCSR(CSRPattern(np.zeros(1, np.int32), np.empty(0, np.int32), (0, n_vars)),
-                         dv._empty(0))
+        key = (n_vars, ctx().device.index)
+        hit = DeviceRowMap._NO_ROWS.get(key)
+        if hit is None:
+            if len(DeviceRowMap._NO_ROWS) >= 8:
+                DeviceRowMap._NO_ROWS.clear()
+            hit = DeviceRowMap._NO_ROWS[key] = DeviceCSR(
+                CSRPattern(np.zeros(1, np.int32), np.empty(0, np.int32), (0, n_vars)),
+                dv._empty(0))
+        return hit
 
     def multipliers(self, v_eq, v_ineq):
         if self.all_eq:
@@ -169,6 +194,27 @@ class DeviceRowMap:
 def _identity_csr(n):
     pat = CSRPattern(np.arange(n + 1, dtype=np.int32), np.arange(n, dtype=np.int32), (n, n))
     return DeviceCSR(pat, torch.ones(n, dtype=_F64, device=ctx().device))
+
+
+_SPEC_CACHE = {}
+
+
+def _spec_key(kind, enforce, m, n):
+    """(kind, enforce_feasibility, rows, variables, device) when the specification consists of
+    a keyword and Python scalars (then it IS its value); None for arrays."""
+    if isinstance(kind, str):
+        kind = (kind,)
+    if not isinstance(kind, (tuple, list)) or not isinstance(enforce, (bool, np.bool_)):
+        return None
+    flat = []
+    for k in kind:
+        if isinstance(k, str):
+            flat.append(k)
+        elif isinstance(k, (int, float, np.integer, np.floating)) and not isinstance(k, bool):
+            flat.append(float(k))
+        else:
+            return None
+    return (tuple(flat), bool(enforce), int(m), int(n), ctx().device.index)
 
 
 class _DeviceConstraint:
@@ -213,8 +259,17 @@ class _DeviceConstraint:
         else:
             raise ValueError("Unknown Constraint type.")
         m = len(f0)
-        self.kind = check_kind(user.kind, m)
-        self.enforce = check_enforce_feasibility(user.enforce_feasibility, m)
+        # kind / enforce_feasibility broadcast to the rows and the canonical row map derived from
+        # them (index maps on the host, their device copies, per Jacobian pattern the row
+        # selections) depend on the SPECIFICATION only: kept across calls for specifications made
+        # of scalars (0.5 + 0.5 ms of a 13 ms config-3 solve went into rebuilding them)
+        key = _spec_key(user.kind, user.enforce_feasibility, m, n)
+        hit = _SPEC_CACHE.get(key) if key is not None else None
+        if hit is None:
+            self.kind = check_kind(user.kind, m)
+            self.enforce = check_enforce_feasibility(user.enforce_feasibility, m)
+        else:
+            self.kind, self.enforce, self.rows = hit
         self.x0 = x0
         if self.enforce.any():
             f0_h = f0.to_host()
@@ -227,7 +282,12 @@ class _DeviceConstraint:
                     f0 = self.x0
                 else:
                     raise ValueError(_INFEASIBLE)
-        self.rows = DeviceRowMap(self.kind, n)
+        if hit is None:
+            self.rows = DeviceRowMap(self.kind, n)
+            if key is not None:
+                if len(_SPEC_CACHE) >= 8:
+                    _SPEC_CACHE.pop(next(iter(_SPEC_CACHE)))
+                _SPEC_CACHE[key] = (self.kind, self.enforce, self.rows)
         self.f0 = f0
         self.J0 = self.jac(self.x0)
 
@@ -295,8 +355,7 @@ class DeviceCanonical:
         self.enforce_feasibility = np.hstack(
             [p.enforce[p.rows.ineq] if p.n_ineq else np.empty(0, dtype=bool)
              for p in self.parts]) if self.parts else np.empty(0, dtype=bool)
-        self._empty = DeviceCSR(CSRPattern(np.zeros(1, np.int32), np.empty(0, np.int32),
-                                           (0, self.n_vars)), dv._empty(0))
+        self._empty = DeviceRowMap._no_rows(self.n_vars)
         vals = [p.rows.values(p.f0) for p in self.parts]
         self.c_ineq0, self.c_eq0 = self._stack_values(vals)
         self.J_ineq0, self.J_eq0 = self._stack_jacs([p.rows.jac(p.J0) for p in self.parts])

@@ -156,7 +156,7 @@ def _minimize_device(fun, x0, grad, hess, constraints, method, xtol, gtol, optio
         if canon.constant_jac:
             xp.mark_constant(canon.J_eq0)      # one factorization for the whole run (N1)
         result = equality_constrained_sqp(
-            lambda x: (float(fun(x.t)), canon.constr(x)[1]),
+            lambda x: (dm.objective_value(fun(x.t)), canon.constr(x)[1]),
             lambda x: (dm.as_dvec(grad(x.t)), canon.jac(x)[1]),
             lambda x, v: xp.hessian_operator(lagr(x, v), n_vars, None),
             x0_dev, f0, g0, canon.c_eq0, canon.J_eq0, stop_criteria, state, xp, **options)
@@ -165,7 +165,8 @@ def _minimize_device(fun, x0, grad, hess, constraints, method, xtol, gtol, optio
             warn("The problem only has equality constraints. The solver "
                  "'equality_constrained_sqp' is a better choice for those situations.")
         result = tr_interior_point(
-            lambda x: float(fun(x.t)), lambda x: dm.as_dvec(grad(x.t)), lagr, n_vars,
+            lambda x: dm.objective_value(fun(x.t)), lambda x: dm.as_dvec(grad(x.t)), lagr,
+            n_vars,
             canon.n_ineq, canon.n_eq, canon.constr, canon.jac, x0_dev, f0, g0, canon.c_ineq0,
             canon.J_ineq0, canon.c_eq0, canon.J_eq0, stop_criteria, canon.enforce_feasibility,
             xtol, state, xp, **options)

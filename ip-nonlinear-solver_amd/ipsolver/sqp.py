@@ -95,7 +95,7 @@ class HostStages:
     def propose(self, pt, H, radius, penalty):
         xp, box = self.xp, self.box
         q = sc.new_block()
-        q[RADIUS], q[PENALTY], q[F], q[NORM_B] = radius, penalty, pt.f, pt.norm_b
+        q[RADIUS], q[PENALTY], q[F], q[NORM_B] = radius, penalty, float(pt.f), pt.norm_b
         known = []
         dn = xp.modified_dogleg(pt.A, pt.Y, pt.b, TR_FACTOR * radius, box.half_lb, box.half_ub,
                                 known)
@@ -128,7 +128,7 @@ class HostStages:
 
     # -- judge
     def judge(self, q, trial, f_next, b_next):
-        q[F_NEXT], q[NORM_B_NEXT] = f_next, self.xp.norm(b_next)
+        q[F_NEXT], q[NORM_B_NEXT] = float(f_next), self.xp.norm(b_next)
         sc.ratio_host(q)
         if not q[SOC]:
             sc.radius_host(q)
@@ -327,8 +327,14 @@ class ChainStages:
     def judge(self, q, trial, f_next, b_next):
         if not trial.on_chain:
             return self.host.judge(q, trial, f_next, b_next)
-        self.chain.judge(b_next, f_next)
-        return self.chain.read()
+        # (an objective value still on the device goes to the verdict's kernel as it is and
+        # comes back in the block: no read of its own)
+        lazy = hasattr(f_next, "known") and not f_next.is_known
+        self.chain.judge(b_next, f_next.t if lazy else float(f_next))
+        q = self.chain.read()
+        if lazy:
+            f_next.known(q[F_NEXT])
+        return q
 
 
 def _settle_key(pt, method):
@@ -374,7 +380,7 @@ def equality_constrained_sqp(fun_and_constr, grad_and_jac, lagr_hess, x0, fun0, 
             xp.note_cg_length(0)
 
     def publish(pt):
-        state.x, state.v, state.fun, state.grad = pt.x, pt.v, pt.f, pt.c
+        state.x, state.v, state.fun, state.grad = pt.x, pt.v, float(pt.f), pt.c
         state.constr, state.jac = pt.b, pt.A
         state.optimality, state.constr_violation = pt.opt, pt.viol
 
@@ -461,6 +467,7 @@ def _second_order_correction(xp, box, pt, trial, q, f_next, b_next, fun_and_cons
     step = d + t * y
     x_soc = pt.x + (pt.S.dot(step) if pt.S is not None else step)
     f_soc, b_soc = fun_and_constr(x_soc)
+    f_soc = float(f_soc)
     state.nfev += 1
     state.ncev += 1
     norm_b_soc = xp.norm(b_soc)

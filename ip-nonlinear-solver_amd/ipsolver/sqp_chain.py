@@ -212,6 +212,7 @@ class StepChain:
     def judge(self, b_next, f_next):
         fdev = None
         if torch.is_tensor(f_next):
+            self.keep_f = f_next
             fdev, f_next = f_next.data_ptr(), 0.0
         _hip.call("ipx_sqp_judge", ctypes.byref(self.args), _p(b_next.t), float(f_next), fdev,
                   stream_ptr())

@@ -298,7 +298,11 @@ class LeanDeviceCallbacks(DeviceCallbacks):
         self._x = None
 
     def _point(self, x):
-        if self._x is not x or self._ver != x._version:
+        # (recognised by its storage and version counter, the tensor kept alive so that the
+        # address cannot be handed out again: the solver passes views of one iterate)
+        seen = self._x
+        if seen is None or seen.data_ptr() != x.data_ptr() or seen.numel() != x.numel() \
+                or self._ver != x._version:
             dl = x - self.x_feas
             self._pt = (dl, self.Q.dot(self.DVec(dl)).t, dl * dl)
             self._x, self._ver = x, x._version
@@ -309,9 +313,10 @@ class LeanDeviceCallbacks(DeviceCallbacks):
         dl, qd, d2 = self._point(x)
         D = self.DVec
         pk = ScalarPack()
-        h1, h2, h3 = pk.dot(D(dl), D(qd)), pk.dot(D(self.q), D(dl)), pk.dot(D(d2), D(d2))
-        v = pk.read()
-        return 0.5 * v[h1] - self.p.eps * v[h2] + 0.25 * self.p.rho * v[h3]
+        h = (pk.dot(D(dl), D(qd)), pk.dot(D(self.q), D(dl)), pk.dot(D(d2), D(d2)))
+        # 0.5 dl'Q dl - eps q'dl + 0.25 rho sum dl^4, left on the device: the step's verdict
+        # consumes it there (the value a host expression over the three sums would have)
+        return pk.combine(h, (0.5, -self.p.eps, 0.25 * self.p.rho))
 
     def grad(self, x):
         dl, qd, d2 = self._point(x)

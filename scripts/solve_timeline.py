@@ -81,6 +81,12 @@ def summarize(d, out=None):
     print(text)
     if out:
         open(out, "w").write(text + "\n")
+        # (the launches in order: offset, duration, gap before, grid, name)
+        with open(out + ".sequence", "w") as fh:
+            for i, (s, e, k) in enumerate(rows):
+                k = k.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:90]
+                fh.write("%9.1f %6.1f %6.1f  %s\n" % ((s - rows[0][0]) / 1e3, (e - s) / 1e3,
+                                                     (s - rows[i - 1][1]) / 1e3 if i else 0.0, k))
 
 
 if __name__ == "__main__":
