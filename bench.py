@@ -546,20 +546,10 @@ def config3_leg(n, m, repeats=5):
             out[name] = (res, walls, dc)
         res, walls, dc = out["lean"]
         # one more solve with the calls counted, one with the CG bracketed by events
-        counts = {"reads": 0}
-        plain = _hip.call
-
-        def counting(fname, *a):
-            if fname in ("ipx_read_doubles", "ipx_read_folded"):
-                counts["reads"] += 1
-            return plain(fname, *a)
-        _hip.call = counting
-        launches0 = int(lib.ipx_launch_count())
-        try:
-            solve(dc)
-        finally:
-            _hip.call = plain
+        launches0, reads0 = int(lib.ipx_launch_count()), int(lib.ipx_read_count())
+        solve(dc)
         launches = int(lib.ipx_launch_count()) - launches0
+        counts = {"reads": int(lib.ipx_read_count()) - reads0}
         before = dict(sqp_chain.STATS)
         sqp.TIMERS["host_cg_seconds"] = 0.0
         lib.ipx_sqp_cg_timing(1, None, None)
@@ -589,8 +579,9 @@ def config3_leg(n, m, repeats=5):
                          "iteration, float(f) by a torch synchronisation)"},
         "note": "config 3 (eps=1e-3), gtol=xtol=1e-8; the reference reaches status 1 in 25 "
                 "outer / 34 CG iterations (SURVEY.md Appendix B: 103 s on the survey host).  "
-                "blocking reads: ipx_read_doubles / ipx_read_folded calls (the lean callbacks' "
-                "objective reads its three dot products through one of them per evaluation); "
+                "blocking reads: every wait of the library for device results (ipx_read_count: "
+                "the chains' blocks, ipx_read_doubles / ipx_read_folded; the lean callbacks' "
+                "objective leaves its value on the device for the step's verdict); "
                 "launches: the library's own (ipx_launch_count), the callbacks' torch kernels "
                 "not included"}
 

@@ -47,6 +47,9 @@ extern "C" {
 const char *ipx_version(void);
 /* Kernel launches of the library since it was loaded (a host counter: diagnostics, bench.py). */
 long long ipx_launch_count(void);
+/* Blocking reads of the library since it was loaded: every wait for device results -- ipx_read_doubles
+ * / ipx_read_folded, and the chains of csrc/sqp.hip that hand over their block themselves. */
+long long ipx_read_count(void);
 /* Text of the last HIP error seen by this thread ("" if none). */
 const char *ipx_last_error(void);
 int ipx_device_info(int *cu_count, int *lds_bytes, char *arch, int arch_len);
@@ -620,9 +623,10 @@ int ipx_banded_status_deferred(void *handle, double *verdict, void *stream);
 /* ---- one outer iteration of the trust-region SQP method as three chains of launches whose
  * decisions are taken on the device (csrc/sqp.hip; reference equality_constrained_sqp.py:102-250,
  * the Newton point of modified_dogleg qp_subproblem.py:366-373, projected_cg :416-643).
- * Every chain ends in a one-workgroup kernel that writes the scalar block q (ipx_sqp_block_size()
- * doubles, layout in csrc/sqp.hip SQ_*, mirrored by ipsolver/sqp_chain.py); the host reads the
- * block once per chain.  CSR Jacobian and Hessian, banded or box-Schur solver (solver_kind 0 / 1
+ * Every chain ends in a reduction whose last workgroup to arrive folds the partial sums in their
+ * fixed order, decides, and writes the scalar block q (ipx_sqp_block_size() doubles, layout in
+ * csrc/sqp.hip SQ_*, mirrored by ipsolver/sqp_chain.py); the host reads the block once per chain
+ * (host_block: the kernel hands it over itself).  CSR Jacobian and Hessian, banded or box-Schur solver (solver_kind 0 / 1
  * of the CG loop's argument block), constraint rows in the projector's own order. */
 typedef struct ipx_sqp_args {
   int64_t n, m;
@@ -644,6 +648,10 @@ typedef struct ipx_sqp_args {
   const double *A_norm_part;        /* ipx_norms_partials over A's values (ipx_sqp_refresh folds
                                      * them into the block's ||A||_F^2), or NULL */
   int64_t A_norm_grid;
+  double *host_block;               /* HOST memory, ipx_sqp_block_size() doubles, or NULL.  Non-NULL:
+                                     * ipx_sqp_front / _model / _judge / _refresh return when the
+                                     * block has arrived there -- the workgroup that completes the
+                                     * block publishes it (no read-back launch behind the chain) */
 } ipx_sqp_args;
 int ipx_sqp_block_size(void);
 int64_t ipx_sqp_part_doubles(const ipx_sqp_args *s);

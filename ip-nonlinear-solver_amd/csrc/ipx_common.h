@@ -16,6 +16,12 @@
 void ipx_note_error(hipError_t e, const char *file, int line);
 // blocking read-back of k ints (csrc/misc.hip: ipx_read_doubles' mechanism); the device array
 // must be readable up to the next multiple of 8 bytes
+// The two halves of a blocking read for a kernel that publishes its results itself (csrc/sqp.hip:
+// the last workgroup of a chain writes the block as tagged granules, csrc/misc.hip k_publish's
+// format, into `pinned`): begin -> (the calling thread's pinned buffer, the tag to write),
+// launch, wait -> k doubles.
+int ipx_read_begin(unsigned int **pinned_out, unsigned int *tag_out);
+int ipx_read_wait(unsigned int *pinned, unsigned int tag, int k, double *host_out, hipStream_t st);
 int ipx_read_ints(const int *dev, int k, int *host_out, hipStream_t st);
 
 // kernel launches of the library since it was loaded (ipx_launch_count; misc.hip): counted where

@@ -26,13 +26,14 @@ k_publish(const double *__restrict__ src, int k, ipx_u4 *dst, unsigned int tag) 
 }
 
 static thread_local char g_last_error[256] = "";
+static std::atomic<long long> g_ipx_reads{0};
 
 void ipx_note_error(hipError_t e, const char *file, int line) {
   snprintf(g_last_error, sizeof(g_last_error), "%s (%s:%d)", hipGetErrorString(e), file, line);
 }
 
 // the calling thread's pinned granule buffer and the next tag
-static int read_begin(unsigned int **pinned_out, unsigned int *tag_out) {
+int ipx_read_begin(unsigned int **pinned_out, unsigned int *tag_out) {
   static thread_local unsigned int *pinned = nullptr;      // [IPX_READ_MAX] granules of 4 words
   static thread_local unsigned int seq = 0;
   if (!pinned) {
@@ -49,8 +50,9 @@ static int read_begin(unsigned int **pinned_out, unsigned int *tag_out) {
 }
 
 // poll the first k granules for `tag`, copy the values out
-static int read_wait(unsigned int *pinned, unsigned int seq, int k, double *host_out, hipStream_t st) {
+int ipx_read_wait(unsigned int *pinned, unsigned int seq, int k, double *host_out, hipStream_t st) {
   volatile unsigned int *w = pinned;
+  g_ipx_reads.fetch_add(1, std::memory_order_relaxed);
   const auto t0 = std::chrono::steady_clock::now();
   unsigned spins = 0;
   int done = 0;                                            // granules [0, done) have arrived
@@ -130,6 +132,8 @@ const char *ipx_version(void) { return "ipx 0.1 (gfx950)"; }
 
 long long ipx_launch_count(void) { return g_ipx_launches; }
 
+long long ipx_read_count(void) { return g_ipx_reads.load(); }
+
 const char *ipx_last_error(void) { return g_last_error; }
 
 int ipx_device_info(int *cu_count, int *lds_bytes, char *arch, int arch_len) {
@@ -157,7 +161,7 @@ int ipx_read_doubles(const double *dev, int k, double *host_out, void *stream) {
   if (!dev || !host_out || k < 0 || k > IPX_READ_MAX) return IPX_EINVAL;
   if (k == 0) return IPX_OK;
   unsigned int *pinned; unsigned int tag;
-  int rc = read_begin(&pinned, &tag);
+  int rc = ipx_read_begin(&pinned, &tag);
   if (rc != IPX_OK) return rc;
   hipLaunchKernelGGL(k_publish, dim3(1), dim3(IPX_READ_MAX), 0, (hipStream_t)stream, dev, k,
                      (ipx_u4 *)pinned, tag);
@@ -166,7 +170,7 @@ int ipx_read_doubles(const double *dev, int k, double *host_out, void *stream) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { ipx_note_error(e, __FILE__, __LINE__); return IPX_ELAUNCH; }
   }
-  return read_wait(pinned, tag, k, host_out, (hipStream_t)stream);
+  return ipx_read_wait(pinned, tag, k, host_out, (hipStream_t)stream);
 }
 
 // Blocking read-back of nd <= IPX_FOLD_MAX scalars, each the fold of a partial array a
@@ -184,7 +188,7 @@ int ipx_read_folded(int nd, const ipx_fold_desc *descs, double *host_out, void *
   }
   for (int q = nd; q < IPX_FOLD_MAX; ++q) D.d[q] = descs[0];
   unsigned int *pinned; unsigned int tag;
-  int rc = read_begin(&pinned, &tag);
+  int rc = ipx_read_begin(&pinned, &tag);
   if (rc != IPX_OK) return rc;
   hipLaunchKernelGGL(k_publish_folded, dim3(1), dim3(IPX_BLOCK), 0, (hipStream_t)stream, D, nd,
                      (ipx_u4 *)pinned, tag);
@@ -193,7 +197,7 @@ int ipx_read_folded(int nd, const ipx_fold_desc *descs, double *host_out, void *
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { ipx_note_error(e, __FILE__, __LINE__); return IPX_ELAUNCH; }
   }
-  return read_wait(pinned, tag, nd, host_out, (hipStream_t)stream);
+  return ipx_read_wait(pinned, tag, nd, host_out, (hipStream_t)stream);
 }
 
 // The weighted sum of nd <= IPX_FOLD_MAX folded scalars into device memory (no read): out[0] =

@@ -170,14 +170,98 @@ constexpr int RU = 4;                     // elements per lane and trip of the v
 
 static int sq_grid(int64_t n) { return ipx_grid_for(n, RB * RU); }
 
+// ---- the decide step inside the kernel that produces its sums -------------------------------
+// A reduction's workgroups leave their partial sums; ONE of them (sq_folds) folds all of them --
+// in the fixed order of ipx_sum_partials: the bits of the one-workgroup kernel that used to
+// follow -- and runs the decision.  No fence anywhere (a device-scope release / acquire pair per
+// workgroup writes back and invalidates L2: measured, +50 us per launch at n = 1e6): a partial
+// travels as ONE 16-byte write-through store that validates itself -- (low word, tag, high
+// word, tag), the launch's sequence number as the tag, the format of csrc/resident.hip's
+// hand-offs -- and the folding workgroup reads past its caches (sc1) until the tag is there.
+typedef unsigned int sq_u4 __attribute__((ext_vector_type(4)));
+struct SqSync { unsigned int tag; };
+__device__ __forceinline__ void sq_put(sq_u4 *slot, double v, unsigned int tag) {
+  const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+  sq_u4 w;
+  w.x = (unsigned)(bits & 0xffffffffull); w.y = tag;
+  w.z = (unsigned)(bits >> 32);           w.w = tag;
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(slot), "v"(w) : "memory");
+}
+__device__ __forceinline__ double sq_value(const sq_u4 &w) {
+  return __longlong_as_double((long long)((unsigned long long)w.x | ((unsigned long long)w.z << 32)));
+}
+// ipx_sum_partials over tagged partials: the same lanes take the same entries in the same order
+// (IPX_FOLD_U granules per lane and trip, requested together, polled until all carry the tag;
+// bounded: ~1 s of polling, then NaN -- a decision on NaN fails loudly on the host, a kernel
+// that never ends takes the machine with it)
+template <int OP>
+__device__ __forceinline__ double sq_fold(const sq_u4 *gr, int count, unsigned int tag,
+                                          double *lds) {
+  static_assert(IPX_FOLD_U == 4, "the load burst below is written for four granules per lane");
+  double v = ipx_identity<OP>();
+  for (int base = threadIdx.x; base < count; base += IPX_FOLD_U * blockDim.x) {
+    const sq_u4 *p0 = gr + base, *p1 = gr + min(base + (int)blockDim.x, count - 1),
+                *p2 = gr + min(base + 2 * (int)blockDim.x, count - 1),
+                *p3 = gr + min(base + 3 * (int)blockDim.x, count - 1);
+    sq_u4 w0, w1, w2, w3;
+    bool ok = false;
+    for (int spin = 0; spin < (1 << 20) && !ok; ++spin) {
+      asm volatile("global_load_dwordx4 %0, %4, off sc1\n\t"
+                   "global_load_dwordx4 %1, %5, off sc1\n\t"
+                   "global_load_dwordx4 %2, %6, off sc1\n\t"
+                   "global_load_dwordx4 %3, %7, off sc1\n\t"
+                   "s_waitcnt vmcnt(0)"
+                   : "=&v"(w0), "=&v"(w1), "=&v"(w2), "=&v"(w3)
+                   : "v"(p0), "v"(p1), "v"(p2), "v"(p3)
+                   : "memory");
+      ok = w0.y == tag && w0.w == tag && w1.y == tag && w1.w == tag && w2.y == tag &&
+           w2.w == tag && w3.y == tag && w3.w == tag;
+      if (!ok) __builtin_amdgcn_s_sleep(1);
+    }
+    const double nan = __builtin_nan("");
+    double t[IPX_FOLD_U] = {ok ? sq_value(w0) : nan, ok ? sq_value(w1) : nan,
+                            ok ? sq_value(w2) : nan, ok ? sq_value(w3) : nan};
+#pragma unroll
+    for (int u = 0; u < IPX_FOLD_U; ++u) {
+      const int i = base + u * blockDim.x;
+      v = ipx_combine<OP>(v, i < count ? t[u] : ipx_identity<OP>());
+    }
+  }
+  return ipx_block_reduce<OP>(v, lds);
+}
+// Who folds: the workgroup with the highest index -- dispatched behind all others, or at least
+// never in their way (it holds one of the device's > 2000 workgroup slots while it polls).  No
+// counter: ~1100 workgroups counting themselves off on one word serialise in L2 (measured:
+// +8..10 us per launch, more than the launch this saves).
+__device__ __forceinline__ bool sq_folds() { return blockIdx.x == gridDim.x - 1; }
+
+// ... and hands the finished block to the host itself: the 64 doubles as self-validating
+// granules into the pinned buffer of the read that waits for them (csrc/misc.hip k_publish's
+// format), by the workgroup that completed the block -- no publish launch behind the chain.
+struct SqPub { unsigned int *dst; unsigned int tag; };
+__device__ __forceinline__ void sq_publish(const double *q, SqPub pub) {
+  __syncthreads();                               // (thread 0's entries of q: visible)
+  if (!pub.dst || threadIdx.x >= SQ_SIZE) return;
+  const unsigned long long bits =
+      (unsigned long long)__double_as_longlong(
+          __hip_atomic_load(q + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  sq_u4 w;
+  w.x = (unsigned)(bits & 0xffffffffull); w.y = pub.tag;
+  w.z = (unsigned)(bits >> 32);           w.w = pub.tag;
+  sq_u4 *d = (sq_u4 *)pub.dst + threadIdx.x;
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(d), "v"(w) : "memory");
+}
+
 // ---- vector kernels ---------------------------------------------------------------------------
 // the Newton point's sum of squares (csrc/vec.hip RedNorms' accumulation: the bits of the host
 // form's norm) and its violations of [f lb, f ub] (either bound may be NULL):
 // part[block] / viol[block]
+__device__ __forceinline__ void sq_after_newton(double nn2, double nviol, double radius,
+                                                double tr_factor, double *q);
 __global__ void __launch_bounds__(RB)
 k_sq_newton_check(int64_t n, const double *__restrict__ v, const double *__restrict__ lb,
-                  const double *__restrict__ ub, double f, double *__restrict__ part,
-                  double *__restrict__ viol) {
+                  const double *__restrict__ ub, double f, sq_u4 *gran, SqSync sync, int boxed,
+                  double radius, double tr_factor, double *__restrict__ q) {
   __shared__ double lds[RB / IPX_WAVE];
   double cnt = 0.0, s = 0.0;
   const int64_t stride = (int64_t)gridDim.x * RB;
@@ -191,7 +275,15 @@ k_sq_newton_check(int64_t n, const double *__restrict__ v, const double *__restr
   }
   const double a = ipx_block_reduce<IPX_SUM>(s, lds);
   const double r = ipx_block_reduce<IPX_SUM>(cnt, lds);
-  if (threadIdx.x == 0) { part[blockIdx.x] = a; viol[blockIdx.x] = r; }
+  const int G = gridDim.x;
+  if (threadIdx.x == 0) {
+    sq_put(gran + blockIdx.x, a, sync.tag);
+    sq_put(gran + G + blockIdx.x, r, sync.tag);
+  }
+  if (!sq_folds()) return;
+  const double nn2 = sq_fold<IPX_SUM>(gran, G, sync.tag, lds);
+  const double nviol = boxed ? sq_fold<IPX_SUM>(gran + G, G, sync.tag, lds) : 0.0;
+  sq_after_newton(nn2, nviol, radius, tr_factor, q);
 }
 
 // two reductions of different lengths in one launch, each with the grid and the accumulation
@@ -255,10 +347,14 @@ k_sq_shift_bounds(int64_t n, const double *__restrict__ lb, const double *__rest
 __global__ void __launch_bounds__(RB)
 k_sq_exit_reduce(int64_t n, const double *__restrict__ st, const double *__restrict__ z,
                  const double *__restrict__ d, const double *__restrict__ lb,
-                 const double *__restrict__ ub, double *__restrict__ part) {
+                 const double *__restrict__ ub, sq_u4 *gran, SqSync sync,
+                 double *__restrict__ q) {
   __shared__ double lds[RB / IPX_WAVE];
   const double stop = st[ST_STOP];
-  if (stop != 2.0 && stop != 3.0) return;
+  if (stop != 2.0 && stop != 3.0) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) { q[SQ_EXIT_TAU] = 0.0; q[SQ_EXIT_DONE] = 0.0; }
+    return;
+  }
   const double dscale = stop == 2.0 ? st[ST_ALPHA] : 1.0;
   double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = -HUGE_VAL, a4 = HUGE_VAL, a5 = 0.0;
   const int64_t stride = (int64_t)gridDim.x * RB;
@@ -275,37 +371,28 @@ k_sq_exit_reduce(int64_t n, const double *__restrict__ st, const double *__restr
     }
   }
   const int g = gridDim.x, b = blockIdx.x;
+  const unsigned int tag = sync.tag;
   double r;
-  r = ipx_block_reduce<IPX_SUM>(a0, lds); if (threadIdx.x == 0) part[b] = r;
-  r = ipx_block_reduce<IPX_SUM>(a1, lds); if (threadIdx.x == 0) part[g + b] = r;
-  r = ipx_block_reduce<IPX_SUM>(a2, lds); if (threadIdx.x == 0) part[2 * g + b] = r;
-  r = ipx_block_reduce<IPX_MAX>(a3, lds); if (threadIdx.x == 0) part[3 * g + b] = r;
-  r = ipx_block_reduce<IPX_MIN>(a4, lds); if (threadIdx.x == 0) part[4 * g + b] = r;
-  r = ipx_block_reduce<IPX_SUM>(a5, lds); if (threadIdx.x == 0) part[5 * g + b] = r;
-}
-
-// the scalar tail of that exit: tau = theta * alpha (code 2) / the line's far intersection
-// (code 3), 0 when the segment misses; one workgroup
-__global__ void __launch_bounds__(RB)
-k_sq_exit_decide(const double *__restrict__ st, const double *__restrict__ part, int grid,
-                 double *__restrict__ q) {
-  __shared__ double lds[RB / IPX_WAVE];
-  const double stop = st[ST_STOP];
-  if (stop != 2.0 && stop != 3.0) {
-    if (threadIdx.x == 0) { q[SQ_EXIT_TAU] = 0.0; q[SQ_EXIT_DONE] = 0.0; }
-    return;
-  }
-  double r[7];
-  r[0] = ipx_sum_partials<IPX_SUM>(part, grid, lds);
-  r[1] = ipx_sum_partials<IPX_SUM>(part + grid, grid, lds);
-  r[2] = ipx_sum_partials<IPX_SUM>(part + 2 * grid, grid, lds);
-  r[3] = ipx_sum_partials<IPX_MAX>(part + 3 * grid, grid, lds);
-  r[4] = ipx_sum_partials<IPX_MIN>(part + 4 * grid, grid, lds);
-  r[5] = ipx_sum_partials<IPX_SUM>(part + 5 * grid, grid, lds);
-  r[6] = 0.0;
+  r = ipx_block_reduce<IPX_SUM>(a0, lds); if (threadIdx.x == 0) sq_put(gran + b, r, tag);
+  r = ipx_block_reduce<IPX_SUM>(a1, lds); if (threadIdx.x == 0) sq_put(gran + g + b, r, tag);
+  r = ipx_block_reduce<IPX_SUM>(a2, lds); if (threadIdx.x == 0) sq_put(gran + 2 * g + b, r, tag);
+  r = ipx_block_reduce<IPX_MAX>(a3, lds); if (threadIdx.x == 0) sq_put(gran + 3 * g + b, r, tag);
+  r = ipx_block_reduce<IPX_MIN>(a4, lds); if (threadIdx.x == 0) sq_put(gran + 4 * g + b, r, tag);
+  r = ipx_block_reduce<IPX_SUM>(a5, lds); if (threadIdx.x == 0) sq_put(gran + 5 * g + b, r, tag);
+  if (!sq_folds()) return;
+  // the scalar tail of that exit, by the workgroup that arrives last: tau = theta * alpha
+  // (code 2) / the line's far intersection (code 3), 0 when the segment misses
+  double rr[7];
+  rr[0] = sq_fold<IPX_SUM>(gran, g, tag, lds);
+  rr[1] = sq_fold<IPX_SUM>(gran + g, g, tag, lds);
+  rr[2] = sq_fold<IPX_SUM>(gran + 2 * g, g, tag, lds);
+  rr[3] = sq_fold<IPX_MAX>(gran + 3 * g, g, tag, lds);
+  rr[4] = sq_fold<IPX_MIN>(gran + 4 * g, g, tag, lds);
+  rr[5] = sq_fold<IPX_SUM>(gran + 5 * g, g, tag, lds);
+  rr[6] = 0.0;
   if (threadIdx.x != 0) return;
   const double radius = st[ST_RADIUS];
-  const sq_interval iv = sq_box_sphere(r, radius, stop == 3.0);
+  const sq_interval iv = sq_box_sphere(rr, radius, stop == 3.0);
   // :565-568 x + alpha p with alpha = tb of the entire line; :588-590 x + theta alpha p
   const double tau = !iv.hit ? 0.0 : (stop == 2.0 ? iv.tb * st[ST_ALPHA] : iv.tb);
   q[SQ_EXIT_TAU] = tau;
@@ -508,12 +595,8 @@ k_sq_after_dogleg(const double *__restrict__ p_nn, int n_nn, double radius,
 
 // ---- decide kernels (one workgroup each) ----------------------------------------------------
 // after the Newton point: ||dn||, inside the box and the ball? the tangential radius
-__global__ void __launch_bounds__(RB)
-k_sq_after_newton(const double *__restrict__ p_nn, int n_nn, const double *__restrict__ p_viol,
-                  int n_viol, double radius, double tr_factor, double *__restrict__ q) {
-  __shared__ double lds[RB / IPX_WAVE];
-  const double nn2 = ipx_sum_partials<IPX_SUM>(p_nn, n_nn, lds);
-  const double nviol = n_viol > 0 ? ipx_sum_partials<IPX_SUM>(p_viol, n_viol, lds) : 0.0;
+__device__ __forceinline__ void sq_after_newton(double nn2, double nviol, double radius,
+                                                double tr_factor, double *q) {
   if (threadIdx.x != 0) return;
   const double norm_dn = sqrt(nn2);
   const bool ok = nviol == 0.0 && norm_dn <= tr_factor * radius;      // qp_subproblem.py:370-373
@@ -539,40 +622,62 @@ k_sq_after_given(const double *__restrict__ p_nn, int n_nn, double radius,
   q[SQ_RADIUS_T] = sqrt(radius * radius - norm_dn * norm_dn);
 }
 
-// the model: folds the step's sums, :135-153, and a copy of the CG loop's state block
+// the model: folds the step's sums, :135-153, and a copy of the CG loop's state block -- run by
+// the last workgroup of the launch that forms (H d).d and ||A d + b||^2 (k_sq_two_sums<true,
+// false>'s sums, grids and bits), which then hands the block to the host
+struct SqModelIn {
+  const double *p_vec; int g_vec;
+  const double *cg_state, *red;
+  double penalty, f, norm_b;
+};
 __global__ void __launch_bounds__(RB)
-k_sq_model(const double *__restrict__ p_vec, int g_vec, const double *__restrict__ p_hd, int n_hd,
-           const double *__restrict__ p_ad, int n_ad, const double *__restrict__ cg_state,
-           const double *__restrict__ red, double penalty, double f, double norm_b,
-           double *__restrict__ q) {
-  __shared__ double lds[5 * (RB / IPX_WAVE)];
-  const double *parts[5] = {p_vec, p_vec + g_vec, p_vec + 2 * g_vec, p_hd, p_ad};
-  const int counts[5] = {g_vec, g_vec, g_vec, n_hd, n_ad};
-  double out[5];
-  ipx_sum_partials_multi<5>(parts, counts, lds, out);
-  const double outside = ipx_sum_partials<IPX_SUM>(p_vec + 3 * g_vec, g_vec, lds);
-  if (threadIdx.x < ST_SIZE) q[SQ_CG + threadIdx.x] = cg_state[threadIdx.x];
-  if (threadIdx.x != 0) return;
-  q[SQ_NORM_D] = sqrt(out[0]);
-  q[SQ_NORM_DT] = sqrt(out[1]);
-  q[SQ_CD] = out[2];
-  q[SQ_HDD] = out[3];
-  q[SQ_LIN] = sqrt(out[4]);
-  q[SQ_X_OUTSIDE] = outside;
-  q[SQ_PRIME_STEPS] = red ? red[16] + red[17] : 0.0;       // (csrc/cg.hip PR_TAKEN)
-  q[SQ_PENALTY] = penalty;
-  q[SQ_F] = f;
-  q[SQ_NORM_B] = norm_b;
-  sqp_model(q);
+k_sq_model_sums(int64_t n1, const double *__restrict__ x1, const double *__restrict__ y1, int g1,
+                int64_t n2, const double *__restrict__ x2, int g2, sq_u4 *gran, SqSync sync,
+                SqModelIn in, double *q, SqPub pub) {
+  __shared__ double lds[RB / IPX_WAVE];
+  const bool second = (int)blockIdx.x >= g1;
+  const int b = second ? blockIdx.x - g1 : blockIdx.x, G = second ? g2 : g1;
+  const int64_t n = second ? n2 : n1;
+  const double *x = second ? x2 : x1;
+  double s = 0.0;
+  const int64_t stride = (int64_t)G * RB;
+  for (int64_t i = (int64_t)b * RB + threadIdx.x; i < n; i += stride) {
+    const double t = x[i];
+    s += second ? t * t : t * y1[i];
+  }
+  const double r = ipx_block_reduce<IPX_SUM>(s, lds);
+  if (threadIdx.x == 0) sq_put(gran + blockIdx.x, r, sync.tag);      // ([0, g1): H d . d; then A d + b)
+  if (!sq_folds()) return;
+  // (each quantity folded on its own: the order ipx_sum_partials_multi gives it)
+  const double *pv = in.p_vec;
+  const int gv = in.g_vec;
+  const double d2 = ipx_sum_partials<IPX_SUM>(pv, gv, lds);
+  const double dt2 = ipx_sum_partials<IPX_SUM>(pv + gv, gv, lds);
+  const double cd = ipx_sum_partials<IPX_SUM>(pv + 2 * gv, gv, lds);
+  const double outside = ipx_sum_partials<IPX_SUM>(pv + 3 * gv, gv, lds);
+  const double hdd = sq_fold<IPX_SUM>(gran, g1, sync.tag, lds);
+  const double lin2 = sq_fold<IPX_SUM>(gran + g1, g2, sync.tag, lds);
+  if (threadIdx.x < ST_SIZE) q[SQ_CG + threadIdx.x] = in.cg_state[threadIdx.x];
+  if (threadIdx.x == 0) {
+    q[SQ_NORM_D] = sqrt(d2);
+    q[SQ_NORM_DT] = sqrt(dt2);
+    q[SQ_CD] = cd;
+    q[SQ_HDD] = hdd;
+    q[SQ_LIN] = sqrt(lin2);
+    q[SQ_X_OUTSIDE] = outside;
+    q[SQ_PRIME_STEPS] = in.red ? in.red[16] + in.red[17] : 0.0;       // (csrc/cg.hip PR_TAKEN)
+    q[SQ_PENALTY] = in.penalty;
+    q[SQ_F] = in.f;
+    q[SQ_NORM_B] = in.norm_b;
+    sqp_model(q);
+  }
+  sq_publish(q, pub);
 }
 
 // the verdict: ||b_next||, :156-173, and -- unless the second-order correction is due, which
 // the host runs -- the ladder and the accept test
-__global__ void __launch_bounds__(RB)
-k_sq_judge(const double *__restrict__ p_bn, int n_bn, double f_next,
-           const double *__restrict__ f_next_dev, double *__restrict__ q) {
-  __shared__ double lds[RB / IPX_WAVE];
-  const double bn2 = n_bn > 0 ? ipx_sum_partials<IPX_SUM>(p_bn, n_bn, lds) : 0.0;
+__device__ __forceinline__ void sq_judge_fold(double bn2, double f_next, const double *f_next_dev,
+                                              double *q) {
   if (threadIdx.x != 0) return;
   q[SQ_F_NEXT] = f_next_dev ? *f_next_dev : f_next;
   q[SQ_NORM_B_NEXT] = sqrt(bn2);
@@ -580,24 +685,77 @@ k_sq_judge(const double *__restrict__ p_bn, int n_bn, double f_next,
   if (q[SQ_SOC] == 0.0) sqp_radius(q);
   else q[SQ_ACCEPT] = 0.0;
 }
+// (no constraint rows: nothing to sum)
+__global__ void __launch_bounds__(RB)
+k_sq_judge(double f_next, const double *__restrict__ f_next_dev, double *q, SqPub pub) {
+  sq_judge_fold(0.0, f_next, f_next_dev, q);
+  sq_publish(q, pub);
+}
+// k_sq_norms over b_next (its grid, its sums) whose last workgroup is the judge
+__global__ void __launch_bounds__(RB)
+k_sq_judge_norms(int64_t n, const double *__restrict__ v, sq_u4 *gran, SqSync sync,
+                 double f_next, const double *__restrict__ f_next_dev, double *q, SqPub pub) {
+  __shared__ double lds[RB / IPX_WAVE];
+  double s = 0.0, mx = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * RB;
+  for (int64_t i = (int64_t)blockIdx.x * RB + threadIdx.x; i < n; i += stride) {
+    const double t = v[i];
+    s += t * t;
+    mx = fmax(mx, fabs(t));
+  }
+  const double a = ipx_block_reduce<IPX_SUM>(s, lds);
+  const double b = ipx_block_reduce<IPX_MAX>(mx, lds);
+  (void)b;                                 // (the verdict takes the 2-norm only)
+  if (threadIdx.x == 0) sq_put(gran + blockIdx.x, a, sync.tag);
+  if (!sq_folds()) return;
+  const double bn2 = sq_fold<IPX_SUM>(gran, gridDim.x, sync.tag, lds);
+  sq_judge_fold(bn2, f_next, f_next_dev, q);
+  sq_publish(q, pub);
+}
 
 // the measures of a new iterate (:86-87, 238-239): ||c + A'v||_inf, ||b||_inf, ||b||, and
 // ||A||_F^2 from the partials of ipx_norms_partials over A's values
+// ... run by the last workgroup of ONE launch that takes both vectors' norms (k_sq_norms' grids
+// and sums: blocks [0, g_t) over c + A'v, [g_t, g_t + g_b) over b)
 __global__ void __launch_bounds__(RB)
-k_sq_measure(const double *__restrict__ p_t, int g_t, const double *__restrict__ p_b, int g_b,
-             const double *__restrict__ p_A, int g_A, const double *__restrict__ verdict,
-             double *__restrict__ q) {
+k_sq_measure_norms(int64_t n1, const double *__restrict__ v1, int g1, int64_t n2,
+                   const double *__restrict__ v2, int g2, sq_u4 *gran, SqSync sync,
+                   const double *__restrict__ p_A, int g_A, const double *__restrict__ verdict,
+                   double *q, SqPub pub) {
   __shared__ double lds[RB / IPX_WAVE];
-  const double opt = g_t > 0 ? ipx_sum_partials<IPX_MAX>(p_t + g_t, g_t, lds) : 0.0;
-  const double viol = g_b > 0 ? ipx_sum_partials<IPX_MAX>(p_b + g_b, g_b, lds) : 0.0;
-  const double nb2 = g_b > 0 ? ipx_sum_partials<IPX_SUM>(p_b, g_b, lds) : 0.0;
+  const bool second = (int)blockIdx.x >= g1;
+  const int b = second ? blockIdx.x - g1 : blockIdx.x, G = second ? g2 : g1;
+  const int64_t n = second ? n2 : n1;
+  const double *v = second ? v2 : v1;
+  double s = 0.0, mx = 0.0;
+  const int64_t stride = (int64_t)G * RB;
+  for (int64_t i = (int64_t)b * RB + threadIdx.x; i < n; i += stride) {
+    const double t = v[i];
+    s += t * t;
+    mx = fmax(mx, fabs(t));
+  }
+  const double a = ipx_block_reduce<IPX_SUM>(s, lds);
+  const double c = ipx_block_reduce<IPX_MAX>(mx, lds);
+  // granules: [0, g1) / [g1, 2 g1) sums / maxima of the first vector, then the second's
+  sq_u4 *mine = gran + (second ? 2 * g1 : 0);
+  if (threadIdx.x == 0) {
+    sq_put(mine + b, a, sync.tag);
+    sq_put(mine + G + b, c, sync.tag);
+  }
+  if (!sq_folds()) return;
+  const sq_u4 *gt = gran, *gb = gran + 2 * g1;
+  const double opt = g1 > 0 ? sq_fold<IPX_MAX>(gt + g1, g1, sync.tag, lds) : 0.0;
+  const double viol = g2 > 0 ? sq_fold<IPX_MAX>(gb + g2, g2, sync.tag, lds) : 0.0;
+  const double nb2 = g2 > 0 ? sq_fold<IPX_SUM>(gb, g2, sync.tag, lds) : 0.0;
   const double na2 = g_A > 0 ? ipx_sum_partials<IPX_SUM>(p_A, g_A, lds) : 0.0;
-  if (threadIdx.x != 0) return;
-  q[SQ_OPT] = opt;
-  q[SQ_VIOL] = viol;
-  q[SQ_NORM_B] = sqrt(nb2);
-  if (g_A > 0) q[SQ_NORM_A2] = na2;
-  q[SQ_FACTOR_BAD] = verdict ? *verdict : 0.0;
+  if (threadIdx.x == 0) {
+    q[SQ_OPT] = opt;
+    q[SQ_VIOL] = viol;
+    q[SQ_NORM_B] = sqrt(nb2);
+    if (g_A > 0) q[SQ_NORM_A2] = na2;
+    q[SQ_FACTOR_BAD] = verdict ? *verdict : 0.0;
+  }
+  sq_publish(q, pub);
 }
 
 }  // namespace
@@ -622,7 +780,7 @@ int ipx_sqp_block_size(void) { return SQ_SIZE; }
 int64_t ipx_sqp_part_doubles(const ipx_sqp_args *s) {
   if (!s || !s->cg) return -1;
   const int64_t g = sq_grid(s->n), gm = sq_grid(s->m);
-  return 4 * g + 6 * g + g + gm + 2 * g + 2 * gm + g + 18 * g + 64;
+  return 4 * g + 6 * g + g + gm + 2 * g + 2 * gm + g + 18 * g + 64 + 2 + 2 * (6 * g + 2 * gm);
 }
 
 /* on != 0: start collecting; on == 0: stop, synchronise, *ms_total = GPU milliseconds between the
@@ -665,7 +823,28 @@ namespace {
 
 struct PartLayout {
   double *vec, *exit, *hd, *ad, *viol, *bn, *tn, *dog, *tail;
-  int g, gm;
+  sq_u4 *gran;                // tagged partials of the kernels that end in their own decision:
+  int g, gm;                  // 6 g + 2 gm granules, one launch's at a time (allocated zeroed)
+};
+// the tag of one launch: its sequence number (never 0: the arena's initial state)
+static unsigned int next_tag() {
+  static unsigned int seq = 0;
+  if (++seq == 0) ++seq;
+  return seq;
+}
+
+// a chain's block on its way to the host: begin the read before the last launch, wait behind it
+struct BlockRead {
+  SqPub pub{nullptr, 0};
+  double *host = nullptr;
+  int begin(const ipx_sqp_args *s) {
+    host = s->host_block;
+    if (!host) return IPX_OK;
+    return ipx_read_begin(&pub.dst, &pub.tag);
+  }
+  int wait(hipStream_t st) {
+    return host ? ipx_read_wait(pub.dst, pub.tag, SQ_SIZE, host, st) : IPX_OK;
+  }
 };
 static PartLayout layout(const ipx_sqp_args *s) {
   PartLayout L;
@@ -680,6 +859,9 @@ static PartLayout layout(const ipx_sqp_args *s) {
   L.viol = p; p += L.g;
   L.dog = p;  p += 18 * (int64_t)L.g;       // the dogleg's three segments
   L.tail = p;
+  p += 64;
+  p += ((p - s->part) & 1);                 // (granules are 16 bytes)
+  L.gran = (sq_u4 *)p;
   return L;
 }
 
@@ -709,9 +891,7 @@ int ipx_sqp_model(const ipx_sqp_args *s, double penalty, double f, double norm_b
                         (int)a->H_ntiles};
   if (!host_cg) {
     hipLaunchKernelGGL(k_sq_exit_reduce, dim3(L.g), dim3(RB), 0, st, s->n, a->state, a->x, a->p,
-                       a->lb, a->ub, L.exit);
-    IPX_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_sq_exit_decide, dim3(1), dim3(RB), 0, st, a->state, L.exit, L.g, s->q);
+                       a->lb, a->ub, L.gran, SqSync{next_tag()}, s->q);
     IPX_CHECK_LAUNCH();
   }
   hipLaunchKernelGGL(k_sq_step_vectors, dim3(L.g), dim3(RB), 0, st, s->n, host_cg ? 0 : 1, s->q,
@@ -724,13 +904,16 @@ int ipx_sqp_model(const ipx_sqp_args *s, double penalty, double f, double norm_b
   if (rc) return rc;
   // (H d).d and ||A d + b||^2 summed as the host form's dot / norm kernels sum them (the
   // products' own epilogue sums come in tile order: other bits), one launch for both
-  hipLaunchKernelGGL((k_sq_two_sums<true, false>), dim3(L.g + L.gm), dim3(RB), 0, st, s->n, s->Hd,
-                     s->d, L.g, L.hd, s->m, s->Ad, s->Ad, L.gm, L.ad, nullptr);
+  // ... whose last workgroup folds the step's sums, decides (:135-153) and publishes the block
+  BlockRead br;
+  rc = br.begin(s);
+  if (rc) return rc;
+  const SqModelIn in{L.vec, L.g, a->state, host_cg ? nullptr : s->red, penalty, f, norm_b};
+  hipLaunchKernelGGL(k_sq_model_sums, dim3(L.g + L.gm), dim3(RB), 0, st, s->n, s->Hd, s->d, L.g,
+                     s->m, s->Ad, L.gm, L.gran, SqSync{next_tag()}, in, s->q,
+                     br.pub);
   IPX_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_sq_model, dim3(1), dim3(RB), 0, st, L.vec, L.g, L.hd, L.g, L.ad, L.gm,
-                     a->state, host_cg ? nullptr : s->red, penalty, f, norm_b, s->q);
-  IPX_CHECK_LAUNCH();
-  return IPX_OK;
+  return br.wait(st);
 }
 
 // have_dn == 0: the Newton point of the dogleg into s->dn, its acceptance decided on the
@@ -759,10 +942,8 @@ int ipx_sqp_front(const ipx_sqp_args *s, int have_dn, int with_dogleg, int with_
     if (rc) return rc;
     const bool boxed = s->lb || s->ub;
     hipLaunchKernelGGL(k_sq_newton_check, dim3(L.g), dim3(RB), 0, st, s->n, s->dn, s->lb, s->ub,
-                       box_factor, L.tn, L.viol);
-    IPX_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_sq_after_newton, dim3(1), dim3(RB), 0, st, L.tn, L.g, L.viol,
-                       boxed ? L.g : 0, radius, tr_factor, s->q);
+                       box_factor, L.gran, SqSync{next_tag()}, boxed ? 1 : 0,
+                       radius, tr_factor, s->q);
     IPX_CHECK_LAUNCH();
     if (with_dogleg) {
       // the dogleg proper behind it, every launch a no-op when the Newton point stands (the
@@ -837,14 +1018,17 @@ int ipx_sqp_judge(const ipx_sqp_args *s, const double *b_next, double f_next,
   if (!s || !s->q || !s->part || (s->m > 0 && !b_next)) return IPX_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const PartLayout L = layout(s);
+  BlockRead br;
+  int rc = br.begin(s);
+  if (rc) return rc;
   if (s->m > 0) {
-    hipLaunchKernelGGL(k_sq_norms, dim3(L.gm), dim3(RB), 0, st, s->m, b_next, L.bn);
-    IPX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_sq_judge_norms, dim3(L.gm), dim3(RB), 0, st, s->m, b_next, L.gran,
+                       SqSync{next_tag()}, f_next, f_next_dev, s->q, br.pub);
+  } else {
+    hipLaunchKernelGGL(k_sq_judge, dim3(1), dim3(RB), 0, st, f_next, f_next_dev, s->q, br.pub);
   }
-  hipLaunchKernelGGL(k_sq_judge, dim3(1), dim3(RB), 0, st, L.bn, s->m > 0 ? L.gm : 0, f_next,
-                     f_next_dev, s->q);
   IPX_CHECK_LAUNCH();
-  return IPX_OK;
+  return br.wait(st);
 }
 
 // v = -LS c (:83,226), optimality, constraint violation, ||b|| (:86-87,238-239)
@@ -867,14 +1051,15 @@ int ipx_sqp_refresh(const ipx_sqp_args *s, void *stream) {
   if (rc) return rc;
   rc = ipx_axpby(s->m, -1.0, a->v, 0.0, nullptr, s->v_out, stream);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_sq_norms, dim3(L.g), dim3(RB), 0, st, s->n, s->ct, L.tn);
+  BlockRead br;
+  rc = br.begin(s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_sq_measure_norms, dim3(L.g + L.gm), dim3(RB), 0, st, s->n, s->ct, L.g,
+                     s->m, s->b, L.gm, L.gran, SqSync{next_tag()},
+                     s->A_norm_part,
+                     s->A_norm_part ? (int)s->A_norm_grid : 0, s->verdict, s->q, br.pub);
   IPX_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_sq_norms, dim3(L.gm), dim3(RB), 0, st, s->m, s->b, L.bn);
-  IPX_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_sq_measure, dim3(1), dim3(RB), 0, st, L.tn, L.g, L.bn, L.gm, s->A_norm_part,
-                     s->A_norm_part ? (int)s->A_norm_grid : 0, s->verdict, s->q);
-  IPX_CHECK_LAUNCH();
-  return IPX_OK;
+  return br.wait(st);
 }
 
 }  // extern "C"

@@ -121,7 +121,7 @@ _SIGNATURES = {
     "ipx_sqp_cg_timing": [_c.c_int, _P, _P],
 }
 _RESTYPES = {"ipx_version": _c.c_char_p, "ipx_last_error": _c.c_char_p,
-             "ipx_launch_count": _c.c_longlong,
+             "ipx_launch_count": _c.c_longlong, "ipx_read_count": _c.c_longlong,
              "ipx_banded_create": _P, "ipx_banded_destroy": None,
              "ipx_dense_padded": _I64, "ipx_gram_ws_doubles": _I64, "ipx_peer_create": _P, "ipx_peer_destroy": None,
              "ipx_peer_halo_capacity": _I64, "ipx_peer_fused_launches": _I64,

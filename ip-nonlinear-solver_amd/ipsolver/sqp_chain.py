@@ -42,7 +42,7 @@ class ChainArgs(ctypes.Structure):
         ("dn", _P), ("ct", _P), ("lbt", _P), ("ubt", _P), ("d", _P), ("Hd", _P), ("x_next", _P),
         ("Ad", _P), ("v_out", _P), ("part", _P), ("red", _P), ("ws", _P),
         ("orth_tol", _F64c), ("cancellation", _F64c), ("verdict", _P),
-        ("A_norm_part", _P), ("A_norm_grid", _I64))]
+        ("A_norm_part", _P), ("A_norm_grid", _I64), ("host_block", _P))]
 
 
 STATS = {"fronts": 0, "host_doglegs": 0, "host_cg": 0, "prime_retries": 0, "refreshes": 0,
@@ -113,6 +113,9 @@ class StepChain:
         self.lbt_vec = DVec(self.lbt) if has_lb else None
         self.ubt_vec = DVec(self.ubt) if has_ub else None
         self.keep = None
+        # every chain returns with the block in here: its last workgroup publishes it
+        self.block = (ctypes.c_double * SIZE)()
+        a.host_block = ctypes.addressof(self.block)
 
     # ---- what qualifies
     @staticmethod
@@ -156,8 +159,10 @@ class StepChain:
         self.keep = (L, P, x, c, b, lb, ub, scale, x_next, v_out)
 
     def read(self):
-        """The block: ONE blocking read (a host copy the decision functions can work on)."""
-        return _block_from(dv.read_doubles(self.q, SIZE))
+        """The block of the chain that just returned (a host copy the decision functions can work
+        on): the chain's last kernel handed it over, the entry point waited for it -- ONE blocking
+        read per chain and no launch of its own."""
+        return type(self.block).from_buffer_copy(self.block)
 
     def bind_refresh(self, P, c, b, v_out):
         """Operands of ``ipx_sqp_refresh``: the Jacobian, its transpose and the solver of the
