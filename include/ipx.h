@@ -619,6 +619,16 @@ int ipx_boxschur_project(const ipx_boxschur_args *a, const double *r, double *g,
  * verdict[0] = 0 when the flags agree, else 1 (then: ipx_banded_status, and repeat the solves).
  * IPX_EUNSUPPORTED: nothing to assume on this handle. */
 int ipx_banded_status_deferred(void *handle, double *verdict, void *stream);
+/* A numeric refresh in THREE launches on a handle that qualifies for the deferred verdict
+ * (tridiagonal A A', rows in their own order): the band of A A' (wcol: column weights or NULL),
+ * the cyclic reduction's check of the matrix alone, the verdict kernel.  The chunked LDL' that the
+ * cyclic-reduction solves never read is left out; a solve that needs it runs it first, with
+ * ipx_banded_status' blocking verdict.  Returns 1: done, read `verdict` as above; 0: the handle
+ * does not qualify and NOTHING was enqueued (ipx_aat_band_w + ipx_banded_factor +
+ * ipx_banded_status); < 0: error. */
+int ipx_banded_refactor(void *handle, int64_t m, int32_t k, const int32_t *rowptr,
+                        const int32_t *colidx, const double *val, const double *wcol,
+                        double *band, double *verdict, void *stream);
 
 /* ---- one outer iteration of the trust-region SQP method as three chains of launches whose
  * decisions are taken on the device (csrc/sqp.hip; reference equality_constrained_sqp.py:102-250,

@@ -76,6 +76,8 @@ struct Banded {
   double *iter_buf;           // 4 m doubles: x (two copies), residual, correction
   double *eta;                // device: max_t || D_t^-1 [E_t,t-1  E_t,t+1] ||_inf  (block Jacobi)
   double eta_host;
+  bool chunk_pending;         // ipx_banded_refactor left the chunk factorization out (solves on
+                              // the cyclic reduction do not read it): ensure_chunks runs it
   int last_L;                 // pcr_L of the last factorization that ipx_banded_status found clean
                               // (no flag bit, decoupled, cyclic reduction usable), else 0: what
                               // ipx_banded_status_deferred assumes for the next one
@@ -570,9 +572,12 @@ constexpr int AAT_CAP = 5120;        // entries a workgroup stages (256 + k rows
 __global__ void __launch_bounds__(IPX_BLOCK)
 k_aat_band_rows(int m, int k, const int32_t *__restrict__ rowptr,
                 const int32_t *__restrict__ colidx, const double *__restrict__ val,
-                const double *__restrict__ wcol, double *__restrict__ band) {
+                const double *__restrict__ wcol, double *__restrict__ band,
+                int *__restrict__ zero = nullptr, int nzero = 0) {
   __shared__ double sval[AAT_CAP];
   __shared__ int32_t scol[AAT_CAP];
+  // (the flags of the factorization this band is made for: cleared here instead of by a memset)
+  if (blockIdx.x == 0 && (int)threadIdx.x < nzero) zero[threadIdx.x] = 0;
   const int i0 = blockIdx.x * IPX_BLOCK, i = i0 + (int)threadIdx.x;
   const int e0 = rowptr[max(i0 - k, 0)], e1 = rowptr[min(i0 + IPX_BLOCK, m)];
   const bool staged = e1 - e0 <= AAT_CAP;                  // (uniform over the workgroup)
@@ -1446,7 +1451,7 @@ k_pcr_check(int m, int rows_wg, const double *__restrict__ band, int *flags) {
   const int R = rows_wg + 2 * H;
   const int64_t g0 = (int64_t)blockIdx.x * rows_wg - H;
   const int tid = threadIdx.x;
-  double a[PCR_NR], b[PCR_NR];
+  double a[PCR_NR], b[PCR_NR], b0[PCR_NR];
   bool own[PCR_NR];
 #pragma unroll
   for (int k = 0; k < PCR_NR; ++k) {
@@ -1457,6 +1462,7 @@ k_pcr_check(int m, int rows_wg, const double *__restrict__ band, int *flags) {
     const double bv = band[gc], av = band[(int64_t)m + gc];
     a[k] = (in && g >= 1 && r >= 1) ? av : 0.0;
     b[k] = in ? bv : 1.0;
+    b0[k] = b[k];
     own[k] = in && r >= H && r < H + rows_wg;
   }
   for (int i = tid; i < 2 * PAD; i += IPX_BLOCK) {
@@ -1486,12 +1492,18 @@ k_pcr_check(int m, int rows_wg, const double *__restrict__ band, int *flags) {
       if (own[k]) {
         if (!(fabs(a[k]) <= tiny * bn)) bits |= 1;
         if (!(bn > 0.0)) bits |= 2;
+        // a reduced diagonal entry -- 1 / (S^-1)_ii in the limit, never above the pivot an
+        // elimination in any order leaves for row i -- lost 43 bits against the entry itself:
+        // whenever the chunked LDL' would raise its soft finding, this is raised too
+        if (!(bn > IPX_PIVOT_RTOL * b0[k])) bits |= 4;
       }
     }
     const bool any0 = __ballot(bits & 1) != 0, any1 = __ballot(bits & 2) != 0;
+    const bool any2 = __ballot(bits & 4) != 0;
     if ((tid & (IPX_WAVE - 1)) == 0) {
       if (any0) flags[s + 1] = 1;
       if (any1) flags[PCR_LMAX + 1 + s + 1] = 1;
+      if (any2) flags[PCR_LMAX + 1] = 1;
     }
   }
 }
@@ -2091,8 +2103,10 @@ int read_flag(Banded *h, int *f, hipStream_t st, int count = 1) {
 __global__ void k_status_verdict(const int *__restrict__ flag, const int *__restrict__ pcr_flags,
                                  int L_assumed, double *__restrict__ verdict) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  const int f = flag[0];
   const int *pf = pcr_flags, *pn = pcr_flags + (PCR_LMAX + 1);
+  // (pn[0]: the reduction's own soft finding -- with the chunk factorization deferred,
+  // ipx_banded_refactor, it stands in for flag[0]'s bits, which nobody has raised yet)
+  const int f = flag[0] | pn[0];
   int L = 0;
   for (int s = 1; s <= PCR_LMAX; ++s) {
     if (pn[s]) break;
@@ -2136,6 +2150,7 @@ void *ipx_banded_create(int64_t m64, int32_t k, int32_t chunk) {
   h->pcr_flags = nullptr;
   h->pcr_L = 0;
   h->last_L = 0;
+  h->chunk_pending = false;
   int m = (int)m64, kk = k;
   if (chunk <= 0) chunk = 64;
   bool ok = true;
@@ -2263,32 +2278,76 @@ int ipx_banded_levels(void *handle) { return handle ? ((Banded *)handle)->nlev :
 
 // band: (k+1) x m lower band storage of S, band[d*m+i] = S[i][i-d]; must stay
 // alive and unchanged until the last solve with this factorization.
+}  // extern "C"
+
+namespace {
+// how many ints the flags are: the pivot word and, right behind it, the cyclic reduction's
+// level flags (cleared together)
+int flag_ints(const Banded *h) { return h->pcr_flags ? 1 + 2 * (PCR_LMAX + 1) : 1; }
+
+int launch_pcr_check(Banded *h, hipStream_t st) {
+  // the cyclic reduction of the matrix alone: at which level has it decoupled?
+  const Level &l0 = h->lev[0];
+  hipLaunchKernelGGL(k_pcr_check, dim3((l0.P + DEC_CHUNKS - 1) / DEC_CHUNKS), dim3(IPX_BLOCK), 0,
+                     st, l0.m, DEC_CHUNKS * l0.q, l0.band, h->pcr_flags);
+  IPX_CHECK_LAUNCH();
+  return IPX_OK;
+}
+
+int chunk_tail(Banded *h, hipStream_t st);
+
+// Level 0 and the separator (Schur complement) matrix, then the separators' decoupling check
+// (or, no candidate for the decoupled solve, the upper levels): everything of a factorization
+// that the cyclic-reduction solve does not read.
+int factor_chunks(Banded *h, hipStream_t st) {
+  int rc = level_factor(h, 0, st);
+  if (rc != IPX_OK) return rc;
+  h->upper_done = false;
+  return IPX_OK;
+}
+
+// ipx_banded_refactor left the chunk factorization out: a solve that needs it (in place, no
+// ELL(2) tables for the tail, a general path) runs it now, with the blocking verdict of
+// ipx_banded_status -- the assumption the refactorization made covers the cyclic reduction only
+int ensure_chunks(Banded *h, hipStream_t st) {
+  if (!h->chunk_pending) return IPX_OK;
+  const int rc = ipx_banded_status(h, st);
+  return rc == IPX_EILLCOND ? IPX_OK : rc;
+}
+}  // namespace
+
+extern "C" {
+
 int ipx_banded_factor(void *handle, const double *band, void *stream) {
   if (!handle || !band) return IPX_EINVAL;
   Banded *h = (Banded *)handle;
   hipStream_t st = (hipStream_t)stream;
-  // (the pivot word and, right behind it, the cyclic reduction's level flags: one memset)
-  if (hipMemsetAsync(h->flag, 0, (h->pcr_flags ? 1 + 2 * (PCR_LMAX + 1) : 1) * sizeof(int), st) !=
-      hipSuccess)
+  // (one memset; a length that is not a multiple of 8 bytes is two fill launches: the buffer is
+  // allocated with a spare int)
+  if (hipMemsetAsync(h->flag, 0, (size_t)((flag_ints(h) + 1) & ~1) * sizeof(int), st) != hipSuccess)
     return IPX_ELAUNCH;
   h->lev[0].band = const_cast<double *>(band);
   h->decoupled = false;
+  h->chunk_pending = false;
   h->fast = h->fast_plan;
   // Level 0 and the separator (Schur complement) matrix first.  When the
   // decoupled path is a candidate the upper levels wait for its verdict
   // (ipx_banded_status): a decoupled solve never touches them.
-  int rc = level_factor(h, 0, st);
+  int rc = factor_chunks(h, st);
   if (rc != IPX_OK) return rc;
-  h->upper_done = false;
   h->pcr_L = 0;
   if (decoupling_candidate(h) && h->pcr_flags) {
-    // the cyclic reduction of the matrix alone: at which level has it decoupled?
-    const Level &l0 = h->lev[0];
-    hipLaunchKernelGGL(k_pcr_check, dim3((l0.P + DEC_CHUNKS - 1) / DEC_CHUNKS), dim3(IPX_BLOCK), 0,
-                       st, l0.m, DEC_CHUNKS * l0.q, band, h->pcr_flags);
-    IPX_CHECK_LAUNCH();
+    rc = launch_pcr_check(h, st);
+    if (rc != IPX_OK) return rc;
   }
   h->iter_N = 0;
+  return chunk_tail(h, st);
+}
+
+}  // extern "C"
+
+namespace {
+int chunk_tail(Banded *h, hipStream_t st) {
   if (decoupling_candidate(h)) {
     if (h->eta && hipMemsetAsync(h->eta, 0, sizeof(double), st) != hipSuccess) return IPX_ELAUNCH;
     const int mR = h->lev[0].mR, K0 = h->lev[0].k, nsep = mR / K0;
@@ -2312,12 +2371,21 @@ int ipx_banded_factor(void *handle, const double *band, void *stream) {
   }
   return factor_upper(h, st);
 }
+}  // namespace
+
+extern "C" {
 
 // Blocking read of the pivot flag: IPX_OK or IPX_ENOTSPD.
 int ipx_banded_status(void *handle, void *stream) {
   if (!handle) return IPX_EINVAL;
   Banded *h = (Banded *)handle;
   hipStream_t st = (hipStream_t)stream;
+  if (h->chunk_pending) {          // (ipx_banded_refactor left it out: now, then the verdict)
+    h->chunk_pending = false;
+    int rc = factor_chunks(h, st);
+    if (rc == IPX_OK) rc = chunk_tail(h, st);
+    if (rc != IPX_OK) return rc;
+  }
   int fl[1 + 2 * (PCR_LMAX + 1)] = {0};
   if (read_flag(h, fl, st, h->pcr_flags ? 1 + 2 * (PCR_LMAX + 1) : 1) != IPX_OK) return IPX_ELAUNCH;
   int f = fl[0];
@@ -2385,6 +2453,48 @@ int ipx_banded_status_deferred(void *handle, double *verdict, void *stream) {
 
 // 1 when solves skip the middle kernel (separator system diagonal to working
 // precision); valid after ipx_banded_status.
+// A numeric refresh on a handle whose previous factorization was clean and runs the cyclic-
+// reduction solve, in THREE launches: the band of A A' (rows in their own order; the kernel also
+// clears the flags), the reduction's check of the matrix alone -- decoupling level, positive
+// reduced diagonal, no entry of it below 2^-43 of the diagonal entry --, and the verdict kernel
+// of ipx_banded_status_deferred.  The chunked LDL' of level 0, the separator matrix and their
+// decoupling check (three more launches, half the refresh's GPU time) are left out: the
+// cyclic-reduction solves read the band only.  A solve that does need them -- in place, a tail
+// without ELL(2) tables, any path once the verdict was bad -- runs them first, with the blocking
+// verdict (ensure_chunks).  Returns 1 when it took this form (the caller reads `verdict` with
+// whatever it reads next and, on a 1 there, calls ipx_banded_status and repeats its solves);
+// 0: the handle does not qualify, nothing was enqueued -- ipx_aat_band_w + ipx_banded_factor +
+// ipx_banded_status as before.
+int ipx_banded_refactor(void *handle, int64_t m, int32_t k, const int32_t *rowptr,
+                        const int32_t *colidx, const double *val, const double *wcol,
+                        double *band, double *verdict, void *stream) {
+  if (!handle || !rowptr || !colidx || !val || !band || !verdict) return IPX_EINVAL;
+  Banded *h = (Banded *)handle;
+  hipStream_t st = (hipStream_t)stream;
+  const Level &l0 = h->lev[0];
+  if (h->last_L <= 0 || !h->pcr_flags || !h->fast_plan || l0.k != 1 || k != 1 || l0.m != m ||
+      flag_ints(h) > IPX_BLOCK)
+    return 0;
+  h->fast = h->fast_plan;
+  if (!decoupling_candidate(h)) return 0;
+  hipLaunchKernelGGL(k_aat_band_rows, dim3((unsigned)((m + IPX_BLOCK - 1) / IPX_BLOCK)),
+                     dim3(IPX_BLOCK), 0, st, (int)m, k, rowptr, colidx, val, wcol, band, h->flag,
+                     flag_ints(h));
+  IPX_CHECK_LAUNCH();
+  h->lev[0].band = band;
+  h->upper_done = false;
+  h->iter_N = 0;
+  int rc = launch_pcr_check(h, st);
+  if (rc != IPX_OK) return rc;
+  hipLaunchKernelGGL(k_status_verdict, dim3(1), dim3(IPX_WAVE), 0, st, h->flag, h->pcr_flags,
+                     h->last_L, verdict);
+  IPX_CHECK_LAUNCH();
+  h->decoupled = true;
+  h->pcr_L = h->last_L;
+  h->chunk_pending = true;
+  return 1;
+}
+
 int ipx_banded_decoupled(void *handle) { return handle && ((Banded *)handle)->decoupled; }
 
 int ipx_banded_set_decoupling(void *handle, int allow) {
@@ -2584,10 +2694,17 @@ int fast_solve(Banded *h, const double *w, double *x, double *partial, int *npar
     if (rc != IPX_OK || !partial) return rc;
     return ipx_banded_residual_launch(h, w, x, partial, npartial, guard, st);
   }
+  if (h->decoupled && w != x && h->pcr_L > 0 && h->lev[0].k == 1)
+    // tridiagonal: parallel cyclic reduction (reads the band only)
+    return launch_solve_pcr(to_dev(h->lev[0], nullptr), h->pcr_L, w, x, partial, npartial, guard,
+                            st);
+  if (h->chunk_pending) {
+    const int rc = ensure_chunks(h, st);
+    if (rc != IPX_OK) return rc;
+    return fast_solve(h, w, x, partial, npartial, guard, st);     // (by the verdict just read)
+  }
   if (h->decoupled && w != x) {
     const LevDev lv = to_dev(h->lev[0], nullptr);
-    if (h->pcr_L > 0 && lv.k == 1)          // tridiagonal: parallel cyclic reduction
-      return launch_solve_pcr(lv, h->pcr_L, w, x, partial, npartial, guard, st);
     switch (lv.k) {
 #define SD(kk) case kk: return launch_solve_decoupled<kk>(lv, w, x, h->rinv, partial, npartial, guard, st)
       SD(1); SD(2); SD(3); SD(4); SD(5); SD(6); SD(7); SD(8);
@@ -2666,6 +2783,11 @@ int ipx_banded_solve_resid_atv_launch(void *handle, const double *w, double *x, 
   if (h->pcr_L > 0 && ell_row && ell_val)
     return launch_solve_pcr(to_dev(h->lev[0], nullptr), h->pcr_L, w, x, partial, npartial, guard,
                             st, &job, qv);
+  if (h->chunk_pending) {
+    const int rc = ensure_chunks(h, st);
+    if (rc != IPX_OK) return rc;
+    if (!ipx_banded_decoupled_geometry(handle, geo)) return IPX_EINVAL;
+  }
   const LevDev lv = to_dev(h->lev[0], nullptr);
   switch (lv.k) {
     case 1: return launch_solve_decoupled<1>(lv, w, x, h->rinv, partial, npartial, guard, st, &job, qv);
@@ -2824,6 +2946,10 @@ extern "C" int ipx_banded_solve_multilaunch(void *handle, const double *w, doubl
                                             void *stream) {
   if (!handle || !w || !x) return IPX_EINVAL;
   Banded *h = (Banded *)handle;
+  if (h->chunk_pending) {
+    const int rc = ensure_chunks(h, (hipStream_t)stream);
+    if (rc != IPX_OK) return rc;
+  }
   const bool keep = h->fast;
   h->fast = false;
   int rc = ipx_banded_solve_guarded(handle, w, x, nullptr, (hipStream_t)stream);

@@ -1957,7 +1957,8 @@ int ipx_cg_prime(const ipx_cg_args *a, const int32_t *A_tiles, int32_t A_ntiles,
                  double orth_tol, double norm_A, double cancellation, int32_t first_end,
                  int32_t steps, void *stream) {
   return ipx_cg_prime_dev(a, A_tiles, A_ntiles, c, b, red, ws, tol_in, radius, nullptr, orth_tol,
-                          norm_A, nullptr, cancellation, first_end, steps, (hipStream_t)stream);
+                          norm_A, nullptr, cancellation, first_end, steps, nullptr, 0, 0,
+                          (hipStream_t)stream);
 }
 
 }  // extern "C"
@@ -1966,7 +1967,8 @@ int ipx_cg_prime_dev(const ipx_cg_args *a, const int32_t *A_tiles, int32_t A_nti
                      const double *c, const double *b, double *red, double *ws, double tol_in,
                      double radius, const double *radius_dev, double orth_tol, double norm_A,
                      const double *norm_A2_dev, double cancellation, int32_t first_end,
-                     int steps, hipStream_t stream) {
+                     int steps, const double *c_part, int32_t c_npart, int x_is_zero,
+                     hipStream_t stream) {
   if (!a || !c || !red || !ws || !A_tiles || a->solver_kind > 1 || a->m <= 0 || a->H_operator ||
       !a->H_rowptr || !a->t || first_end < 0)
     return IPX_EINVAL;
@@ -1994,7 +1996,8 @@ int ipx_cg_prime_dev(const ipx_cg_args *a, const int32_t *A_tiles, int32_t A_nti
     rc = R.spmv(Hm, a->x, 1.0, a->H_diag, 1.0, c, a->Hp, 4, st);
     if (rc) return rc;
     t = a->Hp;
-  } else if (hipMemsetAsync(a->x, 0, (size_t)a->n * sizeof(double), st) != hipSuccess) {
+  } else if (!x_is_zero &&
+             hipMemsetAsync(a->x, 0, (size_t)a->n * sizeof(double), st) != hipSuccess) {
     return IPX_ELAUNCH;
   }
   const double canc2 = cancellation * cancellation;
@@ -2002,7 +2005,12 @@ int ipx_cg_prime_dev(const ipx_cg_args *a, const int32_t *A_tiles, int32_t A_nti
   if (b || !steps) {
     // (b: ||t||^2 = red[4] comes out of the H x0 + c product's partials, folded by the state
     // kernel: the first projection's decision would need it earlier -- no step on this path)
-    rc = prime_project_any(a, A, At, t, a->r, R, 0, b != nullptr, 1.0, st);
+    const bool c_known = !b && c_part && c_npart > 0;
+    if (c_known) {                 // (||c||^2 -> red[4]: folded by the state kernel)
+      PrimeFolds &f = R.f;
+      f.part[f.n] = c_part; f.count[f.n] = c_npart; f.slot[f.n] = 4; f.single[f.n] = 0; ++f.n;
+    }
+    rc = prime_project_any(a, A, At, t, a->r, R, 0, b != nullptr || c_known, 1.0, st);
     if (rc) return rc;
     rc = prime_project_any(a, A, At, a->r, a->p, R, 6, true, -1.0, st);
     if (rc) return rc;

@@ -618,12 +618,16 @@ int ipx_cg_shard2_resident_launch(const ipx_cg_args *a, const ipx_shard2_ext *e,
 // execution time (radius_dev / norm_A2_dev non-NULL override the by-value arguments); steps != 0
 // (b == NULL only): each projection may take one correction step on the device (k_prime_decide)
 // -- eight more launches, no-ops when no step is due; steps == 0: a projection that needs one
-// ends the priming with stop code 9 (the host's)
+// ends the priming with stop code 9 (the host's).  c_part (b == NULL, steps == 0): the 2 x
+// c_npart epilogue partials of the product that formed c (||c||^2 without a norm launch, as
+// the b != NULL path takes it from its own H x0 + c product); x_is_zero: the caller cleared
+// a->x (no memset launch).
 int ipx_cg_prime_dev(const ipx_cg_args *a, const int32_t *A_tiles, int32_t A_ntiles,
                      const double *c, const double *b, double *red, double *ws, double tol_in,
                      double radius, const double *radius_dev, double orth_tol, double norm_A,
                      const double *norm_A2_dev, double cancellation, int32_t first_end,
-                     int steps, hipStream_t stream);
+                     int steps, const double *c_part, int32_t c_npart, int x_is_zero,
+                     hipStream_t stream);
 
 // ---- internal (non-ABI) launchers shared between translation units --------
 struct ipx_csr_view {

@@ -261,12 +261,14 @@ __device__ __forceinline__ void sq_after_newton(double nn2, double nviol, double
 __global__ void __launch_bounds__(RB)
 k_sq_newton_check(int64_t n, const double *__restrict__ v, const double *__restrict__ lb,
                   const double *__restrict__ ub, double f, sq_u4 *gran, SqSync sync, int boxed,
-                  double radius, double tr_factor, double *__restrict__ q) {
+                  double radius, double tr_factor, double *__restrict__ q,
+                  double *__restrict__ zero_out) {
   __shared__ double lds[RB / IPX_WAVE];
   double cnt = 0.0, s = 0.0;
   const int64_t stride = (int64_t)gridDim.x * RB;
   for (int64_t i = (int64_t)blockIdx.x * RB + threadIdx.x; i < n; i += stride) {
     const double t = v[i];
+    zero_out[i] = 0.0;          // (the CG's start x0 = 0: one pass over n less than a memset)
     s += t * t;
     if (lb || ub) {
       const double lo = lb ? f * lb[i] : -HUGE_VAL, hi = ub ? f * ub[i] : HUGE_VAL;
@@ -721,7 +723,8 @@ __global__ void __launch_bounds__(RB)
 k_sq_measure_norms(int64_t n1, const double *__restrict__ v1, int g1, int64_t n2,
                    const double *__restrict__ v2, int g2, sq_u4 *gran, SqSync sync,
                    const double *__restrict__ p_A, int g_A, const double *__restrict__ verdict,
-                   double *q, SqPub pub) {
+                   double *q, SqPub pub, const double *__restrict__ neg_in,
+                   double *__restrict__ neg_out) {
   __shared__ double lds[RB / IPX_WAVE];
   const bool second = (int)blockIdx.x >= g1;
   const int b = second ? blockIdx.x - g1 : blockIdx.x, G = second ? g2 : g1;
@@ -733,6 +736,7 @@ k_sq_measure_norms(int64_t n1, const double *__restrict__ v1, int g1, int64_t n2
     const double t = v[i];
     s += t * t;
     mx = fmax(mx, fabs(t));
+    if (second) neg_out[i] = -neg_in[i];       // (the multipliers v = -(A A')^-1 A c: same length)
   }
   const double a = ipx_block_reduce<IPX_SUM>(s, lds);
   const double c = ipx_block_reduce<IPX_MAX>(mx, lds);
@@ -780,7 +784,8 @@ int ipx_sqp_block_size(void) { return SQ_SIZE; }
 int64_t ipx_sqp_part_doubles(const ipx_sqp_args *s) {
   if (!s || !s->cg) return -1;
   const int64_t g = sq_grid(s->n), gm = sq_grid(s->m);
-  return 4 * g + 6 * g + g + gm + 2 * g + 2 * gm + g + 18 * g + 64 + 2 + 2 * (6 * g + 2 * gm);
+  return 4 * g + 6 * g + g + gm + 2 * g + 2 * gm + g + 18 * g + 64 + 2 + 2 * (6 * g + 2 * gm) +
+         2 * (int64_t)s->cg->H_ntiles;
 }
 
 /* on != 0: start collecting; on == 0: stop, synchronise, *ms_total = GPU milliseconds between the
@@ -825,6 +830,7 @@ struct PartLayout {
   double *vec, *exit, *hd, *ad, *viol, *bn, *tn, *dog, *tail;
   sq_u4 *gran;                // tagged partials of the kernels that end in their own decision:
   int g, gm;                  // 6 g + 2 gm granules, one launch's at a time (allocated zeroed)
+  double *ctn;                // epilogue partials of c_t = H dn + c (2 x H's tiles): ||c_t||^2
 };
 // the tag of one launch: its sequence number (never 0: the arena's initial state)
 static unsigned int next_tag() {
@@ -862,6 +868,8 @@ static PartLayout layout(const ipx_sqp_args *s) {
   p += 64;
   p += ((p - s->part) & 1);                 // (granules are 16 bytes)
   L.gran = (sq_u4 *)p;
+  p += 2 * (6 * (int64_t)L.g + 2 * (int64_t)L.gm);
+  L.ctn = p;
   return L;
 }
 
@@ -943,7 +951,7 @@ int ipx_sqp_front(const ipx_sqp_args *s, int have_dn, int with_dogleg, int with_
     const bool boxed = s->lb || s->ub;
     hipLaunchKernelGGL(k_sq_newton_check, dim3(L.g), dim3(RB), 0, st, s->n, s->dn, s->lb, s->ub,
                        box_factor, L.gran, SqSync{next_tag()}, boxed ? 1 : 0,
-                       radius, tr_factor, s->q);
+                       radius, tr_factor, s->q, a->x);
     IPX_CHECK_LAUNCH();
     if (with_dogleg) {
       // the dogleg proper behind it, every launch a no-op when the Newton point stands (the
@@ -990,7 +998,7 @@ int ipx_sqp_front(const ipx_sqp_args *s, int have_dn, int with_dogleg, int with_
     IPX_CHECK_LAUNCH();
   }
   // c_t = H dn + c   (:125)
-  rc = ipx_spmv_launch(Hm, s->dn, 1.0, a->H_diag, 1.0, s->c, s->ct, nullptr, nullptr, st);
+  rc = ipx_spmv_launch(Hm, s->dn, 1.0, a->H_diag, 1.0, s->c, s->ct, L.ctn, nullptr, st);
   if (rc) return rc;
   if (s->lb || s->ub) {
     hipLaunchKernelGGL(k_sq_shift_bounds, dim3(L.g), dim3(RB), 0, st, s->n, s->lb, s->ub, s->dn,
@@ -1002,7 +1010,7 @@ int ipx_sqp_front(const ipx_sqp_args *s, int have_dn, int with_dogleg, int with_
     (void)hipEventRecord(e0, st);
   rc = ipx_cg_prime_dev(a, s->A_tiles, (int32_t)s->A_ntiles, s->ct, nullptr, s->red, s->ws, tol_in,
                         0.0, s->q + SQ_RADIUS_T, s->orth_tol, norm_A, nullptr, s->cancellation,
-                        first_end, with_steps, st);
+                        first_end, with_steps, L.ctn, (int32_t)a->H_ntiles, have_dn ? 0 : 1, st);
   if (e0 && e1) {
     (void)hipEventRecord(e1, st);
     g_cg_timing.ev.emplace_back(e0, e1);
@@ -1049,15 +1057,14 @@ int ipx_sqp_refresh(const ipx_sqp_args *s, void *stream) {
   // bit, so the product runs on (A A')^-1 A c itself with alpha = -1
   rc = ipx_spmv_launch(At, a->v, -1.0, nullptr, 1.0, s->c, s->ct, nullptr, nullptr, st);
   if (rc) return rc;
-  rc = ipx_axpby(s->m, -1.0, a->v, 0.0, nullptr, s->v_out, stream);
-  if (rc) return rc;
   BlockRead br;
   rc = br.begin(s);
   if (rc) return rc;
   hipLaunchKernelGGL(k_sq_measure_norms, dim3(L.g + L.gm), dim3(RB), 0, st, s->n, s->ct, L.g,
                      s->m, s->b, L.gm, L.gran, SqSync{next_tag()},
                      s->A_norm_part,
-                     s->A_norm_part ? (int)s->A_norm_grid : 0, s->verdict, s->q, br.pub);
+                     s->A_norm_part ? (int)s->A_norm_grid : 0, s->verdict, s->q, br.pub, a->v,
+                     s->v_out);
   IPX_CHECK_LAUNCH();
   return br.wait(st);
 }

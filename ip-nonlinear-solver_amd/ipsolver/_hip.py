@@ -112,6 +112,7 @@ _SIGNATURES = {
     "ipx_boxschur_project": [_P, _P, _P, _P, _P, _P, _P, _P, _P],
     "ipx_boxschur_project_count": [_P],
     "ipx_banded_status_deferred": [_P, _P, _P],
+    "ipx_banded_refactor": [_P, _I64, _I32, _P, _P, _P, _P, _P, _P, _P],
     "ipx_sqp_block_size": [],
     "ipx_sqp_front": [_P, _c.c_int, _c.c_int, _c.c_int, _F64, _F64, _F64, _F64, _F64, _F64, _F64,
                       _F64, _I32, _P],

@@ -153,10 +153,22 @@ class BandedNormalSolver:
             if not self.handle:
                 raise _hip.IpxError("ipx_banded_create failed (m=%d, k=%d)" % (self.m, self.k))
         p = A.pattern
+        self.pending, self.ill_conditioned = False, False
+        if deferred is not None and self.perm is None and self.k == 1:
+            # the whole refresh behind one entry and in three launches where the handle
+            # qualifies (csrc/banded.hip ipx_banded_refactor); 0: it does not, nothing enqueued
+            rc = lib.ipx_banded_refactor(ctypes.c_void_p(self.handle), self.m, self.k,
+                                         _p(p.indptr), _p(p.indices), _p(A.val), _p(col_weights),
+                                         _p(self.band), deferred.verdict.data_ptr(), stream_ptr())
+            if rc < 0:
+                _hip.check(rc, "ipx_banded_refactor")
+            if rc == 1:
+                self.pending, self._verdict = True, deferred.verdict
+                HANDLE_STATS["deferred"] += 1
+                return
         _hip.call("ipx_aat_band_w", self.m, self.k, _p(p.indptr), _p(p.indices), _p(A.val),
                   _p(self.perm), _p(col_weights), _p(self.band), stream_ptr())
         _hip.call("ipx_banded_factor", ctypes.c_void_p(self.handle), _p(self.band), stream_ptr())
-        self.pending, self.ill_conditioned = False, False
         if deferred is not None and lib.ipx_banded_status_deferred(
                 ctypes.c_void_p(self.handle), deferred.verdict.data_ptr(), stream_ptr()) == 0:
             self.pending, self._verdict = True, deferred.verdict
