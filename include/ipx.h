@@ -661,7 +661,11 @@ typedef struct ipx_sqp_args {
   double *host_block;               /* HOST memory, ipx_sqp_block_size() doubles, or NULL.  Non-NULL:
                                      * ipx_sqp_front / _model / _judge / _refresh return when the
                                      * block has arrived there -- the workgroup that completes the
-                                     * block publishes it (no read-back launch behind the chain) */
+                                     * block publishes it (no read-back launch behind the chain).
+                                     * NULL: the entry returns behind its last launch; the block
+                                     * stays in q -- a later chain's block carries all of it (the
+                                     * caller enqueues the user's callbacks and ipx_sqp_judge
+                                     * behind ipx_sqp_front and reads once) */
 } ipx_sqp_args;
 int ipx_sqp_block_size(void);
 int64_t ipx_sqp_part_doubles(const ipx_sqp_args *s);

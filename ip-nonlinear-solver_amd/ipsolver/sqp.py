@@ -52,7 +52,10 @@ class _Point:
 
 
 class _Trial:
-    __slots__ = ("x_next", "d", "cg_info", "on_chain")
+    __slots__ = ("x_next", "d", "cg_info", "on_chain", "finish", "q")
+
+    def __init__(self):
+        self.finish = self.q = None
 
 
 class _Box:
@@ -133,6 +136,12 @@ class HostStages:
         if not q[SOC]:
             sc.radius_host(q)
         return q
+
+
+# ChainStages.propose returns with its chain still running and the caller evaluates the callbacks
+# at the trial point behind it (False: the block is waited for first -- A/B measurements, and
+# the order in which the reference shows its callbacks the points, exactly)
+EVALUATE_BEHIND_THE_CHAIN = True
 
 
 class ChainStages:
@@ -228,8 +237,49 @@ class ChainStages:
                                                            self.BATCH_MAX)))
         # (the dogleg proper rides along when the last normal step needed it: nine launches that
         # do nothing otherwise)
-        chain.front(0, chain.expect_dogleg, radius, penalty, pt.f, pt.norm_b, P.norm_A, first_end)
-        q = chain.read()
+        t = _Trial()
+        t.x_next, t.d, t.on_chain = DVec(x_next), DVec(chain.d), True
+        finish = lambda q: self._finish(q, t, pt, H, radius, penalty, L, key, P, scale, first_end,
+                                        max_iter)
+        if not EVALUATE_BEHIND_THE_CHAIN:
+            chain.front(0, chain.expect_dogleg, radius, penalty, pt.f, pt.norm_b, P.norm_A,
+                        first_end)
+            q, _ = finish(chain.read())
+            return q, t
+        # The chain is enqueued and NOT waited for, its block stays on the device: the caller
+        # evaluates the user's objective and constraints at the trial point right behind it,
+        # ``judge`` enqueues the verdict behind those -- the host's call overhead for all of it
+        # runs while the chain's ~300 us execute -- and reads ONE block that carries the
+        # chain's entries with the verdict's.  In the usual case the block says the step stood
+        # and the verdict is the one the method needs; a step the host has to finish (the dogleg
+        # proper, a longer CG, a box event, a refinement) lands in a NEW trial vector and
+        # evaluation and verdict are repeated there -- the provisional evaluation is not
+        # counted; the callbacks saw a point the reference would not have shown them.
+        chain.front(0, chain.expect_dogleg, radius, penalty, pt.f, pt.norm_b, P.norm_A, first_end,
+                    quiet=True)
+        t.finish = finish
+        return None, t
+
+    def _finish(self, q, t, pt, H, radius, penalty, L, key, P, scale, first_end, max_iter):
+        """The rest of ``propose`` once a block with the chain's entries (``q``) is in:
+        (block, redo) -- redo: the step was finished by the host into a new ``t.x_next``;
+        callbacks and verdict are due there."""
+        import torch
+        from . import _hip, cg_fused
+        from .device import DVec, stream_ptr
+        chain, box, n, m = self.chain, self.box, self.n, self.m
+        lib = _hip.load()
+        redo = [False]
+
+        def fresh():
+            # (the provisional evaluation is remembered by OBJECT, barrier.py's memo and the
+            # callbacks' own: a step written again gets a tensor nobody has seen)
+            x_new = torch.empty(n, dtype=torch.float64, device=pt.x.t.device)
+            chain.bind(L, P, pt.x, pt.c, pt.b, box.lb, box.ub, scale, x_new)
+            t.x_next = DVec(x_new)
+            redo[0] = True
+            return x_new
+        x_next = t.x_next.t
         chain.expect_dogleg = q[sc.NORMAL_KIND] != 1
         if q[sc.NORMAL_KIND] == 0:
             # the Newton point leaves the box or the 0.8-radius ball: the dogleg proper, then the
@@ -238,6 +288,7 @@ class ChainStages:
             dn = self.xp.modified_dogleg(pt.A, pt.Y, pt.b, TR_FACTOR * radius, box.half_lb,
                                          box.half_ub)
             chain.dn.copy_(dn.t)
+            x_next = fresh()
             chain.front(1, 0, radius, penalty, pt.f, pt.norm_b, P.norm_A, first_end)
             q = chain.read()
         P.stats["solves"] += 3
@@ -248,6 +299,7 @@ class ChainStages:
             # more on the device with the steps (the normal step stands: chain.dn)
             sc.STATS["prime_rearmed"] = sc.STATS.get("prime_rearmed", 0) + 1
             chain.expect_steps = True
+            x_next = fresh()
             chain.front(1, 0, radius, penalty, pt.f, pt.norm_b, P.norm_A, first_end)
             q = chain.read()
             st = q[sc.CG:sc.CG + 16]
@@ -305,7 +357,10 @@ class ChainStages:
                                               first_batch=first_end)
             TIMERS["host_cg_seconds"] += time.perf_counter() - t_host
             L.args.x = dt.t.data_ptr()
-            chain.bind(L, P, pt.x, pt.c, pt.b, box.lb, box.ub, scale, x_next)
+            x_next = fresh()
+            # (a verdict enqueued behind the chain before this block was looked at has moved the
+            # block's trust radius along its ladder: the one this step was computed for)
+            chain.q[RADIUS:RADIUS + 1].fill_(radius)
             chain.model(penalty, pt.f, pt.norm_b, host_cg=True)
             q = chain.read()
             chain.keep = chain.keep + (dt,)
@@ -319,12 +374,14 @@ class ChainStages:
                 st[cg_fused.ST_MARGIN] < 64.0 * P.CANCELLATION ** 2
         chain.last_niter = (chain.last_niter[1], info['niter'])
         self.xp.note_cg_length(info['niter'])
-        t = _Trial()
-        t.x_next, t.d, t.cg_info, t.on_chain = DVec(x_next), DVec(chain.d), info, True
-        return q, t
+        t.cg_info = info
+        return q, redo[0]
 
     # -- judge
     def judge(self, q, trial, f_next, b_next):
+        """The verdict's block -- or None: the proposing chain, examined only now, had left its
+        step to the host; ``trial`` holds the finished step (``trial.q`` its block): evaluate
+        the callbacks at the new ``trial.x_next`` and call again."""
         if not trial.on_chain:
             return self.host.judge(q, trial, f_next, b_next)
         # (an objective value still on the device goes to the verdict's kernel as it is and
@@ -332,6 +389,12 @@ class ChainStages:
         lazy = hasattr(f_next, "known") and not f_next.is_known
         self.chain.judge(b_next, f_next.t if lazy else float(f_next))
         q = self.chain.read()
+        finish, trial.finish = trial.finish, None
+        if finish is not None:
+            front_q, redo = finish(q)
+            if redo:
+                trial.q = front_q
+                return None
         if lazy:
             f_next.known(q[F_NEXT])
         return q
@@ -406,6 +469,10 @@ def equality_constrained_sqp(fun_and_constr, grad_and_jac, lagr_hess, x0, fun0, 
         state.nfev += 1
         state.ncev += 1
         q = stages.judge(q, trial, f_next, b_next)
+        if q is None:
+            # (the proposing chain had left its step to the host: ChainStages.propose)
+            f_next, b_next = fun_and_constr(trial.x_next)
+            q = stages.judge(trial.q, trial, f_next, b_next)
         if q[SOC]:
             f_next, b_next = _second_order_correction(xp, box, pt, trial, q, f_next, b_next,
                                                       fun_and_constr, state)

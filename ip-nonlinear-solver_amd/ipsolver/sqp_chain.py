@@ -201,13 +201,23 @@ class StepChain:
         a.part = self.part.data_ptr()
         self.keep = (P, A, At, c, b, v_out)
 
-    def front(self, have_dn, with_dogleg, radius, penalty, f, norm_b, norm_A, first_end):
+    def front(self, have_dn, with_dogleg, radius, penalty, f, norm_b, norm_A, first_end,
+              quiet=False):
+        """``quiet``: return behind the chain's last launch, the block stays on the device --
+        the next chain's block carries all of it (the caller enqueues the callbacks at the
+        trial point and the verdict behind this one and reads once)."""
         a = self.args
+        keep = a.host_block
+        if quiet:
+            a.host_block = None
         # (||A||_F is the host's by now -- the refresh's read brought it: by value)
-        _hip.call("ipx_sqp_front", ctypes.byref(a), int(have_dn), int(with_dogleg),
-                  int(self.expect_steps), float(radius), float(penalty),
-                  float(f), float(norm_b), TR_FACTOR, BOX_FACTOR, float("nan"), float(norm_A),
-                  int(first_end), stream_ptr())
+        try:
+            _hip.call("ipx_sqp_front", ctypes.byref(a), int(have_dn), int(with_dogleg),
+                      int(self.expect_steps), float(radius), float(penalty),
+                      float(f), float(norm_b), TR_FACTOR, BOX_FACTOR, float("nan"), float(norm_A),
+                      int(first_end), stream_ptr())
+        finally:
+            a.host_block = keep
         STATS["fronts"] += 1
 
     def model(self, penalty, f, norm_b, host_cg):

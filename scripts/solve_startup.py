@@ -43,8 +43,16 @@ W = [wrap(dm.DeviceCanonical, "__init__", "DeviceCanonical"),
      wrap(dm, "lagrangian_hessian"),
      wrap(minimize, "tr_interior_point"),
      wrap(barrier, "equality_constrained_sqp") if hasattr(barrier, "equality_constrained_sqp") else None,
-     wrap(sqp.ChainStages, "settle", limit=2), wrap(sqp.ChainStages, "propose", limit=1),
+     wrap(sqp.ChainStages, "settle", limit=2), wrap(sqp.ChainStages, "propose", limit=2),
      wrap(projector, "projections", limit=2)]
+from ipsolver import sqp_chain, cg_fused
+W += [wrap(sqp_chain.StepChain, "front", "chain.front", limit=2),
+      wrap(sqp_chain.StepChain, "bind", "chain.bind", limit=2),
+      wrap(sqp_chain.StepChain, "judge", "chain.judge", limit=2),
+      wrap(sqp_chain.StepChain, "refresh", "chain.refresh", limit=2),
+      wrap(sqp_chain.StepChain, "bind_refresh", "chain.bind_refresh", limit=2),
+      wrap(cg_fused, "_loop_for", limit=2), wrap(cg_fused, "_release", limit=2),
+      wrap(sqp.ChainStages, "judge", "stage.judge", limit=2)]
 for name in ("fun", "grad", "hess", "constr_fun", "constr_jac", "constr_hess"):
     W.append(wrap(dc, name, "user." + name, limit=2))
 
@@ -69,3 +77,4 @@ res, dt = solve()
 print("solve %.2f ms, %d outer / %d CG" % (1e3 * dt, res.niter, res.cg_niter))
 for t, name in LOG:
     print("%9.1f us  %s" % (t, name))
+print({k: v for k, v in sqp_chain.STATS.items() if v})
