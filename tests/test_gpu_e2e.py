@@ -1024,3 +1024,90 @@ def test_step_chain_and_host_stages_agree_bit_for_bit(case, monkeypatch):
     v1 = r1.v.cpu().numpy() if hasattr(r1.v, "cpu") else np.asarray(r1.v)
     v2 = r2.v.cpu().numpy() if hasattr(r2.v, "cpu") else np.asarray(r2.v)
     assert np.array_equal(v1, v2)
+
+
+@pytest.mark.parametrize("case", ["lean_n20000", "ineq_box_n400"])
+def test_callbacks_behind_the_chain_same_solve_and_provisional_points_not_counted(case, monkeypatch):
+    """``sqp.EVALUATE_BEHIND_THE_CHAIN``: the objective / constraints at the trial point and
+    the step's verdict are enqueued behind the proposing chain and ONE block is read for both
+    (two blocking reads per outer iteration instead of three).  A step the host has to finish
+    lands in a new trial vector and is evaluated again.  Same trace rows, x, v and evaluation
+    counts as the form that waits for the chain first; the user's callback is CALLED more often
+    than ``nfev`` says exactly by the number of steps that were finished by the host."""
+    syn = load_synthetic()
+    from ipsolver import sqp, sqp_chain
+    if case == "lean_n20000":
+        from ipsolver.synthetic import LeanDeviceCallbacks
+        prob = syn.CenteredBandedNLP(20000, 2000, eps=1e-3)
+        dc = LeanDeviceCallbacks(prob)
+        calls = {"fun": 0}
+
+        def fun(x):
+            calls["fun"] += 1
+            return dc.fun(x)
+        make = lambda: (fun, dc.x0, dc.grad, dc.hess, dc.constraints(ipsolver))
+        kw = dict(method="tr_interior_point")
+    else:
+        prob = syn.CenteredBandedNLP(400, 40, eps=1.0)
+        calls = {"fun": 0}
+
+        def fun(x):
+            calls["fun"] += 1
+            return prob.fun(x)
+        make = lambda: (fun, prob.x0, prob.grad, prob.hess,
+                        (prob.constraints(ipsolver, ("less", 0.0)),
+                         ipsolver.BoxConstraint(("interval", -0.8, 0.8))))
+        kw = {}
+    outs = []
+    for behind in (True, False):
+        monkeypatch.setattr(sqp, "EVALUATE_BEHIND_THE_CHAIN", behind)
+        calls["fun"] = 0
+        host_cg, doglegs = sqp_chain.STATS["host_cg"], sqp_chain.STATS["host_doglegs"]
+        rearmed = sqp_chain.STATS.get("prime_rearmed", 0)
+        res, rows = run(*make(), **kw)
+        redone = (sqp_chain.STATS["host_cg"] - host_cg + sqp_chain.STATS["host_doglegs"] - doglegs
+                  + sqp_chain.STATS.get("prime_rearmed", 0) - rearmed)
+        outs.append((res, rows, calls["fun"], redone))
+    (r1, rows1, c1, redo1), (r2, rows2, c2, redo2) = outs
+    assert r1.status == r2.status and r1.niter == r2.niter and r1.cg_niter == r2.cg_niter
+    assert r1.nfev == r2.nfev
+    assert np.array_equal(np.array(rows1), np.array(rows2), equal_nan=True)
+    as_np = lambda t: t.cpu().numpy() if hasattr(t, "cpu") else np.asarray(t)
+    assert np.array_equal(as_np(r1.x), as_np(r2.x)) and np.array_equal(as_np(r1.v), as_np(r2.v))
+    # waiting first shows the callbacks exactly the points the method evaluates; behind the
+    # chain, one provisional point per step the host finished (at most: a step can need the
+    # host twice) on top of them
+    assert c2 <= c1 <= c2 + redo1
+
+
+def test_objective_may_stay_on_the_device_until_the_verdict():
+    """``fun`` returning a ``device.DeviceScalar`` (``ScalarPack.combine``: the weighted sum of
+    folded reductions by one kernel, ipx_fold_combine) or a 0-d CUDA tensor instead of a float:
+    the step's verdict consumes it on the device; same solve bit for bit as the float, which is
+    the same expression evaluated on the host over the values read."""
+    import torch
+    syn = load_synthetic()
+    from ipsolver.synthetic import LeanDeviceCallbacks
+    prob = syn.CenteredBandedNLP(20000, 2000, eps=1e-3)
+    dc = LeanDeviceCallbacks(prob)
+    from ipsolver.device import DVec, ScalarPack, DeviceScalar
+
+    def fun_float(x):
+        dl, qd, d2 = dc._point(x)
+        pk = ScalarPack()
+        h = (pk.dot(DVec(dl), DVec(qd)), pk.dot(DVec(dc.q), DVec(dl)), pk.dot(DVec(d2), DVec(d2)))
+        v = pk.read()
+        return 0.5 * v[h[0]] - prob.eps * v[h[1]] + 0.25 * prob.rho * v[h[2]]
+
+    def fun_tensor(x):
+        return float(dc.fun(x)) * torch.ones((), dtype=torch.float64, device=x.device)
+    x0 = dc.x0
+    f_dev = dc.fun(x0)
+    assert isinstance(f_dev, DeviceScalar) and not f_dev.is_known
+    assert float(f_dev) == fun_float(x0)
+    outs = [run(f, dc.x0, dc.grad, dc.hess, dc.constraints(ipsolver), method="tr_interior_point")
+            for f in (dc.fun, fun_float, fun_tensor)]
+    for res, rows in outs[1:]:
+        assert np.array_equal(np.array(rows), np.array(outs[0][1]), equal_nan=True)
+        assert np.array_equal(res.x.cpu().numpy(), outs[0][0].x.cpu().numpy())
+    assert isinstance(outs[0][0].fun, float)

@@ -2028,3 +2028,60 @@ def test_box_schur_tail_is_refused_when_its_workgroups_outnumber_the_partials(ip
     assert (info["stop_cond"], info["hits_boundary"], info["niter"]) == \
         (io["stop_cond"], io["hits_boundary"], io["niter"])
     close(x, xo, 1e-10)
+
+
+def test_banded_refresh_in_three_launches_and_the_chunk_factorization_on_demand():
+    """``ipx_banded_refactor``: on a handle whose last verdict was clean and that runs the
+    cyclic-reduction solve, a numeric refresh is the band, the reduction's own check and the
+    verdict kernel; the chunked LDL' is left out until a solve needs it.  Solves that read the
+    band only (out of place) and solves that need the chunk factors (in place) both equal the
+    solves of a full factorization of the same matrix bit for bit; a matrix whose verdict
+    differs (a row of zeros: a reduced diagonal entry that is not positive) raises the verdict
+    word."""
+    import ctypes
+    import torch
+    from banded_setup import load_synthetic
+    from ipsolver import _hip, device as dv, projector
+    from ipsolver.device import DVec, _p, stream_ptr
+    lib = _hip.load()
+    rng = np.random.default_rng(5)
+    prob = load_synthetic().CenteredBandedNLP(40000, 4000, eps=1e-3)
+    J = prob.constr_jac(prob.x0).tocsr()
+    A = dv.DeviceCSR.from_scipy(J)
+    full = projector.BandedNormalSolver(A)                 # blocking factorization: clean verdict
+    assert lib.ipx_banded_pcr_level(ctypes.c_void_p(full.handle)) > 0
+    launches = lambda: int(lib.ipx_launch_count())
+
+    class Deferred:
+        verdict = torch.zeros(2, dtype=torch.float64, device="cuda")
+    # new values on the same pattern, through the pooled handle
+    J2 = J.copy()
+    J2.data = J.data * (1.0 + 0.1 * rng.standard_normal(J.nnz))
+    A2 = dv.DeviceCSR(A.pattern, torch.from_numpy(J2.data).cuda())
+    ref = projector.BandedNormalSolver(A2)                 # (a second handle: the reference solves)
+    del full                                               # -> the pool: recycled below
+    n0 = launches()
+    lazy = projector.BandedNormalSolver(A2, deferred=Deferred)
+    assert lazy.pending and launches() - n0 == 3
+    assert dv.read_doubles(Deferred.verdict, 1)[0] == 0.0
+    w = DVec(torch.from_numpy(rng.standard_normal(4000)).cuda())
+    out_lazy, out_ref = lazy.solve(w), ref.solve(w)
+    assert torch.equal(out_lazy.t, out_ref.t)
+    # in place: the chunk factors, made now (with the blocking verdict)
+    a, b = w.t.clone(), w.t.clone()
+    n0 = launches()
+    _hip.call("ipx_banded_solve", ctypes.c_void_p(lazy.handle), _p(a), _p(a), stream_ptr())
+    assert launches() - n0 > 3                             # (factor + checks + the solve)
+    _hip.call("ipx_banded_solve", ctypes.c_void_p(ref.handle), _p(b), _p(b), stream_ptr())
+    assert torch.equal(a, b)
+    S = (J2 @ J2.T).tocsc()
+    import scipy.sparse.linalg as spla
+    want = spla.spsolve(S, w.t.cpu().numpy())
+    assert np.abs(a.cpu().numpy() - want).max() <= 1e-10 * np.abs(want).max()
+    # a matrix the assumed verdict does not hold for
+    J3 = J2.copy()
+    J3.data[J3.indptr[1000]:J3.indptr[1001]] = 0.0
+    A3 = dv.DeviceCSR(A.pattern, torch.from_numpy(J3.data).cuda())
+    del lazy
+    bad = projector.BandedNormalSolver(A3, deferred=Deferred)
+    assert bad.pending and dv.read_doubles(Deferred.verdict, 1)[0] != 0.0
