@@ -545,6 +545,16 @@ def config3_leg(n, m, repeats=5):
             walls.sort()
             out[name] = (res, walls, dc)
         res, walls, dc = out["lean"]
+        # the same solves with the chain waited for before the callbacks at the trial point are
+        # called (the reference's order of evaluations exactly; three reads per iteration)
+        sqp.EVALUATE_BEHIND_THE_CHAIN = False
+        try:
+            reads0 = int(lib.ipx_read_count())
+            res_w, _ = solve(dc)
+            reads_w = int(lib.ipx_read_count()) - reads0
+            walls_w = sorted(solve(dc)[1] for _ in range(repeats))
+        finally:
+            sqp.EVALUATE_BEHIND_THE_CHAIN = True
         # one more solve with the calls counted, one with the CG bracketed by events
         launches0, reads0 = int(lib.ipx_launch_count()), int(lib.ipx_read_count())
         solve(dc)
@@ -572,6 +582,13 @@ def config3_leg(n, m, repeats=5):
         "chain": chain,
         "callbacks": "synthetic.LeanDeviceCallbacks (user-land: torch elementwise ops + the "
                      "library's DeviceCSR / ScalarPack; ~20 launches per outer iteration)",
+        "waiting_for_the_chain_first": {
+            "seconds": walls_w[len(walls_w) // 2], "blocking_reads_per_solve": reads_w,
+            "status": int(res_w.status), "niter": int(res_w.niter), "cg_niter": int(res_w.cg_niter),
+            "note": "ipsolver.sqp.EVALUATE_BEHIND_THE_CHAIN = False: the proposing chain's block "
+                    "is read before the objective / constraints are called at the trial point "
+                    "(default: they and the verdict are enqueued behind the chain, one block "
+                    "for both; a step the host has to finish is then evaluated again)"},
         "with_plain_torch_callbacks": {
             "seconds": walls_p[len(walls_p) // 2], "status": int(res_p.status),
             "niter": int(res_p.niter), "cg_niter": int(res_p.cg_niter),

@@ -199,6 +199,7 @@ __device__ __forceinline__ double sq_fold(const sq_u4 *gr, int count, unsigned i
                                           double *lds) {
   static_assert(IPX_FOLD_U == 4, "the load burst below is written for four granules per lane");
   double v = ipx_identity<OP>();
+  bool missing = false;
   for (int base = threadIdx.x; base < count; base += IPX_FOLD_U * blockDim.x) {
     const sq_u4 *p0 = gr + base, *p1 = gr + min(base + (int)blockDim.x, count - 1),
                 *p2 = gr + min(base + 2 * (int)blockDim.x, count - 1),
@@ -218,16 +219,17 @@ __device__ __forceinline__ double sq_fold(const sq_u4 *gr, int count, unsigned i
            w2.w == tag && w3.y == tag && w3.w == tag;
       if (!ok) __builtin_amdgcn_s_sleep(1);
     }
-    const double nan = __builtin_nan("");
-    double t[IPX_FOLD_U] = {ok ? sq_value(w0) : nan, ok ? sq_value(w1) : nan,
-                            ok ? sq_value(w2) : nan, ok ? sq_value(w3) : nan};
+    missing = missing || !ok;
+    const double t[IPX_FOLD_U] = {sq_value(w0), sq_value(w1), sq_value(w2), sq_value(w3)};
 #pragma unroll
     for (int u = 0; u < IPX_FOLD_U; ++u) {
       const int i = base + u * blockDim.x;
       v = ipx_combine<OP>(v, i < count ? t[u] : ipx_identity<OP>());
     }
   }
-  return ipx_block_reduce<OP>(v, lds);
+  const double r = ipx_block_reduce<OP>(v, lds);
+  // (a maximum would swallow a NaN operand: the whole result is NaN when any lane gave up)
+  return __syncthreads_or(missing ? 1 : 0) ? __builtin_nan("") : r;
 }
 // Who folds: the workgroup with the highest index -- dispatched behind all others, or at least
 // never in their way (it holds one of the device's > 2000 workgroup slots while it polls).  No
