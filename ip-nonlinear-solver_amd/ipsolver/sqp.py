@@ -439,6 +439,8 @@ def equality_constrained_sqp(fun_and_constr, grad_and_jac, lagr_hess, x0, fun0, 
         # .hessian_operator: that choice rounds differently, so it must not depend on history)
         if hasattr(stages, "chain"):
             stages.chain.expect_dogleg = True
+            stages.chain.expect_steps = False
+            stages.chain.last_niter = (3, 3)
         if hasattr(xp, "note_cg_length"):
             xp.note_cg_length(0)
 
