@@ -16,6 +16,14 @@ iterations:
                          DeviceDense
     BoxConstraint(kind)  unchanged
 
+Order of evaluations: with the device chains of the outer iteration (sqp.ChainStages) ``fun``
+and the constraints' ``fun`` are enqueued at the trial point BEHIND the kernels that compute it
+and before the host has looked at their outcome; a trial step the host then has to finish (a CG
+loop that needs more iterations, a box event, the dogleg proper) is evaluated again in a new
+vector.  Such a provisional call is not counted (``nfev`` / ``ncev`` are the reference's), but
+the callback was called at a point the reference would not have shown it;
+``ipsolver.sqp.EVALUATE_BEHIND_THE_CHAIN = False`` restores the reference's order exactly.
+
 The canonical form (row selection, sign flips, stacking of several
 constraints, multiplier re-signing; reference _canonical_constraint.py:
 169-480) and the barrier's augmented Jacobian (tr_interior_point.py:165-194)

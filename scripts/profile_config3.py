@@ -5,7 +5,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "ip-nonlinear-solver_amd")); sys.path.insert(0, ROOT)
 import torch
 import ipsolver
-from ipsolver.synthetic import CenteredBandedNLP, DeviceCallbacks
+from ipsolver.synthetic import CenteredBandedNLP, DeviceCallbacks, LeanDeviceCallbacks
+if os.environ.get("LEAN", "1") == "1":
+    DeviceCallbacks = LeanDeviceCallbacks
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
 full = CenteredBandedNLP(n, n // 10, eps=1e-3)
 dc = DeviceCallbacks(full)
