@@ -149,6 +149,30 @@ def _minimize_device(fun, x0, grad, hess, constraints, method, xtol, gtol, optio
     if verbose >= 2:
         _print_header(method)
     start_time = time.time()
+    from . import sqp as _sqp
+    on_device, _sqp._CALLBACKS_ON_DEVICE = _sqp._CALLBACKS_ON_DEVICE, True
+    try:
+        result = _run_device_method(method, canon, fun, grad, lagr, n_vars, x0_dev, f0, g0,
+                                    stop_criteria, state, xp, xtol, options, dm)
+    finally:
+        _sqp._CALLBACKS_ON_DEVICE = on_device
+    result.execution_time = time.time() - start_time
+    result.method = method
+    result.message = TERMINATION_MESSAGES[result.status]
+    for k in _VECTOR_FIELDS:
+        if k in result and hasattr(result[k], "t"):
+            result[k] = result[k].t
+    if return_all:
+        for k in ("allvecs", "allmult", "allslack"):
+            if k in result:
+                result[k] = [t.t for t in result[k]]
+    if verbose >= 1:
+        print(result.message)
+    return result
+
+
+def _run_device_method(method, canon, fun, grad, lagr, n_vars, x0_dev, f0, g0, stop_criteria,
+                       state, xp, xtol, options, dm):
     if method == 'equality_constrained_sqp':
         if canon.n_ineq > 0:
             raise ValueError("'equality_constrained_sqp' does not support "
@@ -170,18 +194,6 @@ def _minimize_device(fun, x0, grad, hess, constraints, method, xtol, gtol, optio
             canon.n_ineq, canon.n_eq, canon.constr, canon.jac, x0_dev, f0, g0, canon.c_ineq0,
             canon.J_ineq0, canon.c_eq0, canon.J_eq0, stop_criteria, canon.enforce_feasibility,
             xtol, state, xp, **options)
-    result.execution_time = time.time() - start_time
-    result.method = method
-    result.message = TERMINATION_MESSAGES[result.status]
-    for k in _VECTOR_FIELDS:
-        if k in result and hasattr(result[k], "t"):
-            result[k] = result[k].t
-    if return_all:
-        for k in ("allvecs", "allmult", "allslack"):
-            if k in result:
-                result[k] = [t.t for t in result[k]]
-    if verbose >= 1:
-        print(result.message)
     return result
 
 

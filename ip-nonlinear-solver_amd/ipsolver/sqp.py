@@ -142,6 +142,10 @@ class HostStages:
 # at the trial point behind it (False: the block is waited for first -- A/B measurements, and
 # the order in which the reference shows its callbacks the points, exactly)
 EVALUATE_BEHIND_THE_CHAIN = True
+# ... in device-callback mode only (minimize._minimize_device sets this for its call): a host
+# callback starts with a copy of the trial point to the host, which waits for the chain anyway --
+# nothing to hide, and a step the host finishes would cost a second evaluation for nothing
+_CALLBACKS_ON_DEVICE = False
 
 
 class ChainStages:
@@ -241,7 +245,7 @@ class ChainStages:
         t.x_next, t.d, t.on_chain = DVec(x_next), DVec(chain.d), True
         finish = lambda q: self._finish(q, t, pt, H, radius, penalty, L, key, P, scale, first_end,
                                         max_iter)
-        if not EVALUATE_BEHIND_THE_CHAIN:
+        if not (EVALUATE_BEHIND_THE_CHAIN and _CALLBACKS_ON_DEVICE):
             chain.front(0, chain.expect_dogleg, radius, penalty, pt.f, pt.norm_b, P.norm_A,
                         first_end)
             q, _ = finish(chain.read())
