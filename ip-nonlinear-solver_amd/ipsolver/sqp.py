@@ -152,10 +152,12 @@ class ChainStages:
     """The stages as device chains (sqp_chain.StepChain); a stage whose operands do not qualify
     goes to the host-driven twin for that call."""
 
-    # CG iterations enqueued behind the priming: one more than the longer of the last two calls
-    # on this problem took (the extra one is the launch that sees the tolerance met), within
-    # these bounds -- an iteration enqueued behind a stopped loop is three launches that do
-    # nothing, ~8 us; a loop that is not done when the block is read costs a second read
+    # CG iterations enqueued behind the priming: as many as the longer of the last two calls on
+    # this problem took, within these bounds -- an iteration enqueued behind a stopped loop is
+    # three launches that do nothing, ~17 us; a loop that is not done when the block is read
+    # costs a second read.  (The launch that would SEE the tolerance met is not enqueued: the
+    # host applies that test -- qp_subproblem.py:551, the first thing an iteration does -- to
+    # the state block itself, _finish.)
     BATCH_MIN, BATCH_MAX = 2, 16
 
     def __init__(self, xp, box, host, n, m):
@@ -237,7 +239,7 @@ class ChainStages:
         scale = pt.S.d if pt.S is not None else None
         chain.bind(L, P, pt.x, pt.c, pt.b, box.lb, box.ub, scale, x_next)
         max_iter = n - m
-        first_end = min(max_iter, max(self.BATCH_MIN, min(max(chain.last_niter) + 1,
+        first_end = min(max_iter, max(self.BATCH_MIN, min(max(chain.last_niter),
                                                            self.BATCH_MAX)))
         # (the dogleg proper rides along when the last normal step needed it: nine launches that
         # do nothing otherwise)
@@ -310,6 +312,12 @@ class ChainStages:
             stop = int(st[cg_fused.ST_STOP])
         steps_taken = st[cg_fused.ST_PRIME_STEPS]
         L.enqueued = (0, first_end) if first_end > 0 else None
+        if stop == 0 and int(st[cg_fused.ST_NITER]) == first_end and \
+                st[cg_fused.ST_RTG0 + (first_end & 1)] < st[cg_fused.ST_TOL]:
+            # every enqueued iteration ran and the next one's first test (:551, rt_g < tol on
+            # the state's own numbers: csrc/cg.hip k_cg_step1) ends the loop before it touches
+            # anything -- the iterate on the device is the call's result
+            stop = 4
         on_device = stop == 4 or (stop in (2, 3) and q[sc.EXIT_DONE] != 0) \
             or (stop == 0 and first_end >= max_iter)
         outside = box.any and q[sc.X_OUTSIDE] > 0
